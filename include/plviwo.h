@@ -1,0 +1,175 @@
+/*
+ * plviwo.h — C-ABI of the MI355X-native per-frame (track + EKF update) path of PL-VIWO.
+ *
+ * This is the drop-in boundary: everything HIP lives behind these entry points.  The host
+ * side (the C++ mirror of ov_core::TrackBase / viw::UpdaterCamera / viw::StateHelper under
+ * pl-viwo_amd/host/, or the reference's own classes through the stubs in INTEGRATION.md)
+ * calls only what is declared here.  No torch / Eigen / OpenCV types cross the boundary:
+ * plain pointers and sizes, `int` status codes, no C++ exceptions.
+ *
+ * Conventions
+ *   - dense matrices are COLUMN-MAJOR with an explicit leading dimension, like Eigen's default,
+ *     so `MatrixXd::data()` passes straight through;
+ *   - images are ROW-MAJOR u8 with an explicit byte stride, like `cv::Mat(CV_8UC1)`;
+ *   - the caller owns every host buffer; the library owns device memory inside `plv_ctx`;
+ *   - one `plv_ctx` per camera, calls on one ctx are serialised by the caller, one HIP stream
+ *     per ctx, every call is synchronous at return unless its name ends in `_async`;
+ *   - pointers are HOST pointers unless the parameter is documented as "device".
+ *
+ * Citations `REF:` are relative to /root/reference (see SURVEY.md for the prefixes).
+ */
+#ifndef PLVIWO_H
+#define PLVIWO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLV_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- status codes */
+enum {
+  PLV_OK = 0,
+  PLV_E_BADARG = -1,    /* null pointer / size mismatch. REF: TrackKLT.cpp:37-43 exits; we return */
+  PLV_E_DEVICE = -2,    /* HIP runtime error (plv_last_error has the text)                        */
+  PLV_E_NOT_PSD = -3,   /* EKFUpdate negative diagonal: P and dx untouched. REF: StateHelper.cpp:143-152 */
+  PLV_E_NOMEM = -4,
+  PLV_E_CAPACITY = -5,  /* problem larger than the ctx was sized for                              */
+  PLV_E_NO_DEVICE = -6, /* no gfx950 device visible: the product path never falls back to a CPU   */
+  PLV_E_NUMERIC = -7    /* NaN / non-finite in a numerical step (REF: UpdaterStatistics.cpp:118)  */
+};
+
+/* ---------------------------------------------------------------- configuration */
+enum { PLV_HIST_NONE = 0, PLV_HIST_HISTOGRAM = 1, PLV_HIST_CLAHE = 2 }; /* REF: TrackBase.h:78 */
+
+typedef struct plv_config {
+  /* image / tracker.  REF: TrackKLT ctor TrackKLT.h:57-62, UpdaterCamera.cpp:41 */
+  int width, height;
+  int num_features;      /* n_pts */
+  int fast_threshold;
+  int grid_x, grid_y;
+  int min_px_dist;
+  int histogram_method;  /* PLV_HIST_* */
+  int win_size;          /* 15  REF: TrackKLT.h:144 */
+  int pyr_levels;        /* 5   REF: TrackKLT.h:143 (OpenCV maxLevel) */
+  int lk_max_iters;      /* 30  REF: TrackKLT.cpp:857 */
+  float lk_eps;          /* 0.01 */
+  double ransac_thr_px;  /* 2.0  REF: TrackKLT.cpp:873 (divided by max focal length inside) */
+  double ransac_conf;    /* 0.999 */
+  int ransac_max_iters;  /* 1000 (OpenCV default for findFundamentalMat) */
+  double intrinsics[8];  /* fx fy cx cy k1 k2 p1 p2  REF: CamBase.h:56-82 */
+  /* line front-end.  REF: TrackLSD.h:269-273, TrackLSD.cpp:200-231,780,824 */
+  int line_length_threshold;   /* 20 (half-res px) */
+  float line_distance_threshold; /* 1.41421356 */
+  int canny_th1, canny_th2, canny_aperture; /* 50,50,3 */
+  float line_min_length_px;    /* 40 (full-res) */
+  float line_assign_px;        /* 5 */
+  float line_similar_px;       /* 6 */
+  /* update sizing */
+  int max_state_dim;     /* capacity for n (rows of P) */
+  int max_meas_rows;     /* capacity for stacked rows before compression */
+  int max_features;      /* capacity for features per update batch */
+  int max_rows_per_feat; /* 2*M_max */
+  double sigma_pix;      /* REF: OptionsCamera.h (sigma_pix) */
+  double chi2_mult;      /* REF: OptionsCamera.h (chi2_mult) */
+  int device;            /* HIP device ordinal */
+} plv_config;
+
+/* Fills every field with the reference's hard-coded / KAIST defaults for a W x H camera. */
+void plv_config_default(plv_config *cfg, int width, int height);
+
+typedef struct plv_ctx plv_ctx;
+
+int plv_abi_version(void);
+const char *plv_last_error(void);
+/* number of visible gfx950 devices (0 => every compute call returns PLV_E_NO_DEVICE) */
+int plv_device_count(void);
+
+int plv_ctx_create(const plv_config *cfg, plv_ctx **out);
+void plv_ctx_destroy(plv_ctx *ctx);
+int plv_ctx_synchronize(plv_ctx *ctx);
+
+/* ---------------------------------------------------------------- profiling hooks
+ * HIP-event timing of the library's own kernels on the ctx stream (bench.py's roofline leg).
+ * `plv_prof_get` returns, for kernel class `name`, the number of launches and the total
+ * device time in milliseconds accumulated since plv_prof_reset. */
+int plv_prof_enable(plv_ctx *ctx, int on);
+int plv_prof_reset(plv_ctx *ctx);
+int plv_prof_count(plv_ctx *ctx);
+int plv_prof_get(plv_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms);
+
+/* ================================================================ EKF update side (fp64)
+ *
+ * plv_ekf_update replaces viw::StateHelper::EKFUpdate  (REF: PL/state/StateHelper.cpp:94-173):
+ *   M = P[:,cols] H^T ; S = H P[cols,cols] H^T + R ; K = M S^-1 ; dx = K res ; P -= K M^T.
+ * `col_to_state[j]` is the row/col of P that column j of H multiplies — the flat equivalent of
+ * the reference's H_order (vector<shared_ptr<Type>> with id()/size()).
+ * R is diagonal (`Rdiag`, r entries) or identity when NULL (REF: UpdaterCamera.cpp:290).
+ * On PLV_E_NOT_PSD neither P nor dx is modified.
+ * If `P` is NULL the device-resident covariance (plv_cov_upload) is updated in place.
+ */
+int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int r, int k, int ldh,
+                   const int *col_to_state, const double *res, const double *Rdiag, double *dx);
+
+/* device-resident covariance (REF: State.h:226 `MatrixXd cov`) */
+int plv_cov_upload(plv_ctx *ctx, const double *P, int n, int ldp);
+int plv_cov_download(plv_ctx *ctx, double *P, int n, int ldp);
+
+/* plv_compress replaces StateHelper::measurement_compress_inplace (REF: StateHelper.cpp:602-614,
+ * 653-672): QR of [H | res], keep the top k rows.  If m <= k nothing happens (m_out = m).
+ * Output R is upper-triangular with non-negative diagonal (the sign convention Eigen's
+ * makeGivens produces), so it is directly comparable with the reference's result. */
+int plv_compress(plv_ctx *ctx, double *H, int m, int k, int ldh, double *res, int *m_out);
+
+/* plv_nullspace_batch replaces StateHelper::nullspace_project_inplace for F features at once
+ * (REF: StateHelper.cpp:616-651).  Feature f owns rows[f] rows; Hf is [F][fdim][ld] , Hx is
+ * [F][k][ld], res is [F][ld] (col-major per feature, ld = padded rows).  On return the first
+ * rows[f]-fdim rows of Hx/res of feature f hold the projected system (the reference drops the
+ * first fdim rows; we shift up the same way). Same rotation order as the reference. */
+int plv_nullspace_batch(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *rows, double *Hf,
+                        double *Hx, double *res);
+
+/* plv_chi2_batch replaces UpdaterStatistics::get_chi2 for F features (REF:
+ * UpdaterStatistics.cpp:94-117): chi2[f] = r^T (H P_s H^T + sigma2 I)^-1 r with
+ * P_s = P[cols, cols]; uses the device-resident covariance when P is NULL. */
+int plv_chi2_batch(plv_ctx *ctx, const double *P, int n, int ldp, int F, int k, int ld,
+                   const int *rows, const double *Hx, const double *res, const int *col_to_state,
+                   double sigma2, double *chi2);
+
+/* 95% chi-square quantile for `dof` degrees of freedom (REF: UpdaterStatistics.cpp:31-37 uses
+ * boost::math::quantile(chi_squared(k), 0.95)). */
+double plv_chi2_quantile95(int dof);
+
+/* plv_msckf_update: the whole of UpdaterCamera::msckf_update after the per-feature Jacobians
+ * (REF: UpdaterCamera.cpp:230-293) in one device pass without host round trips:
+ *   nullspace -> R = sigma^2 I gate (||res|| < res_norm_gate && chi2 < mult*q95) -> stack accepted
+ *   -> compress -> R = I -> EKFUpdate.
+ * `res_norm_gate` <= 0 disables the norm term (lines: REF UpdaterCamera.cpp:420).
+ * accepted[f] (may be NULL) receives 1/0 per feature (REF: Feature::Chi_test).
+ * Returns PLV_OK, or PLV_E_NOT_PSD (state untouched). n_accepted_rows may be NULL. */
+int plv_msckf_update(plv_ctx *ctx, double *P, int n, int ldp, int F, int fdim, int k, int ld,
+                     const int *rows, const double *Hf, const double *Hx, const double *res,
+                     const int *col_to_state, double sigma2, double chi2_mult,
+                     double res_norm_gate, uint8_t *accepted, int *n_accepted_rows, double *dx);
+
+/* Device-resident variants (the per-frame path keeps its operands in HBM between calls):
+ * plv_feat_batch_upload stages one batch of per-feature systems (same layout as
+ * plv_msckf_update) in the ctx; plv_msckf_update_resident runs the update on the staged batch
+ * and the device-resident covariance (plv_cov_upload) and returns only dx / accepted.  The staged
+ * batch is preserved (the kernels work on a device copy), so the call can be repeated.
+ * plv_cov_checkpoint / plv_cov_rollback keep and restore a device copy of the covariance
+ * (REF: StateHelper::initialize rolls the state back on a failed update, StateHelper.cpp:430-435). */
+int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *rows, const double *Hf,
+                          const double *Hx, const double *res, const int *col_to_state);
+int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate,
+                              uint8_t *accepted, int *n_accepted_rows, double *dx);
+int plv_cov_checkpoint(plv_ctx *ctx);
+int plv_cov_rollback(plv_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLVIWO_H */

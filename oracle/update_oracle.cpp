@@ -1,0 +1,286 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see dense.h).  PARITY UNPINNED.
+//
+// CPU fp64 restatement of the EKF-update half of the hot path:
+//   Givens_Rotation / nullspace_project_inplace / measurement_compress_inplace
+//       REF: PL-VIWO/src/state/StateHelper.cpp:602-672
+//   get_marginal_covariance                REF: StateHelper.cpp:466-493
+//   UpdaterStatistics::get_chi2            REF: PL-VIWO/src/update/UpdaterStatistics.cpp:94-117
+//   StateHelper::EKFUpdate                 REF: StateHelper.cpp:94-173
+//   UpdaterCamera::msckf_update (from the nullspace projection on)
+//                                          REF: PL-VIWO/src/update/cam/UpdaterCamera.cpp:230-293
+// Eigen's JacobiRotation::makeGivens / applyOnTheLeft (Eigen 3, Jacobi/Jacobi.h) are restated
+// from their published real-scalar algorithm; Eigen itself is not in /root/reference.
+#include "dense.h"
+#include <cstdint>
+#include <cstdio>
+
+using namespace orc;
+
+namespace {
+
+// Eigen::JacobiRotation<double>::makeGivens(p, q) — real case.  G = [c s; -s c],
+// G^T [p; q] = [r; 0] with r >= 0.
+inline void make_givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0.0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0.0 ? 1.0 : -1.0;
+  } else if (std::fabs(p) > std::fabs(q)) {
+    double t = q / p;
+    double u = std::sqrt(1.0 + t * t);
+    if (p < 0.0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    double t = p / q;
+    double u = std::sqrt(1.0 + t * t);
+    if (q < 0.0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+
+// block.applyOnTheLeft(0, 1, G.adjoint()) on rows (m-1, m):  x' = c x - s y ; y' = s x + c y
+inline void rot_rows(Mat &A, int m, int col0, double c, double s) {
+  for (int j = col0; j < A.c; ++j) {
+    double x = A(m - 1, j), y = A(m, j);
+    A(m - 1, j) = c * x - s * y;
+    A(m, j) = s * x + c * y;
+  }
+}
+
+// StateHelper::Givens_Rotation(A, B, C)  REF: StateHelper.cpp:631-651
+void givens3(Mat &A, Mat &B, Mat &C) {
+  for (int n = 0; n < A.c; ++n) {
+    for (int m = A.r - 1; m > n; m--) {
+      if (A(m, n) == 0.0) continue;
+      double c, s;
+      make_givens(A(m - 1, n), A(m, n), c, s);
+      rot_rows(A, m, n, c, s);
+      A(m, n) = 0.0;
+      rot_rows(B, m, 0, c, s);
+      rot_rows(C, m, 0, c, s);
+    }
+  }
+}
+
+// StateHelper::Givens_Rotation(A, B)  REF: StateHelper.cpp:653-672
+void givens2(Mat &A, Mat &B) {
+  for (int n = 0; n < A.c; ++n) {
+    for (int m = A.r - 1; m > n; m--) {
+      if (A(m, n) == 0.0) continue;
+      double c, s;
+      make_givens(A(m - 1, n), A(m, n), c, s);
+      rot_rows(A, m, n, c, s);
+      A(m, n) = 0.0;
+      rot_rows(B, m, 0, c, s);
+    }
+  }
+}
+
+Mat top_rows(const Mat &A, int row0, int nrows) {
+  Mat R(nrows, A.c);
+  for (int j = 0; j < A.c; ++j)
+    for (int i = 0; i < nrows; ++i) R(i, j) = A(row0 + i, j);
+  return R;
+}
+
+// REF: StateHelper.cpp:616-629
+void nullspace_project(Mat &Hf, Mat &Hx, Mat &res) {
+  givens3(Hf, Hx, res);
+  int f = Hf.c;
+  Hx = top_rows(Hx, f, Hx.r - f);
+  res = top_rows(res, f, res.r - f);
+}
+
+// REF: StateHelper.cpp:602-614
+void compress(Mat &Hx, Mat &res) {
+  if (Hx.r <= Hx.c) return;
+  givens2(Hx, res);
+  int k = Hx.c;
+  Hx = top_rows(Hx, 0, k);
+  res = top_rows(res, 0, k);
+}
+
+// REF: StateHelper.cpp:466-493 with the flat column table instead of Type ids
+Mat marginal_cov(const Mat &P, const int *cols, int k) {
+  Mat S(k, k);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) S(i, j) = P(cols[i], cols[j]);
+  return S;
+}
+
+// REF: UpdaterStatistics.cpp:94-117.  S = (H P H^T + R).selfadjointView<Upper>();
+// chi = res^T S^-1 res  (the reference inverts S explicitly and reads the upper triangle)
+bool chi2(const Mat &Ps, const Mat &H, const Mat &res, double sigma2, double &chi) {
+  Mat T = matmul(H, Ps);
+  Mat S = matmul(T, transpose(H));
+  int m = H.r;
+  for (int i = 0; i < m; ++i) S(i, i) += sigma2;
+  for (int j = 0; j < m; ++j)
+    for (int i = j + 1; i < m; ++i) S(i, j) = S(j, i);
+  Mat Sinv;
+  if (!inverse(S, Sinv)) {
+    chi = NAN;
+    return false;
+  }
+  for (int j = 0; j < m; ++j)
+    for (int i = j + 1; i < m; ++i) Sinv(i, j) = Sinv(j, i);
+  double acc = 0.0;
+  for (int j = 0; j < m; ++j) {
+    double t = 0.0;
+    for (int i = 0; i < m; ++i) t += res(i, 0) * Sinv(i, j);
+    acc += t * res(j, 0);
+  }
+  chi = acc;
+  return !std::isnan(chi);
+}
+
+// REF: StateHelper.cpp:94-173.  Returns false (nothing modified) on a negative diagonal.
+bool ekf_update(Mat &P, const Mat &H, const int *cols, const Mat &res, const double *Rdiag, Mat &dx) {
+  int n = P.r, r = H.r, k = H.c;
+  // M_a = P[:, cols] * H^T
+  Mat M(n, r);
+  for (int j = 0; j < k; ++j) {
+    int cj = cols[j];
+    for (int q = 0; q < r; ++q) {
+      double h = H(q, j);
+      if (h == 0.0) continue;
+      for (int i = 0; i < n; ++i) M(i, q) += P(i, cj) * h;
+    }
+  }
+  Mat Ps = marginal_cov(P, cols, k);
+  Mat S = matmul(matmul(H, Ps), transpose(H));
+  for (int i = 0; i < r; ++i) S(i, i) += Rdiag ? Rdiag[i] : 1.0;
+  Mat L;
+  if (!cholesky_lower_from_upper(S, L)) return false;
+  Mat Sinv = Mat::identity(r);
+  cholesky_solve(L, Sinv);
+  for (int j = 0; j < r; ++j)  // selfadjointView<Upper>
+    for (int i = j + 1; i < r; ++i) Sinv(i, j) = Sinv(j, i);
+  Mat K = matmul(M, Sinv);
+  dx = matmul(K, res);
+  Mat dC = matmul(K, transpose(M));
+  for (int i = 0; i < n; ++i)
+    if (P(i, i) - dC(i, i) < 0.0) return false;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) {
+      P(i, j) -= dC(i, j);
+      P(j, i) = P(i, j);
+    }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_make_givens(double p, double q, double *c, double *s) { make_givens(p, q, *c, *s); }
+
+// One feature: Hf (rows x fdim, ld), Hx (rows x k, ld), res (rows).  Output shifted up like the
+// ABI (first rows-fdim rows valid).
+void orc_nullspace_project(double *Hf, double *Hx, double *res, int rows, int fdim, int k, int ld) {
+  Mat A = Mat::from(Hf, rows, fdim, ld), B = Mat::from(Hx, rows, k, ld), C = Mat::from(res, rows, 1, ld);
+  givens3(A, B, C);
+  A.to(Hf, ld);
+  Mat B2 = top_rows(B, fdim, rows - fdim), C2 = top_rows(C, fdim, rows - fdim);
+  B2.to(Hx, ld);
+  C2.to(res, ld);
+}
+
+void orc_nullspace_batch(int F, int fdim, int k, int ld, const int *rows, double *Hf, double *Hx, double *res) {
+  for (int f = 0; f < F; ++f)
+    orc_nullspace_project(Hf + (size_t)f * fdim * ld, Hx + (size_t)f * k * ld, res + (size_t)f * ld, rows[f], fdim, k, ld);
+}
+
+// H (m x k, ld) / res (m) -> top min(m,k) rows.  Returns the new row count.
+int orc_compress(double *H, int m, int k, int ld, double *res) {
+  Mat A = Mat::from(H, m, k, ld), B = Mat::from(res, m, 1, m);
+  compress(A, B);
+  A.to(H, ld);
+  B.to(res, A.r);
+  return A.r;
+}
+
+int orc_chi2(const double *P, int n, int ldp, const double *H, int m, int k, int ldh, const int *cols,
+             const double *res, double sigma2, double *chi) {
+  Mat Pm = Mat::from(P, n, n, ldp);
+  Mat Ps = marginal_cov(Pm, cols, k);
+  Mat Hm = Mat::from(H, m, k, ldh), r = Mat::from(res, m, 1, m);
+  return chi2(Ps, Hm, r, sigma2, *chi) ? 0 : -7;
+}
+
+int orc_chi2_batch(const double *P, int n, int ldp, int F, int k, int ld, const int *rows, const double *Hx,
+                   const double *res, const int *cols, double sigma2, double *chi) {
+  Mat Pm = Mat::from(P, n, n, ldp);
+  Mat Ps = marginal_cov(Pm, cols, k);
+  for (int f = 0; f < F; ++f) {
+    Mat Hm = Mat::from(Hx + (size_t)f * k * ld, rows[f], k, ld), r = Mat::from(res + (size_t)f * ld, rows[f], 1, ld);
+    chi2(Ps, Hm, r, sigma2, chi[f]);
+  }
+  return 0;
+}
+
+// returns 0, or -3 (PLV_E_NOT_PSD) with P/dx untouched
+int orc_ekf_update(double *P, int n, int ldp, const double *H, int r, int k, int ldh, const int *cols,
+                   const double *res, const double *Rdiag, double *dx) {
+  Mat Pm = Mat::from(P, n, n, ldp), Hm = Mat::from(H, r, k, ldh), rm = Mat::from(res, r, 1, r), d;
+  if (!ekf_update(Pm, Hm, cols, rm, Rdiag, d)) return -3;
+  Pm.to(P, ldp);
+  for (int i = 0; i < n; ++i) dx[i] = d(i, 0);
+  return 0;
+}
+
+// REF: UpdaterCamera.cpp:230-293 (points, fdim=3, res_norm_gate=3) and :400-463 (lines, fdim=6,
+// no norm gate).  Same packed layout as plv_msckf_update.  q95[dof] is the chi-square table.
+// Stacks in the shared column space (union column order).
+int orc_msckf_update(double *P, int n, int ldp, int F, int fdim, int k, int ld, const int *rows, const double *Hf_in,
+                     const double *Hx_in, const double *res_in, const int *cols, double sigma2, double chi2_mult,
+                     double res_norm_gate, const double *q95, uint8_t *accepted, int *n_rows_out, double *dx) {
+  Mat Pm = Mat::from(P, n, n, ldp);
+  Mat Ps = marginal_cov(Pm, cols, k);
+  std::vector<Mat> Hs, Rs;
+  int total = 0;
+  for (int f = 0; f < F; ++f) {
+    if (accepted) accepted[f] = 0;
+    // REF: UpdaterCamera.cpp:228 `L.res.size() < 4` (points) / :406 `< 5` (lines)
+    if (rows[f] < (fdim == 3 ? 4 : 5)) continue;
+    Mat A = Mat::from(Hf_in + (size_t)f * fdim * ld, rows[f], fdim, ld);
+    Mat B = Mat::from(Hx_in + (size_t)f * k * ld, rows[f], k, ld);
+    Mat C = Mat::from(res_in + (size_t)f * ld, rows[f], 1, ld);
+    nullspace_project(A, B, C);
+    if (B.r < 1) continue;
+    double nrm = 0.0;
+    for (int i = 0; i < C.r; ++i) nrm += C(i, 0) * C(i, 0);
+    nrm = std::sqrt(nrm);
+    double chi;
+    bool ok = chi2(Ps, B, C, sigma2, chi);
+    bool pass = ok && (res_norm_gate <= 0.0 || nrm < res_norm_gate) && chi < chi2_mult * q95[C.r];
+    if (!pass) continue;
+    if (accepted) accepted[f] = 1;
+    total += B.r;
+    Hs.push_back(B);
+    Rs.push_back(C);
+  }
+  if (n_rows_out) *n_rows_out = total;
+  for (int i = 0; i < n; ++i) dx[i] = 0.0;
+  if (total < 1) return 0;
+  Mat H(total, k), r(total, 1);
+  int at = 0;
+  for (size_t i = 0; i < Hs.size(); ++i) {
+    for (int j = 0; j < k; ++j)
+      for (int q = 0; q < Hs[i].r; ++q) H(at + q, j) = Hs[i](q, j);
+    for (int q = 0; q < Hs[i].r; ++q) r(at + q, 0) = Rs[i](q, 0);
+    at += Hs[i].r;
+  }
+  compress(H, r);
+  Mat d;
+  if (!ekf_update(Pm, H, cols, r, nullptr, d)) return -3;
+  Pm.to(P, ldp);
+  for (int i = 0; i < n; ++i) dx[i] = d(i, 0);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+"""plviwo_amd — Python plumbing over the C-ABI of the MI355X-native PL-VIWO hot path.
+
+The product is the gfx950 shared library ``lib/libplviwo_hip.so`` (sources under ``csrc/``,
+boundary in ``include/plviwo.h``).  This module only binds that C-ABI with ctypes so tests,
+``bench.py`` and ``__graft_entry__`` can drive it; there is no Python or CPU compute path here,
+and loading fails loudly when the library is missing.
+
+The directory is named ``pl-viwo_amd`` (not importable as written); load it with
+``tests/conftest.py::load_pkg`` / ``__graft_entry__.load_pkg`` which registers it as
+``plviwo_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplviwo_hip.so")
+
+PLV_OK = 0
+PLV_E_BADARG = -1
+PLV_E_DEVICE = -2
+PLV_E_NOT_PSD = -3
+PLV_E_NOMEM = -4
+PLV_E_CAPACITY = -5
+PLV_E_NO_DEVICE = -6
+PLV_E_NUMERIC = -7
+
+
+class PlvConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int),
+        ("num_features", C.c_int), ("fast_threshold", C.c_int),
+        ("grid_x", C.c_int), ("grid_y", C.c_int), ("min_px_dist", C.c_int),
+        ("histogram_method", C.c_int), ("win_size", C.c_int), ("pyr_levels", C.c_int),
+        ("lk_max_iters", C.c_int), ("lk_eps", C.c_float),
+        ("ransac_thr_px", C.c_double), ("ransac_conf", C.c_double), ("ransac_max_iters", C.c_int),
+        ("intrinsics", C.c_double * 8),
+        ("line_length_threshold", C.c_int), ("line_distance_threshold", C.c_float),
+        ("canny_th1", C.c_int), ("canny_th2", C.c_int), ("canny_aperture", C.c_int),
+        ("line_min_length_px", C.c_float), ("line_assign_px", C.c_float), ("line_similar_px", C.c_float),
+        ("max_state_dim", C.c_int), ("max_meas_rows", C.c_int), ("max_features", C.c_int),
+        ("max_rows_per_feat", C.c_int),
+        ("sigma_pix", C.c_double), ("chi2_mult", C.c_double),
+        ("device", C.c_int),
+    ]
+
+
+class PlvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"plv error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libplviwo_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    sig = {
+        "plv_abi_version": (C.c_int, []),
+        "plv_last_error": (C.c_char_p, []),
+        "plv_device_count": (C.c_int, []),
+        "plv_config_default": (None, [C.POINTER(PlvConfig), C.c_int, C.c_int]),
+        "plv_ctx_create": (C.c_int, [C.POINTER(PlvConfig), C.POINTER(vp)]),
+        "plv_ctx_destroy": (None, [vp]),
+        "plv_ctx_synchronize": (C.c_int, [vp]),
+        "plv_prof_enable": (C.c_int, [vp, C.c_int]),
+        "plv_prof_reset": (C.c_int, [vp]),
+        "plv_prof_count": (C.c_int, [vp]),
+        "plv_prof_get": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, ip, dp]),
+        "plv_ekf_update": (C.c_int, [vp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp]),
+        "plv_cov_upload": (C.c_int, [vp, dp, C.c_int, C.c_int]),
+        "plv_cov_download": (C.c_int, [vp, dp, C.c_int, C.c_int]),
+        "plv_cov_checkpoint": (C.c_int, [vp]),
+        "plv_cov_rollback": (C.c_int, [vp]),
+        "plv_compress": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, dp, ip]),
+        "plv_nullspace_batch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp]),
+        "plv_chi2_batch": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, ip,
+                                     C.c_double, dp]),
+        "plv_chi2_quantile95": (C.c_double, [C.c_int]),
+        "plv_msckf_update": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp,
+                                       ip, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
+        "plv_feat_batch_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, ip]),
+        "plv_msckf_update_resident": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._plv_signatures = sig
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+def _f64(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def default_config(width=752, height=480):
+    lib = load_library()
+    cfg = PlvConfig()
+    lib.plv_config_default(C.byref(cfg), width, height)
+    return cfg
+
+
+class Context:
+    """One plv_ctx (one camera / one HIP stream).  Raises PlvError on any non-OK status except
+    where a method documents a returned status."""
+
+    def __init__(self, cfg=None):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config()
+        h = C.c_void_p()
+        rc = self.lib.plv_ctx_create(C.byref(self.cfg), C.byref(h))
+        if rc != PLV_OK:
+            raise PlvError(rc, self.lib.plv_last_error().decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plv_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != PLV_OK and rc not in allow:
+            raise PlvError(rc, self.lib.plv_last_error().decode())
+        return rc
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self._chk(self.lib.plv_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._chk(self.lib.plv_prof_reset(self.h))
+
+    def prof_table(self):
+        out = {}
+        for i in range(self.lib.plv_prof_count(self.h)):
+            name = C.create_string_buffer(128)
+            n, ms = C.c_int(), C.c_double()
+            self.lib.plv_prof_get(self.h, i, name, 128, C.byref(n), C.byref(ms))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+    def synchronize(self):
+        self._chk(self.lib.plv_ctx_synchronize(self.h))
+
+    # ---- update side
+    def cov_upload(self, P):
+        P = _f64(P)
+        self._chk(self.lib.plv_cov_upload(self.h, _dp(P), P.shape[0], P.shape[0]))
+
+    def cov_download(self, n):
+        P = np.zeros((n, n), order="F")
+        self._chk(self.lib.plv_cov_download(self.h, _dp(P), n, n))
+        return P
+
+    def cov_checkpoint(self):
+        self._chk(self.lib.plv_cov_checkpoint(self.h))
+
+    def cov_rollback(self):
+        self._chk(self.lib.plv_cov_rollback(self.h))
+
+    def ekf_update(self, P, H, cols, res, Rdiag=None):
+        """Returns (status, P_new, dx).  status is PLV_OK or PLV_E_NOT_PSD (P unchanged)."""
+        P = _f64(P).copy(order="F")
+        H = _f64(H)
+        cols = _i32(cols)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        Rd = np.ascontiguousarray(Rdiag, dtype=np.float64) if Rdiag is not None else None
+        n, (r, k) = P.shape[0], H.shape
+        dx = np.zeros(n)
+        rc = self.lib.plv_ekf_update(self.h, _dp(P), n, n, _dp(H), r, k, r, _ip(cols), _dp(res), _dp(Rd), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, P, dx
+
+    def compress(self, H, res):
+        H = _f64(H).copy(order="F")
+        res = np.ascontiguousarray(res, dtype=np.float64).copy()
+        m, k = H.shape
+        mo = C.c_int()
+        self._chk(self.lib.plv_compress(self.h, _dp(H), m, k, m, _dp(res), C.byref(mo)))
+        return H[:mo.value, :].copy(), res[:mo.value].copy()
+
+    def nullspace_batch(self, rows, Hf, Hx, res):
+        """Hf [F, fdim, ld], Hx [F, k, ld], res [F, ld] C-contiguous (== col-major per feature)."""
+        Hf = np.ascontiguousarray(Hf, dtype=np.float64).copy()
+        Hx = np.ascontiguousarray(Hx, dtype=np.float64).copy()
+        res = np.ascontiguousarray(res, dtype=np.float64).copy()
+        rows = _i32(rows)
+        F, fdim, ld = Hf.shape
+        k = Hx.shape[1]
+        self._chk(self.lib.plv_nullspace_batch(self.h, F, fdim, k, ld, _ip(rows), _dp(Hf), _dp(Hx), _dp(res)))
+        return Hf, Hx, res
+
+    def chi2_batch(self, P, rows, Hx, res, cols, sigma2):
+        P = _f64(P)
+        Hx = np.ascontiguousarray(Hx, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        rows, cols = _i32(rows), _i32(cols)
+        F, k, ld = Hx.shape
+        n = P.shape[0]
+        chi = np.zeros(F)
+        self._chk(self.lib.plv_chi2_batch(self.h, _dp(P), n, n, F, k, ld, _ip(rows), _dp(Hx), _dp(res), _ip(cols),
+                                          float(sigma2), _dp(chi)))
+        return chi
+
+    def msckf_update(self, P, rows, Hf, Hx, res, cols, sigma2, chi2_mult=1.0, res_norm_gate=3.0):
+        """Returns (status, P_new, dx, accepted, n_rows)."""
+        P = _f64(P).copy(order="F")
+        Hf = np.ascontiguousarray(Hf, dtype=np.float64)
+        Hx = np.ascontiguousarray(Hx, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        rows, cols = _i32(rows), _i32(cols)
+        F, fdim, ld = Hf.shape
+        k = Hx.shape[1]
+        n = P.shape[0]
+        dx = np.zeros(n)
+        acc = np.zeros(F, dtype=np.uint8)
+        nrows = C.c_int()
+        rc = self.lib.plv_msckf_update(self.h, _dp(P), n, n, F, fdim, k, ld, _ip(rows), _dp(Hf), _dp(Hx), _dp(res),
+                                       _ip(cols), float(sigma2), float(chi2_mult), float(res_norm_gate), _u8p(acc),
+                                       C.byref(nrows), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, P, dx, acc, nrows.value
+
+    def feat_batch_upload(self, rows, Hf, Hx, res, cols):
+        Hf = np.ascontiguousarray(Hf, dtype=np.float64)
+        Hx = np.ascontiguousarray(Hx, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        rows, cols = _i32(rows), _i32(cols)
+        F, fdim, ld = Hf.shape
+        k = Hx.shape[1]
+        self._chk(self.lib.plv_feat_batch_upload(self.h, F, fdim, k, ld, _ip(rows), _dp(Hf), _dp(Hx), _dp(res),
+                                                 _ip(cols)))
+        self._batch_F = F
+
+    def msckf_update_resident(self, n, sigma2, chi2_mult=1.0, res_norm_gate=3.0):
+        dx = np.zeros(n)
+        acc = np.zeros(self._batch_F, dtype=np.uint8)
+        nrows = C.c_int()
+        rc = self.lib.plv_msckf_update_resident(self.h, float(sigma2), float(chi2_mult), float(res_norm_gate),
+                                                _u8p(acc), C.byref(nrows), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, dx, acc, nrows.value

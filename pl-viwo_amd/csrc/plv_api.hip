@@ -1,0 +1,616 @@
+// plv_api.hip — the extern "C" boundary declared in include/plviwo.h (context + update side).
+// Product code: no CPU fallback anywhere — without a gfx950 device every compute entry point
+// returns PLV_E_NO_DEVICE.
+#include <cstdarg>
+#include <cmath>
+#include <mutex>
+
+#include "plv_ctx.hpp"
+#include "update_kernels.hpp"
+
+namespace plv {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+double chi2_quantile(int dof, double p);
+
+static const int Q95_N = 1024;
+
+static int h2d(plv_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  PLV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return PLV_OK;
+}
+static int d2h(plv_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  PLV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return PLV_OK;
+}
+static int sync(plv_ctx *ctx) {
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+// upload a col-major matrix with arbitrary ld into a dense (ld = rows) device matrix
+static int upload_mat(plv_ctx *ctx, double *dst, const double *src, int rows, int cols, int ld) {
+  if (ld == rows) return h2d(ctx, dst, src, (size_t)rows * cols * 8);
+  PLV_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)rows * 8, src, (size_t)ld * 8, (size_t)rows * 8, cols,
+                                 hipMemcpyHostToDevice, ctx->stream));
+  return PLV_OK;
+}
+static int download_mat(plv_ctx *ctx, double *dst, const double *src, int rows, int cols, int ld) {
+  if (ld == rows) return d2h(ctx, dst, src, (size_t)rows * cols * 8);
+  PLV_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)ld * 8, src, (size_t)rows * 8, (size_t)rows * 8, cols,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  return PLV_OK;
+}
+
+}  // namespace plv
+
+using namespace plv;
+
+#define REQUIRE_CTX(ctx)                     \
+  do {                                       \
+    if (!(ctx)) {                            \
+      set_last_error("null ctx");            \
+      return PLV_E_BADARG;                   \
+    }                                        \
+    (void)hipSetDevice((ctx)->device);       \
+  } while (0)
+#define TRY(expr)              \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != PLV_OK) return _rc; \
+  } while (0)
+
+// extra per-ctx state that is private to this translation unit
+struct plv_ctx_update_state {
+  plv::DevBuf q95;
+  plv::DevBuf result;   // [dx: max_n doubles][flag: int + pad][accepted: bytes]
+  plv::DevBuf covck;    // covariance checkpoint
+  plv::DevBuf bHf, bHx, bres, brows, bcols;  // staged (pristine) feature batch
+  int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
+  std::vector<int> brows_host;
+};
+static std::mutex g_state_mtx;
+static std::vector<std::pair<plv_ctx *, plv_ctx_update_state *>> g_states;
+static plv_ctx_update_state *ustate(plv_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_state_mtx);
+  for (auto &p : g_states)
+    if (p.first == ctx) return p.second;
+  return nullptr;
+}
+
+extern "C" {
+
+int plv_abi_version(void) { return PLV_ABI_VERSION; }
+const char *plv_last_error(void) { return g_err; }
+
+int plv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+void plv_config_default(plv_config *c, int width, int height) {
+  memset(c, 0, sizeof(*c));
+  c->width = width;
+  c->height = height;
+  c->num_features = 250;
+  c->fast_threshold = 20;
+  c->grid_x = 5;
+  c->grid_y = 5;
+  c->min_px_dist = 10;
+  c->histogram_method = PLV_HIST_HISTOGRAM;
+  c->win_size = 15;
+  c->pyr_levels = 5;
+  c->lk_max_iters = 30;
+  c->lk_eps = 0.01f;
+  c->ransac_thr_px = 2.0;
+  c->ransac_conf = 0.999;
+  c->ransac_max_iters = 1000;
+  const double intr[8] = {458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05};
+  for (int i = 0; i < 8; ++i) c->intrinsics[i] = intr[i];
+  c->intrinsics[2] *= width / 752.0;
+  c->intrinsics[3] *= height / 480.0;
+  c->line_length_threshold = 20;
+  c->line_distance_threshold = 1.414213562f;
+  c->canny_th1 = 50;
+  c->canny_th2 = 50;
+  c->canny_aperture = 3;
+  c->line_min_length_px = 40.f;
+  c->line_assign_px = 5.f;
+  c->line_similar_px = 6.f;
+  c->max_state_dim = 160;
+  c->max_meas_rows = 8192;
+  c->max_features = 512;
+  c->max_rows_per_feat = 48;
+  c->sigma_pix = 1.5;
+  c->chi2_mult = 1.0;
+  c->device = 0;
+}
+
+int plv_ctx_create(const plv_config *cfg, plv_ctx **out) {
+  if (!cfg || !out) {
+    set_last_error("plv_ctx_create: null argument");
+    return PLV_E_BADARG;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+    set_last_error("no HIP device %d visible (this library has no CPU fallback)", cfg->device);
+    return PLV_E_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_last_error("device %d is not gfx950 (the code objects are gfx950-only)", cfg->device);
+    return PLV_E_NO_DEVICE;
+  }
+  PLV_HIP_CHECK(hipSetDevice(cfg->device));
+  plv_ctx *ctx = new plv_ctx();
+  ctx->cfg = *cfg;
+  ctx->device = cfg->device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    set_last_error("hipStreamCreate failed");
+    return PLV_E_DEVICE;
+  }
+  auto *us = new plv_ctx_update_state();
+  // chi-square table (REF: UpdaterStatistics.cpp:31-37)
+  std::vector<double> q(Q95_N, 0.0);
+  for (int i = 1; i < Q95_N; ++i) q[i] = chi2_quantile(i, 0.95);
+  int rc = us->q95.reserve(Q95_N * 8);
+  if (rc == PLV_OK && hipMemcpy(us->q95.p, q.data(), Q95_N * 8, hipMemcpyHostToDevice) != hipSuccess) rc = PLV_E_DEVICE;
+  if (rc != PLV_OK) {
+    delete us;
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_state_mtx);
+    g_states.push_back({ctx, us});
+  }
+  *out = ctx;
+  return PLV_OK;
+}
+
+void plv_frontend_destroy(plv_ctx *ctx);  // frontend_api.hip
+
+void plv_ctx_destroy(plv_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  plv_frontend_destroy(ctx);
+  ctx->prof.destroy();
+  plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
+                         &ctx->d_Mt, &ctx->d_S, &ctx->d_W, &ctx->d_y, &ctx->d_fHf, &ctx->d_fHx, &ctx->d_fres,
+                         &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2};
+  for (auto *b : bufs) b->release();
+  ctx->h_pin.release();
+  plv_ctx_update_state *us = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_state_mtx);
+    for (size_t i = 0; i < g_states.size(); ++i)
+      if (g_states[i].first == ctx) {
+        us = g_states[i].second;
+        g_states.erase(g_states.begin() + i);
+        break;
+      }
+  }
+  if (us) {
+    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols};
+    for (auto *b : ub) b->release();
+    delete us;
+  }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int plv_ctx_synchronize(plv_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  return sync(ctx);
+}
+
+int plv_prof_enable(plv_ctx *ctx, int on) {
+  REQUIRE_CTX(ctx);
+  TRY(sync(ctx));
+  ctx->prof.on = on != 0;
+  return PLV_OK;
+}
+int plv_prof_reset(plv_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  TRY(sync(ctx));
+  ctx->prof.reset();
+  return PLV_OK;
+}
+int plv_prof_count(plv_ctx *ctx) { return ctx ? (int)ctx->prof.recs.size() : 0; }
+int plv_prof_get(plv_ctx *ctx, int idx, char *name, int name_cap, int *launches, double *total_ms) {
+  if (!ctx || idx < 0 || idx >= (int)ctx->prof.recs.size()) return PLV_E_BADARG;
+  const auto &r = ctx->prof.recs[idx];
+  if (name && name_cap > 0) {
+    strncpy(name, r.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (launches) *launches = r.launches;
+  if (total_ms) *total_ms = r.total_ms;
+  return PLV_OK;
+}
+
+double plv_chi2_quantile95(int dof) { return chi2_quantile(dof, 0.95); }
+
+// ------------------------------------------------------------------------------ covariance
+int plv_cov_upload(plv_ctx *ctx, const double *P, int n, int ldp) {
+  REQUIRE_CTX(ctx);
+  if (!P || n < 1 || ldp < n) {
+    set_last_error("plv_cov_upload: bad argument");
+    return PLV_E_BADARG;
+  }
+  TRY(ctx->d_P.reserve((size_t)n * n * 8));
+  TRY(upload_mat(ctx, ctx->d_P.as<double>(), P, n, n, ldp));
+  ctx->cov_n = n;
+  return sync(ctx);
+}
+int plv_cov_download(plv_ctx *ctx, double *P, int n, int ldp) {
+  REQUIRE_CTX(ctx);
+  if (!P || n != ctx->cov_n || ldp < n) {
+    set_last_error("plv_cov_download: bad argument (resident n = %d)", ctx->cov_n);
+    return PLV_E_BADARG;
+  }
+  TRY(download_mat(ctx, P, ctx->d_P.as<double>(), n, n, ldp));
+  return sync(ctx);
+}
+int plv_cov_checkpoint(plv_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  if (ctx->cov_n < 1) return PLV_E_BADARG;
+  size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
+  TRY(us->covck.reserve(bytes));
+  PLV_HIP_CHECK(hipMemcpyAsync(us->covck.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return sync(ctx);
+}
+int plv_cov_rollback(plv_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  if (ctx->cov_n < 1 || !us->covck.p) return PLV_E_BADARG;
+  size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
+  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, us->covck.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return PLV_OK;  // ordered on the ctx stream; no host sync needed
+}
+
+// ------------------------------------------------------------------------------ EKF update
+static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, double **dx, int **flag, unsigned char **acc) {
+  size_t bytes = (size_t)n * 8 + 16 + (size_t)F + 16;
+  TRY(us->result.reserve(bytes));
+  char *b = us->result.as<char>();
+  *dx = (double *)b;
+  *flag = (int *)(b + (size_t)n * 8);
+  *acc = (unsigned char *)(b + (size_t)n * 8 + 16);
+  return PLV_OK;
+}
+
+int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int r, int k, int ldh,
+                   const int *col_to_state, const double *res, const double *Rdiag, double *dx) {
+  REQUIRE_CTX(ctx);
+  if (!H || !col_to_state || !res || !dx || r < 1 || k < 1 || ldh < r || n < 1) {
+    set_last_error("plv_ekf_update: bad argument");
+    return PLV_E_BADARG;
+  }
+  for (int j = 0; j < k; ++j)
+    if (col_to_state[j] < 0 || col_to_state[j] >= n) {
+      set_last_error("plv_ekf_update: col_to_state[%d]=%d out of range", j, col_to_state[j]);
+      return PLV_E_BADARG;
+    }
+  auto *us = ustate(ctx);
+  if (P) {
+    if (ldp < n) return PLV_E_BADARG;
+    TRY(ctx->d_P.reserve((size_t)n * n * 8));
+    TRY(upload_mat(ctx, ctx->d_P.as<double>(), P, n, n, ldp));
+    ctx->cov_n = n;
+  } else if (ctx->cov_n != n) {
+    set_last_error("plv_ekf_update: no device-resident covariance of dimension %d", n);
+    return PLV_E_BADARG;
+  }
+  TRY(ctx->d_H.reserve((size_t)r * k * 8));
+  TRY(ctx->d_res.reserve((size_t)r * 8));
+  TRY(ctx->d_cols.reserve((size_t)k * 4));
+  TRY(upload_mat(ctx, ctx->d_H.as<double>(), H, r, k, ldh));
+  TRY(h2d(ctx, ctx->d_res.p, res, (size_t)r * 8));
+  TRY(h2d(ctx, ctx->d_cols.p, col_to_state, (size_t)k * 4));
+  const double *dR = nullptr;
+  if (Rdiag) {
+    TRY(ctx->d_Rdiag.reserve((size_t)r * 8));
+    TRY(h2d(ctx, ctx->d_Rdiag.p, Rdiag, (size_t)r * 8));
+    dR = ctx->d_Rdiag.as<double>();
+  }
+  double *d_dx;
+  int *d_flag;
+  unsigned char *d_acc;
+  TRY(result_buf(ctx, us, n, 0, &d_dx, &d_flag, &d_acc));
+  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, ctx->d_H.as<double>(), r, k, r, ctx->d_cols.as<int>(),
+                 ctx->d_res.as<double>(), dR, d_dx, d_flag));
+  size_t rb = (size_t)n * 8 + 16;
+  TRY(ctx->h_pin.reserve(rb));
+  TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
+  TRY(sync(ctx));
+  int flag = *(int *)(ctx->h_pin.as<char>() + (size_t)n * 8);
+  if (flag != 0) {
+    set_last_error("EKFUpdate rejected: %s", (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
+    return PLV_E_NOT_PSD;
+  }
+  memcpy(dx, ctx->h_pin.p, (size_t)n * 8);
+  if (P) {
+    TRY(download_mat(ctx, P, ctx->d_P.as<double>(), n, n, ldp));
+    TRY(sync(ctx));
+  }
+  return PLV_OK;
+}
+
+// ------------------------------------------------------------------------------ compress
+int plv_compress(plv_ctx *ctx, double *H, int m, int k, int ldh, double *res, int *m_out) {
+  REQUIRE_CTX(ctx);
+  if (!H || !res || !m_out || m < 1 || k < 1 || ldh < m) {
+    set_last_error("plv_compress: bad argument");
+    return PLV_E_BADARG;
+  }
+  if (m <= k) {  // REF: StateHelper.cpp:605 fat matrix -> nothing to do
+    *m_out = m;
+    return PLV_OK;
+  }
+  const int nc = k + 1;
+  TRY(ctx->d_stack.reserve((size_t)m * nc * 8));
+  size_t tmp_elems = (size_t)(m / (2 * nc) + 2) * nc * nc;
+  TRY(ctx->d_stack2.reserve(tmp_elems * 8));
+  double *A = ctx->d_stack.as<double>();
+  TRY(upload_mat(ctx, A, H, m, k, ldh));
+  TRY(h2d(ctx, A + (size_t)m * k, res, (size_t)m * 8));
+  double *R;
+  int ldr;
+  TRY(launch_tsqr(ctx, A, m, m, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
+  // top k rows of [R | z]
+  PLV_HIP_CHECK(hipMemcpy2DAsync(H, (size_t)ldh * 8, R, (size_t)ldr * 8, (size_t)k * 8, k, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  TRY(d2h(ctx, res, R + (size_t)k * ldr, (size_t)k * 8));
+  TRY(sync(ctx));
+  *m_out = k;
+  return PLV_OK;
+}
+
+// ------------------------------------------------------------------------------ batches
+static int check_batch(int F, int fdim, int k, int ld, const int *rows) {
+  if (F < 1 || fdim < 1 || k < 1 || ld < 1 || !rows) {
+    set_last_error("feature batch: bad argument");
+    return PLV_E_BADARG;
+  }
+  for (int f = 0; f < F; ++f)
+    if (rows[f] < 0 || rows[f] > ld) {
+      set_last_error("feature batch: rows[%d]=%d exceeds ld=%d", f, rows[f], ld);
+      return PLV_E_BADARG;
+    }
+  return PLV_OK;
+}
+
+int plv_nullspace_batch(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *rows, double *Hf, double *Hx,
+                        double *res) {
+  REQUIRE_CTX(ctx);
+  if (!Hf || !Hx || !res) return PLV_E_BADARG;
+  TRY(check_batch(F, fdim, k, ld, rows));
+  size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  TRY(ctx->d_fHf.reserve(nHf * 8));
+  TRY(ctx->d_fHx.reserve(nHx * 8));
+  TRY(ctx->d_fres.reserve(nr * 8));
+  TRY(ctx->d_frows.reserve((size_t)F * 4));
+  TRY(h2d(ctx, ctx->d_fHf.p, Hf, nHf * 8));
+  TRY(h2d(ctx, ctx->d_fHx.p, Hx, nHx * 8));
+  TRY(h2d(ctx, ctx->d_fres.p, res, nr * 8));
+  TRY(h2d(ctx, ctx->d_frows.p, rows, (size_t)F * 4));
+  TRY(launch_nullspace(ctx, F, fdim, k, ld, ctx->d_frows.as<int>(), ctx->d_fHf.as<double>(), ctx->d_fHx.as<double>(),
+                       ctx->d_fres.as<double>()));
+  TRY(d2h(ctx, Hf, ctx->d_fHf.p, nHf * 8));
+  TRY(d2h(ctx, Hx, ctx->d_fHx.p, nHx * 8));
+  TRY(d2h(ctx, res, ctx->d_fres.p, nr * 8));
+  return sync(ctx);
+}
+
+int plv_chi2_batch(plv_ctx *ctx, const double *P, int n, int ldp, int F, int k, int ld, const int *rows,
+                   const double *Hx, const double *res, const int *col_to_state, double sigma2, double *chi2) {
+  REQUIRE_CTX(ctx);
+  if (!Hx || !res || !col_to_state || !chi2) return PLV_E_BADARG;
+  TRY(check_batch(F, 1, k, ld, rows));
+  auto *us = ustate(ctx);
+  if (P) {
+    TRY(ctx->d_P.reserve((size_t)n * n * 8));
+    TRY(upload_mat(ctx, ctx->d_P.as<double>(), P, n, n, ldp));
+    ctx->cov_n = n;
+  } else if (ctx->cov_n != n) {
+    return PLV_E_BADARG;
+  }
+  size_t nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  TRY(ctx->d_fHx.reserve(nHx * 8));
+  TRY(ctx->d_fres.reserve(nr * 8));
+  TRY(ctx->d_frows.reserve((size_t)F * 4));
+  TRY(ctx->d_cols.reserve((size_t)k * 4));
+  TRY(ctx->d_chi2.reserve((size_t)F * 8));
+  TRY(h2d(ctx, ctx->d_fHx.p, Hx, nHx * 8));
+  TRY(h2d(ctx, ctx->d_fres.p, res, nr * 8));
+  TRY(h2d(ctx, ctx->d_frows.p, rows, (size_t)F * 4));
+  TRY(h2d(ctx, ctx->d_cols.p, col_to_state, (size_t)k * 4));
+  int max_mp = 0;
+  for (int f = 0; f < F; ++f) max_mp = rows[f] > max_mp ? rows[f] : max_mp;
+  Chi2Args a{};
+  a.P = ctx->d_P.as<double>();
+  a.ldp = n;
+  a.k = k;
+  a.ld = ld;
+  a.fdim_off = 0;
+  a.rows = ctx->d_frows.as<int>();
+  a.Hx = ctx->d_fHx.as<double>();
+  a.res = ctx->d_fres.as<double>();
+  a.cols = ctx->d_cols.as<int>();
+  a.sigma2 = sigma2;
+  a.chi2 = ctx->d_chi2.as<double>();
+  a.stack = nullptr;
+  a.q95 = us->q95.as<double>();
+  a.q95_n = Q95_N;
+  a.min_rows = 1;
+  TRY(launch_chi2(ctx, F, a, max_mp));
+  TRY(d2h(ctx, chi2, ctx->d_chi2.p, (size_t)F * 8));
+  return sync(ctx);
+}
+
+int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *rows, const double *Hf,
+                          const double *Hx, const double *res, const int *col_to_state) {
+  REQUIRE_CTX(ctx);
+  if (!Hf || !Hx || !res || !col_to_state) return PLV_E_BADARG;
+  TRY(check_batch(F, fdim, k, ld, rows));
+  auto *us = ustate(ctx);
+  size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  TRY(us->bHf.reserve(nHf * 8));
+  TRY(us->bHx.reserve(nHx * 8));
+  TRY(us->bres.reserve(nr * 8));
+  TRY(us->brows.reserve((size_t)F * 4));
+  TRY(us->bcols.reserve((size_t)k * 4));
+  TRY(h2d(ctx, us->bHf.p, Hf, nHf * 8));
+  TRY(h2d(ctx, us->bHx.p, Hx, nHx * 8));
+  TRY(h2d(ctx, us->bres.p, res, nr * 8));
+  TRY(h2d(ctx, us->brows.p, rows, (size_t)F * 4));
+  TRY(h2d(ctx, us->bcols.p, col_to_state, (size_t)k * 4));
+  us->bF = F;
+  us->bfdim = fdim;
+  us->bk = k;
+  us->bld = ld;
+  us->brows_host.assign(rows, rows + F);
+  us->bmaxrows = 0;
+  for (int f = 0; f < F; ++f) us->bmaxrows = rows[f] > us->bmaxrows ? rows[f] : us->bmaxrows;
+  return sync(ctx);
+}
+
+int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate, uint8_t *accepted,
+                              int *n_accepted_rows, double *dx) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  if (us->bF < 1 || ctx->cov_n < 1 || !dx) {
+    set_last_error("plv_msckf_update_resident: no staged batch / covariance");
+    return PLV_E_BADARG;
+  }
+  const int F = us->bF, fdim = us->bfdim, k = us->bk, ld = us->bld, n = ctx->cov_n;
+  size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  TRY(ctx->d_fHf.reserve(nHf * 8));
+  TRY(ctx->d_fHx.reserve(nHx * 8));
+  TRY(ctx->d_fres.reserve(nr * 8));
+  TRY(ctx->d_chi2.reserve((size_t)F * 8));
+  // working copies (the nullspace projection is in place)
+  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fHf.p, us->bHf.p, nHf * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fHx.p, us->bHx.p, nHx * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fres.p, us->bres.p, nr * 8, hipMemcpyDeviceToDevice, ctx->stream));
+
+  const int mp_max = us->bmaxrows - fdim;
+  if (mp_max < 1) {
+    set_last_error("plv_msckf_update: no feature has more than fdim rows");
+    return PLV_E_BADARG;
+  }
+  const int nc = k + 1;
+  const int Mtot = F * mp_max;
+  TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
+  size_t tmp_elems = (size_t)(Mtot / (2 * nc) + 2) * nc * nc;
+  TRY(ctx->d_stack2.reserve(tmp_elems * 8));
+
+  double *d_dx;
+  int *d_flag;
+  unsigned char *d_acc;
+  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc));
+
+  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), ctx->d_fHf.as<double>(), ctx->d_fHx.as<double>(),
+                       ctx->d_fres.as<double>()));
+  Chi2Args a{};
+  a.P = ctx->d_P.as<double>();
+  a.ldp = n;
+  a.k = k;
+  a.ld = ld;
+  a.fdim_off = fdim;
+  a.rows = us->brows.as<int>();
+  a.Hx = ctx->d_fHx.as<double>();
+  a.res = ctx->d_fres.as<double>();
+  a.cols = us->bcols.as<int>();
+  a.sigma2 = sigma2;
+  a.chi2 = ctx->d_chi2.as<double>();
+  a.stack = ctx->d_stack.as<double>();
+  a.lds = Mtot;
+  a.mp_max = mp_max;
+  a.chi2_mult = chi2_mult;
+  a.res_norm_gate = res_norm_gate;
+  a.q95 = us->q95.as<double>();
+  a.q95_n = Q95_N;
+  a.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
+  a.accepted = d_acc;
+  TRY(launch_chi2(ctx, F, a, mp_max));
+
+  const double *dH, *dr;
+  int r, ldh;
+  if (Mtot > k) {
+    double *R;
+    int ldr;
+    TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
+    dH = R;
+    dr = R + (size_t)k * ldr;
+    r = k;
+    ldh = ldr;
+  } else {
+    dH = ctx->d_stack.as<double>();
+    dr = dH + (size_t)k * Mtot;
+    r = Mtot;
+    ldh = Mtot;
+  }
+  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
+  size_t rb = (size_t)n * 8 + 16 + F;
+  TRY(ctx->h_pin.reserve(rb));
+  TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
+  TRY(sync(ctx));
+  const char *hb = ctx->h_pin.as<char>();
+  int flag = *(const int *)(hb + (size_t)n * 8);
+  const unsigned char *hacc = (const unsigned char *)(hb + (size_t)n * 8 + 16);
+  int nrows = 0;
+  for (int f = 0; f < F; ++f) {
+    if (accepted) accepted[f] = hacc[f];
+    if (hacc[f]) nrows += us->brows_host[f] - fdim;
+  }
+  if (n_accepted_rows) *n_accepted_rows = nrows;
+  if (flag != 0) {
+    set_last_error("EKFUpdate rejected: %s", (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
+    return PLV_E_NOT_PSD;
+  }
+  memcpy(dx, hb, (size_t)n * 8);
+  return PLV_OK;
+}
+
+int plv_msckf_update(plv_ctx *ctx, double *P, int n, int ldp, int F, int fdim, int k, int ld, const int *rows,
+                     const double *Hf, const double *Hx, const double *res, const int *col_to_state, double sigma2,
+                     double chi2_mult, double res_norm_gate, uint8_t *accepted, int *n_accepted_rows, double *dx) {
+  REQUIRE_CTX(ctx);
+  if (P) {
+    TRY(plv_cov_upload(ctx, P, n, ldp));
+  } else if (ctx->cov_n != n) {
+    set_last_error("plv_msckf_update: no device-resident covariance of dimension %d", n);
+    return PLV_E_BADARG;
+  }
+  for (int j = 0; j < k; ++j)
+    if (!col_to_state || col_to_state[j] < 0 || col_to_state[j] >= n) {
+      set_last_error("plv_msckf_update: col_to_state out of range");
+      return PLV_E_BADARG;
+    }
+  TRY(plv_feat_batch_upload(ctx, F, fdim, k, ld, rows, Hf, Hx, res, col_to_state));
+  int rc = plv_msckf_update_resident(ctx, sigma2, chi2_mult, res_norm_gate, accepted, n_accepted_rows, dx);
+  if (rc == PLV_OK && P) rc = plv_cov_download(ctx, P, n, ldp);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// plv_ctx.hpp — library context: HIP stream, device workspaces, profiling events.
+// Product code (never includes anything from oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plviwo.h"
+
+namespace plv {
+
+void set_last_error(const char *fmt, ...);
+
+#define PLV_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      plv::set_last_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return PLV_E_DEVICE;                                                               \
+    }                                                                                    \
+  } while (0)
+
+// A grow-only device buffer.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return PLV_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      set_last_error("hipMalloc(%zu) failed", want);
+      return PLV_E_NOMEM;
+    }
+    cap = want;
+    return PLV_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// Pinned host staging buffer (grow-only).
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return PLV_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+      set_last_error("hipHostMalloc(%zu) failed", want);
+      return PLV_E_NOMEM;
+    }
+    cap = want;
+    return PLV_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// HIP-event timing per kernel class, on the ctx stream.
+struct Profiler {
+  struct Rec {
+    std::string name;
+    int launches = 0;
+    double total_ms = 0.0;
+  };
+  struct Pending {
+    int rec;
+    hipEvent_t a, b;
+  };
+  bool on = false;
+  std::vector<Rec> recs;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+
+  int find(const char *name) {
+    for (size_t i = 0; i < recs.size(); ++i)
+      if (recs[i].name == name) return (int)i;
+    recs.push_back(Rec{name, 0, 0.0});
+    return (int)recs.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(const char *name, hipStream_t s) {
+    if (!on) return;
+    Pending p;
+    p.rec = find(name);
+    p.a = get_event();
+    p.b = get_event();
+    (void)hipEventRecord(p.a, s);
+    pending.push_back(p);
+  }
+  void end(hipStream_t s) {
+    if (!on) return;
+    (void)hipEventRecord(pending.back().b, s);
+  }
+  // call after a stream sync
+  void collect() {
+    for (auto &p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        recs[p.rec].launches++;
+        recs[p.rec].total_ms += ms;
+      }
+      pool.push_back(p.a);
+      pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void reset() {
+    for (auto &r : recs) r.launches = 0, r.total_ms = 0.0;
+  }
+  void destroy() {
+    collect();
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+};
+
+struct ProfScope {
+  Profiler &p;
+  hipStream_t s;
+  ProfScope(Profiler &p_, const char *name, hipStream_t s_) : p(p_), s(s_) { p.begin(name, s); }
+  ~ProfScope() { p.end(s); }
+};
+
+}  // namespace plv
+
+struct plv_ctx {
+  plv_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  plv::Profiler prof;
+
+  // ---- update side
+  int cov_n = 0;          // dimension of the device-resident covariance (0 = none)
+  plv::DevBuf d_P;        // n x n col-major, ld = n
+  plv::DevBuf d_H, d_res, d_cols, d_Rdiag, d_dx, d_flag;
+  plv::DevBuf d_Mt, d_S, d_W, d_y;          // EKF workspaces
+  plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
+  plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
+  plv::PinBuf h_pin;
+};

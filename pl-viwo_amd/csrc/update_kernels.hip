@@ -1,0 +1,640 @@
+// update_kernels.hip — gfx950 kernels of the EKF-update half of the hot path (fp64).
+//
+//   nullspace_kernel   K11  StateHelper::nullspace_project_inplace   REF: PL/state/StateHelper.cpp:616-651
+//   chi2_gate_kernel   K12  UpdaterStatistics::get_chi2 + the gate   REF: PL/update/UpdaterStatistics.cpp:94-117,
+//                                                                         PL/update/cam/UpdaterCamera.cpp:237-263
+//   qr_accum_kernel    K13  StateHelper::measurement_compress_inplace REF: StateHelper.cpp:602-614,653-672
+//   ekf_*_kernel       K14  StateHelper::EKFUpdate                   REF: StateHelper.cpp:94-173
+//
+// Design notes (DESIGN.md has the long form):
+//  * wave = 64 lanes; every dense contraction goes through v_mfma_f64_16x16x4_f64 tiles, one
+//    16x16 output tile per wave, operands read straight from L2-resident global memory or LDS
+//    (the matrices are ~100x100: nothing here is HBM-bound, everything is latency-bound);
+//  * the Givens nullspace keeps the reference's exact rotation order, one thread per column with
+//    the pivot column replicated, so no intra-pass communication is needed;
+//  * the compression is a Householder TSQR: a row chunk lives in registers (16 rows x 1 column
+//    per thread), the running R factor in LDS.
+#include "plv_ctx.hpp"
+#include "update_kernels.hpp"
+
+namespace plv {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// One wave computes one 16x16 fp64 tile  acc(i,j) += sum_k a(i,k) * b(k,j)  with
+// v_mfma_f64_16x16x4_f64.  Operand lane map: lane l feeds A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; result lane map: col = l&15, row = (l>>4) + 4*reg.
+// All 64 lanes must call this together (EXEC all ones); accessors return 0 out of range.
+template <class FA, class FB>
+__device__ __forceinline__ d4 mfma_tile_f64(FA a, FB b, int K, d4 acc) {
+  const int lane = threadIdx.x & 63;
+  const int ij = lane & 15, kq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int kk = k0 + kq;
+    const bool in = kk < K;
+    const double av = in ? a(ij, kk) : 0.0;
+    const double bv = in ? b(kk, ij) : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Eigen::JacobiRotation<double>::makeGivens, real case (Eigen/src/Jacobi/Jacobi.h).
+__device__ __forceinline__ void make_givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0.0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0.0 ? 1.0 : -1.0;
+  } else if (fabs(p) > fabs(q)) {
+    double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0.0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0.0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K11: one workgroup per feature.  X = [Hf | Hx | res] (rows x ncol) staged row-major in LDS,
+// one thread per column.  For pivot column n the rotation sequence m = rows-1 .. n+1 is the
+// reference's; (c,s) are recomputed by every thread from a read-only copy of the pivot column,
+// which reproduces bit-for-bit what the column's owner computes, so threads never wait on each
+// other inside a pass.
+__global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld, const int *__restrict__ rows_arr,
+                                                        double *__restrict__ Hf, double *__restrict__ Hx,
+                                                        double *__restrict__ res) {
+  extern __shared__ double smem[];
+  const int f = blockIdx.x;
+  const int rows = rows_arr[f];
+  const int ncol = fdim + k + 1;
+  double *X = smem;               // [ld][ncol]
+  double *piv = smem + ld * ncol; // [ld]
+  double *gHf = Hf + (size_t)f * fdim * ld;
+  double *gHx = Hx + (size_t)f * k * ld;
+  double *gres = res + (size_t)f * ld;
+  if (rows <= fdim) return;
+
+  for (int idx = threadIdx.x; idx < rows * ncol; idx += blockDim.x) {
+    int j = idx / rows, i = idx - j * rows;
+    double v = j < fdim ? gHf[j * ld + i] : (j < fdim + k ? gHx[(j - fdim) * ld + i] : gres[i]);
+    X[i * ncol + j] = v;
+  }
+  for (int n = 0; n < fdim; ++n) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) piv[i] = X[i * ncol + n];
+    __syncthreads();
+    for (int j = n + threadIdx.x; j < ncol; j += blockDim.x) {
+      double carry_p = piv[rows - 1];
+      double carry_o = X[(rows - 1) * ncol + j];
+      for (int m = rows - 1; m > n; --m) {
+        const double p = piv[m - 1];
+        const double q = carry_p;
+        const double up = X[(m - 1) * ncol + j];
+        if (q == 0.0) {  // REF: `if (A(m, n) == 0.0) continue;`
+          X[m * ncol + j] = carry_o;
+          carry_p = p;
+          carry_o = up;
+          continue;
+        }
+        double c, s;
+        make_givens(p, q, c, s);
+        carry_p = c * p - s * q;
+        const double nu = c * up - s * carry_o;
+        const double nl = s * up + c * carry_o;
+        X[m * ncol + j] = (j == n) ? 0.0 : nl;  // REF: `A(m, n) = 0;`
+        carry_o = nu;
+      }
+      X[n * ncol + j] = carry_o;
+    }
+  }
+  __syncthreads();
+  // write back: Hf whole (upper-triangular now), Hx / res shifted up by fdim rows
+  for (int idx = threadIdx.x; idx < rows * fdim; idx += blockDim.x) {
+    int j = idx / rows, i = idx - j * rows;
+    gHf[j * ld + i] = X[i * ncol + j];
+  }
+  const int mp = rows - fdim;
+  for (int idx = threadIdx.x; idx < mp * (k + 1); idx += blockDim.x) {
+    int j = idx / mp, i = idx - j * mp;
+    double v = X[(i + fdim) * ncol + fdim + j];
+    if (j < k)
+      gHx[j * ld + i] = v;
+    else
+      gres[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K12: one workgroup (4 waves) per feature.  mp = rows[f] - fdim_off projected rows.
+//   T = H' * P[cols,cols]   (MFMA tiles, T kept in LDS)
+//   S = T * H'^T + sigma2 I (MFMA tiles, S in LDS)
+//   Cholesky of the bordered matrix [S r; r^T .] by wave 0 (lane = row): the border row is
+//   y = L^-1 r, so chi2 = |y|^2  (== r^T S^-1 r, what the reference gets from S.inverse()).
+// If `stack` is non-null the gate is applied and the accepted system is copied (rejected: zeros)
+// into rows [f*mp_max, (f+1)*mp_max) of the stacked matrix [H | r] (col-major, ld = lds).
+
+#define CHI2_MAXM 63
+
+__global__ void __launch_bounds__(256) chi2_gate_kernel(Chi2Args a) {
+  extern __shared__ double smem[];
+  const int f = blockIdx.x;
+  const int rows_f = a.rows[f];
+  const int mp = rows_f - a.fdim_off;
+  const int k = a.k, ld = a.ld;
+  const int mt = (max(mp, 1) + 15) >> 4, kt = (k + 15) >> 4;
+  const int kp = kt * 16 + 1;            // padded row length of T
+  double *T = smem;                      // [mt*16][kp]
+  double *S = T + mt * 16 * kp;          // [64][65]  bordered
+  const double *H = a.Hx + (size_t)f * k * ld;
+  const double *r = a.res + (size_t)f * ld;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int trow = lane >> 4, tcol = lane & 15;
+
+  bool valid = mp >= 1 && mp <= CHI2_MAXM && rows_f >= a.min_rows;
+  double chi = NAN;
+  double nrm2 = 0.0;
+  if (valid) {
+    // T = H' Ps
+    for (int t = wave; t < mt * kt; t += 4) {
+      const int ti = t / kt, tj = t - ti * kt;
+      d4 acc = {0, 0, 0, 0};
+      auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < mp ? H[kk * ld + row] : 0.0; };
+      auto fb = [&](int kk, int j) {
+        int col = tj * 16 + j;
+        return col < k ? a.P[(size_t)a.cols[col] * a.ldp + a.cols[kk]] : 0.0;
+      };
+      acc = mfma_tile_f64(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[(ti * 16 + trow + 4 * q) * kp + tj * 16 + tcol] = acc[q];
+    }
+    __syncthreads();
+    // S = T H'^T + sigma2 I  (full; symmetric up to rounding, upper triangle is what is used)
+    for (int t = wave; t < mt * mt; t += 4) {
+      const int ti = t / mt, tj = t - ti * mt;
+      d4 acc = {0, 0, 0, 0};
+      auto fa = [&](int i, int kk) { return T[(ti * 16 + i) * kp + kk]; };
+      auto fb = [&](int kk, int j) { int row = tj * 16 + j; return row < mp ? H[kk * ld + row] : 0.0; };
+      acc = mfma_tile_f64(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = ti * 16 + trow + 4 * q, j = tj * 16 + tcol;
+        if (i < mp && j < mp) S[i * 65 + j] = acc[q] + (i == j ? a.sigma2 : 0.0);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // mirror upper -> lower (REF: selfadjointView<Upper>), then border row mp = res
+      for (int j = 0; j < mp; ++j)
+        if (lane < mp && lane > j) S[lane * 65 + j] = S[j * 65 + lane];
+      if (lane < mp) S[mp * 65 + lane] = r[lane];
+      double rv = lane < mp ? r[lane] : 0.0;
+      nrm2 = wave_sum(rv * rv);
+      // left-looking Cholesky, lane = row (rows 0..mp, row mp is the border)
+      bool bad = false;
+      for (int j = 0; j < mp; ++j) {
+        double s = 0.0;
+        if (lane >= j && lane <= mp) {
+          s = S[lane * 65 + j];
+          for (int p = 0; p < j; ++p) s -= S[lane * 65 + p] * S[j * 65 + p];
+        }
+        double d = __shfl(s, j, 64);
+        if (!(d > 0.0)) bad = true;
+        double ljj = sqrt(d);
+        if (lane >= j && lane <= mp) S[lane * 65 + j] = (lane == j) ? ljj : s / ljj;
+      }
+      double y = lane < mp ? S[mp * 65 + lane] : 0.0;
+      chi = wave_sum(y * y);
+      if (bad) chi = NAN;
+    }
+  }
+  if (wave == 0 && lane == 0) {
+    a.chi2[f] = chi;
+    S[64 * 65] = 0.0;
+    if (a.stack) {
+      bool pass = valid && !isnan(chi);
+      if (pass && a.res_norm_gate > 0.0) pass = sqrt(nrm2) < a.res_norm_gate;
+      if (pass) pass = (mp < a.q95_n) && (chi < a.chi2_mult * a.q95[mp]);
+      a.accepted[f] = pass ? 1 : 0;
+      S[64 * 65] = pass ? 1.0 : 0.0;
+    }
+  }
+  if (a.stack) {
+    __syncthreads();
+    const bool pass = S[64 * 65] != 0.0;
+    double *dst = a.stack + (size_t)f * a.mp_max;
+    for (int idx = threadIdx.x; idx < a.mp_max * (k + 1); idx += blockDim.x) {
+      int j = idx / a.mp_max, i = idx - j * a.mp_max;
+      double v = 0.0;
+      if (pass && i < mp) v = j < k ? H[j * ld + i] : r[i];
+      dst[(size_t)j * a.lds + i] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K13: Householder TSQR.  Workgroup w reduces rows [w*rows_per_wg, (w+1)*rows_per_wg) of the
+// m x nc matrix A (col-major, lda; the last column is the residual) to an nc x nc upper
+// triangle R_w, written row-major-free as col-major [nc x nc] at out + w*nc (ld = ldo), so the
+// outputs of all workgroups form the next level's input matrix.
+// Thread t = 4*c + part owns, for column c, rows part*16 .. part*16+15 of the current 64-row
+// chunk in registers; the running R lives in LDS (row-major nc x nc).
+#define QR_RPT 16
+#define QR_PARTS 4
+#define QR_CHUNK (QR_RPT * QR_PARTS)
+
+__global__ void __launch_bounds__(1024) qr_accum_kernel(const double *__restrict__ A, int lda, int m, int nc,
+                                                        int rows_per_wg, double *__restrict__ out, int ldo,
+                                                        int sign_fix) {
+  extern __shared__ double smem[];
+  double *R = smem;              // [nc][nc] row-major
+  double *v = R + nc * nc;       // [QR_CHUNK] reflector tail
+  double *hdr = v + QR_CHUNK;    // [0]=tau  [1]=unused
+  const int t = threadIdx.x;
+  const int c = t >> 2, part = t & 3;
+  const bool active = c < nc;
+  const int row_begin = blockIdx.x * rows_per_wg;
+  const int row_end = min(m, row_begin + rows_per_wg);
+
+  for (int idx = t; idx < nc * nc; idx += blockDim.x) R[idx] = 0.0;
+  __syncthreads();
+
+  for (int r0 = row_begin; r0 < row_end; r0 += QR_CHUNK) {
+    double b[QR_RPT];
+#pragma unroll
+    for (int i = 0; i < QR_RPT; ++i) {
+      int row = r0 + part * QR_RPT + i;
+      b[i] = (active && row < row_end) ? A[(size_t)c * lda + row] : 0.0;
+    }
+    for (int j = 0; j < nc; ++j) {
+      // ---- reflector for column j from [R_jj ; chunk column j]
+      if (c == j) {
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < QR_RPT; ++i) ss += b[i] * b[i];
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        const double alpha = R[j * nc + j];
+        double tau = 0.0, scale = 0.0, beta = alpha;
+        if (ss > 0.0) {
+          beta = sqrt(alpha * alpha + ss);
+          if (alpha >= 0.0) beta = -beta;
+          tau = (beta - alpha) / beta;
+          scale = 1.0 / (alpha - beta);
+        }
+#pragma unroll
+        for (int i = 0; i < QR_RPT; ++i) v[part * QR_RPT + i] = b[i] * scale;
+        if (part == 0) {
+          hdr[0] = tau;
+          R[j * nc + j] = beta;
+        }
+      }
+      __syncthreads();
+      const double tau = hdr[0];
+      if (active && c > j && tau != 0.0) {
+        double vv[QR_RPT];
+        double w = 0.0;
+#pragma unroll
+        for (int i = 0; i < QR_RPT; ++i) {
+          vv[i] = v[part * QR_RPT + i];
+          w += vv[i] * b[i];
+        }
+        w += __shfl_xor(w, 1, 64);
+        w += __shfl_xor(w, 2, 64);
+        const double rjc = R[j * nc + c];
+        w += rjc;
+        const double tw = tau * w;
+        if (part == 0) R[j * nc + c] = rjc - tw;
+#pragma unroll
+        for (int i = 0; i < QR_RPT; ++i) b[i] -= tw * vv[i];
+      }
+      __syncthreads();
+    }
+  }
+  // ---- write R (col-major into the next level's matrix); optionally make diag >= 0
+  for (int idx = t; idx < nc * nc; idx += blockDim.x) {
+    int i = idx / nc, j = idx - i * nc;
+    double val = j >= i ? R[i * nc + j] : 0.0;
+    if (sign_fix && R[i * nc + i] < 0.0) val = -val;
+    out[(size_t)j * ldo + (size_t)blockIdx.x * nc + i] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K14 pieces.  Mt = H * P[cols, :]  (r x n) == (P[:,cols] H^T)^T  == M_a^T of the reference.
+__global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ H, int ldh, int r, int k,
+                                                     const int *__restrict__ cols, const double *__restrict__ P,
+                                                     int ldp, int n, double *__restrict__ Mt, int ldm) {
+  const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= tr_n * tn_n) return;
+  const int tr = tile / tn_n, tn = tile - tr * tn_n;
+  const int lane = threadIdx.x & 63;
+  d4 acc = {0, 0, 0, 0};
+  auto fa = [&](int i, int kk) { int row = tr * 16 + i; return row < r ? H[(size_t)kk * ldh + row] : 0.0; };
+  auto fb = [&](int kk, int j) { int col = tn * 16 + j; return col < n ? P[(size_t)cols[kk] * ldp + col] : 0.0; };
+  acc = mfma_tile_f64(fa, fb, k, acc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int i = tr * 16 + (lane >> 4) + 4 * q, j = tn * 16 + (lane & 15);
+    if (i < r && j < n) Mt[(size_t)j * ldm + i] = acc[q];
+  }
+}
+
+// S = Mt[:, cols] * H^T + diag(R)   (r x r, col-major ld = lds_)
+__global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ Mt, int ldm, const double *__restrict__ H,
+                                                    int ldh, int r, int k, const int *__restrict__ cols,
+                                                    const double *__restrict__ Rdiag, double *__restrict__ S, int lds_) {
+  const int tn = (r + 15) >> 4;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= tn * tn) return;
+  const int ti = tile / tn, tj = tile - ti * tn;
+  const int lane = threadIdx.x & 63;
+  d4 acc = {0, 0, 0, 0};
+  auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < r ? Mt[(size_t)cols[kk] * ldm + row] : 0.0; };
+  auto fb = [&](int kk, int j) { int row = tj * 16 + j; return row < r ? H[(size_t)kk * ldh + row] : 0.0; };
+  acc = mfma_tile_f64(fa, fb, k, acc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
+    if (i < r && j < r) S[(size_t)j * lds_ + i] = acc[q] + (i == j ? (Rdiag ? Rdiag[i] : 1.0) : 0.0);
+  }
+}
+
+// Cholesky S = L L^T from the UPPER triangle of S (REF: `S.selfadjointView<Upper>().llt()`), one
+// workgroup, S staged in LDS.  Root-free right-looking elimination (one barrier per column), the
+// square roots are taken at the end.  Output L (lower, col-major, ld = ldl).  flag |= 2 on a
+// non-positive pivot.
+__global__ void __launch_bounds__(1024) ekf_chol_kernel(const double *__restrict__ S, int lds_, int r, double *__restrict__ L,
+                                                        int ldl, int *__restrict__ flag) {
+  extern __shared__ double smem[];
+  const int rp = r | 1;  // odd pitch: conflict-free column walks
+  double *A = smem;      // A[i*rp + j], i >= j used
+  for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+    int j = idx / r, i = idx - j * r;
+    if (i >= j) A[i * rp + j] = S[(size_t)i * lds_ + j];  // lower(i,j) := upper(j,i)
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < r; ++j) {
+    const double d = A[j * rp + j];
+    if (!(d > 0.0)) bad = true;
+    const double inv = 1.0 / d;
+    const int nrem = r - 1 - j;
+    // trailing update of the lower triangle: (i, c) with j < c <= i < r
+    for (int idx = threadIdx.x; idx < nrem * nrem; idx += blockDim.x) {
+      int ci = idx / nrem, ii = idx - ci * nrem;
+      int c = j + 1 + ci, i = j + 1 + ii;
+      if (i >= c) A[i * rp + c] -= A[i * rp + j] * A[c * rp + j] * inv;
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+    int j = idx / r, i = idx - j * r;
+    double val = 0.0;
+    if (i >= j) {
+      double sq = sqrt(A[j * rp + j]);
+      val = (i == j) ? sq : A[i * rp + j] / sq;
+    }
+    L[(size_t)j * ldl + i] = val;
+  }
+  if (bad && threadIdx.x == 0) atomicOr(flag, 2);
+}
+
+// W = L^-1 * [Mt | res]  — one wave per right-hand side, L staged in LDS (row-major), lanes split
+// each row's dot product.  Column i < n of W is (K M^T) 's factor: diag(K M^T)_i = |W[:,i]|^2, so the
+// reference's negative-diagonal test (StateHelper.cpp:143-152) is evaluated here: flag |= 1.
+// Column n is y = L^-1 res.
+__global__ void __launch_bounds__(256) ekf_trsm_kernel(const double *__restrict__ L, int ldl, int r,
+                                                       const double *__restrict__ Mt, int ldm, int n,
+                                                       const double *__restrict__ res, const double *__restrict__ P,
+                                                       int ldp, double *__restrict__ W, int ldw, int *__restrict__ flag) {
+  extern __shared__ double smem[];
+  const int rp = r | 1;
+  double *Ls = smem;  // Ls[q*rp + p]
+  for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+    int p = idx / r, q = idx - p * r;
+    Ls[q * rp + p] = L[(size_t)p * ldl + q];
+  }
+  __syncthreads();
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col > n) return;
+  const int lane = threadIdx.x & 63;
+  const double *b = col < n ? Mt + (size_t)col * ldm : res;
+  // x distributed: lane l holds x[l], x[l+64], x[l+128], x[l+192]   (r <= 256)
+  double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+  double ssq = 0.0;
+  for (int q = 0; q < r; ++q) {
+    double part = 0.0;
+    if (lane < q) part += Ls[q * rp + lane] * x0;
+    if (lane + 64 < q) part += Ls[q * rp + lane + 64] * x1;
+    if (lane + 128 < q) part += Ls[q * rp + lane + 128] * x2;
+    if (lane + 192 < q) part += Ls[q * rp + lane + 192] * x3;
+    const double sum = wave_sum(part);
+    const double xq = (b[q] - sum) / Ls[q * rp + q];
+    ssq += xq * xq;
+    const int slot = q >> 6, owner = q & 63;
+    if (lane == owner) {
+      if (slot == 0) x0 = xq;
+      else if (slot == 1) x1 = xq;
+      else if (slot == 2) x2 = xq;
+      else x3 = xq;
+      W[(size_t)col * ldw + q] = xq;
+    }
+  }
+  if (col < n && lane == 0) {
+    if (P[(size_t)col * ldp + col] - ssq < 0.0) atomicOr(flag, 1);
+  }
+}
+
+// P -= W^T W (upper triangle, then mirrored: REF StateHelper.cpp:155-156) and dx = W^T y,
+// only when flag == 0.  Tiles with tj >= ti; the last blocks compute dx.
+__global__ void __launch_bounds__(256) ekf_apply_kernel(const double *__restrict__ W, int ldw, int r, int n,
+                                                        double *__restrict__ P, int ldp, double *__restrict__ dx,
+                                                        const int *__restrict__ flag) {
+  if (*flag != 0) return;
+  const int tn = (n + 15) >> 4;
+  const int ntri = tn * (tn + 1) / 2;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wid < ntri) {
+    // unrank (ti <= tj) from wid
+    int ti = 0, rem = wid;
+    while (rem >= tn - ti) {
+      rem -= tn - ti;
+      ++ti;
+    }
+    const int tj = ti + rem;
+    d4 acc = {0, 0, 0, 0};
+    auto fa = [&](int i, int kk) { int c = ti * 16 + i; return c < n ? W[(size_t)c * ldw + kk] : 0.0; };
+    auto fb = [&](int kk, int j) { int c = tj * 16 + j; return c < n ? W[(size_t)c * ldw + kk] : 0.0; };
+    acc = mfma_tile_f64(fa, fb, r, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
+      if (i < n && j < n && i <= j) {
+        double val = P[(size_t)j * ldp + i] - acc[q];
+        P[(size_t)j * ldp + i] = val;
+        P[(size_t)i * ldp + j] = val;
+      }
+    }
+  } else {
+    // dx: one wave per 64 state entries... simple: wave w handles states [w*64, w*64+64)
+    const int w = wid - ntri;
+    const int i = w * 64 + lane;
+    if (i < n) {
+      const double *y = W + (size_t)n * ldw;
+      double s = 0.0;
+      for (int q = 0; q < r; ++q) s += W[(size_t)i * ldw + q] * y[q];
+      dx[i] = s;
+    }
+  }
+}
+
+// ========================================================================================== launchers
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
+                     double *d_res) {
+  size_t shm = (size_t)(ld * (fdim + k + 1) + ld) * sizeof(double);
+  if (shm > 160 * 1024) {
+    set_last_error("nullspace: feature block of %zu bytes exceeds LDS", shm);
+    return PLV_E_CAPACITY;
+  }
+  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)nullspace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  ProfScope ps(ctx->prof, "nullspace_kernel", ctx->stream);
+  hipLaunchKernelGGL(nullspace_kernel, dim3(F), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp) {
+  if (max_mp > CHI2_MAXM) {
+    set_last_error("chi2: %d projected rows per feature exceeds %d", max_mp, CHI2_MAXM);
+    return PLV_E_CAPACITY;
+  }
+  int mt = (max_mp + 15) / 16, kt = (a.k + 15) / 16;
+  size_t shm = ((size_t)mt * 16 * (kt * 16 + 1) + 65 * 65) * sizeof(double);
+  if (shm > 160 * 1024) {
+    set_last_error("chi2: LDS need %zu", shm);
+    return PLV_E_CAPACITY;
+  }
+  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  ProfScope ps(ctx->prof, "chi2_gate_kernel", ctx->stream);
+  hipLaunchKernelGGL(chi2_gate_kernel, dim3(F), dim3(256), shm, ctx->stream, a);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// Reduces the m x nc col-major matrix at d_A (lda) to an nc x nc upper triangle with
+// non-negative diagonal at d_out (ld = nc... returned in *ld_out).  d_A and d_tmp are ping-pong
+// workspaces, both overwritten.  Returns the device pointer holding the result in *result.
+int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,
+                int *ld_out) {
+  size_t shm = ((size_t)nc * nc + QR_CHUNK + 8) * sizeof(double);
+  if (shm > 160 * 1024 || nc * QR_PARTS > 1024) {
+    set_last_error("tsqr: %d columns exceed the LDS-resident R capacity", nc);
+    return PLV_E_CAPACITY;
+  }
+  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)qr_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  int threads = cdiv(nc * QR_PARTS, 64) * 64;
+  double *src = d_A, *dst = d_tmp;
+  size_t cap_src = (size_t)lda * nc, cap_dst = tmp_elems;
+  int src_ld = lda, rows = m;
+  // rows per workgroup: a multiple of the chunk, at least 2*nc so every level at least halves
+  int rpw = cdiv(2 * nc, QR_CHUNK) * QR_CHUNK;
+  for (;;) {
+    int W = cdiv(rows, rpw);
+    if (W < 1) W = 1;
+    int ldo = W * nc;
+    if ((size_t)ldo * nc > cap_dst) {
+      set_last_error("tsqr: workspace too small (%d x %d > %zu)", ldo, nc, cap_dst);
+      return PLV_E_CAPACITY;
+    }
+    {
+      ProfScope ps(ctx->prof, "qr_accum_kernel", ctx->stream);
+      hipLaunchKernelGGL(qr_accum_kernel, dim3(W), dim3(threads), shm, ctx->stream, src, src_ld, rows, nc, rpw, dst, ldo,
+                         W == 1 ? 1 : 0);
+    }
+    PLV_HIP_CHECK(hipGetLastError());
+    if (W == 1) {
+      *result = dst;
+      *ld_out = ldo;
+      return PLV_OK;
+    }
+    rows = W * nc;
+    src_ld = ldo;
+    double *t = src;
+    src = dst;
+    dst = t;
+    size_t tc = cap_src;
+    cap_src = cap_dst;
+    cap_dst = tc;
+  }
+}
+
+// The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
+// 0 (updated), bit0 (negative diagonal), bit1 (S not positive definite).
+int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
+               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag) {
+  int rc;
+  const int ldm = r, ldw = r;
+  if ((rc = ctx->d_Mt.reserve((size_t)r * n * 8)) || (rc = ctx->d_S.reserve((size_t)r * r * 8 * 2)) ||
+      (rc = ctx->d_W.reserve((size_t)r * (n + 1) * 8)))
+    return rc;
+  double *Mt = ctx->d_Mt.as<double>(), *S = ctx->d_S.as<double>(), *L = S + (size_t)r * r, *W = ctx->d_W.as<double>();
+  size_t shm = (size_t)r * (r | 1) * sizeof(double);
+  if (shm > 160 * 1024) {
+    set_last_error("ekf: r=%d exceeds the LDS-resident Cholesky capacity", r);
+    return PLV_E_CAPACITY;
+  }
+  PLV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+  {
+    ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
+    int tiles = cdiv(r, 16) * cdiv(n, 16);
+    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, d_cols, d_P, ldp, n,
+                       Mt, ldm);
+  }
+  {
+    ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
+    int tiles = cdiv(r, 16) * cdiv(r, 16);
+    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt, ldm, d_H, ldh, r, k, d_cols,
+                       d_Rdiag, S, r);
+  }
+  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  {
+    ProfScope ps(ctx->prof, "ekf_chol_kernel", ctx->stream);
+    hipLaunchKernelGGL(ekf_chol_kernel, dim3(1), dim3(1024), shm, ctx->stream, S, r, r, L, r, d_flag);
+  }
+  {
+    ProfScope ps(ctx->prof, "ekf_trsm_kernel", ctx->stream);
+    hipLaunchKernelGGL(ekf_trsm_kernel, dim3(cdiv(n + 1, 4)), dim3(256), shm, ctx->stream, L, r, r, Mt, ldm, n, d_res, d_P,
+                       ldp, W, ldw, d_flag);
+  }
+  {
+    ProfScope ps(ctx->prof, "ekf_apply_kernel", ctx->stream);
+    int tn = cdiv(n, 16);
+    int waves = tn * (tn + 1) / 2 + cdiv(n, 64);
+    hipLaunchKernelGGL(ekf_apply_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, d_P, ldp, d_dx,
+                       d_flag);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+}  // namespace plv

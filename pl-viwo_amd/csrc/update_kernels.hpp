@@ -1,0 +1,34 @@
+// update_kernels.hpp — launcher declarations of update_kernels.hip (product code).
+#pragma once
+#include "plv_ctx.hpp"
+
+namespace plv {
+
+struct Chi2Args {
+  const double *P;
+  int ldp;
+  int k, ld, fdim_off;   // fdim_off: rows already removed by the nullspace (mp = rows - fdim_off)
+  const int *rows;
+  const double *Hx, *res;
+  const int *cols;
+  double sigma2;
+  double *chi2;
+  // gate + stack (optional)
+  double *stack;
+  int lds, mp_max;
+  double chi2_mult, res_norm_gate;
+  const double *q95;      // device table, index = dof
+  int q95_n;
+  int min_rows;
+  unsigned char *accepted;
+};
+
+int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
+                     double *d_res);
+int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp);
+int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,
+                int *ld_out);
+int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
+               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag);
+
+}  // namespace plv
