@@ -103,7 +103,8 @@ def test_chi2_batch_parity(ctx, oracle):
 def test_compress_parity(ctx, oracle, m, k):
     rng = np.random.default_rng(m + k)
     H = rng.normal(size=(m, k))
-    H[rng.uniform(size=m) < 0.2] = 0.0  # zero rows (rejected features are stacked as zeros)
+    if m >= 1.5 * k:  # zero rows (rejected features are stacked as zeros); keep full column rank
+        H[rng.uniform(size=m) < 0.2] = 0.0
     r = rng.normal(size=m)
     R0, z0 = oracle.compress(H, r)
     R1, z1 = ctx.compress(H, r)
