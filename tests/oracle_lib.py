@@ -111,3 +111,123 @@ def load():
             subprocess.check_call(["make", "-C", ORACLE_DIR])
         _inst = Oracle(C.CDLL(LIB))
     return _inst
+
+
+# ------------------------------------------------------------------ front-end oracle
+fp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+
+class FrontOracle:
+    def __init__(self, lib):
+        self.lib = L = lib
+        L.orc_equalize_hist.argtypes = [u8, C.c_int, C.c_int, C.c_int, u8]
+        L.orc_pyramid_build.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_pyramid_build.restype = C.c_void_p
+        L.orc_pyramid_free.argtypes = [C.c_void_p]
+        L.orc_pyramid_levels.argtypes = [C.c_void_p]
+        L.orc_pyramid_levels.restype = C.c_int
+        L.orc_pyramid_level.argtypes = [C.c_void_p, C.c_int, ip, ip, u8, C.POINTER(C.c_int16)]
+        L.orc_lk_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, fp, fp, u8, C.c_int, C.c_int, C.c_float, C.c_int,
+                                   C.POINTER(C.c_longlong)]
+        L.orc_undistort.argtypes = [dp, C.c_int, fp, fp]
+        L.orc_ransac_fundamental.argtypes = [fp, fp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, u8, ip]
+        L.orc_ransac_fundamental.restype = C.c_int
+        L.orc_run7point.argtypes = [fp, fp, ip, dp]
+        L.orc_run7point.restype = C.c_int
+        L.orc_perform_matching.argtypes = [C.c_void_p, C.c_void_p, C.c_int, fp, fp, dp, C.c_int, C.c_int, C.c_float,
+                                           C.c_double, C.c_double, C.c_int, C.c_uint32, u8, fp, fp, C.c_int]
+        L.orc_perform_matching.restype = C.c_int
+
+    def equalize_hist(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty_like(img)
+        self.lib.orc_equalize_hist(img.ctypes.data_as(u8), img.shape[1], img.shape[0], img.shape[1],
+                                   out.ctypes.data_as(u8))
+        return out
+
+    def pyramid(self, img, win=15, max_level=5):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        return OraclePyramid(self, self.lib.orc_pyramid_build(img.ctypes.data_as(u8), img.shape[1], img.shape[0],
+                                                              img.shape[1], win, max_level))
+
+    def lk_track(self, prev, cur, pts0, pts1_init, win=15, max_iters=30, eps=0.01, nthreads=1):
+        pts0 = np.ascontiguousarray(pts0, dtype=np.float32)
+        pts1 = np.ascontiguousarray(pts1_init, dtype=np.float32).copy()
+        n = pts0.shape[0]
+        st = np.zeros(n, dtype=np.uint8)
+        iters = C.c_longlong()
+        self.lib.orc_lk_track(prev.h, cur.h, n, pts0.ctypes.data_as(fp), pts1.ctypes.data_as(fp), st.ctypes.data_as(u8),
+                              win, max_iters, eps, nthreads, C.byref(iters))
+        return pts1, st, iters.value
+
+    def undistort(self, K8, uv):
+        K8 = np.ascontiguousarray(K8, dtype=np.float64)
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        out = np.empty_like(uv)
+        self.lib.orc_undistort(_dp(K8), uv.shape[0], uv.ctypes.data_as(fp), out.ctypes.data_as(fp))
+        return out
+
+    def ransac(self, m1, m2, thr, conf=0.999, max_iters=1000, seed=0):
+        m1 = np.ascontiguousarray(m1, dtype=np.float32)
+        m2 = np.ascontiguousarray(m2, dtype=np.float32)
+        n = m1.shape[0]
+        mask = np.zeros(n, dtype=np.uint8)
+        it = C.c_int()
+        good = self.lib.orc_ransac_fundamental(m1.ctypes.data_as(fp), m2.ctypes.data_as(fp), n, thr, conf, max_iters,
+                                               seed, mask.ctypes.data_as(u8), C.byref(it))
+        return mask, good, it.value
+
+    def run7point(self, m1, m2, idx):
+        m1 = np.ascontiguousarray(m1, dtype=np.float32)
+        m2 = np.ascontiguousarray(m2, dtype=np.float32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        F = np.zeros(27)
+        n = self.lib.orc_run7point(m1.ctypes.data_as(fp), m2.ctypes.data_as(fp), _ip(idx), _dp(F))
+        return F.reshape(3, 3, 3)[:n]
+
+    def perform_matching(self, prev, cur, pts0, pts1_init, K8, win=15, max_iters=30, eps=0.01, thr_px=2.0, conf=0.999,
+                         ransac_iters=1000, seed=0, nthreads=1):
+        pts0 = np.ascontiguousarray(pts0, dtype=np.float32)
+        pts1 = np.ascontiguousarray(pts1_init, dtype=np.float32).copy()
+        K8 = np.ascontiguousarray(K8, dtype=np.float64)
+        n = pts0.shape[0]
+        mask = np.zeros(n, dtype=np.uint8)
+        n0 = np.zeros((n, 2), dtype=np.float32)
+        n1 = np.zeros((n, 2), dtype=np.float32)
+        rc = self.lib.orc_perform_matching(prev.h, cur.h, n, pts0.ctypes.data_as(fp), pts1.ctypes.data_as(fp), _dp(K8),
+                                           win, max_iters, eps, thr_px, conf, ransac_iters, seed,
+                                           mask.ctypes.data_as(u8), n0.ctypes.data_as(fp), n1.ctypes.data_as(fp),
+                                           nthreads)
+        return rc, pts1, mask, n0, n1
+
+
+class OraclePyramid:
+    def __init__(self, fo, h):
+        self.fo, self.h = fo, h
+        self.levels = fo.lib.orc_pyramid_levels(h)
+
+    def level(self, l):
+        w, hh = C.c_int(), C.c_int()
+        self.fo.lib.orc_pyramid_level(self.h, l, C.byref(w), C.byref(hh), None, None)
+        img = np.zeros((hh.value, w.value), dtype=np.uint8)
+        der = np.zeros((hh.value, w.value, 2), dtype=np.int16)
+        self.fo.lib.orc_pyramid_level(self.h, l, C.byref(w), C.byref(hh), img.ctypes.data_as(u8),
+                                      der.ctypes.data_as(C.POINTER(C.c_int16)))
+        return img, der
+
+    def __del__(self):
+        try:
+            self.fo.lib.orc_pyramid_free(self.h)
+        except Exception:
+            pass
+
+
+_front = None
+
+
+def load_front():
+    global _front
+    if _front is None:
+        load()
+        _front = FrontOracle(_inst.lib)
+    return _front

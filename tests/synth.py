@@ -59,3 +59,66 @@ def q95_table(n=1024):
     t = np.zeros(n)
     t[1:] = chi2.ppf(0.95, np.arange(1, n))
     return t
+
+
+# ------------------------------------------------------------------ images (SURVEY.md §8(d) cfg 2)
+def texture_canvas(w, h, seed=42, margin=64, blobs=300, lines=0):
+    """Band-limited noise texture (sigma_blur 1.5 px, contrast-stretched) + Harris-strong blobs,
+    optionally straight high-contrast edges, on a canvas larger than the image by `margin`."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    W, H = w + 2 * margin, h + 2 * margin
+    img = rng.normal(0, 1, (H, W))
+    img = ndi.gaussian_filter(img, 1.5) * 3.0 + ndi.gaussian_filter(rng.normal(0, 1, (H, W)), 6.0) * 6.0
+    for _ in range(blobs):
+        x, y = rng.uniform(8, W - 8), rng.uniform(8, H - 8)
+        s = rng.uniform(2.0, 4.0)
+        amp = rng.choice([-1, 1]) * rng.uniform(1.0, 2.0)
+        x0, x1, y0, y1 = int(x - s), int(x + s), int(y - s), int(y + s)
+        img[y0:y1, x0:x1] += amp
+    for _ in range(lines):
+        L = rng.uniform(60, 300)
+        th = rng.uniform(0, np.pi)
+        cx, cy = rng.uniform(40, W - 40), rng.uniform(40, H - 40)
+        n = int(L)
+        t = np.linspace(-L / 2, L / 2, n)
+        for off in range(-1, 2):
+            xs = np.clip((cx + t * np.cos(th) - off * np.sin(th)).astype(int), 0, W - 1)
+            ys = np.clip((cy + t * np.sin(th) + off * np.cos(th)).astype(int), 0, H - 1)
+            img[ys, xs] += 3.0
+    img = ndi.gaussian_filter(img, 0.8)
+    lo, hi = np.percentile(img, [1, 99])
+    img = np.clip((img - lo) / (hi - lo), 0, 1)
+    return img
+
+
+def render_frame(canvas, w, h, tx=0.0, ty=0.0, rot_deg=0.0, scale=1.0, margin=64):
+    """Samples the canvas under a similarity warp about the image centre (cubic interpolation).
+    Returns the u8 frame; a canvas point c maps to frame pixel p = s R (c - c0) + c0 + t."""
+    from scipy import ndimage as ndi
+    th = np.deg2rad(rot_deg)
+    cx, cy = margin + w / 2.0, margin + h / 2.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    # inverse map: frame pixel -> canvas
+    px, py = xs + margin - cx - tx, ys + margin - cy - ty
+    c, s = np.cos(-th), np.sin(-th)
+    qx = (c * px - s * py) / scale + cx
+    qy = (s * px + c * py) / scale + cy
+    out = ndi.map_coordinates(canvas, [qy, qx], order=3, mode="reflect")
+    return np.clip(np.rint(out * 255.0), 0, 255).astype(np.uint8)
+
+
+def warp_points(pts, w, h, tx, ty, rot_deg, scale):
+    """Where frame-0 (identity warp) pixel positions land in the warped frame."""
+    th = np.deg2rad(rot_deg)
+    c0 = np.array([w / 2.0, h / 2.0])
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    return ((pts - c0) @ R.T) * scale + c0 + np.array([tx, ty])
+
+
+def grid_points(w, h, n, seed=1, border=24):
+    rng = np.random.default_rng(seed)
+    return np.column_stack([rng.uniform(border, w - border, n), rng.uniform(border, h - border, n)]).astype(np.float32)
+
+
+EUROC_K8 = np.array([458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
