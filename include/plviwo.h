@@ -169,6 +169,47 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
 int plv_cov_checkpoint(plv_ctx *ctx);
 int plv_cov_rollback(plv_ctx *ctx);
 
+/* ================================================================ point front-end
+ *
+ * plv_feed_image replaces the per-image preprocessing of TrackKLT::feed_new_camera (REF:
+ * ov_core/src/track/TrackKLT.cpp:54-75): cv::equalizeHist (histogram_method == HISTOGRAM) and
+ * cv::buildOpticalFlowPyramid(win_size, pyr_levels).  The previously current pyramid becomes the
+ * "last" pyramid (REF: the img_pyramid_last <- img_pyramid_curr swap, TrackKLT.cpp:182-189).
+ * `img` is a host CV_8UC1 image, row stride `stride` bytes.  plv_image_stage / plv_feed_staged do
+ * the same from an image already resident in HBM (slots 0..7).
+ * Size mismatch -> PLV_E_BADARG (the reference exits: TrackKLT.cpp:37-43). */
+enum { PLV_PYR_CUR = 0, PLV_PYR_LAST = 1 };
+int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride);
+int plv_image_stage(plv_ctx *ctx, int slot, const uint8_t *img, int stride);
+int plv_feed_staged(plv_ctx *ctx, int slot);
+int plv_pyramid_levels(plv_ctx *ctx, int which);
+/* level geometry and (if out != NULL, w*h bytes, packed) pixels of one pyramid level */
+int plv_pyramid_download(plv_ctx *ctx, int which, int level, int *w, int *h, uint8_t *out);
+
+/* plv_lk_track replaces cv::calcOpticalFlowPyrLK(last_pyr, cur_pyr, pts0, pts1, status, err,
+ * win, maxLevel, {COUNT|EPS, lk_max_iters, lk_eps}, OPTFLOW_USE_INITIAL_FLOW) (REF call site:
+ * TrackKLT.cpp:857-858).  pts0 / pts1 are n x 2 float (x,y); pts1 carries the initial flow in and
+ * the tracked position out; status n bytes; iters (nullable) n ints = LK iterations actually run. */
+int plv_lk_track(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *status, int *iters);
+
+/* plv_undistort replaces CamRadtan::undistort_f per point (REF: ov_core/src/cam/CamRadtan.h:99-120,
+ * cv::undistortPoints with K, D from cfg.intrinsics): pixel uv -> normalised xy, float. */
+int plv_undistort(plv_ctx *ctx, int n, const float *uv, float *xy);
+
+/* plv_ransac_fundamental replaces cv::findFundamentalMat(m1, m2, FM_RANSAC, thr, ransac_conf,
+ * mask) (REF call site: TrackKLT.cpp:870-873); m1/m2 are normalised coordinates, thr in the
+ * same units.  mask n bytes; n_inliers / iters_used nullable. */
+int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2, double thr, uint32_t seed,
+                           uint8_t *mask, int *n_inliers, int *iters_used);
+
+/* plv_perform_matching replaces TrackKLT::perform_matching (REF: TrackKLT.cpp:829-886) on the
+ * last -> current pyramids: LK, undistort both point sets, RANSAC with thr = ransac_thr_px /
+ * max(fx,fy), mask_out = klt & ransac.  n < 10 -> all-zero mask, PLV_OK (REF :848-852).
+ * n0 / n1 (nullable) receive the normalised coordinates; lk_iters (nullable) the total LK
+ * iteration count of the call. */
+int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0,
+                         float *n1, long long *lk_iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ def load_library():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+    fp = C.POINTER(C.c_float)
     vp = C.c_void_p
     sig = {
         "plv_abi_version": (C.c_int, []),
@@ -93,6 +94,15 @@ def load_library():
                                        ip, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
         "plv_feat_batch_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, ip]),
         "plv_msckf_update_resident": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
+        "plv_feed_image": (C.c_int, [vp, u8p, C.c_int]),
+        "plv_image_stage": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
+        "plv_feed_staged": (C.c_int, [vp, C.c_int]),
+        "plv_pyramid_levels": (C.c_int, [vp, C.c_int]),
+        "plv_pyramid_download": (C.c_int, [vp, C.c_int, C.c_int, ip, ip, u8p]),
+        "plv_lk_track": (C.c_int, [vp, C.c_int, fp, fp, u8p, ip]),
+        "plv_undistort": (C.c_int, [vp, C.c_int, fp, fp]),
+        "plv_ransac_fundamental": (C.c_int, [vp, C.c_int, fp, fp, C.c_double, C.c_uint32, u8p, ip, ip]),
+        "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -113,6 +123,10 @@ def _ip(a):
 
 def _u8p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
 
 
 def _f64(a):
@@ -276,3 +290,66 @@ class Context:
                                                 _u8p(acc), C.byref(nrows), _dp(dx))
         self._chk(rc, allow=(PLV_E_NOT_PSD,))
         return rc, dx, acc, nrows.value
+
+    # ---- point front-end
+    def feed_image(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.shape != (self.cfg.height, self.cfg.width):
+            raise PlvError(PLV_E_BADARG, f"image shape {img.shape} != ({self.cfg.height}, {self.cfg.width})")
+        self._chk(self.lib.plv_feed_image(self.h, _u8p(img), img.shape[1]))
+
+    def image_stage(self, slot, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.shape != (self.cfg.height, self.cfg.width):
+            raise PlvError(PLV_E_BADARG, f"image shape {img.shape} != ({self.cfg.height}, {self.cfg.width})")
+        self._chk(self.lib.plv_image_stage(self.h, slot, _u8p(img), img.shape[1]))
+
+    def feed_staged(self, slot):
+        self._chk(self.lib.plv_feed_staged(self.h, slot))
+
+    def pyramid_levels(self, which=0):
+        return self.lib.plv_pyramid_levels(self.h, which)
+
+    def pyramid_level(self, which, level):
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.lib.plv_pyramid_download(self.h, which, level, C.byref(w), C.byref(h), None))
+        out = np.zeros((h.value, w.value), dtype=np.uint8)
+        self._chk(self.lib.plv_pyramid_download(self.h, which, level, C.byref(w), C.byref(h), _u8p(out)))
+        return out
+
+    def lk_track(self, pts0, pts1_init):
+        pts0 = np.ascontiguousarray(pts0, dtype=np.float32)
+        pts1 = np.ascontiguousarray(pts1_init, dtype=np.float32).copy()
+        n = pts0.shape[0]
+        st = np.zeros(n, dtype=np.uint8)
+        it = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.plv_lk_track(self.h, n, _fp(pts0), _fp(pts1), _u8p(st), _ip(it)))
+        return pts1, st, it
+
+    def undistort(self, uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        out = np.zeros_like(uv)
+        self._chk(self.lib.plv_undistort(self.h, uv.shape[0], _fp(uv), _fp(out)))
+        return out
+
+    def ransac(self, m1, m2, thr, seed=0):
+        m1 = np.ascontiguousarray(m1, dtype=np.float32)
+        m2 = np.ascontiguousarray(m2, dtype=np.float32)
+        n = m1.shape[0]
+        mask = np.zeros(n, dtype=np.uint8)
+        good, it = C.c_int(), C.c_int()
+        self._chk(self.lib.plv_ransac_fundamental(self.h, n, _fp(m1), _fp(m2), float(thr), seed, _u8p(mask),
+                                                  C.byref(good), C.byref(it)))
+        return mask, good.value, it.value
+
+    def perform_matching(self, pts0, pts1_init):
+        pts0 = np.ascontiguousarray(pts0, dtype=np.float32)
+        pts1 = np.ascontiguousarray(pts1_init, dtype=np.float32).copy()
+        n = pts0.shape[0]
+        mask = np.zeros(n, dtype=np.uint8)
+        n0 = np.zeros((n, 2), dtype=np.float32)
+        n1 = np.zeros((n, 2), dtype=np.float32)
+        it = C.c_longlong()
+        self._chk(self.lib.plv_perform_matching(self.h, n, _fp(pts0), _fp(pts1), _u8p(mask), _fp(n0), _fp(n1),
+                                                C.byref(it)))
+        return pts1, mask, n0, n1, it.value

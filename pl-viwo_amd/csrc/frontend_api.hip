@@ -1,4 +1,311 @@
-// frontend_api.hip — front-end (tracker) entry points of include/plviwo.h.  (filled in below)
-#include "plv_ctx.hpp"
+// frontend_api.hip — point front-end entry points of include/plviwo.h (product code, no CPU path).
+#include <algorithm>
 
-extern "C" void plv_frontend_destroy(plv_ctx *) {}
+#include "frontend_kernels.hpp"
+
+using namespace plv;
+
+namespace {
+
+struct FrontState {
+  int W = 0, H = 0;
+  PyrDesc pyr[2];          // ping-pong pyramids
+  DevBuf pyr_mem[2];
+  int cur = 0;             // index of the current pyramid; last = 1 - cur
+  int fed = 0;             // number of images fed so far (last is valid when fed >= 2)
+  DevBuf raw;              // incoming raw image (packed)
+  DevBuf slots[8];
+  DevBuf hist;
+  // per-call point buffers
+  DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info;
+};
+
+#define TRY(expr)                  \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != PLV_OK) return _rc; \
+  } while (0)
+
+int level_geometry(int W, int H, int win, int max_level, PyrDesc &p) {
+  p.levels = 0;
+  unsigned off = 0;
+  int w = W, h = H;
+  for (int l = 0; l <= max_level && l < PLV_MAX_LEVELS; ++l) {
+    if (l > 0) {
+      int nw = (w + 1) / 2, nh = (h + 1) / 2;
+      if (nw <= win || nh <= win) break;  // cv::buildOpticalFlowPyramid stops here
+      w = nw;
+      h = nh;
+    }
+    p.w[l] = w;
+    p.h[l] = h;
+    p.off[l] = off;
+    off += (unsigned)(((size_t)w * h + 255) & ~(size_t)255);
+    p.levels = l + 1;
+  }
+  return (int)off;
+}
+
+FrontState *fe(plv_ctx *ctx) {
+  if (!ctx->fe_state) {
+    auto *s = new FrontState();
+    s->W = ctx->cfg.width;
+    s->H = ctx->cfg.height;
+    ctx->fe_state = s;
+  }
+  return (FrontState *)ctx->fe_state;
+}
+
+int ensure_pyramids(plv_ctx *ctx, FrontState *s) {
+  if (s->pyr_mem[0].p) return PLV_OK;
+  if (s->W < 16 || s->H < 16) {
+    set_last_error("front-end: image %dx%d too small", s->W, s->H);
+    return PLV_E_BADARG;
+  }
+  for (int i = 0; i < 2; ++i) {
+    int bytes = level_geometry(s->W, s->H, ctx->cfg.win_size, ctx->cfg.pyr_levels, s->pyr[i]);
+    TRY(s->pyr_mem[i].reserve((size_t)bytes));
+    s->pyr[i].base = s->pyr_mem[i].as<uint8_t>();
+  }
+  TRY(s->hist.reserve(256 * sizeof(unsigned)));
+  TRY(s->raw.reserve((size_t)s->W * s->H));
+  return PLV_OK;
+}
+
+int sync(plv_ctx *ctx) {
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
+// equalize + pyramid of the packed device image d_img into the next "current" pyramid
+int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
+  const int next = s->fed == 0 ? s->cur : 1 - s->cur;
+  PyrDesc &p = s->pyr[next];
+  const int npix = s->W * s->H;
+  switch (ctx->cfg.histogram_method) {
+    case PLV_HIST_HISTOGRAM:
+      TRY(launch_equalize(ctx, d_img, p.base + p.off[0], npix, s->hist.as<unsigned>()));
+      break;
+    case PLV_HIST_NONE:
+      PLV_HIP_CHECK(hipMemcpyAsync(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
+      break;
+    default:
+      set_last_error("front-end: histogram method %d (CLAHE) is not built yet", ctx->cfg.histogram_method);
+      return PLV_E_BADARG;
+  }
+  TRY(launch_pyramid(ctx, p));
+  s->cur = next;
+  s->fed++;
+  return PLV_OK;
+}
+
+int upload_image(plv_ctx *ctx, FrontState *s, void *dst, const uint8_t *img, int stride) {
+  if (!img || stride < s->W) {
+    set_last_error("front-end: null image or stride %d < width %d", stride, s->W);
+    return PLV_E_BADARG;
+  }
+  PLV_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)s->W, img, (size_t)stride, (size_t)s->W, (size_t)s->H, hipMemcpyHostToDevice,
+                                 ctx->stream));
+  return PLV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void plv_frontend_destroy(plv_ctx *ctx) {
+  auto *s = (FrontState *)ctx->fe_state;
+  if (!s) return;
+  DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->pts0, &s->pts1, &s->n0, &s->n1,
+                    &s->status, &s->iters, &s->mask, &s->counts, &s->info};
+  for (auto *b : bufs) b->release();
+  for (auto &b : s->slots) b.release();
+  delete s;
+  ctx->fe_state = nullptr;
+}
+
+int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride) {
+  if (!ctx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(ensure_pyramids(ctx, s));
+  TRY(upload_image(ctx, s, s->raw.p, img, stride));
+  TRY(feed_device(ctx, s, s->raw.as<uint8_t>()));
+  return sync(ctx);
+}
+
+int plv_image_stage(plv_ctx *ctx, int slot, const uint8_t *img, int stride) {
+  if (!ctx || slot < 0 || slot >= 8) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(ensure_pyramids(ctx, s));
+  TRY(s->slots[slot].reserve((size_t)s->W * s->H));
+  TRY(upload_image(ctx, s, s->slots[slot].p, img, stride));
+  return sync(ctx);
+}
+
+int plv_feed_staged(plv_ctx *ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= 8) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  if (!s->slots[slot].p) {
+    set_last_error("plv_feed_staged: slot %d is empty", slot);
+    return PLV_E_BADARG;
+  }
+  TRY(feed_device(ctx, s, s->slots[slot].as<uint8_t>()));
+  return sync(ctx);
+}
+
+int plv_pyramid_levels(plv_ctx *ctx, int which) {
+  if (!ctx || !ctx->fe_state) return 0;
+  FrontState *s = fe(ctx);
+  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) return 0;
+  return s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur].levels;
+}
+
+int plv_pyramid_download(plv_ctx *ctx, int which, int level, int *w, int *h, uint8_t *out) {
+  if (!ctx || !ctx->fe_state) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) return PLV_E_BADARG;
+  const PyrDesc &p = s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur];
+  if (level < 0 || level >= p.levels) return PLV_E_BADARG;
+  if (w) *w = p.w[level];
+  if (h) *h = p.h[level];
+  if (out) {
+    PLV_HIP_CHECK(hipMemcpyAsync(out, p.base + p.off[level], (size_t)p.w[level] * p.h[level], hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    return sync(ctx);
+  }
+  return PLV_OK;
+}
+
+static int need_two(plv_ctx *ctx, FrontState *s, const char *who) {
+  if (s->fed < 2) {
+    set_last_error("%s: needs two fed images (last and current pyramid)", who);
+    return PLV_E_BADARG;
+  }
+  (void)ctx;
+  return PLV_OK;
+}
+
+static int reserve_points(FrontState *s, int n, int ransac_iters) {
+  size_t nn = (size_t)std::max(n, 1);
+  TRY(s->pts0.reserve(nn * 8));
+  TRY(s->pts1.reserve(nn * 8));
+  TRY(s->n0.reserve(nn * 8));
+  TRY(s->n1.reserve(nn * 8));
+  TRY(s->status.reserve(nn));
+  TRY(s->mask.reserve(nn));
+  TRY(s->iters.reserve(nn * 4));
+  TRY(s->counts.reserve((size_t)std::max(ransac_iters, 1) * 3 * 4));
+  TRY(s->info.reserve(16));
+  return PLV_OK;
+}
+
+int plv_lk_track(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *status, int *iters) {
+  if (!ctx || n < 0 || (n > 0 && (!pts0 || !pts1 || !status))) return PLV_E_BADARG;
+  if (n == 0) return PLV_OK;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(need_two(ctx, s, "plv_lk_track"));
+  TRY(reserve_points(s, n, 1));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, pts0, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->pts1.p, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, s->pts0.as<float>(), s->pts1.as<float>(),
+                s->status.as<uint8_t>(), s->iters.as<int>(), ctx->cfg.win_size, ctx->cfg.lk_max_iters, ctx->cfg.lk_eps));
+  PLV_HIP_CHECK(hipMemcpyAsync(pts1, s->pts1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(status, s->status.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (iters) PLV_HIP_CHECK(hipMemcpyAsync(iters, s->iters.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return sync(ctx);
+}
+
+static CamK cam_of(plv_ctx *ctx) {
+  CamK K;
+  for (int i = 0; i < 8; ++i) K.v[i] = ctx->cfg.intrinsics[i];
+  return K;
+}
+
+int plv_undistort(plv_ctx *ctx, int n, const float *uv, float *xy) {
+  if (!ctx || n < 0 || (n > 0 && (!uv || !xy))) return PLV_E_BADARG;
+  if (n == 0) return PLV_OK;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(reserve_points(s, n, 1));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, uv, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(launch_undistort(ctx, cam_of(ctx), n, s->pts0.as<float>(), s->n0.as<float>()));
+  PLV_HIP_CHECK(hipMemcpyAsync(xy, s->n0.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  return sync(ctx);
+}
+
+int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2, double thr, uint32_t seed,
+                           uint8_t *mask, int *n_inliers, int *iters_used) {
+  if (!ctx || n < 0 || (n > 0 && (!m1 || !m2 || !mask))) return PLV_E_BADARG;
+  if (n_inliers) *n_inliers = 0;
+  if (iters_used) *iters_used = 0;
+  if (n == 0) return PLV_OK;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  const int mi = std::max(1, ctx->cfg.ransac_max_iters);
+  TRY(reserve_points(s, n, mi));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->n0.p, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->n1.p, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(launch_ransac(ctx, s->n0.as<float>(), s->n1.as<float>(), n, thr, ctx->cfg.ransac_conf, mi, seed, s->counts.as<int>(),
+                    nullptr, s->mask.as<uint8_t>(), s->info.as<int>()));
+  int info[2] = {0, 0};
+  PLV_HIP_CHECK(hipMemcpyAsync(mask, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(info, s->info.p, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+  TRY(sync(ctx));
+  if (n_inliers) *n_inliers = info[0];
+  if (iters_used) *iters_used = info[1];
+  return PLV_OK;
+}
+
+int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0, float *n1,
+                         long long *lk_iters) {
+  if (!ctx || n < 0 || (n > 0 && (!pts0 || !pts1 || !mask_out))) return PLV_E_BADARG;
+  if (lk_iters) *lk_iters = 0;
+  if (n == 0) return PLV_OK;
+  if (n < 10) {  // REF: TrackKLT.cpp:848-852
+    memset(mask_out, 0, (size_t)n);
+    return PLV_OK;
+  }
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(need_two(ctx, s, "plv_perform_matching"));
+  const int mi = std::max(1, ctx->cfg.ransac_max_iters);
+  TRY(reserve_points(s, n, mi));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, pts0, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(s->pts1.p, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, s->pts0.as<float>(), s->pts1.as<float>(),
+                s->status.as<uint8_t>(), s->iters.as<int>(), ctx->cfg.win_size, ctx->cfg.lk_max_iters, ctx->cfg.lk_eps));
+  TRY(launch_undistort2(ctx, cam_of(ctx), n, s->pts0.as<float>(), s->pts1.as<float>(), s->n0.as<float>(), s->n1.as<float>()));
+  const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
+  TRY(launch_ransac(ctx, s->n0.as<float>(), s->n1.as<float>(), n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi,
+                    0u, s->counts.as<int>(), s->status.as<uint8_t>(), s->mask.as<uint8_t>(), s->info.as<int>()));
+  // results: one pinned block [pts1 | n0 | n1 | iters | mask]
+  size_t o_p1 = 0, o_n0 = (size_t)n * 8, o_n1 = (size_t)n * 16, o_it = (size_t)n * 24, o_mk = (size_t)n * 28,
+         total = (size_t)n * 29;
+  TRY(ctx->h_pin.reserve(total));
+  char *hp = ctx->h_pin.as<char>();
+  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, s->pts1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (n0) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_n0, s->n0.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (n1) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_n1, s->n1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (lk_iters) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_it, s->iters.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_mk, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(sync(ctx));
+  memcpy(pts1, hp + o_p1, (size_t)n * 8);
+  if (n0) memcpy(n0, hp + o_n0, (size_t)n * 8);
+  if (n1) memcpy(n1, hp + o_n1, (size_t)n * 8);
+  memcpy(mask_out, hp + o_mk, (size_t)n);
+  if (lk_iters) {
+    long long t = 0;
+    const int *it = (const int *)(hp + o_it);
+    for (int i = 0; i < n; ++i) t += it[i];
+    *lk_iters = t;
+  }
+  return PLV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,726 @@
+// frontend_kernels.hip — gfx950 kernels of the point front-end (TrackKLT's OpenCV calls).
+//
+//   hist_kernel / equalize_kernel  K1  cv::equalizeHist            REF call site: ov_core/src/track/TrackKLT.cpp:59
+//   pyrdown_kernel                 K2  cv::buildOpticalFlowPyramid REF call site: TrackKLT.cpp:71
+//   lk_kernel                      K3  cv::calcOpticalFlowPyrLK    REF call site: TrackKLT.cpp:857-858
+//   undistort_kernel               K6  cv::undistortPoints         REF call site: ov_core/src/cam/CamRadtan.h:99-120
+//   ransac_*_kernel                K7  cv::findFundamentalMat      REF call site: TrackKLT.cpp:870-873
+//
+// Arithmetic contract (DESIGN.md "Front-end arithmetic"): integer image arithmetic is exact
+// (LUT, 5x5 binomial, Scharr, 14-bit bilinear weights); LK's normal-equation sums are exact
+// int64 wave reductions rounded to float once, so tracked positions are comparable bit-for-bit
+// with the CPU oracle whatever the reduction order.
+#include "frontend_kernels.hpp"
+
+namespace plv {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * len - 2 - p;
+  if (p < 0) p = -p;  // second fold only matters for tiny levels
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------ K1
+__global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ img, int npix, unsigned *__restrict__ hist) {
+  __shared__ unsigned sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int nvec = npix >> 4;
+  const uint4 *v = reinterpret_cast<const uint4 *>(img);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+    uint4 q = v[i];
+    unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&sh[wds[k] & 255], 1u);
+      atomicAdd(&sh[(wds[k] >> 8) & 255], 1u);
+      atomicAdd(&sh[(wds[k] >> 16) & 255], 1u);
+      atomicAdd(&sh[wds[k] >> 24], 1u);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int i = (nvec << 4) + threadIdx.x; i < npix; i += blockDim.x) atomicAdd(&sh[img[i]], 1u);
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// LUT (every block rebuilds it from the 256-bin histogram: 256 adds) + apply.
+__global__ void __launch_bounds__(256) equalize_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int npix,
+                                                       const unsigned *__restrict__ hist) {
+  __shared__ unsigned cdf[256];
+  __shared__ uint8_t lut[256];
+  __shared__ int first_bin;
+  const int t = threadIdx.x;
+  cdf[t] = hist[t];
+  if (t == 0) first_bin = 256;
+  __syncthreads();
+  if (cdf[t]) atomicMin(&first_bin, t);
+  // inclusive scan (Hillis-Steele, 8 steps)
+  for (int off = 1; off < 256; off <<= 1) {
+    unsigned v = t >= off ? cdf[t - off] : 0;
+    __syncthreads();
+    cdf[t] += v;
+    __syncthreads();
+  }
+  const int i0 = first_bin;
+  const unsigned h0 = hist[i0];
+  if ((int)h0 == npix) {
+    lut[t] = (uint8_t)t;  // constant image: copy (cv::equalizeHist sets dst = i0 = src)
+  } else {
+    const float scale = (256 - 1.f) / (float)(npix - (int)h0);
+    int v = 0;
+    if (t > i0) v = __float2int_rn((float)(int)(cdf[t] - h0) * scale);
+    lut[t] = (uint8_t)min(max(v, 0), 255);
+  }
+  __syncthreads();
+  const int nvec = npix >> 4;
+  const uint4 *s = reinterpret_cast<const uint4 *>(src);
+  uint4 *d = reinterpret_cast<uint4 *>(dst);
+  for (int i = blockIdx.x * blockDim.x + t; i < nvec; i += gridDim.x * blockDim.x) {
+    uint4 q = s[i];
+    unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      wds[k] = (unsigned)lut[wds[k] & 255] | ((unsigned)lut[(wds[k] >> 8) & 255] << 8) |
+               ((unsigned)lut[(wds[k] >> 16) & 255] << 16) | ((unsigned)lut[wds[k] >> 24] << 24);
+    d[i] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  }
+  if (blockIdx.x == 0)
+    for (int i = (nvec << 4) + t; i < npix; i += blockDim.x) dst[i] = lut[src[i]];
+}
+
+// ------------------------------------------------------------------------------------------ K2
+// 16x16 output pixels per workgroup; the (35 x 35) source footprint is staged in LDS once,
+// filtered horizontally into an int plane, then vertically: dst = (sum + 128) >> 8.
+#define PD_T 16
+#define PD_S (2 * PD_T + 3)
+__global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict__ src, int sw, int sh_, uint8_t *__restrict__ dst,
+                                                      int dw, int dh) {
+  __shared__ uint8_t tile[PD_S][PD_S + 1];
+  __shared__ int hrow[PD_S][PD_T + 1];
+  const int ox = blockIdx.x * PD_T, oy = blockIdx.y * PD_T;
+  const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+  for (int i = threadIdx.x; i < PD_S * PD_S; i += 256) {
+    int ty = i / PD_S, tx = i - ty * PD_S;
+    tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, sh_) * sw + reflect101(sx0 + tx, sw)];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_S * PD_T; i += 256) {
+    int ty = i / PD_T, x = i - ty * PD_T;
+    const uint8_t *r = &tile[ty][2 * x];
+    hrow[ty][x] = r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4];
+  }
+  __syncthreads();
+  const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+  if (ox + x < dw && oy + y < dh) {
+    int s = hrow[2 * y][x] + 4 * hrow[2 * y + 1][x] + 6 * hrow[2 * y + 2][x] + 4 * hrow[2 * y + 3][x] + hrow[2 * y + 4][x];
+    dst[(size_t)(oy + y) * dw + ox + x] = (uint8_t)((s + 128) >> 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K3
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int lo = __shfl_xor((int)(v & 0xffffffffLL), off, 64);
+    int hi = __shfl_xor((int)(v >> 32), off, 64);
+    v += ((long long)hi << 32) | (unsigned)lo;
+  }
+  return v;
+}
+
+#define LK_MAXWIN 15
+#define LK_TT (LK_MAXWIN + 3)   // template footprint incl. Scharr halo and bilinear +1
+#define LK_JT 32                // search tile edge
+#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+// One wavefront (= one 64-thread workgroup) per point; all pyramid levels, coarse to fine.
+// Lane l owns window pixels l, l+64, l+128, l+192 (< win*win).
+__global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
+                                                float *__restrict__ pts1, uint8_t *__restrict__ status,
+                                                int *__restrict__ iters_out, int win, int max_iters, float eps) {
+  __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
+  __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
+  __shared__ uint8_t jtile[LK_JT][LK_JT];
+  const int pt = blockIdx.x;
+  if (pt >= n) return;
+  const int lane = threadIdx.x;
+  const int W_BITS = 14;
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const float half = (win - 1) * 0.5f;
+  const float ec = fminf(fmaxf(eps, 0.f), 10.f);
+  const double eps2 = (double)ec * (double)ec;
+  const int npx = win * win;
+  const float px0 = pts0[2 * pt], py0 = pts0[2 * pt + 1];
+  const float nx0 = pts1[2 * pt], ny0 = pts1[2 * pt + 1];
+  const int maxLevel = prev.levels - 1;
+  float nextx = nx0, nexty = ny0;
+  int st = 1, iters = 0;
+
+  // this lane's window pixels
+  int wx[4], wy[4];
+  bool own[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int p = lane + 64 * q;
+    own[q] = p < npx;
+    wy[q] = own[q] ? p / win : 0;
+    wx[q] = own[q] ? p - wy[q] * win : 0;
+  }
+
+  for (int level = maxLevel; level >= 0; --level) {
+    const float sc = 1.f / (float)(1 << level);
+    float prevx = px0 * sc, prevy = py0 * sc;
+    if (level == maxLevel) {
+      nextx = nx0 * sc;
+      nexty = ny0 * sc;
+    } else {
+      nextx = nextx * 2.f;
+      nexty = nexty * 2.f;
+    }
+    const int cols = prev.w[level], rows = prev.h[level];
+    const uint8_t *I = prev.base + prev.off[level];
+    const uint8_t *J = cur.base + cur.off[level];
+    prevx -= half;
+    prevy -= half;
+    const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+    if (ipx < -win || ipx >= cols || ipy < -win || ipy >= rows) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    // ---- stage the template footprint [ipx-1, ipx+win+1] x [ipy-1, ipy+win+1] and its Scharr planes
+    const int tt = win + 3;
+    __syncthreads();
+    for (int i = lane; i < tt * tt; i += 64) {
+      int ty = i / tt, tx = i - ty * tt;
+      ttile[ty][tx] = I[(size_t)reflect101(ipy - 1 + ty, rows) * cols + reflect101(ipx - 1 + tx, cols)];
+    }
+    __syncthreads();
+    const int td = win + 1;
+    for (int i = lane; i < td * td; i += 64) {
+      int y = i / td, x = i - y * td;
+      int X = ipx + x, Y = ipy + y;
+      int dx = 0, dy = 0;
+      if (X >= 0 && Y >= 0 && X < cols && Y < rows) {  // derivative plane has a CONSTANT(0) border
+        const uint8_t *r0 = &ttile[y][x], *r1 = &ttile[y + 1][x], *r2 = &ttile[y + 2][x];
+        int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+        int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+        dx = t0p - t0m;
+        dy = (t1m + t1p) * 3 + t1c * 10;
+      }
+      tdx[y][x] = (short)dx;
+      tdy[y][x] = (short)dy;
+    }
+    __syncthreads();
+    float a = prevx - ipx, b = prevy - ipy;
+    int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
+    int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
+    int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
+    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    int Iv[4], Ix[4], Iy[4];
+    long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Iv[q] = Ix[q] = Iy[q] = 0;
+      if (own[q]) {
+        const int x = wx[q], y = wy[q];
+        Iv[q] = DESCALE(ttile[y + 1][x + 1] * iw00 + ttile[y + 1][x + 2] * iw01 + ttile[y + 2][x + 1] * iw10 +
+                            ttile[y + 2][x + 2] * iw11,
+                        W_BITS - 5);
+        Ix[q] = DESCALE(tdx[y][x] * iw00 + tdx[y][x + 1] * iw01 + tdx[y + 1][x] * iw10 + tdx[y + 1][x + 1] * iw11, W_BITS);
+        Iy[q] = DESCALE(tdy[y][x] * iw00 + tdy[y][x + 1] * iw01 + tdy[y + 1][x] * iw10 + tdy[y + 1][x + 1] * iw11, W_BITS);
+        sA11 += (long long)Ix[q] * Ix[q];
+        sA12 += (long long)Ix[q] * Iy[q];
+        sA22 += (long long)Iy[q] * Iy[q];
+      }
+    }
+    sA11 = wave_sum_i64(sA11);
+    sA12 = wave_sum_i64(sA12);
+    sA22 = wave_sum_i64(sA22);
+    const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    D = 1.f / D;
+    nextx -= half;
+    nexty -= half;
+    float pdx = 0.f, pdy = 0.f;
+    float outx = nextx + half, outy = nexty + half;
+    const int jc = cur.w[level], jr = cur.h[level];
+    int jx0 = 0, jy0 = 0;
+    bool have_tile = false;
+    for (int j = 0; j < max_iters; ++j) {
+      const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+      if (inx < -win || inx >= jc || iny < -win || iny >= jr) {
+        if (level == 0) st = 0;
+        break;
+      }
+      ++iters;
+      // ---- (re)stage the 32x32 search tile when the window leaves it
+      if (!have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT) {
+        jx0 = inx - (LK_JT - win - 1) / 2;
+        jy0 = iny - (LK_JT - win - 1) / 2;
+        __syncthreads();
+        {
+          const int r = lane >> 1, hx = (lane & 1) * 16;
+          const int Y = reflect101(jy0 + r, jr);
+#pragma unroll
+          for (int c = 0; c < 16; ++c) jtile[r][hx + c] = J[(size_t)Y * jc + reflect101(jx0 + hx + c, jc)];
+        }
+        __syncthreads();
+        have_tile = true;
+      }
+      a = nextx - inx;
+      b = nexty - iny;
+      iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
+      iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
+      iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      const int bx = inx - jx0, by = iny - jy0;
+      long long sb1 = 0, sb2 = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (own[q]) {
+          const int x = bx + wx[q], y = by + wy[q];
+          const int diff = DESCALE(jtile[y][x] * iw00 + jtile[y][x + 1] * iw01 + jtile[y + 1][x] * iw10 + jtile[y + 1][x + 1] * iw11,
+                                   W_BITS - 5) -
+                           Iv[q];
+          sb1 += (long long)(diff * Ix[q]);
+          sb2 += (long long)(diff * Iy[q]);
+        }
+      }
+      sb1 = wave_sum_i64(sb1);
+      sb2 = wave_sum_i64(sb2);
+      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      const float ddx = (A12 * b2 - A22 * b1) * D;
+      const float ddy = (A12 * b1 - A11 * b2) * D;
+      nextx += ddx;
+      nexty += ddy;
+      outx = nextx + half;
+      outy = nexty + half;
+      if ((double)ddx * ddx + (double)ddy * ddy <= eps2) break;
+      if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
+        outx -= ddx * 0.5f;
+        outy -= ddy * 0.5f;
+        break;
+      }
+      pdx = ddx;
+      pdy = ddy;
+    }
+    nextx = outx;
+    nexty = outy;
+  }
+  if (lane == 0) {
+    pts1[2 * pt] = nextx;
+    pts1[2 * pt + 1] = nexty;
+    status[pt] = (uint8_t)st;
+    if (iters_out) iters_out[pt] = iters;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K6
+__device__ __forceinline__ void undistort_radtan(const double *K, float u, float v, float &xn, float &yn) {
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; ++j) {
+    double r2 = x * x + y * y;
+    double icdist = 1. / (1 + ((0. * r2 + k2) * r2 + k1) * r2);
+    if (icdist < 0) {
+      x = x0;
+      y = y0;
+      break;
+    }
+    double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+    double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  xn = (float)x;
+  yn = (float)y;
+}
+
+__global__ void undistort_kernel(CamK K, int n, const float *__restrict__ uv, float *__restrict__ xy) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  undistort_radtan(K.v, uv[2 * i], uv[2 * i + 1], xy[2 * i], xy[2 * i + 1]);
+}
+// both point sets of perform_matching in one launch
+__global__ void undistort2_kernel(CamK K, int n, const float *__restrict__ uv0, const float *__restrict__ uv1,
+                                  float *__restrict__ xy0, float *__restrict__ xy1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  if (i < n)
+    undistort_radtan(K.v, uv0[2 * i], uv0[2 * i + 1], xy0[2 * i], xy0[2 * i + 1]);
+  else {
+    i -= n;
+    undistort_radtan(K.v, uv1[2 * i], uv1[2 * i + 1], xy1[2 * i], xy1[2 * i + 1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K7
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned rng_draw(unsigned seed, unsigned hyp, unsigned t) {
+  return hash32(seed ^ hash32(hyp * 0x9E3779B9U + hash32(t + 0x85EBCA6BU)));
+}
+__device__ __forceinline__ double det3(const double *m) {
+  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+__device__ int solve_cubic(double c3, double c2, double c1, double c0, double *roots) {
+  if (c3 == 0) {
+    if (c2 == 0) {
+      if (c1 == 0) return 0;
+      roots[0] = -c0 / c1;
+      return 1;
+    }
+    double d = c1 * c1 - 4 * c2 * c0;
+    if (d < 0) return 0;
+    d = sqrt(d);
+    double q = 1. / (2 * c2);
+    roots[0] = (-c1 - d) * q;
+    roots[1] = (-c1 + d) * q;
+    return d > 0 ? 2 : 1;
+  }
+  double a1 = c2 / c3, a2 = c1 / c3, a3 = c0 / c3;
+  double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+  double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+  double Qcubed = Q * Q * Q;
+  double d = Qcubed - R * R;
+  if (d > 0) {
+    double theta = acos(R / sqrt(Qcubed));
+    double sqrtQ = sqrt(Q);
+    double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+    roots[0] = t0 * cos(t1) - t2;
+    roots[1] = t0 * cos(t1 + (2. * M_PI / 3)) - t2;
+    roots[2] = t0 * cos(t1 + (4. * M_PI / 3)) - t2;
+    return 3;
+  } else if (d == 0) {
+    if (R >= 0) {
+      roots[0] = -2 * cbrt(R) - a1 / 3;
+      roots[1] = cbrt(R) - a1 / 3;
+    } else {
+      roots[0] = 2 * cbrt(-R) - a1 / 3;
+      roots[1] = -cbrt(-R) - a1 / 3;
+    }
+    return 2;
+  } else {
+    d = sqrt(-d);
+    double e = cbrt(d + fabs(R));
+    if (R > 0) e = -e;
+    roots[0] = (e + Q / e) - a1 * (1. / 3);
+    return 1;
+  }
+}
+
+// Gauss-Jordan with full pivoting on the 7x9 constraint matrix held in LDS-free private memory
+// is register-hungry; it runs once per hypothesis in lane-uniform code, so the matrix lives in a
+// per-wave LDS scratch instead (A[7][9], written by lane 0 only).
+__device__ bool nullspace_7x9(double (*A)[9], double *f1, double *f2) {
+  int colperm[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) colperm[j] = j;
+  for (int i = 0; i < 7; ++i) {
+    int pr = i, pc = i;
+    double best = 0;
+    for (int r = i; r < 7; ++r)
+      for (int c = i; c < 9; ++c) {
+        double v = fabs(A[r][c]);
+        if (v > best) best = v, pr = r, pc = c;
+      }
+    if (!(best > 1e-14)) return false;
+    if (pr != i)
+      for (int c = 0; c < 9; ++c) {
+        double t = A[pr][c];
+        A[pr][c] = A[i][c];
+        A[i][c] = t;
+      }
+    if (pc != i) {
+      for (int r = 0; r < 7; ++r) {
+        double t = A[r][pc];
+        A[r][pc] = A[r][i];
+        A[r][i] = t;
+      }
+      int t = colperm[pc];
+      colperm[pc] = colperm[i];
+      colperm[i] = t;
+    }
+    double inv = 1.0 / A[i][i];
+    for (int c = 0; c < 9; ++c) A[i][c] *= inv;
+    for (int r = 0; r < 7; ++r) {
+      if (r == i) continue;
+      double f = A[r][i];
+      if (f == 0) continue;
+      for (int c = 0; c < 9; ++c) A[r][c] -= f * A[i][c];
+    }
+  }
+  for (int j = 0; j < 9; ++j) {
+    double v1 = j < 7 ? -A[j][7] : (j == 7 ? 1.0 : 0.0);
+    double v2 = j < 7 ? -A[j][8] : (j == 8 ? 1.0 : 0.0);
+    f1[colperm[j]] = v1;
+    f2[colperm[j]] = v2;
+  }
+  return true;
+}
+
+__device__ int run7point(double (*A)[9], const float *m1, const float *m2, const int *idx, double *F) {
+  for (int i = 0; i < 7; ++i) {
+    double x0 = m1[2 * idx[i]], y0 = m1[2 * idx[i] + 1], x1 = m2[2 * idx[i]], y1 = m2[2 * idx[i] + 1];
+    A[i][0] = x1 * x0, A[i][1] = x1 * y0, A[i][2] = x1, A[i][3] = y1 * x0, A[i][4] = y1 * y0, A[i][5] = y1, A[i][6] = x0,
+    A[i][7] = y0, A[i][8] = 1;
+  }
+  double f1[9], f2[9];
+  if (!nullspace_7x9(A, f1, f2)) return 0;
+  double g[9];
+  for (int i = 0; i < 9; ++i) g[i] = f1[i] - f2[i];
+  double c0 = det3(f2), c3 = det3(g), c1 = 0, c2 = 0;
+  for (int r = 0; r < 3; ++r) {
+    double m[9], q[9];
+    for (int i = 0; i < 9; ++i) m[i] = f2[i], q[i] = g[i];
+    for (int c = 0; c < 3; ++c) {
+      m[3 * r + c] = g[3 * r + c];
+      q[3 * r + c] = f2[3 * r + c];
+    }
+    c1 += det3(m);
+    c2 += det3(q);
+  }
+  double roots[3];
+  int n = solve_cubic(c3, c2, c1, c0, roots);
+  int nout = 0;
+  for (int k = 0; k < n; ++k) {
+    double lambda = roots[k], mu = 1.;
+    double s = g[8] * lambda + f2[8];
+    double *Fk = F + 9 * nout;
+    if (fabs(s) > 2.220446049250313e-16) {
+      mu = 1. / s;
+      lambda *= mu;
+      Fk[8] = 1.;
+    } else
+      Fk[8] = 0.;
+    for (int i = 0; i < 8; ++i) Fk[i] = g[i] * lambda + f2[i] * mu;
+    bool finite = true;
+    for (int i = 0; i < 9; ++i) finite = finite && isfinite(Fk[i]);
+    if (finite) ++nout;
+  }
+  return nout;
+}
+
+__device__ __forceinline__ float epi_err(const double *F, const float *m1, const float *m2, int i) {
+  double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
+  double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  double s2 = 1. / (a * a + b * b);
+  double d2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6];
+  b = F[1] * x2 + F[4] * y2 + F[7];
+  c = F[2] * x2 + F[5] * y2 + F[8];
+  double s1 = 1. / (a * a + b * b);
+  double d1 = x1 * a + y1 * b + c;
+  return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+
+__device__ bool collinear_last(const float *m, const int *idx, int count) {
+  int i = count - 1;
+  for (int j = 0; j < i; ++j) {
+    double dx1 = m[2 * idx[j]] - m[2 * idx[i]], dy1 = m[2 * idx[j] + 1] - m[2 * idx[i] + 1];
+    for (int k = 0; k < j; ++k) {
+      double dx2 = m[2 * idx[k]] - m[2 * idx[i]], dy2 = m[2 * idx[k] + 1] - m[2 * idx[i] + 1];
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920929e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+
+__device__ bool get_subset(const float *m1, const float *m2, int n, unsigned seed, unsigned h, int *idx) {
+  unsigned t = 0;
+  for (int attempt = 0; attempt < 16; ++attempt) {
+    int i = 0, guard = 0;
+    while (i < 7 && guard < 64) {
+      ++guard;
+      int cand = (int)(((unsigned long long)rng_draw(seed, h, t++) * (unsigned long long)n) >> 32);
+      bool dup = false;
+      for (int j = 0; j < i; ++j) dup = dup || idx[j] == cand;
+      if (dup) continue;
+      idx[i++] = cand;
+    }
+    if (i < 7) continue;
+    if (collinear_last(m1, idx, 7) || collinear_last(m2, idx, 7)) continue;
+    return true;
+  }
+  return false;
+}
+
+// Hypothesis h (one wavefront): lane 0 solves the 7-point problem (models go to LDS), all lanes
+// count inliers.  counts[h*3 + k] = inliers of model k, or -1.
+__device__ int hypothesis_models(double (*A)[9], const float *m1, const float *m2, int n, unsigned seed, int h, double *F) {
+  int idx[7];
+  if (n == 7) {
+    for (int i = 0; i < 7; ++i) idx[i] = i;
+  } else if (!get_subset(m1, m2, n, seed, (unsigned)h, idx)) {
+    return 0;
+  }
+  return run7point(A, m1, m2, idx, F);
+}
+
+__global__ void __launch_bounds__(64) ransac_hyp_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
+                                                        float t, unsigned seed, int *__restrict__ counts) {
+  __shared__ double A[7][9];
+  __shared__ double F[27];
+  __shared__ int nm_s;
+  const int h = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) nm_s = hypothesis_models(A, m1, m2, n, seed, h, F);
+  __syncthreads();
+  const int nm = nm_s;
+  for (int k = 0; k < 3; ++k) {
+    int good = -1;
+    if (k < nm) {
+      int c = 0;
+      for (int i = lane; i < n; i += 64) c += epi_err(F + 9 * k, m1, m2, i) <= t;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+      good = c;
+    }
+    if (lane == 0) counts[h * 3 + k] = good;
+  }
+}
+
+__device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+  p = fmin(fmax(p, 0.), 1.);
+  ep = fmin(fmax(ep, 0.), 1.);
+  double num = fmax(1. - p, 2.2250738585072014e-308);
+  double denom = 1. - pow(1. - ep, (double)model_points);
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// Replays cv::RANSACPointSetRegistrator::run's adaptive loop over the precomputed counts in
+// hypothesis order, re-solves the winning hypothesis and writes mask = klt_status & inlier
+// (REF: TrackKLT.cpp:876-879).  klt may be null.  info[0] = inliers, info[1] = iterations used.
+__global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
+                                                           float t, double conf, int max_iters, unsigned seed,
+                                                           const int *__restrict__ counts, const uint8_t *__restrict__ klt,
+                                                           uint8_t *__restrict__ mask, int *__restrict__ info) {
+  __shared__ double A[7][9];
+  __shared__ double F[27];
+  __shared__ int sel[3];
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    int niters = n == 7 ? 1 : max_iters, best = 0, bh = -1, bk = 0, it = 0;
+    for (; it < niters; ++it)
+      for (int k = 0; k < 3; ++k) {
+        int good = counts[it * 3 + k];
+        if (good > max(best, 6)) {
+          best = good;
+          bh = it;
+          bk = k;
+          niters = ransac_update_iters(conf, (double)(n - good) / n, 7, niters);
+        }
+      }
+    sel[0] = bh;
+    sel[1] = bk;
+    sel[2] = best;
+    info[0] = best;
+    info[1] = it;
+    if (bh >= 0) hypothesis_models(A, m1, m2, n, seed, bh, F);
+  }
+  __syncthreads();
+  const int bh = sel[0], bk = sel[1];
+  for (int i = lane; i < n; i += 64) {
+    uint8_t in = 0;
+    if (bh >= 0) in = epi_err(F + 9 * bk, m1, m2, i) <= t;
+    mask[i] = (in && (!klt || klt[i])) ? 1 : 0;
+  }
+}
+
+// ========================================================================================== launchers
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix, unsigned *d_hist) {
+  PLV_HIP_CHECK(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned), ctx->stream));
+  int blocks = min(256, max(1, cdiv(npix / 16, 256)));
+  {
+    ProfScope ps(ctx->prof, "hist_kernel", ctx->stream);
+    hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_src, npix, d_hist);
+  }
+  {
+    ProfScope ps(ctx->prof, "equalize_kernel", ctx->stream);
+    hipLaunchKernelGGL(equalize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_src, d_dst, npix, d_hist);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_pyramid(plv_ctx *ctx, const PyrDesc &p) {
+  for (int l = 0; l + 1 < p.levels; ++l) {
+    ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
+    dim3 grid(cdiv(p.w[l + 1], PD_T), cdiv(p.h[l + 1], PD_T));
+    hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l],
+                       p.base + p.off[l + 1], p.w[l + 1], p.h[l + 1]);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
+              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps) {
+  if (win > LK_MAXWIN || win < 3 || (win & 1) == 0) {
+    set_last_error("lk: window %d unsupported (odd, <= %d)", win, LK_MAXWIN);
+    return PLV_E_CAPACITY;
+  }
+  ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
+  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, ctx->stream, prev, cur, n, d_pts0, d_pts1, d_status, d_iters, win,
+                     max_iters, eps);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_undistort(plv_ctx *ctx, const CamK &K, int n, const float *d_uv, float *d_xy) {
+  ProfScope ps(ctx->prof, "undistort_kernel", ctx->stream);
+  hipLaunchKernelGGL(undistort_kernel, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, K, n, d_uv, d_xy);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, const float *d_uv1, float *d_xy0,
+                      float *d_xy1) {
+  ProfScope ps(ctx->prof, "undistort_kernel", ctx->stream);
+  hipLaunchKernelGGL(undistort2_kernel, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, K, n, d_uv0, d_uv1, d_xy0, d_xy1);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
+                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info) {
+  const float t = (float)(thr * thr);
+  if (n < 7) {
+    PLV_HIP_CHECK(hipMemsetAsync(d_mask, 0, n, ctx->stream));
+    PLV_HIP_CHECK(hipMemsetAsync(d_info, 0, 2 * sizeof(int), ctx->stream));
+    return PLV_OK;
+  }
+  const int nh = n == 7 ? 1 : max_iters;
+  {
+    ProfScope ps(ctx->prof, "ransac_hyp_kernel", ctx->stream);
+    hipLaunchKernelGGL(ransac_hyp_kernel, dim3(nh), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, seed, d_counts);
+  }
+  {
+    ProfScope ps(ctx->prof, "ransac_select_kernel", ctx->stream);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
+                       d_counts, d_klt, d_mask, d_info);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+}  // namespace plv

@@ -1,0 +1,31 @@
+// frontend_kernels.hpp — device-side descriptors and launcher declarations of frontend_kernels.hip.
+#pragma once
+#include "plv_ctx.hpp"
+
+namespace plv {
+
+#define PLV_MAX_LEVELS 8
+
+// One image pyramid in a single device allocation (levels packed, row stride = level width).
+struct PyrDesc {
+  uint8_t *base;
+  int levels;
+  int w[PLV_MAX_LEVELS], h[PLV_MAX_LEVELS];
+  unsigned off[PLV_MAX_LEVELS];
+};
+
+struct CamK {
+  double v[8];
+};
+
+int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix, unsigned *d_hist);
+int launch_pyramid(plv_ctx *ctx, const PyrDesc &p);
+int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
+              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps);
+int launch_undistort(plv_ctx *ctx, const CamK &K, int n, const float *d_uv, float *d_xy);
+int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, const float *d_uv1, float *d_xy0,
+                      float *d_xy1);
+int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
+                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info);
+
+}  // namespace plv

@@ -164,4 +164,7 @@ struct plv_ctx {
   plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
   plv::PinBuf h_pin;
+
+  // ---- front-end (frontend_api.hip owns the object)
+  void *fe_state = nullptr;
 };

@@ -1,0 +1,169 @@
+"""GPU parity tests (through the C-ABI) of the point front-end: HIP vs the CPU oracle.
+Integer image work (equalize, pyramid) is compared bit-exactly.  LK positions are compared
+bit-exactly too: the 2x2 normal-equation sums are exact integers in both implementations, and the
+float tail is the same IEEE operation sequence (both built with -ffp-contract=off)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fo():
+    return oracle_lib.load_front()
+
+
+def _ctx(pkg, w, h, **kw):
+    cfg = pkg.default_config(w, h)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return pkg.Context(cfg)
+
+
+@pytest.fixture(scope="module")
+def seq():
+    """752x480 synthetic stream (SURVEY §8(d) cfg 2): 3 frames under small similarity warps."""
+    w, h = 752, 480
+    canvas = synth.texture_canvas(w, h, seed=42)
+    warps = [dict(tx=0, ty=0, rot_deg=0, scale=1.0), dict(tx=4.2, ty=-3.1, rot_deg=0.3, scale=1.002),
+             dict(tx=-1.7, ty=5.4, rot_deg=-0.2, scale=0.997)]
+    return w, h, [synth.render_frame(canvas, w, h, **wp) for wp in warps], warps
+
+
+@pytest.mark.parametrize("w,h", [(752, 480), (1280, 720), (97, 65), (320, 241)])
+def test_equalize_and_pyramid_bit_exact(pkg, fo, w, h):
+    rng = np.random.default_rng(w)
+    img = np.clip(rng.normal(110, 40, (h, w)), 5, 250).astype(np.uint8)
+    c = _ctx(pkg, w, h)
+    c.feed_image(img)
+    eq = fo.equalize_hist(img)
+    op = fo.pyramid(eq)
+    assert c.pyramid_levels(0) == op.levels
+    for l in range(op.levels):
+        assert np.array_equal(c.pyramid_level(0, l), op.level(l)[0]), f"level {l}"
+    # histogram_method NONE: pyramid of the raw image; constant image: copy
+    c2 = _ctx(pkg, w, h, histogram_method=0)
+    c2.feed_image(img)
+    assert np.array_equal(c2.pyramid_level(0, 1), fo.pyramid(img).level(1)[0])
+    const = np.full((h, w), 93, np.uint8)
+    c.feed_image(const)
+    assert np.array_equal(c.pyramid_level(0, 0), const)
+    assert np.array_equal(c.pyramid_level(1, 0), eq)  # previous current became last
+    c.close()
+    c2.close()
+
+
+def test_feed_rejects_wrong_size(pkg):
+    c = _ctx(pkg, 320, 240)
+    with pytest.raises(pkg.PlvError):
+        c.feed_image(np.zeros((100, 100), np.uint8))
+    with pytest.raises(pkg.PlvError):  # matching before two images were fed
+        c.lk_track(np.zeros((12, 2), np.float32), np.zeros((12, 2), np.float32))
+    c.close()
+
+
+def test_lk_bit_exact_vs_oracle(pkg, fo, seq):
+    w, h, frames, warps = seq
+    c = _ctx(pkg, w, h)
+    c.feed_image(frames[0])
+    c.feed_image(frames[1])
+    p0, p1 = fo.pyramid(fo.equalize_hist(frames[0])), fo.pyramid(fo.equalize_hist(frames[1]))
+    pts0 = synth.grid_points(w, h, 250, seed=3, border=12)
+    # include border / out-of-image / flat cases
+    pts0[:6] = [[2.5, 3.5], [w - 2.0, h - 3.0], [w + 30.0, 50.0], [-30.0, -30.0], [0.0, 0.0], [w - 1.0, h - 1.0]]
+    a1, ast, ait = fo.lk_track(p0, p1, pts0, pts0)
+    b1, bst, bit = c.lk_track(pts0, pts0)
+    assert np.array_equal(ast, bst)
+    assert int(bit.sum()) == ait
+    assert np.array_equal(a1, b1), f"max |diff| {np.max(np.abs(a1 - b1))}"
+    truth = synth.warp_points(pts0.astype(np.float64), w, h, **warps[1])
+    ok = bst.astype(bool)
+    assert ok.mean() > 0.9 and np.median(np.linalg.norm(b1[ok] - truth[ok], axis=1)) < 0.06
+    c.close()
+
+
+def test_lk_large_motion_tile_restage(pkg, fo):
+    """Initial guesses far from the truth force the 32x32 search tile to be re-staged."""
+    w, h = 640, 400
+    canvas = synth.texture_canvas(w, h, seed=9)
+    f0 = synth.render_frame(canvas, w, h)
+    f1 = synth.render_frame(canvas, w, h, tx=14.0, ty=-11.0)
+    c = _ctx(pkg, w, h, histogram_method=0)
+    c.feed_image(f0)
+    c.feed_image(f1)
+    p0, p1 = fo.pyramid(f0), fo.pyramid(f1)
+    pts0 = synth.grid_points(w, h, 100, seed=1, border=40)
+    guess = pts0 + np.float32([30.0, 25.0])
+    a1, ast, _ = fo.lk_track(p0, p1, pts0, guess)
+    b1, bst, _ = c.lk_track(pts0, guess)
+    assert np.array_equal(ast, bst) and np.array_equal(a1, b1)
+    c.close()
+
+
+def test_undistort_bit_exact(pkg, fo):
+    c = _ctx(pkg, 752, 480)
+    rng = np.random.default_rng(0)
+    uv = np.column_stack([rng.uniform(0, 752, 500), rng.uniform(0, 480, 500)]).astype(np.float32)
+    K = np.array(list(c.cfg.intrinsics))
+    assert np.array_equal(c.undistort(uv), fo.undistort(K, uv))
+    c.close()
+
+
+def _two_view(n, seed, outliers):
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 12, n)])
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    X2 = X @ R.T + np.array([0.3, 0.05, 0.1])
+    m1, m2 = X[:, :2] / X[:, 2:], X2[:, :2] / X2[:, 2:]
+    m1 = m1 + rng.normal(0, 0.3 / 458, m1.shape)
+    m2 = m2 + rng.normal(0, 0.3 / 458, m2.shape)
+    bad = rng.choice(n, outliers, replace=False)
+    m2[bad] += rng.uniform(-0.2, 0.2, (outliers, 2))
+    return m1.astype(np.float32), m2.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,outl,seed", [(250, 50, 2), (500, 200, 3), (40, 5, 4), (7, 0, 5), (12, 0, 6)])
+def test_ransac_matches_oracle(pkg, fo, n, outl, seed):
+    c = _ctx(pkg, 752, 480)
+    m1, m2 = _two_view(n, seed, outl)
+    thr = 2.0 / 458.654
+    a, ag, ai = fo.ransac(m1, m2, thr, 0.999, 1000, seed=0)
+    b, bg, bi = c.ransac(m1, m2, thr, seed=0)
+    iou = (a & b).sum() / max(1, (a | b).sum())
+    assert iou >= 0.98, (iou, ag, bg)
+    assert abs(ag - bg) <= max(1, n // 100) and ai == bi
+    c.close()
+
+
+def test_ransac_too_few_points(pkg):
+    c = _ctx(pkg, 752, 480)
+    m1, m2 = _two_view(5, 1, 0)
+    mask, good, it = c.ransac(m1, m2, 0.01)
+    assert not mask.any() and good == 0
+    c.close()
+
+
+def test_perform_matching_vs_oracle(pkg, fo, seq):
+    w, h, frames, _ = seq
+    c = _ctx(pkg, w, h)
+    p = [fo.pyramid(fo.equalize_hist(f)) for f in frames]
+    c.feed_image(frames[0])
+    K = np.array(list(c.cfg.intrinsics))
+    pts = synth.grid_points(w, h, 250, seed=5, border=16)
+    for i in (1, 2):
+        c.feed_image(frames[i])
+        rc, a1, am, an0, an1 = fo.perform_matching(p[i - 1], p[i], pts, pts, K)
+        b1, bm, bn0, bn1, its = c.perform_matching(pts, pts)
+        assert rc == 0
+        assert np.array_equal(a1, b1) and np.array_equal(an0, bn0) and np.array_equal(an1, bn1)
+        assert (am & bm).sum() / max(1, (am | bm).sum()) >= 0.98
+        assert bm.mean() > 0.8 and its > 0
+        pts = b1[bm.astype(bool)]
+    # fewer than 10 points: all-zero mask, not an error (REF: TrackKLT.cpp:848-852)
+    b1, bm, _, _, _ = c.perform_matching(pts[:9], pts[:9])
+    assert not bm.any()
+    c.close()
