@@ -37,6 +37,7 @@ def step(i):
     return out, acc
 
 
+ctx.feed_staged(1)
 for i in range(10):
     step(i)
 ctx.prof_enable(True)
