@@ -1,6 +1,7 @@
 // plv_api.hip — the extern "C" boundary declared in include/plviwo.h (context + update side).
 // Product code: no CPU fallback anywhere — without a gfx950 device every compute entry point
 // returns PLV_E_NO_DEVICE.
+#include <algorithm>
 #include <cstdarg>
 #include <cmath>
 #include <mutex>
@@ -336,8 +337,12 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
   int *d_flag;
   unsigned char *d_acc;
   TRY(result_buf(ctx, us, n, 0, &d_dx, &d_flag, &d_acc));
-  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, ctx->d_H.as<double>(), r, k, r, ctx->d_cols.as<int>(),
-                 ctx->d_res.as<double>(), dR, d_dx, d_flag));
+  if (ekf_fast_fits(r))
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, ctx->d_H.as<double>(), r, k, r, ctx->d_cols.as<int>(),
+                        ctx->d_res.as<double>(), dR, d_dx, d_flag));
+  else
+    TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, ctx->d_H.as<double>(), r, k, r, ctx->d_cols.as<int>(),
+                   ctx->d_res.as<double>(), dR, d_dx, d_flag));
   size_t rb = (size_t)n * 8 + 16;
   TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
@@ -521,7 +526,7 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   const int nc = k + 1;
   const int Mtot = F * mp_max;
   TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
-  size_t tmp_elems = (size_t)(Mtot / (2 * nc) + 2) * nc * nc;
+  size_t tmp_elems = (size_t)std::max(Mtot / (2 * nc) + 2, 16) * nc * nc;
   TRY(ctx->d_stack2.reserve(tmp_elems * 8));
 
   double *d_dx;
@@ -557,20 +562,37 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   const double *dH, *dr;
   int r, ldh;
   if (Mtot > k) {
-    double *R;
-    int ldr;
-    TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
-    dH = R;
-    dr = R + (size_t)k * ldr;
-    r = k;
-    ldh = ldr;
+    // REF: measurement_compress_inplace — [R z] with R^T R = H^T H (Gram + LDS Cholesky)
+    TRY(ctx->d_H.reserve((size_t)k * k * 8));
+    TRY(ctx->d_res.reserve((size_t)k * 8));
+    int crc = launch_gram_compress(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
+                                   ctx->d_H.as<double>(), k, ctx->d_res.as<double>());
+    if (crc == PLV_OK) {
+      dH = ctx->d_H.as<double>();
+      dr = ctx->d_res.as<double>();
+      r = k;
+      ldh = k;
+    } else if (crc == PLV_E_CAPACITY) {  // too many columns for the LDS-resident factorisation: Householder TSQR
+      double *R;
+      int ldr;
+      TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
+      dH = R;
+      dr = R + (size_t)k * ldr;
+      r = k;
+      ldh = ldr;
+    } else {
+      return crc;
+    }
   } else {
     dH = ctx->d_stack.as<double>();
     dr = dH + (size_t)k * Mtot;
     r = Mtot;
     ldh = Mtot;
   }
-  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
+  if (ekf_fast_fits(r))
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
+  else
+    TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
   size_t rb = (size_t)n * 8 + 16 + F;
   TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));

@@ -30,7 +30,18 @@ template <class FA, class FB>
 __device__ __forceinline__ d4 mfma_tile_f64(FA a, FB b, int K, d4 acc) {
   const int lane = threadIdx.x & 63;
   const int ij = lane & 15, kq = lane >> 4;
-  for (int k0 = 0; k0 < K; k0 += 4) {
+  int k0 = 0;
+  for (; k0 + 16 <= K; k0 += 16) {  // operand loads of four k-steps issued ahead of the MFMAs
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = a(ij, k0 + 4 * u + kq);
+      bv[u] = b(k0 + 4 * u + kq, ij);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  for (; k0 < K; k0 += 4) {
     const int kk = k0 + kq;
     const bool in = kk < K;
     const double av = in ? a(ij, kk) : 0.0;
@@ -587,6 +598,23 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
   }
 }
 
+// Mt = H P[cols,:] and S = Mt[:,cols] H^T + R (two tile-parallel launches).
+void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S) {
+  {
+    ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
+    int tiles = cdiv(r, 16) * cdiv(n, 16);
+    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, d_cols, d_P, ldp, n,
+                       Mt, ldm);
+  }
+  {
+    ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
+    int tiles = cdiv(r, 16) * cdiv(r, 16);
+    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt, ldm, d_H, ldh, r, k, d_cols,
+                       d_Rdiag, S, r);
+  }
+}
+
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
 // 0 (updated), bit0 (negative diagonal), bit1 (S not positive definite).
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
@@ -603,18 +631,7 @@ int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int
     return PLV_E_CAPACITY;
   }
   PLV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-  {
-    ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
-    int tiles = cdiv(r, 16) * cdiv(n, 16);
-    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, d_cols, d_P, ldp, n,
-                       Mt, ldm);
-  }
-  {
-    ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
-    int tiles = cdiv(r, 16) * cdiv(r, 16);
-    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt, ldm, d_H, ldh, r, k, d_cols,
-                       d_Rdiag, S, r);
-  }
+  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S);
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   {

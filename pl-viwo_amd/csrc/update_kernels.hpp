@@ -31,4 +31,13 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
                const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag);
 
+void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S);
+// dense_kernels.hip
+int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
+                         double *d_R, int ldr, double *d_z);
+bool ekf_fast_fits(int r);
+int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
+                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag);
+
 }  // namespace plv
