@@ -11,6 +11,7 @@
 // int64 wave reductions rounded to float once, so tracked positions are comparable bit-for-bit
 // with the CPU oracle whatever the reduction order.
 #include "frontend_kernels.hpp"
+#include "wave_ops.hpp"
 
 namespace plv {
 
@@ -120,16 +121,6 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------ K3
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    int lo = __shfl_xor((int)(v & 0xffffffffLL), off, 64);
-    int hi = __shfl_xor((int)(v >> 32), off, 64);
-    v += ((long long)hi << 32) | (unsigned)lo;
-  }
-  return v;
-}
-
 #define LK_MAXWIN 15
 #define LK_TT (LK_MAXWIN + 3)   // template footprint incl. Scharr halo and bilinear +1
 #define LK_JT 32                // search tile edge
@@ -425,99 +416,45 @@ __device__ int solve_cubic(double c3, double c2, double c1, double c0, double *r
   }
 }
 
-// Gauss-Jordan with full pivoting on the 7x9 constraint matrix held in LDS-free private memory
-// is register-hungry; it runs once per hypothesis in lane-uniform code, so the matrix lives in a
-// per-wave LDS scratch instead (A[7][9], written by lane 0 only).
-__device__ bool nullspace_7x9(double (*A)[9], double *f1, double *f2) {
-  int colperm[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) colperm[j] = j;
-  for (int i = 0; i < 7; ++i) {
-    int pr = i, pc = i;
-    double best = 0;
-    for (int r = i; r < 7; ++r)
-      for (int c = i; c < 9; ++c) {
-        double v = fabs(A[r][c]);
-        if (v > best) best = v, pr = r, pc = c;
-      }
-    if (!(best > 1e-14)) return false;
-    if (pr != i)
-      for (int c = 0; c < 9; ++c) {
-        double t = A[pr][c];
-        A[pr][c] = A[i][c];
-        A[i][c] = t;
-      }
-    if (pc != i) {
-      for (int r = 0; r < 7; ++r) {
-        double t = A[r][pc];
-        A[r][pc] = A[r][i];
-        A[r][i] = t;
-      }
-      int t = colperm[pc];
-      colperm[pc] = colperm[i];
-      colperm[i] = t;
-    }
-    double inv = 1.0 / A[i][i];
-    for (int c = 0; c < 9; ++c) A[i][c] *= inv;
-    for (int r = 0; r < 7; ++r) {
-      if (r == i) continue;
-      double f = A[r][i];
-      if (f == 0) continue;
-      for (int c = 0; c < 9; ++c) A[r][c] -= f * A[i][c];
-    }
-  }
-  for (int j = 0; j < 9; ++j) {
-    double v1 = j < 7 ? -A[j][7] : (j == 7 ? 1.0 : 0.0);
-    double v2 = j < 7 ? -A[j][8] : (j == 8 ? 1.0 : 0.0);
-    f1[colperm[j]] = v1;
-    f2[colperm[j]] = v2;
-  }
-  return true;
-}
-
-__device__ int run7point(double (*A)[9], const float *m1, const float *m2, const int *idx, double *F) {
-  for (int i = 0; i < 7; ++i) {
-    double x0 = m1[2 * idx[i]], y0 = m1[2 * idx[i] + 1], x1 = m2[2 * idx[i]], y1 = m2[2 * idx[i] + 1];
-    A[i][0] = x1 * x0, A[i][1] = x1 * y0, A[i][2] = x1, A[i][3] = y1 * x0, A[i][4] = y1 * y0, A[i][5] = y1, A[i][6] = x0,
-    A[i][7] = y0, A[i][8] = 1;
-  }
+// ---- wave-parallel hypothesis solver -------------------------------------------------------
+// One wavefront per hypothesis.  The subset draw, the cubic and the model normalisation are
+// lane-uniform (every lane computes the same scalars, all arrays statically indexed: nothing goes
+// to scratch); the 7x9 Gauss-Jordan with full pivoting is lane-parallel, lane l < 63 owning
+// A[l/9][l%9]: pivot search = DPP max + ballot (lowest lane wins ties = the serial scan order),
+// row/column swaps and the elimination = lane shuffles.  Same arithmetic per element as the
+// serial restatement in oracle/frontend_oracle.cpp.
+struct RansacLds {
   double f1[9], f2[9];
-  if (!nullspace_7x9(A, f1, f2)) return 0;
-  double g[9];
-  for (int i = 0; i < 9; ++i) g[i] = f1[i] - f2[i];
-  double c0 = det3(f2), c3 = det3(g), c1 = 0, c2 = 0;
-  for (int r = 0; r < 3; ++r) {
-    double m[9], q[9];
-    for (int i = 0; i < 9; ++i) m[i] = f2[i], q[i] = g[i];
-    for (int c = 0; c < 3; ++c) {
-      m[3 * r + c] = g[3 * r + c];
-      q[3 * r + c] = f2[3 * r + c];
-    }
-    c1 += det3(m);
-    c2 += det3(q);
-  }
-  double roots[3];
-  int n = solve_cubic(c3, c2, c1, c0, roots);
-  int nout = 0;
-  for (int k = 0; k < n; ++k) {
-    double lambda = roots[k], mu = 1.;
-    double s = g[8] * lambda + f2[8];
-    double *Fk = F + 9 * nout;
-    if (fabs(s) > 2.220446049250313e-16) {
-      mu = 1. / s;
-      lambda *= mu;
-      Fk[8] = 1.;
-    } else
-      Fk[8] = 0.;
-    for (int i = 0; i < 8; ++i) Fk[i] = g[i] * lambda + f2[i] * mu;
-    bool finite = true;
-    for (int i = 0; i < 9; ++i) finite = finite && isfinite(Fk[i]);
-    if (finite) ++nout;
-  }
-  return nout;
+};
+
+template <int CTRL> __device__ __forceinline__ double dpp_max_step(double v) { return fmax(v, dpp_mov_f64<CTRL>(v)); }
+__device__ __forceinline__ double wave_max_nonneg_f64(double v) {  // valid for keys >= -1 with max >= 0
+  v = dpp_max_step<0x111>(v);
+  v = dpp_max_step<0x112>(v);
+  v = dpp_max_step<0x114>(v);
+  v = dpp_max_step<0x118>(v);
+  v = dpp_max_step<0x142>(v);
+  v = dpp_max_step<0x143>(v);
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ float epi_err(const double *F, const float *m1, const float *m2, int i) {
+__device__ __forceinline__ bool collinear_last7(const double (&x)[7], const double (&y)[7]) {
+  bool col = false;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double dx1 = x[j] - x[6], dy1 = y[j] - y[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < j) {
+        const double dx2 = x[k] - x[6], dy2 = y[k] - y[6];
+        col = col || (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920929e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)));
+      }
+  }
+  return col;
+}
+
+__device__ __forceinline__ float epi_err9(const double (&F)[9], const float *m1, const float *m2, int i) {
   double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
   double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
   double s2 = 1. / (a * a + b * b);
@@ -530,69 +467,185 @@ __device__ __forceinline__ float epi_err(const double *F, const float *m1, const
   return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
 }
 
-__device__ bool collinear_last(const float *m, const int *idx, int count) {
-  int i = count - 1;
-  for (int j = 0; j < i; ++j) {
-    double dx1 = m[2 * idx[j]] - m[2 * idx[i]], dy1 = m[2 * idx[j] + 1] - m[2 * idx[i] + 1];
-    for (int k = 0; k < j; ++k) {
-      double dx2 = m[2 * idx[k]] - m[2 * idx[i]], dy2 = m[2 * idx[k] + 1] - m[2 * idx[i] + 1];
-      if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920929e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
-    }
-  }
-  return false;
-}
-
-__device__ bool get_subset(const float *m1, const float *m2, int n, unsigned seed, unsigned h, int *idx) {
+// Models of hypothesis h.  Returns a 3-bit validity mask; model k (root k of the cubic, in
+// cv::solveCubic order) is F[k].  All 64 lanes must call this together.
+__device__ int wave_models(RansacLds &L, const float *m1, const float *m2, int n, unsigned seed, int h, double (&F)[3][9]) {
+  const int lane = threadIdx.x & 63;
+  // ---- 7 distinct indices + collinearity test (uniform)
+  double x1[7], y1[7], x2[7], y2[7];
+  bool ok = false;
   unsigned t = 0;
-  for (int attempt = 0; attempt < 16; ++attempt) {
-    int i = 0, guard = 0;
-    while (i < 7 && guard < 64) {
-      ++guard;
-      int cand = (int)(((unsigned long long)rng_draw(seed, h, t++) * (unsigned long long)n) >> 32);
-      bool dup = false;
-      for (int j = 0; j < i; ++j) dup = dup || idx[j] == cand;
-      if (dup) continue;
-      idx[i++] = cand;
+  for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
+    int idx[7] = {-1, -1, -1, -1, -1, -1, -1};
+    int cnt = 0;
+    if (n == 7) {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) idx[q] = q;
+      cnt = 7;
+    } else {
+      for (int guard = 0; guard < 64 && cnt < 7; ++guard) {
+        const int cand = (int)(((unsigned long long)rng_draw(seed, (unsigned)h, t++) * (unsigned long long)n) >> 32);
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) dup = dup || (q < cnt && idx[q] == cand);
+        if (!dup) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) idx[q] = (q == cnt) ? cand : idx[q];
+          ++cnt;
+        }
+      }
     }
-    if (i < 7) continue;
-    if (collinear_last(m1, idx, 7) || collinear_last(m2, idx, 7)) continue;
-    return true;
+    if (cnt < 7) continue;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      x1[q] = m1[2 * idx[q]];
+      y1[q] = m1[2 * idx[q] + 1];
+      x2[q] = m2[2 * idx[q]];
+      y2[q] = m2[2 * idx[q] + 1];
+    }
+    if (n == 7) {
+      ok = true;
+    } else if (!(collinear_last7(x1, y1) || collinear_last7(x2, y2))) {
+      ok = true;
+    }
   }
-  return false;
+  if (!ok) return 0;
+  // ---- this lane's element of the 7x9 constraint matrix
+  const int r = lane < 63 ? lane / 9 : 7, c = lane < 63 ? lane - 9 * (lane / 9) : 0;
+  double px0 = 0, py0 = 0, px1 = 0, py1 = 0;
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+    if (q == r) px0 = x1[q], py0 = y1[q], px1 = x2[q], py1 = y2[q];
+  double a;
+  switch (c) {
+    case 0: a = px1 * px0; break;
+    case 1: a = px1 * py0; break;
+    case 2: a = px1; break;
+    case 3: a = py1 * px0; break;
+    case 4: a = py1 * py0; break;
+    case 5: a = py1; break;
+    case 6: a = px0; break;
+    case 7: a = py0; break;
+    default: a = 1.0; break;
+  }
+  if (lane == 63) a = 0.0;
+  int cp[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double key = (lane < 63 && r >= i && c >= i) ? fabs(a) : -1.0;
+    const double best = wave_max_nonneg_f64(key);
+    if (!(best > 1e-14)) return 0;
+    const unsigned long long bal = __ballot(key == best);
+    const int pl = __ffsll((long long)bal) - 1;
+    const int pr = pl / 9, pc = pl - 9 * pr;
+    int src = lane;
+    if (lane < 63) {
+      if (r == i) src = pr * 9 + c;
+      else if (r == pr) src = i * 9 + c;
+    }
+    a = __shfl(a, src, 64);
+    src = lane;
+    if (lane < 63) {
+      if (c == i) src = r * 9 + pc;
+      else if (c == pc) src = r * 9 + i;
+    }
+    a = __shfl(a, src, 64);
+    {  // colperm swap (pc dynamic, i static)
+      int cpc = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) cpc = (q == pc) ? cp[q] : cpc;
+      const int cpi = cp[i];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) cp[q] = (q == pc) ? cpi : cp[q];
+      cp[i] = cpc;
+    }
+    const double p = __shfl(a, i * 10, 64);
+    const double inv = 1.0 / p;
+    if (r == i) a *= inv;
+    const double f = __shfl(a, lane < 63 ? r * 9 + i : lane, 64);
+    const double arow = __shfl(a, lane < 63 ? i * 9 + c : lane, 64);
+    if (lane < 63 && r != i && f != 0.0) a -= f * arow;
+  }
+  // ---- null-space basis through LDS: f1[cp[j]] = j < 7 ? -A[j][7] : (j == 7), f2 likewise with column 8
+  {
+    const double v7 = __shfl(a, lane < 7 ? lane * 9 + 7 : lane, 64);
+    const double v8 = __shfl(a, lane < 7 ? lane * 9 + 8 : lane, 64);
+    int cpl = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) cpl = (q == lane) ? cp[q] : cpl;
+    __syncthreads();
+    if (lane < 9) {
+      L.f1[cpl] = lane < 7 ? -v7 : (lane == 7 ? 1.0 : 0.0);
+      L.f2[cpl] = lane < 7 ? -v8 : (lane == 8 ? 1.0 : 0.0);
+    }
+    __syncthreads();
+  }
+  double f2[9], g[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    f2[q] = L.f2[q];
+    g[q] = L.f1[q] - f2[q];
+  }
+  // det(f2 + lambda g) = c0 + c1 lambda + c2 lambda^2 + c3 lambda^3
+  double c0 = det3(f2), c3 = det3(g), c1 = 0, c2 = 0;
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    double m[9], q[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) m[e] = f2[e], q[e] = g[e];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      m[3 * rr + cc] = g[3 * rr + cc];
+      q[3 * rr + cc] = f2[3 * rr + cc];
+    }
+    c1 += det3(m);
+    c2 += det3(q);
+  }
+  double roots[3] = {0, 0, 0};
+  const int nroot = solve_cubic(c3, c2, c1, c0, roots);
+  int valid = 0;
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    double lambda = roots[kk], mu = 1.;
+    const double s = g[8] * lambda + f2[8];
+    if (fabs(s) > 2.220446049250313e-16) {
+      mu = 1. / s;
+      lambda *= mu;
+      F[kk][8] = 1.;
+    } else
+      F[kk][8] = 0.;
+    bool finite = true;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      F[kk][e] = g[e] * lambda + f2[e] * mu;
+      finite = finite && isfinite(F[kk][e]);
+    }
+    if (kk < nroot && finite) valid |= 1 << kk;
+  }
+  return valid;
 }
 
-// Hypothesis h (one wavefront): lane 0 solves the 7-point problem (models go to LDS), all lanes
-// count inliers.  counts[h*3 + k] = inliers of model k, or -1.
-__device__ int hypothesis_models(double (*A)[9], const float *m1, const float *m2, int n, unsigned seed, int h, double *F) {
-  int idx[7];
-  if (n == 7) {
-    for (int i = 0; i < 7; ++i) idx[i] = i;
-  } else if (!get_subset(m1, m2, n, seed, (unsigned)h, idx)) {
-    return 0;
-  }
-  return run7point(A, m1, m2, idx, F);
-}
-
+// counts[h*3 + k] = inliers of the k-th VALID model of hypothesis h (compacted like the serial
+// loop), -1 beyond.
 __global__ void __launch_bounds__(64) ransac_hyp_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
                                                         float t, unsigned seed, int *__restrict__ counts) {
-  __shared__ double A[7][9];
-  __shared__ double F[27];
-  __shared__ int nm_s;
+  __shared__ RansacLds L;
   const int h = blockIdx.x, lane = threadIdx.x;
-  if (lane == 0) nm_s = hypothesis_models(A, m1, m2, n, seed, h, F);
-  __syncthreads();
-  const int nm = nm_s;
-  for (int k = 0; k < 3; ++k) {
-    int good = -1;
-    if (k < nm) {
-      int c = 0;
-      for (int i = lane; i < n; i += 64) c += epi_err(F + 9 * k, m1, m2, i) <= t;
+  double F[3][9];
+  const int valid = wave_models(L, m1, m2, n, seed, h, F);
+  int slot = 0;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-      good = c;
+  for (int k = 0; k < 3; ++k) {
+    if (valid & (1 << k)) {
+      int c = 0;
+      for (int i = lane; i < n; i += 64) c += epi_err9(F[k], m1, m2, i) <= t;
+      c = wave_sum_i32(c);
+      if (lane == 0) counts[h * 3 + slot] = c;
+      ++slot;
     }
-    if (lane == 0) counts[h * 3 + k] = good;
   }
+  if (lane == 0)
+    for (int k = slot; k < 3; ++k) counts[h * 3 + k] = -1;
 }
 
 __device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
@@ -606,41 +659,87 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
-// Replays cv::RANSACPointSetRegistrator::run's adaptive loop over the precomputed counts in
-// hypothesis order, re-solves the winning hypothesis and writes mask = klt_status & inlier
+// Replays cv::RANSACPointSetRegistrator::run's adaptive loop over the precomputed counts, 64
+// hypotheses per pass: hypothesis `it` is processed iff it < niters(best before it), where
+// niters = RANSACUpdateNumIters chained from max_iters is monotone in the running best, so the
+// processed set is a prefix and the winner is the first occurrence of the prefix maximum.
+// Then re-solves the winning hypothesis and writes mask = klt_status & inlier
 // (REF: TrackKLT.cpp:876-879).  klt may be null.  info[0] = inliers, info[1] = iterations used.
 __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
                                                            float t, double conf, int max_iters, unsigned seed,
                                                            const int *__restrict__ counts, const uint8_t *__restrict__ klt,
                                                            uint8_t *__restrict__ mask, int *__restrict__ info) {
-  __shared__ double A[7][9];
-  __shared__ double F[27];
-  __shared__ int sel[3];
+  __shared__ RansacLds L;
   const int lane = threadIdx.x;
-  if (lane == 0) {
-    int niters = n == 7 ? 1 : max_iters, best = 0, bh = -1, bk = 0, it = 0;
-    for (; it < niters; ++it)
-      for (int k = 0; k < 3; ++k) {
-        int good = counts[it * 3 + k];
-        if (good > max(best, 6)) {
-          best = good;
-          bh = it;
-          bk = k;
-          niters = ransac_update_iters(conf, (double)(n - good) / n, 7, niters);
-        }
-      }
-    sel[0] = bh;
-    sel[1] = bk;
-    sel[2] = best;
-    info[0] = best;
-    info[1] = it;
-    if (bh >= 0) hypothesis_models(A, m1, m2, n, seed, bh, F);
+  const int total = n == 7 ? 1 : max_iters;
+  int best = 0, bh = -1, bslot = 0, niters = total, used = total;
+  bool stop = false;
+  for (int base = 0; base < total && !stop; base += 64) {
+    const int it = base + lane;
+    int c0 = -1, c1 = -1, c2 = -1;
+    if (it < total) {
+      c0 = counts[it * 3];
+      c1 = counts[it * 3 + 1];
+      c2 = counts[it * 3 + 2];
+    }
+    const int lmax = max(c0, max(c1, c2));
+    // exclusive prefix maximum over lanes, seeded with the carried best
+    int pre = lmax;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int o = __shfl_up(pre, off, 64);
+      if (lane >= off) pre = max(pre, o);
+    }
+    int excl = __shfl_up(pre, 1, 64);
+    if (lane == 0) excl = -1;
+    excl = max(excl, best);
+    // iteration budget in force when hypothesis `it` is reached
+    int budget = niters;
+    if (excl > 6 && excl > best) budget = min(niters, ransac_update_iters(conf, (double)(n - excl) / n, 7, niters));
+    const bool processed = it < total && it < budget;
+    const unsigned long long pb = __ballot(processed);
+    const int nproc = pb == ~0ULL ? 64 : __ffsll((long long)~pb) - 1;  // processed lanes form a prefix
+    // running best over the processed prefix: first lane (and first slot) reaching the prefix maximum
+    const int cand = (lane < nproc) ? lmax : -1;
+    int cmax = cand;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
+    if (cmax > max(best, 6)) {
+      const unsigned long long wb = __ballot(cand == cmax);
+      const int wl = __ffsll((long long)wb) - 1;
+      const int w0 = __shfl(c0, wl, 64), w1 = __shfl(c1, wl, 64);
+      best = cmax;
+      bh = base + wl;
+      bslot = (w0 == cmax) ? 0 : ((w1 == cmax) ? 1 : 2);
+      niters = min(niters, ransac_update_iters(conf, (double)(n - best) / n, 7, niters));
+    }
+    if (nproc < 64 || base + 64 >= niters) {
+      stop = true;
+      used = min(base + nproc, total);
+      if (nproc == 64) used = min(max(niters, base + 64), total);
+    }
   }
-  __syncthreads();
-  const int bh = sel[0], bk = sel[1];
+  if (!stop) used = min(niters, total);
+  double F[3][9];
+  int valid = 0;
+  if (bh >= 0) valid = wave_models(L, m1, m2, n, seed, bh, F);
+  // slot -> root index
+  int kroot = -1, seen = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (valid & (1 << k)) {
+      if (seen == bslot && kroot < 0) kroot = k;
+      ++seen;
+    }
+  if (lane == 0) {
+    info[0] = best;
+    info[1] = used;
+  }
   for (int i = lane; i < n; i += 64) {
     uint8_t in = 0;
-    if (bh >= 0) in = epi_err(F + 9 * bk, m1, m2, i) <= t;
+    if (kroot == 0) in = epi_err9(F[0], m1, m2, i) <= t;
+    else if (kroot == 1) in = epi_err9(F[1], m1, m2, i) <= t;
+    else if (kroot == 2) in = epi_err9(F[2], m1, m2, i) <= t;
     mask[i] = (in && (!klt || klt[i])) ? 1 : 0;
   }
 }
