@@ -70,7 +70,11 @@ def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
         "chi2_gate_kernel": ("mfma", F_FEATS * (2.0 * mp * k * k + 2.0 * mp * mp * k + mp ** 3 / 3.0)),
         "qr_accum_kernel": ("mfma", (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches)),
         "gram_kernel": ("mfma", 2.0 * m * nc * nc),
-        "chol_kernel": ("mfma", nc ** 3 / 3.0),
+        "chol_compress_kernel": ("mfma", nc ** 3 / 3.0),
+        "chol_inv_kernel": ("mfma", r ** 3 / 3.0 + r ** 3 / 3.0),
+        "ekf_w_kernel": ("mfma", 1.0 * r * r * (n + 1)),
+        "ekf_dc_kernel": ("mfma", 1.0 * n * n * r + 2.0 * n * r),
+        "ekf_commit_kernel": ("hbm", 3.0 * n * n * 8),
         "ekf_mt_kernel": ("mfma", 2.0 * n * k * r),
         "ekf_s_kernel": ("mfma", 2.0 * r * r * k),
         "ekf_chol_kernel": ("mfma", r ** 3 / 3.0),

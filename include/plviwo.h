@@ -176,7 +176,8 @@ int plv_cov_rollback(plv_ctx *ctx);
  * cv::buildOpticalFlowPyramid(win_size, pyr_levels).  The previously current pyramid becomes the
  * "last" pyramid (REF: the img_pyramid_last <- img_pyramid_curr swap, TrackKLT.cpp:182-189).
  * `img` is a host CV_8UC1 image, row stride `stride` bytes.  plv_image_stage / plv_feed_staged do
- * the same from an image already resident in HBM (slots 0..7).
+ * the same from an image already resident in HBM (slots 0..7); plv_feed_staged only enqueues
+ * (stream-ordered, no host synchronisation: the next data-returning call on the ctx waits for it).
  * Size mismatch -> PLV_E_BADARG (the reference exits: TrackKLT.cpp:37-43). */
 enum { PLV_PYR_CUR = 0, PLV_PYR_LAST = 1 };
 int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride);

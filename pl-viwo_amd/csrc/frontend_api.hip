@@ -17,7 +17,7 @@ struct FrontState {
   DevBuf slots[8];
   DevBuf hist;
   // per-call point buffers
-  DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info;
+  DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io;
 };
 
 #define TRY(expr)                  \
@@ -118,7 +118,7 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->pts0, &s->pts1, &s->n0, &s->n1,
-                    &s->status, &s->iters, &s->mask, &s->counts, &s->info};
+                    &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io};
   for (auto *b : bufs) b->release();
   for (auto &b : s->slots) b.release();
   delete s;
@@ -153,8 +153,8 @@ int plv_feed_staged(plv_ctx *ctx, int slot) {
     set_last_error("plv_feed_staged: slot %d is empty", slot);
     return PLV_E_BADARG;
   }
-  TRY(feed_device(ctx, s, s->slots[slot].as<uint8_t>()));
-  return sync(ctx);
+  // stream-ordered, no host sync: the next call on this ctx that returns data synchronises
+  return feed_device(ctx, s, s->slots[slot].as<uint8_t>());
 }
 
 int plv_pyramid_levels(plv_ctx *ctx, int which) {
@@ -276,29 +276,33 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
   TRY(need_two(ctx, s, "plv_perform_matching"));
   const int mi = std::max(1, ctx->cfg.ransac_max_iters);
   TRY(reserve_points(s, n, mi));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, pts0, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->pts1.p, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, s->pts0.as<float>(), s->pts1.as<float>(),
-                s->status.as<uint8_t>(), s->iters.as<int>(), ctx->cfg.win_size, ctx->cfg.lk_max_iters, ctx->cfg.lk_eps));
-  TRY(launch_undistort2(ctx, cam_of(ctx), n, s->pts0.as<float>(), s->pts1.as<float>(), s->n0.as<float>(), s->n1.as<float>()));
-  const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
-  TRY(launch_ransac(ctx, s->n0.as<float>(), s->n1.as<float>(), n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi,
-                    0u, s->counts.as<int>(), s->status.as<uint8_t>(), s->mask.as<uint8_t>(), s->info.as<int>()));
-  // results: one pinned block [pts1 | n0 | n1 | iters | mask]
-  size_t o_p1 = 0, o_n0 = (size_t)n * 8, o_n1 = (size_t)n * 16, o_it = (size_t)n * 24, o_mk = (size_t)n * 28,
-         total = (size_t)n * 29;
+  // one device block  [pts0 | pts1 | n0 | n1 | iters | mask | status]  -> one H2D (first two
+  // fields) and one D2H (pts1 .. mask) per call
+  const size_t nn = (size_t)n;
+  const size_t o_p0 = 0, o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36, o_st = nn * 37,
+               total = nn * 38;
+  TRY(s->io.reserve(total));
   TRY(ctx->h_pin.reserve(total));
   char *hp = ctx->h_pin.as<char>();
-  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, s->pts1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (n0) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_n0, s->n0.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (n1) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_n1, s->n1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (lk_iters) PLV_HIP_CHECK(hipMemcpyAsync(hp + o_it, s->iters.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_mk, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  char *dp_ = s->io.as<char>();
+  memcpy(hp + o_p0, pts0, nn * 8);
+  memcpy(hp + o_p1, pts1, nn * 8);
+  PLV_HIP_CHECK(hipMemcpyAsync(dp_, hp, nn * 16, hipMemcpyHostToDevice, ctx->stream));
+  float *d_p0 = (float *)(dp_ + o_p0), *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
+  int *d_it = (int *)(dp_ + o_it);
+  uint8_t *d_mk = (uint8_t *)(dp_ + o_mk), *d_st = (uint8_t *)(dp_ + o_st);
+  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, d_p0, d_p1, d_st, d_it, ctx->cfg.win_size, ctx->cfg.lk_max_iters,
+                ctx->cfg.lk_eps));
+  TRY(launch_undistort2(ctx, cam_of(ctx), n, d_p0, d_p1, d_n0, d_n1));
+  const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
+  TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
+                    d_mk, s->info.as<int>()));
+  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   TRY(sync(ctx));
-  memcpy(pts1, hp + o_p1, (size_t)n * 8);
-  if (n0) memcpy(n0, hp + o_n0, (size_t)n * 8);
-  if (n1) memcpy(n1, hp + o_n1, (size_t)n * 8);
-  memcpy(mask_out, hp + o_mk, (size_t)n);
+  memcpy(pts1, hp + o_p1, nn * 8);
+  if (n0) memcpy(n0, hp + o_n0, nn * 8);
+  if (n1) memcpy(n1, hp + o_n1, nn * 8);
+  memcpy(mask_out, hp + o_mk, nn);
   if (lk_iters) {
     long long t = 0;
     const int *it = (const int *)(hp + o_it);

@@ -73,7 +73,7 @@ struct plv_ctx_update_state {
   plv::DevBuf q95;
   plv::DevBuf result;   // [dx: max_n doubles][flag: int + pad][accepted: bytes]
   plv::DevBuf covck;    // covariance checkpoint
-  plv::DevBuf bHf, bHx, bres, brows, bcols;  // staged (pristine) feature batch
+  plv::DevBuf bHf, bHx, bres, brows, bcols, bwork;  // staged (pristine) feature batch + working copy
   int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
   std::vector<int> brows_host;
 };
@@ -209,7 +209,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
       }
   }
   if (us) {
-    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols};
+    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
     for (auto *b : ub) b->release();
     delete us;
   }
@@ -479,14 +479,13 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   TRY(check_batch(F, fdim, k, ld, rows));
   auto *us = ustate(ctx);
   size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
-  TRY(us->bHf.reserve(nHf * 8));
-  TRY(us->bHx.reserve(nHx * 8));
-  TRY(us->bres.reserve(nr * 8));
+  // pristine batch in ONE allocation [Hf | Hx | res] so that a single D2D restores the working copy
+  TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   TRY(h2d(ctx, us->bHf.p, Hf, nHf * 8));
-  TRY(h2d(ctx, us->bHx.p, Hx, nHx * 8));
-  TRY(h2d(ctx, us->bres.p, res, nr * 8));
+  TRY(h2d(ctx, us->bHf.as<double>() + nHf, Hx, nHx * 8));
+  TRY(h2d(ctx, us->bHf.as<double>() + nHf + nHx, res, nr * 8));
   TRY(h2d(ctx, us->brows.p, rows, (size_t)F * 4));
   TRY(h2d(ctx, us->bcols.p, col_to_state, (size_t)k * 4));
   us->bF = F;
@@ -509,14 +508,11 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   }
   const int F = us->bF, fdim = us->bfdim, k = us->bk, ld = us->bld, n = ctx->cov_n;
   size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
-  TRY(ctx->d_fHf.reserve(nHf * 8));
-  TRY(ctx->d_fHx.reserve(nHx * 8));
-  TRY(ctx->d_fres.reserve(nr * 8));
+  TRY(us->bwork.reserve((nHf + nHx + nr) * 8));
   TRY(ctx->d_chi2.reserve((size_t)F * 8));
-  // working copies (the nullspace projection is in place)
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fHf.p, us->bHf.p, nHf * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fHx.p, us->bHx.p, nHx * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_fres.p, us->bres.p, nr * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  // working copy (the nullspace projection is in place): one D2D
+  PLV_HIP_CHECK(hipMemcpyAsync(us->bwork.p, us->bHf.p, (nHf + nHx + nr) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  double *wHf = us->bwork.as<double>(), *wHx = wHf + nHf, *wres = wHx + nHx;
 
   const int mp_max = us->bmaxrows - fdim;
   if (mp_max < 1) {
@@ -534,8 +530,7 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   unsigned char *d_acc;
   TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc));
 
-  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), ctx->d_fHf.as<double>(), ctx->d_fHx.as<double>(),
-                       ctx->d_fres.as<double>()));
+  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres));
   Chi2Args a{};
   a.P = ctx->d_P.as<double>();
   a.ldp = n;
@@ -543,8 +538,8 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   a.ld = ld;
   a.fdim_off = fdim;
   a.rows = us->brows.as<int>();
-  a.Hx = ctx->d_fHx.as<double>();
-  a.res = ctx->d_fres.as<double>();
+  a.Hx = wHx;
+  a.res = wres;
   a.cols = us->bcols.as<int>();
   a.sigma2 = sigma2;
   a.chi2 = ctx->d_chi2.as<double>();
