@@ -211,6 +211,67 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
 int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0,
                          float *n1, long long *lk_iters);
 
+/* ================================================================ per-feature Jacobians (K10)
+ *
+ * Flat views of what CamHelper::get_feature_jacobian_full (REF: PL-VIWO/src/update/cam/
+ * CamHelper.cpp:58-267) and State::get_interpolated_jacobian (REF: PL-VIWO/src/state/State.cpp:
+ * 833-973) read from the pointer-linked State / Feature objects.
+ * Rotations are 3x3 ROW-major R_GtoI (PoseJPL::Rot()), positions p_IinG; the 6-dof pose error is
+ * ordered (theta, p) like ov_type::PoseJPL. */
+enum { PLV_FEAT_GLOBAL_3D = 0, PLV_FEAT_GLOBAL_FULL_INVERSE_DEPTH = 1 }; /* REF: LandmarkRepresentation.h */
+
+typedef struct plv_state_view {
+  int n_clones;
+  const double *clone_time;    /* [n_clones] ascending (State::clones is a std::map<double, PoseJPL>) */
+  const double *clone_R;       /* [n_clones][9]  current estimate (Rot())            */
+  const double *clone_p;       /* [n_clones][3]                    (pos())            */
+  const double *clone_R_fej;   /* [n_clones][9]  first estimates   (Rot_fej())        */
+  const double *clone_p_fej;   /* [n_clones][3]                    (pos_fej())        */
+  const int *clone_state_id;   /* [n_clones] covariance index of each clone's 6-dof error (Type::id()) */
+  double R_ItoC[9], p_IinC[3]; /* camera extrinsics, State::cam_extrinsic             */
+  double intrinsics[8];        /* State::cam_intrinsic value (fx fy cx cy k1 k2 p1 p2) */
+  double cam_dt;               /* State::cam_dt value                                  */
+  int extrinsic_state_id;      /* covariance index, or -1 unless do_calib_ext          */
+  int intrinsic_state_id;      /* ... -1 unless do_calib_int                           */
+  int dt_state_id;             /* ... -1 unless do_calib_dt                            */
+  int intr_order;              /* 3 (REF: OptionsEstimator.h intr_order); only 3 is built */
+  double dt_exp;               /* 0.01 s extrapolation allowance (OptionsEstimator.h:56) */
+  double sigma_pix;
+  int use_pol_cov;             /* REF: CamHelper.cpp:214-217 */
+  double intr_ori_cov, intr_pos_cov; /* interpolation_error::ori_cov / pos_cov (OptionsEstimator.h:60-80) */
+  int feat_rep;                /* PLV_FEAT_* */
+} plv_state_view;
+
+typedef struct plv_tracks {
+  int n_feat;
+  const int *obs_ptr;      /* [n_feat+1] CSR into the observation arrays                       */
+  const double *obs_time;  /* [n_obs] measurement time stamps (cam_dt is added inside)         */
+  const float *obs_uv;     /* [n_obs][2] raw pixel measurement   (Feature::uvs)                */
+  const double *p_FinG;    /* [n_feat][3] triangulated position                                */
+  const double *p_FinG_fej;/* [n_feat][3] (== p_FinG for MSCKF features, CamHelper.cpp:556-557) */
+  const double *res_R;     /* optional [n_obs][9]: IMU pose for the RESIDUAL at each obs, e.g. the CPI
+                              pose when use_imu_res (State.cpp:1138-1155); NULL -> estimate polynomial */
+  const double *res_p;     /* optional [n_obs][3] */
+} plv_tracks;
+
+/* Column order of the stacked Jacobians: [extrinsics 6][intrinsics 8][dt 1] when calibrated, then
+ * every clone (6 columns) an observation interpolates over, in first-seen order.  Returns k and
+ * fills col_to_state (capacity cap).  Host-side integer logic only. */
+int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *col_to_state, int cap, int *k_out);
+
+/* plv_build_jacobians replaces, for all features at once, get_feature_jacobian_full +
+ * get_interpolated_jacobian + the (optional) polynomial residual pose: writes the whitened
+ * per-feature systems Hf [F][3][ld], Hx [F][k][ld], res [F][ld] and rows[f] = 2 * (valid
+ * observations of feature f) in the layout plv_msckf_update consumes.  Observations whose time has
+ * no bounding clones are dropped (REF: CamHelper.cpp:115-121).  Host buffers out. */
+int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
+                        const int *col_to_state, int ld, int *rows, double *Hf, double *Hx, double *res);
+
+/* The same, leaving the systems staged on the device as the current feature batch (the input of
+ * plv_msckf_update_resident): the whole update then runs without any host round trip. */
+int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
+                                 const int *col_to_state, int ld);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,667 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see dense.h).  PARITY UNPINNED.
+//
+// CPU fp64 restatement of the per-feature linearisation of the MSCKF update:
+//   State::bounding_times / bounding_poses_n          REF: PL-VIWO/src/state/State.cpp:1023-1136
+//   State::build_polynomial_data / add_polynomial     REF: State.cpp:631-798
+//   State::get_interpolated_jacobian                  REF: State.cpp:833-973
+//   State::get_interpolated_pose_poly                 REF: State.cpp:979-1021
+//   CamRadtan::distort_f / compute_distort_jacobian   REF: open_vins/ov_core/src/cam/CamRadtan.h:127-198
+//   CamBase::distort_d (float round trip)             REF: open_vins/ov_core/src/cam/CamBase.h:150-155
+//   CamHelper::get_feature_jacobian_representation    REF: PL-VIWO/src/update/cam/CamHelper.cpp:21-56
+//   CamHelper::get_feature_jacobian_full              REF: CamHelper.cpp:58-267
+//   FeatureInitializer::single_triangulation / single_gaussnewton / compute_error
+//                                                     REF: open_vins/ov_core/src/feat/FeatureInitializer.cpp:30-112,197-423
+//   SO(3) helpers                                     REF: open_vins/ov_core/src/utils/quat_ops.h:135-535
+// The 9x9 constraint matrix V_t of the reference is (Vandermonde 3x3) (x) I3, so its inverse is
+// taken on the 3x3 factor; Eigen's colPivHouseholderQr 3x3 solves are replaced by a pivoted
+// Gaussian solve and JacobiSVD's condition number by the symmetric eigenvalues (A is SPD).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/plviwo.h"
+
+namespace {
+
+struct V3 {
+  double v[3];
+  double &operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+};
+struct M3 {
+  double m[9];  // row-major
+  double &operator()(int r, int c) { return m[3 * r + c]; }
+  double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+inline M3 eye() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+inline M3 mul(const M3 &a, const M3 &b) {
+  M3 c;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
+  return c;
+}
+inline M3 tr(const M3 &a) {
+  M3 c;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c(i, j) = a(j, i);
+  return c;
+}
+inline V3 mul(const M3 &a, const V3 &x) {
+  return V3{{a(0, 0) * x[0] + a(0, 1) * x[1] + a(0, 2) * x[2], a(1, 0) * x[0] + a(1, 1) * x[1] + a(1, 2) * x[2],
+             a(2, 0) * x[0] + a(2, 1) * x[1] + a(2, 2) * x[2]}};
+}
+inline M3 scale(const M3 &a, double s) {
+  M3 c = a;
+  for (double &x : c.m) x *= s;
+  return c;
+}
+inline M3 add(const M3 &a, const M3 &b) {
+  M3 c;
+  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] + b.m[i];
+  return c;
+}
+inline V3 sub(const V3 &a, const V3 &b) { return V3{{a[0] - b[0], a[1] - b[1], a[2] - b[2]}}; }
+inline V3 addv(const V3 &a, const V3 &b) { return V3{{a[0] + b[0], a[1] + b[1], a[2] + b[2]}}; }
+inline V3 sc(const V3 &a, double s) { return V3{{a[0] * s, a[1] * s, a[2] * s}}; }
+inline double norm(const V3 &a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline M3 skew(const V3 &w) { return M3{{0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}}; }  // quat_ops.h:135
+inline M3 inv3(const M3 &a) {
+  double c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1), c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2),
+         c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  double det = a(0, 0) * c00 + a(0, 1) * c01 + a(0, 2) * c02;
+  double id = 1.0 / det;
+  M3 r;
+  r(0, 0) = c00 * id;
+  r(0, 1) = (a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2)) * id;
+  r(0, 2) = (a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1)) * id;
+  r(1, 0) = c01 * id;
+  r(1, 1) = (a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0)) * id;
+  r(1, 2) = (a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2)) * id;
+  r(2, 0) = c02 * id;
+  r(2, 1) = (a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1)) * id;
+  r(2, 2) = (a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0)) * id;
+  return r;
+}
+
+// quat_ops.h:231-251
+M3 exp_so3(const V3 &w) {
+  M3 wx = skew(w);
+  double theta = norm(w);
+  double A, B;
+  if (theta < 1e-7) {
+    A = 1;
+    B = 0.5;
+  } else {
+    A = std::sin(theta) / theta;
+    B = (1 - std::cos(theta)) / (theta * theta);
+  }
+  if (theta == 0) return eye();
+  return add(add(eye(), scale(wx, A)), scale(mul(wx, wx), B));
+}
+// quat_ops.h:273-313
+V3 log_so3(const M3 &R) {
+  double R11 = R(0, 0), R12 = R(0, 1), R13 = R(0, 2), R21 = R(1, 0), R22 = R(1, 1), R23 = R(1, 2), R31 = R(2, 0),
+         R32 = R(2, 1), R33 = R(2, 2);
+  const double trc = R11 + R22 + R33;
+  V3 omega;
+  if (trc + 1.0 < 1e-10) {
+    if (std::fabs(R33 + 1.0) > 1e-5)
+      omega = sc(V3{{R13, R23, 1.0 + R33}}, M_PI / std::sqrt(2.0 + 2.0 * R33));
+    else if (std::fabs(R22 + 1.0) > 1e-5)
+      omega = sc(V3{{R12, 1.0 + R22, R32}}, M_PI / std::sqrt(2.0 + 2.0 * R22));
+    else
+      omega = sc(V3{{1.0 + R11, R21, R31}}, M_PI / std::sqrt(2.0 + 2.0 * R11));
+  } else {
+    double magnitude;
+    const double tr_3 = trc - 3.0;
+    if (tr_3 < -1e-7) {
+      double theta = std::acos((trc - 1.0) / 2.0);
+      magnitude = theta / (2.0 * std::sin(theta));
+    } else {
+      magnitude = 0.5 - tr_3 / 12.0;
+    }
+    omega = sc(V3{{R32 - R23, R13 - R31, R21 - R12}}, magnitude);
+  }
+  return omega;
+}
+// quat_ops.h:515-526
+M3 Jl_so3(const V3 &w) {
+  double theta = norm(w);
+  if (theta < 1e-6) return eye();
+  V3 a = sc(w, 1.0 / theta);
+  M3 aat;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) aat(i, j) = a[i] * a[j];
+  return add(add(scale(eye(), std::sin(theta) / theta), scale(aat, 1 - std::sin(theta) / theta)),
+             scale(skew(a), (1 - std::cos(theta)) / theta));
+}
+
+inline M3 getM(const double *p) {
+  M3 m;
+  memcpy(m.m, p, sizeof(m.m));
+  return m;
+}
+inline V3 getV(const double *p) { return V3{{p[0], p[1], p[2]}}; }
+
+// State::bounding_times + bounding_poses_n for n_order = 3: index of the first of the 4 clones, or -1
+int bounding_start(const plv_state_view &st, double t) {
+  const int N = st.n_clones, n_order = st.intr_order;
+  if (N < n_order + 1 || N < 2) return -1;
+  const double *ct = st.clone_time;
+  if (t < ct[0] - st.dt_exp || t > ct[N - 1] + st.dt_exp) return -1;
+  int n_b = -1;
+  for (int i = 0; i < N - 1; ++i)
+    if (ct[i] - st.dt_exp <= t && t <= ct[i + 1] + st.dt_exp) {
+      n_b = i;
+      break;
+    }
+  if (n_b < 0) return -1;
+  const int n_e = n_b + 1;
+  const int n_side = (int)((double)(n_order + 1) / 2.0);
+  int start = n_b - n_side + 1;
+  if (n_b - n_side + 1 < 0)
+    start = 0;
+  else if (n_e + n_side - 1 >= N)
+    start = N - 1 - n_order;
+  if (start < 0 || start + 1 + n_order > N) return -1;
+  return start;
+}
+
+struct Interp {
+  int start;          // first of the 4 clones
+  M3 R;               // interpolated R_GtoI
+  V3 p;               // interpolated p_IinG
+  double H[4][2][9];  // per pose: [0] = 3x3 orientation block, [1] = 3x3 position block (the 6x6 is block diagonal)
+  double dt_jac[6];   // dpose/dt_offset
+};
+
+// polynomial through clones start..start+3 evaluated at t; fej selects the first-estimate poses.
+// REF: State.cpp:631-723 (coefficients) + :881-958 (evaluation and Jacobians)
+bool interpolate(const plv_state_view &st, double t, bool fej, bool want_jac, Interp &o) {
+  const int s0 = bounding_start(st, t);
+  if (s0 < 0) return false;
+  if (t > st.clone_time[st.n_clones - 1]) return false;  // State.cpp:852-855 (newer than the state)
+  o.start = s0;
+  const double *Rs = fej ? st.clone_R_fej : st.clone_R, *ps = fej ? st.clone_p_fej : st.clone_p;
+  const M3 R0 = getM(Rs + 9 * s0);
+  const V3 p0 = getV(ps + 3 * s0);
+  V3 th[3], dp[3];
+  M3 Rw[3];
+  double dts[3];
+  for (int w = 0; w < 3; ++w) {
+    const M3 Ri = getM(Rs + 9 * (s0 + 1 + w));
+    Rw[w] = mul(Ri, tr(R0));
+    th[w] = log_so3(Rw[w]);
+    dp[w] = sub(getV(ps + 3 * (s0 + 1 + w)), p0);
+    dts[w] = st.clone_time[s0 + 1 + w] - st.clone_time[s0];
+  }
+  // V(p, i) = dt_p^(i+1);  coefficients = V^-1 * differences
+  M3 V;
+  for (int p = 0; p < 3; ++p)
+    for (int i = 0; i < 3; ++i) V(p, i) = std::pow(dts[p], i + 1);
+  const M3 Vi = inv3(V);
+  const double dtm = t - st.clone_time[s0];
+  double lam[3], lamd[3];
+  for (int w = 0; w < 3; ++w) {
+    lam[w] = lamd[w] = 0;
+    for (int i = 0; i < 3; ++i) {
+      lam[w] += std::pow(dtm, i + 1) * Vi(i, w);
+      lamd[w] += (double)(i + 1) * std::pow(dtm, i) * Vi(i, w);
+    }
+  }
+  V3 A_ori{{0, 0, 0}}, A_pos{{0, 0, 0}};
+  for (int w = 0; w < 3; ++w) {
+    A_ori = addv(A_ori, sc(th[w], lam[w]));
+    A_pos = addv(A_pos, sc(dp[w], lam[w]));
+  }
+  const M3 Rio = exp_so3(A_ori);
+  o.R = mul(Rio, R0);
+  o.p = addv(p0, A_pos);
+  if (!want_jac) return true;
+  const M3 Jl = Jl_so3(A_ori);
+  // H_0 = [ sum_w (-lam_w Jl) (Jl(th_w)^-1 R_w) + Rio , (1 - sum lam) I ]
+  M3 H0o = Rio;
+  double lsum = 0;
+  for (int w = 0; w < 3; ++w) {
+    const M3 JinvW = inv3(Jl_so3(th[w]));
+    H0o = add(H0o, scale(mul(Jl, mul(JinvW, Rw[w])), -lam[w]));
+    const M3 Hw = scale(mul(Jl, JinvW), lam[w]);  // -dth_db_w * JlinOtoiInv_w
+    memcpy(o.H[w + 1][0], Hw.m, sizeof(Hw.m));
+    const M3 Pw = scale(eye(), lam[w]);
+    memcpy(o.H[w + 1][1], Pw.m, sizeof(Pw.m));
+    lsum += lam[w];
+  }
+  memcpy(o.H[0][0], H0o.m, sizeof(H0o.m));
+  const M3 P0 = scale(eye(), 1.0 - lsum);
+  memcpy(o.H[0][1], P0.m, sizeof(P0.m));
+  V3 dori{{0, 0, 0}}, dpos{{0, 0, 0}};
+  for (int w = 0; w < 3; ++w) {
+    dori = addv(dori, sc(th[w], lamd[w]));
+    dpos = addv(dpos, sc(dp[w], lamd[w]));
+  }
+  const V3 top = sc(mul(Jl, dori), -1.0);
+  for (int i = 0; i < 3; ++i) {
+    o.dt_jac[i] = top[i];
+    o.dt_jac[3 + i] = dpos[i];
+  }
+  return true;
+}
+
+// CamRadtan::distort_f via CamBase::distort_d: input and output rounded through float
+void distort_d(const double *K, const double uvn[2], double out[2]) {
+  const float xf = (float)uvn[0], yf = (float)uvn[1];
+  const double x = xf, y = yf;
+  double r = std::sqrt(x * x + y * y);
+  double r_2 = r * r, r_4 = r_2 * r_2;
+  double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
+  double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
+  out[0] = (double)(float)(K[0] * x1 + K[2]);
+  out[1] = (double)(float)(K[1] * y1 + K[3]);
+}
+// CamRadtan::compute_distort_jacobian
+void distort_jacobian(const double *K, const double uvn[2], double dzn[4], double dzeta[16]) {
+  const double x = uvn[0], y = uvn[1];
+  double r = std::sqrt(x * x + y * y);
+  double r_2 = r * r, r_4 = r_2 * r_2;
+  double x_2 = x * x, y_2 = y * y, x_y = x * y;
+  dzn[0] = K[0] * ((1 + K[4] * r_2 + K[5] * r_4) + (2 * K[4] * x_2 + 4 * K[5] * x_2 * r_2) + 2 * K[6] * y + (2 * K[7] * x + 4 * K[7] * x));
+  dzn[1] = K[0] * (2 * K[4] * x_y + 4 * K[5] * x_y * r_2 + 2 * K[6] * x + 2 * K[7] * y);
+  dzn[2] = K[1] * (2 * K[4] * x_y + 4 * K[5] * x_y * r_2 + 2 * K[6] * x + 2 * K[7] * y);
+  dzn[3] = K[1] * ((1 + K[4] * r_2 + K[5] * r_4) + (2 * K[4] * y_2 + 4 * K[5] * y_2 * r_2) + 2 * K[7] * x + (2 * K[6] * y + 4 * K[6] * y));
+  double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
+  double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
+  memset(dzeta, 0, 16 * sizeof(double));
+  dzeta[0] = x1;
+  dzeta[2] = 1;
+  dzeta[4] = K[0] * x * r_2;
+  dzeta[5] = K[0] * x * r_4;
+  dzeta[6] = 2 * K[0] * x * y;
+  dzeta[7] = K[0] * (r_2 + 2 * x * x);
+  dzeta[8 + 1] = y1;
+  dzeta[8 + 3] = 1;
+  dzeta[8 + 4] = K[1] * y * r_2;
+  dzeta[8 + 5] = K[1] * y * r_4;
+  dzeta[8 + 6] = K[1] * (r_2 + 2 * y * y);
+  dzeta[8 + 7] = 2 * K[1] * x * y;
+}
+
+// CamHelper::get_feature_jacobian_representation
+M3 representation_jacobian(int rep, const V3 &pf) {
+  if (rep == PLV_FEAT_GLOBAL_3D) return eye();
+  double g_rho = 1 / norm(pf);
+  double g_phi = std::acos(g_rho * pf[2]);
+  double g_theta = std::atan2(pf[1], pf[0]);
+  double sin_th = std::sin(g_theta), cos_th = std::cos(g_theta), sin_phi = std::sin(g_phi), cos_phi = std::cos(g_phi), rho = g_rho;
+  M3 H;
+  H(0, 0) = -(1.0 / rho) * sin_th * sin_phi;
+  H(0, 1) = (1.0 / rho) * cos_th * cos_phi;
+  H(0, 2) = -(1.0 / (rho * rho)) * cos_th * sin_phi;
+  H(1, 0) = (1.0 / rho) * cos_th * sin_phi;
+  H(1, 1) = (1.0 / rho) * sin_th * cos_phi;
+  H(1, 2) = -(1.0 / (rho * rho)) * sin_th * sin_phi;
+  H(2, 0) = 0.0;
+  H(2, 1) = -(1.0 / rho) * sin_phi;
+  H(2, 2) = -(1.0 / (rho * rho)) * cos_phi;
+  return H;
+}
+
+inline int find_col(const int *col_to_state, int k, int state_id) {
+  for (int j = 0; j < k; ++j)
+    if (col_to_state[j] == state_id) return j;
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// column order: see plv_jacobian_columns
+int orc_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *col_to_state, int cap, int *k_out) {
+  int k = 0;
+  auto push = [&](int id, int size) {
+    if (id < 0) return true;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == id) return true;
+    if (k + size > cap) return false;
+    for (int d = 0; d < size; ++d) col_to_state[k++] = id + d;
+    return true;
+  };
+  if (!push(st->extrinsic_state_id, 6) || !push(st->intrinsic_state_id, 8) || !push(st->dt_state_id, 1)) return -5;
+  for (int f = 0; f < tr->n_feat; ++f)
+    for (int o = tr->obs_ptr[f]; o < tr->obs_ptr[f + 1]; ++o) {
+      int s0 = bounding_start(*st, tr->obs_time[o] + st->cam_dt);
+      if (s0 < 0 || tr->obs_time[o] + st->cam_dt > st->clone_time[st->n_clones - 1]) continue;
+      for (int w = 0; w < 4; ++w)
+        if (!push(st->clone_state_id[s0 + w], 6)) return -5;
+    }
+  *k_out = k;
+  return 0;
+}
+
+// interpolation at one time (exposed for the unit tests): R (9), p (3), H (4 x 2 x 9), dt_jac (6), start
+int orc_interpolate(const plv_state_view *st, double t, int fej, double *R, double *p, double *H, double *dtj, int *start) {
+  Interp it;
+  if (!interpolate(*st, t, fej != 0, true, it)) return -1;
+  memcpy(R, it.R.m, 72);
+  memcpy(p, it.p.v, 24);
+  memcpy(H, it.H, sizeof(it.H));
+  memcpy(dtj, it.dt_jac, 48);
+  *start = it.start;
+  return 0;
+}
+
+// REF: CamHelper.cpp:58-267, all features.  Layout identical to plv_build_jacobians.
+int orc_build_jacobians(const plv_state_view *st, const plv_tracks *tr, int k, const int *col_to_state, int ld, int *rows,
+                        double *Hf, double *Hx, double *res) {
+  const int F = tr->n_feat;
+  memset(Hf, 0, sizeof(double) * (size_t)F * 3 * ld);
+  memset(Hx, 0, sizeof(double) * (size_t)F * k * ld);
+  memset(res, 0, sizeof(double) * (size_t)F * ld);
+  const M3 R_ItoC = getM(st->R_ItoC);
+  const V3 p_IinC = getV(st->p_IinC);
+  const double *K = st->intrinsics;
+  const int col_ext = st->extrinsic_state_id >= 0 ? find_col(col_to_state, k, st->extrinsic_state_id) : -1;
+  const int col_int = st->intrinsic_state_id >= 0 ? find_col(col_to_state, k, st->intrinsic_state_id) : -1;
+  const int col_dt = st->dt_state_id >= 0 ? find_col(col_to_state, k, st->dt_state_id) : -1;
+  for (int f = 0; f < F; ++f) {
+    double *hf = Hf + (size_t)f * 3 * ld, *hx = Hx + (size_t)f * k * ld, *rs = res + (size_t)f * ld;
+    const V3 pf = getV(tr->p_FinG + 3 * f), pf_fej = getV(tr->p_FinG_fej + 3 * f);
+    const M3 dpdl = representation_jacobian(st->feat_rep, pf_fej);
+    int c = 0;
+    for (int o = tr->obs_ptr[f]; o < tr->obs_ptr[f + 1]; ++o) {
+      const double tm = tr->obs_time[o] + st->cam_dt;
+      Interp jac;
+      if (!interpolate(*st, tm, true, true, jac)) continue;  // dropped measurement
+      if (2 * c + 2 > ld) return -5;
+      // ---- residual with the estimate pose (provided, or the estimate polynomial)
+      M3 R_GtoI;
+      V3 p_IinG;
+      if (tr->res_R) {
+        R_GtoI = getM(tr->res_R + 9 * o);
+        p_IinG = getV(tr->res_p + 3 * o);
+      } else {
+        Interp est;
+        if (!interpolate(*st, tm, false, false, est)) continue;
+        R_GtoI = est.R;
+        p_IinG = est.p;
+      }
+      V3 p_FinI = mul(R_GtoI, sub(pf, p_IinG));
+      V3 p_FinC = addv(mul(R_ItoC, p_FinI), p_IinC);
+      double uvn[2] = {p_FinC[0] / p_FinC[2], p_FinC[1] / p_FinC[2]};
+      double uvd[2];
+      distort_d(K, uvn, uvd);
+      double r2[2] = {(double)tr->obs_uv[2 * o] - uvd[0], (double)tr->obs_uv[2 * o + 1] - uvd[1]};
+      // ---- Jacobians at the first estimates
+      R_GtoI = jac.R;
+      p_IinG = jac.p;
+      double dzn[4], dzeta[16];
+      distort_jacobian(K, uvn, dzn, dzeta);
+      p_FinI = mul(R_GtoI, sub(pf_fej, p_IinG));
+      p_FinC = addv(mul(R_ItoC, p_FinI), p_IinC);
+      const double iz = 1 / p_FinC[2];
+      const double dznp[6] = {iz, 0, -p_FinC[0] / (p_FinC[2] * p_FinC[2]), 0, iz, -p_FinC[1] / (p_FinC[2] * p_FinC[2])};
+      const M3 dpC_dpG = mul(R_ItoC, R_GtoI);
+      double dpC_dI[18];  // 3x6: [R_ItoC skew(p_FinI) | -dpC_dpG]
+      const M3 left = mul(R_ItoC, skew(p_FinI));
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          dpC_dI[6 * i + j] = left(i, j);
+          dpC_dI[6 * i + 3 + j] = -dpC_dpG(i, j);
+        }
+      double dz_dpC[6];  // 2x3 = dzn (2x2) * dznp (2x3)
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) dz_dpC[3 * i + j] = dzn[2 * i] * dznp[j] + dzn[2 * i + 1] * dznp[3 + j];
+      double HI[12];  // 2x6
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) HI[6 * i + j] = dz_dpC[3 * i] * dpC_dI[j] + dz_dpC[3 * i + 1] * dpC_dI[6 + j] + dz_dpC[3 * i + 2] * dpC_dI[12 + j];
+      // ---- noise and whitening (REF :207-239; note the reference solves with the SYMMETRIC matrix
+      // built from the lower triangle of chol(R), `R_llt.llt().solve(I)`, reproduced here)
+      double Rn[4] = {st->sigma_pix * st->sigma_pix, 0, 0, st->sigma_pix * st->sigma_pix};
+      bool at_clone = false;
+      for (int i = 0; i < st->n_clones; ++i) at_clone = at_clone || st->clone_time[i] == tm;
+      if (!at_clone && st->use_pol_cov) {
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) {
+            double s = 0;
+            for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? st->intr_ori_cov : st->intr_pos_cov) * HI[6 * j + q];
+            Rn[2 * i + j] += s;
+          }
+      }
+      const double l00 = std::sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = std::sqrt(Rn[3] - l10 * l10);
+      // B = [[l00, l10],[l10, l11]] (selfadjoint lower); X = B^-1 via its own Cholesky
+      const double m00 = std::sqrt(l00), m10 = l10 / m00, m11 = std::sqrt(l11 - m10 * m10);
+      double Wm[4];
+      for (int col = 0; col < 2; ++col) {
+        double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+        double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
+        double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
+        Wm[col] = x0;
+        Wm[2 + col] = x1;
+      }
+      const double rw[2] = {Wm[0] * r2[0] + Wm[1] * r2[1], Wm[2] * r2[0] + Wm[3] * r2[1]};
+      double wz[6], wzeta[16];
+      for (int j = 0; j < 3; ++j) {
+        wz[j] = Wm[0] * dz_dpC[j] + Wm[1] * dz_dpC[3 + j];
+        wz[3 + j] = Wm[2] * dz_dpC[j] + Wm[3] * dz_dpC[3 + j];
+      }
+      for (int j = 0; j < 8; ++j) {
+        wzeta[j] = Wm[0] * dzeta[j] + Wm[1] * dzeta[8 + j];
+        wzeta[8 + j] = Wm[2] * dzeta[j] + Wm[3] * dzeta[8 + j];
+      }
+      rs[2 * c] = rw[0];
+      rs[2 * c + 1] = rw[1];
+      // Hf rows: wz * dpC_dpG * dpdl
+      const M3 G = mul(dpC_dpG, dpdl);
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) hf[(size_t)j * ld + 2 * c + i] += wz[3 * i] * G(0, j) + wz[3 * i + 1] * G(1, j) + wz[3 * i + 2] * G(2, j);
+      // Hx: wz * dpC_dI (2x6) * dTdx_w (6x6 block diagonal) for the 4 poses
+      double WI[12];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) WI[6 * i + j] = wz[3 * i] * dpC_dI[j] + wz[3 * i + 1] * dpC_dI[6 + j] + wz[3 * i + 2] * dpC_dI[12 + j];
+      for (int w = 0; w < 4; ++w) {
+        const int col = find_col(col_to_state, k, st->clone_state_id[jac.start + w]);
+        if (col < 0) return -1;
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 3; ++j) {
+            double so = 0, sp = 0;
+            for (int q = 0; q < 3; ++q) {
+              so += WI[6 * i + q] * jac.H[w][0][3 * q + j];
+              sp += WI[6 * i + 3 + q] * jac.H[w][1][3 * q + j];
+            }
+            hx[(size_t)(col + j) * ld + 2 * c + i] += so;
+            hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += sp;
+          }
+      }
+      if (col_dt >= 0)
+        for (int i = 0; i < 2; ++i) {
+          double s = 0;
+          for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dt_jac[q];
+          hx[(size_t)col_dt * ld + 2 * c + i] += s;
+        }
+      if (col_ext >= 0) {  // dp_FinC_dT_ItoC = [skew(p_FinC - p_IinC) | I]
+        const M3 sk = skew(sub(p_FinC, p_IinC));
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 3; ++j) {
+            hx[(size_t)(col_ext + j) * ld + 2 * c + i] += wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
+            hx[(size_t)(col_ext + 3 + j) * ld + 2 * c + i] += wz[3 * i + j];
+          }
+      }
+      if (col_int >= 0)
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 8; ++j) hx[(size_t)(col_int + j) * ld + 2 * c + i] += wzeta[8 * i + j];
+      ++c;
+    }
+    rows[f] = 2 * c;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- triangulation (a18)
+// cam poses per observation: R_GtoC (9 row-major), p_CinG (3); uvn = normalised float coords.
+// anchor = LAST observation (mono: REF FeatureInitializer.cpp:44-45).  Returns 1 on success.
+static double tri_error(int M, const double *Rc, const double *pc, const float *uvn, const M3 &R_GtoA, const V3 &p_AinG,
+                        double alpha, double beta, double rho) {
+  double err = 0;
+  for (int m = 0; m < M; ++m) {
+    const M3 R_GtoCi = getM(Rc + 9 * m);
+    const M3 R_AtoCi = mul(R_GtoCi, tr(R_GtoA));
+    const V3 p_CiinA = mul(R_GtoA, sub(getV(pc + 3 * m), p_AinG));
+    const V3 p_AinCi = sc(mul(R_AtoCi, p_CiinA), -1.0);
+    double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
+    double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
+    double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
+    float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+    float r0 = uvn[2 * m] - z0, r1 = uvn[2 * m + 1] - z1;
+    float nrm = std::sqrt(r0 * r0 + r1 * r1);
+    err += std::pow((double)nrm, 2);
+  }
+  return err;
+}
+static bool solve3(const M3 &A, const V3 &b, V3 &x) {
+  double a[3][4];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) a[i][j] = A(i, j);
+    a[i][3] = b[i];
+  }
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 3; ++r)
+      if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (a[piv][c] == 0) return false;
+    for (int j = 0; j < 4; ++j) std::swap(a[piv][j], a[c][j]);
+    for (int r = c + 1; r < 3; ++r) {
+      double f = a[r][c] / a[c][c];
+      for (int j = c; j < 4; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 2; i >= 0; --i) {
+    double s = a[i][3];
+    for (int j = i + 1; j < 3; ++j) s -= a[i][j] * x[j];
+    x[i] = s / a[i][i];
+  }
+  return true;
+}
+// eigenvalues of a symmetric 3x3 (for cond(A) = sigma_max / sigma_min of the SPD normal matrix)
+static void sym_eig3(const M3 &A, double ev[3]) {
+  double p1 = A(0, 1) * A(0, 1) + A(0, 2) * A(0, 2) + A(1, 2) * A(1, 2);
+  double q = (A(0, 0) + A(1, 1) + A(2, 2)) / 3;
+  double p2 = (A(0, 0) - q) * (A(0, 0) - q) + (A(1, 1) - q) * (A(1, 1) - q) + (A(2, 2) - q) * (A(2, 2) - q) + 2 * p1;
+  double p = std::sqrt(p2 / 6);
+  if (p == 0) {
+    ev[0] = ev[1] = ev[2] = q;
+    return;
+  }
+  M3 B = scale(add(A, scale(eye(), -q)), 1 / p);
+  double detB = B(0, 0) * (B(1, 1) * B(2, 2) - B(1, 2) * B(2, 1)) - B(0, 1) * (B(1, 0) * B(2, 2) - B(1, 2) * B(2, 0)) +
+                B(0, 2) * (B(1, 0) * B(2, 1) - B(1, 1) * B(2, 0));
+  double r = detB / 2;
+  double phi = r <= -1 ? M_PI / 3 : (r >= 1 ? 0 : std::acos(r) / 3);
+  ev[0] = q + 2 * p * std::cos(phi);
+  ev[2] = q + 2 * p * std::cos(phi + (2 * M_PI / 3));
+  ev[1] = 3 * q - ev[0] - ev[2];
+}
+
+int orc_triangulate(int M, const double *Rc, const double *pc, const float *uvn, double min_dist, double max_dist,
+                    double max_cond, double max_baseline, int refine, double *p_FinG_out) {
+  if (M < 2) return 0;
+  const M3 R_GtoA = getM(Rc + 9 * (M - 1));
+  const V3 p_AinG = getV(pc + 3 * (M - 1));
+  M3 A{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  V3 b{{0, 0, 0}};
+  for (int m = 0; m < M; ++m) {
+    const M3 R_AtoCi = mul(getM(Rc + 9 * m), tr(R_GtoA));
+    const V3 p_CiinA = mul(R_GtoA, sub(getV(pc + 3 * m), p_AinG));
+    V3 bi = mul(tr(R_AtoCi), V3{{(double)uvn[2 * m], (double)uvn[2 * m + 1], 1.0}});
+    bi = sc(bi, 1.0 / norm(bi));
+    const M3 Bp = skew(bi);
+    const M3 Ai = mul(tr(Bp), Bp);
+    A = add(A, Ai);
+    b = addv(b, mul(Ai, p_CiinA));
+  }
+  V3 pf;
+  if (!solve3(A, b, pf)) return 0;
+  double ev[3];
+  sym_eig3(A, ev);
+  double condA = ev[0] / ev[2];
+  if (std::fabs(condA) > max_cond || pf[2] < min_dist || pf[2] > max_dist || std::isnan(norm(pf))) return 0;
+  if (refine) {
+    // FeatureInitializerOptions defaults: max_runs 5, init_lamda 1e-3, max_lamda 1e10, min_dx 1e-6,
+    // min_dcost 1e-6, lam_mult 10  (REF: FeatureInitializerOptions.h:36-69)
+    double rho = 1 / pf[2], alpha = pf[0] / pf[2], beta = pf[1] / pf[2];
+    double lam = 1e-3, eps = 10000;
+    int runs = 0;
+    bool recompute = true;
+    M3 Hess{{0}};
+    V3 grad{{0, 0, 0}};
+    double cost_old = tri_error(M, Rc, pc, uvn, R_GtoA, p_AinG, alpha, beta, rho);
+    while (runs < 5 && lam < 1e10 && eps > 1e-6) {
+      if (recompute) {
+        memset(Hess.m, 0, sizeof(Hess.m));
+        grad = V3{{0, 0, 0}};
+        for (int m = 0; m < M; ++m) {
+          const M3 R_AtoCi = mul(getM(Rc + 9 * m), tr(R_GtoA));
+          const V3 p_CiinA = mul(R_GtoA, sub(getV(pc + 3 * m), p_AinG));
+          const V3 p_AinCi = sc(mul(R_AtoCi, p_CiinA), -1.0);
+          double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
+          double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
+          double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
+          double h3s = std::pow(hi3, 2);
+          double H[6] = {(R_AtoCi(0, 0) * hi3 - hi1 * R_AtoCi(2, 0)) / h3s, (R_AtoCi(0, 1) * hi3 - hi1 * R_AtoCi(2, 1)) / h3s,
+                         (p_AinCi[0] * hi3 - hi1 * p_AinCi[2]) / h3s,        (R_AtoCi(1, 0) * hi3 - hi2 * R_AtoCi(2, 0)) / h3s,
+                         (R_AtoCi(1, 1) * hi3 - hi2 * R_AtoCi(2, 1)) / h3s, (p_AinCi[1] * hi3 - hi2 * p_AinCi[2]) / h3s};
+          float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+          double r0 = (double)(uvn[2 * m] - z0), r1 = (double)(uvn[2 * m + 1] - z1);
+          for (int i = 0; i < 3; ++i) {
+            grad[i] += H[i] * r0 + H[3 + i] * r1;
+            for (int j = 0; j < 3; ++j) Hess(i, j) += H[i] * H[j] + H[3 + i] * H[3 + j];
+          }
+        }
+      }
+      M3 Hl = Hess;
+      for (int r = 0; r < 3; ++r) Hl(r, r) *= (1.0 + lam);
+      V3 dx;
+      if (!solve3(Hl, grad, dx)) break;
+      double cost = tri_error(M, Rc, pc, uvn, R_GtoA, p_AinG, alpha + dx[0], beta + dx[1], rho + dx[2]);
+      if (cost <= cost_old && (cost_old - cost) / cost_old < 1e-6) {
+        alpha += dx[0];
+        beta += dx[1];
+        rho += dx[2];
+        eps = 0;
+        break;
+      }
+      if (cost <= cost_old) {
+        recompute = true;
+        cost_old = cost;
+        alpha += dx[0];
+        beta += dx[1];
+        rho += dx[2];
+        runs++;
+        lam = lam / 10;
+        eps = norm(dx);
+      } else {
+        recompute = false;
+        lam = lam * 10;
+      }
+    }
+    pf = V3{{alpha / rho, beta / rho, 1 / rho}};
+    // baseline test: components of the camera offsets orthogonal to p_FinA (the reference spans that
+    // plane with the last two columns of a Householder Q of p_FinA)
+    const V3 dir = sc(pf, 1.0 / norm(pf));
+    double base_max = 0;
+    for (int m = 0; m < M; ++m) {
+      const V3 p_CiinA = mul(R_GtoA, sub(getV(pc + 3 * m), p_AinG));
+      double along = p_CiinA[0] * dir[0] + p_CiinA[1] * dir[1] + p_CiinA[2] * dir[2];
+      V3 perp = sub(p_CiinA, sc(dir, along));
+      base_max = std::max(base_max, norm(perp));
+    }
+    if (pf[2] < min_dist || pf[2] > max_dist || (norm(pf) / base_max) > max_baseline || std::isnan(norm(pf))) return 0;
+  }
+  const V3 pg = addv(mul(tr(R_GtoA), pf), p_AinG);
+  p_FinG_out[0] = pg[0];
+  p_FinG_out[1] = pg[1];
+  p_FinG_out[2] = pg[2];
+  return 1;
+}
+
+}  // extern "C"

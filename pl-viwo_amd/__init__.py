@@ -137,6 +137,72 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+
+class PlvStateView(C.Structure):
+    _fields_ = [
+        ("n_clones", C.c_int),
+        ("clone_time", C.POINTER(C.c_double)), ("clone_R", C.POINTER(C.c_double)), ("clone_p", C.POINTER(C.c_double)),
+        ("clone_R_fej", C.POINTER(C.c_double)), ("clone_p_fej", C.POINTER(C.c_double)),
+        ("clone_state_id", C.POINTER(C.c_int)),
+        ("R_ItoC", C.c_double * 9), ("p_IinC", C.c_double * 3), ("intrinsics", C.c_double * 8), ("cam_dt", C.c_double),
+        ("extrinsic_state_id", C.c_int), ("intrinsic_state_id", C.c_int), ("dt_state_id", C.c_int),
+        ("intr_order", C.c_int), ("dt_exp", C.c_double), ("sigma_pix", C.c_double),
+        ("use_pol_cov", C.c_int), ("intr_ori_cov", C.c_double), ("intr_pos_cov", C.c_double),
+        ("feat_rep", C.c_int),
+    ]
+
+
+class PlvTracks(C.Structure):
+    _fields_ = [
+        ("n_feat", C.c_int),
+        ("obs_ptr", C.POINTER(C.c_int)), ("obs_time", C.POINTER(C.c_double)), ("obs_uv", C.POINTER(C.c_float)),
+        ("p_FinG", C.POINTER(C.c_double)), ("p_FinG_fej", C.POINTER(C.c_double)),
+        ("res_R", C.POINTER(C.c_double)), ("res_p", C.POINTER(C.c_double)),
+    ]
+
+
+class StateView:
+    """Owns the numpy arrays behind a plv_state_view."""
+
+    def __init__(self, clone_time, clone_R, clone_p, clone_state_id, R_ItoC, p_IinC, intrinsics, clone_R_fej=None,
+                 clone_p_fej=None, cam_dt=0.0, extrinsic_state_id=-1, intrinsic_state_id=-1, dt_state_id=-1, sigma_pix=1.5,
+                 use_pol_cov=0, intr_ori_cov=0.0, intr_pos_cov=0.0, feat_rep=0, dt_exp=0.01):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.t, self.R, self.p = f(clone_time), f(clone_R).reshape(-1, 9), f(clone_p).reshape(-1, 3)
+        self.Rf = f(clone_R_fej).reshape(-1, 9) if clone_R_fej is not None else self.R.copy()
+        self.pf = f(clone_p_fej).reshape(-1, 3) if clone_p_fej is not None else self.p.copy()
+        self.ids = np.ascontiguousarray(clone_state_id, dtype=np.int32)
+        v = PlvStateView()
+        v.n_clones = len(self.t)
+        v.clone_time, v.clone_R, v.clone_p = _dp(self.t), _dp(self.R), _dp(self.p)
+        v.clone_R_fej, v.clone_p_fej, v.clone_state_id = _dp(self.Rf), _dp(self.pf), _ip(self.ids)
+        v.R_ItoC = (C.c_double * 9)(*np.asarray(R_ItoC, dtype=np.float64).ravel())
+        v.p_IinC = (C.c_double * 3)(*np.asarray(p_IinC, dtype=np.float64).ravel())
+        v.intrinsics = (C.c_double * 8)(*np.asarray(intrinsics, dtype=np.float64).ravel())
+        v.cam_dt, v.extrinsic_state_id, v.intrinsic_state_id, v.dt_state_id = cam_dt, extrinsic_state_id, intrinsic_state_id, dt_state_id
+        v.intr_order, v.dt_exp, v.sigma_pix = 3, dt_exp, sigma_pix
+        v.use_pol_cov, v.intr_ori_cov, v.intr_pos_cov, v.feat_rep = use_pol_cov, intr_ori_cov, intr_pos_cov, feat_rep
+        self.c = v
+
+
+class Tracks:
+    """Owns the numpy arrays behind a plv_tracks (CSR observation lists)."""
+
+    def __init__(self, obs_ptr, obs_time, obs_uv, p_FinG, p_FinG_fej=None, res_R=None, res_p=None):
+        self.ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
+        self.t = np.ascontiguousarray(obs_time, dtype=np.float64)
+        self.uv = np.ascontiguousarray(obs_uv, dtype=np.float32).reshape(-1, 2)
+        self.pf = np.ascontiguousarray(p_FinG, dtype=np.float64).reshape(-1, 3)
+        self.pff = np.ascontiguousarray(p_FinG_fej, dtype=np.float64).reshape(-1, 3) if p_FinG_fej is not None else self.pf.copy()
+        self.rR = np.ascontiguousarray(res_R, dtype=np.float64).reshape(-1, 9) if res_R is not None else None
+        self.rp = np.ascontiguousarray(res_p, dtype=np.float64).reshape(-1, 3) if res_p is not None else None
+        v = PlvTracks()
+        v.n_feat = len(self.ptr) - 1
+        v.obs_ptr, v.obs_time, v.obs_uv = _ip(self.ptr), _dp(self.t), _fp(self.uv)
+        v.p_FinG, v.p_FinG_fej, v.res_R, v.res_p = _dp(self.pf), _dp(self.pff), _dp(self.rR), _dp(self.rp)
+        self.c = v
+
+
 def default_config(width=752, height=480):
     lib = load_library()
     cfg = PlvConfig()

@@ -231,3 +231,63 @@ def load_front():
         load()
         _front = FrontOracle(_inst.lib)
     return _front
+
+
+# ------------------------------------------------------------------ Jacobian / triangulation oracle
+class JacOracle:
+    def __init__(self, lib, pkg):
+        self.lib, self.pkg = lib, pkg
+        sv, tk = C.POINTER(pkg.PlvStateView), C.POINTER(pkg.PlvTracks)
+        lib.orc_jacobian_columns.argtypes = [sv, tk, ip, C.c_int, ip]
+        lib.orc_jacobian_columns.restype = C.c_int
+        lib.orc_interpolate.argtypes = [sv, C.c_double, C.c_int, dp, dp, dp, dp, ip]
+        lib.orc_interpolate.restype = C.c_int
+        lib.orc_build_jacobians.argtypes = [sv, tk, C.c_int, ip, C.c_int, ip, dp, dp, dp]
+        lib.orc_build_jacobians.restype = C.c_int
+        lib.orc_triangulate.argtypes = [C.c_int, dp, dp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp]
+        lib.orc_triangulate.restype = C.c_int
+
+    def columns(self, st, tr, cap=512):
+        cols = np.zeros(cap, dtype=np.int32)
+        k = C.c_int()
+        rc = self.lib.orc_jacobian_columns(C.byref(st.c), C.byref(tr.c), _ip(cols), cap, C.byref(k))
+        assert rc == 0
+        return cols[:k.value].copy()
+
+    def interpolate(self, st, t, fej=True):
+        R, p, H, dtj = np.zeros(9), np.zeros(3), np.zeros((4, 2, 3, 3)), np.zeros(6)
+        start = C.c_int()
+        rc = self.lib.orc_interpolate(C.byref(st.c), float(t), 1 if fej else 0, _dp(R), _dp(p), _dp(H), _dp(dtj),
+                                      C.byref(start))
+        if rc != 0:
+            return None
+        return R.reshape(3, 3), p, H, dtj, start.value
+
+    def build_jacobians(self, st, tr, cols, ld):
+        F, k = tr.c.n_feat, len(cols)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        rows = np.zeros(F, dtype=np.int32)
+        Hf, Hx, res = np.zeros((F, 3, ld)), np.zeros((F, k, ld)), np.zeros((F, ld))
+        rc = self.lib.orc_build_jacobians(C.byref(st.c), C.byref(tr.c), k, _ip(cols), ld, _ip(rows), _dp(Hf), _dp(Hx), _dp(res))
+        assert rc == 0, rc
+        return rows, Hf, Hx, res
+
+    def triangulate(self, Rc, pc, uvn, min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True):
+        Rc = np.ascontiguousarray(Rc, dtype=np.float64).reshape(-1, 9)
+        pc = np.ascontiguousarray(pc, dtype=np.float64).reshape(-1, 3)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros(3)
+        ok = self.lib.orc_triangulate(len(Rc), _dp(Rc), _dp(pc), uvn.ctypes.data_as(fp), min_dist, max_dist, max_cond,
+                                      max_baseline, 1 if refine else 0, _dp(out))
+        return bool(ok), out
+
+
+_jac = None
+
+
+def load_jac(pkg):
+    global _jac
+    if _jac is None:
+        load()
+        _jac = JacOracle(_inst.lib, pkg)
+    return _jac

@@ -122,3 +122,86 @@ def grid_points(w, h, n, seed=1, border=24):
 
 
 EUROC_K8 = np.array([458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+
+
+# ------------------------------------------------------------------ visual-inertial scene (SURVEY §8(d) cfg 2 filter problem)
+def _exp_so3(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def radtan_distort(K8, xy):
+    x, y = xy[..., 0], xy[..., 1]
+    r2 = x * x + y * y
+    rad = 1 + K8[4] * r2 + K8[5] * r2 * r2
+    xd = x * rad + 2 * K8[6] * x * y + K8[7] * (r2 + 2 * x * x)
+    yd = y * rad + K8[6] * (r2 + 2 * y * y) + 2 * K8[7] * x * y
+    return np.stack([K8[0] * xd + K8[2], K8[1] * yd + K8[3]], axis=-1)
+
+
+def vio_scene(n_clones=15, F=70, M=15, seed=3, noise_px=1.0, dt_clone=0.05, obs_offset=0.0, w=752, h=480,
+              calib_int=True, fej_noise=0.0):
+    """Smooth 1 m/s arc, clones every dt_clone seconds, F landmarks each observed in its last M (or fewer)
+    clone frames at times clone_time + obs_offset.  State layout: IMU(15) | intrinsics(8) | clones(6 each)
+    -> n = 113, k = 98 for 15 clones.  Returns a dict of plain numpy arrays."""
+    rng = np.random.default_rng(seed)
+    K8 = EUROC_K8.copy()
+    t = 100.0 + dt_clone * np.arange(n_clones)
+    R_ItoC = _exp_so3(np.array([0.01, -0.02, 0.015]))
+    p_IinC = np.array([0.05, -0.02, 0.01])
+
+    def pose(ti):
+        s = ti - t[0]
+        R = _exp_so3(np.array([0.03 * np.sin(1.3 * s), 0.08 * s, 0.02 * np.cos(0.7 * s)]))
+        p = np.array([1.0 * s, 0.05 * np.sin(2.0 * s), 0.1 * s * s])
+        return R, p
+
+    poses = [pose(ti) for ti in t]
+    clone_R = np.array([R for R, _ in poses])
+    clone_p = np.array([p for _, p in poses])
+    first = 15 + (8 if calib_int else 0)
+    ids = (first + 6 * np.arange(n_clones)).astype(np.int32)
+    n_state = first + 6 * n_clones
+    # landmarks visible from every clone
+    pts = []
+    while len(pts) < F:
+        c = np.array([rng.uniform(-20, 20), rng.uniform(-14, 14), rng.uniform(3, 60)])
+        ok = True
+        for R, p in poses:
+            pc = R_ItoC @ (R @ (c - p)) + p_IinC
+            uv = radtan_distort(K8, pc[:2] / pc[2])
+            ok = ok and pc[2] > 1 and 5 < uv[0] < w - 5 and 5 < uv[1] < h - 5 and np.hypot(*(pc[:2] / pc[2])) < 0.9
+        if ok:
+            pts.append(c)
+    pts = np.array(pts)
+    obs_ptr, obs_time, obs_uv, obs_clone = [0], [], [], []
+    for f in range(F):
+        m = M if f % 4 else max(3, M - rng.integers(0, M // 2 + 1))
+        for ci in range(n_clones - m, n_clones):
+            tm = t[ci] + (obs_offset if ci < n_clones - 1 else 0.0)
+            R, p = (clone_R[ci], clone_p[ci]) if tm == t[ci] else pose(tm)
+            pc = R_ItoC @ (R @ (pts[f] - p)) + p_IinC
+            uv = radtan_distort(K8, pc[:2] / pc[2]) + rng.normal(0, noise_px, 2)
+            obs_time.append(tm)
+            obs_uv.append(uv)
+            obs_clone.append(ci)
+        obs_ptr.append(len(obs_time))
+    clone_R_fej, clone_p_fej = clone_R.copy(), clone_p.copy()
+    if fej_noise > 0:
+        for i in range(n_clones):
+            clone_R_fej[i] = _exp_so3(rng.normal(0, fej_noise, 3)) @ clone_R[i]
+            clone_p_fej[i] = clone_p[i] + rng.normal(0, fej_noise, 3)
+    return dict(t=t, R=clone_R, p=clone_p, Rf=clone_R_fej, pf=clone_p_fej, ids=ids, n_state=n_state, R_ItoC=R_ItoC,
+                p_IinC=p_IinC, K8=K8, pts=pts, obs_ptr=np.array(obs_ptr, np.int32), obs_time=np.array(obs_time),
+                obs_uv=np.array(obs_uv, np.float32), obs_clone=np.array(obs_clone), intr_id=15 if calib_int else -1,
+                pose_fn=pose)
+
+
+def scene_views(pkg, sc, p_FinG=None, sigma_pix=1.5, **kw):
+    st = pkg.StateView(sc["t"], sc["R"], sc["p"], sc["ids"], sc["R_ItoC"], sc["p_IinC"], sc["K8"], clone_R_fej=sc["Rf"],
+                       clone_p_fej=sc["pf"], intrinsic_state_id=sc["intr_id"], sigma_pix=sigma_pix, **kw)
+    tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"] if p_FinG is None else p_FinG)
+    return st, tr
