@@ -103,6 +103,10 @@ def load_library():
         "plv_undistort": (C.c_int, [vp, C.c_int, fp, fp]),
         "plv_ransac_fundamental": (C.c_int, [vp, C.c_int, fp, fp, C.c_double, C.c_uint32, u8p, ip, ip]),
         "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
+        "plv_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvTracks), ip, C.c_int, ip]),
+        "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
+                                          dp, dp]),
+        "plv_build_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -419,3 +423,24 @@ class Context:
         self._chk(self.lib.plv_perform_matching(self.h, n, _fp(pts0), _fp(pts1), _u8p(mask), _fp(n0), _fp(n1),
                                                 C.byref(it)))
         return pts1, mask, n0, n1, it.value
+
+    # ---- per-feature Jacobians
+    def jacobian_columns(self, st, tr, cap=1024):
+        cols = np.zeros(cap, dtype=np.int32)
+        k = C.c_int()
+        self._chk(self.lib.plv_jacobian_columns(C.byref(st.c), C.byref(tr.c), _ip(cols), cap, C.byref(k)))
+        return cols[:k.value].copy()
+
+    def build_jacobians(self, st, tr, cols, ld):
+        cols = _i32(cols)
+        F, k = tr.c.n_feat, len(cols)
+        rows = np.zeros(F, dtype=np.int32)
+        Hf, Hx, res = np.zeros((F, 3, ld)), np.zeros((F, k, ld)), np.zeros((F, ld))
+        self._chk(self.lib.plv_build_jacobians(self.h, C.byref(st.c), C.byref(tr.c), k, _ip(cols), ld, _ip(rows), _dp(Hf),
+                                               _dp(Hx), _dp(res)))
+        return rows, Hf, Hx, res
+
+    def build_jacobians_resident(self, st, tr, cols, ld):
+        cols = _i32(cols)
+        self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
+        self._batch_F = tr.c.n_feat

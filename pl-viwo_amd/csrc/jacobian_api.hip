@@ -1,0 +1,232 @@
+// jacobian_api.hip — plv_jacobian_columns / plv_build_jacobians[_resident] (include/plviwo.h).
+// Host side: integer bookkeeping only (column order, CSR -> per-observation feature index, one
+// packed upload); all arithmetic is in jacobian_kernel.  No CPU compute path.
+#include <algorithm>
+#include <vector>
+
+#include "jacobian_kernels.hpp"
+#include "update_state.hpp"
+
+using namespace plv;
+
+#define TRY(expr)                  \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != PLV_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+// State::bounding_times + bounding_poses_n (order 3), host copy used for the column bookkeeping.
+// REF: PL-VIWO/src/state/State.cpp:1023-1136
+int bounding_start_host(const plv_state_view &st, double t) {
+  const int N = st.n_clones;
+  if (N < 4) return -1;
+  const double *ct = st.clone_time;
+  if (t < ct[0] - st.dt_exp || t > ct[N - 1] + st.dt_exp) return -1;
+  if (t > ct[N - 1]) return -1;
+  int n_b = -1;
+  for (int i = 0; i < N - 1; ++i)
+    if (ct[i] - st.dt_exp <= t && t <= ct[i + 1] + st.dt_exp) {
+      n_b = i;
+      break;
+    }
+  if (n_b < 0) return -1;
+  int start = n_b - 1;
+  if (n_b - 1 < 0)
+    start = 0;
+  else if (n_b + 2 >= N)
+    start = N - 4;
+  if (start < 0 || start + 4 > N) return -1;
+  return start;
+}
+
+int check_views(const plv_state_view *st, const plv_tracks *tr) {
+  if (!st || !tr || st->n_clones < 1 || !st->clone_time || !st->clone_R || !st->clone_p || !st->clone_R_fej ||
+      !st->clone_p_fej || !st->clone_state_id || tr->n_feat < 1 || !tr->obs_ptr || !tr->obs_time || !tr->obs_uv ||
+      !tr->p_FinG || !tr->p_FinG_fej) {
+    set_last_error("jacobians: null view field");
+    return PLV_E_BADARG;
+  }
+  if (st->intr_order != 3) {
+    set_last_error("jacobians: only intr_order = 3 is built (got %d)", st->intr_order);
+    return PLV_E_BADARG;
+  }
+  if ((tr->res_R == nullptr) != (tr->res_p == nullptr)) return PLV_E_BADARG;
+  return PLV_OK;
+}
+
+// Packs every input array into one pinned block, uploads it with one copy and fills JacParams.
+int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
+                 const int *col_to_state, int ld, JacParams &P) {
+  const int N = st->n_clones, F = tr->n_feat, nobs = tr->obs_ptr[F];
+  if (nobs < 1) {
+    set_last_error("jacobians: no observations");
+    return PLV_E_BADARG;
+  }
+  auto col_of = [&](int sid) {
+    if (sid < 0) return -1;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == sid) return j;
+    return -1;
+  };
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_time = take(8 * N), o_R = take(72 * N), o_p = take(24 * N), o_Rf = take(72 * N), o_pf = take(24 * N),
+               o_ccol = take(4 * N), o_ptr = take(4 * (F + 1)), o_of = take(4 * nobs), o_ot = take(8 * nobs),
+               o_uv = take(8 * nobs), o_pg = take(24 * F), o_pgf = take(24 * F),
+               o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0;
+  const size_t total = off;
+  TRY(us->h_jin.reserve(total));
+  TRY(us->jin.reserve(total));
+  char *h = us->h_jin.as<char>();
+  memcpy(h + o_time, st->clone_time, 8 * N);
+  memcpy(h + o_R, st->clone_R, 72 * N);
+  memcpy(h + o_p, st->clone_p, 24 * N);
+  memcpy(h + o_Rf, st->clone_R_fej, 72 * N);
+  memcpy(h + o_pf, st->clone_p_fej, 24 * N);
+  int *ccol = (int *)(h + o_ccol);
+  for (int i = 0; i < N; ++i) ccol[i] = col_of(st->clone_state_id[i]);
+  memcpy(h + o_ptr, tr->obs_ptr, 4 * (F + 1));
+  int *of = (int *)(h + o_of);
+  for (int f = 0; f < F; ++f) {
+    if (tr->obs_ptr[f + 1] < tr->obs_ptr[f]) return PLV_E_BADARG;
+    for (int o = tr->obs_ptr[f]; o < tr->obs_ptr[f + 1]; ++o) of[o] = f;
+  }
+  memcpy(h + o_ot, tr->obs_time, 8 * nobs);
+  memcpy(h + o_uv, tr->obs_uv, 8 * nobs);
+  memcpy(h + o_pg, tr->p_FinG, 24 * F);
+  memcpy(h + o_pgf, tr->p_FinG_fej, 24 * F);
+  if (tr->res_R) {
+    memcpy(h + o_rR, tr->res_R, 72 * nobs);
+    memcpy(h + o_rp, tr->res_p, 24 * nobs);
+  }
+  PLV_HIP_CHECK(hipMemcpyAsync(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  const char *d = us->jin.as<char>();
+  P.n_clones = N;
+  P.clone_time = (const double *)(d + o_time);
+  P.clone_R = (const double *)(d + o_R);
+  P.clone_p = (const double *)(d + o_p);
+  P.clone_R_fej = (const double *)(d + o_Rf);
+  P.clone_p_fej = (const double *)(d + o_pf);
+  P.clone_col = (const int *)(d + o_ccol);
+  memcpy(P.R_ItoC, st->R_ItoC, 72);
+  memcpy(P.p_IinC, st->p_IinC, 24);
+  memcpy(P.K, st->intrinsics, 64);
+  P.cam_dt = st->cam_dt;
+  P.dt_exp = st->dt_exp;
+  P.sigma_pix = st->sigma_pix;
+  P.intr_ori_cov = st->intr_ori_cov;
+  P.intr_pos_cov = st->intr_pos_cov;
+  P.use_pol_cov = st->use_pol_cov;
+  P.feat_rep = st->feat_rep;
+  P.col_ext = col_of(st->extrinsic_state_id);
+  P.col_int = col_of(st->intrinsic_state_id);
+  P.col_dt = col_of(st->dt_state_id);
+  P.n_feat = F;
+  P.n_obs = nobs;
+  P.obs_ptr = (const int *)(d + o_ptr);
+  P.obs_feat = (const int *)(d + o_of);
+  P.obs_time = (const double *)(d + o_ot);
+  P.obs_uv = (const float *)(d + o_uv);
+  P.p_FinG = (const double *)(d + o_pg);
+  P.p_FinG_fej = (const double *)(d + o_pgf);
+  P.res_R = tr->res_R ? (const double *)(d + o_rR) : nullptr;
+  P.res_p = tr->res_R ? (const double *)(d + o_rp) : nullptr;
+  P.k = k;
+  P.ld = ld;
+  return PLV_OK;
+}
+
+// builds the batch into us->bHf ([Hf | Hx | res]) and us->brows on the device
+int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
+                    const int *col_to_state, int ld) {
+  TRY(check_views(st, tr));
+  if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
+  const int F = tr->n_feat;
+  const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
+  TRY(us->brows.reserve((size_t)F * 4));
+  TRY(us->bcols.reserve((size_t)k * 4));
+  JacParams P{};
+  TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
+  PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(hipMemsetAsync(us->bHf.p, 0, (nHf + nHx + nr) * 8, ctx->stream));
+  PLV_HIP_CHECK(hipMemsetAsync(us->brows.p, 0, (size_t)F * 4, ctx->stream));
+  P.rows = us->brows.as<int>();
+  P.Hf = us->bHf.as<double>();
+  P.Hx = P.Hf + nHf;
+  P.res = P.Hx + nHx;
+  TRY(launch_jacobians(ctx, P));
+  us->bF = F;
+  us->bfdim = 3;
+  us->bk = k;
+  us->bld = ld;
+  us->bmaxrows = ld;
+  us->b_on_device_rows = true;
+  return PLV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *col_to_state, int cap, int *k_out) {
+  if (!col_to_state || !k_out) return PLV_E_BADARG;
+  TRY(check_views(st, tr));
+  int k = 0;
+  auto push = [&](int id, int size) {
+    if (id < 0) return true;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == id) return true;
+    if (k + size > cap) return false;
+    for (int d = 0; d < size; ++d) col_to_state[k++] = id + d;
+    return true;
+  };
+  // REF: CamHelper.cpp:74-95 calibration blocks first, then :98-110 interpolation poses in first-seen order
+  if (!push(st->extrinsic_state_id, 6) || !push(st->intrinsic_state_id, 8) || !push(st->dt_state_id, 1)) return PLV_E_CAPACITY;
+  for (int f = 0; f < tr->n_feat; ++f)
+    for (int o = tr->obs_ptr[f]; o < tr->obs_ptr[f + 1]; ++o) {
+      const int s0 = bounding_start_host(*st, tr->obs_time[o] + st->cam_dt);
+      if (s0 < 0) continue;
+      for (int w = 0; w < 4; ++w)
+        if (!push(st->clone_state_id[s0 + w], 6)) return PLV_E_CAPACITY;
+    }
+  *k_out = k;
+  return PLV_OK;
+}
+
+int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
+                                 const int *col_to_state, int ld) {
+  if (!ctx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld));
+  us->b_single_use = true;  // consumed in place by the next plv_msckf_update_resident
+  return PLV_OK;            // stream-ordered; no host synchronisation
+}
+
+int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k, const int *col_to_state,
+                        int ld, int *rows, double *Hf, double *Hx, double *res) {
+  if (!ctx || !rows || !Hf || !Hx || !res) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld));
+  us->b_single_use = false;
+  const int F = tr->n_feat;
+  const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  const double *d = us->bHf.as<double>();
+  PLV_HIP_CHECK(hipMemcpyAsync(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(rows, us->brows.p, (size_t)F * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// jacobian_kernels.hip — K10: per-observation linearisation of the MSCKF point measurement (fp64).
+//
+//   jacobian_kernel   CamHelper::get_feature_jacobian_full            REF: PL/update/cam/CamHelper.cpp:58-267
+//                     State::get_interpolated_jacobian (FEJ polynomial) REF: PL/state/State.cpp:833-973
+//                     State::get_interpolated_pose_poly (residual pose) REF: PL/state/State.cpp:979-1021
+//                     CamRadtan::distort_f / compute_distort_jacobian  REF: OV/cam/CamRadtan.h:127-198
+//
+// One THREAD per observation: the work per observation is a few thousand scalar fp64 operations on
+// 3x3 blocks (two polynomial interpolations on so(3) x R^3, projection, distortion Jacobians, 2x2
+// whitening) and nothing is shared between observations except read-only clone poses, so the
+// natural GPU shape is "one lane = one (feature, observation)", ~1000 lanes per frame.  Rows are
+// written straight into the [Hf | Hx | res] batch layout that nullspace_kernel consumes; the batch
+// is zero-filled by a memset node in front of the launch.
+#include "jacobian_kernels.hpp"
+
+namespace plv {
+
+struct V3 {
+  double v[3];
+  __device__ double &operator[](int i) { return v[i]; }
+  __device__ double operator[](int i) const { return v[i]; }
+};
+struct M3 {
+  double m[9];
+  __device__ double &operator()(int r, int c) { return m[3 * r + c]; }
+  __device__ double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+__device__ __forceinline__ M3 eye3() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+__device__ __forceinline__ M3 mm(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
+  return c;
+}
+__device__ __forceinline__ M3 tp(const M3 &a) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c(i, j) = a(j, i);
+  return c;
+}
+__device__ __forceinline__ V3 mv(const M3 &a, const V3 &x) {
+  return V3{{a(0, 0) * x[0] + a(0, 1) * x[1] + a(0, 2) * x[2], a(1, 0) * x[0] + a(1, 1) * x[1] + a(1, 2) * x[2],
+             a(2, 0) * x[0] + a(2, 1) * x[1] + a(2, 2) * x[2]}};
+}
+__device__ __forceinline__ M3 ms(const M3 &a, double s) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] * s;
+  return c;
+}
+__device__ __forceinline__ M3 ma(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] + b.m[i];
+  return c;
+}
+__device__ __forceinline__ V3 vsub(const V3 &a, const V3 &b) { return V3{{a[0] - b[0], a[1] - b[1], a[2] - b[2]}}; }
+__device__ __forceinline__ V3 vadd(const V3 &a, const V3 &b) { return V3{{a[0] + b[0], a[1] + b[1], a[2] + b[2]}}; }
+__device__ __forceinline__ V3 vsc(const V3 &a, double s) { return V3{{a[0] * s, a[1] * s, a[2] * s}}; }
+__device__ __forceinline__ double vnorm(const V3 &a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+__device__ __forceinline__ M3 skew3(const V3 &w) { return M3{{0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}}; }
+__device__ __forceinline__ M3 inv3(const M3 &a) {
+  double c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1), c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2),
+         c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  double det = a(0, 0) * c00 + a(0, 1) * c01 + a(0, 2) * c02;
+  double id = 1.0 / det;
+  M3 r;
+  r(0, 0) = c00 * id;
+  r(0, 1) = (a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2)) * id;
+  r(0, 2) = (a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1)) * id;
+  r(1, 0) = c01 * id;
+  r(1, 1) = (a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0)) * id;
+  r(1, 2) = (a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2)) * id;
+  r(2, 0) = c02 * id;
+  r(2, 1) = (a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1)) * id;
+  r(2, 2) = (a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0)) * id;
+  return r;
+}
+__device__ M3 exp_so3(const V3 &w) {  // REF: quat_ops.h:231-251
+  const M3 wx = skew3(w);
+  const double theta = vnorm(w);
+  double A, B;
+  if (theta < 1e-7) {
+    A = 1;
+    B = 0.5;
+  } else {
+    A = sin(theta) / theta;
+    B = (1 - cos(theta)) / (theta * theta);
+  }
+  if (theta == 0) return eye3();
+  return ma(ma(eye3(), ms(wx, A)), ms(mm(wx, wx), B));
+}
+__device__ V3 log_so3(const M3 &R) {  // REF: quat_ops.h:273-313
+  const double R11 = R(0, 0), R12 = R(0, 1), R13 = R(0, 2), R21 = R(1, 0), R22 = R(1, 1), R23 = R(1, 2), R31 = R(2, 0),
+               R32 = R(2, 1), R33 = R(2, 2);
+  const double trc = R11 + R22 + R33;
+  const double PI = 3.14159265358979323846;
+  if (trc + 1.0 < 1e-10) {
+    if (fabs(R33 + 1.0) > 1e-5) return vsc(V3{{R13, R23, 1.0 + R33}}, PI / sqrt(2.0 + 2.0 * R33));
+    if (fabs(R22 + 1.0) > 1e-5) return vsc(V3{{R12, 1.0 + R22, R32}}, PI / sqrt(2.0 + 2.0 * R22));
+    return vsc(V3{{1.0 + R11, R21, R31}}, PI / sqrt(2.0 + 2.0 * R11));
+  }
+  double magnitude;
+  const double tr_3 = trc - 3.0;
+  if (tr_3 < -1e-7) {
+    const double theta = acos((trc - 1.0) / 2.0);
+    magnitude = theta / (2.0 * sin(theta));
+  } else {
+    magnitude = 0.5 - tr_3 / 12.0;
+  }
+  return vsc(V3{{R32 - R23, R13 - R31, R21 - R12}}, magnitude);
+}
+__device__ M3 Jl_so3(const V3 &w) {  // REF: quat_ops.h:515-526
+  const double theta = vnorm(w);
+  if (theta < 1e-6) return eye3();
+  const V3 a = vsc(w, 1.0 / theta);
+  M3 aat;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) aat(i, j) = a[i] * a[j];
+  return ma(ma(ms(eye3(), sin(theta) / theta), ms(aat, 1 - sin(theta) / theta)), ms(skew3(a), (1 - cos(theta)) / theta));
+}
+__device__ __forceinline__ M3 ldM(const double *p) {
+  M3 m;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m.m[i] = p[i];
+  return m;
+}
+__device__ __forceinline__ V3 ldV(const double *p) { return V3{{p[0], p[1], p[2]}}; }
+
+// State::bounding_times + bounding_poses_n (order 3)   REF: State.cpp:1023-1136
+__device__ int bounding_start(const JacParams &P, double t) {
+  const int N = P.n_clones;
+  if (N < 4) return -1;
+  const double *ct = P.clone_time;
+  if (t < ct[0] - P.dt_exp || t > ct[N - 1] + P.dt_exp) return -1;
+  if (t > ct[N - 1]) return -1;  // State.cpp:852-855
+  int n_b = -1;
+  for (int i = 0; i < N - 1; ++i)
+    if (ct[i] - P.dt_exp <= t && t <= ct[i + 1] + P.dt_exp) {
+      n_b = i;
+      break;
+    }
+  if (n_b < 0) return -1;
+  int start = n_b - 1;
+  if (n_b - 1 < 0)
+    start = 0;
+  else if (n_b + 2 >= N)
+    start = N - 4;
+  if (start < 0 || start + 4 > N) return -1;
+  return start;
+}
+
+struct Interp {
+  M3 R;
+  V3 p;
+  M3 Ho[4];       // orientation blocks of dT/dx for the 4 poses
+  double lam[4];  // position blocks are lam I  (lam[0] = 1 - sum)
+  double dtj[6];
+};
+
+// polynomial through clones s0..s0+3 at time t.  REF: State.cpp:631-723, 881-958
+__device__ void interpolate(const JacParams &P, int s0, double t, bool fej, bool want_jac, Interp &o) {
+  const double *Rs = fej ? P.clone_R_fej : P.clone_R, *ps = fej ? P.clone_p_fej : P.clone_p;
+  const M3 R0 = ldM(Rs + 9 * s0);
+  const V3 p0 = ldV(ps + 3 * s0);
+  V3 th[3], dp[3];
+  M3 Rw[3], V;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    Rw[w] = mm(ldM(Rs + 9 * (s0 + 1 + w)), tp(R0));
+    th[w] = log_so3(Rw[w]);
+    dp[w] = vsub(ldV(ps + 3 * (s0 + 1 + w)), p0);
+    const double d = P.clone_time[s0 + 1 + w] - P.clone_time[s0];
+    V(w, 0) = pow(d, 1.0);
+    V(w, 1) = pow(d, 2.0);
+    V(w, 2) = pow(d, 3.0);
+  }
+  const M3 Vi = inv3(V);
+  const double dtm = t - P.clone_time[s0];
+  const double pw[4] = {pow(dtm, 0.0), pow(dtm, 1.0), pow(dtm, 2.0), pow(dtm, 3.0)};
+  double lam[3], lamd[3];
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    lam[w] = lamd[w] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lam[w] += pw[i + 1] * Vi(i, w);
+      lamd[w] += (double)(i + 1) * pw[i] * Vi(i, w);
+    }
+  }
+  V3 A_ori{{0, 0, 0}}, A_pos{{0, 0, 0}};
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    A_ori = vadd(A_ori, vsc(th[w], lam[w]));
+    A_pos = vadd(A_pos, vsc(dp[w], lam[w]));
+  }
+  const M3 Rio = exp_so3(A_ori);
+  o.R = mm(Rio, R0);
+  o.p = vadd(p0, A_pos);
+  if (!want_jac) return;
+  const M3 Jl = Jl_so3(A_ori);
+  M3 H0o = Rio;
+  double lsum = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const M3 JinvW = inv3(Jl_so3(th[w]));
+    H0o = ma(H0o, ms(mm(Jl, mm(JinvW, Rw[w])), -lam[w]));
+    o.Ho[w + 1] = ms(mm(Jl, JinvW), lam[w]);
+    o.lam[w + 1] = lam[w];
+    lsum += lam[w];
+  }
+  o.Ho[0] = H0o;
+  o.lam[0] = 1.0 - lsum;
+  V3 dori{{0, 0, 0}}, dpos{{0, 0, 0}};
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    dori = vadd(dori, vsc(th[w], lamd[w]));
+    dpos = vadd(dpos, vsc(dp[w], lamd[w]));
+  }
+  const V3 top = vsc(mv(Jl, dori), -1.0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.dtj[i] = top[i];
+    o.dtj[3 + i] = dpos[i];
+  }
+}
+
+__global__ void __launch_bounds__(64) jacobian_kernel(JacParams P) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P.n_obs) return;
+  const int f = P.obs_feat[o];
+  const int o0 = P.obs_ptr[f];
+  const double tm = P.obs_time[o] + P.cam_dt;
+  const int s0 = bounding_start(P, tm);
+  // row slot = number of valid observations of this feature in front of this one
+  int c = 0;
+  for (int q = o0; q < o; ++q) c += bounding_start(P, P.obs_time[q] + P.cam_dt) >= 0;
+  if (o + 1 == P.obs_ptr[f + 1]) P.rows[f] = 2 * (c + (s0 >= 0 ? 1 : 0));
+  if (s0 < 0 || 2 * c + 2 > P.ld) return;
+
+  const int ld = P.ld, k = P.k;
+  double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
+  const M3 R_ItoC = ldM(P.R_ItoC);
+  const V3 p_IinC = ldV(P.p_IinC);
+  const double *K = P.K;
+  const V3 pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
+
+  Interp jac;
+  interpolate(P, s0, tm, true, true, jac);
+  M3 R_GtoI;
+  V3 p_IinG;
+  if (P.res_R) {
+    R_GtoI = ldM(P.res_R + 9 * o);
+    p_IinG = ldV(P.res_p + 3 * o);
+  } else {
+    Interp est;
+    interpolate(P, s0, tm, false, false, est);
+    R_GtoI = est.R;
+    p_IinG = est.p;
+  }
+  // ---- residual (estimate pose); CamBase::distort_d rounds through float both ways
+  V3 p_FinI = mv(R_GtoI, vsub(pf, p_IinG));
+  V3 p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
+  const double un = p_FinC[0] / p_FinC[2], vn = p_FinC[1] / p_FinC[2];
+  double r2[2];
+  {
+    const double x = (double)(float)un, y = (double)(float)vn;
+    const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
+    const double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
+    const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
+    r2[0] = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
+    r2[1] = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
+  }
+  // ---- distortion Jacobians at the estimate's normalised coordinates
+  double dzn[4], dzeta[16];
+  {
+    const double x = un, y = vn;
+    const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
+    const double x_2 = x * x, y_2 = y * y, x_y = x * y;
+    dzn[0] = K[0] * ((1 + K[4] * r_2 + K[5] * r_4) + (2 * K[4] * x_2 + 4 * K[5] * x_2 * r_2) + 2 * K[6] * y + (2 * K[7] * x + 4 * K[7] * x));
+    dzn[1] = K[0] * (2 * K[4] * x_y + 4 * K[5] * x_y * r_2 + 2 * K[6] * x + 2 * K[7] * y);
+    dzn[2] = K[1] * (2 * K[4] * x_y + 4 * K[5] * x_y * r_2 + 2 * K[6] * x + 2 * K[7] * y);
+    dzn[3] = K[1] * ((1 + K[4] * r_2 + K[5] * r_4) + (2 * K[4] * y_2 + 4 * K[5] * y_2 * r_2) + 2 * K[7] * x + (2 * K[6] * y + 4 * K[6] * y));
+    const double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
+    const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dzeta[i] = 0;
+    dzeta[0] = x1;
+    dzeta[2] = 1;
+    dzeta[4] = K[0] * x * r_2;
+    dzeta[5] = K[0] * x * r_4;
+    dzeta[6] = 2 * K[0] * x * y;
+    dzeta[7] = K[0] * (r_2 + 2 * x * x);
+    dzeta[9] = y1;
+    dzeta[11] = 1;
+    dzeta[12] = K[1] * y * r_2;
+    dzeta[13] = K[1] * y * r_4;
+    dzeta[14] = K[1] * (r_2 + 2 * y * y);
+    dzeta[15] = 2 * K[1] * x * y;
+  }
+  // ---- chain at the first estimates
+  R_GtoI = jac.R;
+  p_IinG = jac.p;
+  p_FinI = mv(R_GtoI, vsub(pf_fej, p_IinG));
+  p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
+  const double iz = 1 / p_FinC[2];
+  const double dznp[6] = {iz, 0, -p_FinC[0] / (p_FinC[2] * p_FinC[2]), 0, iz, -p_FinC[1] / (p_FinC[2] * p_FinC[2])};
+  const M3 dpC_dpG = mm(R_ItoC, R_GtoI);
+  const M3 left = mm(R_ItoC, skew3(p_FinI));
+  double dpC_dI[18];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dpC_dI[6 * i + j] = left(i, j);
+      dpC_dI[6 * i + 3 + j] = -dpC_dpG(i, j);
+    }
+  double dz_dpC[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dz_dpC[3 * i + j] = dzn[2 * i] * dznp[j] + dzn[2 * i + 1] * dznp[3 + j];
+  double HI[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) HI[6 * i + j] = dz_dpC[3 * i] * dpC_dI[j] + dz_dpC[3 * i + 1] * dpC_dI[6 + j] + dz_dpC[3 * i + 2] * dpC_dI[12 + j];
+  // ---- noise + whitening (REF :207-239 incl. the `R_llt.llt().solve(I)` form)
+  double Rn[4] = {P.sigma_pix * P.sigma_pix, 0, 0, P.sigma_pix * P.sigma_pix};
+  bool at_clone = false;
+  for (int i = 0; i < P.n_clones; ++i) at_clone = at_clone || P.clone_time[i] == tm;
+  if (!at_clone && P.use_pol_cov) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
+        Rn[2 * i + j] += s;
+      }
+  }
+  const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
+  const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
+  double Wm[4];
+#pragma unroll
+  for (int col = 0; col < 2; ++col) {
+    const double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+    const double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
+    const double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
+    Wm[col] = x0;
+    Wm[2 + col] = x1;
+  }
+  double wz[6], wzeta[16];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    wz[j] = Wm[0] * dz_dpC[j] + Wm[1] * dz_dpC[3 + j];
+    wz[3 + j] = Wm[2] * dz_dpC[j] + Wm[3] * dz_dpC[3 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    wzeta[j] = Wm[0] * dzeta[j] + Wm[1] * dzeta[8 + j];
+    wzeta[8 + j] = Wm[2] * dzeta[j] + Wm[3] * dzeta[8 + j];
+  }
+  rs[2 * c] = Wm[0] * r2[0] + Wm[1] * r2[1];
+  rs[2 * c + 1] = Wm[2] * r2[0] + Wm[3] * r2[1];
+  // ---- Hf
+  M3 G = dpC_dpG;
+  if (P.feat_rep == PLV_FEAT_GLOBAL_FULL_INVERSE_DEPTH) {  // REF: CamHelper.cpp:29-51
+    const double g_rho = 1 / vnorm(pf_fej);
+    const double g_phi = acos(g_rho * pf_fej[2]);
+    const double g_theta = atan2(pf_fej[1], pf_fej[0]);
+    const double sin_th = sin(g_theta), cos_th = cos(g_theta), sin_phi = sin(g_phi), cos_phi = cos(g_phi), rho = g_rho;
+    M3 H;
+    H(0, 0) = -(1.0 / rho) * sin_th * sin_phi;
+    H(0, 1) = (1.0 / rho) * cos_th * cos_phi;
+    H(0, 2) = -(1.0 / (rho * rho)) * cos_th * sin_phi;
+    H(1, 0) = (1.0 / rho) * cos_th * sin_phi;
+    H(1, 1) = (1.0 / rho) * sin_th * cos_phi;
+    H(1, 2) = -(1.0 / (rho * rho)) * sin_th * sin_phi;
+    H(2, 0) = 0.0;
+    H(2, 1) = -(1.0 / rho) * sin_phi;
+    H(2, 2) = -(1.0 / (rho * rho)) * cos_phi;
+    G = mm(dpC_dpG, H);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hf[(size_t)j * ld + 2 * c + i] = wz[3 * i] * G(0, j) + wz[3 * i + 1] * G(1, j) + wz[3 * i + 2] * G(2, j);
+  // ---- Hx: four interpolation poses
+  double WI[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) WI[6 * i + j] = wz[3 * i] * dpC_dI[j] + wz[3 * i + 1] * dpC_dI[6 + j] + wz[3 * i + 2] * dpC_dI[12 + j];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int col = P.clone_col[s0 + w];
+    if (col < 0) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
+        hx[(size_t)(col + j) * ld + 2 * c + i] += so;
+        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += WI[6 * i + 3 + j] * jac.lam[w];
+      }
+  }
+  if (P.col_dt >= 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
+      hx[(size_t)P.col_dt * ld + 2 * c + i] += s;
+    }
+  if (P.col_ext >= 0) {
+    const M3 sk = skew3(vsub(p_FinC, p_IinC));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        hx[(size_t)(P.col_ext + j) * ld + 2 * c + i] += wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
+        hx[(size_t)(P.col_ext + 3 + j) * ld + 2 * c + i] += wz[3 * i + j];
+      }
+  }
+  if (P.col_int >= 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hx[(size_t)(P.col_int + j) * ld + 2 * c + i] += wzeta[8 * i + j];
+}
+
+int launch_jacobians(plv_ctx *ctx, const JacParams &P) {
+  ProfScope ps(ctx->prof, "jacobian_kernel", ctx->stream);
+  hipLaunchKernelGGL(jacobian_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+}  // namespace plv

@@ -1,0 +1,30 @@
+// jacobian_kernels.hpp — device-side view of plv_state_view / plv_tracks for jacobian_kernel.
+#pragma once
+#include "plv_ctx.hpp"
+
+namespace plv {
+
+struct JacParams {
+  // state (device pointers)
+  int n_clones;
+  const double *clone_time, *clone_R, *clone_p, *clone_R_fej, *clone_p_fej;
+  const int *clone_col;  // [n_clones] first column of each clone in the stacked Jacobian, or -1
+  double R_ItoC[9], p_IinC[3], K[8];
+  double cam_dt, dt_exp, sigma_pix, intr_ori_cov, intr_pos_cov;
+  int use_pol_cov, feat_rep;
+  int col_ext, col_int, col_dt;
+  // tracks (device pointers)
+  int n_feat, n_obs;
+  const int *obs_ptr, *obs_feat;
+  const double *obs_time;
+  const float *obs_uv;
+  const double *p_FinG, *p_FinG_fej, *res_R, *res_p;
+  // outputs
+  int k, ld;
+  int *rows;
+  double *Hf, *Hx, *res;
+};
+
+int launch_jacobians(plv_ctx *ctx, const JacParams &P);
+
+}  // namespace plv

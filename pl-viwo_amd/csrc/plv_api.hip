@@ -8,6 +8,7 @@
 
 #include "plv_ctx.hpp"
 #include "update_kernels.hpp"
+#include "update_state.hpp"
 
 namespace plv {
 
@@ -68,23 +69,15 @@ using namespace plv;
     if (_rc != PLV_OK) return _rc; \
   } while (0)
 
-// extra per-ctx state that is private to this translation unit
-struct plv_ctx_update_state {
-  plv::DevBuf q95;
-  plv::DevBuf result;   // [dx: max_n doubles][flag: int + pad][accepted: bytes]
-  plv::DevBuf covck;    // covariance checkpoint
-  plv::DevBuf bHf, bHx, bres, brows, bcols, bwork;  // staged (pristine) feature batch + working copy
-  int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
-  std::vector<int> brows_host;
-};
 static std::mutex g_state_mtx;
 static std::vector<std::pair<plv_ctx *, plv_ctx_update_state *>> g_states;
-static plv_ctx_update_state *ustate(plv_ctx *ctx) {
+plv_ctx_update_state *plv_update_state(plv_ctx *ctx) {
   std::lock_guard<std::mutex> lk(g_state_mtx);
   for (auto &p : g_states)
     if (p.first == ctx) return p.second;
   return nullptr;
 }
+static plv_ctx_update_state *ustate(plv_ctx *ctx) { return plv_update_state(ctx); }
 
 extern "C" {
 
@@ -211,6 +204,8 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   if (us) {
     plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
     for (auto *b : ub) b->release();
+    us->jin.release();
+    us->h_jin.release();
     delete us;
   }
   (void)hipStreamDestroy(ctx->stream);
@@ -289,13 +284,16 @@ int plv_cov_rollback(plv_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------------ EKF update
-static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, double **dx, int **flag, unsigned char **acc) {
-  size_t bytes = (size_t)n * 8 + 16 + (size_t)F + 16;
+static size_t result_rows_off(int n, int F) { return ((size_t)n * 8 + 16 + (size_t)F + 7) & ~(size_t)7; }
+static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, double **dx, int **flag, unsigned char **acc,
+                      int **acc_rows = nullptr) {
+  size_t bytes = result_rows_off(n, F) + (size_t)F * 4 + 16;
   TRY(us->result.reserve(bytes));
   char *b = us->result.as<char>();
   *dx = (double *)b;
   *flag = (int *)(b + (size_t)n * 8);
   *acc = (unsigned char *)(b + (size_t)n * 8 + 16);
+  if (acc_rows) *acc_rows = (int *)(b + result_rows_off(n, F));
   return PLV_OK;
 }
 
@@ -495,6 +493,8 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   us->brows_host.assign(rows, rows + F);
   us->bmaxrows = 0;
   for (int f = 0; f < F; ++f) us->bmaxrows = rows[f] > us->bmaxrows ? rows[f] : us->bmaxrows;
+  us->b_on_device_rows = false;
+  us->b_single_use = false;
   return sync(ctx);
 }
 
@@ -502,19 +502,29 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
                               int *n_accepted_rows, double *dx) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
-  if (us->bF < 1 || ctx->cov_n < 1 || !dx) {
+  const int F_guard = us->bF;
+  if (F_guard < 1 || ctx->cov_n < 1 || !dx) {
     set_last_error("plv_msckf_update_resident: no staged batch / covariance");
     return PLV_E_BADARG;
   }
   const int F = us->bF, fdim = us->bfdim, k = us->bk, ld = us->bld, n = ctx->cov_n;
   size_t nHf = (size_t)F * fdim * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
-  TRY(us->bwork.reserve((nHf + nHx + nr) * 8));
   TRY(ctx->d_chi2.reserve((size_t)F * 8));
-  // working copy (the nullspace projection is in place): one D2D
-  PLV_HIP_CHECK(hipMemcpyAsync(us->bwork.p, us->bHf.p, (nHf + nHx + nr) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  double *wHf = us->bwork.as<double>(), *wHx = wHf + nHf, *wres = wHx + nHx;
+  double *wHf;
+  if (us->b_single_use) {
+    // the batch was just built on the device (plv_build_jacobians_resident): consume it in place
+    wHf = us->bHf.as<double>();
+    us->b_single_use = false;
+    us->bF = 0;
+  } else {
+    // working copy (the nullspace projection is in place): one D2D
+    TRY(us->bwork.reserve((nHf + nHx + nr) * 8));
+    PLV_HIP_CHECK(hipMemcpyAsync(us->bwork.p, us->bHf.p, (nHf + nHx + nr) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    wHf = us->bwork.as<double>();
+  }
+  double *wHx = wHf + nHf, *wres = wHx + nHx;
 
-  const int mp_max = us->bmaxrows - fdim;
+  const int mp_max = (us->b_on_device_rows ? ld : us->bmaxrows) - fdim;
   if (mp_max < 1) {
     set_last_error("plv_msckf_update: no feature has more than fdim rows");
     return PLV_E_BADARG;
@@ -528,7 +538,8 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   double *d_dx;
   int *d_flag;
   unsigned char *d_acc;
-  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc));
+  int *d_acc_rows;
+  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
 
   TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres));
   Chi2Args a{};
@@ -552,6 +563,7 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   a.q95_n = Q95_N;
   a.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
   a.accepted = d_acc;
+  a.acc_rows = d_acc_rows;
   TRY(launch_chi2(ctx, F, a, mp_max));
 
   const double *dH, *dr;
@@ -588,17 +600,18 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
     TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
   else
     TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
-  size_t rb = (size_t)n * 8 + 16 + F;
+  size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
   TRY(sync(ctx));
   const char *hb = ctx->h_pin.as<char>();
+  const int *hrows = (const int *)(hb + result_rows_off(n, F));
   int flag = *(const int *)(hb + (size_t)n * 8);
   const unsigned char *hacc = (const unsigned char *)(hb + (size_t)n * 8 + 16);
   int nrows = 0;
   for (int f = 0; f < F; ++f) {
     if (accepted) accepted[f] = hacc[f];
-    if (hacc[f]) nrows += us->brows_host[f] - fdim;
+    nrows += hrows[f];
   }
   if (n_accepted_rows) *n_accepted_rows = nrows;
   if (flag != 0) {

@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256) chi2_gate_kernel(Chi2Args a) {
       if (pass && a.res_norm_gate > 0.0) pass = sqrt(nrm2) < a.res_norm_gate;
       if (pass) pass = (mp < a.q95_n) && (chi < a.chi2_mult * a.q95[mp]);
       a.accepted[f] = pass ? 1 : 0;
+      if (a.acc_rows) a.acc_rows[f] = pass ? mp : 0;
       S[64 * 65] = pass ? 1.0 : 0.0;
     }
   }

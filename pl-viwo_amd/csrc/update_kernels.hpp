@@ -21,6 +21,7 @@ struct Chi2Args {
   int q95_n;
   int min_rows;
   unsigned char *accepted;
+  int *acc_rows;          // projected rows of each accepted feature (0 when rejected)
 };
 
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,

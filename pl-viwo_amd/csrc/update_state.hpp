@@ -1,0 +1,20 @@
+// update_state.hpp — per-ctx state of the update side shared by plv_api.hip and jacobian_api.hip.
+#pragma once
+#include <vector>
+
+#include "plv_ctx.hpp"
+
+struct plv_ctx_update_state {
+  plv::DevBuf q95;
+  plv::DevBuf result;   // [dx: max_n doubles][flag: int + pad][accepted: bytes]
+  plv::DevBuf covck;    // covariance checkpoint
+  plv::DevBuf bHf, bHx, bres, brows, bcols, bwork;  // staged feature batch ([Hf|Hx|res] in bHf) + working copy
+  int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
+  bool b_on_device_rows = false;  // rows[] produced on the device (plv_build_jacobians_resident)
+  bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy
+  std::vector<int> brows_host;
+  // jacobian inputs
+  plv::DevBuf jin;
+  plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
+};
+plv_ctx_update_state *plv_update_state(plv_ctx *ctx);

@@ -1,0 +1,84 @@
+"""GPU parity tests of K10 (per-feature Jacobians) through the C-ABI: HIP vs the CPU oracle on the
+same seeded scenes.  fp64 with different libm (sin/cos/acos/pow): relative 1e-9."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jo(pkg):
+    return oracle_lib.load_jac(pkg)
+
+
+def _cmp(rows0, a, rows1, b, tol=1e-9):
+    assert np.array_equal(rows0, rows1)
+    for x, y in zip(a, b):
+        scale = max(1.0, np.abs(x).max())
+        assert np.max(np.abs(x - y)) <= tol * scale, np.max(np.abs(x - y))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(obs_offset=0.017), dict(n_clones=20, F=150, M=20), dict(n_clones=6, F=5, M=4),
+                                dict(fej_noise=1e-3)])
+def test_build_jacobians_parity(pkg, ctx, jo, kw):
+    sc = synth.vio_scene(**kw)
+    extra = dict(use_pol_cov=1, intr_ori_cov=1e-6, intr_pos_cov=1e-6) if "obs_offset" in kw else {}
+    st, tr = synth.scene_views(pkg, sc, **extra)
+    cols0 = jo.columns(st, tr)
+    cols1 = ctx.jacobian_columns(st, tr)
+    assert np.array_equal(cols0, cols1)
+    ld = 2 * kw.get("M", 15)
+    r0, Hf0, Hx0, res0 = jo.build_jacobians(st, tr, cols0, ld)
+    r1, Hf1, Hx1, res1 = ctx.build_jacobians(st, tr, cols1, ld)
+    _cmp(r0, (Hf0, Hx0, res0), r1, (Hf1, Hx1, res1))
+
+
+def test_build_jacobians_variants(pkg, ctx, jo):
+    """inverse-depth representation, extrinsic + time-offset calibration columns, provided residual
+    poses (use_imu_res), dropped measurements."""
+    sc = synth.vio_scene(n_clones=10, F=12, M=8, obs_offset=0.011)
+    sc["obs_time"] = sc["obs_time"].copy()
+    sc["obs_time"][3] = sc["t"][0] - 5.0  # no bounding clones -> dropped
+    nobs = len(sc["obs_time"])
+    rng = np.random.default_rng(0)
+    res_R = np.array([synth._exp_so3(rng.normal(0, 1e-3, 3)) @ sc["pose_fn"](t)[0] for t in sc["obs_time"]])
+    res_p = np.array([sc["pose_fn"](t)[1] + rng.normal(0, 1e-3, 3) for t in sc["obs_time"]])
+    st = pkg.StateView(sc["t"], sc["R"], sc["p"], sc["ids"], sc["R_ItoC"], sc["p_IinC"], sc["K8"], intrinsic_state_id=15,
+                       extrinsic_state_id=sc["n_state"], dt_state_id=sc["n_state"] + 6, cam_dt=0.003, sigma_pix=1.0,
+                       use_pol_cov=1, intr_ori_cov=1e-6, intr_pos_cov=1e-6, feat_rep=1)
+    tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"], res_R=res_R, res_p=res_p)
+    cols = ctx.jacobian_columns(st, tr)
+    assert np.array_equal(cols, jo.columns(st, tr)) and len(cols) == 6 + 8 + 1 + 54  # clone 0 is never interpolated over
+    a = jo.build_jacobians(st, tr, cols, 16)
+    b = ctx.build_jacobians(st, tr, cols, 16)
+    _cmp(a[0], a[1:], b[0], b[1:])
+    # feature 0: one observation without bounding clones, and the newest one lands 3 ms (cam_dt) past the
+    # newest clone (REF: State.cpp:852-855) -> both dropped
+    assert a[0][0] == 2 * (sc["obs_ptr"][1] - 2)
+
+
+def test_update_from_tracks_end_to_end(pkg, ctx, jo, oracle):
+    """Jacobians -> nullspace -> gate -> compress -> EKF entirely on the device vs the oracle chain."""
+    # the reference gates on the norm of the WHITENED residual (< 3, UpdaterCamera.cpp:242): 27 rows of
+    # 1 px noise / sigma 1.5 already give ~3.5, so long tracks only pass with sub-pixel noise
+    sc = synth.vio_scene(noise_px=0.4)
+    st, tr = synth.scene_views(pkg, sc)
+    cols = ctx.jacobian_columns(st, tr)
+    n = sc["n_state"]
+    P = synth.spd_cov(n)
+    rows, Hf, Hx, res = jo.build_jacobians(st, tr, cols, 30)
+    rc0, P0, dx0, acc0, nr0 = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 1.0, synth.q95_table())
+    ctx.cov_upload(P)
+    ctx.build_jacobians_resident(st, tr, cols, 30)
+    rc1, dx1, acc1, nr1 = ctx.msckf_update_resident(n, 1.0)
+    assert rc0 == 0 and rc1 == 0
+    assert np.array_equal(acc0, acc1) and nr0 == nr1 and acc1.sum() > 30
+    assert np.max(np.abs(dx1 - dx0)) <= 1e-7 * np.max(np.abs(dx0))
+    P1 = ctx.cov_download(n)
+    assert np.max(np.abs(P1 - P0)) <= 1e-7 * np.max(np.abs(P0))
+    # the device-built batch is single use
+    with pytest.raises(pkg.PlvError):
+        ctx.msckf_update_resident(n, 1.0)
