@@ -211,6 +211,17 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
 int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0,
                          float *n1, long long *lk_iters);
 
+/* plv_perform_detection replaces TrackKLT::perform_detection_monocular (REF: open_vins/ov_core/src/
+ * track/TrackKLT.cpp:395-528, Grider_GRID::perform_griding Grider_GRID.h:74-180): drops tracked
+ * points that are near the border / masked / closer than min_px_dist to another one, and when
+ * fewer than num_features remain tops them up with FAST corners (per under-filled grid cell, best
+ * num_features/(grid_x*grid_y)+1 by response, cv::cornerSubPix refined) on level 0 of the chosen
+ * pyramid (PLV_PYR_LAST for the top-up on the previous image, PLV_PYR_CUR for initialisation).
+ * pts [cap][2] / ids [cap] hold n_in points on entry and *n_out on return; new points get ids
+ * ++*currid (REF: TrackBase::currid).  mask: optional host W x H u8 (255 = masked), may be NULL. */
+int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *pts, uint64_t *ids, int n_in, int cap,
+                          uint64_t *currid, int *n_out);
+
 /* ================================================================ per-feature Jacobians (K10)
  *
  * Flat views of what CamHelper::get_feature_jacobian_full (REF: PL-VIWO/src/update/cam/

@@ -103,6 +103,8 @@ def load_library():
         "plv_undistort": (C.c_int, [vp, C.c_int, fp, fp]),
         "plv_ransac_fundamental": (C.c_int, [vp, C.c_int, fp, fp, C.c_double, C.c_uint32, u8p, ip, ip]),
         "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
+        "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
+                                            C.POINTER(C.c_uint64), ip]),
         "plv_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvTracks), ip, C.c_int, ip]),
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
@@ -444,3 +446,19 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    # ---- detection
+    def perform_detection(self, which, pts, ids, currid, mask=None, cap=None):
+        """Returns (pts, ids, currid) after TrackKLT::perform_detection_monocular."""
+        n_in = len(pts)
+        cap = cap or (n_in + 4 * self.cfg.num_features + 64)
+        P = np.zeros((cap, 2), dtype=np.float32)
+        I = np.zeros(cap, dtype=np.uint64)
+        P[:n_in] = pts
+        I[:n_in] = ids
+        cid = C.c_uint64(currid)
+        n_out = C.c_int()
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        self._chk(self.lib.plv_perform_detection(self.h, which, _u8p(m), _fp(P), I.ctypes.data_as(C.POINTER(C.c_uint64)), n_in,
+                                                 cap, C.byref(cid), C.byref(n_out)))
+        return P[:n_out.value].copy(), I[:n_out.value].copy(), cid.value

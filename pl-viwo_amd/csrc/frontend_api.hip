@@ -1,6 +1,9 @@
 // frontend_api.hip — point front-end entry points of include/plviwo.h (product code, no CPU path).
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
+#include "detect_kernels.hpp"
 #include "frontend_kernels.hpp"
 
 using namespace plv;
@@ -18,6 +21,8 @@ struct FrontState {
   DevBuf hist;
   // per-call point buffers
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io;
+  DevBuf det_in, det_out, det_mask, subpix_tab;  // detection staging
+  PinBuf det_pin;
 };
 
 #define TRY(expr)                  \
@@ -118,9 +123,11 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->pts0, &s->pts1, &s->n0, &s->n1,
-                    &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io};
+                    &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->det_in, &s->det_out,
+                    &s->det_mask, &s->subpix_tab};
   for (auto *b : bufs) b->release();
   for (auto &b : s->slots) b.release();
+  s->det_pin.release();
   delete s;
   ctx->fe_state = nullptr;
 }
@@ -309,6 +316,151 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
     for (int i = 0; i < n; ++i) t += it[i];
     *lk_iters = t;
   }
+  return PLV_OK;
+}
+
+
+// plv_perform_detection replaces TrackKLT::perform_detection_monocular (REF: open_vins/ov_core/src/
+// track/TrackKLT.cpp:395-528).  The occupancy-grid bookkeeping is host logic exactly as in the
+// reference (a few hundred integer operations); the per-cell FAST + top-k (Grider_GRID.h:108-151)
+// and the sub-pixel refinement (:163-174) run on the device on level 0 of the chosen pyramid.
+int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *pts, uint64_t *ids, int n_in, int cap,
+                          uint64_t *currid, int *n_out) {
+  if (!ctx || !pts || !ids || !currid || !n_out || n_in < 0 || cap < n_in) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) {
+    set_last_error("plv_perform_detection: no %s pyramid yet", which == PLV_PYR_LAST ? "last" : "current");
+    return PLV_E_BADARG;
+  }
+  const PyrDesc &pyr = s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur];
+  const int w = s->W, h = s->H;
+  const plv_config &c = ctx->cfg;
+  const int min_px = c.min_px_dist, grid_x = c.grid_x, grid_y = c.grid_y, num_features = c.num_features;
+  if (min_px < 1 || grid_x < 1 || grid_y < 1) return PLV_E_BADARG;
+  // ---- REF :401-464: occupancy grids, drop edge / masked / too-close points, remember the painted boxes
+  const int cw = (int)((float)w / (float)min_px), ch = (int)((float)h / (float)min_px);
+  std::vector<uint8_t> close((size_t)cw * ch, 0), grid((size_t)grid_x * grid_y, 0);
+  const float size_x = (float)w / (float)grid_x, size_y = (float)h / (float)grid_y;
+  std::vector<int> boxes;
+  int n = 0;
+  for (int i = 0; i < n_in; ++i) {
+    const float fx = pts[2 * i], fy = pts[2 * i + 1];
+    const int x = (int)fx, y = (int)fy;
+    const int edge = 10;
+    if (x < edge || x >= w - edge || y < edge || y >= h - edge) continue;
+    const int xc = (int)(fx / (float)min_px), yc = (int)(fy / (float)min_px);
+    if (xc < 0 || xc >= cw || yc < 0 || yc >= ch) continue;
+    const int xg = (int)std::floor(fx / size_x), yg = (int)std::floor(fy / size_y);
+    if (xg < 0 || xg >= grid_x || yg < 0 || yg >= grid_y) continue;
+    if (close[(size_t)yc * cw + xc] > 127) continue;
+    if (mask && mask[(size_t)y * w + x] > 127) continue;
+    close[(size_t)yc * cw + xc] = 255;
+    if (grid[(size_t)yg * grid_x + xg] < 255) grid[(size_t)yg * grid_x + xg] += 1;
+    if (x - min_px >= 0 && x + min_px < w && y - min_px >= 0 && y + min_px < h) {
+      boxes.push_back(x);
+      boxes.push_back(y);
+    }
+    pts[2 * n] = fx;
+    pts[2 * n + 1] = fy;
+    ids[n] = ids[i];
+    ++n;
+  }
+  *n_out = n;
+  // ---- REF :466-471
+  const double min_feat_percent = 0.50;
+  if (num_features - n < std::min(20, (int)(min_feat_percent * num_features))) return PLV_OK;
+  // ---- REF :478-492 cells that still need features and are not fully masked
+  const int nfg_req = std::max(1, (int)(min_feat_percent * ((int)((double)num_features / (double)(grid_x * grid_y)) + 1)));
+  // REF Grider_GRID.h:88-98 grid actually used for extraction
+  int gx = grid_x, gy = grid_y;
+  if (num_features < gx * gy) {
+    double ratio = (double)gx / (double)gy;
+    gy = (int)std::ceil(std::sqrt(num_features / ratio));
+    gx = (int)std::ceil(gy * ratio);
+  }
+  const int nfg = (int)((double)num_features / (double)(gx * gy)) + 1;
+  const int sxp = w / gx, syp = h / gy;
+  std::vector<int> cells;
+  for (int x = 0; x < grid_x; ++x)
+    for (int y = 0; y < grid_y; ++y) {
+      const int sx = std::min((int)std::floor(x * (double)w / grid_x), w - 1), sy = std::min((int)std::floor(y * (double)h / grid_y), h - 1);
+      const bool masked = mask && mask[(size_t)sy * w + sx] == 255;
+      if ((int)grid[(size_t)y * grid_x + x] < nfg_req && !masked) {
+        if (x * sxp + sxp > w || y * syp + syp > h) continue;  // REF Grider_GRID.h:117-118
+        cells.push_back(x);
+        cells.push_back(y);
+      }
+    }
+  const int n_cells = (int)cells.size() / 2;
+  if (n_cells == 0 || sxp < 7 || syp < 7) return PLV_OK;
+  // ---- device: FAST per cell + sub-pixel refinement of every kept slot
+  const int n_slots = n_cells * nfg;
+  const size_t o_cells = 0, o_boxes = ((size_t)n_cells * 8 + 15) & ~(size_t)15, in_total = o_boxes + ((boxes.size() * 4 + 15) & ~(size_t)15);
+  TRY(s->det_pin.reserve(std::max(in_total, (size_t)n_slots * 13 + 64)));
+  TRY(s->det_in.reserve(in_total + 16));
+  const size_t o_xy = 0, o_resp = (size_t)n_slots * 8, o_valid = (size_t)n_slots * 12, out_total = (size_t)n_slots * 13;
+  TRY(s->det_out.reserve(out_total + 16));
+  char *hp = s->det_pin.as<char>();
+  memcpy(hp + o_cells, cells.data(), cells.size() * 4);
+  if (!boxes.empty()) memcpy(hp + o_boxes, boxes.data(), boxes.size() * 4);
+  PLV_HIP_CHECK(hipMemcpyAsync(s->det_in.p, hp, in_total, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t *d_mask = nullptr;
+  if (mask) {
+    TRY(s->det_mask.reserve((size_t)w * h));
+    PLV_HIP_CHECK(hipMemcpyAsync(s->det_mask.p, mask, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    d_mask = s->det_mask.as<uint8_t>();
+  }
+  if (!s->subpix_tab.p) {  // cv::cornerSubPix window weights exp(-(x/5)^2) exp(-(y/5)^2)
+    float tab[121];
+    for (int i = 0; i < 11; ++i) {
+      float y = (float)(i - 5) / 5;
+      float vy = std::exp(-y * y);
+      for (int j = 0; j < 11; ++j) {
+        float x = (float)(j - 5) / 5;
+        tab[i * 11 + j] = (float)(vy * std::exp(-x * x));
+      }
+    }
+    TRY(s->subpix_tab.reserve(sizeof(tab)));
+    PLV_HIP_CHECK(hipMemcpy(s->subpix_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
+  DetectParams P{};
+  P.img = pyr.base + pyr.off[0];
+  P.W = w;
+  P.H = h;
+  P.mask = d_mask;
+  P.cells = (const int *)(s->det_in.as<char>() + o_cells);
+  P.cell_w = sxp;
+  P.cell_h = syp;
+  P.threshold = c.fast_threshold;
+  P.nfg = nfg;
+  P.cand_cap = 4096;
+  P.boxes = (const int *)(s->det_in.as<char>() + o_boxes);
+  P.n_boxes = (int)boxes.size() / 2;
+  P.min_px_dist = min_px;
+  P.out_xy = (float *)(s->det_out.as<char>() + o_xy);
+  P.out_resp = (float *)(s->det_out.as<char>() + o_resp);
+  P.out_valid = (uint8_t *)(s->det_out.as<char>() + o_valid);
+  TRY(launch_fast_cells(ctx, P, n_cells));
+  TRY(launch_subpix(ctx, P.img, w, h, n_slots, P.out_valid, P.out_xy, s->subpix_tab.as<float>(), 5, 20, 0.001));
+  PLV_HIP_CHECK(hipMemcpyAsync(hp, s->det_out.p, out_total, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(sync(ctx));
+  const float *oxy = (const float *)(hp + o_xy);
+  const uint8_t *oval = (const uint8_t *)(hp + o_valid);
+  // ---- REF :497-527 reject near existing points, assign ids in extraction order
+  for (int sl = 0; sl < n_slots && n < cap; ++sl) {
+    if (!oval[sl]) continue;
+    const float px = oxy[2 * sl], py = oxy[2 * sl + 1];
+    const int xg = (int)(px / (float)min_px), yg = (int)(py / (float)min_px);
+    if (xg < 0 || xg >= cw || yg < 0 || yg >= ch) continue;
+    if (close[(size_t)yg * cw + xg] > 127) continue;
+    close[(size_t)yg * cw + xg] = 255;
+    pts[2 * n] = px;
+    pts[2 * n + 1] = py;
+    ids[n] = ++*currid;
+    ++n;
+  }
+  *n_out = n;
   return PLV_OK;
 }
 

@@ -222,6 +222,59 @@ class OraclePyramid:
             pass
 
 
+class DetectOracle:
+    def __init__(self, lib):
+        self.lib = L = lib
+        L.orc_fast_roi.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
+        L.orc_fast_roi.restype = C.c_int
+        L.orc_corner_subpix.argtypes = [u8, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double]
+        L.orc_perform_detection.argtypes = [u8, u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
+                                            C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_perform_detection.restype = C.c_int
+
+    def fast_roi(self, img, x0, y0, w, h, thr, cap=20000):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        xy = np.zeros((cap, 2), dtype=np.float32)
+        r = np.zeros(cap, dtype=np.float32)
+        n = self.lib.orc_fast_roi(img.ctypes.data_as(u8), img.shape[1], x0, y0, w, h, thr, cap, xy.ctypes.data_as(fp),
+                                  r.ctypes.data_as(fp))
+        return xy[:n].copy(), r[:n].copy()
+
+    def corner_subpix(self, img, xy, win=5, max_iters=20, eps=0.001):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        xy = np.ascontiguousarray(xy, dtype=np.float32).copy()
+        self.lib.orc_corner_subpix(img.ctypes.data_as(u8), img.shape[1], img.shape[0], len(xy), xy.ctypes.data_as(fp), win,
+                                   max_iters, eps)
+        return xy
+
+    def perform_detection(self, img, mask, pts, ids, currid, num_features, grid_x, grid_y, min_px_dist, threshold, cap=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        mask = np.zeros((h, w), np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        n_in = len(pts)
+        cap = cap or (n_in + 4 * num_features + 64)
+        P = np.zeros((cap, 2), dtype=np.float32)
+        I = np.zeros(cap, dtype=np.uint64)
+        P[:n_in] = pts
+        I[:n_in] = ids
+        cid = C.c_uint64(currid)
+        n = self.lib.orc_perform_detection(img.ctypes.data_as(u8), mask.ctypes.data_as(u8), w, h, num_features, grid_x, grid_y,
+                                           min_px_dist, threshold, P.ctypes.data_as(fp),
+                                           I.ctypes.data_as(C.POINTER(C.c_uint64)), n_in, cap, C.byref(cid))
+        return P[:n].copy(), I[:n].copy(), cid.value
+
+
+_det = None
+
+
+def load_detect():
+    global _det
+    if _det is None:
+        load()
+        _det = DetectOracle(_inst.lib)
+    return _det
+
+
 _front = None
 
 
