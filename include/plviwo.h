@@ -222,6 +222,26 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
 int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *pts, uint64_t *ids, int n_in, int cap,
                           uint64_t *currid, int *n_out);
 
+/* ================================================================ tracker frame logic + feature database
+ *
+ * Host mirror of ov_core::TrackKLT (monocular) and ov_core::FeatureDatabase for callers that do
+ * not bring the reference's own classes (INTEGRATION.md §2 shows the adapter that keeps them).
+ * plv_tracker_feed = TrackKLT::feed_new_camera (REF: open_vins/ov_core/src/track/TrackKLT.cpp:34-200):
+ * equalize + pyramid, first-frame detection or top-up on the last image, temporal KLT + RANSAC,
+ * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
+int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
+/* TrackBase::get_last_obs / get_last_ids (REF: TrackBase.h:121-131) */
+int plv_tracker_last(plv_ctx *ctx, float *pts, uint64_t *ids, int cap, int *n);
+int plv_db_size(plv_ctx *ctx);
+/* mode 0 = FeatureDatabase::features_not_containing_newer(t), 1 = features_containing_older(t)
+ * (REF: FeatureDatabase.cpp:147-232); ids ascending. */
+int plv_db_select(plv_ctx *ctx, int mode, double t, uint64_t *ids, int cap, int *n);
+/* CSR export of tracks in plv_tracks layout: obs_ptr [n+1], obs_time / obs_uv / obs_uvn [cap_obs] */
+int plv_db_export_tracks(plv_ctx *ctx, const uint64_t *ids, int n, int *obs_ptr, double *obs_time, float *obs_uv,
+                         float *obs_uvn, int cap_obs);
+int plv_db_cleanup_measurements(plv_ctx *ctx, double t); /* REF: FeatureDatabase.cpp:286-323 */
+int plv_db_remove(plv_ctx *ctx, const uint64_t *ids, int n);
+
 /* ================================================================ per-feature Jacobians (K10)
  *
  * Flat views of what CamHelper::get_feature_jacobian_full (REF: PL-VIWO/src/update/cam/

@@ -105,6 +105,13 @@ def load_library():
         "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
         "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
                                             C.POINTER(C.c_uint64), ip]),
+        "plv_tracker_feed": (C.c_int, [vp, C.c_double, u8p, C.c_int, u8p]),
+        "plv_tracker_last": (C.c_int, [vp, fp, C.POINTER(C.c_uint64), C.c_int, ip]),
+        "plv_db_size": (C.c_int, [vp]),
+        "plv_db_select": (C.c_int, [vp, C.c_int, C.c_double, C.POINTER(C.c_uint64), C.c_int, ip]),
+        "plv_db_export_tracks": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int, ip, dp, fp, fp, C.c_int]),
+        "plv_db_cleanup_measurements": (C.c_int, [vp, C.c_double]),
+        "plv_db_remove": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "plv_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvTracks), ip, C.c_int, ip]),
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
@@ -462,3 +469,43 @@ class Context:
         self._chk(self.lib.plv_perform_detection(self.h, which, _u8p(m), _fp(P), I.ctypes.data_as(C.POINTER(C.c_uint64)), n_in,
                                                  cap, C.byref(cid), C.byref(n_out)))
         return P[:n_out.value].copy(), I[:n_out.value].copy(), cid.value
+
+    # ---- tracker frame logic + feature database
+    def tracker_feed(self, timestamp, img, mask=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        self._chk(self.lib.plv_tracker_feed(self.h, float(timestamp), _u8p(img), img.shape[1], _u8p(m)))
+
+    def tracker_last(self, cap=8192):
+        pts = np.zeros((cap, 2), dtype=np.float32)
+        ids = np.zeros(cap, dtype=np.uint64)
+        n = C.c_int()
+        self._chk(self.lib.plv_tracker_last(self.h, _fp(pts), ids.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
+        return pts[:n.value].copy(), ids[:n.value].copy()
+
+    def db_size(self):
+        return self.lib.plv_db_size(self.h)
+
+    def db_select(self, mode, t, cap=65536):
+        ids = np.zeros(cap, dtype=np.uint64)
+        n = C.c_int()
+        self._chk(self.lib.plv_db_select(self.h, mode, float(t), ids.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
+        return ids[:n.value].copy()
+
+    def db_export(self, ids, cap_obs=1 << 20):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        ptr = np.zeros(len(ids) + 1, dtype=np.int32)
+        t = np.zeros(cap_obs)
+        uv = np.zeros((cap_obs, 2), dtype=np.float32)
+        uvn = np.zeros((cap_obs, 2), dtype=np.float32)
+        self._chk(self.lib.plv_db_export_tracks(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids), _ip(ptr), _dp(t),
+                                                _fp(uv), _fp(uvn), cap_obs))
+        n = ptr[-1]
+        return ptr, t[:n].copy(), uv[:n].copy(), uvn[:n].copy()
+
+    def db_cleanup_measurements(self, t):
+        self._chk(self.lib.plv_db_cleanup_measurements(self.h, float(t)))
+
+    def db_remove(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        self._chk(self.lib.plv_db_remove(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids)))

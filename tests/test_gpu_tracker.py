@@ -1,0 +1,100 @@
+"""GPU test of the tracker frame logic (TrackKLT::feed_monocular mirror) + feature database over a
+synthetic 752x480 stream, against the same frame logic composed from the CPU oracle pieces."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleTracker:
+    """TrackKLT::feed_monocular restated on top of the oracle (REF: TrackKLT.cpp:96-200)."""
+
+    def __init__(self, cfg, K8):
+        self.cfg, self.K8 = cfg, K8
+        self.fo, self.do = oracle_lib.load_front(), oracle_lib.load_detect()
+        self.pts = np.zeros((0, 2), np.float32)
+        self.ids = np.zeros(0, np.uint64)
+        self.currid = 0
+        self.prev = None
+        self.db = {}
+
+    def _detect(self, eq, pts, ids):
+        c = self.cfg
+        p, i, self.currid = self.do.perform_detection(eq, None, pts, ids, self.currid, c.num_features, c.grid_x, c.grid_y,
+                                                      c.min_px_dist, c.fast_threshold)
+        return p, i
+
+    def feed(self, t, img):
+        eq = self.fo.equalize_hist(img)
+        pyr = self.fo.pyramid(eq)
+        if len(self.ids) == 0:
+            self.pts, self.ids = self._detect(eq, self.pts, self.ids)
+            self.prev = (eq, pyr)
+            return
+        pts_old, ids_old = self._detect(self.prev[0], self.pts, self.ids)
+        rc, pts_new, mask, n0, n1 = self.fo.perform_matching(self.prev[1], pyr, pts_old, pts_old, self.K8)
+        h, w = img.shape
+        good, gid = [], []
+        for i in range(len(pts_old)):
+            x, y = pts_new[i]
+            if x < 0 or y < 0 or int(x) >= w or int(y) >= h or not mask[i]:
+                continue
+            good.append(pts_new[i])
+            gid.append(ids_old[i])
+            self.db.setdefault(int(ids_old[i]), []).append((t, x, y, n1[i, 0], n1[i, 1]))
+        self.pts = np.array(good, np.float32).reshape(-1, 2)
+        self.ids = np.array(gid, np.uint64)
+        self.prev = (eq, pyr)
+
+
+def test_tracker_stream_matches_oracle(pkg):
+    w, h = 752, 480
+    canvas = synth.texture_canvas(w, h, seed=42)
+    rng = np.random.default_rng(5)
+    cfg = pkg.default_config(w, h)
+    ctx = pkg.Context(cfg)
+    ot = OracleTracker(cfg, np.array(list(cfg.intrinsics)))
+    tx = ty = rot = 0.0
+    for f in range(7):
+        img = synth.render_frame(canvas, w, h, tx=tx, ty=ty, rot_deg=rot, scale=1.0 + 0.002 * f)
+        t = 10.0 + 0.05 * f
+        ctx.tracker_feed(t, img)
+        ot.feed(t, img)
+        pts, ids = ctx.tracker_last()
+        common = np.intersect1d(ids, ot.ids)
+        assert len(common) >= 0.98 * max(len(ids), len(ot.ids)), (f, len(ids), len(ot.ids), len(common))
+        a = {int(i): p for i, p in zip(ids, pts)}
+        b = {int(i): p for i, p in zip(ot.ids, ot.pts)}
+        d = max(np.abs(a[int(i)] - b[int(i)]).max() for i in common)
+        assert d <= 2e-3, (f, d)
+        assert len(ids) >= 150
+        tx += rng.uniform(-6, 6)
+        ty += rng.uniform(-6, 6)
+        rot += rng.uniform(-0.5, 0.5)
+    # database: same track lengths for the common ids, same observations
+    assert ctx.db_size() >= 200
+    some = np.array(sorted(ot.db))[:50].astype(np.uint64)
+    ptr, tt, uv, uvn = ctx.db_export(some)
+    agree = 0
+    for k, fid in enumerate(some):
+        mine = list(zip(tt[ptr[k]:ptr[k + 1]], uv[ptr[k]:ptr[k + 1], 0]))
+        ref = [(o[0], o[1]) for o in ot.db[int(fid)]]
+        if len(mine) == len(ref) and all(abs(m[0] - r[0]) < 1e-12 and abs(m[1] - r[1]) <= 2e-3 for m, r in zip(mine, ref)):
+            agree += 1
+    assert agree >= 48
+    # selection helpers
+    newest = 10.0 + 0.05 * 6
+    lost = ctx.db_select(0, newest)  # not seen in the newest frame
+    assert all(int(i) not in {int(j) for j in ids} for i in lost)
+    old = ctx.db_select(1, 10.0 + 0.05 * 2)
+    assert len(old) > 0
+    ctx.db_cleanup_measurements(10.0 + 0.05 * 3)
+    ptr2, tt2, _, _ = ctx.db_export(old[:10])
+    assert (tt2 >= 10.0 + 0.05 * 3 - 1e-12).all()
+    n0 = ctx.db_size()
+    ctx.db_remove(old[:5])
+    assert ctx.db_size() <= n0
+    ctx.close()
