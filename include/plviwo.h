@@ -283,7 +283,25 @@ typedef struct plv_tracks {
   const double *res_R;     /* optional [n_obs][9]: IMU pose for the RESIDUAL at each obs, e.g. the CPI
                               pose when use_imu_res (State.cpp:1138-1155); NULL -> estimate polynomial */
   const double *res_p;     /* optional [n_obs][3] */
+  const float *obs_uvn;    /* [n_obs][2] normalised coordinates (Feature::uvs_norm); only plv_triangulate reads it */
 } plv_tracks;
+
+/* FeatureInitializerOptions (REF: open_vins/ov_core/src/feat/FeatureInitializerOptions.h:36-69;
+ * KAIST overrides PL-VIWO/config/kaist/kaist_C/config_camera.yaml:32-35) */
+typedef struct plv_tri_options {
+  double min_dist, max_dist, max_cond_number, max_baseline;
+  int refine_features; /* single_gaussnewton after the linear solve (default true) */
+} plv_tri_options;
+
+/* plv_triangulate replaces, for all features at once, CamHelper::get_imu_poses / get_cam_poses /
+ * feature_triangulation / the reprojection part of moving_consistency (REF: PL-VIWO/src/update/cam/
+ * CamHelper.cpp:327-483) and FeatureInitializer::single_triangulation + single_gaussnewton (REF:
+ * open_vins/ov_core/src/feat/FeatureInitializer.cpp:30-112,197-375).  Camera poses come from the
+ * residual poses of `tr` when given (use_imu_res) or from the estimate polynomial.  ok[f] = 1 when
+ * feature f passed every check of the reference; reproj_err[f] (nullable) = mean pixel
+ * reprojection error (moving_consistency compares it with 3 px). */
+int plv_triangulate(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, const plv_tri_options *opt,
+                    double *p_FinG, uint8_t *ok, double *reproj_err);
 
 /* Column order of the stacked Jacobians: [extrinsics 6][intrinsics 8][dt 1] when calibrated, then
  * every clone (6 columns) an observation interpolates over, in first-seen order.  Returns k and

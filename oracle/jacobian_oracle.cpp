@@ -664,4 +664,58 @@ int orc_triangulate(int M, const double *Rc, const double *pc, const float *uvn,
   return 1;
 }
 
+
+// CamHelper::get_imu_poses / get_cam_poses / feature_triangulation + the mean reprojection error of
+// moving_consistency (REF: PL-VIWO/src/update/cam/CamHelper.cpp:327-483), all features.
+int orc_triangulate_batch(const plv_state_view *st, const plv_tracks *trk, const plv_tri_options *opt, double *p_FinG,
+                          uint8_t *ok, double *reproj_err) {
+  const M3 R_ItoC = getM(st->R_ItoC);
+  const V3 p_IinC = getV(st->p_IinC);
+  for (int f = 0; f < trk->n_feat; ++f) {
+    std::vector<double> Rc, pc;
+    std::vector<float> uvn, uv;
+    for (int o = trk->obs_ptr[f]; o < trk->obs_ptr[f + 1]; ++o) {
+      M3 R_GtoI;
+      V3 p_IinG;
+      if (trk->res_R) {
+        const double tq = trk->obs_time[o] + st->cam_dt;
+        if (bounding_start(*st, tq) < 0 || tq > st->clone_time[st->n_clones - 1]) continue;
+        R_GtoI = getM(trk->res_R + 9 * o);
+        p_IinG = getV(trk->res_p + 3 * o);
+      } else {
+        Interp est;
+        if (!interpolate(*st, trk->obs_time[o] + st->cam_dt, false, false, est)) continue;
+        R_GtoI = est.R;
+        p_IinG = est.p;
+      }
+      const M3 R_GtoC = mul(R_ItoC, R_GtoI);                      // CamHelper.cpp:388
+      const V3 p_CinG = sub(p_IinG, mul(tr(R_GtoC), p_IinC));    // :389
+      for (int i = 0; i < 9; ++i) Rc.push_back(R_GtoC.m[i]);
+      for (int i = 0; i < 3; ++i) pc.push_back(p_CinG[i]);
+      uvn.push_back(trk->obs_uvn[2 * o]);
+      uvn.push_back(trk->obs_uvn[2 * o + 1]);
+      uv.push_back(trk->obs_uv[2 * o]);
+      uv.push_back(trk->obs_uv[2 * o + 1]);
+    }
+    const int M = (int)uvn.size() / 2;
+    double *pf = p_FinG + 3 * f;
+    pf[0] = pf[1] = pf[2] = 0;
+    ok[f] = (uint8_t)orc_triangulate(M, Rc.data(), pc.data(), uvn.data(), opt->min_dist, opt->max_dist, opt->max_cond_number,
+                                     opt->max_baseline, opt->refine_features, pf);
+    double e = 0;
+    if (ok[f]) {
+      for (int m = 0; m < M; ++m) {
+        const V3 pC = mul(getM(&Rc[9 * m]), sub(getV(pf), getV(&pc[3 * m])));
+        double un[2] = {pC[0] / pC[2], pC[1] / pC[2]}, ud[2];
+        distort_d(st->intrinsics, un, ud);
+        const double r0 = (double)uv[2 * m] - ud[0], r1 = (double)uv[2 * m + 1] - ud[1];
+        e += std::sqrt(r0 * r0 + r1 * r1);
+      }
+      e /= M;
+    }
+    if (reproj_err) reproj_err[f] = e;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -112,6 +112,7 @@ def load_library():
         "plv_db_export_tracks": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int, ip, dp, fp, fp, C.c_int]),
         "plv_db_cleanup_measurements": (C.c_int, [vp, C.c_double]),
         "plv_db_remove": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+        "plv_triangulate": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.POINTER(PlvTriOptions), dp, u8p, dp]),
         "plv_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvTracks), ip, C.c_int, ip]),
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
@@ -171,7 +172,13 @@ class PlvTracks(C.Structure):
         ("obs_ptr", C.POINTER(C.c_int)), ("obs_time", C.POINTER(C.c_double)), ("obs_uv", C.POINTER(C.c_float)),
         ("p_FinG", C.POINTER(C.c_double)), ("p_FinG_fej", C.POINTER(C.c_double)),
         ("res_R", C.POINTER(C.c_double)), ("res_p", C.POINTER(C.c_double)),
+        ("obs_uvn", C.POINTER(C.c_float)),
     ]
+
+
+class PlvTriOptions(C.Structure):
+    _fields_ = [("min_dist", C.c_double), ("max_dist", C.c_double), ("max_cond_number", C.c_double),
+                ("max_baseline", C.c_double), ("refine_features", C.c_int)]
 
 
 class StateView:
@@ -201,7 +208,7 @@ class StateView:
 class Tracks:
     """Owns the numpy arrays behind a plv_tracks (CSR observation lists)."""
 
-    def __init__(self, obs_ptr, obs_time, obs_uv, p_FinG, p_FinG_fej=None, res_R=None, res_p=None):
+    def __init__(self, obs_ptr, obs_time, obs_uv, p_FinG, p_FinG_fej=None, res_R=None, res_p=None, obs_uvn=None):
         self.ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
         self.t = np.ascontiguousarray(obs_time, dtype=np.float64)
         self.uv = np.ascontiguousarray(obs_uv, dtype=np.float32).reshape(-1, 2)
@@ -213,6 +220,8 @@ class Tracks:
         v.n_feat = len(self.ptr) - 1
         v.obs_ptr, v.obs_time, v.obs_uv = _ip(self.ptr), _dp(self.t), _fp(self.uv)
         v.p_FinG, v.p_FinG_fej, v.res_R, v.res_p = _dp(self.pf), _dp(self.pff), _dp(self.rR), _dp(self.rp)
+        self.uvn = np.ascontiguousarray(obs_uvn, dtype=np.float32).reshape(-1, 2) if obs_uvn is not None else None
+        v.obs_uvn = _fp(self.uvn)
         self.c = v
 
 
@@ -509,3 +518,12 @@ class Context:
     def db_remove(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         self._chk(self.lib.plv_db_remove(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids)))
+
+    def triangulate(self, st, tr, min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True):
+        opt = PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
+        F = tr.c.n_feat
+        p = np.zeros((F, 3))
+        ok = np.zeros(F, dtype=np.uint8)
+        err = np.zeros(F)
+        self._chk(self.lib.plv_triangulate(self.h, C.byref(st.c), C.byref(tr.c), C.byref(opt), _dp(p), _u8p(ok), _dp(err)))
+        return p, ok, err

@@ -229,4 +229,38 @@ int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks
   return PLV_OK;
 }
 
+
+int plv_triangulate(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, const plv_tri_options *opt, double *p_FinG,
+                    uint8_t *ok, double *reproj_err) {
+  if (!ctx || !opt || !p_FinG || !ok) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  // p_FinG of the view is an OUTPUT here: allow it to be missing by pointing the checks at the output
+  plv_tracks t2 = *tr;
+  if (!t2.p_FinG) t2.p_FinG = p_FinG;
+  if (!t2.p_FinG_fej) t2.p_FinG_fej = t2.p_FinG;
+  TRY(check_views(st, &t2));
+  if (!tr->obs_uvn) {
+    set_last_error("plv_triangulate: plv_tracks.obs_uvn is required");
+    return PLV_E_BADARG;
+  }
+  const int F = tr->n_feat, nobs = tr->obs_ptr[F];
+  int dummy_cols[1] = {-1};
+  JacParams P{};
+  TRY(stage_inputs(ctx, us, st, &t2, 0, dummy_cols, 2, P));
+  const size_t o_pose = 0, o_valid = (size_t)nobs * 96, o_uvn = (o_valid + nobs + 15) & ~(size_t)15, o_p = o_uvn + (size_t)nobs * 8,
+               o_err = o_p + (size_t)F * 24, o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
+  TRY(us->tri.reserve(total));
+  char *d = us->tri.as<char>();
+  PLV_HIP_CHECK(hipMemcpyAsync(d + o_uvn, tr->obs_uvn, (size_t)nobs * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(launch_triangulate(ctx, P, (double *)(d + o_pose), (unsigned char *)(d + o_valid), (const float *)(d + o_uvn), *opt,
+                         (double *)(d + o_p), (unsigned char *)(d + o_ok), (double *)(d + o_err)));
+  PLV_HIP_CHECK(hipMemcpyAsync(p_FinG, d + o_p, (size_t)F * 24, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(ok, d + o_ok, (size_t)F, hipMemcpyDeviceToHost, ctx->stream));
+  if (reproj_err) PLV_HIP_CHECK(hipMemcpyAsync(reproj_err, d + o_err, (size_t)F * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
 }  // extern "C"

@@ -437,6 +437,279 @@ __global__ void __launch_bounds__(64) jacobian_kernel(JacParams P) {
       for (int j = 0; j < 8; ++j) hx[(size_t)(P.col_int + j) * ld + 2 * c + i] += wzeta[8 * i + j];
 }
 
+// ------------------------------------------------------------------------------------------
+// a18/a19: camera pose of every observation (thread per observation), then linear triangulation +
+// Levenberg-Marquardt refinement + reprojection error (thread per feature).
+//   CamHelper::get_imu_poses / get_cam_poses          REF: PL/update/cam/CamHelper.cpp:327-395
+//   FeatureInitializer::single_triangulation          REF: OV/feat/FeatureInitializer.cpp:30-112
+//   FeatureInitializer::single_gaussnewton            REF: OV/feat/FeatureInitializer.cpp:197-375
+//   CamHelper::moving_consistency (mean reprojection) REF: PL/update/cam/CamHelper.cpp:426-483
+__global__ void __launch_bounds__(64) campose_kernel(JacParams P, double *__restrict__ poses /*[n_obs][12]*/,
+                                                     unsigned char *__restrict__ valid) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P.n_obs) return;
+  const double tm = P.obs_time[o] + P.cam_dt;
+  const int s0 = bounding_start(P, tm);
+  valid[o] = s0 >= 0;
+  if (s0 < 0) return;
+  M3 R_GtoI;
+  V3 p_IinG;
+  if (P.res_R) {
+    R_GtoI = ldM(P.res_R + 9 * o);
+    p_IinG = ldV(P.res_p + 3 * o);
+  } else {
+    Interp est;
+    interpolate(P, s0, tm, false, false, est);
+    R_GtoI = est.R;
+    p_IinG = est.p;
+  }
+  const M3 R_GtoC = mm(ldM(P.R_ItoC), R_GtoI);
+  const V3 p_CinG = vsub(p_IinG, mv(tp(R_GtoC), ldV(P.p_IinC)));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) poses[12 * o + i] = R_GtoC.m[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) poses[12 * o + 9 + i] = p_CinG[i];
+}
+
+__device__ bool solve3(const M3 &A, const V3 &b, V3 &x) {
+  double a[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[i][j] = A(i, j);
+    a[i][3] = b[i];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (r > c && fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    double pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = piv == 0 ? a[0][j] : (piv == 1 ? a[1][j] : a[2][j]);
+    if (pv[c] == 0) return false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (r == piv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[r][j] = a[c][j];
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[c][j] = pv[j];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (r > c) {
+        const double f = a[r][c] / a[c][c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j >= c) a[r][j] -= f * a[c][j];
+      }
+  }
+  x[2] = a[2][3] / a[2][2];
+  x[1] = (a[1][3] - a[1][2] * x[2]) / a[1][1];
+  x[0] = (a[0][3] - a[0][1] * x[1] - a[0][2] * x[2]) / a[0][0];
+  return true;
+}
+__device__ void sym_eig3(const M3 &A, double ev[3]) {
+  const double PI = 3.14159265358979323846;
+  const double p1 = A(0, 1) * A(0, 1) + A(0, 2) * A(0, 2) + A(1, 2) * A(1, 2);
+  const double q = (A(0, 0) + A(1, 1) + A(2, 2)) / 3;
+  const double p2 = (A(0, 0) - q) * (A(0, 0) - q) + (A(1, 1) - q) * (A(1, 1) - q) + (A(2, 2) - q) * (A(2, 2) - q) + 2 * p1;
+  const double p = sqrt(p2 / 6);
+  if (p == 0) {
+    ev[0] = ev[1] = ev[2] = q;
+    return;
+  }
+  const M3 B = ms(ma(A, ms(eye3(), -q)), 1 / p);
+  const double detB = B(0, 0) * (B(1, 1) * B(2, 2) - B(1, 2) * B(2, 1)) - B(0, 1) * (B(1, 0) * B(2, 2) - B(1, 2) * B(2, 0)) +
+                      B(0, 2) * (B(1, 0) * B(2, 1) - B(1, 1) * B(2, 0));
+  const double r = detB / 2;
+  const double phi = r <= -1 ? PI / 3 : (r >= 1 ? 0 : acos(r) / 3);
+  ev[0] = q + 2 * p * cos(phi);
+  ev[2] = q + 2 * p * cos(phi + (2 * PI / 3));
+  ev[1] = 3 * q - ev[0] - ev[2];
+}
+
+struct TriCtx {
+  const double *poses;
+  const unsigned char *valid;
+  const float *uvn;
+  int o0, o1;
+  M3 R_GtoA;
+  V3 p_AinG;
+};
+__device__ double tri_error(const TriCtx &c, double alpha, double beta, double rho) {
+  double err = 0;
+  for (int o = c.o0; o < c.o1; ++o) {
+    if (!c.valid[o]) continue;
+    const M3 R_AtoCi = mm(ldM(c.poses + 12 * o), tp(c.R_GtoA));
+    const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(c.poses + 12 * o + 9), c.p_AinG));
+    const V3 p_AinCi = vsc(mv(R_AtoCi, p_CiinA), -1.0);
+    const double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
+    const double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
+    const double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
+    const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+    const float r0 = c.uvn[2 * o] - z0, r1 = c.uvn[2 * o + 1] - z1;
+    const float nrm = sqrtf(r0 * r0 + r1 * r1);
+    err += (double)nrm * (double)nrm;
+  }
+  return err;
+}
+
+__global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const double *__restrict__ poses,
+                                                         const unsigned char *__restrict__ valid, const float *__restrict__ uvn,
+                                                         plv_tri_options opt, double *__restrict__ p_out,
+                                                         unsigned char *__restrict__ ok_out, double *__restrict__ err_out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= P.n_feat) return;
+  TriCtx c;
+  c.poses = poses;
+  c.valid = valid;
+  c.uvn = uvn;
+  c.o0 = P.obs_ptr[f];
+  c.o1 = P.obs_ptr[f + 1];
+  int M = 0, last = -1;
+  for (int o = c.o0; o < c.o1; ++o)
+    if (valid[o]) {
+      ++M;
+      last = o;
+    }
+  p_out[3 * f] = p_out[3 * f + 1] = p_out[3 * f + 2] = 0;
+  ok_out[f] = 0;
+  if (err_out) err_out[f] = 0;
+  if (M < 2) return;
+  c.R_GtoA = ldM(poses + 12 * last);  // anchor = newest observation (FeatureInitializer.cpp:44-45)
+  c.p_AinG = ldV(poses + 12 * last + 9);
+  M3 A{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  V3 b{{0, 0, 0}};
+  for (int o = c.o0; o < c.o1; ++o) {
+    if (!valid[o]) continue;
+    const M3 R_AtoCi = mm(ldM(poses + 12 * o), tp(c.R_GtoA));
+    const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
+    V3 bi = mv(tp(R_AtoCi), V3{{(double)uvn[2 * o], (double)uvn[2 * o + 1], 1.0}});
+    bi = vsc(bi, 1.0 / vnorm(bi));
+    const M3 Bp = skew3(bi);
+    const M3 Ai = mm(tp(Bp), Bp);
+    A = ma(A, Ai);
+    b = vadd(b, mv(Ai, p_CiinA));
+  }
+  V3 pf;
+  if (!solve3(A, b, pf)) return;
+  double ev[3];
+  sym_eig3(A, ev);
+  const double condA = ev[0] / ev[2];
+  if (fabs(condA) > opt.max_cond_number || pf[2] < opt.min_dist || pf[2] > opt.max_dist || isnan(vnorm(pf))) return;
+  if (opt.refine_features) {
+    double rho = 1 / pf[2], alpha = pf[0] / pf[2], beta = pf[1] / pf[2];
+    double lam = 1e-3, eps = 10000;
+    int runs = 0;
+    bool recompute = true;
+    M3 Hess{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    V3 grad{{0, 0, 0}};
+    double cost_old = tri_error(c, alpha, beta, rho);
+    while (runs < 5 && lam < 1e10 && eps > 1e-6) {
+      if (recompute) {
+        Hess = M3{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+        grad = V3{{0, 0, 0}};
+        for (int o = c.o0; o < c.o1; ++o) {
+          if (!valid[o]) continue;
+          const M3 R_AtoCi = mm(ldM(poses + 12 * o), tp(c.R_GtoA));
+          const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
+          const V3 p_AinCi = vsc(mv(R_AtoCi, p_CiinA), -1.0);
+          const double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
+          const double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
+          const double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
+          const double h3s = pow(hi3, 2.0);
+          const double Hj[6] = {(R_AtoCi(0, 0) * hi3 - hi1 * R_AtoCi(2, 0)) / h3s, (R_AtoCi(0, 1) * hi3 - hi1 * R_AtoCi(2, 1)) / h3s,
+                                (p_AinCi[0] * hi3 - hi1 * p_AinCi[2]) / h3s,        (R_AtoCi(1, 0) * hi3 - hi2 * R_AtoCi(2, 0)) / h3s,
+                                (R_AtoCi(1, 1) * hi3 - hi2 * R_AtoCi(2, 1)) / h3s, (p_AinCi[1] * hi3 - hi2 * p_AinCi[2]) / h3s};
+          const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+          const double r0 = (double)(uvn[2 * o] - z0), r1 = (double)(uvn[2 * o + 1] - z1);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            grad[i] += Hj[i] * r0 + Hj[3 + i] * r1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Hess(i, j) += Hj[i] * Hj[j] + Hj[3 + i] * Hj[3 + j];
+          }
+        }
+      }
+      M3 Hl = Hess;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Hl(r, r) *= (1.0 + lam);
+      V3 dx;
+      if (!solve3(Hl, grad, dx)) break;
+      const double cost = tri_error(c, alpha + dx[0], beta + dx[1], rho + dx[2]);
+      if (cost <= cost_old && (cost_old - cost) / cost_old < 1e-6) {
+        alpha += dx[0];
+        beta += dx[1];
+        rho += dx[2];
+        eps = 0;
+        break;
+      }
+      if (cost <= cost_old) {
+        recompute = true;
+        cost_old = cost;
+        alpha += dx[0];
+        beta += dx[1];
+        rho += dx[2];
+        runs++;
+        lam = lam / 10;
+        eps = vnorm(dx);
+      } else {
+        recompute = false;
+        lam = lam * 10;
+      }
+    }
+    pf = V3{{alpha / rho, beta / rho, 1 / rho}};
+    const V3 dir = vsc(pf, 1.0 / vnorm(pf));
+    double base_max = 0;
+    for (int o = c.o0; o < c.o1; ++o) {
+      if (!valid[o]) continue;
+      const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
+      const double along = p_CiinA[0] * dir[0] + p_CiinA[1] * dir[1] + p_CiinA[2] * dir[2];
+      base_max = fmax(base_max, vnorm(vsub(p_CiinA, vsc(dir, along))));
+    }
+    if (pf[2] < opt.min_dist || pf[2] > opt.max_dist || (vnorm(pf) / base_max) > opt.max_baseline || isnan(vnorm(pf))) return;
+  }
+  const V3 pg = vadd(mv(tp(c.R_GtoA), pf), c.p_AinG);
+  p_out[3 * f] = pg[0];
+  p_out[3 * f + 1] = pg[1];
+  p_out[3 * f + 2] = pg[2];
+  ok_out[f] = 1;
+  if (err_out) {  // mean pixel reprojection error (CamHelper.cpp:441-470), float round trip of distort_d included
+    double e = 0;
+    const double *K = P.K;
+    for (int o = c.o0; o < c.o1; ++o) {
+      if (!valid[o]) continue;
+      const V3 pC = mv(ldM(poses + 12 * o), vsub(pg, ldV(poses + 12 * o + 9)));
+      const double x = (double)(float)(pC[0] / pC[2]), y = (double)(float)(pC[1] / pC[2]);
+      const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
+      const double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
+      const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
+      const double r0 = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
+      const double r1 = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
+      e += sqrt(r0 * r0 + r1 * r1);
+    }
+    err_out[f] = e / M;
+  }
+}
+
+int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
+                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err) {
+  {
+    ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
+    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid);
+  }
+  {
+    ProfScope ps(ctx->prof, "triangulate_kernel", ctx->stream);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((P.n_feat + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, d_uvn, opt,
+                       d_p, d_ok, d_err);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 int launch_jacobians(plv_ctx *ctx, const JacParams &P) {
   ProfScope ps(ctx->prof, "jacobian_kernel", ctx->stream);
   hipLaunchKernelGGL(jacobian_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P);

@@ -26,5 +26,7 @@ struct JacParams {
 };
 
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
+int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
+                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err);
 
 }  // namespace plv

@@ -207,6 +207,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
     plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
     for (auto *b : ub) b->release();
     us->jin.release();
+    us->tri.release();
     us->h_jin.release();
     delete us;
   }

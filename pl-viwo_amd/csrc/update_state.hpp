@@ -14,7 +14,7 @@ struct plv_ctx_update_state {
   bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy
   std::vector<int> brows_host;
   // jacobian inputs
-  plv::DevBuf jin;
+  plv::DevBuf jin, tri;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);

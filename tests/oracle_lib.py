@@ -299,6 +299,8 @@ class JacOracle:
         lib.orc_build_jacobians.restype = C.c_int
         lib.orc_triangulate.argtypes = [C.c_int, dp, dp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp]
         lib.orc_triangulate.restype = C.c_int
+        lib.orc_triangulate_batch.argtypes = [sv, tk, C.POINTER(pkg.PlvTriOptions), dp, u8p, dp]
+        lib.orc_triangulate_batch.restype = C.c_int
 
     def columns(self, st, tr, cap=512):
         cols = np.zeros(cap, dtype=np.int32)
@@ -334,6 +336,16 @@ class JacOracle:
                                       max_baseline, 1 if refine else 0, _dp(out))
         return bool(ok), out
 
+
+    def _tb(self, st, tr, min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True):
+        opt = self.pkg.PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
+        F = tr.c.n_feat
+        p, ok, err = np.zeros((F, 3)), np.zeros(F, dtype=np.uint8), np.zeros(F)
+        self.lib.orc_triangulate_batch(C.byref(st.c), C.byref(tr.c), C.byref(opt), _dp(p), ok.ctypes.data_as(u8p), _dp(err))
+        return p, ok, err
+
+
+JacOracle.triangulate_batch = JacOracle._tb
 
 _jac = None
 

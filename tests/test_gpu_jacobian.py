@@ -82,3 +82,26 @@ def test_update_from_tracks_end_to_end(pkg, ctx, jo, oracle):
     # the device-built batch is single use
     with pytest.raises(pkg.PlvError):
         ctx.msckf_update_resident(n, 1.0)
+
+
+def test_triangulate_batch_parity(pkg, ctx, jo):
+    """a18/a19: camera poses from the estimate polynomial, linear triangulation, LM refinement,
+    reprojection error — thread per feature on the device vs the oracle."""
+    fo = oracle_lib.load_front()
+    for kw, opt in ((dict(noise_px=0.3), dict(max_cond=1e7, max_dist=150.0, max_baseline=2000.0)),
+                    (dict(noise_px=0.3, obs_offset=0.013), dict(max_cond=1e7, max_dist=150.0, max_baseline=2000.0)),
+                    (dict(noise_px=1.0), dict())):
+        sc = synth.vio_scene(n_clones=15, F=60, M=15, **kw)
+        uvn = fo.undistort(sc["K8"], sc["obs_uv"])
+        st = pkg.StateView(sc["t"], sc["R"], sc["p"], sc["ids"], sc["R_ItoC"], sc["p_IinC"], sc["K8"], intrinsic_state_id=15)
+        tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], np.zeros((60, 3)), obs_uvn=uvn)
+        p0, ok0, e0 = jo.triangulate_batch(st, tr, **opt)
+        p1, ok1, e1 = ctx.triangulate(st, tr, **opt)
+        assert np.array_equal(ok0, ok1)
+        good = ok0.astype(bool)
+        if "max_cond" in opt:
+            assert good.sum() >= 40
+            rel = np.linalg.norm(p1[good] - sc["pts"][good], axis=1) / np.linalg.norm(sc["pts"][good] - sc["p"][-1], axis=1)
+            assert np.median(rel) < 0.1
+        assert np.max(np.abs(p1[good] - p0[good])) <= 1e-6 * max(1.0, np.abs(p0[good]).max()) if good.any() else True
+        assert np.allclose(e1[good], e0[good], rtol=1e-5, atol=1e-6)
