@@ -190,7 +190,8 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   ctx->prof.destroy();
   plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
                          &ctx->d_Mt, &ctx->d_S, &ctx->d_W, &ctx->d_y, &ctx->d_fHf, &ctx->d_fHx, &ctx->d_fres,
-                         &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2};
+                         &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2, &ctx->d_Pc, &ctx->d_Ps,
+                         &ctx->d_inv, &ctx->d_T};
   for (auto *b : bufs) b->release();
   ctx->h_pin.release();
   plv_ctx_update_state *us = nullptr;
@@ -468,6 +469,7 @@ int plv_chi2_batch(plv_ctx *ctx, const double *P, int n, int ldp, int F, int k, 
   a.q95 = us->q95.as<double>();
   a.q95_n = Q95_N;
   a.min_rows = 1;
+  TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, ctx->d_cols.as<int>(), k));
   TRY(launch_chi2(ctx, F, a, max_mp));
   TRY(d2h(ctx, chi2, ctx->d_chi2.p, (size_t)F * 8));
   return sync(ctx);
@@ -567,6 +569,7 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   a.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
   a.accepted = d_acc;
   a.acc_rows = d_acc_rows;
+  TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, us->bcols.as<int>(), k));
   TRY(launch_chi2(ctx, F, a, mp_max));
 
   const double *dH, *dr;
@@ -600,9 +603,9 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
     ldh = Mtot;
   }
   if (ekf_fast_fits(r))
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
   else
-    TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag));
+    TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
   size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));

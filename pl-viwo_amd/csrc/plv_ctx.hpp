@@ -161,6 +161,7 @@ struct plv_ctx {
   plv::DevBuf d_P;        // n x n col-major, ld = n
   plv::DevBuf d_H, d_res, d_cols, d_Rdiag, d_dx, d_flag;
   plv::DevBuf d_Mt, d_S, d_W, d_y;          // EKF workspaces
+  plv::DevBuf d_Pc, d_Ps, d_inv, d_T;       // dense covariance gathers, H'Ps
   plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
   plv::PinBuf h_pin;

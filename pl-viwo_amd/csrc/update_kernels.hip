@@ -14,12 +14,13 @@
 //    the pivot column replicated, so no intra-pass communication is needed;
 //  * the compression is a Householder TSQR: a row chunk lives in registers (16 rows x 1 column
 //    per thread), the running R factor in LDS.
+#include <algorithm>
+
 #include "plv_ctx.hpp"
+#include "mfma_tile.hpp"
 #include "update_kernels.hpp"
 
 namespace plv {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // One wave computes one 16x16 fp64 tile  acc(i,j) += sum_k a(i,k) * b(k,j)  with
@@ -167,10 +168,8 @@ __global__ void __launch_bounds__(256) chi2_gate_kernel(Chi2Args a) {
   const int rows_f = a.rows[f];
   const int mp = rows_f - a.fdim_off;
   const int k = a.k, ld = a.ld;
-  const int mt = (max(mp, 1) + 15) >> 4, kt = (k + 15) >> 4;
-  const int kp = kt * 16 + 1;            // padded row length of T
-  double *T = smem;                      // [mt*16][kp]
-  double *S = T + mt * 16 * kp;          // [64][65]  bordered
+  const int mt = (max(mp, 1) + 15) >> 4;
+  double *S = smem;                      // [64][65]  bordered
   const double *H = a.Hx + (size_t)f * k * ld;
   const double *r = a.res + (size_t)f * ld;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -180,25 +179,14 @@ __global__ void __launch_bounds__(256) chi2_gate_kernel(Chi2Args a) {
   double chi = NAN;
   double nrm2 = 0.0;
   if (valid) {
-    // T = H' Ps
-    for (int t = wave; t < mt * kt; t += 4) {
-      const int ti = t / kt, tj = t - ti * kt;
-      d4 acc = {0, 0, 0, 0};
-      auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < mp ? H[kk * ld + row] : 0.0; };
-      auto fb = [&](int kk, int j) {
-        int col = tj * 16 + j;
-        return col < k ? a.P[(size_t)a.cols[col] * a.ldp + a.cols[kk]] : 0.0;
-      };
-      acc = mfma_tile_f64(fa, fb, k, acc);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) T[(ti * 16 + trow + 4 * q) * kp + tj * 16 + tcol] = acc[q];
-    }
-    __syncthreads();
+    // T = H' Ps was produced for every feature by chi2_t_kernel (col-major, ld)
+    const double *Tg = a.T + (size_t)f * k * ld;
     // S = T H'^T + sigma2 I  (full; symmetric up to rounding, upper triangle is what is used)
     for (int t = wave; t < mt * mt; t += 4) {
       const int ti = t / mt, tj = t - ti * mt;
+      if (tj < ti) continue;  // upper tiles only (REF: selfadjointView<Upper>)
       d4 acc = {0, 0, 0, 0};
-      auto fa = [&](int i, int kk) { return T[(ti * 16 + i) * kp + kk]; };
+      auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < mp ? Tg[kk * ld + row] : 0.0; };
       auto fb = [&](int kk, int j) { int row = tj * 16 + j; return row < mp ? H[kk * ld + row] : 0.0; };
       acc = mfma_tile_f64(fa, fb, k, acc);
 #pragma unroll
@@ -347,6 +335,56 @@ __global__ void __launch_bounds__(1024) qr_accum_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load
+// goes through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols]
+// (k x k, row-major), inv[state] = position of that state in cols or -1.
+__global__ void __launch_bounds__(256) gather_cov_kernel(const double *__restrict__ P, int ldp, int n,
+                                                         const int *__restrict__ cols, int k, double *__restrict__ Pc,
+                                                         double *__restrict__ Ps, int *__restrict__ inv) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < k * n) {
+    const int kk = idx / n, j = idx - kk * n;
+    Pc[idx] = P[(size_t)cols[kk] * ldp + j];  // P symmetric: row cols[kk] == column cols[kk]
+  }
+  if (idx < k * k) {
+    const int kk = idx / k, c = idx - kk * k;
+    Ps[idx] = P[(size_t)cols[kk] * ldp + cols[c]];
+  }
+  if (idx < n) {
+    int pos = -1;
+    for (int q = 0; q < k; ++q) pos = (cols[q] == idx) ? q : pos;
+    inv[idx] = pos;
+  }
+}
+
+// T = Hx' * Ps for every feature at once: one 16x16 tile per wave over (feature, row tile, col tile).
+__global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
+  const int kt = (a.k + 15) >> 4;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_f = mt_max * kt;
+  const int f = wid / per_f;
+  if (f >= a.F) return;
+  const int t = wid - f * per_f, ti = t / kt, tj = t - ti * kt;
+  const int mp = a.rows[f] - a.fdim_off;
+  if (ti * 16 >= mp) return;
+  const int k = a.k, ld = a.ld;
+  const double *H = a.Hx + (size_t)f * k * ld;
+  double *T = a.T + (size_t)f * k * ld;
+  const int lane = threadIdx.x & 63;
+  d4 acc = {0, 0, 0, 0};
+  const double *Hr = H + min(ti * 16 + (lane & 15), mp - 1);  // rows/cols beyond the range only feed unstored entries
+  const double *Pq = a.Ps + min(tj * 16 + (lane & 15), k - 1);
+  auto fa = [&](int, int kk) { return Hr[kk * ld]; };
+  auto fb = [&](int kk, int) { return Pq[(size_t)kk * k]; };
+  acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
+    if (i < mp && j < k) T[(size_t)j * ld + i] = acc[q];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K14 pieces.  Mt = H * P[cols, :]  (r x n) == (P[:,cols] H^T)^T  == M_a^T of the reference.
 __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ H, int ldh, int r, int k,
                                                      const int *__restrict__ cols, const double *__restrict__ P,
@@ -357,13 +395,19 @@ __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ 
   const int tr = tile / tn_n, tn = tile - tr * tn_n;
   const int lane = threadIdx.x & 63;
   d4 acc = {0, 0, 0, 0};
-  auto fa = [&](int i, int kk) { int row = tr * 16 + i; return row < r ? H[(size_t)kk * ldh + row] : 0.0; };
-  auto fb = [&](int kk, int j) { int col = tn * 16 + j; return col < n ? P[(size_t)cols[kk] * ldp + col] : 0.0; };
-  acc = mfma_tile_f64(fa, fb, k, acc);
+  const double *Hr = H + min(tr * 16 + (lane & 15), r - 1);
+  const double *Pq = P + min(tn * 16 + (lane & 15), n - 1);  // P = Pc (k x n)
+  auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
+  auto fb = [&](int kk, int) { return Pq[(size_t)kk * ldp]; };
+  acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int i = tr * 16 + (lane >> 4) + 4 * q, j = tn * 16 + (lane & 15);
-    if (i < r && j < n) Mt[(size_t)j * ldm + i] = acc[q];
+    if (i < r && j < n) {
+      Mt[(size_t)j * ldm + i] = acc[q];
+      const int pos = cols[j];  // cols = inverse map here: position of state j among the measured columns
+      if (pos >= 0) Mt[(size_t)(n + 1 + pos) * ldm + i] = acc[q];  // compact copy Mt[:, cols] behind Mt and y
+    }
   }
 }
 
@@ -377,9 +421,11 @@ __global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ M
   const int ti = tile / tn, tj = tile - ti * tn;
   const int lane = threadIdx.x & 63;
   d4 acc = {0, 0, 0, 0};
-  auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < r ? Mt[(size_t)cols[kk] * ldm + row] : 0.0; };
-  auto fb = [&](int kk, int j) { int row = tj * 16 + j; return row < r ? H[(size_t)kk * ldh + row] : 0.0; };
-  acc = mfma_tile_f64(fa, fb, k, acc);
+  const double *Mr = Mt + min(ti * 16 + (lane & 15), r - 1);  // Mt = compact Mt[:, cols]
+  const double *Hr = H + min(tj * 16 + (lane & 15), r - 1);
+  auto fa = [&](int, int kk) { return Mr[(size_t)kk * ldm]; };
+  auto fb = [&](int kk, int) { return Hr[(size_t)kk * ldh]; };
+  acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
@@ -534,18 +580,37 @@ int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_
   return PLV_OK;
 }
 
-int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp) {
+int launch_gather_cov(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k) {
+  int rc;
+  if ((rc = ctx->d_Pc.reserve((size_t)k * n * 8)) || (rc = ctx->d_Ps.reserve((size_t)k * k * 8)) ||
+      (rc = ctx->d_inv.reserve((size_t)n * 4)))
+    return rc;
+  ProfScope ps(ctx->prof, "gather_cov_kernel", ctx->stream);
+  const int total = std::max(k * n, std::max(k * k, n));
+  hipLaunchKernelGGL(gather_cov_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, d_P, ldp, n, d_cols, k,
+                     ctx->d_Pc.as<double>(), ctx->d_Ps.as<double>(), ctx->d_inv.as<int>());
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// chi2 of F features.  Requires launch_gather_cov for the same (P, cols) beforehand.
+int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a_in, int max_mp) {
   if (max_mp > CHI2_MAXM) {
     set_last_error("chi2: %d projected rows per feature exceeds %d", max_mp, CHI2_MAXM);
     return PLV_E_CAPACITY;
   }
-  int mt = (max_mp + 15) / 16, kt = (a.k + 15) / 16;
-  size_t shm = ((size_t)mt * 16 * (kt * 16 + 1) + 65 * 65) * sizeof(double);
-  if (shm > 160 * 1024) {
-    set_last_error("chi2: LDS need %zu", shm);
-    return PLV_E_CAPACITY;
+  Chi2Args a = a_in;
+  int rc;
+  if ((rc = ctx->d_T.reserve((size_t)F * a.k * a.ld * 8))) return rc;
+  a.F = F;
+  a.Ps = ctx->d_Ps.as<double>();
+  a.T = ctx->d_T.as<double>();
+  const int mt = (max_mp + 15) / 16, kt = (a.k + 15) / 16;
+  {
+    ProfScope ps(ctx->prof, "chi2_t_kernel", ctx->stream);
+    hipLaunchKernelGGL(chi2_t_kernel, dim3(cdiv(F * mt * kt, 4)), dim3(256), 0, ctx->stream, a, mt);
   }
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  size_t shm = (size_t)(65 * 65 + 8) * sizeof(double);
   ProfScope ps(ctx->prof, "chi2_gate_kernel", ctx->stream);
   hipLaunchKernelGGL(chi2_gate_kernel, dim3(F), dim3(256), shm, ctx->stream, a);
   PLV_HIP_CHECK(hipGetLastError());
@@ -601,28 +666,30 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
 
 // Mt = H P[cols,:] and S = Mt[:,cols] H^T + R (two tile-parallel launches).
 void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
-                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S) {
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered) {
+  // Mt holds [Mt (n cols) | spare (1) | Mt[:, cols] (k cols)]: callers size it r x (n + 1 + k)
+  if (!gathered) (void)launch_gather_cov(ctx, d_P, n, ldp, d_cols, k);
   {
     ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
     int tiles = cdiv(r, 16) * cdiv(n, 16);
-    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, d_cols, d_P, ldp, n,
-                       Mt, ldm);
+    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_inv.as<int>(),
+                       ctx->d_Pc.as<double>(), n, n, Mt, ldm);
   }
   {
     ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
     int tiles = cdiv(r, 16) * cdiv(r, 16);
-    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt, ldm, d_H, ldh, r, k, d_cols,
-                       d_Rdiag, S, r);
+    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt + (size_t)(n + 1) * ldm, ldm, d_H, ldh,
+                       r, k, d_cols, d_Rdiag, S, r);
   }
 }
 
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
 // 0 (updated), bit0 (negative diagonal), bit1 (S not positive definite).
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
-               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag) {
+               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered) {
   int rc;
   const int ldm = r, ldw = r;
-  if ((rc = ctx->d_Mt.reserve((size_t)r * n * 8)) || (rc = ctx->d_S.reserve((size_t)r * r * 8 * 2)) ||
+  if ((rc = ctx->d_Mt.reserve((size_t)r * (n + 1 + k) * 8)) || (rc = ctx->d_S.reserve((size_t)r * r * 8 * 2)) ||
       (rc = ctx->d_W.reserve((size_t)r * (n + 1) * 8)))
     return rc;
   double *Mt = ctx->d_Mt.as<double>(), *S = ctx->d_S.as<double>(), *L = S + (size_t)r * r, *W = ctx->d_W.as<double>();
@@ -632,7 +699,7 @@ int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int
     return PLV_E_CAPACITY;
   }
   PLV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S);
+  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered);
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   {

@@ -22,23 +22,34 @@ struct Chi2Args {
   int min_rows;
   unsigned char *accepted;
   int *acc_rows;          // projected rows of each accepted feature (0 when rejected)
+  // filled by launch_chi2
+  int F;
+  const double *Ps;       // dense P[cols, cols] (row-major k x k) from gather_cov_kernel
+  double *T;              // [F][k][ld] H' * Ps
 };
 
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
                      double *d_res);
+int launch_gather_cov(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp);
 int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,
                 int *ld_out);
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
-               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag);
+               const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false);
 
 void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
-                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S);
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered = false);
+// `gathered`: launch_gather_cov already ran for this (P, cols) and P has not changed since
 // dense_kernels.hip
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
                          double *d_R, int ldr, double *d_z);
 bool ekf_fast_fits(int r);
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
-                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag);
+                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false);
+
+// blocked_chol.hip
+int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z);
+int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
+                     const double *d_res, double *d_W, int ldw, int *d_flag);
 
 }  // namespace plv
