@@ -72,12 +72,13 @@ def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
         "ransac_hyp_kernel": ("mfma", 1000 * 3 * N_PTS * 40.0),
         "ransac_select_kernel": ("mfma", N_PTS * 40.0),
         "nullspace_kernel": ("mfma", F_FEATS * 6.0 * (FDIM + k + 1) * (2 * M_OBS * FDIM - FDIM * (FDIM + 1) / 2)),
-        "chi2_gate_kernel": ("mfma", F_FEATS * (2.0 * mp * k * k + 2.0 * mp * mp * k + mp ** 3 / 3.0)),
+        "chi2_gate_kernel": ("mfma", F_FEATS * (2.0 * mp * mp * k + mp ** 3 / 3.0)),
         "qr_accum_kernel": ("mfma", (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches)),
         "gram_kernel": ("mfma", 2.0 * m * nc * nc),
-        "chol_compress_kernel": ("mfma", nc ** 3 / 3.0),
-        "chol_inv_kernel": ("mfma", r ** 3 / 3.0 + r ** 3 / 3.0),
-        "ekf_w_kernel": ("mfma", 1.0 * r * r * (n + 1)),
+        "bchol_compress_kernel": ("mfma", nc ** 3 / 3.0),
+        "bchol_ekf_kernel": ("mfma", r ** 3 / 3.0 + 1.0 * r * r * (n + 1)),
+        "gather_cov_kernel": ("hbm", 2.0 * (k * n + k * k) * 8),
+        "chi2_t_kernel": ("mfma", F_FEATS * 2.0 * mp * k * k),
         "ekf_dc_kernel": ("mfma", 1.0 * n * n * r + 2.0 * n * r),
         "ekf_commit_kernel": ("hbm", 3.0 * n * n * 8),
         "ekf_mt_kernel": ("mfma", 2.0 * n * k * r),
