@@ -153,8 +153,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
       (rc = ctx->d_W.reserve((size_t)r * (n + 1) * 8)) || (rc = ctx->d_y.reserve((size_t)n * n * 8)))
     return rc;
   double *Mt = ctx->d_Mt.as<double>(), *S = ctx->d_S.as<double>(), *W = ctx->d_W.as<double>(), *dC = ctx->d_y.as<double>();
-  PLV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered);
+  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered, d_flag);
   if ((rc = launch_bchol_ekf(ctx, S, r, r, Mt, ldm, n, d_res, W, ldw, d_flag))) return rc;
   {
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);

@@ -72,7 +72,10 @@ int ensure_pyramids(plv_ctx *ctx, FrontState *s) {
     TRY(s->pyr_mem[i].reserve((size_t)bytes));
     s->pyr[i].base = s->pyr_mem[i].as<uint8_t>();
   }
-  TRY(s->hist.reserve(256 * sizeof(unsigned)));
+  if (!s->hist.p) {  // 256 bins + arrival counter; equalize_kernel leaves it zero for the next frame
+    TRY(s->hist.reserve(257 * sizeof(unsigned)));
+    PLV_HIP_CHECK(hipMemsetAsync(s->hist.p, 0, 257 * sizeof(unsigned), ctx->stream));
+  }
   TRY(s->raw.reserve((size_t)s->W * s->H));
   return PLV_OK;
 }

@@ -48,10 +48,11 @@ __global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ i
 
 // LUT (every block rebuilds it from the 256-bin histogram: 256 adds) + apply.
 __global__ void __launch_bounds__(256) equalize_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int npix,
-                                                       const unsigned *__restrict__ hist) {
+                                                       unsigned *__restrict__ hist) {
   __shared__ unsigned cdf[256];
   __shared__ uint8_t lut[256];
   __shared__ int first_bin;
+  __shared__ bool last_block;
   const int t = threadIdx.x;
   cdf[t] = hist[t];
   if (t == 0) first_bin = 256;
@@ -89,6 +90,18 @@ __global__ void __launch_bounds__(256) equalize_kernel(const uint8_t *__restrict
   }
   if (blockIdx.x == 0)
     for (int i = (nvec << 4) + t; i < npix; i += blockDim.x) dst[i] = lut[src[i]];
+  // every workgroup has consumed the histogram before this point (LUT built behind a barrier):
+  // the last one to arrive clears it and the arrival counter for the next frame, so the feed
+  // path needs no memset launch (hist[256] is the counter; the buffer is zeroed once at creation)
+  if (t == 0) {
+    __threadfence();
+    last_block = atomicAdd(&hist[256], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last_block) {
+    hist[t] = 0;
+    if (t == 0) hist[256] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ K2
@@ -748,7 +761,6 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix, unsigned *d_hist) {
-  PLV_HIP_CHECK(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned), ctx->stream));
   int blocks = min(256, max(1, cdiv(npix / 16, 256)));
   {
     ProfScope ps(ctx->prof, "hist_kernel", ctx->stream);

@@ -155,8 +155,6 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   JacParams P{};
   TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
   PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemsetAsync(us->bHf.p, 0, (nHf + nHx + nr) * 8, ctx->stream));
-  PLV_HIP_CHECK(hipMemsetAsync(us->brows.p, 0, (size_t)F * 4, ctx->stream));
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;

@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
 // K14 pieces.  Mt = H * P[cols, :]  (r x n) == (P[:,cols] H^T)^T  == M_a^T of the reference.
 __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ H, int ldh, int r, int k,
                                                      const int *__restrict__ cols, const double *__restrict__ P,
-                                                     int ldp, int n, double *__restrict__ Mt, int ldm) {
+                                                     int ldp, int n, double *__restrict__ Mt, int ldm,
+                                                     int *__restrict__ flag) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;  // update status word, set by the kernels that follow
   const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= tr_n * tn_n) return;
@@ -666,14 +668,14 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
 
 // Mt = H P[cols,:] and S = Mt[:,cols] H^T + R (two tile-parallel launches).
 void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
-                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered) {
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered, int *d_flag) {
   // Mt holds [Mt (n cols) | spare (1) | Mt[:, cols] (k cols)]: callers size it r x (n + 1 + k)
   if (!gathered) (void)launch_gather_cov(ctx, d_P, n, ldp, d_cols, k);
   {
     ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
     int tiles = cdiv(r, 16) * cdiv(n, 16);
     hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_inv.as<int>(),
-                       ctx->d_Pc.as<double>(), n, n, Mt, ldm);
+                       ctx->d_Pc.as<double>(), n, n, Mt, ldm, d_flag);
   }
   {
     ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
@@ -698,8 +700,7 @@ int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int
     set_last_error("ekf: r=%d exceeds the LDS-resident Cholesky capacity", r);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered);
+  launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered, d_flag);
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   {

@@ -38,7 +38,8 @@ int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int
                const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false);
 
 void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
-                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered = false);
+                   const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered = false,
+                   int *d_flag = nullptr);
 // `gathered`: launch_gather_cov already ran for this (P, cols) and P has not changed since
 // dense_kernels.hip
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
