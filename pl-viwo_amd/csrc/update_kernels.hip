@@ -81,12 +81,53 @@ __device__ __forceinline__ void make_givens(double p, double q, double &c, doubl
   }
 }
 
+// Same rotation on the latency-critical path of the nullspace kernel: the chain of rows-1 dependent
+// rotations per pivot column is what bounds that kernel, and an IEEE divide + sqrt + divide is ~42
+// dependent fp64 instructions.  v_rcp_f64 / v_rsq_f64 + two Newton steps each give the same values
+// to within 1-2 ulp in ~17 (the rotation stays orthonormal to rounding: c^2 + s^2 = 1 +- 2 eps).
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-x * r, r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+__device__ __forceinline__ void make_givens_fast(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0.0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0.0 ? 1.0 : -1.0;
+  } else if (fabs(p) > fabs(q)) {
+    const double t = q * rcp_newton(p);
+    double iu = rsqrt_newton(fma(t, t, 1.0));
+    if (p < 0.0) iu = -iu;
+    c = iu;
+    s = -t * c;
+  } else {
+    const double t = p * rcp_newton(q);
+    double iu = rsqrt_newton(fma(t, t, 1.0));
+    if (q < 0.0) iu = -iu;
+    s = -iu;
+    c = -t * s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K11: one workgroup per feature.  X = [Hf | Hx | res] (rows x ncol) staged row-major in LDS,
 // one thread per column.  For pivot column n the rotation sequence m = rows-1 .. n+1 is the
 // reference's; (c,s) are recomputed by every thread from a read-only copy of the pivot column,
 // which reproduces bit-for-bit what the column's owner computes, so threads never wait on each
-// other inside a pass.
+// other inside a pass.  The chain of rows-1 dependent rotations per pivot column is the critical path
+// (a register-resident variant without the LDS round trips measured the same 29-32 us).
 __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld, const int *__restrict__ rows_arr,
                                                         double *__restrict__ Hf, double *__restrict__ Hx,
                                                         double *__restrict__ res) {
@@ -124,7 +165,7 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
           continue;
         }
         double c, s;
-        make_givens(p, q, c, s);
+        make_givens_fast(p, q, c, s);
         carry_p = c * p - s * q;
         const double nu = c * up - s * carry_o;
         const double nl = s * up + c * carry_o;
