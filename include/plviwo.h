@@ -321,6 +321,54 @@ int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks
 int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
                                  const int *col_to_state, int ld);
 
+/* ---------------------------------------------------------------------------------------------
+ * Line features on the update side (a27-a29).
+ * A line is a Pluecker 6-vector line_FinG = [moment n (3); direction v (3)] in the global frame
+ * (REF: PL-VIWO/src/update/cam/linefeat/LineFeature.h:22-107, head = moment, tail = direction).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plv_line_tracks {
+  int n_lines;
+  const int *obs_ptr;       /* [n_lines+1] CSR into the observation arrays                               */
+  const double *obs_time;   /* [n_obs] measurement time stamps (cam_dt is added inside)                  */
+  const float *seg_uv;      /* [n_obs][4] raw pixel end points x1 y1 x2 y2 (LineFeature::line_uvs)       */
+  const float *seg_uvn;     /* [n_obs][4] normalised end points (line_uvs_norm); plv_triangulate_lines    */
+  const double *line_FinG;  /* [n_lines][6] triangulated lines; input of the Jacobians                   */
+  const int *D;             /* [n_lines] structural class 0..3 (LineFeature::D); NULL = all 0             */
+  const double *anchor_pt;  /* [n_lines][3] first triangulated point feature lying on the line            */
+  const uint8_t *has_pt;    /* [n_lines] anchor_pt valid (REF: LineHelper.cpp:231-247); NULL = none       */
+  const double *res_R;      /* optional [n_obs][9] / [n_obs][3]: IMU pose of the residual, as plv_tracks  */
+  const double *res_p;
+} plv_line_tracks;
+
+/* plv_triangulate_lines replaces, for all lines at once, LineHelper::get_imu_poses / get_cam_poses /
+ * line_triangulation (REF: LineHelper.cpp:132-229): with D > 0 and a triangulated point on the line
+ * the direction is R_GtoI^T e_D and the moment p x direction (:231-293); otherwise the plane through
+ * the first view's end points is intersected with the plane of every later view and the Pluecker
+ * results are averaged (:372-495, CompoutePlaneFromPoints :615-623, ComputeLineFramePlanes :625-650).
+ * ok[l] = 0 when the reference returns false (fewer than two usable views, all plane pairs with
+ * |cos| >= 0.99).  LineFeature::EndPoints is left to the caller (the reference stores an
+ * uninitialised vector there, :489-493). */
+int plv_triangulate_lines(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, double *line_FinG,
+                          uint8_t *ok);
+
+/* Column order of the stacked line Jacobians: per observation the four interpolation clones, then the
+ * time offset when it is calibrated, first-seen order (REF: LineHelper.cpp:757-788 with
+ * State::get_interpolated_jacobian's `order`, State.cpp:905-958).  No extrinsic / intrinsic columns:
+ * the reference's line model has no Jacobian with respect to them. */
+int plv_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *lt, int *col_to_state, int cap, int *k_out);
+
+/* plv_build_line_jacobians replaces LineHelper::get_line_feature_jacobian_full (REF: LineHelper.cpp:
+ * 733-1024, point-line coupling off as in UpdaterCamera::lines_update :373) for all lines at once:
+ * Hf [L][6][ld], Hx [L][k][ld], res [L][ld], rows[l] = 2 * (valid observations).  The reference's
+ * arithmetic is kept, including dz/dl built from Identity(2,3) (third column zero) and
+ * ln_2 = l0^2 + l1 + l1 (:921-928). */
+int plv_build_line_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                             const int *col_to_state, int ld, int *rows, double *Hf, double *Hx, double *res);
+/* ... staged on the device as the current feature batch: follow with
+ * plv_msckf_update_resident(fdim = 6, res_norm_gate = 0) = UpdaterCamera::lines_update (:371-464). */
+int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                                      const int *col_to_state, int ld);
+
 #ifdef __cplusplus
 }
 #endif

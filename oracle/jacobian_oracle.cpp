@@ -719,3 +719,291 @@ int orc_triangulate_batch(const plv_state_view *st, const plv_tracks *trk, const
 }
 
 }  // extern "C"
+
+// ================================================================ lines (a27-a29)
+// REF: PL-VIWO/src/update/cam/linefeat/LineHelper.cpp:733-1024 (Jacobians), :132-229, :231-293,
+// :372-495, :615-650 (triangulation).  Point-line coupling is off (UpdaterCamera.cpp:373).
+namespace {
+inline V3 cross(const V3 &a, const V3 &b) {
+  return V3{{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
+}
+inline double dot(const V3 &a, const V3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// pose used for residuals / triangulation at observation o: provided pose or the estimate polynomial
+bool line_est_pose(const plv_state_view &st, const plv_line_tracks &lt, int o, double tm, M3 &R, V3 &p) {
+  if (bounding_start(st, tm) < 0) return false;
+  if (lt.res_R) {
+    R = getM(lt.res_R + 9 * o);
+    p = getV(lt.res_p + 3 * o);
+    return true;
+  }
+  Interp est;
+  if (!interpolate(st, tm, false, false, est)) return false;
+  R = est.R;
+  p = est.p;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int orc_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *lt, int *col_to_state, int cap, int *k_out) {
+  int k = 0;
+  auto push = [&](int id, int size) {
+    if (id < 0) return true;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == id) return true;
+    if (k + size > cap) return false;
+    for (int d = 0; d < size; ++d) col_to_state[k++] = id + d;
+    return true;
+  };
+  for (int l = 0; l < lt->n_lines; ++l)
+    for (int o = lt->obs_ptr[l]; o < lt->obs_ptr[l + 1]; ++o) {
+      const int s0 = bounding_start(*st, lt->obs_time[o] + st->cam_dt);
+      if (s0 < 0) continue;
+      for (int w = 0; w < 4; ++w)
+        if (!push(st->clone_state_id[s0 + w], 6)) return -5;
+      if (!push(st->dt_state_id, 1)) return -5;
+    }
+  *k_out = k;
+  return 0;
+}
+
+int orc_build_line_jacobians(const plv_state_view *st, const plv_line_tracks *lt, int k, const int *col_to_state, int ld,
+                             int *rows, double *Hf, double *Hx, double *res) {
+  const int L = lt->n_lines;
+  memset(Hf, 0, sizeof(double) * (size_t)L * 6 * ld);
+  memset(Hx, 0, sizeof(double) * (size_t)L * k * ld);
+  memset(res, 0, sizeof(double) * (size_t)L * ld);
+  const M3 R_ItoC = getM(st->R_ItoC);
+  const V3 p_IinC = getV(st->p_IinC);
+  const double *Kc = st->intrinsics;  // fx fy cx cy
+  const double Kl[9] = {Kc[1], 0, 0, 0, Kc[0], 0, -Kc[1] * Kc[2], -Kc[0] * Kc[3], Kc[0] * Kc[1]};  // :861-864
+  const int col_dt = st->dt_state_id >= 0 ? find_col(col_to_state, k, st->dt_state_id) : -1;
+  for (int l = 0; l < L; ++l) {
+    double *hf = Hf + (size_t)l * 6 * ld, *hx = Hx + (size_t)l * k * ld, *rs = res + (size_t)l * ld;
+    const V3 nG = getV(lt->line_FinG + 6 * l), vG = getV(lt->line_FinG + 6 * l + 3);
+    int c = 0;
+    for (int o = lt->obs_ptr[l]; o < lt->obs_ptr[l + 1]; ++o) {
+      const double tm = lt->obs_time[o] + st->cam_dt;
+      Interp jac;
+      if (!interpolate(*st, tm, true, true, jac)) continue;
+      if (2 * c + 2 > ld) return -5;
+      M3 Re;
+      V3 pe;
+      if (!line_est_pose(*st, *lt, o, tm, Re, pe)) continue;
+      // G_to_I (6x6) = [R, -R skew(p); 0, R]   :846-850
+      double GtoI[36] = {0};
+      const M3 Rsk = scale(mul(Re, skew(pe)), -1.0);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          GtoI[6 * i + j] = Re(i, j);
+          GtoI[6 * i + 3 + j] = Rsk(i, j);
+          GtoI[6 * (3 + i) + 3 + j] = Re(i, j);
+        }
+      const V3 nI = addv(mul(Re, nG), mul(Rsk, vG)), vI = mul(Re, vG);
+      // I_to_C top rows = [R_ItoC, skew(p_IinC) R_ItoC]   :853-857
+      const M3 SR = mul(skew(p_IinC), R_ItoC);
+      const V3 nC = addv(mul(R_ItoC, nI), mul(SR, vI));
+      const double ld3[3] = {Kl[0] * nC[0] + Kl[1] * nC[1] + Kl[2] * nC[2], Kl[3] * nC[0] + Kl[4] * nC[1] + Kl[5] * nC[2],
+                             Kl[6] * nC[0] + Kl[7] * nC[1] + Kl[8] * nC[2]};
+      const double us[3] = {(double)lt->seg_uv[4 * o], (double)lt->seg_uv[4 * o + 1], 1.0};
+      const double ue[3] = {(double)lt->seg_uv[4 * o + 2], (double)lt->seg_uv[4 * o + 3], 1.0};
+      const double lnorm = std::sqrt(ld3[0] * ld3[0] + ld3[1] * ld3[1]);
+      const double ds = us[0] * ld3[0] + us[1] * ld3[1] + us[2] * ld3[2], de = ue[0] * ld3[0] + ue[1] * ld3[1] + ue[2] * ld3[2];
+      const double r2[2] = {ds / lnorm, de / lnorm};
+      // dz/dl: Identity(2,3) with four entries overwritten, ln_2 = l0^2 + l1 + l1   :921-928
+      const double ln_2 = ld3[0] * ld3[0] + ld3[1] + ld3[1];
+      double dzl[6] = {1, 0, 0, 0, 1, 0};
+      dzl[0] = us[0] - (ld3[0] * ds) / ln_2;
+      dzl[1] = us[1] - (ld3[1] * ds) / ln_2;
+      dzl[3] = ue[0] - (ld3[0] * de) / ln_2;
+      dzl[4] = ue[1] - (ld3[1] * de) / ln_2;
+      const double isq = 1 / std::sqrt(ln_2);
+      for (int i = 0; i < 6; ++i) dzl[i] *= isq;
+      // dz_li (2x6) = dz_l * Kl * [R_ItoC | skew(p_IinC) R_ItoC]
+      double dzK[6];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) dzK[3 * i + j] = dzl[3 * i] * Kl[j] + dzl[3 * i + 1] * Kl[3 + j] + dzl[3 * i + 2] * Kl[6 + j];
+      double dzli[12];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+          dzli[6 * i + j] = dzK[3 * i] * R_ItoC(0, j) + dzK[3 * i + 1] * R_ItoC(1, j) + dzK[3 * i + 2] * R_ItoC(2, j);
+          dzli[6 * i + 3 + j] = dzK[3 * i] * SR(0, j) + dzK[3 * i + 1] * SR(1, j) + dzK[3 * i + 2] * SR(2, j);
+        }
+      // dli_dI (6x6) with the pose get_interpolated_jacobian wrote back (first estimates)   :898,940-945
+      const M3 Rf = jac.R;
+      const V3 pf = jac.p;
+      const M3 A00 = skew(mul(Rf, sub(nG, mul(skew(pf), vG)))), A30 = skew(mul(Rf, vG)), A03 = mul(Rf, skew(vG));
+      double dliI[36] = {0};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          dliI[6 * i + j] = A00(i, j);
+          dliI[6 * (3 + i) + j] = A30(i, j);
+          dliI[6 * i + 3 + j] = A03(i, j);
+        }
+      double HI[12];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double s = 0;
+          for (int q = 0; q < 6; ++q) s += dzli[6 * i + q] * dliI[6 * q + j];
+          HI[6 * i + j] = s;
+        }
+      // noise + whitening (same form as the point path)   :957-998
+      double Rn[4] = {st->sigma_pix * st->sigma_pix, 0, 0, st->sigma_pix * st->sigma_pix};
+      bool at_clone = false;
+      for (int i = 0; i < st->n_clones; ++i) at_clone = at_clone || st->clone_time[i] == tm;
+      if (!at_clone && st->use_pol_cov) {
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) {
+            double s = 0;
+            for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? st->intr_ori_cov : st->intr_pos_cov) * HI[6 * j + q];
+            Rn[2 * i + j] += s;
+          }
+      }
+      const double l00 = std::sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = std::sqrt(Rn[3] - l10 * l10);
+      const double m00 = std::sqrt(l00), m10 = l10 / m00, m11 = std::sqrt(l11 - m10 * m10);
+      double Wm[4];
+      for (int col = 0; col < 2; ++col) {
+        double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+        double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
+        double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
+        Wm[col] = x0;
+        Wm[2 + col] = x1;
+      }
+      rs[2 * c] = Wm[0] * r2[0] + Wm[1] * r2[1];
+      rs[2 * c + 1] = Wm[2] * r2[0] + Wm[3] * r2[1];
+      double wli[12];
+      for (int j = 0; j < 6; ++j) {
+        wli[j] = Wm[0] * dzli[j] + Wm[1] * dzli[6 + j];
+        wli[6 + j] = Wm[2] * dzli[j] + Wm[3] * dzli[6 + j];
+      }
+      // Hf = wli * G_to_I ; Hx = wli * dli_dI * dTdx
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double s = 0;
+          for (int q = 0; q < 6; ++q) s += wli[6 * i + q] * GtoI[6 * q + j];
+          hf[(size_t)j * ld + 2 * c + i] += s;
+        }
+      double WI[12];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double s = 0;
+          for (int q = 0; q < 6; ++q) s += wli[6 * i + q] * dliI[6 * q + j];
+          WI[6 * i + j] = s;
+        }
+      for (int w = 0; w < 4; ++w) {
+        const int col = find_col(col_to_state, k, st->clone_state_id[jac.start + w]);
+        if (col < 0) return -1;
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 3; ++j) {
+            double so = 0, sp = 0;
+            for (int q = 0; q < 3; ++q) {
+              so += WI[6 * i + q] * jac.H[w][0][3 * q + j];
+              sp += WI[6 * i + 3 + q] * jac.H[w][1][3 * q + j];
+            }
+            hx[(size_t)(col + j) * ld + 2 * c + i] += so;
+            hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += sp;
+          }
+      }
+      if (col_dt >= 0)
+        for (int i = 0; i < 2; ++i) {
+          double s = 0;
+          for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dt_jac[q];
+          hx[(size_t)col_dt * ld + 2 * c + i] += s;
+        }
+      ++c;
+    }
+    rows[l] = 2 * c;
+  }
+  return 0;
+}
+
+int orc_triangulate_lines(const plv_state_view *st, const plv_line_tracks *lt, double *line_FinG, unsigned char *ok) {
+  const M3 R_ItoC = getM(st->R_ItoC);
+  const V3 p_IinC = getV(st->p_IinC);
+  for (int l = 0; l < lt->n_lines; ++l) {
+    ok[l] = 0;
+    for (int i = 0; i < 6; ++i) line_FinG[6 * l + i] = 0;
+    // usable views (LineHelper::get_imu_poses drops the ones without bounding clones)
+    std::vector<int> obs;
+    std::vector<M3> RI;
+    std::vector<V3> pI;
+    for (int o = lt->obs_ptr[l]; o < lt->obs_ptr[l + 1]; ++o) {
+      M3 R;
+      V3 p;
+      if (!line_est_pose(*st, *lt, o, lt->obs_time[o] + st->cam_dt, R, p)) continue;
+      obs.push_back(o);
+      RI.push_back(R);
+      pI.push_back(p);
+    }
+    if (obs.size() < 2) continue;  // :204-206
+    const int D = lt->D ? lt->D[l] : 0;
+    if (D > 0 && lt->has_pt && lt->has_pt[l]) {  // :231-293
+      const V3 e{{D == 1 ? 1.0 : 0.0, D == 2 ? 1.0 : 0.0, D == 3 ? 1.0 : 0.0}};
+      const V3 dir = mul(tr(RI[0]), e);
+      const V3 mom = cross(getV(lt->anchor_pt + 3 * l), dir);
+      for (int i = 0; i < 3; ++i) {
+        line_FinG[6 * l + i] = mom[i];
+        line_FinG[6 * l + 3 + i] = dir[i];
+      }
+      ok[l] = 1;
+      continue;
+    }
+    // :372-495
+    std::vector<M3> RC(obs.size());
+    std::vector<V3> pC(obs.size());
+    for (size_t m = 0; m < obs.size(); ++m) {
+      RC[m] = mul(R_ItoC, RI[m]);
+      pC[m] = sub(pI[m], mul(tr(RC[m]), p_IinC));
+    }
+    const float *u0 = lt->seg_uvn + 4 * obs[0];
+    const V3 p11{{(double)u0[0], (double)u0[1], 1.0}}, p12{{(double)u0[2], (double)u0[3], 1.0}}, cam0{{0, 0, 0}};
+    auto plane = [&](const V3 &a, const V3 &b, const V3 &c3, double pl[4]) {  // :615-623
+      const V3 n = cross(sub(a, c3), sub(b, c3));
+      pl[0] = n[0];
+      pl[1] = n[1];
+      pl[2] = n[2];
+      pl[3] = -dot(c3, cross(a, b));
+    };
+    double pl0[4];
+    plane(p11, p12, cam0, pl0);
+    V3 dsum{{0, 0, 0}}, nsum{{0, 0, 0}};
+    double dnorm = 0;
+    int cnt = 0;
+    for (size_t m = 1; m < obs.size(); ++m) {
+      const M3 R0i = mul(RC[m], tr(RC[0]));
+      const V3 pi0 = mul(RC[0], sub(pC[m], pC[0]));
+      const float *um = lt->seg_uvn + 4 * obs[m];
+      V3 p31{{(double)um[0], (double)um[1], 1.0}}, p32{{(double)um[2], (double)um[3], 1.0}};
+      p31 = addv(mul(tr(R0i), p31), pi0);
+      p32 = addv(mul(tr(R0i), p32), pi0);
+      double pl1[4];
+      plane(p31, p32, pi0, pl1);
+      // :625-650
+      V3 n1{{pl0[0], pl0[1], pl0[2]}}, n2{{pl1[0], pl1[1], pl1[2]}};
+      n1 = sc(n1, 1 / norm(n1));
+      n2 = sc(n2, 1 / norm(n2));
+      const double cth = dot(n1, n2) / (norm(n1) * norm(n2));
+      if (std::fabs(cth) >= 0.99) continue;
+      auto dp = [&](int i, int j) { return pl0[i] * pl1[j] - pl1[i] * pl0[j]; };
+      const V3 head{{dp(0, 3), dp(1, 3), dp(2, 3)}}, tail{{-dp(1, 2), dp(0, 2), -dp(0, 1)}};
+      dsum = addv(dsum, tail);  // "direction_vector = lines[i].tail(3)"
+      nsum = addv(nsum, head);
+      dnorm += norm(tail);
+      ++cnt;
+    }
+    if (cnt == 0) continue;
+    const V3 rhead = sc(dsum, 1 / dnorm), rtail = sc(nsum, 1.0 / cnt);  // line_result = [dir; normal]
+    const M3 R0t = tr(RC[0]);
+    const V3 vW = mul(R0t, rhead);
+    const V3 nW = addv(mul(R0t, rtail), mul(skew(pC[0]), mul(R0t, rhead)));
+    for (int i = 0; i < 3; ++i) {
+      line_FinG[6 * l + i] = nW[i];
+      line_FinG[6 * l + 3 + i] = vW[i];
+    }
+    ok[l] = 1;
+  }
+  return 0;
+}
+
+}  // extern "C"

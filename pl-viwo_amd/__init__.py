@@ -117,6 +117,12 @@ def load_library():
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
         "plv_build_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int]),
+        "plv_triangulate_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), dp, u8p]),
+        "plv_line_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), ip, C.c_int, ip]),
+        "plv_build_line_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), C.c_int, ip, C.c_int, ip,
+                                               dp, dp, dp]),
+        "plv_build_line_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), C.c_int, ip,
+                                                        C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -176,6 +182,17 @@ class PlvTracks(C.Structure):
     ]
 
 
+class PlvLineTracks(C.Structure):
+    _fields_ = [
+        ("n_lines", C.c_int),
+        ("obs_ptr", C.POINTER(C.c_int)), ("obs_time", C.POINTER(C.c_double)),
+        ("seg_uv", C.POINTER(C.c_float)), ("seg_uvn", C.POINTER(C.c_float)),
+        ("line_FinG", C.POINTER(C.c_double)), ("D", C.POINTER(C.c_int)),
+        ("anchor_pt", C.POINTER(C.c_double)), ("has_pt", C.POINTER(C.c_uint8)),
+        ("res_R", C.POINTER(C.c_double)), ("res_p", C.POINTER(C.c_double)),
+    ]
+
+
 class PlvTriOptions(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("max_dist", C.c_double), ("max_cond_number", C.c_double),
                 ("max_baseline", C.c_double), ("refine_features", C.c_int)]
@@ -222,6 +239,28 @@ class Tracks:
         v.p_FinG, v.p_FinG_fej, v.res_R, v.res_p = _dp(self.pf), _dp(self.pff), _dp(self.rR), _dp(self.rp)
         self.uvn = np.ascontiguousarray(obs_uvn, dtype=np.float32).reshape(-1, 2) if obs_uvn is not None else None
         v.obs_uvn = _fp(self.uvn)
+        self.c = v
+
+
+class LineTracks:
+    """Owns the numpy arrays behind a plv_line_tracks."""
+
+    def __init__(self, obs_ptr, obs_time, seg_uv, seg_uvn=None, line_FinG=None, D=None, anchor_pt=None, has_pt=None,
+                 res_R=None, res_p=None):
+        f64 = lambda a, w: np.ascontiguousarray(a, dtype=np.float64).reshape(-1, w) if a is not None else None
+        f32 = lambda a, w: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w) if a is not None else None
+        self.ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
+        self.t = np.ascontiguousarray(obs_time, dtype=np.float64)
+        self.uv, self.uvn = f32(seg_uv, 4), f32(seg_uvn, 4)
+        self.lg, self.ap = f64(line_FinG, 6), f64(anchor_pt, 3)
+        self.D = np.ascontiguousarray(D, dtype=np.int32) if D is not None else None
+        self.hp = np.ascontiguousarray(has_pt, dtype=np.uint8) if has_pt is not None else None
+        self.rR, self.rp = f64(res_R, 9), f64(res_p, 3)
+        v = PlvLineTracks()
+        v.n_lines = len(self.ptr) - 1
+        v.obs_ptr, v.obs_time, v.seg_uv, v.seg_uvn = _ip(self.ptr), _dp(self.t), _fp(self.uv), _fp(self.uvn)
+        v.line_FinG, v.D, v.anchor_pt, v.has_pt = _dp(self.lg), _ip(self.D), _dp(self.ap), _u8p(self.hp)
+        v.res_R, v.res_p = _dp(self.rR), _dp(self.rp)
         self.c = v
 
 
@@ -462,6 +501,33 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    # ---- lines (update side)
+    def line_jacobian_columns(self, st, lt, cap=512):
+        cols = np.zeros(cap, dtype=np.int32)
+        k = C.c_int()
+        self._chk(self.lib.plv_line_jacobian_columns(C.byref(st.c), C.byref(lt.c), _ip(cols), cap, C.byref(k)))
+        return cols[:k.value].copy()
+
+    def build_line_jacobians(self, st, lt, cols, ld):
+        cols = _i32(cols)
+        L, k = lt.c.n_lines, len(cols)
+        rows = np.zeros(L, dtype=np.int32)
+        Hf, Hx, res = np.zeros((L, 6, ld)), np.zeros((L, k, ld)), np.zeros((L, ld))
+        self._chk(self.lib.plv_build_line_jacobians(self.h, C.byref(st.c), C.byref(lt.c), k, _ip(cols), ld, _ip(rows), _dp(Hf),
+                                                    _dp(Hx), _dp(res)))
+        return rows, Hf, Hx, res
+
+    def build_line_jacobians_resident(self, st, lt, cols, ld):
+        cols = _i32(cols)
+        self._chk(self.lib.plv_build_line_jacobians_resident(self.h, C.byref(st.c), C.byref(lt.c), len(cols), _ip(cols), ld))
+        self._batch_F = lt.c.n_lines
+
+    def triangulate_lines(self, st, lt):
+        L = lt.c.n_lines
+        out, ok = np.zeros((L, 6)), np.zeros(L, dtype=np.uint8)
+        self._chk(self.lib.plv_triangulate_lines(self.h, C.byref(st.c), C.byref(lt.c), _dp(out), _u8p(ok)))
+        return out, ok
 
     # ---- detection
     def perform_detection(self, which, pts, ids, currid, mask=None, cap=None):

@@ -262,3 +262,221 @@ int plv_triangulate(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr
 }
 
 }  // extern "C"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ lines
+int check_line_views(const plv_state_view *st, const plv_line_tracks *lt, bool need_lines, bool need_uvn) {
+  if (!st || !lt || st->n_clones < 1 || !st->clone_time || !st->clone_R || !st->clone_p || !st->clone_R_fej ||
+      !st->clone_p_fej || !st->clone_state_id || lt->n_lines < 1 || !lt->obs_ptr || !lt->obs_time || !lt->seg_uv ||
+      (need_lines && !lt->line_FinG) || (need_uvn && !lt->seg_uvn)) {
+    set_last_error("line jacobians: null view field");
+    return PLV_E_BADARG;
+  }
+  if (st->intr_order != 3) {
+    set_last_error("line jacobians: only intr_order = 3 is built (got %d)", st->intr_order);
+    return PLV_E_BADARG;
+  }
+  if ((lt->res_R == nullptr) != (lt->res_p == nullptr)) return PLV_E_BADARG;
+  if (lt->has_pt && !lt->anchor_pt) return PLV_E_BADARG;
+  return PLV_OK;
+}
+
+// one packed upload of the state view and the line tracks; fills JacParams (n_feat = n_lines)
+int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                      const int *col_to_state, int ld, JacParams &P) {
+  const int N = st->n_clones, L = lt->n_lines, nobs = lt->obs_ptr[L];
+  if (nobs < 1) {
+    set_last_error("line jacobians: no observations");
+    return PLV_E_BADARG;
+  }
+  auto col_of = [&](int sid) {
+    if (sid < 0) return -1;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == sid) return j;
+    return -1;
+  };
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_time = take(8 * N), o_R = take(72 * N), o_p = take(24 * N), o_Rf = take(72 * N), o_pf = take(24 * N),
+               o_ccol = take(4 * N), o_ptr = take(4 * (L + 1)), o_ot = take(8 * nobs), o_uv = take(16 * nobs),
+               o_uvn = lt->seg_uvn ? take(16 * nobs) : 0, o_lg = lt->line_FinG ? take(48 * L) : 0,
+               o_D = lt->D ? take(4 * L) : 0, o_ap = lt->has_pt ? take(24 * L) : 0, o_hp = lt->has_pt ? take(L) : 0,
+               o_rR = lt->res_R ? take(72 * nobs) : 0, o_rp = lt->res_R ? take(24 * nobs) : 0;
+  const size_t total = off;
+  TRY(us->h_jin.reserve(total));
+  TRY(us->jin.reserve(total));
+  char *h = us->h_jin.as<char>();
+  memcpy(h + o_time, st->clone_time, 8 * N);
+  memcpy(h + o_R, st->clone_R, 72 * N);
+  memcpy(h + o_p, st->clone_p, 24 * N);
+  memcpy(h + o_Rf, st->clone_R_fej, 72 * N);
+  memcpy(h + o_pf, st->clone_p_fej, 24 * N);
+  int *ccol = (int *)(h + o_ccol);
+  for (int i = 0; i < N; ++i) ccol[i] = col_of(st->clone_state_id[i]);
+  for (int l = 0; l < L; ++l)
+    if (lt->obs_ptr[l + 1] < lt->obs_ptr[l]) return PLV_E_BADARG;
+  memcpy(h + o_ptr, lt->obs_ptr, 4 * (L + 1));
+  memcpy(h + o_ot, lt->obs_time, 8 * nobs);
+  memcpy(h + o_uv, lt->seg_uv, 16 * nobs);
+  if (lt->seg_uvn) memcpy(h + o_uvn, lt->seg_uvn, 16 * nobs);
+  if (lt->line_FinG) memcpy(h + o_lg, lt->line_FinG, 48 * L);
+  if (lt->D) memcpy(h + o_D, lt->D, 4 * L);
+  if (lt->has_pt) {
+    memcpy(h + o_ap, lt->anchor_pt, 24 * L);
+    memcpy(h + o_hp, lt->has_pt, L);
+  }
+  if (lt->res_R) {
+    memcpy(h + o_rR, lt->res_R, 72 * nobs);
+    memcpy(h + o_rp, lt->res_p, 24 * nobs);
+  }
+  PLV_HIP_CHECK(hipMemcpyAsync(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  const char *d = us->jin.as<char>();
+  P.n_clones = N;
+  P.clone_time = (const double *)(d + o_time);
+  P.clone_R = (const double *)(d + o_R);
+  P.clone_p = (const double *)(d + o_p);
+  P.clone_R_fej = (const double *)(d + o_Rf);
+  P.clone_p_fej = (const double *)(d + o_pf);
+  P.clone_col = (const int *)(d + o_ccol);
+  memcpy(P.R_ItoC, st->R_ItoC, 72);
+  memcpy(P.p_IinC, st->p_IinC, 24);
+  memcpy(P.K, st->intrinsics, 64);
+  P.cam_dt = st->cam_dt;
+  P.dt_exp = st->dt_exp;
+  P.sigma_pix = st->sigma_pix;
+  P.intr_ori_cov = st->intr_ori_cov;
+  P.intr_pos_cov = st->intr_pos_cov;
+  P.use_pol_cov = st->use_pol_cov;
+  P.feat_rep = st->feat_rep;
+  P.col_ext = P.col_int = -1;
+  P.col_dt = col_of(st->dt_state_id);
+  P.n_feat = L;
+  P.n_obs = nobs;
+  P.obs_ptr = (const int *)(d + o_ptr);
+  P.obs_time = (const double *)(d + o_ot);
+  P.seg_uv = (const float *)(d + o_uv);
+  P.seg_uvn = lt->seg_uvn ? (const float *)(d + o_uvn) : nullptr;
+  P.line_FinG = lt->line_FinG ? (const double *)(d + o_lg) : nullptr;
+  P.lineD = lt->D ? (const int *)(d + o_D) : nullptr;
+  P.anchor_pt = lt->has_pt ? (const double *)(d + o_ap) : nullptr;
+  P.has_pt = lt->has_pt ? (const unsigned char *)(d + o_hp) : nullptr;
+  P.res_R = lt->res_R ? (const double *)(d + o_rR) : nullptr;
+  P.res_p = lt->res_R ? (const double *)(d + o_rp) : nullptr;
+  P.k = k;
+  P.ld = ld;
+  return PLV_OK;
+}
+
+int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                          const int *col_to_state, int ld) {
+  TRY(check_line_views(st, lt, true, false));
+  if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
+  const int L = lt->n_lines;
+  const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
+  TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
+  TRY(us->brows.reserve((size_t)L * 4));
+  TRY(us->bcols.reserve((size_t)k * 4));
+  JacParams P{};
+  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P));
+  PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  P.rows = us->brows.as<int>();
+  P.Hf = us->bHf.as<double>();
+  P.Hx = P.Hf + nHf;
+  P.res = P.Hx + nHx;
+  TRY(launch_line_jacobians(ctx, P));
+  us->bF = L;
+  us->bfdim = 6;
+  us->bk = k;
+  us->bld = ld;
+  us->bmaxrows = ld;
+  us->b_on_device_rows = true;
+  return PLV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plv_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *lt, int *col_to_state, int cap, int *k_out) {
+  if (!col_to_state || !k_out) return PLV_E_BADARG;
+  TRY(check_line_views(st, lt, false, false));
+  int k = 0;
+  auto push = [&](int id, int size) {
+    if (id < 0) return true;
+    for (int j = 0; j < k; ++j)
+      if (col_to_state[j] == id) return true;
+    if (k + size > cap) return false;
+    for (int d = 0; d < size; ++d) col_to_state[k++] = id + d;
+    return true;
+  };
+  // REF: LineHelper.cpp:757-788 — `order` of get_interpolated_jacobian: four poses, then the time offset
+  for (int l = 0; l < lt->n_lines; ++l)
+    for (int o = lt->obs_ptr[l]; o < lt->obs_ptr[l + 1]; ++o) {
+      const int s0 = bounding_start_host(*st, lt->obs_time[o] + st->cam_dt);
+      if (s0 < 0) continue;
+      for (int w = 0; w < 4; ++w)
+        if (!push(st->clone_state_id[s0 + w], 6)) return PLV_E_CAPACITY;
+      if (!push(st->dt_state_id, 1)) return PLV_E_CAPACITY;
+    }
+  *k_out = k;
+  return PLV_OK;
+}
+
+int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                                      const int *col_to_state, int ld) {
+  if (!ctx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld));
+  us->b_single_use = true;
+  return PLV_OK;
+}
+
+int plv_build_line_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, int k,
+                             const int *col_to_state, int ld, int *rows, double *Hf, double *Hx, double *res) {
+  if (!ctx || !rows || !Hf || !Hx || !res) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld));
+  us->b_single_use = false;
+  const int L = lt->n_lines;
+  const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
+  const double *d = us->bHf.as<double>();
+  PLV_HIP_CHECK(hipMemcpyAsync(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(rows, us->brows.p, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
+int plv_triangulate_lines(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, double *line_FinG,
+                          uint8_t *ok) {
+  if (!ctx || !line_FinG || !ok) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  TRY(check_line_views(st, lt, false, true));
+  const int L = lt->n_lines, nobs = lt->obs_ptr[L];
+  int dummy_cols[1] = {-1};
+  JacParams P{};
+  TRY(stage_line_inputs(ctx, us, st, lt, 0, dummy_cols, 2, P));
+  const size_t o_cam = 0, o_imu = (size_t)nobs * 96, o_lines = o_imu + (size_t)nobs * 96, o_valid = o_lines + (size_t)L * 48,
+               o_ok = o_valid + ((nobs + 15) & ~(size_t)15), total = o_ok + L + 16;
+  TRY(us->tri.reserve(total));
+  char *d = us->tri.as<char>();
+  TRY(launch_triangulate_lines(ctx, P, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
+                               (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
+  PLV_HIP_CHECK(hipMemcpyAsync(line_FinG, d + o_lines, (size_t)L * 48, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(ok, d + o_ok, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
+}  // extern "C"

@@ -460,7 +460,7 @@ __device__ void jacobian_rows(const JacParams &P, int f, int o, int s0, double t
 //   FeatureInitializer::single_gaussnewton            REF: OV/feat/FeatureInitializer.cpp:197-375
 //   CamHelper::moving_consistency (mean reprojection) REF: PL/update/cam/CamHelper.cpp:426-483
 __global__ void __launch_bounds__(64) campose_kernel(JacParams P, double *__restrict__ poses /*[n_obs][12]*/,
-                                                     unsigned char *__restrict__ valid) {
+                                                     unsigned char *__restrict__ valid, double *__restrict__ imu = nullptr) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= P.n_obs) return;
   const double tm = P.obs_time[o] + P.cam_dt;
@@ -477,6 +477,12 @@ __global__ void __launch_bounds__(64) campose_kernel(JacParams P, double *__rest
     interpolate(P, s0, tm, false, false, est);
     R_GtoI = est.R;
     p_IinG = est.p;
+  }
+  if (imu) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) imu[12 * o + i] = R_GtoI.m[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) imu[12 * o + 9 + i] = p_IinG[i];
   }
   const M3 R_GtoC = mm(ldM(P.R_ItoC), R_GtoI);
   const V3 p_CinG = vsub(p_IinG, mv(tp(R_GtoC), ldV(P.p_IinC)));
@@ -710,11 +716,319 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const doub
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ lines
+// a28: LineHelper::get_line_feature_jacobian_full   REF: PL-VIWO/src/update/cam/linefeat/LineHelper.cpp:733-1024
+// (point-line coupling off, UpdaterCamera.cpp:373).  One workgroup per line, one lane per
+// observation, same slot / zero-fill scheme as jacobian_kernel.  The reference's arithmetic is
+// kept: dz/dl starts from Identity(2,3) (third column stays zero) and ln_2 = l0^2 + l1 + l1 (:921-928);
+// the pose written back by get_interpolated_jacobian (first estimates) feeds dli_dI (:898,940-945)
+// while G_to_I keeps the estimate pose (:846-850).
+__device__ __forceinline__ V3 cross3(const V3 &a, const V3 &b) {
+  return V3{{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
+}
+__device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs) {
+  const int ld = P.ld;
+  const M3 R_ItoC = ldM(P.R_ItoC);
+  const V3 p_IinC = ldV(P.p_IinC);
+  const double *Kc = P.K;
+  const double Kl[9] = {Kc[1], 0, 0, 0, Kc[0], 0, -Kc[1] * Kc[2], -Kc[0] * Kc[3], Kc[0] * Kc[1]};
+  const V3 nG = ldV(P.line_FinG + 6 * l), vG = ldV(P.line_FinG + 6 * l + 3);
+  Interp jac;
+  interpolate(P, s0, tm, true, true, jac);
+  M3 Re;
+  V3 pe;
+  if (P.res_R) {
+    Re = ldM(P.res_R + 9 * o);
+    pe = ldV(P.res_p + 3 * o);
+  } else {
+    Interp est;
+    interpolate(P, s0, tm, false, false, est);
+    Re = est.R;
+    pe = est.p;
+  }
+  const M3 Rsk = ms(mm(Re, skew3(pe)), -1.0);
+  const V3 nI = vadd(mv(Re, nG), mv(Rsk, vG)), vI = mv(Re, vG);
+  const M3 SR = mm(skew3(p_IinC), R_ItoC);
+  const V3 nC = vadd(mv(R_ItoC, nI), mv(SR, vI));
+  const double l3[3] = {Kl[0] * nC[0] + Kl[1] * nC[1] + Kl[2] * nC[2], Kl[3] * nC[0] + Kl[4] * nC[1] + Kl[5] * nC[2],
+                        Kl[6] * nC[0] + Kl[7] * nC[1] + Kl[8] * nC[2]};
+  const double us[3] = {(double)P.seg_uv[4 * o], (double)P.seg_uv[4 * o + 1], 1.0};
+  const double ue[3] = {(double)P.seg_uv[4 * o + 2], (double)P.seg_uv[4 * o + 3], 1.0};
+  const double lnorm = sqrt(l3[0] * l3[0] + l3[1] * l3[1]);
+  const double ds = us[0] * l3[0] + us[1] * l3[1] + us[2] * l3[2], de = ue[0] * l3[0] + ue[1] * l3[1] + ue[2] * l3[2];
+  const double r2[2] = {ds / lnorm, de / lnorm};
+  const double ln_2 = l3[0] * l3[0] + l3[1] + l3[1];
+  double dzl[6] = {1, 0, 0, 0, 1, 0};
+  dzl[0] = us[0] - (l3[0] * ds) / ln_2;
+  dzl[1] = us[1] - (l3[1] * ds) / ln_2;
+  dzl[3] = ue[0] - (l3[0] * de) / ln_2;
+  dzl[4] = ue[1] - (l3[1] * de) / ln_2;
+  const double isq = 1 / sqrt(ln_2);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dzl[i] *= isq;
+  double dzK[6], dzli[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dzK[3 * i + j] = dzl[3 * i] * Kl[j] + dzl[3 * i + 1] * Kl[3 + j] + dzl[3 * i + 2] * Kl[6 + j];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dzli[6 * i + j] = dzK[3 * i] * R_ItoC(0, j) + dzK[3 * i + 1] * R_ItoC(1, j) + dzK[3 * i + 2] * R_ItoC(2, j);
+      dzli[6 * i + 3 + j] = dzK[3 * i] * SR(0, j) + dzK[3 * i + 1] * SR(1, j) + dzK[3 * i + 2] * SR(2, j);
+    }
+  const M3 Rf = jac.R;
+  const V3 pf = jac.p;
+  const M3 A00 = skew3(mv(Rf, vsub(nG, mv(skew3(pf), vG)))), A30 = skew3(mv(Rf, vG)), A03 = mm(Rf, skew3(vG));
+  // HI = dzli * dli_dI, dli_dI = [A00 A03; A30 0]
+  double HI[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double so = 0, sp = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += dzli[6 * i + q] * A00(q, j);
+        sp += dzli[6 * i + q] * A03(q, j);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += dzli[6 * i + 3 + q] * A30(q, j);
+        sp += dzli[6 * i + 3 + q] * 0.0;
+      }
+      HI[6 * i + j] = so;
+      HI[6 * i + 3 + j] = sp;
+    }
+  double Rn[4] = {P.sigma_pix * P.sigma_pix, 0, 0, P.sigma_pix * P.sigma_pix};
+  bool at_clone = false;
+  for (int i = 0; i < P.n_clones; ++i) at_clone = at_clone || P.clone_time[i] == tm;
+  if (!at_clone && P.use_pol_cov) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
+        Rn[2 * i + j] += s;
+      }
+  }
+  const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
+  const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
+  double Wm[4];
+#pragma unroll
+  for (int col = 0; col < 2; ++col) {
+    const double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+    const double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
+    const double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
+    Wm[col] = x0;
+    Wm[2 + col] = x1;
+  }
+  rs[2 * c] = Wm[0] * r2[0] + Wm[1] * r2[1];
+  rs[2 * c + 1] = Wm[2] * r2[0] + Wm[3] * r2[1];
+  double wli[12];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    wli[j] = Wm[0] * dzli[j] + Wm[1] * dzli[6 + j];
+    wli[6 + j] = Wm[2] * dzli[j] + Wm[3] * dzli[6 + j];
+  }
+  // Hf = wli * G_to_I, G_to_I = [Re Rsk; 0 Re]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double a = 0, b = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a += wli[6 * i + q] * Re(q, j);
+        b += wli[6 * i + q] * Rsk(q, j);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a += wli[6 * i + 3 + q] * 0.0;
+        b += wli[6 * i + 3 + q] * Re(q, j);
+      }
+      hf[(size_t)j * ld + 2 * c + i] = a;
+      hf[(size_t)(3 + j) * ld + 2 * c + i] = b;
+    }
+  double WI[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double so = 0, sp = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += wli[6 * i + q] * A00(q, j);
+        sp += wli[6 * i + q] * A03(q, j);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += wli[6 * i + 3 + q] * A30(q, j);
+        sp += wli[6 * i + 3 + q] * 0.0;
+      }
+      WI[6 * i + j] = so;
+      WI[6 * i + 3 + j] = sp;
+    }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int col = P.clone_col[s0 + w];
+    if (col < 0) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
+        hx[(size_t)(col + j) * ld + 2 * c + i] += so;
+        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += WI[6 * i + 3 + j] * jac.lam[w];
+      }
+  }
+  if (P.col_dt >= 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
+      hx[(size_t)P.col_dt * ld + 2 * c + i] += s;
+    }
+}
+
+__global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
+  const int l = blockIdx.x;
+  const int ld = P.ld, k = P.k;
+  double *hf = P.Hf + (size_t)l * 6 * ld, *hx = P.Hx + (size_t)l * k * ld, *rs = P.res + (size_t)l * ld;
+  for (int i = threadIdx.x; i < 6 * ld; i += 64) hf[i] = 0.0;
+  for (int i = threadIdx.x; i < k * ld; i += 64) hx[i] = 0.0;
+  for (int i = threadIdx.x; i < ld; i += 64) rs[i] = 0.0;
+  __syncthreads();
+  const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
+  int base = 0;
+  for (int ob = o0; ob < o1; ob += 64) {
+    const int o = ob + threadIdx.x;
+    const bool have = o < o1;
+    const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
+    const int s0 = have ? bounding_start(P, tm) : -1;
+    const unsigned long long vmask = __ballot(s0 >= 0);
+    const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
+    base += __popcll(vmask);
+    if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, hf, hx, rs);
+  }
+  if (threadIdx.x == 0) P.rows[l] = 2 * base;
+}
+
+// a27: LineHelper::line_triangulation   REF: LineHelper.cpp:202-293, 372-495, 615-650.  Thread per line;
+// camera / IMU poses of every observation come from campose_kernel.
+__global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, const double *__restrict__ cam,
+                                                              const double *__restrict__ imu,
+                                                              const unsigned char *__restrict__ valid,
+                                                              double *__restrict__ out, unsigned char *__restrict__ ok) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= P.n_feat) return;
+  ok[l] = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[6 * l + i] = 0.0;
+  const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
+  int first = -1, nvalid = 0;
+  for (int o = o0; o < o1; ++o)
+    if (valid[o]) {
+      if (first < 0) first = o;
+      ++nvalid;
+    }
+  if (nvalid < 2) return;
+  const int D = P.lineD ? P.lineD[l] : 0;
+  if (D > 0 && P.has_pt && P.has_pt[l]) {
+    const M3 R = ldM(imu + 12 * first);
+    const V3 e{{D == 1 ? 1.0 : 0.0, D == 2 ? 1.0 : 0.0, D == 3 ? 1.0 : 0.0}};
+    const V3 dir = mv(tp(R), e);
+    const V3 mom = cross3(ldV(P.anchor_pt + 3 * l), dir);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      out[6 * l + i] = mom[i];
+      out[6 * l + 3 + i] = dir[i];
+    }
+    ok[l] = 1;
+    return;
+  }
+  const M3 R0 = ldM(cam + 12 * first);
+  const V3 p0 = ldV(cam + 12 * first + 9);
+  const float *u0 = P.seg_uvn + 4 * first;
+  const V3 p11{{(double)u0[0], (double)u0[1], 1.0}}, p12{{(double)u0[2], (double)u0[3], 1.0}};
+  // plane through (a, b, c3): [ (a-c3) x (b-c3), -c3 . (a x b) ]
+  const V3 n0 = cross3(p11, p12);
+  const double pl0[4] = {n0[0], n0[1], n0[2], 0.0};  // the first camera centre is the origin of its own frame
+  V3 dsum{{0, 0, 0}}, nsum{{0, 0, 0}};
+  double dnorm = 0;
+  int cnt = 0;
+  for (int o = first + 1; o < o1; ++o) {
+    if (!valid[o]) continue;
+    const M3 Ri = ldM(cam + 12 * o);
+    const V3 pi = ldV(cam + 12 * o + 9);
+    const M3 R0i = mm(Ri, tp(R0));
+    const V3 pi0 = mv(R0, vsub(pi, p0));
+    const float *um = P.seg_uvn + 4 * o;
+    V3 p31{{(double)um[0], (double)um[1], 1.0}}, p32{{(double)um[2], (double)um[3], 1.0}};
+    p31 = vadd(mv(tp(R0i), p31), pi0);
+    p32 = vadd(mv(tp(R0i), p32), pi0);
+    const V3 nn = cross3(vsub(p31, pi0), vsub(p32, pi0));
+    const double pl1[4] = {nn[0], nn[1], nn[2], -dot3(pi0, cross3(p31, p32))};
+    V3 n1{{pl0[0], pl0[1], pl0[2]}}, n2{{pl1[0], pl1[1], pl1[2]}};
+    n1 = vsc(n1, 1 / vnorm(n1));
+    n2 = vsc(n2, 1 / vnorm(n2));
+    const double cth = dot3(n1, n2) / (vnorm(n1) * vnorm(n2));
+    if (fabs(cth) >= 0.99) continue;
+#define PLV_DP(i, j) (pl0[i] * pl1[j] - pl1[i] * pl0[j])
+    const V3 head{{PLV_DP(0, 3), PLV_DP(1, 3), PLV_DP(2, 3)}}, tail{{-PLV_DP(1, 2), PLV_DP(0, 2), -PLV_DP(0, 1)}};
+#undef PLV_DP
+    dsum = vadd(dsum, tail);
+    nsum = vadd(nsum, head);
+    dnorm += vnorm(tail);
+    ++cnt;
+  }
+  if (cnt == 0) return;
+  const V3 rhead = vsc(dsum, 1 / dnorm), rtail = vsc(nsum, 1.0 / cnt);
+  const M3 R0t = tp(R0);
+  const V3 vW = mv(R0t, rhead);
+  const V3 nW = vadd(mv(R0t, rtail), mv(skew3(p0), mv(R0t, rhead)));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out[6 * l + i] = nW[i];
+    out[6 * l + 3 + i] = vW[i];
+  }
+  ok[l] = 1;
+}
+
+int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
+  ProfScope ps(ctx->prof, "line_jacobian_kernel", ctx->stream);
+  hipLaunchKernelGGL(line_jacobian_kernel, dim3(P.n_feat), dim3(64), 0, ctx->stream, P);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
+                             double *d_lines, unsigned char *d_ok) {
+  {
+    ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
+    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, d_imu);
+  }
+  {
+    ProfScope ps(ctx->prof, "line_triangulate_kernel", ctx->stream);
+    hipLaunchKernelGGL(line_triangulate_kernel, dim3((P.n_feat + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_imu, d_valid,
+                       d_lines, d_ok);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
                        const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err) {
   {
     ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
-    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid);
+    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, (double *)nullptr);
   }
   {
     ProfScope ps(ctx->prof, "triangulate_kernel", ctx->stream);

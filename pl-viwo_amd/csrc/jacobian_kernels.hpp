@@ -19,6 +19,11 @@ struct JacParams {
   const double *obs_time;
   const float *obs_uv;
   const double *p_FinG, *p_FinG_fej, *res_R, *res_p;
+  // line tracks (plv_line_tracks): obs_ptr / obs_time / res_R / res_p are shared with the point view
+  const float *seg_uv, *seg_uvn;
+  const double *line_FinG, *anchor_pt;
+  const int *lineD;
+  const unsigned char *has_pt;
   // outputs
   int k, ld;
   int *rows;
@@ -26,6 +31,9 @@ struct JacParams {
 };
 
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
+int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
+int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
+                             double *d_lines, unsigned char *d_ok);
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
                        const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err);
 

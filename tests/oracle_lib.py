@@ -301,6 +301,37 @@ class JacOracle:
         lib.orc_triangulate.restype = C.c_int
         lib.orc_triangulate_batch.argtypes = [sv, tk, C.POINTER(pkg.PlvTriOptions), dp, u8p, dp]
         lib.orc_triangulate_batch.restype = C.c_int
+        lk = C.POINTER(pkg.PlvLineTracks)
+        lib.orc_line_jacobian_columns.argtypes = [sv, lk, ip, C.c_int, ip]
+        lib.orc_line_jacobian_columns.restype = C.c_int
+        lib.orc_build_line_jacobians.argtypes = [sv, lk, C.c_int, ip, C.c_int, ip, dp, dp, dp]
+        lib.orc_build_line_jacobians.restype = C.c_int
+        lib.orc_triangulate_lines.argtypes = [sv, lk, dp, u8p]
+        lib.orc_triangulate_lines.restype = C.c_int
+
+    def line_columns(self, st, lt, cap=512):
+        cols = np.zeros(cap, dtype=np.int32)
+        k = C.c_int()
+        rc = self.lib.orc_line_jacobian_columns(C.byref(st.c), C.byref(lt.c), _ip(cols), cap, C.byref(k))
+        assert rc == 0
+        return cols[:k.value].copy()
+
+    def build_line_jacobians(self, st, lt, cols, ld):
+        L, k = lt.c.n_lines, len(cols)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        rows = np.zeros(L, dtype=np.int32)
+        Hf, Hx, res = np.zeros((L, 6, ld)), np.zeros((L, k, ld)), np.zeros((L, ld))
+        rc = self.lib.orc_build_line_jacobians(C.byref(st.c), C.byref(lt.c), k, _ip(cols), ld, _ip(rows), _dp(Hf), _dp(Hx),
+                                               _dp(res))
+        assert rc == 0, rc
+        return rows, Hf, Hx, res
+
+    def triangulate_lines(self, st, lt):
+        L = lt.c.n_lines
+        out, ok = np.zeros((L, 6)), np.zeros(L, dtype=np.uint8)
+        rc = self.lib.orc_triangulate_lines(C.byref(st.c), C.byref(lt.c), _dp(out), ok.ctypes.data_as(u8p))
+        assert rc == 0
+        return out, ok
 
     def columns(self, st, tr, cap=512):
         cols = np.zeros(cap, dtype=np.int32)

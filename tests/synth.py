@@ -205,3 +205,42 @@ def scene_views(pkg, sc, p_FinG=None, sigma_pix=1.5, **kw):
                        clone_p_fej=sc["pf"], intrinsic_state_id=sc["intr_id"], sigma_pix=sigma_pix, **kw)
     tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"] if p_FinG is None else p_FinG)
     return st, tr
+
+
+def line_scene(sc, L=40, M=15, seed=5, noise_px=0.5, w=752, h=480, depth=(6.0, 40.0)):
+    """3-D line segments seen from the clones of a vio_scene: per observation the raw pixel end points
+    (pinhole projection: the reference's line model uses K only, LineHelper.cpp:861-864) and the
+    normalised end points.  The visible end points slide along the line from view to view, as a
+    detector's would.  Returns plain numpy arrays."""
+    rng = np.random.default_rng(seed)
+    K8, R_ItoC, p_IinC = sc["K8"], sc["R_ItoC"], sc["p_IinC"]
+    n_clones = len(sc["t"])
+    lines, obs_ptr, obs_time, seg_uv, seg_uvn = [], [0], [], [], []
+    while len(lines) < L:
+        a = np.array([rng.uniform(-15, 15), rng.uniform(-10, 10), rng.uniform(*depth)])
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        half = rng.uniform(1.0, 4.0)
+        m = M if len(lines) % 3 else max(3, M - int(rng.integers(0, M // 2 + 1)))
+        rows, ok = [], True
+        for ci in range(n_clones - m, n_clones):
+            R, p = sc["R"][ci], sc["p"][ci]
+            ends = []
+            for sgn in (-1.0, 1.0):
+                P3 = a + sgn * half * (1 + 0.1 * rng.uniform(-1, 1)) * d
+                pc = R_ItoC @ (R @ (P3 - p)) + p_IinC
+                xn = pc[:2] / pc[2]
+                uv = np.array([K8[0] * xn[0] + K8[2], K8[1] * xn[1] + K8[3]])
+                ok = ok and pc[2] > 1 and 5 < uv[0] < w - 5 and 5 < uv[1] < h - 5
+                ends.append((uv, xn))
+            rows.append((sc["t"][ci], np.concatenate([ends[0][0], ends[1][0]]), np.concatenate([ends[0][1], ends[1][1]])))
+        if not ok:
+            continue
+        for tm, uv, xn in rows:
+            obs_time.append(tm)
+            seg_uv.append(uv + rng.normal(0, noise_px, 4))
+            seg_uvn.append(xn + rng.normal(0, noise_px / K8[0], 4))
+        obs_ptr.append(len(obs_time))
+        lines.append(np.concatenate([np.cross(a, d), d]))  # Pluecker: moment, direction
+    return dict(lines=np.array(lines), obs_ptr=np.array(obs_ptr, np.int32), obs_time=np.array(obs_time),
+                seg_uv=np.array(seg_uv, np.float32), seg_uvn=np.array(seg_uvn, np.float32))
