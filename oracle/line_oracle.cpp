@@ -1,0 +1,503 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under pl-viwo_amd/ may include, link or call this file;
+// only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+// PARITY UNPINNED: the reference holds no golden vectors for its line front-end, and its line
+// detector is a third-party dependency that is absent from /root/reference:
+//   cv::ximgproc::FastLineDetector (OpenCV contrib 4.2, `find_package(OpenCV 4)`), called at
+//   PL-VIWO/src/update/cam/TrackLSD.cpp:200-205 with (length 20, distance sqrt(2), canny 50/50,
+//   aperture 3, no merge) on the half-resolution image (cv::resize 0.5 INTER_LINEAR).
+// This file restates the published algorithm of that detector (Lee et al., "Outdoor place
+// recognition in urban environments using straight lines", ICRA 2014: Canny -> 8-neighbour chain
+// walking with a running direction -> incremental least-squares segment growing) and of cv::Canny
+// (L1 gradient, 3x3 Sobel with replicated border, fixed-point direction test), and the in-tree
+// logic around it, each function citing what it follows:
+//   TrackLSD::perform_detection_monocular   REF: TrackLSD.cpp:194-235 (+ FilterShortLines :435-448)
+//   TrackLSD::AssignPointToLines            REF: TrackLSD.cpp:744-792 (incl. the x1,y1,x2,y2 -> lx1,lx2,ly1,ly2 mix-up)
+//   TrackLSD::PointLineDistance / LineSimilar   REF: :794-830
+//   TrackLSD::LineMatch                     REF: :368-407
+//   TrackLSD::LineClassification / LineClass    REF: :318-366 (incl. atan(dy)/dx)
+//   LineHelper::Vanishing_Points / Distort  REF: linefeat/LineHelper.cpp:1026-1088
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace {
+
+struct Pt {
+  int x, y;
+};
+struct Seg {
+  float x1, y1, x2, y2;
+};
+
+// cv::resize(src, dst, Size(), 0.5, 0.5, INTER_LINEAR) on 8-bit: an exact 2x decimation is routed to the
+// area path, (a + b + c + d + 2) >> 2.
+void resize_half(const uint8_t *src, int w, int h, uint8_t *dst) {
+  const int w2 = w / 2, h2 = h / 2;
+  for (int y = 0; y < h2; ++y)
+    for (int x = 0; x < w2; ++x) {
+      const uint8_t *p = src + (size_t)(2 * y) * w + 2 * x;
+      dst[(size_t)y * w2 + x] = (uint8_t)((p[0] + p[1] + p[w] + p[w + 1] + 2) >> 2);
+    }
+}
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cv::Canny(src, dst, low, high, 3, L2gradient=false)
+void canny(const uint8_t *src, int w, int h, int low, int high, uint8_t *dst) {
+  if (low > high) std::swap(low, high);
+  std::vector<short> dx((size_t)w * h), dy((size_t)w * h);
+  std::vector<int> mag((size_t)(w + 2) * (h + 2), 0);  // one pixel of zero border
+  auto S = [&](int x, int y) { return (int)src[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)]; };  // BORDER_REPLICATE
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int gx = (S(x + 1, y - 1) - S(x - 1, y - 1)) + 2 * (S(x + 1, y) - S(x - 1, y)) + (S(x + 1, y + 1) - S(x - 1, y + 1));
+      const int gy = (S(x - 1, y + 1) - S(x - 1, y - 1)) + 2 * (S(x, y + 1) - S(x, y - 1)) + (S(x + 1, y + 1) - S(x + 1, y - 1));
+      dx[(size_t)y * w + x] = (short)gx;
+      dy[(size_t)y * w + x] = (short)gy;
+      mag[(size_t)(y + 1) * (w + 2) + x + 1] = std::abs(gx) + std::abs(gy);
+    }
+  // map: 0 = weak candidate, 1 = suppressed, 2 = edge
+  std::vector<uint8_t> map((size_t)w * h, 1);
+  std::vector<int> stack;
+  const int TG22 = 13573;  // tan(22.5 deg) * 2^15
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int *mp = &mag[(size_t)y * (w + 2) + x + 1], *ma = mp + (w + 2), *mn = ma + (w + 2);
+      const int m = ma[0];
+      if (m <= low) continue;
+      const int xs = dx[(size_t)y * w + x], ys = dy[(size_t)y * w + x];
+      const int ax = std::abs(xs), ay = std::abs(ys) << 15;
+      const int tg22x = ax * TG22;
+      bool keep = false;
+      if (ay < tg22x)
+        keep = m > ma[-1] && m >= ma[1];
+      else {
+        const int tg67x = tg22x + (ax << 16);
+        if (ay > tg67x)
+          keep = m > mp[0] && m >= mn[0];
+        else {
+          const int s = (xs ^ ys) < 0 ? -1 : 1;
+          keep = m > mp[-s] && m > mn[s];
+        }
+      }
+      if (!keep) continue;
+      if (m > high) {
+        map[(size_t)y * w + x] = 2;
+        stack.push_back(y * w + x);
+      } else {
+        map[(size_t)y * w + x] = 0;
+      }
+    }
+  while (!stack.empty()) {  // hysteresis (a no-op when low == high)
+    const int p = stack.back();
+    stack.pop_back();
+    const int py = p / w, px = p - py * w;
+    for (int ddy = -1; ddy <= 1; ++ddy)
+      for (int ddx = -1; ddx <= 1; ++ddx) {
+        const int qx = px + ddx, qy = py + ddy;
+        if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
+        if (map[(size_t)qy * w + qx] == 0) {
+          map[(size_t)qy * w + qx] = 2;
+          stack.push_back(qy * w + qx);
+        }
+      }
+  }
+  for (size_t i = 0; i < (size_t)w * h; ++i) dst[i] = map[i] == 2 ? 255 : 0;
+}
+
+// ---- FastLineDetector pieces
+struct Line3 {
+  double a, b, c;
+};
+inline Line3 cross3(double ax, double ay, double az, double bx, double by, double bz) {
+  return Line3{ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
+}
+// distPointLine: normalises the line in place, returns the signed distance
+inline double dist_point_line(double px, double py, Line3 &l) {
+  const double wv = std::sqrt(l.a * l.a + l.b * l.b);
+  l.a /= wv;
+  l.b /= wv;
+  l.c /= wv;
+  return l.a * px + l.b * py + l.c;
+}
+// cv::fitLine(points, DIST_L2, 0, 0.01, 0.01) on integer points: principal axis through the centroid.
+// Sums of integer coordinates and products are exact in double, so running integer sums reproduce it.
+struct FitSums {
+  long long n = 0, sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+  void add(const Pt &p) {
+    ++n;
+    sx += p.x;
+    sy += p.y;
+    sxx += (long long)p.x * p.x;
+    syy += (long long)p.y * p.y;
+    sxy += (long long)p.x * p.y;
+  }
+  void fit(float line[4]) const {
+    const double wv = (double)(float)n;
+    const double x = (double)sx / wv, y = (double)sy / wv, x2 = (double)sxx / wv, y2 = (double)syy / wv, xy = (double)sxy / wv;
+    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
+    const float t = (float)std::atan2(2 * dxy, dx2 - dy2) / 2;
+    line[0] = (float)std::cos(t);
+    line[1] = (float)std::sin(t);
+    line[2] = (float)x;
+    line[3] = (float)y;
+  }
+};
+inline Line3 line_from_fit(const float f[4]) {
+  // p1 = (x0, y0, 1), p2 = (x0 + vx, y0 + vy, 1) in double from the float fit
+  const double ax = f[2], ay = f[3], bx = (double)f[2] + (double)f[0], by = (double)f[3] + (double)f[1];
+  return cross3(ax, ay, 1.0, bx, by, 1.0);
+}
+// incidentPoint: foot of the perpendicular from pt on l, clamped to the image
+template <class T> void incident_point(const Line3 &l, T &px, T &py, int imw, int imh) {
+  const double a[3] = {(double)px, (double)py, 1.0}, b[3] = {l.a, l.b, 0.0};
+  const Line3 lk = cross3(a[0], a[1], a[2], b[0], b[1], b[2]);
+  Line3 xk = cross3(lk.a, lk.b, lk.c, l.a, l.b, l.c);
+  const double s = 1.0 / xk.c;
+  xk.a *= s;
+  xk.b *= s;
+  const float fx = (float)xk.a, fy = (float)xk.b;
+  const float cx = fx < 0.0f ? 0.0f : (fx >= (imw - 1.0f) ? (imw - 1.0f) : fx);
+  const float cy = fy < 0.0f ? 0.0f : (fy >= (imh - 1.0f) ? (imh - 1.0f) : fy);
+  px = (T)cx;  // Point2i target: truncation of the clamped float (cv::Point_<int>(Point2f) saturate-casts = rounds)
+  py = (T)cy;
+}
+inline int cv_round(double v) { return (int)std::nearbyint(v); }
+template <> void incident_point<int>(const Line3 &l, int &px, int &py, int imw, int imh) {
+  float fx = (float)px, fy = (float)py;
+  incident_point<float>(l, fx, fy, imw, imh);
+  px = cv_round(fx);  // Point2i(Point2f) uses saturate_cast<int> = cvRound
+  py = cv_round(fy);
+}
+
+bool get_point_chain(const uint8_t *img, int w, int h, Pt pt, Pt &out, float &direction, int step) {
+  static const int idx[8][2] = {{1, 1}, {1, 0}, {1, -1}, {0, -1}, {-1, -1}, {-1, 0}, {-1, 1}, {0, 1}};
+  float min_dir_diff = 7.0f;
+  Pt cons{0, 0};
+  int cons_dir = 0;
+  for (int i = 0; i < 8; ++i) {
+    const int ci = pt.x + idx[i][1], ri = pt.y + idx[i][0];
+    if (ri < 0 || ri == h || ci < 0 || ci == w) continue;
+    if (img[(size_t)ri * w + ci] == 0) continue;
+    if (step == 0) {
+      out = Pt{ci, ri};
+      direction = i > 4 ? (float)(i - 8) : (float)i;
+      return true;
+    }
+    const float curr = i > 4 ? (float)(i - 8) : (float)i;
+    float diff = std::fabs(curr - direction);
+    diff = diff > 4.0f ? 8.0f - diff : diff;
+    if (diff <= min_dir_diff) {
+      min_dir_diff = diff;
+      cons = Pt{ci, ri};
+      cons_dir = i > 4 ? i - 8 : i;
+    }
+  }
+  if (min_dir_diff < 2.0f) {
+    out = cons;
+    direction = (direction * (float)step + (float)cons_dir) / (float)(step + 1);
+    return true;
+  }
+  return false;
+}
+
+void extract_segments(const std::vector<Pt> &pts, int length_threshold, float distance_threshold, int imw, int imh,
+                      std::vector<Seg> &segs) {
+  const int total = (int)pts.size();
+  for (int i = 0; i + length_threshold < total; ++i) {
+    Pt ps = pts[i], pe = pts[i + length_threshold];
+    Line3 l = cross3(ps.x, ps.y, 1.0, pe.x, pe.y, 1.0);
+    bool is_line = true;
+    FitSums fs;
+    fs.add(ps);
+    for (int j = 1; j < length_threshold; ++j) {
+      const Pt pt = pts[i + j];
+      if (std::fabs(dist_point_line(pt.x, pt.y, l)) > distance_threshold) {
+        is_line = false;
+        break;
+      }
+      fs.add(pt);
+    }
+    if (!is_line) continue;
+    fs.add(pe);
+    float fl[4];
+    fs.fit(fl);
+    l = line_from_fit(fl);
+    incident_point<int>(l, ps.x, ps.y, imw, imh);
+    int j;
+    for (j = length_threshold + 1; i + j < total; ++j) {
+      const Pt pt = pts[i + j];
+      double dist = dist_point_line(pt.x, pt.y, l);
+      if (std::fabs(dist) > distance_threshold) {
+        fs.fit(fl);
+        l = line_from_fit(fl);
+        dist = dist_point_line(pt.x, pt.y, l);
+        if (std::fabs(dist) > distance_threshold) {
+          j--;
+          break;
+        }
+      }
+      pe = pt;
+      fs.add(pt);
+    }
+    fs.fit(fl);
+    l = line_from_fit(fl);
+    float e1x = (float)ps.x, e1y = (float)ps.y, e2x = (float)pe.x, e2y = (float)pe.y;
+    incident_point<float>(l, e1x, e1y, imw, imh);
+    incident_point<float>(l, e2x, e2y, imw, imh);
+    segs.push_back(Seg{e1x, e1y, e2x, e2y});
+    i = i + j;
+  }
+}
+
+inline void inboard(int &x, int &y, int w, int h) {
+  x = x <= 5 ? 5 : (x >= w - 5 ? w - 6 : x);
+  y = y <= 5 ? 5 : (y >= h - 5 ? h - 6 : y);
+}
+// additionalOperationsOnSegment: orient the segment by the brightness of its two sides
+void orient_segment(const uint8_t *src, int w, int h, Seg &s) {
+  if (s.x1 == 0.0f && s.x2 == 0.0f && s.y1 == 0.0f && s.y2 == 0.0f) return;
+  const double ang = (double)std::atan2(s.y2 - s.y1, s.x2 - s.x1);  // float atan2f promoted
+  const double dx = (double)s.x2 - (double)s.x1, dy = (double)s.y2 - (double)s.y1;
+  const int np = 10;
+  const double gap = 1.0;
+  const double ca = std::cos(90.0 * M_PI / 180.0 + ang), sa = std::sin(90.0 * M_PI / 180.0 + ang);
+  int iR = 0, iL = 0;
+  for (int i = 0; i < np; ++i) {
+    float px, py;
+    if (i == 0) {
+      px = s.x1;
+      py = s.y1;
+    } else if (i == np - 1) {
+      px = s.x2;
+      py = s.y2;
+    } else {
+      px = s.x1 + ((float)dx / (float)(np - 1) * (float)i);
+      py = s.y1 + ((float)dy / (float)(np - 1) * (float)i);
+    }
+    int rx = cv_round(px + gap * ca), ry = cv_round(py + gap * sa);
+    int lx = cv_round(px - gap * ca), ly = cv_round(py - gap * sa);
+    inboard(rx, ry, w, h);
+    inboard(lx, ly, w, h);
+    iR += src[(size_t)ry * w + rx];
+    iL += src[(size_t)ly * w + lx];
+  }
+  if (iR > iL) {
+    std::swap(s.x1, s.x2);
+    std::swap(s.y1, s.y2);
+  }
+}
+
+void fld_detect(const uint8_t *src, int w, int h, int length_threshold, float distance_threshold, int canny1, int canny2,
+                std::vector<Seg> &out, std::vector<uint8_t> *edges_out) {
+  std::vector<uint8_t> edges((size_t)w * h);
+  canny(src, w, h, canny1, canny2, edges.data());
+  // `canny.colRange(0,6).rowRange(0,6) = 0; canny.colRange(cols-5,cols).rowRange(rows-5,rows) = 0;`
+  for (int y = 0; y < 6 && y < h; ++y)
+    for (int x = 0; x < 6 && x < w; ++x) edges[(size_t)y * w + x] = 0;
+  for (int y = std::max(0, h - 5); y < h; ++y)
+    for (int x = std::max(0, w - 5); x < w; ++x) edges[(size_t)y * w + x] = 0;
+  if (edges_out) *edges_out = edges;
+  std::vector<Pt> points;
+  std::vector<Seg> segs;
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      if (edges[(size_t)r * w + c] == 0) continue;
+      Pt pt{c, r};
+      points.clear();
+      points.push_back(pt);
+      edges[(size_t)r * w + c] = 0;
+      float direction = 0.0f;
+      int step = 0;
+      while (get_point_chain(edges.data(), w, h, pt, pt, direction, step)) {
+        points.push_back(pt);
+        step++;
+        edges[(size_t)pt.y * w + pt.x] = 0;
+      }
+      if ((int)points.size() < length_threshold + 1) continue;
+      segs.clear();
+      extract_segments(points, length_threshold, distance_threshold, w, h, segs);
+      for (Seg s : segs) {
+        const float length = std::sqrt((s.x1 - s.x2) * (s.x1 - s.x2) + (s.y1 - s.y2) * (s.y1 - s.y2));
+        if (length < length_threshold) continue;
+        if ((s.x1 <= 5.0f && s.x2 <= 5.0f) || (s.y1 <= 5.0f && s.y2 <= 5.0f) || (s.x1 >= w - 5.0f && s.x2 >= w - 5.0f) ||
+            (s.y1 >= h - 5.0f && s.y2 >= h - 5.0f))
+          continue;
+        orient_segment(src, w, h, s);
+        out.push_back(s);
+      }
+    }
+}
+
+float point_line_distance(const float line[4], float x0, float y0) {  // REF: TrackLSD.cpp:794-814
+  const float x1 = line[0], y1 = line[1], x2 = line[2], y2 = line[3];
+  const float cross = (x2 - x1) * (x0 - x1) + (y2 - y1) * (y0 - y1);
+  if (cross <= 0) return std::sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1));
+  const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+  if (cross > d) return std::sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2));
+  return std::abs(std::fabs((y2 - y1) * x0 + (x1 - x2) * y0 + ((x2 * y1) - (x1 * y2))) /
+                  (std::sqrt(std::pow(y2 - y1, 2) + std::pow(x1 - x2, 2))));
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_resize_half(const uint8_t *src, int w, int h, uint8_t *dst) { resize_half(src, w, h, dst); }
+void orc_canny(const uint8_t *src, int w, int h, int low, int high, uint8_t *dst) { canny(src, w, h, low, high, dst); }
+
+// FastLineDetector::detect on an 8-bit image; returns the number of segments (up to cap written)
+int orc_fld(const uint8_t *src, int w, int h, int length_threshold, float distance_threshold, int canny1, int canny2, float *segs,
+            int cap, uint8_t *edges_out) {
+  std::vector<Seg> out;
+  std::vector<uint8_t> edges;
+  fld_detect(src, w, h, length_threshold, distance_threshold, canny1, canny2, out, edges_out ? &edges : nullptr);
+  if (edges_out) memcpy(edges_out, edges.data(), edges.size());
+  for (int i = 0; i < (int)out.size() && i < cap; ++i) {
+    segs[4 * i] = out[i].x1;
+    segs[4 * i + 1] = out[i].y1;
+    segs[4 * i + 2] = out[i].x2;
+    segs[4 * i + 3] = out[i].y2;
+  }
+  return (int)out.size();
+}
+
+// TrackLSD::perform_detection_monocular, numeric part (REF: TrackLSD.cpp:194-235): half-res, FLD, x2, drop
+// length^2 <= min_len^2.  `img` is the (equalised) full-resolution image.
+int orc_detect_lines(const uint8_t *img, int w, int h, int length_threshold, float distance_threshold, int canny1, int canny2,
+                     float min_len, float *lines, int cap) {
+  std::vector<uint8_t> half((size_t)(w / 2) * (h / 2));
+  resize_half(img, w, h, half.data());
+  std::vector<Seg> out;
+  fld_detect(half.data(), w / 2, h / 2, length_threshold, distance_threshold, canny1, canny2, out, nullptr);
+  int n = 0;
+  const float thr2 = min_len * min_len;
+  for (const Seg &s : out) {
+    const float x1 = s.x1 * 2, y1 = s.y1 * 2, x2 = s.x2 * 2, y2 = s.y2 * 2;
+    const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+    if (!(l2 > thr2)) continue;
+    if (n < cap) {
+      lines[4 * n] = x1;
+      lines[4 * n + 1] = y1;
+      lines[4 * n + 2] = x2;
+      lines[4 * n + 3] = y2;
+    }
+    ++n;
+  }
+  return n;
+}
+
+float orc_point_line_distance(const float *line, float x, float y) { return point_line_distance(line, x, y); }
+
+// TrackLSD::AssignPointToLines.  Outputs CSR lists: for kept line q (index into the input: kept[q]),
+// rel_ptr[q]..rel_ptr[q+1] index rel_id / rel_dist (std::map order = ascending point id) and
+// pos_ptr[q].. the point positions in input order.  Returns the number of kept lines.
+int orc_assign_points_to_lines(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, int *kept,
+                               int *rel_ptr, uint64_t *rel_id, double *rel_dist, int *pos_ptr, float *pos_xy) {
+  int nk = 0, nr = 0, npos = 0;
+  rel_ptr[0] = 0;
+  pos_ptr[0] = 0;
+  for (int i = 0; i < nl; ++i) {
+    const double lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];  // (sic)
+    double min_lx = lx1, max_lx = lx2, min_ly = ly1, max_ly = ly2;
+    if (lx1 > lx2) std::swap(min_lx, max_lx);
+    if (ly1 > ly2) std::swap(min_ly, max_ly);
+    std::map<int, double> on;
+    std::vector<float> pos;
+    bool found = false;
+    for (int j = 0; j < np; ++j) {
+      const float x = pts[2 * j], y = pts[2 * j + 1];
+      if (x < min_lx || x > max_lx || y < min_ly || y > max_ly) continue;
+      const float d = point_line_distance(lines + 4 * i, x, y);
+      if (d > 5) continue;
+      on[(int)ids[j]] = d;
+      pos.push_back(x);
+      pos.push_back(y);
+      found = true;
+    }
+    if (!found) continue;
+    kept[nk] = i;
+    for (auto &kv : on) {
+      rel_id[nr] = (uint64_t)kv.first;
+      rel_dist[nr] = kv.second;
+      ++nr;
+    }
+    memcpy(pos_xy + 2 * npos, pos.data(), pos.size() * sizeof(float));
+    npos += (int)pos.size() / 2;
+    ++nk;
+    rel_ptr[nk] = nr;
+    pos_ptr[nk] = npos;
+  }
+  return nk;
+}
+
+// TrackLSD::LineMatch: match_of_new[i] = index of the matched last line or -1.
+void orc_line_match(const float *lines_new, int n_new, const int *rel_ptr_new, const uint64_t *rel_id_new, const float *lines_last,
+                    int n_last, const int *rel_ptr_last, const uint64_t *rel_id_last, int *match_of_new) {
+  for (int i = 0; i < n_new; ++i) match_of_new[i] = -1;
+  if (n_last == 0 || n_new == 0) return;
+  std::vector<int> mm((size_t)n_last * n_new, 0);
+  for (int i = 0; i < n_new; ++i) {
+    if (rel_ptr_new[i + 1] - rel_ptr_new[i] < 1) continue;
+    for (int j = 0; j < n_last; ++j) {
+      if (rel_ptr_last[j + 1] - rel_ptr_last[j] < 1) continue;
+      for (int q = rel_ptr_last[j]; q < rel_ptr_last[j + 1]; ++q) {
+        bool shared = false;
+        for (int p = rel_ptr_new[i]; p < rel_ptr_new[i + 1]; ++p) shared = shared || rel_id_new[p] == rel_id_last[q];
+        if (!shared) continue;
+        int &m = mm[(size_t)j * n_new + i];
+        m += 1;
+        if (m >= 2) {
+          match_of_new[i] = j;
+          break;
+        }
+        // LineSimilar(lines_new[i], lines_last[j]): midpoint of the LAST line within 6 px of the NEW segment
+        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
+        if (m == 1 && point_line_distance(lines_new + 4 * i, mx, my) <= 6) {
+          match_of_new[i] = j;
+          break;
+        }
+      }
+    }
+  }
+}
+
+// TrackLSD::LineClass / LineClassification
+static bool line_class(const float *line, const double *vp) {
+  const double s[3] = {line[0], line[1], 1}, e[3] = {line[2], line[3], 1};
+  const double m[3] = {(s[0] + e[0]) / 2, (s[1] + e[1]) / 2, (s[2] + e[2]) / 2};
+  const double v[3] = {vp[0], vp[1], 1};
+  const double ln[3] = {m[1] * v[2] - m[2] * v[1], m[2] * v[0] - m[0] * v[2], m[0] * v[1] - m[1] * v[0]};
+  const double ds = ln[0] * s[0] + ln[1] * s[1] + ln[2] * s[2], de = ln[0] * e[0] + ln[1] * e[1] + ln[2] * e[2];
+  double dis_error = (std::abs(std::sqrt(ds * ds)) + std::abs(std::sqrt(de * de))) / (2 * std::sqrt(ln[0] * ln[0] + ln[1] * ln[1]));
+  dis_error = std::abs(dis_error);
+  const double angle1 = (double)(std::atan(line[1] - line[3]) / (line[0] - line[2]));  // float arithmetic, atan(dy)/dx (sic)
+  const double angle2 = std::atan(m[1] - vp[1]) / (m[0] - vp[0]);
+  const double angle_error = std::abs(angle1 - angle2);
+  return dis_error <= 5.0 && angle_error <= 0.35;
+}
+int orc_line_classification(const float *line, const double *vps /*[3][2]*/) {
+  if (line_class(line, vps + 4)) return 3;
+  if (line_class(line, vps + 2)) return 2;
+  if (line_class(line, vps)) return 1;
+  return 0;
+}
+
+// LineHelper::Vanishing_Points: radtan "distortion" of the columns of R_ItoC taken as normalised coordinates
+// (no perspective division), float round trip, z's y times 1000.
+void orc_vanishing_points(const double *R_ItoC, const double *K8, double *vps /*[3][2]*/) {
+  for (int a = 0; a < 3; ++a) {
+    const double x = R_ItoC[0 * 3 + a], y = R_ItoC[1 * 3 + a];
+    const double r = std::sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
+    const double x1 = x * (1 + K8[4] * r_2 + K8[5] * r_4) + 2 * K8[6] * x * y + K8[7] * (r_2 + 2 * x * x);
+    const double y1 = y * (1 + K8[4] * r_2 + K8[5] * r_4) + K8[6] * (r_2 + 2 * y * y) + 2 * K8[7] * x * y;
+    vps[2 * a] = (double)(float)(K8[0] * x1 + K8[2]);
+    vps[2 * a + 1] = (double)(float)(K8[1] * y1 + K8[3]);
+  }
+  vps[5] *= 1000;
+}
+
+}  // extern "C"

@@ -387,3 +387,111 @@ def load_jac(pkg):
         load()
         _jac = JacOracle(_inst.lib, pkg)
     return _jac
+
+
+# ------------------------------------------------------------------ line front-end oracle (oracle/line_oracle.cpp)
+class LineOracle:
+    def __init__(self, lib):
+        self.lib = L = lib
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_resize_half.argtypes = [u8, C.c_int, C.c_int, u8]
+        L.orc_canny.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, u8]
+        L.orc_fld.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, C.c_int, u8]
+        L.orc_fld.restype = C.c_int
+        L.orc_detect_lines.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, fp, C.c_int]
+        L.orc_detect_lines.restype = C.c_int
+        L.orc_point_line_distance.argtypes = [fp, C.c_float, C.c_float]
+        L.orc_point_line_distance.restype = C.c_float
+        L.orc_assign_points_to_lines.argtypes = [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp]
+        L.orc_assign_points_to_lines.restype = C.c_int
+        L.orc_line_match.argtypes = [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]
+        L.orc_line_classification.argtypes = [fp, dp]
+        L.orc_line_classification.restype = C.c_int
+        L.orc_vanishing_points.argtypes = [dp, dp, dp]
+
+    def resize_half(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((h // 2, w // 2), dtype=np.uint8)
+        self.lib.orc_resize_half(img.ctypes.data_as(u8), w, h, out.ctypes.data_as(u8))
+        return out
+
+    def canny(self, img, low=50, high=50):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((h, w), dtype=np.uint8)
+        self.lib.orc_canny(img.ctypes.data_as(u8), w, h, low, high, out.ctypes.data_as(u8))
+        return out
+
+    def fld(self, img, length=20, dist=1.414213562, c1=50, c2=50, cap=4096, want_edges=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        segs = np.zeros((cap, 4), dtype=np.float32)
+        edges = np.zeros((h, w), dtype=np.uint8) if want_edges else None
+        n = self.lib.orc_fld(img.ctypes.data_as(u8), w, h, length, dist, c1, c2, segs.ctypes.data_as(fp), cap,
+                             edges.ctypes.data_as(u8) if want_edges else None)
+        assert n <= cap
+        return (segs[:n].copy(), edges) if want_edges else segs[:n].copy()
+
+    def detect_lines(self, img, length=20, dist=1.414213562, c1=50, c2=50, min_len=40.0, cap=4096):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        lines = np.zeros((cap, 4), dtype=np.float32)
+        n = self.lib.orc_detect_lines(img.ctypes.data_as(u8), w, h, length, dist, c1, c2, min_len, lines.ctypes.data_as(fp), cap)
+        assert n <= cap
+        return lines[:n].copy()
+
+    def point_line_distance(self, line, x, y):
+        line = np.ascontiguousarray(line, dtype=np.float32)
+        return self.lib.orc_point_line_distance(line.ctypes.data_as(fp), float(x), float(y))
+
+    def assign_points_to_lines(self, lines, pts, ids):
+        lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        nl, npt = len(lines), len(pts)
+        kept = np.zeros(nl, dtype=np.int32)
+        rel_ptr, pos_ptr = np.zeros(nl + 1, dtype=np.int32), np.zeros(nl + 1, dtype=np.int32)
+        rel_id, rel_d = np.zeros(nl * npt + 1, dtype=np.uint64), np.zeros(nl * npt + 1)
+        pos = np.zeros((nl * npt + 1, 2), dtype=np.float32)
+        u64p = C.POINTER(C.c_uint64)
+        nk = self.lib.orc_assign_points_to_lines(lines.ctypes.data_as(fp), nl, pts.ctypes.data_as(fp), ids.ctypes.data_as(u64p), npt,
+                                                 _ip(kept), _ip(rel_ptr), rel_id.ctypes.data_as(u64p), _dp(rel_d), _ip(pos_ptr),
+                                                 pos.ctypes.data_as(fp))
+        nr, npos = rel_ptr[nk], pos_ptr[nk]
+        return dict(kept=kept[:nk].copy(), rel_ptr=rel_ptr[:nk + 1].copy(), rel_id=rel_id[:nr].copy(), rel_dist=rel_d[:nr].copy(),
+                    pos_ptr=pos_ptr[:nk + 1].copy(), pos=pos[:npos].copy())
+
+    def line_match(self, lines_new, rel_ptr_new, rel_id_new, lines_last, rel_ptr_last, rel_id_last):
+        ln = np.ascontiguousarray(lines_new, dtype=np.float32).reshape(-1, 4)
+        ll = np.ascontiguousarray(lines_last, dtype=np.float32).reshape(-1, 4)
+        rpn, rpl = np.ascontiguousarray(rel_ptr_new, dtype=np.int32), np.ascontiguousarray(rel_ptr_last, dtype=np.int32)
+        rin, ril = np.ascontiguousarray(rel_id_new, dtype=np.uint64), np.ascontiguousarray(rel_id_last, dtype=np.uint64)
+        out = np.zeros(max(1, len(ln)), dtype=np.int32)
+        u64p = C.POINTER(C.c_uint64)
+        self.lib.orc_line_match(ln.ctypes.data_as(fp), len(ln), _ip(rpn), rin.ctypes.data_as(u64p), ll.ctypes.data_as(fp), len(ll),
+                                _ip(rpl), ril.ctypes.data_as(u64p), _ip(out))
+        return out[:len(ln)].copy()
+
+    def line_classification(self, line, vps):
+        line = np.ascontiguousarray(line, dtype=np.float32)
+        vps = np.ascontiguousarray(vps, dtype=np.float64)
+        return self.lib.orc_line_classification(line.ctypes.data_as(fp), _dp(vps))
+
+    def vanishing_points(self, R_ItoC, K8):
+        R = np.ascontiguousarray(R_ItoC, dtype=np.float64)
+        K = np.ascontiguousarray(K8, dtype=np.float64)
+        out = np.zeros((3, 2))
+        self.lib.orc_vanishing_points(_dp(R), _dp(K), _dp(out))
+        return out
+
+
+_line = None
+
+
+def load_line():
+    global _line
+    if _line is None:
+        load()
+        _line = LineOracle(_inst.lib)
+    return _line
