@@ -369,6 +369,43 @@ int plv_build_line_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_l
 int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *lt, int k,
                                       const int *col_to_state, int ld);
 
+/* ---------------------------------------------------------------------------------------------
+ * Line front-end (a9-a14): TrackLSD behind the boundary.
+ * ------------------------------------------------------------------------------------------- */
+/* plv_detect_lines replaces the numeric part of TrackLSD::perform_detection_monocular (REF: PL-VIWO/src/
+ * update/cam/TrackLSD.cpp:194-235): half-resolution image, FastLineDetector(cfg.line_length_threshold,
+ * cfg.line_distance_threshold, cfg.canny_th1, cfg.canny_th2, 3, no merge), x2, drop length^2 <=
+ * cfg.line_min_length_px^2.  Works on the equalised image of the current (PLV_PYR_CUR) or previous
+ * frame held by the ctx; lines = x1 y1 x2 y2 full-resolution pixels, in the detector's output order. */
+int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out);
+
+/* TrackLSD::AssignPointToLines (REF :744-792, including its bounding-box test on (x1,y1) / (x2,y2)):
+ * kept[q] = input index of the q-th line that owns at least one point; CSR lists per kept line:
+ * rel_id / rel_dist (ascending point id, as the reference's std::map) and pos_xy (input order).
+ * Capacities: kept n_lines, rel_ptr / pos_ptr n_lines + 1, the lists n_lines * n_pts. Host logic. */
+int plv_assign_points_to_lines(const float *lines, int n_lines, const float *pts, const uint64_t *ids, int n_pts, int *kept,
+                               int *rel_ptr, uint64_t *rel_id, double *rel_dist, int *pos_ptr, float *pos_xy, int *n_kept);
+/* TrackLSD::LineMatch (REF :368-407): match_of_new[i] = index of the last-frame line or -1. Host logic. */
+int plv_line_match(const float *lines_new, int n_new, const int *rel_ptr_new, const uint64_t *rel_id_new, const float *lines_last,
+                   int n_last, const int *rel_ptr_last, const uint64_t *rel_id_last, int *match_of_new);
+/* TrackLSD::LineClassification (REF :318-366): 0..3 for vps = [x y z][2]. */
+int plv_line_classification(const float *line, const double *vps);
+/* LineHelper::Vanishing_Points (REF: linefeat/LineHelper.cpp:1026-1088): vps[3][2] from R_ItoC (row-major) and
+ * the 8 intrinsics. */
+int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps);
+
+/* TrackLSD::feed_monocular (REF :70-192) for the image currently held by the ctx — call after
+ * plv_tracker_feed (the point tracker's current observations are the ones lines are attached to).
+ * Updates lines_last / ids_last and the line track store (LineFeatureDatabase::update_feature). */
+int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps);
+int plv_line_tracker_last(plv_ctx *ctx, float *lines, uint64_t *ids, int cap, int *n);
+int plv_line_db_size(plv_ctx *ctx);
+int plv_line_db_ids(plv_ctx *ctx, uint64_t *ids, int cap, int *n); /* ascending */
+/* CSR export of line tracks in the layout of plv_line_tracks (+ LineFeature::D and ::points). */
+int plv_line_db_export_tracks(plv_ctx *ctx, const uint64_t *ids, int n_ids, int *obs_ptr, double *obs_time, float *seg_uv,
+                              float *seg_uvn, int obs_cap, int *D, int *pts_ptr, int *pt_ids, int pts_cap);
+int plv_line_db_remove(plv_ctx *ctx, const uint64_t *ids, int n_ids);
+
 #ifdef __cplusplus
 }
 #endif

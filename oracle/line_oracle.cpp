@@ -140,8 +140,8 @@ struct FitSums {
     const double x = (double)sx / wv, y = (double)sy / wv, x2 = (double)sxx / wv, y2 = (double)syy / wv, xy = (double)sxy / wv;
     const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
     const float t = (float)std::atan2(2 * dxy, dx2 - dy2) / 2;
-    line[0] = (float)std::cos(t);
-    line[1] = (float)std::sin(t);
+    line[0] = (float)std::cos((double)t);
+    line[1] = (float)std::sin((double)t);
     line[2] = (float)x;
     line[3] = (float)y;
   }

@@ -67,6 +67,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
     fp = C.POINTER(C.c_float)
+    u64p = C.POINTER(C.c_uint64)
     vp = C.c_void_p
     sig = {
         "plv_abi_version": (C.c_int, []),
@@ -117,6 +118,17 @@ def load_library():
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
         "plv_build_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int]),
+        "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
+        "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
+        "plv_line_match": (C.c_int, [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]),
+        "plv_line_classification": (C.c_int, [fp, dp]),
+        "plv_vanishing_points": (C.c_int, [dp, dp, dp]),
+        "plv_line_tracker_feed": (C.c_int, [vp, C.c_double, dp]),
+        "plv_line_tracker_last": (C.c_int, [vp, fp, u64p, C.c_int, ip]),
+        "plv_line_db_size": (C.c_int, [vp]),
+        "plv_line_db_ids": (C.c_int, [vp, u64p, C.c_int, ip]),
+        "plv_line_db_export_tracks": (C.c_int, [vp, u64p, C.c_int, ip, dp, fp, fp, C.c_int, ip, ip, ip, C.c_int]),
+        "plv_line_db_remove": (C.c_int, [vp, u64p, C.c_int]),
         "plv_triangulate_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), dp, u8p]),
         "plv_line_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), ip, C.c_int, ip]),
         "plv_build_line_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvLineTracks), C.c_int, ip, C.c_int, ip,
@@ -147,6 +159,10 @@ def _u8p(a):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64)) if a is not None else None
 
 
 def _f64(a):
@@ -501,6 +517,89 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    # ---- lines (front-end)
+    def detect_lines(self, which=0, cap=4096):
+        lines = np.zeros((cap, 4), dtype=np.float32)
+        n = C.c_int()
+        self._chk(self.lib.plv_detect_lines(self.h, which, _fp(lines), cap, C.byref(n)))
+        return lines[:n.value].copy()
+
+    def assign_points_to_lines(self, lines, pts, ids):
+        lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        nl, npt = len(lines), len(pts)
+        kept = np.zeros(max(nl, 1), dtype=np.int32)
+        rel_ptr, pos_ptr = np.zeros(nl + 1, dtype=np.int32), np.zeros(nl + 1, dtype=np.int32)
+        rel_id, rel_d = np.zeros(nl * npt + 1, dtype=np.uint64), np.zeros(nl * npt + 1)
+        pos = np.zeros((nl * npt + 1, 2), dtype=np.float32)
+        nk = C.c_int()
+        self._chk(self.lib.plv_assign_points_to_lines(_fp(lines), nl, _fp(pts), _u64p(ids), npt, _ip(kept), _ip(rel_ptr), _u64p(rel_id),
+                                                      _dp(rel_d), _ip(pos_ptr), _fp(pos), C.byref(nk)))
+        nk = nk.value
+        return dict(kept=kept[:nk].copy(), rel_ptr=rel_ptr[:nk + 1].copy(), rel_id=rel_id[:rel_ptr[nk]].copy(),
+                    rel_dist=rel_d[:rel_ptr[nk]].copy(), pos_ptr=pos_ptr[:nk + 1].copy(), pos=pos[:pos_ptr[nk]].copy())
+
+    def line_match(self, lines_new, rel_ptr_new, rel_id_new, lines_last, rel_ptr_last, rel_id_last):
+        ln = np.ascontiguousarray(lines_new, dtype=np.float32).reshape(-1, 4)
+        ll = np.ascontiguousarray(lines_last, dtype=np.float32).reshape(-1, 4)
+        rpn, rpl = _i32(rel_ptr_new), _i32(rel_ptr_last)
+        rin = np.ascontiguousarray(rel_id_new, dtype=np.uint64)
+        ril = np.ascontiguousarray(rel_id_last, dtype=np.uint64)
+        out = np.zeros(max(1, len(ln)), dtype=np.int32)
+        self._chk(self.lib.plv_line_match(_fp(ln), len(ln), _ip(rpn), _u64p(rin), _fp(ll), len(ll), _ip(rpl), _u64p(ril), _ip(out)))
+        return out[:len(ln)].copy()
+
+    def line_classification(self, line, vps):
+        line = np.ascontiguousarray(line, dtype=np.float32)
+        vps = np.ascontiguousarray(vps, dtype=np.float64)
+        return self.lib.plv_line_classification(_fp(line), _dp(vps))
+
+    def vanishing_points(self, R_ItoC, K8):
+        R = np.ascontiguousarray(R_ItoC, dtype=np.float64)  # row-major
+        K = np.ascontiguousarray(K8, dtype=np.float64)
+        out = np.zeros((3, 2))
+        self._chk(self.lib.plv_vanishing_points(_dp(R), _dp(K), _dp(out)))
+        return out
+
+    def line_tracker_feed(self, timestamp, vps):
+        vps = np.ascontiguousarray(vps, dtype=np.float64)
+        self._chk(self.lib.plv_line_tracker_feed(self.h, float(timestamp), _dp(vps)))
+
+    def line_tracker_last(self, cap=4096):
+        lines = np.zeros((cap, 4), dtype=np.float32)
+        ids = np.zeros(cap, dtype=np.uint64)
+        n = C.c_int()
+        self._chk(self.lib.plv_line_tracker_last(self.h, _fp(lines), _u64p(ids), cap, C.byref(n)))
+        return lines[:n.value].copy(), ids[:n.value].copy()
+
+    def line_db_size(self):
+        return self.lib.plv_line_db_size(self.h)
+
+    def line_db_ids(self, cap=65536):
+        ids = np.zeros(cap, dtype=np.uint64)
+        n = C.c_int()
+        self._chk(self.lib.plv_line_db_ids(self.h, _u64p(ids), cap, C.byref(n)))
+        return ids[:n.value].copy()
+
+    def line_db_export(self, ids, obs_cap=65536, pts_cap=262144):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        n = len(ids)
+        obs_ptr, pts_ptr = np.zeros(n + 1, dtype=np.int32), np.zeros(n + 1, dtype=np.int32)
+        t = np.zeros(obs_cap)
+        uv, uvn = np.zeros((obs_cap, 4), dtype=np.float32), np.zeros((obs_cap, 4), dtype=np.float32)
+        D = np.zeros(max(n, 1), dtype=np.int32)
+        pid = np.zeros(pts_cap, dtype=np.int32)
+        self._chk(self.lib.plv_line_db_export_tracks(self.h, _u64p(ids), n, _ip(obs_ptr), _dp(t), _fp(uv), _fp(uvn), obs_cap, _ip(D),
+                                                     _ip(pts_ptr), _ip(pid), pts_cap))
+        no, npt = obs_ptr[n], pts_ptr[n]
+        return dict(obs_ptr=obs_ptr, obs_time=t[:no].copy(), seg_uv=uv[:no].copy(), seg_uvn=uvn[:no].copy(), D=D[:n].copy(),
+                    pts_ptr=pts_ptr, pt_ids=pid[:npt].copy())
+
+    def line_db_remove(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        self._chk(self.lib.plv_line_db_remove(self.h, _u64p(ids), len(ids)))
 
     # ---- lines (update side)
     def line_jacobian_columns(self, st, lt, cap=512):

@@ -5,6 +5,7 @@
 
 #include "detect_kernels.hpp"
 #include "frontend_kernels.hpp"
+#include "line_kernels.hpp"
 
 using namespace plv;
 
@@ -166,6 +167,20 @@ int plv_feed_staged(plv_ctx *ctx, int slot) {
   // stream-ordered, no host sync: the next call on this ctx that returns data synchronises
   return feed_device(ctx, s, s->slots[slot].as<uint8_t>());
 }
+
+}  // extern "C"
+namespace plv {
+const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h) {
+  if (!ctx || !ctx->fe_state) return nullptr;
+  FrontState *s = fe(ctx);
+  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) return nullptr;
+  const PyrDesc &p = s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur];
+  if (w) *w = p.w[0];
+  if (h) *h = p.h[0];
+  return p.base + p.off[0];
+}
+}  // namespace plv
+extern "C" {
 
 int plv_pyramid_levels(plv_ctx *ctx, int which) {
   if (!ctx || !ctx->fe_state) return 0;

@@ -1,0 +1,412 @@
+// line_api.hip — TrackLSD behind the C-ABI (plv_detect_lines, plv_line_tracker_*, plv_line_db_*).
+//   TrackLSD::feed_new_camera / feed_monocular      REF: PL-VIWO/src/update/cam/TrackLSD.cpp:39-192
+//   TrackLSD::perform_detection_monocular           REF: :194-235   (device: line_kernels.hip)
+//   TrackLSD::AssignPointToLines / PointLineDistance    REF: :744-814
+//   TrackLSD::LineMatch / LineSimilar               REF: :368-407, :816-830
+//   TrackLSD::LineClassification / LineClass        REF: :318-366
+//   LineHelper::Vanishing_Points / Distort          REF: linefeat/LineHelper.cpp:1026-1088
+//   LineFeatureDatabase::update_feature             REF: linefeat/LineFeatureDatabase.cpp:40-76
+// Image work (half-resolution, Canny, chain walking, segment fits, end-point undistortion) runs on
+// the device.  What stays here is the reference's own host bookkeeping: which of <= ~100 segments
+// owns which of <= 250 tracked points, id hand-over between frames, the line track store.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "line_kernels.hpp"
+
+using namespace plv;
+
+namespace {
+
+#define TRY(expr)                  \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != PLV_OK) return _rc; \
+  } while (0)
+
+struct LineTrack {  // LineFeature, one camera   REF: linefeat/LineFeature.h:22-107
+  std::vector<double> t;
+  std::vector<float> uv, uvn;  // 4 per observation
+  std::vector<int> points;     // ids of the point features assigned at every observation (appended, REF :50-52)
+  std::map<double, std::vector<float>> point_uvs;
+  int D = 0;
+};
+
+struct LineTracker {
+  std::vector<float> lines_last;  // 4 per line
+  std::vector<uint64_t> ids_last;
+  std::vector<int> rel_ptr_last{0};  // CSR: point ids on each last line (ascending, the reference keeps a std::map)
+  std::vector<uint64_t> rel_id_last;
+  uint64_t currid = 1;  // REF: TrackLSD.cpp:32, ids are pre-incremented (:234)
+  std::unordered_map<uint64_t, LineTrack> db;
+  // device buffers of the detector
+  DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
+  PinBuf pin;
+  std::mutex mtx;
+};
+
+std::mutex g_mtx;
+std::unordered_map<plv_ctx *, LineTracker *> g_lt;
+LineTracker *ltr(plv_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_mtx);
+  auto it = g_lt.find(ctx);
+  if (it != g_lt.end()) return it->second;
+  auto *t = new LineTracker();
+  g_lt[ctx] = t;
+  return t;
+}
+
+const int kChainCap = 4096;
+
+float point_line_distance(const float *line, float x0, float y0) {
+  const float x1 = line[0], y1 = line[1], x2 = line[2], y2 = line[3];
+  const float along = (x2 - x1) * (x0 - x1) + (y2 - y1) * (y0 - y1);
+  if (along <= 0) return std::sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1));
+  const float len2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+  if (along > len2) return std::sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2));
+  return std::abs(std::fabs((y2 - y1) * x0 + (x1 - x2) * y0 + ((x2 * y1) - (x1 * y2))) /
+                  (std::sqrt(std::pow(y2 - y1, 2) + std::pow(x1 - x2, 2))));
+}
+
+// detection on the device + the host tail of perform_detection_monocular (x2, FilterShortLines)
+int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
+  int W = 0, H = 0;
+  const uint8_t *d_img = plv_front_level0(ctx, which, &W, &H);
+  if (!d_img) {
+    set_last_error("plv_detect_lines: no image has been fed");
+    return PLV_E_BADARG;
+  }
+  const int w = W / 2, h = H / 2;
+  const size_t npix = (size_t)w * h;
+  TRY(T->half.reserve(npix));
+  TRY(T->map.reserve(npix));
+  TRY(T->work.reserve(npix));
+  TRY(T->pts.reserve(npix * sizeof(int2)));
+  TRY(T->chains.reserve(kChainCap * sizeof(FldChain)));
+  TRY(T->counts.reserve(4 * sizeof(int)));
+  const size_t slot_cap = npix / (size_t)std::max(1, ctx->cfg.line_length_threshold) + kChainCap;
+  TRY(T->segs.reserve(slot_cap * sizeof(float4)));
+  TRY(T->seg_count.reserve(kChainCap * sizeof(int)));
+  FldBuffers b{T->half.as<uint8_t>(), T->map.as<uint8_t>(), T->work.as<uint8_t>(), T->pts.as<int2>(), T->chains.as<FldChain>(),
+               kChainCap,             T->counts.as<int>(),  T->segs.as<float4>(), T->seg_count.as<int>()};
+  FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
+  TRY(launch_line_detect(ctx, d_img, W, H, fp, b));
+  // download: counts, chain table, per-chain segment counts, segment slots
+  const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
+  TRY(T->pin.reserve(bytes + slot_cap * sizeof(float4)));
+  char *hp = T->pin.as<char>();
+  PLV_HIP_CHECK(hipMemcpyAsync(hp, T->counts.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const int n_chain = ((int *)hp)[0], n_slot = ((int *)hp)[1];
+  if (n_chain >= kChainCap) {
+    set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
+    return PLV_E_CAPACITY;
+  }
+  lines.clear();
+  if (n_chain > 0) {
+    FldChain *hc = (FldChain *)(hp + 16);
+    int *hn = (int *)(hp + 16 + kChainCap * sizeof(FldChain));
+    float4 *hs = (float4 *)(hp + bytes);
+    PLV_HIP_CHECK(hipMemcpyAsync(hc, T->chains.p, n_chain * sizeof(FldChain), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(hipMemcpyAsync(hn, T->seg_count.p, n_chain * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(hipMemcpyAsync(hs, T->segs.p, (size_t)n_slot * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
+    for (int c = 0; c < n_chain; ++c)  // chains are in raster order of their seeds = the detector's output order
+      for (int s = 0; s < hn[c]; ++s) {
+        const float4 sg = hs[hc[c].slot + s];
+        const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+        const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+        if (!(l2 > thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+        lines.insert(lines.end(), {x1, y1, x2, y2});
+      }
+  }
+  ctx->prof.collect();
+  return PLV_OK;
+}
+
+struct Assign {
+  std::vector<int> kept;
+  std::vector<int> rel_ptr{0}, pos_ptr{0};
+  std::vector<uint64_t> rel_id;
+  std::vector<double> rel_dist;
+  std::vector<float> pos;
+};
+
+void assign_points(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A, float assign_px = 5.0f) {
+  A = Assign();
+  for (int i = 0; i < nl; ++i) {
+    // REF :753-764 reads (x1, y1, x2, y2) as (lx1, lx2, ly1, ly2): kept as is
+    const double lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];
+    const double min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
+    std::map<int, double> on;
+    size_t first_pos = A.pos.size();
+    for (int j = 0; j < np; ++j) {
+      const float x = pts[2 * j], y = pts[2 * j + 1];
+      if (x < min_lx || x > max_lx || y < min_ly || y > max_ly) continue;
+      const float d = point_line_distance(lines + 4 * i, x, y);
+      if (d > assign_px) continue;
+      on[(int)ids[j]] = d;
+      A.pos.push_back(x);
+      A.pos.push_back(y);
+    }
+    if (A.pos.size() == first_pos) continue;  // lines without a point are dropped (REF :784-789)
+    A.kept.push_back(i);
+    for (const auto &kv : on) {
+      A.rel_id.push_back((uint64_t)kv.first);
+      A.rel_dist.push_back(kv.second);
+    }
+    A.rel_ptr.push_back((int)A.rel_id.size());
+    A.pos_ptr.push_back((int)A.pos.size() / 2);
+  }
+}
+
+void match_lines(const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new, const float *lines_last, int n_last,
+                 const int *rp_last, const uint64_t *ri_last, int *match) {
+  std::fill(match, match + n_new, -1);
+  if (n_new == 0 || n_last == 0) return;
+  for (int i = 0; i < n_new; ++i) {
+    if (rp_new[i + 1] == rp_new[i]) continue;
+    for (int j = 0; j < n_last; ++j) {
+      int shared = 0;
+      for (int q = rp_last[j]; q < rp_last[j + 1]; ++q) {
+        if (!std::binary_search(ri_new + rp_new[i], ri_new + rp_new[i + 1], ri_last[q])) continue;
+        ++shared;
+        if (shared >= 2) {
+          match[i] = j;
+          break;
+        }
+        // one shared point: accept when the last line's midpoint lies within 6 px of the new segment
+        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
+        if (point_line_distance(lines_new + 4 * i, mx, my) <= 6) {
+          match[i] = j;
+          break;
+        }
+      }
+    }
+  }
+}
+
+bool line_class(const float *line, const double *vp) {
+  const double sx = line[0], sy = line[1], ex = line[2], ey = line[3];
+  const double mx = (sx + ex) / 2, my = (sy + ey) / 2;
+  // line through the midpoint and the vanishing point, homogeneous
+  const double a = my - vp[1], b = vp[0] - mx, c = mx * vp[1] - my * vp[0];
+  const double ds = a * sx + b * sy + c, de = a * ex + b * ey + c;
+  const double dis_error = std::abs((std::abs(std::sqrt(ds * ds)) + std::abs(std::sqrt(de * de))) / (2 * std::sqrt(a * a + b * b)));
+  const double angle1 = (double)(std::atan(line[1] - line[3]) / (line[0] - line[2]));  // (sic) atan(dy)/dx in float
+  const double angle2 = std::atan(my - vp[1]) / (mx - vp[0]);
+  return dis_error <= 5.0 && std::abs(angle1 - angle2) <= 0.35;
+}
+
+}  // namespace
+
+extern "C" {
+
+void plv_line_tracker_destroy(plv_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_mtx);
+  auto it = g_lt.find(ctx);
+  if (it != g_lt.end()) {
+    LineTracker *T = it->second;
+    DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out};
+    for (DevBuf *b : bufs) b->release();
+    T->pin.release();
+    delete T;
+    g_lt.erase(it);
+  }
+}
+
+int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out) {
+  if (!ctx || !n_out) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  std::vector<float> v;
+  TRY(detect(ctx, T, which, v));
+  *n_out = (int)v.size() / 4;
+  if (*n_out > cap) return PLV_E_CAPACITY;
+  if (lines) std::copy(v.begin(), v.end(), lines);
+  return PLV_OK;
+}
+
+int plv_assign_points_to_lines(const float *lines, int n_lines, const float *pts, const uint64_t *ids, int n_pts, int *kept,
+                               int *rel_ptr, uint64_t *rel_id, double *rel_dist, int *pos_ptr, float *pos_xy, int *n_kept) {
+  if (!lines || !pts || !ids || !kept || !rel_ptr || !rel_id || !rel_dist || !pos_ptr || !pos_xy || !n_kept) return PLV_E_BADARG;
+  Assign A;
+  assign_points(lines, n_lines, pts, ids, n_pts, A);
+  *n_kept = (int)A.kept.size();
+  std::copy(A.kept.begin(), A.kept.end(), kept);
+  std::copy(A.rel_ptr.begin(), A.rel_ptr.end(), rel_ptr);
+  std::copy(A.rel_id.begin(), A.rel_id.end(), rel_id);
+  std::copy(A.rel_dist.begin(), A.rel_dist.end(), rel_dist);
+  std::copy(A.pos_ptr.begin(), A.pos_ptr.end(), pos_ptr);
+  std::copy(A.pos.begin(), A.pos.end(), pos_xy);
+  return PLV_OK;
+}
+
+int plv_line_match(const float *lines_new, int n_new, const int *rel_ptr_new, const uint64_t *rel_id_new, const float *lines_last,
+                   int n_last, const int *rel_ptr_last, const uint64_t *rel_id_last, int *match_of_new) {
+  if (!match_of_new || (n_new > 0 && (!lines_new || !rel_ptr_new)) || (n_last > 0 && (!lines_last || !rel_ptr_last)))
+    return PLV_E_BADARG;
+  match_lines(lines_new, n_new, rel_ptr_new, rel_id_new, lines_last, n_last, rel_ptr_last, rel_id_last, match_of_new);
+  return PLV_OK;
+}
+
+int plv_line_classification(const float *line, const double *vps) {
+  if (!line || !vps) return PLV_E_BADARG;
+  if (line_class(line, vps + 4)) return 3;
+  if (line_class(line, vps + 2)) return 2;
+  if (line_class(line, vps)) return 1;
+  return 0;
+}
+
+int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps) {
+  if (!R_ItoC || !K8 || !vps) return PLV_E_BADARG;
+  for (int a = 0; a < 3; ++a) {
+    // column a of R_ItoC, first two components used as normalised coordinates (REF :1037-1046: no division by z)
+    const double x = R_ItoC[a], y = R_ItoC[3 + a];
+    const double r = std::sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
+    const double x1 = x * (1 + K8[4] * r_2 + K8[5] * r_4) + 2 * K8[6] * x * y + K8[7] * (r_2 + 2 * x * x);
+    const double y1 = y * (1 + K8[4] * r_2 + K8[5] * r_4) + K8[6] * (r_2 + 2 * y * y) + 2 * K8[7] * x * y;
+    vps[2 * a] = (double)(float)(K8[0] * x1 + K8[2]);
+    vps[2 * a + 1] = (double)(float)(K8[1] * y1 + K8[3]);
+  }
+  vps[5] *= 1000;  // REF :1051-1054
+  return PLV_OK;
+}
+
+// TrackLSD::feed_monocular for the image currently in the ctx (fed by plv_tracker_feed / plv_feed_image,
+// which also is where the reference's second equalizeHist comes from: same input, same result).
+int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
+  if (!ctx || !vps) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  std::vector<float> lines;
+  TRY(detect(ctx, T, PLV_PYR_CUR, lines));
+  const int nl = (int)lines.size() / 4;
+  std::vector<uint64_t> ids(nl);
+  for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236
+  // the point tracker's current observations (REF :106-107, :131-134)
+  int np = 0;
+  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
+  std::vector<float> pts(2 * (size_t)std::max(np, 1));
+  std::vector<uint64_t> pids((size_t)std::max(np, 1));
+  TRY(plv_tracker_last(ctx, pts.data(), pids.data(), np, &np));
+  Assign A;
+  assign_points(lines.data(), nl, pts.data(), pids.data(), np, A);
+  const int nk = (int)A.kept.size();
+  std::vector<float> fl(4 * (size_t)nk);
+  std::vector<uint64_t> fid(nk);
+  for (int q = 0; q < nk; ++q) {
+    std::copy(lines.begin() + 4 * A.kept[q], lines.begin() + 4 * A.kept[q] + 4, fl.begin() + 4 * q);
+    fid[q] = ids[A.kept[q]];
+  }
+  const bool first = T->lines_last.empty();  // REF :100 (first frame or lost everything: no matching, no DB update)
+  if (!first) {
+    std::vector<int> match((size_t)std::max(nk, 1));
+    match_lines(fl.data(), nk, A.rel_ptr.data(), A.rel_id.data(), T->lines_last.data(), (int)T->ids_last.size(), T->rel_ptr_last.data(),
+                T->rel_id_last.data(), match.data());
+    for (int q = 0; q < nk; ++q)
+      if (match[q] >= 0) fid[q] = (uint64_t)(int)T->ids_last[match[q]];  // REF :153-158 (`int id`)
+    // undistort_line on the device (CamBase::undistort_line, both end points through undistort_f)
+    std::vector<float> un(4 * (size_t)std::max(nk, 1));
+    if (nk > 0) TRY(plv_undistort(ctx, 2 * nk, fl.data(), un.data()));
+    for (int q = 0; q < nk; ++q) {
+      const int D = plv_line_classification(fl.data() + 4 * q, vps);
+      auto it = T->db.find(fid[q]);
+      const bool is_new = it == T->db.end();
+      LineTrack &tr = T->db[fid[q]];
+      if (is_new) tr.D = D;  // REF LineFeatureDatabase.cpp:62-63: only a new feature takes D
+      tr.t.push_back(timestamp);
+      tr.uv.insert(tr.uv.end(), fl.begin() + 4 * q, fl.begin() + 4 * q + 4);
+      tr.uvn.insert(tr.uvn.end(), un.begin() + 4 * q, un.begin() + 4 * q + 4);
+      for (int p = A.rel_ptr[q]; p < A.rel_ptr[q + 1]; ++p) tr.points.push_back((int)A.rel_id[p]);
+      tr.point_uvs[timestamp].assign(A.pos.begin() + 2 * A.pos_ptr[q], A.pos.begin() + 2 * A.pos_ptr[q + 1]);
+    }
+  }
+  T->lines_last.swap(fl);
+  T->ids_last.swap(fid);
+  T->rel_ptr_last = A.rel_ptr;
+  T->rel_id_last = A.rel_id;
+  return PLV_OK;
+}
+
+int plv_line_tracker_last(plv_ctx *ctx, float *lines, uint64_t *ids, int cap, int *n) {
+  if (!ctx || !n) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  *n = (int)T->ids_last.size();
+  if (*n > cap) return PLV_E_CAPACITY;
+  if (lines) std::copy(T->lines_last.begin(), T->lines_last.end(), lines);
+  if (ids) std::copy(T->ids_last.begin(), T->ids_last.end(), ids);
+  return PLV_OK;
+}
+
+int plv_line_db_size(plv_ctx *ctx) {
+  if (!ctx) return 0;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  return (int)T->db.size();
+}
+
+int plv_line_db_ids(plv_ctx *ctx, uint64_t *ids, int cap, int *n) {
+  if (!ctx || !n) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  std::vector<uint64_t> v;
+  for (const auto &kv : T->db) v.push_back(kv.first);
+  std::sort(v.begin(), v.end());
+  *n = (int)v.size();
+  if (*n > cap) return PLV_E_CAPACITY;
+  if (ids) std::copy(v.begin(), v.end(), ids);
+  return PLV_OK;
+}
+
+// CSR export of the chosen line tracks in the layout of plv_line_tracks (+ the assigned point ids)
+int plv_line_db_export_tracks(plv_ctx *ctx, const uint64_t *ids, int n_ids, int *obs_ptr, double *obs_time, float *seg_uv,
+                              float *seg_uvn, int obs_cap, int *D, int *pts_ptr, int *pt_ids, int pts_cap) {
+  if (!ctx || !ids || !obs_ptr) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  int no = 0, npt = 0;
+  obs_ptr[0] = 0;
+  if (pts_ptr) pts_ptr[0] = 0;
+  for (int i = 0; i < n_ids; ++i) {
+    auto it = T->db.find(ids[i]);
+    if (it != T->db.end()) {
+      const LineTrack &tr = it->second;
+      const int m = (int)tr.t.size();
+      if (no + m > obs_cap) return PLV_E_CAPACITY;
+      if (obs_time) std::copy(tr.t.begin(), tr.t.end(), obs_time + no);
+      if (seg_uv) std::copy(tr.uv.begin(), tr.uv.end(), seg_uv + 4 * (size_t)no);
+      if (seg_uvn) std::copy(tr.uvn.begin(), tr.uvn.end(), seg_uvn + 4 * (size_t)no);
+      no += m;
+      if (D) D[i] = tr.D;
+      if (pts_ptr) {
+        if (npt + (int)tr.points.size() > pts_cap) return PLV_E_CAPACITY;
+        if (pt_ids) std::copy(tr.points.begin(), tr.points.end(), pt_ids + npt);
+        npt += (int)tr.points.size();
+      }
+    } else if (D) {
+      D[i] = 0;
+    }
+    obs_ptr[i + 1] = no;
+    if (pts_ptr) pts_ptr[i + 1] = npt;
+  }
+  return PLV_OK;
+}
+
+int plv_line_db_remove(plv_ctx *ctx, const uint64_t *ids, int n_ids) {
+  if (!ctx || (n_ids > 0 && !ids)) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  for (int i = 0; i < n_ids; ++i) T->db.erase(ids[i]);
+  return PLV_OK;
+}
+
+}  // extern "C"

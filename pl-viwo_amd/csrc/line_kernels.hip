@@ -1,0 +1,397 @@
+// line_kernels.hip — line detection of TrackLSD::perform_detection_monocular (a10) on the device.
+//   REF call site: PL-VIWO/src/update/cam/TrackLSD.cpp:194-235 — cv::resize(0.5, INTER_LINEAR),
+//   cv::ximgproc::FastLineDetector(20, sqrt 2, 50, 50, 3, no merge)::detect, x2, FilterShortLines(40).
+// The detector is an OpenCV-contrib dependency that is not under /root/reference; the kernels follow its
+// published algorithm (Lee et al., ICRA 2014) and cv::Canny's (L1 gradient, 3x3 Sobel, fixed-point
+// direction test) — the same restatement the oracle makes, see oracle/line_oracle.cpp.
+//
+//   half_kernel      exact 2x decimation, (a + b + c + d + 2) >> 2                      HBM-bound, elementwise
+//   canny_kernel     Sobel + |gx|+|gy| + non-maximum suppression + double threshold      HBM-bound stencil,
+//                    on a 16x16 tile with the 2-pixel halo staged in LDS                 one read of the image
+//   canny_hyst_kernel  hysteresis flood (only launched when low != high; the reference uses 50/50)
+//   fld_walk_kernel  8-neighbour chain walking.  The walk consumes edge pixels in raster order and
+//                    every step depends on the previous one: it is the sequential core of the
+//                    detector.  One wave; the edge map lives in LDS (90 KB at 376x240) so a step costs
+//                    LDS latency, not HBM latency; the raster seed search tests 64 pixels per step.
+//   fld_fit_kernel   segment growing (incremental least-squares fit on exact integer sums), clamping,
+//                    orientation by side brightness: one lane per chain, chains are independent.
+#include "line_kernels.hpp"
+
+namespace plv {
+
+__global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ src, int w, int h, uint8_t *__restrict__ dst) {
+  const int w2 = w >> 1, h2 = h >> 1;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w2 || y >= h2) return;
+  const uint8_t *p = src + (size_t)(2 * y) * w + 2 * x;
+  dst[(size_t)y * w2 + x] = (uint8_t)((p[0] + p[1] + p[w] + p[w + 1] + 2) >> 2);
+}
+
+#define CN_T 16
+__global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int w, int h, int low, int high,
+                                                            uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */) {
+  __shared__ int px[CN_T + 4][CN_T + 4];
+  __shared__ int mg[CN_T + 2][CN_T + 2];
+  const int tx = threadIdx.x & (CN_T - 1), ty = threadIdx.x / CN_T;
+  const int x0 = blockIdx.x * CN_T, y0 = blockIdx.y * CN_T;
+  for (int i = threadIdx.x; i < (CN_T + 4) * (CN_T + 4); i += CN_T * CN_T) {
+    const int ly = i / (CN_T + 4), lx = i - ly * (CN_T + 4);
+    const int gx = min(max(x0 + lx - 2, 0), w - 1), gy = min(max(y0 + ly - 2, 0), h - 1);  // BORDER_REPLICATE
+    px[ly][lx] = src[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (CN_T + 2) * (CN_T + 2); i += CN_T * CN_T) {
+    const int ly = i / (CN_T + 2), lx = i - ly * (CN_T + 2);
+    const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+    int m = 0;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {  // magnitudes outside the image are zero
+      const int cx = lx + 1, cy = ly + 1;
+      const int sx = (px[cy - 1][cx + 1] - px[cy - 1][cx - 1]) + 2 * (px[cy][cx + 1] - px[cy][cx - 1]) + (px[cy + 1][cx + 1] - px[cy + 1][cx - 1]);
+      const int sy = (px[cy + 1][cx - 1] - px[cy - 1][cx - 1]) + 2 * (px[cy + 1][cx] - px[cy - 1][cx]) + (px[cy + 1][cx + 1] - px[cy - 1][cx + 1]);
+      m = abs(sx) + abs(sy);
+    }
+    mg[ly][lx] = m;
+  }
+  __syncthreads();
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= w || y >= h) return;
+  int mydx, mydy;  // gradient of this thread's own pixel
+  {
+    const int cx = tx + 2, cy = ty + 2;
+    mydx = (px[cy - 1][cx + 1] - px[cy - 1][cx - 1]) + 2 * (px[cy][cx + 1] - px[cy][cx - 1]) + (px[cy + 1][cx + 1] - px[cy + 1][cx - 1]);
+    mydy = (px[cy + 1][cx - 1] - px[cy - 1][cx - 1]) + 2 * (px[cy + 1][cx] - px[cy - 1][cx]) + (px[cy + 1][cx + 1] - px[cy - 1][cx + 1]);
+  }
+  const int m = mg[ty + 1][tx + 1];
+  uint8_t out = 1;
+  if (m > low) {
+    const int ax = abs(mydx), ay = abs(mydy) << 15;
+    const int tg22x = ax * 13573;  // tan(22.5 deg) * 2^15
+    bool keep;
+    if (ay < tg22x)
+      keep = m > mg[ty + 1][tx] && m >= mg[ty + 1][tx + 2];
+    else {
+      const int tg67x = tg22x + (ax << 16);
+      if (ay > tg67x)
+        keep = m > mg[ty][tx + 1] && m >= mg[ty + 2][tx + 1];
+      else {
+        const int s = (mydx ^ mydy) < 0 ? -1 : 1;
+        keep = m > mg[ty][tx + 1 - s] && m > mg[ty + 2][tx + 1 + s];
+      }
+    }
+    if (keep) out = m > high ? 2 : 0;
+  }
+  // FastLineDetector clears the top-left 6x6 and the bottom-right 5x5 corner of the edge map
+  if ((x < 6 && y < 6) || (x >= w - 5 && y >= h - 5)) out = 1;
+  map[(size_t)y * w + x] = out;
+}
+
+// hysteresis: promote weak pixels adjacent to an edge until nothing changes (one workgroup sweep loop)
+__global__ void __launch_bounds__(1024) canny_hyst_kernel(uint8_t *__restrict__ map, int w, int h) {
+  __shared__ int changed;
+  do {
+    __syncthreads();
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+      if (map[i] != 0) continue;
+      const int y = i / w, x = i - y * w;
+      bool near = false;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int qx = x + dx, qy = y + dy;
+          if (qx >= 0 && qy >= 0 && qx < w && qy < h) near = near || map[(size_t)qy * w + qx] == 2;
+        }
+      if (near) {
+        map[i] = 2;
+        changed = 1;
+      }
+    }
+    __syncthreads();
+  } while (changed);
+}
+
+// ------------------------------------------------------------------------------------------ chain walking
+// FastLineDetectorImpl::lineDetection's seed loop + getPointChain.  All lanes run the same scalar
+// walk (uniform control flow, broadcast LDS reads); the lanes only split up the raster seed search.
+template <bool IN_LDS>
+__global__ void __launch_bounds__(64) fld_walk_kernel(const uint8_t *__restrict__ map, int w, int h, int length_threshold,
+                                                      uint8_t *__restrict__ gwork /* w*h scratch when !IN_LDS */,
+                                                      int2 *__restrict__ pts, FldChain *__restrict__ chains, int chain_cap,
+                                                      int *__restrict__ counts /* [0] chains, [1] segment slots, [2] points */) {
+  extern __shared__ uint8_t lmap[];
+  uint8_t *E = IN_LDS ? lmap : gwork;
+  const int lane = threadIdx.x;
+  const int npix = w * h;
+  for (int i = lane; i < npix; i += 64) E[i] = map[i] == 2 ? 255 : 0;
+  __syncthreads();
+  int n_chain = 0, n_slot = 0, n_pts = 0;
+  const int dxs[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dys[8] = {1, 1, 1, 0, -1, -1, -1, 0};  // {row,col} pairs of the reference
+  int scan = 0;
+  while (scan < npix) {
+    // raster search for the next seed: 64 pixels at a time
+    const int idx = scan + lane;
+    const unsigned long long m = __ballot(idx < npix && E[idx] != 0);
+    if (m == 0) {
+      scan += 64;
+      continue;
+    }
+    const int seed = scan + __ffsll((long long)m) - 1;
+    int x = seed % w, y = seed / w;
+    const int start = n_pts;
+    if (lane == 0) {
+      pts[n_pts] = make_int2(x, y);
+      E[seed] = 0;
+    }
+    ++n_pts;
+    __syncthreads();
+    float direction = 0.0f;
+    int step = 0;
+    for (;;) {
+      float min_dir_diff = 7.0f;
+      int cx = 0, cy = 0, cdir = 0;
+      bool found = false, first = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ci = x + dxs[i], ri = y + dys[i];
+        if (ri < 0 || ri == h || ci < 0 || ci == w) continue;
+        if (E[ri * w + ci] == 0) continue;
+        if (step == 0) {
+          if (!first) {
+            first = true;
+            cx = ci;
+            cy = ri;
+            cdir = i;
+          }
+          continue;
+        }
+        const float curr = i > 4 ? (float)(i - 8) : (float)i;
+        float diff = fabsf(curr - direction);
+        diff = diff > 4.0f ? 8.0f - diff : diff;
+        if (diff <= min_dir_diff) {
+          min_dir_diff = diff;
+          cx = ci;
+          cy = ri;
+          cdir = i > 4 ? i - 8 : i;
+          found = true;
+        }
+      }
+      if (step == 0) {
+        if (!first) break;
+        direction = cdir > 4 ? (float)(cdir - 8) : (float)cdir;
+      } else {
+        if (!found || !(min_dir_diff < 2.0f)) break;
+        direction = (direction * (float)step + (float)cdir) / (float)(step + 1);
+      }
+      x = cx;
+      y = cy;
+      if (lane == 0) {
+        pts[n_pts] = make_int2(x, y);
+        E[y * w + x] = 0;
+      }
+      ++n_pts;
+      ++step;
+      __syncthreads();
+    }
+    const int len = n_pts - start;
+    if (len >= length_threshold + 1 && n_chain < chain_cap) {
+      if (lane == 0) chains[n_chain] = FldChain{start, len, n_slot};
+      n_slot += len / length_threshold + 1;
+      ++n_chain;
+    } else {
+      n_pts = start;  // too short: forget the points
+    }
+    scan = seed + 1;
+  }
+  if (lane == 0) {
+    counts[0] = n_chain;
+    counts[1] = n_slot;
+    counts[2] = n_pts;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ segment growing
+struct L3 {
+  double a, b, c;
+};
+__device__ __forceinline__ L3 cr3(double ax, double ay, double az, double bx, double by, double bz) {
+  return L3{ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
+}
+__device__ __forceinline__ double dist_pl(double px, double py, L3 &l) {  // normalises l in place (as the reference does)
+  const double wv = sqrt(l.a * l.a + l.b * l.b);
+  l.a /= wv;
+  l.b /= wv;
+  l.c /= wv;
+  return l.a * px + l.b * py + l.c;
+}
+struct Fit {
+  long long n, sx, sy, sxx, syy, sxy;
+  __device__ void add(int2 p) {
+    ++n;
+    sx += p.x;
+    sy += p.y;
+    sxx += (long long)p.x * p.x;
+    syy += (long long)p.y * p.y;
+    sxy += (long long)p.x * p.y;
+  }
+  // cv::fitLine(DIST_L2) = principal axis through the centroid; integer sums are exact in double
+  __device__ L3 line() const {
+    const double wv = (double)(float)n;
+    const double x = (double)sx / wv, y = (double)sy / wv, x2 = (double)sxx / wv, y2 = (double)syy / wv, xy = (double)sxy / wv;
+    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
+    const float t = (float)atan2(2 * dxy, dx2 - dy2) / 2;
+    const float vx = (float)cos((double)t), vy = (float)sin((double)t), fx = (float)x, fy = (float)y;
+    return cr3((double)fx, (double)fy, 1.0, (double)fx + (double)vx, (double)fy + (double)vy, 1.0);
+  }
+};
+__device__ __forceinline__ void incident(const L3 &l, float &px, float &py, int imw, int imh) {
+  const L3 lk = cr3((double)px, (double)py, 1.0, l.a, l.b, 0.0);
+  L3 xk = cr3(lk.a, lk.b, lk.c, l.a, l.b, l.c);
+  const double s = 1.0 / xk.c;
+  const float fx = (float)(xk.a * s), fy = (float)(xk.b * s);
+  px = fx < 0.0f ? 0.0f : (fx >= (imw - 1.0f) ? (imw - 1.0f) : fx);
+  py = fy < 0.0f ? 0.0f : (fy >= (imh - 1.0f) ? (imh - 1.0f) : fy);
+}
+__device__ __forceinline__ void inboard(int &x, int &y, int w, int h) {
+  x = x <= 5 ? 5 : (x >= w - 5 ? w - 6 : x);
+  y = y <= 5 ? 5 : (y >= h - 5 ? h - 6 : y);
+}
+
+__global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__ src, int w, int h, int length_threshold,
+                                                     float distance_threshold, const int2 *__restrict__ pts,
+                                                     const FldChain *__restrict__ chains, const int *__restrict__ counts,
+                                                     float4 *__restrict__ segs, int *__restrict__ seg_count) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= counts[0]) return;
+  const FldChain ch = chains[c];
+  const int2 *P = pts + ch.start;
+  const int total = ch.len;
+  float4 *out = segs + ch.slot;
+  int nseg = 0;
+  for (int i = 0; i + length_threshold < total; ++i) {
+    int2 ps = P[i], pe = P[i + length_threshold];
+    L3 l = cr3(ps.x, ps.y, 1.0, pe.x, pe.y, 1.0);
+    bool is_line = true;
+    Fit fs{0, 0, 0, 0, 0, 0};
+    fs.add(ps);
+    for (int j = 1; j < length_threshold; ++j) {
+      const int2 pt = P[i + j];
+      if (fabs(dist_pl(pt.x, pt.y, l)) > distance_threshold) {
+        is_line = false;
+        break;
+      }
+      fs.add(pt);
+    }
+    if (!is_line) continue;
+    fs.add(pe);
+    l = fs.line();
+    {
+      float fx = (float)ps.x, fy = (float)ps.y;
+      incident(l, fx, fy, w, h);
+      ps.x = __float2int_rn(fx);  // Point2i(Point2f): saturate_cast = round to nearest even
+      ps.y = __float2int_rn(fy);
+    }
+    int j;
+    for (j = length_threshold + 1; i + j < total; ++j) {
+      const int2 pt = P[i + j];
+      double dist = dist_pl(pt.x, pt.y, l);
+      if (fabs(dist) > distance_threshold) {
+        l = fs.line();
+        dist = dist_pl(pt.x, pt.y, l);
+        if (fabs(dist) > distance_threshold) {
+          j--;
+          break;
+        }
+      }
+      pe = pt;
+      fs.add(pt);
+    }
+    l = fs.line();
+    float e1x = (float)ps.x, e1y = (float)ps.y, e2x = (float)pe.x, e2y = (float)pe.y;
+    incident(l, e1x, e1y, w, h);
+    incident(l, e2x, e2y, w, h);
+    i = i + j;
+    // lineDetection's filters, then additionalOperationsOnSegment (orientation by side brightness)
+    const float length = sqrtf((e1x - e2x) * (e1x - e2x) + (e1y - e2y) * (e1y - e2y));
+    if (length < length_threshold) continue;
+    if ((e1x <= 5.0f && e2x <= 5.0f) || (e1y <= 5.0f && e2y <= 5.0f) || (e1x >= w - 5.0f && e2x >= w - 5.0f) ||
+        (e1y >= h - 5.0f && e2y >= h - 5.0f))
+      continue;
+    if (!(e1x == 0.0f && e2x == 0.0f && e1y == 0.0f && e2y == 0.0f)) {
+      const double ang = (double)atan2f(e2y - e1y, e2x - e1x);
+      const double dx = (double)e2x - (double)e1x, dy = (double)e2y - (double)e1y;
+      const double ca = cos(90.0 * 3.14159265358979323846 / 180.0 + ang), sa = sin(90.0 * 3.14159265358979323846 / 180.0 + ang);
+      int iR = 0, iL = 0;
+      for (int q = 0; q < 10; ++q) {
+        float qx, qy;
+        if (q == 0) {
+          qx = e1x;
+          qy = e1y;
+        } else if (q == 9) {
+          qx = e2x;
+          qy = e2y;
+        } else {
+          qx = e1x + ((float)dx / 9.0f * (float)q);
+          qy = e1y + ((float)dy / 9.0f * (float)q);
+        }
+        int rx = __double2int_rn((double)qx + ca), ry = __double2int_rn((double)qy + sa);
+        int lx = __double2int_rn((double)qx - ca), ly = __double2int_rn((double)qy - sa);
+        inboard(rx, ry, w, h);
+        inboard(lx, ly, w, h);
+        iR += src[(size_t)ry * w + rx];
+        iL += src[(size_t)ly * w + lx];
+      }
+      if (iR > iL) {
+        float t = e1x;
+        e1x = e2x;
+        e2x = t;
+        t = e1y;
+        e1y = e2y;
+        e2y = t;
+      }
+    }
+    out[nseg++] = make_float4(e1x, e1y, e2x, e2y);
+  }
+  seg_count[c] = nseg;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int launch_line_detect(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b) {
+  const int w = W / 2, h = H / 2;
+  {
+    ProfScope ps(ctx->prof, "half_kernel", ctx->stream);
+    hipLaunchKernelGGL(half_kernel, dim3(cdiv(w, 64), cdiv(h, 4)), dim3(256), 0, ctx->stream, d_img, W, H, b.half);
+  }
+  int low = fp.canny_low, high = fp.canny_high;
+  if (low > high) std::swap(low, high);
+  {
+    ProfScope ps(ctx->prof, "canny_kernel", ctx->stream);
+    hipLaunchKernelGGL(canny_kernel, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, ctx->stream, b.half, w, h, low, high,
+                       b.map);
+  }
+  if (low != high) {
+    ProfScope ps(ctx->prof, "canny_hyst_kernel", ctx->stream);
+    hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.map, w, h);
+  }
+  {
+    ProfScope ps(ctx->prof, "fld_walk_kernel", ctx->stream);
+    const size_t need = (size_t)w * h;
+    if (need <= 150 * 1024) {
+      PLV_HIP_CHECK(hipFuncSetAttribute((const void *)fld_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL(fld_walk_kernel<true>, dim3(1), dim3(64), need, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
+                         b.chains, b.chain_cap, b.counts);
+    } else {
+      hipLaunchKernelGGL(fld_walk_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
+                         b.chains, b.chain_cap, b.counts);
+    }
+  }
+  {
+    ProfScope ps(ctx->prof, "fld_fit_kernel", ctx->stream);
+    hipLaunchKernelGGL(fld_fit_kernel, dim3(cdiv(b.chain_cap, 64)), dim3(64), 0, ctx->stream, b.half, w, h, fp.length_threshold,
+                       fp.distance_threshold, b.pts, b.chains, b.counts, b.segs, b.seg_count);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+}  // namespace plv

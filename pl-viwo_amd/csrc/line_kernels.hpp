@@ -1,0 +1,32 @@
+// line_kernels.hpp — device buffers and launcher of the line detector (line_kernels.hip).
+#pragma once
+#include <cstdint>
+
+#include "plv_ctx.hpp"
+
+namespace plv {
+
+struct FldChain {
+  int start, len, slot;  // points [start, start+len) of the chain buffer; first output slot
+};
+struct FldParams {
+  int length_threshold;      // 20   REF: TrackLSD.h:269
+  float distance_threshold;  // sqrt(2)   :270
+  int canny_low, canny_high; // 50, 50   :271-272 (aperture 3 is what canny_kernel implements)
+};
+struct FldBuffers {
+  uint8_t *half, *map, *work;  // half-resolution image, Canny map (0 weak / 1 none / 2 edge), walk scratch
+  int2 *pts;
+  FldChain *chains;
+  int chain_cap;
+  int *counts;     // [0] chains, [1] segment slots, [2] points
+  float4 *segs;    // segment slots, chain c writes segs[chain.slot ...]
+  int *seg_count;  // [chain_cap]
+};
+
+int launch_line_detect(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b);
+
+// frontend_api.hip: equalised level-0 image of the current (which = 0) or previous (1) frame
+const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h);
+
+}  // namespace plv

@@ -180,12 +180,14 @@ int plv_ctx_create(const plv_config *cfg, plv_ctx **out) {
 
 void plv_frontend_destroy(plv_ctx *ctx);  // frontend_api.hip
 void plv_tracker_destroy(plv_ctx *ctx);   // tracker_api.hip
+void plv_line_tracker_destroy(plv_ctx *ctx);  // line_api.hip
 
 void plv_ctx_destroy(plv_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   plv_tracker_destroy(ctx);
+  plv_line_tracker_destroy(ctx);
   plv_frontend_destroy(ctx);
   ctx->prof.destroy();
   plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,

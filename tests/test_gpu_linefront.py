@@ -1,0 +1,131 @@
+"""GPU parity of the line front-end (a9-a14) against the oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 752, 480
+
+
+@pytest.fixture(scope="module")
+def lo():
+    return oracle_lib.load_line()
+
+
+@pytest.fixture(scope="module")
+def frames():
+    canvas = synth.texture_canvas(W, H, seed=11, blobs=200, lines=120)
+    return [synth.render_frame(canvas, W, H, tx=3.0 * i, ty=-2.0 * i, rot_deg=0.2 * i) for i in range(3)]
+
+
+def eq_level0(ctx, img):
+    ctx.feed_image(img)
+    return ctx.pyramid_level(0, 0)
+
+
+def test_detect_lines_parity(ctx, lo, frames):
+    for img in frames[:2]:
+        eq = eq_level0(ctx, img)
+        ref = lo.detect_lines(eq)
+        got = ctx.detect_lines(0)
+        assert len(ref) > 20
+        assert len(got) == len(ref)
+        # same segments in the same order; end points agree to float rounding of the fit (atan2 / cos / sin)
+        assert np.abs(got - ref).max() < 2e-3
+
+
+def test_detect_lines_edge_cases(ctx, lo):
+    flat = np.full((H, W), 90, dtype=np.uint8)
+    eq_level0(ctx, flat)
+    assert len(ctx.detect_lines(0)) == 0
+    # a single bright bar: two long edges; a 30 px stub next to it is dropped by the 40 px filter
+    img = np.full((H, W), 30, dtype=np.uint8)
+    img[200:212, 100:600] = 220
+    img[300:306, 100:130] = 220
+    eq = eq_level0(ctx, img)
+    ref, got = lo.detect_lines(eq), ctx.detect_lines(0)
+    assert len(got) == len(ref) >= 2
+    assert np.abs(got - ref).max() < 2e-3
+    assert (np.hypot(got[:, 2] - got[:, 0], got[:, 3] - got[:, 1]) > 40).all()
+
+
+def test_point_line_logic_parity(ctx, lo, frames):
+    eq = eq_level0(ctx, frames[0])
+    lines = ctx.detect_lines(0)
+    rng = np.random.default_rng(2)
+    # points: half of them sampled on detected segments (+ noise), half anywhere
+    k = rng.integers(0, len(lines), 150)
+    t = rng.uniform(0, 1, 150)[:, None]
+    on = lines[k, :2] * (1 - t) + lines[k, 2:] * t + rng.normal(0, 2.0, (150, 2))
+    pts = np.vstack([on, np.column_stack([rng.uniform(0, W, 100), rng.uniform(0, H, 100)])]).astype(np.float32)
+    ids = rng.permutation(1000)[:250].astype(np.uint64)
+    a, b = ctx.assign_points_to_lines(lines, pts, ids), lo.assign_points_to_lines(lines, pts, ids)
+    for key in ("kept", "rel_ptr", "rel_id", "pos_ptr"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["rel_dist"], b["rel_dist"]) and np.array_equal(a["pos"], b["pos"])
+    assert len(a["kept"]) > 3
+    # matching against a perturbed copy of the same lines with mostly the same point ids
+    last = lines[a["kept"]] + rng.normal(0, 1.0, (len(a["kept"]), 4)).astype(np.float32)
+    keep = rng.uniform(size=len(a["rel_id"])) < 0.8
+    rid_last = np.where(keep, a["rel_id"], a["rel_id"] + 5000)
+    m1 = ctx.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last, a["rel_ptr"], rid_last)
+    m2 = lo.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last, a["rel_ptr"], rid_last)
+    assert np.array_equal(m1, m2) and (m1 >= 0).sum() > 2
+    vps = ctx.vanishing_points(synth._exp_so3(np.array([0.3, -0.2, 0.1])), synth.EUROC_K8)
+    assert np.array_equal(vps, lo.vanishing_points(synth._exp_so3(np.array([0.3, -0.2, 0.1])), synth.EUROC_K8))
+    cls = [ctx.line_classification(l, vps) for l in lines]
+    assert cls == [lo.line_classification(l, vps) for l in lines]
+
+
+def test_line_tracker_stream(pkg, lo, frames):
+    """TrackLSD::feed_monocular over three frames against a composition of oracle pieces."""
+    cfg = pkg.default_config(W, H)
+    ctx = pkg.Context(cfg)
+    vps = lo.vanishing_points(np.eye(3), synth.EUROC_K8)
+    K8 = synth.EUROC_K8
+    fo = oracle_lib.load_front()
+    last = None  # (lines, ids, rel_ptr, rel_id)
+    currid = 1
+    db = {}
+    for i, img in enumerate(frames):
+        t = 10.0 + 0.05 * i
+        ctx.tracker_feed(t, img)
+        ctx.line_tracker_feed(t, vps)
+        pts, pids = ctx.tracker_last()
+        # oracle composition on the same equalised image and the same tracked points
+        eq = ctx.pyramid_level(0, 0)
+        lines = lo.detect_lines(eq)
+        ids = np.arange(currid + 1, currid + 1 + len(lines), dtype=np.uint64)
+        currid += len(lines)
+        a = lo.assign_points_to_lines(lines, pts, pids)
+        fl, fid = lines[a["kept"]], ids[a["kept"]].copy()
+        if last is not None and len(last[0]) > 0:
+            m = lo.line_match(fl, a["rel_ptr"], a["rel_id"], last[0], last[2], last[3])
+            for q in range(len(fl)):
+                if m[q] >= 0:
+                    fid[q] = last[1][m[q]]
+            for q in range(len(fl)):
+                db.setdefault(int(fid[q]), []).append((t, fl[q]))
+        last = (fl, fid, a["rel_ptr"], a["rel_id"])
+        gl, gid = ctx.line_tracker_last()
+        assert np.array_equal(gid, fid)
+        assert np.abs(gl - fl).max() < 2e-3 if len(fl) else len(gl) == 0
+    assert ctx.line_db_size() == len(db) > 0
+    ids = ctx.line_db_ids()
+    ex = ctx.line_db_export(ids)
+    assert sorted(db.keys()) == [int(v) for v in ids]
+    for j, lid in enumerate(ids):
+        obs = db[int(lid)]
+        assert ex["obs_ptr"][j + 1] - ex["obs_ptr"][j] == len(obs)
+        o0 = ex["obs_ptr"][j]
+        for q, (t, l) in enumerate(obs):
+            assert ex["obs_time"][o0 + q] == t
+            assert np.abs(ex["seg_uv"][o0 + q] - l).max() < 2e-3
+            un = fo.undistort(K8, ex["seg_uv"][o0 + q].reshape(2, 2)).ravel()
+            assert np.abs(ex["seg_uvn"][o0 + q] - un).max() < 1e-6
+    tracked_twice = [k for k, v in db.items() if len(v) >= 2]
+    assert len(tracked_twice) >= 1
+    del ctx
