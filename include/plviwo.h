@@ -378,6 +378,10 @@ int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, co
  * cfg.line_min_length_px^2.  Works on the equalised image of the current (PLV_PYR_CUR) or previous
  * frame held by the ctx; lines = x1 y1 x2 y2 full-resolution pixels, in the detector's output order. */
 int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out);
+/* Where the detector's chain walk runs: 0 (default) = on the host between the device stages (Canny map down,
+ * chains up), 1 = fld_walk_kernel on the device.  Same results; the walk is one dependent chain of
+ * ~10^4 scalar steps, which a single GPU lane retires ~25x slower than a host core. */
+int plv_line_walk_mode(plv_ctx *ctx, int on_device);
 
 /* TrackLSD::AssignPointToLines (REF :744-792, including its bounding-box test on (x1,y1) / (x2,y2)):
  * kept[q] = input index of the q-th line that owns at least one point; CSR lists per kept line:

@@ -119,6 +119,7 @@ def load_library():
                                           dp, dp]),
         "plv_build_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int]),
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
+        "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
         "plv_line_match": (C.c_int, [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]),
         "plv_line_classification": (C.c_int, [fp, dp]),
@@ -524,6 +525,9 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.plv_detect_lines(self.h, which, _fp(lines), cap, C.byref(n)))
         return lines[:n.value].copy()
+
+    def line_walk_mode(self, on_device):
+        self._chk(self.lib.plv_line_walk_mode(self.h, 1 if on_device else 0))
 
     def assign_points_to_lines(self, lines, pts, ids):
         lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)

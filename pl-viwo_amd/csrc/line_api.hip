@@ -11,6 +11,7 @@
 // owns which of <= 250 tracked points, id hand-over between frames, the line track store.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -42,6 +43,7 @@ struct LineTracker {
   std::vector<int> rel_ptr_last{0};  // CSR: point ids on each last line (ascending, the reference keeps a std::map)
   std::vector<uint64_t> rel_id_last;
   uint64_t currid = 1;  // REF: TrackLSD.cpp:32, ids are pre-incremented (:234)
+  bool walk_on_device = false;  // plv_line_walk_mode
   std::unordered_map<uint64_t, LineTrack> db;
   // device buffers of the detector
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
@@ -72,6 +74,58 @@ float point_line_distance(const float *line, float x0, float y0) {
                   (std::sqrt(std::pow(y2 - y1, 2) + std::pow(x1 - x2, 2))));
 }
 
+// FastLineDetector's seed loop + getPointChain on a host copy of the Canny map (2 = edge).  Same
+// algorithm as fld_walk_kernel; see detect() for why the default runs it here.
+void walk_chains(uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts) {
+  static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
+  int n_chain = 0, n_slot = 0, n_pts = 0;
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      if (map[(size_t)r * w + c] != 2) continue;
+      const int start = n_pts;
+      int x = c, y = r;
+      pts[n_pts++] = make_int2(x, y);
+      map[(size_t)r * w + c] = 1;
+      float direction = 0.0f;
+      for (int step = 0;; ++step) {
+        int pick = -1;
+        float best = 7.0f;
+        for (int i = 0; i < 8; ++i) {
+          const int ci = x + dx[i], ri = y + dy[i];
+          if (ri < 0 || ri >= h || ci < 0 || ci >= w || map[(size_t)ri * w + ci] != 2) continue;
+          if (step == 0) {
+            pick = i;
+            break;
+          }
+          const float curr = i > 4 ? (float)(i - 8) : (float)i;
+          float diff = std::fabs(curr - direction);
+          diff = diff > 4.0f ? 8.0f - diff : diff;
+          if (diff <= best) {
+            best = diff;
+            pick = i;
+          }
+        }
+        if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
+        const int cdir = pick > 4 ? pick - 8 : pick;
+        direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
+        x += dx[pick];
+        y += dy[pick];
+        pts[n_pts++] = make_int2(x, y);
+        map[(size_t)y * w + x] = 1;
+      }
+      const int len = n_pts - start;
+      if (len >= length_threshold + 1 && n_chain < chain_cap) {
+        chains[n_chain++] = FldChain{start, len, n_slot};
+        n_slot += len / length_threshold + 1;
+      } else {
+        n_pts = start;
+      }
+    }
+  counts[0] = n_chain;
+  counts[1] = n_slot;
+  counts[2] = n_pts;
+}
+
 // detection on the device + the host tail of perform_detection_monocular (x2, FilterShortLines)
 int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
   int W = 0, H = 0;
@@ -94,11 +148,33 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
   FldBuffers b{T->half.as<uint8_t>(), T->map.as<uint8_t>(), T->work.as<uint8_t>(), T->pts.as<int2>(), T->chains.as<FldChain>(),
                kChainCap,             T->counts.as<int>(),  T->segs.as<float4>(), T->seg_count.as<int>()};
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
-  TRY(launch_line_detect(ctx, d_img, W, H, fp, b));
-  // download: counts, chain table, per-chain segment counts, segment slots
+  TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
-  TRY(T->pin.reserve(bytes + slot_cap * sizeof(float4)));
+  TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (1 + sizeof(int2)))));
   char *hp = T->pin.as<char>();
+  if (T->walk_on_device) {
+    TRY(launch_line_walk(ctx, w, h, fp, b));
+  } else {
+    // The chain walk consumes edge pixels in raster order and every step depends on the one before:
+    // a single dependent chain of ~10^4 .. 3*10^4 scalar steps.  One MI355X lane retires such a step in
+    // ~0.8 us (measured, 28 ms per frame on the dense-edge test image), a host core in ~30 ns, so the
+    // walk runs here on the 90 KB edge map between the two device stages (DESIGN.md "Line detector").
+    uint8_t *hmap = (uint8_t *)(hp + bytes);
+    int2 *hpts = (int2 *)(hp + bytes + npix);
+    PLV_HIP_CHECK(hipMemcpyAsync(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    FldChain *hc = (FldChain *)(hp + 16);
+    int hcounts[4] = {0, 0, 0, 0};
+    walk_chains(hmap, w, h, fp.length_threshold, hpts, hc, kChainCap, hcounts);
+    memcpy(hp, hcounts, 16);
+    PLV_HIP_CHECK(hipMemcpyAsync(T->counts.p, hp, 16, hipMemcpyHostToDevice, ctx->stream));
+    if (hcounts[0] > 0) {
+      PLV_HIP_CHECK(hipMemcpyAsync(T->chains.p, hc, hcounts[0] * sizeof(FldChain), hipMemcpyHostToDevice, ctx->stream));
+      PLV_HIP_CHECK(hipMemcpyAsync(T->pts.p, hpts, (size_t)hcounts[2] * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  TRY(launch_line_fit(ctx, w, h, fp, b));
+  // download: counts, chain table, per-chain segment counts, segment slots
   PLV_HIP_CHECK(hipMemcpyAsync(hp, T->counts.p, 16, hipMemcpyDeviceToHost, ctx->stream));
   PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   const int n_chain = ((int *)hp)[0], n_slot = ((int *)hp)[1];
@@ -218,6 +294,14 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
     delete T;
     g_lt.erase(it);
   }
+}
+
+int plv_line_walk_mode(plv_ctx *ctx, int on_device) {
+  if (!ctx) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  T->walk_on_device = on_device != 0;
+  return PLV_OK;
 }
 
 int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out) {

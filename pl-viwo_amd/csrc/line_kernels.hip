@@ -119,10 +119,16 @@ __global__ void __launch_bounds__(64) fld_walk_kernel(const uint8_t *__restrict_
                                                       int2 *__restrict__ pts, FldChain *__restrict__ chains, int chain_cap,
                                                       int *__restrict__ counts /* [0] chains, [1] segment slots, [2] points */) {
   extern __shared__ uint8_t lmap[];
-  uint8_t *E = IN_LDS ? lmap : gwork;
   const int lane = threadIdx.x;
   const int npix = w * h;
-  for (int i = lane; i < npix; i += 64) E[i] = map[i] == 2 ? 255 : 0;
+  auto ld = [&](int i) -> int { return IN_LDS ? (int)lmap[i] : (int)gwork[i]; };
+  auto st = [&](int i, uint8_t v) {
+    if (IN_LDS)
+      lmap[i] = v;
+    else
+      gwork[i] = v;
+  };
+  for (int i = lane; i < npix; i += 64) st(i, map[i] == 2 ? 255 : 0);
   __syncthreads();
   int n_chain = 0, n_slot = 0, n_pts = 0;
   const int dxs[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dys[8] = {1, 1, 1, 0, -1, -1, -1, 0};  // {row,col} pairs of the reference
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(64) fld_walk_kernel(const uint8_t *__restrict_
   while (scan < npix) {
     // raster search for the next seed: 64 pixels at a time
     const int idx = scan + lane;
-    const unsigned long long m = __ballot(idx < npix && E[idx] != 0);
+    const unsigned long long m = __ballot(idx < npix && ld(min(idx, npix - 1)) != 0);
     if (m == 0) {
       scan += 64;
       continue;
@@ -140,53 +146,48 @@ __global__ void __launch_bounds__(64) fld_walk_kernel(const uint8_t *__restrict_
     const int start = n_pts;
     if (lane == 0) {
       pts[n_pts] = make_int2(x, y);
-      E[seed] = 0;
+      st(seed, 0);
     }
     ++n_pts;
     __syncthreads();
     float direction = 0.0f;
     int step = 0;
     for (;;) {
-      float min_dir_diff = 7.0f;
-      int cx = 0, cy = 0, cdir = 0;
-      bool found = false, first = false;
+      // the eight neighbours first (clamped addresses, all loads in flight together), decisions afterwards
+      bool valid[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int ci = x + dxs[i], ri = y + dys[i];
-        if (ri < 0 || ri == h || ci < 0 || ci == w) continue;
-        if (E[ri * w + ci] == 0) continue;
-        if (step == 0) {
-          if (!first) {
-            first = true;
-            cx = ci;
-            cy = ri;
-            cdir = i;
-          }
-          continue;
-        }
-        const float curr = i > 4 ? (float)(i - 8) : (float)i;
-        float diff = fabsf(curr - direction);
-        diff = diff > 4.0f ? 8.0f - diff : diff;
-        if (diff <= min_dir_diff) {
-          min_dir_diff = diff;
-          cx = ci;
-          cy = ri;
-          cdir = i > 4 ? i - 8 : i;
-          found = true;
-        }
+        const bool inb = ri >= 0 && ri < h && ci >= 0 && ci < w;
+        const int v = ld(min(max(ri, 0), h - 1) * w + min(max(ci, 0), w - 1));
+        valid[i] = inb && v != 0;
       }
+      int pick = -1;
       if (step == 0) {
-        if (!first) break;
-        direction = cdir > 4 ? (float)(cdir - 8) : (float)cdir;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) pick = valid[i] ? i : pick;  // first valid neighbour
+        if (pick < 0) break;
+        direction = pick > 4 ? (float)(pick - 8) : (float)pick;
       } else {
-        if (!found || !(min_dir_diff < 2.0f)) break;
+        float min_dir_diff = 7.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float curr = i > 4 ? (float)(i - 8) : (float)i;
+          float diff = fabsf(curr - direction);
+          diff = diff > 4.0f ? 8.0f - diff : diff;
+          const bool take = valid[i] && diff <= min_dir_diff;  // ties: the later neighbour wins
+          min_dir_diff = take ? diff : min_dir_diff;
+          pick = take ? i : pick;
+        }
+        if (pick < 0 || !(min_dir_diff < 2.0f)) break;
+        const int cdir = pick > 4 ? pick - 8 : pick;
         direction = (direction * (float)step + (float)cdir) / (float)(step + 1);
       }
-      x = cx;
-      y = cy;
+      x += dxs[pick];
+      y += dys[pick];
       if (lane == 0) {
         pts[n_pts] = make_int2(x, y);
-        E[y * w + x] = 0;
+        st(y * w + x, 0);
       }
       ++n_pts;
       ++step;
@@ -356,7 +357,8 @@ __global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-int launch_line_detect(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b) {
+// stage 1: half-resolution image and Canny map (0 weak / 1 none / 2 edge; hysteresis applied)
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b) {
   const int w = W / 2, h = H / 2;
   {
     ProfScope ps(ctx->prof, "half_kernel", ctx->stream);
@@ -373,23 +375,31 @@ int launch_line_detect(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const F
     ProfScope ps(ctx->prof, "canny_hyst_kernel", ctx->stream);
     hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.map, w, h);
   }
-  {
-    ProfScope ps(ctx->prof, "fld_walk_kernel", ctx->stream);
-    const size_t need = (size_t)w * h;
-    if (need <= 150 * 1024) {
-      PLV_HIP_CHECK(hipFuncSetAttribute((const void *)fld_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL(fld_walk_kernel<true>, dim3(1), dim3(64), need, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
-                         b.chains, b.chain_cap, b.counts);
-    } else {
-      hipLaunchKernelGGL(fld_walk_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
-                         b.chains, b.chain_cap, b.counts);
-    }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// stage 2 (device variant): chain walking by one wave
+int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b) {
+  ProfScope ps(ctx->prof, "fld_walk_kernel", ctx->stream);
+  const size_t need = (size_t)w * h;
+  if (need <= 150 * 1024) {
+    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)fld_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fld_walk_kernel<true>, dim3(1), dim3(64), need, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
+                       b.chains, b.chain_cap, b.counts);
+  } else {
+    hipLaunchKernelGGL(fld_walk_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
+                       b.chains, b.chain_cap, b.counts);
   }
-  {
-    ProfScope ps(ctx->prof, "fld_fit_kernel", ctx->stream);
-    hipLaunchKernelGGL(fld_fit_kernel, dim3(cdiv(b.chain_cap, 64)), dim3(64), 0, ctx->stream, b.half, w, h, fp.length_threshold,
-                       fp.distance_threshold, b.pts, b.chains, b.counts, b.segs, b.seg_count);
-  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// stage 3: one lane per chain
+int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b) {
+  ProfScope ps(ctx->prof, "fld_fit_kernel", ctx->stream);
+  hipLaunchKernelGGL(fld_fit_kernel, dim3(cdiv(b.chain_cap, 64)), dim3(64), 0, ctx->stream, b.half, w, h, fp.length_threshold,
+                     fp.distance_threshold, b.pts, b.chains, b.counts, b.segs, b.seg_count);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

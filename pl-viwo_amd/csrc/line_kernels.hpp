@@ -24,7 +24,9 @@ struct FldBuffers {
   int *seg_count;  // [chain_cap]
 };
 
-int launch_line_detect(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b);
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b);
+int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
+int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 
 // frontend_api.hip: equalised level-0 image of the current (which = 0) or previous (1) frame
 const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h);

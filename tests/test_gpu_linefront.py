@@ -26,15 +26,20 @@ def eq_level0(ctx, img):
     return ctx.pyramid_level(0, 0)
 
 
-def test_detect_lines_parity(ctx, lo, frames):
-    for img in frames[:2]:
-        eq = eq_level0(ctx, img)
-        ref = lo.detect_lines(eq)
-        got = ctx.detect_lines(0)
-        assert len(ref) > 20
-        assert len(got) == len(ref)
-        # same segments in the same order; end points agree to float rounding of the fit (atan2 / cos / sin)
-        assert np.abs(got - ref).max() < 2e-3
+@pytest.mark.parametrize("walk_on_device", [False, True])
+def test_detect_lines_parity(ctx, lo, frames, walk_on_device):
+    ctx.line_walk_mode(walk_on_device)
+    try:
+        for img in frames[:2]:
+            eq = eq_level0(ctx, img)
+            ref = lo.detect_lines(eq)
+            got = ctx.detect_lines(0)
+            assert len(ref) > 20
+            assert len(got) == len(ref)
+            # same segments in the same order; end points agree to float rounding of the fit (atan2 / cos / sin)
+            assert np.abs(got - ref).max() < 2e-3
+    finally:
+        ctx.line_walk_mode(False)
 
 
 def test_detect_lines_edge_cases(ctx, lo):
