@@ -541,6 +541,88 @@ extern "C" {
 
 void orc_equalize_hist(const uint8_t *src, int w, int h, int stride, uint8_t *dst) { equalize_hist(src, w, h, stride, dst, w); }
 
+// cv::createCLAHE(clip_limit, Size(tiles, tiles))->apply(src, dst) on 8-bit images.
+// REF call sites: open_vins/ov_core/src/track/TrackKLT.cpp:60-64, PL-VIWO/src/update/cam/TrackLSD.cpp:84-88
+// (clip 10.0, 8x8 tiles).  OpenCV's algorithm (imgproc/clahe.cpp): per-tile clipped histogram with the
+// excess redistributed (batch + strided residual), cumulative LUT scaled by 255 / tile area, bilinear
+// blend of the four surrounding tile LUTs in float, saturate_cast<uchar> (round to nearest even).
+void orc_clahe(const uint8_t *src, int w, int h, double clip_limit, int tiles, uint8_t *dst) {
+  const int tx = tiles, ty = tiles;
+  int ew = w, eh = h;
+  std::vector<uint8_t> ext;
+  const uint8_t *lsrc = src;
+  if (w % tx != 0 || h % ty != 0) {  // copyMakeBorder(.., 0, ty - h % ty, 0, tx - w % tx, BORDER_REFLECT_101)
+    ew = w + (tx - (w % tx));
+    eh = h + (ty - (h % ty));
+    ext.resize((size_t)ew * eh);
+    auto refl = [](int p, int n) {
+      if (n == 1) return 0;
+      while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - p - 2;
+      return p;
+    };
+    for (int y = 0; y < eh; ++y)
+      for (int x = 0; x < ew; ++x) ext[(size_t)y * ew + x] = src[(size_t)refl(y, h) * w + refl(x, w)];
+    lsrc = ext.data();
+  }
+  const int tw = ew / tx, th = eh / ty, area = tw * th;
+  const float lut_scale = (float)255 / area;
+  int clip = 0;
+  if (clip_limit > 0.0) {
+    clip = (int)(clip_limit * area / 256);
+    clip = std::max(clip, 1);
+  }
+  std::vector<uint8_t> lut((size_t)tx * ty * 256);
+  for (int j = 0; j < ty; ++j)
+    for (int i = 0; i < tx; ++i) {
+      int hist[256] = {0};
+      for (int y = 0; y < th; ++y)
+        for (int x = 0; x < tw; ++x) hist[lsrc[(size_t)(j * th + y) * ew + i * tw + x]]++;
+      if (clip > 0) {
+        int clipped = 0;
+        for (int b = 0; b < 256; ++b)
+          if (hist[b] > clip) {
+            clipped += hist[b] - clip;
+            hist[b] = clip;
+          }
+        const int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        for (int b = 0; b < 256; ++b) hist[b] += batch;
+        if (residual != 0) {
+          const int step = std::max(256 / residual, 1);
+          for (int b = 0; b < 256 && residual > 0; b += step, residual--) hist[b]++;
+        }
+      }
+      int sum = 0;
+      uint8_t *L = &lut[(size_t)(j * tx + i) * 256];
+      for (int b = 0; b < 256; ++b) {
+        sum += hist[b];
+        const int v = (int)std::nearbyint((float)sum * lut_scale);
+        L[b] = (uint8_t)std::min(std::max(v, 0), 255);
+      }
+    }
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  for (int y = 0; y < h; ++y) {
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)std::floor(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = std::max(ty1, 0);
+    ty2 = std::min(ty2, ty - 1);
+    for (int x = 0; x < w; ++x) {
+      const float txf = x * inv_tw - 0.5f;
+      int tx1 = (int)std::floor(txf), tx2 = tx1 + 1;
+      const float xa = txf - tx1, xa1 = 1.0f - xa;
+      tx1 = std::max(tx1, 0);
+      tx2 = std::min(tx2, tx - 1);
+      const int v = src[(size_t)y * w + x];
+      const float res = (lut[(size_t)(ty1 * tx + tx1) * 256 + v] * xa1 + lut[(size_t)(ty1 * tx + tx2) * 256 + v] * xa) * ya1 +
+                        (lut[(size_t)(ty2 * tx + tx1) * 256 + v] * xa1 + lut[(size_t)(ty2 * tx + tx2) * 256 + v] * xa) * ya;
+      const int r = (int)std::nearbyint(res);
+      dst[(size_t)y * w + x] = (uint8_t)std::min(std::max(r, 0), 255);
+    }
+  }
+}
+
+
 // Pyramid handle
 void *orc_pyramid_build(const uint8_t *img, int w, int h, int stride, int win, int max_level) {
   Pyramid *P = new Pyramid();

@@ -19,7 +19,7 @@ struct FrontState {
   int fed = 0;             // number of images fed so far (last is valid when fed >= 2)
   DevBuf raw;              // incoming raw image (packed)
   DevBuf slots[8];
-  DevBuf hist;
+  DevBuf hist, clahe_lut;
   // per-call point buffers
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io;
   DevBuf det_in, det_out, det_mask, subpix_tab;  // detection staging
@@ -99,8 +99,12 @@ int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
     case PLV_HIST_NONE:
       PLV_HIP_CHECK(hipMemcpyAsync(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
       break;
+    case PLV_HIST_CLAHE:  // REF: TrackKLT.cpp:60-64 — clip 10.0, 8x8 tiles
+      TRY(s->clahe_lut.reserve(64 * 256));
+      TRY(launch_clahe(ctx, d_img, p.base + p.off[0], s->W, s->H, 10.0, 8, s->clahe_lut.as<uint8_t>()));
+      break;
     default:
-      set_last_error("front-end: histogram method %d (CLAHE) is not built yet", ctx->cfg.histogram_method);
+      set_last_error("front-end: unknown histogram method %d", ctx->cfg.histogram_method);
       return PLV_E_BADARG;
   }
   TRY(launch_pyramid(ctx, p));
@@ -126,7 +130,7 @@ extern "C" {
 void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
-  DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->pts0, &s->pts1, &s->n0, &s->n1,
+  DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab};
   for (auto *b : bufs) b->release();

@@ -10,6 +10,8 @@
 // (LUT, 5x5 binomial, Scharr, 14-bit bilinear weights); LK's normal-equation sums are exact
 // int64 wave reductions rounded to float once, so tracked positions are comparable bit-for-bit
 // with the CPU oracle whatever the reduction order.
+#include <algorithm>
+
 #include "frontend_kernels.hpp"
 #include "wave_ops.hpp"
 
@@ -757,6 +759,78 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ CLAHE
+// cv::createCLAHE(10.0, 8x8)->apply   REF call sites: TrackKLT.cpp:60-64, TrackLSD.cpp:84-88.
+// clahe_lut_kernel: workgroup per tile — LDS histogram, clip + redistribution (batch, then the strided
+// residual exactly as OpenCV walks it), inclusive scan, LUT = round(sum * 255 / area).
+// clahe_apply_kernel: per pixel bilinear blend of the four neighbouring tile LUTs in float.
+// The tile grid must divide the image (752x480, 1280x560 and 1280x720 do); otherwise PLV_E_BADARG.
+__global__ void __launch_bounds__(256) clahe_lut_kernel(const uint8_t *__restrict__ src, int w, int tw, int th, int tiles_x,
+                                                        int clip, float lut_scale, uint8_t *__restrict__ lut) {
+  __shared__ int hist[256];
+  __shared__ int scan[256];
+  __shared__ int clipped_total;
+  const int t = threadIdx.x;
+  const int ti = blockIdx.x % tiles_x, tj = blockIdx.x / tiles_x;
+  hist[t] = 0;
+  if (t == 0) clipped_total = 0;
+  __syncthreads();
+  for (int i = t; i < tw * th; i += 256) {
+    const int y = i / tw, x = i - y * tw;
+    atomicAdd(&hist[src[(size_t)(tj * th + y) * w + ti * tw + x]], 1);
+  }
+  __syncthreads();
+  int hv = hist[t];
+  if (clip > 0) {
+    if (hv > clip) {
+      atomicAdd(&clipped_total, hv - clip);
+      hv = clip;
+    }
+    __syncthreads();
+    const int clipped = clipped_total;
+    const int batch = clipped / 256;
+    const int residual = clipped - batch * 256;
+    hv += batch;
+    if (residual != 0) {
+      const int step = max(256 / residual, 1);
+      // bins 0, step, 2*step, ... get one more, `residual` of them at most, while the bin index stays < 256
+      if (t % step == 0 && t / step < residual) hv += 1;
+    }
+  }
+  scan[t] = hv;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = t >= off ? scan[t - off] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const int v = __float2int_rn((float)scan[t] * lut_scale);
+  lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)min(max(v, 0), 255);
+}
+
+__global__ void __launch_bounds__(256) clahe_apply_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h,
+                                                          int tw, int th, int tiles_x, int tiles_y,
+                                                          const uint8_t *__restrict__ lut) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  const float tyf = y * inv_th - 0.5f, txf = x * inv_tw - 0.5f;
+  int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
+  int ty2 = ty1 + 1, tx2 = tx1 + 1;
+  const float ya = tyf - ty1, ya1 = 1.0f - ya, xa = txf - tx1, xa1 = 1.0f - xa;
+  ty1 = max(ty1, 0);
+  ty2 = min(ty2, tiles_y - 1);
+  tx1 = max(tx1, 0);
+  tx2 = min(tx2, tiles_x - 1);
+  const int v = src[(size_t)y * w + x];
+  const float a = lut[(size_t)(ty1 * tiles_x + tx1) * 256 + v], b = lut[(size_t)(ty1 * tiles_x + tx2) * 256 + v];
+  const float c = lut[(size_t)(ty2 * tiles_x + tx1) * 256 + v], d = lut[(size_t)(ty2 * tiles_x + tx2) * 256 + v];
+  const float res = (a * xa1 + b * xa) * ya1 + (c * xa1 + d * xa) * ya;
+  dst[(size_t)y * w + x] = (uint8_t)min(max(__float2int_rn(res), 0), 255);
+}
+
 // ========================================================================================== launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -769,6 +843,28 @@ int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix
   {
     ProfScope ps(ctx->prof, "equalize_kernel", ctx->stream);
     hipLaunchKernelGGL(equalize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_src, d_dst, npix, d_hist);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int h, double clip_limit, int tiles, uint8_t *d_lut) {
+  if (w % tiles != 0 || h % tiles != 0) {
+    set_last_error("CLAHE: %dx%d is not divisible into %dx%d tiles (the padded variant is not built)", w, h, tiles, tiles);
+    return PLV_E_BADARG;
+  }
+  const int tw = w / tiles, th = h / tiles, area = tw * th;
+  int clip = 0;
+  if (clip_limit > 0.0) clip = std::max((int)(clip_limit * area / 256), 1);
+  {
+    ProfScope ps(ctx->prof, "clahe_lut_kernel", ctx->stream);
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles * tiles), dim3(256), 0, ctx->stream, d_src, w, tw, th, tiles, clip,
+                       (float)255 / area, d_lut);
+  }
+  {
+    ProfScope ps(ctx->prof, "clahe_apply_kernel", ctx->stream);
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3(cdiv(w, 64), cdiv(h, 4)), dim3(256), 0, ctx->stream, d_src, d_dst, w, h, tw, th, tiles,
+                       tiles, d_lut);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

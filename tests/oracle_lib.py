@@ -118,6 +118,15 @@ fp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
 
 
 class FrontOracle:
+    def clahe(self, img, clip=10.0, tiles=8):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros_like(img)
+        self.lib.orc_clahe.argtypes = [u8, C.c_int, C.c_int, C.c_double, C.c_int, u8]
+        self.lib.orc_clahe.restype = None
+        self.lib.orc_clahe(img.ctypes.data_as(u8), w, h, float(clip), tiles, out.ctypes.data_as(u8))
+        return out
+
     def __init__(self, lib):
         self.lib = L = lib
         L.orc_equalize_hist.argtypes = [u8, C.c_int, C.c_int, C.c_int, u8]
@@ -231,6 +240,9 @@ class DetectOracle:
         L.orc_perform_detection.argtypes = [u8, u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
                                             C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.orc_perform_detection.restype = C.c_int
+
+    def _unused(self):
+        pass
 
     def fast_roi(self, img, x0, y0, w, h, thr, cap=20000):
         img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -167,3 +167,22 @@ def test_perform_matching_vs_oracle(pkg, fo, seq):
     b1, bm, _, _, _ = c.perform_matching(pts[:9], pts[:9])
     assert not bm.any()
     c.close()
+
+
+def test_clahe_bit_exact(pkg):
+    """cv::createCLAHE(10, 8x8) (TrackKLT.cpp:60-64): CLAHE'd level 0 and the pyramid built from it."""
+    import oracle_lib
+    fo = oracle_lib.load_front()
+    cfg = pkg.default_config(752, 480)
+    cfg.histogram_method = 2  # PLV_HIST_CLAHE
+    c = pkg.Context(cfg)
+    rng = np.random.default_rng(8)
+    canvas = synth.texture_canvas(752, 480, seed=5, blobs=150)
+    imgs = [synth.render_frame(canvas, 752, 480), (100 + 10 * rng.normal(size=(480, 752))).clip(0, 255).astype(np.uint8),
+            np.full((480, 752), 31, dtype=np.uint8)]
+    for img in imgs:
+        c.feed_image(img)
+        ref = fo.clahe(img)
+        assert np.array_equal(c.pyramid_level(0, 0), ref)
+        pyr = fo.pyramid(ref)
+        assert np.array_equal(c.pyramid_level(0, 2), pyr.level(2)[0])

@@ -171,3 +171,24 @@ def test_perform_matching_small_set_is_all_zero(fo, frames):
     pts = synth.grid_points(w, h, 9, seed=7)
     rc, pts1, mask, _, _ = fo.perform_matching(p0, p1, pts, pts, synth.EUROC_K8)
     assert rc == 1 and not mask.any()
+
+
+def test_clahe_oracle_properties():
+    import oracle_lib
+    fo = oracle_lib.load_front()
+    rng = np.random.default_rng(5)
+    # low-contrast texture: CLAHE stretches it, stays in range, is deterministic
+    img = (120 + 6 * rng.normal(size=(480, 752))).clip(0, 255).astype(np.uint8)
+    out = fo.clahe(img)
+    assert out.shape == img.shape and out.dtype == np.uint8
+    assert out.std() > 2.0 * img.std()
+    assert np.array_equal(out, fo.clahe(img))
+    # a tile-constant image: every tile LUT maps its single grey level to round(255 * clipped cdf) and the
+    # blend of equal LUT values is that value; with clip = 10 * area / 256 the cdf at the level is
+    # (level + 1) * batch + clip + residual bins below it, the same in every tile -> constant output
+    flat = np.full((480, 752), 77, dtype=np.uint8)
+    o2 = fo.clahe(flat)
+    assert (o2 == o2[0, 0]).all()
+    # non-divisible sizes go through the reflect-101 padding branch
+    odd = rng.integers(0, 256, (100, 150), dtype=np.uint8)
+    assert fo.clahe(odd).shape == (100, 150)
