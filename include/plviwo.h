@@ -410,6 +410,46 @@ int plv_line_db_export_tracks(plv_ctx *ctx, const uint64_t *ids, int n_ids, int 
                               float *seg_uvn, int obs_cap, int *D, int *pts_ptr, int *pt_ids, int pts_cap);
 int plv_line_db_remove(plv_ctx *ctx, const uint64_t *ids, int n_ids);
 
+/* ---------------------------------------------------------------------------------------------
+ * UpdaterCamera::try_update, point half, as one call (a15-a17, a24, a31).
+ * ------------------------------------------------------------------------------------------- */
+/* FeatureDatabase::append_new_measurements for one feature (REF: open_vins/ov_core/src/feat/
+ * FeatureDatabase.cpp:338-387): appends n observations (time, raw uv, normalised uv) to track `id`,
+ * creating it if needed.  The tracker does this itself; the entry point serves callers that keep
+ * their own tracker (and the tests). */
+int plv_db_append_measurements(plv_ctx *ctx, uint64_t id, int n, const double *t, const float *uv, const float *uvn);
+
+typedef struct plv_update_options {
+  int max_msckf;        /* OptionsCamera::max_msckf (REF: CamHelper.cpp:651-653)                      */
+  int max_obs;          /* capacity: observations per feature kept in the batch (ld = 2 * max_obs)     */
+  double chi2_mult;     /* OptionsCamera::chi2_mult                                                    */
+  plv_tri_options tri;  /* FeatureInitializerOptions                                                   */
+  double t_prev_frame;  /* t_hist[size-2]: features without a newer observation are used (REF :636)    */
+  double state_time;    /* State::time: observations newer than state_time + dt_exp go back to the DB  */
+  int window_full;      /* state->clone_window() > window_size: drop observations older than the oldest clone (:733-737) */
+} plv_update_options;
+
+typedef struct plv_update_result {
+  int n_pool;       /* features taken out of the database                                   */
+  int n_msckf;      /* features that reached msckf_update (triangulated, consistent, capped) */
+  int n_accepted;   /* of those, passed the gate                                             */
+  int n_rows;       /* stacked rows before compression                                       */
+  int n_returned;   /* features handed back to the database                                  */
+  int status;       /* PLV_OK, or PLV_E_NOT_PSD from the EKF step (state untouched)          */
+} plv_update_result;
+
+/* CamHelper::get_features (pool = features_containing_older(2nd-oldest clone) + features_not_containing_newer
+ * (t_prev_frame), remove_unusable_measurements, sort by track length, triangulation + moving-consistency
+ * (3 px) until max_msckf, REF: CamHelper.cpp:613-707) -> UpdaterCamera::msckf_update (:197-294) on the
+ * device-resident covariance -> CamHelper::cleanup_features (:709-738: everything not consumed goes back
+ * to the tracker's database; old observations are dropped when the window is full).
+ * SLAM features (max_slam > 0) are not built: every consistent feature is an MSCKF feature.
+ * Ties in the track-length sort are broken by ascending feature id (the reference's std::sort on an
+ * unordered_map leaves them unspecified).  dx (n) is the state correction of EKFUpdate; msckf_ids /
+ * accepted (capacity max_msckf, may be NULL) list the features of the update in batch order. */
+int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
+                             plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted, double *p_FinG);
+
 #ifdef __cplusplus
 }
 #endif

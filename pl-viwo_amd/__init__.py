@@ -118,6 +118,9 @@ def load_library():
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
                                           dp, dp]),
         "plv_build_jacobians_resident": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int]),
+        "plv_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp]),
+        "plv_camera_update_points": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
+                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
@@ -213,6 +216,16 @@ class PlvLineTracks(C.Structure):
 class PlvTriOptions(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("max_dist", C.c_double), ("max_cond_number", C.c_double),
                 ("max_baseline", C.c_double), ("refine_features", C.c_int)]
+
+
+class PlvUpdateOptions(C.Structure):
+    _fields_ = [("max_msckf", C.c_int), ("max_obs", C.c_int), ("chi2_mult", C.c_double), ("tri", PlvTriOptions),
+                ("t_prev_frame", C.c_double), ("state_time", C.c_double), ("window_full", C.c_int)]
+
+
+class PlvUpdateResult(C.Structure):
+    _fields_ = [("n_pool", C.c_int), ("n_msckf", C.c_int), ("n_accepted", C.c_int), ("n_rows", C.c_int),
+                ("n_returned", C.c_int), ("status", C.c_int)]
 
 
 class StateView:
@@ -518,6 +531,28 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    # ---- UpdaterCamera::try_update, point half
+    def db_append_measurements(self, fid, t, uv, uvn):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32).reshape(-1, 2)
+        self._chk(self.lib.plv_db_append_measurements(self.h, int(fid), len(t), _dp(t), _fp(uv), _fp(uvn)))
+
+    def camera_update_points(self, st, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0,
+                             min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True):
+        opt = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0),
+                               t_prev_frame, state_time, 1 if window_full else 0)
+        res = PlvUpdateResult()
+        dx = np.zeros(n)
+        ids = np.zeros(max_msckf, dtype=np.uint64)
+        acc = np.zeros(max_msckf, dtype=np.uint8)
+        p = np.zeros((max_msckf, 3))
+        self._chk(self.lib.plv_camera_update_points(self.h, C.byref(st.c), C.byref(opt), _dp(dx), C.byref(res), _u64p(ids), _u8p(acc),
+                                                    _dp(p)))
+        m = res.n_msckf
+        return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
+                    status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy())
 
     # ---- lines (front-end)
     def detect_lines(self, which=0, cap=4096):

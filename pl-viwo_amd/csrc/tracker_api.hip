@@ -222,4 +222,217 @@ int plv_db_remove(plv_ctx *ctx, const uint64_t *ids, int n) {
   return PLV_OK;
 }
 
+int plv_db_append_measurements(plv_ctx *ctx, uint64_t id, int n, const double *t, const float *uv, const float *uvn) {
+  if (!ctx || n < 0 || (n > 0 && (!t || !uv || !uvn))) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  Track &tr = T->db[id];
+  tr.t.insert(tr.t.end(), t, t + n);
+  tr.uv.insert(tr.uv.end(), uv, uv + 2 * (size_t)n);
+  tr.uvn.insert(tr.uvn.end(), uvn, uvn + 2 * (size_t)n);
+  return PLV_OK;
+}
+
+// State::bounding_times + bounding_poses_n (order 3): is there an interpolation window for time t?
+// REF: PL-VIWO/src/state/State.cpp:1023-1136 (same test as the kernels' bounding_start)
+static bool has_bounding_poses(const plv_state_view &st, double t) {
+  const int N = st.n_clones;
+  if (N < 4) return false;
+  const double *ct = st.clone_time;
+  if (t < ct[0] - st.dt_exp || t > ct[N - 1] + st.dt_exp) return false;
+  if (t > ct[N - 1]) return false;
+  for (int i = 0; i < N - 1; ++i)
+    if (ct[i] - st.dt_exp <= t && t <= ct[i + 1] + st.dt_exp) return true;
+  return false;
+}
+
+int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
+                             plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted_out, double *p_out) {
+  if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK};
+  const double dt = st->cam_dt;
+  const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
+  struct Cand {
+    uint64_t id;
+    Track tr;
+  };
+  std::vector<Cand> pool;
+  std::unordered_map<uint64_t, Track> unused;  // db_unused: goes back to the database at the end
+  auto give_back = [&](uint64_t id, double t, const float *uv, const float *uvn) {
+    Track &u = unused[id];
+    u.t.push_back(t);
+    u.uv.insert(u.uv.end(), uv, uv + 2);
+    u.uvn.insert(u.uvn.end(), uvn, uvn + 2);
+  };
+  {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    // REF CamHelper.cpp:631-637 — features_containing_older(oldest_2nd_clone_time), then
+    // features_not_containing_newer(t_hist[size-2]); both take the feature out of the database
+    std::vector<uint64_t> take;
+    for (const auto &kv : T->db) {
+      bool older = false, newer = false;
+      for (double t : kv.second.t) {
+        older = older || t < t_oldest2 - dt;
+        newer = newer || t > opt->t_prev_frame - dt;
+      }
+      if (older || !newer) take.push_back(kv.first);
+    }
+    std::sort(take.begin(), take.end());
+    for (uint64_t id : take) {
+      pool.push_back(Cand{id, std::move(T->db[id])});
+      T->db.erase(id);
+    }
+  }
+  res->n_pool = (int)pool.size();
+  // REF :740-775 remove_unusable_measurements, and get_imu_poses' bounding-pose test (:327-372)
+  for (auto it = pool.begin(); it != pool.end();) {
+    Track &tr = it->tr;
+    size_t keep = 0;
+    for (size_t i = 0; i < tr.t.size(); ++i) {
+      const double tm = tr.t[i] + dt;
+      if (tm > opt->state_time + st->dt_exp) {
+        give_back(it->id, tr.t[i], &tr.uv[2 * i], &tr.uvn[2 * i]);  // newer than the window: later
+        continue;
+      }
+      if (tm < t_oldest - st->dt_exp) continue;  // older than the window: discarded
+      tr.t[keep] = tr.t[i];
+      tr.uv[2 * keep] = tr.uv[2 * i], tr.uv[2 * keep + 1] = tr.uv[2 * i + 1];
+      tr.uvn[2 * keep] = tr.uvn[2 * i], tr.uvn[2 * keep + 1] = tr.uvn[2 * i + 1];
+      ++keep;
+    }
+    tr.t.resize(keep);
+    tr.uv.resize(2 * keep);
+    tr.uvn.resize(2 * keep);
+    if (keep < 2)
+      it = pool.erase(it);  // REF :766-771 (no SLAM features here: a single measurement is dropped too)
+    else
+      ++it;
+  }
+  // REF :640 sort(feats_pool, feat_sort): long tracks first
+  std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
+  auto finish = [&](int rc) {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    for (auto &kv : unused) {  // REF :702-703 / :727-729 append_new_measurements
+      Track &d = T->db[kv.first];
+      d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
+      d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
+      d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
+    }
+    res->n_returned = (int)unused.size();
+    return rc;
+  };
+  auto give_back_all = [&](const Cand &c) {
+    for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+  };
+  if (pool.empty()) {
+    std::fill(dx, dx + ctx->cov_n, 0.0);
+    return finish(PLV_OK);
+  }
+  // ---- triangulate the whole pool in one call (the reference goes feature by feature until the cap; a
+  //      feature it never reaches keeps its observations either way)
+  const int Fp = (int)pool.size();
+  std::vector<int> ptr(Fp + 1, 0);
+  for (int f = 0; f < Fp; ++f) ptr[f + 1] = ptr[f] + (int)pool[f].tr.t.size();
+  const int nobs = ptr[Fp];
+  std::vector<double> ot(nobs), pf(3 * (size_t)Fp), err(Fp);
+  std::vector<float> ouv(2 * (size_t)nobs), ouvn(2 * (size_t)nobs);
+  std::vector<uint8_t> ok(Fp);
+  for (int f = 0; f < Fp; ++f) {
+    const Track &tr = pool[f].tr;
+    std::copy(tr.t.begin(), tr.t.end(), ot.begin() + ptr[f]);
+    std::copy(tr.uv.begin(), tr.uv.end(), ouv.begin() + 2 * (size_t)ptr[f]);
+    std::copy(tr.uvn.begin(), tr.uvn.end(), ouvn.begin() + 2 * (size_t)ptr[f]);
+  }
+  plv_tracks all{};
+  all.n_feat = Fp;
+  all.obs_ptr = ptr.data();
+  all.obs_time = ot.data();
+  all.obs_uv = ouv.data();
+  all.obs_uvn = ouvn.data();
+  int rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
+  if (rc != PLV_OK) {
+    for (const Cand &c : pool) give_back_all(c);
+    return finish(rc);
+  }
+  // ---- REF :648-699 the selection loop
+  std::vector<int> sel;
+  for (int f = 0; f < Fp; ++f) {
+    const Cand &c = pool[f];
+    if ((int)sel.size() >= opt->max_msckf) {  // :651-653 break; the rest returns to the database (:702)
+      give_back_all(c);
+      continue;
+    }
+    // get_imu_poses (:327-372): observations without bounding clones go back to the database
+    int valid = 0;
+    for (size_t i = 0; i < c.tr.t.size(); ++i) valid += has_bounding_poses(*st, c.tr.t[i] + dt);
+    if (valid < 2 || !ok[f] || !(err[f] < 3.0) || valid > opt->max_obs) {  // :656-683 (+ batch capacity)
+      give_back_all(c);
+      continue;
+    }
+    sel.push_back(f);
+  }
+  res->n_msckf = (int)sel.size();
+  if (sel.empty()) {
+    std::fill(dx, dx + ctx->cov_n, 0.0);
+    return finish(PLV_OK);
+  }
+  // ---- UpdaterCamera::msckf_update on the selected features
+  const int F = (int)sel.size();
+  std::vector<int> sptr(F + 1, 0);
+  std::vector<double> st_t, sp(3 * (size_t)F);
+  std::vector<float> suv;
+  for (int q = 0; q < F; ++q) {
+    const Cand &c = pool[sel[q]];
+    for (size_t i = 0; i < c.tr.t.size(); ++i) {
+      if (!has_bounding_poses(*st, c.tr.t[i] + dt)) {
+        give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+        continue;
+      }
+      st_t.push_back(c.tr.t[i]);
+      suv.push_back(c.tr.uv[2 * i]);
+      suv.push_back(c.tr.uv[2 * i + 1]);
+    }
+    sptr[q + 1] = (int)st_t.size();
+    std::copy(pf.begin() + 3 * (size_t)sel[q], pf.begin() + 3 * (size_t)sel[q] + 3, sp.begin() + 3 * (size_t)q);
+    if (msckf_ids) msckf_ids[q] = c.id;
+  }
+  if (p_out) std::copy(sp.begin(), sp.end(), p_out);
+  plv_tracks tr{};
+  tr.n_feat = F;
+  tr.obs_ptr = sptr.data();
+  tr.obs_time = st_t.data();
+  tr.obs_uv = suv.data();
+  tr.p_FinG = sp.data();
+  tr.p_FinG_fej = sp.data();  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
+  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  int k = 0;
+  rc = plv_jacobian_columns(st, &tr, cols.data(), (int)cols.size(), &k);
+  if (rc == PLV_OK) rc = plv_build_jacobians_resident(ctx, st, &tr, k, cols.data(), 2 * opt->max_obs);
+  std::vector<uint8_t> acc(F, 0);
+  int n_rows = 0;
+  if (rc == PLV_OK) {
+    rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, acc.data(), &n_rows, dx);
+    res->status = rc;
+    if (rc == PLV_E_NOT_PSD) rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
+  }
+  if (rc != PLV_OK) {
+    for (int q = 0; q < F; ++q) give_back_all(pool[sel[q]]);
+    return finish(rc);
+  }
+  res->n_rows = n_rows;
+  for (int q = 0; q < F; ++q) {
+    res->n_accepted += acc[q];
+    if (accepted_out) accepted_out[q] = acc[q];
+    if (!acc[q] || res->status == PLV_E_NOT_PSD) {  // REF UpdaterCamera.cpp:266-268 failed features go back
+      const Cand &c = pool[sel[q]];
+      for (size_t i = 0; i < c.tr.t.size(); ++i)
+        if (has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+    }
+  }
+  rc = finish(PLV_OK);
+  if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);  // REF CamHelper.cpp:733-737
+  return rc;
+}
+
 }  // extern "C"

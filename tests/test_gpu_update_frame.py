@@ -1,0 +1,84 @@
+"""UpdaterCamera::try_update (point half) as one call against a composition of oracle pieces."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_camera_update_points(pkg, oracle):
+    jo, fo = oracle_lib.load_jac(pkg), oracle_lib.load_front()
+    sc = synth.vio_scene(F=90, M=15, noise_px=0.4, seed=9)
+    t, K8 = sc["t"], sc["K8"]
+    n = sc["n_state"]
+    st, _ = synth.scene_views(pkg, sc)
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    rng = np.random.default_rng(0)
+    tracks = {}
+    for f in range(90):
+        a, b = sc["obs_ptr"][f], sc["obs_ptr"][f + 1]
+        uv = sc["obs_uv"][a:b].astype(np.float32)
+        tracks[f + 1] = (sc["obs_time"][a:b].copy(), uv, fo.undistort(K8, uv))
+    # a feature that is still being tracked and has nothing old: must stay in the database untouched
+    a, b = sc["obs_ptr"][3], sc["obs_ptr"][4]
+    recent = slice(b - 3, b)
+    tracks[500] = (sc["obs_time"][recent].copy(), sc["obs_uv"][recent].astype(np.float32),
+                   fo.undistort(K8, sc["obs_uv"][recent].astype(np.float32)))
+    # a lost feature with one observation left inside the window: taken and dropped
+    tracks[501] = (np.array([t[2]]), np.array([[100.0, 100.0]], dtype=np.float32), np.zeros((1, 2), dtype=np.float32))
+    # an outlier track (consistent geometry but a 12 px bias): triangulates, fails the 3 px consistency check
+    bad = 7
+    tb, ub, nb = tracks[bad]
+    ub = ub + rng.normal(0, 9.0, ub.shape).astype(np.float32)
+    tracks[bad] = (tb, ub, fo.undistort(K8, ub))
+    for fid, (tt, uv, uvn) in tracks.items():
+        ctx.db_append_measurements(fid, tt, uv, uvn)
+    P = synth.spd_cov(n, seed=4) * 1e-4
+    ctx.cov_upload(P)
+    MAX, MOBS = 40, 15
+    # the default condition-number gate (1e4) rejects most landmarks of this short-baseline scene: open it
+    TRI = dict(max_cond=1e7, max_dist=100.0, max_baseline=1e3)
+    out = ctx.camera_update_points(st, n, MAX, MOBS, t_prev_frame=t[-2], state_time=t[-1], window_full=True, **TRI)
+
+    # ---- the same decisions with the oracle
+    pool = [fid for fid, (tt, _, _) in sorted(tracks.items()) if (tt < t[1]).any() or not (tt > t[-2]).any()]
+    assert 500 not in pool and 501 in pool
+    pool = [fid for fid in pool if len(tracks[fid][0]) >= 2]
+    pool.sort(key=lambda fid: -len(tracks[fid][0]))  # stable: ties keep ascending id
+    ptr = np.concatenate([[0], np.cumsum([len(tracks[f][0]) for f in pool])]).astype(np.int32)
+    tr_all = pkg.Tracks(ptr, np.concatenate([tracks[f][0] for f in pool]), np.concatenate([tracks[f][1] for f in pool]),
+                        np.zeros((len(pool), 3)), obs_uvn=np.concatenate([tracks[f][2] for f in pool]))
+    p_o, ok_o, err_o = jo.triangulate_batch(st, tr_all, **TRI)
+    sel = []
+    for q, fid in enumerate(pool):
+        if len(sel) >= MAX:
+            break
+        if ok_o[q] and err_o[q] < 3.0:
+            sel.append(q)
+    assert pool.index(bad) not in sel and len(sel) == MAX  # enough candidates to hit the cap
+    ids_o = np.array([pool[q] for q in sel], dtype=np.uint64)
+    sptr = np.concatenate([[0], np.cumsum([len(tracks[pool[q]][0]) for q in sel])]).astype(np.int32)
+    tr_sel = pkg.Tracks(sptr, np.concatenate([tracks[pool[q]][0] for q in sel]), np.concatenate([tracks[pool[q]][1] for q in sel]),
+                        p_o[sel])
+    cols = jo.columns(st, tr_sel)
+    rows, Hf, Hx, res = jo.build_jacobians(st, tr_sel, cols, 2 * MOBS)
+    rc_o, P_o, dx_o, acc_o, nrows_o = oracle.msckf_update(P, rows, Hf, Hx, res, cols, st.c.sigma_pix ** 2, synth.q95_table())
+
+    assert out["status"] == rc_o == 0
+    assert out["n_pool"] == len([f for f, (tt, _, _) in tracks.items() if (tt < t[1]).any() or not (tt > t[-2]).any()])
+    assert np.array_equal(out["ids"], ids_o)
+    assert np.array_equal(out["accepted"], acc_o) and out["n_rows"] == nrows_o and acc_o.sum() > 20
+    assert np.abs(out["p_FinG"] - p_o[sel]).max() < 1e-6
+    assert np.abs(out["dx"] - dx_o).max() <= 1e-7 * max(1.0, np.abs(dx_o).max())
+    assert np.abs(ctx.cov_download(n) - P_o).max() <= 1e-8 * np.abs(P).max()
+    # ---- database afterwards: consumed features are gone, everything else is back (minus observations older
+    # than the oldest clone, none here), the tracked feature never left
+    used = {int(i) for i, a in zip(ids_o, acc_o) if a}
+    expect = {fid for fid in tracks if fid not in used and fid != 501}
+    got = set()
+    ids_left = ctx.db_select(1, 1e18)  # everything with an observation older than +inf
+    got = {int(i) for i in ids_left}
+    assert got == expect
+    assert ctx.db_size() == len(expect)
