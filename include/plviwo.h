@@ -450,6 +450,28 @@ typedef struct plv_update_result {
 int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                              plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted, double *p_FinG);
 
+/* ---------------------------------------------------------------------------------------------
+ * UpdaterCamera::try_update, line half, as one call (a15/a16, a27-a29, a31).  Call after the caller has
+ * applied the dx of plv_camera_update_points to its state (the reference's EKFUpdate does, StateHelper.cpp:
+ * 159-160) and rebuilt the state view.
+ * ------------------------------------------------------------------------------------------- */
+/* LineFeatureDatabase::update_feature for one line track (REF: linefeat/LineFeatureDatabase.cpp:40-76): appends n
+ * observations (time, raw end points, normalised end points); D is taken when the track is created;
+ * point_ids (n_pts, may be 0) are appended to LineFeature::points. */
+int plv_line_db_append_measurements(plv_ctx *ctx, uint64_t id, int n, const double *t, const float *seg_uv,
+                                    const float *seg_uvn, int D, const int *point_ids, int n_pts);
+/* Triangulated point features the line path may anchor on (the reference's `point_used` database,
+ * UpdaterCamera.h / CamHelper.cpp:671-695): plv_camera_update_points records every triangulated feature it
+ * examined; this entry point lets a caller with its own point pipeline do the same. */
+int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, double newest_obs_time);
+
+/* LineHelper::get_line_features (REF: linefeat/LineHelper.cpp:19-72: pool, remove_unusable_measurements (0.01 s
+ * margins), sort by track length, line_triangulation) -> UpdaterCamera::lines_update (UpdaterCamera.cpp:371-464)
+ * -> LineHelper::cleanup_lines (:522-553).  opt->max_msckf is ignored (no cap on lines).  line_ids / accepted
+ * (capacity cap, may be NULL) list the lines of the update in batch order. */
+int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
+                            plv_update_result *res, uint64_t *line_ids, uint8_t *accepted, double *line_FinG, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,10 @@ def load_library():
         "plv_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp]),
         "plv_camera_update_points": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                                C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
+        "plv_line_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]),
+        "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
+        "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
+                                              C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
@@ -553,6 +557,29 @@ class Context:
         m = res.n_msckf
         return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
                     status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy())
+
+    def line_db_append_measurements(self, lid, t, seg_uv, seg_uvn, D=0, point_ids=()):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        uv = np.ascontiguousarray(seg_uv, dtype=np.float32).reshape(-1, 4)
+        uvn = np.ascontiguousarray(seg_uvn, dtype=np.float32).reshape(-1, 4)
+        pid = np.ascontiguousarray(point_ids, dtype=np.int32)
+        self._chk(self.lib.plv_line_db_append_measurements(self.h, int(lid), len(t), _dp(t), _fp(uv), _fp(uvn), int(D),
+                                                           _ip(pid) if len(pid) else None, len(pid)))
+
+    def point_used_insert(self, fid, p, newest):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self._chk(self.lib.plv_point_used_insert(self.h, int(fid), _dp(p), float(newest)))
+
+    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512):
+        opt = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0)
+        res = PlvUpdateResult()
+        dx = np.zeros(n)
+        ids, acc, lg = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))
+        self._chk(self.lib.plv_camera_update_lines(self.h, C.byref(st.c), C.byref(opt), _dp(dx), C.byref(res), _u64p(ids), _u8p(acc),
+                                                   _dp(lg), cap))
+        m = res.n_msckf
+        return dict(dx=dx, n_pool=res.n_pool, n_lines=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
+                    status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), line_FinG=lg[:m].copy())
 
     # ---- lines (front-end)
     def detect_lines(self, which=0, cap=4096):

@@ -493,4 +493,244 @@ int plv_line_db_remove(plv_ctx *ctx, const uint64_t *ids, int n_ids) {
   return PLV_OK;
 }
 
+int plv_line_db_append_measurements(plv_ctx *ctx, uint64_t id, int n, const double *t, const float *seg_uv,
+                                    const float *seg_uvn, int D, const int *point_ids, int n_pts) {
+  if (!ctx || n < 0 || (n > 0 && (!t || !seg_uv || !seg_uvn)) || (n_pts > 0 && !point_ids)) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  const bool is_new = T->db.find(id) == T->db.end();
+  LineTrack &tr = T->db[id];
+  if (is_new) tr.D = D;
+  tr.t.insert(tr.t.end(), t, t + n);
+  tr.uv.insert(tr.uv.end(), seg_uv, seg_uv + 4 * (size_t)n);
+  tr.uvn.insert(tr.uvn.end(), seg_uvn, seg_uvn + 4 * (size_t)n);
+  tr.points.insert(tr.points.end(), point_ids, point_ids + n_pts);
+  return PLV_OK;
+}
+
+int plv_point_used_lookup(plv_ctx *ctx, uint64_t id, double *p);   // tracker_api.hip
+void plv_point_used_cleanup(plv_ctx *ctx, double t_oldest);
+
+static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as the kernels' bounding_start
+  const int N = st.n_clones;
+  if (N < 4) return false;
+  const double *ct = st.clone_time;
+  if (t < ct[0] - st.dt_exp || t > ct[N - 1] + st.dt_exp || t > ct[N - 1]) return false;
+  for (int i = 0; i < N - 1; ++i)
+    if (ct[i] - st.dt_exp <= t && t <= ct[i + 1] + st.dt_exp) return true;
+  return false;
+}
+
+int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
+                            plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
+  if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK};
+  const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
+  struct Cand {
+    uint64_t id;
+    LineTrack tr;
+  };
+  std::vector<Cand> pool;
+  std::unordered_map<uint64_t, LineTrack> unused;
+  auto give_back = [&](const Cand &c, size_t i) {
+    LineTrack &u = unused[c.id];
+    if (u.t.empty() && u.points.empty()) {
+      u.D = c.tr.D;
+      u.points = c.tr.points;  // copy_to_db copies the feature's point list
+    }
+    u.t.push_back(c.tr.t[i]);
+    u.uv.insert(u.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+    u.uvn.insert(u.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
+  };
+  {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    std::vector<uint64_t> take;
+    for (const auto &kv : T->db) {  // REF LineHelper.cpp:33-38 (:74-130)
+      bool older = false, newer = false;
+      for (double t : kv.second.t) {
+        older = older || t < t_oldest2 - dt;
+        newer = newer || t > opt->t_prev_frame - dt;
+      }
+      if (older || !newer) take.push_back(kv.first);
+    }
+    std::sort(take.begin(), take.end());
+    for (uint64_t id : take) {
+      pool.push_back(Cand{id, std::move(T->db[id])});
+      T->db.erase(id);
+    }
+  }
+  res->n_pool = (int)pool.size();
+  for (auto it = pool.begin(); it != pool.end();) {  // REF :652-682 (hard-coded 0.01 s margins)
+    LineTrack &tr = it->tr;
+    size_t keep = 0;
+    for (size_t i = 0; i < tr.t.size(); ++i) {
+      const double tm = tr.t[i] + dt;
+      if (tm > opt->state_time + 0.01) {
+        give_back(*it, i);
+        continue;
+      }
+      if (tm < t_oldest - 0.01) continue;
+      if (keep != i) {
+        tr.t[keep] = tr.t[i];
+        std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+        std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+      }
+      ++keep;
+    }
+    tr.t.resize(keep);
+    tr.uv.resize(4 * keep);
+    tr.uvn.resize(4 * keep);
+    if (keep < 2)
+      it = pool.erase(it);
+    else
+      ++it;
+  }
+  std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
+  auto finish = [&](int rc) {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    for (auto &kv : unused) {  // REF :71 / cleanup_lines :545-546 append_new_measurements
+      const bool is_new = T->db.find(kv.first) == T->db.end();
+      LineTrack &d = T->db[kv.first];
+      if (is_new) {
+        d.D = kv.second.D;
+        d.points = kv.second.points;
+      }
+      d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
+      d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
+      d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
+    }
+    res->n_returned = (int)unused.size();
+    return rc;
+  };
+  auto give_back_all = [&](const Cand &c) {
+    for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c, i);
+  };
+  std::fill(dx, dx + ctx->cov_n, 0.0);
+  if (pool.empty()) return finish(PLV_OK);
+  // ---- triangulate every pool line (REF :45-63; get_imu_poses drops views without bounding clones)
+  const int Lp = (int)pool.size();
+  std::vector<int> ptr(Lp + 1, 0), D(Lp);
+  std::vector<double> anchor(3 * (size_t)Lp, 0.0);
+  std::vector<uint8_t> has(Lp, 0), ok(Lp);
+  for (int l = 0; l < Lp; ++l) {
+    ptr[l + 1] = ptr[l] + (int)pool[l].tr.t.size();
+    D[l] = pool[l].tr.D;
+    for (int pid : pool[l].tr.points)  // first triangulated point of the line (REF :233-247)
+      if (plv_point_used_lookup(ctx, (uint64_t)pid, &anchor[3 * (size_t)l])) {
+        has[l] = 1;
+        break;
+      }
+  }
+  const int nobs = ptr[Lp];
+  std::vector<double> ot(nobs), lg(6 * (size_t)Lp);
+  std::vector<float> uv(4 * (size_t)nobs), uvn(4 * (size_t)nobs);
+  for (int l = 0; l < Lp; ++l) {
+    const LineTrack &tr = pool[l].tr;
+    std::copy(tr.t.begin(), tr.t.end(), ot.begin() + ptr[l]);
+    std::copy(tr.uv.begin(), tr.uv.end(), uv.begin() + 4 * (size_t)ptr[l]);
+    std::copy(tr.uvn.begin(), tr.uvn.end(), uvn.begin() + 4 * (size_t)ptr[l]);
+  }
+  plv_line_tracks all{};
+  all.n_lines = Lp;
+  all.obs_ptr = ptr.data();
+  all.obs_time = ot.data();
+  all.seg_uv = uv.data();
+  all.seg_uvn = uvn.data();
+  all.D = D.data();
+  all.anchor_pt = anchor.data();
+  all.has_pt = has.data();
+  int rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
+  if (rc != PLV_OK) {
+    for (const Cand &c : pool) give_back_all(c);
+    return finish(rc);
+  }
+  std::vector<int> sel;
+  for (int l = 0; l < Lp; ++l) {
+    int valid = 0;
+    for (double t : pool[l].tr.t) valid += line_has_bounding_poses(*st, t + dt);
+    if (!ok[l] || valid < 2 || valid > opt->max_obs || (int)sel.size() >= cap) {
+      give_back_all(pool[l]);
+      continue;
+    }
+    sel.push_back(l);
+  }
+  res->n_msckf = (int)sel.size();
+  if (sel.empty()) return finish(PLV_OK);
+  // ---- UpdaterCamera::lines_update
+  const int L = (int)sel.size();
+  std::vector<int> sptr(L + 1, 0);
+  std::vector<double> st_t, sl(6 * (size_t)L);
+  std::vector<float> suv;
+  for (int q = 0; q < L; ++q) {
+    const Cand &c = pool[sel[q]];
+    for (size_t i = 0; i < c.tr.t.size(); ++i) {
+      if (!line_has_bounding_poses(*st, c.tr.t[i] + dt)) {
+        give_back(c, i);
+        continue;
+      }
+      st_t.push_back(c.tr.t[i]);
+      suv.insert(suv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+    }
+    sptr[q + 1] = (int)st_t.size();
+    std::copy(lg.begin() + 6 * (size_t)sel[q], lg.begin() + 6 * (size_t)sel[q] + 6, sl.begin() + 6 * (size_t)q);
+    if (line_ids) line_ids[q] = c.id;
+  }
+  if (lines_out) std::copy(sl.begin(), sl.end(), lines_out);
+  plv_line_tracks lt{};
+  lt.n_lines = L;
+  lt.obs_ptr = sptr.data();
+  lt.obs_time = st_t.data();
+  lt.seg_uv = suv.data();
+  lt.line_FinG = sl.data();
+  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  int k = 0;
+  rc = plv_line_jacobian_columns(st, &lt, cols.data(), (int)cols.size(), &k);
+  if (rc == PLV_OK) rc = plv_build_line_jacobians_resident(ctx, st, &lt, k, cols.data(), 2 * opt->max_obs);
+  std::vector<uint8_t> acc(L, 0);
+  int n_rows = 0;
+  if (rc == PLV_OK) {
+    rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 0.0, acc.data(), &n_rows, dx);
+    res->status = rc;
+    if (rc == PLV_E_NOT_PSD) rc = PLV_OK;
+  }
+  if (rc != PLV_OK) {
+    for (int q = 0; q < L; ++q) give_back_all(pool[sel[q]]);
+    return finish(rc);
+  }
+  res->n_rows = n_rows;
+  for (int q = 0; q < L; ++q) {
+    res->n_accepted += acc[q];
+    if (accepted_out) accepted_out[q] = acc[q];
+    if (!acc[q] || res->status == PLV_E_NOT_PSD) {  // REF UpdaterCamera.cpp:441-444 copy_to_db(lbd_unused, line)
+      const Cand &c = pool[sel[q]];
+      for (size_t i = 0; i < c.tr.t.size(); ++i)
+        if (line_has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c, i);
+    }
+  }
+  rc = finish(PLV_OK);
+  if (opt->window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188
+    std::lock_guard<std::mutex> lk(T->mtx);
+    for (auto it = T->db.begin(); it != T->db.end();) {
+      LineTrack &tr = it->second;
+      size_t keep = 0;
+      for (size_t i = 0; i < tr.t.size(); ++i)
+        if (!(tr.t[i] < t_oldest)) {
+          if (keep != i) {
+            tr.t[keep] = tr.t[i];
+            std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+            std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+          }
+          ++keep;
+        }
+      tr.t.resize(keep);
+      tr.uv.resize(4 * keep);
+      tr.uvn.resize(4 * keep);
+      it = keep == 0 ? T->db.erase(it) : std::next(it);
+    }
+    plv_point_used_cleanup(ctx, t_oldest);
+  }
+  return rc;
+}
+
 }  // extern "C"

@@ -24,6 +24,10 @@ struct Tracker {
   std::vector<uint8_t> mask_last;  // W*H or empty
   uint64_t currid = 0;             // REF: TrackBase::currid (4*num_aruco + 1 - 1 = 0 without ArUco tags)
   std::unordered_map<uint64_t, Track> db;
+  struct UsedPoint {
+    double p[3], newest;
+  };
+  std::unordered_map<uint64_t, UsedPoint> used;  // the reference's `point_used` database (triangulated features)
   std::mutex mtx;
 };
 
@@ -366,6 +370,12 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     // get_imu_poses (:327-372): observations without bounding clones go back to the database
     int valid = 0;
     for (size_t i = 0; i < c.tr.t.size(); ++i) valid += has_bounding_poses(*st, c.tr.t[i] + dt);
+    if (valid >= 2 && ok[f]) {  // copy_to_db(db_used, feat): dynamic (:677) and MSCKF (:697) features, Triangulated = true
+      std::lock_guard<std::mutex> lk(T->mtx);
+      Tracker::UsedPoint &u = T->used[c.id];
+      std::copy(pf.begin() + 3 * (size_t)f, pf.begin() + 3 * (size_t)f + 3, u.p);
+      u.newest = c.tr.t.back();
+    }
     if (valid < 2 || !ok[f] || !(err[f] < 3.0) || valid > opt->max_obs) {  // :656-683 (+ batch capacity)
       give_back_all(c);
       continue;
@@ -433,6 +443,33 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   rc = finish(PLV_OK);
   if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);  // REF CamHelper.cpp:733-737
   return rc;
+}
+
+int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, double newest_obs_time) {
+  if (!ctx || !p_FinG) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  Tracker::UsedPoint &u = T->used[id];
+  std::copy(p_FinG, p_FinG + 3, u.p);
+  u.newest = newest_obs_time;
+  return PLV_OK;
+}
+
+// line_api.hip: FeatureDatabase::get_feature(id) on point_used (Triangulated features only)
+int plv_point_used_lookup(plv_ctx *ctx, uint64_t id, double *p) {
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  auto it = T->used.find(id);
+  if (it == T->used.end()) return 0;
+  std::copy(it->second.p, it->second.p + 3, p);
+  return 1;
+}
+// point_used->cleanup_measurements(oldest_clone_time)   REF: UpdaterCamera.cpp:186-188
+void plv_point_used_cleanup(plv_ctx *ctx, double t_oldest) {
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  for (auto it = T->used.begin(); it != T->used.end();)
+    it = it->second.newest < t_oldest ? T->used.erase(it) : std::next(it);
 }
 
 }  // extern "C"
