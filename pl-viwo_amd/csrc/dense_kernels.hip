@@ -27,39 +27,72 @@ namespace plv {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------
-// G (nc x nc, col-major, upper tiles) = A^T A.  One workgroup per upper tile; its GRAM_WAVES waves
-// split the rows and the partial tiles are summed through LDS in a fixed order (deterministic).
+// G (nc x nc, col-major, upper tiles) = A^T A in two launches that read A exactly once.
+// (The first form — a workgroup per output tile streaming its two column blocks — re-read every column
+// block once per tile: rocprofv3 FETCH_SIZE 4.7 MB per launch for a 1.5 MB matrix, 24 us.)
+//   gram_chunk_kernel  one workgroup per GRAM_CH rows: the chunk (all nc columns) is staged in LDS with
+//                      row-contiguous (coalesced) loads, its 16 waves share the upper tiles, partial
+//                      tiles go out in per-lane order;
+//   gram_reduce_kernel one workgroup per tile sums the chunk partials in a fixed order (deterministic).
+#define GRAM_CH 64
 #define GRAM_WAVES 16
-__global__ void __launch_bounds__(64 * GRAM_WAVES) gram_kernel(const double *__restrict__ A, int lda, int m, int nc,
-                                                                double *__restrict__ G) {
-  __shared__ double part[GRAM_WAVES][4][64];
-  const int nt = (nc + 15) >> 4;
-  int rem = blockIdx.x, ti = 0;
+__global__ void __launch_bounds__(64 * GRAM_WAVES) gram_chunk_kernel(const double *__restrict__ A, int lda, int m, int nc,
+                                                                      double *__restrict__ part /* [chunk][tile][4][64] */) {
+  extern __shared__ double As[];  // [nc][GRAM_CH + 1]
+  const int row0 = blockIdx.x * GRAM_CH;
+  const int rows = min(GRAM_CH, m - row0);
+  for (int idx = threadIdx.x; idx < nc * GRAM_CH; idx += blockDim.x) {
+    const int c = idx / GRAM_CH, r = idx - c * GRAM_CH;
+    As[c * (GRAM_CH + 1) + r] = r < rows ? A[(size_t)c * lda + row0 + r] : 0.0;
+  }
+  __syncthreads();
+  const int nt = (nc + 15) >> 4, ntri = nt * (nt + 1) / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+  for (int tile = wave; tile < ntri; tile += GRAM_WAVES) {
+    int rem = tile, ti = 0;
+    while (rem >= nt - ti) {
+      rem -= nt - ti;
+      ++ti;
+    }
+    const int tj = ti + rem;
+    const double *ai = As + min(ti * 16 + li, nc - 1) * (GRAM_CH + 1);  // columns beyond nc only feed entries
+    const double *aj = As + min(tj * 16 + li, nc - 1) * (GRAM_CH + 1);  // that are never read
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < GRAM_CH / 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[4 * u + kq], aj[4 * u + kq], acc, 0, 0, 0);
+    double *out = part + ((size_t)blockIdx.x * ntri + tile) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q * 64 + lane] = acc[q];
+  }
+}
+
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restrict__ part, int nchunks, int nc,
+                                                          double *__restrict__ G) {
+  const int nt = (nc + 15) >> 4, ntri = nt * (nt + 1) / 2;
+  const int tile = blockIdx.x;
+  int rem = tile, ti = 0;
   while (rem >= nt - ti) {
     rem -= nt - ti;
     ++ti;
   }
   const int tj = ti + rem;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rows_per = ((m + GRAM_WAVES - 1) / GRAM_WAVES + 3) & ~3;
-  const int row0 = wave * rows_per;
-  const int nrows = max(0, min(m, row0 + rows_per) - row0);
-  const double *Ai = A + (size_t)min(ti * 16 + (lane & 15), nc - 1) * lda + row0;  // columns beyond nc only feed
-  const double *Aj = A + (size_t)min(tj * 16 + (lane & 15), nc - 1) * lda + row0;  // entries that are not stored
-  d4 acc = {0, 0, 0, 0};
-  auto fa = [&](int, int kk) { return Ai[kk]; };
-  auto fb = [&](int kk, int) { return Aj[kk]; };
-  acc = mfma_tile_f64_pipe<8>(fa, fb, nrows, acc);
+  const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // eight independent partial sums: the loads of eight chunks are in flight together (the order of the
+  // additions is fixed, so the result does not depend on timing)
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const double *p = part + (size_t)tile * 256 + threadIdx.x;
+  const size_t stride = (size_t)ntri * 256;
+  int c = 0;
+  for (; c + 8 <= nchunks; c += 8) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) part[wave][q][lane] = acc[q];
-  __syncthreads();
-  if (wave < 4) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < GRAM_WAVES; ++w) s += part[w][wave][lane];
-    const int i = ti * 16 + (lane >> 4) + 4 * wave, j = tj * 16 + (lane & 15);
-    if (i < nc && j < nc) G[(size_t)j * nc + i] = s;
+    for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(c + u) * stride];
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (c + u < nchunks) s[u] += p[(size_t)(c + u) * stride];
+  const double s0 = (s[0] + s[1]) + (s[2] + s[3]), s1 = (s[4] + s[5]) + (s[6] + s[7]);
+  const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
+  if (i < nc && j < nc) G[(size_t)j * nc + i] = s0 + s1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -127,17 +160,26 @@ __global__ void __launch_bounds__(256) ekf_commit_diag_kernel(double *__restrict
 
 // ========================================================================================== launchers
 // Compression of the stacked m x nc matrix [H | r] (col-major, lda) into R (k x k upper, ldr) and z.
-int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_G, size_t g_elems,
+int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems,
                          double *d_R, int ldr, double *d_z) {
   const int k = nc - 1;
-  if (k > 128 || (size_t)nc * nc > g_elems) {
-    set_last_error("gram compress: %d columns exceed the register-resident factorisation (128)", k);
+  const int nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
+  const int nchunks = cdiv(m, GRAM_CH);
+  const size_t part_elems = (size_t)nchunks * ntri * 256, g_elems = (size_t)nc * nc;
+  if (k > 128 || part_elems + g_elems > tmp_elems) {
+    set_last_error("gram compress: %d columns / %d rows exceed the blocked factorisation's workspace", k, m);
     return PLV_E_CAPACITY;
   }
-  const int nt = cdiv(nc, 16);
+  double *d_part = d_tmp, *d_G = d_tmp + part_elems;
   {
-    ProfScope ps(ctx->prof, "gram_kernel", ctx->stream);
-    hipLaunchKernelGGL(gram_kernel, dim3(nt * (nt + 1) / 2), dim3(64 * GRAM_WAVES), 0, ctx->stream, d_A, lda, m, nc, d_G);
+    ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
+    const size_t shm = (size_t)nc * (GRAM_CH + 1) * sizeof(double);
+    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)gram_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(gram_chunk_kernel, dim3(nchunks), dim3(64 * GRAM_WAVES), shm, ctx->stream, d_A, lda, m, nc, d_part);
+  }
+  {
+    ProfScope ps(ctx->prof, "gram_reduce_kernel", ctx->stream);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_part, nchunks, nc, d_G);
   }
   return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
 }

@@ -539,7 +539,11 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   const int nc = k + 1;
   const int Mtot = F * mp_max;
   TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
-  size_t tmp_elems = (size_t)std::max(Mtot / (2 * nc) + 2, 16) * nc * nc;
+  size_t tmp_elems = (size_t)std::max(Mtot / (2 * nc) + 2, 16) * nc * nc;  // TSQR tree levels
+  {  // Gram path: per-chunk partial tiles (64-row chunks, upper 16x16 tiles) + the reduced matrix
+    const size_t nt = (size_t)(nc + 15) / 16, ntri = nt * (nt + 1) / 2;
+    tmp_elems = std::max(tmp_elems, (size_t)((Mtot + 63) / 64) * ntri * 256 + (size_t)nc * nc);
+  }
   TRY(ctx->d_stack2.reserve(tmp_elems * 8));
 
   double *d_dx;
