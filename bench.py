@@ -74,7 +74,8 @@ def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
         "nullspace_kernel": ("mfma", F_FEATS * 6.0 * (FDIM + k + 1) * (2 * M_OBS * FDIM - FDIM * (FDIM + 1) / 2)),
         "chi2_gate_kernel": ("mfma", F_FEATS * (2.0 * mp * mp * k + mp ** 3 / 3.0)),
         "qr_accum_kernel": ("mfma", (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches)),
-        "gram_kernel": ("mfma", 2.0 * m * nc * nc),
+        "gram_chunk_kernel": ("mfma", 1.0 * m * nc * nc),  # upper tiles only: half of 2 m nc^2
+        "gram_reduce_kernel": ("hbm", (m / 64.0) * (nc * nc / 2.0) * 8),
         "bchol_compress_kernel": ("mfma", nc ** 3 / 3.0),
         "bchol_ekf_kernel": ("mfma", r ** 3 / 3.0 + 1.0 * r * r * (n + 1)),
         "gather_cov_kernel": ("hbm", 2.0 * (k * n + k * k) * 8),

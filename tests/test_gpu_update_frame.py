@@ -138,3 +138,22 @@ def test_camera_update_lines(pkg, oracle):
     assert np.abs(ctx.cov_download(n) - P_o).max() <= 1e-6 * np.abs(P).max()
     used = {order[q] for q, a in zip(sel, acc_o) if a}
     assert {int(i) for i in ctx.line_db_ids()} == set(tracks) - used
+
+
+def test_update_calls_on_empty_databases(pkg):
+    sc = synth.vio_scene(F=4, calib_int=True)
+    st, _ = synth.scene_views(pkg, sc)
+    n = sc["n_state"]
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    P = synth.spd_cov(n, seed=1) * 1e-4
+    ctx.cov_upload(P)
+    t = sc["t"]
+    out = ctx.camera_update_points(st, n, 40, 15, t_prev_frame=t[-2], state_time=t[-1])
+    assert out["n_pool"] == 0 and out["n_msckf"] == 0 and not out["dx"].any() and out["status"] == 0
+    out = ctx.camera_update_lines(st, n, 15, t_prev_frame=t[-2], state_time=t[-1])
+    assert out["n_pool"] == 0 and out["n_lines"] == 0 and not out["dx"].any()
+    assert np.array_equal(ctx.cov_download(n), P)
+    # one feature with a single observation: taken, dropped, nothing updated (REF CamHelper.cpp:766-771)
+    ctx.db_append_measurements(9, [t[0]], [[10.0, 10.0]], [[0.0, 0.0]])
+    out = ctx.camera_update_points(st, n, 40, 15, t_prev_frame=t[-2], state_time=t[-1])
+    assert out["n_pool"] == 1 and out["n_msckf"] == 0 and ctx.db_size() == 0
