@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sequential", action="store_true",
+                    help="one context, update of frame i finished before the front-end of frame i+1 starts")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +149,12 @@ def main():
     pkg = ge.load_pkg()
     cfg = pkg.default_config(W, H)
     cfg.device = local_rank if world > 1 else 0
+    # Two contexts = two HIP streams, as the reference has two objects (TrackKLT / the updater): `ctx` tracks,
+    # `uctx` owns the covariance and runs the update.  In the default (pipelined) mode the update of frame i
+    # is enqueued first and the front-end of frame i+1 runs while it executes (tracking does not depend on
+    # the filter state, TrackKLT.cpp:96-200), so a step still does one full front-end and one full update.
     ctx = pkg.Context(cfg)
+    uctx = ctx if args.sequential else pkg.Context(cfg)
 
     frames, pts, P, scene = build_inputs()
     import synth
@@ -156,23 +163,39 @@ def main():
     assert len(cols) == K_COLS
     ctx.image_stage(0, frames[0])
     ctx.image_stage(1, frames[1])
-    ctx.cov_upload(P)
-    ctx.cov_checkpoint()
+    uctx.cov_upload(P)
+    uctx.cov_checkpoint()
     ctx.feed_staged(0)
 
     state = {}
 
-    def step(i):
-        ctx.feed_staged((i + 1) & 1)
-        out = ctx.perform_matching(pts, pts)
-        ctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
-        ctx.cov_rollback()
-        rc, dx, acc, nr = ctx.msckf_update_resident(N_STATE, SIGMA2)
+    def step_sequential(i, c=None):
+        c = c or ctx
+        c.feed_staged((i + 1) & 1)
+        out = c.perform_matching(pts, pts)
+        c.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
+        c.cov_rollback()
+        rc, dx, acc, nr = c.msckf_update_resident(N_STATE, SIGMA2)
         if rc != 0:
             raise RuntimeError("EKF update rejected inside the benchmark")
         state["tracked"] = int(out[1].sum())
         state["lk_iters"] = out[4]
         state["accepted"] = int(acc.sum())
+
+    def step_pipelined(i):
+        uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)   # update of frame i: enqueue only
+        uctx.cov_rollback()
+        uctx.msckf_update_resident_launch(SIGMA2)
+        ctx.feed_staged((i + 1) & 1)                              # front-end of frame i+1 meanwhile
+        out = ctx.perform_matching(pts, pts)
+        rc, dx, acc, nr = uctx.msckf_update_resident_wait(N_STATE)
+        if rc != 0:
+            raise RuntimeError("EKF update rejected inside the benchmark")
+        state["tracked"] = int(out[1].sum())
+        state["lk_iters"] = out[4]
+        state["accepted"] = int(acc.sum())
+
+    step = step_sequential if args.sequential else step_pipelined
 
     def barrier():
         if dist is not None:
@@ -186,8 +209,24 @@ def main():
     for i in range(args.steps):
         step(i)
     ctx.synchronize()
+    uctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    seq_ms = None
+    if not args.sequential and rank == 0:  # the un-overlapped frame latency, for the record (not `value`)
+        sctx = uctx
+        sctx.image_stage(0, frames[0])
+        sctx.image_stage(1, frames[1])
+        sctx.feed_staged(0)
+        nseq = max(20, min(100, args.steps))
+        for i in range(10):
+            step_sequential(i, sctx)
+        sctx.synchronize()
+        ts = time.perf_counter()
+        for i in range(nseq):
+            step_sequential(i, sctx)
+        sctx.synchronize()
+        seq_ms = (time.perf_counter() - ts) / nseq * 1e3
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -199,12 +238,17 @@ def main():
     roof = None
     if rank == 0:
         nprof = max(20, min(100, args.steps))
-        ctx.prof_enable(True)
-        ctx.prof_reset()
+        for c in {ctx, uctx}:
+            c.prof_enable(True)
+            c.prof_reset()
         for i in range(nprof):
             step(i)
-        ctx.prof_enable(False)
-        table = ctx.prof_table()
+        table = {}
+        for c in {ctx, uctx}:
+            c.prof_enable(False)
+            for kname, (cnt, ms) in c.prof_table().items():
+                a = table.get(kname, (0, 0.0))
+                table[kname] = (a[0] + cnt, a[1] + ms)
         levels = ctx.pyramid_levels(0)
         qr_launches = table.get("qr_accum_kernel", (0, 0))[0] / nprof
         work = algorithmic_work(levels, state["lk_iters"], qr_launches)
@@ -245,11 +289,16 @@ def main():
                                    "MSCKF update of 70 features x 15 clones on n=113 (k=98 columns), points only",
                        "replicas": world, "tracked_points": state["tracked"], "accepted_features": state["accepted"],
                        "lk_iterations_per_frame": int(state["lk_iters"]),
-                       "front_end_arithmetic": "u8/int16/int64 exact + f32 2x2 solve", "update_arithmetic": "f64"},
+                       "front_end_arithmetic": "u8/int16/int64 exact + f32 2x2 solve", "update_arithmetic": "f64",
+                       "schedule": "sequential, one stream" if args.sequential else
+                                   "update of frame i overlapped with the front-end of frame i+1 (two contexts / streams)",
+                       "sequential_ms_per_frame": seq_ms},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if uctx is not ctx:
+        uctx.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -166,6 +166,12 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
                           const double *Hx, const double *res, const int *col_to_state);
 int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate,
                               uint8_t *accepted, int *n_accepted_rows, double *dx);
+/* The same in two halves, for callers that overlap the update with other work (e.g. the front-end of the next
+ * frame on another context / stream): _launch enqueues every kernel and the result copy and returns without
+ * waiting; _wait blocks until they are done and unpacks accepted / rows / dx.  No other call may use this ctx in
+ * between. */
+int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate);
+int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accepted_rows, double *dx);
 int plv_cov_checkpoint(plv_ctx *ctx);
 int plv_cov_rollback(plv_ctx *ctx);
 

@@ -95,6 +95,8 @@ def load_library():
                                        ip, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
         "plv_feat_batch_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, ip]),
         "plv_msckf_update_resident": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, u8p, ip, dp]),
+        "plv_msckf_update_resident_launch": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
+        "plv_msckf_update_resident_wait": (C.c_int, [vp, u8p, ip, dp]),
         "plv_feed_image": (C.c_int, [vp, u8p, C.c_int]),
         "plv_image_stage": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
         "plv_feed_staged": (C.c_int, [vp, C.c_int]),
@@ -449,6 +451,17 @@ class Context:
         nrows = C.c_int()
         rc = self.lib.plv_msckf_update_resident(self.h, float(sigma2), float(chi2_mult), float(res_norm_gate),
                                                 _u8p(acc), C.byref(nrows), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, dx, acc, nrows.value
+
+    def msckf_update_resident_launch(self, sigma2, chi2_mult=1.0, res_norm_gate=3.0):
+        self._chk(self.lib.plv_msckf_update_resident_launch(self.h, float(sigma2), float(chi2_mult), float(res_norm_gate)))
+
+    def msckf_update_resident_wait(self, n):
+        dx = np.zeros(n)
+        acc = np.zeros(self._batch_F, dtype=np.uint8)
+        nrows = C.c_int()
+        rc = self.lib.plv_msckf_update_resident_wait(self.h, _u8p(acc), C.byref(nrows), _dp(dx))
         self._chk(rc, allow=(PLV_E_NOT_PSD,))
         return rc, dx, acc, nrows.value
 

@@ -505,12 +505,12 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   return sync(ctx);
 }
 
-int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate, uint8_t *accepted,
-                              int *n_accepted_rows, double *dx) {
+int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   const int F_guard = us->bF;
-  if (F_guard < 1 || ctx->cov_n < 1 || !dx) {
+  us->pending_F = 0;
+  if (F_guard < 1 || ctx->cov_n < 1) {
     set_last_error("plv_msckf_update_resident: no staged batch / covariance");
     return PLV_E_BADARG;
   }
@@ -615,6 +615,19 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
+  us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
+  return PLV_OK;
+}
+
+int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accepted_rows, double *dx) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  const int F = us->pending_F, n = ctx->cov_n;
+  if (F < 1 || !dx) {
+    set_last_error("plv_msckf_update_resident_wait: nothing was launched");
+    return PLV_E_BADARG;
+  }
+  us->pending_F = 0;
   TRY(sync(ctx));
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
@@ -632,6 +645,13 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
   }
   memcpy(dx, hb, (size_t)n * 8);
   return PLV_OK;
+}
+
+int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate, uint8_t *accepted,
+                              int *n_accepted_rows, double *dx) {
+  if (!dx) return PLV_E_BADARG;
+  TRY(plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate));
+  return plv_msckf_update_resident_wait(ctx, accepted, n_accepted_rows, dx);
 }
 
 int plv_msckf_update(plv_ctx *ctx, double *P, int n, int ldp, int F, int fdim, int k, int ld, const int *rows,

@@ -13,6 +13,7 @@ struct plv_ctx_update_state {
   bool b_on_device_rows = false;  // rows[] produced on the device (plv_build_jacobians_resident)
   bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy
   std::vector<int> brows_host;
+  int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   // jacobian inputs
   plv::DevBuf jin, tri;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
