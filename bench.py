@@ -121,6 +121,16 @@ def cpu_baseline(pkg, frames, pts, P, scene, sample_frames):
                       f"host has {os.cpu_count()} cores"}
 
 
+def reduce_max(elapsed, dist):
+    """MAX over ranks of the timed region (the replicas exchange nothing else)."""
+    if dist is None:
+        return elapsed
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +138,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     ap.add_argument("--sequential", action="store_true",
                     help="one context, update of frame i finished before the front-end of frame i+1 starts")
     args = ap.parse_args()
@@ -144,6 +156,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
         dist = dist_mod
+
+    if args.dry_run:
+        # replicas only: each rank "processes" its own frames (here: sleeps a rank-dependent time), then the
+        # barrier / max-over-ranks / rank-0 JSON logic below it is the same code the real run uses
+        barrier_fn = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+        barrier_fn()
+        t0 = time.perf_counter()
+        time.sleep(0.05 * (1 + rank))
+        elapsed = reduce_max(time.perf_counter() - t0, dist)
+        barrier_fn()
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "value": args.steps * world / elapsed, "unit": "frames/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "elapsed_s": elapsed,
+                              "device_of_rank": local_rank if world > 1 else 0}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import __graft_entry__ as ge
     pkg = ge.load_pkg()
@@ -227,11 +257,7 @@ def main():
             step_sequential(i, sctx)
         sctx.synchronize()
         seq_ms = (time.perf_counter() - ts) / nseq * 1e3
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(elapsed, dist)
 
     # ---- roofline leg: HIP events around every kernel launch on the ctx stream (separate pass so
     # that the event records do not perturb the timed region above)
