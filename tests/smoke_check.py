@@ -26,12 +26,18 @@ def run():
     assert err < 1e-8, err
     assert np.max(np.abs(dx1 - dx0)) / np.max(np.abs(dx0)) < 1e-8
     print(f"smoke: msckf update parity ok (rel err P {err:.2e}, accepted {int(acc1.sum())}/{len(rows)})")
-    if hasattr(sys.modules.get("smoke_frontend"), "run"):
-        pass
-    try:
-        import smoke_frontend
-    except ImportError:
-        smoke_frontend = None
-    if smoke_frontend is not None:
-        smoke_frontend.run(pkg, ctx)
+    # one tracked frame: hist-eq + pyramid + LK + undistort + RANSAC, bit-exact LK vs the oracle
+    fo = oracle_lib.load_front()
+    W, H = 752, 480
+    canvas = synth.texture_canvas(W, H, seed=42, blobs=150)
+    f0, f1 = synth.render_frame(canvas, W, H), synth.render_frame(canvas, W, H, tx=2.5, ty=-1.5, rot_deg=0.2)
+    pts0 = synth.grid_points(W, H, 120)
+    ctx.feed_image(f0)
+    ctx.feed_image(f1)
+    pts1, mask, n0, n1, iters = ctx.perform_matching(pts0, pts0)
+    p0, p1 = fo.pyramid(fo.equalize_hist(f0)), fo.pyramid(fo.equalize_hist(f1))
+    ref1, st, it = fo.lk_track(p0, p1, pts0, pts0)
+    assert np.array_equal(pts1[st > 0], ref1[st > 0]) and it == iters, (it, iters)
+    assert mask.sum() > 80
+    print(f"smoke: tracked frame ok (LK bit-exact on {int((st > 0).sum())} points, {int(mask.sum())} RANSAC inliers)")
     ctx.close()
