@@ -1,263 +1,9 @@
-// blocked_chol.hip — blocked Cholesky with border rows, tiles resident in MFMA accumulators (fp64).
-//
-// Third generation of the two factorisations on the update path (profiles/r01 history: Householder
-// TSQR 440 us x4 -> element-wise register elimination 64 us -> this, 34 us).  Both are "factor a
-// symmetric k x k matrix A = L L^T and push nb border rows B through it (B <- B L^-T)":
-//   compression  (REF: StateHelper::measurement_compress_inplace, PL/state/StateHelper.cpp:602-614)
-//       A = equilibrated Gram matrix of [H r],  border = the (H^T r) row   ->  R = L^T, z
-//   EKF update   (REF: StateHelper::EKFUpdate, StateHelper.cpp:94-173)
-//       A = S = H P H^T + R,  border = [M ; res^T] ((n+1) x r)           ->  W^T = [M ; res^T] L^-T
-//       (then K M^T = W^T W and dx = W^T y, ekf_dc_kernel)
-//
-// Work decomposition (16-column panels, one wave per 16-row strip):
-//   * NT waves own the symmetric row strips: tiles (t, c <= t), each held TRANSPOSED as a
-//     v_mfma_f64_16x16x4 accumulator (reg q of lane l = A[16t + (l&15)][16c + (l>>4) + 4q]).
-//     Held that way, an accumulator register is bit-for-bit a valid MFMA B operand, and row j of a
-//     tile is one k-slab of one register, so panel results feed the next product with no shuffles.
-//   * one more wave owns a border strip (16 border rows); workgroup g takes strip g and
-//     redundantly factors A, so border work spreads over CUs with no inter-workgroup sync.
-//   panel p:  (a) the wave owning the diagonal tile eliminates its 16 pivots one MFMA each
-//                 (diag_chain) and publishes every step through LDS;
-//             (b) every strip below applies the steps to its own panel tile as they appear
-//                 (strip_chain, spin on an LDS counter), ending with X^T = (tile L_d^-T)^T;
-//                 symmetric strips publish X through LDS in per-lane order (the same lane reads it
-//                 back as an A operand);
-//             (c) one barrier, then the trailing update  tile(t,c)^T -= L(c,p) X_t^T  (4 MFMA / tile).
-//   The pivot chain is the critical path: 16 dependent steps per panel.  Strip -> wave assignment
-//   pairs heavy and light strips on the waves that share a SIMD (w, w+4: tools/ubench/simd_map.hip).
-// Pivots <= tau mark a numerically dependent column: its column of L is zero (compression: the
-// gauge directions an MSCKF Jacobian cannot observe; EKF: tau = 0, "not PSD").
+// blocked_chol.hip — the two factorisation kernels of the update path on top of blocked_chol.hpp:
+// compression (Gram matrix -> [R z]) and the EKF solve (S, [M; res^T] -> W).
+#include "blocked_chol.hpp"
 #include "update_kernels.hpp"
-#include "wave_ops.hpp"
 
 namespace plv {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Optional phase stamps (tools/ubench/bchol_time.hip defines PLV_BCHOL_TIMING): s_memtime per wave.
-#ifdef PLV_BCHOL_TIMING
-__device__ long long *g_bchol_stamps = nullptr;  // [waves][64]
-#define BC_STAMP(id)                                                                            \
-  do {                                                                                          \
-    if (g_bchol_stamps && (threadIdx.x & 63) == 0 && blockIdx.x == 0)                           \
-      g_bchol_stamps[(threadIdx.x >> 6) * 64 + (id)] = (long long)__builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define BC_STAMP(id)
-#endif
-
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-// Volatile LDS accesses with the address space spelled out: through a generic pointer the compiler
-// keeps volatile accesses as flat_load / flat_store (it does not infer address spaces for them).
-#define PLV_LDS __attribute__((address_space(3)))
-template <class T> __device__ __forceinline__ void lds_vstore(T *p, T v) { *(volatile PLV_LDS T *)(p) = v; }
-template <class T> __device__ __forceinline__ T lds_vload(const T *p) { return *(const volatile PLV_LDS T *)(p); }
-
-struct BcLds {
-  double Lp[2][8][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity
-  double Ts[16][64][2];    // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
-  double rs[2][16];        // 1 / l_jj (0: dead column), by panel parity
-  int step_flag;           // 16 * panel + steps published so far
-  int rs_flag;             // panels whose rs[] is published
-  int bad;
-};
-
-// 1/x: v_rcp_f64 + two Newton steps (the sequence the compiler's IEEE division starts with, without
-// the scale / fixup instructions that only matter outside the pivots' range).
-__device__ __forceinline__ double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  return r;
-}
-
-// ---- the sequential part: 16 pivots of the diagonal tile ---------------------------------------
-// T is the symmetric 16x16 diagonal tile in MFMA accumulator layout.  Row j of an accumulator sits in
-// the 16 lanes of k-slab (j&3) of register j>>2, which is where the A and B operands of
-// v_mfma_f64_16x16x4 want it, so one elimination step is "scale the register by -1/pivot masked to
-// that slab, one MFMA" (only one operand needs the mask).  Each step is published through LDS
-// ({register, masked multiplier}, then a step counter; LDS executes a wave's instructions in order)
-// and every strip below applies it to its own panel tile while this wave computes the next pivot
-// (strip_chain).  The pivot chain is the critical path of the whole kernel; measured per step on
-// MI355X (tools/ubench/diag_step.hip): 153 ticks for this form, +95 if the same wave also carries
-// an identity border to get L_d^-1, 600 for a one-lane-per-row v_readlane formulation.
-template <bool STORE_L>
-__device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, d4 &cap) {
-  const int lane = threadIdx.x & 63;
-  const int lq = lane >> 4;
-  double mask01[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) mask01[q] = (lq == q) ? 1.0 : 0.0;
-  double mine = 0.0;
-  bool dead_any = false;
-  double pv = readlane_f64(T[0], 0);
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const int kk = jj & 3, rq = jj >> 2;
-    const bool live = pv > tau;  // uniform
-    dead_any |= !live;
-    const double ninv = live ? -rcp_nr(pv) : 0.0;
-    const double nm = ninv * mask01[kk];
-    const double trow = T[rq];
-    lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[jj][lane][0]), d2{trow, nm});
-    lds_vstore(&lds.step_flag, 16 * p + jj + 1);
-    __builtin_amdgcn_sched_barrier(0);  // publish now: the scheduler would sink all 16 stores below the chain
-    mine = (lane == jj) ? pv : mine;
-    if (STORE_L) cap[rq] = (lq == kk) ? trow : cap[rq];
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(trow * nm, trow, T, 0, 0, 0);
-    if (jj < 15) pv = readlane_f64(T[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1);
-  }
-  if (lane < 16) lds_vstore(&lds.rs[p & 1][lane], (mine > tau) ? 1.0 / sqrt(mine) : 0.0);
-  lds_vstore(&lds.rs_flag, p + 1);
-  if (dead_any && lane == 0) lds.bad = 1;
-}
-
-// ---- every strip below the diagonal tile follows the chain on its own (transposed) panel tile ----
-// W[c][i] -= a_c * (W[j][i] / pivot_j): A operand = the published register (slab j&3 holds a), B
-// operand = own register scaled by the published masked multiplier.  Row j is captured before it is
-// eliminated; scaled by 1/l_jj at the end it is row j of X^T = (tile L_d^-T)^T.
-__device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
-  const int lane = threadIdx.x & 63;
-  const int lq = lane >> 4;
-  d4 cap = {0, 0, 0, 0};
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const int kk = jj & 3, rq = jj >> 2;
-    const int want = 16 * p + jj + 1;
-    d2 d;
-    for (;;) {  // flag first, then the data: both loads are in flight together
-      const int f = lds_vload(&lds.step_flag);
-      d = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[jj][lane][0]));
-      if (__builtin_amdgcn_readfirstlane(f) >= want) break;
-      __builtin_amdgcn_s_sleep(1);  // a spinning wave must not take issue slots and LDS cycles from the chain
-    }
-    const double brow = W[rq];
-    cap[rq] = (lq == kk) ? brow : cap[rq];
-    W = __builtin_amdgcn_mfma_f64_16x16x4f64(d[0], brow * d[1], W, 0, 0, 0);
-  }
-  while (__builtin_amdgcn_readfirstlane(lds_vload(&lds.rs_flag)) < p + 1) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) cap[q] *= lds_vload(&lds.rs[p & 1][lq + 4 * q]);
-  return cap;
-}
-
-template <int NT, class Ops>
-__device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb, double tau) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform roles
-  const int li = lane & 15, lq = lane >> 4;
-  const int ntk = (k + 15) >> 4;
-  const bool is_sym = wave < NT;
-  // strip t has (t - p) trailing tiles at panel p and the border strip ntk - 1 - p; waves w, w+4, w+8 share
-  // a SIMD (one matrix pipe), so heavy strips are paired with light ones
-  constexpr int map7[8] = {6, 5, 4, 1, 0, 2, 3, 7};
-  constexpr int map8[8] = {1, 7, 6, 5, 0, 2, 3, 4};
-  const int t = NT == 7 ? map7[wave & 7] : (NT == 8 ? map8[wave & 7] : wave);
-  const int bs = blockIdx.x;  // one border strip per workgroup
-  const bool active = is_sym ? (t < ntk) : (bs * 16 < nb);
-  d4 acc[NT];
-#pragma unroll
-  for (int c = 0; c < NT; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cc = c * 16 + lq + 4 * q;
-      double v = 0.0;
-      if (active && c < ntk) {
-        if (is_sym)
-          v = c <= t ? ops.sym_raw(t * 16 + li, cc) : 0.0;
-        else
-          v = ops.border_raw(bs * 16 + li, cc);
-      }
-      acc[c][q] = v;
-    }
-  ops.scales_ready();  // (compression: column scales into LDS + barrier; the raw loads above are already in flight)
-#pragma unroll
-  for (int c = 0; c < NT; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cc = c * 16 + lq + 4 * q;
-      if (active && c < ntk) {
-        if (is_sym)
-          acc[c][q] = c <= t ? ops.sym_fix(t * 16 + li, cc, acc[c][q]) : 0.0;
-        else
-          acc[c][q] = ops.border_fix(bs * 16 + li, cc, acc[c][q]);
-      }
-    }
-  BC_STAMP(0);
-#pragma unroll
-  for (int p = 0; p < NT; ++p) {
-    if (p < ntk) {
-      const bool below = active && (!is_sym || t > p);
-      d4 x = {0, 0, 0, 0};
-      BC_STAMP(1 + 5 * p);
-      if (is_sym && t == p) {
-        d4 cap = {0, 0, 0, 0};
-        diag_chain<Ops::kStoreL>(acc[p], lds, tau, p, cap);
-        if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = lq + 4 * q;
-            if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * lds.rs[p & 1][c]);
-          }
-        }
-      } else if (below) {
-        x = strip_chain(acc[p], lds, p);
-        acc[p] = x;
-        if (is_sym) *reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]) = x;
-      }
-      BC_STAMP(2 + 5 * p);
-      __syncthreads();
-      BC_STAMP(3 + 5 * p);
-      if (below) {
-#pragma unroll
-        for (int c0 = p + 1; c0 < NT; c0 += 3) {  // three panel tiles per LDS round trip
-          d4 a[3];
-#pragma unroll
-          for (int u = 0; u < 3; ++u)
-            if (c0 + u < NT && c0 + u < ntk && (!is_sym || c0 + u <= t))
-              a[u] = *reinterpret_cast<const d4 *>(&lds.Lp[p & 1][c0 + u][lane][0]);
-#pragma unroll
-          for (int u = 0; u < 3; ++u)
-            if (c0 + u < NT && c0 + u < ntk && (!is_sym || c0 + u <= t)) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-                acc[c0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u][s], x[s], acc[c0 + u], 0, 0, 0);
-            }
-        }
-      }
-      BC_STAMP(4 + 5 * p);
-    }
-  }
-  BC_STAMP(50);
-  if (active) {
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      if (c < ntk && (!is_sym || c < t)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = c * 16 + lq + 4 * q;
-          if (is_sym)
-            ops.store_sym(t * 16 + li, cc, acc[c][q]);
-          else
-            ops.store_border(bs * 16 + li, cc, acc[c][q]);
-        }
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------ compression
 struct CompressOps {
@@ -320,7 +66,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const dou
     lds.rs_flag = 0;
   }
   // pivots of the unit-diagonal matrix lie in [0,1]; below tau a column is numerically dependent
-  blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc);
+  blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc, 0);
 }
 
 // ------------------------------------------------------------------------------------------ EKF
@@ -366,7 +112,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
     lds.rs_flag = 0;
   }
   __syncthreads();
-  blocked_chol<NT>(ops, lds, r, n + 1, 0.0);
+  blocked_chol<NT>(ops, lds, r, n + 1, 0.0, (int)blockIdx.x);
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && lds.bad) atomicOr(flag, 2);
 }

@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "plv_ctx.hpp"
+#include "blocked_chol.hpp"
 #include "mfma_tile.hpp"
 #include "update_kernels.hpp"
 
@@ -203,80 +204,103 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
 
 #define CHI2_MAXM 63
 
-__global__ void __launch_bounds__(256) chi2_gate_kernel(Chi2Args a) {
+// Ops of blocked_chol for one feature's bordered system: S (upper triangle valid, LDS, pitch 65) and the
+// residual as the single border row; the border comes back as y = L^-1 r.
+struct Chi2Ops {
+  static constexpr bool kStoreL = false;
+  const double *S;  // LDS
+  const double *r;  // global
+  int mp;
+  double *y;        // LDS [64]
+  __device__ __forceinline__ double sym_raw(int i, int c) const {
+    const int hi = min(max(i, c), mp - 1), lo = min(min(i, c), mp - 1);
+    return S[lo * 65 + hi];  // REF: selfadjointView<Upper>
+  }
+  __device__ __forceinline__ double border_raw(int, int c) const { return r[min(c, mp - 1)]; }
+  __device__ __forceinline__ void scales_ready() const {}
+  __device__ __forceinline__ double sym_fix(int i, int c, double g) const { return (i >= mp || c >= mp) ? (i == c ? 1.0 : 0.0) : g; }
+  __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b == 0 && c < mp) ? g : 0.0; }
+  __device__ __forceinline__ void store_sym(int, int, double) const {}
+  __device__ __forceinline__ void store_border(int b, int c, double v) const {
+    if (b == 0 && c < mp) y[c] = v;
+  }
+};
+
+// NT = number of 16-row strips of S (2 for mp <= 32, 4 up to 63); blockDim = 64 * max(4, NT + 1).
+template <int NT>
+__global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kernel(Chi2Args a) {
   extern __shared__ double smem[];
+  __shared__ BcLds lds;
+  __shared__ double ybuf[64];
+  __shared__ double passflag;
   const int f = blockIdx.x;
   const int rows_f = a.rows[f];
   const int mp = rows_f - a.fdim_off;
   const int k = a.k, ld = a.ld;
   const int mt = (max(mp, 1) + 15) >> 4;
-  double *S = smem;                      // [64][65]  bordered
+  double *S = smem;  // [64][65]
   const double *H = a.Hx + (size_t)f * k * ld;
   const double *r = a.res + (size_t)f * ld;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int trow = lane >> 4, tcol = lane & 15;
 
-  bool valid = mp >= 1 && mp <= CHI2_MAXM && rows_f >= a.min_rows;
+  const bool valid = mp >= 1 && mp <= 16 * NT && mp <= CHI2_MAXM && rows_f >= a.min_rows;  // block-uniform
   double chi = NAN;
   double nrm2 = 0.0;
   if (valid) {
     // T = H' Ps was produced for every feature by chi2_t_kernel (col-major, ld)
     const double *Tg = a.T + (size_t)f * k * ld;
-    // S = T H'^T + sigma2 I  (full; symmetric up to rounding, upper triangle is what is used)
-    for (int t = wave; t < mt * mt; t += 4) {
+    // S = T H'^T + sigma2 I, upper tiles (REF: selfadjointView<Upper>)
+    for (int t = wave; t < mt * mt; t += nw) {
       const int ti = t / mt, tj = t - ti * mt;
-      if (tj < ti) continue;  // upper tiles only (REF: selfadjointView<Upper>)
+      if (tj < ti) continue;
       d4 acc = {0, 0, 0, 0};
-      auto fa = [&](int i, int kk) { int row = ti * 16 + i; return row < mp ? Tg[kk * ld + row] : 0.0; };
-      auto fb = [&](int kk, int j) { int row = tj * 16 + j; return row < mp ? H[kk * ld + row] : 0.0; };
-      acc = mfma_tile_f64(fa, fb, k, acc);
+      // rows beyond mp only feed entries that are not stored: clamp instead of branching (loads stay in flight)
+      const double *Tr = Tg + min(ti * 16 + tcol, mp - 1), *Hr = H + min(tj * 16 + tcol, mp - 1);
+      auto fa = [&](int, int kk) { return Tr[kk * ld]; };
+      auto fb = [&](int kk, int) { return Hr[kk * ld]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int i = ti * 16 + trow + 4 * q, j = tj * 16 + tcol;
         if (i < mp && j < mp) S[i * 65 + j] = acc[q] + (i == j ? a.sigma2 : 0.0);
       }
     }
+    if (threadIdx.x == 0) {
+      lds.bad = 0;
+      lds.step_flag = 0;
+      lds.rs_flag = 0;
+    }
     __syncthreads();
     if (wave == 0) {
-      // mirror upper -> lower (REF: selfadjointView<Upper>), then border row mp = res
-      for (int j = 0; j < mp; ++j)
-        if (lane < mp && lane > j) S[lane * 65 + j] = S[j * 65 + lane];
-      if (lane < mp) S[mp * 65 + lane] = r[lane];
-      double rv = lane < mp ? r[lane] : 0.0;
+      const double rv = lane < mp ? r[lane] : 0.0;
       nrm2 = wave_sum(rv * rv);
-      // left-looking Cholesky, lane = row (rows 0..mp, row mp is the border)
-      bool bad = false;
-      for (int j = 0; j < mp; ++j) {
-        double s = 0.0;
-        if (lane >= j && lane <= mp) {
-          s = S[lane * 65 + j];
-          for (int p = 0; p < j; ++p) s -= S[lane * 65 + p] * S[j * 65 + p];
-        }
-        double d = __shfl(s, j, 64);
-        if (!(d > 0.0)) bad = true;
-        double ljj = sqrt(d);
-        if (lane >= j && lane <= mp) S[lane * 65 + j] = (lane == j) ? ljj : s / ljj;
-      }
-      double y = lane < mp ? S[mp * 65 + lane] : 0.0;
+    }
+    // bordered Cholesky: the border row ends as y = L^-1 r, chi2 = |y|^2 (== r^T S^-1 r of the reference)
+    Chi2Ops ops{S, r, mp, ybuf};
+    blocked_chol<NT>(ops, lds, mp, 1, 0.0, 0);
+    __syncthreads();
+    if (wave == 0) {
+      const double y = lane < mp ? ybuf[lane] : 0.0;
       chi = wave_sum(y * y);
-      if (bad) chi = NAN;
+      if (lds.bad) chi = NAN;
     }
   }
   if (wave == 0 && lane == 0) {
     a.chi2[f] = chi;
-    S[64 * 65] = 0.0;
+    passflag = 0.0;
     if (a.stack) {
       bool pass = valid && !isnan(chi);
       if (pass && a.res_norm_gate > 0.0) pass = sqrt(nrm2) < a.res_norm_gate;
       if (pass) pass = (mp < a.q95_n) && (chi < a.chi2_mult * a.q95[mp]);
       a.accepted[f] = pass ? 1 : 0;
       if (a.acc_rows) a.acc_rows[f] = pass ? mp : 0;
-      S[64 * 65] = pass ? 1.0 : 0.0;
+      passflag = pass ? 1.0 : 0.0;
     }
   }
   if (a.stack) {
     __syncthreads();
-    const bool pass = S[64 * 65] != 0.0;
+    const bool pass = passflag != 0.0;
     double *dst = a.stack + (size_t)f * a.mp_max;
     for (int idx = threadIdx.x; idx < a.mp_max * (k + 1); idx += blockDim.x) {
       int j = idx / a.mp_max, i = idx - j * a.mp_max;
@@ -655,7 +679,14 @@ int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a_in, int max_mp) {
   }
   size_t shm = (size_t)(65 * 65 + 8) * sizeof(double);
   ProfScope ps(ctx->prof, "chi2_gate_kernel", ctx->stream);
-  hipLaunchKernelGGL(chi2_gate_kernel, dim3(F), dim3(256), shm, ctx->stream, a);
+  // static LDS of blocked_chol (48 KB) + the dynamic S tile exceed the 64 KB default
+  if (max_mp <= 32) {
+    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(chi2_gate_kernel<2>, dim3(F), dim3(256), shm, ctx->stream, a);
+  } else {
+    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(chi2_gate_kernel<4>, dim3(F), dim3(320), shm, ctx->stream, a);
+  }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
