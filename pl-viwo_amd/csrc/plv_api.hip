@@ -552,7 +552,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int *d_acc_rows;
   TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
 
-  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres));
+  // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
+  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
   Chi2Args a{};
   a.P = ctx->d_P.as<double>();
   a.ldp = n;
@@ -575,7 +576,6 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
   a.accepted = d_acc;
   a.acc_rows = d_acc_rows;
-  TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, us->bcols.as<int>(), k));
   TRY(launch_chi2(ctx, F, a, mp_max));
 
   const double *dH, *dr;

@@ -122,6 +122,36 @@ __device__ __forceinline__ void make_givens_fast(double p, double q, double &c, 
   }
 }
 
+// Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load goes
+// through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols] (k x k), inv[state] =
+// position of that state in cols or -1.  256 threads per block; runs as its own launch or as extra
+// blocks of nullspace_kernel (independent work, one launch less on the update stream).
+struct GatherArgs {
+  const double *P;
+  int ldp, n;
+  const int *cols;
+  int k;
+  double *Pc, *Ps;
+  int *inv;
+};
+__device__ __forceinline__ void gather_cov_block(const GatherArgs &g, int block) {
+  const int idx = block * 256 + threadIdx.x;
+  const int n = g.n, k = g.k;
+  if (idx < k * n) {
+    const int kk = idx / n, j = idx - kk * n;
+    g.Pc[idx] = g.P[(size_t)g.cols[kk] * g.ldp + j];  // P symmetric: row cols[kk] == column cols[kk]
+  }
+  if (idx < k * k) {
+    const int kk = idx / k, c = idx - kk * k;
+    g.Ps[idx] = g.P[(size_t)g.cols[kk] * g.ldp + g.cols[c]];
+  }
+  if (idx < n) {
+    int pos = -1;
+    for (int q = 0; q < k; ++q) pos = (g.cols[q] == idx) ? q : pos;
+    g.inv[idx] = pos;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K11: one workgroup per feature.  X = [Hf | Hx | res] (rows x ncol) staged row-major in LDS,
 // one thread per column.  For pivot column n the rotation sequence m = rows-1 .. n+1 is the
@@ -131,8 +161,12 @@ __device__ __forceinline__ void make_givens_fast(double p, double q, double &c, 
 // (a register-resident variant without the LDS round trips measured the same 29-32 us).
 __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld, const int *__restrict__ rows_arr,
                                                         double *__restrict__ Hf, double *__restrict__ Hx,
-                                                        double *__restrict__ res) {
+                                                        double *__restrict__ res, int F, GatherArgs g) {
   extern __shared__ double smem[];
+  if ((int)blockIdx.x >= F) {  // independent work riding on the same launch: the dense covariance gathers
+    gather_cov_block(g, blockIdx.x - F);
+    return;
+  }
   const int f = blockIdx.x;
   const int rows = rows_arr[f];
   const int ncol = fdim + k + 1;
@@ -403,24 +437,7 @@ __global__ void __launch_bounds__(1024) qr_accum_kernel(const double *__restrict
 // Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load
 // goes through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols]
 // (k x k, row-major), inv[state] = position of that state in cols or -1.
-__global__ void __launch_bounds__(256) gather_cov_kernel(const double *__restrict__ P, int ldp, int n,
-                                                         const int *__restrict__ cols, int k, double *__restrict__ Pc,
-                                                         double *__restrict__ Ps, int *__restrict__ inv) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < k * n) {
-    const int kk = idx / n, j = idx - kk * n;
-    Pc[idx] = P[(size_t)cols[kk] * ldp + j];  // P symmetric: row cols[kk] == column cols[kk]
-  }
-  if (idx < k * k) {
-    const int kk = idx / k, c = idx - kk * k;
-    Ps[idx] = P[(size_t)cols[kk] * ldp + cols[c]];
-  }
-  if (idx < n) {
-    int pos = -1;
-    for (int q = 0; q < k; ++q) pos = (cols[q] == idx) ? q : pos;
-    inv[idx] = pos;
-  }
-}
+__global__ void __launch_bounds__(256) gather_cov_kernel(GatherArgs g) { gather_cov_block(g, blockIdx.x); }
 
 // T = Hx' * Ps for every feature at once: one 16x16 tile per wave over (feature, row tile, col tile).
 __global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
@@ -633,29 +650,43 @@ __global__ void __launch_bounds__(256) ekf_apply_kernel(const double *__restrict
 // ========================================================================================== launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+static int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k, GatherArgs &g) {
+  int rc;
+  if ((rc = ctx->d_Pc.reserve((size_t)k * n * 8)) || (rc = ctx->d_Ps.reserve((size_t)k * k * 8)) ||
+      (rc = ctx->d_inv.reserve((size_t)n * 4)))
+    return rc;
+  g = GatherArgs{d_P, ldp, n, d_cols, k, ctx->d_Pc.as<double>(), ctx->d_Ps.as<double>(), ctx->d_inv.as<int>()};
+  return PLV_OK;
+}
+
+// `d_P` non-null: the covariance gathers for (P, cols) ride on the same launch (n, ldp, d_cols describe them)
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
-                     double *d_res) {
+                     double *d_res, const double *d_P, int n, int ldp, const int *d_cols) {
   size_t shm = (size_t)(ld * (fdim + k + 1) + ld) * sizeof(double);
   if (shm > 160 * 1024) {
     set_last_error("nullspace: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
+  GatherArgs g{};
+  int extra = 0;
+  if (d_P) {
+    int rc = gather_args(ctx, d_P, n, ldp, d_cols, k, g);
+    if (rc) return rc;
+    extra = cdiv(std::max(k * n, std::max(k * k, n)), 256);
+  }
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)nullspace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   ProfScope ps(ctx->prof, "nullspace_kernel", ctx->stream);
-  hipLaunchKernelGGL(nullspace_kernel, dim3(F), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res);
+  hipLaunchKernelGGL(nullspace_kernel, dim3(F + extra), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res, F, g);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
 
 int launch_gather_cov(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k) {
-  int rc;
-  if ((rc = ctx->d_Pc.reserve((size_t)k * n * 8)) || (rc = ctx->d_Ps.reserve((size_t)k * k * 8)) ||
-      (rc = ctx->d_inv.reserve((size_t)n * 4)))
-    return rc;
+  GatherArgs g{};
+  int rc = gather_args(ctx, d_P, n, ldp, d_cols, k, g);
+  if (rc) return rc;
   ProfScope ps(ctx->prof, "gather_cov_kernel", ctx->stream);
-  const int total = std::max(k * n, std::max(k * k, n));
-  hipLaunchKernelGGL(gather_cov_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, d_P, ldp, n, d_cols, k,
-                     ctx->d_Pc.as<double>(), ctx->d_Ps.as<double>(), ctx->d_inv.as<int>());
+  hipLaunchKernelGGL(gather_cov_kernel, dim3(cdiv(std::max(k * n, std::max(k * k, n)), 256)), dim3(256), 0, ctx->stream, g);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
