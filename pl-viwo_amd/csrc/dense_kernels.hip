@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restri
 // ------------------------------------------------------------------------------------------
 // [dC | dx] = W[:, :n]^T [W[:, :n] | y]  (upper tiles; dC = K M^T of the reference, y = W[:, n]).
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
-                                                     double *__restrict__ dC, int ldc, double *__restrict__ dx) {
+                                                     double *__restrict__ dC, int ldc, double *__restrict__ dx,
+                                                     const double *__restrict__ P, int ldp, int *__restrict__ flag) {
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -121,41 +122,24 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
     const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
     if (i < n && j < n) dC[(size_t)j * ldc + i] = acc[q];
     if (i < n && j == n) dx[i] = acc[q];
+    // REF: StateHelper.cpp:143-152 — any P_ii - (K M^T)_ii < 0 rejects the update; the commit kernel reads the flag
+    if (i == j && i < n && P[(size_t)i * ldp + i] - acc[q] < 0.0) atomicOr(flag, 1);
   }
 }
 
-// REF: StateHelper.cpp:143-156 — reject when any P_ii - dC_ii < 0 (nothing modified), else
-// P.upper -= dC, mirrored.  Every workgroup re-evaluates the (n-entry) test; block 0 publishes it.
+// REF: StateHelper.cpp:143-156 — the update is rejected (nothing modified) when ekf_dc_kernel found a negative
+// diagonal or the factorisation was not positive definite; else P.upper -= dC, mirrored.
 __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
-                                                         const double *__restrict__ dC, int ldc, int *__restrict__ flag) {
-  __shared__ int neg;
-  if (threadIdx.x == 0) neg = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x)
-    if (P[(size_t)i * ldp + i] - dC[(size_t)i * ldc + i] < 0.0) neg = 1;
-  __syncthreads();
-  const int f = *flag;
-  if (neg || (f & 2)) {
-    if (neg && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 1);
-    return;
-  }
-  // off-diagonal commit only: the diagonal (which every block reads for the test above) is
-  // committed by ekf_commit_diag_kernel, launched after this kernel.
+                                                         const double *__restrict__ dC, int ldc, const int *__restrict__ flag) {
+  if (*flag != 0) return;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
     int j = idx / n, i = idx - j * n;
-    if (i < j) {
+    if (i <= j) {
       double v = P[(size_t)j * ldp + i] - dC[(size_t)j * ldc + i];
       P[(size_t)j * ldp + i] = v;
       P[(size_t)i * ldp + j] = v;
     }
   }
-}
-__global__ void __launch_bounds__(256) ekf_commit_diag_kernel(double *__restrict__ P, int ldp, int n,
-                                                              const double *__restrict__ dC, int ldc,
-                                                              const int *__restrict__ flag) {
-  if (*flag != 0) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) P[(size_t)i * ldp + i] -= dC[(size_t)i * ldc + i];
 }
 
 // ========================================================================================== launchers
@@ -201,13 +185,12 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
     int tn = cdiv(n + 1, 16);
     int waves = tn * (tn + 1) / 2;
-    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx);
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag);
   }
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
                        d_flag);
-    hipLaunchKernelGGL(ekf_commit_diag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n, d_flag);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
