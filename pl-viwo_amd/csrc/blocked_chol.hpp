@@ -87,6 +87,14 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-x * r, r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+
 // ---- the sequential part: 16 pivots of the diagonal tile ---------------------------------------
 // T is the symmetric 16x16 diagonal tile in MFMA accumulator layout.  Row j of an accumulator sits in
 // the 16 lanes of k-slab (j&3) of register j>>2, which is where the A and B operands of
@@ -104,12 +112,13 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
   double mask01[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) mask01[q] = (lq == q) ? 1.0 : 0.0;
-  double mine = 0.0;
   bool dead_any = false;
   double pv = readlane_f64(T[0], 0);
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const int kk = jj & 3, rq = jj >> 2;
+    if (jj == 0) BC_STAMP(40);
+    if (jj == 8) BC_STAMP(41);
     const bool live = pv > tau;  // uniform
     dead_any |= !live;
     const double ninv = live ? -rcp_nr(pv) : 0.0;
@@ -117,13 +126,16 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
     const double trow = T[rq];
     lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[jj][lane][0]), d2{trow, nm});
     lds_vstore(&lds.step_flag, 16 * p + jj + 1);
+#ifndef PLV_BC_NO_SCHED
     __builtin_amdgcn_sched_barrier(0);  // publish now: the scheduler would sink all 16 stores below the chain
-    mine = (lane == jj) ? pv : mine;
+#endif
+    // 1 / l_jj for the strips, in the shadow of the MFMA latency (rsq + two Newton steps)
+    lds_vstore(&lds.rs[p & 1][jj], live ? rsqrt_nr(pv) : 0.0);
     if (STORE_L) cap[rq] = (lq == kk) ? trow : cap[rq];
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(trow * nm, trow, T, 0, 0, 0);
     if (jj < 15) pv = readlane_f64(T[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1);
   }
-  if (lane < 16) lds_vstore(&lds.rs[p & 1][lane], (mine > tau) ? 1.0 / sqrt(mine) : 0.0);
+  BC_STAMP(42);
   lds_vstore(&lds.rs_flag, p + 1);
   if (dead_any && lane == 0) lds.bad = 1;
 }
@@ -145,7 +157,10 @@ __device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
       const int f = lds_vload(&lds.step_flag);
       d = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[jj][lane][0]));
       if (__builtin_amdgcn_readfirstlane(f) >= want) break;
-      __builtin_amdgcn_s_sleep(1);  // a spinning wave must not take issue slots and LDS cycles from the chain
+#ifndef PLV_BC_SLEEP
+#define PLV_BC_SLEEP 1
+#endif
+      __builtin_amdgcn_s_sleep(PLV_BC_SLEEP);  // a spinning wave must not take issue slots and LDS cycles from the chain
     }
     const double brow = W[rq];
     cap[rq] = (lq == kk) ? brow : cap[rq];
@@ -170,6 +185,8 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb
   const int t = NT == 7 ? map7[wave & 7] : (NT == 8 ? map8[wave & 7] : wave);
   const int bs = strip;  // one border strip per workgroup, carried by wave NT (further waves only keep the barriers)
   const bool active = is_sym ? (t < ntk) : (wave == NT && bs * 16 < nb);
+  // acc[j] holds tile (strip, p + j): the array is rotated after every panel, and a finished panel tile is stored
+  // right away instead of being kept to the end.
   d4 acc[NT];
 #pragma unroll
   for (int c = 0; c < NT; ++c)
@@ -199,66 +216,68 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb
       }
     }
   BC_STAMP(0);
+  // The panel loop is unrolled: the same body as a real loop (rotating the accumulators makes it loop
+  // invariant) gave wrong results for NT = 4 with hipcc 7.2 (dx off by 1e-3; correct for NT = 2, 7, 8) and was
+  // not faster, so the suspected instruction-cache effect was not the limiter either.
 #pragma unroll
-  for (int p = 0; p < NT; ++p) {
+  for (int p = 0; p < NT; ++p)
     if (p < ntk) {
-      const bool below = active && (!is_sym || t > p);
-      d4 x = {0, 0, 0, 0};
-      BC_STAMP(1 + 5 * p);
-      if (is_sym && t == p) {
-        d4 cap = {0, 0, 0, 0};
-        diag_chain<Ops::kStoreL>(acc[p], lds, tau, p, cap);
-        if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
+    const bool below = active && (!is_sym || t > p);
+    d4 x = {0, 0, 0, 0};
+    BC_STAMP(1 + 5 * p);
+    if (is_sym && t == p) {
+      d4 cap = {0, 0, 0, 0};
+      diag_chain<Ops::kStoreL>(acc[0], lds, tau, p, cap);
+      if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = lq + 4 * q;
-            if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * lds.rs[p & 1][c]);
-          }
+        for (int q = 0; q < 4; ++q) {
+          const int c = lq + 4 * q;
+          if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * lds.rs[p & 1][c]);
         }
-      } else if (below) {
-        x = strip_chain(acc[p], lds, p);
-        acc[p] = x;
-        if (is_sym) *reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]) = x;
       }
-      BC_STAMP(2 + 5 * p);
-      __syncthreads();
-      BC_STAMP(3 + 5 * p);
-      if (below) {
+#ifdef PLV_BC_SOLO
+    } else if (false) {
+#else
+    } else if (below) {
+#endif
+      x = strip_chain(acc[0], lds, p);
+      if (is_sym) *reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]) = x;
 #pragma unroll
-        for (int c0 = p + 1; c0 < NT; c0 += 3) {  // three panel tiles per LDS round trip
+      for (int q = 0; q < 4; ++q) {  // panel p of this strip is final: out it goes
+        const int cc = p * 16 + lq + 4 * q;
+        if (is_sym)
+          ops.store_sym(t * 16 + li, cc, x[q]);
+        else
+          ops.store_border(bs * 16 + li, cc, x[q]);
+      }
+    }
+    BC_STAMP(2 + 5 * p);
+    __syncthreads();
+    BC_STAMP(3 + 5 * p);
+    if (below) {
+      const int ntrail = (is_sym ? t : ntk - 1) - p;  // tiles (strip, p+1 .. p+ntrail) live in acc[1 .. ntrail]
+#pragma unroll
+      for (int c0 = 1; c0 < NT; c0 += 3) {  // three panel tiles per LDS round trip
+        if (c0 <= ntrail) {
           d4 a[3];
 #pragma unroll
           for (int u = 0; u < 3; ++u)
-            if (c0 + u < NT && c0 + u < ntk && (!is_sym || c0 + u <= t))
-              a[u] = *reinterpret_cast<const d4 *>(&lds.Lp[p & 1][c0 + u][lane][0]);
+            if (c0 + u < NT && c0 + u <= ntrail) a[u] = *reinterpret_cast<const d4 *>(&lds.Lp[p & 1][p + c0 + u][lane][0]);
 #pragma unroll
           for (int u = 0; u < 3; ++u)
-            if (c0 + u < NT && c0 + u < ntk && (!is_sym || c0 + u <= t)) {
+            if (c0 + u < NT && c0 + u <= ntrail) {
 #pragma unroll
               for (int s = 0; s < 4; ++s)
                 acc[c0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u][s], x[s], acc[c0 + u], 0, 0, 0);
             }
         }
       }
-      BC_STAMP(4 + 5 * p);
     }
+#pragma unroll
+    for (int i = 0; i + 1 < NT; ++i) acc[i] = acc[i + 1];
+    BC_STAMP(4 + 5 * p);
   }
   BC_STAMP(50);
-  if (active) {
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      if (c < ntk && (!is_sym || c < t)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = c * 16 + lq + 4 * q;
-          if (is_sym)
-            ops.store_sym(t * 16 + li, cc, acc[c][q]);
-          else
-            ops.store_border(bs * 16 + li, cc, acc[c][q]);
-        }
-      }
-    }
-  }
 }
 
 }  // namespace plv

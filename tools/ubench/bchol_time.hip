@@ -45,7 +45,7 @@ int main() {
     for (int p = 0; p < 7; ++p)
       printf(" p%d: @%lld chain %lld bar %lld trail %lld |", p, s[1 + 5 * p] - t0, s[2 + 5 * p] - s[1 + 5 * p],
              s[3 + 5 * p] - s[2 + 5 * p], s[4 + 5 * p] - s[3 + 5 * p]);
-    printf(" end@%lld\n", s[50] - t0);
+    printf(" end@%lld | last chain: steps0-7 %lld steps8-15 %lld\n", s[50] - t0, s[41] - s[40], s[42] - s[41]);
   }
   return 0;
 }
