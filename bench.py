@@ -121,6 +121,23 @@ def cpu_baseline(pkg, frames, pts, P, scene, sample_frames):
                       f"host has {os.cpu_count()} cores"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate runs, profiles/r01/README.md); None when the summary is missing.  The guide's gfx950
+    correction (FETCH_SIZE x 2) applies to wide coalesced reads only; byte / 8-byte gathers as in lk_kernel are
+    uncalibrated, so the raw counter is reported."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_d_pmc_hbm.csv")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        next(fh)
+        for line in fh:
+            k, n, f_kb, w_kb = line.strip().split(",")
+            if k.split("<")[0].endswith(kernel):
+                return (float(f_kb) + float(w_kb)) * 1024.0, "profiles/r01/bench_d_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE, KB)"
+    return None, None
+
+
 def reduce_max(elapsed, dist):
     """MAX over ranks of the timed region (the replicas exchange nothing else)."""
     if dist is None:
@@ -286,8 +303,9 @@ def main():
             achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, unit = per_launch / avg_s / 1e12, F64_MFMA_PEAK_TF, "TFLOP/s"
+        traffic, traffic_src = pmc_traffic(name)
         roof = {"bound": kind, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                "traffic": None, "kernel": name, "avg_launch_us": avg_s * 1e6,
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": name, "avg_launch_us": avg_s * 1e6,
                 "algorithmic_per_launch": per_launch,
                 "kernels_us_per_frame": {k: round(v[1] / nprof * 1e3, 2) for k, v in
                                          sorted(table.items(), key=lambda kv: -kv[1][1])}}
