@@ -186,3 +186,35 @@ def test_clahe_bit_exact(pkg):
         assert np.array_equal(c.pyramid_level(0, 0), ref)
         pyr = fo.pyramid(ref)
         assert np.array_equal(c.pyramid_level(0, 2), pyr.level(2)[0])
+
+
+def test_front_end_at_config_d(pkg):
+    """BASELINE configs[3]: 1280x720, 500 points (6 pyramid levels): LK / undistort bit-exact, lines identical."""
+    import oracle_lib
+    fo, lo = oracle_lib.load_front(), oracle_lib.load_line()
+    W, H = 1280, 720
+    cfg = pkg.default_config(W, H)
+    cfg.num_features = 500
+    c = pkg.Context(cfg)
+    canvas = synth.texture_canvas(W, H, seed=21, blobs=400, lines=60)
+    f0 = synth.render_frame(canvas, W, H)
+    f1 = synth.render_frame(canvas, W, H, tx=4.0, ty=-3.0, rot_deg=0.3, scale=1.002)
+    pts0 = synth.grid_points(W, H, 500)
+    c.feed_image(f0)
+    c.feed_image(f1)
+    assert c.pyramid_levels(0) == 6
+    pts1, mask, n0, n1, iters = c.perform_matching(pts0, pts0)
+    p0, p1 = fo.pyramid(fo.equalize_hist(f0)), fo.pyramid(fo.equalize_hist(f1))
+    assert p0.levels == 6
+    ref1, st, it = fo.lk_track(p0, p1, pts0, pts0)
+    assert it == iters and np.array_equal(pts1[st > 0], ref1[st > 0])
+    assert mask.sum() > 400
+    K8 = np.array(list(cfg.intrinsics))
+    assert np.array_equal(n1, fo.undistort(K8, pts1))
+    ref_lines = lo.detect_lines(c.pyramid_level(0, 0))
+    got = c.detect_lines(0)
+    assert len(got) == len(ref_lines) > 10 and np.abs(got - ref_lines).max() < 2e-3
+    # the device walk at this size does not fit LDS (640 x 360 bytes): it runs from global memory
+    c.line_walk_mode(True)
+    got2 = c.detect_lines(0)
+    assert np.array_equal(got2, got)
