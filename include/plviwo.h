@@ -478,6 +478,27 @@ int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, doubl
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted, double *line_FinG, int cap);
 
+/* ---------------------------------------------------------------------------------------------
+ * In-state (SLAM) landmarks (a30) on the device-resident covariance, one landmark per call as the reference
+ * loops.  Inactive at the shipped configuration (max_slam: 0).
+ * ------------------------------------------------------------------------------------------- */
+/* UpdaterCamera::slam_update for one landmark (REF: PL-VIWO/src/update/cam/UpdaterCamera.cpp:296-338): H is the
+ * system of get_feature_jacobian_full with the landmark's columns appended ([Hx | Hf], rows x k col-major,
+ * ld), R = I (whitened rows).  Chi2Check (threshold chi2_mult * q95[rows]) then EKFUpdate.  *accepted = 0
+ * when the gate fails or rows < 2 (nothing changed); PLV_E_NOT_PSD when EKFUpdate rejects. */
+int plv_slam_update(plv_ctx *ctx, int rows, int k, int ld, const double *H, const double *res, const int *col_to_state,
+                    double chi2_mult, uint8_t *accepted, double *dx);
+/* StateHelper::initialize (REF: PL-VIWO/src/state/StateHelper.cpp:357-439) for a 3-dof landmark: Givens split of
+ * [Hf (3 cols) | Hx (k cols) | res], Mahalanobis gate on the updating rows (threshold on ALL rows, :415),
+ * initialize_invertible (:495-600: P_LL = H_L^-1 (H P H^T + I) H_L^-T, cross terms -P H^T H_L^-T, the suspicious
+ * / negative-diagonal rejections), EKFUpdate with the updating rows, revert when that fails (:430-435).
+ * On success *ok = 1, the covariance has grown to (n+3) with the landmark at index n, dx_init (3) is the
+ * landmark's own correction H_L^-1 res_init and dx (n+3) the EKF correction that follows it. */
+int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf, const double *Hx, const double *res,
+                        const int *col_to_state, double chi2_mult, uint8_t *ok, double *dx_init, double *dx);
+/* StateHelper::marginalize (REF: StateHelper.cpp:235-303): drop rows / columns [id, id + size). */
+int plv_cov_marginalize(plv_ctx *ctx, int id, int size);
+
 #ifdef __cplusplus
 }
 #endif

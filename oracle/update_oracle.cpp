@@ -283,4 +283,104 @@ int orc_msckf_update(double *P, int n, int ldp, int F, int fdim, int k, int ld, 
   return 0;
 }
 
+
+// ---------------------------------------------------------------- a30: SLAM landmarks
+// UpdaterCamera::slam_update for one landmark   REF: UpdaterCamera.cpp:296-338
+// H = [Hx | Hf] of get_feature_jacobian_full with the landmark's columns appended, R = I (whitened).
+// Returns 0 and accepted = 1/0; -3 when EKFUpdate rejects (state untouched).
+int orc_slam_update(double *P, int n, int ldp, const double *H, int rows, int k, int ldh, const int *cols, const double *res,
+                    double chi2_mult, const double *q95, unsigned char *accepted, double *dx) {
+  Mat Pm = Mat::from(P, n, n, ldp), Hm = Mat::from(H, rows, k, ldh), rm = Mat::from(res, rows, 1, rows), d;
+  *accepted = 0;
+  for (int i = 0; i < n; ++i) dx[i] = 0.0;
+  double chi;
+  Mat Ps = marginal_cov(Pm, cols, k);
+  if (!chi2(Ps, Hm, rm, 1.0, chi) || !(chi < chi2_mult * q95[rows])) return 0;  // Chi2Check (UpdaterStatistics.cpp:47-84)
+  if (!ekf_update(Pm, Hm, cols, rm, nullptr, d)) return -3;
+  *accepted = 1;
+  Pm.to(P, ldp);
+  for (int i = 0; i < n; ++i) dx[i] = d(i, 0);
+  return 0;
+}
+
+// StateHelper::initialize + initialize_invertible (+ marginalize on a failed update)
+// REF: StateHelper.cpp:357-439, 495-600, 235-303.  The new variable (size 3) is appended at index n.
+// P_out is (n+3) x (n+3), ld = n+3.  Returns 1 = initialised, 0 = rejected (P_out undefined).
+// dx_init (3) = H_L^-1 res_init, dx (n+3) = the EKF correction of the updating part (zeros if it has no rows).
+int orc_slam_initialize(const double *P, int n, int ldp, int rows, int k, int ld, const double *Hf_in, const double *Hx_in,
+                        const double *res_in, const int *cols, double chi2_mult, const double *q95, double *P_out, double *dx_init,
+                        double *dx) {
+  const int f = 3;
+  Mat Pm = Mat::from(P, n, n, ldp);
+  Mat HL = Mat::from(Hf_in, rows, f, ld), HR = Mat::from(Hx_in, rows, k, ld), r = Mat::from(res_in, rows, 1, ld);
+  givens3(HL, HR, r);  // :391
+  Mat Hxinit = top_rows(HR, 0, f), Hfinit = top_rows(HL, 0, f), rinit = top_rows(r, 0, f);
+  Mat Hup = top_rows(HR, f, rows - f), rup = top_rows(r, f, rows - f);
+  Mat Ps = marginal_cov(Pm, cols, k);
+  // :409-424 health check: R isotropic = I after whitening; threshold uses res.rows() (all rows)
+  if (rows - f > 0) {
+    double chi;
+    if (!chi2(Ps, Hup, rup, 1.0, chi)) return 0;
+    if (chi > chi2_mult * q95[rows]) return 0;
+  }
+  // ---- initialize_invertible :535-598
+  Mat Ma(n, f);
+  for (int j = 0; j < k; ++j)
+    for (int q = 0; q < f; ++q) {
+      const double h = Hxinit(q, j);
+      for (int i = 0; i < n; ++i) Ma(i, q) += Pm(i, cols[j]) * h;
+    }
+  Mat M = matmul(matmul(Hxinit, Ps), transpose(Hxinit));
+  for (int i = 0; i < f; ++i) M(i, i) += 1.0;
+  for (int j = 0; j < f; ++j)
+    for (int i = j + 1; i < f; ++i) M(i, j) = M(j, i);  // selfadjointView<Upper>
+  Mat HLinv;
+  if (!inverse(Hfinit, HLinv)) return 0;
+  Mat PLL = matmul(matmul(HLinv, M), transpose(HLinv));
+  Mat v = matmul(HLinv, rinit);
+  {
+    Mat PLLinv;
+    if (!inverse(PLL, PLLinv)) return 0;
+    double chi = 0;
+    for (int i = 0; i < f; ++i)
+      for (int j = 0; j < f; ++j) chi += v(i, 0) * PLLinv(i, j) * v(j, 0);
+    const double dn = std::sqrt(PLL(0, 0) * PLL(0, 0) + PLL(1, 1) * PLL(1, 1) + PLL(2, 2) * PLL(2, 2));
+    if (chi < 1e-7 || dn > 1000) return 0;
+  }
+  for (int i = 0; i < f; ++i)
+    if (PLL(i, i) < 0.0) return 0;
+  const int n2 = n + f;
+  Mat P2(n2, n2);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) P2(i, j) = Pm(i, j);
+  Mat cross = matmul(Ma, transpose(HLinv));
+  for (int q = 0; q < f; ++q)
+    for (int i = 0; i < n; ++i) {
+      P2(i, n + q) = -cross(i, q);
+      P2(n + q, i) = -cross(i, q);
+    }
+  for (int i = 0; i < f; ++i)
+    for (int j = 0; j < f; ++j) P2(n + i, n + j) = PLL(i, j);
+  for (int i = 0; i < f; ++i) dx_init[i] = v(i, 0);
+  for (int i = 0; i < n2; ++i) dx[i] = 0.0;
+  // ---- :430-435 update with the remaining rows; a rejected update reverts the initialisation
+  if (rows - f > 0) {
+    Mat d;
+    if (!ekf_update(P2, Hup, cols, rup, nullptr, d)) return 0;
+    for (int i = 0; i < n2; ++i) dx[i] = d(i, 0);
+  }
+  P2.to(P_out, n2);
+  return 1;
+}
+
+// StateHelper::marginalize: drop rows / columns [id, id + size)   REF: StateHelper.cpp:235-303
+void orc_cov_marginalize(const double *P, int n, int id, int size, double *P_out) {
+  const int m = n - size;
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) {
+      const int si = i < id ? i : i + size, sj = j < id ? j : j + size;
+      P_out[(size_t)j * m + i] = P[(size_t)sj * n + si];
+    }
+}
+
 }  // extern "C"

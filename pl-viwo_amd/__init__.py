@@ -127,6 +127,9 @@ def load_library():
         "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
+        "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
+        "plv_slam_initialize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, dp, ip, C.c_double, u8p, dp, dp]),
+        "plv_cov_marginalize": (C.c_int, [vp, C.c_int, C.c_int]),
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
@@ -548,6 +551,30 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    # ---- SLAM landmarks
+    def slam_update(self, n, H, res, cols, chi2_mult=1.0):
+        H = np.asfortranarray(H, dtype=np.float64)      # rows x k
+        rows, k = H.shape
+        res, cols = _f64(res), _i32(cols)
+        acc = np.zeros(1, dtype=np.uint8)
+        dx = np.zeros(n)
+        rc = self.lib.plv_slam_update(self.h, rows, k, rows, _dp(H), _dp(res), _ip(cols), float(chi2_mult), _u8p(acc), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, int(acc[0]), dx
+
+    def slam_initialize(self, n, Hf, Hx, res, cols, chi2_mult=1.0):
+        Hf, Hx = np.asfortranarray(Hf, dtype=np.float64), np.asfortranarray(Hx, dtype=np.float64)  # rows x 3, rows x k
+        rows, k = Hx.shape
+        res, cols = _f64(res), _i32(cols)
+        ok = np.zeros(1, dtype=np.uint8)
+        dxi, dx = np.zeros(3), np.zeros(n + 3)
+        self._chk(self.lib.plv_slam_initialize(self.h, rows, k, rows, _dp(Hf), _dp(Hx), _dp(res), _ip(cols), float(chi2_mult), _u8p(ok),
+                                               _dp(dxi), _dp(dx)))
+        return int(ok[0]), dxi, dx
+
+    def cov_marginalize(self, idx, size):
+        self._chk(self.lib.plv_cov_marginalize(self.h, int(idx), int(size)))
 
     # ---- UpdaterCamera::try_update, point half
     def db_append_measurements(self, fid, t, uv, uvn):

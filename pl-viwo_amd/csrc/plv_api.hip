@@ -190,7 +190,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   plv_line_tracker_destroy(ctx);
   plv_frontend_destroy(ctx);
   ctx->prof.destroy();
-  plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
+  plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_P2, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
                          &ctx->d_Mt, &ctx->d_S, &ctx->d_W, &ctx->d_y, &ctx->d_fHf, &ctx->d_fHx, &ctx->d_fres,
                          &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2, &ctx->d_Pc, &ctx->d_Ps,
                          &ctx->d_inv, &ctx->d_T};

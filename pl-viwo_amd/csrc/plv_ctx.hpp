@@ -159,6 +159,7 @@ struct plv_ctx {
   // ---- update side
   int cov_n = 0;          // dimension of the device-resident covariance (0 = none)
   plv::DevBuf d_P;        // n x n col-major, ld = n
+  plv::DevBuf d_P2;       // second covariance buffer: state augmentation / marginalisation write here, then swap
   plv::DevBuf d_H, d_res, d_cols, d_Rdiag, d_dx, d_flag;
   plv::DevBuf d_Mt, d_S, d_W, d_y;          // EKF workspaces
   plv::DevBuf d_Pc, d_Ps, d_inv, d_T;       // dense covariance gathers, H'Ps

@@ -161,7 +161,7 @@ __device__ __forceinline__ void gather_cov_block(const GatherArgs &g, int block)
 // (a register-resident variant without the LDS round trips measured the same 29-32 us).
 __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld, const int *__restrict__ rows_arr,
                                                         double *__restrict__ Hf, double *__restrict__ Hx,
-                                                        double *__restrict__ res, int F, GatherArgs g) {
+                                                        double *__restrict__ res, int F, GatherArgs g, int shift) {
   extern __shared__ double smem[];
   if ((int)blockIdx.x >= F) {  // independent work riding on the same launch: the dense covariance gathers
     gather_cov_block(g, blockIdx.x - F);
@@ -211,15 +211,16 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
     }
   }
   __syncthreads();
-  // write back: Hf whole (upper-triangular now), Hx / res shifted up by fdim rows
+  // write back: Hf whole (upper-triangular now), Hx / res shifted up by `shift` rows (= fdim for the nullspace
+  // projection; 0 keeps the initialising rows as well: StateHelper::initialize, StateHelper.cpp:391-405)
   for (int idx = threadIdx.x; idx < rows * fdim; idx += blockDim.x) {
     int j = idx / rows, i = idx - j * rows;
     gHf[j * ld + i] = X[i * ncol + j];
   }
-  const int mp = rows - fdim;
+  const int mp = rows - shift;
   for (int idx = threadIdx.x; idx < mp * (k + 1); idx += blockDim.x) {
     int j = idx / mp, i = idx - j * mp;
-    double v = X[(i + fdim) * ncol + fdim + j];
+    double v = X[(i + shift) * ncol + fdim + j];
     if (j < k)
       gHx[j * ld + i] = v;
     else
@@ -661,7 +662,7 @@ static int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const in
 
 // `d_P` non-null: the covariance gathers for (P, cols) ride on the same launch (n, ldp, d_cols describe them)
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
-                     double *d_res, const double *d_P, int n, int ldp, const int *d_cols) {
+                     double *d_res, const double *d_P, int n, int ldp, const int *d_cols, int shift) {
   size_t shm = (size_t)(ld * (fdim + k + 1) + ld) * sizeof(double);
   if (shm > 160 * 1024) {
     set_last_error("nullspace: feature block of %zu bytes exceeds LDS", shm);
@@ -676,7 +677,8 @@ int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_
   }
   PLV_HIP_CHECK(hipFuncSetAttribute((const void *)nullspace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   ProfScope ps(ctx->prof, "nullspace_kernel", ctx->stream);
-  hipLaunchKernelGGL(nullspace_kernel, dim3(F + extra), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res, F, g);
+  hipLaunchKernelGGL(nullspace_kernel, dim3(F + extra), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res, F, g,
+                     shift < 0 ? fdim : shift);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

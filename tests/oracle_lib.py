@@ -101,6 +101,46 @@ class Oracle:
         return rc, P, dx, acc, nrows.value
 
 
+def _slam_bind(cls):
+    def slam_update(self, P, H, res, cols, q95, chi2_mult=1.0):
+        P = np.asfortranarray(P, dtype=np.float64).copy(order="F")
+        H = np.asfortranarray(H, dtype=np.float64)
+        rows, k = H.shape
+        n = P.shape[0]
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        q95 = np.ascontiguousarray(q95, dtype=np.float64)
+        acc = np.zeros(1, dtype=np.uint8)
+        dx = np.zeros(n)
+        rc = self.lib.orc_slam_update(_dp(P), n, n, _dp(H), rows, k, rows, _ip(cols), _dp(res), float(chi2_mult), _dp(q95),
+                                      acc.ctypes.data_as(u8p), _dp(dx))
+        return rc, P, int(acc[0]), dx
+
+    def slam_initialize(self, P, Hf, Hx, res, cols, q95, chi2_mult=1.0):
+        P = np.asfortranarray(P, dtype=np.float64)
+        Hf, Hx = np.asfortranarray(Hf, dtype=np.float64), np.asfortranarray(Hx, dtype=np.float64)
+        rows, k = Hx.shape
+        n = P.shape[0]
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        q95 = np.ascontiguousarray(q95, dtype=np.float64)
+        P2 = np.zeros((n + 3, n + 3), order="F")
+        dxi, dx = np.zeros(3), np.zeros(n + 3)
+        self.lib.orc_slam_initialize.restype = C.c_int
+        ok = self.lib.orc_slam_initialize(_dp(P), n, n, rows, k, rows, _dp(Hf), _dp(Hx), _dp(res), _ip(cols), C.c_double(chi2_mult),
+                                          _dp(q95), _dp(P2), _dp(dxi), _dp(dx))
+        return ok, P2, dxi, dx
+
+    def cov_marginalize(self, P, idx, size):
+        P = np.asfortranarray(P, dtype=np.float64)
+        n = P.shape[0]
+        out = np.zeros((n - size, n - size), order="F")
+        self.lib.orc_cov_marginalize(_dp(P), n, int(idx), int(size), _dp(out))
+        return out
+
+    cls.slam_update, cls.slam_initialize, cls.cov_marginalize = slam_update, slam_initialize, cov_marginalize
+
+
 _inst = None
 
 
@@ -109,7 +149,10 @@ def load():
     if _inst is None:
         if not os.path.exists(LIB):
             subprocess.check_call(["make", "-C", ORACLE_DIR])
+        _slam_bind(Oracle)
         _inst = Oracle(C.CDLL(LIB))
+        _inst.lib.orc_slam_update.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_double, dp, u8p, dp]
+        _inst.lib.orc_slam_update.restype = C.c_int
     return _inst
 
 
