@@ -231,19 +231,122 @@ __device__ void interpolate(const JacParams &P, int s0, double t, bool fej, bool
   }
 }
 
-__device__ void jacobian_rows(const JacParams &P, int f, int o, int s0, double tm, int c, double *hf, double *hx, double *rs);
+
+// ---- window tables: everything in `interpolate` that depends only on the interpolation window (the four
+// clones s0..s0+3) and not on the observation time: R0, p0, the three relative rotations with their logs and
+// inverse left Jacobians, the position differences, the inverse Vandermonde matrix.  A feature's 15
+// observations share at most n_clones - 3 windows, and the transcendental-heavy part (3 log_so3, 3 Jl_so3, 4
+// 3x3 inverses per call) is two thirds of the per-observation work: the table is built once per workgroup by
+// otherwise idle lanes (three lanes per window and variant), the observation lanes then only evaluate the
+// polynomial.  Same expressions in the same order as interpolate(): results are bit-identical.
+struct WinTab {
+  M3 R0, Rw[3], JinvW[3], Vi;
+  V3 p0, th[3], dp[3];
+  double vrow[3][3];  // rows of the Vandermonde matrix (scratch until Vi is formed)
+};
+#define JAC_MAX_WIN 40  // (n_clones - 3) * 2 variants must fit
+
+__device__ void build_window_tables(const JacParams &P, WinTab *tab) {
+  const int nwin = max(P.n_clones - 3, 0);
+  for (int idx = threadIdx.x; idx < nwin * 2 * 3; idx += blockDim.x) {
+    const int w = idx % 3, e = idx / 3, s0 = e >> 1, fej = e & 1;
+    const double *Rs = fej ? P.clone_R_fej : P.clone_R, *ps = fej ? P.clone_p_fej : P.clone_p;
+    WinTab &T = tab[e];
+    const M3 R0 = ldM(Rs + 9 * s0);
+    const V3 p0 = ldV(ps + 3 * s0);
+    const M3 Rw = mm(ldM(Rs + 9 * (s0 + 1 + w)), tp(R0));
+    const V3 th = log_so3(Rw);
+    T.Rw[w] = Rw;
+    T.th[w] = th;
+    T.dp[w] = vsub(ldV(ps + 3 * (s0 + 1 + w)), p0);
+    const double d = P.clone_time[s0 + 1 + w] - P.clone_time[s0];
+    T.vrow[w][0] = d;
+    T.vrow[w][1] = d * d;
+    T.vrow[w][2] = d * d * d;
+    if (fej) T.JinvW[w] = inv3(Jl_so3(th));
+    if (w == 0) {
+      T.R0 = R0;
+      T.p0 = p0;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nwin * 2; e += blockDim.x) {
+    M3 V;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V(w, c) = tab[e].vrow[w][c];
+    tab[e].Vi = inv3(V);
+  }
+  __syncthreads();
+}
+
+__device__ void interpolate_tab(const JacParams &P, const WinTab &T, int s0, double t, bool want_jac, Interp &o) {
+  const double dtm = t - P.clone_time[s0];
+  const double pw[4] = {1.0, dtm, dtm * dtm, dtm * dtm * dtm};
+  double lam[3], lamd[3];
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    lam[w] = lamd[w] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lam[w] += pw[i + 1] * T.Vi(i, w);
+      lamd[w] += (double)(i + 1) * pw[i] * T.Vi(i, w);
+    }
+  }
+  V3 A_ori{{0, 0, 0}}, A_pos{{0, 0, 0}};
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    A_ori = vadd(A_ori, vsc(T.th[w], lam[w]));
+    A_pos = vadd(A_pos, vsc(T.dp[w], lam[w]));
+  }
+  const M3 Rio = exp_so3(A_ori);
+  o.R = mm(Rio, T.R0);
+  o.p = vadd(T.p0, A_pos);
+  if (!want_jac) return;
+  const M3 Jl = Jl_so3(A_ori);
+  M3 H0o = Rio;
+  double lsum = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const M3 JinvW = T.JinvW[w];
+    H0o = ma(H0o, ms(mm(Jl, mm(JinvW, T.Rw[w])), -lam[w]));
+    o.Ho[w + 1] = ms(mm(Jl, JinvW), lam[w]);
+    o.lam[w + 1] = lam[w];
+    lsum += lam[w];
+  }
+  o.Ho[0] = H0o;
+  o.lam[0] = 1.0 - lsum;
+  V3 dori{{0, 0, 0}}, dpos{{0, 0, 0}};
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    dori = vadd(dori, vsc(T.th[w], lamd[w]));
+    dpos = vadd(dpos, vsc(T.dp[w], lamd[w]));
+  }
+  const V3 top = vsc(mv(Jl, dori), -1.0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.dtj[i] = top[i];
+    o.dtj[3 + i] = dpos[i];
+  }
+}
+
+__device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int o, int s0, double tm, int c, double *hf, double *hx,
+                              double *rs);
 
 // One workgroup (one wave) per feature, one lane per observation.  The feature's slice of the
 // batch [Hf | Hx | res] is zero-filled here (no separate memset of the 1.8 MB batch), the row slot
 // of an observation is the number of valid observations in front of it (ballot prefix).
-__global__ void __launch_bounds__(64) jacobian_kernel(JacParams P) {
+__global__ void __launch_bounds__(128) jacobian_kernel(JacParams P) {
+  __shared__ WinTab tab[JAC_MAX_WIN];
   const int f = blockIdx.x;
   const int ld = P.ld, k = P.k;
   double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
-  for (int i = threadIdx.x; i < 3 * ld; i += 64) hf[i] = 0.0;
-  for (int i = threadIdx.x; i < k * ld; i += 64) hx[i] = 0.0;
-  for (int i = threadIdx.x; i < ld; i += 64) rs[i] = 0.0;
-  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * ld; i += blockDim.x) hf[i] = 0.0;
+  for (int i = threadIdx.x; i < k * ld; i += blockDim.x) hx[i] = 0.0;
+  for (int i = threadIdx.x; i < ld; i += blockDim.x) rs[i] = 0.0;
+  build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill before the row writes)
+  if (threadIdx.x >= 64) return;  // observation lanes = wave 0
   const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
   int base = 0;
   for (int ob = o0; ob < o1; ob += 64) {  // (more than 64 observations of one feature: next chunk)
@@ -254,12 +357,13 @@ __global__ void __launch_bounds__(64) jacobian_kernel(JacParams P) {
     const unsigned long long vmask = __ballot(s0 >= 0);
     const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
     base += __popcll(vmask);
-    if (s0 >= 0 && 2 * c + 2 <= ld) jacobian_rows(P, f, o, s0, tm, c, hf, hx, rs);
+    if (s0 >= 0 && 2 * c + 2 <= ld) jacobian_rows(P, tab, f, o, s0, tm, c, hf, hx, rs);
   }
   if (threadIdx.x == 0) P.rows[f] = 2 * base;
 }
 
-__device__ void jacobian_rows(const JacParams &P, int f, int o, int s0, double tm, int c, double *hf, double *hx, double *rs) {
+__device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int o, int s0, double tm, int c, double *hf, double *hx,
+                              double *rs) {
   const int ld = P.ld;
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
@@ -267,7 +371,7 @@ __device__ void jacobian_rows(const JacParams &P, int f, int o, int s0, double t
   const V3 pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
 
   Interp jac;
-  interpolate(P, s0, tm, true, true, jac);
+  interpolate_tab(P, tab[2 * s0 + 1], s0, tm, true, jac);
   M3 R_GtoI;
   V3 p_IinG;
   if (P.res_R) {
@@ -275,7 +379,7 @@ __device__ void jacobian_rows(const JacParams &P, int f, int o, int s0, double t
     p_IinG = ldV(P.res_p + 3 * o);
   } else {
     Interp est;
-    interpolate(P, s0, tm, false, false, est);
+    interpolate_tab(P, tab[2 * s0], s0, tm, false, est);
     R_GtoI = est.R;
     p_IinG = est.p;
   }
@@ -1041,7 +1145,11 @@ int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsign
 
 int launch_jacobians(plv_ctx *ctx, const JacParams &P) {
   ProfScope ps(ctx->prof, "jacobian_kernel", ctx->stream);
-  hipLaunchKernelGGL(jacobian_kernel, dim3(P.n_feat), dim3(64), 0, ctx->stream, P);
+  if (2 * (P.n_clones - 3) > JAC_MAX_WIN) {
+    set_last_error("jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
+    return PLV_E_CAPACITY;
+  }
+  hipLaunchKernelGGL(jacobian_kernel, dim3(P.n_feat), dim3(128), 0, ctx->stream, P);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
