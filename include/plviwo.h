@@ -236,6 +236,15 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * equalize + pyramid, first-frame detection or top-up on the last image, temporal KLT + RANSAC,
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
+/* feed_measurement with OptionsCamera::downsample (REF: UpdaterCamera.cpp:85-98): cv::pyrDown(img, Size(cols / 2.0,
+ * rows / 2.0)) of image and mask on the device, then the same path.  The context is created at the halved
+ * resolution with halved intrinsics, as the reference's option loader does (OptionsCamera.cpp:123-138). */
+int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, int src_w, int src_h,
+                                 const uint8_t *mask, int mask_stride);
+/* The pyrDown alone (host in, host out): dst is (src_w / 2) x (src_h / 2). */
+int plv_downsample(plv_ctx *ctx, const uint8_t *src, int stride, int src_w, int src_h, uint8_t *dst, int dstride);
+/* plv_feed_image on the halved image, without the tracker bookkeeping. */
+int plv_feed_image_downsampled(plv_ctx *ctx, const uint8_t *img, int stride, int src_w, int src_h);
 /* TrackBase::get_last_obs / get_last_ids (REF: TrackBase.h:121-131) */
 int plv_tracker_last(plv_ctx *ctx, float *pts, uint64_t *ids, int cap, int *n);
 int plv_db_size(plv_ctx *ctx);
@@ -433,6 +442,10 @@ typedef struct plv_update_options {
   double t_prev_frame;  /* t_hist[size-2]: features without a newer observation are used (REF :636)    */
   double state_time;    /* State::time: observations newer than state_time + dt_exp go back to the DB  */
   int window_full;      /* state->clone_window() > window_size: drop observations older than the oldest clone (:733-737) */
+  int max_slam;         /* OptionsCamera::max_slam (0 in the shipped configuration)                    */
+  int n_slam;           /* State::cam_SLAM_features.size()                                             */
+  const uint64_t *slam_ids; /* [n_slam] feature ids of the landmarks in the state                      */
+  int init_min_meas;    /* min(window_size * (int)cam_hz - 1, 10): track length that qualifies for SLAM initialisation (:685) */
 } plv_update_options;
 
 typedef struct plv_update_result {
@@ -442,6 +455,8 @@ typedef struct plv_update_result {
   int n_rows;       /* stacked rows before compression                                       */
   int n_returned;   /* features handed back to the database                                  */
   int status;       /* PLV_OK, or PLV_E_NOT_PSD from the EKF step (state untouched)          */
+  int n_slam;       /* landmarks of the state with a usable track (list PLV_LIST_SLAM)       */
+  int n_init;       /* features chosen for SLAM initialisation (list PLV_LIST_INIT)          */
 } plv_update_result;
 
 /* CamHelper::get_features (pool = features_containing_older(2nd-oldest clone) + features_not_containing_newer
@@ -449,12 +464,30 @@ typedef struct plv_update_result {
  * (3 px) until max_msckf, REF: CamHelper.cpp:613-707) -> UpdaterCamera::msckf_update (:197-294) on the
  * device-resident covariance -> CamHelper::cleanup_features (:709-738: everything not consumed goes back
  * to the tracker's database; old observations are dropped when the window is full).
- * SLAM features (max_slam > 0) are not built: every consistent feature is an MSCKF feature.
+ * With max_slam > 0 the call also classifies: landmarks already in the state (opt->slam_ids) with a live track
+ * form the SLAM list (:621-628; the reference does not take them out of the database, so they can enter the
+ * pool as well), and a consistent feature with >= init_min_meas observations becomes a SLAM-initialisation
+ * candidate while n_slam + n_init < max_slam (:685-693) instead of an MSCKF feature.  Both lists are read with
+ * plv_camera_update_list and fed to plv_slam_update / plv_slam_initialize by the caller, who applies each dx to
+ * its state in between as the reference's EKFUpdate does.
  * Ties in the track-length sort are broken by ascending feature id (the reference's std::sort on an
  * unordered_map leaves them unspecified).  dx (n) is the state correction of EKFUpdate; msckf_ids /
  * accepted (capacity max_msckf, may be NULL) list the features of the update in batch order. */
 int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                              plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted, double *p_FinG);
+
+/* The SLAM / SLAM-init lists of the last plv_camera_update_points (a17; REF: CamHelper.cpp:621-628,685-693), as
+ * CSR tracks holding only observations with bounding clones (get_imu_poses, :327-372).  p_FinG (nullable) is
+ * the triangulated position for PLV_LIST_INIT and zero for PLV_LIST_SLAM (the landmark lives in the caller's
+ * state).  Call with ids = obs_ptr = NULL to query *n_feat only.  A candidate whose initialisation fails goes
+ * back to the database with plv_db_append_measurements (REF: UpdaterCamera.cpp:363-364). */
+enum { PLV_LIST_SLAM = 0, PLV_LIST_INIT = 1 };
+int plv_camera_update_list(plv_ctx *ctx, int which, int cap_feat, int cap_obs, int *n_feat, uint64_t *ids, int *obs_ptr,
+                           double *obs_time, float *obs_uv, float *obs_uvn, double *p_FinG);
+/* UpdaterCamera::marginalize_slam_features' flags (REF: UpdaterCamera.cpp:118-137): should_marg[i] = 1 when the
+ * landmark's feature is no longer in the tracker database or update_fail_count[i] > 1 (nullable = all 0).  The
+ * caller then removes flagged landmarks with plv_cov_marginalize (StateHelper::marginalize_slam). */
+int plv_slam_marg_flags(plv_ctx *ctx, int n_slam, const uint64_t *slam_ids, const int *update_fail_count, uint8_t *should_marg);
 
 /* ---------------------------------------------------------------------------------------------
  * UpdaterCamera::try_update, line half, as one call (a15/a16, a27-a29, a31).  Call after the caller has

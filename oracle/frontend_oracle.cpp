@@ -630,6 +630,8 @@ void *orc_pyramid_build(const uint8_t *img, int w, int h, int stride, int win, i
   return P;
 }
 void orc_pyramid_free(void *p) { delete (Pyramid *)p; }
+// cv::pyrDown with an explicit destination size (REF call site: UpdaterCamera.cpp:91,93, Size(cols / 2.0, rows / 2.0))
+void orc_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst, int dw, int dh) { pyr_down(src, w, h, dst, dw, dh); }
 int orc_pyramid_levels(void *p) { return ((Pyramid *)p)->levels; }
 void orc_pyramid_level(void *p, int l, int *w, int *h, uint8_t *img_out, int16_t *der_out) {
   Pyramid *P = (Pyramid *)p;

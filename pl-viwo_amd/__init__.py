@@ -109,6 +109,9 @@ def load_library():
         "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
                                             C.POINTER(C.c_uint64), ip]),
         "plv_tracker_feed": (C.c_int, [vp, C.c_double, u8p, C.c_int, u8p]),
+        "plv_tracker_feed_downsampled": (C.c_int, [vp, C.c_double, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
+        "plv_downsample": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
+        "plv_feed_image_downsampled": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int]),
         "plv_tracker_last": (C.c_int, [vp, fp, C.POINTER(C.c_uint64), C.c_int, ip]),
         "plv_db_size": (C.c_int, [vp]),
         "plv_db_select": (C.c_int, [vp, C.c_int, C.c_double, C.POINTER(C.c_uint64), C.c_int, ip]),
@@ -125,6 +128,8 @@ def load_library():
                                                C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
         "plv_line_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]),
         "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
+        "plv_camera_update_list": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, u64p, ip, dp, fp, fp, dp]),
+        "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -229,12 +234,13 @@ class PlvTriOptions(C.Structure):
 
 class PlvUpdateOptions(C.Structure):
     _fields_ = [("max_msckf", C.c_int), ("max_obs", C.c_int), ("chi2_mult", C.c_double), ("tri", PlvTriOptions),
-                ("t_prev_frame", C.c_double), ("state_time", C.c_double), ("window_full", C.c_int)]
+                ("t_prev_frame", C.c_double), ("state_time", C.c_double), ("window_full", C.c_int),
+                ("max_slam", C.c_int), ("n_slam", C.c_int), ("slam_ids", C.POINTER(C.c_uint64)), ("init_min_meas", C.c_int)]
 
 
 class PlvUpdateResult(C.Structure):
     _fields_ = [("n_pool", C.c_int), ("n_msckf", C.c_int), ("n_accepted", C.c_int), ("n_rows", C.c_int),
-                ("n_returned", C.c_int), ("status", C.c_int)]
+                ("n_returned", C.c_int), ("status", C.c_int), ("n_slam", C.c_int), ("n_init", C.c_int)]
 
 
 class StateView:
@@ -584,9 +590,12 @@ class Context:
         self._chk(self.lib.plv_db_append_measurements(self.h, int(fid), len(t), _dp(t), _fp(uv), _fp(uvn)))
 
     def camera_update_points(self, st, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0,
-                             min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True):
+                             min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True, max_slam=0, slam_ids=(),
+                             init_min_meas=10):
+        sl = np.ascontiguousarray(slam_ids, dtype=np.uint64)
         opt = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0),
-                               t_prev_frame, state_time, 1 if window_full else 0)
+                               t_prev_frame, state_time, 1 if window_full else 0, max_slam, len(sl), _u64p(sl) if len(sl) else None,
+                               init_min_meas)
         res = PlvUpdateResult()
         dx = np.zeros(n)
         ids = np.zeros(max_msckf, dtype=np.uint64)
@@ -596,7 +605,29 @@ class Context:
                                                     _dp(p)))
         m = res.n_msckf
         return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
-                    status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy())
+                    status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=res.n_slam,
+                    n_init=res.n_init)
+
+    def camera_update_list(self, which):
+        """SLAM (0) / SLAM-init (1) list of the last camera_update_points: ids, obs_ptr, obs_time, obs_uv, obs_uvn, p_FinG."""
+        n = C.c_int()
+        self._chk(self.lib.plv_camera_update_list(self.h, which, 0, 0, C.byref(n), None, None, None, None, None, None))
+        F = n.value
+        ids, ptr = np.zeros(F, dtype=np.uint64), np.zeros(F + 1, dtype=np.int32)
+        cap = 4096
+        t, uv, uvn, p = np.zeros(cap), np.zeros((cap, 2), dtype=np.float32), np.zeros((cap, 2), dtype=np.float32), np.zeros((F, 3))
+        if F:
+            self._chk(self.lib.plv_camera_update_list(self.h, which, F, cap, C.byref(n), _u64p(ids), _ip(ptr), _dp(t), _fp(uv), _fp(uvn),
+                                                      _dp(p)))
+        m = int(ptr[-1])
+        return dict(ids=ids, obs_ptr=ptr, obs_time=t[:m].copy(), obs_uv=uv[:m].copy(), obs_uvn=uvn[:m].copy(), p_FinG=p)
+
+    def slam_marg_flags(self, slam_ids, fail_count=None):
+        sl = np.ascontiguousarray(slam_ids, dtype=np.uint64)
+        fc = np.ascontiguousarray(fail_count, dtype=np.int32) if fail_count is not None else None
+        out = np.zeros(len(sl), dtype=np.uint8)
+        self._chk(self.lib.plv_slam_marg_flags(self.h, len(sl), _u64p(sl), _ip(fc) if fc is not None else None, _u8p(out)))
+        return out
 
     def line_db_append_measurements(self, lid, t, seg_uv, seg_uvn, D=0, point_ids=()):
         t = np.ascontiguousarray(t, dtype=np.float64)
@@ -611,7 +642,8 @@ class Context:
         self._chk(self.lib.plv_point_used_insert(self.h, int(fid), _dp(p), float(newest)))
 
     def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512):
-        opt = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0)
+        opt = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0,
+                               0, 0, None, 10)
         res = PlvUpdateResult()
         dx = np.zeros(n)
         ids, acc, lg = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))
@@ -755,6 +787,23 @@ class Context:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
         self._chk(self.lib.plv_tracker_feed(self.h, float(timestamp), _u8p(img), img.shape[1], _u8p(m)))
+
+    def tracker_feed_downsampled(self, timestamp, img, mask=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        self._chk(self.lib.plv_tracker_feed_downsampled(self.h, float(timestamp), _u8p(img), img.shape[1], img.shape[1], img.shape[0],
+                                                        _u8p(m), img.shape[1]))
+
+    def downsample(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((h // 2, w // 2), dtype=np.uint8)
+        self._chk(self.lib.plv_downsample(self.h, _u8p(img), w, w, h, _u8p(out), w // 2))
+        return out
+
+    def feed_image_downsampled(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self._chk(self.lib.plv_feed_image_downsampled(self.h, _u8p(img), img.shape[1], img.shape[1], img.shape[0]))
 
     def tracker_last(self, cap=8192):
         pts = np.zeros((cap, 2), dtype=np.float32)

@@ -20,6 +20,7 @@ struct FrontState {
   DevBuf raw;              // incoming raw image (packed)
   DevBuf slots[8];
   DevBuf hist, clahe_lut;
+  DevBuf ds_src, ds_dst;   // full-resolution staging of plv_downsample / plv_feed_image_downsampled
   // per-call point buffers
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io;
   DevBuf det_in, det_out, det_mask, subpix_tab;  // detection staging
@@ -130,7 +131,7 @@ extern "C" {
 void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
-  DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->pts0, &s->pts1, &s->n0, &s->n1,
+  DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab};
   for (auto *b : bufs) b->release();
@@ -146,6 +147,46 @@ int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride) {
   FrontState *s = fe(ctx);
   TRY(ensure_pyramids(ctx, s));
   TRY(upload_image(ctx, s, s->raw.p, img, stride));
+  TRY(feed_device(ctx, s, s->raw.as<uint8_t>()));
+  return sync(ctx);
+}
+
+// cv::pyrDown(img, out, Size(cols / 2.0, rows / 2.0)) on the device: the Size_<int> constructor truncates, so an
+// odd dimension halves downwards (the default would be (n + 1) / 2).  REF: UpdaterCamera.cpp:85-98
+static int downsample_to(plv_ctx *ctx, FrontState *s, const uint8_t *src, int stride, int sw, int sh, uint8_t *d_dst) {
+  if (!src || sw < 2 || sh < 2 || stride < sw) {
+    set_last_error("downsample: bad source %dx%d stride %d", sw, sh, stride);
+    return PLV_E_BADARG;
+  }
+  TRY(s->ds_src.reserve((size_t)sw * sh));
+  PLV_HIP_CHECK(hipMemcpy2DAsync(s->ds_src.p, (size_t)sw, src, (size_t)stride, (size_t)sw, (size_t)sh, hipMemcpyHostToDevice,
+                                 ctx->stream));
+  return launch_pyrdown(ctx, s->ds_src.as<uint8_t>(), sw, sh, d_dst, sw / 2, sh / 2);
+}
+
+int plv_downsample(plv_ctx *ctx, const uint8_t *src, int stride, int src_w, int src_h, uint8_t *dst, int dstride) {
+  if (!ctx || !dst || dstride < src_w / 2) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  const int dw = src_w / 2, dh = src_h / 2;
+  TRY(s->ds_dst.reserve((size_t)dw * dh));
+  TRY(downsample_to(ctx, s, src, stride, src_w, src_h, s->ds_dst.as<uint8_t>()));
+  PLV_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)dstride, s->ds_dst.p, (size_t)dw, (size_t)dw, (size_t)dh, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  return sync(ctx);
+}
+
+int plv_feed_image_downsampled(plv_ctx *ctx, const uint8_t *img, int stride, int src_w, int src_h) {
+  if (!ctx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(ensure_pyramids(ctx, s));
+  if (src_w / 2 != s->W || src_h / 2 != s->H) {
+    set_last_error("feed_image_downsampled: %dx%d halves to %dx%d, the context tracks %dx%d", src_w, src_h, src_w / 2, src_h / 2,
+                   s->W, s->H);
+    return PLV_E_BADARG;
+  }
+  TRY(downsample_to(ctx, s, img, stride, src_w, src_h, s->raw.as<uint8_t>()));
   TRY(feed_device(ctx, s, s->raw.as<uint8_t>()));
   return sync(ctx);
 }

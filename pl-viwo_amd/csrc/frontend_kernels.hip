@@ -881,6 +881,13 @@ int launch_pyramid(plv_ctx *ctx, const PyrDesc &p) {
   return PLV_OK;
 }
 
+int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *d_dst, int dw, int dh) {
+  ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
+  hipLaunchKernelGGL(pyrdown_kernel, dim3(cdiv(dw, PD_T), cdiv(dh, PD_T)), dim3(256), 0, ctx->stream, d_src, sw, sh, d_dst, dw, dh);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
               uint8_t *d_status, int *d_iters, int win, int max_iters, float eps) {
   if (win > LK_MAXWIN || win < 3 || (win & 1) == 0) {

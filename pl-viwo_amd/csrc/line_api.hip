@@ -525,7 +525,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
-  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK};
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0};
   const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
   struct Cand {
     uint64_t id;

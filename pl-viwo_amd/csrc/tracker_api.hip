@@ -28,6 +28,12 @@ struct Tracker {
     double p[3], newest;
   };
   std::unordered_map<uint64_t, UsedPoint> used;  // the reference's `point_used` database (triangulated features)
+  struct Listed {  // a feature get_features classified as SLAM / SLAM-init in the last update call
+    uint64_t id;
+    Track tr;
+    double p[3];
+  };
+  std::vector<Listed> last_slam, last_init;
   std::mutex mtx;
 };
 
@@ -61,13 +67,35 @@ void plv_tracker_destroy(plv_ctx *ctx) {
   }
 }
 
+static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask);
+
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask) {
   if (!ctx || !img) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);  // REF: mtx_feeds.at(cam_id), TrackKLT.cpp:54,100
+  TRY(plv_feed_image(ctx, img, stride));  // :59 equalizeHist, :71 buildOpticalFlowPyramid
+  return tracker_feed_fed(ctx, T, timestamp, mask);
+}
+
+int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, int src_w, int src_h,
+                                 const uint8_t *mask, int mask_stride) {
+  if (!ctx || !img) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  const int W = ctx->cfg.width, H = ctx->cfg.height;
+  std::vector<uint8_t> small_mask;
+  if (mask) {  // REF UpdaterCamera.cpp:93 the mask is pyrDown'ed like the image (and then thresholded at 127 as usual)
+    small_mask.resize((size_t)W * H);
+    TRY(plv_downsample(ctx, mask, mask_stride, src_w, src_h, small_mask.data(), W));
+  }
+  TRY(plv_feed_image_downsampled(ctx, img, stride, src_w, src_h));
+  return tracker_feed_fed(ctx, T, timestamp, mask ? small_mask.data() : nullptr);
+}
+
+// the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
+static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
   const int cap = std::max(ctx->cfg.num_features * 4, 1024) + (int)T->ids_last.size();
-  TRY(plv_feed_image(ctx, img, stride));  // :59 equalizeHist, :71 buildOpticalFlowPyramid
   std::vector<float> pts(2 * (size_t)cap);
   std::vector<uint64_t> ids(cap);
   int n = 0;
@@ -254,7 +282,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
                              plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted_out, double *p_out) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
-  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK};
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0};
   const double dt = st->cam_dt;
   const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
   struct Cand {
@@ -269,6 +297,53 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     u.uv.insert(u.uv.end(), uv, uv + 2);
     u.uvn.insert(u.uvn.end(), uvn, uvn + 2);
   };
+  T->last_slam.clear();
+  T->last_init.clear();
+  if (opt->n_slam > 0 && !opt->slam_ids) return PLV_E_BADARG;
+  auto is_slam = [&](uint64_t id) {
+    for (int i = 0; i < opt->n_slam; ++i)
+      if (opt->slam_ids[i] == id) return true;
+    return false;
+  };
+  {
+    // REF CamHelper.cpp:621-628 — landmarks of the state with a live track.  get_feature(id) is called without
+    // `remove`, so the Feature object stays in the database (and may enter the pool below as well);
+    // remove_unusable_measurements then edits that shared object: too-new observations are parked in db_unused,
+    // too-old ones are dropped, a landmark may keep a single observation (:766-769).
+    std::lock_guard<std::mutex> lk(T->mtx);
+    for (int i = 0; i < opt->n_slam; ++i) {
+      auto it = T->db.find(opt->slam_ids[i]);
+      if (it == T->db.end()) continue;
+      Track &tr = it->second;
+      size_t keep = 0;
+      for (size_t q = 0; q < tr.t.size(); ++q) {
+        const double tm = tr.t[q] + dt;
+        if (tm > opt->state_time + st->dt_exp) {
+          give_back(it->first, tr.t[q], &tr.uv[2 * q], &tr.uvn[2 * q]);
+          continue;
+        }
+        if (tm < t_oldest - st->dt_exp) continue;
+        tr.t[keep] = tr.t[q];
+        tr.uv[2 * keep] = tr.uv[2 * q], tr.uv[2 * keep + 1] = tr.uv[2 * q + 1];
+        tr.uvn[2 * keep] = tr.uvn[2 * q], tr.uvn[2 * keep + 1] = tr.uvn[2 * q + 1];
+        ++keep;
+      }
+      tr.t.resize(keep);
+      tr.uv.resize(2 * keep);
+      tr.uvn.resize(2 * keep);
+      if (keep == 0) continue;
+      // slam_update's own get_imu_poses (UpdaterCamera.cpp:303-304) leaves out what has no bounding clones
+      Tracker::Listed e{it->first, Track{}, {0, 0, 0}};
+      for (size_t q = 0; q < keep; ++q) {
+        if (!has_bounding_poses(*st, tr.t[q] + dt)) continue;
+        e.tr.t.push_back(tr.t[q]);
+        e.tr.uv.insert(e.tr.uv.end(), &tr.uv[2 * q], &tr.uv[2 * q] + 2);
+        e.tr.uvn.insert(e.tr.uvn.end(), &tr.uvn[2 * q], &tr.uvn[2 * q] + 2);
+      }
+      if (!e.tr.t.empty()) T->last_slam.push_back(std::move(e));
+    }
+  }
+  res->n_slam = (int)T->last_slam.size();
   {
     std::lock_guard<std::mutex> lk(T->mtx);
     // REF CamHelper.cpp:631-637 — features_containing_older(oldest_2nd_clone_time), then
@@ -308,10 +383,14 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     tr.t.resize(keep);
     tr.uv.resize(2 * keep);
     tr.uvn.resize(2 * keep);
-    if (keep < 2)
-      it = pool.erase(it);  // REF :766-771 (no SLAM features here: a single measurement is dropped too)
-    else
+    if (keep == 1 && is_slam(it->id)) {  // REF :766-769 kept, then handed back by the n_meas < 2 test (:656-661)
+      give_back(it->id, tr.t[0], &tr.uv[0], &tr.uvn[0]);
+      it = pool.erase(it);
+    } else if (keep < 2) {
+      it = pool.erase(it);  // REF :766-771 a single measurement is dropped
+    } else {
       ++it;
+    }
   }
   // REF :640 sort(feats_pool, feat_sort): long tracks first
   std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
@@ -376,13 +455,33 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       std::copy(pf.begin() + 3 * (size_t)f, pf.begin() + 3 * (size_t)f + 3, u.p);
       u.newest = c.tr.t.back();
     }
-    if (valid < 2 || !ok[f] || !(err[f] < 3.0) || valid > opt->max_obs) {  // :656-683 (+ batch capacity)
+    if (valid < 2 || !ok[f] || !(err[f] < 3.0)) {  // :656-683
+      give_back_all(c);
+      continue;
+    }
+    // :685-693 a long track becomes a new in-state landmark while there is room
+    if (valid >= opt->init_min_meas && opt->n_slam + (int)T->last_init.size() < opt->max_slam) {
+      Tracker::Listed e{c.id, Track{}, {pf[3 * (size_t)f], pf[3 * (size_t)f + 1], pf[3 * (size_t)f + 2]}};
+      for (size_t i = 0; i < c.tr.t.size(); ++i) {
+        if (!has_bounding_poses(*st, c.tr.t[i] + dt)) {
+          give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+          continue;
+        }
+        e.tr.t.push_back(c.tr.t[i]);
+        e.tr.uv.insert(e.tr.uv.end(), &c.tr.uv[2 * i], &c.tr.uv[2 * i] + 2);
+        e.tr.uvn.insert(e.tr.uvn.end(), &c.tr.uvn[2 * i], &c.tr.uvn[2 * i] + 2);
+      }
+      T->last_init.push_back(std::move(e));
+      continue;
+    }
+    if (valid > opt->max_obs) {  // batch capacity of the MSCKF update
       give_back_all(c);
       continue;
     }
     sel.push_back(f);
   }
   res->n_msckf = (int)sel.size();
+  res->n_init = (int)T->last_init.size();
   if (sel.empty()) {
     std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);
@@ -443,6 +542,43 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   rc = finish(PLV_OK);
   if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);  // REF CamHelper.cpp:733-737
   return rc;
+}
+
+int plv_camera_update_list(plv_ctx *ctx, int which, int cap_feat, int cap_obs, int *n_feat, uint64_t *ids, int *obs_ptr,
+                           double *obs_time, float *obs_uv, float *obs_uvn, double *p_FinG) {
+  if (!ctx || !n_feat || (which != PLV_LIST_SLAM && which != PLV_LIST_INIT)) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  const std::vector<Tracker::Listed> &L = which == PLV_LIST_SLAM ? T->last_slam : T->last_init;
+  *n_feat = (int)L.size();
+  size_t nobs = 0;
+  for (const auto &e : L) nobs += e.tr.t.size();
+  if (!ids && !obs_ptr) return PLV_OK;  // size query
+  if ((int)L.size() > cap_feat || (int)nobs > cap_obs || !ids || !obs_ptr || !obs_time || !obs_uv) return PLV_E_BADARG;
+  int o = 0;
+  obs_ptr[0] = 0;
+  for (size_t f = 0; f < L.size(); ++f) {
+    const Tracker::Listed &e = L[f];
+    ids[f] = e.id;
+    std::copy(e.tr.t.begin(), e.tr.t.end(), obs_time + o);
+    std::copy(e.tr.uv.begin(), e.tr.uv.end(), obs_uv + 2 * (size_t)o);
+    if (obs_uvn) std::copy(e.tr.uvn.begin(), e.tr.uvn.end(), obs_uvn + 2 * (size_t)o);
+    if (p_FinG) std::copy(e.p, e.p + 3, p_FinG + 3 * f);
+    o += (int)e.tr.t.size();
+    obs_ptr[f + 1] = o;
+  }
+  return PLV_OK;
+}
+
+int plv_slam_marg_flags(plv_ctx *ctx, int n_slam, const uint64_t *slam_ids, const int *update_fail_count, uint8_t *should_marg) {
+  if (!ctx || n_slam < 0 || (n_slam > 0 && (!slam_ids || !should_marg))) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  for (int i = 0; i < n_slam; ++i) {
+    const bool lost = T->db.find(slam_ids[i]) == T->db.end();  // REF UpdaterCamera.cpp:125-129 feat == nullptr
+    should_marg[i] = (lost || (update_fail_count && update_fail_count[i] > 1)) ? 1 : 0;  // :130-131
+  }
+  return PLV_OK;
 }
 
 int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, double newest_obs_time) {

@@ -176,6 +176,7 @@ class FrontOracle:
         L.orc_pyramid_build.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_pyramid_build.restype = C.c_void_p
         L.orc_pyramid_free.argtypes = [C.c_void_p]
+        L.orc_pyr_down.argtypes = [u8, C.c_int, C.c_int, u8, C.c_int, C.c_int]
         L.orc_pyramid_levels.argtypes = [C.c_void_p]
         L.orc_pyramid_levels.restype = C.c_int
         L.orc_pyramid_level.argtypes = [C.c_void_p, C.c_int, ip, ip, u8, C.POINTER(C.c_int16)]
@@ -201,6 +202,14 @@ class FrontOracle:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         return OraclePyramid(self, self.lib.orc_pyramid_build(img.ctypes.data_as(u8), img.shape[1], img.shape[0],
                                                               img.shape[1], win, max_level))
+
+    def downsample(self, img):
+        """cv::pyrDown(img, Size(cols / 2.0, rows / 2.0))"""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((h // 2, w // 2), dtype=np.uint8)
+        self.lib.orc_pyr_down(img.ctypes.data_as(u8), w, h, out.ctypes.data_as(u8), w // 2, h // 2)
+        return out
 
     def lk_track(self, prev, cur, pts0, pts1_init, win=15, max_iters=30, eps=0.01, nthreads=1):
         pts0 = np.ascontiguousarray(pts0, dtype=np.float32)

@@ -98,3 +98,38 @@ def test_tracker_stream_matches_oracle(pkg):
     ctx.db_remove(old[:5])
     assert ctx.db_size() <= n0
     ctx.close()
+
+
+def test_downsampled_feed_matches_oracle(pkg):
+    """OptionsCamera::downsample: pyrDown(Size(cols / 2.0, rows / 2.0)) of image and mask, then the usual path
+    (REF: UpdaterCamera.cpp:85-98).  Odd source sizes halve downwards."""
+    fo = oracle_lib.load_front()
+    sw, sh = 1505, 961  # -> 752 x 480
+    canvas = synth.texture_canvas(sw, sh, seed=3, blobs=500)
+    cfg = pkg.default_config(sw // 2, sh // 2)
+    ctx = pkg.Context(cfg)
+    img0 = synth.render_frame(canvas, sw, sh)
+    small = ctx.downsample(img0)
+    assert small.shape == (480, 752) and np.array_equal(small, fo.downsample(img0))
+    assert np.array_equal(ctx.downsample(img0[:100, :64]), fo.downsample(img0[:100, :64]))  # a single 16x16 tile column
+    # the fed pyramid is the pyramid of the equalised halved image
+    ctx.feed_image_downsampled(img0)
+    ref = fo.pyramid(fo.equalize_hist(fo.downsample(img0)))
+    for l in range(ref.levels):
+        assert np.array_equal(ctx.pyramid_level(0, l), ref.level(l)[0]), l
+    # tracker stream on the halved images == tracker stream fed the oracle's halved images; the mask is halved too
+    ot = OracleTracker(cfg, np.array(list(cfg.intrinsics)))
+    ctx2 = pkg.Context(cfg)
+    mask = np.zeros((sh, sw), np.uint8)
+    mask[:, : sw // 4] = 255
+    small_mask = fo.downsample(mask)
+    for f in range(3):
+        img = synth.render_frame(canvas, sw, sh, tx=3.0 * f, ty=-2.0 * f)
+        ctx.tracker_feed_downsampled(20.0 + 0.1 * f, img, mask)
+        ctx2.tracker_feed(20.0 + 0.1 * f, fo.downsample(img), small_mask)
+    p1, i1 = ctx.tracker_last()
+    p2, i2 = ctx2.tracker_last()
+    assert len(i1) > 100 and np.array_equal(i1, i2) and np.array_equal(p1, p2)
+    assert (small_mask[p1[:, 1].astype(int), p1[:, 0].astype(int)] <= 127).all()
+    ctx.close()
+    ctx2.close()

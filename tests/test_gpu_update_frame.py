@@ -157,3 +157,99 @@ def test_update_calls_on_empty_databases(pkg):
     ctx.db_append_measurements(9, [t[0]], [[10.0, 10.0]], [[0.0, 0.0]])
     out = ctx.camera_update_points(st, n, 40, 15, t_prev_frame=t[-2], state_time=t[-1])
     assert out["n_pool"] == 1 and out["n_msckf"] == 0 and ctx.db_size() == 0
+
+
+def test_camera_update_points_slam_branch(pkg, oracle):
+    """max_slam > 0: get_features' three-way split (REF CamHelper.cpp:621-628,685-693) and the landmark flow after it."""
+    jo, fo = oracle_lib.load_jac(pkg), oracle_lib.load_front()
+    sc = synth.vio_scene(F=60, M=15, noise_px=0.4, seed=11)
+    t, K8, n = sc["t"], sc["K8"], sc["n_state"]
+    st, _ = synth.scene_views(pkg, sc)
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    tracks = {}
+    for f in range(60):
+        a, b = sc["obs_ptr"][f], sc["obs_ptr"][f + 1]
+        if f % 4 == 3:
+            a = b - 6  # short tracks: never SLAM-init candidates (init_min_meas = 10)
+        uv = sc["obs_uv"][a:b].astype(np.float32)
+        tracks[f + 1] = (sc["obs_time"][a:b].copy(), uv, fo.undistort(K8, uv))
+    # landmark 300 lives in the state and is still tracked, only recent observations (not in the pool);
+    # landmark 301 lives in the state but has no track left; landmark 6 is a full track (the reference leaves it in
+    # the database, so the pool sees it too)
+    a, b = sc["obs_ptr"][5], sc["obs_ptr"][6]
+    recent = slice(b - 2, b)
+    uvr = sc["obs_uv"][recent].astype(np.float32)
+    tracks[300] = (sc["obs_time"][recent].copy(), uvr, fo.undistort(K8, uvr))
+    for fid, (tt, uv, uvn) in tracks.items():
+        ctx.db_append_measurements(fid, tt, uv, uvn)
+    slam_ids = [300, 301, 6]
+    assert np.array_equal(ctx.slam_marg_flags(slam_ids), [0, 1, 0])
+    assert np.array_equal(ctx.slam_marg_flags(slam_ids, [0, 0, 2]), [0, 1, 1])
+    P = synth.spd_cov(n, seed=4) * 1e-4
+    ctx.cov_upload(P)
+    MAX, MOBS, MAX_SLAM, MIN_INIT = 25, 15, 7, 10
+    TRI = dict(max_cond=1e7, max_dist=100.0, max_baseline=1e3)
+    out = ctx.camera_update_points(st, n, MAX, MOBS, t_prev_frame=t[-2], state_time=t[-1], window_full=True, max_slam=MAX_SLAM,
+                                   slam_ids=slam_ids, init_min_meas=MIN_INIT, **TRI)
+    sl, ini = ctx.camera_update_list(0), ctx.camera_update_list(1)
+
+    # ---- SLAM list: the landmarks with a live track, in state order, observations with bounding clones only
+    assert np.array_equal(sl["ids"], [300, 6]) and out["n_slam"] == 2
+    valid = lambda tt: np.array([t[0] - 0.01 <= x <= t[-1] for x in tt])  # has_bounding_poses at cam_dt = 0
+    for q, fid in enumerate(sl["ids"]):
+        a, b = sl["obs_ptr"][q], sl["obs_ptr"][q + 1]
+        m = valid(tracks[int(fid)][0])
+        assert np.array_equal(sl["obs_time"][a:b], tracks[int(fid)][0][m])
+        assert np.array_equal(sl["obs_uv"][a:b], tracks[int(fid)][1][m])
+    # ---- the oracle's version of the selection loop
+    pool = [fid for fid, (tt, _, _) in sorted(tracks.items()) if (tt < t[1]).any() or not (tt > t[-2]).any()]
+    assert 300 not in pool and 6 in pool
+    pool.sort(key=lambda fid: -len(tracks[fid][0]))
+    ptr = np.concatenate([[0], np.cumsum([len(tracks[f][0]) for f in pool])]).astype(np.int32)
+    tr_all = pkg.Tracks(ptr, np.concatenate([tracks[f][0] for f in pool]), np.concatenate([tracks[f][1] for f in pool]),
+                        np.zeros((len(pool), 3)), obs_uvn=np.concatenate([tracks[f][2] for f in pool]))
+    p_o, ok_o, err_o = jo.triangulate_batch(st, tr_all, **TRI)
+    sel, init = [], []
+    for q, fid in enumerate(pool):
+        if len(sel) >= MAX:
+            break
+        if not (ok_o[q] and err_o[q] < 3.0):
+            continue
+        if valid(tracks[fid][0]).sum() >= MIN_INIT and len(slam_ids) + len(init) < MAX_SLAM:
+            init.append(q)
+            continue
+        sel.append(q)
+    assert len(init) == MAX_SLAM - len(slam_ids) == out["n_init"] and len(sel) == MAX
+    assert np.array_equal(ini["ids"], [pool[q] for q in init])
+    assert np.abs(ini["p_FinG"] - p_o[init]).max() < 1e-6
+    assert np.array_equal(out["ids"], np.array([pool[q] for q in sel], dtype=np.uint64))
+    assert not set(ini["ids"]) & set(out["ids"])
+    # ---- the MSCKF update ran on the remaining features only
+    sptr = np.concatenate([[0], np.cumsum([len(tracks[pool[q]][0]) for q in sel])]).astype(np.int32)
+    tr_sel = pkg.Tracks(sptr, np.concatenate([tracks[pool[q]][0] for q in sel]), np.concatenate([tracks[pool[q]][1] for q in sel]),
+                        p_o[sel])
+    cols = jo.columns(st, tr_sel)
+    rows, Hf, Hx, res = jo.build_jacobians(st, tr_sel, cols, 2 * MOBS)
+    rc_o, P_o, dx_o, acc_o, nrows_o = oracle.msckf_update(P, rows, Hf, Hx, res, cols, st.c.sigma_pix ** 2, synth.q95_table())
+    assert out["status"] == rc_o == 0 and np.array_equal(out["accepted"], acc_o)
+    assert np.abs(out["dx"] - dx_o).max() <= 1e-7 * max(1.0, np.abs(dx_o).max())
+    assert np.abs(ctx.cov_download(n) - P_o).max() <= 1e-8 * np.abs(P).max()
+    # ---- database: SLAM-init candidates and accepted MSCKF features are gone, landmark 300 never left
+    gone = {int(i) for i, a in zip(out["ids"], acc_o) if a} | {int(i) for i in ini["ids"]}
+    assert {int(i) for i in ctx.db_select(1, 1e18)} == set(tracks) - gone
+    # ---- UpdaterCamera::slam_init on the first candidate (state unchanged here: dx is the caller's to apply)
+    a, b = ini["obs_ptr"][0], ini["obs_ptr"][1]
+    tr1 = pkg.Tracks(np.array([0, b - a], dtype=np.int32), ini["obs_time"][a:b], ini["obs_uv"][a:b], ini["p_FinG"][:1])
+    c1 = ctx.jacobian_columns(st, tr1)
+    assert np.array_equal(c1, jo.columns(st, tr1))
+    r1, Hf1, Hx1, res1 = ctx.build_jacobians(st, tr1, c1, 2 * MOBS)
+    m = int(r1[0])
+    ok_o, P2_o, dxi_o, dx2_o = oracle.slam_initialize(P_o, Hf1[0, :, :m].T, Hx1[0, :, :m].T, res1[0, :m], c1, synth.q95_table(), chi2_mult=1.0)
+    ok, dxi, dx2 = ctx.slam_initialize(n, Hf1[0, :, :m].T, Hx1[0, :, :m].T, res1[0, :m], c1, chi2_mult=1.0)
+    assert ok == ok_o
+    if ok:
+        assert np.abs(ctx.cov_download(n + 3) - P2_o).max() <= 1e-8 * np.abs(P2_o).max()
+        assert np.abs(dxi - dxi_o).max() <= 1e-8 * max(1.0, np.abs(dxi_o).max())
+    else:  # REF UpdaterCamera.cpp:363-364 a failed candidate returns to the database
+        ctx.db_append_measurements(int(ini["ids"][0]), ini["obs_time"][a:b], ini["obs_uv"][a:b], ini["obs_uvn"][a:b])
+        assert int(ini["ids"][0]) in {int(i) for i in ctx.db_select(1, 1e18)}
