@@ -336,6 +336,27 @@ int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks
 int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
                                  const int *col_to_state, int ld);
 
+/* a19, use_imu_res branch: State::get_interpolated_pose_imu (REF: PL-VIWO/src/state/State.cpp:1138-1155) on
+ * State::cpis given as a table sorted by time (the std::map's order).  For each query time: the record stored at
+ * exactly that time whose clone is in the window (have_cpi, :273-277), else create_new_cpi_linear between the
+ * neighbouring records when both were integrated from the same clone (:286-355: geodesic interpolation of
+ * R_I0toIk, linear alpha), then R_GtoI = R_I0toIk R_GtoI0, p = p_I0 + v_I0 dt - g dt^2 / 2 + R_GtoI0^T alpha.
+ * ok[q] = 0 where the reference would go on to create_new_cpi_integrate (re-integration from the IMU buffer,
+ * SURVEY 8(f) rank 2 — not built) or would throw on a missing clone / missing record at clone_t.  The poses are
+ * what plv_tracks::res_R / res_p and plv_line_tracks::res_R / res_p take. */
+typedef struct plv_cpi_table {
+  int n;
+  const double *t;        /* [n] strictly ascending                               */
+  const double *clone_t;  /* [n] CPI::clone_t: time of the clone it integrates from */
+  const double *dt;       /* [n] CPI::dt = t - clone_t                            */
+  const double *R_I0toIk; /* [n][9] row-major                                     */
+  const double *alpha;    /* [n][3] CPI::alpha_I0toIk                             */
+  const double *v;        /* [n][3] CPI::v (global velocity at t)                 */
+  double gravity[3];      /* OptionsEstimator::gravity                            */
+} plv_cpi_table;
+int plv_cpi_poses(plv_ctx *ctx, const plv_state_view *st, const plv_cpi_table *cpi, int n_q, const double *t_q, double *R_GtoI,
+                  double *p_IinG, uint8_t *ok);
+
 /* ---------------------------------------------------------------------------------------------
  * Line features on the update side (a27-a29).
  * A line is a Pluecker 6-vector line_FinG = [moment n (3); direction v (3)] in the global frame

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../include/plviwo.h"
@@ -1002,6 +1003,81 @@ int orc_triangulate_lines(const plv_state_view *st, const plv_line_tracks *lt, d
       line_FinG[6 * l + 3 + i] = vW[i];
     }
     ok[l] = 1;
+  }
+  return 0;
+}
+
+// a19, use_imu_res: State::get_interpolated_pose_imu over have_cpi's lookup and create_new_cpi_linear
+// (REF: PL-VIWO/src/state/State.cpp:273-355,1138-1155), query by query in the order given, inserting every
+// interpolated record back into the map exactly as the reference does (`cpis[t_given] = cpi_new`).
+// create_new_cpi_integrate is not restated (needs the IMU buffer): ok = 0 there.
+int orc_cpi_poses(const plv_state_view *st, const plv_cpi_table *tab, int n_q, const double *t_q, double *R_out, double *p_out,
+                  uint8_t *ok) {
+  struct Rec {
+    double clone_t, dt;
+    M3 R;
+    V3 alpha, v;
+  };
+  std::map<double, Rec> cpis;
+  for (int i = 0; i < tab->n; ++i) {
+    Rec r;
+    r.clone_t = tab->clone_t[i], r.dt = tab->dt[i];
+    std::memcpy(r.R.m, tab->R_I0toIk + 9 * i, 72);
+    std::memcpy(r.alpha.v, tab->alpha + 3 * i, 24);
+    std::memcpy(r.v.v, tab->v + 3 * i, 24);
+    cpis[tab->t[i]] = r;
+  }
+  auto clone_at = [&](double t) {
+    for (int i = 0; i < st->n_clones; ++i)
+      if (st->clone_time[i] == t) return i;
+    return -1;
+  };
+  for (int q = 0; q < n_q; ++q) {
+    ok[q] = 0;
+    std::memset(R_out + 9 * q, 0, 72);
+    std::memset(p_out + 3 * q, 0, 24);
+    const double t = t_q[q];
+    auto have = [&]() { return cpis.find(t) != cpis.end() && clone_at(cpis.at(t).clone_t) >= 0; };
+    if (!have()) {  // create_new_cpi_linear
+      if (cpis.empty()) continue;
+      if (t < cpis.begin()->first || t > cpis.rbegin()->first) continue;
+      double t0, t1;
+      if (t == cpis.begin()->first)
+        t0 = t;
+      else
+        t0 = (--cpis.lower_bound(t))->first;
+      if (t == cpis.rbegin()->first)
+        t1 = t;
+      else
+        t1 = cpis.upper_bound(t)->first;
+      const Rec c0 = cpis.at(t0), c1 = cpis.at(t1);
+      if (c0.clone_t != c1.clone_t) continue;
+      if (c0.clone_t < st->clone_time[0]) continue;
+      Rec n;
+      n.dt = t - c0.clone_t;
+      n.clone_t = c0.clone_t;
+      const double lambda = (t - t0) / (t1 - t0);
+      n.R = mul(exp_so3(sc(log_so3(mul(c1.R, tr(c0.R))), lambda)), c0.R);
+      n.alpha = addv(sc(c0.alpha, 1 - lambda), sc(c1.alpha, lambda));
+      n.v = addv(sc(c0.v, 1 - lambda), sc(c1.v, lambda));
+      cpis[t] = n;
+    }
+    const Rec c = cpis.at(t);
+    const int ci = clone_at(c.clone_t);
+    if (ci < 0 || cpis.find(c.clone_t) == cpis.end()) continue;  // the reference's .at() would throw
+    M3 R0;
+    V3 p0;
+    std::memcpy(R0.m, st->clone_R + 9 * ci, 72);
+    std::memcpy(p0.v, st->clone_p + 3 * ci, 24);
+    const V3 v0 = cpis.at(c.clone_t).v;
+    const V3 g{{tab->gravity[0], tab->gravity[1], tab->gravity[2]}};
+    const M3 R = mul(c.R, R0);
+    V3 p = addv(p0, sc(v0, c.dt));
+    p = sub(p, sc(sc(sc(g, 0.5), c.dt), c.dt));
+    p = addv(p, mul(tr(R0), c.alpha));
+    std::memcpy(R_out + 9 * q, R.m, 72);
+    std::memcpy(p_out + 3 * q, p.v, 24);
+    ok[q] = 1;
   }
   return 0;
 }

@@ -128,6 +128,7 @@ def load_library():
                                                C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
         "plv_line_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]),
         "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
+        "plv_cpi_poses": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvCpiTable), C.c_int, dp, dp, dp, u8p]),
         "plv_camera_update_list": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, u64p, ip, dp, fp, fp, dp]),
         "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
@@ -230,6 +231,27 @@ class PlvLineTracks(C.Structure):
 class PlvTriOptions(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("max_dist", C.c_double), ("max_cond_number", C.c_double),
                 ("max_baseline", C.c_double), ("refine_features", C.c_int)]
+
+
+class PlvCpiTable(C.Structure):
+    _fields_ = [("n", C.c_int), ("t", C.POINTER(C.c_double)), ("clone_t", C.POINTER(C.c_double)), ("dt", C.POINTER(C.c_double)),
+                ("R_I0toIk", C.POINTER(C.c_double)), ("alpha", C.POINTER(C.c_double)), ("v", C.POINTER(C.c_double)),
+                ("gravity", C.c_double * 3)]
+
+
+class CpiTable:
+    """Owns the arrays behind a plv_cpi_table (State::cpis sorted by time)."""
+
+    def __init__(self, t, clone_t, R, alpha, v, gravity=(0.0, 0.0, 9.81)):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.t, self.clone_t = f(t), f(clone_t)
+        self.dt = self.t - self.clone_t
+        self.R, self.alpha, self.v = f(R).reshape(-1, 9), f(alpha).reshape(-1, 3), f(v).reshape(-1, 3)
+        c = PlvCpiTable()
+        c.n = len(self.t)
+        c.t, c.clone_t, c.dt, c.R_I0toIk, c.alpha, c.v = _dp(self.t), _dp(self.clone_t), _dp(self.dt), _dp(self.R), _dp(self.alpha), _dp(self.v)
+        c.gravity = (C.c_double * 3)(*gravity)
+        self.c = c
 
 
 class PlvUpdateOptions(C.Structure):
@@ -557,6 +579,12 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    def cpi_poses(self, st, cpi, t_q):
+        t_q = _f64(t_q)
+        R, p, ok = np.zeros((len(t_q), 9)), np.zeros((len(t_q), 3)), np.zeros(len(t_q), dtype=np.uint8)
+        self._chk(self.lib.plv_cpi_poses(self.h, C.byref(st.c), C.byref(cpi.c), len(t_q), _dp(t_q), _dp(R), _dp(p), _u8p(ok)))
+        return R, p, ok
 
     # ---- SLAM landmarks
     def slam_update(self, n, H, res, cols, chi2_mult=1.0):

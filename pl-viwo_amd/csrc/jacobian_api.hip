@@ -479,4 +479,53 @@ int plv_triangulate_lines(plv_ctx *ctx, const plv_state_view *st, const plv_line
   return PLV_OK;
 }
 
+int plv_cpi_poses(plv_ctx *ctx, const plv_state_view *st, const plv_cpi_table *cpi, int n_q, const double *t_q, double *R_GtoI,
+                  double *p_IinG, uint8_t *ok) {
+  if (!ctx || !st || !cpi || n_q < 0 || (n_q > 0 && (!t_q || !R_GtoI || !p_IinG || !ok)) || cpi->n < 0 || st->n_clones < 1)
+    return PLV_E_BADARG;
+  if (cpi->n > 0 && (!cpi->t || !cpi->clone_t || !cpi->dt || !cpi->R_I0toIk || !cpi->alpha || !cpi->v)) return PLV_E_BADARG;
+  for (int i = 1; i < cpi->n; ++i)
+    if (!(cpi->t[i - 1] < cpi->t[i])) {
+      set_last_error("plv_cpi_poses: the table must be strictly ascending in time (record %d)", i);
+      return PLV_E_BADARG;
+    }
+  if (n_q == 0) return PLV_OK;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  const size_t n = (size_t)cpi->n, nc = (size_t)st->n_clones, nq = (size_t)n_q;
+  // one packed upload: [t n][clone_t n][dt n][R 9n][alpha 3n][v 3n][clone_time nc][clone_R 9nc][clone_p 3nc][t_q nq]
+  const size_t in_d = 18 * n + 13 * nc + nq, out_d = 12 * nq;
+  std::vector<double> h(in_d);
+  double *w = h.data();
+  auto put = [&](const double *src, size_t cnt) {
+    if (cnt) std::copy(src, src + cnt, w);
+    w += cnt;
+  };
+  put(cpi->t, n), put(cpi->clone_t, n), put(cpi->dt, n), put(cpi->R_I0toIk, 9 * n), put(cpi->alpha, 3 * n), put(cpi->v, 3 * n);
+  put(st->clone_time, nc), put(st->clone_R, 9 * nc), put(st->clone_p, 3 * nc), put(t_q, nq);
+  TRY(us->tri.reserve((in_d + out_d) * sizeof(double) + nq + 16));
+  double *d = us->tri.as<double>();
+  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  CpiParams C{};
+  C.n = cpi->n, C.n_clones = st->n_clones, C.n_q = n_q;
+  C.t = d, C.clone_t = d + n, C.dt = d + 2 * n, C.R = d + 3 * n, C.alpha = d + 12 * n, C.v = d + 15 * n;
+  C.clone_time = d + 18 * n, C.clone_R = C.clone_time + nc, C.clone_p = C.clone_R + 9 * nc;
+  const double *d_tq = C.clone_p + 3 * nc;
+  double *d_R = d + in_d, *d_p = d_R + 9 * nq;
+  unsigned char *d_ok = (unsigned char *)(d_p + 3 * nq);
+  std::copy(cpi->gravity, cpi->gravity + 3, C.gravity);
+  TRY(launch_cpi_poses(ctx, C, d_tq, d_R, d_p, d_ok));
+  PLV_HIP_CHECK(hipMemcpyAsync(R_GtoI, d_R, 9 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(p_IinG, d_p, 3 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipMemcpyAsync(ok, d_ok, nq, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  for (size_t q = 0; q < nq; ++q)
+    if (!ok[q]) {
+      std::fill(R_GtoI + 9 * q, R_GtoI + 9 * q + 9, 0.0);
+      std::fill(p_IinG + 3 * q, p_IinG + 3 * q + 3, 0.0);
+    }
+  return PLV_OK;
+}
+
 }  // extern "C"

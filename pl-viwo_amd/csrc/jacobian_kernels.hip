@@ -596,6 +596,86 @@ __global__ void __launch_bounds__(64) campose_kernel(JacParams P, double *__rest
   for (int i = 0; i < 3; ++i) poses[12 * o + 9 + i] = p_CinG[i];
 }
 
+// a19, CPI branch: State::get_interpolated_pose_imu (REF: State.cpp:1138-1155) over have_cpi's first two stages
+// (:273-355): the record stored at exactly t, else create_new_cpi_linear between the neighbouring records of the
+// same clone.  Thread per query; the table is sorted by time (State::cpis is a std::map).  The reference inserts
+// every interpolated record back into the map; a later query between two interpolated records then interpolates
+// along the same geodesic / the same line, so answering every query from the original table gives the same pose
+// up to rounding.  ok = 0 where the reference would fall through to create_new_cpi_integrate (needs the IMU
+// buffer: SURVEY 8(f) rank 2).
+__device__ int cpi_find(const double *t, int n, double x) {  // index of the record stored at exactly x, or -1
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (t[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && t[lo] == x) ? lo : -1;
+}
+__device__ int clone_find(const CpiParams &C, double x) {
+  for (int i = 0; i < C.n_clones; ++i)
+    if (C.clone_time[i] == x) return i;
+  return -1;
+}
+__global__ void __launch_bounds__(64) cpi_pose_kernel(CpiParams C, const double *__restrict__ tq, double *__restrict__ Rout,
+                                                      double *__restrict__ pout, unsigned char *__restrict__ ok) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= C.n_q) return;
+  ok[q] = 0;
+  const double t = tq[q];
+  const int n = C.n;
+  M3 R_I0toIk;
+  V3 alpha;
+  double clone_t, dt;
+  const int e = cpi_find(C.t, n, t);
+  if (e >= 0 && clone_find(C, C.clone_t[e]) >= 0) {  // :275-277
+    R_I0toIk = ldM(C.R + 9 * e);
+    alpha = ldV(C.alpha + 3 * e);
+    clone_t = C.clone_t[e];
+    dt = C.dt[e];
+  } else {  // create_new_cpi_linear :286-355
+    if (n == 0 || t < C.t[0] || t > C.t[n - 1]) return;
+    int lo = 0, hi = n;  // lower_bound(t)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (C.t[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    const int i0 = (t == C.t[0]) ? 0 : lo - 1;  // :312-318 equal-or-lower ... strictly lower unless t is the first key
+    int up = lo;                                 // upper_bound(t)
+    while (up < n && C.t[up] <= t) ++up;
+    const int i1 = (t == C.t[n - 1]) ? n - 1 : up;  // :321-328
+    if (C.clone_t[i0] != C.clone_t[i1]) return;     // :334-338
+    if (C.clone_t[i0] < C.clone_time[0]) return;    // :340-344
+    const double lambda = (t - C.t[i0]) / (C.t[i1] - C.t[i0]);
+    const M3 R0 = ldM(C.R + 9 * i0), R1 = ldM(C.R + 9 * i1);
+    R_I0toIk = mm(exp_so3(vsc(log_so3(mm(R1, tp(R0))), lambda)), R0);
+    const V3 a0 = ldV(C.alpha + 3 * i0), a1 = ldV(C.alpha + 3 * i1);
+    alpha = vadd(vsc(a0, 1 - lambda), vsc(a1, lambda));
+    clone_t = C.clone_t[i0];
+    dt = t - clone_t;
+  }
+  const int ci = clone_find(C, clone_t), vi = cpi_find(C.t, n, clone_t);
+  if (ci < 0 || vi < 0) return;  // clones.at / cpis.at would throw
+  const M3 RGtoI0 = ldM(C.clone_R + 9 * ci);
+  const V3 p0 = ldV(C.clone_p + 3 * ci), v0 = ldV(C.v + 3 * vi);
+  const V3 g{{C.gravity[0], C.gravity[1], C.gravity[2]}};
+  const M3 RGtoI = mm(R_I0toIk, RGtoI0);
+  V3 p = vadd(p0, vsc(v0, dt));                   // :1153
+  p = vsub(p, vsc(vsc(vsc(g, 0.5), dt), dt));
+  p = vadd(p, mv(tp(RGtoI0), alpha));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rout[9 * q + i] = RGtoI.m[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pout[3 * q + i] = p[i];
+  ok[q] = 1;
+}
+
+int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, double *d_R, double *d_p, unsigned char *d_ok) {
+  ProfScope ps(ctx->prof, "cpi_pose_kernel", ctx->stream);
+  hipLaunchKernelGGL(cpi_pose_kernel, dim3((C.n_q + 63) / 64), dim3(64), 0, ctx->stream, C, d_tq, d_R, d_p, d_ok);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 __device__ bool solve3(const M3 &A, const V3 &b, V3 &x) {
   double a[3][4];
 #pragma unroll

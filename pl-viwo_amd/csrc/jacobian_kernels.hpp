@@ -30,6 +30,14 @@ struct JacParams {
   double *Hf, *Hx, *res;
 };
 
+struct CpiParams {  // device pointers; State::cpis as a table sorted by time + the clone window
+  int n, n_clones, n_q;
+  const double *t, *clone_t, *dt, *R, *alpha, *v;
+  const double *clone_time, *clone_R, *clone_p;
+  double gravity[3];
+};
+int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, double *d_R, double *d_p, unsigned char *d_ok);
+
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,

@@ -372,6 +372,14 @@ class JacOracle:
         lib.orc_build_line_jacobians.restype = C.c_int
         lib.orc_triangulate_lines.argtypes = [sv, lk, dp, u8p]
         lib.orc_triangulate_lines.restype = C.c_int
+        lib.orc_cpi_poses.argtypes = [sv, C.POINTER(pkg.PlvCpiTable), C.c_int, dp, dp, dp, u8p]
+        lib.orc_cpi_poses.restype = C.c_int
+
+    def cpi_poses(self, st, cpi, t_q):
+        t_q = np.ascontiguousarray(t_q, dtype=np.float64)
+        R, p, ok = np.zeros((len(t_q), 9)), np.zeros((len(t_q), 3)), np.zeros(len(t_q), dtype=np.uint8)
+        assert self.lib.orc_cpi_poses(C.byref(st.c), C.byref(cpi.c), len(t_q), _dp(t_q), _dp(R), _dp(p), ok.ctypes.data_as(u8p)) == 0
+        return R, p, ok
 
     def line_columns(self, st, lt, cap=512):
         cols = np.zeros(cap, dtype=np.int32)

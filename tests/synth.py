@@ -244,3 +244,31 @@ def line_scene(sc, L=40, M=15, seed=5, noise_px=0.5, w=752, h=480, depth=(6.0, 4
         lines.append(np.concatenate([np.cross(a, d), d]))  # Pluecker: moment, direction
     return dict(lines=np.array(lines), obs_ptr=np.array(obs_ptr, np.int32), obs_time=np.array(obs_time),
                 seg_uv=np.array(seg_uv, np.float32), seg_uvn=np.array(seg_uvn, np.float32))
+
+
+def cpi_scene(sc, imu_dt=0.005, gravity=(0.0, 0.0, 9.81)):
+    """State::cpis for the trajectory of a vio_scene: one record at every clone time (R = I, alpha = 0, the clone's
+    velocity) and one every imu_dt after it until the next clone, all integrated from that clone.  The records hold
+    the exact preintegrated quantities of the analytic trajectory: R_I0toIk = R_GtoIk R_GtoI0^T and
+    alpha = R_GtoI0 (p_k - p_0 - v_0 dt + g dt^2 / 2), so get_interpolated_pose_imu reproduces pose_fn at them."""
+    t, pose = sc["t"], sc["pose_fn"]
+    g = np.asarray(gravity, dtype=np.float64)
+
+    def vel(ti, h=1e-6):
+        return (pose(ti + h)[1] - pose(ti - h)[1]) / (2 * h)
+
+    rec = []
+    for i, tc in enumerate(t):
+        R0, p0 = sc["R"][i], sc["p"][i]
+        v0 = vel(tc)
+        rec.append((tc, tc, np.eye(3), np.zeros(3), v0))
+        end = t[i + 1] if i + 1 < len(t) else tc + 4 * imu_dt
+        k = 1
+        while tc + k * imu_dt < end - 1e-9:
+            tk = tc + k * imu_dt
+            Rk, pk = pose(tk)
+            dt = tk - tc
+            rec.append((tk, tc, Rk @ R0.T, R0 @ (pk - p0 - v0 * dt + 0.5 * g * dt * dt), vel(tk)))
+            k += 1
+    return dict(t=np.array([r[0] for r in rec]), clone_t=np.array([r[1] for r in rec]), R=np.array([r[2] for r in rec]),
+                alpha=np.array([r[3] for r in rec]), v=np.array([r[4] for r in rec]), gravity=g)

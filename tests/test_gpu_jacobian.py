@@ -105,3 +105,40 @@ def test_triangulate_batch_parity(pkg, ctx, jo):
             assert np.median(rel) < 0.1
         assert np.max(np.abs(p1[good] - p0[good])) <= 1e-6 * max(1.0, np.abs(p0[good]).max()) if good.any() else True
         assert np.allclose(e1[good], e0[good], rtol=1e-5, atol=1e-6)
+
+
+def test_cpi_poses_parity_and_use(pkg):
+    """a19 use_imu_res: plv_cpi_poses against the oracle, then the poses as the residual poses of the Jacobian build."""
+    from test_oracle_cpi import _setup
+    jo = oracle_lib.load_jac(pkg)
+    sc, cp, st, tab = _setup(pkg, obs_offset=0.0125)
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    rng = np.random.default_rng(2)
+    t = cp["t"]
+    last_of_run = t[:-1][np.diff(cp["clone_t"]) != 0]
+    tq = np.concatenate([t[::2], t[:-1] + rng.uniform(0.0002, 0.0048, len(t) - 1), [t[0] - 1.0, t[-1] + 1.0, last_of_run[1] + 1e-4]])
+    rng.shuffle(tq)
+    R, p, ok = ctx.cpi_poses(st, tab, tq)
+    Ro, po, oko = jo.cpi_poses(st, tab, tq)
+    assert np.array_equal(ok, oko) and 0 < (ok == 0).sum() < 40
+    assert np.abs(R - Ro).max() < 1e-12 and np.abs(p - po).max() < 1e-12
+    # a shrunken window: records of marginalised clones drop out identically
+    st2 = pkg.StateView(sc["t"][2:], sc["R"][2:], sc["p"][2:], sc["ids"][2:], sc["R_ItoC"], sc["p_IinC"], sc["K8"])
+    R2, p2, ok2 = ctx.cpi_poses(st2, tab, tq)
+    Ro2, po2, oko2 = jo.cpi_poses(st2, tab, tq)
+    assert np.array_equal(ok2, oko2) and ok2.sum() < ok.sum()
+    assert np.abs(R2 - Ro2).max() < 1e-12 and np.abs(p2 - po2).max() < 1e-12
+    # the observation times of the scene (clone time + 12.5 ms) through the CPI table -> residual poses of a19/a20
+    Rq, pq, okq = ctx.cpi_poses(st, tab, sc["obs_time"])
+    assert okq.all()
+    tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"], res_R=Rq, res_p=pq)
+    cols = ctx.jacobian_columns(st, tr)
+    rows, Hf, Hx, res = ctx.build_jacobians(st, tr, cols, 30)
+    rows_o, Hf_o, Hx_o, res_o = jo.build_jacobians(st, tr, cols, 30)
+    assert np.array_equal(rows, rows_o)
+    assert np.abs(res - res_o).max() < 1e-9 and np.abs(Hx - Hx_o).max() < 1e-9 * max(1.0, np.abs(Hx_o).max())
+    # exact IMU poses instead of the cubic through the clones: the residual is pixel noise again
+    tr_poly = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"])
+    _, _, _, res_poly = ctx.build_jacobians(st, tr_poly, cols, 30)
+    assert np.abs(res).max() < 4.0 / 1.5 * 1.5 and np.abs(res).max() <= np.abs(res_poly).max() + 1e-9
+    ctx.close()
