@@ -553,6 +553,37 @@ int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf,
 /* StateHelper::marginalize (REF: StateHelper.cpp:235-303): drop rows / columns [id, id + size). */
 int plv_cov_marginalize(plv_ctx *ctx, int id, int size);
 
+/* ---------------------------------------------------------------------------------------------
+ * Trajectory I/O and the ATE evaluator: the accuracy half of the metric.
+ * Poses are [n][7] = tx ty tz qx qy qz qw (JPL quaternion), as the reference logs and loads them.
+ * ------------------------------------------------------------------------------------------- */
+/* State_Logger's header line and one `t x y z qx qy qz qw [12 covariance terms]` line (REF: PL-VIWO/src/utils/
+ * State_Logger.h:166-205: ios::fixed, precision 6, covariance terms precision 10; P = 6x6 row-major marginal of the
+ * IMU pose [orientation; position], NULL = the 8-column form).  Return the number of characters written. */
+int plv_traj_header(char *buf, int cap);
+int plv_traj_format(char *buf, int cap, double t, const double *p, const double *q, const double *P);
+/* ov_eval::Loader::load_data (REF: open_vins/ov_eval/src/utils/Loader.cpp:26-90): space-separated, lines starting
+ * with '#' skipped, 8 or 20 columns.  times [cap], poses [cap][7], cov_ori / cov_pos [cap][9] (nullable).  *n = lines
+ * parsed, *n_cov = lines that carried a covariance.  Call with times = NULL to count.  PLV_E_BADARG when the file
+ * cannot be opened or holds no pose (the reference exits), PLV_E_CAPACITY when n > cap. */
+int plv_traj_load(const char *path, int cap, double *times, double *poses, double *cov_ori, double *cov_pos, int *n, int *n_cov);
+/* Loader::get_total_length (:388-398) */
+double plv_traj_length(int n, const double *poses);
+/* AlignUtils::perform_association (REF: open_vins/ov_eval/src/alignment/AlignUtils.cpp:101-189): for every estimate
+ * the closest ground-truth time within max_difference of est + offset, the ground-truth pointer only ever
+ * advancing.  est_idx / gt_idx (capacity n_est) list the matched pairs. */
+int plv_traj_associate(double offset, double max_difference, int n_est, const double *est_times, int n_gt, const double *gt_times,
+                       int *est_idx, int *gt_idx, int *n_match);
+enum { PLV_ALIGN_POSYAW = 0, PLV_ALIGN_POSYAW_SINGLE = 1, PLV_ALIGN_SE3 = 2, PLV_ALIGN_SE3_SINGLE = 3, PLV_ALIGN_SIM3 = 4,
+       PLV_ALIGN_NONE = 5 }; /* REF: AlignTrajectory.cpp:31-53 (rosbag.launch uses posyaw) */
+typedef struct plv_stats { double min, max, median, mean, rmse, std, ninetynine; } plv_stats; /* REF: ov_eval Statistics.h:72-119 */
+/* ResultTrajectory's alignment + calculate_ate on n associated pose pairs (REF: open_vins/ov_eval/src/calc/
+ * ResultTrajectory.cpp:55-121): align est to gt with AlignTrajectory::align_trajectory (Umeyama's two passes over
+ * the positions and the per-pose errors run on the device), aligned[i] = {s R p_est + t, q_est (x) q_ESTtoGT^-1},
+ * ori_err[i] = |log_so3(R_aligned^T R_gt)| in degrees, pos_err[i] = |p_gt - p_aligned|.  Every output is nullable. */
+int plv_traj_ate(plv_ctx *ctx, int method, int n, const double *est_poses, const double *gt_poses, int n_aligned, double *R,
+                 double *t, double *s, double *aligned, double *ori_err, double *pos_err, plv_stats *ori, plv_stats *pos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,13 @@ def load_library():
                                                C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
         "plv_line_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]),
         "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
+        "plv_traj_header": (C.c_int, [C.c_char_p, C.c_int]),
+        "plv_traj_format": (C.c_int, [C.c_char_p, C.c_int, C.c_double, dp, dp, dp]),
+        "plv_traj_load": (C.c_int, [C.c_char_p, C.c_int, dp, dp, dp, dp, ip, ip]),
+        "plv_traj_length": (C.c_double, [C.c_int, dp]),
+        "plv_traj_associate": (C.c_int, [C.c_double, C.c_double, C.c_int, dp, C.c_int, dp, ip, ip, ip]),
+        "plv_traj_ate": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp, dp, dp, dp, C.POINTER(PlvStats),
+                                   C.POINTER(PlvStats)]),
         "plv_cpi_poses": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvCpiTable), C.c_int, dp, dp, dp, u8p]),
         "plv_camera_update_list": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, u64p, ip, dp, fp, fp, dp]),
         "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
@@ -186,6 +193,10 @@ def _u64p(a):
 
 def _f64(a):
     return np.asfortranarray(a, dtype=np.float64)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
 
 
 def _i32(a):
@@ -254,6 +265,16 @@ class CpiTable:
         self.c = c
 
 
+class PlvStats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("min", "max", "median", "mean", "rmse", "std", "ninetynine")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+ALIGN = {"posyaw": 0, "posyawsingle": 1, "se3": 2, "se3single": 3, "sim3": 4, "none": 5}
+
+
 class PlvUpdateOptions(C.Structure):
     _fields_ = [("max_msckf", C.c_int), ("max_obs", C.c_int), ("chi2_mult", C.c_double), ("tri", PlvTriOptions),
                 ("t_prev_frame", C.c_double), ("state_time", C.c_double), ("window_full", C.c_int),
@@ -263,6 +284,50 @@ class PlvUpdateOptions(C.Structure):
 class PlvUpdateResult(C.Structure):
     _fields_ = [("n_pool", C.c_int), ("n_msckf", C.c_int), ("n_accepted", C.c_int), ("n_rows", C.c_int),
                 ("n_returned", C.c_int), ("status", C.c_int), ("n_slam", C.c_int), ("n_init", C.c_int)]
+
+
+def traj_header():
+    buf = C.create_string_buffer(256)
+    n = load_library().plv_traj_header(buf, 256)
+    assert n > 0
+    return buf.value.decode()
+
+
+def traj_format(t, p, q, P=None):
+    buf = C.create_string_buffer(512)
+    p, q = _f64(p), _f64(q)
+    Pm = _f64(np.asarray(P).reshape(36)) if P is not None else None
+    n = load_library().plv_traj_format(buf, 512, float(t), _dp(p), _dp(q), _dp(Pm))
+    assert n > 0, n
+    return buf.value.decode()
+
+
+def traj_load(path):
+    lib = load_library()
+    n, nc = C.c_int(), C.c_int()
+    rc = lib.plv_traj_load(str(path).encode(), 0, None, None, None, None, C.byref(n), C.byref(nc))
+    if rc != 0:
+        raise PlvError(rc, lib.plv_last_error().decode())
+    N = n.value
+    t, poses, co, cp = np.zeros(N), np.zeros((N, 7)), np.zeros((N, 3, 3)), np.zeros((N, 3, 3))
+    rc = lib.plv_traj_load(str(path).encode(), N, _dp(t), _dp(poses), _dp(co), _dp(cp), C.byref(n), C.byref(nc))
+    if rc != 0:
+        raise PlvError(rc, lib.plv_last_error().decode())
+    return t, poses, co[:nc.value], cp[:nc.value]
+
+
+def traj_length(poses):
+    poses = _c64(poses)
+    return load_library().plv_traj_length(len(poses), _dp(poses))
+
+
+def traj_associate(est_times, gt_times, offset=0.0, max_difference=0.02):
+    et, gt = _f64(est_times), _f64(gt_times)
+    ei, gi = np.zeros(max(len(et), 1), dtype=np.int32), np.zeros(max(len(et), 1), dtype=np.int32)
+    m = C.c_int()
+    rc = load_library().plv_traj_associate(float(offset), float(max_difference), len(et), _dp(et), len(gt), _dp(gt), _ip(ei), _ip(gi), C.byref(m))
+    assert rc == 0, rc
+    return ei[:m.value].copy(), gi[:m.value].copy()
 
 
 class StateView:
@@ -579,6 +644,16 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    def traj_ate(self, est, gt, method="posyaw", n_aligned=-1):
+        est, gt = _c64(est), _c64(gt)
+        n = len(est)
+        R, t, s = np.zeros((3, 3)), np.zeros(3), C.c_double()
+        al, oe, pe = np.zeros((n, 7)), np.zeros(n), np.zeros(n)
+        so, sp = PlvStats(), PlvStats()
+        self._chk(self.lib.plv_traj_ate(self.h, ALIGN[method], n, _dp(est), _dp(gt), n_aligned, _dp(R), _dp(t), C.byref(s), _dp(al),
+                                        _dp(oe), _dp(pe), C.byref(so), C.byref(sp)))
+        return dict(R=R, t=t, s=s.value, aligned=al, ori_err=oe, pos_err=pe, ori=so.as_dict(), pos=sp.as_dict())
 
     def cpi_poses(self, st, cpi, t_q):
         t_q = _f64(t_q)

@@ -211,6 +211,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
     for (auto *b : ub) b->release();
     us->jin.release();
     us->tri.release();
+    us->eval.release();
     us->h_jin.release();
     delete us;
   }

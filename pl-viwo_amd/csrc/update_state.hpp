@@ -15,7 +15,7 @@ struct plv_ctx_update_state {
   std::vector<int> brows_host;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   // jacobian inputs
-  plv::DevBuf jin, tri;
+  plv::DevBuf jin, tri, eval;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
