@@ -554,6 +554,49 @@ int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf,
 int plv_cov_marginalize(plv_ctx *ctx, int id, int size);
 
 /* ---------------------------------------------------------------------------------------------
+ * IMU propagation + window maintenance on the device-resident covariance.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plv_imu_state { /* ov_type::IMU value() and fej() (REF: PL-VIWO/src/types/IMU.h) */
+  double q[4], p[3], v[3], bg[3], ba[3]; /* JPL quaternion global->IMU, p_IinG, v_IinG, gyro / accel bias */
+  double q_fej[4], p_fej[3], v_fej[3];
+} plv_imu_state;
+typedef struct plv_imu_noise { /* OptionsIMU sigma_w / sigma_wb / sigma_a / sigma_ab, OptionsEstimator::gravity */
+  double sigma_w, sigma_wb, sigma_a, sigma_ab;
+  double gravity[3];
+} plv_imu_noise;
+typedef struct plv_cpi_accum { /* CpiV1's running state between two Propagator::reset_cpi calls */
+  double clone_t, DT;
+  double R_k2tau[9], alpha_tau[3], beta_tau[3];
+  double b_w_lin[3], b_a_lin[3];
+  double v_clone[3];   /* cpis.at(cpi_clone_t).v */
+  double P_meas[225];  /* 15 x 15 row-major */
+} plv_cpi_accum;
+typedef struct plv_cpi_record { /* State::CPI as Propagator::propagate fills it (REF: Propagator.cpp:65-82) */
+  double t, dt, clone_t;
+  double R_I0toIk[9], alpha[3], v[3], w[3];
+  double Q[36];        /* 6 x 6 row-major: P_meas blocks (0,0) (0,12) (12,0) (12,12) */
+} plv_cpi_record;
+
+/* Propagator::select_imu_readings + interpolate_data (REF: PL-VIWO/src/state/Propagator.cpp:93-152,320-331) on an
+ * ascending IMU buffer t / wm [n][3] / am [n][3].  *n_out = 0 and PLV_OK with *ok = 0 where the reference returns
+ * false (fewer than two samples, time1 <= time0, window outside the buffer).  Host logic. */
+int plv_select_imu_readings(int n, const double *t, const double *wm, const double *am, double time0, double time1, int cap,
+                            double *out_t, double *out_wm, double *out_am, int *n_out, int *ok);
+/* Propagator::reset_cpi for the accumulator (REF: Propagator.cpp:333-357); the caller keeps State::cpis. */
+void plv_reset_cpi(plv_cpi_accum *acc, const plv_imu_state *imu, double clone_t);
+/* Propagator::propagate over already selected samples (REF: Propagator.cpp:30-91): per interval predict_mean_rk4
+ * (:240-318) + predict_and_compute (:154-238: F, G Qc G^T with first-estimate Jacobians, value and fej replaced by the
+ * propagated mean), Phi = F Phi, Qd = F Qd F^T + Qdi symmetrised, optionally CpiV1::feed_IMU (REF: open_vins/ov_core/
+ * src/cpi/CpiV1.cpp:32-315, means + RK4 measurement covariance, imu_avg) with one State::CPI record per interval;
+ * then StateHelper::EKFPropagation (REF: PL-VIWO/src/state/StateHelper.cpp:20-92) of the resident covariance with the
+ * IMU block at imu_id.  imu is updated in place; acc / records / Phi / Qd (15 x 15 row-major) are nullable. */
+int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *noise, int n_data, const double *t, const double *wm,
+                  const double *am, plv_cpi_accum *acc, plv_cpi_record *records, int n, int imu_id, double *Phi, double *Qd);
+/* StateHelper::clone as augment_clone uses it (REF: StateHelper.cpp:175-201,305-355): the resident covariance grows
+ * from n to n + size, the new rows / columns copy those at src_id (the IMU pose: size 6). */
+int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size);
+
+/* ---------------------------------------------------------------------------------------------
  * Trajectory I/O and the ATE evaluator: the accuracy half of the metric.
  * Poses are [n][7] = tx ty tz qx qy qz qw (JPL quaternion), as the reference logs and loads them.
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,456 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see dense.h).  PARITY UNPINNED: the reference holds no
+// known-answer test for the propagator; this restatement is checked against closed-form motion, finite differences
+// of its own mean propagation and a numpy restatement of EKFPropagation (tests/test_oracle_propagate.py).
+//
+// CPU fp64 restatement of SURVEY §8(f) rank 2, IMU propagation + window maintenance:
+//   Propagator::select_imu_readings / interpolate_data   REF: PL-VIWO/src/state/Propagator.cpp:93-152,320-331
+//   Propagator::propagate                                REF: Propagator.cpp:30-91
+//   Propagator::predict_and_compute                      REF: Propagator.cpp:154-238
+//   Propagator::predict_mean_rk4                         REF: Propagator.cpp:240-318
+//   Propagator::reset_cpi                                REF: Propagator.cpp:333-357
+//   CpiV1::feed_IMU (means + measurement covariance)     REF: open_vins/ov_core/src/cpi/CpiV1.cpp:32-315
+//   StateHelper::EKFPropagation                          REF: PL-VIWO/src/state/StateHelper.cpp:20-92
+//   StateHelper::clone / augment_clone                   REF: StateHelper.cpp:175-201,305-355
+//   quaternion helpers                                   REF: open_vins/ov_core/src/utils/quat_ops.h:88-195,482-537
+// CpiV1's bias Jacobians (J_q, J_a, J_b, H_a, H_b) are not restated: nothing in PL-VIWO reads them.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../include/plviwo.h"
+
+namespace {
+
+template <int R, int C> struct Mat {
+  double a[R * C];
+  double &operator()(int r, int c) { return a[r * C + c]; }
+  double operator()(int r, int c) const { return a[r * C + c]; }
+  static Mat zero() {
+    Mat m;
+    std::memset(m.a, 0, sizeof(m.a));
+    return m;
+  }
+  static Mat eye() {
+    Mat m = zero();
+    for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1;
+    return m;
+  }
+};
+template <int R, int K, int C> Mat<R, C> operator*(const Mat<R, K> &x, const Mat<K, C> &y) {
+  Mat<R, C> o = Mat<R, C>::zero();
+  for (int r = 0; r < R; ++r)
+    for (int k = 0; k < K; ++k) {
+      const double v = x(r, k);
+      if (v == 0) continue;
+      for (int c = 0; c < C; ++c) o(r, c) += v * y(k, c);
+    }
+  return o;
+}
+template <int R, int C> Mat<R, C> operator+(const Mat<R, C> &x, const Mat<R, C> &y) {
+  Mat<R, C> o;
+  for (int i = 0; i < R * C; ++i) o.a[i] = x.a[i] + y.a[i];
+  return o;
+}
+template <int R, int C> Mat<R, C> operator-(const Mat<R, C> &x, const Mat<R, C> &y) {
+  Mat<R, C> o;
+  for (int i = 0; i < R * C; ++i) o.a[i] = x.a[i] - y.a[i];
+  return o;
+}
+template <int R, int C> Mat<R, C> operator*(double s, const Mat<R, C> &x) {
+  Mat<R, C> o;
+  for (int i = 0; i < R * C; ++i) o.a[i] = s * x.a[i];
+  return o;
+}
+template <int R, int C> Mat<C, R> T(const Mat<R, C> &x) {
+  Mat<C, R> o;
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < C; ++c) o(c, r) = x(r, c);
+  return o;
+}
+using M3 = Mat<3, 3>;
+using V3 = Mat<3, 1>;
+using V4 = Mat<4, 1>;
+using M15 = Mat<15, 15>;
+
+V3 v3(const double *p) { return V3{{p[0], p[1], p[2]}}; }
+V4 v4(const double *p) { return V4{{p[0], p[1], p[2], p[3]}}; }
+double norm(const V3 &v) { return std::sqrt(v.a[0] * v.a[0] + v.a[1] * v.a[1] + v.a[2] * v.a[2]); }
+M3 skew(const V3 &w) { return M3{{0, -w.a[2], w.a[1], w.a[2], 0, -w.a[0], -w.a[1], w.a[0], 0}}; }
+
+M3 quat_2_Rot(const V4 &q) {  // quat_ops.h:152-157
+  const V3 qv{{q.a[0], q.a[1], q.a[2]}};
+  return ((2 * q.a[3] * q.a[3] - 1) * M3::eye() - (2 * q.a[3]) * skew(qv)) + 2.0 * (qv * T(qv));
+}
+V4 quat_multiply(const V4 &q, const V4 &p) {  // quat_ops.h:180-195
+  Mat<4, 4> Qm = Mat<4, 4>::zero();
+  const V3 qv{{q.a[0], q.a[1], q.a[2]}};
+  const M3 B = q.a[3] * M3::eye() - skew(qv);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Qm(r, c) = B(r, c);
+    Qm(r, 3) = q.a[r];
+    Qm(3, r) = -q.a[r];
+  }
+  Qm(3, 3) = q.a[3];
+  V4 o = Qm * p;
+  if (o.a[3] < 0) o = -1.0 * o;
+  const double n = std::sqrt(o.a[0] * o.a[0] + o.a[1] * o.a[1] + o.a[2] * o.a[2] + o.a[3] * o.a[3]);
+  for (double &x : o.a) x /= n;
+  return o;
+}
+V4 quatnorm(V4 q) {  // quat_ops.h:496-501
+  if (q.a[3] < 0) q = -1.0 * q;
+  const double n = std::sqrt(q.a[0] * q.a[0] + q.a[1] * q.a[1] + q.a[2] * q.a[2] + q.a[3] * q.a[3]);
+  V4 o;
+  for (int i = 0; i < 4; ++i) o.a[i] = q.a[i] / n;
+  return o;
+}
+Mat<4, 4> Omega(const V3 &w) {  // quat_ops.h:482-489
+  Mat<4, 4> m = Mat<4, 4>::zero();
+  const M3 s = skew(w);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) m(r, c) = -s(r, c);
+    m(3, r) = -w.a[r];
+    m(r, 3) = w.a[r];
+  }
+  return m;
+}
+M3 Jl_so3(const V3 &w) {  // quat_ops.h:515-525
+  const double th = norm(w);
+  if (th < 1e-6) return M3::eye();
+  const V3 a = (1.0 / th) * w;
+  return ((std::sin(th) / th) * M3::eye() + (1 - std::sin(th) / th) * (a * T(a))) + ((1 - std::cos(th)) / th) * skew(a);
+}
+M3 Jr_so3(const V3 &w) { return Jl_so3(-1.0 * w); }
+
+M3 rot_of(const double *q) { return quat_2_Rot(v4(q)); }
+
+// Propagator::predict_mean_rk4
+void predict_mean_rk4(const plv_imu_state &s, const V3 &g, double dt, const V3 &w_hat1, const V3 &a_hat1, const V3 &w_hat2,
+                      const V3 &a_hat2, V4 &new_q, V3 &new_v, V3 &new_p) {
+  V3 w_hat = w_hat1, a_hat = a_hat1;
+  const V3 w_alpha = (1.0 / dt) * (w_hat2 - w_hat1), a_jerk = (1.0 / dt) * (a_hat2 - a_hat1);
+  const V4 q_0 = v4(s.q);
+  const V3 p_0 = v3(s.p), v_0 = v3(s.v);
+  const V4 dq_0{{0, 0, 0, 1}};
+  const V4 q0_dot = 0.5 * (Omega(w_hat) * dq_0);
+  const V3 p0_dot = v_0;
+  const M3 R_Gto0 = quat_2_Rot(quat_multiply(dq_0, q_0));
+  const V3 v0_dot = T(R_Gto0) * a_hat - g;
+  const V4 k1_q = dt * q0_dot;
+  const V3 k1_p = dt * p0_dot, k1_v = dt * v0_dot;
+
+  w_hat = w_hat + (0.5 * dt) * w_alpha;  // 0.5 * w_alpha * dt
+  a_hat = a_hat + (0.5 * dt) * a_jerk;
+  const V4 dq_1 = quatnorm(dq_0 + 0.5 * k1_q);
+  const V3 v_1 = v_0 + 0.5 * k1_v;
+  const V4 q1_dot = 0.5 * (Omega(w_hat) * dq_1);
+  const V3 p1_dot = v_1;
+  const M3 R_Gto1 = quat_2_Rot(quat_multiply(dq_1, q_0));
+  const V3 v1_dot = T(R_Gto1) * a_hat - g;
+  const V4 k2_q = dt * q1_dot;
+  const V3 k2_p = dt * p1_dot, k2_v = dt * v1_dot;
+
+  const V4 dq_2 = quatnorm(dq_0 + 0.5 * k2_q);
+  const V3 v_2 = v_0 + 0.5 * k2_v;
+  const V4 q2_dot = 0.5 * (Omega(w_hat) * dq_2);
+  const V3 p2_dot = v_2;
+  const M3 R_Gto2 = quat_2_Rot(quat_multiply(dq_2, q_0));
+  const V3 v2_dot = T(R_Gto2) * a_hat - g;
+  const V4 k3_q = dt * q2_dot;
+  const V3 k3_p = dt * p2_dot, k3_v = dt * v2_dot;
+
+  w_hat = w_hat + (0.5 * dt) * w_alpha;
+  a_hat = a_hat + (0.5 * dt) * a_jerk;
+  const V4 dq_3 = quatnorm(dq_0 + k3_q);
+  const V3 v_3 = v_0 + k3_v;
+  const V4 q3_dot = 0.5 * (Omega(w_hat) * dq_3);
+  const V3 p3_dot = v_3;
+  const M3 R_Gto3 = quat_2_Rot(quat_multiply(dq_3, q_0));
+  const V3 v3_dot = T(R_Gto3) * a_hat - g;
+  const V4 k4_q = dt * q3_dot;
+  const V3 k4_p = dt * p3_dot, k4_v = dt * v3_dot;
+
+  const V4 dq = quatnorm((((dq_0 + (1.0 / 6.0) * k1_q) + (1.0 / 3.0) * k2_q) + (1.0 / 3.0) * k3_q) + (1.0 / 6.0) * k4_q);
+  new_q = quat_multiply(dq, q_0);
+  new_p = (((p_0 + (1.0 / 6.0) * k1_p) + (1.0 / 3.0) * k2_p) + (1.0 / 3.0) * k3_p) + (1.0 / 6.0) * k4_p;
+  new_v = (((v_0 + (1.0 / 6.0) * k1_v) + (1.0 / 3.0) * k2_v) + (1.0 / 3.0) * k3_v) + (1.0 / 6.0) * k4_v;
+}
+
+template <int R, int C, int RR, int CC> void put(Mat<RR, CC> &dst, int r0, int c0, const Mat<R, C> &src) {
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < C; ++c) dst(r0 + r, c0 + c) = src(r, c);
+}
+
+// Propagator::predict_and_compute (IMU local ids: theta 0, p 3, v 6, bg 9, ba 12)
+void predict_and_compute(plv_imu_state &s, const plv_imu_noise &nz, double t0, const double *wm0, const double *am0, double t1,
+                         const double *wm1, const double *am1, M15 &F, M15 &Qd) {
+  const int th = 0, p = 3, v = 6, bg = 9, ba = 12;
+  F = M15::zero();
+  const double dt = t1 - t0;
+  const V3 g = v3(nz.gravity);
+  const V3 w_hat = v3(wm0) - v3(s.bg), a_hat = v3(am0) - v3(s.ba), w_hat2 = v3(wm1) - v3(s.bg), a_hat2 = v3(am1) - v3(s.ba);
+  V4 new_q;
+  V3 new_v, new_p;
+  predict_mean_rk4(s, g, dt, w_hat, a_hat, w_hat2, a_hat2, new_q, new_v, new_p);
+  Mat<15, 12> G = Mat<15, 12>::zero();
+  const M3 Rfej = rot_of(s.q_fej);
+  const M3 dR = quat_2_Rot(new_q) * T(Rfej);
+  const V3 v_fej = v3(s.v_fej), p_fej = v3(s.p_fej);
+  const M3 I3 = M3::eye(), RfT = T(Rfej);
+  const M3 thbg = dt * ((-1.0 * dR) * Jr_so3((-dt) * w_hat));  // -dR * Jr_so3(-w_hat * dt) * dt
+  put(F, th, th, dR);
+  put(F, th, bg, thbg);
+  put(F, bg, bg, I3);
+  put(F, v, th, (-1.0 * skew((new_v - v_fej) + dt * g)) * RfT);
+  put(F, v, v, I3);
+  put(F, v, ba, (-dt) * RfT);
+  put(F, ba, ba, I3);
+  put(F, p, th, (-1.0 * skew(((new_p - p_fej) - dt * v_fej) + (0.5 * dt * dt) * g)) * RfT);
+  put(F, p, v, dt * I3);
+  put(F, p, ba, (-0.5 * dt * dt) * RfT);
+  put(F, p, p, I3);
+  put(G, th, 0, thbg);
+  put(G, v, 3, (-dt) * RfT);
+  put(G, p, 3, (-0.5 * dt * dt) * RfT);
+  put(G, bg, 6, I3);
+  put(G, ba, 9, I3);
+  Mat<12, 12> Qc = Mat<12, 12>::zero();
+  for (int i = 0; i < 3; ++i) {
+    Qc(i, i) = nz.sigma_w * nz.sigma_w / dt;
+    Qc(3 + i, 3 + i) = nz.sigma_a * nz.sigma_a / dt;
+    Qc(6 + i, 6 + i) = nz.sigma_wb * nz.sigma_wb * dt;
+    Qc(9 + i, 9 + i) = nz.sigma_ab * nz.sigma_ab * dt;
+  }
+  Qd = (G * Qc) * T(G);
+  Qd = 0.5 * (Qd + T(Qd));
+  for (int i = 0; i < 4; ++i) s.q[i] = s.q_fej[i] = new_q.a[i];
+  for (int i = 0; i < 3; ++i) {
+    s.p[i] = s.p_fej[i] = new_p.a[i];
+    s.v[i] = s.v_fej[i] = new_v.a[i];
+  }
+}
+
+// CpiV1::feed_IMU with imu_avg = true: means and the RK4 measurement covariance
+void cpi_feed(plv_cpi_accum &c, const plv_imu_noise &nz, double t0, double t1, const double *w0, const double *a0, const double *w1,
+              const double *a1) {
+  const double delta_t = t1 - t0;
+  c.DT += delta_t;
+  if (delta_t == 0) return;
+  V3 w_hat = v3(w0) - v3(c.b_w_lin), a_hat = v3(a0) - v3(c.b_a_lin);
+  w_hat = w_hat + (v3(w1) - v3(c.b_w_lin));
+  w_hat = 0.5 * w_hat;
+  a_hat = a_hat + (v3(a1) - v3(c.b_a_lin));
+  a_hat = 0.5 * a_hat;
+  const double mag_w = norm(w_hat), w_dt = mag_w * delta_t;
+  const bool small_w = mag_w < 0.008726646;
+  const double dt_2 = delta_t * delta_t, cos_wt = std::cos(w_dt), sin_wt = std::sin(w_dt);
+  const M3 w_x = skew(w_hat), a_x = skew(a_hat), w_x_2 = w_x * w_x, eye3 = M3::eye();
+  M3 R_k2tau;
+  std::memcpy(R_k2tau.a, c.R_k2tau, 72);
+  const M3 R_tau2tau1 = small_w ? (eye3 - delta_t * w_x) + (dt_2 / 2) * w_x_2
+                                : (eye3 - (sin_wt / mag_w) * w_x) + ((1.0 - cos_wt) / (mag_w * mag_w)) * w_x_2;
+  const M3 R_k2tau1 = R_tau2tau1 * R_k2tau, R_tau12k = T(R_k2tau1);
+  double f_1, f_2, f_3, f_4;
+  if (small_w) {
+    f_1 = -(std::pow(delta_t, 3) / 3);
+    f_2 = std::pow(delta_t, 4) / 8;
+    f_3 = -(dt_2 / 2);
+    f_4 = std::pow(delta_t, 3) / 6;
+  } else {
+    f_1 = (w_dt * cos_wt - sin_wt) / std::pow(mag_w, 3);
+    f_2 = (w_dt * w_dt - 2 * cos_wt - 2 * w_dt * sin_wt + 2) / (2 * std::pow(mag_w, 4));
+    f_3 = -(1 - cos_wt) / (mag_w * mag_w);
+    f_4 = (w_dt - sin_wt) / std::pow(mag_w, 3);
+  }
+  const M3 alpha_arg = ((dt_2 / 2.0) * eye3 + f_1 * w_x) + f_2 * w_x_2;
+  const M3 Beta_arg = (delta_t * eye3 + f_3 * w_x) + f_4 * w_x_2;
+  const M3 H_al = R_tau12k * alpha_arg, H_be = R_tau12k * Beta_arg;
+  V3 alpha = v3(c.alpha_tau), beta = v3(c.beta_tau);
+  alpha = alpha + (delta_t * beta + H_al * a_hat);
+  beta = beta + H_be * a_hat;
+  // measurement covariance, RK4
+  const double hw = mag_w * .5 * delta_t;
+  M3 R_mid = small_w ? (eye3 - (.5 * delta_t) * w_x) + (std::pow(.5 * delta_t, 2) / 2) * w_x_2
+                     : (eye3 - (std::sin(hw) / mag_w) * w_x) + ((1.0 - std::cos(hw)) / (mag_w * mag_w)) * w_x_2;
+  R_mid = R_mid * R_k2tau;
+  Mat<12, 12> Q_c = Mat<12, 12>::zero();  // CpiBase ctor: sigma_w^2, sigma_wb^2, sigma_a^2, sigma_ab^2
+  for (int i = 0; i < 3; ++i) {
+    Q_c(i, i) = nz.sigma_w * nz.sigma_w;
+    Q_c(3 + i, 3 + i) = nz.sigma_wb * nz.sigma_wb;
+    Q_c(6 + i, 6 + i) = nz.sigma_a * nz.sigma_a;
+    Q_c(9 + i, 9 + i) = nz.sigma_ab * nz.sigma_ab;
+  }
+  auto FG = [&](const M3 &R, M15 &F, Mat<15, 12> &G) {
+    F = M15::zero();
+    G = Mat<15, 12>::zero();
+    put(F, 0, 0, -1.0 * w_x);
+    put(F, 0, 3, -1.0 * eye3);
+    put(F, 6, 0, (-1.0 * T(R)) * a_x);
+    put(F, 6, 9, -1.0 * T(R));
+    put(F, 12, 6, eye3);
+    put(G, 0, 0, -1.0 * eye3);
+    put(G, 3, 3, eye3);
+    put(G, 6, 6, -1.0 * T(R));
+    put(G, 9, 9, eye3);
+  };
+  M15 P;
+  std::memcpy(P.a, c.P_meas, sizeof(P.a));
+  auto Pdot = [&](const M15 &F, const Mat<15, 12> &G, const M15 &Pk) { return (F * Pk + Pk * T(F)) + (G * Q_c) * T(G); };
+  M15 F1, F2, F4;
+  Mat<15, 12> G1, G2, G4;
+  FG(R_k2tau, F1, G1);
+  FG(R_mid, F2, G2);
+  FG(R_k2tau1, F4, G4);
+  const M15 Pd1 = Pdot(F1, G1, P);
+  const M15 Pd2 = Pdot(F2, G2, P + (delta_t / 2.0) * Pd1);
+  const M15 Pd3 = Pdot(F2, G2, P + (delta_t / 2.0) * Pd2);
+  const M15 Pd4 = Pdot(F4, G4, P + delta_t * Pd3);
+  P = P + (delta_t / 6.0) * (((Pd1 + 2.0 * Pd2) + 2.0 * Pd3) + Pd4);
+  P = 0.5 * (P + T(P));
+  std::memcpy(c.P_meas, P.a, sizeof(P.a));
+  std::memcpy(c.R_k2tau, R_k2tau1.a, 72);
+  std::memcpy(c.alpha_tau, alpha.a, 24);
+  std::memcpy(c.beta_tau, beta.a, 24);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Propagator::select_imu_readings.  Returns 1 and fills the outputs on success, 0 when the reference returns false.
+int orc_select_imu_readings(int n, const double *t, const double *wm, const double *am, double time0, double time1, int cap,
+                            double *ot, double *owm, double *oam, int *n_out) {
+  *n_out = 0;
+  if (n < 2) return 0;
+  if (time1 <= time0) return 0;
+  if (t[0] > time0) return 0;
+  if (t[n - 1] < time1) return 0;
+  int m = 0;
+  auto push = [&](double tt, const double *w, const double *a) {
+    if (m < cap) {
+      ot[m] = tt;
+      std::memcpy(owm + 3 * m, w, 24);
+      std::memcpy(oam + 3 * m, a, 24);
+    }
+    ++m;
+  };
+  auto interp = [&](int i, double ts) {
+    const double lambda = (ts - t[i]) / (t[i + 1] - t[i]);
+    double w[3], a[3];
+    for (int c = 0; c < 3; ++c) {
+      a[c] = (1 - lambda) * am[3 * i + c] + lambda * am[3 * (i + 1) + c];
+      w[c] = (1 - lambda) * wm[3 * i + c] + lambda * wm[3 * (i + 1) + c];
+    }
+    push(ts, w, a);
+  };
+  size_t i = 0;
+  const size_t N = (size_t)n;
+  for (; i < N - 1; i++)
+    if (t[i] <= time0 && time0 <= t[i + 1]) {
+      interp((int)i, time0);
+      break;
+    }
+  for (i == 0 ? i = 0 : i--; i < N - 1; i++) {
+    if (time0 < t[i] && t[i + 1] < time1) push(t[i], wm + 3 * i, am + 3 * i);
+    if (t[i + 1] > time1) break;
+  }
+  for (i == 0 ? i = 0 : i--; i < N - 1; i++)
+    if (t[i] <= time1 && time1 <= t[i + 1]) {
+      interp((int)i, time1);
+      break;
+    }
+  *n_out = m;
+  return m <= cap ? 1 : 0;
+}
+
+// Propagator::reset_cpi for the accumulator (the caller keeps State::cpis)
+void orc_reset_cpi(plv_cpi_accum *c, const plv_imu_state *imu, double clone_t) {
+  std::memset(c, 0, sizeof(*c));
+  c->clone_t = clone_t;
+  c->R_k2tau[0] = c->R_k2tau[4] = c->R_k2tau[8] = 1;
+  std::memcpy(c->b_w_lin, imu->bg, 24);
+  std::memcpy(c->b_a_lin, imu->ba, 24);
+  std::memcpy(c->v_clone, imu->v, 24);
+}
+
+// Propagator::propagate over the selected samples + StateHelper::EKFPropagation on P (n x n col-major, ld; IMU block at
+// imu_id).  records: n_data - 1 entries, nullable with cpi.
+int orc_propagate(plv_imu_state *imu, const plv_imu_noise *nz, int n_data, const double *t, const double *wm, const double *am,
+                  plv_cpi_accum *cpi, plv_cpi_record *records, double *P, int n, int ld, int imu_id, double *Phi_out,
+                  double *Qd_out) {
+  if (n_data < 2) return -1;
+  M15 Phi = M15::eye(), Qd = M15::zero();
+  M3 R_GtoIk = rot_of(imu->q);
+  const V3 g = v3(nz->gravity);
+  for (int i = 0; i < n_data - 1; ++i) {
+    M15 F, Qdi;
+    predict_and_compute(*imu, *nz, t[i], wm + 3 * i, am + 3 * i, t[i + 1], wm + 3 * (i + 1), am + 3 * (i + 1), F, Qdi);
+    Phi = F * Phi;
+    Qd = (F * Qd) * T(F) + Qdi;
+    Qd = 0.5 * (Qd + T(Qd));
+    if (cpi) {
+      cpi_feed(*cpi, *nz, t[i], t[i + 1], wm + 3 * i, am + 3 * i, wm + 3 * (i + 1), am + 3 * (i + 1));
+      M3 Rk;
+      std::memcpy(Rk.a, cpi->R_k2tau, 72);
+      if (records) {
+        plv_cpi_record &r = records[i];
+        r.t = t[i + 1];
+        r.dt = cpi->DT;
+        r.clone_t = cpi->clone_t;
+        std::memcpy(r.R_I0toIk, cpi->R_k2tau, 72);
+        std::memcpy(r.alpha, cpi->alpha_tau, 24);
+        const V3 w = v3(wm + 3 * (i + 1)) - v3(imu->bg);
+        std::memcpy(r.w, w.a, 24);
+        const V3 vv = (v3(cpi->v_clone) - cpi->DT * g) + T(R_GtoIk) * v3(cpi->beta_tau);
+        std::memcpy(r.v, vv.a, 24);
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            r.Q[6 * a + b] = cpi->P_meas[15 * a + b];
+            r.Q[6 * a + 3 + b] = cpi->P_meas[15 * a + 12 + b];
+            r.Q[6 * (3 + a) + b] = cpi->P_meas[15 * (12 + a) + b];
+            r.Q[6 * (3 + a) + 3 + b] = cpi->P_meas[15 * (12 + a) + 12 + b];
+          }
+      }
+      R_GtoIk = Rk * R_GtoIk;
+    }
+  }
+  if (Phi_out) std::memcpy(Phi_out, Phi.a, sizeof(Phi.a));
+  if (Qd_out) std::memcpy(Qd_out, Qd.a, sizeof(Qd.a));
+  if (P) {  // EKFPropagation with order_NEW = order_OLD = {imu}
+    std::vector<double> CovPhiT((size_t)n * 15, 0.0);  // n x 15 row-major
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < 15; ++c) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += P[(size_t)(imu_id + k) * ld + r] * Phi(c, k);
+        CovPhiT[(size_t)r * 15 + c] = s;
+      }
+    M15 PCP;
+    for (int r = 0; r < 15; ++r)
+      for (int c = 0; c < 15; ++c) {
+        double s = r <= c ? Qd(r, c) : Qd(c, r);  // selfadjointView<Upper>
+        for (int k = 0; k < 15; ++k) s += Phi(r, k) * CovPhiT[(size_t)(imu_id + k) * 15 + c];
+        PCP(r, c) = s;
+      }
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < 15; ++c) {
+        P[(size_t)r * ld + imu_id + c] = CovPhiT[(size_t)r * 15 + c];      // row block = Cov_PhiT^T  (col-major: P(imu+c, r))
+        P[(size_t)(imu_id + c) * ld + r] = CovPhiT[(size_t)r * 15 + c];    // column block = Cov_PhiT
+      }
+    for (int r = 0; r < 15; ++r)
+      for (int c = 0; c < 15; ++c) P[(size_t)(imu_id + c) * ld + imu_id + r] = PCP(r, c);
+  }
+  return 0;
+}
+
+// StateHelper::clone: append `size` rows / columns copying the block at src_id.  P has room for (n + size) (ld >= n + size).
+void orc_cov_clone(double *P, int n, int ld, int src_id, int size) {
+  for (int c = 0; c < size; ++c)
+    for (int r = 0; r < n; ++r) {
+      P[(size_t)(n + c) * ld + r] = P[(size_t)(src_id + c) * ld + r];  // (0, new_loc) block
+      P[(size_t)r * ld + n + c] = P[(size_t)r * ld + src_id + c];      // (new_loc, 0) block
+    }
+  for (int c = 0; c < size; ++c)
+    for (int r = 0; r < size; ++r) P[(size_t)(n + c) * ld + n + r] = P[(size_t)(src_id + c) * ld + src_id + r];
+}
+
+}  // extern "C"

@@ -128,6 +128,11 @@ def load_library():
                                                C.POINTER(PlvUpdateResult), u64p, u8p, dp]),
         "plv_line_db_append_measurements": (C.c_int, [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]),
         "plv_point_used_insert": (C.c_int, [vp, C.c_uint64, dp, C.c_double]),
+        "plv_select_imu_readings": (C.c_int, [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip, ip]),
+        "plv_reset_cpi": (None, [C.POINTER(PlvCpiAccum), C.POINTER(PlvImuState), C.c_double]),
+        "plv_propagate": (C.c_int, [vp, C.POINTER(PlvImuState), C.POINTER(PlvImuNoise), C.c_int, dp, dp, dp, C.POINTER(PlvCpiAccum),
+                                    C.POINTER(PlvCpiRecord), C.c_int, C.c_int, dp, dp]),
+        "plv_cov_clone": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "plv_traj_header": (C.c_int, [C.c_char_p, C.c_int]),
         "plv_traj_format": (C.c_int, [C.c_char_p, C.c_int, C.c_double, dp, dp, dp]),
         "plv_traj_load": (C.c_int, [C.c_char_p, C.c_int, dp, dp, dp, dp, ip, ip]),
@@ -265,6 +270,54 @@ class CpiTable:
         self.c = c
 
 
+class PlvImuState(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("p", C.c_double * 3), ("v", C.c_double * 3), ("bg", C.c_double * 3), ("ba", C.c_double * 3),
+                ("q_fej", C.c_double * 4), ("p_fej", C.c_double * 3), ("v_fej", C.c_double * 3)]
+
+    @classmethod
+    def make(cls, q, p, v, bg=(0, 0, 0), ba=(0, 0, 0), q_fej=None, p_fej=None, v_fej=None):
+        s = cls()
+        for name, val in (("q", q), ("p", p), ("v", v), ("bg", bg), ("ba", ba), ("q_fej", q if q_fej is None else q_fej),
+                          ("p_fej", p if p_fej is None else p_fej), ("v_fej", v if v_fej is None else v_fej)):
+            arr = getattr(s, name)
+            for i, x in enumerate(val):
+                arr[i] = float(x)
+        return s
+
+    def copy(self):
+        c = PlvImuState()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(self))
+        return c
+
+    def vec(self):
+        return np.array(list(self.q) + list(self.p) + list(self.v) + list(self.bg) + list(self.ba))
+
+
+class PlvImuNoise(C.Structure):
+    _fields_ = [("sigma_w", C.c_double), ("sigma_wb", C.c_double), ("sigma_a", C.c_double), ("sigma_ab", C.c_double),
+                ("gravity", C.c_double * 3)]
+
+
+class PlvCpiAccum(C.Structure):
+    _fields_ = [("clone_t", C.c_double), ("DT", C.c_double), ("R_k2tau", C.c_double * 9), ("alpha_tau", C.c_double * 3),
+                ("beta_tau", C.c_double * 3), ("b_w_lin", C.c_double * 3), ("b_a_lin", C.c_double * 3), ("v_clone", C.c_double * 3),
+                ("P_meas", C.c_double * 225)]
+
+    def copy(self):
+        c = PlvCpiAccum()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(self))
+        return c
+
+
+class PlvCpiRecord(C.Structure):
+    _fields_ = [("t", C.c_double), ("dt", C.c_double), ("clone_t", C.c_double), ("R_I0toIk", C.c_double * 9), ("alpha", C.c_double * 3),
+                ("v", C.c_double * 3), ("w", C.c_double * 3), ("Q", C.c_double * 36)]
+
+
+def imu_noise(sigma_w=1.6968e-4, sigma_wb=1.9393e-5, sigma_a=2.0e-3, sigma_ab=3.0e-3, gravity=(0.0, 0.0, 9.81)):
+    return PlvImuNoise(sigma_w, sigma_wb, sigma_a, sigma_ab, (C.c_double * 3)(*gravity))
+
+
 class PlvStats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("min", "max", "median", "mean", "rmse", "std", "ninetynine")]
 
@@ -284,6 +337,23 @@ class PlvUpdateOptions(C.Structure):
 class PlvUpdateResult(C.Structure):
     _fields_ = [("n_pool", C.c_int), ("n_msckf", C.c_int), ("n_accepted", C.c_int), ("n_rows", C.c_int),
                 ("n_returned", C.c_int), ("status", C.c_int), ("n_slam", C.c_int), ("n_init", C.c_int)]
+
+
+def select_imu_readings(t, wm, am, time0, time1):
+    t, wm, am = _c64(t), _c64(wm), _c64(am)
+    cap = len(t) + 2
+    ot, ow, oa = np.zeros(cap), np.zeros((cap, 3)), np.zeros((cap, 3))
+    n, ok = C.c_int(), C.c_int()
+    rc = load_library().plv_select_imu_readings(len(t), _dp(t), _dp(wm), _dp(am), float(time0), float(time1), cap, _dp(ot), _dp(ow), _dp(oa),
+                                                C.byref(n), C.byref(ok))
+    assert rc == 0, rc
+    return bool(ok.value), ot[:n.value].copy(), ow[:n.value].copy(), oa[:n.value].copy()
+
+
+def reset_cpi(imu, clone_t):
+    acc = PlvCpiAccum()
+    load_library().plv_reset_cpi(C.byref(acc), C.byref(imu), float(clone_t))
+    return acc
 
 
 def traj_header():
@@ -644,6 +714,18 @@ class Context:
         cols = _i32(cols)
         self._chk(self.lib.plv_build_jacobians_resident(self.h, C.byref(st.c), C.byref(tr.c), len(cols), _ip(cols), ld))
         self._batch_F = tr.c.n_feat
+
+    def propagate(self, imu, noise, t, wm, am, n, acc=None, imu_id=0, want_records=True):
+        """Propagator::propagate over the given samples on the resident covariance; imu / acc are updated in place."""
+        t, wm, am = _c64(t), _c64(wm), _c64(am)
+        rec = (PlvCpiRecord * max(len(t) - 1, 1))() if (acc is not None and want_records) else None
+        Phi, Qd = np.zeros((15, 15)), np.zeros((15, 15))
+        self._chk(self.lib.plv_propagate(self.h, C.byref(imu), C.byref(noise), len(t), _dp(t), _dp(wm), _dp(am),
+                                         C.byref(acc) if acc is not None else None, rec, n, imu_id, _dp(Phi), _dp(Qd)))
+        return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else [])
+
+    def cov_clone(self, n, src_id, size=6):
+        self._chk(self.lib.plv_cov_clone(self.h, n, src_id, size))
 
     def traj_ate(self, est, gt, method="posyaw", n_aligned=-1):
         est, gt = _c64(est), _c64(gt)

@@ -453,6 +453,65 @@ JacOracle.triangulate_batch = JacOracle._tb
 _jac = None
 
 
+class PropOracle:
+    """oracle/propagate_oracle.cpp"""
+
+    def __init__(self, lib, pkg):
+        self.lib, self.pkg = lib, pkg
+        S, N, A, R = C.POINTER(pkg.PlvImuState), C.POINTER(pkg.PlvImuNoise), C.POINTER(pkg.PlvCpiAccum), C.POINTER(pkg.PlvCpiRecord)
+        lib.orc_select_imu_readings.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip]
+        lib.orc_select_imu_readings.restype = C.c_int
+        lib.orc_reset_cpi.argtypes = [A, S, C.c_double]
+        lib.orc_reset_cpi.restype = None
+        lib.orc_propagate.argtypes = [S, N, C.c_int, dp, dp, dp, A, R, dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        lib.orc_propagate.restype = C.c_int
+        lib.orc_cov_clone.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_cov_clone.restype = None
+
+    def select_imu_readings(self, t, wm, am, time0, time1):
+        t, wm, am = (np.ascontiguousarray(x, dtype=np.float64) for x in (t, wm, am))
+        cap = len(t) + 2
+        ot, ow, oa = np.zeros(cap), np.zeros((cap, 3)), np.zeros((cap, 3))
+        n = C.c_int()
+        ok = self.lib.orc_select_imu_readings(len(t), _dp(t), _dp(wm), _dp(am), time0, time1, cap, _dp(ot), _dp(ow), _dp(oa), C.byref(n))
+        return bool(ok), ot[:n.value].copy(), ow[:n.value].copy(), oa[:n.value].copy()
+
+    def reset_cpi(self, imu, clone_t):
+        acc = self.pkg.PlvCpiAccum()
+        self.lib.orc_reset_cpi(C.byref(acc), C.byref(imu), clone_t)
+        return acc
+
+    def propagate(self, imu, noise, t, wm, am, P=None, acc=None, imu_id=0):
+        """imu / acc updated in place; returns Phi, Qd, records, P' (col-major semantics: symmetric anyway)."""
+        t, wm, am = (np.ascontiguousarray(x, dtype=np.float64) for x in (t, wm, am))
+        rec = (self.pkg.PlvCpiRecord * max(len(t) - 1, 1))() if acc is not None else None
+        Phi, Qd = np.zeros((15, 15)), np.zeros((15, 15))
+        Pn = np.asfortranarray(P, dtype=np.float64).copy(order="F") if P is not None else None
+        n = Pn.shape[0] if Pn is not None else 0
+        rc = self.lib.orc_propagate(C.byref(imu), C.byref(noise), len(t), _dp(t), _dp(wm), _dp(am), C.byref(acc) if acc is not None else None,
+                                    rec, _dp(Pn), n, n, imu_id, _dp(Phi), _dp(Qd))
+        assert rc == 0
+        return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else []), Pn
+
+    def cov_clone(self, P, src_id, size=6):
+        n = P.shape[0]
+        out = np.zeros((n + size, n + size), order="F")
+        out[:n, :n] = P
+        self.lib.orc_cov_clone(_dp(out), n, n + size, src_id, size)
+        return out
+
+
+_prop = None
+
+
+def load_prop(pkg):
+    global _prop
+    if _prop is None:
+        load()
+        _prop = PropOracle(_inst.lib, pkg)
+    return _prop
+
+
 def load_jac(pkg):
     global _jac
     if _jac is None:

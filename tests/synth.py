@@ -272,3 +272,21 @@ def cpi_scene(sc, imu_dt=0.005, gravity=(0.0, 0.0, 9.81)):
             k += 1
     return dict(t=np.array([r[0] for r in rec]), clone_t=np.array([r[1] for r in rec]), R=np.array([r[2] for r in rec]),
                 alpha=np.array([r[3] for r in rec]), v=np.array([r[4] for r in rec]), gravity=g)
+
+
+def imu_stream(pose_fn, t0, t1, rate=200.0, gravity=(0.0, 0.0, 9.81), bg=(0, 0, 0), ba=(0, 0, 0), h=1e-4):
+    """Noise-free IMU samples of an analytic trajectory pose_fn(t) -> (R_GtoI, p_IinG), JPL conventions of the reference:
+    R_GtoI(t + dt) = exp(-[w dt]x) R_GtoI(t),  a_m = R_GtoI (p'' + g)."""
+    from scipy.spatial.transform import Rotation
+    g = np.asarray(gravity, dtype=np.float64)
+    n = int(round((t1 - t0) * rate)) + 1
+    t = t0 + np.arange(n) / rate
+    wm, am = np.zeros((n, 3)), np.zeros((n, 3))
+    for i, ti in enumerate(t):
+        Rm, _ = pose_fn(ti - h)
+        Rp, _ = pose_fn(ti + h)
+        R, _ = pose_fn(ti)
+        wm[i] = -Rotation.from_matrix(Rp @ Rm.T).as_rotvec() / (2 * h) + np.asarray(bg)
+        acc = (pose_fn(ti + h)[1] - 2 * pose_fn(ti)[1] + pose_fn(ti - h)[1]) / (h * h)
+        am[i] = R @ (acc + g) + np.asarray(ba)
+    return t, wm, am
