@@ -592,6 +592,19 @@ void plv_reset_cpi(plv_cpi_accum *acc, const plv_imu_state *imu, double clone_t)
  * IMU block at imu_id.  imu is updated in place; acc / records / Phi / Qd (15 x 15 row-major) are nullable. */
 int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *noise, int n_data, const double *t, const double *wm,
                   const double *am, plv_cpi_accum *acc, plv_cpi_record *records, int n, int imu_id, double *Phi, double *Qd);
+/* State::create_new_cpi_integrate (REF: PL-VIWO/src/state/State.cpp:357-415), the last stage of have_cpi: CpiV1 from the
+ * clone at clone_t to t_given over the IMU buffer (select_imu_readings between the two, reversed when the clone is the later
+ * one), producing the State::CPI record the caller inserts into its table; plv_cpi_poses then answers t_given from it.
+ * R_GtoI_clone = clones.at(clone_t)->Rot(); v_clone / bg / ba = cpis.at(clone_t).v / .bg / .ba.  *ok = 0 when the IMU
+ * buffer does not cover the interval (the reference returns false). */
+int plv_cpi_integrate(plv_ctx *ctx, const plv_imu_noise *noise, double t_given, double clone_t, const double *R_GtoI_clone,
+                      const double *v_clone, const double *bg, const double *ba, int n_imu, const double *t, const double *wm,
+                      const double *am, plv_cpi_record *out, int *ok);
+/* State::closest_clone_time_not_imu (REF: State.cpp:524-538) as intended: the clone nearest to t_given, leaving out the
+ * newest entry when it is the IMU pose itself (exclude_newest).  The reference's loop compares against
+ * abs(t - clone.first) with t read before its first assignment (uninitialised on the first pass), so its result is not
+ * defined; this is the evident intent.  Host logic. */
+int plv_closest_clone_time(const plv_state_view *st, int exclude_newest, double t_given, double *clone_t, int *found);
 /* StateHelper::clone as augment_clone uses it (REF: StateHelper.cpp:175-201,305-355): the resident covariance grows
  * from n to n + size, the new rows / columns copy those at src_id (the IMU pose: size 6). */
 int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size);

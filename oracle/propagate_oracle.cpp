@@ -442,6 +442,58 @@ int orc_propagate(plv_imu_state *imu, const plv_imu_noise *nz, int n_data, const
   return 0;
 }
 
+// State::create_new_cpi_integrate (REF: PL-VIWO/src/state/State.cpp:357-415) for one query; returns 1 on success.
+int orc_cpi_integrate(const plv_imu_noise *nz, double t_given, double clone_t, const double *R_GtoI_clone, const double *v_clone,
+                      const double *bg, const double *ba, int n_imu, const double *t, const double *wm, const double *am,
+                      plv_cpi_record *out) {
+  std::vector<double> st((size_t)n_imu + 2), sw(3 * ((size_t)n_imu + 2)), sa(3 * ((size_t)n_imu + 2));
+  int m = 0;
+  const bool fwd = clone_t <= t_given;
+  if (!orc_select_imu_readings(n_imu, t, wm, am, fwd ? clone_t : t_given, fwd ? t_given : clone_t, n_imu + 2, st.data(), sw.data(),
+                               sa.data(), &m))
+    return 0;
+  if (!fwd)
+    for (int i = 0; i < m / 2; ++i) {
+      std::swap(st[i], st[m - 1 - i]);
+      for (int c = 0; c < 3; ++c) {
+        std::swap(sw[3 * i + c], sw[3 * (m - 1 - i) + c]);
+        std::swap(sa[3 * i + c], sa[3 * (m - 1 - i) + c]);
+      }
+    }
+  plv_cpi_accum c;
+  std::memset(&c, 0, sizeof(c));
+  c.clone_t = clone_t;
+  c.R_k2tau[0] = c.R_k2tau[4] = c.R_k2tau[8] = 1;
+  std::memcpy(c.b_w_lin, bg, 24);
+  std::memcpy(c.b_a_lin, ba, 24);
+  std::memcpy(c.v_clone, v_clone, 24);
+  M3 R_GtoIk;
+  std::memcpy(R_GtoIk.a, R_GtoI_clone, 72);
+  for (int i = 0; i < m - 1; ++i) {
+    M3 Rk;
+    std::memcpy(Rk.a, c.R_k2tau, 72);
+    R_GtoIk = Rk * R_GtoIk;
+    cpi_feed(c, *nz, st[i], st[i + 1], &sw[3 * i], &sa[3 * i], &sw[3 * (i + 1)], &sa[3 * (i + 1)]);
+  }
+  out->t = t_given;
+  out->dt = t_given - clone_t;
+  out->clone_t = clone_t;
+  std::memcpy(out->R_I0toIk, c.R_k2tau, 72);
+  std::memcpy(out->alpha, c.alpha_tau, 24);
+  const V3 w = v3(&sw[3 * (m - 1)]) - v3(bg);
+  std::memcpy(out->w, w.a, 24);
+  const V3 vv = (v3(v_clone) - c.DT * v3(nz->gravity)) + T(R_GtoIk) * v3(c.beta_tau);
+  std::memcpy(out->v, vv.a, 24);
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      out->Q[6 * a + b] = c.P_meas[15 * a + b];
+      out->Q[6 * a + 3 + b] = c.P_meas[15 * a + 12 + b];
+      out->Q[6 * (3 + a) + b] = c.P_meas[15 * (12 + a) + b];
+      out->Q[6 * (3 + a) + 3 + b] = c.P_meas[15 * (12 + a) + 12 + b];
+    }
+  return 1;
+}
+
 // StateHelper::clone: append `size` rows / columns copying the block at src_id.  P has room for (n + size) (ld >= n + size).
 void orc_cov_clone(double *P, int n, int ld, int src_id, int size) {
   for (int c = 0; c < size; ++c)

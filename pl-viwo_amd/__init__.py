@@ -133,6 +133,9 @@ def load_library():
         "plv_propagate": (C.c_int, [vp, C.POINTER(PlvImuState), C.POINTER(PlvImuNoise), C.c_int, dp, dp, dp, C.POINTER(PlvCpiAccum),
                                     C.POINTER(PlvCpiRecord), C.c_int, C.c_int, dp, dp]),
         "plv_cov_clone": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "plv_cpi_integrate": (C.c_int, [vp, C.POINTER(PlvImuNoise), C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp,
+                                        C.POINTER(PlvCpiRecord), ip]),
+        "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
         "plv_traj_header": (C.c_int, [C.c_char_p, C.c_int]),
         "plv_traj_format": (C.c_int, [C.c_char_p, C.c_int, C.c_double, dp, dp, dp]),
         "plv_traj_load": (C.c_int, [C.c_char_p, C.c_int, dp, dp, dp, dp, ip, ip]),
@@ -348,6 +351,13 @@ def select_imu_readings(t, wm, am, time0, time1):
                                                 C.byref(n), C.byref(ok))
     assert rc == 0, rc
     return bool(ok.value), ot[:n.value].copy(), ow[:n.value].copy(), oa[:n.value].copy()
+
+
+def closest_clone_time(st, t_given, exclude_newest=False):
+    ct, found = C.c_double(), C.c_int()
+    rc = load_library().plv_closest_clone_time(C.byref(st.c), 1 if exclude_newest else 0, float(t_given), C.byref(ct), C.byref(found))
+    assert rc == 0, rc
+    return (ct.value if found.value else None)
 
 
 def reset_cpi(imu, clone_t):
@@ -723,6 +733,15 @@ class Context:
         self._chk(self.lib.plv_propagate(self.h, C.byref(imu), C.byref(noise), len(t), _dp(t), _dp(wm), _dp(am),
                                          C.byref(acc) if acc is not None else None, rec, n, imu_id, _dp(Phi), _dp(Qd)))
         return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else [])
+
+    def cpi_integrate(self, noise, t_given, clone_t, R_clone, v_clone, bg, ba, t, wm, am):
+        """State::create_new_cpi_integrate: (ok, PlvCpiRecord)."""
+        t, wm, am = _c64(t), _c64(wm), _c64(am)
+        Rc, vc, bg, ba = _c64(R_clone), _c64(v_clone), _c64(bg), _c64(ba)
+        rec, ok = PlvCpiRecord(), C.c_int()
+        self._chk(self.lib.plv_cpi_integrate(self.h, C.byref(noise), float(t_given), float(clone_t), _dp(Rc), _dp(vc), _dp(bg), _dp(ba),
+                                             len(t), _dp(t), _dp(wm), _dp(am), C.byref(rec), C.byref(ok)))
+        return bool(ok.value), rec
 
     def cov_clone(self, n, src_id, size=6):
         self._chk(self.lib.plv_cov_clone(self.h, n, src_id, size))

@@ -122,6 +122,8 @@ struct PropArgs {
   double *cpi;                // plv_cpi_accum image in/out, or null
   double *records;            // [n_data-1][sizeof(plv_cpi_record)/8] or null
   double *Phi, *Qd;           // [225] out, row-major
+  int mode;                   // 0 = Propagator::propagate, 1 = State::create_new_cpi_integrate (CPI only, one record at the end)
+  double R0[9], t_given;      // mode 1: clones.at(clone_t)->Rot(), the requested time
 };
 
 __device__ __forceinline__ void put3(double *M, int ldm, int r0, int c0, const DM3 &B) {
@@ -296,13 +298,22 @@ __global__ void __launch_bounds__(256) propagate_kernel(PropArgs A) {
     Qd[tid] = 0.0;
   }
   __syncthreads();
-  if (tid == 0) {  // R_GtoIk = state->imu->Rot() at entry (:46)
+  if (tid == 0) {  // R_GtoIk = state->imu->Rot() at entry (:46) / clones.at(clone_t)->Rot() (State.cpp:389)
     const DM3 R0 = q2R(DQ{imu[IQ], imu[IQ + 1], imu[IQ + 2], imu[IQ + 3]});
-    for (int e = 0; e < 9; ++e) RGtoIk[e] = R0.m[e];
+    for (int e = 0; e < 9; ++e) RGtoIk[e] = A.mode == 1 ? A.R0[e] : R0.m[e];
   }
   for (int i = 0; i < A.n_data - 1; ++i) {
     __syncthreads();
-    if (tid == 0) mean_and_jacobians(imu, A, i, F, G);
+    if (A.mode == 1) {
+      if (tid == 0) {  // State.cpp:393 — the orientation advances BEFORE the feed, with the previous R_k2tau
+        double nr[9];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) nr[3 * a + b] = cpi[CA_R + 3 * a] * RGtoIk[b] + cpi[CA_R + 3 * a + 1] * RGtoIk[3 + b] + cpi[CA_R + 3 * a + 2] * RGtoIk[6 + b];
+        for (int e = 0; e < 9; ++e) RGtoIk[e] = nr[e];
+      }
+    } else if (tid == 0) {
+      mean_and_jacobians(imu, A, i, F, G);
+    }
     const double delta_t = A.t[i + 1] - A.t[i];
     const bool do_cpi = A.cpi != nullptr;
     if (do_cpi && tid == 64) {
@@ -313,7 +324,7 @@ __global__ void __launch_bounds__(256) propagate_kernel(PropArgs A) {
     __syncthreads();
     // ---- Qdi = sym(G Qc G^T), Phi = F Phi, Qd = sym(F Qd F^T + Qdi)   (:56-58, :222-224)
     double q = 0.0, ph = 0.0, fq = 0.0;
-    if (el) {
+    if (el && A.mode == 0) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
         const double qc = k < 3 ? A.sw * A.sw / delta_t : (k < 6 ? A.sa * A.sa / delta_t : (k < 9 ? A.swb * A.swb * delta_t : A.sab * A.sab * delta_t));
@@ -329,16 +340,16 @@ __global__ void __launch_bounds__(256) propagate_kernel(PropArgs A) {
     }
     __syncthreads();
     double s = 0.0, qdi = 0.0;
-    if (el) {
+    if (el && A.mode == 0) {
       Phi[tid] = ph;
 #pragma unroll
       for (int k = 0; k < 15; ++k) s += Y[r * 15 + k] * F[c * 15 + k];
       qdi = 0.5 * (X[tid] + X[c * 15 + r]);
     }
     __syncthreads();
-    if (el) X[tid] = s + qdi;
+    if (el && A.mode == 0) X[tid] = s + qdi;
     __syncthreads();
-    if (el) Qd[tid] = 0.5 * (X[tid] + X[c * 15 + r]);
+    if (el && A.mode == 0) Qd[tid] = 0.5 * (X[tid] + X[c * 15 + r]);
     // ---- CPI measurement covariance, RK4 (:197-306), and the State::CPI record (Propagator.cpp:62-82)
     if (do_cpi && delta_t != 0) {
       __syncthreads();
@@ -375,7 +386,7 @@ __global__ void __launch_bounds__(256) propagate_kernel(PropArgs A) {
       if (tid < 9) cpi[CA_R + tid] = Rs[2][tid];
       __syncthreads();
     }
-    if (do_cpi) {
+    if (do_cpi && A.mode == 0) {
       __syncthreads();
       if (A.records && tid == 0) {
         double *rec = A.records + (size_t)i * CR_N;
@@ -408,6 +419,27 @@ __global__ void __launch_bounds__(256) propagate_kernel(PropArgs A) {
     }
   }
   __syncthreads();
+  if (A.mode == 1 && tid == 0) {  // State.cpp:398-411
+    double *rec = A.records;
+    const int last = A.n_data - 1;
+    rec[CR_T] = A.t_given;
+    rec[CR_DT] = A.t_given - cpi[CA_CLONE];
+    rec[CR_CL] = cpi[CA_CLONE];
+    for (int e = 0; e < 9; ++e) rec[CR_R + e] = cpi[CA_R + e];
+    for (int e = 0; e < 3; ++e) {
+      rec[CR_AL + e] = cpi[CA_AL + e];
+      rec[CR_W + e] = A.wm[3 * last + e] - cpi[CA_BW + e];
+      const double rb = RGtoIk[e] * cpi[CA_BE] + RGtoIk[3 + e] * cpi[CA_BE + 1] + RGtoIk[6 + e] * cpi[CA_BE + 2];
+      rec[CR_V + e] = (cpi[CA_V + e] - A.g[e] * cpi[CA_DT]) + rb;
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        rec[CR_Q + 6 * a + b] = cpi[CA_P + 15 * a + b];
+        rec[CR_Q + 6 * a + 3 + b] = cpi[CA_P + 15 * a + 12 + b];
+        rec[CR_Q + 6 * (3 + a) + b] = cpi[CA_P + 15 * (12 + a) + b];
+        rec[CR_Q + 6 * (3 + a) + 3 + b] = cpi[CA_P + 15 * (12 + a) + 12 + b];
+      }
+  }
   if (tid < IMU_N) A.imu[tid] = imu[tid];
   if (A.cpi)
     for (int e = tid; e < CA_N; e += 256) A.cpi[e] = cpi[e];
@@ -581,6 +613,85 @@ int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *nz, int
   if (Phi_out) std::copy(back.begin() + IMU_N + CA_N, back.begin() + IMU_N + CA_N + 225, Phi_out);
   if (Qd_out) std::copy(back.begin() + IMU_N + CA_N + 225, back.begin() + IMU_N + CA_N + 450, Qd_out);
   if (nrec) std::memcpy(records, back.data() + IMU_N + CA_N + 450, nrec * 8);
+  return PLV_OK;
+}
+
+int plv_closest_clone_time(const plv_state_view *st, int exclude_newest, double t_given, double *clone_t, int *found) {
+  if (!st || !clone_t || !found || st->n_clones < 0) return PLV_E_BADARG;
+  *found = 0;
+  double best = INFINITY;
+  const int N = st->n_clones - (exclude_newest ? 1 : 0);
+  for (int i = 0; i < N; ++i) {
+    const double d = std::fabs(t_given - st->clone_time[i]);
+    if (d < best) {
+      best = d;
+      *clone_t = st->clone_time[i];
+      *found = 1;
+    }
+  }
+  return PLV_OK;
+}
+
+int plv_cpi_integrate(plv_ctx *ctx, const plv_imu_noise *nz, double t_given, double clone_t, const double *R_GtoI_clone,
+                      const double *v_clone, const double *bg, const double *ba, int n_imu, const double *t, const double *wm,
+                      const double *am, plv_cpi_record *out, int *ok) {
+  if (!ctx || !nz || !R_GtoI_clone || !v_clone || !bg || !ba || !out || !ok || n_imu < 0) return PLV_E_BADARG;
+  *ok = 0;
+  // State.cpp:378-384: the readings between the two times, reversed when the clone is the later one
+  std::vector<double> st_((size_t)n_imu + 2), sw_(3 * ((size_t)n_imu + 2)), sa_(3 * ((size_t)n_imu + 2));
+  int m = 0, sel_ok = 0;
+  const double lo = clone_t <= t_given ? clone_t : t_given, hi = clone_t <= t_given ? t_given : clone_t;
+  TRY(plv_select_imu_readings(n_imu, t, wm, am, lo, hi, n_imu + 2, st_.data(), sw_.data(), sa_.data(), &m, &sel_ok));
+  if (!sel_ok || m < 2) return PLV_OK;
+  if (!(clone_t <= t_given)) {
+    std::reverse(st_.begin(), st_.begin() + m);
+    for (int i = 0; i < m / 2; ++i)
+      for (int c = 0; c < 3; ++c) {
+        std::swap(sw_[3 * (size_t)i + c], sw_[3 * (size_t)(m - 1 - i) + c]);
+        std::swap(sa_[3 * (size_t)i + c], sa_[3 * (size_t)(m - 1 - i) + c]);
+      }
+  }
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  plv_cpi_accum acc;
+  std::memset(&acc, 0, sizeof(acc));
+  acc.clone_t = clone_t;
+  acc.R_k2tau[0] = acc.R_k2tau[4] = acc.R_k2tau[8] = 1.0;
+  std::copy(bg, bg + 3, acc.b_w_lin);
+  std::copy(ba, ba + 3, acc.b_a_lin);
+  std::copy(v_clone, v_clone + 3, acc.v_clone);
+  const size_t nd = (size_t)m, o_imu = 7 * nd, o_cpi = o_imu + IMU_N, o_phi = o_cpi + CA_N, o_qd = o_phi + 225, o_rec = o_qd + 225,
+               total = o_rec + CR_N;
+  TRY(us->eval.reserve(total * 8));
+  double *d = us->eval.as<double>();
+  std::vector<double> h(o_phi, 0.0);
+  std::copy(st_.begin(), st_.begin() + nd, h.begin());
+  std::copy(sw_.begin(), sw_.begin() + 3 * nd, h.begin() + nd);
+  std::copy(sa_.begin(), sa_.begin() + 3 * nd, h.begin() + 4 * nd);
+  h[o_imu + IQ + 3] = 1.0;  // the IMU image is not used in this mode
+  std::memcpy(h.data() + o_cpi, &acc, sizeof(acc));
+  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), o_phi * 8, hipMemcpyHostToDevice, ctx->stream));
+  PropArgs A{};
+  A.n_data = m;
+  A.t = d, A.wm = d + nd, A.am = d + 4 * nd;
+  A.imu = d + o_imu;
+  A.cpi = d + o_cpi;
+  A.records = d + o_rec;
+  A.Phi = d + o_phi, A.Qd = d + o_qd;
+  A.sw = nz->sigma_w, A.swb = nz->sigma_wb, A.sa = nz->sigma_a, A.sab = nz->sigma_ab;
+  std::copy(nz->gravity, nz->gravity + 3, A.g);
+  A.mode = 1;
+  std::copy(R_GtoI_clone, R_GtoI_clone + 9, A.R0);
+  A.t_given = t_given;
+  {
+    ProfScope ps(ctx->prof, "propagate_kernel", ctx->stream);
+    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, ctx->stream, A);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  PLV_HIP_CHECK(hipMemcpyAsync(out, d + o_rec, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  *ok = 1;
   return PLV_OK;
 }
 

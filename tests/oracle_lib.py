@@ -467,6 +467,8 @@ class PropOracle:
         lib.orc_propagate.restype = C.c_int
         lib.orc_cov_clone.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.orc_cov_clone.restype = None
+        lib.orc_cpi_integrate.argtypes = [N, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp, R]
+        lib.orc_cpi_integrate.restype = C.c_int
 
     def select_imu_readings(self, t, wm, am, time0, time1):
         t, wm, am = (np.ascontiguousarray(x, dtype=np.float64) for x in (t, wm, am))
@@ -492,6 +494,14 @@ class PropOracle:
                                     rec, _dp(Pn), n, n, imu_id, _dp(Phi), _dp(Qd))
         assert rc == 0
         return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else []), Pn
+
+    def cpi_integrate(self, noise, t_given, clone_t, R_clone, v_clone, bg, ba, t, wm, am):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        t, wm, am, Rc, vc, bg, ba = f(t), f(wm), f(am), f(R_clone), f(v_clone), f(bg), f(ba)
+        rec = self.pkg.PlvCpiRecord()
+        ok = self.lib.orc_cpi_integrate(C.byref(noise), t_given, clone_t, _dp(Rc), _dp(vc), _dp(bg), _dp(ba), len(t), _dp(t), _dp(wm),
+                                        _dp(am), C.byref(rec))
+        return bool(ok), rec
 
     def cov_clone(self, P, src_id, size=6):
         n = P.shape[0]

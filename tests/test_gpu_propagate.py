@@ -95,3 +95,37 @@ def test_clone_window_cycle(pkg, oracle):
     with pytest.raises(pkg.PlvError):
         ctx.cov_clone(n0 + 1, 0, 6)   # stale n
     ctx.close()
+
+
+def test_cpi_integrate_parity_and_pose(pkg):
+    """a19's last stage: plv_cpi_integrate against the oracle, then the record through plv_cpi_poses."""
+    po, jo = oracle_lib.load_prop(pkg), oracle_lib.load_jac(pkg)
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    t, wm, am = synth.imu_stream(traj, 50.0, 50.4, rate=400.0)
+    rng = np.random.default_rng(5)
+    wm, am = wm + rng.normal(0, 1e-3, wm.shape), am + rng.normal(0, 1e-2, am.shape)
+    nz = pkg.imu_noise()
+    Rc, pc = traj(50.2)
+    vc = (traj(50.2 + 1e-5)[1] - traj(50.2 - 1e-5)[1]) / 2e-5
+    bg, ba = (0.001, -0.002, 0.0005), (0.01, 0.02, -0.01)
+    recs = []
+    for tq in (50.2 + 0.0437, 50.2 - 0.0612, t[100], 50.2 + 0.0001):
+        ok_o, r_o = po.cpi_integrate(nz, tq, 50.2, Rc, vc, bg, ba, t, wm, am)
+        ok_d, r_d = ctx.cpi_integrate(nz, tq, 50.2, Rc, vc, bg, ba, t, wm, am)
+        assert ok_o and ok_d
+        _rec_eq(r_d, r_o)
+        recs.append(r_d)
+    assert not ctx.cpi_integrate(nz, 49.0, 50.2, Rc, vc, bg, ba, t, wm, am)[0]
+    # the caller's State::cpis: the clone's own record + the new ones; plv_cpi_poses answers the requested times from them
+    rows = sorted([(50.2, 50.2, np.eye(3).ravel(), np.zeros(3), vc)] + [(r.t, r.clone_t, np.array(r.R_I0toIk), np.array(r.alpha), np.array(r.v))
+                                                                          for r in recs])
+    tab = pkg.CpiTable([x[0] for x in rows], [x[1] for x in rows], [x[2] for x in rows], [x[3] for x in rows], [x[4] for x in rows])
+    st = pkg.StateView([50.2], [Rc], [pc], [15], np.eye(3), np.zeros(3), synth.EUROC_K8)
+    tq = np.array([r.t for r in recs])
+    R, p, ok = ctx.cpi_poses(st, tab, tq)
+    Ro, po_, oko = jo.cpi_poses(st, tab, tq)
+    assert ok.all() and oko.all() and np.abs(R - Ro).max() < 1e-13 and np.abs(p - po_).max() < 1e-13
+    for q, tt in enumerate(tq):   # noisy IMU: the pose is the trajectory up to the injected noise over <= 60 ms
+        Rt, pt = traj(tt)
+        assert np.abs(R[q].reshape(3, 3) - Rt).max() < 1e-3 and np.abs(p[q] - pt).max() < 1e-3
+    ctx.close()

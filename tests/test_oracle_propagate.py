@@ -169,3 +169,41 @@ def test_cpi_records_are_the_preintegrated_trajectory(pkg):
     assert np.abs(np.array(acc2.alpha_tau) - np.array(acc.alpha_tau)).max() < 1e-14
     assert np.abs(np.array(recs2[-1].R_I0toIk) - np.array(recs[-1].R_I0toIk)).max() < 1e-14
     assert np.abs(np.array(recs2[0].v) - np.array(recs[0].v)).max() < 1e-14
+
+
+def test_cpi_integrate_oracle_and_clone_choice(pkg):
+    """create_new_cpi_integrate: forward it lands on the records Propagator::propagate makes; backward (clone after the
+    requested time) it still gives the pose of the trajectory through get_interpolated_pose_imu's formula."""
+    po = oracle_lib.load_prop(pkg)
+    t, wm, am = synth.imu_stream(traj, 50.0, 50.4, rate=400.0)
+    nz = pkg.imu_noise()
+    imu = imu_at(pkg, 50.1)
+    Rc, pc = traj(50.1)
+    vc = vel(50.1)
+    # forward, ending on an IMU sample: the same numbers as the propagate chain started at the clone
+    acc = po.reset_cpi(imu, 50.1)
+    i0 = int(np.argmin(np.abs(t - 50.1)))
+    _, st_, sw_, sa_ = po.select_imu_readings(t, wm, am, t[i0], t[i0 + 20])   # (drops the sample before time1, as the reference)
+    assert len(st_) == 20
+    recs = po.propagate(imu_at(pkg, 50.1), nz, st_, sw_, sa_, acc=acc)[2]
+    ok, r = po.cpi_integrate(nz, t[i0 + 20], t[i0], Rc, vc, (0, 0, 0), (0, 0, 0), t, wm, am)
+    assert ok and abs(r.dt - (t[i0 + 20] - t[i0])) < 1e-15
+    assert np.abs(np.array(r.R_I0toIk) - np.array(recs[-1].R_I0toIk)).max() < 1e-14
+    assert np.abs(np.array(r.alpha) - np.array(recs[-1].alpha)).max() < 1e-14
+    assert np.abs(np.array(r.Q) - np.array(recs[-1].Q)).max() <= 1e-12 * np.abs(np.array(r.Q)).max()
+    # between samples, forward and backward: p = p0 + v0 dt - g dt^2 / 2 + R0^T alpha is the trajectory
+    for tq in (50.1 + 0.0437, 50.1 - 0.0612):
+        ok, r = po.cpi_integrate(nz, tq, 50.1, Rc, vc, (0, 0, 0), (0, 0, 0), t, wm, am)
+        assert ok and abs(r.dt - (tq - 50.1)) < 1e-15 and r.clone_t == 50.1
+        Rq, pq = traj(tq)
+        assert np.abs(np.array(r.R_I0toIk).reshape(3, 3) @ Rc - Rq).max() < 1e-6
+        p = pc + vc * r.dt - 0.5 * G * r.dt ** 2 + Rc.T @ np.array(r.alpha)
+        assert np.abs(p - pq).max() < 1e-6
+    # outside the IMU buffer
+    assert not po.cpi_integrate(nz, 49.9, 50.1, Rc, vc, (0, 0, 0), (0, 0, 0), t, wm, am)[0]
+    # the clone choice (intent of closest_clone_time_not_imu)
+    sc = synth.vio_scene(n_clones=6, F=4, M=5)
+    st, _ = synth.scene_views(pkg, sc)
+    ct = sc["t"]
+    assert pkg.closest_clone_time(st, ct[2] + 0.01) == ct[2] and pkg.closest_clone_time(st, ct[2] + 0.03) == ct[3]
+    assert pkg.closest_clone_time(st, ct[5] + 1.0) == ct[5] and pkg.closest_clone_time(st, ct[5] + 1.0, exclude_newest=True) == ct[4]
