@@ -126,15 +126,18 @@ def pmc_traffic(kernel):
     collected in separate runs, profiles/r01/README.md); None when the summary is missing.  The guide's gfx950
     correction (FETCH_SIZE x 2) applies to wide coalesced reads only; byte / 8-byte gathers as in lk_kernel are
     uncalibrated, so the raw counter is reported."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_d_pmc_hbm.csv")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_*_pmc_hbm.csv")))
+    if not found:
         return None, None
+    path = found[-1]  # the most recent round / letter
+    rel = os.path.relpath(path, ROOT)
     with open(path) as fh:
         next(fh)
         for line in fh:
             k, n, f_kb, w_kb = line.strip().split(",")
             if k.split("<")[0].endswith(kernel):
-                return (float(f_kb) + float(w_kb)) * 1024.0, "profiles/r01/bench_d_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE, KB)"
+                return (float(f_kb) + float(w_kb)) * 1024.0, rel + " (FETCH_SIZE + WRITE_SIZE, KB)"
     return None, None
 
 
