@@ -605,6 +605,23 @@ int plv_cpi_integrate(plv_ctx *ctx, const plv_imu_noise *noise, double t_given, 
  * abs(t - clone.first) with t read before its first assignment (uninitialised on the first pass), so its result is not
  * defined; this is the evident intent.  Host logic. */
 int plv_closest_clone_time(const plv_state_view *st, int exclude_newest, double t_given, double *clone_t, int *found);
+/* SystemManager::get_next_clone_time (REF: PL-VIWO/src/core/SystemManager.cpp:172-267) for one camera: the time of the next
+ * clone, snapped to the nearest camera measurement.  dynamic_cloning's choice of clone_freq (:290-310, from the
+ * interpolation-error tables of the configuration) is the caller's: pass the frequency in use.  *ok = 0 where the
+ * reference returns false (no IMU coverage, or no measurement at / before the desired time).  Host logic. */
+typedef struct plv_clone_schedule {
+  int n_clones;                     /* state->clones.size() */
+  double state_time, meas_t;        /* State::time, the time stamp of the IMU message being fed */
+  double newest_clone_time, second_newest_clone_time;
+  int newest_is_imu_pose;           /* clones.at(newest)->id() == imu->id() */
+  int clone_freq;                   /* OptionsEstimator::clone_freq (after dynamic_cloning) */
+  int n_sensor_times;               /* UpdaterCamera::t_hist of the camera, ascending */
+  const double *sensor_times;
+  double sensor_dt;                 /* State::cam_dt */
+  double imu_oldest_t, imu_newest_t;/* Propagator::imu_data front / back */
+  int wheel_enabled;
+} plv_clone_schedule;
+int plv_next_clone_time(const plv_clone_schedule *in, double *clone_time, int *ok);
 /* StateHelper::clone as augment_clone uses it (REF: StateHelper.cpp:175-201,305-355): the resident covariance grows
  * from n to n + size, the new rows / columns copy those at src_id (the IMU pose: size 6). */
 int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size);

@@ -135,6 +135,7 @@ def load_library():
         "plv_cov_clone": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "plv_cpi_integrate": (C.c_int, [vp, C.POINTER(PlvImuNoise), C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp,
                                         C.POINTER(PlvCpiRecord), ip]),
+        "plv_next_clone_time": (C.c_int, [C.POINTER(PlvCloneSchedule), dp, ip]),
         "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
         "plv_traj_header": (C.c_int, [C.c_char_p, C.c_int]),
         "plv_traj_format": (C.c_int, [C.c_char_p, C.c_int, C.c_double, dp, dp, dp]),
@@ -321,6 +322,13 @@ def imu_noise(sigma_w=1.6968e-4, sigma_wb=1.9393e-5, sigma_a=2.0e-3, sigma_ab=3.
     return PlvImuNoise(sigma_w, sigma_wb, sigma_a, sigma_ab, (C.c_double * 3)(*gravity))
 
 
+class PlvCloneSchedule(C.Structure):
+    _fields_ = [("n_clones", C.c_int), ("state_time", C.c_double), ("meas_t", C.c_double), ("newest_clone_time", C.c_double),
+                ("second_newest_clone_time", C.c_double), ("newest_is_imu_pose", C.c_int), ("clone_freq", C.c_int),
+                ("n_sensor_times", C.c_int), ("sensor_times", C.POINTER(C.c_double)), ("sensor_dt", C.c_double),
+                ("imu_oldest_t", C.c_double), ("imu_newest_t", C.c_double), ("wheel_enabled", C.c_int)]
+
+
 class PlvStats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("min", "max", "median", "mean", "rmse", "std", "ninetynine")]
 
@@ -351,6 +359,17 @@ def select_imu_readings(t, wm, am, time0, time1):
                                                 C.byref(n), C.byref(ok))
     assert rc == 0, rc
     return bool(ok.value), ot[:n.value].copy(), ow[:n.value].copy(), oa[:n.value].copy()
+
+
+def next_clone_time(n_clones, state_time, meas_t, newest, second_newest, newest_is_imu, freq, sensor_times, sensor_dt, imu_oldest,
+                    imu_newest, wheel_enabled=False):
+    stt = _c64(sensor_times)
+    s = PlvCloneSchedule(n_clones, state_time, meas_t, newest, second_newest, 1 if newest_is_imu else 0, freq, len(stt),
+                         _dp(stt) if len(stt) else None, sensor_dt, imu_oldest, imu_newest, 1 if wheel_enabled else 0)
+    ct, ok = C.c_double(), C.c_int()
+    rc = load_library().plv_next_clone_time(C.byref(s), C.byref(ct), C.byref(ok))
+    assert rc == 0, rc
+    return (ct.value if ok.value else None)
 
 
 def closest_clone_time(st, t_given, exclude_newest=False):

@@ -616,6 +616,39 @@ int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *nz, int
   return PLV_OK;
 }
 
+int plv_next_clone_time(const plv_clone_schedule *in, double *clone_time, int *ok) {
+  if (!in || !clone_time || !ok || in->clone_freq < 1 || in->n_sensor_times < 0 || (in->n_sensor_times > 0 && !in->sensor_times))
+    return PLV_E_BADARG;
+  *ok = 0;
+  *clone_time = -1;
+  if (in->n_clones == 0) {  // SystemManager.cpp:178-181 create a clone RIGHT NOW
+    *clone_time = in->state_time;
+    *ok = 1;
+    return PLV_OK;
+  }
+  const int freq = in->clone_freq;
+  // :189-197 desired time: one period after the newest real clone, never before the state time
+  double ct = (in->newest_is_imu_pose ? in->second_newest_clone_time : in->newest_clone_time) + 1.0 / freq;
+  ct = ct < in->state_time ? in->meas_t : ct;
+  // :200-222 the nearest sensor measurement, at most 10 % of a period early, not before the state time
+  double min_t_diff = INFINITY, tmp = ct;
+  bool have_meas = false;
+  for (int i = in->n_sensor_times - 1; i >= 0; --i) {  // newest first (rbegin -> rend)
+    const double sensor_t = in->sensor_times[i] + in->sensor_dt;
+    if (in->newest_clone_time < sensor_t) have_meas = true;
+    if (sensor_t < ct - 0.1 / freq) break;
+    if (std::fabs(sensor_t - ct) < min_t_diff && sensor_t >= in->state_time) {
+      min_t_diff = std::fabs(sensor_t - ct);
+      tmp = sensor_t;
+    }
+  }
+  if (in->imu_newest_t < tmp || in->imu_oldest_t > tmp) return PLV_OK;             // :241-246
+  if (std::isinf(min_t_diff) && !have_meas && !in->wheel_enabled) return PLV_OK;  // :248-253
+  *clone_time = tmp;
+  *ok = 1;
+  return PLV_OK;
+}
+
 int plv_closest_clone_time(const plv_state_view *st, int exclude_newest, double t_given, double *clone_t, int *found) {
   if (!st || !clone_t || !found || st->n_clones < 0) return PLV_E_BADARG;
   *found = 0;

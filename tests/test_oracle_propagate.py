@@ -207,3 +207,43 @@ def test_cpi_integrate_oracle_and_clone_choice(pkg):
     ct = sc["t"]
     assert pkg.closest_clone_time(st, ct[2] + 0.01) == ct[2] and pkg.closest_clone_time(st, ct[2] + 0.03) == ct[3]
     assert pkg.closest_clone_time(st, ct[5] + 1.0) == ct[5] and pkg.closest_clone_time(st, ct[5] + 1.0, exclude_newest=True) == ct[4]
+
+
+def test_next_clone_time(pkg):
+    """SystemManager::get_next_clone_time (REF: SystemManager.cpp:172-267) against a direct Python restatement."""
+    def ref(nc, st, mt, new, new2, is_imu, f, times, sdt, io, inew, wheel):
+        if nc == 0:
+            return st
+        ct = (new2 if is_imu else new) + 1.0 / f
+        ct = mt if ct < st else ct
+        mind, tmp, have = np.inf, ct, False
+        for x in reversed(times):
+            s = x + sdt
+            have = have or new < s
+            if s < ct - 0.1 / f:
+                break
+            if abs(s - ct) < mind and s >= st:
+                mind, tmp = abs(s - ct), s
+        if inew < tmp or io > tmp:
+            return None
+        if np.isinf(mind) and not have and not wheel:
+            return None
+        return tmp
+
+    rng = np.random.default_rng(3)
+    cam = 10.0 + 0.05 * np.arange(40) + rng.uniform(-0.004, 0.004, 40)
+    hits = 0
+    for trial in range(300):
+        new = 10.0 + rng.uniform(0, 1.5)
+        args = dict(nc=int(rng.integers(0, 3)), st=new + rng.uniform(0, 0.12), mt=new + rng.uniform(0.0, 0.2), new=new,
+                    new2=new - 0.1, is_imu=bool(rng.integers(0, 2)), f=int(rng.choice([10, 20])), times=cam[cam < new + rng.uniform(0, 0.3)],
+                    sdt=rng.choice([0.0, 0.003]), io=9.0, inew=new + rng.uniform(0.0, 0.4), wheel=bool(rng.integers(0, 2)))
+        got = pkg.next_clone_time(args["nc"], args["st"], args["mt"], args["new"], args["new2"], args["is_imu"], args["f"], args["times"],
+                                  args["sdt"], args["io"], args["inew"], args["wheel"])
+        exp = ref(**args)
+        assert (got is None) == (exp is None) and (got is None or got == exp), (trial, got, exp)
+        hits += got is not None
+    assert 60 < hits < 300
+    # snapping: a camera frame 2 ms after the desired time wins over the desired time itself
+    got = pkg.next_clone_time(3, 10.0, 10.0, 10.0, 9.9, False, 10, [9.9, 10.0, 10.102], 0.0, 9.0, 10.2)
+    assert got == 10.102
