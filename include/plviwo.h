@@ -627,6 +627,42 @@ int plv_next_clone_time(const plv_clone_schedule *in, double *clone_time, int *o
 int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size);
 
 /* ---------------------------------------------------------------------------------------------
+ * Wheel odometry updater, 3D types (REF: PL-VIWO/src/update/wheel/UpdaterWheel.cpp).
+ * Wheel3DAng (the shipped configuration): m1 / m2 = left / right wheel angular velocity.
+ * ------------------------------------------------------------------------------------------- */
+enum { PLV_WHEEL3D_ANG = 0, PLV_WHEEL3D_LIN = 1, PLV_WHEEL3D_CEN = 2 }; /* REF: WheelTypes.h */
+typedef struct plv_wheel_options { /* OptionsWheel */
+  int type;
+  double noise_w, noise_v, noise_p;
+  int do_calib_ext, do_calib_dt, do_calib_int;
+  double chi2_mult;
+} plv_wheel_options;
+typedef struct plv_wheel_state { /* what compute_linear_system_3D reads from the State (UpdaterWheel.cpp:327-424) */
+  double intr[3];                 /* wheel_intrinsic: r_l, r_r, base length                   */
+  double R_ItoO[9], p_IinO[3];    /* wheel_extrinsic                                          */
+  double R0[9], p0[3], R0_fej[9], p0_fej[3]; /* clones.at(time0): Rot(), pos(), first estimates */
+  double R1[9], p1[3], R1_fej[9], p1_fej[3]; /* clones.at(time1)                                */
+  double w0[3], v0[3], w1[3], v1[3];         /* cpis.at(time0 / time1).w / .v (do_calib_dt only) */
+  int pose0_id, pose1_id, ext_id, dt_id, intr_id; /* covariance indices (Type::id()); unused ones -1 */
+} plv_wheel_state;
+
+/* UpdaterWheel::select_wheel_data + interpolate_data (REF: UpdaterWheel.cpp:142-215,784-794) on an ascending buffer
+ * t / m1 / m2 [n].  *ok = 0 where the reference returns false.  Host logic. */
+int plv_select_wheel_data(int n, const double *t, const double *m1, const double *m2, double time0, double time1, int cap,
+                          double *out_t, double *out_m1, double *out_m2, int *n_out, int *ok);
+/* preintegration_3D (+ preintegration_intrinsics_3D) over the selected samples and compute_linear_system_3D (REF: :86-101,
+ * 327-424, 472-500, 648-782) on the device: res (6), H (6 x k, col-major, k = 12 [+6 ext] [+1 dt] [+3 intr]), Cov_3D (6 x 6
+ * row-major), col_to_state (k).  Also returns the preintegrated R_3D (9) / p_3D (3) when asked (nullable). */
+int plv_wheel_linear_system(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel_state *st, int n_data, const double *t,
+                            const double *m1, const double *m2, double *H, double *res, double *Cov, int *col_to_state, int *k,
+                            double *R_3D, double *p_3D);
+/* UpdaterWheel::update from the selected samples on (REF: :72-139): the system above, Chi2Check with the full Cov_3D and
+ * StateHelper::EKFUpdate on the resident covariance.  The 6 x 6 noise is applied by whitening (H <- L^-1 H, res <- L^-1 res
+ * with Cov_3D = L L^T), which is the same update.  *accepted = 0 when the gate fails; PLV_E_NOT_PSD as plv_ekf_update. */
+int plv_wheel_update(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel_state *st, int n_data, const double *t,
+                     const double *m1, const double *m2, uint8_t *accepted, double *dx);
+
+/* ---------------------------------------------------------------------------------------------
  * Trajectory I/O and the ATE evaluator: the accuracy half of the metric.
  * Poses are [n][7] = tx ty tz qx qy qz qw (JPL quaternion), as the reference logs and loads them.
  * ------------------------------------------------------------------------------------------- */

@@ -12,6 +12,8 @@
 //   StateHelper::EKFPropagation                          REF: PL-VIWO/src/state/StateHelper.cpp:20-92
 //   StateHelper::clone / augment_clone                   REF: StateHelper.cpp:175-201,305-355
 //   quaternion helpers                                   REF: open_vins/ov_core/src/utils/quat_ops.h:88-195,482-537
+//   UpdaterWheel (3D types): select_wheel_data, preintegration_3D, preintegration_intrinsics_3D, compute_linear_system_3D
+//                                                        REF: PL-VIWO/src/update/wheel/UpdaterWheel.cpp:72-215,327-424,472-500,648-794
 // CpiV1's bias Jacobians (J_q, J_a, J_b, H_a, H_b) are not restated: nothing in PL-VIWO reads them.
 #include <cmath>
 #include <cstring>
@@ -492,6 +494,275 @@ int orc_cpi_integrate(const plv_imu_noise *nz, double t_given, double clone_t, c
       out->Q[6 * (3 + a) + 3 + b] = c.P_meas[15 * (12 + a) + 12 + b];
     }
   return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------- wheel (3D)
+// UpdaterWheel::select_wheel_data
+int orc_select_wheel_data(int n, const double *t, const double *m1, const double *m2, double time0, double time1, int cap, double *ot,
+                          double *o1, double *o2, int *n_out) {
+  *n_out = 0;
+  if (n < 1) return 0;
+  if (t[n - 1] <= time1 || t[0] > time0) return 0;
+  std::vector<double> vt, v1, v2;
+  auto push = [&](double a, double b, double c) {
+    vt.push_back(a);
+    v1.push_back(b);
+    v2.push_back(c);
+  };
+  auto interp = [&](int a, int b, double ts) {
+    const double lambda = (ts - t[a]) / (t[b] - t[a]);
+    push(ts, (1 - lambda) * m1[a] + lambda * m1[b], (1 - lambda) * m2[a] + lambda * m2[b]);
+  };
+  for (int i = 0; i < n - 1; i++) {
+    if (t[i + 1] > time0 && t[i] < time0) {
+      interp(i, i + 1, time0);
+      continue;
+    }
+    if (t[i] >= time0 && t[i + 1] <= time1) {
+      push(t[i], m1[i], m2[i]);
+      continue;
+    }
+    if (t[i + 1] > time1) {
+      if (t[i] > time1)
+        interp(i - 1, i, time1);
+      else
+        push(t[i], m1[i], m2[i]);
+      if (vt.back() != time1) interp(i, i + 1, time1);
+      break;
+    }
+  }
+  if (vt.size() < 2) return 0;
+  for (size_t i = 0; i + 1 < vt.size(); i++)
+    if (std::fabs(vt[i + 1] - vt[i]) < 1e-12) {
+      vt.erase(vt.begin() + i);
+      v1.erase(v1.begin() + i);
+      v2.erase(v2.begin() + i);
+      i--;
+    }
+  *n_out = (int)vt.size();
+  if ((int)vt.size() > cap) return 0;
+  std::copy(vt.begin(), vt.end(), ot);
+  std::copy(v1.begin(), v1.end(), o1);
+  std::copy(v2.begin(), v2.end(), o2);
+  return 1;
+}
+
+namespace {
+V4 rot_2_quat(const M3 &rot) {  // quat_ops.h:88-120
+  V4 q;
+  const double Tr = rot(0, 0) + rot(1, 1) + rot(2, 2);
+  if ((rot(0, 0) >= Tr) && (rot(0, 0) >= rot(1, 1)) && (rot(0, 0) >= rot(2, 2))) {
+    q.a[0] = std::sqrt((1 + (2 * rot(0, 0)) - Tr) / 4);
+    q.a[1] = (1 / (4 * q.a[0])) * (rot(0, 1) + rot(1, 0));
+    q.a[2] = (1 / (4 * q.a[0])) * (rot(0, 2) + rot(2, 0));
+    q.a[3] = (1 / (4 * q.a[0])) * (rot(1, 2) - rot(2, 1));
+  } else if ((rot(1, 1) >= Tr) && (rot(1, 1) >= rot(0, 0)) && (rot(1, 1) >= rot(2, 2))) {
+    q.a[1] = std::sqrt((1 + (2 * rot(1, 1)) - Tr) / 4);
+    q.a[0] = (1 / (4 * q.a[1])) * (rot(0, 1) + rot(1, 0));
+    q.a[2] = (1 / (4 * q.a[1])) * (rot(1, 2) + rot(2, 1));
+    q.a[3] = (1 / (4 * q.a[1])) * (rot(2, 0) - rot(0, 2));
+  } else if ((rot(2, 2) >= Tr) && (rot(2, 2) >= rot(0, 0)) && (rot(2, 2) >= rot(1, 1))) {
+    q.a[2] = std::sqrt((1 + (2 * rot(2, 2)) - Tr) / 4);
+    q.a[0] = (1 / (4 * q.a[2])) * (rot(0, 2) + rot(2, 0));
+    q.a[1] = (1 / (4 * q.a[2])) * (rot(1, 2) + rot(2, 1));
+    q.a[3] = (1 / (4 * q.a[2])) * (rot(0, 1) - rot(1, 0));
+  } else {
+    q.a[3] = std::sqrt((1 + Tr) / 4);
+    q.a[0] = (1 / (4 * q.a[3])) * (rot(1, 2) - rot(2, 1));
+    q.a[1] = (1 / (4 * q.a[3])) * (rot(2, 0) - rot(0, 2));
+    q.a[2] = (1 / (4 * q.a[3])) * (rot(0, 1) - rot(1, 0));
+  }
+  if (q.a[3] < 0) q = -1.0 * q;
+  const double n = std::sqrt(q.a[0] * q.a[0] + q.a[1] * q.a[1] + q.a[2] * q.a[2] + q.a[3] * q.a[3]);
+  for (double &x : q.a) x /= n;
+  return q;
+}
+M3 exp_so3(const V3 &w) {  // quat_ops.h:231-251
+  const M3 wx = skew(w);
+  const double theta = norm(w);
+  double A, B;
+  if (theta < 1e-7) {
+    A = 1;
+    B = 0.5;
+  } else {
+    A = std::sin(theta) / theta;
+    B = (1 - std::cos(theta)) / (theta * theta);
+  }
+  if (theta == 0) return M3::eye();
+  return (M3::eye() + A * wx) + B * (wx * wx);
+}
+V3 log_so3(const M3 &R) {  // quat_ops.h:273-313
+  const double R11 = R(0, 0), R12 = R(0, 1), R13 = R(0, 2), R21 = R(1, 0), R22 = R(1, 1), R23 = R(1, 2), R31 = R(2, 0), R32 = R(2, 1),
+               R33 = R(2, 2);
+  const double trc = R11 + R22 + R33;
+  if (trc + 1.0 < 1e-10) {
+    if (std::fabs(R33 + 1.0) > 1e-5) return (M_PI / std::sqrt(2.0 + 2.0 * R33)) * V3{{R13, R23, 1.0 + R33}};
+    if (std::fabs(R22 + 1.0) > 1e-5) return (M_PI / std::sqrt(2.0 + 2.0 * R22)) * V3{{R12, 1.0 + R22, R32}};
+    return (M_PI / std::sqrt(2.0 + 2.0 * R11)) * V3{{1.0 + R11, R21, R31}};
+  }
+  double magnitude;
+  const double tr_3 = trc - 3.0;
+  if (tr_3 < -1e-7) {
+    const double theta = std::acos((trc - 1.0) / 2.0);
+    magnitude = theta / (2.0 * std::sin(theta));
+  } else {
+    magnitude = 0.5 - tr_3 / 12.0;
+  }
+  return magnitude * V3{{R32 - R23, R13 - R31, R21 - R12}};
+}
+M3 m3(const double *p) {
+  M3 m;
+  std::memcpy(m.a, p, 72);
+  return m;
+}
+}  // namespace
+
+// UpdaterWheel::update up to the linear system (3D types).  H is 6 x k col-major; returns k.
+int orc_wheel_linear_system(const plv_wheel_options *op, const plv_wheel_state *st, int n_data, const double *t, const double *m1,
+                            const double *m2, double *H, double *res, double *Cov, int *col_to_state, double *R_out, double *p_out) {
+  using M6 = Mat<6, 6>;
+  M3 R_3D = M3::eye(), dR_di = M3::zero(), dp_di = M3::zero();
+  V3 p_3D = V3::zero();
+  M6 Cov_3D = M6::zero();
+  const double rl = st->intr[0], rr = st->intr[1], b = st->intr[2];
+  auto vel = [&](double a1, double a2, V3 &w, V3 &v) {
+    if (op->type == PLV_WHEEL3D_ANG) {
+      w = V3{{0, 0, (a2 * rr - a1 * rl) / b}};
+      v = V3{{(a2 * rr + a1 * rl) / 2, 0, 0}};
+    } else if (op->type == PLV_WHEEL3D_LIN) {
+      w = V3{{0, 0, (a2 - a1) / b}};
+      v = V3{{(a2 + a1) / 2, 0, 0}};
+    } else {
+      w = V3{{0, 0, a1}};
+      v = V3{{a2, 0, 0}};
+    }
+  };
+  for (int i = 0; i < n_data - 1; ++i) {
+    const double dt = t[i + 1] - t[i];
+    if (op->do_calib_int) {  // preintegration_intrinsics_3D :472-500
+      const double w_l = m1[i], w_r = m2[i];
+      const V3 w{{0, 0, (w_r * rr - w_l * rl) / b}}, v{{(w_r * rr + w_l * rl) / 2, 0, 0}};
+      M3 Hwx = M3::zero(), Hvx = M3::zero();
+      Hwx(2, 0) = -w_l / b;
+      Hwx(2, 1) = w_r / b;
+      Hwx(2, 2) = -(w_r * rr - w_l * rl) / (b * b);
+      Hvx(0, 0) = w_l / 2;
+      Hvx(0, 1) = w_r / 2;
+      const M3 R = exp_so3((-dt) * w);
+      const M3 Hth = dt * Jl_so3((-dt) * w);
+      dp_di = (dp_di - (T(R_3D) * skew(dt * v)) * dR_di) + dt * (T(R_3D) * Hvx);
+      dR_di = R * dR_di + Hth * Hwx;
+    }
+    // preintegration_3D :648-782
+    V3 w_hat1, v_hat1, w_hat2, v_hat2;
+    vel(m1[i], m2[i], w_hat1, v_hat1);
+    vel(m1[i + 1], m2[i + 1], w_hat2, v_hat2);
+    V3 w_hat = w_hat1, v_hat = v_hat1;
+    const V3 w_alpha = (1.0 / dt) * (w_hat2 - w_hat1), v_jerk = (1.0 / dt) * (v_hat2 - v_hat1);
+    const V4 q_local = rot_2_quat(R_3D);
+    const V4 dq_0{{0, 0, 0, 1}};
+    auto qdot = [&](const V4 &dq) { return 0.5 * (Omega(w_hat) * dq); };
+    auto pdot = [&](const V4 &dq) { return T(quat_2_Rot(quat_multiply(dq, q_local))) * v_hat; };
+    const V4 k1_q = dt * qdot(dq_0);
+    const V3 k1_p = dt * pdot(dq_0);
+    w_hat = w_hat + (0.5 * dt) * w_alpha;
+    v_hat = v_hat + (0.5 * dt) * v_jerk;
+    const V4 dq_1 = quatnorm(dq_0 + 0.5 * k1_q);
+    const V4 k2_q = dt * qdot(dq_1);
+    const V3 k2_p = dt * pdot(dq_1);
+    const V4 dq_2 = quatnorm(dq_0 + 0.5 * k2_q);
+    const V4 k3_q = dt * qdot(dq_2);
+    const V3 k3_p = dt * pdot(dq_2);
+    w_hat = w_hat + (0.5 * dt) * w_alpha;
+    v_hat = v_hat + (0.5 * dt) * v_jerk;
+    const V4 dq_3 = quatnorm(dq_0 + k3_q);
+    const V4 k4_q = dt * qdot(dq_3);
+    const V3 k4_p = dt * pdot(dq_3);
+    const V4 dq = quatnorm((((dq_0 + (1.0 / 6.0) * k1_q) + (1.0 / 3.0) * k2_q) + (1.0 / 3.0) * k3_q) + (1.0 / 6.0) * k4_q);
+    const M3 R_new = quat_2_Rot(quat_multiply(dq, q_local));
+    const V3 new_p = (((p_3D + (1.0 / 6.0) * k1_p) + (1.0 / 3.0) * k2_p) + (1.0 / 3.0) * k3_p) + (1.0 / 6.0) * k4_p;
+    M6 Q = M6::zero();
+    const double nw = op->noise_w * op->noise_w, nv = op->noise_v * op->noise_v, np = op->noise_p * op->noise_p;
+    if (op->type == PLV_WHEEL3D_ANG) {
+      Q(0, 0) = nw / dt, Q(3, 3) = nw / dt;
+    } else if (op->type == PLV_WHEEL3D_LIN) {
+      Q(0, 0) = nv / b / b / dt, Q(3, 3) = nv / 2 / 2 / dt;
+    } else {
+      Q(0, 0) = nw / dt, Q(3, 3) = nv / dt;
+    }
+    Q(1, 1) = Q(2, 2) = Q(4, 4) = Q(5, 5) = np / dt;
+    M6 Phi_tr = M6::zero(), Phi_ns = M6::zero();
+    put(Phi_tr, 0, 0, R_new * T(R_3D));
+    put(Phi_tr, 3, 0, (-1.0 * T(R_3D)) * skew(T(R_3D) * (new_p - p_3D)));
+    put(Phi_tr, 3, 3, M3::eye());
+    put(Phi_ns, 0, 0, dt * M3::eye());
+    put(Phi_ns, 3, 3, dt * T(R_3D));
+    Cov_3D = (Phi_tr * Cov_3D) * T(Phi_tr) + (Phi_ns * Q) * T(Phi_ns);
+    Cov_3D = 0.5 * (Cov_3D + T(Cov_3D));
+    R_3D = R_new;
+    p_3D = new_p;
+  }
+  // compute_linear_system_3D :327-424
+  V3 pI0 = v3(st->p0), pI1 = v3(st->p1);
+  M3 RG0 = m3(st->R0), RG1 = m3(st->R1);
+  const V3 pIinO = v3(st->p_IinO);
+  const M3 RItoO = m3(st->R_ItoO);
+  const V3 pOinI = (-1.0 * T(RItoO)) * pIinO;
+  M3 RO0toO1 = ((RItoO * RG1) * T(RG0)) * T(RItoO);
+  const V3 r_ori = -1.0 * log_so3(R_3D * T(RO0toO1));
+  const V3 p_est = (RItoO * RG0) * (((pI1 + T(RG1) * pOinI) - pI0) - T(RG0) * pOinI);
+  const V3 r_pos = p_3D - p_est;
+  for (int i = 0; i < 3; ++i) {
+    res[i] = r_ori.a[i];
+    res[3 + i] = r_pos.a[i];
+  }
+  const int k = 12 + (op->do_calib_ext ? 6 : 0) + (op->do_calib_dt ? 1 : 0) + (op->do_calib_int ? 3 : 0);
+  std::vector<double> Hr((size_t)6 * k, 0.0);  // row-major scratch
+  auto putH = [&](int r0, int c0, const M3 &B) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Hr[(size_t)(r0 + r) * k + c0 + c] = B(r, c);
+  };
+  pI0 = v3(st->p0_fej), pI1 = v3(st->p1_fej), RG0 = m3(st->R0_fej), RG1 = m3(st->R1_fej);
+  RO0toO1 = ((RItoO * RG1) * T(RG0)) * T(RItoO);
+  const M3 RO1toO0 = T(RO0toO1);
+  const M3 dzr_dth0 = ((-1.0 * RItoO) * RG1) * T(RG0), dzr_dth1 = RItoO;
+  const M3 dzp_dth0 = RItoO * skew((RG0 * pI1 + (RG0 * T(RG1)) * pOinI) - RG0 * pI0);
+  const M3 dzp_dp0 = (-1.0 * RItoO) * RG0;
+  const M3 dzp_dth1 = (((-1.0 * RItoO) * RG0) * T(RG1)) * skew(pOinI);
+  const M3 dzp_dp1 = RItoO * RG0;
+  putH(0, 0, dzr_dth0), putH(0, 6, dzr_dth1), putH(3, 0, dzp_dth0), putH(3, 3, dzp_dp0), putH(3, 6, dzp_dth1), putH(3, 9, dzp_dp1);
+  int hc = 12, nc = 0;
+  for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->pose0_id + i;
+  for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->pose1_id + i;
+  if (op->do_calib_ext) {
+    putH(0, hc, M3::eye() - RO0toO1);
+    putH(3, hc, skew((RItoO * RG0) * (pI1 - pI0) - RO1toO0 * pIinO) + RO1toO0 * skew(pIinO));
+    putH(3, hc + 3, (-1.0 * RO1toO0) + M3::eye());
+    for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->ext_id + i;
+    hc += 6;
+  }
+  if (op->do_calib_dt) {
+    const V3 w0 = v3(st->w0), v0 = v3(st->v0), w1 = v3(st->w1), v1 = v3(st->v1);
+    const V3 a = dzr_dth0 * w0 + dzr_dth1 * w1;
+    const V3 c = ((dzp_dth0 * w0 + dzp_dp0 * v0) + dzp_dth1 * w1) + dzp_dp1 * v1;
+    for (int r = 0; r < 3; ++r) {
+      Hr[(size_t)r * k + hc] = a.a[r];
+      Hr[(size_t)(3 + r) * k + hc] = c.a[r];
+    }
+    col_to_state[nc++] = st->dt_id;
+    hc += 1;
+  }
+  if (op->do_calib_int) {
+    putH(0, hc, -1.0 * dR_di);
+    putH(3, hc, -1.0 * dp_di);
+    for (int i = 0; i < 3; ++i) col_to_state[nc++] = st->intr_id + i;
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < k; ++c) H[(size_t)c * 6 + r] = Hr[(size_t)r * k + c];
+  std::memcpy(Cov, Cov_3D.a, sizeof(Cov_3D.a));
+  if (R_out) std::memcpy(R_out, R_3D.a, 72);
+  if (p_out) std::memcpy(p_out, p_3D.a, 24);
+  return k;
 }
 
 // StateHelper::clone: append `size` rows / columns copying the block at src_id.  P has room for (n + size) (ld >= n + size).

@@ -135,6 +135,10 @@ def load_library():
         "plv_cov_clone": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "plv_cpi_integrate": (C.c_int, [vp, C.POINTER(PlvImuNoise), C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp,
                                         C.POINTER(PlvCpiRecord), ip]),
+        "plv_select_wheel_data": (C.c_int, [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip, ip]),
+        "plv_wheel_linear_system": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, dp, dp, dp, ip, ip,
+                                              dp, dp]),
+        "plv_wheel_update": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, u8p, dp]),
         "plv_next_clone_time": (C.c_int, [C.POINTER(PlvCloneSchedule), dp, ip]),
         "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
         "plv_traj_header": (C.c_int, [C.c_char_p, C.c_int]),
@@ -322,6 +326,33 @@ def imu_noise(sigma_w=1.6968e-4, sigma_wb=1.9393e-5, sigma_a=2.0e-3, sigma_ab=3.
     return PlvImuNoise(sigma_w, sigma_wb, sigma_a, sigma_ab, (C.c_double * 3)(*gravity))
 
 
+class PlvWheelOptions(C.Structure):
+    _fields_ = [("type", C.c_int), ("noise_w", C.c_double), ("noise_v", C.c_double), ("noise_p", C.c_double), ("do_calib_ext", C.c_int),
+                ("do_calib_dt", C.c_int), ("do_calib_int", C.c_int), ("chi2_mult", C.c_double)]
+
+
+class PlvWheelState(C.Structure):
+    _fields_ = [("intr", C.c_double * 3), ("R_ItoO", C.c_double * 9), ("p_IinO", C.c_double * 3),
+                ("R0", C.c_double * 9), ("p0", C.c_double * 3), ("R0_fej", C.c_double * 9), ("p0_fej", C.c_double * 3),
+                ("R1", C.c_double * 9), ("p1", C.c_double * 3), ("R1_fej", C.c_double * 9), ("p1_fej", C.c_double * 3),
+                ("w0", C.c_double * 3), ("v0", C.c_double * 3), ("w1", C.c_double * 3), ("v1", C.c_double * 3),
+                ("pose0_id", C.c_int), ("pose1_id", C.c_int), ("ext_id", C.c_int), ("dt_id", C.c_int), ("intr_id", C.c_int)]
+
+    @classmethod
+    def make(cls, intr, R_ItoO, p_IinO, R0, p0, R1, p1, pose0_id, pose1_id, R0_fej=None, p0_fej=None, R1_fej=None, p1_fej=None,
+             w0=(0, 0, 0), v0=(0, 0, 0), w1=(0, 0, 0), v1=(0, 0, 0), ext_id=-1, dt_id=-1, intr_id=-1):
+        s = cls()
+        vals = dict(intr=intr, R_ItoO=R_ItoO, p_IinO=p_IinO, R0=R0, p0=p0, R1=R1, p1=p1, R0_fej=R0 if R0_fej is None else R0_fej,
+                    p0_fej=p0 if p0_fej is None else p0_fej, R1_fej=R1 if R1_fej is None else R1_fej,
+                    p1_fej=p1 if p1_fej is None else p1_fej, w0=w0, v0=v0, w1=w1, v1=v1)
+        for name, val in vals.items():
+            arr = getattr(s, name)
+            for i, x in enumerate(np.asarray(val, dtype=np.float64).ravel()):
+                arr[i] = float(x)
+        s.pose0_id, s.pose1_id, s.ext_id, s.dt_id, s.intr_id = pose0_id, pose1_id, ext_id, dt_id, intr_id
+        return s
+
+
 class PlvCloneSchedule(C.Structure):
     _fields_ = [("n_clones", C.c_int), ("state_time", C.c_double), ("meas_t", C.c_double), ("newest_clone_time", C.c_double),
                 ("second_newest_clone_time", C.c_double), ("newest_is_imu_pose", C.c_int), ("clone_freq", C.c_int),
@@ -359,6 +390,18 @@ def select_imu_readings(t, wm, am, time0, time1):
                                                 C.byref(n), C.byref(ok))
     assert rc == 0, rc
     return bool(ok.value), ot[:n.value].copy(), ow[:n.value].copy(), oa[:n.value].copy()
+
+
+def select_wheel_data(t, m1, m2, time0, time1):
+    t, m1, m2 = _c64(t), _c64(m1), _c64(m2)
+    cap = len(t) + 4
+    ot, o1, o2 = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    n, ok = C.c_int(), C.c_int()
+    rc = load_library().plv_select_wheel_data(len(t), _dp(t), _dp(m1), _dp(m2), float(time0), float(time1), cap, _dp(ot), _dp(o1), _dp(o2),
+                                              C.byref(n), C.byref(ok))
+    assert rc == 0, rc
+    m = n.value if ok.value else 0
+    return bool(ok.value), ot[:m].copy(), o1[:m].copy(), o2[:m].copy()
 
 
 def next_clone_time(n_clones, state_time, meas_t, newest, second_newest, newest_is_imu, freq, sensor_times, sensor_dt, imu_oldest,
@@ -752,6 +795,21 @@ class Context:
         self._chk(self.lib.plv_propagate(self.h, C.byref(imu), C.byref(noise), len(t), _dp(t), _dp(wm), _dp(am),
                                          C.byref(acc) if acc is not None else None, rec, n, imu_id, _dp(Phi), _dp(Qd)))
         return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else [])
+
+    def wheel_linear_system(self, opt, st, t, m1, m2):
+        t, m1, m2 = _c64(t), _c64(m1), _c64(m2)
+        H, res, Cov, cols, k = np.zeros((22, 6)), np.zeros(6), np.zeros((6, 6)), np.zeros(22, dtype=np.int32), C.c_int()
+        R, p = np.zeros((3, 3)), np.zeros(3)
+        self._chk(self.lib.plv_wheel_linear_system(self.h, C.byref(opt), C.byref(st), len(t), _dp(t), _dp(m1), _dp(m2), _dp(H), _dp(res),
+                                                   _dp(Cov), _ip(cols), C.byref(k), _dp(R), _dp(p)))
+        return H[:k.value].T.copy(), res, Cov, cols[:k.value].copy(), R, p   # H as rows x k
+
+    def wheel_update(self, opt, st, t, m1, m2, n):
+        t, m1, m2 = _c64(t), _c64(m1), _c64(m2)
+        acc, dx = np.zeros(1, dtype=np.uint8), np.zeros(n)
+        rc = self.lib.plv_wheel_update(self.h, C.byref(opt), C.byref(st), len(t), _dp(t), _dp(m1), _dp(m2), _u8p(acc), _dp(dx))
+        self._chk(rc, allow=(PLV_E_NOT_PSD,))
+        return rc, int(acc[0]), dx
 
     def cpi_integrate(self, noise, t_given, clone_t, R_clone, v_clone, bg, ba, t, wm, am):
         """State::create_new_cpi_integrate: (ok, PlvCpiRecord)."""

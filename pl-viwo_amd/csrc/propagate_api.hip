@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "plv_ctx.hpp"
+#include "so3_dev.hpp"
 #include "update_state.hpp"
 
 namespace plv {
@@ -30,86 +31,7 @@ namespace {
     if (_rc != PLV_OK) return _rc; \
   } while (0)
 
-struct D3 {
-  double x, y, z;
-};
-struct DM3 {
-  double m[9];
-};
-struct DQ {
-  double x, y, z, w;
-};
-__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ D3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
-__device__ __forceinline__ void st3(double *p, D3 a) { p[0] = a.x, p[1] = a.y, p[2] = a.z; }
-__device__ __forceinline__ double nrm3(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-__device__ __forceinline__ DM3 skewm(D3 w) { return {{0, -w.z, w.y, w.z, 0, -w.x, -w.y, w.x, 0}}; }
-__device__ __forceinline__ DM3 eyem() { return {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
-__device__ __forceinline__ DM3 mmul(const DM3 &a, const DM3 &b) {
-  DM3 c;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
-  return c;
-}
-__device__ __forceinline__ DM3 mtr(const DM3 &a) { return {{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}}; }
-__device__ __forceinline__ DM3 madd(const DM3 &a, const DM3 &b) {
-  DM3 c;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] + b.m[i];
-  return c;
-}
-__device__ __forceinline__ DM3 msub(const DM3 &a, const DM3 &b) {
-  DM3 c;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] - b.m[i];
-  return c;
-}
-__device__ __forceinline__ DM3 mscale(double s, const DM3 &a) {
-  DM3 c;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) c.m[i] = s * a.m[i];
-  return c;
-}
-__device__ __forceinline__ D3 mvec(const DM3 &a, D3 v) {
-  return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
-}
-__device__ __forceinline__ DM3 outer(D3 a, D3 b) { return {{a.x * b.x, a.x * b.y, a.x * b.z, a.y * b.x, a.y * b.y, a.y * b.z, a.z * b.x, a.z * b.y, a.z * b.z}}; }
-
-__device__ DM3 q2R(DQ q) {  // quat_ops.h:152-157
-  const D3 v{q.x, q.y, q.z};
-  return madd(msub(mscale(2 * q.w * q.w - 1, eyem()), mscale(2 * q.w, skewm(v))), mscale(2.0, outer(v, v)));
-}
-__device__ DQ qmul(DQ q, DQ p) {  // quat_ops.h:180-195
-  DQ r;
-  r.x = q.w * p.x + q.z * p.y - q.y * p.z + q.x * p.w;
-  r.y = -q.z * p.x + q.w * p.y + q.x * p.z + q.y * p.w;
-  r.z = q.y * p.x - q.x * p.y + q.w * p.z + q.z * p.w;
-  r.w = -q.x * p.x - q.y * p.y - q.z * p.z + q.w * p.w;
-  if (r.w < 0) r = {-r.x, -r.y, -r.z, -r.w};
-  const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
-  return {r.x / n, r.y / n, r.z / n, r.w / n};
-}
-__device__ DQ qnorm(DQ q) {  // quat_ops.h:496-501
-  if (q.w < 0) q = {-q.x, -q.y, -q.z, -q.w};
-  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  return {q.x / n, q.y / n, q.z / n, q.w / n};
-}
-__device__ DQ omega_times(D3 w, DQ q) {  // Omega(w) * q, quat_ops.h:482-489
-  return {-(-w.z * q.y + w.y * q.z) + w.x * q.w, -(w.z * q.x - w.x * q.z) + w.y * q.w, -(-w.y * q.x + w.x * q.y) + w.z * q.w,
-          -w.x * q.x - w.y * q.y - w.z * q.z};
-}
-__device__ DQ qaxpy(DQ a, double s, DQ b) { return {a.x + s * b.x, a.y + s * b.y, a.z + s * b.z, a.w + s * b.w}; }
-__device__ DM3 Jl(D3 w) {  // quat_ops.h:515-525
-  const double th = nrm3(w);
-  if (th < 1e-6) return eyem();
-  const D3 a = (1.0 / th) * w;
-  const double sth = sin(th) / th;
-  return madd(madd(mscale(sth, eyem()), mscale(1 - sth, outer(a, a))), mscale((1 - cos(th)) / th, skewm(a)));
-}
+using namespace so3;
 
 // LDS image of plv_imu_state: q4 p3 v3 bg3 ba3 qf4 pf3 vf3
 enum { IQ = 0, IP = 4, IV = 7, IBG = 10, IBA = 13, IQF = 16, IPF = 20, IVF = 23, IMU_N = 26 };

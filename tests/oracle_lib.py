@@ -469,6 +469,11 @@ class PropOracle:
         lib.orc_cov_clone.restype = None
         lib.orc_cpi_integrate.argtypes = [N, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp, R]
         lib.orc_cpi_integrate.restype = C.c_int
+        lib.orc_select_wheel_data.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip]
+        lib.orc_select_wheel_data.restype = C.c_int
+        lib.orc_wheel_linear_system.argtypes = [C.POINTER(pkg.PlvWheelOptions), C.POINTER(pkg.PlvWheelState), C.c_int, dp, dp, dp, dp, dp, dp,
+                                                ip, dp, dp]
+        lib.orc_wheel_linear_system.restype = C.c_int
 
     def select_imu_readings(self, t, wm, am, time0, time1):
         t, wm, am = (np.ascontiguousarray(x, dtype=np.float64) for x in (t, wm, am))
@@ -494,6 +499,25 @@ class PropOracle:
                                     rec, _dp(Pn), n, n, imu_id, _dp(Phi), _dp(Qd))
         assert rc == 0
         return Phi, Qd, (list(rec)[:len(t) - 1] if rec is not None else []), Pn
+
+    def select_wheel_data(self, t, m1, m2, time0, time1):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        t, m1, m2 = f(t), f(m1), f(m2)
+        cap = len(t) + 4
+        ot, o1, o2 = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        n = C.c_int()
+        ok = self.lib.orc_select_wheel_data(len(t), _dp(t), _dp(m1), _dp(m2), time0, time1, cap, _dp(ot), _dp(o1), _dp(o2), C.byref(n))
+        m = n.value if ok else 0
+        return bool(ok), ot[:m].copy(), o1[:m].copy(), o2[:m].copy()
+
+    def wheel_linear_system(self, opt, st, t, m1, m2):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        t, m1, m2 = f(t), f(m1), f(m2)
+        H, res, Cov, cols = np.zeros((22, 6)), np.zeros(6), np.zeros((6, 6)), np.zeros(22, dtype=np.int32)
+        R, p = np.zeros((3, 3)), np.zeros(3)
+        k = self.lib.orc_wheel_linear_system(C.byref(opt), C.byref(st), len(t), _dp(t), _dp(m1), _dp(m2), _dp(H), _dp(res), _dp(Cov), _ip(cols),
+                                             _dp(R), _dp(p))
+        return H[:k].T.copy(), res, Cov, cols[:k].copy(), R, p
 
     def cpi_integrate(self, noise, t_given, clone_t, R_clone, v_clone, bg, ba, t, wm, am):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
