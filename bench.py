@@ -233,6 +233,9 @@ def main():
         state["accepted"] = int(acc.sum())
 
     def step_pipelined(i):
+        # (enqueueing the front-end between the Jacobians and the rest of the update — plv_perform_matching_launch /
+        # _wait — was measured 5-9 % slower than this order on the same box: the update chain is the long one and
+        # every launch in front of it delays it)
         uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)   # update of frame i: enqueue only
         uctx.cov_rollback()
         uctx.msckf_update_resident_launch(SIGMA2)

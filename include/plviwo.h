@@ -216,6 +216,11 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
  * iteration count of the call. */
 int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0,
                          float *n1, long long *lk_iters);
+/* The same in two halves, as plv_msckf_update_resident_launch / _wait: _launch enqueues the copy-in, LK, undistortion, RANSAC
+ * and the copy-back on the context's stream and returns; _wait blocks for them and hands the results over.  No other call
+ * that returns data may be made on this context in between (they share the pinned staging block). */
+int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const float *pts1_init);
+int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, float *n0, float *n1, long long *lk_iters);
 
 /* plv_perform_detection replaces TrackKLT::perform_detection_monocular (REF: open_vins/ov_core/src/
  * track/TrackKLT.cpp:395-528, Grider_GRID::perform_griding Grider_GRID.h:74-180): drops tracked

@@ -106,6 +106,8 @@ def load_library():
         "plv_undistort": (C.c_int, [vp, C.c_int, fp, fp]),
         "plv_ransac_fundamental": (C.c_int, [vp, C.c_int, fp, fp, C.c_double, C.c_uint32, u8p, ip, ip]),
         "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
+        "plv_perform_matching_launch": (C.c_int, [vp, C.c_int, fp, fp]),
+        "plv_perform_matching_wait": (C.c_int, [vp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
         "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
                                             C.POINTER(C.c_uint64), ip]),
         "plv_tracker_feed": (C.c_int, [vp, C.c_double, u8p, C.c_int, u8p]),
@@ -753,6 +755,20 @@ class Context:
         self._chk(self.lib.plv_ransac_fundamental(self.h, n, _fp(m1), _fp(m2), float(thr), seed, _u8p(mask),
                                                   C.byref(good), C.byref(it)))
         return mask, good.value, it.value
+
+    def perform_matching_launch(self, pts0, pts1_init):
+        pts0 = np.ascontiguousarray(pts0, dtype=np.float32)
+        pts1 = np.ascontiguousarray(pts1_init, dtype=np.float32)
+        self._match_n = pts0.shape[0]
+        self._chk(self.lib.plv_perform_matching_launch(self.h, self._match_n, _fp(pts0), _fp(pts1)))
+
+    def perform_matching_wait(self):
+        n = self._match_n
+        pts1, mask = np.zeros((n, 2), dtype=np.float32), np.zeros(n, dtype=np.uint8)
+        n0, n1 = np.zeros((n, 2), dtype=np.float32), np.zeros((n, 2), dtype=np.float32)
+        it = C.c_longlong()
+        self._chk(self.lib.plv_perform_matching_wait(self.h, _fp(pts1), _u8p(mask), _fp(n0), _fp(n1), C.byref(it)))
+        return pts1, mask, n0, n1, it.value
 
     def perform_matching(self, pts0, pts1_init):
         pts0 = np.ascontiguousarray(pts0, dtype=np.float32)

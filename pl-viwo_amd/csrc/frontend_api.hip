@@ -17,6 +17,8 @@ struct FrontState {
   DevBuf pyr_mem[2];
   int cur = 0;             // index of the current pyramid; last = 1 - cur
   int fed = 0;             // number of images fed so far (last is valid when fed >= 2)
+  int pending_n = -1;      // plv_perform_matching_launch .. _wait
+  bool pending_ran = false;
   DevBuf raw;              // incoming raw image (packed)
   DevBuf slots[8];
   DevBuf hist, clahe_lut;
@@ -332,17 +334,17 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
   return PLV_OK;
 }
 
-int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0, float *n1,
-                         long long *lk_iters) {
-  if (!ctx || n < 0 || (n > 0 && (!pts0 || !pts1 || !mask_out))) return PLV_E_BADARG;
-  if (lk_iters) *lk_iters = 0;
-  if (n == 0) return PLV_OK;
-  if (n < 10) {  // REF: TrackKLT.cpp:848-852
-    memset(mask_out, 0, (size_t)n);
+int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const float *pts1_init) {
+  if (!ctx || n < 0 || (n > 0 && (!pts0 || !pts1_init))) return PLV_E_BADARG;
+  FrontState *s0 = fe(ctx);
+  s0->pending_n = -1;
+  if (n < 10) {  // REF: TrackKLT.cpp:848-852 (nothing to run: the wait returns an all-zero mask)
+    s0->pending_n = n;
+    s0->pending_ran = false;
     return PLV_OK;
   }
   (void)hipSetDevice(ctx->device);
-  FrontState *s = fe(ctx);
+  FrontState *s = s0;
   TRY(need_two(ctx, s, "plv_perform_matching"));
   const int mi = std::max(1, ctx->cfg.ransac_max_iters);
   TRY(reserve_points(s, n, mi));
@@ -356,7 +358,7 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
   char *hp = ctx->h_pin.as<char>();
   char *dp_ = s->io.as<char>();
   memcpy(hp + o_p0, pts0, nn * 8);
-  memcpy(hp + o_p1, pts1, nn * 8);
+  memcpy(hp + o_p1, pts1_init, nn * 8);
   PLV_HIP_CHECK(hipMemcpyAsync(dp_, hp, nn * 16, hipMemcpyHostToDevice, ctx->stream));
   float *d_p0 = (float *)(dp_ + o_p0), *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
   int *d_it = (int *)(dp_ + o_it);
@@ -368,7 +370,32 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
                     d_mk, s->info.as<int>()));
   PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
+  s->pending_n = n;
+  s->pending_ran = true;
+  return PLV_OK;
+}
+
+int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, float *n0, float *n1, long long *lk_iters) {
+  if (!ctx) return PLV_E_BADARG;
+  FrontState *s = fe(ctx);
+  const int n = s->pending_n;
+  if (n < 0) {
+    set_last_error("plv_perform_matching_wait: nothing was launched");
+    return PLV_E_BADARG;
+  }
+  s->pending_n = -1;
+  if (lk_iters) *lk_iters = 0;
+  if (n == 0) return PLV_OK;
+  if (!pts1 || !mask_out) return PLV_E_BADARG;
+  if (!s->pending_ran) {
+    memset(mask_out, 0, (size_t)n);
+    return PLV_OK;
+  }
+  (void)hipSetDevice(ctx->device);
   TRY(sync(ctx));
+  const size_t nn = (size_t)n;
+  const size_t o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36;
+  const char *hp = ctx->h_pin.as<char>();
   memcpy(pts1, hp + o_p1, nn * 8);
   if (n0) memcpy(n0, hp + o_n0, nn * 8);
   if (n1) memcpy(n1, hp + o_n1, nn * 8);
@@ -380,6 +407,15 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
     *lk_iters = t;
   }
   return PLV_OK;
+}
+
+int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *mask_out, float *n0, float *n1,
+                         long long *lk_iters) {
+  if (!ctx || n < 0 || (n > 0 && (!pts0 || !pts1 || !mask_out))) return PLV_E_BADARG;
+  if (lk_iters) *lk_iters = 0;
+  if (n == 0) return PLV_OK;
+  TRY(plv_perform_matching_launch(ctx, n, pts0, pts1));
+  return plv_perform_matching_wait(ctx, pts1, mask_out, n0, n1, lk_iters);
 }
 
 

@@ -218,3 +218,26 @@ def test_front_end_at_config_d(pkg):
     c.line_walk_mode(True)
     got2 = c.detect_lines(0)
     assert np.array_equal(got2, got)
+
+
+def test_perform_matching_launch_wait_equals_sync(pkg):
+    W, H = 752, 480
+    canvas = synth.texture_canvas(W, H, seed=11, blobs=200)
+    f0, f1 = synth.render_frame(canvas, W, H), synth.render_frame(canvas, W, H, tx=3.0, ty=1.0, rot_deg=0.3)
+    pts0 = synth.grid_points(W, H, 200)
+    a, b = pkg.Context(pkg.default_config(W, H)), pkg.Context(pkg.default_config(W, H))
+    for c in (a, b):
+        c.feed_image(f0)
+        c.feed_image(f1)
+    ref = a.perform_matching(pts0, pts0)
+    b.perform_matching_launch(pts0, pts0)
+    got = b.perform_matching_wait()
+    for x, y in zip(ref[:4], got[:4]):
+        assert np.array_equal(x, y)
+    assert ref[4] == got[4]
+    with pytest.raises(pkg.PlvError):
+        b.perform_matching_wait()          # nothing pending
+    b.perform_matching_launch(pts0[:5], pts0[:5])   # fewer than ten points: an all-zero mask, no launch
+    assert not b.perform_matching_wait()[1].any()
+    a.close()
+    b.close()
