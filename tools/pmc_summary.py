@@ -16,22 +16,24 @@ def short(name):
 def main():
     out, specs = sys.argv[1], sys.argv[2:]
     table = defaultdict(dict)
+    counters = []
     for spec in specs:
-        counter, d = spec.split("=")
+        names, d = spec.split("=")   # COUNTER=dir or A+B+C=dir (several counters collected in one pass)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        acc = defaultdict(lambda: [0.0, 0])
-        for f in files:
-            with open(f) as fh:
-                for row in csv.DictReader(fh):
-                    if row.get("Counter_Name") != counter:
-                        continue
-                    k = short(row["Kernel_Name"])
-                    acc[k][0] += float(row["Counter_Value"])
-                    acc[k][1] += 1
-        for k, (s, n) in acc.items():
-            table[k][counter] = s / max(n, 1)
-            table[k]["dispatches"] = n
-    counters = [s.split("=")[0] for s in specs]
+        for counter in names.split("+"):
+            counters.append(counter)
+            acc = defaultdict(lambda: [0.0, 0])
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        k = short(row["Kernel_Name"])
+                        acc[k][0] += float(row["Counter_Value"])
+                        acc[k][1] += 1
+            for k, (s, n) in acc.items():
+                table[k][counter] = s / max(n, 1)
+                table[k]["dispatches"] = n
     with open(out, "w") as fh:
         fh.write("kernel,dispatches," + ",".join(c + "_avg_per_dispatch" for c in counters) + "\n")
         for k in sorted(table):
