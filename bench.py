@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
+    ap.add_argument("--update-graph", type=int, default=0,
+                    help="1: replay the update launch sequence as a hipGraph (plv_update_graph_mode)")
     ap.add_argument("--sequential", action="store_true",
                     help="one context, update of frame i finished before the front-end of frame i+1 starts")
     args = ap.parse_args()
@@ -215,6 +217,8 @@ def main():
     ctx.image_stage(1, frames[1])
     uctx.cov_upload(P)
     uctx.cov_checkpoint()
+    if args.update_graph:
+        uctx.update_graph_mode(1)
     ctx.feed_staged(0)
 
     state = {}

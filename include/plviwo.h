@@ -172,6 +172,11 @@ int plv_msckf_update_resident(plv_ctx *ctx, double sigma2, double chi2_mult, dou
  * between. */
 int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate);
 int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accepted_rows, double *dx);
+/* Optional hipGraph replay of the launch sequence behind plv_msckf_update_resident_launch (nullspace .. EKF commit + the copy
+ * of the result block): on = 1 / 0 switches it, -1 only queries.  The first call with a given shape (batch sizes, state
+ * dimension, gate parameters, buffer addresses) runs eagerly, the second is captured, later ones are one hipGraphLaunch.
+ * Any change of shape or any device (re)allocation retires the graph.  Off by default.  captures / replays (nullable) count. */
+int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
 int plv_cov_checkpoint(plv_ctx *ctx);
 int plv_cov_rollback(plv_ctx *ctx);
 

@@ -106,6 +106,7 @@ def load_library():
         "plv_undistort": (C.c_int, [vp, C.c_int, fp, fp]),
         "plv_ransac_fundamental": (C.c_int, [vp, C.c_int, fp, fp, C.c_double, C.c_uint32, u8p, ip, ip]),
         "plv_perform_matching": (C.c_int, [vp, C.c_int, fp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
+        "plv_update_graph_mode": (C.c_int, [vp, C.c_int, ip, ip]),
         "plv_perform_matching_launch": (C.c_int, [vp, C.c_int, fp, fp]),
         "plv_perform_matching_wait": (C.c_int, [vp, fp, u8p, fp, fp, C.POINTER(C.c_longlong)]),
         "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
@@ -693,6 +694,11 @@ class Context:
                                                 _u8p(acc), C.byref(nrows), _dp(dx))
         self._chk(rc, allow=(PLV_E_NOT_PSD,))
         return rc, dx, acc, nrows.value
+
+    def update_graph_mode(self, on=-1):
+        c, r = C.c_int(), C.c_int()
+        self._chk(self.lib.plv_update_graph_mode(self.h, int(on), C.byref(c), C.byref(r)))
+        return c.value, r.value
 
     def msckf_update_resident_launch(self, sigma2, chi2_mult=1.0, res_norm_gate=3.0):
         self._chk(self.lib.plv_msckf_update_resident_launch(self.h, float(sigma2), float(chi2_mult), float(res_norm_gate)))

@@ -553,6 +553,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int *d_acc_rows;
   TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
 
+  const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
+  TRY(ctx->h_pin.reserve(rb));
+  auto enqueue = [&]() -> int {
   // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
   TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
   Chi2Args a{};
@@ -613,10 +616,68 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
   else
     TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
-  size_t rb = result_rows_off(n, F) + (size_t)F * 4;
-  TRY(ctx->h_pin.reserve(rb));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
+    return PLV_OK;
+  };
+  if (us->graph_mode && !ctx->prof.on) {
+    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, F, fdim, k, ld, n, mp_max,
+                                       sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch()};
+    if (us->gexec && key == us->gkey) {
+      PLV_HIP_CHECK(hipGraphLaunch(us->gexec, ctx->stream));
+      ++us->graph_replays;
+    } else if (us->gseen && key == us->gkey_seen) {
+      if (us->gexec) {
+        (void)hipGraphExecDestroy(us->gexec);
+        us->gexec = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      PLV_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+      const int crc = enqueue();
+      const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+      if (crc != PLV_OK || ce != hipSuccess || !g || plv::alloc_epoch() != key.epoch) {
+        if (g) (void)hipGraphDestroy(g);
+        us->gseen = false;
+        if (crc != PLV_OK) return crc;
+        TRY(enqueue());  // capture refused or a buffer grew under it: run this one eagerly
+      } else {
+        const hipError_t ie = hipGraphInstantiate(&us->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) {
+          us->gexec = nullptr;
+          us->gseen = false;
+          TRY(enqueue());
+        } else {
+          us->gkey = key;
+          ++us->graph_captures;
+          PLV_HIP_CHECK(hipGraphLaunch(us->gexec, ctx->stream));
+        }
+      }
+    } else {
+      TRY(enqueue());
+      us->gkey_seen = key;
+      us->gkey_seen.epoch = plv::alloc_epoch();  // the eager run may have grown buffers
+      us->gseen = true;
+    }
+  } else {
+    TRY(enqueue());
+  }
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
+  return PLV_OK;
+}
+
+int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  if (on >= 0) {
+    us->graph_mode = on != 0;
+    if (!us->graph_mode && us->gexec) {
+      (void)hipGraphExecDestroy(us->gexec);
+      us->gexec = nullptr;
+      us->gseen = false;
+    }
+  }
+  if (captures) *captures = us->graph_captures;
+  if (replays) *replays = us->graph_replays;
   return PLV_OK;
 }
 

@@ -24,11 +24,18 @@ void set_last_error(const char *fmt, ...);
   } while (0)
 
 // A grow-only device buffer.
+// Bumped by every device (re)allocation: a captured graph holds raw device pointers, so any growth anywhere retires it.
+inline unsigned long long &alloc_epoch() {
+  static unsigned long long e = 0;
+  return e;
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
+    ++alloc_epoch();
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;

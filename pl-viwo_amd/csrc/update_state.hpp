@@ -14,6 +14,23 @@ struct plv_ctx_update_state {
   bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy
   std::vector<int> brows_host;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
+  // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a
+  // kernel argument is made of; first sight of a key runs eagerly (sizes every buffer), the second captures, later ones replay
+  struct GraphKey {
+    const void *P, *Hf, *rows, *cols, *result, *hpin;
+    int F, fdim, k, ld, n, mp_max;
+    double s2, cm, rg;
+    unsigned long long epoch;
+    bool operator==(const GraphKey &o) const {
+      return P == o.P && Hf == o.Hf && rows == o.rows && cols == o.cols && result == o.result && hpin == o.hpin && F == o.F &&
+             fdim == o.fdim && k == o.k && ld == o.ld && n == o.n && mp_max == o.mp_max && s2 == o.s2 && cm == o.cm && rg == o.rg &&
+             epoch == o.epoch;
+    }
+  };
+  bool graph_mode = false, gseen = false;
+  GraphKey gkey_seen{}, gkey{};
+  hipGraphExec_t gexec = nullptr;
+  int graph_replays = 0, graph_captures = 0;
   // jacobian inputs
   plv::DevBuf jin, tri, eval;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync

@@ -168,3 +168,38 @@ def test_msckf_update_resident_repeatable(ctx, oracle):
         assert rc == 0 and np.array_equal(acc, acc0)
         assert _rel(dx, dx0) < 1e-8
     assert _rel(ctx.cov_download(n), P0) < 1e-8
+
+
+def test_update_graph_replay_matches_eager(pkg, oracle):
+    """plv_update_graph_mode: eager, captured and replayed launches give the same bits; a new shape retires the graph."""
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    n, k = 113, 98
+    P = synth.spd_cov(n)
+    cols = synth.col_map(n, k)
+    rows, Hf, Hx, res = synth.msckf_batch(F=40, M=15, k=k, seed=5)
+    ref = None
+    ctx.update_graph_mode(1)
+    for it in range(5):
+        ctx.cov_upload(P)
+        ctx.feat_batch_upload(rows, Hf, Hx, res, cols)
+        rc, dx, acc, nr = ctx.msckf_update_resident(n, 2.25)
+        out = (rc, dx.copy(), acc.copy(), nr, ctx.cov_download(n))
+        if ref is None:
+            ref = out
+            rc_o, P_o, dx_o, acc_o, _ = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, synth.q95_table())
+            assert rc == rc_o == 0 and np.array_equal(acc, acc_o) and np.abs(out[4] - P_o).max() < 1e-8 * np.abs(P_o).max()
+        else:
+            assert out[0] == ref[0] and np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]) and np.array_equal(out[4], ref[4])
+    cap, rep = ctx.update_graph_mode()
+    assert cap == 1 and rep == 3          # eager, capture (+ its launch), three replays
+    rows2, Hf2, Hx2, res2 = synth.msckf_batch(F=25, M=15, k=k, seed=6)   # another shape: eager again, then a new capture
+    for it in range(3):
+        ctx.cov_upload(P)
+        ctx.feat_batch_upload(rows2, Hf2, Hx2, res2, cols)
+        rc, dx, acc, nr = ctx.msckf_update_resident(n, 2.25)
+        rc_o, P_o, dx_o, acc_o, _ = oracle.msckf_update(P, rows2, Hf2, Hx2, res2, cols, 2.25, synth.q95_table())
+        assert rc == rc_o and np.array_equal(acc, acc_o) and np.abs(ctx.cov_download(n) - P_o).max() < 1e-8 * np.abs(P_o).max()
+    cap2, rep2 = ctx.update_graph_mode()
+    assert cap2 == 2 and rep2 == 4
+    ctx.update_graph_mode(0)
+    ctx.close()
