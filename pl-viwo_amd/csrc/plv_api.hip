@@ -212,6 +212,8 @@ void plv_ctx_destroy(plv_ctx *ctx) {
     us->jin.release();
     us->tri.release();
     us->eval.release();
+    if (us->gexec) (void)hipGraphExecDestroy(us->gexec);
+    us->gexec = nullptr;
     us->h_jin.release();
     delete us;
   }
@@ -621,7 +623,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   };
   if (us->graph_mode && !ctx->prof.on) {
     plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, F, fdim, k, ld, n, mp_max,
-                                       sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch()};
+                                       sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch().load()};
     if (us->gexec && key == us->gkey) {
       PLV_HIP_CHECK(hipGraphLaunch(us->gexec, ctx->stream));
       ++us->graph_replays;
@@ -634,7 +636,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       PLV_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
       const int crc = enqueue();
       const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
-      if (crc != PLV_OK || ce != hipSuccess || !g || plv::alloc_epoch() != key.epoch) {
+      if (crc != PLV_OK || ce != hipSuccess || !g || plv::alloc_epoch().load() != key.epoch) {
         if (g) (void)hipGraphDestroy(g);
         us->gseen = false;
         if (crc != PLV_OK) return crc;
@@ -655,7 +657,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     } else {
       TRY(enqueue());
       us->gkey_seen = key;
-      us->gkey_seen.epoch = plv::alloc_epoch();  // the eager run may have grown buffers
+      us->gkey_seen.epoch = plv::alloc_epoch().load();  // the eager run may have grown buffers
       us->gseen = true;
     }
   } else {

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -25,8 +26,8 @@ void set_last_error(const char *fmt, ...);
 
 // A grow-only device buffer.
 // Bumped by every device (re)allocation: a captured graph holds raw device pointers, so any growth anywhere retires it.
-inline unsigned long long &alloc_epoch() {
-  static unsigned long long e = 0;
+inline std::atomic<unsigned long long> &alloc_epoch() {  // contexts may live on different threads
+  static std::atomic<unsigned long long> e{0};
   return e;
 }
 
