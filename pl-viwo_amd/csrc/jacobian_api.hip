@@ -79,11 +79,12 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   const size_t o_time = take(8 * N), o_R = take(72 * N), o_p = take(24 * N), o_Rf = take(72 * N), o_pf = take(24 * N),
                o_ccol = take(4 * N), o_ptr = take(4 * (F + 1)), o_of = take(4 * nobs), o_ot = take(8 * nobs),
                o_uv = take(8 * nobs), o_pg = take(24 * F), o_pgf = take(24 * F),
-               o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0;
+               o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0, o_cols = take(4 * (size_t)k);
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
   char *h = us->h_jin.as<char>();
+  memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
   memcpy(h + o_p, st->clone_p, 24 * N);
@@ -139,6 +140,8 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   P.res_p = tr->res_R ? (const double *)(d + o_rp) : nullptr;
   P.k = k;
   P.ld = ld;
+  P.cols_in = (const int *)(d + o_cols);
+  P.cols_out = nullptr;
   return PLV_OK;
 }
 
@@ -154,7 +157,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{};
   TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
-  PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  P.cols_out = us->bcols.as<int>();
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;

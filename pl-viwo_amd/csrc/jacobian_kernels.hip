@@ -345,6 +345,8 @@ __global__ void __launch_bounds__(128) jacobian_kernel(JacParams P) {
   for (int i = threadIdx.x; i < 3 * ld; i += blockDim.x) hf[i] = 0.0;
   for (int i = threadIdx.x; i < k * ld; i += blockDim.x) hx[i] = 0.0;
   for (int i = threadIdx.x; i < ld; i += blockDim.x) rs[i] = 0.0;
+  if (f == 0 && P.cols_out)
+    for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
   build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill before the row writes)
   if (threadIdx.x >= 64) return;  // observation lanes = wave 0
   const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];

@@ -28,6 +28,9 @@ struct JacParams {
   int k, ld;
   int *rows;
   double *Hf, *Hx, *res;
+  // col_to_state rides in the packed input block; workgroup 0 copies it to its resident home (no separate H2D on the chain)
+  const int *cols_in;
+  int *cols_out;
 };
 
 struct CpiParams {  // device pointers; State::cpis as a table sorted by time + the clone window
