@@ -129,8 +129,14 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 
 // REF: StateHelper.cpp:143-156 — the update is rejected (nothing modified) when ekf_dc_kernel found a negative
 // diagonal or the factorisation was not positive definite; else P.upper -= dC, mirrored.
+// The last kernel of the update also mirrors the small result block (dx, flag, accepted, rows) into the caller's pinned host
+// buffer, so that no copy command sits between the end of the chain and the host's wait.
 __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
-                                                         const double *__restrict__ dC, int ldc, const int *__restrict__ flag) {
+                                                         const double *__restrict__ dC, int ldc, const int *__restrict__ flag,
+                                                         const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
+                                                         int mirror_words) {
+  if (blockIdx.x == 0 && mirror_dst)
+    for (int i = threadIdx.x; i < mirror_words; i += blockDim.x) mirror_dst[i] = mirror_src[i];
   if (*flag != 0) return;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
     int j = idx / n, i = idx - j * n;
@@ -172,7 +178,8 @@ bool ekf_fast_fits(int r) { return r <= 128; }
 
 // EKF update with the identity-border Cholesky.  Requires ekf_fast_fits(r).
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
-                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered) {
+                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered, const void *mirror_src,
+                    void *mirror_dst, size_t mirror_bytes) {
   int rc;
   const int ldm = r, ldw = r;
   if ((rc = ctx->d_Mt.reserve((size_t)r * (n + 1 + k) * 8)) || (rc = ctx->d_S.reserve((size_t)r * r * 8 * 2)) ||
@@ -190,7 +197,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
-                       d_flag);
+                       d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4));
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

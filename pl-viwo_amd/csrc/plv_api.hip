@@ -614,10 +614,12 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     r = Mtot;
     ldh = Mtot;
   }
-  if (ekf_fast_fits(r))
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
-  else
-    TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
+  if (ekf_fast_fits(r)) {  // (its last kernel mirrors the result block into h_pin: no copy command after the chain)
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true,
+                        us->result.p, ctx->h_pin.p, (rb + 3) & ~(size_t)3));
+    return PLV_OK;
+  }
+  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
   TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
     return PLV_OK;
   };

@@ -47,7 +47,8 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
                          double *d_R, int ldr, double *d_z);
 bool ekf_fast_fits(int r);
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
-                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false);
+                    const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false, const void *mirror_src = nullptr,
+                    void *mirror_dst = nullptr, size_t mirror_bytes = 0);
 
 // blocked_chol.hip
 int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z);
