@@ -123,7 +123,7 @@ def test_compress_fat_is_identity(ctx):
 
 
 @pytest.mark.parametrize("F,M,n,k,fdim,gate", [(70, 15, 113, 98, 3, 3.0), (250, 15, 113, 98, 3, 3.0),
-                                               (80, 15, 105, 90, 6, 0.0), (70, 20, 143, 128, 3, 3.0),
+                                               (80, 15, 105, 90, 6, 0.0), (70, 20, 143, 128, 3, 3.0), (500, 20, 143, 128, 3, 3.0),
                                                (3, 4, 40, 26, 3, 3.0), (40, 8, 60, 45, 3, 3.0),
                                                (20, 6, 40, 26, 3, 3.0)])
 def test_msckf_update_parity(ctx, oracle, F, M, n, k, fdim, gate):
