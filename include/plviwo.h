@@ -637,10 +637,12 @@ int plv_next_clone_time(const plv_clone_schedule *in, double *clone_time, int *o
 int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size);
 
 /* ---------------------------------------------------------------------------------------------
- * Wheel odometry updater, 3D types (REF: PL-VIWO/src/update/wheel/UpdaterWheel.cpp).
- * Wheel3DAng (the shipped configuration): m1 / m2 = left / right wheel angular velocity.
+ * Wheel odometry updater (REF: PL-VIWO/src/update/wheel/UpdaterWheel.cpp).
+ * Wheel3DAng (the shipped configuration): m1 / m2 = left / right wheel angular velocity.  The 3D types measure the
+ * relative rotation and translation of the odometry frame (6 rows), the 2D types yaw and planar translation (3 rows).
  * ------------------------------------------------------------------------------------------- */
-enum { PLV_WHEEL3D_ANG = 0, PLV_WHEEL3D_LIN = 1, PLV_WHEEL3D_CEN = 2 }; /* REF: WheelTypes.h */
+enum { PLV_WHEEL3D_ANG = 0, PLV_WHEEL3D_LIN = 1, PLV_WHEEL3D_CEN = 2, PLV_WHEEL2D_ANG = 3, PLV_WHEEL2D_LIN = 4,
+       PLV_WHEEL2D_CEN = 5 }; /* REF: WheelTypes.h */
 typedef struct plv_wheel_options { /* OptionsWheel */
   int type;
   double noise_w, noise_v, noise_p;
@@ -660,14 +662,16 @@ typedef struct plv_wheel_state { /* what compute_linear_system_3D reads from the
  * t / m1 / m2 [n].  *ok = 0 where the reference returns false.  Host logic. */
 int plv_select_wheel_data(int n, const double *t, const double *m1, const double *m2, double time0, double time1, int cap,
                           double *out_t, double *out_m1, double *out_m2, int *n_out, int *ok);
-/* preintegration_3D (+ preintegration_intrinsics_3D) over the selected samples and compute_linear_system_3D (REF: :86-101,
- * 327-424, 472-500, 648-782) on the device: res (6), H (6 x k, col-major, k = 12 [+6 ext] [+1 dt] [+3 intr]), Cov_3D (6 x 6
- * row-major), col_to_state (k).  Also returns the preintegrated R_3D (9) / p_3D (3) when asked (nullable). */
+/* preintegration_3D / _2D (+ preintegration_intrinsics_*) over the selected samples and compute_linear_system_3D / _2D (REF:
+ * :86-101, 217-325, 327-424, 426-500, 502-646, 648-782) on the device: rows = 6 (3D) or 3 (2D); res (rows), H (rows x k,
+ * col-major, k = 12 [+6 ext] [+1 dt] [+3 intr]), Cov (rows x rows row-major), col_to_state (k).  Capacities: H 6 x 22, res 6,
+ * Cov 36.  Also returns the preintegrated measurement when asked (nullable): R_3D (9) / p_3D (3); for the 2D types
+ * p_3D = (theta, x, y) and R_3D is the identity. */
 int plv_wheel_linear_system(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel_state *st, int n_data, const double *t,
                             const double *m1, const double *m2, double *H, double *res, double *Cov, int *col_to_state, int *k,
-                            double *R_3D, double *p_3D);
+                            int *rows, double *R_3D, double *p_3D);
 /* UpdaterWheel::update from the selected samples on (REF: :72-139): the system above, Chi2Check with the full Cov_3D and
- * StateHelper::EKFUpdate on the resident covariance.  The 6 x 6 noise is applied by whitening (H <- L^-1 H, res <- L^-1 res
+ * StateHelper::EKFUpdate on the resident covariance.  The full (6 x 6 or 3 x 3) noise is applied by whitening (H <- L^-1 H, res <- L^-1 res
  * with Cov_3D = L L^T), which is the same update.  *accepted = 0 when the gate fails; PLV_E_NOT_PSD as plv_ekf_update. */
 int plv_wheel_update(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel_state *st, int n_data, const double *t,
                      const double *m1, const double *m2, uint8_t *accepted, double *dx);

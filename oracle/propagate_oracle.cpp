@@ -618,8 +618,21 @@ M3 m3(const double *p) {
 }  // namespace
 
 // UpdaterWheel::update up to the linear system (3D types).  H is 6 x k col-major; returns k.
+int orc_wheel_linear_system_2d(const plv_wheel_options *op, const plv_wheel_state *st, int n_data, const double *t, const double *m1,
+                               const double *m2, double *H, double *res, double *Cov, int *col_to_state, double *meas);
+
 int orc_wheel_linear_system(const plv_wheel_options *op, const plv_wheel_state *st, int n_data, const double *t, const double *m1,
                             const double *m2, double *H, double *res, double *Cov, int *col_to_state, double *R_out, double *p_out) {
+  if (op->type >= PLV_WHEEL2D_ANG) {
+    if (R_out) {
+      const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      std::memcpy(R_out, I, 72);
+    }
+    double meas[3];
+    const int k2 = orc_wheel_linear_system_2d(op, st, n_data, t, m1, m2, H, res, Cov, col_to_state, meas);
+    if (p_out) std::memcpy(p_out, meas, 24);
+    return k2;
+  }
   using M6 = Mat<6, 6>;
   M3 R_3D = M3::eye(), dR_di = M3::zero(), dp_di = M3::zero();
   V3 p_3D = V3::zero();
@@ -762,6 +775,182 @@ int orc_wheel_linear_system(const plv_wheel_options *op, const plv_wheel_state *
   std::memcpy(Cov, Cov_3D.a, sizeof(Cov_3D.a));
   if (R_out) std::memcpy(R_out, R_3D.a, 72);
   if (p_out) std::memcpy(p_out, p_3D.a, 24);
+  return k;
+}
+
+// The 2D types: preintegration_2D (:502-646), preintegration_intrinsics_2D (:426-470), compute_linear_system_2D (:217-325).
+// H is 3 x k col-major.
+int orc_wheel_linear_system_2d(const plv_wheel_options *op, const plv_wheel_state *st, int n_data, const double *t, const double *m1,
+                               const double *m2, double *H, double *res, double *Cov, int *col_to_state, double *meas) {
+  double th_2D = 0, x_2D = 0, y_2D = 0;
+  M3 C2 = M3::zero();
+  Mat<1, 3> dth_di = Mat<1, 3>::zero(), dx_di = Mat<1, 3>::zero(), dy_di = Mat<1, 3>::zero();
+  const double rl = st->intr[0], rr = st->intr[1], b = st->intr[2];
+  for (int i = 0; i < n_data - 1; ++i) {
+    const double dt = t[i + 1] - t[i];
+    if (op->do_calib_int) {
+      const double w_l = m1[i], w_r = m2[i];
+      const double w = (w_r * rr - w_l * rl) / b, v = (w_r * rr + w_l * rl) / 2;
+      const Mat<1, 3> Hwx{{-w_l / b, w_r / b, -(w_r * rr - w_l * rl) / (b * b)}}, Hvx{{w_l / 2, w_r / 2, 0}};
+      double h_thw = dt;
+      double h_xth = (v * (std::cos(th_2D - w * dt) - std::cos(th_2D))) / w;
+      double h_yth = -(v * (std::sin(th_2D - w * dt) - std::sin(th_2D))) / w;
+      double h_xw = (v * (std::sin(th_2D - w * dt) - std::sin(th_2D))) / w / w + (v * std::cos(th_2D - w * dt) * dt) / w;
+      double h_yw = (v * (std::cos(th_2D - w * dt) - std::cos(th_2D))) / w / w - (v * std::sin(th_2D - w * dt) * dt) / w;
+      double h_xv = -(std::sin(th_2D - w * dt) - std::sin(th_2D)) / w;
+      double h_yv = -(std::cos(th_2D - w * dt) - std::cos(th_2D)) / w;
+      if (std::fabs(w) < 0.0001) {
+        h_xth = v * std::sin(th_2D) * dt;
+        h_yth = v * std::cos(th_2D) * dt;
+        h_xw = v * std::sin(th_2D) * dt * dt / 2;
+        h_yw = v * std::cos(th_2D) * dt * dt / 2;
+        h_xv = std::cos(th_2D) * dt;
+        h_yv = -std::sin(th_2D) * dt;
+      }
+      dx_di = ((dx_di + h_xth * dth_di) + h_xw * Hwx) + h_xv * Hvx;
+      dy_di = ((dy_di + h_yth * dth_di) + h_yw * Hwx) + h_yv * Hvx;
+      dth_di = dth_di + h_thw * Hwx;
+    }
+    double w1, w2, v1, v2;
+    if (op->type == PLV_WHEEL2D_ANG) {
+      w1 = (m2[i] * rr - m1[i] * rl) / b, v1 = (m2[i] * rr + m1[i] * rl) / 2;
+      w2 = (m2[i + 1] * rr - m1[i + 1] * rl) / b, v2 = (m2[i + 1] * rr + m1[i + 1] * rl) / 2;
+    } else if (op->type == PLV_WHEEL2D_LIN) {
+      w1 = (m2[i] - m1[i]) / b, v1 = (m2[i] + m1[i]) / 2;
+      w2 = (m2[i + 1] - m1[i + 1]) / b, v2 = (m2[i + 1] + m1[i + 1]) / 2;
+    } else {
+      w1 = m1[i], v1 = m2[i], w2 = m1[i + 1], v2 = m2[i + 1];
+    }
+    const double w_alpha = (w2 - w1) / dt, v_jerk = (v2 - v1) / dt;
+    double w = w1, v = v1;
+    const double k1_th = -w * dt, k1_x = v * 1 * dt;
+    const double th2 = 0.5 * k1_th;
+    w += 0.5 * w_alpha * dt;
+    v += 0.5 * v_jerk * dt;
+    const double k2_th = -w * dt, k2_x = v * std::cos(th2) * dt;
+    const double th3 = 0.5 * k2_th;
+    const double k3_th = -w * dt, k3_x = v * std::cos(th3) * dt;
+    const double th4 = k3_th;
+    w += 0.5 * w_alpha * dt;
+    v += 0.5 * v_jerk * dt;
+    const double k4_th = -w * dt, k4_x = v * std::cos(th4) * dt;
+    const double th_next = th_2D + (1.0 / 6.0) * (k1_th + 2 * k2_th + 2 * k3_th + k4_th);
+    const double x_next = x_2D + (1.0 / 6.0) * (k1_x + 2 * k2_x + 2 * k3_x + k4_x);
+    double y_next;  // the RK4 value is overwritten by the closed form (:568-571)
+    if (std::fabs(w1) < 0.0001)
+      y_next = y_2D - v1 * std::sin(th_2D - w1 * dt) * dt;
+    else
+      y_next = y_2D - (v1 * (std::cos(th_2D - w1 * dt) - std::cos(th_2D))) / w1;
+    Mat<1, 2> Hwn, Hvn;
+    if (op->type == PLV_WHEEL2D_ANG) {
+      Hwn = Mat<1, 2>{{rl / b, -rr / b}};
+      Hvn = Mat<1, 2>{{-rl / 2, -rr / 2}};
+    } else if (op->type == PLV_WHEEL2D_LIN) {
+      Hwn = Mat<1, 2>{{1.0 / b, -1.0 / b}};
+      Hvn = Mat<1, 2>{{-1.0 / 2, -1.0 / 2}};
+    } else {
+      Hwn = Mat<1, 2>{{1, 0}};
+      Hvn = Mat<1, 2>{{0, 1}};
+    }
+    double h_thw = dt;
+    double h_xth = (v1 * (std::cos(th_2D - w1 * dt) - std::cos(th_2D))) / w1;
+    double h_yth = -(v1 * (std::sin(th_2D - w1 * dt) - std::sin(th_2D))) / w1;
+    double h_xw = (v1 * (std::sin(th_2D - w1 * dt) - std::sin(th_2D))) / w1 / w1 + (v1 * std::cos(th_2D - w1 * dt) * dt) / w1;
+    double h_yw = (v1 * (std::cos(th_2D - w1 * dt) - std::cos(th_2D))) / w1 / w1 - (v1 * std::sin(th_2D - w1 * dt) * dt) / w1;
+    double h_xv = -(std::sin(th_2D - w1 * dt) - std::sin(th_2D)) / w1;
+    double h_yv = -(std::cos(th_2D - w1 * dt) - std::cos(th_2D)) / w1;
+    if (std::fabs(w1) < 0.0001) {
+      h_xth = v1 * std::sin(th_2D) * dt;
+      h_yth = v1 * std::cos(th_2D) * dt;
+      h_xw = v1 * std::sin(th_2D) * dt * dt / 2;
+      h_yw = v1 * std::cos(th_2D) * dt * dt / 2;
+      h_xv = std::cos(th_2D) * dt;
+      h_yv = -std::sin(th_2D) * dt;
+    }
+    M3 Phi_tr = M3::eye();
+    Phi_tr(1, 0) = h_xth;
+    Phi_tr(2, 0) = h_yth;
+    Mat<3, 2> Phi_ns = Mat<3, 2>::zero();
+    const Mat<1, 2> r0 = h_thw * Hwn, r1 = h_xw * Hwn + h_xv * Hvn, r2 = h_yw * Hwn + h_yv * Hvn;
+    for (int c = 0; c < 2; ++c) Phi_ns(0, c) = r0.a[c], Phi_ns(1, c) = r1.a[c], Phi_ns(2, c) = r2.a[c];
+    Mat<2, 2> Q = Mat<2, 2>::zero();
+    if (op->type == PLV_WHEEL2D_ANG)
+      Q(0, 0) = Q(1, 1) = op->noise_w * op->noise_w / dt;
+    else if (op->type == PLV_WHEEL2D_LIN)
+      Q(0, 0) = Q(1, 1) = op->noise_v * op->noise_v / dt;
+    else
+      Q(0, 0) = op->noise_w * op->noise_w / dt, Q(1, 1) = op->noise_v * op->noise_v / dt;
+    C2 = (Phi_tr * C2) * T(Phi_tr) + (Phi_ns * Q) * T(Phi_ns);
+    C2 = 0.5 * (C2 + T(C2));
+    th_2D = th_next, x_2D = x_next, y_2D = y_next;
+  }
+  // compute_linear_system_2D
+  V3 pI0 = v3(st->p0), pI1 = v3(st->p1);
+  M3 RG0 = m3(st->R0), RG1 = m3(st->R1);
+  const V3 pIinO = v3(st->p_IinO);
+  const M3 RItoO = m3(st->R_ItoO);
+  const V3 pOinI = (-1.0 * T(RItoO)) * pIinO;
+  const double theta_est = log_so3(((RItoO * RG1) * T(RG0)) * T(RItoO)).a[2];
+  res[0] = theta_est - th_2D;
+  const V3 d_est3 = (RItoO * RG0) * (((pI1 + T(RG1) * pOinI) - pI0) - T(RG0) * pOinI);
+  res[1] = x_2D - d_est3.a[0];
+  res[2] = y_2D - d_est3.a[1];
+  const int k = 12 + (op->do_calib_ext ? 6 : 0) + (op->do_calib_dt ? 1 : 0) + (op->do_calib_int ? 3 : 0);
+  std::vector<double> Hr((size_t)3 * k, 0.0);
+  pI0 = v3(st->p0_fej), pI1 = v3(st->p1_fej), RG0 = m3(st->R0_fej), RG1 = m3(st->R1_fej);
+  const M3 RO0toO1 = ((RItoO * RG1) * T(RG0)) * T(RItoO), RO1toO0 = T(RO0toO1);
+  const M3 A0 = ((-1.0 * RItoO) * RG1) * T(RG0);   // row 2 = -e3^T RItoO RG1 RG0^T
+  const M3 Pth0 = RItoO * skew(RG0 * ((pI1 + T(RG1) * pOinI) - pI0));
+  const M3 Pp0 = (-1.0 * RItoO) * RG0;
+  const M3 Pth1 = (((-1.0 * RItoO) * RG0) * T(RG1)) * skew(pOinI);
+  const M3 Pp1 = RItoO * RG0;
+  auto row_of = [&](int r, int c0, const M3 &B, int br) {
+    for (int c = 0; c < 3; ++c) Hr[(size_t)r * k + c0 + c] = B(br, c);
+  };
+  row_of(0, 0, A0, 2);
+  row_of(0, 6, RItoO, 2);
+  for (int r = 0; r < 2; ++r) {
+    row_of(1 + r, 0, Pth0, r);
+    row_of(1 + r, 3, Pp0, r);
+    row_of(1 + r, 6, Pth1, r);
+    row_of(1 + r, 9, Pp1, r);
+  }
+  int hc = 12, nc = 0;
+  for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->pose0_id + i;
+  for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->pose1_id + i;
+  if (op->do_calib_ext) {
+    row_of(0, hc, M3::eye() - RO0toO1, 2);
+    const M3 Dth = skew((RItoO * RG0) * (pI1 - pI0) - RO1toO0 * pIinO) + RO1toO0 * skew(pIinO);
+    const M3 Dp = (-1.0 * RO1toO0) + M3::eye();
+    for (int r = 0; r < 2; ++r) {
+      row_of(1 + r, hc, Dth, r);
+      row_of(1 + r, hc + 3, Dp, r);
+    }
+    for (int i = 0; i < 6; ++i) col_to_state[nc++] = st->ext_id + i;
+    hc += 6;
+  }
+  if (op->do_calib_dt) {
+    const V3 w0 = v3(st->w0), v0 = v3(st->v0), w1 = v3(st->w1), v1 = v3(st->v1);
+    const V3 a = A0 * w0 + RItoO * w1;
+    const V3 c = ((Pth0 * w0 + Pp0 * v0) + Pth1 * w1) + Pp1 * v1;
+    Hr[(size_t)0 * k + hc] = a.a[2];
+    Hr[(size_t)1 * k + hc] = c.a[0];
+    Hr[(size_t)2 * k + hc] = c.a[1];
+    col_to_state[nc++] = st->dt_id;
+    hc += 1;
+  }
+  if (op->do_calib_int) {
+    for (int c = 0; c < 3; ++c) {
+      Hr[(size_t)0 * k + hc + c] = -dth_di.a[c];
+      Hr[(size_t)1 * k + hc + c] = -dx_di.a[c];
+      Hr[(size_t)2 * k + hc + c] = -dy_di.a[c];
+    }
+    for (int i = 0; i < 3; ++i) col_to_state[nc++] = st->intr_id + i;
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < k; ++c) H[(size_t)c * 3 + r] = Hr[(size_t)r * k + c];
+  std::memcpy(Cov, C2.a, sizeof(C2.a));
+  meas[0] = th_2D, meas[1] = x_2D, meas[2] = y_2D;
   return k;
 }
 

@@ -140,7 +140,7 @@ def load_library():
                                         C.POINTER(PlvCpiRecord), ip]),
         "plv_select_wheel_data": (C.c_int, [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip, ip]),
         "plv_wheel_linear_system": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, dp, dp, dp, ip, ip,
-                                              dp, dp]),
+                                              ip, dp, dp]),
         "plv_wheel_update": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, u8p, dp]),
         "plv_next_clone_time": (C.c_int, [C.POINTER(PlvCloneSchedule), dp, ip]),
         "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
@@ -820,11 +820,12 @@ class Context:
 
     def wheel_linear_system(self, opt, st, t, m1, m2):
         t, m1, m2 = _c64(t), _c64(m1), _c64(m2)
-        H, res, Cov, cols, k = np.zeros((22, 6)), np.zeros(6), np.zeros((6, 6)), np.zeros(22, dtype=np.int32), C.c_int()
+        H, res, Cov, cols, k, rows = np.zeros(22 * 6), np.zeros(6), np.zeros(36), np.zeros(22, dtype=np.int32), C.c_int(), C.c_int()
         R, p = np.zeros((3, 3)), np.zeros(3)
         self._chk(self.lib.plv_wheel_linear_system(self.h, C.byref(opt), C.byref(st), len(t), _dp(t), _dp(m1), _dp(m2), _dp(H), _dp(res),
-                                                   _dp(Cov), _ip(cols), C.byref(k), _dp(R), _dp(p)))
-        return H[:k.value].T.copy(), res, Cov, cols[:k.value].copy(), R, p   # H as rows x k
+                                                   _dp(Cov), _ip(cols), C.byref(k), C.byref(rows), _dp(R), _dp(p)))
+        r, kk = rows.value, k.value
+        return (H[:r * kk].reshape(kk, r).T.copy(), res[:r].copy(), Cov[:r * r].reshape(r, r).copy(), cols[:kk].copy(), R, p)   # H as rows x k
 
     def wheel_update(self, opt, st, t, m1, m2, n):
         t, m1, m2 = _c64(t), _c64(m1), _c64(m2)

@@ -267,6 +267,229 @@ __global__ void __launch_bounds__(64) wheel_kernel(WheelArgs A) {
   }
 }
 
+// The 2D types (REF: preintegration_2D :502-646, preintegration_intrinsics_2D :426-470, compute_linear_system_2D :217-325):
+// scalar recursions and a 3x3 covariance, all on lane 0; the lanes then whiten one column each.
+// out: [H 3*k col-major][res 3][Cov 9][R 9 = I][meas 3 = theta x y][Hw 3*k][resw 3]
+__global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
+  __shared__ double Hr[3 * 24], resv[3], L[9], C2[9], meas[3];
+  const int tid = threadIdx.x, k = A.k;
+  if (tid == 0) {
+    double th_2D = 0, x_2D = 0, y_2D = 0;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double dth_di[3] = {0, 0, 0}, dx_di[3] = {0, 0, 0}, dy_di[3] = {0, 0, 0};
+    const double rl = A.st.intr[0], rr = A.st.intr[1], b = A.st.intr[2];
+    for (int i = 0; i < A.n_data - 1; ++i) {
+      const double dt = A.t[i + 1] - A.t[i];
+      if (A.op.do_calib_int) {
+        const double w_l = A.m1[i], w_r = A.m2[i];
+        const double w = (w_r * rr - w_l * rl) / b, v = (w_r * rr + w_l * rl) / 2;
+        const double Hwx[3] = {-w_l / b, w_r / b, -(w_r * rr - w_l * rl) / (b * b)}, Hvx[3] = {w_l / 2, w_r / 2, 0};
+        double h_thw = dt;
+        double h_xth = (v * (cos(th_2D - w * dt) - cos(th_2D))) / w;
+        double h_yth = -(v * (sin(th_2D - w * dt) - sin(th_2D))) / w;
+        double h_xw = (v * (sin(th_2D - w * dt) - sin(th_2D))) / w / w + (v * cos(th_2D - w * dt) * dt) / w;
+        double h_yw = (v * (cos(th_2D - w * dt) - cos(th_2D))) / w / w - (v * sin(th_2D - w * dt) * dt) / w;
+        double h_xv = -(sin(th_2D - w * dt) - sin(th_2D)) / w;
+        double h_yv = -(cos(th_2D - w * dt) - cos(th_2D)) / w;
+        if (fabs(w) < 0.0001) {
+          h_xth = v * sin(th_2D) * dt;
+          h_yth = v * cos(th_2D) * dt;
+          h_xw = v * sin(th_2D) * dt * dt / 2;
+          h_yw = v * cos(th_2D) * dt * dt / 2;
+          h_xv = cos(th_2D) * dt;
+          h_yv = -sin(th_2D) * dt;
+        }
+        for (int c = 0; c < 3; ++c) {
+          dx_di[c] = ((dx_di[c] + h_xth * dth_di[c]) + h_xw * Hwx[c]) + h_xv * Hvx[c];
+          dy_di[c] = ((dy_di[c] + h_yth * dth_di[c]) + h_yw * Hwx[c]) + h_yv * Hvx[c];
+        }
+        for (int c = 0; c < 3; ++c) dth_di[c] = dth_di[c] + h_thw * Hwx[c];
+      }
+      double w1, w2, v1, v2;
+      if (A.op.type == PLV_WHEEL2D_ANG) {
+        w1 = (A.m2[i] * rr - A.m1[i] * rl) / b, v1 = (A.m2[i] * rr + A.m1[i] * rl) / 2;
+        w2 = (A.m2[i + 1] * rr - A.m1[i + 1] * rl) / b, v2 = (A.m2[i + 1] * rr + A.m1[i + 1] * rl) / 2;
+      } else if (A.op.type == PLV_WHEEL2D_LIN) {
+        w1 = (A.m2[i] - A.m1[i]) / b, v1 = (A.m2[i] + A.m1[i]) / 2;
+        w2 = (A.m2[i + 1] - A.m1[i + 1]) / b, v2 = (A.m2[i + 1] + A.m1[i + 1]) / 2;
+      } else {
+        w1 = A.m1[i], v1 = A.m2[i], w2 = A.m1[i + 1], v2 = A.m2[i + 1];
+      }
+      const double w_alpha = (w2 - w1) / dt, v_jerk = (v2 - v1) / dt;
+      double w = w1, v = v1;
+      const double k1_th = -w * dt, k1_x = v * 1 * dt;
+      const double th2 = 0.5 * k1_th;
+      w += 0.5 * w_alpha * dt;
+      v += 0.5 * v_jerk * dt;
+      const double k2_th = -w * dt, k2_x = v * cos(th2) * dt;
+      const double th3 = 0.5 * k2_th;
+      const double k3_th = -w * dt, k3_x = v * cos(th3) * dt;
+      const double th4 = k3_th;
+      w += 0.5 * w_alpha * dt;
+      v += 0.5 * v_jerk * dt;
+      const double k4_th = -w * dt, k4_x = v * cos(th4) * dt;
+      const double th_next = th_2D + (1.0 / 6.0) * (k1_th + 2 * k2_th + 2 * k3_th + k4_th);
+      const double x_next = x_2D + (1.0 / 6.0) * (k1_x + 2 * k2_x + 2 * k3_x + k4_x);
+      double y_next;
+      if (fabs(w1) < 0.0001)
+        y_next = y_2D - v1 * sin(th_2D - w1 * dt) * dt;
+      else
+        y_next = y_2D - (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1;
+      double Hwn[2], Hvn[2];
+      if (A.op.type == PLV_WHEEL2D_ANG) {
+        Hwn[0] = rl / b, Hwn[1] = -rr / b, Hvn[0] = -rl / 2, Hvn[1] = -rr / 2;
+      } else if (A.op.type == PLV_WHEEL2D_LIN) {
+        Hwn[0] = 1.0 / b, Hwn[1] = -1.0 / b, Hvn[0] = -1.0 / 2, Hvn[1] = -1.0 / 2;
+      } else {
+        Hwn[0] = 1, Hwn[1] = 0, Hvn[0] = 0, Hvn[1] = 1;
+      }
+      double h_thw = dt;
+      double h_xth = (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1;
+      double h_yth = -(v1 * (sin(th_2D - w1 * dt) - sin(th_2D))) / w1;
+      double h_xw = (v1 * (sin(th_2D - w1 * dt) - sin(th_2D))) / w1 / w1 + (v1 * cos(th_2D - w1 * dt) * dt) / w1;
+      double h_yw = (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1 / w1 - (v1 * sin(th_2D - w1 * dt) * dt) / w1;
+      double h_xv = -(sin(th_2D - w1 * dt) - sin(th_2D)) / w1;
+      double h_yv = -(cos(th_2D - w1 * dt) - cos(th_2D)) / w1;
+      if (fabs(w1) < 0.0001) {
+        h_xth = v1 * sin(th_2D) * dt;
+        h_yth = v1 * cos(th_2D) * dt;
+        h_xw = v1 * sin(th_2D) * dt * dt / 2;
+        h_yw = v1 * cos(th_2D) * dt * dt / 2;
+        h_xv = cos(th_2D) * dt;
+        h_yv = -sin(th_2D) * dt;
+      }
+      const double Ptr[9] = {1, 0, 0, h_xth, 1, 0, h_yth, 0, 1};
+      double Pns[6];
+      for (int c = 0; c < 2; ++c) {
+        Pns[c] = h_thw * Hwn[c];
+        Pns[2 + c] = h_xw * Hwn[c] + h_xv * Hvn[c];
+        Pns[4 + c] = h_yw * Hwn[c] + h_yv * Hvn[c];
+      }
+      double Q0, Q1;
+      if (A.op.type == PLV_WHEEL2D_ANG)
+        Q0 = Q1 = A.op.noise_w * A.op.noise_w / dt;
+      else if (A.op.type == PLV_WHEEL2D_LIN)
+        Q0 = Q1 = A.op.noise_v * A.op.noise_v / dt;
+      else
+        Q0 = A.op.noise_w * A.op.noise_w / dt, Q1 = A.op.noise_v * A.op.noise_v / dt;
+      double X[9], N[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double a = 0;
+          for (int q = 0; q < 3; ++q) a += Ptr[3 * r + q] * C[3 * q + c];
+          X[3 * r + c] = a;
+        }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double a = 0;
+          for (int q = 0; q < 3; ++q) a += X[3 * r + q] * Ptr[3 * c + q];
+          const double nn = (Pns[2 * r] * Q0) * Pns[2 * c] + (Pns[2 * r + 1] * Q1) * Pns[2 * c + 1];
+          N[3 * r + c] = a + nn;
+        }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = 0.5 * (N[3 * r + c] + N[3 * c + r]);
+      th_2D = th_next, x_2D = x_next, y_2D = y_next;
+    }
+    // compute_linear_system_2D
+    D3 pI0 = ld3(A.st.p0), pI1 = ld3(A.st.p1);
+    DM3 RG0 = ldm(A.st.R0), RG1 = ldm(A.st.R1);
+    const D3 pIinO = ld3(A.st.p_IinO);
+    const DM3 RItoO = ldm(A.st.R_ItoO);
+    const D3 pOinI = mvec(mscale(-1.0, mtr(RItoO)), pIinO);
+    const double theta_est = log3(mmul(mmul(mmul(RItoO, RG1), mtr(RG0)), mtr(RItoO))).z;
+    const D3 d_est = mvec(mmul(RItoO, RG0), ((pI1 + mvec(mtr(RG1), pOinI)) - pI0) - mvec(mtr(RG0), pOinI));
+    resv[0] = theta_est - th_2D;
+    resv[1] = x_2D - d_est.x;
+    resv[2] = y_2D - d_est.y;
+    for (int e = 0; e < 3 * k; ++e) Hr[e] = 0.0;
+    pI0 = ld3(A.st.p0_fej), pI1 = ld3(A.st.p1_fej), RG0 = ldm(A.st.R0_fej), RG1 = ldm(A.st.R1_fej);
+    const DM3 RO0toO1 = mmul(mmul(mmul(RItoO, RG1), mtr(RG0)), mtr(RItoO)), RO1toO0 = mtr(RO0toO1);
+    const DM3 A0 = mmul(mmul(mscale(-1.0, RItoO), RG1), mtr(RG0));
+    const DM3 Pth0 = mmul(RItoO, skewm(mvec(RG0, (pI1 + mvec(mtr(RG1), pOinI)) - pI0)));
+    const DM3 Pp0 = mmul(mscale(-1.0, RItoO), RG0);
+    const DM3 Pth1 = mmul(mmul(mmul(mscale(-1.0, RItoO), RG0), mtr(RG1)), skewm(pOinI));
+    const DM3 Pp1 = mmul(RItoO, RG0);
+    auto row_of = [&](int r, int c0, const DM3 &B, int br) {
+      for (int c = 0; c < 3; ++c) Hr[r * k + c0 + c] = B.m[3 * br + c];
+    };
+    row_of(0, 0, A0, 2);
+    row_of(0, 6, RItoO, 2);
+    for (int r = 0; r < 2; ++r) {
+      row_of(1 + r, 0, Pth0, r);
+      row_of(1 + r, 3, Pp0, r);
+      row_of(1 + r, 6, Pth1, r);
+      row_of(1 + r, 9, Pp1, r);
+    }
+    int hc = 12;
+    if (A.op.do_calib_ext) {
+      row_of(0, hc, msub(eyem(), RO0toO1), 2);
+      const DM3 Dth = madd(skewm(mvec(mmul(RItoO, RG0), pI1 - pI0) - mvec(RO1toO0, pIinO)), mmul(RO1toO0, skewm(pIinO)));
+      const DM3 Dp = madd(mscale(-1.0, RO1toO0), eyem());
+      for (int r = 0; r < 2; ++r) {
+        row_of(1 + r, hc, Dth, r);
+        row_of(1 + r, hc + 3, Dp, r);
+      }
+      hc += 6;
+    }
+    if (A.op.do_calib_dt) {
+      const D3 w0 = ld3(A.st.w0), v0 = ld3(A.st.v0), w1 = ld3(A.st.w1), v1 = ld3(A.st.v1);
+      const D3 a = mvec(A0, w0) + mvec(RItoO, w1);
+      const D3 cc = ((mvec(Pth0, w0) + mvec(Pp0, v0)) + mvec(Pth1, w1)) + mvec(Pp1, v1);
+      Hr[0 * k + hc] = a.z;
+      Hr[1 * k + hc] = cc.x;
+      Hr[2 * k + hc] = cc.y;
+      hc += 1;
+    }
+    if (A.op.do_calib_int)
+      for (int c = 0; c < 3; ++c) {
+        Hr[0 * k + hc + c] = -dth_di[c];
+        Hr[1 * k + hc + c] = -dx_di[c];
+        Hr[2 * k + hc + c] = -dy_di[c];
+      }
+    for (int e = 0; e < 9; ++e) {
+      C2[e] = C[e];
+      L[e] = 0.0;
+    }
+    for (int j = 0; j < 3; ++j) {
+      double d = C[j * 3 + j];
+      for (int q = 0; q < j; ++q) d -= L[j * 3 + q] * L[j * 3 + q];
+      d = sqrt(d);
+      L[j * 3 + j] = d;
+      for (int i2 = j + 1; i2 < 3; ++i2) {
+        double v = C[i2 * 3 + j];
+        for (int q = 0; q < j; ++q) v -= L[i2 * 3 + q] * L[j * 3 + q];
+        L[i2 * 3 + j] = v / d;
+      }
+    }
+    meas[0] = th_2D, meas[1] = x_2D, meas[2] = y_2D;
+  }
+  __syncthreads();
+  double *oH = A.out, *ores = oH + 3 * k, *oC = ores + 3, *oR = oC + 9, *op = oR + 9, *oHw = op + 3, *oresw = oHw + 3 * k;
+  for (int e = tid; e < 3 * k; e += 64) oH[e] = Hr[(e % 3) * k + e / 3];
+  if (tid < 3) {
+    ores[tid] = resv[tid];
+    op[tid] = meas[tid];
+  }
+  if (tid < 9) {
+    oC[tid] = C2[tid];
+    oR[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
+  }
+  for (int col = tid; col <= k; col += 64) {
+    double y[3];
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) {
+      double v = col < k ? Hr[i2 * k + col] : resv[i2];
+      for (int q = 0; q < i2; ++q) v -= L[i2 * 3 + q] * y[q];
+      y[i2] = v / L[i2 * 3 + i2];
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) {
+      if (col < k) oHw[col * 3 + i2] = y[i2];
+      else oresw[i2] = y[i2];
+    }
+  }
+}
+
 int wheel_columns(const plv_wheel_options *op, const plv_wheel_state *st, int *cols) {
   int nc = 0;
   for (int i = 0; i < 6; ++i) cols[nc++] = st->pose0_id + i;
@@ -281,12 +504,13 @@ int wheel_columns(const plv_wheel_options *op, const plv_wheel_state *st, int *c
 
 // runs the kernel; host copies of every output block
 int wheel_system(plv_ctx *ctx, const plv_wheel_options *op, const plv_wheel_state *st, int n_data, const double *t, const double *m1,
-                 const double *m2, std::vector<double> &out, int &k) {
-  if (!ctx || !op || !st || n_data < 2 || !t || !m1 || !m2 || op->type < 0 || op->type > 2) return PLV_E_BADARG;
+                 const double *m2, std::vector<double> &out, int &k, int &rows) {
+  if (!ctx || !op || !st || n_data < 2 || !t || !m1 || !m2 || op->type < 0 || op->type > PLV_WHEEL2D_CEN) return PLV_E_BADARG;
   k = 12 + (op->do_calib_ext ? 6 : 0) + (op->do_calib_dt ? 1 : 0) + (op->do_calib_int ? 3 : 0);
+  rows = op->type >= PLV_WHEEL2D_ANG ? 3 : 6;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  const size_t nd = (size_t)n_data, n_out = (size_t)12 * k + 6 + 36 + 9 + 3 + 6;
+  const size_t nd = (size_t)n_data, n_out = (size_t)2 * rows * k + rows + (size_t)rows * rows + 9 + 3 + rows;
   TRY(us->eval.reserve((3 * nd + n_out) * 8));
   double *d = us->eval.as<double>();
   std::vector<double> h(3 * nd);
@@ -303,7 +527,10 @@ int wheel_system(plv_ctx *ctx, const plv_wheel_options *op, const plv_wheel_stat
   A.out = d + 3 * nd;
   {
     ProfScope ps(ctx->prof, "wheel_kernel", ctx->stream);
-    hipLaunchKernelGGL(wheel_kernel, dim3(1), dim3(64), 0, ctx->stream, A);
+    if (rows == 6)
+      hipLaunchKernelGGL(wheel_kernel, dim3(1), dim3(64), 0, ctx->stream, A);
+    else
+      hipLaunchKernelGGL(wheel2d_kernel, dim3(1), dim3(64), 0, ctx->stream, A);
   }
   PLV_HIP_CHECK(hipGetLastError());
   out.resize(n_out);
@@ -375,17 +602,19 @@ int plv_select_wheel_data(int n, const double *t, const double *m1, const double
 
 int plv_wheel_linear_system(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel_state *st, int n_data, const double *t,
                             const double *m1, const double *m2, double *H, double *res, double *Cov, int *col_to_state, int *k_out,
-                            double *R_3D, double *p_3D) {
+                            int *rows_out, double *R_3D, double *p_3D) {
   if (!H || !res || !Cov || !col_to_state || !k_out) return PLV_E_BADARG;
   std::vector<double> out;
-  int k = 0;
-  TRY(wheel_system(ctx, opt, st, n_data, t, m1, m2, out, k));
-  std::copy(out.begin(), out.begin() + 6 * k, H);
-  std::copy(out.begin() + 6 * k, out.begin() + 6 * k + 6, res);
-  std::copy(out.begin() + 6 * k + 6, out.begin() + 6 * k + 42, Cov);
-  if (R_3D) std::copy(out.begin() + 6 * k + 42, out.begin() + 6 * k + 51, R_3D);
-  if (p_3D) std::copy(out.begin() + 6 * k + 51, out.begin() + 6 * k + 54, p_3D);
+  int k = 0, rows = 0;
+  TRY(wheel_system(ctx, opt, st, n_data, t, m1, m2, out, k, rows));
+  const size_t o_res = (size_t)rows * k, o_cov = o_res + rows, o_R = o_cov + (size_t)rows * rows, o_p = o_R + 9;
+  std::copy(out.begin(), out.begin() + o_res, H);
+  std::copy(out.begin() + o_res, out.begin() + o_cov, res);
+  std::copy(out.begin() + o_cov, out.begin() + o_R, Cov);
+  if (R_3D) std::copy(out.begin() + o_R, out.begin() + o_p, R_3D);
+  if (p_3D) std::copy(out.begin() + o_p, out.begin() + o_p + 3, p_3D);
   *k_out = wheel_columns(opt, st, col_to_state);
+  if (rows_out) *rows_out = rows;
   return PLV_OK;
 }
 
@@ -393,8 +622,8 @@ int plv_wheel_update(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel
                      const double *m1, const double *m2, uint8_t *accepted, double *dx) {
   if (!accepted || !dx || !ctx || ctx->cov_n < 1) return PLV_E_BADARG;
   std::vector<double> out;
-  int k = 0;
-  TRY(wheel_system(ctx, opt, st, n_data, t, m1, m2, out, k));
+  int k = 0, rows = 0;
+  TRY(wheel_system(ctx, opt, st, n_data, t, m1, m2, out, k, rows));
   int cols[24];
   wheel_columns(opt, st, cols);
   for (int i = 0; i < k; ++i)
@@ -402,14 +631,14 @@ int plv_wheel_update(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel
       set_last_error("plv_wheel_update: column %d maps to state %d outside the covariance (%d)", i, cols[i], ctx->cov_n);
       return PLV_E_BADARG;
     }
-  const double *Hw = out.data() + 6 * k + 54, *resw = Hw + 6 * k;
-  for (int i = 0; i < 6 * k + 6; ++i)
+  const double *Hw = out.data() + (size_t)rows * k + rows + (size_t)rows * rows + 12, *resw = Hw + (size_t)rows * k;
+  for (int i = 0; i < rows * k + rows; ++i)
     if (!std::isfinite(Hw[i])) {
       set_last_error("plv_wheel_update: the preintegrated covariance is not positive definite");
       return PLV_E_NUMERIC;
     }
-  // Chi2Check(H, res, Cov_3D) + EKFUpdate(H, res, Cov_3D) == the same two steps on the whitened system with R = I
-  return plv_slam_update(ctx, 6, k, 6, Hw, resw, cols, opt->chi2_mult, accepted, dx);
+  // Chi2Check(H, res, Cov) + EKFUpdate(H, res, Cov) == the same two steps on the whitened system with R = I
+  return plv_slam_update(ctx, rows, k, rows, Hw, resw, cols, opt->chi2_mult, accepted, dx);
 }
 
 }  // extern "C"

@@ -513,11 +513,12 @@ class PropOracle:
     def wheel_linear_system(self, opt, st, t, m1, m2):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         t, m1, m2 = f(t), f(m1), f(m2)
-        H, res, Cov, cols = np.zeros((22, 6)), np.zeros(6), np.zeros((6, 6)), np.zeros(22, dtype=np.int32)
+        H, res, Cov, cols = np.zeros(22 * 6), np.zeros(6), np.zeros(36), np.zeros(22, dtype=np.int32)
         R, p = np.zeros((3, 3)), np.zeros(3)
         k = self.lib.orc_wheel_linear_system(C.byref(opt), C.byref(st), len(t), _dp(t), _dp(m1), _dp(m2), _dp(H), _dp(res), _dp(Cov), _ip(cols),
                                              _dp(R), _dp(p))
-        return H[:k].T.copy(), res, Cov, cols[:k].copy(), R, p
+        r = 3 if opt.type >= 3 else 6
+        return H[:r * k].reshape(k, r).T.copy(), res[:r].copy(), Cov[:r * r].reshape(r, r).copy(), cols[:k].copy(), R, p
 
     def cpi_integrate(self, noise, t_given, clone_t, R_clone, v_clone, bg, ba, t, wm, am):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)

@@ -47,11 +47,11 @@ def wheel_stream(t0, t1, rate=100.0, kind=0):
     t = t0 + np.arange(n) / rate
     wv = np.array([vehicle(x) for x in t])
     w, v = wv[:, 0], wv[:, 1]
-    if kind == 0:    # Wheel3DAng: wheel angular velocities
+    if kind % 3 == 0:    # Wheel3DAng / Wheel2DAng: wheel angular velocities
         return t, (v - w * B / 2) / RL, (v + w * B / 2) / RR
-    if kind == 1:    # Wheel3DLin: wheel linear velocities
+    if kind % 3 == 1:    # ...Lin: wheel linear velocities
         return t, v - w * B / 2, v + w * B / 2
-    return t, w, v   # Wheel3DCen
+    return t, w, v       # ...Cen
 
 
 def make(pkg, kind=0, ext=False, dt=False, intr=False, t0=20.3, t1=20.8, d0=None, d1=None, intr_v=(RL, RR, B)):
@@ -141,3 +141,70 @@ def test_calibration_blocks_and_types(pkg):
     # extrinsic block: dzr/dth = I - R_O0toO1, dzp/dp = I - R_O1toO0
     R_O0toO1 = R_ITOO @ imu_pose(20.8)[0] @ imu_pose(20.3)[0].T @ R_ITOO.T
     assert np.abs(H[0:3, 12:15] - (np.eye(3) - R_O0toO1)).max() < 1e-12 and np.abs(H[3:6, 15:18] - (np.eye(3) - R_O0toO1.T)).max() < 1e-12
+
+
+def test_2d_types(pkg):
+    """Wheel2DAng / Lin / Cen: yaw + planar translation (3 rows).  Level odometry frame, so the planar model is exact."""
+    po = oracle_lib.load_prop(pkg)
+    global R_ITOO
+    keep = R_ITOO
+    try:
+        R_ITOO = Rotation.from_rotvec([0.0, 0.0, 0.6]).as_matrix()   # the 2D model assumes the wheel frame's z is the yaw axis
+        odom_pose.cache_clear()
+        for kind in (3, 4, 5):
+            t, m1, m2 = wheel_stream(20.0, 21.0, rate=400.0, kind=kind)
+            ok, st_, s1, s2 = po.select_wheel_data(t, m1, m2, 20.3, 20.8)
+            opt, st = make(pkg, kind, ext=True, dt=True, intr=(kind == 3))
+            H, res, Cov, cols, _, meas = po.wheel_linear_system(opt, st, st_, s1, s2)
+            kk = 19 + (3 if kind == 3 else 0)
+            assert H.shape == (3, kk) and Cov.shape == (3, 3) and len(res) == 3
+            # an independent transcription of preintegration_2D's mean recursion (UpdaterWheel.cpp:502-571)
+            th = x = y = 0.0
+            for i in range(len(st_) - 1):
+                dt = st_[i + 1] - st_[i]
+                if kind == 3:
+                    wv = [((s2[j] * RR - s1[j] * RL) / B, (s2[j] * RR + s1[j] * RL) / 2) for j in (i, i + 1)]
+                elif kind == 4:
+                    wv = [((s2[j] - s1[j]) / B, (s2[j] + s1[j]) / 2) for j in (i, i + 1)]
+                else:
+                    wv = [(s1[j], s2[j]) for j in (i, i + 1)]
+                (w1, v1), (w2, v2) = wv
+                wa, vj = (w2 - w1) / dt, (v2 - v1) / dt
+                w, v = w1, v1
+                k1t, k1x = -w * dt, v * dt
+                w, v = w + 0.5 * wa * dt, v + 0.5 * vj * dt
+                k2t, k2x = -w * dt, v * np.cos(0.5 * k1t) * dt
+                k3t, k3x = -w * dt, v * np.cos(0.5 * k2t) * dt
+                w, v = w + 0.5 * wa * dt, v + 0.5 * vj * dt
+                k4t, k4x = -w * dt, v * np.cos(k3t) * dt
+                y = y - v1 * np.sin(th - w1 * dt) * dt if abs(w1) < 1e-4 else y - (v1 * (np.cos(th - w1 * dt) - np.cos(th))) / w1
+                x = x + (k1x + 2 * k2x + 2 * k3x + k4x) / 6
+                th = th + (k1t + 2 * k2t + 2 * k3t + k4t) / 6
+            assert np.abs(meas - [th, x, y]).max() < 1e-12
+            # against the vehicle's true motion: the yaw is exact; the reference integrates x in the frame of each step's start and
+            # y with a first-order closed form, so the translation is only good to centimetres over half a second of turning
+            R_O0, p_O0 = odom_pose(20.3)
+            R_O1, p_O1 = odom_pose(20.8)
+            d = R_O0 @ (p_O1 - p_O0)
+            yaw = Rotation.from_matrix(R_O1 @ R_O0.T).as_rotvec()[2]
+            assert abs(meas[0] - yaw) < 1e-6 and abs(meas[1] - d[0]) < 0.05 and abs(meas[2] - d[1]) < 0.05
+            assert abs(res[0]) < 1e-6 and abs(res[1] - (meas[1] - d[0])) < 1e-6 and abs(res[2] - (meas[2] - d[1])) < 1e-6
+            assert np.abs(Cov - Cov.T).max() == 0 and np.linalg.eigvalsh(Cov).min() > 0
+            # pose Jacobians by finite differences of the residual
+            eps = 1e-6
+            J = np.zeros((3, 12))
+            for c in range(12):
+                dd = np.zeros(12)
+                dd[c] = eps
+                r = []
+                for sgn in (1, -1):
+                    o2, s2_ = make(pkg, kind, ext=True, dt=True, intr=(kind == 3), d0=sgn * dd[:6], d1=sgn * dd[6:])
+                    r.append(po.wheel_linear_system(o2, s2_, st_, s1, s2)[1])
+                J[:, c] = -(r[0] - r[1]) / (2 * eps)
+            assert np.abs(J - H[:, :12]).max() < 1e-5
+            # the time-offset column = pose Jacobians applied to the clone velocities
+            w0, v0, w1, v1 = np.array(st.w0), np.array(st.v0), np.array(st.w1), np.array(st.v1)
+            assert np.abs(H[:, 18] - (H[:, 0:3] @ w0 + H[:, 3:6] @ v0 + H[:, 6:9] @ w1 + H[:, 9:12] @ v1)).max() < 1e-12
+    finally:
+        R_ITOO = keep
+        odom_pose.cache_clear()
