@@ -177,10 +177,18 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
   double *gres = res + (size_t)f * ld;
   if (rows <= fdim) return;
 
-  for (int idx = threadIdx.x; idx < rows * ncol; idx += blockDim.x) {
-    int j = idx / rows, i = idx - j * rows;
-    double v = j < fdim ? gHf[j * ld + i] : (j < fdim + k ? gHx[(j - fdim) * ld + i] : gres[i]);
-    X[i * ncol + j] = v;
+  // thread per column: `rows` contiguous doubles of its column, eight loads in flight at a time; a wave then covers one
+  // contiguous stretch of the batch and the LDS writes of a row are conflict-free
+  for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
+    const double *src = j < fdim ? gHf + j * ld : (j < fdim + k ? gHx + (size_t)(j - fdim) * ld : gres);
+    for (int i0 = 0; i0 < rows; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u, rows - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < rows) X[(i0 + u) * ncol + j] = v[u];
+    }
   }
   for (int n = 0; n < fdim; ++n) {
     __syncthreads();
@@ -213,18 +221,19 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
   __syncthreads();
   // write back: Hf whole (upper-triangular now), Hx / res shifted up by `shift` rows (= fdim for the nullspace
   // projection; 0 keeps the initialising rows as well: StateHelper::initialize, StateHelper.cpp:391-405)
-  for (int idx = threadIdx.x; idx < rows * fdim; idx += blockDim.x) {
-    int j = idx / rows, i = idx - j * rows;
-    gHf[j * ld + i] = X[i * ncol + j];
-  }
   const int mp = rows - shift;
-  for (int idx = threadIdx.x; idx < mp * (k + 1); idx += blockDim.x) {
-    int j = idx / mp, i = idx - j * mp;
-    double v = X[(i + shift) * ncol + fdim + j];
-    if (j < k)
-      gHx[j * ld + i] = v;
-    else
-      gres[i] = v;
+  for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
+    const bool isf = j < fdim;
+    double *dst = isf ? gHf + j * ld : (j < fdim + k ? gHx + (size_t)(j - fdim) * ld : gres);
+    const int cnt = isf ? rows : mp, off = isf ? 0 : shift;
+    for (int i0 = 0; i0 < cnt; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = X[(min(i0 + u, cnt - 1) + off) * ncol + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < cnt) dst[i0 + u] = v[u];
+    }
   }
 }
 
