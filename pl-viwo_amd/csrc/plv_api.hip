@@ -306,6 +306,9 @@ static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, doub
   return PLV_OK;
 }
 
+// rows one EKF factorisation takes: the blocked kernel up to 128, the LDS-resident general one up to r (r | 1) 8 B <= 160 KB
+static const int EKF_MAX_ROWS = 128;
+
 int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int r, int k, int ldh,
                    const int *col_to_state, const double *res, const double *Rdiag, double *dx) {
   REQUIRE_CTX(ctx);
@@ -327,6 +330,39 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
   } else if (ctx->cov_n != n) {
     set_last_error("plv_ekf_update: no device-resident covariance of dimension %d", n);
     return PLV_E_BADARG;
+  }
+  if (r > EKF_MAX_ROWS) {
+    // More rows than one factorisation holds.  The noise is diagonal, so the rows are independent measurements and the update
+    // equals the same rows applied block after block (each block's residual taken at the state the earlier blocks produced).
+    // A rejection anywhere rejects everything: the covariance is restored and dx left untouched, as EKFUpdate would.
+    const size_t bytes = (size_t)n * n * 8;
+    TRY(ctx->d_P2.reserve(bytes));
+    PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P2.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<double> dx_tot(n, 0.0), dx_b(n), res_b;
+    int rc = PLV_OK;
+    for (int r0 = 0; r0 < r && rc == PLV_OK; r0 += EKF_MAX_ROWS) {
+      const int rb_ = std::min(EKF_MAX_ROWS, r - r0);
+      res_b.assign(res + r0, res + r0 + rb_);
+      for (int j = 0; j < k; ++j) {
+        const double d = dx_tot[col_to_state[j]];
+        if (d != 0.0)
+          for (int i = 0; i < rb_; ++i) res_b[i] -= H[(size_t)j * ldh + r0 + i] * d;
+      }
+      rc = plv_ekf_update(ctx, nullptr, n, n, H + r0, rb_, k, ldh, col_to_state, res_b.data(), Rdiag ? Rdiag + r0 : nullptr, dx_b.data());
+      if (rc == PLV_OK)
+        for (int i = 0; i < n; ++i) dx_tot[i] += dx_b[i];
+    }
+    if (rc != PLV_OK) {
+      PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, ctx->d_P2.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      TRY(sync(ctx));
+      return rc;
+    }
+    std::copy(dx_tot.begin(), dx_tot.end(), dx);
+    if (P) {
+      TRY(download_mat(ctx, P, ctx->d_P.as<double>(), n, n, ldp));
+      TRY(sync(ctx));
+    }
+    return PLV_OK;
   }
   TRY(ctx->d_H.reserve((size_t)r * k * 8));
   TRY(ctx->d_res.reserve((size_t)r * 8));

@@ -203,3 +203,58 @@ def test_update_graph_replay_matches_eager(pkg, oracle):
     assert cap2 == 2 and rep2 == 4
     ctx.update_graph_mode(0)
     ctx.close()
+
+
+@pytest.mark.parametrize("k", [12, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 95, 96, 97, 111, 112, 113, 127, 128])
+def test_msckf_update_tile_boundaries(ctx, oracle, k):
+    """Every 16-column tile boundary of the blocked factorisations (the kernels are instantiated for 2, 4, 7 and 8 tiles), with
+    fewer stacked rows than columns for the small ones (no compression) and more for the rest."""
+    n = k + 15
+    F, M = (4, 4) if k >= 31 and k % 2 else (30, 8)
+    P = synth.spd_cov(n, seed=k)
+    cols = synth.col_map(n, k, seed=k, skip=15)
+    rows, Hf, Hx, res = synth.msckf_batch(F=F, M=M, k=k, seed=k)
+    q95 = synth.q95_table()
+    rc0, P0, dx0, acc0, nr0 = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, q95, 1.0, 3.0)
+    rc1, P1, dx1, acc1, nr1 = ctx.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, 1.0, 3.0)
+    assert rc0 == rc1 == 0 and np.array_equal(acc0, acc1) and nr0 == nr1
+    if acc1.sum():
+        assert _rel(dx1, dx0) < 1e-8 and _rel(P1, P0) < 1e-8
+    else:
+        assert np.array_equal(P1, P)
+
+
+@pytest.mark.parametrize("r", [1, 2, 15, 16, 17, 31, 33, 63, 65, 96, 97, 111, 113, 127, 128, 129, 150, 260])
+def test_ekf_update_row_boundaries(ctx, oracle, r):
+    """Measurement-row counts around every tile boundary, including r > 128 (the factorisation that does not fit LDS takes the
+    general path) and r > k (more rows than columns, as the wheel / GPS updaters may pass)."""
+    n, k = 113, 98
+    P = synth.spd_cov(n, seed=r)
+    cols = synth.col_map(n, k, seed=r, skip=15)
+    rng = np.random.default_rng(r)
+    H = rng.normal(size=(r, k))
+    res = rng.normal(size=r)
+    Rd = rng.uniform(0.5, 2.0, r)
+    rc0, P0, dx0 = oracle.ekf_update(P, H, cols, res, Rd)
+    rc1, P1, dx1 = ctx.ekf_update(P, H, cols, res, Rd)
+    assert rc0 == rc1 == 0
+    assert _rel(dx1, dx0) < 1e-8 and _rel(P1, P0) < 1e-8 and np.array_equal(P1, P1.T)
+
+
+def test_ekf_update_chunked_rejection_restores_state(ctx, pkg):
+    """r > 128 goes block after block; a rejection in a LATER block must undo the earlier ones (EKFUpdate is all-or-nothing)."""
+    n = 20
+    P = np.eye(n) * 1e-4
+    P[0, 1] = P[1, 0] = 5e-3                      # indefinite in the (0, 1) plane
+    cols = np.arange(n, dtype=np.int32)
+    r = 150
+    H = np.zeros((r, n))
+    H[:128, 2:] = np.random.default_rng(0).normal(size=(128, n - 2)) * 0.1   # the first block never touches states 0 and 1
+    H[128:128 + n, :] = np.eye(n)                 # the second block does
+    res = np.ones(r)
+    Rd = np.full(r, 1e-8)
+    ctx.cov_upload(P)
+    rc, P1, dx1 = ctx.ekf_update(P, H, cols, res, Rd)
+    assert rc == pkg.PLV_E_NOT_PSD
+    assert np.array_equal(P1, P) and np.all(dx1 == 0)
+    assert np.array_equal(ctx.cov_download(n), P)
