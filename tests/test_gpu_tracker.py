@@ -133,3 +133,25 @@ def test_downsampled_feed_matches_oracle(pkg):
     assert (small_mask[p1[:, 1].astype(int), p1[:, 0].astype(int)] <= 127).all()
     ctx.close()
     ctx2.close()
+
+
+def test_kaist_sized_tracker(pkg):
+    """The shipped KAIST camera settings (n_pts 1500, 15x15 grid, FAST 20, min_px_dist 10; config_camera.yaml) on a 1280x720 stream."""
+    w, h = 1280, 720
+    canvas = synth.texture_canvas(w, h, seed=12, blobs=3000)
+    cfg = pkg.default_config(w, h)
+    cfg.num_features, cfg.grid_x, cfg.grid_y, cfg.min_px_dist, cfg.fast_threshold = 1500, 15, 15, 10, 20
+    ctx = pkg.Context(cfg)
+    ot = OracleTracker(cfg, np.array(list(cfg.intrinsics)))
+    for f in range(3):
+        img = synth.render_frame(canvas, w, h, tx=4.0 * f, ty=-3.0 * f, rot_deg=0.2 * f)
+        ctx.tracker_feed(30.0 + 0.05 * f, img)
+        ot.feed(30.0 + 0.05 * f, img)
+    pts, ids = ctx.tracker_last()
+    assert len(ids) > 900
+    common = np.intersect1d(ids, ot.ids)
+    assert len(common) >= 0.98 * max(len(ids), len(ot.ids))
+    a = {int(i): p for i, p in zip(ids, pts)}
+    b = {int(i): p for i, p in zip(ot.ids, ot.pts)}
+    assert max(np.abs(a[int(i)] - b[int(i)]).max() for i in common) <= 2e-3
+    ctx.close()
