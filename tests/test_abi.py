@@ -52,3 +52,19 @@ def test_product_does_not_reference_oracle():
                 if re.search(r'#include\s+"[^"]*oracle|liboracle|import\s+oracle|oracle_lib', t):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_links(pkg, tmp_path):
+    """include/plviwo.h compiles as C11 (no C++ in the signatures) and a C program links against the shared library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "plviwo.h"\n#include <stdio.h>\n'
+                   'int main(void) { plv_config c; plv_config_default(&c, 752, 480);\n'
+                   '  printf("%d %d %d\\n", plv_abi_version(), c.width, c.win_size); return 0; }\n')
+    exe = tmp_path / "cabi"
+    lib_dir = os.path.join(root, "pl-viwo_amd", "lib")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-lplviwo_hip", "-Wl,-rpath," + lib_dir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) >= 1 and out[1:] == ["752", "15"]
