@@ -200,7 +200,8 @@ def main():
     import __graft_entry__ as ge
     pkg = ge.load_pkg()
     cfg = pkg.default_config(W, H)
-    cfg.device = local_rank if world > 1 else 0
+    ndev = max(1, pkg.load_library().plv_device_count())
+    cfg.device = (local_rank % ndev) if world > 1 else 0   # one GPU per rank; wraps only when a node has fewer GPUs than ranks
     # Two contexts = two HIP streams, as the reference has two objects (TrackKLT / the updater): `ctx` tracks,
     # `uctx` owns the covariance and runs the update.  In the default (pipelined) mode the update of frame i
     # is enqueued first and the front-end of frame i+1 runs while it executes (tracking does not depend on
