@@ -125,6 +125,33 @@ __device__ M3 Jl_so3(const V3 &w) {  // REF: quat_ops.h:515-526
     for (int j = 0; j < 3; ++j) aat(i, j) = a[i] * a[j];
   return ma(ma(ms(eye3(), sin(theta) / theta), ms(aat, 1 - sin(theta) / theta)), ms(skew3(a), (1 - cos(theta)) / theta));
 }
+// exp_so3(w) and Jl_so3(w) for the same w with ONE sin / cos evaluation (the transcendental calls are the long poles of the
+// per-observation chain); every other operation is the one of the two functions above, so the results are bit-identical.
+__device__ void exp_and_Jl(const V3 &w, M3 &Rexp, M3 &J) {
+  const M3 wx = skew3(w);
+  const double theta = vnorm(w);
+  const double st = sin(theta), ct = cos(theta);
+  double A, B;
+  if (theta < 1e-7) {
+    A = 1;
+    B = 0.5;
+  } else {
+    A = st / theta;
+    B = (1 - ct) / (theta * theta);
+  }
+  Rexp = theta == 0 ? eye3() : ma(ma(eye3(), ms(wx, A)), ms(mm(wx, wx), B));
+  if (theta < 1e-6) {
+    J = eye3();
+    return;
+  }
+  const V3 a = vsc(w, 1.0 / theta);
+  M3 aat;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) aat(i, j) = a[i] * a[j];
+  J = ma(ma(ms(eye3(), st / theta), ms(aat, 1 - st / theta)), ms(skew3(a), (1 - ct) / theta));
+}
 __device__ __forceinline__ M3 ldM(const double *p) {
   M3 m;
 #pragma unroll
@@ -300,11 +327,14 @@ __device__ void interpolate_tab(const JacParams &P, const WinTab &T, int s0, dou
     A_ori = vadd(A_ori, vsc(T.th[w], lam[w]));
     A_pos = vadd(A_pos, vsc(T.dp[w], lam[w]));
   }
-  const M3 Rio = exp_so3(A_ori);
+  M3 Rio, Jl;
+  if (want_jac)
+    exp_and_Jl(A_ori, Rio, Jl);
+  else
+    Rio = exp_so3(A_ori);
   o.R = mm(Rio, T.R0);
   o.p = vadd(T.p0, A_pos);
   if (!want_jac) return;
-  const M3 Jl = Jl_so3(A_ori);
   M3 H0o = Rio;
   double lsum = 0;
 #pragma unroll
@@ -514,7 +544,9 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) hf[(size_t)j * ld + 2 * c + i] = wz[3 * i] * G(0, j) + wz[3 * i + 1] * G(1, j) + wz[3 * i + 2] * G(2, j);
-  // ---- Hx: four interpolation poses
+  // ---- Hx: four interpolation poses.  The slice was zero-filled by this workgroup and every (row, column) below is written
+  // once (the clones of a window, the time offset, the extrinsics and the intrinsics are distinct state blocks), so these are
+  // plain stores: an accumulate would put a global load in front of every one of them on the observation's chain.
   double WI[12];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -529,8 +561,8 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
-        hx[(size_t)(col + j) * ld + 2 * c + i] += so;
-        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += WI[6 * i + 3 + j] * jac.lam[w];
+        hx[(size_t)(col + j) * ld + 2 * c + i] = so;
+        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] = WI[6 * i + 3 + j] * jac.lam[w];
       }
   }
   if (P.col_dt >= 0)
@@ -539,7 +571,7 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
       double s = 0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
-      hx[(size_t)P.col_dt * ld + 2 * c + i] += s;
+      hx[(size_t)P.col_dt * ld + 2 * c + i] = s;
     }
   if (P.col_ext >= 0) {
     const M3 sk = skew3(vsub(p_FinC, p_IinC));
@@ -547,15 +579,15 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        hx[(size_t)(P.col_ext + j) * ld + 2 * c + i] += wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
-        hx[(size_t)(P.col_ext + 3 + j) * ld + 2 * c + i] += wz[3 * i + j];
+        hx[(size_t)(P.col_ext + j) * ld + 2 * c + i] = wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
+        hx[(size_t)(P.col_ext + 3 + j) * ld + 2 * c + i] = wz[3 * i + j];
       }
   }
   if (P.col_int >= 0)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hx[(size_t)(P.col_int + j) * ld + 2 * c + i] += wzeta[8 * i + j];
+      for (int j = 0; j < 8; ++j) hx[(size_t)(P.col_int + j) * ld + 2 * c + i] = wzeta[8 * i + j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1070,8 +1102,8 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
-        hx[(size_t)(col + j) * ld + 2 * c + i] += so;
-        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] += WI[6 * i + 3 + j] * jac.lam[w];
+        hx[(size_t)(col + j) * ld + 2 * c + i] = so;  // (written once: plain stores, as in jacobian_rows)
+        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] = WI[6 * i + 3 + j] * jac.lam[w];
       }
   }
   if (P.col_dt >= 0)
@@ -1080,7 +1112,7 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
       double s = 0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
-      hx[(size_t)P.col_dt * ld + 2 * c + i] += s;
+      hx[(size_t)P.col_dt * ld + 2 * c + i] = s;
     }
 }
 
