@@ -8,13 +8,34 @@ import sys
 
 def main():
     d = sys.argv[1]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+    which = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "avg" else -3
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     name = lambda r: r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
     # a frame starts at every hist_kernel
     starts = [i for i, r in enumerate(rows) if name(r) == "hist_kernel"]
+    if len(sys.argv) > 2 and sys.argv[2] == "avg":
+        # sequential schedule: average device-side spans over the frames (first / last few dropped)
+        fe, up, tot = [], [], []
+        for a, b in zip(starts[5:-3], starts[6:-2]):
+            fr = rows[a:b]
+            nm = [name(r) for r in fr]
+            if "jacobian_kernel" not in nm or "ekf_commit_kernel" not in nm:
+                continue
+            j = nm.index("jacobian_kernel")
+            c = len(nm) - 1 - nm[::-1].index("ekf_commit_kernel")
+            r_end = max(i for i, x in enumerate(nm) if x == "ransac_select_kernel")
+            t0 = int(fr[0]["Start_Timestamp"])
+            fe.append((int(fr[r_end]["End_Timestamp"]) - t0) / 1e3)
+            # the update chain: from the copy in front of the jacobian kernel to the end of the commit kernel
+            js = int(fr[j - 1]["Start_Timestamp"]) if nm[j - 1].startswith("__amd_rocclr_copy") else int(fr[j]["Start_Timestamp"])
+            up.append((int(fr[c]["End_Timestamp"]) - js) / 1e3)
+            tot.append((int(fr[c]["End_Timestamp"]) - t0) / 1e3)
+        import statistics
+        print(f"frames {len(up)}: front-end span {statistics.mean(fe):.1f} us, update chain span {statistics.mean(up):.1f} us "
+              f"(median {statistics.median(up):.1f}), hist..commit {statistics.mean(tot):.1f} us")
+        return
     a = starts[which]
     b = starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
     t0 = int(rows[a]["Start_Timestamp"])
