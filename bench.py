@@ -228,8 +228,8 @@ def main():
         c = c or ctx
         c.feed_staged((i + 1) & 1)
         out = c.perform_matching(pts, pts)
+        c.cov_rollback()   # (before the Jacobians: their launch also gathers the covariance blocks of the update)
         c.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
-        c.cov_rollback()
         rc, dx, acc, nr = c.msckf_update_resident(N_STATE, SIGMA2)
         if rc != 0:
             raise RuntimeError("EKF update rejected inside the benchmark")
@@ -241,8 +241,8 @@ def main():
         # (enqueueing the front-end between the Jacobians and the rest of the update — plv_perform_matching_launch /
         # _wait — was measured 5-9 % slower than this order on the same box: the update chain is the long one and
         # every launch in front of it delays it)
-        uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)   # update of frame i: enqueue only
-        uctx.cov_rollback()
+        uctx.cov_rollback()                                       # update of frame i: enqueue only
+        uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
         uctx.msckf_update_resident_launch(SIGMA2)
         ctx.feed_staged((i + 1) & 1)                              # front-end of frame i+1 meanwhile
         out = ctx.perform_matching(pts, pts)

@@ -5,6 +5,8 @@
 #include <vector>
 
 #include "jacobian_kernels.hpp"
+#include "nullspace_core.hpp"
+#include "update_kernels.hpp"
 #include "update_state.hpp"
 
 using namespace plv;
@@ -147,7 +149,7 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
 
 // builds the batch into us->bHf ([Hf | Hx | res]) and us->brows on the device
 int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
-                    const int *col_to_state, int ld) {
+                    const int *col_to_state, int ld, bool project) {
   TRY(check_views(st, tr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int F = tr->n_feat;
@@ -162,7 +164,25 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;
   P.res = P.Hx + nHx;
-  TRY(launch_jacobians(ctx, P));
+  us->b_projected = false;
+  us->b_gather_token = 0;
+  if (project) {
+    // resident update path: build + project in one launch; when a covariance of matching size is resident its gathers ride along
+    bool can_gather = ctx->cov_n > 0;
+    for (int j = 0; j < k && can_gather; ++j) can_gather = col_to_state[j] >= 0 && col_to_state[j] < ctx->cov_n;
+    GatherArgs g{};
+    int gblocks = 0;
+    if (can_gather) {
+      const int n = ctx->cov_n;
+      TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
+      gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
+    }
+    TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    us->b_projected = true;
+    us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
+  } else {
+    TRY(launch_jacobians(ctx, P));
+  }
   us->bF = F;
   us->bfdim = 3;
   us->bk = k;
@@ -206,7 +226,7 @@ int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const p
   if (!ctx) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld));
+  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld, true));
   us->b_single_use = true;  // consumed in place by the next plv_msckf_update_resident
   return PLV_OK;            // stream-ordered; no host synchronisation
 }
@@ -216,7 +236,7 @@ int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks
   if (!ctx || !rows || !Hf || !Hx || !res) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld));
+  TRY(build_on_device(ctx, us, st, tr, k, col_to_state, ld, false));  // host out: the un-projected systems
   us->b_single_use = false;
   const int F = tr->n_feat;
   const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
@@ -386,6 +406,8 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{};
   TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P));
+  us->b_projected = false;
+  us->b_gather_token = 0;
   PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();

@@ -42,6 +42,9 @@ struct CpiParams {  // device pointers; State::cpis as a table sorted by time + 
 int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, double *d_R, double *d_p, unsigned char *d_ok);
 
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
+struct GatherArgs;
+// the batch built AND null-space projected in one launch (resident update path); g != null: the covariance gathers ride along
+int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks);
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
                              double *d_lines, unsigned char *d_ok);

@@ -1,0 +1,114 @@
+// nullspace_core.hpp — the Givens null-space projection of one feature's [Hf | Hx | res] block held row-major in LDS, shared by
+// nullspace_kernel (update_kernels.hip) and the fused jacobian_nullspace_kernel (jacobian_kernels.hip); plus the dense covariance
+// gathers that ride on either launch.   REF: PL-VIWO/src/state/StateHelper.cpp:616-651
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace plv {
+
+// Same rotation on the latency-critical path of the nullspace kernel: the chain of rows-1 dependent
+// rotations per pivot column is what bounds that kernel, and an IEEE divide + sqrt + divide is ~42
+// dependent fp64 instructions.  v_rcp_f64 / v_rsq_f64 + two Newton steps each give the same values
+// to within 1-2 ulp in ~17 (the rotation stays orthonormal to rounding: c^2 + s^2 = 1 +- 2 eps).
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-x * r, r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+__device__ __forceinline__ void make_givens_fast(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0.0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0.0 ? 1.0 : -1.0;
+  } else if (fabs(p) > fabs(q)) {
+    const double t = q * rcp_newton(p);
+    double iu = rsqrt_newton(fma(t, t, 1.0));
+    if (p < 0.0) iu = -iu;
+    c = iu;
+    s = -t * c;
+  } else {
+    const double t = p * rcp_newton(q);
+    double iu = rsqrt_newton(fma(t, t, 1.0));
+    if (q < 0.0) iu = -iu;
+    s = -iu;
+    c = -t * s;
+  }
+}
+
+// Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load goes
+// through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols] (k x k), inv[state] =
+// position of that state in cols or -1.  256 threads per block; runs as its own launch or as extra
+// blocks of nullspace_kernel (independent work, one launch less on the update stream).
+struct GatherArgs {
+  const double *P;
+  int ldp, n;
+  const int *cols;
+  int k;
+  double *Pc, *Ps;
+  int *inv;
+};
+__device__ __forceinline__ void gather_cov_block(const GatherArgs &g, int block) {
+  const int idx = block * 256 + threadIdx.x;
+  const int n = g.n, k = g.k;
+  if (idx < k * n) {
+    const int kk = idx / n, j = idx - kk * n;
+    g.Pc[idx] = g.P[(size_t)g.cols[kk] * g.ldp + j];  // P symmetric: row cols[kk] == column cols[kk]
+  }
+  if (idx < k * k) {
+    const int kk = idx / k, c = idx - kk * k;
+    g.Ps[idx] = g.P[(size_t)g.cols[kk] * g.ldp + g.cols[c]];
+  }
+  if (idx < n) {
+    int pos = -1;
+    for (int q = 0; q < k; ++q) pos = (g.cols[q] == idx) ? q : pos;
+    g.inv[idx] = pos;
+  }
+}
+
+// X [rows][ncol] row-major in LDS, piv [rows] scratch.  For pivot column n the rotation sequence m = rows-1 .. n+1 is the
+// reference's; (c, s) are recomputed by every thread from a read-only copy of the pivot column, which reproduces bit-for-bit
+// what the column's owner computes, so threads never wait on each other inside a pass.  Called by the whole workgroup.
+__device__ __forceinline__ void nullspace_rotate(double *X, double *piv, int rows, int ncol, int fdim) {
+  for (int n = 0; n < fdim; ++n) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) piv[i] = X[i * ncol + n];
+    __syncthreads();
+    for (int j = n + threadIdx.x; j < ncol; j += blockDim.x) {
+      double carry_p = piv[rows - 1];
+      double carry_o = X[(rows - 1) * ncol + j];
+      for (int m = rows - 1; m > n; --m) {
+        const double p = piv[m - 1];
+        const double q = carry_p;
+        const double up = X[(m - 1) * ncol + j];
+        if (q == 0.0) {  // REF: `if (A(m, n) == 0.0) continue;`
+          X[m * ncol + j] = carry_o;
+          carry_p = p;
+          carry_o = up;
+          continue;
+        }
+        double c, s;
+        make_givens_fast(p, q, c, s);
+        carry_p = c * p - s * q;
+        const double nu = c * up - s * carry_o;
+        const double nl = s * up + c * carry_o;
+        X[m * ncol + j] = (j == n) ? 0.0 : nl;  // REF: `A(m, n) = 0;`
+        carry_o = nu;
+      }
+      X[n * ncol + j] = carry_o;
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace plv

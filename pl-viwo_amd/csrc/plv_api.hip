@@ -263,6 +263,7 @@ int plv_cov_upload(plv_ctx *ctx, const double *P, int n, int ldp) {
   TRY(ctx->d_P.reserve((size_t)n * n * 8));
   TRY(upload_mat(ctx, ctx->d_P.as<double>(), P, n, n, ldp));
   ctx->cov_n = n;
+  ++ctx->gather_stamp;
   return sync(ctx);
 }
 int plv_cov_download(plv_ctx *ctx, double *P, int n, int ldp) {
@@ -289,6 +290,7 @@ int plv_cov_rollback(plv_ctx *ctx) {
   if (ctx->cov_n < 1 || !us->covck.p) return PLV_E_BADARG;
   size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
   PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, us->covck.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  ++ctx->gather_stamp;
   return PLV_OK;  // ordered on the ctx stream; no host sync needed
 }
 
@@ -322,6 +324,7 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
       return PLV_E_BADARG;
     }
   auto *us = ustate(ctx);
+  ++ctx->gather_stamp;  // this call rewrites the covariance (and gathers for its own columns)
   if (P) {
     if (ldp < n) return PLV_E_BADARG;
     TRY(ctx->d_P.reserve((size_t)n * n * 8));
@@ -475,6 +478,7 @@ int plv_chi2_batch(plv_ctx *ctx, const double *P, int n, int ldp, int F, int k, 
   if (!Hx || !res || !col_to_state || !chi2) return PLV_E_BADARG;
   TRY(check_batch(F, 1, k, ld, rows));
   auto *us = ustate(ctx);
+  ++ctx->gather_stamp;  // (gathers for its own columns; may replace the covariance)
   if (P) {
     TRY(ctx->d_P.reserve((size_t)n * n * 8));
     TRY(upload_mat(ctx, ctx->d_P.as<double>(), P, n, n, ldp));
@@ -541,6 +545,8 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   for (int f = 0; f < F; ++f) us->bmaxrows = rows[f] > us->bmaxrows ? rows[f] : us->bmaxrows;
   us->b_on_device_rows = false;
   us->b_single_use = false;
+  us->b_projected = false;
+  us->b_gather_token = 0;
   return sync(ctx);
 }
 
@@ -591,11 +597,20 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int *d_acc_rows;
   TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
 
+  // a batch from plv_build_jacobians_resident arrives projected, with the covariance gathers done on its launch: they stand as
+  // long as nothing has touched the covariance or the gathered blocks since (plv_ctx::gather_stamp)
+  const bool projected = us->b_projected;
+  const bool gathers_valid = projected && us->b_gather_token != 0 && us->b_gather_token == ctx->gather_stamp;
+  us->b_gather_token = 0;
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
   auto enqueue = [&]() -> int {
-  // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
-  TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
+  if (!projected) {
+    // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
+    TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
+  } else if (!gathers_valid) {
+    TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, us->bcols.as<int>(), k));
+  }
   Chi2Args a{};
   a.P = ctx->d_P.as<double>();
   a.ldp = n;
@@ -660,7 +675,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     return PLV_OK;
   };
   if (us->graph_mode && !ctx->prof.on) {
-    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, F, fdim, k, ld, n, mp_max,
+    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, F, fdim + 16 * (projected ? 1 : 0) + 32 * (gathers_valid ? 1 : 0), k, ld, n, mp_max,
                                        sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch().load()};
     if (us->gexec && key == us->gkey) {
       PLV_HIP_CHECK(hipGraphLaunch(us->gexec, ctx->stream));
@@ -701,6 +716,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   } else {
     TRY(enqueue());
   }
+  ++ctx->gather_stamp;  // the update rewrites the covariance
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
   return PLV_OK;
 }

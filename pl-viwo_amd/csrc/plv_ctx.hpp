@@ -166,6 +166,9 @@ struct plv_ctx {
 
   // ---- update side
   int cov_n = 0;          // dimension of the device-resident covariance (0 = none)
+  // Bumped whenever the resident covariance changes OR the gathered blocks (d_Pc / d_Ps / d_inv) are rewritten: a batch whose
+  // covariance gathers rode on an earlier launch (plv_build_jacobians_resident) may only reuse them while the stamp stands.
+  unsigned long long gather_stamp = 1;
   plv::DevBuf d_P;        // n x n col-major, ld = n
   plv::DevBuf d_P2;       // second covariance buffer: state augmentation / marginalisation write here, then swap
   plv::DevBuf d_H, d_res, d_cols, d_Rdiag, d_dx, d_flag;

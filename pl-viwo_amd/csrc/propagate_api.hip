@@ -514,6 +514,7 @@ int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *nz, int
     hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, ctx->stream, A);
   }
   if (n > 0) {
+    ++ctx->gather_stamp;  // EKFPropagation rewrites the covariance
     const int blocks = (n * 15 + 255) / 256;
     {
       ProfScope ps(ctx->prof, "ekf_prop_strip_kernel", ctx->stream);
@@ -666,6 +667,7 @@ int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size) {
   ctx->prof.collect();
   std::swap(ctx->d_P, ctx->d_P2);
   ctx->cov_n = m;
+  ++ctx->gather_stamp;
   return PLV_OK;
 }
 

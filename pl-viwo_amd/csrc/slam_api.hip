@@ -167,6 +167,7 @@ int plv_cov_marginalize(plv_ctx *ctx, int id, int size) {
   PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   std::swap(ctx->d_P, ctx->d_P2);
   ctx->cov_n = m;
+  ++ctx->gather_stamp;
   return PLV_OK;
 }
 
@@ -241,6 +242,7 @@ int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf,
   if (flag != 0) return PLV_OK;
   std::swap(ctx->d_P, ctx->d_P2);  // the old covariance stays intact in d_P2 until the update below succeeded
   ctx->cov_n = n2;
+  ++ctx->gather_stamp;
   // ---- EKFUpdate with the updating rows; failure reverts the initialisation (:430-435)
   if (mup > 0) {
     const int rc = plv_ekf_update(ctx, nullptr, n2, n2, hHx.data() + f, mup, k, ld, col_to_state, hres.data() + f, nullptr, dx);

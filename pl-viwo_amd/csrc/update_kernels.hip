@@ -19,6 +19,7 @@
 #include "plv_ctx.hpp"
 #include "blocked_chol.hpp"
 #include "mfma_tile.hpp"
+#include "nullspace_core.hpp"
 #include "update_kernels.hpp"
 
 namespace plv {
@@ -82,76 +83,6 @@ __device__ __forceinline__ void make_givens(double p, double q, double &c, doubl
   }
 }
 
-// Same rotation on the latency-critical path of the nullspace kernel: the chain of rows-1 dependent
-// rotations per pivot column is what bounds that kernel, and an IEEE divide + sqrt + divide is ~42
-// dependent fp64 instructions.  v_rcp_f64 / v_rsq_f64 + two Newton steps each give the same values
-// to within 1-2 ulp in ~17 (the rotation stays orthonormal to rounding: c^2 + s^2 = 1 +- 2 eps).
-__device__ __forceinline__ double rcp_newton(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-__device__ __forceinline__ double rsqrt_newton(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  e = fma(-x * r, r, 1.0);
-  return fma(0.5 * r, e, r);
-}
-__device__ __forceinline__ void make_givens_fast(double p, double q, double &c, double &s) {
-  if (q == 0.0) {
-    c = p < 0.0 ? -1.0 : 1.0;
-    s = 0.0;
-  } else if (p == 0.0) {
-    c = 0.0;
-    s = q < 0.0 ? 1.0 : -1.0;
-  } else if (fabs(p) > fabs(q)) {
-    const double t = q * rcp_newton(p);
-    double iu = rsqrt_newton(fma(t, t, 1.0));
-    if (p < 0.0) iu = -iu;
-    c = iu;
-    s = -t * c;
-  } else {
-    const double t = p * rcp_newton(q);
-    double iu = rsqrt_newton(fma(t, t, 1.0));
-    if (q < 0.0) iu = -iu;
-    s = -iu;
-    c = -t * s;
-  }
-}
-
-// Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load goes
-// through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols] (k x k), inv[state] =
-// position of that state in cols or -1.  256 threads per block; runs as its own launch or as extra
-// blocks of nullspace_kernel (independent work, one launch less on the update stream).
-struct GatherArgs {
-  const double *P;
-  int ldp, n;
-  const int *cols;
-  int k;
-  double *Pc, *Ps;
-  int *inv;
-};
-__device__ __forceinline__ void gather_cov_block(const GatherArgs &g, int block) {
-  const int idx = block * 256 + threadIdx.x;
-  const int n = g.n, k = g.k;
-  if (idx < k * n) {
-    const int kk = idx / n, j = idx - kk * n;
-    g.Pc[idx] = g.P[(size_t)g.cols[kk] * g.ldp + j];  // P symmetric: row cols[kk] == column cols[kk]
-  }
-  if (idx < k * k) {
-    const int kk = idx / k, c = idx - kk * k;
-    g.Ps[idx] = g.P[(size_t)g.cols[kk] * g.ldp + g.cols[c]];
-  }
-  if (idx < n) {
-    int pos = -1;
-    for (int q = 0; q < k; ++q) pos = (g.cols[q] == idx) ? q : pos;
-    g.inv[idx] = pos;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // K11: one workgroup per feature.  X = [Hf | Hx | res] (rows x ncol) staged row-major in LDS,
 // one thread per column.  For pivot column n the rotation sequence m = rows-1 .. n+1 is the
@@ -190,35 +121,7 @@ __global__ void __launch_bounds__(256) nullspace_kernel(int fdim, int k, int ld,
         if (i0 + u < rows) X[(i0 + u) * ncol + j] = v[u];
     }
   }
-  for (int n = 0; n < fdim; ++n) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) piv[i] = X[i * ncol + n];
-    __syncthreads();
-    for (int j = n + threadIdx.x; j < ncol; j += blockDim.x) {
-      double carry_p = piv[rows - 1];
-      double carry_o = X[(rows - 1) * ncol + j];
-      for (int m = rows - 1; m > n; --m) {
-        const double p = piv[m - 1];
-        const double q = carry_p;
-        const double up = X[(m - 1) * ncol + j];
-        if (q == 0.0) {  // REF: `if (A(m, n) == 0.0) continue;`
-          X[m * ncol + j] = carry_o;
-          carry_p = p;
-          carry_o = up;
-          continue;
-        }
-        double c, s;
-        make_givens_fast(p, q, c, s);
-        carry_p = c * p - s * q;
-        const double nu = c * up - s * carry_o;
-        const double nl = s * up + c * carry_o;
-        X[m * ncol + j] = (j == n) ? 0.0 : nl;  // REF: `A(m, n) = 0;`
-        carry_o = nu;
-      }
-      X[n * ncol + j] = carry_o;
-    }
-  }
-  __syncthreads();
+  nullspace_rotate(X, piv, rows, ncol, fdim);
   // write back: Hf whole (upper-triangular now), Hx / res shifted up by `shift` rows (= fdim for the nullspace
   // projection; 0 keeps the initialising rows as well: StateHelper::initialize, StateHelper.cpp:391-405)
   const int mp = rows - shift;
@@ -660,12 +563,13 @@ __global__ void __launch_bounds__(256) ekf_apply_kernel(const double *__restrict
 // ========================================================================================== launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-static int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k, GatherArgs &g) {
+int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k, GatherArgs &g) {
   int rc;
   if ((rc = ctx->d_Pc.reserve((size_t)k * n * 8)) || (rc = ctx->d_Ps.reserve((size_t)k * k * 8)) ||
       (rc = ctx->d_inv.reserve((size_t)n * 4)))
     return rc;
   g = GatherArgs{d_P, ldp, n, d_cols, k, ctx->d_Pc.as<double>(), ctx->d_Ps.as<double>(), ctx->d_inv.as<int>()};
+  ++ctx->gather_stamp;  // the gathered blocks are about to be rewritten
   return PLV_OK;
 }
 

@@ -31,6 +31,8 @@ struct Chi2Args {
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
                      double *d_res, const double *d_P = nullptr, int n = 0, int ldp = 0, const int *d_cols = nullptr,
                      int shift = -1 /* rows dropped from Hx / res on write-back; -1 = fdim */);
+struct GatherArgs;
+int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k, GatherArgs &g);
 int launch_gather_cov(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp);
 int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,

@@ -12,6 +12,8 @@ struct plv_ctx_update_state {
   int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
   bool b_on_device_rows = false;  // rows[] produced on the device (plv_build_jacobians_resident)
   bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy
+  bool b_projected = false;       // the batch is already null-space projected (jacobian_nullspace_kernel)
+  unsigned long long b_gather_token = 0;  // plv_ctx::gather_stamp right after the gathers that rode on the batch's launch (0: none)
   std::vector<int> brows_host;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a

@@ -142,3 +142,37 @@ def test_cpi_poses_parity_and_use(pkg):
     _, _, _, res_poly = ctx.build_jacobians(st, tr_poly, cols, 30)
     assert np.abs(res).max() < 4.0 / 1.5 * 1.5 and np.abs(res).max() <= np.abs(res_poly).max() + 1e-9
     ctx.close()
+
+
+def test_fused_build_project_paths_agree(pkg, oracle):
+    """plv_build_jacobians_resident builds AND projects in one launch and lets the update's covariance gathers ride on it; the
+    gathers are only reused while nothing has touched the covariance since.  Three routes, one result."""
+    jo = oracle_lib.load_jac(pkg)
+    sc = synth.vio_scene(F=50, M=15, noise_px=0.4, seed=21)
+    st, tr = synth.scene_views(pkg, sc)
+    n = sc["n_state"]
+    P = synth.spd_cov(n, seed=4) * 1e-4
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    cols = ctx.jacobian_columns(st, tr)
+    s2 = st.c.sigma_pix ** 2
+    # (a) host systems -> the general update entry point (separate nullspace launch)
+    rows, Hf, Hx, res = ctx.build_jacobians(st, tr, cols, 30)
+    rc_a, P_a, dx_a, acc_a, nr_a = ctx.msckf_update(P, rows, Hf, Hx, res, cols, s2)
+    rc_o, P_o, dx_o, acc_o, _ = oracle.msckf_update(P, *jo.build_jacobians(st, tr, cols, 30), cols, s2, synth.q95_table())
+    assert rc_a == rc_o == 0 and np.array_equal(acc_a, acc_o) and acc_a.sum() > 20
+    # (b) resident, gathers reused
+    ctx.cov_upload(P)
+    ctx.build_jacobians_resident(st, tr, cols, 30)
+    rc_b, dx_b, acc_b, nr_b = ctx.msckf_update_resident(n, s2)
+    P_b = ctx.cov_download(n)
+    # (c) resident, covariance replaced between the build and the update: the gathers must be redone
+    ctx.cov_upload(P * 0.5)
+    ctx.build_jacobians_resident(st, tr, cols, 30)
+    ctx.cov_upload(P)
+    rc_c, dx_c, acc_c, nr_c = ctx.msckf_update_resident(n, s2)
+    P_c = ctx.cov_download(n)
+    for rc, dx, acc, nr, Pn in ((rc_b, dx_b, acc_b, nr_b, P_b), (rc_c, dx_c, acc_c, nr_c, P_c)):
+        assert rc == 0 and np.array_equal(acc, acc_a) and nr == nr_a
+        assert np.abs(dx - dx_a).max() <= 1e-12 * max(1.0, np.abs(dx_a).max()) and np.abs(Pn - P_a).max() <= 1e-12 * np.abs(P_a).max()
+    assert np.abs(P_a - P_o).max() <= 1e-8 * np.abs(P_o).max()
+    ctx.close()

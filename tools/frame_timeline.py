@@ -21,16 +21,18 @@ def main():
         for a, b in zip(starts[5:-3], starts[6:-2]):
             fr = rows[a:b]
             nm = [name(r) for r in fr]
-            if "jacobian_kernel" not in nm or "ekf_commit_kernel" not in nm:
+            jn = "jacobian_nullspace_kernel" if "jacobian_nullspace_kernel" in nm else "jacobian_kernel"
+            if jn not in nm or "ekf_commit_kernel" not in nm:
                 continue
-            j = nm.index("jacobian_kernel")
+            j = nm.index(jn)
             c = len(nm) - 1 - nm[::-1].index("ekf_commit_kernel")
             r_end = max(i for i, x in enumerate(nm) if x == "ransac_select_kernel")
             t0 = int(fr[0]["Start_Timestamp"])
             fe.append((int(fr[r_end]["End_Timestamp"]) - t0) / 1e3)
             # the update chain: from the copy in front of the jacobian kernel to the end of the commit kernel
-            js = int(fr[j - 1]["Start_Timestamp"]) if nm[j - 1].startswith("__amd_rocclr_copy") else int(fr[j]["Start_Timestamp"])
-            up.append((int(fr[c]["End_Timestamp"]) - js) / 1e3)
+            js = int(fr[j]["Start_Timestamp"])
+            busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in fr[j:c + 1]) / 1e3
+            up.append(busy)   # device-busy time of the chain (Jacobians .. commit), host-side gaps excluded
             tot.append((int(fr[c]["End_Timestamp"]) - t0) / 1e3)
         import statistics
         print(f"frames {len(up)}: front-end span {statistics.mean(fe):.1f} us, update chain span {statistics.mean(up):.1f} us "
