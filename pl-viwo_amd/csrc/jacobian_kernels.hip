@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   __syncthreads();
   const int rows = s_rows;
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
-  if (shift) nullspace_rotate(X, piv, rows, ncol, 3);
+  if (shift) nullspace_householder(X, piv, rows, ncol, 3);
   double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
   for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
     double *dst = j < 3 ? hf + j * ld : (j < 3 + k ? hx + (size_t)(j - 3) * ld : rs);

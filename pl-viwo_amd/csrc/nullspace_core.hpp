@@ -111,4 +111,40 @@ __device__ __forceinline__ void nullspace_rotate(double *X, double *piv, int row
   __syncthreads();
 }
 
+// The same projection by three Householder reflections instead of fdim * (rows - 1) dependent Givens rotations.  Q^T [Hf] = [R; 0]
+// either way, so rows fdim.. of [Hx | res] span the same left null space of Hf: every quantity the update forms from them (the
+// norm of the projected residual, chi2 = r'^T S^-1 r', the Gram matrix H'^T H' of the stacked system and with it the compressed
+// R up to row signs, dx, P) is invariant to the choice of orthonormal basis and agrees with the Givens route to rounding.  The
+// dependent chain drops from ~87 rotations (rcp + rsq + Newton each) to three passes of ~2 * rows fused multiply-adds per
+// column: 14 us -> ~1 us in the fused kernel.  (plv_nullspace_batch, whose OUTPUT is the projected block itself, keeps the
+// reference's rotation order.)
+__device__ __forceinline__ void nullspace_householder(double *X, double *piv, int rows, int ncol, int fdim) {
+  for (int n = 0; n < fdim; ++n) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) piv[i] = X[i * ncol + n];
+    __syncthreads();
+    double nrm2 = 0.0;  // every thread forms the reflector from the shared copy of column n: the same bits everywhere
+    for (int i = n; i < rows; ++i) nrm2 = fma(piv[i], piv[i], nrm2);
+    if (nrm2 == 0.0) continue;  // (uniform) nothing to eliminate
+    const double x0 = piv[n];
+    const double nrm = sqrt(nrm2);
+    const double alpha = x0 >= 0.0 ? -nrm : nrm;  // v = x - alpha e1 without cancellation
+    const double v0 = x0 - alpha;
+    const double tau = 1.0 / (nrm2 - alpha * x0);  // 2 / v^T v
+    for (int j = n + threadIdx.x; j < ncol; j += blockDim.x) {
+      if (j == n) {
+        X[n * ncol + n] = alpha;
+        for (int i = n + 1; i < rows; ++i) X[i * ncol + n] = 0.0;
+        continue;
+      }
+      double w = v0 * X[n * ncol + j];
+      for (int i = n + 1; i < rows; ++i) w = fma(piv[i], X[i * ncol + j], w);
+      w *= tau;
+      X[n * ncol + j] = fma(-v0, w, X[n * ncol + j]);
+      for (int i = n + 1; i < rows; ++i) X[i * ncol + j] = fma(-piv[i], w, X[i * ncol + j]);
+    }
+  }
+  __syncthreads();
+}
+
 }  // namespace plv

@@ -173,6 +173,8 @@ def test_fused_build_project_paths_agree(pkg, oracle):
     P_c = ctx.cov_download(n)
     for rc, dx, acc, nr, Pn in ((rc_b, dx_b, acc_b, nr_b, P_b), (rc_c, dx_c, acc_c, nr_c, P_c)):
         assert rc == 0 and np.array_equal(acc, acc_a) and nr == nr_a
-        assert np.abs(dx - dx_a).max() <= 1e-12 * max(1.0, np.abs(dx_a).max()) and np.abs(Pn - P_a).max() <= 1e-12 * np.abs(P_a).max()
-    assert np.abs(P_a - P_o).max() <= 1e-8 * np.abs(P_o).max()
+        # (the fused launch projects with Householder reflections, route (a) with the reference's Givens order: same null space,
+        #  another orthonormal basis of it)
+        assert np.abs(dx - dx_a).max() <= 1e-9 * max(1.0, np.abs(dx_a).max()) and np.abs(Pn - P_a).max() <= 1e-9 * np.abs(P_a).max()
+    assert np.abs(P_a - P_o).max() <= 1e-8 * np.abs(P_o).max() and np.abs(P_b - P_c).max() <= 1e-13 * np.abs(P_b).max()
     ctx.close()
