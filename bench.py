@@ -154,8 +154,8 @@ def reduce_max(elapsed, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
