@@ -363,9 +363,9 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   float *d_p0 = (float *)(dp_ + o_p0), *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
   int *d_it = (int *)(dp_ + o_it);
   uint8_t *d_mk = (uint8_t *)(dp_ + o_mk), *d_st = (uint8_t *)(dp_ + o_st);
+  const CamK camk = cam_of(ctx);
   TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, d_p0, d_p1, d_st, d_it, ctx->cfg.win_size, ctx->cfg.lk_max_iters,
-                ctx->cfg.lk_eps));
-  TRY(launch_undistort2(ctx, cam_of(ctx), n, d_p0, d_p1, d_n0, d_n1));
+                ctx->cfg.lk_eps, &camk, d_n0, d_n1));  // (+ the undistortion of both point sets on the same launch)
   const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
                     d_mk, s->info.as<int>()));

@@ -141,11 +141,14 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict_
 #define LK_JT 32                // search tile edge
 #define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
+__device__ __forceinline__ void undistort_radtan(const double *K, float u, float v, float &xn, float &yn);
+
 // One wavefront (= one 64-thread workgroup) per point; all pyramid levels, coarse to fine.
 // Lane l owns window pixels l, l+64, l+128, l+192 (< win*win).
 __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
                                                 float *__restrict__ pts1, uint8_t *__restrict__ status,
-                                                int *__restrict__ iters_out, int win, int max_iters, float eps) {
+                                                int *__restrict__ iters_out, int win, int max_iters, float eps, CamK K,
+                                                float *__restrict__ n0, float *__restrict__ n1) {
   __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
   __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
   __shared__ uint8_t jtile[LK_JT][LK_JT];
@@ -325,6 +328,15 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
     pts1[2 * pt + 1] = nexty;
     status[pt] = (uint8_t)st;
     if (iters_out) iters_out[pt] = iters;
+  }
+  // perform_matching undistorts both point sets right after the flow (TrackKLT.cpp:864-865): two lanes do it here, the
+  // separate launch is only kept for plv_undistort
+  if (n0 && lane < 2) {
+    float xn, yn;
+    undistort_radtan(K.v, lane == 0 ? px0 : nextx, lane == 0 ? py0 : nexty, xn, yn);
+    float *dst = lane == 0 ? n0 : n1;
+    dst[2 * pt] = xn;
+    dst[2 * pt + 1] = yn;
   }
 }
 
@@ -889,14 +901,15 @@ int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *
 }
 
 int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
-              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps) {
+              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps, const CamK *K, float *d_n0, float *d_n1) {
   if (win > LK_MAXWIN || win < 3 || (win & 1) == 0) {
     set_last_error("lk: window %d unsupported (odd, <= %d)", win, LK_MAXWIN);
     return PLV_E_CAPACITY;
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
+  CamK none{};
   hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, ctx->stream, prev, cur, n, d_pts0, d_pts1, d_status, d_iters, win,
-                     max_iters, eps);
+                     max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

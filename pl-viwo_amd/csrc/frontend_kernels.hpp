@@ -23,7 +23,8 @@ int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int 
 int launch_pyramid(plv_ctx *ctx, const PyrDesc &p);
 int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *d_dst, int dw, int dh);
 int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
-              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps);
+              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps,
+              const CamK *K = nullptr, float *d_n0 = nullptr, float *d_n1 = nullptr);
 int launch_undistort(plv_ctx *ctx, const CamK &K, int n, const float *d_uv, float *d_xy);
 int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, const float *d_uv1, float *d_xy0,
                       float *d_xy1);
