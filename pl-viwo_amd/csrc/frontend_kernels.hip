@@ -135,6 +135,83 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict_
   }
 }
 
+// Two pyramid levels per launch: a workgroup owns a 16x16 tile of level l+2 and the 32x32 tile of level l+1 under it.  It stages
+// the 73x73 footprint of level l, builds the 35x35 piece of level l+1 that the upper tile needs (rounded to u8 exactly as the
+// single-level kernel writes it, so every value is the one pyrdown_kernel produces; the halo rows are recomputed by the
+// neighbours) and filters again.  Halves the launches of cv::buildOpticalFlowPyramid's chain.
+#define PD2_T 16
+#define PD2_M (2 * PD2_T + 3)   // 35: level l+1 piece
+#define PD2_S (2 * PD2_M + 3)   // 73: level l footprint
+__global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ mid,
+                                                       int mw, int mh, uint8_t *__restrict__ dst, int dw, int dh) {
+  __shared__ uint8_t t0[PD2_S][PD2_S + 3];
+  __shared__ int h0[PD2_S][PD2_M + 1];
+  __shared__ uint8_t t1[PD2_M][PD2_M + 1];
+  __shared__ int h1[PD2_M][PD2_T + 1];
+  const int ox = blockIdx.x * PD2_T, oy = blockIdx.y * PD2_T;   // level l+2 tile origin
+  // level l+1 rows / columns held in t1: [my0, my0 + PD2_M), clamped at 0 (reads below 0 reflect to 1, 2: inside)
+  const int my0 = max(2 * oy - 2, 0), mx0 = max(2 * ox - 2, 0);
+  const int sy0 = max(2 * my0 - 2, 0), sx0 = max(2 * mx0 - 2, 0);  // level l origin of t0, same rule
+  for (int i = threadIdx.x; i < PD2_S * PD2_S; i += 256) {
+    const int ty = i / PD2_S, tx = i - ty * PD2_S;
+    const int Y = min(sy0 + ty, sh - 1), X = min(sx0 + tx, sw - 1);
+    t0[ty][tx] = src[(size_t)Y * sw + X];
+  }
+  __syncthreads();
+  // level l -> l+1, horizontal then vertical; t1[y][x] = level l+1 pixel (my0 + y, mx0 + x)
+  for (int i = threadIdx.x; i < PD2_S * PD2_M; i += 256) {
+    const int ty = i / PD2_M, x = i - ty * PD2_M;
+    const int X = mx0 + x;
+    int v = 0;
+    if (X < mw && sy0 + ty < sh) {
+      const uint8_t *r = t0[ty];
+      const int c = 2 * X;
+      v = r[reflect101(c - 2, sw) - sx0] + 4 * r[reflect101(c - 1, sw) - sx0] + 6 * r[reflect101(c, sw) - sx0] +
+          4 * r[reflect101(c + 1, sw) - sx0] + r[reflect101(c + 2, sw) - sx0];
+    }
+    h0[ty][x] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD2_M * PD2_M; i += 256) {
+    const int y = i / PD2_M, x = i - y * PD2_M;
+    const int Y = my0 + y, X = mx0 + x;
+    if (Y < mh && X < mw) {
+      const int c = 2 * Y;
+      const int s = h0[reflect101(c - 2, sh) - sy0][x] + 4 * h0[reflect101(c - 1, sh) - sy0][x] + 6 * h0[reflect101(c, sh) - sy0][x] +
+                    4 * h0[reflect101(c + 1, sh) - sy0][x] + h0[reflect101(c + 2, sh) - sy0][x];
+      const uint8_t px = (uint8_t)((s + 128) >> 8);
+      t1[y][x] = px;
+      // this workgroup owns level l+1 rows [2 oy, 2 oy + 32) x columns [2 ox, 2 ox + 32)
+      if (Y >= 2 * oy && Y < 2 * oy + 2 * PD2_T && X >= 2 * ox && X < 2 * ox + 2 * PD2_T) mid[(size_t)Y * mw + X] = px;
+    }
+  }
+  __syncthreads();
+  // level l+1 -> l+2
+  for (int i = threadIdx.x; i < PD2_M * PD2_T; i += 256) {
+    const int ty = i / PD2_T, x = i - ty * PD2_T;
+    const int X = ox + x;
+    int v = 0;
+    if (X < dw && my0 + ty < mh) {
+      const uint8_t *r = t1[ty];
+      const int c = 2 * X;
+      v = r[reflect101(c - 2, mw) - mx0] + 4 * r[reflect101(c - 1, mw) - mx0] + 6 * r[reflect101(c, mw) - mx0] +
+          4 * r[reflect101(c + 1, mw) - mx0] + r[reflect101(c + 2, mw) - mx0];
+    }
+    h1[ty][x] = v;
+  }
+  __syncthreads();
+  {
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int X = ox + x, Y = oy + y;
+    if (X < dw && Y < dh) {
+      const int c = 2 * Y;
+      const int s = h1[reflect101(c - 2, mh) - my0][x] + 4 * h1[reflect101(c - 1, mh) - my0][x] + 6 * h1[reflect101(c, mh) - my0][x] +
+                    4 * h1[reflect101(c + 1, mh) - my0][x] + h1[reflect101(c + 2, mh) - my0][x];
+      dst[(size_t)Y * dw + X] = (uint8_t)((s + 128) >> 8);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K3
 #define LK_MAXWIN 15
 #define LK_TT (LK_MAXWIN + 3)   // template footprint incl. Scharr halo and bilinear +1
@@ -883,7 +960,15 @@ int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int 
 }
 
 int launch_pyramid(plv_ctx *ctx, const PyrDesc &p) {
-  for (int l = 0; l + 1 < p.levels; ++l) {
+  int l = 0;
+  for (; l + 2 < p.levels; l += 2) {  // two levels per launch
+    ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
+    dim3 grid(cdiv(p.w[l + 2], PD2_T), cdiv(p.h[l + 2], PD2_T));
+    // (the grid of the upper level also covers the level under it: ceil(w2 / 16) * 32 >= w1 because w2 = (w1 + 1) / 2)
+    hipLaunchKernelGGL(pyrdown2_kernel, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l], p.base + p.off[l + 1],
+                       p.w[l + 1], p.h[l + 1], p.base + p.off[l + 2], p.w[l + 2], p.h[l + 2]);
+  }
+  for (; l + 1 < p.levels; ++l) {
     ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[l + 1], PD_T), cdiv(p.h[l + 1], PD_T));
     hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l],

@@ -241,3 +241,20 @@ def test_perform_matching_launch_wait_equals_sync(pkg):
     assert not b.perform_matching_wait()[1].any()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("w,h", [(333, 251), (752, 480), (1280, 720), (97, 131), (160, 64)])
+def test_pyramid_levels_bit_exact_any_size(pkg, w, h):
+    """Every level of the optical-flow pyramid against the oracle, including odd sizes (reflect-101 borders inside the two-level
+    kernel) and sizes where only some levels exist."""
+    fo = oracle_lib.load_front()
+    rng = np.random.default_rng(w * h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ctx = pkg.Context(pkg.default_config(w, h))
+    ctx.feed_image(img)
+    ref = fo.pyramid(fo.equalize_hist(img))
+    assert ctx.pyramid_levels(0) == ref.levels
+    for l in range(ref.levels):
+        got = ctx.pyramid_level(0, l)
+        assert got.shape == ref.level(l)[0].shape and np.array_equal(got, ref.level(l)[0]), (w, h, l)
+    ctx.close()
