@@ -96,9 +96,11 @@ int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
   PyrDesc &p = s->pyr[next];
   const int npix = s->W * s->H;
   switch (ctx->cfg.histogram_method) {
-    case PLV_HIST_HISTOGRAM:
-      TRY(launch_equalize(ctx, d_img, p.base + p.off[0], npix, s->hist.as<unsigned>()));
-      break;
+    case PLV_HIST_HISTOGRAM:  // (the equalisation rides on the first pyramid launch)
+      TRY(launch_equalize_pyramid(ctx, d_img, p, s->hist.as<unsigned>()));
+      s->cur = next;
+      s->fed++;
+      return PLV_OK;
     case PLV_HIST_NONE:
       PLV_HIP_CHECK(hipMemcpyAsync(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
       break;

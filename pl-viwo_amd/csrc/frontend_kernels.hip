@@ -142,20 +142,60 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict_
 #define PD2_T 16
 #define PD2_M (2 * PD2_T + 3)   // 35: level l+1 piece
 #define PD2_S (2 * PD2_M + 3)   // 73: level l footprint
+// EQ: `src` is the RAW image and level l is its histogram-equalised version: the workgroup rebuilds the LUT from the finished
+// histogram (as equalize_kernel does), maps the footprint while staging it, writes the 64x64 piece of level 0 it owns and clears
+// the histogram when it is the last to arrive: cv::equalizeHist's second half and two pyramid levels in one launch.
+template <bool EQ>
 __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ mid,
-                                                       int mw, int mh, uint8_t *__restrict__ dst, int dw, int dh) {
+                                                       int mw, int mh, uint8_t *__restrict__ dst, int dw, int dh,
+                                                       unsigned *__restrict__ hist, uint8_t *__restrict__ lvl0) {
   __shared__ uint8_t t0[PD2_S][PD2_S + 3];
   __shared__ int h0[PD2_S][PD2_M + 1];
   __shared__ uint8_t t1[PD2_M][PD2_M + 1];
   __shared__ int h1[PD2_M][PD2_T + 1];
+  __shared__ unsigned cdf[256];
+  __shared__ uint8_t lut[256];
+  __shared__ int first_bin;
+  __shared__ bool last_block;
   const int ox = blockIdx.x * PD2_T, oy = blockIdx.y * PD2_T;   // level l+2 tile origin
   // level l+1 rows / columns held in t1: [my0, my0 + PD2_M), clamped at 0 (reads below 0 reflect to 1, 2: inside)
   const int my0 = max(2 * oy - 2, 0), mx0 = max(2 * ox - 2, 0);
   const int sy0 = max(2 * my0 - 2, 0), sx0 = max(2 * mx0 - 2, 0);  // level l origin of t0, same rule
+  if (EQ) {  // the LUT of cv::equalizeHist (same code as equalize_kernel)
+    const int t = threadIdx.x, npix = sw * sh;
+    cdf[t] = hist[t];
+    if (t == 0) first_bin = 256;
+    __syncthreads();
+    if (cdf[t]) atomicMin(&first_bin, t);
+    for (int off = 1; off < 256; off <<= 1) {
+      unsigned v = t >= off ? cdf[t - off] : 0;
+      __syncthreads();
+      cdf[t] += v;
+      __syncthreads();
+    }
+    const int i0 = first_bin;
+    const unsigned hh0 = hist[i0];
+    if ((int)hh0 == npix) {
+      lut[t] = (uint8_t)t;
+    } else {
+      const float scale = (256 - 1.f) / (float)(npix - (int)hh0);
+      int v = 0;
+      if (t > i0) v = __float2int_rn((float)(int)(cdf[t] - hh0) * scale);
+      lut[t] = (uint8_t)min(max(v, 0), 255);
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < PD2_S * PD2_S; i += 256) {
     const int ty = i / PD2_S, tx = i - ty * PD2_S;
-    const int Y = min(sy0 + ty, sh - 1), X = min(sx0 + tx, sw - 1);
-    t0[ty][tx] = src[(size_t)Y * sw + X];
+    const int Yr = sy0 + ty, Xr = sx0 + tx;
+    const int Y = min(Yr, sh - 1), X = min(Xr, sw - 1);
+    uint8_t v = src[(size_t)Y * sw + X];
+    if (EQ) {
+      v = lut[v];
+      // level 0 rows [4 oy, 4 oy + 64) x columns [4 ox, 4 ox + 64) belong to this workgroup
+      if (Yr < sh && Xr < sw && Yr >= 4 * oy && Yr < 4 * oy + 4 * PD2_T && Xr >= 4 * ox && Xr < 4 * ox + 4 * PD2_T) lvl0[(size_t)Yr * sw + Xr] = v;
+    }
+    t0[ty][tx] = v;
   }
   __syncthreads();
   // level l -> l+1, horizontal then vertical; t1[y][x] = level l+1 pixel (my0 + y, mx0 + x)
@@ -208,6 +248,18 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
       const int s = h1[reflect101(c - 2, mh) - my0][x] + 4 * h1[reflect101(c - 1, mh) - my0][x] + 6 * h1[reflect101(c, mh) - my0][x] +
                     4 * h1[reflect101(c + 1, mh) - my0][x] + h1[reflect101(c + 2, mh) - my0][x];
       dst[(size_t)Y * dw + X] = (uint8_t)((s + 128) >> 8);
+    }
+  }
+  if (EQ) {  // every workgroup has consumed the histogram (LUT built behind a barrier): the last one clears it for the next frame
+    const int t = threadIdx.x;
+    if (t == 0) {
+      __threadfence();
+      last_block = atomicAdd(&hist[256], 1u) == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (last_block) {
+      hist[t] = 0;
+      if (t == 0) hist[256] = 0;
     }
   }
 }
@@ -959,14 +1011,37 @@ int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int 
   return PLV_OK;
 }
 
-int launch_pyramid(plv_ctx *ctx, const PyrDesc &p) {
-  int l = 0;
+// cv::equalizeHist + cv::buildOpticalFlowPyramid from the raw image: histogram, then the equalisation rides on the first
+// two-level pyramid launch (needs at least three levels; otherwise the separate kernels)
+int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p, unsigned *d_hist) {
+  const int npix = p.w[0] * p.h[0];
+  if (p.levels < 3) {
+    int rc = launch_equalize(ctx, d_raw, p.base + p.off[0], npix, d_hist);
+    return rc ? rc : launch_pyramid(ctx, p);
+  }
+  {
+    ProfScope ps(ctx->prof, "hist_kernel", ctx->stream);
+    const int blocks = min(256, max(1, cdiv(npix / 16, 256)));
+    hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, npix, d_hist);
+  }
+  {
+    ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
+    dim3 grid(cdiv(p.w[2], PD2_T), cdiv(p.h[2], PD2_T));
+    hipLaunchKernelGGL(pyrdown2_kernel<true>, grid, dim3(256), 0, ctx->stream, d_raw, p.w[0], p.h[0], p.base + p.off[1], p.w[1], p.h[1],
+                       p.base + p.off[2], p.w[2], p.h[2], d_hist, p.base + p.off[0]);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return launch_pyramid(ctx, p, 2);
+}
+
+int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level) {
+  int l = first_level;
   for (; l + 2 < p.levels; l += 2) {  // two levels per launch
     ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[l + 2], PD2_T), cdiv(p.h[l + 2], PD2_T));
     // (the grid of the upper level also covers the level under it: ceil(w2 / 16) * 32 >= w1 because w2 = (w1 + 1) / 2)
-    hipLaunchKernelGGL(pyrdown2_kernel, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l], p.base + p.off[l + 1],
-                       p.w[l + 1], p.h[l + 1], p.base + p.off[l + 2], p.w[l + 2], p.h[l + 2]);
+    hipLaunchKernelGGL(pyrdown2_kernel<false>, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l], p.base + p.off[l + 1],
+                       p.w[l + 1], p.h[l + 1], p.base + p.off[l + 2], p.w[l + 2], p.h[l + 2], (unsigned *)nullptr, (uint8_t *)nullptr);
   }
   for (; l + 1 < p.levels; ++l) {
     ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
