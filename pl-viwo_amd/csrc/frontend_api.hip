@@ -24,7 +24,7 @@ struct FrontState {
   DevBuf hist, clahe_lut;
   DevBuf ds_src, ds_dst;   // full-resolution staging of plv_downsample / plv_feed_image_downsampled
   // per-call point buffers
-  DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io;
+  DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io, models;
   DevBuf det_in, det_out, det_mask, subpix_tab;  // detection staging
   PinBuf det_pin;
 };
@@ -136,7 +136,7 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
-                    &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->det_in, &s->det_out,
+                    &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab};
   for (auto *b : bufs) b->release();
   for (auto &b : s->slots) b.release();
@@ -274,6 +274,7 @@ static int reserve_points(FrontState *s, int n, int ransac_iters) {
   TRY(s->mask.reserve(nn));
   TRY(s->iters.reserve(nn * 4));
   TRY(s->counts.reserve((size_t)std::max(ransac_iters, 1) * 3 * 4));
+  TRY(s->models.reserve((size_t)std::max(ransac_iters, 1) * 28 * 8));
   TRY(s->info.reserve(16));
   return PLV_OK;
 }
@@ -326,7 +327,7 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
   PLV_HIP_CHECK(hipMemcpyAsync(s->n0.p, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
   PLV_HIP_CHECK(hipMemcpyAsync(s->n1.p, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_ransac(ctx, s->n0.as<float>(), s->n1.as<float>(), n, thr, ctx->cfg.ransac_conf, mi, seed, s->counts.as<int>(),
-                    nullptr, s->mask.as<uint8_t>(), s->info.as<int>()));
+                    nullptr, s->mask.as<uint8_t>(), s->info.as<int>(), s->models.as<double>()));
   int info[2] = {0, 0};
   PLV_HIP_CHECK(hipMemcpyAsync(mask, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   PLV_HIP_CHECK(hipMemcpyAsync(info, s->info.p, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
@@ -370,7 +371,7 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
                 ctx->cfg.lk_eps, &camk, d_n0, d_n1));  // (+ the undistortion of both point sets on the same launch)
   const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
-                    d_mk, s->info.as<int>()));
+                    d_mk, s->info.as<int>(), s->models.as<double>()));
   PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   s->pending_n = n;
   s->pending_ran = true;

@@ -784,11 +784,18 @@ __device__ int wave_models(RansacLds &L, const float *m1, const float *m2, int n
 // counts[h*3 + k] = inliers of the k-th VALID model of hypothesis h (compacted like the serial
 // loop), -1 beyond.
 __global__ void __launch_bounds__(64) ransac_hyp_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
-                                                        float t, unsigned seed, int *__restrict__ counts) {
+                                                        float t, unsigned seed, int *__restrict__ counts,
+                                                        double *__restrict__ models /* [hyp][28]: 3 x 9 + valid mask, or null */) {
   __shared__ RansacLds L;
   const int h = blockIdx.x, lane = threadIdx.x;
   double F[3][9];
   const int valid = wave_models(L, m1, m2, n, seed, h, F);
+  if (models && lane < 28) {  // kept for ransac_select_kernel: the winner's model is read back instead of being solved again
+    double v = (double)valid;
+#pragma unroll
+    for (int e = 0; e < 27; ++e) v = (lane == e) ? F[e / 9][e % 9] : v;
+    models[(size_t)h * 28 + lane] = v;
+  }
   int slot = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -824,7 +831,8 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
 __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
                                                            float t, double conf, int max_iters, unsigned seed,
                                                            const int *__restrict__ counts, const uint8_t *__restrict__ klt,
-                                                           uint8_t *__restrict__ mask, int *__restrict__ info) {
+                                                           uint8_t *__restrict__ mask, int *__restrict__ info,
+                                                           const double *__restrict__ models) {
   __shared__ RansacLds L;
   const int lane = threadIdx.x;
   const int total = n == 7 ? 1 : max_iters;
@@ -878,7 +886,15 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
   if (!stop) used = min(niters, total);
   double F[3][9];
   int valid = 0;
-  if (bh >= 0) valid = wave_models(L, m1, m2, n, seed, bh, F);
+  if (bh >= 0) {
+    if (models) {  // the models ransac_hyp_kernel solved (same bits as a second solve)
+#pragma unroll
+      for (int e = 0; e < 27; ++e) F[e / 9][e % 9] = models[(size_t)bh * 28 + e];
+      valid = (int)models[(size_t)bh * 28 + 27];
+    } else {
+      valid = wave_models(L, m1, m2, n, seed, bh, F);
+    }
+  }
   // slot -> root index
   int kroot = -1, seen = 0;
 #pragma unroll
@@ -1089,7 +1105,7 @@ int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, co
 }
 
 int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
-                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info) {
+                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info, double *d_models) {
   const float t = (float)(thr * thr);
   if (n < 7) {
     PLV_HIP_CHECK(hipMemsetAsync(d_mask, 0, n, ctx->stream));
@@ -1099,12 +1115,12 @@ int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, dou
   const int nh = n == 7 ? 1 : max_iters;
   {
     ProfScope ps(ctx->prof, "ransac_hyp_kernel", ctx->stream);
-    hipLaunchKernelGGL(ransac_hyp_kernel, dim3(nh), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, seed, d_counts);
+    hipLaunchKernelGGL(ransac_hyp_kernel, dim3(nh), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, seed, d_counts, d_models);
   }
   {
     ProfScope ps(ctx->prof, "ransac_select_kernel", ctx->stream);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
-                       d_counts, d_klt, d_mask, d_info);
+                       d_counts, d_klt, d_mask, d_info, (const double *)d_models);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

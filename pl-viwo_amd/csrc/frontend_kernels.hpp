@@ -30,6 +30,6 @@ int launch_undistort(plv_ctx *ctx, const CamK &K, int n, const float *d_uv, floa
 int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, const float *d_uv1, float *d_xy0,
                       float *d_xy1);
 int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
-                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info);
+                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info, double *d_models = nullptr);
 
 }  // namespace plv
