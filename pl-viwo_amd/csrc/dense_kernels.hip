@@ -164,7 +164,7 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
   {
     ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
     const size_t shm = (size_t)nc * (GRAM_CH + 1) * sizeof(double);
-    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)gram_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    PLV_HIP_CHECK(ensure_dyn_smem((const void *)gram_chunk_kernel, (int)shm));
     hipLaunchKernelGGL(gram_chunk_kernel, dim3(nchunks), dim3(64 * GRAM_WAVES), shm, ctx->stream, d_A, lda, m, nc, d_part);
   }
   {

@@ -200,7 +200,7 @@ int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells) {
     set_last_error("FAST: cell %dx%d does not fit LDS", P.cell_w, P.cell_h);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)fast_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)fast_cells_kernel, (int)shm));
   ProfScope ps(ctx->prof, "fast_cells_kernel", ctx->stream);
   hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells), dim3(256), shm, ctx->stream, P);
   PLV_HIP_CHECK(hipGetLastError());

@@ -1329,7 +1329,7 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)jacobian_nullspace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
                      g ? *g : none);

@@ -384,7 +384,7 @@ int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers
   ProfScope ps(ctx->prof, "fld_walk_kernel", ctx->stream);
   const size_t need = (size_t)w * h;
   if (need <= 150 * 1024) {
-    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)fld_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    PLV_HIP_CHECK(ensure_dyn_smem((const void *)fld_walk_kernel<true>, (int)need));
     hipLaunchKernelGGL(fld_walk_kernel<true>, dim3(1), dim3(64), need, ctx->stream, b.map, w, h, fp.length_threshold, b.work, b.pts,
                        b.chains, b.chain_cap, b.counts);
   } else {

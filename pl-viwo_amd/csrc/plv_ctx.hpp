@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/plviwo.h"
@@ -80,6 +82,22 @@ struct PinBuf {
   }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize only has to grow: remember the largest size set per kernel and skip the runtime call
+// (a lock + a driver query on every launch otherwise) when the request fits.
+inline hipError_t ensure_dyn_smem(const void *fn, int bytes) {
+  static std::mutex mtx;
+  static std::unordered_map<unsigned long long, int> seen;  // (device, kernel): the attribute is per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long key = (unsigned long long)(uintptr_t)fn * 64ull + (unsigned)(dev & 63);
+  std::lock_guard<std::mutex> lk(mtx);
+  auto it = seen.find(key);
+  if (it != seen.end() && it->second >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) seen[key] = bytes;
+  return e;
+}
 
 // HIP-event timing per kernel class, on the ctx stream.
 struct Profiler {

@@ -588,7 +588,7 @@ int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_
     if (rc) return rc;
     extra = cdiv(std::max(k * n, std::max(k * k, n)), 256);
   }
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)nullspace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)nullspace_kernel, (int)shm));
   ProfScope ps(ctx->prof, "nullspace_kernel", ctx->stream);
   hipLaunchKernelGGL(nullspace_kernel, dim3(F + extra), dim3(256), shm, ctx->stream, fdim, k, ld, d_rows, d_Hf, d_Hx, d_res, F, g,
                      shift < 0 ? fdim : shift);
@@ -627,10 +627,10 @@ int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a_in, int max_mp) {
   ProfScope ps(ctx->prof, "chi2_gate_kernel", ctx->stream);
   // static LDS of blocked_chol (48 KB) + the dynamic S tile exceed the 64 KB default
   if (max_mp <= 32) {
-    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    PLV_HIP_CHECK(ensure_dyn_smem((const void *)chi2_gate_kernel<2>, (int)shm));
     hipLaunchKernelGGL(chi2_gate_kernel<2>, dim3(F), dim3(256), shm, ctx->stream, a);
   } else {
-    PLV_HIP_CHECK(hipFuncSetAttribute((const void *)chi2_gate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    PLV_HIP_CHECK(ensure_dyn_smem((const void *)chi2_gate_kernel<4>, (int)shm));
     hipLaunchKernelGGL(chi2_gate_kernel<4>, dim3(F), dim3(320), shm, ctx->stream, a);
   }
   PLV_HIP_CHECK(hipGetLastError());
@@ -647,7 +647,7 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
     set_last_error("tsqr: %d columns exceed the LDS-resident R capacity", nc);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)qr_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)qr_accum_kernel, (int)shm));
   int threads = cdiv(nc * QR_PARTS, 64) * 64;
   double *src = d_A, *dst = d_tmp;
   size_t cap_src = (size_t)lda * nc, cap_dst = tmp_elems;
@@ -719,8 +719,8 @@ int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int
     return PLV_E_CAPACITY;
   }
   launch_ekf_ms(ctx, d_P, n, ldp, d_H, r, k, ldh, d_cols, d_Rdiag, Mt, ldm, S, gathered, d_flag);
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  PLV_HIP_CHECK(hipFuncSetAttribute((const void *)ekf_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)ekf_chol_kernel, (int)shm));
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)ekf_trsm_kernel, (int)shm));
   {
     ProfScope ps(ctx->prof, "ekf_chol_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_chol_kernel, dim3(1), dim3(1024), shm, ctx->stream, S, r, r, L, r, d_flag);
