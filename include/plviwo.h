@@ -677,6 +677,47 @@ int plv_wheel_update(plv_ctx *ctx, const plv_wheel_options *opt, const plv_wheel
                      const double *m1, const double *m2, uint8_t *accepted, double *dx);
 
 /* ---------------------------------------------------------------------------------------------
+ * State initialisation (REF: PL-VIWO/src/init/Initializer.cpp:93-113 picks one of the two).
+ * imustate [17] = time, q_GtoI (JPL x y z w), p_IinG, v_IinG, bias_g, bias_a, as Initializer::set_state takes it
+ * (REF: Initializer.cpp:175-180; the initial covariance is cov_size * I_15 there).  Host logic, no device work.
+ * ------------------------------------------------------------------------------------------- */
+/* I_Initializer::initialization (REF: PL-VIWO/src/init/imu/I_Initializer.cpp:44-150) on the ascending IMU buffer:
+ * waits for two windows of window_time, wants the older one still (accel. std <= imu_thresh) and the newer one moving
+ * (>= imu_thresh); orientation from the mean specific force of the still window, biases from its means.  *ok = 0
+ * where the reference returns false. */
+int plv_init_imu_static(int n, const double *t, const double *wm, const double *am, double window_time, double imu_thresh,
+                        const double *gravity, double *imustate, int *ok);
+typedef struct plv_iw_init_options { /* IW_Initializer::IW_Initializer_Options (REF: IW_Initializer.h:50-58) */
+  int wheel_type;                 /* PLV_WHEEL*                                                          */
+  double intrinsics[3];           /* r_l, r_r, base length                                               */
+  double R_ItoO[9], p_IinO[3];    /* wheel_extrinsic->Rot() (row-major), ->pos()                         */
+  double toff;                    /* wheel_dt                                                            */
+  double threshold;               /* init.imu_wheel_thresh                                               */
+  double gravity[3];
+  int imu_gravity_aligned;        /* init.imu_gravity_aligned: gravity in {I0} = `gravity`, no estimate  */
+} plv_iw_init_options;
+typedef struct plv_iw_init_state { /* what IW_Initializer keeps between calls (REF: IW_Initializer.h:104-108) */
+  int cnt_smooth;
+  int reserved;
+  double prev_init[12];           /* bg, ba, g in {I0}, v in {I0}                                        */
+} plv_iw_init_state;
+void plv_iw_init_reset(plv_iw_init_state *state); /* cnt_smooth = -1 */
+/* IW_Initializer::initialization (REF: PL-VIWO/src/init/imu_wheel/IW_Initializer.cpp:44-104) on the IMU buffer
+ * (Propagator::imu_data) and the wheel buffer (UpdaterWheel::data_stack): common window, gyro bias against the wheel
+ * yaw rate, velocity from the wheels, gravity direction (mean of per-interval estimates when every wheel reading is
+ * zero, the norm-constrained least squares of :266-432 otherwise), accelerometer bias, residual check, and success
+ * only after more than three consecutive calls whose 12-vector moved by less than `threshold`.  *mode (nullable) =
+ * 0 static / 1 dynamic / -1 not enough data; init12 (nullable) receives this call's [bg ba g_I0 v_I0] when the
+ * stages all succeeded.  Where a nested select_imu_readings fails the reference asserts; this returns *ok = 0. */
+int plv_init_imu_wheel(const plv_iw_init_options *opt, plv_iw_init_state *state, int n_imu, const double *t, const double *wm,
+                       const double *am, int n_wheel, const double *tw, const double *m1, const double *m2, double *imustate, int *ok,
+                       int *mode, double *init12);
+/* StateHelper::EKFUpdate refreshes the tracker's camera model after every update when the intrinsics are calibrated
+ * online (REF: PL-VIWO/src/state/StateHelper.cpp:163-168): same for the ctx (undistortion, RANSAC threshold). */
+int plv_set_camera_intrinsics(plv_ctx *ctx, const double *K8);
+
+
+/* ---------------------------------------------------------------------------------------------
  * Trajectory I/O and the ATE evaluator: the accuracy half of the metric.
  * Poses are [n][7] = tx ty tz qx qy qz qw (JPL quaternion), as the reference logs and loads them.
  * ------------------------------------------------------------------------------------------- */

@@ -141,6 +141,11 @@ def load_library():
         "plv_select_wheel_data": (C.c_int, [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp, dp, dp, ip, ip]),
         "plv_wheel_linear_system": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, dp, dp, dp, ip, ip,
                                               ip, dp, dp]),
+        "plv_init_imu_static": (C.c_int, [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp, dp, ip]),
+        "plv_iw_init_reset": (None, [C.POINTER(PlvIwInitState)]),
+        "plv_init_imu_wheel": (C.c_int, [C.POINTER(PlvIwInitOptions), C.POINTER(PlvIwInitState), C.c_int, dp, dp, dp, C.c_int, dp, dp, dp,
+                                         dp, ip, ip, dp]),
+        "plv_set_camera_intrinsics": (C.c_int, [vp, dp]),
         "plv_wheel_update": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, u8p, dp]),
         "plv_next_clone_time": (C.c_int, [C.POINTER(PlvCloneSchedule), dp, ip]),
         "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
@@ -429,6 +434,56 @@ def reset_cpi(imu, clone_t):
     acc = PlvCpiAccum()
     load_library().plv_reset_cpi(C.byref(acc), C.byref(imu), float(clone_t))
     return acc
+
+
+WHEEL_TYPES = {"Wheel3DAng": 0, "Wheel3DLin": 1, "Wheel3DCen": 2, "Wheel2DAng": 3, "Wheel2DLin": 4, "Wheel2DCen": 5}
+
+
+class PlvIwInitOptions(C.Structure):
+    _fields_ = [("wheel_type", C.c_int), ("intrinsics", C.c_double * 3), ("R_ItoO", C.c_double * 9), ("p_IinO", C.c_double * 3),
+                ("toff", C.c_double), ("threshold", C.c_double), ("gravity", C.c_double * 3), ("imu_gravity_aligned", C.c_int)]
+
+
+class PlvIwInitState(C.Structure):
+    _fields_ = [("cnt_smooth", C.c_int), ("reserved", C.c_int), ("prev_init", C.c_double * 12)]
+
+
+def init_imu_static(t, wm, am, window_time, imu_thresh, gravity=(0.0, 0.0, 9.81)):
+    """I_Initializer::initialization: the 17-vector [t q p v bg ba] or None."""
+    t, wm, am, g = _c64(t), _c64(wm), _c64(am), _c64(gravity)
+    out, ok = np.zeros(17), C.c_int()
+    rc = load_library().plv_init_imu_static(len(t), _dp(t), _dp(wm), _dp(am), float(window_time), float(imu_thresh), _dp(g), _dp(out),
+                                            C.byref(ok))
+    if rc != PLV_OK:
+        raise PlvError(rc, "plv_init_imu_static")
+    return out if ok.value else None
+
+
+class IwInitializer:
+    """IW_Initializer: options + the memory it keeps between attempts (plv_iw_init_state)."""
+
+    def __init__(self, wheel_type, intrinsics, R_ItoO, p_IinO, toff, threshold, gravity=(0.0, 0.0, 9.81), imu_gravity_aligned=False):
+        o = PlvIwInitOptions()
+        o.wheel_type = WHEEL_TYPES[wheel_type] if isinstance(wheel_type, str) else int(wheel_type)
+        for name, val in dict(intrinsics=intrinsics, R_ItoO=R_ItoO, p_IinO=p_IinO, gravity=gravity).items():
+            arr = getattr(o, name)
+            for i, x in enumerate(np.asarray(val, dtype=np.float64).ravel()):
+                arr[i] = float(x)
+        o.toff, o.threshold, o.imu_gravity_aligned = float(toff), float(threshold), 1 if imu_gravity_aligned else 0
+        self.opt, self.state = o, PlvIwInitState()
+        load_library().plv_iw_init_reset(C.byref(self.state))
+        self.last_init, self.last_mode = None, -1
+
+    def initialization(self, t, wm, am, tw, m1, m2):
+        t, wm, am, tw, m1, m2 = _c64(t), _c64(wm), _c64(am), _c64(tw), _c64(m1), _c64(m2)
+        out, init = np.zeros(17), np.full(12, np.nan)
+        ok, mode = C.c_int(), C.c_int()
+        rc = load_library().plv_init_imu_wheel(C.byref(self.opt), C.byref(self.state), len(t), _dp(t), _dp(wm), _dp(am), len(tw), _dp(tw),
+                                               _dp(m1), _dp(m2), _dp(out), C.byref(ok), C.byref(mode), _dp(init))
+        if rc != PLV_OK:
+            raise PlvError(rc, "plv_init_imu_wheel")
+        self.last_init, self.last_mode = (None if np.isnan(init[0]) else init), mode.value
+        return out if ok.value else None
 
 
 def traj_header():
@@ -882,6 +937,10 @@ class Context:
         self._chk(self.lib.plv_slam_initialize(self.h, rows, k, rows, _dp(Hf), _dp(Hx), _dp(res), _ip(cols), float(chi2_mult), _u8p(ok),
                                                _dp(dxi), _dp(dx)))
         return int(ok[0]), dxi, dx
+
+    def set_camera_intrinsics(self, K8):
+        K8 = _c64(K8)
+        self._chk(self.lib.plv_set_camera_intrinsics(self.h, _dp(K8)))
 
     def cov_marginalize(self, idx, size):
         self._chk(self.lib.plv_cov_marginalize(self.h, int(idx), int(size)))

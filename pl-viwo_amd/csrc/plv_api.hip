@@ -133,6 +133,15 @@ void plv_config_default(plv_config *c, int width, int height) {
   c->device = 0;
 }
 
+int plv_set_camera_intrinsics(plv_ctx *ctx, const double *K8) {
+  if (!ctx || !K8) return PLV_E_BADARG;
+  for (int i = 0; i < 8; ++i)
+    if (!std::isfinite(K8[i])) return PLV_E_BADARG;
+  // cfg.intrinsics is read at every undistortion / RANSAC-threshold use, so this takes effect with the next frame
+  for (int i = 0; i < 8; ++i) ctx->cfg.intrinsics[i] = K8[i];
+  return PLV_OK;
+}
+
 int plv_ctx_create(const plv_config *cfg, plv_ctx **out) {
   if (!cfg || !out) {
     set_last_error("plv_ctx_create: null argument");
