@@ -1,0 +1,574 @@
+"""SystemManager, State, Initializer, Propagator and the camera / wheel updaters as one host-side driver over the C-ABI
+(SURVEY §8(f) rank 4): everything numeric runs behind `plv_*` on the GPU, this module keeps the state vector, the clone
+window and the measurement buffers, in the order the reference does.
+
+REF: PL-VIWO/src/core/SystemManager.cpp:55-135 (feed_measurement_imu / _camera / _wheel), :172-312 (clone schedule, accelerations,
+     dynamic cloning); PL-VIWO/src/state/State.cpp:30-120,228-268 (variable order, prior), StateHelper.cpp:120-172,175-232;
+     PL-VIWO/src/state/Propagator.cpp:17-91,333-357; PL-VIWO/src/init/Initializer.cpp:58-180;
+     PL-VIWO/src/update/cam/UpdaterCamera.cpp:77-195; PL-VIWO/src/update/wheel/UpdaterWheel.cpp:21-139.
+
+The camera path follows the intended flow feed_measurement -> try_update (as published, SystemManager.cpp:107-127 returns
+before try_update once the filter is initialised).  Scope of this driver: one camera (monocular), MSCKF points and lines
+(cam.max_slam must be 0, the shipped value), wheel optional; GPS / LiDAR / stereo / simulation are outside SURVEY §8.
+"""
+import math
+import time as _time
+
+import numpy as np
+
+from . import (Context, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, WHEEL_TYPES, default_config,
+               imu_noise, init_imu_static, next_clone_time, reset_cpi, select_imu_readings, select_wheel_data)
+from .options import OptionsError
+
+
+# ------------------------------------------------------------------------------------------------ JPL helpers (host side)
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def quat_2_Rot(q):
+    """REF: open_vins/ov_core/src/utils/quat_ops.h:152-157"""
+    q = np.asarray(q, dtype=np.float64)
+    return (2 * q[3] ** 2 - 1) * np.eye(3) - 2 * q[3] * skew(q[:3]) + 2 * np.outer(q[:3], q[:3])
+
+
+def quat_left_update(q, dth):
+    """JPLQuat::update: q <- quatnorm([dth / 2, 1]) (x) q  (REF: open_vins/ov_core/src/types/JPLQuat.h:62-73)."""
+    dq = np.array([0.5 * dth[0], 0.5 * dth[1], 0.5 * dth[2], 1.0])
+    dq /= np.linalg.norm(dq)
+    M = np.zeros((4, 4))
+    M[:3, :3] = dq[3] * np.eye(3) - skew(dq[:3])
+    M[:3, 3], M[3, :3], M[3, 3] = dq[:3], -dq[:3], dq[3]
+    r = M @ np.asarray(q, dtype=np.float64)
+    if r[3] < 0:
+        r = -r
+    return r / np.linalg.norm(r)
+
+
+class Stat:
+    """viw::STAT (REF: PL-VIWO/src/utils/Jabdongsani.cpp:8-33), float arithmetic as there."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.mean, self.var, self.cnt = np.float32(0), np.float32(0), np.float32(0)
+
+    def add_stat(self, val):
+        val = np.float32(val)
+        self.cnt = np.float32(self.cnt + 1)
+        if self.cnt > 1:
+            self.var = np.float32((self.cnt - 2) / (self.cnt - 1) * self.var + 1.0 / self.cnt * (val - self.mean) ** 2)
+        self.mean = np.float32((val + (self.cnt - 1) * self.mean) / self.cnt)
+
+
+class Pose:
+    """ov_type::PoseJPL: value and first estimate."""
+
+    def __init__(self, q, p, var_id=-1):
+        self.q, self.p = np.array(q, dtype=np.float64), np.array(p, dtype=np.float64)
+        self.q_fej, self.p_fej = self.q.copy(), self.p.copy()
+        self.id = var_id
+
+    def Rot(self):
+        return quat_2_Rot(self.q)
+
+    def Rot_fej(self):
+        return quat_2_Rot(self.q_fej)
+
+    def update(self, dx):
+        self.q = quat_left_update(self.q, dx[0:3])
+        self.p = self.p + dx[3:6]
+
+    def clone(self, var_id):
+        c = Pose(self.q, self.p, var_id)
+        c.q_fej, c.p_fej = self.q_fej.copy(), self.p_fej.copy()
+        return c
+
+
+class Vec:
+    def __init__(self, v, var_id=-1):
+        self.v = np.array(v, dtype=np.float64).ravel()
+        self.id = var_id
+
+    def update(self, dx):
+        self.v = self.v + dx
+
+
+class State:
+    """viw::State: mean, variable order, clone window (the covariance itself is resident in the plv_ctx)."""
+
+    def __init__(self, op, ctx):
+        self.op, self.ctx = op, ctx
+        e = op.est
+        self.time, self.startup_time, self.initialized = -1.0, -1.0, False
+        self.imu = PlvImuState.make([0, 0, 0, 1], [0, 0, 0], [0, 0, 0])
+        self.clones = {}            # time -> Pose (real clones; the IMU pose pseudo-clone is added by clone_list())
+        self.imu_pose_in_clones = False
+        self.cpis = {}              # time -> PlvCpiRecord-like dict (t, dt, clone_t, R, w, v)
+        self.est_a, self.est_A = Stat(), Stat()
+        cur = 15                    # State.cpp:27-32: the IMU first
+        self.cam_ext = self.cam_intr = self.cam_dt = None
+        prior = []                  # (id, values on the diagonal)
+        if e.cam.enabled:           # set_camera_state :58-112: extrinsic, intrinsic, time offset
+            c = e.cam
+            self.cam_ext = Pose(c.extrinsics[0][:4], c.extrinsics[0][4:])
+            self.cam_intr, self.cam_dt = Vec(c.intrinsics[0]), Vec([c.dt[0]])
+            if c.do_calib_ext:
+                self.cam_ext.id = cur
+                prior.append((cur, [c.init_cov_ex_o] * 3 + [c.init_cov_ex_p] * 3))
+                cur += 6
+            if c.do_calib_int:
+                self.cam_intr.id = cur
+                r2 = (math.sqrt(c.init_cov_in_r) / 10.0) ** 2 if c.init_cov_in_r > 1e-5 else c.init_cov_in_r   # State.cpp:245-249
+                prior.append((cur, [c.init_cov_in_k] * 2 + [c.init_cov_in_c] * 2 + [c.init_cov_in_r] * 2 + [r2] * 2))
+                cur += 8
+            if c.do_calib_dt:
+                self.cam_dt.id = cur
+                prior.append((cur, [c.init_cov_dt]))
+                cur += 1
+        self.wheel_ext = self.wheel_intr = self.wheel_dt = None
+        if e.wheel.enabled:         # set_wheel_state :151-190: time offset, extrinsic, intrinsic
+            w = e.wheel
+            self.wheel_dt, self.wheel_ext, self.wheel_intr = Vec([w.dt]), Pose(w.extrinsics[:4], w.extrinsics[4:]), Vec(w.intrinsics)
+            if w.do_calib_dt:
+                self.wheel_dt.id = cur
+                prior.append((cur, [w.init_cov_dt]))
+                cur += 1
+            if w.do_calib_ext:
+                self.wheel_ext.id = cur
+                prior.append((cur, [w.init_cov_ex_o] * 3 + [w.init_cov_ex_p] * 3))
+                cur += 6
+            if w.do_calib_int:
+                self.wheel_intr.id = cur
+                prior.append((cur, [w.init_cov_in_r] * 2 + [w.init_cov_in_b]))
+                cur += 3
+        self.n = cur
+        # set_state_covariance :228-268 (the IMU block is overwritten at initialisation, Initializer.cpp:182-186)
+        P = e.init.cov_size * np.eye(cur)
+        P[6:9, 6:9] *= 2
+        for i, d in prior:
+            P[i:i + len(d), i:i + len(d)] = np.diag(d)
+        ctx.cov_upload(P)
+
+    # ---- clone bookkeeping
+    def clone_times(self):
+        t = sorted(self.clones)
+        if self.imu_pose_in_clones and self.time not in self.clones:
+            t.append(self.time)
+        return t
+
+    def imu_pose(self):
+        p = Pose(self.imu.q, self.imu.p, 0)
+        p.q_fej, p.p_fej = np.array(self.imu.q_fej), np.array(self.imu.p_fej)
+        return p
+
+    def clone_at(self, t):
+        return self.clones[t] if t in self.clones else self.imu_pose()
+
+    def clone_window(self):
+        t = self.clone_times()
+        return t[-1] - t[0] if t else 0.0
+
+    def intr_cov(self):
+        ie, e = self.op.est.intr_err, self.op.est
+        hz, order = e.clone_freq, e.intr_order
+        if not e.use_pol_cov or hz not in ie.ori_slope:
+            return 0.0, 0.0
+        return ie.ori_cov(hz, order, float(self.est_A.mean)), ie.pos_cov(hz, order, float(self.est_a.mean))
+
+    def view(self):
+        """The plv_state_view of the current window: real clones, then the IMU pose (id 0) when it sits in the clone list."""
+        ts = self.clone_times()
+        cl = [self.clone_at(t) for t in ts]
+        oc, pc = self.intr_cov()
+        c = self.op.est.cam
+        return StateView(ts, [x.Rot() for x in cl], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
+                         clone_R_fej=[x.Rot_fej() for x in cl], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
+                         extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
+                         sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
+                         feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp)
+
+    # ---- x <- x [+] dx for every variable (StateHelper::EKFUpdate :156-168)
+    def apply(self, dx):
+        q = quat_left_update(np.array(self.imu.q), dx[0:3])
+        for i in range(4):
+            self.imu.q[i] = q[i]
+        for i in range(3):
+            self.imu.p[i] += dx[3 + i]
+            self.imu.v[i] += dx[6 + i]
+            self.imu.bg[i] += dx[9 + i]
+            self.imu.ba[i] += dx[12 + i]
+        for var, size in ((self.cam_ext, 6), (self.cam_intr, 8), (self.cam_dt, 1), (self.wheel_dt, 1), (self.wheel_ext, 6), (self.wheel_intr, 3)):
+            if var is not None and var.id >= 0:
+                var.update(dx[var.id:var.id + size])
+        for c in self.clones.values():
+            c.update(dx[c.id:c.id + 6])
+        if self.cam_intr is not None and self.op.est.cam.do_calib_int:
+            self.ctx.set_camera_intrinsics(self.cam_intr.v)     # StateHelper.cpp:163-168
+
+    # ---- StateHelper::augment_clone / marginalize_old_clone
+    def augment_clone(self):
+        if self.time in self.clones:
+            raise RuntimeError("TRIED TO INSERT A CLONE AT THE SAME TIME AS AN EXISTING CLONE")   # StateHelper.cpp:178-181
+        self.ctx.cov_clone(self.n, 0, 6)
+        self.clones[self.time] = self.imu_pose().clone(self.n)
+        self.n += 6
+
+    def marginalize_old_clone(self):
+        while self.clone_window() > self.op.est.window_size and self.clones:
+            c = self.clones.pop(min(self.clones))
+            self.ctx.cov_marginalize(c.id, 6)
+            self.n -= 6
+            for o in self.clones.values():
+                if o.id > c.id:
+                    o.id -= 6
+
+    def flush_old_data(self):   # State.cpp:605-628
+        if not self.clones:
+            return
+        old_t = min(self.clones)
+        for t in sorted(self.cpis):
+            if old_t > self.cpis[t]["clone_t"]:
+                del self.cpis[t]
+            else:
+                break
+
+
+class TimeChecker:
+    """ding / dong totals per label (REF: PL-VIWO/src/utils/TimeChecker.h:56-135)."""
+
+    def __init__(self):
+        self.total, self.count, self._t0 = {}, {}, {}
+
+    def ding(self, k):
+        self._t0[k] = _time.perf_counter()
+
+    def dong(self, k):
+        self.total[k] = self.total.get(k, 0.0) + _time.perf_counter() - self._t0.pop(k)
+        self.count[k] = self.count.get(k, 0) + 1
+
+
+class SystemManager:
+    """viw::SystemManager for IMU + one camera (+ wheel)."""
+
+    def __init__(self, op, device=0, max_obs=24):
+        e = op.est
+        if e.cam.enabled and e.cam.max_n != 1:
+            raise OptionsError("replay driver: one camera (cam.max_n: 1, use_stereo: false)")
+        if e.cam.enabled and e.cam.max_slam != 0:
+            raise OptionsError("replay driver: cam.max_slam must be 0 (plv_slam_update / plv_slam_initialize are not driven from here yet)")
+        if e.cam.enabled and e.cam.distortion_model[0] != "radtan":
+            raise OptionsError("only the radtan camera model is built (SURVEY §8 a7)")
+        if e.init.use_gt:
+            raise OptionsError("init.use_gt needs the simulator / ground-truth reader, outside SURVEY §8")
+        self.op = op
+        w, h = (e.cam.wh[0] if e.cam.enabled else (752, 480))
+        cfg = default_config(w, h)
+        if e.cam.enabled:
+            c = e.cam
+            cfg.num_features, cfg.fast_threshold, cfg.grid_x, cfg.grid_y, cfg.min_px_dist = c.n_pts, c.fast, c.grid_x, c.grid_y, c.min_px_dist
+            cfg.histogram_method = c.histogram
+            for i in range(8):
+                cfg.intrinsics[i] = float(c.intrinsics[0][i])
+            cfg.sigma_pix, cfg.chi2_mult = c.sigma_pix, c.chi2_mult
+        clones_max = int(e.window_size * max(e.clone_freq, max(e.intr_err.available_clone_hz() or [e.clone_freq]))) + 3
+        cfg.max_state_dim = max(cfg.max_state_dim, 15 + 30 + 6 * clones_max)
+        cfg.max_rows_per_feat = max(cfg.max_rows_per_feat, 2 * max_obs)
+        cfg.device = device
+        self.ctx = Context(cfg)
+        self.max_obs = max_obs
+        self.state = State(op, self.ctx)
+        self.noise = imu_noise(e.imu.sigma_w, e.imu.sigma_wb, e.imu.sigma_a, e.imu.sigma_ab, tuple(e.gravity))
+        # Propagator
+        self.imu_t, self.imu_w, self.imu_a = [], [], []
+        self.cpi_acc = None
+        # UpdaterCamera
+        self.cam_t_hist = []
+        self.use_lines = bool(e.cam.enabled and e.cam.use_lines)
+        # UpdaterWheel
+        self.whl_t, self.whl_m1, self.whl_m2 = [], [], []
+        self.whl_last_updated = -1.0
+        self.wheel_opt = None
+        if e.wheel.enabled:
+            wl = e.wheel
+            self.wheel_opt = PlvWheelOptions(WHEEL_TYPES[wl.type], wl.noise_w, wl.noise_v, wl.noise_p, int(wl.do_calib_ext), int(wl.do_calib_dt),
+                                             int(wl.do_calib_int), wl.chi2_mult)
+        # Initializer (REF: Initializer.cpp:58-91)
+        self.iw_init = None
+        if not e.init.imu_only_init and e.wheel.enabled:
+            st = self.state
+            self.iw_init = IwInitializer(e.wheel.type, st.wheel_intr.v, st.wheel_ext.Rot(), st.wheel_ext.p, float(st.wheel_dt.v[0]),
+                                         e.init.imu_wheel_thresh, e.gravity, e.init.imu_gravity_aligned)
+        self.last_cam_delete_t = -math.inf
+        self.tc = TimeChecker()
+        self.stats = dict(clones=0, cam_updates=0, cam_features=0, cam_accepted=0, line_updates=0, lines_accepted=0, wheel_updates=0, wheel_accepted=0,
+                          not_psd=0, frames=0, line_pool=0, lines_triangulated=0, lines_tracked=0)
+        self.distance = 0.0
+
+    def close(self):
+        self.ctx.close()
+
+    # ================================================================================================ Initializer
+    def _try_initialization(self):
+        e = self.op.est
+        t, wm, am = np.array(self.imu_t), np.array(self.imu_w).reshape(-1, 3), np.array(self.imu_a).reshape(-1, 3)
+        if self.iw_init is not None:
+            x = self.iw_init.initialization(t, wm, am, np.array(self.whl_t), np.array(self.whl_m1), np.array(self.whl_m2))
+        else:
+            x = init_imu_static(t, wm, am, e.init.window_time, e.init.imu_thresh, e.gravity)
+        if x is None:
+            self._delete_old_measurements()
+            return False
+        self._set_state(x)
+        return True
+
+    def _delete_old_measurements(self):   # Initializer.cpp:115-172
+        W = self.op.est.init.window_time
+        if not self.imu_t or self.imu_t[-1] - self.imu_t[0] <= 3 * W:
+            return
+        old = self.imu_t[-1] - 3 * W
+        k = next(i for i, t in enumerate(self.imu_t) if not t < old)
+        del self.imu_t[:k], self.imu_w[:k], self.imu_a[:k]
+        if self.op.est.cam.enabled and len(self.cam_t_hist) > 1:
+            cam_hz = (len(self.cam_t_hist) - 1) / (self.cam_t_hist[-1] - self.cam_t_hist[0])
+            if self.last_cam_delete_t + 100.0 / cam_hz < old:
+                self.ctx.db_cleanup_measurements(old)
+                self.last_cam_delete_t = old
+        if self.op.est.wheel.enabled:
+            k = next((i for i, t in enumerate(self.whl_t) if not t < old), len(self.whl_t))
+            del self.whl_t[:k], self.whl_m1[:k], self.whl_m2[:k]
+
+    def _set_state(self, x):   # Initializer.cpp:174-220
+        st = self.state
+        st.imu = PlvImuState.make(x[1:5], x[5:8], x[8:11], x[11:14], x[14:17])
+        P = self.ctx.cov_download(st.n)
+        P[:15, :] = 0
+        P[:, :15] = 0
+        P[:15, :15] = self.op.est.init.cov_size * np.eye(15)
+        self.ctx.cov_upload(P)
+        st.time = st.startup_time = float(x[0])
+        st.initialized = True
+
+    # ================================================================================================ Propagator
+    def _feed_imu(self, t, wm, am):   # Propagator.cpp:17-28
+        self.imu_t.append(float(t)), self.imu_w.append(np.asarray(wm, dtype=np.float64)), self.imu_a.append(np.asarray(am, dtype=np.float64))
+        st = self.state
+        if st.clones:
+            old = min(st.clones) - 1
+            k = next((i for i, x in enumerate(self.imu_t) if not x < old), 0)
+            if k:
+                del self.imu_t[:k], self.imu_w[:k], self.imu_a[:k]
+
+    def _propagate(self, timestamp):   # Propagator.cpp:30-91
+        st = self.state
+        ok, t, wm, am = select_imu_readings(np.array(self.imu_t), np.array(self.imu_w).reshape(-1, 3), np.array(self.imu_a).reshape(-1, 3),
+                                            st.time, timestamp)
+        if not ok:
+            return
+        _, _, recs = self.ctx.propagate(st.imu, self.noise, t, wm, am, st.n, acc=self.cpi_acc, imu_id=0, want_records=True)
+        for r in recs:
+            st.cpis[r.t] = dict(t=r.t, dt=r.dt, clone_t=r.clone_t, R=np.array(r.R_I0toIk).reshape(3, 3), w=np.array(r.w), v=np.array(r.v))
+        st.time = float(timestamp)
+
+    def _reset_cpi(self, clone_t):   # Propagator.cpp:333-357
+        st = self.state
+        self.cpi_acc = reset_cpi(st.imu, clone_t)
+        w = st.cpis[clone_t]["w"] if clone_t in st.cpis else np.zeros(3)
+        st.cpis[clone_t] = dict(t=clone_t, dt=0.0, clone_t=clone_t, R=np.eye(3), w=w, v=np.array(st.imu.v))
+
+    # ================================================================================================ SystemManager
+    def feed_measurement_imu(self, t, wm, am):
+        """REF: SystemManager.cpp:55-105.  Returns True when a clone was created (the reference's cue to log / visualise)."""
+        self._feed_imu(t, wm, am)
+        st = self.state
+        if not st.initialized and not self._try_initialization():
+            return False
+        self.tc.ding("IMU")
+        st.imu_pose_in_clones = False                      # erase the IMU pose from the clone list
+        clone_time = self._get_next_clone_time(t)
+        if clone_time is not None:
+            self._propagate(clone_time)
+            st.augment_clone()
+            st.marginalize_old_clone()
+            self._reset_cpi(st.time)
+            st.est_A.reset(), st.est_a.reset()
+            st.flush_old_data()
+            self.stats["clones"] += 1
+            ct = sorted(st.clones)
+            if len(ct) > 1:
+                self.distance += float(np.linalg.norm(st.clones[ct[-1]].p - st.clones[ct[-2]].p))
+        self._propagate(t)
+        if st.time not in st.clones:
+            st.imu_pose_in_clones = True
+        self.tc.dong("IMU")
+        return clone_time is not None
+
+    def _get_next_clone_time(self, meas_t):   # SystemManager.cpp:172-267
+        st, e = self.state, self.op.est
+        if not st.initialized:
+            return None
+        if not st.clones:
+            return st.time
+        self._compute_accelerations()
+        freq = e.clone_freq
+        if e.dynamic_cloning:
+            freq = self._dynamic_cloning()
+        ct = sorted(st.clones)
+        sensor_t = self.cam_t_hist if e.cam.enabled else []
+        sensor_dt = float(st.cam_dt.v[0]) if e.cam.enabled else 0.0
+        r = next_clone_time(len(ct), st.time, meas_t, ct[-1], ct[-2] if len(ct) > 1 else -math.inf, False, freq, sensor_t, sensor_dt,
+                            self.imu_t[0], self.imu_t[-1], wheel_enabled=e.wheel.enabled)
+        if r is not None and e.dynamic_cloning:
+            e.clone_freq = freq
+        return r
+
+    def _compute_accelerations(self):   # SystemManager.cpp:269-295
+        st = self.state
+        if len(self.imu_t) < 2:
+            return
+        t1 = self.imu_t[-2]
+        c1 = st.cpis.get(t1)
+        if c1 is None or c1["clone_t"] not in st.clones:
+            return   # State::have_cpi would try to create one (linear / integrated): only stored records are used here
+        R_I0toG = st.clones[c1["clone_t"]].Rot().T
+        R_IktoI0 = c1["R"].T
+        a = R_I0toG @ R_IktoI0 @ self.imu_a[-2] - quat_2_Rot(st.imu.q).T @ np.array(st.imu.ba) - self.op.est.gravity
+        st.est_a.add_stat(np.linalg.norm(a))
+        if c1["dt"] != 0:
+            st.est_A.reset()
+            c0 = st.cpis.get(c1["clone_t"])
+            if c0 is not None:
+                st.est_A.add_stat(np.linalg.norm((R_IktoI0 @ c1["w"] - c0["w"]) / c1["dt"]))
+
+    def _dynamic_cloning(self):   # SystemManager.cpp:297-312
+        st, ie = self.state, self.op.est.intr_err
+        hzs = ie.available_clone_hz()
+        if not hzs:
+            return self.op.est.clone_freq
+        for hz in hzs:
+            if hz < 4:
+                continue
+            if ie.ori_std(hz, 3, float(st.est_A.mean)) < ie.threshold_ori and ie.pos_std(hz, 3, float(st.est_a.mean)) < ie.threshold_pos:
+                return hz
+        return hzs[-1]
+
+    # ---------------------------------------------------------------------------------------------- camera
+    def feed_measurement_camera(self, t, img, mask=None):
+        """UpdaterCamera::feed_measurement + try_update (REF: UpdaterCamera.cpp:77-195)."""
+        e, st = self.op.est, self.state
+        if not e.cam.enabled:
+            return
+        if st.initialized:
+            self.tc.ding("CAM")
+        if len(self.cam_t_hist) > 100:
+            self.cam_t_hist.pop(0)
+        self.cam_t_hist.append(float(t))
+        if e.cam.downsample:
+            self.ctx.tracker_feed_downsampled(t, img, mask)
+        else:
+            self.ctx.tracker_feed(t, img, mask)
+        if self.use_lines:
+            vps = self.ctx.vanishing_points(st.cam_ext.Rot(), st.cam_intr.v)
+            self.ctx.line_tracker_feed(t, vps)
+            self.stats["lines_tracked"] += self.ctx.line_db_size()
+        self.stats["frames"] += 1
+        if st.initialized:
+            self._camera_try_update()
+            self.tc.dong("CAM")
+
+    def _camera_try_update(self):
+        st, e = self.state, self.op.est
+        ts = st.clone_times()
+        if len(ts) < e.intr_order + 1 or len(self.cam_t_hist) < 2:      # have_polynomial, CamHelper.cpp:615-616
+            return
+        c, fi = e.cam, e.cam.featinit
+        full = st.clone_window() > e.window_size
+        kw = dict(t_prev_frame=self.cam_t_hist[-2], state_time=st.time, window_full=full, chi2_mult=c.chi2_mult)
+        out = self.ctx.camera_update_points(st.view(), st.n, min(c.max_msckf, self.ctx.cfg.max_features), self.max_obs, min_dist=fi.min_dist,
+                                            max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline,
+                                            refine=fi.refine_features, **kw)
+        if out["status"] != 0:
+            self.stats["not_psd"] += 1
+        elif out["n_accepted"] > 0:
+            st.apply(out["dx"])
+            self.stats["cam_updates"] += 1
+        self.stats["cam_features"] += out["n_msckf"]
+        self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
+        if self.use_lines:
+            lo = self.ctx.camera_update_lines(st.view(), st.n, self.max_obs, **kw)
+            self.stats["line_pool"] += lo["n_pool"]
+            self.stats["lines_triangulated"] += lo["n_lines"]
+            if lo["status"] != 0:
+                self.stats["not_psd"] += 1
+            elif lo["n_accepted"] > 0:
+                st.apply(lo["dx"])
+                self.stats["line_updates"] += 1
+                self.stats["lines_accepted"] += lo["n_accepted"]
+
+    # ---------------------------------------------------------------------------------------------- wheel
+    def feed_measurement_wheel(self, t, m1, m2):
+        """REF: SystemManager.cpp:129-137, UpdaterWheel.cpp:21-70."""
+        if not self.op.est.wheel.enabled:
+            return
+        st = self.state
+        if st.initialized:
+            self.tc.ding("WHL")
+        self.whl_t.append(float(t)), self.whl_m1.append(float(m1)), self.whl_m2.append(float(m2))
+        while self.whl_t and t - self.whl_t[0] > 1000:
+            del self.whl_t[0], self.whl_m1[0], self.whl_m2[0]
+        if st.initialized:
+            self._wheel_try_update()
+            self.tc.dong("WHL")
+
+    def _wheel_try_update(self):
+        st, wl = self.state, self.op.est.wheel
+        ts = st.clone_times()
+        if not ts:
+            return
+        if wl.reuse_of_information:   # UpdaterWheel.cpp:38-49
+            if st.clone_window() > self.op.est.window_size:
+                return
+            older = [t for t in ts if t < self.whl_t[-1] + float(st.wheel_dt.v[0])]
+            if older:
+                self._wheel_update(ts[0], older[-1])
+            return
+        if self.whl_last_updated not in ts:   # :52-60
+            newer = [t for t in ts if t > self.whl_last_updated]
+            if not newer:
+                self.whl_last_updated = ts[-1]
+                return
+            self.whl_last_updated = newer[0]
+        for t in ts:
+            if t <= self.whl_last_updated:
+                continue
+            if not self._wheel_update(self.whl_last_updated, t):
+                break
+
+    def _wheel_update(self, time0, time1):   # UpdaterWheel.cpp:72-139
+        st = self.state
+        toff = float(st.wheel_dt.v[0])
+        ok, t, m1, m2 = select_wheel_data(np.array(self.whl_t), np.array(self.whl_m1), np.array(self.whl_m2), time0 - toff, time1 - toff)
+        if not ok:
+            return False
+        c0, c1 = st.clone_at(time0), st.clone_at(time1)
+        z = np.zeros(3)
+        r0, r1 = st.cpis.get(time0), st.cpis.get(time1)
+        ws = PlvWheelState.make(st.wheel_intr.v, st.wheel_ext.Rot(), st.wheel_ext.p, c0.Rot(), c0.p, c1.Rot(), c1.p, c0.id, c1.id,
+                                R0_fej=c0.Rot_fej(), p0_fej=c0.p_fej, R1_fej=c1.Rot_fej(), p1_fej=c1.p_fej,
+                                w0=r0["w"] if r0 else z, v0=r0["v"] if r0 else z, w1=r1["w"] if r1 else z, v1=r1["v"] if r1 else z,
+                                ext_id=st.wheel_ext.id, dt_id=st.wheel_dt.id, intr_id=st.wheel_intr.id)
+        rc, acc, dx = self.ctx.wheel_update(self.wheel_opt, ws, t, m1, m2, st.n)
+        self.stats["wheel_updates"] += 1
+        if rc != 0:
+            self.stats["not_psd"] += 1
+        elif acc:
+            st.apply(dx)
+            self.stats["wheel_accepted"] += 1
+        self.whl_last_updated = time1
+        return True
+
+    # ---------------------------------------------------------------------------------------------- logging
+    def imu_pose_covariance(self):
+        """StateHelper::get_marginal_covariance(state, {imu->pose()}) as State_Logger logs it (6 x 6)."""
+        return self.ctx.cov_download(self.state.n)[:6, :6]

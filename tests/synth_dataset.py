@@ -1,0 +1,349 @@
+"""A synthetic dataset on disk in the layout pl-viwo_amd/replay.py reads (test infrastructure): a wheeled vehicle drives a circle on a
+textured ground inside a square room with textured walls; a forward-looking radtan camera is rendered by ray casting (per-pixel rays
+undistorted once, mip-mapped texture lookup), the IMU is sampled from the analytic trajectory, the wheel encoders from the unicycle
+model.  Also writes the configuration directory (the reference's YAML layout) and the ground-truth trajectory.
+
+    python tests/synth_dataset.py OUT_DIR [--seconds 12]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
+
+G = np.array([0.0, 0.0, 9.81])
+W, H = 752, 480
+K8 = synth.EUROC_K8.copy()
+RADIUS, WALL_R, WALL_H = 8.0, 21.0, 9.0
+RL, RR, BASE = 0.31, 0.305, 1.52
+# IMU: mounted flat (z up), 0.9 m above the odometry frame, slightly yawed.  wheel_extrinsic = (R_ItoO, p_IinO)
+R_ITOO = Rotation.from_rotvec([0.0, 0.0, 0.02]).as_matrix()
+P_IINO = np.array([0.35, -0.05, 0.9])
+# camera: z forward (body x), x right (-body y), y down (-body z), pitched 12 deg down, 0.4 m ahead of and above the IMU
+R_CTOI = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]]) @ Rotation.from_rotvec([np.deg2rad(12.0), 0, 0]).as_matrix()
+P_CINI = np.array([0.4, 0.02, 0.35])
+BG, BA = np.array([0.003, -0.002, 0.0015]), np.array([0.03, -0.02, 0.025])
+SIG = dict(gyro_noise=1.7e-4, gyro_bias=1.9e-5, accel_noise=2.0e-3, accel_bias=3.0e-3)
+
+
+def arc(t):
+    """arc length and speed along the circle: 2.6 m/s with a slow modulation (never at rest: the IMU-wheel initialiser runs its
+    dynamic branch)"""
+    return 2.6 * t + 0.8 * np.sin(0.7 * t) / 0.7, 2.6 + 0.8 * np.cos(0.7 * t)
+
+
+def odom_pose(t):
+    s, _ = arc(t)
+    th = s / RADIUS
+    R_OtoG = Rotation.from_rotvec([0, 0, th]).as_matrix()
+    return R_OtoG.T, np.array([RADIUS * np.sin(th), RADIUS * (1 - np.cos(th)), 0.0])
+
+
+def imu_pose(t):
+    R_GtoO, p_O = odom_pose(t)
+    R_GtoI = R_ITOO.T @ R_GtoO
+    return R_GtoI, p_O + R_GtoI.T @ (R_ITOO.T @ P_IINO)
+
+
+def rot_2_quat(R):
+    q = Rotation.from_matrix(R.T).as_quat()   # JPL q_GtoI has the Hamilton components of R_ItoG
+    return -q if q[3] < 0 else q
+
+
+# --------------------------------------------------------------------------------------------------------------- rendering
+def _undistorted_rays():
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    x0, y0 = (xs - K8[2]) / K8[0], (ys - K8[3]) / K8[1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(12):
+        r2 = x * x + y * y
+        rad = 1 + K8[4] * r2 + K8[5] * r2 * r2
+        dx = 2 * K8[6] * x * y + K8[7] * (r2 + 2 * x * x)
+        dy = K8[6] * (r2 + 2 * y * y) + 2 * K8[7] * x * y
+        x, y = (x0 - dx) / rad, (y0 - dy) / rad
+    d = np.stack([x, y, np.ones_like(x)], axis=-1)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def _mips(seed):
+    base = synth.texture_canvas(2048 - 128, 2048 - 128, seed=seed, margin=64, blobs=9000, lines=120)
+    out = [base]
+    while out[-1].shape[0] > 16:
+        a = out[-1]
+        out.append(0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2]))
+    return out
+
+
+def _sample(mips, u, v, level):
+    """bilinear lookup of texel coordinates (u, v) of level 0 at the mip level chosen per pixel, wrapping around"""
+    out = np.zeros(u.shape)
+    lv = np.clip(np.rint(level), 0, len(mips) - 1).astype(int)
+    for l in np.unique(lv):
+        m = lv == l
+        tex = mips[l]
+        n = tex.shape[0]
+        uu, vv = u[m] / (1 << l) - 0.5, v[m] / (1 << l) - 0.5
+        i0, j0 = np.floor(uu).astype(int), np.floor(vv).astype(int)
+        fu, fv = uu - i0, vv - j0
+        i0, j0, i1, j1 = i0 % n, j0 % n, (i0 + 1) % n, (j0 + 1) % n
+        out[m] = (1 - fv) * ((1 - fu) * tex[j0, i0] + fu * tex[j0, i1]) + fv * ((1 - fu) * tex[j1, i0] + fu * tex[j1, i1])
+    return out
+
+
+class Renderer:
+    TEXEL = 0.012   # metres per level-0 texel
+
+    def __init__(self, seed=7):
+        self.rays = _undistorted_rays().reshape(-1, 3)
+        self.ground, self.wall = _mips(seed), _mips(seed + 1)
+        self.f = 0.5 * (K8[0] + K8[1])
+
+    def render(self, t):
+        R_GtoI, p_I = imu_pose(t)
+        R_CtoG = R_GtoI.T @ R_CTOI
+        c = p_I + R_GtoI.T @ P_CINI
+        d = self.rays @ R_CtoG.T
+        img = np.full(len(d), 0.55)
+        # ground z = 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = np.where(d[:, 2] < -1e-6, -c[2] / d[:, 2], np.inf)
+        # four planar walls of a square room (half side WALL_R) centred on the circle: lines drawn on them are straight in 3D
+        best_t = np.where(np.isfinite(tg), tg, np.inf)
+        img_hit = np.full(len(d), -1)            # -1 sky, 0 ground, 1.. wall index + 1
+        img_hit[np.isfinite(tg)] = 0
+        ox, oy = c[0], c[1] - RADIUS
+        walls = []
+        for k, (axis, sign) in enumerate(((0, 1.0), (0, -1.0), (1, 1.0), (1, -1.0))):
+            o, dd = (ox, d[:, 0]) if axis == 0 else (oy, d[:, 1])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tw = np.where(sign * dd > 1e-9, (sign * WALL_R - o) / dd, np.inf)
+            zw = c[2] + tw * d[:, 2]
+            other = (oy + tw * d[:, 1]) if axis == 0 else (ox + tw * d[:, 0])
+            ok = np.isfinite(tw) & (zw >= 0) & (zw <= WALL_H) & (np.abs(other) <= WALL_R)
+            tw = np.where(ok, tw, np.inf)
+            closer = tw < best_t
+            best_t = np.where(closer, tw, best_t)
+            img_hit[closer] = k + 1
+            walls.append((axis, sign))
+        for which in range(0, 5):
+            hit = img_hit == which
+            if not hit.any():
+                continue
+            dist = best_t[hit]
+            p = c + dist[:, None] * d[hit]
+            if which == 0:
+                mips = self.ground
+                u, v = p[:, 0] / self.TEXEL, p[:, 1] / self.TEXEL
+                cosi = np.abs(d[hit, 2])
+            else:
+                axis, sign = walls[which - 1]
+                mips = self.wall
+                along = (p[:, 1] - RADIUS) if axis == 0 else p[:, 0]
+                u, v = (along + 2.0 * WALL_R * which) / self.TEXEL, p[:, 2] / self.TEXEL
+                cosi = np.abs(d[hit, axis])
+            foot = dist / self.f / np.maximum(cosi, 0.15)
+            level = np.log2(np.maximum(foot / self.TEXEL, 1.0))
+            img[hit] = _sample(mips, u, v, level)
+        return np.clip(np.rint(img.reshape(H, W) * 255.0), 0, 255).astype(np.uint8)
+
+
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
+
+
+# ------------------------------------------------------------------------------------------------------------------ config
+def write_config(cfg_dir, dataset_dir, traj_path, use_wheel=True, use_lines=True, aligned=True):
+    os.makedirs(cfg_dir, exist_ok=True)
+    T_ic = np.eye(4)
+    T_ic[:3, :3], T_ic[:3, 3] = R_CTOI, P_CINI
+    # T_imu_wheel = [R_OtoI  p_OinI]
+    T_iw = np.eye(4)
+    T_iw[:3, :3], T_iw[:3, 3] = R_ITOO.T, -R_ITOO.T @ P_IINO
+    mat = lambda T: "\n".join("    - [" + ", ".join(f"{x:.12g}" for x in row) + "]" for row in T)
+    files = {
+        "config.yaml": "%YAML:1.0\n\n" + "\n".join(f'config_{k}: "config_{k}.yaml"' for k in ("system", "estimator", "camera", "imu", "wheel", "init")) + "\n",
+        "config_system.yaml": f'''%YAML:1.0
+
+sys:
+  verbosity: 2
+  save_timing: false
+  path_timing: "{os.path.join(os.path.dirname(traj_path), "timing.txt")}"
+  save_state: false
+  path_state: "{os.path.dirname(traj_path)}"
+  save_trajectory: true
+  path_trajectory: "{traj_path}"
+  save_prints: false
+  exp_id: 0
+  path_bag: "{dataset_dir}"
+  bag_start: 0
+  bag_durr: -1
+''',
+        "config_estimator.yaml": '''%YAML:1.0
+
+est:
+  gravity_mag: 9.81
+  clone_freq: 10
+  window_size: 1.0
+  intr_order: 3
+  intr_error_mlt: 3
+  intr_error_ori_thr: 0.007
+  intr_error_pos_thr: 0.003
+  intr_error_thr_mlt: 0.5
+  dt_extrapolation: 0.01
+  use_imu_res: false
+  use_imu_cov: false
+  use_pol_cov: true
+  dynamic_cloning: false
+
+intr_ori:
+  Hz_10: [0.00288, 0.00126, 0.00108, 0.00102, 0.00102]
+  Hz_20: [0.00084, 0.00012, 0.00006, 0.00003, 0.00003]
+intr_pos:
+  Hz_10: [0.00312, 0.00087, 0.00072, 0.00066, 0.00066]
+  Hz_20: [0.00084, 0.00009, 0.00006, 0.00003, 0.00003]
+''',
+        "config_camera.yaml": f'''%YAML:1.0
+
+cam:
+  enabled: true
+  max_n: 1
+  use_stereo: false
+  do_calib_ext: false
+  do_calib_int: false
+  do_calib_dt: false
+  n_pts: 250
+  fast: 20
+  grid_x: 5
+  grid_y: 5
+  min_px_dist: 10
+  knn: 0.85
+  downsample: false
+  histogram_method: "HISTOGRAM"
+  max_slam: 0
+  max_msckf: 60
+  feat_rep: "GLOBAL_3D"
+  init_cov_dt: 1e-4
+  init_cov_ex_o: 1e-4
+  init_cov_ex_p: 1e-4
+  init_cov_in_k: 1e-2
+  init_cov_in_c: 1e-1
+  init_cov_in_r: 1e-6
+  sigma_px: 1.0
+  chi2_mult: 1
+  fi_max_dist: 80
+  fi_max_baseline: 2000
+  fi_max_cond_number: 30000
+
+cam0:
+  timeoffset: 0.0
+  T_imu_cam:
+{mat(T_ic)}
+  distortion_coeffs: [{", ".join(f"{x:.10g}" for x in K8[4:])}]
+  distortion_model: radtan
+  intrinsics: [{", ".join(f"{x:.10g}" for x in K8[:4])}]
+  resolution: [{W}, {H}]
+  topic: "cam0"
+''',
+        "config_imu.yaml": f'''%YAML:1.0
+
+imu:
+  accel_noise: {SIG["accel_noise"]}
+  accel_bias: {SIG["accel_bias"]}
+  gyro_noise: {SIG["gyro_noise"]}
+  gyro_bias: {SIG["gyro_bias"]}
+  topic: "imu0"
+''',
+        "config_wheel.yaml": f'''%YAML:1.0
+
+wheel:
+  enabled: {"true" if use_wheel else "false"}
+  type: "Wheel3DAng"
+  do_calib_dt: false
+  do_calib_ext: false
+  do_calib_int: false
+  noise_w: 0.02
+  noise_v: 0.02
+  noise_p: 0.05
+  init_cov_dt: 1e-4
+  init_cov_ex_o: 1e-4
+  init_cov_ex_p: 1e-3
+  init_cov_in_b: 1e-3
+  init_cov_in_r: 1e-3
+  chi2_mult: 2
+  timeoffset: 0.0
+  intrinsics: [{RL}, {RR}, {BASE}]
+  reuse_of_information: false
+  T_imu_wheel:
+{mat(T_iw)}
+  topic: "wheel"
+''',
+        "config_init.yaml": f'''%YAML:1.0
+
+init:
+  window_time: 1.0
+  imu_thresh: 0.3
+  imu_wheel_thresh: 0.1
+  imu_only_init: false
+  imu_gravity_aligned: {"true" if aligned else "false"}
+  use_gt: false
+  cov_size: 1e-3
+''',
+    }
+    for name, text in files.items():
+        with open(os.path.join(cfg_dir, name), "w") as f:
+            f.write(text)
+    return os.path.join(cfg_dir, "config.yaml")
+
+
+# ----------------------------------------------------------------------------------------------------------------- dataset
+def make_dataset(out_dir, seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, render=True, log=None):
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(out_dir, "cam0", "data"), exist_ok=True)
+    t, wm, am = synth.imu_stream(imu_pose, 0.0, seconds + 0.1, rate=imu_hz, bg=BG, ba=BA)
+    wm = wm + rng.normal(0, SIG["gyro_noise"] * np.sqrt(imu_hz), wm.shape)
+    am = am + rng.normal(0, SIG["accel_noise"] * np.sqrt(imu_hz), am.shape)
+    with open(os.path.join(out_dir, "imu.csv"), "w") as f:
+        f.write("# t wx wy wz ax ay az\n")
+        for i in range(len(t)):
+            f.write(f"{t[i]:.9f},{wm[i, 0]:.12g},{wm[i, 1]:.12g},{wm[i, 2]:.12g},{am[i, 0]:.12g},{am[i, 1]:.12g},{am[i, 2]:.12g}\n")
+    tw = 0.0031 + np.arange(int((seconds + 0.1) * wheel_hz)) / wheel_hz
+    with open(os.path.join(out_dir, "wheel.csv"), "w") as f:
+        f.write("# t left right (wheel angular velocities, rad/s)\n")
+        for x in tw:
+            v = arc(x)[1]
+            w = v / RADIUS
+            m1, m2 = (v - w * BASE / 2) / RL + rng.normal(0, 0.02), (v + w * BASE / 2) / RR + rng.normal(0, 0.02)
+            f.write(f"{x:.9f},{m1:.12g},{m2:.12g}\n")
+    tc = 0.05 + np.arange(int(seconds * cam_hz)) / cam_hz
+    rd = Renderer() if render else None
+    with open(os.path.join(out_dir, "cam0", "data.csv"), "w") as f:
+        f.write("# t file\n")
+        for k, x in enumerate(tc):
+            name = f"{k:06d}.pgm"
+            f.write(f"{x:.9f},{name}\n")
+            if rd is not None:
+                write_pgm(os.path.join(out_dir, "cam0", "data", name), rd.render(x))
+            if log and k % 20 == 0:
+                log(f"rendered {k}/{len(tc)}")
+    with open(os.path.join(out_dir, "gt.txt"), "w") as f:
+        f.write("# timestamp(s) tx ty tz qx qy qz qw\n")
+        for x in t[::2]:
+            R, p = imu_pose(x)
+            q = rot_2_quat(R)
+            f.write(f"{x:.6f} {p[0]:.6f} {p[1]:.6f} {p[2]:.6f} {q[0]:.8f} {q[1]:.8f} {q[2]:.8f} {q[3]:.8f}\n")
+    return dict(imu=(t, wm, am), cam_times=tc)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--seconds", type=float, default=12.0)
+    a = ap.parse_args()
+    make_dataset(a.out, a.seconds, log=print)
+    print(write_config(os.path.join(a.out, "config"), a.out, os.path.join(a.out, "out", "traj.txt")))
