@@ -220,7 +220,7 @@ def replay(op, dataset=None, trajectory_path=None, device=0, progress=None, max_
     if log:
         log.close()
     stats = dict(sys.stats)
-    stats.update(distance_m=sys.distance, time_s={k: round(v, 3) for k, v in sys.tc.total.items()}, initialized=sys.state.initialized,
+    stats.update(distance_m=sys.distance, time_s={k: round(v, 4) for k, v in sys.tc.total.items()}, initialized=sys.state.initialized,
                  startup_time=sys.state.startup_time, end_time=sys.state.time, n_state=sys.state.n, clone_freq=op.est.clone_freq)
     sys.close()
     return stats, np.array(times), np.array(poses).reshape(-1, 7)

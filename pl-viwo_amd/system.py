@@ -464,14 +464,18 @@ class SystemManager:
         if len(self.cam_t_hist) > 100:
             self.cam_t_hist.pop(0)
         self.cam_t_hist.append(float(t))
+        self.tc.ding("[Time-Cam] feed measurement: points")      # labels of UpdaterCamera.cpp:79-190
         if e.cam.downsample:
             self.ctx.tracker_feed_downsampled(t, img, mask)
         else:
             self.ctx.tracker_feed(t, img, mask)
+        self.tc.dong("[Time-Cam] feed measurement: points")
         if self.use_lines:
+            self.tc.ding("[Time-Cam] feed measurement: lines")
             vps = self.ctx.vanishing_points(st.cam_ext.Rot(), st.cam_intr.v)
             self.ctx.line_tracker_feed(t, vps)
             self.stats["lines_tracked"] += self.ctx.line_db_size()
+            self.tc.dong("[Time-Cam] feed measurement: lines")
         self.stats["frames"] += 1
         if st.initialized:
             self._camera_try_update()
@@ -485,6 +489,7 @@ class SystemManager:
         c, fi = e.cam, e.cam.featinit
         full = st.clone_window() > e.window_size
         kw = dict(t_prev_frame=self.cam_t_hist[-2], state_time=st.time, window_full=full, chi2_mult=c.chi2_mult)
+        self.tc.ding("[Time-Cam] get features + MSCKF update")
         out = self.ctx.camera_update_points(st.view(), st.n, min(c.max_msckf, self.ctx.cfg.max_features), self.max_obs, min_dist=fi.min_dist,
                                             max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline,
                                             refine=fi.refine_features, **kw)
@@ -493,9 +498,11 @@ class SystemManager:
         elif out["n_accepted"] > 0:
             st.apply(out["dx"])
             self.stats["cam_updates"] += 1
+        self.tc.dong("[Time-Cam] get features + MSCKF update")
         self.stats["cam_features"] += out["n_msckf"]
         self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
         if self.use_lines:
+            self.tc.ding("[Time-Cam] LINE update")
             lo = self.ctx.camera_update_lines(st.view(), st.n, self.max_obs, **kw)
             self.stats["line_pool"] += lo["n_pool"]
             self.stats["lines_triangulated"] += lo["n_lines"]
@@ -505,6 +512,7 @@ class SystemManager:
                 st.apply(lo["dx"])
                 self.stats["line_updates"] += 1
                 self.stats["lines_accepted"] += lo["n_accepted"]
+            self.tc.dong("[Time-Cam] LINE update")
 
     # ---------------------------------------------------------------------------------------------- wheel
     def feed_measurement_wheel(self, t, m1, m2):
