@@ -477,6 +477,10 @@ typedef struct plv_update_options {
   int n_slam;           /* State::cam_SLAM_features.size()                                             */
   const uint64_t *slam_ids; /* [n_slam] feature ids of the landmarks in the state                      */
   int init_min_meas;    /* min(window_size * (int)cam_hz - 1, 10): track length that qualifies for SLAM initialisation (:685) */
+  const plv_cpi_table *cpi; /* OptionsEstimator::use_imu_res: State::get_interpolated_pose = get_interpolated_pose_imu (REF:
+                         * State.cpp:975-977): the pose of every observation (validity, triangulation, residual) comes from this
+                         * table through plv_cpi_poses; an observation it cannot serve goes back to the database as one without
+                         * bounding clones does (CamHelper.cpp:360-365).  NULL = polynomial poses.                               */
 } plv_update_options;
 
 typedef struct plv_update_result {

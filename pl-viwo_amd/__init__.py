@@ -381,7 +381,8 @@ ALIGN = {"posyaw": 0, "posyawsingle": 1, "se3": 2, "se3single": 3, "sim3": 4, "n
 class PlvUpdateOptions(C.Structure):
     _fields_ = [("max_msckf", C.c_int), ("max_obs", C.c_int), ("chi2_mult", C.c_double), ("tri", PlvTriOptions),
                 ("t_prev_frame", C.c_double), ("state_time", C.c_double), ("window_full", C.c_int),
-                ("max_slam", C.c_int), ("n_slam", C.c_int), ("slam_ids", C.POINTER(C.c_uint64)), ("init_min_meas", C.c_int)]
+                ("max_slam", C.c_int), ("n_slam", C.c_int), ("slam_ids", C.POINTER(C.c_uint64)), ("init_min_meas", C.c_int),
+                ("cpi", C.POINTER(PlvCpiTable))]
 
 
 class PlvUpdateResult(C.Structure):
@@ -954,11 +955,11 @@ class Context:
 
     def camera_update_points(self, st, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0,
                              min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True, max_slam=0, slam_ids=(),
-                             init_min_meas=10):
+                             init_min_meas=10, cpi=None):
         sl = np.ascontiguousarray(slam_ids, dtype=np.uint64)
         opt = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0),
                                t_prev_frame, state_time, 1 if window_full else 0, max_slam, len(sl), _u64p(sl) if len(sl) else None,
-                               init_min_meas)
+                               init_min_meas, C.pointer(cpi.c) if cpi is not None else None)
         res = PlvUpdateResult()
         dx = np.zeros(n)
         ids = np.zeros(max_msckf, dtype=np.uint64)
@@ -1004,9 +1005,9 @@ class Context:
         p = np.ascontiguousarray(p, dtype=np.float64)
         self._chk(self.lib.plv_point_used_insert(self.h, int(fid), _dp(p), float(newest)))
 
-    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512):
+    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512, cpi=None):
         opt = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0,
-                               0, 0, None, 10)
+                               0, 0, None, 10, C.pointer(cpi.c) if cpi is not None else None)
         res = PlvUpdateResult()
         dx = np.zeros(n)
         ids, acc, lg = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))

@@ -610,6 +610,39 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   if (pool.empty()) return finish(PLV_OK);
   // ---- triangulate every pool line (REF :45-63; get_imu_poses drops views without bounding clones)
   const int Lp = (int)pool.size();
+  // ---- use_imu_res: poses from the CPI table (plv_update_options::cpi); views it cannot serve go back to the database
+  std::vector<std::vector<double>> cpiR(opt->cpi ? Lp : 0), cpip(opt->cpi ? Lp : 0);
+  if (opt->cpi) {
+    std::vector<double> tq;
+    for (const Cand &c : pool)
+      for (double t : c.tr.t) tq.push_back(t + dt);
+    std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
+    std::vector<uint8_t> okq(tq.size());
+    int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
+    if (rc0 != PLV_OK) {
+      for (const Cand &c : pool) give_back_all(c);
+      return finish(rc0);
+    }
+    size_t o = 0;
+    for (int l = 0; l < Lp; ++l) {
+      Cand &c = pool[l];
+      LineTrack kept;
+      kept.D = c.tr.D;
+      kept.points = c.tr.points;
+      for (size_t i = 0; i < c.tr.t.size(); ++i, ++o) {
+        if (!okq[o]) {
+          give_back(c, i);
+          continue;
+        }
+        kept.t.push_back(c.tr.t[i]);
+        kept.uv.insert(kept.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+        kept.uvn.insert(kept.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
+        cpiR[l].insert(cpiR[l].end(), &Rq[9 * o], &Rq[9 * o] + 9);
+        cpip[l].insert(cpip[l].end(), &pq[3 * o], &pq[3 * o] + 3);
+      }
+      c.tr = std::move(kept);
+    }
+  }
   std::vector<int> ptr(Lp + 1, 0), D(Lp);
   std::vector<double> anchor(3 * (size_t)Lp, 0.0);
   std::vector<uint8_t> has(Lp, 0), ok(Lp);
@@ -623,6 +656,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       }
   }
   const int nobs = ptr[Lp];
+  if (nobs == 0) return finish(PLV_OK);
   std::vector<double> ot(nobs), lg(6 * (size_t)Lp);
   std::vector<float> uv(4 * (size_t)nobs), uvn(4 * (size_t)nobs);
   for (int l = 0; l < Lp; ++l) {
@@ -640,6 +674,15 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   all.D = D.data();
   all.anchor_pt = anchor.data();
   all.has_pt = has.data();
+  std::vector<double> allR, allp;
+  if (opt->cpi) {
+    for (int l = 0; l < Lp; ++l) {
+      allR.insert(allR.end(), cpiR[l].begin(), cpiR[l].end());
+      allp.insert(allp.end(), cpip[l].begin(), cpip[l].end());
+    }
+    all.res_R = allR.data();
+    all.res_p = allp.data();
+  }
   int rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
   if (rc != PLV_OK) {
     for (const Cand &c : pool) give_back_all(c);
@@ -660,7 +703,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   // ---- UpdaterCamera::lines_update
   const int L = (int)sel.size();
   std::vector<int> sptr(L + 1, 0);
-  std::vector<double> st_t, sl(6 * (size_t)L);
+  std::vector<double> st_t, sl(6 * (size_t)L), selR, selp;
   std::vector<float> suv;
   for (int q = 0; q < L; ++q) {
     const Cand &c = pool[sel[q]];
@@ -671,6 +714,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       }
       st_t.push_back(c.tr.t[i]);
       suv.insert(suv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+      if (opt->cpi) {
+        selR.insert(selR.end(), &cpiR[sel[q]][9 * i], &cpiR[sel[q]][9 * i] + 9);
+        selp.insert(selp.end(), &cpip[sel[q]][3 * i], &cpip[sel[q]][3 * i] + 3);
+      }
     }
     sptr[q + 1] = (int)st_t.size();
     std::copy(lg.begin() + 6 * (size_t)sel[q], lg.begin() + 6 * (size_t)sel[q] + 6, sl.begin() + 6 * (size_t)q);
@@ -683,6 +730,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   lt.obs_time = st_t.data();
   lt.seg_uv = suv.data();
   lt.line_FinG = sl.data();
+  if (opt->cpi) {
+    lt.res_R = selR.data();
+    lt.res_p = selp.data();
+  }
   std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
   int k = 0;
   rc = plv_line_jacobian_columns(st, &lt, cols.data(), (int)cols.size(), &k);

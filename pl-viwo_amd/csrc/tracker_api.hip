@@ -415,9 +415,44 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // ---- triangulate the whole pool in one call (the reference goes feature by feature until the cap; a
   //      feature it never reaches keeps its observations either way)
   const int Fp = (int)pool.size();
+  // ---- use_imu_res: poses from the CPI table; what it cannot serve leaves the track here (get_imu_poses, :356-365)
+  std::vector<std::vector<double>> cpiR(opt->cpi ? Fp : 0), cpip(opt->cpi ? Fp : 0);
+  if (opt->cpi) {
+    std::vector<double> tq;
+    for (const Cand &c : pool)
+      for (double t : c.tr.t) tq.push_back(t + dt);
+    std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
+    std::vector<uint8_t> okq(tq.size());
+    int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
+    if (rc0 != PLV_OK) {
+      for (const Cand &c : pool) give_back_all(c);
+      return finish(rc0);
+    }
+    size_t o = 0;
+    for (int f = 0; f < Fp; ++f) {
+      Cand &c = pool[f];
+      Track kept;
+      for (size_t i = 0; i < c.tr.t.size(); ++i, ++o) {
+        if (!okq[o]) {
+          give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+          continue;
+        }
+        kept.t.push_back(c.tr.t[i]);
+        kept.uv.insert(kept.uv.end(), &c.tr.uv[2 * i], &c.tr.uv[2 * i] + 2);
+        kept.uvn.insert(kept.uvn.end(), &c.tr.uvn[2 * i], &c.tr.uvn[2 * i] + 2);
+        cpiR[f].insert(cpiR[f].end(), &Rq[9 * o], &Rq[9 * o] + 9);
+        cpip[f].insert(cpip[f].end(), &pq[3 * o], &pq[3 * o] + 3);
+      }
+      c.tr = std::move(kept);
+    }
+  }
   std::vector<int> ptr(Fp + 1, 0);
   for (int f = 0; f < Fp; ++f) ptr[f + 1] = ptr[f] + (int)pool[f].tr.t.size();
   const int nobs = ptr[Fp];
+  if (nobs == 0) {
+    std::fill(dx, dx + ctx->cov_n, 0.0);
+    return finish(PLV_OK);
+  }
   std::vector<double> ot(nobs), pf(3 * (size_t)Fp), err(Fp);
   std::vector<float> ouv(2 * (size_t)nobs), ouvn(2 * (size_t)nobs);
   std::vector<uint8_t> ok(Fp);
@@ -433,6 +468,15 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   all.obs_time = ot.data();
   all.obs_uv = ouv.data();
   all.obs_uvn = ouvn.data();
+  std::vector<double> allR, allp;
+  if (opt->cpi) {
+    for (int f = 0; f < Fp; ++f) {
+      allR.insert(allR.end(), cpiR[f].begin(), cpiR[f].end());
+      allp.insert(allp.end(), cpip[f].begin(), cpip[f].end());
+    }
+    all.res_R = allR.data();
+    all.res_p = allp.data();
+  }
   int rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
   if (rc != PLV_OK) {
     for (const Cand &c : pool) give_back_all(c);
@@ -489,7 +533,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // ---- UpdaterCamera::msckf_update on the selected features
   const int F = (int)sel.size();
   std::vector<int> sptr(F + 1, 0);
-  std::vector<double> st_t, sp(3 * (size_t)F);
+  std::vector<double> st_t, sp(3 * (size_t)F), selR, selp;
   std::vector<float> suv;
   for (int q = 0; q < F; ++q) {
     const Cand &c = pool[sel[q]];
@@ -501,6 +545,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       st_t.push_back(c.tr.t[i]);
       suv.push_back(c.tr.uv[2 * i]);
       suv.push_back(c.tr.uv[2 * i + 1]);
+      if (opt->cpi) {
+        selR.insert(selR.end(), &cpiR[sel[q]][9 * i], &cpiR[sel[q]][9 * i] + 9);
+        selp.insert(selp.end(), &cpip[sel[q]][3 * i], &cpip[sel[q]][3 * i] + 3);
+      }
     }
     sptr[q + 1] = (int)st_t.size();
     std::copy(pf.begin() + 3 * (size_t)sel[q], pf.begin() + 3 * (size_t)sel[q] + 3, sp.begin() + 3 * (size_t)q);
@@ -514,6 +562,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   tr.obs_uv = suv.data();
   tr.p_FinG = sp.data();
   tr.p_FinG_fej = sp.data();  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
+  if (opt->cpi) {
+    tr.res_R = selR.data();
+    tr.res_p = selp.data();
+  }
   std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
   int k = 0;
   rc = plv_jacobian_columns(st, &tr, cols.data(), (int)cols.size(), &k);

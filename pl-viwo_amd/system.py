@@ -9,14 +9,15 @@ REF: PL-VIWO/src/core/SystemManager.cpp:55-135 (feed_measurement_imu / _camera /
 
 The camera path follows the intended flow feed_measurement -> try_update (as published, SystemManager.cpp:107-127 returns
 before try_update once the filter is initialised).  Scope of this driver: one camera (monocular), MSCKF points and lines
-(cam.max_slam must be 0, the shipped value), wheel optional; GPS / LiDAR / stereo / simulation are outside SURVEY §8.
+(cam.max_slam must be 0, the shipped value), wheel optional; `use_imu_res` takes the poses of the camera update from the CPI records of plv_propagate; GPS / LiDAR / stereo /
+simulation are outside SURVEY §8.
 """
 import math
 import time as _time
 
 import numpy as np
 
-from . import (Context, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, WHEEL_TYPES, default_config,
+from . import (Context, CpiTable, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, WHEEL_TYPES, default_config,
                imu_noise, init_imu_static, next_clone_time, reset_cpi, select_imu_readings, select_wheel_data)
 from .options import OptionsError
 
@@ -188,6 +189,13 @@ class State:
                          extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
                          sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
                          feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp)
+
+    def cpi_table(self):
+        """State::cpis as the plv_cpi_table of plv_cpi_poses / plv_update_options::cpi."""
+        ts = sorted(self.cpis)
+        r = [self.cpis[t] for t in ts]
+        return CpiTable(ts, [x["clone_t"] for x in r], [x["R"] for x in r], [x["alpha"] for x in r], [x["v"] for x in r],
+                        gravity=tuple(self.op.est.gravity))
 
     # ---- x <- x [+] dx for every variable (StateHelper::EKFUpdate :156-168)
     def apply(self, dx):
@@ -368,14 +376,15 @@ class SystemManager:
             return
         _, _, recs = self.ctx.propagate(st.imu, self.noise, t, wm, am, st.n, acc=self.cpi_acc, imu_id=0, want_records=True)
         for r in recs:
-            st.cpis[r.t] = dict(t=r.t, dt=r.dt, clone_t=r.clone_t, R=np.array(r.R_I0toIk).reshape(3, 3), w=np.array(r.w), v=np.array(r.v))
+            st.cpis[r.t] = dict(t=r.t, dt=r.dt, clone_t=r.clone_t, R=np.array(r.R_I0toIk).reshape(3, 3), alpha=np.array(r.alpha),
+                                w=np.array(r.w), v=np.array(r.v))
         st.time = float(timestamp)
 
     def _reset_cpi(self, clone_t):   # Propagator.cpp:333-357
         st = self.state
         self.cpi_acc = reset_cpi(st.imu, clone_t)
         w = st.cpis[clone_t]["w"] if clone_t in st.cpis else np.zeros(3)
-        st.cpis[clone_t] = dict(t=clone_t, dt=0.0, clone_t=clone_t, R=np.eye(3), w=w, v=np.array(st.imu.v))
+        st.cpis[clone_t] = dict(t=clone_t, dt=0.0, clone_t=clone_t, R=np.eye(3), alpha=np.zeros(3), w=w, v=np.array(st.imu.v))
 
     # ================================================================================================ SystemManager
     def feed_measurement_imu(self, t, wm, am):
@@ -489,6 +498,8 @@ class SystemManager:
         c, fi = e.cam, e.cam.featinit
         full = st.clone_window() > e.window_size
         kw = dict(t_prev_frame=self.cam_t_hist[-2], state_time=st.time, window_full=full, chi2_mult=c.chi2_mult)
+        if e.use_imu_res:      # State::get_interpolated_pose = get_interpolated_pose_imu (State.cpp:975-977)
+            kw["cpi"] = st.cpi_table()
         self.tc.ding("[Time-Cam] get features + MSCKF update")
         out = self.ctx.camera_update_points(st.view(), st.n, min(c.max_msckf, self.ctx.cfg.max_features), self.max_obs, min_dist=fi.min_dist,
                                             max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline,

@@ -69,8 +69,19 @@ def _undistorted_rays():
     return d / np.linalg.norm(d, axis=-1, keepdims=True)
 
 
-def _mips(seed):
-    base = synth.texture_canvas(2048 - 128, 2048 - 128, seed=seed, margin=64, blobs=9000, lines=120)
+def _mips(seed, manhattan=True):
+    """texture + its mip pyramid; with `manhattan` the bright straight edges run along the two texture axes only (on the walls:
+    horizontal and vertical structural lines, the kind the line front-end classifies by vanishing point)"""
+    base = synth.texture_canvas(2048 - 128, 2048 - 128, seed=seed, margin=64, blobs=9000, lines=0 if manhattan else 120)
+    if manhattan:
+        rng = np.random.default_rng(seed + 100)
+        n = base.shape[0]
+        for _ in range(140):
+            L, c0, c1 = int(rng.uniform(80, 400)), int(rng.uniform(8, n - 8)), int(rng.uniform(0, n - 400))
+            if rng.random() < 0.5:
+                base[c0 - 1:c0 + 2, c1:c1 + L] = 1.0
+            else:
+                base[c1:c1 + L, c0 - 1:c0 + 2] = 1.0
     out = [base]
     while out[-1].shape[0] > 16:
         a = out[-1]

@@ -49,6 +49,22 @@ def test_replay_camera_imu_wheel(pkg, dataset, tmp_path):
     assert all(len(x) == 20 for x in rows) and all(float(x[8]) > 0 and float(x[14]) > 0 for x in rows)
 
 
+def test_replay_with_imu_residual_poses(pkg, dataset, tmp_path):
+    """est.use_imu_res (the shipped configuration's choice): observation poses from the preintegrated IMU records instead of the
+    polynomial through the clones.  Camera frames sit on clone times here, so both give the same filter to a few millimetres."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    res = {}
+    for flag in (False, True):
+        traj = str(tmp_path / f"traj_{int(flag)}.txt")
+        op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+        op.est.use_imu_res, op.est.cam.use_lines = flag, False
+        stats, times, poses = rp.replay(op)
+        assert stats["cam_accepted"] >= 800 and stats["not_psd"] == 0
+        res[flag] = (poses, _score(pkg, traj, os.path.join(dataset, "gt.txt"))[0])
+    assert res[True][1]["pos"]["rmse"] < 0.10
+    assert len(res[True][0]) == len(res[False][0]) and np.abs(res[True][0][:, :3] - res[False][0][:, :3]).max() < 0.05
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""

@@ -253,3 +253,65 @@ def test_camera_update_points_slam_branch(pkg, oracle):
     else:  # REF UpdaterCamera.cpp:363-364 a failed candidate returns to the database
         ctx.db_append_measurements(int(ini["ids"][0]), ini["obs_time"][a:b], ini["obs_uv"][a:b], ini["obs_uvn"][a:b])
         assert int(ini["ids"][0]) in {int(i) for i in ctx.db_select(1, 1e18)}
+
+
+def test_camera_update_points_with_cpi_poses(pkg, oracle):
+    """use_imu_res in the one-call updates (plv_update_options::cpi): poses of every observation from the CPI table (validity,
+    triangulation, residual), against the same composition of oracle pieces; observations the table cannot serve return to the
+    database."""
+    jo, fo = oracle_lib.load_jac(pkg), oracle_lib.load_front()
+    sc = synth.vio_scene(n_clones=8, F=60, M=8, noise_px=0.4, seed=12, obs_offset=0.0125)
+    cp = synth.cpi_scene(sc)
+    t, K8, n = sc["t"], sc["K8"], sc["n_state"]
+    st, _ = synth.scene_views(pkg, sc)
+    # observations sit 12.5 ms after the clones: between two records of the table (create_new_cpi_linear)
+    tab = pkg.CpiTable(cp["t"], cp["clone_t"], cp["R"], cp["alpha"], cp["v"], gravity=cp["gravity"])
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    tracks = {}
+    for f in range(60):
+        a, b = sc["obs_ptr"][f], sc["obs_ptr"][f + 1]
+        uv = sc["obs_uv"][a:b].astype(np.float32)
+        tracks[f + 1] = [sc["obs_time"][a:b].copy(), uv, fo.undistort(K8, uv)]
+    # an observation beyond the last record of the table: nothing to interpolate towards (create_new_cpi_integrate territory)
+    late = float(cp["t"][-1] + 0.004)
+    tracks[5][0][-1] = late
+    for fid, (tt, uv, uvn) in tracks.items():
+        ctx.db_append_measurements(fid, tt, uv, uvn)
+    P = synth.spd_cov(n, seed=4) * 1e-4
+    ctx.cov_upload(P)
+    MAX, MOBS = 30, 10
+    TRI = dict(max_cond=1e7, max_dist=100.0, max_baseline=1e3)
+    state_time = late + 0.1
+    out = ctx.camera_update_points(st, n, MAX, MOBS, t_prev_frame=t[-2], state_time=state_time, window_full=True, cpi=tab, **TRI)
+
+    # ---- oracle composition
+    pool = [fid for fid, (tt, _, _) in sorted(tracks.items()) if (tt < t[1]).any() or not (tt > t[-2]).any()]
+    pool.sort(key=lambda fid: -len(tracks[fid][0]))
+    tq = np.concatenate([tracks[f][0] for f in pool])
+    Rq, pq, okq = jo.cpi_poses(st, tab, tq)
+    assert (okq == 0).sum() == 1 and not okq[np.flatnonzero(tq == late)[0]]
+    ptr = np.concatenate([[0], np.cumsum([len(tracks[f][0]) for f in pool])])
+    kept = {}
+    for j, f in enumerate(pool):
+        m = okq[ptr[j]:ptr[j + 1]].astype(bool)
+        kept[f] = (tracks[f][0][m], tracks[f][1][m], tracks[f][2][m], Rq[ptr[j]:ptr[j + 1]][m], pq[ptr[j]:ptr[j + 1]][m])
+    kptr = np.concatenate([[0], np.cumsum([len(kept[f][0]) for f in pool])]).astype(np.int32)
+    cat = lambda i: np.concatenate([kept[f][i] for f in pool])
+    tr_all = pkg.Tracks(kptr, cat(0), cat(1), np.zeros((len(pool), 3)), obs_uvn=cat(2), res_R=cat(3), res_p=cat(4))
+    p_o, ok_o, err_o = jo.triangulate_batch(st, tr_all, **TRI)
+    sel = [q for q in range(len(pool)) if ok_o[q] and err_o[q] < 3.0][:MAX]
+    sptr = np.concatenate([[0], np.cumsum([len(kept[pool[q]][0]) for q in sel])]).astype(np.int32)
+    scat = lambda i: np.concatenate([kept[pool[q]][i] for q in sel])
+    tr_sel = pkg.Tracks(sptr, scat(0), scat(1), p_o[sel], res_R=scat(3), res_p=scat(4))
+    cols = jo.columns(st, tr_sel)
+    rows, Hf, Hx, res = jo.build_jacobians(st, tr_sel, cols, 2 * MOBS)
+    rc_o, P_o, dx_o, acc_o, nrows_o = oracle.msckf_update(P, rows, Hf, Hx, res, cols, st.c.sigma_pix ** 2, synth.q95_table())
+    assert out["status"] == rc_o == 0 and len(sel) >= 20
+    assert np.array_equal(out["ids"], np.array([pool[q] for q in sel], dtype=np.uint64))
+    assert np.array_equal(out["accepted"], acc_o) and acc_o.sum() >= 15 and out["n_rows"] == nrows_o
+    assert np.abs(out["p_FinG"] - p_o[sel]).max() < 1e-6
+    assert np.abs(out["dx"] - dx_o).max() <= 1e-7 * max(1.0, np.abs(dx_o).max())
+    assert np.abs(ctx.cov_download(n) - P_o).max() <= 1e-8 * np.abs(P).max()
+    ptr_l, tt_l, _, _ = ctx.db_export(np.array([5], dtype=np.uint64))
+    assert late in list(tt_l[ptr_l[0]:ptr_l[1]])          # the observation without a pose is back in the database
+    ctx.close()
