@@ -12,6 +12,7 @@ Dataset layout (`sys.path_bag` names the directory):
     wheel.csv            t, m1, m2                          (the two readings of the configured wheel type; optional)
     cam0/data.csv        t, file name                       (optional: without it the file stem is the time stamp)
     cam0/data/*          8-bit grey images: .pgm (P5), .png (grey / RGB, not interlaced) or .npy
+A directory in the EuRoC MAV (ASL) layout is read as it is: mav0/imu0/data.csv, mav0/cam0/data.csv + mav0/cam0/data/*.png.
 """
 import os
 import struct
@@ -142,7 +143,11 @@ class Dataset:
 
     def __init__(self, root, cam_dir="cam0", use_wheel=True, use_cam=True):
         self.root = root
-        imu = _read_csv(os.path.join(root, "imu.csv"), 7)
+        imu_path = os.path.join(root, "imu.csv")
+        if not os.path.exists(imu_path) and os.path.isdir(os.path.join(root, "mav0")):   # EuRoC MAV (ASL) layout
+            imu_path = os.path.join(root, "mav0", "imu0", "data.csv")
+            cam_dir = os.path.join("mav0", cam_dir)
+        imu = _read_csv(imu_path, 7)
         self.imu = np.array([[_stamp(r[0])] + [float(x) for x in r[1:]] for r in imu])
         self.wheel = np.zeros((0, 3))
         wp = os.path.join(root, "wheel.csv")

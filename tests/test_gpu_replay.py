@@ -65,6 +65,20 @@ def test_replay_with_imu_residual_poses(pkg, dataset, tmp_path):
     assert len(res[True][0]) == len(res[False][0]) and np.abs(res[True][0][:, :3] - res[False][0][:, :3]).max() < 0.05
 
 
+def test_replay_with_dynamic_cloning(pkg, dataset, tmp_path):
+    """est.dynamic_cloning: the clone rate follows the acceleration statistics of the CPI records through the interpolation-error
+    tables (SystemManager.cpp:269-312); the configuration offers 10 and 20 Hz."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    traj = str(tmp_path / "traj.txt")
+    op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+    op.est.dynamic_cloning, op.est.cam.use_lines = True, False
+    stats, times, poses = rp.replay(op)
+    assert stats["clone_freq"] in (10, 20) and stats["clones"] >= 70 and stats["not_psd"] == 0
+    assert stats["n_state"] <= 15 + 6 * 23
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.10, r
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""

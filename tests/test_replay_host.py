@@ -102,6 +102,19 @@ def test_time_stamps_in_nanoseconds(rp, tmp_path):
     assert [m[1] for m in ds.msgs] == [rp.IMU, rp.IMU, rp.CAM]
 
 
+def test_euroc_layout(rp, tmp_path):
+    d = tmp_path / "MH_01"
+    os.makedirs(d / "mav0" / "cam0" / "data")
+    os.makedirs(d / "mav0" / "imu0")
+    (d / "mav0" / "imu0" / "data.csv").write_text("#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y,w_RS_S_z,a_RS_S_x [m s^-2],a_RS_S_y,a_RS_S_z\n"
+                                                  "1403636579758555392,-0.09,0.02,0.07,8.1,-0.3,-3.9\n1403636579763555584,-0.09,0.03,0.07,8.2,-0.3,-3.9\n")
+    (d / "mav0" / "cam0" / "data.csv").write_text("#timestamp [ns],filename\n1403636579763555584,1403636579763555584.png\n")
+    _png(str(d / "mav0" / "cam0" / "data" / "1403636579763555584.png"), np.full((6, 8), 7, dtype=np.uint8), filt=4)
+    ds = rp.Dataset(str(d))
+    assert len(ds.imu) == 2 and len(ds.frames) == 1 and ds.imu[1, 4] == 8.2
+    assert rp.read_image(ds.frames[0][1]).shape == (6, 8) and [m[1] for m in ds.msgs] == [rp.IMU, rp.IMU, rp.CAM]
+
+
 def test_stat_matches_the_running_formulas(pkg):
     system = importlib.import_module("plviwo_amd.system")
     s = system.Stat()
