@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the per-frame (track + EKF update) hot path on MI355X.
 
-One "step" = one camera frame of BASELINE.json config[1] ("752x480 mono, 250 KLT points,
-15-clone MSCKF"), every input already resident in HBM when the timed region starts:
+One "step" = one camera frame of the configuration BASELINE.json's metric is quoted on ("752x480 mono, 250 pts+80 lines" =
+configs[2]: configs[1]'s point path plus the line front-end and the line update), every input already resident in HBM when
+the timed region starts (`--workload B` times configs[1], points only; its rate is also reported in `config.points_only`):
     plv_feed_staged          equalizeHist + 5-level pyramid of the staged 752x480 image
     plv_perform_matching     15x15 pyramidal LK on 250 points, radtan undistort, 7-point RANSAC
     plv_build_jacobians_resident  70 features x 15 observations: FEJ clone-polynomial interpolation,
@@ -10,6 +11,10 @@ One "step" = one camera frame of BASELINE.json config[1] ("752x480 mono, 250 KLT
     plv_cov_rollback         (restores P so that every step does identical work)
     plv_msckf_update_resident  Givens nullspace, chi2 gate, compression, EKFUpdate on the n = 113
                              covariance (fp64)
+    plv_line_tracker_feed_points  TrackLSD::feed_monocular: half-resolution Canny + fast line detector, point-line assignment
+                             with the frame's tracked points, line matching, undistortion, classification, track store
+    plv_build_line_jacobians_resident + plv_msckf_update_resident  80 lines x 15 observations (Pluecker Jacobians 30 x 6,
+                             null space of 6, chi2-only gate), second EKFUpdate of the frame as UpdaterCamera::try_update
 Feature selection and triangulation (host logic in the reference) are outside the timed step.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; N > 1 is launched by torchrun, one rank
@@ -34,12 +39,14 @@ F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix spec; v_mfma_
 W, H = 752, 480
 N_PTS, WIN = 250, 15
 N_STATE, K_COLS, F_FEATS, M_OBS, FDIM = 113, 98, 70, 15, 3
+N_LINES, LINE_LD = 80, 32
 SIGMA2 = 2.25  # the gate's R = sigma_pix^2 I on rows that are already whitened (UpdaterCamera.cpp:237-238), kept as is
 
 
-def build_inputs():
+def build_inputs(with_lines=False):
     import synth
-    canvas = synth.texture_canvas(W, H, seed=42)
+    # SURVEY §8(d) cfg 3: the cfg 2 stream + straight high-contrast edges rendered before the blur
+    canvas = synth.texture_canvas(W, H, seed=42, lines=200 if with_lines else 0)
     frames = [synth.render_frame(canvas, W, H),
               synth.render_frame(canvas, W, H, tx=4.2, ty=-3.1, rot_deg=0.3, scale=1.002)]
     pts = synth.grid_points(W, H, N_PTS, seed=5, border=16)
@@ -50,6 +57,22 @@ def build_inputs():
     scene = synth.vio_scene(n_clones=15, F=F_FEATS, M=M_OBS, seed=3, noise_px=0.4)
     assert scene["n_state"] == N_STATE
     return frames, pts, P, scene
+
+
+def points_on_lines(lines, base_pts, n_lines):
+    """250 point positions of which two lie on each of the `n_lines` longest detected segments (FAST corners sit on such edges
+    and their ends; TrackLSD keeps only lines that own a point, TrackLSD.cpp:744-792), the rest from the grid set."""
+    length = np.hypot(lines[:, 2] - lines[:, 0], lines[:, 3] - lines[:, 1])
+    order = np.argsort(-length, kind="stable")[:n_lines]
+    on = []
+    for i in order:
+        a, b = lines[i, :2], lines[i, 2:]
+        on += [a + 0.3 * (b - a), a + 0.7 * (b - a)]
+    on = np.array(on, dtype=np.float32).reshape(-1, 2)
+    keep = np.ones(len(on), dtype=bool)
+    keep &= (on[:, 0] > 16) & (on[:, 0] < W - 16) & (on[:, 1] > 16) & (on[:, 1] < H - 16)
+    on = on[keep]
+    return np.concatenate([on, base_pts[:N_PTS - len(on)]]).astype(np.float32), len(order)
 
 
 def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
@@ -90,34 +113,60 @@ def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
     }
 
 
-def cpu_baseline(pkg, frames, pts, P, scene, sample_frames):
+def cpu_baseline(pkg, frames, pts_of, P, scene, sample_frames, lt=None, cols_l=None, vps=None):
     """The CPU oracle (fp64 / OpenCV-contract restatement, g++ -O3, 1 thread) timed on this host on a
     bounded sample of the same workload.  kind = "port": the upstream binary cannot be built
     (Eigen/OpenCV/Boost/ROS absent — DESIGN.md)."""
     import oracle_lib
     import synth
     orc, fo, jo = oracle_lib.load(), oracle_lib.load_front(), oracle_lib.load_jac(pkg)
+    lo = oracle_lib.load_line() if lt is not None else None
     st, tr = synth.scene_views(pkg, scene)
     cols = jo.columns(st, tr)
     q95 = synth.q95_table()
     K8 = synth.EUROC_K8
-    prev = fo.pyramid(fo.equalize_hist(frames[0]))
-    t_front = t_upd = 0.0
+    ids = np.arange(1, N_PTS + 1, dtype=np.uint64)
+    eq_prev = fo.equalize_hist(frames[0])
+    prev = fo.pyramid(eq_prev)
+    last = None
+    t_front = t_upd = t_lfront = t_lupd = 0.0
     for i in range(sample_frames):
+        p0 = pts_of[i & 1]
         t0 = time.perf_counter()
-        cur = fo.pyramid(fo.equalize_hist(frames[(i + 1) & 1]))
-        fo.perform_matching(prev, cur, pts, pts, K8, nthreads=1)
+        eq = fo.equalize_hist(frames[(i + 1) & 1])
+        cur = fo.pyramid(eq)
+        out = fo.perform_matching(prev, cur, p0, p0, K8, nthreads=1)
         t1 = time.perf_counter()
-        rows, Hf, Hx, res = jo.build_jacobians(st, tr, cols, 2 * M_OBS)
-        orc.msckf_update(P, rows, Hf, Hx, res, cols, SIGMA2, q95)
+        if lo is not None:   # TrackLSD::feed_monocular: detection, assignment, matching, undistortion, classification
+            lines = lo.detect_lines(eq)
+            a = lo.assign_points_to_lines(lines, out[1], ids)
+            kept = lines[a["kept"]]
+            if last is not None and len(kept):
+                lo.line_match(kept, a["rel_ptr"], a["rel_id"], last[0], last[1], last[2])
+                fo.undistort(K8, kept.reshape(-1, 2))
+                for q in range(len(kept)):
+                    lo.line_classification(kept[q], vps)
+            last = (kept, a["rel_ptr"], a["rel_id"])
         t2 = time.perf_counter()
+        rows, Hf, Hx, res = jo.build_jacobians(st, tr, cols, 2 * M_OBS)
+        rc, P1, _, _, _ = orc.msckf_update(P, rows, Hf, Hx, res, cols, SIGMA2, q95)
+        t3 = time.perf_counter()
+        if lo is not None:
+            rows, Hf, Hx, res = jo.build_line_jacobians(st, lt, cols_l, LINE_LD)
+            orc.msckf_update(P1, rows, Hf, Hx, res, cols_l, SIGMA2, q95, res_norm_gate=0.0)
+        t4 = time.perf_counter()
         prev = cur
         t_front += t1 - t0
-        t_upd += t2 - t1
-    tot = t_front + t_upd
+        t_lfront += t2 - t1
+        t_upd += t3 - t2
+        t_lupd += t4 - t3
+    tot = t_front + t_upd + t_lfront + t_lupd
+    ms = lambda x: x / sample_frames * 1e3
+    parts = f"point front-end {ms(t_front):.2f} ms + point update {ms(t_upd):.2f} ms"
+    if lo is not None:
+        parts += f" + line front-end {ms(t_lfront):.2f} ms + line update {ms(t_lupd):.2f} ms"
     return {"value": sample_frames / tot, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_frames} frames of the same workload (front-end {t_front / sample_frames * 1e3:.2f} ms + "
-                      f"update {t_upd / sample_frames * 1e3:.2f} ms per frame), oracle g++ -O3 single thread, "
+            "sample": f"{sample_frames} frames of the same workload ({parts} per frame), oracle g++ -O3 single thread, "
                       f"host has {os.cpu_count()} cores"}
 
 
@@ -162,6 +211,9 @@ def main():
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     ap.add_argument("--update-graph", type=int, default=0,
                     help="1: replay the update launch sequence as a hipGraph (plv_update_graph_mode)")
+    ap.add_argument("--workload", choices=["B", "C"], default="C",
+                    help="C (default) = BASELINE configs[2], 250 points + 80 lines: the configuration the metric is quoted on; "
+                         "B = configs[1], points only")
     ap.add_argument("--sequential", action="store_true",
                     help="one context, update of frame i finished before the front-end of frame i+1 starts")
     args = ap.parse_args()
@@ -209,7 +261,8 @@ def main():
     ctx = pkg.Context(cfg)
     uctx = ctx if args.sequential else pkg.Context(cfg)
 
-    frames, pts, P, scene = build_inputs()
+    with_lines = args.workload == "C"
+    frames, pts, P, scene = build_inputs(with_lines)
     import synth
     st, tr = synth.scene_views(pkg, scene)
     cols = ctx.jacobian_columns(st, tr)
@@ -223,16 +276,51 @@ def main():
     ctx.feed_staged(0)
 
     state = {}
+    pts_of = [pts, pts]                 # positions in frame 0 / frame 1 (the "last" image of even / odd steps)
+    ids = np.arange(1, N_PTS + 1, dtype=np.uint64)
+    lt = cols_l = vps = None
+    if with_lines:
+        # untimed set-up: the 80 longest segments of each frame get two tracked points each, so that ~80 lines survive the
+        # point-line assignment every frame (SURVEY §8(d) cfg 3: "+80 lines kept after assignment")
+        ctx.feed_staged(1)
+        lines1 = ctx.detect_lines(1)    # PLV_PYR_CUR = frame 1
+        lines0 = ctx.detect_lines(0)    # PLV_PYR_LAST = frame 0
+        pts_of = [points_on_lines(lines0, pts, N_LINES)[0], points_on_lines(lines1, pts, N_LINES)[0]]
+        ctx.feed_staged(0)
+        ls = synth.line_scene(scene, L=N_LINES, M=M_OBS, noise_px=0.4)
+        lt = pkg.LineTracks(ls["obs_ptr"], ls["obs_time"], ls["seg_uv"], seg_uvn=ls["seg_uvn"], line_FinG=ls["lines"])
+        cols_l = ctx.line_jacobian_columns(st, lt)
+        vps = ctx.vanishing_points(scene["R_ItoC"], scene["K8"])
 
-    def step_sequential(i, c=None):
+    def line_front_end(c, i, pts_cur):
+        """TrackLSD::feed_monocular for the current image with the frame's tracked points; the track store is emptied once per
+        window as LineHelper::cleanup_lines prunes it in the reference (LineHelper.cpp:522-553)."""
+        c.line_tracker_feed_points(float(i), vps, pts_cur, ids)
+        if i % M_OBS == M_OBS - 1:
+            c.line_db_remove(c.line_db_ids())
+
+    def line_update(c):
+        c.build_line_jacobians_resident(st, lt, cols_l, LINE_LD)
+        rc, dx, acc, nr = c.msckf_update_resident(N_STATE, SIGMA2, res_norm_gate=0.0)
+        if rc != 0:
+            raise RuntimeError("line EKF update rejected inside the benchmark")
+        state["accepted_lines"] = int(acc.sum())
+
+    def step_sequential(i, c=None, lines=None):
         c = c or ctx
+        lines = with_lines if lines is None else lines
+        p0 = pts_of[i & 1] if lines else pts
         c.feed_staged((i + 1) & 1)
-        out = c.perform_matching(pts, pts)
+        out = c.perform_matching(p0, p0)
+        if lines:
+            line_front_end(c, i, out[0])
         c.cov_rollback()   # (before the Jacobians: their launch also gathers the covariance blocks of the update)
         c.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
         rc, dx, acc, nr = c.msckf_update_resident(N_STATE, SIGMA2)
         if rc != 0:
             raise RuntimeError("EKF update rejected inside the benchmark")
+        if lines:
+            line_update(c)
         state["tracked"] = int(out[1].sum())
         state["lk_iters"] = out[4]
         state["accepted"] = int(acc.sum())
@@ -253,7 +341,30 @@ def main():
         state["lk_iters"] = out[4]
         state["accepted"] = int(acc.sum())
 
-    step = step_sequential if args.sequential else step_pipelined
+    def step_pipelined_lines(i):
+        # points: as step_pipelined.  Lines: the line update of frame i is enqueued once the point update has been collected (both
+        # work on the one covariance, in this order, UpdaterCamera.cpp:139-195) and runs while the line front-end of frame i+1 does.
+        p0 = pts_of[i & 1]
+        uctx.cov_rollback()
+        uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
+        uctx.msckf_update_resident_launch(SIGMA2)
+        ctx.feed_staged((i + 1) & 1)
+        out = ctx.perform_matching(p0, p0)
+        rc, dx, acc, nr = uctx.msckf_update_resident_wait(N_STATE)
+        if rc != 0:
+            raise RuntimeError("EKF update rejected inside the benchmark")
+        uctx.build_line_jacobians_resident(st, lt, cols_l, LINE_LD)
+        uctx.msckf_update_resident_launch(SIGMA2, res_norm_gate=0.0)
+        line_front_end(ctx, i, out[0])
+        rc, dx, acc_l, nr = uctx.msckf_update_resident_wait(N_STATE)
+        if rc != 0:
+            raise RuntimeError("line EKF update rejected inside the benchmark")
+        state["tracked"] = int(out[1].sum())
+        state["lk_iters"] = out[4]
+        state["accepted"] = int(acc.sum())
+        state["accepted_lines"] = int(acc_l.sum())
+
+    step = step_sequential if args.sequential else (step_pipelined_lines if with_lines else step_pipelined)
 
     def barrier():
         if dist is not None:
@@ -270,6 +381,21 @@ def main():
     uctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    points_only = None
+    if with_lines:
+        state["lines_kept"] = len(ctx.line_tracker_last()[1])
+        if rank == 0 and not args.sequential:   # configs[1] in the same run, for the record (not `value`)
+            for i in range(min(args.warmup, 100)):
+                step_pipelined(i)
+            ctx.synchronize()
+            tb = time.perf_counter()
+            for i in range(args.steps):
+                step_pipelined(i)
+            ctx.synchronize()
+            uctx.synchronize()
+            eb = time.perf_counter() - tb
+            points_only = {"workload": "BASELINE configs[1] (250 points, no lines), same run", "value": args.steps / eb, "unit": "frames/s",
+                           "ms_per_step": eb / args.steps * 1e3}
     seq_ms = None
     if not args.sequential and rank == 0:  # the un-overlapped frame latency, for the record (not `value`)
         sctx = uctx
@@ -323,12 +449,13 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu:
-        cpu = cpu_baseline(pkg, frames, pts, P, scene, args.cpu_frames)
+        cpu = cpu_baseline(pkg, frames, pts_of, P, scene, args.cpu_frames, lt, cols_l, vps)
 
     if rank == 0:
         total_frames = args.steps * world
         line = {
-            "metric": "frames/sec (track+EKF update), 752x480 mono, 250 pts; ATE vs CPU ref",
+            "metric": "frames/sec (track+EKF update), 752x480 mono, 250 pts+80 lines; ATE vs CPU ref" if with_lines else
+                      "frames/sec (track+EKF update), 752x480 mono, 250 pts; ATE vs CPU ref",
             "value": total_frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -340,9 +467,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 752x480 mono, 250 KLT points (15x15 window, 5 pyramid levels), "
-                                   "MSCKF update of 70 features x 15 clones on n=113 (k=98 columns), points only",
+            "config": {"workload": ("BASELINE configs[2]: 752x480 mono, 250 KLT points (15x15 window, 5 pyramid levels) + line front-end "
+                                    "(half-resolution Canny + fast line detector, ~80 lines kept after the point-line assignment), MSCKF "
+                                    "update of 70 features x 15 clones then of 80 lines x 15 clones on n=113" if with_lines else
+                                    "BASELINE configs[1]: 752x480 mono, 250 KLT points (15x15 window, 5 pyramid levels), "
+                                    "MSCKF update of 70 features x 15 clones on n=113 (k=98 columns), points only"),
                        "replicas": world, "tracked_points": state["tracked"], "accepted_features": state["accepted"],
+                       "lines_kept": state.get("lines_kept"), "accepted_lines": state.get("accepted_lines"), "points_only": points_only,
                        "lk_iterations_per_frame": int(state["lk_iters"]),
                        "front_end_arithmetic": "u8/int16/int64 exact + f32 2x2 solve", "update_arithmetic": "f64",
                        "schedule": "sequential, one stream" if args.sequential else

@@ -448,6 +448,10 @@ int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps);
  * plv_tracker_feed (the point tracker's current observations are the ones lines are attached to).
  * Updates lines_last / ids_last and the line track store (LineFeatureDatabase::update_feature). */
 int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps);
+/* The same with the caller's point observations of this frame (pts [n][2] pixels, ids [n]) in place of the ctx's own point
+ * tracker: what an adapter that keeps the reference's TrackKLT object hands to TrackLSD (REF: TrackLSD.cpp:106-107 reads
+ * trackFEATS->get_last_obs() / get_last_ids()). */
+int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *vps, int n, const float *pts, const uint64_t *ids);
 int plv_line_tracker_last(plv_ctx *ctx, float *lines, uint64_t *ids, int cap, int *n);
 int plv_line_db_size(plv_ctx *ctx);
 int plv_line_db_ids(plv_ctx *ctx, uint64_t *ids, int cap, int *n); /* ascending */

@@ -171,6 +171,7 @@ def load_library():
         "plv_line_classification": (C.c_int, [fp, dp]),
         "plv_vanishing_points": (C.c_int, [dp, dp, dp]),
         "plv_line_tracker_feed": (C.c_int, [vp, C.c_double, dp]),
+        "plv_line_tracker_feed_points": (C.c_int, [vp, C.c_double, dp, C.c_int, fp, u64p]),
         "plv_line_tracker_last": (C.c_int, [vp, fp, u64p, C.c_int, ip]),
         "plv_line_db_size": (C.c_int, [vp]),
         "plv_line_db_ids": (C.c_int, [vp, u64p, C.c_int, ip]),
@@ -1068,6 +1069,12 @@ class Context:
     def line_tracker_feed(self, timestamp, vps):
         vps = np.ascontiguousarray(vps, dtype=np.float64)
         self._chk(self.lib.plv_line_tracker_feed(self.h, float(timestamp), _dp(vps)))
+
+    def line_tracker_feed_points(self, timestamp, vps, pts, ids):
+        vps = _c64(vps)
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        self._chk(self.lib.plv_line_tracker_feed_points(self.h, float(timestamp), _dp(vps), len(ids), _fp(pts), _u64p(ids)))
 
     def line_tracker_last(self, cap=4096):
         lines = np.zeros((cap, 4), dtype=np.float32)

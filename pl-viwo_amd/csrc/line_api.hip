@@ -10,6 +10,7 @@
 // the device.  What stays here is the reference's own host bookkeeping: which of <= ~100 segments
 // owns which of <= 250 tracked points, id hand-over between frames, the line track store.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -17,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "fld_fit_core.hpp"
 #include "line_kernels.hpp"
 
 using namespace plv;
@@ -48,6 +50,7 @@ struct LineTracker {
   // device buffers of the detector
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
   PinBuf pin;
+  std::vector<uint8_t> pad;  // host walk: bordered copy of the edge map
   std::mutex mtx;
 };
 
@@ -75,34 +78,47 @@ float point_line_distance(const float *line, float x0, float y0) {
 }
 
 // FastLineDetector's seed loop + getPointChain on a host copy of the Canny map (2 = edge).  Same
-// algorithm as fld_walk_kernel; see detect() for why the default runs it here.
-void walk_chains(uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts) {
+// algorithm as fld_walk_kernel; see detect() for why the default runs it here.  The map is copied into a
+// buffer with a one-pixel non-edge border so that the eight neighbour tests need no bounds checks.
+void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
+                 std::vector<uint8_t> &pad) {
   static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
+  const int pw = w + 2;
+  pad.assign((size_t)pw * (h + 2), 1);
+  for (int r = 0; r < h; ++r) memcpy(&pad[(size_t)(r + 1) * pw + 1], map + (size_t)r * w, w);
+  int off[8];
+  for (int i = 0; i < 8; ++i) off[i] = dy[i] * pw + dx[i];
+  uint8_t *m = pad.data();
   int n_chain = 0, n_slot = 0, n_pts = 0;
-  for (int r = 0; r < h; ++r)
+  for (int r = 0; r < h; ++r) {
+    const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
     for (int c = 0; c < w; ++c) {
-      if (map[(size_t)r * w + c] != 2) continue;
+      if (row[c] != 2) continue;
       const int start = n_pts;
       int x = c, y = r;
+      size_t idx = (size_t)(r + 1) * pw + c + 1;
       pts[n_pts++] = make_int2(x, y);
-      map[(size_t)r * w + c] = 1;
+      m[idx] = 1;
       float direction = 0.0f;
       for (int step = 0;; ++step) {
         int pick = -1;
         float best = 7.0f;
-        for (int i = 0; i < 8; ++i) {
-          const int ci = x + dx[i], ri = y + dy[i];
-          if (ri < 0 || ri >= h || ci < 0 || ci >= w || map[(size_t)ri * w + ci] != 2) continue;
-          if (step == 0) {
-            pick = i;
-            break;
-          }
-          const float curr = i > 4 ? (float)(i - 8) : (float)i;
-          float diff = std::fabs(curr - direction);
-          diff = diff > 4.0f ? 8.0f - diff : diff;
-          if (diff <= best) {
-            best = diff;
-            pick = i;
+        if (step == 0) {
+          for (int i = 0; i < 8; ++i)
+            if (m[idx + off[i]] == 2) {
+              pick = i;
+              break;
+            }
+        } else {
+          for (int i = 0; i < 8; ++i) {
+            if (m[idx + off[i]] != 2) continue;
+            const float curr = i > 4 ? (float)(i - 8) : (float)i;
+            float diff = std::fabs(curr - direction);
+            diff = diff > 4.0f ? 8.0f - diff : diff;
+            if (diff <= best) {
+              best = diff;
+              pick = i;
+            }
           }
         }
         if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
@@ -110,8 +126,9 @@ void walk_chains(uint8_t *map, int w, int h, int length_threshold, int2 *pts, Fl
         direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
         x += dx[pick];
         y += dy[pick];
+        idx += off[pick];
         pts[n_pts++] = make_int2(x, y);
-        map[(size_t)y * w + x] = 1;
+        m[idx] = 1;
       }
       const int len = n_pts - start;
       if (len >= length_threshold + 1 && n_chain < chain_cap) {
@@ -121,6 +138,7 @@ void walk_chains(uint8_t *map, int w, int h, int length_threshold, int2 *pts, Fl
         n_pts = start;
       }
     }
+  }
   counts[0] = n_chain;
   counts[1] = n_slot;
   counts[2] = n_pts;
@@ -150,29 +168,57 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
   TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
-  TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (1 + sizeof(int2)))));
+  TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (2 + sizeof(int2)) + 64)));
   char *hp = T->pin.as<char>();
-  if (T->walk_on_device) {
-    TRY(launch_line_walk(ctx, w, h, fp, b));
-  } else {
-    // The chain walk consumes edge pixels in raster order and every step depends on the one before:
-    // a single dependent chain of ~10^4 .. 3*10^4 scalar steps.  One MI355X lane retires such a step in
-    // ~0.8 us (measured, 28 ms per frame on the dense-edge test image), a host core in ~30 ns, so the
-    // walk runs here on the 90 KB edge map between the two device stages (DESIGN.md "Line detector").
+  const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
+  auto emit = [&](const float4 &sg) {
+    const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+    const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+    if (!(l2 > thr2)) return;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+    lines.insert(lines.end(), {x1, y1, x2, y2});
+  };
+  lines.clear();
+  if (!T->walk_on_device) {
+    // The chain walk consumes edge pixels in raster order and every step depends on the one before, and so does the growth of
+    // the segments along a chain: one dependent scalar sequence of ~10^4 .. 3*10^4 steps.  One MI355X lane retires such a step
+    // in ~0.8 us (measured: 28 ms per frame for the walk on the dense-edge test image, 160 us for fld_fit_kernel's longest
+    // chain), a host core in ~30 ns, so both run here on the 90 KB edge map and the half-resolution image (DESIGN.md "Line
+    // detector"); the pixel work (resize, Sobel, non-maximum suppression, hysteresis) stays on the device.
     uint8_t *hmap = (uint8_t *)(hp + bytes);
-    int2 *hpts = (int2 *)(hp + bytes + npix);
+    uint8_t *hhalf = hmap + npix;
+    int2 *hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
+    const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
     PLV_HIP_CHECK(hipMemcpyAsync(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(hipMemcpyAsync(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
     PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    auto T1 = std::chrono::steady_clock::now();
     FldChain *hc = (FldChain *)(hp + 16);
     int hcounts[4] = {0, 0, 0, 0};
-    walk_chains(hmap, w, h, fp.length_threshold, hpts, hc, kChainCap, hcounts);
-    memcpy(hp, hcounts, 16);
-    PLV_HIP_CHECK(hipMemcpyAsync(T->counts.p, hp, 16, hipMemcpyHostToDevice, ctx->stream));
-    if (hcounts[0] > 0) {
-      PLV_HIP_CHECK(hipMemcpyAsync(T->chains.p, hc, hcounts[0] * sizeof(FldChain), hipMemcpyHostToDevice, ctx->stream));
-      PLV_HIP_CHECK(hipMemcpyAsync(T->pts.p, hpts, (size_t)hcounts[2] * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    walk_chains(hmap, w, h, fp.length_threshold, hpts, hc, kChainCap, hcounts, T->pad);
+    auto T2 = std::chrono::steady_clock::now();
+    if (hcounts[0] >= kChainCap) {
+      set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
+      return PLV_E_CAPACITY;
     }
+    std::vector<float4> seg;
+    for (int c = 0; c < hcounts[0]; ++c) {  // chains are in raster order of their seeds = the detector's output order
+      seg.resize((size_t)hc[c].len / fp.length_threshold + 1);
+      const int ns = fit_chain(hhalf, w, h, fp.length_threshold, fp.distance_threshold, hpts + hc[c].start, hc[c].len, seg.data());
+      for (int q = 0; q < ns; ++q) emit(seg[q]);
+    }
+    if (timing) {
+      auto T3 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      size_t edges = 0;
+      for (size_t i = 0; i < npix; ++i) edges += hmap[i] == 2;
+      fprintf(stderr, "edges+d2h %.1f us, walk %.1f us, fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T0, T1), us(T1, T2),
+              us(T2, T3), hcounts[0], hcounts[2], edges);
+    }
+    ctx->prof.collect();
+    return PLV_OK;
   }
+  TRY(launch_line_walk(ctx, w, h, fp, b));
   TRY(launch_line_fit(ctx, w, h, fp, b));
   // download: counts, chain table, per-chain segment counts, segment slots
   PLV_HIP_CHECK(hipMemcpyAsync(hp, T->counts.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -182,7 +228,6 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
     set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
     return PLV_E_CAPACITY;
   }
-  lines.clear();
   if (n_chain > 0) {
     FldChain *hc = (FldChain *)(hp + 16);
     int *hn = (int *)(hp + 16 + kChainCap * sizeof(FldChain));
@@ -191,15 +236,8 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
     PLV_HIP_CHECK(hipMemcpyAsync(hn, T->seg_count.p, n_chain * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PLV_HIP_CHECK(hipMemcpyAsync(hs, T->segs.p, (size_t)n_slot * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
     for (int c = 0; c < n_chain; ++c)  // chains are in raster order of their seeds = the detector's output order
-      for (int s = 0; s < hn[c]; ++s) {
-        const float4 sg = hs[hc[c].slot + s];
-        const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
-        const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
-        if (!(l2 > thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
-        lines.insert(lines.end(), {x1, y1, x2, y2});
-      }
+      for (int q = 0; q < hn[c]; ++q) emit(hs[hc[c].slot + q]);
   }
   ctx->prof.collect();
   return PLV_OK;
@@ -367,6 +405,17 @@ int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps) {
 // which also is where the reference's second equalizeHist comes from: same input, same result).
 int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
   if (!ctx || !vps) return PLV_E_BADARG;
+  // the point tracker's current observations (REF :106-107, :131-134)
+  int np = 0;
+  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
+  std::vector<float> pts(2 * (size_t)std::max(np, 1));
+  std::vector<uint64_t> pids((size_t)std::max(np, 1));
+  TRY(plv_tracker_last(ctx, pts.data(), pids.data(), np, &np));
+  return plv_line_tracker_feed_points(ctx, timestamp, vps, np, pts.data(), pids.data());
+}
+
+int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
+  if (!ctx || !vps || np < 0 || (np > 0 && (!pts || !pids))) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   LineTracker *T = ltr(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
@@ -375,14 +424,8 @@ int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
   const int nl = (int)lines.size() / 4;
   std::vector<uint64_t> ids(nl);
   for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236
-  // the point tracker's current observations (REF :106-107, :131-134)
-  int np = 0;
-  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
-  std::vector<float> pts(2 * (size_t)std::max(np, 1));
-  std::vector<uint64_t> pids((size_t)std::max(np, 1));
-  TRY(plv_tracker_last(ctx, pts.data(), pids.data(), np, &np));
   Assign A;
-  assign_points(lines.data(), nl, pts.data(), pids.data(), np, A);
+  assign_points(lines.data(), nl, pts, pids, np, A);
   const int nk = (int)A.kept.size();
   std::vector<float> fl(4 * (size_t)nk);
   std::vector<uint64_t> fid(nk);

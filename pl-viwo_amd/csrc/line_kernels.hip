@@ -17,6 +17,8 @@
 //                    orientation by side brightness: one lane per chain, chains are independent.
 #include "line_kernels.hpp"
 
+#include "fld_fit_core.hpp"
+
 namespace plv {
 
 __global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ src, int w, int h, uint8_t *__restrict__ dst) {
@@ -211,52 +213,6 @@ __global__ void __launch_bounds__(64) fld_walk_kernel(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------ segment growing
-struct L3 {
-  double a, b, c;
-};
-__device__ __forceinline__ L3 cr3(double ax, double ay, double az, double bx, double by, double bz) {
-  return L3{ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
-}
-__device__ __forceinline__ double dist_pl(double px, double py, L3 &l) {  // normalises l in place (as the reference does)
-  const double wv = sqrt(l.a * l.a + l.b * l.b);
-  l.a /= wv;
-  l.b /= wv;
-  l.c /= wv;
-  return l.a * px + l.b * py + l.c;
-}
-struct Fit {
-  long long n, sx, sy, sxx, syy, sxy;
-  __device__ void add(int2 p) {
-    ++n;
-    sx += p.x;
-    sy += p.y;
-    sxx += (long long)p.x * p.x;
-    syy += (long long)p.y * p.y;
-    sxy += (long long)p.x * p.y;
-  }
-  // cv::fitLine(DIST_L2) = principal axis through the centroid; integer sums are exact in double
-  __device__ L3 line() const {
-    const double wv = (double)(float)n;
-    const double x = (double)sx / wv, y = (double)sy / wv, x2 = (double)sxx / wv, y2 = (double)syy / wv, xy = (double)sxy / wv;
-    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
-    const float t = (float)atan2(2 * dxy, dx2 - dy2) / 2;
-    const float vx = (float)cos((double)t), vy = (float)sin((double)t), fx = (float)x, fy = (float)y;
-    return cr3((double)fx, (double)fy, 1.0, (double)fx + (double)vx, (double)fy + (double)vy, 1.0);
-  }
-};
-__device__ __forceinline__ void incident(const L3 &l, float &px, float &py, int imw, int imh) {
-  const L3 lk = cr3((double)px, (double)py, 1.0, l.a, l.b, 0.0);
-  L3 xk = cr3(lk.a, lk.b, lk.c, l.a, l.b, l.c);
-  const double s = 1.0 / xk.c;
-  const float fx = (float)(xk.a * s), fy = (float)(xk.b * s);
-  px = fx < 0.0f ? 0.0f : (fx >= (imw - 1.0f) ? (imw - 1.0f) : fx);
-  py = fy < 0.0f ? 0.0f : (fy >= (imh - 1.0f) ? (imh - 1.0f) : fy);
-}
-__device__ __forceinline__ void inboard(int &x, int &y, int w, int h) {
-  x = x <= 5 ? 5 : (x >= w - 5 ? w - 6 : x);
-  y = y <= 5 ? 5 : (y >= h - 5 ? h - 6 : y);
-}
-
 __global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__ src, int w, int h, int length_threshold,
                                                      float distance_threshold, const int2 *__restrict__ pts,
                                                      const FldChain *__restrict__ chains, const int *__restrict__ counts,
@@ -264,95 +220,7 @@ __global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= counts[0]) return;
   const FldChain ch = chains[c];
-  const int2 *P = pts + ch.start;
-  const int total = ch.len;
-  float4 *out = segs + ch.slot;
-  int nseg = 0;
-  for (int i = 0; i + length_threshold < total; ++i) {
-    int2 ps = P[i], pe = P[i + length_threshold];
-    L3 l = cr3(ps.x, ps.y, 1.0, pe.x, pe.y, 1.0);
-    bool is_line = true;
-    Fit fs{0, 0, 0, 0, 0, 0};
-    fs.add(ps);
-    for (int j = 1; j < length_threshold; ++j) {
-      const int2 pt = P[i + j];
-      if (fabs(dist_pl(pt.x, pt.y, l)) > distance_threshold) {
-        is_line = false;
-        break;
-      }
-      fs.add(pt);
-    }
-    if (!is_line) continue;
-    fs.add(pe);
-    l = fs.line();
-    {
-      float fx = (float)ps.x, fy = (float)ps.y;
-      incident(l, fx, fy, w, h);
-      ps.x = __float2int_rn(fx);  // Point2i(Point2f): saturate_cast = round to nearest even
-      ps.y = __float2int_rn(fy);
-    }
-    int j;
-    for (j = length_threshold + 1; i + j < total; ++j) {
-      const int2 pt = P[i + j];
-      double dist = dist_pl(pt.x, pt.y, l);
-      if (fabs(dist) > distance_threshold) {
-        l = fs.line();
-        dist = dist_pl(pt.x, pt.y, l);
-        if (fabs(dist) > distance_threshold) {
-          j--;
-          break;
-        }
-      }
-      pe = pt;
-      fs.add(pt);
-    }
-    l = fs.line();
-    float e1x = (float)ps.x, e1y = (float)ps.y, e2x = (float)pe.x, e2y = (float)pe.y;
-    incident(l, e1x, e1y, w, h);
-    incident(l, e2x, e2y, w, h);
-    i = i + j;
-    // lineDetection's filters, then additionalOperationsOnSegment (orientation by side brightness)
-    const float length = sqrtf((e1x - e2x) * (e1x - e2x) + (e1y - e2y) * (e1y - e2y));
-    if (length < length_threshold) continue;
-    if ((e1x <= 5.0f && e2x <= 5.0f) || (e1y <= 5.0f && e2y <= 5.0f) || (e1x >= w - 5.0f && e2x >= w - 5.0f) ||
-        (e1y >= h - 5.0f && e2y >= h - 5.0f))
-      continue;
-    if (!(e1x == 0.0f && e2x == 0.0f && e1y == 0.0f && e2y == 0.0f)) {
-      const double ang = (double)atan2f(e2y - e1y, e2x - e1x);
-      const double dx = (double)e2x - (double)e1x, dy = (double)e2y - (double)e1y;
-      const double ca = cos(90.0 * 3.14159265358979323846 / 180.0 + ang), sa = sin(90.0 * 3.14159265358979323846 / 180.0 + ang);
-      int iR = 0, iL = 0;
-      for (int q = 0; q < 10; ++q) {
-        float qx, qy;
-        if (q == 0) {
-          qx = e1x;
-          qy = e1y;
-        } else if (q == 9) {
-          qx = e2x;
-          qy = e2y;
-        } else {
-          qx = e1x + ((float)dx / 9.0f * (float)q);
-          qy = e1y + ((float)dy / 9.0f * (float)q);
-        }
-        int rx = __double2int_rn((double)qx + ca), ry = __double2int_rn((double)qy + sa);
-        int lx = __double2int_rn((double)qx - ca), ly = __double2int_rn((double)qy - sa);
-        inboard(rx, ry, w, h);
-        inboard(lx, ly, w, h);
-        iR += src[(size_t)ry * w + rx];
-        iL += src[(size_t)ly * w + lx];
-      }
-      if (iR > iL) {
-        float t = e1x;
-        e1x = e2x;
-        e2x = t;
-        t = e1y;
-        e1y = e2y;
-        e2y = t;
-      }
-    }
-    out[nseg++] = make_float4(e1x, e1y, e2x, e2y);
-  }
-  seg_count[c] = nseg;
+  seg_count[c] = fit_chain(src, w, h, length_threshold, distance_threshold, pts + ch.start, ch.len, segs + ch.slot);
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
