@@ -39,14 +39,14 @@ F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix spec; v_mfma_
 W, H = 752, 480
 N_PTS, WIN = 250, 15
 N_STATE, K_COLS, F_FEATS, M_OBS, FDIM = 113, 98, 70, 15, 3
-N_LINES, LINE_LD = 80, 32
+N_LINES, LINE_LD, LINE_EDGES = 80, 32, 200
 SIGMA2 = 2.25  # the gate's R = sigma_pix^2 I on rows that are already whitened (UpdaterCamera.cpp:237-238), kept as is
 
 
 def build_inputs(with_lines=False):
     import synth
     # SURVEY §8(d) cfg 3: the cfg 2 stream + straight high-contrast edges rendered before the blur
-    canvas = synth.texture_canvas(W, H, seed=42, lines=200 if with_lines else 0)
+    canvas = synth.texture_canvas(W, H, seed=42, lines=LINE_EDGES if with_lines else 0)
     frames = [synth.render_frame(canvas, W, H),
               synth.render_frame(canvas, W, H, tx=4.2, ty=-3.1, rot_deg=0.3, scale=1.002)]
     pts = synth.grid_points(W, H, N_PTS, seed=5, border=16)
@@ -60,57 +60,79 @@ def build_inputs(with_lines=False):
 
 
 def points_on_lines(lines, base_pts, n_lines):
-    """250 point positions of which two lie on each of the `n_lines` longest detected segments (FAST corners sit on such edges
-    and their ends; TrackLSD keeps only lines that own a point, TrackLSD.cpp:744-792), the rest from the grid set."""
+    """250 point positions of which up to two lie on each detected segment (FAST corners sit on such edges and their ends; TrackLSD
+    keeps only lines that own a point, TrackLSD.cpp:744-792), the rest from the grid set.  The positions honour the reference's
+    bounding-box test, which reads (x1, y1, x2, y2) as (lx1, lx2, ly1, ly2) (TrackLSD.cpp:753-764): a line whose own points all
+    fail that test cannot be kept by any tracker and gets none."""
     length = np.hypot(lines[:, 2] - lines[:, 0], lines[:, 3] - lines[:, 1])
-    order = np.argsort(-length, kind="stable")[:n_lines]
     on = []
-    for i in order:
-        a, b = lines[i, :2], lines[i, 2:]
-        on += [a + 0.3 * (b - a), a + 0.7 * (b - a)]
+    for i in np.argsort(-length, kind="stable"):
+        x1, y1, x2, y2 = lines[i]
+        inside = [sgm for sgm in np.linspace(0.04, 0.96, 47)
+                  if min(x1, y1) + 3 <= x1 + sgm * (x2 - x1) <= max(x1, y1) - 3 and min(x2, y2) + 3 <= y1 + sgm * (y2 - y1) <= max(x2, y2) - 3
+                  and 16 < x1 + sgm * (x2 - x1) < W - 16 and 16 < y1 + sgm * (y2 - y1) < H - 16]
+        for sgm in ([inside[len(inside) // 4], inside[(3 * len(inside)) // 4]] if len(inside) >= 2 else inside):
+            on.append((x1 + sgm * (x2 - x1), y1 + sgm * (y2 - y1)))
+        if len(on) >= 2 * n_lines:
+            break
     on = np.array(on, dtype=np.float32).reshape(-1, 2)
-    keep = np.ones(len(on), dtype=bool)
-    keep &= (on[:, 0] > 16) & (on[:, 0] < W - 16) & (on[:, 1] > 16) & (on[:, 1] < H - 16)
-    on = on[keep]
-    return np.concatenate([on, base_pts[:N_PTS - len(on)]]).astype(np.float32), len(order)
+    return np.concatenate([on, base_pts[:N_PTS - len(on)]]).astype(np.float32), len(on)
 
 
-def algorithmic_work(levels, lk_iters_per_frame, qr_launches):
+def update_work(F, rows_f, fdim, k, n, qr_launches=1):
+    """Algorithmic flops per launch of the update kernels for F features of rows_f rows (before the null-space projection removes
+    fdim of them) on k columns of an n-state filter (formulas of SURVEY.md §8(d), restated in DESIGN.md)."""
+    mp = rows_f - fdim
+    m = F * mp
+    nc = k + 1
+    r = k
+    return {
+        "nullspace_kernel": F * 6.0 * (fdim + k + 1) * (rows_f * fdim - fdim * (fdim + 1) / 2),
+        "chi2_gate_kernel": F * (2.0 * mp * mp * k + mp ** 3 / 3.0),
+        "chi2_t_kernel": F * 2.0 * mp * k * k,
+        "qr_accum_kernel": (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches),
+        "gram_chunk_kernel": 1.0 * m * nc * nc,  # upper tiles only: half of 2 m nc^2
+        "gram_reduce_kernel": (m / 64.0) * (nc * nc / 2.0) * 8,
+        "bchol_compress_kernel": nc ** 3 / 3.0,
+        "bchol_ekf_kernel": r ** 3 / 3.0 + 1.0 * r * r * (n + 1),
+        "gather_cov_kernel": 2.0 * (k * n + k * k) * 8,
+        "ekf_dc_kernel": 1.0 * n * n * r + 2.0 * n * r,
+        "ekf_commit_kernel": 3.0 * n * n * 8,
+        "ekf_mt_kernel": 2.0 * n * k * r,
+        "ekf_s_kernel": 2.0 * r * r * k,
+    }
+
+
+def algorithmic_work(levels, lk_iters_per_frame, qr_launches, with_lines=False, k_lines=90):
     """Per-LAUNCH algorithmic bytes (HBM-class kernels) or flops (dense fp64 kernels); formulas
-    from SURVEY.md §8(d), restated in DESIGN.md."""
-    mp = 2 * M_OBS - FDIM
-    m = F_FEATS * mp
-    nc = K_COLS + 1
-    n, k, r = N_STATE, K_COLS, K_COLS
+    from SURVEY.md §8(d), restated in DESIGN.md.  With lines, the kernels both updates of a frame launch carry the mean of the
+    two launches (70 x 27 rows on 98 columns, 80 x 24 rows on 90 columns)."""
     lv = levels
     it_per_pl = lk_iters_per_frame / float(N_PTS * lv)
     pyr_reads_writes = (4.0 / 3 + 1.0 / 3) * W * H
-    return {
+    hbm = {"gram_reduce_kernel", "gather_cov_kernel", "ekf_commit_kernel"}
+    up = update_work(F_FEATS, 2 * M_OBS, FDIM, K_COLS, N_STATE, qr_launches)
+    if with_lines:
+        ul = update_work(N_LINES, 2 * M_OBS, 6, k_lines, N_STATE, qr_launches)
+        up = {kname: (0.5 * (v + ul[kname]) if kname != "nullspace_kernel" else ul[kname]) for kname, v in up.items()}
+    work = {
         "hist_kernel": ("hbm", W * H),
         "equalize_kernel": ("hbm", 2 * W * H),
         "pyrdown_kernel": ("hbm", pyr_reads_writes / max(1, lv - 1)),
+        "pyrdown2_kernel": ("hbm", pyr_reads_writes / 2.0),
         "lk_kernel": ("hbm", N_PTS * lv * ((WIN + 2) ** 2 + it_per_pl * (WIN + 1) ** 2) + N_PTS * 17),
         "undistort_kernel": ("hbm", 2 * N_PTS * 16),
+        "half_kernel": ("hbm", W * H + W * H / 4.0),
+        "canny_kernel": ("hbm", 2 * W * H / 4.0),
         "jacobian_kernel": ("mfma", F_FEATS * M_OBS * 3000.0),
+        "jacobian_nullspace_kernel": ("mfma", F_FEATS * M_OBS * 3000.0 + update_work(F_FEATS, 2 * M_OBS, FDIM, K_COLS, N_STATE)["nullspace_kernel"]),
+        "line_jacobian_kernel": ("mfma", N_LINES * M_OBS * 6000.0),
         "ransac_hyp_kernel": ("mfma", 1000 * 3 * N_PTS * 40.0),
         "ransac_select_kernel": ("mfma", N_PTS * 40.0),
-        "nullspace_kernel": ("mfma", F_FEATS * 6.0 * (FDIM + k + 1) * (2 * M_OBS * FDIM - FDIM * (FDIM + 1) / 2)),
-        "chi2_gate_kernel": ("mfma", F_FEATS * (2.0 * mp * mp * k + mp ** 3 / 3.0)),
-        "qr_accum_kernel": ("mfma", (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches)),
-        "gram_chunk_kernel": ("mfma", 1.0 * m * nc * nc),  # upper tiles only: half of 2 m nc^2
-        "gram_reduce_kernel": ("hbm", (m / 64.0) * (nc * nc / 2.0) * 8),
-        "bchol_compress_kernel": ("mfma", nc ** 3 / 3.0),
-        "bchol_ekf_kernel": ("mfma", r ** 3 / 3.0 + 1.0 * r * r * (n + 1)),
-        "gather_cov_kernel": ("hbm", 2.0 * (k * n + k * k) * 8),
-        "chi2_t_kernel": ("mfma", F_FEATS * 2.0 * mp * k * k),
-        "ekf_dc_kernel": ("mfma", 1.0 * n * n * r + 2.0 * n * r),
-        "ekf_commit_kernel": ("hbm", 3.0 * n * n * 8),
-        "ekf_mt_kernel": ("mfma", 2.0 * n * k * r),
-        "ekf_s_kernel": ("mfma", 2.0 * r * r * k),
-        "ekf_chol_kernel": ("mfma", r ** 3 / 3.0),
-        "ekf_trsm_kernel": ("mfma", (n + 1) * r * r * 1.0),
-        "ekf_apply_kernel": ("mfma", n * n * r * 1.0 + 2.0 * n * r),
     }
+    for kname, v in up.items():
+        work[kname] = ("hbm" if kname in hbm else "mfma", v)
+    return work
 
 
 def cpu_baseline(pkg, frames, pts_of, P, scene, sample_frames, lt=None, cols_l=None, vps=None):
@@ -283,9 +305,17 @@ def main():
         # untimed set-up: the 80 longest segments of each frame get two tracked points each, so that ~80 lines survive the
         # point-line assignment every frame (SURVEY §8(d) cfg 3: "+80 lines kept after assignment")
         ctx.feed_staged(1)
-        lines1 = ctx.detect_lines(1)    # PLV_PYR_CUR = frame 1
-        lines0 = ctx.detect_lines(0)    # PLV_PYR_LAST = frame 0
-        pts_of = [points_on_lines(lines0, pts, N_LINES)[0], points_on_lines(lines1, pts, N_LINES)[0]]
+        lines1 = ctx.detect_lines(0)    # PLV_PYR_CUR = frame 1
+        lines0 = ctx.detect_lines(1)    # PLV_PYR_LAST = frame 0
+        # positions ON the lines of the image a step tracks INTO, carried back into the image it tracks FROM through the known
+        # frame-to-frame warp: pts_of[f] are positions in frame f whose tracked positions lie on the other frame's lines
+        q0, q1 = points_on_lines(lines0, pts, N_LINES)[0], points_on_lines(lines1, pts, N_LINES)[0]
+        th, c0, tr_, sc_ = np.deg2rad(0.3), np.array([W / 2.0, H / 2.0]), np.array([4.2, -3.1]), 1.002
+        Rw = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        fwd = lambda p: ((p - c0) @ Rw.T) * sc_ + c0 + tr_          # frame 0 -> frame 1 (synth.warp_points)
+        inv = lambda q: ((q - c0 - tr_) / sc_) @ Rw + c0
+        clip = lambda p: np.clip(p, 16, [W - 17, H - 17]).astype(np.float32)
+        pts_of = [clip(inv(q1)), clip(fwd(q0))]
         ctx.feed_staged(0)
         ls = synth.line_scene(scene, L=N_LINES, M=M_OBS, noise_px=0.4)
         lt = pkg.LineTracks(ls["obs_ptr"], ls["obs_time"], ls["seg_uv"], seg_uvn=ls["seg_uvn"], line_FinG=ls["lines"])
@@ -384,6 +414,7 @@ def main():
     points_only = None
     if with_lines:
         state["lines_kept"] = len(ctx.line_tracker_last()[1])
+        state["lines_detected"] = len(ctx.detect_lines(0))
         if rank == 0 and not args.sequential:   # configs[1] in the same run, for the record (not `value`)
             for i in range(min(args.warmup, 100)):
                 step_pipelined(i)
@@ -431,7 +462,7 @@ def main():
                 table[kname] = (a[0] + cnt, a[1] + ms)
         levels = ctx.pyramid_levels(0)
         qr_launches = table.get("qr_accum_kernel", (0, 0))[0] / nprof
-        work = algorithmic_work(levels, state["lk_iters"], qr_launches)
+        work = algorithmic_work(levels, state["lk_iters"], qr_launches, with_lines, len(cols_l) if with_lines else 90)
         dom = max(table.items(), key=lambda kv: kv[1][1])
         name, (cnt, ms) = dom
         kind, per_launch = work.get(name, ("hbm", 0.0))
@@ -473,7 +504,7 @@ def main():
                                     "BASELINE configs[1]: 752x480 mono, 250 KLT points (15x15 window, 5 pyramid levels), "
                                     "MSCKF update of 70 features x 15 clones on n=113 (k=98 columns), points only"),
                        "replicas": world, "tracked_points": state["tracked"], "accepted_features": state["accepted"],
-                       "lines_kept": state.get("lines_kept"), "accepted_lines": state.get("accepted_lines"), "points_only": points_only,
+                       "lines_detected": state.get("lines_detected"), "lines_kept": state.get("lines_kept"), "accepted_lines": state.get("accepted_lines"), "points_only": points_only,
                        "lk_iterations_per_frame": int(state["lk_iters"]),
                        "front_end_arithmetic": "u8/int16/int64 exact + f32 2x2 solve", "update_arithmetic": "f64",
                        "schedule": "sequential, one stream" if args.sequential else
