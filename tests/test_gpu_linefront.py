@@ -134,3 +134,29 @@ def test_line_tracker_stream(pkg, lo, frames):
     tracked_twice = [k for k, v in db.items() if len(v) >= 2]
     assert len(tracked_twice) >= 1
     del ctx
+
+
+def test_line_tracker_with_the_callers_points(pkg, lo, frames):
+    """plv_line_tracker_feed_points (an adapter that keeps its own point tracker): the same stream, the points handed in instead of
+    read from the ctx's tracker -> the same lines, ids and track store as plv_line_tracker_feed."""
+    vps = lo.vanishing_points(np.eye(3), synth.EUROC_K8)
+    a, b = pkg.Context(pkg.default_config(W, H)), pkg.Context(pkg.default_config(W, H))
+    for i, img in enumerate(frames):
+        t = 10.0 + 0.05 * i
+        a.tracker_feed(t, img)
+        a.line_tracker_feed(t, vps)
+        pts, pids = a.tracker_last()
+        b.feed_image(img)                       # equalise + pyramid only: no point tracker state in this ctx
+        b.line_tracker_feed_points(t, vps, pts, pids)
+        la, ia = a.line_tracker_last()
+        lb, ib = b.line_tracker_last()
+        assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    assert a.line_db_size() == b.line_db_size() > 0
+    ids = a.line_db_ids()
+    ea, eb = a.line_db_export(ids), b.line_db_export(ids)
+    for k in ("obs_ptr", "obs_time", "seg_uv", "seg_uvn", "D", "pts_ptr", "pt_ids"):
+        assert np.array_equal(ea[k], eb[k]), k
+    # no points: every line is dropped by the assignment (TrackLSD.cpp:784-789)
+    b.line_tracker_feed_points(11.0, vps, np.zeros((0, 2), dtype=np.float32), np.zeros(0, dtype=np.uint64))
+    assert len(b.line_tracker_last()[1]) == 0
+    a.close(), b.close()
