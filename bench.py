@@ -341,9 +341,14 @@ def main():
         lines = with_lines if lines is None else lines
         p0 = pts_of[i & 1] if lines else pts
         c.feed_staged((i + 1) & 1)
-        out = c.perform_matching(p0, p0)
         if lines:
+            c.line_detect_launch(0)
+            c.perform_matching_launch(p0, p0)
+            c.line_detect_finish(0)
+            out = c.perform_matching_wait()
             line_front_end(c, i, out[0])
+        else:
+            out = c.perform_matching(p0, p0)
         c.cov_rollback()   # (before the Jacobians: their launch also gathers the covariance blocks of the update)
         c.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
         rc, dx, acc, nr = c.msckf_update_resident(N_STATE, SIGMA2)
@@ -379,7 +384,10 @@ def main():
         uctx.build_jacobians_resident(st, tr, cols, 2 * M_OBS)
         uctx.msckf_update_resident_launch(SIGMA2)
         ctx.feed_staged((i + 1) & 1)
-        out = ctx.perform_matching(p0, p0)
+        ctx.line_detect_launch(0)             # resize + Canny + copies of the new image, then LK behind them on the stream:
+        ctx.perform_matching_launch(p0, p0)   # the host walks the edge chains while the device tracks the points
+        ctx.line_detect_finish(0)
+        out = ctx.perform_matching_wait()
         rc, dx, acc, nr = uctx.msckf_update_resident_wait(N_STATE)
         if rc != 0:
             raise RuntimeError("EKF update rejected inside the benchmark")

@@ -424,6 +424,15 @@ int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, co
  * cfg.line_min_length_px^2.  Works on the equalised image of the current (PLV_PYR_CUR) or previous
  * frame held by the ctx; lines = x1 y1 x2 y2 full-resolution pixels, in the detector's output order. */
 int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out);
+/* Optional first half of the detector for the image `which`: enqueues the resize, the Canny map and their copies to the host on the
+ * ctx's stream and returns.  The next detection of the same image (plv_detect_lines, plv_line_tracker_feed[_points]) then only
+ * waits for those copies before its host stage, so that work enqueued in between (plv_perform_matching_launch) runs on the device
+ * while the host walks the edge chains.  Feeding another image in between is the caller's error (the maps would be stale). */
+int plv_line_detect_launch(plv_ctx *ctx, int which);
+/* Second half, ahead of time: runs the detection of image `which` now (after plv_line_detect_launch: only its host stage) and keeps
+ * the segments; the next plv_line_tracker_feed[_points] of the SAME frame (no image fed in between) takes them instead of
+ * detecting again.  Lets the caller place the host stage between plv_perform_matching_launch and _wait. */
+int plv_line_detect_finish(plv_ctx *ctx, int which);
 /* Where the detector's chain walk runs: 0 (default) = on the host between the device stages (Canny map down,
  * chains up), 1 = fld_walk_kernel on the device.  Same results; the walk is one dependent chain of
  * ~10^4 scalar steps, which a single GPU lane retires ~25x slower than a host core. */

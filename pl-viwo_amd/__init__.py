@@ -165,6 +165,8 @@ def load_library():
         "plv_slam_initialize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, dp, ip, C.c_double, u8p, dp, dp]),
         "plv_cov_marginalize": (C.c_int, [vp, C.c_int, C.c_int]),
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
+        "plv_line_detect_launch": (C.c_int, [vp, C.c_int]),
+        "plv_line_detect_finish": (C.c_int, [vp, C.c_int]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
         "plv_line_match": (C.c_int, [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]),
@@ -1024,6 +1026,12 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.plv_detect_lines(self.h, which, _fp(lines), cap, C.byref(n)))
         return lines[:n.value].copy()
+
+    def line_detect_launch(self, which=0):
+        self._chk(self.lib.plv_line_detect_launch(self.h, which))
+
+    def line_detect_finish(self, which=0):
+        self._chk(self.lib.plv_line_detect_finish(self.h, which))
 
     def line_walk_mode(self, on_device):
         self._chk(self.lib.plv_line_walk_mode(self.h, 1 if on_device else 0))

@@ -219,6 +219,7 @@ int plv_feed_staged(plv_ctx *ctx, int slot) {
 
 }  // extern "C"
 namespace plv {
+int plv_front_fed_count(plv_ctx *ctx) { return (ctx && ctx->fe_state) ? fe(ctx)->fed : 0; }
 const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h) {
   if (!ctx || !ctx->fe_state) return nullptr;
   FrontState *s = fe(ctx);

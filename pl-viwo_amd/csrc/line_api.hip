@@ -51,6 +51,10 @@ struct LineTracker {
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
   PinBuf pin;
   std::vector<uint8_t> pad;  // host walk: bordered copy of the edge map
+  hipEvent_t edges_ready = nullptr;  // plv_line_detect_launch: the maps of image `pending_which` are on their way to the host
+  int pending_which = -1, pending_fed = -1;
+  std::vector<float> cached;  // plv_line_detect_finish: the segments of image `cached_which` of frame `cached_fed`
+  int cached_which = -1, cached_fed = -1;
   std::mutex mtx;
 };
 
@@ -145,7 +149,9 @@ void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *p
 }
 
 // detection on the device + the host tail of perform_detection_monocular (x2, FilterShortLines)
-int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
+int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, bool launch_only = false) {
+  const bool prelaunched = !launch_only && !T->walk_on_device && T->pending_which == which && T->pending_fed == plv_front_fed_count(ctx);
+  if (!launch_only) T->pending_which = -1;
   int W = 0, H = 0;
   const uint8_t *d_img = plv_front_level0(ctx, which, &W, &H);
   if (!d_img) {
@@ -166,7 +172,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
   FldBuffers b{T->half.as<uint8_t>(), T->map.as<uint8_t>(), T->work.as<uint8_t>(), T->pts.as<int2>(), T->chains.as<FldChain>(),
                kChainCap,             T->counts.as<int>(),  T->segs.as<float4>(), T->seg_count.as<int>()};
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
-  TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
+  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
   TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (2 + sizeof(int2)) + 64)));
   char *hp = T->pin.as<char>();
@@ -189,9 +195,20 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines) {
     int2 *hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
     const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
-    PLV_HIP_CHECK(hipMemcpyAsync(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(hipMemcpyAsync(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (prelaunched) {  // plv_line_detect_launch put the kernels and the two copies on the stream: wait for those only
+      PLV_HIP_CHECK(hipEventSynchronize(T->edges_ready));
+    } else {
+      PLV_HIP_CHECK(hipMemcpyAsync(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+      PLV_HIP_CHECK(hipMemcpyAsync(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+      if (launch_only) {
+        if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
+        PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
+        T->pending_which = which;
+        T->pending_fed = plv_front_fed_count(ctx);
+        return PLV_OK;
+      }
+      PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     auto T1 = std::chrono::steady_clock::now();
     FldChain *hc = (FldChain *)(hp + 16);
     int hcounts[4] = {0, 0, 0, 0};
@@ -403,6 +420,28 @@ int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps) {
 
 // TrackLSD::feed_monocular for the image currently in the ctx (fed by plv_tracker_feed / plv_feed_image,
 // which also is where the reference's second equalizeHist comes from: same input, same result).
+int plv_line_detect_launch(plv_ctx *ctx, int which) {
+  if (!ctx || (which != PLV_PYR_CUR && which != PLV_PYR_LAST)) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  if (T->walk_on_device) return PLV_OK;  // nothing to overlap: the device variant has no host stage
+  std::vector<float> none;
+  return detect(ctx, T, which, none, true);
+}
+
+int plv_line_detect_finish(plv_ctx *ctx, int which) {
+  if (!ctx || (which != PLV_PYR_CUR && which != PLV_PYR_LAST)) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  T->cached_which = -1;
+  TRY(detect(ctx, T, which, T->cached));
+  T->cached_which = which;
+  T->cached_fed = plv_front_fed_count(ctx);
+  return PLV_OK;
+}
+
 int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
   if (!ctx || !vps) return PLV_E_BADARG;
   // the point tracker's current observations (REF :106-107, :131-134)
@@ -420,7 +459,12 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
   LineTracker *T = ltr(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
   std::vector<float> lines;
-  TRY(detect(ctx, T, PLV_PYR_CUR, lines));
+  if (T->cached_which == PLV_PYR_CUR && T->cached_fed == plv_front_fed_count(ctx)) {
+    lines.swap(T->cached);  // detected ahead of time for this very frame (plv_line_detect_finish)
+    T->cached_which = -1;
+  } else {
+    TRY(detect(ctx, T, PLV_PYR_CUR, lines));
+  }
   const int nl = (int)lines.size() / 4;
   std::vector<uint64_t> ids(nl);
   for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236

@@ -30,5 +30,6 @@ int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers 
 
 // frontend_api.hip: equalised level-0 image of the current (which = 0) or previous (1) frame
 const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h);
+int plv_front_fed_count(plv_ctx *ctx);  // images fed so far: identifies the frame a cached detection belongs to
 
 }  // namespace plv

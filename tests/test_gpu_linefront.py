@@ -160,3 +160,40 @@ def test_line_tracker_with_the_callers_points(pkg, lo, frames):
     b.line_tracker_feed_points(11.0, vps, np.zeros((0, 2), dtype=np.float32), np.zeros(0, dtype=np.uint64))
     assert len(b.line_tracker_last()[1]) == 0
     a.close(), b.close()
+
+
+def test_detection_ahead_of_time(pkg, lo, frames):
+    """plv_line_detect_launch / _finish: the detector split around other work on the stream gives the same segments, the line
+    tracker takes a finished detection of the same frame and ignores one of an older frame."""
+    vps = lo.vanishing_points(np.eye(3), synth.EUROC_K8)
+    a, b = pkg.Context(pkg.default_config(W, H)), pkg.Context(pkg.default_config(W, H))
+    pts = synth.grid_points(W, H, 200, seed=2)
+    ids = np.arange(1, 201, dtype=np.uint64)
+    for c in (a, b):
+        c.feed_image(frames[0])
+    for i, img in enumerate(frames[1:]):
+        a.feed_image(img)
+        b.feed_image(img)
+        ref = a.detect_lines(0)
+        b.line_detect_launch(0)
+        b.perform_matching_launch(pts, pts)        # device work queued behind the edge maps
+        b.line_detect_finish(0)
+        out = b.perform_matching_wait()
+        assert np.array_equal(b.detect_lines(0), ref)
+        b.line_detect_launch(0)                    # launch without finish: the next detection waits for it
+        assert np.array_equal(b.detect_lines(0), ref)
+        b.line_detect_launch(1)                    # asked for the other image: a detection of image 0 starts from scratch
+        assert np.array_equal(b.detect_lines(0), ref)
+        a.line_tracker_feed_points(float(i), vps, out[0], ids)
+        b.line_detect_launch(0)
+        b.line_detect_finish(0)
+        b.line_tracker_feed_points(float(i), vps, out[0], ids)
+        assert np.array_equal(a.line_tracker_last()[0], b.line_tracker_last()[0])
+    # a finished detection that belongs to an older frame is not used
+    b.line_detect_finish(0)
+    b.feed_image(frames[0])
+    a.feed_image(frames[0])
+    a.line_tracker_feed_points(9.0, vps, pts, ids)
+    b.line_tracker_feed_points(9.0, vps, pts, ids)
+    assert np.array_equal(a.line_tracker_last()[0], b.line_tracker_last()[0]) and np.array_equal(a.line_tracker_last()[1], b.line_tracker_last()[1])
+    a.close(), b.close()
