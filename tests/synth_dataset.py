@@ -30,9 +30,16 @@ BG, BA = np.array([0.003, -0.002, 0.0015]), np.array([0.03, -0.02, 0.025])
 SIG = dict(gyro_noise=1.7e-4, gyro_bias=1.9e-5, accel_noise=2.0e-3, accel_bias=3.0e-3)
 
 
+REST = 0.0   # seconds at rest before the vehicle pulls away (make_dataset(rest=...)); 0 = moving from the first sample
+
+
 def arc(t):
-    """arc length and speed along the circle: 2.6 m/s with a slow modulation (never at rest: the IMU-wheel initialiser runs its
-    dynamic branch)"""
+    """arc length and speed along the circle.  REST = 0: 2.6 m/s with a slow modulation, never at rest (the IMU-wheel initialiser
+    runs its dynamic branch).  REST > 0: standing still, then pulling away with 2.6 m/s^2 towards 2.6 m/s (the jerk the static IMU
+    initialiser waits for)."""
+    if REST > 0:
+        x = np.maximum(t - REST, 0.0)
+        return 2.6 * (x - (1 - np.exp(-x))), 2.6 * (1 - np.exp(-x))
     return 2.6 * t + 0.8 * np.sin(0.7 * t) / 0.7, 2.6 + 0.8 * np.cos(0.7 * t)
 
 
@@ -313,7 +320,9 @@ init:
 
 
 # ----------------------------------------------------------------------------------------------------------------- dataset
-def make_dataset(out_dir, seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, render=True, log=None):
+def make_dataset(out_dir, seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, render=True, log=None, rest=0.0):
+    global REST
+    REST = float(rest)
     rng = np.random.default_rng(seed)
     os.makedirs(os.path.join(out_dir, "cam0", "data"), exist_ok=True)
     t, wm, am = synth.imu_stream(imu_pose, 0.0, seconds + 0.1, rate=imu_hz, bg=BG, ba=BA)

@@ -89,6 +89,25 @@ def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_
     assert not stats["initialized"] and stats["frames"] >= 40 and stats["clones"] == 0 and len(times) == 0
 
 
+def test_replay_camera_imu_from_rest(pkg, tmp_path):
+    """No wheel: the static IMU initialiser waits through 2.5 s at rest for the jerk of pulling away, then the filter runs on the camera
+    and the IMU alone."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    d = str(tmp_path / "ds")
+    try:
+        sd.make_dataset(d, seconds=9.0, rest=2.5)
+        traj = str(tmp_path / "traj.txt")
+        op = options.load_options(sd.write_config(str(tmp_path / "config"), d, traj, use_wheel=False))
+        op.est.cam.use_lines = False
+        stats, times, poses = rp.replay(op)
+    finally:
+        sd.REST = 0.0
+    assert stats["initialized"] and 1.5 <= stats["startup_time"] <= 2.6          # the last sample of the still window
+    assert stats["wheel_updates"] == 0 and stats["cam_accepted"] >= 300 and stats["not_psd"] == 0
+    r, n = _score(pkg, traj, os.path.join(d, "gt.txt"))
+    assert n >= 50 and r["pos"]["rmse"] < 0.5, r                                 # ~13 m, monocular + IMU only
+
+
 def test_replay_window_options(pkg, dataset, tmp_path):
     """bag_start / bag_durr (run_bag.cpp:214-220) and a run with online intrinsic calibration and the line features off."""
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
