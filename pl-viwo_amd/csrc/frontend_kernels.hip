@@ -10,6 +10,7 @@
 // (LUT, 5x5 binomial, Scharr, 14-bit bilinear weights); LK's normal-equation sums are exact
 // int64 wave reductions rounded to float once, so tracked positions are comparable bit-for-bit
 // with the CPU oracle whatever the reduction order.
+#include "radtan_core.hpp"
 #include <algorithm>
 
 #include "frontend_kernels.hpp"
@@ -270,7 +271,6 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 #define LK_JT 32                // search tile edge
 #define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-__device__ __forceinline__ void undistort_radtan(const double *K, float u, float v, float &xn, float &yn);
 
 // One wavefront (= one 64-thread workgroup) per point; all pyramid levels, coarse to fine.
 // Lane l owns window pixels l, l+64, l+128, l+192 (< win*win).
@@ -470,28 +470,6 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
 }
 
 // ------------------------------------------------------------------------------------------ K6
-__device__ __forceinline__ void undistort_radtan(const double *K, float u, float v, float &xn, float &yn) {
-  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7];
-  const double ifx = 1. / fx, ify = 1. / fy;
-  double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
-  const double x0 = x, y0 = y;
-  for (int j = 0; j < 5; ++j) {
-    double r2 = x * x + y * y;
-    double icdist = 1. / (1 + ((0. * r2 + k2) * r2 + k1) * r2);
-    if (icdist < 0) {
-      x = x0;
-      y = y0;
-      break;
-    }
-    double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-    double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-    x = (x0 - deltaX) * icdist;
-    y = (y0 - deltaY) * icdist;
-  }
-  xn = (float)x;
-  yn = (float)y;
-}
-
 __global__ void undistort_kernel(CamK K, int n, const float *__restrict__ uv, float *__restrict__ xy) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "fld_fit_core.hpp"
+#include "radtan_core.hpp"
 #include "line_kernels.hpp"
 
 using namespace plv;
@@ -484,9 +485,11 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
                 T->rel_id_last.data(), match.data());
     for (int q = 0; q < nk; ++q)
       if (match[q] >= 0) fid[q] = (uint64_t)(int)T->ids_last[match[q]];  // REF :153-158 (`int id`)
-    // undistort_line on the device (CamBase::undistort_line, both end points through undistort_f)
+    // CamBase::undistort_line: both end points through undistort_f.  A few dozen points: the arithmetic of undistort_kernel
+    // (radtan_core.hpp, bit-identical on host and device) run here instead of a launch + copy + synchronisation round trip
     std::vector<float> un(4 * (size_t)std::max(nk, 1));
-    if (nk > 0) TRY(plv_undistort(ctx, 2 * nk, fl.data(), un.data()));
+    for (int q = 0; q < 2 * nk; ++q)
+      undistort_radtan(ctx->cfg.intrinsics, fl[2 * (size_t)q], fl[2 * (size_t)q + 1], un[2 * (size_t)q], un[2 * (size_t)q + 1]);
     for (int q = 0; q < nk; ++q) {
       const int D = plv_line_classification(fl.data() + 4 * q, vps);
       auto it = T->db.find(fid[q]);
