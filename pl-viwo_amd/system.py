@@ -9,7 +9,7 @@ REF: PL-VIWO/src/core/SystemManager.cpp:55-135 (feed_measurement_imu / _camera /
 
 The camera path follows the intended flow feed_measurement -> try_update (as published, SystemManager.cpp:107-127 returns
 before try_update once the filter is initialised).  Scope of this driver: one camera (monocular), MSCKF points and lines
-(cam.max_slam must be 0, the shipped value), wheel optional; `use_imu_res` takes the poses of the camera update from the CPI records of plv_propagate; GPS / LiDAR / stereo /
+(in-state SLAM landmarks in the GLOBAL_3D representation; the shipped configuration has cam.max_slam: 0), wheel optional; `use_imu_res` takes the poses of the camera update from the CPI records of plv_propagate; GPS / LiDAR / stereo /
 simulation are outside SURVEY §8.
 """
 import math
@@ -17,7 +17,7 @@ import time as _time
 
 import numpy as np
 
-from . import (Context, CpiTable, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, WHEEL_TYPES, default_config,
+from . import (Context, CpiTable, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, Tracks, WHEEL_TYPES, default_config,
                imu_noise, init_imu_static, next_clone_time, reset_cpi, select_imu_readings, select_wheel_data)
 from .options import OptionsError
 
@@ -96,6 +96,14 @@ class Vec:
         self.v = self.v + dx
 
 
+class Landmark:
+    """ov_type::Landmark, GLOBAL_3D: value, first estimate, covariance index (REF: open_vins/ov_core/src/types/Landmark.h)."""
+
+    def __init__(self, featid, p, var_id):
+        self.featid, self.p, self.p_fej, self.id = int(featid), np.array(p, dtype=np.float64), np.array(p, dtype=np.float64), var_id
+        self.update_fail_count = 0   # read by marginalize_slam_features (UpdaterCamera.cpp:130); nothing in the reference increments it
+
+
 class State:
     """viw::State: mean, variable order, clone window (the covariance itself is resident in the plv_ctx)."""
 
@@ -105,6 +113,7 @@ class State:
         self.time, self.startup_time, self.initialized = -1.0, -1.0, False
         self.imu = PlvImuState.make([0, 0, 0, 1], [0, 0, 0], [0, 0, 0])
         self.clones = {}            # time -> Pose (real clones; the IMU pose pseudo-clone is added by clone_list())
+        self.slam = {}              # feature id -> Landmark (State::cam_SLAM_features)
         self.imu_pose_in_clones = False
         self.cpis = {}              # time -> PlvCpiRecord-like dict (t, dt, clone_t, R, w, v)
         self.est_a, self.est_A = Stat(), Stat()
@@ -212,6 +221,8 @@ class State:
                 var.update(dx[var.id:var.id + size])
         for c in self.clones.values():
             c.update(dx[c.id:c.id + 6])
+        for lm in self.slam.values():
+            lm.p = lm.p + dx[lm.id:lm.id + 3]
         if self.cam_intr is not None and self.op.est.cam.do_calib_int:
             self.ctx.set_camera_intrinsics(self.cam_intr.v)     # StateHelper.cpp:163-168
 
@@ -226,11 +237,14 @@ class State:
     def marginalize_old_clone(self):
         while self.clone_window() > self.op.est.window_size and self.clones:
             c = self.clones.pop(min(self.clones))
-            self.ctx.cov_marginalize(c.id, 6)
-            self.n -= 6
-            for o in self.clones.values():
-                if o.id > c.id:
-                    o.id -= 6
+            self.marginalize(c.id, 6)
+
+    def marginalize(self, var_id, size):   # StateHelper::marginalize :234-303: later variables move up
+        self.ctx.cov_marginalize(var_id, size)
+        self.n -= size
+        for o in list(self.clones.values()) + list(self.slam.values()):
+            if o.id > var_id:
+                o.id -= size
 
     def flush_old_data(self):   # State.cpp:605-628
         if not self.clones:
@@ -264,8 +278,8 @@ class SystemManager:
         e = op.est
         if e.cam.enabled and e.cam.max_n != 1:
             raise OptionsError("replay driver: one camera (cam.max_n: 1, use_stereo: false)")
-        if e.cam.enabled and e.cam.max_slam != 0:
-            raise OptionsError("replay driver: cam.max_slam must be 0 (plv_slam_update / plv_slam_initialize are not driven from here yet)")
+        if e.cam.enabled and e.cam.max_slam != 0 and e.cam.feat_rep != 0:
+            raise OptionsError("replay driver: in-state landmarks (cam.max_slam > 0) are driven in the GLOBAL_3D representation only")
         if e.cam.enabled and e.cam.distortion_model[0] != "radtan":
             raise OptionsError("only the radtan camera model is built (SURVEY §8 a7)")
         if e.init.use_gt:
@@ -281,7 +295,7 @@ class SystemManager:
                 cfg.intrinsics[i] = float(c.intrinsics[0][i])
             cfg.sigma_pix, cfg.chi2_mult = c.sigma_pix, c.chi2_mult
         clones_max = int(e.window_size * max(e.clone_freq, max(e.intr_err.available_clone_hz() or [e.clone_freq]))) + 3
-        cfg.max_state_dim = max(cfg.max_state_dim, 15 + 30 + 6 * clones_max)
+        cfg.max_state_dim = max(cfg.max_state_dim, 15 + 30 + 6 * clones_max + 3 * (e.cam.max_slam if e.cam.enabled else 0))
         cfg.max_rows_per_feat = max(cfg.max_rows_per_feat, 2 * max_obs)
         cfg.device = device
         self.ctx = Context(cfg)
@@ -311,7 +325,8 @@ class SystemManager:
         self.last_cam_delete_t = -math.inf
         self.tc = TimeChecker()
         self.stats = dict(clones=0, cam_updates=0, cam_features=0, cam_accepted=0, line_updates=0, lines_accepted=0, wheel_updates=0, wheel_accepted=0,
-                          not_psd=0, frames=0, line_pool=0, lines_triangulated=0, lines_tracked=0)
+                          not_psd=0, frames=0, line_pool=0, lines_triangulated=0, lines_tracked=0, slam_initialized=0, slam_updates=0,
+                          slam_marginalized=0)
         self.distance = 0.0
 
     def close(self):
@@ -485,10 +500,22 @@ class SystemManager:
             self.ctx.line_tracker_feed(t, vps)
             self.stats["lines_tracked"] += self.ctx.line_db_size()
             self.tc.dong("[Time-Cam] feed measurement: lines")
+        self._marginalize_slam_features()
         self.stats["frames"] += 1
         if st.initialized:
             self._camera_try_update()
             self.tc.dong("CAM")
+
+    def _marginalize_slam_features(self):   # UpdaterCamera.cpp:118-137 + StateHelper::marginalize_slam :203-213
+        st = self.state
+        if not st.slam:
+            return
+        ids = list(st.slam)
+        flags = self.ctx.slam_marg_flags(ids, [st.slam[i].update_fail_count for i in ids])
+        for fid, f in zip(ids, flags):
+            if f:
+                st.marginalize(st.slam.pop(fid).id, 3)
+                self.stats["slam_marginalized"] += 1
 
     def _camera_try_update(self):
         st, e = self.state, self.op.est
@@ -501,9 +528,11 @@ class SystemManager:
         if e.use_imu_res:      # State::get_interpolated_pose = get_interpolated_pose_imu (State.cpp:975-977)
             kw["cpi"] = st.cpi_table()
         self.tc.ding("[Time-Cam] get features + MSCKF update")
+        cam_hz = (len(self.cam_t_hist) - 1) / (self.cam_t_hist[-1] - self.cam_t_hist[0])
         out = self.ctx.camera_update_points(st.view(), st.n, min(c.max_msckf, self.ctx.cfg.max_features), self.max_obs, min_dist=fi.min_dist,
                                             max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline,
-                                            refine=fi.refine_features, **kw)
+                                            refine=fi.refine_features, max_slam=c.max_slam, slam_ids=list(st.slam),
+                                            init_min_meas=min(int(e.window_size) * int(cam_hz) - 1, 10), **kw)   # CamHelper.cpp:686
         if out["status"] != 0:
             self.stats["not_psd"] += 1
         elif out["n_accepted"] > 0:
@@ -512,6 +541,8 @@ class SystemManager:
         self.tc.dong("[Time-Cam] get features + MSCKF update")
         self.stats["cam_features"] += out["n_msckf"]
         self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
+        if c.max_slam > 0:
+            self._slam_update_and_init(out)
         if self.use_lines:
             self.tc.ding("[Time-Cam] LINE update")
             lo = self.ctx.camera_update_lines(st.view(), st.n, self.max_obs, **kw)
@@ -524,6 +555,60 @@ class SystemManager:
                 self.stats["line_updates"] += 1
                 self.stats["lines_accepted"] += lo["n_accepted"]
             self.tc.dong("[Time-Cam] LINE update")
+
+    def _landmark_system(self, t, uv, p, p_fej):
+        """get_feature_jacobian_full for one feature: (rows, Hf [rows][3], Hx [rows][k], res, cols)."""
+        st = self.state.view()
+        tr = Tracks([0, len(t)], t, uv, [p], p_FinG_fej=[p_fej])
+        cols = self.ctx.jacobian_columns(st, tr)
+        rows, Hf, Hx, res = self.ctx.build_jacobians(st, tr, cols, 2 * self.max_obs)
+        r = int(rows[0])
+        return r, Hf[0].T[:r].copy(), Hx[0].T[:r].copy(), res[0][:r].copy(), cols
+
+    def _slam_update_and_init(self, out):   # UpdaterCamera::slam_update :296-338, slam_init :340-369
+        st, c = self.state, self.op.est.cam
+        if out["n_slam"]:
+            lst = self.ctx.camera_update_list(0)
+            for j, fid in enumerate(lst["ids"]):
+                a, b = lst["obs_ptr"][j], lst["obs_ptr"][j + 1]
+                lm = st.slam.get(int(fid))
+                if lm is None or b - a < 1 or b - a > self.max_obs:
+                    continue
+                r, Hf, Hx, res, cols = self._landmark_system(lst["obs_time"][a:b], lst["obs_uv"][a:b], lm.p, lm.p_fej)
+                if r < 2:
+                    continue
+                H = np.hstack([Hx, Hf])
+                cols_f = np.concatenate([cols, [lm.id, lm.id + 1, lm.id + 2]]).astype(np.int32)
+                rc, acc, dx = self.ctx.slam_update(st.n, H, res, cols_f, c.chi2_mult)
+                if rc != 0:
+                    self.stats["not_psd"] += 1
+                elif acc:
+                    st.apply(dx)
+                    self.stats["slam_updates"] += 1
+        if out["n_init"]:
+            lst = self.ctx.camera_update_list(1)
+            for j, fid in enumerate(lst["ids"]):
+                a, b = lst["obs_ptr"][j], lst["obs_ptr"][j + 1]
+                t, uv, p = lst["obs_time"][a:b], lst["obs_uv"][a:b], lst["p_FinG"][j]
+                if int(fid) in st.slam:
+                    # A landmark of the state stays in the tracker's database (FeatureDatabase::get_feature does not remove it,
+                    # CamHelper.cpp:621-628) and can come back through the pool as an initialisation candidate.  The reference
+                    # initialises a second copy whose map insert then fails (UpdaterCamera.cpp:361): three orphaned columns that
+                    # are never marginalised.  Here the candidate is consumed without growing the state.
+                    continue
+                ok = 0
+                if 2 <= b - a <= self.max_obs:
+                    r, Hf, Hx, res, cols = self._landmark_system(t, uv, p, p)
+                    if r >= 4:
+                        ok, dxi, dx = self.ctx.slam_initialize(st.n, Hf, Hx, res, cols, c.chi2_mult)
+                if ok:   # StateHelper::initialize :357-439: the landmark joins the state at the end, then the EKF correction
+                    st.slam[int(fid)] = Landmark(fid, p + dxi, st.n)
+                    st.slam[int(fid)].p_fej = np.array(p, dtype=np.float64)
+                    st.n += 3
+                    st.apply(dx)
+                    self.stats["slam_initialized"] += 1
+                else:    # UpdaterCamera.cpp:363-364: back to the database
+                    self.ctx.db_append_measurements(int(fid), t, uv, lst["obs_uvn"][a:b])
 
     # ---------------------------------------------------------------------------------------------- wheel
     def feed_measurement_wheel(self, t, m1, m2):

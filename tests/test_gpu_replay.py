@@ -79,6 +79,20 @@ def test_replay_with_dynamic_cloning(pkg, dataset, tmp_path):
     assert r["pos"]["rmse"] < 0.10, r
 
 
+def test_replay_with_slam_landmarks(pkg, dataset, tmp_path):
+    """cam.max_slam > 0: long tracks become in-state landmarks (StateHelper::initialize), are updated one by one while tracked
+    (UpdaterCamera::slam_update) and marginalised when the tracker loses them (marginalize_slam_features)."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    traj = str(tmp_path / "traj.txt")
+    op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+    op.est.cam.max_slam, op.est.cam.use_lines = 12, False
+    stats, times, poses = rp.replay(op)
+    assert stats["not_psd"] == 0 and stats["slam_initialized"] >= 12 and stats["slam_updates"] >= 50 and stats["slam_marginalized"] >= 1
+    assert stats["n_state"] <= 15 + 6 * 12 + 3 * 12
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.10, r
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""
