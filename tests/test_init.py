@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 from scipy.spatial.transform import Rotation
 
 import synth
@@ -197,3 +198,26 @@ def test_constraint_polynomial_roots(pkg):
             n_ok += 1
             assert abs(np.linalg.norm(hip.last_init[6:9]) - 9.81) < 1e-3
     assert n_ok >= 6
+
+
+def test_argument_checks(pkg):
+    import ctypes as C
+    lib = pkg.load_library()
+    z = np.zeros(3)
+    out, ok = np.zeros(17), C.c_int(7)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.plv_init_imu_static(5, None, None, None, 1.0, 0.3, dp(z), dp(out), C.byref(ok)) == pkg.PLV_E_BADARG
+    assert lib.plv_init_imu_static(0, None, None, None, 1.0, 0.3, dp(z), dp(out), C.byref(ok)) == pkg.PLV_OK and ok.value == 0
+    assert lib.plv_init_imu_static(0, None, None, None, 1.0, 0.3, dp(z), dp(out), None) == pkg.PLV_E_BADARG
+    init = pkg.IwInitializer("Wheel3DAng", (RL, RR, B), R_ITOO, P_IINO, 0.0, 0.1, G, False)
+    init.opt.wheel_type = 9
+    with pytest.raises(pkg.PlvError):
+        init.initialization(np.zeros(4), np.zeros((4, 3)), np.zeros((4, 3)), np.zeros(4), np.zeros(4), np.zeros(4))
+    with pytest.raises(KeyError):
+        pkg.IwInitializer("Wheel5D", (RL, RR, B), R_ITOO, P_IINO, 0.0, 0.1, G, False)
+    # a fresh state starts at cnt_smooth = -1 (IW_Initializer.h) and a reset brings it back
+    init2 = pkg.IwInitializer("Wheel2DCen", (RL, RR, B), R_ITOO, P_IINO, 0.0, 0.1, G, True)
+    assert init2.state.cnt_smooth == -1
+    init2.state.cnt_smooth = 3
+    lib.plv_iw_init_reset(C.byref(init2.state))
+    assert init2.state.cnt_smooth == -1 and not any(init2.state.prev_init)
