@@ -191,10 +191,10 @@ class TrajectoryLogger:
         self.f.close()
 
 
-def replay(op, dataset=None, trajectory_path=None, device=0, progress=None, max_obs=24):
+def replay(op, dataset=None, trajectory_path=None, device=0, progress=None, max_obs=24, **system_kw):
     """run_bag's main loop.  Returns (SystemManager statistics, times, poses [n][7] = p, q)."""
     ds = dataset if dataset is not None else Dataset(op.sys.path_bag, use_wheel=op.est.wheel.enabled, use_cam=op.est.cam.enabled)
-    sys = SystemManager(op, device=device, max_obs=max_obs)
+    sys = SystemManager(op, device=device, max_obs=max_obs, **system_kw)
     path = trajectory_path if trajectory_path is not None else (op.sys.path_trajectory if op.sys.save_trajectory else None)
     log = TrajectoryLogger(path) if path else None
     t_init = ds.t_begin() + op.sys.bag_start                               # run_bag.cpp:214-216

@@ -274,7 +274,9 @@ class TimeChecker:
 class SystemManager:
     """viw::SystemManager for IMU + one camera (+ wheel)."""
 
-    def __init__(self, op, device=0, max_obs=24):
+    def __init__(self, op, device=0, max_obs=24, context_factory=None, iw_initializer_factory=None):
+        """context_factory / iw_initializer_factory: stand-ins with the interface of Context / IwInitializer (the tests run the same
+        driver over the CPU oracle through them); the defaults are the HIP library."""
         e = op.est
         if e.cam.enabled and e.cam.max_n != 1:
             raise OptionsError("replay driver: one camera (cam.max_n: 1, use_stereo: false)")
@@ -298,7 +300,7 @@ class SystemManager:
         cfg.max_state_dim = max(cfg.max_state_dim, 15 + 30 + 6 * clones_max + 3 * (e.cam.max_slam if e.cam.enabled else 0))
         cfg.max_rows_per_feat = max(cfg.max_rows_per_feat, 2 * max_obs)
         cfg.device = device
-        self.ctx = Context(cfg)
+        self.ctx = (context_factory or Context)(cfg)
         self.max_obs = max_obs
         self.state = State(op, self.ctx)
         self.noise = imu_noise(e.imu.sigma_w, e.imu.sigma_wb, e.imu.sigma_a, e.imu.sigma_ab, tuple(e.gravity))
@@ -320,7 +322,7 @@ class SystemManager:
         self.iw_init = None
         if not e.init.imu_only_init and e.wheel.enabled:
             st = self.state
-            self.iw_init = IwInitializer(e.wheel.type, st.wheel_intr.v, st.wheel_ext.Rot(), st.wheel_ext.p, float(st.wheel_dt.v[0]),
+            self.iw_init = (iw_initializer_factory or IwInitializer)(e.wheel.type, st.wheel_intr.v, st.wheel_ext.Rot(), st.wheel_ext.p, float(st.wheel_dt.v[0]),
                                          e.init.imu_wheel_thresh, e.gravity, e.init.imu_gravity_aligned)
         self.last_cam_delete_t = -math.inf
         self.tc = TimeChecker()
