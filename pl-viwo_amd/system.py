@@ -257,6 +257,43 @@ class State:
                 break
 
 
+class SampleBuffer:
+    """Time-ordered measurement buffer (Propagator::imu_data, UpdaterWheel::data_stack) as one growing array with a moving front:
+    appending and dropping old samples cost nothing per message and the live part is handed to the C-ABI without a copy."""
+
+    def __init__(self, width):
+        self.a = np.zeros((1024, width))
+        self.lo = self.hi = 0
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def append(self, row):
+        if self.hi == len(self.a):
+            n = self.hi - self.lo
+            if self.lo >= len(self.a) // 2:
+                self.a[:n] = self.a[self.lo:self.hi]
+            else:
+                b = np.zeros((2 * len(self.a), self.a.shape[1]))
+                b[:n] = self.a[self.lo:self.hi]
+                self.a = b
+            self.lo, self.hi = 0, n
+        self.a[self.hi] = row
+        self.hi += 1
+
+    def drop_before(self, t):
+        """erases the samples with time < t (column 0)"""
+        k = int(np.searchsorted(self.a[self.lo:self.hi, 0], t, side="left"))
+        self.lo += k
+        return k
+
+    def view(self):
+        return self.a[self.lo:self.hi]
+
+    def t(self, i):
+        return float(self.a[self.hi + i if i < 0 else self.lo + i, 0])
+
+
 class TimeChecker:
     """ding / dong totals per label (REF: PL-VIWO/src/utils/TimeChecker.h:56-135)."""
 
@@ -305,7 +342,7 @@ class SystemManager:
         self.state = State(op, self.ctx)
         self.noise = imu_noise(e.imu.sigma_w, e.imu.sigma_wb, e.imu.sigma_a, e.imu.sigma_ab, tuple(e.gravity))
         # Propagator
-        self.imu_t, self.imu_w, self.imu_a = [], [], []
+        self.imu = SampleBuffer(7)   # t, wm (3), am (3)
         self.cpi_acc = None
         # UpdaterCamera
         self.cam_t_hist = []
@@ -337,7 +374,8 @@ class SystemManager:
     # ================================================================================================ Initializer
     def _try_initialization(self):
         e = self.op.est
-        t, wm, am = np.array(self.imu_t), np.array(self.imu_w).reshape(-1, 3), np.array(self.imu_a).reshape(-1, 3)
+        v = self.imu.view()
+        t, wm, am = np.ascontiguousarray(v[:, 0]), np.ascontiguousarray(v[:, 1:4]), np.ascontiguousarray(v[:, 4:7])
         if self.iw_init is not None:
             x = self.iw_init.initialization(t, wm, am, np.array(self.whl_t), np.array(self.whl_m1), np.array(self.whl_m2))
         else:
@@ -350,11 +388,10 @@ class SystemManager:
 
     def _delete_old_measurements(self):   # Initializer.cpp:115-172
         W = self.op.est.init.window_time
-        if not self.imu_t or self.imu_t[-1] - self.imu_t[0] <= 3 * W:
+        if not len(self.imu) or self.imu.t(-1) - self.imu.t(0) <= 3 * W:
             return
-        old = self.imu_t[-1] - 3 * W
-        k = next(i for i, t in enumerate(self.imu_t) if not t < old)
-        del self.imu_t[:k], self.imu_w[:k], self.imu_a[:k]
+        old = self.imu.t(-1) - 3 * W
+        self.imu.drop_before(old)
         if self.op.est.cam.enabled and len(self.cam_t_hist) > 1:
             cam_hz = (len(self.cam_t_hist) - 1) / (self.cam_t_hist[-1] - self.cam_t_hist[0])
             if self.last_cam_delete_t + 100.0 / cam_hz < old:
@@ -377,17 +414,17 @@ class SystemManager:
 
     # ================================================================================================ Propagator
     def _feed_imu(self, t, wm, am):   # Propagator.cpp:17-28
-        self.imu_t.append(float(t)), self.imu_w.append(np.asarray(wm, dtype=np.float64)), self.imu_a.append(np.asarray(am, dtype=np.float64))
+        self.imu.append((t, wm[0], wm[1], wm[2], am[0], am[1], am[2]))
         st = self.state
         if st.clones:
-            old = min(st.clones) - 1
-            k = next((i for i, x in enumerate(self.imu_t) if not x < old), 0)
-            if k:
-                del self.imu_t[:k], self.imu_w[:k], self.imu_a[:k]
+            self.imu.drop_before(min(st.clones) - 1)
 
     def _propagate(self, timestamp):   # Propagator.cpp:30-91
         st = self.state
-        ok, t, wm, am = select_imu_readings(np.array(self.imu_t), np.array(self.imu_w).reshape(-1, 3), np.array(self.imu_a).reshape(-1, 3),
+        v = self.imu.view()
+        # only the tail that can matter: from the sample before the state time on (the buffer reaches a second further back)
+        k = max(0, int(np.searchsorted(v[:, 0], st.time, side="right")) - 2)
+        ok, t, wm, am = select_imu_readings(np.ascontiguousarray(v[k:, 0]), np.ascontiguousarray(v[k:, 1:4]), np.ascontiguousarray(v[k:, 4:7]),
                                             st.time, timestamp)
         if not ok:
             return
@@ -444,22 +481,22 @@ class SystemManager:
         sensor_t = self.cam_t_hist if e.cam.enabled else []
         sensor_dt = float(st.cam_dt.v[0]) if e.cam.enabled else 0.0
         r = next_clone_time(len(ct), st.time, meas_t, ct[-1], ct[-2] if len(ct) > 1 else -math.inf, False, freq, sensor_t, sensor_dt,
-                            self.imu_t[0], self.imu_t[-1], wheel_enabled=e.wheel.enabled)
+                            self.imu.t(0), self.imu.t(-1), wheel_enabled=e.wheel.enabled)
         if r is not None and e.dynamic_cloning:
             e.clone_freq = freq
         return r
 
     def _compute_accelerations(self):   # SystemManager.cpp:269-295
         st = self.state
-        if len(self.imu_t) < 2:
+        if len(self.imu) < 2:
             return
-        t1 = self.imu_t[-2]
+        t1 = self.imu.t(-2)
         c1 = st.cpis.get(t1)
         if c1 is None or c1["clone_t"] not in st.clones:
             return   # State::have_cpi would try to create one (linear / integrated): only stored records are used here
         R_I0toG = st.clones[c1["clone_t"]].Rot().T
         R_IktoI0 = c1["R"].T
-        a = R_I0toG @ R_IktoI0 @ self.imu_a[-2] - quat_2_Rot(st.imu.q).T @ np.array(st.imu.ba) - self.op.est.gravity
+        a = R_I0toG @ R_IktoI0 @ self.imu.view()[-2, 4:7] - quat_2_Rot(st.imu.q).T @ np.array(st.imu.ba) - self.op.est.gravity
         st.est_a.add_stat(np.linalg.norm(a))
         if c1["dt"] != 0:
             st.est_A.reset()
