@@ -125,6 +125,24 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     assert abs(ate["hip"] - ate["cpu"]) < 0.01, ate
 
 
+def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
+    """cam.downsample (pyrDown of every image, halved intrinsics: OptionsCamera.cpp:123-138, UpdaterCamera.cpp:85-98) with the CLAHE
+    front-end on the 376 x 240 images."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    traj = str(tmp_path / "traj.txt")
+    cfg = sd.write_config(str(tmp_path / "config"), dataset, traj)
+    cam = os.path.join(os.path.dirname(cfg), "config_camera.yaml")
+    text = open(cam).read().replace("downsample: false", "downsample: true").replace('histogram_method: "HISTOGRAM"', 'histogram_method: "CLAHE"')
+    open(cam, "w").write(text)
+    op = options.load_options(cfg)
+    assert op.est.cam.wh[0] == [376, 240] and abs(op.est.cam.intrinsics[0][0] - sd.K8[0] / 2) < 1e-9 and op.est.cam.histogram == 2
+    op.est.cam.use_lines = False
+    stats, times, poses = rp.replay(op)
+    assert stats["initialized"] and stats["cam_accepted"] >= 300 and stats["not_psd"] == 0
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.15, r
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""
