@@ -143,6 +143,40 @@ def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
     assert r["pos"]["rmse"] < 0.15, r
 
 
+def test_replay_with_every_online_calibration(pkg, dataset, tmp_path):
+    """Camera extrinsics / intrinsics / time offset and wheel extrinsics / intrinsics / time offset in the state (n = 15 + 15 + 10 +
+    clones): the variable order of State.cpp:58-190 carried through every Jacobian column map; the estimates stay at the truth they
+    start from."""
+    options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
+    traj = str(tmp_path / "traj.txt")
+    op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+    c, w = op.est.cam, op.est.wheel
+    c.do_calib_ext = c.do_calib_int = c.do_calib_dt = True
+    w.do_calib_ext = w.do_calib_int = w.do_calib_dt = True
+    c.use_lines = False
+    keep = {}
+    orig = system.SystemManager.close
+
+    def grab(self):
+        st = self.state
+        keep.update(K=st.cam_intr.v.copy(), p=st.cam_ext.p.copy(), dt=float(st.cam_dt.v[0]), wi=st.wheel_intr.v.copy(), wdt=float(st.wheel_dt.v[0]),
+                    ids=(st.cam_ext.id, st.cam_intr.id, st.cam_dt.id, st.wheel_dt.id, st.wheel_ext.id, st.wheel_intr.id))
+        orig(self)
+    system.SystemManager.close = grab
+    try:
+        stats, times, poses = rp.replay(op)
+    finally:
+        system.SystemManager.close = orig
+    assert keep["ids"] == (15, 21, 29, 30, 31, 37)
+    assert stats["initialized"] and stats["not_psd"] == 0 and stats["cam_accepted"] >= 800 and stats["wheel_accepted"] >= 60
+    assert stats["n_state"] <= 40 + 6 * 12
+    assert np.abs(keep["K"][:4] - sd.K8[:4]).max() < 2.0 and np.abs(keep["K"][4:] - sd.K8[4:]).max() < 0.02
+    assert np.abs(keep["p"] - c.extrinsics[0][4:]).max() < 0.03 and abs(keep["dt"]) < 5e-3 and abs(keep["wdt"]) < 2e-2
+    assert np.abs(keep["wi"] - [sd.RL, sd.RR, sd.BASE]).max() < 0.02
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.10, r
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""
