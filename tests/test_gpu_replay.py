@@ -177,6 +177,22 @@ def test_replay_with_every_online_calibration(pkg, dataset, tmp_path):
     assert r["pos"]["rmse"] < 0.10, r
 
 
+@pytest.mark.parametrize("wtype,reuse", [("Wheel2DAng", False), ("Wheel3DAng", True)])
+def test_replay_wheel_variants(pkg, dataset, tmp_path, wtype, reuse):
+    """The planar wheel model (3 rows per update) on the same encoder file, and wheel.reuse_of_information (one update from the oldest
+    clone to the newest one the wheel data reaches, UpdaterWheel.cpp:38-49)."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    traj = str(tmp_path / "traj.txt")
+    op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+    op.est.wheel.type, op.est.wheel.reuse_of_information = wtype, reuse
+    op.est.cam.use_lines = False
+    op.sys.bag_durr = 5.0
+    stats, times, poses = rp.replay(op)
+    assert stats["initialized"] and stats["not_psd"] == 0 and stats["wheel_updates"] >= 20 and stats["wheel_accepted"] >= 0.8 * stats["wheel_updates"]
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.10, r
+
+
 def test_replay_without_wheel_uses_the_static_imu_initialiser(pkg, dataset, tmp_path):
     """imu_only_init on a vehicle that is already moving: the static initialiser never sees a still window and the filter stays
     uninitialised (the tracker keeps running, measurements older than three windows are dropped)."""
