@@ -348,7 +348,7 @@ class SystemManager:
         self.cam_t_hist = []
         self.use_lines = bool(e.cam.enabled and e.cam.use_lines)
         # UpdaterWheel
-        self.whl_t, self.whl_m1, self.whl_m2 = [], [], []
+        self.whl = SampleBuffer(3)   # t, m1, m2
         self.whl_last_updated = -1.0
         self.wheel_opt = None
         if e.wheel.enabled:
@@ -377,7 +377,8 @@ class SystemManager:
         v = self.imu.view()
         t, wm, am = np.ascontiguousarray(v[:, 0]), np.ascontiguousarray(v[:, 1:4]), np.ascontiguousarray(v[:, 4:7])
         if self.iw_init is not None:
-            x = self.iw_init.initialization(t, wm, am, np.array(self.whl_t), np.array(self.whl_m1), np.array(self.whl_m2))
+            w = self.whl.view()
+            x = self.iw_init.initialization(t, wm, am, np.ascontiguousarray(w[:, 0]), np.ascontiguousarray(w[:, 1]), np.ascontiguousarray(w[:, 2]))
         else:
             x = init_imu_static(t, wm, am, e.init.window_time, e.init.imu_thresh, e.gravity)
         if x is None:
@@ -398,8 +399,7 @@ class SystemManager:
                 self.ctx.db_cleanup_measurements(old)
                 self.last_cam_delete_t = old
         if self.op.est.wheel.enabled:
-            k = next((i for i, t in enumerate(self.whl_t) if not t < old), len(self.whl_t))
-            del self.whl_t[:k], self.whl_m1[:k], self.whl_m2[:k]
+            self.whl.drop_before(old)
 
     def _set_state(self, x):   # Initializer.cpp:174-220
         st = self.state
@@ -657,9 +657,9 @@ class SystemManager:
         st = self.state
         if st.initialized:
             self.tc.ding("WHL")
-        self.whl_t.append(float(t)), self.whl_m1.append(float(m1)), self.whl_m2.append(float(m2))
-        while self.whl_t and t - self.whl_t[0] > 1000:
-            del self.whl_t[0], self.whl_m1[0], self.whl_m2[0]
+        self.whl.append((t, m1, m2))
+        if t - self.whl.t(0) > 1000:   # UpdaterWheel.cpp:24-30
+            self.whl.drop_before(t - 1000)
         if st.initialized:
             self._wheel_try_update()
             self.tc.dong("WHL")
@@ -672,7 +672,7 @@ class SystemManager:
         if wl.reuse_of_information:   # UpdaterWheel.cpp:38-49
             if st.clone_window() > self.op.est.window_size:
                 return
-            older = [t for t in ts if t < self.whl_t[-1] + float(st.wheel_dt.v[0])]
+            older = [t for t in ts if t < self.whl.t(-1) + float(st.wheel_dt.v[0])]
             if older:
                 self._wheel_update(ts[0], older[-1])
             return
@@ -691,7 +691,12 @@ class SystemManager:
     def _wheel_update(self, time0, time1):   # UpdaterWheel.cpp:72-139
         st = self.state
         toff = float(st.wheel_dt.v[0])
-        ok, t, m1, m2 = select_wheel_data(np.array(self.whl_t), np.array(self.whl_m1), np.array(self.whl_m2), time0 - toff, time1 - toff)
+        w = self.whl.view()
+        if w[0, 0] > time0 - toff:     # the reference's own test on the whole stack (UpdaterWheel.cpp:150)
+            return False
+        k = max(0, int(np.searchsorted(w[:, 0], time0 - toff, side="right")) - 2)   # only the tail that can matter
+        ok, t, m1, m2 = select_wheel_data(np.ascontiguousarray(w[k:, 0]), np.ascontiguousarray(w[k:, 1]), np.ascontiguousarray(w[k:, 2]),
+                                          time0 - toff, time1 - toff)
         if not ok:
             return False
         c0, c1 = st.clone_at(time0), st.clone_at(time1)
