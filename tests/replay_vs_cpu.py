@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The accuracy half of the metric on a rendered dataset ("ATE vs CPU ref"): the replay driver once over the HIP library and once
+over the CPU oracle (tests/oracle_context.py: points + wheel, lines off), both trajectories scored against the simulated truth and
+against each other.  Test infrastructure (it runs the oracle), like tests/vio_sequence.py.
+
+    python tests/replay_vs_cpu.py [--seconds 24] [--out profiles/r01/replay_vs_cpu.json]        (needs a GPU)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import __graft_entry__ as ge  # noqa: E402
+import oracle_context as oc  # noqa: E402
+import synth_dataset as sd  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=24.0)
+    ap.add_argument("--out")
+    a = ap.parse_args()
+    pkg = ge.load_pkg()
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    d = tempfile.mkdtemp(prefix="plv_synth_")
+    sd.make_dataset(d, a.seconds)
+    gt = os.path.join(d, "gt.txt")
+    res, runs = dict(seconds=a.seconds, dataset="tests/synth_dataset.py (rendered 752x480 images, 200 Hz IMU, 50 Hz wheel)", lines="off in both runs"), {}
+    ctx = pkg.Context(pkg.default_config(752, 480))
+    for name, kw in (("hip", {}), ("cpu_oracle", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
+        traj = os.path.join(d, "out", f"traj_{name}.txt")
+        op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj))
+        op.est.cam.use_lines = False
+        t0 = time.time()
+        stats, times, poses = rp.replay(op, **kw)
+        et, ep = pkg.traj_load(traj)[:2]
+        gt_t, gt_p = pkg.traj_load(gt)[:2]
+        ei, gi = pkg.traj_associate(et, gt_t)
+        r = ctx.traj_ate(ep[ei], gt_p[gi], "posyaw")
+        res[name] = dict(wall_s=round(time.time() - t0, 2), stats=stats, ate=dict(method="posyaw", n=len(ei), pos=r["pos"], ori=r["ori"]))
+        runs[name] = (times, poses)
+    (th, ph), (tc, pc) = runs["hip"], runs["cpu_oracle"]
+    if len(th) == len(tc) and np.array_equal(th, tc):
+        r = ctx.traj_ate(ph, pc, "none")
+        res["hip_vs_cpu"] = dict(n=len(th), max_pos_diff_m=float(np.abs(ph[:, :3] - pc[:, :3]).max()), pos=r["pos"], ori=r["ori"],
+                                 ate_difference_m=abs(res["hip"]["ate"]["pos"]["rmse"] - res["cpu_oracle"]["ate"]["pos"]["rmse"]))
+    ctx.close()
+    print(json.dumps(res, indent=1, default=float))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1, default=float)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,9 +28,6 @@ def main():
     ap.add_argument("--no-wheel", action="store_true")
     ap.add_argument("--no-lines", action="store_true")
     ap.add_argument("--keep", help="directory to keep the synthetic dataset in")
-    ap.add_argument("--cpu-oracle", action="store_true",
-                    help="also run the same driver over the CPU oracle (tests/oracle_context.py; points + wheel, no lines) and report the "
-                         "difference between the two trajectories")
     a = ap.parse_args()
     pkg = ge.load_pkg()
     options = importlib.import_module("plviwo_amd.options")
@@ -65,31 +62,6 @@ def main():
         res["ate"] = dict(method=a.align, n=len(ei), pos=r["pos"], ori=r["ori"], length_m=pkg.traj_length(ep))
         ctx.close()
     print(json.dumps(res, indent=1, default=float))
-    if a.cpu_oracle:
-        import numpy as np
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_context as oc
-        opc = options.load_options(a.config)
-        if a.dataset:
-            opc.sys.path_bag = a.dataset
-        opc.est.cam.use_lines = False
-        opc.sys.save_trajectory, opc.sys.path_trajectory = True, op.sys.path_trajectory + ".cpu"
-        t0 = time.time()
-        cstats, ctimes, cposes = rp.replay(opc, context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer)
-        res["cpu_oracle"] = dict(wall_s=round(time.time() - t0, 2), stats=cstats, note="lines off in both runs" if a.no_lines else
-                                 "the GPU run above had lines ON unless --no-lines was given")
-        if len(ctimes) == len(times) and np.array_equal(ctimes, times):
-            ctx = pkg.Context(pkg.default_config(752, 480))
-            r = ctx.traj_ate(poses, cposes, "none")
-            res["hip_vs_cpu"] = dict(n=len(times), max_pos_diff_m=float(np.abs(poses[:, :3] - cposes[:, :3]).max()), pos=r["pos"], ori=r["ori"])
-            if a.gt:
-                et, ep = pkg.traj_load(opc.sys.path_trajectory)[:2]
-                gt_t, gt_p = pkg.traj_load(a.gt)[:2]
-                ei, gi = pkg.traj_associate(et, gt_t)
-                rc_ = ctx.traj_ate(ep[ei], gt_p[gi], a.align)
-                res["cpu_oracle"]["ate"] = dict(method=a.align, n=len(ei), pos=rc_["pos"], ori=rc_["ori"])
-            ctx.close()
-        print(json.dumps({k: res[k] for k in ("cpu_oracle", "hip_vs_cpu") if k in res}, indent=1, default=float))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:
