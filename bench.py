@@ -184,12 +184,18 @@ def cpu_baseline(pkg, frames, pts_of, P, scene, sample_frames, lt=None, cols_l=N
         t_lupd += t4 - t3
     tot = t_front + t_upd + t_lfront + t_lupd
     ms = lambda x: x / sample_frames * 1e3
+    # the one stage the reference runs through cv::parallel_for_ (the per-point LK), with the host's cores
+    nthr = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    for i in range(4):
+        fo.perform_matching(prev, cur, pts_of[i & 1], pts_of[i & 1], K8, nthreads=nthr)
+    t_mt = (time.perf_counter() - t0) / 4
     parts = f"point front-end {ms(t_front):.2f} ms + point update {ms(t_upd):.2f} ms"
     if lo is not None:
         parts += f" + line front-end {ms(t_lfront):.2f} ms + line update {ms(t_lupd):.2f} ms"
     return {"value": sample_frames / tot, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{sample_frames} frames of the same workload ({parts} per frame), oracle g++ -O3 single thread, "
-                      f"host has {os.cpu_count()} cores"}
+                      f"host has {os.cpu_count()} cores; LK + RANSAC alone with {nthr} threads: {t_mt * 1e3:.2f} ms"}
 
 
 def pmc_traffic(kernel):
