@@ -246,6 +246,9 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * equalize + pyramid, first-frame detection or top-up on the last image, temporal KLT + RANSAC,
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
+/* plv_tracker_feed from an image already resident in HBM (plv_image_stage, slots 0..7): the camera driver's DMA target in a
+ * deployment, and the form bench.py times (no PCIe copy inside the frame). */
+int plv_tracker_feed_staged(plv_ctx *ctx, double timestamp, int slot, const uint8_t *mask);
 /* feed_measurement with OptionsCamera::downsample (REF: UpdaterCamera.cpp:85-98): cv::pyrDown(img, Size(cols / 2.0,
  * rows / 2.0)) of image and mask on the device, then the same path.  The context is created at the halved
  * resolution with halved intrinsics, as the reference's option loader does (OptionsCamera.cpp:123-138). */
@@ -505,6 +508,7 @@ typedef struct plv_update_result {
   int status;       /* PLV_OK, or PLV_E_NOT_PSD from the EKF step (state untouched)          */
   int n_slam;       /* landmarks of the state with a usable track (list PLV_LIST_SLAM)       */
   int n_init;       /* features chosen for SLAM initialisation (list PLV_LIST_INIT)          */
+  int n_truncated;  /* tracks with more than max_obs usable observations: the newest max_obs were used */
 } plv_update_result;
 
 /* CamHelper::get_features (pool = features_containing_older(2nd-oldest clone) + features_not_containing_newer

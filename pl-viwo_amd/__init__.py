@@ -112,6 +112,7 @@ def load_library():
         "plv_perform_detection": (C.c_int, [vp, C.c_int, u8p, fp, C.POINTER(C.c_uint64), C.c_int, C.c_int,
                                             C.POINTER(C.c_uint64), ip]),
         "plv_tracker_feed": (C.c_int, [vp, C.c_double, u8p, C.c_int, u8p]),
+        "plv_tracker_feed_staged": (C.c_int, [vp, C.c_double, C.c_int, u8p]),
         "plv_tracker_feed_downsampled": (C.c_int, [vp, C.c_double, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
         "plv_downsample": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
         "plv_feed_image_downsampled": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int]),
@@ -390,7 +391,7 @@ class PlvUpdateOptions(C.Structure):
 
 class PlvUpdateResult(C.Structure):
     _fields_ = [("n_pool", C.c_int), ("n_msckf", C.c_int), ("n_accepted", C.c_int), ("n_rows", C.c_int),
-                ("n_returned", C.c_int), ("status", C.c_int), ("n_slam", C.c_int), ("n_init", C.c_int)]
+                ("n_returned", C.c_int), ("status", C.c_int), ("n_slam", C.c_int), ("n_init", C.c_int), ("n_truncated", C.c_int)]
 
 
 def select_imu_readings(t, wm, am, time0, time1):
@@ -973,7 +974,7 @@ class Context:
         m = res.n_msckf
         return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
                     status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=res.n_slam,
-                    n_init=res.n_init)
+                    n_init=res.n_init, n_truncated=res.n_truncated)
 
     def camera_update_list(self, which):
         """SLAM (0) / SLAM-init (1) list of the last camera_update_points: ids, obs_ptr, obs_time, obs_uv, obs_uvn, p_FinG."""
@@ -1166,6 +1167,10 @@ class Context:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
         self._chk(self.lib.plv_tracker_feed(self.h, float(timestamp), _u8p(img), img.shape[1], _u8p(m)))
+
+    def tracker_feed_staged(self, timestamp, slot, mask=None):
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        self._chk(self.lib.plv_tracker_feed_staged(self.h, float(timestamp), int(slot), _u8p(m)))
 
     def tracker_feed_downsampled(self, timestamp, img, mask=None):
         img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -615,7 +615,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
-  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0};
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
   struct Cand {
     uint64_t id;
@@ -691,6 +691,26 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
     }
     res->n_returned = (int)unused.size();
+    if (opt->window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188: on every try_update
+      for (auto it = T->db.begin(); it != T->db.end();) {
+        LineTrack &tr = it->second;
+        size_t keep = 0;
+        for (size_t i = 0; i < tr.t.size(); ++i)
+          if (!(tr.t[i] < t_oldest)) {
+            if (keep != i) {
+              tr.t[keep] = tr.t[i];
+              std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+              std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+            }
+            ++keep;
+          }
+        tr.t.resize(keep);
+        tr.uv.resize(4 * keep);
+        tr.uvn.resize(4 * keep);
+        it = keep == 0 ? T->db.erase(it) : std::next(it);
+      }
+      plv_point_used_cleanup(ctx, t_oldest);
+    }
     return rc;
   };
   auto give_back_all = [&](const Cand &c) {
@@ -779,12 +799,21 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     return finish(rc);
   }
   std::vector<int> sel;
+  std::vector<double> t_first(Lp, -1e300);  // oldest observation time a truncated track keeps
   for (int l = 0; l < Lp; ++l) {
     int valid = 0;
     for (double t : pool[l].tr.t) valid += line_has_bounding_poses(*st, t + dt);
-    if (!ok[l] || valid < 2 || valid > opt->max_obs || (int)sel.size() >= cap) {
+    if (!ok[l] || valid < 2 || (int)sel.size() >= cap) {
       give_back_all(pool[l]);
       continue;
+    }
+    if (valid > opt->max_obs) {  // batch capacity (none in the reference): the newest max_obs observations, counted in n_truncated
+      std::vector<double> tv;
+      for (double t : pool[l].tr.t)
+        if (line_has_bounding_poses(*st, t + dt)) tv.push_back(t);
+      std::nth_element(tv.begin(), tv.begin() + (valid - opt->max_obs), tv.end());
+      t_first[l] = tv[valid - opt->max_obs];
+      ++res->n_truncated;
     }
     sel.push_back(l);
   }
@@ -802,6 +831,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
         give_back(c, i);
         continue;
       }
+      if (c.tr.t[i] < t_first[sel[q]]) continue;
       st_t.push_back(c.tr.t[i]);
       suv.insert(suv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
       if (opt->cpi) {
@@ -843,35 +873,13 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   for (int q = 0; q < L; ++q) {
     res->n_accepted += acc[q];
     if (accepted_out) accepted_out[q] = acc[q];
-    if (!acc[q] || res->status == PLV_E_NOT_PSD) {  // REF UpdaterCamera.cpp:441-444 copy_to_db(lbd_unused, line)
+    if (!acc[q]) {  // REF UpdaterCamera.cpp:441-444 copy_to_db(lbd_unused, line): gate failures only
       const Cand &c = pool[sel[q]];
       for (size_t i = 0; i < c.tr.t.size(); ++i)
         if (line_has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c, i);
     }
   }
-  rc = finish(PLV_OK);
-  if (opt->window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188
-    std::lock_guard<std::mutex> lk(T->mtx);
-    for (auto it = T->db.begin(); it != T->db.end();) {
-      LineTrack &tr = it->second;
-      size_t keep = 0;
-      for (size_t i = 0; i < tr.t.size(); ++i)
-        if (!(tr.t[i] < t_oldest)) {
-          if (keep != i) {
-            tr.t[keep] = tr.t[i];
-            std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
-            std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
-          }
-          ++keep;
-        }
-      tr.t.resize(keep);
-      tr.uv.resize(4 * keep);
-      tr.uvn.resize(4 * keep);
-      it = keep == 0 ? T->db.erase(it) : std::next(it);
-    }
-    plv_point_used_cleanup(ctx, t_oldest);
-  }
-  return rc;
+  return finish(PLV_OK);
 }
 
 }  // extern "C"

@@ -291,14 +291,23 @@ int plv_cov_checkpoint(plv_ctx *ctx) {
   size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
   TRY(us->covck.reserve(bytes));
   PLV_HIP_CHECK(hipMemcpyAsync(us->covck.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  us->covck_n = ctx->cov_n;
   return sync(ctx);
 }
 int plv_cov_rollback(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
-  if (ctx->cov_n < 1 || !us->covck.p) return PLV_E_BADARG;
-  size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
+  if (us->covck_n < 1 || !us->covck.p) {
+    set_last_error("plv_cov_rollback: no checkpoint");
+    return PLV_E_BADARG;
+  }
+  // the checkpoint carries its own dimension: after plv_cov_clone / plv_cov_marginalize / plv_slam_initialize changed the resident
+  // one, the rollback restores the dimension together with the data (the clone / marginalise calls may have swapped d_P for a
+  // buffer of another size)
+  size_t bytes = (size_t)us->covck_n * us->covck_n * 8;
+  TRY(ctx->d_P.reserve(bytes));
   PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, us->covck.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->cov_n = us->covck_n;
   ++ctx->gather_stamp;
   return PLV_OK;  // ordered on the ctx stream; no host sync needed
 }

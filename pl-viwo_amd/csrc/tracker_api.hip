@@ -77,6 +77,14 @@ int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int str
   return tracker_feed_fed(ctx, T, timestamp, mask);
 }
 
+int plv_tracker_feed_staged(plv_ctx *ctx, double timestamp, int slot, const uint8_t *mask) {
+  if (!ctx) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  TRY(plv_feed_staged(ctx, slot));  // the image is already in HBM (plv_image_stage)
+  return tracker_feed_fed(ctx, T, timestamp, mask);
+}
+
 int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, int src_w, int src_h,
                                  const uint8_t *mask, int mask_stride) {
   if (!ctx || !img) return PLV_E_BADARG;
@@ -282,7 +290,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
                              plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted_out, double *p_out) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
-  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0};
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   const double dt = st->cam_dt;
   const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
   struct Cand {
@@ -395,14 +403,18 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // REF :640 sort(feats_pool, feat_sort): long tracks first
   std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
   auto finish = [&](int rc) {
-    std::lock_guard<std::mutex> lk(T->mtx);
-    for (auto &kv : unused) {  // REF :702-703 / :727-729 append_new_measurements
-      Track &d = T->db[kv.first];
-      d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
-      d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
-      d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
+    {
+      std::lock_guard<std::mutex> lk(T->mtx);
+      for (auto &kv : unused) {  // REF :702-703 / :727-729 append_new_measurements
+        Track &d = T->db[kv.first];
+        d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
+        d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
+        d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
+      }
+      res->n_returned = (int)unused.size();
     }
-    res->n_returned = (int)unused.size();
+    // REF CamHelper.cpp:733-737: cleanup_features runs on every try_update, whether or not anything was updated
+    if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);
     return rc;
   };
   auto give_back_all = [&](const Cand &c) {
@@ -484,6 +496,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   }
   // ---- REF :648-699 the selection loop
   std::vector<int> sel;
+  std::vector<double> t_first(Fp, -1e300);  // oldest observation time a truncated track keeps
   for (int f = 0; f < Fp; ++f) {
     const Cand &c = pool[f];
     if ((int)sel.size() >= opt->max_msckf) {  // :651-653 break; the rest returns to the database (:702)
@@ -518,9 +531,15 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       T->last_init.push_back(std::move(e));
       continue;
     }
-    if (valid > opt->max_obs) {  // batch capacity of the MSCKF update
-      give_back_all(c);
-      continue;
+    // batch capacity of the MSCKF update (the reference has none): the newest max_obs observations are used, the older ones are
+    // consumed with the feature; counted in res->n_truncated
+    if (valid > opt->max_obs) {
+      std::vector<double> tv;
+      for (size_t i = 0; i < c.tr.t.size(); ++i)
+        if (has_bounding_poses(*st, c.tr.t[i] + dt)) tv.push_back(c.tr.t[i]);
+      std::nth_element(tv.begin(), tv.begin() + (valid - opt->max_obs), tv.end());
+      t_first[f] = tv[valid - opt->max_obs];
+      ++res->n_truncated;
     }
     sel.push_back(f);
   }
@@ -542,6 +561,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
         give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
         continue;
       }
+      if (c.tr.t[i] < t_first[sel[q]]) continue;
       st_t.push_back(c.tr.t[i]);
       suv.push_back(c.tr.uv[2 * i]);
       suv.push_back(c.tr.uv[2 * i + 1]);
@@ -585,15 +605,13 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   for (int q = 0; q < F; ++q) {
     res->n_accepted += acc[q];
     if (accepted_out) accepted_out[q] = acc[q];
-    if (!acc[q] || res->status == PLV_E_NOT_PSD) {  // REF UpdaterCamera.cpp:266-268 failed features go back
+    if (!acc[q]) {  // REF UpdaterCamera.cpp:266-268: only gate failures go back; what EKFUpdate then rejects is consumed all the same
       const Cand &c = pool[sel[q]];
       for (size_t i = 0; i < c.tr.t.size(); ++i)
         if (has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
     }
   }
-  rc = finish(PLV_OK);
-  if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);  // REF CamHelper.cpp:733-737
-  return rc;
+  return finish(PLV_OK);
 }
 
 int plv_camera_update_list(plv_ctx *ctx, int which, int cap_feat, int cap_obs, int *n_feat, uint64_t *ids, int *obs_ptr,

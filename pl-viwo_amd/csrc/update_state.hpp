@@ -8,6 +8,7 @@ struct plv_ctx_update_state {
   plv::DevBuf q95;
   plv::DevBuf result;   // [dx: max_n doubles][flag: int + pad][accepted: bytes]
   plv::DevBuf covck;    // covariance checkpoint
+  int covck_n = 0;      // dimension of the checkpointed covariance (a rollback restores it together with the data)
   plv::DevBuf bHf, bHx, bres, brows, bcols, bwork;  // staged feature batch ([Hf|Hx|res] in bHf) + working copy
   int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
   bool b_on_device_rows = false;  // rows[] produced on the device (plv_build_jacobians_resident)

@@ -321,6 +321,10 @@ class SystemManager:
             raise OptionsError("replay driver: in-state landmarks (cam.max_slam > 0) are driven in the GLOBAL_3D representation only")
         if e.cam.enabled and e.cam.distortion_model[0] != "radtan":
             raise OptionsError("only the radtan camera model is built (SURVEY §8 a7)")
+        if e.use_imu_cov and not e.use_pol_cov:
+            # CamHelper.cpp:217-224 / LineHelper's twin: R += H_ Q_cpi H_^T * intr_err.mlt for interpolated poses (use_pol_cov wins when both
+            # are set); the Jacobian kernels build the polynomial-covariance branch only
+            raise OptionsError("est.use_imu_cov (CPI covariance as interpolation noise) is not built; use est.use_pol_cov")
         if e.init.use_gt:
             raise OptionsError("init.use_gt needs the simulator / ground-truth reader, outside SURVEY §8")
         self.op = op
@@ -483,7 +487,7 @@ class SystemManager:
         r = next_clone_time(len(ct), st.time, meas_t, ct[-1], ct[-2] if len(ct) > 1 else -math.inf, False, freq, sensor_t, sensor_dt,
                             self.imu.t(0), self.imu.t(-1), wheel_enabled=e.wheel.enabled)
         if r is not None and e.dynamic_cloning:
-            e.clone_freq = freq
+            e.clone_freq, e.intr_order = freq, 3   # SystemManager.cpp:186-189,253-256 overwrite both
         return r
 
     def _compute_accelerations(self):   # SystemManager.cpp:269-295

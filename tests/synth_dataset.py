@@ -43,11 +43,31 @@ def arc(t):
     return 2.6 * t + 0.8 * np.sin(0.7 * t) / 0.7, 2.6 + 0.8 * np.cos(0.7 * t)
 
 
+PATH = "circle"   # "circle": radius-8 m circle (the replay tests); "street": straight down a corridor along +x with a slight weave
+WEAVE_A, WEAVE_K = 0.25, 2 * np.pi / 45.0
+
+
 def odom_pose(t):
     s, _ = arc(t)
+    if PATH == "street":
+        # the reference classifies lines by the vanishing points of the IMU axes (LineHelper.cpp:1026-1088) and triangulates a
+        # classified line from one of its points and that axis (:226-293): structure along / across the driving direction, as on a road
+        th = np.arctan(WEAVE_A * WEAVE_K * np.cos(WEAVE_K * s))
+        R_OtoG = Rotation.from_rotvec([0, 0, th]).as_matrix()
+        return R_OtoG.T, np.array([s, WEAVE_A * np.sin(WEAVE_K * s), 0.0])
     th = s / RADIUS
     R_OtoG = Rotation.from_rotvec([0, 0, th]).as_matrix()
     return R_OtoG.T, np.array([RADIUS * np.sin(th), RADIUS * (1 - np.cos(th)), 0.0])
+
+
+def twist(t, h=1e-4):
+    """speed along the path and yaw rate of the odometry frame"""
+    if PATH != "street":
+        v = arc(t)[1]
+        return v, v / RADIUS
+    (Rm, pm), (Rp, pp) = odom_pose(t - h), odom_pose(t + h)
+    dth = Rotation.from_matrix(Rp.T @ Rm).as_rotvec()[2]
+    return np.linalg.norm(pp - pm) / (2 * h), dth / (2 * h)
 
 
 def imu_pose(t):
@@ -96,6 +116,43 @@ def _mips(seed, manhattan=True):
     return out
 
 
+def _mips_street(seed, ground=False):
+    """"street" style texture (the bench / line-test scene): a smooth large-scale shading with little fine texture, covered with
+    axis-aligned high-contrast rectangles (facade panels and windows on the walls, paving slabs on the ground): long straight edges that
+    end in corners, so that FAST corners sit on the segments the line detector finds (TrackLSD keeps a line only when a tracked point lies
+    on it, TrackLSD.cpp:744-792)."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    n = 2048 - 128
+    base = ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 48.0, mode="wrap")
+    base = 0.5 + 0.22 * base / np.abs(base).max() + 0.018 * ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 1.2, mode="wrap") / 0.2
+    if ground:
+        tile = 120                                  # 1.4 m slabs, every one its own grey level
+        g = rng.uniform(0.12, 0.88, (n // tile + 1, n // tile + 1))
+        base = 0.35 * base + 0.65 * np.kron(g, np.ones((tile, tile)))[:n, :n]
+    else:
+        def rect(x, y, w, h):
+            v = rng.uniform(0.04, 0.3) if rng.random() < 0.5 else rng.uniform(0.7, 0.96)
+            base[y:y + h, x:x + w] = 0.15 * base[y:y + h, x:x + w] + 0.85 * v
+
+        for _ in range(110):                        # panels 1.7 .. 5.5 m wide
+            w, h = int(rng.uniform(140, 460)), int(rng.uniform(90, 300))
+            rect(int(rng.uniform(0, n - w)), int(rng.uniform(0, n - h)), w, h)
+        for _ in range(40):                         # window grids: rows of 0.7 x 1.1 m openings
+            w, h, gx, gy = int(rng.uniform(50, 75)), int(rng.uniform(80, 110)), int(rng.integers(2, 6)), int(rng.integers(1, 4))
+            px, py = int(w * rng.uniform(1.5, 2.2)), int(h * rng.uniform(1.3, 1.8))
+            x0, y0 = int(rng.uniform(0, n - gx * px)), int(rng.uniform(0, n - gy * py))
+            for i in range(gx):
+                for j in range(gy):
+                    rect(x0 + i * px, y0 + j * py, w, h)
+    base = np.clip(ndi.gaussian_filter(base, 0.7, mode="wrap"), 0, 1)
+    out = [base]
+    while out[-1].shape[0] > 16:
+        a = out[-1]
+        out.append(0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2]))
+    return out
+
+
 def _sample(mips, u, v, level):
     """bilinear lookup of texel coordinates (u, v) of level 0 at the mip level chosen per pixel, wrapping around"""
     out = np.zeros(u.shape)
@@ -115,9 +172,17 @@ def _sample(mips, u, v, level):
 class Renderer:
     TEXEL = 0.012   # metres per level-0 texel
 
-    def __init__(self, seed=7):
+    def __init__(self, seed=7, style="room"):
+        """style "room": noise-textured walls 21 m out with thin bright lines (the replay tests' scene); "street": a corridor with facades 9 m to either side with
+        panels / windows and a paved ground (_mips_street), 7 m high with a ceiling instead of the empty sky"""
         self.rays = _undistorted_rays().reshape(-1, 3)
-        self.ground, self.wall = _mips(seed), _mips(seed + 1)
+        self.style = style
+        if style == "street":
+            self.ground, self.wall = _mips_street(seed, ground=True), _mips_street(seed + 1)
+            self.wall_r, self.wall_h = 9.0, 7.0
+        else:
+            self.ground, self.wall = _mips(seed), _mips(seed + 1)
+            self.wall_r, self.wall_h = WALL_R, WALL_H
         self.f = 0.5 * (K8[0] + K8[1])
 
     def render(self, t):
@@ -133,35 +198,47 @@ class Renderer:
         best_t = np.where(np.isfinite(tg), tg, np.inf)
         img_hit = np.full(len(d), -1)            # -1 sky, 0 ground, 1.. wall index + 1
         img_hit[np.isfinite(tg)] = 0
-        ox, oy = c[0], c[1] - RADIUS
+        if self.style == "street":   # a corridor along x: side walls at y = +-wall_r, end walls far away
+            ox, oy = c[0] - 50.0, c[1]
+            plan = ((0, 1.0, 150.0, self.wall_r), (0, -1.0, 150.0, self.wall_r), (1, 1.0, self.wall_r, 150.0), (1, -1.0, self.wall_r, 150.0))
+        else:                        # a square room centred on the circle
+            ox, oy = c[0], c[1] - RADIUS
+            plan = tuple((axis, sign, self.wall_r, self.wall_r) for axis, sign in ((0, 1.0), (0, -1.0), (1, 1.0), (1, -1.0)))
         walls = []
-        for k, (axis, sign) in enumerate(((0, 1.0), (0, -1.0), (1, 1.0), (1, -1.0))):
+        for k, (axis, sign, dist_w, half_w) in enumerate(plan):
             o, dd = (ox, d[:, 0]) if axis == 0 else (oy, d[:, 1])
             with np.errstate(divide="ignore", invalid="ignore"):
-                tw = np.where(sign * dd > 1e-9, (sign * WALL_R - o) / dd, np.inf)
+                tw = np.where(sign * dd > 1e-9, (sign * dist_w - o) / dd, np.inf)
             zw = c[2] + tw * d[:, 2]
             other = (oy + tw * d[:, 1]) if axis == 0 else (ox + tw * d[:, 0])
-            ok = np.isfinite(tw) & (zw >= 0) & (zw <= WALL_H) & (np.abs(other) <= WALL_R)
+            ok = np.isfinite(tw) & (zw >= 0) & (zw <= self.wall_h) & (np.abs(other) <= half_w)
             tw = np.where(ok, tw, np.inf)
             closer = tw < best_t
             best_t = np.where(closer, tw, best_t)
             img_hit[closer] = k + 1
             walls.append((axis, sign))
-        for which in range(0, 5):
+        if self.style == "street":               # ceiling z = wall_h, paved like the ground (shifted)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tc = np.where(d[:, 2] > 1e-6, (self.wall_h - c[2]) / d[:, 2], np.inf)
+            closer = tc < best_t
+            best_t = np.where(closer, tc, best_t)
+            img_hit[closer] = 5
+        for which in range(0, 6):
             hit = img_hit == which
             if not hit.any():
                 continue
             dist = best_t[hit]
             p = c + dist[:, None] * d[hit]
-            if which == 0:
+            if which == 0 or which == 5:
                 mips = self.ground
-                u, v = p[:, 0] / self.TEXEL, p[:, 1] / self.TEXEL
+                off = 0.0 if which == 0 else 777.0
+                u, v = p[:, 0] / self.TEXEL + off, p[:, 1] / self.TEXEL + 2 * off
                 cosi = np.abs(d[hit, 2])
             else:
                 axis, sign = walls[which - 1]
                 mips = self.wall
-                along = (p[:, 1] - RADIUS) if axis == 0 else p[:, 0]
-                u, v = (along + 2.0 * WALL_R * which) / self.TEXEL, p[:, 2] / self.TEXEL
+                along = (p[:, 1] - (0.0 if self.style == "street" else RADIUS)) if axis == 0 else p[:, 0]
+                u, v = (along + 2.0 * self.wall_r * which) / self.TEXEL, p[:, 2] / self.TEXEL
                 cosi = np.abs(d[hit, axis])
             foot = dist / self.f / np.maximum(cosi, 0.15)
             level = np.log2(np.maximum(foot / self.TEXEL, 1.0))
@@ -320,43 +397,79 @@ init:
 
 
 # ----------------------------------------------------------------------------------------------------------------- dataset
-def make_dataset(out_dir, seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, render=True, log=None, rest=0.0):
-    global REST
+def simulate(seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, rest=0.0, style="room"):
+    """The sensor streams of the synthetic drive, in memory: imu (t, wm, am), wheel (t, m1, m2), cam_times, gt (t, p, q)."""
+    global REST, PATH
     REST = float(rest)
+    PATH = "street" if style == "street" else "circle"
     rng = np.random.default_rng(seed)
-    os.makedirs(os.path.join(out_dir, "cam0", "data"), exist_ok=True)
     t, wm, am = synth.imu_stream(imu_pose, 0.0, seconds + 0.1, rate=imu_hz, bg=BG, ba=BA)
     wm = wm + rng.normal(0, SIG["gyro_noise"] * np.sqrt(imu_hz), wm.shape)
     am = am + rng.normal(0, SIG["accel_noise"] * np.sqrt(imu_hz), am.shape)
+    tw = 0.0031 + np.arange(int((seconds + 0.1) * wheel_hz)) / wheel_hz
+    m = np.zeros((len(tw), 2))
+    for i, x in enumerate(tw):
+        v, w = twist(x)
+        m[i] = (v - w * BASE / 2) / RL + rng.normal(0, 0.02), (v + w * BASE / 2) / RR + rng.normal(0, 0.02)
+    tc = 0.05 + np.arange(int(seconds * cam_hz)) / cam_hz
+    gt = []
+    for x in t[::2]:
+        R, p = imu_pose(x)
+        gt.append(np.concatenate([[x], p, rot_2_quat(R)]))
+    return dict(imu=(t, wm, am), wheel=(tw, m[:, 0], m[:, 1]), cam_times=tc, gt=np.array(gt), style=style)
+
+
+_POOL_RD = None
+
+
+def _render_one(x):
+    return _POOL_RD.render(x)
+
+
+def render_frames(times, style="room", workers=1, seed=7):
+    """The camera images at `times`; workers > 1 renders in forked processes (call before anything initialises the GPU)."""
+    global _POOL_RD, PATH
+    PATH = "street" if style == "street" else "circle"
+    _POOL_RD = Renderer(seed=seed, style=style)
+    if workers <= 1 or len(times) < 4:
+        return [_POOL_RD.render(x) for x in times]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, len(times))) as pool:
+        return pool.map(_render_one, list(times), chunksize=1)
+
+
+def make_dataset(out_dir, seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, render=True, log=None, rest=0.0, style="room",
+                 workers=1):
+    sim = simulate(seconds, cam_hz, imu_hz, wheel_hz, seed, rest, style)
+    os.makedirs(os.path.join(out_dir, "cam0", "data"), exist_ok=True)
+    t, wm, am = sim["imu"]
     with open(os.path.join(out_dir, "imu.csv"), "w") as f:
         f.write("# t wx wy wz ax ay az\n")
         for i in range(len(t)):
             f.write(f"{t[i]:.9f},{wm[i, 0]:.12g},{wm[i, 1]:.12g},{wm[i, 2]:.12g},{am[i, 0]:.12g},{am[i, 1]:.12g},{am[i, 2]:.12g}\n")
-    tw = 0.0031 + np.arange(int((seconds + 0.1) * wheel_hz)) / wheel_hz
+    tw, m1, m2 = sim["wheel"]
     with open(os.path.join(out_dir, "wheel.csv"), "w") as f:
         f.write("# t left right (wheel angular velocities, rad/s)\n")
-        for x in tw:
-            v = arc(x)[1]
-            w = v / RADIUS
-            m1, m2 = (v - w * BASE / 2) / RL + rng.normal(0, 0.02), (v + w * BASE / 2) / RR + rng.normal(0, 0.02)
-            f.write(f"{x:.9f},{m1:.12g},{m2:.12g}\n")
-    tc = 0.05 + np.arange(int(seconds * cam_hz)) / cam_hz
-    rd = Renderer() if render else None
+        for i in range(len(tw)):
+            f.write(f"{tw[i]:.9f},{m1[i]:.12g},{m2[i]:.12g}\n")
+    tc = sim["cam_times"]
+    imgs = None
+    if render and workers > 1:
+        imgs = render_frames(tc, style, workers)
+    rd = Renderer(style=style) if render and imgs is None else None
     with open(os.path.join(out_dir, "cam0", "data.csv"), "w") as f:
         f.write("# t file\n")
         for k, x in enumerate(tc):
             name = f"{k:06d}.pgm"
             f.write(f"{x:.9f},{name}\n")
-            if rd is not None:
-                write_pgm(os.path.join(out_dir, "cam0", "data", name), rd.render(x))
+            if render:
+                write_pgm(os.path.join(out_dir, "cam0", "data", name), imgs[k] if imgs is not None else rd.render(x))
             if log and k % 20 == 0:
                 log(f"rendered {k}/{len(tc)}")
     with open(os.path.join(out_dir, "gt.txt"), "w") as f:
         f.write("# timestamp(s) tx ty tz qx qy qz qw\n")
-        for x in t[::2]:
-            R, p = imu_pose(x)
-            q = rot_2_quat(R)
-            f.write(f"{x:.6f} {p[0]:.6f} {p[1]:.6f} {p[2]:.6f} {q[0]:.8f} {q[1]:.8f} {q[2]:.8f} {q[3]:.8f}\n")
+        for g in sim["gt"]:
+            f.write(f"{g[0]:.6f} {g[1]:.6f} {g[2]:.6f} {g[3]:.6f} {g[4]:.8f} {g[5]:.8f} {g[6]:.8f} {g[7]:.8f}\n")
     return dict(imu=(t, wm, am), cam_times=tc)
 
 

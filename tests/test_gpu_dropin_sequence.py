@@ -10,7 +10,7 @@ import vio_sequence as vs
 
 pytestmark = pytest.mark.gpu
 
-MAX_MSCKF, MAX_OBS = 30, 12
+MAX_MSCKF, MAX_OBS, CHI2_MULT = 30, 12, 1.0
 TRI = dict(max_cond=1e6, max_dist=60.0, max_baseline=1e3)
 
 
@@ -20,6 +20,7 @@ class MirrorUpdater:
     def __init__(self, pkg):
         self.pkg = pkg
         self.db = {}  # id -> [t list, uv list, uvn list]
+        self.used = {}  # point_used: id -> (p_FinG, newest observation time) of triangulated features (REF CamHelper.cpp:677,697)
         self.o, self.jo = oracle_lib.load(), oracle_lib.load_jac(pkg)
         self.q95 = synth.q95_table()
 
@@ -64,17 +65,22 @@ class MirrorUpdater:
             tr_all = pkg.Tracks(ptr, np.concatenate([k[0] for _, k in kept]), np.concatenate([k[1] for _, k in kept]),
                                 np.zeros((len(kept), 3)), obs_uvn=np.concatenate([k[2] for _, k in kept]))
             pf, ok, err = self.jo.triangulate_batch(st, tr_all, **TRI)
-            sel = []
+            sel, t_first = [], {}
             for q, (fid, k) in enumerate(kept):
                 if len(sel) >= MAX_MSCKF:
                     for x in zip(*k):
                         give(fid, *x)
                     continue
                 valid = sum(self._bounding(ct, t) for t in k[0])
-                if valid < 2 or not ok[q] or not (err[q] < 3.0) or valid > MAX_OBS:
+                if valid >= 2 and ok[q]:
+                    self.used[fid] = (pf[q].copy(), k[0][-1])
+                if valid < 2 or not ok[q] or not (err[q] < 3.0):
                     for x in zip(*k):
                         give(fid, *x)
                     continue
+                if valid > MAX_OBS:   # batch capacity: the newest MAX_OBS usable observations
+                    tv = sorted(t for t in k[0] if self._bounding(ct, t))
+                    t_first[q] = tv[valid - MAX_OBS]
                 sel.append(q)
             if sel:
                 tt, uvs, counts = [], [], []
@@ -85,6 +91,8 @@ class MirrorUpdater:
                         if not self._bounding(ct, t):
                             give(fid, t, uv, uvn)
                             continue
+                        if t < t_first.get(q, -1e300):
+                            continue
                         tt.append(t), uvs.append(uv)
                         c += 1
                     counts.append(c)
@@ -92,9 +100,9 @@ class MirrorUpdater:
                 tr = pkg.Tracks(sptr, np.array(tt), np.array(uvs, dtype=np.float32), pf[sel])
                 cols = self.jo.columns(st, tr)
                 rows, Hf, Hx, res = self.jo.build_jacobians(st, tr, cols, 2 * MAX_OBS)
-                rc, P2, dx, acc, _ = self.o.msckf_update(P, rows, Hf, Hx, res, cols, sigma_pix ** 2, self.q95)
+                rc, P2, dx, acc, _ = self.o.msckf_update(P, rows, Hf, Hx, res, cols, sigma_pix ** 2, self.q95, chi2_mult=CHI2_MULT)
                 assert rc == 0
-                out.update(ids=[kept[q][0] for q in sel], accepted=list(acc), dx=dx, P=P2)
+                out.update(ids=[kept[q][0] for q in sel], accepted=list(acc), dx=dx, P=P2, p_FinG=pf[sel])
                 for q, a in zip(sel, acc):
                     if not a:
                         fid, k = kept[q]
