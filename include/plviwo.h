@@ -177,6 +177,10 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
  * dimension, gate parameters, buffer addresses) runs eagerly, the second is captured, later ones are one hipGraphLaunch.
  * Any change of shape or any device (re)allocation retires the graph.  Off by default.  captures / replays (nullable) count. */
 int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
+/* Process-wide activity counters since load (measurement aid, no reference counterpart): out[0] kernel launches, [1] host
+ * synchronisations (stream / event waits), [2] asynchronous copies, [3] bytes copied, [4] LK iterations over all points and levels
+ * (plv_perform_matching), [5] line segments the detector returned inside plv_line_tracker_feed*. */
+void plv_counters(unsigned long long *out6);
 int plv_cov_checkpoint(plv_ctx *ctx);
 int plv_cov_rollback(plv_ctx *ctx);
 

@@ -601,6 +601,15 @@ class LineTracks:
         self.c = v
 
 
+def counters():
+    """plv_counters: dict(launches, syncs, copies, copy_bytes, lk_iters, lines_detected) since the library was loaded"""
+    lib = load_library()
+    out = (C.c_ulonglong * 6)()
+    lib.plv_counters.restype = None
+    lib.plv_counters(out)
+    return dict(zip(("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected"), [int(x) for x in out]))
+
+
 def default_config(width=752, height=480):
     lib = load_library()
     cfg = PlvConfig()

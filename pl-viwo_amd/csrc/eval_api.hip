@@ -464,8 +464,8 @@ static int device_align(plv_ctx *ctx, int method, int n, const double *d_est, co
     ProfScope ps(ctx->prof, "traj_mean_kernel", ctx->stream);
     hipLaunchKernelGGL(traj_mean_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, d_est, d_gt, d_part);
   }
-  PLV_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, (size_t)blocks * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(part.data(), d_part, (size_t)blocks * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   Means mu{};
   for (int b = 0; b < blocks; ++b)
     for (int c = 0; c < 3; ++c) {
@@ -480,8 +480,8 @@ static int device_align(plv_ctx *ctx, int method, int n, const double *d_est, co
     ProfScope ps(ctx->prof, "traj_corr_kernel", ctx->stream);
     hipLaunchKernelGGL(traj_corr_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, d_est, d_gt, mu, d_part);
   }
-  PLV_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, (size_t)blocks * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(part.data(), d_part, (size_t)blocks * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   double C[9] = {0}, sigma2 = 0;
   for (int b = 0; b < blocks; ++b) {
     for (int c = 0; c < 9; ++c) C[c] += part[10 * (size_t)b + c];
@@ -516,8 +516,8 @@ int plv_traj_ate(plv_ctx *ctx, int method, int n, const double *est_poses, const
   TRY(us->eval.reserve(bytes * 3 + (size_t)n * 2 * sizeof(double)));
   double *d_est = us->eval.as<double>(), *d_gt = d_est + (size_t)n * 7, *d_al = d_gt + (size_t)n * 7, *d_oe = d_al + (size_t)n * 7,
          *d_pe = d_oe + n;
-  PLV_HIP_CHECK(hipMemcpyAsync(d_est, est_poses, bytes, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(d_gt, gt_poses, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d_est, est_poses, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d_gt, gt_poses, bytes, hipMemcpyHostToDevice, ctx->stream));
   Align A{};
   TRY(device_align(ctx, method, n, d_est, d_gt, est_poses, gt_poses, n_aligned, A.R, A.t, &A.s));
   double q[4];
@@ -529,10 +529,10 @@ int plv_traj_ate(plv_ctx *ctx, int method, int n, const double *est_poses, const
   }
   PLV_HIP_CHECK(hipGetLastError());
   std::vector<double> oe(n), pe(n);
-  PLV_HIP_CHECK(hipMemcpyAsync(oe.data(), d_oe, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(pe.data(), d_pe, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (aligned) PLV_HIP_CHECK(hipMemcpyAsync(aligned, d_al, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(oe.data(), d_oe, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(pe.data(), d_pe, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (aligned) PLV_HIP_CHECK(plv::memcpy_async(aligned, d_al, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   if (R_out) std::copy(A.R, A.R + 9, R_out);
   if (t_out) std::copy(A.t, A.t + 3, t_out);

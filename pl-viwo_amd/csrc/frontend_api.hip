@@ -85,7 +85,7 @@ int ensure_pyramids(plv_ctx *ctx, FrontState *s) {
 }
 
 int sync(plv_ctx *ctx) {
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -102,7 +102,7 @@ int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
       s->fed++;
       return PLV_OK;
     case PLV_HIST_NONE:
-      PLV_HIP_CHECK(hipMemcpyAsync(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
+      PLV_HIP_CHECK(plv::memcpy_async(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
       break;
     case PLV_HIST_CLAHE:  // REF: TrackKLT.cpp:60-64 — clip 10.0, 8x8 tiles
       TRY(s->clahe_lut.reserve(64 * 256));
@@ -249,7 +249,7 @@ int plv_pyramid_download(plv_ctx *ctx, int which, int level, int *w, int *h, uin
   if (w) *w = p.w[level];
   if (h) *h = p.h[level];
   if (out) {
-    PLV_HIP_CHECK(hipMemcpyAsync(out, p.base + p.off[level], (size_t)p.w[level] * p.h[level], hipMemcpyDeviceToHost,
+    PLV_HIP_CHECK(plv::memcpy_async(out, p.base + p.off[level], (size_t)p.w[level] * p.h[level], hipMemcpyDeviceToHost,
                                  ctx->stream));
     return sync(ctx);
   }
@@ -287,13 +287,13 @@ int plv_lk_track(plv_ctx *ctx, int n, const float *pts0, float *pts1, uint8_t *s
   FrontState *s = fe(ctx);
   TRY(need_two(ctx, s, "plv_lk_track"));
   TRY(reserve_points(s, n, 1));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, pts0, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->pts1.p, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->pts0.p, pts0, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->pts1.p, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, s->pts0.as<float>(), s->pts1.as<float>(),
                 s->status.as<uint8_t>(), s->iters.as<int>(), ctx->cfg.win_size, ctx->cfg.lk_max_iters, ctx->cfg.lk_eps));
-  PLV_HIP_CHECK(hipMemcpyAsync(pts1, s->pts1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(status, s->status.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (iters) PLV_HIP_CHECK(hipMemcpyAsync(iters, s->iters.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(pts1, s->pts1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(status, s->status.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (iters) PLV_HIP_CHECK(plv::memcpy_async(iters, s->iters.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   return sync(ctx);
 }
 
@@ -309,9 +309,9 @@ int plv_undistort(plv_ctx *ctx, int n, const float *uv, float *xy) {
   (void)hipSetDevice(ctx->device);
   FrontState *s = fe(ctx);
   TRY(reserve_points(s, n, 1));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->pts0.p, uv, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->pts0.p, uv, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_undistort(ctx, cam_of(ctx), n, s->pts0.as<float>(), s->n0.as<float>()));
-  PLV_HIP_CHECK(hipMemcpyAsync(xy, s->n0.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(xy, s->n0.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   return sync(ctx);
 }
 
@@ -325,13 +325,13 @@ int plv_ransac_fundamental(plv_ctx *ctx, int n, const float *m1, const float *m2
   FrontState *s = fe(ctx);
   const int mi = std::max(1, ctx->cfg.ransac_max_iters);
   TRY(reserve_points(s, n, mi));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->n0.p, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(s->n1.p, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->n0.p, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->n1.p, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_ransac(ctx, s->n0.as<float>(), s->n1.as<float>(), n, thr, ctx->cfg.ransac_conf, mi, seed, s->counts.as<int>(),
                     nullptr, s->mask.as<uint8_t>(), s->info.as<int>(), s->models.as<double>()));
   int info[2] = {0, 0};
-  PLV_HIP_CHECK(hipMemcpyAsync(mask, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(info, s->info.p, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(mask, s->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(info, s->info.p, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
   TRY(sync(ctx));
   if (n_inliers) *n_inliers = info[0];
   if (iters_used) *iters_used = info[1];
@@ -363,7 +363,7 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   char *dp_ = s->io.as<char>();
   memcpy(hp + o_p0, pts0, nn * 8);
   memcpy(hp + o_p1, pts1_init, nn * 8);
-  PLV_HIP_CHECK(hipMemcpyAsync(dp_, hp, nn * 16, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dp_, hp, nn * 16, hipMemcpyHostToDevice, ctx->stream));
   float *d_p0 = (float *)(dp_ + o_p0), *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
   int *d_it = (int *)(dp_ + o_it);
   uint8_t *d_mk = (uint8_t *)(dp_ + o_mk), *d_st = (uint8_t *)(dp_ + o_st);
@@ -373,7 +373,7 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
                     d_mk, s->info.as<int>(), s->models.as<double>()));
-  PLV_HIP_CHECK(hipMemcpyAsync(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   s->pending_n = n;
   s->pending_ran = true;
   return PLV_OK;
@@ -404,12 +404,11 @@ int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, floa
   if (n0) memcpy(n0, hp + o_n0, nn * 8);
   if (n1) memcpy(n1, hp + o_n1, nn * 8);
   memcpy(mask_out, hp + o_mk, nn);
-  if (lk_iters) {
-    long long t = 0;
-    const int *it = (const int *)(hp + o_it);
-    for (int i = 0; i < n; ++i) t += it[i];
-    *lk_iters = t;
-  }
+  long long t = 0;
+  const int *it = (const int *)(hp + o_it);
+  for (int i = 0; i < n; ++i) t += it[i];
+  plv::counters().lk_iters += (unsigned long long)t;
+  if (lk_iters) *lk_iters = t;
   return PLV_OK;
 }
 
@@ -507,11 +506,11 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
   char *hp = s->det_pin.as<char>();
   memcpy(hp + o_cells, cells.data(), cells.size() * 4);
   if (!boxes.empty()) memcpy(hp + o_boxes, boxes.data(), boxes.size() * 4);
-  PLV_HIP_CHECK(hipMemcpyAsync(s->det_in.p, hp, in_total, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(s->det_in.p, hp, in_total, hipMemcpyHostToDevice, ctx->stream));
   const uint8_t *d_mask = nullptr;
   if (mask) {
     TRY(s->det_mask.reserve((size_t)w * h));
-    PLV_HIP_CHECK(hipMemcpyAsync(s->det_mask.p, mask, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(s->det_mask.p, mask, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     d_mask = s->det_mask.as<uint8_t>();
   }
   if (!s->subpix_tab.p) {  // cv::cornerSubPix window weights exp(-(x/5)^2) exp(-(y/5)^2)
@@ -546,7 +545,7 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
   P.out_valid = (uint8_t *)(s->det_out.as<char>() + o_valid);
   TRY(launch_fast_cells(ctx, P, n_cells));
   TRY(launch_subpix(ctx, P.img, w, h, n_slots, P.out_valid, P.out_xy, s->subpix_tab.as<float>(), 5, 20, 0.001));
-  PLV_HIP_CHECK(hipMemcpyAsync(hp, s->det_out.p, out_total, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(hp, s->det_out.p, out_total, hipMemcpyDeviceToHost, ctx->stream));
   TRY(sync(ctx));
   const float *oxy = (const float *)(hp + o_xy);
   const uint8_t *oval = (const uint8_t *)(hp + o_valid);

@@ -108,7 +108,7 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
     memcpy(h + o_rR, tr->res_R, 72 * nobs);
     memcpy(h + o_rp, tr->res_p, 24 * nobs);
   }
-  PLV_HIP_CHECK(hipMemcpyAsync(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = us->jin.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
@@ -241,11 +241,11 @@ int plv_build_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_tracks
   const int F = tr->n_feat;
   const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
   const double *d = us->bHf.as<double>();
-  PLV_HIP_CHECK(hipMemcpyAsync(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(rows, us->brows.p, (size_t)F * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(rows, us->brows.p, (size_t)F * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -273,13 +273,13 @@ int plv_triangulate(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr
                o_err = o_p + (size_t)F * 24, o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
   TRY(us->tri.reserve(total));
   char *d = us->tri.as<char>();
-  PLV_HIP_CHECK(hipMemcpyAsync(d + o_uvn, tr->obs_uvn, (size_t)nobs * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d + o_uvn, tr->obs_uvn, (size_t)nobs * 8, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_triangulate(ctx, P, (double *)(d + o_pose), (unsigned char *)(d + o_valid), (const float *)(d + o_uvn), *opt,
                          (double *)(d + o_p), (unsigned char *)(d + o_ok), (double *)(d + o_err)));
-  PLV_HIP_CHECK(hipMemcpyAsync(p_FinG, d + o_p, (size_t)F * 24, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ok, d + o_ok, (size_t)F, hipMemcpyDeviceToHost, ctx->stream));
-  if (reproj_err) PLV_HIP_CHECK(hipMemcpyAsync(reproj_err, d + o_err, (size_t)F * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(p_FinG, d + o_p, (size_t)F * 24, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ok, d + o_ok, (size_t)F, hipMemcpyDeviceToHost, ctx->stream));
+  if (reproj_err) PLV_HIP_CHECK(plv::memcpy_async(reproj_err, d + o_err, (size_t)F * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -357,7 +357,7 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
     memcpy(h + o_rR, lt->res_R, 72 * nobs);
     memcpy(h + o_rp, lt->res_p, 24 * nobs);
   }
-  PLV_HIP_CHECK(hipMemcpyAsync(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = us->jin.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
@@ -408,7 +408,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P));
   us->b_projected = false;
   us->b_gather_token = 0;
-  PLV_HIP_CHECK(hipMemcpyAsync(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;
@@ -472,11 +472,11 @@ int plv_build_line_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_l
   const int L = lt->n_lines;
   const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
   const double *d = us->bHf.as<double>();
-  PLV_HIP_CHECK(hipMemcpyAsync(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(rows, us->brows.p, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(Hf, d, nHf * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(Hx, d + nHf, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(res, d + nHf + nHx, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(rows, us->brows.p, (size_t)L * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -497,9 +497,9 @@ int plv_triangulate_lines(plv_ctx *ctx, const plv_state_view *st, const plv_line
   char *d = us->tri.as<char>();
   TRY(launch_triangulate_lines(ctx, P, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
                                (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
-  PLV_HIP_CHECK(hipMemcpyAsync(line_FinG, d + o_lines, (size_t)L * 48, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ok, d + o_ok, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(line_FinG, d + o_lines, (size_t)L * 48, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ok, d + o_ok, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -530,7 +530,7 @@ int plv_cpi_poses(plv_ctx *ctx, const plv_state_view *st, const plv_cpi_table *c
   put(st->clone_time, nc), put(st->clone_R, 9 * nc), put(st->clone_p, 3 * nc), put(t_q, nq);
   TRY(us->tri.reserve((in_d + out_d) * sizeof(double) + nq + 16));
   double *d = us->tri.as<double>();
-  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d, h.data(), in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   CpiParams C{};
   C.n = cpi->n, C.n_clones = st->n_clones, C.n_q = n_q;
   C.t = d, C.clone_t = d + n, C.dt = d + 2 * n, C.R = d + 3 * n, C.alpha = d + 12 * n, C.v = d + 15 * n;
@@ -540,10 +540,10 @@ int plv_cpi_poses(plv_ctx *ctx, const plv_state_view *st, const plv_cpi_table *c
   unsigned char *d_ok = (unsigned char *)(d_p + 3 * nq);
   std::copy(cpi->gravity, cpi->gravity + 3, C.gravity);
   TRY(launch_cpi_poses(ctx, C, d_tq, d_R, d_p, d_ok));
-  PLV_HIP_CHECK(hipMemcpyAsync(R_GtoI, d_R, 9 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(p_IinG, d_p, 3 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ok, d_ok, nq, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(R_GtoI, d_R, 9 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(p_IinG, d_p, 3 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ok, d_ok, nq, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   for (size_t q = 0; q < nq; ++q)
     if (!ok[q]) {

@@ -197,10 +197,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     if (prelaunched) {  // plv_line_detect_launch put the kernels and the two copies on the stream: wait for those only
-      PLV_HIP_CHECK(hipEventSynchronize(T->edges_ready));
+      PLV_HIP_CHECK(plv::event_sync(T->edges_ready));
     } else {
-      PLV_HIP_CHECK(hipMemcpyAsync(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-      PLV_HIP_CHECK(hipMemcpyAsync(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+      PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+      PLV_HIP_CHECK(plv::memcpy_async(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
       if (launch_only) {
         if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
         PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
@@ -208,7 +208,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
         T->pending_fed = plv_front_fed_count(ctx);
         return PLV_OK;
       }
-      PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
     }
     auto T1 = std::chrono::steady_clock::now();
     FldChain *hc = (FldChain *)(hp + 16);
@@ -239,8 +239,8 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   TRY(launch_line_walk(ctx, w, h, fp, b));
   TRY(launch_line_fit(ctx, w, h, fp, b));
   // download: counts, chain table, per-chain segment counts, segment slots
-  PLV_HIP_CHECK(hipMemcpyAsync(hp, T->counts.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(hp, T->counts.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   const int n_chain = ((int *)hp)[0], n_slot = ((int *)hp)[1];
   if (n_chain >= kChainCap) {
     set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
@@ -250,10 +250,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     FldChain *hc = (FldChain *)(hp + 16);
     int *hn = (int *)(hp + 16 + kChainCap * sizeof(FldChain));
     float4 *hs = (float4 *)(hp + bytes);
-    PLV_HIP_CHECK(hipMemcpyAsync(hc, T->chains.p, n_chain * sizeof(FldChain), hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(hipMemcpyAsync(hn, T->seg_count.p, n_chain * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(hipMemcpyAsync(hs, T->segs.p, (size_t)n_slot * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(hc, T->chains.p, n_chain * sizeof(FldChain), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(hn, T->seg_count.p, n_chain * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(hs, T->segs.p, (size_t)n_slot * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
     for (int c = 0; c < n_chain; ++c)  // chains are in raster order of their seeds = the detector's output order
       for (int q = 0; q < hn[c]; ++q) emit(hs[hc[c].slot + q]);
   }
@@ -467,6 +467,7 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
     TRY(detect(ctx, T, PLV_PYR_CUR, lines));
   }
   const int nl = (int)lines.size() / 4;
+  plv::counters().lines_detected += (unsigned long long)nl;
   std::vector<uint64_t> ids(nl);
   for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236
   Assign A;

@@ -25,15 +25,15 @@ double chi2_quantile(int dof, double p);
 static const int Q95_N = 1024;
 
 static int h2d(plv_ctx *ctx, void *dst, const void *src, size_t bytes) {
-  PLV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return PLV_OK;
 }
 static int d2h(plv_ctx *ctx, void *dst, const void *src, size_t bytes) {
-  PLV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   return PLV_OK;
 }
 static int sync(plv_ctx *ctx) {
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -194,7 +194,7 @@ void plv_line_tracker_destroy(plv_ctx *ctx);  // line_api.hip
 void plv_ctx_destroy(plv_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)plv::stream_sync(ctx->stream);
   plv_tracker_destroy(ctx);
   plv_line_tracker_destroy(ctx);
   plv_frontend_destroy(ctx);
@@ -284,13 +284,17 @@ int plv_cov_download(plv_ctx *ctx, double *P, int n, int ldp) {
   TRY(download_mat(ctx, P, ctx->d_P.as<double>(), n, n, ldp));
   return sync(ctx);
 }
+void plv_counters(unsigned long long *out) {
+  plv::Counters &c = plv::counters();
+  out[0] = c.launches, out[1] = c.syncs, out[2] = c.copies, out[3] = c.copy_bytes, out[4] = c.lk_iters, out[5] = c.lines_detected;
+}
 int plv_cov_checkpoint(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   if (ctx->cov_n < 1) return PLV_E_BADARG;
   size_t bytes = (size_t)ctx->cov_n * ctx->cov_n * 8;
   TRY(us->covck.reserve(bytes));
-  PLV_HIP_CHECK(hipMemcpyAsync(us->covck.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(us->covck.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   us->covck_n = ctx->cov_n;
   return sync(ctx);
 }
@@ -306,7 +310,7 @@ int plv_cov_rollback(plv_ctx *ctx) {
   // buffer of another size)
   size_t bytes = (size_t)us->covck_n * us->covck_n * 8;
   TRY(ctx->d_P.reserve(bytes));
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, us->covck.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ctx->d_P.p, us->covck.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   ctx->cov_n = us->covck_n;
   ++ctx->gather_stamp;
   return PLV_OK;  // ordered on the ctx stream; no host sync needed
@@ -358,7 +362,7 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
     // A rejection anywhere rejects everything: the covariance is restored and dx left untouched, as EKFUpdate would.
     const size_t bytes = (size_t)n * n * 8;
     TRY(ctx->d_P2.reserve(bytes));
-    PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P2.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(ctx->d_P2.p, ctx->d_P.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     std::vector<double> dx_tot(n, 0.0), dx_b(n), res_b;
     int rc = PLV_OK;
     for (int r0 = 0; r0 < r && rc == PLV_OK; r0 += EKF_MAX_ROWS) {
@@ -374,7 +378,7 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
         for (int i = 0; i < n; ++i) dx_tot[i] += dx_b[i];
     }
     if (rc != PLV_OK) {
-      PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_P.p, ctx->d_P2.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      PLV_HIP_CHECK(plv::memcpy_async(ctx->d_P.p, ctx->d_P2.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
       TRY(sync(ctx));
       return rc;
     }
@@ -589,7 +593,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   } else {
     // working copy (the nullspace projection is in place): one D2D
     TRY(us->bwork.reserve((nHf + nHx + nr) * 8));
-    PLV_HIP_CHECK(hipMemcpyAsync(us->bwork.p, us->bHf.p, (nHf + nHx + nr) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(us->bwork.p, us->bHf.p, (nHf + nHx + nr) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     wHf = us->bwork.as<double>();
   }
   double *wHx = wHf + nHf, *wres = wHx + nHx;

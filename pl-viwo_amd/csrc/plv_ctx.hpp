@@ -26,6 +26,28 @@ void set_last_error(const char *fmt, ...);
     }                                                                                    \
   } while (0)
 
+// Process-wide activity counters (plv_counters): what a frame costs in submissions, read by bench.py around the timed steps.
+struct Counters {
+  std::atomic<unsigned long long> launches{0}, syncs{0}, copies{0}, copy_bytes{0}, lk_iters{0}, lines_detected{0};
+};
+inline Counters &counters() {
+  static Counters c;
+  return c;
+}
+inline hipError_t stream_sync(hipStream_t s) {
+  ++counters().syncs;
+  return hipStreamSynchronize(s);
+}
+inline hipError_t event_sync(hipEvent_t e) {
+  ++counters().syncs;
+  return hipEventSynchronize(e);
+}
+inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+  ++counters().copies;
+  counters().copy_bytes += bytes;
+  return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+
 // A grow-only device buffer.
 // Bumped by every device (re)allocation: a captured graph holds raw device pointers, so any growth anywhere retires it.
 inline std::atomic<unsigned long long> &alloc_epoch() {  // contexts may live on different threads
@@ -170,7 +192,10 @@ struct Profiler {
 struct ProfScope {
   Profiler &p;
   hipStream_t s;
-  ProfScope(Profiler &p_, const char *name, hipStream_t s_) : p(p_), s(s_) { p.begin(name, s); }
+  ProfScope(Profiler &p_, const char *name, hipStream_t s_) : p(p_), s(s_) {
+    ++counters().launches;
+    p.begin(name, s);
+  }
   ~ProfScope() { p.end(s); }
 };
 

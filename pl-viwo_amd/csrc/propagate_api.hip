@@ -499,7 +499,7 @@ int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *nz, int
   std::copy(am, am + 3 * nd, h.begin() + 4 * nd);
   std::memcpy(h.data() + o_imu, imu, sizeof(*imu));
   if (acc) std::memcpy(h.data() + o_cpi, acc, sizeof(*acc));
-  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), o_phi * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d, h.data(), o_phi * 8, hipMemcpyHostToDevice, ctx->stream));
   PropArgs A{};
   A.n_data = n_data;
   A.t = d, A.wm = d + nd, A.am = d + 4 * nd;
@@ -528,8 +528,8 @@ int plv_propagate(plv_ctx *ctx, plv_imu_state *imu, const plv_imu_noise *nz, int
   }
   PLV_HIP_CHECK(hipGetLastError());
   std::vector<double> back(IMU_N + CA_N + 450 + nrec);
-  PLV_HIP_CHECK(hipMemcpyAsync(back.data(), d + o_imu, back.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(back.data(), d + o_imu, back.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   std::memcpy(imu, back.data(), sizeof(*imu));
   if (acc) std::memcpy(acc, back.data() + IMU_N, sizeof(*acc));
@@ -626,7 +626,7 @@ int plv_cpi_integrate(plv_ctx *ctx, const plv_imu_noise *nz, double t_given, dou
   std::copy(sa_.begin(), sa_.begin() + 3 * nd, h.begin() + 4 * nd);
   h[o_imu + IQ + 3] = 1.0;  // the IMU image is not used in this mode
   std::memcpy(h.data() + o_cpi, &acc, sizeof(acc));
-  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), o_phi * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d, h.data(), o_phi * 8, hipMemcpyHostToDevice, ctx->stream));
   PropArgs A{};
   A.n_data = m;
   A.t = d, A.wm = d + nd, A.am = d + 4 * nd;
@@ -644,8 +644,8 @@ int plv_cpi_integrate(plv_ctx *ctx, const plv_imu_noise *nz, double t_given, dou
     hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, ctx->stream, A);
   }
   PLV_HIP_CHECK(hipGetLastError());
-  PLV_HIP_CHECK(hipMemcpyAsync(out, d + o_rec, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(out, d + o_rec, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   *ok = 1;
   return PLV_OK;
@@ -663,7 +663,7 @@ int plv_cov_clone(plv_ctx *ctx, int n, int src_id, int size) {
                        size, ctx->d_P2.as<double>());
   }
   PLV_HIP_CHECK(hipGetLastError());
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   std::swap(ctx->d_P, ctx->d_P2);
   ctx->cov_n = m;

@@ -164,7 +164,7 @@ int plv_cov_marginalize(plv_ctx *ctx, int id, int size) {
   hipLaunchKernelGGL(cov_marginalize_kernel, dim3(std::min(64, (m * m + 255) / 256)), dim3(256), 0, ctx->stream,
                      ctx->d_P.as<double>(), n, id, size, ctx->d_P2.as<double>());
   PLV_HIP_CHECK(hipGetLastError());
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   std::swap(ctx->d_P, ctx->d_P2);
   ctx->cov_n = m;
   ++ctx->gather_stamp;
@@ -204,16 +204,16 @@ int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf,
   TRY(ctx->d_frows.reserve(4));
   TRY(ctx->d_cols.reserve((size_t)k * 4));
   double *dHf = ctx->d_fHf.as<double>(), *dHx = dHf + nHf, *dres = dHx + nHx;
-  PLV_HIP_CHECK(hipMemcpyAsync(dHf, Hf, nHf * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(dHx, Hx, nHx * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(dres, res, (size_t)ld * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_frows.p, &rows, 4, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_cols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dHf, Hf, nHf * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dHx, Hx, nHx * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dres, res, (size_t)ld * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ctx->d_frows.p, &rows, 4, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ctx->d_cols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
   TRY(launch_nullspace(ctx, 1, f, k, ld, ctx->d_frows.as<int>(), dHf, dHx, dres, nullptr, 0, 0, nullptr, /*shift*/ 0));
   std::vector<double> hHx(nHx), hres(ld);
-  PLV_HIP_CHECK(hipMemcpyAsync(hHx.data(), dHx, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(hres.data(), dres, (size_t)ld * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(hHx.data(), dHx, nHx * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(hres.data(), dres, (size_t)ld * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   // ---- Mahalanobis gate on the updating rows; the threshold uses ALL rows (:409-424)
   const int mup = rows - f;
   if (mup > 0) {
@@ -227,18 +227,18 @@ int plv_slam_initialize(plv_ctx *ctx, int rows, int k, int ld, const double *Hf,
   TRY(ctx->d_dx.reserve(64));
   TRY(ctx->d_flag.reserve(16));
   // (plv_chi2_batch re-staged Hx from row f on: the rotated full system is still in dHf / dHx / dres)
-  PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_cols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(dHx, hHx.data(), nHx * 8, hipMemcpyHostToDevice, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(dres, hres.data(), (size_t)ld * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(ctx->d_cols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dHx, hHx.data(), nHx * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(dres, hres.data(), (size_t)ld * 8, hipMemcpyHostToDevice, ctx->stream));
   const size_t shm = (size_t)(3 * n + 32) * sizeof(double);
   hipLaunchKernelGGL(cov_init_invertible_kernel, dim3(1), dim3(256), shm, ctx->stream, ctx->d_P.as<double>(), n, ctx->d_cols.as<int>(),
                      k, dHx, dHf, dres, ld, ctx->d_P2.as<double>(), ctx->d_dx.as<double>(), ctx->d_flag.as<int>());
   PLV_HIP_CHECK(hipGetLastError());
   int flag = 1;
   double v[3];
-  PLV_HIP_CHECK(hipMemcpyAsync(&flag, ctx->d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipMemcpyAsync(v, ctx->d_dx.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(&flag, ctx->d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(v, ctx->d_dx.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   if (flag != 0) return PLV_OK;
   std::swap(ctx->d_P, ctx->d_P2);  // the old covariance stays intact in d_P2 until the update below succeeded
   ctx->cov_n = n2;

@@ -517,7 +517,7 @@ int wheel_system(plv_ctx *ctx, const plv_wheel_options *op, const plv_wheel_stat
   std::copy(t, t + nd, h.begin());
   std::copy(m1, m1 + nd, h.begin() + nd);
   std::copy(m2, m2 + nd, h.begin() + 2 * nd);
-  PLV_HIP_CHECK(hipMemcpyAsync(d, h.data(), 3 * nd * 8, hipMemcpyHostToDevice, ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(d, h.data(), 3 * nd * 8, hipMemcpyHostToDevice, ctx->stream));
   WheelArgs A{};
   A.op = *op;
   A.st = *st;
@@ -534,8 +534,8 @@ int wheel_system(plv_ctx *ctx, const plv_wheel_options *op, const plv_wheel_stat
   }
   PLV_HIP_CHECK(hipGetLastError());
   out.resize(n_out);
-  PLV_HIP_CHECK(hipMemcpyAsync(out.data(), A.out, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PLV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  PLV_HIP_CHECK(plv::memcpy_async(out.data(), A.out, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
   return PLV_OK;
 }

@@ -521,8 +521,9 @@ class SystemManager:
         return hzs[-1]
 
     # ---------------------------------------------------------------------------------------------- camera
-    def feed_measurement_camera(self, t, img, mask=None):
-        """UpdaterCamera::feed_measurement + try_update (REF: UpdaterCamera.cpp:77-195)."""
+    def feed_measurement_camera(self, t, img, mask=None, staged_slot=None):
+        """UpdaterCamera::feed_measurement + try_update (REF: UpdaterCamera.cpp:77-195).  staged_slot: the image already sits in that
+        HBM slot of the context (Context.image_stage); `img` is then not read."""
         e, st = self.op.est, self.state
         if not e.cam.enabled:
             return
@@ -532,7 +533,9 @@ class SystemManager:
             self.cam_t_hist.pop(0)
         self.cam_t_hist.append(float(t))
         self.tc.ding("[Time-Cam] feed measurement: points")      # labels of UpdaterCamera.cpp:79-190
-        if e.cam.downsample:
+        if staged_slot is not None and not e.cam.downsample:
+            self.ctx.tracker_feed_staged(t, staged_slot, mask)
+        elif e.cam.downsample:
             self.ctx.tracker_feed_downsampled(t, img, mask)
         else:
             self.ctx.tracker_feed(t, img, mask)

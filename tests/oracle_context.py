@@ -64,7 +64,7 @@ class OracleContext:
             self.prev = (eq, pyr)
             return
         pts_old, ids_old = self._detect(self.prev[0], self.pts, self.ids, mask)
-        rc, pts_new, ok, n0, n1 = self.fo.perform_matching(self.prev[1], pyr, pts_old, pts_old, self.K8)
+        rc, pts_new, ok, n0, n1 = self.fo.perform_matching(self.prev[1], pyr, pts_old, pts_old, self.K8, nthreads=getattr(self, "lk_threads", 1))
         h, w = img.shape
         good, gid = [], []
         for i in range(len(pts_old)):

@@ -18,6 +18,17 @@ import synth  # noqa: E402
 G = np.array([0.0, 0.0, 9.81])
 W, H = 752, 480
 K8 = synth.EUROC_K8.copy()
+
+
+def set_camera(width=752, height=480):
+    """Image size of the rendered camera (module-wide, like PATH / REST): 752x480 with the EuRoC intrinsics, or those intrinsics
+    scaled to another width (BASELINE configs[3]: 1280x720)."""
+    global W, H, K8
+    W, H = int(width), int(height)
+    K8 = synth.EUROC_K8.copy()
+    if (W, H) != (752, 480):
+        sx = W / 752.0
+        K8[:4] = K8[0] * sx, K8[1] * sx, W / 2.0 + 7.0, H / 2.0 + 8.5
 RADIUS, WALL_R, WALL_H = 8.0, 21.0, 9.0
 RL, RR, BASE = 0.31, 0.305, 1.52
 # IMU: mounted flat (z up), 0.9 m above the odometry frame, slightly yawed.  wheel_extrinsic = (R_ItoO, p_IinO)
@@ -253,7 +264,8 @@ def write_pgm(path, img):
 
 
 # ------------------------------------------------------------------------------------------------------------------ config
-def write_config(cfg_dir, dataset_dir, traj_path, use_wheel=True, use_lines=True, aligned=True):
+def write_config(cfg_dir, dataset_dir, traj_path, use_wheel=True, use_lines=True, aligned=True, clone_freq=10, n_pts=250, max_msckf=60,
+                 calib_int=False, sigma_px=1.0):
     os.makedirs(cfg_dir, exist_ok=True)
     T_ic = np.eye(4)
     T_ic[:3, :3], T_ic[:3, 3] = R_CTOI, P_CINI
@@ -279,11 +291,11 @@ sys:
   bag_start: 0
   bag_durr: -1
 ''',
-        "config_estimator.yaml": '''%YAML:1.0
+        "config_estimator.yaml": f'''%YAML:1.0
 
 est:
   gravity_mag: 9.81
-  clone_freq: 10
+  clone_freq: {clone_freq}
   window_size: 1.0
   intr_order: 3
   intr_error_mlt: 3
@@ -298,9 +310,11 @@ est:
 
 intr_ori:
   Hz_10: [0.00288, 0.00126, 0.00108, 0.00102, 0.00102]
+  Hz_15: [0.00138, 0.00066, 0.00063, 0.00069, 0.00087]
   Hz_20: [0.00084, 0.00012, 0.00006, 0.00003, 0.00003]
 intr_pos:
   Hz_10: [0.00312, 0.00087, 0.00072, 0.00066, 0.00066]
+  Hz_15: [0.00144, 0.00021, 0.00018, 0.00015, 0.00015]
   Hz_20: [0.00084, 0.00009, 0.00006, 0.00003, 0.00003]
 ''',
         "config_camera.yaml": f'''%YAML:1.0
@@ -310,9 +324,9 @@ cam:
   max_n: 1
   use_stereo: false
   do_calib_ext: false
-  do_calib_int: false
+  do_calib_int: {'true' if calib_int else 'false'}
   do_calib_dt: false
-  n_pts: 250
+  n_pts: {n_pts}
   fast: 20
   grid_x: 5
   grid_y: 5
@@ -321,7 +335,7 @@ cam:
   downsample: false
   histogram_method: "HISTOGRAM"
   max_slam: 0
-  max_msckf: 60
+  max_msckf: {max_msckf}
   feat_rep: "GLOBAL_3D"
   init_cov_dt: 1e-4
   init_cov_ex_o: 1e-4
@@ -329,7 +343,7 @@ cam:
   init_cov_in_k: 1e-2
   init_cov_in_c: 1e-1
   init_cov_in_r: 1e-6
-  sigma_px: 1.0
+  sigma_px: {sigma_px}
   chi2_mult: 1
   fi_max_dist: 80
   fi_max_baseline: 2000

@@ -7,7 +7,6 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
-python3 bench.py --sequential --no-cpu > "$OUT/bench_line_sequential.json" 2>> "$OUT/bench_stderr.log"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/stats" -o run -- python3 "$REPO/bench.py" --steps 200 --warmup 20 --no-cpu > "$REPO/$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/$OUT/pmc_fetch" -o run -- python3 "$REPO/bench.py" --steps 60 --warmup 10 --no-cpu > "$REPO/$OUT/pmc_fetch.log" 2>&1
@@ -18,4 +17,5 @@ find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" 
 python3 tools/pmc_summary.py "$OUT/pmc_hbm.csv" FETCH_SIZE="$OUT/pmc_fetch" WRITE_SIZE="$OUT/pmc_write" > /dev/null
 python3 tools/pmc_summary.py "$OUT/pmc_sq.csv" SQ_INSTS_VALU_MFMA_MOPS_F64+SQ_VALU_MFMA_BUSY_CYCLES+SQ_LDS_BANK_CONFLICT+SQ_BUSY_CYCLES="$OUT/pmc_sq" > /dev/null
 rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+rm -f "$OUT"/*.log
 ls -la "$OUT"
