@@ -4,11 +4,10 @@
 //                      REF: open_vins/ov_core/src/track/Grider_GRID.h:108-151
 //   subpix_kernel      cv::cornerSubPix(5x5 window, (-1,-1), 20 it | 1e-3)   REF: Grider_GRID.h:163-174
 //
-// One workgroup per grid cell: the cell ROI (e.g. 150 x 96 u8) and its score plane live in LDS,
-// FAST runs on the ROI exactly like the reference (3-px border of the ROI skipped, so corners next
-// to a cell edge are never found — reproduced).  The per-cell "sort by response, keep the first
-// num_features_grid" becomes k rounds of a workgroup arg-max on the key (score, raster order),
-// which also fixes the tie order that std::sort leaves unspecified.
+// FAST runs on every requested cell's ROI exactly like the reference (3-px border of the ROI skipped, so corners next
+// to a cell edge are never found — reproduced), as 32 x 32 tiles (fast_tiles_kernel); the per-cell "sort by response, keep
+// the first num_features_grid" is a rank count on the key (score, raster order) per cell (fast_topk_kernel), which also fixes
+// the tie order that std::sort leaves unspecified.
 #include "detect_kernels.hpp"
 #include "wave_ops.hpp"
 
@@ -41,86 +40,100 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *roi, int pitch, int
   return a <= thr ? 0 : a - 1;
 }
 
-__global__ void __launch_bounds__(256) fast_cells_kernel(DetectParams P) {
-  extern __shared__ unsigned char smem_u8[];
-  const int cell = blockIdx.x;
+// ---- K4, stage 1: scores + non-maximum suppression on 32 x 32 tiles of every requested cell (n_cells * tiles workgroups: the
+// chip is filled, where one workgroup per cell used 25 CUs).  The tile and a 4-pixel ring are staged in LDS (3 for the FAST circle,
+// 1 for the neighbours of the suppression); a cheap necessary test (a 9-arc of 16 contains one pixel of every antipodal pair) sends
+// ~5 % of the pixels to the full score through a compacted list, so that the lanes of a wave stay busy; local maxima go to the
+// cell's candidate list as keys (score << 32 | ~raster index): a larger key comes earlier in the reference's sorted order
+// (response descending, raster ascending) and keys are unique, so the order they arrive in does not matter.
+#define FAST_TILE 32
+__global__ void __launch_bounds__(256) fast_tiles_kernel(DetectParams P, int tiles_x, int tiles_y, unsigned long long *__restrict__ cand,
+                                                         int *__restrict__ cand_n) {
+  constexpr int RW = FAST_TILE + 8, SW = FAST_TILE + 2;
+  __shared__ uint8_t roi[RW * RW];
+  __shared__ short sc[SW * SW];
+  __shared__ short list[SW * SW];
+  __shared__ int nlist;
+  const int per_cell = tiles_x * tiles_y;
+  const int cell = blockIdx.x / per_cell, tile = blockIdx.x - cell * per_cell;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int cw = P.cell_w, chh = P.cell_h;
-  const int pitch = (cw + 3) & ~3;
-  uint8_t *roi = smem_u8;                                           // [chh][pitch]
-  short *sc = reinterpret_cast<short *>(smem_u8 + ((chh * pitch + 15) & ~15));  // [chh][cw]
-  unsigned long long *cand = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(sc) + (((size_t)chh * cw * 2 + 15) & ~(size_t)15));
-  __shared__ int ncand;
-  __shared__ unsigned long long red[4];
   const int x0 = P.cells[2 * cell] * cw, y0 = P.cells[2 * cell + 1] * chh;
+  const int lx0 = tx * FAST_TILE, ly0 = ty * FAST_TILE;
   const int t = threadIdx.x;
-  if (t == 0) ncand = 0;
-  for (int i = t; i < chh * cw; i += 256) {
-    const int y = i / cw, x = i - y * cw;
-    roi[y * pitch + x] = P.img[(size_t)(y0 + y) * P.W + x0 + x];
+  if (t == 0) nlist = 0;
+  for (int i = t; i < RW * RW; i += 256) {
+    const int ry = i / RW, rx = i - ry * RW;
+    const int lx = min(max(lx0 + rx - 4, 0), cw - 1), ly = min(max(ly0 + ry - 4, 0), chh - 1);
+    roi[i] = P.img[(size_t)(y0 + ly) * P.W + x0 + lx];
+  }
+  for (int i = t; i < SW * SW; i += 256) sc[i] = 0;
+  __syncthreads();
+  const int thr = P.threshold;
+  for (int i = t; i < SW * SW; i += 256) {
+    const int sy = i / SW, sx = i - sy * SW;
+    const int lx = lx0 + sx - 1, ly = ly0 + sy - 1;
+    if (lx < 3 || lx >= cw - 3 || ly < 3 || ly >= chh - 3) continue;  // FAST skips a 3-pixel border of the ROI it is given
+    const uint8_t *c = &roi[(sy + 3) * RW + sx + 3];
+    const int v = c[0];
+    const int d0 = v - c[3 * RW], d8 = v - c[-3 * RW], d4 = v - c[3], d12 = v - c[-3];
+    const bool dark = (d0 > thr || d8 > thr) && (d4 > thr || d12 > thr);
+    const bool bright = (-d0 > thr || -d8 > thr) && (-d4 > thr || -d12 > thr);
+    if (dark || bright) list[atomicAdd(&nlist, 1)] = (short)i;
   }
   __syncthreads();
-  for (int i = t; i < chh * cw; i += 256) {
-    const int y = i / cw, x = i - y * cw;
-    int s = 0;
-    if (x >= 3 && x < cw - 3 && y >= 3 && y < chh - 3) s = fast_score_lds(roi, pitch, x, y, P.threshold);
-    sc[i] = (short)s;
+  const int nl = nlist;
+  for (int j = t; j < nl; j += 256) {
+    const int i = list[j];
+    const int sy = i / SW, sx = i - sy * SW;
+    sc[i] = (short)fast_score_lds(roi, RW, sx + 3, sy + 3, thr);
   }
   __syncthreads();
-  // strict 3x3 non-max suppression -> candidate keys (score << 32 | ~raster index): larger key = earlier in the
-  // reference's sorted order (response desc, raster asc)
-  for (int i = t; i < chh * cw; i += 256) {
-    const int y = i / cw, x = i - y * cw;
-    const int s = sc[i];
+  for (int i = t; i < FAST_TILE * FAST_TILE; i += 256) {
+    const int yy = i / FAST_TILE, xx = i - yy * FAST_TILE;
+    const short *q = &sc[(yy + 1) * SW + xx + 1];
+    const int s = q[0];
     if (s == 0) continue;
-    bool mx = true;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
-        if ((dx || dy) && sc[(y + dy) * cw + x + dx] >= s) mx = false;
-    if (mx) {
-      const int slot = atomicAdd(&ncand, 1);
-      if (slot < P.cand_cap) cand[slot] = ((unsigned long long)(unsigned)s << 32) | (unsigned)(0x7fffffff - i);
-    }
+    // strict 3x3 non-max suppression
+    if (q[-SW - 1] >= s || q[-SW] >= s || q[-SW + 1] >= s || q[-1] >= s || q[1] >= s || q[SW - 1] >= s || q[SW] >= s || q[SW + 1] >= s) continue;
+    const int lx = lx0 + xx, ly = ly0 + yy;
+    const int slot = atomicAdd(&cand_n[cell], 1);
+    if (slot < P.cand_cap)
+      cand[(size_t)cell * P.cand_cap + slot] = ((unsigned long long)(unsigned)s << 32) | (unsigned)(0x7fffffff - (ly * cw + lx));
   }
+}
+
+// ---- K4, stage 2: the reference's "sort by response, keep the first num_features_grid" per cell.  Every candidate counts the
+// keys above its own: that is its position in the sorted order, the first nfg write their slot.  Then the bounds / mask /
+// occupied-box tests of Grider_GRID.h:141-147 and TrackKLT.cpp:455-461 per kept corner.
+__global__ void __launch_bounds__(256) fast_topk_kernel(DetectParams P, const unsigned long long *__restrict__ cand, int *__restrict__ cand_n) {
+  extern __shared__ unsigned long long keys[];
+  const int cell = blockIdx.x, t = threadIdx.x;
+  const int nc = min(cand_n[cell], P.cand_cap);
+  const int cw = P.cell_w, chh = P.cell_h;
+  const int x0 = P.cells[2 * cell] * cw, y0 = P.cells[2 * cell + 1] * chh;
+  for (int i = t; i < nc; i += 256) keys[i] = cand[(size_t)cell * P.cand_cap + i];
+  for (int r = nc + t; r < P.nfg; r += 256) P.out_valid[cell * P.nfg + r] = 0;
   __syncthreads();
-  const int nc = min(ncand, P.cand_cap);
-  // k rounds of arg-max
-  for (int r = 0; r < P.nfg; ++r) {
-    unsigned long long best = 0;
-    for (int i = t; i < nc; i += 256) best = max(best, cand[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffULL), off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
-      best = max(best, ((unsigned long long)hi << 32) | lo);
-    }
-    if ((t & 63) == 0) red[t >> 6] = best;
-    __syncthreads();
-    best = max(max(red[0], red[1]), max(red[2], red[3]));
-    const int slot = cell * P.nfg + r;
-    if (best == 0) {
-      if (t == 0) P.out_valid[slot] = 0;
-    } else {
-      for (int i = t; i < nc; i += 256)
-        if (cand[i] == best) cand[i] = 0;  // remove the winner (keys are unique)
-      if (t == 0) {
-        const int idx = 0x7fffffff - (int)(best & 0xffffffffULL);
-        const int y = idx / cw, x = idx - y * cw;
-        const float gx = (float)x + (float)x0, gy = (float)y + (float)y0;
-        // REF: Grider_GRID.h:141-147 bounds + mask (the mask already carries the +-min_px_dist boxes
-        // painted around the tracked points, TrackKLT.cpp:455-461: tested here against the point list)
-        bool ok = !((int)gx < 0 || (int)gx > P.W || (int)gy < 0 || (int)gy > P.H);
-        const int ix = (int)gx, iy = (int)gy;
-        if (ok && P.mask && P.mask[(size_t)iy * P.W + ix] > 127) ok = false;
-        for (int q = 0; ok && q < P.n_boxes; ++q)
-          if (abs(ix - P.boxes[2 * q]) <= P.min_px_dist && abs(iy - P.boxes[2 * q + 1]) <= P.min_px_dist) ok = false;
-        P.out_xy[2 * slot] = gx;
-        P.out_xy[2 * slot + 1] = gy;
-        P.out_resp[slot] = (float)(unsigned)(best >> 32);
-        P.out_valid[slot] = ok ? 1 : 0;
-      }
-    }
-    __syncthreads();
+  if (t == 0) cand_n[cell] = 0;  // ready for the next frame (stream order: stage 1 of the next detection comes after this kernel)
+  for (int i = t; i < nc; i += 256) {
+    const unsigned long long k = keys[i];
+    int rank = 0;
+    for (int j = 0; j < nc; ++j) rank += keys[j] > k;
+    if (rank >= P.nfg) continue;
+    const int idx = 0x7fffffff - (int)(k & 0xffffffffULL);
+    const int y = idx / cw, x = idx - y * cw;
+    const float gx = (float)x + (float)x0, gy = (float)y + (float)y0;
+    bool ok = !((int)gx < 0 || (int)gx > P.W || (int)gy < 0 || (int)gy > P.H);
+    const int ix = (int)gx, iy = (int)gy;
+    if (ok && P.mask && P.mask[(size_t)iy * P.W + ix] > 127) ok = false;
+    for (int q = 0; ok && q < P.n_boxes; ++q)
+      if (abs(ix - P.boxes[2 * q]) <= P.min_px_dist && abs(iy - P.boxes[2 * q + 1]) <= P.min_px_dist) ok = false;
+    const int slot = cell * P.nfg + rank;
+    P.out_xy[2 * slot] = gx;
+    P.out_xy[2 * slot + 1] = gy;
+    P.out_resp[slot] = (float)(unsigned)(k >> 32);
+    P.out_valid[slot] = ok ? 1 : 0;
   }
 }
 
@@ -191,18 +204,20 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
   }
 }
 
-int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells) {
-  const int pitch = (P.cell_w + 3) & ~3;
-  size_t shm = ((size_t)P.cell_h * pitch + 15) & ~(size_t)15;
-  shm += ((size_t)P.cell_h * P.cell_w * 2 + 15) & ~(size_t)15;
-  shm += (size_t)P.cand_cap * 8;
-  if (shm > 150 * 1024) {
-    set_last_error("FAST: cell %dx%d does not fit LDS", P.cell_w, P.cell_h);
+int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned long long *d_cand, int *d_cand_n) {
+  if (P.cell_w * P.cell_h > 0x7fffffff / 2 || (size_t)P.cand_cap * 8 > 64 * 1024) {
+    set_last_error("FAST: cell %dx%d / candidate capacity %d out of range", P.cell_w, P.cell_h, P.cand_cap);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(ensure_dyn_smem((const void *)fast_cells_kernel, (int)shm));
-  ProfScope ps(ctx->prof, "fast_cells_kernel", ctx->stream);
-  hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells), dim3(256), shm, ctx->stream, P);
+  const int tiles_x = (P.cell_w + FAST_TILE - 1) / FAST_TILE, tiles_y = (P.cell_h + FAST_TILE - 1) / FAST_TILE;
+  {
+    ProfScope ps(ctx->prof, "fast_tiles_kernel", ctx->stream);
+    hipLaunchKernelGGL(fast_tiles_kernel, dim3(n_cells * tiles_x * tiles_y), dim3(256), 0, ctx->stream, P, tiles_x, tiles_y, d_cand, d_cand_n);
+  }
+  {
+    ProfScope ps(ctx->prof, "fast_topk_kernel", ctx->stream);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3(n_cells), dim3(256), (size_t)P.cand_cap * 8, ctx->stream, P, d_cand, d_cand_n);
+  }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -18,7 +18,7 @@ struct DetectParams {
   uint8_t *out_valid;   // [n_cells * nfg]
 };
 
-int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells);
+int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned long long *d_cand, int *d_cand_n);
 int launch_subpix(plv_ctx *ctx, const uint8_t *d_img, int W, int H, int n, const uint8_t *d_valid, float *d_xy,
                   const float *d_mask, int win, int max_iters, double eps);
 

@@ -25,7 +25,7 @@ struct FrontState {
   DevBuf ds_src, ds_dst;   // full-resolution staging of plv_downsample / plv_feed_image_downsampled
   // per-call point buffers
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io, models;
-  DevBuf det_in, det_out, det_mask, subpix_tab;  // detection staging
+  DevBuf det_in, det_out, det_mask, subpix_tab, det_cand, det_cand_n;  // detection staging
   PinBuf det_pin;
 };
 
@@ -137,7 +137,7 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   if (!s) return;
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
-                    &s->det_mask, &s->subpix_tab};
+                    &s->det_mask, &s->subpix_tab, &s->det_cand, &s->det_cand_n};
   for (auto *b : bufs) b->release();
   for (auto &b : s->slots) b.release();
   s->det_pin.release();
@@ -543,7 +543,15 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
   P.out_xy = (float *)(s->det_out.as<char>() + o_xy);
   P.out_resp = (float *)(s->det_out.as<char>() + o_resp);
   P.out_valid = (uint8_t *)(s->det_out.as<char>() + o_valid);
-  TRY(launch_fast_cells(ctx, P, n_cells));
+  {  // per-cell candidate lists of fast_tiles_kernel; the counters start at zero and fast_topk_kernel leaves them at zero
+    const size_t all_cells = (size_t)grid_x * grid_y;
+    if (s->det_cand_n.cap < all_cells * 4) {
+      TRY(s->det_cand_n.reserve(all_cells * 4));
+      PLV_HIP_CHECK(hipMemsetAsync(s->det_cand_n.p, 0, s->det_cand_n.cap, ctx->stream));
+    }
+    TRY(s->det_cand.reserve(all_cells * (size_t)P.cand_cap * 8));
+  }
+  TRY(launch_fast_cells(ctx, P, n_cells, s->det_cand.as<unsigned long long>(), s->det_cand_n.as<int>()));
   TRY(launch_subpix(ctx, P.img, w, h, n_slots, P.out_valid, P.out_xy, s->subpix_tab.as<float>(), 5, 20, 0.001));
   PLV_HIP_CHECK(plv::memcpy_async(hp, s->det_out.p, out_total, hipMemcpyDeviceToHost, ctx->stream));
   TRY(sync(ctx));

@@ -59,8 +59,14 @@ int check_views(const plv_state_view *st, const plv_tracks *tr) {
 }
 
 // Packs every input array into one pinned block, uploads it with one copy and fills JacParams.
+struct StageExtra {  // optional riders of the packed block (one-submission update): normalised coordinates, admissibility flags
+  const float *uvn = nullptr;
+  const uint8_t *flags = nullptr;
+  const float *d_uvn = nullptr;
+  const uint8_t *d_flags = nullptr;
+};
 int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
-                 const int *col_to_state, int ld, JacParams &P) {
+                 const int *col_to_state, int ld, JacParams &P, StageExtra *ex = nullptr) {
   const int N = st->n_clones, F = tr->n_feat, nobs = tr->obs_ptr[F];
   if (nobs < 1) {
     set_last_error("jacobians: no observations");
@@ -81,12 +87,15 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   const size_t o_time = take(8 * N), o_R = take(72 * N), o_p = take(24 * N), o_Rf = take(72 * N), o_pf = take(24 * N),
                o_ccol = take(4 * N), o_ptr = take(4 * (F + 1)), o_of = take(4 * nobs), o_ot = take(8 * nobs),
                o_uv = take(8 * nobs), o_pg = take(24 * F), o_pgf = take(24 * F),
-               o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0, o_cols = take(4 * (size_t)k);
+               o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0, o_cols = take(4 * (size_t)k),
+               o_xuvn = ex && ex->uvn ? take(8 * nobs) : 0, o_xfl = ex && ex->flags ? take(F) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
   char *h = us->h_jin.as<char>();
   memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
+  if (ex && ex->uvn) memcpy(h + o_xuvn, ex->uvn, 8 * nobs);
+  if (ex && ex->flags) memcpy(h + o_xfl, ex->flags, F);
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
   memcpy(h + o_p, st->clone_p, 24 * N);
@@ -144,12 +153,23 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   P.ld = ld;
   P.cols_in = (const int *)(d + o_cols);
   P.cols_out = nullptr;
+  if (ex) {
+    ex->d_uvn = ex->uvn ? (const float *)(d + o_xuvn) : nullptr;
+    ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
+  }
   return PLV_OK;
 }
 
 // builds the batch into us->bHf ([Hf | Hx | res]) and us->brows on the device
+struct FusedTri {  // triangulate on the device first and let the Jacobian launch take its candidates from the result
+  const plv_tri_options *opt;
+  const float *uvn;
+  const uint8_t *flags;
+  int max_sel;
+  size_t o_p, o_err, o_ok;  // out: where the results sit in us->tri (p [F][3], err [F], ok [F], contiguous)
+};
 int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
-                    const int *col_to_state, int ld, bool project) {
+                    const int *col_to_state, int ld, bool project, FusedTri *ft = nullptr) {
   TRY(check_views(st, tr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int F = tr->n_feat;
@@ -158,7 +178,29 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{};
-  TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
+  if (ft) {
+    StageExtra ex;
+    ex.uvn = ft->uvn;
+    ex.flags = ft->flags;
+    TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P, &ex));
+    const int nobs = tr->obs_ptr[F];
+    const size_t o_pose = 0, o_valid = (size_t)nobs * 96, o_p = (o_valid + nobs + 15) & ~(size_t)15, o_err = o_p + (size_t)F * 24,
+                 o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
+    TRY(us->tri.reserve(total));
+    char *d = us->tri.as<char>();
+    int max_obs = 1;
+    for (int f = 0; f < F; ++f) max_obs = std::max(max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
+    TRY(launch_triangulate(ctx, P, (double *)(d + o_pose), (unsigned char *)(d + o_valid), ex.d_uvn, *ft->opt, (double *)(d + o_p),
+                           (unsigned char *)(d + o_ok), (double *)(d + o_err), max_obs));
+    P.p_FinG = P.p_FinG_fej = (const double *)(d + o_p);  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
+    P.sel_flags = ex.d_flags;
+    P.tri_ok = (const unsigned char *)(d + o_ok);
+    P.tri_err = (const double *)(d + o_err);
+    P.max_sel = ft->max_sel;
+    ft->o_p = o_p, ft->o_err = o_err, ft->o_ok = o_ok;
+  } else {
+    TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
+  }
   P.cols_out = us->bcols.as<int>();
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
@@ -221,6 +263,37 @@ int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *co
   return PLV_OK;
 }
 
+// One-submission point update (plv_camera_update_points): triangulation of every pool candidate, the selection loop, Jacobians +
+// null-space projection, gate, compression and EKFUpdate are enqueued back to back; one upload, one result download, one host
+// synchronisation.  `all` carries obs_uvn; flags[f] = the host's part of the selection test.  Returns as plv_msckf_update_resident
+// (PLV_E_NOT_PSD: covariance untouched); p / ok / err (per candidate) and accepted (per candidate, 0 for unselected ones) are filled
+// in both cases.
+int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
+                            const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
+                            double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows,
+                            double *dx) {
+  if (!ctx || !all || !tri || !flags || !p_out || !ok_out || !err_out || !accepted || !dx || !all->obs_uvn) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  plv_tracks t2 = *all;
+  t2.p_FinG = t2.p_FinG_fej = p_out;  // (outputs of the triangulation: the staged copy is never read)
+  FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
+  TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
+  us->b_single_use = true;
+  const int F = all->n_feat;
+  TRY(us->h_tri.reserve((size_t)F * 33 + 16));
+  int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
+  // (stream order: lands before the wait below returns)
+  PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
+  if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
+  else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  const char *h = us->h_tri.as<char>();
+  memcpy(p_out, h, (size_t)F * 24);
+  memcpy(err_out, h + (size_t)F * 24, (size_t)F * 8);
+  memcpy(ok_out, h + (size_t)F * 32, (size_t)F);
+  return rc;
+}
+
 int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
                                  const int *col_to_state, int ld) {
   if (!ctx) return PLV_E_BADARG;
@@ -274,8 +347,10 @@ int plv_triangulate(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr
   TRY(us->tri.reserve(total));
   char *d = us->tri.as<char>();
   PLV_HIP_CHECK(plv::memcpy_async(d + o_uvn, tr->obs_uvn, (size_t)nobs * 8, hipMemcpyHostToDevice, ctx->stream));
+  int max_obs = 1;
+  for (int f = 0; f < F; ++f) max_obs = std::max(max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
   TRY(launch_triangulate(ctx, P, (double *)(d + o_pose), (unsigned char *)(d + o_valid), (const float *)(d + o_uvn), *opt,
-                         (double *)(d + o_p), (unsigned char *)(d + o_ok), (double *)(d + o_err)));
+                         (double *)(d + o_p), (unsigned char *)(d + o_ok), (double *)(d + o_err), max_obs));
   PLV_HIP_CHECK(plv::memcpy_async(p_FinG, d + o_p, (size_t)F * 24, hipMemcpyDeviceToHost, ctx->stream));
   PLV_HIP_CHECK(plv::memcpy_async(ok, d + o_ok, (size_t)F, hipMemcpyDeviceToHost, ctx->stream));
   if (reproj_err) PLV_HIP_CHECK(plv::memcpy_async(reproj_err, d + o_err, (size_t)F * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -395,9 +470,14 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   return PLV_OK;
 }
 
+struct FusedLineTri {
+  const uint8_t *flags;
+  int max_sel;
+  size_t o_lines, o_ok;  // out: results in us->tri (lines [L][6], ok [L])
+};
 int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
-                          const int *col_to_state, int ld) {
-  TRY(check_line_views(st, lt, true, false));
+                          const int *col_to_state, int ld, FusedLineTri *ft = nullptr) {
+  TRY(check_line_views(st, lt, ft == nullptr, ft != nullptr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int L = lt->n_lines;
   const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
@@ -409,6 +489,22 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   us->b_projected = false;
   us->b_gather_token = 0;
   PLV_HIP_CHECK(plv::memcpy_async(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ft) {
+    const int nobs = lt->obs_ptr[L];
+    const size_t o_cam = 0, o_imu = (size_t)nobs * 96, o_lines = o_imu + (size_t)nobs * 96, o_ok = o_lines + (size_t)L * 48,
+                 o_fl = (o_ok + L + 15) & ~(size_t)15, o_valid = (o_fl + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
+    TRY(us->tri.reserve(total));
+    char *d = us->tri.as<char>();
+    PLV_HIP_CHECK(plv::memcpy_async(d + o_fl, ft->flags, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch_triangulate_lines(ctx, P, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
+                                 (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
+    P.line_FinG = (const double *)(d + o_lines);
+    P.sel_flags = (const unsigned char *)(d + o_fl);
+    P.tri_ok = (const unsigned char *)(d + o_ok);
+    P.tri_err = nullptr;
+    P.max_sel = ft->max_sel;
+    ft->o_lines = o_lines, ft->o_ok = o_ok;
+  }
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;
@@ -426,6 +522,28 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
 }  // namespace
 
 extern "C" {
+
+// The line twin (plv_camera_update_lines): line triangulation, selection, Pluecker Jacobians, null space, gate, compression, EKF.
+int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *all, const uint8_t *flags, int max_sel, int k,
+                           const int *col_to_state, int ld, double sigma2, double chi2_mult, double *lines_out, uint8_t *ok_out,
+                           uint8_t *accepted, int *n_rows, double *dx) {
+  if (!ctx || !all || !flags || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  FusedLineTri ft{flags, max_sel, 0, 0};
+  TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, &ft));
+  us->b_single_use = true;
+  const int L = all->n_lines;
+  TRY(us->h_tri.reserve((size_t)L * 49 + 16));
+  int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, 0.0);
+  PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_lines, (size_t)L * 49, hipMemcpyDeviceToHost, ctx->stream));
+  if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
+  else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  const char *h = us->h_tri.as<char>();
+  memcpy(lines_out, h, (size_t)L * 48);
+  memcpy(ok_out, h + (size_t)L * 48, (size_t)L);
+  return rc;
+}
 
 int plv_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *lt, int *col_to_state, int cap, int *k_out) {
   if (!col_to_state || !k_out) return PLV_E_BADARG;

@@ -395,6 +395,18 @@ __global__ void __launch_bounds__(128) jacobian_kernel(JacParams P) {
   if (threadIdx.x == 0) P.rows[f] = 2 * base;
 }
 
+// The reference's selection loop on the device: candidate f is taken when it passes its own tests and fewer than max_sel
+// candidates before it did.  Called by every thread of the workgroup.
+__device__ bool candidate_selected(const JacParams &P, int f) {
+  auto base = [&](int g) { return P.sel_flags[g] && P.tri_ok[g] && (!P.tri_err || P.tri_err[g] < 3.0); };
+  int before = 0;
+  for (int g0 = 0; g0 < f; g0 += blockDim.x) {
+    const int g = g0 + threadIdx.x;
+    before += __syncthreads_count(g < f && base(g));
+  }
+  return base(f) && before < P.max_sel;
+}
+
 // jacobian_kernel + nullspace_kernel in one launch for the resident update path: the feature's [Hf | Hx | res] block is built
 // row-major in LDS, projected there (nullspace_core.hpp) and only the projected block goes to global memory — one launch, one
 // 1.7 MB write and one 1.7 MB read less on the update chain.  The covariance gathers of the update ride on it as extra workgroups
@@ -413,8 +425,14 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
   if (f == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
+  const bool selected = !P.tri_ok || candidate_selected(P, f);
   build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill before the row writes)
-  if (threadIdx.x < 64) {
+  if (!selected) {
+    if (threadIdx.x == 0) {
+      s_rows = 0;
+      P.rows[f] = 0;
+    }
+  } else if (threadIdx.x < 64) {
     const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
     int base = 0;
     for (int ob = o0; ob < o1; ob += 64) {
@@ -831,75 +849,103 @@ __device__ void sym_eig3(const M3 &A, double ev[3]) {
   ev[1] = 3 * q - ev[0] - ev[2];
 }
 
-struct TriCtx {
-  const double *poses;
-  const unsigned char *valid;
-  const float *uvn;
-  int o0, o1;
-  M3 R_GtoA;
-  V3 p_AinG;
+// a18: FeatureInitializer::single_triangulation + single_gaussnewton and the reprojection check of CamHelper::feature_triangulation
+// (REF: open_vins/ov_core/src/feat/FeatureInitializer.cpp:29-309, PL-VIWO/src/update/cam/CamHelper.cpp:397-483).
+// One wave per feature.  Every pass of the algorithm (linear system, cost of a trial point, Hessian + gradient, baseline, mean
+// reprojection error) is "a term per observation, summed": the lanes compute the terms of their observations into LDS, then lane c
+// adds up component c over the observations IN OBSERVATION ORDER, so the sums are the ones of the serial loop, bit for bit
+// (both sides are built -ffp-contract=off), and the Levenberg-Marquardt control flow, which every lane executes on the same totals,
+// takes the same branches as a thread-per-feature version (160 us for a pool of ~20 features; this form: a few us).
+struct TriObs {     // per valid observation, relative to the anchor pose (the newest observation)
+  double R[9];      // R_AtoCi
+  double pa[3];     // p_AinCi
+  double pc[3];     // p_CiinA
 };
-__device__ double tri_error(const TriCtx &c, double alpha, double beta, double rho) {
-  double err = 0;
-  for (int o = c.o0; o < c.o1; ++o) {
-    if (!c.valid[o]) continue;
-    const M3 R_AtoCi = mm(ldM(c.poses + 12 * o), tp(c.R_GtoA));
-    const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(c.poses + 12 * o + 9), c.p_AinG));
-    const V3 p_AinCi = vsc(mv(R_AtoCi, p_CiinA), -1.0);
-    const double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
-    const double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
-    const double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
-    const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
-    const float r0 = c.uvn[2 * o] - z0, r1 = c.uvn[2 * o + 1] - z1;
-    const float nrm = sqrtf(r0 * r0 + r1 * r1);
-    err += (double)nrm * (double)nrm;
-  }
-  return err;
-}
-
+#define TRI_TERMS 10
 __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const double *__restrict__ poses,
                                                          const unsigned char *__restrict__ valid, const float *__restrict__ uvn,
                                                          plv_tri_options opt, double *__restrict__ p_out,
-                                                         unsigned char *__restrict__ ok_out, double *__restrict__ err_out) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= P.n_feat) return;
-  TriCtx c;
-  c.poses = poses;
-  c.valid = valid;
-  c.uvn = uvn;
-  c.o0 = P.obs_ptr[f];
-  c.o1 = P.obs_ptr[f + 1];
-  int M = 0, last = -1;
-  for (int o = c.o0; o < c.o1; ++o)
-    if (valid[o]) {
-      ++M;
-      last = o;
-    }
-  p_out[3 * f] = p_out[3 * f + 1] = p_out[3 * f + 2] = 0;
-  ok_out[f] = 0;
-  if (err_out) err_out[f] = 0;
+                                                         unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
+  extern __shared__ double tri_smem[];
+  TriObs *ob = reinterpret_cast<TriObs *>(tri_smem);                       // [max_obs]
+  double *term = tri_smem + (size_t)max_obs * (sizeof(TriObs) / 8);        // [max_obs][TRI_TERMS]
+  int *list = reinterpret_cast<int *>(term + (size_t)max_obs * TRI_TERMS);  // [max_obs] indices of the valid observations
+  __shared__ double tot[TRI_TERMS];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
+  // ordered compaction of the valid observations
+  int M = 0;
+  for (int base = o0; base < o1; base += 64) {
+    const int o = base + lane;
+    const bool v = o < o1 && valid[o];
+    const unsigned long long m = __ballot(v);
+    if (v) list[M + __popcll(m & ((1ull << lane) - 1ull))] = o;
+    M += __popcll(m);
+  }
+  if (lane == 0) {
+    p_out[3 * f] = p_out[3 * f + 1] = p_out[3 * f + 2] = 0;
+    ok_out[f] = 0;
+    if (err_out) err_out[f] = 0;
+  }
   if (M < 2) return;
-  c.R_GtoA = ldM(poses + 12 * last);  // anchor = newest observation (FeatureInitializer.cpp:44-45)
-  c.p_AinG = ldV(poses + 12 * last + 9);
-  M3 A{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
-  V3 b{{0, 0, 0}};
-  for (int o = c.o0; o < c.o1; ++o) {
-    if (!valid[o]) continue;
-    const M3 R_AtoCi = mm(ldM(poses + 12 * o), tp(c.R_GtoA));
-    const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
+  __syncthreads();
+  const int last = list[M - 1];
+  const M3 R_GtoA = ldM(poses + 12 * last);  // anchor = newest observation (FeatureInitializer.cpp:44-45)
+  const V3 p_AinG = ldV(poses + 12 * last + 9);
+  // sums `n` terms per observation in observation order; afterwards tot[0..n) holds the totals for every lane
+  auto reduce = [&](int n) {
+    __syncthreads();
+    if (lane < n) {
+      double s = 0;
+      for (int q = 0; q < M; ++q) s += term[q * TRI_TERMS + lane];
+      tot[lane] = s;
+    }
+    __syncthreads();
+  };
+  // ---- linear triangulation: A = sum Bp^T Bp, b = sum Ai p_CiinA
+  for (int q = lane; q < M; q += 64) {
+    const int o = list[q];
+    const M3 R_AtoCi = mm(ldM(poses + 12 * o), tp(R_GtoA));
+    const V3 p_CiinA = mv(R_GtoA, vsub(ldV(poses + 12 * o + 9), p_AinG));
+    const V3 p_AinCi = vsc(mv(R_AtoCi, p_CiinA), -1.0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ob[q].R[i] = R_AtoCi.m[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ob[q].pa[i] = p_AinCi[i], ob[q].pc[i] = p_CiinA[i];
     V3 bi = mv(tp(R_AtoCi), V3{{(double)uvn[2 * o], (double)uvn[2 * o + 1], 1.0}});
     bi = vsc(bi, 1.0 / vnorm(bi));
     const M3 Bp = skew3(bi);
     const M3 Ai = mm(tp(Bp), Bp);
-    A = ma(A, Ai);
-    b = vadd(b, mv(Ai, p_CiinA));
+    const V3 bq = mv(Ai, p_CiinA);
+    double *tq = term + q * TRI_TERMS;
+    tq[0] = Ai(0, 0), tq[1] = Ai(0, 1), tq[2] = Ai(0, 2), tq[3] = Ai(1, 1), tq[4] = Ai(1, 2), tq[5] = Ai(2, 2);
+    tq[6] = bq[0], tq[7] = bq[1], tq[8] = bq[2];
   }
+  reduce(9);
+  M3 A;
+  A(0, 0) = tot[0], A(0, 1) = A(1, 0) = tot[1], A(0, 2) = A(2, 0) = tot[2], A(1, 1) = tot[3], A(1, 2) = A(2, 1) = tot[4], A(2, 2) = tot[5];
+  const V3 b{{tot[6], tot[7], tot[8]}};
   V3 pf;
   if (!solve3(A, b, pf)) return;
   double ev[3];
   sym_eig3(A, ev);
   const double condA = ev[0] / ev[2];
   if (fabs(condA) > opt.max_cond_number || pf[2] < opt.min_dist || pf[2] > opt.max_dist || isnan(vnorm(pf))) return;
+  auto tri_error = [&](double alpha, double beta, double rho) {
+    for (int q = lane; q < M; q += 64) {
+      const TriObs &c = ob[q];
+      const int o = list[q];
+      const double hi1 = c.R[0] * alpha + c.R[1] * beta + c.R[2] + rho * c.pa[0];
+      const double hi2 = c.R[3] * alpha + c.R[4] * beta + c.R[5] + rho * c.pa[1];
+      const double hi3 = c.R[6] * alpha + c.R[7] * beta + c.R[8] + rho * c.pa[2];
+      const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+      const float r0 = uvn[2 * o] - z0, r1 = uvn[2 * o + 1] - z1;
+      const float nrm = sqrtf(r0 * r0 + r1 * r1);
+      term[q * TRI_TERMS] = (double)nrm * (double)nrm;
+    }
+    reduce(1);
+    return tot[0];
+  };
   if (opt.refine_features) {
     double rho = 1 / pf[2], alpha = pf[0] / pf[2], beta = pf[1] / pf[2];
     double lam = 1e-3, eps = 10000;
@@ -907,39 +953,36 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const doub
     bool recompute = true;
     M3 Hess{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
     V3 grad{{0, 0, 0}};
-    double cost_old = tri_error(c, alpha, beta, rho);
+    double cost_old = tri_error(alpha, beta, rho);
     while (runs < 5 && lam < 1e10 && eps > 1e-6) {
       if (recompute) {
-        Hess = M3{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
-        grad = V3{{0, 0, 0}};
-        for (int o = c.o0; o < c.o1; ++o) {
-          if (!valid[o]) continue;
-          const M3 R_AtoCi = mm(ldM(poses + 12 * o), tp(c.R_GtoA));
-          const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
-          const V3 p_AinCi = vsc(mv(R_AtoCi, p_CiinA), -1.0);
-          const double hi1 = R_AtoCi(0, 0) * alpha + R_AtoCi(0, 1) * beta + R_AtoCi(0, 2) + rho * p_AinCi[0];
-          const double hi2 = R_AtoCi(1, 0) * alpha + R_AtoCi(1, 1) * beta + R_AtoCi(1, 2) + rho * p_AinCi[1];
-          const double hi3 = R_AtoCi(2, 0) * alpha + R_AtoCi(2, 1) * beta + R_AtoCi(2, 2) + rho * p_AinCi[2];
+        for (int q = lane; q < M; q += 64) {
+          const TriObs &c = ob[q];
+          const int o = list[q];
+          const double hi1 = c.R[0] * alpha + c.R[1] * beta + c.R[2] + rho * c.pa[0];
+          const double hi2 = c.R[3] * alpha + c.R[4] * beta + c.R[5] + rho * c.pa[1];
+          const double hi3 = c.R[6] * alpha + c.R[7] * beta + c.R[8] + rho * c.pa[2];
           const double h3s = pow(hi3, 2.0);
-          const double Hj[6] = {(R_AtoCi(0, 0) * hi3 - hi1 * R_AtoCi(2, 0)) / h3s, (R_AtoCi(0, 1) * hi3 - hi1 * R_AtoCi(2, 1)) / h3s,
-                                (p_AinCi[0] * hi3 - hi1 * p_AinCi[2]) / h3s,        (R_AtoCi(1, 0) * hi3 - hi2 * R_AtoCi(2, 0)) / h3s,
-                                (R_AtoCi(1, 1) * hi3 - hi2 * R_AtoCi(2, 1)) / h3s, (p_AinCi[1] * hi3 - hi2 * p_AinCi[2]) / h3s};
+          const double Hj[6] = {(c.R[0] * hi3 - hi1 * c.R[6]) / h3s, (c.R[1] * hi3 - hi1 * c.R[7]) / h3s, (c.pa[0] * hi3 - hi1 * c.pa[2]) / h3s,
+                                (c.R[3] * hi3 - hi2 * c.R[6]) / h3s, (c.R[4] * hi3 - hi2 * c.R[7]) / h3s, (c.pa[1] * hi3 - hi2 * c.pa[2]) / h3s};
           const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
           const double r0 = (double)(uvn[2 * o] - z0), r1 = (double)(uvn[2 * o + 1] - z1);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            grad[i] += Hj[i] * r0 + Hj[3 + i] * r1;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) Hess(i, j) += Hj[i] * Hj[j] + Hj[3 + i] * Hj[3 + j];
-          }
+          double *tq = term + q * TRI_TERMS;
+          tq[0] = Hj[0] * r0 + Hj[3] * r1, tq[1] = Hj[1] * r0 + Hj[4] * r1, tq[2] = Hj[2] * r0 + Hj[5] * r1;
+          tq[3] = Hj[0] * Hj[0] + Hj[3] * Hj[3], tq[4] = Hj[0] * Hj[1] + Hj[3] * Hj[4], tq[5] = Hj[0] * Hj[2] + Hj[3] * Hj[5];
+          tq[6] = Hj[1] * Hj[1] + Hj[4] * Hj[4], tq[7] = Hj[1] * Hj[2] + Hj[4] * Hj[5], tq[8] = Hj[2] * Hj[2] + Hj[5] * Hj[5];
         }
+        reduce(9);
+        grad = V3{{tot[0], tot[1], tot[2]}};
+        Hess(0, 0) = tot[3], Hess(0, 1) = Hess(1, 0) = tot[4], Hess(0, 2) = Hess(2, 0) = tot[5];
+        Hess(1, 1) = tot[6], Hess(1, 2) = Hess(2, 1) = tot[7], Hess(2, 2) = tot[8];
       }
       M3 Hl = Hess;
 #pragma unroll
       for (int r = 0; r < 3; ++r) Hl(r, r) *= (1.0 + lam);
       V3 dx;
       if (!solve3(Hl, grad, dx)) break;
-      const double cost = tri_error(c, alpha + dx[0], beta + dx[1], rho + dx[2]);
+      const double cost = tri_error(alpha + dx[0], beta + dx[1], rho + dx[2]);
       if (cost <= cost_old && (cost_old - cost) / cost_old < 1e-6) {
         alpha += dx[0];
         beta += dx[1];
@@ -963,25 +1006,23 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const doub
     }
     pf = V3{{alpha / rho, beta / rho, 1 / rho}};
     const V3 dir = vsc(pf, 1.0 / vnorm(pf));
-    double base_max = 0;
-    for (int o = c.o0; o < c.o1; ++o) {
-      if (!valid[o]) continue;
-      const V3 p_CiinA = mv(c.R_GtoA, vsub(ldV(poses + 12 * o + 9), c.p_AinG));
+    for (int q = lane; q < M; q += 64) {
+      const V3 p_CiinA{{ob[q].pc[0], ob[q].pc[1], ob[q].pc[2]}};
       const double along = p_CiinA[0] * dir[0] + p_CiinA[1] * dir[1] + p_CiinA[2] * dir[2];
-      base_max = fmax(base_max, vnorm(vsub(p_CiinA, vsc(dir, along))));
+      term[q * TRI_TERMS] = vnorm(vsub(p_CiinA, vsc(dir, along)));
     }
+    __syncthreads();
+    double base_max = 0;
+    for (int q = 0; q < M; ++q) base_max = fmax(base_max, term[q * TRI_TERMS]);
+    __syncthreads();
     if (pf[2] < opt.min_dist || pf[2] > opt.max_dist || (vnorm(pf) / base_max) > opt.max_baseline || isnan(vnorm(pf))) return;
   }
-  const V3 pg = vadd(mv(tp(c.R_GtoA), pf), c.p_AinG);
-  p_out[3 * f] = pg[0];
-  p_out[3 * f + 1] = pg[1];
-  p_out[3 * f + 2] = pg[2];
-  ok_out[f] = 1;
+  const V3 pg = vadd(mv(tp(R_GtoA), pf), p_AinG);
+  double e = 0;
   if (err_out) {  // mean pixel reprojection error (CamHelper.cpp:441-470), float round trip of distort_d included
-    double e = 0;
     const double *K = P.K;
-    for (int o = c.o0; o < c.o1; ++o) {
-      if (!valid[o]) continue;
+    for (int q = lane; q < M; q += 64) {
+      const int o = list[q];
       const V3 pC = mv(ldM(poses + 12 * o), vsub(pg, ldV(poses + 12 * o + 9)));
       const double x = (double)(float)(pC[0] / pC[2]), y = (double)(float)(pC[1] / pC[2]);
       const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
@@ -989,9 +1030,17 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const doub
       const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
       const double r0 = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
       const double r1 = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
-      e += sqrt(r0 * r0 + r1 * r1);
+      term[q * TRI_TERMS] = sqrt(r0 * r0 + r1 * r1);
     }
-    err_out[f] = e / M;
+    reduce(1);
+    e = tot[0];
+  }
+  if (lane == 0) {
+    p_out[3 * f] = pg[0];
+    p_out[3 * f + 1] = pg[1];
+    p_out[3 * f + 2] = pg[2];
+    ok_out[f] = 1;
+    if (err_out) err_out[f] = e / M;
   }
 }
 
@@ -1185,6 +1234,10 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
   for (int i = threadIdx.x; i < k * ld; i += 64) hx[i] = 0.0;
   for (int i = threadIdx.x; i < ld; i += 64) rs[i] = 0.0;
   __syncthreads();
+  if (P.tri_ok && !candidate_selected(P, l)) {
+    if (threadIdx.x == 0) P.rows[l] = 0;
+    return;
+  }
   const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
   int base = 0;
   for (int ob = o0; ob < o1; ob += 64) {
@@ -1304,15 +1357,21 @@ int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, 
 }
 
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
-                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err) {
+                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err, int max_obs) {
   {
     ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
     hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, (double *)nullptr);
   }
   {
     ProfScope ps(ctx->prof, "triangulate_kernel", ctx->stream);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((P.n_feat + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, d_uvn, opt,
-                       d_p, d_ok, d_err);
+    const size_t shm = (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16;
+    if (shm > 150 * 1024) {
+      set_last_error("triangulation: a track of %d observations exceeds LDS", max_obs);
+      return PLV_E_CAPACITY;
+    }
+    PLV_HIP_CHECK(ensure_dyn_smem((const void *)triangulate_kernel, (int)shm));
+    hipLaunchKernelGGL(triangulate_kernel, dim3(P.n_feat), dim3(64), shm, ctx->stream, P, d_poses, d_valid, d_uvn, opt, d_p, d_ok, d_err,
+                       std::max(max_obs, 1));
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -31,6 +31,13 @@ struct JacParams {
   // col_to_state rides in the packed input block; workgroup 0 copies it to its resident home (no separate H2D on the chain)
   const int *cols_in;
   int *cols_out;
+  // one-submission update (plv_camera_update_points / _lines): the batch holds EVERY pool candidate and the Jacobian kernels decide
+  // on the device which ones the reference's selection loop would take (CamHelper.cpp:648-699): sel_flags = the host's part of the
+  // test (enough observations with bounding clones), tri_ok / tri_err = the triangulation kernel's verdict (err: mean reprojection
+  // error, < 3 px; null for lines), at most max_sel candidates in batch order.  The others become empty (zero-row) systems.
+  const unsigned char *sel_flags, *tri_ok;
+  const double *tri_err;
+  int max_sel;
 };
 
 struct CpiParams {  // device pointers; State::cpis as a table sorted by time + the clone window
@@ -49,6 +56,6 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
                              double *d_lines, unsigned char *d_ok);
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
-                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err);
+                       const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err, int max_obs);
 
 }  // namespace plv

@@ -21,6 +21,7 @@
 #include "fld_fit_core.hpp"
 #include "radtan_core.hpp"
 #include "line_kernels.hpp"
+#include "update_state.hpp"
 
 using namespace plv;
 
@@ -794,16 +795,53 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     all.res_R = allR.data();
     all.res_p = allp.data();
   }
-  int rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
-  if (rc != PLV_OK) {
-    for (const Cand &c : pool) give_back_all(c);
-    return finish(rc);
+  std::vector<int> valid_n(Lp, 0);
+  int most_valid = 0;
+  for (int l = 0; l < Lp; ++l) {
+    for (double t : pool[l].tr.t) valid_n[l] += line_has_bounding_poses(*st, t + dt);
+    most_valid = std::max(most_valid, valid_n[l]);
+  }
+  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  int k = 0, n_rows = 0, rc = PLV_OK;
+  // ---- one submission (see plv_camera_update_points): line triangulation, the selection below, Jacobians, null space, gate,
+  // compression and EKFUpdate back to back on the stream, one synchronisation.  CPI poses and over-long tracks take the two-step route.
+  const bool fused = !opt->cpi && most_valid <= opt->max_obs;
+  std::vector<uint8_t> acc_all(Lp, 0);
+  bool fused_ran = false;
+  if (fused) {
+    std::vector<uint8_t> flags(Lp);
+    bool any = false;
+    for (int l = 0; l < Lp; ++l) any = (flags[l] = valid_n[l] >= 2) || any;
+    if (any) {
+      rc = plv_line_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
+      if (rc == PLV_OK && k > 0) {
+        rc = plv_lines_update_fused(ctx, st, &all, flags.data(), cap, k, cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
+                                    opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx);
+        res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
+        if (rc == PLV_E_NOT_PSD) {
+          rc = PLV_OK;
+          std::fill(dx, dx + ctx->cov_n, 0.0);
+        }
+        fused_ran = rc == PLV_OK;
+      }
+      if (rc != PLV_OK) {
+        for (const Cand &c : pool) give_back_all(c);
+        return finish(rc);
+      }
+    } else {
+      std::fill(ok.begin(), ok.end(), 0);
+    }
+  } else {
+    rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
+    if (rc != PLV_OK) {
+      for (const Cand &c : pool) give_back_all(c);
+      return finish(rc);
+    }
   }
   std::vector<int> sel;
   std::vector<double> t_first(Lp, -1e300);  // oldest observation time a truncated track keeps
   for (int l = 0; l < Lp; ++l) {
-    int valid = 0;
-    for (double t : pool[l].tr.t) valid += line_has_bounding_poses(*st, t + dt);
+    const int valid = valid_n[l];
     if (!ok[l] || valid < 2 || (int)sel.size() >= cap) {
       give_back_all(pool[l]);
       continue;
@@ -819,7 +857,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     sel.push_back(l);
   }
   res->n_msckf = (int)sel.size();
-  if (sel.empty()) return finish(PLV_OK);
+  if (sel.empty()) {
+    if (fused_ran) std::fill(dx, dx + ctx->cov_n, 0.0);
+    return finish(PLV_OK);
+  }
   // ---- UpdaterCamera::lines_update
   const int L = (int)sel.size();
   std::vector<int> sptr(L + 1, 0);
@@ -855,20 +896,21 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     lt.res_R = selR.data();
     lt.res_p = selp.data();
   }
-  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
-  int k = 0;
-  rc = plv_line_jacobian_columns(st, &lt, cols.data(), (int)cols.size(), &k);
-  if (rc == PLV_OK) rc = plv_build_line_jacobians_resident(ctx, st, &lt, k, cols.data(), 2 * opt->max_obs);
   std::vector<uint8_t> acc(L, 0);
-  int n_rows = 0;
-  if (rc == PLV_OK) {
-    rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 0.0, acc.data(), &n_rows, dx);
-    res->status = rc;
-    if (rc == PLV_E_NOT_PSD) rc = PLV_OK;
-  }
-  if (rc != PLV_OK) {
-    for (int q = 0; q < L; ++q) give_back_all(pool[sel[q]]);
-    return finish(rc);
+  if (fused_ran) {
+    for (int q = 0; q < L; ++q) acc[q] = acc_all[sel[q]];
+  } else {
+    rc = plv_line_jacobian_columns(st, &lt, cols.data(), (int)cols.size(), &k);
+    if (rc == PLV_OK) rc = plv_build_line_jacobians_resident(ctx, st, &lt, k, cols.data(), 2 * opt->max_obs);
+    if (rc == PLV_OK) {
+      rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 0.0, acc.data(), &n_rows, dx);
+      res->status = rc;
+      if (rc == PLV_E_NOT_PSD) rc = PLV_OK;
+    }
+    if (rc != PLV_OK) {
+      for (int q = 0; q < L; ++q) give_back_all(pool[sel[q]]);
+      return finish(rc);
+    }
   }
   res->n_rows = n_rows;
   for (int q = 0; q < L; ++q) {

@@ -224,6 +224,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
     if (us->gexec) (void)hipGraphExecDestroy(us->gexec);
     us->gexec = nullptr;
     us->h_jin.release();
+    us->h_tri.release();
     delete us;
   }
   (void)hipStreamDestroy(ctx->stream);

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "plv_ctx.hpp"
+#include "update_state.hpp"
 
 namespace {
 
@@ -458,8 +459,14 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       c.tr = std::move(kept);
     }
   }
-  std::vector<int> ptr(Fp + 1, 0);
-  for (int f = 0; f < Fp; ++f) ptr[f + 1] = ptr[f] + (int)pool[f].tr.t.size();
+  std::vector<int> ptr(Fp + 1, 0), valid_n(Fp, 0);
+  int most_valid = 0;
+  for (int f = 0; f < Fp; ++f) {
+    ptr[f + 1] = ptr[f] + (int)pool[f].tr.t.size();
+    // get_imu_poses (:327-372): observations without bounding clones do not count (and go back to the database below)
+    for (double t : pool[f].tr.t) valid_n[f] += has_bounding_poses(*st, t + dt);
+    most_valid = std::max(most_valid, valid_n[f]);
+  }
   const int nobs = ptr[Fp];
   if (nobs == 0) {
     std::fill(dx, dx + ctx->cov_n, 0.0);
@@ -489,10 +496,46 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     all.res_R = allR.data();
     all.res_p = allp.data();
   }
-  int rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
-  if (rc != PLV_OK) {
-    for (const Cand &c : pool) give_back_all(c);
-    return finish(rc);
+  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  int k = 0, n_rows = 0, rc = PLV_OK;
+  // ---- one submission (the default): every pool candidate is triangulated, the selection loop below runs on the device too
+  // (jacobian_nullspace_kernel: candidate_selected), Jacobians / gate / compression / EKFUpdate follow on the stream, and the host
+  // reads triangulation results, gate decisions and dx after ONE synchronisation.  The batch then holds all candidates (the ones
+  // the loop does not take are empty systems) and its column set is the union over all of them: a permutation / zero columns of the
+  // reference's, which changes neither dx nor P beyond rounding.  Poses from the CPI table, in-state landmarks and tracks longer
+  // than the batch rows take the two-step route (triangulate, select on the host, then build + update).
+  const bool fused = !opt->cpi && opt->max_slam == 0 && most_valid <= opt->max_obs;
+  std::vector<uint8_t> acc_all(Fp, 0);
+  bool fused_ran = false;
+  if (fused) {
+    std::vector<uint8_t> flags(Fp);
+    bool any = false;
+    for (int f = 0; f < Fp; ++f) any = (flags[f] = valid_n[f] >= 2) || any;
+    if (any) {
+      all.p_FinG = all.p_FinG_fej = pf.data();
+      rc = plv_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
+      if (rc == PLV_OK && k > 0) {
+        rc = plv_points_update_fused(ctx, st, &all, &opt->tri, flags.data(), opt->max_msckf, k, cols.data(), 2 * opt->max_obs,
+                                     st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, pf.data(), ok.data(), err.data(), acc_all.data(),
+                                     &n_rows, dx);
+        res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
+        if (rc == PLV_E_NOT_PSD) {
+          rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
+          std::fill(dx, dx + ctx->cov_n, 0.0);
+        }
+        fused_ran = rc == PLV_OK;
+      }
+      if (rc != PLV_OK) {
+        for (const Cand &c : pool) give_back_all(c);
+        return finish(rc);
+      }
+    }
+  } else {
+    rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
+    if (rc != PLV_OK) {
+      for (const Cand &c : pool) give_back_all(c);
+      return finish(rc);
+    }
   }
   // ---- REF :648-699 the selection loop
   std::vector<int> sel;
@@ -503,9 +546,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       give_back_all(c);
       continue;
     }
-    // get_imu_poses (:327-372): observations without bounding clones go back to the database
-    int valid = 0;
-    for (size_t i = 0; i < c.tr.t.size(); ++i) valid += has_bounding_poses(*st, c.tr.t[i] + dt);
+    const int valid = valid_n[f];
     if (valid >= 2 && ok[f]) {  // copy_to_db(db_used, feat): dynamic (:677) and MSCKF (:697) features, Triangulated = true
       std::lock_guard<std::mutex> lk(T->mtx);
       Tracker::UsedPoint &u = T->used[c.id];
@@ -546,7 +587,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   res->n_msckf = (int)sel.size();
   res->n_init = (int)T->last_init.size();
   if (sel.empty()) {
-    std::fill(dx, dx + ctx->cov_n, 0.0);
+    if (!fused_ran) std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);
   }
   // ---- UpdaterCamera::msckf_update on the selected features
@@ -575,31 +616,32 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     if (msckf_ids) msckf_ids[q] = c.id;
   }
   if (p_out) std::copy(sp.begin(), sp.end(), p_out);
-  plv_tracks tr{};
-  tr.n_feat = F;
-  tr.obs_ptr = sptr.data();
-  tr.obs_time = st_t.data();
-  tr.obs_uv = suv.data();
-  tr.p_FinG = sp.data();
-  tr.p_FinG_fej = sp.data();  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
-  if (opt->cpi) {
-    tr.res_R = selR.data();
-    tr.res_p = selp.data();
-  }
-  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
-  int k = 0;
-  rc = plv_jacobian_columns(st, &tr, cols.data(), (int)cols.size(), &k);
-  if (rc == PLV_OK) rc = plv_build_jacobians_resident(ctx, st, &tr, k, cols.data(), 2 * opt->max_obs);
   std::vector<uint8_t> acc(F, 0);
-  int n_rows = 0;
-  if (rc == PLV_OK) {
-    rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, acc.data(), &n_rows, dx);
-    res->status = rc;
-    if (rc == PLV_E_NOT_PSD) rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
-  }
-  if (rc != PLV_OK) {
-    for (int q = 0; q < F; ++q) give_back_all(pool[sel[q]]);
-    return finish(rc);
+  if (fused_ran) {
+    for (int q = 0; q < F; ++q) acc[q] = acc_all[sel[q]];
+  } else {
+    plv_tracks tr{};
+    tr.n_feat = F;
+    tr.obs_ptr = sptr.data();
+    tr.obs_time = st_t.data();
+    tr.obs_uv = suv.data();
+    tr.p_FinG = sp.data();
+    tr.p_FinG_fej = sp.data();  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
+    if (opt->cpi) {
+      tr.res_R = selR.data();
+      tr.res_p = selp.data();
+    }
+    rc = plv_jacobian_columns(st, &tr, cols.data(), (int)cols.size(), &k);
+    if (rc == PLV_OK) rc = plv_build_jacobians_resident(ctx, st, &tr, k, cols.data(), 2 * opt->max_obs);
+    if (rc == PLV_OK) {
+      rc = plv_msckf_update_resident(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, acc.data(), &n_rows, dx);
+      res->status = rc;
+      if (rc == PLV_E_NOT_PSD) rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
+    }
+    if (rc != PLV_OK) {
+      for (int q = 0; q < F; ++q) give_back_all(pool[sel[q]]);
+      return finish(rc);
+    }
   }
   res->n_rows = n_rows;
   for (int q = 0; q < F; ++q) {

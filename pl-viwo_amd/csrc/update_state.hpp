@@ -37,5 +37,15 @@ struct plv_ctx_update_state {
   // jacobian inputs
   plv::DevBuf jin, tri, eval;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
+  plv::PinBuf h_tri;  // triangulation results of the one-submission updates
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
+
+// internal entry points of jacobian_api.hip used by the one-call camera updates (tracker_api.hip, line_api.hip)
+extern "C" int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
+                                       const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
+                                       double chi2_mult, double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out,
+                                       uint8_t *accepted, int *n_rows, double *dx);
+extern "C" int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *all, const uint8_t *flags, int max_sel,
+                                      int k, const int *col_to_state, int ld, double sigma2, double chi2_mult, double *lines_out,
+                                      uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx);

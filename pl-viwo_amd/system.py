@@ -46,6 +46,28 @@ def quat_left_update(q, dth):
     return r / np.linalg.norm(r)
 
 
+def quats_2_Rots(Q):
+    """quat_2_Rot for a stack of quaternions [n][4] -> [n][3][3] (one numpy pass per window instead of a Python call per clone)."""
+    Q = np.asarray(Q, dtype=np.float64).reshape(-1, 4)
+    v, w = Q[:, :3], Q[:, 3]
+    K = np.zeros((len(Q), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -v[:, 2], v[:, 1], v[:, 2], -v[:, 0], -v[:, 1], v[:, 0]
+    return (2 * w * w - 1)[:, None, None] * np.eye(3) - (2 * w)[:, None, None] * K + 2 * v[:, :, None] * v[:, None, :]
+
+
+def quats_left_update(Q, dth):
+    """quat_left_update for stacks: Q [n][4], dth [n][3]."""
+    Q = np.asarray(Q, dtype=np.float64).reshape(-1, 4)
+    dq = np.concatenate([0.5 * np.asarray(dth, dtype=np.float64).reshape(-1, 3), np.ones((len(Q), 1))], axis=1)
+    dq /= np.linalg.norm(dq, axis=1)[:, None]
+    a, b, v, w = dq[:, :3], dq[:, 3], Q[:, :3], Q[:, 3]
+    r = np.empty_like(Q)
+    r[:, :3] = b[:, None] * v - np.cross(a, v) + a * w[:, None]
+    r[:, 3] = -np.einsum("ij,ij->i", a, v) + b * w
+    r[r[:, 3] < 0] *= -1
+    return r / np.linalg.norm(r, axis=1)[:, None]
+
+
 class Stat:
     """viw::STAT (REF: PL-VIWO/src/utils/Jabdongsani.cpp:8-33), float arithmetic as there."""
 
@@ -193,8 +215,9 @@ class State:
         cl = [self.clone_at(t) for t in ts]
         oc, pc = self.intr_cov()
         c = self.op.est.cam
-        return StateView(ts, [x.Rot() for x in cl], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
-                         clone_R_fej=[x.Rot_fej() for x in cl], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
+        R = quats_2_Rots([x.q for x in cl] + [x.q_fej for x in cl])
+        return StateView(ts, R[:len(cl)], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
+                         clone_R_fej=R[len(cl):], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
                          extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
                          sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
                          feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp)
@@ -219,8 +242,12 @@ class State:
         for var, size in ((self.cam_ext, 6), (self.cam_intr, 8), (self.cam_dt, 1), (self.wheel_dt, 1), (self.wheel_ext, 6), (self.wheel_intr, 3)):
             if var is not None and var.id >= 0:
                 var.update(dx[var.id:var.id + size])
-        for c in self.clones.values():
-            c.update(dx[c.id:c.id + 6])
+        cl = list(self.clones.values())
+        if cl:
+            d = np.array([dx[c.id:c.id + 6] for c in cl])
+            Q = quats_left_update([c.q for c in cl], d[:, :3])
+            for i, c in enumerate(cl):
+                c.q, c.p = Q[i], c.p + d[i, 3:]
         for lm in self.slam.values():
             lm.p = lm.p + dx[lm.id:lm.id + 3]
         if self.cam_intr is not None and self.op.est.cam.do_calib_int:
