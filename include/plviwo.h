@@ -431,6 +431,10 @@ int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, co
  * cfg.line_min_length_px^2.  Works on the equalised image of the current (PLV_PYR_CUR) or previous
  * frame held by the ctx; lines = x1 y1 x2 y2 full-resolution pixels, in the detector's output order. */
 int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out);
+/* With the prefetch on, plv_tracker_feed / _staged / _downsampled run the line detector of the new image themselves: resize + Canny
+ * go on the stream ahead of the point front-end, the host walks the edge chains and grows the segments while the device runs LK and
+ * RANSAC, and the following plv_line_tracker_feed of the same frame takes the finished detection (same segments as without). */
+int plv_line_prefetch_mode(plv_ctx *ctx, int on);
 /* Optional first half of the detector for the image `which`: enqueues the resize, the Canny map and their copies to the host on the
  * ctx's stream and returns.  The next detection of the same image (plv_detect_lines, plv_line_tracker_feed[_points]) then only
  * waits for those copies before its host stage, so that work enqueued in between (plv_perform_matching_launch) runs on the device

@@ -168,7 +168,9 @@ def load_library():
         "plv_detect_lines": (C.c_int, [vp, C.c_int, fp, C.c_int, ip]),
         "plv_line_detect_launch": (C.c_int, [vp, C.c_int]),
         "plv_line_detect_finish": (C.c_int, [vp, C.c_int]),
+        "plv_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
+        "plv_line_prefetch_mode": (C.c_int, [vp, C.c_int]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
         "plv_line_match": (C.c_int, [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]),
         "plv_line_classification": (C.c_int, [fp, dp]),
@@ -605,7 +607,6 @@ def counters():
     """plv_counters: dict(launches, syncs, copies, copy_bytes, lk_iters, lines_detected) since the library was loaded"""
     lib = load_library()
     out = (C.c_ulonglong * 6)()
-    lib.plv_counters.restype = None
     lib.plv_counters(out)
     return dict(zip(("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected"), [int(x) for x in out]))
 
@@ -1042,6 +1043,9 @@ class Context:
 
     def line_detect_finish(self, which=0):
         self._chk(self.lib.plv_line_detect_finish(self.h, which))
+
+    def line_prefetch_mode(self, on):
+        self._chk(self.lib.plv_line_prefetch_mode(self.h, 1 if on else 0))
 
     def line_walk_mode(self, on_device):
         self._chk(self.lib.plv_line_walk_mode(self.h, 1 if on_device else 0))

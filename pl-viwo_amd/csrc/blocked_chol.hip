@@ -54,7 +54,8 @@ struct CompressOps {
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
                                                                       double *__restrict__ R, int ldr,
-                                                                      double *__restrict__ z) {
+                                                                      double *__restrict__ z, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
   __shared__ BcLds lds;
   __shared__ double sc[256];  // [0,128) 1/sqrt(d), [128,256) sqrt(d)
   const int k = nc - 1;
@@ -103,8 +104,9 @@ template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *__restrict__ S, int lds_, int r,
                                                          const double *__restrict__ Mt, int ldm, int n,
                                                          const double *__restrict__ res, double *__restrict__ W, int ldw,
-                                                         int *__restrict__ flag) {
+                                                         int *__restrict__ flag, const int *__restrict__ skip) {
   __shared__ BcLds lds;
+  if (skip && *skip == 0) return;
   EkfOps ops{S, lds_, r, Mt, ldm, n, res, W, ldw};
   if (threadIdx.x == 0) {
     lds.bad = 0;
@@ -125,13 +127,13 @@ int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, 
   if (k > 128) return PLV_E_CAPACITY;
   ProfScope ps(ctx->prof, "bchol_compress_kernel", ctx->stream);
   if (k <= 32)
-    hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z);
+    hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   else if (k <= 64)
-    hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z);
+    hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   else if (k <= 112)
-    hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z);
+    hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   else
-    hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z);
+    hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -143,16 +145,16 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);
   if (r <= 32)
     hipLaunchKernelGGL(bchol_ekf_kernel<2>, dim3(groups), dim3(64 * 3), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag);
+                       ldw, d_flag, ctx->skip_word);
   else if (r <= 64)
     hipLaunchKernelGGL(bchol_ekf_kernel<4>, dim3(groups), dim3(64 * 5), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag);
+                       ldw, d_flag, ctx->skip_word);
   else if (r <= 112)
     hipLaunchKernelGGL(bchol_ekf_kernel<7>, dim3(groups), dim3(64 * 8), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag);
+                       ldw, d_flag, ctx->skip_word);
   else
     hipLaunchKernelGGL(bchol_ekf_kernel<8>, dim3(groups), dim3(64 * 9), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag);
+                       ldw, d_flag, ctx->skip_word);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

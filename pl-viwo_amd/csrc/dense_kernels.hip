@@ -37,7 +37,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 #define GRAM_CH 64
 #define GRAM_WAVES 16
 __global__ void __launch_bounds__(64 * GRAM_WAVES) gram_chunk_kernel(const double *__restrict__ A, int lda, int m, int nc,
-                                                                      double *__restrict__ part /* [chunk][tile][4][64] */) {
+                                                                      double *__restrict__ part /* [chunk][tile][4][64] */, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
   extern __shared__ double As[];  // [nc][GRAM_CH + 1]
   const int row0 = blockIdx.x * GRAM_CH;
   const int rows = min(GRAM_CH, m - row0);
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) gram_chunk_kernel(const doubl
 }
 
 __global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restrict__ part, int nchunks, int nc,
-                                                          double *__restrict__ G) {
+                                                          double *__restrict__ G, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
   const int nt = (nc + 15) >> 4, ntri = nt * (nt + 1) / 2;
   const int tile = blockIdx.x;
   int rem = tile, ti = 0;
@@ -99,7 +101,8 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restri
 // [dC | dx] = W[:, :n]^T [W[:, :n] | y]  (upper tiles; dC = K M^T of the reference, y = W[:, n]).
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
                                                      double *__restrict__ dC, int ldc, double *__restrict__ dx,
-                                                     const double *__restrict__ P, int ldp, int *__restrict__ flag) {
+                                                     const double *__restrict__ P, int ldp, int *__restrict__ flag, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -134,10 +137,17 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
                                                          const double *__restrict__ dC, int ldc, const int *__restrict__ flag,
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
-                                                         int mirror_words) {
-  if (blockIdx.x == 0 && mirror_dst)
-    for (int i = threadIdx.x; i < mirror_words; i += blockDim.x) mirror_dst[i] = mirror_src[i];
-  if (*flag != 0) return;
+                                                         int mirror_words, const int *__restrict__ skip, double *__restrict__ dx) {
+  const bool skipped = skip && *skip == 0;  // the gate accepted nothing: no correction, the covariance stays
+  if (blockIdx.x == 0) {
+    if (skipped && dx) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.0;
+      __syncthreads();
+    }
+    if (mirror_dst)
+      for (int i = threadIdx.x; i < mirror_words; i += blockDim.x) mirror_dst[i] = mirror_src[i];
+  }
+  if (skipped || *flag != 0) return;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
     int j = idx / n, i = idx - j * n;
     if (i <= j) {
@@ -165,11 +175,11 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
     ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
     const size_t shm = (size_t)nc * (GRAM_CH + 1) * sizeof(double);
     PLV_HIP_CHECK(ensure_dyn_smem((const void *)gram_chunk_kernel, (int)shm));
-    hipLaunchKernelGGL(gram_chunk_kernel, dim3(nchunks), dim3(64 * GRAM_WAVES), shm, ctx->stream, d_A, lda, m, nc, d_part);
+    hipLaunchKernelGGL(gram_chunk_kernel, dim3(nchunks), dim3(64 * GRAM_WAVES), shm, ctx->stream, d_A, lda, m, nc, d_part, ctx->skip_word);
   }
   {
     ProfScope ps(ctx->prof, "gram_reduce_kernel", ctx->stream);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_part, nchunks, nc, d_G);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_part, nchunks, nc, d_G, ctx->skip_word);
   }
   return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
 }
@@ -192,12 +202,12 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
     int tn = cdiv(n + 1, 16);
     int waves = tn * (tn + 1) / 2;
-    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag);
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word);
   }
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
-                       d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4));
+                       d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -13,8 +13,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -48,6 +51,7 @@ struct LineTracker {
   std::vector<uint64_t> rel_id_last;
   uint64_t currid = 1;  // REF: TrackLSD.cpp:32, ids are pre-incremented (:234)
   bool walk_on_device = false;  // plv_line_walk_mode
+  bool prefetch = false;        // plv_line_prefetch_mode: plv_tracker_feed* detects the lines of the new image ahead of plv_line_tracker_feed
   std::unordered_map<uint64_t, LineTrack> db;
   // device buffers of the detector
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
@@ -58,6 +62,22 @@ struct LineTracker {
   std::vector<float> cached;  // plv_line_detect_finish: the segments of image `cached_which` of frame `cached_fed`
   int cached_which = -1, cached_fed = -1;
   std::mutex mtx;
+  // Host stage of the detector (wait for the edge maps, chain walk, segment growth) on a worker thread: plv_line_detect_launch
+  // hands it a job, the caller's thread goes on enqueuing / waiting for the point front-end, whoever needs the segments joins.
+  struct Job {
+    int device = 0, w = 0, h = 0, length_threshold = 0;
+    float distance_threshold = 0, thr2 = 0;
+    const uint8_t *hmap = nullptr, *hhalf = nullptr;
+    int2 *hpts = nullptr;
+    FldChain *hc = nullptr;
+    std::vector<float> lines;
+    int rc = PLV_OK;
+  } job;
+  std::thread worker;
+  std::mutex jm;
+  std::condition_variable jcv;
+  int job_state = 0;  // 0 idle, 1 posted, 2 done; -1 quit
+  std::chrono::steady_clock::time_point job_posted;
 };
 
 std::mutex g_mtx;
@@ -150,6 +170,81 @@ void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *p
   counts[2] = n_pts;
 }
 
+// The host stage on the maps a job points to: chains in raster order of their seeds = the detector's output order; the tail of
+// perform_detection_monocular (x2, FilterShortLines) on every segment.
+int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
+  auto T1 = std::chrono::steady_clock::now();
+  int hcounts[4] = {0, 0, 0, 0};
+  walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad);
+  auto T2 = std::chrono::steady_clock::now();
+  J.lines.clear();
+  if (hcounts[0] >= kChainCap) {
+    set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
+    return PLV_E_CAPACITY;
+  }
+  std::vector<float4> seg;
+  for (int c = 0; c < hcounts[0]; ++c) {
+    seg.resize((size_t)J.hc[c].len / J.length_threshold + 1);
+    const int ns = fit_chain(J.hhalf, J.w, J.h, J.length_threshold, J.distance_threshold, J.hpts + J.hc[c].start, J.hc[c].len, seg.data());
+    for (int q = 0; q < ns; ++q) {
+      const float4 &sg = seg[q];
+      const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+      const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+      if (!(l2 > J.thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+      J.lines.insert(J.lines.end(), {x1, y1, x2, y2});
+    }
+  }
+  if (timing) {
+    auto T3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    size_t edges = 0;
+    for (size_t i = 0; i < (size_t)J.w * J.h; ++i) edges += J.hmap[i] == 2;
+    fprintf(stderr, "walk %.1f us, fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T1, T2), us(T2, T3), hcounts[0],
+            hcounts[2], edges);
+  }
+  return PLV_OK;
+}
+
+void line_worker(LineTracker *T) {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(T->jm);
+      T->jcv.wait(lk, [&] { return T->job_state == 1 || T->job_state == -1; });
+      if (T->job_state == -1) return;
+    }
+    static const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+    auto W0 = std::chrono::steady_clock::now();
+    (void)hipSetDevice(T->job.device);
+    int rc = PLV_OK;
+    if (plv::event_sync(T->edges_ready) != hipSuccess) rc = PLV_E_DEVICE;  // the two maps are on the host
+    auto W1 = std::chrono::steady_clock::now();
+    if (rc == PLV_OK) rc = host_extract(T, T->job, timing);
+    if (timing) {
+      auto W2 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      fprintf(stderr, "line worker: woke %.1f us after the post, edge maps %.1f us, walk + fit %.1f us\n", us(T->job_posted, W0), us(W0, W1), us(W1, W2));
+    }
+    {
+      std::lock_guard<std::mutex> lk(T->jm);
+      T->job.rc = rc;
+      if (T->job_state == 1) T->job_state = 2;
+    }
+    T->jcv.notify_all();
+  }
+}
+// waits for a posted job; true when one was in flight (its result is then in T->job)
+bool join_job(LineTracker *T) {
+  std::unique_lock<std::mutex> lk(T->jm);
+  if (T->job_state == 0) return false;
+  auto J0 = std::chrono::steady_clock::now();
+  T->jcv.wait(lk, [&] { return T->job_state == 2; });
+  T->job_state = 0;
+  if (getenv("PLV_LINE_TIMING"))
+    fprintf(stderr, "line join: waited %.1f us (posted %.1f us ago)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - J0).count(),
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
+  return true;
+}
+
 // detection on the device + the host tail of perform_detection_monocular (x2, FilterShortLines)
 int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, bool launch_only = false) {
   const bool prelaunched = !launch_only && !T->walk_on_device && T->pending_which == which && T->pending_fed == plv_front_fed_count(ctx);
@@ -190,50 +285,46 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     // The chain walk consumes edge pixels in raster order and every step depends on the one before, and so does the growth of
     // the segments along a chain: one dependent scalar sequence of ~10^4 .. 3*10^4 steps.  One MI355X lane retires such a step
     // in ~0.8 us (measured: 28 ms per frame for the walk on the dense-edge test image, 160 us for fld_fit_kernel's longest
-    // chain), a host core in ~30 ns, so both run here on the 90 KB edge map and the half-resolution image (DESIGN.md "Line
+    // chain), a host core in ~30 ns, so both run on the host on the 90 KB edge map and the half-resolution image (DESIGN.md "Line
     // detector"); the pixel work (resize, Sobel, non-maximum suppression, hysteresis) stays on the device.
-    uint8_t *hmap = (uint8_t *)(hp + bytes);
-    uint8_t *hhalf = hmap + npix;
-    int2 *hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
     const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
-    auto T0 = std::chrono::steady_clock::now();
-    if (prelaunched) {  // plv_line_detect_launch put the kernels and the two copies on the stream: wait for those only
-      PLV_HIP_CHECK(plv::event_sync(T->edges_ready));
-    } else {
-      PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-      PLV_HIP_CHECK(plv::memcpy_async(hhalf, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-      if (launch_only) {
-        if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
-        PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
-        T->pending_which = which;
-        T->pending_fed = plv_front_fed_count(ctx);
+    if (prelaunched) {  // plv_line_detect_launch posted the job: the worker thread has been walking meanwhile
+      const bool had = join_job(T);
+      if (had && T->job.rc == PLV_OK) {
+        lines.swap(T->job.lines);
+        ctx->prof.collect();
         return PLV_OK;
       }
-      PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+      if (had && T->job.rc != PLV_OK) return T->job.rc;
+    } else {
+      (void)join_job(T);  // a stale job (another image / frame) must be off the buffers before they are reused
     }
-    auto T1 = std::chrono::steady_clock::now();
-    FldChain *hc = (FldChain *)(hp + 16);
-    int hcounts[4] = {0, 0, 0, 0};
-    walk_chains(hmap, w, h, fp.length_threshold, hpts, hc, kChainCap, hcounts, T->pad);
-    auto T2 = std::chrono::steady_clock::now();
-    if (hcounts[0] >= kChainCap) {
-      set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
-      return PLV_E_CAPACITY;
+    LineTracker::Job &J = T->job;
+    J.device = ctx->device, J.w = w, J.h = h, J.length_threshold = fp.length_threshold, J.distance_threshold = fp.distance_threshold;
+    J.thr2 = thr2;
+    uint8_t *hmap = (uint8_t *)(hp + bytes);
+    J.hmap = hmap, J.hhalf = hmap + npix;
+    J.hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
+    J.hc = (FldChain *)(hp + 16);
+    PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (launch_only) {
+      if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
+      PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
+      T->pending_which = which;
+      T->pending_fed = plv_front_fed_count(ctx);
+      if (!T->worker.joinable()) T->worker = std::thread(line_worker, T);
+      {
+        std::lock_guard<std::mutex> lk(T->jm);
+        T->job_state = 1;
+        T->job_posted = std::chrono::steady_clock::now();
+      }
+      T->jcv.notify_all();
+      return PLV_OK;
     }
-    std::vector<float4> seg;
-    for (int c = 0; c < hcounts[0]; ++c) {  // chains are in raster order of their seeds = the detector's output order
-      seg.resize((size_t)hc[c].len / fp.length_threshold + 1);
-      const int ns = fit_chain(hhalf, w, h, fp.length_threshold, fp.distance_threshold, hpts + hc[c].start, hc[c].len, seg.data());
-      for (int q = 0; q < ns; ++q) emit(seg[q]);
-    }
-    if (timing) {
-      auto T3 = std::chrono::steady_clock::now();
-      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-      size_t edges = 0;
-      for (size_t i = 0; i < npix; ++i) edges += hmap[i] == 2;
-      fprintf(stderr, "edges+d2h %.1f us, walk %.1f us, fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T0, T1), us(T1, T2),
-              us(T2, T3), hcounts[0], hcounts[2], edges);
-    }
+    PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+    TRY(host_extract(T, J, timing));
+    lines.swap(J.lines);
     ctx->prof.collect();
     return PLV_OK;
   }
@@ -272,15 +363,27 @@ struct Assign {
 
 void assign_points(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A, float assign_px = 5.0f) {
   A = Assign();
+  // ~200 lines x ~250 points box tests per frame: the coordinates are split once so that the test of one line against all points is
+  // a branch-free pass the compiler vectorises (the reference compares the float coordinates as doubles: same outcome), and only the
+  // few points inside a box go through the distance test
+  std::vector<float> xs(np), ys(np);
+  std::vector<int> hit((size_t)np + 1);
+  for (int j = 0; j < np; ++j) xs[j] = pts[2 * j], ys[j] = pts[2 * j + 1];
   for (int i = 0; i < nl; ++i) {
     // REF :753-764 reads (x1, y1, x2, y2) as (lx1, lx2, ly1, ly2): kept as is
-    const double lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];
-    const double min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
+    const float lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];
+    const float min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
+    int nh = 0;
+    for (int j = 0; j < np; ++j) {
+      hit[nh] = j;
+      nh += (int)(xs[j] >= min_lx) & (int)(xs[j] <= max_lx) & (int)(ys[j] >= min_ly) & (int)(ys[j] <= max_ly);
+    }
+    if (nh == 0) continue;
     std::map<int, double> on;
     size_t first_pos = A.pos.size();
-    for (int j = 0; j < np; ++j) {
-      const float x = pts[2 * j], y = pts[2 * j + 1];
-      if (x < min_lx || x > max_lx || y < min_ly || y > max_ly) continue;
+    for (int q = 0; q < nh; ++q) {
+      const int j = hit[q];
+      const float x = xs[j], y = ys[j];
       const float d = point_line_distance(lines + 4 * i, x, y);
       if (d > assign_px) continue;
       on[(int)ids[j]] = d;
@@ -345,6 +448,15 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
   auto it = g_lt.find(ctx);
   if (it != g_lt.end()) {
     LineTracker *T = it->second;
+    if (T->worker.joinable()) {
+      {
+        std::unique_lock<std::mutex> lk(T->jm);
+        T->jcv.wait(lk, [&] { return T->job_state != 1; });  // let a posted job finish: it reads the pinned buffer released below
+        T->job_state = -1;
+      }
+      T->jcv.notify_all();
+      T->worker.join();
+    }
     DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out};
     for (DevBuf *b : bufs) b->release();
     T->pin.release();
@@ -359,6 +471,23 @@ int plv_line_walk_mode(plv_ctx *ctx, int on_device) {
   std::lock_guard<std::mutex> lk(T->mtx);
   T->walk_on_device = on_device != 0;
   return PLV_OK;
+}
+
+int plv_line_prefetch_mode(plv_ctx *ctx, int on) {
+  if (!ctx) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  T->prefetch = on != 0;
+  return PLV_OK;
+}
+int plv_line_prefetch_enabled(plv_ctx *ctx) {
+  {
+    std::lock_guard<std::mutex> lk(g_mtx);
+    if (g_lt.find(ctx) == g_lt.end()) return 0;  // no line tracker was ever touched on this ctx
+  }
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  return T->prefetch && !T->walk_on_device ? 1 : 0;
 }
 
 int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out) {
@@ -467,12 +596,15 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
   } else {
     TRY(detect(ctx, T, PLV_PYR_CUR, lines));
   }
+  const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+  auto F0 = std::chrono::steady_clock::now();
   const int nl = (int)lines.size() / 4;
   plv::counters().lines_detected += (unsigned long long)nl;
   std::vector<uint64_t> ids(nl);
   for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236
   Assign A;
   assign_points(lines.data(), nl, pts, pids, np, A);
+  auto F1 = std::chrono::steady_clock::now();
   const int nk = (int)A.kept.size();
   std::vector<float> fl(4 * (size_t)nk);
   std::vector<uint64_t> fid(nk);
@@ -509,6 +641,11 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
   T->ids_last.swap(fid);
   T->rel_ptr_last = A.rel_ptr;
   T->rel_id_last = A.rel_id;
+  if (timing) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "line feed: assignment %.1f us (%d lines x %d points), match + undistort + classify + store %.1f us (%d kept)\n", us(F0, F1), nl, np,
+            us(F1, std::chrono::steady_clock::now()), nk);
+  }
   return PLV_OK;
 }
 

@@ -627,6 +627,10 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   us->b_gather_token = 0;
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
+  struct SkipGuard {  // the word is only meaningful for the kernels of this update
+    plv_ctx *c;
+    ~SkipGuard() { c->skip_word = nullptr; }
+  } skip_guard{ctx};
   auto enqueue = [&]() -> int {
   if (!projected) {
     // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
@@ -656,6 +660,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
   a.accepted = d_acc;
   a.acc_rows = d_acc_rows;
+  a.n_acc = d_flag + 1;           // second word of the status block
+  ctx->skip_word = d_flag + 1;    // read by every kernel enqueued from here on (cleared after enqueue())
   TRY(launch_chi2(ctx, F, a, mp_max));
 
   const double *dH, *dr;

@@ -221,6 +221,11 @@ struct plv_ctx {
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
   plv::PinBuf h_pin;
 
+  // Device word holding the number of features the gate accepted in the update being enqueued (null outside
+  // plv_msckf_update_resident_launch): the compression and EKF kernels return at once when it is zero — an update in which the gate
+  // took nothing (most line updates) costs their launches, not their pivot chains; ekf_commit_kernel then reports dx = 0.
+  const int *skip_word = nullptr;
+
   // ---- front-end (frontend_api.hip owns the object)
   void *fe_state = nullptr;
 };

@@ -102,8 +102,13 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 }
 
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
+extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
+  // With the line prefetch on (plv_line_prefetch_mode), resize + Canny of the new image and the copies of the two maps go first on
+  // the stream and the library's line worker thread walks the edge chains and grows the segments while this thread runs the point
+  // front-end; plv_line_tracker_feed of the same frame joins it.
+  if (plv_line_prefetch_enabled(ctx)) (void)plv_line_detect_launch(ctx, PLV_PYR_CUR);
   const int cap = std::max(ctx->cfg.num_features * 4, 1024) + (int)T->ids_last.size();
   std::vector<float> pts(2 * (size_t)cap);
   std::vector<uint64_t> ids(cap);

@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kern
       if (pass) pass = (mp < a.q95_n) && (chi < a.chi2_mult * a.q95[mp]);
       a.accepted[f] = pass ? 1 : 0;
       if (a.acc_rows) a.acc_rows[f] = pass ? mp : 0;
+      if (pass && a.n_acc) atomicAdd(a.n_acc, 1);
       passflag = pass ? 1.0 : 0.0;
     }
   }
@@ -354,6 +355,7 @@ __global__ void __launch_bounds__(256) gather_cov_kernel(GatherArgs g) { gather_
 
 // T = Hx' * Ps for every feature at once: one 16x16 tile per wave over (feature, row tile, col tile).
 __global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
+  if (a.n_acc && blockIdx.x == 0 && threadIdx.x == 0) *a.n_acc = 0;  // counted by chi2_gate_kernel, the next launch
   const int kt = (a.k + 15) >> 4;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int per_f = mt_max * kt;
@@ -384,8 +386,9 @@ __global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
 __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ H, int ldh, int r, int k,
                                                      const int *__restrict__ cols, const double *__restrict__ P,
                                                      int ldp, int n, double *__restrict__ Mt, int ldm,
-                                                     int *__restrict__ flag) {
+                                                     int *__restrict__ flag, const int *__restrict__ skip) {
   if (flag && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;  // update status word, set by the kernels that follow
+  if (skip && *skip == 0) return;
   const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= tr_n * tn_n) return;
@@ -411,7 +414,8 @@ __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ 
 // S = Mt[:, cols] * H^T + diag(R)   (r x r, col-major ld = lds_)
 __global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ Mt, int ldm, const double *__restrict__ H,
                                                     int ldh, int r, int k, const int *__restrict__ cols,
-                                                    const double *__restrict__ Rdiag, double *__restrict__ S, int lds_) {
+                                                    const double *__restrict__ Rdiag, double *__restrict__ S, int lds_, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
   const int tn = (r + 15) >> 4;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= tn * tn) return;
@@ -693,13 +697,13 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
     ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
     int tiles = cdiv(r, 16) * cdiv(n, 16);
     hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_inv.as<int>(),
-                       ctx->d_Pc.as<double>(), n, n, Mt, ldm, d_flag);
+                       ctx->d_Pc.as<double>(), n, n, Mt, ldm, d_flag, ctx->skip_word);
   }
   {
     ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
     int tiles = cdiv(r, 16) * cdiv(r, 16);
     hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt + (size_t)(n + 1) * ldm, ldm, d_H, ldh,
-                       r, k, d_cols, d_Rdiag, S, r);
+                       r, k, d_cols, d_Rdiag, S, r, ctx->skip_word);
   }
 }
 

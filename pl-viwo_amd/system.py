@@ -378,6 +378,8 @@ class SystemManager:
         # UpdaterCamera
         self.cam_t_hist = []
         self.use_lines = bool(e.cam.enabled and e.cam.use_lines)
+        if self.use_lines and hasattr(self.ctx, "line_prefetch_mode"):
+            self.ctx.line_prefetch_mode(True)     # the tracker feed detects the frame's lines while the device tracks the points
         # UpdaterWheel
         self.whl = SampleBuffer(3)   # t, m1, m2
         self.whl_last_updated = -1.0

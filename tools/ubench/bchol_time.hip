@@ -32,7 +32,7 @@ int main() {
   CK(hipMemset(dst, 0, 16 * 64 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(plv::g_bchol_stamps), &dst, sizeof(dst)));
   for (int it = 0; it < 3; ++it) {
-    hipLaunchKernelGGL(plv::bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, 0, dG, nc, dR, k, dz);
+    hipLaunchKernelGGL(plv::bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, 0, dG, nc, dR, k, dz, (const int *)nullptr);
     CK(hipDeviceSynchronize());
   }
   std::vector<long long> st(16 * 64);
