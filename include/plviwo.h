@@ -435,6 +435,13 @@ int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out)
  * go on the stream ahead of the point front-end, the host walks the edge chains and grows the segments while the device runs LK and
  * RANSAC, and the following plv_line_tracker_feed of the same frame takes the finished detection (same segments as without). */
 int plv_line_prefetch_mode(plv_ctx *ctx, int on);
+/* plv_line_tracker_feed without waiting for it: with the prefetch on, the rest of TrackLSD::feed_monocular (point-line assignment,
+ * matching, classification, track store) runs on the library's line worker thread behind the detection, so the caller can enqueue
+ * the point update (plv_camera_update_points) meanwhile; both only read the tracker's output of this frame, as feed_measurement
+ * precedes try_update in the reference (UpdaterCamera.cpp:77-116 before :139-195).  Every line entry point joins the feed first;
+ * plv_line_tracker_feed_wait joins and returns its status.  Without a detection in flight the call is plv_line_tracker_feed. */
+int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vps);
+int plv_line_tracker_feed_wait(plv_ctx *ctx);
 /* Optional first half of the detector for the image `which`: enqueues the resize, the Canny map and their copies to the host on the
  * ctx's stream and returns.  The next detection of the same image (plv_detect_lines, plv_line_tracker_feed[_points]) then only
  * waits for those copies before its host stage, so that work enqueued in between (plv_perform_matching_launch) runs on the device

@@ -171,6 +171,8 @@ def load_library():
         "plv_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_prefetch_mode": (C.c_int, [vp, C.c_int]),
+        "plv_line_tracker_feed_async": (C.c_int, [vp, C.c_double, dp]),
+        "plv_line_tracker_feed_wait": (C.c_int, [vp]),
         "plv_assign_points_to_lines": (C.c_int, [fp, C.c_int, fp, u64p, C.c_int, ip, ip, u64p, dp, ip, fp, ip]),
         "plv_line_match": (C.c_int, [fp, C.c_int, ip, u64p, fp, C.c_int, ip, u64p, ip]),
         "plv_line_classification": (C.c_int, [fp, dp]),
@@ -1043,6 +1045,13 @@ class Context:
 
     def line_detect_finish(self, which=0):
         self._chk(self.lib.plv_line_detect_finish(self.h, which))
+
+    def line_tracker_feed_async(self, timestamp, vps):
+        v = _c64(vps)
+        self._chk(self.lib.plv_line_tracker_feed_async(self.h, float(timestamp), _dp(v)))
+
+    def line_tracker_feed_wait(self):
+        self._chk(self.lib.plv_line_tracker_feed_wait(self.h))
 
     def line_prefetch_mode(self, on):
         self._chk(self.lib.plv_line_prefetch_mode(self.h, 1 if on else 0))

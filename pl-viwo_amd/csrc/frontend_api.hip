@@ -92,6 +92,7 @@ int sync(plv_ctx *ctx) {
 
 // equalize + pyramid of the packed device image d_img into the next "current" pyramid
 int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
+  plv::HostPhase ph("feed image (enqueue hist + pyramid)");
   const int next = s->fed == 0 ? s->cur : 1 - s->cur;
   PyrDesc &p = s->pyr[next];
   const int npix = s->W * s->H;

@@ -28,6 +28,7 @@
 
 using namespace plv;
 
+int plv_tracker_last(plv_ctx *ctx, float *pts, uint64_t *ids, int cap, int *n);
 namespace {
 
 #define TRY(expr)                  \
@@ -77,19 +78,22 @@ struct LineTracker {
   std::mutex jm;
   std::condition_variable jcv;
   int job_state = 0;  // 0 idle, 1 posted, 2 done; -1 quit
+  // plv_line_tracker_feed_async: the rest of TrackLSD::feed_monocular (assignment, matching, classification, track store) as a
+  // second job of the same thread.  While it is posted the worker owns the tracker state; every entry point joins it first (ltr()).
+  struct FeedJob {
+    plv_ctx *ctx = nullptr;
+    double timestamp = 0, vps[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> pts;
+    std::vector<uint64_t> pids;
+    int rc = PLV_OK;
+  } feed;
+  int feed_state = 0;  // 0 idle, 1 posted, 2 done
   std::chrono::steady_clock::time_point job_posted;
 };
 
 std::mutex g_mtx;
 std::unordered_map<plv_ctx *, LineTracker *> g_lt;
-LineTracker *ltr(plv_ctx *ctx) {
-  std::lock_guard<std::mutex> lk(g_mtx);
-  auto it = g_lt.find(ctx);
-  if (it != g_lt.end()) return it->second;
-  auto *t = new LineTracker();
-  g_lt[ctx] = t;
-  return t;
-}
+LineTracker *ltr(plv_ctx *ctx);  // (defined after LineTracker's worker protocol)
 
 const int kChainCap = 4096;
 
@@ -205,12 +209,28 @@ int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
   return PLV_OK;
 }
 
+// (feed_points_impl is defined further down, outside this namespace: the worker reaches it through this pointer)
+int (*g_feed_impl)(plv_ctx *, LineTracker *, double, const double *, int, const float *, const uint64_t *) = nullptr;
 void line_worker(LineTracker *T) {
   for (;;) {
+    bool do_detect = false, do_feed = false;
     {
       std::unique_lock<std::mutex> lk(T->jm);
-      T->jcv.wait(lk, [&] { return T->job_state == 1 || T->job_state == -1; });
+      T->jcv.wait(lk, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1; });
       if (T->job_state == -1) return;
+      do_detect = T->job_state == 1;
+      do_feed = !do_detect && T->feed_state == 1;
+    }
+    if (do_feed) {
+      LineTracker::FeedJob &F = T->feed;
+      const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data());
+      {
+        std::lock_guard<std::mutex> lk(T->jm);
+        F.rc = rc;
+        T->feed_state = 2;
+      }
+      T->jcv.notify_all();
+      continue;
     }
     static const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
     auto W0 = std::chrono::steady_clock::now();
@@ -243,6 +263,28 @@ bool join_job(LineTracker *T) {
     fprintf(stderr, "line join: waited %.1f us (posted %.1f us ago)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - J0).count(),
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
   return true;
+}
+
+// Every entry point reaches the tracker through here: an asynchronous feed still running on the worker is joined first (its status
+// is kept for plv_line_tracker_feed_wait).
+LineTracker *ltr(plv_ctx *ctx) {
+  LineTracker *T;
+  {
+    std::lock_guard<std::mutex> lk(g_mtx);
+    auto it = g_lt.find(ctx);
+    if (it == g_lt.end()) {
+      T = new LineTracker();
+      g_lt[ctx] = T;
+      return T;
+    }
+    T = it->second;
+  }
+  std::unique_lock<std::mutex> lk(T->jm);
+  if (T->feed_state != 0) {
+    T->jcv.wait(lk, [&] { return T->feed_state == 2; });
+    T->feed_state = 0;
+  }
+  return T;
 }
 
 // detection on the device + the host tail of perform_detection_monocular (x2, FilterShortLines)
@@ -291,8 +333,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     if (prelaunched) {  // plv_line_detect_launch posted the job: the worker thread has been walking meanwhile
       const bool had = join_job(T);
       if (had && T->job.rc == PLV_OK) {
-        lines.swap(T->job.lines);
-        ctx->prof.collect();
+        lines.swap(T->job.lines);  // (no profiler collection here: this branch may run on the worker thread)
         return PLV_OK;
       }
       if (had && T->job.rc != PLV_OK) return T->job.rc;
@@ -451,7 +492,7 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
     if (T->worker.joinable()) {
       {
         std::unique_lock<std::mutex> lk(T->jm);
-        T->jcv.wait(lk, [&] { return T->job_state != 1; });  // let a posted job finish: it reads the pinned buffer released below
+        T->jcv.wait(lk, [&] { return T->job_state != 1 && T->feed_state != 1; });  // let posted jobs finish: they read what is released below
         T->job_state = -1;
       }
       T->jcv.notify_all();
@@ -584,11 +625,18 @@ int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
   return plv_line_tracker_feed_points(ctx, timestamp, vps, np, pts.data(), pids.data());
 }
 
+static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids);
 int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
   if (!ctx || !vps || np < 0 || (np > 0 && (!pts || !pids))) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   LineTracker *T = ltr(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
+  return feed_points_impl(ctx, T, timestamp, vps, np, pts, pids);
+}
+
+// TrackLSD::feed_monocular after the histogram equalisation, on the tracker state of T (the caller holds T->mtx or is the worker)
+static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
+  plv::HostPhase ph_all("line_tracker_feed: whole call");
   std::vector<float> lines;
   if (T->cached_which == PLV_PYR_CUR && T->cached_fed == plv_front_fed_count(ctx)) {
     lines.swap(T->cached);  // detected ahead of time for this very frame (plv_line_detect_finish)
@@ -647,6 +695,42 @@ int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *v
             us(F1, std::chrono::steady_clock::now()), nk);
   }
   return PLV_OK;
+}
+
+int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vps) {
+  if (!ctx || !vps) return PLV_E_BADARG;
+  int np = 0;
+  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  LineTracker::FeedJob &F = T->feed;
+  F.pts.resize(2 * (size_t)std::max(np, 1));
+  F.pids.resize((size_t)std::max(np, 1));
+  TRY(plv_tracker_last(ctx, F.pts.data(), F.pids.data(), np, &np));
+  F.pts.resize(2 * (size_t)np);
+  F.pids.resize((size_t)np);
+  const bool detecting = !T->walk_on_device && T->worker.joinable() && T->pending_which == PLV_PYR_CUR && T->pending_fed == plv_front_fed_count(ctx);
+  if (!detecting) {  // no detection of this frame on the worker: nothing to overlap with, and the detector's HIP calls stay on this thread
+    F.rc = feed_points_impl(ctx, T, timestamp, vps, np, F.pts.data(), F.pids.data());
+    return F.rc;
+  }
+  g_feed_impl = feed_points_impl;
+  F.ctx = ctx;
+  F.timestamp = timestamp;
+  std::copy(vps, vps + 6, F.vps);
+  F.rc = PLV_OK;
+  {
+    std::lock_guard<std::mutex> lk2(T->jm);
+    T->feed_state = 1;
+  }
+  T->jcv.notify_all();
+  return PLV_OK;
+}
+
+int plv_line_tracker_feed_wait(plv_ctx *ctx) {
+  if (!ctx) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);  // joins
+  return T->feed.rc;
 }
 
 int plv_line_tracker_last(plv_ctx *ctx, float *lines, uint64_t *ids, int cap, int *n) {
@@ -755,6 +839,11 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
+  static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
+  plv::HostPhase ph_all("update_lines: whole call");
+  plv::HostPhase ph_pool("update_lines: pool + staging");
+  const auto U0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
   struct Cand {
     uint64_t id;
@@ -822,8 +911,8 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       const bool is_new = T->db.find(kv.first) == T->db.end();
       LineTrack &d = T->db[kv.first];
       if (is_new) {
-        d.D = kv.second.D;
-        d.points = kv.second.points;
+        d = std::move(kv.second);
+        continue;
       }
       d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
       d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
@@ -852,7 +941,12 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     }
     return rc;
   };
-  auto give_back_all = [&](const Cand &c) {
+  auto give_back_all = [&](Cand &c) {
+    if (unused.find(c.id) == unused.end()) {  // nothing of this line went back earlier: hand the track over as it is
+      unused.emplace(c.id, std::move(c.tr));
+      c.tr = LineTrack{};
+      return;
+    }
     for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c, i);
   };
   std::fill(dx, dx + ctx->cov_n, 0.0);
@@ -869,7 +963,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     std::vector<uint8_t> okq(tq.size());
     int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
     if (rc0 != PLV_OK) {
-      for (const Cand &c : pool) give_back_all(c);
+      for (Cand &c : pool) give_back_all(c);
       return finish(rc0);
     }
     size_t o = 0;
@@ -943,6 +1037,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   // ---- one submission (see plv_camera_update_points): line triangulation, the selection below, Jacobians, null space, gate,
   // compression and EKFUpdate back to back on the stream, one synchronisation.  CPI poses and over-long tracks take the two-step route.
   const bool fused = !opt->cpi && most_valid <= opt->max_obs;
+  const double us_pool = since(U0);
+  ph_pool.stop();
+  plv::HostPhase ph_dev("update_lines: device submission + wait");
+  const auto U1 = std::chrono::steady_clock::now();
   std::vector<uint8_t> acc_all(Lp, 0);
   bool fused_ran = false;
   if (fused) {
@@ -962,7 +1060,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
         fused_ran = rc == PLV_OK;
       }
       if (rc != PLV_OK) {
-        for (const Cand &c : pool) give_back_all(c);
+        for (Cand &c : pool) give_back_all(c);
         return finish(rc);
       }
     } else {
@@ -971,10 +1069,14 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   } else {
     rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
     if (rc != PLV_OK) {
-      for (const Cand &c : pool) give_back_all(c);
+      for (Cand &c : pool) give_back_all(c);
       return finish(rc);
     }
   }
+  const double us_dev = since(U1);
+  ph_dev.stop();
+  plv::HostPhase ph_post("update_lines: selection + database");
+  if (timing) fprintf(stderr, "update lines: pool + staging %.1f us (%d lines, %d observations), device submission + wait %.1f us\n", us_pool, Lp, nobs, us_dev);
   std::vector<int> sel;
   std::vector<double> t_first(Lp, -1e300);  // oldest observation time a truncated track keeps
   for (int l = 0; l < Lp; ++l) {

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -47,6 +49,50 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
   counters().copy_bytes += bytes;
   return hipMemcpyAsync(dst, src, bytes, kind, s);
 }
+
+// Host-side phase timing (PLV_HOST_TIMING=1): accumulated wall time per label, printed to stderr when the library unloads.
+struct HostPhases {
+  struct Rec {
+    const char *label;
+    double us = 0;
+    long n = 0;
+  };
+  bool on = getenv("PLV_HOST_TIMING") != nullptr;
+  std::mutex mtx;
+  std::vector<Rec> recs;
+  void add(const char *label, double us) {
+    std::lock_guard<std::mutex> lk(mtx);
+    for (auto &r : recs)
+      if (r.label == label || !strcmp(r.label, label)) {
+        r.us += us;
+        ++r.n;
+        return;
+      }
+    recs.push_back(Rec{label, us, 1});
+  }
+  ~HostPhases() {
+    if (!on) return;
+    for (auto &r : recs) fprintf(stderr, "[plv host] %-44s %8ld calls  %9.1f us/call\n", r.label, r.n, r.us / (double)r.n);
+  }
+};
+inline HostPhases &host_phases() {
+  static HostPhases h;
+  return h;
+}
+struct HostPhase {  // scope timer
+  const char *label;
+  std::chrono::steady_clock::time_point t0;
+  bool on;
+  explicit HostPhase(const char *l) : label(l), on(host_phases().on) {
+    if (on) t0 = std::chrono::steady_clock::now();
+  }
+  void stop() {
+    if (!on) return;
+    host_phases().add(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    on = false;
+  }
+  ~HostPhase() { stop(); }
+};
 
 // A grow-only device buffer.
 // Bumped by every device (re)allocation: a captured graph holds raw device pointers, so any growth anywhere retires it.

@@ -105,6 +105,7 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
+  plv::HostPhase ph_all("tracker_feed (after the image feed)");
   // With the line prefetch on (plv_line_prefetch_mode), resize + Canny of the new image and the copies of the two maps go first on
   // the stream and the library's line worker thread walks the edge chains and grows the segments while this thread runs the point
   // front-end; plv_line_tracker_feed of the same frame joins it.
@@ -130,8 +131,11 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   n = (int)T->ids_last.size();
   std::copy(T->pts_last.begin(), T->pts_last.end(), pts.begin());
   std::copy(T->ids_last.begin(), T->ids_last.end(), ids.begin());
-  TRY(plv_perform_detection(ctx, PLV_PYR_LAST, T->mask_last.empty() ? nullptr : T->mask_last.data(), pts.data(), ids.data(), n,
-                            cap, &T->currid, &n));
+  {
+    plv::HostPhase ph("tracker_feed: perform_detection");
+    TRY(plv_perform_detection(ctx, PLV_PYR_LAST, T->mask_last.empty() ? nullptr : T->mask_last.data(), pts.data(), ids.data(), n,
+                              cap, &T->currid, &n));
+  }
   // :134-139 temporal KLT with the previous positions as the initial flow
   std::vector<float> pts_new(pts.begin(), pts.begin() + 2 * (size_t)n), n1(2 * (size_t)std::max(n, 1));
   std::vector<uint8_t> mask_ll((size_t)std::max(n, 1), 0);
@@ -141,7 +145,11 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     keep_mask();
     return PLV_OK;
   }
-  TRY(plv_perform_matching(ctx, n, pts.data(), pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
+  {
+    plv::HostPhase ph("tracker_feed: perform_matching");
+    TRY(plv_perform_matching(ctx, n, pts.data(), pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
+  }
+  plv::HostPhase ph_db("tracker_feed: database update");
   // :158-173 keep in-bounds, unmasked, matched points; :176-179 database update
   std::vector<float> good;
   std::vector<uint64_t> good_ids;
@@ -297,6 +305,8 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
+  plv::HostPhase ph_all("update_points: whole call");
+  plv::HostPhase ph_pool("update_points: pool + staging");
   const double dt = st->cam_dt;
   const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
   struct Cand {
@@ -413,6 +423,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       std::lock_guard<std::mutex> lk(T->mtx);
       for (auto &kv : unused) {  // REF :702-703 / :727-729 append_new_measurements
         Track &d = T->db[kv.first];
+        if (d.t.empty()) {
+          d = std::move(kv.second);
+          continue;
+        }
         d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
         d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
         d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
@@ -423,7 +437,12 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);
     return rc;
   };
-  auto give_back_all = [&](const Cand &c) {
+  auto give_back_all = [&](Cand &c) {
+    if (unused.find(c.id) == unused.end()) {  // nothing of this feature went back earlier: hand the track over as it is
+      unused.emplace(c.id, std::move(c.tr));
+      c.tr = Track{};
+      return;
+    }
     for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
   };
   if (pool.empty()) {
@@ -443,7 +462,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     std::vector<uint8_t> okq(tq.size());
     int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
     if (rc0 != PLV_OK) {
-      for (const Cand &c : pool) give_back_all(c);
+      for (Cand &c : pool) give_back_all(c);
       return finish(rc0);
     }
     size_t o = 0;
@@ -510,6 +529,8 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // reference's, which changes neither dx nor P beyond rounding.  Poses from the CPI table, in-state landmarks and tracks longer
   // than the batch rows take the two-step route (triangulate, select on the host, then build + update).
   const bool fused = !opt->cpi && opt->max_slam == 0 && most_valid <= opt->max_obs;
+  ph_pool.stop();
+  plv::HostPhase ph_dev("update_points: device submission + wait");
   std::vector<uint8_t> acc_all(Fp, 0);
   bool fused_ran = false;
   if (fused) {
@@ -531,22 +552,24 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
         fused_ran = rc == PLV_OK;
       }
       if (rc != PLV_OK) {
-        for (const Cand &c : pool) give_back_all(c);
+        for (Cand &c : pool) give_back_all(c);
         return finish(rc);
       }
     }
   } else {
     rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
     if (rc != PLV_OK) {
-      for (const Cand &c : pool) give_back_all(c);
+      for (Cand &c : pool) give_back_all(c);
       return finish(rc);
     }
   }
+  ph_dev.stop();
+  plv::HostPhase ph_post("update_points: selection + database");
   // ---- REF :648-699 the selection loop
   std::vector<int> sel;
   std::vector<double> t_first(Fp, -1e300);  // oldest observation time a truncated track keeps
   for (int f = 0; f < Fp; ++f) {
-    const Cand &c = pool[f];
+    Cand &c = pool[f];
     if ((int)sel.size() >= opt->max_msckf) {  // :651-653 break; the rest returns to the database (:702)
       give_back_all(c);
       continue;

@@ -92,16 +92,22 @@ class Pose:
         self.q, self.p = np.array(q, dtype=np.float64), np.array(p, dtype=np.float64)
         self.q_fej, self.p_fej = self.q.copy(), self.p.copy()
         self.id = var_id
+        self._R = self._Rf = None     # rotation matrices of q / q_fej, built when first asked for, dropped when q changes
 
     def Rot(self):
-        return quat_2_Rot(self.q)
+        if self._R is None:
+            self._R = quat_2_Rot(self.q)
+        return self._R
 
     def Rot_fej(self):
-        return quat_2_Rot(self.q_fej)
+        if self._Rf is None:
+            self._Rf = quat_2_Rot(self.q_fej)
+        return self._Rf
 
     def update(self, dx):
         self.q = quat_left_update(self.q, dx[0:3])
         self.p = self.p + dx[3:6]
+        self._R = None
 
     def clone(self, var_id):
         c = Pose(self.q, self.p, var_id)
@@ -215,9 +221,8 @@ class State:
         cl = [self.clone_at(t) for t in ts]
         oc, pc = self.intr_cov()
         c = self.op.est.cam
-        R = quats_2_Rots([x.q for x in cl] + [x.q_fej for x in cl])
-        return StateView(ts, R[:len(cl)], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
-                         clone_R_fej=R[len(cl):], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
+        return StateView(ts, [x.Rot() for x in cl], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
+                         clone_R_fej=[x.Rot_fej() for x in cl], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
                          extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
                          sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
                          feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp)
@@ -246,8 +251,9 @@ class State:
         if cl:
             d = np.array([dx[c.id:c.id + 6] for c in cl])
             Q = quats_left_update([c.q for c in cl], d[:, :3])
+            R = quats_2_Rots(Q)
             for i, c in enumerate(cl):
-                c.q, c.p = Q[i], c.p + d[i, 3:]
+                c.q, c.p, c._R = Q[i], c.p + d[i, 3:], R[i]
         for lm in self.slam.values():
             lm.p = lm.p + dx[lm.id:lm.id + 3]
         if self.cam_intr is not None and self.op.est.cam.do_calib_int:
@@ -396,6 +402,7 @@ class SystemManager:
                                          e.init.imu_wheel_thresh, e.gravity, e.init.imu_gravity_aligned)
         self.last_cam_delete_t = -math.inf
         self.tc = TimeChecker()
+        self._lines_in_flight = False
         self.stats = dict(clones=0, cam_updates=0, cam_features=0, cam_accepted=0, line_updates=0, lines_accepted=0, wheel_updates=0, wheel_accepted=0,
                           not_psd=0, frames=0, line_pool=0, lines_triangulated=0, lines_tracked=0, slam_initialized=0, slam_updates=0,
                           slam_marginalized=0)
@@ -569,17 +576,31 @@ class SystemManager:
         else:
             self.ctx.tracker_feed(t, img, mask)
         self.tc.dong("[Time-Cam] feed measurement: points")
+        self._lines_in_flight = False
         if self.use_lines:
             self.tc.ding("[Time-Cam] feed measurement: lines")
             vps = self.ctx.vanishing_points(st.cam_ext.Rot(), st.cam_intr.v)
-            self.ctx.line_tracker_feed(t, vps)
-            self.stats["lines_tracked"] += self.ctx.line_db_size()
+            if st.initialized and hasattr(self.ctx, "line_tracker_feed_async"):
+                # the line tracker's host logic runs on the library's worker thread while this thread enqueues the point update; both
+                # read only what the point tracker produced for this frame (feed_measurement precedes try_update in the reference)
+                self.ctx.line_tracker_feed_async(t, vps)
+                self._lines_in_flight = True
+            else:
+                self.ctx.line_tracker_feed(t, vps)
+                self.stats["lines_tracked"] += self.ctx.line_db_size()
             self.tc.dong("[Time-Cam] feed measurement: lines")
         self._marginalize_slam_features()
         self.stats["frames"] += 1
         if st.initialized:
             self._camera_try_update()
             self.tc.dong("CAM")
+        self._join_lines()
+
+    def _join_lines(self):
+        if self._lines_in_flight:
+            self.ctx.line_tracker_feed_wait()
+            self.stats["lines_tracked"] += self.ctx.line_db_size()
+            self._lines_in_flight = False
 
     def _marginalize_slam_features(self):   # UpdaterCamera.cpp:118-137 + StateHelper::marginalize_slam :203-213
         st = self.state
@@ -620,6 +641,7 @@ class SystemManager:
             self._slam_update_and_init(out)
         if self.use_lines:
             self.tc.ding("[Time-Cam] LINE update")
+            self._join_lines()
             lo = self.ctx.camera_update_lines(st.view(), st.n, self.max_obs, **kw)
             self.stats["line_pool"] += lo["n_pool"]
             self.stats["lines_triangulated"] += lo["n_lines"]
