@@ -303,6 +303,34 @@ inline double det3(const double *m) {
   return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
+// cos(acos(x) / 3) and the cube root from +, -, *, / and sqrt only (all correctly rounded on the host and on gfx950), so that the
+// CPU restatement and the HIP kernel produce the same fundamental-matrix candidates bit for bit; libm's acos / cos / cbrt differ
+// in the last place between the two.  cos(acos(x)/3) is the root of 4 t^3 - 3 t = x in [1/2, 1] (monotone there): 64 bisection
+// steps.  Near x = -1 the root is double (t = 1/2) and only sqrt(eps) of it is determined — as ill-conditioned as the cubic's own
+// roots are there.  The cube root: bit-level first guess, six Newton steps.
+double det_cos_third(double x) {
+  double lo = 0.5, hi = 1.0;
+  for (int it = 0; it < 64; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    const double f = ((4.0 * mid) * mid) * mid - 3.0 * mid - x;
+    if (f < 0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+double det_cbrt(double x) {  // x >= 0
+  if (!(x > 0)) return 0.0;
+  unsigned long long i;
+  memcpy(&i, &x, 8);
+  i = i / 3 + 0x2A9F7893782DA1CEull;
+  double y;
+  memcpy(&y, &i, 8);
+  for (int it = 0; it < 6; ++it) y = y - (y * y * y - x) / (3.0 * y * y);
+  return y;
+}
+
 // real roots of c3 x^3 + c2 x^2 + c1 x + c0 (cv::solveCubic's case analysis, trigonometric form)
 int solve_cubic(double c3, double c2, double c1, double c0, double *roots) {
   if (c3 == 0) {
@@ -325,26 +353,28 @@ int solve_cubic(double c3, double c2, double c1, double c0, double *roots) {
   double Qcubed = Q * Q * Q;
   double d = Qcubed - R * R;
   if (d > 0) {
-    double theta = std::acos(R / std::sqrt(Qcubed));
+    // theta = acos(R / sqrt(Q^3)); the roots are -2 sqrt(Q) cos(theta / 3 + 2 pi k / 3) - a1 / 3
+    double xr = R / std::sqrt(Qcubed);
+    xr = xr < -1.0 ? -1.0 : (xr > 1.0 ? 1.0 : xr);
+    const double ct = det_cos_third(xr), st = std::sqrt(1.0 - ct * ct);
     double sqrtQ = std::sqrt(Q);
-    double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
-    roots[0] = t0 * std::cos(t1) - t2;
-    roots[1] = t0 * std::cos(t1 + (2. * M_PI / 3)) - t2;
-    roots[2] = t0 * std::cos(t1 + (4. * M_PI / 3)) - t2;
+    double t0 = -2 * sqrtQ, t2 = a1 * (1. / 3);
+    roots[0] = t0 * ct - t2;
+    roots[1] = t0 * (-0.5 * ct - 0.8660254037844386 * st) - t2;
+    roots[2] = t0 * (-0.5 * ct + 0.8660254037844386 * st) - t2;
     return 3;
   } else if (d == 0) {
     if (R >= 0) {
-      roots[0] = -2 * std::cbrt(R) - a1 / 3;
-      roots[1] = std::cbrt(R) - a1 / 3;
+      roots[0] = -2 * det_cbrt(R) - a1 / 3;
+      roots[1] = det_cbrt(R) - a1 / 3;
     } else {
-      roots[0] = 2 * std::cbrt(-R) - a1 / 3;
-      roots[1] = -std::cbrt(-R) - a1 / 3;
+      roots[0] = 2 * det_cbrt(-R) - a1 / 3;
+      roots[1] = -det_cbrt(-R) - a1 / 3;
     }
     return 2;
   } else {
-    double e;
     d = std::sqrt(-d);
-    e = std::cbrt(d + std::fabs(R));
+    double e = det_cbrt(d + std::fabs(R));
     if (R > 0) e = -e;
     roots[0] = (e + Q / e) - a1 * (1. / 3);
     return 1;

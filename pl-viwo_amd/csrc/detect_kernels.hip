@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
                                                     const uint8_t *__restrict__ valid, float *__restrict__ xy,
                                                     const float *__restrict__ mask, int win, int max_iters, double eps) {
   __shared__ float sub[13 * 13];
+  __shared__ double term[5][121], tot[5];
   const int s = blockIdx.x;
   if (s >= n || !valid[s]) return;
   const int lane = threadIdx.x;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
                (float)img[(size_t)yb * W + xb] * a22;
     }
     __syncthreads();
-    double A = 0, B = 0, Cc = 0, bb1 = 0, bb2 = 0;
+    // the five sums of the normal equations, each added up in raster order by one lane: the result is the serial loop's, bit for bit
     for (int i = lane; i < ww * ww; i += 64) {
       const int r = i / ww, c = i - r * ww;
       const float m = mask[i];
@@ -173,17 +174,20 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
       const float tgx = sp[1] - sp[-1], tgy = sp[sw] - sp[-sw];
       const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
       const double pxx = c - win, pyy = r - win;
-      A += gxx;
-      B += gxy;
-      Cc += gyy;
-      bb1 += gxx * pxx + gxy * pyy;
-      bb2 += gxy * pxx + gyy * pyy;
+      term[0][i] = gxx;
+      term[1][i] = gxy;
+      term[2][i] = gyy;
+      term[3][i] = gxx * pxx + gxy * pyy;
+      term[4][i] = gxy * pxx + gyy * pyy;
     }
-    A = wave_sum_f64(A);
-    B = wave_sum_f64(B);
-    Cc = wave_sum_f64(Cc);
-    bb1 = wave_sum_f64(bb1);
-    bb2 = wave_sum_f64(bb2);
+    __syncthreads();
+    if (lane < 5) {
+      double acc = 0;
+      for (int i = 0; i < ww * ww; ++i) acc += term[lane][i];
+      tot[lane] = acc;
+    }
+    __syncthreads();
+    const double A = tot[0], B = tot[1], Cc = tot[2], bb1 = tot[3], bb2 = tot[4];
     const double det = A * Cc - B * B;
     if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
     const double scale = 1.0 / det;

@@ -133,9 +133,9 @@ def test_ransac_matches_oracle(pkg, fo, n, outl, seed):
     thr = 2.0 / 458.654
     a, ag, ai = fo.ransac(m1, m2, thr, 0.999, 1000, seed=0)
     b, bg, bi = c.ransac(m1, m2, thr, seed=0)
-    iou = (a & b).sum() / max(1, (a | b).sum())
-    assert iou >= 0.98, (iou, ag, bg)
-    assert abs(ag - bg) <= max(1, n // 100) and ai == bi
+    # same hypothesis order, same Gauss-Jordan pivot order, cubic roots from + - * / sqrt only on both sides: identical masks
+    assert np.array_equal(a, b), ((a != b).sum(), ag, bg)
+    assert ag == bg and ai == bi
     c.close()
 
 
@@ -160,7 +160,7 @@ def test_perform_matching_vs_oracle(pkg, fo, seq):
         b1, bm, bn0, bn1, its = c.perform_matching(pts, pts)
         assert rc == 0
         assert np.array_equal(a1, b1) and np.array_equal(an0, bn0) and np.array_equal(an1, bn1)
-        assert (am & bm).sum() / max(1, (am | bm).sum()) >= 0.98
+        assert np.array_equal(am, bm)
         assert bm.mean() > 0.8 and its > 0
         pts = b1[bm.astype(bool)]
     # fewer than 10 points: all-zero mask, not an error (REF: TrackKLT.cpp:848-852)
@@ -213,7 +213,7 @@ def test_front_end_at_config_d(pkg):
     assert np.array_equal(n1, fo.undistort(K8, pts1))
     ref_lines = lo.detect_lines(c.pyramid_level(0, 0))
     got = c.detect_lines(0)
-    assert len(got) == len(ref_lines) > 10 and np.abs(got - ref_lines).max() < 2e-3
+    assert len(got) == len(ref_lines) > 10 and np.array_equal(got, ref_lines)
     # the device walk at this size does not fit LDS (640 x 360 bytes): it runs from global memory
     c.line_walk_mode(True)
     got2 = c.detect_lines(0)

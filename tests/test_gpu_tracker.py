@@ -64,12 +64,10 @@ def test_tracker_stream_matches_oracle(pkg):
         ctx.tracker_feed(t, img)
         ot.feed(t, img)
         pts, ids = ctx.tracker_last()
-        common = np.intersect1d(ids, ot.ids)
-        assert len(common) >= 0.98 * max(len(ids), len(ot.ids)), (f, len(ids), len(ot.ids), len(common))
-        a = {int(i): p for i, p in zip(ids, pts)}
-        b = {int(i): p for i, p in zip(ot.ids, ot.pts)}
-        d = max(np.abs(a[int(i)] - b[int(i)]).max() for i in common)
-        assert d <= 2e-3, (f, d)
+        # the whole front-end is bit-reproducible (integer image work, exact LK sums, ordered sub-pixel sums, deterministic RANSAC):
+        # identical id lists and positions frame after frame
+        assert np.array_equal(ids, ot.ids), (f, len(ids), len(ot.ids))
+        assert np.array_equal(pts, np.asarray(ot.pts, dtype=np.float32).reshape(-1, 2)), f
         assert len(ids) >= 150
         tx += rng.uniform(-6, 6)
         ty += rng.uniform(-6, 6)
@@ -82,9 +80,9 @@ def test_tracker_stream_matches_oracle(pkg):
     for k, fid in enumerate(some):
         mine = list(zip(tt[ptr[k]:ptr[k + 1]], uv[ptr[k]:ptr[k + 1], 0]))
         ref = [(o[0], o[1]) for o in ot.db[int(fid)]]
-        if len(mine) == len(ref) and all(abs(m[0] - r[0]) < 1e-12 and abs(m[1] - r[1]) <= 2e-3 for m, r in zip(mine, ref)):
+        if len(mine) == len(ref) and all(m[0] == r[0] and m[1] == r[1] for m, r in zip(mine, ref)):
             agree += 1
-    assert agree >= 48
+    assert agree == len(some)
     # selection helpers
     newest = 10.0 + 0.05 * 6
     lost = ctx.db_select(0, newest)  # not seen in the newest frame
@@ -149,9 +147,6 @@ def test_kaist_sized_tracker(pkg):
         ot.feed(30.0 + 0.05 * f, img)
     pts, ids = ctx.tracker_last()
     assert len(ids) > 900
-    common = np.intersect1d(ids, ot.ids)
-    assert len(common) >= 0.98 * max(len(ids), len(ot.ids))
-    a = {int(i): p for i, p in zip(ids, pts)}
-    b = {int(i): p for i, p in zip(ot.ids, ot.pts)}
-    assert max(np.abs(a[int(i)] - b[int(i)]).max() for i in common) <= 2e-3
+    assert np.array_equal(ids, ot.ids)
+    assert np.array_equal(pts, np.asarray(ot.pts, dtype=np.float32).reshape(-1, 2))
     ctx.close()
