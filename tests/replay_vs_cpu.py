@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The accuracy half of the metric on a rendered dataset ("ATE vs CPU ref"): the replay driver once over the HIP library and once
-over the CPU oracle (tests/oracle_context.py: points + wheel, lines off), both trajectories scored against the simulated truth and
+over the CPU oracle (tests/oracle_context.py: points + lines + wheel), both trajectories scored against the simulated truth and
 against each other.  Test infrastructure (it runs the oracle), like tests/vio_sequence.py.
 
     python tests/replay_vs_cpu.py [--seconds 24] [--out profiles/r01/replay_vs_cpu.json]        (needs a GPU)
@@ -28,18 +28,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=24.0)
     ap.add_argument("--out")
+    ap.add_argument("--style", default="street", choices=["street", "room"], help="street: corridor drive (lines on); room: round 1's scene")
+    ap.add_argument("--no-lines", action="store_true")
+    ap.add_argument("--cam-hz", type=float, default=10.0)
     a = ap.parse_args()
     pkg = ge.load_pkg()
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     d = tempfile.mkdtemp(prefix="plv_synth_")
-    sd.make_dataset(d, a.seconds)
+    sd.make_dataset(d, a.seconds, cam_hz=a.cam_hz, style=a.style, workers=min(32, os.cpu_count() or 1))
     gt = os.path.join(d, "gt.txt")
-    res, runs = dict(seconds=a.seconds, dataset="tests/synth_dataset.py (rendered 752x480 images, 200 Hz IMU, 50 Hz wheel)", lines="off in both runs"), {}
+    lines = not a.no_lines
+    res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered 752x480 images at {a.cam_hz:g} Hz, 200 Hz IMU, 50 Hz wheel)",
+                     lines="on in both runs" if lines else "off in both runs"), {}
     ctx = pkg.Context(pkg.default_config(752, 480))
     for name, kw in (("hip", {}), ("cpu_oracle", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
         traj = os.path.join(d, "out", f"traj_{name}.txt")
         op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj))
-        op.est.cam.use_lines = False
+        op.est.cam.use_lines = lines
         t0 = time.time()
         stats, times, poses = rp.replay(op, **kw)
         et, ep = pkg.traj_load(traj)[:2]

@@ -112,17 +112,57 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     assert sh["clones"] == sc["clones"] and sh["startup_time"] == sc["startup_time"]
     assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.03 * sc["cam_features"]
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
-    # The two front-ends agree to 2e-3 px on detections and 98 % on RANSAC masks, not to the bit, so now and then a track ends
-    # a frame apart and the filters see slightly different measurement sets: the trajectories differ by a fraction of the
-    # estimator's own noise (profiles/r01/replay_vs_cpu.json: 1.2 cm RMSE over 60 m), the ATE by less than BASELINE's 1 cm.
+    # The two front-ends are bit-identical (round 2), so the filters are handed the same tracks.  The update side is fp64 on both
+    # sides with different libm's behind the pose interpolation, so the trajectories agree to ~1e-10 m until a feature sits on a
+    # threshold (3 px consistency, condition number, chi2): about one in a thousand is then taken by one side only (here feature 308
+    # at t = 4.45 s) and the two runs continue a millimetre apart.
+    assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.01 * sc["cam_features"] and abs(sh["cam_accepted"] - sc["cam_accepted"]) <= 0.01 * sc["cam_accepted"]
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
-    assert d < 0.02, d
+    assert d < 0.005, d
+    assert np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max() < 1e-8
     ctx = pkg.Context(pkg.default_config(752, 480))
     r = ctx.traj_ate(runs["hip"][2], runs["cpu"][2], "none")
     ctx.close()
     assert r["pos"]["rmse"] < 0.01 and r["ori"]["rmse"] < 0.1, r
     ate = {name: _score(pkg, runs[name][3], os.path.join(dataset, "gt.txt"))[0]["pos"]["rmse"] for name in runs}
     assert abs(ate["hip"] - ate["cpu"]) < 0.01, ate
+
+
+@pytest.fixture(scope="module")
+def street_dataset(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("street"))
+    sd.make_dataset(d, seconds=6.0, cam_hz=10.0, style="street", workers=min(16, os.cpu_count() or 1))
+    return d
+
+
+def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path):
+    """Points AND lines, end to end: the street-corridor drive (structure along the driving direction, the case the reference's line
+    classification and point-anchored triangulation are made for) through the driver over the HIP library and over the CPU oracle
+    (tests/oracle_context.py, line half included: detection -> assignment -> matching -> classification -> get_line_features ->
+    lines_update -> cleanup).  The front-ends are bit-identical, so both filters see the same measurements: same features and lines
+    pooled, triangulated and accepted, trajectories a rounding error apart."""
+    import oracle_context as oc
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs = {}
+    for name, kw in (("hip", {}), ("cpu", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
+        traj = str(tmp_path / f"traj_{name}.txt")
+        op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, traj))
+        op.est.cam.use_lines = True
+        stats, times, poses = rp.replay(op, **kw)
+        assert stats["initialized"] and stats["not_psd"] == 0, (name, stats)
+        runs[name] = (stats, times, poses, traj)
+    sh, sc = runs["hip"][0], runs["cpu"][0]
+    for key in ("clones", "frames", "lines_tracked", "wheel_accepted"):   # what the (bit-identical) front-ends alone decide
+        assert sh[key] == sc[key], (key, sh[key], sc[key])
+    for key in ("cam_features", "cam_accepted", "cam_updates", "line_pool", "lines_triangulated", "lines_accepted", "line_updates"):
+        assert abs(sh[key] - sc[key]) <= max(2, 0.03 * sc[key]), (key, sh[key], sc[key])   # threshold ties of the fp64 update side
+    assert sh["cam_accepted"] >= 500 and sh["lines_triangulated"] >= 200 and sh["line_updates"] >= 10, sh
+    assert np.array_equal(runs["hip"][1], runs["cpu"][1])
+    d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
+    assert d < 0.005, d
+    assert np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max() < 1e-8
+    ate = {name: _score(pkg, runs[name][3], os.path.join(street_dataset, "gt.txt"))[0]["pos"]["rmse"] for name in runs}
+    assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
 
 def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
