@@ -24,11 +24,11 @@ struct CompressOps {
   __device__ __forceinline__ double border_raw(int, int c) const { return G[(size_t)k * nc + min(c, k - 1)]; }
   __device__ __forceinline__ void scales_ready() const {
     const int j = threadIdx.x;
-    if (j < 128) {
+    if (j < 192) {
       const bool ok = j < k && dval > 0.0;
       const double rt = sqrt(ok ? dval : 1.0);
       scw[j] = ok ? 1.0 / rt : 0.0;
-      scw[128 + j] = ok ? rt : 0.0;
+      scw[192 + j] = ok ? rt : 0.0;
     }
     __syncthreads();
   }
@@ -42,7 +42,7 @@ struct CompressOps {
   // R = L^T D^-1:  R(c, i) = l_ic * sqrt(G_ii)
   __device__ __forceinline__ void store_sym(int i, int c, double l) const {
     if (i < k && c <= i) {
-      R[(size_t)i * ldr + c] = l * sc[128 + i];
+      R[(size_t)i * ldr + c] = l * sc[192 + i];
       if (c < i) R[(size_t)c * ldr + i] = 0.0;
     }
   }
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const dou
                                                                       double *__restrict__ z, const int *__restrict__ skip) {
   if (skip && *skip == 0) return;
   __shared__ BcLds lds;
-  __shared__ double sc[256];  // [0,128) 1/sqrt(d), [128,256) sqrt(d)
+  __shared__ double sc[384];  // [0,192) 1/sqrt(d), [192,384) sqrt(d)
   const int k = nc - 1;
   const int jd = min((int)threadIdx.x, k - 1);
   CompressOps ops{G, nc, k, sc, R, ldr, z, G[(size_t)jd * nc + jd], sc};
@@ -124,7 +124,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z) {
   const int k = nc - 1;
-  if (k > 128) return PLV_E_CAPACITY;
+  if (k > 192) return PLV_E_CAPACITY;
   ProfScope ps(ctx->prof, "bchol_compress_kernel", ctx->stream);
   if (k <= 32)
     hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
@@ -132,15 +132,19 @@ int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, 
     hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   else if (k <= 112)
     hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
-  else
+  else if (k <= 128)
     hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+  else if (k <= 160)  // (20-clone windows with the calibration blocks: BASELINE configs[3])
+    hipLaunchKernelGGL(bchol_compress_kernel<10>, dim3(1), dim3(64 * 11), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+  else
+    hipLaunchKernelGGL(bchol_compress_kernel<12>, dim3(1), dim3(64 * 13), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
 
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
                      const double *d_res, double *d_W, int ldw, int *d_flag) {
-  if (r > 128) return PLV_E_CAPACITY;
+  if (r > 192) return PLV_E_CAPACITY;
   const int groups = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);
   if (r <= 32)
@@ -152,8 +156,14 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   else if (r <= 112)
     hipLaunchKernelGGL(bchol_ekf_kernel<7>, dim3(groups), dim3(64 * 8), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
                        ldw, d_flag, ctx->skip_word);
-  else
+  else if (r <= 128)
     hipLaunchKernelGGL(bchol_ekf_kernel<8>, dim3(groups), dim3(64 * 9), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
+                       ldw, d_flag, ctx->skip_word);
+  else if (r <= 160)
+    hipLaunchKernelGGL(bchol_ekf_kernel<10>, dim3(groups), dim3(64 * 11), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
+                       ldw, d_flag, ctx->skip_word);
+  else
+    hipLaunchKernelGGL(bchol_ekf_kernel<12>, dim3(groups), dim3(64 * 13), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
                        ldw, d_flag, ctx->skip_word);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

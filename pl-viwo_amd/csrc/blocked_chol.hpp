@@ -68,7 +68,7 @@ template <class T> __device__ __forceinline__ void lds_vstore(T *p, T v) { *(vol
 template <class T> __device__ __forceinline__ T lds_vload(const T *p) { return *(const volatile PLV_LDS T *)(p); }
 
 struct BcLds {
-  double Lp[2][8][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity
+  double Lp[2][12][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity (NT <= 12)
   double Ts[16][64][2];    // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
   double rs[2][16];        // 1 / l_jj (0: dead column), by panel parity
   int step_flag;           // 16 * panel + steps published so far

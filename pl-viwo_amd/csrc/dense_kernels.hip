@@ -166,7 +166,7 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
   const int nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
   const int nchunks = cdiv(m, GRAM_CH);
   const size_t part_elems = (size_t)nchunks * ntri * 256, g_elems = (size_t)nc * nc;
-  if (k > 128 || part_elems + g_elems > tmp_elems) {
+  if (k > 192 || part_elems + g_elems > tmp_elems) {
     set_last_error("gram compress: %d columns / %d rows exceed the blocked factorisation's workspace", k, m);
     return PLV_E_CAPACITY;
   }
@@ -184,7 +184,7 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
   return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
 }
 
-bool ekf_fast_fits(int r) { return r <= 128; }
+bool ekf_fast_fits(int r) { return r <= 192; }
 
 // EKF update with the identity-border Cholesky.  Requires ekf_fast_fits(r).
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,

@@ -661,7 +661,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.accepted = d_acc;
   a.acc_rows = d_acc_rows;
   a.n_acc = d_flag + 1;           // second word of the status block
-  ctx->skip_word = d_flag + 1;    // read by every kernel enqueued from here on (cleared after enqueue())
+  // read by every kernel enqueued from here on (cleared after enqueue()); only the blocked-Cholesky route honours it in all of
+  // its kernels, so the Householder / LDS-resident fallbacks (more than 192 columns) run unconditionally
+  ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;
   TRY(launch_chi2(ctx, F, a, mp_max));
 
   const double *dH, *dr;

@@ -125,7 +125,11 @@ def test_compress_fat_is_identity(ctx):
 @pytest.mark.parametrize("F,M,n,k,fdim,gate", [(70, 15, 113, 98, 3, 3.0), (250, 15, 113, 98, 3, 3.0),
                                                (80, 15, 105, 90, 6, 0.0), (70, 20, 143, 128, 3, 3.0), (500, 20, 143, 128, 3, 3.0),
                                                (3, 4, 40, 26, 3, 3.0), (40, 8, 60, 45, 3, 3.0),
-                                               (20, 6, 40, 26, 3, 3.0)])
+                                               (20, 6, 40, 26, 3, 3.0),
+                                               # BASELINE configs[3]: 20-clone window + the pose of the newest frame, intrinsics calibrated
+                                               # (n = 149, k = 134 columns), 70 point features / 150 lines of 20 observations
+                                               (70, 20, 149, 134, 3, 3.0), (150, 20, 149, 127, 6, 0.0), (150, 20, 149, 134, 6, 0.0),
+                                               (60, 24, 205, 190, 3, 3.0)])
 def test_msckf_update_parity(ctx, oracle, F, M, n, k, fdim, gate):
     P = synth.spd_cov(n, seed=F)
     cols = synth.col_map(n, k, seed=M, skip=min(15, n - k))
@@ -205,9 +209,10 @@ def test_update_graph_replay_matches_eager(pkg, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("k", [12, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 95, 96, 97, 111, 112, 113, 127, 128])
+@pytest.mark.parametrize("k", [12, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 95, 96, 97, 111, 112, 113, 127, 128, 129, 143, 144, 145,
+                               159, 160, 161, 176, 191, 192])
 def test_msckf_update_tile_boundaries(ctx, oracle, k):
-    """Every 16-column tile boundary of the blocked factorisations (the kernels are instantiated for 2, 4, 7 and 8 tiles), with
+    """Every 16-column tile boundary of the blocked factorisations (the kernels are instantiated for 2, 4, 7, 8, 10 and 12 tiles), with
     fewer stacked rows than columns for the small ones (no compression) and more for the rest."""
     n = k + 15
     F, M = (4, 4) if k >= 31 and k % 2 else (30, 8)
@@ -218,8 +223,9 @@ def test_msckf_update_tile_boundaries(ctx, oracle, k):
     rc0, P0, dx0, acc0, nr0 = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, q95, 1.0, 3.0)
     rc1, P1, dx1, acc1, nr1 = ctx.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, 1.0, 3.0)
     assert rc0 == rc1 == 0 and np.array_equal(acc0, acc1) and nr0 == nr1
+    tol = 1e-8 if k <= 160 else 1e-7   # (the Gram matrix squares the condition number: 190 columns of this generator cost a digit)
     if acc1.sum():
-        assert _rel(dx1, dx0) < 1e-8 and _rel(P1, P0) < 1e-8
+        assert _rel(dx1, dx0) < tol and _rel(P1, P0) < tol
     else:
         assert np.array_equal(P1, P)
 
