@@ -88,7 +88,21 @@ def test_point_line_logic_parity(ctx, lo, frames):
 
 def test_line_tracker_stream(pkg, lo, frames):
     """TrackLSD::feed_monocular over three frames against a composition of oracle pieces."""
+    _line_tracker_stream(pkg, lo, frames, W, H)
+
+
+def test_line_tracker_stream_1280x720(pkg, lo):
+    """BASELINE configs[3]: the same stream test on 1280 x 720 frames with 500 points."""
+    w, h = 1280, 720
+    canvas = synth.texture_canvas(w, h, seed=13, blobs=400, lines=260)
+    fr = [synth.render_frame(canvas, w, h, tx=3.0 * i, ty=-2.0 * i, rot_deg=0.15 * i) for i in range(3)]
+    _line_tracker_stream(pkg, lo, fr, w, h, num_features=500)
+
+
+def _line_tracker_stream(pkg, lo, frames, W, H, num_features=None):
     cfg = pkg.default_config(W, H)
+    if num_features:
+        cfg.num_features = num_features
     ctx = pkg.Context(cfg)
     vps = lo.vanishing_points(np.eye(3), synth.EUROC_K8)
     K8 = synth.EUROC_K8
