@@ -183,7 +183,13 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
     __syncthreads();
     if (lane < 5) {
       double acc = 0;
-      for (int i = 0; i < ww * ww; ++i) acc += term[lane][i];
+      for (int i0 = 0; i0 < 121; i0 += 11) {  // (win = 5: 11 rows of 11; a row's loads are issued together, the adds stay in raster order)
+        double v[11];
+#pragma unroll
+        for (int u = 0; u < 11; ++u) v[u] = term[lane][i0 + u];
+#pragma unroll
+        for (int u = 0; u < 11; ++u) acc += v[u];
+      }
       tot[lane] = acc;
     }
     __syncthreads();

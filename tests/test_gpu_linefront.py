@@ -104,8 +104,8 @@ def _line_tracker_stream(pkg, lo, frames, W, H, num_features=None):
     if num_features:
         cfg.num_features = num_features
     ctx = pkg.Context(cfg)
-    vps = lo.vanishing_points(np.eye(3), synth.EUROC_K8)
-    K8 = synth.EUROC_K8
+    K8 = np.array(list(cfg.intrinsics))
+    vps = lo.vanishing_points(np.eye(3), K8)
     fo = oracle_lib.load_front()
     last = None  # (lines, ids, rel_ptr, rel_id)
     currid = 1
