@@ -676,10 +676,8 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
 //   FeatureInitializer::single_triangulation          REF: OV/feat/FeatureInitializer.cpp:30-112
 //   FeatureInitializer::single_gaussnewton            REF: OV/feat/FeatureInitializer.cpp:197-375
 //   CamHelper::moving_consistency (mean reprojection) REF: PL/update/cam/CamHelper.cpp:426-483
-__global__ void __launch_bounds__(64) campose_kernel(JacParams P, double *__restrict__ poses /*[n_obs][12]*/,
-                                                     unsigned char *__restrict__ valid, double *__restrict__ imu = nullptr) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= P.n_obs) return;
+__device__ void campose_one(const JacParams &P, int o, double *__restrict__ poses /*[n_obs][12]*/, unsigned char *__restrict__ valid,
+                            double *__restrict__ imu) {
   const double tm = P.obs_time[o] + P.cam_dt;
   const int s0 = bounding_start(P, tm);
   valid[o] = s0 >= 0;
@@ -862,11 +860,16 @@ struct TriObs {     // per valid observation, relative to the anchor pose (the n
   double pc[3];     // p_CiinA
 };
 #define TRI_TERMS 10
-__global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, const double *__restrict__ poses,
-                                                         const unsigned char *__restrict__ valid, const float *__restrict__ uvn,
+__global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *poses, unsigned char *valid, const float *__restrict__ uvn,
                                                          plv_tri_options opt, double *__restrict__ p_out,
                                                          unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
   extern __shared__ double tri_smem[];
+  {  // camera poses of this feature's observations (CamHelper::get_imu_poses / get_cam_poses), one lane each: no separate launch
+    const int o0 = P.obs_ptr[blockIdx.x], o1 = P.obs_ptr[blockIdx.x + 1];
+    for (int o = o0 + (int)threadIdx.x; o < o1; o += 64) campose_one(P, o, poses, valid, nullptr);
+    __threadfence_block();
+    __syncthreads();
+  }
   TriObs *ob = reinterpret_cast<TriObs *>(tri_smem);                       // [max_obs]
   double *term = tri_smem + (size_t)max_obs * (sizeof(TriObs) / 8);        // [max_obs][TRI_TERMS]
   int *list = reinterpret_cast<int *>(term + (size_t)max_obs * TRI_TERMS);  // [max_obs] indices of the valid observations
@@ -1253,18 +1256,29 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
   if (threadIdx.x == 0) P.rows[l] = 2 * base;
 }
 
-// a27: LineHelper::line_triangulation   REF: LineHelper.cpp:202-293, 372-495, 615-650.  Thread per line;
-// camera / IMU poses of every observation come from campose_kernel.
-__global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, const double *__restrict__ cam,
-                                                              const double *__restrict__ imu,
-                                                              const unsigned char *__restrict__ valid,
-                                                              double *__restrict__ out, unsigned char *__restrict__ ok) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= P.n_feat) return;
-  ok[l] = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) out[6 * l + i] = 0.0;
+__device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
+                                     double *out, unsigned char &ok);
+// a27: LineHelper::line_triangulation   REF: LineHelper.cpp:202-293, 372-495, 615-650.  One wave per line: the lanes first
+// compute the camera / IMU poses of the line's observations (one each), then every lane runs the (short, serial) plane
+// intersection on them and lane 0 stores the result.
+__global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, double *cam, double *imu, unsigned char *valid, double *out_g,
+                                                              unsigned char *ok_g) {
+  const int l = blockIdx.x;
   const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
+  for (int o = o0 + (int)threadIdx.x; o < o1; o += 64) campose_one(P, o, cam, valid, imu);
+  __threadfence_block();
+  __syncthreads();
+  double out_l[6] = {0, 0, 0, 0, 0, 0};
+  unsigned char ok_l = 0;
+  line_triangulate_one(P, l, o0, o1, cam, imu, valid, out_l, ok_l);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out_g[6 * l + i] = out_l[i];
+    ok_g[l] = ok_l;
+  }
+}
+__device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
+                                     double *out /*[6], zero on entry*/, unsigned char &ok) {
   int first = -1, nvalid = 0;
   for (int o = o0; o < o1; ++o)
     if (valid[o]) {
@@ -1280,10 +1294,10 @@ __global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, const
     const V3 mom = cross3(ldV(P.anchor_pt + 3 * l), dir);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      out[6 * l + i] = mom[i];
-      out[6 * l + 3 + i] = dir[i];
+      out[i] = mom[i];
+      out[3 + i] = dir[i];
     }
-    ok[l] = 1;
+    ok = 1;
     return;
   }
   const M3 R0 = ldM(cam + 12 * first);
@@ -1328,10 +1342,10 @@ __global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, const
   const V3 nW = vadd(mv(R0t, rtail), mv(skew3(p0), mv(R0t, rhead)));
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    out[6 * l + i] = nW[i];
-    out[6 * l + 3 + i] = vW[i];
+    out[i] = nW[i];
+    out[3 + i] = vW[i];
   }
-  ok[l] = 1;
+  ok = 1;
 }
 
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
@@ -1344,13 +1358,8 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
                              double *d_lines, unsigned char *d_ok) {
   {
-    ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
-    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, d_imu);
-  }
-  {
     ProfScope ps(ctx->prof, "line_triangulate_kernel", ctx->stream);
-    hipLaunchKernelGGL(line_triangulate_kernel, dim3((P.n_feat + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_imu, d_valid,
-                       d_lines, d_ok);
+    hipLaunchKernelGGL(line_triangulate_kernel, dim3(P.n_feat), dim3(64), 0, ctx->stream, P, d_poses, d_imu, d_valid, d_lines, d_ok);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
@@ -1358,10 +1367,6 @@ int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, 
 
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,
                        const plv_tri_options &opt, double *d_p, unsigned char *d_ok, double *d_err, int max_obs) {
-  {
-    ProfScope ps(ctx->prof, "campose_kernel", ctx->stream);
-    hipLaunchKernelGGL(campose_kernel, dim3((P.n_obs + 63) / 64), dim3(64), 0, ctx->stream, P, d_poses, d_valid, (double *)nullptr);
-  }
   {
     ProfScope ps(ctx->prof, "triangulate_kernel", ctx->stream);
     const size_t shm = (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16;

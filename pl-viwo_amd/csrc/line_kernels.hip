@@ -30,8 +30,13 @@ __global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ s
 }
 
 #define CN_T 16
-__global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int w, int h, int low, int high,
-                                                            uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */) {
+// FULL = true: `src` is the full-resolution image (fw wide) and the tile of the half-resolution image the stencil needs is decimated
+// on the fly (the arithmetic of half_kernel); the workgroup also writes its 16 x 16 piece of the half-resolution image, which the
+// segment fit reads.  One launch for cv::resize + cv::Canny.
+template <bool FULL>
+__global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int fw, int w, int h, int low, int high,
+                                                            uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */,
+                                                            uint8_t *__restrict__ half_out) {
   __shared__ int px[CN_T + 4][CN_T + 4];
   __shared__ int mg[CN_T + 2][CN_T + 2];
   const int tx = threadIdx.x & (CN_T - 1), ty = threadIdx.x / CN_T;
@@ -39,9 +44,15 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
   for (int i = threadIdx.x; i < (CN_T + 4) * (CN_T + 4); i += CN_T * CN_T) {
     const int ly = i / (CN_T + 4), lx = i - ly * (CN_T + 4);
     const int gx = min(max(x0 + lx - 2, 0), w - 1), gy = min(max(y0 + ly - 2, 0), h - 1);  // BORDER_REPLICATE
-    px[ly][lx] = src[(size_t)gy * w + gx];
+    if (FULL) {
+      const uint8_t *p = src + (size_t)(2 * gy) * fw + 2 * gx;
+      px[ly][lx] = (p[0] + p[1] + p[fw] + p[fw + 1] + 2) >> 2;
+    } else {
+      px[ly][lx] = src[(size_t)gy * w + gx];
+    }
   }
   __syncthreads();
+  if (FULL && half_out && x0 + tx < w && y0 + ty < h) half_out[(size_t)(y0 + ty) * w + x0 + tx] = (uint8_t)px[ty + 2][tx + 2];
   for (int i = threadIdx.x; i < (CN_T + 2) * (CN_T + 2); i += CN_T * CN_T) {
     const int ly = i / (CN_T + 2), lx = i - ly * (CN_T + 2);
     const int gx = x0 + lx - 1, gy = y0 + ly - 1;
@@ -228,16 +239,12 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // stage 1: half-resolution image and Canny map (0 weak / 1 none / 2 edge; hysteresis applied)
 int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b) {
   const int w = W / 2, h = H / 2;
-  {
-    ProfScope ps(ctx->prof, "half_kernel", ctx->stream);
-    hipLaunchKernelGGL(half_kernel, dim3(cdiv(w, 64), cdiv(h, 4)), dim3(256), 0, ctx->stream, d_img, W, H, b.half);
-  }
   int low = fp.canny_low, high = fp.canny_high;
   if (low > high) std::swap(low, high);
   {
-    ProfScope ps(ctx->prof, "canny_kernel", ctx->stream);
-    hipLaunchKernelGGL(canny_kernel, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, ctx->stream, b.half, w, h, low, high,
-                       b.map);
+    ProfScope ps(ctx->prof, "half_canny_kernel", ctx->stream);
+    hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, ctx->stream, d_img, W, w, h, low,
+                       high, b.map, b.half);
   }
   if (low != high) {
     ProfScope ps(ctx->prof, "canny_hyst_kernel", ctx->stream);
