@@ -250,6 +250,11 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * equalize + pyramid, first-frame detection or top-up on the last image, temporal KLT + RANSAC,
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
+/* On (the default), plv_tracker_feed* ends by starting the NEXT frame's top-up detection (TrackKLT.cpp:127-131 runs it on the then-last
+ * image with the then-last points: this image, these points) on a side stream, next to the updates the caller enqueues; the next
+ * feed collects it.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
+ * plv_tracker state was edited) or the per-kernel profiler is on. */
+int plv_tracker_detect_ahead(plv_ctx *ctx, int on);
 /* plv_tracker_feed from an image already resident in HBM (plv_image_stage, slots 0..7): the camera driver's DMA target in a
  * deployment, and the form bench.py times (no PCIe copy inside the frame). */
 int plv_tracker_feed_staged(plv_ctx *ctx, double timestamp, int slot, const uint8_t *mask);

@@ -113,6 +113,7 @@ def load_library():
                                             C.POINTER(C.c_uint64), ip]),
         "plv_tracker_feed": (C.c_int, [vp, C.c_double, u8p, C.c_int, u8p]),
         "plv_tracker_feed_staged": (C.c_int, [vp, C.c_double, C.c_int, u8p]),
+        "plv_tracker_detect_ahead": (C.c_int, [vp, C.c_int]),
         "plv_tracker_feed_downsampled": (C.c_int, [vp, C.c_double, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
         "plv_downsample": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
         "plv_feed_image_downsampled": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int]),
@@ -1189,6 +1190,9 @@ class Context:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
         self._chk(self.lib.plv_tracker_feed(self.h, float(timestamp), _u8p(img), img.shape[1], _u8p(m)))
+
+    def tracker_detect_ahead(self, on):
+        self._chk(self.lib.plv_tracker_detect_ahead(self.h, 1 if on else 0))
 
     def tracker_feed_staged(self, timestamp, slot, mask=None):
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None

@@ -11,6 +11,21 @@ using namespace plv;
 
 namespace {
 
+struct DetJob {  // one top-up detection between its host stages (plv_perform_detection / _ahead)
+  std::vector<uint8_t> close;        // occupancy grid of the kept points (min_px_dist cells)
+  std::vector<int> boxes, cells;
+  std::vector<float> pts;            // kept points
+  std::vector<uint64_t> ids;
+  int cw = 0, ch = 0, nfg = 0, sxp = 0, syp = 0, n_cells = 0, n_slots = 0;
+  char *h_out = nullptr;             // pinned: [xy n_slots x 2 f32][resp n_slots f32][valid n_slots u8]
+  // what an ahead-of-time job was started from
+  bool active = false, has_mask = false;
+  int fed = 0, n_in = 0;
+  std::vector<float> in_pts;
+  std::vector<uint64_t> in_ids;
+  std::vector<uint8_t> in_mask;
+};
+
 struct FrontState {
   int W = 0, H = 0;
   PyrDesc pyr[2];          // ping-pong pyramids
@@ -27,6 +42,9 @@ struct FrontState {
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io, models;
   DevBuf det_in, det_out, det_mask, subpix_tab, det_cand, det_cand_n;  // detection staging
   PinBuf det_pin;
+  DetJob det_pending;
+  hipStream_t det_stream = nullptr;
+  hipEvent_t det_done = nullptr;
 };
 
 #define TRY(expr)                  \
@@ -136,6 +154,9 @@ extern "C" {
 void plv_frontend_destroy(plv_ctx *ctx) {
   auto *s = (FrontState *)ctx->fe_state;
   if (!s) return;
+  if (s->det_pending.active) (void)hipEventSynchronize(s->det_done);
+  if (s->det_done) (void)hipEventDestroy(s->det_done);
+  if (s->det_stream) (void)hipStreamDestroy(s->det_stream);
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab, &s->det_cand, &s->det_cand_n};
@@ -427,51 +448,50 @@ int plv_perform_matching(plv_ctx *ctx, int n, const float *pts0, float *pts1, ui
 // track/TrackKLT.cpp:395-528).  The occupancy-grid bookkeeping is host logic exactly as in the
 // reference (a few hundred integer operations); the per-cell FAST + top-k (Grider_GRID.h:108-151)
 // and the sub-pixel refinement (:163-174) run on the device on level 0 of the chosen pyramid.
-int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *pts, uint64_t *ids, int n_in, int cap,
-                          uint64_t *currid, int *n_out) {
-  if (!ctx || !pts || !ids || !currid || !n_out || n_in < 0 || cap < n_in) return PLV_E_BADARG;
-  (void)hipSetDevice(ctx->device);
-  FrontState *s = fe(ctx);
-  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) {
-    set_last_error("plv_perform_detection: no %s pyramid yet", which == PLV_PYR_LAST ? "last" : "current");
-    return PLV_E_BADARG;
-  }
-  const PyrDesc &pyr = s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur];
+// Three stages: det_pre (host: grids, cells that need features), det_launch (device, on any stream), det_post (host: reject
+// near existing points, ids in extraction order).  plv_perform_detection runs them back to back; plv_perform_detection_ahead runs
+// the first two on a side stream as soon as a frame's points are known, so that the top-up the NEXT frame starts with (it works on
+// the then-last image with these very points, TrackKLT.cpp:127-131) is waiting for it instead of sitting on its critical path.
+namespace {
+int det_pre(plv_ctx *ctx, FrontState *s, const uint8_t *mask, const float *pts_in, const uint64_t *ids_in, int n_in, DetJob &J) {
   const int w = s->W, h = s->H;
   const plv_config &c = ctx->cfg;
   const int min_px = c.min_px_dist, grid_x = c.grid_x, grid_y = c.grid_y, num_features = c.num_features;
   if (min_px < 1 || grid_x < 1 || grid_y < 1) return PLV_E_BADARG;
   // ---- REF :401-464: occupancy grids, drop edge / masked / too-close points, remember the painted boxes
-  const int cw = (int)((float)w / (float)min_px), ch = (int)((float)h / (float)min_px);
-  std::vector<uint8_t> close((size_t)cw * ch, 0), grid((size_t)grid_x * grid_y, 0);
+  J.cw = (int)((float)w / (float)min_px), J.ch = (int)((float)h / (float)min_px);
+  J.close.assign((size_t)J.cw * J.ch, 0);
+  std::vector<uint8_t> grid((size_t)grid_x * grid_y, 0);
   const float size_x = (float)w / (float)grid_x, size_y = (float)h / (float)grid_y;
-  std::vector<int> boxes;
-  int n = 0;
+  J.boxes.clear();
+  J.pts.clear();
+  J.ids.clear();
   for (int i = 0; i < n_in; ++i) {
-    const float fx = pts[2 * i], fy = pts[2 * i + 1];
+    const float fx = pts_in[2 * i], fy = pts_in[2 * i + 1];
     const int x = (int)fx, y = (int)fy;
     const int edge = 10;
     if (x < edge || x >= w - edge || y < edge || y >= h - edge) continue;
     const int xc = (int)(fx / (float)min_px), yc = (int)(fy / (float)min_px);
-    if (xc < 0 || xc >= cw || yc < 0 || yc >= ch) continue;
+    if (xc < 0 || xc >= J.cw || yc < 0 || yc >= J.ch) continue;
     const int xg = (int)std::floor(fx / size_x), yg = (int)std::floor(fy / size_y);
     if (xg < 0 || xg >= grid_x || yg < 0 || yg >= grid_y) continue;
-    if (close[(size_t)yc * cw + xc] > 127) continue;
+    if (J.close[(size_t)yc * J.cw + xc] > 127) continue;
     if (mask && mask[(size_t)y * w + x] > 127) continue;
-    close[(size_t)yc * cw + xc] = 255;
+    J.close[(size_t)yc * J.cw + xc] = 255;
     if (grid[(size_t)yg * grid_x + xg] < 255) grid[(size_t)yg * grid_x + xg] += 1;
     if (x - min_px >= 0 && x + min_px < w && y - min_px >= 0 && y + min_px < h) {
-      boxes.push_back(x);
-      boxes.push_back(y);
+      J.boxes.push_back(x);
+      J.boxes.push_back(y);
     }
-    pts[2 * n] = fx;
-    pts[2 * n + 1] = fy;
-    ids[n] = ids[i];
-    ++n;
+    J.pts.push_back(fx);
+    J.pts.push_back(fy);
+    J.ids.push_back(ids_in[i]);
   }
-  *n_out = n;
+  J.n_cells = 0;
+  J.n_slots = 0;
   // ---- REF :466-471
   const double min_feat_percent = 0.50;
+  const int n = (int)J.ids.size();
   if (num_features - n < std::min(20, (int)(min_feat_percent * num_features))) return PLV_OK;
   // ---- REF :478-492 cells that still need features and are not fully masked
   const int nfg_req = std::max(1, (int)(min_feat_percent * ((int)((double)num_features / (double)(grid_x * grid_y)) + 1)));
@@ -482,36 +502,45 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
     gy = (int)std::ceil(std::sqrt(num_features / ratio));
     gx = (int)std::ceil(gy * ratio);
   }
-  const int nfg = (int)((double)num_features / (double)(gx * gy)) + 1;
-  const int sxp = w / gx, syp = h / gy;
-  std::vector<int> cells;
+  J.nfg = (int)((double)num_features / (double)(gx * gy)) + 1;
+  J.sxp = w / gx, J.syp = h / gy;
+  J.cells.clear();
   for (int x = 0; x < grid_x; ++x)
     for (int y = 0; y < grid_y; ++y) {
       const int sx = std::min((int)std::floor(x * (double)w / grid_x), w - 1), sy = std::min((int)std::floor(y * (double)h / grid_y), h - 1);
       const bool masked = mask && mask[(size_t)sy * w + sx] == 255;
       if ((int)grid[(size_t)y * grid_x + x] < nfg_req && !masked) {
-        if (x * sxp + sxp > w || y * syp + syp > h) continue;  // REF Grider_GRID.h:117-118
-        cells.push_back(x);
-        cells.push_back(y);
+        if (x * J.sxp + J.sxp > w || y * J.syp + J.syp > h) continue;  // REF Grider_GRID.h:117-118
+        J.cells.push_back(x);
+        J.cells.push_back(y);
       }
     }
-  const int n_cells = (int)cells.size() / 2;
-  if (n_cells == 0 || sxp < 7 || syp < 7) return PLV_OK;
-  // ---- device: FAST per cell + sub-pixel refinement of every kept slot
-  const int n_slots = n_cells * nfg;
-  const size_t o_cells = 0, o_boxes = ((size_t)n_cells * 8 + 15) & ~(size_t)15, in_total = o_boxes + ((boxes.size() * 4 + 15) & ~(size_t)15);
-  TRY(s->det_pin.reserve(std::max(in_total, (size_t)n_slots * 13 + 64)));
+  const int n_cells = (int)J.cells.size() / 2;
+  if (n_cells == 0 || J.sxp < 7 || J.syp < 7) return PLV_OK;
+  J.n_cells = n_cells;
+  J.n_slots = n_cells * J.nfg;
+  return PLV_OK;
+}
+
+// FAST per cell + sub-pixel refinement of every kept slot + the copy of the slots to pinned memory, all on `stream`
+int det_launch(plv_ctx *ctx, FrontState *s, const PyrDesc &pyr, const uint8_t *mask, DetJob &J, hipStream_t stream) {
+  const int w = s->W, h = s->H;
+  const plv_config &c = ctx->cfg;
+  const int n_cells = J.n_cells, n_slots = J.n_slots;
+  const size_t o_cells = 0, o_boxes = ((size_t)n_cells * 8 + 15) & ~(size_t)15, in_total = o_boxes + ((J.boxes.size() * 4 + 15) & ~(size_t)15);
+  TRY(s->det_pin.reserve(in_total + (size_t)n_slots * 13 + 128));
   TRY(s->det_in.reserve(in_total + 16));
   const size_t o_xy = 0, o_resp = (size_t)n_slots * 8, o_valid = (size_t)n_slots * 12, out_total = (size_t)n_slots * 13;
   TRY(s->det_out.reserve(out_total + 16));
   char *hp = s->det_pin.as<char>();
-  memcpy(hp + o_cells, cells.data(), cells.size() * 4);
-  if (!boxes.empty()) memcpy(hp + o_boxes, boxes.data(), boxes.size() * 4);
-  PLV_HIP_CHECK(plv::memcpy_async(s->det_in.p, hp, in_total, hipMemcpyHostToDevice, ctx->stream));
+  J.h_out = hp + ((in_total + 63) & ~(size_t)63);  // results land behind the inputs (both may be in flight at once)
+  memcpy(hp + o_cells, J.cells.data(), J.cells.size() * 4);
+  if (!J.boxes.empty()) memcpy(hp + o_boxes, J.boxes.data(), J.boxes.size() * 4);
+  PLV_HIP_CHECK(plv::memcpy_async(s->det_in.p, hp, in_total, hipMemcpyHostToDevice, stream));
   const uint8_t *d_mask = nullptr;
   if (mask) {
     TRY(s->det_mask.reserve((size_t)w * h));
-    PLV_HIP_CHECK(plv::memcpy_async(s->det_mask.p, mask, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(s->det_mask.p, mask, (size_t)w * h, hipMemcpyHostToDevice, stream));
     d_mask = s->det_mask.as<uint8_t>();
   }
   if (!s->subpix_tab.p) {  // cv::cornerSubPix window weights exp(-(x/5)^2) exp(-(y/5)^2)
@@ -533,45 +562,131 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
   P.H = h;
   P.mask = d_mask;
   P.cells = (const int *)(s->det_in.as<char>() + o_cells);
-  P.cell_w = sxp;
-  P.cell_h = syp;
+  P.cell_w = J.sxp;
+  P.cell_h = J.syp;
   P.threshold = c.fast_threshold;
-  P.nfg = nfg;
+  P.nfg = J.nfg;
   P.cand_cap = 4096;
   P.boxes = (const int *)(s->det_in.as<char>() + o_boxes);
-  P.n_boxes = (int)boxes.size() / 2;
-  P.min_px_dist = min_px;
+  P.n_boxes = (int)J.boxes.size() / 2;
+  P.min_px_dist = c.min_px_dist;
   P.out_xy = (float *)(s->det_out.as<char>() + o_xy);
   P.out_resp = (float *)(s->det_out.as<char>() + o_resp);
   P.out_valid = (uint8_t *)(s->det_out.as<char>() + o_valid);
   {  // per-cell candidate lists of fast_tiles_kernel; the counters start at zero and fast_topk_kernel leaves them at zero
-    const size_t all_cells = (size_t)grid_x * grid_y;
+    const size_t all_cells = (size_t)c.grid_x * c.grid_y;
     if (s->det_cand_n.cap < all_cells * 4) {
       TRY(s->det_cand_n.reserve(all_cells * 4));
-      PLV_HIP_CHECK(hipMemsetAsync(s->det_cand_n.p, 0, s->det_cand_n.cap, ctx->stream));
+      PLV_HIP_CHECK(hipMemsetAsync(s->det_cand_n.p, 0, s->det_cand_n.cap, stream));
     }
     TRY(s->det_cand.reserve(all_cells * (size_t)P.cand_cap * 8));
   }
-  TRY(launch_fast_cells(ctx, P, n_cells, s->det_cand.as<unsigned long long>(), s->det_cand_n.as<int>()));
-  TRY(launch_subpix(ctx, P.img, w, h, n_slots, P.out_valid, P.out_xy, s->subpix_tab.as<float>(), 5, 20, 0.001));
-  PLV_HIP_CHECK(plv::memcpy_async(hp, s->det_out.p, out_total, hipMemcpyDeviceToHost, ctx->stream));
-  TRY(sync(ctx));
-  const float *oxy = (const float *)(hp + o_xy);
-  const uint8_t *oval = (const uint8_t *)(hp + o_valid);
-  // ---- REF :497-527 reject near existing points, assign ids in extraction order
-  for (int sl = 0; sl < n_slots && n < cap; ++sl) {
-    if (!oval[sl]) continue;
-    const float px = oxy[2 * sl], py = oxy[2 * sl + 1];
-    const int xg = (int)(px / (float)min_px), yg = (int)(py / (float)min_px);
-    if (xg < 0 || xg >= cw || yg < 0 || yg >= ch) continue;
-    if (close[(size_t)yg * cw + xg] > 127) continue;
-    close[(size_t)yg * cw + xg] = 255;
-    pts[2 * n] = px;
-    pts[2 * n + 1] = py;
-    ids[n] = ++*currid;
-    ++n;
+  hipStream_t keep = ctx->stream;
+  ctx->stream = stream;  // (the launchers take the stream from the ctx)
+  int rc = launch_fast_cells(ctx, P, n_cells, s->det_cand.as<unsigned long long>(), s->det_cand_n.as<int>());
+  if (rc == PLV_OK) rc = launch_subpix(ctx, P.img, w, h, n_slots, P.out_valid, P.out_xy, s->subpix_tab.as<float>(), 5, 20, 0.001);
+  ctx->stream = keep;
+  TRY(rc);
+  PLV_HIP_CHECK(plv::memcpy_async(J.h_out, s->det_out.p, out_total, hipMemcpyDeviceToHost, stream));
+  return PLV_OK;
+}
+
+// ---- REF :497-527 reject near existing points, assign ids in extraction order
+void det_post(plv_ctx *ctx, const DetJob &J, float *pts, uint64_t *ids, int cap, uint64_t *currid, int *n_out) {
+  int n = (int)J.ids.size();
+  std::copy(J.pts.begin(), J.pts.end(), pts);
+  std::copy(J.ids.begin(), J.ids.end(), ids);
+  if (J.n_slots > 0) {
+    const int min_px = ctx->cfg.min_px_dist;
+    std::vector<uint8_t> close = J.close;
+    const float *oxy = (const float *)(J.h_out);
+    const uint8_t *oval = (const uint8_t *)(J.h_out + (size_t)J.n_slots * 12);
+    for (int sl = 0; sl < J.n_slots && n < cap; ++sl) {
+      if (!oval[sl]) continue;
+      const float px = oxy[2 * sl], py = oxy[2 * sl + 1];
+      const int xg = (int)(px / (float)min_px), yg = (int)(py / (float)min_px);
+      if (xg < 0 || xg >= J.cw || yg < 0 || yg >= J.ch) continue;
+      if (close[(size_t)yg * J.cw + xg] > 127) continue;
+      close[(size_t)yg * J.cw + xg] = 255;
+      pts[2 * n] = px;
+      pts[2 * n + 1] = py;
+      ids[n] = ++*currid;
+      ++n;
+    }
   }
   *n_out = n;
+}
+
+// a detection that was started ahead of time and has not been collected: wait for it so that its buffers can be reused
+void det_drop_pending(FrontState *s) {
+  if (s->det_pending.active) {
+    (void)plv::event_sync(s->det_done);
+    s->det_pending.active = false;
+  }
+}
+}  // namespace
+
+int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *pts, uint64_t *ids, int n_in, int cap,
+                          uint64_t *currid, int *n_out) {
+  if (!ctx || !pts || !ids || !currid || !n_out || n_in < 0 || cap < n_in) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  if (s->fed < (which == PLV_PYR_LAST ? 2 : 1)) {
+    set_last_error("plv_perform_detection: no %s pyramid yet", which == PLV_PYR_LAST ? "last" : "current");
+    return PLV_E_BADARG;
+  }
+  // ---- a detection started ahead of time on what is now the last image, with these very points (and mask)?
+  DetJob &A = s->det_pending;
+  if (A.active) {
+    const bool same = which == PLV_PYR_LAST && A.fed + 1 == s->fed && A.n_in == n_in && A.has_mask == (mask != nullptr) &&
+                      (n_in == 0 || (!memcmp(A.in_pts.data(), pts, (size_t)n_in * 8) && !memcmp(A.in_ids.data(), ids, (size_t)n_in * 8))) &&
+                      (!mask || !memcmp(A.in_mask.data(), mask, (size_t)s->W * s->H));
+    (void)plv::event_sync(s->det_done);
+    A.active = false;
+    if (same) {
+      if ((int)A.ids.size() > cap) return PLV_E_CAPACITY;
+      det_post(ctx, A, pts, ids, cap, currid, n_out);
+      return PLV_OK;
+    }
+  }
+  const PyrDesc &pyr = s->pyr[which == PLV_PYR_LAST ? 1 - s->cur : s->cur];
+  DetJob J;
+  TRY(det_pre(ctx, s, mask, pts, ids, n_in, J));
+  if (J.n_slots > 0) {
+    TRY(det_launch(ctx, s, pyr, mask, J, ctx->stream));
+    TRY(sync(ctx));
+  }
+  det_post(ctx, J, pts, ids, cap, currid, n_out);
+  return PLV_OK;
+}
+
+// The top-up detection of the NEXT frame, started now: on the current image (the next frame's last image) with the points this frame
+// ended with.  Runs on a side stream next to whatever the caller enqueues on the ctx stream (the updates); plv_perform_detection of
+// the next frame finds it finished.  Not while the per-kernel profiler is on (its events live on the ctx stream).
+int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in) {
+  if (!ctx || n_in < 0 || (n_in > 0 && (!pts || !ids))) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  if (s->fed < 1 || ctx->prof.on) return PLV_OK;
+  det_drop_pending(s);
+  DetJob &A = s->det_pending;
+  TRY(det_pre(ctx, s, mask, pts, ids, n_in, A));
+  A.fed = s->fed;
+  A.n_in = n_in;
+  A.has_mask = mask != nullptr;
+  A.in_pts.assign(pts, pts + 2 * (size_t)n_in);
+  A.in_ids.assign(ids, ids + n_in);
+  if (mask)
+    A.in_mask.assign(mask, mask + (size_t)s->W * s->H);
+  else
+    A.in_mask.clear();
+  if (!s->det_stream) {
+    PLV_HIP_CHECK(hipStreamCreateWithFlags(&s->det_stream, hipStreamNonBlocking));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&s->det_done, hipEventDisableTiming));
+  }
+  if (A.n_slots > 0) TRY(det_launch(ctx, s, s->pyr[s->cur], mask ? A.in_mask.data() : nullptr, A, s->det_stream));  // (the job's own copy of the mask)
+  PLV_HIP_CHECK(hipEventRecord(s->det_done, s->det_stream));
+  A.active = true;
   return PLV_OK;
 }
 

@@ -24,6 +24,7 @@ struct Tracker {
   std::vector<uint64_t> ids_last;
   std::vector<uint8_t> mask_last;  // W*H or empty
   uint64_t currid = 0;             // REF: TrackBase::currid (4*num_aruco + 1 - 1 = 0 without ArUco tags)
+  bool detect_ahead = true;        // plv_tracker_detect_ahead: start the next frame's top-up detection at the end of this feed
   std::unordered_map<uint64_t, Track> db;
   struct UsedPoint {
     double p[3], newest;
@@ -103,6 +104,7 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
+extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in);  // frontend_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
   plv::HostPhase ph_all("tracker_feed (after the image feed)");
@@ -171,6 +173,17 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   T->pts_last.swap(good);
   T->ids_last.swap(good_ids);
   keep_mask();
+  // the next frame's top-up works on this image with these points (:127-131): start it now, on a side stream, next to the updates
+  if (T->detect_ahead && !T->ids_last.empty())
+    (void)plv_perform_detection_ahead(ctx, mask, T->pts_last.data(), T->ids_last.data(), (int)T->ids_last.size());
+  return PLV_OK;
+}
+
+int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
+  if (!ctx) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  T->detect_ahead = on != 0;
   return PLV_OK;
 }
 
