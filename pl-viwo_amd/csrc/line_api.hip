@@ -1078,19 +1078,15 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   plv::HostPhase ph_post("update_lines: selection + database");
   if (timing) fprintf(stderr, "update lines: pool + staging %.1f us (%d lines, %d observations), device submission + wait %.1f us\n", us_pool, Lp, nobs, us_dev);
   std::vector<int> sel;
-  std::vector<double> t_first(Lp, -1e300);  // oldest observation time a truncated track keeps
+  std::vector<int> n_skip(Lp, 0);  // usable observations a truncated track leaves out (its first ones)
   for (int l = 0; l < Lp; ++l) {
     const int valid = valid_n[l];
     if (!ok[l] || valid < 2 || (int)sel.size() >= cap) {
       give_back_all(pool[l]);
       continue;
     }
-    if (valid > opt->max_obs) {  // batch capacity (none in the reference): the newest max_obs observations, counted in n_truncated
-      std::vector<double> tv;
-      for (double t : pool[l].tr.t)
-        if (line_has_bounding_poses(*st, t + dt)) tv.push_back(t);
-      std::nth_element(tv.begin(), tv.begin() + (valid - opt->max_obs), tv.end());
-      t_first[l] = tv[valid - opt->max_obs];
+    if (valid > opt->max_obs) {  // batch capacity (none in the reference): the last max_obs usable observations, counted in n_truncated
+      n_skip[l] = valid - opt->max_obs;
       ++res->n_truncated;
     }
     sel.push_back(l);
@@ -1107,12 +1103,13 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   std::vector<float> suv;
   for (int q = 0; q < L; ++q) {
     const Cand &c = pool[sel[q]];
+    int seen = 0;
     for (size_t i = 0; i < c.tr.t.size(); ++i) {
       if (!line_has_bounding_poses(*st, c.tr.t[i] + dt)) {
         give_back(c, i);
         continue;
       }
-      if (c.tr.t[i] < t_first[sel[q]]) continue;
+      if (seen++ < n_skip[sel[q]]) continue;
       st_t.push_back(c.tr.t[i]);
       suv.insert(suv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
       if (opt->cpi) {

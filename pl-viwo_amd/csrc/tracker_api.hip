@@ -580,7 +580,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   plv::HostPhase ph_post("update_points: selection + database");
   // ---- REF :648-699 the selection loop
   std::vector<int> sel;
-  std::vector<double> t_first(Fp, -1e300);  // oldest observation time a truncated track keeps
+  std::vector<int> n_skip(Fp, 0);  // usable observations a truncated track leaves out (its oldest)
   for (int f = 0; f < Fp; ++f) {
     Cand &c = pool[f];
     if ((int)sel.size() >= opt->max_msckf) {  // :651-653 break; the rest returns to the database (:702)
@@ -616,11 +616,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     // batch capacity of the MSCKF update (the reference has none): the newest max_obs observations are used, the older ones are
     // consumed with the feature; counted in res->n_truncated
     if (valid > opt->max_obs) {
-      std::vector<double> tv;
-      for (size_t i = 0; i < c.tr.t.size(); ++i)
-        if (has_bounding_poses(*st, c.tr.t[i] + dt)) tv.push_back(c.tr.t[i]);
-      std::nth_element(tv.begin(), tv.begin() + (valid - opt->max_obs), tv.end());
-      t_first[f] = tv[valid - opt->max_obs];
+      n_skip[f] = valid - opt->max_obs;  // the first (oldest) usable observations are left out
       ++res->n_truncated;
     }
     sel.push_back(f);
@@ -638,12 +634,13 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   std::vector<float> suv;
   for (int q = 0; q < F; ++q) {
     const Cand &c = pool[sel[q]];
+    int seen = 0;
     for (size_t i = 0; i < c.tr.t.size(); ++i) {
       if (!has_bounding_poses(*st, c.tr.t[i] + dt)) {
         give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
         continue;
       }
-      if (c.tr.t[i] < t_first[sel[q]]) continue;
+      if (seen++ < n_skip[sel[q]]) continue;
       st_t.push_back(c.tr.t[i]);
       suv.push_back(c.tr.uv[2 * i]);
       suv.push_back(c.tr.uv[2 * i + 1]);

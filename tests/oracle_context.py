@@ -190,19 +190,19 @@ class OracleContext:
                         give(lid, e, i)
                     continue
                 if valid > max_obs:
-                    tv = sorted(t for t in e["t"] if bounding(t))
-                    t_first[l] = tv[valid - max_obs]
+                    t_first[l] = valid - max_obs
                 sel.append(l)
             if sel:
                 tt, uv, counts = [], [], []
                 for l in sel:
                     lid, e = kept[l]
-                    c = 0
+                    c = seen = 0
                     for i, t in enumerate(e["t"]):
                         if not bounding(t):
                             give(lid, e, i)
                             continue
-                        if t < t_first.get(l, -1e300):
+                        seen += 1
+                        if seen <= t_first.get(l, 0):
                             continue
                         tt.append(t), uv.append(e["uv"][i])
                         c += 1

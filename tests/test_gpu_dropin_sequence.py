@@ -78,20 +78,20 @@ class MirrorUpdater:
                     for x in zip(*k):
                         give(fid, *x)
                     continue
-                if valid > MAX_OBS:   # batch capacity: the newest MAX_OBS usable observations
-                    tv = sorted(t for t in k[0] if self._bounding(ct, t))
-                    t_first[q] = tv[valid - MAX_OBS]
+                if valid > MAX_OBS:   # batch capacity: the last MAX_OBS usable observations
+                    t_first[q] = valid - MAX_OBS
                 sel.append(q)
             if sel:
                 tt, uvs, counts = [], [], []
                 for q in sel:
                     fid, k = kept[q]
-                    c = 0
+                    c = seen = 0
                     for t, uv, uvn in zip(*k):
                         if not self._bounding(ct, t):
                             give(fid, t, uv, uvn)
                             continue
-                        if t < t_first.get(q, -1e300):
+                        seen += 1
+                        if seen <= t_first.get(q, 0):
                             continue
                         tt.append(t), uvs.append(uv)
                         c += 1
