@@ -308,6 +308,10 @@ typedef struct plv_state_view {
   int use_pol_cov;             /* REF: CamHelper.cpp:214-217 */
   double intr_ori_cov, intr_pos_cov; /* interpolation_error::ori_cov / pos_cov (OptionsEstimator.h:60-80) */
   int feat_rep;                /* PLV_FEAT_* */
+  int use_imu_cov;             /* OptionsEstimator::use_imu_cov (REF: CamHelper.cpp:217-224, LineHelper's twin): the CPI covariance of the
+                                  pose an observation was made at inflates its noise; read only when use_pol_cov is 0 and the
+                                  tracks carry res_Q / res_clone */
+  double intr_err_mlt;         /* OptionsEstimator::intr_err.mlt, the factor on that covariance */
 } plv_state_view;
 
 typedef struct plv_tracks {
@@ -321,6 +325,8 @@ typedef struct plv_tracks {
                               pose when use_imu_res (State.cpp:1138-1155); NULL -> estimate polynomial */
   const double *res_p;     /* optional [n_obs][3] */
   const float *obs_uvn;    /* [n_obs][2] normalised coordinates (Feature::uvs_norm); only plv_triangulate reads it */
+  const double *res_Q;     /* optional [n_obs][36], row-major 6x6: State::CPI::Q of the record behind res_R / res_p (use_imu_cov) */
+  const int *res_clone;    /* optional [n_obs]: index into the view's clone arrays of that record's clone (CPI::clone_t)      */
 } plv_tracks;
 
 /* FeatureInitializerOptions (REF: open_vins/ov_core/src/feat/FeatureInitializerOptions.h:36-69;
@@ -375,9 +381,15 @@ typedef struct plv_cpi_table {
   const double *alpha;    /* [n][3] CPI::alpha_I0toIk                             */
   const double *v;        /* [n][3] CPI::v (global velocity at t)                 */
   double gravity[3];      /* OptionsEstimator::gravity                            */
+  const double *Q;        /* optional [n][36] row-major: CPI::Q (plv_cpi_record::Q); read by plv_cpi_noise */
 } plv_cpi_table;
 int plv_cpi_poses(plv_ctx *ctx, const plv_state_view *st, const plv_cpi_table *cpi, int n_q, const double *t_q, double *R_GtoI,
                   double *p_IinG, uint8_t *ok);
+/* The noise side of the same lookup (use_imu_cov): Q of the record stored at t_q, else (1 - lambda) Q0 + lambda Q1 between the
+ * neighbouring records of the same clone (create_new_cpi_linear, REF: State.cpp:287-355), and the index of that clone in the
+ * view.  ok = 0 where plv_cpi_poses answers 0 as well.  Host arithmetic. */
+int plv_cpi_noise(const plv_state_view *st, const plv_cpi_table *cpi, int n_q, const double *t_q, double *Q /*[n_q][36]*/,
+                  int *clone_index, uint8_t *ok);
 
 /* ---------------------------------------------------------------------------------------------
  * Line features on the update side (a27-a29).
@@ -396,6 +408,8 @@ typedef struct plv_line_tracks {
   const uint8_t *has_pt;    /* [n_lines] anchor_pt valid (REF: LineHelper.cpp:231-247); NULL = none       */
   const double *res_R;      /* optional [n_obs][9] / [n_obs][3]: IMU pose of the residual, as plv_tracks  */
   const double *res_p;
+  const double *res_Q;      /* optional [n_obs][36] + [n_obs]: CPI covariance and clone index, as plv_tracks (use_imu_cov) */
+  const int *res_clone;
 } plv_line_tracks;
 
 /* plv_triangulate_lines replaces, for all lines at once, LineHelper::get_imu_poses / get_cam_poses /

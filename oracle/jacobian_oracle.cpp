@@ -315,6 +315,29 @@ inline int find_col(const int *col_to_state, int k, int state_id) {
 
 }  // namespace
 
+// REF: CamHelper.cpp:217-224 (and LineHelper's twin): R += H_ Q H_^T * mlt with H_ = HI * blockdiag(I, R_clone_fej^T)
+static void add_imu_cov(const plv_state_view *st, const double *Q, int clone, const double *HI, double *Rn) {
+  const double *Rc = st->clone_R_fej + 9 * (size_t)clone;
+  double Hc[12], HQ[12];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Hc[6 * i + j] = HI[6 * i + j];
+      Hc[6 * i + 3 + j] = HI[6 * i + 3] * Rc[3 * j] + HI[6 * i + 4] * Rc[3 * j + 1] + HI[6 * i + 5] * Rc[3 * j + 2];
+    }
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int q = 0; q < 6; ++q) s += Hc[6 * i + q] * Q[6 * q + j];
+      HQ[6 * i + j] = s;
+    }
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      double s = 0;
+      for (int q = 0; q < 6; ++q) s += HQ[6 * i + q] * Hc[6 * j + q];
+      Rn[2 * i + j] += s * st->intr_err_mlt;
+    }
+}
+
 extern "C" {
 
 // column order: see plv_jacobian_columns
@@ -428,6 +451,8 @@ int orc_build_jacobians(const plv_state_view *st, const plv_tracks *tr, int k, c
             for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? st->intr_ori_cov : st->intr_pos_cov) * HI[6 * j + q];
             Rn[2 * i + j] += s;
           }
+      } else if (!at_clone && st->use_imu_cov && tr->res_Q) {
+        add_imu_cov(st, tr->res_Q + 36 * (size_t)o, tr->res_clone[o], HI, Rn);
       }
       const double l00 = std::sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = std::sqrt(Rn[3] - l10 * l10);
       // B = [[l00, l10],[l10, l11]] (selfadjoint lower); X = B^-1 via its own Cholesky
@@ -860,6 +885,8 @@ int orc_build_line_jacobians(const plv_state_view *st, const plv_line_tracks *lt
             for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? st->intr_ori_cov : st->intr_pos_cov) * HI[6 * j + q];
             Rn[2 * i + j] += s;
           }
+      } else if (!at_clone && st->use_imu_cov && lt->res_Q) {
+        add_imu_cov(st, lt->res_Q + 36 * (size_t)o, lt->res_clone[o], HI, Rn);
       }
       const double l00 = std::sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = std::sqrt(Rn[3] - l10 * l10);
       const double m00 = std::sqrt(l00), m10 = l10 / m00, m11 = std::sqrt(l11 - m10 * m10);

@@ -123,6 +123,7 @@ def load_library():
         "plv_db_export_tracks": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int, ip, dp, fp, fp, C.c_int]),
         "plv_db_cleanup_measurements": (C.c_int, [vp, C.c_double]),
         "plv_db_remove": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+        "plv_cpi_noise": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvCpiTable), C.c_int, dp, dp, ip, u8p]),
         "plv_triangulate": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.POINTER(PlvTriOptions), dp, u8p, dp]),
         "plv_jacobian_columns": (C.c_int, [C.POINTER(PlvStateView), C.POINTER(PlvTracks), ip, C.c_int, ip]),
         "plv_build_jacobians": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTracks), C.c_int, ip, C.c_int, ip, dp,
@@ -244,7 +245,7 @@ class PlvStateView(C.Structure):
         ("extrinsic_state_id", C.c_int), ("intrinsic_state_id", C.c_int), ("dt_state_id", C.c_int),
         ("intr_order", C.c_int), ("dt_exp", C.c_double), ("sigma_pix", C.c_double),
         ("use_pol_cov", C.c_int), ("intr_ori_cov", C.c_double), ("intr_pos_cov", C.c_double),
-        ("feat_rep", C.c_int),
+        ("feat_rep", C.c_int), ("use_imu_cov", C.c_int), ("intr_err_mlt", C.c_double),
     ]
 
 
@@ -255,6 +256,7 @@ class PlvTracks(C.Structure):
         ("p_FinG", C.POINTER(C.c_double)), ("p_FinG_fej", C.POINTER(C.c_double)),
         ("res_R", C.POINTER(C.c_double)), ("res_p", C.POINTER(C.c_double)),
         ("obs_uvn", C.POINTER(C.c_float)),
+        ("res_Q", C.POINTER(C.c_double)), ("res_clone", C.POINTER(C.c_int)),
     ]
 
 
@@ -266,6 +268,7 @@ class PlvLineTracks(C.Structure):
         ("line_FinG", C.POINTER(C.c_double)), ("D", C.POINTER(C.c_int)),
         ("anchor_pt", C.POINTER(C.c_double)), ("has_pt", C.POINTER(C.c_uint8)),
         ("res_R", C.POINTER(C.c_double)), ("res_p", C.POINTER(C.c_double)),
+        ("res_Q", C.POINTER(C.c_double)), ("res_clone", C.POINTER(C.c_int)),
     ]
 
 
@@ -277,20 +280,22 @@ class PlvTriOptions(C.Structure):
 class PlvCpiTable(C.Structure):
     _fields_ = [("n", C.c_int), ("t", C.POINTER(C.c_double)), ("clone_t", C.POINTER(C.c_double)), ("dt", C.POINTER(C.c_double)),
                 ("R_I0toIk", C.POINTER(C.c_double)), ("alpha", C.POINTER(C.c_double)), ("v", C.POINTER(C.c_double)),
-                ("gravity", C.c_double * 3)]
+                ("gravity", C.c_double * 3), ("Q", C.POINTER(C.c_double))]
 
 
 class CpiTable:
     """Owns the arrays behind a plv_cpi_table (State::cpis sorted by time)."""
 
-    def __init__(self, t, clone_t, R, alpha, v, gravity=(0.0, 0.0, 9.81)):
+    def __init__(self, t, clone_t, R, alpha, v, gravity=(0.0, 0.0, 9.81), Q=None):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         self.t, self.clone_t = f(t), f(clone_t)
+        self.Q = f(Q).reshape(-1, 36) if Q is not None else None
         self.dt = self.t - self.clone_t
         self.R, self.alpha, self.v = f(R).reshape(-1, 9), f(alpha).reshape(-1, 3), f(v).reshape(-1, 3)
         c = PlvCpiTable()
         c.n = len(self.t)
         c.t, c.clone_t, c.dt, c.R_I0toIk, c.alpha, c.v = _dp(self.t), _dp(self.clone_t), _dp(self.dt), _dp(self.R), _dp(self.alpha), _dp(self.v)
+        c.Q = _dp(self.Q)
         c.gravity = (C.c_double * 3)(*gravity)
         self.c = c
 
@@ -545,7 +550,7 @@ class StateView:
 
     def __init__(self, clone_time, clone_R, clone_p, clone_state_id, R_ItoC, p_IinC, intrinsics, clone_R_fej=None,
                  clone_p_fej=None, cam_dt=0.0, extrinsic_state_id=-1, intrinsic_state_id=-1, dt_state_id=-1, sigma_pix=1.5,
-                 use_pol_cov=0, intr_ori_cov=0.0, intr_pos_cov=0.0, feat_rep=0, dt_exp=0.01):
+                 use_pol_cov=0, intr_ori_cov=0.0, intr_pos_cov=0.0, feat_rep=0, dt_exp=0.01, use_imu_cov=0, intr_err_mlt=1.0):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         self.t, self.R, self.p = f(clone_time), f(clone_R).reshape(-1, 9), f(clone_p).reshape(-1, 3)
         self.Rf = f(clone_R_fej).reshape(-1, 9) if clone_R_fej is not None else self.R.copy()
@@ -561,13 +566,14 @@ class StateView:
         v.cam_dt, v.extrinsic_state_id, v.intrinsic_state_id, v.dt_state_id = cam_dt, extrinsic_state_id, intrinsic_state_id, dt_state_id
         v.intr_order, v.dt_exp, v.sigma_pix = 3, dt_exp, sigma_pix
         v.use_pol_cov, v.intr_ori_cov, v.intr_pos_cov, v.feat_rep = use_pol_cov, intr_ori_cov, intr_pos_cov, feat_rep
+        v.use_imu_cov, v.intr_err_mlt = int(use_imu_cov), float(intr_err_mlt)
         self.c = v
 
 
 class Tracks:
     """Owns the numpy arrays behind a plv_tracks (CSR observation lists)."""
 
-    def __init__(self, obs_ptr, obs_time, obs_uv, p_FinG, p_FinG_fej=None, res_R=None, res_p=None, obs_uvn=None):
+    def __init__(self, obs_ptr, obs_time, obs_uv, p_FinG, p_FinG_fej=None, res_R=None, res_p=None, obs_uvn=None, res_Q=None, res_clone=None):
         self.ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
         self.t = np.ascontiguousarray(obs_time, dtype=np.float64)
         self.uv = np.ascontiguousarray(obs_uv, dtype=np.float32).reshape(-1, 2)
@@ -581,6 +587,9 @@ class Tracks:
         v.p_FinG, v.p_FinG_fej, v.res_R, v.res_p = _dp(self.pf), _dp(self.pff), _dp(self.rR), _dp(self.rp)
         self.uvn = np.ascontiguousarray(obs_uvn, dtype=np.float32).reshape(-1, 2) if obs_uvn is not None else None
         v.obs_uvn = _fp(self.uvn)
+        self.rQ = np.ascontiguousarray(res_Q, dtype=np.float64).reshape(-1, 36) if res_Q is not None else None
+        self.rc = np.ascontiguousarray(res_clone, dtype=np.int32) if res_clone is not None else None
+        v.res_Q, v.res_clone = _dp(self.rQ), _ip(self.rc)
         self.c = v
 
 
@@ -588,7 +597,7 @@ class LineTracks:
     """Owns the numpy arrays behind a plv_line_tracks."""
 
     def __init__(self, obs_ptr, obs_time, seg_uv, seg_uvn=None, line_FinG=None, D=None, anchor_pt=None, has_pt=None,
-                 res_R=None, res_p=None):
+                 res_R=None, res_p=None, res_Q=None, res_clone=None):
         f64 = lambda a, w: np.ascontiguousarray(a, dtype=np.float64).reshape(-1, w) if a is not None else None
         f32 = lambda a, w: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w) if a is not None else None
         self.ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
@@ -603,7 +612,20 @@ class LineTracks:
         v.obs_ptr, v.obs_time, v.seg_uv, v.seg_uvn = _ip(self.ptr), _dp(self.t), _fp(self.uv), _fp(self.uvn)
         v.line_FinG, v.D, v.anchor_pt, v.has_pt = _dp(self.lg), _ip(self.D), _dp(self.ap), _u8p(self.hp)
         v.res_R, v.res_p = _dp(self.rR), _dp(self.rp)
+        self.rQ = np.ascontiguousarray(res_Q, dtype=np.float64).reshape(-1, 36) if res_Q is not None else None
+        self.rc = np.ascontiguousarray(res_clone, dtype=np.int32) if res_clone is not None else None
+        v.res_Q, v.res_clone = _dp(self.rQ), _ip(self.rc)
         self.c = v
+
+
+def cpi_noise(st, cpi, t_q):
+    """plv_cpi_noise: (Q [n][36], clone index [n], ok [n]) of the CPI record behind each query time."""
+    t_q = np.ascontiguousarray(t_q, dtype=np.float64)
+    Q, ci, ok = np.zeros((len(t_q), 36)), np.zeros(len(t_q), dtype=np.int32), np.zeros(len(t_q), dtype=np.uint8)
+    rc = load_library().plv_cpi_noise(C.byref(st.c), C.byref(cpi.c), len(t_q), _dp(t_q), _dp(Q), _ip(ci), _u8p(ok))
+    if rc != PLV_OK:
+        raise PlvError(rc, load_library().plv_last_error().decode())
+    return Q, ci, ok
 
 
 def counters():

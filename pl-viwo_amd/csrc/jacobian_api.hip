@@ -88,7 +88,8 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
                o_ccol = take(4 * N), o_ptr = take(4 * (F + 1)), o_of = take(4 * nobs), o_ot = take(8 * nobs),
                o_uv = take(8 * nobs), o_pg = take(24 * F), o_pgf = take(24 * F),
                o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0, o_cols = take(4 * (size_t)k),
-               o_xuvn = ex && ex->uvn ? take(8 * nobs) : 0, o_xfl = ex && ex->flags ? take(F) : 0;
+               o_xuvn = ex && ex->uvn ? take(8 * nobs) : 0, o_xfl = ex && ex->flags ? take(F) : 0,
+               o_rQ = tr->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = tr->res_Q ? take(4 * (size_t)nobs) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
@@ -117,6 +118,11 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
     memcpy(h + o_rR, tr->res_R, 72 * nobs);
     memcpy(h + o_rp, tr->res_p, 24 * nobs);
   }
+  if (tr->res_Q) {
+    if (!tr->res_clone) return PLV_E_BADARG;
+    memcpy(h + o_rQ, tr->res_Q, 288 * (size_t)nobs);
+    memcpy(h + o_rc, tr->res_clone, 4 * (size_t)nobs);
+  }
   PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = us->jin.as<char>();
   P.n_clones = N;
@@ -135,6 +141,10 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   P.intr_ori_cov = st->intr_ori_cov;
   P.intr_pos_cov = st->intr_pos_cov;
   P.use_pol_cov = st->use_pol_cov;
+  P.use_imu_cov = st->use_imu_cov && tr->res_Q ? 1 : 0;
+  P.intr_err_mlt = st->intr_err_mlt;
+  P.res_Q = tr->res_Q ? (const double *)(d + o_rQ) : nullptr;
+  P.res_clone = tr->res_Q ? (const int *)(d + o_rc) : nullptr;
   P.feat_rep = st->feat_rep;
   P.col_ext = col_of(st->extrinsic_state_id);
   P.col_int = col_of(st->intrinsic_state_id);
@@ -404,7 +414,8 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
                o_ccol = take(4 * N), o_ptr = take(4 * (L + 1)), o_ot = take(8 * nobs), o_uv = take(16 * nobs),
                o_uvn = lt->seg_uvn ? take(16 * nobs) : 0, o_lg = lt->line_FinG ? take(48 * L) : 0,
                o_D = lt->D ? take(4 * L) : 0, o_ap = lt->has_pt ? take(24 * L) : 0, o_hp = lt->has_pt ? take(L) : 0,
-               o_rR = lt->res_R ? take(72 * nobs) : 0, o_rp = lt->res_R ? take(24 * nobs) : 0;
+               o_rR = lt->res_R ? take(72 * nobs) : 0, o_rp = lt->res_R ? take(24 * nobs) : 0,
+               o_rQ = lt->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = lt->res_Q ? take(4 * (size_t)nobs) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
@@ -432,6 +443,11 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
     memcpy(h + o_rR, lt->res_R, 72 * nobs);
     memcpy(h + o_rp, lt->res_p, 24 * nobs);
   }
+  if (lt->res_Q) {
+    if (!lt->res_clone) return PLV_E_BADARG;
+    memcpy(h + o_rQ, lt->res_Q, 288 * (size_t)nobs);
+    memcpy(h + o_rc, lt->res_clone, 4 * (size_t)nobs);
+  }
   PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = us->jin.as<char>();
   P.n_clones = N;
@@ -450,6 +466,10 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   P.intr_ori_cov = st->intr_ori_cov;
   P.intr_pos_cov = st->intr_pos_cov;
   P.use_pol_cov = st->use_pol_cov;
+  P.use_imu_cov = st->use_imu_cov && lt->res_Q ? 1 : 0;
+  P.intr_err_mlt = st->intr_err_mlt;
+  P.res_Q = lt->res_Q ? (const double *)(d + o_rQ) : nullptr;
+  P.res_clone = lt->res_Q ? (const int *)(d + o_rc) : nullptr;
   P.feat_rep = st->feat_rep;
   P.col_ext = P.col_int = -1;
   P.col_dt = col_of(st->dt_state_id);
@@ -619,6 +639,52 @@ int plv_triangulate_lines(plv_ctx *ctx, const plv_state_view *st, const plv_line
   PLV_HIP_CHECK(plv::memcpy_async(ok, d + o_ok, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
   PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   ctx->prof.collect();
+  return PLV_OK;
+}
+
+// The record behind a query time, as cpi_pose_kernel finds it, for its covariance (host arithmetic: a search and one blend).
+int plv_cpi_noise(const plv_state_view *st, const plv_cpi_table *cpi, int n_q, const double *t_q, double *Q, int *clone_index, uint8_t *ok) {
+  if (!st || !cpi || n_q < 0 || (n_q > 0 && (!t_q || !Q || !clone_index || !ok)) || st->n_clones < 1) return PLV_E_BADARG;
+  if (cpi->n > 0 && (!cpi->t || !cpi->clone_t || !cpi->Q)) {
+    set_last_error("plv_cpi_noise: the table carries no covariances (plv_cpi_table::Q)");
+    return PLV_E_BADARG;
+  }
+  const int n = cpi->n;
+  auto find_t = [&](double t) {
+    const double *e = std::lower_bound(cpi->t, cpi->t + n, t);
+    return (e != cpi->t + n && *e == t) ? (int)(e - cpi->t) : -1;
+  };
+  auto find_clone = [&](double t) {
+    for (int i = 0; i < st->n_clones; ++i)
+      if (st->clone_time[i] == t) return i;
+    return -1;
+  };
+  for (int q = 0; q < n_q; ++q) {
+    ok[q] = 0;
+    clone_index[q] = -1;
+    std::fill(Q + 36 * (size_t)q, Q + 36 * (size_t)q + 36, 0.0);
+    const double t = t_q[q];
+    double clone_t;
+    const int e = find_t(t);
+    if (e >= 0 && find_clone(cpi->clone_t[e]) >= 0) {  // REF State.cpp:275-277
+      std::copy(cpi->Q + 36 * (size_t)e, cpi->Q + 36 * (size_t)e + 36, Q + 36 * (size_t)q);
+      clone_t = cpi->clone_t[e];
+    } else {  // create_new_cpi_linear :286-355
+      if (n == 0 || t < cpi->t[0] || t > cpi->t[n - 1]) continue;
+      const int lo = (int)(std::lower_bound(cpi->t, cpi->t + n, t) - cpi->t);
+      const int i0 = (t == cpi->t[0]) ? 0 : lo - 1;
+      const int up = (int)(std::upper_bound(cpi->t, cpi->t + n, t) - cpi->t);
+      const int i1 = (t == cpi->t[n - 1]) ? n - 1 : up;
+      if (cpi->clone_t[i0] != cpi->clone_t[i1] || cpi->clone_t[i0] < st->clone_time[0]) continue;
+      const double lambda = (t - cpi->t[i0]) / (cpi->t[i1] - cpi->t[i0]);
+      for (int j = 0; j < 36; ++j) Q[36 * (size_t)q + j] = (1 - lambda) * cpi->Q[36 * (size_t)i0 + j] + lambda * cpi->Q[36 * (size_t)i1 + j];
+      clone_t = cpi->clone_t[i0];
+    }
+    const int ci = find_clone(clone_t);
+    if (ci < 0 || find_t(clone_t) < 0) continue;
+    clone_index[q] = ci;
+    ok[q] = 1;
+  }
   return PLV_OK;
 }
 

@@ -472,6 +472,40 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   }
 }
 
+// REF: CamHelper.cpp:217-224 (and LineHelper's twin): R += H_ Q H_^T * mlt with H_ = HI * blockdiag(I, R_clone_fej^T), HI the 2 x 6
+// Jacobian of the measurement in the interpolated pose, Q the CPI covariance of that pose.
+__device__ __forceinline__ void add_imu_cov(const JacParams &P, int o, const double *HI, double *Rn) {
+  const double *Q = P.res_Q + 36 * (size_t)o;
+  const double *Rc = P.clone_R_fej + 9 * (size_t)P.res_clone[o];  // Rot_fej of the clone, row-major; H_cpi(3:6,3:6) = its transpose
+  double Hc[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Hc[6 * i + j] = HI[6 * i + j];
+      Hc[6 * i + 3 + j] = HI[6 * i + 3] * Rc[3 * j] + HI[6 * i + 4] * Rc[3 * j + 1] + HI[6 * i + 5] * Rc[3 * j + 2];
+    }
+  double HQ[12];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += Hc[6 * i + q] * Q[6 * q + j];
+      HQ[6 * i + j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += HQ[6 * i + q] * Hc[6 * j + q];
+      Rn[2 * i + j] += s * P.intr_err_mlt;
+    }
+}
+
 // Element (row, col) of a block goes to base[col * cstr + row * rstr]: (ld, 1) for the batch in global memory (column-major per
 // feature), (1, ncol) for the row-major LDS image the fused kernel projects in place.
 __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int o, int s0, double tm, int c, double *hf, double *hx,
@@ -575,6 +609,8 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
         for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
         Rn[2 * i + j] += s;
       }
+  } else if (!at_clone && P.use_imu_cov) {
+    add_imu_cov(P, o, HI, Rn);
   }
   const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
   const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
@@ -1148,6 +1184,8 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
         for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
         Rn[2 * i + j] += s;
       }
+  } else if (!at_clone && P.use_imu_cov) {
+    add_imu_cov(P, o, HI, Rn);
   }
   const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
   const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);

@@ -38,6 +38,11 @@ struct JacParams {
   const unsigned char *sel_flags, *tri_ok;
   const double *tri_err;
   int max_sel;
+  // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
+  int use_imu_cov;
+  double intr_err_mlt;
+  const double *res_Q;
+  const int *res_clone;
 };
 
 struct CpiParams {  // device pointers; State::cpis as a table sorted by time + the clone window

@@ -954,7 +954,9 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   // ---- triangulate every pool line (REF :45-63; get_imu_poses drops views without bounding clones)
   const int Lp = (int)pool.size();
   // ---- use_imu_res: poses from the CPI table (plv_update_options::cpi); views it cannot serve go back to the database
-  std::vector<std::vector<double>> cpiR(opt->cpi ? Lp : 0), cpip(opt->cpi ? Lp : 0);
+  std::vector<std::vector<double>> cpiR(opt->cpi ? Lp : 0), cpip(opt->cpi ? Lp : 0), cpiQ(opt->cpi ? Lp : 0);
+  std::vector<std::vector<int>> cpiC(opt->cpi ? Lp : 0);
+  const bool imu_cov = opt->cpi && opt->cpi->Q && st->use_imu_cov && !st->use_pol_cov;
   if (opt->cpi) {
     std::vector<double> tq;
     for (const Cand &c : pool)
@@ -962,6 +964,13 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
     std::vector<uint8_t> okq(tq.size());
     int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
+    std::vector<double> Qq(imu_cov ? 36 * tq.size() : 0);
+    std::vector<int> Cq(imu_cov ? tq.size() : 0);
+    if (rc0 == PLV_OK && imu_cov) {
+      std::vector<uint8_t> okn(tq.size());
+      rc0 = plv_cpi_noise(st, opt->cpi, (int)tq.size(), tq.data(), Qq.data(), Cq.data(), okn.data());
+      for (size_t i = 0; i < tq.size(); ++i) okq[i] = okq[i] && okn[i];
+    }
     if (rc0 != PLV_OK) {
       for (Cand &c : pool) give_back_all(c);
       return finish(rc0);
@@ -982,6 +991,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
         kept.uvn.insert(kept.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
         cpiR[l].insert(cpiR[l].end(), &Rq[9 * o], &Rq[9 * o] + 9);
         cpip[l].insert(cpip[l].end(), &pq[3 * o], &pq[3 * o] + 3);
+        if (imu_cov) {
+          cpiQ[l].insert(cpiQ[l].end(), &Qq[36 * o], &Qq[36 * o] + 36);
+          cpiC[l].push_back(Cq[o]);
+        }
       }
       c.tr = std::move(kept);
     }
@@ -1099,7 +1112,8 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   // ---- UpdaterCamera::lines_update
   const int L = (int)sel.size();
   std::vector<int> sptr(L + 1, 0);
-  std::vector<double> st_t, sl(6 * (size_t)L), selR, selp;
+  std::vector<double> st_t, sl(6 * (size_t)L), selR, selp, selQ;
+  std::vector<int> selC;
   std::vector<float> suv;
   for (int q = 0; q < L; ++q) {
     const Cand &c = pool[sel[q]];
@@ -1115,6 +1129,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       if (opt->cpi) {
         selR.insert(selR.end(), &cpiR[sel[q]][9 * i], &cpiR[sel[q]][9 * i] + 9);
         selp.insert(selp.end(), &cpip[sel[q]][3 * i], &cpip[sel[q]][3 * i] + 3);
+        if (imu_cov) {
+          selQ.insert(selQ.end(), &cpiQ[sel[q]][36 * i], &cpiQ[sel[q]][36 * i] + 36);
+          selC.push_back(cpiC[sel[q]][i]);
+        }
       }
     }
     sptr[q + 1] = (int)st_t.size();
@@ -1131,6 +1149,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   if (opt->cpi) {
     lt.res_R = selR.data();
     lt.res_p = selp.data();
+    if (imu_cov) {
+      lt.res_Q = selQ.data();
+      lt.res_clone = selC.data();
+    }
   }
   std::vector<uint8_t> acc(L, 0);
   if (fused_ran) {

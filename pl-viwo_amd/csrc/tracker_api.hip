@@ -466,7 +466,9 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   //      feature it never reaches keeps its observations either way)
   const int Fp = (int)pool.size();
   // ---- use_imu_res: poses from the CPI table; what it cannot serve leaves the track here (get_imu_poses, :356-365)
-  std::vector<std::vector<double>> cpiR(opt->cpi ? Fp : 0), cpip(opt->cpi ? Fp : 0);
+  std::vector<std::vector<double>> cpiR(opt->cpi ? Fp : 0), cpip(opt->cpi ? Fp : 0), cpiQ(opt->cpi ? Fp : 0);
+  std::vector<std::vector<int>> cpiC(opt->cpi ? Fp : 0);
+  const bool imu_cov = opt->cpi && opt->cpi->Q && st->use_imu_cov && !st->use_pol_cov;  // REF CamHelper.cpp:214-224
   if (opt->cpi) {
     std::vector<double> tq;
     for (const Cand &c : pool)
@@ -474,6 +476,13 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
     std::vector<uint8_t> okq(tq.size());
     int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
+    std::vector<double> Qq(imu_cov ? 36 * tq.size() : 0);
+    std::vector<int> Cq(imu_cov ? tq.size() : 0);
+    if (rc0 == PLV_OK && imu_cov) {
+      std::vector<uint8_t> okn(tq.size());
+      rc0 = plv_cpi_noise(st, opt->cpi, (int)tq.size(), tq.data(), Qq.data(), Cq.data(), okn.data());
+      for (size_t i = 0; i < tq.size(); ++i) okq[i] = okq[i] && okn[i];
+    }
     if (rc0 != PLV_OK) {
       for (Cand &c : pool) give_back_all(c);
       return finish(rc0);
@@ -492,6 +501,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
         kept.uvn.insert(kept.uvn.end(), &c.tr.uvn[2 * i], &c.tr.uvn[2 * i] + 2);
         cpiR[f].insert(cpiR[f].end(), &Rq[9 * o], &Rq[9 * o] + 9);
         cpip[f].insert(cpip[f].end(), &pq[3 * o], &pq[3 * o] + 3);
+        if (imu_cov) {
+          cpiQ[f].insert(cpiQ[f].end(), &Qq[36 * o], &Qq[36 * o] + 36);
+          cpiC[f].push_back(Cq[o]);
+        }
       }
       c.tr = std::move(kept);
     }
@@ -630,7 +643,8 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // ---- UpdaterCamera::msckf_update on the selected features
   const int F = (int)sel.size();
   std::vector<int> sptr(F + 1, 0);
-  std::vector<double> st_t, sp(3 * (size_t)F), selR, selp;
+  std::vector<double> st_t, sp(3 * (size_t)F), selR, selp, selQ;
+  std::vector<int> selC;
   std::vector<float> suv;
   for (int q = 0; q < F; ++q) {
     const Cand &c = pool[sel[q]];
@@ -647,6 +661,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       if (opt->cpi) {
         selR.insert(selR.end(), &cpiR[sel[q]][9 * i], &cpiR[sel[q]][9 * i] + 9);
         selp.insert(selp.end(), &cpip[sel[q]][3 * i], &cpip[sel[q]][3 * i] + 3);
+        if (imu_cov) {
+          selQ.insert(selQ.end(), &cpiQ[sel[q]][36 * i], &cpiQ[sel[q]][36 * i] + 36);
+          selC.push_back(cpiC[sel[q]][i]);
+        }
       }
     }
     sptr[q + 1] = (int)st_t.size();
@@ -668,6 +686,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     if (opt->cpi) {
       tr.res_R = selR.data();
       tr.res_p = selp.data();
+      if (imu_cov) {
+        tr.res_Q = selQ.data();
+        tr.res_clone = selC.data();
+      }
     }
     rc = plv_jacobian_columns(st, &tr, cols.data(), (int)cols.size(), &k);
     if (rc == PLV_OK) rc = plv_build_jacobians_resident(ctx, st, &tr, k, cols.data(), 2 * opt->max_obs);

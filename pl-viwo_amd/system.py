@@ -225,14 +225,15 @@ class State:
                          clone_R_fej=[x.Rot_fej() for x in cl], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
                          extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
                          sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
-                         feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp)
+                         feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp, use_imu_cov=1 if self.op.est.use_imu_cov else 0,
+                         intr_err_mlt=self.op.est.intr_err.mlt)
 
     def cpi_table(self):
         """State::cpis as the plv_cpi_table of plv_cpi_poses / plv_update_options::cpi."""
         ts = sorted(self.cpis)
         r = [self.cpis[t] for t in ts]
         return CpiTable(ts, [x["clone_t"] for x in r], [x["R"] for x in r], [x["alpha"] for x in r], [x["v"] for x in r],
-                        gravity=tuple(self.op.est.gravity))
+                        gravity=tuple(self.op.est.gravity), Q=[x.get("Q", np.zeros(36)) for x in r] if self.op.est.use_imu_cov else None)
 
     # ---- x <- x [+] dx for every variable (StateHelper::EKFUpdate :156-168)
     def apply(self, dx):
@@ -354,10 +355,9 @@ class SystemManager:
             raise OptionsError("replay driver: in-state landmarks (cam.max_slam > 0) are driven in the GLOBAL_3D representation only")
         if e.cam.enabled and e.cam.distortion_model[0] != "radtan":
             raise OptionsError("only the radtan camera model is built (SURVEY §8 a7)")
-        if e.use_imu_cov and not e.use_pol_cov:
-            # CamHelper.cpp:217-224 / LineHelper's twin: R += H_ Q_cpi H_^T * intr_err.mlt for interpolated poses (use_pol_cov wins when both
-            # are set); the Jacobian kernels build the polynomial-covariance branch only
-            raise OptionsError("est.use_imu_cov (CPI covariance as interpolation noise) is not built; use est.use_pol_cov")
+        if e.use_imu_cov and not e.use_pol_cov and not e.use_imu_res:
+            # CamHelper.cpp:217-224 reads state->cpis.at(tm + dt), a record that only get_interpolated_pose_imu creates (use_imu_res)
+            raise OptionsError("est.use_imu_cov needs est.use_imu_res (the CPI records behind the observation poses)")
         if e.init.use_gt:
             raise OptionsError("init.use_gt needs the simulator / ground-truth reader, outside SURVEY §8")
         self.op = op
@@ -471,14 +471,14 @@ class SystemManager:
         _, _, recs = self.ctx.propagate(st.imu, self.noise, t, wm, am, st.n, acc=self.cpi_acc, imu_id=0, want_records=True)
         for r in recs:
             st.cpis[r.t] = dict(t=r.t, dt=r.dt, clone_t=r.clone_t, R=np.array(r.R_I0toIk).reshape(3, 3), alpha=np.array(r.alpha),
-                                w=np.array(r.w), v=np.array(r.v))
+                                w=np.array(r.w), v=np.array(r.v), Q=np.array(r.Q))
         st.time = float(timestamp)
 
     def _reset_cpi(self, clone_t):   # Propagator.cpp:333-357
         st = self.state
         self.cpi_acc = reset_cpi(st.imu, clone_t)
         w = st.cpis[clone_t]["w"] if clone_t in st.cpis else np.zeros(3)
-        st.cpis[clone_t] = dict(t=clone_t, dt=0.0, clone_t=clone_t, R=np.eye(3), alpha=np.zeros(3), w=w, v=np.array(st.imu.v))
+        st.cpis[clone_t] = dict(t=clone_t, dt=0.0, clone_t=clone_t, R=np.eye(3), alpha=np.zeros(3), w=w, v=np.array(st.imu.v), Q=np.zeros(36))
 
     # ================================================================================================ SystemManager
     def feed_measurement_imu(self, t, wm, am):

@@ -60,6 +60,37 @@ def test_build_jacobians_variants(pkg, ctx, jo):
     assert a[0][0] == 2 * (sc["obs_ptr"][1] - 2)
 
 
+def _cpi_cov(rng, nobs, n_clones):
+    """a CPI covariance (SPD 6 x 6, gamma / alpha blocks) and the clone it hangs on, per observation"""
+    A = rng.normal(0, 1.0, (nobs, 6, 6)) * np.array([2e-3] * 3 + [8e-3] * 3)[None, :, None]
+    return (A @ np.transpose(A, (0, 2, 1))).reshape(nobs, 36), rng.integers(0, n_clones, nobs).astype(np.int32)
+
+
+def test_jacobians_with_the_cpi_covariance_as_noise(pkg, ctx, jo):
+    """est.use_imu_cov (REF CamHelper.cpp:217-224): R += H_ Q H_^T * mlt for poses between clones."""
+    sc = synth.vio_scene(n_clones=10, F=12, M=8, obs_offset=0.011)
+    rng = np.random.default_rng(0)
+    res_R = np.array([synth._exp_so3(rng.normal(0, 1e-3, 3)) @ sc["pose_fn"](t)[0] for t in sc["obs_time"]])
+    res_p = np.array([sc["pose_fn"](t)[1] + rng.normal(0, 1e-3, 3) for t in sc["obs_time"]])
+    Q, ci = _cpi_cov(rng, len(sc["obs_time"]), len(sc["t"]))
+    out = {}
+    for mode in (0, 1):
+        st = pkg.StateView(sc["t"], sc["R"], sc["p"], sc["ids"], sc["R_ItoC"], sc["p_IinC"], sc["K8"], intrinsic_state_id=15,
+                           extrinsic_state_id=sc["n_state"], dt_state_id=sc["n_state"] + 6, cam_dt=0.003, sigma_pix=1.0,
+                           use_imu_cov=mode, intr_err_mlt=3.0)
+        tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], sc["pts"], res_R=res_R, res_p=res_p, res_Q=Q, res_clone=ci)
+        cols = ctx.jacobian_columns(st, tr)
+        a = jo.build_jacobians(st, tr, cols, 16)
+        b = ctx.build_jacobians(st, tr, cols, 16)
+        assert np.array_equal(a[0], b[0])
+        for x, y in zip(a[1:], b[1:]):   # (a strongly correlated R makes the reference's whitening NaN: same places on both sides)
+            assert np.array_equal(np.isnan(x), np.isnan(y))
+            fin = ~np.isnan(x)
+            assert np.abs(x[fin] - y[fin]).max() <= 1e-9 * max(1.0, np.abs(x[fin]).max())
+        out[mode] = a
+    assert not np.array_equal(np.nan_to_num(out[1][2]), np.nan_to_num(out[0][2]))   # the covariance does enter
+
+
 def test_update_from_tracks_end_to_end(pkg, ctx, jo, oracle):
     """Jacobians -> nullspace -> gate -> compress -> EKF entirely on the device vs the oracle chain."""
     # the reference gates on the norm of the WHITENED residual (< 3, UpdaterCamera.cpp:242): 27 rows of

@@ -41,6 +41,34 @@ def test_line_jacobians_parity(ctx, pkg, jo, calib_dt, fej_noise, offset, pol):
         assert np.abs(a[fin] - b[fin]).max() <= 1e-9 * max(1.0, np.abs(b[fin]).max())
 
 
+def test_line_jacobians_with_the_cpi_covariance_as_noise(ctx, pkg, jo):
+    """est.use_imu_cov, line twin (LineHelper's noise block): parity with res_R / res_p / res_Q / res_clone on the tracks."""
+    sc = synth.vio_scene(F=4, calib_int=True, obs_offset=0.013)
+    ls = synth.line_scene(sc, L=40, noise_px=0.7)
+    ls["obs_time"] = ls["obs_time"] + np.where(ls["obs_time"] < sc["t"][-1], 0.013, 0.0)
+    rng = np.random.default_rng(4)
+    nobs = len(ls["obs_time"])
+    res_R = np.array([synth._exp_so3(rng.normal(0, 1e-3, 3)) @ sc["pose_fn"](t)[0] for t in ls["obs_time"]])
+    res_p = np.array([sc["pose_fn"](t)[1] + rng.normal(0, 1e-3, 3) for t in ls["obs_time"]])
+    A = rng.normal(0, 1.0, (nobs, 6, 6)) * np.array([2e-3] * 3 + [8e-3] * 3)[None, :, None]
+    Q, ci = (A @ np.transpose(A, (0, 2, 1))).reshape(nobs, 36), rng.integers(0, len(sc["t"]), nobs).astype(np.int32)
+    norms = {}
+    for mode in (0, 1):
+        st, _ = make(pkg, sc, ls, use_imu_cov=mode, intr_err_mlt=3.0)
+        lt = pkg.LineTracks(ls["obs_ptr"], ls["obs_time"], ls["seg_uv"], seg_uvn=ls["seg_uvn"], line_FinG=ls["lines"], res_R=res_R, res_p=res_p,
+                            res_Q=Q, res_clone=ci)
+        cols = ctx.line_jacobian_columns(st, lt)
+        rows, Hf, Hx, res = ctx.build_line_jacobians(st, lt, cols, 32)
+        rows_o, Hf_o, Hx_o, res_o = jo.build_line_jacobians(st, lt, cols, 32)
+        assert (rows == rows_o).all()
+        for a, b in ((Hf, Hf_o), (Hx, Hx_o), (res, res_o)):
+            assert (np.isnan(a) == np.isnan(b)).all()
+            fin = ~np.isnan(b)
+            assert np.abs(a[fin] - b[fin]).max() <= 1e-9 * max(1.0, np.abs(b[fin]).max())
+        norms[mode] = np.nansum(np.abs(Hx_o))
+    assert norms[1] != norms[0]   # the covariance does enter
+
+
 def test_line_triangulation_parity(ctx, pkg, jo):
     sc = synth.vio_scene(F=4, calib_int=False, dt_clone=0.5)
     ls = synth.line_scene(sc, L=60, noise_px=0.3, depth=(4.0, 14.0))

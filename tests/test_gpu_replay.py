@@ -65,6 +65,22 @@ def test_replay_with_imu_residual_poses(pkg, dataset, tmp_path):
     assert len(res[True][0]) == len(res[False][0]) and np.abs(res[True][0][:, :3] - res[False][0][:, :3]).max() < 0.05
 
 
+def test_replay_with_the_cpi_covariance_as_noise(pkg, dataset, tmp_path):
+    """est.use_imu_res + est.use_imu_cov (instead of use_pol_cov): the observation poses come from the CPI records of plv_propagate and
+    each record's covariance inflates the noise of the observation made at it (CamHelper.cpp:217-224, plv_cpi_noise)."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    traj = str(tmp_path / "traj.txt")
+    op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, traj))
+    op.est.use_imu_res, op.est.use_imu_cov, op.est.use_pol_cov, op.est.cam.use_lines = True, True, False, True
+    stats, times, poses = rp.replay(op)
+    assert stats["cam_accepted"] >= 800 and stats["not_psd"] == 0, stats
+    r, n = _score(pkg, traj, os.path.join(dataset, "gt.txt"))
+    assert r["pos"]["rmse"] < 0.10, r
+    op.est.use_imu_res = False
+    with pytest.raises(options.OptionsError, match="use_imu_res"):
+        importlib.import_module("plviwo_amd.system").SystemManager(op)
+
+
 def test_replay_with_dynamic_cloning(pkg, dataset, tmp_path):
     """est.dynamic_cloning: the clone rate follows the acceleration statistics of the CPI records through the interpolation-error
     tables (SystemManager.cpp:269-312); the configuration offers 10, 15 and 20 Hz."""
