@@ -770,6 +770,10 @@ int plv_init_imu_wheel(const plv_iw_init_options *opt, plv_iw_init_state *state,
 /* StateHelper::EKFUpdate refreshes the tracker's camera model after every update when the intrinsics are calibrated
  * online (REF: PL-VIWO/src/state/StateHelper.cpp:163-168): same for the ctx (undistortion, RANSAC threshold). */
 int plv_set_camera_intrinsics(plv_ctx *ctx, const double *K8);
+/* ov_type::JPLQuat::update for n orientations at once (REF: open_vins/ov_core/src/types/JPLQuat.h:62-73): q [n][4] <- quatnorm([dth / 2, 1]) (x) q
+ * with w >= 0 (dth [n][3]; NULL = leave q as it is), and R [n][9] (nullable) = quat_2_Rot(q) row-major.  Host arithmetic for the driver's
+ * application of dx to the clone window. */
+void plv_jpl_left_update(int n, double *q, const double *dth, double *R);
 
 
 /* ---------------------------------------------------------------------------------------------

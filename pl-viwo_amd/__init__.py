@@ -171,6 +171,7 @@ def load_library():
         "plv_line_detect_launch": (C.c_int, [vp, C.c_int]),
         "plv_line_detect_finish": (C.c_int, [vp, C.c_int]),
         "plv_counters": (None, [C.POINTER(C.c_ulonglong)]),
+        "plv_jpl_left_update": (None, [C.c_int, dp, dp, dp]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_prefetch_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_tracker_feed_async": (C.c_int, [vp, C.c_double, dp]),
@@ -626,6 +627,14 @@ def cpi_noise(st, cpi, t_q):
     if rc != PLV_OK:
         raise PlvError(rc, load_library().plv_last_error().decode())
     return Q, ci, ok
+
+
+def jpl_left_update(q, dth=None, R=None):
+    """plv_jpl_left_update in place: q [n][4] (C-contiguous float64) <- [dth / 2, 1] (x) q; R [n][9] receives the rotation matrices."""
+    lib = load_library()
+    n = q.shape[0] if q.ndim == 2 else 1
+    d = np.ascontiguousarray(dth, dtype=np.float64) if dth is not None else None
+    lib.plv_jpl_left_update(n, _dp(q), _dp(d), _dp(R))
 
 
 def counters():

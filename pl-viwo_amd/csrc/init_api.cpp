@@ -311,6 +311,40 @@ std::vector<double> real_roots(const Poly &p) {
 
 extern "C" {
 
+// ov_type::JPLQuat::update for a stack of orientations (REF: open_vins/ov_core/src/types/JPLQuat.h:62-73, utils/quat_ops.h:152-157,
+// 232-252): q <- quatnorm([dth / 2, 1]) (x) q, w >= 0, renormalised; R (nullable) receives quat_2_Rot(q) row-major.  Host arithmetic
+// for the driver's dx application (StateHelper::EKFUpdate :156-160 calls it per variable).
+void plv_jpl_left_update(int n, double *q, const double *dth, double *R) {
+  for (int k = 0; k < n; ++k) {
+    double *Q = q + 4 * (size_t)k;
+    if (dth) {
+      const double *d = dth + 3 * (size_t)k;
+      double a[3] = {0.5 * d[0], 0.5 * d[1], 0.5 * d[2]}, b = 1.0;
+      const double nd = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + 1.0);
+      a[0] /= nd, a[1] /= nd, a[2] /= nd, b /= nd;
+      const double v[3] = {Q[0], Q[1], Q[2]}, w = Q[3];
+      double r[4];
+      r[0] = b * v[0] - (a[1] * v[2] - a[2] * v[1]) + a[0] * w;
+      r[1] = b * v[1] - (a[2] * v[0] - a[0] * v[2]) + a[1] * w;
+      r[2] = b * v[2] - (a[0] * v[1] - a[1] * v[0]) + a[2] * w;
+      r[3] = -(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + b * w;
+      if (r[3] < 0)
+        for (double &x : r) x = -x;
+      const double nr = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+      for (int i = 0; i < 4; ++i) Q[i] = r[i] / nr;
+    }
+    if (R) {
+      const double x = Q[0], y = Q[1], z = Q[2], w = Q[3], c = 2 * w * w - 1;
+      double *M = R + 9 * (size_t)k;
+      // (2 w^2 - 1) I - 2 w [q x] + 2 q q^T
+      M[0] = c + 2 * x * x, M[1] = 2 * w * z + 2 * x * y, M[2] = -2 * w * y + 2 * x * z;
+      M[3] = -2 * w * z + 2 * y * x, M[4] = c + 2 * y * y, M[5] = 2 * w * x + 2 * y * z;
+      M[6] = 2 * w * y + 2 * z * x, M[7] = -2 * w * x + 2 * z * y, M[8] = c + 2 * z * z;
+    }
+  }
+}
+
+
 int plv_init_imu_static(int n, const double *t, const double *wm, const double *am, double window_time, double imu_thresh,
                         const double *gravity, double *imustate, int *ok) {
   if (!ok || !imustate || !gravity || n < 0 || (n > 0 && (!t || !wm || !am))) return PLV_E_BADARG;

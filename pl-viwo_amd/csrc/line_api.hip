@@ -88,7 +88,7 @@ struct LineTracker {
     int rc = PLV_OK;
   } feed;
   int feed_state = 0;  // 0 idle, 1 posted, 2 done
-  std::chrono::steady_clock::time_point job_posted;
+  std::chrono::steady_clock::time_point job_posted, feed_posted;
 };
 
 std::mutex g_mtx;
@@ -223,6 +223,8 @@ void line_worker(LineTracker *T) {
     }
     if (do_feed) {
       LineTracker::FeedJob &F = T->feed;
+      if (plv::host_phases().on)
+        plv::host_phases().add("line worker: feed job starts after its post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
       const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data());
       {
         std::lock_guard<std::mutex> lk(T->jm);
@@ -239,6 +241,8 @@ void line_worker(LineTracker *T) {
     if (plv::event_sync(T->edges_ready) != hipSuccess) rc = PLV_E_DEVICE;  // the two maps are on the host
     auto W1 = std::chrono::steady_clock::now();
     if (rc == PLV_OK) rc = host_extract(T, T->job, timing);
+    if (plv::host_phases().on)
+      plv::host_phases().add("line worker: detect job, post to done", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
     if (timing) {
       auto W2 = std::chrono::steady_clock::now();
       auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -281,8 +285,11 @@ LineTracker *ltr(plv_ctx *ctx) {
   }
   std::unique_lock<std::mutex> lk(T->jm);
   if (T->feed_state != 0) {
+    plv::HostPhase ph("line feed join: wait");
     T->jcv.wait(lk, [&] { return T->feed_state == 2; });
     T->feed_state = 0;
+    if (plv::host_phases().on)
+      plv::host_phases().add("line feed join: time since the post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
   }
   return T;
 }
@@ -722,6 +729,7 @@ int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vp
   {
     std::lock_guard<std::mutex> lk2(T->jm);
     T->feed_state = 1;
+    T->feed_posted = std::chrono::steady_clock::now();
   }
   T->jcv.notify_all();
   return PLV_OK;

@@ -17,6 +17,7 @@ import time as _time
 
 import numpy as np
 
+from . import jpl_left_update
 from . import (Context, CpiTable, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, Tracks, WHEEL_TYPES, default_config,
                imu_noise, init_imu_static, next_clone_time, reset_cpi, select_imu_readings, select_wheel_data)
 from .options import OptionsError
@@ -105,8 +106,8 @@ class Pose:
         return self._Rf
 
     def update(self, dx):
-        self.q = quat_left_update(self.q, dx[0:3])
-        self.p = self.p + dx[3:6]
+        self.q[:] = quat_left_update(self.q, dx[0:3])
+        self.p[:] = self.p + dx[3:6]
         self._R = None
 
     def clone(self, var_id):
@@ -141,6 +142,7 @@ class State:
         self.time, self.startup_time, self.initialized = -1.0, -1.0, False
         self.imu = PlvImuState.make([0, 0, 0, 1], [0, 0, 0], [0, 0, 0])
         self.clones = {}            # time -> Pose (real clones; the IMU pose pseudo-clone is added by clone_list())
+        self._win, self._win_dirty = None, True   # array form of the window (_window_arrays)
         self.slam = {}              # feature id -> Landmark (State::cam_SLAM_features)
         self.imu_pose_in_clones = False
         self.cpis = {}              # time -> PlvCpiRecord-like dict (t, dt, clone_t, R, w, v)
@@ -196,6 +198,28 @@ class State:
             t.append(self.time)
         return t
 
+    def _window_arrays(self):
+        """The clone window as contiguous arrays (times, q, p, first estimates, rotation matrices, covariance ids) with one spare row for
+        the IMU pose; rebuilt when the set of clones changed, updated in place by apply().  The Pose objects of the clones are views of
+        their rows, so the two never disagree."""
+        w = self._win
+        if w is not None and not self._win_dirty:
+            return w
+        ts = sorted(self.clones)
+        n = len(ts)
+        w = dict(n=n, t=np.zeros(n + 1), q=np.zeros((n + 1, 4)), p=np.zeros((n + 1, 3)), qf=np.zeros((n + 1, 4)), pf=np.zeros((n + 1, 3)),
+                 R=np.zeros((n + 1, 9)), Rf=np.zeros((n + 1, 9)), id=np.zeros(n + 1, dtype=np.int32))
+        for i, t in enumerate(ts):
+            c = self.clones[t]
+            w["t"][i], w["id"][i] = t, c.id
+            w["q"][i], w["p"][i], w["qf"][i], w["pf"][i] = c.q, c.p, c.q_fej, c.p_fej
+            w["R"][i], w["Rf"][i] = c.Rot().ravel(), c.Rot_fej().ravel()
+            c.q, c.p, c.q_fej, c.p_fej = w["q"][i], w["p"][i], w["qf"][i], w["pf"][i]      # views from here on
+            c._R, c._Rf = w["R"][i].reshape(3, 3), w["Rf"][i].reshape(3, 3)
+        w["idx"] = w["id"][:n, None] + np.arange(6)[None, :]
+        self._win, self._win_dirty = w, False
+        return w
+
     def imu_pose(self):
         p = Pose(self.imu.q, self.imu.p, 0)
         p.q_fej, p.p_fej = np.array(self.imu.q_fej), np.array(self.imu.p_fej)
@@ -217,16 +241,39 @@ class State:
 
     def view(self):
         """The plv_state_view of the current window: real clones, then the IMU pose (id 0) when it sits in the clone list."""
-        ts = self.clone_times()
-        cl = [self.clone_at(t) for t in ts]
+        w = self._window_arrays()
+        m = w["n"]
+        if self.imu_pose_in_clones and self.time not in self.clones:    # the IMU pose closes the list (covariance id 0)
+            x = np.frombuffer(self.imu, dtype=np.float64)   # q, p, v, bg, ba, q_fej, p_fej, v_fej
+            w["t"][m], w["id"][m] = self.time, 0
+            w["q"][m], w["p"][m], w["qf"][m], w["pf"][m] = x[0:4], x[4:7], x[16:20], x[20:23]
+            jpl_left_update(w["q"][m:m + 1], None, w["R"][m:m + 1])
+            jpl_left_update(w["qf"][m:m + 1], None, w["Rf"][m:m + 1])
+            m += 1
         oc, pc = self.intr_cov()
         c = self.op.est.cam
-        return StateView(ts, [x.Rot() for x in cl], [x.p for x in cl], [x.id for x in cl], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
-                         clone_R_fej=[x.Rot_fej() for x in cl], clone_p_fej=[x.p_fej for x in cl], cam_dt=float(self.cam_dt.v[0]),
-                         extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
-                         sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
-                         feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp, use_imu_cov=1 if self.op.est.use_imu_cov else 0,
-                         intr_err_mlt=self.op.est.intr_err.mlt)
+        sv = w.get("sv")
+        if sv is None:     # the view object wraps the window arrays themselves: built once per window, refreshed in place afterwards
+            sv = w["sv"] = StateView(w["t"], w["R"], w["p"], w["id"], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
+                                     clone_R_fej=w["Rf"], clone_p_fej=w["pf"], cam_dt=float(self.cam_dt.v[0]),
+                                     extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
+                                     sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
+                                     feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp, use_imu_cov=1 if self.op.est.use_imu_cov else 0,
+                                     intr_err_mlt=self.op.est.intr_err.mlt)
+            assert np.shares_memory(sv.R, w["R"]) and np.shares_memory(sv.p, w["p"]) and np.shares_memory(sv.t, w["t"])    # no copies
+        v = sv.c
+        v.n_clones = m
+        sv.t = w["t"][:m]          # (what the tests and the oracle context read)
+        v.cam_dt, v.intr_ori_cov, v.intr_pos_cov = float(self.cam_dt.v[0]), oc, pc
+        if self.cam_ext.id >= 0:       # calibrated online: the values move with every dx
+            for i, xv in enumerate(self.cam_ext.Rot().ravel()):
+                v.R_ItoC[i] = xv
+            for i in range(3):
+                v.p_IinC[i] = self.cam_ext.p[i]
+        if self.cam_intr.id >= 0:
+            for i in range(8):
+                v.intrinsics[i] = self.cam_intr.v[i]
+        return sv
 
     def cpi_table(self):
         """State::cpis as the plv_cpi_table of plv_cpi_poses / plv_update_options::cpi."""
@@ -237,24 +284,18 @@ class State:
 
     # ---- x <- x [+] dx for every variable (StateHelper::EKFUpdate :156-168)
     def apply(self, dx):
-        q = quat_left_update(np.array(self.imu.q), dx[0:3])
-        for i in range(4):
-            self.imu.q[i] = q[i]
-        for i in range(3):
-            self.imu.p[i] += dx[3 + i]
-            self.imu.v[i] += dx[6 + i]
-            self.imu.bg[i] += dx[9 + i]
-            self.imu.ba[i] += dx[12 + i]
+        x = np.frombuffer(self.imu, dtype=np.float64)      # the IMU state in place: q (4), p, v, bg, ba (3 each), then the first estimates
+        jpl_left_update(x[0:4], dx[0:3])
+        x[4:16] += dx[3:15]
         for var, size in ((self.cam_ext, 6), (self.cam_intr, 8), (self.cam_dt, 1), (self.wheel_dt, 1), (self.wheel_ext, 6), (self.wheel_intr, 3)):
             if var is not None and var.id >= 0:
                 var.update(dx[var.id:var.id + size])
-        cl = list(self.clones.values())
-        if cl:
-            d = np.array([dx[c.id:c.id + 6] for c in cl])
-            Q = quats_left_update([c.q for c in cl], d[:, :3])
-            R = quats_2_Rots(Q)
-            for i, c in enumerate(cl):
-                c.q, c.p, c._R = Q[i], c.p + d[i, 3:], R[i]
+        if self.clones:      # the whole window in a few array operations (the Pose objects are views of these rows)
+            w = self._window_arrays()
+            n = w["n"]
+            d = dx[w["idx"]]
+            jpl_left_update(w["q"], d[:, :3], w["R"]) if n == len(w["q"]) else jpl_left_update(w["q"][:n], d[:, :3], w["R"][:n])
+            w["p"][:n] += d[:, 3:]
         for lm in self.slam.values():
             lm.p = lm.p + dx[lm.id:lm.id + 3]
         if self.cam_intr is not None and self.op.est.cam.do_calib_int:
@@ -267,10 +308,12 @@ class State:
         self.ctx.cov_clone(self.n, 0, 6)
         self.clones[self.time] = self.imu_pose().clone(self.n)
         self.n += 6
+        self._win_dirty = True
 
     def marginalize_old_clone(self):
         while self.clone_window() > self.op.est.window_size and self.clones:
             c = self.clones.pop(min(self.clones))
+            self._win_dirty = True
             self.marginalize(c.id, 6)
 
     def marginalize(self, var_id, size):   # StateHelper::marginalize :234-303: later variables move up
@@ -279,6 +322,7 @@ class State:
         for o in list(self.clones.values()) + list(self.slam.values()):
             if o.id > var_id:
                 o.id -= size
+        self._win_dirty = True
 
     def flush_old_data(self):   # State.cpp:605-628
         if not self.clones:
