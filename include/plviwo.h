@@ -250,9 +250,10 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * equalize + pyramid, first-frame detection or top-up on the last image, temporal KLT + RANSAC,
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
-/* On (the default), plv_tracker_feed* ends by starting the NEXT frame's top-up detection (TrackKLT.cpp:127-131 runs it on the then-last
- * image with the then-last points: this image, these points) on a side stream, next to the updates the caller enqueues; the next
- * feed collects it.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
+/* On (the default), the NEXT frame's top-up detection (TrackKLT.cpp:127-131 runs it on the then-last image with the then-last
+ * points: this image, these points) is started ahead of time on a side stream: plv_camera_update_points starts it right after it
+ * has submitted the point update of this frame (host stage and launches sit in the update's wait), the next feed collects it;
+ * without an update in between the next feed detects in place.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
  * plv_tracker state was edited) or the per-kernel profiler is on. */
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on);
 /* plv_tracker_feed from an image already resident in HBM (plv_image_stage, slots 0..7): the camera driver's DMA target in a
@@ -596,6 +597,47 @@ int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, doubl
  * (capacity cap, may be NULL) list the lines of the update in batch order. */
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted, double *line_FinG, int cap);
+
+/* x <- x [+] dx for every variable of the state in one call (REF: StateHelper::EKFUpdate, PL-VIWO/src/state/StateHelper.cpp:156-160,
+ * which calls Type::update(dx.block(id, 0, size, 1)) variable by variable: ov_type::Vec adds, JPLQuat composes on the left, PoseJPL is
+ * a quaternion at id and a 3-vector at id + 3).  `out` of a quaternion (nullable) receives its rotation matrix [9]; `mirror` (nullable)
+ * receives a second copy of what the variable now holds (value of a vector, rotation matrix of a quaternion), e.g. the field of a
+ * plv_state_view the caller keeps current.  Host arithmetic. */
+enum { PLV_VAR_VEC = 0, PLV_VAR_QUAT = 1 };
+typedef struct plv_state_var {
+  int kind;       /* PLV_VAR_* */
+  int id;         /* covariance index of the variable's error state (Type::id()) */
+  int size;       /* values of a vector (its error state has the same size); ignored for a quaternion (4 values, 3 error states) */
+  double *val;    /* vector [size] / quaternion [4] (JPL: x y z w), updated in place */
+  double *out;    /* quaternion: rotation matrix [9], row-major, or NULL */
+  double *mirror; /* or NULL */
+} plv_state_var;
+int plv_state_boxplus(int n_var, const plv_state_var *vars, const double *dx, int n_dx);
+
+/* UpdaterCamera::try_update as ONE call (REF: PL-VIWO/src/update/cam/UpdaterCamera.cpp:139-195 without the SLAM branch, which needs
+ * the two-call form): plv_camera_update_points; its dx applied to the caller's state (plv_state_boxplus over `vars` when the update
+ * was accepted, StateHelper.cpp:156-160, and plv_set_camera_intrinsics when the intrinsics are calibrated, :163-168); then, when
+ * opt_lines is given, the join of an asynchronous line feed, plv_camera_update_lines on the updated state and its dx applied the
+ * same way.  `st` must stay current under plv_state_boxplus: its clone arrays are the `val` / `out` arrays of the clone variables
+ * and its calibration fields are their `mirror`s.  The point half's database hand-back (CamHelper::cleanup_features) is run while
+ * the line update executes on the device.  Outputs as in the two calls; line_db_size = LineFeatureDatabase size after the feed. */
+typedef struct plv_try_update {
+  const plv_update_options *opt_points;
+  const plv_update_options *opt_lines;   /* NULL: points only */
+  int n_var;
+  const plv_state_var *vars;             /* every variable of the state (n_var may be 0: dx is returned, nothing applied) */
+  double *dx_points, *dx_lines;          /* [cov_n] each */
+  plv_update_result *res_points, *res_lines;
+  uint64_t *msckf_ids;                   /* capacity opt_points->max_msckf (nullable, like the next two) */
+  uint8_t *msckf_accepted;
+  double *p_FinG;
+  uint64_t *line_ids;                    /* capacity line_cap (nullable, like the next two) */
+  uint8_t *line_accepted;
+  double *line_FinG;
+  int line_cap;
+  int line_db_size;                      /* out */
+} plv_try_update;
+int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update *io);
 
 /* ---------------------------------------------------------------------------------------------
  * In-state (SLAM) landmarks (a30) on the device-resident covariance, one landmark per call as the reference

@@ -172,6 +172,8 @@ def load_library():
         "plv_line_detect_finish": (C.c_int, [vp, C.c_int]),
         "plv_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_jpl_left_update": (None, [C.c_int, dp, dp, dp]),
+        "plv_state_boxplus": (C.c_int, [C.c_int, C.POINTER(PlvStateVar), dp, C.c_int]),
+        "plv_camera_try_update": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTryUpdate)]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_prefetch_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_tracker_feed_async": (C.c_int, [vp, C.c_double, dp]),
@@ -276,6 +278,39 @@ class PlvLineTracks(C.Structure):
 class PlvTriOptions(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("max_dist", C.c_double), ("max_cond_number", C.c_double),
                 ("max_baseline", C.c_double), ("refine_features", C.c_int)]
+
+
+class PlvStateVar(C.Structure):
+    _fields_ = [("kind", C.c_int), ("id", C.c_int), ("size", C.c_int), ("val", C.c_void_p), ("out", C.c_void_p), ("mirror", C.c_void_p)]
+
+
+class PlvTryUpdate(C.Structure):
+    _fields_ = [("opt_points", C.c_void_p), ("opt_lines", C.c_void_p), ("n_var", C.c_int), ("vars", C.c_void_p),
+                ("dx_points", C.c_void_p), ("dx_lines", C.c_void_p), ("res_points", C.c_void_p), ("res_lines", C.c_void_p),
+                ("msckf_ids", C.c_void_p), ("msckf_accepted", C.c_void_p), ("p_FinG", C.c_void_p),
+                ("line_ids", C.c_void_p), ("line_accepted", C.c_void_p), ("line_FinG", C.c_void_p), ("line_cap", C.c_int),
+                ("line_db_size", C.c_int)]
+
+
+class BoxPlus:
+    """A prepared plv_state_boxplus call: the list of variables (arrays updated in place) is laid out once, apply(dx) is one C call.
+    entries: (kind 'vec'|'quat', id, value array, out array or None, mirror address or array or None)."""
+
+    def __init__(self, entries):
+        self.lib = load_library()
+        self.keep = entries            # the arrays must outlive the plan
+        self.vars = (PlvStateVar * max(1, len(entries)))()
+        self.n = len(entries)
+        addr = lambda a: None if a is None else (a if isinstance(a, int) else a.ctypes.data)
+        for v, (kind, vid, val, out, mirror) in zip(self.vars, entries):
+            assert val.dtype == np.float64 and val.flags.c_contiguous and (out is None or out.flags.c_contiguous)
+            v.kind, v.id, v.size = (1 if kind == "quat" else 0), int(vid), (4 if kind == "quat" else val.size)
+            v.val, v.out, v.mirror = addr(val), addr(out), addr(mirror)
+
+    def apply(self, dx):
+        rc = self.lib.plv_state_boxplus(self.n, self.vars, dx.ctypes.data_as(C.POINTER(C.c_double)), dx.size)
+        if rc != 0:
+            raise PlvError(rc, "plv_state_boxplus")
 
 
 class PlvCpiTable(C.Structure):
@@ -1065,6 +1100,33 @@ class Context:
         return dict(dx=dx, n_pool=res.n_pool, n_lines=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
                     status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), line_FinG=lg[:m].copy())
 
+    def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0,
+                          min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True, init_min_meas=10, lines=True, cap=512):
+        """plv_camera_try_update: the point update, its dx applied through `plus` (a BoxPlus whose arrays back `st`), then the line
+        update on the updated state and its dx applied.  Returns (points dict, lines dict or None, line database size after the feed)
+        in the form of camera_update_points / camera_update_lines."""
+        tri = PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
+        op = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, tri, t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, init_min_meas, None)
+        ol = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, 10, None)
+        rp, rl = PlvUpdateResult(), PlvUpdateResult()
+        dxp, dxl = np.zeros(n), np.zeros(n)
+        ids, acc, p = np.zeros(max_msckf, dtype=np.uint64), np.zeros(max_msckf, dtype=np.uint8), np.zeros((max_msckf, 3))
+        lids, lacc, lg = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))
+        a = lambda x: x.ctypes.data
+        io = PlvTryUpdate(C.addressof(op), C.addressof(ol) if lines else None, plus.n if plus is not None else 0,
+                          C.addressof(plus.vars) if plus is not None else None, a(dxp), a(dxl), C.addressof(rp), C.addressof(rl),
+                          a(ids), a(acc), a(p), a(lids), a(lacc), a(lg), cap, 0)
+        self._chk(self.lib.plv_camera_try_update(self.h, C.byref(st.c), C.byref(io)))
+        m = rp.n_msckf
+        pts = dict(dx=dxp, n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned,
+                   status=rp.status, ids=ids[:m], accepted=acc[:m], p_FinG=p[:m], n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
+        if not lines:
+            return pts, None, 0
+        m = rl.n_msckf
+        lns = dict(dx=dxl, n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
+                   status=rl.status, ids=lids[:m], accepted=lacc[:m], line_FinG=lg[:m])
+        return pts, lns, io.line_db_size
+
     # ---- lines (front-end)
     def detect_lines(self, which=0, cap=4096):
         lines = np.zeros((cap, 4), dtype=np.float32)
@@ -1223,7 +1285,7 @@ class Context:
         self._chk(self.lib.plv_tracker_feed(self.h, float(timestamp), _u8p(img), img.shape[1], _u8p(m)))
 
     def tracker_detect_ahead(self, on):
-        self._chk(self.lib.plv_tracker_detect_ahead(self.h, 1 if on else 0))
+        self._chk(self.lib.plv_tracker_detect_ahead(self.h, int(on)))
 
     def tracker_feed_staged(self, timestamp, slot, mask=None):
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None

@@ -344,6 +344,30 @@ void plv_jpl_left_update(int n, double *q, const double *dth, double *R) {
   }
 }
 
+// x <- x [+] dx for every variable of the state in one call (REF: StateHelper::EKFUpdate, StateHelper.cpp:156-160, calls
+// Type::update(dx.block(id, 0, size, 1)) per variable: Vec adds, JPLQuat composes on the left, PoseJPL is one of each).
+// `out` of a quaternion receives its rotation matrix; `mirror` (nullable) a second copy of what the variable now holds (the value of
+// a vector, the rotation matrix of a quaternion) — e.g. the field of a plv_state_view the caller keeps current.
+int plv_state_boxplus(int n_var, const plv_state_var *vars, const double *dx, int n_dx) {
+  if (n_var < 0 || (n_var > 0 && !vars) || !dx) return PLV_E_BADARG;
+  for (int i = 0; i < n_var; ++i) {
+    const plv_state_var &v = vars[i];
+    if (!v.val || v.id < 0 || v.size < 1 || v.id + (v.kind == PLV_VAR_QUAT ? 3 : v.size) > n_dx) return PLV_E_BADARG;
+    if (v.kind == PLV_VAR_QUAT) {
+      double R[9];
+      plv_jpl_left_update(1, v.val, dx + v.id, v.out || v.mirror ? R : nullptr);
+      if (v.out) std::copy(R, R + 9, v.out);
+      if (v.mirror) std::copy(R, R + 9, v.mirror);
+    } else if (v.kind == PLV_VAR_VEC) {
+      for (int j = 0; j < v.size; ++j) v.val[j] = v.val[j] + dx[v.id + j];
+      if (v.mirror) std::copy(v.val, v.val + v.size, v.mirror);
+    } else {
+      return PLV_E_BADARG;
+    }
+  }
+  return PLV_OK;
+}
+
 
 int plv_init_imu_static(int n, const double *t, const double *wm, const double *am, double window_time, double imu_thresh,
                         const double *gravity, double *imustate, int *ok) {

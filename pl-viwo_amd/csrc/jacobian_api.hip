@@ -281,22 +281,31 @@ int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *co
 int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
                             const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
                             double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows,
-                            double *dx) {
+                            double *dx, void (*before_wait)(void *), void *before_wait_arg) {
   if (!ctx || !all || !tri || !flags || !p_out || !ok_out || !err_out || !accepted || !dx || !all->obs_uvn) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
   plv_tracks t2 = *all;
   t2.p_FinG = t2.p_FinG_fej = p_out;  // (outputs of the triangulation: the staged copy is never read)
   FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
+  plv::HostPhase ph_a("points fused: stage + triangulate + jacobians enqueued");
   TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
+  ph_a.stop();
   us->b_single_use = true;
   const int F = all->n_feat;
   TRY(us->h_tri.reserve((size_t)F * 33 + 16));
+  plv::HostPhase ph_b("points fused: gate .. EKF enqueued");
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
   // (stream order: lands before the wait below returns)
   PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
+  ph_b.stop();
+  plv::HostPhase ph_c("points fused: host work inside the wait");
+  if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
+  ph_c.stop();
+  plv::HostPhase ph_d("points fused: wait");
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
   else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  ph_d.stop();
   const char *h = us->h_tri.as<char>();
   memcpy(p_out, h, (size_t)F * 24);
   memcpy(err_out, h + (size_t)F * 24, (size_t)F * 8);
@@ -546,7 +555,7 @@ extern "C" {
 // The line twin (plv_camera_update_lines): line triangulation, selection, Pluecker Jacobians, null space, gate, compression, EKF.
 int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *all, const uint8_t *flags, int max_sel, int k,
                            const int *col_to_state, int ld, double sigma2, double chi2_mult, double *lines_out, uint8_t *ok_out,
-                           uint8_t *accepted, int *n_rows, double *dx) {
+                           uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *), void *before_wait_arg) {
   if (!ctx || !all || !flags || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
@@ -557,6 +566,7 @@ int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_lin
   TRY(us->h_tri.reserve((size_t)L * 49 + 16));
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, 0.0);
   PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_lines, (size_t)L * 49, hipMemcpyDeviceToHost, ctx->stream));
+  if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
   else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   const char *h = us->h_tri.as<char>();

@@ -5,6 +5,8 @@
 // This is bookkeeping (vectors and a hash map), exactly what the reference keeps on the host;
 // every image / point computation goes through the device entry points of frontend_api.hip.
 #include <algorithm>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -24,7 +26,10 @@ struct Tracker {
   std::vector<uint64_t> ids_last;
   std::vector<uint8_t> mask_last;  // W*H or empty
   uint64_t currid = 0;             // REF: TrackBase::currid (4*num_aruco + 1 - 1 = 0 without ArUco tags)
-  bool detect_ahead = true;        // plv_tracker_detect_ahead: start the next frame's top-up detection at the end of this feed
+  int detect_ahead = 2;            // plv_tracker_detect_ahead: start the next frame's top-up detection ahead of time (1: at the end of the feed, 2: once the point update is submitted)
+  bool ahead_deferred = false;     // ... asked for by the last feed, not started yet (start_detection_ahead)
+  bool defer_db = false;           // plv_camera_try_update: the point update leaves its database hand-back to run_deferred_db
+  std::function<void()> deferred_db;
   std::unordered_map<uint64_t, Track> db;
   struct UsedPoint {
     double p[3], newest;
@@ -112,6 +117,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   // the stream and the library's line worker thread walks the edge chains and grows the segments while this thread runs the point
   // front-end; plv_line_tracker_feed of the same frame joins it.
   if (plv_line_prefetch_enabled(ctx)) (void)plv_line_detect_launch(ctx, PLV_PYR_CUR);
+  T->ahead_deferred = false;  // (no update came in between: the detection below runs in place)
   const int cap = std::max(ctx->cfg.num_features * 4, 1024) + (int)T->ids_last.size();
   std::vector<float> pts(2 * (size_t)cap);
   std::vector<uint64_t> ids(cap);
@@ -173,17 +179,31 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   T->pts_last.swap(good);
   T->ids_last.swap(good_ids);
   keep_mask();
-  // the next frame's top-up works on this image with these points (:127-131): start it now, on a side stream, next to the updates
-  if (T->detect_ahead && !T->ids_last.empty())
+  // the next frame's top-up works on this image with these points (:127-131): it is started on a side stream once the point update
+  // of this frame has been submitted (start_detection_ahead below), so that its host stage and launches sit in the update's wait
+  // instead of in front of it; without an update in between, the next feed detects in place as usual
+  T->ahead_deferred = T->detect_ahead == 2 && !T->ids_last.empty();
+  if (T->detect_ahead == 1 && !T->ids_last.empty())
     (void)plv_perform_detection_ahead(ctx, mask, T->pts_last.data(), T->ids_last.data(), (int)T->ids_last.size());
   return PLV_OK;
+}
+
+// (called without T->mtx held)
+static void start_detection_ahead(void *arg) {
+  plv_ctx *ctx = (plv_ctx *)arg;
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  if (!T->ahead_deferred) return;
+  T->ahead_deferred = false;
+  (void)plv_perform_detection_ahead(ctx, T->mask_last.empty() ? nullptr : T->mask_last.data(), T->pts_last.data(), T->ids_last.data(),
+                                    (int)T->ids_last.size());
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
   if (!ctx) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
-  T->detect_ahead = on != 0;
+  T->detect_ahead = on < 0 ? 0 : on > 2 ? 2 : on;
   return PLV_OK;
 }
 
@@ -432,22 +452,31 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // REF :640 sort(feats_pool, feat_sort): long tracks first
   std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
   auto finish = [&](int rc) {
-    {
-      std::lock_guard<std::mutex> lk(T->mtx);
-      for (auto &kv : unused) {  // REF :702-703 / :727-729 append_new_measurements
-        Track &d = T->db[kv.first];
-        if (d.t.empty()) {
-          d = std::move(kv.second);
-          continue;
+    res->n_returned = (int)unused.size();
+    const bool window_full = opt->window_full != 0;
+    auto hand_back = [ctx, T, window_full, t_oldest](std::unordered_map<uint64_t, Track> &un) {
+      {
+        std::lock_guard<std::mutex> lk(T->mtx);
+        for (auto &kv : un) {  // REF :702-703 / :727-729 append_new_measurements
+          Track &d = T->db[kv.first];
+          if (d.t.empty()) {
+            d = std::move(kv.second);
+            continue;
+          }
+          d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
+          d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
+          d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
         }
-        d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
-        d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
-        d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
       }
-      res->n_returned = (int)unused.size();
+      // REF CamHelper.cpp:733-737: cleanup_features runs on every try_update, whether or not anything was updated
+      if (window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);
+    };
+    if (T->defer_db) {  // plv_camera_try_update: nothing before the line update's submission reads the point database
+      auto held = std::make_shared<std::unordered_map<uint64_t, Track>>(std::move(unused));
+      T->deferred_db = [hand_back, held]() { hand_back(*held); };
+    } else {
+      hand_back(unused);
     }
-    // REF CamHelper.cpp:733-737: cleanup_features runs on every try_update, whether or not anything was updated
-    if (opt->window_full) (void)plv_db_cleanup_measurements(ctx, t_oldest);
     return rc;
   };
   auto give_back_all = [&](Cand &c) {
@@ -569,7 +598,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       if (rc == PLV_OK && k > 0) {
         rc = plv_points_update_fused(ctx, st, &all, &opt->tri, flags.data(), opt->max_msckf, k, cols.data(), 2 * opt->max_obs,
                                      st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, pf.data(), ok.data(), err.data(), acc_all.data(),
-                                     &n_rows, dx);
+                                     &n_rows, dx, start_detection_ahead, ctx);
         res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
         if (rc == PLV_E_NOT_PSD) {
           rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
@@ -583,6 +612,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       }
     }
   } else {
+    start_detection_ahead(ctx);
     rc = plv_triangulate(ctx, st, &all, &opt->tri, pf.data(), ok.data(), err.data());
     if (rc != PLV_OK) {
       for (Cand &c : pool) give_back_all(c);
@@ -778,6 +808,48 @@ void plv_point_used_cleanup(plv_ctx *ctx, double t_oldest) {
   std::lock_guard<std::mutex> lk(T->mtx);
   for (auto it = T->used.begin(); it != T->used.end();)
     it = it->second.newest < t_oldest ? T->used.erase(it) : std::next(it);
+}
+
+// the database hand-back a point update left behind (plv_camera_try_update); runs inside the line update's wait
+void plv_tracker_run_deferred(void *arg) {
+  plv_ctx *ctx = (plv_ctx *)arg;
+  Tracker *T = trk(ctx);
+  if (!T->deferred_db) return;
+  std::function<void()> f;
+  f.swap(T->deferred_db);
+  f();
+}
+
+int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update *io) {
+  if (!ctx || !st || !io || !io->opt_points || !io->dx_points || !io->res_points || (io->n_var > 0 && !io->vars)) return PLV_E_BADARG;
+  if (io->opt_lines && (!io->dx_lines || !io->res_lines)) return PLV_E_BADARG;
+  if (io->opt_points->max_slam > 0) {  // the in-state landmark updates sit between the two halves and are the caller's
+    plv::set_last_error("plv_camera_try_update: max_slam > 0 needs the two-call form (plv_slam_update in between)");
+    return PLV_E_BADARG;
+  }
+  Tracker *T = trk(ctx);
+  const int n = ctx->cov_n;
+  auto apply = [&](const plv_update_result &r, const double *dx) {  // StateHelper::EKFUpdate's mean update (:156-168)
+    if (r.status != PLV_OK || r.n_accepted < 1 || io->n_var < 1) return (int)PLV_OK;
+    TRY(plv_state_boxplus(io->n_var, io->vars, dx, n));
+    if (st->intrinsic_state_id >= 0) TRY(plv_set_camera_intrinsics(ctx, st->intrinsics));
+    return (int)PLV_OK;
+  };
+  T->defer_db = io->opt_lines != nullptr;
+  int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
+  T->defer_db = false;
+  if (rc == PLV_OK) rc = apply(*io->res_points, io->dx_points);
+  if (rc == PLV_OK && io->opt_lines) {
+    rc = plv_line_tracker_feed_wait(ctx);
+    io->line_db_size = plv_line_db_size(ctx);
+    if (rc == PLV_OK)
+      rc = plv_camera_update_lines(ctx, st, io->opt_lines, io->dx_lines, io->res_lines, io->line_ids, io->line_accepted, io->line_FinG,
+                                   io->line_cap);
+    plv_tracker_run_deferred(ctx);
+    if (rc == PLV_OK) rc = apply(*io->res_lines, io->dx_lines);
+  }
+  plv_tracker_run_deferred(ctx);
+  return rc;
 }
 
 }  // extern "C"

@@ -12,12 +12,13 @@ before try_update once the filter is initialised).  Scope of this driver: one ca
 (in-state SLAM landmarks in the GLOBAL_3D representation; the shipped configuration has cam.max_slam: 0), wheel optional; `use_imu_res` takes the poses of the camera update from the CPI records of plv_propagate; GPS / LiDAR / stereo /
 simulation are outside SURVEY §8.
 """
+import ctypes
 import math
 import time as _time
 
 import numpy as np
 
-from . import jpl_left_update
+from . import BoxPlus, PlvStateView, jpl_left_update
 from . import (Context, CpiTable, IwInitializer, PlvError, PlvImuState, PlvWheelOptions, PlvWheelState, StateView, Tracks, WHEEL_TYPES, default_config,
                imu_noise, init_imu_static, next_clone_time, reset_cpi, select_imu_readings, select_wheel_data)
 from .options import OptionsError
@@ -108,7 +109,8 @@ class Pose:
     def update(self, dx):
         self.q[:] = quat_left_update(self.q, dx[0:3])
         self.p[:] = self.p + dx[3:6]
-        self._R = None
+        if self._R is not None:      # in place: State's prepared boxplus call and the state view hold on to the array
+            self._R[...] = quat_2_Rot(self.q)
 
     def clone(self, var_id):
         c = Pose(self.q, self.p, var_id)
@@ -122,7 +124,7 @@ class Vec:
         self.id = var_id
 
     def update(self, dx):
-        self.v = self.v + dx
+        self.v += dx      # in place (State's prepared boxplus call holds on to the array)
 
 
 class Landmark:
@@ -216,9 +218,41 @@ class State:
             w["R"][i], w["Rf"][i] = c.Rot().ravel(), c.Rot_fej().ravel()
             c.q, c.p, c.q_fej, c.p_fej = w["q"][i], w["p"][i], w["qf"][i], w["pf"][i]      # views from here on
             c._R, c._Rf = w["R"][i].reshape(3, 3), w["Rf"][i].reshape(3, 3)
-        w["idx"] = w["id"][:n, None] + np.arange(6)[None, :]
         self._win, self._win_dirty = w, False
+        # the state view wraps the window arrays themselves and is refreshed in place (view()); the prepared boxplus call lists every
+        # variable dx moves, with the view's calibration fields as mirrors, so that apply() is one C call and leaves the view current
+        c = self.op.est.cam
+        if self.cam_ext is not None:
+            self.cam_ext.Rot()
+            sv = w["sv"] = StateView(w["t"], w["R"], w["p"], w["id"], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
+                                     clone_R_fej=w["Rf"], clone_p_fej=w["pf"], cam_dt=float(self.cam_dt.v[0]),
+                                     extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
+                                     sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0,
+                                     feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp, use_imu_cov=1 if self.op.est.use_imu_cov else 0,
+                                     intr_err_mlt=self.op.est.intr_err.mlt)
+            assert np.shares_memory(sv.R, w["R"]) and np.shares_memory(sv.p, w["p"]) and np.shares_memory(sv.t, w["t"])    # no copies
+            base = ctypes.addressof(sv.c)
+            m_R, m_p, m_K, m_dt = (base + getattr(PlvStateView, f).offset for f in ("R_ItoC", "p_IinC", "intrinsics", "cam_dt"))
+        else:
+            m_R = m_p = m_K = m_dt = None
+        x = np.frombuffer(self.imu, dtype=np.float64)      # q (4), p, v, bg, ba (3 each), then the first estimates
+        # (row n of the window arrays is the IMU pose when it closes the clone list, view(): kept current as well)
+        ent = [("quat", 0, x[0:4], w["R"][n], None), ("vec", 3, x[4:7], None, w["p"][n]), ("vec", 6, x[7:16], None, None)]
+        for var, mr, mp in ((self.cam_ext, m_R, m_p), (self.wheel_ext, None, None)):
+            if var is not None and var.id >= 0:
+                var.Rot()
+                ent += [("quat", var.id, var.q, var._R.reshape(9), mr), ("vec", var.id + 3, var.p, None, mp)]
+        for var, mv in ((self.cam_intr, m_K), (self.cam_dt, m_dt), (self.wheel_dt, None), (self.wheel_intr, None)):
+            if var is not None and var.id >= 0:
+                ent.append(("vec", var.id, var.v, None, mv))
+        for i in range(n):
+            ent += [("quat", int(w["id"][i]), w["q"][i], w["R"][i], None), ("vec", int(w["id"][i]) + 3, w["p"][i], None, None)]
+        w["plus"], w["imu"] = BoxPlus(ent), self.imu
         return w
+
+    def refresh_window(self):
+        """Rebuilds the array form of the window now (after a clone was added or marginalised) rather than at its next use."""
+        self._window_arrays()
 
     def imu_pose(self):
         p = Pose(self.imu.q, self.imu.p, 0)
@@ -251,28 +285,11 @@ class State:
             jpl_left_update(w["qf"][m:m + 1], None, w["Rf"][m:m + 1])
             m += 1
         oc, pc = self.intr_cov()
-        c = self.op.est.cam
-        sv = w.get("sv")
-        if sv is None:     # the view object wraps the window arrays themselves: built once per window, refreshed in place afterwards
-            sv = w["sv"] = StateView(w["t"], w["R"], w["p"], w["id"], self.cam_ext.Rot(), self.cam_ext.p, self.cam_intr.v,
-                                     clone_R_fej=w["Rf"], clone_p_fej=w["pf"], cam_dt=float(self.cam_dt.v[0]),
-                                     extrinsic_state_id=self.cam_ext.id, intrinsic_state_id=self.cam_intr.id, dt_state_id=self.cam_dt.id,
-                                     sigma_pix=c.sigma_pix, use_pol_cov=1 if self.op.est.use_pol_cov else 0, intr_ori_cov=oc, intr_pos_cov=pc,
-                                     feat_rep=c.feat_rep, dt_exp=self.op.est.dt_exp, use_imu_cov=1 if self.op.est.use_imu_cov else 0,
-                                     intr_err_mlt=self.op.est.intr_err.mlt)
-            assert np.shares_memory(sv.R, w["R"]) and np.shares_memory(sv.p, w["p"]) and np.shares_memory(sv.t, w["t"])    # no copies
+        sv = w["sv"]
         v = sv.c
         v.n_clones = m
         sv.t = w["t"][:m]          # (what the tests and the oracle context read)
-        v.cam_dt, v.intr_ori_cov, v.intr_pos_cov = float(self.cam_dt.v[0]), oc, pc
-        if self.cam_ext.id >= 0:       # calibrated online: the values move with every dx
-            for i, xv in enumerate(self.cam_ext.Rot().ravel()):
-                v.R_ItoC[i] = xv
-            for i in range(3):
-                v.p_IinC[i] = self.cam_ext.p[i]
-        if self.cam_intr.id >= 0:
-            for i in range(8):
-                v.intrinsics[i] = self.cam_intr.v[i]
+        v.intr_ori_cov, v.intr_pos_cov = oc, pc        # (the calibration fields are kept current by apply())
         return sv
 
     def cpi_table(self):
@@ -284,18 +301,11 @@ class State:
 
     # ---- x <- x [+] dx for every variable (StateHelper::EKFUpdate :156-168)
     def apply(self, dx):
-        x = np.frombuffer(self.imu, dtype=np.float64)      # the IMU state in place: q (4), p, v, bg, ba (3 each), then the first estimates
-        jpl_left_update(x[0:4], dx[0:3])
-        x[4:16] += dx[3:15]
-        for var, size in ((self.cam_ext, 6), (self.cam_intr, 8), (self.cam_dt, 1), (self.wheel_dt, 1), (self.wheel_ext, 6), (self.wheel_intr, 3)):
-            if var is not None and var.id >= 0:
-                var.update(dx[var.id:var.id + size])
-        if self.clones:      # the whole window in a few array operations (the Pose objects are views of these rows)
+        w = self._window_arrays()
+        if w["imu"] is not self.imu:      # the IMU state object was replaced (initialisation): lay the call out again
+            self._win_dirty = True
             w = self._window_arrays()
-            n = w["n"]
-            d = dx[w["idx"]]
-            jpl_left_update(w["q"], d[:, :3], w["R"]) if n == len(w["q"]) else jpl_left_update(w["q"][:n], d[:, :3], w["R"][:n])
-            w["p"][:n] += d[:, 3:]
+        w["plus"].apply(dx)               # every variable, the clone window and the state view's calibration fields: one C call
         for lm in self.slam.values():
             lm.p = lm.p + dx[lm.id:lm.id + 3]
         if self.cam_intr is not None and self.op.est.cam.do_calib_int:
@@ -389,6 +399,8 @@ class TimeChecker:
 class SystemManager:
     """viw::SystemManager for IMU + one camera (+ wheel)."""
 
+    one_call_update = True      # try_update through plv_camera_try_update (False: plv_camera_update_points / _lines with the dx applied here)
+
     def __init__(self, op, device=0, max_obs=24, context_factory=None, iw_initializer_factory=None):
         """context_factory / iw_initializer_factory: stand-ins with the interface of Context / IwInitializer (the tests run the same
         driver over the CPU oracle through them); the defaults are the HIP library."""
@@ -419,6 +431,9 @@ class SystemManager:
         cfg.max_rows_per_feat = max(cfg.max_rows_per_feat, 2 * max_obs)
         cfg.device = device
         self.ctx = (context_factory or Context)(cfg)
+        import os
+        if os.environ.get("PLV_AHEAD") and hasattr(self.ctx, "tracker_detect_ahead"):
+            self.ctx.tracker_detect_ahead(int(os.environ["PLV_AHEAD"]))
         self.max_obs = max_obs
         self.state = State(op, self.ctx)
         self.noise = imu_noise(e.imu.sigma_w, e.imu.sigma_wb, e.imu.sigma_a, e.imu.sigma_ab, tuple(e.gravity))
@@ -541,6 +556,7 @@ class SystemManager:
             self._reset_cpi(st.time)
             st.est_A.reset(), st.est_a.reset()
             st.flush_old_data()
+            st.refresh_window()       # window maintenance belongs to the cloning step, not to the next camera frame
             self.stats["clones"] += 1
             ct = sorted(st.clones)
             if len(ct) > 1:
@@ -667,35 +683,57 @@ class SystemManager:
         kw = dict(t_prev_frame=self.cam_t_hist[-2], state_time=st.time, window_full=full, chi2_mult=c.chi2_mult)
         if e.use_imu_res:      # State::get_interpolated_pose = get_interpolated_pose_imu (State.cpp:975-977)
             kw["cpi"] = st.cpi_table()
-        self.tc.ding("[Time-Cam] get features + MSCKF update")
         cam_hz = (len(self.cam_t_hist) - 1) / (self.cam_t_hist[-1] - self.cam_t_hist[0])
-        out = self.ctx.camera_update_points(st.view(), st.n, min(c.max_msckf, self.ctx.cfg.max_features), self.max_obs, min_dist=fi.min_dist,
-                                            max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline,
-                                            refine=fi.refine_features, max_slam=c.max_slam, slam_ids=list(st.slam),
-                                            init_min_meas=min(int(e.window_size) * int(cam_hz) - 1, 10), **kw)   # CamHelper.cpp:686
-        if out["status"] != 0:
-            self.stats["not_psd"] += 1
-        elif out["n_accepted"] > 0:
+        pk = dict(min_dist=fi.min_dist, max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline, refine=fi.refine_features,
+                  init_min_meas=min(int(e.window_size) * int(cam_hz) - 1, 10))      # CamHelper.cpp:686
+        max_msckf = min(c.max_msckf, self.ctx.cfg.max_features)
+        if self.one_call_update and c.max_slam == 0 and "cpi" not in kw and hasattr(self.ctx, "camera_try_update"):
+            # the whole of try_update in one library call: point update, dx applied, line update on the updated state, dx applied
+            label = "[Time-Cam] get features + MSCKF update + LINE update" if self.use_lines else "[Time-Cam] get features + MSCKF update"
+            self.tc.ding(label)
+            sv = st.view()
+            out, lo, n_db = self.ctx.camera_try_update(sv, st._window_arrays()["plus"], st.n, max_msckf, self.max_obs, lines=self.use_lines, **pk, **kw)
+            self.tc.dong(label)
+            if self._lines_in_flight:       # (joined inside the call)
+                self.stats["lines_tracked"] += n_db
+                self._lines_in_flight = False
+            self._count_points(out)
+            if lo is not None:
+                self._count_lines(lo)
+            return
+        self.tc.ding("[Time-Cam] get features + MSCKF update")
+        out = self.ctx.camera_update_points(st.view(), st.n, max_msckf, self.max_obs, max_slam=c.max_slam, slam_ids=list(st.slam), **pk, **kw)
+        if out["status"] == 0 and out["n_accepted"] > 0:
             st.apply(out["dx"])
-            self.stats["cam_updates"] += 1
         self.tc.dong("[Time-Cam] get features + MSCKF update")
-        self.stats["cam_features"] += out["n_msckf"]
-        self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
+        self._count_points(out)
         if c.max_slam > 0:
             self._slam_update_and_init(out)
         if self.use_lines:
             self.tc.ding("[Time-Cam] LINE update")
             self._join_lines()
             lo = self.ctx.camera_update_lines(st.view(), st.n, self.max_obs, **kw)
-            self.stats["line_pool"] += lo["n_pool"]
-            self.stats["lines_triangulated"] += lo["n_lines"]
-            if lo["status"] != 0:
-                self.stats["not_psd"] += 1
-            elif lo["n_accepted"] > 0:
+            if lo["status"] == 0 and lo["n_accepted"] > 0:
                 st.apply(lo["dx"])
-                self.stats["line_updates"] += 1
-                self.stats["lines_accepted"] += lo["n_accepted"]
+            self._count_lines(lo)
             self.tc.dong("[Time-Cam] LINE update")
+
+    def _count_points(self, out):
+        if out["status"] != 0:
+            self.stats["not_psd"] += 1
+        elif out["n_accepted"] > 0:
+            self.stats["cam_updates"] += 1
+        self.stats["cam_features"] += out["n_msckf"]
+        self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
+
+    def _count_lines(self, lo):
+        self.stats["line_pool"] += lo["n_pool"]
+        self.stats["lines_triangulated"] += lo["n_lines"]
+        if lo["status"] != 0:
+            self.stats["not_psd"] += 1
+        elif lo["n_accepted"] > 0:
+            self.stats["line_updates"] += 1
+            self.stats["lines_accepted"] += lo["n_accepted"]
 
     def _landmark_system(self, t, uv, p, p_fej):
         """get_feature_jacobian_full for one feature: (rows, Hf [rows][3], Hx [rows][k], res, cols)."""

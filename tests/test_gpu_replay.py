@@ -181,6 +181,26 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
 
+def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path, monkeypatch):
+    """plv_camera_try_update (point update, dx applied inside the library, line update, dx applied; the point half's database
+    hand-back deferred into the line update's wait) against plv_camera_update_points / _lines with the dx applied by the driver:
+    the same filter, bit for bit."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    system = importlib.import_module("plviwo_amd.system")
+    runs = {}
+    for one_call in (True, False):
+        monkeypatch.setattr(system.SystemManager, "one_call_update", one_call)
+        op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{int(one_call)}.txt")))
+        op.est.cam.use_lines = True
+        runs[one_call] = rp.replay(op)
+    (s1, t1, p1), (s0, t0, p0) = runs[True], runs[False]
+    assert s1["line_updates"] >= 10 and s1["cam_updates"] >= 40
+    for key in s0:
+        if not key.startswith("time"):
+            assert s1[key] == s0[key], (key, s1[key], s0[key])
+    assert np.array_equal(t1, t0) and np.array_equal(p1, p0)
+
+
 def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
     """cam.downsample (pyrDown of every image, halved intrinsics: OptionsCamera.cpp:123-138, UpdaterCamera.cpp:85-98) with the CLAHE
     front-end on the 376 x 240 images."""
