@@ -401,7 +401,7 @@ int check_line_views(const plv_state_view *st, const plv_line_tracks *lt, bool n
 
 // one packed upload of the state view and the line tracks; fills JacParams (n_feat = n_lines)
 int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
-                      const int *col_to_state, int ld, JacParams &P) {
+                      const int *col_to_state, int ld, JacParams &P, StageExtra *ex = nullptr) {
   const int N = st->n_clones, L = lt->n_lines, nobs = lt->obs_ptr[L];
   if (nobs < 1) {
     set_last_error("line jacobians: no observations");
@@ -424,11 +424,14 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
                o_uvn = lt->seg_uvn ? take(16 * nobs) : 0, o_lg = lt->line_FinG ? take(48 * L) : 0,
                o_D = lt->D ? take(4 * L) : 0, o_ap = lt->has_pt ? take(24 * L) : 0, o_hp = lt->has_pt ? take(L) : 0,
                o_rR = lt->res_R ? take(72 * nobs) : 0, o_rp = lt->res_R ? take(24 * nobs) : 0,
-               o_rQ = lt->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = lt->res_Q ? take(4 * (size_t)nobs) : 0;
+               o_rQ = lt->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = lt->res_Q ? take(4 * (size_t)nobs) : 0,
+               o_cols = take(4 * (size_t)k), o_xfl = ex && ex->flags ? take(L) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
   char *h = us->h_jin.as<char>();
+  memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
+  if (ex && ex->flags) memcpy(h + o_xfl, ex->flags, L);
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
   memcpy(h + o_p, st->clone_p, 24 * N);
@@ -496,6 +499,9 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   P.res_p = lt->res_R ? (const double *)(d + o_rp) : nullptr;
   P.k = k;
   P.ld = ld;
+  P.cols_in = (const int *)(d + o_cols);
+  P.cols_out = nullptr;
+  if (ex) ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
   return PLV_OK;
 }
 
@@ -505,7 +511,7 @@ struct FusedLineTri {
   size_t o_lines, o_ok;  // out: results in us->tri (lines [L][6], ok [L])
 };
 int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
-                          const int *col_to_state, int ld, FusedLineTri *ft = nullptr) {
+                          const int *col_to_state, int ld, bool project, FusedLineTri *ft = nullptr) {
   TRY(check_line_views(st, lt, ft == nullptr, ft != nullptr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int L = lt->n_lines;
@@ -514,21 +520,21 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{};
-  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P));
+  StageExtra ex;
+  if (ft) ex.flags = ft->flags;
+  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex));
   us->b_projected = false;
   us->b_gather_token = 0;
-  PLV_HIP_CHECK(plv::memcpy_async(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
   if (ft) {
     const int nobs = lt->obs_ptr[L];
     const size_t o_cam = 0, o_imu = (size_t)nobs * 96, o_lines = o_imu + (size_t)nobs * 96, o_ok = o_lines + (size_t)L * 48,
-                 o_fl = (o_ok + L + 15) & ~(size_t)15, o_valid = (o_fl + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
+                 o_valid = (o_ok + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    PLV_HIP_CHECK(plv::memcpy_async(d + o_fl, ft->flags, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch_triangulate_lines(ctx, P, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
                                  (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
     P.line_FinG = (const double *)(d + o_lines);
-    P.sel_flags = (const unsigned char *)(d + o_fl);
+    P.sel_flags = ex.d_flags;
     P.tri_ok = (const unsigned char *)(d + o_ok);
     P.tri_err = nullptr;
     P.max_sel = ft->max_sel;
@@ -538,7 +544,26 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   P.Hf = us->bHf.as<double>();
   P.Hx = P.Hf + nHf;
   P.res = P.Hx + nHx;
-  TRY(launch_line_jacobians(ctx, P));
+  if (project) {
+    // resident update path: build + project in one launch (the column map is published by its workgroup 0); when a covariance of
+    // matching size is resident its gathers ride along
+    P.cols_out = us->bcols.as<int>();
+    bool can_gather = ctx->cov_n > 0;
+    for (int j = 0; j < k && can_gather; ++j) can_gather = col_to_state[j] >= 0 && col_to_state[j] < ctx->cov_n;
+    GatherArgs g{};
+    int gblocks = 0;
+    if (can_gather) {
+      const int n = ctx->cov_n;
+      TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
+      gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
+    }
+    TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    us->b_projected = true;
+    us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
+  } else {
+    PLV_HIP_CHECK(plv::memcpy_async(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch_line_jacobians(ctx, P));
+  }
   us->bF = L;
   us->bfdim = 6;
   us->bk = k;
@@ -560,7 +585,7 @@ int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_lin
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
   FusedLineTri ft{flags, max_sel, 0, 0};
-  TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, &ft));
+  TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, true, &ft));
   us->b_single_use = true;
   const int L = all->n_lines;
   TRY(us->h_tri.reserve((size_t)L * 49 + 16));
@@ -605,7 +630,7 @@ int plv_build_line_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, co
   if (!ctx) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld));
+  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld, true));
   us->b_single_use = true;
   return PLV_OK;
 }
@@ -615,7 +640,7 @@ int plv_build_line_jacobians(plv_ctx *ctx, const plv_state_view *st, const plv_l
   if (!ctx || !rows || !Hf || !Hx || !res) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld));
+  TRY(build_lines_on_device(ctx, us, st, lt, k, col_to_state, ld, false));
   us->b_single_use = false;
   const int L = lt->n_lines;
   const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;

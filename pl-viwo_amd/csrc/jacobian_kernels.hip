@@ -1096,8 +1096,9 @@ __device__ __forceinline__ V3 cross3(const V3 &a, const V3 &b) {
 }
 __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-__device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs) {
-  const int ld = P.ld;
+// Element (row, col) of a block goes to base[col * cstr + row * rstr], as in jacobian_rows.
+__device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs, int cstr,
+                          int rstr) {
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
   const double *Kc = P.K;
@@ -1198,8 +1199,8 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
     Wm[col] = x0;
     Wm[2 + col] = x1;
   }
-  rs[2 * c] = Wm[0] * r2[0] + Wm[1] * r2[1];
-  rs[2 * c + 1] = Wm[2] * r2[0] + Wm[3] * r2[1];
+  rs[(2 * c) * rstr] = Wm[0] * r2[0] + Wm[1] * r2[1];
+  rs[(2 * c + 1) * rstr] = Wm[2] * r2[0] + Wm[3] * r2[1];
   double wli[12];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -1222,8 +1223,8 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
         a += wli[6 * i + 3 + q] * 0.0;
         b += wli[6 * i + 3 + q] * Re(q, j);
       }
-      hf[(size_t)j * ld + 2 * c + i] = a;
-      hf[(size_t)(3 + j) * ld + 2 * c + i] = b;
+      hf[(size_t)j * cstr + (2 * c + i) * rstr] = a;
+      hf[(size_t)(3 + j) * cstr + (2 * c + i) * rstr] = b;
     }
   double WI[12];
 #pragma unroll
@@ -1253,8 +1254,8 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
-        hx[(size_t)(col + j) * ld + 2 * c + i] = so;  // (written once: plain stores, as in jacobian_rows)
-        hx[(size_t)(col + 3 + j) * ld + 2 * c + i] = WI[6 * i + 3 + j] * jac.lam[w];
+        hx[(size_t)(col + j) * cstr + (2 * c + i) * rstr] = so;  // (written once: plain stores, as in jacobian_rows)
+        hx[(size_t)(col + 3 + j) * cstr + (2 * c + i) * rstr] = WI[6 * i + 3 + j] * jac.lam[w];
       }
   }
   if (P.col_dt >= 0)
@@ -1263,7 +1264,7 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
       double s = 0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
-      hx[(size_t)P.col_dt * ld + 2 * c + i] = s;
+      hx[(size_t)P.col_dt * cstr + (2 * c + i) * rstr] = s;
     }
 }
 
@@ -1289,9 +1290,73 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
     const unsigned long long vmask = __ballot(s0 >= 0);
     const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
     base += __popcll(vmask);
-    if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, hf, hx, rs);
+    if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, hf, hx, rs, ld, 1);
   }
   if (threadIdx.x == 0) P.rows[l] = 2 * base;
+}
+
+// line_jacobian_kernel + the null-space projection in one launch for the resident update path (the line twin of
+// jacobian_nullspace_kernel): the line's [Hf (6) | Hx | res] block is built row-major in LDS, projected there by six Householder
+// reflections and only the projected block goes to global memory.  The covariance gathers of the update ride on it as extra
+// workgroups, and workgroup 0 publishes the column map.
+__global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g) {
+  extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
+  __shared__ int s_rows;
+  if ((int)blockIdx.x >= L) {
+    gather_cov_block(g, blockIdx.x - L);
+    return;
+  }
+  const int l = blockIdx.x;
+  const int ld = P.ld, k = P.k, ncol = 6 + k + 1;
+  double *X = jsm, *piv = jsm + ld * ncol;
+  for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
+  if (l == 0 && P.cols_out)
+    for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
+  const bool selected = !P.tri_ok || candidate_selected(P, l);
+  __syncthreads();  // (orders the zero fill before the row writes)
+  if (!selected) {
+    if (threadIdx.x == 0) {
+      s_rows = 0;
+      P.rows[l] = 0;
+    }
+  } else if (threadIdx.x < 64) {
+    const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
+    int base = 0;
+    for (int ob = o0; ob < o1; ob += 64) {
+      const int o = ob + threadIdx.x;
+      const bool have = o < o1;
+      const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
+      const int s0 = have ? bounding_start(P, tm) : -1;
+      const unsigned long long vmask = __ballot(s0 >= 0);
+      const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
+      base += __popcll(vmask);
+      if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, X, X + 6, X + 6 + k, 1, ncol);
+    }
+    if (threadIdx.x == 0) {
+      s_rows = min(2 * base, ld & ~1);
+      P.rows[l] = 2 * base;
+    }
+  }
+  __syncthreads();
+  const int rows = s_rows;
+  const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
+  if (shift) nullspace_householder(X, piv, rows, ncol, 6);
+  double *hf = P.Hf + (size_t)l * 6 * ld, *hx = P.Hx + (size_t)l * k * ld, *rs = P.res + (size_t)l * ld;
+  for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
+    double *dst = j < 6 ? hf + j * ld : (j < 6 + k ? hx + (size_t)(j - 6) * ld : rs);
+    const int off = j < 6 ? 0 : shift;
+    for (int i0 = 0; i0 < ld; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = i0 + u + off;
+        v[u] = r < ld ? X[r * ncol + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < ld) dst[i0 + u] = v[u];
+    }
+  }
 }
 
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
@@ -1389,6 +1454,21 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
   ProfScope ps(ctx->prof, "line_jacobian_kernel", ctx->stream);
   hipLaunchKernelGGL(line_jacobian_kernel, dim3(P.n_feat), dim3(64), 0, ctx->stream, P);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks) {
+  ProfScope ps(ctx->prof, "line_jacobian_nullspace_kernel", ctx->stream);
+  const size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
+  if (shm + 64 > 160 * 1024) {
+    set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
+    return PLV_E_CAPACITY;
+  }
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
+  GatherArgs none{};
+  hipLaunchKernelGGL(line_jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
+                     g ? *g : none);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
