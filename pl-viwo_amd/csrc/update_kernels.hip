@@ -387,7 +387,10 @@ __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ 
                                                      const int *__restrict__ cols, const double *__restrict__ P,
                                                      int ldp, int n, double *__restrict__ Mt, int ldm,
                                                      int *__restrict__ flag, const int *__restrict__ skip) {
-  if (flag && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;  // update status word, set by the kernels that follow
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    flag[0] = 0;  // update status word, set by the kernels that follow
+    flag[2] = 0;  // arrival counter of ekf_dc_kernel
+  }
   if (skip && *skip == 0) return;
   const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -431,6 +434,71 @@ __global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ M
   for (int q = 0; q < 4; ++q) {
     int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
     if (i < r && j < r) S[(size_t)j * lds_ + i] = acc[q] + (i == j ? (Rdiag ? Rdiag[i] : 1.0) : 0.0);
+  }
+}
+
+// ekf_mt_kernel and ekf_s_kernel in one launch.  The first mt_blocks workgroups form Mt = H Pc tile by tile; every further workgroup
+// owns one 16-row strip of S: it first forms its strip of H Ps (= the columns `cols` of Mt, the same sums in the same order, kept in
+// LDS) and multiplies it with H^T for the tiles on and above the diagonal — S no longer waits for Mt, and the compact copy of
+// Mt[:, cols] is never written.
+__global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ H, int ldh, int r, int k, const double *__restrict__ Pc,
+                                                     int ldp, int n, const double *__restrict__ Ps, double *__restrict__ Mt, int ldm,
+                                                     const double *__restrict__ Rdiag, double *__restrict__ S, int lds_,
+                                                     int mt_blocks, int *__restrict__ flag, const int *__restrict__ skip) {
+  __shared__ double strip[192 * 17];  // (H Ps)[16 rows][k], element (i, kk) at kk * 17 + i
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    flag[0] = 0;  // update status word, set by the kernels that follow
+    flag[2] = 0;  // arrival counter of ekf_dc_kernel
+  }
+  if (skip && *skip == 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15;
+  if ((int)blockIdx.x < mt_blocks) {
+    const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tr_n * tn_n) return;
+    const int tr = tile / tn_n, tn = tile - tr * tn_n;
+    d4 acc = {0, 0, 0, 0};
+    const double *Hr = H + min(tr * 16 + li, r - 1);
+    const double *Pq = Pc + min(tn * 16 + li, n - 1);  // Pc = P[cols, :] (k x n)
+    auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
+    auto fb = [&](int kk, int) { return Pq[(size_t)kk * ldp]; };
+    acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tr * 16 + (lane >> 4) + 4 * q, j = tn * 16 + li;
+      if (i < r && j < n) Mt[(size_t)j * ldm + i] = acc[q];
+    }
+    return;
+  }
+  const int ti = blockIdx.x - mt_blocks;
+  const int kt = (k + 15) >> 4, tr_n = (r + 15) >> 4;
+  {
+    const double *Hr = H + min(ti * 16 + li, r - 1);
+    for (int tj = wave; tj < kt; tj += 4) {
+      d4 acc = {0, 0, 0, 0};
+      const double *Pq = Ps + min(tj * 16 + li, k - 1);  // Ps = P[cols, cols] (k x k)
+      auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
+      auto fb = [&](int kk, int) { return Pq[(size_t)kk * k]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = tj * 16 + li;
+        if (j < k) strip[j * 17 + (lane >> 4) + 4 * q] = acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int tj = ti + wave; tj < tr_n; tj += 4) {
+    d4 acc = {0, 0, 0, 0};
+    const double *Hc = H + min(tj * 16 + li, r - 1);
+    auto fa = [&](int, int kk) { return strip[kk * 17 + li]; };
+    auto fb = [&](int kk, int) { return Hc[(size_t)kk * ldh]; };
+    acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + li;
+      if (i < r && j < r) S[(size_t)j * lds_ + i] = acc[q] + (i == j ? (Rdiag ? Rdiag[i] : 1.0) : 0.0);
+    }
   }
 }
 
@@ -688,23 +756,21 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
   }
 }
 
-// Mt = H P[cols,:] and S = Mt[:,cols] H^T + R (two tile-parallel launches).
+// Mt = H P[cols,:] and S = Mt[:,cols] H^T + R in one launch (S: tiles on and above the diagonal).
 void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh,
                    const int *d_cols, const double *d_Rdiag, double *Mt, int ldm, double *S, bool gathered, int *d_flag) {
-  // Mt holds [Mt (n cols) | spare (1) | Mt[:, cols] (k cols)]: callers size it r x (n + 1 + k)
   if (!gathered) (void)launch_gather_cov(ctx, d_P, n, ldp, d_cols, k);
-  {
-    ProfScope ps(ctx->prof, "ekf_mt_kernel", ctx->stream);
-    int tiles = cdiv(r, 16) * cdiv(n, 16);
-    hipLaunchKernelGGL(ekf_mt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_inv.as<int>(),
+  ProfScope ps(ctx->prof, "ekf_ms_kernel", ctx->stream);
+  const int mt_blocks = cdiv(cdiv(r, 16) * cdiv(n, 16), 4);
+  if (k > 192) {  // (the strip buffer of the fused kernel; launch_ekf's callers stay below: PLV_E_CAPACITY earlier)
+    hipLaunchKernelGGL(ekf_mt_kernel, dim3(mt_blocks), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_inv.as<int>(),
                        ctx->d_Pc.as<double>(), n, n, Mt, ldm, d_flag, ctx->skip_word);
+    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(cdiv(r, 16) * cdiv(r, 16), 4)), dim3(256), 0, ctx->stream, Mt + (size_t)(n + 1) * ldm, ldm,
+                       d_H, ldh, r, k, d_cols, d_Rdiag, S, r, ctx->skip_word);
+    return;
   }
-  {
-    ProfScope ps(ctx->prof, "ekf_s_kernel", ctx->stream);
-    int tiles = cdiv(r, 16) * cdiv(r, 16);
-    hipLaunchKernelGGL(ekf_s_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, ctx->stream, Mt + (size_t)(n + 1) * ldm, ldm, d_H, ldh,
-                       r, k, d_cols, d_Rdiag, S, r, ctx->skip_word);
-  }
+  hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(r, 16)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_Pc.as<double>(), n, n,
+                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word);
 }
 
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
