@@ -41,7 +41,6 @@ struct LineTrack {  // LineFeature, one camera   REF: linefeat/LineFeature.h:22-
   std::vector<double> t;
   std::vector<float> uv, uvn;  // 4 per observation
   std::vector<int> points;     // ids of the point features assigned at every observation (appended, REF :50-52)
-  std::map<double, std::vector<float>> point_uvs;
   int D = 0;
 };
 
@@ -689,7 +688,6 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
       tr.uv.insert(tr.uv.end(), fl.begin() + 4 * q, fl.begin() + 4 * q + 4);
       tr.uvn.insert(tr.uvn.end(), un.begin() + 4 * q, un.begin() + 4 * q + 4);
       for (int p = A.rel_ptr[q]; p < A.rel_ptr[q + 1]; ++p) tr.points.push_back((int)A.rel_id[p]);
-      tr.point_uvs[timestamp].assign(A.pos.begin() + 2 * A.pos_ptr[q], A.pos.begin() + 2 * A.pos_ptr[q + 1]);
     }
   }
   T->lines_last.swap(fl);
@@ -887,6 +885,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     }
   }
   res->n_pool = (int)pool.size();
+  plv::HostPhase ph_p1("update_lines: pool a (scan + take) done -> b (trim + sort)");
   for (auto it = pool.begin(); it != pool.end();) {  // REF :652-682 (hard-coded 0.01 s margins)
     LineTrack &tr = it->tr;
     size_t keep = 0;
@@ -1007,6 +1006,8 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       c.tr = std::move(kept);
     }
   }
+  ph_p1.stop();
+  plv::HostPhase ph_p2("update_lines: pool c (anchors + arrays + valid)");
   std::vector<int> ptr(Lp + 1, 0), D(Lp);
   std::vector<double> anchor(3 * (size_t)Lp, 0.0);
   std::vector<uint8_t> has(Lp, 0), ok(Lp);
@@ -1059,6 +1060,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   // compression and EKFUpdate back to back on the stream, one synchronisation.  CPI poses and over-long tracks take the two-step route.
   const bool fused = !opt->cpi && most_valid <= opt->max_obs;
   const double us_pool = since(U0);
+  ph_p2.stop();
   ph_pool.stop();
   plv::HostPhase ph_dev("update_lines: device submission + wait");
   const auto U1 = std::chrono::steady_clock::now();
