@@ -18,7 +18,7 @@ wrap(sm.state,'view','view'); wrap(sm.state,'apply','apply')
 wrap(sm.ctx,'camera_update_points','py:update_points'); wrap(sm.ctx,'camera_update_lines','py:update_lines')
 wrap(sm.ctx,'tracker_feed_staged','py:tracker_feed'); wrap(sm.ctx,'line_tracker_feed_async','py:line_async'); wrap(sm.ctx,'line_tracker_feed_wait','py:line_wait')
 wrap(sm.ctx,'vanishing_points','py:vps'); wrap(sm.ctx,'line_db_size','py:line_db_size')
-wrap(sm,'_camera_try_update','try_update'); 
+wrap(sm,'_camera_try_update','try_update'); wrap(sm.ctx,'camera_frame','py:camera_frame'); wrap(sm,'_try_update_args','py:args'); 
 for f in range(bench.PROLOGUE+20): pl.camera(*pl.next_frame())
 acc.clear(); tot=0; N=200
 for f in range(N):

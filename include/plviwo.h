@@ -638,6 +638,23 @@ typedef struct plv_try_update {
   int line_db_size;                      /* out */
 } plv_try_update;
 int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update *io);
+/* One camera frame as one call: UpdaterCamera::feed_measurement (REF: UpdaterCamera.cpp:77-116: TrackKLT::feed_new_camera, then
+ * LineHelper::Vanishing_Points + TrackLSD::feed_new_camera when lines are on) followed by try_update (:139-195) through
+ * plv_camera_try_update.  The image comes from HBM slot `slot` (plv_image_stage; slot >= 0) or from the host (img, stride).
+ * update == NULL: feed only (not initialised yet / fewer than intr_order + 1 clones, CamHelper.cpp:615-616); with lines on and
+ * update->opt_lines == NULL the lines are tracked but not used.  `st` is the state at the time of the call (the extrinsics and
+ * intrinsics the vanishing points are made from are st's).  line_db_size: LineFeatureDatabase size after the feed. */
+typedef struct plv_camera_frame_io {
+  double timestamp;
+  int slot;                /* >= 0: staged image; < 0: img / stride */
+  const uint8_t *img;
+  int stride;
+  const uint8_t *mask;     /* W x H, > 127 = masked out; may be NULL */
+  int use_lines;           /* OptionsCamera::use_lines */
+  plv_try_update *update;  /* or NULL */
+  int line_db_size;        /* out */
+} plv_camera_frame_io;
+int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io *io);
 
 /* ---------------------------------------------------------------------------------------------
  * In-state (SLAM) landmarks (a30) on the device-resident covariance, one landmark per call as the reference

@@ -174,6 +174,7 @@ def load_library():
         "plv_jpl_left_update": (None, [C.c_int, dp, dp, dp]),
         "plv_state_boxplus": (C.c_int, [C.c_int, C.POINTER(PlvStateVar), dp, C.c_int]),
         "plv_camera_try_update": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvTryUpdate)]),
+        "plv_camera_frame": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvCameraFrameIo)]),
         "plv_line_walk_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_prefetch_mode": (C.c_int, [vp, C.c_int]),
         "plv_line_tracker_feed_async": (C.c_int, [vp, C.c_double, dp]),
@@ -290,6 +291,11 @@ class PlvTryUpdate(C.Structure):
                 ("msckf_ids", C.c_void_p), ("msckf_accepted", C.c_void_p), ("p_FinG", C.c_void_p),
                 ("line_ids", C.c_void_p), ("line_accepted", C.c_void_p), ("line_FinG", C.c_void_p), ("line_cap", C.c_int),
                 ("line_db_size", C.c_int)]
+
+
+class PlvCameraFrameIo(C.Structure):
+    _fields_ = [("timestamp", C.c_double), ("slot", C.c_int), ("img", C.c_void_p), ("stride", C.c_int), ("mask", C.c_void_p),
+                ("use_lines", C.c_int), ("update", C.c_void_p), ("line_db_size", C.c_int)]
 
 
 class BoxPlus:
@@ -1100,11 +1106,9 @@ class Context:
         return dict(dx=dx, n_pool=res.n_pool, n_lines=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned,
                     status=res.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), line_FinG=lg[:m].copy())
 
-    def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0,
-                          min_dist=0.1, max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True, init_min_meas=10, lines=True, cap=512):
-        """plv_camera_try_update: the point update, its dx applied through `plus` (a BoxPlus whose arrays back `st`), then the line
-        update on the updated state and its dx applied.  Returns (points dict, lines dict or None, line database size after the feed)
-        in the form of camera_update_points / camera_update_lines."""
+    def _try_update_io(self, plus, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, min_dist=0.1, max_dist=60.0,
+                       max_cond=1e4, max_baseline=40.0, refine=True, init_min_meas=10, lines=True, cap=512):
+        """plv_try_update for the given options + a function that turns the filled structure into the result dicts"""
         tri = PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
         op = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, tri, t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, init_min_meas, None)
         ol = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, 10, None)
@@ -1116,16 +1120,47 @@ class Context:
         io = PlvTryUpdate(C.addressof(op), C.addressof(ol) if lines else None, plus.n if plus is not None else 0,
                           C.addressof(plus.vars) if plus is not None else None, a(dxp), a(dxl), C.addressof(rp), C.addressof(rl),
                           a(ids), a(acc), a(p), a(lids), a(lacc), a(lg), cap, 0)
+
+        def results(keep=(op, ol, plus)):      # (the structures io points to live as long as this closure)
+            m = rp.n_msckf
+            pts = dict(dx=dxp, n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned, status=rp.status,
+                       ids=ids[:m], accepted=acc[:m], p_FinG=p[:m], n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
+            if not lines:
+                return pts, None, 0
+            m = rl.n_msckf
+            lns = dict(dx=dxl, n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
+                       status=rl.status, ids=lids[:m], accepted=lacc[:m], line_FinG=lg[:m])
+            return pts, lns, io.line_db_size
+        return io, results
+
+    def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw):
+        """plv_camera_try_update: the point update, its dx applied through `plus` (a BoxPlus whose arrays back `st`), then the line
+        update on the updated state and its dx applied.  Returns (points dict, lines dict or None, line database size after the feed)
+        in the form of camera_update_points / camera_update_lines."""
+        io, results = self._try_update_io(plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw)
         self._chk(self.lib.plv_camera_try_update(self.h, C.byref(st.c), C.byref(io)))
-        m = rp.n_msckf
-        pts = dict(dx=dxp, n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned,
-                   status=rp.status, ids=ids[:m], accepted=acc[:m], p_FinG=p[:m], n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
-        if not lines:
-            return pts, None, 0
-        m = rl.n_msckf
-        lns = dict(dx=dxl, n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
-                   status=rl.status, ids=lids[:m], accepted=lacc[:m], line_FinG=lg[:m])
-        return pts, lns, io.line_db_size
+        return results()
+
+    def camera_frame(self, st, timestamp, slot=None, img=None, mask=None, use_lines=False, update=None):
+        """plv_camera_frame: tracker feed (+ vanishing points and line tracker feed) and, with update = dict(plus=, n=, max_msckf=,
+        max_obs=, t_prev_frame=, state_time=, ...) (the arguments of camera_try_update), the whole of try_update.  Returns
+        (points dict, lines dict, line database size) — (None, None, size) without an update."""
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if slot is None:
+            img = np.ascontiguousarray(img, dtype=np.uint8)
+            if img.shape != (self.cfg.height, self.cfg.width):
+                raise PlvError(PLV_E_BADARG, f"image shape {img.shape} != ({self.cfg.height}, {self.cfg.width})")
+        io, results = self._try_update_io(**update) if update is not None else (None, None)
+        f = PlvCameraFrameIo(float(timestamp), -1 if slot is None else int(slot), img.ctypes.data if slot is None else None,
+                             self.cfg.width, m.ctypes.data if m is not None else None, 1 if use_lines else 0,
+                             C.addressof(io) if io is not None else None, 0)
+        self._chk(self.lib.plv_camera_frame(self.h, C.byref(st.c), C.byref(f)))
+        if results is None:
+            return None, None, f.line_db_size
+        pts, lns, _ = results()
+        return pts, lns, f.line_db_size
 
     # ---- lines (front-end)
     def detect_lines(self, which=0, cap=4096):

@@ -113,9 +113,13 @@ __global__ void __launch_bounds__(256) equalize_kernel(const uint8_t *__restrict
 #define PD_T 16
 #define PD_S (2 * PD_T + 3)
 __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict__ src, int sw, int sh_, uint8_t *__restrict__ dst,
-                                                      int dw, int dh) {
+                                                      int dw, int dh, unsigned *__restrict__ clear_hist) {
   __shared__ uint8_t tile[PD_S][PD_S + 1];
   __shared__ int hrow[PD_S][PD_T + 1];
+  if (clear_hist && blockIdx.x == 0 && blockIdx.y == 0) {  // (see pyrdown2_kernel)
+    clear_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) clear_hist[256] = 0;
+  }
   const int ox = blockIdx.x * PD_T, oy = blockIdx.y * PD_T;
   const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
   for (int i = threadIdx.x; i < PD_S * PD_S; i += 256) {
@@ -140,63 +144,95 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const uint8_t *__restrict_
 // the 73x73 footprint of level l, builds the 35x35 piece of level l+1 that the upper tile needs (rounded to u8 exactly as the
 // single-level kernel writes it, so every value is the one pyrdown_kernel produces; the halo rows are recomputed by the
 // neighbours) and filters again.  Halves the launches of cv::buildOpticalFlowPyramid's chain.
-#define PD2_T 16
-#define PD2_M (2 * PD2_T + 3)   // 35: level l+1 piece
-#define PD2_S (2 * PD2_M + 3)   // 73: level l footprint
+#define PD2_T 8    // (8: 4x the workgroups of 16 — 360 at 752x480 — each a third of the serial staging / filter passes)
+#define PD2_M (2 * PD2_T + 3)   // 19: level l+1 piece
+#define PD2_S (2 * PD2_M + 3)   // 41: level l footprint
 // EQ: `src` is the RAW image and level l is its histogram-equalised version: the workgroup rebuilds the LUT from the finished
 // histogram (as equalize_kernel does), maps the footprint while staging it, writes the 64x64 piece of level 0 it owns and clears
 // the histogram when it is the last to arrive: cv::equalizeHist's second half and two pyramid levels in one launch.
 template <bool EQ>
 __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ mid,
                                                        int mw, int mh, uint8_t *__restrict__ dst, int dw, int dh,
-                                                       unsigned *__restrict__ hist, uint8_t *__restrict__ lvl0) {
+                                                       unsigned *__restrict__ hist, uint8_t *__restrict__ lvl0, int clear_hist) {
   __shared__ uint8_t t0[PD2_S][PD2_S + 3];
   __shared__ int h0[PD2_S][PD2_M + 1];
   __shared__ uint8_t t1[PD2_M][PD2_M + 1];
   __shared__ int h1[PD2_M][PD2_T + 1];
   __shared__ unsigned cdf[256];
   __shared__ uint8_t lut[256];
-  __shared__ int first_bin;
   __shared__ bool last_block;
   const int ox = blockIdx.x * PD2_T, oy = blockIdx.y * PD2_T;   // level l+2 tile origin
   // level l+1 rows / columns held in t1: [my0, my0 + PD2_M), clamped at 0 (reads below 0 reflect to 1, 2: inside)
   const int my0 = max(2 * oy - 2, 0), mx0 = max(2 * ox - 2, 0);
   const int sy0 = max(2 * my0 - 2, 0), sx0 = max(2 * mx0 - 2, 0);  // level l origin of t0, same rule
-  if (EQ) {  // the LUT of cv::equalizeHist (same code as equalize_kernel)
-    const int t = threadIdx.x, npix = sw * sh;
-    cdf[t] = hist[t];
-    if (t == 0) first_bin = 256;
-    __syncthreads();
-    if (cdf[t]) atomicMin(&first_bin, t);
-    for (int off = 1; off < 256; off <<= 1) {
-      unsigned v = t >= off ? cdf[t - off] : 0;
-      __syncthreads();
-      cdf[t] += v;
-      __syncthreads();
+  if (EQ) {  // the LUT of cv::equalizeHist (equalize_kernel's arithmetic; the prefix sum by wave scans: two barriers instead of 17)
+    const int t = threadIdx.x, npix = sw * sh, lane = t & 63, wv = t >> 6;
+    const unsigned hv = hist[t];
+    unsigned c = hv;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned u = __shfl_up(c, off);
+      if (lane >= off) c += u;
     }
-    const int i0 = first_bin;
-    const unsigned hh0 = hist[i0];
+    const unsigned long long nz = __ballot(hv != 0);
+    if (lane == 63) cdf[wv] = c;                                         // wave totals
+    if (lane == 0) cdf[4 + wv] = nz ? (unsigned)(64 * wv + __ffsll((long long)nz) - 1) : 256u;  // first non-empty bin of the wave
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) c += cdf[w];
+    const int i0 = (int)min(min(cdf[4], cdf[5]), min(cdf[6], cdf[7]));
+    if (t == i0) cdf[8] = hv;
+    __syncthreads();
+    const unsigned hh0 = cdf[8];
     if ((int)hh0 == npix) {
       lut[t] = (uint8_t)t;
     } else {
       const float scale = (256 - 1.f) / (float)(npix - (int)hh0);
       int v = 0;
-      if (t > i0) v = __float2int_rn((float)(int)(cdf[t] - hh0) * scale);
+      if (t > i0) v = __float2int_rn((float)(int)(c - hh0) * scale);
       lut[t] = (uint8_t)min(max(v, 0), 255);
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < PD2_S * PD2_S; i += 256) {
-    const int ty = i / PD2_S, tx = i - ty * PD2_S;
-    const int Yr = sy0 + ty, Xr = sx0 + tx;
-    const int Y = min(Yr, sh - 1), X = min(Xr, sw - 1);
-    uint8_t v = src[(size_t)Y * sw + X];
-    if (EQ) {
-      v = lut[v];
-      // level 0 rows [4 oy, 4 oy + 64) x columns [4 ox, 4 ox + 64) belong to this workgroup
-      if (Yr < sh && Xr < sw && Yr >= 4 * oy && Yr < 4 * oy + 4 * PD2_T && Xr >= 4 * ox && Xr < 4 * ox + 4 * PD2_T) lvl0[(size_t)Yr * sw + Xr] = v;
+  if ((sw & 3) == 0) {
+    // rows of the footprint as aligned 4-byte words (level widths that are multiples of 4: every word lies inside the row or past its
+    // end, and the 64-pixel level-0 piece starts on a word): a quarter of the load / store instructions of the byte loop below
+    const int xw0 = sx0 & ~3;
+    const int nw = (sx0 + PD2_S - xw0 + 3) >> 2;
+    for (int i = threadIdx.x; i < PD2_S * nw; i += 256) {
+      const int ty = i / nw, w = i - ty * nw;
+      const int Yr = sy0 + ty, Y = min(Yr, sh - 1);
+      const int X0 = xw0 + 4 * w;
+      unsigned q;
+      if (X0 < sw) {
+        q = *reinterpret_cast<const unsigned *>(src + (size_t)Y * sw + X0);
+      } else {
+        q = src[(size_t)Y * sw + sw - 1] * 0x01010101u;  // past the right edge: the last pixel
+      }
+      if (EQ) {
+        q = (unsigned)lut[q & 255] | ((unsigned)lut[(q >> 8) & 255] << 8) | ((unsigned)lut[(q >> 16) & 255] << 16) | ((unsigned)lut[q >> 24] << 24);
+        // level 0 rows [4 oy, 4 oy + 64) x columns [4 ox, 4 ox + 64) belong to this workgroup
+        if (Yr < sh && X0 < sw && Yr >= 4 * oy && Yr < 4 * oy + 4 * PD2_T && X0 >= 4 * ox && X0 < 4 * ox + 4 * PD2_T)
+          *reinterpret_cast<unsigned *>(lvl0 + (size_t)Yr * sw + X0) = q;
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int tx = X0 + b - sx0;
+        if (tx >= 0 && tx < PD2_S) t0[ty][tx] = (uint8_t)(q >> (8 * b));
+      }
     }
-    t0[ty][tx] = v;
+  } else {
+    for (int i = threadIdx.x; i < PD2_S * PD2_S; i += 256) {
+      const int ty = i / PD2_S, tx = i - ty * PD2_S;
+      const int Yr = sy0 + ty, Xr = sx0 + tx;
+      const int Y = min(Yr, sh - 1), X = min(Xr, sw - 1);
+      uint8_t v = src[(size_t)Y * sw + X];
+      if (EQ) {
+        v = lut[v];
+        // level 0 rows [4 oy, 4 oy + 64) x columns [4 ox, 4 ox + 64) belong to this workgroup
+        if (Yr < sh && Xr < sw && Yr >= 4 * oy && Yr < 4 * oy + 4 * PD2_T && Xr >= 4 * ox && Xr < 4 * ox + 4 * PD2_T) lvl0[(size_t)Yr * sw + Xr] = v;
+      }
+      t0[ty][tx] = v;
+    }
   }
   __syncthreads();
   // level l -> l+1, horizontal then vertical; t1[y][x] = level l+1 pixel (my0 + y, mx0 + x)
@@ -241,8 +277,8 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
     h1[ty][x] = v;
   }
   __syncthreads();
-  {
-    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+  if (threadIdx.x < PD2_T * PD2_T) {
+    const int x = threadIdx.x % PD2_T, y = threadIdx.x / PD2_T;
     const int X = ox + x, Y = oy + y;
     if (X < dw && Y < dh) {
       const int c = 2 * Y;
@@ -251,7 +287,12 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
       dst[(size_t)Y * dw + X] = (uint8_t)((s + 128) >> 8);
     }
   }
-  if (EQ) {  // every workgroup has consumed the histogram (LUT built behind a barrier): the last one clears it for the next frame
+  if (!EQ && clear_hist && blockIdx.x == 0 && blockIdx.y == 0) {  // the histogram the previous launch equalised with: zero for the next frame
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) hist[256] = 0;
+  }
+  if (EQ && clear_hist) {  // no further pyramid launch to do it: every workgroup has consumed the histogram (LUT built behind a
+                           // barrier), the last one to arrive clears it (an agent-scope fence per workgroup)
     const int t = threadIdx.x;
     if (t == 0) {
       __threadfence();
@@ -1052,27 +1093,30 @@ int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p
   {
     ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[2], PD2_T), cdiv(p.h[2], PD2_T));
+    // the histogram is cleared for the next frame by the pyramid launch that follows, or here when there is none
     hipLaunchKernelGGL(pyrdown2_kernel<true>, grid, dim3(256), 0, ctx->stream, d_raw, p.w[0], p.h[0], p.base + p.off[1], p.w[1], p.h[1],
-                       p.base + p.off[2], p.w[2], p.h[2], d_hist, p.base + p.off[0]);
+                       p.base + p.off[2], p.w[2], p.h[2], d_hist, p.base + p.off[0], p.levels > 3 ? 0 : 1);
   }
   PLV_HIP_CHECK(hipGetLastError());
-  return launch_pyramid(ctx, p, 2);
+  return launch_pyramid(ctx, p, 2, d_hist);
 }
 
-int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level) {
+int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level, unsigned *clear_hist) {
   int l = first_level;
   for (; l + 2 < p.levels; l += 2) {  // two levels per launch
     ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[l + 2], PD2_T), cdiv(p.h[l + 2], PD2_T));
-    // (the grid of the upper level also covers the level under it: ceil(w2 / 16) * 32 >= w1 because w2 = (w1 + 1) / 2)
+    // (the grid of the upper level also covers the level under it: ceil(w2 / T) * 2 T >= w1 because w2 = (w1 + 1) / 2)
     hipLaunchKernelGGL(pyrdown2_kernel<false>, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l], p.base + p.off[l + 1],
-                       p.w[l + 1], p.h[l + 1], p.base + p.off[l + 2], p.w[l + 2], p.h[l + 2], (unsigned *)nullptr, (uint8_t *)nullptr);
+                       p.w[l + 1], p.h[l + 1], p.base + p.off[l + 2], p.w[l + 2], p.h[l + 2], clear_hist, (uint8_t *)nullptr, clear_hist ? 1 : 0);
+    clear_hist = nullptr;
   }
   for (; l + 1 < p.levels; ++l) {
     ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[l + 1], PD_T), cdiv(p.h[l + 1], PD_T));
     hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, ctx->stream, p.base + p.off[l], p.w[l], p.h[l],
-                       p.base + p.off[l + 1], p.w[l + 1], p.h[l + 1]);
+                       p.base + p.off[l + 1], p.w[l + 1], p.h[l + 1], clear_hist);
+    clear_hist = nullptr;
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
@@ -1080,7 +1124,7 @@ int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level) {
 
 int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *d_dst, int dw, int dh) {
   ProfScope ps(ctx->prof, "pyrdown_kernel", ctx->stream);
-  hipLaunchKernelGGL(pyrdown_kernel, dim3(cdiv(dw, PD_T), cdiv(dh, PD_T)), dim3(256), 0, ctx->stream, d_src, sw, sh, d_dst, dw, dh);
+  hipLaunchKernelGGL(pyrdown_kernel, dim3(cdiv(dw, PD_T), cdiv(dh, PD_T)), dim3(256), 0, ctx->stream, d_src, sw, sh, d_dst, dw, dh, (unsigned *)nullptr);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -852,4 +852,32 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   return rc;
 }
 
+// UpdaterCamera::feed_measurement followed by try_update (REF: UpdaterCamera.cpp:77-116, 139-195), one call per camera frame.
+int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io *io) {
+  if (!ctx || !st || !io || (io->slot < 0 && !io->img)) return PLV_E_BADARG;
+  if (io->slot >= 0)
+    TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
+  else
+    TRY(plv_tracker_feed(ctx, io->timestamp, io->img, io->stride, io->mask));
+  const bool lines = io->use_lines != 0;
+  if (lines) {
+    double vps[6];
+    TRY(plv_vanishing_points(st->R_ItoC, st->intrinsics, vps));
+    // with an update to follow, the line tracker's host logic runs on the worker thread next to the point update (joined inside
+    // plv_camera_try_update); otherwise in place
+    if (io->update && io->update->opt_lines)
+      TRY(plv_line_tracker_feed_async(ctx, io->timestamp, vps));
+    else
+      TRY(plv_line_tracker_feed(ctx, io->timestamp, vps));
+  }
+  if (!io->update) {
+    io->line_db_size = lines ? plv_line_db_size(ctx) : 0;
+    return PLV_OK;
+  }
+  const int rc = plv_camera_try_update(ctx, st, io->update);
+  if (lines && !io->update->opt_lines) (void)plv_line_tracker_feed_wait(ctx);
+  io->line_db_size = io->update->opt_lines ? io->update->line_db_size : (lines ? plv_line_db_size(ctx) : 0);
+  return rc;
+}
+
 }  // extern "C"

@@ -13,6 +13,7 @@ before try_update once the filter is initialised).  Scope of this driver: one ca
 simulation are outside SURVEY §8.
 """
 import ctypes
+import os
 import math
 import time as _time
 
@@ -399,6 +400,7 @@ class TimeChecker:
 class SystemManager:
     """viw::SystemManager for IMU + one camera (+ wheel)."""
 
+    one_call_frame = os.environ.get("PLV_ONE_CALL", "2") == "2"
     one_call_update = True      # try_update through plv_camera_try_update (False: plv_camera_update_points / _lines with the dx applied here)
 
     def __init__(self, op, device=0, max_obs=24, context_factory=None, iw_initializer_factory=None):
@@ -628,6 +630,29 @@ class SystemManager:
         if len(self.cam_t_hist) > 100:
             self.cam_t_hist.pop(0)
         self.cam_t_hist.append(float(t))
+        if (self.one_call_update and self.one_call_frame and e.cam.max_slam == 0 and not e.use_imu_res and not e.cam.downsample and not st.slam
+                and hasattr(self.ctx, "camera_frame")):
+            # feed_measurement + try_update in one library call (plv_camera_frame)
+            upd = None
+            args = self._try_update_args() if st.initialized else None
+            sv = st.view()
+            if args is not None:
+                pk, kw, max_msckf = args
+                upd = dict(plus=st._window_arrays()["plus"], n=st.n, max_msckf=max_msckf, max_obs=self.max_obs, lines=self.use_lines, **pk, **kw)
+            self.tc.ding("[Time-Cam] feed measurement + try_update")
+            out, lo, n_db = self.ctx.camera_frame(sv, t, slot=staged_slot, img=img, mask=mask, use_lines=self.use_lines, update=upd)
+            self.tc.dong("[Time-Cam] feed measurement + try_update")
+            self._lines_in_flight = False
+            self.stats["frames"] += 1
+            if self.use_lines:
+                self.stats["lines_tracked"] += n_db
+            if out is not None:
+                self._count_points(out)
+                if lo is not None:
+                    self._count_lines(lo)
+            if st.initialized:
+                self.tc.dong("CAM")
+            return
         self.tc.ding("[Time-Cam] feed measurement: points")      # labels of UpdaterCamera.cpp:79-190
         if staged_slot is not None and not e.cam.downsample:
             self.ctx.tracker_feed_staged(t, staged_slot, mask)
@@ -673,11 +698,12 @@ class SystemManager:
                 st.marginalize(st.slam.pop(fid).id, 3)
                 self.stats["slam_marginalized"] += 1
 
-    def _camera_try_update(self):
+    def _try_update_args(self):
+        """the options of try_update for the current window, or None when there is no interpolation polynomial yet"""
         st, e = self.state, self.op.est
         ts = st.clone_times()
         if len(ts) < e.intr_order + 1 or len(self.cam_t_hist) < 2:      # have_polynomial, CamHelper.cpp:615-616
-            return
+            return None
         c, fi = e.cam, e.cam.featinit
         full = st.clone_window() > e.window_size
         kw = dict(t_prev_frame=self.cam_t_hist[-2], state_time=st.time, window_full=full, chi2_mult=c.chi2_mult)
@@ -686,7 +712,15 @@ class SystemManager:
         cam_hz = (len(self.cam_t_hist) - 1) / (self.cam_t_hist[-1] - self.cam_t_hist[0])
         pk = dict(min_dist=fi.min_dist, max_dist=fi.max_dist, max_cond=fi.max_cond_number, max_baseline=fi.max_baseline, refine=fi.refine_features,
                   init_min_meas=min(int(e.window_size) * int(cam_hz) - 1, 10))      # CamHelper.cpp:686
-        max_msckf = min(c.max_msckf, self.ctx.cfg.max_features)
+        return pk, kw, min(c.max_msckf, self.ctx.cfg.max_features)
+
+    def _camera_try_update(self):
+        st, e = self.state, self.op.est
+        args = self._try_update_args()
+        if args is None:
+            return
+        pk, kw, max_msckf = args
+        c = e.cam
         if self.one_call_update and c.max_slam == 0 and "cpi" not in kw and hasattr(self.ctx, "camera_try_update"):
             # the whole of try_update in one library call: point update, dx applied, line update on the updated state, dx applied
             label = "[Time-Cam] get features + MSCKF update + LINE update" if self.use_lines else "[Time-Cam] get features + MSCKF update"
