@@ -460,7 +460,9 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
       iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
       iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
       const int bx = inx - jx0, by = iny - jy0;
-      long long sb1 = 0, sb2 = 0;
+      // |diff| <= 255 * 32 and |Ix|, |Iy| <= 16 * 255 (Scharr on 8-bit pixels): a lane's four products sum to < 2^27 and a 16-lane
+      // row to < 2^31, so the in-row reduction steps stay in 32 bits (wave_sum_i32_rows); the totals are exact 64-bit integers
+      int pb1 = 0, pb2 = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (own[q]) {
@@ -468,12 +470,11 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
           const int diff = DESCALE(jtile[y][x] * iw00 + jtile[y][x + 1] * iw01 + jtile[y + 1][x] * iw10 + jtile[y + 1][x + 1] * iw11,
                                    W_BITS - 5) -
                            Iv[q];
-          sb1 += (long long)(diff * Ix[q]);
-          sb2 += (long long)(diff * Iy[q]);
+          pb1 += diff * Ix[q];
+          pb2 += diff * Iy[q];
         }
       }
-      sb1 = wave_sum_i64(sb1);
-      sb2 = wave_sum_i64(sb2);
+      const long long sb1 = wave_sum_i32_rows(pb1), sb2 = wave_sum_i32_rows(pb2);
       const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;
       const float ddy = (A12 * b1 - A11 * b2) * D;

@@ -1098,14 +1098,17 @@ __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a[0] *
 
 // Element (row, col) of a block goes to base[col * cstr + row * rstr], as in jacobian_rows.
 __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs, int cstr,
-                          int rstr) {
+                          int rstr, const WinTab *tab = nullptr) {
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
   const double *Kc = P.K;
   const double Kl[9] = {Kc[1], 0, 0, 0, Kc[0], 0, -Kc[1] * Kc[2], -Kc[0] * Kc[3], Kc[0] * Kc[1]};
   const V3 nG = ldV(P.line_FinG + 6 * l), vG = ldV(P.line_FinG + 6 * l + 3);
   Interp jac;
-  interpolate(P, s0, tm, true, true, jac);
+  if (tab)  // (window tables: the same values, see build_window_tables)
+    interpolate_tab(P, tab[2 * s0 + 1], s0, tm, true, jac);
+  else
+    interpolate(P, s0, tm, true, true, jac);
   M3 Re;
   V3 pe;
   if (P.res_R) {
@@ -1113,7 +1116,10 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
     pe = ldV(P.res_p + 3 * o);
   } else {
     Interp est;
-    interpolate(P, s0, tm, false, false, est);
+    if (tab)
+      interpolate_tab(P, tab[2 * s0], s0, tm, false, est);
+    else
+      interpolate(P, s0, tm, false, false, est);
     Re = est.R;
     pe = est.p;
   }
@@ -1301,6 +1307,7 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
 // workgroups, and workgroup 0 publishes the column map.
 __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
+  __shared__ WinTab tab[JAC_MAX_WIN];
   __shared__ int s_rows;
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
@@ -1313,7 +1320,10 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   if (l == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
   const bool selected = !P.tri_ok || candidate_selected(P, l);
-  __syncthreads();  // (orders the zero fill before the row writes)
+  if (selected)
+    build_window_tables(P, tab);  // (block-uniform; ends with a barrier: also orders the zero fill before the row writes)
+  else
+    __syncthreads();
   if (!selected) {
     if (threadIdx.x == 0) {
       s_rows = 0;
@@ -1330,7 +1340,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
       const unsigned long long vmask = __ballot(s0 >= 0);
       const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
       base += __popcll(vmask);
-      if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, X, X + 6, X + 6 + k, 1, ncol);
+      if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, X, X + 6, X + 6 + k, 1, ncol, tab);
     }
     if (threadIdx.x == 0) {
       s_rows = min(2 * base, ld & ~1);
@@ -1460,8 +1470,12 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
 
 int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks) {
   ProfScope ps(ctx->prof, "line_jacobian_nullspace_kernel", ctx->stream);
+  if (2 * (P.n_clones - 3) > JAC_MAX_WIN) {
+    set_last_error("line jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
+    return PLV_E_CAPACITY;
+  }
   const size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
-  if (shm + 64 > 160 * 1024) {
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 64 > 160 * 1024) {
     set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }

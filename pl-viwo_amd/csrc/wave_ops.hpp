@@ -40,6 +40,19 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
   int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
   return ((long long)hi << 32) | (unsigned)lo;
 }
+// Exact 64-bit sum of 32-bit lane values whose sums over any 16-lane row fit in int32: the four in-row steps run on 32-bit
+// registers (one DPP move + one add each), only the two cross-row steps carry 64 bits.
+__device__ __forceinline__ long long wave_sum_i32_rows(int v) {
+  v += dpp_mov_i32<0x111>(v);
+  v += dpp_mov_i32<0x112>(v);
+  v += dpp_mov_i32<0x114>(v);
+  v += dpp_mov_i32<0x118>(v);
+  long long w = v;  // (lane 15 of every row holds the row's sum)
+  w += dpp_mov_i64<0x142>(w);
+  w += dpp_mov_i64<0x143>(w);
+  int lo = __builtin_amdgcn_readlane((int)(w & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(w >> 32), 63);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
   PLV_WAVE_REDUCE_BODY(dpp_mov_i32)
   return __builtin_amdgcn_readlane(v, 63);
