@@ -397,9 +397,10 @@ def main():
             "config": {
                 "workload": f"BASELINE {wl['cfg']}: {what}; {wl['hz']}-clone window ({wl['hz']} Hz camera and clones, 1 s), n = {n_state}; "
                             "rendered street-corridor drive with IMU + wheel odometry; the update consumes the tracker's own database",
-                "step": "plv_tracker_feed_staged -> plv_vanishing_points + plv_line_tracker_feed -> plv_camera_update_points -> dx applied -> "
-                        "plv_camera_update_lines; sequential, one stream, device synchronised at both ends of every step; IMU propagation, "
-                        "cloning, marginalisation, wheel updates and image staging run between the steps, untimed",
+                "step": "plv_camera_frame = plv_tracker_feed_staged -> plv_vanishing_points + plv_line_tracker_feed -> plv_camera_try_update "
+                        "(plv_camera_update_points -> dx applied -> plv_camera_update_lines -> dx applied); sequential, device synchronised at both "
+                        "ends of every step; IMU propagation, cloning, marginalisation, wheel updates and image staging run between the steps, "
+                        "untimed",
                 "replicas": world, "n_state": n_state,
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "host_split_ms_per_frame": split,

@@ -683,7 +683,12 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
       auto it = T->db.find(fid[q]);
       const bool is_new = it == T->db.end();
       LineTrack &tr = T->db[fid[q]];
-      if (is_new) tr.D = D;  // REF LineFeatureDatabase.cpp:62-63: only a new feature takes D
+      if (is_new) {
+        tr.D = D;  // REF LineFeatureDatabase.cpp:62-63: only a new feature takes D
+        tr.t.reserve(32);
+        tr.uv.reserve(128);
+        tr.uvn.reserve(128);
+      }
       tr.t.push_back(timestamp);
       tr.uv.insert(tr.uv.end(), fl.begin() + 4 * q, fl.begin() + 4 * q + 4);
       tr.uvn.insert(tr.uvn.end(), un.begin() + 4 * q, un.begin() + 4 * q + 4);

@@ -170,6 +170,11 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     good.push_back(y);
     good_ids.push_back(ids[i]);
     Track &tr = T->db[ids[i]];
+    if (tr.t.capacity() == 0) {  // a new track: room for a window's worth of observations (no regrowth frame after frame)
+      tr.t.reserve(32);
+      tr.uv.reserve(64);
+      tr.uvn.reserve(64);
+    }
     tr.t.push_back(timestamp);
     tr.uv.push_back(x);
     tr.uv.push_back(y);

@@ -26,6 +26,7 @@ def update_work(F, rows_f, fdim, k, n, qr_launches=1):
         "ekf_commit_kernel": 3.0 * n * n * 8,
         "ekf_mt_kernel": 2.0 * n * k * r,
         "ekf_s_kernel": 2.0 * r * r * k,
+        "ekf_ms_kernel": 2.0 * n * k * r + 2.0 * r * k * k + 1.0 * r * r * k,     # Mt tiles + every strip's own H Ps + the upper S tiles
     }
 
 
@@ -58,6 +59,7 @@ def frame_work(W, H, levels, n_pts, lk_iters, win, F, M, k, n, L=0, Ml=0, kl=0, 
     work["jacobian_nullspace_kernel"] = ("mfma", F * M * 3000.0 + up["nullspace_kernel"])
     if L > 0:
         ul = update_work(L, 2 * Ml, 6, kl, n)
+        work["line_jacobian_nullspace_kernel"] = ("mfma", L * Ml * 6000.0 + ul["nullspace_kernel"])
         for name, v in up.items():   # kernels both updates launch: the mean of the two launches
             up[name] = ul[name] if name == "nullspace_kernel" else 0.5 * (v + ul[name])
     for name, v in up.items():
