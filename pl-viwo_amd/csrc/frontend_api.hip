@@ -45,6 +45,7 @@ struct FrontState {
   DetJob det_pending;
   hipStream_t det_stream = nullptr;
   hipEvent_t det_done = nullptr;
+  hipEvent_t match_done = nullptr;  // behind the result copy of plv_perform_matching_launch: the wait does not cover what is enqueued after it
 };
 
 #define TRY(expr)                  \
@@ -156,6 +157,7 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   if (!s) return;
   if (s->det_pending.active) (void)hipEventSynchronize(s->det_done);
   if (s->det_done) (void)hipEventDestroy(s->det_done);
+  if (s->match_done) (void)hipEventDestroy(s->match_done);
   if (s->det_stream) (void)hipStreamDestroy(s->det_stream);
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
@@ -396,6 +398,8 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
                     d_mk, s->info.as<int>(), s->models.as<double>()));
   PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
+  if (!s->match_done) PLV_HIP_CHECK(hipEventCreateWithFlags(&s->match_done, hipEventDisableTiming));
+  PLV_HIP_CHECK(hipEventRecord(s->match_done, ctx->stream));
   s->pending_n = n;
   s->pending_ran = true;
   return PLV_OK;
@@ -418,7 +422,10 @@ int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, floa
     return PLV_OK;
   }
   (void)hipSetDevice(ctx->device);
-  TRY(sync(ctx));
+  if (ctx->prof.on)
+    TRY(sync(ctx));  // (the per-kernel timer reads every event recorded so far)
+  else
+    PLV_HIP_CHECK(plv::event_sync(s->match_done));  // not the whole stream: the caller may have enqueued more behind the flow
   const size_t nn = (size_t)n;
   const size_t o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36;
   const char *hp = ctx->h_pin.as<char>();

@@ -88,6 +88,20 @@ struct LineTracker {
   } feed;
   int feed_state = 0;  // 0 idle, 1 posted, 2 done
   std::chrono::steady_clock::time_point job_posted, feed_posted;
+  // Second half of the host stage on a thread of its own: segments are grown along chain c while the walk is still producing chain
+  // c + 1 (the walk publishes its chain count after every chain; both halves are sequential in themselves, the two overlap)
+  struct Fit {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;  // 0 idle, 1 posted, 2 done; -1 quit
+    const Job *job = nullptr;
+    alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
+    alignas(64) std::atomic<bool> walk_done{false};
+    alignas(64) std::atomic<int> next{0};  // next chain to fit: this thread and, once its walk is over, the walking thread claim chains here
+    alignas(64) std::vector<float4> segs;  // chain c's segments at its slot (FldChain::slot)
+    std::vector<int> seg_n;    // per chain
+  } fit;
 };
 
 std::mutex g_mtx;
@@ -110,7 +124,7 @@ float point_line_distance(const float *line, float x0, float y0) {
 // algorithm as fld_walk_kernel; see detect() for why the default runs it here.  The map is copied into a
 // buffer with a one-pixel non-edge border so that the eight neighbour tests need no bounds checks.
 void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
-                 std::vector<uint8_t> &pad) {
+                 std::vector<uint8_t> &pad, std::atomic<int> *published = nullptr) {
   static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
   const int pw = w + 2;
   pad.assign((size_t)pw * (h + 2), 1);
@@ -163,6 +177,7 @@ void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *p
       if (len >= length_threshold + 1 && n_chain < chain_cap) {
         chains[n_chain++] = FldChain{start, len, n_slot};
         n_slot += len / length_threshold + 1;
+        if (published) published->store(n_chain, std::memory_order_release);  // chain n_chain - 1 and its points are final
       } else {
         n_pts = start;
       }
@@ -175,21 +190,78 @@ void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *p
 
 // The host stage on the maps a job points to: chains in raster order of their seeds = the detector's output order; the tail of
 // perform_detection_monocular (x2, FilterShortLines) on every segment.
+// claims the next unfitted chain below `avail`, or -1
+int claim_chain(LineTracker::Fit &F, int avail) {
+  int c = F.next.load(std::memory_order_relaxed);
+  while (c < avail && !F.next.compare_exchange_weak(c, c + 1, std::memory_order_relaxed)) {
+  }
+  return c < avail ? c : -1;
+}
+void fit_one(LineTracker::Fit &F, const LineTracker::Job &J, int c) {
+  F.seg_n[c] = fit_chain(J.hhalf, J.w, J.h, J.length_threshold, J.distance_threshold, J.hpts + J.hc[c].start, J.hc[c].len,
+                         F.segs.data() + J.hc[c].slot);
+}
+
+void fit_worker(LineTracker *T) {
+  LineTracker::Fit &F = T->fit;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(F.m);
+      F.cv.wait(lk, [&] { return F.state == 1 || F.state == -1; });
+      if (F.state == -1) return;
+    }
+    const LineTracker::Job &J = *F.job;
+    for (;;) {
+      const int avail = F.published.load(std::memory_order_acquire);
+      const int c = claim_chain(F, avail);
+      if (c >= 0) {
+        fit_one(F, J, c);
+        continue;
+      }
+      if (F.walk_done.load(std::memory_order_acquire) && F.next.load(std::memory_order_relaxed) >= F.published.load(std::memory_order_acquire)) break;
+      for (int i = 0; i < 64; ++i) __builtin_ia32_pause();  // (poll every few hundred ns: the walk owns the counter's cache line meanwhile)
+    }
+    {
+      std::lock_guard<std::mutex> lk(F.m);
+      F.state = 2;
+    }
+    F.cv.notify_all();
+  }
+}
+
 int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
   auto T1 = std::chrono::steady_clock::now();
   int hcounts[4] = {0, 0, 0, 0};
-  walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad);
+  LineTracker::Fit &F = T->fit;
+  F.segs.resize((size_t)J.w * J.h / (size_t)std::max(1, J.length_threshold) + kChainCap);
+  F.seg_n.resize(kChainCap);
+  F.published.store(0, std::memory_order_relaxed);
+  F.next.store(0, std::memory_order_relaxed);
+  F.walk_done.store(false, std::memory_order_relaxed);
+  if (!F.th.joinable()) F.th = std::thread(fit_worker, T);
+  {
+    std::lock_guard<std::mutex> lk(F.m);
+    F.job = &J;
+    F.state = 1;
+  }
+  F.cv.notify_all();
+  walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
+  F.walk_done.store(true, std::memory_order_release);
   auto T2 = std::chrono::steady_clock::now();
+  for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
+  {
+    std::unique_lock<std::mutex> lk(F.m);
+    F.cv.wait(lk, [&] { return F.state == 2; });
+    F.state = 0;
+  }
   J.lines.clear();
   if (hcounts[0] >= kChainCap) {
     set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
     return PLV_E_CAPACITY;
   }
-  std::vector<float4> seg;
   for (int c = 0; c < hcounts[0]; ++c) {
-    seg.resize((size_t)J.hc[c].len / J.length_threshold + 1);
-    const int ns = fit_chain(J.hhalf, J.w, J.h, J.length_threshold, J.distance_threshold, J.hpts + J.hc[c].start, J.hc[c].len, seg.data());
-    for (int q = 0; q < ns; ++q) {
+    const float4 *seg = F.segs.data() + J.hc[c].slot;
+    for (int q = 0; q < F.seg_n[c]; ++q) {
       const float4 &sg = seg[q];
       const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
       const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
@@ -202,7 +274,7 @@ int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     size_t edges = 0;
     for (size_t i = 0; i < (size_t)J.w * J.h; ++i) edges += J.hmap[i] == 2;
-    fprintf(stderr, "walk %.1f us, fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T1, T2), us(T2, T3), hcounts[0],
+    fprintf(stderr, "walk %.1f us, rest of the fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T1, T2), us(T2, T3), hcounts[0],
             hcounts[2], edges);
   }
   return PLV_OK;
@@ -504,9 +576,18 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
       T->jcv.notify_all();
       T->worker.join();
     }
+    if (T->fit.th.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(T->fit.m);
+        T->fit.state = -1;
+      }
+      T->fit.cv.notify_all();
+      T->fit.th.join();
+    }
     DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out};
     for (DevBuf *b : bufs) b->release();
     T->pin.release();
+    if (T->edges_ready) (void)hipEventDestroy(T->edges_ready);
     delete T;
     g_lt.erase(it);
   }

@@ -116,7 +116,13 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   // With the line prefetch on (plv_line_prefetch_mode), resize + Canny of the new image and the copies of the two maps go first on
   // the stream and the library's line worker thread walks the edge chains and grows the segments while this thread runs the point
   // front-end; plv_line_tracker_feed of the same frame joins it.
-  if (plv_line_prefetch_enabled(ctx)) (void)plv_line_detect_launch(ctx, PLV_PYR_CUR);
+  // (enqueued further down, behind the flow + RANSAC of this frame: the point front-end starts the moment the pyramid is built, and
+  // the line worker, whose host stage has slack against the point update, gets its edge maps ~0.1 ms later)
+  bool prefetch_lines = plv_line_prefetch_enabled(ctx) != 0;
+  auto launch_prefetch = [&]() {
+    if (prefetch_lines) (void)plv_line_detect_launch(ctx, PLV_PYR_CUR);
+    prefetch_lines = false;
+  };
   T->ahead_deferred = false;  // (no update came in between: the detection below runs in place)
   const int cap = std::max(ctx->cfg.num_features * 4, 1024) + (int)T->ids_last.size();
   std::vector<float> pts(2 * (size_t)cap);
@@ -129,6 +135,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
       T->mask_last.clear();
   };
   if (T->ids_last.empty()) {  // :110-122 first frame / lost everything: detect on the current image
+    launch_prefetch();
     TRY(plv_perform_detection(ctx, PLV_PYR_CUR, mask, pts.data(), ids.data(), 0, cap, &T->currid, &n));
     T->pts_last.assign(pts.begin(), pts.begin() + 2 * (size_t)n);
     T->ids_last.assign(ids.begin(), ids.begin() + n);
@@ -148,6 +155,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   std::vector<float> pts_new(pts.begin(), pts.begin() + 2 * (size_t)n), n1(2 * (size_t)std::max(n, 1));
   std::vector<uint8_t> mask_ll((size_t)std::max(n, 1), 0);
   if (n == 0) {  // :143-152
+    launch_prefetch();
     T->pts_last.clear();
     T->ids_last.clear();
     keep_mask();
@@ -155,7 +163,10 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   }
   {
     plv::HostPhase ph("tracker_feed: perform_matching");
-    TRY(plv_perform_matching(ctx, n, pts.data(), pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
+    const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
+    launch_prefetch();  // (inside the wait for the flow)
+    TRY(rc_l);
+    TRY(plv_perform_matching_wait(ctx, pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
   }
   plv::HostPhase ph_db("tracker_feed: database update");
   // :158-173 keep in-bounds, unmasked, matched points; :176-179 database update
