@@ -15,6 +15,8 @@
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -59,6 +61,8 @@ struct LineTracker {
   std::vector<uint8_t> pad;  // host walk: bordered copy of the edge map
   hipEvent_t edges_ready = nullptr;  // plv_line_detect_launch: the maps of image `pending_which` are on their way to the host
   int pending_which = -1, pending_fed = -1;
+  bool defer_finish = false;        // plv_camera_try_update: the line update leaves its database hand-back (cleanup_lines) behind ...
+  std::function<void()> deferred;   // ... to run before anything else reads the tracker: in the next frame's wait for the flow (ltr())
   std::vector<float> cached;  // plv_line_detect_finish: the segments of image `cached_which` of frame `cached_fed`
   int cached_which = -1, cached_fed = -1;
   std::mutex mtx;
@@ -106,7 +110,7 @@ struct LineTracker {
 
 std::mutex g_mtx;
 std::unordered_map<plv_ctx *, LineTracker *> g_lt;
-LineTracker *ltr(plv_ctx *ctx);  // (defined after LineTracker's worker protocol)
+LineTracker *ltr(plv_ctx *ctx, bool run_deferred = true);  // (defined after LineTracker's worker protocol)
 
 const int kChainCap = 4096;
 
@@ -342,7 +346,7 @@ bool join_job(LineTracker *T) {
 
 // Every entry point reaches the tracker through here: an asynchronous feed still running on the worker is joined first (its status
 // is kept for plv_line_tracker_feed_wait).
-LineTracker *ltr(plv_ctx *ctx) {
+LineTracker *ltr(plv_ctx *ctx, bool run_deferred) {
   LineTracker *T;
   {
     std::lock_guard<std::mutex> lk(g_mtx);
@@ -361,6 +365,12 @@ LineTracker *ltr(plv_ctx *ctx) {
     T->feed_state = 0;
     if (plv::host_phases().on)
       plv::host_phases().add("line feed join: time since the post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
+  }
+  lk.unlock();
+  if (run_deferred && T->deferred) {  // (only the thread that owns the ctx gets here: the worker reaches the tracker directly)
+    std::function<void()> f;
+    f.swap(T->deferred);
+    f();
   }
   return T;
 }
@@ -567,6 +577,7 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
   auto it = g_lt.find(ctx);
   if (it != g_lt.end()) {
     LineTracker *T = it->second;
+    T->deferred = nullptr;
     if (T->worker.joinable()) {
       {
         std::unique_lock<std::mutex> lk(T->jm);
@@ -682,7 +693,7 @@ int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps) {
 int plv_line_detect_launch(plv_ctx *ctx, int which) {
   if (!ctx || (which != PLV_PYR_CUR && which != PLV_PYR_LAST)) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
-  LineTracker *T = ltr(ctx);
+  LineTracker *T = ltr(ctx, false);  // (touches the detector's buffers only: a hand-back left behind may still wait)
   std::lock_guard<std::mutex> lk(T->mtx);
   if (T->walk_on_device) return PLV_OK;  // nothing to overlap: the device variant has no host stage
   std::vector<float> none;
@@ -926,6 +937,10 @@ static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as
   return false;
 }
 
+// (internal) plv_camera_try_update turns the deferral on around its line update; plv_tracker_feed* runs what was left behind
+void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish = on != 0; }
+void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
+
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
@@ -999,38 +1014,51 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   }
   std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
   auto finish = [&](int rc) {
-    std::lock_guard<std::mutex> lk(T->mtx);
-    for (auto &kv : unused) {  // REF :71 / cleanup_lines :545-546 append_new_measurements
-      const bool is_new = T->db.find(kv.first) == T->db.end();
-      LineTrack &d = T->db[kv.first];
-      if (is_new) {
-        d = std::move(kv.second);
-        continue;
-      }
-      d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
-      d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
-      d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
-    }
     res->n_returned = (int)unused.size();
-    if (opt->window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188: on every try_update
-      for (auto it = T->db.begin(); it != T->db.end();) {
-        LineTrack &tr = it->second;
-        size_t keep = 0;
-        for (size_t i = 0; i < tr.t.size(); ++i)
-          if (!(tr.t[i] < t_oldest)) {
-            if (keep != i) {
-              tr.t[keep] = tr.t[i];
-              std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
-              std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
-            }
-            ++keep;
-          }
-        tr.t.resize(keep);
-        tr.uv.resize(4 * keep);
-        tr.uvn.resize(4 * keep);
-        it = keep == 0 ? T->db.erase(it) : std::next(it);
+    const bool window_full = opt->window_full != 0;
+    auto hand_back = [T, window_full, t_oldest](std::unordered_map<uint64_t, LineTrack> &un) {
+      std::lock_guard<std::mutex> lk(T->mtx);
+      for (auto &kv : un) {  // REF :71 / cleanup_lines :545-546 append_new_measurements
+        const bool is_new = T->db.find(kv.first) == T->db.end();
+        LineTrack &d = T->db[kv.first];
+        if (is_new) {
+          d = std::move(kv.second);
+          continue;
+        }
+        d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
+        d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
+        d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
       }
-      plv_point_used_cleanup(ctx, t_oldest);
+      if (window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188: on every try_update
+        for (auto it = T->db.begin(); it != T->db.end();) {
+          LineTrack &tr = it->second;
+          size_t keep = 0;
+          for (size_t i = 0; i < tr.t.size(); ++i)
+            if (!(tr.t[i] < t_oldest)) {
+              if (keep != i) {
+                tr.t[keep] = tr.t[i];
+                std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+                std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+              }
+              ++keep;
+            }
+          tr.t.resize(keep);
+          tr.uv.resize(4 * keep);
+          tr.uvn.resize(4 * keep);
+          it = keep == 0 ? T->db.erase(it) : std::next(it);
+        }
+      }
+    };
+    // (point_used->cleanup_measurements is not deferred: it takes the point tracker's lock, which a feed in progress holds)
+    if (window_full) plv_point_used_cleanup(ctx, t_oldest);
+    if (T->defer_finish) {
+      // plv_camera_try_update: nothing reads the line database before the next frame's feed; the hand-back (and the release of the
+      // pooled tracks) runs in that frame's wait for the flow, or at the next call that reaches the tracker
+      auto held = std::make_shared<std::unordered_map<uint64_t, LineTrack>>(std::move(unused));
+      auto used_up = std::make_shared<std::vector<Cand>>(std::move(pool));
+      T->deferred = [hand_back, held, used_up]() { hand_back(*held); };
+    } else {
+      hand_back(unused);
     }
     return rc;
   };

@@ -109,6 +109,8 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
+extern "C" void plv_line_defer_finish(plv_ctx *ctx, int on);
+extern "C" void plv_line_run_deferred(plv_ctx *ctx);
 extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in);  // frontend_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
@@ -165,6 +167,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     plv::HostPhase ph("tracker_feed: perform_matching");
     const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
     launch_prefetch();  // (inside the wait for the flow)
+    if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
     TRY(rc_l);
     TRY(plv_perform_matching_wait(ctx, pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
   }
@@ -858,9 +861,12 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);
     io->line_db_size = plv_line_db_size(ctx);
-    if (rc == PLV_OK)
+    if (rc == PLV_OK) {
+      plv_line_defer_finish(ctx, 1);
       rc = plv_camera_update_lines(ctx, st, io->opt_lines, io->dx_lines, io->res_lines, io->line_ids, io->line_accepted, io->line_FinG,
                                    io->line_cap);
+      plv_line_defer_finish(ctx, 0);
+    }
     plv_tracker_run_deferred(ctx);
     if (rc == PLV_OK) rc = apply(*io->res_lines, io->dx_lines);
   }
