@@ -109,6 +109,101 @@ public:
     return ok;
   }
 
+  // ---- feed_measurement + try_update as ONE library call (plv_camera_frame; no in-state landmarks).  The mean of the state lives
+  // in flat arrays that also back the plv_state_view: plv_state_boxplus moves them in place (the arithmetic of Type::update), the view
+  // the line half reads is current without being rebuilt, and write_back() puts the values into the reference's Type objects.
+  struct Mean {
+    View w;                         // clone R / p arrays = `out` / `val` of the clone variables
+    std::vector<double> q;          // clone quaternions [n][4] (JPL), then the IMU's and the extrinsics'
+    std::vector<double> vec;        // IMU p v bg ba (12), extrinsic p (3), intrinsics (8), dt (1)
+    std::vector<plv_state_var> vars;
+  };
+  void build_mean(Mean &m) const {
+    build_view(m.w);
+    const int n = m.w.v.n_clones, cam_id = 0;
+    m.q.assign(4 * (size_t)(n + 2), 0.0);
+    m.vec.assign(24, 0.0);
+    m.vars.clear();
+    int i = 0;
+    for (const auto &c : state->clones) {
+      Eigen::Map<Eigen::Vector4d>(&m.q[4 * i]) = c.second->quat();
+      m.vars.push_back({PLV_VAR_QUAT, c.second->id(), 4, &m.q[4 * i], &m.w.R[9 * i], nullptr});
+      m.vars.push_back({PLV_VAR_VEC, c.second->id() + 3, 3, &m.w.p[3 * i], nullptr, nullptr});
+      ++i;
+    }
+    auto imu = state->imu;
+    Eigen::Map<Eigen::Vector4d>(&m.q[4 * n]) = imu->quat();
+    Eigen::Map<Eigen::Matrix<double, 12, 1>>(&m.vec[0]) = imu->value().block(4, 0, 12, 1);
+    m.vars.push_back({PLV_VAR_QUAT, imu->id(), 4, &m.q[4 * n], nullptr, nullptr});
+    m.vars.push_back({PLV_VAR_VEC, imu->id() + 3, 12, &m.vec[0], nullptr, nullptr});
+    plv_state_view &v = m.w.v;
+    if (v.extrinsic_state_id >= 0) {
+      Eigen::Map<Eigen::Vector4d>(&m.q[4 * (n + 1)]) = state->cam_extrinsic.at(cam_id)->quat();
+      Eigen::Map<Eigen::Vector3d>(&m.vec[12]) = state->cam_extrinsic.at(cam_id)->pos();
+      m.vars.push_back({PLV_VAR_QUAT, v.extrinsic_state_id, 4, &m.q[4 * (n + 1)], nullptr, v.R_ItoC});
+      m.vars.push_back({PLV_VAR_VEC, v.extrinsic_state_id + 3, 3, &m.vec[12], nullptr, v.p_IinC});
+    }
+    if (v.intrinsic_state_id >= 0) {
+      Eigen::Map<Eigen::Matrix<double, 8, 1>>(&m.vec[15]) = state->cam_intrinsic.at(cam_id)->value();
+      m.vars.push_back({PLV_VAR_VEC, v.intrinsic_state_id, 8, &m.vec[15], nullptr, v.intrinsics});
+    }
+    if (v.dt_state_id >= 0) {
+      m.vec[23] = v.cam_dt;
+      m.vars.push_back({PLV_VAR_VEC, v.dt_state_id, 1, &m.vec[23], nullptr, &v.cam_dt});
+    }
+    // (wheel calibration variables, when estimated, are listed the same way)
+  }
+  void write_back(const Mean &m) {  // Type::set_value for every variable the updates moved (StateHelper.cpp:156-160)
+    const int n = m.w.v.n_clones, cam_id = 0;
+    int i = 0;
+    for (auto &c : state->clones) {
+      Eigen::Matrix<double, 7, 1> x;
+      x << Eigen::Map<const Eigen::Vector4d>(&m.q[4 * i]), Eigen::Map<const Eigen::Vector3d>(&m.w.p[3 * i]);
+      c.second->set_value(x);
+      ++i;
+    }
+    Eigen::Matrix<double, 16, 1> xi;
+    xi << Eigen::Map<const Eigen::Vector4d>(&m.q[4 * n]), Eigen::Map<const Eigen::Matrix<double, 12, 1>>(&m.vec[0]);
+    state->imu->set_value(xi);
+    const plv_state_view &v = m.w.v;
+    if (v.extrinsic_state_id >= 0) {
+      Eigen::Matrix<double, 7, 1> x;
+      x << Eigen::Map<const Eigen::Vector4d>(&m.q[4 * (n + 1)]), Eigen::Map<const Eigen::Vector3d>(&m.vec[12]);
+      state->cam_extrinsic.at(cam_id)->set_value(x);
+    }
+    if (v.intrinsic_state_id >= 0) state->cam_intrinsic.at(cam_id)->set_value(Eigen::Map<const Eigen::Matrix<double, 8, 1>>(&m.vec[15]));
+    if (v.dt_state_id >= 0) state->cam_dt.at(cam_id)->set_value(Eigen::Matrix<double, 1, 1>(m.vec[23]));
+  }
+  // returns false when EKFUpdate rejected one of the two updates (the state is then as the other one left it)
+  bool frame(const ov_core::CameraData &camdata) {
+    t_hist.push_back(camdata.timestamp);
+    if (t_hist.size() > 100) t_hist.pop_front();
+    const auto &oc = state->op->cam;
+    plv_update_options o{};
+    o.max_msckf = oc->max_msckf, o.max_obs = max_obs, o.chi2_mult = oc->chi2_mult;
+    o.tri.min_dist = oc->featinit_options.min_dist, o.tri.max_dist = oc->featinit_options.max_dist;
+    o.tri.max_cond_number = oc->featinit_options.max_cond_number, o.tri.max_baseline = oc->featinit_options.max_baseline;
+    o.tri.refine_features = oc->featinit_options.refine_features ? 1 : 0;
+    o.state_time = state->time;
+    o.window_full = state->clone_window() > state->op->window_size ? 1 : 0;
+    o.init_min_meas = 10;
+    const bool update = state->have_polynomial() && t_hist.size() >= 2;
+    if (update) o.t_prev_frame = t_hist.at(t_hist.size() - 2);
+    const int n = (int)state->cov.rows();
+    Eigen::VectorXd dx_p = Eigen::VectorXd::Zero(n), dx_l = Eigen::VectorXd::Zero(n);
+    plv_update_result rp{}, rl{};
+    Mean m;
+    build_mean(m);
+    plv_try_update up{&o, trackLSDS ? &o : nullptr, (int)m.vars.size(), m.vars.data(), dx_p.data(), dx_l.data(), &rp, &rl,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0x7fffffff, 0};
+    const cv::Mat &img = camdata.images.at(0), &mask = camdata.masks.at(0);
+    plv_camera_frame_io io{camdata.timestamp, -1, img.data, (int)img.step, mask.empty() ? nullptr : mask.data, trackLSDS ? 1 : 0,
+                           update ? &up : nullptr, 0};
+    if (plv_camera_frame(ctx, &m.w.v, &io) != PLV_OK) return false;
+    if (update) write_back(m);
+    return rp.status == PLV_OK && rl.status == PLV_OK;
+  }
+
 private:
   std::shared_ptr<State> state;
   plv_ctx *ctx;
