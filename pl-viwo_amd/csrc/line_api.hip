@@ -95,10 +95,12 @@ struct LineTracker {
   // Second half of the host stage on a thread of its own: segments are grown along chain c while the walk is still producing chain
   // c + 1 (the walk publishes its chain count after every chain; both halves are sequential in themselves, the two overlap)
   struct Fit {
-    std::thread th;
+    static const int kThreads = 2;  // (the fit is ~1.15x the walk: two fitters keep pace with it, the walking thread joins in at its end)
+    std::thread th[kThreads];
     std::mutex m;
     std::condition_variable cv;
-    int state = 0;  // 0 idle, 1 posted, 2 done; -1 quit
+    int gen = 0, done_gen[kThreads] = {0, 0};  // a job = a new generation; thread i reports the last one it finished
+    bool quit = false;
     const Job *job = nullptr;
     alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
     alignas(64) std::atomic<bool> walk_done{false};
@@ -113,6 +115,23 @@ std::unordered_map<plv_ctx *, LineTracker *> g_lt;
 LineTracker *ltr(plv_ctx *ctx, bool run_deferred = true);  // (defined after LineTracker's worker protocol)
 
 const int kChainCap = 4096;
+
+// Condition wait that polls first: the library's threads hand each other work several times per frame and a thread that blocked
+// pays tens of microseconds (sometimes a millisecond) to be woken.  Polls for up to spin_us (the lock is released between probes),
+// then blocks as usual — at camera rates the threads sleep between frames, back to back frames keep them awake.
+template <class Pred>
+void wait_polling(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, Pred pred, int spin_us = 2000) {
+  if (pred()) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    lk.unlock();
+    for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+    lk.lock();
+    if (pred()) return;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+  }
+  cv.wait(lk, pred);
+}
 
 float point_line_distance(const float *line, float x0, float y0) {
   const float x1 = line[0], y1 = line[1], x2 = line[2], y2 = line[3];
@@ -206,13 +225,15 @@ void fit_one(LineTracker::Fit &F, const LineTracker::Job &J, int c) {
                          F.segs.data() + J.hc[c].slot);
 }
 
-void fit_worker(LineTracker *T) {
+void fit_worker(LineTracker *T, int me) {
   LineTracker::Fit &F = T->fit;
+  int seen = 0;
   for (;;) {
     {
       std::unique_lock<std::mutex> lk(F.m);
-      F.cv.wait(lk, [&] { return F.state == 1 || F.state == -1; });
-      if (F.state == -1) return;
+      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
+      if (F.quit) return;
+      seen = F.gen;
     }
     const LineTracker::Job &J = *F.job;
     for (;;) {
@@ -227,7 +248,7 @@ void fit_worker(LineTracker *T) {
     }
     {
       std::lock_guard<std::mutex> lk(F.m);
-      F.state = 2;
+      F.done_gen[me] = seen;
     }
     F.cv.notify_all();
   }
@@ -242,11 +263,13 @@ int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
   F.published.store(0, std::memory_order_relaxed);
   F.next.store(0, std::memory_order_relaxed);
   F.walk_done.store(false, std::memory_order_relaxed);
-  if (!F.th.joinable()) F.th = std::thread(fit_worker, T);
+  for (int i = 0; i < LineTracker::Fit::kThreads; ++i)
+    if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i);
+  int gen;
   {
     std::lock_guard<std::mutex> lk(F.m);
     F.job = &J;
-    F.state = 1;
+    gen = ++F.gen;
   }
   F.cv.notify_all();
   walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
@@ -255,8 +278,11 @@ int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
   for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
   {
     std::unique_lock<std::mutex> lk(F.m);
-    F.cv.wait(lk, [&] { return F.state == 2; });
-    F.state = 0;
+    wait_polling(lk, F.cv, [&] {
+      for (int i = 0; i < LineTracker::Fit::kThreads; ++i)
+        if (F.done_gen[i] != gen) return false;
+      return true;
+    });
   }
   J.lines.clear();
   if (hcounts[0] >= kChainCap) {
@@ -291,7 +317,7 @@ void line_worker(LineTracker *T) {
     bool do_detect = false, do_feed = false;
     {
       std::unique_lock<std::mutex> lk(T->jm);
-      T->jcv.wait(lk, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1; });
+      wait_polling(lk, T->jcv, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1; });
       if (T->job_state == -1) return;
       do_detect = T->job_state == 1;
       do_feed = !do_detect && T->feed_state == 1;
@@ -336,7 +362,7 @@ bool join_job(LineTracker *T) {
   std::unique_lock<std::mutex> lk(T->jm);
   if (T->job_state == 0) return false;
   auto J0 = std::chrono::steady_clock::now();
-  T->jcv.wait(lk, [&] { return T->job_state == 2; });
+  wait_polling(lk, T->jcv, [&] { return T->job_state == 2; });
   T->job_state = 0;
   if (getenv("PLV_LINE_TIMING"))
     fprintf(stderr, "line join: waited %.1f us (posted %.1f us ago)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - J0).count(),
@@ -361,7 +387,7 @@ LineTracker *ltr(plv_ctx *ctx, bool run_deferred) {
   std::unique_lock<std::mutex> lk(T->jm);
   if (T->feed_state != 0) {
     plv::HostPhase ph("line feed join: wait");
-    T->jcv.wait(lk, [&] { return T->feed_state == 2; });
+    wait_polling(lk, T->jcv, [&] { return T->feed_state == 2; });
     T->feed_state = 0;
     if (plv::host_phases().on)
       plv::host_phases().add("line feed join: time since the post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
@@ -587,13 +613,14 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
       T->jcv.notify_all();
       T->worker.join();
     }
-    if (T->fit.th.joinable()) {
+    if (T->fit.th[0].joinable()) {
       {
         std::lock_guard<std::mutex> lk(T->fit.m);
-        T->fit.state = -1;
+        T->fit.quit = true;
       }
       T->fit.cv.notify_all();
-      T->fit.th.join();
+      for (auto &th : T->fit.th)
+        if (th.joinable()) th.join();
     }
     DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out};
     for (DevBuf *b : bufs) b->release();
