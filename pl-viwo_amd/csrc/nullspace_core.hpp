@@ -123,8 +123,21 @@ __device__ __forceinline__ void nullspace_householder(double *X, double *piv, in
     __syncthreads();
     for (int i = threadIdx.x; i < rows; i += blockDim.x) piv[i] = X[i * ncol + n];
     __syncthreads();
+    // (the row loops below are unrolled by eight with the LDS reads of a batch issued ahead of its dependent fma chain; the order of
+    // the additions is unchanged.  Measured inside jacobian_nullspace_kernel at 32 rows: three reflections 9.4 -> 8.6 us — the
+    // dependent fp64 chains (norm, sqrt, divide, dot product), not the LDS latency, are what a reflection costs)
     double nrm2 = 0.0;  // every thread forms the reflector from the shared copy of column n: the same bits everywhere
-    for (int i = n; i < rows; ++i) nrm2 = fma(piv[i], piv[i], nrm2);
+    {
+      int i = n;
+      for (; i + 8 <= rows; i += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = piv[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nrm2 = fma(a[u], a[u], nrm2);
+      }
+      for (; i < rows; ++i) nrm2 = fma(piv[i], piv[i], nrm2);
+    }
     if (nrm2 == 0.0) continue;  // (uniform) nothing to eliminate
     const double x0 = piv[n];
     const double nrm = sqrt(nrm2);
@@ -138,10 +151,30 @@ __device__ __forceinline__ void nullspace_householder(double *X, double *piv, in
         continue;
       }
       double w = v0 * X[n * ncol + j];
-      for (int i = n + 1; i < rows; ++i) w = fma(piv[i], X[i * ncol + j], w);
+      {
+        int i = n + 1;
+        for (; i + 8 <= rows; i += 8) {
+          double a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = piv[i + u], b[u] = X[(i + u) * ncol + j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w = fma(a[u], b[u], w);
+        }
+        for (; i < rows; ++i) w = fma(piv[i], X[i * ncol + j], w);
+      }
       w *= tau;
       X[n * ncol + j] = fma(-v0, w, X[n * ncol + j]);
-      for (int i = n + 1; i < rows; ++i) X[i * ncol + j] = fma(-piv[i], w, X[i * ncol + j]);
+      {
+        int i = n + 1;
+        for (; i + 8 <= rows; i += 8) {
+          double a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = piv[i + u], b[u] = X[(i + u) * ncol + j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) X[(i + u) * ncol + j] = fma(-a[u], w, b[u]);
+        }
+        for (; i < rows; ++i) X[i * ncol + j] = fma(-piv[i], w, X[i * ncol + j]);
+      }
     }
   }
   __syncthreads();
