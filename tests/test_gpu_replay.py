@@ -190,17 +190,21 @@ def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path,
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     system = importlib.import_module("plviwo_amd.system")
     runs = {}
-    for one_call in (True, False):
-        monkeypatch.setattr(system.SystemManager, "one_call_update", one_call)
-        op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{int(one_call)}.txt")))
+    # plv_camera_frame (feed + try_update in one call) / plv_camera_try_update after separate feeds / the two update calls
+    for mode, (update, frame) in (("frame", (True, True)), ("try_update", (True, False)), ("two_calls", (False, False))):
+        monkeypatch.setattr(system.SystemManager, "one_call_update", update)
+        monkeypatch.setattr(system.SystemManager, "one_call_frame", frame)
+        op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{mode}.txt")))
         op.est.cam.use_lines = True
-        runs[one_call] = rp.replay(op)
-    (s1, t1, p1), (s0, t0, p0) = runs[True], runs[False]
-    assert s1["line_updates"] >= 10 and s1["cam_updates"] >= 40
-    for key in s0:
-        if not key.startswith("time"):
-            assert s1[key] == s0[key], (key, s1[key], s0[key])
-    assert np.array_equal(t1, t0) and np.array_equal(p1, p0)
+        runs[mode] = rp.replay(op)
+    s0, t0, p0 = runs["two_calls"]
+    assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
+    for mode in ("frame", "try_update"):
+        s1, t1, p1 = runs[mode]
+        for key in s0:
+            if not key.startswith("time"):
+                assert s1[key] == s0[key], (mode, key, s1[key], s0[key])
+        assert np.array_equal(t1, t0) and np.array_equal(p1, p0), mode
 
 
 def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
