@@ -313,18 +313,25 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 #define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 
-// One wavefront (= one 64-thread workgroup) per point; all pyramid levels, coarse to fine.
-// Lane l owns window pixels l, l+64, l+128, l+192 (< win*win).
-__global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
-                                                float *__restrict__ pts1, uint8_t *__restrict__ status,
-                                                int *__restrict__ iters_out, int win, int max_iters, float eps, CamK K,
-                                                float *__restrict__ n0, float *__restrict__ n1) {
+// One workgroup of four waves per point; all pyramid levels, coarse to fine.  One window pixel per lane (15 x 15 = 225 of the 256
+// lanes).  The mismatch sums are exact integers: reduced inside each wave on 32-bit registers (|diff| <= 255 * 32 and |Ix|, |Iy| <=
+// 16 * 255 — Scharr on 8-bit pixels — so a pixel's product stays below 2^25 and a wave's sum below 2^31), the four wave sums meet in
+// LDS (two slots, alternating by iteration: one barrier per iteration) and every lane adds them as 64-bit integers, so every lane
+// takes the same float step.  (Round 2: one wave per point with four pixels per lane took 52 us per launch, this form 45 — the
+// launch lasts as long as its slowest point, up to 30 iterations on each of 5 levels.)
+#define LK4_WAVES 4
+__global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
+                                                            float *__restrict__ pts1, uint8_t *__restrict__ status,
+                                                            int *__restrict__ iters_out, int win, int max_iters, float eps, CamK K,
+                                                            float *__restrict__ n0, float *__restrict__ n1) {
   __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
   __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
   __shared__ uint8_t jtile[LK_JT][LK_JT];
+  __shared__ int part[2][LK4_WAVES][2];
+  __shared__ int partA[LK4_WAVES][3];
   const int pt = blockIdx.x;
   if (pt >= n) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int W_BITS = 14;
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (win - 1) * 0.5f;
@@ -335,18 +342,9 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
   const float nx0 = pts1[2 * pt], ny0 = pts1[2 * pt + 1];
   const int maxLevel = prev.levels - 1;
   float nextx = nx0, nexty = ny0;
-  int st = 1, iters = 0;
-
-  // this lane's window pixels
-  int wx[4], wy[4];
-  bool own[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int p = lane + 64 * q;
-    own[q] = p < npx;
-    wy[q] = own[q] ? p / win : 0;
-    wx[q] = own[q] ? p - wy[q] * win : 0;
-  }
+  int st = 1, iters = 0, slot = 0;
+  const bool own = tid < npx;
+  const int wy = own ? tid / win : 0, wx = own ? tid - wy * win : 0;
 
   for (int level = maxLevel; level >= 0; --level) {
     const float sc = 1.f / (float)(1 << level);
@@ -368,16 +366,15 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
       if (level == 0) st = 0;
       continue;
     }
-    // ---- stage the template footprint [ipx-1, ipx+win+1] x [ipy-1, ipy+win+1] and its Scharr planes
     const int tt = win + 3;
     __syncthreads();
-    for (int i = lane; i < tt * tt; i += 64) {
+    for (int i = tid; i < tt * tt; i += 64 * LK4_WAVES) {
       int ty = i / tt, tx = i - ty * tt;
       ttile[ty][tx] = I[(size_t)reflect101(ipy - 1 + ty, rows) * cols + reflect101(ipx - 1 + tx, cols)];
     }
     __syncthreads();
     const int td = win + 1;
-    for (int i = lane; i < td * td; i += 64) {
+    for (int i = tid; i < td * td; i += 64 * LK4_WAVES) {
       int y = i / td, x = i - y * td;
       int X = ipx + x, Y = ipy + y;
       int dx = 0, dy = 0;
@@ -397,26 +394,21 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
     int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
     int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-    int Iv[4], Ix[4], Iy[4];
+    int Iv = 0, Ix = 0, Iy = 0;
+    if (own) {
+      Iv = DESCALE(ttile[wy + 1][wx + 1] * iw00 + ttile[wy + 1][wx + 2] * iw01 + ttile[wy + 2][wx + 1] * iw10 + ttile[wy + 2][wx + 2] * iw11,
+                   W_BITS - 5);
+      Ix = DESCALE(tdx[wy][wx] * iw00 + tdx[wy][wx + 1] * iw01 + tdx[wy + 1][wx] * iw10 + tdx[wy + 1][wx + 1] * iw11, W_BITS);
+      Iy = DESCALE(tdy[wy][wx] * iw00 + tdy[wy][wx + 1] * iw01 + tdy[wy + 1][wx] * iw10 + tdy[wy + 1][wx + 1] * iw11, W_BITS);
+    }
+    {  // |Ix|, |Iy| <= 4080: a product < 2^24, a wave's sum < 2^30
+      const int a11 = wave_sum_i32(Ix * Ix), a12 = wave_sum_i32(Ix * Iy), a22 = wave_sum_i32(Iy * Iy);
+      if (lane == 0) partA[wave][0] = a11, partA[wave][1] = a12, partA[wave][2] = a22;
+    }
+    __syncthreads();
     long long sA11 = 0, sA12 = 0, sA22 = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Iv[q] = Ix[q] = Iy[q] = 0;
-      if (own[q]) {
-        const int x = wx[q], y = wy[q];
-        Iv[q] = DESCALE(ttile[y + 1][x + 1] * iw00 + ttile[y + 1][x + 2] * iw01 + ttile[y + 2][x + 1] * iw10 +
-                            ttile[y + 2][x + 2] * iw11,
-                        W_BITS - 5);
-        Ix[q] = DESCALE(tdx[y][x] * iw00 + tdx[y][x + 1] * iw01 + tdx[y + 1][x] * iw10 + tdx[y + 1][x + 1] * iw11, W_BITS);
-        Iy[q] = DESCALE(tdy[y][x] * iw00 + tdy[y][x + 1] * iw01 + tdy[y + 1][x] * iw10 + tdy[y + 1][x + 1] * iw11, W_BITS);
-        sA11 += (long long)Ix[q] * Ix[q];
-        sA12 += (long long)Ix[q] * Iy[q];
-        sA22 += (long long)Iy[q] * Iy[q];
-      }
-    }
-    sA11 = wave_sum_i64(sA11);
-    sA12 = wave_sum_i64(sA12);
-    sA22 = wave_sum_i64(sA22);
+    for (int w = 0; w < LK4_WAVES; ++w) sA11 += partA[w][0], sA12 += partA[w][1], sA22 += partA[w][2];
     const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -439,16 +431,15 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
         break;
       }
       ++iters;
-      // ---- (re)stage the 32x32 search tile when the window leaves it
       if (!have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT) {
         jx0 = inx - (LK_JT - win - 1) / 2;
         jy0 = iny - (LK_JT - win - 1) / 2;
         __syncthreads();
         {
-          const int r = lane >> 1, hx = (lane & 1) * 16;
+          const int r = tid >> 3, hx = (tid & 7) * 4;
           const int Y = reflect101(jy0 + r, jr);
 #pragma unroll
-          for (int c = 0; c < 16; ++c) jtile[r][hx + c] = J[(size_t)Y * jc + reflect101(jx0 + hx + c, jc)];
+          for (int c = 0; c < 4; ++c) jtile[r][hx + c] = J[(size_t)Y * jc + reflect101(jx0 + hx + c, jc)];
         }
         __syncthreads();
         have_tile = true;
@@ -459,22 +450,22 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
       iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
       iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
       iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-      const int bx = inx - jx0, by = iny - jy0;
-      // |diff| <= 255 * 32 and |Ix|, |Iy| <= 16 * 255 (Scharr on 8-bit pixels): a lane's four products sum to < 2^27 and a 16-lane
-      // row to < 2^31, so the in-row reduction steps stay in 32 bits (wave_sum_i32_rows); the totals are exact 64-bit integers
       int pb1 = 0, pb2 = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (own[q]) {
-          const int x = bx + wx[q], y = by + wy[q];
-          const int diff = DESCALE(jtile[y][x] * iw00 + jtile[y][x + 1] * iw01 + jtile[y + 1][x] * iw10 + jtile[y + 1][x + 1] * iw11,
-                                   W_BITS - 5) -
-                           Iv[q];
-          pb1 += diff * Ix[q];
-          pb2 += diff * Iy[q];
-        }
+      if (own) {
+        const int x = inx - jx0 + wx, y = iny - jy0 + wy;
+        const int diff =
+            DESCALE(jtile[y][x] * iw00 + jtile[y][x + 1] * iw01 + jtile[y + 1][x] * iw10 + jtile[y + 1][x + 1] * iw11, W_BITS - 5) - Iv;
+        pb1 = diff * Ix;
+        pb2 = diff * Iy;
       }
-      const long long sb1 = wave_sum_i32_rows(pb1), sb2 = wave_sum_i32_rows(pb2);
+      pb1 = wave_sum_i32(pb1);  // |diff| <= 8160, |Ix| <= 4080: 64 products < 2^31
+      pb2 = wave_sum_i32(pb2);
+      if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
+      __syncthreads();
+      long long sb1 = 0, sb2 = 0;
+#pragma unroll
+      for (int w = 0; w < LK4_WAVES; ++w) sb1 += part[slot][w][0], sb2 += part[slot][w][1];
+      slot ^= 1;
       const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;
       const float ddy = (A12 * b1 - A11 * b2) * D;
@@ -494,18 +485,16 @@ __global__ void __launch_bounds__(64) lk_kernel(PyrDesc prev, PyrDesc cur, int n
     nextx = outx;
     nexty = outy;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     pts1[2 * pt] = nextx;
     pts1[2 * pt + 1] = nexty;
     status[pt] = (uint8_t)st;
     if (iters_out) iters_out[pt] = iters;
   }
-  // perform_matching undistorts both point sets right after the flow (TrackKLT.cpp:864-865): two lanes do it here, the
-  // separate launch is only kept for plv_undistort
-  if (n0 && lane < 2) {
+  if (n0 && tid < 2) {
     float xn, yn;
-    undistort_radtan(K.v, lane == 0 ? px0 : nextx, lane == 0 ? py0 : nexty, xn, yn);
-    float *dst = lane == 0 ? n0 : n1;
+    undistort_radtan(K.v, tid == 0 ? px0 : nextx, tid == 0 ? py0 : nexty, xn, yn);
+    float *dst = tid == 0 ? n0 : n1;
     dst[2 * pt] = xn;
     dst[2 * pt + 1] = yn;
   }
@@ -1138,7 +1127,7 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, ctx->stream, prev, cur, n, d_pts0, d_pts1, d_status, d_iters, win,
+  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, d_pts1, d_status, d_iters, win,
                      max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
