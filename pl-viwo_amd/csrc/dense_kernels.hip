@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
                                                          const double *__restrict__ dC, int ldc, const int *__restrict__ flag,
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
-                                                         int mirror_words, const int *__restrict__ skip, double *__restrict__ dx) {
+                                                         int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
+                                                         const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
+                                                         int mirror2_words) {
   const bool skipped = skip && *skip == 0;  // the gate accepted nothing: no correction, the covariance stays
   if (blockIdx.x == 0) {
     if (skipped && dx) {
@@ -147,6 +149,8 @@ __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P,
     if (mirror_dst)
       for (int i = threadIdx.x; i < mirror_words; i += blockDim.x) mirror_dst[i] = mirror_src[i];
   }
+  if (mirror2_dst && blockIdx.x == gridDim.x - 1)  // (written by kernels launched earlier: complete)
+    for (int i = threadIdx.x; i < mirror2_words; i += blockDim.x) mirror2_dst[i] = mirror2_src[i];
   if (skipped || *flag != 0) return;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
     int j = idx / n, i = idx - j * n;
@@ -207,7 +211,10 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
-                       d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx);
+                       d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx,
+                       (const unsigned *)(mirror_dst ? ctx->mirror2_src : nullptr), (unsigned *)(mirror_dst ? ctx->mirror2_dst : nullptr),
+                       (int)((ctx->mirror2_bytes + 3) / 4));
+    if (mirror_dst && ctx->mirror2_dst) ctx->mirror2_taken = true;
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -385,19 +385,22 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   TRY(ctx->h_pin.reserve(total));
   char *hp = ctx->h_pin.as<char>();
   char *dp_ = s->io.as<char>();
+  // No copy commands around the two kernels: lk_kernel reads the points and the initial guesses straight from the pinned buffer
+  // (16 B per point, once) and the last kernel of the call copies the results back into it (ransac_select_kernel).
   memcpy(hp + o_p0, pts0, nn * 8);
   memcpy(hp + o_p1, pts1_init, nn * 8);
-  PLV_HIP_CHECK(plv::memcpy_async(dp_, hp, nn * 16, hipMemcpyHostToDevice, ctx->stream));
-  float *d_p0 = (float *)(dp_ + o_p0), *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
+  float *d_p1 = (float *)(dp_ + o_p1), *d_n0 = (float *)(dp_ + o_n0), *d_n1 = (float *)(dp_ + o_n1);
   int *d_it = (int *)(dp_ + o_it);
   uint8_t *d_mk = (uint8_t *)(dp_ + o_mk), *d_st = (uint8_t *)(dp_ + o_st);
   const CamK camk = cam_of(ctx);
-  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, d_p0, d_p1, d_st, d_it, ctx->cfg.win_size, ctx->cfg.lk_max_iters,
-                ctx->cfg.lk_eps, &camk, d_n0, d_n1));  // (+ the undistortion of both point sets on the same launch)
+  TRY(launch_lk(ctx, s->pyr[1 - s->cur], s->pyr[s->cur], n, (const float *)(hp + o_p0), d_p1, d_st, d_it, ctx->cfg.win_size,
+                ctx->cfg.lk_max_iters, ctx->cfg.lk_eps, &camk, d_n0, d_n1,
+                (const float *)(hp + o_p1)));  // (+ the undistortion of both point sets on the same launch)
   const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
+  bool mirrored = false;
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
-                    d_mk, s->info.as<int>(), s->models.as<double>()));
-  PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
+                    d_mk, s->info.as<int>(), s->models.as<double>(), dp_ + o_p1, hp + o_p1, o_mk - o_p1, (uint8_t *)(hp + o_mk), &mirrored));
+  if (!mirrored) PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   if (!s->match_done) PLV_HIP_CHECK(hipEventCreateWithFlags(&s->match_done, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(s->match_done, ctx->stream));
   s->pending_n = n;

@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 // launch lasts as long as its slowest point, up to 30 iterations on each of 5 levels.)
 #define LK4_WAVES 4
 __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
-                                                            float *__restrict__ pts1, uint8_t *__restrict__ status,
+                                                            const float *__restrict__ pts1_init, float *__restrict__ pts1,
+                                                            uint8_t *__restrict__ status,
                                                             int *__restrict__ iters_out, int win, int max_iters, float eps, CamK K,
                                                             float *__restrict__ n0, float *__restrict__ n1) {
   __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const double eps2 = (double)ec * (double)ec;
   const int npx = win * win;
   const float px0 = pts0[2 * pt], py0 = pts0[2 * pt + 1];
-  const float nx0 = pts1[2 * pt], ny0 = pts1[2 * pt + 1];
+  const float nx0 = pts1_init[2 * pt], ny0 = pts1_init[2 * pt + 1];
   const int maxLevel = prev.levels - 1;
   float nextx = nx0, nexty = ny0;
   int st = 1, iters = 0, slot = 0;
@@ -872,9 +873,14 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
                                                            float t, double conf, int max_iters, unsigned seed,
                                                            const int *__restrict__ counts, const uint8_t *__restrict__ klt,
                                                            uint8_t *__restrict__ mask, int *__restrict__ info,
-                                                           const double *__restrict__ models) {
+                                                           const double *__restrict__ models, const unsigned *__restrict__ mir_src,
+                                                           unsigned *__restrict__ mir_dst, int mir_words, uint8_t *__restrict__ mir_mask) {
   __shared__ RansacLds L;
   const int lane = threadIdx.x;
+  // (perform_matching: this is the last kernel of the call; it copies what lk_kernel left for the host — positions, normalised
+  // coordinates, iteration counts — and its own mask into the caller's pinned buffer, so that no copy command follows it)
+  if (mir_dst)
+    for (int i = lane; i < mir_words; i += 64) mir_dst[i] = mir_src[i];
   const int total = n == 7 ? 1 : max_iters;
   int best = 0, bh = -1, bslot = 0, niters = total, used = total;
   bool stop = false;
@@ -952,7 +958,9 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
     if (kroot == 0) in = epi_err9(F[0], m1, m2, i) <= t;
     else if (kroot == 1) in = epi_err9(F[1], m1, m2, i) <= t;
     else if (kroot == 2) in = epi_err9(F[2], m1, m2, i) <= t;
-    mask[i] = (in && (!klt || klt[i])) ? 1 : 0;
+    const uint8_t mv = (in && (!klt || klt[i])) ? 1 : 0;
+    mask[i] = mv;
+    if (mir_mask) mir_mask[i] = mv;
   }
 }
 
@@ -1120,15 +1128,16 @@ int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *
 }
 
 int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
-              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps, const CamK *K, float *d_n0, float *d_n1) {
+              uint8_t *d_status, int *d_iters, int win, int max_iters, float eps, const CamK *K, float *d_n0, float *d_n1,
+              const float *pts1_init) {
   if (win > LK_MAXWIN || win < 3 || (win & 1) == 0) {
     set_last_error("lk: window %d unsupported (odd, <= %d)", win, LK_MAXWIN);
     return PLV_E_CAPACITY;
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, d_pts1, d_status, d_iters, win,
-                     max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
+  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, d_pts1,
+                     d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -1148,7 +1157,9 @@ int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, co
 }
 
 int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
-                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info, double *d_models) {
+                  unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info, double *d_models,
+                  const void *mir_src, void *mir_dst, size_t mir_bytes, uint8_t *mir_mask, bool *mirrored) {
+  if (mirrored) *mirrored = false;
   const float t = (float)(thr * thr);
   if (n < 7) {
     PLV_HIP_CHECK(hipMemsetAsync(d_mask, 0, n, ctx->stream));
@@ -1163,7 +1174,9 @@ int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, dou
   {
     ProfScope ps(ctx->prof, "ransac_select_kernel", ctx->stream);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
-                       d_counts, d_klt, d_mask, d_info, (const double *)d_models);
+                       d_counts, d_klt, d_mask, d_info, (const double *)d_models, (const unsigned *)mir_src, (unsigned *)mir_dst,
+                       (int)(mir_bytes / 4), mir_mask);
+    if (mirrored) *mirrored = mir_dst != nullptr;
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -295,9 +295,14 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   const int F = all->n_feat;
   TRY(us->h_tri.reserve((size_t)F * 33 + 16));
   plv::HostPhase ph_b("points fused: gate .. EKF enqueued");
+  // the triangulation results reach the host with the update's result block (copied by its last kernel), or by a copy command when
+  // the chain ended another way; either lands before the wait below returns
+  ctx->mirror2_src = us->tri.as<char>() + ft.o_p, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = (size_t)F * 33, ctx->mirror2_taken = false;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
-  // (stream order: lands before the wait below returns)
-  PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
+  const bool mirrored = ctx->mirror2_taken;
+  ctx->mirror2_src = nullptr, ctx->mirror2_dst = nullptr, ctx->mirror2_bytes = 0, ctx->mirror2_taken = false;
+  if (!mirrored)
+    PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
   ph_b.stop();
   plv::HostPhase ph_c("points fused: host work inside the wait");
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
@@ -589,8 +594,12 @@ int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_lin
   us->b_single_use = true;
   const int L = all->n_lines;
   TRY(us->h_tri.reserve((size_t)L * 49 + 16));
+  ctx->mirror2_src = us->tri.as<char>() + ft.o_lines, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = (size_t)L * 49, ctx->mirror2_taken = false;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, 0.0);
-  PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_lines, (size_t)L * 49, hipMemcpyDeviceToHost, ctx->stream));
+  const bool mirrored = ctx->mirror2_taken;  // (see plv_points_update_fused)
+  ctx->mirror2_src = nullptr, ctx->mirror2_dst = nullptr, ctx->mirror2_bytes = 0, ctx->mirror2_taken = false;
+  if (!mirrored)
+    PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_lines, (size_t)L * 49, hipMemcpyDeviceToHost, ctx->stream));
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
   else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
