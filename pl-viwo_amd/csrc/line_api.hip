@@ -425,10 +425,17 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   FldBuffers b{T->half.as<uint8_t>(), T->map.as<uint8_t>(), T->work.as<uint8_t>(), T->pts.as<int2>(), T->chains.as<FldChain>(),
                kChainCap,             T->counts.as<int>(),  T->segs.as<float4>(), T->seg_count.as<int>()};
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
-  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
   TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (2 + sizeof(int2)) + 64)));
   char *hp = T->pin.as<char>();
+  // host walk without hysteresis (the shipped thresholds are equal): the edge kernel writes the two maps straight into the pinned
+  // buffer the host stage reads — no device copies of them, no copy commands behind the kernel
+  const bool maps_to_host = !T->walk_on_device && fp.canny_low == fp.canny_high;
+  if (maps_to_host) {
+    b.map = (uint8_t *)(hp + bytes);
+    b.half = b.map + npix;
+  }
+  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
   auto emit = [&](const float4 &sg) {
     const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
@@ -461,8 +468,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     J.hmap = hmap, J.hhalf = hmap + npix;
     J.hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
     J.hc = (FldChain *)(hp + 16);
-    PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-    PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (!maps_to_host) {
+      PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+      PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (launch_only) {
       if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
       PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
