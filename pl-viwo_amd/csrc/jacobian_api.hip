@@ -594,13 +594,14 @@ int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_lin
   us->b_single_use = true;
   const int L = all->n_lines;
   TRY(us->h_tri.reserve((size_t)L * 49 + 16));
-  ctx->mirror2_src = us->tri.as<char>() + ft.o_lines, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = (size_t)L * 49, ctx->mirror2_taken = false;
+  // the gate's workgroups leave their verdicts and the triangulated lines in pinned memory and the launch function looks at them
+  // before it enqueues compression + EKF (plv_ctx::probe): a line update in which nothing passes the gate ends there
+  ctx->probe = true, ctx->probe_done = false;
+  ctx->probe_src = us->tri.as<char>() + ft.o_lines, ctx->probe_dst = us->h_tri.p;
+  ctx->probe_stride_a = 48, ctx->probe_off_b = L * 48, ctx->probe_stride_b = 1;
+  ctx->probe_hook = before_wait, ctx->probe_hook_arg = before_wait_arg;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, 0.0);
-  const bool mirrored = ctx->mirror2_taken;  // (see plv_points_update_fused)
-  ctx->mirror2_src = nullptr, ctx->mirror2_dst = nullptr, ctx->mirror2_bytes = 0, ctx->mirror2_taken = false;
-  if (!mirrored)
-    PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_lines, (size_t)L * 49, hipMemcpyDeviceToHost, ctx->stream));
-  if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
+  ctx->probe = false, ctx->probe_src = nullptr, ctx->probe_dst = nullptr, ctx->probe_hook = nullptr, ctx->probe_hook_arg = nullptr;
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
   else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
   const char *h = us->h_tri.as<char>();

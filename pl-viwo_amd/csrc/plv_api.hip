@@ -664,7 +664,30 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   // read by every kernel enqueued from here on (cleared after enqueue()); only the blocked-Cholesky route honours it in all of
   // its kernels, so the Householder / LDS-resident fallbacks (more than 192 columns) run unconditionally
   ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;
+  const bool probe = ctx->probe && !us->graph_mode;
+  if (probe) {
+    char *hb = ctx->h_pin.as<char>();
+    a.h_accepted = (unsigned char *)(hb + (size_t)n * 8 + 16);
+    a.h_acc_rows = (int *)(hb + result_rows_off(n, F));
+    a.probe_src = (const unsigned char *)ctx->probe_src;
+    a.probe_dst = (unsigned char *)ctx->probe_dst;
+    a.probe_stride_a = ctx->probe_stride_a, a.probe_off_b = ctx->probe_off_b, a.probe_stride_b = ctx->probe_stride_b;
+  }
   TRY(launch_chi2(ctx, F, a, mp_max));
+  if (probe) {
+    // the gate's verdicts are in pinned memory when its launch has finished: most line updates end here (three frames in four at
+    // BASELINE configs[2] accept no line), without the six launches that would find nothing to do
+    if (ctx->probe_hook) ctx->probe_hook(ctx->probe_hook_arg);
+    TRY(sync(ctx));
+    const unsigned char *hacc = (const unsigned char *)(ctx->h_pin.as<char>() + (size_t)n * 8 + 16);
+    int any = 0;
+    for (int f = 0; f < F; ++f) any |= hacc[f];
+    if (!any) {
+      memset(ctx->h_pin.p, 0, (size_t)n * 8 + 16);  // dx = 0, status = updated-with-nothing (as the skipped chain reports it)
+      ctx->probe_done = true;
+      return PLV_OK;
+    }
+  }
 
   const double *dH, *dr;
   int r, ldh;
@@ -777,7 +800,10 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     return PLV_E_BADARG;
   }
   us->pending_F = 0;
-  TRY(sync(ctx));
+  if (ctx->probe_done)
+    ctx->probe_done = false;  // (ended at the gate: already synchronised, the result block in h_pin is complete)
+  else
+    TRY(sync(ctx));
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   int flag = *(const int *)(hb + (size_t)n * 8);

@@ -278,6 +278,15 @@ struct plv_ctx {
   void *mirror2_dst = nullptr;
   size_t mirror2_bytes = 0;
   bool mirror2_taken = false;
+  // gate probe of the one-submission line update: plv_msckf_update_resident_launch waits for the gate, reads its verdicts from
+  // pinned memory and enqueues compression + EKF only when something was accepted (probe_* describe the second block the gate's
+  // workgroups copy, update_kernels.hpp; probe_hook runs right before that wait).  probe_done: the update ended at the gate.
+  bool probe = false, probe_done = false;
+  const void *probe_src = nullptr;
+  void *probe_dst = nullptr;
+  int probe_stride_a = 0, probe_off_b = 0, probe_stride_b = 0;
+  void (*probe_hook)(void *) = nullptr;
+  void *probe_hook_arg = nullptr;
 
   // ---- front-end (frontend_api.hip owns the object)
   void *fe_state = nullptr;

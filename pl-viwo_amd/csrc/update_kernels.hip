@@ -242,9 +242,16 @@ __global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kern
       if (pass) pass = (mp < a.q95_n) && (chi < a.chi2_mult * a.q95[mp]);
       a.accepted[f] = pass ? 1 : 0;
       if (a.acc_rows) a.acc_rows[f] = pass ? mp : 0;
+      if (a.h_accepted) a.h_accepted[f] = pass ? 1 : 0;
+      if (a.h_acc_rows) a.h_acc_rows[f] = pass ? mp : 0;
       if (pass && a.n_acc) atomicAdd(a.n_acc, 1);
       passflag = pass ? 1.0 : 0.0;
     }
+  }
+  if (a.probe_dst) {
+    for (int i = threadIdx.x; i < a.probe_stride_a; i += blockDim.x) a.probe_dst[(size_t)f * a.probe_stride_a + i] = a.probe_src[(size_t)f * a.probe_stride_a + i];
+    for (int i = threadIdx.x; i < a.probe_stride_b; i += blockDim.x)
+      a.probe_dst[(size_t)a.probe_off_b + (size_t)f * a.probe_stride_b + i] = a.probe_src[(size_t)a.probe_off_b + (size_t)f * a.probe_stride_b + i];
   }
   if (a.stack) {
     __syncthreads();

@@ -27,6 +27,14 @@ struct Chi2Args {
   int F;
   const double *Ps;       // dense P[cols, cols] (row-major k x k) from gather_cov_kernel
   double *T;              // [F][k][ld] H' * Ps
+  // gate probe (optional): every workgroup also leaves its verdict and a slice of a second block (the triangulation result of its
+  // candidate) in pinned host memory, so that the host can read the gate's outcome as soon as the launch has finished — no copy
+  // command, no further launch
+  unsigned char *h_accepted;          // [F]
+  int *h_acc_rows;                    // [F]
+  const unsigned char *probe_src;     // block f copies [f * stride_a, +stride_a) and [off_b + f * stride_b, +stride_b)
+  unsigned char *probe_dst;
+  int probe_stride_a, probe_off_b, probe_stride_b;
 };
 
 int launch_nullspace(plv_ctx *ctx, int F, int fdim, int k, int ld, const int *d_rows, double *d_Hf, double *d_Hx,
