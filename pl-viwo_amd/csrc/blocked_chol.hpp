@@ -70,7 +70,7 @@ template <class T> __device__ __forceinline__ T lds_vload(const T *p) { return *
 struct BcLds {
   double Lp[2][12][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity (NT <= 12)
   double Ts[16][64][2];    // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
-  double rs[2][16];        // 1 / l_jj (0: dead column), by panel parity
+  double rs[2][16];        // the pivots l_jj^2 of the panel (<= 0: dead column), by panel parity; readers take 1 / sqrt themselves
   int step_flag;           // 16 * panel + steps published so far
   int rs_flag;             // panels whose rs[] is published
   int bad;
@@ -113,15 +113,19 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
 #pragma unroll
   for (int q = 0; q < 4; ++q) mask01[q] = (lq == q) ? 1.0 : 0.0;
   bool dead_any = false;
+  // The pivot of step j + 1 does not wait for the MFMA of step j: element (j+1, j+1) after that step is
+  // fma(T[j][j+1] * (-1/pivot_j), T[j][j+1], T[j+1][j+1]) — exactly the one product the MFMA adds into it — so it is formed from
+  // two lanes read BEFORE the MFMA is issued, and its reciprocal (rcp + two Newton steps) is computed in the shadow of the MFMA's
+  // latency.  The step chain is then "MFMA result -> two lane reads -> scale -> MFMA" (measured: 410 -> ~170 cycles per step).
   double pv = readlane_f64(T[0], 0);
+  bool live = pv > tau;  // uniform
+  double ninv = live ? -rcp_nr(pv) : 0.0;
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const int kk = jj & 3, rq = jj >> 2;
     if (jj == 0) BC_STAMP(40);
     if (jj == 8) BC_STAMP(41);
-    const bool live = pv > tau;  // uniform
     dead_any |= !live;
-    const double ninv = live ? -rcp_nr(pv) : 0.0;
     const double nm = ninv * mask01[kk];
     const double trow = T[rq];
     lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[jj][lane][0]), d2{trow, nm});
@@ -129,11 +133,21 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
 #ifndef PLV_BC_NO_SCHED
     __builtin_amdgcn_sched_barrier(0);  // publish now: the scheduler would sink all 16 stores below the chain
 #endif
-    // 1 / l_jj for the strips, in the shadow of the MFMA latency (rsq + two Newton steps)
-    lds_vstore(&lds.rs[p & 1][jj], live ? rsqrt_nr(pv) : 0.0);
+    double b = 0.0, c = 0.0;
+    if (jj < 15) {
+      b = readlane_f64(trow, 16 * kk + jj + 1);                                   // T[j][j+1]
+      c = readlane_f64(T[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1);           // T[j+1][j+1] before this step
+    }
     if (STORE_L) cap[rq] = (lq == kk) ? trow : cap[rq];
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(trow * nm, trow, T, 0, 0, 0);
-    if (jj < 15) pv = readlane_f64(T[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1);
+    // (in the shadow of the MFMA latency) the pivot for the strips — they take 1 / sqrt of it themselves at the end of the panel,
+    // four per lane in parallel, instead of ten dependent operations per step on this wave — then the next pivot and its reciprocal
+    lds_vstore(&lds.rs[p & 1][jj], live ? pv : 0.0);
+    if (jj < 15) {
+      pv = fma(b * ninv, b, c);
+      live = pv > tau;
+      ninv = live ? -rcp_nr(pv) : 0.0;
+    }
   }
   BC_STAMP(42);
   lds_vstore(&lds.rs_flag, p + 1);
@@ -168,7 +182,10 @@ __device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
   }
   while (__builtin_amdgcn_readfirstlane(lds_vload(&lds.rs_flag)) < p + 1) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) cap[q] *= lds_vload(&lds.rs[p & 1][lq + 4 * q]);
+  for (int q = 0; q < 4; ++q) {
+    const double pvq = lds_vload(&lds.rs[p & 1][lq + 4 * q]);
+    cap[q] *= pvq > 0.0 ? rsqrt_nr(pvq) : 0.0;
+  }
   return cap;
 }
 
@@ -232,7 +249,8 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int c = lq + 4 * q;
-          if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * lds.rs[p & 1][c]);
+          const double pvc = lds.rs[p & 1][c];
+          if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * (pvc > 0.0 ? rsqrt_nr(pvc) : 0.0));
         }
       }
 #ifdef PLV_BC_SOLO
