@@ -251,9 +251,10 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
 /* On (the default), the NEXT frame's top-up detection (TrackKLT.cpp:127-131 runs it on the then-last image with the then-last
- * points: this image, these points) is started ahead of time on a side stream: plv_camera_update_points starts it right after it
- * has submitted the point update of this frame (host stage and launches sit in the update's wait), the next feed collects it;
- * without an update in between the next feed detects in place.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
+ * points: this image, these points) is started ahead of time: plv_camera_update_points enqueues it right behind the point update of
+ * this frame (its host stage and launches sit in the update's wait, which ends at the update's own last kernel; the detection runs
+ * in the device's idle time before the next submission), the next feed collects it; without an update in between the next feed
+ * detects in place.  on = 1: at the end of the feed, on a side stream.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
  * plv_tracker state was edited) or the per-kernel profiler is on. */
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on);
 /* plv_tracker_feed from an image already resident in HBM (plv_image_stage, slots 0..7): the camera driver's DMA target in a

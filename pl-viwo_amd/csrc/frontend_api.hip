@@ -673,7 +673,9 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
 // The top-up detection of the NEXT frame, started now: on the current image (the next frame's last image) with the points this frame
 // ended with.  Runs on a side stream next to whatever the caller enqueues on the ctx stream (the updates); plv_perform_detection of
 // the next frame finds it finished.  Not while the per-kernel profiler is on (its events live on the ctx stream).
-int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in) {
+// on_ctx_stream: enqueue behind what is on the ctx stream instead (the caller has submitted an update whose wait ends at its own
+// last kernel: the detection then runs in the device's idle time between that update and the next submission, not next to it).
+int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in, int on_ctx_stream) {
   if (!ctx || n_in < 0 || (n_in > 0 && (!pts || !ids))) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   FrontState *s = fe(ctx);
@@ -694,8 +696,9 @@ int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *
     PLV_HIP_CHECK(hipStreamCreateWithFlags(&s->det_stream, hipStreamNonBlocking));
     PLV_HIP_CHECK(hipEventCreateWithFlags(&s->det_done, hipEventDisableTiming));
   }
-  if (A.n_slots > 0) TRY(det_launch(ctx, s, s->pyr[s->cur], mask ? A.in_mask.data() : nullptr, A, s->det_stream));  // (the job's own copy of the mask)
-  PLV_HIP_CHECK(hipEventRecord(s->det_done, s->det_stream));
+  hipStream_t st = on_ctx_stream ? ctx->stream : s->det_stream;
+  if (A.n_slots > 0) TRY(det_launch(ctx, s, s->pyr[s->cur], mask ? A.in_mask.data() : nullptr, A, st));  // (the job's own copy of the mask)
+  PLV_HIP_CHECK(hipEventRecord(s->det_done, st));
   A.active = true;
   return PLV_OK;
 }

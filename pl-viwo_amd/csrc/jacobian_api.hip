@@ -308,8 +308,8 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
   ph_c.stop();
   plv::HostPhase ph_d("points fused: wait");
-  if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
-  else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)
+  if (rc != PLV_OK || !mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));      // (the copy command enqueued behind it)
   ph_d.stop();
   const char *h = us->h_tri.as<char>();
   memcpy(p_out, h, (size_t)F * 24);

@@ -221,6 +221,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
     us->jin.release();
     us->tri.release();
     us->eval.release();
+    if (us->done_ev) (void)hipEventDestroy(us->done_ev);
     if (us->gexec) (void)hipGraphExecDestroy(us->gexec);
     us->gexec = nullptr;
     us->h_jin.release();
@@ -772,6 +773,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   ++ctx->gather_stamp;  // the update rewrites the covariance
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
+  if (!us->done_ev) PLV_HIP_CHECK(hipEventCreateWithFlags(&us->done_ev, hipEventDisableTiming));
+  PLV_HIP_CHECK(hipEventRecord(us->done_ev, ctx->stream));
   return PLV_OK;
 }
 
@@ -802,8 +805,10 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   us->pending_F = 0;
   if (ctx->probe_done)
     ctx->probe_done = false;  // (ended at the gate: already synchronised, the result block in h_pin is complete)
-  else
+  else if (ctx->prof.on || !us->done_ev)
     TRY(sync(ctx));
+  else
+    PLV_HIP_CHECK(plv::event_sync(us->done_ev));  // (not the whole stream: the caller may have enqueued more behind the update)
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   int flag = *(const int *)(hb + (size_t)n * 8);

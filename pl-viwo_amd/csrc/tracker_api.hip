@@ -111,7 +111,7 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
 extern "C" void plv_line_defer_finish(plv_ctx *ctx, int on);
 extern "C" void plv_line_run_deferred(plv_ctx *ctx);
-extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in);  // frontend_api.hip
+extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in, int on_ctx_stream);  // frontend_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
   plv::HostPhase ph_all("tracker_feed (after the image feed)");
@@ -203,7 +203,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   // instead of in front of it; without an update in between, the next feed detects in place as usual
   T->ahead_deferred = T->detect_ahead == 2 && !T->ids_last.empty();
   if (T->detect_ahead == 1 && !T->ids_last.empty())
-    (void)plv_perform_detection_ahead(ctx, mask, T->pts_last.data(), T->ids_last.data(), (int)T->ids_last.size());
+    (void)plv_perform_detection_ahead(ctx, mask, T->pts_last.data(), T->ids_last.data(), (int)T->ids_last.size(), 0);
   return PLV_OK;
 }
 
@@ -214,8 +214,10 @@ static void start_detection_ahead(void *arg) {
   std::lock_guard<std::mutex> lk(T->mtx);
   if (!T->ahead_deferred) return;
   T->ahead_deferred = false;
+  // (behind the point update on the ctx stream: its wait ends at the update's own last kernel, the detection fills the device's
+  // idle time until the line update is submitted)
   (void)plv_perform_detection_ahead(ctx, T->mask_last.empty() ? nullptr : T->mask_last.data(), T->pts_last.data(), T->ids_last.data(),
-                                    (int)T->ids_last.size());
+                                    (int)T->ids_last.size(), 1);
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {

@@ -17,6 +17,7 @@ struct plv_ctx_update_state {
   unsigned long long b_gather_token = 0;  // plv_ctx::gather_stamp right after the gathers that rode on the batch's launch (0: none)
   std::vector<int> brows_host;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
+  hipEvent_t done_ev = nullptr;  // behind the update's last command: the wait does not cover what the caller enqueues after the launch
   // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a
   // kernel argument is made of; first sight of a key runs eagerly (sizes every buffer), the second captures, later ones replay
   struct GraphKey {
