@@ -251,9 +251,10 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
  * in-bounds / mask filter, database update (u, v, u_n, v_n, timestamp per id).  mask may be NULL. */
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask);
 /* On (the default), the NEXT frame's top-up detection (TrackKLT.cpp:127-131 runs it on the then-last image with the then-last
- * points: this image, these points) is started ahead of time: plv_camera_update_points enqueues it right behind the point update of
- * this frame (its host stage and launches sit in the update's wait, which ends at the update's own last kernel; the detection runs
- * in the device's idle time before the next submission), the next feed collects it; without an update in between the next feed
+ * points: this image, these points) is started ahead of time: plv_camera_update_points starts it once the point update of this frame
+ * is submitted (its host stage and launches sit in the update's wait) — on a side stream, or, inside plv_camera_try_update with a
+ * line update to follow, on the ctx stream behind the update, whose wait ends at its own last kernel, so that the detection runs in
+ * the device's idle time before the line update is submitted; the next feed collects it; without an update in between the next feed
  * detects in place.  on = 1: at the end of the feed, on a side stream.  Same points, same ids.  Falls back to the in-line detection whenever the inputs differ (e.g. after
  * plv_tracker state was edited) or the per-kernel profiler is on. */
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on);

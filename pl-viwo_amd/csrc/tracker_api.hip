@@ -28,6 +28,7 @@ struct Tracker {
   uint64_t currid = 0;             // REF: TrackBase::currid (4*num_aruco + 1 - 1 = 0 without ArUco tags)
   int detect_ahead = 2;            // plv_tracker_detect_ahead: start the next frame's top-up detection ahead of time (1: at the end of the feed, 2: once the point update is submitted)
   bool ahead_deferred = false;     // ... asked for by the last feed, not started yet (start_detection_ahead)
+  bool ahead_on_ctx_stream = false;  // plv_camera_try_update with a line update to follow: the detection goes behind the point update
   bool defer_db = false;           // plv_camera_try_update: the point update leaves its database hand-back to run_deferred_db
   std::function<void()> deferred_db;
   std::unordered_map<uint64_t, Track> db;
@@ -214,10 +215,10 @@ static void start_detection_ahead(void *arg) {
   std::lock_guard<std::mutex> lk(T->mtx);
   if (!T->ahead_deferred) return;
   T->ahead_deferred = false;
-  // (behind the point update on the ctx stream: its wait ends at the update's own last kernel, the detection fills the device's
-  // idle time until the line update is submitted)
+  // (with a line update to follow: behind the point update on the ctx stream — its wait ends at the update's own last kernel and the
+  // detection fills the device's idle time until the line update is submitted; else on the side stream, next to the update)
   (void)plv_perform_detection_ahead(ctx, T->mask_last.empty() ? nullptr : T->mask_last.data(), T->pts_last.data(), T->ids_last.data(),
-                                    (int)T->ids_last.size(), 1);
+                                    (int)T->ids_last.size(), T->ahead_on_ctx_stream ? 1 : 0);
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
@@ -856,9 +857,9 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
     if (st->intrinsic_state_id >= 0) TRY(plv_set_camera_intrinsics(ctx, st->intrinsics));
     return (int)PLV_OK;
   };
-  T->defer_db = io->opt_lines != nullptr;
+  T->defer_db = T->ahead_on_ctx_stream = io->opt_lines != nullptr;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
-  T->defer_db = false;
+  T->defer_db = T->ahead_on_ctx_stream = false;
   if (rc == PLV_OK) rc = apply(*io->res_points, io->dx_points);
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);
