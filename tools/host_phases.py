@@ -1,5 +1,7 @@
+"""Wall time per host phase of one camera frame (workload C): the Python-level calls of the driver and, with PLV_HOST_TIMING=1, the
+library's own phase timers (printed when it unloads).   usage (GPU box): PLV_HOST_TIMING=1 python tools/host_phases.py"""
 import sys, os, time, importlib
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 wl=bench.WORKLOADS['C']
 stream=bench.build_stream(wl, bench.PROLOGUE+225, 32)
