@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/bench_chain.py (round 1's bench.py) — kernel-chain rate: frames/sec of the per-frame (track + EKF update) hot path on MI355X.
+"""tests/bench_chain.py (round 1's bench.py) — kernel-chain rate: frames/sec of the per-frame (track + EKF update) hot path on MI355X.
 
 One "step" = one camera frame of the configuration BASELINE.json's metric is quoted on ("752x480 mono, 250 pts+80 lines" =
 configs[2]: configs[1]'s point path plus the line front-end and the line update), every input already resident in HBM when
@@ -33,6 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix spec; v_mfma_f64_16x16x4_f64

@@ -1,5 +1,5 @@
 """Algorithmic work per kernel launch (bytes for HBM-class kernels, flops for the dense fp64 ones): the per-unit figures of
-SURVEY.md §8(d), restated in DESIGN.md §4, times the units one launch processes.  Shared by bench.py and tools/bench_chain.py."""
+SURVEY.md §8(d), restated in DESIGN.md §4, times the units one launch processes.  Shared by bench.py and tests/bench_chain.py."""
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix figure (v_mfma_f64_16x16x4_f64)
