@@ -1016,9 +1016,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       if (older || !newer) take.push_back(kv.first);
     }
     std::sort(take.begin(), take.end());
+    pool.reserve(take.size());
     for (uint64_t id : take) {
-      pool.push_back(Cand{id, std::move(T->db[id])});
-      T->db.erase(id);
+      auto node = T->db.extract(id);  // (one lookup: the track leaves the database with its node)
+      pool.push_back(Cand{id, std::move(node.mapped())});
     }
   }
   res->n_pool = (int)pool.size();

@@ -437,9 +437,10 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       if (older || !newer) take.push_back(kv.first);
     }
     std::sort(take.begin(), take.end());
+    pool.reserve(take.size());
     for (uint64_t id : take) {
-      pool.push_back(Cand{id, std::move(T->db[id])});
-      T->db.erase(id);
+      auto node = T->db.extract(id);  // (one lookup: the track leaves the database with its node)
+      pool.push_back(Cand{id, std::move(node.mapped())});
     }
   }
   res->n_pool = (int)pool.size();
