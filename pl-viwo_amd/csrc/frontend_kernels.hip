@@ -407,9 +407,9 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
       if (lane == 0) partA[wave][0] = a11, partA[wave][1] = a12, partA[wave][2] = a22;
     }
     __syncthreads();
-    long long sA11 = 0, sA12 = 0, sA22 = 0;
+    double sA11 = 0.0, sA12 = 0.0, sA22 = 0.0;  // (exact, see the mismatch sums below)
 #pragma unroll
-    for (int w = 0; w < LK4_WAVES; ++w) sA11 += partA[w][0], sA12 += partA[w][1], sA22 += partA[w][2];
+    for (int w = 0; w < LK4_WAVES; ++w) sA11 += (double)partA[w][0], sA12 += (double)partA[w][1], sA22 += (double)partA[w][2];
     const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -463,9 +463,11 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
       pb2 = wave_sum_i32(pb2);
       if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
       __syncthreads();
-      long long sb1 = 0, sb2 = 0;
+      // the four wave sums (|.| < 2^31 each) are added as doubles: exact (the total stays below 2^33), and (float) of that double
+      // rounds once, as (float) of the 64-bit integer does — without the scalar-unit sequence an int64 -> float conversion compiles to
+      double sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
-      for (int w = 0; w < LK4_WAVES; ++w) sb1 += part[slot][w][0], sb2 += part[slot][w][1];
+      for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
       slot ^= 1;
       const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;
