@@ -84,6 +84,31 @@ def test_line_triangulation_parity(ctx, pkg, jo):
     assert np.abs(out - out_o).max() <= 1e-9 * max(1.0, np.abs(out_o).max())
 
 
+def test_lines_update_at_configs3_size(ctx, pkg, jo, oracle):
+    """BASELINE configs[3]: 150 lines seen from a 20-clone window (up to 20 observations each: ld = 40, k = 6 * 20 + the time offset),
+    Jacobians -> null space -> gate -> compression -> EKFUpdate on the device against the oracle."""
+    sc = synth.vio_scene(n_clones=20, F=4, calib_int=True, w=1280, h=720)
+    ls = synth.line_scene(sc, L=150, M=20, noise_px=0.4, w=1280, h=720)
+    st, lt = make(pkg, sc, ls, dt_state_id=14)
+    cols = ctx.line_jacobian_columns(st, lt)
+    assert len(cols) == 121
+    ld = 40
+    n = sc["n_state"]
+    P = synth.spd_cov(n, seed=6) * 1e-4
+    q95 = synth.q95_table()
+    rows_o, Hf_o, Hx_o, res_o = jo.build_line_jacobians(st, lt, cols, ld)
+    assert rows_o.max() == 40
+    rc_o, P_o, dx_o, acc_o, nrows_o = oracle.msckf_update(P, rows_o, Hf_o, Hx_o, res_o, cols, 2.25, q95, res_norm_gate=0.0)
+    ctx.cov_upload(P)
+    ctx.build_line_jacobians_resident(st, lt, cols, ld)
+    rc, dx, acc, nrows = ctx.msckf_update_resident(n, 2.25, res_norm_gate=0.0)
+    Pn = ctx.cov_download(n)
+    assert rc == rc_o == 0
+    assert (acc == acc_o).all() and acc.sum() > 20 and nrows == nrows_o
+    assert np.abs(dx - dx_o).max() <= 1e-7 * max(1.0, np.abs(dx_o).max())
+    assert np.abs(Pn - P_o).max() <= 1e-8 * np.abs(P).max()
+
+
 def test_lines_update_end_to_end(ctx, pkg, jo, oracle):
     """UpdaterCamera::lines_update: Jacobians -> nullspace (6) -> chi2-only gate -> compress -> EKF."""
     sc = synth.vio_scene(F=4, calib_int=True)
