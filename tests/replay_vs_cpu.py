@@ -31,19 +31,24 @@ def main():
     ap.add_argument("--style", default="street", choices=["street", "room"], help="street: corridor drive (lines on); room: round 1's scene")
     ap.add_argument("--no-lines", action="store_true")
     ap.add_argument("--cam-hz", type=float, default=10.0)
+    ap.add_argument("--size", default="752x480", help="image size; 1280x720 with --points 500 --cam-hz 20 is BASELINE configs[3]")
+    ap.add_argument("--points", type=int, default=250)
     a = ap.parse_args()
+    W, H = (int(v) for v in a.size.split("x"))
+    sd.set_camera(W, H)
     pkg = ge.load_pkg()
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     d = tempfile.mkdtemp(prefix="plv_synth_")
     sd.make_dataset(d, a.seconds, cam_hz=a.cam_hz, style=a.style, workers=min(32, os.cpu_count() or 1))
     gt = os.path.join(d, "gt.txt")
     lines = not a.no_lines
-    res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered 752x480 images at {a.cam_hz:g} Hz, 200 Hz IMU, 50 Hz wheel)",
+    res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered {a.size} images at {a.cam_hz:g} Hz, {a.points} points, 200 Hz IMU, 50 Hz wheel)",
                      lines="on in both runs" if lines else "off in both runs"), {}
-    ctx = pkg.Context(pkg.default_config(752, 480))
+    ctx = pkg.Context(pkg.default_config(W, H))
+    cfg_kw = dict(clone_freq=int(a.cam_hz), n_pts=a.points, max_msckf=70, calib_int=True, sigma_px=1.5) if (W, H) != (752, 480) else {}
     for name, kw in (("hip", {}), ("cpu_oracle", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
         traj = os.path.join(d, "out", f"traj_{name}.txt")
-        op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj))
+        op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj, **cfg_kw))
         op.est.cam.use_lines = lines
         t0 = time.time()
         stats, times, poses = rp.replay(op, **kw)

@@ -183,6 +183,47 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
 
+@pytest.fixture(scope="module")
+def street_dataset_d(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("street_d"))
+    sd.set_camera(1280, 720)
+    try:
+        sd.make_dataset(d, seconds=5.0, cam_hz=20.0, style="street", workers=min(16, os.cpu_count() or 1))
+    finally:
+        sd.set_camera(752, 480)
+    return d
+
+
+def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, tmp_path):
+    """BASELINE configs[3] end to end: 1280 x 720 frames at 20 Hz, 500 points + lines, 20-clone window, intrinsics calibrated online,
+    through the driver over the HIP library and over the CPU oracle: the same features and lines pooled, triangulated and
+    accepted, trajectories a rounding error (a threshold tie at most) apart."""
+    import oracle_context as oc
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    sd.set_camera(1280, 720)
+    try:
+        runs = {}
+        for name, kw in (("hip", {}), ("cpu", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
+            traj = str(tmp_path / f"traj_{name}.txt")
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset_d, traj, clone_freq=20, n_pts=500, max_msckf=70,
+                                                      calib_int=True, sigma_px=1.5))
+            op.est.cam.use_lines = True
+            stats, times, poses = rp.replay(op, **kw)
+            assert stats["initialized"] and stats["not_psd"] == 0, (name, stats)
+            runs[name] = (stats, times, poses)
+    finally:
+        sd.set_camera(752, 480)
+    sh, sc = runs["hip"][0], runs["cpu"][0]
+    assert sh["n_state"] >= 15 + 8 + 6 * 20
+    for key in ("clones", "frames", "lines_tracked", "wheel_accepted"):
+        assert sh[key] == sc[key], (key, sh[key], sc[key])
+    for key in ("cam_features", "cam_accepted", "cam_updates", "line_pool", "lines_triangulated", "lines_accepted", "line_updates"):
+        assert abs(sh[key] - sc[key]) <= max(2, 0.03 * sc[key]), (key, sh[key], sc[key])
+    assert sh["cam_accepted"] >= 800 and sh["lines_triangulated"] >= 1000 and sh["line_updates"] >= 10, sh
+    assert np.array_equal(runs["hip"][1], runs["cpu"][1])
+    assert np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max() < 0.005
+
+
 def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path, monkeypatch):
     """plv_camera_try_update (point update, dx applied inside the library, line update, dx applied; the point half's database
     hand-back deferred into the line update's wait) against plv_camera_update_points / _lines with the dx applied by the driver:
