@@ -350,9 +350,13 @@ void plv_jpl_left_update(int n, double *q, const double *dth, double *R) {
 // a vector, the rotation matrix of a quaternion) — e.g. the field of a plv_state_view the caller keeps current.
 int plv_state_boxplus(int n_var, const plv_state_var *vars, const double *dx, int n_dx) {
   if (n_var < 0 || (n_var > 0 && !vars) || !dx) return PLV_E_BADARG;
+  for (int i = 0; i < n_var; ++i) {  // every entry is checked before the first one is applied: a bad list leaves the state as it was
+    const plv_state_var &v = vars[i];
+    if (v.kind != PLV_VAR_QUAT && v.kind != PLV_VAR_VEC) return PLV_E_BADARG;
+    if (!v.val || v.id < 0 || v.size < 1 || v.id + (v.kind == PLV_VAR_QUAT ? 3 : v.size) > n_dx) return PLV_E_BADARG;
+  }
   for (int i = 0; i < n_var; ++i) {
     const plv_state_var &v = vars[i];
-    if (!v.val || v.id < 0 || v.size < 1 || v.id + (v.kind == PLV_VAR_QUAT ? 3 : v.size) > n_dx) return PLV_E_BADARG;
     if (v.kind == PLV_VAR_QUAT) {
       double R[9];
       plv_jpl_left_update(1, v.val, dx + v.id, v.out || v.mirror ? R : nullptr);
@@ -361,8 +365,6 @@ int plv_state_boxplus(int n_var, const plv_state_var *vars, const double *dx, in
     } else if (v.kind == PLV_VAR_VEC) {
       for (int j = 0; j < v.size; ++j) v.val[j] = v.val[j] + dx[v.id + j];
       if (v.mirror) std::copy(v.val, v.val + v.size, v.mirror);
-    } else {
-      return PLV_E_BADARG;
     }
   }
   return PLV_OK;

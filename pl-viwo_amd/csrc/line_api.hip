@@ -6,9 +6,10 @@
 //   TrackLSD::LineClassification / LineClass        REF: :318-366
 //   LineHelper::Vanishing_Points / Distort          REF: linefeat/LineHelper.cpp:1026-1088
 //   LineFeatureDatabase::update_feature             REF: linefeat/LineFeatureDatabase.cpp:40-76
-// Image work (half-resolution, Canny, chain walking, segment fits, end-point undistortion) runs on
-// the device.  What stays here is the reference's own host bookkeeping: which of <= ~100 segments
-// owns which of <= 250 tracked points, id hand-over between frames, the line track store.
+// Pixel work (half-resolution resize, Sobel, non-maximum suppression, hysteresis) runs on the device; the
+// detector's list processing (chain walk + segment growth) is a HOST stage by default (plv_line_walk_mode
+// selects the device kernels; DESIGN.md "Line detector" has the measurements behind that choice).  The rest
+// here is the reference's own host bookkeeping: id hand-over between frames and the line track store.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -86,6 +87,7 @@ struct LineTracker {
   struct FeedJob {
     plv_ctx *ctx = nullptr;
     double timestamp = 0, vps[6] = {0, 0, 0, 0, 0, 0};
+    double K8[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the camera model at post time (the caller may refresh ctx->cfg.intrinsics while the job runs)
     std::vector<float> pts;
     std::vector<uint64_t> pids;
     int rc = PLV_OK;
@@ -311,7 +313,7 @@ int host_extract(LineTracker *T, LineTracker::Job &J, bool timing) {
 }
 
 // (feed_points_impl is defined further down, outside this namespace: the worker reaches it through this pointer)
-int (*g_feed_impl)(plv_ctx *, LineTracker *, double, const double *, int, const float *, const uint64_t *) = nullptr;
+int (*g_feed_impl)(plv_ctx *, LineTracker *, double, const double *, int, const float *, const uint64_t *, const double *) = nullptr;
 void line_worker(LineTracker *T) {
   for (;;) {
     bool do_detect = false, do_feed = false;
@@ -326,7 +328,7 @@ void line_worker(LineTracker *T) {
       LineTracker::FeedJob &F = T->feed;
       if (plv::host_phases().on)
         plv::host_phases().add("line worker: feed job starts after its post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
-      const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data());
+      const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data(), F.K8);
       {
         std::lock_guard<std::mutex> lk(T->jm);
         F.rc = rc;
@@ -759,17 +761,19 @@ int plv_line_tracker_feed(plv_ctx *ctx, double timestamp, const double *vps) {
   return plv_line_tracker_feed_points(ctx, timestamp, vps, np, pts.data(), pids.data());
 }
 
-static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids);
+static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids, const double *K8);
 int plv_line_tracker_feed_points(plv_ctx *ctx, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
   if (!ctx || !vps || np < 0 || (np > 0 && (!pts || !pids))) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   LineTracker *T = ltr(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
-  return feed_points_impl(ctx, T, timestamp, vps, np, pts, pids);
+  return feed_points_impl(ctx, T, timestamp, vps, np, pts, pids, ctx->cfg.intrinsics);
 }
 
-// TrackLSD::feed_monocular after the histogram equalisation, on the tracker state of T (the caller holds T->mtx or is the worker)
-static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
+// TrackLSD::feed_monocular after the histogram equalisation, on the tracker state of T (the caller holds T->mtx or is the worker).
+// K8: the camera model of feed_measurement's time (REF: UpdaterCamera.cpp:77-116 runs before try_update refreshes it,
+// StateHelper.cpp:163-168) — a snapshot when the call runs on the worker next to the point update.
+static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids, const double *K8) {
   plv::HostPhase ph_all("line_tracker_feed: whole call");
   std::vector<float> lines;
   if (T->cached_which == PLV_PYR_CUR && T->cached_fed == plv_front_fed_count(ctx)) {
@@ -805,7 +809,7 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
     // (radtan_core.hpp, bit-identical on host and device) run here instead of a launch + copy + synchronisation round trip
     std::vector<float> un(4 * (size_t)std::max(nk, 1));
     for (int q = 0; q < 2 * nk; ++q)
-      undistort_radtan(ctx->cfg.intrinsics, fl[2 * (size_t)q], fl[2 * (size_t)q + 1], un[2 * (size_t)q], un[2 * (size_t)q + 1]);
+      undistort_radtan(K8, fl[2 * (size_t)q], fl[2 * (size_t)q + 1], un[2 * (size_t)q], un[2 * (size_t)q + 1]);
     for (int q = 0; q < nk; ++q) {
       const int D = plv_line_classification(fl.data() + 4 * q, vps);
       auto it = T->db.find(fid[q]);
@@ -849,13 +853,14 @@ int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vp
   F.pids.resize((size_t)np);
   const bool detecting = !T->walk_on_device && T->worker.joinable() && T->pending_which == PLV_PYR_CUR && T->pending_fed == plv_front_fed_count(ctx);
   if (!detecting) {  // no detection of this frame on the worker: nothing to overlap with, and the detector's HIP calls stay on this thread
-    F.rc = feed_points_impl(ctx, T, timestamp, vps, np, F.pts.data(), F.pids.data());
+    F.rc = feed_points_impl(ctx, T, timestamp, vps, np, F.pts.data(), F.pids.data(), ctx->cfg.intrinsics);
     return F.rc;
   }
   g_feed_impl = feed_points_impl;
   F.ctx = ctx;
   F.timestamp = timestamp;
   std::copy(vps, vps + 6, F.vps);
+  std::copy(ctx->cfg.intrinsics, ctx->cfg.intrinsics + 8, F.K8);
   F.rc = PLV_OK;
   {
     std::lock_guard<std::mutex> lk2(T->jm);

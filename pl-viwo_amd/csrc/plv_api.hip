@@ -579,6 +579,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   auto *us = ustate(ctx);
   const int F_guard = us->bF;
   us->pending_F = 0;
+  ctx->probe_done = false;  // (a launch that failed after setting it, or a wait that was skipped, must not short-cut this update's wait)
   if (F_guard < 1 || ctx->cov_n < 1) {
     set_last_error("plv_msckf_update_resident: no staged batch / covariance");
     return PLV_E_BADARG;
@@ -730,7 +731,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     return PLV_OK;
   };
   if (us->graph_mode && !ctx->prof.on) {
-    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, F, fdim + 16 * (projected ? 1 : 0) + 32 * (gathers_valid ? 1 : 0), k, ld, n, mp_max,
+    // (the skip word is chosen inside enqueue() from Mtot, k and d_flag: all functions of the key's own fields and of `result`)
+    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, ctx->mirror2_src, ctx->mirror2_dst,
+                                       (const void *)(d_flag + 1), ctx->mirror2_bytes, F, fdim + 16 * (projected ? 1 : 0) + 32 * (gathers_valid ? 1 : 0), k, ld, n, mp_max,
                                        sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch().load()};
     if (us->gexec && key == us->gkey) {
       PLV_HIP_CHECK(hipGraphLaunch(us->gexec, ctx->stream));

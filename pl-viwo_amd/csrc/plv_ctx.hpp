@@ -132,6 +132,7 @@ struct PinBuf {
   size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
+    ++alloc_epoch();  // kernels write into pinned blocks too (result mirrors): a captured graph holds their addresses
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;

@@ -22,11 +22,14 @@ struct plv_ctx_update_state {
   // kernel argument is made of; first sight of a key runs eagerly (sizes every buffer), the second captures, later ones replay
   struct GraphKey {
     const void *P, *Hf, *rows, *cols, *result, *hpin;
+    const void *m2_src, *m2_dst, *skip;  // the second mirror block of ekf_commit_kernel and the skip word are kernel arguments too
+    size_t m2_bytes;
     int F, fdim, k, ld, n, mp_max;
     double s2, cm, rg;
     unsigned long long epoch;
     bool operator==(const GraphKey &o) const {
-      return P == o.P && Hf == o.Hf && rows == o.rows && cols == o.cols && result == o.result && hpin == o.hpin && F == o.F &&
+      return P == o.P && Hf == o.Hf && rows == o.rows && cols == o.cols && result == o.result && hpin == o.hpin &&
+             m2_src == o.m2_src && m2_dst == o.m2_dst && skip == o.skip && m2_bytes == o.m2_bytes && F == o.F &&
              fdim == o.fdim && k == o.k && ld == o.ld && n == o.n && mp_max == o.mp_max && s2 == o.s2 && cm == o.cm && rg == o.rg &&
              epoch == o.epoch;
     }
