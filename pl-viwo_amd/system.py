@@ -737,6 +737,11 @@ class SystemManager:
             return
         self.tc.ding("[Time-Cam] get features + MSCKF update")
         out = self.ctx.camera_update_points(st.view(), st.n, max_msckf, self.max_obs, max_slam=c.max_slam, slam_ids=list(st.slam), **pk, **kw)
+        if self.use_lines and hasattr(self.ctx, "camera_get_line_features"):
+            # LineHelper::get_line_features runs before msckf_update's correction reaches the state (UpdaterCamera.cpp:148-152): the line pool
+            # is formed and triangulated on the state as it is now; camera_update_lines below linearises on the updated one
+            self._join_lines()
+            self.ctx.camera_get_line_features(st.view(), st.n, self.max_obs, **kw)
         if out["status"] == 0 and out["n_accepted"] > 0:
             st.apply(out["dx"])
         self.tc.dong("[Time-Cam] get features + MSCKF update")

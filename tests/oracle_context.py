@@ -1,7 +1,8 @@
 """The slice of plviwo_amd.Context that pl-viwo_amd/system.py drives (IMU + one camera, points and lines, wheel), served by the CPU oracle:
 the same SystemManager then runs the whole filter on the CPU and its trajectory is the "CPU reference" of the replay tests.
-Test infrastructure; compositions of oracle pieces as in test_gpu_tracker.py (frame logic) and test_gpu_dropin_sequence.py
-(try_update)."""
+Test infrastructure.  OracleContext = the compiled CPU frame (oracle/frame_oracle.cpp: tracker, databases, try_update in C++);
+PyMirrorContext = the same bookkeeping in Python over the oracle's numeric pieces (compositions as in test_gpu_tracker.py and
+test_gpu_dropin_sequence.py), kept as the cross-check of the compiled one (tests/test_frame_oracle.py)."""
 import numpy as np
 
 import oracle_lib
@@ -9,7 +10,7 @@ import synth
 from test_gpu_dropin_sequence import MirrorUpdater
 
 
-class OracleContext:
+class PyMirrorContext:
     def __init__(self, cfg):
         import __graft_entry__ as ge
         self.pkg = ge.load_pkg()
@@ -135,15 +136,14 @@ class OracleContext:
                 e["points"].extend(int(x) for x in a["rel_id"][a["rel_ptr"][q]:a["rel_ptr"][q + 1]])
         self.line_last = (fl, fid, a["rel_ptr"], a["rel_id"])
 
-    # ---- UpdaterCamera::try_update, line half: get_line_features -> lines_update -> cleanup_lines
-    # (REF: linefeat/LineHelper.cpp:19-72, UpdaterCamera.cpp:371-464, LineHelper.cpp:522-553), the bookkeeping of plv_camera_update_lines
-    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512, cpi=None):
+    def camera_get_line_features(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cpi=None):
+        """LineHelper::get_line_features (REF: linefeat/LineHelper.cpp:19-72): pool, unusable measurements, sort, triangulation — on the
+        state handed in, which in the reference is the one BEFORE the point update is applied (UpdaterCamera.cpp:148-152)."""
         assert cpi is None
         pkg, mir = self.pkg, self.mir
         ct = [float(x) for x in st.t]
         dt = float(st.c.cam_dt)
         t_oldest, t_oldest2 = ct[0], ct[1]
-        bounding = lambda t: mir._bounding(ct, t + dt)
         unused = {}
 
         def give(lid, e, i):
@@ -154,7 +154,6 @@ class OracleContext:
 
         take = sorted(k for k, e in self.ldb.items() if any(t < t_oldest2 - dt for t in e["t"]) or not any(t > t_prev_frame - dt for t in e["t"]))
         pool = [(k, self.ldb.pop(k)) for k in take]
-        out = dict(dx=np.zeros(n), n_pool=len(pool), n_lines=0, n_accepted=0, n_rows=0, status=0, ids=[], accepted=[])
         kept = []
         for lid, e in pool:
             keep = []
@@ -170,6 +169,7 @@ class OracleContext:
                 kept.append((lid, dict(t=[e["t"][i] for i in keep], uv=[e["uv"][i] for i in keep], uvn=[e["uvn"][i] for i in keep],
                                        points=e["points"], D=e["D"])))
         kept.sort(key=lambda x: -len(x[1]["t"]))     # stable
+        lg, ok = np.zeros((0, 6)), np.zeros(0, dtype=np.uint8)
         if kept:
             ptr = np.concatenate([[0], np.cumsum([len(e["t"]) for _, e in kept])]).astype(np.int32)
             anchor, has = np.zeros((len(kept), 3)), np.zeros(len(kept), dtype=np.uint8)
@@ -182,6 +182,23 @@ class OracleContext:
                                     seg_uvn=np.concatenate([e["uvn"] for _, e in kept]), D=[e["D"] for _, e in kept], anchor_pt=anchor,
                                     has_pt=has)
             lg, ok = self.jo.triangulate_lines(st, lt_all)
+        self._prep = dict(n_pool=len(pool), kept=kept, unused=unused, give=give, lg=lg, ok=ok)
+
+    # ---- UpdaterCamera::lines_update -> cleanup_lines (REF: UpdaterCamera.cpp:371-464, LineHelper.cpp:522-553) on what
+    # camera_get_line_features prepared (two-call form without it: pool and triangulation on the state handed in here)
+    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512, cpi=None):
+        assert cpi is None
+        if getattr(self, "_prep", None) is None:
+            self.camera_get_line_features(st, n, max_obs, t_prev_frame, state_time, window_full, chi2_mult)
+        prep, self._prep = self._prep, None
+        pkg, mir = self.pkg, self.mir
+        ct = [float(x) for x in st.t]
+        dt = float(st.c.cam_dt)
+        t_oldest = ct[0]
+        bounding = lambda t: mir._bounding(ct, t + dt)
+        kept, unused, give, lg, ok = prep["kept"], prep["unused"], prep["give"], prep["lg"], prep["ok"]
+        out = dict(dx=np.zeros(n), n_pool=prep["n_pool"], n_lines=0, n_accepted=0, n_rows=0, status=0, ids=[], accepted=[])
+        if kept:
             sel, t_first = [], {}
             for l, (lid, e) in enumerate(kept):
                 valid = sum(bounding(t) for t in e["t"])
@@ -260,6 +277,83 @@ class OracleContext:
         Pn = P - dP
         self.P = np.asfortranarray(0.5 * (Pn + Pn.T))
         return 0, 1, K @ res
+
+
+class OracleContext(PyMirrorContext):
+    """The camera path through the compiled CPU frame (oracle/frame_oracle.cpp).  Covariance bookkeeping between the frames (propagation,
+    cloning, marginalisation, wheel updates) as in PyMirrorContext: numpy + the oracle's pieces on self.P."""
+
+    def __init__(self, cfg):
+        PyMirrorContext.__init__(self, cfg)
+        self.frame = oracle_lib.FrameOracle(self.pkg, cfg, self.q95)
+        self._lk_threads = 1
+
+    def close(self):
+        self.frame.close()
+
+    @property
+    def lk_threads(self):
+        return self._lk_threads
+
+    @lk_threads.setter
+    def lk_threads(self, n):
+        self._lk_threads = int(n)
+        self.frame.set_threads(int(n))
+
+    def _Pf(self):
+        if not (self.P.flags.f_contiguous and self.P.dtype == np.float64):
+            self.P = np.asfortranarray(self.P, dtype=np.float64)
+        return self.P
+
+    def set_camera_intrinsics(self, K8):
+        self.K8 = np.array(K8, dtype=np.float64)
+        self.frame.set_intrinsics(self.K8)
+
+    def tracker_feed(self, t, img, mask=None):
+        self.frame.tracker_feed(t, img, mask)
+
+    def tracker_last(self):
+        return self.frame.tracker_last()
+
+    def line_tracker_last(self):
+        return self.frame.line_last()
+
+    def db_size(self):
+        return self.frame.db_size()
+
+    def db_cleanup_measurements(self, t):
+        self.frame.db_cleanup_measurements(t)
+
+    def line_db_size(self):
+        return self.frame.line_db_size()
+
+    def line_tracker_feed(self, t, vps):
+        self.frame.line_feed(t, vps)
+
+    def camera_update_points(self, st, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, min_dist=0.1,
+                             max_dist=60.0, max_cond=1e4, max_baseline=40.0, refine=True, max_slam=0, slam_ids=(), init_min_meas=10,
+                             cpi=None):
+        assert max_slam == 0 and cpi is None
+        return self.frame.update_points(self._Pf(), st, max_msckf, max_obs, t_prev_frame, state_time, window_full, chi2_mult, min_dist, max_dist,
+                                        max_cond, max_baseline, refine)
+
+    def camera_get_line_features(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cpi=None):
+        """LineHelper::get_line_features on the state handed in: in the reference it runs BEFORE the point update is applied
+        (UpdaterCamera.cpp:148-152); camera_update_lines then uses what it prepared."""
+        assert cpi is None
+        self.frame.get_line_features(st, max_obs, t_prev_frame, state_time, window_full, chi2_mult)
+
+    def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512, cpi=None):
+        assert cpi is None
+        return self.frame.update_lines(self._Pf(), st, max_obs, t_prev_frame, state_time, window_full, chi2_mult, cap)
+
+    def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw):
+        return self.frame.try_update(self._Pf(), st, dict(plus=plus, n=n, max_msckf=max_msckf, max_obs=max_obs, t_prev_frame=t_prev_frame,
+                                                          state_time=state_time, **kw))
+
+    def camera_frame(self, st, timestamp, slot=None, img=None, mask=None, use_lines=False, update=None):
+        assert slot is None
+        return self.frame.camera_frame(self._Pf() if self.P is not None else None, st, timestamp, img, mask, use_lines, update)
 
 
 class OracleIwInitializer:

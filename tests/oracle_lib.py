@@ -661,3 +661,211 @@ def load_line():
         load()
         _line = LineOracle(_inst.lib)
     return _line
+
+
+# ------------------------------------------------------------------ the compiled CPU frame (oracle/frame_oracle.cpp)
+class FrameOracle:
+    """One camera of the reference on the CPU, compiled end to end: tracker + databases + try_update (oracle/frame_oracle.cpp).  The
+    covariance stays with the caller (a Fortran-ordered numpy array handed to every update call, modified in place)."""
+
+    def __init__(self, pkg, cfg, q95):
+        load()
+        self.pkg, self.cfg = pkg, cfg
+        self.lib = L = _inst.lib
+        vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+        L.orc_frame_create.restype = vp
+        L.orc_frame_create.argtypes = [vp, dp, C.c_int]
+        L.orc_frame_destroy.argtypes = [vp]
+        L.orc_frame_set_intrinsics.argtypes = [vp, dp]
+        L.orc_frame_set_threads.argtypes = [vp, C.c_int]
+        L.orc_frame_tracker_feed.argtypes = [vp, C.c_double, vp, C.c_int, vp]
+        L.orc_frame_line_feed.argtypes = [vp, C.c_double, dp]
+        L.orc_frame_update_points.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp]
+        L.orc_frame_get_line_features.argtypes = [vp, vp, vp]
+        L.orc_frame_update_lines.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp, C.c_int]
+        L.orc_frame_try_update.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp]
+        L.orc_frame_camera_frame.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp]
+        L.orc_frame_tracker_last.argtypes = [vp, fp, u64p, C.c_int]
+        L.orc_frame_line_last.argtypes = [vp, fp, u64p, C.c_int]
+        L.orc_frame_db_ids.argtypes = [vp, u64p, ip, C.c_int]
+        L.orc_frame_line_db_ids.argtypes = [vp, u64p, ip, C.c_int]
+        L.orc_frame_db_track.argtypes = [vp, C.c_uint64, dp, fp, fp, C.c_int]
+        L.orc_frame_line_db_track.argtypes = [vp, C.c_uint64, dp, fp, fp, C.c_int, ip, ip]
+        L.orc_frame_db_append.argtypes = [vp, C.c_uint64, C.c_int, dp, fp, fp]
+        L.orc_frame_line_db_append.argtypes = [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]
+        L.orc_frame_used_insert.argtypes = [vp, C.c_uint64, dp, C.c_double]
+        L.orc_frame_db_cleanup_measurements.argtypes = [vp, C.c_double]
+        for f in ("orc_frame_db_size", "orc_frame_line_db_size", "orc_frame_used_size", "orc_frame_lines_detected"):
+            getattr(L, f).argtypes = [vp]
+        self.q95 = np.ascontiguousarray(q95, dtype=np.float64)
+        self.h = L.orc_frame_create(C.addressof(cfg), _dp(self.q95), len(self.q95))
+        assert self.h
+        self.timing_ms = np.zeros(6)       # accumulated by camera_frame: feed points, feed lines, points update, get lines, lines update, whole
+
+    def close(self):
+        if self.h:
+            self.lib.orc_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_intrinsics(self, K8):
+        K8 = np.ascontiguousarray(K8, dtype=np.float64)
+        self.lib.orc_frame_set_intrinsics(self.h, _dp(K8))
+
+    def set_threads(self, n):
+        self.lib.orc_frame_set_threads(self.h, int(n))
+
+    def tracker_feed(self, t, img, mask=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        rc = self.lib.orc_frame_tracker_feed(self.h, float(t), img.ctypes.data, img.shape[1], m.ctypes.data if m is not None else None)
+        assert rc == 0, rc
+
+    def line_feed(self, t, vps):
+        vps = np.ascontiguousarray(vps, dtype=np.float64)
+        rc = self.lib.orc_frame_line_feed(self.h, float(t), _dp(vps))
+        assert rc == 0, rc
+
+    def _P(self, P):
+        assert P.flags.f_contiguous and P.dtype == np.float64 and P.shape[0] == P.shape[1]
+        return _dp(P), P.shape[0], P.shape[0]
+
+    def update_points(self, P, st, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, min_dist=0.1, max_dist=60.0,
+                      max_cond=1e4, max_baseline=40.0, refine=True):
+        pkg = self.pkg
+        opt = pkg.PlvUpdateOptions(max_msckf, max_obs, chi2_mult, pkg.PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0),
+                                   t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, 10, None)
+        res = pkg.PlvUpdateResult()
+        n = P.shape[0]
+        dx, ids, acc, p = np.zeros(n), np.zeros(max_msckf, dtype=np.uint64), np.zeros(max_msckf, dtype=np.uint8), np.zeros((max_msckf, 3))
+        rc = self.lib.orc_frame_update_points(self.h, *self._P(P), C.addressof(st.c), C.addressof(opt), _dp(dx), C.addressof(res),
+                                              ids.ctypes.data_as(C.POINTER(C.c_uint64)), acc.ctypes.data_as(u8p), _dp(p))
+        assert rc == 0, rc
+        m = res.n_msckf
+        return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned, status=res.status,
+                    ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=0, n_init=0, n_truncated=res.n_truncated)
+
+    def _line_opt(self, max_obs, t_prev_frame, state_time, window_full, chi2_mult):
+        pkg = self.pkg
+        return pkg.PlvUpdateOptions(0, max_obs, chi2_mult, pkg.PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0, 0, 0,
+                                    None, 10, None)
+
+    def get_line_features(self, st, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0):
+        opt = self._line_opt(max_obs, t_prev_frame, state_time, window_full, chi2_mult)
+        rc = self.lib.orc_frame_get_line_features(self.h, C.addressof(st.c), C.addressof(opt))
+        assert rc == 0, rc
+
+    def update_lines(self, P, st, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512):
+        opt = self._line_opt(max_obs, t_prev_frame, state_time, window_full, chi2_mult)
+        res = self.pkg.PlvUpdateResult()
+        n = P.shape[0]
+        dx, ids, acc, lg = np.zeros(n), np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))
+        rc = self.lib.orc_frame_update_lines(self.h, *self._P(P), C.addressof(st.c), C.addressof(opt), _dp(dx), C.addressof(res),
+                                             ids.ctypes.data_as(C.POINTER(C.c_uint64)), acc.ctypes.data_as(u8p), _dp(lg), cap)
+        assert rc == 0, rc
+        m = res.n_msckf
+        return dict(dx=dx, n_pool=res.n_pool, n_lines=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned, status=res.status,
+                    ids=ids[:m].copy(), accepted=acc[:m].copy(), line_FinG=lg[:m].copy())
+
+    def camera_frame(self, P, st, timestamp, img, mask=None, use_lines=False, update=None):
+        """orc_frame_camera_frame with the structures of Context.camera_frame; update = the argument dict of Context._try_update_io"""
+        pkg = self.pkg
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        io, results = pkg.Context._try_update_io(None, **update) if update is not None else (None, None)
+        f = pkg.PlvCameraFrameIo(float(timestamp), -1, img.ctypes.data, img.shape[1], m.ctypes.data if m is not None else None, 1 if use_lines else 0,
+                                 C.addressof(io) if io is not None else None, 0)
+        if P is None:
+            assert update is None
+            rc = self.lib.orc_frame_camera_frame(self.h, None, 0, 0, C.addressof(st.c), C.addressof(f), _dp(self.timing_ms))
+        else:
+            rc = self.lib.orc_frame_camera_frame(self.h, *self._P(P), C.addressof(st.c), C.addressof(f), _dp(self.timing_ms))
+        assert rc == 0, rc
+        if results is None:
+            return None, None, f.line_db_size
+        pts, lns, _ = results()
+        return pts, lns, f.line_db_size
+
+    def try_update(self, P, st, update):
+        io, results = self.pkg.Context._try_update_io(None, **update)
+        rc = self.lib.orc_frame_try_update(self.h, *self._P(P), C.addressof(st.c), C.addressof(io))
+        assert rc == 0, rc
+        return results()
+
+    # ---- inspection
+    def tracker_last(self):
+        n = self.lib.orc_frame_tracker_last(self.h, None, None, 0)
+        pts, ids = np.zeros((n, 2), dtype=np.float32), np.zeros(n, dtype=np.uint64)
+        if n:
+            self.lib.orc_frame_tracker_last(self.h, pts.ctypes.data_as(fp), ids.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return pts, ids
+
+    def line_last(self):
+        n = self.lib.orc_frame_line_last(self.h, None, None, 0)
+        ln, ids = np.zeros((n, 4), dtype=np.float32), np.zeros(n, dtype=np.uint64)
+        if n:
+            self.lib.orc_frame_line_last(self.h, ln.ctypes.data_as(fp), ids.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return ln, ids
+
+    def db_size(self):
+        return self.lib.orc_frame_db_size(self.h)
+
+    def line_db_size(self):
+        return self.lib.orc_frame_line_db_size(self.h)
+
+    def used_size(self):
+        return self.lib.orc_frame_used_size(self.h)
+
+    def lines_detected(self):
+        return self.lib.orc_frame_lines_detected(self.h)
+
+    def db_ids(self, lines=False):
+        fn = self.lib.orc_frame_line_db_ids if lines else self.lib.orc_frame_db_ids
+        n = fn(self.h, None, None, 0)
+        ids, cnt = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.int32)
+        if n:
+            fn(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), _ip(cnt), n)
+        return ids, cnt
+
+    def db_track(self, fid):
+        m = self.lib.orc_frame_db_track(self.h, int(fid), None, None, None, 0)
+        if m < 0:
+            return None
+        t, uv, uvn = np.zeros(m), np.zeros((m, 2), dtype=np.float32), np.zeros((m, 2), dtype=np.float32)
+        self.lib.orc_frame_db_track(self.h, int(fid), _dp(t), uv.ctypes.data_as(fp), uvn.ctypes.data_as(fp), m)
+        return t, uv, uvn
+
+    def line_db_track(self, lid):
+        D, npt = C.c_int(), C.c_int()
+        m = self.lib.orc_frame_line_db_track(self.h, int(lid), None, None, None, 0, C.byref(D), C.byref(npt))
+        if m < 0:
+            return None
+        t, uv, uvn = np.zeros(m), np.zeros((m, 4), dtype=np.float32), np.zeros((m, 4), dtype=np.float32)
+        self.lib.orc_frame_line_db_track(self.h, int(lid), _dp(t), uv.ctypes.data_as(fp), uvn.ctypes.data_as(fp), m, C.byref(D), C.byref(npt))
+        return t, uv, uvn, D.value, npt.value
+
+    def db_append(self, fid, t, uv, uvn):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32).reshape(-1, 2)
+        self.lib.orc_frame_db_append(self.h, int(fid), len(t), _dp(t), uv.ctypes.data_as(fp), uvn.ctypes.data_as(fp))
+
+    def line_db_append(self, lid, t, uv, uvn, D=0, point_ids=()):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 4)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32).reshape(-1, 4)
+        pid = np.ascontiguousarray(point_ids, dtype=np.int32)
+        self.lib.orc_frame_line_db_append(self.h, int(lid), len(t), _dp(t), uv.ctypes.data_as(fp), uvn.ctypes.data_as(fp), int(D),
+                                          _ip(pid) if len(pid) else None, len(pid))
+
+    def used_insert(self, fid, p, newest):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self.lib.orc_frame_used_insert(self.h, int(fid), _dp(p), float(newest))
+
+    def db_cleanup_measurements(self, t):
+        self.lib.orc_frame_db_cleanup_measurements(self.h, float(t))
