@@ -2,30 +2,39 @@
 """bench.py — frames/sec of the reference's per-frame camera path (track + EKF update) on MI355X.
 
 One "step" = one camera frame through UpdaterCamera::feed_measurement + try_update (REF: PL-VIWO/src/update/cam/UpdaterCamera.cpp:
-77-116,139-195) of a running filter, every call through the C-ABI of libplviwo_hip.so:
-    plv_tracker_feed_staged   TrackKLT::feed_new_camera / feed_monocular: equalizeHist, 5-level pyramid, FAST top-up detection on the
+77-116,139-195) of a running filter, one call through the C-ABI of libplviwo_hip.so (plv_camera_frame), which runs
+    plv_tracker_feed[_staged] TrackKLT::feed_new_camera / feed_monocular: equalizeHist, 5-level pyramid, FAST top-up detection on the
                               last image (+ cornerSubPix), pyramidal LK, radtan undistortion, 7-point RANSAC, FeatureDatabase update
     plv_vanishing_points + plv_line_tracker_feed
                               TrackLSD::feed_monocular: half-resolution Canny + fast line detector, point-line assignment with the
                               frame's tracked points, line matching, undistortion, classification, LineFeatureDatabase update
-    plv_camera_update_points  get_features (pool, unusable measurements, sort, triangulation + refinement, 3 px consistency, cap) ->
-                              msckf_update (Jacobians, null space, chi2 gate, compression, EKFUpdate, fp64) -> cleanup_features
-    (the driver applies dx to its state, as StateHelper::EKFUpdate does)
-    plv_camera_update_lines   get_line_features -> lines_update -> cleanup_lines
-The stream is a rendered drive (tests/synth_dataset.py, "street" scene: a camera on a wheeled vehicle going down a corridor with
+    plv_camera_try_update     get_features (pool, unusable measurements, sort, triangulation + refinement, 3 px consistency, cap) ->
+                              get_line_features' state recorded -> msckf_update (Jacobians, null space, chi2 gate, compression,
+                              EKFUpdate, fp64) -> cleanup_features -> dx applied -> get_line_features + lines_update ->
+                              cleanup_lines -> dx applied
+The stream is a rendered drive (tests/synth_dataset.py, "avenue" scene: a camera on a wheeled vehicle going down a corridor with
 facades, 200 Hz IMU, 50 Hz wheel odometry); the update consumes the tracker's own database.  Between two frames the driver
 (pl-viwo_amd/system.py = SystemManager) feeds the IMU and wheel messages: plv_propagate, plv_cov_clone, plv_cov_marginalize,
-plv_wheel_update run for real but outside the timed step, and the next image is staged into HBM (plv_image_stage) there too.
-`value` = K / (sum over the K timed steps of the step's wall time, device synchronised at both ends).
+plv_wheel_update run for real but outside the timed step.
 
-Workloads: C (default) = BASELINE configs[2], the configuration the metric is quoted on (752x480, 250 points + lines, 15-clone
-window); B = configs[1] (no lines); D = configs[3] (1280x720, 500 points + lines, 20-clone window).
+Two timed segments of K steps each over consecutive frames of the stream: (1) the image already resident in HBM when the step starts
+(plv_image_stage between the steps) -> `value`; (2) the image handed over as a host buffer, its PCIe copy inside the step ->
+`config.pcie_inclusive`.  Every step ends with plv_ctx_synchronize (ctx stream, the detection side stream, the line worker).
+`value` = K / (sum over the K timed steps of the step's wall time).
+
+`cpu_baseline`: the same frames through oracle/frame_oracle.cpp (the CPU frame compiled end to end, g++ -O3), timed inside the
+library with std::chrono::steady_clock.  `config.stress`: the update chain alone at SURVEY §8(d)'s sizing (F = 70 features x 15
+observations, then L = 80 lines x 15) on the HIP library and on the oracle.
+
+Workloads: C (default) = BASELINE configs[2], the configuration the metric is quoted on (752x480, 250 tracked points + lines,
+15-clone window); B = configs[1] (no lines); D = configs[3] (1280x720, 500 points + lines, 20-clone window).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; N > 1 is launched by torchrun, one rank per GPU.  The path does not shard
 ("replicas only"): N ranks run N independent replicas of the same stream, `value` is their aggregate frames/s
 ("weak" scaling), no data-path collective.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -40,24 +49,37 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 WORKLOADS = {
-    # name: (width, height, camera Hz = clone Hz, points, lines, BASELINE config)
-    "B": dict(w=752, h=480, hz=15, n_pts=250, lines=False, cfg="configs[1]"),
-    "C": dict(w=752, h=480, hz=15, n_pts=250, lines=True, cfg="configs[2]"),
-    "D": dict(w=1280, h=720, hz=20, n_pts=500, lines=True, cfg="configs[3]"),
+    # points = the tracked-point count the metric names; num_features = TrackKLT's n_pts setting that sustains it on this scene (the
+    # reference tops a grid cell up only while it holds fewer than half its share, TrackKLT.cpp:474-495, so the count it sustains sits
+    # at ~70 % of the setting)
+    "B": dict(w=752, h=480, hz=15, points=250, num_features=360, lines=False, cfg="configs[1]"),
+    "C": dict(w=752, h=480, hz=15, points=250, num_features=360, lines=True, cfg="configs[2]"),
+    "D": dict(w=1280, h=720, hz=20, points=500, num_features=780, lines=True, cfg="configs[3]"),
 }
+SCENE = "avenue"
 PROLOGUE = 24      # frames before the warm-up: initialisation + the first full clone window (untimed set-up)
 IMU, WHEEL, CAM = 0, 1, 2
+ROUND = "r03"
 
 
 # --------------------------------------------------------------------------------------------------------------- the stream
-def build_stream(wl, n_frames, workers):
+def build_stream(wl, n_frames, workers, cache=None):
     """Sensor streams + rendered frames of the drive, in memory.  Rendering forks worker processes: called before anything touches
-    the GPU."""
+    the GPU — or not at all when `cache` names a stream an earlier run saved (a profiled run must not fork: the profiler's library
+    has initialised the GPU before Python starts)."""
     import synth_dataset as sd
     sd.set_camera(wl["w"], wl["h"])
-    sim = sd.simulate(seconds=n_frames / wl["hz"] + 0.2, cam_hz=wl["hz"], style="street")
+    sim = sd.simulate(seconds=n_frames / wl["hz"] + 0.2, cam_hz=wl["hz"], style=SCENE)
     tc = sim["cam_times"][:n_frames]
-    imgs = sd.render_frames(tc, "street", workers)
+    imgs = None
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        if z["imgs"].shape[0] >= n_frames and z["imgs"].shape[1:] == (wl["h"], wl["w"]) and np.array_equal(z["tc"][:n_frames], tc):
+            imgs = list(z["imgs"][:n_frames])
+    if imgs is None:
+        imgs = sd.render_frames(tc, SCENE, workers)
+        if cache:
+            np.savez(cache, imgs=np.array(imgs), tc=tc)
     t, wm, am = sim["imu"]
     tw, m1, m2 = sim["wheel"]
     msgs = [(x, IMU, i) for i, x in enumerate(t)] + [(x, WHEEL, i) for i, x in enumerate(tw)] + [(x, CAM, i) for i, x in enumerate(tc)]
@@ -75,7 +97,7 @@ def load_options(wl):
     sd.set_camera(wl["w"], wl["h"])
     # the authors' KAIST settings where they apply to one camera: max_msckf 70, sigma_px 1.5, intrinsics calibrated
     # online, polynomial interpolation of order 3 with its covariance; clone rate = camera rate
-    op = options.load_options(sd.write_config(d, d, os.path.join(d, "traj.txt"), clone_freq=wl["hz"], n_pts=wl["n_pts"], max_msckf=70,
+    op = options.load_options(sd.write_config(d, d, os.path.join(d, "traj.txt"), clone_freq=wl["hz"], n_pts=wl["num_features"], max_msckf=70,
                                               calib_int=True, sigma_px=1.5))
     op.est.cam.use_lines = bool(wl["lines"])
     return op
@@ -110,9 +132,10 @@ class Player:
     def camera(self, t, i):
         if self.staged:
             self.sys.feed_measurement_camera(t, None, staged_slot=self.slot)
-            self.sys.ctx.synchronize()
         else:
             self.sys.feed_measurement_camera(t, self.s["imgs"][i])
+        if hasattr(self.sys.ctx, "synchronize"):
+            self.sys.ctx.synchronize()     # ctx stream + detection side stream + line worker
 
 
 def pct(a, q):
@@ -120,93 +143,148 @@ def pct(a, q):
 
 
 # --------------------------------------------------------------------------------------------------------------- CPU baseline
-class TimedLib:
-    """Forwards to a ctypes library and accumulates the wall time spent inside its functions."""
-    total = 0.0
-
-    def __init__(self, lib):
-        object.__setattr__(self, "_lib", lib)
-
-    def __getattr__(self, name):
-        fn = getattr(self._lib, name)
-
-        def call(*a):
-            t0 = time.perf_counter()
-            try:
-                return fn(*a)
-            finally:
-                TimedLib.total += time.perf_counter() - t0
-        return call
-
-
-def cpu_baseline(wl, stream, n_frames, budget_s, threads):
-    """The same driver over the CPU oracle (tests/oracle_context.py: fp64 / OpenCV-contract restatement of the same calls, g++ -O3):
-    per-frame wall time of feed_measurement_camera on the host, mean / p50 / p99, 1 thread and `threads` threads for the stage the
-    reference parallelises (cv::parallel_for_ in calcOpticalFlowPyrLK).  kind = "port": the upstream binary cannot be built (Eigen /
-    OpenCV / Boost / ROS absent — DESIGN.md §5).  `inside_oracle` = the part of that time spent inside liboracle.so (the rest is the
-    Python bookkeeping of the mirror: database, selection lists)."""
+def cpu_baseline(wl, stream, n_frames, budget_s, thread_counts):
+    """The same frames through the compiled CPU frame (oracle/frame_oracle.cpp behind tests/oracle_context.py: the reference's
+    feed_measurement + try_update restated in C++ fp64 / OpenCV-contract arithmetic, g++ -O3): per-frame time measured INSIDE the
+    library with std::chrono::steady_clock (`value`), and the wall time of the driver's call around it.  1 thread, and more threads
+    for the one stage the reference parallelises (cv::parallel_for_ in calcOpticalFlowPyrLK).  kind = "port": the upstream binary
+    cannot be built (Eigen / OpenCV / Boost / ROS absent — DESIGN.md §5)."""
     import importlib
     import __graft_entry__ as ge
     ge.load_pkg()
     import oracle_context as oc
     system = importlib.import_module("plviwo_amd.system")
     out = {}
-    for label, nthr in (("1_thread", 1), ("n_threads", threads)):
-        if nthr == 1 and label != "1_thread":
-            continue
+    for nthr in thread_counts:
         sm = system.SystemManager(load_options(wl), context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer)
         ctx = sm.ctx
         ctx.lk_threads = nthr
-        for o in (ctx.o, ctx.fo, ctx.do, ctx.jo, ctx.lo):
-            if not isinstance(o.lib, TimedLib):
-                o.lib = TimedLib(o.lib)
         pl = Player(stream, sm, staged=False)
-        per, inside, t_begin = [], [], time.perf_counter()
-        frames = n_frames if nthr == 1 else max(20, n_frames // 4)
+        per, inside, parts, t_begin = [], [], [], time.perf_counter()
+        frames = n_frames if nthr == thread_counts[0] else max(20, n_frames // 4)
+        tracked, kept = [], []
         for f in range(PROLOGUE + frames):
             nf = pl.next_frame()
             if nf is None or (f >= PROLOGUE + 20 and time.perf_counter() - t_begin > budget_s):
                 break
-            TimedLib.total = 0.0
+            tm0 = ctx.frame.timing_ms.copy()
             t0 = time.perf_counter()
             pl.camera(*nf)
             dt = time.perf_counter() - t0
             if f >= PROLOGUE:
+                d = ctx.frame.timing_ms - tm0
                 per.append(dt * 1e3)
-                inside.append(TimedLib.total * 1e3)
+                inside.append(d[5])
+                parts.append(d[:5])
+                tracked.append(len(ctx.tracker_last()[1]))
+                kept.append(len(ctx.line_tracker_last()[1]))
         st = sm.stats
-        out[label] = dict(threads=nthr, frames=len(per), mean_ms=float(np.mean(per)), p50_ms=pct(per, 50), p99_ms=pct(per, 99),
-                          inside_oracle_mean_ms=float(np.mean(inside)),
-                          split_ms={k.replace("[Time-Cam] ", ""): round(v / max(1, sm.tc.count[k]) * 1e3, 3) for k, v in sm.tc.total.items()
-                                    if k.startswith("[Time-Cam]")},
-                          cam_features=st["cam_features"], cam_accepted=st["cam_accepted"], lines_accepted=st["lines_accepted"])
-        for o in (ctx.o, ctx.fo, ctx.do, ctx.jo, ctx.lo):
-            if isinstance(o.lib, TimedLib):
-                o.lib = o.lib._lib
+        parts = np.mean(parts, axis=0)
+        out[f"{nthr}_thread" + ("s" if nthr > 1 else "")] = dict(
+            threads=nthr, frames=len(per), inside_mean_ms=float(np.mean(inside)), inside_p50_ms=pct(inside, 50), inside_p99_ms=pct(inside, 99),
+            driver_call_mean_ms=float(np.mean(per)),
+            split_ms={"feed points (equalize, pyramid, detection, LK, RANSAC, database)": round(parts[0], 3), "feed lines": round(parts[1], 3),
+                      "get_features + msckf_update + cleanup": round(parts[2], 3), "get_line_features": round(parts[3], 3),
+                      "lines_update + cleanup": round(parts[4], 3)},
+            tracked_points=round(float(np.mean(tracked)), 1), lines_kept=round(float(np.mean(kept)), 1),
+            cam_features=st["cam_features"], cam_accepted=st["cam_accepted"], lines_accepted=st["lines_accepted"])
+        sm.close()
     one = out["1_thread"]
-    return {"value": 1e3 / one["mean_ms"], "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{one['frames']} frames of the same stream through the same driver over the CPU oracle (liboracle.so, g++ -O3): "
-                      f"feed_measurement + try_update {one['mean_ms']:.2f} ms mean / {one['p50_ms']:.2f} p50 / {one['p99_ms']:.2f} p99 per frame on 1 "
-                      f"thread, of which {one['inside_oracle_mean_ms']:.2f} ms inside the oracle library; host has {os.cpu_count()} cores",
+    return {"value": 1e3 / one["inside_mean_ms"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{one['frames']} frames of the same stream through oracle/frame_oracle.cpp (feed_measurement + try_update compiled end to "
+                      f"end, g++ -O3, timed inside the library with steady_clock): {one['inside_mean_ms']:.2f} ms mean / {one['inside_p50_ms']:.2f} p50 / "
+                      f"{one['inside_p99_ms']:.2f} p99 per frame on 1 thread ({one['driver_call_mean_ms']:.2f} ms with the Python driver's call around "
+                      f"it); host has {os.cpu_count()} cores",
             "detail": out}
 
 
+# --------------------------------------------------------------------------------------------------------------- stress leg
+def stress_update(pkg, device, steps, with_cpu):
+    """SURVEY §8(d)'s update sizing on its own: F = 70 MSCKF features x 15 observations (k = 98 of n = 113), then L = 80 lines x 15
+    observations, each as Jacobians + null space + gate + compression + EKFUpdate on the resident covariance (restored every step so
+    that every step does the same work); the same two updates on the CPU oracle."""
+    import bench_chain as bc
+    import synth
+    cfg = pkg.default_config(752, 480)
+    cfg.device = device
+    ctx = pkg.Context(cfg)
+    scene = synth.vio_scene(n_clones=15, F=bc.F_FEATS, M=bc.M_OBS, seed=3, noise_px=0.4)
+    st, tr = synth.scene_views(pkg, scene)
+    cols = ctx.jacobian_columns(st, tr)
+    ls = synth.line_scene(scene, L=bc.N_LINES, M=bc.M_OBS, noise_px=0.4)
+    lt = pkg.LineTracks(ls["obs_ptr"], ls["obs_time"], ls["seg_uv"], seg_uvn=ls["seg_uvn"], line_FinG=ls["lines"])
+    cols_l = ctx.line_jacobian_columns(st, lt)
+    P = synth.spd_cov(scene["n_state"])
+    ctx.cov_upload(P)
+    ctx.cov_checkpoint()
+    n = scene["n_state"]
+    acc = [0, 0]
+
+    def one():
+        ctx.cov_rollback()
+        ctx.build_jacobians_resident(st, tr, cols, 2 * bc.M_OBS)
+        rc, dx, a, nr = ctx.msckf_update_resident(n, bc.SIGMA2)
+        acc[0] = int(a.sum())
+        ctx.build_line_jacobians_resident(st, lt, cols_l, bc.LINE_LD)
+        rc2, dx2, a2, nr2 = ctx.msckf_update_resident(n, bc.SIGMA2, res_norm_gate=0.0)
+        acc[1] = int(a2.sum())
+        if rc != 0 or rc2 != 0:
+            raise RuntimeError("stress update rejected")
+
+    for _ in range(5):
+        one()
+    ctx.synchronize()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        one()
+        ctx.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(10):
+        one()
+    ctx.prof_enable(False)
+    table = {k: v for k, v in ctx.prof_table().items() if v[0] > 0}
+    ctx.close()
+    out = {"what": f"update chain alone: F = {bc.F_FEATS} features x {bc.M_OBS} observations (k = {len(cols)}, n = {n}), then L = {bc.N_LINES} lines x "
+                   f"{bc.M_OBS} (k = {len(cols_l)}): Jacobians + null space + chi2 gate + compression + EKFUpdate each, covariance restored per step",
+           "ms_per_step": float(np.mean(ts)), "p50_ms": pct(ts, 50), "steps": steps, "accepted_features": acc[0], "accepted_lines": acc[1],
+           "kernels_us_per_step": {k: round(v[1] / 10 * 1e3, 2) for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])}}
+    if with_cpu:
+        import oracle_lib
+        orc, jo = oracle_lib.load(), oracle_lib.load_jac(pkg)
+        q95 = synth.q95_table()
+        cs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rows, Hf, Hx, res = jo.build_jacobians(st, tr, jo.columns(st, tr), 2 * bc.M_OBS)
+            rc, P1, _, _, _ = orc.msckf_update(P, rows, Hf, Hx, res, jo.columns(st, tr), bc.SIGMA2, q95)
+            rows, Hf, Hx, res = jo.build_line_jacobians(st, lt, jo.line_columns(st, lt), bc.LINE_LD)
+            orc.msckf_update(P1, rows, Hf, Hx, res, jo.line_columns(st, lt), bc.SIGMA2, q95, res_norm_gate=0.0)
+            cs.append((time.perf_counter() - t0) * 1e3)
+        out["cpu_oracle_ms_per_step"] = float(np.min(cs))
+        out["ratio_vs_cpu_oracle"] = out["cpu_oracle_ms_per_step"] / out["ms_per_step"]
+    return out
+
+
 # --------------------------------------------------------------------------------------------------------------- roofline
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this round (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs, profiles/r02/README.md); None when the summary is missing."""
-    import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "bench_*_pmc_hbm.csv")))
+def pmc_table():
+    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    profiles/rNN/README.md): the newest summary of this workload family; {} when none is committed."""
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*", "bench_c_pmc_hbm.csv")))
     if not found:
-        return None, None
+        return {}, None
     path = found[-1]
+    out = {}
     with open(path) as fh:
         next(fh)
         for line in fh:
             k, n, f_kb, w_kb = line.strip().split(",")
-            if k.split("<")[0].endswith(kernel):
-                return (float(f_kb) + float(w_kb)) * 1024.0, os.path.relpath(path, ROOT) + " (FETCH_SIZE + WRITE_SIZE, KB)"
-    return None, None
+            k = k.split("<")[0]
+            if k and f_kb != "nan" and w_kb != "nan":
+                out[k] = (float(f_kb) + float(w_kb)) * 1024.0
+    return out, os.path.relpath(path, ROOT) + " (FETCH_SIZE + WRITE_SIZE, KB per dispatch)"
 
 
 def reduce_max(elapsed, dist):
@@ -227,8 +305,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=200)
     ap.add_argument("--cpu-budget-s", type=float, default=40.0, help="upper bound of the CPU baseline's wall time per pass")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--host-images", action="store_true", help="PCIe-inclusive variant: plv_tracker_feed with the host image")
+    ap.add_argument("--no-stress", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the second timed segment (host images)")
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
+    ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     args = ap.parse_args()
@@ -242,11 +322,12 @@ def main():
     stream = None
     if not args.dry_run:
         nprof = max(10, min(40, args.steps))
-        n_gpu_frames = PROLOGUE + args.warmup + args.steps + nprof
+        seg2 = 0 if args.no_pcie else args.steps
+        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof
         n_cpu_frames = 0 if (args.no_cpu or rank != 0) else PROLOGUE + args.cpu_frames
         workers = args.render_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
         t0 = time.perf_counter()
-        stream = build_stream(wl, max(n_gpu_frames, n_cpu_frames), workers)
+        stream = build_stream(wl, max(n_gpu_frames, n_cpu_frames), workers, args.stream_cache)
         t_render = time.perf_counter() - t0
 
     dist = None
@@ -284,50 +365,55 @@ def main():
     op = load_options(wl)
     sm = system.SystemManager(op, device=device)
     ctx = sm.ctx
-    pl = Player(stream, sm, staged=not args.host_images)
+    pl = Player(stream, sm, staged=True)
 
-    per_frame = {"kept": [], "tracked": []}
-    cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected")}
-
-    def sample_counts(f):
-        per_frame["tracked"].append(len(ctx.tracker_last()[1]))
-        if wl["lines"]:
-            per_frame["kept"].append(len(ctx.line_tracker_last()[1]))
+    def timed_segment(n_steps):
+        per_frame = {"kept": [], "tracked": []}
+        cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected")}
+        base = dict(sm.stats)
+        tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
+        ctx.synchronize()
+        barrier()
+        elapsed, per = 0.0, []
+        for f in range(n_steps):
+            nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
+            c0 = pkg.counters()
+            t0 = time.perf_counter()
+            pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
+            dt = time.perf_counter() - t0
+            elapsed += dt
+            per.append(dt * 1e3)
+            c1 = pkg.counters()
+            for k in cnt:
+                cnt[k] += c1[k] - c0[k]
+            per_frame["tracked"].append(len(ctx.tracker_last()[1]))
+            if wl["lines"]:
+                per_frame["kept"].append(len(ctx.line_tracker_last()[1]))
+        ctx.synchronize()
+        barrier()
+        stats = {k: sm.stats[k] - base.get(k, 0) for k in sm.stats}
+        split = {}
+        for k, v in sm.tc.total.items():
+            if k.startswith("[Time-Cam]"):
+                a, c = tc0.get(k, (0.0, 0))
+                split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
+        return dict(elapsed=reduce_max(elapsed, dist), per=per, per_frame=per_frame, cnt=cnt, stats=stats, split=split)
 
     for f in range(PROLOGUE + args.warmup):
         pl.camera(*pl.next_frame())
     if not sm.state.initialized or len(sm.state.clones) < wl["hz"] - 1:
         raise RuntimeError("the filter did not reach a full window during the prologue")
-    base = dict(sm.stats)
-    tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
-    ctx.synchronize()
-    barrier()
-    elapsed, per = 0.0, []
-    for f in range(args.steps):
-        nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation, staging of the image
-        c0 = pkg.counters()
-        t0 = time.perf_counter()
-        pl.camera(*nf)                  # timed: feed_measurement + try_update, synchronised
-        dt = time.perf_counter() - t0
-        elapsed += dt
-        per.append(dt * 1e3)
-        c1 = pkg.counters()
-        for k in cnt:
-            cnt[k] += c1[k] - c0[k]
-        sample_counts(f)
-    ctx.synchronize()
-    barrier()
-    stats = {k: sm.stats[k] - base.get(k, 0) for k in sm.stats}
-    split = {}
-    for k, v in sm.tc.total.items():
-        if k.startswith("[Time-Cam]"):
-            a, c = tc0.get(k, (0.0, 0))
-            split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
+    seg = timed_segment(args.steps)                                   # (1) images resident in HBM -> `value`
+    seg_pcie = None
+    if not args.no_pcie:
+        pl.staged = False
+        seg_pcie = timed_segment(args.steps)                          # (2) host images: the PCIe copy inside the step
+        pl.staged = True
+    elapsed, per, per_frame, cnt, stats, split = (seg[k] for k in ("elapsed", "per", "per_frame", "cnt", "stats", "split"))
     n_state = sm.state.n
-    elapsed = reduce_max(elapsed, dist)
 
-    # ---- roofline leg: HIP events around every kernel launch on the ctx stream (a separate pass over the next frames of the stream,
-    # so that the event records do not perturb the timed region above)
+    # ---- roofline leg: HIP events around every kernel launch of the camera step, on the stream each kernel is launched on (a separate
+    # pass over the next frames of the stream, same schedule as the timed passes, so that the event records do not perturb them)
     roof = None
     if rank == 0:
         import work_model as wm
@@ -342,53 +428,84 @@ def main():
             pl.camera(*nf)
             ctx.prof_enable(False)
             done += 1
+        ctx.synchronize()
         table = ctx.prof_table()
         s2 = {k: sm.stats[k] - b2.get(k, 0) for k in sm.stats}
-        upd = max(1, s2["cam_updates"])
         F = s2["cam_features"] / max(1, done)
         L = s2["lines_triangulated"] / max(1, done)
         k_cols = n_state - 15 - 6    # every clone + the intrinsics (the IMU pose of the newest frame excluded)
         M = wl["hz"]
-        work = wm.frame_work(wl["w"], wl["h"], ctx.pyramid_levels(0), int(np.mean(per_frame["tracked"])), cnt["lk_iters"] / args.steps, 15, F, M, k_cols,
-                             n_state, L=L, Ml=max(2, M // 3), kl=k_cols, n_new=max(1, wl["n_pts"] // M),
+        tracked = int(np.mean(per_frame["tracked"]))
+        work = wm.frame_work(wl["w"], wl["h"], ctx.pyramid_levels(0), tracked, cnt["lk_iters"] / args.steps, 15, F, M, k_cols,
+                             n_state, L=L, Ml=max(2, M // 3), kl=k_cols, n_new=max(1, wl["num_features"] // M),
                              pool_pts=stats["cam_features"] / max(1, args.steps) * 1.5, pool_lines=stats["line_pool"] / max(1, args.steps))
         kernels = {k: v for k, v in table.items() if v[0] > 0}
-        name, (n_launch, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
-        kind, per_launch = work.get(name, ("hbm", 0.0))
-        avg_s = ms / max(n_launch, 1) * 1e-3
-        if kind == "hbm":
-            achieved, peak, unit = per_launch / avg_s / 1e9, wm.HBM_PEAK_GBS, "GB/s"
-        else:
-            achieved, peak, unit = per_launch / avg_s / 1e12, wm.F64_MFMA_PEAK_TF, "TFLOP/s"
-        traffic, traffic_src = pmc_traffic(name)
-        roof = {"bound": kind, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
-                "traffic_source": traffic_src, "kernel": name, "avg_launch_us": avg_s * 1e6, "algorithmic_per_launch": per_launch,
+        traffic_tab, traffic_src = pmc_table()
+
+        def entry(name):
+            n_launch, ms = kernels[name]
+            kind, per_launch = work.get(name, ("hbm", 0.0))
+            avg_s = ms / max(n_launch, 1) * 1e-3
+            if kind == "hbm":
+                achieved, peak, unit = per_launch / avg_s / 1e9, wm.HBM_PEAK_GBS, "GB/s"
+            else:
+                achieved, peak, unit = per_launch / avg_s / 1e12, wm.F64_MFMA_PEAK_TF, "TFLOP/s"
+            tr = traffic_tab.get(name)
+            return {"kernel": name, "bound": kind, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_frame": round(n_launch / max(1, done), 2),
+                    "us_per_frame": round(ms / max(1, done) * 1e3, 2), "algorithmic_per_launch": per_launch, "achieved": achieved, "peak": peak,
+                    "unit": unit, "frac": achieved / peak, "traffic": tr,
+                    "traffic_over_algorithmic": (round(tr / per_launch, 2) if (tr and per_launch and kind == "hbm") else None)}
+
+        order = sorted(kernels, key=lambda k: -kernels[k][1])
+        top = entry(order[0])
+        roof = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                "traffic": top["traffic"], "traffic_source": traffic_src, "kernel": top["kernel"], "avg_launch_us": top["avg_launch_us"],
+                "algorithmic_per_launch": top["algorithmic_per_launch"],
                 "launches_per_frame": round(sum(v[0] for v in kernels.values()) / max(1, done), 1),
                 "kernel_us_per_frame_total": round(sum(v[1] for v in kernels.values()) / max(1, done) * 1e3, 1),
-                "kernels_us_per_frame": {k: round(v[1] / max(1, done) * 1e3, 2) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][1])},
-                "kernels_launches_per_frame": {k: round(v[0] / max(1, done), 2) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][1])}}
+                "per_kernel": [entry(k) for k in order[:8]],
+                "kernels_us_per_frame": {k: round(kernels[k][1] / max(1, done) * 1e3, 2) for k in order},
+                "note": "traffic = counter bytes per dispatch from the committed PMC pass named in traffic_source (an earlier run of this "
+                        "workload: same kernels, sizes of that run); mfma-class entries are latency-bound fp64 chains, their frac is against the "
+                        "dense fp64 MFMA peak"}
     sm.close()
+
+    stress = None
+    if rank == 0 and not args.no_stress:
+        stress = stress_update(pkg, device, max(20, min(100, args.steps)), not args.no_cpu)
 
     cpu = None
     if rank == 0 and not args.no_cpu:
-        cpu = cpu_baseline(wl, stream, args.cpu_frames, args.cpu_budget_s, max(1, min(16, os.cpu_count() or 1)))
+        cpu = cpu_baseline(wl, stream, args.cpu_frames, args.cpu_budget_s, [1, 4, max(1, min(16, os.cpu_count() or 1))])
 
     if rank == 0:
         mean = lambda a: (round(float(np.mean(a)), 1) if len(a) else None)
-        what = f"{wl['w']}x{wl['h']} mono, {wl['n_pts']} KLT points (15x15 window, 5 pyramid levels)"
+        what = (f"{wl['w']}x{wl['h']} mono, {mean(per_frame['tracked'])} KLT points tracked per frame (TrackKLT n_pts {wl['num_features']}; 15x15 "
+                "window, 5 pyramid levels)")
         if wl["lines"]:
             what += (f" + line front-end (half-resolution Canny + fast line detector: {cnt['lines_detected'] / args.steps:.1f} segments detected, "
                      f"{mean(per_frame['kept'])} kept per frame by the reference's point-line assignment, whose bounding-box test reads the "
-                     "end-point coordinates in the wrong order and drops about three of four lines that own a point)")
+                     "end-point coordinates in the wrong order and drops most lines that own a point: the metric's 80 kept lines are not reachable "
+                     "with it; config.stress runs the 80-line update)")
+        ms_step = elapsed / args.steps * 1e3
+        vs = {}
+        if cpu is not None:
+            one = cpu["detail"]["1_thread"]
+            vs = {"cpu_compiled_ms_per_frame": one["inside_mean_ms"], "speedup_resident": one["inside_mean_ms"] / ms_step}
+            if seg_pcie is not None:
+                vs["speedup_pcie_inclusive"] = one["inside_mean_ms"] / (seg_pcie["elapsed"] / args.steps * 1e3)
+            for key, d in cpu["detail"].items():
+                if key != "1_thread":
+                    vs[f"speedup_vs_cpu_{key}"] = d["inside_mean_ms"] / ms_step
         line = {
             "metric": ("frames/sec (track+EKF update), 752x480 mono, 250 pts+80 lines; ATE vs CPU ref" if args.workload == "C" else
-                       f"frames/sec (track+EKF update), {wl['w']}x{wl['h']} mono, {wl['n_pts']} pts" + (" + lines" if wl["lines"] else "")),
+                       f"frames/sec (track+EKF update), {wl['w']}x{wl['h']} mono, {wl['points']} pts" + (" + lines" if wl["lines"] else "")),
             "value": args.steps * world / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -396,13 +513,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE {wl['cfg']}: {what}; {wl['hz']}-clone window ({wl['hz']} Hz camera and clones, 1 s), n = {n_state}; "
-                            "rendered street-corridor drive with IMU + wheel odometry; the update consumes the tracker's own database",
-                "step": "plv_camera_frame = plv_tracker_feed_staged -> plv_vanishing_points + plv_line_tracker_feed -> plv_camera_try_update "
-                        "(plv_camera_update_points -> dx applied -> plv_camera_update_lines -> dx applied); sequential, device synchronised at both "
-                        "ends of every step; IMU propagation, cloning, marginalisation, wheel updates and image staging run between the steps, "
-                        "untimed",
+                            "rendered corridor drive ('avenue' scene) with IMU + wheel odometry; the update consumes the tracker's own database",
+                "step": "plv_camera_frame = plv_tracker_feed[_staged] -> plv_vanishing_points + plv_line_tracker_feed -> plv_camera_try_update "
+                        "(plv_camera_update_points -> plv_camera_get_line_features -> dx applied -> plv_camera_update_lines -> dx applied), then "
+                        "plv_ctx_synchronize (ctx stream, detection side stream, line worker); sequential; IMU propagation, cloning, "
+                        "marginalisation and wheel updates run between the steps, untimed",
                 "replicas": world, "n_state": n_state,
+                "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0, "library_segment_fitters": 2 if wl["lines"] else 0,
+                                 "note": "the library's threads run the line detector's host stage (chain walk + segment growth) and the line "
+                                         "tracker's bookkeeping next to the caller's thread; they poll for up to 2 ms after a hand-over, then block"},
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
+                "pcie_inclusive": None if seg_pcie is None else {
+                    "what": "second timed segment, the next frames of the stream: the image is a host buffer (plv_tracker_feed), its "
+                            f"{wl['w'] * wl['h'] // 1024} KB PCIe copy inside the step",
+                    "value": args.steps * world / seg_pcie["elapsed"], "ms_per_step": seg_pcie["elapsed"] / args.steps * 1e3,
+                    "latency_ms": {"mean": float(np.mean(seg_pcie["per"])), "p50": pct(seg_pcie["per"], 50), "p99": pct(seg_pcie["per"], 99)}},
+                "vs_cpu": vs,
                 "host_split_ms_per_frame": split,
                 "per_frame": {"tracked_points": mean(per_frame["tracked"]), "lines_detected": round(cnt["lines_detected"] / args.steps, 1),
                               "lines_kept": mean(per_frame["kept"]),
@@ -416,8 +542,9 @@ def main():
                                           "lk_iterations": round(cnt["lk_iters"] / args.steps)},
                 "updates": {"point_updates": stats["cam_updates"], "line_updates": stats["line_updates"], "not_psd": stats["not_psd"],
                             "frames": args.steps},
-                "images": "host (PCIe inside the step)" if args.host_images else "resident in HBM (plv_image_stage between the steps)",
+                "images": "resident in HBM (plv_image_stage between the steps); config.pcie_inclusive has the host-buffer variant",
                 "front_end_arithmetic": "u8/int16/int64 exact + f32 2x2 solve", "update_arithmetic": "f64",
+                "stress": stress,
                 "render_s": round(t_render, 1),
             },
             "roofline": roof,

@@ -593,8 +593,17 @@ int plv_line_db_append_measurements(plv_ctx *ctx, uint64_t id, int n, const doub
  * examined; this entry point lets a caller with its own point pipeline do the same. */
 int plv_point_used_insert(plv_ctx *ctx, uint64_t id, const double *p_FinG, double newest_obs_time);
 
+/* LineHelper::get_line_features' place in try_update (REF: UpdaterCamera.cpp:148-152): the reference forms and triangulates the
+ * line pool after get_features and BEFORE msckf_update's correction reaches the state; lines_update then linearises on the
+ * updated state.  Call this with the state as it is before the dx of plv_camera_update_points is applied: it records the clone
+ * poses / extrinsics / time offset the following plv_camera_update_lines triangulates on (the pool and the triangulation
+ * themselves run inside that call; nothing they read changes in between).  Without it plv_camera_update_lines triangulates on
+ * the state it is handed.  plv_camera_try_update / plv_camera_frame do this themselves. */
+int plv_camera_get_line_features(plv_ctx *ctx, const plv_state_view *st);
+
 /* LineHelper::get_line_features (REF: linefeat/LineHelper.cpp:19-72: pool, remove_unusable_measurements (0.01 s
- * margins), sort by track length, line_triangulation) -> UpdaterCamera::lines_update (UpdaterCamera.cpp:371-464)
+ * margins), sort by track length, line_triangulation — on the state recorded by plv_camera_get_line_features when
+ * there is one) -> UpdaterCamera::lines_update (UpdaterCamera.cpp:371-464) on `st`
  * -> LineHelper::cleanup_lines (:522-553).  opt->max_msckf is ignored (no cap on lines).  line_ids / accepted
  * (capacity cap, may be NULL) list the lines of the update in batch order. */
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,

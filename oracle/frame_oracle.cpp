@@ -117,6 +117,7 @@ struct Frame {
   std::vector<uint64_t> rel_id_last;
   uint64_t line_currid = 1;  // REF: TrackLSD.cpp:32
   int lines_detected = 0;
+  long long lk_points = 0, lk_frames = 0;  // points handed to perform_matching, frames that tracked
   std::map<uint64_t, LnTrack> ldb;
   PreparedLines prep;
   ~Frame() {
@@ -187,6 +188,7 @@ int tracker_feed(Frame &F, double t, const uint8_t *img, int stride, const uint8
   // :134-139 temporal KLT with the previous positions as the initial flow, undistortion, RANSAC
   std::vector<float> p1(p.begin(), p.begin() + 2 * (size_t)n), n0(2 * (size_t)n), n1(2 * (size_t)n);
   std::vector<uint8_t> ok(n, 0);
+  F.lk_points += n, ++F.lk_frames;
   orc_perform_matching(F.pyr_prev, pyr, n, p.data(), p1.data(), F.K8, c.win_size, c.lk_max_iters, c.lk_eps, c.ransac_thr_px,
                        c.ransac_conf, c.ransac_max_iters, 0u, ok.data(), n0.data(), n1.data(), F.lk_threads);
   std::vector<float> good;
@@ -848,6 +850,7 @@ int orc_frame_line_last(void *h, float *lines, uint64_t *ids, int cap) {
   return n;
 }
 int orc_frame_lines_detected(void *h) { return ((Frame *)h)->lines_detected; }
+long long orc_frame_lk_points(void *h) { return ((Frame *)h)->lk_points; }
 int orc_frame_db_size(void *h) { return (int)((Frame *)h)->db.size(); }
 int orc_frame_line_db_size(void *h) { return (int)((Frame *)h)->ldb.size(); }
 int orc_frame_used_size(void *h) { return (int)((Frame *)h)->used.size(); }

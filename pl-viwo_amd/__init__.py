@@ -162,6 +162,7 @@ def load_library():
         "plv_cpi_poses": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvCpiTable), C.c_int, dp, dp, dp, u8p]),
         "plv_camera_update_list": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, u64p, ip, dp, fp, fp, dp]),
         "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
+        "plv_camera_get_line_features": (C.c_int, [vp, C.POINTER(PlvStateView)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -1093,6 +1094,11 @@ class Context:
     def point_used_insert(self, fid, p, newest):
         p = np.ascontiguousarray(p, dtype=np.float64)
         self._chk(self.lib.plv_point_used_insert(self.h, int(fid), _dp(p), float(newest)))
+
+    def camera_get_line_features(self, st, n=None, max_obs=None, **kw):
+        """plv_camera_get_line_features: records the state (before the point update's dx is applied) the next camera_update_lines
+        triangulates its pool on, as the reference's try_update orders it"""
+        self._chk(self.lib.plv_camera_get_line_features(self.h, C.byref(st.c)))
 
     def camera_update_lines(self, st, n, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, cap=512, cpi=None):
         opt = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0,

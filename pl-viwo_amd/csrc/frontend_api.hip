@@ -628,6 +628,16 @@ void det_post(plv_ctx *ctx, const DetJob &J, float *pts, uint64_t *ids, int cap,
 }
 
 // a detection that was started ahead of time and has not been collected: wait for it so that its buffers can be reused
+void det_drop_pending(FrontState *s);
+}  // namespace
+// plv_ctx_synchronize: the side stream's work belongs to the frame that started it — wait for it too (the job stays collectable)
+extern "C" int plv_front_quiesce(plv_ctx *ctx) {
+  if (!ctx || !ctx->fe_state) return PLV_OK;
+  FrontState *s = (FrontState *)ctx->fe_state;
+  if (s->det_pending.active && s->det_done) PLV_HIP_CHECK(plv::event_sync(s->det_done));
+  return PLV_OK;
+}
+namespace {
 void det_drop_pending(FrontState *s) {
   if (s->det_pending.active) {
     (void)plv::event_sync(s->det_done);
@@ -672,14 +682,14 @@ int plv_perform_detection(plv_ctx *ctx, int which, const uint8_t *mask, float *p
 
 // The top-up detection of the NEXT frame, started now: on the current image (the next frame's last image) with the points this frame
 // ended with.  Runs on a side stream next to whatever the caller enqueues on the ctx stream (the updates); plv_perform_detection of
-// the next frame finds it finished.  Not while the per-kernel profiler is on (its events live on the ctx stream).
+// the next frame finds it finished (the per-kernel profiler follows it onto the side stream: Profiler::collect).
 // on_ctx_stream: enqueue behind what is on the ctx stream instead (the caller has submitted an update whose wait ends at its own
 // last kernel: the detection then runs in the device's idle time between that update and the next submission, not next to it).
 int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in, int on_ctx_stream) {
   if (!ctx || n_in < 0 || (n_in > 0 && (!pts || !ids))) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   FrontState *s = fe(ctx);
-  if (s->fed < 1 || ctx->prof.on) return PLV_OK;
+  if (s->fed < 1) return PLV_OK;
   det_drop_pending(s);
   DetJob &A = s->det_pending;
   TRY(det_pre(ctx, s, mask, pts, ids, n_in, A));

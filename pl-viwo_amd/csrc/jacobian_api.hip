@@ -405,8 +405,11 @@ int check_line_views(const plv_state_view *st, const plv_line_tracks *lt, bool n
 }
 
 // one packed upload of the state view and the line tracks; fills JacParams (n_feat = n_lines)
+// st_tri (optional): a second state whose clone poses ride in the same block; *Pt then is P with the poses, extrinsics and time
+// offset of that state (the view the line triangulation works on when it differs from the one the Jacobians are taken at)
 int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
-                      const int *col_to_state, int ld, JacParams &P, StageExtra *ex = nullptr) {
+                      const int *col_to_state, int ld, JacParams &P, StageExtra *ex = nullptr, const plv_state_view *st_tri = nullptr,
+                      JacParams *Pt = nullptr) {
   const int N = st->n_clones, L = lt->n_lines, nobs = lt->obs_ptr[L];
   if (nobs < 1) {
     set_last_error("line jacobians: no observations");
@@ -431,12 +434,18 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
                o_rR = lt->res_R ? take(72 * nobs) : 0, o_rp = lt->res_R ? take(24 * nobs) : 0,
                o_rQ = lt->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = lt->res_Q ? take(4 * (size_t)nobs) : 0,
                o_cols = take(4 * (size_t)k), o_xfl = ex && ex->flags ? take(L) : 0;
+  const bool two_states = st_tri && Pt && st_tri != st && st_tri->n_clones == N;
+  const size_t o_tR = two_states ? take(72 * N) : 0, o_tp = two_states ? take(24 * N) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
   char *h = us->h_jin.as<char>();
   memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
   if (ex && ex->flags) memcpy(h + o_xfl, ex->flags, L);
+  if (two_states) {
+    memcpy(h + o_tR, st_tri->clone_R, 72 * N);
+    memcpy(h + o_tp, st_tri->clone_p, 24 * N);
+  }
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
   memcpy(h + o_p, st->clone_p, 24 * N);
@@ -507,6 +516,16 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   P.cols_in = (const int *)(d + o_cols);
   P.cols_out = nullptr;
   if (ex) ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
+  if (Pt) {
+    *Pt = P;
+    if (two_states) {
+      Pt->clone_R = (const double *)(d + o_tR);
+      Pt->clone_p = (const double *)(d + o_tp);
+      memcpy(Pt->R_ItoC, st_tri->R_ItoC, 72);
+      memcpy(Pt->p_IinC, st_tri->p_IinC, 24);
+      Pt->cam_dt = st_tri->cam_dt;
+    }
+  }
   return PLV_OK;
 }
 
@@ -514,6 +533,7 @@ struct FusedLineTri {
   const uint8_t *flags;
   int max_sel;
   size_t o_lines, o_ok;  // out: results in us->tri (lines [L][6], ok [L])
+  const plv_state_view *st_tri = nullptr;  // the state of the triangulation when it is not the one of the Jacobians
 };
 int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_line_tracks *lt, int k,
                           const int *col_to_state, int ld, bool project, FusedLineTri *ft = nullptr) {
@@ -524,10 +544,10 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
-  JacParams P{};
+  JacParams P{}, Pt{};
   StageExtra ex;
   if (ft) ex.flags = ft->flags;
-  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex));
+  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex, ft ? ft->st_tri : nullptr, &Pt));
   us->b_projected = false;
   us->b_gather_token = 0;
   if (ft) {
@@ -536,7 +556,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
                  o_valid = (o_ok + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    TRY(launch_triangulate_lines(ctx, P, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
+    TRY(launch_triangulate_lines(ctx, Pt, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
                                  (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
     P.line_FinG = (const double *)(d + o_lines);
     P.sel_flags = ex.d_flags;
@@ -583,13 +603,16 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
 extern "C" {
 
 // The line twin (plv_camera_update_lines): line triangulation, selection, Pluecker Jacobians, null space, gate, compression, EKF.
-int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *all, const uint8_t *flags, int max_sel, int k,
-                           const int *col_to_state, int ld, double sigma2, double chi2_mult, double *lines_out, uint8_t *ok_out,
-                           uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *), void *before_wait_arg) {
+// st_tri: the state the lines are triangulated on (the one before the point update, plv_camera_get_line_features); the Jacobians
+// are taken at st.
+int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
+                           const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
+                           double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *),
+                           void *before_wait_arg) {
   if (!ctx || !all || !flags || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
-  FusedLineTri ft{flags, max_sel, 0, 0};
+  FusedLineTri ft{flags, max_sel, 0, 0, st_tri};
   TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, true, &ft));
   us->b_single_use = true;
   const int L = all->n_lines;

@@ -64,6 +64,14 @@ struct LineTracker {
   int pending_which = -1, pending_fed = -1;
   bool defer_finish = false;        // plv_camera_try_update: the line update leaves its database hand-back (cleanup_lines) behind ...
   std::function<void()> deferred;   // ... to run before anything else reads the tracker: in the next frame's wait for the flow (ltr())
+  // plv_camera_get_line_features: the state the line pool is triangulated on (the reference runs get_line_features BEFORE the point
+  // update's correction is applied, UpdaterCamera.cpp:148-152), kept until the next plv_camera_update_lines
+  struct TriState {
+    bool valid = false;
+    plv_state_view view;
+    std::vector<double> clone_time, clone_R, clone_p;
+    std::vector<int> clone_id;
+  } tri_state;
   std::vector<float> cached;  // plv_line_detect_finish: the segments of image `cached_which` of frame `cached_fed`
   int cached_which = -1, cached_fed = -1;
   std::mutex mtx;
@@ -982,10 +990,44 @@ static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as
 void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish = on != 0; }
 void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
 
+// LineHelper::get_line_features' place in try_update (REF: UpdaterCamera.cpp:148-152: after get_features, before msckf_update's
+// correction reaches the state): records the state the line pool is to be triangulated on.  The pool itself (LineHelper.cpp:33-44)
+// and its triangulation (:45-63) are formed inside the following plv_camera_update_lines, on this state; nothing they read changes
+// in between (the line database, point_used), so the result is what the reference computes at this point.
+int plv_camera_get_line_features(plv_ctx *ctx, const plv_state_view *st) {
+  if (!ctx || !st || st->n_clones < 1 || !st->clone_time || !st->clone_R || !st->clone_p || !st->clone_state_id) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx, false);
+  LineTracker::TriState &S = T->tri_state;
+  const int N = st->n_clones;
+  S.clone_time.assign(st->clone_time, st->clone_time + N);
+  S.clone_R.assign(st->clone_R, st->clone_R + 9 * (size_t)N);
+  S.clone_p.assign(st->clone_p, st->clone_p + 3 * (size_t)N);
+  S.clone_id.assign(st->clone_state_id, st->clone_state_id + N);
+  S.view = *st;
+  S.view.clone_time = S.clone_time.data();
+  S.view.clone_R = S.view.clone_R_fej = S.clone_R.data();  // (the triangulation reads estimates only)
+  S.view.clone_p = S.view.clone_p_fej = S.clone_p.data();
+  S.view.clone_state_id = S.clone_id.data();
+  S.valid = true;
+  return PLV_OK;
+}
+
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
+  // the state of the triangulation: what plv_camera_get_line_features recorded (same window), else the state handed in
+  LineTracker::TriState tri_keep;
+  std::swap(tri_keep, T->tri_state);
+  T->tri_state.valid = false;
+  if (tri_keep.valid) {  // (the vectors moved: re-point the view)
+    tri_keep.view.clone_time = tri_keep.clone_time.data();
+    tri_keep.view.clone_R = tri_keep.view.clone_R_fej = tri_keep.clone_R.data();
+    tri_keep.view.clone_p = tri_keep.view.clone_p_fej = tri_keep.clone_p.data();
+    tri_keep.view.clone_state_id = tri_keep.clone_id.data();
+    if (tri_keep.view.n_clones != st->n_clones || memcmp(tri_keep.clone_time.data(), st->clone_time, 8 * (size_t)st->n_clones) != 0) tri_keep.valid = false;
+  }
+  const plv_state_view *st_tri = tri_keep.valid ? &tri_keep.view : st;
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
   plv::HostPhase ph_all("update_lines: whole call");
@@ -1229,7 +1271,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     if (any) {
       rc = plv_line_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
       if (rc == PLV_OK && k > 0) {
-        rc = plv_lines_update_fused(ctx, st, &all, flags.data(), cap, k, cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
+        rc = plv_lines_update_fused(ctx, st, st_tri, &all, flags.data(), cap, k, cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
                                     opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx, plv_tracker_run_deferred, ctx);
         res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
         if (rc == PLV_E_NOT_PSD) {
@@ -1246,7 +1288,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       std::fill(ok.begin(), ok.end(), 0);
     }
   } else {
-    rc = plv_triangulate_lines(ctx, st, &all, lg.data(), ok.data());
+    rc = plv_triangulate_lines(ctx, st_tri, &all, lg.data(), ok.data());
     if (rc != PLV_OK) {
       for (Cand &c : pool) give_back_all(c);
       return finish(rc);

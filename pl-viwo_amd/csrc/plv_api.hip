@@ -232,9 +232,18 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   delete ctx;
 }
 
+extern "C" int plv_front_quiesce(plv_ctx *ctx);        // frontend_api.hip: a detection started ahead of time on the side stream
+extern "C" int plv_line_tracker_feed_wait(plv_ctx *ctx);
+// Everything the calls so far have started is finished at return: the ctx stream, the side stream of the detection that a point
+// update starts ahead of time, and the library's line worker (an asynchronous feed is joined; its status stays with
+// plv_line_tracker_feed_wait).  bench.py ends every timed step here.
 int plv_ctx_synchronize(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);
-  return sync(ctx);
+  TRY(plv_front_quiesce(ctx));
+  (void)plv_line_tracker_feed_wait(ctx);
+  TRY(sync(ctx));
+  ctx->prof.collect();
+  return PLV_OK;
 }
 
 int plv_prof_enable(plv_ctx *ctx, int on) {

@@ -213,9 +213,15 @@ struct Profiler {
     if (!on) return;
     (void)hipEventRecord(pending.back().b, s);
   }
-  // call after a stream sync
+  // call after a stream sync.  Launches on another stream (the detection started ahead of time) may still be running: their
+  // records stay pending until a later collect finds them finished.
   void collect() {
+    size_t keep = 0;
     for (auto &p : pending) {
+      if (hipEventQuery(p.b) == hipErrorNotReady) {
+        pending[keep++] = p;
+        continue;
+      }
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
         recs[p.rec].launches++;
@@ -224,13 +230,16 @@ struct Profiler {
       pool.push_back(p.a);
       pool.push_back(p.b);
     }
-    pending.clear();
+    pending.resize(keep);
   }
   void reset() {
     for (auto &r : recs) r.launches = 0, r.total_ms = 0.0;
   }
   void destroy() {
+    (void)hipDeviceSynchronize();
     collect();
+    for (auto &p : pending) pool.push_back(p.a), pool.push_back(p.b);
+    pending.clear();
     for (auto e : pool) (void)hipEventDestroy(e);
     pool.clear();
   }

@@ -861,6 +861,9 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   T->defer_db = T->ahead_on_ctx_stream = io->opt_lines != nullptr;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
   T->defer_db = T->ahead_on_ctx_stream = false;
+  // REF UpdaterCamera.cpp:148-152: get_line_features runs between get_features and msckf_update — the line pool is triangulated on
+  // the state as it is before the point update's correction is applied
+  if (rc == PLV_OK && io->opt_lines) rc = plv_camera_get_line_features(ctx, st);
   if (rc == PLV_OK) rc = apply(*io->res_points, io->dx_points);
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);

@@ -50,8 +50,8 @@ extern "C" int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, c
                                        const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
                                        double chi2_mult, double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out,
                                        uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *), void *before_wait_arg);
-extern "C" int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_line_tracks *all, const uint8_t *flags, int max_sel,
-                                      int k, const int *col_to_state, int ld, double sigma2, double chi2_mult, double *lines_out,
-                                      uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *),
-                                      void *before_wait_arg);
+extern "C" int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
+                                      const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
+                                      double chi2_mult, double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx,
+                                      void (*before_wait)(void *), void *before_wait_arg);
 extern "C" void plv_tracker_run_deferred(void *ctx);  // tracker_api.hip

@@ -695,8 +695,9 @@ class FrameOracle:
         L.orc_frame_line_db_append.argtypes = [vp, C.c_uint64, C.c_int, dp, fp, fp, C.c_int, ip, C.c_int]
         L.orc_frame_used_insert.argtypes = [vp, C.c_uint64, dp, C.c_double]
         L.orc_frame_db_cleanup_measurements.argtypes = [vp, C.c_double]
-        for f in ("orc_frame_db_size", "orc_frame_line_db_size", "orc_frame_used_size", "orc_frame_lines_detected"):
+        for f in ("orc_frame_db_size", "orc_frame_line_db_size", "orc_frame_used_size", "orc_frame_lines_detected", "orc_frame_lk_points"):
             getattr(L, f).argtypes = [vp]
+        L.orc_frame_lk_points.restype = C.c_longlong
         self.q95 = np.ascontiguousarray(q95, dtype=np.float64)
         self.h = L.orc_frame_create(C.addressof(cfg), _dp(self.q95), len(self.q95))
         assert self.h
@@ -823,6 +824,10 @@ class FrameOracle:
 
     def lines_detected(self):
         return self.lib.orc_frame_lines_detected(self.h)
+
+    def lk_points(self):
+        """points handed to perform_matching so far (all frames)"""
+        return self.lib.orc_frame_lk_points(self.h)
 
     def db_ids(self, lines=False):
         fn = self.lib.orc_frame_line_db_ids if lines else self.lib.orc_frame_db_ids

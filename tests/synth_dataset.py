@@ -127,7 +127,7 @@ def _mips(seed, manhattan=True):
     return out
 
 
-def _mips_street(seed, ground=False):
+def _mips_street(seed, ground=False, dense=False):
     """"street" style texture (the bench / line-test scene): a smooth large-scale shading with little fine texture, covered with
     axis-aligned high-contrast rectangles (facade panels and windows on the walls, paving slabs on the ground): long straight edges that
     end in corners, so that FAST corners sit on the segments the line detector finds (TrackLSD keeps a line only when a tracked point lies
@@ -138,7 +138,7 @@ def _mips_street(seed, ground=False):
     base = ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 48.0, mode="wrap")
     base = 0.5 + 0.22 * base / np.abs(base).max() + 0.018 * ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 1.2, mode="wrap") / 0.2
     if ground:
-        tile = 120                                  # 1.4 m slabs, every one its own grey level
+        tile = 64 if dense else 120                 # 1.4 m slabs (dense: 0.77 m), every one its own grey level
         g = rng.uniform(0.12, 0.88, (n // tile + 1, n // tile + 1))
         base = 0.35 * base + 0.65 * np.kron(g, np.ones((tile, tile)))[:n, :n]
     else:
@@ -146,10 +146,10 @@ def _mips_street(seed, ground=False):
             v = rng.uniform(0.04, 0.3) if rng.random() < 0.5 else rng.uniform(0.7, 0.96)
             base[y:y + h, x:x + w] = 0.15 * base[y:y + h, x:x + w] + 0.85 * v
 
-        for _ in range(110):                        # panels 1.7 .. 5.5 m wide
-            w, h = int(rng.uniform(140, 460)), int(rng.uniform(90, 300))
+        for _ in range(260 if dense else 110):      # panels 1.7 .. 5.5 m wide (dense: more and smaller ones, 0.8 .. 4 m)
+            w, h = (int(rng.uniform(70, 330)), int(rng.uniform(60, 220))) if dense else (int(rng.uniform(140, 460)), int(rng.uniform(90, 300)))
             rect(int(rng.uniform(0, n - w)), int(rng.uniform(0, n - h)), w, h)
-        for _ in range(40):                         # window grids: rows of 0.7 x 1.1 m openings
+        for _ in range(90 if dense else 40):        # window grids: rows of 0.7 x 1.1 m openings
             w, h, gx, gy = int(rng.uniform(50, 75)), int(rng.uniform(80, 110)), int(rng.integers(2, 6)), int(rng.integers(1, 4))
             px, py = int(w * rng.uniform(1.5, 2.2)), int(h * rng.uniform(1.3, 1.8))
             x0, y0 = int(rng.uniform(0, n - gx * px)), int(rng.uniform(0, n - gy * py))
@@ -188,9 +188,11 @@ class Renderer:
         panels / windows and a paved ground (_mips_street), 7 m high with a ceiling instead of the empty sky"""
         self.rays = _undistorted_rays().reshape(-1, 3)
         self.style = style
-        if style == "street":
-            self.ground, self.wall = _mips_street(seed, ground=True), _mips_street(seed + 1)
+        if style in ("street", "avenue"):           # "avenue": the street with twice the structure (the round-3 bench scene)
+            dense = style == "avenue"
+            self.ground, self.wall = _mips_street(seed, ground=True, dense=dense), _mips_street(seed + 1, dense=dense)
             self.wall_r, self.wall_h = 9.0, 7.0
+            self.style = "street"
         else:
             self.ground, self.wall = _mips(seed), _mips(seed + 1)
             self.wall_r, self.wall_h = WALL_R, WALL_H
@@ -415,7 +417,7 @@ def simulate(seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, res
     """The sensor streams of the synthetic drive, in memory: imu (t, wm, am), wheel (t, m1, m2), cam_times, gt (t, p, q)."""
     global REST, PATH
     REST = float(rest)
-    PATH = "street" if style == "street" else "circle"
+    PATH = "street" if style in ("street", "avenue") else "circle"
     rng = np.random.default_rng(seed)
     t, wm, am = synth.imu_stream(imu_pose, 0.0, seconds + 0.1, rate=imu_hz, bg=BG, ba=BA)
     wm = wm + rng.normal(0, SIG["gyro_noise"] * np.sqrt(imu_hz), wm.shape)
@@ -443,7 +445,7 @@ def _render_one(x):
 def render_frames(times, style="room", workers=1, seed=7):
     """The camera images at `times`; workers > 1 renders in forked processes (call before anything initialises the GPU)."""
     global _POOL_RD, PATH
-    PATH = "street" if style == "street" else "circle"
+    PATH = "street" if style in ("street", "avenue") else "circle"
     _POOL_RD = Renderer(seed=seed, style=style)
     if workers <= 1 or len(times) < 4:
         return [_POOL_RD.render(x) for x in times]
