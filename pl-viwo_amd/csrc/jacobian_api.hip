@@ -545,6 +545,9 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{}, Pt{};
+  bool fuse_tri = false;
+  double *tri_cam = nullptr, *tri_imu = nullptr, *tri_lines = nullptr;
+  unsigned char *tri_valid = nullptr, *tri_ok = nullptr;
   StageExtra ex;
   if (ft) ex.flags = ft->flags;
   TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex, ft ? ft->st_tri : nullptr, &Pt));
@@ -556,8 +559,11 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
                  o_valid = (o_ok + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    TRY(launch_triangulate_lines(ctx, Pt, (double *)(d + o_cam), (double *)(d + o_imu), (unsigned char *)(d + o_valid),
-                                 (double *)(d + o_lines), (unsigned char *)(d + o_ok)));
+    // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
+    fuse_tri = project && L <= ft->max_sel && !getenv("PLV_LINE_TRI_SEPARATE");
+    tri_cam = (double *)(d + o_cam), tri_imu = (double *)(d + o_imu), tri_valid = (unsigned char *)(d + o_valid);
+    tri_lines = (double *)(d + o_lines), tri_ok = (unsigned char *)(d + o_ok);
+    if (!fuse_tri) TRY(launch_triangulate_lines(ctx, Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
     P.line_FinG = (const double *)(d + o_lines);
     P.sel_flags = ex.d_flags;
     P.tri_ok = (const unsigned char *)(d + o_ok);
@@ -582,7 +588,10 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
     }
-    TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    if (fuse_tri)
+      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
+    else
+      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

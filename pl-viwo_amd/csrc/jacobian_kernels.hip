@@ -1305,10 +1305,23 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
 // jacobian_nullspace_kernel): the line's [Hf (6) | Hx | res] block is built row-major in LDS, projected there by six Householder
 // reflections and only the projected block goes to global memory.  The covariance gathers of the update ride on it as extra
 // workgroups, and workgroup 0 publishes the column map.
-__global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g) {
+__device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
+                                     double *out, unsigned char &ok);
+// tri.on: the line is triangulated first, by this very workgroup, on the state Pt (LineHelper::get_line_features runs on the state
+// before the point update, lines_update linearises on the updated one: two views of the same window) — one launch for what were
+// line_triangulate_kernel + this one.  Only while the selection loop has no cap to enforce (n_feat <= max_sel): a line is then
+// taken on its own merits and needs no count over the lines before it.
+struct LineTriStage {
+  int on;
+  double *cam, *imu;      // [n_obs][12] camera / IMU poses of the observations (scratch)
+  unsigned char *valid;   // [n_obs]
+  double *out_g;          // [L][6]  == P.line_FinG of the Jacobian stage
+  unsigned char *ok_g;    // [L]
+};
+__global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g, JacParams Pt, LineTriStage tri) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
   __shared__ WinTab tab[JAC_MAX_WIN];
-  __shared__ int s_rows;
+  __shared__ int s_rows, s_ok;
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
     return;
@@ -1319,7 +1332,29 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
   if (l == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-  const bool selected = !P.tri_ok || candidate_selected(P, l);
+  bool selected;
+  if (tri.on) {
+    const int o0 = Pt.obs_ptr[l], o1 = Pt.obs_ptr[l + 1];
+    for (int o = o0 + (int)threadIdx.x; o < o1; o += blockDim.x) campose_one(Pt, o, tri.cam, tri.valid, tri.imu);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double out_l[6] = {0, 0, 0, 0, 0, 0};
+      unsigned char ok_l = 0;
+      line_triangulate_one(Pt, l, o0, o1, tri.cam, tri.imu, tri.valid, out_l, ok_l);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tri.out_g[6 * l + i] = out_l[i];
+        tri.ok_g[l] = ok_l;
+        s_ok = ok_l;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    selected = P.sel_flags[l] && s_ok;
+  } else {
+    selected = !P.tri_ok || candidate_selected(P, l);
+  }
   if (selected)
     build_window_tables(P, tab);  // (block-uniform; ends with a barrier: also orders the zero fill before the row writes)
   else
@@ -1468,8 +1503,9 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
   return PLV_OK;
 }
 
-int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks) {
-  ProfScope ps(ctx->prof, "line_jacobian_nullspace_kernel", ctx->stream);
+int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const JacParams *Pt, double *d_cam,
+                                    double *d_imu, unsigned char *d_valid, double *d_lines, unsigned char *d_ok) {
+  ProfScope ps(ctx->prof, Pt ? "line_tri_jacobian_nullspace_kernel" : "line_jacobian_nullspace_kernel", ctx->stream);
   if (2 * (P.n_clones - 3) > JAC_MAX_WIN) {
     set_last_error("line jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
     return PLV_E_CAPACITY;
@@ -1481,8 +1517,9 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
   }
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
+  LineTriStage tri{Pt ? 1 : 0, d_cam, d_imu, d_valid, d_lines, d_ok};
   hipLaunchKernelGGL(line_jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
-                     g ? *g : none);
+                     g ? *g : none, Pt ? *Pt : P, tri);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -58,7 +58,10 @@ struct GatherArgs;
 // the batch built AND null-space projected in one launch (resident update path); g != null: the covariance gathers ride along
 int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks);
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
-int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks);
+// Pt != null: every workgroup first triangulates its line on the state Pt (scratch and results as launch_triangulate_lines takes them)
+int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const JacParams *Pt = nullptr,
+                                    double *d_cam = nullptr, double *d_imu = nullptr, unsigned char *d_valid = nullptr, double *d_lines = nullptr,
+                                    unsigned char *d_ok = nullptr);
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
                              double *d_lines, unsigned char *d_ok);
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,

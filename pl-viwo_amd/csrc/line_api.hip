@@ -47,7 +47,23 @@ struct LineTrack {  // LineFeature, one camera   REF: linefeat/LineFeature.h:22-
   int D = 0;
 };
 
+struct LineCand {
+  uint64_t id;
+  LineTrack tr;
+};
+// The pool of LineHelper::get_line_features (REF: linefeat/LineHelper.cpp:33-44: features_containing_older + features_not_containing_newer,
+// remove_unusable_measurements, sort) taken out of the database.  It reads times only, so plv_camera_try_update forms it while the
+// point update is still running on the device (form_line_pool below); plv_camera_update_lines consumes it.
+struct LinePool {
+  bool valid = false;
+  double t_prev_frame = 0, state_time = 0, t_oldest = 0, t_oldest2 = 0, dt = 0;
+  int n_clones = 0, n_pool = 0, db_size_before = 0;
+  std::vector<LineCand> pool;                       // trimmed, sorted long to short
+  std::unordered_map<uint64_t, LineTrack> unused;   // db_unused so far (observations newer than the window)
+};
+
 struct LineTracker {
+  LinePool pool_prep;
   std::vector<float> lines_last;  // 4 per line
   std::vector<uint64_t> ids_last;
   std::vector<int> rel_ptr_last{0};  // CSR: point ids on each last line (ascending, the reference keeps a std::map)
@@ -990,6 +1006,122 @@ static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as
 void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish = on != 0; }
 void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
 
+static void line_give_back(std::unordered_map<uint64_t, LineTrack> &unused, const LineCand &c, size_t i) {
+  LineTrack &u = unused[c.id];
+  if (u.t.empty() && u.points.empty()) {
+    u.D = c.tr.D;
+    u.points = c.tr.points;  // copy_to_db copies the feature's point list
+  }
+  u.t.push_back(c.tr.t[i]);
+  u.uv.insert(u.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+  u.uvn.insert(u.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
+}
+
+static void form_line_pool(LineTracker *T, const plv_state_view *st, const plv_update_options *opt, LinePool &R) {
+  R = LinePool();
+  R.valid = true;
+  R.t_prev_frame = opt->t_prev_frame, R.state_time = opt->state_time, R.dt = st->cam_dt, R.n_clones = st->n_clones;
+  R.t_oldest = st->clone_time[0], R.t_oldest2 = st->clone_time[1];
+  const double dt = R.dt, t_oldest = R.t_oldest, t_oldest2 = R.t_oldest2;
+  {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    R.db_size_before = (int)T->db.size();
+    std::vector<uint64_t> take;
+    for (const auto &kv : T->db) {  // REF LineHelper.cpp:33-38 (:74-130)
+      bool older = false, newer = false;
+      for (double t : kv.second.t) {
+        older = older || t < t_oldest2 - dt;
+        newer = newer || t > opt->t_prev_frame - dt;
+      }
+      if (older || !newer) take.push_back(kv.first);
+    }
+    std::sort(take.begin(), take.end());
+    R.pool.reserve(take.size());
+    for (uint64_t id : take) {
+      auto node = T->db.extract(id);  // (one lookup: the track leaves the database with its node)
+      R.pool.push_back(LineCand{id, std::move(node.mapped())});
+    }
+  }
+  R.n_pool = (int)R.pool.size();
+  for (auto it = R.pool.begin(); it != R.pool.end();) {  // REF :652-682 (hard-coded 0.01 s margins)
+    LineTrack &tr = it->tr;
+    size_t keep = 0;
+    for (size_t i = 0; i < tr.t.size(); ++i) {
+      const double tm = tr.t[i] + dt;
+      if (tm > opt->state_time + 0.01) {
+        line_give_back(R.unused, *it, i);
+        continue;
+      }
+      if (tm < t_oldest - 0.01) continue;
+      if (keep != i) {
+        tr.t[keep] = tr.t[i];
+        std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+        std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+      }
+      ++keep;
+    }
+    tr.t.resize(keep);
+    tr.uv.resize(4 * keep);
+    tr.uvn.resize(4 * keep);
+    if (keep < 2)
+      it = R.pool.erase(it);
+    else
+      ++it;
+  }
+  std::stable_sort(R.pool.begin(), R.pool.end(), [](const LineCand &a, const LineCand &b) { return a.tr.t.size() > b.tr.t.size(); });
+}
+
+// a pool that was formed ahead of time and is not going to be used: everything goes back where it came from
+static void discard_line_pool(LineTracker *T) {
+  LinePool &R = T->pool_prep;
+  if (!R.valid) return;
+  std::lock_guard<std::mutex> lk(T->mtx);
+  auto put = [&](uint64_t id, LineTrack &tr) {
+    const bool is_new = T->db.find(id) == T->db.end();
+    LineTrack &d = T->db[id];
+    if (is_new) {
+      d = std::move(tr);
+      return;
+    }
+    d.t.insert(d.t.end(), tr.t.begin(), tr.t.end());
+    d.uv.insert(d.uv.end(), tr.uv.begin(), tr.uv.end());
+    d.uvn.insert(d.uvn.end(), tr.uvn.begin(), tr.uvn.end());
+  };
+  for (auto &c : R.pool) put(c.id, c.tr);
+  for (auto &kv : R.unused) put(kv.first, kv.second);
+  R = LinePool();
+}
+
+// (internal, plv_camera_try_update) forms the line pool now if the line feed of this frame has finished — called while the point
+// update runs on the device.  Never blocks: with the feed still on the worker the pool is formed inside plv_camera_update_lines.
+void plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
+  static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;  // (measurement aid: the pool formed after the point update as before)
+  if (late || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return;  // (a calibrated time offset moves the window test)
+  LineTracker *T;
+  {
+    std::lock_guard<std::mutex> lk(g_mtx);
+    auto it = g_lt.find(ctx);
+    if (it == g_lt.end()) return;
+    T = it->second;
+  }
+  {
+    std::lock_guard<std::mutex> lk(T->jm);
+    if (T->feed_state == 1) return;  // still running
+  }
+  T = ltr(ctx);  // (joins a finished feed, runs a hand-back left behind)
+  if (T->feed.rc != PLV_OK) return;
+  plv::HostPhase ph("update_lines: pool formed inside the point update's wait");
+  discard_line_pool(T);
+  form_line_pool(T, st, opt, T->pool_prep);
+}
+void plv_line_pool_discard(plv_ctx *ctx) { discard_line_pool(ltr(ctx, false)); }
+int plv_line_db_size_after_feed(plv_ctx *ctx) {
+  LineTracker *T = ltr(ctx);
+  if (T->pool_prep.valid) return T->pool_prep.db_size_before;
+  std::lock_guard<std::mutex> lk(T->mtx);
+  return (int)T->db.size();
+}
+
 // LineHelper::get_line_features' place in try_update (REF: UpdaterCamera.cpp:148-152: after get_features, before msckf_update's
 // correction reaches the state): records the state the line pool is to be triangulated on.  The pool itself (LineHelper.cpp:33-44)
 // and its triangulation (:45-63) are formed inside the following plv_camera_update_lines, on this state; nothing they read changes
@@ -1034,69 +1166,22 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   plv::HostPhase ph_pool("update_lines: pool + staging");
   const auto U0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
-  const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
-  struct Cand {
-    uint64_t id;
-    LineTrack tr;
-  };
-  std::vector<Cand> pool;
-  std::unordered_map<uint64_t, LineTrack> unused;
-  auto give_back = [&](const Cand &c, size_t i) {
-    LineTrack &u = unused[c.id];
-    if (u.t.empty() && u.points.empty()) {
-      u.D = c.tr.D;
-      u.points = c.tr.points;  // copy_to_db copies the feature's point list
-    }
-    u.t.push_back(c.tr.t[i]);
-    u.uv.insert(u.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
-    u.uvn.insert(u.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
-  };
-  {
-    std::lock_guard<std::mutex> lk(T->mtx);
-    std::vector<uint64_t> take;
-    for (const auto &kv : T->db) {  // REF LineHelper.cpp:33-38 (:74-130)
-      bool older = false, newer = false;
-      for (double t : kv.second.t) {
-        older = older || t < t_oldest2 - dt;
-        newer = newer || t > opt->t_prev_frame - dt;
-      }
-      if (older || !newer) take.push_back(kv.first);
-    }
-    std::sort(take.begin(), take.end());
-    pool.reserve(take.size());
-    for (uint64_t id : take) {
-      auto node = T->db.extract(id);  // (one lookup: the track leaves the database with its node)
-      pool.push_back(Cand{id, std::move(node.mapped())});
-    }
+  const double dt = st->cam_dt, t_oldest = st->clone_time[0];
+  typedef LineCand Cand;
+  LinePool LP;
+  if (T->pool_prep.valid && T->pool_prep.t_prev_frame == opt->t_prev_frame && T->pool_prep.state_time == opt->state_time && T->pool_prep.dt == dt &&
+      T->pool_prep.n_clones == st->n_clones && T->pool_prep.t_oldest == t_oldest && T->pool_prep.t_oldest2 == st->clone_time[1]) {
+    LP = std::move(T->pool_prep);  // formed while the point update was running (plv_line_pool_prepare)
+    T->pool_prep = LinePool();
+  } else {
+    discard_line_pool(T);
+    form_line_pool(T, st, opt, LP);
   }
-  res->n_pool = (int)pool.size();
+  std::vector<Cand> &pool = LP.pool;
+  std::unordered_map<uint64_t, LineTrack> &unused = LP.unused;
+  auto give_back = [&](const Cand &c, size_t i) { line_give_back(unused, c, i); };
+  res->n_pool = LP.n_pool;
   plv::HostPhase ph_p1("update_lines: pool a (scan + take) done -> b (trim + sort)");
-  for (auto it = pool.begin(); it != pool.end();) {  // REF :652-682 (hard-coded 0.01 s margins)
-    LineTrack &tr = it->tr;
-    size_t keep = 0;
-    for (size_t i = 0; i < tr.t.size(); ++i) {
-      const double tm = tr.t[i] + dt;
-      if (tm > opt->state_time + 0.01) {
-        give_back(*it, i);
-        continue;
-      }
-      if (tm < t_oldest - 0.01) continue;
-      if (keep != i) {
-        tr.t[keep] = tr.t[i];
-        std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
-        std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
-      }
-      ++keep;
-    }
-    tr.t.resize(keep);
-    tr.uv.resize(4 * keep);
-    tr.uvn.resize(4 * keep);
-    if (keep < 2)
-      it = pool.erase(it);
-    else
-      ++it;
-  }
-  std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.tr.t.size() > b.tr.t.size(); });
   auto finish = [&](int rc) {
     res->n_returned = (int)unused.size();
     const bool window_full = opt->window_full != 0;

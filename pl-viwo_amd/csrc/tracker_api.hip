@@ -30,6 +30,8 @@ struct Tracker {
   bool ahead_deferred = false;     // ... asked for by the last feed, not started yet (start_detection_ahead)
   bool ahead_on_ctx_stream = false;  // plv_camera_try_update with a line update to follow: the detection goes behind the point update
   bool defer_db = false;           // plv_camera_try_update: the point update leaves its database hand-back to run_deferred_db
+  const plv_state_view *early_st = nullptr;       // plv_camera_try_update with a line update to follow: the line pool is formed inside
+  const plv_update_options *early_lines = nullptr;  // the point update's wait when the frame's line feed has finished by then
   std::function<void()> deferred_db;
   std::unordered_map<uint64_t, Track> db;
   struct UsedPoint {
@@ -166,6 +168,11 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   }
   {
     plv::HostPhase ph("tracker_feed: perform_matching");
+    // the line detector's pixel work (18 us) goes in FRONT of the flow: the edge maps then reach the library's line worker ~0.1 ms
+    // earlier than behind flow + RANSAC, and the worker (chain walk, segment growth, assignment, matching) is the longer of the two
+    // paths that meet at the line update; PLV_LINE_EDGES_LATE=1 restores the old order
+    static const bool edges_late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
+    if (!edges_late) launch_prefetch();
     const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
     launch_prefetch();  // (inside the wait for the flow)
     if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
@@ -208,17 +215,25 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   return PLV_OK;
 }
 
-// (called without T->mtx held)
+extern "C" void plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt);  // line_api.hip
+extern "C" void plv_line_pool_discard(plv_ctx *ctx);
+extern "C" int plv_line_db_size_after_feed(plv_ctx *ctx);
+// host work placed inside the point update's wait (called without T->mtx held)
 static void start_detection_ahead(void *arg) {
   plv_ctx *ctx = (plv_ctx *)arg;
   Tracker *T = trk(ctx);
-  std::lock_guard<std::mutex> lk(T->mtx);
-  if (!T->ahead_deferred) return;
-  T->ahead_deferred = false;
-  // (with a line update to follow: behind the point update on the ctx stream — its wait ends at the update's own last kernel and the
-  // detection fills the device's idle time until the line update is submitted; else on the side stream, next to the update)
-  (void)plv_perform_detection_ahead(ctx, T->mask_last.empty() ? nullptr : T->mask_last.data(), T->pts_last.data(), T->ids_last.data(),
-                                    (int)T->ids_last.size(), T->ahead_on_ctx_stream ? 1 : 0);
+  {
+    std::lock_guard<std::mutex> lk(T->mtx);
+    if (T->ahead_deferred) {
+      T->ahead_deferred = false;
+      // (with a line update to follow: behind the point update on the ctx stream — its wait ends at the update's own last kernel and
+      // the detection fills the device's idle time until the line update is submitted; else on the side stream, next to the update)
+      (void)plv_perform_detection_ahead(ctx, T->mask_last.empty() ? nullptr : T->mask_last.data(), T->pts_last.data(), T->ids_last.data(),
+                                        (int)T->ids_last.size(), T->ahead_on_ctx_stream ? 1 : 0);
+    }
+  }
+  // LineHelper::get_line_features' pool (times only: nothing the point update changes) while the device is busy with that update
+  if (T->early_lines && T->early_st) plv_line_pool_prepare(ctx, T->early_st, T->early_lines);
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
@@ -859,15 +874,20 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
     return (int)PLV_OK;
   };
   T->defer_db = T->ahead_on_ctx_stream = io->opt_lines != nullptr;
+  T->early_st = io->opt_lines ? st : nullptr;
+  T->early_lines = io->opt_lines;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
   T->defer_db = T->ahead_on_ctx_stream = false;
+  T->early_st = nullptr, T->early_lines = nullptr;
+  if (rc != PLV_OK && io->opt_lines) plv_line_pool_discard(ctx);
   // REF UpdaterCamera.cpp:148-152: get_line_features runs between get_features and msckf_update — the line pool is triangulated on
   // the state as it is before the point update's correction is applied
   if (rc == PLV_OK && io->opt_lines) rc = plv_camera_get_line_features(ctx, st);
   if (rc == PLV_OK) rc = apply(*io->res_points, io->dx_points);
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);
-    io->line_db_size = plv_line_db_size(ctx);
+    io->line_db_size = plv_line_db_size_after_feed(ctx);
+    if (rc != PLV_OK) plv_line_pool_discard(ctx);
     if (rc == PLV_OK) {
       plv_line_defer_finish(ctx, 1);
       rc = plv_camera_update_lines(ctx, st, io->opt_lines, io->dx_lines, io->res_lines, io->line_ids, io->line_accepted, io->line_FinG,
