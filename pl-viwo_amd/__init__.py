@@ -1119,9 +1119,17 @@ class Context:
         op = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, tri, t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, init_min_meas, None)
         ol = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, 10, None)
         rp, rl = PlvUpdateResult(), PlvUpdateResult()
-        dxp, dxl = np.zeros(n), np.zeros(n)
-        ids, acc, p = np.zeros(max_msckf, dtype=np.uint64), np.zeros(max_msckf, dtype=np.uint8), np.zeros((max_msckf, 3))
-        lids, lacc, lg = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6))
+        # the output arrays of a given shape are laid out once per context and reused (the results below are copies)
+        bufs = None
+        if self is not None:
+            cache = self.__dict__.setdefault("_io_bufs", {})
+            bufs = cache.get((n, max_msckf, cap))
+        if bufs is None:
+            bufs = (np.zeros(n), np.zeros(n), np.zeros(max_msckf, dtype=np.uint64), np.zeros(max_msckf, dtype=np.uint8), np.zeros((max_msckf, 3)),
+                    np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6)))
+            if self is not None:
+                cache[(n, max_msckf, cap)] = bufs
+        dxp, dxl, ids, acc, p, lids, lacc, lg = bufs
         a = lambda x: x.ctypes.data
         io = PlvTryUpdate(C.addressof(op), C.addressof(ol) if lines else None, plus.n if plus is not None else 0,
                           C.addressof(plus.vars) if plus is not None else None, a(dxp), a(dxl), C.addressof(rp), C.addressof(rl),
@@ -1129,13 +1137,13 @@ class Context:
 
         def results(keep=(op, ol, plus)):      # (the structures io points to live as long as this closure)
             m = rp.n_msckf
-            pts = dict(dx=dxp, n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned, status=rp.status,
-                       ids=ids[:m], accepted=acc[:m], p_FinG=p[:m], n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
+            pts = dict(dx=dxp.copy(), n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned, status=rp.status,
+                       ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
             if not lines:
                 return pts, None, 0
             m = rl.n_msckf
-            lns = dict(dx=dxl, n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
-                       status=rl.status, ids=lids[:m], accepted=lacc[:m], line_FinG=lg[:m])
+            lns = dict(dx=dxl.copy(), n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
+                       status=rl.status, ids=lids[:m].copy(), accepted=lacc[:m].copy(), line_FinG=lg[:m].copy())
             return pts, lns, io.line_db_size
         return io, results
 

@@ -97,6 +97,56 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restri
   if (i < nc && j < nc) G[(size_t)j * nc + i] = s0 + s1;
 }
 
+// G = A^T A in ONE launch, over the rows that exist: the stack holds a slot of mp_max rows per batch entry, and an entry the gate
+// did not take (or an empty system: a pool candidate the selection skipped) is all zeros, so the chunk + reduce pair below multiplied
+// mostly padding (rocprofv3, round 2: 2 MB moved for 0.3 MB of rows).  Here one workgroup owns an upper tile; its four waves share
+// the accepted entries (acc_rows[f] > 0) and walk only their rows straight from the L2-resident stack — a wave's operand loads go
+// down 16 columns, 16 k-steps in flight — and the four accumulators are added in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restrict__ A, int lda, int nc, const int *__restrict__ acc_rows, int F,
+                                                          int mp_max, double *__restrict__ G, const int *__restrict__ skip) {
+  if (skip && *skip == 0) return;
+  __shared__ double part[3][256];
+  const int nt = (nc + 15) >> 4;
+  int rem = blockIdx.x, ti = 0;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ++ti;
+  }
+  const int tj = ti + rem;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15;
+  const double *ai = A + (size_t)min(ti * 16 + li, nc - 1) * lda;  // columns beyond nc only feed entries that are never stored
+  const double *aj = A + (size_t)min(tj * 16 + li, nc - 1) * lda;
+  d4 acc = {0, 0, 0, 0};
+  int turn = 0;
+  for (int f0 = 0; f0 < F; f0 += 64) {  // 64 entries' row counts per load; the accepted ones are dealt to the waves in turn
+    const int fr = f0 + lane < F ? acc_rows[f0 + lane] : 0;
+    unsigned long long mask = __ballot(fr > 0);
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if ((turn++ & 3) != wave) continue;
+      const int rows = min(__shfl(fr, b, 64), mp_max);
+      const double *af = ai + (size_t)(f0 + b) * mp_max, *bf = aj + (size_t)(f0 + b) * mp_max;
+      auto fa = [&](int, int kk) { return af[kk]; };
+      auto fb = [&](int kk, int) { return bf[kk]; };
+      acc = mfma_tile_f64_pipe<8>(fa, fb, rows, acc);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave - 1][q * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = ((acc[q] + part[0][q * 64 + lane]) + part[1][q * 64 + lane]) + part[2][q * 64 + lane];
+      const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + li;
+      if (i < nc && j < nc) G[(size_t)j * nc + i] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // [dC | dx] = W[:, :n]^T [W[:, :n] | y]  (upper tiles; dC = K M^T of the reference, y = W[:, n]).
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
@@ -165,7 +215,7 @@ __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P,
 // ========================================================================================== launchers
 // Compression of the stacked m x nc matrix [H | r] (col-major, lda) into R (k x k upper, ldr) and z.
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems,
-                         double *d_R, int ldr, double *d_z) {
+                         double *d_R, int ldr, double *d_z, const int *d_acc_rows, int F, int mp_max) {
   const int k = nc - 1;
   const int nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
   const int nchunks = cdiv(m, GRAM_CH);
@@ -175,6 +225,14 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
     return PLV_E_CAPACITY;
   }
   double *d_part = d_tmp, *d_G = d_tmp + part_elems;
+  static const bool chunked_only = getenv("PLV_GRAM_CHUNKED") != nullptr;  // (measurement aid)
+  if (d_acc_rows && F * mp_max == m && !chunked_only) {
+    {
+      ProfScope ps(ctx->prof, "gram_direct_kernel", ctx->stream);
+      hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_G, ctx->skip_word);
+    }
+    return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
+  }
   {
     ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
     const size_t shm = (size_t)nc * (GRAM_CH + 1) * sizeof(double);

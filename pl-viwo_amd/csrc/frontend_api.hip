@@ -42,6 +42,8 @@ struct FrontState {
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io, models;
   DevBuf det_in, det_out, det_mask, subpix_tab, det_cand, det_cand_n;  // detection staging
   PinBuf det_pin;
+  PinBuf img_pin[2];       // host images on their way to the device (plv_feed_image_enqueue): the caller's buffer is free at return
+  int img_pin_next = 0;
   DetJob det_pending;
   hipStream_t det_stream = nullptr;
   hipEvent_t det_done = nullptr;
@@ -159,6 +161,8 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   if (s->det_done) (void)hipEventDestroy(s->det_done);
   if (s->match_done) (void)hipEventDestroy(s->match_done);
   if (s->det_stream) (void)hipStreamDestroy(s->det_stream);
+  s->img_pin[0].release();
+  s->img_pin[1].release();
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab, &s->det_cand, &s->det_cand_n};
@@ -167,6 +171,33 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   s->det_pin.release();
   delete s;
   ctx->fe_state = nullptr;
+}
+
+// plv_feed_image without the wait at its end (the tracker's path: plv_tracker_feed goes on to enqueue the flow and waits there).
+// The image is copied into one of two pinned blocks of the library first, so the caller's buffer is free when the call returns
+// although the transfer and the kernels are only enqueued.
+int plv_feed_image_enqueue(plv_ctx *ctx, const uint8_t *img, int stride) {
+  if (!ctx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(ensure_pyramids(ctx, s));
+  if (!img || stride < s->W) {
+    set_last_error("front-end: null image or stride %d < width %d", stride, s->W);
+    return PLV_E_BADARG;
+  }
+  plv::HostPhase ph("feed image: host copy into the pinned block + enqueue");
+  PinBuf &pin = s->img_pin[s->img_pin_next];
+  s->img_pin_next ^= 1;
+  const size_t bytes = (size_t)s->W * s->H;
+  TRY(pin.reserve(bytes));
+  if (stride == s->W) {
+    memcpy(pin.p, img, bytes);
+  } else {
+    for (int y = 0; y < s->H; ++y) memcpy(pin.as<uint8_t>() + (size_t)y * s->W, img + (size_t)y * stride, s->W);
+  }
+  // (a block is reused two images later: the wait for that image's flow lies in between)
+  PLV_HIP_CHECK(plv::memcpy_async(s->raw.p, pin.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return feed_device(ctx, s, s->raw.as<uint8_t>());
 }
 
 int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride) {

@@ -306,6 +306,14 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   ph_b.stop();
   plv::HostPhase ph_c("points fused: host work inside the wait");
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
+  // ... and work that becomes possible DURING the wait (the line pool, once the line worker has finished the frame's feed): the
+  // caller's poll function is tried until it reports that nothing is left, or the update is done
+  if (rc == PLV_OK && ctx->wait_poll && us->done_ev) {
+    while (hipEventQuery(us->done_ev) == hipErrorNotReady) {
+      if (ctx->wait_poll(ctx->wait_poll_arg)) break;
+      for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+    }
+  }
   ph_c.stop();
   plv::HostPhase ph_d("points fused: wait");
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)

@@ -1092,27 +1092,29 @@ static void discard_line_pool(LineTracker *T) {
   R = LinePool();
 }
 
-// (internal, plv_camera_try_update) forms the line pool now if the line feed of this frame has finished — called while the point
-// update runs on the device.  Never blocks: with the feed still on the worker the pool is formed inside plv_camera_update_lines.
-void plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
+// (internal, plv_camera_try_update) forms the line pool now if the line feed of this frame has finished — polled while the point
+// update runs on the device.  Never blocks: returns 0 while the feed is still on the worker (try again), 1 when the pool is formed or
+// cannot be formed ahead of time (plv_camera_update_lines then forms it).
+int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
   static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;  // (measurement aid: the pool formed after the point update as before)
-  if (late || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return;  // (a calibrated time offset moves the window test)
+  if (late || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return 1;  // (a calibrated time offset moves the window test)
   LineTracker *T;
   {
     std::lock_guard<std::mutex> lk(g_mtx);
     auto it = g_lt.find(ctx);
-    if (it == g_lt.end()) return;
+    if (it == g_lt.end()) return 1;
     T = it->second;
   }
   {
     std::lock_guard<std::mutex> lk(T->jm);
-    if (T->feed_state == 1) return;  // still running
+    if (T->feed_state == 1) return 0;  // still running
   }
   T = ltr(ctx);  // (joins a finished feed, runs a hand-back left behind)
-  if (T->feed.rc != PLV_OK) return;
+  if (T->feed.rc != PLV_OK) return 1;
   plv::HostPhase ph("update_lines: pool formed inside the point update's wait");
   discard_line_pool(T);
   form_line_pool(T, st, opt, T->pool_prep);
+  return 1;
 }
 void plv_line_pool_discard(plv_ctx *ctx) { discard_line_pool(ltr(ctx, false)); }
 int plv_line_db_size_after_feed(plv_ctx *ctx) {

@@ -707,7 +707,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     TRY(ctx->d_H.reserve((size_t)k * k * 8));
     TRY(ctx->d_res.reserve((size_t)k * 8));
     int crc = launch_gram_compress(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
-                                   ctx->d_H.as<double>(), k, ctx->d_res.as<double>());
+                                   ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max);
     if (crc == PLV_OK) {
       dH = ctx->d_H.as<double>();
       dr = ctx->d_res.as<double>();

@@ -298,6 +298,11 @@ struct plv_ctx {
   void (*probe_hook)(void *) = nullptr;
   void *probe_hook_arg = nullptr;
 
+  // host work of the caller that becomes possible while a point update runs on the device (plv_points_update_fused polls it inside
+  // its wait until it returns nonzero = done / nothing to do)
+  int (*wait_poll)(void *) = nullptr;
+  void *wait_poll_arg = nullptr;
+
   // ---- front-end (frontend_api.hip owns the object)
   void *fe_state = nullptr;
 };

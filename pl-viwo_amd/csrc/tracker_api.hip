@@ -78,12 +78,13 @@ void plv_tracker_destroy(plv_ctx *ctx) {
 }
 
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask);
+extern "C" int plv_feed_image_enqueue(plv_ctx *ctx, const uint8_t *img, int stride);  // frontend_api.hip
 
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask) {
   if (!ctx || !img) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);  // REF: mtx_feeds.at(cam_id), TrackKLT.cpp:54,100
-  TRY(plv_feed_image(ctx, img, stride));  // :59 equalizeHist, :71 buildOpticalFlowPyramid
+  TRY(plv_feed_image_enqueue(ctx, img, stride));  // :59 equalizeHist, :71 buildOpticalFlowPyramid (enqueued; the feed below waits for its flow)
   return tracker_feed_fed(ctx, T, timestamp, mask);
 }
 
@@ -215,7 +216,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   return PLV_OK;
 }
 
-extern "C" void plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt);  // line_api.hip
+extern "C" int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt);  // line_api.hip
 extern "C" void plv_line_pool_discard(plv_ctx *ctx);
 extern "C" int plv_line_db_size_after_feed(plv_ctx *ctx);
 // host work placed inside the point update's wait (called without T->mtx held)
@@ -232,8 +233,14 @@ static void start_detection_ahead(void *arg) {
                                         (int)T->ids_last.size(), T->ahead_on_ctx_stream ? 1 : 0);
     }
   }
-  // LineHelper::get_line_features' pool (times only: nothing the point update changes) while the device is busy with that update
-  if (T->early_lines && T->early_st) plv_line_pool_prepare(ctx, T->early_st, T->early_lines);
+}
+// LineHelper::get_line_features' pool (times only: nothing the point update changes) while the device is busy with that update;
+// polled inside the update's wait (plv_ctx::wait_poll) until the line worker has finished the frame's feed
+static int poll_line_pool(void *arg) {
+  plv_ctx *ctx = (plv_ctx *)arg;
+  Tracker *T = trk(ctx);
+  if (!T->early_lines || !T->early_st) return 1;
+  return plv_line_pool_prepare(ctx, T->early_st, T->early_lines);
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
@@ -873,10 +880,18 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
     if (st->intrinsic_state_id >= 0) TRY(plv_set_camera_intrinsics(ctx, st->intrinsics));
     return (int)PLV_OK;
   };
-  T->defer_db = T->ahead_on_ctx_stream = io->opt_lines != nullptr;
+  // the next frame's top-up detection runs on the side stream next to the point update.  (Round 2 placed it on the ctx stream behind
+  // the update when a line update follows; since the line pool is formed inside the point update's wait, the line update is submitted
+  // right after that wait and would queue behind the detection: PLV_AHEAD_CTX=1 restores that placement for measurements.)
+  static const bool ahead_ctx = getenv("PLV_AHEAD_CTX") != nullptr;
+  T->defer_db = io->opt_lines != nullptr;
+  T->ahead_on_ctx_stream = io->opt_lines != nullptr && ahead_ctx;
   T->early_st = io->opt_lines ? st : nullptr;
   T->early_lines = io->opt_lines;
+  ctx->wait_poll = io->opt_lines ? poll_line_pool : nullptr;
+  ctx->wait_poll_arg = ctx;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
+  ctx->wait_poll = nullptr;
   T->defer_db = T->ahead_on_ctx_stream = false;
   T->early_st = nullptr, T->early_lines = nullptr;
   if (rc != PLV_OK && io->opt_lines) plv_line_pool_discard(ctx);

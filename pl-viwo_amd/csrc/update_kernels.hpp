@@ -54,8 +54,10 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
                    int *d_flag = nullptr);
 // `gathered`: launch_gather_cov already ran for this (P, cols) and P has not changed since
 // dense_kernels.hip
+// d_acc_rows (F entries, slot of mp_max rows each, F * mp_max == m): rows per entry the gate accepted (0: the slot is all zeros) —
+// the Gram matrix is then formed over those rows only, in one launch
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
-                         double *d_R, int ldr, double *d_z);
+                         double *d_R, int ldr, double *d_z, const int *d_acc_rows = nullptr, int F = 0, int mp_max = 0);
 bool ekf_fast_fits(int r);
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
                     const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false, const void *mirror_src = nullptr,
