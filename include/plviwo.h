@@ -177,6 +177,18 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
  * dimension, gate parameters, buffer addresses) runs eagerly, the second is captured, later ones are one hipGraphLaunch.
  * Any change of shape or any device (re)allocation retires the graph.  Off by default.  captures / replays (nullable) count. */
 int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
+/* How StateHelper::measurement_compress_inplace (REF: StateHelper.cpp:602-672, Givens rotations on the stacked Jacobian) is carried
+ * out inside plv_msckf_update* / the one-call camera updates:
+ *   0 (default)  Gram matrix of the accepted rows + blocked Cholesky: [R z] with R^T R = H^T H.  One chain of k pivots; it carries a
+ *                direction of relative strength s with a relative error of eps / s^2, so P' agrees with the reference's QR to 1e-9
+ *                throughout, dx to 1e-8 as long as no pivot of the unit-diagonal Gram matrix falls below 1e-9 — near-gauge directions of
+ *                a running filter do (they combine negligible information with a large prior variance): measured worst 3e-5 of |dx|;
+ *   1            Householder TSQR on the stacked rows themselves (orthogonal transformations: the reference's accuracy, ~0.7 ms);
+ *   2            automatic: Gram first; when its factorisation reports pivots it could not tell from zero, nothing is committed and the
+ *                update is redone through the Householder route.
+ * mode < 0 only queries.  Returns the mode in force.  last_route (nullable): how the last update was compressed — 0 not at all (fewer
+ * rows than columns), 1 Gram, 2 Householder, 3 Gram vetoed and redone; last_ambiguous (nullable): the pivots below 1e-9 it met. */
+int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *last_ambiguous);
 /* Process-wide activity counters since load (measurement aid, no reference counterpart): out[0] kernel launches, [1] host
  * synchronisations (stream / event waits), [2] asynchronous copies, [3] bytes copied, [4] LK iterations over all points and levels
  * (plv_perform_matching), [5] line segments the detector returned inside plv_line_tracker_feed*. */

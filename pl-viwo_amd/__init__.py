@@ -163,6 +163,7 @@ def load_library():
         "plv_camera_update_list": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, u64p, ip, dp, fp, fp, dp]),
         "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
         "plv_camera_get_line_features": (C.c_int, [vp, C.POINTER(PlvStateView)]),
+        "plv_update_compression_mode": (C.c_int, [vp, C.c_int, ip, ip]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -840,6 +841,15 @@ class Context:
                                                 _u8p(acc), C.byref(nrows), _dp(dx))
         self._chk(rc, allow=(PLV_E_NOT_PSD,))
         return rc, dx, acc, nrows.value
+
+    def update_compression_mode(self, mode=-1):
+        """plv_update_compression_mode: sets (0 Gram + Cholesky, 1 Householder, 2 automatic) or queries (-1); returns (mode, route of the last
+        update, ambiguous pivots its Gram factorisation met)"""
+        route, amb = C.c_int(), C.c_int()
+        m = self.lib.plv_update_compression_mode(self.h, int(mode), C.byref(route), C.byref(amb))
+        if m < 0:
+            raise PlvError(m, "plv_update_compression_mode")
+        return m, route.value, amb.value
 
     def update_graph_mode(self, on=-1):
         c, r = C.c_int(), C.c_int()

@@ -51,10 +51,13 @@ struct CompressOps {
   }
 };
 
+#define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
                                                                       double *__restrict__ R, int ldr,
-                                                                      double *__restrict__ z, const int *__restrict__ skip) {
+                                                                      double *__restrict__ z, const int *__restrict__ skip,
+                                                                      int *__restrict__ n_ambiguous) {
+  if (n_ambiguous && threadIdx.x == 0) *n_ambiguous = 0;
   if (skip && *skip == 0) return;
   __shared__ BcLds lds;
   __shared__ double sc[384];  // [0,192) 1/sqrt(d), [192,384) sqrt(d)
@@ -65,9 +68,12 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const dou
     lds.bad = 0;
     lds.step_flag = 0;
     lds.rs_flag = 0;
+    lds.n_amb = 0;
   }
   // pivots of the unit-diagonal matrix lie in [0,1]; below tau a column is numerically dependent
-  blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc, 0);
+  blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc, 0, PLV_COMPRESS_AMBIGUOUS);
+  __syncthreads();
+  if (n_ambiguous && threadIdx.x == 0) *n_ambiguous = lds.n_amb;
 }
 
 // ------------------------------------------------------------------------------------------ EKF
@@ -122,22 +128,22 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
 #ifndef PLV_BCHOL_NO_LAUNCHERS
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z) {
+int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z, int *d_n_ambiguous) {
   const int k = nc - 1;
   if (k > 192) return PLV_E_CAPACITY;
   ProfScope ps(ctx->prof, "bchol_compress_kernel", ctx->stream);
   if (k <= 32)
-    hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   else if (k <= 64)
-    hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   else if (k <= 112)
-    hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   else if (k <= 128)
-    hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   else if (k <= 160)  // (20-clone windows with the calibration blocks: BASELINE configs[3])
-    hipLaunchKernelGGL(bchol_compress_kernel<10>, dim3(1), dim3(64 * 11), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<10>, dim3(1), dim3(64 * 11), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   else
-    hipLaunchKernelGGL(bchol_compress_kernel<12>, dim3(1), dim3(64 * 13), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word);
+    hipLaunchKernelGGL(bchol_compress_kernel<12>, dim3(1), dim3(64 * 13), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -74,6 +74,7 @@ struct BcLds {
   int step_flag;           // 16 * panel + steps published so far
   int rs_flag;             // panels whose rs[] is published
   int bad;
+  int n_amb;               // pivots the factorisation could not tell from zero (diag_chain's `amb` band)
 };
 
 // 1/x: v_rcp_f64 + two Newton steps (the sequence the compiler's IEEE division starts with, without
@@ -105,14 +106,18 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // (strip_chain).  The pivot chain is the critical path of the whole kernel; measured per step on
 // MI355X (tools/ubench/diag_step.hip): 153 ticks for this form, +95 if the same wave also carries
 // an identity border to get L_d^-1, 600 for a one-lane-per-row v_readlane formulation.
+// amb > 0 (compression): a pivot 0 < |pv| < amb is counted in lds.n_amb — on a unit-diagonal Gram matrix it is the square of a
+// relative singular value below sqrt(amb), which the Gram matrix carries with a relative error of eps / |pv| or worse: whether such a
+// column lives or dies (tau) is decided by rounding.  Exactly zero pivots (columns no row touches) are not counted.
 template <bool STORE_L>
-__device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, d4 &cap) {
+__device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, d4 &cap, double amb = 0.0) {
   const int lane = threadIdx.x & 63;
   const int lq = lane >> 4;
   double mask01[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) mask01[q] = (lq == q) ? 1.0 : 0.0;
   bool dead_any = false;
+  int n_amb = 0;
   // The pivot of step j + 1 does not wait for the MFMA of step j: element (j+1, j+1) after that step is
   // fma(T[j][j+1] * (-1/pivot_j), T[j][j+1], T[j+1][j+1]) — exactly the one product the MFMA adds into it — so it is formed from
   // two lanes read BEFORE the MFMA is issued, and its reciprocal (rcp + two Newton steps) is computed in the shadow of the MFMA's
@@ -126,6 +131,7 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
     if (jj == 0) BC_STAMP(40);
     if (jj == 8) BC_STAMP(41);
     dead_any |= !live;
+    n_amb += (amb > 0.0 && pv != 0.0 && fabs(pv) < amb) ? 1 : 0;
     const double nm = ninv * mask01[kk];
     const double trow = T[rq];
     lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[jj][lane][0]), d2{trow, nm});
@@ -152,6 +158,7 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
   BC_STAMP(42);
   lds_vstore(&lds.rs_flag, p + 1);
   if (dead_any && lane == 0) lds.bad = 1;
+  if (n_amb && lane == 0) lds.n_amb += n_amb;  // (one diagonal wave per panel, panels in sequence: no race)
 }
 
 // ---- every strip below the diagonal tile follows the chain on its own (transposed) panel tile ----
@@ -190,7 +197,7 @@ __device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
 }
 
 template <int NT, class Ops>
-__device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb, double tau, int strip) {
+__device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb, double tau, int strip, double amb = 0.0) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform roles
   const int li = lane & 15, lq = lane >> 4;
   const int ntk = (k + 15) >> 4;
@@ -244,7 +251,7 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb
     BC_STAMP(1 + 5 * p);
     if (is_sym && t == p) {
       d4 cap = {0, 0, 0, 0};
-      diag_chain<Ops::kStoreL>(acc[0], lds, tau, p, cap);
+      diag_chain<Ops::kStoreL>(acc[0], lds, tau, p, cap, amb);
       if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -189,8 +189,10 @@ __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P,
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
                                                          int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
                                                          const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
-                                                         int mirror2_words) {
-  const bool skipped = skip && *skip == 0;  // the gate accepted nothing: no correction, the covariance stays
+                                                         int mirror2_words, const int *__restrict__ veto) {
+  // veto (automatic compression mode): the compression met pivots it could not resolve — nothing is committed, the host redoes the
+  // update through the Householder route (plv_msckf_update_resident_wait)
+  const bool skipped = (skip && *skip == 0) || (veto && *veto != 0);  // (or: the gate accepted nothing: no correction, the covariance stays)
   if (blockIdx.x == 0) {
     if (skipped && dx) {
       for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.0;
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P,
 // ========================================================================================== launchers
 // Compression of the stacked m x nc matrix [H | r] (col-major, lda) into R (k x k upper, ldr) and z.
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems,
-                         double *d_R, int ldr, double *d_z, const int *d_acc_rows, int F, int mp_max) {
+                         double *d_R, int ldr, double *d_z, const int *d_acc_rows, int F, int mp_max, int *d_n_ambiguous) {
   const int k = nc - 1;
   const int nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
   const int nchunks = cdiv(m, GRAM_CH);
@@ -231,7 +233,7 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
       ProfScope ps(ctx->prof, "gram_direct_kernel", ctx->stream);
       hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_G, ctx->skip_word);
     }
-    return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
+    return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z, d_n_ambiguous);
   }
   {
     ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
@@ -243,7 +245,7 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
     ProfScope ps(ctx->prof, "gram_reduce_kernel", ctx->stream);
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_part, nchunks, nc, d_G, ctx->skip_word);
   }
-  return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z);
+  return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z, d_n_ambiguous);
 }
 
 bool ekf_fast_fits(int r) { return r <= 192; }
@@ -271,7 +273,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
                        d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx,
                        (const unsigned *)(mirror_dst ? ctx->mirror2_src : nullptr), (unsigned *)(mirror_dst ? ctx->mirror2_dst : nullptr),
-                       (int)((ctx->mirror2_bytes + 3) / 4));
+                       (int)((ctx->mirror2_bytes + 3) / 4), ctx->commit_veto);
     if (mirror_dst && ctx->mirror2_dst) ctx->mirror2_taken = true;
   }
   PLV_HIP_CHECK(hipGetLastError());

@@ -638,9 +638,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   us->b_gather_token = 0;
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
-  struct SkipGuard {  // the word is only meaningful for the kernels of this update
+  struct SkipGuard {  // the words are only meaningful for the kernels of this update
     plv_ctx *c;
-    ~SkipGuard() { c->skip_word = nullptr; }
+    ~SkipGuard() { c->skip_word = nullptr, c->commit_veto = nullptr; }
   } skip_guard{ctx};
   auto enqueue = [&]() -> int {
   if (!projected) {
@@ -702,12 +702,24 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
 
   const double *dH, *dr;
   int r, ldh;
+  us->last_route = 0;
+  us->redo.armed = false;
   if (Mtot > k) {
     // REF: measurement_compress_inplace — [R z] with R^T R = H^T H (Gram + LDS Cholesky)
     TRY(ctx->d_H.reserve((size_t)k * k * 8));
     TRY(ctx->d_res.reserve((size_t)k * 8));
-    int crc = launch_gram_compress(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
-                                   ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max);
+    int crc = PLV_E_CAPACITY;
+    if (us->compress_mode != 1) {
+      crc = launch_gram_compress(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
+                                 ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max, d_flag + 3);
+      if (crc == PLV_OK) {
+        us->last_route = 1;
+        if (us->compress_mode == 2 && ekf_fast_fits(k) && !us->graph_mode) {  // the commit waits for the verdict on the pivots
+          ctx->commit_veto = d_flag + 3;
+          us->redo = plv_ctx_update_state::Redo{true, Mtot, k, n, tmp_elems, rb, d_dx, d_flag};
+        }
+      }
+    }
     if (crc == PLV_OK) {
       dH = ctx->d_H.as<double>();
       dr = ctx->d_res.as<double>();
@@ -721,6 +733,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       dr = R + (size_t)k * ldr;
       r = k;
       ldh = ldr;
+      us->last_route = 2;
     } else {
       return crc;
     }
@@ -790,6 +803,18 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   return PLV_OK;
 }
 
+int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *last_ambiguous) {
+  REQUIRE_CTX(ctx);
+  auto *us = ustate(ctx);
+  if (mode >= 0) {
+    if (mode > 2) return PLV_E_BADARG;
+    us->compress_mode = mode;
+  }
+  if (last_route) *last_route = us->last_route;
+  if (last_ambiguous) *last_ambiguous = us->last_ambiguous;
+  return us->compress_mode;
+}
+
 int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
@@ -823,6 +848,24 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     PLV_HIP_CHECK(plv::event_sync(us->done_ev));  // (not the whole stream: the caller may have enqueued more behind the update)
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
+  us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;
+  if (us->redo.armed && us->last_ambiguous > 0 && *(const int *)(hb + (size_t)n * 8) == 0 && ((const int *)(hb + (size_t)n * 8))[1] > 0) {
+    // automatic mode: the Gram factorisation met pivots it could not tell from zero and ekf_commit_kernel left the covariance alone.
+    // The stacked rows are still in place: compress them by Householder reflections (orthogonal transformations on the rows
+    // themselves resolve what the squared matrix cannot) and run the EKF step again.
+    const plv_ctx_update_state::Redo rd = us->redo;
+    us->redo.armed = false;
+    double *R;
+    int ldr;
+    const int nc = rd.k + 1;
+    TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols.as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx,
+                        rd.d_flag, true, us->result.p, ctx->h_pin.p, ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3));
+    TRY(sync(ctx));
+    ++ctx->gather_stamp;
+    us->last_route = 3;
+  }
+  us->redo.armed = false;
   int flag = *(const int *)(hb + (size_t)n * 8);
   const unsigned char *hacc = (const unsigned char *)(hb + (size_t)n * 8 + 16);
   int nrows = 0;

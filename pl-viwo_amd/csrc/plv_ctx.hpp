@@ -281,6 +281,7 @@ struct plv_ctx {
   // plv_msckf_update_resident_launch): the compression and EKF kernels return at once when it is zero — an update in which the gate
   // took nothing (most line updates) costs their launches, not their pivot chains; ekf_commit_kernel then reports dx = 0.
   const int *skip_word = nullptr;
+  const int *commit_veto = nullptr;  // automatic compression mode: ekf_commit_kernel leaves the covariance alone while this word is nonzero
   // a second block the update's last kernel copies to pinned host memory next to its result block (the triangulation results of the
   // one-submission updates): set by the caller before plv_msckf_update_resident_launch, cleared (taken = true) when the chain ended in
   // the kernel that does it — else the caller enqueues a copy command as before

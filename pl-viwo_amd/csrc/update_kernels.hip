@@ -362,7 +362,10 @@ __global__ void __launch_bounds__(256) gather_cov_kernel(GatherArgs g) { gather_
 
 // T = Hx' * Ps for every feature at once: one 16x16 tile per wave over (feature, row tile, col tile).
 __global__ void __launch_bounds__(256) chi2_t_kernel(Chi2Args a, int mt_max) {
-  if (a.n_acc && blockIdx.x == 0 && threadIdx.x == 0) *a.n_acc = 0;  // counted by chi2_gate_kernel, the next launch
+  if (a.n_acc && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.n_acc[0] = 0;  // counted by chi2_gate_kernel, the next launch
+    a.n_acc[2] = 0;  // ambiguous pivots of the compression (status block word 3), written by bchol_compress_kernel when it runs
+  }
   const int kt = (a.k + 15) >> 4;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int per_f = mt_max * kt;

@@ -57,14 +57,16 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
 // d_acc_rows (F entries, slot of mp_max rows each, F * mp_max == m): rows per entry the gate accepted (0: the slot is all zeros) —
 // the Gram matrix is then formed over those rows only, in one launch
 int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
-                         double *d_R, int ldr, double *d_z, const int *d_acc_rows = nullptr, int F = 0, int mp_max = 0);
+                         double *d_R, int ldr, double *d_z, const int *d_acc_rows = nullptr, int F = 0, int mp_max = 0,
+                         int *d_n_ambiguous = nullptr);
 bool ekf_fast_fits(int r);
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
                     const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false, const void *mirror_src = nullptr,
                     void *mirror_dst = nullptr, size_t mirror_bytes = 0);
 
 // blocked_chol.hip
-int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z);
+// d_n_ambiguous (nullable): receives the number of pivots the factorisation could not tell from zero (blocked_chol.hpp, diag_chain)
+int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z, int *d_n_ambiguous = nullptr);
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
                      const double *d_res, double *d_W, int ldw, int *d_flag);
 

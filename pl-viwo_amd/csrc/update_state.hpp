@@ -16,6 +16,18 @@ struct plv_ctx_update_state {
   bool b_projected = false;       // the batch is already null-space projected (jacobian_nullspace_kernel)
   unsigned long long b_gather_token = 0;  // plv_ctx::gather_stamp right after the gathers that rode on the batch's launch (0: none)
   std::vector<int> brows_host;
+  // measurement compression (plv_update_compression_mode): 0 = Gram matrix + blocked Cholesky, 1 = Householder TSQR on the stacked
+  // rows, 2 = Gram first, redone through the Householder route when its factorisation reports pivots it could not resolve
+  int compress_mode = 0;
+  int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder
+  int last_ambiguous = 0;   // pivots the last Gram factorisation could not tell from zero
+  struct Redo {             // what the automatic mode needs to run the update again from the stacked rows
+    bool armed = false;
+    int Mtot = 0, k = 0, n = 0;
+    size_t tmp_elems = 0, rb = 0;
+    double *d_dx = nullptr;
+    int *d_flag = nullptr;
+  } redo;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   hipEvent_t done_ev = nullptr;  // behind the update's last command: the wait does not cover what the caller enqueues after the launch
   // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a

@@ -143,7 +143,7 @@ def radtan_distort(K8, xy):
 
 
 def vio_scene(n_clones=15, F=70, M=15, seed=3, noise_px=1.0, dt_clone=0.05, obs_offset=0.0, w=752, h=480,
-              calib_int=True, fej_noise=0.0):
+              calib_int=True, fej_noise=0.0, depth_scale=1.0):
     """Smooth 1 m/s arc, clones every dt_clone seconds, F landmarks each observed in its last M (or fewer)
     clone frames at times clone_time + obs_offset.  State layout: IMU(15) | intrinsics(8) | clones(6 each)
     -> n = 113, k = 98 for 15 clones.  Returns a dict of plain numpy arrays."""
@@ -168,7 +168,7 @@ def vio_scene(n_clones=15, F=70, M=15, seed=3, noise_px=1.0, dt_clone=0.05, obs_
     # landmarks visible from every clone
     pts = []
     while len(pts) < F:
-        c = np.array([rng.uniform(-20, 20), rng.uniform(-14, 14), rng.uniform(3, 60)])
+        c = depth_scale * np.array([rng.uniform(-20, 20), rng.uniform(-14, 14), rng.uniform(3, 60)])   # (depth_scale >> 1: weak parallax)
         ok = True
         for R, p in poses:
             pc = R_ItoC @ (R @ (c - p)) + p_IinC
