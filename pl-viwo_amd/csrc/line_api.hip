@@ -1165,6 +1165,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
   plv::HostPhase ph_all("update_lines: whole call");
+  plv::RoctxRange rx_line("[Time-Cam] LINE update");
   plv::HostPhase ph_pool("update_lines: pool + staging");
   const auto U0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };

@@ -3,6 +3,7 @@
 // returns PLV_E_NO_DEVICE.
 #include <algorithm>
 #include <cstdarg>
+#include <dlfcn.h>
 #include <cmath>
 #include <mutex>
 
@@ -21,6 +22,18 @@ void set_last_error(const char *fmt, ...) {
 }
 
 double chi2_quantile(int dof, double p);
+
+Roctx::Roctx() {
+  if (!getenv("PLV_ROCTX")) return;
+  for (const char *name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+    void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (push && pop) return;
+    push = nullptr, pop = nullptr;
+  }
+}
 
 static const int Q95_N = 1024;
 

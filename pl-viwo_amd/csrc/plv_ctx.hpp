@@ -94,6 +94,30 @@ struct HostPhase {  // scope timer
   ~HostPhase() { stop(); }
 };
 
+// roctx ranges with the reference's TimeChecker labels (REF: PL-VIWO/src/utils/TimeChecker.h:65-135, the dingdong() pairs of
+// UpdaterCamera.cpp:79-190) so that a rocprofv3 --marker-trace timeline reads like the reference's own timing printout.  The roctx
+// library is looked up at run time (PLV_ROCTX=1): no link dependency, no cost when it is off.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx();
+};
+inline Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *label) : on(roctx().push != nullptr) {
+    if (on) roctx().push(label);
+  }
+  void stop() {
+    if (on) roctx().pop();
+    on = false;
+  }
+  ~RoctxRange() { stop(); }
+};
+
 // A grow-only device buffer.
 // Bumped by every device (re)allocation: a captured graph holds raw device pointers, so any growth anywhere retires it.
 inline std::atomic<unsigned long long> &alloc_epoch() {  // contexts may live on different threads

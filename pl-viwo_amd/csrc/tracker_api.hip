@@ -384,6 +384,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   plv::HostPhase ph_all("update_points: whole call");
   plv::HostPhase ph_pool("update_points: pool + staging");
+  plv::RoctxRange rx_get("[Time-Cam] get features");
   const double dt = st->cam_dt;
   const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
   struct Cand {
@@ -630,6 +631,8 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   // than the batch rows take the two-step route (triangulate, select on the host, then build + update).
   const bool fused = !opt->cpi && opt->max_slam == 0 && most_valid <= opt->max_obs;
   ph_pool.stop();
+  rx_get.stop();
+  plv::RoctxRange rx_upd("[Time-Cam] MSCKF update");
   plv::HostPhase ph_dev("update_points: device submission + wait");
   std::vector<uint8_t> acc_all(Fp, 0);
   bool fused_ran = false;
@@ -665,6 +668,8 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     }
   }
   ph_dev.stop();
+  rx_upd.stop();
+  plv::RoctxRange rx_db("[Time-Cam] DB clan up");  // (sic, UpdaterCamera.cpp:174)
   plv::HostPhase ph_post("update_points: selection + database");
   // ---- REF :648-699 the selection loop
   std::vector<int> sel;
@@ -919,6 +924,7 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
 // UpdaterCamera::feed_measurement followed by try_update (REF: UpdaterCamera.cpp:77-116, 139-195), one call per camera frame.
 int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io *io) {
   if (!ctx || !st || !io || (io->slot < 0 && !io->img)) return PLV_E_BADARG;
+  plv::RoctxRange rx_feed("[Time-Cam] feed measurement");
   if (io->slot >= 0)
     TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
   else
@@ -938,6 +944,7 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
     io->line_db_size = lines ? plv_line_db_size(ctx) : 0;
     return PLV_OK;
   }
+  rx_feed.stop();
   const int rc = plv_camera_try_update(ctx, st, io->update);
   if (lines && !io->update->opt_lines) (void)plv_line_tracker_feed_wait(ctx);
   io->line_db_size = io->update->opt_lines ? io->update->line_db_size : (lines ? plv_line_db_size(ctx) : 0);

@@ -12,7 +12,8 @@ Dataset layout (`sys.path_bag` names the directory):
     wheel.csv            t, m1, m2                          (the two readings of the configured wheel type; optional)
     cam0/data.csv        t, file name                       (optional: without it the file stem is the time stamp)
     cam0/data/*          8-bit grey images: .pgm (P5), .png (grey / RGB, not interlaced) or .npy
-A directory in the EuRoC MAV (ASL) layout is read as it is: mav0/imu0/data.csv, mav0/cam0/data.csv + mav0/cam0/data/*.png.
+A directory in the EuRoC MAV (ASL) layout is read as it is: mav0/imu0/data.csv, mav0/cam0/data.csv + mav0/cam0/data/*.png; a KAIST
+Complex Urban raw directory (sensor_data/xsens_imu.csv, encoder.csv, image/stereo_left) through kaist.KaistDataset (open_dataset).
 """
 import os
 import struct
@@ -170,6 +171,17 @@ class Dataset:
     def t_begin(self):
         return self.msgs[0][0]
 
+    def image(self, i):
+        return read_image(self.frames[i][1])
+
+
+def open_dataset(root, use_wheel=True, use_cam=True):
+    """Dataset for this layout / EuRoC, or kaist.KaistDataset for a KAIST Complex Urban raw directory (sensor_data/xsens_imu.csv)"""
+    from . import kaist
+    if kaist.is_kaist_raw(root):
+        return kaist.KaistDataset(root, use_wheel=use_wheel, use_cam=use_cam)
+    return Dataset(root, use_wheel=use_wheel, use_cam=use_cam)
+
 
 class TrajectoryLogger:
     """State_Logger::save_trajectory_to_file (REF: State_Logger.h:160-205)."""
@@ -193,7 +205,7 @@ class TrajectoryLogger:
 
 def replay(op, dataset=None, trajectory_path=None, device=0, progress=None, max_obs=24, **system_kw):
     """run_bag's main loop.  Returns (SystemManager statistics, times, poses [n][7] = p, q)."""
-    ds = dataset if dataset is not None else Dataset(op.sys.path_bag, use_wheel=op.est.wheel.enabled, use_cam=op.est.cam.enabled)
+    ds = dataset if dataset is not None else open_dataset(op.sys.path_bag, use_wheel=op.est.wheel.enabled, use_cam=op.est.cam.enabled)
     sys = SystemManager(op, device=device, max_obs=max_obs, **system_kw)
     path = trajectory_path if trajectory_path is not None else (op.sys.path_trajectory if op.sys.save_trajectory else None)
     log = TrajectoryLogger(path) if path else None
@@ -216,7 +228,7 @@ def replay(op, dataset=None, trajectory_path=None, device=0, progress=None, max_
                 if log:
                     log.save(sys)
         elif kind == CAM:
-            sys.feed_measurement_camera(t, read_image(ds.frames[i][1]), mask)
+            sys.feed_measurement_camera(t, ds.image(i), mask)
         else:
             r = ds.wheel[i]
             sys.feed_measurement_wheel(r[0], r[1], r[2])
