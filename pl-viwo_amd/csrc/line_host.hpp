@@ -1,0 +1,350 @@
+// line_host.hpp — the HOST stage of the line front-end, free of device calls: FastLineDetector's chain walk on the Canny map, the
+// segment growth along the chains on the library's fitter threads (fld_fit_core.hpp), and TrackLSD's point-line assignment, line
+// matching and classification (REF: PL-VIWO/src/update/cam/TrackLSD.cpp:318-407,744-830; OpenCV contract of
+// ximgproc::FastLineDetector).  line_api.hip builds the tracker around it; tests/host_sanitize/ compiles this
+// header alone with -fsanitize=thread / address and drives the thread protocol with recorded edge maps.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "fld_fit_core.hpp"
+#include "line_kernels.hpp"
+
+namespace plv {
+namespace linehost {
+
+// one detection's host stage: the maps a job points to and its result
+struct Job {
+  int device = 0, w = 0, h = 0, length_threshold = 0;
+  float distance_threshold = 0, thr2 = 0;
+  const uint8_t *hmap = nullptr, *hhalf = nullptr;
+  int2 *hpts = nullptr;
+  FldChain *hc = nullptr;
+  std::vector<float> lines;
+  int rc = PLV_OK;
+};
+
+// Second half of the host stage on threads of their own (see host_extract)
+struct Fit {
+  static const int kThreads = 2;  // (the fit is ~1.15x the walk: two fitters keep pace with it, the walking thread joins in at its end)
+  std::thread th[kThreads];
+  std::mutex m;
+  std::condition_variable cv;
+  int gen = 0, done_gen[kThreads] = {0, 0};  // a job = a new generation; thread i reports the last one it finished
+  bool quit = false;
+  const Job *job = nullptr;
+  alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
+  alignas(64) std::atomic<bool> walk_done{false};
+  alignas(64) std::atomic<int> next{0};  // next chain to fit: this thread and, once its walk is over, the walking thread claim chains here
+  alignas(64) std::vector<float4> segs;  // chain c's segments at its slot (FldChain::slot)
+  std::vector<int> seg_n;    // per chain
+};
+
+struct HostStage {  // what the host stage keeps between detections
+  Fit fit;
+  std::vector<uint8_t> pad;  // bordered copy of the edge map for the walk
+  ~HostStage() {
+    if (fit.th[0].joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(fit.m);
+        fit.quit = true;
+      }
+      fit.cv.notify_all();
+      for (auto &th : fit.th)
+        if (th.joinable()) th.join();
+    }
+  }
+};
+
+const int kChainCap = 4096;
+
+// Condition wait that polls first: the library's threads hand each other work several times per frame and a thread that blocked
+// pays tens of microseconds (sometimes a millisecond) to be woken.  Polls for up to spin_us (the lock is released between probes),
+// then blocks as usual — at camera rates the threads sleep between frames, back to back frames keep them awake.
+template <class Pred>
+inline void wait_polling(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, Pred pred, int spin_us = 2000) {
+  if (pred()) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    lk.unlock();
+    for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+    lk.lock();
+    if (pred()) return;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+  }
+  cv.wait(lk, pred);
+}
+
+inline float point_line_distance(const float *line, float x0, float y0) {
+  const float x1 = line[0], y1 = line[1], x2 = line[2], y2 = line[3];
+  const float along = (x2 - x1) * (x0 - x1) + (y2 - y1) * (y0 - y1);
+  if (along <= 0) return std::sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1));
+  const float len2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+  if (along > len2) return std::sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2));
+  return std::abs(std::fabs((y2 - y1) * x0 + (x1 - x2) * y0 + ((x2 * y1) - (x1 * y2))) /
+                  (std::sqrt(std::pow(y2 - y1, 2) + std::pow(x1 - x2, 2))));
+}
+
+// FastLineDetector's seed loop + getPointChain on a host copy of the Canny map (2 = edge).  Same
+// algorithm as fld_walk_kernel; see detect() for why the default runs it here.  The map is copied into a
+// buffer with a one-pixel non-edge border so that the eight neighbour tests need no bounds checks.
+inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
+                 std::vector<uint8_t> &pad, std::atomic<int> *published = nullptr) {
+  static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
+  const int pw = w + 2;
+  pad.assign((size_t)pw * (h + 2), 1);
+  for (int r = 0; r < h; ++r) memcpy(&pad[(size_t)(r + 1) * pw + 1], map + (size_t)r * w, w);
+  int off[8];
+  for (int i = 0; i < 8; ++i) off[i] = dy[i] * pw + dx[i];
+  uint8_t *m = pad.data();
+  int n_chain = 0, n_slot = 0, n_pts = 0;
+  for (int r = 0; r < h; ++r) {
+    const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
+    for (int c = 0; c < w; ++c) {
+      if (row[c] != 2) continue;
+      const int start = n_pts;
+      int x = c, y = r;
+      size_t idx = (size_t)(r + 1) * pw + c + 1;
+      pts[n_pts++] = make_int2(x, y);
+      m[idx] = 1;
+      float direction = 0.0f;
+      for (int step = 0;; ++step) {
+        int pick = -1;
+        float best = 7.0f;
+        if (step == 0) {
+          for (int i = 0; i < 8; ++i)
+            if (m[idx + off[i]] == 2) {
+              pick = i;
+              break;
+            }
+        } else {
+          for (int i = 0; i < 8; ++i) {
+            if (m[idx + off[i]] != 2) continue;
+            const float curr = i > 4 ? (float)(i - 8) : (float)i;
+            float diff = std::fabs(curr - direction);
+            diff = diff > 4.0f ? 8.0f - diff : diff;
+            if (diff <= best) {
+              best = diff;
+              pick = i;
+            }
+          }
+        }
+        if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
+        const int cdir = pick > 4 ? pick - 8 : pick;
+        direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
+        x += dx[pick];
+        y += dy[pick];
+        idx += off[pick];
+        pts[n_pts++] = make_int2(x, y);
+        m[idx] = 1;
+      }
+      const int len = n_pts - start;
+      if (len >= length_threshold + 1 && n_chain < chain_cap) {
+        chains[n_chain++] = FldChain{start, len, n_slot};
+        n_slot += len / length_threshold + 1;
+        if (published) published->store(n_chain, std::memory_order_release);  // chain n_chain - 1 and its points are final
+      } else {
+        n_pts = start;
+      }
+    }
+  }
+  counts[0] = n_chain;
+  counts[1] = n_slot;
+  counts[2] = n_pts;
+}
+
+// The host stage on the maps a job points to: chains in raster order of their seeds = the detector's output order; the tail of
+// perform_detection_monocular (x2, FilterShortLines) on every segment.
+// claims the next unfitted chain below `avail`, or -1
+inline int claim_chain(Fit &F, int avail) {
+  int c = F.next.load(std::memory_order_relaxed);
+  while (c < avail && !F.next.compare_exchange_weak(c, c + 1, std::memory_order_relaxed)) {
+  }
+  return c < avail ? c : -1;
+}
+inline void fit_one(Fit &F, const Job &J, int c) {
+  F.seg_n[c] = fit_chain(J.hhalf, J.w, J.h, J.length_threshold, J.distance_threshold, J.hpts + J.hc[c].start, J.hc[c].len,
+                         F.segs.data() + J.hc[c].slot);
+}
+
+inline void fit_worker(HostStage *T, int me) {
+  Fit &F = T->fit;
+  int seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(F.m);
+      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
+      if (F.quit) return;
+      seen = F.gen;
+    }
+    const Job &J = *F.job;
+    for (;;) {
+      const int avail = F.published.load(std::memory_order_acquire);
+      const int c = claim_chain(F, avail);
+      if (c >= 0) {
+        fit_one(F, J, c);
+        continue;
+      }
+      if (F.walk_done.load(std::memory_order_acquire) && F.next.load(std::memory_order_relaxed) >= F.published.load(std::memory_order_acquire)) break;
+      for (int i = 0; i < 64; ++i) __builtin_ia32_pause();  // (poll every few hundred ns: the walk owns the counter's cache line meanwhile)
+    }
+    {
+      std::lock_guard<std::mutex> lk(F.m);
+      F.done_gen[me] = seen;
+    }
+    F.cv.notify_all();
+  }
+}
+
+inline int host_extract(HostStage *T, Job &J, bool timing) {
+  auto T1 = std::chrono::steady_clock::now();
+  int hcounts[4] = {0, 0, 0, 0};
+  Fit &F = T->fit;
+  F.segs.resize((size_t)J.w * J.h / (size_t)std::max(1, J.length_threshold) + kChainCap);
+  F.seg_n.resize(kChainCap);
+  F.published.store(0, std::memory_order_relaxed);
+  F.next.store(0, std::memory_order_relaxed);
+  F.walk_done.store(false, std::memory_order_relaxed);
+  for (int i = 0; i < Fit::kThreads; ++i)
+    if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i);
+  int gen;
+  {
+    std::lock_guard<std::mutex> lk(F.m);
+    F.job = &J;
+    gen = ++F.gen;
+  }
+  F.cv.notify_all();
+  walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
+  F.walk_done.store(true, std::memory_order_release);
+  auto T2 = std::chrono::steady_clock::now();
+  for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
+  {
+    std::unique_lock<std::mutex> lk(F.m);
+    wait_polling(lk, F.cv, [&] {
+      for (int i = 0; i < Fit::kThreads; ++i)
+        if (F.done_gen[i] != gen) return false;
+      return true;
+    });
+  }
+  J.lines.clear();
+  if (hcounts[0] >= kChainCap) {
+    set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
+    return PLV_E_CAPACITY;
+  }
+  for (int c = 0; c < hcounts[0]; ++c) {
+    const float4 *seg = F.segs.data() + J.hc[c].slot;
+    for (int q = 0; q < F.seg_n[c]; ++q) {
+      const float4 &sg = seg[q];
+      const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+      const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+      if (!(l2 > J.thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+      J.lines.insert(J.lines.end(), {x1, y1, x2, y2});
+    }
+  }
+  if (timing) {
+    auto T3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    size_t edges = 0;
+    for (size_t i = 0; i < (size_t)J.w * J.h; ++i) edges += J.hmap[i] == 2;
+    fprintf(stderr, "walk %.1f us, rest of the fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T1, T2), us(T2, T3), hcounts[0],
+            hcounts[2], edges);
+  }
+  return PLV_OK;
+}
+
+struct Assign {
+  std::vector<int> kept;
+  std::vector<int> rel_ptr{0}, pos_ptr{0};
+  std::vector<uint64_t> rel_id;
+  std::vector<double> rel_dist;
+  std::vector<float> pos;
+};
+
+inline void assign_points(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A, float assign_px = 5.0f) {
+  A = Assign();
+  // ~200 lines x ~250 points box tests per frame: the coordinates are split once so that the test of one line against all points is
+  // a branch-free pass the compiler vectorises (the reference compares the float coordinates as doubles: same outcome), and only the
+  // few points inside a box go through the distance test
+  std::vector<float> xs(np), ys(np);
+  std::vector<int> hit((size_t)np + 1);
+  for (int j = 0; j < np; ++j) xs[j] = pts[2 * j], ys[j] = pts[2 * j + 1];
+  for (int i = 0; i < nl; ++i) {
+    // REF :753-764 reads (x1, y1, x2, y2) as (lx1, lx2, ly1, ly2): kept as is
+    const float lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];
+    const float min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
+    int nh = 0;
+    for (int j = 0; j < np; ++j) {
+      hit[nh] = j;
+      nh += (int)(xs[j] >= min_lx) & (int)(xs[j] <= max_lx) & (int)(ys[j] >= min_ly) & (int)(ys[j] <= max_ly);
+    }
+    if (nh == 0) continue;
+    std::map<int, double> on;
+    size_t first_pos = A.pos.size();
+    for (int q = 0; q < nh; ++q) {
+      const int j = hit[q];
+      const float x = xs[j], y = ys[j];
+      const float d = point_line_distance(lines + 4 * i, x, y);
+      if (d > assign_px) continue;
+      on[(int)ids[j]] = d;
+      A.pos.push_back(x);
+      A.pos.push_back(y);
+    }
+    if (A.pos.size() == first_pos) continue;  // lines without a point are dropped (REF :784-789)
+    A.kept.push_back(i);
+    for (const auto &kv : on) {
+      A.rel_id.push_back((uint64_t)kv.first);
+      A.rel_dist.push_back(kv.second);
+    }
+    A.rel_ptr.push_back((int)A.rel_id.size());
+    A.pos_ptr.push_back((int)A.pos.size() / 2);
+  }
+}
+
+inline void match_lines(const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new, const float *lines_last, int n_last,
+                 const int *rp_last, const uint64_t *ri_last, int *match) {
+  std::fill(match, match + n_new, -1);
+  if (n_new == 0 || n_last == 0) return;
+  for (int i = 0; i < n_new; ++i) {
+    if (rp_new[i + 1] == rp_new[i]) continue;
+    for (int j = 0; j < n_last; ++j) {
+      int shared = 0;
+      for (int q = rp_last[j]; q < rp_last[j + 1]; ++q) {
+        if (!std::binary_search(ri_new + rp_new[i], ri_new + rp_new[i + 1], ri_last[q])) continue;
+        ++shared;
+        if (shared >= 2) {
+          match[i] = j;
+          break;
+        }
+        // one shared point: accept when the last line's midpoint lies within 6 px of the new segment
+        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
+        if (point_line_distance(lines_new + 4 * i, mx, my) <= 6) {
+          match[i] = j;
+          break;
+        }
+      }
+    }
+  }
+}
+
+inline bool line_class(const float *line, const double *vp) {
+  const double sx = line[0], sy = line[1], ex = line[2], ey = line[3];
+  const double mx = (sx + ex) / 2, my = (sy + ey) / 2;
+  // line through the midpoint and the vanishing point, homogeneous
+  const double a = my - vp[1], b = vp[0] - mx, c = mx * vp[1] - my * vp[0];
+  const double ds = a * sx + b * sy + c, de = a * ex + b * ey + c;
+  const double dis_error = std::abs((std::abs(std::sqrt(ds * ds)) + std::abs(std::sqrt(de * de))) / (2 * std::sqrt(a * a + b * b)));
+  const double angle1 = (double)(std::atan(line[1] - line[3]) / (line[0] - line[2]));  // (sic) atan(dy)/dx in float
+  const double angle2 = std::atan(my - vp[1]) / (mx - vp[0]);
+  return dis_error <= 5.0 && std::abs(angle1 - angle2) <= 0.35;
+}
+
+}  // namespace linehost
+}  // namespace plv

@@ -1,0 +1,92 @@
+// Sanitizer driver of the line front-end's host stage (pl-viwo_amd/csrc/line_host.hpp): the chain walk publishing chains to two
+// fitter threads, the hand-over protocol between them, and the assignment / matching logic — compiled with g++ -fsanitize=thread
+// or -fsanitize=address,undefined by tests/test_host_sanitize.py and fed recorded edge maps.  No device is touched.
+//   usage: line_host_check <maps.bin> <repeats>
+//   maps.bin: int32 w, h, n; then n x { w*h bytes Canny map (2 = edge), w*h bytes half-resolution image }
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../pl-viwo_amd/csrc/line_host.hpp"
+
+namespace plv {
+void set_last_error(const char *, ...) {}
+}  // namespace plv
+
+using namespace plv;
+using namespace plv::linehost;
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  int hdr[3];
+  if (fread(hdr, 4, 3, f) != 3) return 2;
+  const int w = hdr[0], h = hdr[1], n = hdr[2], reps = atoi(argv[2]);
+  const size_t npix = (size_t)w * h;
+  std::vector<std::vector<uint8_t>> maps(n, std::vector<uint8_t>(npix)), halves(n, std::vector<uint8_t>(npix));
+  for (int i = 0; i < n; ++i)
+    if (fread(maps[i].data(), 1, npix, f) != npix || fread(halves[i].data(), 1, npix, f) != npix) return 2;
+  fclose(f);
+  HostStage stage;
+  std::vector<int2> pts(npix);
+  std::vector<FldChain> chains(kChainCap);
+  long total_lines = 0, total_kept = 0;
+  std::mt19937 rng(7);
+  std::vector<float> last_lines;
+  Assign last;
+  for (int r = 0; r < reps; ++r)
+    for (int i = 0; i < n; ++i) {
+      Job J;
+      J.w = w, J.h = h, J.length_threshold = 20, J.distance_threshold = 1.414213562f, J.thr2 = 1600.0f;
+      J.hmap = maps[i].data(), J.hhalf = halves[i].data(), J.hpts = pts.data(), J.hc = chains.data();
+      if (host_extract(&stage, J, false) != 0) return 3;
+      // the same detection on this thread alone: the threaded one must give the same segments in the same order
+      std::vector<int2> p2(npix);
+      std::vector<FldChain> c2(kChainCap);
+      std::vector<uint8_t> pad;
+      int counts[4] = {0, 0, 0, 0};
+      walk_chains(maps[i].data(), w, h, 20, p2.data(), c2.data(), kChainCap, counts, pad);
+      std::vector<float> ref;
+      std::vector<float4> seg(npix / 20 + kChainCap);
+      for (int c = 0; c < counts[0]; ++c) {
+        const int ns = fit_chain(halves[i].data(), w, h, 20, 1.414213562f, p2.data() + c2[c].start, c2[c].len, seg.data());
+        for (int q = 0; q < ns; ++q) {
+          const float x1 = seg[q].x * 2, y1 = seg[q].y * 2, x2 = seg[q].z * 2, y2 = seg[q].w * 2;
+          if (!((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) > 1600.0f)) continue;
+          ref.insert(ref.end(), {x1, y1, x2, y2});
+        }
+      }
+      if (ref != J.lines) {
+        fprintf(stderr, "frame %d: threaded detection differs from the serial one (%zu vs %zu values)\n", i, J.lines.size(), ref.size());
+        return 4;
+      }
+      total_lines += (long)J.lines.size() / 4;
+      // TrackLSD's assignment + matching on points scattered along the segments
+      const int nl = (int)J.lines.size() / 4;
+      std::vector<float> ptsf;
+      std::vector<uint64_t> ids;
+      std::uniform_real_distribution<float> u(0.f, 1.f);
+      for (int q = 0; q < nl; q += 2) {
+        const float s = u(rng);
+        ptsf.push_back(J.lines[4 * q] + s * (J.lines[4 * q + 2] - J.lines[4 * q]) + 2 * u(rng));
+        ptsf.push_back(J.lines[4 * q + 1] + s * (J.lines[4 * q + 3] - J.lines[4 * q + 1]) + 2 * u(rng));
+        ids.push_back(1000 + q);
+      }
+      Assign A;
+      assign_points(J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), A);
+      std::vector<float> kept_lines;
+      for (int q : A.kept) kept_lines.insert(kept_lines.end(), J.lines.begin() + 4 * q, J.lines.begin() + 4 * q + 4);
+      if (!last_lines.empty() && !A.kept.empty()) {
+        std::vector<int> match(A.kept.size());
+        match_lines(kept_lines.data(), (int)A.kept.size(), A.rel_ptr.data(), A.rel_id.data(), last_lines.data(), (int)last_lines.size() / 4,
+                    last.rel_ptr.data(), last.rel_id.data(), match.data());
+      }
+      total_kept += (long)A.kept.size();
+      last_lines = kept_lines;
+      last = A;
+    }
+  printf("ok: %d maps x %d repeats, %ld segments, %ld kept by the assignment\n", n, reps, total_lines, total_kept);
+  return 0;
+}

@@ -1,0 +1,70 @@
+"""The library's threaded host code under ThreadSanitizer and AddressSanitizer: pl-viwo_amd/csrc/line_host.hpp — the
+line detector's chain walk handing chains to two fitter threads while it is still producing them, plus the assignment / matching
+logic — compiled on its own with g++ (no device code, no GPU) and driven with Canny maps of rendered frames.  The threaded detection
+must equal the serial one, and neither sanitizer may report anything."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth_dataset as sd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_sanitize", "line_host_check.cpp")
+
+
+@pytest.fixture(scope="module")
+def maps(tmp_path_factory):
+    sd.set_camera(752, 480)
+    sim = sd.simulate(seconds=1.0, cam_hz=10, style="avenue")
+    imgs = sd.render_frames(sim["cam_times"][:4], "avenue", 4)
+    lo, fo = oracle_lib.load_line(), oracle_lib.load_front()
+    path = str(tmp_path_factory.mktemp("maps") / "maps.bin")
+    with open(path, "wb") as f:
+        half0 = lo.resize_half(fo.equalize_hist(imgs[0]))
+        h, w = half0.shape
+        f.write(np.array([w, h, len(imgs)], dtype=np.int32).tobytes())
+        for im in imgs:
+            half = lo.resize_half(fo.equalize_hist(im))
+            edges = lo.canny(half)
+            # FastLineDetector clears two corners of the map (REF: the oracle's fld_detect); the library's edge kernel does the same
+            edges[:6, :6] = 0
+            edges[h - 5:, w - 5:] = 0
+            f.write(np.where(edges > 0, 2, 1).astype(np.uint8).tobytes())
+            f.write(np.ascontiguousarray(half).tobytes())
+    return path
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_line_host_stage_under_sanitizers(maps, tmp_path, san):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / ("check_" + san.replace(",", "_")))
+    cmd = ["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={san}", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe, maps, "6"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok:" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_adapters_need_the_reference_headers():
+    """pl-viwo_amd/host/*.h (the C++ adapters of INTEGRATION.md: TrackKLT_HIP : ov_core::TrackBase, ...) include the reference's own
+    headers and Eigen / OpenCV; a -fsyntax-only pass needs those on the include path.  They are absent from this image, so
+    the pass is attempted only where they exist — here it records why it cannot run."""
+    have = [p for p in ("/usr/include/eigen3/Eigen/Dense", "/usr/include/opencv4/opencv2/core.hpp") if os.path.exists(p)]
+    ref = "/root/reference/open_vins/ov_core/src"
+    if len(have) < 2 or not os.path.isdir(ref):
+        pytest.skip("Eigen / OpenCV headers (and the reference tree) are not in this image: the adapters cannot be syntax-checked here")
+    for name in sorted(os.listdir(os.path.join(ROOT, "pl-viwo_amd", "host"))):
+        if not name.endswith(".h"):
+            continue
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I/usr/include/eigen3", "-I/usr/include/opencv4", "-I" + ref,
+                            "-I/root/reference/PL-VIWO/src", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "pl-viwo_amd", "host", name)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
