@@ -34,6 +34,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; N > 1 is launched by 
 ("weak" scaling), no data-path collective.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -307,6 +308,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second timed segment (host images)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the short segments with non-default library settings (config.variants)")
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
     ap.add_argument("--dry-run", action="store_true",
@@ -323,7 +325,8 @@ def main():
     if not args.dry_run:
         nprof = max(10, min(40, args.steps))
         seg2 = 0 if args.no_pcie else args.steps
-        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof
+        nvar = 0 if args.no_variants else max(10, min(40, args.steps))
+        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof + 2 * nvar
         n_cpu_frames = 0 if (args.no_cpu or rank != 0) else PROLOGUE + args.cpu_frames
         workers = args.render_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
         t0 = time.perf_counter()
@@ -369,10 +372,12 @@ def main():
 
     def timed_segment(n_steps):
         per_frame = {"kept": [], "tracked": []}
-        cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected")}
+        cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "ambiguous_frames", "redone_frames")}
         base = dict(sm.stats)
         tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
         ctx.synchronize()
+        gc.collect()
+        gc.disable()      # (the driver is Python: its collector must not land inside a 0.6 ms step)
         barrier()
         elapsed, per = 0.0, []
         for f in range(n_steps):
@@ -384,13 +389,17 @@ def main():
             elapsed += dt
             per.append(dt * 1e3)
             c1 = pkg.counters()
-            for k in cnt:
+            for k in c1:
                 cnt[k] += c1[k] - c0[k]
             per_frame["tracked"].append(len(ctx.tracker_last()[1]))
             if wl["lines"]:
                 per_frame["kept"].append(len(ctx.line_tracker_last()[1]))
+            _, route, amb = ctx.update_compression_mode()
+            cnt["ambiguous_frames"] += 1 if amb > 0 else 0
+            cnt["redone_frames"] += 1 if route == 3 else 0
         ctx.synchronize()
         barrier()
+        gc.enable()
         stats = {k: sm.stats[k] - base.get(k, 0) for k in sm.stats}
         split = {}
         for k, v in sm.tc.total.items():
@@ -411,6 +420,23 @@ def main():
         pl.staged = True
     elapsed, per, per_frame, cnt, stats, split = (seg[k] for k in ("elapsed", "per", "per_frame", "cnt", "stats", "split"))
     n_state = sm.state.n
+    spin_us, fit_threads = pkg.line_worker_config()
+    variants = None
+    if not args.no_variants:
+        # non-default library settings over the next frames of the stream (short segments, resident images): (a) the automatic
+        # compression mode — an update whose Gram factorisation reports pivots it could not resolve is redone by Householder
+        # reflections (the reference's accuracy on near-gauge directions); (b) the library's threads blocking at once instead of polling
+        variants = {}
+        ctx.update_compression_mode(2)
+        v = timed_segment(nvar)
+        ctx.update_compression_mode(0)
+        variants["compression_automatic"] = {"ms_per_step": v["elapsed"] / nvar * 1e3, "frames": nvar,
+                                             "frames_whose_last_update_was_redone": v["cnt"]["redone_frames"]}
+        pkg.line_worker_config(0, -1)
+        v = timed_segment(nvar)
+        pkg.line_worker_config(spin_us, -1)
+        variants["line_threads_blocking"] = {"ms_per_step": v["elapsed"] / nvar * 1e3, "frames": nvar,
+                                            "what": "PLV_LINE_SPIN_US=0: the line worker and the fitters sleep on their condition variables"}
 
     # ---- roofline leg: HIP events around every kernel launch of the camera step, on the stream each kernel is launched on (a separate
     # pass over the next frames of the stream, same schedule as the timed passes, so that the event records do not perturb them)
@@ -519,9 +545,17 @@ def main():
                         "plv_ctx_synchronize (ctx stream, detection side stream, line worker); sequential; IMU propagation, cloning, "
                         "marginalisation and wheel updates run between the steps, untimed",
                 "replicas": world, "n_state": n_state,
-                "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0, "library_segment_fitters": 2 if wl["lines"] else 0,
+                "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0,
+                                 "library_segment_fitters": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,
                                  "note": "the library's threads run the line detector's host stage (chain walk + segment growth) and the line "
-                                         "tracker's bookkeeping next to the caller's thread; they poll for up to 2 ms after a hand-over, then block"},
+                                         "tracker's bookkeeping next to the caller's thread; a waiting thread polls for poll_before_blocking_us, "
+                                         "then blocks (plv_line_worker_config); cpu_baseline.detail has the CPU frame at 1, 4 and 16 threads"},
+                "compression": {"mode": "Gram matrix + blocked Cholesky (plv_update_compression_mode 0)",
+                                "frames_whose_last_update_met_ambiguous_pivots": cnt["ambiguous_frames"], "frames": args.steps,
+                                "note": "pivots of the unit-diagonal Gram matrix below 1e-9 (near-gauge directions): P' agrees with the "
+                                        "reference's Givens QR to 1e-9 regardless, dx to 1e-8 without them and to 3e-5 at worst with them "
+                                        "(tests/test_gpu_update_hard.py); config.variants.compression_automatic redoes such updates by Householder"},
+                "variants": variants,
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "pcie_inclusive": None if seg_pcie is None else {
                     "what": "second timed segment, the next frames of the stream: the image is a host buffer (plv_tracker_feed), its "

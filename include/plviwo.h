@@ -469,6 +469,13 @@ int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out)
  * go on the stream ahead of the point front-end, the host walks the edge chains and grows the segments while the device runs LK and
  * RANSAC, and the following plv_line_tracker_feed of the same frame takes the finished detection (same segments as without). */
 int plv_line_prefetch_mode(plv_ctx *ctx, int on);
+/* The library's own threads (process-wide).  With the prefetch on the line detector's host stage runs on ONE worker thread per
+ * context plus up to two segment-fitter threads; a thread that waits for work polls for spin_us microseconds before it blocks
+ * (default 300: the hand-overs inside one frame follow each other within that time and then cost no wake-up; between frames the
+ * threads sleep — at 15 Hz that is at most 3 x 0.3 ms of polling per 66 ms frame).  spin_us = 0: block at once (no polling at all, every hand-over pays a wake-up
+ * of tens of microseconds); fit_threads = 0: the worker grows the segments itself after the walk.  Negative arguments only query.
+ * Environment: PLV_LINE_SPIN_US, PLV_LINE_FIT_THREADS. */
+int plv_line_worker_config(int spin_us, int fit_threads, int *spin_us_out, int *fit_threads_out);
 /* plv_line_tracker_feed without waiting for it: with the prefetch on, the rest of TrackLSD::feed_monocular (point-line assignment,
  * matching, classification, track store) runs on the library's line worker thread behind the detection, so the caller can enqueue
  * the point update (plv_camera_update_points) meanwhile; both only read the tracker's output of this frame, as feed_measurement

@@ -164,6 +164,7 @@ def load_library():
         "plv_slam_marg_flags": (C.c_int, [vp, C.c_int, u64p, ip, u8p]),
         "plv_camera_get_line_features": (C.c_int, [vp, C.POINTER(PlvStateView)]),
         "plv_update_compression_mode": (C.c_int, [vp, C.c_int, ip, ip]),
+        "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -678,6 +679,13 @@ def jpl_left_update(q, dth=None, R=None):
     n = q.shape[0] if q.ndim == 2 else 1
     d = np.ascontiguousarray(dth, dtype=np.float64) if dth is not None else None
     lib.plv_jpl_left_update(n, _dp(q), _dp(d), _dp(R))
+
+
+def line_worker_config(spin_us=-1, fit_threads=-1):
+    """plv_line_worker_config: (polling budget in us, fitter threads) of the library's line threads; negative = query only"""
+    a, b = C.c_int(), C.c_int()
+    load_library().plv_line_worker_config(int(spin_us), int(fit_threads), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def counters():

@@ -102,6 +102,8 @@ int ensure_pyramids(plv_ctx *ctx, FrontState *s) {
     PLV_HIP_CHECK(hipMemsetAsync(s->hist.p, 0, 257 * sizeof(unsigned), ctx->stream));
   }
   TRY(s->raw.reserve((size_t)s->W * s->H));
+  TRY(s->img_pin[0].reserve((size_t)s->W * s->H));  // (pinned blocks of plv_feed_image_enqueue: not allocated inside a frame)
+  TRY(s->img_pin[1].reserve((size_t)s->W * s->H));
   return PLV_OK;
 }
 

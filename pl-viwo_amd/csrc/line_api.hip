@@ -365,6 +365,14 @@ int plv_line_walk_mode(plv_ctx *ctx, int on_device) {
   return PLV_OK;
 }
 
+int plv_line_worker_config(int spin_us, int fit_threads_n, int *spin_us_out, int *fit_threads_out) {
+  if (spin_us >= 0) spin_budget_us().store(spin_us);
+  if (fit_threads_n >= 0) fit_threads().store(std::min(fit_threads_n, (int)plv::linehost::Fit::kThreads));
+  if (spin_us_out) *spin_us_out = spin_budget_us().load();
+  if (fit_threads_out) *fit_threads_out = fit_threads().load();
+  return PLV_OK;
+}
+
 int plv_line_prefetch_mode(plv_ctx *ctx, int on) {
   if (!ctx) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -69,9 +70,26 @@ const int kChainCap = 4096;
 // Condition wait that polls first: the library's threads hand each other work several times per frame and a thread that blocked
 // pays tens of microseconds (sometimes a millisecond) to be woken.  Polls for up to spin_us (the lock is released between probes),
 // then blocks as usual — at camera rates the threads sleep between frames, back to back frames keep them awake.
+// How long a waiting library thread polls before it blocks: process-wide, PLV_LINE_SPIN_US (default 300: the hand-overs inside one
+// frame follow each other within that time, between frames the threads sleep; 0 = block at once, measured +10..25 us per frame) or
+// plv_line_worker_config.
+inline std::atomic<int> &spin_budget_us() {
+  static std::atomic<int> v{getenv("PLV_LINE_SPIN_US") ? atoi(getenv("PLV_LINE_SPIN_US")) : 300};
+  return v;
+}
+// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 = the walk's own thread fits afterwards
+inline std::atomic<int> &fit_threads() {
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 2};
+  return v;
+}
 template <class Pred>
-inline void wait_polling(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, Pred pred, int spin_us = 2000) {
+inline void wait_polling(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, Pred pred, int spin_us = -1) {
   if (pred()) return;
+  if (spin_us < 0) spin_us = spin_budget_us().load(std::memory_order_relaxed);
+  if (spin_us == 0) {
+    cv.wait(lk, pred);
+    return;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     lk.unlock();
@@ -213,7 +231,8 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   F.published.store(0, std::memory_order_relaxed);
   F.next.store(0, std::memory_order_relaxed);
   F.walk_done.store(false, std::memory_order_relaxed);
-  for (int i = 0; i < Fit::kThreads; ++i)
+  const int nfit = fit_threads().load(std::memory_order_relaxed);
+  for (int i = 0; i < nfit; ++i)
     if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i);
   int gen;
   {
@@ -230,7 +249,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     std::unique_lock<std::mutex> lk(F.m);
     wait_polling(lk, F.cv, [&] {
       for (int i = 0; i < Fit::kThreads; ++i)
-        if (F.done_gen[i] != gen) return false;
+        if (F.th[i].joinable() && F.done_gen[i] != gen) return false;
       return true;
     });
   }

@@ -18,6 +18,7 @@ def update_work(F, rows_f, fdim, k, n, qr_launches=1):
         "chi2_t_kernel": F * 2.0 * mp * k * k,
         "qr_accum_kernel": (2.0 * m * nc * nc - (2.0 / 3) * nc ** 3) / max(1, qr_launches),
         "gram_chunk_kernel": 1.0 * m * nc * nc,
+        "gram_direct_kernel": 1.0 * m * nc * nc,     # (upper tiles: m (k+1)^2 multiply-adds over the accepted rows)
         "gram_reduce_kernel": (m / 64.0) * (nc * nc / 2.0) * 8,
         "bchol_compress_kernel": nc ** 3 / 3.0,
         "bchol_ekf_kernel": r ** 3 / 3.0 + 1.0 * r * r * (n + 1),
@@ -60,6 +61,7 @@ def frame_work(W, H, levels, n_pts, lk_iters, win, F, M, k, n, L=0, Ml=0, kl=0, 
     if L > 0:
         ul = update_work(L, 2 * Ml, 6, kl, n)
         work["line_jacobian_nullspace_kernel"] = ("mfma", L * Ml * 6000.0 + ul["nullspace_kernel"])
+        work["line_tri_jacobian_nullspace_kernel"] = ("mfma", pool_lines * Ml * 300.0 + L * Ml * 6000.0 + ul["nullspace_kernel"])
         for name, v in up.items():   # kernels both updates launch: the mean of the two launches
             up[name] = ul[name] if name == "nullspace_kernel" else 0.5 * (v + ul[name])
     for name, v in up.items():
