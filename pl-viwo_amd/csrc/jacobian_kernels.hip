@@ -452,6 +452,8 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   }
   __syncthreads();
   const int rows = s_rows;
+  if (P.tri_ok && rows == 0) return;  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
+                                      // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
   if (shift) nullspace_householder(X, piv, rows, ncol, 3);
   double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
@@ -1384,6 +1386,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   }
   __syncthreads();
   const int rows = s_rows;
+  if ((tri.on || P.tri_ok) && rows == 0) return;  // (an unselected pool line: empty system, nothing reads its block)
   const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
   if (shift) nullspace_householder(X, piv, rows, ncol, 6);
   double *hf = P.Hf + (size_t)l * 6 * ld, *hx = P.Hx + (size_t)l * k * ld, *rs = P.res + (size_t)l * ld;

@@ -685,6 +685,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.accepted = d_acc;
   a.acc_rows = d_acc_rows;
   a.n_acc = d_flag + 1;           // second word of the status block
+  // with more rows than columns the stack goes to gram_direct_kernel, which walks the accepted entries only (not in the modes that may
+  // hand the whole stack to the Householder route, nor beyond its 192-column capacity)
+  a.stack_accepted_only = (Mtot > k && k <= 192 && us->compress_mode == 0 && !getenv("PLV_GRAM_CHUNKED")) ? 1 : 0;
   // read by every kernel enqueued from here on (cleared after enqueue()); only the blocked-Cholesky route honours it in all of
   // its kernels, so the Householder / LDS-resident fallbacks (more than 192 columns) run unconditionally
   ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;

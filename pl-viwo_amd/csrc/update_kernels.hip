@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kern
   if (a.stack) {
     __syncthreads();
     const bool pass = passflag != 0.0;
+    if (!pass && a.stack_accepted_only) return;  // (1.2 MB of zeros per update that nothing reads: rocprofv3 WRITE_SIZE, profiles/r03)
     double *dst = a.stack + (size_t)f * a.mp_max;
     for (int idx = threadIdx.x; idx < a.mp_max * (k + 1); idx += blockDim.x) {
       int j = idx / a.mp_max, i = idx - j * a.mp_max;

@@ -23,6 +23,7 @@ struct Chi2Args {
   unsigned char *accepted;
   int *acc_rows;          // projected rows of each accepted feature (0 when rejected)
   int *n_acc;             // (optional) number of accepted features: zeroed by chi2_t_kernel, counted by chi2_gate_kernel
+  int stack_accepted_only;  // the consumer of the stack walks acc_rows (gram_direct_kernel): a rejected entry's slot is left unwritten
   // filled by launch_chi2
   int F;
   const double *Ps;       // dense P[cols, cols] (row-major k x k) from gather_cov_kernel
