@@ -188,6 +188,12 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   JacParams P{};
+  bool fuse_tri = false;
+  int tri_max_obs = 1;
+  double *tri_poses = nullptr, *tri_p = nullptr, *tri_err = nullptr;
+  unsigned char *tri_valid = nullptr, *tri_ok = nullptr;
+  const float *tri_uvn = nullptr;
+  const plv_tri_options *tri_opt = nullptr;
   if (ft) {
     StageExtra ex;
     ex.uvn = ft->uvn;
@@ -198,10 +204,13 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
                  o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    int max_obs = 1;
-    for (int f = 0; f < F; ++f) max_obs = std::max(max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
-    TRY(launch_triangulate(ctx, P, (double *)(d + o_pose), (unsigned char *)(d + o_valid), ex.d_uvn, *ft->opt, (double *)(d + o_p),
-                           (unsigned char *)(d + o_ok), (double *)(d + o_err), max_obs));
+    for (int f = 0; f < F; ++f) tri_max_obs = std::max(tri_max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
+    // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
+    fuse_tri = project && F <= ft->max_sel && !getenv("PLV_POINT_TRI_SEPARATE");
+    tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
+    tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
+    tri_opt = ft->opt;
+    if (!fuse_tri) TRY(launch_triangulate(ctx, P, tri_poses, tri_valid, tri_uvn, *ft->opt, tri_p, tri_ok, tri_err, tri_max_obs));
     P.p_FinG = P.p_FinG_fej = (const double *)(d + o_p);  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
     P.sel_flags = ex.d_flags;
     P.tri_ok = (const unsigned char *)(d + o_ok);
@@ -229,7 +238,10 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
     }
-    TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    if (fuse_tri)
+      TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, tri_opt, tri_poses, tri_valid, tri_uvn, tri_p, tri_ok, tri_err, tri_max_obs));
+    else
+      TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

@@ -411,10 +411,26 @@ __device__ bool candidate_selected(const JacParams &P, int f) {
 // row-major in LDS, projected there (nullspace_core.hpp) and only the projected block goes to global memory — one launch, one
 // 1.7 MB write and one 1.7 MB read less on the update chain.  The covariance gathers of the update ride on it as extra workgroups
 // (they read the column map from the packed input block: the resident copy is being written by workgroup 0).
-__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g) {
-  extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
+__device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
+                                    const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot);
+// tri.on: the workgroup's first wave triangulates the feature before the Jacobians are built (what triangulate_kernel did in a launch
+// of its own) — while the selection loop has no cap to enforce (n_feat <= max_sel) a candidate is taken on its own verdict.
+struct PointTriStage {
+  int on, max_obs;
+  double *poses;          // [n_obs][12] scratch
+  unsigned char *valid;   // [n_obs]
+  const float *uvn;       // [n_obs][2]
+  plv_tri_options opt;
+  double *p_out;          // [F][3] == P.p_FinG of the Jacobian stage
+  unsigned char *ok_out;  // [F]
+  double *err_out;        // [F]
+};
+__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri) {
+  extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld] | triangulation scratch
   __shared__ WinTab tab[JAC_MAX_WIN];
   __shared__ int s_rows;
+  __shared__ double tri_tot[10];
   if ((int)blockIdx.x >= F) {
     gather_cov_block(g, blockIdx.x - F);
     return;
@@ -425,7 +441,15 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
   if (f == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-  const bool selected = !P.tri_ok || candidate_selected(P, f);
+  bool selected;
+  if (tri.on) {
+    if (threadIdx.x < 64) triangulate_feature(P, f, tri.poses, tri.valid, tri.uvn, tri.opt, tri.p_out, tri.ok_out, tri.err_out, tri.max_obs, piv + ld, tri_tot);
+    __threadfence_block();
+    __syncthreads();
+    selected = P.sel_flags[f] && tri.ok_out[f] && tri.err_out[f] < 3.0;
+  } else {
+    selected = !P.tri_ok || candidate_selected(P, f);
+  }
   build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill before the row writes)
   if (!selected) {
     if (threadIdx.x == 0) {
@@ -452,7 +476,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   }
   __syncthreads();
   const int rows = s_rows;
-  if (P.tri_ok && rows == 0) return;  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
+  if ((tri.on || P.tri_ok) && rows == 0) return;  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
                                       // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
   if (shift) nullspace_householder(X, piv, rows, ncol, 3);
@@ -898,21 +922,27 @@ struct TriObs {     // per valid observation, relative to the anchor pose (the n
   double pc[3];     // p_CiinA
 };
 #define TRI_TERMS 10
-__global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *poses, unsigned char *valid, const float *__restrict__ uvn,
-                                                         plv_tri_options opt, double *__restrict__ p_out,
-                                                         unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
-  extern __shared__ double tri_smem[];
+// One feature, ONE wave (the 64 lanes that call it; other waves of the workgroup must not): poses of its observations, linear
+// triangulation, Levenberg-Marquardt refinement, reprojection error.  tri_smem: max_obs * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 bytes
+// of LDS, tot: TRI_TERMS doubles of LDS.  Wave-level synchronisation only (the lanes run in lockstep; the fences order the LDS traffic).
+__device__ __forceinline__ void tri_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
+                                    const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot) {
+  const int lane = threadIdx.x & 63;
   {  // camera poses of this feature's observations (CamHelper::get_imu_poses / get_cam_poses), one lane each: no separate launch
-    const int o0 = P.obs_ptr[blockIdx.x], o1 = P.obs_ptr[blockIdx.x + 1];
-    for (int o = o0 + (int)threadIdx.x; o < o1; o += 64) campose_one(P, o, poses, valid, nullptr);
+    const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
+    for (int o = o0 + lane; o < o1; o += 64) campose_one(P, o, poses, valid, nullptr);
     __threadfence_block();
-    __syncthreads();
+    tri_wave_sync();
   }
   TriObs *ob = reinterpret_cast<TriObs *>(tri_smem);                       // [max_obs]
   double *term = tri_smem + (size_t)max_obs * (sizeof(TriObs) / 8);        // [max_obs][TRI_TERMS]
   int *list = reinterpret_cast<int *>(term + (size_t)max_obs * TRI_TERMS);  // [max_obs] indices of the valid observations
-  __shared__ double tot[TRI_TERMS];
-  const int f = blockIdx.x, lane = threadIdx.x;
   const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
   // ordered compaction of the valid observations
   int M = 0;
@@ -929,19 +959,19 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *po
     if (err_out) err_out[f] = 0;
   }
   if (M < 2) return;
-  __syncthreads();
+  tri_wave_sync();
   const int last = list[M - 1];
   const M3 R_GtoA = ldM(poses + 12 * last);  // anchor = newest observation (FeatureInitializer.cpp:44-45)
   const V3 p_AinG = ldV(poses + 12 * last + 9);
   // sums `n` terms per observation in observation order; afterwards tot[0..n) holds the totals for every lane
   auto reduce = [&](int n) {
-    __syncthreads();
+    tri_wave_sync();
     if (lane < n) {
       double s = 0;
       for (int q = 0; q < M; ++q) s += term[q * TRI_TERMS + lane];
       tot[lane] = s;
     }
-    __syncthreads();
+    tri_wave_sync();
   };
   // ---- linear triangulation: A = sum Bp^T Bp, b = sum Ai p_CiinA
   for (int q = lane; q < M; q += 64) {
@@ -1052,10 +1082,10 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *po
       const double along = p_CiinA[0] * dir[0] + p_CiinA[1] * dir[1] + p_CiinA[2] * dir[2];
       term[q * TRI_TERMS] = vnorm(vsub(p_CiinA, vsc(dir, along)));
     }
-    __syncthreads();
+    tri_wave_sync();
     double base_max = 0;
     for (int q = 0; q < M; ++q) base_max = fmax(base_max, term[q * TRI_TERMS]);
-    __syncthreads();
+    tri_wave_sync();
     if (pf[2] < opt.min_dist || pf[2] > opt.max_dist || (vnorm(pf) / base_max) > opt.max_baseline || isnan(vnorm(pf))) return;
   }
   const V3 pg = vadd(mv(tp(R_GtoA), pf), p_AinG);
@@ -1083,6 +1113,14 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *po
     ok_out[f] = 1;
     if (err_out) err_out[f] = e / M;
   }
+}
+
+__global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *poses, unsigned char *valid, const float *__restrict__ uvn,
+                                                         plv_tri_options opt, double *__restrict__ p_out,
+                                                         unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
+  extern __shared__ double tri_smem[];
+  __shared__ double tot[TRI_TERMS];
+  triangulate_feature(P, blockIdx.x, poses, valid, uvn, opt, p_out, ok_out, err_out, max_obs, tri_smem, tot);
 }
 
 
@@ -1554,21 +1592,25 @@ int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsign
   return PLV_OK;
 }
 
-int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks) {
-  ProfScope ps(ctx->prof, "jacobian_nullspace_kernel", ctx->stream);
+int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const plv_tri_options *tri_opt,
+                               double *d_poses, unsigned char *d_valid, const float *d_uvn, double *d_p, unsigned char *d_ok, double *d_err, int max_obs) {
+  ProfScope ps(ctx->prof, tri_opt ? "tri_jacobian_nullspace_kernel" : "jacobian_nullspace_kernel", ctx->stream);
   if (2 * (P.n_clones - 3) > JAC_MAX_WIN) {
     set_last_error("jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
     return PLV_E_CAPACITY;
   }
-  const size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double);
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 64 > 160 * 1024) {
+  const size_t tri_shm = tri_opt ? (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 : 0;
+  const size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double) + tri_shm;
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 256 > 160 * 1024) {
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
+  PointTriStage tri{};
+  if (tri_opt) tri = PointTriStage{1, std::max(max_obs, 1), d_poses, d_valid, d_uvn, *tri_opt, d_p, d_ok, d_err};
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
-                     g ? *g : none);
+                     g ? *g : none, tri);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

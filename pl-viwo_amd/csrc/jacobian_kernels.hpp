@@ -56,7 +56,10 @@ int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, doubl
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
 struct GatherArgs;
 // the batch built AND null-space projected in one launch (resident update path); g != null: the covariance gathers ride along
-int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks);
+// tri_opt != null: every workgroup first triangulates its feature (arguments as launch_triangulate takes them)
+int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const plv_tri_options *tri_opt = nullptr,
+                               double *d_poses = nullptr, unsigned char *d_valid = nullptr, const float *d_uvn = nullptr, double *d_p = nullptr,
+                               unsigned char *d_ok = nullptr, double *d_err = nullptr, int max_obs = 0);
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
 // Pt != null: every workgroup first triangulates its line on the state Pt (scratch and results as launch_triangulate_lines takes them)
 int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const JacParams *Pt = nullptr,

@@ -330,6 +330,24 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
 
 }  // namespace
 
+// the same test answered from a small memo: the observations of a window carry ~16 distinct time stamps (the camera frames), asked
+// for thousands of times per update
+template <class F> struct BoundingMemo {
+  F f;
+  double t[40];
+  bool v[40];
+  int n = 0;
+  explicit BoundingMemo(F f_) : f(f_) {}
+  bool operator()(double tq) {
+    for (int i = n - 1; i >= 0; --i)
+      if (t[i] == tq) return v[i];
+    const bool r = f(tq);
+    if (n < 40) t[n] = tq, v[n++] = r;
+    return r;
+  }
+};
+template <class F> BoundingMemo<F> bounding_memo(F f) { return BoundingMemo<F>(f); }
+
 extern "C" {
 
 void plv_line_tracker_destroy(plv_ctx *ctx) {
@@ -701,6 +719,7 @@ static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as
   return false;
 }
 
+
 // (internal) plv_camera_try_update turns the deferral on around its line update; plv_tracker_feed* runs what was left behind
 void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish = on != 0; }
 void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
@@ -869,6 +888,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   const auto U0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   const double dt = st->cam_dt, t_oldest = st->clone_time[0];
+  auto has_bounding = bounding_memo([st](double tq) { return line_has_bounding_poses(*st, tq); });
   typedef LineCand Cand;
   LinePool LP;
   if (T->pool_prep.valid && T->pool_prep.t_prev_frame == opt->t_prev_frame && T->pool_prep.state_time == opt->state_time && T->pool_prep.dt == dt &&
@@ -1036,7 +1056,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   std::vector<int> valid_n(Lp, 0);
   int most_valid = 0;
   for (int l = 0; l < Lp; ++l) {
-    for (double t : pool[l].tr.t) valid_n[l] += line_has_bounding_poses(*st, t + dt);
+    for (double t : pool[l].tr.t) valid_n[l] += has_bounding(t + dt);
     most_valid = std::max(most_valid, valid_n[l]);
   }
   std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
@@ -1114,7 +1134,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     const Cand &c = pool[sel[q]];
     int seen = 0;
     for (size_t i = 0; i < c.tr.t.size(); ++i) {
-      if (!line_has_bounding_poses(*st, c.tr.t[i] + dt)) {
+      if (!has_bounding(c.tr.t[i] + dt)) {
         give_back(c, i);
         continue;
       }
@@ -1172,7 +1192,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     if (!acc[q]) {  // REF UpdaterCamera.cpp:441-444 copy_to_db(lbd_unused, line): gate failures only
       const Cand &c = pool[sel[q]];
       for (size_t i = 0; i < c.tr.t.size(); ++i)
-        if (line_has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c, i);
+        if (has_bounding(c.tr.t[i] + dt)) give_back(c, i);
     }
   }
   return finish(PLV_OK);

@@ -66,6 +66,24 @@ Tracker *trk(plv_ctx *ctx) {
 
 }  // namespace
 
+// the same test answered from a small memo: the observations of a window carry ~16 distinct time stamps (the camera frames), asked
+// for thousands of times per update
+template <class F> struct BoundingMemo {
+  F f;
+  double t[40];
+  bool v[40];
+  int n = 0;
+  explicit BoundingMemo(F f_) : f(f_) {}
+  bool operator()(double tq) {
+    for (int i = n - 1; i >= 0; --i)
+      if (t[i] == tq) return v[i];
+    const bool r = f(tq);
+    if (n < 40) t[n] = tq, v[n++] = r;
+    return r;
+  }
+};
+template <class F> BoundingMemo<F> bounding_memo(F f) { return BoundingMemo<F>(f); }
+
 extern "C" {
 
 void plv_tracker_destroy(plv_ctx *ctx) {
@@ -377,6 +395,7 @@ static bool has_bounding_poses(const plv_state_view &st, double t) {
   return false;
 }
 
+
 int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                              plv_update_result *res, uint64_t *msckf_ids, uint8_t *accepted_out, double *p_out) {
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
@@ -386,6 +405,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   plv::HostPhase ph_pool("update_points: pool + staging");
   plv::RoctxRange rx_get("[Time-Cam] get features");
   const double dt = st->cam_dt;
+  auto has_bounding = bounding_memo([st](double tq) { return has_bounding_poses(*st, tq); });
   const double t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];  // no keyframes on this path
   struct Cand {
     uint64_t id;
@@ -437,7 +457,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       // slam_update's own get_imu_poses (UpdaterCamera.cpp:303-304) leaves out what has no bounding clones
       Tracker::Listed e{it->first, Track{}, {0, 0, 0}};
       for (size_t q = 0; q < keep; ++q) {
-        if (!has_bounding_poses(*st, tr.t[q] + dt)) continue;
+        if (!has_bounding(tr.t[q] + dt)) continue;
         e.tr.t.push_back(tr.t[q]);
         e.tr.uv.insert(e.tr.uv.end(), &tr.uv[2 * q], &tr.uv[2 * q] + 2);
         e.tr.uvn.insert(e.tr.uvn.end(), &tr.uvn[2 * q], &tr.uvn[2 * q] + 2);
@@ -589,7 +609,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   for (int f = 0; f < Fp; ++f) {
     ptr[f + 1] = ptr[f] + (int)pool[f].tr.t.size();
     // get_imu_poses (:327-372): observations without bounding clones do not count (and go back to the database below)
-    for (double t : pool[f].tr.t) valid_n[f] += has_bounding_poses(*st, t + dt);
+    for (double t : pool[f].tr.t) valid_n[f] += has_bounding(t + dt);
     most_valid = std::max(most_valid, valid_n[f]);
   }
   const int nobs = ptr[Fp];
@@ -695,7 +715,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     if (valid >= opt->init_min_meas && opt->n_slam + (int)T->last_init.size() < opt->max_slam) {
       Tracker::Listed e{c.id, Track{}, {pf[3 * (size_t)f], pf[3 * (size_t)f + 1], pf[3 * (size_t)f + 2]}};
       for (size_t i = 0; i < c.tr.t.size(); ++i) {
-        if (!has_bounding_poses(*st, c.tr.t[i] + dt)) {
+        if (!has_bounding(c.tr.t[i] + dt)) {
           give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
           continue;
         }
@@ -730,7 +750,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     const Cand &c = pool[sel[q]];
     int seen = 0;
     for (size_t i = 0; i < c.tr.t.size(); ++i) {
-      if (!has_bounding_poses(*st, c.tr.t[i] + dt)) {
+      if (!has_bounding(c.tr.t[i] + dt)) {
         give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
         continue;
       }
@@ -790,7 +810,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     if (!acc[q]) {  // REF UpdaterCamera.cpp:266-268: only gate failures go back; what EKFUpdate then rejects is consumed all the same
       const Cand &c = pool[sel[q]];
       for (size_t i = 0; i < c.tr.t.size(); ++i)
-        if (has_bounding_poses(*st, c.tr.t[i] + dt)) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
+        if (has_bounding(c.tr.t[i] + dt)) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
     }
   }
   return finish(PLV_OK);

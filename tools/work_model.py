@@ -58,6 +58,7 @@ def frame_work(W, H, levels, n_pts, lk_iters, win, F, M, k, n, L=0, Ml=0, kl=0, 
     }
     up = update_work(F, 2 * M, 3, k, n)
     work["jacobian_nullspace_kernel"] = ("mfma", F * M * 3000.0 + up["nullspace_kernel"])
+    work["tri_jacobian_nullspace_kernel"] = ("mfma", pool_pts * (M * 120.0 + 5 * M * 200.0) + F * M * 3000.0 + up["nullspace_kernel"])
     if L > 0:
         ul = update_work(L, 2 * Ml, 6, kl, n)
         work["line_jacobian_nullspace_kernel"] = ("mfma", L * Ml * 6000.0 + ul["nullspace_kernel"])
