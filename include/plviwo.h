@@ -191,8 +191,10 @@ int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
 int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *last_ambiguous);
 /* Process-wide activity counters since load (measurement aid, no reference counterpart): out[0] kernel launches, [1] host
  * synchronisations (stream / event waits), [2] asynchronous copies, [3] bytes copied, [4] LK iterations over all points and levels
- * (plv_perform_matching), [5] line segments the detector returned inside plv_line_tracker_feed*. */
-void plv_counters(unsigned long long *out6);
+ * (plv_perform_matching), [5] line segments the detector returned inside plv_line_tracker_feed*, [6] nanoseconds spent inside
+ * plv_camera_frame and [7] inside plv_ctx_synchronize (std::chrono::steady_clock: the library's own per-frame time, the twin of the
+ * timer inside the CPU oracle's frame). */
+void plv_counters(unsigned long long *out8);
 int plv_cov_checkpoint(plv_ctx *ctx);
 int plv_cov_rollback(plv_ctx *ctx);
 

@@ -689,11 +689,11 @@ def line_worker_config(spin_us=-1, fit_threads=-1):
 
 
 def counters():
-    """plv_counters: dict(launches, syncs, copies, copy_bytes, lk_iters, lines_detected) since the library was loaded"""
+    """plv_counters: dict(launches, syncs, copies, copy_bytes, lk_iters, lines_detected, frame_ns, sync_ns) since the library was loaded"""
     lib = load_library()
-    out = (C.c_ulonglong * 6)()
+    out = (C.c_ulonglong * 8)()
     lib.plv_counters(out)
-    return dict(zip(("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected"), [int(x) for x in out]))
+    return dict(zip(("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "frame_ns", "sync_ns"), [int(x) for x in out]))
 
 
 def default_config(width=752, height=480):

@@ -252,6 +252,7 @@ extern "C" int plv_line_tracker_feed_wait(plv_ctx *ctx);
 // plv_line_tracker_feed_wait).  bench.py ends every timed step here.
 int plv_ctx_synchronize(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);
+  plv::NsScope ns(plv::counters().sync_ns);
   TRY(plv_front_quiesce(ctx));
   (void)plv_line_tracker_feed_wait(ctx);
   TRY(sync(ctx));
@@ -311,6 +312,7 @@ int plv_cov_download(plv_ctx *ctx, double *P, int n, int ldp) {
 void plv_counters(unsigned long long *out) {
   plv::Counters &c = plv::counters();
   out[0] = c.launches, out[1] = c.syncs, out[2] = c.copies, out[3] = c.copy_bytes, out[4] = c.lk_iters, out[5] = c.lines_detected;
+  out[6] = c.frame_ns, out[7] = c.sync_ns;
 }
 int plv_cov_checkpoint(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);

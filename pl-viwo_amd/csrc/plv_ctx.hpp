@@ -31,6 +31,7 @@ void set_last_error(const char *fmt, ...);
 // Process-wide activity counters (plv_counters): what a frame costs in submissions, read by bench.py around the timed steps.
 struct Counters {
   std::atomic<unsigned long long> launches{0}, syncs{0}, copies{0}, copy_bytes{0}, lk_iters{0}, lines_detected{0};
+  std::atomic<unsigned long long> frame_ns{0}, sync_ns{0};  // wall time inside plv_camera_frame / plv_ctx_synchronize (steady_clock)
 };
 inline Counters &counters() {
   static Counters c;
@@ -79,6 +80,12 @@ inline HostPhases &host_phases() {
   static HostPhases h;
   return h;
 }
+struct NsScope {  // adds the scope's wall time to one of the counters above
+  std::atomic<unsigned long long> &acc;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit NsScope(std::atomic<unsigned long long> &a) : acc(a) {}
+  ~NsScope() { acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 struct HostPhase {  // scope timer
   const char *label;
   std::chrono::steady_clock::time_point t0;

@@ -944,6 +944,7 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
 // UpdaterCamera::feed_measurement followed by try_update (REF: UpdaterCamera.cpp:77-116, 139-195), one call per camera frame.
 int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io *io) {
   if (!ctx || !st || !io || (io->slot < 0 && !io->img)) return PLV_E_BADARG;
+  plv::NsScope ns(plv::counters().frame_ns);
   plv::RoctxRange rx_feed("[Time-Cam] feed measurement");
   if (io->slot >= 0)
     TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
