@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=24.0)
     ap.add_argument("--out")
-    ap.add_argument("--style", default="street", choices=["street", "room"], help="street: corridor drive (lines on); room: round 1's scene")
+    ap.add_argument("--style", default="street", choices=["street", "room", "avenue"], help="street: corridor drive (lines on); room: round 1's scene")
     ap.add_argument("--no-lines", action="store_true")
     ap.add_argument("--cam-hz", type=float, default=10.0)
     ap.add_argument("--size", default="752x480", help="image size; 1280x720 with --points 500 --cam-hz 20 is BASELINE configs[3]")
@@ -45,7 +45,10 @@ def main():
     res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered {a.size} images at {a.cam_hz:g} Hz, {a.points} points, 200 Hz IMU, 50 Hz wheel)",
                      lines="on in both runs" if lines else "off in both runs"), {}
     ctx = pkg.Context(pkg.default_config(W, H))
-    cfg_kw = dict(clone_freq=int(a.cam_hz), n_pts=a.points, max_msckf=70, calib_int=True, sigma_px=1.5) if (W, H) != (752, 480) else {}
+    # (the default invocation keeps round 2's configuration: 10 Hz clones, write_config's defaults; any other rate / size / point count
+    # runs with bench.py's settings: clones at the camera rate, max_msckf 70, intrinsics calibrated online, sigma_px 1.5)
+    default = (W, H) == (752, 480) and a.cam_hz == 10.0 and a.points == 250
+    cfg_kw = {} if default else dict(clone_freq=int(a.cam_hz), n_pts=a.points, max_msckf=70, calib_int=True, sigma_px=1.5)
     for name, kw in (("hip", {}), ("cpu_oracle", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
         traj = os.path.join(d, "out", f"traj_{name}.txt")
         op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj, **cfg_kw))
