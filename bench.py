@@ -373,7 +373,7 @@ def main():
     def timed_segment(n_steps):
         per_frame = {"kept": [], "tracked": []}
         cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "frame_ns", "sync_ns", "ambiguous_frames",
-                              "redone_frames")}
+                              "redone_frames", "whitened_frames")}
         base = dict(sm.stats)
         tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
         ctx.synchronize()
@@ -398,6 +398,7 @@ def main():
             _, route, amb = ctx.update_compression_mode()
             cnt["ambiguous_frames"] += 1 if amb > 0 else 0
             cnt["redone_frames"] += 1 if route == 3 else 0
+            cnt["whitened_frames"] += 1 if route == 4 else 0
         ctx.synchronize()
         barrier()
         gc.enable()
@@ -424,15 +425,15 @@ def main():
     spin_us, fit_threads = pkg.line_worker_config()
     variants = None
     if not args.no_variants:
-        # non-default library settings over the next frames of the stream (short segments, resident images): (a) the automatic
-        # compression mode — an update whose Gram factorisation reports pivots it could not resolve is redone by Householder
-        # reflections (the reference's accuracy on near-gauge directions); (b) the library's threads blocking at once instead of polling
+        # non-default library settings over the next frames of the stream (short segments, resident images): (a) the round-2
+        # compression (Gram matrix + Cholesky -> R, then the EKF step on R: one more pivot chain on the critical path, and dx loses
+        # accuracy on near-gauge directions); (b) the library's threads blocking at once instead of polling
         variants = {}
-        ctx.update_compression_mode(2)
+        ctx.update_compression_mode(3)
         v = timed_segment(nvar)
         ctx.update_compression_mode(0)
-        variants["compression_automatic"] = {"ms_per_step": v["elapsed"] / nvar * 1e3, "frames": nvar,
-                                             "frames_whose_last_update_was_redone": v["cnt"]["redone_frames"]}
+        variants["compression_gram_cholesky"] = {"ms_per_step": v["elapsed"] / nvar * 1e3, "frames": nvar,
+                                                 "frames_whose_last_update_met_ambiguous_pivots": v["cnt"]["ambiguous_frames"]}
         pkg.line_worker_config(0, -1)
         v = timed_segment(nvar)
         pkg.line_worker_config(spin_us, -1)
@@ -556,11 +557,12 @@ def main():
                                  "note": "the library's threads run the line detector's host stage (chain walk + segment growth) and the line "
                                          "tracker's bookkeeping next to the caller's thread; a waiting thread polls for poll_before_blocking_us, "
                                          "then blocks (plv_line_worker_config); cpu_baseline.detail has the CPU frame at 1, 4 and 16 threads"},
-                "compression": {"mode": "Gram matrix + blocked Cholesky (plv_update_compression_mode 0)",
-                                "frames_whose_last_update_met_ambiguous_pivots": cnt["ambiguous_frames"], "frames": args.steps,
-                                "note": "pivots of the unit-diagonal Gram matrix below 1e-9 (near-gauge directions): P' agrees with the "
-                                        "reference's Givens QR to 1e-9 regardless, dx to 1e-8 without them and to 3e-5 at worst with them "
-                                        "(tests/test_gpu_update_hard.py); config.variants.compression_automatic redoes such updates by Householder"},
+                "compression": {"mode": "whitened update (plv_update_compression_mode 0): information matrix of the accepted rows + factor "
+                                        "of the prior block on a side stream; no factor of the measurements",
+                                "frames_whose_last_update_took_it": cnt["whitened_frames"], "frames": args.steps,
+                                "note": "agrees with the Givens oracle to 1e-10 (P') and 1e-9 (dx) on every captured replay batch and up to "
+                                        "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_gram_cholesky is the "
+                                        "round-2 route (mode 3)"},
                 "variants": variants,
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "pcie_inclusive": None if seg_pcie is None else {

@@ -177,17 +177,26 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
  * dimension, gate parameters, buffer addresses) runs eagerly, the second is captured, later ones are one hipGraphLaunch.
  * Any change of shape or any device (re)allocation retires the graph.  Off by default.  captures / replays (nullable) count. */
 int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
-/* How StateHelper::measurement_compress_inplace (REF: StateHelper.cpp:602-672, Givens rotations on the stacked Jacobian) is carried
- * out inside plv_msckf_update* / the one-call camera updates:
- *   0 (default)  Gram matrix of the accepted rows + blocked Cholesky: [R z] with R^T R = H^T H.  One chain of k pivots; it carries a
- *                direction of relative strength s with a relative error of eps / s^2, so P' agrees with the reference's QR to 1e-9
- *                throughout, dx to 1e-8 as long as no pivot of the unit-diagonal Gram matrix falls below 1e-9 — near-gauge directions of
- *                a running filter do (they combine negligible information with a large prior variance): measured worst 3e-5 of |dx|;
+/* How StateHelper::measurement_compress_inplace + StateHelper::EKFUpdate (REF: StateHelper.cpp:602-672 Givens rotations on the stacked
+ * Jacobian, :94-173 the update with the compressed system) are carried out inside plv_msckf_update* / the one-call camera updates
+ * when there are more rows than columns:
+ *   0 (default)  whitened update: G = H^T H, g = H^T r over the accepted rows; Ps = P[cols, cols] = Lp Lp^T (unit-diagonal scaling,
+ *                exact dependencies such as the IMU pose and its fresh clone dropped); B = I + Lp^T G Lp = Lb Lb^T;
+ *                P' = P - W0^T W0 + V^T V, dx = V^T v with W0 = Lp^-1 P[cols, :], [V | v] = Lb^-1 [W0 | Lp^T g].  The same P', dx as
+ *                the reference's R-based update in exact arithmetic; no pivot of the measurement side is ever divided by, so the
+ *                gauge directions of an MSCKF Jacobian cost nothing: agrees with the Givens oracle to 1e-10 (P') / 1e-9 (dx) on
+ *                every captured replay batch and up to condition 1e8 of the stacked Jacobian.  The prior factor runs on a side
+ *                stream during the Jacobian / gate launches;
  *   1            Householder TSQR on the stacked rows themselves (orthogonal transformations: the reference's accuracy, ~0.7 ms);
- *   2            automatic: Gram first; when its factorisation reports pivots it could not tell from zero, nothing is committed and the
- *                update is redone through the Householder route.
- * mode < 0 only queries.  Returns the mode in force.  last_route (nullable): how the last update was compressed — 0 not at all (fewer
- * rows than columns), 1 Gram, 2 Householder, 3 Gram vetoed and redone; last_ambiguous (nullable): the pivots below 1e-9 it met. */
+ *   2            automatic: Gram + Cholesky first; when its factorisation reports pivots it could not tell from zero, nothing is
+ *                committed and the update is redone through the Householder route;
+ *   3            Gram matrix + blocked Cholesky: [R z] with R^T R = H^T H (the round-2 default).  It carries a direction of relative
+ *                strength s with a relative error of eps / s^2: P' agrees to 1e-9 throughout, dx to 1e-8 as long as no pivot of the
+ *                unit-diagonal Gram matrix falls below 1e-9 — near-gauge directions of a running filter do: measured worst 3e-5 of |dx|.
+ * (Beyond 192 measured columns, or in graph mode, 0 behaves as 3 / falls back to 1.)
+ * mode < 0 only queries.  Returns the mode in force.  last_route (nullable): how the last update was carried out — 0 not compressed
+ * (fewer rows than columns), 1 Gram, 2 Householder, 3 Gram vetoed and redone, 4 whitened; last_ambiguous (nullable): the pivots below
+ * 1e-9 a Gram factorisation met. */
 int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *last_ambiguous);
 /* Process-wide activity counters since load (measurement aid, no reference counterpart): out[0] kernel launches, [1] host
  * synchronisations (stream / event waits), [2] asynchronous copies, [3] bytes copied, [4] LK iterations over all points and levels

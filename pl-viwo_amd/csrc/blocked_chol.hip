@@ -51,6 +51,9 @@ struct CompressOps {
   }
 };
 
+// pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
+// the smallest live one 1.5e-7; DESIGN.md "Whitened update")
+#define PLV_PRIOR_TAU 2e-13
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
@@ -74,6 +77,73 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const dou
   blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc, 0, PLV_COMPRESS_AMBIGUOUS);
   __syncthreads();
   if (n_ambiguous && threadIdx.x == 0) *n_ambiguous = lds.n_amb;
+}
+
+// ------------------------------------------------------------------------------------------ prior factor
+// The whitened route of the compressed update (DESIGN.md "Whitened update"): Ps = P[cols, cols] = Lp Lp^T with the rows
+// P[:, cols] as borders,  W0^T = P[:, cols] Lp^-T.  Ps is factored after scaling to unit diagonal; a pivot below tau marks a state that
+// is an exact linear function of earlier ones (the IMU pose and the clone just taken of it): its column of Lp is zero and it carries
+// no weight, which is what the semi-definite prior says.  Outputs in the layouts the EKF kernels already use:
+//   Lt (k x k, Lt(c, i) = Lp(i, c) at Lt[i * ldl + c]) — the "H" operand of ekf_ms_kernel;  W0 (border b = state b at W0[b * ldw + c]).
+struct PriorOps {
+  static constexpr bool kStoreL = true;
+  const double *P;  // n x n, both triangles valid
+  int ldp, n;
+  const int *cols;
+  int k;
+  const double *sc;
+  double *Lt;
+  int ldl;
+  double *W0;
+  int ldw;
+  double dval;
+  double *scw;
+  bool store_l;  // one workgroup writes the factor, every workgroup its own border strip
+  __device__ __forceinline__ double sym_raw(int i, int c) const {
+    return P[(size_t)cols[min(i, k - 1)] * ldp + cols[min(c, k - 1)]];
+  }
+  __device__ __forceinline__ double border_raw(int b, int c) const { return P[(size_t)cols[min(c, k - 1)] * ldp + min(b, n - 1)]; }
+  __device__ __forceinline__ void scales_ready() const {
+    const int j = threadIdx.x;
+    if (j < 192) {
+      const bool ok = j < k && dval > 0.0;
+      const double rt = sqrt(ok ? dval : 1.0);
+      scw[j] = ok ? 1.0 / rt : 0.0;
+      scw[192 + j] = ok ? rt : 0.0;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ double sym_fix(int i, int c, double g) const {
+    const bool pad = i >= k || c >= k;
+    return pad ? (i == c ? 1.0 : 0.0) : g * sc[min(i, k - 1)] * sc[min(c, k - 1)];
+  }
+  __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b < n && c < k) ? g * sc[min(c, k - 1)] : 0.0; }
+  __device__ __forceinline__ void store_sym(int i, int c, double l) const {
+    if (store_l && i < k && c <= i) {
+      Lt[(size_t)i * ldl + c] = l * sc[192 + i];
+      if (c < i) Lt[(size_t)c * ldl + i] = 0.0;
+    }
+  }
+  __device__ __forceinline__ void store_border(int b, int c, double v) const {
+    if (b < n && c < k) W0[(size_t)b * ldw + c] = v;
+  }
+};
+
+template <int NT>
+__global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double *__restrict__ P, int ldp, int n, const int *__restrict__ cols,
+                                                                   int k, double *__restrict__ Lt, int ldl, double *__restrict__ W0, int ldw) {
+  __shared__ BcLds lds;
+  __shared__ double sc[384];
+  const int jd = cols[min((int)threadIdx.x, k - 1)];
+  PriorOps ops{P, ldp, n, cols, k, sc, Lt, ldl, W0, ldw, P[(size_t)jd * ldp + jd], sc, blockIdx.x == 0};
+  if (threadIdx.x == 0) {
+    lds.bad = 0;
+    lds.step_flag = 0;
+    lds.rs_flag = 0;
+    lds.n_amb = 0;
+  }
+  // (no barrier needed here: scales_ready() has one before any wave reads the flags)
+  blocked_chol<NT>(ops, lds, k, n, PLV_PRIOR_TAU, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------ EKF
@@ -171,6 +241,30 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   else
     hipLaunchKernelGGL(bchol_ekf_kernel<12>, dim3(groups), dim3(64 * 13), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
                        ldw, d_flag, ctx->skip_word);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+// Prior factor of the whitened route on stream `st` (a side stream: it only needs the covariance).
+int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp, int n, const int *d_cols, int k, double *d_Lt, int ldl,
+                       double *d_W0, int ldw) {
+  if (k > 192) return PLV_E_CAPACITY;
+  const int groups = cdiv(n, 16);
+  ProfScope ps(ctx->prof, "bchol_prior_kernel", st);
+#define PLV_PRIOR_LAUNCH(NT) \
+  hipLaunchKernelGGL(bchol_prior_kernel<NT>, dim3(groups), dim3(64 * (NT + 1)), 0, st, d_P, ldp, n, d_cols, k, d_Lt, ldl, d_W0, ldw)
+  if (k <= 32)
+    PLV_PRIOR_LAUNCH(2);
+  else if (k <= 64)
+    PLV_PRIOR_LAUNCH(4);
+  else if (k <= 112)
+    PLV_PRIOR_LAUNCH(7);
+  else if (k <= 128)
+    PLV_PRIOR_LAUNCH(8);
+  else if (k <= 160)
+    PLV_PRIOR_LAUNCH(10);
+  else
+    PLV_PRIOR_LAUNCH(12);
+#undef PLV_PRIOR_LAUNCH
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restri
 // the accepted entries (acc_rows[f] > 0) and walk only their rows straight from the L2-resident stack — a wave's operand loads go
 // down 16 columns, 16 k-steps in flight — and the four accumulators are added in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restrict__ A, int lda, int nc, const int *__restrict__ acc_rows, int F,
-                                                          int mp_max, double *__restrict__ G, const int *__restrict__ skip) {
+                                                          int mp_max, double *__restrict__ G, const int *__restrict__ skip,
+                                                          double *__restrict__ Gs, double *__restrict__ gv) {
   if (skip && *skip == 0) return;
   __shared__ double part[3][256];
   const int nt = (nc + 15) >> 4;
@@ -142,7 +143,13 @@ __global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restri
     for (int q = 0; q < 4; ++q) {
       const double v = ((acc[q] + part[0][q * 64 + lane]) + part[1][q * 64 + lane]) + part[2][q * 64 + lane];
       const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + li;
-      if (i < nc && j < nc) G[(size_t)j * nc + i] = v;
+      if (Gs) {  // whitened route: the information matrix H^T H as a full symmetric k x k block and H^T r as a vector
+        const int k = nc - 1;
+        if (i < k && j < k) Gs[(size_t)j * k + i] = v, Gs[(size_t)i * k + j] = v;
+        if (i < k && j == k) gv[i] = v;
+      } else if (i < nc && j < nc) {
+        G[(size_t)j * nc + i] = v;
+      }
     }
   }
 }
@@ -151,7 +158,10 @@ __global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restri
 // [dC | dx] = W[:, :n]^T [W[:, :n] | y]  (upper tiles; dC = K M^T of the reference, y = W[:, n]).
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
                                                      double *__restrict__ dC, int ldc, double *__restrict__ dx,
-                                                     const double *__restrict__ P, int ldp, int *__restrict__ flag, const int *__restrict__ skip) {
+                                                     const double *__restrict__ P, int ldp, int *__restrict__ flag, const int *__restrict__ skip,
+                                                     const double *__restrict__ dW) {
+  // dW (whitened route): dC = dW - W^T W with dW = W0^T W0 formed ahead of time on the side stream (same tiles, same layout);
+  // that earlier launch is this kernel with dx = P = null: products only
   if (skip && *skip == 0) return;
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
@@ -173,10 +183,11 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
-    if (i < n && j < n) dC[(size_t)j * ldc + i] = acc[q];
-    if (i < n && j == n) dx[i] = acc[q];
+    const double v = (dW && i < n && j < n) ? dW[(size_t)j * ldc + i] - acc[q] : acc[q];
+    if (i < n && j < n) dC[(size_t)j * ldc + i] = v;
+    if (dx && i < n && j == n) dx[i] = acc[q];
     // REF: StateHelper.cpp:143-152 — any P_ii - (K M^T)_ii < 0 rejects the update; the commit kernel reads the flag
-    if (i == j && i < n && P[(size_t)i * ldp + i] - acc[q] < 0.0) atomicOr(flag, 1);
+    if (P && i == j && i < n && P[(size_t)i * ldp + i] - v < 0.0) atomicOr(flag, 1);
   }
 }
 
@@ -231,7 +242,8 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
   if (d_acc_rows && F * mp_max == m && !chunked_only) {
     {
       ProfScope ps(ctx->prof, "gram_direct_kernel", ctx->stream);
-      hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_G, ctx->skip_word);
+      hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_G, ctx->skip_word,
+                         (double *)nullptr, (double *)nullptr);
     }
     return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z, d_n_ambiguous);
   }
@@ -249,6 +261,8 @@ int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc
 }
 
 bool ekf_fast_fits(int r) { return r <= 192; }
+static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const double *dC, double *d_dx, int *d_flag, const void *mirror_src,
+                             void *mirror_dst, size_t mirror_bytes);
 
 // EKF update with the identity-border Cholesky.  Requires ekf_fast_fits(r).
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
@@ -266,8 +280,14 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
     int tn = cdiv(n + 1, 16);
     int waves = tn * (tn + 1) / 2;
-    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word);
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
+                       (const double *)nullptr);
   }
+  return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
+}
+
+static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const double *dC, double *d_dx, int *d_flag, const void *mirror_src,
+                             void *mirror_dst, size_t mirror_bytes) {
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
     hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
@@ -278,6 +298,62 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
+}
+
+// ------------------------------------------------------------------------------------------ whitened update
+// The compressed update without a factorisation of the measurement side (DESIGN.md "Whitened update").  With G = H^T H, g = H^T r
+// (noise-normalised, as the reference's compression leaves them) and Ps = P[cols, cols] = Lp Lp^T:
+//     S^-1 on the compressed system  ==  the k x k matrix  B = I + Lp^T G Lp  on the whitened one, and
+//     P' = P - W0^T W0 + V^T V,   dx = V^T v      with  W0 = Lp^-1 P[cols, :],  [V | v] = Lb^-1 [W0 | Lp^T g],  B = Lb Lb^T.
+// Nothing is ever divided by a pivot of G: directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian)
+// simply add nothing to B.  The prior factor and W0^T W0 only need the covariance, so they run on a side stream while the main
+// stream triangulates, builds Jacobians and gates; the main chain after the gate is  gram -> B -> factor B -> dC -> commit.
+int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k) {
+  int rc;
+  if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
+      (rc = ctx->d_dW.reserve((size_t)n * n * 8)))
+    return rc;
+  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k))) return rc;
+  {
+    ProfScope ps(ctx->prof, "prior_gain_kernel", st);
+    const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, st, ctx->d_W0.as<double>(), k, k, n, ctx->d_dW.as<double>(), n,
+                       (double *)nullptr, (const double *)nullptr, 0, (int *)nullptr, (const int *)nullptr, (const double *)nullptr);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// Information matrix of the accepted rows of the stack (d_Gs k x k, d_gv k), on the main stream.
+int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max) {
+  const int k = nc - 1, nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
+  int rc;
+  if ((rc = ctx->d_Gs.reserve(((size_t)k * k + k) * 8))) return rc;
+  ProfScope ps(ctx->prof, "gram_direct_kernel", ctx->stream);
+  hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, (double *)nullptr,
+                     ctx->skip_word, ctx->d_Gs.as<double>(), ctx->d_Gs.as<double>() + (size_t)k * k);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// The main-stream part after launch_gram_information; the caller has made the stream wait for launch_prior_factor's end.
+int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, double *d_dx, int *d_flag, const void *mirror_src, void *mirror_dst,
+                        size_t mirror_bytes) {
+  int rc;
+  if ((rc = ctx->d_Mt.reserve((size_t)k * 8)) || (rc = ctx->d_S.reserve((size_t)k * k * 8)) || (rc = ctx->d_W.reserve((size_t)k * (n + 1) * 8)) ||
+      (rc = ctx->d_y.reserve((size_t)n * n * 8)))
+    return rc;
+  double *cv = ctx->d_Mt.as<double>(), *B = ctx->d_S.as<double>(), *V = ctx->d_W.as<double>(), *dC = ctx->d_y.as<double>();
+  const double *Gs = ctx->d_Gs.as<double>(), *gv = Gs + (size_t)k * k;
+  launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag);
+  if ((rc = launch_bchol_ekf(ctx, B, k, k, ctx->d_W0.as<double>(), k, n, cv, V, k, d_flag))) return rc;
+  {
+    ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
+    const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
+                       ctx->d_dW.as<double>());
+  }
+  return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
 
 }  // namespace plv

@@ -237,11 +237,13 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       const int n = ctx->cov_n;
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
+      TRY(plv_prior_prefetch(ctx, 0, P.cols_in, k, F, ld - 3));
     }
     if (fuse_tri)
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, tri_opt, tri_poses, tri_valid, tri_uvn, tri_p, tri_ok, tri_err, tri_max_obs));
     else
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    if (can_gather) TRY(plv_prior_prefetch(ctx, 1, P.cols_in, k, F, ld - 3));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {
@@ -607,11 +609,13 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
       const int n = ctx->cov_n;
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
+      TRY(plv_prior_prefetch(ctx, 0, P.cols_in, k, L, ld - 6));
     }
     if (fuse_tri)
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
     else
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    if (can_gather) TRY(plv_prior_prefetch(ctx, 1, P.cols_in, k, L, ld - 6));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

@@ -181,6 +181,10 @@ int plv_ctx_create(const plv_config *cfg, plv_ctx **out) {
     return PLV_E_DEVICE;
   }
   auto *us = new plv_ctx_update_state();
+  if (const char *e = getenv("PLV_COMPRESS_MODE")) {  // (measurement aid: tools/ab.sh compares the routes on one box)
+    const int m = atoi(e);
+    if (m >= 0 && m <= 3) us->compress_mode = m;
+  }
   // chi-square table (REF: UpdaterStatistics.cpp:31-37)
   std::vector<double> q(Q95_N, 0.0);
   for (int i = 1; i < Q95_N; ++i) q[i] = chi2_quantile(i, 0.95);
@@ -215,8 +219,14 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_P2, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
                          &ctx->d_Mt, &ctx->d_S, &ctx->d_W, &ctx->d_y, &ctx->d_fHf, &ctx->d_fHx, &ctx->d_fres,
                          &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2, &ctx->d_Pc, &ctx->d_Ps,
-                         &ctx->d_inv, &ctx->d_T};
+                         &ctx->d_inv, &ctx->d_T, &ctx->d_Lt, &ctx->d_W0, &ctx->d_dW, &ctx->d_Gs};
   for (auto *b : bufs) b->release();
+  if (ctx->aux_stream) {
+    (void)plv::stream_sync(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+  }
+  if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   ctx->h_pin.release();
   plv_ctx_update_state *us = nullptr;
   {
@@ -598,6 +608,42 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   return sync(ctx);
 }
 
+static bool whitened_route(const plv_ctx_update_state *us, int Mtot, int k) {
+  return Mtot > k && k <= 192 && us->compress_mode == 0 && !us->graph_mode;
+}
+// Side stream: behind everything the main stream held when prior_mark() was called (the previous update's commit, the upload that
+// carries d_cols), factor the prior block and form W0^T W0; aux_join is recorded behind them.  Two steps so that a caller can mark,
+// enqueue its own next launch on the main stream first (the host's enqueue time of the side work then overlaps that launch's run
+// time instead of delaying it), and start the side work afterwards.
+static int prior_mark(plv_ctx *ctx) {
+  if (!ctx->aux_stream) {
+    PLV_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  }
+  PLV_HIP_CHECK(hipEventRecord(ctx->aux_fork, ctx->stream));
+  return PLV_OK;
+}
+static int prior_start(plv_ctx *ctx, const int *d_cols, int k) {
+  const int n = ctx->cov_n;
+  PLV_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+  TRY(launch_prior_factor(ctx, ctx->aux_stream, ctx->d_P.as<double>(), n, n, d_cols, k));
+  PLV_HIP_CHECK(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+  return PLV_OK;
+}
+// Called by the one-submission updates (jacobian_api.hip) with the update's shape: phase 0 between their upload and their Jacobian
+// launch, phase 1 right after that launch.  When the update will take the whitened route its prior factor runs next to triangulation,
+// Jacobians and gate.
+int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max) {
+  auto *us = ustate(ctx);
+  if (!whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
+  if (phase == 0) return prior_mark(ctx);
+  TRY(prior_start(ctx, d_cols, k));
+  ctx->prior_pending = true;
+  ctx->prior_k = k;
+  return PLV_OK;
+}
+
 int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mult, double res_norm_gate) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
@@ -651,13 +697,33 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   const bool projected = us->b_projected;
   const bool gathers_valid = projected && us->b_gather_token != 0 && us->b_gather_token == ctx->gather_stamp;
   us->b_gather_token = 0;
+  // (the prefetched prior factor stands exactly as long as the gathers that rode on the same launch do)
+  const bool prior_was_pending = ctx->prior_pending;
+  const bool prefetched = prior_was_pending && ctx->prior_k == k && gathers_valid;
+  ctx->prior_pending = false;
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
   TRY(ctx->h_pin.reserve(rb));
   struct SkipGuard {  // the words are only meaningful for the kernels of this update
     plv_ctx *c;
     ~SkipGuard() { c->skip_word = nullptr, c->commit_veto = nullptr; }
   } skip_guard{ctx};
+  // Whitened route (mode 0, DESIGN.md "Whitened update").  Its prior factor only needs the covariance: the one-submission updates
+  // start it on the side stream before their Jacobian launch (plv_prior_prefetch); otherwise it starts here.
+  const bool whiten = whitened_route(us, Mtot, k);
+  bool aux_open = prior_was_pending;  // (a prefetch that is not taken after all is still joined: the main stream rewrites the covariance)
+  auto aux_join = [&]() -> int {  // the main stream goes on only when the side work is done (it reads the covariance)
+    if (!aux_open) return PLV_OK;
+    aux_open = false;
+    PLV_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+    return PLV_OK;
+  };
   auto enqueue = [&]() -> int {
+  if (whiten && !prefetched) {
+    TRY(aux_join());
+    TRY(prior_mark(ctx));
+    TRY(prior_start(ctx, us->bcols.as<int>(), k));
+    aux_open = true;
+  }
   if (!projected) {
     // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
     TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
@@ -689,7 +755,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.n_acc = d_flag + 1;           // second word of the status block
   // with more rows than columns the stack goes to gram_direct_kernel, which walks the accepted entries only (not in the modes that may
   // hand the whole stack to the Householder route, nor beyond its 192-column capacity)
-  a.stack_accepted_only = (Mtot > k && k <= 192 && us->compress_mode == 0 && !getenv("PLV_GRAM_CHUNKED")) ? 1 : 0;
+  a.stack_accepted_only = (Mtot > k && k <= 192 && (whiten || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
   // read by every kernel enqueued from here on (cleared after enqueue()); only the blocked-Cholesky route honours it in all of
   // its kernels, so the Householder / LDS-resident fallbacks (more than 192 columns) run unconditionally
   ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;
@@ -714,7 +780,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     if (!any) {
       memset(ctx->h_pin.p, 0, (size_t)n * 8 + 16);  // dx = 0, status = updated-with-nothing (as the skipped chain reports it)
       ctx->probe_done = true;
-      return PLV_OK;
+      return aux_join();
     }
   }
 
@@ -722,6 +788,14 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int r, ldh;
   us->last_route = 0;
   us->redo.armed = false;
+  if (whiten) {
+    // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
+    TRY(launch_gram_information(ctx, ctx->d_stack.as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
+    TRY(aux_join());
+    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, d_dx, d_flag, us->result.p, ctx->h_pin.p, (rb + 3) & ~(size_t)3));
+    us->last_route = 4;
+    return PLV_OK;
+  }
   if (Mtot > k) {
     // REF: measurement_compress_inplace — [R z] with R^T R = H^T H (Gram + LDS Cholesky)
     TRY(ctx->d_H.reserve((size_t)k * k * 8));
@@ -812,7 +886,10 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       us->gseen = true;
     }
   } else {
-    TRY(enqueue());
+    const int erc = enqueue();
+    const int jrc = aux_join();  // (also on an error path: what follows on the main stream may rewrite the covariance)
+    if (erc) return erc;
+    if (jrc) return jrc;
   }
   ++ctx->gather_stamp;  // the update rewrites the covariance
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
@@ -825,7 +902,7 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   if (mode >= 0) {
-    if (mode > 2) return PLV_E_BADARG;
+    if (mode > 3) return PLV_E_BADARG;
     us->compress_mode = mode;
   }
   if (last_route) *last_route = us->last_route;

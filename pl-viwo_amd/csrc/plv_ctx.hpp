@@ -306,6 +306,12 @@ struct plv_ctx {
   plv::DevBuf d_Pc, d_Ps, d_inv, d_T;       // dense covariance gathers, H'Ps
   plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
+  // whitened route: prior factor Lp^T, W0 = Lp^-1 P[cols, :], W0^T W0 (side stream), information matrix [G | g] (main stream)
+  plv::DevBuf d_Lt, d_W0, d_dW, d_Gs;
+  hipStream_t aux_stream = nullptr;  // work that only needs the covariance, concurrent with the Jacobians and the gate
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  bool prior_pending = false;  // plv_prior_prefetch started the prior factor for the update about to be launched (k = prior_k)
+  int prior_k = 0;
   plv::PinBuf h_pin;
 
   // Device word holding the number of features the gate accepted in the update being enqueued (null outside

@@ -784,6 +784,15 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
                      ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word);
 }
 
+// Whitened route: B = Lp^T G Lp + I (k x k, upper tiles) and c = Lp^T g — ekf_ms_kernel with H := Lp^T (Lt), "Ps" := G (full
+// symmetric) and "Pc" := g as a k x 1 block.
+void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag) {
+  ProfScope ps(ctx->prof, "ekf_ms_kernel", ctx->stream);
+  const int mt_blocks = cdiv(cdiv(k, 16), 4);
+  hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(k, 16)), dim3(256), 0, ctx->stream, Lt, k, k, k, gv, 1, 1, Gs, cv, k,
+                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word);
+}
+
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
 // 0 (updated), bit0 (negative diagonal), bit1 (S not positive definite).
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,

@@ -16,10 +16,11 @@ struct plv_ctx_update_state {
   bool b_projected = false;       // the batch is already null-space projected (jacobian_nullspace_kernel)
   unsigned long long b_gather_token = 0;  // plv_ctx::gather_stamp right after the gathers that rode on the batch's launch (0: none)
   std::vector<int> brows_host;
-  // measurement compression (plv_update_compression_mode): 0 = Gram matrix + blocked Cholesky, 1 = Householder TSQR on the stacked
-  // rows, 2 = Gram first, redone through the Householder route when its factorisation reports pivots it could not resolve
+  // measurement compression (plv_update_compression_mode): 0 = whitened update (information matrix + factor of the prior block; no
+  // factor of the measurements), 1 = Householder TSQR on the stacked rows, 2 = Gram + Cholesky first, redone through the Householder
+  // route when its factorisation reports pivots it could not resolve, 3 = Gram matrix + blocked Cholesky (the round-2 default)
   int compress_mode = 0;
-  int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder
+  int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder, 4 whitened
   int last_ambiguous = 0;   // pivots the last Gram factorisation could not tell from zero
   struct Redo {             // what the automatic mode needs to run the update again from the stacked rows
     bool armed = false;
@@ -56,6 +57,8 @@ struct plv_ctx_update_state {
   plv::PinBuf h_tri;  // triangulation results of the one-submission updates
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
+
+extern "C" int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max);  // plv_api.hip
 
 // internal entry points of jacobian_api.hip used by the one-call camera updates (tracker_api.hip, line_api.hip)
 extern "C" int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,

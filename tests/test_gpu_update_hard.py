@@ -1,15 +1,18 @@
-"""Parity of the SUBSTITUTED algorithms of the update path on inputs that are not benign: the library compresses by Gram matrix +
-blocked Cholesky where the reference (and the oracle) run Givens rotations on the stacked Jacobian (StateHelper.cpp:602-672), and its
-fused Jacobian launches project with Householder reflections where the reference runs Givens (:616-651).  Cases:
+"""Parity of the SUBSTITUTED algorithms of the update path on inputs that are not benign: where the reference (and the oracle) run
+Givens rotations on the stacked Jacobian and then the EKF step (StateHelper.cpp:602-672, :94-173), the library forms the information
+matrix of the stacked rows and updates in coordinates whitened by a factor of the prior block (the default, "whitened" route; the
+round-2 route — Gram matrix + Cholesky giving the same R as the Givens QR — stays selectable as mode 3), and its fused Jacobian
+launches project with Householder reflections where the reference runs Givens (:616-651).  Cases:
   * batches a running filter produced (tests/golden/replay_batches.npz, made by tests/golden/make_replay_batches.py from the CPU
     oracle's replay of a rendered drive): FEJ linearisation points, unobservable gauge directions, calibration columns, ragged tracks;
   * column spaces of prescribed condition number 1e2 .. 1e8;
   * duplicated features and rows scaled by 1e+-3;
   * exact null directions (columns that cancel to rounding).
-What is compared is what the filter keeps: the accepted set, dx and P' (both sides fp64).  Tolerance as a function of the condition
-number c of the column-equilibrated stacked Jacobian: P' and dx agree to 1e-8 relative up to c = 1e4 (everything a replay produced sits
-below 1.1e5), 1e-7 at 1e6; beyond that the Gram matrix no longer resolves the weakest directions (eps c^2 > 1) and the library says so
-instead of answering: see test_compression_reports_what_it_cannot_resolve."""
+What is compared is what the filter keeps: the accepted set, dx and P' (both sides fp64).  Tolerances: the default route agrees with
+the oracle to 1e-9 (P' and dx, relative to the largest entry) on every replay batch and for column spaces of condition 1e2 .. 1e8; the
+Gram + Cholesky route (mode 3) holds 1e-8 up to condition 1e4 and 1e-7 at 1e6 on well-posed priors, loses dx to 3e-5 on replay batches
+whose Gram matrix has pivots it cannot tell from zero (it reports them), and cannot resolve condition 1e8 at all (eps c^2 > 1): see
+test_compression_reports_what_it_cannot_resolve."""
 import os
 
 import numpy as np
@@ -31,10 +34,10 @@ def _batches():
         yield j, {k[len(f"b{j}_"):]: g[k] for k in g.files if k.startswith(f"b{j}_")}
 
 
-@pytest.mark.parametrize("mode", [0, 2, 1])
+@pytest.mark.parametrize("mode", [0, 3, 2, 1])
 def test_replay_captured_batches(ctx, mode):
-    """mode 0 = Gram + blocked Cholesky (the default), 2 = automatic (redone by Householder when the Gram factorisation reports pivots it
-    could not resolve), 1 = Householder throughout (plv_update_compression_mode)"""
+    """mode 0 = whitened update (the default), 3 = Gram + blocked Cholesky, 2 = automatic (Gram first, redone by Householder when its
+    factorisation reports pivots it could not resolve), 1 = Householder throughout (plv_update_compression_mode)"""
     ctx.update_compression_mode(mode)
     try:
         n_checked = n_amb = n_redone = 0
@@ -52,6 +55,9 @@ def test_replay_captured_batches(ctx, mode):
             assert np.array_equal(P1, P1.T)
             assert e_P < 1e-9, (j, e_P)
             if mode == 0:
+                assert e_dx < 1e-9 and e_P < 1e-10, (j, e_dx, e_P)
+                assert route in (0, 4) and amb == 0, (j, route)
+            elif mode == 3:
                 if amb == 0:
                     worst_dx_clean = max(worst_dx_clean, e_dx)
                     assert e_dx < 1e-8, (j, e_dx)
@@ -113,9 +119,17 @@ def _truth(P, rows, Hf, Hx, res, cols, acc):
     return (Pl - M @ KT).astype(np.float64), (KT.T @ rl).astype(np.float64)
 
 
-@pytest.mark.parametrize("cond,tol", [(1e2, 1e-8), (1e4, 1e-8), (1e6, 1e-7)])
-def test_msckf_update_conditioned_columns(ctx, oracle, cond, tol):
+@pytest.mark.parametrize("mode,cond,tol", [(0, 1e2, 1e-9), (0, 1e4, 1e-9), (0, 1e6, 1e-9), (0, 1e8, 1e-9), (3, 1e2, 1e-8), (3, 1e4, 1e-8), (3, 1e6, 1e-7)])
+def test_msckf_update_conditioned_columns(ctx, oracle, mode, cond, tol):
     """every feature's Jacobian mixed through one k x k matrix of the given condition number: the stacked Jacobian inherits it"""
+    ctx.update_compression_mode(mode)
+    try:
+        _conditioned_case(ctx, oracle, cond, tol)
+    finally:
+        ctx.update_compression_mode(0)
+
+
+def _conditioned_case(ctx, oracle, cond, tol):
     n, k, F, M = 60, 44, 12, 6
     P = synth.spd_cov(n, seed=3)
     cols = synth.col_map(n, k, seed=4, skip=15)
@@ -144,8 +158,12 @@ def test_compression_reports_what_it_cannot_resolve(ctx, oracle, pkg):
     rows, Hf, Hx, res = synth.msckf_batch(F=F, M=M, k=k, seed=5, outlier_frac=0.0)
     Hx = np.einsum("ab,fbi->fai", _conditioned(k, 1e8, 6).T, Hx)
     rc0, P0, dx0, acc0, _ = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, synth.q95_table(), 1e6, 0.0)
-    rc1, P1, dx1, acc1, _ = ctx.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, 1e6, 0.0)
-    _, route, amb = ctx.update_compression_mode()
+    ctx.update_compression_mode(3)
+    try:
+        rc1, P1, dx1, acc1, _ = ctx.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, 1e6, 0.0)
+        _, route, amb = ctx.update_compression_mode()
+    finally:
+        ctx.update_compression_mode(0)
     assert rc0 == rc1 == 0 and np.array_equal(acc0, acc1)
     assert route == 1 and amb > 0                      # it knows
     print(f"cond 1e8, Gram route: {amb} ambiguous pivots, library vs oracle dx {_rel(dx1, dx0):.2e} P {_rel(P1, P0):.2e}")

@@ -6,13 +6,18 @@ F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix figure (v_mfma_f64_16x16x4_f64)
 HBM_KERNELS = {"gram_reduce_kernel", "gather_cov_kernel", "ekf_commit_kernel"}
 
 
-def update_work(F, rows_f, fdim, k, n, qr_launches=1):
-    """F features of rows_f rows (before the null-space projection removes fdim of them) on k columns of an n-state filter."""
+def update_work(F, rows_f, fdim, k, n, qr_launches=1, whitened=True):
+    """F features of rows_f rows (before the null-space projection removes fdim of them) on k columns of an n-state filter.
+    whitened: the default route when there are more rows than columns (DESIGN.md "Whitened update") — ekf_ms_kernel then forms
+    B = I + Lp^T G Lp and Lp^T g instead of Mt and S."""
     mp = max(rows_f - fdim, 0)
     m = F * mp
     nc = k + 1
     r = min(k, m) if m > 0 else k
+    wh = whitened and m > k and k <= 192
     return {
+        "bchol_prior_kernel": k ** 3 / 3.0 + 1.0 * k * k * n,      # factor of P[cols, cols] + the n border rows P[:, cols]
+        "prior_gain_kernel": 1.0 * n * n * k,                      # W0^T W0, upper tiles
         "nullspace_kernel": F * 6.0 * (fdim + k + 1) * max(rows_f * fdim - fdim * (fdim + 1) / 2, 0),
         "chi2_gate_kernel": F * (2.0 * mp * mp * k + mp ** 3 / 3.0),
         "chi2_t_kernel": F * 2.0 * mp * k * k,
@@ -27,7 +32,8 @@ def update_work(F, rows_f, fdim, k, n, qr_launches=1):
         "ekf_commit_kernel": 3.0 * n * n * 8,
         "ekf_mt_kernel": 2.0 * n * k * r,
         "ekf_s_kernel": 2.0 * r * r * k,
-        "ekf_ms_kernel": 2.0 * n * k * r + 2.0 * r * k * k + 1.0 * r * r * k,     # Mt tiles + every strip's own H Ps + the upper S tiles
+        # Mt tiles + every strip's own H Ps + the upper S tiles (whitened: one column instead of the n of Mt)
+        "ekf_ms_kernel": 2.0 * (1 if wh else n) * k * r + 2.0 * r * k * k + 1.0 * r * r * k,
     }
 
 
