@@ -311,6 +311,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the short segments with non-default library settings (config.variants)")
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
+    ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
+                    "plv_update_compression_mode settings frame by frame and stderr gets the mean step time of each (drift-free A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     args = ap.parse_args()
@@ -370,6 +372,8 @@ def main():
     ctx = sm.ctx
     pl = Player(stream, sm, staged=True)
 
+    alt_modes = [int(m) for m in args.alternate_modes.split(",")] if args.alternate_modes else None
+
     def timed_segment(n_steps):
         per_frame = {"kept": [], "tracked": []}
         cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "frame_ns", "sync_ns", "ambiguous_frames",
@@ -383,6 +387,8 @@ def main():
         elapsed, per = 0.0, []
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
+            if alt_modes:
+                ctx.update_compression_mode(alt_modes[f % len(alt_modes)])
             c0 = pkg.counters()
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
@@ -402,6 +408,11 @@ def main():
         ctx.synchronize()
         barrier()
         gc.enable()
+        if alt_modes:
+            ctx.update_compression_mode(0)
+            for j, m in enumerate(alt_modes):
+                v = per[j::len(alt_modes)]
+                print(f"[alternate] mode {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
         stats = {k: sm.stats[k] - base.get(k, 0) for k in sm.stats}
         split = {}
         for k, v in sm.tc.total.items():

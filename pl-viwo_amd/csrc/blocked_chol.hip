@@ -130,10 +130,16 @@ struct PriorOps {
 };
 
 template <int NT>
-__global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double *__restrict__ P, int ldp, int n, const int *__restrict__ cols,
+__global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double *__restrict__ P, int ldp, int n, const int *__restrict__ cols_g,
                                                                    int k, double *__restrict__ Lt, int ldl, double *__restrict__ W0, int ldw) {
   __shared__ BcLds lds;
   __shared__ double sc[384];
+  __shared__ int scols[192];
+  // the column map may sit in pinned host memory (the one-submission updates start this kernel before their upload has run): it is
+  // read once, coalesced, and indexed from LDS afterwards
+  if (threadIdx.x < 192) scols[threadIdx.x] = cols_g[min((int)threadIdx.x, k - 1)];
+  __syncthreads();
+  const int *cols = scols;
   const int jd = cols[min((int)threadIdx.x, k - 1)];
   PriorOps ops{P, ldp, n, cols, k, sc, Lt, ldl, W0, ldw, P[(size_t)jd * ldp + jd], sc, blockIdx.x == 0};
   if (threadIdx.x == 0) {

@@ -47,6 +47,7 @@ struct FrontState {
   DetJob det_pending;
   hipStream_t det_stream = nullptr;
   hipEvent_t det_done = nullptr;
+  unsigned long long match_done_stamp = 0;  // plv_ctx::gather_stamp when match_done was recorded
   hipEvent_t match_done = nullptr;  // behind the result copy of plv_perform_matching_launch: the wait does not cover what is enqueued after it
 };
 
@@ -108,7 +109,9 @@ int ensure_pyramids(plv_ctx *ctx, FrontState *s) {
 }
 
 int sync(plv_ctx *ctx) {
+  const unsigned long long stamp = ctx->gather_stamp;
   PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  ctx->cov_host_synced = stamp;
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -436,6 +439,7 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   if (!mirrored) PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   if (!s->match_done) PLV_HIP_CHECK(hipEventCreateWithFlags(&s->match_done, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(s->match_done, ctx->stream));
+  s->match_done_stamp = ctx->gather_stamp;
   s->pending_n = n;
   s->pending_ran = true;
   return PLV_OK;
@@ -461,7 +465,10 @@ int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, floa
   if (ctx->prof.on)
     TRY(sync(ctx));  // (the per-kernel timer reads every event recorded so far)
   else
+  {
     PLV_HIP_CHECK(plv::event_sync(s->match_done));  // not the whole stream: the caller may have enqueued more behind the flow
+    if (s->match_done_stamp > ctx->cov_host_synced) ctx->cov_host_synced = s->match_done_stamp;
+  }
   const size_t nn = (size_t)n;
   const size_t o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36;
   const char *hp = ctx->h_pin.as<char>();

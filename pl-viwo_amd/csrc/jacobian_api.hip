@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <vector>
 
+#include <chrono>
 #include "jacobian_kernels.hpp"
 #include "nullspace_core.hpp"
 #include "update_kernels.hpp"
@@ -187,6 +188,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
+  if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, F, ld - 3));  // (before the upload goes onto the stream)
   JacParams P{};
   bool fuse_tri = false;
   int tri_max_obs = 1;
@@ -237,13 +239,13 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       const int n = ctx->cov_n;
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
-      TRY(plv_prior_prefetch(ctx, 0, P.cols_in, k, F, ld - 3));
     }
     if (fuse_tri)
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, tri_opt, tri_poses, tri_valid, tri_uvn, tri_p, tri_ok, tri_err, tri_max_obs));
     else
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
-    if (can_gather) TRY(plv_prior_prefetch(ctx, 1, P.cols_in, k, F, ld - 3));
+    if (can_gather)  // (the column map as the host staged it: same offset in the pinned block as in the device copy)
+      TRY(plv_prior_prefetch(ctx, 1, (const int *)(us->h_jin.as<char>() + ((const char *)P.cols_in - us->jin.as<char>())), k, F, ld - 3));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {
@@ -302,9 +304,20 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   plv_tracks t2 = *all;
   t2.p_FinG = t2.p_FinG_fej = p_out;  // (outputs of the triangulation: the staged copy is never read)
   FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
+  // PLV_CHAIN_EVENTS=1 (with PLV_HOST_TIMING=1): three timed events on the stream — at entry (the stream is idle: stamped at once),
+  // behind the Jacobian launch, behind the update's last kernel — to set the device's view of the chain against the host's phases
+  static const bool chain_events = getenv("PLV_CHAIN_EVENTS") != nullptr && plv::host_phases().on;
+  static hipEvent_t ce[3] = {nullptr, nullptr, nullptr};
+  const auto t_entry = std::chrono::steady_clock::now();
+  if (chain_events) {
+    for (auto &e : ce)
+      if (!e) (void)hipEventCreate(&e);
+    (void)hipEventRecord(ce[0], ctx->stream);
+  }
   plv::HostPhase ph_a("points fused: stage + triangulate + jacobians enqueued");
   TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
   ph_a.stop();
+  if (chain_events) (void)hipEventRecord(ce[1], ctx->stream);
   us->b_single_use = true;
   const int F = all->n_feat;
   TRY(us->h_tri.reserve((size_t)F * 33 + 16));
@@ -318,6 +331,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   if (!mirrored)
     PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
   ph_b.stop();
+  if (chain_events) (void)hipEventRecord(ce[2], ctx->stream);
   plv::HostPhase ph_c("points fused: host work inside the wait");
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
   // ... and work that becomes possible DURING the wait (the line pool, once the line worker has finished the frame's feed): the
@@ -333,6 +347,16 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)
   if (rc != PLV_OK || !mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));      // (the copy command enqueued behind it)
   ph_d.stop();
+  if (chain_events) {
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
+    (void)hipEventSynchronize(ce[2]);
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, ce[0], ce[1]) == hipSuccess && hipEventElapsedTime(&b, ce[1], ce[2]) == hipSuccess) {
+      plv::host_phases().add("points fused: DEVICE entry -> Jacobian launch done", a * 1e3);
+      plv::host_phases().add("points fused: DEVICE Jacobian done -> last kernel done", b * 1e3);
+      plv::host_phases().add("points fused: HOST entry -> results read", host_us);
+    }
+  }
   const char *h = us->h_tri.as<char>();
   memcpy(p_out, h, (size_t)F * 24);
   memcpy(err_out, h + (size_t)F * 24, (size_t)F * 8);
@@ -566,6 +590,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
+  if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, L, ld - 6));  // (before the upload goes onto the stream)
   JacParams P{}, Pt{};
   bool fuse_tri = false;
   double *tri_cam = nullptr, *tri_imu = nullptr, *tri_lines = nullptr;
@@ -609,13 +634,13 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
       const int n = ctx->cov_n;
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
-      TRY(plv_prior_prefetch(ctx, 0, P.cols_in, k, L, ld - 6));
     }
     if (fuse_tri)
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
     else
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
-    if (can_gather) TRY(plv_prior_prefetch(ctx, 1, P.cols_in, k, L, ld - 6));
+    if (can_gather)
+      TRY(plv_prior_prefetch(ctx, 1, (const int *)(us->h_jin.as<char>() + ((const char *)P.cols_in - us->jin.as<char>())), k, L, ld - 6));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

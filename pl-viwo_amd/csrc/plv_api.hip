@@ -46,7 +46,9 @@ static int d2h(plv_ctx *ctx, void *dst, const void *src, size_t bytes) {
   return PLV_OK;
 }
 static int sync(plv_ctx *ctx) {
+  const unsigned long long stamp = ctx->gather_stamp;
   PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
+  ctx->cov_host_synced = stamp;
   ctx->prof.collect();
   return PLV_OK;
 }
@@ -621,22 +623,26 @@ static int prior_mark(plv_ctx *ctx) {
     PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
     PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
   }
-  PLV_HIP_CHECK(hipEventRecord(ctx->aux_fork, ctx->stream));
+  // the host has waited for the covariance's last writer (plv_ctx::cov_host_synced): nothing to order the side stream behind
+  ctx->aux_fork_needed = ctx->cov_host_synced != ctx->gather_stamp;
+  if (ctx->aux_fork_needed) PLV_HIP_CHECK(hipEventRecord(ctx->aux_fork, ctx->stream));
   return PLV_OK;
 }
 static int prior_start(plv_ctx *ctx, const int *d_cols, int k) {
   const int n = ctx->cov_n;
-  PLV_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+  if (ctx->aux_fork_needed) PLV_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
   TRY(launch_prior_factor(ctx, ctx->aux_stream, ctx->d_P.as<double>(), n, n, d_cols, k));
   PLV_HIP_CHECK(hipEventRecord(ctx->aux_join, ctx->aux_stream));
   return PLV_OK;
 }
-// Called by the one-submission updates (jacobian_api.hip) with the update's shape: phase 0 between their upload and their Jacobian
-// launch, phase 1 right after that launch.  When the update will take the whitened route its prior factor runs next to triangulation,
+// Called by the one-submission updates (jacobian_api.hip) with the update's shape: phase 0 before anything of the update is on the main
+// stream (its upload included), phase 1 right after the Jacobian launch with the column map in memory the device can read NOW (the
+// pinned staging block: the side stream does not wait for the upload).  When the update will take the whitened route its prior factor runs next to triangulation,
 // Jacobians and gate.
 int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max) {
   auto *us = ustate(ctx);
-  if (!whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
+  static const bool late = getenv("PLV_PRIOR_LATE") != nullptr;  // (measurement aid: the prior factor starts behind the Jacobian launch)
+  if (late || us->prior_late || !whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
   if (phase == 0) return prior_mark(ctx);
   TRY(prior_start(ctx, d_cols, k));
   ctx->prior_pending = true;
@@ -895,6 +901,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
   if (!us->done_ev) PLV_HIP_CHECK(hipEventCreateWithFlags(&us->done_ev, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(us->done_ev, ctx->stream));
+  us->done_stamp = ctx->gather_stamp;
   return PLV_OK;
 }
 
@@ -902,8 +909,9 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   if (mode >= 0) {
-    if (mode > 3) return PLV_E_BADARG;
-    us->compress_mode = mode;
+    if (mode > 4) return PLV_E_BADARG;
+    us->prior_late = mode == 4;  // (measurement aid: mode 0 with the prior factor started behind the Jacobian launch)
+    us->compress_mode = mode == 4 ? 0 : mode;
   }
   if (last_route) *last_route = us->last_route;
   if (last_ambiguous) *last_ambiguous = us->last_ambiguous;
@@ -940,7 +948,10 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   else if (ctx->prof.on || !us->done_ev)
     TRY(sync(ctx));
   else
+  {
     PLV_HIP_CHECK(plv::event_sync(us->done_ev));  // (not the whole stream: the caller may have enqueued more behind the update)
+    if (us->done_stamp > ctx->cov_host_synced) ctx->cov_host_synced = us->done_stamp;
+  }
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;

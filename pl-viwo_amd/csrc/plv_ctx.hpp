@@ -63,8 +63,16 @@ struct HostPhases {
   std::vector<Rec> recs;
   void add(const char *label, double us) {
     std::lock_guard<std::mutex> lk(mtx);
+    // by address first: comparing the text of every earlier label walks the library's string pages, and those page in on first touch
+    // (measured: 16 minor faults, 30 us, charged to whatever phase came next)
     for (auto &r : recs)
-      if (r.label == label || !strcmp(r.label, label)) {
+      if (r.label == label) {
+        r.us += us;
+        ++r.n;
+        return;
+      }
+    for (auto &r : recs)
+      if (!strcmp(r.label, label)) {
         r.us += us;
         ++r.n;
         return;
@@ -299,6 +307,11 @@ struct plv_ctx {
   // Bumped whenever the resident covariance changes OR the gathered blocks (d_Pc / d_Ps / d_inv) are rewritten: a batch whose
   // covariance gathers rode on an earlier launch (plv_build_jacobians_resident) may only reuse them while the stamp stands.
   unsigned long long gather_stamp = 1;
+  // value of gather_stamp up to which the HOST knows the main stream's work to be finished (set where the host waits on the stream
+  // or on an event recorded with the stamp of that moment).  Equal to gather_stamp: the covariance's last writer has finished, work
+  // on another stream may read it without an event (plv_api.hip, prior_mark: the event itself is cheap, the first event call on a
+  // stream the host has just waited on is not — 35 us measured).
+  unsigned long long cov_host_synced = 0;
   plv::DevBuf d_P;        // n x n col-major, ld = n
   plv::DevBuf d_P2;       // second covariance buffer: state augmentation / marginalisation write here, then swap
   plv::DevBuf d_H, d_res, d_cols, d_Rdiag, d_dx, d_flag;
@@ -310,6 +323,7 @@ struct plv_ctx {
   plv::DevBuf d_Lt, d_W0, d_dW, d_Gs;
   hipStream_t aux_stream = nullptr;  // work that only needs the covariance, concurrent with the Jacobians and the gate
   hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  bool aux_fork_needed = false;  // the main stream held work when the side work was marked: aux_fork orders the side stream behind it
   bool prior_pending = false;  // plv_prior_prefetch started the prior factor for the update about to be launched (k = prior_k)
   int prior_k = 0;
   plv::PinBuf h_pin;

@@ -20,6 +20,7 @@ struct plv_ctx_update_state {
   // factor of the measurements), 1 = Householder TSQR on the stacked rows, 2 = Gram + Cholesky first, redone through the Householder
   // route when its factorisation reports pivots it could not resolve, 3 = Gram matrix + blocked Cholesky (the round-2 default)
   int compress_mode = 0;
+  bool prior_late = false;  // measurement aid (mode 4)
   int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder, 4 whitened
   int last_ambiguous = 0;   // pivots the last Gram factorisation could not tell from zero
   struct Redo {             // what the automatic mode needs to run the update again from the stacked rows
@@ -30,6 +31,7 @@ struct plv_ctx_update_state {
     int *d_flag = nullptr;
   } redo;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
+  unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   hipEvent_t done_ev = nullptr;  // behind the update's last command: the wait does not cover what the caller enqueues after the launch
   // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a
   // kernel argument is made of; first sight of a key runs eagerly (sizes every buffer), the second captures, later ones replay

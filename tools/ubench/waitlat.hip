@@ -32,7 +32,7 @@ int main() {
   const long long ticks = 3000;  // wall_clock64 runs at 100 MHz: 30 us
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     std::vector<double> t;
     for (int it = 0; it < 300; ++it) {
       const unsigned val = (unsigned)(mode * 1000 + it + 1);
@@ -43,8 +43,13 @@ int main() {
       } else if (mode == 1) {
         hipEventRecord(ev, s);
         hipEventSynchronize(ev);
-      } else {
+      } else if (mode == 2) {
         while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != val) _mm_pause();
+      } else if (mode == 3) {
+        hipEventRecord(ev, s);
+        while (hipEventQuery(ev) == hipErrorNotReady) _mm_pause();
+      } else {
+        while (hipStreamQuery(s) == hipErrorNotReady) _mm_pause();
       }
       auto b = now();
       if (it >= 20) t.push_back(us(a, b));
@@ -52,7 +57,7 @@ int main() {
     }
     std::sort(t.begin(), t.end());
     printf("%-28s launch + 30 us kernel + wait: p50 %.1f us  p10 %.1f  p90 %.1f\n",
-           mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "hipEventSynchronize" : "spin on pinned word", t[t.size() / 2], t[t.size() / 10],
+           mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "hipEventSynchronize" : mode == 2 ? "spin on pinned word" : mode == 3 ? "spin on hipEventQuery" : "spin on hipStreamQuery", t[t.size() / 2], t[t.size() / 10],
            t[t.size() * 9 / 10]);
   }
   return 0;
