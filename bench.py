@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
     ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
                     "plv_update_compression_mode settings frame by frame and stderr gets the mean step time of each (drift-free A/B)")
+    ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
+                    "mean step time of each on stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     args = ap.parse_args()
@@ -373,6 +375,7 @@ def main():
     pl = Player(stream, sm, staged=True)
 
     alt_modes = [int(m) for m in args.alternate_modes.split(",")] if args.alternate_modes else None
+    alt_knobs = [int(m) for m in args.alternate_knobs.split(",")] if args.alternate_knobs else None
 
     def timed_segment(n_steps):
         per_frame = {"kept": [], "tracked": []}
@@ -389,6 +392,8 @@ def main():
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if alt_modes:
                 ctx.update_compression_mode(alt_modes[f % len(alt_modes)])
+            if alt_knobs:
+                pkg.debug_knobs(alt_knobs[f % len(alt_knobs)])
             c0 = pkg.counters()
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
@@ -408,6 +413,11 @@ def main():
         ctx.synchronize()
         barrier()
         gc.enable()
+        if alt_knobs:
+            pkg.debug_knobs(0)
+            for j, m in enumerate(alt_knobs):
+                v = per[j::len(alt_knobs)]
+                print(f"[alternate] knobs {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
         if alt_modes:
             ctx.update_compression_mode(0)
             for j, m in enumerate(alt_modes):

@@ -165,6 +165,7 @@ def load_library():
         "plv_camera_get_line_features": (C.c_int, [vp, C.POINTER(PlvStateView)]),
         "plv_update_compression_mode": (C.c_int, [vp, C.c_int, ip, ip]),
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
+        "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -686,6 +687,11 @@ def line_worker_config(spin_us=-1, fit_threads=-1):
     a, b = C.c_int(), C.c_int()
     load_library().plv_line_worker_config(int(spin_us), int(fit_threads), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def debug_knobs(mask=-1):
+    """plv_debug_knobs (measurement aid): sets the mask of alternative placements (csrc/plv_ctx.hpp "Measurement knobs"), returns the previous one"""
+    return int(load_library().plv_debug_knobs(int(mask)))
 
 
 def counters():

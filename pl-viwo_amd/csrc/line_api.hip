@@ -77,6 +77,11 @@ struct LineTracker {
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
   PinBuf pin;
   hipEvent_t edges_ready = nullptr;  // plv_line_detect_launch: the maps of image `pending_which` are on their way to the host
+  // measurement knob PLV_KNOB_EDGES_SIDE: the edge kernel of a prefetched detection on its own stream, behind the pyramid only
+  // (plv_line_edges_fork records pyr_done on the ctx stream before the flow is enqueued).  Slower than the default by 6-15 us per frame.
+  hipStream_t edge_stream = nullptr;
+  hipEvent_t pyr_done = nullptr;
+  bool edge_fork = false;
   int pending_which = -1, pending_fed = -1;
   bool defer_finish = false;        // plv_camera_try_update: the line update leaves its database hand-back (cleanup_lines) behind ...
   std::function<void()> deferred;   // ... to run before anything else reads the tracker: in the next frame's wait for the flow (ltr())
@@ -245,7 +250,13 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     b.map = (uint8_t *)(hp + bytes);
     b.half = b.map + npix;
   }
-  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b));
+  hipStream_t es = ctx->stream;
+  if (launch_only && maps_to_host && T->edge_fork) {
+    PLV_HIP_CHECK(hipStreamWaitEvent(T->edge_stream, T->pyr_done, 0));
+    es = T->edge_stream;
+  }
+  T->edge_fork = false;
+  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es));
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
   auto emit = [&](const float4 &sg) {
     const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
@@ -284,7 +295,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     }
     if (launch_only) {
       if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
-      PLV_HIP_CHECK(hipEventRecord(T->edges_ready, ctx->stream));
+      PLV_HIP_CHECK(hipEventRecord(T->edges_ready, es));
       T->pending_which = which;
       T->pending_fed = plv_front_fed_count(ctx);
       if (!T->worker.joinable()) T->worker = std::thread(line_worker, T);
@@ -370,6 +381,8 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
     for (DevBuf *b : bufs) b->release();
     T->pin.release();
     if (T->edges_ready) (void)hipEventDestroy(T->edges_ready);
+    if (T->pyr_done) (void)hipEventDestroy(T->pyr_done);
+    if (T->edge_stream) (void)hipStreamDestroy(T->edge_stream);
     delete T;
     g_lt.erase(it);
   }
@@ -469,6 +482,23 @@ int plv_vanishing_points(const double *R_ItoC, const double *K8, double *vps) {
 
 // TrackLSD::feed_monocular for the image currently in the ctx (fed by plv_tracker_feed / plv_feed_image,
 // which also is where the reference's second equalizeHist comes from: same input, same result).
+// (internal, the tracker feed) marks the point on the ctx stream the prefetched edge kernel has to wait for — the pyramid of the image
+// just fed — so that the kernel can be enqueued on its own stream after the flow has been enqueued on the ctx stream.
+int plv_line_edges_fork(plv_ctx *ctx) {
+  if (!ctx) return PLV_E_BADARG;
+  if (!plv::knob(plv::PLV_KNOB_EDGES_SIDE)) return 1;  // default: on the ctx stream, in front of the flow (plv_ctx.hpp "Measurement knobs")
+  LineTracker *T = ltr(ctx, false);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  if (T->walk_on_device) return 1;
+  if (!T->edge_stream) {
+    PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->edge_stream, hipStreamNonBlocking));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&T->pyr_done, hipEventDisableTiming));
+  }
+  PLV_HIP_CHECK(hipEventRecord(T->pyr_done, ctx->stream));
+  T->edge_fork = true;
+  return PLV_OK;
+}
+
 int plv_line_detect_launch(plv_ctx *ctx, int which) {
   if (!ctx || (which != PLV_PYR_CUR && which != PLV_PYR_LAST)) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);

@@ -237,18 +237,19 @@ __global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // stage 1: half-resolution image and Canny map (0 weak / 1 none / 2 edge; hysteresis applied)
-int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b) {
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st) {
+  if (!st) st = ctx->stream;
   const int w = W / 2, h = H / 2;
   int low = fp.canny_low, high = fp.canny_high;
   if (low > high) std::swap(low, high);
   {
-    ProfScope ps(ctx->prof, "half_canny_kernel", ctx->stream);
-    hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, ctx->stream, d_img, W, w, h, low,
+    ProfScope ps(ctx->prof, "half_canny_kernel", st);
+    hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, st, d_img, W, w, h, low,
                        high, b.map, b.half);
   }
   if (low != high) {
-    ProfScope ps(ctx->prof, "canny_hyst_kernel", ctx->stream);
-    hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.map, w, h);
+    ProfScope ps(ctx->prof, "canny_hyst_kernel", st);
+    hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, st, b.map, w, h);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -24,7 +24,7 @@ struct FldBuffers {
   int *seg_count;  // [chain_cap]
 };
 
-int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b);
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */);
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 

@@ -97,6 +97,12 @@ static plv_ctx_update_state *ustate(plv_ctx *ctx) { return plv_update_state(ctx)
 extern "C" {
 
 int plv_abi_version(void) { return PLV_ABI_VERSION; }
+// (measurement aid, not part of the drop-in surface: plv_ctx.hpp "Measurement knobs")  set < 0 only queries; returns the previous mask
+unsigned plv_debug_knobs(long long set) {
+  const unsigned prev = plv::knobs().load();
+  if (set >= 0) plv::knobs().store((unsigned)set);
+  return prev;
+}
 const char *plv_last_error(void) { return g_err; }
 
 int plv_device_count(void) {
@@ -642,7 +648,7 @@ static int prior_start(plv_ctx *ctx, const int *d_cols, int k) {
 int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max) {
   auto *us = ustate(ctx);
   static const bool late = getenv("PLV_PRIOR_LATE") != nullptr;  // (measurement aid: the prior factor starts behind the Jacobian launch)
-  if (late || us->prior_late || !whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
+  if (late || us->prior_late || plv::knob(plv::PLV_KNOB_PRIOR_LATE) || !whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
   if (phase == 0) return prior_mark(ctx);
   TRY(prior_start(ctx, d_cols, k));
   ctx->prior_pending = true;

@@ -51,6 +51,18 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
   return hipMemcpyAsync(dst, src, bytes, kind, s);
 }
 
+// Measurement knobs (plv_debug_knobs): alternative placements kept in the library so that tools can switch them frame by frame inside
+// one process — run-to-run drift on a box (+-25 us per frame) is larger than what most single changes move.
+//   1  the prefetched edge kernel on its own stream behind the pyramid instead of on the ctx stream in front of the flow (measured
+//      with tools: 6-15 us per frame SLOWER, four alternating runs of 600 frames; the default stays on the ctx stream)
+//   2  the whitened update's prior factor started behind the Jacobian launch instead of before the update's upload
+enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u };
+inline std::atomic<unsigned> &knobs() {
+  static std::atomic<unsigned> k{0};
+  return k;
+}
+inline bool knob(unsigned bit) { return (knobs().load(std::memory_order_relaxed) & bit) != 0; }
+
 // Host-side phase timing (PLV_HOST_TIMING=1): accumulated wall time per label, printed to stderr when the library unloads.
 struct HostPhases {
   struct Rec {

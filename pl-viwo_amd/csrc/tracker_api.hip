@@ -131,6 +131,7 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
+extern "C" int plv_line_edges_fork(plv_ctx *ctx);         // line_api.hip
 extern "C" void plv_line_defer_finish(plv_ctx *ctx, int on);
 extern "C" void plv_line_run_deferred(plv_ctx *ctx);
 extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in, int on_ctx_stream);  // frontend_api.hip
@@ -190,8 +191,10 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     // the line detector's pixel work (18 us) goes in FRONT of the flow: the edge maps then reach the library's line worker ~0.1 ms
     // earlier than behind flow + RANSAC, and the worker (chain walk, segment growth, assignment, matching) is the longer of the two
     // paths that meet at the line update; PLV_LINE_EDGES_LATE=1 restores the old order
+    // (plv_line_edges_fork: a measurement knob that puts the kernel on its own stream behind the pyramid instead — the flow then does
+    //  not wait 18 us for it, and yet the frame is 6-15 us slower, measured alternating frame by frame)
     static const bool edges_late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
-    if (!edges_late) launch_prefetch();
+    if (!edges_late && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
     const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
     launch_prefetch();  // (inside the wait for the flow)
     if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
