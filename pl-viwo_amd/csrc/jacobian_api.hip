@@ -124,8 +124,11 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
     memcpy(h + o_rQ, tr->res_Q, 288 * (size_t)nobs);
     memcpy(h + o_rc, tr->res_clone, 4 * (size_t)nobs);
   }
-  PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-  const char *d = us->jin.as<char>();
+  // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
+  // few times; what a workgroup reuses it keeps in LDS)
+  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
   P.clone_R = (const double *)(d + o_R);
@@ -172,6 +175,12 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
 }
 
 // builds the batch into us->bHf ([Hf | Hx | res]) and us->brows on the device
+// the column map as the host staged it: same offset in the pinned block as in the device copy (or the pinned block itself)
+static const int *host_copy_of(plv_ctx_update_state *us, const int *cols_in) {
+  const char *c = (const char *)cols_in, *hj = us->h_jin.as<char>();
+  if (c >= hj && c < hj + us->h_jin.cap) return cols_in;
+  return (const int *)(hj + (c - us->jin.as<char>()));
+}
 struct FusedTri {  // triangulate on the device first and let the Jacobian launch take its candidates from the result
   const plv_tri_options *opt;
   const float *uvn;
@@ -208,7 +217,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     char *d = us->tri.as<char>();
     for (int f = 0; f < F; ++f) tri_max_obs = std::max(tri_max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
-    fuse_tri = project && F <= ft->max_sel && !getenv("PLV_POINT_TRI_SEPARATE");
+    fuse_tri = project && F <= ft->max_sel && !getenv("PLV_POINT_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
     tri_opt = ft->opt;
@@ -245,7 +254,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     else
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
     if (can_gather)  // (the column map as the host staged it: same offset in the pinned block as in the device copy)
-      TRY(plv_prior_prefetch(ctx, 1, (const int *)(us->h_jin.as<char>() + ((const char *)P.cols_in - us->jin.as<char>())), k, F, ld - 3));
+      TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in), k, F, ld - 3));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {
@@ -520,8 +529,11 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
     memcpy(h + o_rQ, lt->res_Q, 288 * (size_t)nobs);
     memcpy(h + o_rc, lt->res_clone, 4 * (size_t)nobs);
   }
-  PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-  const char *d = us->jin.as<char>();
+  // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
+  // few times; what a workgroup reuses it keeps in LDS)
+  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
   P.clone_R = (const double *)(d + o_R);
@@ -607,7 +619,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
-    fuse_tri = project && L <= ft->max_sel && !getenv("PLV_LINE_TRI_SEPARATE");
+    fuse_tri = project && L <= ft->max_sel && !getenv("PLV_LINE_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_LINE_TRI_SEPARATE);
     tri_cam = (double *)(d + o_cam), tri_imu = (double *)(d + o_imu), tri_valid = (unsigned char *)(d + o_valid);
     tri_lines = (double *)(d + o_lines), tri_ok = (unsigned char *)(d + o_ok);
     if (!fuse_tri) TRY(launch_triangulate_lines(ctx, Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
@@ -640,7 +652,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     else
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
     if (can_gather)
-      TRY(plv_prior_prefetch(ctx, 1, (const int *)(us->h_jin.as<char>() + ((const char *)P.cols_in - us->jin.as<char>())), k, L, ld - 6));
+      TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in), k, L, ld - 6));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

@@ -845,7 +845,7 @@ static void discard_line_pool(LineTracker *T) {
 // cannot be formed ahead of time (plv_camera_update_lines then forms it).
 int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
   static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;  // (measurement aid: the pool formed after the point update as before)
-  if (late || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return 1;  // (a calibrated time offset moves the window test)
+  if (late || plv::knob(plv::PLV_KNOB_POOL_LATE) || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return 1;  // (a calibrated time offset moves the window test)
   LineTracker *T;
   {
     std::lock_guard<std::mutex> lk(g_mtx);

@@ -56,7 +56,11 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 //   1  the prefetched edge kernel on its own stream behind the pyramid instead of on the ctx stream in front of the flow (measured
 //      with tools: 6-15 us per frame SLOWER, four alternating runs of 600 frames; the default stays on the ctx stream)
 //   2  the whitened update's prior factor started behind the Jacobian launch instead of before the update's upload
-enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u };
+//   4  the edge kernel behind flow + RANSAC (PLV_LINE_EDGES_LATE)          8  the next frame's detection on the ctx stream (PLV_AHEAD_CTX)
+//  16  the line pool formed after the point update (PLV_LINE_POOL_LATE)    32 / 64  point / line triangulation as its own launch
+// 128  the Jacobian launches read their inputs from the pinned staging block instead of an uploaded copy
+enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
   return k;

@@ -194,7 +194,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     // (plv_line_edges_fork: a measurement knob that puts the kernel on its own stream behind the pyramid instead — the flow then does
     //  not wait 18 us for it, and yet the frame is 6-15 us slower, measured alternating frame by frame)
     static const bool edges_late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
-    if (!edges_late && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
+    if (!edges_late && !plv::knob(plv::PLV_KNOB_EDGES_LATE) && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
     const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
     launch_prefetch();  // (inside the wait for the flow)
     if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
@@ -913,7 +913,7 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   // right after that wait and would queue behind the detection: PLV_AHEAD_CTX=1 restores that placement for measurements.)
   static const bool ahead_ctx = getenv("PLV_AHEAD_CTX") != nullptr;
   T->defer_db = io->opt_lines != nullptr;
-  T->ahead_on_ctx_stream = io->opt_lines != nullptr && ahead_ctx;
+  T->ahead_on_ctx_stream = io->opt_lines != nullptr && (ahead_ctx || plv::knob(plv::PLV_KNOB_AHEAD_CTX));
   T->early_st = io->opt_lines ? st : nullptr;
   T->early_lines = io->opt_lines;
   ctx->wait_poll = io->opt_lines ? poll_line_pool : nullptr;
