@@ -195,12 +195,14 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 // diagonal or the factorisation was not positive definite; else P.upper -= dC, mirrored.
 // The last kernel of the update also mirrors the small result block (dx, flag, accepted, rows) into the caller's pinned host
 // buffer, so that no copy command sits between the end of the chain and the host's wait.
-__global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
+__global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
                                                          const double *__restrict__ dC, int ldc, const int *__restrict__ flag,
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
                                                          int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
                                                          const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
-                                                         int mirror2_words, const int *__restrict__ veto) {
+                                                         int mirror2_words, const int *__restrict__ veto, unsigned *done_word, unsigned done_val) {
+  // done_word (pinned, optional; the launch then has ONE workgroup): behind the mirrors AND the covariance commit the workgroup stores
+  // done_val there, and the host, spinning on the word, knows both the results and the covariance to be final
   // veto (automatic compression mode): the compression met pivots it could not resolve — nothing is committed, the host redoes the
   // update through the Householder route (plv_msckf_update_resident_wait)
   const bool skipped = (skip && *skip == 0) || (veto && *veto != 0);  // (or: the gate accepted nothing: no correction, the covariance stays)
@@ -214,14 +216,20 @@ __global__ void __launch_bounds__(256) ekf_commit_kernel(double *__restrict__ P,
   }
   if (mirror2_dst && blockIdx.x == gridDim.x - 1)  // (written by kernels launched earlier: complete)
     for (int i = threadIdx.x; i < mirror2_words; i += blockDim.x) mirror2_dst[i] = mirror2_src[i];
-  if (skipped || *flag != 0) return;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
-    int j = idx / n, i = idx - j * n;
-    if (i <= j) {
-      double v = P[(size_t)j * ldp + i] - dC[(size_t)j * ldc + i];
-      P[(size_t)j * ldp + i] = v;
-      P[(size_t)i * ldp + j] = v;
+  if (!(skipped || *flag != 0)) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
+      int j = idx / n, i = idx - j * n;
+      if (i <= j) {
+        double v = P[(size_t)j * ldp + i] - dC[(size_t)j * ldc + i];
+        P[(size_t)j * ldp + i] = v;
+        P[(size_t)i * ldp + j] = v;
+      }
     }
+  }
+  if (done_word) {  // (gridDim.x == 1)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done_word, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -290,10 +298,14 @@ static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const do
                              void *mirror_dst, size_t mirror_bytes) {
   {
     ProfScope ps(ctx->prof, "ekf_commit_kernel", ctx->stream);
-    hipLaunchKernelGGL(ekf_commit_kernel, dim3(std::min(64, cdiv(n * n, 256))), dim3(256), 0, ctx->stream, d_P, ldp, n, dC, n,
+    // with a completion word: one workgroup of 1024 threads does mirrors + commit + word (14 passes over a 119 x 119 covariance)
+    unsigned *dw = (mirror_dst && ctx->update_word_armed) ? (unsigned *)ctx->done_word(16) : nullptr;
+    const dim3 grid(dw ? 1 : std::min(64, cdiv(n * n, 256))), block(dw ? 1024 : 256);
+    hipLaunchKernelGGL(ekf_commit_kernel, grid, block, 0, ctx->stream, d_P, ldp, n, dC, n,
                        d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx,
                        (const unsigned *)(mirror_dst ? ctx->mirror2_src : nullptr), (unsigned *)(mirror_dst ? ctx->mirror2_dst : nullptr),
-                       (int)((ctx->mirror2_bytes + 3) / 4), ctx->commit_veto);
+                       (int)((ctx->mirror2_bytes + 3) / 4), ctx->commit_veto, dw, ctx->update_seq);
+    ctx->update_word_used = dw != nullptr;
     if (mirror_dst && ctx->mirror2_dst) ctx->mirror2_taken = true;
   }
   PLV_HIP_CHECK(hipGetLastError());

@@ -48,6 +48,7 @@ struct FrontState {
   hipStream_t det_stream = nullptr;
   hipEvent_t det_done = nullptr;
   unsigned long long match_done_stamp = 0;  // plv_ctx::gather_stamp when match_done was recorded
+  unsigned match_word_seq = 0;              // nonzero: the flow's last kernel stores this number to plv_ctx::done_word(0)
   hipEvent_t match_done = nullptr;  // behind the result copy of plv_perform_matching_launch: the wait does not cover what is enqueued after it
 };
 
@@ -434,8 +435,12 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
                 (const float *)(hp + o_p1)));  // (+ the undistortion of both point sets on the same launch)
   const double fmax = std::max(ctx->cfg.intrinsics[0], ctx->cfg.intrinsics[1]);
   bool mirrored = false;
+  TRY(ctx->h_done.reserve(256));
+  const unsigned seq = ++ctx->match_seq;
   TRY(launch_ransac(ctx, d_n0, d_n1, n, ctx->cfg.ransac_thr_px / fmax, ctx->cfg.ransac_conf, mi, 0u, s->counts.as<int>(), d_st,
-                    d_mk, s->info.as<int>(), s->models.as<double>(), dp_ + o_p1, hp + o_p1, o_mk - o_p1, (uint8_t *)(hp + o_mk), &mirrored));
+                    d_mk, s->info.as<int>(), s->models.as<double>(), dp_ + o_p1, hp + o_p1, o_mk - o_p1, (uint8_t *)(hp + o_mk), &mirrored,
+                    (unsigned *)ctx->done_word(0), seq));
+  s->match_word_seq = mirrored ? seq : 0;
   if (!mirrored) PLV_HIP_CHECK(plv::memcpy_async(hp + o_p1, dp_ + o_p1, o_st - o_p1, hipMemcpyDeviceToHost, ctx->stream));
   if (!s->match_done) PLV_HIP_CHECK(hipEventCreateWithFlags(&s->match_done, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(s->match_done, ctx->stream));
@@ -466,7 +471,12 @@ int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, floa
     TRY(sync(ctx));  // (the per-kernel timer reads every event recorded so far)
   else
   {
-    PLV_HIP_CHECK(plv::event_sync(s->match_done));  // not the whole stream: the caller may have enqueued more behind the flow
+    // not the whole stream: the caller may have enqueued more behind the flow.  The flow's last kernel says when its results are in
+    // pinned memory; everything enqueued on the stream before it has finished by then as well (in-order stream).
+    if (s->match_word_seq && plv::knob(plv::PLV_KNOB_DONE_WORDS))
+      PLV_HIP_CHECK(plv::wait_done_word(ctx->done_word(0), s->match_word_seq, s->match_done));
+    else
+      PLV_HIP_CHECK(plv::event_sync(s->match_done));
     if (s->match_done_stamp > ctx->cov_host_synced) ctx->cov_host_synced = s->match_done_stamp;
   }
   const size_t nn = (size_t)n;

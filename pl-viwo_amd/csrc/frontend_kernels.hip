@@ -876,7 +876,8 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
                                                            const int *__restrict__ counts, const uint8_t *__restrict__ klt,
                                                            uint8_t *__restrict__ mask, int *__restrict__ info,
                                                            const double *__restrict__ models, const unsigned *__restrict__ mir_src,
-                                                           unsigned *__restrict__ mir_dst, int mir_words, uint8_t *__restrict__ mir_mask) {
+                                                           unsigned *__restrict__ mir_dst, int mir_words, uint8_t *__restrict__ mir_mask,
+                                                           unsigned *done_word, unsigned done_val) {
   __shared__ RansacLds L;
   const int lane = threadIdx.x;
   // (perform_matching: this is the last kernel of the call; it copies what lk_kernel left for the host — positions, normalised
@@ -963,6 +964,10 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
     const uint8_t mv = (in && (!klt || klt[i])) ? 1 : 0;
     mask[i] = mv;
     if (mir_mask) mir_mask[i] = mv;
+  }
+  if (done_word) {  // everything the host reads of this call is written: say so (one wave: every lane's stores precede the fence)
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(done_word, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1160,7 +1165,7 @@ int launch_undistort2(plv_ctx *ctx, const CamK &K, int n, const float *d_uv0, co
 
 int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, double thr, double conf, int max_iters,
                   unsigned seed, int *d_counts, const uint8_t *d_klt, uint8_t *d_mask, int *d_info, double *d_models,
-                  const void *mir_src, void *mir_dst, size_t mir_bytes, uint8_t *mir_mask, bool *mirrored) {
+                  const void *mir_src, void *mir_dst, size_t mir_bytes, uint8_t *mir_mask, bool *mirrored, unsigned *done_word, unsigned done_val) {
   if (mirrored) *mirrored = false;
   const float t = (float)(thr * thr);
   if (n < 7) {
@@ -1177,7 +1182,7 @@ int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, dou
     ProfScope ps(ctx->prof, "ransac_select_kernel", ctx->stream);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
                        d_counts, d_klt, d_mask, d_info, (const double *)d_models, (const unsigned *)mir_src, (unsigned *)mir_dst,
-                       (int)(mir_bytes / 4), mir_mask);
+                       (int)(mir_bytes / 4), mir_mask, mir_dst ? done_word : nullptr, done_val);
     if (mirrored) *mirrored = mir_dst != nullptr;
   }
   PLV_HIP_CHECK(hipGetLastError());

@@ -35,6 +35,8 @@ int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, dou
                   // optional: the selection kernel copies mir_bytes from mir_src to mir_dst (pinned host) and its mask to mir_mask;
                   // *mirrored tells whether a kernel that does it was launched (not for n < 7)
                   const void *mir_src = nullptr, void *mir_dst = nullptr, size_t mir_bytes = 0, uint8_t *mir_mask = nullptr,
-                  bool *mirrored = nullptr);
+                  bool *mirrored = nullptr,
+                  // optional (with mir_dst): pinned word the selection kernel stores done_val to behind everything it wrote
+                  unsigned *done_word = nullptr, unsigned done_val = 0);
 
 }  // namespace plv

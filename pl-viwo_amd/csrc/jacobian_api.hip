@@ -346,7 +346,11 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   // ... and work that becomes possible DURING the wait (the line pool, once the line worker has finished the frame's feed): the
   // caller's poll function is tried until it reports that nothing is left, or the update is done
   if (rc == PLV_OK && ctx->wait_poll && us->done_ev) {
-    while (hipEventQuery(us->done_ev) == hipErrorNotReady) {
+    auto running = [&]() {
+      if (us->word_seq) return __atomic_load_n((const unsigned *)ctx->done_word(16), __ATOMIC_ACQUIRE) != us->word_seq;
+      return hipEventQuery(us->done_ev) == hipErrorNotReady;
+    };
+    while (running()) {
       if (ctx->wait_poll(ctx->wait_poll_arg)) break;
       for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
     }

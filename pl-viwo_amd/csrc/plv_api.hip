@@ -236,6 +236,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   ctx->h_pin.release();
+  ctx->h_done.release();
   plv_ctx_update_state *us = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_state_mtx);
@@ -729,6 +730,11 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     PLV_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
     return PLV_OK;
   };
+  TRY(ctx->h_done.reserve(256));
+  ++ctx->update_seq;
+  ctx->update_word_armed = !us->graph_mode && plv::knob(plv::PLV_KNOB_DONE_WORDS);
+  ctx->update_word_used = false;
+  us->word_seq = 0;
   auto enqueue = [&]() -> int {
   if (whiten && !prefetched) {
     TRY(aux_join());
@@ -908,6 +914,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   if (!us->done_ev) PLV_HIP_CHECK(hipEventCreateWithFlags(&us->done_ev, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(us->done_ev, ctx->stream));
   us->done_stamp = ctx->gather_stamp;
+  us->word_seq = ctx->update_word_used ? ctx->update_seq : 0;
+  ctx->update_word_armed = ctx->update_word_used = false;
   return PLV_OK;
 }
 
@@ -955,9 +963,14 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     TRY(sync(ctx));
   else
   {
-    PLV_HIP_CHECK(plv::event_sync(us->done_ev));  // (not the whole stream: the caller may have enqueued more behind the update)
+    // (not the whole stream: the caller may have enqueued more behind the update)
+    if (us->word_seq)
+      PLV_HIP_CHECK(plv::wait_done_word(ctx->done_word(16), us->word_seq, us->done_ev));
+    else
+      PLV_HIP_CHECK(plv::event_sync(us->done_ev));
     if (us->done_stamp > ctx->cov_host_synced) ctx->cov_host_synced = us->done_stamp;
   }
+  us->word_seq = 0;
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;

@@ -59,8 +59,11 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 //   4  the edge kernel behind flow + RANSAC (PLV_LINE_EDGES_LATE)          8  the next frame's detection on the ctx stream (PLV_AHEAD_CTX)
 //  16  the line pool formed after the point update (PLV_LINE_POOL_LATE)    32 / 64  point / line triangulation as its own launch
 // 128  the Jacobian launches read their inputs from the pinned staging block instead of an uploaded copy
+// 256  the flow's and the updates' waits on completion words their last kernels write into pinned memory (plv_ctx::h_done) instead of
+//      on HIP events: a bare word is seen 4.8 us earlier (tools/ubench/waitlat.hip), in the frame it gains nothing (0 .. 9 us SLOWER over
+//      four alternating runs: the commit then runs as one workgroup so that the word also covers the covariance)
 enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
-                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u };
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
   return k;
@@ -300,6 +303,21 @@ struct Profiler {
   }
 };
 
+// Waits until *word == want (a kernel stores it behind its results).  `ev` (recorded behind that kernel) is looked at now and then: a
+// chain that ended another way, or failed, must not hang the host.
+inline hipError_t wait_done_word(volatile unsigned *word, unsigned want, hipEvent_t ev) {
+  ++counters().syncs;
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n((const unsigned *)word, __ATOMIC_ACQUIRE) == want) return hipSuccess;
+    if ((spins & 8191u) == 0 && ev && hipEventQuery(ev) != hipErrorNotReady) {
+      const hipError_t e = hipEventSynchronize(ev);
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return e;
+    }
+    __builtin_ia32_pause();
+  }
+}
+
 struct ProfScope {
   Profiler &p;
   hipStream_t s;
@@ -343,6 +361,14 @@ struct plv_ctx {
   bool prior_pending = false;  // plv_prior_prefetch started the prior factor for the update about to be launched (k = prior_k)
   int prior_k = 0;
   plv::PinBuf h_pin;
+  // Measurement knob PLV_KNOB_DONE_WORDS — completion words in pinned memory: the last kernel of the flow (word 0) and of an update
+  // (word 16) stores the call's sequence number there behind its result block (system-scope release) and the host spins on the word
+  // instead of waiting on an event.  Off by default (no gain in the frame, see the knob list).
+  plv::PinBuf h_done;
+  unsigned match_seq = 0, update_seq = 0;
+  bool update_word_armed = false;  // the update being enqueued may end in a kernel that stores update_seq to done_word(16) ...
+  bool update_word_used = false;   // ... and did
+  volatile unsigned *done_word(int i) { return h_done.p ? (volatile unsigned *)h_done.p + i : nullptr; }
 
   // Device word holding the number of features the gate accepted in the update being enqueued (null outside
   // plv_msckf_update_resident_launch): the compression and EKF kernels return at once when it is zero — an update in which the gate

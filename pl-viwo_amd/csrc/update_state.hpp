@@ -32,6 +32,7 @@ struct plv_ctx_update_state {
   } redo;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
+  unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)
   hipEvent_t done_ev = nullptr;  // behind the update's last command: the wait does not cover what the caller enqueues after the launch
   // optional hipGraph replay of the update launch sequence (plv_update_graph_mode): key = every pointer / size / scalar a
   // kernel argument is made of; first sight of a key runs eagerly (sizes every buffer), the second captures, later ones replay
