@@ -2,6 +2,7 @@
 // Product code (never includes anything from oracle/).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sys/resource.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -113,16 +114,30 @@ struct NsScope {  // adds the scope's wall time to one of the counters above
   explicit NsScope(std::atomic<unsigned long long> &a) : acc(a) {}
   ~NsScope() { acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
-struct HostPhase {  // scope timer
+inline long thread_minor_faults() {
+  struct rusage ru;
+  getrusage(RUSAGE_THREAD, &ru);
+  return ru.ru_minflt;
+}
+struct HostPhase {  // scope timer (PLV_HOST_FAULTS=1: the scope's minor page faults instead of its time)
   const char *label;
   std::chrono::steady_clock::time_point t0;
+  long f0 = 0;
   bool on;
+  static bool faults() {
+    static const bool f = getenv("PLV_HOST_FAULTS") != nullptr;
+    return f;
+  }
   explicit HostPhase(const char *l) : label(l), on(host_phases().on) {
+    if (on && faults()) f0 = thread_minor_faults();
     if (on) t0 = std::chrono::steady_clock::now();
   }
   void stop() {
     if (!on) return;
-    host_phases().add(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    if (faults())
+      host_phases().add(label, (double)(thread_minor_faults() - f0));
+    else
+      host_phases().add(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     on = false;
   }
   ~HostPhase() { stop(); }

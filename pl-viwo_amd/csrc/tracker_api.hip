@@ -11,6 +11,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <sys/resource.h>
 #include "plv_ctx.hpp"
 #include "update_state.hpp"
 
@@ -948,6 +949,22 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
 int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io *io) {
   if (!ctx || !st || !io || (io->slot < 0 && !io->img)) return PLV_E_BADARG;
   plv::NsScope ns(plv::counters().frame_ns);
+  struct RuScope {  // PLV_HOST_TIMING: page faults and system time of the caller's thread inside the frame
+    struct rusage a;
+    bool on = plv::host_phases().on;
+    RuScope() {
+      if (on) getrusage(RUSAGE_THREAD, &a);
+    }
+    ~RuScope() {
+      if (!on) return;
+      struct rusage b;
+      getrusage(RUSAGE_THREAD, &b);
+      plv::host_phases().add("frame: minor page faults of the caller's thread (count)", (double)(b.ru_minflt - a.ru_minflt));
+      plv::host_phases().add("frame: system time of the caller's thread", (double)((b.ru_stime.tv_sec - a.ru_stime.tv_sec) * 1000000L + (b.ru_stime.tv_usec - a.ru_stime.tv_usec)));
+      plv::host_phases().add("frame: involuntary context switches (count)", (double)(b.ru_nivcsw - a.ru_nivcsw));
+      plv::host_phases().add("frame: voluntary context switches (count)", (double)(b.ru_nvcsw - a.ru_nvcsw));
+    }
+  } ru_scope;
   plv::RoctxRange rx_feed("[Time-Cam] feed measurement");
   if (io->slot >= 0)
     TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
