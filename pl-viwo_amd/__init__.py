@@ -1138,37 +1138,48 @@ class Context:
 
     def _try_update_io(self, plus, n, max_msckf, max_obs, t_prev_frame, state_time, window_full=True, chi2_mult=1.0, min_dist=0.1, max_dist=60.0,
                        max_cond=1e4, max_baseline=40.0, refine=True, init_min_meas=10, lines=True, cap=512):
-        """plv_try_update for the given options + a function that turns the filled structure into the result dicts"""
-        tri = PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
-        op = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, tri, t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, init_min_meas, None)
-        ol = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1 if window_full else 0, 0, 0, None, 10, None)
-        rp, rl = PlvUpdateResult(), PlvUpdateResult()
-        # the output arrays of a given shape are laid out once per context and reused (the results below are copies)
-        bufs = None
-        if self is not None:
-            cache = self.__dict__.setdefault("_io_bufs", {})
-            bufs = cache.get((n, max_msckf, cap))
-        if bufs is None:
+        """plv_try_update for the given options + a function that turns the filled structure into the result dicts.  The structures and
+        the output arrays of a given set of options are laid out once per context; a call only writes the fields that change from frame
+        to frame (the two times, the window flag, the variable list).  The results are copies."""
+        key = (n, max_msckf, max_obs, chi2_mult, min_dist, max_dist, max_cond, max_baseline, bool(refine), init_min_meas, bool(lines), cap)
+        cache = self.__dict__.setdefault("_io_sets", {}) if self is not None else None
+        hit = cache.get(key) if cache is not None else None
+        if hit is None:
+            tri = PlvTriOptions(min_dist, max_dist, max_cond, max_baseline, 1 if refine else 0)
+            op = PlvUpdateOptions(max_msckf, max_obs, chi2_mult, tri, t_prev_frame, state_time, 1, 0, 0, None, init_min_meas, None)
+            ol = PlvUpdateOptions(0, max_obs, chi2_mult, PlvTriOptions(0, 0, 0, 0, 0), t_prev_frame, state_time, 1, 0, 0, None, 10, None)
+            rp, rl = PlvUpdateResult(), PlvUpdateResult()
             bufs = (np.zeros(n), np.zeros(n), np.zeros(max_msckf, dtype=np.uint64), np.zeros(max_msckf, dtype=np.uint8), np.zeros((max_msckf, 3)),
                     np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros((cap, 6)))
-            if self is not None:
-                cache[(n, max_msckf, cap)] = bufs
-        dxp, dxl, ids, acc, p, lids, lacc, lg = bufs
-        a = lambda x: x.ctypes.data
-        io = PlvTryUpdate(C.addressof(op), C.addressof(ol) if lines else None, plus.n if plus is not None else 0,
-                          C.addressof(plus.vars) if plus is not None else None, a(dxp), a(dxl), C.addressof(rp), C.addressof(rl),
-                          a(ids), a(acc), a(p), a(lids), a(lacc), a(lg), cap, 0)
+            a = lambda x: x.ctypes.data
+            dxp, dxl, ids, acc, p, lids, lacc, lg = bufs
+            io = PlvTryUpdate(C.addressof(op), C.addressof(ol) if lines else None, 0, None, a(dxp), a(dxl), C.addressof(rp), C.addressof(rl),
+                              a(ids), a(acc), a(p), a(lids), a(lacc), a(lg), cap, 0)
 
-        def results(keep=(op, ol, plus)):      # (the structures io points to live as long as this closure)
-            m = rp.n_msckf
-            pts = dict(dx=dxp.copy(), n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned, status=rp.status,
-                       ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=rp.n_slam, n_init=rp.n_init, n_truncated=rp.n_truncated)
-            if not lines:
-                return pts, None, 0
-            m = rl.n_msckf
-            lns = dict(dx=dxl.copy(), n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
-                       status=rl.status, ids=lids[:m].copy(), accepted=lacc[:m].copy(), line_FinG=lg[:m].copy())
-            return pts, lns, io.line_db_size
+            def results():
+                m = rp.n_msckf
+                pts = dict(dx=dxp.copy(), n_pool=rp.n_pool, n_msckf=m, n_accepted=rp.n_accepted, n_rows=rp.n_rows, n_returned=rp.n_returned,
+                           status=rp.status, ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=rp.n_slam, n_init=rp.n_init,
+                           n_truncated=rp.n_truncated)
+                if not lines:
+                    return pts, None, 0
+                m = rl.n_msckf
+                lns = dict(dx=dxl.copy(), n_pool=rl.n_pool, n_lines=m, n_accepted=rl.n_accepted, n_rows=rl.n_rows, n_returned=rl.n_returned,
+                           status=rl.status, ids=lids[:m].copy(), accepted=lacc[:m].copy(), line_FinG=lg[:m].copy())
+                return pts, lns, io.line_db_size
+            hit = (op, ol, io, results, bufs, rp, rl, tri, [None])      # (everything io points to lives as long as the entry)
+            if cache is not None:
+                cache[key] = hit
+        op, ol, io, results = hit[0], hit[1], hit[2], hit[3]
+        wf = 1 if window_full else 0
+        op.t_prev_frame = ol.t_prev_frame = t_prev_frame
+        op.state_time = ol.state_time = state_time
+        op.window_full = ol.window_full = wf
+        hit[8][0] = plus                     # (the variable list must outlive the call)
+        results.keep = hit                   # (... and so must everything io points to, also without a context to cache it in)
+        io.n_var = plus.n if plus is not None else 0
+        io.vars = C.addressof(plus.vars) if plus is not None else None
+        io.line_db_size = 0
         return io, results
 
     def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw):
