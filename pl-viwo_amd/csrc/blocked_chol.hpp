@@ -67,8 +67,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ void lds_vstore(T *p, T v) { *(volatile PLV_LDS T *)(p) = v; }
 template <class T> __device__ __forceinline__ T lds_vload(const T *p) { return *(const volatile PLV_LDS T *)(p); }
 
-struct BcLds {
-  double Lp[2][12][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity (NT <= 12)
+template <int NTL>
+struct BcLdsT {
+  double Lp[2][NTL][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity (NT <= NTL)
   double Ts[16][64][2];    // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
   double rs[2][16];        // the pivots l_jj^2 of the panel (<= 0: dead column), by panel parity; readers take 1 / sqrt themselves
   int step_flag;           // 16 * panel + steps published so far
@@ -76,6 +77,7 @@ struct BcLds {
   int bad;
   int n_amb;               // pivots the factorisation could not tell from zero (diag_chain's `amb` band)
 };
+typedef BcLdsT<12> BcLds;    // the update's factorisations (up to 192 columns); the gate inside the Jacobian launches uses BcLdsT<2>
 
 // 1/x: v_rcp_f64 + two Newton steps (the sequence the compiler's IEEE division starts with, without
 // the scale / fixup instructions that only matter outside the pivots' range).
@@ -109,8 +111,8 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // amb > 0 (compression): a pivot 0 < |pv| < amb is counted in lds.n_amb — on a unit-diagonal Gram matrix it is the square of a
 // relative singular value below sqrt(amb), which the Gram matrix carries with a relative error of eps / |pv| or worse: whether such a
 // column lives or dies (tau) is decided by rounding.  Exactly zero pivots (columns no row touches) are not counted.
-template <bool STORE_L>
-__device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, d4 &cap, double amb = 0.0) {
+template <bool STORE_L, class LDS>
+__device__ __forceinline__ void diag_chain(d4 T, LDS &lds, double tau, int p, d4 &cap, double amb = 0.0) {
   const int lane = threadIdx.x & 63;
   const int lq = lane >> 4;
   double mask01[4];
@@ -165,7 +167,8 @@ __device__ __forceinline__ void diag_chain(d4 T, BcLds &lds, double tau, int p, 
 // W[c][i] -= a_c * (W[j][i] / pivot_j): A operand = the published register (slab j&3 holds a), B
 // operand = own register scaled by the published masked multiplier.  Row j is captured before it is
 // eliminated; scaled by 1/l_jj at the end it is row j of X^T = (tile L_d^-T)^T.
-__device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
+template <class LDS>
+__device__ __forceinline__ d4 strip_chain(d4 W, LDS &lds, int p) {
   const int lane = threadIdx.x & 63;
   const int lq = lane >> 4;
   d4 cap = {0, 0, 0, 0};
@@ -196,8 +199,8 @@ __device__ __forceinline__ d4 strip_chain(d4 W, BcLds &lds, int p) {
   return cap;
 }
 
-template <int NT, class Ops>
-__device__ __forceinline__ void blocked_chol(Ops &ops, BcLds &lds, int k, int nb, double tau, int strip, double amb = 0.0) {
+template <int NT, class Ops, class LDS>
+__device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, double tau, int strip, double amb = 0.0) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform roles
   const int li = lane & 15, lq = lane >> 4;
   const int ntk = (k + 15) >> 4;

@@ -1,0 +1,152 @@
+// gate_core.hpp — the chi2 gate of one batch entry inside the workgroup that built and projected its rows
+// (REF: UpdaterStatistics::get_chi2, PL/update/UpdaterStatistics.cpp:94-117, + the gate of UpdaterCamera.cpp:237-245 / :406-419).
+//
+// The update chain used to reach the gate in three launches: [triangulation + Jacobians + null space] -> chi2_t_kernel (T = H' Ps for
+// every entry as one tile grid) -> chi2_gate_kernel (S = T H'^T + sigma^2 I, bordered Cholesky, verdict, stack).  All of it is per
+// entry, so the Jacobian launch's workgroup can go on: its projected block H' (mp <= 32 rows, k <= GATE_KMAX columns) is still in
+// LDS, Ps is read straight from the covariance through the column map (L2-resident, one pass), T stays in LDS.  One launch to the
+// gate: two kernel boundaries and the T round trip through memory less.  Same arithmetic as the two kernels it
+// replaces (MFMA tile products with the same operand order, blocked_chol<2>), so chi2 agrees with them to the last bits.
+#pragma once
+#include "blocked_chol.hpp"
+#include "gate_stage.hpp"
+#include "mfma_tile.hpp"
+#include "wave_ops.hpp"
+
+namespace plv {
+
+struct GateLds {
+  double T[GATE_MMAX * GATE_KMAX];
+  double S[GATE_MMAX * (GATE_MMAX + 1)];
+  BcLdsT<2> bc;
+  double ybuf[64];
+  double passflag;
+  int cols[GATE_KMAX];
+};
+
+__device__ __forceinline__ double gate_wave_sum(double v) {  // (the butterfly of chi2_gate_kernel: same bits)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct GateOps {  // the bordered factorisation of S with r as the border row: y = L^-1 r
+  static constexpr bool kStoreL = false;
+  const double *S;  // LDS, stride GATE_MMAX + 1
+  const double *r;  // LDS, stride rstr
+  int rstr, mp;
+  double *y;
+  __device__ __forceinline__ double sym_raw(int i, int c) const {
+    const int hi = min(max(i, c), mp - 1), lo = min(min(i, c), mp - 1);
+    return S[lo * (GATE_MMAX + 1) + hi];  // REF: selfadjointView<Upper>
+  }
+  __device__ __forceinline__ double border_raw(int, int c) const { return r[(size_t)min(c, mp - 1) * rstr]; }
+  __device__ __forceinline__ void scales_ready() const {}
+  __device__ __forceinline__ double sym_fix(int i, int c, double g) const { return (i >= mp || c >= mp) ? (i == c ? 1.0 : 0.0) : g; }
+  __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b == 0 && c < mp) ? g : 0.0; }
+  __device__ __forceinline__ void store_sym(int, int, double) const {}
+  __device__ __forceinline__ void store_border(int b, int c, double v) const {
+    if (b == 0 && c < mp) y[c] = v;
+  }
+};
+
+// Called by ALL 256 threads of the workgroup of entry f (block-uniform arguments).  X: the entry's block in LDS, row-major with
+// ncol = fdim + k + 1 columns; rows `shift` .. rows - 1 hold the projected system [.. | H' | r] (shift = fdim when the null space was
+// applied, rows = 0 for an entry the selection did not take).  cols_g: the column map (k entries).
+__device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f, const double *X, int ncol, int fdim, int shift, int rows, int k,
+                                          const int *cols_g) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const int mp = rows - fdim;
+  const bool valid = shift == fdim && mp >= 1 && mp <= GATE_MMAX && rows >= g.min_rows;  // block-uniform
+  if (f == 0 && threadIdx.x == 0 && g.n_acc_next) *g.n_acc_next = 0;
+  double chi = NAN, nrm2 = 0.0;
+  if (valid) {
+    const double *Hp = X + (size_t)shift * ncol + fdim;  // H'(i, a) = Hp[i * ncol + a], r(i) = Hp[i * ncol + k]
+    for (int i = threadIdx.x; i < k; i += blockDim.x) L.cols[i] = cols_g[i];
+    if (threadIdx.x == 0) {
+      L.bc.bad = 0;
+      L.bc.step_flag = 0;
+      L.bc.rs_flag = 0;
+      L.bc.n_amb = 0;
+    }
+    __syncthreads();
+    const int mt = (mp + 15) >> 4, kt = (k + 15) >> 4;
+    // T = H' Ps, Ps(a, b) = P[cols[a], cols[b]]
+    for (int t = wave; t < mt * kt; t += 4) {
+      const int ti = t / kt, tj = t - ti * kt;
+      const double *Hr = Hp + (size_t)min(ti * 16 + li, mp - 1) * ncol;
+      const double *Pq = g.P + L.cols[min(tj * 16 + li, k - 1)];
+      d4 acc = {0, 0, 0, 0};
+      auto fa = [&](int, int kk) { return Hr[kk]; };
+      auto fb = [&](int kk, int) { return Pq[(size_t)L.cols[kk] * g.ldp]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
+        if (i < mp && j < k) L.T[i * GATE_KMAX + j] = acc[q];
+      }
+    }
+    __syncthreads();
+    // S = T H'^T + sigma2 I, tiles on and above the diagonal
+    for (int t = wave; t < mt * mt; t += 4) {
+      const int ti = t / mt, tj = t - ti * mt;
+      if (tj < ti) continue;
+      const double *Tr = L.T + (size_t)min(ti * 16 + li, mp - 1) * GATE_KMAX;
+      const double *Hr = Hp + (size_t)min(tj * 16 + li, mp - 1) * ncol;
+      d4 acc = {0, 0, 0, 0};
+      auto fa = [&](int, int kk) { return Tr[kk]; };
+      auto fb = [&](int kk, int) { return Hr[kk]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
+        if (i < mp && j < mp) L.S[i * (GATE_MMAX + 1) + j] = acc[q] + (i == j ? g.sigma2 : 0.0);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const double rv = lane < mp ? Hp[(size_t)lane * ncol + k] : 0.0;
+      nrm2 = gate_wave_sum(rv * rv);
+    }
+    GateOps ops{L.S, Hp + k, ncol, mp, L.ybuf};
+    blocked_chol<2>(ops, L.bc, mp, 1, 0.0, 0);
+    __syncthreads();
+    if (wave == 0) {
+      const double y = lane < mp ? L.ybuf[lane] : 0.0;
+      chi = gate_wave_sum(y * y);
+      if (L.bc.bad) chi = NAN;
+    }
+  }
+  if (wave == 0 && lane == 0) {
+    g.chi2[f] = chi;
+    bool pass = valid && !isnan(chi);
+    if (pass && g.res_norm_gate > 0.0) pass = sqrt(nrm2) < g.res_norm_gate;
+    if (pass) pass = (mp < g.q95_n) && (chi < g.chi2_mult * g.q95[mp]);
+    g.accepted[f] = pass ? 1 : 0;
+    if (g.acc_rows) g.acc_rows[f] = pass ? mp : 0;
+    if (g.h_accepted) g.h_accepted[f] = pass ? 1 : 0;
+    if (g.h_acc_rows) g.h_acc_rows[f] = pass ? mp : 0;
+    if (pass && g.n_acc) atomicAdd(g.n_acc, 1);
+    L.passflag = pass ? 1.0 : 0.0;
+  }
+  if (g.probe_dst) {
+    for (int i = threadIdx.x; i < g.probe_stride_a; i += blockDim.x) g.probe_dst[(size_t)f * g.probe_stride_a + i] = g.probe_src[(size_t)f * g.probe_stride_a + i];
+    for (int i = threadIdx.x; i < g.probe_stride_b; i += blockDim.x)
+      g.probe_dst[(size_t)g.probe_off_b + (size_t)f * g.probe_stride_b + i] = g.probe_src[(size_t)g.probe_off_b + (size_t)f * g.probe_stride_b + i];
+  }
+  if (g.stack) {
+    __syncthreads();
+    const bool pass = L.passflag != 0.0;
+    if (!pass && g.stack_accepted_only) return;
+    const double *Hp = X + (size_t)shift * ncol + fdim;
+    double *dst = g.stack + (size_t)f * g.mp_max;
+    for (int idx = threadIdx.x; idx < g.mp_max * (k + 1); idx += blockDim.x) {
+      const int j = idx / g.mp_max, i = idx - j * g.mp_max;
+      double v = 0.0;
+      if (pass && i < mp) v = Hp[(size_t)i * ncol + j];  // (column k of the block is r)
+      dst[(size_t)j * g.lds + i] = v;
+    }
+  }
+}
+
+}  // namespace plv

@@ -324,6 +324,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
     (void)hipEventRecord(ce[0], ctx->stream);
   }
   plv::HostPhase ph_a("points fused: stage + triangulate + jacobians enqueued");
+  TRY(plv_update_gate_prepare(ctx, all->n_feat, 3, k, ld, sigma2, chi2_mult, res_norm_gate, 0));
   TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
   ph_a.stop();
   if (chain_events) (void)hipEventRecord(ce[1], ctx->stream);
@@ -633,6 +634,10 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     P.tri_err = nullptr;
     P.max_sel = ft->max_sel;
     ft->o_lines = o_lines, ft->o_ok = o_ok;
+    if (ctx->gate_stage.on && ctx->gate_stage.probe_dst) {  // the gate inside the launch also carries the triangulated lines to the host
+      ctx->gate_stage.probe_src = (const unsigned char *)(d + o_lines);
+      ctx->gate_stage.probe_stride_a = 48, ctx->gate_stage.probe_off_b = L * 48, ctx->gate_stage.probe_stride_b = 1;
+    }
   }
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
@@ -687,10 +692,12 @@ int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_sta
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
   FusedLineTri ft{flags, max_sel, 0, 0, st_tri};
-  TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, true, &ft));
-  us->b_single_use = true;
   const int L = all->n_lines;
   TRY(us->h_tri.reserve((size_t)L * 49 + 16));
+  TRY(plv_update_gate_prepare(ctx, L, 6, k, ld, sigma2, chi2_mult, 0.0, 1));
+  ctx->gate_stage.probe_dst = (unsigned char *)us->h_tri.p;  // (probe_src and the strides: build_lines_on_device, where the results' place is decided)
+  TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, true, &ft));
+  us->b_single_use = true;
   // the gate's workgroups leave their verdicts and the triangulated lines in pinned memory and the launch function looks at them
   // before it enqueues compression + EKF (plv_ctx::probe): a line update in which nothing passes the gate ends there
   ctx->probe = true, ctx->probe_done = false;

@@ -11,6 +11,7 @@
 // natural GPU shape is "one lane = one (feature, observation)", ~1000 lanes per frame.  Rows are
 // written straight into the [Hf | Hx | res] batch layout that nullspace_kernel consumes; the batch
 // is zero-filled by a memset node in front of the launch.
+#include "gate_core.hpp"
 #include "jacobian_kernels.hpp"
 #include "nullspace_core.hpp"
 
@@ -426,9 +427,10 @@ struct PointTriStage {
   unsigned char *ok_out;  // [F]
   double *err_out;        // [F]
 };
-__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri) {
+__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri, GateStage gate) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld] | triangulation scratch
   __shared__ WinTab tab[JAC_MAX_WIN];
+  __shared__ GateLds gate_lds;
   __shared__ int s_rows;
   __shared__ double tri_tot[10];
   if ((int)blockIdx.x >= F) {
@@ -476,8 +478,11 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   }
   __syncthreads();
   const int rows = s_rows;
-  if ((tri.on || P.tri_ok) && rows == 0) return;  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
-                                      // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
+  if ((tri.on || P.tri_ok) && rows == 0) {  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
+                                            // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
+    if (gate.on) gate_tail(gate, gate_lds, f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
+    return;
+  }
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
   if (shift) nullspace_householder(X, piv, rows, ncol, 3);
   double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
@@ -495,6 +500,9 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
       for (int u = 0; u < 8; ++u)
         if (i0 + u < ld) dst[i0 + u] = v[u];
     }
+  }
+  if (gate.on) {  // (X is only read from here on: no barrier needed between the write-out and the gate)
+    gate_tail(gate, gate_lds, f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);
   }
 }
 
@@ -1358,9 +1366,10 @@ struct LineTriStage {
   double *out_g;          // [L][6]  == P.line_FinG of the Jacobian stage
   unsigned char *ok_g;    // [L]
 };
-__global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g, JacParams Pt, LineTriStage tri) {
+__global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g, JacParams Pt, LineTriStage tri, GateStage gate) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
   __shared__ WinTab tab[JAC_MAX_WIN];
+  __shared__ GateLds gate_lds;
   __shared__ int s_rows, s_ok;
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
@@ -1424,7 +1433,10 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   }
   __syncthreads();
   const int rows = s_rows;
-  if ((tri.on || P.tri_ok) && rows == 0) return;  // (an unselected pool line: empty system, nothing reads its block)
+  if ((tri.on || P.tri_ok) && rows == 0) {  // (an unselected pool line: empty system, nothing reads its block)
+    if (gate.on) gate_tail(gate, gate_lds, l, X, ncol, 6, 0, 0, k, P.cols_in);
+    return;
+  }
   const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
   if (shift) nullspace_householder(X, piv, rows, ncol, 6);
   double *hf = P.Hf + (size_t)l * 6 * ld, *hx = P.Hx + (size_t)l * k * ld, *rs = P.res + (size_t)l * ld;
@@ -1443,6 +1455,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
         if (i0 + u < ld) dst[i0 + u] = v[u];
     }
   }
+  if (gate.on) gate_tail(gate, gate_lds, l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
 }
 
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
@@ -1552,15 +1565,19 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
     return PLV_E_CAPACITY;
   }
   const size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 64 > 160 * 1024) {
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + sizeof(GateLds) + 64 > 160 * 1024) {
     set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
   LineTriStage tri{Pt ? 1 : 0, d_cam, d_imu, d_valid, d_lines, d_ok};
+  GateStage gate = ctx->gate_stage;
+  ctx->gate_stage.on = 0;  // (one launch takes it)
+  if (P.k > GATE_KMAX) gate.on = 0;
+  ctx->gate_stage_taken = gate.on != 0;
   hipLaunchKernelGGL(line_jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
-                     g ? *g : none, Pt ? *Pt : P, tri);
+                     g ? *g : none, Pt ? *Pt : P, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -1601,7 +1618,7 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   }
   const size_t tri_shm = tri_opt ? (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 : 0;
   const size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double) + tri_shm;
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 256 > 160 * 1024) {
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + sizeof(GateLds) + 256 > 160 * 1024) {
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
@@ -1609,8 +1626,12 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   GatherArgs none{};
   PointTriStage tri{};
   if (tri_opt) tri = PointTriStage{1, std::max(max_obs, 1), d_poses, d_valid, d_uvn, *tri_opt, d_p, d_ok, d_err};
+  GateStage gate = ctx->gate_stage;
+  ctx->gate_stage.on = 0;  // (one launch takes it)
+  if (P.k > GATE_KMAX) gate.on = 0;  // (rows: plv_update_gate_prepare knows the most an entry can have)
+  ctx->gate_stage_taken = gate.on != 0;
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
-                     g ? *g : none, tri);
+                     g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

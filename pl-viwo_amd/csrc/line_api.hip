@@ -1108,6 +1108,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     if (any) {
       rc = plv_line_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
       if (rc == PLV_OK && k > 0) {
+        ctx->gate_rows_hint = 2 * most_valid;
         rc = plv_lines_update_fused(ctx, st, st_tri, &all, flags.data(), cap, k, cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
                                     opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx, plv_tracker_run_deferred, ctx);
         res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;

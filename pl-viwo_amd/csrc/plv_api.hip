@@ -366,7 +366,10 @@ static size_t result_rows_off(int n, int F) { return ((size_t)n * 8 + 16 + (size
 static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, double **dx, int **flag, unsigned char **acc,
                       int **acc_rows = nullptr) {
   size_t bytes = result_rows_off(n, F) + (size_t)F * 4 + 16;
+  const void *before = us->result.p;
   TRY(us->result.reserve(bytes));
+  if (us->result.p != before)  // (the accepted-entry counters of the fused gate are zeroed by the update before, not by their own)
+    PLV_HIP_CHECK(hipMemsetAsync(us->result.p, 0, us->result.cap, ctx->stream));
   char *b = us->result.as<char>();
   *dx = (double *)b;
   *flag = (int *)(b + (size_t)n * 8);
@@ -617,6 +620,54 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   return sync(ctx);
 }
 
+static bool whitened_route(const plv_ctx_update_state *us, int Mtot, int k);
+// Called by the one-submission updates before they build their batch: fills plv_ctx::gate_stage so that the projected Jacobian
+// launch ends with the gate of every entry (gate_core.hpp) — verdicts, counter, stack — and plv_msckf_update_resident_launch starts
+// behind it.  The buffers are the ones that launch function reserves (same sizes: no reallocation in between).
+int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double sigma2, double chi2_mult, double res_norm_gate, int probe) {
+  auto *us = ustate(ctx);
+  ctx->gate_stage = plv::GateStage{};
+  ctx->gate_stage_taken = false;
+  const int n = ctx->cov_n, mp_max = ld - fdim;
+  const int rows_most = ctx->gate_rows_hint > 0 ? std::min(ctx->gate_rows_hint, ld) : ld;
+  ctx->gate_rows_hint = 0;
+  if (plv::knob(plv::PLV_KNOB_GATE_SEPARATE) || us->graph_mode || n < 1 || F < 1 || mp_max < 1 || rows_most - fdim > GATE_MMAX || k > GATE_KMAX)
+    return PLV_OK;
+  const int nc = k + 1, Mtot = F * mp_max;
+  TRY(ctx->d_chi2.reserve((size_t)F * 8));
+  TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
+  double *d_dx;
+  int *d_flag;
+  unsigned char *d_acc;
+  int *d_acc_rows;
+  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
+  const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
+  TRY(ctx->h_pin.reserve(rb));
+  us->acc_word = us->acc_word == 1 ? 2 : 1;  // the two counters alternate: this update counts in one and zeroes the other for the next
+  plv::GateStage &g = ctx->gate_stage;
+  g.on = 1;
+  g.P = ctx->d_P.as<double>();
+  g.ldp = n;
+  g.sigma2 = sigma2, g.chi2_mult = chi2_mult, g.res_norm_gate = res_norm_gate;
+  g.q95 = us->q95.as<double>();
+  g.q95_n = Q95_N;
+  g.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
+  g.chi2 = ctx->d_chi2.as<double>();
+  g.accepted = d_acc;
+  g.acc_rows = d_acc_rows;
+  g.n_acc = d_flag + us->acc_word;
+  g.n_acc_next = d_flag + (3 - us->acc_word);
+  g.stack = ctx->d_stack.as<double>();
+  g.lds = Mtot;
+  g.mp_max = mp_max;
+  g.stack_accepted_only = (Mtot > k && k <= 192 && (whitened_route(us, Mtot, k) || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
+  if (probe) {  // the verdicts also go to pinned memory (the caller adds the second block: probe_src / probe_dst / strides)
+    char *hb = ctx->h_pin.as<char>();
+    g.h_accepted = (unsigned char *)(hb + (size_t)n * 8 + 16);
+    g.h_acc_rows = (int *)(hb + result_rows_off(n, F));
+  }
+  return PLV_OK;
+}
 static bool whitened_route(const plv_ctx_update_state *us, int Mtot, int k) {
   return Mtot > k && k <= 192 && us->compress_mode == 0 && !us->graph_mode;
 }
@@ -786,7 +837,16 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     a.probe_dst = (unsigned char *)ctx->probe_dst;
     a.probe_stride_a = ctx->probe_stride_a, a.probe_off_b = ctx->probe_off_b, a.probe_stride_b = ctx->probe_stride_b;
   }
-  TRY(launch_chi2(ctx, F, a, mp_max));
+  // the gate already ran as the tail of the Jacobian launch (plv_update_gate_prepare): same buffers, its own counter word
+  const bool gated = ctx->gate_stage_taken && projected && ctx->gate_stage.stack == a.stack && ctx->gate_stage.lds == a.lds &&
+                     ctx->gate_stage.accepted == a.accepted && ctx->gate_stage.stack_accepted_only == a.stack_accepted_only;
+  if (gated) {
+    ctx->skip_word = ctx->skip_word ? ctx->gate_stage.n_acc : nullptr;
+    us->acc_word_used = us->acc_word;
+  } else {
+    us->acc_word_used = 1;
+    TRY(launch_chi2(ctx, F, a, mp_max));
+  }
   if (probe) {
     // the gate's verdicts are in pinned memory when its launch has finished: most line updates end here (three frames in four at
     // BASELINE configs[2] accept no line), without the six launches that would find nothing to do
@@ -909,6 +969,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     if (erc) return erc;
     if (jrc) return jrc;
   }
+  ctx->gate_stage.on = 0, ctx->gate_stage_taken = false;
   ++ctx->gather_stamp;  // the update rewrites the covariance
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
   if (!us->done_ev) PLV_HIP_CHECK(hipEventCreateWithFlags(&us->done_ev, hipEventDisableTiming));
@@ -974,7 +1035,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   const char *hb = ctx->h_pin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;
-  if (us->redo.armed && us->last_ambiguous > 0 && *(const int *)(hb + (size_t)n * 8) == 0 && ((const int *)(hb + (size_t)n * 8))[1] > 0) {
+  if (us->redo.armed && us->last_ambiguous > 0 && *(const int *)(hb + (size_t)n * 8) == 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
     // automatic mode: the Gram factorisation met pivots it could not tell from zero and ekf_commit_kernel left the covariance alone.
     // The stacked rows are still in place: compress them by Householder reflections (orthogonal transformations on the rows
     // themselves resolve what the squared matrix cannot) and run the EKF step again.

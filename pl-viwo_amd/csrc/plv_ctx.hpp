@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <sys/resource.h>
+
+#include "gate_stage.hpp"
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -60,11 +62,12 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 //   4  the edge kernel behind flow + RANSAC (PLV_LINE_EDGES_LATE)          8  the next frame's detection on the ctx stream (PLV_AHEAD_CTX)
 //  16  the line pool formed after the point update (PLV_LINE_POOL_LATE)    32 / 64  point / line triangulation as its own launch
 // 128  the Jacobian launches read their inputs from the pinned staging block instead of an uploaded copy
+// 1024 the gate as chi2_t_kernel + chi2_gate_kernel behind the Jacobian launch instead of as that launch's tail (gate_core.hpp)
 // 256  the flow's and the updates' waits on completion words their last kernels write into pinned memory (plv_ctx::h_done) instead of
 //      on HIP events: a bare word is seen 4.8 us earlier (tools/ubench/waitlat.hip), in the frame it gains nothing (0 .. 9 us SLOWER over
 //      four alternating runs: the commit then runs as one workgroup so that the word also covers the covariance)
 enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
-                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u };
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
   return k;
@@ -406,6 +409,13 @@ struct plv_ctx {
   int probe_stride_a = 0, probe_off_b = 0, probe_stride_b = 0;
   void (*probe_hook)(void *) = nullptr;
   void *probe_hook_arg = nullptr;
+
+  // the gate as the tail of the next projected Jacobian launch (gate_core.hpp): filled by plv_update_gate_prepare for the update the
+  // one-submission entry points are about to build; the launcher takes it (gate_stage_taken) when the batch fits, and
+  // plv_msckf_update_resident_launch then starts behind the gate
+  plv::GateStage gate_stage{};
+  bool gate_stage_taken = false;
+  int gate_rows_hint = 0;  // most rows any entry of the batch about to be built can have (0: unknown, the batch's row capacity counts)
 
   // host work of the caller that becomes possible while a point update runs on the device (plv_points_update_fused polls it inside
   // its wait until it returns nonzero = done / nothing to do)

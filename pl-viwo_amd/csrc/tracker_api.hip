@@ -668,6 +668,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       all.p_FinG = all.p_FinG_fej = pf.data();
       rc = plv_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
       if (rc == PLV_OK && k > 0) {
+        ctx->gate_rows_hint = 2 * most_valid;
         rc = plv_points_update_fused(ctx, st, &all, &opt->tri, flags.data(), opt->max_msckf, k, cols.data(), 2 * opt->max_obs,
                                      st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, pf.data(), ok.data(), err.data(), acc_all.data(),
                                      &n_rows, dx, start_detection_ahead, ctx);

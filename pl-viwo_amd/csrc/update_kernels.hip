@@ -400,7 +400,6 @@ __global__ void __launch_bounds__(256) ekf_mt_kernel(const double *__restrict__ 
                                                      int *__restrict__ flag, const int *__restrict__ skip) {
   if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
     flag[0] = 0;  // update status word, set by the kernels that follow
-    flag[2] = 0;  // arrival counter of ekf_dc_kernel
   }
   if (skip && *skip == 0) return;
   const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
@@ -459,7 +458,6 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
   __shared__ double strip[192 * 17];  // (H Ps)[16 rows][k], element (i, kk) at kk * 17 + i
   if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
     flag[0] = 0;  // update status word, set by the kernels that follow
-    flag[2] = 0;  // arrival counter of ekf_dc_kernel
   }
   if (skip && *skip == 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15;

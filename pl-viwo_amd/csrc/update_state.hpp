@@ -30,6 +30,8 @@ struct plv_ctx_update_state {
     double *d_dx = nullptr;
     int *d_flag = nullptr;
   } redo;
+  int acc_word = 2;        // word of the status block the fused gate's next update counts its accepted entries in (1 or 2, alternating)
+  int acc_word_used = 1;   // ... and the word the last launched update's chain read as its skip word (1: chi2_gate_kernel's)
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)
@@ -61,6 +63,7 @@ struct plv_ctx_update_state {
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
 
+extern "C" int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double sigma2, double chi2_mult, double res_norm_gate, int probe);  // plv_api.hip
 extern "C" int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max);  // plv_api.hip
 
 // internal entry points of jacobian_api.hip used by the one-call camera updates (tracker_api.hip, line_api.hip)
