@@ -248,6 +248,33 @@ def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path,
         assert np.array_equal(t1, t0) and np.array_equal(p1, p0), mode
 
 
+def test_gate_inside_the_jacobian_launch_equals_the_separate_launches(pkg, street_dataset, tmp_path):
+    """The chi2 gate as the tail of the projected Jacobian launches (csrc/gate_core.hpp: T = H' Ps, S, bordered Cholesky and verdict
+    in the workgroup that built the rows) against chi2_t_kernel + chi2_gate_kernel behind that launch (measurement knob 1024): the same
+    tile products in the same order, so the same chi2 bits, verdicts, stacks and therefore the same filter, bit for bit — and four
+    launches per frame less."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs, launches = {}, {}
+    try:
+        for name, mask in (("fused", 0), ("separate", 1024)):
+            pkg.debug_knobs(mask)
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{name}.txt")))
+            op.est.cam.use_lines = True
+            c0 = pkg.counters()["launches"]
+            runs[name] = rp.replay(op)
+            launches[name] = pkg.counters()["launches"] - c0
+    finally:
+        pkg.debug_knobs(0)
+    s0, t0, p0 = runs["separate"]
+    s1, t1, p1 = runs["fused"]
+    assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
+    for key in s0:
+        if not key.startswith("time"):
+            assert s1[key] == s0[key], (key, s1[key], s0[key])
+    assert np.array_equal(t1, t0) and np.array_equal(p1, p0)
+    assert launches["fused"] <= launches["separate"] - 3 * s0["cam_updates"], launches     # (it did run)
+
+
 def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
     """cam.downsample (pyrDown of every image, halved intrinsics: OptionsCamera.cpp:123-138, UpdaterCamera.cpp:85-98) with the CLAHE
     front-end on the 376 x 240 images."""
