@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
     ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
                     "plv_update_compression_mode settings frame by frame and stderr gets the mean step time of each (drift-free A/B)")
+    ap.add_argument("--alternate-spin", default=None, help="measurement aid: e.g. 300,0 — plv_line_worker_config polling budgets (us) cycled frame by frame")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
                     "mean step time of each on stderr")
     ap.add_argument("--dry-run", action="store_true",
@@ -376,6 +377,7 @@ def main():
 
     alt_modes = [int(m) for m in args.alternate_modes.split(",")] if args.alternate_modes else None
     alt_knobs = [int(m) for m in args.alternate_knobs.split(",")] if args.alternate_knobs else None
+    alt_spin = [int(m) for m in args.alternate_spin.split(",")] if args.alternate_spin else None
 
     def timed_segment(n_steps, hook=None):
         per_frame = {"kept": [], "tracked": []}
@@ -396,6 +398,8 @@ def main():
                 ctx.update_compression_mode(alt_modes[f % len(alt_modes)])
             if alt_knobs:
                 pkg.debug_knobs(alt_knobs[f % len(alt_knobs)])
+            if alt_spin:
+                pkg.line_worker_config(alt_spin[f % len(alt_spin)], -1)
             c0 = pkg.counters()
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
@@ -415,6 +419,10 @@ def main():
         ctx.synchronize()
         barrier()
         gc.enable()
+        if alt_spin:
+            for j, m in enumerate(alt_spin):
+                v = per[j::len(alt_spin)]
+                print(f"[alternate] poll {m} us: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
         if alt_knobs:
             pkg.debug_knobs(0)
             for j, m in enumerate(alt_knobs):

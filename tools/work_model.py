@@ -63,12 +63,16 @@ def frame_work(W, H, levels, n_pts, lk_iters, win, F, M, k, n, L=0, Ml=0, kl=0, 
         "line_jacobian_kernel": ("mfma", L * Ml * 6000.0),
     }
     up = update_work(F, 2 * M, 3, k, n)
+    # (the gate runs as the tail of these launches when an entry has at most 32 projected rows and 128 columns: gate_core.hpp)
+    gate_in = (2 * M - 3) <= 32 and k <= 128
+    gate_pts = (up["chi2_t_kernel"] + up["chi2_gate_kernel"]) if gate_in else 0.0
     work["jacobian_nullspace_kernel"] = ("mfma", F * M * 3000.0 + up["nullspace_kernel"])
-    work["tri_jacobian_nullspace_kernel"] = ("mfma", pool_pts * (M * 120.0 + 5 * M * 200.0) + F * M * 3000.0 + up["nullspace_kernel"])
+    work["tri_jacobian_nullspace_kernel"] = ("mfma", pool_pts * (M * 120.0 + 5 * M * 200.0) + F * M * 3000.0 + up["nullspace_kernel"] + gate_pts)
     if L > 0:
         ul = update_work(L, 2 * Ml, 6, kl, n)
         work["line_jacobian_nullspace_kernel"] = ("mfma", L * Ml * 6000.0 + ul["nullspace_kernel"])
-        work["line_tri_jacobian_nullspace_kernel"] = ("mfma", pool_lines * Ml * 300.0 + L * Ml * 6000.0 + ul["nullspace_kernel"])
+        gate_l = (ul["chi2_t_kernel"] + ul["chi2_gate_kernel"]) if ((2 * Ml - 6) <= 32 and kl <= 128) else 0.0
+        work["line_tri_jacobian_nullspace_kernel"] = ("mfma", pool_lines * Ml * 300.0 + L * Ml * 6000.0 + ul["nullspace_kernel"] + gate_l)
         for name, v in up.items():   # kernels both updates launch: the mean of the two launches
             up[name] = ul[name] if name == "nullspace_kernel" else 0.5 * (v + ul[name])
     for name, v in up.items():
