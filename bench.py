@@ -512,7 +512,10 @@ def main():
                 achieved, peak, unit = per_launch / avg_s / 1e9, wm.HBM_PEAK_GBS, "GB/s"
             else:
                 achieved, peak, unit = per_launch / avg_s / 1e12, wm.F64_MFMA_PEAK_TF, "TFLOP/s"
-            tr = traffic_tab.get(name)
+            # (the in-library profiler labels the fused launches by what they carry; rocprofv3 names the __global__ function)
+            alias = {"tri_jacobian_nullspace_kernel": "jacobian_nullspace_kernel", "line_tri_jacobian_nullspace_kernel": "line_jacobian_nullspace_kernel",
+                     "half_canny_kernel": "canny_kernel"}
+            tr = traffic_tab.get(name, traffic_tab.get(alias.get(name, name)))
             return {"kernel": name, "bound": kind, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_frame": round(n_launch / max(1, done), 2),
                     "us_per_frame": round(ms / max(1, done) * 1e3, 2), "algorithmic_per_launch": per_launch, "achieved": achieved, "peak": peak,
                     "unit": unit, "frac": achieved / peak, "traffic": tr,

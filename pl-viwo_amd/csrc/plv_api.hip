@@ -840,6 +840,10 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   // the gate already ran as the tail of the Jacobian launch (plv_update_gate_prepare): same buffers, its own counter word
   const bool gated = ctx->gate_stage_taken && projected && ctx->gate_stage.stack == a.stack && ctx->gate_stage.lds == a.lds &&
                      ctx->gate_stage.accepted == a.accepted && ctx->gate_stage.stack_accepted_only == a.stack_accepted_only;
+  if (ctx->gate_stage_taken && !gated) {  // (the launch that took the gate did not write the projected blocks a separate gate would read)
+    set_last_error("plv_msckf_update_resident: the batch was gated inside its Jacobian launch for other buffers than this update's");
+    return PLV_E_BADARG;
+  }
   if (gated) {
     ctx->skip_word = ctx->skip_word ? ctx->gate_stage.n_acc : nullptr;
     us->acc_word_used = us->acc_word;
