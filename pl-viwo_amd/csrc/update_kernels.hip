@@ -454,7 +454,9 @@ __global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ M
 __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ H, int ldh, int r, int k, const double *__restrict__ Pc,
                                                      int ldp, int n, const double *__restrict__ Ps, double *__restrict__ Mt, int ldm,
                                                      const double *__restrict__ Rdiag, double *__restrict__ S, int lds_,
-                                                     int mt_blocks, int *__restrict__ flag, const int *__restrict__ skip) {
+                                                     int mt_blocks, int *__restrict__ flag, const int *__restrict__ skip, int h_upper) {
+  // h_upper (whitened update: H = Lp^T): H(i, kk) = 0 for kk < i, so a 16-row strip's sums start at its own first column — the
+  // skipped terms are exact zeros, the results the same bits, about half of the tile products gone
   __shared__ double strip[192 * 17];  // (H Ps)[16 rows][k], element (i, kk) at kk * 17 + i
   if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
     flag[0] = 0;  // update status word, set by the kernels that follow
@@ -467,11 +469,12 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
     if (tile >= tr_n * tn_n) return;
     const int tr = tile / tn_n, tn = tile - tr * tn_n;
     d4 acc = {0, 0, 0, 0};
-    const double *Hr = H + min(tr * 16 + li, r - 1);
-    const double *Pq = Pc + min(tn * 16 + li, n - 1);  // Pc = P[cols, :] (k x n)
+    const int k0 = h_upper ? min(tr * 16, k) : 0;
+    const double *Hr = H + min(tr * 16 + li, r - 1) + (size_t)k0 * ldh;
+    const double *Pq = Pc + min(tn * 16 + li, n - 1) + (size_t)k0 * ldp;  // Pc = P[cols, :] (k x n)
     auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
     auto fb = [&](int kk, int) { return Pq[(size_t)kk * ldp]; };
-    acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+    acc = mfma_tile_f64_pipe<16>(fa, fb, k - k0, acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = tr * 16 + (lane >> 4) + 4 * q, j = tn * 16 + li;
@@ -482,13 +485,14 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
   const int ti = blockIdx.x - mt_blocks;
   const int kt = (k + 15) >> 4, tr_n = (r + 15) >> 4;
   {
-    const double *Hr = H + min(ti * 16 + li, r - 1);
+    const int k0 = h_upper ? min(ti * 16, k) : 0;
+    const double *Hr = H + min(ti * 16 + li, r - 1) + (size_t)k0 * ldh;
     for (int tj = wave; tj < kt; tj += 4) {
       d4 acc = {0, 0, 0, 0};
-      const double *Pq = Ps + min(tj * 16 + li, k - 1);  // Ps = P[cols, cols] (k x k)
+      const double *Pq = Ps + min(tj * 16 + li, k - 1) + (size_t)k0 * k;  // Ps = P[cols, cols] (k x k)
       auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
       auto fb = [&](int kk, int) { return Pq[(size_t)kk * k]; };
-      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k - k0, acc);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j = tj * 16 + li;
@@ -499,10 +503,12 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
   __syncthreads();
   for (int tj = ti + wave; tj < tr_n; tj += 4) {
     d4 acc = {0, 0, 0, 0};
-    const double *Hc = H + min(tj * 16 + li, r - 1);
-    auto fa = [&](int, int kk) { return strip[kk * 17 + li]; };
+    const int k0 = h_upper ? min(tj * 16, k) : 0;  // (H(j, kk) = 0 for kk < j)
+    const double *Hc = H + min(tj * 16 + li, r - 1) + (size_t)k0 * ldh;
+    const double *sp = strip + k0 * 17;
+    auto fa = [&](int, int kk) { return sp[kk * 17 + li]; };
     auto fb = [&](int kk, int) { return Hc[(size_t)kk * ldh]; };
-    acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+    acc = mfma_tile_f64_pipe<16>(fa, fb, k - k0, acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + li;
@@ -779,7 +785,7 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
     return;
   }
   hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(r, 16)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_Pc.as<double>(), n, n,
-                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word);
+                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word, 0);
 }
 
 // Whitened route: B = Lp^T G Lp + I (k x k, upper tiles) and c = Lp^T g — ekf_ms_kernel with H := Lp^T (Lt), "Ps" := G (full
@@ -788,7 +794,7 @@ void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, co
   ProfScope ps(ctx->prof, "ekf_ms_kernel", ctx->stream);
   const int mt_blocks = cdiv(cdiv(k, 16), 4);
   hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(k, 16)), dim3(256), 0, ctx->stream, Lt, k, k, k, gv, 1, 1, Gs, cv, k,
-                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word);
+                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word, 1);
 }
 
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds
