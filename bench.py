@@ -139,6 +139,16 @@ class Player:
             self.sys.ctx.synchronize()     # ctx stream + detection side stream + line worker
 
 
+def cgroup_cpu():
+    """cpu.stat of this process's control group (v2), or None"""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            kv = dict(line.split() for line in fh if line.strip())
+        return {k: int(kv.get(k, 0)) for k in ("usage_usec", "nr_periods", "nr_throttled")}
+    except (OSError, ValueError):
+        return None
+
+
 def pct(a, q):
     return float(np.percentile(np.asarray(a), q)) if len(a) else None
 
@@ -389,7 +399,8 @@ def main():
         gc.collect()
         gc.disable()      # (the driver is Python: its collector must not land inside a 0.6 ms step)
         barrier()
-        elapsed, per = 0.0, []
+        cg0, wall0 = cgroup_cpu(), time.perf_counter()
+        elapsed, per, grew = 0.0, [], []
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if hook:
@@ -401,11 +412,14 @@ def main():
             if alt_spin:
                 pkg.line_worker_config(alt_spin[f % len(alt_spin)], -1)
             c0 = pkg.counters()
+            a0 = pkg.alloc_count()
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
             dt = time.perf_counter() - t0
             elapsed += dt
             per.append(dt * 1e3)
+            if pkg.alloc_count() != a0:
+                grew.append(f)
             c1 = pkg.counters()
             for k in c1:
                 cnt[k] += c1[k] - c0[k]
@@ -419,15 +433,22 @@ def main():
         ctx.synchronize()
         barrier()
         gc.enable()
+        cg1, wall1 = cgroup_cpu(), time.perf_counter()
+        host_cpu = None
+        if cg0 and cg1:   # CPU time of the whole control group (every thread of the library and of the driver) over the segment's wall time
+            host_cpu = {"cpu_seconds_per_second": round((cg1["usage_usec"] - cg0["usage_usec"]) * 1e-6 / max(wall1 - wall0, 1e-9), 2),
+                        "cfs_periods_throttled": cg1["nr_throttled"] - cg0["nr_throttled"], "cfs_periods": cg1["nr_periods"] - cg0["nr_periods"]}
         if alt_spin:
             for j, m in enumerate(alt_spin):
                 v = per[j::len(alt_spin)]
-                print(f"[alternate] poll {m} us: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
+                print(f"[alternate] poll {m} us: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  max {np.max(v) * 1e3:.1f}  "
+                      f"frames above 1 ms: {int(np.sum(np.asarray(v) > 1.0))}  over {len(v)} frames", file=sys.stderr)
         if alt_knobs:
             pkg.debug_knobs(0)
             for j, m in enumerate(alt_knobs):
                 v = per[j::len(alt_knobs)]
-                print(f"[alternate] knobs {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
+                print(f"[alternate] knobs {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  max {np.max(v) * 1e3:.1f}  "
+                      f"frames above 1 ms: {int(np.sum(np.asarray(v) > 1.0))}  over {len(v)} frames", file=sys.stderr)
         if alt_modes:
             ctx.update_compression_mode(0)
             for j, m in enumerate(alt_modes):
@@ -439,7 +460,9 @@ def main():
             if k.startswith("[Time-Cam]"):
                 a, c = tc0.get(k, (0.0, 0))
                 split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
-        return dict(elapsed=reduce_max(elapsed, dist), per=per, per_frame=per_frame, cnt=cnt, stats=stats, split=split)
+        if os.environ.get("PLV_BENCH_FRAMES"):
+            print("[frames] ms per step:", " ".join(f"{v:.3f}" for v in per), "| steps that (re)allocated a buffer:", grew, "| host cpu:", host_cpu, file=sys.stderr)
+        return dict(elapsed=reduce_max(elapsed, dist), per=per, per_frame=per_frame, cnt=cnt, stats=stats, split=split, grew=grew, host_cpu=host_cpu)
 
     for f in range(PROLOGUE + args.warmup):
         pl.camera(*pl.next_frame())
@@ -606,6 +629,7 @@ def main():
                                         "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_gram_cholesky is the "
                                         "round-2 route (mode 3)"},
                 "variants": variants,
+                "host_cpu": seg.get("host_cpu"),
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "pcie_inclusive": None if seg_pcie is None else {
                     "what": "second timed segment, the next frames of the stream: the image is a host buffer (plv_tracker_feed), its "

@@ -166,6 +166,7 @@ def load_library():
         "plv_update_compression_mode": (C.c_int, [vp, C.c_int, ip, ip]),
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
+        "plv_alloc_count": (C.c_ulonglong, []),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -687,6 +688,11 @@ def line_worker_config(spin_us=-1, fit_threads=-1):
     a, b = C.c_int(), C.c_int()
     load_library().plv_line_worker_config(int(spin_us), int(fit_threads), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def alloc_count():
+    """plv_alloc_count (measurement aid): device / pinned buffer (re)allocations since the library was loaded"""
+    return int(load_library().plv_alloc_count())
 
 
 def debug_knobs(mask=-1):

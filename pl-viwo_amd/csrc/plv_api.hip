@@ -98,6 +98,8 @@ extern "C" {
 
 int plv_abi_version(void) { return PLV_ABI_VERSION; }
 // (measurement aid, not part of the drop-in surface: plv_ctx.hpp "Measurement knobs")  set < 0 only queries; returns the previous mask
+// (measurement aid) device / pinned (re)allocations since the library was loaded: a frame that grows a buffer pays a hipMalloc
+unsigned long long plv_alloc_count(void) { return plv::alloc_epoch().load(); }
 unsigned plv_debug_knobs(long long set) {
   const unsigned prev = plv::knobs().load();
   if (set >= 0) plv::knobs().store((unsigned)set);
