@@ -59,6 +59,7 @@ WORKLOADS = {
 }
 SCENE = "avenue"
 PROLOGUE = 24      # frames before the warm-up: initialisation + the first full clone window (untimed set-up)
+LEAD_IN = 2        # untimed steps at the start of every timed segment, after its garbage collection (see timed_segment)
 IMU, WHEEL, CAM = 0, 1, 2
 ROUND = "r03"
 
@@ -341,7 +342,7 @@ def main():
         nprof = max(10, min(40, args.steps))
         seg2 = 0 if args.no_pcie else args.steps
         nvar = 0 if args.no_variants else max(10, min(40, args.steps))
-        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof + 4 * nvar
+        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof + 4 * nvar + 5 * LEAD_IN
         n_cpu_frames = 0 if (args.no_cpu or rank != 0) else PROLOGUE + args.cpu_frames
         workers = args.render_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
         t0 = time.perf_counter()
@@ -393,11 +394,19 @@ def main():
         per_frame = {"kept": [], "tracked": []}
         cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "frame_ns", "sync_ns", "ambiguous_frames",
                               "redone_frames", "whitened_frames")}
-        base = dict(sm.stats)
-        tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
         ctx.synchronize()
         gc.collect()
         gc.disable()      # (the driver is Python: its collector must not land inside a 0.6 ms step)
+        # the collection above is a pause of milliseconds in which the library's threads go to sleep and the caches cool: two untimed
+        # steps (more warm-up, same code path) lead back into the steady state the timed steps are meant to show
+        for _ in range(LEAD_IN):
+            nf = pl.next_frame()
+            if hook:
+                hook(0)
+            pl.camera(*nf)
+        base = dict(sm.stats)
+        tc0 = {k: (sm.tc.total.get(k, 0.0), sm.tc.count.get(k, 0)) for k in list(sm.tc.total)}
+        ctx.synchronize()
         barrier()
         cg0, wall0 = cgroup_cpu(), time.perf_counter()
         elapsed, per, grew = 0.0, [], []
