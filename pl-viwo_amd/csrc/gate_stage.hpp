@@ -8,6 +8,7 @@ namespace plv {
 
 struct GateStage {  // kernel argument; on == 0: the launch ends with the projected blocks as before
   int on;
+  int lds_off;      // byte offset of the gate's LDS block (GateLds) inside the launch's dynamic shared memory (set by the launcher)
   const double *P;  // covariance, n x n, both triangles valid
   int ldp;
   double sigma2, chi2_mult, res_norm_gate;

@@ -430,7 +430,6 @@ struct PointTriStage {
 __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri, GateStage gate) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld] | triangulation scratch
   __shared__ WinTab tab[JAC_MAX_WIN];
-  __shared__ GateLds gate_lds;
   __shared__ int s_rows;
   __shared__ double tri_tot[10];
   if ((int)blockIdx.x >= F) {
@@ -480,7 +479,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   const int rows = s_rows;
   if ((tri.on || P.tri_ok) && rows == 0) {  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
                                             // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
-    if (gate.on) gate_tail(gate, gate_lds, f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
+    if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
     return;
   }
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
@@ -504,7 +503,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     }
   }
   if (gate.on) {  // (X is only read from here on: no barrier needed between the write-out and the gate)
-    gate_tail(gate, gate_lds, f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);
+    gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);
   }
 }
 
@@ -1371,7 +1370,6 @@ struct LineTriStage {
 __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g, JacParams Pt, LineTriStage tri, GateStage gate) {
   extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
   __shared__ WinTab tab[JAC_MAX_WIN];
-  __shared__ GateLds gate_lds;
   __shared__ int s_rows, s_ok;
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
@@ -1436,7 +1434,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   __syncthreads();
   const int rows = s_rows;
   if ((tri.on || P.tri_ok) && rows == 0) {  // (an unselected pool line: empty system, nothing reads its block)
-    if (gate.on) gate_tail(gate, gate_lds, l, X, ncol, 6, 0, 0, k, P.cols_in);
+    if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), l, X, ncol, 6, 0, 0, k, P.cols_in);
     return;
   }
   const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
@@ -1457,7 +1455,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
         if (i0 + u < ld) dst[i0 + u] = v[u];
     }
   }
-  if (gate.on) gate_tail(gate, gate_lds, l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
+  if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
 }
 
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
@@ -1566,18 +1564,23 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
     set_last_error("line jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
     return PLV_E_CAPACITY;
   }
-  const size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + sizeof(GateLds) + 64 > 160 * 1024) {
+  size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 64 > 160 * 1024) {
     set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
   LineTriStage tri{Pt ? 1 : 0, d_cam, d_imu, d_valid, d_lines, d_ok};
   GateStage gate = ctx->gate_stage;
   ctx->gate_stage.on = 0;  // (one launch takes it)
-  if (P.k > GATE_KMAX) gate.on = 0;
+  const size_t gate_off = (shm + 63) & ~(size_t)63;
+  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + sizeof(WinTab) * JAC_MAX_WIN + 512 > 160 * 1024) gate.on = 0;
+  if (gate.on) {
+    gate.lds_off = (int)gate_off;
+    shm = gate_off + sizeof(GateLds);
+  }
   ctx->gate_stage_taken = gate.on != 0;
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
   hipLaunchKernelGGL(line_jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
                      g ? *g : none, Pt ? *Pt : P, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
@@ -1619,19 +1622,25 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
     return PLV_E_CAPACITY;
   }
   const size_t tri_shm = tri_opt ? (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 : 0;
-  const size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double) + tri_shm;
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + sizeof(GateLds) + 256 > 160 * 1024) {
+  size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double) + tri_shm;
+  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 256 > 160 * 1024) {
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
-  PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   GatherArgs none{};
   PointTriStage tri{};
   if (tri_opt) tri = PointTriStage{1, std::max(max_obs, 1), d_poses, d_valid, d_uvn, *tri_opt, d_p, d_ok, d_err};
   GateStage gate = ctx->gate_stage;
   ctx->gate_stage.on = 0;  // (one launch takes it)
-  if (P.k > GATE_KMAX) gate.on = 0;  // (rows: plv_update_gate_prepare knows the most an entry can have)
+  // the gate's LDS block sits behind the entry's block in the launch's dynamic shared memory: taken only where both fit
+  const size_t gate_off = (shm + 63) & ~(size_t)63;
+  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + sizeof(WinTab) * JAC_MAX_WIN + 512 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
+  if (gate.on) {
+    gate.lds_off = (int)gate_off;
+    shm = gate_off + sizeof(GateLds);
+  }
   ctx->gate_stage_taken = gate.on != 0;
+  PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
                      g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
