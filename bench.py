@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
                     "plv_update_compression_mode settings frame by frame and stderr gets the mean step time of each (drift-free A/B)")
     ap.add_argument("--alternate-spin", default=None, help="measurement aid: e.g. 300,0 — plv_line_worker_config polling budgets (us) cycled frame by frame")
+    ap.add_argument("--alternate-fit", default=None, help="measurement aid: e.g. 2,0 — segment-fitter thread counts cycled frame by frame")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
                     "mean step time of each on stderr")
     ap.add_argument("--dry-run", action="store_true",
@@ -389,6 +390,7 @@ def main():
     alt_modes = [int(m) for m in args.alternate_modes.split(",")] if args.alternate_modes else None
     alt_knobs = [int(m) for m in args.alternate_knobs.split(",")] if args.alternate_knobs else None
     alt_spin = [int(m) for m in args.alternate_spin.split(",")] if args.alternate_spin else None
+    alt_fit = [int(m) for m in args.alternate_fit.split(",")] if args.alternate_fit else None
 
     def timed_segment(n_steps, hook=None):
         per_frame = {"kept": [], "tracked": []}
@@ -409,7 +411,8 @@ def main():
         ctx.synchronize()
         barrier()
         cg0, wall0 = cgroup_cpu(), time.perf_counter()
-        elapsed, per, grew = 0.0, [], []
+        elapsed, per, grew, slow = 0.0, [], [], []
+        trace_frames = bool(os.environ.get("PLV_BENCH_FRAMES"))
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if hook:
@@ -420,8 +423,11 @@ def main():
                 pkg.debug_knobs(alt_knobs[f % len(alt_knobs)])
             if alt_spin:
                 pkg.line_worker_config(alt_spin[f % len(alt_spin)], -1)
+            if alt_fit:
+                pkg.line_worker_config(-1, alt_fit[f % len(alt_fit)])
             c0 = pkg.counters()
             a0 = pkg.alloc_count()
+            ph0 = pkg.phase_counters() if trace_frames else None
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
             dt = time.perf_counter() - t0
@@ -429,6 +435,11 @@ def main():
             per.append(dt * 1e3)
             if pkg.alloc_count() != a0:
                 grew.append(f)
+            if trace_frames and dt > 1e-3:      # where did a slow step spend its time?
+                ph1 = pkg.phase_counters()
+                c1_ = pkg.counters()
+                slow.append((f, round(dt * 1e3, 3), {k: round((ph1[k] - ph0[k]) * 1e-6, 3) for k in ph1},
+                             round((c1_["frame_ns"] - c0["frame_ns"]) * 1e-6, 3), round((c1_["sync_ns"] - c0["sync_ns"]) * 1e-6, 3)))
             c1 = pkg.counters()
             for k in c1:
                 cnt[k] += c1[k] - c0[k]
@@ -447,6 +458,11 @@ def main():
         if cg0 and cg1:   # CPU time of the whole control group (every thread of the library and of the driver) over the segment's wall time
             host_cpu = {"cpu_seconds_per_second": round((cg1["usage_usec"] - cg0["usage_usec"]) * 1e-6 / max(wall1 - wall0, 1e-9), 2),
                         "cfs_periods_throttled": cg1["nr_throttled"] - cg0["nr_throttled"], "cfs_periods": cg1["nr_periods"] - cg0["nr_periods"]}
+        if alt_fit:
+            for j, m in enumerate(alt_fit):
+                v = per[j::len(alt_fit)]
+                print(f"[alternate] fit threads {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  max {np.max(v) * 1e3:.1f}  "
+                      f"frames above 1 ms: {int(np.sum(np.asarray(v) > 1.0))}  over {len(v)} frames", file=sys.stderr)
         if alt_spin:
             for j, m in enumerate(alt_spin):
                 v = per[j::len(alt_spin)]
@@ -471,6 +487,8 @@ def main():
                 split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
         if os.environ.get("PLV_BENCH_FRAMES"):
             print("[frames] ms per step:", " ".join(f"{v:.3f}" for v in per), "| steps that (re)allocated a buffer:", grew, "| host cpu:", host_cpu, file=sys.stderr)
+            for row in slow:
+                print("[slow step] step %d: %.3f ms; inside its parts (ms) %s; plv_camera_frame %.3f, plv_ctx_synchronize %.3f" % row, file=sys.stderr)
         return dict(elapsed=reduce_max(elapsed, dist), per=per, per_frame=per_frame, cnt=cnt, stats=stats, split=split, grew=grew, host_cpu=host_cpu)
 
     for f in range(PROLOGUE + args.warmup):

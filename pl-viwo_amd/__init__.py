@@ -167,6 +167,7 @@ def load_library():
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
         "plv_alloc_count": (C.c_ulonglong, []),
+        "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
                                               C.POINTER(PlvUpdateResult), u64p, u8p, dp, C.c_int]),
         "plv_slam_update": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, C.c_double, u8p, dp]),
@@ -688,6 +689,14 @@ def line_worker_config(spin_us=-1, fit_threads=-1):
     a, b = C.c_int(), C.c_int()
     load_library().plv_line_worker_config(int(spin_us), int(fit_threads), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def phase_counters():
+    """plv_phase_counters (measurement aid): ns inside the parts of plv_camera_frame since the library was loaded"""
+    out = (C.c_ulonglong * 10)()
+    load_library().plv_phase_counters(out)
+    return dict(zip(("flow_wait", "points", "points_wait", "lines", "line_join", "w_wake", "w_maps", "w_extract", "w_feed_start", "w_feed"),
+                    [int(x) for x in out]))
 
 
 def alloc_count():

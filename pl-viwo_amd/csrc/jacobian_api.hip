@@ -357,6 +357,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
     }
   }
   ph_c.stop();
+  plv::NsScope ns_pw(plv::counters().points_wait_ns);
   plv::HostPhase ph_d("points fused: wait");
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)
   if (rc != PLV_OK || !mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));      // (the copy command enqueued behind it)

@@ -141,7 +141,10 @@ void line_worker(LineTracker *T) {
       LineTracker::FeedJob &F = T->feed;
       if (plv::host_phases().on)
         plv::host_phases().add("line worker: feed job starts after its post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
+      const auto Fs = std::chrono::steady_clock::now();
+      plv::counters().w_feed_start_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(Fs - T->feed_posted).count();
       const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data(), F.K8);
+      plv::counters().w_feed_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - Fs).count();
       {
         std::lock_guard<std::mutex> lk(T->jm);
         F.rc = rc;
@@ -157,6 +160,12 @@ void line_worker(LineTracker *T) {
     if (plv::event_sync(T->edges_ready) != hipSuccess) rc = PLV_E_DEVICE;  // the two maps are on the host
     auto W1 = std::chrono::steady_clock::now();
     if (rc == PLV_OK) rc = host_extract(&T->host, T->job, timing);
+    {
+      auto ns = [](auto a, auto b) { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+      plv::counters().w_wake_ns += ns(T->job_posted, W0);
+      plv::counters().w_maps_ns += ns(W0, W1);
+      plv::counters().w_extract_ns += ns(W1, std::chrono::steady_clock::now());
+    }
     if (plv::host_phases().on)
       plv::host_phases().add("line worker: detect job, post to done", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
     if (timing) {
@@ -201,6 +210,7 @@ LineTracker *ltr(plv_ctx *ctx, bool run_deferred) {
   }
   std::unique_lock<std::mutex> lk(T->jm);
   if (T->feed_state != 0) {
+    plv::NsScope ns_join(plv::counters().line_join_ns);
     plv::HostPhase ph("line feed join: wait");
     wait_polling(lk, T->jcv, [&] { return T->feed_state == 2; });
     T->feed_state = 0;
@@ -912,6 +922,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   const plv_state_view *st_tri = tri_keep.valid ? &tri_keep.view : st;
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
   static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
+  plv::NsScope ns_lines(plv::counters().lines_ns);
   plv::HostPhase ph_all("update_lines: whole call");
   plv::RoctxRange rx_line("[Time-Cam] LINE update");
   plv::HostPhase ph_pool("update_lines: pool + staging");

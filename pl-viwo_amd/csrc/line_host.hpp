@@ -77,9 +77,12 @@ inline std::atomic<int> &spin_budget_us() {
   static std::atomic<int> v{getenv("PLV_LINE_SPIN_US") ? atoi(getenv("PLV_LINE_SPIN_US")) : 300};
   return v;
 }
-// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 = the walk's own thread fits afterwards
+// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 (the default since the end of round 3) =
+// the walk's own thread fits afterwards.  With the line pool formed inside the point update's wait the worker's path has the slack:
+// the frame is the same to +-3 us with 0, 1 or 2 fitters (alternating frame by frame, 4 x 1000 frames), and every extra thread is one
+// more hand-over that a busy host can delay by milliseconds (the slow steps of a noisy box are the worker's side waiting for one).
 inline std::atomic<int> &fit_threads() {
-  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 2};
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 0};
   return v;
 }
 template <class Pred>

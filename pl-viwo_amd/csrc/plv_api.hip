@@ -98,6 +98,15 @@ extern "C" {
 
 int plv_abi_version(void) { return PLV_ABI_VERSION; }
 // (measurement aid, not part of the drop-in surface: plv_ctx.hpp "Measurement knobs")  set < 0 only queries; returns the previous mask
+// (measurement aid) wall time inside the parts of plv_camera_frame since the library was loaded: [0] the wait for flow + RANSAC,
+// [1] plv_camera_update_points, [2] of it the wait for the device, [3] plv_camera_update_lines, [4] the join of the line worker
+// [5..9] the line worker: post -> wake-up, wait for the edge maps, walk + fit, feed post -> start, the feed
+void plv_phase_counters(unsigned long long *out10) {
+  if (!out10) return;
+  auto &c = plv::counters();
+  out10[0] = c.flow_wait_ns, out10[1] = c.points_ns, out10[2] = c.points_wait_ns, out10[3] = c.lines_ns, out10[4] = c.line_join_ns;
+  out10[5] = c.w_wake_ns, out10[6] = c.w_maps_ns, out10[7] = c.w_extract_ns, out10[8] = c.w_feed_start_ns, out10[9] = c.w_feed_ns;
+}
 // (measurement aid) device / pinned (re)allocations since the library was loaded: a frame that grows a buffer pays a hipMalloc
 unsigned long long plv_alloc_count(void) { return plv::alloc_epoch().load(); }
 unsigned plv_debug_knobs(long long set) {

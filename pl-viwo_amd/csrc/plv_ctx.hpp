@@ -35,6 +35,11 @@ void set_last_error(const char *fmt, ...);
 struct Counters {
   std::atomic<unsigned long long> launches{0}, syncs{0}, copies{0}, copy_bytes{0}, lk_iters{0}, lines_detected{0};
   std::atomic<unsigned long long> frame_ns{0}, sync_ns{0};  // wall time inside plv_camera_frame / plv_ctx_synchronize (steady_clock)
+  // ... and inside its parts (plv_phase_counters): waiting for flow + RANSAC, the point update, the point update's device wait, the
+  // line update, the join of the line worker
+  std::atomic<unsigned long long> flow_wait_ns{0}, points_ns{0}, points_wait_ns{0}, lines_ns{0}, line_join_ns{0};
+  // the line worker's side: post -> wake-up, the wait for the edge maps, chain walk + segment growth, feed post -> start, the feed
+  std::atomic<unsigned long long> w_wake_ns{0}, w_maps_ns{0}, w_extract_ns{0}, w_feed_start_ns{0}, w_feed_ns{0};
 };
 inline Counters &counters() {
   static Counters c;

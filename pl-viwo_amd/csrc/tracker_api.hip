@@ -200,6 +200,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     launch_prefetch();  // (inside the wait for the flow)
     if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
     TRY(rc_l);
+    plv::NsScope ns_wait(plv::counters().flow_wait_ns);
     TRY(plv_perform_matching_wait(ctx, pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
   }
   plv::HostPhase ph_db("tracker_feed: database update");
@@ -405,6 +406,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_msckf < 1 || opt->max_obs < 2) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
+  plv::NsScope ns_points(plv::counters().points_ns);
   plv::HostPhase ph_all("update_points: whole call");
   plv::HostPhase ph_pool("update_points: pool + staging");
   plv::RoctxRange rx_get("[Time-Cam] get features");
