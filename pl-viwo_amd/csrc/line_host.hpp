@@ -77,12 +77,13 @@ inline std::atomic<int> &spin_budget_us() {
   static std::atomic<int> v{getenv("PLV_LINE_SPIN_US") ? atoi(getenv("PLV_LINE_SPIN_US")) : 300};
   return v;
 }
-// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 (the default since the end of round 3) =
-// the walk's own thread fits afterwards.  With the line pool formed inside the point update's wait the worker's path has the slack:
-// the frame is the same to +-3 us with 0, 1 or 2 fitters (alternating frame by frame, 4 x 1000 frames), and every extra thread is one
-// more hand-over that a busy host can delay by milliseconds (the slow steps of a noisy box are the worker's side waiting for one).
+// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 = the walk's own thread fits afterwards.
+// One is the default: whole runs at workload C give 0.56 ms per frame with one or two and 0.70 ms with none (without a fitter the worker
+// finishes after the point update and the caller waits for it); the second buys nothing on a quiet host (+-10 us) and on a busy one it
+// is one more hand-over that can be delayed by milliseconds (mean 0.64 ms with one against 0.70 with two on such a box).  A thread
+// beyond the configured number that already exists sits a job out.
 inline std::atomic<int> &fit_threads() {
-  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 0};
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 1};
   return v;
 }
 template <class Pred>
@@ -207,7 +208,7 @@ inline void fit_worker(HostStage *T, int me) {
       seen = F.gen;
     }
     const Job &J = *F.job;
-    for (;;) {
+    for (; me < fit_threads().load(std::memory_order_relaxed);) {  // (a thread the configuration no longer counts takes nothing)
       const int avail = F.published.load(std::memory_order_acquire);
       const int c = claim_chain(F, avail);
       if (c >= 0) {
