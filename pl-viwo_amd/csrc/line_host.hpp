@@ -293,39 +293,44 @@ struct Assign {
 
 inline void assign_points(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A, float assign_px = 5.0f) {
   A = Assign();
-  // ~200 lines x ~250 points box tests per frame: the coordinates are split once so that the test of one line against all points is
-  // a branch-free pass the compiler vectorises (the reference compares the float coordinates as doubles: same outcome), and only the
-  // few points inside a box go through the distance test
-  const int npad = (np + 7) & ~7;
-  std::vector<float> xs(npad, 0.f), ys(npad, 0.f);
-  std::vector<int> hit((size_t)np + 1);
-  std::vector<uint8_t> in((size_t)npad + 8, 0);
-  for (int j = 0; j < np; ++j) xs[j] = pts[2 * j], ys[j] = pts[2 * j + 1];
+  // A point is assigned to a line when it lies inside the reference's box (REF :753-764, which reads (x1, y1, x2, y2) as
+  // (lx1, lx2, ly1, ly2): kept as is) AND within assign_px of the segment.  The box is so wide that most points pass it (~47 000
+  // tests per frame for 190 lines x 250 points, 60-70 us), but only points within assign_px of the segment's TRUE bounding box can
+  // pass the distance test: the points are binned once into 32-pixel cells and a line only looks at the cells its true box (grown
+  // by the threshold and half a pixel for rounding) touches — a few points instead of all of them, in point order, through the same
+  // two tests.  Same assignments, ~10 x less work.
+  constexpr int kCell = 32;
+  float xmax = 0.f, ymax = 0.f;
+  for (int j = 0; j < np; ++j) xmax = std::max(xmax, pts[2 * j]), ymax = std::max(ymax, pts[2 * j + 1]);
+  const int gx = std::max(1, (int)(xmax / kCell) + 1), gy = std::max(1, (int)(ymax / kCell) + 1);
+  auto cell_of = [&](float v, int g) { return std::min(std::max((int)std::floor(v / kCell), 0), g - 1); };
+  std::vector<int> cstart((size_t)gx * gy + 1, 0), cidx((size_t)std::max(np, 1));
+  for (int j = 0; j < np; ++j) ++cstart[(size_t)cell_of(pts[2 * j + 1], gy) * gx + cell_of(pts[2 * j], gx) + 1];
+  for (size_t c = 0; c < (size_t)gx * gy; ++c) cstart[c + 1] += cstart[c];
+  {
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    for (int j = 0; j < np; ++j) cidx[fill[(size_t)cell_of(pts[2 * j + 1], gy) * gx + cell_of(pts[2 * j], gx)]++] = j;  // ascending j within a cell
+  }
+  std::vector<int> cand;
+  const float grow = assign_px + 0.5f;
   for (int i = 0; i < nl; ++i) {
-    // REF :753-764 reads (x1, y1, x2, y2) as (lx1, lx2, ly1, ly2): kept as is
-    const float lx1 = lines[4 * i], lx2 = lines[4 * i + 1], ly1 = lines[4 * i + 2], ly2 = lines[4 * i + 3];
+    const float *ln = lines + 4 * i;
+    const float lx1 = ln[0], lx2 = ln[1], ly1 = ln[2], ly2 = ln[3];  // (sic)
     const float min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
-    // pass 1 (vector code: no dependence between iterations): one flag per point; pass 2: the set flags in point order, eight per
-    // 64-bit load.  (What the assignment costs — 60-70 us per frame for 190 lines x 250 points — is the distance test below: the
-    // reference's box is so wide that a third of the points pass it, ~14 000 point_line_distance calls per frame.)
-    const float *xp = xs.data(), *yp = ys.data();
-    uint8_t *ip = in.data();
-    for (int j = 0; j < npad; ++j) ip[j] = (uint8_t)((xp[j] >= min_lx) & (xp[j] <= max_lx) & (yp[j] >= min_ly) & (yp[j] <= max_ly));
-    int nh = 0;
-    for (int j0 = 0; j0 < np; j0 += 8) {
-      uint64_t w;
-      memcpy(&w, ip + j0, 8);
-      if (!w) continue;
-      for (int u = 0; u < 8 && j0 + u < np; ++u)
-        if (ip[j0 + u]) hit[nh++] = j0 + u;
-    }
-    if (nh == 0) continue;
+    const float tx0 = std::min(ln[0], ln[2]) - grow, tx1 = std::max(ln[0], ln[2]) + grow, ty0 = std::min(ln[1], ln[3]) - grow, ty1 = std::max(ln[1], ln[3]) + grow;
+    cand.clear();
+    const int cx0 = cell_of(tx0, gx), cx1 = cell_of(tx1, gx), cy0 = cell_of(ty0, gy), cy1 = cell_of(ty1, gy);
+    for (int cy = cy0; cy <= cy1; ++cy)
+      for (int cx = cx0; cx <= cx1; ++cx)
+        for (int q = cstart[(size_t)cy * gx + cx]; q < cstart[(size_t)cy * gx + cx + 1]; ++q) cand.push_back(cidx[q]);
+    if (cand.empty()) continue;
+    std::sort(cand.begin(), cand.end());  // point order, as the reference's loop meets them
     std::map<int, double> on;
     size_t first_pos = A.pos.size();
-    for (int q = 0; q < nh; ++q) {
-      const int j = hit[q];
-      const float x = xs[j], y = ys[j];
-      const float d = point_line_distance(lines + 4 * i, x, y);
+    for (int j : cand) {
+      const float x = pts[2 * j], y = pts[2 * j + 1];
+      if (!((x >= min_lx) & (x <= max_lx) & (y >= min_ly) & (y <= max_ly))) continue;
+      const float d = point_line_distance(ln, x, y);
       if (d > assign_px) continue;
       on[(int)ids[j]] = d;
       A.pos.push_back(x);
