@@ -131,7 +131,11 @@ inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, 
   for (int r = 0; r < h; ++r) {
     const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
     for (int c = 0; c < w; ++c) {
-      if (row[c] != 2) continue;
+      // the next seed of this row: a vectorised byte search instead of a test per pixel (90 000 pixels, 20 000 of them edges, most
+      // of those consumed by earlier chains by the time the scan reaches them)
+      const uint8_t *nx = (const uint8_t *)memchr(row + c, 2, (size_t)(w - c));
+      if (!nx) break;
+      c = (int)(nx - row);
       const int start = n_pts;
       int x = c, y = r;
       size_t idx = (size_t)(r + 1) * pw + c + 1;
