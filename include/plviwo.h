@@ -481,7 +481,7 @@ int plv_detect_lines(plv_ctx *ctx, int which, float *lines, int cap, int *n_out)
  * RANSAC, and the following plv_line_tracker_feed of the same frame takes the finished detection (same segments as without). */
 int plv_line_prefetch_mode(plv_ctx *ctx, int on);
 /* The library's own threads (process-wide).  With the prefetch on the line detector's host stage runs on ONE worker thread per
- * context plus up to two segment-fitter threads (default 1); a thread that waits for work polls for spin_us microseconds before it blocks
+ * context plus up to two segment-fitter threads (default: at most 2, one of them used below 150 000 half-resolution pixels); a thread that waits for work polls for spin_us microseconds before it blocks
  * (default 300: the hand-overs inside one frame follow each other within that time and then cost no wake-up; between frames the
  * threads sleep — at 15 Hz that is at most 3 x 0.3 ms of polling per 66 ms frame).  spin_us = 0: block at once (no polling at all, every hand-over pays a wake-up
  * of tens of microseconds); fit_threads = 0: the worker grows the segments itself after the walk.  Negative arguments only query.

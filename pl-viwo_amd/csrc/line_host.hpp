@@ -42,6 +42,7 @@ struct Fit {
   int gen = 0, done_gen[kThreads] = {0, 0};  // a job = a new generation; thread i reports the last one it finished
   bool quit = false;
   const Job *job = nullptr;
+  std::atomic<int> nfit_job{0};  // fitter threads the current job uses (thread i takes part when i < nfit_job)
   alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
   alignas(64) std::atomic<bool> walk_done{false};
   alignas(64) std::atomic<int> next{0};  // next chain to fit: this thread and, once its walk is over, the walking thread claim chains here
@@ -77,13 +78,11 @@ inline std::atomic<int> &spin_budget_us() {
   static std::atomic<int> v{getenv("PLV_LINE_SPIN_US") ? atoi(getenv("PLV_LINE_SPIN_US")) : 300};
   return v;
 }
-// fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads): 0 = the walk's own thread fits afterwards.
-// One is the default: whole runs at workload C give 0.56 ms per frame with one or two and 0.70 ms with none (without a fitter the worker
-// finishes after the point update and the caller waits for it); the second buys nothing on a quiet host (+-10 us) and on a busy one it
-// is one more hand-over that can be delayed by milliseconds (mean 0.64 ms with one against 0.70 with two on such a box).  A thread
-// beyond the configured number that already exists sits a job out.
+// The most fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads; 0 = the walk's own thread fits
+// afterwards).  host_extract takes one of them for a small map and both for a large one (see there).  Whole runs at workload C: 0.56 ms
+// per frame with one or two, 0.70 ms with none (without a fitter the worker finishes after the point update and the caller waits for it).
 inline std::atomic<int> &fit_threads() {
-  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 1};
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 2};
   return v;
 }
 template <class Pred>
@@ -212,7 +211,7 @@ inline void fit_worker(HostStage *T, int me) {
       seen = F.gen;
     }
     const Job &J = *F.job;
-    for (; me < fit_threads().load(std::memory_order_relaxed);) {  // (a thread the configuration no longer counts takes nothing)
+    for (; me < F.nfit_job.load(std::memory_order_acquire);) {  // (a thread this job does not count takes nothing and is not waited for)
       const int avail = F.published.load(std::memory_order_acquire);
       const int c = claim_chain(F, avail);
       if (c >= 0) {
@@ -239,7 +238,11 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   F.published.store(0, std::memory_order_relaxed);
   F.next.store(0, std::memory_order_relaxed);
   F.walk_done.store(false, std::memory_order_relaxed);
-  const int nfit = fit_threads().load(std::memory_order_relaxed);
+  // one fitter keeps pace with the walk of a 376 x 240 map (BASELINE configs[2]); a 640 x 360 map (configs[3]: 2.5 x the chains, the fit
+  // left over at the end of the walk 110 us with one fitter, 20 with two) takes the second one as well — a thread a job does not need
+  // is not part of it: every hand-over between threads is a chance of a delayed wake-up on a busy host
+  const int nfit = std::min(fit_threads().load(std::memory_order_relaxed), (size_t)J.w * J.h >= 150000 ? 2 : 1);
+  F.nfit_job.store(nfit, std::memory_order_release);
   for (int i = 0; i < nfit; ++i)
     if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i);
   int gen;
@@ -256,7 +259,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   {
     std::unique_lock<std::mutex> lk(F.m);
     wait_polling(lk, F.cv, [&] {
-      for (int i = 0; i < Fit::kThreads; ++i)
+      for (int i = 0; i < nfit; ++i)
         if (F.th[i].joinable() && F.done_gen[i] != gen) return false;
       return true;
     });
