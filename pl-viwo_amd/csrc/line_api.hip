@@ -801,7 +801,10 @@ static void form_line_pool(LineTracker *T, const plv_state_view *st, const plv_u
     }
   }
   R.n_pool = (int)R.pool.size();
-  for (auto it = R.pool.begin(); it != R.pool.end();) {  // REF :652-682 (hard-coded 0.01 s margins)
+  R.unused.reserve(R.pool.size());
+  size_t kept_cands = 0;  // (candidates that stay are moved down once: erasing from the middle of the vector shifted the rest every time)
+  for (size_t ci = 0; ci < R.pool.size(); ++ci) {  // REF :652-682 (hard-coded 0.01 s margins)
+    LineCand *it = &R.pool[ci];
     LineTrack &tr = it->tr;
     size_t keep = 0;
     for (size_t i = 0; i < tr.t.size(); ++i) {
@@ -821,11 +824,12 @@ static void form_line_pool(LineTracker *T, const plv_state_view *st, const plv_u
     tr.t.resize(keep);
     tr.uv.resize(4 * keep);
     tr.uvn.resize(4 * keep);
-    if (keep < 2)
-      it = R.pool.erase(it);
-    else
-      ++it;
+    if (keep >= 2) {
+      if (kept_cands != ci) R.pool[kept_cands] = std::move(*it);
+      ++kept_cands;
+    }
   }
+  R.pool.resize(kept_cands);
   std::stable_sort(R.pool.begin(), R.pool.end(), [](const LineCand &a, const LineCand &b) { return a.tr.t.size() > b.tr.t.size(); });
 }
 
@@ -945,8 +949,18 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   auto give_back = [&](const Cand &c, size_t i) { line_give_back(unused, c, i); };
   res->n_pool = LP.n_pool;
   plv::HostPhase ph_p1("update_lines: pool a (scan + take) done -> b (trim + sort)");
+  auto give_back_all = [&](Cand &c) {
+    if (unused.find(c.id) == unused.end()) {  // nothing of this line went back earlier: hand the track over as it is
+      unused.emplace(c.id, std::move(c.tr));
+      c.tr = LineTrack{};
+      return;
+    }
+    for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c, i);
+  };
+  std::vector<int> lazy_back;  // pool candidates whose whole track returns to the database: moved there by the deferred hand-back
   auto finish = [&](int rc) {
     res->n_returned = (int)unused.size();
+    for (int l : lazy_back) res->n_returned += unused.find(pool[l].id) == unused.end() ? 1 : 0;
     const bool window_full = opt->window_full != 0;
     auto hand_back = [T, window_full, t_oldest](std::unordered_map<uint64_t, LineTrack> &un) {
       std::lock_guard<std::mutex> lk(T->mtx);
@@ -988,19 +1002,25 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       // pooled tracks) runs in that frame's wait for the flow, or at the next call that reaches the tracker
       auto held = std::make_shared<std::unordered_map<uint64_t, LineTrack>>(std::move(unused));
       auto used_up = std::make_shared<std::vector<Cand>>(std::move(pool));
-      T->deferred = [hand_back, held, used_up]() { hand_back(*held); };
+      auto lazy = std::make_shared<std::vector<int>>(std::move(lazy_back));
+      T->deferred = [hand_back, held, used_up, lazy]() {
+        for (int l : *lazy) {  // (give_back_all, off the frame's critical path)
+          Cand &c = (*used_up)[l];
+          if (held->find(c.id) == held->end()) {
+            held->emplace(c.id, std::move(c.tr));
+            c.tr = LineTrack{};
+          } else {
+            for (size_t i = 0; i < c.tr.t.size(); ++i) line_give_back(*held, c, i);
+          }
+        }
+        hand_back(*held);
+      };
     } else {
+      for (int l : lazy_back) give_back_all(pool[l]);
+      lazy_back.clear();
       hand_back(unused);
     }
     return rc;
-  };
-  auto give_back_all = [&](Cand &c) {
-    if (unused.find(c.id) == unused.end()) {  // nothing of this line went back earlier: hand the track over as it is
-      unused.emplace(c.id, std::move(c.tr));
-      c.tr = LineTrack{};
-      return;
-    }
-    for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c, i);
   };
   std::fill(dx, dx + ctx->cov_n, 0.0);
   if (pool.empty()) return finish(PLV_OK);
@@ -1152,7 +1172,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   for (int l = 0; l < Lp; ++l) {
     const int valid = valid_n[l];
     if (!ok[l] || valid < 2 || (int)sel.size() >= cap) {
-      give_back_all(pool[l]);
+      lazy_back.push_back(l);  // (the whole track goes back: finish() does it, deferred when the caller allows)
       continue;
     }
     if (valid > opt->max_obs) {  // batch capacity (none in the reference): the last max_obs usable observations, counted in n_truncated
