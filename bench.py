@@ -645,7 +645,8 @@ def main():
                         "marginalisation and wheel updates run between the steps, untimed",
                 "replicas": world, "n_state": n_state,
                 "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0,
-                                 "library_segment_fitters": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,
+                                 "library_segment_fitters": (min(fit_threads, 2 if (wl["w"] // 2) * (wl["h"] // 2) >= 150000 else 1) if wl["lines"] else 0),
+                                 "library_segment_fitters_configured_maximum": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,
                                  "note": "the library's threads run the line detector's host stage (chain walk + segment growth) and the line "
                                          "tracker's bookkeeping next to the caller's thread; a waiting thread polls for poll_before_blocking_us, "
                                          "then blocks (plv_line_worker_config); cpu_baseline.detail has the CPU frame at 1, 4 and 16 threads"},
