@@ -413,6 +413,12 @@ def main():
         cg0, wall0 = cgroup_cpu(), time.perf_counter()
         elapsed, per, grew, slow = 0.0, [], [], []
         trace_frames = bool(os.environ.get("PLV_BENCH_FRAMES"))
+        fw = None
+        if os.environ.get("PLV_BENCH_FAULTWHERE"):     # tools/ubench/faultwhere.c: address + ip of every minor fault of this thread
+            import ctypes
+            fw = ctypes.CDLL(os.environ["PLV_BENCH_FAULTWHERE"])
+            if fw.fw_start() != 0:
+                fw = None
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if hook:
@@ -428,9 +434,18 @@ def main():
             c0 = pkg.counters()
             a0 = pkg.alloc_count()
             ph0 = pkg.phase_counters() if trace_frames else None
+            if fw:
+                import resource
+                ru0 = resource.getrusage(resource.RUSAGE_THREAD)
+                fw.fw_mark()
             t0 = time.perf_counter()
             pl.camera(*nf)                  # timed: feed_measurement + try_update, everything the frame started finished at return
             dt = time.perf_counter() - t0
+            if fw:
+                fw.fw_end()
+                ru1 = resource.getrusage(resource.RUSAGE_THREAD)
+                fw_ru = fw_ru + [(ru1.ru_minflt - ru0.ru_minflt, (ru1.ru_stime - ru0.ru_stime) * 1e6, (ru1.ru_utime - ru0.ru_utime) * 1e6,
+                                  ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw)] if f else []
             elapsed += dt
             per.append(dt * 1e3)
             if pkg.alloc_count() != a0:
@@ -451,6 +466,11 @@ def main():
             cnt["redone_frames"] += 1 if route == 3 else 0
             cnt["whitened_frames"] += 1 if route == 4 else 0
         ctx.synchronize()
+        if fw:
+            fw.fw_stop(os.environ.get("PLV_BENCH_FAULTWHERE_OUT", "").encode())
+            m = np.mean(np.array(fw_ru, float), axis=0)
+            print("[faultwhere] getrusage of the caller's thread per step: %.1f minor faults, %.1f us system, %.1f us user, %.2f voluntary / %.2f "
+                  "involuntary switches" % tuple(m), file=sys.stderr)
         barrier()
         gc.enable()
         cg1, wall1 = cgroup_cpu(), time.perf_counter()

@@ -197,7 +197,11 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
-  if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, F, ld - 3));  // (before the upload goes onto the stream)
+  {
+    plv::HostPhase ph("build: prior prefetch, phase 0");
+    if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, F, ld - 3));  // (before the upload goes onto the stream)
+  }
+  plv::HostPhase ph_stage("build: inputs staged + upload enqueued");
   JacParams P{};
   bool fuse_tri = false;
   int tri_max_obs = 1;
@@ -231,6 +235,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   } else {
     TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
   }
+  ph_stage.stop();
   P.cols_out = us->bcols.as<int>();
   P.rows = us->brows.as<int>();
   P.Hf = us->bHf.as<double>();
@@ -244,6 +249,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     for (int j = 0; j < k && can_gather; ++j) can_gather = col_to_state[j] >= 0 && col_to_state[j] < ctx->cov_n;
     GatherArgs g{};
     int gblocks = 0;
+    plv::HostPhase ph_l("build: gather arguments + Jacobian launch");
     if (can_gather) {
       const int n = ctx->cov_n;
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
@@ -253,8 +259,11 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, tri_opt, tri_poses, tri_valid, tri_uvn, tri_p, tri_ok, tri_err, tri_max_obs));
     else
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+    ph_l.stop();
+    plv::HostPhase ph_p1("build: prior prefetch, phase 1 (side stream)");
     if (can_gather)  // (the column map as the host staged it: same offset in the pinned block as in the device copy)
       TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in), k, F, ld - 3));
+    ph_p1.stop();
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {

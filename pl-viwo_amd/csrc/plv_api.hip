@@ -694,6 +694,8 @@ static int prior_mark(plv_ctx *ctx) {
   }
   // the host has waited for the covariance's last writer (plv_ctx::cov_host_synced): nothing to order the side stream behind
   ctx->aux_fork_needed = ctx->cov_host_synced != ctx->gather_stamp;
+  if (plv::host_phases().on) plv::host_phases().add("prior_mark: fork event needed (1 = yes)", ctx->aux_fork_needed ? 1.0 : 0.0);
+  plv::HostPhase ph("prior_mark: fork event recorded");
   if (ctx->aux_fork_needed) PLV_HIP_CHECK(hipEventRecord(ctx->aux_fork, ctx->stream));
   return PLV_OK;
 }

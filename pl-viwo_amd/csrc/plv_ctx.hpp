@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -85,6 +86,20 @@ struct HostPhases {
     const char *label;
     double us = 0;
     long n = 0;
+    float last[64] = {};  // the last 64 samples: their median is what a steady-state call costs (the mean carries the first call's
+                          // stream / buffer creation: milliseconds)
+    void put(double v) {
+      last[n & 63] = (float)v;
+      us += v;
+      ++n;
+    }
+    double median() const {
+      float tmp[64];
+      const int m = (int)(n < 64 ? n : 64);
+      for (int i = 0; i < m; ++i) tmp[i] = last[i];
+      std::sort(tmp, tmp + m);
+      return m ? tmp[m / 2] : 0.0;
+    }
   };
   bool on = getenv("PLV_HOST_TIMING") != nullptr;
   std::mutex mtx;
@@ -95,21 +110,21 @@ struct HostPhases {
     // (measured: 16 minor faults, 30 us, charged to whatever phase came next)
     for (auto &r : recs)
       if (r.label == label) {
-        r.us += us;
-        ++r.n;
+        r.put(us);
         return;
       }
     for (auto &r : recs)
       if (!strcmp(r.label, label)) {
-        r.us += us;
-        ++r.n;
+        r.put(us);
         return;
       }
-    recs.push_back(Rec{label, us, 1});
+    recs.push_back(Rec{label});
+    recs.back().put(us);
   }
   ~HostPhases() {
     if (!on) return;
-    for (auto &r : recs) fprintf(stderr, "[plv host] %-44s %8ld calls  %9.1f us/call\n", r.label, r.n, r.us / (double)r.n);
+    for (auto &r : recs)
+      fprintf(stderr, "[plv host] %-44s %8ld calls  %9.1f us/call  (median of the last %d: %.1f)\n", r.label, r.n, r.us / (double)r.n, (int)(r.n < 64 ? r.n : 64), r.median());
   }
 };
 inline HostPhases &host_phases() {
