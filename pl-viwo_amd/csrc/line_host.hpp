@@ -121,11 +121,19 @@ inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, 
                  std::vector<uint8_t> &pad, std::atomic<int> *published = nullptr) {
   static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
   const int pw = w + 2;
-  pad.assign((size_t)pw * (h + 2), 1);
-  for (int r = 0; r < h; ++r) memcpy(&pad[(size_t)(r + 1) * pw + 1], map + (size_t)r * w, w);
+  // bordered copy of the map (border = 1: never an edge)
+  pad.resize((size_t)pw * (h + 2));
+  uint8_t *m = pad.data();
+  memset(m, 1, (size_t)pw);
+  memset(m + (size_t)(h + 1) * pw, 1, (size_t)pw);
+  for (int r = 0; r < h; ++r) {
+    uint8_t *row = m + (size_t)(r + 1) * pw;
+    row[0] = 1;
+    memcpy(row + 1, map + (size_t)r * w, w);
+    row[w + 1] = 1;
+  }
   int off[8];
   for (int i = 0; i < 8; ++i) off[i] = dy[i] * pw + dx[i];
-  uint8_t *m = pad.data();
   int n_chain = 0, n_slot = 0, n_pts = 0;
   for (int r = 0; r < h; ++r) {
     const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
@@ -142,6 +150,10 @@ inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, 
       m[idx] = 1;
       float direction = 0.0f;
       for (int step = 0;; ++step) {
+        // (eight byte tests per step.  Measured against it on the bench scene's maps: the neighbourhood read as three 32-bit words
+        // and a bit mask is 1.7x SLOWER — the words overlap the byte the previous step has just cleared and wait for that store — and
+        // eight branch-free byte loads + a loop over the set bits 1.15x slower: chains are mostly straight, the branches predict, and
+        // what a step costs is the float recurrence of `direction` (multiply, add, divide: ~20 cycles), which must stay as it is.)
         int pick = -1;
         float best = 7.0f;
         if (step == 0) {

@@ -17,6 +17,52 @@ void set_last_error(const char *, ...) {}
 using namespace plv;
 using namespace plv::linehost;
 
+// The chain walk written out plainly (eight byte tests per step, in the detector's order: REF FastLineDetector's chain loop as the
+// oracle restates it): the checker of line_host.hpp's walk_chains, which reads the neighbourhood as three words and a bit mask.
+static void walk_chains_plain(const uint8_t *map, int w, int h, int length_threshold, std::vector<int2> &pts, std::vector<FldChain> &chains) {
+  static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
+  std::vector<uint8_t> m(map, map + (size_t)w * h);
+  auto edge = [&](int x, int y) { return x >= 0 && y >= 0 && x < w && y < h && m[(size_t)y * w + x] == 2; };
+  int n_slot = 0;
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      if (m[(size_t)r * w + c] != 2) continue;
+      const size_t start = pts.size();
+      int x = c, y = r;
+      pts.push_back(make_int2(x, y));
+      m[(size_t)y * w + x] = 1;
+      float direction = 0.0f;
+      for (int step = 0;; ++step) {
+        int pick = -1;
+        float best = 7.0f;
+        for (int i = 0; i < 8; ++i) {
+          if (!edge(x + dx[i], y + dy[i])) continue;
+          if (step == 0) {
+            pick = i;
+            break;
+          }
+          const float curr = i > 4 ? (float)(i - 8) : (float)i;
+          float diff = std::fabs(curr - direction);
+          if (diff > 4.0f) diff = 8.0f - diff;
+          if (diff <= best) best = diff, pick = i;
+        }
+        if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
+        const int cdir = pick > 4 ? pick - 8 : pick;
+        direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
+        x += dx[pick], y += dy[pick];
+        pts.push_back(make_int2(x, y));
+        m[(size_t)y * w + x] = 1;
+      }
+      const int len = (int)(pts.size() - start);
+      if (len >= length_threshold + 1 && (int)chains.size() < kChainCap) {
+        chains.push_back(FldChain{(int)start, len, n_slot});
+        n_slot += len / length_threshold + 1;
+      } else {
+        pts.resize(start);
+      }
+    }
+}
+
 int main(int argc, char **argv) {
   if (argc < 3) return 2;
   FILE *f = fopen(argv[1], "rb");
@@ -48,6 +94,22 @@ int main(int argc, char **argv) {
       std::vector<uint8_t> pad;
       int counts[4] = {0, 0, 0, 0};
       walk_chains(maps[i].data(), w, h, 20, p2.data(), c2.data(), kChainCap, counts, pad);
+      if (r == 0) {  // the word-and-mask walk against the plain one: same chains, same points, same order
+        std::vector<int2> p3;
+        std::vector<FldChain> c3;
+        walk_chains_plain(maps[i].data(), w, h, 20, p3, c3);
+        bool same = (int)c3.size() == counts[0] && (int)p3.size() == counts[2];
+        for (int c = 0; same && c < counts[0]; ++c) same = c3[c].start == c2[c].start && c3[c].len == c2[c].len && c3[c].slot == c2[c].slot;
+        for (int q = 0; same && q < counts[2]; ++q) same = p3[q].x == p2[q].x && p3[q].y == p2[q].y;
+        if (!same) {
+          fprintf(stderr, "frame %d: walk_chains differs from the plain walk (%d vs %zu chains, %d vs %zu points)\n", i, counts[0], c3.size(), counts[2], p3.size());
+          return 5;
+        }
+        if (counts[0] < 20) {
+          fprintf(stderr, "frame %d: only %d chains: the map does not exercise the walk\n", i, counts[0]);
+          return 5;
+        }
+      }
       std::vector<float> ref;
       std::vector<float4> seg(npix / 20 + kChainCap);
       for (int c = 0; c < counts[0]; ++c) {
