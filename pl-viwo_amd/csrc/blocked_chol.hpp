@@ -177,15 +177,17 @@ __device__ __forceinline__ d4 strip_chain(d4 W, LDS &lds, int p) {
     const int kk = jj & 3, rq = jj >> 2;
     const int want = 16 * p + jj + 1;
     d2 d;
+#ifndef PLV_BC_SLEEP
+#define PLV_BC_SLEEP 1
+#endif
     for (;;) {  // flag first, then the data: both loads are in flight together
       const int f = lds_vload(&lds.step_flag);
       d = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[jj][lane][0]));
       if (__builtin_amdgcn_readfirstlane(f) >= want) break;
-#ifndef PLV_BC_SLEEP
-#define PLV_BC_SLEEP 1
-#endif
       __builtin_amdgcn_s_sleep(PLV_BC_SLEEP);  // a spinning wave must not take issue slots and LDS cycles from the chain
     }
+    // (polling only the 4-byte flag and reading the step's data once afterwards, or sleeping longer, changes nothing measurable:
+    // tools/ubench/bchol_time.hip, 80.0 k ticks per factorisation either way)
     const double brow = W[rq];
     cap[rq] = (lq == kk) ? brow : cap[rq];
     W = __builtin_amdgcn_mfma_f64_16x16x4f64(d[0], brow * d[1], W, 0, 0, 0);
@@ -255,6 +257,7 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
     if (is_sym && t == p) {
       d4 cap = {0, 0, 0, 0};
       diag_chain<Ops::kStoreL>(acc[0], lds, tau, p, cap, amb);
+      BC_STAMP(43 + p);
       if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -269,6 +272,7 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
     } else if (below) {
 #endif
       x = strip_chain(acc[0], lds, p);
+      BC_STAMP(43 + p);
       if (is_sym) *reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]) = x;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // panel p of this strip is final: out it goes
