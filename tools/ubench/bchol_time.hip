@@ -48,14 +48,66 @@ int main() {
              s[2 + 5 * p] - s[43 + p], s[3 + 5 * p] - s[2 + 5 * p], s[4 + 5 * p] - s[3 + 5 * p]);
     printf(" end@%lld | last chain: steps0-7 %lld steps8-15 %lld\n", s[50] - t0, s[41] - s[40], s[42] - s[41]);
   }
-  {  // the factorisation's length, and the sum over panels of the diagonal wave's chain (the wave with the longest chain of each panel)
-    long long chain = 0;
+  auto report = [&](const char *what, int nwaves) {
+    std::vector<long long> st2(16 * 64);
+    if (hipMemcpy(st2.data(), dst, st2.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    // the critical path panel by panel: the diagonal wave's chain (stamp 1+5p -> 43+p of the wave with the SHORTEST such interval
+    // that is positive: strips start early and end late), then everything up to the next panel's start on the next diagonal wave
+    long long t00 = st2[0];
+    for (int w = 1; w < nwaves; ++w) t00 = std::min(t00, st2[w * 64]);
+    long long end = 0;
+    for (int w = 0; w < nwaves; ++w) end = std::max(end, st2[w * 64 + 50]);
+    printf("%s: %lld ticks from the first load to the end;", what, end - t00);
     for (int p = 0; p < 7; ++p) {
-      long long best = 0;
-      for (int w = 0; w < 7; ++w) best = std::max(best, st[w * 64 + 2 + 5 * p] - st[w * 64 + 1 + 5 * p]);
-      chain += best;
+      long long chain = 1ll << 60, start = 0;
+      for (int w = 0; w < nwaves; ++w) {
+        const long long a = st2[w * 64 + 1 + 5 * p], b = st2[w * 64 + 43 + p];
+        if (a > 0 && b > a && b - a < chain) chain = b - a, start = a;
+      }
+      printf(" p%d chain %lld", p, chain < (1ll << 60) ? chain : -1);
+      (void)start;
     }
-    printf("total %lld ticks, diagonal chains %lld (%.0f per pivot)\n", st[50] - t0, chain, chain / 112.0);
+    printf("\n");
+  };
+  report("compression (k = 98)", 8);
+  {  // the EKF solve: S = G[:k, :k] (positive definite), [Mt ; res] = 119 + 1 border rows -> 8 workgroups, stamps of workgroup 0
+    const int r = k, n = 119;
+    double *dMt, *dres, *dW;
+    int *dflag;
+    CK(hipMalloc(&dMt, (size_t)n * r * 8));
+    CK(hipMalloc(&dres, r * 8));
+    CK(hipMalloc(&dW, (size_t)(n + 1) * r * 8));
+    CK(hipMalloc(&dflag, 16));
+    std::vector<double> Mt((size_t)n * r), res(r);
+    for (auto &v : Mt) v = nd(rng);
+    for (auto &v : res) v = nd(rng);
+    CK(hipMemcpy(dMt, Mt.data(), Mt.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dres, res.data(), res.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dflag, 0, 16));
+    CK(hipMemset(dst, 0, 16 * 64 * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int it = 0; it < 4; ++it) {
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(plv::bchol_ekf_kernel<7>, dim3((n + 1 + 15) / 16), dim3(64 * 8), 0, 0, dG, nc, r, dMt, r, n, dres, dW, r, dflag, (const int *)nullptr);
+      CK(hipEventRecord(e1, 0));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("bchol_ekf_kernel<7>, r = %d, n = %d: %.1f us by events\n", r, n, ms * 1e3);
+    std::vector<long long> s2(16 * 64);
+    CK(hipMemcpy(s2.data(), dst, s2.size() * 8, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 8; ++w) {
+      long long *s = &s2[w * 64];
+      printf("ekf wave %d:", w);
+      for (int p = 0; p < 7; ++p)
+        printf(" p%d: @%lld chain %lld (+%lld) bar %lld trail %lld |", p, s[1 + 5 * p] - s2[0], s[43 + p] - s[1 + 5 * p], s[2 + 5 * p] - s[43 + p],
+               s[3 + 5 * p] - s[2 + 5 * p], s[4 + 5 * p] - s[3 + 5 * p]);
+      printf(" end@%lld\n", s[50] - s2[0]);
+    }
+    report("EKF solve (r = 98, 120 border rows)", 8);
   }
   return 0;
 }
