@@ -5,6 +5,7 @@
 #define PLV_BCHOL_NO_LAUNCHERS 1
 #include "../../pl-viwo_amd/csrc/blocked_chol.hip"
 #include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <vector>
 #include <random>
@@ -108,6 +109,21 @@ int main() {
       printf(" end@%lld\n", s[50] - s2[0]);
     }
     report("EKF solve (r = 98, 120 border rows)", 8);
+    {  // fingerprints of the results: a restructured hand-over must leave every bit where it was
+      std::vector<double> Wh((size_t)(n + 1) * r), Rh((size_t)k * k);
+      CK(hipMemcpy(Wh.data(), dW, Wh.size() * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(Rh.data(), dR, Rh.size() * 8, hipMemcpyDeviceToHost));
+      auto fp = [](const std::vector<double> &v) {
+        unsigned long long h = 1469598103934665603ull;
+        for (double x : v) {
+          unsigned long long b;
+          memcpy(&b, &x, 8);
+          h = (h ^ b) * 1099511628211ull;
+        }
+        return h;
+      };
+      printf("fingerprints: W %016llx  R %016llx\n", fp(Wh), fp(Rh));
+    }
   }
   return 0;
 }
