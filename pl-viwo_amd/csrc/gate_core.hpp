@@ -13,10 +13,14 @@
 #include "mfma_tile.hpp"
 #include "wave_ops.hpp"
 
+#ifndef GATE_STAMP
+#define GATE_STAMP(id)
+#endif
+
 namespace plv {
 
 struct GateLds {
-  double T[GATE_MMAX * GATE_KMAX];
+  double T[GATE_MMAX * GATE_TLD];
   double S[GATE_MMAX * (GATE_MMAX + 1)];
   BcLdsT<2> bc;
   double ybuf[64];
@@ -50,6 +54,26 @@ struct GateOps {  // the bordered factorisation of S with r as the border row: y
   }
 };
 
+// Pulls the rows P[cols[a], :] — everything T = H' Ps will read through the column map — into this XCD's L2, one load per 128-byte
+// line, by `nthreads` threads (tid = 0 .. nthreads - 1) that have nothing else to do while the entry is being triangulated.  The
+// values are summed into a number that is never stored (the compiler must keep the loads).
+__device__ __forceinline__ void gate_prefetch_rows(const GateStage &g, const int *cols_g, int k, int tid, int nthreads) {
+  const int lpr = (g.ldp + 15) / 16 + 1;  // lines per row (the row's start is not aligned)
+  double acc = 0.0;
+  for (int idx = tid; idx < k * lpr; idx += 4 * nthreads) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int id = min(idx + u * nthreads, k * lpr - 1);
+      const int a = id / lpr, l = id - a * lpr;
+      v[u] = *(const volatile double *)(g.P + (size_t)cols_g[a] * g.ldp + min(l * 16, g.ldp - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u];
+  }
+  if (acc == 1.2345678e300) *(volatile double *)g.chi2 = acc;  // (never: keeps the loads alive)
+}
+
 // Called by ALL 256 threads of the workgroup of entry f (block-uniform arguments).  X: the entry's block in LDS, row-major with
 // ncol = fdim + k + 1 columns; rows `shift` .. rows - 1 hold the projected system [.. | H' | r] (shift = fdim when the null space was
 // applied, rows = 0 for an entry the selection did not take).  cols_g: the column map (k entries).
@@ -70,28 +94,48 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
       L.bc.n_amb = 0;
     }
     __syncthreads();
+    GATE_STAMP(13);
     const int mt = (mp + 15) >> 4, kt = (k + 15) >> 4;
-    // T = H' Ps, Ps(a, b) = P[cols[a], cols[b]]
-    for (int t = wave; t < mt * kt; t += 4) {
-      const int ti = t / kt, tj = t - ti * kt;
-      const double *Hr = Hp + (size_t)min(ti * 16 + li, mp - 1) * ncol;
-      const double *Pq = g.P + L.cols[min(tj * 16 + li, k - 1)];
-      d4 acc = {0, 0, 0, 0};
-      auto fa = [&](int, int kk) { return Hr[kk]; };
-      auto fb = [&](int kk, int) { return Pq[(size_t)L.cols[kk] * g.ldp]; };
-      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+    // T = H' Ps, Ps(a, b) = P[cols[a], cols[b]].  A wave owns tile columns tj = wave, wave + 4, ..: its B operand (16 columns of Ps
+    // over all k, read through the column map) is requested in ONE batch and serves every row tile — round 3 went tile by tile in
+    // chunks of 64 k, eight dependent rounds of loads that mostly missed this XCD's L2 (8 us of the gate; the rows are now pulled in
+    // early by gate_prefetch_rows).  The MFMA sequence per tile is the same as chi2_t_kernel's: the same bits.
+    int roff[GATE_KMAX / 4];  // element offsets of the rows this lane's k-slab reads (the map is looked up once, not in front of every load)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
-        if (i < mp && j < k) L.T[i * GATE_KMAX + j] = acc[q];
+    for (int u = 0; u < GATE_KMAX / 4; ++u) roff[u] = L.cols[min(4 * u + lq, k - 1)] * g.ldp;
+    for (int tj = wave; tj < kt; tj += 4) {
+      const double *Pq = g.P + L.cols[min(tj * 16 + li, k - 1)];
+      double bv[GATE_KMAX / 4];
+#pragma unroll
+      for (int u = 0; u < GATE_KMAX / 4; ++u) bv[u] = Pq[roff[u]];
+      for (int ti = 0; ti < mt; ++ti) {
+        const double *Hr = Hp + (size_t)min(ti * 16 + li, mp - 1) * ncol;
+        double av[GATE_KMAX / 4];
+#pragma unroll
+        for (int u = 0; u < GATE_KMAX / 4; ++u) {
+          const int kk = 4 * u + lq;
+          const double x = Hr[min(kk, k - 1)];
+          av[u] = kk < k ? x : 0.0;
+        }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < GATE_KMAX / 4; ++u)
+          if (4 * u < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);  // (uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
+          if (i < mp && j < k) L.T[i * GATE_TLD + j] = acc[q];
+        }
       }
+      if (tj == wave) GATE_STAMP(14);
     }
     __syncthreads();
+    GATE_STAMP(6);
     // S = T H'^T + sigma2 I, tiles on and above the diagonal
     for (int t = wave; t < mt * mt; t += 4) {
       const int ti = t / mt, tj = t - ti * mt;
       if (tj < ti) continue;
-      const double *Tr = L.T + (size_t)min(ti * 16 + li, mp - 1) * GATE_KMAX;
+      const double *Tr = L.T + (size_t)min(ti * 16 + li, mp - 1) * GATE_TLD;
       const double *Hr = Hp + (size_t)min(tj * 16 + li, mp - 1) * ncol;
       d4 acc = {0, 0, 0, 0};
       auto fa = [&](int, int kk) { return Tr[kk]; };
@@ -104,6 +148,7 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
       }
     }
     __syncthreads();
+    GATE_STAMP(7);
     if (wave == 0) {
       const double rv = lane < mp ? Hp[(size_t)lane * ncol + k] : 0.0;
       nrm2 = gate_wave_sum(rv * rv);
@@ -111,6 +156,7 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
     GateOps ops{L.S, Hp + k, ncol, mp, L.ybuf};
     blocked_chol<2>(ops, L.bc, mp, 1, 0.0, 0);
     __syncthreads();
+    GATE_STAMP(8);
     if (wave == 0) {
       const double y = lane < mp ? L.ybuf[lane] : 0.0;
       chi = gate_wave_sum(y * y);
@@ -140,12 +186,12 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
     if (!pass && g.stack_accepted_only) return;
     const double *Hp = X + (size_t)shift * ncol + fdim;
     double *dst = g.stack + (size_t)f * g.mp_max;
-    for (int idx = threadIdx.x; idx < g.mp_max * (k + 1); idx += blockDim.x) {
-      const int j = idx / g.mp_max, i = idx - j * g.mp_max;
-      double v = 0.0;
-      if (pass && i < mp) v = Hp[(size_t)i * ncol + j];  // (column k of the block is r)
-      dst[(size_t)j * g.lds + i] = v;
-    }
+    for (int i = threadIdx.x & 31; i < g.mp_max; i += 32)      // (32 rows x 8 columns per pass: no integer division per element)
+      for (int j = threadIdx.x >> 5; j <= k; j += 8) {
+        double v = 0.0;
+        if (pass && i < mp) v = Hp[(size_t)i * ncol + j];  // (column k of the block is r)
+        dst[(size_t)j * g.lds + i] = v;
+      }
   }
 }
 

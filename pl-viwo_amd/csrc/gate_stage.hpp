@@ -5,6 +5,7 @@ namespace plv {
 
 #define GATE_KMAX 128  // columns the fused gate holds (T in LDS: 32 x GATE_KMAX doubles)
 #define GATE_MMAX 32   // projected rows per entry (two 16-row strips)
+#define GATE_TLD (GATE_KMAX + 4)  // row stride of T in LDS: 16 rows x 4 k-slabs of an MFMA operand read land on distinct banks (a stride of 128 doubles put all 16 rows on one)
 
 struct GateStage {  // kernel argument; on == 0: the launch ends with the projected blocks as before
   int on;

@@ -167,6 +167,8 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   P.ld = ld;
   P.cols_in = (const int *)(d + o_cols);
   P.cols_out = nullptr;
+  P.in_base = d;
+  P.in_bytes = (int)total;
   if (ex) {
     ex->d_uvn = ex->uvn ? (const float *)(d + o_xuvn) : nullptr;
     ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
@@ -209,6 +211,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   unsigned char *tri_valid = nullptr, *tri_ok = nullptr;
   const float *tri_uvn = nullptr;
   const plv_tri_options *tri_opt = nullptr;
+  for (int f = 0; f < F; ++f) tri_max_obs = std::max(tri_max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);  // (sizes the launch's LDS)
   if (ft) {
     StageExtra ex;
     ex.uvn = ft->uvn;
@@ -219,7 +222,6 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
                  o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    for (int f = 0; f < F; ++f) tri_max_obs = std::max(tri_max_obs, tr->obs_ptr[f + 1] - tr->obs_ptr[f]);
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
     fuse_tri = project && F <= ft->max_sel && !getenv("PLV_POINT_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
@@ -258,7 +260,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     if (fuse_tri)
       TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, tri_opt, tri_poses, tri_valid, tri_uvn, tri_p, tri_ok, tri_err, tri_max_obs));
     else
-      TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+      TRY(launch_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tri_max_obs));
     ph_l.stop();
     plv::HostPhase ph_p1("build: prior prefetch, phase 1 (side stream)");
     if (can_gather)  // (the column map as the host staged it: same offset in the pinned block as in the device copy)
@@ -587,6 +589,8 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   P.k = k;
   P.ld = ld;
   P.cols_in = (const int *)(d + o_cols);
+  P.in_base = d;
+  P.in_bytes = (int)total;
   P.cols_out = nullptr;
   if (ex) ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
   if (Pt) {
@@ -666,10 +670,12 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
       TRY(gather_args(ctx, ctx->d_P.as<double>(), n, n, P.cols_in, k, g));
       gblocks = (std::max(k * n, std::max(k * k, n)) + 255) / 256;
     }
+    int line_max_obs = 1;  // (sizes the launch's LDS)
+    for (int l = 0; l < L; ++l) line_max_obs = std::max(line_max_obs, lt->obs_ptr[l + 1] - lt->obs_ptr[l]);
     if (fuse_tri)
-      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));
+      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok, line_max_obs));
     else
-      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks));
+      TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, line_max_obs));
     if (can_gather)
       TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in), k, L, ld - 6));
     us->b_projected = true;

@@ -11,6 +11,18 @@
 // natural GPU shape is "one lane = one (feature, observation)", ~1000 lanes per frame.  Rows are
 // written straight into the [Hf | Hx | res] batch layout that nullspace_kernel consumes; the batch
 // is zero-filled by a memset node in front of the launch.
+#include <hip/hip_runtime.h>
+// Phase stamps of the projected Jacobian launches (measurement aid, PLV_KERNEL_STAMPS=1: the launcher hangs a buffer on the pointer
+// and prints mean / max cycles per phase when the library unloads).  Off: one scalar load and a branch per stamp.
+namespace plv {
+#define JAC_NSTAMP 32
+__device__ long long *g_jac_stamps = nullptr;  // [workgroups][JAC_NSTAMP]
+__device__ __forceinline__ void jac_stamp(int id) {
+  long long *s = g_jac_stamps;
+  if (s && threadIdx.x == 0) s[blockIdx.x * JAC_NSTAMP + id] = (long long)__builtin_amdgcn_s_memtime();
+}
+}  // namespace plv
+#define GATE_STAMP(id) jac_stamp(id)
 #include "gate_core.hpp"
 #include "jacobian_kernels.hpp"
 #include "nullspace_core.hpp"
@@ -275,11 +287,16 @@ struct WinTab {
 };
 #define JAC_MAX_WIN 40  // (n_clones - 3) * 2 variants must fit
 
-__device__ void build_window_tables(const JacParams &P, WinTab *tab) {
+// Pt != null: the estimate-variant tables of a second state of the same window (clone times shared) follow at tab[2 * nwin + s0]
+// (the line update triangulates on the state before the point correction and linearises on the corrected one).
+__device__ void build_window_tables(const JacParams &P, WinTab *tab, const JacParams *Pt = nullptr) {
   const int nwin = max(P.n_clones - 3, 0);
-  for (int idx = threadIdx.x; idx < nwin * 2 * 3; idx += blockDim.x) {
-    const int w = idx % 3, e = idx / 3, s0 = e >> 1, fej = e & 1;
-    const double *Rs = fej ? P.clone_R_fej : P.clone_R, *ps = fej ? P.clone_p_fej : P.clone_p;
+  const int ntask = nwin * (Pt ? 3 : 2);
+  for (int idx = threadIdx.x; idx < ntask * 3; idx += blockDim.x) {
+    const int w = idx % 3, e = idx / 3;
+    const bool second = e >= 2 * nwin;
+    const int s0 = second ? e - 2 * nwin : e >> 1, fej = second ? 0 : e & 1;
+    const double *Rs = second ? Pt->clone_R : (fej ? P.clone_R_fej : P.clone_R), *ps = second ? Pt->clone_p : (fej ? P.clone_p_fej : P.clone_p);
     WinTab &T = tab[e];
     const M3 R0 = ldM(Rs + 9 * s0);
     const V3 p0 = ldV(ps + 3 * s0);
@@ -299,7 +316,7 @@ __device__ void build_window_tables(const JacParams &P, WinTab *tab) {
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nwin * 2; e += blockDim.x) {
+  for (int e = threadIdx.x; e < ntask; e += blockDim.x) {
     M3 V;
 #pragma unroll
     for (int w = 0; w < 3; ++w)
@@ -365,6 +382,8 @@ __device__ void interpolate_tab(const JacParams &P, const WinTab &T, int s0, dou
 
 __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int o, int s0, double tm, int c, double *hf, double *hx,
                               double *rs, int cstr, int rstr);
+__device__ void jacobian_rows_core(const JacParams &P, int f, int o, int s0, double tm, int c, const Interp &jac, M3 R_GtoI, V3 p_IinG, double *hf,
+                                   double *hx, double *rs, int cstr, int rstr);
 
 // One workgroup (one wave) per feature, one lane per observation.  The feature's slice of the
 // batch [Hf | Hx | res] is zero-filled here (no separate memset of the 1.8 MB batch), the row slot
@@ -414,9 +433,14 @@ __device__ bool candidate_selected(const JacParams &P, int f) {
 // (they read the column map from the packed input block: the resident copy is being written by workgroup 0).
 __device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
                                     const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
-                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot);
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, int obase = 0, bool poses_ready = false,
+                                    double *res_l = nullptr);
 // tri.on: the workgroup's first wave triangulates the feature before the Jacobians are built (what triangulate_kernel did in a launch
 // of its own) — while the selection loop has no cap to enforce (n_feat <= max_sel) a candidate is taken on its own verdict.
+#define TRI_TERMS 10
+__host__ __device__ inline int tri_smem_doubles(int max_obs) {  // TriObs [max_obs] | terms [max_obs][TRI_TERMS] | list [max_obs] (ints)
+  return max_obs * (15 + TRI_TERMS) + (max_obs + 1) / 2 + 2;
+}
 struct PointTriStage {
   int on, max_obs;
   double *poses;          // [n_obs][12] scratch
@@ -427,86 +451,6 @@ struct PointTriStage {
   unsigned char *ok_out;  // [F]
   double *err_out;        // [F]
 };
-__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri, GateStage gate) {
-  extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld] | triangulation scratch
-  __shared__ WinTab tab[JAC_MAX_WIN];
-  __shared__ int s_rows;
-  __shared__ double tri_tot[10];
-  if ((int)blockIdx.x >= F) {
-    gather_cov_block(g, blockIdx.x - F);
-    return;
-  }
-  const int f = blockIdx.x;
-  const int ld = P.ld, k = P.k, ncol = 3 + k + 1;
-  double *X = jsm, *piv = jsm + ld * ncol;
-  for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
-  if (f == 0 && P.cols_out)
-    for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-  bool selected;
-  if (tri.on) {
-    if (threadIdx.x < 64) triangulate_feature(P, f, tri.poses, tri.valid, tri.uvn, tri.opt, tri.p_out, tri.ok_out, tri.err_out, tri.max_obs, piv + ld, tri_tot);
-    __threadfence_block();
-    __syncthreads();
-    selected = P.sel_flags[f] && tri.ok_out[f] && tri.err_out[f] < 3.0;
-  } else {
-    selected = !P.tri_ok || candidate_selected(P, f);
-  }
-  build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill before the row writes)
-  if (!selected) {
-    if (threadIdx.x == 0) {
-      s_rows = 0;
-      P.rows[f] = 0;
-    }
-  } else if (threadIdx.x < 64) {
-    const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
-    int base = 0;
-    for (int ob = o0; ob < o1; ob += 64) {
-      const int o = ob + threadIdx.x;
-      const bool have = o < o1;
-      const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
-      const int s0 = have ? bounding_start(P, tm) : -1;
-      const unsigned long long vmask = __ballot(s0 >= 0);
-      const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
-      base += __popcll(vmask);
-      if (s0 >= 0 && 2 * c + 2 <= ld) jacobian_rows(P, tab, f, o, s0, tm, c, X, X + 3, X + 3 + k, 1, ncol);
-    }
-    if (threadIdx.x == 0) {
-      s_rows = min(2 * base, ld & ~1);
-      P.rows[f] = 2 * base;
-    }
-  }
-  __syncthreads();
-  const int rows = s_rows;
-  if ((tri.on || P.tri_ok) && rows == 0) {  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
-                                            // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
-    if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
-    return;
-  }
-  const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
-  if (shift) nullspace_householder(X, piv, rows, ncol, 3);
-  double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
-  // (with the gate as this launch's tail nothing reads the projected block from memory any more: the gate takes it from LDS and
-  //  leaves the accepted rows in the stack — 0.7 MB of writes per launch less, rocprofv3 WRITE_SIZE)
-  for (int j = gate.on ? ncol : (int)threadIdx.x; j < ncol; j += blockDim.x) {
-    double *dst = j < 3 ? hf + j * ld : (j < 3 + k ? hx + (size_t)(j - 3) * ld : rs);
-    const int off = j < 3 ? 0 : shift;
-    for (int i0 = 0; i0 < ld; i0 += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = i0 + u + off;
-        v[u] = r < ld ? X[r * ncol + j] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u < ld) dst[i0 + u] = v[u];
-    }
-  }
-  if (gate.on) {  // (X is only read from here on: no barrier needed between the write-out and the gate)
-    gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);
-  }
-}
-
 // REF: CamHelper.cpp:217-224 (and LineHelper's twin): R += H_ Q H_^T * mlt with H_ = HI * blockdiag(I, R_clone_fej^T), HI the 2 x 6
 // Jacobian of the measurement in the interpolated pose, Q the CPI covariance of that pose.
 __device__ __forceinline__ void add_imu_cov(const JacParams &P, int o, const double *HI, double *Rn) {
@@ -545,11 +489,6 @@ __device__ __forceinline__ void add_imu_cov(const JacParams &P, int o, const dou
 // feature), (1, ncol) for the row-major LDS image the fused kernel projects in place.
 __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int o, int s0, double tm, int c, double *hf, double *hx,
                               double *rs, int cstr, int rstr) {
-  const M3 R_ItoC = ldM(P.R_ItoC);
-  const V3 p_IinC = ldV(P.p_IinC);
-  const double *K = P.K;
-  const V3 pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
-
   Interp jac;
   interpolate_tab(P, tab[2 * s0 + 1], s0, tm, true, jac);
   M3 R_GtoI;
@@ -563,11 +502,21 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
     R_GtoI = est.R;
     p_IinG = est.p;
   }
-  // ---- residual (estimate pose); CamBase::distort_d rounds through float both ways
-  V3 p_FinI = mv(R_GtoI, vsub(pf, p_IinG));
-  V3 p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
+  jacobian_rows_core(P, f, o, s0, tm, c, jac, R_GtoI, p_IinG, hf, hx, rs, cstr, rstr);
+}
+// ---- the rows of one observation behind the two interpolations, in pieces (jacobian_rows_core runs them one after the other on one
+// lane; the fused launch spreads them over the four waves of the workgroup, jacobian_rows_split).  Every value is formed by the same
+// expression wherever its piece runs.
+// (1) residual at the estimate pose (CamBase::distort_d rounds through float both ways) + distortion Jacobians at the estimate's
+//     normalised coordinates
+__device__ __forceinline__ void rows_est_part(const JacParams &P, const V3 &pf, int o, const M3 &R_GtoI, const V3 &p_IinG, double *r2, double *dzn,
+                                              double *dzeta) {
+  const M3 R_ItoC = ldM(P.R_ItoC);
+  const V3 p_IinC = ldV(P.p_IinC);
+  const double *K = P.K;
+  const V3 p_FinI = mv(R_GtoI, vsub(pf, p_IinG));
+  const V3 p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
   const double un = p_FinC[0] / p_FinC[2], vn = p_FinC[1] / p_FinC[2];
-  double r2[2];
   {
     const double x = (double)(float)un, y = (double)(float)vn;
     const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
@@ -576,8 +525,6 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
     r2[0] = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
     r2[1] = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
   }
-  // ---- distortion Jacobians at the estimate's normalised coordinates
-  double dzn[4], dzeta[16];
   {
     const double x = un, y = vn;
     const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
@@ -603,16 +550,20 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
     dzeta[14] = K[1] * (r_2 + 2 * y * y);
     dzeta[15] = 2 * K[1] * x * y;
   }
-  // ---- chain at the first estimates
-  R_GtoI = jac.R;
-  p_IinG = jac.p;
-  p_FinI = mv(R_GtoI, vsub(pf_fej, p_IinG));
-  p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
+}
+// (2) projection chain at the first estimates: dznp = d(normalised)/d(p_FinC), dpC_dpG, dpC_dI = [R_ItoC skew(p_FinI) | -dpC_dpG],
+//     lever = p_FinC - p_IinC (extrinsic block)
+__device__ __forceinline__ void rows_fej_part(const JacParams &P, const V3 &pf_fej, const M3 &R_GtoI, const V3 &p_IinG, double *dznp, M3 &dpC_dpG,
+                                              double *dpC_dI, V3 &lever) {
+  const M3 R_ItoC = ldM(P.R_ItoC);
+  const V3 p_IinC = ldV(P.p_IinC);
+  const V3 p_FinI = mv(R_GtoI, vsub(pf_fej, p_IinG));
+  const V3 p_FinC = vadd(mv(R_ItoC, p_FinI), p_IinC);
   const double iz = 1 / p_FinC[2];
-  const double dznp[6] = {iz, 0, -p_FinC[0] / (p_FinC[2] * p_FinC[2]), 0, iz, -p_FinC[1] / (p_FinC[2] * p_FinC[2])};
-  const M3 dpC_dpG = mm(R_ItoC, R_GtoI);
+  dznp[0] = iz, dznp[1] = 0, dznp[2] = -p_FinC[0] / (p_FinC[2] * p_FinC[2]);
+  dznp[3] = 0, dznp[4] = iz, dznp[5] = -p_FinC[1] / (p_FinC[2] * p_FinC[2]);
+  dpC_dpG = mm(R_ItoC, R_GtoI);
   const M3 left = mm(R_ItoC, skew3(p_FinI));
-  double dpC_dI[18];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -620,6 +571,17 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
       dpC_dI[6 * i + j] = left(i, j);
       dpC_dI[6 * i + 3 + j] = -dpC_dpG(i, j);
     }
+  lever = vsub(p_FinC, p_IinC);
+}
+__device__ __forceinline__ bool rows_at_clone(const JacParams &P, double tm) {
+  bool at_clone = false;
+  for (int i = 0; i < P.n_clones; ++i) at_clone = at_clone || P.clone_time[i] == tm;
+  return at_clone;
+}
+// (3) measurement Jacobian in the interpolated pose, noise (REF :207-239 incl. the `R_llt.llt().solve(I)` form), whitening:
+//     Wm (2 x 2), wz = Wm dz_dpC (2 x 3), WI = wz dpC_dI (2 x 6)
+__device__ __forceinline__ void rows_whiten_part(const JacParams &P, int o, bool at_clone, const double *dzn, const double *dznp, const double *dpC_dI,
+                                                 double *Wm, double *wz, double *WI) {
   double dz_dpC[6];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -630,10 +592,7 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) HI[6 * i + j] = dz_dpC[3 * i] * dpC_dI[j] + dz_dpC[3 * i + 1] * dpC_dI[6 + j] + dz_dpC[3 * i + 2] * dpC_dI[12 + j];
-  // ---- noise + whitening (REF :207-239 incl. the `R_llt.llt().solve(I)` form)
   double Rn[4] = {P.sigma_pix * P.sigma_pix, 0, 0, P.sigma_pix * P.sigma_pix};
-  bool at_clone = false;
-  for (int i = 0; i < P.n_clones; ++i) at_clone = at_clone || P.clone_time[i] == tm;
   if (!at_clone && P.use_pol_cov) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -649,7 +608,6 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
   }
   const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
   const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
-  double Wm[4];
 #pragma unroll
   for (int col = 0; col < 2; ++col) {
     const double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
@@ -658,20 +616,25 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
     Wm[col] = x0;
     Wm[2 + col] = x1;
   }
-  double wz[6], wzeta[16];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     wz[j] = Wm[0] * dz_dpC[j] + Wm[1] * dz_dpC[3 + j];
     wz[3 + j] = Wm[2] * dz_dpC[j] + Wm[3] * dz_dpC[3 + j];
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    wzeta[j] = Wm[0] * dzeta[j] + Wm[1] * dzeta[8 + j];
-    wzeta[8 + j] = Wm[2] * dzeta[j] + Wm[3] * dzeta[8 + j];
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) WI[6 * i + j] = wz[3 * i] * dpC_dI[j] + wz[3 * i + 1] * dpC_dI[6 + j] + wz[3 * i + 2] * dpC_dI[12 + j];
+}
+// (4) the blocks.  Element (row, col) goes to base[col * cstr + row * rstr].  The slice was zero-filled by this workgroup and every
+// (row, column) is written once (the clones of a window, the time offset, the extrinsics and the intrinsics are distinct state
+// blocks), so these are plain stores: an accumulate would put a load in front of every one of them on the observation's chain.
+__device__ __forceinline__ void rows_write_res(int c, const double *Wm, const double *r2, double *rs, int rstr) {
   rs[(2 * c) * rstr] = Wm[0] * r2[0] + Wm[1] * r2[1];
   rs[(2 * c + 1) * rstr] = Wm[2] * r2[0] + Wm[3] * r2[1];
-  // ---- Hf
+}
+__device__ __forceinline__ void rows_write_hf(const JacParams &P, const V3 &pf_fej, int c, const double *wz, const M3 &dpC_dpG, double *hf, int cstr,
+                                              int rstr) {
   M3 G = dpC_dpG;
   if (P.feat_rep == PLV_FEAT_GLOBAL_FULL_INVERSE_DEPTH) {  // REF: CamHelper.cpp:29-51
     const double g_rho = 1 / vnorm(pf_fej);
@@ -694,50 +657,406 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) hf[(size_t)j * cstr + (2 * c + i) * rstr] = wz[3 * i] * G(0, j) + wz[3 * i + 1] * G(1, j) + wz[3 * i + 2] * G(2, j);
-  // ---- Hx: four interpolation poses.  The slice was zero-filled by this workgroup and every (row, column) below is written
-  // once (the clones of a window, the time offset, the extrinsics and the intrinsics are distinct state blocks), so these are
-  // plain stores: an accumulate would put a global load in front of every one of them on the observation's chain.
-  double WI[12];
+}
+__device__ __forceinline__ void rows_write_pose(int col, int c, const double *WI, const M3 &Ho, double lam, double *hx, int cstr, int rstr) {
+  if (col < 0) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) WI[6 * i + j] = wz[3 * i] * dpC_dI[j] + wz[3 * i + 1] * dpC_dI[6 + j] + wz[3 * i + 2] * dpC_dI[12 + j];
+    for (int j = 0; j < 3; ++j) {
+      const double so = WI[6 * i] * Ho(0, j) + WI[6 * i + 1] * Ho(1, j) + WI[6 * i + 2] * Ho(2, j);
+      hx[(size_t)(col + j) * cstr + (2 * c + i) * rstr] = so;
+      hx[(size_t)(col + 3 + j) * cstr + (2 * c + i) * rstr] = WI[6 * i + 3 + j] * lam;
+    }
+}
+__device__ __forceinline__ void rows_write_dt(const JacParams &P, int c, const double *WI, const double *dtj, double *hx, int cstr, int rstr) {
+  if (P.col_dt < 0) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * dtj[q];
+    hx[(size_t)P.col_dt * cstr + (2 * c + i) * rstr] = s;
+  }
+}
+__device__ __forceinline__ void rows_write_ext(const JacParams &P, int c, const double *wz, const V3 &lever, double *hx, int cstr, int rstr) {
+  if (P.col_ext < 0) return;
+  const M3 sk = skew3(lever);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      hx[(size_t)(P.col_ext + j) * cstr + (2 * c + i) * rstr] = wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
+      hx[(size_t)(P.col_ext + 3 + j) * cstr + (2 * c + i) * rstr] = wz[3 * i + j];
+    }
+}
+__device__ __forceinline__ void rows_write_int(const JacParams &P, int c, const double *Wm, const double *dzeta, double *hx, int cstr, int rstr) {
+  if (P.col_int < 0) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hx[(size_t)(P.col_int + j) * cstr + (2 * c) * rstr] = Wm[0] * dzeta[j] + Wm[1] * dzeta[8 + j];
+    hx[(size_t)(P.col_int + j) * cstr + (2 * c + 1) * rstr] = Wm[2] * dzeta[j] + Wm[3] * dzeta[8 + j];
+  }
+}
+
+// Everything of an observation's rows behind the two interpolations: jac = the first-estimate polynomial with its Jacobians, (R_GtoI,
+// p_IinG) = the estimate pose the residual is taken at.
+__device__ void jacobian_rows_core(const JacParams &P, int f, int o, int s0, double tm, int c, const Interp &jac, M3 R_GtoI, V3 p_IinG, double *hf,
+                                   double *hx, double *rs, int cstr, int rstr) {
+  double r2[2], dzn[4], dzeta[16], dznp[6], dpC_dI[18], Wm[4], wz[6], WI[12];
+  M3 dpC_dpG;
+  V3 lever;
+  const V3 pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
+  rows_est_part(P, pf, o, R_GtoI, p_IinG, r2, dzn, dzeta);
+  rows_fej_part(P, pf_fej, jac.R, jac.p, dznp, dpC_dpG, dpC_dI, lever);
+  rows_whiten_part(P, o, rows_at_clone(P, tm), dzn, dznp, dpC_dI, Wm, wz, WI);
+  rows_write_res(c, Wm, r2, rs, rstr);
+  rows_write_hf(P, pf_fej, c, wz, dpC_dpG, hf, cstr, rstr);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) rows_write_pose(P.clone_col[s0 + w], c, WI, jac.Ho[w], jac.lam[w], hx, cstr, rstr);
+  rows_write_dt(P, c, WI, jac.dtj, hx, cstr, rstr);
+  rows_write_ext(P, c, wz, lever, hx, cstr, rstr);
+  rows_write_int(P, c, Wm, dzeta, hx, cstr, rstr);
+}
+
+// Per-observation scratch of the fused launches in LDS, one slot per row pair (stride PRE_STRIDE doubles: one lane per slot reads and
+// writes without bank conflicts): the first-estimate interpolation with its Jacobians (what jacobian_rows_core takes as `jac`) and
+// the estimate pose.  Neither depends on the feature's position, so three waves fill the slots while the first wave triangulates.
+__device__ __forceinline__ void tri_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#define PRE_STRIDE 127
+#define LPRE_STRIDE 113  // lines: the same slots up to PRE_PE, then the exchange of line_rows_split
+enum { LPRE_R2 = 70, LPRE_DZLI = 72, LPRE_ATC = 84, LPRE_WM = 85, LPRE_WLI = 89, LPRE_WI = 101 };
+enum { PRE_R = 0, PRE_P = 9, PRE_HO = 12, PRE_LAM = 48, PRE_DTJ = 52, PRE_RE = 58, PRE_PE = 67,
+       // exchange between the waves of jacobian_rows_split
+       PRE_R2 = 70, PRE_DZN = 72, PRE_DZETA = 76, PRE_ATC = 92, PRE_WM = 93, PRE_WZ = 97, PRE_WI = 103, PRE_G = 115, PRE_LEVER = 124 };
+__device__ __forceinline__ void pre_store_jac(double *pre, const Interp &j) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pre[PRE_R + i] = j.R.m[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pre[PRE_P + i] = j.p[i];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    const int col = P.clone_col[s0 + w];
-    if (col < 0) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
-        hx[(size_t)(col + j) * cstr + (2 * c + i) * rstr] = so;
-        hx[(size_t)(col + 3 + j) * cstr + (2 * c + i) * rstr] = WI[6 * i + 3 + j] * jac.lam[w];
-      }
+    for (int i = 0; i < 9; ++i) pre[PRE_HO + 9 * w + i] = j.Ho[w].m[i];
+    pre[PRE_LAM + w] = j.lam[w];
   }
-  if (P.col_dt >= 0)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      double s = 0;
+  for (int i = 0; i < 6; ++i) pre[PRE_DTJ + i] = j.dtj[i];
+}
+__device__ __forceinline__ void pre_load_jac(const double *pre, Interp &j) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
-      hx[(size_t)P.col_dt * cstr + (2 * c + i) * rstr] = s;
+  for (int i = 0; i < 9; ++i) j.R.m[i] = pre[PRE_R + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) j.p[i] = pre[PRE_P + i];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) j.Ho[w].m[i] = pre[PRE_HO + 9 * w + i];
+    j.lam[w] = pre[PRE_LAM + w];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) j.dtj[i] = pre[PRE_DTJ + i];
+}
+// Row slots of a feature's observations (wave 0 of the workgroup): slot = number of observations with bounding clones in front of it
+// (ballot prefix), -1 for an observation without a row pair.  s0 = first clone of its interpolation window or -1.  Returns the
+// number of observations with bounding clones.
+__device__ __forceinline__ int assign_row_slots(const JacParams &P, int o0, int o1, int ld, int *s0_l, int *slot_l) {
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int ob = o0; ob < o1; ob += 64) {
+    const int o = ob + lane;
+    const bool have = o < o1;
+    const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
+    const int s0 = have ? bounding_start(P, tm) : -1;
+    const unsigned long long vmask = __ballot(s0 >= 0);
+    const int c = base + __popcll(vmask & ((1ull << lane) - 1ull));
+    base += __popcll(vmask);
+    if (have) {
+      s0_l[o - o0] = s0;
+      slot_l[o - o0] = (s0 >= 0 && 2 * c + 2 <= ld) ? c : -1;
     }
-  if (P.col_ext >= 0) {
-    const M3 sk = skew3(vsub(p_FinC, p_IinC));
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        hx[(size_t)(P.col_ext + j) * cstr + (2 * c + i) * rstr] = wz[3 * i] * sk(0, j) + wz[3 * i + 1] * sk(1, j) + wz[3 * i + 2] * sk(2, j);
-        hx[(size_t)(P.col_ext + 3 + j) * cstr + (2 * c + i) * rstr] = wz[3 * i + j];
-      }
   }
-  if (P.col_int >= 0)
+  return base;
+}
+// estimate pose of observation o (CamHelper::get_imu_poses) from the window tables; the same values as campose_one's
+__device__ __forceinline__ void est_pose_tab(const JacParams &P, const WinTab &T, int o, int s0, M3 &R_GtoI, V3 &p_IinG) {
+  if (P.res_R) {
+    R_GtoI = ldM(P.res_R + 9 * o);
+    p_IinG = ldV(P.res_p + 3 * o);
+  } else {
+    Interp est;
+    interpolate_tab(P, T, s0, P.obs_time[o] + P.cam_dt, false, est);
+    R_GtoI = est.R;
+    p_IinG = est.p;
+  }
+}
+
+// The rows of every observation of the workgroup's feature from the LDS slots, the pieces of jacobian_rows_core spread over the four
+// waves (lane = observation in all of them; two barriers):
+//   A  wave 0: projection chain at the first estimates | wave 1: residual + distortion Jacobians | wave 2: "observed at a clone time"
+//   B  wave 0: Jacobian in the interpolated pose, noise, whitening (the long pole: four square roots and six divisions in a row)
+//   C  wave w: the block of interpolation pose w; + wave 0: residual rows, time offset | 1: extrinsics | 2: intrinsics | 3: Hf
+// One lane doing all of it in sequence took 17 k cycles (a wave retires a dependent fp64 operation every ~8 cycles whatever its lanes
+// do); this form ~7 k.  Called by all 256 threads.
+__device__ __forceinline__ void jacobian_rows_split(const JacParams &P, const V3 &pf, const V3 &pf_fej, int o0, int n_o, const int *s0_l,
+                                                    const int *slot_l, double *pre, double *X, int ncol, int k) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *hf = X, *hx = X + 3, *rs = X + 3 + k;
+  for (int ib = 0; ib < n_o; ib += 64) {
+    const int i = ib + lane;
+    const int c = i < n_o ? slot_l[i] : -1;
+    const int o = o0 + i;
+    double *pr = pre + (size_t)max(c, 0) * PRE_STRIDE;
+    double dznp[6], dpC_dI[18];  // (wave 0, stage A -> B)
+    if (c >= 0) {
+      if (wave == 0) {
+        M3 dpC_dpG;
+        V3 lever;
+        rows_fej_part(P, pf_fej, ldM(pr + PRE_R), ldV(pr + PRE_P), dznp, dpC_dpG, dpC_dI, lever);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 9; ++q) pr[PRE_G + q] = dpC_dpG.m[q];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hx[(size_t)(P.col_int + j) * cstr + (2 * c + i) * rstr] = wzeta[8 * i + j];
+        for (int q = 0; q < 3; ++q) pr[PRE_LEVER + q] = lever[q];
+      } else if (wave == 1) {
+        double r2[2], dzn[4], dzeta[16];
+        rows_est_part(P, pf, o, ldM(pr + PRE_RE), ldV(pr + PRE_PE), r2, dzn, dzeta);
+        pr[PRE_R2] = r2[0], pr[PRE_R2 + 1] = r2[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pr[PRE_DZN + q] = dzn[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pr[PRE_DZETA + q] = dzeta[q];
+      } else if (wave == 2) {
+        pr[PRE_ATC] = rows_at_clone(P, P.obs_time[o] + P.cam_dt) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    if (c >= 0 && wave == 0) {
+      double dzn[4], Wm[4], wz[6], WI[12];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dzn[q] = pr[PRE_DZN + q];
+      rows_whiten_part(P, o, pr[PRE_ATC] != 0.0, dzn, dznp, dpC_dI, Wm, wz, WI);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pr[PRE_WM + q] = Wm[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) pr[PRE_WZ + q] = wz[q];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) pr[PRE_WI + q] = WI[q];
+    }
+    __syncthreads();
+    if (c >= 0) {
+      double WI[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) WI[q] = pr[PRE_WI + q];
+      rows_write_pose(P.clone_col[s0_l[i] + wave], c, WI, ldM(pr + PRE_HO + 9 * wave), pr[PRE_LAM + wave], hx, 1, ncol);
+      if (wave == 0) {
+        double Wm[4], r2[2] = {pr[PRE_R2], pr[PRE_R2 + 1]}, dtj[6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Wm[q] = pr[PRE_WM + q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dtj[q] = pr[PRE_DTJ + q];
+        rows_write_res(c, Wm, r2, rs, ncol);
+        rows_write_dt(P, c, WI, dtj, hx, 1, ncol);
+      } else if (wave == 1) {
+        double wz[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wz[q] = pr[PRE_WZ + q];
+        rows_write_ext(P, c, wz, ldV(pr + PRE_LEVER), hx, 1, ncol);
+      } else if (wave == 2) {
+        double Wm[4], dzeta[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Wm[q] = pr[PRE_WM + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dzeta[q] = pr[PRE_DZETA + q];
+        rows_write_int(P, c, Wm, dzeta, hx, 1, ncol);
+      } else {
+        double wz[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wz[q] = pr[PRE_WZ + q];
+        rows_write_hf(P, pf_fej, c, wz, ldM(pr + PRE_G), hf, 1, ncol);
+      }
+    }
+    __syncthreads();  // (a second pass reuses nothing of the slots, but its stage A must not overtake this pass's readers of X rows: distinct rows — kept for the slots)
+  }
+}
+
+// jacobian_kernel + nullspace_kernel (+ triangulation in front, + the gate behind) in one launch, one workgroup of four waves per
+// batch entry.  Round 4 order of work (stamps: PLV_KERNEL_STAMPS=1):
+//   1. window tables (all threads), row slots (wave 0)
+//   2. wave 0: estimate poses of the observations from the tables, then the triangulation (serial in the observations: LM);
+//      waves 1-3 meanwhile: the first-estimate interpolation + its Jacobians of every observation (position independent) into LDS,
+//      and the rows of the covariance the gate will read are pulled into this XCD's L2
+//   3. one lane per observation finishes its two rows from the LDS slots (residual, projection chain, whitening, blocks)
+//   4. null space (compact WY: the three reflectors from the Hf panel by one wave, one pass over the other columns), 5. gate.
+// Round 3 ran 2 -> 1 -> 3 with both interpolations inside step 3 and the poses of step 2 from the untabulated polynomial:
+// 69 us mean per workgroup, of it poses 10, rows 13, null space 8 (profiles/r04).
+// Dynamic LDS of the fused launches (doubles): X [ld][ncol] | null-space scratch | { window tables | triangulation scratch | slots
+// [min(ld / 2, max_obs)][PRE_STRIDE] | camera poses [max_obs][12] | s0, slot (ints), valid (bytes) [max_obs] }; the gate's block
+// (GateLds) overlays everything behind the null-space scratch: tables, scratch and slots are dead when the gate starts.
+struct FusedLds {
+  int ns, tab, tri, pre, cam, idx, end;  // offsets in doubles
+};
+// fdim 3 (points: one pose array, per observation time + uv + uvn = 3 doubles, 2 ints + 1 byte) or 6 (lines: camera and IMU poses, time
+// + two segments = 5 doubles, 3 ints + 1 byte)
+__host__ __device__ inline FusedLds fused_lds_layout(int ld, int ncol, int fdim, int n_tab, int max_obs, bool with_tri) {
+  const bool lines = fdim == 6;
+  FusedLds L;
+  L.ns = ld * ncol;
+  L.tab = (L.ns + nullspace_wy_scratch(ld, fdim) + 7) & ~7;
+  L.tri = L.tab + n_tab * (int)(sizeof(WinTab) / 8);
+  L.pre = L.tri + (with_tri && !lines ? tri_smem_doubles(max_obs) : 0);
+  L.cam = L.pre + (ld / 2 < max_obs ? ld / 2 : max_obs) * (lines ? LPRE_STRIDE : PRE_STRIDE);
+  L.idx = L.cam + max_obs * 12 * (lines ? 2 : 1);
+  L.end = L.idx + (lines ? 5 : 3) * max_obs + (max_obs * (lines ? 13 : 9) + 7) / 8 + 1;
+  return L;
+}
+static_assert(sizeof(WinTab) % 8 == 0, "fused_lds_layout counts WinTab in doubles");
+
+__global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri, GateStage gate) {
+  extern __shared__ double jsm[];
+  __shared__ int s_rows, s_base;
+  __shared__ double tri_tot[10], s_tri[5];
+  __shared__ double s_ct[JAC_MAX_WIN / 2 + 3];
+  __shared__ int s_ccol[JAC_MAX_WIN / 2 + 3];
+  if ((int)blockIdx.x >= F) {
+    gather_cov_block(g, blockIdx.x - F);
+    return;
+  }
+  const int f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double touch = 0.0;  // (one load per 128-byte line of the input block, see JacParams::in_base; never stored)
+  for (int off = threadIdx.x * 128; off < P.in_bytes; off += 256 * 128) touch += *(const volatile double *)(P.in_base + off);
+  const int ld = P.ld, k = P.k, ncol = 3 + k + 1, max_obs = tri.max_obs;
+  const FusedLds lay = fused_lds_layout(ld, ncol, 3, 2 * max(P.n_clones - 3, 0), max_obs, tri.on != 0);
+  double *X = jsm, *piv = jsm + lay.ns, *tri_smem = jsm + lay.tri, *pre = jsm + lay.pre, *cam = jsm + lay.cam;
+  WinTab *tab = reinterpret_cast<WinTab *>(jsm + lay.tab);
+  double *tm_l = jsm + lay.idx;
+  float *uv_l = reinterpret_cast<float *>(tm_l + max_obs), *uvn_l = uv_l + 2 * max_obs;
+  int *s0_l = reinterpret_cast<int *>(uvn_l + 2 * max_obs), *slot_l = s0_l + max_obs;
+  unsigned char *valid_l = reinterpret_cast<unsigned char *>(slot_l + max_obs);
+  jac_stamp(0);
+  // What the workgroup reads more than once goes to LDS in one round of loads — clone times and columns, its observations' times and
+  // image points: a dependent load from memory is 500+ cycles even when it hits, and the bounding-clone search, the row pieces and
+  // the triangulation's passes are chains of them.  The pointers are then redirected (same indices as before).
+  const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
+  if ((int)threadIdx.x < P.n_clones) s_ct[threadIdx.x] = P.clone_time[threadIdx.x], s_ccol[threadIdx.x] = P.clone_col[threadIdx.x];
+  for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) {
+    tm_l[i] = P.obs_time[o0 + i];
+    uv_l[2 * i] = P.obs_uv[2 * (o0 + i)], uv_l[2 * i + 1] = P.obs_uv[2 * (o0 + i) + 1];
+    if (tri.on) uvn_l[2 * i] = tri.uvn[2 * (o0 + i)], uvn_l[2 * i + 1] = tri.uvn[2 * (o0 + i) + 1];
+  }
+  for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
+  if (f == 0 && P.cols_out)
+    for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
+  __syncthreads();
+  P.clone_time = s_ct, P.clone_col = s_ccol;
+  P.obs_time = tm_l - o0, P.obs_uv = uv_l - 2 * o0;
+  tri.uvn = uvn_l - 2 * o0;
+  if (wave == 0) {
+    const int base = assign_row_slots(P, o0, o1, ld, s0_l, slot_l);
+    if (lane == 0) s_base = base;
+    jac_stamp(15);
+  }
+  build_window_tables(P, tab);  // (ends with a barrier: also orders the zero fill and the slots before what follows)
+  jac_stamp(2);
+  if (wave == 0) {
+    // estimate poses: IMU pose into the observation's slot (rows), camera pose for the triangulation
+    for (int i = lane; i < o1 - o0; i += 64) {
+      const int s0 = s0_l[i], c = slot_l[i];
+      valid_l[i] = s0 >= 0;
+      if (s0 < 0) continue;
+      M3 R_GtoI;
+      V3 p_IinG;
+      est_pose_tab(P, tab[2 * s0], o0 + i, s0, R_GtoI, p_IinG);
+      if (c >= 0) {
+        double *pr = pre + (size_t)c * PRE_STRIDE;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pr[PRE_RE + q] = R_GtoI.m[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pr[PRE_PE + q] = p_IinG[q];
+      }
+      if (tri.on) {  // REF: CamHelper::get_cam_poses (as campose_one)
+        const M3 R_GtoC = mm(ldM(P.R_ItoC), R_GtoI);
+        const V3 p_CinG = vsub(p_IinG, mv(tp(R_GtoC), ldV(P.p_IinC)));
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cam[12 * i + q] = R_GtoC.m[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cam[12 * i + 9 + q] = p_CinG[q];
+      }
+    }
+    if (tri.on) {
+      tri_wave_sync();
+      triangulate_feature(P, f, cam, valid_l, tri.uvn, tri.opt, tri.p_out, tri.ok_out, tri.err_out, max_obs, tri_smem, tri_tot, o0, true, s_tri);
+    }
+  } else {
+    for (int i = threadIdx.x - 64; i < o1 - o0; i += 192) {
+      const int c = slot_l[i];
+      if (c < 0) continue;
+      Interp jac;
+      const int s0 = s0_l[i];
+      interpolate_tab(P, tab[2 * s0 + 1], s0, P.obs_time[o0 + i] + P.cam_dt, true, jac);
+      pre_store_jac(pre + (size_t)c * PRE_STRIDE, jac);
+    }
+    if (gate.on) gate_prefetch_rows(gate, P.cols_in, k, threadIdx.x - 64, 192);
+  }
+  __threadfence_block();
+  __syncthreads();
+  jac_stamp(1);
+  bool selected;
+  V3 pf, pf_fej;
+  if (tri.on) {  // (the workgroup's own result from LDS: no trip through memory)
+    selected = P.sel_flags[f] && s_tri[3] != 0.0 && s_tri[4] < 3.0;
+    pf = pf_fej = ldV(s_tri);  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
+  } else {
+    selected = !P.tri_ok || candidate_selected(P, f);
+    pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
+  }
+  if (selected) {  // (block-uniform)
+    jacobian_rows_split(P, pf, pf_fej, o0, o1 - o0, s0_l, slot_l, pre, X, ncol, k);
+    if (threadIdx.x == 0) {
+      s_rows = min(2 * s_base, ld & ~1);
+      P.rows[f] = 2 * s_base;
+    }
+  } else if (threadIdx.x == 0) {
+    s_rows = 0;
+    P.rows[f] = 0;
+  }
+  __syncthreads();
+  jac_stamp(3);
+  const int rows = s_rows;
+  GateLds &gl = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
+  if ((tri.on || P.tri_ok) && rows == 0) {  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
+                                            // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
+    if (gate.on) gate_tail(gate, gl, f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
+    return;
+  }
+  const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
+  if (shift) nullspace_householder_wy<3>(X, piv, rows, ncol);
+  jac_stamp(4);
+  double *hf = P.Hf + (size_t)f * 3 * ld, *hx = P.Hx + (size_t)f * k * ld, *rs = P.res + (size_t)f * ld;
+  // (with the gate as this launch's tail nothing reads the projected block from memory any more: the gate takes it from LDS and
+  //  leaves the accepted rows in the stack — 0.7 MB of writes per launch less, rocprofv3 WRITE_SIZE)
+  for (int j = gate.on ? ncol : (int)threadIdx.x; j < ncol; j += blockDim.x) {
+    double *dst = j < 3 ? hf + j * ld : (j < 3 + k ? hx + (size_t)(j - 3) * ld : rs);
+    const int off = j < 3 ? 0 : shift;
+    for (int i0 = 0; i0 < ld; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = i0 + u + off;
+        v[u] = r < ld ? X[r * ncol + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < ld) dst[i0 + u] = v[u];
+    }
+  }
+  jac_stamp(5);
+  if (gate.on) gate_tail(gate, gl, f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);  // (X is only read from here on)
+  if (touch == 1.2345678e300) P.rows[f] = -1;  // (never: keeps the touch loads)
+  jac_stamp(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -930,25 +1249,26 @@ struct TriObs {     // per valid observation, relative to the anchor pose (the n
   double pa[3];     // p_AinCi
   double pc[3];     // p_CiinA
 };
-#define TRI_TERMS 10
+static_assert(sizeof(TriObs) == 15 * 8, "tri_smem_doubles counts 15 doubles per TriObs");
 // One feature, ONE wave (the 64 lanes that call it; other waves of the workgroup must not): poses of its observations, linear
 // triangulation, Levenberg-Marquardt refinement, reprojection error.  tri_smem: max_obs * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 bytes
 // of LDS, tot: TRI_TERMS doubles of LDS.  Wave-level synchronisation only (the lanes run in lockstep; the fences order the LDS traffic).
-__device__ __forceinline__ void tri_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
+// poses / valid are indexed by (o - obase): the global scratch arrays of triangulate_kernel (obase = 0) or a workgroup's LDS copy of
+// its own feature's observations (obase = obs_ptr[f], poses_ready: the caller has filled them).
 __device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
                                     const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
-                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot) {
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, int obase, bool poses_ready,
+                                    double *res_l /* LDS copy of the result for the caller's workgroup: p [3], ok, err */) {
   const int lane = threadIdx.x & 63;
-  {  // camera poses of this feature's observations (CamHelper::get_imu_poses / get_cam_poses), one lane each: no separate launch
+  if (!poses_ready) {  // camera poses of this feature's observations (CamHelper::get_imu_poses / get_cam_poses), one lane each: no separate launch
     const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
     for (int o = o0 + lane; o < o1; o += 64) campose_one(P, o, poses, valid, nullptr);
     __threadfence_block();
     tri_wave_sync();
   }
+  jac_stamp(10);
+  poses -= 12 * (size_t)obase;
+  valid -= obase;
   TriObs *ob = reinterpret_cast<TriObs *>(tri_smem);                       // [max_obs]
   double *term = tri_smem + (size_t)max_obs * (sizeof(TriObs) / 8);        // [max_obs][TRI_TERMS]
   int *list = reinterpret_cast<int *>(term + (size_t)max_obs * TRI_TERMS);  // [max_obs] indices of the valid observations
@@ -966,6 +1286,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
     p_out[3 * f] = p_out[3 * f + 1] = p_out[3 * f + 2] = 0;
     ok_out[f] = 0;
     if (err_out) err_out[f] = 0;
+    if (res_l) res_l[0] = res_l[1] = res_l[2] = res_l[3] = res_l[4] = 0.0;
   }
   if (M < 2) return;
   tri_wave_sync();
@@ -975,9 +1296,17 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
   // sums `n` terms per observation in observation order; afterwards tot[0..n) holds the totals for every lane
   auto reduce = [&](int n) {
     tri_wave_sync();
-    if (lane < n) {
+    if (lane < n) {  // (the terms of eight observations are requested together, then added in observation order)
       double s = 0;
-      for (int q = 0; q < M; ++q) s += term[q * TRI_TERMS + lane];
+      int q = 0;
+      for (; q + 8 <= M; q += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = term[(q + u) * TRI_TERMS + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+      }
+      for (; q < M; ++q) s += term[q * TRI_TERMS + lane];
       tot[lane] = s;
     }
     tri_wave_sync();
@@ -1011,6 +1340,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
   sym_eig3(A, ev);
   const double condA = ev[0] / ev[2];
   if (fabs(condA) > opt.max_cond_number || pf[2] < opt.min_dist || pf[2] > opt.max_dist || isnan(vnorm(pf))) return;
+  jac_stamp(11);
   auto tri_error = [&](double alpha, double beta, double rho) {
     for (int q = lane; q < M; q += 64) {
       const TriObs &c = ob[q];
@@ -1034,7 +1364,9 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
     M3 Hess{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
     V3 grad{{0, 0, 0}};
     double cost_old = tri_error(alpha, beta, rho);
+    int lm_pass = 0;
     while (runs < 5 && lam < 1e10 && eps > 1e-6) {
+      jac_stamp(16 + min(lm_pass++, 11));
       if (recompute) {
         for (int q = lane; q < M; q += 64) {
           const TriObs &c = ob[q];
@@ -1084,6 +1416,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
         lam = lam * 10;
       }
     }
+    jac_stamp(12);
     pf = V3{{alpha / rho, beta / rho, 1 / rho}};
     const V3 dir = vsc(pf, 1.0 / vnorm(pf));
     for (int q = lane; q < M; q += 64) {
@@ -1121,6 +1454,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
     p_out[3 * f + 2] = pg[2];
     ok_out[f] = 1;
     if (err_out) err_out[f] = e / M;
+    if (res_l) res_l[0] = pg[0], res_l[1] = pg[1], res_l[2] = pg[2], res_l[3] = 1.0, res_l[4] = e / M;
   }
 }
 
@@ -1145,13 +1479,137 @@ __device__ __forceinline__ V3 cross3(const V3 &a, const V3 &b) {
 }
 __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-// Element (row, col) of a block goes to base[col * cstr + row * rstr], as in jacobian_rows.
-__device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs, int cstr,
-                          int rstr, const WinTab *tab = nullptr) {
+// ---- the rows of one line observation in pieces (line_rows runs them one after the other on one lane; the fused launch spreads
+// them over the four waves, line_rows_split).  Every value is formed by the same expression wherever its piece runs.
+// (1) residual (signed distances of the segment's end points to the projected line) and dzli = d(residual)/d(line in the IMU frame,
+//     [n; v]) at the estimate pose; Rsk = -Re skew(pe) (Hf needs it with Re)
+__device__ __forceinline__ void line_est_part(const JacParams &P, const V3 &nG, const V3 &vG, int o, const M3 &Re, const V3 &pe, double *r2, double *dzli,
+                                              M3 &Rsk) {
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
   const double *Kc = P.K;
   const double Kl[9] = {Kc[1], 0, 0, 0, Kc[0], 0, -Kc[1] * Kc[2], -Kc[0] * Kc[3], Kc[0] * Kc[1]};
+  Rsk = ms(mm(Re, skew3(pe)), -1.0);
+  const V3 nI = vadd(mv(Re, nG), mv(Rsk, vG)), vI = mv(Re, vG);
+  const M3 SR = mm(skew3(p_IinC), R_ItoC);
+  const V3 nC = vadd(mv(R_ItoC, nI), mv(SR, vI));
+  const double l3[3] = {Kl[0] * nC[0] + Kl[1] * nC[1] + Kl[2] * nC[2], Kl[3] * nC[0] + Kl[4] * nC[1] + Kl[5] * nC[2],
+                        Kl[6] * nC[0] + Kl[7] * nC[1] + Kl[8] * nC[2]};
+  const double us[3] = {(double)P.seg_uv[4 * o], (double)P.seg_uv[4 * o + 1], 1.0};
+  const double ue[3] = {(double)P.seg_uv[4 * o + 2], (double)P.seg_uv[4 * o + 3], 1.0};
+  const double lnorm = sqrt(l3[0] * l3[0] + l3[1] * l3[1]);
+  const double ds = us[0] * l3[0] + us[1] * l3[1] + us[2] * l3[2], de = ue[0] * l3[0] + ue[1] * l3[1] + ue[2] * l3[2];
+  r2[0] = ds / lnorm, r2[1] = de / lnorm;
+  const double ln_2 = l3[0] * l3[0] + l3[1] + l3[1];
+  double dzl[6] = {1, 0, 0, 0, 1, 0};
+  dzl[0] = us[0] - (l3[0] * ds) / ln_2;
+  dzl[1] = us[1] - (l3[1] * ds) / ln_2;
+  dzl[3] = ue[0] - (l3[0] * de) / ln_2;
+  dzl[4] = ue[1] - (l3[1] * de) / ln_2;
+  const double isq = 1 / sqrt(ln_2);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dzl[i] *= isq;
+  double dzK[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dzK[3 * i + j] = dzl[3 * i] * Kl[j] + dzl[3 * i + 1] * Kl[3 + j] + dzl[3 * i + 2] * Kl[6 + j];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dzli[6 * i + j] = dzK[3 * i] * R_ItoC(0, j) + dzK[3 * i + 1] * R_ItoC(1, j) + dzK[3 * i + 2] * R_ItoC(2, j);
+      dzli[6 * i + 3 + j] = dzK[3 * i] * SR(0, j) + dzK[3 * i + 1] * SR(1, j) + dzK[3 * i + 2] * SR(2, j);
+    }
+}
+// (2) d(line in the IMU frame)/d(IMU pose) at the first estimates: dli_dI = [A00 A03; A30 0]
+__device__ __forceinline__ void line_fej_part(const V3 &nG, const V3 &vG, const M3 &Rf, const V3 &pf, M3 &A00, M3 &A30, M3 &A03) {
+  A00 = skew3(mv(Rf, vsub(nG, mv(skew3(pf), vG))));
+  A30 = skew3(mv(Rf, vG));
+  A03 = mm(Rf, skew3(vG));
+}
+// x = a * dli_dI for a 2 x 6 matrix a
+__device__ __forceinline__ void line_times_dli(const double *a, const M3 &A00, const M3 &A30, const M3 &A03, double *x) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double so = 0, sp = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += a[6 * i + q] * A00(q, j);
+        sp += a[6 * i + q] * A03(q, j);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        so += a[6 * i + 3 + q] * A30(q, j);
+        sp += a[6 * i + 3 + q] * 0.0;
+      }
+      x[6 * i + j] = so;
+      x[6 * i + 3 + j] = sp;
+    }
+}
+// (3) Jacobian in the interpolated pose, noise, whitening: Wm (2 x 2), wli = Wm dzli (2 x 6), WI = wli dli_dI (2 x 6)
+__device__ __forceinline__ void line_whiten_part(const JacParams &P, int o, bool at_clone, const double *dzli, const M3 &A00, const M3 &A30, const M3 &A03,
+                                                 double *Wm, double *wli, double *WI) {
+  double HI[12];
+  line_times_dli(dzli, A00, A30, A03, HI);
+  double Rn[4] = {P.sigma_pix * P.sigma_pix, 0, 0, P.sigma_pix * P.sigma_pix};
+  if (!at_clone && P.use_pol_cov) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
+        Rn[2 * i + j] += s;
+      }
+  } else if (!at_clone && P.use_imu_cov) {
+    add_imu_cov(P, o, HI, Rn);
+  }
+  const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
+  const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
+#pragma unroll
+  for (int col = 0; col < 2; ++col) {
+    const double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+    const double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
+    const double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
+    Wm[col] = x0;
+    Wm[2 + col] = x1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    wli[j] = Wm[0] * dzli[j] + Wm[1] * dzli[6 + j];
+    wli[6 + j] = Wm[2] * dzli[j] + Wm[3] * dzli[6 + j];
+  }
+  line_times_dli(wli, A00, A30, A03, WI);
+}
+// (4) Hf = wli * G_to_I, G_to_I = [Re Rsk; 0 Re]
+__device__ __forceinline__ void line_write_hf(int c, const double *wli, const M3 &Re, const M3 &Rsk, double *hf, int cstr, int rstr) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double a = 0, b = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a += wli[6 * i + q] * Re(q, j);
+        b += wli[6 * i + q] * Rsk(q, j);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a += wli[6 * i + 3 + q] * 0.0;
+        b += wli[6 * i + 3 + q] * Re(q, j);
+      }
+      hf[(size_t)j * cstr + (2 * c + i) * rstr] = a;
+      hf[(size_t)(3 + j) * cstr + (2 * c + i) * rstr] = b;
+    }
+}
+
+// Element (row, col) of a block goes to base[col * cstr + row * rstr], as in jacobian_rows.
+__device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, int c, double *hf, double *hx, double *rs, int cstr,
+                          int rstr, const WinTab *tab = nullptr) {
   const V3 nG = ldV(P.line_FinG + 6 * l), vG = ldV(P.line_FinG + 6 * l + 3);
   Interp jac;
   if (tab)  // (window tables: the same values, see build_window_tables)
@@ -1172,155 +1630,16 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
     Re = est.R;
     pe = est.p;
   }
-  const M3 Rsk = ms(mm(Re, skew3(pe)), -1.0);
-  const V3 nI = vadd(mv(Re, nG), mv(Rsk, vG)), vI = mv(Re, vG);
-  const M3 SR = mm(skew3(p_IinC), R_ItoC);
-  const V3 nC = vadd(mv(R_ItoC, nI), mv(SR, vI));
-  const double l3[3] = {Kl[0] * nC[0] + Kl[1] * nC[1] + Kl[2] * nC[2], Kl[3] * nC[0] + Kl[4] * nC[1] + Kl[5] * nC[2],
-                        Kl[6] * nC[0] + Kl[7] * nC[1] + Kl[8] * nC[2]};
-  const double us[3] = {(double)P.seg_uv[4 * o], (double)P.seg_uv[4 * o + 1], 1.0};
-  const double ue[3] = {(double)P.seg_uv[4 * o + 2], (double)P.seg_uv[4 * o + 3], 1.0};
-  const double lnorm = sqrt(l3[0] * l3[0] + l3[1] * l3[1]);
-  const double ds = us[0] * l3[0] + us[1] * l3[1] + us[2] * l3[2], de = ue[0] * l3[0] + ue[1] * l3[1] + ue[2] * l3[2];
-  const double r2[2] = {ds / lnorm, de / lnorm};
-  const double ln_2 = l3[0] * l3[0] + l3[1] + l3[1];
-  double dzl[6] = {1, 0, 0, 0, 1, 0};
-  dzl[0] = us[0] - (l3[0] * ds) / ln_2;
-  dzl[1] = us[1] - (l3[1] * ds) / ln_2;
-  dzl[3] = ue[0] - (l3[0] * de) / ln_2;
-  dzl[4] = ue[1] - (l3[1] * de) / ln_2;
-  const double isq = 1 / sqrt(ln_2);
+  double r2[2], dzli[12], Wm[4], wli[12], WI[12];
+  M3 Rsk, A00, A30, A03;
+  line_est_part(P, nG, vG, o, Re, pe, r2, dzli, Rsk);
+  line_fej_part(nG, vG, jac.R, jac.p, A00, A30, A03);
+  line_whiten_part(P, o, rows_at_clone(P, tm), dzli, A00, A30, A03, Wm, wli, WI);
+  rows_write_res(c, Wm, r2, rs, rstr);
+  line_write_hf(c, wli, Re, Rsk, hf, cstr, rstr);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dzl[i] *= isq;
-  double dzK[6], dzli[12];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) dzK[3 * i + j] = dzl[3 * i] * Kl[j] + dzl[3 * i + 1] * Kl[3 + j] + dzl[3 * i + 2] * Kl[6 + j];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      dzli[6 * i + j] = dzK[3 * i] * R_ItoC(0, j) + dzK[3 * i + 1] * R_ItoC(1, j) + dzK[3 * i + 2] * R_ItoC(2, j);
-      dzli[6 * i + 3 + j] = dzK[3 * i] * SR(0, j) + dzK[3 * i + 1] * SR(1, j) + dzK[3 * i + 2] * SR(2, j);
-    }
-  const M3 Rf = jac.R;
-  const V3 pf = jac.p;
-  const M3 A00 = skew3(mv(Rf, vsub(nG, mv(skew3(pf), vG)))), A30 = skew3(mv(Rf, vG)), A03 = mm(Rf, skew3(vG));
-  // HI = dzli * dli_dI, dli_dI = [A00 A03; A30 0]
-  double HI[12];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double so = 0, sp = 0;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        so += dzli[6 * i + q] * A00(q, j);
-        sp += dzli[6 * i + q] * A03(q, j);
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        so += dzli[6 * i + 3 + q] * A30(q, j);
-        sp += dzli[6 * i + 3 + q] * 0.0;
-      }
-      HI[6 * i + j] = so;
-      HI[6 * i + 3 + j] = sp;
-    }
-  double Rn[4] = {P.sigma_pix * P.sigma_pix, 0, 0, P.sigma_pix * P.sigma_pix};
-  bool at_clone = false;
-  for (int i = 0; i < P.n_clones; ++i) at_clone = at_clone || P.clone_time[i] == tm;
-  if (!at_clone && P.use_pol_cov) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        double s = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) s += HI[6 * i + q] * (q < 3 ? P.intr_ori_cov : P.intr_pos_cov) * HI[6 * j + q];
-        Rn[2 * i + j] += s;
-      }
-  } else if (!at_clone && P.use_imu_cov) {
-    add_imu_cov(P, o, HI, Rn);
-  }
-  const double l00 = sqrt(Rn[0]), l10 = Rn[2] / l00, l11 = sqrt(Rn[3] - l10 * l10);
-  const double m00 = sqrt(l00), m10 = l10 / m00, m11 = sqrt(l11 - m10 * m10);
-  double Wm[4];
-#pragma unroll
-  for (int col = 0; col < 2; ++col) {
-    const double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
-    const double y0 = b0 / m00, y1 = (b1 - m10 * y0) / m11;
-    const double x1 = y1 / m11, x0 = (y0 - m10 * x1) / m00;
-    Wm[col] = x0;
-    Wm[2 + col] = x1;
-  }
-  rs[(2 * c) * rstr] = Wm[0] * r2[0] + Wm[1] * r2[1];
-  rs[(2 * c + 1) * rstr] = Wm[2] * r2[0] + Wm[3] * r2[1];
-  double wli[12];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    wli[j] = Wm[0] * dzli[j] + Wm[1] * dzli[6 + j];
-    wli[6 + j] = Wm[2] * dzli[j] + Wm[3] * dzli[6 + j];
-  }
-  // Hf = wli * G_to_I, G_to_I = [Re Rsk; 0 Re]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double a = 0, b = 0;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        a += wli[6 * i + q] * Re(q, j);
-        b += wli[6 * i + q] * Rsk(q, j);
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        a += wli[6 * i + 3 + q] * 0.0;
-        b += wli[6 * i + 3 + q] * Re(q, j);
-      }
-      hf[(size_t)j * cstr + (2 * c + i) * rstr] = a;
-      hf[(size_t)(3 + j) * cstr + (2 * c + i) * rstr] = b;
-    }
-  double WI[12];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double so = 0, sp = 0;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        so += wli[6 * i + q] * A00(q, j);
-        sp += wli[6 * i + q] * A03(q, j);
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        so += wli[6 * i + 3 + q] * A30(q, j);
-        sp += wli[6 * i + 3 + q] * 0.0;
-      }
-      WI[6 * i + j] = so;
-      WI[6 * i + 3 + j] = sp;
-    }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int col = P.clone_col[s0 + w];
-    if (col < 0) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double so = WI[6 * i] * jac.Ho[w](0, j) + WI[6 * i + 1] * jac.Ho[w](1, j) + WI[6 * i + 2] * jac.Ho[w](2, j);
-        hx[(size_t)(col + j) * cstr + (2 * c + i) * rstr] = so;  // (written once: plain stores, as in jacobian_rows)
-        hx[(size_t)(col + 3 + j) * cstr + (2 * c + i) * rstr] = WI[6 * i + 3 + j] * jac.lam[w];
-      }
-  }
-  if (P.col_dt >= 0)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      double s = 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) s += WI[6 * i + q] * jac.dtj[q];
-      hx[(size_t)P.col_dt * cstr + (2 * c + i) * rstr] = s;
-    }
+  for (int w = 0; w < 4; ++w) rows_write_pose(P.clone_col[s0 + w], c, WI, jac.Ho[w], jac.lam[w], hx, cstr, rstr);  // (written once: plain stores)
+  rows_write_dt(P, c, WI, jac.dtj, hx, cstr, rstr);
 }
 
 __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
@@ -1361,84 +1680,217 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
 // line_triangulate_kernel + this one.  Only while the selection loop has no cap to enforce (n_feat <= max_sel): a line is then
 // taken on its own merits and needs no count over the lines before it.
 struct LineTriStage {
-  int on;
+  int on, max_obs;
   double *cam, *imu;      // [n_obs][12] camera / IMU poses of the observations (scratch)
   unsigned char *valid;   // [n_obs]
   double *out_g;          // [L][6]  == P.line_FinG of the Jacobian stage
   unsigned char *ok_g;    // [L]
 };
+// The rows of every observation of the workgroup's line from the LDS slots, the pieces of line_rows spread over the four waves
+// (the line twin of jacobian_rows_split; lane = observation, two barriers):
+//   A  wave 0: d(line)/d(pose) at the first estimates | wave 1: residual + its Jacobian in the line at the estimate pose | wave 2: "at a clone"
+//   B  wave 0: Jacobian in the interpolated pose, noise, whitening
+//   C  wave w: the block of interpolation pose w; + wave 0: residual rows, time offset | wave 1: Hf
+__device__ __forceinline__ void line_rows_split(const JacParams &P, const V3 &nG, const V3 &vG, int o0, int n_o, const int *s0_l, const int *slot_l,
+                                                double *pre, double *X, int ncol, int k) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *hf = X, *hx = X + 6, *rs = X + 6 + k;
+  for (int ib = 0; ib < n_o; ib += 64) {
+    const int i = ib + lane;
+    const int c = i < n_o ? slot_l[i] : -1;
+    const int o = o0 + i;
+    double *pr = pre + (size_t)max(c, 0) * LPRE_STRIDE;
+    M3 A00, A30, A03;  // (wave 0, stage A -> B)
+    M3 Re, Rsk;        // (wave 1, stage A -> C)
+    if (c >= 0) {
+      if (wave == 0) {
+        line_fej_part(nG, vG, ldM(pr + PRE_R), ldV(pr + PRE_P), A00, A30, A03);
+      } else if (wave == 1) {
+        double r2[2], dzli[12];
+        Re = ldM(pr + PRE_RE);
+        line_est_part(P, nG, vG, o, Re, ldV(pr + PRE_PE), r2, dzli, Rsk);
+        pr[LPRE_R2] = r2[0], pr[LPRE_R2 + 1] = r2[1];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) pr[LPRE_DZLI + q] = dzli[q];
+      } else if (wave == 2) {
+        pr[LPRE_ATC] = rows_at_clone(P, P.obs_time[o] + P.cam_dt) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    if (c >= 0 && wave == 0) {
+      double dzli[12], Wm[4], wli[12], WI[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) dzli[q] = pr[LPRE_DZLI + q];
+      line_whiten_part(P, o, pr[LPRE_ATC] != 0.0, dzli, A00, A30, A03, Wm, wli, WI);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pr[LPRE_WM + q] = Wm[q];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) pr[LPRE_WLI + q] = wli[q], pr[LPRE_WI + q] = WI[q];
+    }
+    __syncthreads();
+    if (c >= 0) {
+      double WI[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) WI[q] = pr[LPRE_WI + q];
+      rows_write_pose(P.clone_col[s0_l[i] + wave], c, WI, ldM(pr + PRE_HO + 9 * wave), pr[PRE_LAM + wave], hx, 1, ncol);
+      if (wave == 0) {
+        double Wm[4], r2[2] = {pr[LPRE_R2], pr[LPRE_R2 + 1]}, dtj[6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Wm[q] = pr[LPRE_WM + q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dtj[q] = pr[PRE_DTJ + q];
+        rows_write_res(c, Wm, r2, rs, ncol);
+        rows_write_dt(P, c, WI, dtj, hx, 1, ncol);
+      } else if (wave == 1) {
+        double wli[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) wli[q] = pr[LPRE_WLI + q];
+        line_write_hf(c, wli, Re, Rsk, hf, 1, ncol);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// line_jacobian_kernel + the null-space projection (+ triangulation in front, + the gate behind) in one launch: the line twin of
+// jacobian_nullspace_kernel, same order of work (inputs to LDS, window tables, [wave 0: poses on the state Pt + plane intersection |
+// waves 1-3: both interpolations on the state P into the LDS slots], rows over four waves, compact-WY null space with six
+// reflectors, gate).  tri.on: the line is triangulated on the state Pt (LineHelper::get_line_features runs on the state before the
+// point update, lines_update linearises on the updated one: two views of the same window).  Only while the selection loop has no
+// cap to enforce (n_feat <= max_sel): a line is then taken on its own merits and needs no count over the lines before it.
 __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams P, int L, GatherArgs g, JacParams Pt, LineTriStage tri, GateStage gate) {
-  extern __shared__ double jsm[];  // X [ld][ncol] | piv [ld]
-  __shared__ WinTab tab[JAC_MAX_WIN];
-  __shared__ int s_rows, s_ok;
+  extern __shared__ double jsm[];
+  __shared__ int s_rows, s_base, s_ok;
+  __shared__ double s_line[6];
+  __shared__ double s_ct[JAC_MAX_WIN / 2 + 3];
+  __shared__ int s_ccol[JAC_MAX_WIN / 2 + 3];
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
     return;
   }
-  const int l = blockIdx.x;
-  const int ld = P.ld, k = P.k, ncol = 6 + k + 1;
-  double *X = jsm, *piv = jsm + ld * ncol;
+  const int l = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double touch = 0.0;  // (one load per 128-byte line of the input block, see JacParams::in_base; never stored)
+  for (int off = threadIdx.x * 128; off < P.in_bytes; off += 256 * 128) touch += *(const volatile double *)(P.in_base + off);
+  const int ld = P.ld, k = P.k, ncol = 6 + k + 1, max_obs = tri.max_obs, nwin = max(P.n_clones - 3, 0);
+  const FusedLds lay = fused_lds_layout(ld, ncol, 6, (tri.on ? 3 : 2) * nwin, max_obs, tri.on != 0);
+  double *X = jsm, *piv = jsm + lay.ns, *pre = jsm + lay.pre, *cam = jsm + lay.cam, *imu = cam + (size_t)max_obs * 12;
+  WinTab *tab = reinterpret_cast<WinTab *>(jsm + lay.tab);
+  double *tm_l = jsm + lay.idx;
+  float *uv_l = reinterpret_cast<float *>(tm_l + max_obs), *uvn_l = uv_l + 4 * max_obs;
+  int *s0_l = reinterpret_cast<int *>(uvn_l + 4 * max_obs), *slot_l = s0_l + max_obs, *s0t_l = slot_l + max_obs;
+  unsigned char *valid_l = reinterpret_cast<unsigned char *>(s0t_l + max_obs);
+  jac_stamp(0);
+  const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
+  if ((int)threadIdx.x < P.n_clones) s_ct[threadIdx.x] = P.clone_time[threadIdx.x], s_ccol[threadIdx.x] = P.clone_col[threadIdx.x];
+  for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) {
+    tm_l[i] = P.obs_time[o0 + i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) uv_l[4 * i + q] = P.seg_uv[4 * (o0 + i) + q];
+    if (tri.on)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) uvn_l[4 * i + q] = Pt.seg_uvn[4 * (o0 + i) + q];
+  }
   for (int i = threadIdx.x; i < ld * ncol; i += blockDim.x) X[i] = 0.0;
   if (l == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-  bool selected;
-  if (tri.on) {
-    const int o0 = Pt.obs_ptr[l], o1 = Pt.obs_ptr[l + 1];
-    for (int o = o0 + (int)threadIdx.x; o < o1; o += blockDim.x) campose_one(Pt, o, tri.cam, tri.valid, tri.imu);
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x < 64) {
+  __syncthreads();
+  P.clone_time = s_ct, P.clone_col = s_ccol, Pt.clone_time = s_ct;  // (the two states share the window: stage_line_inputs)
+  P.obs_time = Pt.obs_time = tm_l - o0;
+  P.seg_uv = uv_l - 4 * o0, Pt.seg_uvn = uvn_l - 4 * o0;
+  if (wave == 0) {
+    const int base = assign_row_slots(P, o0, o1, ld, s0_l, slot_l);
+    if (lane == 0) s_base = base;
+    jac_stamp(15);
+  } else if (wave == 1 && tri.on) {
+    for (int i = lane; i < o1 - o0; i += 64) s0t_l[i] = bounding_start(Pt, tm_l[i] + Pt.cam_dt);
+  }
+  build_window_tables(P, tab, tri.on ? &Pt : nullptr);  // (ends with a barrier: also orders the zero fill and the slots before what follows)
+  jac_stamp(2);
+  if (wave == 0) {
+    if (tri.on) {
+      // poses of the observations on the state of the triangulation (CamHelper::get_imu_poses / get_cam_poses, as campose_one)
+      for (int i = lane; i < o1 - o0; i += 64) {
+        const int s0 = s0t_l[i];
+        valid_l[i] = s0 >= 0;
+        if (s0 < 0) continue;
+        M3 R_GtoI;
+        V3 p_IinG;
+        est_pose_tab(Pt, tab[2 * nwin + s0], o0 + i, s0, R_GtoI, p_IinG);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) imu[12 * i + q] = R_GtoI.m[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) imu[12 * i + 9 + q] = p_IinG[q];
+        const M3 R_GtoC = mm(ldM(Pt.R_ItoC), R_GtoI);
+        const V3 p_CinG = vsub(p_IinG, mv(tp(R_GtoC), ldV(Pt.p_IinC)));
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cam[12 * i + q] = R_GtoC.m[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cam[12 * i + 9 + q] = p_CinG[q];
+      }
+      tri_wave_sync();
+      jac_stamp(10);
       double out_l[6] = {0, 0, 0, 0, 0, 0};
       unsigned char ok_l = 0;
-      line_triangulate_one(Pt, l, o0, o1, tri.cam, tri.imu, tri.valid, out_l, ok_l);
-      if (threadIdx.x == 0) {
+      line_triangulate_one(Pt, l, o0, o1, cam - 12 * (size_t)o0, imu - 12 * (size_t)o0, valid_l - o0, out_l, ok_l);
+      if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) tri.out_g[6 * l + i] = out_l[i];
+        for (int i = 0; i < 6; ++i) tri.out_g[6 * l + i] = out_l[i], s_line[i] = out_l[i];
         tri.ok_g[l] = ok_l;
         s_ok = ok_l;
       }
     }
-    __threadfence_block();
-    __syncthreads();
+  } else {
+    for (int i = threadIdx.x - 64; i < o1 - o0; i += 192) {
+      const int c = slot_l[i];
+      if (c < 0) continue;
+      const int s0 = s0_l[i];
+      double *pr = pre + (size_t)c * LPRE_STRIDE;
+      Interp jac;
+      interpolate_tab(P, tab[2 * s0 + 1], s0, tm_l[i] + P.cam_dt, true, jac);
+      pre_store_jac(pr, jac);
+      M3 Re;
+      V3 pe;
+      est_pose_tab(P, tab[2 * s0], o0 + i, s0, Re, pe);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) pr[PRE_RE + q] = Re.m[q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pr[PRE_PE + q] = pe[q];
+    }
+    if (gate.on) gate_prefetch_rows(gate, P.cols_in, k, threadIdx.x - 64, 192);
+  }
+  __threadfence_block();
+  __syncthreads();
+  jac_stamp(1);
+  bool selected;
+  V3 nG, vG;
+  if (tri.on) {  // (the workgroup's own result from LDS)
     selected = P.sel_flags[l] && s_ok;
+    nG = ldV(s_line), vG = ldV(s_line + 3);
   } else {
     selected = !P.tri_ok || candidate_selected(P, l);
+    nG = ldV(P.line_FinG + 6 * l), vG = ldV(P.line_FinG + 6 * l + 3);
   }
-  if (selected)
-    build_window_tables(P, tab);  // (block-uniform; ends with a barrier: also orders the zero fill before the row writes)
-  else
-    __syncthreads();
-  if (!selected) {
+  if (selected) {  // (block-uniform)
+    line_rows_split(P, nG, vG, o0, o1 - o0, s0_l, slot_l, pre, X, ncol, k);
     if (threadIdx.x == 0) {
-      s_rows = 0;
-      P.rows[l] = 0;
+      s_rows = min(2 * s_base, ld & ~1);
+      P.rows[l] = 2 * s_base;
     }
-  } else if (threadIdx.x < 64) {
-    const int o0 = P.obs_ptr[l], o1 = P.obs_ptr[l + 1];
-    int base = 0;
-    for (int ob = o0; ob < o1; ob += 64) {
-      const int o = ob + threadIdx.x;
-      const bool have = o < o1;
-      const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
-      const int s0 = have ? bounding_start(P, tm) : -1;
-      const unsigned long long vmask = __ballot(s0 >= 0);
-      const int c = base + __popcll(vmask & ((1ull << threadIdx.x) - 1ull));
-      base += __popcll(vmask);
-      if (s0 >= 0 && 2 * c + 2 <= ld) line_rows(P, l, o, s0, tm, c, X, X + 6, X + 6 + k, 1, ncol, tab);
-    }
-    if (threadIdx.x == 0) {
-      s_rows = min(2 * base, ld & ~1);
-      P.rows[l] = 2 * base;
-    }
+  } else if (threadIdx.x == 0) {
+    s_rows = 0;
+    P.rows[l] = 0;
   }
   __syncthreads();
+  jac_stamp(3);
   const int rows = s_rows;
+  GateLds &gl = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
   if ((tri.on || P.tri_ok) && rows == 0) {  // (an unselected pool line: empty system, nothing reads its block)
-    if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), l, X, ncol, 6, 0, 0, k, P.cols_in);
+    if (gate.on) gate_tail(gate, gl, l, X, ncol, 6, 0, 0, k, P.cols_in);
     return;
   }
   const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
-  if (shift) nullspace_householder(X, piv, rows, ncol, 6);
+  if (shift) nullspace_householder_wy<6>(X, piv, rows, ncol);
+  jac_stamp(4);
   double *hf = P.Hf + (size_t)l * 6 * ld, *hx = P.Hx + (size_t)l * k * ld, *rs = P.res + (size_t)l * ld;
   for (int j = gate.on ? ncol : (int)threadIdx.x; j < ncol; j += blockDim.x) {  // (not written when the gate follows in this launch)
     double *dst = j < 6 ? hf + j * ld : (j < 6 + k ? hx + (size_t)(j - 6) * ld : rs);
@@ -1455,7 +1907,10 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
         if (i0 + u < ld) dst[i0 + u] = v[u];
     }
   }
-  if (gate.on) gate_tail(gate, *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off), l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
+  jac_stamp(5);
+  if (gate.on) gate_tail(gate, gl, l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
+  if (touch == 1.2345678e300) P.rows[l] = -1;  // (never: keeps the touch loads)
+  jac_stamp(9);
 }
 
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
@@ -1550,6 +2005,70 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
   ok = 1;
 }
 
+// PLV_KERNEL_STAMPS=1: per-phase cycle stamps of the projected Jacobian launches (see jac_stamp): offsets from the workgroup's start,
+// mean and max over the workgroups that went all the way (entries the selection took), printed when the library unloads.
+#define TRY_STAMP(x)          \
+  do {                        \
+    const int _rc = (x);      \
+    if (_rc != PLV_OK) return _rc; \
+  } while (0)
+struct JacStampHost {
+  bool on = getenv("PLV_KERNEL_STAMPS") != nullptr;
+  long long *d = nullptr;
+  int cap = 0;
+  struct Acc {
+    const char *name;
+    double sum[JAC_NSTAMP] = {}, mx[JAC_NSTAMP] = {}, slowest = 0;
+    long n[JAC_NSTAMP] = {}, launches = 0;
+  } acc[2] = {{"tri_jacobian_nullspace_kernel"}, {"line_tri_jacobian_nullspace_kernel"}};
+  int arm(hipStream_t s, int blocks) {
+    if (blocks > cap) {
+      if (d) (void)hipFree(d);
+      cap = blocks + 64;
+      PLV_HIP_CHECK(hipMalloc(&d, (size_t)cap * JAC_NSTAMP * 8));
+      PLV_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_jac_stamps), &d, sizeof(d)));
+    }
+    PLV_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)blocks * JAC_NSTAMP * 8, s));
+    return PLV_OK;
+  }
+  int collect(hipStream_t s, int blocks, int which) {
+    PLV_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<long long> h((size_t)blocks * JAC_NSTAMP);
+    PLV_HIP_CHECK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    Acc &a = acc[which];
+    double slow = 0;
+    for (int b = 0; b < blocks; ++b) {
+      const long long *t = &h[(size_t)b * JAC_NSTAMP];
+      if (!t[0] || !t[9]) continue;
+      slow = std::max(slow, (double)(t[9] - t[0]));
+      if (!t[4]) continue;  // (not taken: no rows)
+      for (int i = 1; i < JAC_NSTAMP; ++i)
+        if (t[i]) a.sum[i] += (double)(t[i] - t[0]), a.mx[i] = std::max(a.mx[i], (double)(t[i] - t[0])), ++a.n[i];
+    }
+    a.slowest += slow;
+    ++a.launches;
+    return PLV_OK;
+  }
+  ~JacStampHost() {
+    if (!on) return;
+    static const char *label[JAC_NSTAMP] = {"start", "triangulated", "window tables", "rows built", "null space", "block written", "gate: T", "gate: S",
+                                            "gate: factor", "end", "tri: camera poses", "tri: linear solve", "tri: refined", "gate: map staged", "gate: T first column", "row slots",
+                                            "LM pass 1", "LM pass 2", "LM pass 3", "LM pass 4", "LM pass 5", "LM pass 6", "LM pass 7", "LM pass 8", "LM pass 9", "LM pass 10", "LM pass 11", "LM pass 12+",
+                                            "", "", "", ""};
+    static const int order[] = {15, 2, 10, 11, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 12, 1, 3, 4, 5, 13, 14, 6, 7, 8, 9};
+    for (const Acc &a : acc) {
+      if (!a.launches) continue;
+      fprintf(stderr, "[plv stamps] %s: %ld launches, slowest workgroup %.0f cycles on average\n", a.name, a.launches, a.slowest / (double)a.launches);
+      for (int i : order)
+        if (a.n[i]) fprintf(stderr, "[plv stamps]   %-20s @ %8.0f mean  %8.0f max  (%ld workgroups)\n", label[i], a.sum[i] / (double)a.n[i], a.mx[i], a.n[i]);
+    }
+  }
+};
+static JacStampHost &jac_stamps() {
+  static JacStampHost h;
+  return h;
+}
+
 int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
   ProfScope ps(ctx->prof, "line_jacobian_kernel", ctx->stream);
   hipLaunchKernelGGL(line_jacobian_kernel, dim3(P.n_feat), dim3(64), 0, ctx->stream, P);
@@ -1558,32 +2077,36 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P) {
 }
 
 int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const JacParams *Pt, double *d_cam,
-                                    double *d_imu, unsigned char *d_valid, double *d_lines, unsigned char *d_ok) {
+                                    double *d_imu, unsigned char *d_valid, double *d_lines, unsigned char *d_ok, int max_obs) {
   ProfScope ps(ctx->prof, Pt ? "line_tri_jacobian_nullspace_kernel" : "line_jacobian_nullspace_kernel", ctx->stream);
   if (2 * (P.n_clones - 3) > JAC_MAX_WIN) {
     set_last_error("line jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
     return PLV_E_CAPACITY;
   }
-  size_t shm = (size_t)(P.ld * (6 + P.k + 1) + P.ld) * sizeof(double);
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 64 > 160 * 1024) {
+  max_obs = std::max(max_obs, 1);
+  const FusedLds lay = fused_lds_layout(P.ld, 6 + P.k + 1, 6, (Pt ? 3 : 2) * std::max(P.n_clones - 3, 0), max_obs, Pt != nullptr);
+  size_t shm = (size_t)lay.end * sizeof(double);
+  if (shm + 1024 > 160 * 1024) {
     set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
   GatherArgs none{};
-  LineTriStage tri{Pt ? 1 : 0, d_cam, d_imu, d_valid, d_lines, d_ok};
+  LineTriStage tri{Pt ? 1 : 0, max_obs, d_cam, d_imu, d_valid, d_lines, d_ok};
   GateStage gate = ctx->gate_stage;
   ctx->gate_stage.on = 0;  // (one launch takes it)
-  const size_t gate_off = (shm + 63) & ~(size_t)63;
-  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + sizeof(WinTab) * JAC_MAX_WIN + 512 > 160 * 1024) gate.on = 0;
+  const size_t gate_off = ((size_t)lay.tab * sizeof(double) + 63) & ~(size_t)63;  // (overlays tables and slots: fused_lds_layout)
+  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + 1024 > 160 * 1024) gate.on = 0;
   if (gate.on) {
     gate.lds_off = (int)gate_off;
-    shm = gate_off + sizeof(GateLds);
+    shm = std::max(shm, gate_off + sizeof(GateLds));
   }
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
+  if (jac_stamps().on) TRY_STAMP(jac_stamps().arm(ctx->stream, P.n_feat));
   hipLaunchKernelGGL(line_jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
                      g ? *g : none, Pt ? *Pt : P, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
+  if (jac_stamps().on) TRY_STAMP(jac_stamps().collect(ctx->stream, P.n_feat, 1));
   return PLV_OK;
 }
 
@@ -1621,29 +2144,33 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
     set_last_error("jacobians: %d clones exceed the window table (%d)", P.n_clones, JAC_MAX_WIN / 2 + 3);
     return PLV_E_CAPACITY;
   }
-  const size_t tri_shm = tri_opt ? (size_t)std::max(max_obs, 1) * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 : 0;
-  size_t shm = (size_t)(P.ld * (3 + P.k + 1) + P.ld) * sizeof(double) + tri_shm;
-  if (shm + sizeof(WinTab) * JAC_MAX_WIN + 256 > 160 * 1024) {
+  max_obs = std::max(max_obs, 1);
+  const FusedLds lay = fused_lds_layout(P.ld, 3 + P.k + 1, 3, 2 * std::max(P.n_clones - 3, 0), max_obs, tri_opt != nullptr);
+  size_t shm = (size_t)lay.end * sizeof(double);
+  if (shm + 1024 > 160 * 1024) {
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
   GatherArgs none{};
   PointTriStage tri{};
-  if (tri_opt) tri = PointTriStage{1, std::max(max_obs, 1), d_poses, d_valid, d_uvn, *tri_opt, d_p, d_ok, d_err};
+  tri.max_obs = max_obs;
+  if (tri_opt) tri = PointTriStage{1, max_obs, d_poses, d_valid, d_uvn, *tri_opt, d_p, d_ok, d_err};
   GateStage gate = ctx->gate_stage;
   ctx->gate_stage.on = 0;  // (one launch takes it)
-  // the gate's LDS block sits behind the entry's block in the launch's dynamic shared memory: taken only where both fit
-  const size_t gate_off = (shm + 63) & ~(size_t)63;
-  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + sizeof(WinTab) * JAC_MAX_WIN + 512 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
+  // the gate's LDS block overlays tables, scratch and slots (fused_lds_layout): taken where it fits behind the entry's block
+  const size_t gate_off = ((size_t)lay.tab * sizeof(double) + 63) & ~(size_t)63;
+  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + 1024 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
   if (gate.on) {
     gate.lds_off = (int)gate_off;
-    shm = gate_off + sizeof(GateLds);
+    shm = std::max(shm, gate_off + sizeof(GateLds));
   }
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
+  if (jac_stamps().on) TRY_STAMP(jac_stamps().arm(ctx->stream, P.n_feat));
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
                      g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
+  if (jac_stamps().on) TRY_STAMP(jac_stamps().collect(ctx->stream, P.n_feat, 0));
   return PLV_OK;
 }
 

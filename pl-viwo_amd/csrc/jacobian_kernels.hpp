@@ -38,6 +38,10 @@ struct JacParams {
   const unsigned char *sel_flags, *tri_ok;
   const double *tri_err;
   int max_sel;
+  // the packed input block all the pointers above lead into (stage_inputs): the fused launches touch its lines first thing, so that
+  // the chains of dependent loads behind (obs_ptr -> obs_time -> clone poses) meet one cold miss, not one each
+  const char *in_base;
+  int in_bytes;
   // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
   int use_imu_cov;
   double intr_err_mlt;
@@ -64,7 +68,7 @@ int launch_line_jacobians(plv_ctx *ctx, const JacParams &P);
 // Pt != null: every workgroup first triangulates its line on the state Pt (scratch and results as launch_triangulate_lines takes them)
 int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArgs *g, int gather_blocks, const JacParams *Pt = nullptr,
                                     double *d_cam = nullptr, double *d_imu = nullptr, unsigned char *d_valid = nullptr, double *d_lines = nullptr,
-                                    unsigned char *d_ok = nullptr);
+                                    unsigned char *d_ok = nullptr, int max_obs = 0);
 int launch_triangulate_lines(plv_ctx *ctx, const JacParams &P, double *d_poses, double *d_imu, unsigned char *d_valid,
                              double *d_lines, unsigned char *d_ok);
 int launch_triangulate(plv_ctx *ctx, const JacParams &P, double *d_poses, unsigned char *d_valid, const float *d_uvn,

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "wave_ops.hpp"
+
 namespace plv {
 
 // Same rotation on the latency-critical path of the nullspace kernel: the chain of rows-1 dependent
@@ -175,6 +177,125 @@ __device__ __forceinline__ void nullspace_householder(double *X, double *piv, in
         }
         for (; i < rows; ++i) X[i * ncol + j] = fma(-piv[i], w, X[i * ncol + j]);
       }
+    }
+  }
+  __syncthreads();
+}
+
+// The Householder projection in compact form (round 4).  nullspace_householder spends a reflection on: every thread forming the
+// reflector from the pivot column (a chain over the rows, sqrt, divide), a dot product over the rows, an update pass, two barriers —
+// 2.6 us each at 30 rows, three (points) or six (lines) in sequence.  Here wave 0 factors the rows x FD panel Hf alone, one lane
+// per row with DPP wave sums (the FD reflectors v_n, tau_n and their Gram matrix G), and every other column is then projected in ONE
+// pass: d_n = v_n . x for all n at once (FD independent chains), w_n = tau_n (d_n - sum_{b<n} G_nb w_b) — what the reflections
+// applied one after the other would have used — and x -= sum_n v_n w_n.  The same orthogonal transformation up to rounding.
+// scratch: nullspace_wy_scratch(ld, FD) doubles.  rows <= 64 (one lane per row), else the reflection-by-reflection form.
+__host__ __device__ inline int nullspace_wy_scratch(int ld, int fd) { return ld * fd + fd + fd * fd + 2; }
+__device__ __forceinline__ double ns_readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+template <int FD> __device__ __forceinline__ void nullspace_householder_wy(double *X, double *scr, int rows, int ncol) {
+  if (rows > 64) {
+    nullspace_householder(X, scr, rows, ncol, FD);
+    return;
+  }
+  double *V = scr, *tau = scr + rows * FD, *G = tau + FD;  // V [rows][FD], G [FD][FD] (entries a > b)
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double a[FD], v[FD], t[FD];
+#pragma unroll
+    for (int c = 0; c < FD; ++c) a[c] = lane < rows ? X[lane * ncol + c] : 0.0;
+#pragma unroll
+    for (int n = 0; n < FD; ++n) {
+      const double xn = lane >= n ? a[n] : 0.0;
+      const double nrm2 = wave_sum_f64(xn * xn);
+      v[n] = 0.0, t[n] = 0.0;
+      if (nrm2 == 0.0) continue;  // (uniform) nothing to eliminate
+      const double x0 = ns_readlane_f64(a[n], n);
+      const double nrm = sqrt(nrm2);
+      const double alpha = x0 >= 0.0 ? -nrm : nrm;  // v = x - alpha e1 without cancellation
+      t[n] = 1.0 / (nrm2 - alpha * x0);             // 2 / v^T v
+      v[n] = lane == n ? x0 - alpha : xn;
+      if (lane < n) v[n] = 0.0;
+      double w[FD];
+#pragma unroll
+      for (int c = n + 1; c < FD; ++c) w[c] = wave_sum_f64(v[n] * a[c]);
+#pragma unroll
+      for (int c = n + 1; c < FD; ++c) a[c] = fma(-v[n], t[n] * w[c], a[c]);
+      a[n] = lane == n ? alpha : (lane > n ? 0.0 : a[n]);
+    }
+    double gm[FD * FD];
+#pragma unroll
+    for (int p = 1; p < FD; ++p)
+#pragma unroll
+      for (int q = 0; q < p; ++q) gm[p * FD + q] = wave_sum_f64(v[p] * v[q]);
+    if (lane < rows) {
+#pragma unroll
+      for (int c = 0; c < FD; ++c) X[lane * ncol + c] = a[c], V[lane * FD + c] = v[c];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < FD; ++c) tau[c] = t[c];
+#pragma unroll
+      for (int p = 1; p < FD; ++p)
+#pragma unroll
+        for (int q = 0; q < p; ++q) G[p * FD + q] = gm[p * FD + q];
+    }
+  }
+  __syncthreads();
+  for (int j = FD + threadIdx.x; j < ncol; j += blockDim.x) {
+    double d[FD];
+#pragma unroll
+    for (int c = 0; c < FD; ++c) d[c] = 0.0;
+    int i = 0;
+    for (; i + 4 <= rows; i += 4) {
+      double x[4], vv[4][FD];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = X[(i + u) * ncol + j];
+#pragma unroll
+        for (int c = 0; c < FD; ++c) vv[u][c] = V[(i + u) * FD + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < FD; ++c) d[c] = fma(vv[u][c], x[u], d[c]);
+    }
+    for (; i < rows; ++i) {
+      const double x = X[i * ncol + j];
+#pragma unroll
+      for (int c = 0; c < FD; ++c) d[c] = fma(V[i * FD + c], x, d[c]);
+    }
+    double w[FD];
+#pragma unroll
+    for (int c = 0; c < FD; ++c) {
+      double sacc = d[c];
+#pragma unroll
+      for (int b = 0; b < c; ++b) sacc = fma(-G[c * FD + b], w[b], sacc);
+      w[c] = tau[c] * sacc;
+    }
+    i = 0;
+    for (; i + 4 <= rows; i += 4) {
+      double x[4], vv[4][FD];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = X[(i + u) * ncol + j];
+#pragma unroll
+        for (int c = 0; c < FD; ++c) vv[u][c] = V[(i + u) * FD + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int c = 0; c < FD; ++c) x[u] = fma(-vv[u][c], w[c], x[u]);
+        X[(i + u) * ncol + j] = x[u];
+      }
+    }
+    for (; i < rows; ++i) {
+      double x = X[i * ncol + j];
+#pragma unroll
+      for (int c = 0; c < FD; ++c) x = fma(-V[i * FD + c], w[c], x);
+      X[i * ncol + j] = x;
     }
   }
   __syncthreads();
