@@ -419,6 +419,7 @@ def main():
             fw = ctypes.CDLL(os.environ["PLV_BENCH_FAULTWHERE"])
             if fw.fw_start() != 0:
                 fw = None
+        chain0 = pkg.chain_count()
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if hook:
@@ -466,6 +467,7 @@ def main():
             cnt["redone_frames"] += 1 if route == 3 else 0
             cnt["whitened_frames"] += 1 if route == 4 else 0
         ctx.synchronize()
+        cnt["chained"] = pkg.chain_count() - chain0
         if fw:
             fw.fw_stop(os.environ.get("PLV_BENCH_FAULTWHERE_OUT", "").encode())
             m = np.mean(np.array(fw_ru, float), axis=0)
@@ -695,7 +697,8 @@ def main():
                               "lines_accepted": round(stats["lines_accepted"] / args.steps, 3)},
                 "submissions_per_frame": {"kernel_launches": round(cnt["launches"] / args.steps, 1), "host_synchronisations": round(cnt["syncs"] / args.steps, 1),
                                           "copies": round(cnt["copies"] / args.steps, 1), "copy_kB": round(cnt["copy_bytes"] / args.steps / 1024, 1),
-                                          "lk_iterations": round(cnt["lk_iters"] / args.steps)},
+                                          "lk_iterations": round(cnt["lk_iters"] / args.steps),
+                                          "line_launches_chained_behind_the_point_update": round(cnt.get("chained", 0) / args.steps, 2)},
                 "updates": {"point_updates": stats["cam_updates"], "line_updates": stats["line_updates"], "not_psd": stats["not_psd"],
                             "frames": args.steps},
                 "images": "resident in HBM (plv_image_stage between the steps); config.pcie_inclusive has the host-buffer variant",

@@ -166,6 +166,7 @@ def load_library():
         "plv_update_compression_mode": (C.c_int, [vp, C.c_int, ip, ip]),
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
+        "plv_chain_count": (C.c_ulonglong, []),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
@@ -702,6 +703,11 @@ def phase_counters():
 def alloc_count():
     """plv_alloc_count (measurement aid): device / pinned buffer (re)allocations since the library was loaded"""
     return int(load_library().plv_alloc_count())
+
+
+def chain_count():
+    """plv_chain_count (measurement aid): line launches plv_camera_try_update enqueued behind a point update that was still running"""
+    return int(load_library().plv_chain_count())
 
 
 def debug_knobs(mask=-1):

@@ -178,10 +178,12 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
 
 // builds the batch into us->bHf ([Hf | Hx | res]) and us->brows on the device
 // the column map as the host staged it: same offset in the pinned block as in the device copy (or the pinned block itself)
-static const int *host_copy_of(plv_ctx_update_state *us, const int *cols_in) {
-  const char *c = (const char *)cols_in, *hj = us->h_jin.as<char>();
-  if (c >= hj && c < hj + us->h_jin.cap) return cols_in;
-  return (const int *)(hj + (c - us->jin.as<char>()));
+static const int *host_copy_of(plv_ctx_update_state *us, const int *cols_in, bool lines = false) {
+  plv::PinBuf &hb = lines ? us->h_jin_l : us->h_jin;
+  plv::DevBuf &db = lines ? us->jin_l : us->jin;
+  const char *c = (const char *)cols_in, *hj = hb.as<char>();
+  if (c >= hj && c < hj + hb.cap) return cols_in;
+  return (const int *)(hj + (c - db.as<char>()));
 }
 struct FusedTri {  // triangulate on the device first and let the Jacobian launch take its candidates from the result
   const plv_tri_options *opt;
@@ -338,6 +340,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   TRY(plv_update_gate_prepare(ctx, all->n_feat, 3, k, ld, sigma2, chi2_mult, res_norm_gate, 0));
   TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
   ph_a.stop();
+  plv::frame_mark("@ point Jacobian launch enqueued");
   if (chain_events) (void)hipEventRecord(ce[1], ctx->stream);
   us->b_single_use = true;
   const int F = all->n_feat;
@@ -346,12 +349,20 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   // the triangulation results reach the host with the update's result block (copied by its last kernel), or by a copy command when
   // the chain ended another way; either lands before the wait below returns
   ctx->mirror2_src = us->tri.as<char>() + ft.o_p, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = (size_t)F * 33, ctx->mirror2_taken = false;
+  // (for a line launch chained behind this update, plv_camera_try_update: the commit kernel leaves "state changed" in a device word)
+  TRY(us->chain_words.reserve(64));
+  us->applied_word = us->chain_words.as<int>();
+  ctx->applied_word = us->compress_mode == 2 ? nullptr : us->applied_word, ctx->applied_used = false;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
+  us->applied_armed = rc == PLV_OK && ctx->applied_used;
+  ctx->applied_word = nullptr, ctx->applied_used = false;
+  us->pt_tri_p = (const double *)(us->tri.as<char>() + ft.o_p), us->pt_tri_ok = (const unsigned char *)(us->tri.as<char>() + ft.o_ok), us->pt_tri_F = F;
   const bool mirrored = ctx->mirror2_taken;
   ctx->mirror2_src = nullptr, ctx->mirror2_dst = nullptr, ctx->mirror2_bytes = 0, ctx->mirror2_taken = false;
   if (!mirrored)
     PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
   ph_b.stop();
+  plv::frame_mark("@ point chain enqueued");
   if (chain_events) (void)hipEventRecord(ce[2], ctx->stream);
   plv::HostPhase ph_c("points fused: host work inside the wait");
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
@@ -362,17 +373,19 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
       if (us->word_seq) return __atomic_load_n((const unsigned *)ctx->done_word(16), __ATOMIC_ACQUIRE) != us->word_seq;
       return hipEventQuery(us->done_ev) == hipErrorNotReady;
     };
-    while (running()) {
+    while (running() || plv::knob(plv::PLV_KNOB_CHAIN_ALWAYS)) {
       if (ctx->wait_poll(ctx->wait_poll_arg)) break;
       for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
     }
   }
   ph_c.stop();
+  plv::frame_mark("@ host work inside the point wait done");
   plv::NsScope ns_pw(plv::counters().points_wait_ns);
   plv::HostPhase ph_d("points fused: wait");
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)
   if (rc != PLV_OK || !mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));      // (the copy command enqueued behind it)
   ph_d.stop();
+  plv::frame_mark("@ point update collected");
   if (chain_events) {
     const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
     (void)hipEventSynchronize(ce[2]);
@@ -508,15 +521,35 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
                o_cols = take(4 * (size_t)k), o_xfl = ex && ex->flags ? take(L) : 0;
   const bool two_states = st_tri && Pt && st_tri != st && st_tri->n_clones == N;
   const size_t o_tR = two_states ? take(72 * N) : 0, o_tp = two_states ? take(24 * N) : 0;
+  // chained launch (plv_ctx::chain): quaternions + covariance indices for the kernel's own x (+) dx, anchor candidates
+  const plv_ctx::ChainState &ch = ctx->chain;
+  const bool chained = ch.on && ch.ready && !two_states && (int)ch.q.size() == 4 * N && (int)ch.ids.size() == N + 3 && (int)ch.anc_ptr.size() == L + 1;
+  const size_t n_anc = chained ? ch.anc_f.size() : 0;
+  const size_t o_cq = chained ? take(32 * (size_t)N) : 0, o_cid = chained ? take(4 * (size_t)(N + 3)) : 0, o_aptr = chained ? take(4 * (size_t)(L + 1)) : 0,
+               o_af = chained ? take(4 * n_anc + 4) : 0, o_aho = chained ? take(n_anc + 4) : 0, o_aold = chained ? take(24 * n_anc + 8) : 0;
+  if (ch.on && !chained) {
+    set_last_error("line jacobians: chained launch asked for without its state");
+    return PLV_E_BADARG;
+  }
   const size_t total = off;
-  TRY(us->h_jin.reserve(total));
-  TRY(us->jin.reserve(total));
-  char *h = us->h_jin.as<char>();
+  TRY(us->h_jin_l.reserve(total));
+  TRY(us->jin_l.reserve(total));
+  char *h = us->h_jin_l.as<char>();
   memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
   if (ex && ex->flags) memcpy(h + o_xfl, ex->flags, L);
   if (two_states) {
     memcpy(h + o_tR, st_tri->clone_R, 72 * N);
     memcpy(h + o_tp, st_tri->clone_p, 24 * N);
+  }
+  if (chained) {
+    memcpy(h + o_cq, ch.q.data(), 32 * (size_t)N);
+    memcpy(h + o_cid, ch.ids.data(), 4 * (size_t)(N + 3));
+    memcpy(h + o_aptr, ch.anc_ptr.data(), 4 * (size_t)(L + 1));
+    if (n_anc) {
+      memcpy(h + o_af, ch.anc_f.data(), 4 * n_anc);
+      memcpy(h + o_aho, ch.anc_has_old.data(), n_anc);
+      memcpy(h + o_aold, ch.anc_old.data(), 24 * n_anc);
+    }
   }
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
@@ -549,8 +582,8 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
   // few times; what a workgroup reuses it keeps in LDS)
   const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
-  if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-  const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
+  if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin_l.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  const char *d = pinned_inputs ? (const char *)h : us->jin_l.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
   P.clone_R = (const double *)(d + o_R);
@@ -592,6 +625,20 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   P.in_base = d;
   P.in_bytes = (int)total;
   P.cols_out = nullptr;
+  if (chained) {
+    auto *us2 = us;
+    P.chain_dx = us2->result.as<double>();  // (dx leads the status block of the update launched last: the point update)
+    P.chain_applied = us2->applied_word;
+    P.chain_q = (const double *)(d + o_cq);
+    P.chain_id = (const int *)(d + o_cid);
+    memcpy(P.chain_qe, ch.qe, 32);
+    P.anc_ptr = (const int *)(d + o_aptr);
+    P.anc_f = (const int *)(d + o_af);
+    P.anc_has_old = (const unsigned char *)(d + o_aho);
+    P.anc_old = (const double *)(d + o_aold);
+    P.anc_tri_p = us2->pt_tri_p;
+    P.anc_tri_ok = us2->pt_tri_ok;
+  }
   if (ex) ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
   if (Pt) {
     *Pt = P;
@@ -635,8 +682,8 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     const int nobs = lt->obs_ptr[L];
     const size_t o_cam = 0, o_imu = (size_t)nobs * 96, o_lines = o_imu + (size_t)nobs * 96, o_ok = o_lines + (size_t)L * 48,
                  o_valid = (o_ok + L + 15) & ~(size_t)15, total = o_valid + nobs + 16;
-    TRY(us->tri.reserve(total));
-    char *d = us->tri.as<char>();
+    TRY(us->tri_l.reserve(total));
+    char *d = us->tri_l.as<char>();
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
     fuse_tri = project && L <= ft->max_sel && !getenv("PLV_LINE_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_LINE_TRI_SEPARATE);
     tri_cam = (double *)(d + o_cam), tri_imu = (double *)(d + o_imu), tri_valid = (unsigned char *)(d + o_valid);
@@ -677,7 +724,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     else
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, line_max_obs));
     if (can_gather)
-      TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in), k, L, ld - 6));
+      TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in, true), k, L, ld - 6));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {
@@ -700,34 +747,53 @@ extern "C" {
 // The line twin (plv_camera_update_lines): line triangulation, selection, Pluecker Jacobians, null space, gate, compression, EKF.
 // st_tri: the state the lines are triangulated on (the one before the point update, plv_camera_get_line_features); the Jacobians
 // are taken at st.
-int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
-                           const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
-                           double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *),
-                           void *before_wait_arg) {
-  if (!ctx || !all || !flags || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
+// The line half's one-submission update in two steps: `submit` stages the pool and enqueues triangulation + Jacobians + null space +
+// gate (one launch, the gate's verdicts and the triangulated lines go to pinned memory); `finish` waits for the gate, enqueues
+// compression + EKFUpdate only when something was accepted, and collects.  plv_camera_try_update calls `submit` while the point
+// update of the frame is still running (plv_ctx::chain.on: the launch then forms the corrected state itself, JacParams::chain_dx).
+int plv_lines_update_fused_submit(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
+                                  const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult) {
+  if (!ctx || !all || !flags) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
   FusedLineTri ft{flags, max_sel, 0, 0, st_tri};
   const int L = all->n_lines;
-  TRY(us->h_tri.reserve((size_t)L * 49 + 16));
+  TRY(us->h_tri_l.reserve((size_t)L * 49 + 16));
   TRY(plv_update_gate_prepare(ctx, L, 6, k, ld, sigma2, chi2_mult, 0.0, 1));
-  ctx->gate_stage.probe_dst = (unsigned char *)us->h_tri.p;  // (probe_src and the strides: build_lines_on_device, where the results' place is decided)
+  ctx->gate_stage.probe_dst = (unsigned char *)us->h_tri_l.p;  // (probe_src and the strides: build_lines_on_device, where the results' place is decided)
   TRY(build_lines_on_device(ctx, us, st, all, k, col_to_state, ld, true, &ft));
   us->b_single_use = true;
+  us->lt_o_lines = ft.o_lines, us->lt_L = L;
+  return PLV_OK;
+}
+int plv_lines_update_fused_finish(plv_ctx *ctx, double sigma2, double chi2_mult, double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows,
+                                  double *dx, void (*before_wait)(void *), void *before_wait_arg) {
+  if (!ctx || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  auto *us = plv_update_state(ctx);
+  const int L = us->lt_L;
   // the gate's workgroups leave their verdicts and the triangulated lines in pinned memory and the launch function looks at them
   // before it enqueues compression + EKF (plv_ctx::probe): a line update in which nothing passes the gate ends there
   ctx->probe = true, ctx->probe_done = false;
-  ctx->probe_src = us->tri.as<char>() + ft.o_lines, ctx->probe_dst = us->h_tri.p;
+  ctx->probe_src = us->tri_l.as<char>() + us->lt_o_lines, ctx->probe_dst = us->h_tri_l.p;
   ctx->probe_stride_a = 48, ctx->probe_off_b = L * 48, ctx->probe_stride_b = 1;
   ctx->probe_hook = before_wait, ctx->probe_hook_arg = before_wait_arg;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, 0.0);
   ctx->probe = false, ctx->probe_src = nullptr, ctx->probe_dst = nullptr, ctx->probe_hook = nullptr, ctx->probe_hook_arg = nullptr;
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);
   else PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
-  const char *h = us->h_tri.as<char>();
+  const char *h = us->h_tri_l.as<char>();
   memcpy(lines_out, h, (size_t)L * 48);
   memcpy(ok_out, h + (size_t)L * 48, (size_t)L);
   return rc;
+}
+int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
+                           const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
+                           double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx, void (*before_wait)(void *),
+                           void *before_wait_arg) {
+  if (!ctx || !all || !flags || !lines_out || !ok_out || !accepted || !dx) return PLV_E_BADARG;
+  TRY(plv_lines_update_fused_submit(ctx, st, st_tri, all, flags, max_sel, k, col_to_state, ld, sigma2, chi2_mult));
+  return plv_lines_update_fused_finish(ctx, sigma2, chi2_mult, lines_out, ok_out, accepted, n_rows, dx, before_wait, before_wait_arg);
 }
 
 int plv_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *lt, int *col_to_state, int cap, int *k_out) {

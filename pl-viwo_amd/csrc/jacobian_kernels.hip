@@ -431,9 +431,9 @@ __device__ bool candidate_selected(const JacParams &P, int f) {
 // row-major in LDS, projected there (nullspace_core.hpp) and only the projected block goes to global memory — one launch, one
 // 1.7 MB write and one 1.7 MB read less on the update chain.  The covariance gathers of the update ride on it as extra workgroups
 // (they read the column map from the packed input block: the resident copy is being written by workgroup 0).
-__device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
+__device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, double *poses, unsigned char *valid, const float *uvn, const float *uv,
                                     const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
-                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, int obase = 0, bool poses_ready = false,
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, bool poses_ready = false,
                                     double *res_l = nullptr);
 // tri.on: the workgroup's first wave triangulates the feature before the Jacobians are built (what triangulate_kernel did in a launch
 // of its own) — while the selection loop has no cap to enforce (n_feat <= max_sel) a candidate is taken on its own verdict.
@@ -509,8 +509,8 @@ __device__ void jacobian_rows(const JacParams &P, const WinTab *tab, int f, int 
 // expression wherever its piece runs.
 // (1) residual at the estimate pose (CamBase::distort_d rounds through float both ways) + distortion Jacobians at the estimate's
 //     normalised coordinates
-__device__ __forceinline__ void rows_est_part(const JacParams &P, const V3 &pf, int o, const M3 &R_GtoI, const V3 &p_IinG, double *r2, double *dzn,
-                                              double *dzeta) {
+__device__ __forceinline__ void rows_est_part(const JacParams &P, const V3 &pf, const float *uv /* the observation's image point */, const M3 &R_GtoI,
+                                              const V3 &p_IinG, double *r2, double *dzn, double *dzeta) {
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
   const double *K = P.K;
@@ -522,8 +522,8 @@ __device__ __forceinline__ void rows_est_part(const JacParams &P, const V3 &pf, 
     const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
     const double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
     const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
-    r2[0] = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
-    r2[1] = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
+    r2[0] = (double)uv[0] - (double)(float)(K[0] * x1 + K[2]);
+    r2[1] = (double)uv[1] - (double)(float)(K[1] * y1 + K[3]);
   }
   {
     const double x = un, y = vn;
@@ -707,7 +707,7 @@ __device__ void jacobian_rows_core(const JacParams &P, int f, int o, int s0, dou
   M3 dpC_dpG;
   V3 lever;
   const V3 pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
-  rows_est_part(P, pf, o, R_GtoI, p_IinG, r2, dzn, dzeta);
+  rows_est_part(P, pf, P.obs_uv + 2 * o, R_GtoI, p_IinG, r2, dzn, dzeta);
   rows_fej_part(P, pf_fej, jac.R, jac.p, dznp, dpC_dpG, dpC_dI, lever);
   rows_whiten_part(P, o, rows_at_clone(P, tm), dzn, dznp, dpC_dI, Wm, wz, WI);
   rows_write_res(c, Wm, r2, rs, rstr);
@@ -764,13 +764,13 @@ __device__ __forceinline__ void pre_load_jac(const double *pre, Interp &j) {
 // Row slots of a feature's observations (wave 0 of the workgroup): slot = number of observations with bounding clones in front of it
 // (ballot prefix), -1 for an observation without a row pair.  s0 = first clone of its interpolation window or -1.  Returns the
 // number of observations with bounding clones.
-__device__ __forceinline__ int assign_row_slots(const JacParams &P, int o0, int o1, int ld, int *s0_l, int *slot_l) {
+__device__ __forceinline__ int assign_row_slots(const JacParams &P, int o0, int o1, int ld, const double *tm_l /* times of o0 .. */, int *s0_l, int *slot_l) {
   const int lane = threadIdx.x & 63;
   int base = 0;
   for (int ob = o0; ob < o1; ob += 64) {
     const int o = ob + lane;
     const bool have = o < o1;
-    const double tm = (have ? P.obs_time[o] : 0.0) + P.cam_dt;
+    const double tm = (have ? tm_l[o - o0] : 0.0) + P.cam_dt;
     const int s0 = have ? bounding_start(P, tm) : -1;
     const unsigned long long vmask = __ballot(s0 >= 0);
     const int c = base + __popcll(vmask & ((1ull << lane) - 1ull));
@@ -783,13 +783,13 @@ __device__ __forceinline__ int assign_row_slots(const JacParams &P, int o0, int 
   return base;
 }
 // estimate pose of observation o (CamHelper::get_imu_poses) from the window tables; the same values as campose_one's
-__device__ __forceinline__ void est_pose_tab(const JacParams &P, const WinTab &T, int o, int s0, M3 &R_GtoI, V3 &p_IinG) {
+__device__ __forceinline__ void est_pose_tab(const JacParams &P, const WinTab &T, int o, int s0, double tm, M3 &R_GtoI, V3 &p_IinG) {
   if (P.res_R) {
     R_GtoI = ldM(P.res_R + 9 * o);
     p_IinG = ldV(P.res_p + 3 * o);
   } else {
     Interp est;
-    interpolate_tab(P, T, s0, P.obs_time[o] + P.cam_dt, false, est);
+    interpolate_tab(P, T, s0, tm, false, est);
     R_GtoI = est.R;
     p_IinG = est.p;
   }
@@ -803,7 +803,7 @@ __device__ __forceinline__ void est_pose_tab(const JacParams &P, const WinTab &T
 // One lane doing all of it in sequence took 17 k cycles (a wave retires a dependent fp64 operation every ~8 cycles whatever its lanes
 // do); this form ~7 k.  Called by all 256 threads.
 __device__ __forceinline__ void jacobian_rows_split(const JacParams &P, const V3 &pf, const V3 &pf_fej, int o0, int n_o, const int *s0_l,
-                                                    const int *slot_l, double *pre, double *X, int ncol, int k) {
+                                                    const int *slot_l, const double *tm_l, const float *uv_l, double *pre, double *X, int ncol, int k) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *hf = X, *hx = X + 3, *rs = X + 3 + k;
   for (int ib = 0; ib < n_o; ib += 64) {
@@ -823,14 +823,14 @@ __device__ __forceinline__ void jacobian_rows_split(const JacParams &P, const V3
         for (int q = 0; q < 3; ++q) pr[PRE_LEVER + q] = lever[q];
       } else if (wave == 1) {
         double r2[2], dzn[4], dzeta[16];
-        rows_est_part(P, pf, o, ldM(pr + PRE_RE), ldV(pr + PRE_PE), r2, dzn, dzeta);
+        rows_est_part(P, pf, uv_l + 2 * i, ldM(pr + PRE_RE), ldV(pr + PRE_PE), r2, dzn, dzeta);
         pr[PRE_R2] = r2[0], pr[PRE_R2 + 1] = r2[1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pr[PRE_DZN + q] = dzn[q];
 #pragma unroll
         for (int q = 0; q < 16; ++q) pr[PRE_DZETA + q] = dzeta[q];
       } else if (wave == 2) {
-        pr[PRE_ATC] = rows_at_clone(P, P.obs_time[o] + P.cam_dt) ? 1.0 : 0.0;
+        pr[PRE_ATC] = rows_at_clone(P, tm_l[i] + P.cam_dt) ? 1.0 : 0.0;
       }
     }
     __syncthreads();
@@ -951,11 +951,9 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   if (f == 0 && P.cols_out)
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
   __syncthreads();
-  P.clone_time = s_ct, P.clone_col = s_ccol;
-  P.obs_time = tm_l - o0, P.obs_uv = uv_l - 2 * o0;
-  tri.uvn = uvn_l - 2 * o0;
+  P.clone_time = s_ct, P.clone_col = s_ccol;  // (same indices; what is indexed by observation is read from the LDS copies by local index)
   if (wave == 0) {
-    const int base = assign_row_slots(P, o0, o1, ld, s0_l, slot_l);
+    const int base = assign_row_slots(P, o0, o1, ld, tm_l, s0_l, slot_l);
     if (lane == 0) s_base = base;
     jac_stamp(15);
   }
@@ -969,7 +967,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
       if (s0 < 0) continue;
       M3 R_GtoI;
       V3 p_IinG;
-      est_pose_tab(P, tab[2 * s0], o0 + i, s0, R_GtoI, p_IinG);
+      est_pose_tab(P, tab[2 * s0], o0 + i, s0, tm_l[i] + P.cam_dt, R_GtoI, p_IinG);
       if (c >= 0) {
         double *pr = pre + (size_t)c * PRE_STRIDE;
 #pragma unroll
@@ -988,7 +986,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     }
     if (tri.on) {
       tri_wave_sync();
-      triangulate_feature(P, f, cam, valid_l, tri.uvn, tri.opt, tri.p_out, tri.ok_out, tri.err_out, max_obs, tri_smem, tri_tot, o0, true, s_tri);
+      triangulate_feature(P, f, 0, o1 - o0, cam, valid_l, uvn_l, uv_l, tri.opt, tri.p_out, tri.ok_out, tri.err_out, max_obs, tri_smem, tri_tot, true, s_tri);
     }
   } else {
     for (int i = threadIdx.x - 64; i < o1 - o0; i += 192) {
@@ -996,7 +994,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
       if (c < 0) continue;
       Interp jac;
       const int s0 = s0_l[i];
-      interpolate_tab(P, tab[2 * s0 + 1], s0, P.obs_time[o0 + i] + P.cam_dt, true, jac);
+      interpolate_tab(P, tab[2 * s0 + 1], s0, tm_l[i] + P.cam_dt, true, jac);
       pre_store_jac(pre + (size_t)c * PRE_STRIDE, jac);
     }
     if (gate.on) gate_prefetch_rows(gate, P.cols_in, k, threadIdx.x - 64, 192);
@@ -1014,7 +1012,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     pf = ldV(P.p_FinG + 3 * f), pf_fej = ldV(P.p_FinG_fej + 3 * f);
   }
   if (selected) {  // (block-uniform)
-    jacobian_rows_split(P, pf, pf_fej, o0, o1 - o0, s0_l, slot_l, pre, X, ncol, k);
+    jacobian_rows_split(P, pf, pf_fej, o0, o1 - o0, s0_l, slot_l, tm_l, uv_l, pre, X, ncol, k);
     if (threadIdx.x == 0) {
       s_rows = min(2 * s_base, ld & ~1);
       P.rows[f] = 2 * s_base;
@@ -1253,26 +1251,22 @@ static_assert(sizeof(TriObs) == 15 * 8, "tri_smem_doubles counts 15 doubles per 
 // One feature, ONE wave (the 64 lanes that call it; other waves of the workgroup must not): poses of its observations, linear
 // triangulation, Levenberg-Marquardt refinement, reprojection error.  tri_smem: max_obs * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 bytes
 // of LDS, tot: TRI_TERMS doubles of LDS.  Wave-level synchronisation only (the lanes run in lockstep; the fences order the LDS traffic).
-// poses / valid are indexed by (o - obase): the global scratch arrays of triangulate_kernel (obase = 0) or a workgroup's LDS copy of
-// its own feature's observations (obase = obs_ptr[f], poses_ready: the caller has filled them).
-__device__ void triangulate_feature(const JacParams &P, int f, double *poses, unsigned char *valid, const float *__restrict__ uvn,
+// Observations o0 .. o1 - 1 index poses / valid / uvn / uv: the global arrays of triangulate_kernel (o0 = obs_ptr[f]) or a workgroup's
+// LDS copies of its own feature's observations (o0 = 0, poses_ready: the caller has filled poses and valid).
+__device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, double *poses, unsigned char *valid, const float *uvn, const float *uv,
                                     const plv_tri_options &opt, double *__restrict__ p_out, unsigned char *__restrict__ ok_out,
-                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, int obase, bool poses_ready,
+                                    double *__restrict__ err_out, int max_obs, double *tri_smem, double *tot, bool poses_ready,
                                     double *res_l /* LDS copy of the result for the caller's workgroup: p [3], ok, err */) {
   const int lane = threadIdx.x & 63;
   if (!poses_ready) {  // camera poses of this feature's observations (CamHelper::get_imu_poses / get_cam_poses), one lane each: no separate launch
-    const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
     for (int o = o0 + lane; o < o1; o += 64) campose_one(P, o, poses, valid, nullptr);
     __threadfence_block();
     tri_wave_sync();
   }
   jac_stamp(10);
-  poses -= 12 * (size_t)obase;
-  valid -= obase;
   TriObs *ob = reinterpret_cast<TriObs *>(tri_smem);                       // [max_obs]
   double *term = tri_smem + (size_t)max_obs * (sizeof(TriObs) / 8);        // [max_obs][TRI_TERMS]
   int *list = reinterpret_cast<int *>(term + (size_t)max_obs * TRI_TERMS);  // [max_obs] indices of the valid observations
-  const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
   // ordered compaction of the valid observations
   int M = 0;
   for (int base = o0; base < o1; base += 64) {
@@ -1441,8 +1435,8 @@ __device__ void triangulate_feature(const JacParams &P, int f, double *poses, un
       const double r = sqrt(x * x + y * y), r_2 = r * r, r_4 = r_2 * r_2;
       const double x1 = x * (1 + K[4] * r_2 + K[5] * r_4) + 2 * K[6] * x * y + K[7] * (r_2 + 2 * x * x);
       const double y1 = y * (1 + K[4] * r_2 + K[5] * r_4) + K[6] * (r_2 + 2 * y * y) + 2 * K[7] * x * y;
-      const double r0 = (double)P.obs_uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
-      const double r1 = (double)P.obs_uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
+      const double r0 = (double)uv[2 * o] - (double)(float)(K[0] * x1 + K[2]);
+      const double r1 = (double)uv[2 * o + 1] - (double)(float)(K[1] * y1 + K[3]);
       term[q * TRI_TERMS] = sqrt(r0 * r0 + r1 * r1);
     }
     reduce(1);
@@ -1463,7 +1457,8 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *po
                                                          unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
   extern __shared__ double tri_smem[];
   __shared__ double tot[TRI_TERMS];
-  triangulate_feature(P, blockIdx.x, poses, valid, uvn, opt, p_out, ok_out, err_out, max_obs, tri_smem, tot);
+  triangulate_feature(P, blockIdx.x, P.obs_ptr[blockIdx.x], P.obs_ptr[blockIdx.x + 1], poses, valid, uvn, P.obs_uv, opt, p_out, ok_out, err_out, max_obs, tri_smem,
+                      tot);
 }
 
 
@@ -1483,8 +1478,8 @@ __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a[0] *
 // them over the four waves, line_rows_split).  Every value is formed by the same expression wherever its piece runs.
 // (1) residual (signed distances of the segment's end points to the projected line) and dzli = d(residual)/d(line in the IMU frame,
 //     [n; v]) at the estimate pose; Rsk = -Re skew(pe) (Hf needs it with Re)
-__device__ __forceinline__ void line_est_part(const JacParams &P, const V3 &nG, const V3 &vG, int o, const M3 &Re, const V3 &pe, double *r2, double *dzli,
-                                              M3 &Rsk) {
+__device__ __forceinline__ void line_est_part(const JacParams &P, const V3 &nG, const V3 &vG, const float *seg /* the observed segment: x1 y1 x2 y2 */, const M3 &Re,
+                                              const V3 &pe, double *r2, double *dzli, M3 &Rsk) {
   const M3 R_ItoC = ldM(P.R_ItoC);
   const V3 p_IinC = ldV(P.p_IinC);
   const double *Kc = P.K;
@@ -1495,8 +1490,8 @@ __device__ __forceinline__ void line_est_part(const JacParams &P, const V3 &nG, 
   const V3 nC = vadd(mv(R_ItoC, nI), mv(SR, vI));
   const double l3[3] = {Kl[0] * nC[0] + Kl[1] * nC[1] + Kl[2] * nC[2], Kl[3] * nC[0] + Kl[4] * nC[1] + Kl[5] * nC[2],
                         Kl[6] * nC[0] + Kl[7] * nC[1] + Kl[8] * nC[2]};
-  const double us[3] = {(double)P.seg_uv[4 * o], (double)P.seg_uv[4 * o + 1], 1.0};
-  const double ue[3] = {(double)P.seg_uv[4 * o + 2], (double)P.seg_uv[4 * o + 3], 1.0};
+  const double us[3] = {(double)seg[0], (double)seg[1], 1.0};
+  const double ue[3] = {(double)seg[2], (double)seg[3], 1.0};
   const double lnorm = sqrt(l3[0] * l3[0] + l3[1] * l3[1]);
   const double ds = us[0] * l3[0] + us[1] * l3[1] + us[2] * l3[2], de = ue[0] * l3[0] + ue[1] * l3[1] + ue[2] * l3[2];
   r2[0] = ds / lnorm, r2[1] = de / lnorm;
@@ -1632,7 +1627,7 @@ __device__ void line_rows(const JacParams &P, int l, int o, int s0, double tm, i
   }
   double r2[2], dzli[12], Wm[4], wli[12], WI[12];
   M3 Rsk, A00, A30, A03;
-  line_est_part(P, nG, vG, o, Re, pe, r2, dzli, Rsk);
+  line_est_part(P, nG, vG, P.seg_uv + 4 * o, Re, pe, r2, dzli, Rsk);
   line_fej_part(nG, vG, jac.R, jac.p, A00, A30, A03);
   line_whiten_part(P, o, rows_at_clone(P, tm), dzli, A00, A30, A03, Wm, wli, WI);
   rows_write_res(c, Wm, r2, rs, rstr);
@@ -1674,7 +1669,7 @@ __global__ void __launch_bounds__(64) line_jacobian_kernel(JacParams P) {
 // reflections and only the projected block goes to global memory.  The covariance gathers of the update ride on it as extra
 // workgroups, and workgroup 0 publishes the column map.
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
-                                     double *out, unsigned char &ok);
+                                     const float *seg_uvn, const double *anchor, bool has_anchor, double *out, unsigned char &ok);
 // tri.on: the line is triangulated first, by this very workgroup, on the state Pt (LineHelper::get_line_features runs on the state
 // before the point update, lines_update linearises on the updated one: two views of the same window) — one launch for what were
 // line_triangulate_kernel + this one.  Only while the selection loop has no cap to enforce (n_feat <= max_sel): a line is then
@@ -1692,7 +1687,7 @@ struct LineTriStage {
 //   B  wave 0: Jacobian in the interpolated pose, noise, whitening
 //   C  wave w: the block of interpolation pose w; + wave 0: residual rows, time offset | wave 1: Hf
 __device__ __forceinline__ void line_rows_split(const JacParams &P, const V3 &nG, const V3 &vG, int o0, int n_o, const int *s0_l, const int *slot_l,
-                                                double *pre, double *X, int ncol, int k) {
+                                                const double *tm_l, const float *seg_l, double *pre, double *X, int ncol, int k) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *hf = X, *hx = X + 6, *rs = X + 6 + k;
   for (int ib = 0; ib < n_o; ib += 64) {
@@ -1708,12 +1703,12 @@ __device__ __forceinline__ void line_rows_split(const JacParams &P, const V3 &nG
       } else if (wave == 1) {
         double r2[2], dzli[12];
         Re = ldM(pr + PRE_RE);
-        line_est_part(P, nG, vG, o, Re, ldV(pr + PRE_PE), r2, dzli, Rsk);
+        line_est_part(P, nG, vG, seg_l + 4 * i, Re, ldV(pr + PRE_PE), r2, dzli, Rsk);
         pr[LPRE_R2] = r2[0], pr[LPRE_R2 + 1] = r2[1];
 #pragma unroll
         for (int q = 0; q < 12; ++q) pr[LPRE_DZLI + q] = dzli[q];
       } else if (wave == 2) {
-        pr[LPRE_ATC] = rows_at_clone(P, P.obs_time[o] + P.cam_dt) ? 1.0 : 0.0;
+        pr[LPRE_ATC] = rows_at_clone(P, tm_l[i] + P.cam_dt) ? 1.0 : 0.0;
       }
     }
     __syncthreads();
@@ -1752,6 +1747,33 @@ __device__ __forceinline__ void line_rows_split(const JacParams &P, const V3 &nG
   }
 }
 
+// ov_type::JPLQuat::update on the device, operation for operation what plv_jpl_left_update (init_api.cpp) does on the host
+// (REF: open_vins/ov_core/src/types/JPLQuat.h:62-73, utils/quat_ops.h:152-157, 232-252): both sides are built -ffp-contract=off and
+// use + - * / sqrt only, so the state a chained launch forms is bit for bit the one the host forms when it applies the same dx.
+__device__ __forceinline__ void jpl_left_update_dev(const double *Qin, const double *d, double *M) {
+  double a[3] = {0.5 * d[0], 0.5 * d[1], 0.5 * d[2]}, b = 1.0;
+  const double nd = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + 1.0);
+  a[0] /= nd, a[1] /= nd, a[2] /= nd, b /= nd;
+  const double v[3] = {Qin[0], Qin[1], Qin[2]}, w0 = Qin[3];
+  double r[4];
+  r[0] = b * v[0] - (a[1] * v[2] - a[2] * v[1]) + a[0] * w0;
+  r[1] = b * v[1] - (a[2] * v[0] - a[0] * v[2]) + a[1] * w0;
+  r[2] = b * v[2] - (a[0] * v[1] - a[1] * v[0]) + a[2] * w0;
+  r[3] = -(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + b * w0;
+  if (r[3] < 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = -r[i];
+  }
+  const double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  double Q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) Q[i] = r[i] / nr;
+  const double x = Q[0], y = Q[1], z = Q[2], w = Q[3], c = 2 * w * w - 1;
+  M[0] = c + 2 * x * x, M[1] = 2 * w * z + 2 * x * y, M[2] = -2 * w * y + 2 * x * z;
+  M[3] = -2 * w * z + 2 * y * x, M[4] = c + 2 * y * y, M[5] = 2 * w * x + 2 * y * z;
+  M[6] = 2 * w * y + 2 * z * x, M[7] = -2 * w * x + 2 * z * y, M[8] = c + 2 * z * z;
+}
+
 // line_jacobian_kernel + the null-space projection (+ triangulation in front, + the gate behind) in one launch: the line twin of
 // jacobian_nullspace_kernel, same order of work (inputs to LDS, window tables, [wave 0: poses on the state Pt + plane intersection |
 // waves 1-3: both interpolations on the state P into the LDS slots], rows over four waves, compact-WY null space with six
@@ -1764,6 +1786,8 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   __shared__ double s_line[6];
   __shared__ double s_ct[JAC_MAX_WIN / 2 + 3];
   __shared__ int s_ccol[JAC_MAX_WIN / 2 + 3];
+  __shared__ double s_cR[(JAC_MAX_WIN / 2 + 3) * 9], s_cp[(JAC_MAX_WIN / 2 + 3) * 3], s_cal[9 + 3 + 8 + 1], s_anchor[3];
+  __shared__ unsigned char s_has;
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
     return;
@@ -1795,10 +1819,51 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
     for (int i = threadIdx.x; i < k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
   __syncthreads();
   P.clone_time = s_ct, P.clone_col = s_ccol, Pt.clone_time = s_ct;  // (the two states share the window: stage_line_inputs)
-  P.obs_time = Pt.obs_time = tm_l - o0;
-  P.seg_uv = uv_l - 4 * o0, Pt.seg_uvn = uvn_l - 4 * o0;
+  if (P.chain_dx && *P.chain_applied != 0) {  // (block-uniform) the state of the linearisation = the staged state (+) dx, see JacParams::chain_dx
+    const double *dx = P.chain_dx;
+    const int N = P.n_clones, t = threadIdx.x;
+    if (t < N) {
+      const int id = P.chain_id[t];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s_cp[3 * t + q] = id >= 0 ? P.clone_p[3 * t + q] + dx[id + 3 + q] : P.clone_p[3 * t + q];
+      if (id >= 0) {
+        jpl_left_update_dev(P.chain_q + 4 * t, dx + id, s_cR + 9 * t);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s_cR[9 * t + q] = P.clone_R[9 * t + q];
+      }
+    } else if (t == 64) {
+      const int id = P.chain_id[N];
+      if (id >= 0) {
+        jpl_left_update_dev(P.chain_qe, dx + id, s_cal);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_cal[9 + q] = P.p_IinC[q] + dx[id + 3 + q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s_cal[q] = P.R_ItoC[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_cal[9 + q] = P.p_IinC[q];
+      }
+    } else if (t == 65) {
+      const int id = P.chain_id[N + 1];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s_cal[12 + q] = id >= 0 ? P.K[q] + dx[id + q] : P.K[q];
+    } else if (t == 66) {
+      const int id = P.chain_id[N + 2];
+      s_cal[20] = id >= 0 ? P.cam_dt + dx[id] : P.cam_dt;
+    }
+    __syncthreads();
+    P.clone_R = s_cR, P.clone_p = s_cp;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) P.R_ItoC[q] = s_cal[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) P.p_IinC[q] = s_cal[9 + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) P.K[q] = s_cal[12 + q];
+    P.cam_dt = s_cal[20];
+  }
   if (wave == 0) {
-    const int base = assign_row_slots(P, o0, o1, ld, s0_l, slot_l);
+    const int base = assign_row_slots(P, o0, o1, ld, tm_l, s0_l, slot_l);
     if (lane == 0) s_base = base;
     jac_stamp(15);
   } else if (wave == 1 && tri.on) {
@@ -1815,7 +1880,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
         if (s0 < 0) continue;
         M3 R_GtoI;
         V3 p_IinG;
-        est_pose_tab(Pt, tab[2 * nwin + s0], o0 + i, s0, R_GtoI, p_IinG);
+        est_pose_tab(Pt, tab[2 * nwin + s0], o0 + i, s0, tm_l[i] + Pt.cam_dt, R_GtoI, p_IinG);
 #pragma unroll
         for (int q = 0; q < 9; ++q) imu[12 * i + q] = R_GtoI.m[q];
 #pragma unroll
@@ -1827,11 +1892,26 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
 #pragma unroll
         for (int q = 0; q < 3; ++q) cam[12 * i + 9 + q] = p_CinG[q];
       }
+      if (Pt.anc_ptr && lane == 0) {  // the line's anchor: its first point that is triangulated (JacParams::anc_ptr)
+        unsigned char has = 0;
+        for (int c = Pt.anc_ptr[l]; c < Pt.anc_ptr[l + 1] && !has; ++c) {
+          const int pf = Pt.anc_f[c];
+          if (pf >= 0 && Pt.anc_tri_ok[pf]) {
+            s_anchor[0] = Pt.anc_tri_p[3 * pf], s_anchor[1] = Pt.anc_tri_p[3 * pf + 1], s_anchor[2] = Pt.anc_tri_p[3 * pf + 2];
+            has = 1;
+          } else if (Pt.anc_has_old[c]) {
+            s_anchor[0] = Pt.anc_old[3 * c], s_anchor[1] = Pt.anc_old[3 * c + 1], s_anchor[2] = Pt.anc_old[3 * c + 2];
+            has = 1;
+          }
+        }
+        s_has = has;
+      }
       tri_wave_sync();
       jac_stamp(10);
       double out_l[6] = {0, 0, 0, 0, 0, 0};
       unsigned char ok_l = 0;
-      line_triangulate_one(Pt, l, o0, o1, cam - 12 * (size_t)o0, imu - 12 * (size_t)o0, valid_l - o0, out_l, ok_l);
+      const bool has_anchor = Pt.anc_ptr ? s_has != 0 : (Pt.has_pt && Pt.has_pt[l]);
+      line_triangulate_one(Pt, l, 0, o1 - o0, cam, imu, valid_l, uvn_l, Pt.anc_ptr ? s_anchor : Pt.anchor_pt + 3 * l, has_anchor, out_l, ok_l);
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) tri.out_g[6 * l + i] = out_l[i], s_line[i] = out_l[i];
@@ -1850,7 +1930,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
       pre_store_jac(pr, jac);
       M3 Re;
       V3 pe;
-      est_pose_tab(P, tab[2 * s0], o0 + i, s0, Re, pe);
+      est_pose_tab(P, tab[2 * s0], o0 + i, s0, tm_l[i] + P.cam_dt, Re, pe);
 #pragma unroll
       for (int q = 0; q < 9; ++q) pr[PRE_RE + q] = Re.m[q];
 #pragma unroll
@@ -1871,7 +1951,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
     nG = ldV(P.line_FinG + 6 * l), vG = ldV(P.line_FinG + 6 * l + 3);
   }
   if (selected) {  // (block-uniform)
-    line_rows_split(P, nG, vG, o0, o1 - o0, s0_l, slot_l, pre, X, ncol, k);
+    line_rows_split(P, nG, vG, o0, o1 - o0, s0_l, slot_l, tm_l, uv_l, pre, X, ncol, k);
     if (threadIdx.x == 0) {
       s_rows = min(2 * s_base, ld & ~1);
       P.rows[l] = 2 * s_base;
@@ -1914,7 +1994,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
 }
 
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
-                                     double *out, unsigned char &ok);
+                                     const float *seg_uvn, const double *anchor, bool has_anchor, double *out, unsigned char &ok);
 // a27: LineHelper::line_triangulation   REF: LineHelper.cpp:202-293, 372-495, 615-650.  One wave per line: the lanes first
 // compute the camera / IMU poses of the line's observations (one each), then every lane runs the (short, serial) plane
 // intersection on them and lane 0 stores the result.
@@ -1927,15 +2007,16 @@ __global__ void __launch_bounds__(64) line_triangulate_kernel(JacParams P, doubl
   __syncthreads();
   double out_l[6] = {0, 0, 0, 0, 0, 0};
   unsigned char ok_l = 0;
-  line_triangulate_one(P, l, o0, o1, cam, imu, valid, out_l, ok_l);
+  line_triangulate_one(P, l, o0, o1, cam, imu, valid, P.seg_uvn, P.anchor_pt + 3 * l, P.has_pt && P.has_pt[l], out_l, ok_l);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) out_g[6 * l + i] = out_l[i];
     ok_g[l] = ok_l;
   }
 }
+// Observations o0 .. o1 - 1 index cam / imu / valid / seg_uvn (global arrays, or the workgroup's LDS copies with o0 = 0).
 __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, const double *cam, const double *imu, const unsigned char *valid,
-                                     double *out /*[6], zero on entry*/, unsigned char &ok) {
+                                     const float *seg_uvn, const double *anchor, bool has_anchor, double *out /*[6], zero on entry*/, unsigned char &ok) {
   int first = -1, nvalid = 0;
   for (int o = o0; o < o1; ++o)
     if (valid[o]) {
@@ -1944,11 +2025,11 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
     }
   if (nvalid < 2) return;
   const int D = P.lineD ? P.lineD[l] : 0;
-  if (D > 0 && P.has_pt && P.has_pt[l]) {
+  if (D > 0 && has_anchor) {
     const M3 R = ldM(imu + 12 * first);
     const V3 e{{D == 1 ? 1.0 : 0.0, D == 2 ? 1.0 : 0.0, D == 3 ? 1.0 : 0.0}};
     const V3 dir = mv(tp(R), e);
-    const V3 mom = cross3(ldV(P.anchor_pt + 3 * l), dir);
+    const V3 mom = cross3(ldV(anchor), dir);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       out[i] = mom[i];
@@ -1959,7 +2040,7 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
   }
   const M3 R0 = ldM(cam + 12 * first);
   const V3 p0 = ldV(cam + 12 * first + 9);
-  const float *u0 = P.seg_uvn + 4 * first;
+  const float *u0 = seg_uvn + 4 * first;
   const V3 p11{{(double)u0[0], (double)u0[1], 1.0}}, p12{{(double)u0[2], (double)u0[3], 1.0}};
   // plane through (a, b, c3): [ (a-c3) x (b-c3), -c3 . (a x b) ]
   const V3 n0 = cross3(p11, p12);
@@ -1973,7 +2054,7 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
     const V3 pi = ldV(cam + 12 * o + 9);
     const M3 R0i = mm(Ri, tp(R0));
     const V3 pi0 = mv(R0, vsub(pi, p0));
-    const float *um = P.seg_uvn + 4 * o;
+    const float *um = seg_uvn + 4 * o;
     V3 p31{{(double)um[0], (double)um[1], 1.0}}, p32{{(double)um[2], (double)um[3], 1.0}};
     p31 = vadd(mv(tp(R0i), p31), pi0);
     p32 = vadd(mv(tp(R0i), p32), pi0);

@@ -42,6 +42,24 @@ struct JacParams {
   // the chains of dependent loads behind (obs_ptr -> obs_time -> clone poses) meet one cold miss, not one each
   const char *in_base;
   int in_bytes;
+  // Chained launch (the line update enqueued behind a point update whose result the host has not seen, plv_camera_try_update): the
+  // state above is the one BEFORE that update's correction; the kernel forms x (+) dx itself (StateHelper::EKFUpdate's mean update,
+  // the arithmetic of plv_state_boxplus) for what it linearises on — clone poses, extrinsics, intrinsics, time offset — when the
+  // update's commit kernel left 1 in *chain_applied.  chain_id: covariance index of every clone pose (orientation; position = + 3),
+  // then of the extrinsics (same), the intrinsics and the time offset (-1: not estimated).  null chain_dx: not chained.
+  const double *chain_dx;
+  const int *chain_applied;
+  const double *chain_q;  // [n_clones][4] JPL quaternions of the clones
+  const int *chain_id;    // [n_clones + 3]
+  double chain_qe[4];     // extrinsic quaternion (R_ItoC)
+  // ... and a line's anchor point (LineHelper.cpp:233-247: the first point of the line that is triangulated) is looked up by the
+  // kernel: per line a list of candidates in the line's point order — index into that point update's triangulation results (or -1)
+  // and the value point_used held before (if any).  null anc_ptr: anchor_pt / has_pt as staged.
+  const int *anc_ptr, *anc_f;          // [n_feat + 1], [candidates]
+  const unsigned char *anc_has_old;    // [candidates]
+  const double *anc_old;               // [candidates][3]
+  const double *anc_tri_p;             // [F][3] of the point launch
+  const unsigned char *anc_tri_ok;     // [F]
   // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
   int use_imu_cov;
   double intr_err_mlt;

@@ -55,6 +55,16 @@ struct LineCand {
 // The pool of LineHelper::get_line_features (REF: linefeat/LineHelper.cpp:33-44: features_containing_older + features_not_containing_newer,
 // remove_unusable_measurements, sort) taken out of the database.  It reads times only, so plv_camera_try_update forms it while the
 // point update is still running on the device (form_line_pool below); plv_camera_update_lines consumes it.
+struct PoolArgs {  // what form_line_pool reads of the state and the update options: times only
+  double t_prev_frame = 0, state_time = 0, dt = 0, t_oldest = 0, t_oldest2 = 0;
+  int n_clones = 0;
+  static PoolArgs of(const plv_state_view *st, const plv_update_options *opt) {
+    PoolArgs a;
+    a.t_prev_frame = opt->t_prev_frame, a.state_time = opt->state_time, a.dt = st->cam_dt, a.n_clones = st->n_clones;
+    a.t_oldest = st->clone_time[0], a.t_oldest2 = st->clone_time[1];
+    return a;
+  }
+};
 struct LinePool {
   bool valid = false;
   double t_prev_frame = 0, state_time = 0, t_oldest = 0, t_oldest2 = 0, dt = 0;
@@ -63,8 +73,33 @@ struct LinePool {
   std::unordered_map<uint64_t, LineTrack> unused;   // db_unused so far (observations newer than the window)
 };
 
+// plv_camera_update_lines in two halves: what the first (pool, staging, launch of triangulation + Jacobians + gate) hands to the
+// second (gate verdicts, compression + EKFUpdate, selection, database).  plv_camera_try_update runs the first half inside the point
+// update's wait ("chained": the launch sits behind that update on the stream and forms the corrected state itself), the second
+// after it has applied the point update's dx; called on its own, plv_camera_update_lines runs one after the other.
+struct LinesJob {
+  enum Stage { NONE = 0, EMPTY, FAILED, FUSED_LAUNCHED, FUSED_NOTHING, TWO_STEP };
+  bool pending = false;  // a chained first half waits for its second
+  Stage stage = NONE;
+  int rc = 0;            // FAILED: the status to return
+  LinePool LP;
+  int Lp = 0, nobs = 0, most_valid = 0, k = 0, cap = 0, n_clones = 0;
+  double state_time = 0, t_prev_frame = 0;
+  std::vector<int> ptr, D, valid_n, cols;
+  std::vector<double> anchor, ot;
+  std::vector<float> uv, uvn;
+  std::vector<uint8_t> has, flags;
+  std::vector<std::vector<double>> cpiR, cpip, cpiQ;
+  std::vector<std::vector<int>> cpiC;
+  std::vector<double> allR, allp;
+  std::vector<double> lg_two_step;   // TWO_STEP: the triangulation ran as its own call inside the first half
+  std::vector<uint8_t> ok_two_step;
+  double us_pool = 0;
+};
+
 struct LineTracker {
   LinePool pool_prep;
+  LinesJob ujob;  // the line update in two halves (plv_camera_update_lines)
   std::vector<float> lines_last;  // 4 per line
   std::vector<uint64_t> ids_last;
   std::vector<int> rel_ptr_last{0};  // CSR: point ids on each last line (ascending, the reference keeps a std::map)
@@ -112,6 +147,11 @@ struct LineTracker {
     std::vector<float> pts;
     std::vector<uint64_t> pids;
     int rc = PLV_OK;
+    // plv_camera_frame with a line update to follow: the worker forms the update's pool (form_line_pool: times only) as the last step
+    // of the feed — the caller's thread, busy enqueuing the point update, finds it ready (round 3 formed it on that thread, inside
+    // the point update's wait; with the chained line launch that was 30 us in front of the line launch)
+    bool pool_on = false;
+    PoolArgs pool_args;
   } feed;
   int feed_state = 0;  // 0 idle, 1 posted, 2 done
   std::chrono::steady_clock::time_point job_posted, feed_posted;
@@ -125,6 +165,8 @@ std::unordered_map<plv_ctx *, LineTracker *> g_lt;
 LineTracker *ltr(plv_ctx *ctx, bool run_deferred = true);  // (defined after LineTracker's worker protocol)
 
 
+void form_line_pool(LineTracker *T, const PoolArgs &A, LinePool &R);
+void discard_line_pool(LineTracker *T);
 // (feed_points_impl is defined further down, outside this namespace: the worker reaches it through this pointer)
 int (*g_feed_impl)(plv_ctx *, LineTracker *, double, const double *, int, const float *, const uint64_t *, const double *) = nullptr;
 void line_worker(LineTracker *T) {
@@ -144,6 +186,12 @@ void line_worker(LineTracker *T) {
       const auto Fs = std::chrono::steady_clock::now();
       plv::counters().w_feed_start_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(Fs - T->feed_posted).count();
       const int rc = g_feed_impl(F.ctx, T, F.timestamp, F.vps, (int)F.pids.size(), F.pts.data(), F.pids.data(), F.K8);
+      if (rc == PLV_OK && F.pool_on) {
+        discard_line_pool(T);
+        form_line_pool(T, F.pool_args, T->pool_prep);
+      }
+      F.pool_on = false;
+      plv::frame_mark("@ (worker) line feed + pool done");
       plv::counters().w_feed_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - Fs).count();
       {
         std::lock_guard<std::mutex> lk(T->jm);
@@ -168,6 +216,7 @@ void line_worker(LineTracker *T) {
     }
     if (plv::host_phases().on)
       plv::host_phases().add("line worker: detect job, post to done", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
+    plv::frame_mark("@ (worker) line detection done");
     if (timing) {
       auto W2 = std::chrono::steady_clock::now();
       auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -634,6 +683,7 @@ int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vp
   F.pids.resize((size_t)np);
   const bool detecting = !T->walk_on_device && T->worker.joinable() && T->pending_which == PLV_PYR_CUR && T->pending_fed == plv_front_fed_count(ctx);
   if (!detecting) {  // no detection of this frame on the worker: nothing to overlap with, and the detector's HIP calls stay on this thread
+    F.pool_on = false;
     F.rc = feed_points_impl(ctx, T, timestamp, vps, np, F.pts.data(), F.pids.data(), ctx->cfg.intrinsics);
     return F.rc;
   }
@@ -764,6 +814,8 @@ static bool line_has_bounding_poses(const plv_state_view &st, double t) {  // as
 void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish = on != 0; }
 void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
 
+extern "C" int plv_point_chain_lookup(plv_ctx *ctx, uint64_t id);  // tracker_api.hip: index of a feature in the running point update's pool, or -1
+extern "C" int plv_camera_get_line_features(plv_ctx *ctx, const plv_state_view *st);
 static void line_give_back(std::unordered_map<uint64_t, LineTrack> &unused, const LineCand &c, size_t i) {
   LineTrack &u = unused[c.id];
   if (u.t.empty() && u.points.empty()) {
@@ -775,12 +827,14 @@ static void line_give_back(std::unordered_map<uint64_t, LineTrack> &unused, cons
   u.uvn.insert(u.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
 }
 
-static void form_line_pool(LineTracker *T, const plv_state_view *st, const plv_update_options *opt, LinePool &R) {
+namespace {
+void form_line_pool(LineTracker *T, const PoolArgs &A, LinePool &R) {
   R = LinePool();
   R.valid = true;
-  R.t_prev_frame = opt->t_prev_frame, R.state_time = opt->state_time, R.dt = st->cam_dt, R.n_clones = st->n_clones;
-  R.t_oldest = st->clone_time[0], R.t_oldest2 = st->clone_time[1];
+  R.t_prev_frame = A.t_prev_frame, R.state_time = A.state_time, R.dt = A.dt, R.n_clones = A.n_clones;
+  R.t_oldest = A.t_oldest, R.t_oldest2 = A.t_oldest2;
   const double dt = R.dt, t_oldest = R.t_oldest, t_oldest2 = R.t_oldest2;
+  const PoolArgs *opt = &A;  // (t_prev_frame, state_time)
   {
     std::lock_guard<std::mutex> lk(T->mtx);
     R.db_size_before = (int)T->db.size();
@@ -832,9 +886,11 @@ static void form_line_pool(LineTracker *T, const plv_state_view *st, const plv_u
   R.pool.resize(kept_cands);
   std::stable_sort(R.pool.begin(), R.pool.end(), [](const LineCand &a, const LineCand &b) { return a.tr.t.size() > b.tr.t.size(); });
 }
+}  // namespace
 
 // a pool that was formed ahead of time and is not going to be used: everything goes back where it came from
-static void discard_line_pool(LineTracker *T) {
+namespace {
+void discard_line_pool(LineTracker *T) {
   LinePool &R = T->pool_prep;
   if (!R.valid) return;
   std::lock_guard<std::mutex> lk(T->mtx);
@@ -853,6 +909,7 @@ static void discard_line_pool(LineTracker *T) {
   for (auto &kv : R.unused) put(kv.first, kv.second);
   R = LinePool();
 }
+}  // namespace
 
 // (internal, plv_camera_try_update) forms the line pool now if the line feed of this frame has finished — polled while the point
 // update runs on the device.  Never blocks: returns 0 while the feed is still on the worker (try again), 1 when the pool is formed or
@@ -873,15 +930,31 @@ int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_upda
   }
   T = ltr(ctx);  // (joins a finished feed, runs a hand-back left behind)
   if (T->feed.rc != PLV_OK) return 1;
+  const PoolArgs A = PoolArgs::of(st, opt);
+  const LinePool &R = T->pool_prep;
+  if (R.valid && R.t_prev_frame == A.t_prev_frame && R.state_time == A.state_time && R.dt == A.dt && R.n_clones == A.n_clones && R.t_oldest == A.t_oldest &&
+      R.t_oldest2 == A.t_oldest2)
+    return 1;  // (the worker formed it at the end of the feed: plv_line_feed_pool_args)
   plv::HostPhase ph("update_lines: pool formed inside the point update's wait");
   discard_line_pool(T);
-  form_line_pool(T, st, opt, T->pool_prep);
+  form_line_pool(T, A, T->pool_prep);
   return 1;
+}
+// (internal, plv_camera_frame) the frame's line feed is about to be posted and a line update follows: the worker forms that update's
+// pool at the end of the feed.  Same conditions as plv_line_pool_prepare.
+void plv_line_feed_pool_args(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
+  static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;
+  LineTracker *T = ltr(ctx);
+  T->feed.pool_on = false;
+  if (late || plv::knob(plv::PLV_KNOB_POOL_LATE) || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return;
+  T->feed.pool_args = PoolArgs::of(st, opt);
+  T->feed.pool_on = true;
 }
 void plv_line_pool_discard(plv_ctx *ctx) { discard_line_pool(ltr(ctx, false)); }
 int plv_line_db_size_after_feed(plv_ctx *ctx) {
   LineTracker *T = ltr(ctx);
   if (T->pool_prep.valid) return T->pool_prep.db_size_before;
+  if (T->ujob.pending && T->ujob.LP.valid) return T->ujob.LP.db_size_before;  // (the chained first half holds the pool)
   std::lock_guard<std::mutex> lk(T->mtx);
   return (int)T->db.size();
 }
@@ -908,47 +981,275 @@ int plv_camera_get_line_features(plv_ctx *ctx, const plv_state_view *st) {
   return PLV_OK;
 }
 
-int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
-                            plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
-  if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
-  LineTracker *T = ltr(ctx);
-  // the state of the triangulation: what plv_camera_get_line_features recorded (same window), else the state handed in
-  LineTracker::TriState tri_keep;
-  std::swap(tri_keep, T->tri_state);
-  T->tri_state.valid = false;
-  if (tri_keep.valid) {  // (the vectors moved: re-point the view)
-    tri_keep.view.clone_time = tri_keep.clone_time.data();
-    tri_keep.view.clone_R = tri_keep.view.clone_R_fej = tri_keep.clone_R.data();
-    tri_keep.view.clone_p = tri_keep.view.clone_p_fej = tri_keep.clone_p.data();
-    tri_keep.view.clone_state_id = tri_keep.clone_id.data();
-    if (tri_keep.view.n_clones != st->n_clones || memcmp(tri_keep.clone_time.data(), st->clone_time, 8 * (size_t)st->n_clones) != 0) tri_keep.valid = false;
-  }
-  const plv_state_view *st_tri = tri_keep.valid ? &tri_keep.view : st;
-  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
-  static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
-  plv::NsScope ns_lines(plv::counters().lines_ns);
-  plv::HostPhase ph_all("update_lines: whole call");
-  plv::RoctxRange rx_line("[Time-Cam] LINE update");
-  plv::HostPhase ph_pool("update_lines: pool + staging");
+// First half of plv_camera_update_lines (see LinesJob).  st: the state of the pool's window tests and — unless `chained` — of the
+// linearisation; st_tri: the state of the triangulation.  chained: plv_ctx::chain carries the caller's quaternions / covariance
+// indices, the launch is enqueued behind the point update and linearises on st (+) that update's dx.
+static int lines_first_half(plv_ctx *ctx, LineTracker *T, const plv_state_view *st, const plv_state_view *st_tri, const plv_update_options *opt, int cap,
+                            LinesJob &J, bool chained) {
+  J = LinesJob();
+  J.cap = cap, J.n_clones = st->n_clones, J.state_time = opt->state_time, J.t_prev_frame = opt->t_prev_frame;
   const auto U0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  plv::HostPhase ph_pool("update_lines: pool + staging");
   const double dt = st->cam_dt, t_oldest = st->clone_time[0];
   auto has_bounding = bounding_memo([st](double tq) { return line_has_bounding_poses(*st, tq); });
   typedef LineCand Cand;
-  LinePool LP;
+  LinePool &LP = J.LP;
   if (T->pool_prep.valid && T->pool_prep.t_prev_frame == opt->t_prev_frame && T->pool_prep.state_time == opt->state_time && T->pool_prep.dt == dt &&
       T->pool_prep.n_clones == st->n_clones && T->pool_prep.t_oldest == t_oldest && T->pool_prep.t_oldest2 == st->clone_time[1]) {
     LP = std::move(T->pool_prep);  // formed while the point update was running (plv_line_pool_prepare)
     T->pool_prep = LinePool();
   } else {
     discard_line_pool(T);
-    form_line_pool(T, st, opt, LP);
+    form_line_pool(T, PoolArgs::of(st, opt), LP);
   }
   std::vector<Cand> &pool = LP.pool;
   std::unordered_map<uint64_t, LineTrack> &unused = LP.unused;
   auto give_back = [&](const Cand &c, size_t i) { line_give_back(unused, c, i); };
-  res->n_pool = LP.n_pool;
   plv::HostPhase ph_p1("update_lines: pool a (scan + take) done -> b (trim + sort)");
+  if (pool.empty()) {
+    J.stage = LinesJob::EMPTY;
+    return PLV_OK;
+  }
+  // ---- triangulate every pool line (REF :45-63; get_imu_poses drops views without bounding clones)
+  const int Lp = J.Lp = (int)pool.size();
+  // ---- use_imu_res: poses from the CPI table (plv_update_options::cpi); views it cannot serve go back to the database
+  J.cpiR.resize(opt->cpi ? Lp : 0), J.cpip.resize(opt->cpi ? Lp : 0), J.cpiQ.resize(opt->cpi ? Lp : 0), J.cpiC.resize(opt->cpi ? Lp : 0);
+  auto &cpiR = J.cpiR, &cpip = J.cpip, &cpiQ = J.cpiQ;
+  auto &cpiC = J.cpiC;
+  const bool imu_cov = opt->cpi && opt->cpi->Q && st->use_imu_cov && !st->use_pol_cov;
+  if (opt->cpi) {
+    std::vector<double> tq;
+    for (const Cand &c : pool)
+      for (double t : c.tr.t) tq.push_back(t + dt);
+    std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
+    std::vector<uint8_t> okq(tq.size());
+    int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
+    std::vector<double> Qq(imu_cov ? 36 * tq.size() : 0);
+    std::vector<int> Cq(imu_cov ? tq.size() : 0);
+    if (rc0 == PLV_OK && imu_cov) {
+      std::vector<uint8_t> okn(tq.size());
+      rc0 = plv_cpi_noise(st, opt->cpi, (int)tq.size(), tq.data(), Qq.data(), Cq.data(), okn.data());
+      for (size_t i = 0; i < tq.size(); ++i) okq[i] = okq[i] && okn[i];
+    }
+    if (rc0 != PLV_OK) {
+      J.stage = LinesJob::FAILED, J.rc = rc0;
+      return PLV_OK;
+    }
+    size_t o = 0;
+    for (int l = 0; l < Lp; ++l) {
+      Cand &c = pool[l];
+      LineTrack kept;
+      kept.D = c.tr.D;
+      kept.points = c.tr.points;
+      for (size_t i = 0; i < c.tr.t.size(); ++i, ++o) {
+        if (!okq[o]) {
+          give_back(c, i);
+          continue;
+        }
+        kept.t.push_back(c.tr.t[i]);
+        kept.uv.insert(kept.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
+        kept.uvn.insert(kept.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
+        cpiR[l].insert(cpiR[l].end(), &Rq[9 * o], &Rq[9 * o] + 9);
+        cpip[l].insert(cpip[l].end(), &pq[3 * o], &pq[3 * o] + 3);
+        if (imu_cov) {
+          cpiQ[l].insert(cpiQ[l].end(), &Qq[36 * o], &Qq[36 * o] + 36);
+          cpiC[l].push_back(Cq[o]);
+        }
+      }
+      c.tr = std::move(kept);
+    }
+  }
+  ph_p1.stop();
+  plv::HostPhase ph_p2("update_lines: pool c (anchors + arrays + valid)");
+  J.ptr.assign(Lp + 1, 0), J.D.resize(Lp), J.anchor.assign(3 * (size_t)Lp, 0.0), J.has.assign(Lp, 0);
+  std::vector<int> &ptr = J.ptr, &D = J.D;
+  plv_ctx::ChainState &ch = ctx->chain;
+  if (chained) ch.anc_ptr.assign(1, 0), ch.anc_f.clear(), ch.anc_has_old.clear(), ch.anc_old.clear();
+  for (int l = 0; l < Lp; ++l) {
+    ptr[l + 1] = ptr[l] + (int)pool[l].tr.t.size();
+    D[l] = pool[l].tr.D;
+    if (chained) {
+      // the anchor is decided by the launch itself: the point update whose triangulation may (re)write point_used is still running.
+      // Per point of the line, in order: its index in that update's pool (plv_point_chain_lookup) and what point_used holds now.
+      for (int pid : pool[l].tr.points) {
+        double old[3] = {0, 0, 0};
+        const int pf = plv_point_chain_lookup(ctx, (uint64_t)pid);
+        const int has_old = plv_point_used_lookup(ctx, (uint64_t)pid, old);
+        if (pf < 0 && !has_old) continue;
+        ch.anc_f.push_back(pf);
+        ch.anc_has_old.push_back(has_old ? 1 : 0);
+        ch.anc_old.insert(ch.anc_old.end(), old, old + 3);
+        if (has_old) break;  // (point_used holds this point whatever the update does to it: the search ends here either way)
+      }
+      ch.anc_ptr.push_back((int)ch.anc_f.size());
+      continue;
+    }
+    for (int pid : pool[l].tr.points)  // first triangulated point of the line (REF :233-247)
+      if (plv_point_used_lookup(ctx, (uint64_t)pid, &J.anchor[3 * (size_t)l])) {
+        J.has[l] = 1;
+        break;
+      }
+  }
+  const int nobs = J.nobs = ptr[Lp];
+  if (nobs == 0) {
+    J.stage = LinesJob::EMPTY;
+    return PLV_OK;
+  }
+  J.ot.resize(nobs), J.uv.resize(4 * (size_t)nobs), J.uvn.resize(4 * (size_t)nobs);
+  for (int l = 0; l < Lp; ++l) {
+    const LineTrack &tr = pool[l].tr;
+    std::copy(tr.t.begin(), tr.t.end(), J.ot.begin() + ptr[l]);
+    std::copy(tr.uv.begin(), tr.uv.end(), J.uv.begin() + 4 * (size_t)ptr[l]);
+    std::copy(tr.uvn.begin(), tr.uvn.end(), J.uvn.begin() + 4 * (size_t)ptr[l]);
+  }
+  plv_line_tracks all{};
+  all.n_lines = Lp;
+  all.obs_ptr = ptr.data();
+  all.obs_time = J.ot.data();
+  all.seg_uv = J.uv.data();
+  all.seg_uvn = J.uvn.data();
+  all.D = D.data();
+  all.anchor_pt = J.anchor.data();
+  all.has_pt = J.has.data();
+  if (opt->cpi) {
+    for (int l = 0; l < Lp; ++l) {
+      J.allR.insert(J.allR.end(), cpiR[l].begin(), cpiR[l].end());
+      J.allp.insert(J.allp.end(), cpip[l].begin(), cpip[l].end());
+    }
+    all.res_R = J.allR.data();
+    all.res_p = J.allp.data();
+  }
+  J.valid_n.assign(Lp, 0);
+  for (int l = 0; l < Lp; ++l) {
+    for (double t : pool[l].tr.t) J.valid_n[l] += has_bounding(t + dt);
+    J.most_valid = std::max(J.most_valid, J.valid_n[l]);
+  }
+  J.cols.resize(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  // ---- one submission (see plv_camera_update_points): line triangulation, the selection below, Jacobians, null space, gate,
+  // compression and EKFUpdate back to back on the stream, one synchronisation.  CPI poses and over-long tracks take the two-step route.
+  const bool fused = !opt->cpi && J.most_valid <= opt->max_obs;
+  J.us_pool = since(U0);
+  ph_p2.stop();
+  ph_pool.stop();
+  if (!fused) {
+    J.stage = LinesJob::TWO_STEP;
+    return PLV_OK;
+  }
+  J.flags.resize(Lp);
+  bool any = false;
+  for (int l = 0; l < Lp; ++l) any = (J.flags[l] = J.valid_n[l] >= 2) || any;
+  if (!any) {
+    J.stage = LinesJob::FUSED_NOTHING;
+    return PLV_OK;
+  }
+  int rc = plv_line_jacobian_columns(st, &all, J.cols.data(), (int)J.cols.size(), &J.k);
+  if (rc == PLV_OK && J.k > 0) {
+    ctx->gate_rows_hint = 2 * J.most_valid;
+    ch.on = chained;
+    rc = plv_lines_update_fused_submit(ctx, st, st_tri, &all, J.flags.data(), cap, J.k, J.cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
+                                       opt->chi2_mult);
+    ch.on = false;
+    if (rc == PLV_OK) {
+      J.stage = LinesJob::FUSED_LAUNCHED;
+      return PLV_OK;
+    }
+  }
+  if (rc == PLV_OK) {  // (no column: nothing to linearise)
+    J.stage = LinesJob::FUSED_NOTHING;
+    return PLV_OK;
+  }
+  J.stage = LinesJob::FAILED, J.rc = rc;
+  return PLV_OK;
+}
+
+// (internal, plv_camera_try_update) the chained first half: called inside the point update's wait once the frame's line feed has
+// finished.  0: not possible now (the caller goes on as before), 1: the line launch is on the stream behind the point update.
+int plv_camera_lines_submit_chained(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, int cap) {
+  if (!ctx || !st || !opt || opt->cpi || st->n_clones < 2 || opt->max_obs < 2 || st->dt_state_id >= 0 || !ctx->chain.ready) return 0;
+  LineTracker *T = ltr(ctx);
+  if (T->ujob.pending || T->feed.rc != PLV_OK) return 0;
+  plv::frame_mark("@ chained first half starts");
+  plv::HostPhase ph("update_lines: first half inside the point update's wait (chained)");
+  T->tri_state.valid = false;  // (REF UpdaterCamera.cpp:148-152: the pool is triangulated on st — the one state the chained launch stages; the corrected one it forms itself)
+  (void)lines_first_half(ctx, T, st, st, opt, cap, T->ujob, true);
+  if (T->ujob.stage == LinesJob::TWO_STEP) {  // (tracks longer than the batch rows: the two-step route needs the corrected state on the host)
+    T->pool_prep = std::move(T->ujob.LP);     // the pool as it was formed goes back to where plv_camera_update_lines looks for it
+    T->pool_prep.valid = true;
+    T->ujob = LinesJob();
+    return 0;
+  }
+  T->ujob.pending = true;
+  plv::frame_mark("@ chained first half done (line launch enqueued)");
+  if (T->ujob.stage == LinesJob::FUSED_LAUNCHED) ++plv::counters().chained;
+  return 1;
+}
+
+int plv_camera_lines_job_pending(plv_ctx *ctx) { return ltr(ctx, false)->ujob.pending ? 1 : 0; }
+// (internal) a chained first half whose second half will not run (the point update failed): its launch is waited for and everything
+// it took out of the line database goes back
+void plv_camera_lines_job_abort(plv_ctx *ctx) {
+  LineTracker *T = ltr(ctx, false);
+  if (!T->ujob.pending) return;
+  (void)plv::stream_sync(ctx->stream);
+  ctx->gate_stage.on = 0, ctx->gate_stage_taken = false;
+  T->pool_prep = std::move(T->ujob.LP);
+  T->pool_prep.valid = true;
+  discard_line_pool(T);
+  T->ujob = LinesJob();
+}
+
+int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
+                            plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {
+  if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
+  static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
+  plv::NsScope ns_lines(plv::counters().lines_ns);
+  plv::HostPhase ph_all("update_lines: whole call");
+  plv::RoctxRange rx_line("[Time-Cam] LINE update");
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  LinesJob Jlocal;
+  const bool resumed = T->ujob.pending && T->ujob.cap == cap && T->ujob.n_clones == st->n_clones && T->ujob.state_time == opt->state_time &&
+                       T->ujob.t_prev_frame == opt->t_prev_frame;
+  if (T->ujob.pending && !resumed) {  // (a chained first half for other arguments than these: cannot be — its launch may be on the stream)
+    plv::set_last_error("plv_camera_update_lines: a chained submission for another window is pending");
+    return PLV_E_BADARG;
+  }
+  LinesJob &J = resumed ? T->ujob : Jlocal;
+  if (!resumed) {
+    // the state of the triangulation: what plv_camera_get_line_features recorded (same window), else the state handed in
+    LineTracker::TriState tri_keep;
+    std::swap(tri_keep, T->tri_state);
+    T->tri_state.valid = false;
+    if (tri_keep.valid) {  // (the vectors moved: re-point the view)
+      tri_keep.view.clone_time = tri_keep.clone_time.data();
+      tri_keep.view.clone_R = tri_keep.view.clone_R_fej = tri_keep.clone_R.data();
+      tri_keep.view.clone_p = tri_keep.view.clone_p_fej = tri_keep.clone_p.data();
+      tri_keep.view.clone_state_id = tri_keep.clone_id.data();
+      if (tri_keep.view.n_clones != st->n_clones || memcmp(tri_keep.clone_time.data(), st->clone_time, 8 * (size_t)st->n_clones) != 0) tri_keep.valid = false;
+    }
+    const plv_state_view *st_tri = tri_keep.valid ? &tri_keep.view : st;
+    TRY(lines_first_half(ctx, T, st, st_tri, opt, cap, J, false));
+    if (J.stage == LinesJob::TWO_STEP) {  // (triangulation as its own synchronous call, on st_tri while it is in scope)
+      J.ok_two_step.resize(J.Lp), J.lg_two_step.resize(6 * (size_t)J.Lp);
+      plv_line_tracks all{};
+      all.n_lines = J.Lp, all.obs_ptr = J.ptr.data(), all.obs_time = J.ot.data(), all.seg_uv = J.uv.data(), all.seg_uvn = J.uvn.data();
+      all.D = J.D.data(), all.anchor_pt = J.anchor.data(), all.has_pt = J.has.data();
+      if (opt->cpi) all.res_R = J.allR.data(), all.res_p = J.allp.data();
+      const int rc2 = plv_triangulate_lines(ctx, st_tri, &all, J.lg_two_step.data(), J.ok_two_step.data());
+      if (rc2 != PLV_OK) J.stage = LinesJob::FAILED, J.rc = rc2;
+    }
+  }
+  T->ujob.pending = false;
+  const double dt = st->cam_dt, t_oldest = st->clone_time[0];
+  auto has_bounding = bounding_memo([st](double tq) { return line_has_bounding_poses(*st, tq); });
+  typedef LineCand Cand;
+  LinePool &LP = J.LP;
+  std::vector<Cand> &pool = LP.pool;
+  std::unordered_map<uint64_t, LineTrack> &unused = LP.unused;
+  auto give_back = [&](const Cand &c, size_t i) { line_give_back(unused, c, i); };
+  res->n_pool = LP.n_pool;
   auto give_back_all = [&](Cand &c) {
     if (unused.find(c.id) == unused.end()) {  // nothing of this line went back earlier: hand the track over as it is
       unused.emplace(c.id, std::move(c.tr));
@@ -1023,148 +1324,46 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     return rc;
   };
   std::fill(dx, dx + ctx->cov_n, 0.0);
-  if (pool.empty()) return finish(PLV_OK);
-  // ---- triangulate every pool line (REF :45-63; get_imu_poses drops views without bounding clones)
-  const int Lp = (int)pool.size();
-  // ---- use_imu_res: poses from the CPI table (plv_update_options::cpi); views it cannot serve go back to the database
-  std::vector<std::vector<double>> cpiR(opt->cpi ? Lp : 0), cpip(opt->cpi ? Lp : 0), cpiQ(opt->cpi ? Lp : 0);
-  std::vector<std::vector<int>> cpiC(opt->cpi ? Lp : 0);
+  if (J.stage == LinesJob::EMPTY) return finish(PLV_OK);
+  if (J.stage == LinesJob::FAILED) {
+    for (Cand &c : pool) give_back_all(c);
+    return finish(J.rc);
+  }
+  const int Lp = J.Lp, nobs = J.nobs;
+  std::vector<int> &valid_n = J.valid_n, &cols = J.cols;
+  auto &cpiR = J.cpiR, &cpip = J.cpip, &cpiQ = J.cpiQ;
+  auto &cpiC = J.cpiC;
   const bool imu_cov = opt->cpi && opt->cpi->Q && st->use_imu_cov && !st->use_pol_cov;
-  if (opt->cpi) {
-    std::vector<double> tq;
-    for (const Cand &c : pool)
-      for (double t : c.tr.t) tq.push_back(t + dt);
-    std::vector<double> Rq(9 * tq.size()), pq(3 * tq.size());
-    std::vector<uint8_t> okq(tq.size());
-    int rc0 = plv_cpi_poses(ctx, st, opt->cpi, (int)tq.size(), tq.data(), Rq.data(), pq.data(), okq.data());
-    std::vector<double> Qq(imu_cov ? 36 * tq.size() : 0);
-    std::vector<int> Cq(imu_cov ? tq.size() : 0);
-    if (rc0 == PLV_OK && imu_cov) {
-      std::vector<uint8_t> okn(tq.size());
-      rc0 = plv_cpi_noise(st, opt->cpi, (int)tq.size(), tq.data(), Qq.data(), Cq.data(), okn.data());
-      for (size_t i = 0; i < tq.size(); ++i) okq[i] = okq[i] && okn[i];
-    }
-    if (rc0 != PLV_OK) {
-      for (Cand &c : pool) give_back_all(c);
-      return finish(rc0);
-    }
-    size_t o = 0;
-    for (int l = 0; l < Lp; ++l) {
-      Cand &c = pool[l];
-      LineTrack kept;
-      kept.D = c.tr.D;
-      kept.points = c.tr.points;
-      for (size_t i = 0; i < c.tr.t.size(); ++i, ++o) {
-        if (!okq[o]) {
-          give_back(c, i);
-          continue;
-        }
-        kept.t.push_back(c.tr.t[i]);
-        kept.uv.insert(kept.uv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
-        kept.uvn.insert(kept.uvn.end(), c.tr.uvn.begin() + 4 * i, c.tr.uvn.begin() + 4 * i + 4);
-        cpiR[l].insert(cpiR[l].end(), &Rq[9 * o], &Rq[9 * o] + 9);
-        cpip[l].insert(cpip[l].end(), &pq[3 * o], &pq[3 * o] + 3);
-        if (imu_cov) {
-          cpiQ[l].insert(cpiQ[l].end(), &Qq[36 * o], &Qq[36 * o] + 36);
-          cpiC[l].push_back(Cq[o]);
-        }
-      }
-      c.tr = std::move(kept);
-    }
-  }
-  ph_p1.stop();
-  plv::HostPhase ph_p2("update_lines: pool c (anchors + arrays + valid)");
-  std::vector<int> ptr(Lp + 1, 0), D(Lp);
-  std::vector<double> anchor(3 * (size_t)Lp, 0.0);
-  std::vector<uint8_t> has(Lp, 0), ok(Lp);
-  for (int l = 0; l < Lp; ++l) {
-    ptr[l + 1] = ptr[l] + (int)pool[l].tr.t.size();
-    D[l] = pool[l].tr.D;
-    for (int pid : pool[l].tr.points)  // first triangulated point of the line (REF :233-247)
-      if (plv_point_used_lookup(ctx, (uint64_t)pid, &anchor[3 * (size_t)l])) {
-        has[l] = 1;
-        break;
-      }
-  }
-  const int nobs = ptr[Lp];
-  if (nobs == 0) return finish(PLV_OK);
-  std::vector<double> ot(nobs), lg(6 * (size_t)Lp);
-  std::vector<float> uv(4 * (size_t)nobs), uvn(4 * (size_t)nobs);
-  for (int l = 0; l < Lp; ++l) {
-    const LineTrack &tr = pool[l].tr;
-    std::copy(tr.t.begin(), tr.t.end(), ot.begin() + ptr[l]);
-    std::copy(tr.uv.begin(), tr.uv.end(), uv.begin() + 4 * (size_t)ptr[l]);
-    std::copy(tr.uvn.begin(), tr.uvn.end(), uvn.begin() + 4 * (size_t)ptr[l]);
-  }
-  plv_line_tracks all{};
-  all.n_lines = Lp;
-  all.obs_ptr = ptr.data();
-  all.obs_time = ot.data();
-  all.seg_uv = uv.data();
-  all.seg_uvn = uvn.data();
-  all.D = D.data();
-  all.anchor_pt = anchor.data();
-  all.has_pt = has.data();
-  std::vector<double> allR, allp;
-  if (opt->cpi) {
-    for (int l = 0; l < Lp; ++l) {
-      allR.insert(allR.end(), cpiR[l].begin(), cpiR[l].end());
-      allp.insert(allp.end(), cpip[l].begin(), cpip[l].end());
-    }
-    all.res_R = allR.data();
-    all.res_p = allp.data();
-  }
-  std::vector<int> valid_n(Lp, 0);
-  int most_valid = 0;
-  for (int l = 0; l < Lp; ++l) {
-    for (double t : pool[l].tr.t) valid_n[l] += has_bounding(t + dt);
-    most_valid = std::max(most_valid, valid_n[l]);
-  }
-  std::vector<int> cols(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
-  int k = 0, n_rows = 0, rc = PLV_OK;
-  // ---- one submission (see plv_camera_update_points): line triangulation, the selection below, Jacobians, null space, gate,
-  // compression and EKFUpdate back to back on the stream, one synchronisation.  CPI poses and over-long tracks take the two-step route.
-  const bool fused = !opt->cpi && most_valid <= opt->max_obs;
-  const double us_pool = since(U0);
-  ph_p2.stop();
-  ph_pool.stop();
+  std::vector<double> lg(6 * (size_t)Lp);
+  std::vector<uint8_t> ok(Lp);
+  int k = J.k, n_rows = 0, rc = PLV_OK;
+  const double us_pool = J.us_pool;
   plv::HostPhase ph_dev("update_lines: device submission + wait");
   const auto U1 = std::chrono::steady_clock::now();
   std::vector<uint8_t> acc_all(Lp, 0);
   bool fused_ran = false;
-  if (fused) {
-    std::vector<uint8_t> flags(Lp);
-    bool any = false;
-    for (int l = 0; l < Lp; ++l) any = (flags[l] = valid_n[l] >= 2) || any;
-    if (any) {
-      rc = plv_line_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
-      if (rc == PLV_OK && k > 0) {
-        ctx->gate_rows_hint = 2 * most_valid;
-        rc = plv_lines_update_fused(ctx, st, st_tri, &all, flags.data(), cap, k, cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
-                                    opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx, plv_tracker_run_deferred, ctx);
-        res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
-        if (rc == PLV_E_NOT_PSD) {
-          rc = PLV_OK;
-          std::fill(dx, dx + ctx->cov_n, 0.0);
-        }
-        fused_ran = rc == PLV_OK;
-      }
-      if (rc != PLV_OK) {
-        for (Cand &c : pool) give_back_all(c);
-        return finish(rc);
-      }
-    } else {
-      std::fill(ok.begin(), ok.end(), 0);
+  if (J.stage == LinesJob::FUSED_LAUNCHED) {
+    rc = plv_lines_update_fused_finish(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx,
+                                       plv_tracker_run_deferred, ctx);
+    res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
+    if (rc == PLV_E_NOT_PSD) {
+      rc = PLV_OK;
+      std::fill(dx, dx + ctx->cov_n, 0.0);
     }
-  } else {
-    rc = plv_triangulate_lines(ctx, st_tri, &all, lg.data(), ok.data());
+    fused_ran = rc == PLV_OK;
     if (rc != PLV_OK) {
       for (Cand &c : pool) give_back_all(c);
       return finish(rc);
     }
+  } else if (J.stage == LinesJob::FUSED_NOTHING) {
+    std::fill(ok.begin(), ok.end(), 0);
+  } else {  // TWO_STEP
+    lg = J.lg_two_step;
+    ok = J.ok_two_step;
   }
   const double us_dev = since(U1);
   ph_dev.stop();
+  plv::frame_mark("@ line gate / update collected");
   plv::HostPhase ph_post("update_lines: selection + database");
   if (timing) fprintf(stderr, "update lines: pool + staging %.1f us (%d lines, %d observations), device submission + wait %.1f us\n", us_pool, Lp, nobs, us_dev);
   std::vector<int> sel;

@@ -109,6 +109,8 @@ void plv_phase_counters(unsigned long long *out10) {
 }
 // (measurement aid) device / pinned (re)allocations since the library was loaded: a frame that grows a buffer pays a hipMalloc
 unsigned long long plv_alloc_count(void) { return plv::alloc_epoch().load(); }
+// (measurement aid) line launches that plv_camera_try_update enqueued behind a point update still running (the chained line launch)
+unsigned long long plv_chain_count(void) { return plv::counters().chained.load(); }
 unsigned plv_debug_knobs(long long set) {
   const unsigned prev = plv::knobs().load();
   if (set >= 0) plv::knobs().store((unsigned)set);
@@ -247,6 +249,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   ctx->h_pin.release();
+  ctx->h_pin_l.release();
   ctx->h_done.release();
   plv_ctx_update_state *us = nullptr;
   {
@@ -259,10 +262,15 @@ void plv_ctx_destroy(plv_ctx *ctx) {
       }
   }
   if (us) {
-    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
+    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->result_l, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
     for (auto *b : ub) b->release();
     us->jin.release();
     us->tri.release();
+    us->jin_l.release();
+    us->tri_l.release();
+    us->h_jin_l.release();
+    us->h_tri_l.release();
+    us->chain_words.release();
     us->eval.release();
     if (us->done_ev) (void)hipEventDestroy(us->done_ev);
     if (us->gexec) (void)hipGraphExecDestroy(us->gexec);
@@ -375,13 +383,13 @@ int plv_cov_rollback(plv_ctx *ctx) {
 // ------------------------------------------------------------------------------ EKF update
 static size_t result_rows_off(int n, int F) { return ((size_t)n * 8 + 16 + (size_t)F + 7) & ~(size_t)7; }
 static int result_buf(plv_ctx *ctx, plv_ctx_update_state *us, int n, int F, double **dx, int **flag, unsigned char **acc,
-                      int **acc_rows = nullptr) {
+                      int **acc_rows = nullptr, int fdim = 3) {
   size_t bytes = result_rows_off(n, F) + (size_t)F * 4 + 16;
-  const void *before = us->result.p;
-  TRY(us->result.reserve(bytes));
-  if (us->result.p != before)  // (the accepted-entry counters of the fused gate are zeroed by the update before, not by their own)
-    PLV_HIP_CHECK(hipMemsetAsync(us->result.p, 0, us->result.cap, ctx->stream));
-  char *b = us->result.as<char>();
+  plv::DevBuf &rb = us->result_of(fdim);
+  const void *before = rb.p;
+  TRY(rb.reserve(bytes));
+  if (rb.p != before) PLV_HIP_CHECK(hipMemsetAsync(rb.p, 0, rb.cap, ctx->stream));
+  char *b = rb.as<char>();
   *dx = (double *)b;
   *flag = (int *)(b + (size_t)n * 8);
   *acc = (unsigned char *)(b + (size_t)n * 8 + 16);
@@ -651,10 +659,16 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   int *d_flag;
   unsigned char *d_acc;
   int *d_acc_rows;
-  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
+  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows, fdim));
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
-  TRY(ctx->h_pin.reserve(rb));
-  us->acc_word = us->acc_word == 1 ? 2 : 1;  // the two counters alternate: this update counts in one and zeroes the other for the next
+  plv::PinBuf &hpin = ctx->res_pin(fdim);
+  TRY(hpin.reserve(rb));
+  plv_ctx_update_state::AccWords &aw = us->acc_of(fdim);
+  aw.word = aw.word == 1 ? 2 : 1;  // the two counters alternate: this update counts in one and zeroes the other for the next
+  // the word must be zero when the launch starts: the gate of the update before in this block zeroed it — unless this is the first
+  // use, the block moved, cov_n changed (the words sit behind dx) or that launch declined the gate: then a memset does
+  if (!(aw.z_ptr == us->result_of(fdim).p && aw.z_n == n && aw.z_word == aw.word)) PLV_HIP_CHECK(hipMemsetAsync(d_flag + aw.word, 0, 4, ctx->stream));
+  aw.z_ptr = nullptr;  // (known again once a launch has taken the gate: plv_msckf_update_resident_launch)
   plv::GateStage &g = ctx->gate_stage;
   g.on = 1;
   g.P = ctx->d_P.as<double>();
@@ -666,14 +680,14 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   g.chi2 = ctx->d_chi2.as<double>();
   g.accepted = d_acc;
   g.acc_rows = d_acc_rows;
-  g.n_acc = d_flag + us->acc_word;
-  g.n_acc_next = d_flag + (3 - us->acc_word);
+  g.n_acc = d_flag + aw.word;
+  g.n_acc_next = d_flag + (3 - aw.word);
   g.stack = ctx->d_stack.as<double>();
   g.lds = Mtot;
   g.mp_max = mp_max;
   g.stack_accepted_only = (Mtot > k && k <= 192 && (whitened_route(us, Mtot, k) || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
   if (probe) {  // the verdicts also go to pinned memory (the caller adds the second block: probe_src / probe_dst / strides)
-    char *hb = ctx->h_pin.as<char>();
+    char *hb = hpin.as<char>();
     g.h_accepted = (unsigned char *)(hb + (size_t)n * 8 + 16);
     g.h_acc_rows = (int *)(hb + result_rows_off(n, F));
   }
@@ -686,14 +700,16 @@ static bool whitened_route(const plv_ctx_update_state *us, int Mtot, int k) {
 // carries d_cols), factor the prior block and form W0^T W0; aux_join is recorded behind them.  Two steps so that a caller can mark,
 // enqueue its own next launch on the main stream first (the host's enqueue time of the side work then overlaps that launch's run
 // time instead of delaying it), and start the side work afterwards.
-static int prior_mark(plv_ctx *ctx) {
+static int prior_mark(plv_ctx *ctx, bool always_fork = false) {
   if (!ctx->aux_stream) {
     PLV_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
     PLV_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
   }
   // the host has waited for the covariance's last writer (plv_ctx::cov_host_synced): nothing to order the side stream behind
-  ctx->aux_fork_needed = ctx->cov_host_synced != ctx->gather_stamp;
+  // always_fork: the side work reads something the main stream is still producing besides the covariance (the column map a Jacobian
+  // launch publishes: that launch does not move gather_stamp) — ADVICE r3
+  ctx->aux_fork_needed = always_fork || ctx->cov_host_synced != ctx->gather_stamp;
   if (plv::host_phases().on) plv::host_phases().add("prior_mark: fork event needed (1 = yes)", ctx->aux_fork_needed ? 1.0 : 0.0);
   plv::HostPhase ph("prior_mark: fork event recorded");
   if (ctx->aux_fork_needed) PLV_HIP_CHECK(hipEventRecord(ctx->aux_fork, ctx->stream));
@@ -767,7 +783,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int *d_flag;
   unsigned char *d_acc;
   int *d_acc_rows;
-  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows));
+  TRY(result_buf(ctx, us, n, F, &d_dx, &d_flag, &d_acc, &d_acc_rows, fdim));
+  plv::DevBuf &resbuf = us->result_of(fdim);
 
   // a batch from plv_build_jacobians_resident arrives projected, with the covariance gathers done on its launch: they stand as
   // long as nothing has touched the covariance or the gathered blocks since (plv_ctx::gather_stamp)
@@ -779,7 +796,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   const bool prefetched = prior_was_pending && ctx->prior_k == k && gathers_valid;
   ctx->prior_pending = false;
   const size_t rb = result_rows_off(n, F) + (size_t)F * 4;
-  TRY(ctx->h_pin.reserve(rb));
+  plv::PinBuf &hpin = ctx->res_pin(fdim);
+  TRY(hpin.reserve(rb));
   struct SkipGuard {  // the words are only meaningful for the kernels of this update
     plv_ctx *c;
     ~SkipGuard() { c->skip_word = nullptr, c->commit_veto = nullptr; }
@@ -802,7 +820,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   auto enqueue = [&]() -> int {
   if (whiten && !prefetched) {
     TRY(aux_join());
-    TRY(prior_mark(ctx));
+    TRY(prior_mark(ctx, true));  // (us->bcols is written by the Jacobian launch queued on the main stream)
     TRY(prior_start(ctx, us->bcols.as<int>(), k));
     aux_open = true;
   }
@@ -843,7 +861,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;
   const bool probe = ctx->probe && !us->graph_mode;
   if (probe) {
-    char *hb = ctx->h_pin.as<char>();
+    char *hb = hpin.as<char>();
     a.h_accepted = (unsigned char *)(hb + (size_t)n * 8 + 16);
     a.h_acc_rows = (int *)(hb + result_rows_off(n, F));
     a.probe_src = (const unsigned char *)ctx->probe_src;
@@ -859,7 +877,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   if (gated) {
     ctx->skip_word = ctx->skip_word ? ctx->gate_stage.n_acc : nullptr;
-    us->acc_word_used = us->acc_word;
+    plv_ctx_update_state::AccWords &aw = us->acc_of(fdim);
+    us->acc_word_used = aw.word;
+    aw.z_ptr = resbuf.p, aw.z_n = n, aw.z_word = 3 - aw.word;  // (workgroup 0 of the gated launch zeroed the other counter)
   } else {
     us->acc_word_used = 1;
     TRY(launch_chi2(ctx, F, a, mp_max));
@@ -869,11 +889,11 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     // BASELINE configs[2] accept no line), without the six launches that would find nothing to do
     if (ctx->probe_hook) ctx->probe_hook(ctx->probe_hook_arg);
     TRY(sync(ctx));
-    const unsigned char *hacc = (const unsigned char *)(ctx->h_pin.as<char>() + (size_t)n * 8 + 16);
+    const unsigned char *hacc = (const unsigned char *)(hpin.as<char>() + (size_t)n * 8 + 16);
     int any = 0;
     for (int f = 0; f < F; ++f) any |= hacc[f];
     if (!any) {
-      memset(ctx->h_pin.p, 0, (size_t)n * 8 + 16);  // dx = 0, status = updated-with-nothing (as the skipped chain reports it)
+      memset(hpin.p, 0, (size_t)n * 8 + 16);  // dx = 0, status = updated-with-nothing (as the skipped chain reports it)
       ctx->probe_done = true;
       return aux_join();
     }
@@ -887,7 +907,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
     TRY(launch_gram_information(ctx, ctx->d_stack.as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
     TRY(aux_join());
-    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, d_dx, d_flag, us->result.p, ctx->h_pin.p, (rb + 3) & ~(size_t)3));
+    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     us->last_route = 4;
     return PLV_OK;
   }
@@ -932,16 +952,16 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   if (ekf_fast_fits(r)) {  // (its last kernel mirrors the result block into h_pin: no copy command after the chain)
     TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true,
-                        us->result.p, ctx->h_pin.p, (rb + 3) & ~(size_t)3));
+                        resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     return PLV_OK;
   }
   TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
-  TRY(d2h(ctx, ctx->h_pin.p, us->result.p, rb));
+  TRY(d2h(ctx, hpin.p, resbuf.p, rb));
     return PLV_OK;
   };
   if (us->graph_mode && !ctx->prof.on) {
     // (the skip word is chosen inside enqueue() from Mtot, k and d_flag: all functions of the key's own fields and of `result`)
-    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, us->result.p, ctx->h_pin.p, ctx->mirror2_src, ctx->mirror2_dst,
+    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, resbuf.p, hpin.p, ctx->mirror2_src, ctx->mirror2_dst,
                                        (const void *)(d_flag + 1), ctx->mirror2_bytes, F, fdim + 16 * (projected ? 1 : 0) + 32 * (gathers_valid ? 1 : 0), k, ld, n, mp_max,
                                        sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch().load()};
     if (us->gexec && key == us->gkey) {
@@ -988,6 +1008,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   ctx->gate_stage.on = 0, ctx->gate_stage_taken = false;
   ++ctx->gather_stamp;  // the update rewrites the covariance
+  us->pending_fdim = fdim;
   us->pending_F = F;  // stream-ordered: the result block lands in h_pin; plv_msckf_update_resident_wait reads it
   if (!us->done_ev) PLV_HIP_CHECK(hipEventCreateWithFlags(&us->done_ev, hipEventDisableTiming));
   PLV_HIP_CHECK(hipEventRecord(us->done_ev, ctx->stream));
@@ -1001,7 +1022,7 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   if (mode >= 0) {
-    if (mode > 4) return PLV_E_BADARG;
+    if (mode > 4) return PLV_E_BADARG;  // (4 = measurement aid, not in the header: mode 0 with the prior factor started behind the Jacobian launch)
     us->prior_late = mode == 4;  // (measurement aid: mode 0 with the prior factor started behind the Jacobian launch)
     us->compress_mode = mode == 4 ? 0 : mode;
   }
@@ -1030,6 +1051,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   const int F = us->pending_F, n = ctx->cov_n;
+  plv::PinBuf &hpin = ctx->res_pin(us->pending_fdim);
   if (F < 1 || !dx) {
     set_last_error("plv_msckf_update_resident_wait: nothing was launched");
     return PLV_E_BADARG;
@@ -1049,7 +1071,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     if (us->done_stamp > ctx->cov_host_synced) ctx->cov_host_synced = us->done_stamp;
   }
   us->word_seq = 0;
-  const char *hb = ctx->h_pin.as<char>();
+  const char *hb = hpin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;
   if (us->redo.armed && us->last_ambiguous > 0 && *(const int *)(hb + (size_t)n * 8) == 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
@@ -1063,7 +1085,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     const int nc = rd.k + 1;
     TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
     TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols.as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx,
-                        rd.d_flag, true, us->result.p, ctx->h_pin.p, ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3));
+                        rd.d_flag, true, us->result_of(us->pending_fdim).p, hpin.p, ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3));
     TRY(sync(ctx));
     ++ctx->gather_stamp;
     us->last_route = 3;

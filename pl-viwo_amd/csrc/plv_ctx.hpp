@@ -41,6 +41,7 @@ struct Counters {
   std::atomic<unsigned long long> flow_wait_ns{0}, points_ns{0}, points_wait_ns{0}, lines_ns{0}, line_join_ns{0};
   // the line worker's side: post -> wake-up, the wait for the edge maps, chain walk + segment growth, feed post -> start, the feed
   std::atomic<unsigned long long> w_wake_ns{0}, w_maps_ns{0}, w_extract_ns{0}, w_feed_start_ns{0}, w_feed_ns{0};
+  std::atomic<unsigned long long> chained{0};  // line launches enqueued behind a running point update (plv_chain_count)
 };
 inline Counters &counters() {
   static Counters c;
@@ -72,7 +73,10 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 // 256  the flow's and the updates' waits on completion words their last kernels write into pinned memory (plv_ctx::h_done) instead of
 //      on HIP events: a bare word is seen 4.8 us earlier (tools/ubench/waitlat.hip), in the frame it gains nothing (0 .. 9 us SLOWER over
 //      four alternating runs: the commit then runs as one workgroup so that the word also covers the covariance)
-enum : unsigned { PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
+// 2048 no chained line launch: the line half is staged and enqueued after the host has collected and applied the point update (round 3)
+// 4096 the point update's wait keeps polling its hook until the hook is done even when the device has finished (tests: every frame's
+//      line launch is chained, whatever the timing of the line worker)
+enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
                   PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
@@ -130,6 +134,17 @@ struct HostPhases {
 inline HostPhases &host_phases() {
   static HostPhases h;
   return h;
+}
+// PLV_HOST_TIMING=1: where inside the frame an event falls (microseconds since plv_camera_frame was entered), per label
+inline std::atomic<long long> &frame_t0_ns() {
+  static std::atomic<long long> t{0};
+  return t;
+}
+inline void frame_mark(const char *label) {
+  if (!host_phases().on) return;
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  const long long t0 = frame_t0_ns().load(std::memory_order_relaxed);
+  if (t0) host_phases().add(label, (double)(now - t0) * 1e-3);
 }
 struct NsScope {  // adds the scope's wall time to one of the counters above
   std::atomic<unsigned long long> &acc;
@@ -399,6 +414,22 @@ struct plv_ctx {
   bool prior_pending = false;  // plv_prior_prefetch started the prior factor for the update about to be launched (k = prior_k)
   int prior_k = 0;
   plv::PinBuf h_pin;
+  plv::PinBuf h_pin_l;  // result block of a LINE update (fdim 6): the point update's block may still be unread when the line gate writes
+  plv::PinBuf &res_pin(int fdim) { return fdim == 6 ? h_pin_l : h_pin; }
+  // What a line launch chained behind the point update needs beyond its own inputs (JacParams::chain_dx ...): filled by
+  // plv_camera_try_update (quaternions and covariance indices from the caller's variable list) and by the line half's submit
+  // (anchor candidates); `on` while a chained submit is being staged
+  struct ChainState {
+    bool ready = false, on = false;
+    std::vector<double> q;  // [n_clones][4]
+    std::vector<int> ids;   // [n_clones + 3]
+    double qe[4] = {0, 0, 0, 1};
+    std::vector<int> anc_ptr, anc_f;
+    std::vector<unsigned char> anc_has_old;
+    std::vector<double> anc_old;
+  } chain;
+  int *applied_word = nullptr;  // set by the caller of a launch that may end in ekf_commit_kernel: the kernel stores "state changed" there
+  bool applied_used = false;
   // Measurement knob PLV_KNOB_DONE_WORDS — completion words in pinned memory: the last kernel of the flow (word 0) and of an update
   // (word 16) stores the call's sequence number there behind its result block (system-scope release) and the host spins on the word
   // instead of waiting on an event.  Off by default (no gain in the frame, see the knob list).

@@ -33,6 +33,11 @@ struct Tracker {
   bool defer_db = false;           // plv_camera_try_update: the point update leaves its database hand-back to run_deferred_db
   const plv_state_view *early_st = nullptr;       // plv_camera_try_update with a line update to follow: the line pool is formed inside
   const plv_update_options *early_lines = nullptr;  // the point update's wait when the frame's line feed has finished by then
+  int early_cap = 0;                              // ... and, chained, the whole first half of the line update (line_cap)
+  // the pool of the fused point update being run: feature id -> index (only where the selection cannot hit its cap and the
+  // candidate has enough observations with bounding clones); the chained line launch finds its anchors through it
+  std::unordered_map<uint64_t, int> chain_index;
+  bool chain_ok = false;
   std::function<void()> deferred_db;
   std::unordered_map<uint64_t, Track> db;
   struct UsedPoint {
@@ -259,11 +264,26 @@ static void start_detection_ahead(void *arg) {
 }
 // LineHelper::get_line_features' pool (times only: nothing the point update changes) while the device is busy with that update;
 // polled inside the update's wait (plv_ctx::wait_poll) until the line worker has finished the frame's feed
+extern "C" void plv_line_feed_pool_args(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt);  // line_api.hip
+extern "C" int plv_camera_lines_submit_chained(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, int cap);  // line_api.hip
+extern "C" int plv_camera_lines_job_pending(plv_ctx *ctx);
+extern "C" void plv_camera_lines_job_abort(plv_ctx *ctx);
 static int poll_line_pool(void *arg) {
   plv_ctx *ctx = (plv_ctx *)arg;
   Tracker *T = trk(ctx);
   if (!T->early_lines || !T->early_st) return 1;
-  return plv_line_pool_prepare(ctx, T->early_st, T->early_lines);
+  if (!plv_line_pool_prepare(ctx, T->early_st, T->early_lines)) return 0;  // (the frame's line feed is still on the worker: try again)
+  // The line half's first half right here, its launch enqueued behind the point update that is still running (round 4): what used to
+  // sit between the two device chains — wake-up, selection, dx applied, line staging, upload, launch: ~45 us of idle device — is gone.
+  if (T->chain_ok && ctx->chain.ready && plv_update_state(ctx)->applied_armed && !plv::knob(plv::PLV_KNOB_NO_CHAIN))
+    (void)plv_camera_lines_submit_chained(ctx, T->early_st, T->early_lines, T->early_cap);
+  return 1;
+}
+// index of a feature in the pool of the point update being run (its triangulation result decides whether point_used gets the point)
+int plv_point_chain_lookup(plv_ctx *ctx, uint64_t id) {
+  Tracker *T = trk(ctx);
+  auto it = T->chain_index.find(id);
+  return it == T->chain_index.end() ? -1 : it->second;
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
@@ -671,9 +691,15 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       rc = plv_jacobian_columns(st, &all, cols.data(), (int)cols.size(), &k);
       if (rc == PLV_OK && k > 0) {
         ctx->gate_rows_hint = 2 * most_valid;
+        T->chain_index.clear();
+        T->chain_ok = Fp <= opt->max_msckf;  // (the selection loop cannot reach its cap: a candidate is taken on its own verdict)
+        if (T->chain_ok && T->early_lines)
+          for (int f = 0; f < Fp; ++f)
+            if (flags[f]) T->chain_index.emplace(pool[f].id, f);
         rc = plv_points_update_fused(ctx, st, &all, &opt->tri, flags.data(), opt->max_msckf, k, cols.data(), 2 * opt->max_obs,
                                      st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, pf.data(), ok.data(), err.data(), acc_all.data(),
                                      &n_rows, dx, start_detection_ahead, ctx);
+        T->chain_ok = false;
         res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
         if (rc == PLV_E_NOT_PSD) {
           rc = PLV_OK;  // EKFUpdate returned false: nothing changed, the call itself succeeded
@@ -920,16 +946,56 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   T->ahead_on_ctx_stream = io->opt_lines != nullptr && (ahead_ctx || plv::knob(plv::PLV_KNOB_AHEAD_CTX));
   T->early_st = io->opt_lines ? st : nullptr;
   T->early_lines = io->opt_lines;
+  T->early_cap = io->line_cap;
+  T->chain_ok = false;
+  // what a line launch chained behind the point update needs to form x (+) dx itself: the quaternions behind the view's rotation
+  // matrices and the covariance indices, from the caller's variable list (poses are PoseJPL: orientation at id, position at id + 3)
+  plv_ctx::ChainState &ch = ctx->chain;
+  ch.ready = false;
+  if (io->opt_lines && io->n_var > 0 && st->dt_state_id < 0 && !io->opt_lines->cpi) {
+    const int N = st->n_clones;
+    auto find = [&](int kind, int id, int size) -> const plv_state_var * {
+      for (int i = 0; i < io->n_var; ++i)
+        if (io->vars[i].kind == kind && io->vars[i].id == id && (kind == PLV_VAR_QUAT || io->vars[i].size == size)) return &io->vars[i];
+      return nullptr;
+    };
+    bool okc = true;
+    ch.q.assign(4 * (size_t)N, 0.0), ch.ids.assign(N + 3, -1);
+    for (int i = 0; i < N && okc; ++i) {
+      const int sid = st->clone_state_id[i];
+      const plv_state_var *vq = find(PLV_VAR_QUAT, sid, 3), *vp = find(PLV_VAR_VEC, sid + 3, 3);
+      // (the view must be what plv_state_boxplus keeps current: the variable's own array or its mirror)
+      const double *vR = st->clone_R + 9 * (size_t)i, *vP = st->clone_p + 3 * (size_t)i;
+      okc = sid >= 0 && vq && vp && (vq->out == vR || vq->mirror == vR) && (vp->val == vP || vp->mirror == vP);
+      if (okc) std::copy(vq->val, vq->val + 4, ch.q.begin() + 4 * (size_t)i), ch.ids[i] = sid;
+    }
+    if (okc && st->extrinsic_state_id >= 0) {
+      const plv_state_var *vq = find(PLV_VAR_QUAT, st->extrinsic_state_id, 3), *vp = find(PLV_VAR_VEC, st->extrinsic_state_id + 3, 3);
+      okc = vq && vp;
+      if (okc) std::copy(vq->val, vq->val + 4, ch.qe), ch.ids[N] = st->extrinsic_state_id;
+    }
+    if (okc && st->intrinsic_state_id >= 0) {
+      okc = find(PLV_VAR_VEC, st->intrinsic_state_id, 8) != nullptr;
+      ch.ids[N + 1] = st->intrinsic_state_id;
+    }
+    ch.ready = okc;
+  }
   ctx->wait_poll = io->opt_lines ? poll_line_pool : nullptr;
   ctx->wait_poll_arg = ctx;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
   ctx->wait_poll = nullptr;
+  ch.ready = false;
   T->defer_db = T->ahead_on_ctx_stream = false;
   T->early_st = nullptr, T->early_lines = nullptr;
-  if (rc != PLV_OK && io->opt_lines) plv_line_pool_discard(ctx);
+  const bool chained = io->opt_lines && plv_camera_lines_job_pending(ctx);
+  if (rc != PLV_OK && io->opt_lines) {
+    if (chained) plv_camera_lines_job_abort(ctx);
+    plv_line_pool_discard(ctx);
+  }
   // REF UpdaterCamera.cpp:148-152: get_line_features runs between get_features and msckf_update — the line pool is triangulated on
-  // the state as it is before the point update's correction is applied
-  if (rc == PLV_OK && io->opt_lines) rc = plv_camera_get_line_features(ctx, st);
+  // the state as it is before the point update's correction is applied (chained: its launch is already on the stream, staged from st)
+  if (rc == PLV_OK && io->opt_lines && !chained) rc = plv_camera_get_line_features(ctx, st);
+  plv::frame_mark("@ update_points returned");
   if (rc == PLV_OK) rc = apply(*io->res_points, io->dx_points);
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);
@@ -968,6 +1034,8 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
       plv::host_phases().add("frame: voluntary context switches (count)", (double)(b.ru_nvcsw - a.ru_nvcsw));
     }
   } ru_scope;
+  if (plv::host_phases().on)
+    plv::frame_t0_ns().store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
   plv::RoctxRange rx_feed("[Time-Cam] feed measurement");
   if (io->slot >= 0)
     TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
@@ -979,8 +1047,10 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
     TRY(plv_vanishing_points(st->R_ItoC, st->intrinsics, vps));
     // with an update to follow, the line tracker's host logic runs on the worker thread next to the point update (joined inside
     // plv_camera_try_update); otherwise in place
-    if (io->update && io->update->opt_lines)
+    if (io->update && io->update->opt_lines) {
+      plv_line_feed_pool_args(ctx, st, io->update->opt_lines);  // (the worker forms the line update's pool at the end of the feed)
       TRY(plv_line_tracker_feed_async(ctx, io->timestamp, vps));
+    }
     else
       TRY(plv_line_tracker_feed(ctx, io->timestamp, vps));
   }
@@ -989,7 +1059,9 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
     return PLV_OK;
   }
   rx_feed.stop();
+  plv::frame_mark("@ feed done, try_update starts");
   const int rc = plv_camera_try_update(ctx, st, io->update);
+  plv::frame_mark("@ try_update returned");
   if (lines && !io->update->opt_lines) (void)plv_line_tracker_feed_wait(ctx);
   io->line_db_size = io->update->opt_lines ? io->update->line_db_size : (lines ? plv_line_db_size(ctx) : 0);
   return rc;

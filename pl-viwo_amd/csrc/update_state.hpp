@@ -30,8 +30,18 @@ struct plv_ctx_update_state {
     double *d_dx = nullptr;
     int *d_flag = nullptr;
   } redo;
-  int acc_word = 2;        // word of the status block the fused gate's next update counts its accepted entries in (1 or 2, alternating)
-  int acc_word_used = 1;   // ... and the word the last launched update's chain read as its skip word (1: chi2_gate_kernel's)
+  // Status block of a LINE update (round 4): the chained line launch reads the point update's dx from `result` while its own gate
+  // writes verdicts — and a larger line batch may make its block grow — so the two measurement kinds keep separate blocks, each with
+  // its own pair of alternating accepted-entry counters.
+  plv::DevBuf result_l;
+  struct AccWords {
+    int word = 2;             // word of the status block the fused gate's next update counts its accepted entries in (1 or 2, alternating)
+    const void *z_ptr = nullptr;  // (z_ptr, z_n, z_word): the counter word known to be zero on the stream — the gate of the update before
+    int z_n = 0, z_word = 0;      // zeroed it; anything else (first use, the block moved or grew, cov_n changed, a launch declined the gate) is zeroed by a memset
+  } acc[2];
+  plv::DevBuf &result_of(int fdim) { return fdim == 6 ? result_l : result; }
+  AccWords &acc_of(int fdim) { return acc[fdim == 6 ? 1 : 0]; }
+  int acc_word_used = 1;   // the word the last launched update's chain read as its skip word (1: chi2_gate_kernel's)
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)
@@ -60,6 +70,21 @@ struct plv_ctx_update_state {
   plv::DevBuf jin, tri, eval;
   plv::PinBuf h_jin;  // dedicated pinned staging: its upload is not followed by a host sync
   plv::PinBuf h_tri;  // triangulation results of the one-submission updates
+  // the line half's own staging, triangulation and result blocks (round 4): the line launch of a frame is staged and enqueued while
+  // the point update is still running and being collected (plv_camera_try_update's chained line launch), so nothing of the two
+  // halves may share a buffer the host writes or reads
+  plv::DevBuf jin_l, tri_l;
+  plv::PinBuf h_jin_l, h_tri_l;
+  size_t lt_o_lines = 0;  // plv_lines_update_fused_submit -> _finish: where the triangulated lines sit in tri_l, how many
+  int lt_L = 0;
+  int pending_fdim = 3;  // measurement size of the launched, not yet collected update (selects the pinned result block)
+  // where the last fused point launch left its triangulation results on the device (the chained line launch reads its anchors there)
+  const double *pt_tri_p = nullptr;
+  const unsigned char *pt_tri_ok = nullptr;
+  int pt_tri_F = 0;
+  plv::DevBuf chain_words;      // home of applied_word
+  int *applied_word = nullptr;  // device word ekf_commit_kernel sets to 1 when the point update changed the state (0: dx is not to be applied)
+  bool applied_armed = false;   // ... and the last point launch ended in that kernel with the word as its argument
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
 
@@ -75,4 +100,8 @@ extern "C" int plv_lines_update_fused(plv_ctx *ctx, const plv_state_view *st, co
                                       const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
                                       double chi2_mult, double *lines_out, uint8_t *ok_out, uint8_t *accepted, int *n_rows, double *dx,
                                       void (*before_wait)(void *), void *before_wait_arg);
+extern "C" int plv_lines_update_fused_submit(plv_ctx *ctx, const plv_state_view *st, const plv_state_view *st_tri, const plv_line_tracks *all,
+                                             const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult);
+extern "C" int plv_lines_update_fused_finish(plv_ctx *ctx, double sigma2, double chi2_mult, double *lines_out, uint8_t *ok_out, uint8_t *accepted,
+                                             int *n_rows, double *dx, void (*before_wait)(void *), void *before_wait_arg);
 extern "C" void plv_tracker_run_deferred(void *ctx);  // tracker_api.hip

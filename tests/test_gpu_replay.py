@@ -275,6 +275,58 @@ def test_gate_inside_the_jacobian_launch_equals_the_separate_launches(pkg, stree
     assert launches["fused"] <= launches["separate"] - 3 * s0["cam_updates"], launches     # (it did run)
 
 
+def test_chained_line_launch_equals_the_unchained(pkg, street_dataset, tmp_path):
+    """plv_camera_try_update's chained line launch (round 4: the line half is staged inside the point update's wait and its launch
+    enqueued behind that update; the kernel applies the point update's dx to the staged state itself — the arithmetic of
+    plv_state_boxplus — and looks its anchor points up in that update's triangulation results) against the round-3 order (knob 2048:
+    wait for the point update, apply dx on the host, then stage and launch the lines): the same filter, bit for bit — and it did run
+    chained (plv_chain_count)."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs, chained = {}, {}
+    try:
+        for name, mask in (("chained", 4096), ("unchained", 2048)):     # (4096: chained in every frame, whatever the line worker's timing)
+            pkg.debug_knobs(mask)
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{name}.txt")))
+            op.est.cam.use_lines = True
+            c0 = pkg.chain_count()
+            runs[name] = rp.replay(op)
+            chained[name] = pkg.chain_count() - c0
+    finally:
+        pkg.debug_knobs(0)
+    s0, t0, p0 = runs["unchained"]
+    s1, t1, p1 = runs["chained"]
+    assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
+    for key in s0:
+        if not key.startswith("time"):
+            assert s1[key] == s0[key], (key, s1[key], s0[key])
+    assert np.array_equal(t1, t0) and np.array_equal(p1, p0)
+    assert chained["unchained"] == 0 and chained["chained"] >= 0.9 * s0["line_updates"] and chained["chained"] >= 10, chained
+
+
+def test_prior_factor_started_late_equals_the_prefetched(pkg, street_dataset, tmp_path):
+    """The whitened update's prior factor started behind the Jacobian launch (measurement knob 2 = plv_update_compression_mode 4: the
+    side stream reads the column map that launch publishes, so it must be ordered behind it — ADVICE r3: it was not) against the
+    default (started from the pinned staging block before the launch): the same filter, bit for bit, over alternating point and
+    line updates (their column sets differ, so a stale map would show at once)."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs = {}
+    try:
+        for name, mask in (("prefetched", 0), ("late", 2)):
+            pkg.debug_knobs(mask)
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{name}.txt")))
+            op.est.cam.use_lines = True
+            runs[name] = rp.replay(op)
+    finally:
+        pkg.debug_knobs(0)
+    s0, t0, p0 = runs["prefetched"]
+    s1, t1, p1 = runs["late"]
+    assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
+    for key in s0:
+        if not key.startswith("time"):
+            assert s1[key] == s0[key], (key, s1[key], s0[key])
+    assert np.array_equal(t1, t0) and np.array_equal(p1, p0)
+
+
 def test_replay_downsampled_clahe(pkg, dataset, tmp_path):
     """cam.downsample (pyrDown of every image, halved intrinsics: OptionsCamera.cpp:123-138, UpdaterCamera.cpp:85-98) with the CLAHE
     front-end on the 376 x 240 images."""
