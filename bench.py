@@ -202,7 +202,13 @@ def cpu_baseline(wl, stream, n_frames, budget_s, thread_counts):
             cam_features=st["cam_features"], cam_accepted=st["cam_accepted"], lines_accepted=st["lines_accepted"])
         sm.close()
     one = out["1_thread"]
+    best_key = min(out, key=lambda kk: out[kk]["inside_mean_ms"])
+    best = out[best_key]
     return {"value": 1e3 / one["inside_mean_ms"], "unit": "frames/s", "cores": 1, "kind": "port",
+            #  the fastest thread count next to the 1-thread figure, each with its cores
+            "value_all_cores": 1e3 / best["inside_mean_ms"], "cores_all_cores": best["threads"], "ms_per_frame_1_thread": one["inside_mean_ms"],
+            "ms_per_frame_all_cores": best["inside_mean_ms"], "host_cores": os.cpu_count(),
+            "threads_tried": sorted(d["threads"] for d in out.values()),
             "sample": f"{one['frames']} frames of the same stream through oracle/frame_oracle.cpp (feed_measurement + try_update compiled end to "
                       f"end, g++ -O3, timed inside the library with steady_clock): {one['inside_mean_ms']:.2f} ms mean / {one['inside_p50_ms']:.2f} p50 / "
                       f"{one['inside_p99_ms']:.2f} p99 per frame on 1 thread ({one['driver_call_mean_ms']:.2f} ms with the Python driver's call around "
@@ -542,6 +548,12 @@ def main():
         var_ms, def_ms, v = alternating(lambda: ctx.update_compression_mode(3), lambda: ctx.update_compression_mode(0))
         variants["compression_gram_cholesky"] = {"ms_per_step": var_ms, "default_ms_per_step_on_the_alternate_frames": def_ms, "frames": nvar,
                                                  "frames_whose_last_update_met_ambiguous_pivots": v["cnt"]["ambiguous_frames"]}
+        # (c) the north star's 21 x 21 LK patch (plv_config.win_size; 15 is the reference's value and the parity setting): every lane of a
+        # point's workgroup carries a second window pixel
+        var_ms, def_ms, v = alternating(lambda: ctx.set_lk_window(21), lambda: ctx.set_lk_window(15))
+        variants["win21"] = {"ms_per_step": var_ms, "default_ms_per_step_on_the_alternate_frames": def_ms, "frames": nvar,
+                             "what": "plv_set_lk_window(21): 21 x 21 LK window (441 pixels per point per level) instead of 15 x 15; the tracks differ, "
+                                     "so this is a cost figure, not a parity run"}
         var_ms, def_ms, v = alternating(lambda: pkg.line_worker_config(0, -1), lambda: pkg.line_worker_config(spin_us, -1))
         variants["line_threads_blocking"] = {"ms_per_step": var_ms, "default_ms_per_step_on_the_alternate_frames": def_ms, "frames": nvar,
                                             "what": "PLV_LINE_SPIN_US=0: the line worker and the fitters sleep on their condition variables"}
@@ -575,6 +587,10 @@ def main():
                              pool_pts=stats["cam_features"] / max(1, args.steps) * 1.5, pool_lines=stats["line_pool"] / max(1, args.steps))
         kernels = {k: v for k, v in table.items() if v[0] > 0}
         traffic_tab, traffic_src = pmc_table()
+        abytes = wm.frame_bytes(wl["w"], wl["h"], ctx.pyramid_levels(0), tracked, cnt["lk_iters"] / args.steps, 15, F, M, k_cols, n_state, L=L,
+                                Ml=max(2, M // 3), kl=k_cols, n_new=max(1, wl["num_features"] // M),
+                                pool_pts=stats["cam_features"] / max(1, args.steps) * 1.5, pool_lines=stats["line_pool"] / max(1, args.steps),
+                                n_clones=wl["hz"] + 1)
 
         def entry(name):
             n_launch, ms = kernels[name]
@@ -588,10 +604,14 @@ def main():
             alias = {"tri_jacobian_nullspace_kernel": "jacobian_nullspace_kernel", "line_tri_jacobian_nullspace_kernel": "line_jacobian_nullspace_kernel",
                      "half_canny_kernel": "canny_kernel"}
             tr = traffic_tab.get(name, traffic_tab.get(alias.get(name, name)))
+            ab = abytes.get(name, abytes.get(alias.get(name, name), per_launch if kind == "hbm" else 0.0))
             return {"kernel": name, "bound": kind, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_frame": round(n_launch / max(1, done), 2),
                     "us_per_frame": round(ms / max(1, done) * 1e3, 2), "algorithmic_per_launch": per_launch, "achieved": achieved, "peak": peak,
                     "unit": unit, "frac": achieved / peak, "traffic": tr,
-                    "traffic_over_algorithmic": (round(tr / per_launch, 2) if (tr and per_launch and kind == "hbm") else None)}
+                    # bytes for EVERY kernel (tools/work_model.py frame_bytes): counter traffic well above them = wasted re-reads
+                    "algorithmic_bytes_per_launch": round(ab), "traffic_over_algorithmic": (round(tr / ab, 2) if (tr and ab) else None),
+                    "achieved_GBps": round(ab / avg_s / 1e9, 2) if ab else None,
+                    "work_model": wm.PROVENANCE.get(name, wm.PROVENANCE.get(alias.get(name, name), "estimate"))}
 
         # kernels on side streams, next to the chain the frame waits for: the whitened update's prior factor (every update starts one;
         # its result is only consumed when the gate accepts something), the next frame's detection
@@ -601,7 +621,8 @@ def main():
         top = entry(on_path[0])
         roof = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
                 "traffic": top["traffic"], "traffic_source": traffic_src, "kernel": top["kernel"], "avg_launch_us": top["avg_launch_us"],
-                "algorithmic_per_launch": top["algorithmic_per_launch"],
+                "algorithmic_per_launch": top["algorithmic_per_launch"], "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                "traffic_over_algorithmic": top["traffic_over_algorithmic"], "work_model": top["work_model"],
                 "launches_per_frame": round(sum(v[0] for v in kernels.values()) / max(1, done), 1),
                 "kernel_us_per_frame_total": round(sum(v[1] for v in kernels.values()) / max(1, done) * 1e3, 1),
                 "per_kernel": [dict(entry(k), on_the_critical_stream=k not in side) for k in order[:10]],
@@ -644,6 +665,8 @@ def main():
             for key, d in cpu["detail"].items():
                 if key != "1_thread":
                     vs[f"speedup_vs_cpu_{key}"] = d["inside_mean_ms"] / ms_step
+            vs["speedup_vs_cpu_all_cores"] = cpu["ms_per_frame_all_cores"] / ms_step
+            vs["cpu_all_cores_threads"] = cpu["cores_all_cores"]
         line = {
             "metric": ("frames/sec (track+EKF update), 752x480 mono, 250 pts+80 lines; ATE vs CPU ref" if args.workload == "C" else
                        f"frames/sec (track+EKF update), {wl['w']}x{wl['h']} mono, {wl['points']} pts" + (" + lines" if wl["lines"] else "")),
@@ -658,6 +681,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            # scalars first (whatever keeps only the scalar fields of this line still gets them); `value` is the
+            # resident-image step (the contract), *_pcie_inclusive the drop-in adapter's call (host cv::Mat pointer, slot -1)
+            "latency_p50_ms": pct(per, 50), "latency_p99_ms": pct(per, 99),
+            "ms_per_step_pcie_inclusive": None if seg_pcie is None else seg_pcie["elapsed"] / args.steps * 1e3,
+            "value_pcie_inclusive": None if seg_pcie is None else args.steps * world / seg_pcie["elapsed"],
+            "vs_cpu_1_thread": vs.get("speedup_resident"), "vs_cpu_all_cores": vs.get("speedup_vs_cpu_all_cores"),
+            "vs_cpu_all_cores_pcie_inclusive": (None if (cpu is None or seg_pcie is None) else cpu["ms_per_frame_all_cores"] / (seg_pcie["elapsed"] / args.steps * 1e3)),
+            "cpu_all_cores_threads": None if cpu is None else cpu["cores_all_cores"],
             "config": {
                 "workload": f"BASELINE {wl['cfg']}: {what}; {wl['hz']}-clone window ({wl['hz']} Hz camera and clones, 1 s), n = {n_state}; "
                             "rendered corridor drive ('avenue' scene) with IMU + wheel odometry; the update consumes the tracker's own database",
@@ -666,6 +697,13 @@ def main():
                         "plv_ctx_synchronize (ctx stream, detection side stream, line worker); sequential; IMU propagation, cloning, "
                         "marginalisation and wheel updates run between the steps, untimed",
                 "replicas": world, "n_state": n_state,
+                # (scalar copies of what the nested blocks below hold)
+                "tracked_points_per_frame": mean(per_frame["tracked"]), "lines_kept_per_frame": mean(per_frame["kept"]) if wl["lines"] else 0,
+                "msckf_features_per_update": round(stats["cam_features"] / args.steps, 2), "lines_triangulated_per_frame": round(stats["lines_triangulated"] / args.steps, 2),
+                "kernel_launches_per_frame": round(cnt["launches"] / args.steps, 1), "host_synchronisations_per_frame": round(cnt["syncs"] / args.steps, 1),
+                "line_launches_chained_per_frame": round(cnt.get("chained", 0) / args.steps, 2),
+                "ms_per_step_inside_the_library": round((cnt["frame_ns"] + cnt["sync_ns"]) / args.steps * 1e-6, 4),
+                "ms_per_step_pcie_inclusive": None if seg_pcie is None else round(seg_pcie["elapsed"] / args.steps * 1e3, 4),
                 "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0,
                                  "library_segment_fitters": (min(fit_threads, 2 if (wl["w"] // 2) * (wl["h"] // 2) >= 150000 else 1) if wl["lines"] else 0),
                                  "library_segment_fitters_configured_maximum": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,

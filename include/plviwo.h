@@ -870,6 +870,11 @@ int plv_init_imu_wheel(const plv_iw_init_options *opt, plv_iw_init_state *state,
 /* StateHelper::EKFUpdate refreshes the tracker's camera model after every update when the intrinsics are calibrated
  * online (REF: PL-VIWO/src/state/StateHelper.cpp:163-168): same for the ctx (undistortion, RANSAC threshold). */
 int plv_set_camera_intrinsics(plv_ctx *ctx, const double *K8);
+/* plv_config::win_size after the context was made (REF: TrackKLT.h:143-144 `win_size`, the winSize of calcOpticalFlowPyrLK at
+ * TrackKLT.cpp:857-858 and of buildOpticalFlowPyramid at :71): odd, 3 .. 21.  The pyramids are laid out for the window they were
+ * made with (a level exists while both its sides exceed the window): a window that would change the number of levels is refused
+ * (PLV_E_BADARG) once an image was fed.  Takes effect with the next flow. */
+int plv_set_lk_window(plv_ctx *ctx, int win_size);
 /* ov_type::JPLQuat::update for n orientations at once (REF: open_vins/ov_core/src/types/JPLQuat.h:62-73): q [n][4] <- quatnorm([dth / 2, 1]) (x) q
  * with w >= 0 (dth [n][3]; NULL = leave q as it is), and R [n][9] (nullable) = quat_2_Rot(q) row-major.  Host arithmetic for the driver's
  * application of dx to the clone window. */

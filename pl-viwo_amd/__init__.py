@@ -149,6 +149,7 @@ def load_library():
         "plv_init_imu_wheel": (C.c_int, [C.POINTER(PlvIwInitOptions), C.POINTER(PlvIwInitState), C.c_int, dp, dp, dp, C.c_int, dp, dp, dp,
                                          dp, ip, ip, dp]),
         "plv_set_camera_intrinsics": (C.c_int, [vp, dp]),
+        "plv_set_lk_window": (C.c_int, [vp, C.c_int]),
         "plv_wheel_update": (C.c_int, [vp, C.POINTER(PlvWheelOptions), C.POINTER(PlvWheelState), C.c_int, dp, dp, dp, u8p, dp]),
         "plv_next_clone_time": (C.c_int, [C.POINTER(PlvCloneSchedule), dp, ip]),
         "plv_closest_clone_time": (C.c_int, [C.POINTER(PlvStateView), C.c_int, C.c_double, dp, ip]),
@@ -1073,6 +1074,10 @@ class Context:
         self._chk(self.lib.plv_slam_initialize(self.h, rows, k, rows, _dp(Hf), _dp(Hx), _dp(res), _ip(cols), float(chi2_mult), _u8p(ok),
                                                _dp(dxi), _dp(dx)))
         return int(ok[0]), dxi, dx
+
+    def set_lk_window(self, win):
+        """plv_set_lk_window: the LK window (plv_config.win_size) of a live context"""
+        self._chk(self.lib.plv_set_lk_window(self.h, int(win)))
 
     def set_camera_intrinsics(self, K8):
         K8 = _c64(K8)

@@ -54,6 +54,13 @@ struct CompressOps {
 // pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
 // the smallest live one 1.5e-7; DESIGN.md "Whitened update")
 #define PLV_PRIOR_TAU 2e-13
+// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies: the factor divides by them and the
+// rows of W0 they scale lose eps / pivot of their digits (round 4: with time stamps of 1.5e9 s the IMU pose sits a quarter of a
+// microsecond of propagation behind the clone taken of it: three pivots of 1e-11 .. 1e-9, a first update rejected as "not positive
+// definite", later ones off by 1e-7).  Healthy windows have their smallest live pivot at 7e-8 or above (profiles/r04 README).  The
+// kernel reports their number; the update's commit is then withheld and the host runs the update through the S = H P H^T + R route
+// (plv_api.hip, RedoW).
+#define PLV_PRIOR_AMB 3e-9
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
@@ -99,6 +106,9 @@ struct PriorOps {
   double dval;
   double *scw;
   bool store_l;  // one workgroup writes the factor, every workgroup its own border strip
+  int *n_near;   // (that workgroup) counts the near-dependent pivots here: a diagonal entry l_cc of the unit-diagonal factor with
+                 // 0 < l_cc^2 < PLV_PRIOR_AMB.  Counted where the factor is stored, not inside the pivot chain: that code is as
+                 // fragile under hipcc 7.2 as the panel loop (an extra test in it gave a wrong factor for ten tiles)
   __device__ __forceinline__ double sym_raw(int i, int c) const {
     return P[(size_t)cols[min(i, k - 1)] * ldp + cols[min(c, k - 1)]];
   }
@@ -120,6 +130,7 @@ struct PriorOps {
   __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b < n && c < k) ? g * sc[min(c, k - 1)] : 0.0; }
   __device__ __forceinline__ void store_sym(int i, int c, double l) const {
     if (store_l && i < k && c <= i) {
+      if (c == i && n_near && l > 0.0 && l * l < PLV_PRIOR_AMB) atomicAdd(n_near, 1);
       Lt[(size_t)i * ldl + c] = l * sc[192 + i];
       if (c < i) Lt[(size_t)c * ldl + i] = 0.0;
     }
@@ -131,7 +142,8 @@ struct PriorOps {
 
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double *__restrict__ P, int ldp, int n, const int *__restrict__ cols_g,
-                                                                   int k, double *__restrict__ Lt, int ldl, double *__restrict__ W0, int ldw) {
+                                                                   int k, double *__restrict__ Lt, int ldl, double *__restrict__ W0, int ldw,
+                                                                   int *__restrict__ n_near /* near-dependent pivots (workgroup 0 writes it) */) {
   __shared__ BcLds lds;
   __shared__ double sc[384];
   __shared__ int scols[192];
@@ -141,8 +153,9 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double
   __syncthreads();
   const int *cols = scols;
   const int jd = cols[min((int)threadIdx.x, k - 1)];
-  PriorOps ops{P, ldp, n, cols, k, sc, Lt, ldl, W0, ldw, P[(size_t)jd * ldp + jd], sc, blockIdx.x == 0};
+  PriorOps ops{P, ldp, n, cols, k, sc, Lt, ldl, W0, ldw, P[(size_t)jd * ldp + jd], sc, blockIdx.x == 0, blockIdx.x == 0 ? n_near : nullptr};
   if (threadIdx.x == 0) {
+    if (n_near && blockIdx.x == 0) *n_near = 0;
     lds.bad = 0;
     lds.step_flag = 0;
     lds.rs_flag = 0;
@@ -252,12 +265,12 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
 }
 // Prior factor of the whitened route on stream `st` (a side stream: it only needs the covariance).
 int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp, int n, const int *d_cols, int k, double *d_Lt, int ldl,
-                       double *d_W0, int ldw) {
+                       double *d_W0, int ldw, int *d_n_near) {
   if (k > 192) return PLV_E_CAPACITY;
   const int groups = cdiv(n, 16);
   ProfScope ps(ctx->prof, "bchol_prior_kernel", st);
 #define PLV_PRIOR_LAUNCH(NT) \
-  hipLaunchKernelGGL(bchol_prior_kernel<NT>, dim3(groups), dim3(64 * (NT + 1)), 0, st, d_P, ldp, n, d_cols, k, d_Lt, ldl, d_W0, ldw)
+  hipLaunchKernelGGL(bchol_prior_kernel<NT>, dim3(groups), dim3(64 * (NT + 1)), 0, st, d_P, ldp, n, d_cols, k, d_Lt, ldl, d_W0, ldw, d_n_near)
   if (k <= 32)
     PLV_PRIOR_LAUNCH(2);
   else if (k <= 64)

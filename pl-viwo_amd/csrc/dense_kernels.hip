@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
 // The last kernel of the update also mirrors the small result block (dx, flag, accepted, rows) into the caller's pinned host
 // buffer, so that no copy command sits between the end of the chain and the host's wait.
 __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P, int ldp, int n,
-                                                         const double *__restrict__ dC, int ldc, const int *__restrict__ flag,
+                                                         const double *__restrict__ dC, int ldc, int *__restrict__ flag,
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
                                                          int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
                                                          const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
@@ -210,6 +210,12 @@ __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P
   // applied_out: "this update changed the state" — StateHelper::EKFUpdate reached its mean update (:156-168): read by a launch that is
   // enqueued behind the update before the host has seen its result and applies dx to its own copy of the state (the chained line launch)
   if (applied_out && blockIdx.x == 0 && threadIdx.x == 0) *applied_out = (skipped || *flag != 0) ? 0 : 1;
+  // a veto is part of the status the host (and a launch chained behind this update) reads: bit 8 = "withheld, to be run again"
+  const bool vetoed = veto && *veto != 0 && !(skip && *skip == 0);
+  if (blockIdx.x == 0) {
+    if (vetoed && threadIdx.x == 0) atomicOr(flag, 8);
+    if (vetoed) __syncthreads();
+  }
   if (blockIdx.x == 0) {
     if (skipped && dx) {
       for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.0;
@@ -317,6 +323,25 @@ static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const do
   return PLV_OK;
 }
 
+// The gate leaves only the accepted entries in the stack when the Gram-based routes follow (they walk the accepted entries); before a
+// Householder factorisation of the WHOLE stack (the last resort of a whitened update that was run again, plv_api.hip RedoW) the slots
+// of the other entries are cleared: a zero row changes no QR factor.
+__global__ void __launch_bounds__(256) stack_zero_rejected_kernel(double *__restrict__ A, int lda, int nc, const int *__restrict__ acc_rows, int F, int mp_max) {
+  const int f = blockIdx.x;
+  if (f >= F) return;
+  const int keep = max(acc_rows[f], 0);
+  for (int idx = threadIdx.x; idx < nc * mp_max; idx += blockDim.x) {
+    const int j = idx / mp_max, i = idx - j * mp_max;
+    if (i >= keep) A[(size_t)j * lda + (size_t)f * mp_max + i] = 0.0;
+  }
+}
+int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max) {
+  ProfScope ps(ctx->prof, "stack_zero_rejected_kernel", ctx->stream);
+  hipLaunchKernelGGL(stack_zero_rejected_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 // ------------------------------------------------------------------------------------------ whitened update
 // The compressed update without a factorisation of the measurement side (DESIGN.md "Whitened update").  With G = H^T H, g = H^T r
 // (noise-normalised, as the reference's compression leaves them) and Ps = P[cols, cols] = Lp Lp^T:
@@ -330,7 +355,8 @@ int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, 
   if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
       (rc = ctx->d_dW.reserve((size_t)n * n * 8)))
     return rc;
-  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k))) return rc;
+  if ((rc = ctx->d_prior_near.reserve(64))) return rc;
+  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
   {
     ProfScope ps(ctx->prof, "prior_gain_kernel", st);
     const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
@@ -370,7 +396,11 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, double
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
                        ctx->d_dW.as<double>());
   }
-  return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
+  const int *veto_keep = ctx->commit_veto;
+  ctx->commit_veto = ctx->d_prior_near.as<int>();  // (the prior factor's own verdict: see PLV_PRIOR_AMB)
+  rc = launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
+  ctx->commit_veto = veto_keep;
+  return rc;
 }
 
 }  // namespace plv

@@ -78,6 +78,27 @@ int level_geometry(int W, int H, int win, int max_level, PyrDesc &p) {
   return (int)off;
 }
 
+}  // namespace
+extern "C" int plv_set_lk_window(plv_ctx *ctx, int win) {
+  if (!ctx || win < 3 || win > 21 || (win & 1) == 0) {
+    set_last_error("plv_set_lk_window: odd window sizes 3 .. 21");
+    return PLV_E_BADARG;
+  }
+  if (ctx->fe_state) {
+    FrontState *s = (FrontState *)ctx->fe_state;
+    if (s->pyr_mem[0].p) {
+      PyrDesc want{};
+      (void)level_geometry(s->W, s->H, win, ctx->cfg.pyr_levels, want);
+      if (want.levels != s->pyr[0].levels) {
+        set_last_error("plv_set_lk_window: a %d x %d window gives %d pyramid levels, the pyramids of this context have %d", win, win, want.levels, s->pyr[0].levels);
+        return PLV_E_BADARG;
+      }
+    }
+  }
+  ctx->cfg.win_size = win;
+  return PLV_OK;
+}
+namespace {
 FrontState *fe(plv_ctx *ctx) {
   if (!ctx->fe_state) {
     auto *s = new FrontState();

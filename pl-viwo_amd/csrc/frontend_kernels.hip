@@ -307,14 +307,16 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------ K3
-#define LK_MAXWIN 15
+#define LK_MAXWIN 21             // 15 is the reference's setting and the parity value (TrackKLT.h:143-144); SURVEY D1 / the north star name 21
 #define LK_TT (LK_MAXWIN + 3)   // template footprint incl. Scharr halo and bilinear +1
 #define LK_JT 32                // search tile edge
 #define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 
 // One workgroup of four waves per point; all pyramid levels, coarse to fine.  One window pixel per lane (15 x 15 = 225 of the 256
-// lanes).  The mismatch sums are exact integers: reduced inside each wave on 32-bit registers (|diff| <= 255 * 32 and |Ix|, |Iy| <=
+// lanes); windows of more than 256 pixels (17 x 17 .. 21 x 21, round 4) give the lanes a second pixel each, summed in a wave
+// reduction of its own (a wave's sum of one pixel per lane stays below 2^31; of two it would not), and nothing changes for 15 x 15.
+// The mismatch sums are exact integers: reduced inside each wave on 32-bit registers (|diff| <= 255 * 32 and |Ix|, |Iy| <=
 // 16 * 255 — Scharr on 8-bit pixels — so a pixel's product stays below 2^25 and a wave's sum below 2^31), the four wave sums meet in
 // LDS (two slots, alternating by iteration: one barrier per iteration) and every lane adds them as 64-bit integers, so every lane
 // takes the same float step.  (Round 2: one wave per point with four pixels per lane took 52 us per launch, this form 45 — the
@@ -328,8 +330,8 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
   __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
   __shared__ uint8_t jtile[LK_JT][LK_JT];
-  __shared__ int part[2][LK4_WAVES][2];
-  __shared__ int partA[LK4_WAVES][3];
+  __shared__ int part[2][LK4_WAVES][2], part2[2][LK4_WAVES][2];
+  __shared__ int partA[LK4_WAVES][3], partA2[LK4_WAVES][3];
   const int pt = blockIdx.x;
   if (pt >= n) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -346,6 +348,9 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   int st = 1, iters = 0, slot = 0;
   const bool own = tid < npx;
   const int wy = own ? tid / win : 0, wx = own ? tid - wy * win : 0;
+  const bool two = npx > 64 * LK4_WAVES;  // (uniform) a second window pixel per lane
+  const bool own2 = two && tid + 64 * LK4_WAVES < npx;
+  const int wy2 = own2 ? (tid + 64 * LK4_WAVES) / win : 0, wx2 = own2 ? tid + 64 * LK4_WAVES - wy2 * win : 0;
 
   for (int level = maxLevel; level >= 0; --level) {
     const float sc = 1.f / (float)(1 << level);
@@ -395,21 +400,34 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
     int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-    int Iv = 0, Ix = 0, Iy = 0;
+    int Iv = 0, Ix = 0, Iy = 0, Iv2 = 0, Ix2 = 0, Iy2 = 0;
     if (own) {
       Iv = DESCALE(ttile[wy + 1][wx + 1] * iw00 + ttile[wy + 1][wx + 2] * iw01 + ttile[wy + 2][wx + 1] * iw10 + ttile[wy + 2][wx + 2] * iw11,
                    W_BITS - 5);
       Ix = DESCALE(tdx[wy][wx] * iw00 + tdx[wy][wx + 1] * iw01 + tdx[wy + 1][wx] * iw10 + tdx[wy + 1][wx + 1] * iw11, W_BITS);
       Iy = DESCALE(tdy[wy][wx] * iw00 + tdy[wy][wx + 1] * iw01 + tdy[wy + 1][wx] * iw10 + tdy[wy + 1][wx + 1] * iw11, W_BITS);
     }
+    if (own2) {
+      Iv2 = DESCALE(ttile[wy2 + 1][wx2 + 1] * iw00 + ttile[wy2 + 1][wx2 + 2] * iw01 + ttile[wy2 + 2][wx2 + 1] * iw10 + ttile[wy2 + 2][wx2 + 2] * iw11,
+                    W_BITS - 5);
+      Ix2 = DESCALE(tdx[wy2][wx2] * iw00 + tdx[wy2][wx2 + 1] * iw01 + tdx[wy2 + 1][wx2] * iw10 + tdx[wy2 + 1][wx2 + 1] * iw11, W_BITS);
+      Iy2 = DESCALE(tdy[wy2][wx2] * iw00 + tdy[wy2][wx2 + 1] * iw01 + tdy[wy2 + 1][wx2] * iw10 + tdy[wy2 + 1][wx2 + 1] * iw11, W_BITS);
+    }
     {  // |Ix|, |Iy| <= 4080: a product < 2^24, a wave's sum < 2^30
       const int a11 = wave_sum_i32(Ix * Ix), a12 = wave_sum_i32(Ix * Iy), a22 = wave_sum_i32(Iy * Iy);
       if (lane == 0) partA[wave][0] = a11, partA[wave][1] = a12, partA[wave][2] = a22;
+      if (two) {
+        const int c11 = wave_sum_i32(Ix2 * Ix2), c12 = wave_sum_i32(Ix2 * Iy2), c22 = wave_sum_i32(Iy2 * Iy2);
+        if (lane == 0) partA2[wave][0] = c11, partA2[wave][1] = c12, partA2[wave][2] = c22;
+      }
     }
     __syncthreads();
     double sA11 = 0.0, sA12 = 0.0, sA22 = 0.0;  // (exact, see the mismatch sums below)
 #pragma unroll
     for (int w = 0; w < LK4_WAVES; ++w) sA11 += (double)partA[w][0], sA12 += (double)partA[w][1], sA22 += (double)partA[w][2];
+    if (two)
+#pragma unroll
+      for (int w = 0; w < LK4_WAVES; ++w) sA11 += (double)partA2[w][0], sA12 += (double)partA2[w][1], sA22 += (double)partA2[w][2];
     const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -462,12 +480,28 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
       pb1 = wave_sum_i32(pb1);  // |diff| <= 8160, |Ix| <= 4080: 64 products < 2^31
       pb2 = wave_sum_i32(pb2);
       if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
+      if (two) {
+        int qb1 = 0, qb2 = 0;
+        if (own2) {
+          const int x = inx - jx0 + wx2, y = iny - jy0 + wy2;
+          const int diff =
+              DESCALE(jtile[y][x] * iw00 + jtile[y][x + 1] * iw01 + jtile[y + 1][x] * iw10 + jtile[y + 1][x + 1] * iw11, W_BITS - 5) - Iv2;
+          qb1 = diff * Ix2;
+          qb2 = diff * Iy2;
+        }
+        qb1 = wave_sum_i32(qb1);
+        qb2 = wave_sum_i32(qb2);
+        if (lane == 0) part2[slot][wave][0] = qb1, part2[slot][wave][1] = qb2;
+      }
       __syncthreads();
       // the four wave sums (|.| < 2^31 each) are added as doubles: exact (the total stays below 2^33), and (float) of that double
       // rounds once, as (float) of the 64-bit integer does — without the scalar-unit sequence an int64 -> float conversion compiles to
       double sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
       for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
+      if (two)
+#pragma unroll
+        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part2[slot][w][0], sb2 += (double)part2[slot][w][1];
       slot ^= 1;
       const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;

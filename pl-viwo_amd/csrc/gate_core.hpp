@@ -169,9 +169,12 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
     if (pass && g.res_norm_gate > 0.0) pass = sqrt(nrm2) < g.res_norm_gate;
     if (pass) pass = (mp < g.q95_n) && (chi < g.chi2_mult * g.q95[mp]);
     g.accepted[f] = pass ? 1 : 0;
-    if (g.acc_rows) g.acc_rows[f] = pass ? mp : 0;
+    // an entry with more projected rows than the gate holds cannot be judged here: -1 (the host's wait reports PLV_E_CAPACITY instead
+    // of losing the measurement silently; the launcher's row hint is meant to keep such a batch on the separate kernels)
+    const bool overflow = shift == fdim && mp > GATE_MMAX;
+    if (g.acc_rows) g.acc_rows[f] = pass ? mp : (overflow ? -1 : 0);
     if (g.h_accepted) g.h_accepted[f] = pass ? 1 : 0;
-    if (g.h_acc_rows) g.h_acc_rows[f] = pass ? mp : 0;
+    if (g.h_acc_rows) g.h_acc_rows[f] = pass ? mp : (overflow ? -1 : 0);
     if (pass && g.n_acc) atomicAdd(g.n_acc, 1);
     L.passflag = pass ? 1.0 : 0.0;
   }

@@ -629,6 +629,7 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
     auto *us2 = us;
     P.chain_dx = us2->result.as<double>();  // (dx leads the status block of the update launched last: the point update)
     P.chain_applied = us2->applied_word;
+    P.chain_status = (const int *)(us2->result.as<char>() + (size_t)ctx->cov_n * 8);
     P.chain_q = (const double *)(d + o_cq);
     P.chain_id = (const int *)(d + o_cid);
     memcpy(P.chain_qe, ch.qe, 32);

@@ -1788,6 +1788,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   __shared__ int s_ccol[JAC_MAX_WIN / 2 + 3];
   __shared__ double s_cR[(JAC_MAX_WIN / 2 + 3) * 9], s_cp[(JAC_MAX_WIN / 2 + 3) * 3], s_cal[9 + 3 + 8 + 1], s_anchor[3];
   __shared__ unsigned char s_has;
+  if (P.chain_dx && *P.chain_status != 0) return;  // (every workgroup, the gathers included: see JacParams::chain_status)
   if ((int)blockIdx.x >= L) {
     gather_cov_block(g, blockIdx.x - L);
     return;

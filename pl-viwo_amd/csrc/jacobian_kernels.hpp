@@ -49,6 +49,8 @@ struct JacParams {
   // then of the extrinsics (same), the intrinsics and the time offset (-1: not estimated).  null chain_dx: not chained.
   const double *chain_dx;
   const int *chain_applied;
+  const int *chain_status;  // status word of that update: nonzero = rejected — the host may run it again from the buffers both updates
+                            // share (stack, column map, gathers), so this launch then ends at once, touching nothing (plv_api.hip, RedoW)
   const double *chain_q;  // [n_clones][4] JPL quaternions of the clones
   const int *chain_id;    // [n_clones + 3]
   double chain_qe[4];     // extrinsic quaternion (R_ItoC)

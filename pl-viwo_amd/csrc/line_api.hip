@@ -901,9 +901,24 @@ void discard_line_pool(LineTracker *T) {
       d = std::move(tr);
       return;
     }
-    d.t.insert(d.t.end(), tr.t.begin(), tr.t.end());
-    d.uv.insert(d.uv.end(), tr.uv.begin(), tr.uv.end());
-    d.uvn.insert(d.uvn.end(), tr.uvn.begin(), tr.uvn.end());
+    // the database has the id again (a feed re-created it with newer observations while the pool held the older ones): the track
+    // stays ordered in time (appended, the returning older observations ended up behind the newer ones)
+    const size_t na = d.t.size(), nb = tr.t.size();
+    std::vector<std::pair<double, std::pair<int, int>>> order;  // (time, (source, index))
+    order.reserve(na + nb);
+    for (size_t i = 0; i < na; ++i) order.push_back({d.t[i], {0, (int)i}});
+    for (size_t i = 0; i < nb; ++i) order.push_back({tr.t[i], {1, (int)i}});
+    std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    LineTrack m;
+    m.D = d.D, m.points = d.points;
+    for (const auto &e : order) {
+      const LineTrack &src = e.second.first ? tr : d;
+      const size_t i = (size_t)e.second.second;
+      m.t.push_back(src.t[i]);
+      m.uv.insert(m.uv.end(), src.uv.begin() + 4 * i, src.uv.begin() + 4 * i + 4);
+      m.uvn.insert(m.uvn.end(), src.uvn.begin() + 4 * i, src.uvn.begin() + 4 * i + 4);
+    }
+    d = std::move(m);
   };
   for (auto &c : R.pool) put(c.id, c.tr);
   for (auto &kv : R.unused) put(kv.first, kv.second);

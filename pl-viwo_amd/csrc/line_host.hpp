@@ -42,7 +42,8 @@ struct Fit {
   int gen = 0, done_gen[kThreads] = {0, 0};  // a job = a new generation; thread i reports the last one it finished
   bool quit = false;
   const Job *job = nullptr;
-  std::atomic<int> nfit_job{0};  // fitter threads the current job uses (thread i takes part when i < nfit_job)
+  int nfit_job = 0;  // fitter threads the current job uses (thread i takes part when i < nfit_job); guarded by m: a thread reads it
+                     // together with gen and job, so that one waking late for a job it was not part of cannot mix two jobs
   alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
   alignas(64) std::atomic<bool> walk_done{false};
   alignas(64) std::atomic<int> next{0};  // next chain to fit: this thread and, once its walk is over, the walking thread claim chains here
@@ -212,18 +213,19 @@ inline void fit_one(Fit &F, const Job &J, int c) {
                          F.segs.data() + J.hc[c].slot);
 }
 
-inline void fit_worker(HostStage *T, int me) {
+inline void fit_worker(HostStage *T, int me, int seen /* the generation current when the thread was made: it waits for the next */) {
   Fit &F = T->fit;
-  int seen = 0;
   for (;;) {
+    const Job *job;
+    int nfit;
     {
       std::unique_lock<std::mutex> lk(F.m);
       wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
       if (F.quit) return;
-      seen = F.gen;
+      seen = F.gen, job = F.job, nfit = F.nfit_job;
     }
-    const Job &J = *F.job;
-    for (; me < F.nfit_job.load(std::memory_order_acquire);) {  // (a thread this job does not count takes nothing and is not waited for)
+    const Job &J = *job;
+    for (; me < nfit;) {  // (a thread this job does not count takes nothing and is not waited for)
       const int avail = F.published.load(std::memory_order_acquire);
       const int c = claim_chain(F, avail);
       if (c >= 0) {
@@ -254,13 +256,20 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   // left over at the end of the walk 110 us with one fitter, 20 with two) takes the second one as well — a thread a job does not need
   // is not part of it: every hand-over between threads is a chance of a delayed wake-up on a busy host
   const int nfit = std::min(fit_threads().load(std::memory_order_relaxed), (size_t)J.w * J.h >= 150000 ? 2 : 1);
-  F.nfit_job.store(nfit, std::memory_order_release);
-  for (int i = 0; i < nfit; ++i)
-    if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i);
+  {
+    int gen_now;
+    {
+      std::lock_guard<std::mutex> lk(F.m);
+      gen_now = F.gen;
+    }
+    for (int i = 0; i < nfit; ++i)
+      if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
+  }
   int gen;
   {
     std::lock_guard<std::mutex> lk(F.m);
     F.job = &J;
+    F.nfit_job = nfit;
     gen = ++F.gen;
   }
   F.cv.notify_all();

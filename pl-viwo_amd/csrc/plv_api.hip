@@ -903,12 +903,14 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   int r, ldh;
   us->last_route = 0;
   us->redo.armed = false;
+  us->redo_w.armed = false;
   if (whiten) {
     // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
     TRY(launch_gram_information(ctx, ctx->d_stack.as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
     TRY(aux_join());
     TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     us->last_route = 4;
+    us->redo_w = plv_ctx_update_state::RedoW{!us->graph_mode, Mtot, k, n, F, mp_max, fdim, tmp_elems, rb, d_dx, d_flag, d_acc_rows};
     return PLV_OK;
   }
   if (Mtot > k) {
@@ -1074,7 +1076,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   const char *hb = hpin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;
-  if (us->redo.armed && us->last_ambiguous > 0 && *(const int *)(hb + (size_t)n * 8) == 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
+  if (us->redo.armed && us->last_ambiguous > 0 && (*(const int *)(hb + (size_t)n * 8) & ~8) == 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
     // automatic mode: the Gram factorisation met pivots it could not tell from zero and ekf_commit_kernel left the covariance alone.
     // The stacked rows are still in place: compress them by Householder reflections (orthogonal transformations on the rows
     // themselves resolve what the squared matrix cannot) and run the EKF step again.
@@ -1091,14 +1093,42 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     us->last_route = 3;
   }
   us->redo.armed = false;
+  if (us->redo_w.armed && us->last_route == 4 && *(const int *)(hb + (size_t)n * 8) != 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
+    // The whitened update came back rejected, or withheld because its prior factor met near dependencies (bit 8; update_state.hpp,
+    // RedoW): nothing was committed.  The stacked rows are run again the reference's way — compression, then S = R P R^T + I — with
+    // the compression by Householder reflections on the rows themselves: the Gram + Cholesky route squares the condition number and
+    // has its own pivots to be unsure of, and this path is rare (a first update after the initialisation, synthetic priors).  Its
+    // verdict is the update's.
+    const plv_ctx_update_state::RedoW rd = us->redo_w;
+    us->redo_w.armed = false;
+    const int nc = rd.k + 1;
+    const size_t mb = ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3;
+    ctx->skip_word = nullptr, ctx->commit_veto = nullptr;
+    double *R;
+    int ldr;
+    TRY(launch_stack_zero_rejected(ctx, ctx->d_stack.as<double>(), rd.Mtot, nc, rd.d_acc_rows, rd.F, rd.mp_max));
+    TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols.as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx, rd.d_flag,
+                        true, us->result_of(rd.fdim).p, hpin.p, mb));
+    TRY(sync(ctx));
+    us->last_route = 5;
+    ++ctx->gather_stamp;
+    ctx->cov_host_synced = ctx->gather_stamp;
+  }
+  us->redo_w.armed = false;
   int flag = *(const int *)(hb + (size_t)n * 8);
   const unsigned char *hacc = (const unsigned char *)(hb + (size_t)n * 8 + 16);
-  int nrows = 0;
+  int nrows = 0, overflow = 0;
   for (int f = 0; f < F; ++f) {
     if (accepted) accepted[f] = hacc[f];
-    nrows += hrows[f];
+    if (hrows[f] < 0) ++overflow;  // (gate_core.hpp: an entry with more rows than the gate inside the Jacobian launch holds)
+    else nrows += hrows[f];
   }
   if (n_accepted_rows) *n_accepted_rows = nrows;
+  if (overflow) {
+    set_last_error("update: %d batch entries had more projected rows than the gate inside the Jacobian launch holds (%d): they were left out", overflow, GATE_MMAX);
+    return PLV_E_CAPACITY;
+  }
   if (flag != 0) {
     set_last_error("EKFUpdate rejected: %s", (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
     return PLV_E_NOT_PSD;

@@ -987,10 +987,12 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   ch.ready = false;
   T->defer_db = T->ahead_on_ctx_stream = false;
   T->early_st = nullptr, T->early_lines = nullptr;
-  const bool chained = io->opt_lines && plv_camera_lines_job_pending(ctx);
-  if (rc != PLV_OK && io->opt_lines) {
-    if (chained) plv_camera_lines_job_abort(ctx);
-    plv_line_pool_discard(ctx);
+  bool chained = io->opt_lines && plv_camera_lines_job_pending(ctx);
+  if (chained && (plv_update_state(ctx)->last_route >= 5 || io->res_points->status != PLV_OK)) {
+    // the point update came back rejected — and was perhaps run again on the host's verdict (update_state.hpp, RedoW): the chained
+    // line launch saw the rejection and ended without touching anything (JacParams::chain_status).  The line half goes the unchained way.
+    plv_camera_lines_job_abort(ctx);
+    chained = false;
   }
   // REF UpdaterCamera.cpp:148-152: get_line_features runs between get_features and msckf_update — the line pool is triangulated on
   // the state as it is before the point update's correction is applied (chained: its launch is already on the stream, staged from st)
@@ -1000,7 +1002,6 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   if (rc == PLV_OK && io->opt_lines) {
     rc = plv_line_tracker_feed_wait(ctx);
     io->line_db_size = plv_line_db_size_after_feed(ctx);
-    if (rc != PLV_OK) plv_line_pool_discard(ctx);
     if (rc == PLV_OK) {
       plv_line_defer_finish(ctx, 1);
       rc = plv_camera_update_lines(ctx, st, io->opt_lines, io->dx_lines, io->res_lines, io->line_ids, io->line_accepted, io->line_FinG,
@@ -1009,6 +1010,10 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
     }
     plv_tracker_run_deferred(ctx);
     if (rc == PLV_OK) rc = apply(*io->res_lines, io->dx_lines);
+  }
+  if (rc != PLV_OK && io->opt_lines) {  // (every failing exit — a pool formed ahead of time or a chained launch must not outlive the call)
+    if (plv_camera_lines_job_pending(ctx)) plv_camera_lines_job_abort(ctx);
+    plv_line_pool_discard(ctx);
   }
   plv_tracker_run_deferred(ctx);
   return rc;

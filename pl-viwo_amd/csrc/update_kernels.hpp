@@ -67,12 +67,13 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
 
 // whitened route (dense_kernels.hip; DESIGN.md "Whitened update")
 void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag);
+int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, double *d_dx, int *d_flag, const void *mirror_src, void *mirror_dst,
                         size_t mirror_bytes);
 int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp, int n, const int *d_cols, int k, double *d_Lt, int ldl,
-                       double *d_W0, int ldw);
+                       double *d_W0, int ldw, int *d_n_near);
 
 // blocked_chol.hip
 // d_n_ambiguous (nullable): receives the number of pivots the factorisation could not tell from zero (blocked_chol.hpp, diag_chain)

@@ -21,7 +21,8 @@ struct plv_ctx_update_state {
   // route when its factorisation reports pivots it could not resolve, 3 = Gram matrix + blocked Cholesky (the round-2 default)
   int compress_mode = 0;
   bool prior_late = false;  // measurement aid (mode 4)
-  int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder, 4 whitened
+  int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder, 4 whitened,
+                            // 5 whitened came back rejected / withheld and was run again by Householder reflections (redo_w)
   int last_ambiguous = 0;   // pivots the last Gram factorisation could not tell from zero
   struct Redo {             // what the automatic mode needs to run the update again from the stacked rows
     bool armed = false;
@@ -42,6 +43,18 @@ struct plv_ctx_update_state {
   plv::DevBuf &result_of(int fdim) { return fdim == 6 ? result_l : result; }
   AccWords &acc_of(int fdim) { return acc[fdim == 6 ? 1 : 0]; }
   int acc_word_used = 1;   // the word the last launched update's chain read as its skip word (1: chi2_gate_kernel's)
+  // The whitened update divides by the pivots of the PRIOR block.  A prior direction of relative variance 1e-13 .. 1e-9 (round 4: the
+  // IMU pose a quarter of a microsecond of propagation away from the clone just taken of it — time stamps of 1.5e9 s resolve no
+  // finer) is neither an exact dependency nor well conditioned, and the update can come back "not positive definite" where the
+  // reference's S = H P H^T + R has no trouble.  Such a verdict is therefore not final: the stacked rows are still on the device and
+  // the update is run again through a Householder compression and the EKF step on R (last_route 5) before NOT_PSD is reported.
+  struct RedoW {
+    bool armed = false;
+    int Mtot = 0, k = 0, n = 0, F = 0, mp_max = 0, fdim = 3;
+    size_t tmp_elems = 0, rb = 0;
+    double *d_dx = nullptr;
+    int *d_flag = nullptr, *d_acc_rows = nullptr;
+  } redo_w;
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)

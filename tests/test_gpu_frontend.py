@@ -65,16 +65,20 @@ def test_feed_rejects_wrong_size(pkg):
     c.close()
 
 
-def test_lk_bit_exact_vs_oracle(pkg, fo, seq):
+@pytest.mark.parametrize("win", [15, 17, 21, 9])
+def test_lk_bit_exact_vs_oracle(pkg, fo, seq, win):
+    """plv_config.win_size (REF: TrackKLT.h:143-144, the winSize of calcOpticalFlowPyrLK at TrackKLT.cpp:857-858): 15 is the
+    reference's value; 17 and 21 (the north star's patch) give every lane of the point's workgroup a second window pixel; the
+    pyramid's level count follows the window (buildOpticalFlowPyramid stops where a level is not larger than it)."""
     w, h, frames, warps = seq
-    c = _ctx(pkg, w, h)
+    c = _ctx(pkg, w, h, win_size=win)
     c.feed_image(frames[0])
     c.feed_image(frames[1])
-    p0, p1 = fo.pyramid(fo.equalize_hist(frames[0])), fo.pyramid(fo.equalize_hist(frames[1]))
+    p0, p1 = fo.pyramid(fo.equalize_hist(frames[0]), win=win), fo.pyramid(fo.equalize_hist(frames[1]), win=win)
     pts0 = synth.grid_points(w, h, 250, seed=3, border=12)
     # include border / out-of-image / flat cases
     pts0[:6] = [[2.5, 3.5], [w - 2.0, h - 3.0], [w + 30.0, 50.0], [-30.0, -30.0], [0.0, 0.0], [w - 1.0, h - 1.0]]
-    a1, ast, ait = fo.lk_track(p0, p1, pts0, pts0)
+    a1, ast, ait = fo.lk_track(p0, p1, pts0, pts0, win=win)
     b1, bst, bit = c.lk_track(pts0, pts0)
     assert np.array_equal(ast, bst)
     assert int(bit.sum()) == ait
@@ -85,19 +89,20 @@ def test_lk_bit_exact_vs_oracle(pkg, fo, seq):
     c.close()
 
 
-def test_lk_large_motion_tile_restage(pkg, fo):
-    """Initial guesses far from the truth force the 32x32 search tile to be re-staged."""
+@pytest.mark.parametrize("win", [15, 21])
+def test_lk_large_motion_tile_restage(pkg, fo, win):
+    """Initial guesses far from the truth force the 32x32 search tile to be re-staged (a 21 x 21 window leaves it 10 pixels of slack)."""
     w, h = 640, 400
     canvas = synth.texture_canvas(w, h, seed=9)
     f0 = synth.render_frame(canvas, w, h)
     f1 = synth.render_frame(canvas, w, h, tx=14.0, ty=-11.0)
-    c = _ctx(pkg, w, h, histogram_method=0)
+    c = _ctx(pkg, w, h, histogram_method=0, win_size=win)
     c.feed_image(f0)
     c.feed_image(f1)
-    p0, p1 = fo.pyramid(f0), fo.pyramid(f1)
+    p0, p1 = fo.pyramid(f0, win=win), fo.pyramid(f1, win=win)
     pts0 = synth.grid_points(w, h, 100, seed=1, border=40)
     guess = pts0 + np.float32([30.0, 25.0])
-    a1, ast, _ = fo.lk_track(p0, p1, pts0, guess)
+    a1, ast, _ = fo.lk_track(p0, p1, pts0, guess, win=win)
     b1, bst, _ = c.lk_track(pts0, guess)
     assert np.array_equal(ast, bst) and np.array_equal(a1, b1)
     c.close()

@@ -10,12 +10,7 @@ import zlib
 import numpy as np
 
 
-def _png(path, a):
-    h, w = a.shape
-    raw = b"".join(b"\x00" + a[i].tobytes() for i in range(h))
-    ch = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + ch(b"IDAT", zlib.compress(raw)) + ch(b"IEND", b""))
+from kaist_synth import write_png as _png
 
 
 def _make(root, rng):
@@ -77,3 +72,25 @@ def test_kaist_raw_directory(pkg, tmp_path):
     want = (200 * 4899 + 100 * 9617 + 50 * 1868 + 8192) >> 14
     assert np.all(np.abs(kaist.bayer_rg_to_grey(mosaic).astype(int) - want) <= 1)
     assert np.all(kaist.bayer_rg_to_grey(np.full((6, 6), 77, dtype=np.uint8)) == 77)
+
+
+def test_converter_round_trip(pkg, tmp_path):
+    """tests/kaist_synth.py (the generator of the GPU suite's KAIST-layout replay): a rendered drive rewritten in the KAIST layout reads
+    back as the same IMU stream, the same frame times, wheel speeds to the encoder's quantisation and frames to the demosaicing."""
+    import kaist_synth
+    import synth_dataset as sd
+    replay = importlib.import_module("plviwo_amd.replay")
+    src = str(tmp_path / "src")
+    sd.make_dataset(src, seconds=1.0, cam_hz=10.0, style="street", workers=4)
+    dst = kaist_synth.convert(src, str(tmp_path / "urban_synth"), sd.RL, sd.RR, sd.BASE)
+    a, b = replay.Dataset(src), replay.open_dataset(dst)
+    off = kaist_synth.T0_NS * 1e-9
+    assert b.imu.shape == a.imu.shape and np.array_equal(b.imu[:, 1:], a.imu[:, 1:]) and np.abs(b.imu[:, 0] - off - a.imu[:, 0]).max() < 1e-6
+    assert len(b.frames) == len(a.frames) and all(abs(tb - off - ta) < 1e-6 for (tb, _), (ta, _) in zip(b.frames, a.frames))
+    assert b.wheel.shape == a.wheel.shape
+    q = 2 * math.pi / 4096 / np.diff(a.wheel[:, 0]).min()       # one count per sample interval
+    assert np.abs(b.wheel[:, 1:] - a.wheel[:, 1:]).max() <= 1.01 * q
+    ia, ib = a.image(0).astype(int), b.image(0).astype(int)
+    assert ia.shape == ib.shape and np.abs(ia - ib)[2:-2, 2:-2].mean() < 6.0
+    rl, rr, base = b.wheel_intrinsics()
+    assert (rl, rr, base) == (sd.RL, sd.RR, sd.BASE)
