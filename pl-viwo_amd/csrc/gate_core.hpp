@@ -19,8 +19,9 @@
 
 namespace plv {
 
+// LDS of the gate: this block (it may overlay whatever the launch no longer needs when the gate starts), the prior block
+// Ps = P[cols, cols] as its upper triangle — gate_ps_doubles(k) doubles, filled early by gate_stage_prior — and T [GATE_MMAX][GATE_TLD].
 struct GateLds {
-  double T[GATE_MMAX * GATE_TLD];
   double S[GATE_MMAX * (GATE_MMAX + 1)];
   BcLdsT<2> bc;
   double ybuf[64];
@@ -54,31 +55,47 @@ struct GateOps {  // the bordered factorisation of S with r as the border row: y
   }
 };
 
-// Pulls the rows P[cols[a], :] — everything T = H' Ps will read through the column map — into this XCD's L2, one load per 128-byte
-// line, by `nthreads` threads (tid = 0 .. nthreads - 1) that have nothing else to do while the entry is being triangulated.  The
-// values are summed into a number that is never stored (the compiler must keep the loads).
-__device__ __forceinline__ void gate_prefetch_rows(const GateStage &g, const int *cols_g, int k, int tid, int nthreads) {
-  const int lpr = (g.ldp + 15) / 16 + 1;  // lines per row (the row's start is not aligned)
-  double acc = 0.0;
-  for (int idx = tid; idx < k * lpr; idx += 4 * nthreads) {
-    double v[4];
+__host__ __device__ inline int gate_ps_doubles(int k) { return k * (k + 1) / 2 + (k + 1) / 2 + 2; }  // triangle + the column map (ints)
+__device__ __forceinline__ int gate_tri(int a, int b) {  // position of Ps(a, b) in the packed upper triangle
+  const int hi = max(a, b), lo = min(a, b);
+  return hi * (hi + 1) / 2 + lo;
+}
+// Stages Ps = P[cols, cols] (the covariance block T = H' Ps contracts with) into LDS as a packed triangle, by `nthreads` threads
+// (tid = 0 .. nthreads - 1, a multiple of 64) that have nothing else to do while the entry is being triangulated: every element one
+// load through the column map, issued eight rows at a time.  Round 4a read the B operands of T straight from memory at the gate: 25
+// gather loads per tile column, each lane-scattered over ~10 cache lines — 8 us of the gate's 20.  The caller puts a barrier
+// between this and gate_tail.
+__device__ __forceinline__ void gate_stage_prior(const GateStage &g, double *Ps, const int *cols_g, int k, int tid, int nthreads) {
+  int *cols_l = reinterpret_cast<int *>(Ps + k * (k + 1) / 2);
+  for (int i = tid; i < k; i += nthreads) cols_l[i] = cols_g[i];
+  const int w = tid >> 6, nw = nthreads >> 6, lane = tid & 63;
+  for (int h0 = w; h0 < k; h0 += 8 * nw) {  // rows h0, h0 + nw, .. of this wave, eight per round; columns lane, lane + 64 (<= row)
+    double v[8][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int id = min(idx + u * nthreads, k * lpr - 1);
-      const int a = id / lpr, l = id - a * lpr;
-      v[u] = *(const volatile double *)(g.P + (size_t)cols_g[a] * g.ldp + min(l * 16, g.ldp - 1));
+    for (int u = 0; u < 8; ++u) {
+      const int hi = min(h0 + u * nw, k - 1);
+      const double *row = g.P + (size_t)cols_g[hi] * g.ldp;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) v[u][c] = row[cols_g[min(lane + 64 * c, hi)]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc += v[u];
+    for (int u = 0; u < 8; ++u) {
+      const int hi = h0 + u * nw;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int lo = lane + 64 * c;
+        if (hi < k && lo <= hi) Ps[hi * (hi + 1) / 2 + lo] = v[u][c];
+      }
+    }
   }
-  if (acc == 1.2345678e300) *(volatile double *)g.chi2 = acc;  // (never: keeps the loads alive)
 }
 
 // Called by ALL 256 threads of the workgroup of entry f (block-uniform arguments).  X: the entry's block in LDS, row-major with
 // ncol = fdim + k + 1 columns; rows `shift` .. rows - 1 hold the projected system [.. | H' | r] (shift = fdim when the null space was
 // applied, rows = 0 for an entry the selection did not take).  cols_g: the column map (k entries).
-__device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f, const double *X, int ncol, int fdim, int shift, int rows, int k,
-                                          const int *cols_g) {
+// Ps: the staged prior block (gate_stage_prior, complete and visible: a barrier in between), T: GATE_MMAX x GATE_TLD doubles.
+__device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, const double *Ps, double *T, int f, const double *X, int ncol, int fdim,
+                                          int shift, int rows, int k, const int *cols_g) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int mp = rows - fdim;
   const bool valid = shift == fdim && mp >= 1 && mp <= GATE_MMAX && rows >= g.min_rows;  // block-uniform
@@ -86,48 +103,46 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
   double chi = NAN, nrm2 = 0.0;
   if (valid) {
     const double *Hp = X + (size_t)shift * ncol + fdim;  // H'(i, a) = Hp[i * ncol + a], r(i) = Hp[i * ncol + k]
-    for (int i = threadIdx.x; i < k; i += blockDim.x) L.cols[i] = cols_g[i];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {  // (read behind the two barriers below)
       L.bc.bad = 0;
       L.bc.step_flag = 0;
       L.bc.rs_flag = 0;
       L.bc.n_amb = 0;
     }
-    __syncthreads();
-    GATE_STAMP(13);
     const int mt = (mp + 15) >> 4, kt = (k + 15) >> 4;
-    // T = H' Ps, Ps(a, b) = P[cols[a], cols[b]].  A wave owns tile columns tj = wave, wave + 4, ..: its B operand (16 columns of Ps
-    // over all k, read through the column map) is requested in ONE batch and serves every row tile — round 3 went tile by tile in
-    // chunks of 64 k, eight dependent rounds of loads that mostly missed this XCD's L2 (8 us of the gate; the rows are now pulled in
-    // early by gate_prefetch_rows).  The MFMA sequence per tile is the same as chi2_t_kernel's: the same bits.
-    int roff[GATE_KMAX / 4];  // element offsets of the rows this lane's k-slab reads (the map is looked up once, not in front of every load)
-#pragma unroll
-    for (int u = 0; u < GATE_KMAX / 4; ++u) roff[u] = L.cols[min(4 * u + lq, k - 1)] * g.ldp;
+    // T = H' Ps from LDS: H' in the entry's block, Ps(a, b) in the staged triangle.  Per tile the MFMA sequence is chi2_t_kernel's
+    // (k ascending, four k per step): the same bits.  What sets the pace here is the number of instructions around the MFMAs, not
+    // the matrix pipe (a wave issues one every 5-8 cycles): a wave therefore owns tile COLUMNS — the B operands of a column block
+    // (a triangle lookup each) are formed once and serve every row tile — B carries the zero beyond k (A then needs no clamp: what
+    // lies behind column k of a row of the block is finite), and the MFMAs run in groups of four without a test in between.
+    const int ngroups = (k + 15) >> 4;
     for (int tj = wave; tj < kt; tj += 4) {
-      const double *Pq = g.P + L.cols[min(tj * 16 + li, k - 1)];
+      const int jb = min(tj * 16 + li, k - 1);
       double bv[GATE_KMAX / 4];
 #pragma unroll
-      for (int u = 0; u < GATE_KMAX / 4; ++u) bv[u] = Pq[roff[u]];
+      for (int u = 0; u < GATE_KMAX / 4; ++u) {
+        const int kk = 4 * u + lq;
+        const double x = Ps[kk < k ? gate_tri(kk, jb) : 0];
+        bv[u] = kk < k ? x : 0.0;
+      }
       for (int ti = 0; ti < mt; ++ti) {
-        const double *Hr = Hp + (size_t)min(ti * 16 + li, mp - 1) * ncol;
-        double av[GATE_KMAX / 4];
-#pragma unroll
-        for (int u = 0; u < GATE_KMAX / 4; ++u) {
-          const int kk = 4 * u + lq;
-          const double x = Hr[min(kk, k - 1)];
-          av[u] = kk < k ? x : 0.0;
-        }
+        const double *Hr = Hp + (size_t)min(ti * 16 + li, mp - 1) * ncol + lq;
         d4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < GATE_KMAX / 4; ++u)
-          if (4 * u < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);  // (uniform)
+        for (int gq = 0; gq < GATE_KMAX / 16; ++gq)
+          if (gq < ngroups) {  // (uniform)
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = Hr[16 * gq + 4 * u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[4 * gq + u], acc, 0, 0, 0);
+          }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
-          if (i < mp && j < k) L.T[i * GATE_TLD + j] = acc[q];
+          if (i < mp && j < k) T[i * GATE_TLD + j] = acc[q];
         }
       }
-      if (tj == wave) GATE_STAMP(14);
     }
     __syncthreads();
     GATE_STAMP(6);
@@ -135,7 +150,7 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, int f,
     for (int t = wave; t < mt * mt; t += 4) {
       const int ti = t / mt, tj = t - ti * mt;
       if (tj < ti) continue;
-      const double *Tr = L.T + (size_t)min(ti * 16 + li, mp - 1) * GATE_TLD;
+      const double *Tr = T + (size_t)min(ti * 16 + li, mp - 1) * GATE_TLD;
       const double *Hr = Hp + (size_t)min(tj * 16 + li, mp - 1) * ncol;
       d4 acc = {0, 0, 0, 0};
       auto fa = [&](int, int kk) { return Tr[kk]; };

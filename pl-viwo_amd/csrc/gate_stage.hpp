@@ -9,7 +9,9 @@ namespace plv {
 
 struct GateStage {  // kernel argument; on == 0: the launch ends with the projected blocks as before
   int on;
-  int lds_off;      // byte offset of the gate's LDS block (GateLds) inside the launch's dynamic shared memory (set by the launcher)
+  int lds_off;      // byte offsets inside the launch's dynamic shared memory (set by the launcher): the gate's block (GateLds: S, the
+  int ps_off;       // factorisation's block — it overlays scratch that is dead when the gate starts), the prior block Ps (upper
+  int t_off;        // triangle, staged while the entry is triangulated: gate_stage_prior) and T = H' Ps
   const double *P;  // covariance, n x n, both triangles valid
   int ldp;
   double sigma2, chi2_mult, res_norm_gate;

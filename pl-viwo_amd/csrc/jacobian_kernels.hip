@@ -918,7 +918,7 @@ static_assert(sizeof(WinTab) % 8 == 0, "fused_lds_layout counts WinTab in double
 __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, int F, GatherArgs g, PointTriStage tri, GateStage gate) {
   extern __shared__ double jsm[];
   __shared__ int s_rows, s_base;
-  __shared__ double tri_tot[10], s_tri[5];
+  __shared__ double tri_tot[32], s_tri[5];
   __shared__ double s_ct[JAC_MAX_WIN / 2 + 3];
   __shared__ int s_ccol[JAC_MAX_WIN / 2 + 3];
   if ((int)blockIdx.x >= F) {
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
       interpolate_tab(P, tab[2 * s0 + 1], s0, tm_l[i] + P.cam_dt, true, jac);
       pre_store_jac(pre + (size_t)c * PRE_STRIDE, jac);
     }
-    if (gate.on) gate_prefetch_rows(gate, P.cols_in, k, threadIdx.x - 64, 192);
+    if (gate.on) gate_stage_prior(gate, reinterpret_cast<double *>(reinterpret_cast<char *>(jsm) + gate.ps_off), P.cols_in, k, threadIdx.x - 64, 192);
   }
   __threadfence_block();
   __syncthreads();
@@ -1025,9 +1025,11 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   jac_stamp(3);
   const int rows = s_rows;
   GateLds &gl = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
+  const double *gPs = reinterpret_cast<const double *>(reinterpret_cast<char *>(jsm) + gate.ps_off);
+  double *gT = reinterpret_cast<double *>(reinterpret_cast<char *>(jsm) + gate.t_off);
   if ((tri.on || P.tri_ok) && rows == 0) {  // one-submission update: a candidate the selection did not take is an empty system (rows[f] = 0) that
                                             // nothing reads — its padded block is not written (rocprofv3, round 2: 1.6 MB per launch, mostly these)
-    if (gate.on) gate_tail(gate, gl, f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
+    if (gate.on) gate_tail(gate, gl, gPs, gT, f, X, ncol, 3, 0, 0, k, P.cols_in);  // (verdict "not accepted" + its share of the probe block)
     return;
   }
   const int shift = rows > 3 ? 3 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
@@ -1052,7 +1054,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     }
   }
   jac_stamp(5);
-  if (gate.on) gate_tail(gate, gl, f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);  // (X is only read from here on)
+  if (gate.on) gate_tail(gate, gl, gPs, gT, f, X, ncol, 3, shift, min(rows, ld), k, P.cols_in);  // (X is only read from here on)
   if (touch == 1.2345678e300) P.rows[f] = -1;  // (never: keeps the touch loads)
   jac_stamp(9);
 }
@@ -1250,7 +1252,7 @@ struct TriObs {     // per valid observation, relative to the anchor pose (the n
 static_assert(sizeof(TriObs) == 15 * 8, "tri_smem_doubles counts 15 doubles per TriObs");
 // One feature, ONE wave (the 64 lanes that call it; other waves of the workgroup must not): poses of its observations, linear
 // triangulation, Levenberg-Marquardt refinement, reprojection error.  tri_smem: max_obs * (sizeof(TriObs) + TRI_TERMS * 8 + 4) + 16 bytes
-// of LDS, tot: TRI_TERMS doubles of LDS.  Wave-level synchronisation only (the lanes run in lockstep; the fences order the LDS traffic).
+// of LDS, tot: 32 doubles of LDS.  Wave-level synchronisation only (the lanes run in lockstep; the fences order the LDS traffic).
 // Observations o0 .. o1 - 1 index poses / valid / uvn / uv: the global arrays of triangulate_kernel (o0 = obs_ptr[f]) or a workgroup's
 // LDS copies of its own feature's observations (o0 = 0, poses_ready: the caller has filled poses and valid).
 __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, double *poses, unsigned char *valid, const float *uvn, const float *uv,
@@ -1359,6 +1361,9 @@ __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, d
     V3 grad{{0, 0, 0}};
     double cost_old = tri_error(alpha, beta, rho);
     int lm_pass = 0;
+    const bool spec = M <= 16;  // (uniform) room for four damping factors side by side: 16 lanes each
+    const int grp = lane >> 4, ql = lane & 15;
+    bool stop = false;
     while (runs < 5 && lam < 1e10 && eps > 1e-6) {
       jac_stamp(16 + min(lm_pass++, 11));
       if (recompute) {
@@ -1382,6 +1387,79 @@ __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, d
         grad = V3{{tot[0], tot[1], tot[2]}};
         Hess(0, 0) = tot[3], Hess(0, 1) = Hess(1, 0) = tot[4], Hess(0, 2) = Hess(2, 0) = tot[5];
         Hess(1, 1) = tot[6], Hess(1, 2) = Hess(2, 1) = tot[7], Hess(2, 2) = tot[8];
+      }
+      if (spec) {
+        // Four damping factors at once (round 4): a failed step changes nothing but lam (x 10), so the steps the serial loop would
+        // try next — lam, 10 lam, 100 lam, 1000 lam on the same Hessian — are independent.  Lane group g (16 lanes, one per
+        // observation) solves for 10^g lam and forms its cost terms; the four costs are summed in observation order as before
+        // (component g of reduce); then the serial loop's decisions are replayed on them: the first group whose step the loop
+        // would have reached AND taken decides, exactly as if the groups before it had been tried one by one.  A streak of failed
+        // steps (the tail of most refinements: ~1.5 passes of 4.7 on average, 8 of 12 for the slowest) costs one pass per four.
+        double lamg = lam;
+        for (int i = 0; i < grp; ++i) lamg = lamg * 10;
+        M3 Hl = Hess;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Hl(r, r) *= (1.0 + lamg);
+        V3 dxg{{0, 0, 0}};
+        const bool okg = solve3(Hl, grad, dxg);
+        if (ql < M) {
+          double tv = 0.0;
+          if (okg) {
+            const TriObs &c = ob[ql];
+            const int o = list[ql];
+            const double a2 = alpha + dxg[0], b2 = beta + dxg[1], r2 = rho + dxg[2];
+            const double hi1 = c.R[0] * a2 + c.R[1] * b2 + c.R[2] + r2 * c.pa[0];
+            const double hi2 = c.R[3] * a2 + c.R[4] * b2 + c.R[5] + r2 * c.pa[1];
+            const double hi3 = c.R[6] * a2 + c.R[7] * b2 + c.R[8] + r2 * c.pa[2];
+            const float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+            const float r0 = uvn[2 * o] - z0, r1 = uvn[2 * o + 1] - z1;
+            const float nrm = sqrtf(r0 * r0 + r1 * r1);
+            tv = (double)nrm * (double)nrm;
+          }
+          term[ql * TRI_TERMS + grp] = tv;
+        }
+        if (ql == 0) {
+          tot[16 + 4 * grp] = dxg[0], tot[17 + 4 * grp] = dxg[1], tot[18 + 4 * grp] = dxg[2];
+          tot[19 + 4 * grp] = okg ? 1.0 : 0.0;
+        }
+        reduce(4);
+        bool leave = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (leave || !(lam < 1e10)) {  // (the while condition in front of the pass the serial loop would run now; runs and eps have not moved)
+            leave = true;
+            continue;
+          }
+          if (tot[19 + 4 * j] == 0.0) {  // solve3 failed: break
+            stop = leave = true;
+            continue;
+          }
+          const double cost = tot[j];
+          const V3 dx{{tot[16 + 4 * j], tot[17 + 4 * j], tot[18 + 4 * j]}};
+          if (cost <= cost_old && (cost_old - cost) / cost_old < 1e-6) {
+            alpha += dx[0];
+            beta += dx[1];
+            rho += dx[2];
+            eps = 0;
+            stop = leave = true;
+          } else if (cost <= cost_old) {
+            recompute = true;
+            cost_old = cost;
+            alpha += dx[0];
+            beta += dx[1];
+            rho += dx[2];
+            runs++;
+            lam = lam / 10;
+            eps = vnorm(dx);
+            leave = true;  // (a new linearisation: the other groups' steps belong to the old one)
+          } else {
+            recompute = false;
+            lam = lam * 10;
+          }
+        }
+        tri_wave_sync();  // (tot is rewritten by the next pass)
+        if (stop) break;
+        continue;
       }
       M3 Hl = Hess;
 #pragma unroll
@@ -1456,7 +1534,7 @@ __global__ void __launch_bounds__(64) triangulate_kernel(JacParams P, double *po
                                                          plv_tri_options opt, double *__restrict__ p_out,
                                                          unsigned char *__restrict__ ok_out, double *__restrict__ err_out, int max_obs) {
   extern __shared__ double tri_smem[];
-  __shared__ double tot[TRI_TERMS];
+  __shared__ double tot[32];  // (totals of a pass + the four candidate steps of a speculative one)
   triangulate_feature(P, blockIdx.x, P.obs_ptr[blockIdx.x], P.obs_ptr[blockIdx.x + 1], poses, valid, uvn, P.obs_uv, opt, p_out, ok_out, err_out, max_obs, tri_smem,
                       tot);
 }
@@ -1937,7 +2015,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
 #pragma unroll
       for (int q = 0; q < 3; ++q) pr[PRE_PE + q] = pe[q];
     }
-    if (gate.on) gate_prefetch_rows(gate, P.cols_in, k, threadIdx.x - 64, 192);
+    if (gate.on) gate_stage_prior(gate, reinterpret_cast<double *>(reinterpret_cast<char *>(jsm) + gate.ps_off), P.cols_in, k, threadIdx.x - 64, 192);
   }
   __threadfence_block();
   __syncthreads();
@@ -1965,8 +2043,10 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   jac_stamp(3);
   const int rows = s_rows;
   GateLds &gl = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
+  const double *gPs = reinterpret_cast<const double *>(reinterpret_cast<char *>(jsm) + gate.ps_off);
+  double *gT = reinterpret_cast<double *>(reinterpret_cast<char *>(jsm) + gate.t_off);
   if ((tri.on || P.tri_ok) && rows == 0) {  // (an unselected pool line: empty system, nothing reads its block)
-    if (gate.on) gate_tail(gate, gl, l, X, ncol, 6, 0, 0, k, P.cols_in);
+    if (gate.on) gate_tail(gate, gl, gPs, gT, l, X, ncol, 6, 0, 0, k, P.cols_in);
     return;
   }
   const int shift = rows > 6 ? 6 : 0;  // (a block with no more rows than Hf has columns is left as it is, as nullspace_kernel does)
@@ -1989,7 +2069,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
     }
   }
   jac_stamp(5);
-  if (gate.on) gate_tail(gate, gl, l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
+  if (gate.on) gate_tail(gate, gl, gPs, gT, l, X, ncol, 6, shift, min(rows, ld), k, P.cols_in);
   if (touch == 1.2345678e300) P.rows[l] = -1;  // (never: keeps the touch loads)
   jac_stamp(9);
 }
@@ -2177,10 +2257,13 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
   GateStage gate = ctx->gate_stage;
   ctx->gate_stage.on = 0;  // (one launch takes it)
   const size_t gate_off = ((size_t)lay.tab * sizeof(double) + 63) & ~(size_t)63;  // (overlays tables and slots: fused_lds_layout)
-  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + 1024 > 160 * 1024) gate.on = 0;
+  const size_t t_off = (gate_off + sizeof(GateLds) + 63) & ~(size_t)63;
+  const size_t ps_off = (std::max(shm, t_off + (size_t)GATE_MMAX * GATE_TLD * sizeof(double)) + 63) & ~(size_t)63;
+  const size_t gate_end = ps_off + (size_t)gate_ps_doubles(P.k) * sizeof(double);
+  if (P.k > GATE_KMAX || gate_end + 1024 > 160 * 1024) gate.on = 0;
   if (gate.on) {
-    gate.lds_off = (int)gate_off;
-    shm = std::max(shm, gate_off + sizeof(GateLds));
+    gate.lds_off = (int)gate_off, gate.ps_off = (int)ps_off, gate.t_off = (int)t_off;
+    shm = gate_end;
   }
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)line_jacobian_nullspace_kernel, (int)shm));
@@ -2241,10 +2324,14 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   ctx->gate_stage.on = 0;  // (one launch takes it)
   // the gate's LDS block overlays tables, scratch and slots (fused_lds_layout): taken where it fits behind the entry's block
   const size_t gate_off = ((size_t)lay.tab * sizeof(double) + 63) & ~(size_t)63;
-  if (P.k > GATE_KMAX || gate_off + sizeof(GateLds) + 1024 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
+  // (GateLds and T overlay tables, scratch and slots: dead when the gate starts; the prior block, staged early, sits behind them)
+  const size_t t_off = (gate_off + sizeof(GateLds) + 63) & ~(size_t)63;  // (T too: it is written when the scratch is dead)
+  const size_t ps_off = (std::max(shm, t_off + (size_t)GATE_MMAX * GATE_TLD * sizeof(double)) + 63) & ~(size_t)63;
+  const size_t gate_end = ps_off + (size_t)gate_ps_doubles(P.k) * sizeof(double);
+  if (P.k > GATE_KMAX || gate_end + 1024 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
   if (gate.on) {
-    gate.lds_off = (int)gate_off;
-    shm = std::max(shm, gate_off + sizeof(GateLds));
+    gate.lds_off = (int)gate_off, gate.ps_off = (int)ps_off, gate.t_off = (int)t_off;
+    shm = gate_end;
   }
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
