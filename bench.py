@@ -425,7 +425,7 @@ def main():
             fw = ctypes.CDLL(os.environ["PLV_BENCH_FAULTWHERE"])
             if fw.fw_start() != 0:
                 fw = None
-        chain0 = pkg.chain_count()
+        chain0, routes0 = pkg.chain_count(), pkg.route_counts()
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if hook:
@@ -474,6 +474,7 @@ def main():
             cnt["whitened_frames"] += 1 if route == 4 else 0
         ctx.synchronize()
         cnt["chained"] = pkg.chain_count() - chain0
+        cnt["routes"] = [a - b for a, b in zip(pkg.route_counts(), routes0)]
         if fw:
             fw.fw_stop(os.environ.get("PLV_BENCH_FAULTWHERE_OUT", "").encode())
             m = np.mean(np.array(fw_ru, float), axis=0)
@@ -713,6 +714,11 @@ def main():
                 "compression": {"mode": "whitened update (plv_update_compression_mode 0): information matrix of the accepted rows + factor "
                                         "of the prior block on a side stream; no factor of the measurements",
                                 "frames_whose_last_update_took_it": cnt["whitened_frames"], "frames": args.steps,
+                                "updates_by_route": dict(zip(("uncompressed", "gram_cholesky", "householder", "gram_then_householder",
+                                                              "whitened", "whitened_withheld_then_householder"), cnt["routes"][:6])),
+                                "withheld": "a prior block whose unit-diagonal factor meets a pivot below 1e-10 (a near dependency: the "
+                                            "absolute variances outgrow the clone-to-clone ones as a drive gets longer) has its whitened "
+                                            "update withheld, run again by Householder + S = H P H^T + R, and the next 45 updates of that kind take the standard route",
                                 "note": "agrees with the Givens oracle to 1e-10 (P') and 1e-9 (dx) on every captured replay batch and up to "
                                         "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_gram_cholesky is the "
                                         "round-2 route (mode 3)"},

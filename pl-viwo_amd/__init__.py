@@ -168,6 +168,7 @@ def load_library():
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
         "plv_chain_count": (C.c_ulonglong, []),
+        "plv_route_counts": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
@@ -704,6 +705,13 @@ def phase_counters():
 def alloc_count():
     """plv_alloc_count (measurement aid): device / pinned buffer (re)allocations since the library was loaded"""
     return int(load_library().plv_alloc_count())
+
+
+def route_counts():
+    """plv_route_counts (measurement aid): updates collected so far by the route they took (index = update_compression_mode()[1])"""
+    out = (C.c_ulonglong * 8)()
+    load_library().plv_route_counts(out)
+    return [int(v) for v in out]
 
 
 def chain_count():

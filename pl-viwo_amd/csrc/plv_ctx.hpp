@@ -42,6 +42,7 @@ struct Counters {
   // the line worker's side: post -> wake-up, the wait for the edge maps, chain walk + segment growth, feed post -> start, the feed
   std::atomic<unsigned long long> w_wake_ns{0}, w_maps_ns{0}, w_extract_ns{0}, w_feed_start_ns{0}, w_feed_ns{0};
   std::atomic<unsigned long long> chained{0};  // line launches enqueued behind a running point update (plv_chain_count)
+  std::atomic<unsigned long long> route[8] = {};  // collected updates by plv_ctx_update_state::last_route (plv_route_counts)
 };
 inline Counters &counters() {
   static Counters c;

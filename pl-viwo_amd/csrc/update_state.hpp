@@ -55,6 +55,11 @@ struct plv_ctx_update_state {
     double *d_dx = nullptr;
     int *d_flag = nullptr, *d_acc_rows = nullptr;
   } redo_w;
+  // ... and the next updates of that kind (index: fdim == 6) go straight to the standard route as plv_update_compression_mode 2 runs
+  // it (Gram + Cholesky; Householder when its pivots are ambiguous): a prior that had a near dependency usually has it again in the
+  // next frame, and a withheld update costs the whitened chain, a host round trip and the second chain.  The whitened route is
+  // tried again after this many updates.
+  int whiten_holdoff[2] = {0, 0};
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)

@@ -84,8 +84,8 @@ def test_whitened_update_withheld_on_a_near_dependent_prior(pkg, kaist_dir, tmp_
     """Stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind the clone taken of it: the prior block has
     pivots of 1e-11 the whitened update would divide by (round 4: a first update rejected as not positive definite, later ones off by
     1e-7).  The prior factor reports them (blocked_chol.hip PLV_PRIOR_AMB), the commit is withheld and the update runs again through
-    the reference's S = H P H^T + R route (plv_api.hip RedoW): no update is lost, and the trajectory is the one the Householder route
-    (plv_update_compression_mode 1) gives, to rounding."""
+    the reference's S = H P H^T + R route (plv_api.hip RedoW; the following updates start there): no update is lost, and the trajectory
+    is the one the Householder route (plv_update_compression_mode 1) gives to a tenth of a millimetre."""
     options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
     dst = kaist_synth.convert(kaist_dir[1], str(tmp_path / "urban_1p5e9"), sd.RL, sd.RR, sd.BASE)     # (default stamps: 1.5e9 s)
     out, routes = {}, {}
@@ -110,4 +110,4 @@ def test_whitened_update_withheld_on_a_near_dependent_prior(pkg, kaist_dir, tmp_
         routes[name] = seen
     assert out["default"][0]["not_psd"] == 0 and out["default"][0]["cam_accepted"] == out["householder"][0]["cam_accepted"]
     assert sum(r >= 5 for r in routes["default"]) >= 1, routes["default"][:10]       # (run again at least once: the first update)
-    assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 1e-6
+    assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 1e-5
