@@ -138,7 +138,7 @@ struct PriorOps {
     }
   }
   __device__ __forceinline__ void store_border(int b, int c, double v) const {
-    if (b < n && c < k) W0[(size_t)b * ldw + c] = v;
+    if (W0 && b < n && c < k) W0[(size_t)b * ldw + c] = v;
   }
 };
 
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double
     lds.n_amb = 0;
   }
   // (no barrier needed here: scales_ready() has one before any wave reads the flags)
-  blocked_chol<NT>(ops, lds, k, n, PLV_PRIOR_TAU, (int)blockIdx.x);
+  blocked_chol<NT>(ops, lds, k, W0 ? n : 1, PLV_PRIOR_TAU, (int)blockIdx.x);  // (W0 null: the factor alone — one border the kernel forms and drops)
 }
 
 // ------------------------------------------------------------------------------------------ EKF
@@ -196,14 +196,52 @@ struct EkfOps {
   }
 };
 
+// Whitened update (dense_kernels.hip "whitened update"): the workgroups from `first` on do not factor anything — each of their waves
+// forms one 16 x 16 tile (on or above the diagonal) of  C1 = P[:, cols] GP  from the GP = G P[cols, :] the launch before stored
+// (update_kernels.hip WhitenPanels).  C1 is wanted by the launch after this one; here it costs nothing, the factorisation is a chain.
+struct WhitenC1 {
+  const double *P;
+  int ldp, k;
+  const int *cols;
+  const double *GP;  // GP[b * k + c]
+  double *C1;        // C1[b * n + b']
+  int first;         // < 0: none
+};
+
 // W = L^-1 [Mt | res] with S = L L^T (upper triangle of S valid).  flag |= 2 when S is not PD.
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *__restrict__ S, int lds_, int r,
                                                          const double *__restrict__ Mt, int ldm, int n,
                                                          const double *__restrict__ res, double *__restrict__ W, int ldw,
-                                                         int *__restrict__ flag, const int *__restrict__ skip) {
+                                                         int *__restrict__ flag, const int *__restrict__ skip, WhitenC1 c1) {
   __shared__ BcLds lds;
   if (skip && *skip == 0) return;
+  if (c1.first >= 0 && (int)blockIdx.x >= c1.first) {
+    __shared__ int scols[192];
+    if (threadIdx.x < 192) scols[threadIdx.x] = c1.cols[min((int)threadIdx.x, c1.k - 1)];
+    __syncthreads();
+    const int tn = (n + 15) >> 4, ntri = tn * (tn + 1) / 2;
+    const int tile = ((int)blockIdx.x - c1.first) * (NT + 1) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 15;
+    if (tile >= ntri) return;
+    int ti = 0, rem = tile;
+    while (rem >= tn - ti) {
+      rem -= tn - ti;
+      ++ti;
+    }
+    const int tj = ti + rem;
+    const int bq = min(ti * 16 + li, n - 1);
+    const double *Gq = c1.GP + (size_t)min(tj * 16 + li, n - 1) * c1.k;
+    d4 acc = {0, 0, 0, 0};
+    auto fa = [&](int, int kk) { return c1.P[(size_t)scols[kk] * c1.ldp + bq]; };
+    auto fb = [&](int kk, int) { return Gq[kk]; };
+    acc = mfma_tile_f64_pipe<16>(fa, fb, c1.k, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bp = ti * 16 + (lane >> 4) + 4 * q, b = tj * 16 + li;
+      if (bp < n && b < n) c1.C1[(size_t)b * n + bp] = acc[q];
+    }
+    return;
+  }
   EkfOps ops{S, lds_, r, Mt, ldm, n, res, W, ldw};
   if (threadIdx.x == 0) {
     lds.bad = 0;
@@ -240,28 +278,31 @@ int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, 
 }
 
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
-                     const double *d_res, double *d_W, int ldw, int *d_flag) {
+                     const double *d_res, double *d_W, int ldw, int *d_flag, const WhitenC1Args *wc) {
   if (r > 192) return PLV_E_CAPACITY;
-  const int groups = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
+  const int strips = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
+  const int nt_waves = r <= 32 ? 3 : r <= 64 ? 5 : r <= 112 ? 8 : r <= 128 ? 9 : r <= 160 ? 11 : 13;
+  const int tn = cdiv(n, 16), c1_groups = wc ? cdiv(tn * (tn + 1) / 2, nt_waves) : 0, groups = strips + c1_groups;
+  const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, strips} : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, -1};
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);
   if (r <= 32)
     hipLaunchKernelGGL(bchol_ekf_kernel<2>, dim3(groups), dim3(64 * 3), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   else if (r <= 64)
     hipLaunchKernelGGL(bchol_ekf_kernel<4>, dim3(groups), dim3(64 * 5), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   else if (r <= 112)
     hipLaunchKernelGGL(bchol_ekf_kernel<7>, dim3(groups), dim3(64 * 8), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   else if (r <= 128)
     hipLaunchKernelGGL(bchol_ekf_kernel<8>, dim3(groups), dim3(64 * 9), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   else if (r <= 160)
     hipLaunchKernelGGL(bchol_ekf_kernel<10>, dim3(groups), dim3(64 * 11), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   else
     hipLaunchKernelGGL(bchol_ekf_kernel<12>, dim3(groups), dim3(64 * 13), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,
-                       ldw, d_flag, ctx->skip_word);
+                       ldw, d_flag, ctx->skip_word, c1);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -269,7 +310,7 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
 int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp, int n, const int *d_cols, int k, double *d_Lt, int ldl,
                        double *d_W0, int ldw, int *d_n_near) {
   if (k > 192) return PLV_E_CAPACITY;
-  const int groups = cdiv(n, 16);
+  const int groups = d_W0 ? cdiv(n, 16) : 1;
   ProfScope ps(ctx->prof, "bchol_prior_kernel", st);
 #define PLV_PRIOR_LAUNCH(NT) \
   hipLaunchKernelGGL(bchol_prior_kernel<NT>, dim3(groups), dim3(64 * (NT + 1)), 0, st, d_P, ldp, n, d_cols, k, d_Lt, ldl, d_W0, ldw, d_n_near)

@@ -159,9 +159,9 @@ __global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restri
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
                                                      double *__restrict__ dC, int ldc, double *__restrict__ dx,
                                                      const double *__restrict__ P, int ldp, int *__restrict__ flag, const int *__restrict__ skip,
-                                                     const double *__restrict__ dW) {
-  // dW (whitened route): dC = dW - W^T W with dW = W0^T W0 formed ahead of time on the side stream (same tiles, same layout);
-  // that earlier launch is this kernel with dx = P = null: products only
+                                                     const double *__restrict__ dW, const double *__restrict__ d0) {
+  // dW, d0 (whitened route): dC = dW - W^T W and dx = d0 - W^T y with dW = P[:, cols] G P[cols, :] and d0 = P[:, cols] g (same
+  // tiles, same layout: ekf_ms_kernel's WhitenPanels)
   if (skip && *skip == 0) return;
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
     const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
     const double v = (dW && i < n && j < n) ? dW[(size_t)j * ldc + i] - acc[q] : acc[q];
     if (i < n && j < n) dC[(size_t)j * ldc + i] = v;
-    if (dx && i < n && j == n) dx[i] = acc[q];
+    if (dx && i < n && j == n) dx[i] = d0 ? d0[i] - acc[q] : acc[q];
     // REF: StateHelper.cpp:143-152 — any P_ii - (K M^T)_ii < 0 rejects the update; the commit kernel reads the flag
     if (P && i == j && i < n && P[(size_t)i * ldp + i] - v < 0.0) atomicOr(flag, 1);
   }
@@ -299,7 +299,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     int tn = cdiv(n + 1, 16);
     int waves = tn * (tn + 1) / 2;
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
-                       (const double *)nullptr);
+                       (const double *)nullptr, (const double *)nullptr);
   }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
@@ -344,25 +344,22 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 
 // ------------------------------------------------------------------------------------------ whitened update
 // The compressed update without a factorisation of the measurement side (DESIGN.md "Whitened update").  With G = H^T H, g = H^T r
-// (noise-normalised, as the reference's compression leaves them) and Ps = P[cols, cols] = Lp Lp^T:
-//     S^-1 on the compressed system  ==  the k x k matrix  B = I + Lp^T G Lp  on the whitened one, and
-//     P' = P - W0^T W0 + V^T V,   dx = V^T v      with  W0 = Lp^-1 P[cols, :],  [V | v] = Lb^-1 [W0 | Lp^T g],  B = Lb Lb^T.
-// Nothing is ever divided by a pivot of G: directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian)
-// simply add nothing to B.  The prior factor and W0^T W0 only need the covariance, so they run on a side stream while the main
-// stream triangulates, builds Jacobians and gates; the main chain after the gate is  gram -> B -> factor B -> dC -> commit.
+// (noise-normalised, as the reference's compression leaves them), Pc = P[cols, :] and Ps = P[cols, cols] = M M^T:
+//     H^T S^-1 H = (I + G Ps)^-1 G = G - G M B^-1 M^T G      with the k x k matrix  B = I + M^T G M = Lb Lb^T,  so
+//     P' = P - (C1 - Z^T Z),   dx = d0 - Z^T z      with  GP = G Pc,  C1 = Pc^T GP,  d0 = Pc^T g,  [Z | z] = Lb^-1 M^T [GP | g].
+// Nothing is ever divided by a pivot of G — directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian)
+// simply add nothing to B — and nothing by a pivot of the prior either: M enters as a factor, never as an inverse, so a prior whose
+// clones are almost functions of one another (pivots of 1e-9 of the unit-diagonal block late in a drive, 1e-11 with stamps of
+// 1.5e9 s; rounds 3 and 4 formed W0 = M^-1 Pc and lost eps / pivot there) costs no digits: the factor is backward stable, M M^T is Ps
+// to rounding, and the update depends on M only through that product.  What is lost instead is eps x (how much better than the
+// prior the measurements know a direction), C1 and Z^T Z both growing with it.  The prior factor only needs the covariance, so it
+// runs on a side stream while the main stream triangulates, builds Jacobians and gates; the main chain after the gate is
+// gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit   (four launches; "|": workgroups of the same launch).
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k) {
   int rc;
-  if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
-      (rc = ctx->d_dW.reserve((size_t)n * n * 8)))
-    return rc;
-  if ((rc = ctx->d_prior_near.reserve(64))) return rc;
-  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
-  {
-    ProfScope ps(ctx->prof, "prior_gain_kernel", st);
-    const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
-    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, st, ctx->d_W0.as<double>(), k, k, n, ctx->d_dW.as<double>(), n,
-                       (double *)nullptr, (const double *)nullptr, 0, (int *)nullptr, (const int *)nullptr, (const double *)nullptr);
-  }
+  if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_prior_near.reserve(64))) return rc;
+  // (one workgroup: the factor alone, no borders)
+  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, nullptr, k, ctx->d_prior_near.as<int>()))) return rc;
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -380,27 +377,28 @@ int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, co
 }
 
 // The main-stream part after launch_gram_information; the caller has made the stream wait for launch_prior_factor's end.
-int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, double *d_dx, int *d_flag, const void *mirror_src, void *mirror_dst,
-                        size_t mirror_bytes) {
+int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const int *d_cols, double *d_dx, int *d_flag, const void *mirror_src,
+                        void *mirror_dst, size_t mirror_bytes) {
   int rc;
   if ((rc = ctx->d_Mt.reserve((size_t)k * 8)) || (rc = ctx->d_S.reserve((size_t)k * k * 8)) || (rc = ctx->d_W.reserve((size_t)k * (n + 1) * 8)) ||
       (rc = ctx->d_y.reserve((size_t)n * n * 8)))
     return rc;
   double *cv = ctx->d_Mt.as<double>(), *B = ctx->d_S.as<double>(), *V = ctx->d_W.as<double>(), *dC = ctx->d_y.as<double>();
   const double *Gs = ctx->d_Gs.as<double>(), *gv = Gs + (size_t)k * k;
-  launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag);
-  if ((rc = launch_bchol_ekf(ctx, B, k, k, ctx->d_W0.as<double>(), k, n, cv, V, k, d_flag))) return rc;
+  if ((rc = ctx->d_dW.reserve(((size_t)n * n + n) * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8))) return rc;
+  double *Y0 = ctx->d_W0.as<double>(), *C1 = ctx->d_dW.as<double>(), *d0 = C1 + (size_t)n * n;
+  if ((rc = ctx->d_GP.reserve((size_t)k * n * 8))) return rc;
+  double *GP = ctx->d_GP.as<double>();
+  launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag, d_P, ldp, n, d_cols, Y0, GP, d0);
+  const WhitenC1Args wc{d_P, ldp, d_cols, GP, C1};
+  if ((rc = launch_bchol_ekf(ctx, B, k, k, Y0, k, n, cv, V, k, d_flag, &wc))) return rc;
   {
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
     const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
-                       ctx->d_dW.as<double>());
+                       C1, d0);
   }
-  const int *veto_keep = ctx->commit_veto;
-  ctx->commit_veto = ctx->d_prior_near.as<int>();  // (the prior factor's own verdict: see PLV_PRIOR_AMB)
-  rc = launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
-  ctx->commit_veto = veto_keep;
-  return rc;
+  return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
 
 }  // namespace plv

@@ -916,7 +916,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
     TRY(launch_gram_information(ctx, ctx->d_stack.as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
     TRY(aux_join());
-    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
+    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, us->bcols.as<int>(), d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     us->last_route = 4;
     us->redo_w = plv_ctx_update_state::RedoW{!us->graph_mode, Mtot, k, n, F, mp_max, fdim, tmp_elems, rb, d_dx, d_flag, d_acc_rows};
     return PLV_OK;

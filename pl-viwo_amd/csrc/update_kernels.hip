@@ -451,10 +451,25 @@ __global__ void __launch_bounds__(256) ekf_s_kernel(const double *__restrict__ M
 // owns one 16-row strip of S: it first forms its strip of H Ps (= the columns `cols` of Mt, the same sums in the same order, kept in
 // LDS) and multiplies it with H^T for the tiles on and above the diagonal — S no longer waits for Mt, and the compact copy of
 // Mt[:, cols] is never written.
-__global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ H, int ldh, int r, int k, const double *__restrict__ Pc,
+// Whitened update (dense_kernels.hip "whitened update"): workgroups from `first` on each own 16 columns b of the state and form, with
+// H = M^T (Lt), "Ps" = G, g:   GP = G P[cols, b] (LDS, and stored for the C1 tiles of the next launch: blocked_chol.hip WhitenC1),
+// Y0[:, b] = M^T GP,   d0[b] = P[cols, b]^T g.
+struct WhitenPanels {
+  const double *P;  // the covariance, both triangles valid
+  int ldp, n;
+  const int *cols;  // (may sit in pinned host memory: read once into LDS)
+  const double *g;
+  double *Y0;  // border layout of the factorisation kernels: Y0[b * k + c]
+  double *GP;  // GP[b * k + c]
+  double *d0;
+  int first;   // first workgroup of this part; < 0: none
+};
+
+__global__ void __launch_bounds__(512) ekf_ms_kernel(const double *__restrict__ H, int ldh, int r, int k, const double *__restrict__ Pc,
                                                      int ldp, int n, const double *__restrict__ Ps, double *__restrict__ Mt, int ldm,
                                                      const double *__restrict__ Rdiag, double *__restrict__ S, int lds_,
-                                                     int mt_blocks, int *__restrict__ flag, const int *__restrict__ skip, int h_upper) {
+                                                     int mt_blocks, int *__restrict__ flag, const int *__restrict__ skip, int h_upper,
+                                                     WhitenPanels wp) {
   // h_upper (whitened update: H = Lp^T): H(i, kk) = 0 for kk < i, so a 16-row strip's sums start at its own first column — the
   // skipped terms are exact zeros, the results the same bits, about half of the tile products gone
   __shared__ double strip[192 * 17];  // (H Ps)[16 rows][k], element (i, kk) at kk * 17 + i
@@ -462,10 +477,10 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
     flag[0] = 0;  // update status word, set by the kernels that follow
   }
   if (skip && *skip == 0) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, nw = blockDim.x >> 6;  // (4 or 8 waves)
   if ((int)blockIdx.x < mt_blocks) {
     const int tr_n = (r + 15) >> 4, tn_n = (n + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * nw + wave;
     if (tile >= tr_n * tn_n) return;
     const int tr = tile / tn_n, tn = tile - tr * tn_n;
     d4 acc = {0, 0, 0, 0};
@@ -482,12 +497,54 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
     }
     return;
   }
-  const int ti = blockIdx.x - mt_blocks;
   const int kt = (k + 15) >> 4, tr_n = (r + 15) >> 4;
+  if (wp.first >= 0 && (int)blockIdx.x >= wp.first) {
+    __shared__ int scols[192];
+    const int b0 = ((int)blockIdx.x - wp.first) * 16, bl = min(b0 + li, wp.n - 1);
+    if (threadIdx.x < 192) scols[threadIdx.x] = wp.cols[min((int)threadIdx.x, k - 1)];
+    __syncthreads();
+    for (int tj = wave; tj < kt; tj += nw) {  // GP = G Pc[:, b]
+      d4 acc = {0, 0, 0, 0};
+      const double *Gr = Ps + min(tj * 16 + li, k - 1);
+      auto fa = [&](int, int kk) { return Gr[(size_t)kk * k]; };
+      auto fb = [&](int kk, int) { return wp.P[(size_t)scols[kk] * wp.ldp + bl]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = tj * 16 + (lane >> 4) + 4 * q;
+        if (c < k) strip[c * 17 + li] = acc[q];
+        if (c < k && b0 + li < wp.n) wp.GP[(size_t)(b0 + li) * k + c] = acc[q];
+      }
+    }
+    if (wave == nw - 1) {  // d0[b] = sum_c Pc(c, b) g[c]: four partial sums per column, in a fixed order
+      double sum = 0.0;
+      for (int c = lane >> 4; c < k; c += 4) sum += wp.P[(size_t)scols[c] * wp.ldp + bl] * wp.g[c];
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (lane < 16 && b0 + li < wp.n) wp.d0[b0 + li] = sum;
+    }
+    __syncthreads();
+    for (int tj = wave; tj < kt; tj += nw) {  // Y0[:, b] = M^T GP  (M^T(c, kk) = 0 for kk < c)
+      d4 acc = {0, 0, 0, 0};
+      const int k0 = min(tj * 16, k);
+      const double *Hr = H + min(tj * 16 + li, k - 1) + (size_t)k0 * ldh;
+      const double *sp = strip + k0 * 17;
+      auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
+      auto fb = [&](int kk, int) { return sp[kk * 17 + li]; };
+      acc = mfma_tile_f64_pipe<16>(fa, fb, k - k0, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = tj * 16 + (lane >> 4) + 4 * q;
+        if (c < k && b0 + li < wp.n) wp.Y0[(size_t)(b0 + li) * k + c] = acc[q];
+      }
+    }
+    return;
+  }
+  const int ti = blockIdx.x - mt_blocks;
   {
     const int k0 = h_upper ? min(ti * 16, k) : 0;
     const double *Hr = H + min(ti * 16 + li, r - 1) + (size_t)k0 * ldh;
-    for (int tj = wave; tj < kt; tj += 4) {
+    for (int tj = wave; tj < kt; tj += nw) {
       d4 acc = {0, 0, 0, 0};
       const double *Pq = Ps + min(tj * 16 + li, k - 1) + (size_t)k0 * k;  // Ps = P[cols, cols] (k x k)
       auto fa = [&](int, int kk) { return Hr[(size_t)kk * ldh]; };
@@ -501,7 +558,7 @@ __global__ void __launch_bounds__(256) ekf_ms_kernel(const double *__restrict__ 
     }
   }
   __syncthreads();
-  for (int tj = ti + wave; tj < tr_n; tj += 4) {
+  for (int tj = ti + wave; tj < tr_n; tj += nw) {
     d4 acc = {0, 0, 0, 0};
     const int k0 = h_upper ? min(tj * 16, k) : 0;  // (H(j, kk) = 0 for kk < j)
     const double *Hc = H + min(tj * 16 + li, r - 1) + (size_t)k0 * ldh;
@@ -785,16 +842,18 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
     return;
   }
   hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(r, 16)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_Pc.as<double>(), n, n,
-                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word, 0);
+                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word, 0, WhitenPanels{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, -1});
 }
 
-// Whitened route: B = Lp^T G Lp + I (k x k, upper tiles) and c = Lp^T g — ekf_ms_kernel with H := Lp^T (Lt), "Ps" := G (full
-// symmetric) and "Pc" := g as a k x 1 block.
-void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag) {
+// Whitened route: B = M^T G M + I (k x k, upper tiles) and c = M^T g — ekf_ms_kernel with H := M^T (Lt), "Ps" := G (full
+// symmetric) and "Pc" := g as a k x 1 block — and, in further workgroups of the same launch, the products with the covariance
+// columns (WhitenPanels): GP = G P[cols, :], Y0 = M^T GP, d0 = P[:, cols] g.
+void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
+                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0) {
   ProfScope ps(ctx->prof, "ekf_ms_kernel", ctx->stream);
-  const int mt_blocks = cdiv(cdiv(k, 16), 4);
-  hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(k, 16)), dim3(256), 0, ctx->stream, Lt, k, k, k, gv, 1, 1, Gs, cv, k,
-                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word, 1);
+  const int mt_blocks = cdiv(cdiv(k, 16), 8), first = mt_blocks + cdiv(k, 16);  // eight waves a workgroup: one round of tiles per phase up to k = 128
+  hipLaunchKernelGGL(ekf_ms_kernel, dim3(first + cdiv(n, 16)), dim3(512), 0, ctx->stream, Lt, k, k, k, gv, 1, 1, Gs, cv, k,
+                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word, 1, WhitenPanels{d_P, ldp, n, d_cols, gv, Y0, GP, d0, first});
 }
 
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds

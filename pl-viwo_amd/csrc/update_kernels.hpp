@@ -66,11 +66,12 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
                     void *mirror_dst = nullptr, size_t mirror_bytes = 0);
 
 // whitened route (dense_kernels.hip; DESIGN.md "Whitened update")
-void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag);
+void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
+                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0);
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
-int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, double *d_dx, int *d_flag, const void *mirror_src, void *mirror_dst,
+int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const int *d_cols, double *d_dx, int *d_flag, const void *mirror_src, void *mirror_dst,
                         size_t mirror_bytes);
 int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp, int n, const int *d_cols, int k, double *d_Lt, int ldl,
                        double *d_W0, int ldw, int *d_n_near);
@@ -78,7 +79,14 @@ int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp,
 // blocked_chol.hip
 // d_n_ambiguous (nullable): receives the number of pivots the factorisation could not tell from zero (blocked_chol.hpp, diag_chain)
 int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z, int *d_n_ambiguous = nullptr);
+struct WhitenC1Args {  // (whitened update: the tiles of C1 = P[:, cols] GP ride along in spare workgroups: blocked_chol.hip WhitenC1)
+  const double *P;
+  int ldp;
+  const int *cols;
+  const double *GP;
+  double *C1;
+};
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
-                     const double *d_res, double *d_W, int ldw, int *d_flag);
+                     const double *d_res, double *d_W, int ldw, int *d_flag, const WhitenC1Args *wc = nullptr);
 
 }  // namespace plv
