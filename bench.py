@@ -715,10 +715,7 @@ def main():
                                         "of the prior block on a side stream; no factor of the measurements",
                                 "frames_whose_last_update_took_it": cnt["whitened_frames"], "frames": args.steps,
                                 "updates_by_route": dict(zip(("uncompressed", "gram_cholesky", "householder", "gram_then_householder",
-                                                              "whitened", "whitened_withheld_then_householder"), cnt["routes"][:6])),
-                                "withheld": "a prior block whose unit-diagonal factor meets a pivot below 1e-10 (a near dependency: the "
-                                            "absolute variances outgrow the clone-to-clone ones as a drive gets longer) has its whitened "
-                                            "update withheld, run again by Householder + S = H P H^T + R, and the next 45 updates of that kind take the standard route",
+                                                              "whitened", "whitened_rejected_then_householder"), cnt["routes"][:6])),
                                 "note": "agrees with the Givens oracle to 1e-10 (P') and 1e-9 (dx) on every captured replay batch and up to "
                                         "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_gram_cholesky is the "
                                         "round-2 route (mode 3)"},

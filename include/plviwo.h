@@ -205,7 +205,7 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
  * timer inside the CPU oracle's frame). */
 void plv_counters(unsigned long long *out8);
 /* (measurement aid) updates collected since the library was loaded, by route: index = plv_update_compression_mode's last_route
- * (0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened withheld / rejected then Householder) */
+ * (0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened rejected, then Householder) */
 void plv_route_counts(unsigned long long *out8);
 /* (measurement aid) line launches plv_camera_try_update enqueued behind a point update that was still running */
 unsigned long long plv_chain_count(void);

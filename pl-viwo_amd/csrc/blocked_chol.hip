@@ -54,14 +54,12 @@ struct CompressOps {
 // pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
 // the smallest live one 1.5e-7; DESIGN.md "Whitened update")
 #define PLV_PRIOR_TAU 2e-13
-// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies: the factor divides by them and the
-// rows of W0 they scale lose eps / pivot of their digits.  Round 4 met them twice: time stamps of 1.5e9 s (the IMU pose a quarter of
-// a microsecond of propagation behind the clone taken of it: pivots of 1e-11, a first update rejected as "not positive definite"),
-// and, milder, late in the bench drive — the filter's unobservable directions (global position, yaw) make the absolute variances
-// grow without bound while a clone's variance given its neighbour stays small, so the smallest pivots sink with the length of the
-// drive (7e-8 after 10 s, 1e-9 after 25 s).  Down to this limit the loss stays below 1e-6 x (how strongly the measurements couple
-// the direction), which the parity tests do not see; below it the kernel reports the pivot, the update's commit is withheld and the
-// host runs the update through the S = H P H^T + R route, then stays on that route for a while (plv_api.hip, RedoW).
+// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies, counted for the record (n_near):
+// time stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind the clone taken of it (pivots of 1e-11),
+// and the filter's unobservable directions (global position, yaw) make the absolute variances grow without bound while a clone's
+// variance given its neighbour stays small, so the smallest pivots sink with the length of a drive (7e-8 after 10 s of the bench
+// drive, 1e-9 after 25 s).  Rounds 3 and 4 divided by them (W0 = M^-1 Pc) and lost eps / pivot; the update now only multiplies by
+// the factor (dense_kernels.hip "whitened update"), and they cost nothing.
 #define PLV_PRIOR_AMB 1e-10
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>

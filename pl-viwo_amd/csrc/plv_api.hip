@@ -112,7 +112,7 @@ unsigned long long plv_alloc_count(void) { return plv::alloc_epoch().load(); }
 // (measurement aid) line launches that plv_camera_try_update enqueued behind a point update still running (the chained line launch)
 unsigned long long plv_chain_count(void) { return plv::counters().chained.load(); }
 // (measurement aid) updates collected since the library was loaded, by the route they took (plv_update_compression_mode's last_route:
-// 0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened withheld / rejected then Householder)
+// 0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened rejected, then Householder)
 void plv_route_counts(unsigned long long *out8) {
   if (!out8) return;
   for (int i = 0; i < 8; ++i) out8[i] = plv::counters().route[i].load();
@@ -700,7 +700,7 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   return PLV_OK;
 }
 static bool whitened_route(const plv_ctx_update_state *us, int Mtot, int k) {
-  return Mtot > k && k <= 192 && us->compress_mode == 0 && !us->graph_mode && us->whiten_holdoff[us->bfdim == 6 ? 1 : 0] <= 0;
+  return Mtot > k && k <= 192 && us->compress_mode == 0 && !us->graph_mode;
 }
 // Side stream: behind everything the main stream held when prior_mark() was called (the previous update's commit, the upload that
 // carries d_cols), factor the prior block and form W0^T W0; aux_join is recorded behind them.  Two steps so that a caller can mark,
@@ -811,8 +811,6 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   // Whitened route (mode 0, DESIGN.md "Whitened update").  Its prior factor only needs the covariance: the one-submission updates
   // start it on the side stream before their Jacobian launch (plv_prior_prefetch); otherwise it starts here.
   const bool whiten = whitened_route(us, Mtot, k);
-  const bool held_off = us->compress_mode == 0 && us->whiten_holdoff[fdim == 6 ? 1 : 0] > 0;  // (update_state.hpp: back to the whitened route after a while)
-  if (held_off) --us->whiten_holdoff[fdim == 6 ? 1 : 0];
   bool aux_open = prior_was_pending;  // (a prefetch that is not taken after all is still joined: the main stream rewrites the covariance)
   auto aux_join = [&]() -> int {  // the main stream goes on only when the side work is done (it reads the covariance)
     if (!aux_open) return PLV_OK;
@@ -931,8 +929,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
                                  ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max, d_flag + 3);
       if (crc == PLV_OK) {
         us->last_route = 1;
-        // the commit waits for the verdict on the pivots (mode 0 comes here while the whitened route is held off: update_state.hpp)
-        if ((us->compress_mode == 2 || held_off) && ekf_fast_fits(k) && !us->graph_mode) {
+        if (us->compress_mode == 2 && ekf_fast_fits(k) && !us->graph_mode) {  // the commit waits for the verdict on the pivots
           ctx->commit_veto = d_flag + 3;
           us->redo = plv_ctx_update_state::Redo{true, Mtot, k, n, tmp_elems, rb, d_dx, d_flag};
         }
@@ -1103,11 +1100,10 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   }
   us->redo.armed = false;
   if (us->redo_w.armed && us->last_route == 4 && *(const int *)(hb + (size_t)n * 8) != 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
-    // The whitened update came back rejected, or withheld because its prior factor met near dependencies (bit 8; update_state.hpp,
-    // RedoW): nothing was committed.  The stacked rows are run again the reference's way — compression, then S = R P R^T + I — with
-    // the compression by Householder reflections on the rows themselves (a prior like that comes with measurements the Gram +
-    // Cholesky route is unsure of too: on the KAIST-layout drive with stamps of 1.5e9 s it ended 5.6 cm from this one).  Its verdict
-    // is the update's; the next updates of this kind start on the standard route (Gram + Cholesky, Householder when that is unsure).
+    // The whitened update came back rejected (update_state.hpp, RedoW): nothing was committed.  The stacked rows are run again the
+    // reference's way — compression, then S = R P R^T + I — with the compression by Householder reflections on the rows themselves
+    // (on the KAIST-layout drive with stamps of 1.5e9 s, where this happens to the first update after the initialisation, the Gram +
+    // Cholesky compression ended 5.6 cm from this one).  Its verdict is the update's.
     const plv_ctx_update_state::RedoW rd = us->redo_w;
     us->redo_w.armed = false;
     const int nc = rd.k + 1;
@@ -1121,7 +1117,6 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
                         true, us->result_of(rd.fdim).p, hpin.p, mb));
     TRY(sync(ctx));
     us->last_route = 5;
-    us->whiten_holdoff[rd.fdim == 6 ? 1 : 0] = 45;
     ++ctx->gather_stamp;
     ctx->cov_host_synced = ctx->gather_stamp;
   }

@@ -43,11 +43,10 @@ struct plv_ctx_update_state {
   plv::DevBuf &result_of(int fdim) { return fdim == 6 ? result_l : result; }
   AccWords &acc_of(int fdim) { return acc[fdim == 6 ? 1 : 0]; }
   int acc_word_used = 1;   // the word the last launched update's chain read as its skip word (1: chi2_gate_kernel's)
-  // The whitened update divides by the pivots of the PRIOR block.  A prior direction of relative variance 1e-13 .. 1e-9 (round 4: the
-  // IMU pose a quarter of a microsecond of propagation away from the clone just taken of it — time stamps of 1.5e9 s resolve no
-  // finer) is neither an exact dependency nor well conditioned, and the update can come back "not positive definite" where the
-  // reference's S = H P H^T + R has no trouble.  Such a verdict is therefore not final: the stacked rows are still on the device and
-  // the update is run again through a Householder compression and the EKF step on R (last_route 5) before NOT_PSD is reported.
+  // A whitened update that comes back rejected (negative diagonal of P', B not positive definite) is not final: its formulas are
+  // not the reference's and lose digits elsewhere (dense_kernels.hip "whitened update": eps x how much better than the prior the
+  // measurements know a direction — large for the first update after an initialisation).  The stacked rows are still on the device
+  // and the update is run again through a Householder compression and the EKF step on R (last_route 5) before the verdict is reported.
   struct RedoW {
     bool armed = false;
     int Mtot = 0, k = 0, n = 0, F = 0, mp_max = 0, fdim = 3;
@@ -55,11 +54,6 @@ struct plv_ctx_update_state {
     double *d_dx = nullptr;
     int *d_flag = nullptr, *d_acc_rows = nullptr;
   } redo_w;
-  // ... and the next updates of that kind (index: fdim == 6) go straight to the standard route as plv_update_compression_mode 2 runs
-  // it (Gram + Cholesky; Householder when its pivots are ambiguous): a prior that had a near dependency usually has it again in the
-  // next frame, and a withheld update costs the whitened chain, a host round trip and the second chain.  The whitened route is
-  // tried again after this many updates.
-  int whiten_holdoff[2] = {0, 0};
   int pending_F = 0;  // features of a launched, not yet collected plv_msckf_update_resident_launch
   unsigned long long done_stamp = 0;  // plv_ctx::gather_stamp when done_ev was recorded
   unsigned word_seq = 0;              // nonzero: the launched update's last kernel stores this number to plv_ctx::done_word(16)
