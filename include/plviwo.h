@@ -207,6 +207,19 @@ void plv_counters(unsigned long long *out8);
 /* (measurement aid) updates collected since the library was loaded, by route: index = plv_update_compression_mode's last_route
  * (0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened rejected, then Householder) */
 void plv_route_counts(unsigned long long *out8);
+/* (test aid) Decision trace.  With it on, plv_camera_update_points (alone or inside plv_camera_try_update / plv_camera_frame) keeps, for
+ * every feature of its pool, the values its verdicts were taken on; plv_last_point_decisions returns them for the last update:
+ * ids [n] in pool order and vals [n][PLV_DECISION_VALUES] =
+ *   0 usable observations   1 triangulated (0 / 1)   2 mean reprojection error, px (the 3 px test, REF UpdaterCamera.cpp:656-683)
+ *   3 passed the gate (0 / 1)
+ *   4 condition number and 5 depth of the linear triangulation (REF FeatureInitializer.cpp:105-117: max_cond_number, min / max_dist)
+ *   6 depth and 7 baseline ratio after the refinement (REF FeatureInitializer.cpp:283-301: min / max_dist, max_baseline)
+ *   8 chi2, 9 the threshold it was held against (chi2_mult x the 95 % quantile), 10 the norm of the projected residual
+ * NaN: a test that was not reached (or a route that does not report: the two-step update of CPI poses / in-state landmarks).  cap = 0
+ * asks for n only.  The device values cost two small copies per update: not for timed runs. */
+#define PLV_DECISION_VALUES 11
+int plv_decision_trace(plv_ctx *ctx, int on);
+int plv_last_point_decisions(plv_ctx *ctx, uint64_t *ids, double *vals, int cap, int *n);
 /* (measurement aid) line launches plv_camera_try_update enqueued behind a point update that was still running */
 unsigned long long plv_chain_count(void);
 int plv_cov_checkpoint(plv_ctx *ctx);

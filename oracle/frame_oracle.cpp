@@ -58,6 +58,8 @@ int orc_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *l
 int orc_build_line_jacobians(const plv_state_view *st, const plv_line_tracks *lt, int k, const int *col_to_state, int ld, int *rows,
                              double *Hf, double *Hx, double *res);
 int orc_triangulate_lines(const plv_state_view *st, const plv_line_tracks *lt, double *line_FinG, unsigned char *ok);
+void orc_set_tri_debug(double *four_per_feature);
+void orc_set_gate_debug(double *three_per_entry);
 int orc_msckf_update(double *P, int n, int ldp, int F, int fdim, int k, int ld, const int *rows, const double *Hf_in,
                      const double *Hx_in, const double *res_in, const int *cols, double sigma2, double chi2_mult, double res_norm_gate,
                      const double *q95, uint8_t *accepted, int *n_rows_out, double *dx);
@@ -109,6 +111,8 @@ struct Frame {
   uint64_t currid = 0;
   std::map<uint64_t, PtTrack> db;
   std::map<uint64_t, UsedPoint> used;  // point_used
+  std::vector<uint64_t> dec_ids;       // the last point update's pool and the values behind its verdicts (orc_frame_last_point_decisions)
+  std::vector<double> dec_vals;        // [pool][11]
   // TrackLSD
   bool have_last = false;
   std::vector<float> lines_last;
@@ -380,7 +384,20 @@ int update_points(Frame &F, double *P, int n, int ldp, const plv_state_view *st,
   all.obs_uvn = ouvn.data();
   all.p_FinG = all.p_FinG_fej = pf.data();
   // (the reference triangulates feature by feature until the cap is reached; a feature it never reaches keeps its observations either way)
+  // (the values behind the verdicts, in the layout of the library's plv_last_point_decisions: tests/decision_trace.py)
+  const double nan = std::nan("");
+  std::vector<double> tdbg(4 * (size_t)Fp, nan);
+  orc_set_tri_debug(tdbg.data());
   orc_triangulate_batch(st, &all, &opt->tri, pf.data(), ok.data(), err.data());
+  orc_set_tri_debug(nullptr);
+  F.dec_ids.resize(Fp);
+  F.dec_vals.assign((size_t)Fp * 11, nan);
+  for (int f = 0; f < Fp; ++f) {
+    double *v = &F.dec_vals[(size_t)f * 11];
+    F.dec_ids[f] = pool[f].id;
+    v[0] = valid_n[f], v[1] = ok[f], v[2] = ok[f] ? err[f] : nan;
+    for (int i = 0; i < 4; ++i) v[4 + i] = tdbg[4 * (size_t)f + i];
+  }
   // REF :648-699 the selection loop
   std::vector<int> sel, n_skip(Fp, 0);
   for (int f = 0; f < Fp; ++f) {
@@ -450,8 +467,16 @@ int update_points(Frame &F, double *P, int n, int ldp, const plv_state_view *st,
   int n_rows = 0;
   std::vector<double> Pw((size_t)n * n);  // (orc_msckf_update writes P only on success, but takes a packed matrix)
   for (int j = 0; j < n; ++j) std::copy(P + (size_t)j * ldp, P + (size_t)j * ldp + n, Pw.begin() + (size_t)j * n);
+  std::vector<double> gdbg(3 * (size_t)Fs, nan);
+  orc_set_gate_debug(gdbg.data());
   const int rc = orc_msckf_update(Pw.data(), n, n, Fs, 3, k, ld, rows.data(), Hf.data(), Hx.data(), r.data(), cols.data(),
                                   st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, F.q95.data(), acc.data(), &n_rows, dx);
+  orc_set_gate_debug(nullptr);
+  for (int q = 0; q < Fs; ++q) {
+    double *v = &F.dec_vals[(size_t)sel[q] * 11];
+    v[3] = acc[q];
+    for (int i = 0; i < 3; ++i) v[8 + i] = gdbg[3 * (size_t)q + i];
+  }
   res->status = rc == -3 ? PLV_E_NOT_PSD : PLV_OK;
   if (rc == 0) {
     for (int j = 0; j < n; ++j) std::copy(Pw.begin() + (size_t)j * n, Pw.begin() + (size_t)j * n + n, P + (size_t)j * ldp);
@@ -791,6 +816,16 @@ int orc_frame_line_feed(void *h, double t, const double *vps) { return line_feed
 int orc_frame_update_points(void *h, double *P, int n, int ldp, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *ids, uint8_t *acc, double *p_FinG) {
   return update_points(*(Frame *)h, P, n, ldp, st, opt, dx, res, ids, acc, p_FinG);
+}
+// (test aid) the library's plv_last_point_decisions for the oracle: ids [n], vals [n][11], same columns
+int orc_frame_last_point_decisions(void *h, uint64_t *ids, double *vals, int cap, int *n) {
+  Frame &F = *(Frame *)h;
+  *n = (int)F.dec_ids.size();
+  if (cap == 0) return 0;
+  if (*n > cap) return PLV_E_CAPACITY;
+  std::copy(F.dec_ids.begin(), F.dec_ids.end(), ids);
+  std::copy(F.dec_vals.begin(), F.dec_vals.end(), vals);
+  return 0;
 }
 int orc_frame_get_line_features(void *h, const plv_state_view *st, const plv_update_options *opt) {
   if (!st || !opt || st->n_clones < 2) return PLV_E_BADARG;

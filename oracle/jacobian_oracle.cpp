@@ -588,8 +588,14 @@ static void sym_eig3(const M3 &A, double ev[3]) {
   ev[1] = 3 * q - ev[0] - ev[2];
 }
 
+// (test aid, tests/decision_trace.py) when set, orc_triangulate leaves the values its tests looked at here: condition number and
+// depth of the linear solution, depth and baseline ratio of the refined one
+static double *g_tri_debug = nullptr;
+void orc_set_tri_debug(double *four) { g_tri_debug = four; }
+
 int orc_triangulate(int M, const double *Rc, const double *pc, const float *uvn, double min_dist, double max_dist,
                     double max_cond, double max_baseline, int refine, double *p_FinG_out) {
+  if (g_tri_debug) g_tri_debug[0] = g_tri_debug[1] = g_tri_debug[2] = g_tri_debug[3] = std::nan("");
   if (M < 2) return 0;
   const M3 R_GtoA = getM(Rc + 9 * (M - 1));
   const V3 p_AinG = getV(pc + 3 * (M - 1));
@@ -610,6 +616,7 @@ int orc_triangulate(int M, const double *Rc, const double *pc, const float *uvn,
   double ev[3];
   sym_eig3(A, ev);
   double condA = ev[0] / ev[2];
+  if (g_tri_debug) g_tri_debug[0] = std::fabs(condA), g_tri_debug[1] = pf[2];
   if (std::fabs(condA) > max_cond || pf[2] < min_dist || pf[2] > max_dist || std::isnan(norm(pf))) return 0;
   if (refine) {
     // FeatureInitializerOptions defaults: max_runs 5, init_lamda 1e-3, max_lamda 1e10, min_dx 1e-6,
@@ -681,6 +688,7 @@ int orc_triangulate(int M, const double *Rc, const double *pc, const float *uvn,
       V3 perp = sub(p_CiinA, sc(dir, along));
       base_max = std::max(base_max, norm(perp));
     }
+    if (g_tri_debug) g_tri_debug[2] = pf[2], g_tri_debug[3] = norm(pf) / base_max;
     if (pf[2] < min_dist || pf[2] > max_dist || (norm(pf) / base_max) > max_baseline || std::isnan(norm(pf))) return 0;
   }
   const V3 pg = addv(mul(tr(R_GtoA), pf), p_AinG);
@@ -726,8 +734,11 @@ int orc_triangulate_batch(const plv_state_view *st, const plv_tracks *trk, const
     const int M = (int)uvn.size() / 2;
     double *pf = p_FinG + 3 * f;
     pf[0] = pf[1] = pf[2] = 0;
+    double *const dbg_all = g_tri_debug;  // (batch form: four values per feature)
+    if (dbg_all) g_tri_debug = dbg_all + 4 * (size_t)f;
     ok[f] = (uint8_t)orc_triangulate(M, Rc.data(), pc.data(), uvn.data(), opt->min_dist, opt->max_dist, opt->max_cond_number,
                                      opt->max_baseline, opt->refine_features, pf);
+    g_tri_debug = dbg_all;
     double e = 0;
     if (ok[f]) {
       for (int m = 0; m < M; ++m) {

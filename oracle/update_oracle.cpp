@@ -236,6 +236,10 @@ int orc_ekf_update(double *P, int n, int ldp, const double *H, int r, int k, int
 // REF: UpdaterCamera.cpp:230-293 (points, fdim=3, res_norm_gate=3) and :400-463 (lines, fdim=6,
 // no norm gate).  Same packed layout as plv_msckf_update.  q95[dof] is the chi-square table.
 // Stacks in the shared column space (union column order).
+// (test aid, tests/decision_trace.py) when set, orc_msckf_update leaves [F][3] = chi2, the threshold, the norm of the projected residual
+static double *g_gate_debug = nullptr;
+void orc_set_gate_debug(double *three_per_entry) { g_gate_debug = three_per_entry; }
+
 int orc_msckf_update(double *P, int n, int ldp, int F, int fdim, int k, int ld, const int *rows, const double *Hf_in,
                      const double *Hx_in, const double *res_in, const int *cols, double sigma2, double chi2_mult,
                      double res_norm_gate, const double *q95, uint8_t *accepted, int *n_rows_out, double *dx) {
@@ -257,6 +261,7 @@ int orc_msckf_update(double *P, int n, int ldp, int F, int fdim, int k, int ld, 
     nrm = std::sqrt(nrm);
     double chi;
     bool ok = chi2(Ps, B, C, sigma2, chi);
+    if (g_gate_debug) g_gate_debug[3 * f] = ok ? chi : std::nan(""), g_gate_debug[3 * f + 1] = chi2_mult * q95[C.r], g_gate_debug[3 * f + 2] = nrm;
     bool pass = ok && (res_norm_gate <= 0.0 || nrm < res_norm_gate) && chi < chi2_mult * q95[C.r];
     if (!pass) continue;
     if (accepted) accepted[f] = 1;

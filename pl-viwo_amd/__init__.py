@@ -168,6 +168,8 @@ def load_library():
         "plv_line_worker_config": (C.c_int, [C.c_int, C.c_int, ip, ip]),
         "plv_debug_knobs": (C.c_uint, [C.c_longlong]),
         "plv_chain_count": (C.c_ulonglong, []),
+        "plv_decision_trace": (C.c_int, [C.c_void_p, C.c_int]),
+        "plv_last_point_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
         "plv_route_counts": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
@@ -1264,6 +1266,23 @@ class Context:
 
     def line_tracker_feed_wait(self):
         self._chk(self.lib.plv_line_tracker_feed_wait(self.h))
+
+    DECISION_VALUES = ("n_obs", "triangulated", "reproj_px", "gate_passed", "tri_cond", "tri_depth", "refined_depth", "baseline_ratio", "chi2",
+                       "chi2_threshold", "res_norm")
+
+    def decision_trace(self, on=True):
+        """plv_decision_trace (test aid): keep the values behind the point update's verdicts (last_point_decisions)"""
+        self._chk(self.lib.plv_decision_trace(self.h, 1 if on else 0))
+
+    def last_point_decisions(self):
+        """plv_last_point_decisions: (ids [n], values [n][11], columns = Context.DECISION_VALUES) of the last point update's pool"""
+        n = C.c_int(0)
+        self._chk(self.lib.plv_last_point_decisions(self.h, None, None, 0, C.byref(n)))
+        ids, vals = np.zeros(n.value, dtype=np.uint64), np.zeros((n.value, len(self.DECISION_VALUES)))
+        if n.value:
+            self._chk(self.lib.plv_last_point_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), vals.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        n.value, C.byref(n)))
+        return ids, vals
 
     def line_prefetch_mode(self, on):
         self._chk(self.lib.plv_line_prefetch_mode(self.h, 1 if on else 0))

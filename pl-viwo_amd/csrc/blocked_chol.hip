@@ -54,13 +54,14 @@ struct CompressOps {
 // pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
 // the smallest live one 1.5e-7; DESIGN.md "Whitened update")
 #define PLV_PRIOR_TAU 2e-13
-// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies, counted for the record (n_near):
-// time stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind the clone taken of it (pivots of 1e-11),
-// and the filter's unobservable directions (global position, yaw) make the absolute variances grow without bound while a clone's
-// variance given its neighbour stays small, so the smallest pivots sink with the length of a drive (7e-8 after 10 s of the bench
-// drive, 1e-9 after 25 s).  Rounds 3 and 4 divided by them (W0 = M^-1 Pc) and lost eps / pivot; the update now only multiplies by
-// the factor (dense_kernels.hip "whitened update"), and they cost nothing.
-#define PLV_PRIOR_AMB 1e-10
+// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies: the whitened form of the update
+// divides by them and loses eps / pivot.  The factor counts them (n_near) and with one or more the update takes its factor form
+// (dense_kernels.hip "whitened update").  Time stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind
+// the clone taken of it (pivots of 1e-11); and the filter's unobservable directions (global position, yaw) make the absolute
+// variances grow without bound while a clone's variance given its neighbour stays small, so the smallest pivots sink with the
+// length of a drive (7e-8 after 10 s of the bench drive, 1e-9 after 25 s).
+#define PLV_PRIOR_AMB 1e-8
+#define PLV_WHITEN_LAMBDA_MAX 1e4
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
@@ -203,6 +204,8 @@ struct WhitenC1 {
   const int *cols;
   const double *GP;  // GP[b * k + c]
   double *C1;        // C1[b * n + b']
+  const double *Y0;  // factor form: the borders the factorisation solves for instead of Mt
+  const int *use_m;  // device word: != 0 = this update takes the factor form (else these workgroups have nothing to do)
   int first;         // < 0: none
 };
 
@@ -214,8 +217,20 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
                                                          int *__restrict__ flag, const int *__restrict__ skip, WhitenC1 c1) {
   __shared__ BcLds lds;
   if (skip && *skip == 0) return;
+  const bool factor_form = c1.first >= 0 && *c1.use_m != 0;
   if (c1.first >= 0 && (int)blockIdx.x >= c1.first) {
     __shared__ int scols[192];
+    if (!factor_form) return;
+    if ((int)blockIdx.x == c1.first && threadIdx.x < 64) {
+      // The factor form loses eps x lambda^2 of the posterior covariance in a direction the measurements know lambda times better than
+      // the prior (B's diagonal is 1 + lambda): beyond PLV_WHITEN_LAMBDA_MAX the update is left to the reference's route (status bit 8,
+      // plv_api.hip RedoW).  Only with a near-dependent prior: otherwise the whitened form runs, which loses nothing there.
+      double m = 0.0;
+      for (int i = threadIdx.x; i < r; i += 64) m = fmax(m, S[(size_t)i * lds_ + i]);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      if (threadIdx.x == 0 && m > PLV_WHITEN_LAMBDA_MAX) atomicOr(flag, 8);
+    }
     if (threadIdx.x < 192) scols[threadIdx.x] = c1.cols[min((int)threadIdx.x, c1.k - 1)];
     __syncthreads();
     const int tn = (n + 15) >> 4, ntri = tn * (tn + 1) / 2;
@@ -240,7 +255,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
     }
     return;
   }
-  EkfOps ops{S, lds_, r, Mt, ldm, n, res, W, ldw};
+  EkfOps ops{S, lds_, r, factor_form ? c1.Y0 : Mt, ldm, n, res, W, ldw};
   if (threadIdx.x == 0) {
     lds.bad = 0;
     lds.step_flag = 0;
@@ -281,7 +296,8 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   const int strips = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
   const int nt_waves = r <= 32 ? 3 : r <= 64 ? 5 : r <= 112 ? 8 : r <= 128 ? 9 : r <= 160 ? 11 : 13;
   const int tn = cdiv(n, 16), c1_groups = wc ? cdiv(tn * (tn + 1) / 2, nt_waves) : 0, groups = strips + c1_groups;
-  const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, strips} : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, -1};
+  const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, wc->Y0, wc->use_m, strips}
+                         : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, -1};
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);
   if (r <= 32)
     hipLaunchKernelGGL(bchol_ekf_kernel<2>, dim3(groups), dim3(64 * 3), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,

@@ -159,10 +159,15 @@ __global__ void __launch_bounds__(256) gram_direct_kernel(const double *__restri
 __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ W, int ldw, int r, int n,
                                                      double *__restrict__ dC, int ldc, double *__restrict__ dx,
                                                      const double *__restrict__ P, int ldp, int *__restrict__ flag, const int *__restrict__ skip,
-                                                     const double *__restrict__ dW, const double *__restrict__ d0) {
-  // dW, d0 (whitened route): dC = dW - W^T W and dx = d0 - W^T y with dW = P[:, cols] G P[cols, :] and d0 = P[:, cols] g (same
-  // tiles, same layout: ekf_ms_kernel's WhitenPanels)
+                                                     const double *__restrict__ dW, const double *__restrict__ C1,
+                                                     const double *__restrict__ d0, const int *__restrict__ use_m) {
+  // whitened route, its two forms (see "whitened update" below; use_m: device word, != 0 = factor form):
+  //   whitened form  dC = dW - W^T W, dx = W^T y         dW = W0^T W0, formed ahead of time on the side stream (this kernel with
+  //                                                      dx = P = null: products only)
+  //   factor form    dC = C1 - W^T W, dx = d0 - W^T y    C1 = P[:, cols] G P[cols, :], d0 = P[:, cols] g (same tiles, same layout)
   if (skip && *skip == 0) return;
+  const bool fm = use_m && *use_m != 0;
+  if (fm) dW = C1;
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -185,7 +190,7 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
     const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
     const double v = (dW && i < n && j < n) ? dW[(size_t)j * ldc + i] - acc[q] : acc[q];
     if (i < n && j < n) dC[(size_t)j * ldc + i] = v;
-    if (dx && i < n && j == n) dx[i] = d0 ? d0[i] - acc[q] : acc[q];
+    if (dx && i < n && j == n) dx[i] = fm ? d0[i] - acc[q] : acc[q];
     // REF: StateHelper.cpp:143-152 — any P_ii - (K M^T)_ii < 0 rejects the update; the commit kernel reads the flag
     if (P && i == j && i < n && P[(size_t)i * ldp + i] - v < 0.0) atomicOr(flag, 1);
   }
@@ -299,7 +304,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
     int tn = cdiv(n + 1, 16);
     int waves = tn * (tn + 1) / 2;
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, W, ldw, r, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
-                       (const double *)nullptr, (const double *)nullptr);
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const int *)nullptr);
   }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
@@ -344,22 +349,39 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 
 // ------------------------------------------------------------------------------------------ whitened update
 // The compressed update without a factorisation of the measurement side (DESIGN.md "Whitened update").  With G = H^T H, g = H^T r
-// (noise-normalised, as the reference's compression leaves them), Pc = P[cols, :] and Ps = P[cols, cols] = M M^T:
-//     H^T S^-1 H = (I + G Ps)^-1 G = G - G M B^-1 M^T G      with the k x k matrix  B = I + M^T G M = Lb Lb^T,  so
-//     P' = P - (C1 - Z^T Z),   dx = d0 - Z^T z      with  GP = G Pc,  C1 = Pc^T GP,  d0 = Pc^T g,  [Z | z] = Lb^-1 M^T [GP | g].
-// Nothing is ever divided by a pivot of G — directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian)
-// simply add nothing to B — and nothing by a pivot of the prior either: M enters as a factor, never as an inverse, so a prior whose
-// clones are almost functions of one another (pivots of 1e-9 of the unit-diagonal block late in a drive, 1e-11 with stamps of
-// 1.5e9 s; rounds 3 and 4 formed W0 = M^-1 Pc and lost eps / pivot there) costs no digits: the factor is backward stable, M M^T is Ps
-// to rounding, and the update depends on M only through that product.  What is lost instead is eps x (how much better than the
-// prior the measurements know a direction), C1 and Z^T Z both growing with it.  The prior factor only needs the covariance, so it
-// runs on a side stream while the main stream triangulates, builds Jacobians and gates; the main chain after the gate is
-// gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit   (four launches; "|": workgroups of the same launch).
+// (noise-normalised, as the reference's compression leaves them), Pc = P[cols, :] and Ps = P[cols, cols] = M M^T, S^-1 on the
+// compressed system is the k x k matrix  B = I + M^T G M = Lb Lb^T  on the whitened one.  Two ways to the update from there:
+//   whitened form   P' = P - W0^T W0 + V^T V,  dx = V^T v       W0 = M^-1 Pc,  [V | v] = Lb^-1 [W0 | M^T g]
+//   factor form     P' = P - C1 + Z^T Z,       dx = d0 - Z^T z   GP = G Pc, C1 = Pc^T GP, d0 = Pc^T g, [Z | z] = Lb^-1 M^T [GP | g]
+//                   (H^T S^-1 H = (I + G Ps)^-1 G = G - G M B^-1 M^T G)
+// Neither divides by a pivot of G: directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian) simply add
+// nothing to B.  They differ in what costs digits (round 4, measured against the Householder route on the configs[3] drive):
+//   * the whitened form builds the posterior of a well-measured direction as a sum of squares (P - W0^T W0 vanishes on the clone
+//     block) and is at least as accurate there as the reference's P - K H P; but W0 divides by the pivots of the prior's unit-
+//     diagonal factor and loses eps / pivot — clones that are almost functions of one another: 1e-9 late in the bench drive (the
+//     unobservable global position and yaw let the absolute variances grow without bound), 1e-11 with stamps of 1.5e9 s;
+//   * the factor form only multiplies by M (backward stable: M M^T is Ps to rounding) and is indifferent to those pivots, but C1 and
+//     Z^T Z both grow with lambda = how much better than the prior the measurements know a direction, and the posterior there is
+//     their difference: eps x lambda^2 of it is lost (lambda 1e4 .. 1e5 in the first updates after an initialisation with the
+//     intrinsics in the state: dx of the NEXT update off by 2e-5 of its largest entry).
+// The prior factor decides on the device: no pivot below PLV_PRIOR_AMB -> whitened form; else factor form, and if B's diagonal then
+// exceeds PLV_WHITEN_LAMBDA_MAX the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  The prior
+// factor, W0 and W0^T W0 only need the covariance, so they run on a side stream while the main stream triangulates, builds Jacobians
+// and gates; the main chain after the gate is  gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches;
+// "|": workgroups of the same launch, those of the factor form return at once when the update takes the whitened one).
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k) {
   int rc;
-  if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_prior_near.reserve(64))) return rc;
-  // (one workgroup: the factor alone, no borders)
-  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, nullptr, k, ctx->d_prior_near.as<int>()))) return rc;
+  if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
+      (rc = ctx->d_dW.reserve((size_t)n * n * 8)) || (rc = ctx->d_prior_near.reserve(64)))
+    return rc;
+  if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
+  {
+    ProfScope ps(ctx->prof, "prior_gain_kernel", st);
+    const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
+    hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, st, ctx->d_W0.as<double>(), k, k, n, ctx->d_dW.as<double>(), n,
+                       (double *)nullptr, (const double *)nullptr, 0, (int *)nullptr, (const int *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (const int *)nullptr);
+  }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
@@ -385,18 +407,18 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     return rc;
   double *cv = ctx->d_Mt.as<double>(), *B = ctx->d_S.as<double>(), *V = ctx->d_W.as<double>(), *dC = ctx->d_y.as<double>();
   const double *Gs = ctx->d_Gs.as<double>(), *gv = Gs + (size_t)k * k;
-  if ((rc = ctx->d_dW.reserve(((size_t)n * n + n) * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8))) return rc;
-  double *Y0 = ctx->d_W0.as<double>(), *C1 = ctx->d_dW.as<double>(), *d0 = C1 + (size_t)n * n;
-  if ((rc = ctx->d_GP.reserve((size_t)k * n * 8))) return rc;
-  double *GP = ctx->d_GP.as<double>();
-  launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag, d_P, ldp, n, d_cols, Y0, GP, d0);
-  const WhitenC1Args wc{d_P, ldp, d_cols, GP, C1};
-  if ((rc = launch_bchol_ekf(ctx, B, k, k, Y0, k, n, cv, V, k, d_flag, &wc))) return rc;
+  if ((rc = ctx->d_C1.reserve(((size_t)n * n + n) * 8)) || (rc = ctx->d_Y0.reserve((size_t)k * (n + 1) * 8)) || (rc = ctx->d_GP.reserve((size_t)k * n * 8)))
+    return rc;
+  double *Y0 = ctx->d_Y0.as<double>(), *C1 = ctx->d_C1.as<double>(), *d0 = C1 + (size_t)n * n, *GP = ctx->d_GP.as<double>();
+  const int *use_m = ctx->d_prior_near.as<int>();  // (written by the prior factor; the caller has joined the side stream)
+  launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag, d_P, ldp, n, d_cols, Y0, GP, d0, use_m);
+  const WhitenC1Args wc{d_P, ldp, d_cols, GP, C1, Y0, use_m};
+  if ((rc = launch_bchol_ekf(ctx, B, k, k, ctx->d_W0.as<double>(), k, n, cv, V, k, d_flag, &wc))) return rc;
   {
     ProfScope ps(ctx->prof, "ekf_dc_kernel", ctx->stream);
     const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
-                       C1, d0);
+                       ctx->d_dW.as<double>(), C1, d0, use_m);
   }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }

@@ -180,6 +180,7 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, const 
   }
   if (wave == 0 && lane == 0) {
     g.chi2[f] = chi;
+    if (g.dec) g.dec[3 * f] = valid ? chi : NAN, g.dec[3 * f + 1] = (valid && mp < g.q95_n) ? g.chi2_mult * g.q95[mp] : NAN, g.dec[3 * f + 2] = valid ? sqrt(nrm2) : NAN;
     bool pass = valid && !isnan(chi);
     if (pass && g.res_norm_gate > 0.0) pass = sqrt(nrm2) < g.res_norm_gate;
     if (pass) pass = (mp < g.q95_n) && (chi < g.chi2_mult * g.q95[mp]);

@@ -18,6 +18,7 @@ struct GateStage {  // kernel argument; on == 0: the launch ends with the projec
   const double *q95;
   int q95_n, min_rows;
   double *chi2;             // [F]
+  double *dec;              // (optional, plv_decision_trace) [F][3]: chi2, the threshold it was held against, the norm of the projected residual
   unsigned char *accepted;  // [F]
   int *acc_rows;            // [F]
   int *n_acc;               // counter of accepted entries (zero when the launch starts)

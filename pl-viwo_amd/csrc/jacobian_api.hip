@@ -229,6 +229,11 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
     tri_opt = ft->opt;
+    if (ctx->decision_trace) {
+      TRY(ctx->d_tri_dbg.reserve((size_t)F * 32));
+      P.tri_dbg = ctx->d_tri_dbg.as<double>();
+      ctx->dec_F = F;
+    }
     if (!fuse_tri) TRY(launch_triangulate(ctx, P, tri_poses, tri_valid, tri_uvn, *ft->opt, tri_p, tri_ok, tri_err, tri_max_obs));
     P.p_FinG = P.p_FinG_fej = (const double *)(d + o_p);  // MSCKF features: FEJ value = estimate (REF CamHelper.cpp:556-557)
     P.sel_flags = ex.d_flags;
@@ -236,6 +241,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     P.tri_err = (const double *)(d + o_err);
     P.max_sel = ft->max_sel;
     ft->o_p = o_p, ft->o_err = o_err, ft->o_ok = o_ok;
+
   } else {
     TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P));
   }

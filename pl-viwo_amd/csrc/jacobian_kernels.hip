@@ -1283,6 +1283,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, d
     ok_out[f] = 0;
     if (err_out) err_out[f] = 0;
     if (res_l) res_l[0] = res_l[1] = res_l[2] = res_l[3] = res_l[4] = 0.0;
+    if (P.tri_dbg) P.tri_dbg[4 * f] = P.tri_dbg[4 * f + 1] = P.tri_dbg[4 * f + 2] = P.tri_dbg[4 * f + 3] = NAN;
   }
   if (M < 2) return;
   tri_wave_sync();
@@ -1335,6 +1336,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, d
   double ev[3];
   sym_eig3(A, ev);
   const double condA = ev[0] / ev[2];
+  if (P.tri_dbg && lane == 0) P.tri_dbg[4 * f] = fabs(condA), P.tri_dbg[4 * f + 1] = pf[2];
   if (fabs(condA) > opt.max_cond_number || pf[2] < opt.min_dist || pf[2] > opt.max_dist || isnan(vnorm(pf))) return;
   jac_stamp(11);
   auto tri_error = [&](double alpha, double beta, double rho) {
@@ -1500,6 +1502,7 @@ __device__ void triangulate_feature(const JacParams &P, int f, int o0, int o1, d
     double base_max = 0;
     for (int q = 0; q < M; ++q) base_max = fmax(base_max, term[q * TRI_TERMS]);
     tri_wave_sync();
+    if (P.tri_dbg && lane == 0) P.tri_dbg[4 * f + 2] = pf[2], P.tri_dbg[4 * f + 3] = vnorm(pf) / base_max;
     if (pf[2] < opt.min_dist || pf[2] > opt.max_dist || (vnorm(pf) / base_max) > opt.max_baseline || isnan(vnorm(pf))) return;
   }
   const V3 pg = vadd(mv(tp(R_GtoA), pf), p_AinG);
@@ -2248,7 +2251,8 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
   max_obs = std::max(max_obs, 1);
   const FusedLds lay = fused_lds_layout(P.ld, 6 + P.k + 1, 6, (Pt ? 3 : 2) * std::max(P.n_clones - 3, 0), max_obs, Pt != nullptr);
   size_t shm = (size_t)lay.end * sizeof(double);
-  if (shm + 1024 > 160 * 1024) {
+  const size_t lds_cap = 160 * 1024 - static_smem_bytes((const void *)line_jacobian_nullspace_kernel);
+  if (shm > lds_cap) {
     set_last_error("line jacobians: block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
@@ -2260,7 +2264,7 @@ int launch_line_jacobians_projected(plv_ctx *ctx, const JacParams &P, const Gath
   const size_t t_off = (gate_off + sizeof(GateLds) + 63) & ~(size_t)63;
   const size_t ps_off = (std::max(shm, t_off + (size_t)GATE_MMAX * GATE_TLD * sizeof(double)) + 63) & ~(size_t)63;
   const size_t gate_end = ps_off + (size_t)gate_ps_doubles(P.k) * sizeof(double);
-  if (P.k > GATE_KMAX || gate_end + 1024 > 160 * 1024) gate.on = 0;
+  if (P.k > GATE_KMAX || gate_end > lds_cap) gate.on = 0;
   if (gate.on) {
     gate.lds_off = (int)gate_off, gate.ps_off = (int)ps_off, gate.t_off = (int)t_off;
     shm = gate_end;
@@ -2312,7 +2316,8 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   max_obs = std::max(max_obs, 1);
   const FusedLds lay = fused_lds_layout(P.ld, 3 + P.k + 1, 3, 2 * std::max(P.n_clones - 3, 0), max_obs, tri_opt != nullptr);
   size_t shm = (size_t)lay.end * sizeof(double);
-  if (shm + 1024 > 160 * 1024) {
+  const size_t lds_cap = 160 * 1024 - static_smem_bytes((const void *)jacobian_nullspace_kernel);
+  if (shm > lds_cap) {
     set_last_error("jacobians: feature block of %zu bytes exceeds LDS", shm);
     return PLV_E_CAPACITY;
   }
@@ -2328,7 +2333,7 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   const size_t t_off = (gate_off + sizeof(GateLds) + 63) & ~(size_t)63;  // (T too: it is written when the scratch is dead)
   const size_t ps_off = (std::max(shm, t_off + (size_t)GATE_MMAX * GATE_TLD * sizeof(double)) + 63) & ~(size_t)63;
   const size_t gate_end = ps_off + (size_t)gate_ps_doubles(P.k) * sizeof(double);
-  if (P.k > GATE_KMAX || gate_end + 1024 > 160 * 1024) gate.on = 0;  // (rows: plv_update_gate_prepare)
+  if (P.k > GATE_KMAX || gate_end > lds_cap) gate.on = 0;  // (rows: plv_update_gate_prepare)
   if (gate.on) {
     gate.lds_off = (int)gate_off, gate.ps_off = (int)ps_off, gate.t_off = (int)t_off;
     shm = gate_end;

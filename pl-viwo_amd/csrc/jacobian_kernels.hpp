@@ -42,6 +42,9 @@ struct JacParams {
   // the chains of dependent loads behind (obs_ptr -> obs_time -> clone poses) meet one cold miss, not one each
   const char *in_base;
   int in_bytes;
+  // (optional, plv_decision_trace) [n_feat][4]: the values the triangulation's tests looked at — condition number and depth of the
+  // linear solution, depth and baseline ratio of the refined one (NaN: not reached)
+  double *tri_dbg;
   // Chained launch (the line update enqueued behind a point update whose result the host has not seen, plv_camera_try_update): the
   // state above is the one BEFORE that update's correction; the kernel forms x (+) dx itself (StateHelper::EKFUpdate's mean update,
   // the arithmetic of plv_state_boxplus) for what it linearises on — clone poses, extrinsics, intrinsics, time offset — when the

@@ -684,6 +684,12 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   g.q95_n = Q95_N;
   g.min_rows = fdim == 3 ? 4 : 5;  // REF: UpdaterCamera.cpp:228 / :406
   g.chi2 = ctx->d_chi2.as<double>();
+  g.dec = nullptr;
+  if (ctx->decision_trace && fdim == 3) {
+    TRY(ctx->d_gate_dec.reserve((size_t)F * 24));
+    g.dec = ctx->d_gate_dec.as<double>();
+    ctx->dec_gate = true;
+  }
   g.accepted = d_acc;
   g.acc_rows = d_acc_rows;
   g.n_acc = d_flag + aw.word;
@@ -848,6 +854,12 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.cols = us->bcols.as<int>();
   a.sigma2 = sigma2;
   a.chi2 = ctx->d_chi2.as<double>();
+  a.dec = nullptr;
+  if (ctx->decision_trace && fdim == 3) {
+    TRY(ctx->d_gate_dec.reserve((size_t)F * 24));
+    a.dec = ctx->d_gate_dec.as<double>();
+    ctx->dec_gate = true;
+  }
   a.stack = ctx->d_stack.as<double>();
   a.lds = Mtot;
   a.mp_max = mp_max;

@@ -280,6 +280,19 @@ inline hipError_t ensure_dyn_smem(const void *fn, int bytes) {
   return e;
 }
 
+// A kernel's static LDS (its __shared__ arrays), which the limit of 160 KB holds next to the dynamic block; asked once per kernel.
+inline size_t static_smem_bytes(const void *fn) {
+  static std::mutex mtx;
+  static std::unordered_map<uintptr_t, size_t> seen;
+  std::lock_guard<std::mutex> lk(mtx);
+  auto it = seen.find((uintptr_t)fn);
+  if (it != seen.end()) return it->second;
+  hipFuncAttributes a{};
+  const size_t v = hipFuncGetAttributes(&a, fn) == hipSuccess ? a.sharedSizeBytes : 4096;
+  seen[(uintptr_t)fn] = v;
+  return v;
+}
+
 // HIP-event timing per kernel class, on the ctx stream.
 struct Profiler {
   struct Rec {
@@ -406,9 +419,14 @@ struct plv_ctx {
   plv::DevBuf d_Mt, d_S, d_W, d_y;          // EKF workspaces
   plv::DevBuf d_Pc, d_Ps, d_inv, d_T;       // dense covariance gathers, H'Ps
   plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
+  // plv_decision_trace: the values behind every verdict of the point update stay on the device until plv_last_point_decisions asks
+  bool decision_trace = false;
+  plv::DevBuf d_tri_dbg, d_gate_dec;
+  int dec_F = 0;          // entries of the last point batch whose values are in d_tri_dbg
+  bool dec_gate = false;  // ... and in d_gate_dec: that batch reached a gate
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
   // whitened route: prior factor Lp^T, W0 = Lp^-1 P[cols, :], W0^T W0 (side stream), information matrix [G | g] (main stream)
-  plv::DevBuf d_Lt, d_W0, d_dW, d_Gs, d_GP;
+  plv::DevBuf d_Lt, d_W0, d_dW, d_Gs, d_GP, d_Y0, d_C1;
   plv::DevBuf d_prior_near;  // int: near-dependent pivots the last prior factor met (blocked_chol.hip, PLV_PRIOR_AMB)
   hipStream_t aux_stream = nullptr;  // work that only needs the covariance, concurrent with the Jacobians and the gate
   hipEvent_t aux_fork = nullptr, aux_join = nullptr;

@@ -50,6 +50,9 @@ struct Tracker {
     double p[3];
   };
   std::vector<Listed> last_slam, last_init;
+  // plv_decision_trace: the last point update's pool, feature by feature (plv_last_point_decisions)
+  std::vector<uint64_t> dec_ids;
+  std::vector<double> dec_vals;  // [pool][PLV_DECISION_VALUES]
   std::mutex mtx;
 };
 
@@ -284,6 +287,21 @@ int plv_point_chain_lookup(plv_ctx *ctx, uint64_t id) {
   Tracker *T = trk(ctx);
   auto it = T->chain_index.find(id);
   return it == T->chain_index.end() ? -1 : it->second;
+}
+
+int plv_decision_trace(plv_ctx *ctx, int on) {
+  if (!ctx) return PLV_E_BADARG;
+  ctx->decision_trace = on != 0;
+  return PLV_OK;
+}
+int plv_last_point_decisions(plv_ctx *ctx, uint64_t *ids, double *vals, int cap, int *n) {
+  if (!ctx || !n || cap < 0 || (cap > 0 && (!ids || !vals))) return PLV_E_BADARG;
+  Tracker *T = trk(ctx);
+  *n = (int)T->dec_ids.size();
+  if (*n > cap) return cap == 0 ? PLV_OK : PLV_E_CAPACITY;
+  std::copy(T->dec_ids.begin(), T->dec_ids.end(), ids);
+  std::copy(T->dec_vals.begin(), T->dec_vals.end(), vals);
+  return PLV_OK;
 }
 
 int plv_tracker_detect_ahead(plv_ctx *ctx, int on) {
@@ -722,6 +740,26 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   }
   ph_dev.stop();
   rx_upd.stop();
+  if (ctx->decision_trace) {
+    // the values behind the verdicts, for the comparison of two runs decision by decision (tests/decision_trace.py): what the host
+    // already holds, and what the kernels left on the device (NaN: a test that was not reached, or a route that does not report)
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    T->dec_ids.resize(Fp);
+    T->dec_vals.assign((size_t)Fp * PLV_DECISION_VALUES, nan);
+    std::vector<double> tri(4 * (size_t)Fp, nan), gate(3 * (size_t)Fp, nan);
+    if (fused_ran && ctx->dec_F == Fp) {
+      PLV_HIP_CHECK(hipMemcpy(tri.data(), ctx->d_tri_dbg.p, tri.size() * 8, hipMemcpyDeviceToHost));
+      if (ctx->dec_gate) PLV_HIP_CHECK(hipMemcpy(gate.data(), ctx->d_gate_dec.p, gate.size() * 8, hipMemcpyDeviceToHost));
+    }
+    ctx->dec_F = 0, ctx->dec_gate = false;
+    for (int f = 0; f < Fp; ++f) {
+      double *v = &T->dec_vals[(size_t)f * PLV_DECISION_VALUES];
+      T->dec_ids[f] = pool[f].id;
+      v[0] = valid_n[f], v[1] = ok[f], v[2] = ok[f] ? err[f] : nan, v[3] = fused_ran ? acc_all[f] : nan;
+      for (int i = 0; i < 4; ++i) v[4 + i] = tri[4 * (size_t)f + i];
+      for (int i = 0; i < 3; ++i) v[8 + i] = gate[3 * (size_t)f + i];
+    }
+  }
   plv::RoctxRange rx_db("[Time-Cam] DB clan up");  // (sic, UpdaterCamera.cpp:174)
   plv::HostPhase ph_post("update_points: selection + database");
   // ---- REF :648-699 the selection loop

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kern
   }
   if (wave == 0 && lane == 0) {
     a.chi2[f] = chi;
+    if (a.dec) a.dec[3 * f] = valid ? chi : NAN, a.dec[3 * f + 1] = (valid && mp < a.q95_n) ? a.chi2_mult * a.q95[mp] : NAN, a.dec[3 * f + 2] = valid ? sqrt(nrm2) : NAN;
     passflag = 0.0;
     if (a.stack) {
       bool pass = valid && !isnan(chi);
@@ -462,6 +463,7 @@ struct WhitenPanels {
   double *Y0;  // border layout of the factorisation kernels: Y0[b * k + c]
   double *GP;  // GP[b * k + c]
   double *d0;
+  const int *use_m;  // device word (the prior factor's count of near-dependent pivots): 0 = this update does not take the factor form, nothing to do here
   int first;   // first workgroup of this part; < 0: none
 };
 
@@ -500,6 +502,7 @@ __global__ void __launch_bounds__(512) ekf_ms_kernel(const double *__restrict__ 
   const int kt = (k + 15) >> 4, tr_n = (r + 15) >> 4;
   if (wp.first >= 0 && (int)blockIdx.x >= wp.first) {
     __shared__ int scols[192];
+    if (*wp.use_m == 0) return;
     const int b0 = ((int)blockIdx.x - wp.first) * 16, bl = min(b0 + li, wp.n - 1);
     if (threadIdx.x < 192) scols[threadIdx.x] = wp.cols[min((int)threadIdx.x, k - 1)];
     __syncthreads();
@@ -842,18 +845,18 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
     return;
   }
   hipLaunchKernelGGL(ekf_ms_kernel, dim3(mt_blocks + cdiv(r, 16)), dim3(256), 0, ctx->stream, d_H, ldh, r, k, ctx->d_Pc.as<double>(), n, n,
-                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word, 0, WhitenPanels{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, -1});
+                     ctx->d_Ps.as<double>(), Mt, ldm, d_Rdiag, S, r, mt_blocks, d_flag, ctx->skip_word, 0, WhitenPanels{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, -1});
 }
 
 // Whitened route: B = M^T G M + I (k x k, upper tiles) and c = M^T g — ekf_ms_kernel with H := M^T (Lt), "Ps" := G (full
 // symmetric) and "Pc" := g as a k x 1 block — and, in further workgroups of the same launch, the products with the covariance
 // columns (WhitenPanels): GP = G P[cols, :], Y0 = M^T GP, d0 = P[:, cols] g.
 void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
-                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0) {
+                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0, const int *use_m) {
   ProfScope ps(ctx->prof, "ekf_ms_kernel", ctx->stream);
   const int mt_blocks = cdiv(cdiv(k, 16), 8), first = mt_blocks + cdiv(k, 16);  // eight waves a workgroup: one round of tiles per phase up to k = 128
   hipLaunchKernelGGL(ekf_ms_kernel, dim3(first + cdiv(n, 16)), dim3(512), 0, ctx->stream, Lt, k, k, k, gv, 1, 1, Gs, cv, k,
-                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word, 1, WhitenPanels{d_P, ldp, n, d_cols, gv, Y0, GP, d0, first});
+                     (const double *)nullptr, B, k, mt_blocks, d_flag, ctx->skip_word, 1, WhitenPanels{d_P, ldp, n, d_cols, gv, Y0, GP, d0, use_m, first});
 }
 
 // The EKF kernels on device-resident operands.  d_P is n x n (ldp).  On return *d_flag holds

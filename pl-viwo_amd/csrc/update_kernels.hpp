@@ -13,6 +13,7 @@ struct Chi2Args {
   const int *cols;
   double sigma2;
   double *chi2;
+  double *dec;            // (optional, plv_decision_trace) [F][3]: chi2, threshold, norm of the projected residual
   // gate + stack (optional)
   double *stack;
   int lds, mp_max;
@@ -67,7 +68,7 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
 
 // whitened route (dense_kernels.hip; DESIGN.md "Whitened update")
 void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
-                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0);
+                     const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0, const int *use_m);
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
@@ -85,6 +86,8 @@ struct WhitenC1Args {  // (whitened update: the tiles of C1 = P[:, cols] GP ride
   const int *cols;
   const double *GP;
   double *C1;
+  const double *Y0;   // the borders of the factor form (d_Mt of the call: those of the whitened form)
+  const int *use_m;   // device word: != 0 = factor form
 };
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
                      const double *d_res, double *d_W, int ldw, int *d_flag, const WhitenC1Args *wc = nullptr);

@@ -403,9 +403,13 @@ class SystemManager:
     one_call_frame = os.environ.get("PLV_ONE_CALL", "2") == "2"
     one_call_update = True      # try_update through plv_camera_try_update (False: plv_camera_update_points / _lines with the dx applied here)
 
-    def __init__(self, op, device=0, max_obs=24, context_factory=None, iw_initializer_factory=None):
+    def __init__(self, op, device=0, max_obs=24, context_factory=None, iw_initializer_factory=None, decisions=None):
         """context_factory / iw_initializer_factory: stand-ins with the interface of Context / IwInitializer (the tests run the same
-        driver over the CPU oracle through them); the defaults are the HIP library."""
+        driver over the CPU oracle through them); the defaults are the HIP library.  decisions: a list that receives one record per
+        camera update — (kind, frame, state time, pool size, ids that were triangulated, accepted flags, status, the values behind the verdicts
+        where the context reports them, dx) — for the
+        comparison of two runs decision by decision (tests/decision_trace.py)."""
+        self.decisions = decisions
         e = op.est
         if e.cam.enabled and e.cam.max_n != 1:
             raise OptionsError("replay driver: one camera (cam.max_n: 1, use_stereo: false)")
@@ -437,6 +441,8 @@ class SystemManager:
         if os.environ.get("PLV_AHEAD") and hasattr(self.ctx, "tracker_detect_ahead"):
             self.ctx.tracker_detect_ahead(int(os.environ["PLV_AHEAD"]))
         self.max_obs = max_obs
+        if decisions is not None and hasattr(self.ctx, "decision_trace"):
+            self.ctx.decision_trace(True)
         self.state = State(op, self.ctx)
         self.noise = imu_noise(e.imu.sigma_w, e.imu.sigma_wb, e.imu.sigma_a, e.imu.sigma_ab, tuple(e.gravity))
         # Propagator
@@ -758,6 +764,10 @@ class SystemManager:
             self.tc.dong("[Time-Cam] LINE update")
 
     def _count_points(self, out):
+        if self.decisions is not None:
+            vals = self.ctx.last_point_decisions() if hasattr(self.ctx, "last_point_decisions") else None
+            self.decisions.append(("points", self.stats["frames"], self.state.time, int(out["n_pool"]), np.array(out["ids"], dtype=np.uint64),
+                                   np.array(out["accepted"], dtype=np.uint8), int(out["status"]), vals, np.array(out["dx"], dtype=float)))
         if out["status"] != 0:
             self.stats["not_psd"] += 1
         elif out["n_accepted"] > 0:
@@ -766,6 +776,9 @@ class SystemManager:
         self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
 
     def _count_lines(self, lo):
+        if self.decisions is not None:
+            self.decisions.append(("lines", self.stats["frames"], self.state.time, int(lo["n_pool"]), np.array(lo["ids"], dtype=np.uint64),
+                                   np.array(lo["accepted"], dtype=np.uint8), int(lo["status"]), None, np.array(lo["dx"], dtype=float)))
         self.stats["line_pool"] += lo["n_pool"]
         self.stats["lines_triangulated"] += lo["n_lines"]
         if lo["status"] != 0:

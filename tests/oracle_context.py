@@ -347,6 +347,9 @@ class OracleContext(PyMirrorContext):
         assert cpi is None
         return self.frame.update_lines(self._Pf(), st, max_obs, t_prev_frame, state_time, window_full, chi2_mult, cap)
 
+    def last_point_decisions(self):
+        return self.frame.last_point_decisions()
+
     def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw):
         return self.frame.try_update(self._Pf(), st, dict(plus=plus, n=n, max_msckf=max_msckf, max_obs=max_obs, t_prev_frame=t_prev_frame,
                                                           state_time=state_time, **kw))

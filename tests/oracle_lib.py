@@ -682,6 +682,7 @@ class FrameOracle:
         L.orc_frame_line_feed.argtypes = [vp, C.c_double, dp]
         L.orc_frame_update_points.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp]
         L.orc_frame_get_line_features.argtypes = [vp, vp, vp]
+        L.orc_frame_last_point_decisions.argtypes = [vp, u64p, dp, C.c_int, ip]
         L.orc_frame_update_lines.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp, C.c_int]
         L.orc_frame_try_update.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp]
         L.orc_frame_camera_frame.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp]
@@ -750,6 +751,16 @@ class FrameOracle:
         m = res.n_msckf
         return dict(dx=dx, n_pool=res.n_pool, n_msckf=m, n_accepted=res.n_accepted, n_rows=res.n_rows, n_returned=res.n_returned, status=res.status,
                     ids=ids[:m].copy(), accepted=acc[:m].copy(), p_FinG=p[:m].copy(), n_slam=0, n_init=0, n_truncated=res.n_truncated)
+
+    def last_point_decisions(self):
+        """(ids [n], values [n][11]) of the last point update's pool: the library's Context.last_point_decisions for the oracle"""
+        n = C.c_int(0)
+        self.lib.orc_frame_last_point_decisions(self.h, None, None, 0, C.byref(n))
+        ids, vals = np.zeros(n.value, dtype=np.uint64), np.zeros((n.value, 11))
+        if n.value:
+            rc = self.lib.orc_frame_last_point_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(vals), n.value, C.byref(n))
+            assert rc == 0, rc
+        return ids, vals
 
     def _line_opt(self, max_obs, t_prev_frame, state_time, window_full, chi2_mult):
         pkg = self.pkg

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 import __graft_entry__ as ge  # noqa: E402
+import decision_trace as dt  # noqa: E402
 import oracle_context as oc  # noqa: E402
 import synth_dataset as sd  # noqa: E402
 
@@ -54,14 +55,16 @@ def main():
         op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj, **cfg_kw))
         op.est.cam.use_lines = lines
         t0 = time.time()
-        stats, times, poses = rp.replay(op, **kw)
+        dec = []
+        stats, times, poses = rp.replay(op, decisions=dec, **kw)
         et, ep = pkg.traj_load(traj)[:2]
         gt_t, gt_p = pkg.traj_load(gt)[:2]
         ei, gi = pkg.traj_associate(et, gt_t)
         r = ctx.traj_ate(ep[ei], gt_p[gi], "posyaw")
         res[name] = dict(wall_s=round(time.time() - t0, 2), stats=stats, ate=dict(method="posyaw", n=len(ei), pos=r["pos"], ori=r["ori"]))
-        runs[name] = (times, poses)
-    (th, ph), (tc, pc) = runs["hip"], runs["cpu_oracle"]
+        runs[name] = (times, poses, dec)
+    (th, ph, dh), (tc, pc, dc) = runs["hip"], runs["cpu_oracle"]
+    res["decisions"] = dt.summary(dh, dc, thr=dt.thresholds(op))
     if len(th) == len(tc) and np.array_equal(th, tc):
         r = ctx.traj_ate(ph, pc, "none")
         res["hip_vs_cpu"] = dict(n=len(th), max_pos_diff_m=float(np.abs(ph[:, :3] - pc[:, :3]).max()), pos=r["pos"], ori=r["ori"],
