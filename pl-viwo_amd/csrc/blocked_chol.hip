@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
   const bool factor_form = c1.first >= 0 && *c1.use_m != 0;
   if (c1.first >= 0 && (int)blockIdx.x >= c1.first) {
     __shared__ int scols[192];
-    if (!factor_form) return;
     if ((int)blockIdx.x == c1.first && threadIdx.x < 64) {
       // The factor form loses eps x lambda^2 of the posterior covariance in a direction the measurements know lambda times better than
       // the prior (B's diagonal is 1 + lambda): beyond PLV_WHITEN_LAMBDA_MAX the update is left to the reference's route (status bit 8,
@@ -229,8 +228,10 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
       for (int i = threadIdx.x; i < r; i += 64) m = fmax(m, S[(size_t)i * lds_ + i]);
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-      if (threadIdx.x == 0 && m > PLV_WHITEN_LAMBDA_MAX) atomicOr(flag, 8);
+      if (threadIdx.x == 0 && factor_form && m > PLV_WHITEN_LAMBDA_MAX) atomicOr(flag, 8);
+      if (threadIdx.x == 0) ((double *)(c1.use_m + 2))[0] = m;  // (for the record: plv_whiten_stats)
     }
+    if (!factor_form) return;
     if (threadIdx.x < 192) scols[threadIdx.x] = c1.cols[min((int)threadIdx.x, c1.k - 1)];
     __syncthreads();
     const int tn = (n + 15) >> 4, ntri = tn * (tn + 1) / 2;

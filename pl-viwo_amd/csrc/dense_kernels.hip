@@ -420,6 +420,12 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
                        ctx->d_dW.as<double>(), C1, d0, use_m);
   }
+  if (getenv("PLV_LAMBDA_DEBUG")) {
+    struct { int near, pad; double lam; } h;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(&h, use_m, 16, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[plv lambda] k %d near %d largest diagonal of B %.4g\n", k, h.near, h.lam);
+  }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
 

@@ -540,6 +540,9 @@ class SystemManager:
             st.cpis[r.t] = dict(t=r.t, dt=r.dt, clone_t=r.clone_t, R=np.array(r.R_I0toIk).reshape(3, 3), alpha=np.array(r.alpha),
                                 w=np.array(r.w), v=np.array(r.v), Q=np.array(r.Q))
         st.time = float(timestamp)
+        if self.decisions is not None and getattr(self.decisions, "probe_state", False):
+            self.decisions.states_prop.append((float(timestamp), len(t), np.concatenate([np.asarray(st.imu.q, float), np.asarray(st.imu.p, float), np.asarray(st.imu.v, float)]),
+                                               np.array(t, float), np.array(am, float)))
 
     def _reset_cpi(self, clone_t):   # Propagator.cpp:333-357
         st = self.state
@@ -641,6 +644,8 @@ class SystemManager:
             # feed_measurement + try_update in one library call (plv_camera_frame)
             upd = None
             args = self._try_update_args() if st.initialized else None
+            if self.decisions is not None and getattr(self.decisions, "probe_state", False) and args is not None:
+                self.decisions.states_pre.append((self.stats["frames"], self._state_probe(), self.ctx.cov_download(st.n) if hasattr(self.ctx, "cov_download") else None))
             sv = st.view()
             if args is not None:
                 pk, kw, max_msckf = args
@@ -722,6 +727,8 @@ class SystemManager:
 
     def _camera_try_update(self):
         st, e = self.state, self.op.est
+        if self.decisions is not None and getattr(self.decisions, "probe_state", False):
+            self.decisions.states_pre.append((self.stats["frames"], self._state_probe(), self.ctx.cov_download(st.n) if hasattr(self.ctx, "cov_download") else None))
         args = self._try_update_args()
         if args is None:
             return
@@ -763,7 +770,18 @@ class SystemManager:
             self._count_lines(lo)
             self.tc.dong("[Time-Cam] LINE update")
 
+    def _state_probe(self):
+        st = self.state
+        x = [np.asarray(st.imu.q, float), np.asarray(st.imu.p, float), np.asarray(st.imu.v, float), np.asarray(st.imu.bg, float), np.asarray(st.imu.ba, float)]
+        if st.cam_intr is not None:
+            x.append(np.asarray(st.cam_intr.v, float))
+        for t in sorted(st.clones):
+            x.append(np.asarray(st.clones[t].q, float)), x.append(np.asarray(st.clones[t].p, float))
+        return np.concatenate(x)
+
     def _count_points(self, out):
+        if self.decisions is not None and getattr(self.decisions, "probe_state", False):
+            self.decisions.states.append(self._state_probe())
         if self.decisions is not None:
             vals = self.ctx.last_point_decisions() if hasattr(self.ctx, "last_point_decisions") else None
             self.decisions.append(("points", self.stats["frames"], self.state.time, int(out["n_pool"]), np.array(out["ids"], dtype=np.uint64),
@@ -899,6 +917,9 @@ class SystemManager:
                                 w0=r0["w"] if r0 else z, v0=r0["v"] if r0 else z, w1=r1["w"] if r1 else z, v1=r1["v"] if r1 else z,
                                 ext_id=st.wheel_ext.id, dt_id=st.wheel_dt.id, intr_id=st.wheel_intr.id)
         rc, acc, dx = self.ctx.wheel_update(self.wheel_opt, ws, t, m1, m2, st.n)
+        if self.decisions is not None:
+            self.decisions.append(("wheel", self.stats["frames"], st.time, 1, np.zeros(1, dtype=np.uint64), np.array([1 if (rc == 0 and acc) else 0], dtype=np.uint8),
+                                   int(rc), None, np.array(dx, dtype=float)))
         self.stats["wheel_updates"] += 1
         if rc != 0:
             self.stats["not_psd"] += 1

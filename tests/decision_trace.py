@@ -8,7 +8,8 @@ threshold.  first_divergence() finds the first update whose decisions differ and
     pool            the pools differ in size — measurements differ: never a tie
     triangulation   an id was triangulated by one side only (condition number / depth range / baseline ratio of
                     FeatureInitializer::single_triangulation, single_gaussnewton; LineHelper's triangulation for lines)
-    chi2            an id was triangulated by both and accepted by one only (UpdaterStatistics::Chi2Check, the residual-norm gate)
+    chi2            an id was triangulated by both and accepted by one only (UpdaterStatistics::Chi2Check, the residual-norm gate;
+                    for a wheel update: its one chi2 test)
     status          the update as a whole was rejected by one side only
 
 and tie_margin() puts a number on it: the test value's relative distance to its threshold, evaluated by the CPU oracle on the state of
@@ -131,7 +132,7 @@ def value_drift(a, b, thr):
     return out
 
 
-def check_tie(summary_, first_updates=3, first_tol=1e-6, window=10, factor=20.0):
+def check_tie(summary_, first_updates=3, first_tol=1e-8, window=10, factor=20.0):
     """What the replay tests assert about a divergence.  (1) It is a decision on values (triangulation / chi2), never on the
     measurements (pool), the sequence of updates or an update's status.  (2) The two implementations agree on identical input: over
     the first updates — the states have not had time to part — every passing entry's values agree to first_tol.  (3) The entry that

@@ -413,6 +413,9 @@ init:
 
 
 # ----------------------------------------------------------------------------------------------------------------- dataset
+CAM_PHASE = float(os.environ.get("PLV_SYNTH_CAM_PHASE", "0.0017"))
+
+
 def simulate(seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, rest=0.0, style="room"):
     """The sensor streams of the synthetic drive, in memory: imu (t, wm, am), wheel (t, m1, m2), cam_times, gt (t, p, q)."""
     global REST, PATH
@@ -427,7 +430,10 @@ def simulate(seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, res
     for i, x in enumerate(tw):
         v, w = twist(x)
         m[i] = (v - w * BASE / 2) / RL + rng.normal(0, 0.02), (v + w * BASE / 2) / RR + rng.normal(0, 0.02)
-    tc = 0.05 + np.arange(int(seconds * cam_hz)) / cam_hz
+    # (the camera is not synchronised with the IMU, as on the KAIST car: a frame stamped on an IMU sample's instant makes the clone
+    # taken for it and the IMU pose of the same instant two window poses 1e-15 s apart whenever the clone time was formed as
+    # "last clone + 1 / rate" — the interpolation polynomial through such a pair is undefined, in the reference as much as here)
+    tc = 0.05 + CAM_PHASE + np.arange(int(seconds * cam_hz)) / cam_hz
     gt = []
     for x in t[::2]:
         R, p = imu_pose(x)

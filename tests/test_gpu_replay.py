@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import decision_trace as dt
 import synth_dataset as sd
 
 pytestmark = pytest.mark.gpu
@@ -164,9 +165,15 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
         traj = str(tmp_path / f"traj_{name}.txt")
         op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, traj))
         op.est.cam.use_lines = True
-        stats, times, poses = rp.replay(op, **kw)
+        dec = []
+        stats, times, poses = rp.replay(op, decisions=dec, **kw)
         assert stats["initialized"] and stats["not_psd"] == 0, (name, stats)
-        runs[name] = (stats, times, poses, traj)
+        runs[name] = (stats, times, poses, traj, dec)
+    # decision by decision (tests/decision_trace.py): where the runs part it is on a test value sitting on its threshold
+    dsum = dt.summary(runs["hip"][4], runs["cpu"][4], thr=dt.thresholds(op))
+    print("decisions:", {k: dsum[k] for k in ("updates", "updates_with_identical_decisions", "first_divergence")})
+    assert dsum["tie_check"] == [], dsum["tie_check"]
+    assert dsum["updates_with_identical_decisions"] >= 0.9 * dsum["updates"], dsum
     sh, sc = runs["hip"][0], runs["cpu"][0]
     for key in ("clones", "frames", "lines_tracked", "wheel_accepted"):   # what the (bit-identical) front-ends alone decide
         assert sh[key] == sc[key], (key, sh[key], sc[key])
@@ -208,9 +215,14 @@ def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, t
             op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset_d, traj, clone_freq=20, n_pts=500, max_msckf=70,
                                                       calib_int=True, sigma_px=1.5))
             op.est.cam.use_lines = True
-            stats, times, poses = rp.replay(op, **kw)
+            dec = []
+            stats, times, poses = rp.replay(op, decisions=dec, **kw)
             assert stats["initialized"] and stats["not_psd"] == 0, (name, stats)
-            runs[name] = (stats, times, poses)
+            runs[name] = (stats, times, poses, dec)
+        dsum = dt.summary(runs["hip"][3], runs["cpu"][3], thr=dt.thresholds(op))
+        print("decisions:", {k: dsum[k] for k in ("updates", "updates_with_identical_decisions", "first_divergence")})
+        assert dsum["tie_check"] == [], dsum["tie_check"]
+        assert dsum["updates_with_identical_decisions"] >= 0.9 * dsum["updates"], dsum
     finally:
         sd.set_camera(752, 480)
     sh, sc = runs["hip"][0], runs["cpu"][0]

@@ -76,7 +76,7 @@ def test_dataset_message_order(rp, tmp_path):
     assert len(ds.imu) == 221 and len(ds.wheel) == 55 and len(ds.frames) == 10
     t = [m[0] for m in ds.msgs]
     assert t == sorted(t) and len(ds.msgs) == 221 + 55 + 10 and ds.t_begin() == 0.0
-    assert ds.frames[3][1].endswith(os.path.join("cam0", "data", "000003.pgm")) and abs(ds.frames[3][0] - 0.35) < 1e-9
+    assert ds.frames[3][1].endswith(os.path.join("cam0", "data", "000003.pgm")) and abs(ds.frames[3][0] - (0.35 + sd.CAM_PHASE)) < 1e-9
     # messages with one time stamp: IMU before wheel before camera
     with open(os.path.join(d, "wheel.csv"), "a") as f:
         f.write("1.200000000,5.0,6.0\n")
