@@ -130,12 +130,14 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.03 * sc["cam_features"]
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
     # The two front-ends are bit-identical (round 2), so the filters are handed the same tracks.  The update side is fp64 on both
-    # sides with different libm's behind the pose interpolation, so the trajectories agree to ~1e-10 m until a feature sits on a
-    # threshold (3 px consistency, condition number, chi2): about one in a thousand is then taken by one side only (here feature 308
-    # at t = 4.45 s) and the two runs continue a millimetre apart.
+    # sides in different arithmetic (Householder reflections / the whitened update here, Givens rotations / S = H P H^T + R there):
+    # the states agree to 1e-11 until the refinement of a triangulation (FeatureInitializer::single_gaussnewton) stops one
+    # iteration apart on some feature — its termination tests are thresholds like any other — which puts the two runs 1e-7 .. 1e-6
+    # apart; a feature on one of the gates' thresholds is then taken by one side only once in a few thousand (round 4:
+    # tests/decision_trace.py, profiles/r04/replay_vs_cpu*.json — none in these drives).
     assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.01 * sc["cam_features"] and abs(sh["cam_accepted"] - sc["cam_accepted"]) <= 0.01 * sc["cam_accepted"]
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
-    assert d < 0.005, d
+    assert d < 2e-4, d
     assert np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max() < 1e-8
     ctx = pkg.Context(pkg.default_config(752, 480))
     r = ctx.traj_ate(runs["hip"][2], runs["cpu"][2], "none")
@@ -173,7 +175,7 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     dsum = dt.summary(runs["hip"][4], runs["cpu"][4], thr=dt.thresholds(op))
     print("decisions:", {k: dsum[k] for k in ("updates", "updates_with_identical_decisions", "first_divergence")})
     assert dsum["tie_check"] == [], dsum["tie_check"]
-    assert dsum["updates_with_identical_decisions"] >= 0.9 * dsum["updates"], dsum
+    assert dsum["updates_with_identical_decisions"] >= 0.97 * dsum["updates"], dsum
     sh, sc = runs["hip"][0], runs["cpu"][0]
     for key in ("clones", "frames", "lines_tracked", "wheel_accepted"):   # what the (bit-identical) front-ends alone decide
         assert sh[key] == sc[key], (key, sh[key], sc[key])
@@ -182,7 +184,7 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     assert sh["cam_accepted"] >= 500 and sh["lines_triangulated"] >= 200 and sh["line_updates"] >= 10, sh
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
-    assert d < 0.005, d
+    assert d < 2e-4, d
     # (before the first threshold tie: rounding only.  The line blocks are projected by Householder reflections here and by the
     # reference's Givens sequence in the oracle: the same left null space in another basis, conditioning ~1e4 of the Pluecker Hf)
     assert np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max() < 1e-7
@@ -222,7 +224,7 @@ def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, t
         dsum = dt.summary(runs["hip"][3], runs["cpu"][3], thr=dt.thresholds(op))
         print("decisions:", {k: dsum[k] for k in ("updates", "updates_with_identical_decisions", "first_divergence")})
         assert dsum["tie_check"] == [], dsum["tie_check"]
-        assert dsum["updates_with_identical_decisions"] >= 0.9 * dsum["updates"], dsum
+        assert dsum["updates_with_identical_decisions"] >= 0.97 * dsum["updates"], dsum
     finally:
         sd.set_camera(752, 480)
     sh, sc = runs["hip"][0], runs["cpu"][0]
@@ -233,7 +235,7 @@ def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, t
         assert abs(sh[key] - sc[key]) <= max(2, 0.03 * sc[key]), (key, sh[key], sc[key])
     assert sh["cam_accepted"] >= 800 and sh["lines_triangulated"] >= 1000 and sh["line_updates"] >= 10, sh
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
-    assert np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max() < 0.005
+    assert np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max() < 2e-4
 
 
 def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path, monkeypatch):
