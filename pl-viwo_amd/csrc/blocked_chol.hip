@@ -131,7 +131,7 @@ struct PriorOps {
   __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b < n && c < k) ? g * sc[min(c, k - 1)] : 0.0; }
   __device__ __forceinline__ void store_sym(int i, int c, double l) const {
     if (store_l && i < k && c <= i) {
-      if (c == i && n_near && l > 0.0 && l * l < PLV_PRIOR_AMB) atomicAdd(n_near, 1);
+      if (c == i && n_near && l * l < PLV_PRIOR_AMB) atomicAdd(n_near, 1);  // (a dead pivot — l = 0, below PLV_PRIOR_TAU — counts: round 4 met whitened-form updates with one that came back with dC ten times P)
       Lt[(size_t)i * ldl + c] = l * sc[192 + i];
       if (c < i) Lt[(size_t)c * ldl + i] = 0.0;
     }

@@ -425,6 +425,17 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemcpy(&h, use_m, 16, hipMemcpyDeviceToHost);
     fprintf(stderr, "[plv lambda] k %d near %d largest diagonal of B %.4g\n", k, h.near, h.lam);
+    int fl = 0;
+    (void)hipMemcpy(&fl, d_flag, 4, hipMemcpyDeviceToHost);
+    if (fl) {
+      std::vector<double> Pd((size_t)n * n), dc((size_t)n * n);
+      (void)hipMemcpy(Pd.data(), d_P, Pd.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(dc.data(), dC, dc.size() * 8, hipMemcpyDeviceToHost);
+      for (int i = 0; i < n; ++i)
+        if (Pd[(size_t)i * n + i] - dc[(size_t)i * n + i] < 0)
+          fprintf(stderr, "[plv negdiag] status %d near %d lam %.3g state %d P_ii %.6g dC_ii %.6g (P' %.3g)\n", fl, h.near, h.lam, i, Pd[(size_t)i * n + i], dc[(size_t)i * n + i],
+                  Pd[(size_t)i * n + i] - dc[(size_t)i * n + i]);
+    }
   }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }

@@ -1118,6 +1118,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     // Cholesky compression ended 5.6 cm from this one).  Its verdict is the update's.
     const plv_ctx_update_state::RedoW rd = us->redo_w;
     us->redo_w.armed = false;
+    if (getenv("PLV_LAMBDA_DEBUG")) fprintf(stderr, "[plv redo] k %d status %d\n", rd.k, *(const int *)(hb + (size_t)n * 8));
     const int nc = rd.k + 1;
     const size_t mb = ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3;
     ctx->skip_word = nullptr, ctx->commit_veto = nullptr;
