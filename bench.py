@@ -349,7 +349,7 @@ def main():
         nprof = max(10, min(40, args.steps))
         seg2 = 0 if args.no_pcie else args.steps
         nvar = 0 if args.no_variants else max(10, min(40, args.steps))
-        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof + 4 * nvar + 5 * LEAD_IN
+        n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + nprof + 6 * nvar + 7 * LEAD_IN   # (three alternating variants of 2 * nvar frames)
         n_cpu_frames = 0 if (args.no_cpu or rank != 0) else PROLOGUE + args.cpu_frames
         workers = args.render_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
         t0 = time.perf_counter()
@@ -428,6 +428,8 @@ def main():
         chain0, routes0 = pkg.chain_count(), pkg.route_counts()
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
+            if nf is None:
+                raise RuntimeError(f"bench: the rendered stream ended {n_steps - f} frames before a timed segment did (n_gpu_frames undersized)")
             if hook:
                 hook(f)
             if alt_modes:
