@@ -1,5 +1,7 @@
 """GPU parity tests of K10 (per-feature Jacobians) through the C-ABI: HIP vs the CPU oracle on the
 same seeded scenes.  fp64 with different libm (sin/cos/acos/pow): relative 1e-9."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,6 +138,44 @@ def test_triangulate_batch_parity(pkg, ctx, jo):
             assert np.median(rel) < 0.1
         assert np.max(np.abs(p1[good] - p0[good])) <= 1e-6 * max(1.0, np.abs(p0[good]).max()) if good.any() else True
         assert np.allclose(e1[good], e0[good], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,n_clones,offset", [(17, 18, 0.0), (21, 21, 0.004), (21, 22, -0.004), (23, 24, 0.0), (11, 11, -0.004)])
+def test_triangulate_long_tracks_and_window_edges(pkg, ctx, jo, M, n_clones, offset):
+    """Tracks longer than 16 observations take the refinement's one-candidate-at-a-time path (the four-candidate passes are for up to
+    16), and observations offset from the clone times reach the interpolation windows at both ends of the clone list: position to
+    1e-9 against the oracle, the reprojection error with it."""
+    fo = oracle_lib.load_front()
+    sc = synth.vio_scene(n_clones=n_clones, F=60, M=M, noise_px=0.3, obs_offset=offset)
+    uvn = fo.undistort(sc["K8"], sc["obs_uv"])
+    st = pkg.StateView(sc["t"], sc["R"], sc["p"], sc["ids"], sc["R_ItoC"], sc["p_IinC"], sc["K8"], intrinsic_state_id=15)
+    tr = pkg.Tracks(sc["obs_ptr"], sc["obs_time"], sc["obs_uv"], np.zeros((60, 3)), obs_uvn=uvn)
+    opt = dict(max_cond=1e7, max_dist=150.0, max_baseline=2000.0)
+    p0, ok0, e0 = jo.triangulate_batch(st, tr, **opt)
+    p1, ok1, e1 = ctx.triangulate(st, tr, **opt)
+    assert np.array_equal(ok0, ok1) and ok0.sum() >= 50
+    good = ok0.astype(bool)
+    assert np.abs(p1[good] - p0[good]).max() < 1e-9 and np.allclose(e1[good], e0[good], rtol=1e-7, atol=1e-9)
+
+
+def test_triangulate_with_two_window_poses_at_one_instant(pkg, ctx, jo):
+    """A batch captured from a replay whose camera was stamped on IMU sample instants (round 4): the newest clone and the IMU
+    pose that closes the window are 9e-16 s apart, and the interpolation polynomial through such a pair is undefined — the reference's
+    as much as this one's.  Tracks that do not reach the pair agree to rounding; the others are triangulated by both implementations
+    (same verdicts), a few centimetres apart.  The synthetic drives no longer produce such windows; the case stays as a record of why."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triangulate_window_edge.npz"))
+    assert d["t"][-1] - d["t"][-2] < 1e-12 and len(d["t"]) == 22
+    st = pkg.StateView(d["t"], d["R"], d["p"], d["ids"], d["R_ItoC"], d["p_IinC"], d["K8"], clone_R_fej=d["Rf"], clone_p_fej=d["pf"], cam_dt=float(d["cam_dt"]),
+                       dt_exp=float(d["dt_exp"]))
+    tr = pkg.Tracks(d["ptr"], d["ot"], d["uv"], np.zeros((len(d["ptr"]) - 1, 3)), obs_uvn=d["uvn"])
+    kw = dict(zip(("min_dist", "max_dist", "max_cond", "max_baseline"), (float(x) for x in d["kw"])))
+    p0, ok0, _ = jo.triangulate_batch(st, tr, **kw)
+    p1, ok1, _ = ctx.triangulate(st, tr, **kw)
+    assert np.array_equal(ok0, ok1)
+    good, nobs = ok0.astype(bool), np.diff(d["ptr"])
+    short = good & (nobs < 21)
+    assert short.sum() >= 5 and np.abs(p1[short] - p0[short]).max() < 1e-8
+    assert np.abs(p1[good] - p0[good]).max() < 0.2
 
 
 def test_cpi_poses_parity_and_use(pkg):
