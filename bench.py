@@ -708,7 +708,7 @@ def main():
                 "ms_per_step_inside_the_library": round((cnt["frame_ns"] + cnt["sync_ns"]) / args.steps * 1e-6, 4),
                 "ms_per_step_pcie_inclusive": None if seg_pcie is None else round(seg_pcie["elapsed"] / args.steps * 1e3, 4),
                 "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0,
-                                 "library_segment_fitters": (min(fit_threads, 2 if (wl["w"] // 2) * (wl["h"] // 2) >= 150000 else 1) if wl["lines"] else 0),
+                                 "library_segment_fitters": (min(fit_threads, 2 if (wl["w"] // 2) * (wl["h"] // 2) >= 60000 else 1) if wl["lines"] else 0),
                                  "library_segment_fitters_configured_maximum": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,
                                  "note": "the library's threads run the line detector's host stage (chain walk + segment growth) and the line "
                                          "tracker's bookkeeping next to the caller's thread; a waiting thread polls for poll_before_blocking_us, "

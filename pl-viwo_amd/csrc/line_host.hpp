@@ -252,10 +252,12 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   F.published.store(0, std::memory_order_relaxed);
   F.next.store(0, std::memory_order_relaxed);
   F.walk_done.store(false, std::memory_order_relaxed);
-  // one fitter keeps pace with the walk of a 376 x 240 map (BASELINE configs[2]); a 640 x 360 map (configs[3]: 2.5 x the chains, the fit
-  // left over at the end of the walk 110 us with one fitter, 20 with two) takes the second one as well — a thread a job does not need
-  // is not part of it: every hand-over between threads is a chance of a delayed wake-up on a busy host
-  const int nfit = std::min(fit_threads().load(std::memory_order_relaxed), (size_t)J.w * J.h >= 150000 ? 2 : 1);
+  // one fitter keeps pace with the walk of a 376 x 240 map (BASELINE configs[2]) on a quiet host; a 640 x 360 map (configs[3]: 2.5 x the
+  // chains, the fit left over at the end of the walk 110 us with one fitter, 20 with two) needs the second one.  Since round 4 the
+  // worker's path decides whether the line launch can be chained behind the point update (tracker_api.hip poll_line_pool), so the
+  // second fitter joins at configs[2] as well: alternating frame by frame -9 us on the mean and -80 .. -130 us on p99
+  // (bench.py --alternate-fit 1,2).  Tiny maps keep one: every hand-over between threads is a chance of a delayed wake-up.
+  const int nfit = std::min(fit_threads().load(std::memory_order_relaxed), (size_t)J.w * J.h >= 60000 ? 2 : 1);
   {
     int gen_now;
     {
