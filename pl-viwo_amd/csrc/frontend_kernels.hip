@@ -15,6 +15,7 @@
 
 #include "frontend_kernels.hpp"
 #include "wave_ops.hpp"
+#include "equalize_lut.hpp"
 
 namespace plv {
 
@@ -165,34 +166,7 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
   // level l+1 rows / columns held in t1: [my0, my0 + PD2_M), clamped at 0 (reads below 0 reflect to 1, 2: inside)
   const int my0 = max(2 * oy - 2, 0), mx0 = max(2 * ox - 2, 0);
   const int sy0 = max(2 * my0 - 2, 0), sx0 = max(2 * mx0 - 2, 0);  // level l origin of t0, same rule
-  if (EQ) {  // the LUT of cv::equalizeHist (equalize_kernel's arithmetic; the prefix sum by wave scans: two barriers instead of 17)
-    const int t = threadIdx.x, npix = sw * sh, lane = t & 63, wv = t >> 6;
-    const unsigned hv = hist[t];
-    unsigned c = hv;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned u = __shfl_up(c, off);
-      if (lane >= off) c += u;
-    }
-    const unsigned long long nz = __ballot(hv != 0);
-    if (lane == 63) cdf[wv] = c;                                         // wave totals
-    if (lane == 0) cdf[4 + wv] = nz ? (unsigned)(64 * wv + __ffsll((long long)nz) - 1) : 256u;  // first non-empty bin of the wave
-    __syncthreads();
-    for (int w = 0; w < wv; ++w) c += cdf[w];
-    const int i0 = (int)min(min(cdf[4], cdf[5]), min(cdf[6], cdf[7]));
-    if (t == i0) cdf[8] = hv;
-    __syncthreads();
-    const unsigned hh0 = cdf[8];
-    if ((int)hh0 == npix) {
-      lut[t] = (uint8_t)t;
-    } else {
-      const float scale = (256 - 1.f) / (float)(npix - (int)hh0);
-      int v = 0;
-      if (t > i0) v = __float2int_rn((float)(int)(c - hh0) * scale);
-      lut[t] = (uint8_t)min(max(v, 0), 255);
-    }
-    __syncthreads();
-  }
+  if (EQ) equalize_lut_256(hist, sw * sh, cdf, lut);  // the LUT of cv::equalizeHist (equalize_lut.hpp)
   if ((sw & 3) == 0) {
     // rows of the footprint as aligned 4-byte words (level widths that are multiples of 4: every word lies inside the row or past its
     // end, and the 64-pixel level-0 piece starts on a word): a quarter of the load / store instructions of the byte loop below
@@ -1129,6 +1103,9 @@ int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p
     const int blocks = min(256, max(1, cdiv(npix / 16, 256)));
     hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, npix, d_hist);
   }
+  // (the line detector's edge kernel, when the tracker feed asked for it: it equalises the raw image itself and so need not wait for
+  // the pyramid — its maps reach the library's line worker two launches earlier, and the flow starts when it always did)
+  if (ctx->edges_hook) ctx->edges_hook(ctx, d_raw, p.w[0], p.h[0], d_hist);
   {
     ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
     dim3 grid(cdiv(p.w[2], PD2_T), cdiv(p.h[2], PD2_T));

@@ -117,6 +117,11 @@ struct LineTracker {
   hipStream_t edge_stream = nullptr;
   hipEvent_t pyr_done = nullptr;
   bool edge_fork = false;
+  // plv_line_edges_early: the detection being launched reads the RAW image of the frame being fed (the pyramid that will hold its
+  // equalised form is not current yet) through its histogram
+  const uint8_t *early_raw = nullptr;
+  const unsigned *early_hist = nullptr;
+  int early_w = 0, early_h = 0;
   int pending_which = -1, pending_fed = -1;
   bool defer_finish = false;        // plv_camera_try_update: the line update leaves its database hand-back (cleanup_lines) behind ...
   std::function<void()> deferred;   // ... to run before anything else reads the tracker: in the next frame's wait for the flow (ltr())
@@ -280,7 +285,9 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   const bool prelaunched = !launch_only && !T->walk_on_device && T->pending_which == which && T->pending_fed == plv_front_fed_count(ctx);
   if (!launch_only) T->pending_which = -1;
   int W = 0, H = 0;
-  const uint8_t *d_img = plv_front_level0(ctx, which, &W, &H);
+  const bool early = launch_only && T->early_raw != nullptr;
+  const uint8_t *d_img = early ? T->early_raw : plv_front_level0(ctx, which, &W, &H);
+  if (early) W = T->early_w, H = T->early_h;
   if (!d_img) {
     set_last_error("plv_detect_lines: no image has been fed");
     return PLV_E_BADARG;
@@ -315,7 +322,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     es = T->edge_stream;
   }
   T->edge_fork = false;
-  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es));
+  if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es, early ? T->early_hist : nullptr));
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
   auto emit = [&](const float4 &sg) {
     const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
@@ -356,7 +363,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
       if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
       PLV_HIP_CHECK(hipEventRecord(T->edges_ready, es));
       T->pending_which = which;
-      T->pending_fed = plv_front_fed_count(ctx);
+      T->pending_fed = plv_front_fed_count(ctx) + (early ? 1 : 0);  // (early: the image becomes the current one when its feed returns)
       if (!T->worker.joinable()) T->worker = std::thread(line_worker, T);
       {
         std::lock_guard<std::mutex> lk(T->jm);
@@ -556,6 +563,19 @@ int plv_line_edges_fork(plv_ctx *ctx) {
   PLV_HIP_CHECK(hipEventRecord(T->pyr_done, ctx->stream));
   T->edge_fork = true;
   return PLV_OK;
+}
+
+// The tracker feed's hook into the image feed (plv_ctx::edges_hook): plv_line_detect_launch for the image being fed, between its
+// histogram and its pyramid — the edge kernel equalises the raw image itself (canny_kernel), the worker gets the maps two launches
+// earlier, and the flow starts when it always did.  Host-walk configuration without hysteresis only (the shipped one).
+extern "C" void plv_line_edges_early(plv_ctx *ctx, const uint8_t *d_raw, int W, int H, const unsigned *d_hist) {
+  LineTracker *T = ltr(ctx, false);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  if (T->walk_on_device || !T->prefetch || ctx->cfg.canny_th1 != ctx->cfg.canny_th2) return;
+  T->early_raw = d_raw, T->early_hist = d_hist, T->early_w = W, T->early_h = H;
+  std::vector<float> none;
+  if (detect(ctx, T, PLV_PYR_CUR, none, true) == PLV_OK) ctx->edges_hook_fired = true;
+  T->early_raw = nullptr, T->early_hist = nullptr;
 }
 
 int plv_line_detect_launch(plv_ctx *ctx, int which) {

@@ -18,6 +18,7 @@
 #include "line_kernels.hpp"
 
 #include "fld_fit_core.hpp"
+#include "equalize_lut.hpp"
 
 namespace plv {
 
@@ -33,12 +34,18 @@ __global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ s
 // FULL = true: `src` is the full-resolution image (fw wide) and the tile of the half-resolution image the stencil needs is decimated
 // on the fly (the arithmetic of half_kernel); the workgroup also writes its 16 x 16 piece of the half-resolution image, which the
 // segment fit reads.  One launch for cv::resize + cv::Canny.
+// hist (FULL only, nullable): `src` is the RAW image and hist its 256-bin histogram — the workgroup builds cv::equalizeHist's look-up
+// table itself and reads the image through it: the launch then need not wait for the pyramid launch that writes the equalised image.
 template <bool FULL>
 __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int fw, int w, int h, int low, int high,
                                                             uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */,
-                                                            uint8_t *__restrict__ half_out) {
+                                                            uint8_t *__restrict__ half_out, const unsigned *__restrict__ hist, int npix_full) {
   __shared__ int px[CN_T + 4][CN_T + 4];
   __shared__ int mg[CN_T + 2][CN_T + 2];
+  __shared__ unsigned cdf[16];
+  __shared__ uint8_t lut[256];
+  const bool eq = FULL && hist != nullptr;  // (uniform)
+  if (eq) equalize_lut_256(hist, npix_full, cdf, lut);
   const int tx = threadIdx.x & (CN_T - 1), ty = threadIdx.x / CN_T;
   const int x0 = blockIdx.x * CN_T, y0 = blockIdx.y * CN_T;
   for (int i = threadIdx.x; i < (CN_T + 4) * (CN_T + 4); i += CN_T * CN_T) {
@@ -46,7 +53,7 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
     const int gx = min(max(x0 + lx - 2, 0), w - 1), gy = min(max(y0 + ly - 2, 0), h - 1);  // BORDER_REPLICATE
     if (FULL) {
       const uint8_t *p = src + (size_t)(2 * gy) * fw + 2 * gx;
-      px[ly][lx] = (p[0] + p[1] + p[fw] + p[fw + 1] + 2) >> 2;
+      px[ly][lx] = eq ? (lut[p[0]] + lut[p[1]] + lut[p[fw]] + lut[p[fw + 1]] + 2) >> 2 : (p[0] + p[1] + p[fw] + p[fw + 1] + 2) >> 2;
     } else {
       px[ly][lx] = src[(size_t)gy * w + gx];
     }
@@ -237,7 +244,7 @@ __global__ void __launch_bounds__(64) fld_fit_kernel(const uint8_t *__restrict__
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // stage 1: half-resolution image and Canny map (0 weak / 1 none / 2 edge; hysteresis applied)
-int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st) {
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st, const unsigned *d_hist) {
   if (!st) st = ctx->stream;
   const int w = W / 2, h = H / 2;
   int low = fp.canny_low, high = fp.canny_high;
@@ -245,7 +252,7 @@ int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const Fl
   {
     ProfScope ps(ctx->prof, "half_canny_kernel", st);
     hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, st, d_img, W, w, h, low,
-                       high, b.map, b.half);
+                       high, b.map, b.half, d_hist, W * H);
   }
   if (low != high) {
     ProfScope ps(ctx->prof, "canny_hyst_kernel", st);

@@ -24,7 +24,9 @@ struct FldBuffers {
   int *seg_count;  // [chain_cap]
 };
 
-int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */);
+// d_hist: d_img is the RAW image and d_hist its histogram (the kernel equalises on the fly: canny_kernel); null: d_img is the equalised image
+int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */,
+                      const unsigned *d_hist = nullptr);
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 

@@ -74,11 +74,13 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 // 256  the flow's and the updates' waits on completion words their last kernels write into pinned memory (plv_ctx::h_done) instead of
 //      on HIP events: a bare word is seen 4.8 us earlier (tools/ubench/waitlat.hip), in the frame it gains nothing (0 .. 9 us SLOWER over
 //      four alternating runs: the commit then runs as one workgroup so that the word also covers the covariance)
+//  512 the prefetched edge kernel behind the pyramid (rounds 2-3) instead of between the histogram and the pyramid (round 4: it equalises
+//      the raw image itself, canny_kernel; the maps reach the line worker two launches earlier)
 // 2048 no chained line launch: the line half is staged and enqueued after the host has collected and applied the point update (round 3)
 // 4096 the point update's wait keeps polling its hook until the hook is done even when the device has finished (tests: every frame's
 //      line launch is chained, whatever the timing of the line worker)
 enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
-                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u };
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u, PLV_KNOB_EDGES_AFTER_PYRAMID = 512u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
   return k;
@@ -419,6 +421,11 @@ struct plv_ctx {
   plv::DevBuf d_Mt, d_S, d_W, d_y;          // EKF workspaces
   plv::DevBuf d_Pc, d_Ps, d_inv, d_T;       // dense covariance gathers, H'Ps
   plv::DevBuf d_fHf, d_fHx, d_fres, d_frows, d_chi2, d_acc;  // per-feature batches
+  // Set by the tracker feed around the image feed while the line prefetch is on: called between the histogram launch and the first
+  // pyramid launch with the raw image and its histogram (frontend_kernels.hip launch_equalize_pyramid) — the line detector's edge
+  // kernel goes there (line_api.hip plv_line_edges_early); edges_hook_fired: it did, the feed must not launch the detection again
+  void (*edges_hook)(plv_ctx *, const uint8_t *d_raw, int W, int H, const unsigned *d_hist) = nullptr;
+  bool edges_hook_fired = false;
   // plv_decision_trace: the values behind every verdict of the point update stay on the device until plv_last_point_decisions asks
   bool decision_trace = false;
   plv::DevBuf d_tri_dbg, d_gate_dec;

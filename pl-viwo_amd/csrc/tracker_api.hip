@@ -106,12 +106,26 @@ void plv_tracker_destroy(plv_ctx *ctx) {
 
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask);
 extern "C" int plv_feed_image_enqueue(plv_ctx *ctx, const uint8_t *img, int stride);  // frontend_api.hip
+extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);                               // line_api.hip
+extern "C" void plv_line_edges_early(plv_ctx *ctx, const uint8_t *d_raw, int W, int H, const unsigned *d_hist);
+// the image feed with the line detector's edge kernel between its histogram and its pyramid (plv_ctx::edges_hook) when the frame's
+// lines are detected ahead of the line tracker's feed anyway; PLV_LINE_EDGES_LATE / the edge knobs keep the older orders
+static int feed_with_early_edges(plv_ctx *ctx, const std::function<int()> &feed) {
+  static const bool late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
+  const bool early = !late && !plv::knob(plv::PLV_KNOB_EDGES_LATE | plv::PLV_KNOB_EDGES_SIDE | plv::PLV_KNOB_EDGES_AFTER_PYRAMID) && plv_line_prefetch_enabled(ctx) != 0;
+  ctx->edges_hook_fired = false;
+  ctx->edges_hook = early ? plv_line_edges_early : nullptr;
+  const int rc = feed();
+  ctx->edges_hook = nullptr;
+  return rc;
+}
 
 int plv_tracker_feed(plv_ctx *ctx, double timestamp, const uint8_t *img, int stride, const uint8_t *mask) {
   if (!ctx || !img) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);  // REF: mtx_feeds.at(cam_id), TrackKLT.cpp:54,100
-  TRY(plv_feed_image_enqueue(ctx, img, stride));  // :59 equalizeHist, :71 buildOpticalFlowPyramid (enqueued; the feed below waits for its flow)
+  // :59 equalizeHist, :71 buildOpticalFlowPyramid (enqueued; the feed below waits for its flow)
+  TRY(feed_with_early_edges(ctx, [&] { return plv_feed_image_enqueue(ctx, img, stride); }));
   return tracker_feed_fed(ctx, T, timestamp, mask);
 }
 
@@ -119,7 +133,7 @@ int plv_tracker_feed_staged(plv_ctx *ctx, double timestamp, int slot, const uint
   if (!ctx) return PLV_E_BADARG;
   Tracker *T = trk(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
-  TRY(plv_feed_staged(ctx, slot));  // the image is already in HBM (plv_image_stage)
+  TRY(feed_with_early_edges(ctx, [&] { return plv_feed_staged(ctx, slot); }));  // the image is already in HBM (plv_image_stage)
   return tracker_feed_fed(ctx, T, timestamp, mask);
 }
 
@@ -139,7 +153,6 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
 }
 
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
-extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);  // line_api.hip
 extern "C" int plv_line_edges_fork(plv_ctx *ctx);         // line_api.hip
 extern "C" void plv_line_defer_finish(plv_ctx *ctx, int on);
 extern "C" void plv_line_run_deferred(plv_ctx *ctx);
@@ -152,7 +165,8 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   // front-end; plv_line_tracker_feed of the same frame joins it.
   // (enqueued further down, behind the flow + RANSAC of this frame: the point front-end starts the moment the pyramid is built, and
   // the line worker, whose host stage has slack against the point update, gets its edge maps ~0.1 ms later)
-  bool prefetch_lines = plv_line_prefetch_enabled(ctx) != 0;
+  bool prefetch_lines = plv_line_prefetch_enabled(ctx) != 0 && !ctx->edges_hook_fired;  // (fired: the image feed launched it already)
+  ctx->edges_hook_fired = false;
   auto launch_prefetch = [&]() {
     if (prefetch_lines) (void)plv_line_detect_launch(ctx, PLV_PYR_CUR);
     prefetch_lines = false;

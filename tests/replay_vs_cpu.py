@@ -56,7 +56,11 @@ def main():
         op.est.cam.use_lines = lines
         t0 = time.time()
         dec = []
+        r0 = pkg.route_counts()
         stats, times, poses = rp.replay(op, decisions=dec, **kw)
+        if name == "hip":
+            res["hip_updates_by_route"] = dict(zip(("uncompressed", "gram_cholesky", "householder", "gram_then_householder", "whitened", "whitened_rejected_then_householder"),
+                                                   [a - b for a, b in zip(pkg.route_counts(), r0)][:6]))
         et, ep = pkg.traj_load(traj)[:2]
         gt_t, gt_p = pkg.traj_load(gt)[:2]
         ei, gi = pkg.traj_associate(et, gt_t)
