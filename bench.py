@@ -527,6 +527,9 @@ def main():
     if not sm.state.initialized or len(sm.state.clones) < wl["hz"] - 1:
         raise RuntimeError("the filter did not reach a full window during the prologue")
     seg = timed_segment(args.steps)                                   # (1) images resident in HBM -> `value`
+    if os.environ.get("PLV_BENCH_FINGERPRINT"):     # (determinism checks: the filter's state after the timed segment, to the last bit)
+        print("[fingerprint] p = %r  q = %r  trace(P) = %r  routes = %r" % (tuple(float(x) for x in sm.state.imu.p), tuple(float(x) for x in sm.state.imu.q),
+                                                                          float(np.trace(ctx.cov_download(sm.state.n))), pkg.route_counts()), file=sys.stderr)
     seg_pcie = None
     if not args.no_pcie:
         pl.staged = False

@@ -206,6 +206,7 @@ struct WhitenC1 {
   double *C1;        // C1[b * n + b']
   const double *Y0;  // factor form: the borders the factorisation solves for instead of Mt
   const int *use_m;  // device word: != 0 = this update takes the factor form (else these workgroups have nothing to do)
+  double lam_max;    // PLV_WHITEN_LAMBDA_MAX (a launch parameter so that tools can move it: PLV_WHITEN_LAMBDA_MAX in the environment)
   int first;         // < 0: none
 };
 
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
       for (int i = threadIdx.x; i < r; i += 64) m = fmax(m, S[(size_t)i * lds_ + i]);
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-      if (threadIdx.x == 0 && factor_form && m > PLV_WHITEN_LAMBDA_MAX) atomicOr(flag, 8);
+      if (threadIdx.x == 0 && factor_form && m > c1.lam_max) atomicOr(flag, 8);
       if (threadIdx.x == 0) ((double *)(c1.use_m + 2))[0] = m;  // (for the record: plv_whiten_stats)
     }
     if (!factor_form) return;
@@ -297,8 +298,9 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   const int strips = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
   const int nt_waves = r <= 32 ? 3 : r <= 64 ? 5 : r <= 112 ? 8 : r <= 128 ? 9 : r <= 160 ? 11 : 13;
   const int tn = cdiv(n, 16), c1_groups = wc ? cdiv(tn * (tn + 1) / 2, nt_waves) : 0, groups = strips + c1_groups;
-  const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, wc->Y0, wc->use_m, strips}
-                         : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, -1};
+  static const double lam_max = getenv("PLV_WHITEN_LAMBDA_MAX") ? atof(getenv("PLV_WHITEN_LAMBDA_MAX")) : PLV_WHITEN_LAMBDA_MAX;
+  const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, wc->Y0, wc->use_m, lam_max, strips}
+                         : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, -1};
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);
   if (r <= 32)
     hipLaunchKernelGGL(bchol_ekf_kernel<2>, dim3(groups), dim3(64 * 3), 0, ctx->stream, d_S, lds_, r, d_Mt, ldm, n, d_res, d_W,

@@ -92,7 +92,7 @@ int main() {
     float ms = 0.f;
     for (int it = 0; it < 4; ++it) {
       CK(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(plv::bchol_ekf_kernel<7>, dim3((n + 1 + 15) / 16), dim3(64 * 8), 0, 0, dG, nc, r, dMt, r, n, dres, dW, r, dflag, (const int *)nullptr, plv::WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, -1});
+      hipLaunchKernelGGL(plv::bchol_ekf_kernel<7>, dim3((n + 1 + 15) / 16), dim3(64 * 8), 0, 0, dG, nc, r, dMt, r, n, dres, dW, r, dflag, (const int *)nullptr, plv::WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, -1});
       CK(hipEventRecord(e1, 0));
       CK(hipDeviceSynchronize());
       CK(hipEventElapsedTime(&ms, e0, e1));
