@@ -60,8 +60,8 @@ struct CompressOps {
 // the clone taken of it (pivots of 1e-11); and the filter's unobservable directions (global position, yaw) make the absolute
 // variances grow without bound while a clone's variance given its neighbour stays small, so the smallest pivots sink with the
 // length of a drive (7e-8 after 10 s of the bench drive, 1e-9 after 25 s).
-#define PLV_PRIOR_AMB 1e-8
-#define PLV_WHITEN_LAMBDA_MAX 1e4
+#define PLV_PRIOR_AMB 1e-4
+#define PLV_WHITEN_LAMBDA_MAX 1e2
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
 template <int NT>
 __global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
@@ -131,7 +131,7 @@ struct PriorOps {
   __device__ __forceinline__ double border_fix(int b, int c, double g) const { return (b < n && c < k) ? g * sc[min(c, k - 1)] : 0.0; }
   __device__ __forceinline__ void store_sym(int i, int c, double l) const {
     if (store_l && i < k && c <= i) {
-      if (c == i && n_near && l * l < PLV_PRIOR_AMB) atomicAdd(n_near, 1);  // (a dead pivot — l = 0, below PLV_PRIOR_TAU — counts: round 4 met whitened-form updates with one that came back with dC ten times P)
+      if (c == i && n_near && l * l < PLV_PRIOR_AMB) atomicAdd(n_near + (l == 0.0 ? 1 : 0), 1);  // [0] near, [1] dead  // (a dead pivot — l = 0, below PLV_PRIOR_TAU — counts: round 4 met whitened-form updates with one that came back with dC ten times P)
       Lt[(size_t)i * ldl + c] = l * sc[192 + i];
       if (c < i) Lt[(size_t)c * ldl + i] = 0.0;
     }
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_prior_kernel(const double
   const int jd = cols[min((int)threadIdx.x, k - 1)];
   PriorOps ops{P, ldp, n, cols, k, sc, Lt, ldl, W0, ldw, P[(size_t)jd * ldp + jd], sc, blockIdx.x == 0, blockIdx.x == 0 ? n_near : nullptr};
   if (threadIdx.x == 0) {
-    if (n_near && blockIdx.x == 0) *n_near = 0;
+    if (n_near && blockIdx.x == 0) n_near[0] = n_near[1] = 0;
     lds.bad = 0;
     lds.step_flag = 0;
     lds.rs_flag = 0;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
                                                          int *__restrict__ flag, const int *__restrict__ skip, WhitenC1 c1) {
   __shared__ BcLds lds;
   if (skip && *skip == 0) return;
-  const bool factor_form = c1.first >= 0 && *c1.use_m != 0;
+  const bool factor_form = c1.first >= 0 && (c1.use_m[0] | c1.use_m[1]) != 0;  // (near or dead pivots in the prior factor)
   if (c1.first >= 0 && (int)blockIdx.x >= c1.first) {
     __shared__ int scols[192];
     if ((int)blockIdx.x == c1.first && threadIdx.x < 64) {

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) ekf_dc_kernel(const double *__restrict__ 
   //                                                      dx = P = null: products only)
   //   factor form    dC = C1 - W^T W, dx = d0 - W^T y    C1 = P[:, cols] G P[cols, :], d0 = P[:, cols] g (same tiles, same layout)
   if (skip && *skip == 0) return;
-  const bool fm = use_m && *use_m != 0;
+  const bool fm = use_m && (use_m[0] | use_m[1]) != 0;
   if (fm) dW = C1;
   const int tn = (n + 1 + 15) >> 4;
   const int ntri = tn * (tn + 1) / 2;
@@ -411,6 +411,11 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     return rc;
   double *Y0 = ctx->d_Y0.as<double>(), *C1 = ctx->d_C1.as<double>(), *d0 = C1 + (size_t)n * n, *GP = ctx->d_GP.as<double>();
   const int *use_m = ctx->d_prior_near.as<int>();  // (written by the prior factor; the caller has joined the side stream)
+  static const bool force_factor = getenv("PLV_FORCE_FACTOR_FORM") != nullptr;  // (tools / tests: every update takes the factor form)
+  if (force_factor) {
+    static const int one[2] = {1, 0};
+    PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_prior_near.p, one, 8, hipMemcpyHostToDevice, ctx->stream));
+  }
   launch_whiten_b(ctx, ctx->d_Lt.as<double>(), k, Gs, gv, cv, B, d_flag, d_P, ldp, n, d_cols, Y0, GP, d0, use_m);
   const WhitenC1Args wc{d_P, ldp, d_cols, GP, C1, Y0, use_m};
   if ((rc = launch_bchol_ekf(ctx, B, k, k, ctx->d_W0.as<double>(), k, n, cv, V, k, d_flag, &wc))) return rc;
@@ -421,10 +426,20 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
                        ctx->d_dW.as<double>(), C1, d0, use_m);
   }
   if (getenv("PLV_LAMBDA_DEBUG")) {
-    struct { int near, pad; double lam; } h;
+    struct { int near, dead; double lam; } h;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemcpy(&h, use_m, 16, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[plv lambda] k %d near %d largest diagonal of B %.4g\n", k, h.near, h.lam);
+    fprintf(stderr, "[plv lambda] k %d near %d dead %d largest diagonal of B %.4g\n", k, h.near, h.dead, h.lam);
+    if (h.dead > 6 && getenv("PLV_PIVOT_DEBUG")) {
+      std::vector<double> Lt((size_t)k * k), Pd((size_t)n * n);
+      std::vector<int> hc(k);
+      (void)hipMemcpy(Lt.data(), ctx->d_Lt.p, Lt.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(Pd.data(), d_P, Pd.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hc.data(), d_cols, k * 4, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[plv pivots] (column: state, pivot of the unit-diagonal factor)");
+      for (int i = 0; i < k; ++i) fprintf(stderr, " %d:%d,%.2e", i, hc[i], Lt[(size_t)i * k + i] * Lt[(size_t)i * k + i] / Pd[(size_t)hc[i] * n + hc[i]]);
+      fprintf(stderr, "\n");
+    }
     int fl = 0;
     (void)hipMemcpy(&fl, d_flag, 4, hipMemcpyDeviceToHost);
     if (fl) {

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(512) ekf_ms_kernel(const double *__restrict__ 
   const int kt = (k + 15) >> 4, tr_n = (r + 15) >> 4;
   if (wp.first >= 0 && (int)blockIdx.x >= wp.first) {
     __shared__ int scols[192];
-    if (*wp.use_m == 0) return;
+    if ((wp.use_m[0] | wp.use_m[1]) == 0) return;
     const int b0 = ((int)blockIdx.x - wp.first) * 16, bl = min(b0 + li, wp.n - 1);
     if (threadIdx.x < 192) scols[threadIdx.x] = wp.cols[min((int)threadIdx.x, k - 1)];
     __syncthreads();

@@ -568,6 +568,7 @@ class SystemManager:
             st.est_A.reset(), st.est_a.reset()
             st.flush_old_data()
             st.refresh_window()       # window maintenance belongs to the cloning step, not to the next camera frame
+            self._cov_probe("after propagation to the clone time, cloning and marginalisation")
             self.stats["clones"] += 1
             ct = sorted(st.clones)
             if len(ct) > 1:
@@ -770,6 +771,11 @@ class SystemManager:
             self._count_lines(lo)
             self.tc.dong("[Time-Cam] LINE update")
 
+    def _cov_probe(self, label):
+        d = self.decisions
+        if d is not None and getattr(d, "probe_cov", None) is not None and d.probe_cov[0] <= self.stats["frames"] <= d.probe_cov[1] and hasattr(self.ctx, "cov_download"):
+            d.cov_probes.append((label, self.stats["frames"], self.state.time, self.ctx.cov_download(self.state.n)))
+
     def _state_probe(self):
         st = self.state
         x = [np.asarray(st.imu.q, float), np.asarray(st.imu.p, float), np.asarray(st.imu.v, float), np.asarray(st.imu.bg, float), np.asarray(st.imu.ba, float)]
@@ -790,6 +796,7 @@ class SystemManager:
             self.stats["not_psd"] += 1
         elif out["n_accepted"] > 0:
             self.stats["cam_updates"] += 1
+        self._cov_probe("after the point update")
         self.stats["cam_features"] += out["n_msckf"]
         self.stats["cam_accepted"] += out["n_accepted"] if out["status"] == 0 else 0
 
@@ -797,6 +804,7 @@ class SystemManager:
         if self.decisions is not None:
             self.decisions.append(("lines", self.stats["frames"], self.state.time, int(lo["n_pool"]), np.array(lo["ids"], dtype=np.uint64),
                                    np.array(lo["accepted"], dtype=np.uint8), int(lo["status"]), None, np.array(lo["dx"], dtype=float)))
+        self._cov_probe("after the line update")
         self.stats["line_pool"] += lo["n_pool"]
         self.stats["lines_triangulated"] += lo["n_lines"]
         if lo["status"] != 0:
@@ -920,6 +928,7 @@ class SystemManager:
         if self.decisions is not None:
             self.decisions.append(("wheel", self.stats["frames"], st.time, 1, np.zeros(1, dtype=np.uint64), np.array([1 if (rc == 0 and acc) else 0], dtype=np.uint8),
                                    int(rc), None, np.array(dx, dtype=float)))
+        self._cov_probe("after a wheel update")
         self.stats["wheel_updates"] += 1
         if rc != 0:
             self.stats["not_psd"] += 1

