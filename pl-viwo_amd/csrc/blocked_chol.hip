@@ -54,12 +54,13 @@ struct CompressOps {
 // pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
 // the smallest live one 1.5e-7; DESIGN.md "Whitened update")
 #define PLV_PRIOR_TAU 2e-13
-// Pivots of the unit-diagonal prior block between PLV_PRIOR_TAU and this are NEAR dependencies: the whitened form of the update
-// divides by them and loses eps / pivot.  The factor counts them (n_near) and with one or more the update takes its factor form
-// (dense_kernels.hip "whitened update").  Time stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind
-// the clone taken of it (pivots of 1e-11); and the filter's unobservable directions (global position, yaw) make the absolute
-// variances grow without bound while a clone's variance given its neighbour stays small, so the smallest pivots sink with the
-// length of a drive (7e-8 after 10 s of the bench drive, 1e-9 after 25 s).
+// Pivots of the unit-diagonal prior block below this are NEAR dependencies: the whitened form of the update divides by them and
+// loses eps / pivot^2 of what they stand for (the conditional variance of the state given the ones before it).  The factor counts
+// them (n_near[0]; n_near[1]: the dead ones, below PLV_PRIOR_TAU) and with one or more the update takes its factor form
+// (dense_kernels.hip "whitened update").  Clone positions reach 1e-8 within seconds of a drive — the global position's variance
+// grows without bound while a clone's position given its neighbour stays at tenths of a millimetre — orientations 1e-4; time
+// stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind the clone taken of it (1e-11).
+// PLV_WHITEN_LAMBDA_MAX: the factor form's own limit (B's largest diagonal entry beyond which it hands the update to Householder).
 #define PLV_PRIOR_AMB 1e-4
 #define PLV_WHITEN_LAMBDA_MAX 1e2
 #define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)

@@ -355,20 +355,26 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 //   factor form     P' = P - C1 + Z^T Z,       dx = d0 - Z^T z   GP = G Pc, C1 = Pc^T GP, d0 = Pc^T g, [Z | z] = Lb^-1 M^T [GP | g]
 //                   (H^T S^-1 H = (I + G Ps)^-1 G = G - G M B^-1 M^T G)
 // Neither divides by a pivot of G: directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian) simply add
-// nothing to B.  They differ in what costs digits (round 4, measured against the Householder route on the configs[3] drive):
-//   * the whitened form builds the posterior of a well-measured direction as a sum of squares (P - W0^T W0 vanishes on the clone
-//     block) and is at least as accurate there as the reference's P - K H P; but W0 divides by the pivots of the prior's unit-
-//     diagonal factor and loses eps / pivot — clones that are almost functions of one another: 1e-9 late in the bench drive (the
-//     unobservable global position and yaw let the absolute variances grow without bound), 1e-11 with stamps of 1.5e9 s;
-//   * the factor form only multiplies by M (backward stable: M M^T is Ps to rounding) and is indifferent to those pivots, but C1 and
-//     Z^T Z both grow with lambda = how much better than the prior the measurements know a direction, and the posterior there is
-//     their difference: eps x lambda^2 of it is lost (lambda 1e4 .. 1e5 in the first updates after an initialisation with the
-//     intrinsics in the state: dx of the NEXT update off by 2e-5 of its largest entry).
-// The prior factor decides on the device: no pivot below PLV_PRIOR_AMB -> whitened form; else factor form, and if B's diagonal then
-// exceeds PLV_WHITEN_LAMBDA_MAX the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  The prior
-// factor, W0 and W0^T W0 only need the covariance, so they run on a side stream while the main stream triangulates, builds Jacobians
-// and gates; the main chain after the gate is  gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches;
-// "|": workgroups of the same launch, those of the factor form return at once when the update takes the whitened one).
+// nothing to B.  They differ in what costs digits.  The quantity at stake is the CONDITIONAL variance of a state given the ones
+// before it — pivot x its variance, the pivot being that of the prior block's unit-diagonal factor: clone positions of this filter
+// sit at 1e-8 (known to 1e-4 of the global position's uncertainty, which grows without bound), orientations at 1e-4.  Relative to
+// it an update loses (round 4, measured against the Householder route and the CPU oracle on the configs[2] / [3] drives):
+//   * whitened form   eps / pivot^2   (W0 divides by the factor's pivots).  Harmless at the start of a drive (pivots 1e-2 .. 1, and
+//     there it is the more accurate of the two: the posterior of a well-measured direction is a sum of squares); at pivots of 1e-8
+//     it is of order one per update: after 24 s of the configs[2] drive the position pivots had gone from +1e-8 to -1e-6, and the
+//     next update left the covariance indefinite at -0.19 of a unit diagonal;
+//   * factor form     eps x lambda / pivot, and eps x lambda^2 of the posterior variance itself, lambda = how much better than the
+//     prior the measurements know a direction (B's diagonal - 1).  Only multiplies by M (backward stable: M M^T is Ps to rounding).
+//     lambda is ~1 in the steady state, 1e4 .. 1e5 in the first updates after an initialisation with the intrinsics in the state
+//     (there: dx of the NEXT update off by 2e-5);
+//   * the reference's P - K H P: eps / pivot.
+// The prior factor decides on the device: no pivot below PLV_PRIOR_AMB (1e-4) -> whitened form; else factor form, and if B's diagonal
+// then exceeds PLV_WHITEN_LAMBDA_MAX (1e2) the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  With
+// these limits the covariance's pivots follow the CPU oracle's to two or three digits over a 34 s drive and every gate decision of
+// the three recorded drives is the oracle's (profiles/r04/replay_vs_cpu_*.json).  The prior factor, W0 and W0^T W0 only need the
+// covariance, so they run on a side stream while the main stream triangulates, builds Jacobians and gates; the main chain after
+// the gate is  gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches; "|": workgroups of the same
+// launch, those of the factor form return at once when the update takes the whitened one).
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k) {
   int rc;
   if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
