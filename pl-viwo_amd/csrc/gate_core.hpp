@@ -205,7 +205,10 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, const 
     if (!pass && g.stack_accepted_only) return;
     const double *Hp = X + (size_t)shift * ncol + fdim;
     double *dst = g.stack + (size_t)f * g.mp_max;
-    for (int i = threadIdx.x & 31; i < g.mp_max; i += 32)      // (32 rows x 8 columns per pass: no integer division per element)
+    // (the consumer of an accepted-only stack walks acc_rows rows of every entry — gram_direct_kernel — and the Householder route zeroes
+    // the rest of a slot itself, stack_zero_rejected_kernel: the padding rows of an entry are not written — 40 % of the launch's writes)
+    const int rows_w = g.stack_accepted_only ? mp : g.mp_max;
+    for (int i = threadIdx.x & 31; i < rows_w; i += 32)      // (32 rows x 8 columns per pass: no integer division per element)
       for (int j = threadIdx.x >> 5; j <= k; j += 8) {
         double v = 0.0;
         if (pass && i < mp) v = Hp[(size_t)i * ncol + j];  // (column k of the block is r)

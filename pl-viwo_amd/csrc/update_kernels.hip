@@ -259,8 +259,9 @@ __global__ void __launch_bounds__(64 * (NT + 1 > 4 ? NT + 1 : 4)) chi2_gate_kern
     const bool pass = passflag != 0.0;
     if (!pass && a.stack_accepted_only) return;  // (1.2 MB of zeros per update that nothing reads: rocprofv3 WRITE_SIZE, profiles/r03)
     double *dst = a.stack + (size_t)f * a.mp_max;
-    for (int idx = threadIdx.x; idx < a.mp_max * (k + 1); idx += blockDim.x) {
-      int j = idx / a.mp_max, i = idx - j * a.mp_max;
+    const int rows_w = a.stack_accepted_only ? mp : a.mp_max;  // (padding rows of an accepted-only stack are never read: gate_core.hpp)
+    for (int idx = threadIdx.x; idx < rows_w * (k + 1); idx += blockDim.x) {
+      int j = idx / rows_w, i = idx - j * rows_w;
       double v = 0.0;
       if (pass && i < mp) v = j < k ? H[j * ld + i] : r[i];
       dst[(size_t)j * a.lds + i] = v;
