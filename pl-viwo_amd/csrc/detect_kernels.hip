@@ -107,33 +107,84 @@ __global__ void __launch_bounds__(256) fast_tiles_kernel(DetectParams P, int til
 // keys above its own: that is its position in the sorted order, the first nfg write their slot.  Then the bounds / mask /
 // occupied-box tests of Grider_GRID.h:141-147 and TrackKLT.cpp:455-461 per kept corner.
 __global__ void __launch_bounds__(256) fast_topk_kernel(DetectParams P, const unsigned long long *__restrict__ cand, int *__restrict__ cand_n) {
+  // Round 4: the rank of a key is only wanted when it is below nfg (REF Grider_GRID.h:125-128 keeps the first num_features_grid of the
+  // sorted cell), and a key's rank is the number of LARGER keys — so only keys at or above the score of the nfg-th best can have one,
+  // and only such keys count towards it.  A 256-bin histogram of the scores (a FAST score is at most 255) gives that cut-off score; the
+  // rank count then runs over the survivors alone: ~nfg + ties keys instead of the cell's ~2000 local maxima.  Same ranks, same
+  // output slots; a cell whose maxima all share one score costs what it used to.
   extern __shared__ unsigned long long keys[];
-  const int cell = blockIdx.x, t = threadIdx.x;
+  __shared__ int hist[256], wtot[4], wcut[4], n_sel;
+  const int cell = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nc = min(cand_n[cell], P.cand_cap);
+  int *sel = (int *)(keys + P.cand_cap);  // indices of the survivors
   const int cw = P.cell_w, chh = P.cell_h;
   const int x0 = P.cells[2 * cell] * cw, y0 = P.cells[2 * cell + 1] * chh;
-  for (int i = t; i < nc; i += 256) keys[i] = cand[(size_t)cell * P.cand_cap + i];
+  hist[t] = 0;
+  if (t == 0) n_sel = 0;
   for (int r = nc + t; r < P.nfg; r += 256) P.out_valid[cell * P.nfg + r] = 0;
   __syncthreads();
-  if (t == 0) cand_n[cell] = 0;  // ready for the next frame (stream order: stage 1 of the next detection comes after this kernel)
   for (int i = t; i < nc; i += 256) {
-    const unsigned long long k = keys[i];
+    const unsigned long long k = cand[(size_t)cell * P.cand_cap + i];
+    keys[i] = k;
+    atomicAdd(&hist[min((int)(k >> 32), 255)], 1);
+  }
+  __syncthreads();
+  if (t == 0) cand_n[cell] = 0;  // ready for the next frame (stream order: stage 1 of the next detection comes after this kernel)
+  // suffix counts S[t] = keys with score >= t (scores above 255 sit in bin 255), then the largest t with S[t] >= nfg
+  int v = hist[t];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_down(v, off);
+    if (lane + off < 64) v += u;
+  }
+  if (lane == 0) wtot[wave] = v;
+  __syncthreads();
+  for (int w = wave + 1; w < 4; ++w) v += wtot[w];
+  const unsigned long long ok_mask = __ballot(v >= P.nfg);
+  if (lane == 0) wcut[wave] = ok_mask ? 64 * wave + 63 - __clzll((long long)ok_mask) : -1;
+  __syncthreads();
+  const int cut = max(max(wcut[0], wcut[1]), max(wcut[2], wcut[3]));  // -1: fewer than nfg keys in the cell, all of them rank
+  for (int i = t; i < nc; i += 256)
+    if (min((int)(keys[i] >> 32), 255) >= cut) sel[atomicAdd(&n_sel, 1)] = i;
+  __syncthreads();
+  const int M = n_sel;
+  // ranks of the survivors; the keys that get an output slot (rank < nfg) are collected
+  __shared__ unsigned long long wkey[256];
+  __shared__ int wrank[256], n_win;
+  if (t == 0) n_win = 0;
+  __syncthreads();
+  for (int q = t; q < M; q += 256) {
+    const unsigned long long k = keys[sel[q]];
     int rank = 0;
-    for (int j = 0; j < nc; ++j) rank += keys[j] > k;
+    for (int j = 0; j < M; ++j) rank += keys[sel[j]] > k;
     if (rank >= P.nfg) continue;
+    const int w = atomicAdd(&n_win, 1);  // (< nfg <= 256: launch_fast_cells checks)
+    wkey[w] = k, wrank[w] = rank;
+  }
+  __syncthreads();
+  // REF TrackKLT.cpp:486-520: a detection inside the mask or within min_px_dist of an existing point is dropped — the test against the
+  // existing points by the whole workgroup per winner (it used to be one thread walking all of them per winner: 500 dependent loads at
+  // configs[3], the launch's slowest thread and most of its 90 us)
+  const int nw = n_win;
+  for (int w = 0; w < nw; ++w) {
+    const unsigned long long k = wkey[w];
     const int idx = 0x7fffffff - (int)(k & 0xffffffffULL);
     const int y = idx / cw, x = idx - y * cw;
     const float gx = (float)x + (float)x0, gy = (float)y + (float)y0;
     bool ok = !((int)gx < 0 || (int)gx > P.W || (int)gy < 0 || (int)gy > P.H);
     const int ix = (int)gx, iy = (int)gy;
     if (ok && P.mask && P.mask[(size_t)iy * P.W + ix] > 127) ok = false;
-    for (int q = 0; ok && q < P.n_boxes; ++q)
-      if (abs(ix - P.boxes[2 * q]) <= P.min_px_dist && abs(iy - P.boxes[2 * q + 1]) <= P.min_px_dist) ok = false;
-    const int slot = cell * P.nfg + rank;
-    P.out_xy[2 * slot] = gx;
-    P.out_xy[2 * slot + 1] = gy;
-    P.out_resp[slot] = (float)(unsigned)(k >> 32);
-    P.out_valid[slot] = ok ? 1 : 0;
+    int near = 0;
+    if (ok)  // (uniform)
+      for (int b = t; b < P.n_boxes; b += 256) near |= (abs(ix - P.boxes[2 * b]) <= P.min_px_dist && abs(iy - P.boxes[2 * b + 1]) <= P.min_px_dist) ? 1 : 0;
+    near = __syncthreads_or(near);
+    if (t == 0) {
+      const int slot = cell * P.nfg + wrank[w];
+      P.out_xy[2 * slot] = gx;
+      P.out_xy[2 * slot + 1] = gy;
+      P.out_resp[slot] = (float)(unsigned)(k >> 32);
+      P.out_valid[slot] = (ok && !near) ? 1 : 0;
+    }
   }
 }
 
@@ -215,7 +266,7 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
 }
 
 int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned long long *d_cand, int *d_cand_n) {
-  if (P.cell_w * P.cell_h > 0x7fffffff / 2 || (size_t)P.cand_cap * 8 > 64 * 1024) {
+  if (P.cell_w * P.cell_h > 0x7fffffff / 2 || (size_t)P.cand_cap * 12 > 60 * 1024 || P.nfg > 256) {
     set_last_error("FAST: cell %dx%d / candidate capacity %d out of range", P.cell_w, P.cell_h, P.cand_cap);
     return PLV_E_CAPACITY;
   }
@@ -226,7 +277,7 @@ int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned
   }
   {
     ProfScope ps(ctx->prof, "fast_topk_kernel", ctx->stream);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3(n_cells), dim3(256), (size_t)P.cand_cap * 8, ctx->stream, P, d_cand, d_cand_n);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3(n_cells), dim3(256), (size_t)P.cand_cap * 12, ctx->stream, P, d_cand, d_cand_n);  // keys + survivor indices
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
