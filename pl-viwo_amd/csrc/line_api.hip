@@ -85,7 +85,7 @@ struct LinesJob {
   LinePool LP;
   int Lp = 0, nobs = 0, most_valid = 0, k = 0, cap = 0, n_clones = 0;
   double state_time = 0, t_prev_frame = 0;
-  std::vector<int> ptr, D, valid_n, cols;
+  std::vector<int> ptr, D, valid_n, cols, pt_ptr, pt_ids;
   std::vector<double> anchor, ot;
   std::vector<float> uv, uvn;
   std::vector<uint8_t> has, flags;
@@ -835,6 +835,7 @@ void plv_line_defer_finish(plv_ctx *ctx, int on) { ltr(ctx, false)->defer_finish
 void plv_line_run_deferred(plv_ctx *ctx) { (void)ltr(ctx); }
 
 extern "C" int plv_point_chain_lookup(plv_ctx *ctx, uint64_t id);  // tracker_api.hip: index of a feature in the running point update's pool, or -1
+extern "C" void plv_point_anchor_fill(plv_ctx *ctx, int Lp, const int *pt_ptr, const int *pt_ids, int chained, double *anchor, uint8_t *has);  // tracker_api.hip
 extern "C" int plv_camera_get_line_features(plv_ctx *ctx, const plv_state_view *st);
 static void line_give_back(std::unordered_map<uint64_t, LineTrack> &unused, const LineCand &c, size_t i) {
   LineTrack &u = unused[c.id];
@@ -1100,31 +1101,18 @@ static int lines_first_half(plv_ctx *ctx, LineTracker *T, const plv_state_view *
   J.ptr.assign(Lp + 1, 0), J.D.resize(Lp), J.anchor.assign(3 * (size_t)Lp, 0.0), J.has.assign(Lp, 0);
   std::vector<int> &ptr = J.ptr, &D = J.D;
   plv_ctx::ChainState &ch = ctx->chain;
-  if (chained) ch.anc_ptr.assign(1, 0), ch.anc_f.clear(), ch.anc_has_old.clear(), ch.anc_old.clear();
-  for (int l = 0; l < Lp; ++l) {
-    ptr[l + 1] = ptr[l] + (int)pool[l].tr.t.size();
-    D[l] = pool[l].tr.D;
-    if (chained) {
-      // the anchor is decided by the launch itself: the point update whose triangulation may (re)write point_used is still running.
-      // Per point of the line, in order: its index in that update's pool (plv_point_chain_lookup) and what point_used holds now.
-      for (int pid : pool[l].tr.points) {
-        double old[3] = {0, 0, 0};
-        const int pf = plv_point_chain_lookup(ctx, (uint64_t)pid);
-        const int has_old = plv_point_used_lookup(ctx, (uint64_t)pid, old);
-        if (pf < 0 && !has_old) continue;
-        ch.anc_f.push_back(pf);
-        ch.anc_has_old.push_back(has_old ? 1 : 0);
-        ch.anc_old.insert(ch.anc_old.end(), old, old + 3);
-        if (has_old) break;  // (point_used holds this point whatever the update does to it: the search ends here either way)
-      }
-      ch.anc_ptr.push_back((int)ch.anc_f.size());
-      continue;
+  {
+    std::vector<int> &pp = J.pt_ptr, &pi = J.pt_ids;
+    pp.assign(1, 0), pi.clear();
+    for (int l = 0; l < Lp; ++l) {
+      ptr[l + 1] = ptr[l] + (int)pool[l].tr.t.size();
+      D[l] = pool[l].tr.D;
+      pi.insert(pi.end(), pool[l].tr.points.begin(), pool[l].tr.points.end());
+      pp.push_back((int)pi.size());
     }
-    for (int pid : pool[l].tr.points)  // first triangulated point of the line (REF :233-247)
-      if (plv_point_used_lookup(ctx, (uint64_t)pid, &J.anchor[3 * (size_t)l])) {
-        J.has[l] = 1;
-        break;
-      }
+    // first triangulated point of every line (REF :233-247) — chained: the candidates, the launch decides (the point update whose
+    // triangulation may (re)write point_used is still running)
+    plv_point_anchor_fill(ctx, Lp, pp.data(), pi.data(), chained ? 1 : 0, J.anchor.data(), J.has.data());
   }
   const int nobs = J.nobs = ptr[Lp];
   if (nobs == 0) {

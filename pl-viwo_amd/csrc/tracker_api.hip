@@ -957,6 +957,40 @@ int plv_point_used_lookup(plv_ctx *ctx, uint64_t id, double *p) {
   std::copy(it->second.p, it->second.p + 3, p);
   return 1;
 }
+// The anchors of a pool of lines in one pass under one lock (the line update's first half looked every point of every line up through
+// two locked calls: 12-19 us of the chained first half at configs[2]).  pt_ptr / pt_ids: the lines' related points (CSR, in the
+// order LineHelper.cpp:233-247 walks them).  chained: the candidates for the launch to decide from (plv_ctx::chain: per point its
+// index in the running point update's pool and what point_used holds now; the walk of a line ends at the first point point_used
+// holds); else the first point point_used holds (anchor [Lp][3], has [Lp]).
+void plv_point_anchor_fill(plv_ctx *ctx, int Lp, const int *pt_ptr, const int *pt_ids, int chained, double *anchor, uint8_t *has) {
+  Tracker *T = trk(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  plv_ctx::ChainState &ch = ctx->chain;
+  if (chained) ch.anc_ptr.assign(1, 0), ch.anc_f.clear(), ch.anc_has_old.clear(), ch.anc_old.clear();
+  for (int l = 0; l < Lp; ++l) {
+    for (int q = pt_ptr[l]; q < pt_ptr[l + 1]; ++q) {
+      const uint64_t id = (uint64_t)pt_ids[q];
+      const auto it = T->used.find(id);
+      const bool has_old = it != T->used.end();
+      if (!chained) {
+        if (!has_old) continue;
+        std::copy(it->second.p, it->second.p + 3, anchor + 3 * (size_t)l);
+        has[l] = 1;
+        break;
+      }
+      const auto ci = T->chain_index.find(id);
+      const int pf = ci == T->chain_index.end() ? -1 : ci->second;
+      if (pf < 0 && !has_old) continue;
+      static const double zero[3] = {0, 0, 0};
+      const double *old = has_old ? it->second.p : zero;
+      ch.anc_f.push_back(pf);
+      ch.anc_has_old.push_back(has_old ? 1 : 0);
+      ch.anc_old.insert(ch.anc_old.end(), old, old + 3);
+      if (has_old) break;  // (point_used holds this point whatever the update does to it: the search ends here either way)
+    }
+    if (chained) ch.anc_ptr.push_back((int)ch.anc_f.size());
+  }
+}
 // point_used->cleanup_measurements(oldest_clone_time)   REF: UpdaterCamera.cpp:186-188
 void plv_point_used_cleanup(plv_ctx *ctx, double t_oldest) {
   Tracker *T = trk(ctx);
