@@ -306,10 +306,14 @@ int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *co
   };
   // REF: CamHelper.cpp:74-95 calibration blocks first, then :98-110 interpolation poses in first-seen order
   if (!push(st->extrinsic_state_id, 6) || !push(st->intrinsic_state_id, 8) || !push(st->dt_state_id, 1)) return PLV_E_CAPACITY;
+  // (a window start that has been seen adds nothing: 700 observations meet ~14 distinct windows, and the search through the
+  // column list per pose was 29 us of the caller's thread in front of the point launch at configs[2])
+  std::vector<uint8_t> seen_s0((size_t)std::max(st->n_clones, 1), 0);
   for (int f = 0; f < tr->n_feat; ++f)
     for (int o = tr->obs_ptr[f]; o < tr->obs_ptr[f + 1]; ++o) {
       const int s0 = bounding_start_host(*st, tr->obs_time[o] + st->cam_dt);
-      if (s0 < 0) continue;
+      if (s0 < 0 || seen_s0[s0]) continue;
+      seen_s0[s0] = 1;
       for (int w = 0; w < 4; ++w)
         if (!push(st->clone_state_id[s0 + w], 6)) return PLV_E_CAPACITY;
     }
@@ -816,10 +820,12 @@ int plv_line_jacobian_columns(const plv_state_view *st, const plv_line_tracks *l
     return true;
   };
   // REF: LineHelper.cpp:757-788 — `order` of get_interpolated_jacobian: four poses, then the time offset
+  std::vector<uint8_t> seen_s0((size_t)std::max(st->n_clones, 1), 0);  // (see plv_jacobian_columns)
   for (int l = 0; l < lt->n_lines; ++l)
     for (int o = lt->obs_ptr[l]; o < lt->obs_ptr[l + 1]; ++o) {
       const int s0 = bounding_start_host(*st, lt->obs_time[o] + st->cam_dt);
-      if (s0 < 0) continue;
+      if (s0 < 0 || seen_s0[s0]) continue;
+      seen_s0[s0] = 1;
       for (int w = 0; w < 4; ++w)
         if (!push(st->clone_state_id[s0 + w], 6)) return PLV_E_CAPACITY;
       if (!push(st->dt_state_id, 1)) return PLV_E_CAPACITY;

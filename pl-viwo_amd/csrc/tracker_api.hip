@@ -710,6 +710,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   const bool fused = !opt->cpi && opt->max_slam == 0 && most_valid <= opt->max_obs;
   ph_pool.stop();
   rx_get.stop();
+  plv::frame_mark("@ update_points: pool + staging done");
   plv::RoctxRange rx_upd("[Time-Cam] MSCKF update");
   plv::HostPhase ph_dev("update_points: device submission + wait");
   std::vector<uint8_t> acc_all(Fp, 0);
@@ -728,6 +729,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
         if (T->chain_ok && T->early_lines)
           for (int f = 0; f < Fp; ++f)
             if (flags[f]) T->chain_index.emplace(pool[f].id, f);
+        plv::frame_mark("@ update_points: columns done, fused call");
         rc = plv_points_update_fused(ctx, st, &all, &opt->tri, flags.data(), opt->max_msckf, k, cols.data(), 2 * opt->max_obs,
                                      st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, pf.data(), ok.data(), err.data(), acc_all.data(),
                                      &n_rows, dx, start_detection_ahead, ctx);
@@ -1066,6 +1068,7 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
     }
     ch.ready = okc;
   }
+  plv::frame_mark("@ try_update: chain state ready");
   ctx->wait_poll = io->opt_lines ? poll_line_pool : nullptr;
   ctx->wait_poll_arg = ctx;
   int rc = plv_camera_update_points(ctx, st, io->opt_points, io->dx_points, io->res_points, io->msckf_ids, io->msckf_accepted, io->p_FinG);
