@@ -418,7 +418,7 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
   double *Y0 = ctx->d_Y0.as<double>(), *C1 = ctx->d_C1.as<double>(), *d0 = C1 + (size_t)n * n, *GP = ctx->d_GP.as<double>();
   const int *use_m = ctx->d_prior_near.as<int>();  // (written by the prior factor; the caller has joined the side stream)
   static const bool force_factor = getenv("PLV_FORCE_FACTOR_FORM") != nullptr;  // (tools / tests: every update takes the factor form)
-  if (force_factor) {
+  if (force_factor || plv::knob(plv::PLV_KNOB_FORCE_FACTOR_FORM)) {
     static const int one[2] = {1, 0};
     PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_prior_near.p, one, 8, hipMemcpyHostToDevice, ctx->stream));
   }

@@ -77,10 +77,12 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 //  512 the prefetched edge kernel behind the pyramid (rounds 2-3) instead of between the histogram and the pyramid (round 4: it equalises
 //      the raw image itself, canny_kernel; the maps reach the line worker two launches earlier)
 // 2048 no chained line launch: the line half is staged and enqueued after the host has collected and applied the point update (round 3)
+// 8192 every whitened update takes its factor form (dense_kernels.hip "whitened update"; tests: the form the prior factor would pick
+//      only late in a drive runs on every batch)
 // 4096 the point update's wait keeps polling its hook until the hook is done even when the device has finished (tests: every frame's
 //      line launch is chained, whatever the timing of the line worker)
 enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
-                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u, PLV_KNOB_EDGES_AFTER_PYRAMID = 512u };
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u, PLV_KNOB_EDGES_AFTER_PYRAMID = 512u, PLV_KNOB_FORCE_FACTOR_FORM = 8192u };
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{0};
   return k;

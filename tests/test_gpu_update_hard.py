@@ -74,6 +74,28 @@ def test_replay_captured_batches(ctx, mode):
         ctx.update_compression_mode(0)
 
 
+def test_replay_captured_batches_in_the_factor_form(ctx, pkg):
+    """The whitened update's other form — what the prior factor picks once it meets a pivot below 1e-4, i.e. late in a drive
+    (dense_kernels.hip "whitened update") — forced onto every captured batch (plv_debug_knobs 8192): same verdicts, dx and P' to the
+    tolerances of the whitened form where the measurements are not far better than the prior; an update it hands to the Householder
+    route (B's diagonal above 100: route 5) agrees like that route."""
+    prev = pkg.debug_knobs(8192)
+    ctx.update_compression_mode(0)
+    try:
+        routes = []
+        for j, b in _batches():
+            rc, P1, dx1, acc, nr = ctx.msckf_update(b["P"], b["rows"], b["Hf"], b["Hx"], b["res"], b["cols"], float(b["sigma2"]), float(b["chi2_mult"]),
+                                                    float(b["gate"]))
+            _, route, _ = ctx.update_compression_mode()
+            routes.append(route)
+            assert rc == 0 and np.array_equal(acc, b["accepted"]) and nr == int(b["n_rows"]), j
+            assert route in (0, 4, 5), (j, route)
+            assert _rel(dx1, b["dx"]) < 1e-8 and _rel(P1, b["P_new"]) < 1e-9 and np.array_equal(P1, P1.T), (j, route, _rel(dx1, b["dx"]), _rel(P1, b["P_new"]))
+        assert routes.count(4) >= 5, routes        # (the form itself was exercised, not only its hand-over)
+    finally:
+        pkg.debug_knobs(prev)
+
+
 def _conditioned(k, cond, seed):
     rng = np.random.default_rng(seed)
     Q, _ = np.linalg.qr(rng.normal(size=(k, k)))
