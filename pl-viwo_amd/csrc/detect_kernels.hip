@@ -149,8 +149,9 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(DetectParams P, const un
   __syncthreads();
   const int M = n_sel;
   // ranks of the survivors; the keys that get an output slot (rank < nfg) are collected
-  __shared__ unsigned long long wkey[256];
-  __shared__ int wrank[256], n_win;
+  unsigned long long *wkey = (unsigned long long *)(sel + P.cand_cap + (P.cand_cap & 1));  // [nfg] (8-byte aligned: the index list is padded to even)
+  int *wrank = (int *)(wkey + P.nfg);                                                       // [nfg]
+  __shared__ int n_win;
   if (t == 0) n_win = 0;
   __syncthreads();
   for (int q = t; q < M; q += 256) {
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(DetectParams P, const un
     int rank = 0;
     for (int j = 0; j < M; ++j) rank += keys[sel[j]] > k;
     if (rank >= P.nfg) continue;
-    const int w = atomicAdd(&n_win, 1);  // (< nfg <= 256: launch_fast_cells checks)
+    const int w = atomicAdd(&n_win, 1);  // (< nfg: ranks below nfg are distinct)
     wkey[w] = k, wrank[w] = rank;
   }
   __syncthreads();
@@ -266,7 +267,8 @@ __global__ void __launch_bounds__(64) subpix_kernel(const uint8_t *__restrict__ 
 }
 
 int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned long long *d_cand, int *d_cand_n) {
-  if (P.cell_w * P.cell_h > 0x7fffffff / 2 || (size_t)P.cand_cap * 12 > 60 * 1024 || P.nfg > 256) {
+  const size_t topk_lds = (size_t)P.cand_cap * 8 + (size_t)(P.cand_cap + (P.cand_cap & 1)) * 4 + (size_t)std::max(P.nfg, 1) * 12;
+  if (P.cell_w * P.cell_h > 0x7fffffff / 2 || topk_lds > 60 * 1024) {
     set_last_error("FAST: cell %dx%d / candidate capacity %d out of range", P.cell_w, P.cell_h, P.cand_cap);
     return PLV_E_CAPACITY;
   }
@@ -277,7 +279,7 @@ int launch_fast_cells(plv_ctx *ctx, const DetectParams &P, int n_cells, unsigned
   }
   {
     ProfScope ps(ctx->prof, "fast_topk_kernel", ctx->stream);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3(n_cells), dim3(256), (size_t)P.cand_cap * 12, ctx->stream, P, d_cand, d_cand_n);  // keys + survivor indices
+    hipLaunchKernelGGL(fast_topk_kernel, dim3(n_cells), dim3(256), topk_lds, ctx->stream, P, d_cand, d_cand_n);  // keys + survivor indices + winners
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
