@@ -220,6 +220,9 @@ void plv_route_counts(unsigned long long *out8);
 #define PLV_DECISION_VALUES 11
 int plv_decision_trace(plv_ctx *ctx, int on);
 int plv_last_point_decisions(plv_ctx *ctx, uint64_t *ids, double *vals, int cap, int *n);
+/* ... and of the last line update: ids [n] as plv_camera_update_lines returned them, vals [n][3] = chi2, its threshold, the norm of the
+ * projected residual (REF UpdaterCamera.cpp:406-419; NaN: the line did not reach the gate). */
+int plv_last_line_decisions(plv_ctx *ctx, uint64_t *ids, double *vals, int cap, int *n);
 /* (measurement aid) line launches plv_camera_try_update enqueued behind a point update that was still running */
 unsigned long long plv_chain_count(void);
 int plv_cov_checkpoint(plv_ctx *ctx);

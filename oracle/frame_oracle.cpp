@@ -113,6 +113,8 @@ struct Frame {
   std::map<uint64_t, UsedPoint> used;  // point_used
   std::vector<uint64_t> dec_ids;       // the last point update's pool and the values behind its verdicts (orc_frame_last_point_decisions)
   std::vector<double> dec_vals;        // [pool][11]
+  std::vector<uint64_t> ldec_ids;      // ... and the last line update's batch with its gate values [L][3] (orc_frame_last_line_decisions)
+  std::vector<double> ldec_vals;
   // TrackLSD
   bool have_last = false;
   std::vector<float> lines_last;
@@ -699,8 +701,13 @@ int update_lines(Frame &F, double *P, int n, int ldp, const plv_state_view *st, 
   int n_rows = 0;
   std::vector<double> Pw((size_t)n * n);
   for (int j = 0; j < n; ++j) std::copy(P + (size_t)j * ldp, P + (size_t)j * ldp + n, Pw.begin() + (size_t)j * n);
+  F.ldec_vals.assign(3 * (size_t)L, std::nan(""));  // (the gate's values, for the library's plv_last_line_decisions: tests/decision_trace.py)
+  F.ldec_ids.resize(L);
+  for (int q = 0; q < L; ++q) F.ldec_ids[q] = R.pool[sel[q]].id;
+  orc_set_gate_debug(F.ldec_vals.data());
   const int rc = orc_msckf_update(Pw.data(), n, n, L, 6, k, ld, rows.data(), Hf.data(), Hx.data(), r.data(), cols.data(),
                                   st->sigma_pix * st->sigma_pix, opt->chi2_mult, 0.0, F.q95.data(), acc.data(), &n_rows, dx);
+  orc_set_gate_debug(nullptr);
   res->status = rc == -3 ? PLV_E_NOT_PSD : PLV_OK;
   if (rc == 0) {
     for (int j = 0; j < n; ++j) std::copy(Pw.begin() + (size_t)j * n, Pw.begin() + (size_t)j * n + n, P + (size_t)j * ldp);
@@ -825,6 +832,15 @@ int orc_frame_last_point_decisions(void *h, uint64_t *ids, double *vals, int cap
   if (*n > cap) return PLV_E_CAPACITY;
   std::copy(F.dec_ids.begin(), F.dec_ids.end(), ids);
   std::copy(F.dec_vals.begin(), F.dec_vals.end(), vals);
+  return 0;
+}
+int orc_frame_last_line_decisions(void *h, uint64_t *ids, double *vals, int cap, int *n) {
+  Frame &F = *(Frame *)h;
+  *n = (int)F.ldec_ids.size();
+  if (cap == 0) return 0;
+  if (*n > cap) return PLV_E_CAPACITY;
+  std::copy(F.ldec_ids.begin(), F.ldec_ids.end(), ids);
+  std::copy(F.ldec_vals.begin(), F.ldec_vals.end(), vals);
   return 0;
 }
 int orc_frame_get_line_features(void *h, const plv_state_view *st, const plv_update_options *opt) {

@@ -170,6 +170,7 @@ def load_library():
         "plv_chain_count": (C.c_ulonglong, []),
         "plv_decision_trace": (C.c_int, [C.c_void_p, C.c_int]),
         "plv_last_point_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
+        "plv_last_line_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
         "plv_route_counts": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
@@ -1282,6 +1283,16 @@ class Context:
         if n.value:
             self._chk(self.lib.plv_last_point_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), vals.ctypes.data_as(C.POINTER(C.c_double)),
                                                         n.value, C.byref(n)))
+        return ids, vals
+
+    def last_line_decisions(self):
+        """plv_last_line_decisions: (ids [n], values [n][3] = chi2, threshold, residual norm) of the last line update's batch"""
+        n = C.c_int(0)
+        self._chk(self.lib.plv_last_line_decisions(self.h, None, None, 0, C.byref(n)))
+        ids, vals = np.zeros(n.value, dtype=np.uint64), np.zeros((n.value, 3))
+        if n.value:
+            self._chk(self.lib.plv_last_line_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), vals.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       n.value, C.byref(n)))
         return ids, vals
 
     def line_prefetch_mode(self, on):

@@ -119,6 +119,8 @@ struct LineTracker {
   bool edge_fork = false;
   // plv_line_edges_early: the detection being launched reads the RAW image of the frame being fed (the pyramid that will hold its
   // equalised form is not current yet) through its histogram
+  std::vector<uint64_t> dec_ids;  // plv_decision_trace: the last line update's batch and its gate values (plv_last_line_decisions)
+  std::vector<double> dec_vals;
   const uint8_t *early_raw = nullptr;
   const unsigned *early_hist = nullptr;
   int early_w = 0, early_h = 0;
@@ -576,6 +578,20 @@ extern "C" void plv_line_edges_early(plv_ctx *ctx, const uint8_t *d_raw, int W, 
   std::vector<float> none;
   if (detect(ctx, T, PLV_PYR_CUR, none, true) == PLV_OK) ctx->edges_hook_fired = true;
   T->early_raw = nullptr, T->early_hist = nullptr;
+}
+
+// (test aid, plv_decision_trace) the last line update's batch: ids [n] as plv_camera_update_lines returned them and vals [n][3] = chi2,
+// the threshold it was held against, the norm of the projected residual (NaN: the line did not reach the gate)
+int plv_last_line_decisions(plv_ctx *ctx, uint64_t *ids, double *vals, int cap, int *n) {
+  if (!ctx || !n || cap < 0 || (cap > 0 && (!ids || !vals))) return PLV_E_BADARG;
+  LineTracker *T = ltr(ctx);
+  std::lock_guard<std::mutex> lk(T->mtx);
+  *n = (int)T->dec_ids.size();
+  if (cap == 0) return PLV_OK;
+  if (*n > cap) return PLV_E_CAPACITY;
+  std::copy(T->dec_ids.begin(), T->dec_ids.end(), ids);
+  std::copy(T->dec_vals.begin(), T->dec_vals.end(), vals);
+  return PLV_OK;
 }
 
 int plv_line_detect_launch(plv_ctx *ctx, int which) {
@@ -1470,6 +1486,19 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     }
   }
   res->n_rows = n_rows;
+  if (ctx->decision_trace) {  // (plv_last_line_decisions: the gate's values of the lines that reached it, in the order of line_ids)
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const int Fg = ctx->dec_F_l;
+    std::vector<double> gv(3 * (size_t)std::max(Fg, 1), nan);
+    if (Fg > 0) PLV_HIP_CHECK(hipMemcpy(gv.data(), ctx->d_gate_dec_l.p, (size_t)Fg * 24, hipMemcpyDeviceToHost));
+    ctx->dec_F_l = 0;
+    T->dec_ids.resize(L), T->dec_vals.assign(3 * (size_t)L, nan);
+    for (int q = 0; q < L; ++q) {
+      const int gi = fused_ran ? sel[q] : q;
+      T->dec_ids[q] = pool[sel[q]].id;
+      if (gi < Fg) std::copy(gv.begin() + 3 * (size_t)gi, gv.begin() + 3 * (size_t)gi + 3, T->dec_vals.begin() + 3 * (size_t)q);
+    }
+  }
   for (int q = 0; q < L; ++q) {
     res->n_accepted += acc[q];
     if (accepted_out) accepted_out[q] = acc[q];

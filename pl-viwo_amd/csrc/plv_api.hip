@@ -689,6 +689,10 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
     TRY(ctx->d_gate_dec.reserve((size_t)F * 24));
     g.dec = ctx->d_gate_dec.as<double>();
     ctx->dec_gate = true;
+  } else if (ctx->decision_trace) {
+    TRY(ctx->d_gate_dec_l.reserve((size_t)F * 24));
+    g.dec = ctx->d_gate_dec_l.as<double>();
+    ctx->dec_F_l = F;
   }
   g.accepted = d_acc;
   g.acc_rows = d_acc_rows;
@@ -859,6 +863,10 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     TRY(ctx->d_gate_dec.reserve((size_t)F * 24));
     a.dec = ctx->d_gate_dec.as<double>();
     ctx->dec_gate = true;
+  } else if (ctx->decision_trace) {
+    TRY(ctx->d_gate_dec_l.reserve((size_t)F * 24));
+    a.dec = ctx->d_gate_dec_l.as<double>();
+    ctx->dec_F_l = F;
   }
   a.stack = ctx->d_stack.as<double>();
   a.lds = Mtot;

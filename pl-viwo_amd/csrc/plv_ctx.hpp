@@ -430,7 +430,8 @@ struct plv_ctx {
   bool edges_hook_fired = false;
   // plv_decision_trace: the values behind every verdict of the point update stay on the device until plv_last_point_decisions asks
   bool decision_trace = false;
-  plv::DevBuf d_tri_dbg, d_gate_dec;
+  plv::DevBuf d_tri_dbg, d_gate_dec, d_gate_dec_l;  // (_l: the line update's gate)
+  int dec_F_l = 0;        // entries of the last line batch whose gate values are in d_gate_dec_l (0: none)
   int dec_F = 0;          // entries of the last point batch whose values are in d_tri_dbg
   bool dec_gate = false;  // ... and in d_gate_dec: that batch reached a gate
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong

@@ -802,8 +802,10 @@ class SystemManager:
 
     def _count_lines(self, lo):
         if self.decisions is not None:
+            vals = self.ctx.last_line_decisions() if (hasattr(self.ctx, "last_line_decisions") and lo["n_lines"] > 0) else None
             self.decisions.append(("lines", self.stats["frames"], self.state.time, int(lo["n_pool"]), np.array(lo["ids"], dtype=np.uint64),
-                                   np.array(lo["accepted"], dtype=np.uint8), int(lo["status"]), None, np.array(lo["dx"], dtype=float)))
+                                   np.array(lo["accepted"], dtype=np.uint8), int(lo["status"]), vals, np.array(lo["dx"], dtype=float),
+                                   np.array(lo["line_FinG"], dtype=float) if "line_FinG" in lo else None))
         self._cov_probe("after the line update")
         self.stats["line_pool"] += lo["n_pool"]
         self.stats["lines_triangulated"] += lo["n_lines"]

@@ -51,9 +51,18 @@ def tests_of(v, thr):
     return out
 
 
+def line_tests_of(v):
+    """a line entry's gate (REF UpdaterCamera.cpp:406-419: chi2 against chi2_mult x the 95 % quantile; no residual-norm gate): values =
+    chi2, threshold, residual norm as plv_last_line_decisions returns them"""
+    if np.isnan(v[0]) or np.isnan(v[1]):
+        return []
+    return [("chi2 of the line", float(v[0]), float(v[1]), bool(v[0] < v[1]))]
+
+
 def tie_record(fid, rec_a, rec_b, thr, names=("hip", "cpu")):
     """The test that split the two runs on feature `fid` and its margin — |value - threshold| / |threshold| — on both sides."""
     sides = {}
+    lines = rec_a[0] == "lines"
     for name, rec in zip(names, (rec_a, rec_b)):
         if rec[7] is None:
             return dict(id=int(fid), note=f"{name}: no values recorded")
@@ -61,7 +70,7 @@ def tie_record(fid, rec_a, rec_b, thr, names=("hip", "cpu")):
         i = np.nonzero(ids == np.uint64(fid))[0]
         if len(i) == 0:
             return dict(id=int(fid), note=f"{name}: the feature is not in the pool")
-        sides[name] = tests_of(vals[i[0]], thr)
+        sides[name] = line_tests_of(vals[i[0]]) if lines else tests_of(vals[i[0]], thr)
     ta, tb = sides[names[0]], sides[names[1]]
     for (na, va, la, pa), (nb, vb, lb, pb) in zip(ta, tb):
         if pa != pb:
@@ -76,7 +85,7 @@ def first_divergence(a, b, names=("hip", "cpu"), thr=None):
     """a, b: decision lists of two runs.  Returns None when every decision agrees, else a dict describing the first difference (with
     thr — the thresholds of tests_of — and recorded values: the test that split the runs and its margins, `tie`)."""
     d = _first_divergence(a, b, names)
-    if d is not None and thr is not None and d.get("kind") == "points" and "ids" in d:
+    if d is not None and thr is not None and d.get("kind") in ("points", "lines") and "ids" in d:
         k = d["update"]
         d["tie"] = [tie_record(fid, a[k], b[k], thr, names) for fid in sorted(set(d["ids"][names[0] + "_only"]) | set(d["ids"][names[1] + "_only"]))]
     return d
@@ -148,8 +157,8 @@ def check_tie(summary_, first_updates=3, first_tol=1e-8, window=10, factor=20.0)
         return bad
     if fd["split"] not in ("triangulation", "chi2"):
         return bad + [f"the runs part on '{fd['split']}', not on a test value: {fd}"]
-    if fd["kind"] != "points":
-        return bad      # (line updates record decisions only; their values are the point gate's arithmetic on other rows)
+    if fd["kind"] not in ("points", "lines"):
+        return bad
     before = [d[1] for d in drift["all"] if d[0] < fd["update"]][-window:]
     allowed = max(1e-9, factor * max(before)) if before else 1e-9
     for t in fd.get("tie", []):

@@ -350,6 +350,9 @@ class OracleContext(PyMirrorContext):
     def last_point_decisions(self):
         return self.frame.last_point_decisions()
 
+    def last_line_decisions(self):
+        return self.frame.last_line_decisions()
+
     def camera_try_update(self, st, plus, n, max_msckf, max_obs, t_prev_frame, state_time, **kw):
         return self.frame.try_update(self._Pf(), st, dict(plus=plus, n=n, max_msckf=max_msckf, max_obs=max_obs, t_prev_frame=t_prev_frame,
                                                           state_time=state_time, **kw))

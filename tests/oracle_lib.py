@@ -683,6 +683,7 @@ class FrameOracle:
         L.orc_frame_update_points.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp]
         L.orc_frame_get_line_features.argtypes = [vp, vp, vp]
         L.orc_frame_last_point_decisions.argtypes = [vp, u64p, dp, C.c_int, ip]
+        L.orc_frame_last_line_decisions.argtypes = [vp, u64p, dp, C.c_int, ip]
         L.orc_frame_update_lines.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp, vp, u64p, u8p, dp, C.c_int]
         L.orc_frame_try_update.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp]
         L.orc_frame_camera_frame.argtypes = [vp, dp, C.c_int, C.c_int, vp, vp, dp]
@@ -759,6 +760,16 @@ class FrameOracle:
         ids, vals = np.zeros(n.value, dtype=np.uint64), np.zeros((n.value, 11))
         if n.value:
             rc = self.lib.orc_frame_last_point_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(vals), n.value, C.byref(n))
+            assert rc == 0, rc
+        return ids, vals
+
+    def last_line_decisions(self):
+        """(ids [n], values [n][3] = chi2, threshold, residual norm) of the last line update's batch"""
+        n = C.c_int(0)
+        self.lib.orc_frame_last_line_decisions(self.h, None, None, 0, C.byref(n))
+        ids, vals = np.zeros(n.value, dtype=np.uint64), np.zeros((n.value, 3))
+        if n.value:
+            rc = self.lib.orc_frame_last_line_decisions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(vals), n.value, C.byref(n))
             assert rc == 0, rc
         return ids, vals
 
