@@ -407,12 +407,36 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 // covariance, so they run on a side stream while the main stream triangulates, builds Jacobians and gates; the main chain after
 // the gate is  gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches; "|": workgroups of the same
 // launch, those of the factor form return at once when the update takes the whitened one).
+// W0 = M^-1 Pc holds M^T in the columns of the update's own states, and the prior factor has M itself: those columns are COPIED from
+// the factor instead of kept as the substitution left them (M^-1 Ps is M^T only to eps x cond(M)^2 of the block: see "whitened update").
+// near_selects == 0 (the default): near-dependent pivots no longer select the factor form — their count moves to n_near[4] for the
+// record — only dead ones do.
+__global__ void __launch_bounds__(64) prior_exact_cols_kernel(const double *__restrict__ Lt, int ldl, int k, const int *__restrict__ cols,
+                                                              double *__restrict__ W0, int ldw, int *__restrict__ n_near, int near_selects) {
+  const int j = blockIdx.x;
+  double *dst = W0 + (size_t)cols[j] * ldw;
+  const double *src = Lt + (size_t)j * ldl;
+  for (int c = threadIdx.x; c < k; c += 64) dst[c] = c <= j ? src[c] : 0.0;
+  if (j == 0 && threadIdx.x == 0) {
+    n_near[4] = n_near[0];
+    if (!near_selects) n_near[0] = 0;
+  }
+}
+
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k) {
   int rc;
   if ((rc = ctx->d_Lt.reserve((size_t)k * k * 8)) || (rc = ctx->d_W0.reserve((size_t)k * (n + 1) * 8)) ||
       (rc = ctx->d_dW.reserve((size_t)n * n * 8)) || (rc = ctx->d_prior_near.reserve(64)))
     return rc;
   if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
+  // PLV_W0_EXACT (tools): 0 = round 4's first scheme (columns as substituted, near-dependent pivots select the factor form), 1 = exact
+  // columns but that selection; default 2
+  static const int exact_cols = getenv("PLV_W0_EXACT") ? atoi(getenv("PLV_W0_EXACT")) : 2;
+  if (exact_cols) {
+    ProfScope ps(ctx->prof, "prior_exact_cols_kernel", st);
+    hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, ctx->d_Lt.as<double>(), k, k, d_cols, ctx->d_W0.as<double>(), k,
+                       ctx->d_prior_near.as<int>(), exact_cols >= 2 ? 0 : 1);
+  }
   {
     ProfScope ps(ctx->prof, "prior_gain_kernel", st);
     const int tn = cdiv(n + 1, 16), waves = tn * (tn + 1) / 2;
@@ -464,10 +488,10 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
                        ctx->d_dW.as<double>(), C1, d0, use_m);
   }
   if (getenv("PLV_LAMBDA_DEBUG")) {
-    struct { int near, dead; double lam; } h;
+    struct { int near, dead; double lam; int near_rec; } h;
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpy(&h, use_m, 16, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[plv lambda] k %d near %d dead %d largest diagonal of B %.4g\n", k, h.near, h.dead, h.lam);
+    (void)hipMemcpy(&h, use_m, 20, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[plv lambda] k %d near %d (counted %d) dead %d largest diagonal of B %.4g\n", k, h.near, h.near_rec, h.dead, h.lam);
     if (h.dead > 6 && getenv("PLV_PIVOT_DEBUG")) {
       std::vector<double> Lt((size_t)k * k), Pd((size_t)n * n);
       std::vector<int> hc(k);
