@@ -389,26 +389,30 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 // Neither divides by a pivot of G: directions the measurements do not observe (the gauge freedom of an MSCKF Jacobian) simply add
 // nothing to B.  They differ in what costs digits.  The quantity at stake is the CONDITIONAL variance of a state given the ones
 // before it — pivot x its variance, the pivot being that of the prior block's unit-diagonal factor: clone positions of this filter
-// sit at 1e-8 (known to 1e-4 of the global position's uncertainty, which grows without bound), orientations at 1e-4.  Relative to
-// it an update loses (round 4, measured against the Householder route and the CPU oracle on the configs[2] / [3] drives):
-//   * whitened form   eps / pivot^2   (W0 divides by the factor's pivots).  Harmless at the start of a drive (pivots 1e-2 .. 1, and
-//     there it is the more accurate of the two: the posterior of a well-measured direction is a sum of squares); at pivots of 1e-8
-//     it is of order one per update: after 24 s of the configs[2] drive the position pivots had gone from +1e-8 to -1e-6, and the
-//     next update left the covariance indefinite at -0.19 of a unit diagonal;
-//   * factor form     eps x lambda / pivot, and eps x lambda^2 of the posterior variance itself, lambda = how much better than the
-//     prior the measurements know a direction (B's diagonal - 1).  Only multiplies by M (backward stable: M M^T is Ps to rounding).
-//     lambda is ~1 in the steady state, 1e4 .. 1e5 in the first updates after an initialisation with the intrinsics in the state
-//     (there: dx of the NEXT update off by 2e-5);
+// sit at 1e-9 .. 1e-8 (known to 1e-4 of the global position's uncertainty, which grows without bound), orientations at 1e-4.
+// Relative to it an update loses (round 4, measured against the Householder route and the CPU oracle on the configs[2] / [3] drives;
+// DESIGN 10.3 has the table):
+//   * whitened form with every column of W0 obtained by substitution (round 3): eps / pivot^2.  The columns of the update's OWN states
+//     are M^-1 Ps = M^T, which substitution delivers only to its own rounding, amplified by the factor's small pivots; after 24 s of the configs[2] drive the
+//     position pivots had gone from +1e-8 to -1e-6 and the next update left the covariance indefinite;
+//   * whitened form with those columns COPIED from the factor (prior_exact_cols_kernel; the default): eps / pivot — P[cols, cols] -
+//     W0c^T W0c is then the factorisation's backward error and the block's posterior the sum of squares Vc^T Vc.  The library's
+//     covariance pivots are the oracle's to two or three digits over 34 s of the configs[3] drive, the trajectories micrometres apart;
+//   * factor form: eps x lambda / pivot (with a constant that grows with the window: covariance pivots negative from frame 130 of that
+//     drive on, indefinite at frame 550) and eps x lambda^2 of the posterior variance itself, lambda = how much better than the prior
+//     the measurements know a direction (B's diagonal - 1): 1e4 .. 1e5 in the first updates after an initialisation with the
+//     intrinsics in the state (dx of the NEXT update off by 2e-5).  Only multiplies by M;
 //   * the reference's P - K H P: eps / pivot.
-// The prior factor decides on the device: no pivot below PLV_PRIOR_AMB (1e-4) -> whitened form; else factor form, and if B's diagonal
-// then exceeds PLV_WHITEN_LAMBDA_MAX (1e2) the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  With
-// these limits the covariance's pivots follow the CPU oracle's to two or three digits over a 34 s drive and every gate decision of
-// the three recorded drives is the oracle's (profiles/r04/replay_vs_cpu_*.json).  The prior factor, W0 and W0^T W0 only need the
-// covariance, so they run on a side stream while the main stream triangulates, builds Jacobians and gates; the main chain after
-// the gate is  gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches; "|": workgroups of the same
-// launch, those of the factor form return at once when the update takes the whitened one).
+// The prior factor decides on the device: the whitened form unless a pivot is DEAD (below PLV_PRIOR_TAU: M has a zero column, W0 a
+// zero row, and the whitened form returned dC ten times P); then the factor form, and if B's diagonal exceeds PLV_WHITEN_LAMBDA_MAX
+// (1e2) the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  Near-dependent pivots (below
+// PLV_PRIOR_AMB) are counted for the record; they selected the factor form until the columns were made exact (PLV_W0_EXACT=1 / 0:
+// the earlier rules, for comparison).  The prior factor, W0 and W0^T W0 only need the covariance, so they run on a side stream while
+// the main stream triangulates, builds Jacobians and gates; the main chain after the gate is
+// gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches; "|": workgroups of the same launch, those of
+// the factor form return at once when the update takes the whitened one).
 // W0 = M^-1 Pc holds M^T in the columns of the update's own states, and the prior factor has M itself: those columns are COPIED from
-// the factor instead of kept as the substitution left them (M^-1 Ps is M^T only to eps x cond(M)^2 of the block: see "whitened update").
+// the factor instead of kept as the substitution left them (M^-1 Ps is M^T only to the substitution's rounding, amplified by the factor's small pivots: see "whitened update").
 // near_selects == 0 (the default): near-dependent pivots no longer select the factor form — their count moves to n_near[4] for the
 // record — only dead ones do.
 __global__ void __launch_bounds__(64) prior_exact_cols_kernel(const double *__restrict__ Lt, int ldl, int k, const int *__restrict__ cols,

@@ -197,3 +197,33 @@ def summary(a, b, thr=None):
     out["tie_check"] = check_tie(out) if thr is not None else None
     del out["value_drift"]["all"]
     return out
+
+
+class ProbedTrace(list):
+    """a decision list that also asks the driver (plviwo_amd.system.SystemManager) for the state and covariance in front of every
+    camera update (states_pre: (frame, state vector, covariance)) and, with probe_cov = (first frame, last frame), for the covariance
+    after every step of those frames"""
+    probe_state = True
+    probe_cov = None
+
+    def __init__(self):
+        super().__init__()
+        self.states, self.states_pre, self.states_prop, self.cov_probes = [], [], [], []
+
+
+def min_unit_pivot(P):
+    """smallest pivot of the Cholesky factorisation (no pivoting) of the covariance scaled to unit diagonal: the conditional variance
+    of the most dependent state given the ones before it, as a fraction of its variance (<= 0: not positive definite to rounding).
+    Clone positions of this filter sit at 1e-9 .. 1e-8: the quantity an update's rounding is measured against."""
+    d = np.sqrt(np.abs(np.diag(P)))
+    A = P / np.outer(d, d)
+    lo = 1.0
+    for j in range(len(A)):
+        piv = A[j, j]
+        lo = min(lo, piv)
+        if piv <= 1e-300:
+            A[j + 1:, j] = 0.0
+            continue
+        A[j + 1:, j] /= piv
+        A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j]) * piv
+    return lo

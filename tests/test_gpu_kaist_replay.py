@@ -80,15 +80,15 @@ def test_kaist_layout_drives_like_the_source(pkg, kaist_dir, tmp_path):
     assert n >= 30 and np.abs(pk[:n, :3] - ps[:n, :3]).max() < 0.10
 
 
-def test_whitened_update_on_a_near_dependent_prior(kaist_dir, tmp_path):
+def test_whitened_update_on_a_near_dependent_prior(pkg, kaist_dir, tmp_path):
     """Real KAIST stamps are nanoseconds since 1970: at 1.5e9 s a double resolves 0.24 us, the IMU pose at the newest camera time and the
-    clone just taken of it differ by that much propagation, and the prior block of the compressed update is within 1e-11 of singular.
-    Round 4's first whitened update divided by those pivots (a first update rejected as not positive definite, later ones off by
-    1e-7); it now multiplies by the prior's factor only (dense_kernels.hip "whitened update").  What remains is the first update after
+    clone just taken of it differ by that much propagation, and the prior block of the compressed update is within 1e-11 of singular
+    (39 of its 66 pivots below 1e-4 of a unit diagonal).  Round 3's whitened update obtained every column of W0 by substitution through
+    those pivots (a first update rejected as not positive definite, later ones off by 1e-7); the columns of the update's own states
+    are now copied from the prior factor (dense_kernels.hip "whitened update").  What remains is the first update after
     the initialisation, rejected for a negative diagonal and run again through the reference's S = H P H^T + R route (plv_api.hip
-    RedoW): no update is lost, and the trajectory is the one the Householder route (plv_update_compression_mode 1) gives to a
-    millimetre — this drive amplifies rounding by 1e11 (the library's Householder route and the CPU oracle end 3.9 mm apart on it), and
-    the hand-over reduces the accepted rows in another tree shape than mode 1 reduces the whole stack."""
+    RedoW): no update is lost, and the trajectory is the one the Householder route (plv_update_compression_mode 1) gives to 0.4 mm —
+    this drive amplifies rounding by 1e11 (the library's Householder route and the CPU oracle end 3.9 mm apart on it)."""
     options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
     dst = kaist_synth.convert(kaist_dir[1], str(tmp_path / "urban_1p5e9"), sd.RL, sd.RR, sd.BASE)     # (default stamps: 1.5e9 s)
     out, routes = {}, {}

@@ -28,14 +28,7 @@ import oracle_context as oc  # noqa: E402
 import synth_dataset as sd  # noqa: E402
 
 
-class Trace(list):
-    """a decision list that also asks the driver for state probes (plviwo_amd.system.SystemManager)"""
-    probe_state = True
-    probe_cov = None     # (first frame, last frame): covariance snapshots after every step of those frames
-
-    def __init__(self):
-        super().__init__()
-        self.states, self.states_pre, self.states_prop, self.cov_probes = [], [], [], []
+Trace = dt.ProbedTrace
 
 
 def main():
@@ -86,22 +79,7 @@ def main():
         print("  %d: %.2g @ %d, %.2g;" % (fa, dx.max(), int(np.argmax(dx)), np.abs(Pa - Pb).max() / np.abs(Pb).max()), end="")
     print()
 
-    def min_pivot(P):
-        """smallest pivot of the Cholesky factorisation of the covariance scaled to unit diagonal (no pivoting): how close the most
-        dependent state is to being a function of the ones before it (<= 0: the matrix is not positive definite to rounding)"""
-        d = np.sqrt(np.abs(np.diag(P)))
-        A = P / np.outer(d, d)
-        n, lo = len(A), 1.0
-        A = A.copy()
-        for j in range(n):
-            piv = A[j, j]
-            lo = min(lo, piv)
-            if piv <= 1e-300:
-                A[j + 1:, j] = 0.0
-                continue
-            A[j + 1:, j] /= piv
-            A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j]) * piv
-        return lo
+    min_pivot = dt.min_unit_pivot
     print("smallest unit-diagonal Cholesky pivot of the covariance in front of every 10th camera update (frame: hip / cpu):")
     for (fa, xa, Pa), (fb, xb, Pb) in list(zip(h.states_pre, c.states_pre))[::10]:
         print("  %d: %.2g / %.2g;" % (fa, min_pivot(Pa), min_pivot(Pb)), end="")
