@@ -621,7 +621,7 @@ def main():
 
         # kernels on side streams, next to the chain the frame waits for: the whitened update's prior factor (every update starts one;
         # its result is only consumed when the gate accepts something), the next frame's detection
-        side = {"bchol_prior_kernel", "prior_gain_kernel", "fast_tiles_kernel", "fast_topk_kernel", "subpix_kernel"}
+        side = {"bchol_prior_kernel", "prior_exact_cols_kernel", "prior_gain_kernel", "fast_tiles_kernel", "fast_topk_kernel", "subpix_kernel"}
         order = sorted(kernels, key=lambda k: -kernels[k][1])
         on_path = [k for k in order if k not in side] or order
         top = entry(on_path[0])

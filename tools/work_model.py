@@ -3,7 +3,7 @@ SURVEY.md §8(d), restated in DESIGN.md §4, times the units one launch processe
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TF = 78.6    # vendor FP64 matrix figure (v_mfma_f64_16x16x4_f64)
-HBM_KERNELS = {"gram_reduce_kernel", "gather_cov_kernel", "ekf_commit_kernel"}
+HBM_KERNELS = {"gram_reduce_kernel", "gather_cov_kernel", "ekf_commit_kernel", "prior_exact_cols_kernel"}
 
 # Where each per-launch figure comes from (bench.py prints it next to the figure):
 #   "8d"       SURVEY.md 8(d)'s formula, verbatim (front-end bytes B_frame; null space, chi2 gate, compression, EKF flops)
@@ -21,6 +21,7 @@ PROVENANCE = {
     "nullspace_kernel": "8d", "chi2_gate_kernel": "8d-split", "chi2_t_kernel": "8d-split", "qr_accum_kernel": "8d",
     "gram_chunk_kernel": "8d-split", "gram_direct_kernel": "8d-split", "gram_reduce_kernel": "estimate", "bchol_compress_kernel": "8d-split",
     "bchol_ekf_kernel": "8d-split", "bchol_prior_kernel": "estimate (whitened route: not in 8d)", "prior_gain_kernel": "estimate (whitened route: not in 8d)",
+    "prior_exact_cols_kernel": "estimate (whitened route: not in 8d)",
     "gather_cov_kernel": "estimate", "ekf_dc_kernel": "8d-split", "ekf_commit_kernel": "8d-split", "ekf_mt_kernel": "8d-split",
     "ekf_s_kernel": "8d-split", "ekf_ms_kernel": "8d-split",
 }
@@ -37,6 +38,7 @@ def update_bytes(F, rows_f, fdim, k, n):
     return {
         "bchol_prior_kernel": (k * n + k * k + k * (n + 1)) * d,          # P[cols, :] in; Lp^T, W0 out
         "prior_gain_kernel": (k * (n + 1) + n * n / 2.0) * d,              # W0 in; W0^T W0 (upper) out
+        "prior_exact_cols_kernel": 2.0 * k * k * d,                        # Lp^T in, the k columns of W0 that are its rows out
         "nullspace_kernel": 2.0 * F * rows_f * (fdim + k + 1) * d,
         "chi2_t_kernel": (F * mp * k * 2 + k * k) * d,                     # H' in, T out, Ps once
         "chi2_gate_kernel": (F * mp * (2 * k + 1) + F * mp * nc) * d,      # T, H', r in; accepted rows to the stack
@@ -97,6 +99,7 @@ def update_work(F, rows_f, fdim, k, n, qr_launches=1, whitened=True):
     return {
         "bchol_prior_kernel": k ** 3 / 3.0 + 1.0 * k * k * n,      # factor of P[cols, cols] + the n border rows P[:, cols]
         "prior_gain_kernel": 1.0 * n * n * k,                      # W0^T W0, upper tiles
+        "prior_exact_cols_kernel": 2.0 * k * k * 8.0,              # a copy: bytes (HBM_KERNELS)
         "nullspace_kernel": F * 6.0 * (fdim + k + 1) * max(rows_f * fdim - fdim * (fdim + 1) / 2, 0),
         "chi2_gate_kernel": F * (2.0 * mp * mp * k + mp ** 3 / 3.0),
         "chi2_t_kernel": F * 2.0 * mp * k * k,
