@@ -67,17 +67,49 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ void lds_vstore(T *p, T v) { *(volatile PLV_LDS T *)(p) = v; }
 template <class T> __device__ __forceinline__ T lds_vload(const T *p) { return *(const volatile PLV_LDS T *)(p); }
 
+// PLV_BC_FLAGS (tools/ubench/bchol_time.hip): the barrier behind every panel replaced by per-strip ready flags.
+// A strip's trailing update waits only for the panel tiles it multiplies with, the next diagonal tile only for its own strip, and a
+// heavy strip may run a panel behind: the step buffer is then kept by panel parity like the panel tiles and the pivots, and two
+// counters per panel say when a parity's buffers may be overwritten.
+#ifdef PLV_BC_FLAGS
+#define PLV_BC_TSP 2
+#else
+#define PLV_BC_TSP 1
+#endif
+#ifndef PLV_BC_NTL
+#define PLV_BC_NTL 12
+#endif
 template <int NTL>
 struct BcLdsT {
   double Lp[2][NTL][64][4];  // published panel tiles of the symmetric strips (per-lane order), by panel parity (NT <= NTL)
-  double Ts[16][64][2];    // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
+  double Ts[PLV_BC_TSP][16][64][2];  // step j of the running factorisation: {register dump holding row j, masked -1/pivot}
   double rs[2][16];        // the pivots l_jj^2 of the panel (<= 0: dead column), by panel parity; readers take 1 / sqrt themselves
   int step_flag;           // 16 * panel + steps published so far
   int rs_flag;             // panels whose rs[] is published
   int bad;
   int n_amb;               // pivots the factorisation could not tell from zero (diag_chain's `amb` band)
+#ifdef PLV_BC_FLAGS
+  int x_flag[NTL];         // strip t: panels whose tile X_t is published in Lp
+  int cdone[NTL];          // panel p: followers that have finished its chain (they no longer read Ts / rs of that parity)
+  int tdone[NTL];          // panel p: followers that have finished its trailing update (they no longer read Lp of that parity)
+#endif
 };
-typedef BcLdsT<12> BcLds;    // the update's factorisations (up to 192 columns); the gate inside the Jacobian launches uses BcLdsT<2>
+typedef BcLdsT<PLV_BC_NTL> BcLds;    // the update's factorisations (up to 192 columns); the gate inside the Jacobian launches uses BcLdsT<2>
+
+#ifdef PLV_BC_FLAGS
+// bounded spin on an LDS word (a flag that is never set must not hang the device: the factorisation is then marked bad)
+template <class LDS>
+__device__ __forceinline__ void bc_wait_ge(LDS &lds, const int *w, int want) {
+  int spins = 0;
+  while (__builtin_amdgcn_readfirstlane(lds_vload(w)) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) {
+      lds.bad = 2;
+      break;
+    }
+  }
+}
+#endif
 
 // 1/x: v_rcp_f64 + two Newton steps (the sequence the compiler's IEEE division starts with, without
 // the scale / fixup instructions that only matter outside the pivots' range).
@@ -136,7 +168,7 @@ __device__ __forceinline__ void diag_chain(d4 T, LDS &lds, double tau, int p, d4
     n_amb += (amb > 0.0 && pv != 0.0 && fabs(pv) < amb) ? 1 : 0;
     const double nm = ninv * mask01[kk];
     const double trow = T[rq];
-    lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[jj][lane][0]), d2{trow, nm});
+    lds_vstore(reinterpret_cast<d2 *>(&lds.Ts[p & (PLV_BC_TSP - 1)][jj][lane][0]), d2{trow, nm});
     lds_vstore(&lds.step_flag, 16 * p + jj + 1);
 #ifndef PLV_BC_NO_SCHED
     __builtin_amdgcn_sched_barrier(0);  // publish now: the scheduler would sink all 16 stores below the chain
@@ -182,7 +214,7 @@ __device__ __forceinline__ d4 strip_chain(d4 W, LDS &lds, int p) {
 #endif
     for (;;) {  // flag first, then the data: both loads are in flight together
       const int f = lds_vload(&lds.step_flag);
-      d = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[jj][lane][0]));
+      d = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[p & (PLV_BC_TSP - 1)][jj][lane][0]));
       if (__builtin_amdgcn_readfirstlane(f) >= want) break;
       __builtin_amdgcn_s_sleep(PLV_BC_SLEEP);  // a spinning wave must not take issue slots and LDS cycles from the chain
     }
@@ -214,6 +246,9 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
   const int t = NT == 7 ? map7[wave & 7] : (NT == 8 ? map8[wave & 7] : wave);
   const int bs = strip;  // one border strip per workgroup, carried by wave NT (further waves only keep the barriers)
   const bool active = is_sym ? (t < ntk) : (wave == NT && bs * 16 < nb);
+#ifdef PLV_BC_FLAGS
+  const int nbord = bs * 16 < nb ? 1 : 0;  // followers of panel p: the symmetric strips below it and the border strip
+#endif
   // acc[j] holds tile (strip, p + j): the array is rotated after every panel, and a finished panel tile is stored
   // right away instead of being kept to the end.
   d4 acc[NT];
@@ -231,7 +266,13 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
       }
       acc[c][q] = v;
     }
+#ifdef PLV_BC_FLAGS
+  if (threadIdx.x < NT) lds.x_flag[threadIdx.x] = lds.cdone[threadIdx.x] = lds.tdone[threadIdx.x] = 0;
+#endif
   ops.scales_ready();  // (compression: column scales into LDS + barrier; the raw loads above are already in flight)
+#ifdef PLV_BC_FLAGS
+  __syncthreads();
+#endif
 #pragma unroll
   for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -254,8 +295,21 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
     const bool below = active && (!is_sym || t > p);
     d4 x = {0, 0, 0, 0};
     BC_STAMP(1 + 5 * p);
+#ifdef PLV_BC_PRIO
+    // the wave on the critical path gets the issue slots and the matrix pipe of its SIMD first: the diagonal wave of this panel, and
+    // (PLV_BC_PRIO >= 2) the strip that holds the next diagonal tile
+    if (is_sym && t == p)
+      __builtin_amdgcn_s_setprio(3);
+    else if (PLV_BC_PRIO >= 2 && is_sym && t == p + 1)
+      __builtin_amdgcn_s_setprio(2);
+    else
+      __builtin_amdgcn_s_setprio(0);
+#endif
     if (is_sym && t == p) {
       d4 cap = {0, 0, 0, 0};
+#ifdef PLV_BC_FLAGS
+      if (p >= 2) bc_wait_ge(lds, &lds.cdone[p - 2], ntk - 1 - (p - 2) + nbord);  // the followers of panel p - 2 are out of this parity's step buffer and pivots
+#endif
       diag_chain<Ops::kStoreL>(acc[0], lds, tau, p, cap, amb);
       BC_STAMP(43 + p);
       if (Ops::kStoreL) {  // rows of L_d: cap[q] = l_ic * l_cc with i = li, c = lq + 4q
@@ -273,7 +327,22 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
 #endif
       x = strip_chain(acc[0], lds, p);
       BC_STAMP(43 + p);
+#ifdef PLV_BC_FLAGS
+      // the strip that holds the next diagonal tile: that tile needs nothing but this strip's own X (which the lane that would read
+      // it back from Lp holds in x already) — updated first, before anything is published
+      if (is_sym && t == p + 1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[s], x[s], acc[1], 0, 0, 0);
+      }
+      if (lane == 0) __hip_atomic_fetch_add((PLV_LDS int *)&lds.cdone[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (is_sym) {
+        if (p >= 2) bc_wait_ge(lds, &lds.tdone[p - 2], ntk - 1 - (p - 2) + nbord);  // nobody reads this parity's panel tiles any more
+        lds_vstore(reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]), x);
+        lds_vstore(&lds.x_flag[t], p + 1);
+      }
+#else
       if (is_sym) *reinterpret_cast<d4 *>(&lds.Lp[p & 1][t][lane][0]) = x;
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // panel p of this strip is final: out it goes
         const int cc = p * 16 + lq + 4 * q;
@@ -284,7 +353,9 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
       }
     }
     BC_STAMP(2 + 5 * p);
+#ifndef PLV_BC_FLAGS
     __syncthreads();
+#endif
     BC_STAMP(3 + 5 * p);
     if (below) {
       const int ntrail = (is_sym ? t : ntk - 1) - p;  // tiles (strip, p+1 .. p+ntrail) live in acc[1 .. ntrail]
@@ -294,22 +365,42 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
           d4 a[3];
 #pragma unroll
           for (int u = 0; u < 3; ++u)
-            if (c0 + u < NT && c0 + u <= ntrail) a[u] = *reinterpret_cast<const d4 *>(&lds.Lp[p & 1][p + c0 + u][lane][0]);
+            if (c0 + u < NT && c0 + u <= ntrail) {
+#ifdef PLV_BC_FLAGS
+              if (is_sym && p + c0 + u == t) {
+                a[u] = x;  // (its own tile: the lane holds what it would read back)
+              } else {
+                bc_wait_ge(lds, &lds.x_flag[p + c0 + u], p + 1);
+                a[u] = lds_vload(reinterpret_cast<const d4 *>(&lds.Lp[p & 1][p + c0 + u][lane][0]));
+              }
+#else
+              a[u] = *reinterpret_cast<const d4 *>(&lds.Lp[p & 1][p + c0 + u][lane][0]);
+#endif
+            }
 #pragma unroll
           for (int u = 0; u < 3; ++u)
             if (c0 + u < NT && c0 + u <= ntrail) {
+#ifdef PLV_BC_FLAGS
+              if (is_sym && t == p + 1) continue;  // (done above)
+#endif
 #pragma unroll
               for (int s = 0; s < 4; ++s)
                 acc[c0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u][s], x[s], acc[c0 + u], 0, 0, 0);
             }
         }
       }
+#ifdef PLV_BC_FLAGS
+      if (lane == 0) __hip_atomic_fetch_add((PLV_LDS int *)&lds.tdone[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
 #pragma unroll
     for (int i = 0; i + 1 < NT; ++i) acc[i] = acc[i + 1];
     BC_STAMP(4 + 5 * p);
   }
   BC_STAMP(50);
+#ifdef PLV_BC_FLAGS
+  __syncthreads();  // (what follows the factorisation in the kernels expects every wave to be through)
+#endif
 }
 
 }  // namespace plv

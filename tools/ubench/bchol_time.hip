@@ -1,7 +1,9 @@
 // Phase timing of the blocked Cholesky kernels (s_memtime stamps per wave).  Build on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I pl-viwo_amd/csrc -I include \
 //         tools/ubench/bchol_time.hip -o tools/ubench/bchol_time.bin
+#ifndef NO_STAMPS
 #define PLV_BCHOL_TIMING 1
+#endif
 #define PLV_BCHOL_NO_LAUNCHERS 1
 #include "../../pl-viwo_amd/csrc/blocked_chol.hip"
 #include <cstdio>
@@ -32,7 +34,9 @@ int main() {
   CK(hipMalloc(&dst, 16 * 64 * 8));
   CK(hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemset(dst, 0, 16 * 64 * 8));
+#ifndef NO_STAMPS
   CK(hipMemcpyToSymbol(HIP_SYMBOL(plv::g_bchol_stamps), &dst, sizeof(dst)));
+#endif
   for (int it = 0; it < 3; ++it) {
     hipLaunchKernelGGL(plv::bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, 0, dG, nc, dR, k, dz, (const int *)nullptr, (int *)nullptr);
     CK(hipDeviceSynchronize());
@@ -98,6 +102,22 @@ int main() {
       CK(hipEventElapsedTime(&ms, e0, e1));
     }
     printf("bchol_ekf_kernel<7>, r = %d, n = %d: %.1f us by events\n", r, n, ms * 1e3);
+    {  // 200 launches back to back: (total / 200) = kernel + launch gap, the figure to compare variants on (build with -DNO_STAMPS)
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < 200; ++it)
+        hipLaunchKernelGGL(plv::bchol_ekf_kernel<7>, dim3((n + 1 + 15) / 16), dim3(64 * 8), 0, 0, dG, nc, r, dMt, r, n, dres, dW, r, dflag, (const int *)nullptr, plv::WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, -1});
+      CK(hipEventRecord(e1, 0));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("bchol_ekf_kernel<7> x 200 back to back: %.2f us per launch\n", ms * 1e3 / 200);
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < 200; ++it)
+        hipLaunchKernelGGL(plv::bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, 0, dG, nc, dR, k, dz, (const int *)nullptr, (int *)nullptr);
+      CK(hipEventRecord(e1, 0));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("bchol_compress_kernel<7> x 200 back to back: %.2f us per launch\n", ms * 1e3 / 200);
+    }
     std::vector<long long> s2(16 * 64);
     CK(hipMemcpy(s2.data(), dst, s2.size() * 8, hipMemcpyDeviceToHost));
     for (int w = 0; w < 8; ++w) {
