@@ -182,7 +182,9 @@ int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
  * when there are more rows than columns:
  *   0 (default)  whitened update: G = H^T H, g = H^T r over the accepted rows; Ps = P[cols, cols] = Lp Lp^T (unit-diagonal scaling,
  *                exact dependencies such as the IMU pose and its fresh clone dropped); B = I + Lp^T G Lp = Lb Lb^T;
- *                P' = P - W0^T W0 + V^T V, dx = V^T v with W0 = Lp^-1 P[cols, :], [V | v] = Lb^-1 [W0 | Lp^T g].  The same P', dx as
+ *                P' = P - W0^T W0 + V^T V, dx = V^T v with W0 = Lp^-1 P[cols, :] (its columns of the update's own states are
+ *                Lp^T and are copied from the factor, which keeps the conditional variances of nearly dependent states — clone
+ *                positions — to eps / pivot as the reference's form does), [V | v] = Lb^-1 [W0 | Lp^T g].  The same P', dx as
  *                the reference's R-based update in exact arithmetic; no pivot of the measurement side is ever divided by, so the
  *                gauge directions of an MSCKF Jacobian cost nothing: agrees with the Givens oracle to 1e-10 (P') / 1e-9 (dx) on
  *                every captured replay batch and up to condition 1e8 of the stacked Jacobian.  The prior factor runs on a side

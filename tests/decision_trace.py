@@ -5,7 +5,9 @@ were triangulated and which of those passed the gate.  The front-ends of the HIP
 the two filters see the same measurements and their decisions can only part where a floating-point test value sits on its
 threshold.  first_divergence() finds the first update whose decisions differ and says which test split them:
 
-    pool            the pools differ in size — measurements differ: never a tie
+    pool            the pools differ in size — measurements differ: not a tie this module can put a margin on (seen once in 13 480
+                    updates of a 300 s drive with the intrinsics calibrated online: the tracker's RANSAC undistorts with the state's
+                    intrinsics, so a track can end a frame apart in the two runs; summary()'s differing_updates names the feature)
     triangulation   an id was triangulated by one side only (condition number / depth range / baseline ratio of
                     FeatureInitializer::single_triangulation, single_gaussnewton; LineHelper's triangulation for lines)
     chi2            an id was triangulated by both and accepted by one only (UpdaterStatistics::Chi2Check, the residual-norm gate;
@@ -181,14 +183,22 @@ def summary(a, b, thr=None):
     """Counts over the whole of both runs: updates, updates that agree in every decision, the first divergence."""
     n = min(len(a), len(b))
     same = 0
-    for ra, rb in zip(a, b):
+    differing = []
+    for k, (ra, rb) in enumerate(zip(a, b)):
         if (ra[0] == rb[0] and ra[3] == rb[3] and ra[6] == rb[6] and np.array_equal(ra[4], rb[4]) and np.array_equal(ra[5], rb[5])):
             same += 1
+        elif len(differing) < 12:
+            ia, ib = set(int(v) for v in ra[4]), set(int(v) for v in rb[4])
+            acc_a = set(int(v) for v, f in zip(ra[4], ra[5]) if f)
+            acc_b = set(int(v) for v, f in zip(rb[4], rb[5]) if f)
+            differing.append(dict(update=k, kind=[ra[0], rb[0]], frame=[int(ra[1]), int(rb[1])], pool=[int(ra[3]), int(rb[3])], status=[int(ra[6]), int(rb[6])],
+                                  ids_a_only=sorted(ia - ib)[:8], ids_b_only=sorted(ib - ia)[:8],
+                                  accepted_a_only=sorted(acc_a - acc_b)[:8], accepted_b_only=sorted(acc_b - acc_a)[:8]))
     drift = value_drift(a, b, thr) if thr is not None else []
     fd = first_divergence(a, b, thr=thr)
     upto = fd["update"] if fd is not None and "update" in fd else n
     before = [d for d in drift if d[0] < upto]
-    out = dict(updates=n, updates_with_identical_decisions=same, first_divergence=fd,
+    out = dict(updates=n, updates_with_identical_decisions=same, first_divergence=fd, differing_updates=differing,
                 value_drift=dict(what="largest relative difference between the two runs' recorded test values per point update, over the entries that pass every test in both (update, difference, value, feature)",
                                  all=drift, first_updates=drift[:5], before_the_first_divergence=before[-5:],
                                  largest_before_the_first_divergence=max(before, key=lambda d: d[1]) if before else None,

@@ -137,10 +137,10 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     # tests/decision_trace.py, profiles/r04/replay_vs_cpu*.json — none in these drives).
     assert abs(sh["cam_features"] - sc["cam_features"]) <= 0.01 * sc["cam_features"] and abs(sh["cam_accepted"] - sc["cam_accepted"]) <= 0.01 * sc["cam_accepted"]
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
+    d20 = np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max()
+    print("largest distance between the two trajectories %.3g m, over the first 20 poses %.3g m" % (d, d20))
     assert d < 2e-4, d
-    # (the first poses: 1e-10 while every update takes the whitened form; from the first prior pivot below 1e-4 on the factor form
-    # runs, which loses eps x lambda, lambda <= 100: 6e-8 measured)
-    assert np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max() < 2e-7
+    assert d20 < 2e-7
     ctx = pkg.Context(pkg.default_config(752, 480))
     r = ctx.traj_ate(runs["hip"][2], runs["cpu"][2], "none")
     ctx.close()
@@ -186,10 +186,12 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     assert sh["cam_accepted"] >= 500 and sh["lines_triangulated"] >= 200 and sh["line_updates"] >= 10, sh
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
+    d15 = np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max()
+    print("largest distance between the two trajectories %.3g m, over the first 15 poses %.3g m" % (d, d15))
     assert d < 2e-4, d
     # (before the first threshold tie: rounding only.  The line blocks are projected by Householder reflections here and by the
     # reference's Givens sequence in the oracle: the same left null space in another basis, conditioning ~1e4 of the Pluecker Hf)
-    assert np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max() < 3e-7
+    assert d15 < 3e-7
     ate = {name: _score(pkg, runs[name][3], os.path.join(street_dataset, "gt.txt"))[0]["pos"]["rmse"] for name in runs}
     assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
@@ -237,7 +239,9 @@ def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, t
         assert abs(sh[key] - sc[key]) <= max(2, 0.03 * sc[key]), (key, sh[key], sc[key])
     assert sh["cam_accepted"] >= 800 and sh["lines_triangulated"] >= 1000 and sh["line_updates"] >= 10, sh
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
-    assert np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max() < 2e-4
+    d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
+    print("largest distance between the two trajectories %.3g m" % d)
+    assert d < 2e-4
 
 
 @pytest.fixture(scope="module")
