@@ -139,8 +139,10 @@ def test_replay_against_the_cpu_oracle(pkg, dataset, tmp_path):
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
     d20 = np.abs(runs["hip"][2][:20, :3] - runs["cpu"][2][:20, :3]).max()
     print("largest distance between the two trajectories %.3g m, over the first 20 poses %.3g m" % (d, d20))
-    assert d < 2e-4, d
-    assert d20 < 2e-7
+    # (measured 1.4e-12 / 1.9e-13 since the whitened update takes its own columns of W0 from the prior factor; 2e-5 /
+    # 6e-8 with the factor form before.  A refinement that stops one iteration apart would show as ~1e-6: none on this drive)
+    assert d < 1e-8, d
+    assert d20 < 1e-10
     ctx = pkg.Context(pkg.default_config(752, 480))
     r = ctx.traj_ate(runs["hip"][2], runs["cpu"][2], "none")
     ctx.close()
@@ -188,10 +190,10 @@ def test_replay_with_lines_against_the_cpu_oracle(pkg, street_dataset, tmp_path)
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
     d15 = np.abs(runs["hip"][2][:15, :3] - runs["cpu"][2][:15, :3]).max()
     print("largest distance between the two trajectories %.3g m, over the first 15 poses %.3g m" % (d, d15))
-    assert d < 2e-4, d
-    # (before the first threshold tie: rounding only.  The line blocks are projected by Householder reflections here and by the
+    # (rounding only: measured 4.3e-12 / 8.8e-13.  The line blocks are projected by Householder reflections here and by the
     # reference's Givens sequence in the oracle: the same left null space in another basis, conditioning ~1e4 of the Pluecker Hf)
-    assert d15 < 3e-7
+    assert d < 1e-8, d
+    assert d15 < 1e-10
     ate = {name: _score(pkg, runs[name][3], os.path.join(street_dataset, "gt.txt"))[0]["pos"]["rmse"] for name in runs}
     assert ate["hip"] < 0.10 and abs(ate["hip"] - ate["cpu"]) < 0.005, ate
 
@@ -241,7 +243,7 @@ def test_replay_at_configs3_size_against_the_cpu_oracle(pkg, street_dataset_d, t
     assert np.array_equal(runs["hip"][1], runs["cpu"][1])
     d = np.abs(runs["hip"][2][:, :3] - runs["cpu"][2][:, :3]).max()
     print("largest distance between the two trajectories %.3g m" % d)
-    assert d < 2e-4
+    assert d < 5e-6      # (measured 4.4e-8: the intrinsics are in the state here, lambda 1e4 .. 1e5 in the first updates)
 
 
 @pytest.fixture(scope="module")
