@@ -424,6 +424,7 @@ __global__ void __launch_bounds__(64) prior_exact_cols_kernel(const double *__re
   if (j == 0 && threadIdx.x == 0) {
     n_near[4] = n_near[0];
     if (!near_selects) n_near[0] = 0;
+    if (near_selects < 0) n_near[5] = n_near[1], n_near[1] = 0;  // (PLV_W0_EXACT=3, experiment: dead pivots do not select the factor form either)
   }
 }
 
@@ -434,12 +435,12 @@ int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, 
     return rc;
   if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
   // PLV_W0_EXACT (tools): 0 = round 4's first scheme (columns as substituted, near-dependent pivots select the factor form), 1 = exact
-  // columns but that selection; default 2
+  // columns but that selection; default 2; 3 = experiment: dead pivots do not select the factor form either
   static const int exact_cols = getenv("PLV_W0_EXACT") ? atoi(getenv("PLV_W0_EXACT")) : 2;
   if (exact_cols) {
     ProfScope ps(ctx->prof, "prior_exact_cols_kernel", st);
     hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, ctx->d_Lt.as<double>(), k, k, d_cols, ctx->d_W0.as<double>(), k,
-                       ctx->d_prior_near.as<int>(), exact_cols >= 2 ? 0 : 1);
+                       ctx->d_prior_near.as<int>(), exact_cols >= 3 ? -1 : (exact_cols >= 2 ? 0 : 1));
   }
   {
     ProfScope ps(ctx->prof, "prior_gain_kernel", st);
