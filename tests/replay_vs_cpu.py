@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--cam-hz", type=float, default=10.0)
     ap.add_argument("--size", default="752x480", help="image size; 1280x720 with --points 500 --cam-hz 20 is BASELINE configs[3]")
     ap.add_argument("--points", type=int, default=250)
+    ap.add_argument("--fixed-intrinsics", action="store_true", help="bench settings but the intrinsics not in the state: the trackers (which undistort "
+                    "with the state's intrinsics before their RANSAC) are then fed identical inputs for the whole drive, and the comparison "
+                    "measures the update arithmetic alone")
     a = ap.parse_args()
     W, H = (int(v) for v in a.size.split("x"))
     sd.set_camera(W, H)
@@ -44,12 +47,13 @@ def main():
     gt = os.path.join(d, "gt.txt")
     lines = not a.no_lines
     res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered {a.size} images at {a.cam_hz:g} Hz, {a.points} points, 200 Hz IMU, 50 Hz wheel)",
-                     lines="on in both runs" if lines else "off in both runs"), {}
+                     lines="on in both runs" if lines else "off in both runs",
+                     intrinsics="fixed (not in the state)" if a.fixed_intrinsics else "calibrated online where the bench settings apply"), {}
     ctx = pkg.Context(pkg.default_config(W, H))
     # (the default invocation keeps round 2's configuration: 10 Hz clones, write_config's defaults; any other rate / size / point count
     # runs with bench.py's settings: clones at the camera rate, max_msckf 70, intrinsics calibrated online, sigma_px 1.5)
     default = (W, H) == (752, 480) and a.cam_hz == 10.0 and a.points == 250
-    cfg_kw = {} if default else dict(clone_freq=int(a.cam_hz), n_pts=a.points, max_msckf=70, calib_int=True, sigma_px=1.5)
+    cfg_kw = {} if default else dict(clone_freq=int(a.cam_hz), n_pts=a.points, max_msckf=70, calib_int=not a.fixed_intrinsics, sigma_px=1.5)
     for name, kw in (("hip", {}), ("cpu_oracle", dict(context_factory=oc.OracleContext, iw_initializer_factory=oc.OracleIwInitializer))):
         traj = os.path.join(d, "out", f"traj_{name}.txt")
         op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj, **cfg_kw))
