@@ -170,6 +170,60 @@ def _conditioned_case(ctx, oracle, cond, tol):
     assert e_lib < max(10 * e_orc, tol)
 
 
+def _unit_pivots(P, order):
+    """pivots of the Cholesky factorisation of P scaled to unit diagonal, states eliminated in `order`: the conditional variance of
+    every state given the ones before it, as a fraction of its variance"""
+    d = np.sqrt(np.diag(P))
+    A = (P / np.outer(d, d))[np.ix_(order, order)].astype(np.longdouble)
+    out = np.zeros(len(order))
+    for j in range(len(order)):
+        out[j] = float(A[j, j])
+        A[j + 1:, j] /= A[j, j]
+        A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j]) * A[j, j]
+    return out
+
+
+def test_whitened_update_keeps_small_conditional_variances(ctx, oracle):
+    """A window of clones as a running filter has it: every clone position is the one before plus 1e-9 of its variance (known to 3e-5
+    of the global position's uncertainty).  What an update must not lose is that conditional variance — the pivot of the covariance
+    scaled to unit diagonal.  The whitened update obtains W0 = M^-1 P[cols, :] by substitution through the factor's small pivots; its
+    columns of the update's own states are rows of the factor and are copied from it (dense_kernels.hip prior_exact_cols_kernel,
+    DESIGN 10.3): with them the posterior's small pivots agree with an extended-precision update to 1e-6 of themselves (measured
+    9.8e-7; the Givens oracle's P - K H P: 2.9e-7) — eps / pivot, the class of the reference's own form.  One update does not tell
+    the forms apart the way a drive does (the factor form, PLV_W0_EXACT=0, is at 2e-7 here and lost the covariance of a drive after
+    130 frames: test_gpu_replay.py test_covariance_pivots_follow_the_cpu_oracle); this test pins the default at the kernel."""
+    n, k, F, M = 60, 44, 12, 6
+    P0 = synth.spd_cov(n, seed=3)
+    cols = synth.col_map(n, k, seed=4, skip=15)
+    chain = [int(c) for c in cols[8:20]]                 # twelve states of the update's own columns, each "the one before + a little"
+    T = np.eye(n)
+    for a, b in zip(chain[:-1], chain[1:]):
+        T[b] = T[a]
+    P = T @ P0 @ T.T
+    for i, b in enumerate(chain[1:]):
+        for c in chain[i + 1:]:
+            for c2 in chain[i + 1:]:
+                P[c, c2] += 1e-9 * P0[chain[0], chain[0]]
+    P = 0.5 * (P + P.T)
+    rows, Hf, Hx, res = synth.msckf_batch(F=F, M=M, k=k, seed=5, outlier_frac=0.0)
+    q95 = synth.q95_table()
+    rc0, Pg, dx0, acc0, _ = oracle.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, q95, 1e6, 0.0)
+    rc1, P1, dx1, acc1, _ = ctx.msckf_update(P, rows, Hf, Hx, res, cols, 2.25, 1e6, 0.0)
+    _, route, _ = ctx.update_compression_mode()
+    assert rc0 == rc1 == 0 and np.array_equal(acc0, acc1) and acc1.all() and route == 4
+    Pt, dxt = _truth(P, rows, Hf, Hx, res, cols, acc1)
+    order = [int(c) for c in cols] + [i for i in range(n) if i not in set(int(c) for c in cols)]
+    pos = [order.index(b) for b in chain[1:]]
+    piv_prior = _unit_pivots(P, order)[pos]
+    piv_t, piv_l, piv_g = (_unit_pivots(X, order)[pos] for X in (Pt, P1, Pg))
+    e_l, e_g = np.abs(piv_l - piv_t) / piv_t, np.abs(piv_g - piv_t) / piv_t
+    print("small pivots of the prior %.2e .. %.2e, of the posterior %.2e .. %.2e; largest relative error: library %.2e, Givens oracle %.2e"
+          % (piv_prior.min(), piv_prior.max(), piv_t.min(), piv_t.max(), e_l.max(), e_g.max()))
+    assert piv_prior.max() < 1e-8 and piv_t.min() > 0
+    assert (piv_l > 0).all() and e_l.max() < 1e-5 and e_l.max() < max(30 * e_g.max(), 1e-6)
+    assert _rel(dx1, dxt) < 1e-8 and _rel(P1, Pt) < 1e-9
+
+
 def test_compression_reports_what_it_cannot_resolve(ctx, oracle, pkg):
     """cond 1e8: eps * cond^2 > 1, the Gram matrix has lost the weakest directions.  The library must not return a silently different
     filter: the factorisation reports the pivots it could not resolve, and in the automatic mode the update is redone by Householder
