@@ -420,7 +420,8 @@ __global__ void __launch_bounds__(64) prior_exact_cols_kernel(const double *__re
   const int j = blockIdx.x;
   double *dst = W0 + (size_t)cols[j] * ldw;
   const double *src = Lt + (size_t)j * ldl;
-  for (int c = threadIdx.x; c < k; c += 64) dst[c] = c <= j ? src[c] : 0.0;
+  if (Lt)  // (null: PLV_W0_EXACT=-1, round 3's form for comparison — the columns stay as substituted, no pivot selects the factor form)
+    for (int c = threadIdx.x; c < k; c += 64) dst[c] = c <= j ? src[c] : 0.0;
   if (j == 0 && threadIdx.x == 0) {
     n_near[4] = n_near[0];
     if (!near_selects) n_near[0] = 0;
@@ -435,12 +436,13 @@ int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, 
     return rc;
   if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
   // PLV_W0_EXACT (tools): 0 = round 4's first scheme (columns as substituted, near-dependent pivots select the factor form), 1 = exact
-  // columns but that selection; default 2; 3 = experiment: dead pivots do not select the factor form either
+  // columns but that selection; default 2; 3 = experiment: dead pivots do not select the factor form either;
+  // -1 = round 3's form: the whitened form always, every column as substituted
   static const int exact_cols = getenv("PLV_W0_EXACT") ? atoi(getenv("PLV_W0_EXACT")) : 2;
   if (exact_cols) {
     ProfScope ps(ctx->prof, "prior_exact_cols_kernel", st);
-    hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, ctx->d_Lt.as<double>(), k, k, d_cols, ctx->d_W0.as<double>(), k,
-                       ctx->d_prior_near.as<int>(), exact_cols >= 3 ? -1 : (exact_cols >= 2 ? 0 : 1));
+    hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, exact_cols < 0 ? (const double *)nullptr : ctx->d_Lt.as<double>(), k, k, d_cols,
+                       ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>(), (exact_cols >= 3 || exact_cols < 0) ? -1 : (exact_cols >= 2 ? 0 : 1));
   }
   {
     ProfScope ps(ctx->prof, "prior_gain_kernel", st);
