@@ -1227,10 +1227,9 @@ class Context:
         self._chk(self.lib.plv_camera_try_update(self.h, C.byref(st.c), C.byref(io)))
         return results()
 
-    def camera_frame(self, st, timestamp, slot=None, img=None, mask=None, use_lines=False, update=None):
-        """plv_camera_frame: tracker feed (+ vanishing points and line tracker feed) and, with update = dict(plus=, n=, max_msckf=,
-        max_obs=, t_prev_frame=, state_time=, ...) (the arguments of camera_try_update), the whole of try_update.  Returns
-        (points dict, lines dict, line database size) — (None, None, size) without an update."""
+    def camera_frame_prepare(self, st, timestamp, slot=None, img=None, mask=None, use_lines=False, update=None):
+        """The arguments of plv_camera_frame marshalled into their C structures (what a C++ caller holds already): returns the record
+        camera_frame_run / camera_frame_collect take."""
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
@@ -1242,11 +1241,30 @@ class Context:
         f = PlvCameraFrameIo(float(timestamp), -1 if slot is None else int(slot), img.ctypes.data if slot is None else None,
                              self.cfg.width, m.ctypes.data if m is not None else None, 1 if use_lines else 0,
                              C.addressof(io) if io is not None else None, 0)
-        self._chk(self.lib.plv_camera_frame(self.h, C.byref(st.c), C.byref(f)))
-        if results is None:
-            return None, None, f.line_db_size
-        pts, lns, _ = results()
-        return pts, lns, f.line_db_size
+        return dict(st=st, st_ref=C.byref(st.c), f=f, f_ref=C.byref(f), io=io, results=results, keep=(img, m), rc=None, rc_sync=None)
+
+    def camera_frame_run(self, prep, sync=False):
+        """plv_camera_frame (+ plv_ctx_synchronize): the C-ABI calls and nothing else (bench.py times exactly this)"""
+        prep["rc"] = self.lib.plv_camera_frame(self.h, prep["st_ref"], prep["f_ref"])
+        if sync:
+            prep["rc_sync"] = self.lib.plv_ctx_synchronize(self.h)
+
+    def camera_frame_collect(self, prep):
+        self._chk(prep["rc"])
+        if prep["rc_sync"] is not None:
+            self._chk(prep["rc_sync"])
+        if prep["results"] is None:
+            return None, None, prep["f"].line_db_size
+        pts, lns, _ = prep["results"]()
+        return pts, lns, prep["f"].line_db_size
+
+    def camera_frame(self, st, timestamp, slot=None, img=None, mask=None, use_lines=False, update=None):
+        """plv_camera_frame: tracker feed (+ vanishing points and line tracker feed) and, with update = dict(plus=, n=, max_msckf=,
+        max_obs=, t_prev_frame=, state_time=, ...) (the arguments of camera_try_update), the whole of try_update.  Returns
+        (points dict, lines dict, line database size) — (None, None, size) without an update."""
+        prep = self.camera_frame_prepare(st, timestamp, slot, img, mask, use_lines, update)
+        self.camera_frame_run(prep)
+        return self.camera_frame_collect(prep)
 
     # ---- lines (front-end)
     def detect_lines(self, which=0, cap=4096):

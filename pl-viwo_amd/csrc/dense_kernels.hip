@@ -494,33 +494,6 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     hipLaunchKernelGGL(ekf_dc_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, V, k, k, n, dC, n, d_dx, d_P, ldp, d_flag, ctx->skip_word,
                        ctx->d_dW.as<double>(), C1, d0, use_m);
   }
-  if (getenv("PLV_LAMBDA_DEBUG")) {
-    struct { int near, dead; double lam; int near_rec; } h;
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpy(&h, use_m, 20, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[plv lambda] k %d near %d (counted %d) dead %d largest diagonal of B %.4g\n", k, h.near, h.near_rec, h.dead, h.lam);
-    if (h.dead > 6 && getenv("PLV_PIVOT_DEBUG")) {
-      std::vector<double> Lt((size_t)k * k), Pd((size_t)n * n);
-      std::vector<int> hc(k);
-      (void)hipMemcpy(Lt.data(), ctx->d_Lt.p, Lt.size() * 8, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(Pd.data(), d_P, Pd.size() * 8, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hc.data(), d_cols, k * 4, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[plv pivots] (column: state, pivot of the unit-diagonal factor)");
-      for (int i = 0; i < k; ++i) fprintf(stderr, " %d:%d,%.2e", i, hc[i], Lt[(size_t)i * k + i] * Lt[(size_t)i * k + i] / Pd[(size_t)hc[i] * n + hc[i]]);
-      fprintf(stderr, "\n");
-    }
-    int fl = 0;
-    (void)hipMemcpy(&fl, d_flag, 4, hipMemcpyDeviceToHost);
-    if (fl) {
-      std::vector<double> Pd((size_t)n * n), dc((size_t)n * n);
-      (void)hipMemcpy(Pd.data(), d_P, Pd.size() * 8, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(dc.data(), dC, dc.size() * 8, hipMemcpyDeviceToHost);
-      for (int i = 0; i < n; ++i)
-        if (Pd[(size_t)i * n + i] - dc[(size_t)i * n + i] < 0)
-          fprintf(stderr, "[plv negdiag] status %d near %d lam %.3g state %d P_ii %.6g dC_ii %.6g (P' %.3g)\n", fl, h.near, h.lam, i, Pd[(size_t)i * n + i], dc[(size_t)i * n + i],
-                  Pd[(size_t)i * n + i] - dc[(size_t)i * n + i]);
-    }
-  }
   return launch_ekf_commit(ctx, d_P, n, ldp, dC, d_dx, d_flag, mirror_src, mirror_dst, mirror_bytes);
 }
 

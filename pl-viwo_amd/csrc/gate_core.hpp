@@ -26,7 +26,6 @@ struct GateLds {
   BcLdsT<2> bc;
   double ybuf[64];
   double passflag;
-  int cols[GATE_KMAX];
 };
 
 __device__ __forceinline__ double gate_wave_sum(double v) {  // (the butterfly of chi2_gate_kernel: same bits)
@@ -133,7 +132,7 @@ __device__ __forceinline__ void gate_tail(const GateStage &g, GateLds &L, const 
           if (gq < ngroups) {  // (uniform)
             double av[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = Hr[16 * gq + 4 * u];
+            for (int u = 0; u < 4; ++u) av[u] = (16 * gq + 4 * u + lq < k) ? Hr[16 * gq + 4 * u] : 0.0;  // (columns beyond k: whatever LDS holds there must not reach the MFMA, 0 * NaN = NaN)
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[4 * gq + u], acc, 0, 0, 0);
           }

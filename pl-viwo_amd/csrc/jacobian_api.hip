@@ -678,7 +678,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)L * 4));
-  TRY(us->bcols.reserve((size_t)k * 4));
+  TRY(us->bcols_l.reserve((size_t)k * 4));
   if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, L, ld - 6));  // (before the upload goes onto the stream)
   JacParams P{}, Pt{};
   bool fuse_tri = false;
@@ -718,7 +718,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   if (project) {
     // resident update path: build + project in one launch (the column map is published by its workgroup 0); when a covariance of
     // matching size is resident its gathers ride along
-    P.cols_out = us->bcols.as<int>();
+    P.cols_out = us->bcols_l.as<int>();
     bool can_gather = ctx->cov_n > 0;
     for (int j = 0; j < k && can_gather; ++j) can_gather = col_to_state[j] >= 0 && col_to_state[j] < ctx->cov_n;
     GatherArgs g{};
@@ -739,7 +739,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;
   } else {
-    PLV_HIP_CHECK(plv::memcpy_async(us->bcols.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(us->bcols_l.p, col_to_state, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch_line_jacobians(ctx, P));
   }
   us->bF = L;

@@ -245,7 +245,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   ctx->prof.destroy();
   plv::DevBuf *bufs[] = {&ctx->d_P, &ctx->d_P2, &ctx->d_H, &ctx->d_res, &ctx->d_cols, &ctx->d_Rdiag, &ctx->d_dx, &ctx->d_flag,
                          &ctx->d_Mt, &ctx->d_S, &ctx->d_W, &ctx->d_y, &ctx->d_fHf, &ctx->d_fHx, &ctx->d_fres,
-                         &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack2, &ctx->d_Pc, &ctx->d_Ps,
+                         &ctx->d_frows, &ctx->d_chi2, &ctx->d_acc, &ctx->d_stack, &ctx->d_stack_l, &ctx->d_stack2, &ctx->d_Pc, &ctx->d_Ps,
                          &ctx->d_inv, &ctx->d_T, &ctx->d_Lt, &ctx->d_W0, &ctx->d_dW, &ctx->d_Gs};
   for (auto *b : bufs) b->release();
   if (ctx->aux_stream) {
@@ -268,7 +268,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
       }
   }
   if (us) {
-    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->result_l, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bwork};
+    plv::DevBuf *ub[] = {&us->q95, &us->result, &us->result_l, &us->covck, &us->bHf, &us->bHx, &us->bres, &us->brows, &us->bcols, &us->bcols_l, &us->bwork};
     for (auto *b : ub) b->release();
     us->jin.release();
     us->tri.release();
@@ -625,12 +625,12 @@ int plv_feat_batch_upload(plv_ctx *ctx, int F, int fdim, int k, int ld, const in
   // pristine batch in ONE allocation [Hf | Hx | res] so that a single D2D restores the working copy
   TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
   TRY(us->brows.reserve((size_t)F * 4));
-  TRY(us->bcols.reserve((size_t)k * 4));
+  TRY(us->bcols_of(fdim).reserve((size_t)k * 4));
   TRY(h2d(ctx, us->bHf.p, Hf, nHf * 8));
   TRY(h2d(ctx, us->bHf.as<double>() + nHf, Hx, nHx * 8));
   TRY(h2d(ctx, us->bHf.as<double>() + nHf + nHx, res, nr * 8));
   TRY(h2d(ctx, us->brows.p, rows, (size_t)F * 4));
-  TRY(h2d(ctx, us->bcols.p, col_to_state, (size_t)k * 4));
+  TRY(h2d(ctx, us->bcols_of(fdim).p, col_to_state, (size_t)k * 4));
   us->bF = F;
   us->bfdim = fdim;
   us->bk = k;
@@ -660,7 +660,7 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
     return PLV_OK;
   const int nc = k + 1, Mtot = F * mp_max;
   TRY(ctx->d_chi2.reserve((size_t)F * 8));
-  TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
+  TRY(ctx->stack_of(fdim).reserve((size_t)Mtot * nc * 8));
   double *d_dx;
   int *d_flag;
   unsigned char *d_acc;
@@ -698,7 +698,7 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   g.acc_rows = d_acc_rows;
   g.n_acc = d_flag + aw.word;
   g.n_acc_next = d_flag + (3 - aw.word);
-  g.stack = ctx->d_stack.as<double>();
+  g.stack = ctx->stack_of(fdim).as<double>();
   g.lds = Mtot;
   g.mp_max = mp_max;
   g.stack_accepted_only = (Mtot > k && k <= 192 && (whitened_route(us, Mtot, k) || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
@@ -787,7 +787,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   const int nc = k + 1;
   const int Mtot = F * mp_max;
-  TRY(ctx->d_stack.reserve((size_t)Mtot * nc * 8));
+  TRY(ctx->stack_of(fdim).reserve((size_t)Mtot * nc * 8));
   size_t tmp_elems = (size_t)std::max(Mtot / (2 * nc) + 2, 16) * nc * nc;  // TSQR tree levels
   {  // Gram path: per-chunk partial tiles (64-row chunks, upper 16x16 tiles) + the reduced matrix
     const size_t nt = (size_t)(nc + 15) / 16, ntri = nt * (nt + 1) / 2;
@@ -837,14 +837,14 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   if (whiten && !prefetched) {
     TRY(aux_join());
     TRY(prior_mark(ctx, true));  // (us->bcols is written by the Jacobian launch queued on the main stream)
-    TRY(prior_start(ctx, us->bcols.as<int>(), k));
+    TRY(prior_start(ctx, us->bcols_of(fdim).as<int>(), k));
     aux_open = true;
   }
   if (!projected) {
     // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
-    TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols.as<int>()));
+    TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols_of(fdim).as<int>()));
   } else if (!gathers_valid) {
-    TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, us->bcols.as<int>(), k));
+    TRY(launch_gather_cov(ctx, ctx->d_P.as<double>(), n, n, us->bcols_of(fdim).as<int>(), k));
   }
   Chi2Args a{};
   a.P = ctx->d_P.as<double>();
@@ -855,7 +855,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.rows = us->brows.as<int>();
   a.Hx = wHx;
   a.res = wres;
-  a.cols = us->bcols.as<int>();
+  a.cols = us->bcols_of(fdim).as<int>();
   a.sigma2 = sigma2;
   a.chi2 = ctx->d_chi2.as<double>();
   a.dec = nullptr;
@@ -868,7 +868,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     a.dec = ctx->d_gate_dec_l.as<double>();
     ctx->dec_F_l = F;
   }
-  a.stack = ctx->d_stack.as<double>();
+  a.stack = ctx->stack_of(fdim).as<double>();
   a.lds = Mtot;
   a.mp_max = mp_max;
   a.chi2_mult = chi2_mult;
@@ -910,6 +910,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     us->acc_word_used = 1;
     TRY(launch_chi2(ctx, F, a, mp_max));
   }
+  us->last_route = 0;  // (before the probe's early return: a line update that ends at the gate must not report the point update's route)
+  us->redo.armed = false;
+  us->redo_w.armed = false;
   if (probe) {
     // the gate's verdicts are in pinned memory when its launch has finished: most line updates end here (three frames in four at
     // BASELINE configs[2] accept no line), without the six launches that would find nothing to do
@@ -932,9 +935,9 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   us->redo_w.armed = false;
   if (whiten) {
     // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
-    TRY(launch_gram_information(ctx, ctx->d_stack.as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
+    TRY(launch_gram_information(ctx, ctx->stack_of(fdim).as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
     TRY(aux_join());
-    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, us->bcols.as<int>(), d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
+    TRY(launch_ekf_whitened(ctx, ctx->d_P.as<double>(), n, n, k, us->bcols_of(fdim).as<int>(), d_dx, d_flag, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     us->last_route = 4;
     us->redo_w = plv_ctx_update_state::RedoW{!us->graph_mode, Mtot, k, n, F, mp_max, fdim, tmp_elems, rb, d_dx, d_flag, d_acc_rows};
     return PLV_OK;
@@ -945,7 +948,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     TRY(ctx->d_res.reserve((size_t)k * 8));
     int crc = PLV_E_CAPACITY;
     if (us->compress_mode != 1) {
-      crc = launch_gram_compress(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
+      crc = launch_gram_compress(ctx, ctx->stack_of(fdim).as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
                                  ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max, d_flag + 3);
       if (crc == PLV_OK) {
         us->last_route = 1;
@@ -963,7 +966,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     } else if (crc == PLV_E_CAPACITY) {  // too many columns for the LDS-resident factorisation: Householder TSQR
       double *R;
       int ldr;
-      TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
+      TRY(launch_tsqr(ctx, ctx->stack_of(fdim).as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
       dH = R;
       dr = R + (size_t)k * ldr;
       r = k;
@@ -973,23 +976,23 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       return crc;
     }
   } else {
-    dH = ctx->d_stack.as<double>();
+    dH = ctx->stack_of(fdim).as<double>();
     dr = dH + (size_t)k * Mtot;
     r = Mtot;
     ldh = Mtot;
   }
   if (ekf_fast_fits(r)) {  // (its last kernel mirrors the result block into h_pin: no copy command after the chain)
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true,
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols_of(fdim).as<int>(), dr, nullptr, d_dx, d_flag, true,
                         resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
     return PLV_OK;
   }
-  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols.as<int>(), dr, nullptr, d_dx, d_flag, true));
+  TRY(launch_ekf(ctx, ctx->d_P.as<double>(), n, n, dH, r, k, ldh, us->bcols_of(fdim).as<int>(), dr, nullptr, d_dx, d_flag, true));
   TRY(d2h(ctx, hpin.p, resbuf.p, rb));
     return PLV_OK;
   };
   if (us->graph_mode && !ctx->prof.on) {
     // (the skip word is chosen inside enqueue() from Mtot, k and d_flag: all functions of the key's own fields and of `result`)
-    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols.p, resbuf.p, hpin.p, ctx->mirror2_src, ctx->mirror2_dst,
+    plv_ctx_update_state::GraphKey key{ctx->d_P.p, wHf, us->brows.p, us->bcols_of(fdim).p, resbuf.p, hpin.p, ctx->mirror2_src, ctx->mirror2_dst,
                                        (const void *)(d_flag + 1), ctx->mirror2_bytes, F, fdim + 16 * (projected ? 1 : 0) + 32 * (gathers_valid ? 1 : 0), k, ld, n, mp_max,
                                        sigma2, chi2_mult, res_norm_gate, plv::alloc_epoch().load()};
     if (us->gexec && key == us->gkey) {
@@ -1078,7 +1081,7 @@ int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays) {
 int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accepted_rows, double *dx) {
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
-  const int F = us->pending_F, n = ctx->cov_n;
+  const int F = us->pending_F, n = ctx->cov_n, wfdim = us->pending_fdim;
   plv::PinBuf &hpin = ctx->res_pin(us->pending_fdim);
   if (F < 1 || !dx) {
     set_last_error("plv_msckf_update_resident_wait: nothing was launched");
@@ -1111,8 +1114,8 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     double *R;
     int ldr;
     const int nc = rd.k + 1;
-    TRY(launch_tsqr(ctx, ctx->d_stack.as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols.as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx,
+    TRY(launch_tsqr(ctx, ctx->stack_of(wfdim).as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols_of(wfdim).as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx,
                         rd.d_flag, true, us->result_of(us->pending_fdim).p, hpin.p, ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3));
     TRY(sync(ctx));
     ++ctx->gather_stamp;
@@ -1128,7 +1131,6 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     // so trying that compression first would only add its 0.1 ms to the 2 ms of this one).  Its verdict is the update's.
     const plv_ctx_update_state::RedoW rd = us->redo_w;
     us->redo_w.armed = false;
-    if (getenv("PLV_LAMBDA_DEBUG")) fprintf(stderr, "[plv redo] k %d status %d\n", rd.k, *(const int *)(hb + (size_t)n * 8));
     const int nc = rd.k + 1;
     const size_t mb = ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3;
     ctx->skip_word = nullptr, ctx->commit_veto = nullptr;
@@ -1140,9 +1142,9 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     for (int f = 0; f < rd.F; ++f) m_acc += std::max(hrows[f], 0);
     const int m_c = std::max(m_acc, 2 * nc);
     TRY(ctx->d_stackc.reserve((size_t)m_c * nc * 8));
-    TRY(launch_stack_compact(ctx, ctx->d_stack.as<double>(), rd.Mtot, nc, rd.d_acc_rows, rd.F, rd.mp_max, ctx->d_stackc.as<double>(), m_c));
+    TRY(launch_stack_compact(ctx, ctx->stack_of(wfdim).as<double>(), rd.Mtot, nc, rd.d_acc_rows, rd.F, rd.mp_max, ctx->d_stackc.as<double>(), m_c));
     TRY(launch_tsqr(ctx, ctx->d_stackc.as<double>(), m_c, m_c, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols.as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx, rd.d_flag,
+    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols_of(wfdim).as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx, rd.d_flag,
                         true, us->result_of(rd.fdim).p, hpin.p, mb));
     TRY(sync(ctx));
     us->last_route = 5;

@@ -435,6 +435,11 @@ struct plv_ctx {
   int dec_F = 0;          // entries of the last point batch whose values are in d_tri_dbg
   bool dec_gate = false;  // ... and in d_gate_dec: that batch reached a gate
   plv::DevBuf d_stack, d_stack2;            // stacked [H | r] and TSQR ping-pong
+  // The line half's stacked rows have their own buffer: a line launch chained behind a point update that is still running
+  // reserves its stack inside the point update's wait, and a reserve that grows frees the old block — the point update's re-run
+  // (plv_msckf_update_resident_wait: redo / redo_w) would read rows that are gone.
+  plv::DevBuf d_stack_l;
+  plv::DevBuf &stack_of(int fdim) { return fdim == 6 ? d_stack_l : d_stack; }
   // whitened route: prior factor Lp^T, W0 = Lp^-1 P[cols, :], W0^T W0 (side stream), information matrix [G | g] (main stream)
   plv::DevBuf d_Lt, d_W0, d_dW, d_Gs, d_GP, d_Y0, d_C1, d_stackc;
   plv::DevBuf d_prior_near;  // int: near-dependent pivots the last prior factor met (blocked_chol.hip, PLV_PRIOR_AMB)

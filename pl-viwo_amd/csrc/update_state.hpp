@@ -10,6 +10,8 @@ struct plv_ctx_update_state {
   plv::DevBuf covck;    // covariance checkpoint
   int covck_n = 0;      // dimension of the checkpointed covariance (a rollback restores it together with the data)
   plv::DevBuf bHf, bHx, bres, brows, bcols, bwork;  // staged feature batch ([Hf|Hx|res] in bHf) + working copy
+  plv::DevBuf bcols_l;                               // the line batch's column map (same reason as plv_ctx::d_stack_l)
+  plv::DevBuf &bcols_of(int fdim) { return fdim == 6 ? bcols_l : bcols; }
   int bF = 0, bfdim = 0, bk = 0, bld = 0, bmaxrows = 0;
   bool b_on_device_rows = false;  // rows[] produced on the device (plv_build_jacobians_resident)
   bool b_single_use = false;      // batch is rebuilt every frame: consume it in place, no working copy

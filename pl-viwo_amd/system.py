@@ -629,6 +629,62 @@ class SystemManager:
         return hzs[-1]
 
     # ---------------------------------------------------------------------------------------------- camera
+    def camera_prepare(self, t, img, mask=None, staged_slot=None, _bookkeeping_done=False):
+        """First third of feed_measurement_camera on the one-call path (plv_camera_frame): the frame-time bookkeeping and the call's
+        arguments marshalled into their C structures (the state view, the update options).  Returns the record camera_run /
+        camera_finish take, or None when this frame has to go the long way (feed_measurement_camera does that by itself).  bench.py
+        calls the three parts separately so that its timed region is the C-ABI call alone, as a C++ caller would make it."""
+        e, st = self.op.est, self.state
+        if not e.cam.enabled:
+            return None
+        if not (self.one_call_update and self.one_call_frame and e.cam.max_slam == 0 and not e.use_imu_res and not e.cam.downsample and not st.slam
+                and hasattr(self.ctx, "camera_frame")):
+            return None
+        if not _bookkeeping_done:
+            if st.initialized:
+                self.tc.ding("CAM")
+            if len(self.cam_t_hist) > 100:
+                self.cam_t_hist.pop(0)
+            self.cam_t_hist.append(float(t))
+        # feed_measurement + try_update in one library call (plv_camera_frame)
+        upd = None
+        args = self._try_update_args() if st.initialized else None
+        if self.decisions is not None and getattr(self.decisions, "probe_state", False) and args is not None:
+            self.decisions.states_pre.append((self.stats["frames"], self._state_probe(), self.ctx.cov_download(st.n) if hasattr(self.ctx, "cov_download") else None))
+        sv = st.view()
+        if args is not None:
+            pk, kw, max_msckf = args
+            upd = dict(plus=st._window_arrays()["plus"], n=st.n, max_msckf=max_msckf, max_obs=self.max_obs, lines=self.use_lines, **pk, **kw)
+        kw = dict(slot=staged_slot, img=img, mask=mask, use_lines=self.use_lines, update=upd)
+        if hasattr(self.ctx, "camera_frame_prepare"):
+            return dict(frame=self.ctx.camera_frame_prepare(sv, t, **kw))
+        return dict(frame=None, call=(sv, t, kw), out=None)      # (a context without the split: the CPU frame of tests/oracle_context.py)
+
+    def camera_run(self, prep, sync=True):
+        """plv_camera_frame + plv_ctx_synchronize on the prepared arguments"""
+        if prep["frame"] is not None:
+            self.ctx.camera_frame_run(prep["frame"], sync=sync)
+            return
+        sv, t, kw = prep["call"]
+        prep["out"] = self.ctx.camera_frame(sv, t, **kw)
+        if sync and hasattr(self.ctx, "synchronize"):
+            self.ctx.synchronize()
+
+    def camera_finish(self, prep):
+        """Last third: return codes checked, the update's results counted"""
+        st = self.state
+        out, lo, n_db = self.ctx.camera_frame_collect(prep["frame"]) if prep["frame"] is not None else prep["out"]
+        self._lines_in_flight = False
+        self.stats["frames"] += 1
+        if self.use_lines:
+            self.stats["lines_tracked"] += n_db
+        if out is not None:
+            self._count_points(out)
+            if lo is not None:
+                self._count_lines(lo)
+        if st.initialized:
+            self.tc.dong("CAM")
+
     def feed_measurement_camera(self, t, img, mask=None, staged_slot=None):
         """UpdaterCamera::feed_measurement + try_update (REF: UpdaterCamera.cpp:77-195).  staged_slot: the image already sits in that
         HBM slot of the context (Context.image_stage); `img` is then not read."""
@@ -640,30 +696,12 @@ class SystemManager:
         if len(self.cam_t_hist) > 100:
             self.cam_t_hist.pop(0)
         self.cam_t_hist.append(float(t))
-        if (self.one_call_update and self.one_call_frame and e.cam.max_slam == 0 and not e.use_imu_res and not e.cam.downsample and not st.slam
-                and hasattr(self.ctx, "camera_frame")):
-            # feed_measurement + try_update in one library call (plv_camera_frame)
-            upd = None
-            args = self._try_update_args() if st.initialized else None
-            if self.decisions is not None and getattr(self.decisions, "probe_state", False) and args is not None:
-                self.decisions.states_pre.append((self.stats["frames"], self._state_probe(), self.ctx.cov_download(st.n) if hasattr(self.ctx, "cov_download") else None))
-            sv = st.view()
-            if args is not None:
-                pk, kw, max_msckf = args
-                upd = dict(plus=st._window_arrays()["plus"], n=st.n, max_msckf=max_msckf, max_obs=self.max_obs, lines=self.use_lines, **pk, **kw)
+        prep = self.camera_prepare(t, img, mask, staged_slot, _bookkeeping_done=True)
+        if prep is not None:
             self.tc.ding("[Time-Cam] feed measurement + try_update")
-            out, lo, n_db = self.ctx.camera_frame(sv, t, slot=staged_slot, img=img, mask=mask, use_lines=self.use_lines, update=upd)
+            self.camera_run(prep, sync=False)
             self.tc.dong("[Time-Cam] feed measurement + try_update")
-            self._lines_in_flight = False
-            self.stats["frames"] += 1
-            if self.use_lines:
-                self.stats["lines_tracked"] += n_db
-            if out is not None:
-                self._count_points(out)
-                if lo is not None:
-                    self._count_lines(lo)
-            if st.initialized:
-                self.tc.dong("CAM")
+            self.camera_finish(prep)
             return
         self.tc.ding("[Time-Cam] feed measurement: points")      # labels of UpdaterCamera.cpp:79-190
         if staged_slot is not None and not e.cam.downsample:

@@ -8,6 +8,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+FRAME_LIB = None   # bench.py's cpu_baseline: another build of the same sources for FrameOracle only (build_native: -march=native, timing)
+
+
+def build_native(out_dir):
+    """oracle/*.cpp compiled for the machine this runs on (-O3 -march=native, contraction allowed): used by bench.py's cpu_baseline for
+    TIMING only (SURVEY 8(d) / BASELINE.md ask for -march=native); the parity tests keep liboracle.so (-ffp-contract=off).  Returns
+    the path, or None when the compiler is missing or fails."""
+    import glob
+    out = os.path.join(out_dir, "liboracle_native.so")
+    cmd = ["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-Wno-unused-function", "-shared", "-o", out] + \
+        sorted(glob.glob(os.path.join(ORACLE_DIR, "*.cpp"))) + ["-lpthread"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return out
 
 dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
 
@@ -671,7 +687,7 @@ class FrameOracle:
     def __init__(self, pkg, cfg, q95):
         load()
         self.pkg, self.cfg = pkg, cfg
-        self.lib = L = _inst.lib
+        self.lib = L = C.CDLL(FRAME_LIB) if FRAME_LIB else _inst.lib
         vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
         L.orc_frame_create.restype = vp
         L.orc_frame_create.argtypes = [vp, dp, C.c_int]

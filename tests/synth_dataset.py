@@ -30,6 +30,7 @@ def set_camera(width=752, height=480):
         sx = W / 752.0
         K8[:4] = K8[0] * sx, K8[1] * sx, W / 2.0 + 7.0, H / 2.0 + 8.5
 RADIUS, WALL_R, WALL_H = 8.0, 21.0, 9.0
+BOULEVARD = dict(wall_r=6.5)   # "boulevard" style: overrides of _mips_boulevard's bar geometry (texels of 0.012 m)
 RL, RR, BASE = 0.31, 0.305, 1.52
 # IMU: mounted flat (z up), 0.9 m above the odometry frame, slightly yawed.  wheel_extrinsic = (R_ItoO, p_IinO)
 R_ITOO = Rotation.from_rotvec([0.0, 0.0, 0.02]).as_matrix()
@@ -37,6 +38,13 @@ P_IINO = np.array([0.35, -0.05, 0.9])
 # camera: z forward (body x), x right (-body y), y down (-body z), pitched 12 deg down, 0.4 m ahead of and above the IMU
 R_CTOI = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]]) @ Rotation.from_rotvec([np.deg2rad(12.0), 0, 0]).as_matrix()
 P_CINI = np.array([0.4, 0.02, 0.35])
+
+
+def set_mount(pitch_down_deg=12.0, yaw_right_deg=0.0):
+    """Camera mount (module-wide, like set_camera): pitched down and yawed to the right of the driving direction."""
+    global R_CTOI
+    R_CTOI = (np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]]) @ Rotation.from_rotvec([0, np.deg2rad(yaw_right_deg), 0]).as_matrix()
+              @ Rotation.from_rotvec([np.deg2rad(pitch_down_deg), 0, 0]).as_matrix())
 BG, BA = np.array([0.003, -0.002, 0.0015]), np.array([0.03, -0.02, 0.025])
 SIG = dict(gyro_noise=1.7e-4, gyro_bias=1.9e-5, accel_noise=2.0e-3, accel_bias=3.0e-3)
 
@@ -164,6 +172,49 @@ def _mips_street(seed, ground=False, dense=False):
     return out
 
 
+def _mips_boulevard(seed, plain=False, angle=24.0, pitch=16.0, cell=104.0, joint=9.0, zig=4.2, period=(13.0, 21.0), **_):
+    """"boulevard" style wall texture (the round-5 bench scene, BASELINE configs[2] with the metric's 80 kept lines): slanted courses of
+    two-tone strips (`pitch` texels = 0.19 m wide, `angle` degrees off the horizontal; upper half bright, lower half dark, the boundary
+    between the halves an irregular zigzag), cut into ~1.2 m pieces by narrow joints of the background tone, each piece with its own
+    offset across the slant.  The straight edges are the course boundaries (dark above, bright below, all stepping the same way); the
+    zigzag boundary yields no straight segment, and its teeth put corners within 5 px of the course boundaries, away from their ends.
+    Why: FastLineDetector orients a segment by the brightness of its two sides, and TrackLSD::AssignPointToLines' bounding-box test
+    (with its end-point mix-up, TrackLSD.cpp:754-765) passes a point of a segment only when the segment runs up-left in the image's
+    x > y part (down-right in the x < y part) and the point is not beyond the segment's ends.  With random polarity and mostly
+    axis-parallel edges two thirds of the segments that own a tracked point are dropped ('avenue': 190 detected, 95 with a point, 32
+    kept per frame); here the side-looking camera of the boulevard drive sees every course boundary run up-left with the darker side
+    on its upper right.  `plain`: the background only (ground and ceiling)."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    n = 2048 - 128
+    base = ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 48.0, mode="wrap")
+    base = 0.5 + 0.05 * base / np.abs(base).max() + 0.003 * ndi.gaussian_filter(rng.normal(0, 1, (n, n)), 1.2, mode="wrap") / 0.2
+    if not plain:
+        th = np.deg2rad(angle)
+        X, Y = np.meshgrid(np.arange(n) + 0.5, np.arange(n) + 0.5)       # texture u (columns), v (rows; up on a wall)
+        al, ac = X * np.cos(th) + Y * np.sin(th), -X * np.sin(th) + Y * np.cos(th)
+        ci = np.floor(al / cell).astype(int)
+        c0, ncell = ci.min(), ci.max() - ci.min() + 1
+        ac = ac + rng.uniform(0, pitch, ncell)[ci - c0]                    # every piece column has its own offset across the slant
+        row = np.floor(ac / pitch).astype(int)
+        bb = ac - row * pitch
+        r0, nr = row.min(), row.max() - row.min() + 1
+        key = (row - r0) * ncell + (ci - c0)                                # one strip piece
+        T = rng.uniform(*period, nr * ncell)[key]
+        ph = rng.uniform(0, 1.0, nr * ncell)[key]
+        hi, lo = (0.5 + rng.uniform(0.3, 0.42, nr * ncell))[key], (0.5 - rng.uniform(0.3, 0.42, nr * ncell))[key]
+        x = al / T + ph + 0.35 * np.sin(al / 57.0 + 6.28 * ph)
+        tri = 2.0 * np.abs(2.0 * (x - np.floor(x + 0.5))) - 1.0           # triangle wave in [-1, 1]
+        strip = np.where(bb > 0.5 * pitch + zig * tri, hi, lo)
+        base = np.where(al - ci * cell < joint, base, strip)
+    base = np.clip(ndi.gaussian_filter(base, 0.7, mode="wrap"), 0, 1)
+    out = [base]
+    while out[-1].shape[0] > 16:
+        a = out[-1]
+        out.append(0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2]))
+    return out
+
+
 def _sample(mips, u, v, level):
     """bilinear lookup of texel coordinates (u, v) of level 0 at the mip level chosen per pixel, wrapping around"""
     out = np.zeros(u.shape)
@@ -188,10 +239,14 @@ class Renderer:
         panels / windows and a paved ground (_mips_street), 7 m high with a ceiling instead of the empty sky"""
         self.rays = _undistorted_rays().reshape(-1, 3)
         self.style = style
-        if style in ("street", "avenue"):           # "avenue": the street with twice the structure (the round-3 bench scene)
+        self.mirror = False
+        if style in ("street", "avenue", "boulevard"):   # "avenue": the street with twice the structure (the round-3 bench scene)
             dense = style == "avenue"
-            self.ground, self.wall = _mips_street(seed, ground=True, dense=dense), _mips_street(seed + 1, dense=dense)
-            self.wall_r, self.wall_h = 9.0, 7.0
+            if style == "boulevard":                # slanted ramp-shaded bars on the walls, plain ground and ceiling (_mips_boulevard)
+                self.ground, self.wall = _mips_boulevard(seed, plain=True), _mips_boulevard(seed + 1, **BOULEVARD)
+            else:
+                self.ground, self.wall = _mips_street(seed, ground=True, dense=dense), _mips_street(seed + 1, dense=dense)
+            self.wall_r, self.wall_h = (BOULEVARD.get("wall_r", 9.0), 7.0) if style == "boulevard" else (9.0, 7.0)
             self.style = "street"
         else:
             self.ground, self.wall = _mips(seed), _mips(seed + 1)
@@ -246,12 +301,16 @@ class Renderer:
                 mips = self.ground
                 off = 0.0 if which == 0 else 777.0
                 u, v = p[:, 0] / self.TEXEL + off, p[:, 1] / self.TEXEL + 2 * off
+                if self.mirror and which == 5:
+                    u = -u
                 cosi = np.abs(d[hit, 2])
             else:
                 axis, sign = walls[which - 1]
                 mips = self.wall
                 along = (p[:, 1] - (0.0 if self.style == "street" else RADIUS)) if axis == 0 else p[:, 0]
                 u, v = (along + 2.0 * self.wall_r * which) / self.TEXEL, p[:, 2] / self.TEXEL
+                if self.mirror and sign < 0:
+                    u = -u
                 cosi = np.abs(d[hit, axis])
             foot = dist / self.f / np.maximum(cosi, 0.15)
             level = np.log2(np.maximum(foot / self.TEXEL, 1.0))
@@ -420,7 +479,7 @@ def simulate(seconds=12.0, cam_hz=10.0, imu_hz=200.0, wheel_hz=50.0, seed=0, res
     """The sensor streams of the synthetic drive, in memory: imu (t, wm, am), wheel (t, m1, m2), cam_times, gt (t, p, q)."""
     global REST, PATH
     REST = float(rest)
-    PATH = "street" if style in ("street", "avenue") else "circle"
+    PATH = "street" if style in ("street", "avenue", "boulevard") else "circle"
     rng = np.random.default_rng(seed)
     t, wm, am = synth.imu_stream(imu_pose, 0.0, seconds + 0.1, rate=imu_hz, bg=BG, ba=BA)
     wm = wm + rng.normal(0, SIG["gyro_noise"] * np.sqrt(imu_hz), wm.shape)
@@ -451,7 +510,7 @@ def _render_one(x):
 def render_frames(times, style="room", workers=1, seed=7):
     """The camera images at `times`; workers > 1 renders in forked processes (call before anything initialises the GPU)."""
     global _POOL_RD, PATH
-    PATH = "street" if style in ("street", "avenue") else "circle"
+    PATH = "street" if style in ("street", "avenue", "boulevard") else "circle"
     _POOL_RD = Renderer(seed=seed, style=style)
     if workers <= 1 or len(times) < 4:
         return [_POOL_RD.render(x) for x in times]
