@@ -110,6 +110,11 @@ struct LineTracker {
   std::unordered_map<uint64_t, LineTrack> db;
   // device buffers of the detector
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
+  // Component labels of the edge map (line_kernels.hip ccl_*_kernel) for the worker's host stage: formed on a stream of their own behind
+  // the edge kernel, next to the point front-end's flow; the worker waits for labels_ready before it splits the detection by them
+  DevBuf lab;
+  hipStream_t ccl_stream = nullptr;
+  hipEvent_t canny_done = nullptr, labels_ready = nullptr;
   PinBuf pin;
   hipEvent_t edges_ready = nullptr;  // plv_line_detect_launch: the maps of image `pending_which` are on their way to the host
   // measurement knob PLV_KNOB_EDGES_SIDE: the edge kernel of a prefetched detection on its own stream, behind the pyramid only
@@ -213,6 +218,7 @@ void line_worker(LineTracker *T) {
     (void)hipSetDevice(T->job.device);
     int rc = PLV_OK;
     if (plv::event_sync(T->edges_ready) != hipSuccess) rc = PLV_E_DEVICE;  // the two maps are on the host
+    if (rc == PLV_OK && T->job.hlab && plv::event_sync(T->labels_ready) != hipSuccess) rc = PLV_E_DEVICE;  // ... and the component labels
     auto W1 = std::chrono::steady_clock::now();
     if (rc == PLV_OK) rc = host_extract(&T->host, T->job, timing);
     {
@@ -309,7 +315,8 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
                kChainCap,             T->counts.as<int>(),  T->segs.as<float4>(), T->seg_count.as<int>()};
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
-  TRY(T->pin.reserve(bytes + std::max(slot_cap * sizeof(float4), npix * (2 + sizeof(int2)) + 64)));
+  const size_t lab_off = bytes + ((2 * npix + 63) & ~(size_t)63) + npix * sizeof(int2);  // (behind the host stage's chain points)
+  TRY(T->pin.reserve(std::max(bytes + slot_cap * sizeof(float4), lab_off + npix + 64)));
   char *hp = T->pin.as<char>();
   // host walk without hysteresis (the shipped thresholds are equal): the edge kernel writes the two maps straight into the pinned
   // buffer the host stage reads — no device copies of them, no copy commands behind the kernel
@@ -318,6 +325,15 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     b.map = (uint8_t *)(hp + bytes);
     b.half = b.map + npix;
   }
+  // the worker's host stage splits its work by the components of the edge map when the device labels them (PLV_LINE_LABELS=0: it walks
+  // the map as one sequence, as rounds 2-4 did)
+  static const bool labels_off = getenv("PLV_LINE_LABELS") && atoi(getenv("PLV_LINE_LABELS")) == 0;
+  const bool with_labels = launch_only && maps_to_host && !labels_off;
+  if (with_labels) {
+    TRY(T->lab.reserve(npix * sizeof(int)));
+    b.lab_work = T->lab.as<int>();
+    b.lab_out = (uint8_t *)(hp + lab_off);
+  }
   hipStream_t es = ctx->stream;
   if (launch_only && maps_to_host && T->edge_fork) {
     PLV_HIP_CHECK(hipStreamWaitEvent(T->edge_stream, T->pyr_done, 0));
@@ -325,6 +341,17 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   }
   T->edge_fork = false;
   if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es, early ? T->early_hist : nullptr));
+  if (with_labels) {
+    if (!T->ccl_stream) {
+      PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->ccl_stream, hipStreamNonBlocking));
+      PLV_HIP_CHECK(hipEventCreateWithFlags(&T->canny_done, hipEventDisableTiming));
+      PLV_HIP_CHECK(hipEventCreateWithFlags(&T->labels_ready, hipEventDisableTiming));
+    }
+    PLV_HIP_CHECK(hipEventRecord(T->canny_done, es));
+    PLV_HIP_CHECK(hipStreamWaitEvent(T->ccl_stream, T->canny_done, 0));
+    TRY(launch_line_labels(ctx, w, h, plv::linehost::Fit::kParts, b, T->ccl_stream));
+    PLV_HIP_CHECK(hipEventRecord(T->labels_ready, T->ccl_stream));
+  }
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
   auto emit = [&](const float4 &sg) {
     const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
@@ -357,6 +384,8 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     J.hmap = hmap, J.hhalf = hmap + npix;
     J.hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
     J.hc = (FldChain *)(hp + 16);
+    J.hlab = with_labels ? b.lab_out : nullptr;
+    J.parts = with_labels ? plv::linehost::Fit::kParts : 0;
     if (!maps_to_host) {
       PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
       PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
@@ -445,11 +474,14 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
       T->worker.join();
     }
     // (the fitter threads end with T->host: ~HostStage)
-    DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out};
+    DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out, &T->lab};
     for (DevBuf *b : bufs) b->release();
     T->pin.release();
     if (T->edges_ready) (void)hipEventDestroy(T->edges_ready);
     if (T->pyr_done) (void)hipEventDestroy(T->pyr_done);
+    if (T->canny_done) (void)hipEventDestroy(T->canny_done);
+    if (T->labels_ready) (void)hipEventDestroy(T->labels_ready);
+    if (T->ccl_stream) (void)hipStreamDestroy(T->ccl_stream);
     if (T->edge_stream) (void)hipStreamDestroy(T->edge_stream);
     delete T;
     g_lt.erase(it);

@@ -27,6 +27,10 @@ struct Job {
   int device = 0, w = 0, h = 0, length_threshold = 0;
   float distance_threshold = 0, thr2 = 0;
   const uint8_t *hmap = nullptr, *hhalf = nullptr;
+  // Component labels of the edge pixels (ccl_merge_kernel + ccl_flatten_kernel, line_kernels.hip): 0 = not an edge, else 1 + (a hash of
+  // the root of the pixel's 8-connected component) % parts.  With them the host stage splits the detection by components (host_extract).
+  const uint8_t *hlab = nullptr;
+  int parts = 0;
   int2 *hpts = nullptr;
   FldChain *hc = nullptr;
   std::vector<float> lines;
@@ -35,11 +39,26 @@ struct Job {
 
 // Second half of the host stage on threads of their own (see host_extract)
 struct Fit {
-  static const int kThreads = 2;  // (the fit is ~1.15x the walk: two fitters keep pace with it, the walking thread joins in at its end)
+  static const int kThreads = 7;  // helper threads next to the walking thread (fit_threads() says how many a job uses)
+  static const int kParts = 16;   // parts a labelled detection is split into (Job::parts <= kParts)
   std::thread th[kThreads];
   std::mutex m;
   std::condition_variable cv;
-  int gen = 0, done_gen[kThreads] = {0, 0};  // a job = a new generation; thread i reports the last one it finished
+  int gen = 0, done_gen[kThreads] = {0, 0, 0, 0, 0, 0, 0};  // a job = a new generation; thread i reports the last one it finished
+  // A labelled job (Job::hlab): its parts are claimed here by the walking thread and the helpers; a part = the components whose
+  // label it is, walked and fitted by the thread that claimed it (detect_part) into part[p]
+  bool by_parts = false;  // (guarded by m, read together with gen and job)
+  alignas(64) std::atomic<int> next_part{0};
+  struct PartOut {
+    std::vector<int> seed, seg_at, seg_n;  // per chain: raster index of its seed, first segment, segments
+    std::vector<float4> segs;
+    int chains = 0;
+  } part[kParts];
+  struct Scratch {  // one per thread (index 0: the walking thread)
+    std::vector<uint8_t> pad;
+    std::vector<int2> pts;
+    std::vector<FldChain> chains;
+  } scratch[kThreads + 1];
   bool quit = false;
   const Job *job = nullptr;
   int nfit_job = 0;  // fitter threads the current job uses (thread i takes part when i < nfit_job); guarded by m: a thread reads it
@@ -83,7 +102,7 @@ inline std::atomic<int> &spin_budget_us() {
 // afterwards).  host_extract takes one of them for a small map and both for a large one (see there).  Whole runs at workload C: 0.56 ms
 // per frame with one or two, 0.70 ms with none (without a fitter the worker finishes after the point update and the caller waits for it).
 inline std::atomic<int> &fit_threads() {
-  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min(2, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 2};
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min((int)Fit::kThreads, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 7};
   return v;
 }
 template <class Pred>
@@ -118,9 +137,10 @@ inline float point_line_distance(const float *line, float x0, float y0) {
 // FastLineDetector's seed loop + getPointChain on a host copy of the Canny map (2 = edge).  Same
 // algorithm as fld_walk_kernel; see detect() for why the default runs it here.  The map is copied into a
 // buffer with a one-pixel non-edge border so that the eight neighbour tests need no bounds checks.
+inline void walk_padded(uint8_t *m, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
+                        std::atomic<int> *published = nullptr);
 inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
                  std::vector<uint8_t> &pad, std::atomic<int> *published = nullptr) {
-  static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
   const int pw = w + 2;
   // bordered copy of the map (border = 1: never an edge)
   pad.resize((size_t)pw * (h + 2));
@@ -133,6 +153,13 @@ inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, 
     memcpy(row + 1, map + (size_t)r * w, w);
     row[w + 1] = 1;
   }
+  walk_padded(m, w, h, length_threshold, pts, chains, chain_cap, counts, published);
+}
+// (the walk proper, on a map with a one-pixel border that is never an edge; it clears what it consumes)
+inline void walk_padded(uint8_t *m, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
+                        std::atomic<int> *published) {
+  static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
+  const int pw = w + 2;
   int off[8];
   for (int i = 0; i < 8; ++i) off[i] = dy[i] * pw + dx[i];
   int n_chain = 0, n_slot = 0, n_pts = 0;
@@ -213,19 +240,58 @@ inline void fit_one(Fit &F, const Job &J, int c) {
                          F.segs.data() + J.hc[c].slot);
 }
 
+// One part of a labelled detection: the components whose label is `p + 1`, alone on a map of their own — a pixel's eight neighbours
+// that are edges lie in its own component, and the walk only ever reads and clears those, so the raster walk over this map yields
+// exactly the chains the raster walk over the whole map yields inside these components, in the same order; the segments of a chain
+// depend on nothing but the chain.  The caller puts the parts' chains back into the raster order of their seeds.
+inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S) {
+  const int w = J.w, h = J.h, pw = w + 2;
+  S.pad.resize((size_t)pw * (h + 2));
+  uint8_t *m = S.pad.data();
+  memset(m, 1, (size_t)pw);
+  memset(m + (size_t)(h + 1) * pw, 1, (size_t)pw);
+  const uint8_t want = (uint8_t)(p + 1);
+  for (int r = 0; r < h; ++r) {
+    uint8_t *row = m + (size_t)(r + 1) * pw;
+    const uint8_t *lr = J.hlab + (size_t)r * w;
+    row[0] = 1;
+    for (int x = 0; x < w; ++x) row[x + 1] = (uint8_t)(1 + (lr[x] == want));
+    row[w + 1] = 1;
+  }
+  S.pts.resize((size_t)w * h);
+  S.chains.resize(kChainCap);
+  int counts[4] = {0, 0, 0, 0};
+  walk_padded(m, w, h, J.length_threshold, S.pts.data(), S.chains.data(), kChainCap, counts);
+  Fit::PartOut &O = F.part[p];
+  O.chains = counts[0];
+  O.seed.resize(counts[0]), O.seg_at.resize(counts[0]), O.seg_n.resize(counts[0]);
+  O.segs.resize((size_t)counts[1] + 1);
+  for (int c = 0; c < counts[0] && c < kChainCap; ++c) {
+    const FldChain &ch = S.chains[c];
+    O.seed[c] = S.pts[ch.start].y * w + S.pts[ch.start].x;
+    O.seg_at[c] = ch.slot;
+    O.seg_n[c] = fit_chain(J.hhalf, w, h, J.length_threshold, J.distance_threshold, S.pts.data() + ch.start, ch.len, O.segs.data() + ch.slot);
+  }
+}
+inline void claim_parts(Fit &F, const Job &J, int slot) {
+  for (int p; (p = F.next_part.fetch_add(1, std::memory_order_relaxed)) < J.parts;) detect_part(F, J, p, F.scratch[slot]);
+}
+
 inline void fit_worker(HostStage *T, int me, int seen /* the generation current when the thread was made: it waits for the next */) {
   Fit &F = T->fit;
   for (;;) {
     const Job *job;
     int nfit;
+    bool by_parts;
     {
       std::unique_lock<std::mutex> lk(F.m);
       wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
       if (F.quit) return;
-      seen = F.gen, job = F.job, nfit = F.nfit_job;
+      seen = F.gen, job = F.job, nfit = F.nfit_job, by_parts = F.by_parts;
     }
     const Job &J = *job;
-    for (; me < nfit;) {  // (a thread this job does not count takes nothing and is not waited for)
+    if (by_parts && me < nfit) claim_parts(F, J, me + 1);
+    for (; !by_parts && me < nfit;) {  // (a thread this job does not count takes nothing and is not waited for)
       const int avail = F.published.load(std::memory_order_acquire);
       const int c = claim_chain(F, avail);
       if (c >= 0) {
@@ -257,7 +323,12 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   // worker's path decides whether the line launch can be chained behind the point update (tracker_api.hip poll_line_pool), so the
   // second fitter joins at configs[2] as well: alternating frame by frame -9 us on the mean and -80 .. -130 us on p99
   // (bench.py --alternate-fit 1,2).  Tiny maps keep one: every hand-over between threads is a chance of a delayed wake-up.
-  const int nfit = std::min(fit_threads().load(std::memory_order_relaxed), (size_t)J.w * J.h >= 60000 ? 2 : 1);
+  // A labelled job is split by components over the walking thread and every configured helper (detect_part); without labels the walk
+  // is one sequence and the helpers only grow segments behind it.
+  const bool by_parts = J.hlab != nullptr && J.parts >= 1 && J.parts <= Fit::kParts;
+  const int nfit = by_parts ? std::min(fit_threads().load(std::memory_order_relaxed), J.parts - 1)
+                            : std::min(std::min(fit_threads().load(std::memory_order_relaxed), 2), (size_t)J.w * J.h >= 60000 ? 2 : 1);
+  F.next_part.store(0, std::memory_order_relaxed);
   {
     int gen_now;
     {
@@ -272,13 +343,19 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     std::lock_guard<std::mutex> lk(F.m);
     F.job = &J;
     F.nfit_job = nfit;
+    F.by_parts = by_parts;
     gen = ++F.gen;
   }
   F.cv.notify_all();
-  walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
-  F.walk_done.store(true, std::memory_order_release);
+  if (by_parts) {
+    claim_parts(F, J, 0);
+  } else {
+    walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
+    F.walk_done.store(true, std::memory_order_release);
+  }
   auto T2 = std::chrono::steady_clock::now();
-  for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
+  if (!by_parts)
+    for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
   {
     std::unique_lock<std::mutex> lk(F.m);
     wait_polling(lk, F.cv, [&] {
@@ -288,11 +365,36 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     });
   }
   J.lines.clear();
-  if (hcounts[0] >= kChainCap) {
+  if (by_parts) {
+    // the parts' chains back in the raster order of their seeds = the detector's output order
+    int total = 0;
+    for (int p = 0; p < J.parts; ++p) total += F.part[p].chains;
+    if (total >= kChainCap) {
+      set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
+      return PLV_E_CAPACITY;
+    }
+    std::vector<std::pair<int, int>> order;  // (seed, part << 16 | chain)
+    order.reserve(total);
+    for (int p = 0; p < J.parts; ++p)
+      for (int c = 0; c < F.part[p].chains; ++c) order.emplace_back(F.part[p].seed[c], (p << 16) | c);
+    std::sort(order.begin(), order.end());
+    for (const auto &o : order) {
+      const Fit::PartOut &O = F.part[o.second >> 16];
+      const int c = o.second & 0xffff;
+      for (int q = 0; q < O.seg_n[c]; ++q) {
+        const float4 &sg = O.segs[O.seg_at[c] + q];
+        const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+        const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+        if (!(l2 > J.thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+        J.lines.insert(J.lines.end(), {x1, y1, x2, y2});
+      }
+    }
+    hcounts[0] = total;
+  } else if (hcounts[0] >= kChainCap) {
     set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
     return PLV_E_CAPACITY;
   }
-  for (int c = 0; c < hcounts[0]; ++c) {
+  for (int c = 0; !by_parts && c < hcounts[0]; ++c) {
     const float4 *seg = F.segs.data() + J.hc[c].slot;
     for (int q = 0; q < F.seg_n[c]; ++q) {
       const float4 &sg = seg[q];

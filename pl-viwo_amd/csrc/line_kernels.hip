@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ s
 template <bool FULL>
 __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int fw, int w, int h, int low, int high,
                                                             uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */,
-                                                            uint8_t *__restrict__ half_out, const unsigned *__restrict__ hist, int npix_full) {
+                                                            uint8_t *__restrict__ half_out, const unsigned *__restrict__ hist, int npix_full,
+                                                            int *__restrict__ lab_init /* nullable: own index for an edge, -1 else (ccl_*_kernel) */) {
   __shared__ int px[CN_T + 4][CN_T + 4];
   __shared__ int mg[CN_T + 2][CN_T + 2];
   __shared__ unsigned cdf[16];
@@ -103,6 +104,54 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
   // FastLineDetector clears the top-left 6x6 and the bottom-right 5x5 corner of the edge map
   if ((x < 6 && y < 6) || (x >= w - 5 && y >= h - 5)) out = 1;
   map[(size_t)y * w + x] = out;
+  if (lab_init) lab_init[(size_t)y * w + x] = out == 2 ? y * w + x : -1;
+}
+
+// ------------------------------------------------------------------------------------------ component labels
+// 8-connected components of the edge map by union-find on the device (label equivalence with atomicMin: Playne & Hawick's scheme):
+// L[i] = i for an edge pixel (canny_kernel), ccl_merge_kernel unites every edge pixel with its W / NW / N / NE neighbours, and
+// ccl_flatten_kernel writes, for every pixel, 0 (not an edge) or 1 + hash(root) % parts into the host-visible label map — the root of
+// a component is its smallest pixel index.  The host stage of the detector splits its work by these labels (line_host.hpp
+// detect_part): the chain walk never leaves a component, so components can be walked independently of each other.
+__device__ __forceinline__ int ccl_find(const int *L, int i) {
+  for (;;) {
+    const int p = __atomic_load_n(L + i, __ATOMIC_RELAXED);
+    if (p == i) return i;
+    i = p;
+  }
+}
+__device__ __forceinline__ void ccl_union(int *L, int a, int b) {
+  for (;;) {
+    a = ccl_find(L, a);
+    b = ccl_find(L, b);
+    if (a == b) return;
+    if (a < b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }  // a > b: hang a under b unless someone got there first
+    const int old = atomicMin(L + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+__global__ void __launch_bounds__(256) ccl_merge_kernel(int *__restrict__ L, int w, int h) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h || L[i] < 0) return;
+  const int y = i / w, x = i - y * w;
+  if (x > 0 && L[i - 1] >= 0) ccl_union(L, i, i - 1);
+  if (y > 0) {
+    if (x > 0 && L[i - w - 1] >= 0) ccl_union(L, i, i - w - 1);
+    if (L[i - w] >= 0) ccl_union(L, i, i - w);
+    if (x + 1 < w && L[i - w + 1] >= 0) ccl_union(L, i, i - w + 1);
+  }
+}
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, int parts, uint8_t *__restrict__ lab_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint8_t v = 0;
+  if (L[i] >= 0) v = (uint8_t)(1 + ((unsigned)ccl_find(L, i) * 2654435761u >> 8) % (unsigned)parts);
+  lab_out[i] = v;
 }
 
 // hysteresis: promote weak pixels adjacent to an edge until nothing changes (one workgroup sweep loop)
@@ -252,11 +301,25 @@ int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const Fl
   {
     ProfScope ps(ctx->prof, "half_canny_kernel", st);
     hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, st, d_img, W, w, h, low,
-                       high, b.map, b.half, d_hist, W * H);
+                       high, b.map, b.half, d_hist, W * H, b.lab_work);
   }
   if (low != high) {
     ProfScope ps(ctx->prof, "canny_hyst_kernel", st);
     hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, st, b.map, w, h);
+  }
+  PLV_HIP_CHECK(hipGetLastError());
+  return PLV_OK;
+}
+
+// stage 1b: component labels of the edge map canny_kernel left in b.lab_work, into b.lab_out (host-visible), on stream st
+int launch_line_labels(plv_ctx *ctx, int w, int h, int parts, FldBuffers &b, hipStream_t st) {
+  {
+    ProfScope ps(ctx->prof, "ccl_merge_kernel", st);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(w * h, 256)), dim3(256), 0, st, b.lab_work, w, h);
+  }
+  {
+    ProfScope ps(ctx->prof, "ccl_flatten_kernel", st);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(w * h, 256)), dim3(256), 0, st, b.lab_work, w * h, parts, b.lab_out);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -22,11 +22,14 @@ struct FldBuffers {
   int *counts;     // [0] chains, [1] segment slots, [2] points
   float4 *segs;    // segment slots, chain c writes segs[chain.slot ...]
   int *seg_count;  // [chain_cap]
+  int *lab_work = nullptr;      // [w*h] union-find forest of the component labelling (null: no labels for this detection)
+  uint8_t *lab_out = nullptr;   // [w*h] labels, host-visible (0 not an edge, else 1 + hash(root) % parts)
 };
 
 // d_hist: d_img is the RAW image and d_hist its histogram (the kernel equalises on the fly: canny_kernel); null: d_img is the equalised image
 int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */,
                       const unsigned *d_hist = nullptr);
+int launch_line_labels(plv_ctx *ctx, int w, int h, int parts, FldBuffers &b, hipStream_t st);
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 

@@ -63,6 +63,33 @@ static void walk_chains_plain(const uint8_t *map, int w, int h, int length_thres
     }
 }
 
+// component labels of the edge pixels as ccl_merge_kernel / ccl_flatten_kernel produce them on the device (8-connectivity, root = the
+// smallest pixel index of the component): 0 = not an edge, else 1 + hash(root) % parts
+static std::vector<uint8_t> component_labels(const uint8_t *map, int w, int h, int parts) {
+  std::vector<int> root((size_t)w * h, -1), stack;
+  for (int s = 0; s < w * h; ++s) {
+    if (map[s] != 2 || root[s] >= 0) continue;
+    root[s] = s;
+    stack.assign(1, s);
+    while (!stack.empty()) {
+      const int p = stack.back();
+      stack.pop_back();
+      const int y = p / w, x = p - y * w;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int qx = x + dx, qy = y + dy;
+          if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
+          const int q = qy * w + qx;
+          if (map[q] == 2 && root[q] < 0) root[q] = s, stack.push_back(q);
+        }
+    }
+  }
+  std::vector<uint8_t> lab((size_t)w * h, 0);
+  for (int s = 0; s < w * h; ++s)
+    if (root[s] >= 0) lab[s] = (uint8_t)(1 + ((unsigned)root[s] * 2654435761u >> 8) % (unsigned)parts);
+  return lab;
+}
+
 int main(int argc, char **argv) {
   if (argc < 3) return 2;
   FILE *f = fopen(argv[1], "rb");
@@ -87,6 +114,14 @@ int main(int argc, char **argv) {
       Job J;
       J.w = w, J.h = h, J.length_threshold = 20, J.distance_threshold = 1.414213562f, J.thr2 = 1600.0f;
       J.hmap = maps[i].data(), J.hhalf = halves[i].data(), J.hpts = pts.data(), J.hc = chains.data();
+      // every other pass with the components labelled: the detection split into 16, 3 or 1 parts over the walking thread and the
+      // helpers (host_extract -> detect_part) must give the same segments in the same order
+      std::vector<uint8_t> lab;
+      if ((r + i) % 2 == 1) {
+        J.parts = r % 3 == 0 ? plv::linehost::Fit::kParts : (r % 3 == 1 ? 3 : 1);
+        lab = component_labels(maps[i].data(), w, h, J.parts);
+        J.hlab = lab.data();
+      }
       if (host_extract(&stage, J, false) != 0) return 3;
       // the same detection on this thread alone: the threaded one must give the same segments in the same order
       std::vector<int2> p2(npix);
