@@ -17,7 +17,7 @@ struct PlvContext {
   plv_ctx *ctx = nullptr;
   PlvContext(const std::shared_ptr<OptionsCamera> &op, const std::shared_ptr<State> &state, int cam_id, int device = 0) {
     plv_config cfg;
-    plv_config_default(&cfg, op->wh.at(cam_id).first, op->wh.at(cam_id).second);
+    plv_config_default(&cfg, op->wh.at(cam_id).at(0), op->wh.at(cam_id).at(1));  // OptionsCamera.h:45 (width, height)
     cfg.device = device;
     cfg.num_features = op->n_pts;
     cfg.fast_threshold = op->fast;

@@ -37,18 +37,32 @@ public:
       for (auto &calib : state->cam_intrinsic) state->cam_intrinsic_model.at(calib.first)->set_value(calib.second->value());
       plv_set_camera_intrinsics(ctx, state->cam_intrinsic.at(0)->value().data());  // the tracker's undistortion follows
     }
-    state->build_polynomial_data(false);
+    if (!state->op->use_imu_res) state->build_polynomial_data(false);  // StateHelper.cpp:171 (KAIST sets use_imu_res: the polynomial is not rebuilt)
   }
 
-  // StateHelper::EKFUpdate with a diagonal R (the camera path passes I, UpdaterCamera.cpp:290).  resident = covariance mode (b).
+  // StateHelper::EKFUpdate.  The camera path passes R = I (UpdaterCamera.cpp:290), the GPS path a diagonal, the wheel path a DENSE 6 x 6 /
+  // 3 x 3 preintegration covariance (UpdaterWheel.cpp:130-134).  plv_ekf_update takes a diagonal; a dense R is applied by whitening
+  // with its Cholesky factor, R = L L^T: H <- L^-1 H, res <- L^-1 res, R <- I — the same K res and the same K M^T (what
+  // plv_wheel_update does inside its kernel).  resident = covariance mode (b).
   static bool EKFUpdate(plv_ctx *ctx, std::shared_ptr<State> state, const VEC_TYPE &H_order, const Eigen::MatrixXd &H,
                         const Eigen::VectorXd &res, const Eigen::MatrixXd &R, bool resident = false) {
     const std::vector<int> cols = col_to_state(H_order);
-    const Eigen::VectorXd Rdiag = R.diagonal();
     const int n = (int)state->cov.rows();
     Eigen::VectorXd dx = Eigen::VectorXd::Zero(n);
-    const int rc = plv_ekf_update(ctx, resident ? nullptr : state->cov.data(), n, (int)state->cov.outerStride(), H.data(), (int)H.rows(),
-                                  (int)H.cols(), (int)H.outerStride(), cols.data(), res.data(), Rdiag.data(), dx.data());
+    Eigen::MatrixXd Hw = H;
+    Eigen::VectorXd rw = res, Rdiag;
+    const double *rd = nullptr;
+    if (R.isDiagonal()) {
+      Rdiag = R.diagonal();
+      rd = Rdiag.data();
+    } else {
+      Eigen::LLT<Eigen::MatrixXd> llt(R);
+      if (llt.info() != Eigen::Success) return false;  // (a noise matrix that is not positive definite)
+      Hw = llt.matrixL().solve(H);
+      rw = llt.matrixL().solve(res);
+    }
+    const int rc = plv_ekf_update(ctx, resident ? nullptr : state->cov.data(), n, (int)state->cov.outerStride(), Hw.data(), (int)Hw.rows(),
+                                  (int)Hw.cols(), (int)Hw.outerStride(), cols.data(), rw.data(), rd, dx.data());
     if (rc != PLV_OK) return false;  // PLV_E_NOT_PSD: nothing was modified (StateHelper.cpp:143-152)
     apply(ctx, state, dx);
     return true;

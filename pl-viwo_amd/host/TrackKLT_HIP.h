@@ -8,6 +8,7 @@
 // img_last / img_mask_last, and the ov_core::FeatureDatabase (update_feature with the frame's observations), so code that walks
 // `get_feature_database()` keeps working.  UpdaterCameraHIP.h uses the library's own track store instead and does not need it.
 #pragma once
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 

@@ -7,8 +7,10 @@
 // first; the reference's second equalizeHist, TrackLSD.cpp:83, reproduces the same image).  The line track store lives in the
 // library (plv_line_db_*); `export_tracks` hands it out in the layout of plv_line_tracks for code that wants LineFeature objects.
 #pragma once
-#include <Eigen/Eigen>
+#include <cstdlib>
 #include <vector>
+
+#include <Eigen/Eigen>
 
 #include "plviwo.h"
 #include "utils/print.h"

@@ -85,9 +85,9 @@ public:
     const auto &oc = state->op->cam;
     plv_update_options o{};
     o.max_msckf = oc->max_msckf, o.max_obs = max_obs, o.chi2_mult = oc->chi2_mult;
-    o.tri.min_dist = oc->featinit_options.min_dist, o.tri.max_dist = oc->featinit_options.max_dist;
-    o.tri.max_cond_number = oc->featinit_options.max_cond_number, o.tri.max_baseline = oc->featinit_options.max_baseline;
-    o.tri.refine_features = oc->featinit_options.refine_features ? 1 : 0;
+    o.tri.min_dist = oc->featinit_options->min_dist, o.tri.max_dist = oc->featinit_options->max_dist;
+    o.tri.max_cond_number = oc->featinit_options->max_cond_number, o.tri.max_baseline = oc->featinit_options->max_baseline;
+    o.tri.refine_features = oc->featinit_options->refine_features ? 1 : 0;
     o.t_prev_frame = t_hist.at(t_hist.size() - 2), o.state_time = state->time;
     o.window_full = state->clone_window() > state->op->window_size ? 1 : 0;
     o.init_min_meas = 10;
@@ -181,9 +181,9 @@ public:
     const auto &oc = state->op->cam;
     plv_update_options o{};
     o.max_msckf = oc->max_msckf, o.max_obs = max_obs, o.chi2_mult = oc->chi2_mult;
-    o.tri.min_dist = oc->featinit_options.min_dist, o.tri.max_dist = oc->featinit_options.max_dist;
-    o.tri.max_cond_number = oc->featinit_options.max_cond_number, o.tri.max_baseline = oc->featinit_options.max_baseline;
-    o.tri.refine_features = oc->featinit_options.refine_features ? 1 : 0;
+    o.tri.min_dist = oc->featinit_options->min_dist, o.tri.max_dist = oc->featinit_options->max_dist;
+    o.tri.max_cond_number = oc->featinit_options->max_cond_number, o.tri.max_baseline = oc->featinit_options->max_baseline;
+    o.tri.refine_features = oc->featinit_options->refine_features ? 1 : 0;
     o.state_time = state->time;
     o.window_full = state->clone_window() > state->op->window_size ? 1 : 0;
     o.init_min_meas = 10;
