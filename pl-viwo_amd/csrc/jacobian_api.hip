@@ -198,7 +198,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int F = tr->n_feat;
   const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
-  TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
+  TRY(us->bHf.reserve_units((size_t)F, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)(3 + k + 1) * ld * 8));
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
   {
@@ -676,7 +676,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int L = lt->n_lines;
   const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
-  TRY(us->bHf.reserve((nHf + nHx + nr) * 8));
+  TRY(us->bHf.reserve_units((size_t)L, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)(6 + k + 1) * ld * 8));
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols_l.reserve((size_t)k * 4));
   if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, L, ld - 6));  // (before the upload goes onto the stream)

@@ -687,7 +687,7 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
   std::vector<uint64_t> ids(nl);
   for (int i = 0; i < nl; ++i) ids[i] = ++T->currid;  // REF :233-236
   Assign A;
-  assign_points(lines.data(), nl, pts, pids, np, A);
+  assign_points_parallel(&T->host, fit_threads().load(std::memory_order_relaxed), lines.data(), nl, pts, pids, np, A);
   auto F1 = std::chrono::steady_clock::now();
   const int nk = (int)A.kept.size();
   std::vector<float> fl(4 * (size_t)nk);
@@ -699,8 +699,8 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
   const bool first = T->lines_last.empty();  // REF :100 (first frame or lost everything: no matching, no DB update)
   if (!first) {
     std::vector<int> match((size_t)std::max(nk, 1));
-    match_lines(fl.data(), nk, A.rel_ptr.data(), A.rel_id.data(), T->lines_last.data(), (int)T->ids_last.size(), T->rel_ptr_last.data(),
-                T->rel_id_last.data(), match.data());
+    match_lines_parallel(&T->host, fit_threads().load(std::memory_order_relaxed), fl.data(), nk, A.rel_ptr.data(), A.rel_id.data(), T->lines_last.data(),
+                         (int)T->ids_last.size(), T->rel_ptr_last.data(), T->rel_id_last.data(), match.data());
     for (int q = 0; q < nk; ++q)
       if (match[q] >= 0) fid[q] = (uint64_t)(int)T->ids_last[match[q]];  // REF :153-158 (`int id`)
     // CamBase::undistort_line: both end points through undistort_f.  A few dozen points: the arithmetic of undistort_kernel

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -48,6 +49,8 @@ struct Fit {
   // A labelled job (Job::hlab): its parts are claimed here by the walking thread and the helpers; a part = the components whose
   // label it is, walked and fitted by the thread that claimed it (detect_part) into part[p]
   bool by_parts = false;  // (guarded by m, read together with gen and job)
+  // a generic job for the same threads (run_on_helpers): every thread it counts calls task(slot), slot 1 .. nfit_job (0 = the poster)
+  std::function<void(int)> task;  // (guarded by m, read together with gen)
   alignas(64) std::atomic<int> next_part{0};
   struct PartOut {
     std::vector<int> seed, seg_at, seg_n;  // per chain: raster index of its seed, first segment, segments
@@ -283,11 +286,21 @@ inline void fit_worker(HostStage *T, int me, int seen /* the generation current 
     const Job *job;
     int nfit;
     bool by_parts;
+    std::function<void(int)> task;
     {
       std::unique_lock<std::mutex> lk(F.m);
       wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
       if (F.quit) return;
-      seen = F.gen, job = F.job, nfit = F.nfit_job, by_parts = F.by_parts;
+      seen = F.gen, job = F.job, nfit = F.nfit_job, by_parts = F.by_parts, task = F.task;
+    }
+    if (task || !job) {  // (a task, or a thread the task did not count waking after the poster has withdrawn it)
+      if (task && me < nfit) task(me + 1);
+      {
+        std::lock_guard<std::mutex> lk(F.m);
+        F.done_gen[me] = seen;
+      }
+      F.cv.notify_all();
+      continue;
     }
     const Job &J = *job;
     if (by_parts && me < nfit) claim_parts(F, J, me + 1);
@@ -344,6 +357,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     F.job = &J;
     F.nfit_job = nfit;
     F.by_parts = by_parts;
+    F.task = nullptr;
     gen = ++F.gen;
   }
   F.cv.notify_all();
@@ -479,6 +493,71 @@ inline void assign_points(const float *lines, int nl, const float *pts, const ui
   }
 }
 
+// fn(slot) on the calling thread (slot 0) and on `nhelpers` helper threads of the stage (slots 1 .. nhelpers), all at once; returns
+// when every one of them has returned
+inline void run_on_helpers(HostStage *T, int nhelpers, const std::function<void(int)> &fn) {
+  Fit &F = T->fit;
+  nhelpers = std::max(0, std::min(nhelpers, (int)Fit::kThreads));
+  if (nhelpers == 0) {
+    fn(0);
+    return;
+  }
+  {
+    int gen_now;
+    {
+      std::lock_guard<std::mutex> lk(F.m);
+      gen_now = F.gen;
+    }
+    for (int i = 0; i < nhelpers; ++i)
+      if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
+  }
+  int gen;
+  {
+    std::lock_guard<std::mutex> lk(F.m);
+    F.job = nullptr;
+    F.nfit_job = nhelpers;
+    F.by_parts = false;
+    F.task = fn;
+    gen = ++F.gen;
+  }
+  F.cv.notify_all();
+  fn(0);
+  std::unique_lock<std::mutex> lk(F.m);
+  wait_polling(lk, F.cv, [&] {
+    for (int i = 0; i < nhelpers; ++i)
+      if (F.th[i].joinable() && F.done_gen[i] != gen) return false;
+    return true;
+  });
+  F.task = nullptr;
+}
+
+// assign_points with the lines split into contiguous ranges over the stage's threads: a line's assignment depends on nothing but the
+// line and the points, and the ranges' results are joined in line order — the same Assign as the serial call.
+inline void assign_points_parallel(HostStage *T, int nhelpers, const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A,
+                                   float assign_px = 5.0f) {
+  const int nt = std::max(1, std::min(nhelpers + 1, nl / 48));  // (a range of fewer than ~50 lines is not worth a hand-over)
+  if (nt == 1) {
+    assign_points(lines, nl, pts, ids, np, A, assign_px);
+    return;
+  }
+  std::vector<Assign> part(nt);
+  run_on_helpers(T, nt - 1, [&](int slot) {
+    const int i0 = (int)((long long)nl * slot / nt), i1 = (int)((long long)nl * (slot + 1) / nt);
+    assign_points(lines + 4 * (size_t)i0, i1 - i0, pts, ids, np, part[slot], assign_px);
+    for (int &k : part[slot].kept) k += i0;
+  });
+  A = Assign();
+  for (const Assign &P : part) {
+    A.kept.insert(A.kept.end(), P.kept.begin(), P.kept.end());
+    const int r0 = (int)A.rel_id.size(), p0 = (int)A.pos.size() / 2;
+    for (size_t q = 1; q < P.rel_ptr.size(); ++q) A.rel_ptr.push_back(r0 + P.rel_ptr[q]);
+    for (size_t q = 1; q < P.pos_ptr.size(); ++q) A.pos_ptr.push_back(p0 + P.pos_ptr[q]);
+    A.rel_id.insert(A.rel_id.end(), P.rel_id.begin(), P.rel_id.end());
+    A.rel_dist.insert(A.rel_dist.end(), P.rel_dist.begin(), P.rel_dist.end());
+    A.pos.insert(A.pos.end(), P.pos.begin(), P.pos.end());
+  }
+}
+
 inline void match_lines(const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new, const float *lines_last, int n_last,
                  const int *rp_last, const uint64_t *ri_last, int *match) {
   std::fill(match, match + n_new, -1);
@@ -503,6 +582,22 @@ inline void match_lines(const float *lines_new, int n_new, const int *rp_new, co
       }
     }
   }
+}
+
+// match_lines with the new lines split into contiguous ranges over the stage's threads (a new line's match depends on nothing but
+// that line and the last frame's lines)
+inline void match_lines_parallel(HostStage *T, int nhelpers, const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new,
+                                 const float *lines_last, int n_last, const int *rp_last, const uint64_t *ri_last, int *match) {
+  const int nt = std::max(1, std::min(nhelpers + 1, n_new / 8));
+  if (nt == 1 || n_last == 0) {
+    match_lines(lines_new, n_new, rp_new, ri_new, lines_last, n_last, rp_last, ri_last, match);
+    return;
+  }
+  run_on_helpers(T, nt - 1, [&](int slot) {
+    const int i0 = (int)((long long)n_new * slot / nt), i1 = (int)((long long)n_new * (slot + 1) / nt);
+    // (rp_new + i0 still indexes ri_new from its start: the offsets are absolute)
+    match_lines(lines_new + 4 * (size_t)i0, i1 - i0, rp_new + i0, ri_new, lines_last, n_last, rp_last, ri_last, match + i0);
+  });
 }
 
 inline bool line_class(const float *line, const double *vp) {

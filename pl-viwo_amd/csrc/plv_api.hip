@@ -660,7 +660,7 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
     return PLV_OK;
   const int nc = k + 1, Mtot = F * mp_max;
   TRY(ctx->d_chi2.reserve((size_t)F * 8));
-  TRY(ctx->stack_of(fdim).reserve((size_t)Mtot * nc * 8));
+  TRY(ctx->stack_of(fdim).reserve_units((size_t)F, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)mp_max * nc * 8));
   double *d_dx;
   int *d_flag;
   unsigned char *d_acc;
@@ -787,7 +787,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   }
   const int nc = k + 1;
   const int Mtot = F * mp_max;
-  TRY(ctx->stack_of(fdim).reserve((size_t)Mtot * nc * 8));
+  TRY(ctx->stack_of(fdim).reserve_units((size_t)F, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)mp_max * nc * 8));
   size_t tmp_elems = (size_t)std::max(Mtot / (2 * nc) + 2, 16) * nc * nc;  // TSQR tree levels
   {  // Gram path: per-chunk partial tiles (64-row chunks, upper 16x16 tiles) + the reduced matrix
     const size_t nt = (size_t)(nc + 15) / 16, ntri = nt * (nt + 1) / 2;

@@ -7,6 +7,7 @@
 #include "gate_stage.hpp"
 #include <cstdint>
 #include <cstdio>
+#include <execinfo.h>
 #include <cstring>
 #include <algorithm>
 #include <atomic>
@@ -223,10 +224,19 @@ struct DevBuf {
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
     ++alloc_epoch();
+    static const bool dbg = getenv("PLV_ALLOC_DEBUG") != nullptr;
+    if (dbg) {
+      fprintf(stderr, "[plv alloc] device buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
+      void *bt[8];
+      backtrace_symbols_fd(bt, backtrace(bt, 8), 2);
+    }
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    // Twice what is asked for and never less than 1 MB (the device has 288 GB): batch sizes wander from frame to frame (pool sizes,
+    // accepted rows, chain counts) and a buffer that regrows inside a frame costs that frame 0.3 - 0.4 ms (hipFree waits for the
+    // device, hipMalloc maps pages) — round 4's driver-timed run had three such frames in its twenty
+    size_t want = std::max<size_t>(2 * bytes + 256, (size_t)1 << 20);
     if (hipMalloc(&p, want) != hipSuccess) {
       set_last_error("hipMalloc(%zu) failed", want);
       return PLV_E_NOMEM;
@@ -239,6 +249,9 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  // reserve for a batch of `units` entries of `bytes_per_unit` with room for `units_floor` of them: the buffers of the per-feature
+  // batches are sized by the pool of the frame, which peaks when many tracks end at once (up to every tracked feature)
+  int reserve_units(size_t units, size_t units_floor, size_t bytes_per_unit) { return reserve(std::max(units, units_floor) * bytes_per_unit); }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
@@ -249,10 +262,12 @@ struct PinBuf {
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
     ++alloc_epoch();  // kernels write into pinned blocks too (result mirrors): a captured graph holds their addresses
+    static const bool dbg = getenv("PLV_ALLOC_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[plv alloc] pinned buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = std::max<size_t>(2 * bytes + 256, (size_t)1 << 18);  // (as DevBuf::reserve: generous once instead of regrowing inside a frame)
     if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
       set_last_error("hipHostMalloc(%zu) failed", want);
       return PLV_E_NOMEM;

@@ -762,7 +762,7 @@ int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a_in, int max_mp) {
   }
   Chi2Args a = a_in;
   int rc;
-  if ((rc = ctx->d_T.reserve((size_t)F * a.k * a.ld * 8))) return rc;
+  if ((rc = ctx->d_T.reserve_units((size_t)F, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)a.k * a.ld * 8))) return rc;  // (sized for the peak pool: DevBuf::reserve_units)
   a.F = F;
   a.Ps = ctx->d_Ps.as<double>();
   a.T = ctx->d_T.as<double>();

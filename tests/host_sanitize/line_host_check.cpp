@@ -171,14 +171,27 @@ int main(int argc, char **argv) {
         ptsf.push_back(J.lines[4 * q + 1] + s * (J.lines[4 * q + 3] - J.lines[4 * q + 1]) + 2 * u(rng));
         ids.push_back(1000 + q);
       }
-      Assign A;
+      Assign A, Ap;
       assign_points(J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), A);
+      // the same assignment with the lines split over the stage's threads: the same lists
+      assign_points_parallel(&stage, 3, J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), Ap);
+      if (Ap.kept != A.kept || Ap.rel_ptr != A.rel_ptr || Ap.rel_id != A.rel_id || Ap.rel_dist != A.rel_dist || Ap.pos_ptr != A.pos_ptr || Ap.pos != A.pos) {
+        fprintf(stderr, "frame %d: the parallel assignment differs from the serial one\n", i);
+        return 6;
+      }
       std::vector<float> kept_lines;
       for (int q : A.kept) kept_lines.insert(kept_lines.end(), J.lines.begin() + 4 * q, J.lines.begin() + 4 * q + 4);
       if (!last_lines.empty() && !A.kept.empty()) {
         std::vector<int> match(A.kept.size());
         match_lines(kept_lines.data(), (int)A.kept.size(), A.rel_ptr.data(), A.rel_id.data(), last_lines.data(), (int)last_lines.size() / 4,
                     last.rel_ptr.data(), last.rel_id.data(), match.data());
+        std::vector<int> match_p(A.kept.size());
+        match_lines_parallel(&stage, 3, kept_lines.data(), (int)A.kept.size(), A.rel_ptr.data(), A.rel_id.data(), last_lines.data(),
+                             (int)last_lines.size() / 4, last.rel_ptr.data(), last.rel_id.data(), match_p.data());
+        if (match_p != match) {
+          fprintf(stderr, "frame %d: the parallel matching differs from the serial one\n", i);
+          return 7;
+        }
       }
       total_kept += (long)A.kept.size();
       last_lines = kept_lines;
