@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
     ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
-                    "plv_update_compression_mode settings frame by frame and stderr gets the mean step time of each (drift-free A/B)")
+                    "plv_update_compression_mode settings (0, 1) frame by frame and stderr gets the mean step time of each (drift-free A/B)")
     ap.add_argument("--alternate-spin", default=None, help="measurement aid: e.g. 300,0 — plv_line_worker_config polling budgets (us) cycled frame by frame")
     ap.add_argument("--alternate-fit", default=None, help="measurement aid: e.g. 2,0 — segment-fitter thread counts cycled frame by frame")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
@@ -578,9 +578,8 @@ def main():
     spin_us, fit_threads = pkg.line_worker_config()
     variants = None
     if not args.no_variants:
-        # non-default library settings over the next frames of the stream (short segments, resident images): (a) the round-2
-        # compression (Gram matrix + Cholesky -> R, then the EKF step on R: one more pivot chain on the critical path, and dx loses
-        # accuracy on near-gauge directions); (b) the library's threads blocking at once instead of polling
+        # non-default library settings over the next frames of the stream (short segments, resident images): (a) the reference's own
+        # update route (Householder compression + EKF step); (b) the library's threads blocking at once instead of polling
         # Each variant is measured ALTERNATING with the default, frame by frame, over the next 2 * nvar frames of the stream: later
         # frames are other frames, and a box drifts by +-25 us between segments — more than either variant moves.
         variants = {}
@@ -589,9 +588,10 @@ def main():
             v = timed_segment(2 * nvar, hook=lambda f: (set_variant if f % 2 else set_default)())
             set_default()
             return float(np.mean(v["per"][1::2])), float(np.mean(v["per"][0::2])), v
-        var_ms, def_ms, v = alternating(lambda: ctx.update_compression_mode(3), lambda: ctx.update_compression_mode(0))
-        variants["compression_gram_cholesky"] = {"ms_per_step": var_ms, "default_ms_per_step_on_the_alternate_frames": def_ms, "frames": nvar,
-                                                 "frames_whose_last_update_met_ambiguous_pivots": v["cnt"]["ambiguous_frames"]}
+        var_ms, def_ms, v = alternating(lambda: ctx.update_compression_mode(1), lambda: ctx.update_compression_mode(0))
+        variants["compression_householder"] = {"ms_per_step": var_ms, "default_ms_per_step_on_the_alternate_frames": def_ms, "frames": nvar,
+                                               "what": "plv_update_compression_mode(1): the reference's route (compression of the stacked rows by "
+                                                       "Householder reflections, then S = R P R^T + I) instead of the whitened update"}
         # (c) the north star's 21 x 21 LK patch (plv_config.win_size; 15 is the reference's value and the parity setting): every lane of a
         # point's workgroup carries a second window pixel
         var_ms, def_ms, v = alternating(lambda: ctx.set_lk_window(21), lambda: ctx.set_lk_window(15))
@@ -762,11 +762,11 @@ def main():
                 "compression": {"mode": "whitened update (plv_update_compression_mode 0): information matrix of the accepted rows + factor "
                                         "of the prior block on a side stream; no factor of the measurements",
                                 "frames_whose_last_update_took_it": cnt["whitened_frames"], "frames": args.steps,
-                                "updates_by_route": dict(zip(("uncompressed", "gram_cholesky", "householder", "gram_then_householder",
-                                                              "whitened", "whitened_rejected_then_householder"), cnt["routes"][:6])),
+                                "updates_by_route": {k: v for k, v in zip(("uncompressed", None, "householder", None, "whitened",
+                                                                          "whitened_rejected_then_householder"), cnt["routes"][:6]) if k},
                                 "note": "agrees with the Givens oracle to 1e-10 (P') and 1e-9 (dx) on every captured replay batch and up to "
-                                        "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_gram_cholesky is the "
-                                        "round-2 route (mode 3)"},
+                                        "condition 1e8 (tests/test_gpu_update_hard.py); config.variants.compression_householder is the "
+                                        "reference's route (mode 1)"},
                 "variants": variants,
                 "host_cpu": seg.get("host_cpu"),
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},

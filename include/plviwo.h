@@ -190,15 +190,11 @@ int plv_update_graph_mode(plv_ctx *ctx, int on, int *captures, int *replays);
  *                every captured replay batch and up to condition 1e8 of the stacked Jacobian.  The prior factor runs on a side
  *                stream during the Jacobian / gate launches;
  *   1            Householder TSQR on the stacked rows themselves (orthogonal transformations: the reference's accuracy, ~0.7 ms);
- *   2            automatic: Gram + Cholesky first; when its factorisation reports pivots it could not tell from zero, nothing is
- *                committed and the update is redone through the Householder route;
- *   3            Gram matrix + blocked Cholesky: [R z] with R^T R = H^T H (the round-2 default).  It carries a direction of relative
- *                strength s with a relative error of eps / s^2: P' agrees to 1e-9 throughout, dx to 1e-8 as long as no pivot of the
- *                unit-diagonal Gram matrix falls below 1e-9 — near-gauge directions of a running filter do: measured worst 3e-5 of |dx|.
- * (Beyond 192 measured columns, or in graph mode, 0 behaves as 3 / falls back to 1.)
+ * (Rounds 2-3 also offered a Gram + Cholesky compression, modes 2 and 3; it squared the condition number of the stacked Jacobian and was
+ * removed in round 5: modes above 1 return PLV_E_BADARG.  Beyond 192 measured columns, or in graph mode, 0 falls back to 1.)
  * mode < 0 only queries.  Returns the mode in force.  last_route (nullable): how the last update was carried out — 0 not compressed
- * (fewer rows than columns), 1 Gram, 2 Householder, 3 Gram vetoed and redone, 4 whitened; last_ambiguous (nullable): the pivots below
- * 1e-9 a Gram factorisation met. */
+ * (fewer rows than columns), 2 Householder, 4 whitened, 5 whitened rejected on the device and redone by Householder (1 and 3 were the
+ * removed routes); last_ambiguous (nullable): always 0 (kept for the signature). */
 int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *last_ambiguous);
 /* Process-wide activity counters since load (measurement aid, no reference counterpart): out[0] kernel launches, [1] host
  * synchronisations (stream / event waits), [2] asynchronous copies, [3] bytes copied, [4] LK iterations over all points and levels
@@ -207,7 +203,7 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
  * timer inside the CPU oracle's frame). */
 void plv_counters(unsigned long long *out8);
 /* (measurement aid) updates collected since the library was loaded, by route: index = plv_update_compression_mode's last_route
- * (0 no compression, 1 Gram + Cholesky, 2 Householder, 3 Gram then Householder, 4 whitened, 5 whitened rejected, then Householder) */
+ * (0 no compression, 2 Householder, 4 whitened, 5 whitened rejected, then Householder; 1 and 3: unused since round 5) */
 void plv_route_counts(unsigned long long *out8);
 /* (test aid) Decision trace.  With it on, plv_camera_update_points (alone or inside plv_camera_try_update / plv_camera_frame) keeps, for
  * every feature of its pool, the values its verdicts were taken on; plv_last_point_decisions returns them for the last update:

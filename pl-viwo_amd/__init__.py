@@ -890,7 +890,7 @@ class Context:
         return rc, dx, acc, nrows.value
 
     def update_compression_mode(self, mode=-1):
-        """plv_update_compression_mode: sets (0 whitened update, 1 Householder, 2 automatic, 3 Gram + Cholesky) or queries (-1); returns (mode, route of the last
+        """plv_update_compression_mode: sets (0 whitened update, 1 Householder) or queries (-1); returns (mode, route of the last
         update, ambiguous pivots its Gram factorisation met)"""
         route, amb = C.c_int(), C.c_int()
         m = self.lib.plv_update_compression_mode(self.h, int(mode), C.byref(route), C.byref(amb))

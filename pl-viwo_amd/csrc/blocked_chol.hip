@@ -5,89 +5,16 @@
 
 namespace plv {
 
-// ------------------------------------------------------------------------------------------ compression
-struct CompressOps {
-  static constexpr bool kStoreL = true;  // rows of L_d are wanted (R output)
-  const double *G;   // nc x nc col-major, upper tiles valid
-  int nc, k;
-  const double *sc;  // LDS: column scales 1/sqrt(G_ii) (0 for an all-zero column), then sqrt(G_ii)
-  double *R;
-  int ldr;
-  double *z;
-  double dval;       // this thread's diagonal entry G_jj, j = threadIdx.x (loaded before the tiles)
-  double *scw;
-  // loads are branch-free (clamped index, select afterwards) so that all of them are in flight together
-  __device__ __forceinline__ double sym_raw(int i, int c) const {
-    const int hi = min(max(i, c), k - 1), lo = min(min(i, c), k - 1);
-    return G[(size_t)hi * nc + lo];  // upper (lo, hi) of the Gram matrix
-  }
-  __device__ __forceinline__ double border_raw(int, int c) const { return G[(size_t)k * nc + min(c, k - 1)]; }
-  __device__ __forceinline__ void scales_ready() const {
-    const int j = threadIdx.x;
-    if (j < 192) {
-      const bool ok = j < k && dval > 0.0;
-      const double rt = sqrt(ok ? dval : 1.0);
-      scw[j] = ok ? 1.0 / rt : 0.0;
-      scw[192 + j] = ok ? rt : 0.0;
-    }
-    __syncthreads();
-  }
-  __device__ __forceinline__ double sym_fix(int i, int c, double g) const {
-    const bool pad = i >= k || c >= k;
-    return pad ? (i == c ? 1.0 : 0.0) : g * sc[min(i, k - 1)] * sc[min(c, k - 1)];
-  }
-  __device__ __forceinline__ double border_fix(int b, int c, double g) const {
-    return (b == 0 && c < k) ? g * sc[min(c, k - 1)] : 0.0;
-  }
-  // R = L^T D^-1:  R(c, i) = l_ic * sqrt(G_ii)
-  __device__ __forceinline__ void store_sym(int i, int c, double l) const {
-    if (i < k && c <= i) {
-      R[(size_t)i * ldr + c] = l * sc[192 + i];
-      if (c < i) R[(size_t)c * ldr + i] = 0.0;
-    }
-  }
-  __device__ __forceinline__ void store_border(int b, int c, double v) const {
-    if (b == 0 && c < k) z[c] = v;
-  }
-};
-
 // pivots of the unit-diagonal prior block below this are exact dependencies (measured on the replay batches: dead pivots <= 1e-14,
 // the smallest live one 1.5e-7; DESIGN.md "Whitened update")
 #define PLV_PRIOR_TAU 2e-13
-// Pivots of the unit-diagonal prior block below this are NEAR dependencies: the whitened form of the update divides by them and
-// loses eps / pivot^2 of what they stand for (the conditional variance of the state given the ones before it).  The factor counts
-// them (n_near[0]; n_near[1]: the dead ones, below PLV_PRIOR_TAU) and with one or more the update takes its factor form
-// (dense_kernels.hip "whitened update").  Clone positions reach 1e-8 within seconds of a drive — the global position's variance
-// grows without bound while a clone's position given its neighbour stays at tenths of a millimetre — orientations 1e-4; time
-// stamps of 1.5e9 s put the IMU pose a quarter of a microsecond of propagation behind the clone taken of it (1e-11).
+// Pivots of the unit-diagonal prior block below this are NEAR dependencies (counted for the record, n_near[4]): clone positions reach
+// 1e-8 within seconds of a drive — the global position's variance grows without bound while a clone's position given its neighbour
+// stays at tenths of a millimetre — orientations 1e-4.  The columns of W0 that belong to the update's own states are copied from the
+// factor (prior_exact_cols_kernel), which is what keeps the whitened form exact there.
 // PLV_WHITEN_LAMBDA_MAX: the factor form's own limit (B's largest diagonal entry beyond which it hands the update to Householder).
 #define PLV_PRIOR_AMB 1e-4
 #define PLV_WHITEN_LAMBDA_MAX 1e2
-#define PLV_COMPRESS_AMBIGUOUS 1e-9  // pivots of the unit-diagonal Gram matrix below this are reported (relative singular value 3e-5)
-template <int NT>
-__global__ void __launch_bounds__(64 * (NT + 1)) bchol_compress_kernel(const double *__restrict__ G, int nc,
-                                                                      double *__restrict__ R, int ldr,
-                                                                      double *__restrict__ z, const int *__restrict__ skip,
-                                                                      int *__restrict__ n_ambiguous) {
-  if (n_ambiguous && threadIdx.x == 0) *n_ambiguous = 0;
-  if (skip && *skip == 0) return;
-  __shared__ BcLds lds;
-  __shared__ double sc[384];  // [0,192) 1/sqrt(d), [192,384) sqrt(d)
-  const int k = nc - 1;
-  const int jd = min((int)threadIdx.x, k - 1);
-  CompressOps ops{G, nc, k, sc, R, ldr, z, G[(size_t)jd * nc + jd], sc};
-  if (threadIdx.x == 0) {
-    lds.bad = 0;
-    lds.step_flag = 0;
-    lds.rs_flag = 0;
-    lds.n_amb = 0;
-  }
-  // pivots of the unit-diagonal matrix lie in [0,1]; below tau a column is numerically dependent
-  blocked_chol<NT>(ops, lds, k, 1, 64.0 * 2.220446049250313e-16 * (double)nc, 0, PLV_COMPRESS_AMBIGUOUS);
-  __syncthreads();
-  if (n_ambiguous && threadIdx.x == 0) *n_ambiguous = lds.n_amb;
-}
-
 // ------------------------------------------------------------------------------------------ prior factor
 // The whitened route of the compressed update (DESIGN.md "Whitened update"): Ps = P[cols, cols] = Lp Lp^T with the rows
 // P[:, cols] as borders,  W0^T = P[:, cols] Lp^-T.  Ps is factored after scaling to unit diagonal; a pivot below tau marks a state that
@@ -273,25 +200,6 @@ __global__ void __launch_bounds__(64 * (NT + 1)) bchol_ekf_kernel(const double *
 #ifndef PLV_BCHOL_NO_LAUNCHERS
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z, int *d_n_ambiguous) {
-  const int k = nc - 1;
-  if (k > 192) return PLV_E_CAPACITY;
-  ProfScope ps(ctx->prof, "bchol_compress_kernel", ctx->stream);
-  if (k <= 32)
-    hipLaunchKernelGGL(bchol_compress_kernel<2>, dim3(1), dim3(64 * 3), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  else if (k <= 64)
-    hipLaunchKernelGGL(bchol_compress_kernel<4>, dim3(1), dim3(64 * 5), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  else if (k <= 112)
-    hipLaunchKernelGGL(bchol_compress_kernel<7>, dim3(1), dim3(64 * 8), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  else if (k <= 128)
-    hipLaunchKernelGGL(bchol_compress_kernel<8>, dim3(1), dim3(64 * 9), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  else if (k <= 160)  // (20-clone windows with the calibration blocks: BASELINE configs[3])
-    hipLaunchKernelGGL(bchol_compress_kernel<10>, dim3(1), dim3(64 * 11), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  else
-    hipLaunchKernelGGL(bchol_compress_kernel<12>, dim3(1), dim3(64 * 13), 0, ctx->stream, d_G, nc, d_R, ldr, d_z, ctx->skip_word, d_n_ambiguous);
-  PLV_HIP_CHECK(hipGetLastError());
-  return PLV_OK;
-}
 
 int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const double *d_Mt, int ldm, int n,
                      const double *d_res, double *d_W, int ldw, int *d_flag, const WhitenC1Args *wc) {
@@ -299,7 +207,7 @@ int launch_bchol_ekf(plv_ctx *ctx, const double *d_S, int lds_, int r, const dou
   const int strips = cdiv(n + 1, 16);  // one border strip per workgroup; every workgroup factors S itself
   const int nt_waves = r <= 32 ? 3 : r <= 64 ? 5 : r <= 112 ? 8 : r <= 128 ? 9 : r <= 160 ? 11 : 13;
   const int tn = cdiv(n, 16), c1_groups = wc ? cdiv(tn * (tn + 1) / 2, nt_waves) : 0, groups = strips + c1_groups;
-  static const double lam_max = getenv("PLV_WHITEN_LAMBDA_MAX") ? atof(getenv("PLV_WHITEN_LAMBDA_MAX")) : PLV_WHITEN_LAMBDA_MAX;
+  const double lam_max = PLV_WHITEN_LAMBDA_MAX;
   const WhitenC1 c1 = wc ? WhitenC1{wc->P, wc->ldp, r, wc->cols, wc->GP, wc->C1, wc->Y0, wc->use_m, lam_max, strips}
                          : WhitenC1{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, -1};
   ProfScope ps(ctx->prof, "bchol_ekf_kernel", ctx->stream);

@@ -2,15 +2,11 @@
 // them with the blocked factorisations of blocked_chol.hip.
 //
 // Measured on MI355X (profiles/r01): a Householder TSQR of the stacked Jacobian is latency-bound
-// (99 reflector steps x 4 row chunks x 4 tree levels ~ 1600 dependent steps).  The compression
-// (REF: StateHelper::measurement_compress_inplace, PL/state/StateHelper.cpp:602-614) is therefore
-// re-expressed so that only ONE chain of k dependent pivots remains:
-//     G = [H r]^T [H r]             gram_kernel            (v_mfma_f64_16x16x4_f64, rows split over waves)
-//     G = [R z]^T [R z]             bchol_compress_kernel  (blocked Cholesky, blocked_chol.hip)
-// R is the same upper-triangular factor the reference's Givens QR produces (unique for full
-// column rank, diag >= 0).  Columns whose pivot vanishes after equilibration (the gauge directions
-// an MSCKF Jacobian cannot observe) give a zero row, which is what an exact QR gives as well.
-// DESIGN.md "Compression numerics" has the error analysis (backward error eps*|G| either way).
+// (99 reflector steps x 4 row chunks x 4 tree levels ~ 1600 dependent steps).  The default route therefore forms no factor of the
+// measurements at all (REF: StateHelper::measurement_compress_inplace + EKFUpdate as one whitened step, launch_ekf_whitened below):
+//     [G | g] = H^T [H | r] over the accepted rows      gram_direct_kernel  (v_mfma_f64_16x16x4_f64)
+// (Rounds 2-3 factored G by a blocked Cholesky into the R the reference's Givens QR produces; that route squared the condition
+// number and was removed in round 5 — the Householder TSQR of update_kernels.hip is the reference-equivalent route that remains.)
 //
 // The EKF step (REF: StateHelper::EKFUpdate, StateHelper.cpp:94-173):
 //     Mt = H P[cols,:], S = Mt[:,cols] H^T + R      ekf_mt_kernel, ekf_s_kernel (update_kernels.hip)
@@ -27,76 +23,6 @@ namespace plv {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------
-// G (nc x nc, col-major, upper tiles) = A^T A in two launches that read A exactly once.
-// (The first form — a workgroup per output tile streaming its two column blocks — re-read every column
-// block once per tile: rocprofv3 FETCH_SIZE 4.7 MB per launch for a 1.5 MB matrix, 24 us.)
-//   gram_chunk_kernel  one workgroup per GRAM_CH rows: the chunk (all nc columns) is staged in LDS with
-//                      row-contiguous (coalesced) loads, its 16 waves share the upper tiles, partial
-//                      tiles go out in per-lane order;
-//   gram_reduce_kernel one workgroup per tile sums the chunk partials in a fixed order (deterministic).
-#define GRAM_CH 64
-#define GRAM_WAVES 16
-__global__ void __launch_bounds__(64 * GRAM_WAVES) gram_chunk_kernel(const double *__restrict__ A, int lda, int m, int nc,
-                                                                      double *__restrict__ part /* [chunk][tile][4][64] */, const int *__restrict__ skip) {
-  if (skip && *skip == 0) return;
-  extern __shared__ double As[];  // [nc][GRAM_CH + 1]
-  const int row0 = blockIdx.x * GRAM_CH;
-  const int rows = min(GRAM_CH, m - row0);
-  for (int idx = threadIdx.x; idx < nc * GRAM_CH; idx += blockDim.x) {
-    const int c = idx / GRAM_CH, r = idx - c * GRAM_CH;
-    As[c * (GRAM_CH + 1) + r] = r < rows ? A[(size_t)c * lda + row0 + r] : 0.0;
-  }
-  __syncthreads();
-  const int nt = (nc + 15) >> 4, ntri = nt * (nt + 1) / 2;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
-  for (int tile = wave; tile < ntri; tile += GRAM_WAVES) {
-    int rem = tile, ti = 0;
-    while (rem >= nt - ti) {
-      rem -= nt - ti;
-      ++ti;
-    }
-    const int tj = ti + rem;
-    const double *ai = As + min(ti * 16 + li, nc - 1) * (GRAM_CH + 1);  // columns beyond nc only feed entries
-    const double *aj = As + min(tj * 16 + li, nc - 1) * (GRAM_CH + 1);  // that are never read
-    d4 acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int u = 0; u < GRAM_CH / 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[4 * u + kq], aj[4 * u + kq], acc, 0, 0, 0);
-    double *out = part + ((size_t)blockIdx.x * ntri + tile) * 256;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) out[q * 64 + lane] = acc[q];
-  }
-}
-
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const double *__restrict__ part, int nchunks, int nc,
-                                                          double *__restrict__ G, const int *__restrict__ skip) {
-  if (skip && *skip == 0) return;
-  const int nt = (nc + 15) >> 4, ntri = nt * (nt + 1) / 2;
-  const int tile = blockIdx.x;
-  int rem = tile, ti = 0;
-  while (rem >= nt - ti) {
-    rem -= nt - ti;
-    ++ti;
-  }
-  const int tj = ti + rem;
-  const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // eight independent partial sums: the loads of eight chunks are in flight together (the order of the
-  // additions is fixed, so the result does not depend on timing)
-  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const double *p = part + (size_t)tile * 256 + threadIdx.x;
-  const size_t stride = (size_t)ntri * 256;
-  int c = 0;
-  for (; c + 8 <= nchunks; c += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(c + u) * stride];
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (c + u < nchunks) s[u] += p[(size_t)(c + u) * stride];
-  const double s0 = (s[0] + s[1]) + (s[2] + s[3]), s1 = (s[4] + s[5]) + (s[6] + s[7]);
-  const int i = ti * 16 + (lane >> 4) + 4 * q, j = tj * 16 + (lane & 15);
-  if (i < nc && j < nc) G[(size_t)j * nc + i] = s0 + s1;
-}
-
 // G = A^T A in ONE launch, over the rows that exist: the stack holds a slot of mp_max rows per batch entry, and an entry the gate
 // did not take (or an empty system: a pool candidate the selection skipped) is all zeros, so the chunk + reduce pair below multiplied
 // mostly padding (rocprofv3, round 2: 2 MB moved for 0.3 MB of rows).  Here one workgroup owns an upper tile; its four waves share
@@ -249,40 +175,6 @@ __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P
 }
 
 // ========================================================================================== launchers
-// Compression of the stacked m x nc matrix [H | r] (col-major, lda) into R (k x k upper, ldr) and z.
-int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems,
-                         double *d_R, int ldr, double *d_z, const int *d_acc_rows, int F, int mp_max, int *d_n_ambiguous) {
-  const int k = nc - 1;
-  const int nt = cdiv(nc, 16), ntri = nt * (nt + 1) / 2;
-  const int nchunks = cdiv(m, GRAM_CH);
-  const size_t part_elems = (size_t)nchunks * ntri * 256, g_elems = (size_t)nc * nc;
-  if (k > 192 || part_elems + g_elems > tmp_elems) {
-    set_last_error("gram compress: %d columns / %d rows exceed the blocked factorisation's workspace", k, m);
-    return PLV_E_CAPACITY;
-  }
-  double *d_part = d_tmp, *d_G = d_tmp + part_elems;
-  static const bool chunked_only = getenv("PLV_GRAM_CHUNKED") != nullptr;  // (measurement aid)
-  if (d_acc_rows && F * mp_max == m && !chunked_only) {
-    {
-      ProfScope ps(ctx->prof, "gram_direct_kernel", ctx->stream);
-      hipLaunchKernelGGL(gram_direct_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_G, ctx->skip_word,
-                         (double *)nullptr, (double *)nullptr);
-    }
-    return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z, d_n_ambiguous);
-  }
-  {
-    ProfScope ps(ctx->prof, "gram_chunk_kernel", ctx->stream);
-    const size_t shm = (size_t)nc * (GRAM_CH + 1) * sizeof(double);
-    PLV_HIP_CHECK(ensure_dyn_smem((const void *)gram_chunk_kernel, (int)shm));
-    hipLaunchKernelGGL(gram_chunk_kernel, dim3(nchunks), dim3(64 * GRAM_WAVES), shm, ctx->stream, d_A, lda, m, nc, d_part, ctx->skip_word);
-  }
-  {
-    ProfScope ps(ctx->prof, "gram_reduce_kernel", ctx->stream);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntri), dim3(256), 0, ctx->stream, d_part, nchunks, nc, d_G, ctx->skip_word);
-  }
-  return launch_bchol_compress(ctx, d_G, nc, d_R, ldr, d_z, d_n_ambiguous);
-}
-
 bool ekf_fast_fits(int r) { return r <= 192; }
 static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const double *dC, double *d_dx, int *d_flag, const void *mirror_src,
                              void *mirror_dst, size_t mirror_bytes);
@@ -406,26 +298,22 @@ int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const
 // The prior factor decides on the device: the whitened form unless a pivot is DEAD (below PLV_PRIOR_TAU: M has a zero column, W0 a
 // zero row, and the whitened form returned dC ten times P); then the factor form, and if B's diagonal exceeds PLV_WHITEN_LAMBDA_MAX
 // (1e2) the update is handed to the reference's route (status bit 8 -> plv_api.hip RedoW).  Near-dependent pivots (below
-// PLV_PRIOR_AMB) are counted for the record; they selected the factor form until the columns were made exact (PLV_W0_EXACT=1 / 0:
-// the earlier rules, for comparison).  The prior factor, W0 and W0^T W0 only need the covariance, so they run on a side stream while
+// PLV_PRIOR_AMB) are counted for the record.  The prior factor, W0 and W0^T W0 only need the covariance, so they run on a side stream while
 // the main stream triangulates, builds Jacobians and gates; the main chain after the gate is
 // gram -> [B | GP, M^T GP] -> [factor B, solve | C1] -> dC -> commit  (four launches; "|": workgroups of the same launch, those of
 // the factor form return at once when the update takes the whitened one).
 // W0 = M^-1 Pc holds M^T in the columns of the update's own states, and the prior factor has M itself: those columns are COPIED from
 // the factor instead of kept as the substitution left them (M^-1 Ps is M^T only to the substitution's rounding, amplified by the factor's small pivots: see "whitened update").
-// near_selects == 0 (the default): near-dependent pivots no longer select the factor form — their count moves to n_near[4] for the
-// record — only dead ones do.
+// Near-dependent pivots do not select the factor form — their count moves to n_near[4] for the record — only dead ones do.
 __global__ void __launch_bounds__(64) prior_exact_cols_kernel(const double *__restrict__ Lt, int ldl, int k, const int *__restrict__ cols,
-                                                              double *__restrict__ W0, int ldw, int *__restrict__ n_near, int near_selects) {
+                                                              double *__restrict__ W0, int ldw, int *__restrict__ n_near) {
   const int j = blockIdx.x;
   double *dst = W0 + (size_t)cols[j] * ldw;
   const double *src = Lt + (size_t)j * ldl;
-  if (Lt)  // (null: PLV_W0_EXACT=-1, round 3's form for comparison — the columns stay as substituted, no pivot selects the factor form)
-    for (int c = threadIdx.x; c < k; c += 64) dst[c] = c <= j ? src[c] : 0.0;
-  if (j == 0 && threadIdx.x == 0) {
+  for (int c = threadIdx.x; c < k; c += 64) dst[c] = c <= j ? src[c] : 0.0;
+  if (j == 0 && threadIdx.x == 0) {  // near-dependent pivots do not select the factor form: their count moves to n_near[4] for the record
     n_near[4] = n_near[0];
-    if (!near_selects) n_near[0] = 0;
-    if (near_selects < 0) n_near[5] = n_near[1], n_near[1] = 0;  // (PLV_W0_EXACT=3, experiment: dead pivots do not select the factor form either)
+    n_near[0] = 0;
   }
 }
 
@@ -435,14 +323,10 @@ int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, 
       (rc = ctx->d_dW.reserve((size_t)n * n * 8)) || (rc = ctx->d_prior_near.reserve(64)))
     return rc;
   if ((rc = launch_bchol_prior(ctx, st, d_P, ldp, n, d_cols, k, ctx->d_Lt.as<double>(), k, ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>()))) return rc;
-  // PLV_W0_EXACT (tools): 0 = round 4's first scheme (columns as substituted, near-dependent pivots select the factor form), 1 = exact
-  // columns but that selection; default 2; 3 = experiment: dead pivots do not select the factor form either;
-  // -1 = round 3's form: the whitened form always, every column as substituted
-  static const int exact_cols = getenv("PLV_W0_EXACT") ? atoi(getenv("PLV_W0_EXACT")) : 2;
-  if (exact_cols) {
+  {  // the columns of W0 that belong to the update's own states, exact (copied from the factor); near-dependent pivots only counted
     ProfScope ps(ctx->prof, "prior_exact_cols_kernel", st);
-    hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, exact_cols < 0 ? (const double *)nullptr : ctx->d_Lt.as<double>(), k, k, d_cols,
-                       ctx->d_W0.as<double>(), k, ctx->d_prior_near.as<int>(), (exact_cols >= 3 || exact_cols < 0) ? -1 : (exact_cols >= 2 ? 0 : 1));
+    hipLaunchKernelGGL(prior_exact_cols_kernel, dim3(k), dim3(64), 0, st, ctx->d_Lt.as<double>(), k, k, d_cols, ctx->d_W0.as<double>(), k,
+                       ctx->d_prior_near.as<int>());
   }
   {
     ProfScope ps(ctx->prof, "prior_gain_kernel", st);
@@ -480,8 +364,7 @@ int launch_ekf_whitened(plv_ctx *ctx, double *d_P, int n, int ldp, int k, const 
     return rc;
   double *Y0 = ctx->d_Y0.as<double>(), *C1 = ctx->d_C1.as<double>(), *d0 = C1 + (size_t)n * n, *GP = ctx->d_GP.as<double>();
   const int *use_m = ctx->d_prior_near.as<int>();  // (written by the prior factor; the caller has joined the side stream)
-  static const bool force_factor = getenv("PLV_FORCE_FACTOR_FORM") != nullptr;  // (tools / tests: every update takes the factor form)
-  if (force_factor || plv::knob(plv::PLV_KNOB_FORCE_FACTOR_FORM)) {
+  if (plv::knob(plv::PLV_KNOB_FORCE_FACTOR_FORM)) {  // (tools / tests: every update takes the factor form)
     static const int one[2] = {1, 0};
     PLV_HIP_CHECK(hipMemcpyAsync(ctx->d_prior_near.p, one, 8, hipMemcpyHostToDevice, ctx->stream));
   }

@@ -197,7 +197,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
   TRY(check_views(st, tr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int F = tr->n_feat;
-  const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld, nr = (size_t)F * ld;
+  const size_t nHf = (size_t)F * 3 * ld, nHx = (size_t)F * k * ld;
   TRY(us->bHf.reserve_units((size_t)F, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)(3 + k + 1) * ld * 8));
   TRY(us->brows.reserve((size_t)F * 4));
   TRY(us->bcols.reserve((size_t)k * 4));
@@ -225,7 +225,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
-    fuse_tri = project && F <= ft->max_sel && !getenv("PLV_POINT_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
+    fuse_tri = project && F <= ft->max_sel && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
     tri_opt = ft->opt;
@@ -338,7 +338,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
   // PLV_CHAIN_EVENTS=1 (with PLV_HOST_TIMING=1): three timed events on the stream — at entry (the stream is idle: stamped at once),
   // behind the Jacobian launch, behind the update's last kernel — to set the device's view of the chain against the host's phases
-  static const bool chain_events = getenv("PLV_CHAIN_EVENTS") != nullptr && plv::host_phases().on;
+  const bool chain_events = plv::knob(plv::PLV_KNOB_CHAIN_EVENTS) && plv::host_phases().on;
   static hipEvent_t ce[3] = {nullptr, nullptr, nullptr};
   const auto t_entry = std::chrono::steady_clock::now();
   if (chain_events) {
@@ -675,7 +675,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(check_line_views(st, lt, ft == nullptr, ft != nullptr));
   if (k < 1 || ld < 2 || !col_to_state) return PLV_E_BADARG;
   const int L = lt->n_lines;
-  const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld, nr = (size_t)L * ld;
+  const size_t nHf = (size_t)L * 6 * ld, nHx = (size_t)L * k * ld;
   TRY(us->bHf.reserve_units((size_t)L, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)(6 + k + 1) * ld * 8));
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols_l.reserve((size_t)k * 4));
@@ -696,7 +696,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
     TRY(us->tri_l.reserve(total));
     char *d = us->tri_l.as<char>();
     // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
-    fuse_tri = project && L <= ft->max_sel && !getenv("PLV_LINE_TRI_SEPARATE") && !plv::knob(plv::PLV_KNOB_LINE_TRI_SEPARATE);
+    fuse_tri = project && L <= ft->max_sel && !plv::knob(plv::PLV_KNOB_LINE_TRI_SEPARATE);
     tri_cam = (double *)(d + o_cam), tri_imu = (double *)(d + o_imu), tri_valid = (unsigned char *)(d + o_valid);
     tri_lines = (double *)(d + o_lines), tri_ok = (unsigned char *)(d + o_ok);
     if (!fuse_tri) TRY(launch_triangulate_lines(ctx, Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok));

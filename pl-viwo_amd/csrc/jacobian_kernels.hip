@@ -2178,7 +2178,7 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
     if (_rc != PLV_OK) return _rc; \
   } while (0)
 struct JacStampHost {
-  bool on = getenv("PLV_KERNEL_STAMPS") != nullptr;
+  bool on = plv::knob(plv::PLV_KNOB_KERNEL_STAMPS);
   long long *d = nullptr;
   int cap = 0;
   struct Acc {

@@ -213,7 +213,7 @@ void line_worker(LineTracker *T) {
       T->jcv.notify_all();
       continue;
     }
-    static const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+    const bool timing = plv::knob(plv::PLV_KNOB_LINE_TIMING);
     auto W0 = std::chrono::steady_clock::now();
     (void)hipSetDevice(T->job.device);
     int rc = PLV_OK;
@@ -250,7 +250,7 @@ bool join_job(LineTracker *T) {
   auto J0 = std::chrono::steady_clock::now();
   wait_polling(lk, T->jcv, [&] { return T->job_state == 2; });
   T->job_state = 0;
-  if (getenv("PLV_LINE_TIMING"))
+  if (plv::knob(plv::PLV_KNOB_LINE_TIMING))
     fprintf(stderr, "line join: waited %.1f us (posted %.1f us ago)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - J0).count(),
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->job_posted).count());
   return true;
@@ -366,7 +366,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     // in ~0.8 us (measured: 28 ms per frame for the walk on the dense-edge test image, 160 us for fld_fit_kernel's longest
     // chain), a host core in ~30 ns, so both run on the host on the 90 KB edge map and the half-resolution image (DESIGN.md "Line
     // detector"); the pixel work (resize, Sobel, non-maximum suppression, hysteresis) stays on the device.
-    const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+    const bool timing = plv::knob(plv::PLV_KNOB_LINE_TIMING);
     if (prelaunched) {  // plv_line_detect_launch posted the job: the worker thread has been walking meanwhile
       const bool had = join_job(T);
       if (had && T->job.rc == PLV_OK) {
@@ -680,7 +680,7 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
   } else {
     TRY(detect(ctx, T, PLV_PYR_CUR, lines));
   }
-  const bool timing = getenv("PLV_LINE_TIMING") != nullptr;
+  const bool timing = plv::knob(plv::PLV_KNOB_LINE_TIMING);
   auto F0 = std::chrono::steady_clock::now();
   const int nl = (int)lines.size() / 4;
   plv::counters().lines_detected += (unsigned long long)nl;
@@ -999,8 +999,7 @@ void discard_line_pool(LineTracker *T) {
 // update runs on the device.  Never blocks: returns 0 while the feed is still on the worker (try again), 1 when the pool is formed or
 // cannot be formed ahead of time (plv_camera_update_lines then forms it).
 int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
-  static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;  // (measurement aid: the pool formed after the point update as before)
-  if (late || plv::knob(plv::PLV_KNOB_POOL_LATE) || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return 1;  // (a calibrated time offset moves the window test)
+  if (plv::knob(plv::PLV_KNOB_POOL_LATE) || !ctx || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return 1;  // (a calibrated time offset moves the window test)
   LineTracker *T;
   {
     std::lock_guard<std::mutex> lk(g_mtx);
@@ -1027,10 +1026,9 @@ int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_upda
 // (internal, plv_camera_frame) the frame's line feed is about to be posted and a line update follows: the worker forms that update's
 // pool at the end of the feed.  Same conditions as plv_line_pool_prepare.
 void plv_line_feed_pool_args(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt) {
-  static const bool late = getenv("PLV_LINE_POOL_LATE") != nullptr;
   LineTracker *T = ltr(ctx);
   T->feed.pool_on = false;
-  if (late || plv::knob(plv::PLV_KNOB_POOL_LATE) || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return;
+  if (plv::knob(plv::PLV_KNOB_POOL_LATE) || !st || !opt || opt->cpi || st->n_clones < 2 || st->dt_state_id >= 0) return;
   T->feed.pool_args = PoolArgs::of(st, opt);
   T->feed.pool_on = true;
 }
@@ -1275,7 +1273,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   if (!ctx || !st || !opt || !dx || !res || st->n_clones < 2 || opt->max_obs < 2) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
   *res = plv_update_result{0, 0, 0, 0, 0, PLV_OK, 0, 0, 0};
-  static const bool timing = getenv("PLV_UPDATE_TIMING") != nullptr;
+  const bool timing = plv::knob(plv::PLV_KNOB_UPDATE_TIMING);
   plv::NsScope ns_lines(plv::counters().lines_ns);
   plv::HostPhase ph_all("update_lines: whole call");
   plv::RoctxRange rx_line("[Time-Cam] LINE update");

@@ -208,10 +208,6 @@ int plv_ctx_create(const plv_config *cfg, plv_ctx **out) {
     return PLV_E_DEVICE;
   }
   auto *us = new plv_ctx_update_state();
-  if (const char *e = getenv("PLV_COMPRESS_MODE")) {  // (measurement aid: tools/ab.sh compares the routes on one box)
-    const int m = atoi(e);
-    if (m >= 0 && m <= 3) us->compress_mode = m;
-  }
   // chi-square table (REF: UpdaterStatistics.cpp:31-37)
   std::vector<double> q(Q95_N, 0.0);
   for (int i = 1; i < Q95_N; ++i) q[i] = chi2_quantile(i, 0.95);
@@ -701,7 +697,7 @@ int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double
   g.stack = ctx->stack_of(fdim).as<double>();
   g.lds = Mtot;
   g.mp_max = mp_max;
-  g.stack_accepted_only = (Mtot > k && k <= 192 && (whitened_route(us, Mtot, k) || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
+  g.stack_accepted_only = (Mtot > k && k <= 192 && whitened_route(us, Mtot, k)) ? 1 : 0;
   if (probe) {  // the verdicts also go to pinned memory (the caller adds the second block: probe_src / probe_dst / strides)
     char *hb = hpin.as<char>();
     g.h_accepted = (unsigned char *)(hb + (size_t)n * 8 + 16);
@@ -744,8 +740,7 @@ static int prior_start(plv_ctx *ctx, const int *d_cols, int k) {
 // Jacobians and gate.
 int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max) {
   auto *us = ustate(ctx);
-  static const bool late = getenv("PLV_PRIOR_LATE") != nullptr;  // (measurement aid: the prior factor starts behind the Jacobian launch)
-  if (late || us->prior_late || plv::knob(plv::PLV_KNOB_PRIOR_LATE) || !whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
+  if (plv::knob(plv::PLV_KNOB_PRIOR_LATE) || !whitened_route(us, F * mp_max, k) || ctx->cov_n < 1) return PLV_OK;
   if (phase == 0) return prior_mark(ctx);
   TRY(prior_start(ctx, d_cols, k));
   ctx->prior_pending = true;
@@ -816,7 +811,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   TRY(hpin.reserve(rb));
   struct SkipGuard {  // the words are only meaningful for the kernels of this update
     plv_ctx *c;
-    ~SkipGuard() { c->skip_word = nullptr, c->commit_veto = nullptr; }
+    ~SkipGuard() { c->skip_word = nullptr; }
   } skip_guard{ctx};
   // Whitened route (mode 0, DESIGN.md "Whitened update").  Its prior factor only needs the covariance: the one-submission updates
   // start it on the side stream before their Jacobian launch (plv_prior_prefetch); otherwise it starts here.
@@ -881,7 +876,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   a.n_acc = d_flag + 1;           // second word of the status block
   // with more rows than columns the stack goes to gram_direct_kernel, which walks the accepted entries only (not in the modes that may
   // hand the whole stack to the Householder route, nor beyond its 192-column capacity)
-  a.stack_accepted_only = (Mtot > k && k <= 192 && (whiten || (us->compress_mode == 3 && !getenv("PLV_GRAM_CHUNKED")))) ? 1 : 0;
+  a.stack_accepted_only = (Mtot > k && k <= 192 && whiten) ? 1 : 0;
   // read by every kernel enqueued from here on (cleared after enqueue()); only the blocked-Cholesky route honours it in all of
   // its kernels, so the Householder / LDS-resident fallbacks (more than 192 columns) run unconditionally
   ctx->skip_word = (Mtot > k ? k <= 192 : ekf_fast_fits(Mtot)) ? d_flag + 1 : nullptr;
@@ -911,7 +906,6 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     TRY(launch_chi2(ctx, F, a, mp_max));
   }
   us->last_route = 0;  // (before the probe's early return: a line update that ends at the gate must not report the point update's route)
-  us->redo.armed = false;
   us->redo_w.armed = false;
   if (probe) {
     // the gate's verdicts are in pinned memory when its launch has finished: most line updates end here (three frames in four at
@@ -930,9 +924,6 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
 
   const double *dH, *dr;
   int r, ldh;
-  us->last_route = 0;
-  us->redo.armed = false;
-  us->redo_w.armed = false;
   if (whiten) {
     // REF: measurement_compress_inplace + EKFUpdate as one whitened step: no triangular factor of the measurements is formed
     TRY(launch_gram_information(ctx, ctx->stack_of(fdim).as<double>(), Mtot, nc, d_acc_rows, F, mp_max));
@@ -943,38 +934,16 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
     return PLV_OK;
   }
   if (Mtot > k) {
-    // REF: measurement_compress_inplace — [R z] with R^T R = H^T H (Gram + LDS Cholesky)
-    TRY(ctx->d_H.reserve((size_t)k * k * 8));
-    TRY(ctx->d_res.reserve((size_t)k * 8));
-    int crc = PLV_E_CAPACITY;
-    if (us->compress_mode != 1) {
-      crc = launch_gram_compress(ctx, ctx->stack_of(fdim).as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems,
-                                 ctx->d_H.as<double>(), k, ctx->d_res.as<double>(), d_acc_rows, F, mp_max, d_flag + 3);
-      if (crc == PLV_OK) {
-        us->last_route = 1;
-        if (us->compress_mode == 2 && ekf_fast_fits(k) && !us->graph_mode) {  // the commit waits for the verdict on the pivots
-          ctx->commit_veto = d_flag + 3;
-          us->redo = plv_ctx_update_state::Redo{true, Mtot, k, n, tmp_elems, rb, d_dx, d_flag};
-        }
-      }
-    }
-    if (crc == PLV_OK) {
-      dH = ctx->d_H.as<double>();
-      dr = ctx->d_res.as<double>();
-      r = k;
-      ldh = k;
-    } else if (crc == PLV_E_CAPACITY) {  // too many columns for the LDS-resident factorisation: Householder TSQR
-      double *R;
-      int ldr;
-      TRY(launch_tsqr(ctx, ctx->stack_of(fdim).as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
-      dH = R;
-      dr = R + (size_t)k * ldr;
-      r = k;
-      ldh = ldr;
-      us->last_route = 2;
-    } else {
-      return crc;
-    }
+    // REF: measurement_compress_inplace — [R z] by Householder reflections on the stacked rows (TSQR): mode 1, and whatever the
+    // whitened update does not take (more than 192 columns, graph mode)
+    double *R;
+    int ldr;
+    TRY(launch_tsqr(ctx, ctx->stack_of(fdim).as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr));
+    dH = R;
+    dr = R + (size_t)k * ldr;
+    r = k;
+    ldh = ldr;
+    us->last_route = 2;
   } else {
     dH = ctx->stack_of(fdim).as<double>();
     dr = dH + (size_t)k * Mtot;
@@ -1053,9 +1022,8 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
   REQUIRE_CTX(ctx);
   auto *us = ustate(ctx);
   if (mode >= 0) {
-    if (mode > 4) return PLV_E_BADARG;  // (4 = measurement aid, not in the header: mode 0 with the prior factor started behind the Jacobian launch)
-    us->prior_late = mode == 4;  // (measurement aid: mode 0 with the prior factor started behind the Jacobian launch)
-    us->compress_mode = mode == 4 ? 0 : mode;
+    if (mode > 1) return PLV_E_BADARG;  // (round 5: the Gram + Cholesky compression of rounds 2-3 — modes 2 and 3 — is gone)
+    us->compress_mode = mode;
   }
   if (last_route) *last_route = us->last_route;
   if (last_ambiguous) *last_ambiguous = us->last_ambiguous;
@@ -1104,24 +1072,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   us->word_seq = 0;
   const char *hb = hpin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
-  us->last_ambiguous = us->last_route == 1 ? ((const int *)(hb + (size_t)n * 8))[3] : 0;
-  if (us->redo.armed && us->last_ambiguous > 0 && (*(const int *)(hb + (size_t)n * 8) & ~8) == 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
-    // automatic mode: the Gram factorisation met pivots it could not tell from zero and ekf_commit_kernel left the covariance alone.
-    // The stacked rows are still in place: compress them by Householder reflections (orthogonal transformations on the rows
-    // themselves resolve what the squared matrix cannot) and run the EKF step again.
-    const plv_ctx_update_state::Redo rd = us->redo;
-    us->redo.armed = false;
-    double *R;
-    int ldr;
-    const int nc = rd.k + 1;
-    TRY(launch_tsqr(ctx, ctx->stack_of(wfdim).as<double>(), rd.Mtot, rd.Mtot, nc, ctx->d_stack2.as<double>(), rd.tmp_elems, &R, &ldr));
-    TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), rd.n, rd.n, R, rd.k, rd.k, ldr, us->bcols_of(wfdim).as<int>(), R + (size_t)rd.k * ldr, nullptr, rd.d_dx,
-                        rd.d_flag, true, us->result_of(us->pending_fdim).p, hpin.p, ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3));
-    TRY(sync(ctx));
-    ++ctx->gather_stamp;
-    us->last_route = 3;
-  }
-  us->redo.armed = false;
+  us->last_ambiguous = 0;
   if (us->redo_w.armed && us->last_route == 4 && *(const int *)(hb + (size_t)n * 8) != 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
     // The whitened update came back rejected (update_state.hpp, RedoW): nothing was committed.  The stacked rows are run again the
     // reference's way — compression, then S = R P R^T + I — with the compression by Householder reflections on the rows themselves
@@ -1133,7 +1084,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     us->redo_w.armed = false;
     const int nc = rd.k + 1;
     const size_t mb = ((size_t)rd.n * 8 + 16 + 3) & ~(size_t)3;
-    ctx->skip_word = nullptr, ctx->commit_veto = nullptr;
+    ctx->skip_word = nullptr;
     double *R;
     int ldr;
     // (the accepted rows gathered into a dense matrix first: the stack is F x mp_max slots, most of them empty, and the tree of

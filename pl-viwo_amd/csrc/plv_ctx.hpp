@@ -83,12 +83,22 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 // 4096 the point update's wait keeps polling its hook until the hook is done even when the device has finished (tests: every frame's
 //      line launch is chained, whatever the timing of the line worker)
 enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_KNOB_EDGES_SIDE = 1u, PLV_KNOB_PRIOR_LATE = 2u, PLV_KNOB_EDGES_LATE = 4u, PLV_KNOB_AHEAD_CTX = 8u, PLV_KNOB_POOL_LATE = 16u,
-                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u, PLV_KNOB_EDGES_AFTER_PYRAMID = 512u, PLV_KNOB_FORCE_FACTOR_FORM = 8192u };
+                  PLV_KNOB_POINT_TRI_SEPARATE = 32u, PLV_KNOB_LINE_TRI_SEPARATE = 64u, PLV_KNOB_INPUTS_PINNED = 128u, PLV_KNOB_DONE_WORDS = 256u, PLV_KNOB_GATE_SEPARATE = 1024u, PLV_KNOB_EDGES_AFTER_PYRAMID = 512u, PLV_KNOB_FORCE_FACTOR_FORM = 8192u,
+                  // reporting aids (round 5: every measurement switch that used to be an environment variable of its own is a bit here)
+                  PLV_KNOB_HOST_TIMING = 1u << 14,    // phase table of the host side on stderr when the library unloads (HostPhases)
+                  PLV_KNOB_LINE_TIMING = 1u << 15,    // the line worker's stages, per frame, on stderr
+                  PLV_KNOB_UPDATE_TIMING = 1u << 16,  // the line update's stages, per call, on stderr
+                  PLV_KNOB_KERNEL_STAMPS = 1u << 17,  // s_memtime stamps of the fused Jacobian launches' phases
+                  PLV_KNOB_CHAIN_EVENTS = 1u << 18,   // HIP events around the chained launches (with HOST_TIMING)
+                  PLV_KNOB_ALLOC_DEBUG = 1u << 19,    // every (re)allocation of a library buffer with a backtrace
+                  PLV_KNOB_HOST_FAULTS = 1u << 20 };  // HostPhase counts minor page faults instead of time
+// The mask starts from PLV_DEBUG_KNOBS in the environment (the library's only measurement variable; plv_debug_knobs changes it at run time)
 inline std::atomic<unsigned> &knobs() {
-  static std::atomic<unsigned> k{0};
+  static std::atomic<unsigned> k{getenv("PLV_DEBUG_KNOBS") ? (unsigned)strtoul(getenv("PLV_DEBUG_KNOBS"), nullptr, 0) : 0u};
   return k;
 }
 inline bool knob(unsigned bit) { return (knobs().load(std::memory_order_relaxed) & bit) != 0; }
+inline bool alloc_debug() { return knob(PLV_KNOB_ALLOC_DEBUG); }
 
 // Host-side phase timing (PLV_HOST_TIMING=1): accumulated wall time per label, printed to stderr when the library unloads.
 struct HostPhases {
@@ -111,7 +121,7 @@ struct HostPhases {
       return m ? tmp[m / 2] : 0.0;
     }
   };
-  bool on = getenv("PLV_HOST_TIMING") != nullptr;
+  bool on = knob(PLV_KNOB_HOST_TIMING);
   std::mutex mtx;
   std::vector<Rec> recs;
   void add(const char *label, double us) {
@@ -169,8 +179,7 @@ struct HostPhase {  // scope timer (PLV_HOST_FAULTS=1: the scope's minor page fa
   long f0 = 0;
   bool on;
   static bool faults() {
-    static const bool f = getenv("PLV_HOST_FAULTS") != nullptr;
-    return f;
+    return knob(PLV_KNOB_HOST_FAULTS);
   }
   explicit HostPhase(const char *l) : label(l), on(host_phases().on) {
     if (on && faults()) f0 = thread_minor_faults();
@@ -224,8 +233,7 @@ struct DevBuf {
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
     ++alloc_epoch();
-    static const bool dbg = getenv("PLV_ALLOC_DEBUG") != nullptr;
-    if (dbg) {
+    if (alloc_debug()) {
       fprintf(stderr, "[plv alloc] device buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
       void *bt[8];
       backtrace_symbols_fd(bt, backtrace(bt, 8), 2);
@@ -262,8 +270,7 @@ struct PinBuf {
   int reserve(size_t bytes) {
     if (bytes <= cap) return PLV_OK;
     ++alloc_epoch();  // kernels write into pinned blocks too (result mirrors): a captured graph holds their addresses
-    static const bool dbg = getenv("PLV_ALLOC_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[plv alloc] pinned buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
+    if (alloc_debug()) fprintf(stderr, "[plv alloc] pinned buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;

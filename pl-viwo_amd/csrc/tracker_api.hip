@@ -111,8 +111,7 @@ extern "C" void plv_line_edges_early(plv_ctx *ctx, const uint8_t *d_raw, int W, 
 // the image feed with the line detector's edge kernel between its histogram and its pyramid (plv_ctx::edges_hook) when the frame's
 // lines are detected ahead of the line tracker's feed anyway; PLV_LINE_EDGES_LATE / the edge knobs keep the older orders
 static int feed_with_early_edges(plv_ctx *ctx, const std::function<int()> &feed) {
-  static const bool late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
-  const bool early = !late && !plv::knob(plv::PLV_KNOB_EDGES_LATE | plv::PLV_KNOB_EDGES_SIDE | plv::PLV_KNOB_EDGES_AFTER_PYRAMID) && plv_line_prefetch_enabled(ctx) != 0;
+  const bool early = !plv::knob(plv::PLV_KNOB_EDGES_LATE | plv::PLV_KNOB_EDGES_SIDE | plv::PLV_KNOB_EDGES_AFTER_PYRAMID) && plv_line_prefetch_enabled(ctx) != 0;
   ctx->edges_hook_fired = false;
   ctx->edges_hook = early ? plv_line_edges_early : nullptr;
   const int rc = feed();
@@ -216,8 +215,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     // paths that meet at the line update; PLV_LINE_EDGES_LATE=1 restores the old order
     // (plv_line_edges_fork: a measurement knob that puts the kernel on its own stream behind the pyramid instead — the flow then does
     //  not wait 18 us for it, and yet the frame is 6-15 us slower, measured alternating frame by frame)
-    static const bool edges_late = getenv("PLV_LINE_EDGES_LATE") != nullptr;
-    if (!edges_late && !plv::knob(plv::PLV_KNOB_EDGES_LATE) && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
+    if (!plv::knob(plv::PLV_KNOB_EDGES_LATE) && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
     const int rc_l = plv_perform_matching_launch(ctx, n, pts.data(), pts_new.data());
     launch_prefetch();  // (inside the wait for the flow)
     if (rc_l == PLV_OK) plv_line_run_deferred(ctx);  // the previous frame's line database hand-back, if one was left behind
@@ -1029,9 +1027,8 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   // the next frame's top-up detection runs on the side stream next to the point update.  (Round 2 placed it on the ctx stream behind
   // the update when a line update follows; since the line pool is formed inside the point update's wait, the line update is submitted
   // right after that wait and would queue behind the detection: PLV_AHEAD_CTX=1 restores that placement for measurements.)
-  static const bool ahead_ctx = getenv("PLV_AHEAD_CTX") != nullptr;
   T->defer_db = io->opt_lines != nullptr;
-  T->ahead_on_ctx_stream = io->opt_lines != nullptr && (ahead_ctx || plv::knob(plv::PLV_KNOB_AHEAD_CTX));
+  T->ahead_on_ctx_stream = io->opt_lines != nullptr && plv::knob(plv::PLV_KNOB_AHEAD_CTX);
   T->early_st = io->opt_lines ? st : nullptr;
   T->early_lines = io->opt_lines;
   T->early_cap = io->line_cap;

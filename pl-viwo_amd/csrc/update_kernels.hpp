@@ -56,11 +56,6 @@ void launch_ekf_ms(plv_ctx *ctx, const double *d_P, int n, int ldp, const double
                    int *d_flag = nullptr);
 // `gathered`: launch_gather_cov already ran for this (P, cols) and P has not changed since
 // dense_kernels.hip
-// d_acc_rows (F entries, slot of mp_max rows each, F * mp_max == m): rows per entry the gate accepted (0: the slot is all zeros) —
-// the Gram matrix is then formed over those rows only, in one launch
-int launch_gram_compress(plv_ctx *ctx, const double *d_A, int lda, int m, int nc, double *d_Gp, size_t gp_elems,
-                         double *d_R, int ldr, double *d_z, const int *d_acc_rows = nullptr, int F = 0, int mp_max = 0,
-                         int *d_n_ambiguous = nullptr);
 bool ekf_fast_fits(int r);
 int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
                     const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false, const void *mirror_src = nullptr,
@@ -79,8 +74,6 @@ int launch_bchol_prior(plv_ctx *ctx, hipStream_t st, const double *d_P, int ldp,
                        double *d_W0, int ldw, int *d_n_near);
 
 // blocked_chol.hip
-// d_n_ambiguous (nullable): receives the number of pivots the factorisation could not tell from zero (blocked_chol.hpp, diag_chain)
-int launch_bchol_compress(plv_ctx *ctx, const double *d_G, int nc, double *d_R, int ldr, double *d_z, int *d_n_ambiguous = nullptr);
 struct WhitenC1Args {  // (whitened update: the tiles of C1 = P[:, cols] GP ride along in spare workgroups: blocked_chol.hip WhitenC1)
   const double *P;
   int ldp;

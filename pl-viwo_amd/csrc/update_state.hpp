@@ -22,17 +22,9 @@ struct plv_ctx_update_state {
   // factor of the measurements), 1 = Householder TSQR on the stacked rows, 2 = Gram + Cholesky first, redone through the Householder
   // route when its factorisation reports pivots it could not resolve, 3 = Gram matrix + blocked Cholesky (the round-2 default)
   int compress_mode = 0;
-  bool prior_late = false;  // measurement aid (mode 4)
   int last_route = 0;       // of the last update: 0 none / not compressed, 1 Gram + Cholesky, 2 Householder, 3 Gram vetoed and redone by Householder, 4 whitened,
                             // 5 whitened came back rejected / withheld and was run again by Householder reflections (redo_w)
   int last_ambiguous = 0;   // pivots the last Gram factorisation could not tell from zero
-  struct Redo {             // what the automatic mode needs to run the update again from the stacked rows
-    bool armed = false;
-    int Mtot = 0, k = 0, n = 0;
-    size_t tmp_elems = 0, rb = 0;
-    double *d_dx = nullptr;
-    int *d_flag = nullptr;
-  } redo;
   // Status block of a LINE update (round 4): the chained line launch reads the point update's dx from `result` while its own gate
   // writes verdicts — and a larger line batch may make its block grow — so the two measurement kinds keep separate blocks, each with
   // its own pair of alternating accepted-entry counters.

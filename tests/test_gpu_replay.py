@@ -376,7 +376,7 @@ def test_chained_line_launch_equals_the_unchained(pkg, street_dataset, tmp_path)
 
 
 def test_prior_factor_started_late_equals_the_prefetched(pkg, street_dataset, tmp_path):
-    """The whitened update's prior factor started behind the Jacobian launch (measurement knob 2 = plv_update_compression_mode 4: the
+    """The whitened update's prior factor started behind the Jacobian launch (measurement knob 2, plv_debug_knobs: the
     side stream reads the column map that launch publishes, so it must be ordered behind it — ADVICE r3: it was not) against the
     default (started from the pinned staging block before the launch): the same filter, bit for bit, over alternating point and
     line updates (their column sets differ, so a stale map would show at once)."""

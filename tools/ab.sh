@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of library variants on ONE box (box-to-box variation is larger than most single changes): runs bench.py (GPU leg only) once per
 # environment setting given as arguments ("-" = default), alternating three times, and prints mean / p50 / p99 of each run.
-# usage: bash tools/ab.sh "-" "PLV_LINE_EDGES_LATE=1" ...
+# usage: bash tools/ab.sh "-" "PLV_DEBUG_KNOBS=4" ...
 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-stress --no-pcie --no-variants --stream-cache /tmp/plv_stream_c.npz > /dev/null 2>&1   # renders once
 for rep in 1 2 3; do
   for v in "$@"; do

@@ -1,5 +1,5 @@
-"""Wall time per host phase of one camera frame (workload C): the Python-level calls of the driver and, with PLV_HOST_TIMING=1, the
-library's own phase timers (printed when it unloads).   usage (GPU box): PLV_HOST_TIMING=1 python tools/host_phases.py"""
+"""Wall time per host phase of one camera frame (workload C): the Python-level calls of the driver and, with PLV_DEBUG_KNOBS=16384, the
+library's own phase timers (printed when it unloads).   usage (GPU box): PLV_DEBUG_KNOBS=16384 python tools/host_phases.py"""
 import sys, os, time, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
