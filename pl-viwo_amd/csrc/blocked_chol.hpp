@@ -233,6 +233,42 @@ __device__ __forceinline__ d4 strip_chain(d4 W, LDS &lds, int p) {
   return cap;
 }
 
+// -DPLV_BC_FOLLOW_BARRIER (round 5; NOT the default): the same sixteen steps applied once the diagonal wave has
+// published ALL of them (blocked_chol then puts a barrier in between): no polling, the step records come out of LDS eight at a time
+// ahead of the MFMAs that use them.  Same operations in the same order as strip_chain: the same bits (fingerprint in
+// tools/ubench/bchol_time.hip).  The premise was that the strips' polling slows the pivot chain down (340-390 cycles per step in the
+// kernel against 170 in tools/ubench/diag_step.hip).  Measured with stamps at r = 104, n = 121 (profiles/r05/bchol_time.txt): the
+// diagonal wave's chain takes 5.7-5.8 k cycles per panel with the strips asleep at the barrier and 5.8-6.6 k with them polling — the
+// step's own dependent sequence (four lane reads, ~11 double-precision operations and a reciprocal behind an MFMA result: ~360
+// cycles) is what it costs, not the company — and putting the strips' 2 k cycles behind it instead of beside it makes the kernel
+// SLOWER: 33.3 us against 30.8 us per launch back to back.  Kept for the record and for the next attempt, which has to shorten the
+// step itself.
+template <class LDS>
+__device__ __forceinline__ d4 strip_follow(d4 W, LDS &lds, int p) {
+  const int lane = threadIdx.x & 63;
+  const int lq = lane >> 4;
+  d4 cap = {0, 0, 0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    d2 d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = lds_vload(reinterpret_cast<const d2 *>(&lds.Ts[p & (PLV_BC_TSP - 1)][8 * h + u][lane][0]));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int jj = 8 * h + u, kk = jj & 3, rq = jj >> 2;
+      const double brow = W[rq];
+      cap[rq] = (lq == kk) ? brow : cap[rq];
+      W = __builtin_amdgcn_mfma_f64_16x16x4f64(d[u][0], brow * d[u][1], W, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double pvq = lds_vload(&lds.rs[p & 1][lq + 4 * q]);
+    cap[q] *= pvq > 0.0 ? rsqrt_nr(pvq) : 0.0;
+  }
+  return cap;
+}
+
 template <int NT, class Ops, class LDS>
 __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, double tau, int strip, double amb = 0.0) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform roles
@@ -320,12 +356,20 @@ __device__ __forceinline__ void blocked_chol(Ops &ops, LDS &lds, int k, int nb, 
           if (c <= li) ops.store_sym(p * 16 + li, p * 16 + c, cap[q] * (pvc > 0.0 ? rsqrt_nr(pvc) : 0.0));
         }
       }
-#ifdef PLV_BC_SOLO
-    } else if (false) {
-#else
-    } else if (below) {
+    }
+#if !defined(PLV_BC_FLAGS) && defined(PLV_BC_FOLLOW_BARRIER)
+    __syncthreads();  // the panel's sixteen steps and its pivots are in LDS: the strips apply them in one go (strip_follow)
 #endif
+#ifdef PLV_BC_SOLO
+    if (false) {
+#else
+    if (!(is_sym && t == p) && below) {
+#endif
+#if !defined(PLV_BC_FLAGS) && defined(PLV_BC_FOLLOW_BARRIER)
+      x = strip_follow(acc[0], lds, p);
+#else
       x = strip_chain(acc[0], lds, p);
+#endif
       BC_STAMP(43 + p);
 #ifdef PLV_BC_FLAGS
       // the strip that holds the next diagonal tile: that tile needs nothing but this strip's own X (which the lane that would read
