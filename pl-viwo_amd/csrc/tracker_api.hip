@@ -288,6 +288,12 @@ static int poll_line_pool(void *arg) {
   Tracker *T = trk(ctx);
   if (!T->early_lines || !T->early_st) return 1;
   if (!plv_line_pool_prepare(ctx, T->early_st, T->early_lines)) return 0;  // (the frame's line feed is still on the worker: try again)
+  if (plv::host_phases().on) {  // (why a frame's line launch was or was not chained: counts in the phase table)
+    plv::host_phases().add("chain: pool ready inside the point wait (count)", 1.0);
+    if (!T->chain_ok) plv::host_phases().add("chain: no - the point pool exceeds max_msckf or holds no candidate (count)", 1.0);
+    if (!ctx->chain.ready) plv::host_phases().add("chain: no - state variables not chainable (count)", 1.0);
+    if (!plv_update_state(ctx)->applied_armed) plv::host_phases().add("chain: no - the point launch did not arm the applied word (count)", 1.0);
+  }
   // The line half's first half right here, its launch enqueued behind the point update that is still running (round 4): what used to
   // sit between the two device chains — wake-up, selection, dx applied, line staging, upload, launch: ~45 us of idle device — is gone.
   if (T->chain_ok && ctx->chain.ready && plv_update_state(ctx)->applied_armed && !plv::knob(plv::PLV_KNOB_NO_CHAIN))

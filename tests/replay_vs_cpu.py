@@ -29,7 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=24.0)
     ap.add_argument("--out")
-    ap.add_argument("--style", default="street", choices=["street", "room", "avenue"], help="street: corridor drive (lines on); room: round 1's scene")
+    ap.add_argument("--style", default="street", choices=["street", "room", "avenue", "boulevard"], help="street: corridor drive (lines on); room: round 1's scene; boulevard: round 5's bench scene (use --mount 16,90)")
+    ap.add_argument("--mount", default="12,0", help="camera mount: pitch, yaw to the right of the driving direction, degrees (tests/synth_dataset.py set_mount)")
     ap.add_argument("--no-lines", action="store_true")
     ap.add_argument("--cam-hz", type=float, default=10.0)
     ap.add_argument("--size", default="752x480", help="image size; 1280x720 with --points 500 --cam-hz 20 is BASELINE configs[3]")
@@ -40,13 +41,14 @@ def main():
     a = ap.parse_args()
     W, H = (int(v) for v in a.size.split("x"))
     sd.set_camera(W, H)
+    sd.set_mount(*(float(v) for v in a.mount.split(",")))
     pkg = ge.load_pkg()
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     d = tempfile.mkdtemp(prefix="plv_synth_")
     sd.make_dataset(d, a.seconds, cam_hz=a.cam_hz, style=a.style, workers=min(32, os.cpu_count() or 1))
     gt = os.path.join(d, "gt.txt")
     lines = not a.no_lines
-    res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene (rendered {a.size} images at {a.cam_hz:g} Hz, {a.points} points, 200 Hz IMU, 50 Hz wheel)",
+    res, runs = dict(seconds=a.seconds, dataset=f"tests/synth_dataset.py, {a.style} scene, camera mount {a.mount} (rendered {a.size} images at {a.cam_hz:g} Hz, {a.points} points, 200 Hz IMU, 50 Hz wheel)",
                      lines="on in both runs" if lines else "off in both runs",
                      intrinsics="fixed (not in the state)" if a.fixed_intrinsics else "calibrated online where the bench settings apply"), {}
     ctx = pkg.Context(pkg.default_config(W, H))
@@ -63,8 +65,8 @@ def main():
         r0 = pkg.route_counts()
         stats, times, poses = rp.replay(op, decisions=dec, **kw)
         if name == "hip":
-            res["hip_updates_by_route"] = dict(zip(("uncompressed", "gram_cholesky", "householder", "gram_then_householder", "whitened", "whitened_rejected_then_householder"),
-                                                   [a - b for a, b in zip(pkg.route_counts(), r0)][:6]))
+            res["hip_updates_by_route"] = {k: v for k, v in zip(("uncompressed", None, "householder", None, "whitened", "whitened_rejected_then_householder"),
+                                                                [x - y for x, y in zip(pkg.route_counts(), r0)][:6]) if k}
         et, ep = pkg.traj_load(traj)[:2]
         gt_t, gt_p = pkg.traj_load(gt)[:2]
         ei, gi = pkg.traj_associate(et, gt_t)
