@@ -65,7 +65,7 @@ WORKLOADS = {
 PROLOGUE = 24      # frames before the warm-up: initialisation + the first full clone window (untimed set-up)
 LEAD_IN = 2        # untimed steps at the start of every timed segment, after its garbage collection (see timed_segment)
 IMU, WHEEL, CAM = 0, 1, 2
-ROUND = "r04"
+ROUND = "r05"
 
 
 # --------------------------------------------------------------------------------------------------------------- the stream
