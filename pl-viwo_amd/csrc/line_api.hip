@@ -112,7 +112,7 @@ struct LineTracker {
   DevBuf half, map, work, pts, chains, counts, segs, seg_count, uv_in, uv_out;
   // Component labels of the edge map (line_kernels.hip ccl_*_kernel) for the worker's host stage: formed on a stream of their own behind
   // the edge kernel, next to the point front-end's flow; the worker waits for labels_ready before it splits the detection by them
-  DevBuf lab;
+  DevBuf lab, lab_cnt, lab_roots;
   hipStream_t ccl_stream = nullptr;
   hipEvent_t canny_done = nullptr, labels_ready = nullptr;
   PinBuf pin;
@@ -149,7 +149,7 @@ struct LineTracker {
   std::thread worker;
   std::mutex jm;
   std::condition_variable jcv;
-  int job_state = 0;  // 0 idle, 1 posted, 2 done; -1 quit
+  std::atomic<int> job_state{0};  // 0 idle, 1 posted, 2 done; -1 quit (written under jm, polled without it: wait_polling)
   // plv_line_tracker_feed_async: the rest of TrackLSD::feed_monocular (assignment, matching, classification, track store) as a
   // second job of the same thread.  While it is posted the worker owns the tracker state; every entry point joins it first (ltr()).
   struct FeedJob {
@@ -165,7 +165,7 @@ struct LineTracker {
     bool pool_on = false;
     PoolArgs pool_args;
   } feed;
-  int feed_state = 0;  // 0 idle, 1 posted, 2 done
+  std::atomic<int> feed_state{0};  // 0 idle, 1 posted, 2 done
   std::chrono::steady_clock::time_point job_posted, feed_posted;
   // Second half of the host stage on a thread of its own: segments are grown along chain c while the walk is still producing chain
   // c + 1 (the walk publishes its chain count after every chain; both halves are sequential in themselves, the two overlap)
@@ -331,7 +331,11 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   const bool with_labels = launch_only && maps_to_host && !labels_off;
   if (with_labels) {
     TRY(T->lab.reserve(npix * sizeof(int)));
+    TRY(T->lab_cnt.reserve(npix * sizeof(int)));
+    TRY(T->lab_roots.reserve(plv::line_label_roots_bytes()));
     b.lab_work = T->lab.as<int>();
+    b.lab_cnt = T->lab_cnt.as<int>();
+    b.lab_roots = T->lab_roots.as<int>();
     b.lab_out = (uint8_t *)(hp + lab_off);
   }
   hipStream_t es = ctx->stream;
@@ -349,7 +353,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     }
     PLV_HIP_CHECK(hipEventRecord(T->canny_done, es));
     PLV_HIP_CHECK(hipStreamWaitEvent(T->ccl_stream, T->canny_done, 0));
-    TRY(launch_line_labels(ctx, w, h, plv::linehost::Fit::kParts, b, T->ccl_stream));
+    TRY(launch_line_labels(ctx, w, h, b, T->ccl_stream));
     PLV_HIP_CHECK(hipEventRecord(T->labels_ready, T->ccl_stream));
   }
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;
@@ -385,7 +389,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     J.hpts = (int2 *)(hp + bytes + ((2 * npix + 63) & ~(size_t)63));
     J.hc = (FldChain *)(hp + 16);
     J.hlab = with_labels ? b.lab_out : nullptr;
-    J.parts = with_labels ? plv::linehost::Fit::kParts : 0;
+    J.parts = with_labels ? plv::line_label_parts() : 0;
     if (!maps_to_host) {
       PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
       PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
@@ -402,6 +406,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
         T->job_posted = std::chrono::steady_clock::now();
       }
       T->jcv.notify_all();
+      prewake_helpers(&T->host);  // (the host stage's helper threads: awake and polling by the time the maps and labels are on the host)
       return PLV_OK;
     }
     PLV_HIP_CHECK(plv::stream_sync(ctx->stream));
@@ -474,7 +479,7 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
       T->worker.join();
     }
     // (the fitter threads end with T->host: ~HostStage)
-    DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out, &T->lab};
+    DevBuf *bufs[] = {&T->half, &T->map, &T->work, &T->pts, &T->chains, &T->counts, &T->segs, &T->seg_count, &T->uv_in, &T->uv_out, &T->lab, &T->lab_cnt, &T->lab_roots};
     for (DevBuf *b : bufs) b->release();
     T->pin.release();
     if (T->edges_ready) (void)hipEventDestroy(T->edges_ready);
@@ -697,17 +702,20 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
     fid[q] = ids[A.kept[q]];
   }
   const bool first = T->lines_last.empty();  // REF :100 (first frame or lost everything: no matching, no DB update)
+  auto F_match = F1, F_und = F1;
   if (!first) {
     std::vector<int> match((size_t)std::max(nk, 1));
     match_lines_parallel(&T->host, fit_threads().load(std::memory_order_relaxed), fl.data(), nk, A.rel_ptr.data(), A.rel_id.data(), T->lines_last.data(),
                          (int)T->ids_last.size(), T->rel_ptr_last.data(), T->rel_id_last.data(), match.data());
     for (int q = 0; q < nk; ++q)
       if (match[q] >= 0) fid[q] = (uint64_t)(int)T->ids_last[match[q]];  // REF :153-158 (`int id`)
+    if (timing) F_match = std::chrono::steady_clock::now();
     // CamBase::undistort_line: both end points through undistort_f.  A few dozen points: the arithmetic of undistort_kernel
     // (radtan_core.hpp, bit-identical on host and device) run here instead of a launch + copy + synchronisation round trip
     std::vector<float> un(4 * (size_t)std::max(nk, 1));
     for (int q = 0; q < 2 * nk; ++q)
       undistort_radtan(K8, fl[2 * (size_t)q], fl[2 * (size_t)q + 1], un[2 * (size_t)q], un[2 * (size_t)q + 1]);
+    if (timing) F_und = std::chrono::steady_clock::now();
     for (int q = 0; q < nk; ++q) {
       const int D = plv_line_classification(fl.data() + 4 * q, vps);
       auto it = T->db.find(fid[q]);
@@ -731,6 +739,8 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
   T->rel_id_last = A.rel_id;
   if (timing) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "line feed: kept-line copy + match %.1f us, undistort %.1f us, classify + store -> end %.1f us\n", us(F1, F_match), us(F_match, F_und),
+            us(F_und, std::chrono::steady_clock::now()));
     fprintf(stderr, "line feed: assignment %.1f us (%d lines x %d points), match + undistort + classify + store %.1f us (%d kept)\n", us(F0, F1), nl, np,
             us(F1, std::chrono::steady_clock::now()), nk);
   }

@@ -40,15 +40,17 @@ struct Job {
 
 // Second half of the host stage on threads of their own (see host_extract)
 struct Fit {
-  static const int kThreads = 7;  // helper threads next to the walking thread (fit_threads() says how many a job uses)
-  static const int kParts = 16;   // parts a labelled detection is split into (Job::parts <= kParts)
+  static const int kThreads = 15;  // helper threads next to the walking thread (fit_threads() says how many a job uses)
+  static const int kParts = 32;   // parts a labelled detection is split into (Job::parts <= kParts)
   std::thread th[kThreads];
   std::mutex m;
   std::condition_variable cv;
-  int gen = 0, done_gen[kThreads] = {0, 0, 0, 0, 0, 0, 0};  // a job = a new generation; thread i reports the last one it finished
+  // (atomics: written under m, read without it by a polling thread — wait_polling spins on them lock-free)
+  std::atomic<int> gen{0}, done_gen[kThreads] = {};  // a job = a new generation; thread i reports the last one it finished
   // A labelled job (Job::hlab): its parts are claimed here by the walking thread and the helpers; a part = the components whose
   // label it is, walked and fitted by the thread that claimed it (detect_part) into part[p]
   bool by_parts = false;  // (guarded by m, read together with gen and job)
+  std::atomic<int> prewake{0};  // bumped (under m) when a job is on its way (prewake_helpers): sleeping helpers wake and poll for it
   // a generic job for the same threads (run_on_helpers): every thread it counts calls task(slot), slot 1 .. nfit_job (0 = the poster)
   std::function<void(int)> task;  // (guarded by m, read together with gen)
   alignas(64) std::atomic<int> next_part{0};
@@ -56,13 +58,16 @@ struct Fit {
     std::vector<int> seed, seg_at, seg_n;  // per chain: raster index of its seed, first segment, segments
     std::vector<float4> segs;
     int chains = 0;
+    float us_build = 0, us_walk = 0, us_fit = 0, us_start = 0;  // (reporting: PLV_KNOB_LINE_TIMING)
+    int slot = 0, pixels = 0;
   } part[kParts];
+  std::chrono::steady_clock::time_point job_t0;
   struct Scratch {  // one per thread (index 0: the walking thread)
     std::vector<uint8_t> pad;
     std::vector<int2> pts;
     std::vector<FldChain> chains;
   } scratch[kThreads + 1];
-  bool quit = false;
+  std::atomic<bool> quit{false};
   const Job *job = nullptr;
   int nfit_job = 0;  // fitter threads the current job uses (thread i takes part when i < nfit_job); guarded by m: a thread reads it
                      // together with gen and job, so that one waking late for a job it was not part of cannot mix two jobs
@@ -110,19 +115,20 @@ inline std::atomic<int> &fit_threads() {
 }
 template <class Pred>
 inline void wait_polling(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, Pred pred, int spin_us = -1) {
+  // `pred` reads atomics only (they are written under the mutex): the polling phase runs WITHOUT the mutex — round 5: eight threads
+  // polling by locking and unlocking it kept the thread that wanted to post a job out of it for tens of microseconds
   if (pred()) return;
   if (spin_us < 0) spin_us = spin_budget_us().load(std::memory_order_relaxed);
-  if (spin_us == 0) {
-    cv.wait(lk, pred);
-    return;
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
+  if (spin_us > 0) {
     lk.unlock();
-    for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+      if (pred()) break;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
     lk.lock();
     if (pred()) return;
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
   }
   cv.wait(lk, pred);
 }
@@ -247,7 +253,8 @@ inline void fit_one(Fit &F, const Job &J, int c) {
 // that are edges lie in its own component, and the walk only ever reads and clears those, so the raster walk over this map yields
 // exactly the chains the raster walk over the whole map yields inside these components, in the same order; the segments of a chain
 // depend on nothing but the chain.  The caller puts the parts' chains back into the raster order of their seeds.
-inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S) {
+inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot = 0) {
+  const auto tp0 = std::chrono::steady_clock::now();
   const int w = J.w, h = J.h, pw = w + 2;
   S.pad.resize((size_t)pw * (h + 2));
   uint8_t *m = S.pad.data();
@@ -264,7 +271,9 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S) {
   S.pts.resize((size_t)w * h);
   S.chains.resize(kChainCap);
   int counts[4] = {0, 0, 0, 0};
+  const auto tp1 = std::chrono::steady_clock::now();
   walk_padded(m, w, h, J.length_threshold, S.pts.data(), S.chains.data(), kChainCap, counts);
+  const auto tp2 = std::chrono::steady_clock::now();
   Fit::PartOut &O = F.part[p];
   O.chains = counts[0];
   O.seed.resize(counts[0]), O.seg_at.resize(counts[0]), O.seg_n.resize(counts[0]);
@@ -275,13 +284,17 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S) {
     O.seg_at[c] = ch.slot;
     O.seg_n[c] = fit_chain(J.hhalf, w, h, J.length_threshold, J.distance_threshold, S.pts.data() + ch.start, ch.len, O.segs.data() + ch.slot);
   }
+  const auto tp3 = std::chrono::steady_clock::now();
+  auto us = [](auto a, auto b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
+  O.us_start = us(F.job_t0, tp0), O.us_build = us(tp0, tp1), O.us_walk = us(tp1, tp2), O.us_fit = us(tp2, tp3), O.slot = slot, O.pixels = counts[2];
 }
 inline void claim_parts(Fit &F, const Job &J, int slot) {
-  for (int p; (p = F.next_part.fetch_add(1, std::memory_order_relaxed)) < J.parts;) detect_part(F, J, p, F.scratch[slot]);
+  for (int p; (p = F.next_part.fetch_add(1, std::memory_order_relaxed)) < J.parts;) detect_part(F, J, p, F.scratch[slot], slot);
 }
 
 inline void fit_worker(HostStage *T, int me, int seen /* the generation current when the thread was made: it waits for the next */) {
   Fit &F = T->fit;
+  int seen_pw = 0;
   for (;;) {
     const Job *job;
     int nfit;
@@ -289,8 +302,14 @@ inline void fit_worker(HostStage *T, int me, int seen /* the generation current 
     std::function<void(int)> task;
     {
       std::unique_lock<std::mutex> lk(F.m);
-      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.quit; });
+      // (a pre-wake ends the wait without a job: the thread comes round and polls again — awake when the job arrives)
+      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.prewake != seen_pw || F.quit; });
       if (F.quit) return;
+      if (F.gen == seen) {
+        seen_pw = F.prewake;
+        continue;
+      }
+      seen_pw = F.prewake;
       seen = F.gen, job = F.job, nfit = F.nfit_job, by_parts = F.by_parts, task = F.task;
     }
     if (task || !job) {  // (a task, or a thread the task did not count waking after the poster has withdrawn it)
@@ -342,6 +361,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   const int nfit = by_parts ? std::min(fit_threads().load(std::memory_order_relaxed), J.parts - 1)
                             : std::min(std::min(fit_threads().load(std::memory_order_relaxed), 2), (size_t)J.w * J.h >= 60000 ? 2 : 1);
   F.next_part.store(0, std::memory_order_relaxed);
+  F.job_t0 = T1;
   {
     int gen_now;
     {
@@ -425,6 +445,12 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     for (size_t i = 0; i < (size_t)J.w * J.h; ++i) edges += J.hmap[i] == 2;
     fprintf(stderr, "walk %.1f us, rest of the fit %.1f us; %d chains, %d chain points, %zu edge pixels\n", us(T1, T2), us(T2, T3), hcounts[0],
             hcounts[2], edges);
+    if (by_parts) {
+      fprintf(stderr, "  parts (thread: start + build + walk + fit us, chain points):");
+      for (int p = 0; p < J.parts; ++p)
+        fprintf(stderr, " %d(t%d: %.0f + %.0f + %.0f + %.0f, %d)", p + 1, F.part[p].slot, F.part[p].us_start, F.part[p].us_build, F.part[p].us_walk, F.part[p].us_fit, F.part[p].pixels);
+      fprintf(stderr, "\n");
+    }
   }
   return PLV_OK;
 }
@@ -491,6 +517,18 @@ inline void assign_points(const float *lines, int nl, const float *pts, const ui
     A.rel_ptr.push_back((int)A.rel_id.size());
     A.pos_ptr.push_back((int)A.pos.size() / 2);
   }
+}
+
+// A job for the helpers is on its way (the edge maps of a frame have been launched: the host stage follows within ~0.1 ms): helpers
+// asleep on their condition variable are woken now and poll (wait_polling's budget) instead of being woken when the work is there —
+// a wake-up costs 30-100 us, which used to be the tail of every frame's detection ("rest of the fit")
+inline void prewake_helpers(HostStage *T) {
+  Fit &F = T->fit;
+  {
+    std::lock_guard<std::mutex> lk(F.m);
+    ++F.prewake;
+  }
+  F.cv.notify_all();
 }
 
 // fn(slot) on the calling thread (slot 0) and on `nhelpers` helper threads of the stage (slots 1 .. nhelpers), all at once; returns

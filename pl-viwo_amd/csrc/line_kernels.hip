@@ -36,11 +36,38 @@ __global__ void __launch_bounds__(256) half_kernel(const uint8_t *__restrict__ s
 // segment fit reads.  One launch for cv::resize + cv::Canny.
 // hist (FULL only, nullable): `src` is the RAW image and hist its 256-bin histogram — the workgroup builds cv::equalizeHist's look-up
 // table itself and reads the image through it: the launch then need not wait for the pyramid launch that writes the equalised image.
+// ------------------------------------------------------------------------------------------ component labels (helpers)
+// Union-find with atomicMin (label equivalence, Playne & Hawick's scheme): L[i] = parent of i, a root is its own parent and the
+// smallest index of its set.  Works on LDS (inside canny_kernel) and on global memory (ccl_boundary_kernel) alike.
+__device__ __forceinline__ int ccl_find(const int *L, int i) {
+  for (;;) {
+    const int p = __atomic_load_n(L + i, __ATOMIC_RELAXED);
+    if (p == i) return i;
+    i = p;
+  }
+}
+__device__ __forceinline__ void ccl_union(int *L, int a, int b) {
+  for (;;) {
+    a = ccl_find(L, a);
+    b = ccl_find(L, b);
+    if (a == b) return;
+    if (a < b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }  // a > b: hang a under b unless someone got there first
+    const int old = atomicMin(L + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
 template <bool FULL>
 __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__restrict__ src, int fw, int w, int h, int low, int high,
                                                             uint8_t *__restrict__ map /* 0 weak, 1 none, 2 edge */,
                                                             uint8_t *__restrict__ half_out, const unsigned *__restrict__ hist, int npix_full,
-                                                            int *__restrict__ lab_init /* nullable: own index for an edge, -1 else (ccl_*_kernel) */) {
+                                                            int *__restrict__ lab_init /* nullable: component labels, first pass */,
+                                                            int *__restrict__ cnt_init /* nullable: zeroed per pixel (ccl_roots_kernel counts in it) */) {
   __shared__ int px[CN_T + 4][CN_T + 4];
   __shared__ int mg[CN_T + 2][CN_T + 2];
   __shared__ unsigned cdf[16];
@@ -75,7 +102,8 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
   }
   __syncthreads();
   const int x = x0 + tx, y = y0 + ty;
-  if (x >= w || y >= h) return;
+  const bool inside = x < w && y < h;
+  if (!lab_init && !inside) return;  // (with labels every thread stays for the tile's barriers)
   int mydx, mydy;  // gradient of this thread's own pixel
   {
     const int cx = tx + 2, cy = ty + 2;
@@ -103,54 +131,116 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
   }
   // FastLineDetector clears the top-left 6x6 and the bottom-right 5x5 corner of the edge map
   if ((x < 6 && y < 6) || (x >= w - 5 && y >= h - 5)) out = 1;
-  map[(size_t)y * w + x] = out;
-  if (lab_init) lab_init[(size_t)y * w + x] = out == 2 ? y * w + x : -1;
+  if (inside) map[(size_t)y * w + x] = out;
+  if (lab_init) {
+    // component labels, first pass: union-find inside the tile, in LDS (W / NW / N / NE neighbours of the same tile); every edge pixel
+    // leaves with the global index of its tile-component's first pixel (ccl_boundary_kernel joins the tiles)
+    __shared__ int lab[CN_T * CN_T], lcnt[CN_T * CN_T];
+    const int me = ty * CN_T + tx;
+    const bool edge = inside && out == 2;
+    lab[me] = edge ? me : -1;
+    lcnt[me] = 0;
+    __syncthreads();
+    if (edge) {
+      if (tx > 0 && lab[me - 1] >= 0) ccl_union(lab, me, me - 1);
+      if (ty > 0) {
+        if (tx > 0 && lab[me - CN_T - 1] >= 0) ccl_union(lab, me, me - CN_T - 1);
+        if (lab[me - CN_T] >= 0) ccl_union(lab, me, me - CN_T);
+        if (tx + 1 < CN_T && lab[me - CN_T + 1] >= 0) ccl_union(lab, me, me - CN_T + 1);
+      }
+    }
+    __syncthreads();
+    int r = -1;
+    if (edge) {
+      r = ccl_find(lab, me);
+      atomicAdd(&lcnt[r], 1);  // pixels of the tile-component, at its first pixel
+    }
+    __syncthreads();
+    if (inside) {
+      lab_init[(size_t)y * w + x] = edge ? (y0 + r / CN_T) * w + x0 + (r & (CN_T - 1)) : -1;
+      if (cnt_init) cnt_init[(size_t)y * w + x] = lcnt[me];  // (0 everywhere but at the first pixel of a tile-component)
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ component labels
-// 8-connected components of the edge map by union-find on the device (label equivalence with atomicMin: Playne & Hawick's scheme):
-// L[i] = i for an edge pixel (canny_kernel), ccl_merge_kernel unites every edge pixel with its W / NW / N / NE neighbours, and
-// ccl_flatten_kernel writes, for every pixel, 0 (not an edge) or 1 + hash(root) % parts into the host-visible label map — the root of
-// a component is its smallest pixel index.  The host stage of the detector splits its work by these labels (line_host.hpp
-// detect_part): the chain walk never leaves a component, so components can be walked independently of each other.
-__device__ __forceinline__ int ccl_find(const int *L, int i) {
-  for (;;) {
-    const int p = __atomic_load_n(L + i, __ATOMIC_RELAXED);
-    if (p == i) return i;
-    i = p;
-  }
-}
-__device__ __forceinline__ void ccl_union(int *L, int a, int b) {
-  for (;;) {
-    a = ccl_find(L, a);
-    b = ccl_find(L, b);
-    if (a == b) return;
-    if (a < b) {
-      const int t = a;
-      a = b;
-      b = t;
-    }  // a > b: hang a under b unless someone got there first
-    const int old = atomicMin(L + a, b);
-    if (old == a) return;
-    a = old;
-  }
-}
-__global__ void __launch_bounds__(256) ccl_merge_kernel(int *__restrict__ L, int w, int h) {
+// 8-connected components of the edge map, so that the host stage of the detector can split its work (line_host.hpp detect_part: the
+// chain walk never leaves a component).  canny_kernel has united the pixels of every 16 x 16 tile; ccl_boundary_kernel unites across
+// tile borders (global union-find, only the pixels on a tile's first row / first column / last column take part);
+// ccl_roots_kernel flattens, counts the pixels of every component and lists the roots; ccl_assign_kernel gives the CCL_BIG largest
+// components a part of their own (1 .. CCL_BIG: they bound the host stage's longest thread) and hashes the others into CCL_HASHED
+// more; ccl_flatten_kernel writes the part of every pixel (0: not an edge) into the host-visible map.
+#define CCL_BIG 8
+#define CCL_HASHED 16
+#define CCL_ROOT_CAP 4096
+__global__ void __launch_bounds__(256) ccl_boundary_kernel(int *__restrict__ L, int w, int h, int *__restrict__ n_roots) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *n_roots = 0;
   if (i >= w * h || L[i] < 0) return;
   const int y = i / w, x = i - y * w;
-  if (x > 0 && L[i - 1] >= 0) ccl_union(L, i, i - 1);
+  const int lx = x & (CN_T - 1), ly = y & (CN_T - 1);
+  if (lx == 0 && x > 0 && L[i - 1] >= 0) ccl_union(L, i, i - 1);
   if (y > 0) {
-    if (x > 0 && L[i - w - 1] >= 0) ccl_union(L, i, i - w - 1);
-    if (L[i - w] >= 0) ccl_union(L, i, i - w);
-    if (x + 1 < w && L[i - w + 1] >= 0) ccl_union(L, i, i - w + 1);
+    if ((lx == 0 || ly == 0) && x > 0 && L[i - w - 1] >= 0) ccl_union(L, i, i - w - 1);
+    if (ly == 0 && L[i - w] >= 0) ccl_union(L, i, i - w);
+    if ((ly == 0 || lx == CN_T - 1) && x + 1 < w && L[i - w + 1] >= 0) ccl_union(L, i, i - w + 1);
   }
 }
-__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, int parts, uint8_t *__restrict__ lab_out) {
+__global__ void __launch_bounds__(256) ccl_roots_kernel(int *__restrict__ L, int n, int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ n_roots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || L[i] < 0) return;
+  const int r = ccl_find(L, i);
+  if (r != i) {
+    __atomic_store_n(L + i, r, __ATOMIC_RELAXED);  // (path compression: still an ancestor for whoever reads it meanwhile)
+    const int c = cnt[i];  // canny_kernel left the size of a tile-component at its first pixel: one atomic per tile-component
+    if (c > 0) {
+      atomicAdd(cnt + r, c);
+      cnt[i] = 0;  // (nobody adds into a pixel that is not a root)
+    }
+  }
+  if (r == i) {
+    const int at = atomicAdd(n_roots, 1);
+    if (at < CCL_ROOT_CAP) roots[at] = i;
+  }
+}
+// part of a component: 1 + its rank by size when it is one of the CCL_BIG largest (ties: smaller root first), else
+// 1 + CCL_BIG + hash(root) % CCL_HASHED.  One workgroup; written into cnt[root] as -(part) (the counts are no longer needed).
+__global__ void __launch_bounds__(256) ccl_assign_kernel(int *__restrict__ cnt, const int *__restrict__ roots, const int *__restrict__ n_roots) {
+  // only a component of 64 pixels or more can matter for the balance (most have a handful): those are collected into a short list
+  // and ranked among themselves; when fewer than CCL_BIG are that large the rest of the own parts stay empty
+  __shared__ int lsz[512], lrt[512];
+  __shared__ int n_large;
+  const int n = min(*n_roots, CCL_ROOT_CAP);
+  const bool listed = *n_roots <= CCL_ROOT_CAP;  // (more components than the list holds: every one is hashed, none gets a part of its own)
+  if (threadIdx.x == 0) n_large = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int root = roots[j], c = cnt[root];
+    bool large = false;
+    if (listed && c >= 64) {
+      const int at = atomicAdd(&n_large, 1);
+      if (at < 512) lsz[at] = c, lrt[at] = root, large = true;
+    }
+    if (!large) cnt[root] = -(1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
+  }
+  __syncthreads();
+  const int m = min(n_large, 512);
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const int mine = lsz[j], root = lrt[j];
+    int rank = 0;
+    for (int q = 0; q < m && rank < CCL_BIG; ++q) rank += (lsz[q] > mine) || (lsz[q] == mine && lrt[q] < root);
+    cnt[root] = -(rank < CCL_BIG ? 1 + rank : 1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
+  }
+}
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, const int *__restrict__ cnt, uint8_t *__restrict__ lab_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint8_t v = 0;
-  if (L[i] >= 0) v = (uint8_t)(1 + ((unsigned)ccl_find(L, i) * 2654435761u >> 8) % (unsigned)parts);
+  const int r = L[i];
+  if (r >= 0) {
+    const int c = cnt[r];  // -(part) for a listed root; a root beyond the list keeps its positive count
+    v = (uint8_t)(c < 0 ? -c : 1 + CCL_BIG + (int)(((unsigned)r * 2654435761u >> 8) % (unsigned)CCL_HASHED));
+  }
   lab_out[i] = v;
 }
 
@@ -301,7 +391,7 @@ int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const Fl
   {
     ProfScope ps(ctx->prof, "half_canny_kernel", st);
     hipLaunchKernelGGL(canny_kernel<true>, dim3(cdiv(w, CN_T), cdiv(h, CN_T)), dim3(CN_T * CN_T), 0, st, d_img, W, w, h, low,
-                       high, b.map, b.half, d_hist, W * H, b.lab_work);
+                       high, b.map, b.half, d_hist, W * H, b.lab_work, b.lab_cnt);
   }
   if (low != high) {
     ProfScope ps(ctx->prof, "canny_hyst_kernel", st);
@@ -311,19 +401,31 @@ int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const Fl
   return PLV_OK;
 }
 
-// stage 1b: component labels of the edge map canny_kernel left in b.lab_work, into b.lab_out (host-visible), on stream st
-int launch_line_labels(plv_ctx *ctx, int w, int h, int parts, FldBuffers &b, hipStream_t st) {
+// stage 1b: component labels of the edge map (canny_kernel left the tile-local pass in b.lab_work) as parts 1 .. kLineParts per
+// edge pixel in b.lab_out (host-visible), on stream st
+int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st) {
+  const int n = w * h;
   {
-    ProfScope ps(ctx->prof, "ccl_merge_kernel", st);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(w * h, 256)), dim3(256), 0, st, b.lab_work, w, h);
+    ProfScope ps(ctx->prof, "ccl_boundary_kernel", st);
+    hipLaunchKernelGGL(ccl_boundary_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, w, h, b.lab_roots + CCL_ROOT_CAP);
+  }
+  {
+    ProfScope ps(ctx->prof, "ccl_roots_kernel", st);
+    hipLaunchKernelGGL(ccl_roots_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_roots, b.lab_roots + CCL_ROOT_CAP);
+  }
+  {
+    ProfScope ps(ctx->prof, "ccl_assign_kernel", st);
+    hipLaunchKernelGGL(ccl_assign_kernel, dim3(1), dim3(256), 0, st, b.lab_cnt, b.lab_roots, b.lab_roots + CCL_ROOT_CAP);
   }
   {
     ProfScope ps(ctx->prof, "ccl_flatten_kernel", st);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(w * h, 256)), dim3(256), 0, st, b.lab_work, w * h, parts, b.lab_out);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_out);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
+int line_label_parts() { return CCL_BIG + CCL_HASHED; }
+size_t line_label_roots_bytes() { return (CCL_ROOT_CAP + 4) * sizeof(int); }
 
 // stage 2 (device variant): chain walking by one wave
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b) {

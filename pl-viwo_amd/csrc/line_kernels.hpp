@@ -23,13 +23,17 @@ struct FldBuffers {
   float4 *segs;    // segment slots, chain c writes segs[chain.slot ...]
   int *seg_count;  // [chain_cap]
   int *lab_work = nullptr;      // [w*h] union-find forest of the component labelling (null: no labels for this detection)
-  uint8_t *lab_out = nullptr;   // [w*h] labels, host-visible (0 not an edge, else 1 + hash(root) % parts)
+  int *lab_cnt = nullptr;       // [w*h] pixels per component at its root, then -(part) there
+  int *lab_roots = nullptr;     // [line_label_roots_bytes()] the roots' list and its counter
+  uint8_t *lab_out = nullptr;   // [w*h] parts, host-visible (0 not an edge, else 1 .. line_label_parts())
 };
 
 // d_hist: d_img is the RAW image and d_hist its histogram (the kernel equalises on the fly: canny_kernel); null: d_img is the equalised image
 int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */,
                       const unsigned *d_hist = nullptr);
-int launch_line_labels(plv_ctx *ctx, int w, int h, int parts, FldBuffers &b, hipStream_t st);
+int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st);
+int line_label_parts();         // parts launch_line_labels writes (the largest components first: 1 .. 8, then 8 hashed ones)
+size_t line_label_roots_bytes();
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 int launch_line_fit(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
 
