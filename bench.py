@@ -460,6 +460,7 @@ def main():
             if fw.fw_start() != 0:
                 fw = None
         chain0, routes0 = pkg.chain_count(), pkg.route_counts()
+        last_stats = dict(sm.stats)
         for f in range(n_steps):
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if nf is None:
@@ -504,6 +505,14 @@ def main():
             c1 = pkg.counters()
             for k in c1:
                 cnt[k] += c1[k] - c0[k]
+            if trace_frames:      # what this frame's updates worked on, next to its time (PLV_BENCH_FRAMES=1)
+                cur = dict(sm.stats)
+                ph1t = pkg.phase_counters()
+                per_frame.setdefault("trace", []).append((round(dt * 1e3, 3), cur["cam_features"] - last_stats.get("cam_features", 0), cur["line_pool"] - last_stats.get("line_pool", 0),
+                                                          cur["lines_triangulated"] - last_stats.get("lines_triangulated", 0), cur["lines_accepted"] - last_stats.get("lines_accepted", 0),
+                                                          c1["lk_iters"] - c0["lk_iters"], c1["lines_detected"] - c0["lines_detected"]) +
+                                                         tuple(round((ph1t[k] - ph0[k]) * 1e-3, 1) for k in ("flow_wait", "points", "lines", "w_maps", "w_extract", "w_feed")))
+                last_stats = cur
             per_frame["tracked"].append(len(ctx.tracker_last()[1]))
             if wl["lines"]:
                 per_frame["kept"].append(len(ctx.line_tracker_last()[1]))
@@ -555,6 +564,7 @@ def main():
                 split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
         if os.environ.get("PLV_BENCH_FRAMES"):
             print("[frames] ms per step:", " ".join(f"{v:.3f}" for v in per), "| steps that (re)allocated a buffer:", grew, "| host cpu:", host_cpu, file=sys.stderr)
+            print("[frames] (ms, msckf features, line pool, lines triangulated, lines accepted, LK iterations, segments detected; us inside: flow wait, point update, line update, worker: maps wait, detection, feed) per step:", per_frame.get("trace"), file=sys.stderr)
             for row in slow:
                 print("[slow step] step %d: %.3f ms; inside its parts (ms) %s; plv_camera_frame %.3f, plv_ctx_synchronize %.3f" % row, file=sys.stderr)
         return dict(elapsed=reduce_max(elapsed, dist), per=per, per_frame=per_frame, cnt=cnt, stats=stats, split=split, grew=grew, host_cpu=host_cpu)
