@@ -759,6 +759,7 @@ def main():
                 "kernel_launches_per_frame": round(cnt["launches"] / args.steps, 1), "host_synchronisations_per_frame": round(cnt["syncs"] / args.steps, 1),
                 "line_launches_chained_per_frame": round(cnt.get("chained", 0) / args.steps, 2),
                 "ms_per_step_inside_the_library": round((cnt["frame_ns"] + cnt["sync_ns"]) / args.steps * 1e-6, 4),
+                "us_per_step_in_plv_ctx_synchronize": round(cnt["sync_ns"] / args.steps * 1e-3, 1),
                 "timed_region": "plv_camera_frame + plv_ctx_synchronize on arguments marshalled beforehand (SystemManager.camera_prepare): two ctypes calls; "
                                 "ms_per_step_python = the same step with the Python driver's marshalling inside it, over the next frames",
                 "ms_per_step_python": round(seg_py["elapsed"] / npy * 1e3, 4),

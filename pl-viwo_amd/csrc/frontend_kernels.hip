@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 // takes the same float step.  (Round 2: one wave per point with four pixels per lane took 52 us per launch, this form 45 — the
 // launch lasts as long as its slowest point, up to 30 iterations on each of 5 levels.)
 #define LK4_WAVES 4
+template <int V>
 __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
                                                             const float *__restrict__ pts1_init, float *__restrict__ pts1,
                                                             uint8_t *__restrict__ status,
@@ -314,6 +315,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const float half = (win - 1) * 0.5f;
   const float ec = fminf(fmaxf(eps, 0.f), 10.f);
   const double eps2 = (double)ec * (double)ec;
+  const float eps2_lo = (float)(eps2 * (1.0 - 1e-6)), eps2_hi = (float)(eps2 * (1.0 + 1e-6));
   const int npx = win * win;
   const float px0 = pts0[2 * pt], py0 = pts0[2 * pt + 1];
   const float nx0 = pts1_init[2 * pt], ny0 = pts1_init[2 * pt + 1];
@@ -326,7 +328,15 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const bool own2 = two && tid + 64 * LK4_WAVES < npx;
   const int wy2 = own2 ? (tid + 64 * LK4_WAVES) / win : 0, wx2 = own2 ? tid + 64 * LK4_WAVES - wy2 * win : 0;
 
+  // (V >= 8: diagnostic builds, tools/lk_exp.py — cycles of one phase in place of the iteration count)
+  unsigned long long dg_acc = 0, dg_t = 0;
+#define LK_DG(PH, BEGIN)                                                  \
+  if (V >= 8 && (V - 8) == (PH)) {                                          \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+    if (BEGIN) dg_t = now_; else dg_acc += now_ - dg_t;                   \
+  }
   for (int level = maxLevel; level >= 0; --level) {
+    LK_DG(3, 1)
     const float sc = 1.f / (float)(1 << level);
     float prevx = px0 * sc, prevy = py0 * sc;
     if (level == maxLevel) {
@@ -415,16 +425,27 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     float pdx = 0.f, pdy = 0.f;
     float outx = nextx + half, outy = nexty + half;
     const int jc = cur.w[level], jr = cur.h[level];
-    int jx0 = 0, jy0 = 0;
+    int jx0 = (V & 4) ? -(1 << 24) : 0, jy0 = jx0;  // (V & 4: no tile yet = a tile far away)
     bool have_tile = false;
+    LK_DG(3, 0)
     for (int j = 0; j < max_iters; ++j) {
-      const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
-      if (inx < -win || inx >= jc || iny < -win || iny >= jr) {
+      LK_DG(0, 1)
+      int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+      bool outside, reload;
+      if (V & 4) {  // the same two tests as unsigned range checks on scalar registers (every lane holds the same position)
+        inx = __builtin_amdgcn_readfirstlane(inx), iny = __builtin_amdgcn_readfirstlane(iny);
+        outside = ((unsigned)(inx + win) >= (unsigned)(jc + win)) | ((unsigned)(iny + win) >= (unsigned)(jr + win));
+        reload = ((unsigned)(inx - jx0) > (unsigned)(LK_JT - win - 1)) | ((unsigned)(iny - jy0) > (unsigned)(LK_JT - win - 1));
+      } else {
+        outside = inx < -win || inx >= jc || iny < -win || iny >= jr;
+        reload = !have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT;
+      }
+      if (outside) {
         if (level == 0) st = 0;
         break;
       }
       ++iters;
-      if (!have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT) {
+      if (reload) {
         jx0 = inx - (LK_JT - win - 1) / 2;
         jy0 = iny - (LK_JT - win - 1) / 2;
         __syncthreads();
@@ -451,6 +472,8 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
         pb1 = diff * Ix;
         pb2 = diff * Iy;
       }
+      LK_DG(0, 0)
+      LK_DG(1, 1)
       pb1 = wave_sum_i32(pb1);  // |diff| <= 8160, |Ix| <= 4080: 64 products < 2^31
       pb2 = wave_sum_i32(pb2);
       if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
@@ -468,24 +491,50 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
         if (lane == 0) part2[slot][wave][0] = qb1, part2[slot][wave][1] = qb2;
       }
       __syncthreads();
+      LK_DG(1, 0)
+      LK_DG(2, 1)
       // the four wave sums (|.| < 2^31 each) are added as doubles: exact (the total stays below 2^33), and (float) of that double
       // rounds once, as (float) of the 64-bit integer does — without the scalar-unit sequence an int64 -> float conversion compiles to
-      double sb1 = 0.0, sb2 = 0.0;
+      float b1, b2;
+      if ((V & 2) && !two) {
+        // the four wave sums as 64-bit integers (32-bit adds with carry: no double-precision conversions on the iteration's chain);
+        // a total that fits 32 bits — every frame seen so far — converts with one instruction, rounding once like the double does
+        long long t1 = 0, t2 = 0;
 #pragma unroll
-      for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
-      if (two)
+        for (int w = 0; w < LK4_WAVES; ++w) t1 += part[slot][w][0], t2 += part[slot][w][1];
+        if ((long long)(int)t1 == t1 && (long long)(int)t2 == t2)
+          b1 = (float)(int)t1 * FLT_SCALE, b2 = (float)(int)t2 * FLT_SCALE;
+        else
+          b1 = (float)(double)t1 * FLT_SCALE, b2 = (float)(double)t2 * FLT_SCALE;
+      } else {
+        double sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part2[slot][w][0], sb2 += (double)part2[slot][w][1];
+        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
+        if (two)
+#pragma unroll
+          for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part2[slot][w][0], sb2 += (double)part2[slot][w][1];
+        b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      }
       slot ^= 1;
-      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;
       const float ddy = (A12 * b1 - A11 * b2) * D;
       nextx += ddx;
       nexty += ddy;
       outx = nextx + half;
       outy = nexty + half;
-      if ((double)ddx * ddx + (double)ddy * ddy <= eps2) break;
-      if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
+      LK_DG(2, 0)
+      if (V & 1) {
+        // (double)ddx * ddx + (double)ddy * ddy <= eps2, decided in single precision where that is safe: the float expression is
+        // within 3 ulp (2^-21 relative) of the exact value; only inside that band does the exact double test run.  Every lane holds
+        // the same values, so the branches are uniform.
+        const float q = ddx * ddx + ddy * ddy;
+        if (q <= eps2_lo && q >= 1e-30f) break;
+        if (q < eps2_hi && (double)ddx * ddx + (double)ddy * ddy <= eps2) break;
+      } else if ((double)ddx * ddx + (double)ddy * ddy <= eps2)
+        break;
+      // (V & 1: |(double)s| < 0.01 for a float s is |s| <= 0.01f: 0.01 is not a float, 0.01f is the largest float below it)
+      if ((V & 1) ? (j > 0 && fabsf(ddx + pdx) <= 0.01f && fabsf(ddy + pdy) <= 0.01f)
+                  : (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01)) {
         outx -= ddx * 0.5f;
         outy -= ddy * 0.5f;
         break;
@@ -500,7 +549,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     pts1[2 * pt] = nextx;
     pts1[2 * pt + 1] = nexty;
     status[pt] = (uint8_t)st;
-    if (iters_out) iters_out[pt] = iters;
+    if (iters_out) iters_out[pt] = V >= 8 ? (int)dg_acc : iters;
   }
   if (n0 && tid < 2) {
     float xn, yn;
@@ -1154,8 +1203,22 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, d_pts1,
-                     d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
+  const unsigned variant = (plv::knobs().load(std::memory_order_relaxed) >> 21) & 15u;  // (experiment: tools/lk_exp.py)
+#define LK_LAUNCH(VV)                                                                                                                     \
+  hipLaunchKernelGGL(lk_kernel<VV>, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, \
+                     d_pts1, d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr)
+  switch (variant) {
+    case 1: LK_LAUNCH(1); break;
+    case 2: LK_LAUNCH(2); break;
+    case 4: LK_LAUNCH(4); break;
+    case 7: LK_LAUNCH(7); break;
+    case 8: LK_LAUNCH(8); break;
+    case 9: LK_LAUNCH(9); break;
+    case 10: LK_LAUNCH(10); break;
+    case 11: LK_LAUNCH(11); break;
+    default: LK_LAUNCH(0); break;
+  }
+#undef LK_LAUNCH
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

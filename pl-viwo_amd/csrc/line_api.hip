@@ -907,6 +907,36 @@ static void line_give_back(std::unordered_map<uint64_t, LineTrack> &unused, cons
 }
 
 namespace {
+// cleanup_measurements on one track (REF LineHelper.cpp:549-551): observations older than the oldest clone go; true = nothing left
+inline bool line_track_drop_before(LineTrack &tr, double t_oldest) {
+  size_t keep = 0;
+  for (size_t i = 0; i < tr.t.size(); ++i)
+    if (!(tr.t[i] < t_oldest)) {
+      if (keep != i) {
+        tr.t[keep] = tr.t[i];
+        std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
+        std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
+      }
+      ++keep;
+    }
+  tr.t.resize(keep);
+  tr.uv.resize(4 * keep);
+  tr.uvn.resize(4 * keep);
+  return keep == 0;
+}
+// host work placed inside the line update's wait: the point database's hand-back, then the caller's own
+struct LineWaitHook {
+  plv_ctx *ctx;
+  std::function<void()> *fn;
+};
+void line_wait_hook(void *arg) {
+  LineWaitHook *h = (LineWaitHook *)arg;
+  plv_tracker_run_deferred(h->ctx);
+  if (h->fn && *h->fn) (*h->fn)();
+}
+}  // namespace
+
+namespace {
 void form_line_pool(LineTracker *T, const PoolArgs &A, LinePool &R) {
   R = LinePool();
   R.valid = true;
@@ -1338,42 +1368,49 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c, i);
   };
   std::vector<int> lazy_back;  // pool candidates whose whole track returns to the database: moved there by the deferred hand-back
+  // cleanup_measurements over the tracks that stayed in the database, placed inside the update's wait for the device (they do not
+  // depend on its result); finish() then cleans only what returns
+  bool db_scanned_early = false;
+  std::function<void()> scan_db_early = [&]() {
+    if (!opt->window_full || db_scanned_early) return;
+    std::lock_guard<std::mutex> lk(T->mtx);
+    for (auto it = T->db.begin(); it != T->db.end();) it = line_track_drop_before(it->second, t_oldest) ? T->db.erase(it) : std::next(it);
+    db_scanned_early = true;
+  };
   auto finish = [&](int rc) {
     res->n_returned = (int)unused.size();
     for (int l : lazy_back) res->n_returned += unused.find(pool[l].id) == unused.end() ? 1 : 0;
     const bool window_full = opt->window_full != 0;
-    auto hand_back = [T, window_full, t_oldest](std::unordered_map<uint64_t, LineTrack> &un) {
+    const bool scanned = db_scanned_early;
+    // REF :71 / cleanup_lines :545-546 append_new_measurements, then LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188 (on every
+    // try_update) cleanup_measurements(oldest clone).  Whole tracks (`whole`: candidates the update did not take and of which nothing
+    // went back earlier) enter the database with one insertion; the cleanup touches every track, or — when the database was cleaned
+    // inside the update's wait (scan_db_early below) — only the tracks that return now.
+    auto hand_back = [T, window_full, t_oldest, scanned](std::unordered_map<uint64_t, LineTrack> &un, std::vector<Cand> *cands, const std::vector<int> *whole) {
       std::lock_guard<std::mutex> lk(T->mtx);
-      for (auto &kv : un) {  // REF :71 / cleanup_lines :545-546 append_new_measurements
-        const bool is_new = T->db.find(kv.first) == T->db.end();
-        LineTrack &d = T->db[kv.first];
-        if (is_new) {
-          d = std::move(kv.second);
-          continue;
+      auto put = [&](uint64_t id, LineTrack &tr) {
+        auto ins = T->db.try_emplace(id);
+        LineTrack &d = ins.first->second;
+        if (ins.second) {
+          d = std::move(tr);
+        } else {
+          d.t.insert(d.t.end(), tr.t.begin(), tr.t.end());
+          d.uv.insert(d.uv.end(), tr.uv.begin(), tr.uv.end());
+          d.uvn.insert(d.uvn.end(), tr.uvn.begin(), tr.uvn.end());
         }
-        d.t.insert(d.t.end(), kv.second.t.begin(), kv.second.t.end());
-        d.uv.insert(d.uv.end(), kv.second.uv.begin(), kv.second.uv.end());
-        d.uvn.insert(d.uvn.end(), kv.second.uvn.begin(), kv.second.uvn.end());
-      }
-      if (window_full) {  // REF LineHelper.cpp:549-551, UpdaterCamera.cpp:186-188: on every try_update
-        for (auto it = T->db.begin(); it != T->db.end();) {
-          LineTrack &tr = it->second;
-          size_t keep = 0;
-          for (size_t i = 0; i < tr.t.size(); ++i)
-            if (!(tr.t[i] < t_oldest)) {
-              if (keep != i) {
-                tr.t[keep] = tr.t[i];
-                std::copy(tr.uv.begin() + 4 * i, tr.uv.begin() + 4 * i + 4, tr.uv.begin() + 4 * keep);
-                std::copy(tr.uvn.begin() + 4 * i, tr.uvn.begin() + 4 * i + 4, tr.uvn.begin() + 4 * keep);
-              }
-              ++keep;
-            }
-          tr.t.resize(keep);
-          tr.uv.resize(4 * keep);
-          tr.uvn.resize(4 * keep);
-          it = keep == 0 ? T->db.erase(it) : std::next(it);
+        if (window_full && scanned && line_track_drop_before(d, t_oldest)) T->db.erase(ins.first);
+      };
+      if (whole)
+        for (int l : *whole) {
+          Cand &c = (*cands)[l];
+          if (un.find(c.id) == un.end())
+            put(c.id, c.tr);
+          else  // (parts of it went back earlier: behind those, as give_back_all does)
+            for (size_t i = 0; i < c.tr.t.size(); ++i) line_give_back(un, c, i);
         }
-      }
+      for (auto &kv : un) put(kv.first, kv.second);
+      if (window_full && !scanned)
+        for (auto it = T->db.begin(); it != T->db.end();) it = line_track_drop_before(it->second, t_oldest) ? T->db.erase(it) : std::next(it);
     };
     // (point_used->cleanup_measurements is not deferred: it takes the point tracker's lock, which a feed in progress holds)
     if (window_full) plv_point_used_cleanup(ctx, t_oldest);
@@ -1383,22 +1420,10 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       auto held = std::make_shared<std::unordered_map<uint64_t, LineTrack>>(std::move(unused));
       auto used_up = std::make_shared<std::vector<Cand>>(std::move(pool));
       auto lazy = std::make_shared<std::vector<int>>(std::move(lazy_back));
-      T->deferred = [hand_back, held, used_up, lazy]() {
-        for (int l : *lazy) {  // (give_back_all, off the frame's critical path)
-          Cand &c = (*used_up)[l];
-          if (held->find(c.id) == held->end()) {
-            held->emplace(c.id, std::move(c.tr));
-            c.tr = LineTrack{};
-          } else {
-            for (size_t i = 0; i < c.tr.t.size(); ++i) line_give_back(*held, c, i);
-          }
-        }
-        hand_back(*held);
-      };
+      T->deferred = [hand_back, held, used_up, lazy]() { hand_back(*held, used_up.get(), lazy.get()); };
     } else {
-      for (int l : lazy_back) give_back_all(pool[l]);
+      hand_back(unused, &pool, &lazy_back);
       lazy_back.clear();
-      hand_back(unused);
     }
     return rc;
   };
@@ -1422,8 +1447,9 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   std::vector<uint8_t> acc_all(Lp, 0);
   bool fused_ran = false;
   if (J.stage == LinesJob::FUSED_LAUNCHED) {
+    LineWaitHook hook{ctx, &scan_db_early};
     rc = plv_lines_update_fused_finish(ctx, st->sigma_pix * st->sigma_pix, opt->chi2_mult, lg.data(), ok.data(), acc_all.data(), &n_rows, dx,
-                                       plv_tracker_run_deferred, ctx);
+                                       line_wait_hook, &hook);
     res->status = rc == PLV_E_NOT_PSD ? rc : PLV_OK;
     if (rc == PLV_E_NOT_PSD) {
       rc = PLV_OK;

@@ -293,8 +293,15 @@ extern "C" int plv_line_tracker_feed_wait(plv_ctx *ctx);
 int plv_ctx_synchronize(plv_ctx *ctx) {
   REQUIRE_CTX(ctx);
   plv::NsScope ns(plv::counters().sync_ns);
-  TRY(plv_front_quiesce(ctx));
-  (void)plv_line_tracker_feed_wait(ctx);
+  {
+    plv::HostPhase ph("ctx_synchronize: detection side stream");
+    TRY(plv_front_quiesce(ctx));
+  }
+  {
+    plv::HostPhase ph("ctx_synchronize: line worker");
+    (void)plv_line_tracker_feed_wait(ctx);
+  }
+  plv::HostPhase ph("ctx_synchronize: ctx stream");
   TRY(sync(ctx));
   ctx->prof.collect();
   return PLV_OK;
