@@ -296,6 +296,10 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 // takes the same float step.  (Round 2: one wave per point with four pixels per lane took 52 us per launch, this form 45 — the
 // launch lasts as long as its slowest point, up to 30 iterations on each of 5 levels.)
 #define LK4_WAVES 4
+typedef short lk_short2 __attribute__((ext_vector_type(2)));
+typedef unsigned __attribute__((aligned(2))) lk_u32a2;  // a 32-bit LDS read at a 16-bit boundary (gfx950 reads LDS unaligned)
+// V: bit 0 = the lean iteration (below; windows of up to 256 pixels), V >> 4 = diagnostic build (tools/lk_exp.py: cycles of one phase
+// in place of the iteration count).  launch_lk picks <1>; <0> is the loop of rounds 2-4, kept for the comparison.
 template <int V>
 __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
                                                             const float *__restrict__ pts1_init, float *__restrict__ pts1,
@@ -305,6 +309,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   __shared__ uint8_t ttile[LK_TT][LK_TT + 2];
   __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
   __shared__ uint8_t jtile[LK_JT][LK_JT];
+  __shared__ unsigned short jt16[LK_JT][LK_JT];  // (lean iteration: the search tile as 16-bit pixels, two of them per 32-bit read)
   __shared__ int part[2][LK4_WAVES][2], part2[2][LK4_WAVES][2];
   __shared__ int partA[LK4_WAVES][3], partA2[LK4_WAVES][3];
   const int pt = blockIdx.x;
@@ -315,7 +320,6 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const float half = (win - 1) * 0.5f;
   const float ec = fminf(fmaxf(eps, 0.f), 10.f);
   const double eps2 = (double)ec * (double)ec;
-  const float eps2_lo = (float)(eps2 * (1.0 - 1e-6)), eps2_hi = (float)(eps2 * (1.0 + 1e-6));
   const int npx = win * win;
   const float px0 = pts0[2 * pt], py0 = pts0[2 * pt + 1];
   const float nx0 = pts1_init[2 * pt], ny0 = pts1_init[2 * pt + 1];
@@ -326,15 +330,16 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const int wy = own ? tid / win : 0, wx = own ? tid - wy * win : 0;
   const bool two = npx > 64 * LK4_WAVES;  // (uniform) a second window pixel per lane
   const bool own2 = two && tid + 64 * LK4_WAVES < npx;
+  constexpr bool LEAN = (V & 1) != 0;
+  constexpr int DIAG = V >> 4;
+  unsigned long long dg_acc = 0, dg_t = 0;
+#define LK_DG(PH, BEGIN)                                          \
+  if (DIAG == (PH) + 1) {                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (BEGIN) dg_t = now_; else dg_acc += now_ - dg_t;           \
+  }
   const int wy2 = own2 ? (tid + 64 * LK4_WAVES) / win : 0, wx2 = own2 ? tid + 64 * LK4_WAVES - wy2 * win : 0;
 
-  // (V >= 8: diagnostic builds, tools/lk_exp.py — cycles of one phase in place of the iteration count)
-  unsigned long long dg_acc = 0, dg_t = 0;
-#define LK_DG(PH, BEGIN)                                                  \
-  if (V >= 8 && (V - 8) == (PH)) {                                          \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-    if (BEGIN) dg_t = now_; else dg_acc += now_ - dg_t;                   \
-  }
   for (int level = maxLevel; level >= 0; --level) {
     LK_DG(3, 1)
     const float sc = 1.f / (float)(1 << level);
@@ -425,27 +430,110 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     float pdx = 0.f, pdy = 0.f;
     float outx = nextx + half, outy = nexty + half;
     const int jc = cur.w[level], jr = cur.h[level];
-    int jx0 = (V & 4) ? -(1 << 24) : 0, jy0 = jx0;  // (V & 4: no tile yet = a tile far away)
+    int jx0 = 0, jy0 = 0;
     bool have_tile = false;
     LK_DG(3, 0)
-    for (int j = 0; j < max_iters; ++j) {
-      LK_DG(0, 1)
-      int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
-      bool outside, reload;
-      if (V & 4) {  // the same two tests as unsigned range checks on scalar registers (every lane holds the same position)
-        inx = __builtin_amdgcn_readfirstlane(inx), iny = __builtin_amdgcn_readfirstlane(iny);
-        outside = ((unsigned)(inx + win) >= (unsigned)(jc + win)) | ((unsigned)(iny + win) >= (unsigned)(jr + win));
-        reload = ((unsigned)(inx - jx0) > (unsigned)(LK_JT - win - 1)) | ((unsigned)(iny - jy0) > (unsigned)(LK_JT - win - 1));
-      } else {
-        outside = inx < -win || inx >= jc || iny < -win || iny >= jr;
-        reload = !have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT;
+    if (LEAN && !two) {
+      // The iteration with as few instructions on the wave as the arithmetic allows (a lone wave retires one instruction per ~7
+      // cycles whatever it is: the launch lasts as long as its slowest point's instruction count).  Same values, bit for bit:
+      //  * one range test per iteration: the window position against the part of the tile's usable range that lies inside the
+      //    image's (fixed when the tile is loaded); the slow path behind it tells "left the image" from "needs another tile";
+      //  * the fractions from floorf's own result ((float)(int)floorf(x) == floorf(x)); the bilinear weights scaled by 2^14 before
+      //    the product instead of after it (a power of two commutes with the rounding), rounded to nearest-even by adding 2^23;
+      //  * the tile holds 16-bit pixels: one 32-bit read per row fetches the pixel pair, two v_dot2_i32_i16 form the interpolation
+      //    sum (the fourth weight can be -1: signed);
+      //  * (double)ddx * ddx + (double)ddy * ddy as one fma on the exact product (both products are exact in double);
+      //  * |(double)s| < 0.01 for a float s is |s| <= 0.01f (0.01 is not a float; 0.01f is the largest float below it); the j > 0
+      //    of that test is an infinite previous step.
+      int lo_x = -(1 << 28), lo_y = lo_x;
+      unsigned span_x = 0, span_y = 0;
+      const int lane_off = wy * LK_JT + wx;
+      float pvx = __builtin_inff(), pvy = __builtin_inff(), ddx = 0.f, ddy = 0.f;
+      bool osc = false;
+      for (int j = 0; j < max_iters; ++j) {
+        LK_DG(0, 1)
+        const float fx = floorf(nextx), fy = floorf(nexty);
+        const int inx = (int)fx, iny = (int)fy;
+        if (((unsigned)(inx - lo_x) > span_x) | ((unsigned)(iny - lo_y) > span_y)) {
+          if (inx < -win || inx >= jc || iny < -win || iny >= jr) {
+            if (level == 0) st = 0;
+            break;
+          }
+          jx0 = inx - (LK_JT - win - 1) / 2;
+          jy0 = iny - (LK_JT - win - 1) / 2;
+          __syncthreads();
+          {
+            const int r = tid >> 3, hx = (tid & 7) * 4;
+            const int Y = reflect101(jy0 + r, jr);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jt16[r][hx + c] = J[(size_t)Y * jc + reflect101(jx0 + hx + c, jc)];
+          }
+          __syncthreads();
+          lo_x = max(jx0, -win), lo_y = max(jy0, -win);
+          span_x = (unsigned)(min(jx0 + LK_JT - win - 1, jc - 1) - lo_x);
+          span_y = (unsigned)(min(jy0 + LK_JT - win - 1, jr - 1) - lo_y);
+        }
+        ++iters;
+        const float fa = nextx - fx, fb = nexty - fy;
+        const float sa = (1.f - fa) * 16384.f, sb = 1.f - fb, la = fa * 16384.f;
+        const unsigned u00 = __float_as_uint(sa * sb + 8388608.f), u01 = __float_as_uint(la * sb + 8388608.f),
+                       u10 = __float_as_uint(sa * fb + 8388608.f);
+        const unsigned u11 = (16384u + 3u * 0x4B000000u) - u00 - u01 - u10;  // (the biases of the three cancel: the weight itself)
+        const unsigned w0 = __builtin_amdgcn_perm(u01, u00, 0x05040100), w1 = __builtin_amdgcn_perm(u11, u10, 0x05040100);
+        int pb1 = 0, pb2 = 0;
+        if (own) {
+          const unsigned short *p = &jt16[0][0] + ((iny - jy0) * LK_JT + (inx - jx0) + lane_off);
+          const unsigned r0 = *(const lk_u32a2 *)p, r1 = *(const lk_u32a2 *)(p + LK_JT);
+          int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, r0), __builtin_bit_cast(lk_short2, w0), 1 << (W_BITS - 5 - 1), false);
+          v = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, r1), __builtin_bit_cast(lk_short2, w1), v, false);
+          const int diff = (v >> (W_BITS - 5)) - Iv;
+          pb1 = diff * Ix;
+          pb2 = diff * Iy;
+        }
+        LK_DG(0, 0)
+        LK_DG(1, 1)
+        pb1 = wave_sum_i32(pb1);
+        pb2 = wave_sum_i32(pb2);
+        if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
+        __syncthreads();
+        LK_DG(1, 0)
+        LK_DG(2, 1)
+        double sb1 = 0.0, sb2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
+        slot ^= 1;
+        const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+        ddx = (A12 * b2 - A22 * b1) * D;
+        ddy = (A12 * b1 - A11 * b2) * D;
+        nextx += ddx;
+        nexty += ddy;
+        LK_DG(2, 0)
+        if (fma((double)ddx, (double)ddx, (double)ddy * (double)ddy) <= eps2) break;
+        if (fabsf(ddx + pvx) <= 0.01f && fabsf(ddy + pvy) <= 0.01f) {
+          osc = true;
+          break;
+        }
+        pvx = ddx;
+        pvy = ddy;
       }
-      if (outside) {
+      outx = nextx + half;
+      outy = nexty + half;
+      if (osc) {
+        outx -= ddx * 0.5f;
+        outy -= ddy * 0.5f;
+      }
+      nextx = outx;
+      nexty = outy;
+      continue;
+    }
+    for (int j = 0; j < max_iters; ++j) {
+      const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+      if (inx < -win || inx >= jc || iny < -win || iny >= jr) {
         if (level == 0) st = 0;
         break;
       }
       ++iters;
-      if (reload) {
+      if (!have_tile || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + LK_JT || iny + win + 1 > jy0 + LK_JT) {
         jx0 = inx - (LK_JT - win - 1) / 2;
         jy0 = iny - (LK_JT - win - 1) / 2;
         __syncthreads();
@@ -472,8 +560,6 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
         pb1 = diff * Ix;
         pb2 = diff * Iy;
       }
-      LK_DG(0, 0)
-      LK_DG(1, 1)
       pb1 = wave_sum_i32(pb1);  // |diff| <= 8160, |Ix| <= 4080: 64 products < 2^31
       pb2 = wave_sum_i32(pb2);
       if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
@@ -491,50 +577,24 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
         if (lane == 0) part2[slot][wave][0] = qb1, part2[slot][wave][1] = qb2;
       }
       __syncthreads();
-      LK_DG(1, 0)
-      LK_DG(2, 1)
       // the four wave sums (|.| < 2^31 each) are added as doubles: exact (the total stays below 2^33), and (float) of that double
       // rounds once, as (float) of the 64-bit integer does — without the scalar-unit sequence an int64 -> float conversion compiles to
-      float b1, b2;
-      if ((V & 2) && !two) {
-        // the four wave sums as 64-bit integers (32-bit adds with carry: no double-precision conversions on the iteration's chain);
-        // a total that fits 32 bits — every frame seen so far — converts with one instruction, rounding once like the double does
-        long long t1 = 0, t2 = 0;
+      double sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < LK4_WAVES; ++w) t1 += part[slot][w][0], t2 += part[slot][w][1];
-        if ((long long)(int)t1 == t1 && (long long)(int)t2 == t2)
-          b1 = (float)(int)t1 * FLT_SCALE, b2 = (float)(int)t2 * FLT_SCALE;
-        else
-          b1 = (float)(double)t1 * FLT_SCALE, b2 = (float)(double)t2 * FLT_SCALE;
-      } else {
-        double sb1 = 0.0, sb2 = 0.0;
+      for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
+      if (two)
 #pragma unroll
-        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
-        if (two)
-#pragma unroll
-          for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part2[slot][w][0], sb2 += (double)part2[slot][w][1];
-        b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
-      }
+        for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part2[slot][w][0], sb2 += (double)part2[slot][w][1];
       slot ^= 1;
+      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D;
       const float ddy = (A12 * b1 - A11 * b2) * D;
       nextx += ddx;
       nexty += ddy;
       outx = nextx + half;
       outy = nexty + half;
-      LK_DG(2, 0)
-      if (V & 1) {
-        // (double)ddx * ddx + (double)ddy * ddy <= eps2, decided in single precision where that is safe: the float expression is
-        // within 3 ulp (2^-21 relative) of the exact value; only inside that band does the exact double test run.  Every lane holds
-        // the same values, so the branches are uniform.
-        const float q = ddx * ddx + ddy * ddy;
-        if (q <= eps2_lo && q >= 1e-30f) break;
-        if (q < eps2_hi && (double)ddx * ddx + (double)ddy * ddy <= eps2) break;
-      } else if ((double)ddx * ddx + (double)ddy * ddy <= eps2)
-        break;
-      // (V & 1: |(double)s| < 0.01 for a float s is |s| <= 0.01f: 0.01 is not a float, 0.01f is the largest float below it)
-      if ((V & 1) ? (j > 0 && fabsf(ddx + pdx) <= 0.01f && fabsf(ddy + pdy) <= 0.01f)
-                  : (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01)) {
+      if ((double)ddx * ddx + (double)ddy * ddy <= eps2) break;
+      if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
         outx -= ddx * 0.5f;
         outy -= ddy * 0.5f;
         break;
@@ -549,7 +609,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     pts1[2 * pt] = nextx;
     pts1[2 * pt + 1] = nexty;
     status[pt] = (uint8_t)st;
-    if (iters_out) iters_out[pt] = V >= 8 ? (int)dg_acc : iters;
+    if (iters_out) iters_out[pt] = DIAG ? (int)dg_acc : iters;
   }
   if (n0 && tid < 2) {
     float xn, yn;
@@ -1203,20 +1263,17 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  const unsigned variant = (plv::knobs().load(std::memory_order_relaxed) >> 21) & 15u;  // (experiment: tools/lk_exp.py)
+  const unsigned variant = (plv::knobs().load(std::memory_order_relaxed) >> 21) & 127u;  // (measurement: tools/lk_exp.py)
 #define LK_LAUNCH(VV)                                                                                                                     \
   hipLaunchKernelGGL(lk_kernel<VV>, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, \
                      d_pts1, d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr)
   switch (variant) {
-    case 1: LK_LAUNCH(1); break;
-    case 2: LK_LAUNCH(2); break;
-    case 4: LK_LAUNCH(4); break;
-    case 7: LK_LAUNCH(7); break;
-    case 8: LK_LAUNCH(8); break;
-    case 9: LK_LAUNCH(9); break;
-    case 10: LK_LAUNCH(10); break;
-    case 11: LK_LAUNCH(11); break;
-    default: LK_LAUNCH(0); break;
+    case 2: LK_LAUNCH(0); break;
+    case 17: LK_LAUNCH(17); break;
+    case 33: LK_LAUNCH(33); break;
+    case 49: LK_LAUNCH(49); break;
+    case 65: LK_LAUNCH(65); break;
+    default: LK_LAUNCH(1); break;
   }
 #undef LK_LAUNCH
   PLV_HIP_CHECK(hipGetLastError());

@@ -3,7 +3,7 @@
 
 Renders a few frames of the workload's drive, tracks the library's own detections through them (so that the points are tracks of a
 few frames' age, like the bench's), then times plv_lk_track of the last pair under every value of the experimental variant knob
-(bits 21-23 of plv_debug_knobs: template argument of lk_kernel) and checks that every variant returns the same bits.
+(bits 21-27 of plv_debug_knobs: template argument of lk_kernel) and checks that every variant returns the same bits.
 
 usage: python tools/lk_exp.py [workload] [variants, comma separated]"""
 import os
@@ -16,7 +16,7 @@ import numpy as np
 import bench
 
 wl_name = sys.argv[1] if len(sys.argv) > 1 else "C"
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 0]   # 2: the loop of rounds 2-4, 0: the lean iteration (default)
 wl = bench.WORKLOADS[wl_name]
 N_FRAMES = 8
 stream = bench.build_stream(wl, N_FRAMES + 30, 8)      # (forks: before the GPU is touched)
@@ -83,9 +83,9 @@ ctx2.feed_image(imgs[-2])
 ctx2.feed_image(imgs[-1])
 pkg.debug_knobs(0)
 its = ctx2.lk_track(p0, p0)[2].astype(np.float64)
-for v, name, per in ((8, "position -> products", its), (9, "wave sums + write + barrier", its), (10, "partials -> step", its), (11, "level set-up", 5.0)):
+for v, name, per in ((17, "position -> products", its), (33, "wave sums + write + barrier", its), (49, "partials -> step", its), (65, "level set-up", 5.0)):
     pkg.debug_knobs(v << SHIFT)
     cyc = ctx2.lk_track(p0, p0)[2].astype(np.float64)
     q = cyc / per
-    print(f"phase {name:30s}: cycles per {'iteration' if v < 11 else 'level'}: median {np.median(q):7.0f}  p10 {np.percentile(q, 10):7.0f}  p90 {np.percentile(q, 90):7.0f}")
+    print(f"phase {name:30s}: cycles per {'iteration' if v < 65 else 'level'}: median {np.median(q):7.0f}  p10 {np.percentile(q, 10):7.0f}  p90 {np.percentile(q, 90):7.0f}")
 pkg.debug_knobs(0)
