@@ -718,9 +718,9 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
     if (timing) F_und = std::chrono::steady_clock::now();
     for (int q = 0; q < nk; ++q) {
       const int D = plv_line_classification(fl.data() + 4 * q, vps);
-      auto it = T->db.find(fid[q]);
-      const bool is_new = it == T->db.end();
-      LineTrack &tr = T->db[fid[q]];
+      auto ins = T->db.try_emplace(fid[q]);
+      const bool is_new = ins.second;
+      LineTrack &tr = ins.first->second;
       if (is_new) {
         tr.D = D;  // REF LineFeatureDatabase.cpp:62-63: only a new feature takes D
         tr.t.reserve(32);

@@ -475,44 +475,73 @@ inline void assign_points(const float *lines, int nl, const float *pts, const ui
   float xmax = 0.f, ymax = 0.f;
   for (int j = 0; j < np; ++j) xmax = std::max(xmax, pts[2 * j]), ymax = std::max(ymax, pts[2 * j + 1]);
   const int gx = std::max(1, (int)(xmax / kCell) + 1), gy = std::max(1, (int)(ymax / kCell) + 1);
-  auto cell_of = [&](float v, int g) { return std::min(std::max((int)std::floor(v / kCell), 0), g - 1); };
-  std::vector<int> cstart((size_t)gx * gy + 1, 0), cidx((size_t)std::max(np, 1));
-  for (int j = 0; j < np; ++j) ++cstart[(size_t)cell_of(pts[2 * j + 1], gy) * gx + cell_of(pts[2 * j], gx) + 1];
+  auto cell_of = [&](float v, int g) { return std::min(std::max((int)std::floor(v * (1.0f / kCell)), 0), g - 1); };  // (a power of two: exact)
+  // (the scratch of the binning lives with the thread: a frame's assignment allocates nothing but its result)
+  static thread_local std::vector<int> cstart, cidx, fill, pcell;
+  cstart.assign((size_t)gx * gy + 1, 0), cidx.resize((size_t)std::max(np, 1)), pcell.resize((size_t)std::max(np, 1));
+  for (int j = 0; j < np; ++j) ++cstart[(size_t)(pcell[j] = cell_of(pts[2 * j + 1], gy) * gx + cell_of(pts[2 * j], gx)) + 1];
   for (size_t c = 0; c < (size_t)gx * gy; ++c) cstart[c + 1] += cstart[c];
-  {
-    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
-    for (int j = 0; j < np; ++j) cidx[fill[(size_t)cell_of(pts[2 * j + 1], gy) * gx + cell_of(pts[2 * j], gx)]++] = j;  // ascending j within a cell
-  }
-  std::vector<int> cand;
+  fill.assign(cstart.begin(), cstart.end() - 1);
+  for (int j = 0; j < np; ++j) cidx[fill[pcell[j]]++] = j;  // ascending j within a cell
+  constexpr int kCand = 64;
+  int cand[kCand];
+  std::vector<int> cand_more;
+  std::vector<std::pair<int, double>> on;
   const float grow = assign_px + 0.5f;
   for (int i = 0; i < nl; ++i) {
     const float *ln = lines + 4 * i;
     const float lx1 = ln[0], lx2 = ln[1], ly1 = ln[2], ly2 = ln[3];  // (sic)
     const float min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
     const float tx0 = std::min(ln[0], ln[2]) - grow, tx1 = std::max(ln[0], ln[2]) + grow, ty0 = std::min(ln[1], ln[3]) - grow, ty1 = std::max(ln[1], ln[3]) + grow;
-    cand.clear();
-    const int cx0 = cell_of(tx0, gx), cx1 = cell_of(tx1, gx), cy0 = cell_of(ty0, gy), cy1 = cell_of(ty1, gy);
-    for (int cy = cy0; cy <= cy1; ++cy)
-      for (int cx = cx0; cx <= cx1; ++cx)
-        for (int q = cstart[(size_t)cy * gx + cx]; q < cstart[(size_t)cy * gx + cx + 1]; ++q) cand.push_back(cidx[q]);
-    if (cand.empty()) continue;
-    std::sort(cand.begin(), cand.end());  // point order, as the reference's loop meets them
-    std::map<int, double> on;
-    size_t first_pos = A.pos.size();
-    for (int j : cand) {
+    // (no point of the true box can pass the reference's box when the two do not meet: nothing to look up)
+    if (tx1 < min_lx || tx0 > max_lx || ty1 < min_ly || ty0 > max_ly) continue;
+    const int cx0 = cell_of(std::max(tx0, min_lx), gx), cx1 = cell_of(std::min(tx1, max_lx), gx), cy0 = cell_of(std::max(ty0, min_ly), gy),
+              cy1 = cell_of(std::min(ty1, max_ly), gy);
+    int nc = 0;
+    cand_more.clear();
+    for (int cy = cy0; cy <= cy1; ++cy) {
+      const int q0 = cstart[(size_t)cy * gx + cx0], q1 = cstart[(size_t)cy * gx + cx1 + 1];  // (the cells of a row are contiguous)
+      for (int q = q0; q < q1; ++q) {
+        if (nc < kCand)
+          cand[nc++] = cidx[q];
+        else
+          cand_more.push_back(cidx[q]);
+      }
+    }
+    if (nc == 0) continue;
+    const int *cp = cand;
+    if (!cand_more.empty()) {
+      cand_more.insert(cand_more.end(), cand, cand + nc);
+      cp = cand_more.data(), nc = (int)cand_more.size();
+      std::sort(cand_more.begin(), cand_more.end());
+    } else {
+      for (int a = 1; a < nc; ++a) {  // point order, as the reference's loop meets them (a handful: insertion sort)
+        const int v = cand[a];
+        int b = a - 1;
+        for (; b >= 0 && cand[b] > v; --b) cand[b + 1] = cand[b];
+        cand[b + 1] = v;
+      }
+    }
+    on.clear();
+    const size_t first_pos = A.pos.size();
+    for (int q = 0; q < nc; ++q) {
+      const int j = cp[q];
       const float x = pts[2 * j], y = pts[2 * j + 1];
       if (!((x >= min_lx) & (x <= max_lx) & (y >= min_ly) & (y <= max_ly))) continue;
       const float d = point_line_distance(ln, x, y);
       if (d > assign_px) continue;
-      on[(int)ids[j]] = d;
+      on.emplace_back((int)ids[j], (double)d);
       A.pos.push_back(x);
       A.pos.push_back(y);
     }
     if (A.pos.size() == first_pos) continue;  // lines without a point are dropped (REF :784-789)
     A.kept.push_back(i);
-    for (const auto &kv : on) {
-      A.rel_id.push_back((uint64_t)kv.first);
-      A.rel_dist.push_back(kv.second);
+    // (the reference keeps the relations in a std::map<int, double>: ascending ids, a later point with the same id replaces the earlier)
+    std::stable_sort(on.begin(), on.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+    for (size_t q = 0; q < on.size(); ++q) {
+      if (q + 1 < on.size() && on[q + 1].first == on[q].first) continue;
+      A.rel_id.push_back((uint64_t)on[q].first);
+      A.rel_dist.push_back(on[q].second);
     }
     A.rel_ptr.push_back((int)A.rel_id.size());
     A.pos_ptr.push_back((int)A.pos.size() / 2);
@@ -573,7 +602,7 @@ inline void run_on_helpers(HostStage *T, int nhelpers, const std::function<void(
 // line and the points, and the ranges' results are joined in line order — the same Assign as the serial call.
 inline void assign_points_parallel(HostStage *T, int nhelpers, const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A,
                                    float assign_px = 5.0f) {
-  const int nt = std::max(1, std::min(nhelpers + 1, nl / 48));  // (a range of fewer than ~50 lines is not worth a hand-over)
+  const int nt = std::max(1, std::min(nhelpers + 1, nl / 400));  // (a range of a few hundred lines takes ~10 us: less is not worth a hand-over)
   if (nt == 1) {
     assign_points(lines, nl, pts, ids, np, A, assign_px);
     return;
@@ -596,28 +625,47 @@ inline void assign_points_parallel(HostStage *T, int nhelpers, const float *line
   }
 }
 
+// TrackLSD's line matching (REF: TrackLSD.cpp LineMatch as the oracle restates it): for a new line i the reference walks every line j
+// of the last frame and that line's points; the first shared point accepts j when j's midpoint lies within 6 px of the new segment,
+// the second accepts it outright, and a later j overwrites an earlier one.  So match[i] = the LAST j that shares two points with i, or
+// one point and the midpoint test.  Only lines that share a point can match: an index from point id to the last frame's lines
+// replaces the walk over all pairs (90 x 90 pairs x their points: 30-40 us per frame) by a look-up per point of the new line.
 inline void match_lines(const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new, const float *lines_last, int n_last,
                  const int *rp_last, const uint64_t *ri_last, int *match) {
   std::fill(match, match + n_new, -1);
   if (n_new == 0 || n_last == 0) return;
+  static thread_local std::vector<std::pair<uint64_t, int>> by_id;  // (point id, line of the last frame), sorted
+  by_id.clear();
+  for (int j = 0; j < n_last; ++j)
+    for (int q = rp_last[j]; q < rp_last[j + 1]; ++q) by_id.emplace_back(ri_last[q], j);
+  std::sort(by_id.begin(), by_id.end());
+  by_id.erase(std::unique(by_id.begin(), by_id.end()), by_id.end());  // (a point listed twice on a line counts once per listing in the
+                                                                      //  reference too, but the lists are map keys: no duplicates)
+  static thread_local std::vector<std::pair<int, int>> hit;  // (line j, shared points)
   for (int i = 0; i < n_new; ++i) {
-    if (rp_new[i + 1] == rp_new[i]) continue;
-    for (int j = 0; j < n_last; ++j) {
-      int shared = 0;
-      for (int q = rp_last[j]; q < rp_last[j + 1]; ++q) {
-        if (!std::binary_search(ri_new + rp_new[i], ri_new + rp_new[i + 1], ri_last[q])) continue;
-        ++shared;
-        if (shared >= 2) {
-          match[i] = j;
-          break;
-        }
-        // one shared point: accept when the last line's midpoint lies within 6 px of the new segment
-        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
-        if (point_line_distance(lines_new + 4 * i, mx, my) <= 6) {
-          match[i] = j;
-          break;
-        }
+    hit.clear();
+    for (int p = rp_new[i]; p < rp_new[i + 1]; ++p) {
+      if (p > rp_new[i] && ri_new[p] == ri_new[p - 1]) continue;
+      auto lo = std::lower_bound(by_id.begin(), by_id.end(), std::make_pair(ri_new[p], -1));
+      for (; lo != by_id.end() && lo->first == ri_new[p]; ++lo) {
+        bool seen = false;
+        for (auto &h : hit)
+          if (h.first == lo->second) {
+            ++h.second, seen = true;
+            break;
+          }
+        if (!seen) hit.emplace_back(lo->second, 1);
       }
+    }
+    for (const auto &h : hit) {
+      const int j = h.first;
+      if (j < match[i]) continue;
+      bool ok = h.second >= 2;
+      if (!ok) {
+        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
+        ok = point_line_distance(lines_new + 4 * i, mx, my) <= 6;
+      }
+      if (ok) match[i] = j;
     }
   }
 }
@@ -626,7 +674,7 @@ inline void match_lines(const float *lines_new, int n_new, const int *rp_new, co
 // that line and the last frame's lines)
 inline void match_lines_parallel(HostStage *T, int nhelpers, const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new,
                                  const float *lines_last, int n_last, const int *rp_last, const uint64_t *ri_last, int *match) {
-  const int nt = std::max(1, std::min(nhelpers + 1, n_new / 8));
+  const int nt = std::max(1, std::min(nhelpers + 1, n_new / 2000));  // (the indexed match takes a few us: one thread)
   if (nt == 1 || n_last == 0) {
     match_lines(lines_new, n_new, rp_new, ri_new, lines_last, n_last, rp_last, ri_last, match);
     return;

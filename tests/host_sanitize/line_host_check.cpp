@@ -17,6 +17,56 @@ void set_last_error(const char *, ...) {}
 using namespace plv;
 using namespace plv::linehost;
 
+// AssignPointToLines and LineMatch written out plainly (every line against every point / every pair of lines and their points, as
+// the reference's loops run and the oracle restates them): the checkers of line_host.hpp's binned assignment and indexed matching.
+static void assign_points_plain(const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A, float assign_px = 5.0f) {
+  A = Assign();
+  for (int i = 0; i < nl; ++i) {
+    const float *ln = lines + 4 * i;
+    const float lx1 = ln[0], lx2 = ln[1], ly1 = ln[2], ly2 = ln[3];  // (sic: the reference reads the segment this way)
+    const float min_lx = std::min(lx1, lx2), max_lx = std::max(lx1, lx2), min_ly = std::min(ly1, ly2), max_ly = std::max(ly1, ly2);
+    std::map<int, double> on;
+    const size_t first_pos = A.pos.size();
+    for (int j = 0; j < np; ++j) {
+      const float x = pts[2 * j], y = pts[2 * j + 1];
+      if (!(x >= min_lx && x <= max_lx && y >= min_ly && y <= max_ly)) continue;
+      const float d = point_line_distance(ln, x, y);
+      if (d > assign_px) continue;
+      on[(int)ids[j]] = d;
+      A.pos.push_back(x);
+      A.pos.push_back(y);
+    }
+    if (A.pos.size() == first_pos) continue;
+    A.kept.push_back(i);
+    for (const auto &kv : on) A.rel_id.push_back((uint64_t)kv.first), A.rel_dist.push_back(kv.second);
+    A.rel_ptr.push_back((int)A.rel_id.size());
+    A.pos_ptr.push_back((int)A.pos.size() / 2);
+  }
+}
+static void match_lines_plain(const float *lines_new, int n_new, const int *rp_new, const uint64_t *ri_new, const float *lines_last, int n_last,
+                              const int *rp_last, const uint64_t *ri_last, int *match) {
+  std::fill(match, match + n_new, -1);
+  for (int i = 0; i < n_new; ++i) {
+    if (rp_new[i + 1] == rp_new[i]) continue;
+    for (int j = 0; j < n_last; ++j) {
+      int shared = 0;
+      for (int q = rp_last[j]; q < rp_last[j + 1]; ++q) {
+        if (!std::binary_search(ri_new + rp_new[i], ri_new + rp_new[i + 1], ri_last[q])) continue;
+        ++shared;
+        if (shared >= 2) {
+          match[i] = j;
+          break;
+        }
+        const float mx = (lines_last[4 * j] + lines_last[4 * j + 2]) / 2, my = (lines_last[4 * j + 1] + lines_last[4 * j + 3]) / 2;
+        if (point_line_distance(lines_new + 4 * i, mx, my) <= 6) {
+          match[i] = j;
+          break;
+        }
+      }
+    }
+  }
+}
+
 // The chain walk written out plainly (eight byte tests per step, in the detector's order: REF FastLineDetector's chain loop as the
 // oracle restates it): the checker of line_host.hpp's walk_chains, which reads the neighbourhood as three words and a bit mask.
 static void walk_chains_plain(const uint8_t *map, int w, int h, int length_threshold, std::vector<int2> &pts, std::vector<FldChain> &chains) {
@@ -105,7 +155,7 @@ int main(int argc, char **argv) {
   HostStage stage;
   std::vector<int2> pts(npix);
   std::vector<FldChain> chains(kChainCap);
-  long total_lines = 0, total_kept = 0;
+  long total_lines = 0, total_kept = 0, total_matched = 0;
   std::mt19937 rng(7);
   std::vector<float> last_lines;
   Assign last;
@@ -171,8 +221,33 @@ int main(int argc, char **argv) {
         ptsf.push_back(J.lines[4 * q + 1] + s * (J.lines[4 * q + 3] - J.lines[4 * q + 1]) + 2 * u(rng));
         ids.push_back(1000 + q);
       }
-      Assign A, Ap;
+      // ... and points that live on from map to map (ids that meet again: what the matching works on), some of them piled up
+      // at the segments' first end points (several points per line, the same point on several lines)
+      for (int q = 0; q < 260; ++q) {
+        const int l = (q * 7) % std::max(nl, 1);
+        const bool near = nl > 0 && q % 3 != 0;
+        ptsf.push_back(near ? J.lines[4 * l] + 6 * u(rng) - 3 : 2.f * w * u(rng));
+        ptsf.push_back(near ? J.lines[4 * l + 1] + 6 * u(rng) - 3 : 2.f * h * u(rng));
+        ids.push_back(50000 + q);
+      }
+      // ... and two or three points on every third segment whose ids go with the segment's index: lines of consecutive maps that
+      // share two points (the matching's first rule), or one (its second)
+      for (int l = 0; l < nl; l += 3)
+        for (int k = 0; k < 2 + (l % 2); ++k) {
+          if ((l + k) % 5 == 0) continue;
+          const float s = 0.2f + 0.3f * k;
+          ptsf.push_back(J.lines[4 * l] + s * (J.lines[4 * l + 2] - J.lines[4 * l]) + u(rng));
+          ptsf.push_back(J.lines[4 * l + 1] + s * (J.lines[4 * l + 3] - J.lines[4 * l + 1]) + u(rng));
+          ids.push_back(60000 + 4 * (uint64_t)l + k);
+        }
+      Assign A, Ap, Aplain;
       assign_points(J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), A);
+      assign_points_plain(J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), Aplain);
+      if (Aplain.kept != A.kept || Aplain.rel_ptr != A.rel_ptr || Aplain.rel_id != A.rel_id || Aplain.rel_dist != A.rel_dist || Aplain.pos_ptr != A.pos_ptr ||
+          Aplain.pos != A.pos) {
+        fprintf(stderr, "frame %d: the binned assignment differs from the plain one (%zu vs %zu lines kept)\n", i, A.kept.size(), Aplain.kept.size());
+        return 8;
+      }
       // the same assignment with the lines split over the stage's threads: the same lists
       assign_points_parallel(&stage, 3, J.lines.data(), nl, ptsf.data(), ids.data(), (int)ids.size(), Ap);
       if (Ap.kept != A.kept || Ap.rel_ptr != A.rel_ptr || Ap.rel_id != A.rel_id || Ap.rel_dist != A.rel_dist || Ap.pos_ptr != A.pos_ptr || Ap.pos != A.pos) {
@@ -192,11 +267,20 @@ int main(int argc, char **argv) {
           fprintf(stderr, "frame %d: the parallel matching differs from the serial one\n", i);
           return 7;
         }
+        std::vector<int> match_plain(A.kept.size());
+        match_lines_plain(kept_lines.data(), (int)A.kept.size(), A.rel_ptr.data(), A.rel_id.data(), last_lines.data(), (int)last_lines.size() / 4,
+                          last.rel_ptr.data(), last.rel_id.data(), match_plain.data());
+        if (match_plain != match) {
+          fprintf(stderr, "frame %d: the indexed matching differs from the plain one\n", i);
+          return 9;
+        }
+        for (int m : match) total_matched += m >= 0;
       }
       total_kept += (long)A.kept.size();
       last_lines = kept_lines;
       last = A;
     }
-  printf("ok: %d maps x %d repeats, %ld segments, %ld kept by the assignment\n", n, reps, total_lines, total_kept);
+  printf("ok: %d maps x %d repeats, %ld segments, %ld kept by the assignment, %ld matched to a line of the map before\n", n, reps, total_lines, total_kept,
+         total_matched);
   return 0;
 }

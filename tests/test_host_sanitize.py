@@ -50,6 +50,9 @@ def test_line_host_stage_under_sanitizers(maps, tmp_path, san):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([exe, maps, "6"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok:" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    import re
+    m = re.search(r"(\d+) kept by the assignment, (\d+) matched", r.stdout)
+    assert m and int(m.group(1)) > 100 and int(m.group(2)) > 50, r.stdout[-500:]   # (the plain checkers had something to check)
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
 
 
