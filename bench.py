@@ -95,6 +95,67 @@ def build_stream(wl, n_frames, workers, cache=None):
     return dict(msgs=msgs, imu=np.column_stack([t, wm, am]), wheel=np.column_stack([tw, m1, m2]), cam_t=tc, imgs=imgs, gt=sim["gt"])
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_to_device(pkg, device, mode, rank_on_node=None):
+    """The process (and every thread it starts afterwards) onto the cores next to the GPU: its NUMA node's, or one L3 complex of that
+    node.  What `numactl --cpunodebind` does for a launcher; a two-socket host otherwise schedules the caller and the library's line
+    threads on either socket, and a frame's ~40 hand-overs between them and the device's pinned result blocks cross the sockets.
+    Returns what was done, for the bench line."""
+    if mode == "none" or not hasattr(os, "sched_setaffinity"):
+        return {"mode": "none"}
+    try:
+        node = pkg.device_numa_node(device)
+        allowed = os.sched_getaffinity(0)
+        if node < 0:
+            return {"mode": "none", "why": "the device's NUMA node is unknown"}
+        cpus = [c for c in _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in allowed]
+        if len(cpus) < 4:
+            return {"mode": "none", "why": "fewer than four allowed cores on the device's node"}
+        chosen, info = cpus, {"mode": "node", "numa_node": node, "cpus": len(cpus)}
+        if mode == "ccx":
+            groups = {}
+            for c in cpus:
+                try:
+                    key = open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read().strip()
+                except OSError:
+                    key = "all"
+                groups.setdefault(key, []).append(c)
+            groups = [g for g in groups.values() if len(g) >= 8]
+            if groups:
+                def busy_snapshot():
+                    out = {}
+                    for line in open("/proc/stat"):
+                        if line.startswith("cpu") and line[3].isdigit():
+                            f = line.split()
+                            v = [int(x) for x in f[1:9]]
+                            out[int(f[0][3:])] = (sum(v) - v[3] - v[4], sum(v))
+                    return out
+                if rank_on_node is None:
+                    a = busy_snapshot()
+                    time.sleep(0.1)
+                    b = busy_snapshot()
+                    load = [sum(b[c][0] - a[c][0] for c in g) / max(1, sum(b[c][1] - a[c][1] for c in g)) for g in groups]
+                    k = int(np.argmin(load))
+                    info["ccx_busy_fraction"] = round(float(load[k]), 3)
+                else:
+                    k = rank_on_node % len(groups)
+                chosen = groups[k]
+                info.update(mode="ccx", cpus=len(chosen), first_cpu=min(chosen))
+        os.sched_setaffinity(0, set(chosen))
+        return info
+    except OSError as e:
+        return {"mode": "none", "why": str(e)}
+
+
 def load_options(wl):
     import importlib
     import __graft_entry__ as ge
@@ -367,6 +428,9 @@ def main():
     ap.add_argument("--alternate-fit", default=None, help="measurement aid: e.g. 2,0 — segment-fitter thread counts cycled frame by frame")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
                     "mean step time of each on stderr")
+    ap.add_argument("--pin", choices=("none", "node", "ccx"), default=os.environ.get("PLV_BENCH_PIN", "ccx"),
+                    help="CPU affinity of this process and the library's threads: the cores of the GPU's NUMA node, or one L3 complex of that "
+                         "node (the least busy one; with several ranks, one complex per rank)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises the multi-process plumbing only (tests/test_bench_dist.py)")
     args = ap.parse_args()
@@ -422,6 +486,8 @@ def main():
     system = importlib.import_module("plviwo_amd.system")
     ndev = max(1, pkg.load_library().plv_device_count())
     device = (local_rank % ndev) if world > 1 else 0   # one GPU per rank; wraps only when a node has fewer GPUs than ranks
+    cpus_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = pin_to_device(pkg, device, args.pin, local_rank if world > 1 else None)   # (before the library starts its threads: they inherit it)
     op = load_options(wl)
     sm = system.SystemManager(op, device=device)
     ctx = sm.ctx
@@ -693,6 +759,8 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu:
+        if cpus_before is not None:
+            os.sched_setaffinity(0, cpus_before)   # (the CPU baseline gets every core the process is allowed, not the GPU path's L3 complex)
         cpu = cpu_baseline(wl, stream, args.cpu_frames, args.cpu_budget_s, [1, 4, max(1, min(16, os.cpu_count() or 1))])
 
     if rank == 0:
@@ -760,6 +828,7 @@ def main():
                 "line_launches_chained_per_frame": round(cnt.get("chained", 0) / args.steps, 2),
                 "ms_per_step_inside_the_library": round((cnt["frame_ns"] + cnt["sync_ns"]) / args.steps * 1e-6, 4),
                 "us_per_step_in_plv_ctx_synchronize": round(cnt["sync_ns"] / args.steps * 1e-3, 1),
+                "cpu_affinity": pinned,
                 "timed_region": "plv_camera_frame + plv_ctx_synchronize on arguments marshalled beforehand (SystemManager.camera_prepare): two ctypes calls; "
                                 "ms_per_step_python = the same step with the Python driver's marshalling inside it, over the next frames",
                 "ms_per_step_python": round(seg_py["elapsed"] / npy * 1e3, 4),

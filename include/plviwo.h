@@ -87,6 +87,9 @@ int plv_abi_version(void);
 const char *plv_last_error(void);
 /* number of visible gfx950 devices (0 => every compute call returns PLV_E_NO_DEVICE) */
 int plv_device_count(void);
+/* NUMA node of HIP device `device` (from its PCI function in sysfs), -1 when the system does not say.  Host threads that drive a
+ * ctx — and the library's own, which inherit the creating thread's affinity — are best kept on that node's cores. */
+int plv_device_numa_node(int device);
 
 int plv_ctx_create(const plv_config *cfg, plv_ctx **out);
 void plv_ctx_destroy(plv_ctx *ctx);

@@ -73,6 +73,7 @@ def load_library():
         "plv_abi_version": (C.c_int, []),
         "plv_last_error": (C.c_char_p, []),
         "plv_device_count": (C.c_int, []),
+        "plv_device_numa_node": (C.c_int, [C.c_int]),
         "plv_config_default": (None, [C.POINTER(PlvConfig), C.c_int, C.c_int]),
         "plv_ctx_create": (C.c_int, [C.POINTER(PlvConfig), C.POINTER(vp)]),
         "plv_ctx_destroy": (None, [vp]),
@@ -715,6 +716,11 @@ def route_counts():
     out = (C.c_ulonglong * 8)()
     load_library().plv_route_counts(out)
     return [int(v) for v in out]
+
+
+def device_numa_node(device=0):
+    """plv_device_numa_node: NUMA node of the HIP device's PCI function, -1 when unknown"""
+    return int(load_library().plv_device_numa_node(int(device)))
 
 
 def chain_count():

@@ -135,6 +135,22 @@ int plv_device_count(void) {
   return ok;
 }
 
+// NUMA node of a HIP device's PCI function (sysfs), -1 when unknown: the caller's threads belong on that node's cores — the ctx
+// stream's doorbell, the pinned result blocks the host polls and the library's worker threads all live next to the device then
+int plv_device_numa_node(int device) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return -1;
+  for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
 void plv_config_default(plv_config *c, int width, int height) {
   memset(c, 0, sizeof(*c));
   c->width = width;
