@@ -62,7 +62,8 @@ WORKLOADS = {
     "C_avenue": dict(w=752, h=480, hz=15, points=250, num_features=360, lines=True, cfg="configs[2]", scene="avenue", mount=(12.0, 0.0)),
     "D": dict(w=1280, h=720, hz=20, points=500, num_features=780, lines=True, cfg="configs[3]", scene="avenue", mount=(12.0, 0.0)),
 }
-PROLOGUE = 24      # frames before the warm-up: initialisation + the first full clone window (untimed set-up)
+PROLOGUE = 60      # frames before the warm-up: initialisation, the first full clone window, and the library's buffers and threads reaching
+                   # their steady state (untimed set-up: with 24 the driver's 20-step run sat 10-20 % above the 200-step one)
 LEAD_IN = 2        # untimed steps at the start of every timed segment, after its garbage collection (see timed_segment)
 IMU, WHEEL, CAM = 0, 1, 2
 ROUND = "r05"
@@ -643,6 +644,10 @@ def main():
     if os.environ.get("PLV_BENCH_FINGERPRINT"):     # (determinism checks: the filter's state after the timed segment, to the last bit)
         print("[fingerprint] p = %r  q = %r  trace(P) = %r  routes = %r" % (tuple(float(x) for x in sm.state.imu.p), tuple(float(x) for x in sm.state.imu.q),
                                                                           float(np.trace(ctx.cov_download(sm.state.n))), pkg.route_counts()), file=sys.stderr)
+    if os.environ.get("PLV_BENCH_STOP_AFTER_MAIN"):   # (measurement aid: the library's phase table then covers the timed segment only)
+        print("[main segment] ms per step %.4f  p50 %.4f" % (seg["elapsed"] / args.steps * 1e3, float(np.median(seg["per"]))), file=sys.stderr)
+        sm.close()
+        sys.exit(0)
     seg_pcie = None
     if not args.no_pcie:
         pl.staged = False

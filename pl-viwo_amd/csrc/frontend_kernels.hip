@@ -298,8 +298,8 @@ __global__ void __launch_bounds__(256) pyrdown2_kernel(const uint8_t *__restrict
 #define LK4_WAVES 4
 typedef short lk_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned __attribute__((aligned(2))) lk_u32a2;  // a 32-bit LDS read at a 16-bit boundary (gfx950 reads LDS unaligned)
-// V: bit 0 = the lean iteration (below; windows of up to 256 pixels), V >> 4 = diagnostic build (tools/lk_exp.py: cycles of one phase
-// in place of the iteration count).  launch_lk picks <1>; <0> is the loop of rounds 2-4, kept for the comparison.
+// V: 1 = the lean iteration (below; windows of up to 256 pixels), what launch_lk picks; 0 = the loop of rounds 2-4, kept for the
+// comparison (tools/lk_exp.py: same bits, 80 -> 73 us per launch at workload C).
 template <int V>
 __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
                                                             const float *__restrict__ pts1_init, float *__restrict__ pts1,
@@ -330,18 +330,10 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
   const int wy = own ? tid / win : 0, wx = own ? tid - wy * win : 0;
   const bool two = npx > 64 * LK4_WAVES;  // (uniform) a second window pixel per lane
   const bool own2 = two && tid + 64 * LK4_WAVES < npx;
-  constexpr bool LEAN = (V & 1) != 0;
-  constexpr int DIAG = V >> 4;
-  unsigned long long dg_acc = 0, dg_t = 0;
-#define LK_DG(PH, BEGIN)                                          \
-  if (DIAG == (PH) + 1) {                                         \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-    if (BEGIN) dg_t = now_; else dg_acc += now_ - dg_t;           \
-  }
   const int wy2 = own2 ? (tid + 64 * LK4_WAVES) / win : 0, wx2 = own2 ? tid + 64 * LK4_WAVES - wy2 * win : 0;
+  constexpr bool LEAN = (V & 1) != 0;
 
   for (int level = maxLevel; level >= 0; --level) {
-    LK_DG(3, 1)
     const float sc = 1.f / (float)(1 << level);
     float prevx = px0 * sc, prevy = py0 * sc;
     if (level == maxLevel) {
@@ -432,7 +424,6 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     const int jc = cur.w[level], jr = cur.h[level];
     int jx0 = 0, jy0 = 0;
     bool have_tile = false;
-    LK_DG(3, 0)
     if (LEAN && !two) {
       // The iteration with as few instructions on the wave as the arithmetic allows (a lone wave retires one instruction per ~7
       // cycles whatever it is: the launch lasts as long as its slowest point's instruction count).  Same values, bit for bit:
@@ -451,7 +442,6 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
       float pvx = __builtin_inff(), pvy = __builtin_inff(), ddx = 0.f, ddy = 0.f;
       bool osc = false;
       for (int j = 0; j < max_iters; ++j) {
-        LK_DG(0, 1)
         const float fx = floorf(nextx), fy = floorf(nexty);
         const int inx = (int)fx, iny = (int)fy;
         if (((unsigned)(inx - lo_x) > span_x) | ((unsigned)(iny - lo_y) > span_y)) {
@@ -490,14 +480,10 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
           pb1 = diff * Ix;
           pb2 = diff * Iy;
         }
-        LK_DG(0, 0)
-        LK_DG(1, 1)
-        pb1 = wave_sum_i32(pb1);
-        pb2 = wave_sum_i32(pb2);
-        if (lane == 0) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;
+        pb1 = wave_sum_i32_lane63(pb1);
+        pb2 = wave_sum_i32_lane63(pb2);
+        if (lane == 63) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;  // (the lane the reduction ends in: no broadcast)
         __syncthreads();
-        LK_DG(1, 0)
-        LK_DG(2, 1)
         double sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
         for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
@@ -507,7 +493,6 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
         ddy = (A12 * b1 - A11 * b2) * D;
         nextx += ddx;
         nexty += ddy;
-        LK_DG(2, 0)
         if (fma((double)ddx, (double)ddx, (double)ddy * (double)ddy) <= eps2) break;
         if (fabsf(ddx + pvx) <= 0.01f && fabsf(ddy + pvy) <= 0.01f) {
           osc = true;
@@ -609,7 +594,7 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     pts1[2 * pt] = nextx;
     pts1[2 * pt + 1] = nexty;
     status[pt] = (uint8_t)st;
-    if (iters_out) iters_out[pt] = DIAG ? (int)dg_acc : iters;
+    if (iters_out) iters_out[pt] = iters;
   }
   if (n0 && tid < 2) {
     float xn, yn;
@@ -1263,18 +1248,14 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  const unsigned variant = (plv::knobs().load(std::memory_order_relaxed) >> 21) & 127u;  // (measurement: tools/lk_exp.py)
+  // (measurement: bit 21 of plv_debug_knobs launches the loop of rounds 2-4 instead, tools/lk_exp.py)
 #define LK_LAUNCH(VV)                                                                                                                     \
   hipLaunchKernelGGL(lk_kernel<VV>, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, \
                      d_pts1, d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr)
-  switch (variant) {
-    case 2: LK_LAUNCH(0); break;
-    case 17: LK_LAUNCH(17); break;
-    case 33: LK_LAUNCH(33); break;
-    case 49: LK_LAUNCH(49); break;
-    case 65: LK_LAUNCH(65); break;
-    default: LK_LAUNCH(1); break;
-  }
+  if (plv::knob(1u << 21))
+    LK_LAUNCH(0);
+  else
+    LK_LAUNCH(1);
 #undef LK_LAUNCH
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

@@ -57,6 +57,11 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   PLV_WAVE_REDUCE_BODY(dpp_mov_i32)
   return __builtin_amdgcn_readlane(v, 63);
 }
+// the same sum, left where the reduction ends: valid in lane 63 only (no broadcast: for a caller whose lane 63 stores it)
+__device__ __forceinline__ int wave_sum_i32_lane63(int v) {
+  PLV_WAVE_REDUCE_BODY(dpp_mov_i32)
+  return v;
+}
 // Sum over each aligned group of 4 lanes, result in all 4 lanes.
 __device__ __forceinline__ double quad_sum_f64(double v) {
   v += dpp_mov_f64<0xB1>(v);

@@ -2,8 +2,8 @@
 """lk_kernel on two consecutive frames of a bench workload, launch time per variant (measurement aid).
 
 Renders a few frames of the workload's drive, tracks the library's own detections through them (so that the points are tracks of a
-few frames' age, like the bench's), then times plv_lk_track of the last pair under every value of the experimental variant knob
-(bits 21-27 of plv_debug_knobs: template argument of lk_kernel) and checks that every variant returns the same bits.
+few frames' age, like the bench's), then times plv_lk_track of the last pair under both values of the variant knob
+(bit 21 of plv_debug_knobs: the loop of rounds 2-4 instead of the lean iteration) and checks that every variant returns the same bits.
 
 usage: python tools/lk_exp.py [workload] [variants, comma separated]"""
 import os
@@ -16,10 +16,10 @@ import numpy as np
 import bench
 
 wl_name = sys.argv[1] if len(sys.argv) > 1 else "C"
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 0]   # 2: the loop of rounds 2-4, 0: the lean iteration (default)
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0]   # 1: the loop of rounds 2-4, 0: the lean iteration (default)
 wl = bench.WORKLOADS[wl_name]
 N_FRAMES = 8
-stream = bench.build_stream(wl, N_FRAMES + 30, 8)      # (forks: before the GPU is touched)
+stream = bench.build_stream(wl, N_FRAMES + 30, 8, os.environ.get("PLV_STREAM_CACHE"))      # (forks: before the GPU is touched; a profiled run loads the cache)
 import __graft_entry__ as ge
 pkg = ge.load_pkg()
 cfg = pkg.default_config(wl["w"], wl["h"])
@@ -61,31 +61,20 @@ ctx.close()
 
 # launch time against the iteration cap and the number of levels (what a level's set-up costs, what an iteration costs)
 print("default: lk_max_iters", cfg.lk_max_iters, "pyr_levels", cfg.pyr_levels, "win", cfg.win_size)
-for iters, lv in ((cfg.lk_max_iters, cfg.pyr_levels), (1, cfg.pyr_levels), (2, cfg.pyr_levels), (4, cfg.pyr_levels), (8, cfg.pyr_levels), (cfg.lk_max_iters, 1), (1, 1), (cfg.lk_max_iters, 3), (1, 3)):
-    c2 = pkg.default_config(wl["w"], wl["h"])
-    c2.num_features = wl["num_features"]
-    c2.lk_max_iters, c2.pyr_levels = iters, lv
-    x = pkg.Context(c2)
-    x.feed_image(imgs[-2])
-    x.feed_image(imgs[-1])
-    x.prof_enable(True)
-    x.prof_reset()
-    for _ in range(40):
-        out = x.lk_track(p0, p0)
-    t = x.prof_table()["lk_kernel"]
-    print(f"max_iters {iters:2d} levels {lv}: lk_kernel {t[1] / t[0] * 1e3:6.1f} us, iterations/pt mean {out[2].mean():.1f} max {out[2].max()}")
-    x.close()
-
-# diagnostic builds: cycles of one phase summed over a point's iterations (8: position -> products, 9: wave sums + barrier,
-# 10: partials -> step, 11: a level's set-up), per point in place of the iteration count
-ctx2 = pkg.Context(cfg)
-ctx2.feed_image(imgs[-2])
-ctx2.feed_image(imgs[-1])
-pkg.debug_knobs(0)
-its = ctx2.lk_track(p0, p0)[2].astype(np.float64)
-for v, name, per in ((17, "position -> products", its), (33, "wave sums + write + barrier", its), (49, "partials -> step", its), (65, "level set-up", 5.0)):
+for v in variants:
     pkg.debug_knobs(v << SHIFT)
-    cyc = ctx2.lk_track(p0, p0)[2].astype(np.float64)
-    q = cyc / per
-    print(f"phase {name:30s}: cycles per {'iteration' if v < 65 else 'level'}: median {np.median(q):7.0f}  p10 {np.percentile(q, 10):7.0f}  p90 {np.percentile(q, 90):7.0f}")
+    for iters, lv in ((cfg.lk_max_iters, cfg.pyr_levels), (1, cfg.pyr_levels), (2, cfg.pyr_levels), (8, cfg.pyr_levels), (cfg.lk_max_iters, 1), (1, 1)):
+        c2 = pkg.default_config(wl["w"], wl["h"])
+        c2.num_features = wl["num_features"]
+        c2.lk_max_iters, c2.pyr_levels = iters, lv
+        x = pkg.Context(c2)
+        x.feed_image(imgs[-2])
+        x.feed_image(imgs[-1])
+        x.prof_enable(True)
+        x.prof_reset()
+        for _ in range(40):
+            out = x.lk_track(p0, p0)
+        t = x.prof_table()["lk_kernel"]
+        print(f"variant {v}: max_iters {iters:2d} levels {lv}: lk_kernel {t[1] / t[0] * 1e3:6.1f} us, iterations/pt mean {out[2].mean():.1f} max {out[2].max()}")
+        x.close()
 pkg.debug_knobs(0)
