@@ -1505,6 +1505,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
         continue;
       }
       if (seen++ < n_skip[sel[q]]) continue;
+      if (fused_ran) continue;  // (the batch was built on the device: the two-step route's arrays are not needed)
       st_t.push_back(c.tr.t[i]);
       suv.insert(suv.end(), c.tr.uv.begin() + 4 * i, c.tr.uv.begin() + 4 * i + 4);
       if (opt->cpi) {
@@ -1570,6 +1571,14 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     if (accepted_out) accepted_out[q] = acc[q];
     if (!acc[q]) {  // REF UpdaterCamera.cpp:441-444 copy_to_db(lbd_unused, line): gate failures only
       const Cand &c = pool[sel[q]];
+      // (every view usable and nothing of the line handed back earlier — the usual case: the copy the reference makes view by view
+      // is the track itself, returned whole by the hand-back like the candidates the update never took)
+      bool whole = unused.find(c.id) == unused.end();
+      for (size_t i = 0; whole && i < c.tr.t.size(); ++i) whole = has_bounding(c.tr.t[i] + dt);
+      if (whole) {
+        lazy_back.push_back(sel[q]);
+        continue;
+      }
       for (size_t i = 0; i < c.tr.t.size(); ++i)
         if (has_bounding(c.tr.t[i] + dt)) give_back(c, i);
     }

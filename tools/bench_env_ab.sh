@@ -1,0 +1,4 @@
+# A/B of an environment setting over alternating bench runs (measurement aid): bash tools/bench_env_ab.sh VAR valueA valueB [rounds]
+VAR=$1; A=$2; B=$3; R=${4:-3}
+for r in $(seq $R); do for v in $A $B; do env $VAR=$v python3 bench.py --steps 150 --warmup 10 --no-cpu --no-stress --no-pcie --no-variants 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('$VAR=$v', round(d['ms_per_step'],4), 'p50', round(d['latency_p50_ms'],4), 'chained', c['line_launches_chained_per_frame'])"; done; done
