@@ -686,7 +686,11 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   unsigned char *tri_valid = nullptr, *tri_ok = nullptr;
   StageExtra ex;
   if (ft) ex.flags = ft->flags;
-  TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex, ft ? ft->st_tri : nullptr, &Pt));
+  {
+    plv::HostPhase ph_stage("build lines: inputs staged + upload enqueued");
+    TRY(stage_line_inputs(ctx, us, st, lt, k, col_to_state, ld, P, &ex, ft ? ft->st_tri : nullptr, &Pt));
+  }
+  plv::HostPhase ph_rest("build lines: gather arguments + launch + prior prefetch");
   us->b_projected = false;
   us->b_gather_token = 0;
   if (ft) {

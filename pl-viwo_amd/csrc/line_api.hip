@@ -1252,8 +1252,11 @@ static int lines_first_half(plv_ctx *ctx, LineTracker *T, const plv_state_view *
     J.stage = LinesJob::FUSED_NOTHING;
     return PLV_OK;
   }
+  plv::HostPhase ph_cols("update_lines: columns");
   int rc = plv_line_jacobian_columns(st, &all, J.cols.data(), (int)J.cols.size(), &J.k);
+  ph_cols.stop();
   if (rc == PLV_OK && J.k > 0) {
+    plv::HostPhase ph_sub("update_lines: fused submit (gate prepare + stage + upload + launch)");
     ctx->gate_rows_hint = 2 * J.most_valid;
     ch.on = chained;
     rc = plv_lines_update_fused_submit(ctx, st, st_tri, &all, J.flags.data(), cap, J.k, J.cols.data(), 2 * opt->max_obs, st->sigma_pix * st->sigma_pix,
