@@ -1199,16 +1199,38 @@ int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p
   }
   // (the line detector's edge kernel, when the tracker feed asked for it: it equalises the raw image itself and so need not wait for
   // the pyramid — its maps reach the library's line worker two launches earlier, and the flow starts when it always did)
-  if (ctx->edges_hook) ctx->edges_hook(ctx, d_raw, p.w[0], p.h[0], d_hist);
-  {
-    ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
-    dim3 grid(cdiv(p.w[2], PD2_T), cdiv(p.h[2], PD2_T));
-    // the histogram is cleared for the next frame by the pyramid launch that follows, or here when there is none
-    hipLaunchKernelGGL(pyrdown2_kernel<true>, grid, dim3(256), 0, ctx->stream, d_raw, p.w[0], p.h[0], p.base + p.off[1], p.w[1], p.h[1],
-                       p.base + p.off[2], p.w[2], p.h[2], d_hist, p.base + p.off[0], p.levels > 3 ? 0 : 1);
+  struct Rest {
+    plv_ctx *ctx;
+    const uint8_t *d_raw;
+    const PyrDesc *p;
+    unsigned *d_hist;
+    bool done;
+    int rc;
+  } rest{ctx, d_raw, &p, d_hist, false, PLV_OK};
+  auto run_rest = [](void *a) -> int {
+    Rest &R = *(Rest *)a;
+    if (R.done) return R.rc;
+    R.done = true;
+    plv_ctx *ctx = R.ctx;
+    const PyrDesc &p = *R.p;
+    {
+      ProfScope ps(ctx->prof, "pyrdown2_kernel", ctx->stream);
+      dim3 grid(cdiv(p.w[2], PD2_T), cdiv(p.h[2], PD2_T));
+      // the histogram is cleared for the next frame by the pyramid launch that follows, or here when there is none
+      hipLaunchKernelGGL(pyrdown2_kernel<true>, grid, dim3(256), 0, ctx->stream, R.d_raw, p.w[0], p.h[0], p.base + p.off[1], p.w[1], p.h[1],
+                         p.base + p.off[2], p.w[2], p.h[2], R.d_hist, p.base + p.off[0], p.levels > 3 ? 0 : 1);
+    }
+    if (hipGetLastError() != hipSuccess) return R.rc = PLV_E_DEVICE;
+    return R.rc = launch_pyramid(ctx, p, 2, R.d_hist);
+  };
+  if (ctx->edges_hook) {
+    // (the hook launches its edge kernel, then calls after_edges — the pyramid goes onto the stream right behind that kernel — and
+    // only then spends its host time on the label kernels, the events and the line worker's job)
+    ctx->after_edges = run_rest, ctx->after_edges_arg = &rest;
+    ctx->edges_hook(ctx, d_raw, p.w[0], p.h[0], d_hist);
+    ctx->after_edges = nullptr, ctx->after_edges_arg = nullptr;
   }
-  PLV_HIP_CHECK(hipGetLastError());
-  return launch_pyramid(ctx, p, 2, d_hist);
+  return run_rest(&rest);
 }
 
 int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level, unsigned *clear_hist) {

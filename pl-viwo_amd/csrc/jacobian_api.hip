@@ -127,6 +127,7 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
   // few times; what a workgroup reuses it keeps in LDS)
   const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  // (an upload by a kernel of the ctx stream instead of the copy command was measured, alternating frame by frame: no difference)
   if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
   P.n_clones = N;
@@ -592,6 +593,7 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
   // few times; what a workgroup reuses it keeps in LDS)
   const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  // (an upload by a kernel of the ctx stream instead of the copy command was measured, alternating frame by frame: no difference)
   if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin_l.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = pinned_inputs ? (const char *)h : us->jin_l.as<char>();
   P.n_clones = N;

@@ -345,13 +345,17 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   }
   T->edge_fork = false;
   if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es, early ? T->early_hist : nullptr));
+  if (with_labels && !T->ccl_stream) {
+    PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->ccl_stream, hipStreamNonBlocking));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&T->canny_done, hipEventDisableTiming));
+    PLV_HIP_CHECK(hipEventCreateWithFlags(&T->labels_ready, hipEventDisableTiming));
+  }
+  if (with_labels) PLV_HIP_CHECK(hipEventRecord(T->canny_done, es));
+  if (launch_only && !T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
+  if (launch_only && maps_to_host) PLV_HIP_CHECK(hipEventRecord(T->edges_ready, es));  // (the two maps are the edge kernel's own stores)
+  // the image feed's remaining launches (the pyramid) go behind the edge kernel NOW: what follows here is host work
+  if (early && ctx->after_edges) TRY(ctx->after_edges(ctx->after_edges_arg));
   if (with_labels) {
-    if (!T->ccl_stream) {
-      PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->ccl_stream, hipStreamNonBlocking));
-      PLV_HIP_CHECK(hipEventCreateWithFlags(&T->canny_done, hipEventDisableTiming));
-      PLV_HIP_CHECK(hipEventCreateWithFlags(&T->labels_ready, hipEventDisableTiming));
-    }
-    PLV_HIP_CHECK(hipEventRecord(T->canny_done, es));
     PLV_HIP_CHECK(hipStreamWaitEvent(T->ccl_stream, T->canny_done, 0));
     TRY(launch_line_labels(ctx, w, h, b, T->ccl_stream));
     PLV_HIP_CHECK(hipEventRecord(T->labels_ready, T->ccl_stream));
@@ -395,8 +399,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
       PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (launch_only) {
-      if (!T->edges_ready) PLV_HIP_CHECK(hipEventCreateWithFlags(&T->edges_ready, hipEventDisableTiming));
-      PLV_HIP_CHECK(hipEventRecord(T->edges_ready, es));
+      if (!maps_to_host) PLV_HIP_CHECK(hipEventRecord(T->edges_ready, es));  // (behind the two copy commands above)
       T->pending_which = which;
       T->pending_fed = plv_front_fed_count(ctx) + (early ? 1 : 0);  // (early: the image becomes the current one when its feed returns)
       if (!T->worker.joinable()) T->worker = std::thread(line_worker, T);

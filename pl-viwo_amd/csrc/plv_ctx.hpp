@@ -450,6 +450,11 @@ struct plv_ctx {
   // kernel goes there (line_api.hip plv_line_edges_early); edges_hook_fired: it did, the feed must not launch the detection again
   void (*edges_hook)(plv_ctx *, const uint8_t *d_raw, int W, int H, const unsigned *d_hist) = nullptr;
   bool edges_hook_fired = false;
+  // set around the call of edges_hook: the rest of the image feed's launches (the pyramid).  The hook runs it right behind its edge
+  // kernel — in front of the label kernels, the events and the hand-over to the line worker, ~35 us of host work that used to sit
+  // between the edge kernel and the pyramid on the ctx stream (the flow started that much later).
+  int (*after_edges)(void *) = nullptr;
+  void *after_edges_arg = nullptr;
   // plv_decision_trace: the values behind every verdict of the point update stay on the device until plv_last_point_decisions asks
   bool decision_trace = false;
   plv::DevBuf d_tri_dbg, d_gate_dec, d_gate_dec_l;  // (_l: the line update's gate)
