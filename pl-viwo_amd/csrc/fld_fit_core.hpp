@@ -40,10 +40,16 @@ PLV_HD inline L3 cr3(double ax, double ay, double az, double bx, double by, doub
   return L3{ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
 }
 PLV_HD inline double dist_pl(double px, double py, L3 &l) {  // normalises l in place (as the reference does)
-  const double wv = sqrt(l.a * l.a + l.b * l.b);
-  l.a /= wv;
-  l.b /= wv;
-  l.c /= wv;
+  // (a line that went through here before has a^2 + b^2 within an ulp of 1: for 1 and for 1 + 2^-52 the correctly rounded square
+  // root is exactly 1 and the three divisions change nothing — the common case skips them, ~40 cycles of the ~80 a chain point
+  // costs; 1 - 2^-53 has the root 1 - 2^-53 and takes the divisions like any other value)
+  const double s2 = l.a * l.a + l.b * l.b;
+  if (!(s2 == 1.0 || s2 == 1.0 + 2.220446049250313e-16)) {
+    const double wv = sqrt(s2);
+    l.a /= wv;
+    l.b /= wv;
+    l.c /= wv;
+  }
   return l.a * px + l.b * py + l.c;
 }
 struct Fit {
