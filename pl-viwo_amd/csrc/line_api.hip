@@ -1384,6 +1384,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     db_scanned_early = true;
   };
   auto finish = [&](int rc) {
+    plv::HostPhase ph_fin("update_lines: finish (counts, point_used clean-up, hand-back closure)");
     res->n_returned = (int)unused.size();
     for (int l : lazy_back) res->n_returned += unused.find(pool[l].id) == unused.end() ? 1 : 0;
     const bool window_full = opt->window_full != 0;
@@ -1492,6 +1493,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
     sel.push_back(l);
   }
   res->n_msckf = (int)sel.size();
+  plv::frame_mark("@ line selection loop done");
   if (sel.empty()) {
     if (fused_ran) std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);
@@ -1505,7 +1507,9 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
   for (int q = 0; q < L; ++q) {
     const Cand &c = pool[sel[q]];
     int seen = 0;
-    for (size_t i = 0; i < c.tr.t.size(); ++i) {
+    // (behind a fused launch the loop only hands back views without bounding clones: none when every view counted as usable)
+    const bool nothing_to_do = fused_ran && valid_n[sel[q]] == (int)c.tr.t.size();
+    for (size_t i = 0; !nothing_to_do && i < c.tr.t.size(); ++i) {
       if (!has_bounding(c.tr.t[i] + dt)) {
         give_back(c, i);
         continue;
@@ -1572,6 +1576,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       if (gi < Fg) std::copy(gv.begin() + 3 * (size_t)gi, gv.begin() + 3 * (size_t)gi + 3, T->dec_vals.begin() + 3 * (size_t)q);
     }
   }
+  plv::frame_mark("@ line arrays of the selected done");
   for (int q = 0; q < L; ++q) {
     res->n_accepted += acc[q];
     if (accepted_out) accepted_out[q] = acc[q];
@@ -1579,8 +1584,7 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       const Cand &c = pool[sel[q]];
       // (every view usable and nothing of the line handed back earlier — the usual case: the copy the reference makes view by view
       // is the track itself, returned whole by the hand-back like the candidates the update never took)
-      bool whole = unused.find(c.id) == unused.end();
-      for (size_t i = 0; whole && i < c.tr.t.size(); ++i) whole = has_bounding(c.tr.t[i] + dt);
+      const bool whole = valid_n[sel[q]] == (int)c.tr.t.size() && unused.find(c.id) == unused.end();  // (valid_n: the views with bounding clones)
       if (whole) {
         lazy_back.push_back(sel[q]);
         continue;
