@@ -947,6 +947,7 @@ void form_line_pool(LineTracker *T, const PoolArgs &A, LinePool &R) {
   R.t_oldest = A.t_oldest, R.t_oldest2 = A.t_oldest2;
   const double dt = R.dt, t_oldest = R.t_oldest, t_oldest2 = R.t_oldest2;
   const PoolArgs *opt = &A;  // (t_prev_frame, state_time)
+  plv::HostPhase ph_scan("line pool: scan + take");
   {
     std::lock_guard<std::mutex> lk(T->mtx);
     R.db_size_before = (int)T->db.size();
@@ -966,6 +967,8 @@ void form_line_pool(LineTracker *T, const PoolArgs &A, LinePool &R) {
       R.pool.push_back(LineCand{id, std::move(node.mapped())});
     }
   }
+  ph_scan.stop();
+  plv::HostPhase ph_trim("line pool: trim + sort");
   R.n_pool = (int)R.pool.size();
   R.unused.reserve(R.pool.size());
   size_t kept_cands = 0;  // (candidates that stay are moved down once: erasing from the middle of the vector shifted the rest every time)
