@@ -39,3 +39,36 @@ def test_single_process_dry_run():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1
+
+
+def test_cpu_affinity_of_the_bench():
+    """bench.pin_to_device: the list parser, the cases in which nothing is pinned, and — where this machine's sysfs names NUMA node 0 —
+    a pin that stays inside the allowed set and is undone afterwards"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert bench._cpulist("") == []
+
+    class Pkg:
+        def __init__(self, node):
+            self.node = node
+
+        def device_numa_node(self, device):
+            return self.node
+
+    assert bench.pin_to_device(Pkg(0), 0, "none")["mode"] == "none"
+    assert bench.pin_to_device(Pkg(-1), 0, "ccx")["mode"] == "none"            # the device's node is unknown: nothing is touched
+    if not hasattr(os, "sched_getaffinity") or not os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        return
+    before = os.sched_getaffinity(0)
+    try:
+        for mode, rank in (("node", None), ("ccx", None), ("ccx", 1)):
+            info = bench.pin_to_device(Pkg(0), 0, mode, rank)
+            now = os.sched_getaffinity(0)
+            assert now <= before and len(now) >= 1
+            if info["mode"] != "none":
+                assert info["cpus"] == len(now)
+            os.sched_setaffinity(0, before)
+    finally:
+        os.sched_setaffinity(0, before)
