@@ -108,6 +108,38 @@ def test_lk_large_motion_tile_restage(pkg, fo, win):
     c.close()
 
 
+@pytest.mark.parametrize("w,h,win", [(752, 480, 15), (97, 65, 15), (160, 120, 9)])
+def test_lk_border_sweep_bit_exact(pkg, fo, w, h, win):
+    """The flow next to the image border (round 5's lean iteration tests the window position against the search tile's usable range
+    clipped to the image's, and tells "left the image" from "needs another tile" only behind that test): points in a band along all
+    four borders, initial guesses pushed towards and across the border, a shift that carries windows out of the image during the
+    iterations, tiles that straddle the border or are larger than a pyramid level.  Positions, status and iteration counts are the
+    oracle's, bit for bit."""
+    canvas = synth.texture_canvas(w, h, seed=21)
+    f0 = synth.render_frame(canvas, w, h)
+    f1 = synth.render_frame(canvas, w, h, tx=6.5, ty=-5.25, rot_deg=0.4)
+    c = _ctx(pkg, w, h, histogram_method=0, win_size=win)
+    c.feed_image(f0)
+    c.feed_image(f1)
+    p0, p1 = fo.pyramid(f0, win=win), fo.pyramid(f1, win=win)
+    rng = np.random.default_rng(5)
+    pts, guess = [], []
+    for k in range(240):
+        side, d, s = k % 4, rng.uniform(-3.0, 22.0), rng.uniform(0.0, 1.0)
+        x, y = [(d, s * h), (w - 1 - d, s * h), (s * w, d), (s * w, h - 1 - d)][side]
+        pts.append((x, y))
+        push = rng.uniform(-26.0, 26.0, size=2)
+        guess.append((x + push[0], y + push[1]))
+    pts, guess = np.float32(pts), np.float32(guess)
+    a1, ast, ait = fo.lk_track(p0, p1, pts, guess, win=win)
+    b1, bst, bit = c.lk_track(pts, guess)
+    assert np.array_equal(ast, bst), np.flatnonzero(ast != bst)[:10]
+    assert int(bit.sum()) == ait
+    assert np.array_equal(a1, b1), f"max |diff| {np.max(np.abs(a1 - b1))}"
+    assert 0 < int(bst.sum()) < len(pts)      # (both outcomes occur: tracked and left the image)
+    c.close()
+
+
 def test_undistort_bit_exact(pkg, fo):
     c = _ctx(pkg, 752, 480)
     rng = np.random.default_rng(0)
