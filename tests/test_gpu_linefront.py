@@ -80,6 +80,23 @@ def test_point_line_logic_parity(ctx, lo, frames):
     m1 = ctx.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last, a["rel_ptr"], rid_last)
     m2 = lo.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last, a["rel_ptr"], rid_last)
     assert np.array_equal(m1, m2) and (m1 >= 0).sum() > 2
+    # several lines of the last frame share points with one new line (two perturbed copies of the kept lines, one of them far away, ids
+    # kept / replaced independently): the reference's walk lets a LATER line of the last frame overwrite an earlier match, and accepts a
+    # single shared point only with the midpoint test — the indexed matching of round 5 has to arrive at the same line
+    nk = len(a["kept"])
+    last2 = np.vstack([last, lines[a["kept"]] + rng.normal(0, 8.0, (nk, 4)).astype(np.float32), last + np.float32(40.0)])
+    n_rel = np.diff(a["rel_ptr"])
+    rptr2 = np.concatenate([[0], np.cumsum(np.tile(n_rel, 3))]).astype(a["rel_ptr"].dtype)
+    rid2 = np.concatenate([np.where(rng.uniform(size=len(a["rel_id"])) < p_keep, a["rel_id"], a["rel_id"] + 7000 * (q + 1))
+                           for q, p_keep in enumerate((0.6, 0.5, 0.25))]).astype(a["rel_id"].dtype)
+    for q in range(3):  # (the relations of a line are a std::map's keys: ascending)
+        for l in range(nk):
+            lo_i, hi_i = rptr2[q * nk + l], rptr2[q * nk + l + 1]
+            rid2[lo_i:hi_i] = np.sort(rid2[lo_i:hi_i])
+    m3 = ctx.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last2, rptr2, rid2)
+    m4 = lo.line_match(lines[a["kept"]], a["rel_ptr"], a["rel_id"], last2, rptr2, rid2)
+    assert np.array_equal(m3, m4)
+    assert len(set((m3[m3 >= 0] // nk).tolist())) >= 2     # (matches in more than one of the copies: the later line wins where both share points)
     vps = ctx.vanishing_points(synth._exp_so3(np.array([0.3, -0.2, 0.1])), synth.EUROC_K8)
     assert np.array_equal(vps, lo.vanishing_points(synth._exp_so3(np.array([0.3, -0.2, 0.1])), synth.EUROC_K8))
     cls = [ctx.line_classification(l, vps) for l in lines]
