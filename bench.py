@@ -150,6 +150,8 @@ def pin_to_device(pkg, device, mode, rank_on_node=None):
                 else:
                     k = rank_on_node % len(groups)
                 chosen = groups[k]
+                if len(chosen) < 10 and len(groups) > 1:   # (no SMT: the caller + worker + seven helpers need more than one complex's cores)
+                    chosen = chosen + groups[k + 1 if k + 1 < len(groups) else k - 1]
                 info.update(mode="ccx", cpus=len(chosen), first_cpu=min(chosen))
         os.sched_setaffinity(0, set(chosen))
         return info
