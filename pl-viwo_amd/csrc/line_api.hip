@@ -357,7 +357,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   if (early && ctx->after_edges) TRY(ctx->after_edges(ctx->after_edges_arg));
   if (with_labels) {
     PLV_HIP_CHECK(hipStreamWaitEvent(T->ccl_stream, T->canny_done, 0));
-    TRY(launch_line_labels(ctx, w, h, b, T->ccl_stream));
+    TRY(launch_line_labels(ctx, w, h, b, T->ccl_stream, fp.length_threshold));
     PLV_HIP_CHECK(hipEventRecord(T->labels_ready, T->ccl_stream));
   }
   const float thr2 = ctx->cfg.line_min_length_px * ctx->cfg.line_min_length_px;

@@ -205,7 +205,10 @@ __global__ void __launch_bounds__(256) ccl_roots_kernel(int *__restrict__ L, int
 }
 // part of a component: 1 + its rank by size when it is one of the CCL_BIG largest (ties: smaller root first), else
 // 1 + CCL_BIG + hash(root) % CCL_HASHED.  One workgroup; written into cnt[root] as -(part) (the counts are no longer needed).
-__global__ void __launch_bounds__(256) ccl_assign_kernel(int *__restrict__ cnt, const int *__restrict__ roots, const int *__restrict__ n_roots) {
+// min_px: a component with fewer pixels cannot hold a chain the detector keeps (a chain's pixels are distinct pixels of ONE component and
+// a kept chain has length_threshold + 1 of them or more), and what its short chains consume no other component can reach: such a
+// component gets part 255 — no part's — and the host stage never walks it (most components are that small: a fifth of the edge pixels)
+__global__ void __launch_bounds__(256) ccl_assign_kernel(int *__restrict__ cnt, const int *__restrict__ roots, const int *__restrict__ n_roots, int min_px) {
   // only a component of 64 pixels or more can matter for the balance (most have a handful): those are collected into a short list
   // and ranked among themselves; when fewer than CCL_BIG are that large the rest of the own parts stay empty
   __shared__ int lsz[512], lrt[512];
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256) ccl_assign_kernel(int *__restrict__ cnt, 
       const int at = atomicAdd(&n_large, 1);
       if (at < 512) lsz[at] = c, lrt[at] = root, large = true;
     }
-    if (!large) cnt[root] = -(1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
+    if (!large) cnt[root] = c < min_px ? -255 : -(1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
   }
   __syncthreads();
   const int m = min(n_large, 512);
@@ -232,14 +235,14 @@ __global__ void __launch_bounds__(256) ccl_assign_kernel(int *__restrict__ cnt, 
     cnt[root] = -(rank < CCL_BIG ? 1 + rank : 1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
   }
 }
-__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, const int *__restrict__ cnt, uint8_t *__restrict__ lab_out) {
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, const int *__restrict__ cnt, uint8_t *__restrict__ lab_out, int min_px) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint8_t v = 0;
   const int r = L[i];
   if (r >= 0) {
     const int c = cnt[r];  // -(part) for a listed root; a root beyond the list keeps its positive count
-    v = (uint8_t)(c < 0 ? -c : 1 + CCL_BIG + (int)(((unsigned)r * 2654435761u >> 8) % (unsigned)CCL_HASHED));
+    v = (uint8_t)(c < 0 ? -c : (c < min_px ? 255 : 1 + CCL_BIG + (int)(((unsigned)r * 2654435761u >> 8) % (unsigned)CCL_HASHED)));
   }
   lab_out[i] = v;
 }
@@ -403,8 +406,9 @@ int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const Fl
 
 // stage 1b: component labels of the edge map (canny_kernel left the tile-local pass in b.lab_work) as parts 1 .. kLineParts per
 // edge pixel in b.lab_out (host-visible), on stream st
-int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st) {
+int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st, int length_threshold) {
   const int n = w * h;
+  const int min_px = length_threshold + 1;  // (fld_walk: a chain is kept when it has length_threshold + 1 points or more)
   {
     ProfScope ps(ctx->prof, "ccl_boundary_kernel", st);
     hipLaunchKernelGGL(ccl_boundary_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, w, h, b.lab_roots + CCL_ROOT_CAP);
@@ -415,11 +419,11 @@ int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st
   }
   {
     ProfScope ps(ctx->prof, "ccl_assign_kernel", st);
-    hipLaunchKernelGGL(ccl_assign_kernel, dim3(1), dim3(256), 0, st, b.lab_cnt, b.lab_roots, b.lab_roots + CCL_ROOT_CAP);
+    hipLaunchKernelGGL(ccl_assign_kernel, dim3(1), dim3(256), 0, st, b.lab_cnt, b.lab_roots, b.lab_roots + CCL_ROOT_CAP, min_px);
   }
   {
     ProfScope ps(ctx->prof, "ccl_flatten_kernel", st);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_out);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_out, min_px);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

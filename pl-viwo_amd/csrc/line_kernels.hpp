@@ -31,7 +31,7 @@ struct FldBuffers {
 // d_hist: d_img is the RAW image and d_hist its histogram (the kernel equalises on the fly: canny_kernel); null: d_img is the equalised image
 int launch_line_edges(plv_ctx *ctx, const uint8_t *d_img, int W, int H, const FldParams &fp, FldBuffers &b, hipStream_t st = nullptr /* default: the ctx stream */,
                       const unsigned *d_hist = nullptr);
-int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st);
+int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st, int length_threshold);
 int line_label_parts();         // parts launch_line_labels writes (the largest components first: 1 .. 8, then 8 hashed ones)
 size_t line_label_roots_bytes();
 int launch_line_walk(plv_ctx *ctx, int w, int h, const FldParams &fp, FldBuffers &b);
