@@ -132,6 +132,8 @@ struct LineTracker {
   int pending_which = -1, pending_fed = -1;
   bool defer_finish = false;        // plv_camera_try_update: the line update leaves its database hand-back (cleanup_lines) behind ...
   std::function<void()> deferred;   // ... to run before anything else reads the tracker: in the next frame's wait for the flow (ltr())
+  std::atomic<int> defer_state{0};  // 0: not posted; 1: `deferred` is the worker's third kind of job (round 5: it runs there while the
+                                    // caller finishes the frame); 2: done.  Every entry point joins it like the feed (ltr())
   // plv_camera_get_line_features: the state the line pool is triangulated on (the reference runs get_line_features BEFORE the point
   // update's correction is applied, UpdaterCamera.cpp:148-152), kept until the next plv_camera_update_lines
   struct TriState {
@@ -183,13 +185,25 @@ void discard_line_pool(LineTracker *T);
 int (*g_feed_impl)(plv_ctx *, LineTracker *, double, const double *, int, const float *, const uint64_t *, const double *) = nullptr;
 void line_worker(LineTracker *T) {
   for (;;) {
-    bool do_detect = false, do_feed = false;
+    bool do_detect = false, do_feed = false, do_deferred = false;
     {
       std::unique_lock<std::mutex> lk(T->jm);
-      wait_polling(lk, T->jcv, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1; });
+      wait_polling(lk, T->jcv, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1 || T->defer_state == 1; });
       if (T->job_state == -1) return;
       do_detect = T->job_state == 1;
       do_feed = !do_detect && T->feed_state == 1;
+      do_deferred = !do_detect && !do_feed && T->defer_state == 1;
+    }
+    if (do_deferred) {  // the line update's database hand-back (plv_camera_update_lines: finish), off the caller's thread
+      std::function<void()> f;
+      f.swap(T->deferred);
+      if (f) f();
+      {
+        std::lock_guard<std::mutex> lk(T->jm);
+        T->defer_state = 2;
+      }
+      T->jcv.notify_all();
+      continue;
     }
     if (do_feed) {
       LineTracker::FeedJob &F = T->feed;
@@ -278,6 +292,10 @@ LineTracker *ltr(plv_ctx *ctx, bool run_deferred) {
     T->feed_state = 0;
     if (plv::host_phases().on)
       plv::host_phases().add("line feed join: time since the post", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T->feed_posted).count());
+  }
+  if (T->defer_state != 0) {  // a hand-back posted to the worker: done before anything reads the tracker
+    wait_polling(lk, T->jcv, [&] { return T->defer_state == 2; });
+    T->defer_state = 0;
   }
   lk.unlock();
   if (run_deferred && T->deferred) {  // (only the thread that owns the ctx gets here: the worker reaches the tracker directly)
@@ -471,11 +489,10 @@ void plv_line_tracker_destroy(plv_ctx *ctx) {
   auto it = g_lt.find(ctx);
   if (it != g_lt.end()) {
     LineTracker *T = it->second;
-    T->deferred = nullptr;
     if (T->worker.joinable()) {
       {
         std::unique_lock<std::mutex> lk(T->jm);
-        T->jcv.wait(lk, [&] { return T->job_state != 1 && T->feed_state != 1; });  // let posted jobs finish: they read what is released below
+        T->jcv.wait(lk, [&] { return T->job_state != 1 && T->feed_state != 1 && T->defer_state != 1; });  // let posted jobs finish: they read what is released below
         T->job_state = -1;
       }
       T->jcv.notify_all();
@@ -1431,6 +1448,13 @@ int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_up
       auto used_up = std::make_shared<std::vector<Cand>>(std::move(pool));
       auto lazy = std::make_shared<std::vector<int>>(std::move(lazy_back));
       T->deferred = [hand_back, held, used_up, lazy]() { hand_back(*held, used_up.get(), lazy.get()); };
+      if (T->worker.joinable()) {  // the worker is idle (and still polling) at this point of the frame: it starts at once
+        {
+          std::lock_guard<std::mutex> lk(T->jm);
+          T->defer_state = 1;
+        }
+        T->jcv.notify_all();
+      }
     } else {
       hand_back(unused, &pool, &lazy_back);
       lazy_back.clear();
