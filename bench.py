@@ -141,10 +141,16 @@ def pin_to_device(pkg, device, mode, rank_on_node=None):
                             out[int(f[0][3:])] = (sum(v) - v[3] - v[4], sum(v))
                     return out
                 if rank_on_node is None:
+                    # three 0.1 s samples; a complex is as busy as its busiest sample (other tenants' load comes in bursts, and a
+                    # burst on the pinned cores costs whole time slices: frames of several ms)
+                    load = [0.0] * len(groups)
                     a = busy_snapshot()
-                    time.sleep(0.1)
-                    b = busy_snapshot()
-                    load = [sum(b[c][0] - a[c][0] for c in g) / max(1, sum(b[c][1] - a[c][1] for c in g)) for g in groups]
+                    for _ in range(3):
+                        time.sleep(0.1)
+                        b = busy_snapshot()
+                        for gi, g in enumerate(groups):
+                            load[gi] = max(load[gi], sum(b[c][0] - a[c][0] for c in g) / max(1, sum(b[c][1] - a[c][1] for c in g)))
+                        a = b
                     k = int(np.argmin(load))
                     info["ccx_busy_fraction"] = round(float(load[k]), 3)
                 else:
