@@ -185,8 +185,11 @@ def load_options(wl):
 class Player:
     """run_bag's message loop, split at the camera messages."""
 
-    def __init__(self, stream, system, staged):
-        self.s, self.sys, self.k, self.staged, self.slot = stream, system, 0, staged, 0
+    def __init__(self, stream, system, staged, pinned=False):
+        # staged: the image is put into HBM between the steps (plv_image_stage); pinned (with staged off): the image is written into
+        # one of the library's page-locked blocks between the steps (plv_image_buffer: where the ROS callback's copy of the message
+        # would land) and crosses PCIe inside the step; neither: any host buffer (the call copies it into such a block first)
+        self.s, self.sys, self.k, self.staged, self.slot, self.pinned, self.pin_view = stream, system, 0, staged, 0, pinned, None
 
     def next_frame(self):
         """feeds IMU / wheel messages up to the next camera message (untimed), stages its image; returns (t, frame index) or None"""
@@ -205,15 +208,22 @@ class Player:
                     self.slot ^= 1
                     sm.ctx.image_stage(self.slot, s["imgs"][i])
                     sm.ctx.synchronize()
+                elif self.pinned:
+                    self.slot ^= 1
+                    self.pin_view = sm.ctx.image_buffer(self.slot)
+                    np.copyto(self.pin_view, s["imgs"][i])
                 return t, i
         return None
+
+    def image(self, i):
+        return self.pin_view if (self.pinned and not self.staged) else self.s["imgs"][i]
 
     def camera(self, t, i):
         """the whole frame through the Python driver (prologue, warm-up, the CPU frame, `ms_per_step_python`)"""
         if self.staged:
             self.sys.feed_measurement_camera(t, None, staged_slot=self.slot)
         else:
-            self.sys.feed_measurement_camera(t, self.s["imgs"][i])
+            self.sys.feed_measurement_camera(t, self.image(i))
         if hasattr(self.sys.ctx, "synchronize"):
             self.sys.ctx.synchronize()     # ctx stream + detection side stream + line worker
 
@@ -223,7 +233,7 @@ class Player:
         wheel work between the frames), the timed region is plv_camera_frame + plv_ctx_synchronize and nothing else (two ctypes calls
         on prepared arguments), the results are counted afterwards.  Returns the step's seconds."""
         sm = self.sys
-        prep = sm.camera_prepare(t, None if self.staged else self.s["imgs"][i], None, self.slot if self.staged else None)
+        prep = sm.camera_prepare(t, None if self.staged else self.image(i), None, self.slot if self.staged else None)
         if prep is None:
             t0 = time.perf_counter()
             self.camera(t, i)
@@ -427,7 +437,10 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=40.0, help="upper bound of the CPU baseline's wall time per pass")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the second timed segment (host images)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the timed segments with host images")
+    ap.add_argument("--images", choices=("resident", "host", "pinned"), default="resident",
+                    help="measurement aid: where the FIRST timed segment's images are when a step starts (resident = in HBM, the contract's "
+                         "`value`; host = any host buffer; pinned = the library's page-locked block, plv_image_buffer)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short segments with non-default library settings (config.variants)")
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
@@ -435,6 +448,8 @@ def main():
                     "plv_update_compression_mode settings (0, 1) frame by frame and stderr gets the mean step time of each (drift-free A/B)")
     ap.add_argument("--alternate-spin", default=None, help="measurement aid: e.g. 300,0 — plv_line_worker_config polling budgets (us) cycled frame by frame")
     ap.add_argument("--alternate-fit", default=None, help="measurement aid: e.g. 2,0 — segment-fitter thread counts cycled frame by frame")
+    ap.add_argument("--alternate-images", default=None, help="measurement aid: e.g. resident,pinned,host — the hand-over of the image cycled frame by "
+                    "frame in the first timed segment, mean step time of each on stderr")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
                     "mean step time of each on stderr")
     ap.add_argument("--pin", choices=("none", "node", "ccx"), default=os.environ.get("PLV_BENCH_PIN", "ccx"),
@@ -453,7 +468,7 @@ def main():
     stream = None
     if not args.dry_run:
         nprof = max(10, min(40, args.steps))
-        seg2 = 0 if args.no_pcie else args.steps
+        seg2 = 0 if args.no_pcie else 2 * args.steps
         nvar = 0 if args.no_variants else max(10, min(40, args.steps))
         npy = max(10, min(40, args.steps))      # (the segment timed through the Python driver: config.ms_per_step_python)
         n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + npy + nprof + 6 * nvar + 8 * LEAD_IN   # (three alternating variants of 2 * nvar frames)
@@ -506,6 +521,7 @@ def main():
     alt_knobs = [int(m) for m in args.alternate_knobs.split(",")] if args.alternate_knobs else None
     alt_spin = [int(m) for m in args.alternate_spin.split(",")] if args.alternate_spin else None
     alt_fit = [int(m) for m in args.alternate_fit.split(",")] if args.alternate_fit else None
+    alt_img = args.alternate_images.split(",") if args.alternate_images else None
 
     def timed_segment(n_steps, hook=None, through_python=False):
         per_frame = {"kept": [], "tracked": []}
@@ -537,6 +553,8 @@ def main():
         chain0, routes0 = pkg.chain_count(), pkg.route_counts()
         last_stats = dict(sm.stats)
         for f in range(n_steps):
+            if alt_img:
+                pl.staged, pl.pinned = alt_img[f % len(alt_img)] == "resident", alt_img[f % len(alt_img)] == "pinned"
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if nf is None:
                 raise RuntimeError(f"bench: the rendered stream ended {n_steps - f} frames before a timed segment did (n_gpu_frames undersized)")
@@ -620,6 +638,10 @@ def main():
                 v = per[j::len(alt_spin)]
                 print(f"[alternate] poll {m} us: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  max {np.max(v) * 1e3:.1f}  "
                       f"frames above 1 ms: {int(np.sum(np.asarray(v) > 1.0))}  over {len(v)} frames", file=sys.stderr)
+        if alt_img:
+            for j, m in enumerate(alt_img):
+                v = per[j::len(alt_img)]
+                print(f"[alternate] images {m}: mean {np.mean(v) * 1e3:.1f} us  p50 {pct(v, 50) * 1e3:.1f}  p99 {pct(v, 99) * 1e3:.1f}  over {len(v)} frames", file=sys.stderr)
         if alt_knobs:
             pkg.debug_knobs(0)
             for j, m in enumerate(alt_knobs):
@@ -648,7 +670,9 @@ def main():
         pl.camera(*pl.next_frame())
     if not sm.state.initialized or len(sm.state.clones) < wl["hz"] - 1:
         raise RuntimeError("the filter did not reach a full window during the prologue")
+    pl.staged, pl.pinned = args.images == "resident", args.images == "pinned"
     seg = timed_segment(args.steps)                                   # (1) images resident in HBM -> `value`
+    pl.staged, pl.pinned = True, False
     if os.environ.get("PLV_BENCH_FINGERPRINT"):     # (determinism checks: the filter's state after the timed segment, to the last bit)
         print("[fingerprint] p = %r  q = %r  trace(P) = %r  routes = %r" % (tuple(float(x) for x in sm.state.imu.p), tuple(float(x) for x in sm.state.imu.q),
                                                                           float(np.trace(ctx.cov_download(sm.state.n))), pkg.route_counts()), file=sys.stderr)
@@ -656,11 +680,13 @@ def main():
         print("[main segment] ms per step %.4f  p50 %.4f" % (seg["elapsed"] / args.steps * 1e3, float(np.median(seg["per"]))), file=sys.stderr)
         sm.close()
         sys.exit(0)
-    seg_pcie = None
+    seg_pcie = seg_pin = None
     if not args.no_pcie:
         pl.staged = False
-        seg_pcie = timed_segment(args.steps)                          # (2) host images: the PCIe copy inside the step
-        pl.staged = True
+        seg_pcie = timed_segment(args.steps)                          # (2) host images: the host copy + the PCIe transfer inside the step
+        pl.pinned = True
+        seg_pin = timed_segment(args.steps)                           # (2b) the image in the library's page-locked block: the PCIe transfer inside the step
+        pl.staged, pl.pinned = True, False
     seg_py = timed_segment(npy, through_python=True)                  # (3) as (1), the Python driver's marshalling inside the step
     elapsed, per, per_frame, cnt, stats, split = (seg[k] for k in ("elapsed", "per", "per_frame", "cnt", "stats", "split"))
     n_state = sm.state.n
@@ -823,6 +849,10 @@ def main():
             "ms_per_step_python": seg_py["elapsed"] / npy * 1e3,
             "ms_per_step_pcie_inclusive": None if seg_pcie is None else seg_pcie["elapsed"] / args.steps * 1e3,
             "value_pcie_inclusive": None if seg_pcie is None else args.steps * world / seg_pcie["elapsed"],
+            # the image in the library's page-locked block when the step starts (plv_image_buffer: the adapters' route): the transfer is inside
+            "ms_per_step_pinned_host_image": None if seg_pin is None else seg_pin["elapsed"] / args.steps * 1e3,
+            "value_pinned_host_image": None if seg_pin is None else args.steps * world / seg_pin["elapsed"],
+            "vs_cpu_all_cores_pinned_host_image": (None if (cpu is None or seg_pin is None) else cpu["ms_per_frame_all_cores"] / (seg_pin["elapsed"] / args.steps * 1e3)),
             "vs_cpu_1_thread": vs.get("speedup_resident"), "vs_cpu_all_cores": vs.get("speedup_vs_cpu_all_cores"),
             "vs_cpu_all_cores_pcie_inclusive": (None if (cpu is None or seg_pcie is None) else cpu["ms_per_frame_all_cores"] / (seg_pcie["elapsed"] / args.steps * 1e3)),
             "cpu_all_cores_threads": None if cpu is None else cpu["cores_all_cores"],
@@ -846,6 +876,7 @@ def main():
                                 "ms_per_step_python = the same step with the Python driver's marshalling inside it, over the next frames",
                 "ms_per_step_python": round(seg_py["elapsed"] / npy * 1e3, 4),
                 "ms_per_step_pcie_inclusive": None if seg_pcie is None else round(seg_pcie["elapsed"] / args.steps * 1e3, 4),
+                "ms_per_step_pinned_host_image": None if seg_pin is None else round(seg_pin["elapsed"] / args.steps * 1e3, 4),
                 "host_threads": {"caller": 1, "library_line_worker": 1 if wl["lines"] else 0,
                                  "library_segment_fitters": (min(fit_threads, 2 if (wl["w"] // 2) * (wl["h"] // 2) >= 60000 else 1) if wl["lines"] else 0),
                                  "library_segment_fitters_configured_maximum": fit_threads if wl["lines"] else 0, "poll_before_blocking_us": spin_us,
@@ -864,8 +895,11 @@ def main():
                 "host_cpu": seg.get("host_cpu"),
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "pcie_inclusive": None if seg_pcie is None else {
-                    "what": "second timed segment, the next frames of the stream: the image is a host buffer (plv_tracker_feed), its "
-                            f"{wl['w'] * wl['h'] // 1024} KB PCIe copy inside the step",
+                    "what": "second timed segment, the next frames of the stream: the image is any host buffer (plv_tracker_feed), its "
+                            f"{wl['w'] * wl['h'] // 1024} KB host copy into the library's page-locked block and the PCIe transfer inside the step; "
+                            "pinned_host_image: third segment, the image already in that block (plv_image_buffer), the transfer inside the step",
+                    "pinned_host_image": None if seg_pin is None else {"ms_per_step": seg_pin["elapsed"] / args.steps * 1e3,
+                        "latency_ms": {"mean": float(np.mean(seg_pin["per"])), "p50": pct(seg_pin["per"], 50), "p99": pct(seg_pin["per"], 99)}},
                     "value": args.steps * world / seg_pcie["elapsed"], "ms_per_step": seg_pcie["elapsed"] / args.steps * 1e3,
                     "latency_ms": {"mean": float(np.mean(seg_pcie["per"])), "p50": pct(seg_pcie["per"], 50), "p99": pct(seg_pcie["per"], 99)}},
                 "vs_cpu": vs,

@@ -243,6 +243,14 @@ enum { PLV_PYR_CUR = 0, PLV_PYR_LAST = 1 };
 int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride);
 int plv_image_stage(plv_ctx *ctx, int slot, const uint8_t *img, int stride);
 int plv_feed_staged(plv_ctx *ctx, int slot);
+/* A page-locked host block of the library (index 0..3, width x height bytes, packed rows: *stride = width) for the caller to
+ * produce the next image in — the target of the copy the reference's ROS callback makes anyway (cv_bridge's clone() of the
+ * message: `cv::Mat(h, w, CV_8UC1, ptr)`) or of a camera driver's DMA.  plv_feed_image / plv_tracker_feed / plv_camera_frame
+ * recognise an `img` that points at such a block and read it from where it lies (their first kernel brings the pixels across
+ * PCIe: no host copy, no copy command); any other `img` is first copied into a block like these by the call.  A block must not
+ * be overwritten before the call it was handed to has returned.  REF: the CameraData the caller builds, ROSSubscriber /
+ * run_bag -> UpdaterCamera::feed_measurement (UpdaterCamera.cpp:77). */
+int plv_image_buffer(plv_ctx *ctx, int index, uint8_t **ptr, int *stride);
 int plv_pyramid_levels(plv_ctx *ctx, int which);
 /* level geometry and (if out != NULL, w*h bytes, packed) pixels of one pyramid level */
 int plv_pyramid_download(plv_ctx *ctx, int which, int level, int *w, int *h, uint8_t *out);

@@ -101,6 +101,7 @@ def load_library():
         "plv_feed_image": (C.c_int, [vp, u8p, C.c_int]),
         "plv_image_stage": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
         "plv_feed_staged": (C.c_int, [vp, C.c_int]),
+        "plv_image_buffer": (C.c_int, [vp, C.c_int, C.POINTER(u8p), ip]),
         "plv_pyramid_levels": (C.c_int, [vp, C.c_int]),
         "plv_pyramid_download": (C.c_int, [vp, C.c_int, C.c_int, ip, ip, u8p]),
         "plv_lk_track": (C.c_int, [vp, C.c_int, fp, fp, u8p, ip]),
@@ -935,6 +936,14 @@ class Context:
 
     def feed_staged(self, slot):
         self._chk(self.lib.plv_feed_staged(self.h, slot))
+
+    def image_buffer(self, index):
+        """numpy view (height x width, uint8) of the library's page-locked image block `index` (plv_image_buffer): an image written
+        into it is read by the frame's first kernel from where it lies (no host copy inside the call)"""
+        ptr, stride = C.POINTER(C.c_uint8)(), C.c_int()
+        self._chk(self.lib.plv_image_buffer(self.h, index, C.byref(ptr), C.byref(stride)))
+        buf = (C.c_uint8 * (self.cfg.height * stride.value)).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.cfg.height, stride.value)[:, :self.cfg.width]
 
     def pyramid_levels(self, which=0):
         return self.lib.plv_pyramid_levels(self.h, which)

@@ -42,7 +42,7 @@ struct FrontState {
   DevBuf pts0, pts1, n0, n1, status, iters, mask, counts, info, io, models;
   DevBuf det_in, det_out, det_mask, subpix_tab, det_cand, det_cand_n;  // detection staging
   PinBuf det_pin;
-  PinBuf img_pin[2];       // host images on their way to the device (plv_feed_image_enqueue): the caller's buffer is free at return
+  PinBuf img_pin[6];       // host images on their way to the device (plv_feed_image_enqueue): the caller's buffer is free at return
   int img_pin_next = 0;
   DetJob det_pending;
   hipStream_t det_stream = nullptr;
@@ -139,21 +139,24 @@ int sync(plv_ctx *ctx) {
 }
 
 // equalize + pyramid of the packed device image d_img into the next "current" pyramid
-int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img) {
+// h_src != null: d_img is still empty and the image sits in pinned host memory at h_src (the first kernel that reads it brings it in)
+int feed_device(plv_ctx *ctx, FrontState *s, const uint8_t *d_img, const uint8_t *h_src = nullptr) {
   plv::HostPhase ph("feed image (enqueue hist + pyramid)");
   const int next = s->fed == 0 ? s->cur : 1 - s->cur;
   PyrDesc &p = s->pyr[next];
   const int npix = s->W * s->H;
   switch (ctx->cfg.histogram_method) {
     case PLV_HIST_HISTOGRAM:  // (the equalisation rides on the first pyramid launch)
-      TRY(launch_equalize_pyramid(ctx, d_img, p, s->hist.as<unsigned>()));
+      TRY(launch_equalize_pyramid(ctx, d_img, p, s->hist.as<unsigned>(), h_src));
       s->cur = next;
       s->fed++;
       return PLV_OK;
     case PLV_HIST_NONE:
+      if (h_src) PLV_HIP_CHECK(plv::memcpy_async((void *)d_img, h_src, (size_t)npix, hipMemcpyHostToDevice, ctx->stream));
       PLV_HIP_CHECK(plv::memcpy_async(p.base + p.off[0], d_img, (size_t)npix, hipMemcpyDeviceToDevice, ctx->stream));
       break;
     case PLV_HIST_CLAHE:  // REF: TrackKLT.cpp:60-64 — clip 10.0, 8x8 tiles
+      if (h_src) PLV_HIP_CHECK(plv::memcpy_async((void *)d_img, h_src, (size_t)npix, hipMemcpyHostToDevice, ctx->stream));
       TRY(s->clahe_lut.reserve(64 * 256));
       TRY(launch_clahe(ctx, d_img, p.base + p.off[0], s->W, s->H, 10.0, 8, s->clahe_lut.as<uint8_t>()));
       break;
@@ -188,8 +191,7 @@ void plv_frontend_destroy(plv_ctx *ctx) {
   if (s->det_done) (void)hipEventDestroy(s->det_done);
   if (s->match_done) (void)hipEventDestroy(s->match_done);
   if (s->det_stream) (void)hipStreamDestroy(s->det_stream);
-  s->img_pin[0].release();
-  s->img_pin[1].release();
+  for (auto &b : s->img_pin) b.release();
   DevBuf *bufs[] = {&s->pyr_mem[0], &s->pyr_mem[1], &s->raw, &s->hist, &s->clahe_lut, &s->ds_src, &s->ds_dst, &s->pts0, &s->pts1, &s->n0, &s->n1,
                     &s->status, &s->iters, &s->mask, &s->counts, &s->info, &s->io, &s->models, &s->det_in, &s->det_out,
                     &s->det_mask, &s->subpix_tab, &s->det_cand, &s->det_cand_n};
@@ -212,19 +214,40 @@ int plv_feed_image_enqueue(plv_ctx *ctx, const uint8_t *img, int stride) {
     set_last_error("front-end: null image or stride %d < width %d", stride, s->W);
     return PLV_E_BADARG;
   }
-  plv::HostPhase ph("feed image: host copy into the pinned block + enqueue");
-  PinBuf &pin = s->img_pin[s->img_pin_next];
-  s->img_pin_next ^= 1;
   const size_t bytes = (size_t)s->W * s->H;
-  TRY(pin.reserve(bytes));
-  if (stride == s->W) {
-    memcpy(pin.p, img, bytes);
-  } else {
-    for (int y = 0; y < s->H; ++y) memcpy(pin.as<uint8_t>() + (size_t)y * s->W, img + (size_t)y * stride, s->W);
+  // an image the caller wrote straight into one of the library's pinned blocks (plv_image_buffer): nothing to copy on the host
+  const uint8_t *h_src = nullptr;
+  if (stride == s->W)
+    for (auto &b : s->img_pin)
+      if (b.p && img >= b.as<uint8_t>() && img + bytes <= b.as<uint8_t>() + b.cap) h_src = img;
+  if (!h_src) {
+    plv::HostPhase ph("feed image: host copy into the pinned block");
+    PinBuf &pin = s->img_pin[s->img_pin_next];
+    s->img_pin_next ^= 1;
+    TRY(pin.reserve(bytes));
+    if (stride == s->W) {
+      memcpy(pin.p, img, bytes);
+    } else {
+      for (int y = 0; y < s->H; ++y) memcpy(pin.as<uint8_t>() + (size_t)y * s->W, img + (size_t)y * stride, s->W);
+    }
+    h_src = pin.as<uint8_t>();  // (a block is reused two images later: the wait for that image's flow lies in between)
   }
-  // (a block is reused two images later: the wait for that image's flow lies in between)
-  PLV_HIP_CHECK(plv::memcpy_async(s->raw.p, pin.p, bytes, hipMemcpyHostToDevice, ctx->stream));
-  return feed_device(ctx, s, s->raw.as<uint8_t>());
+  // no copy command: the histogram kernel reads the pinned block over PCIe (16 bytes per lane) and leaves the image in s->raw
+  return feed_device(ctx, s, s->raw.as<uint8_t>(), h_src);
+}
+
+// A pinned host block of the library for the caller to write the next image into (a camera driver's DMA target, cv_bridge's copy
+// target: `cv::Mat(h, w, CV_8UC1, ptr)`): plv_tracker_feed / plv_camera_frame recognise a pointer into it and skip their own host
+// copy.  index 0 .. 3; packed rows (stride = width).  The block must not be overwritten before the call it was handed to has returned.
+int plv_image_buffer(plv_ctx *ctx, int index, uint8_t **ptr, int *stride) {
+  if (!ctx || !ptr || index < 0 || index >= 4) return PLV_E_BADARG;
+  (void)hipSetDevice(ctx->device);
+  FrontState *s = fe(ctx);
+  TRY(ensure_pyramids(ctx, s));
+  TRY(s->img_pin[2 + index].reserve((size_t)s->W * s->H));  // (blocks 0 and 1 are the library's own)
+  *ptr = s->img_pin[2 + index].as<uint8_t>();
+  if (stride) *stride = s->W;
+  return PLV_OK;
 }
 
 int plv_feed_image(plv_ctx *ctx, const uint8_t *img, int stride) {

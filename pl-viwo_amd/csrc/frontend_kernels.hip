@@ -27,7 +27,11 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 // ------------------------------------------------------------------------------------------ K1
-__global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ img, int npix, unsigned *__restrict__ hist) {
+// COPY_IN: `img` is the library's pinned host block (the caller's image on its way in) and the kernel also leaves the image in
+// `raw` (HBM) for everything behind it — the pixels cross PCIe once, as 16-byte loads of this kernel, and no copy command sits in
+// front of the frame (plv_feed_image_enqueue).
+template <bool COPY_IN>
+__global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ img, int npix, unsigned *__restrict__ hist, uint8_t *__restrict__ raw) {
   __shared__ unsigned sh[256];
   sh[threadIdx.x] = 0;
   __syncthreads();
@@ -35,6 +39,7 @@ __global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ i
   const uint4 *v = reinterpret_cast<const uint4 *>(img);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
     uint4 q = v[i];
+    if (COPY_IN) reinterpret_cast<uint4 *>(raw)[i] = q;
     unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -45,7 +50,11 @@ __global__ void __launch_bounds__(256) hist_kernel(const uint8_t *__restrict__ i
     }
   }
   if (blockIdx.x == 0)
-    for (int i = (nvec << 4) + threadIdx.x; i < npix; i += blockDim.x) atomicAdd(&sh[img[i]], 1u);
+    for (int i = (nvec << 4) + threadIdx.x; i < npix; i += blockDim.x) {
+      const uint8_t px = img[i];
+      if (COPY_IN) raw[i] = px;
+      atomicAdd(&sh[px], 1u);
+    }
   __syncthreads();
   if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
@@ -1152,7 +1161,7 @@ int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix
   int blocks = min(256, max(1, cdiv(npix / 16, 256)));
   {
     ProfScope ps(ctx->prof, "hist_kernel", ctx->stream);
-    hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_src, npix, d_hist);
+    hipLaunchKernelGGL(hist_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, d_src, npix, d_hist, (uint8_t *)nullptr);
   }
   {
     ProfScope ps(ctx->prof, "equalize_kernel", ctx->stream);
@@ -1186,16 +1195,21 @@ int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int 
 
 // cv::equalizeHist + cv::buildOpticalFlowPyramid from the raw image: histogram, then the equalisation rides on the first
 // two-level pyramid launch (needs at least three levels; otherwise the separate kernels)
-int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p, unsigned *d_hist) {
+int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p, unsigned *d_hist, const uint8_t *h_src) {
   const int npix = p.w[0] * p.h[0];
   if (p.levels < 3) {
+    if (h_src) PLV_HIP_CHECK(plv::memcpy_async((void *)d_raw, h_src, (size_t)npix, hipMemcpyHostToDevice, ctx->stream));
     int rc = launch_equalize(ctx, d_raw, p.base + p.off[0], npix, d_hist);
     return rc ? rc : launch_pyramid(ctx, p);
   }
   {
     ProfScope ps(ctx->prof, "hist_kernel", ctx->stream);
     const int blocks = min(256, max(1, cdiv(npix / 16, 256)));
-    hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, npix, d_hist);
+    // h_src: the image is still in the library's pinned host block — this kernel reads it from there and leaves it in d_raw
+    if (h_src)
+      hipLaunchKernelGGL(hist_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, h_src, npix, d_hist, const_cast<uint8_t *>(d_raw));
+    else
+      hipLaunchKernelGGL(hist_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, npix, d_hist, (uint8_t *)nullptr);
   }
   // (the line detector's edge kernel, when the tracker feed asked for it: it equalises the raw image itself and so need not wait for
   // the pyramid — its maps reach the library's line worker two launches earlier, and the flow starts when it always did)

@@ -21,7 +21,8 @@ struct CamK {
 int launch_equalize(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int npix, unsigned *d_hist);
 int launch_clahe(plv_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, int w, int h, double clip_limit, int tiles, uint8_t *d_lut);
 int launch_pyramid(plv_ctx *ctx, const PyrDesc &p, int first_level = 0, unsigned *clear_hist = nullptr);
-int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p, unsigned *d_hist);
+// h_src != null: the raw image is still in pinned host memory; the histogram kernel reads it from there and writes d_raw (no copy command)
+int launch_equalize_pyramid(plv_ctx *ctx, const uint8_t *d_raw, const PyrDesc &p, unsigned *d_hist, const uint8_t *h_src = nullptr);
 int launch_pyrdown(plv_ctx *ctx, const uint8_t *d_src, int sw, int sh, uint8_t *d_dst, int dw, int dh);
 int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, const float *d_pts0, float *d_pts1,
               uint8_t *d_status, int *d_iters, int win, int max_iters, float eps,

@@ -287,16 +287,20 @@ struct WinTab {
 };
 #define JAC_MAX_WIN 40  // (n_clones - 3) * 2 variants must fit
 
-// Pt != null: the estimate-variant tables of a second state of the same window (clone times shared) follow at tab[2 * nwin + s0]
-// (the line update triangulates on the state before the point correction and linearises on the corrected one).
-__device__ void build_window_tables(const JacParams &P, WinTab *tab, const JacParams *Pt = nullptr) {
+// Rt != null: the estimate-variant tables of a second state of the same window (clone rotations Rt, positions pt; clone times
+// shared) follow at tab[2 * nwin + s0] (the line update triangulates on the state before the point correction and linearises on
+// the corrected one).  The second state comes in as two pointer VALUES: a pointer to its JacParams keeps that whole struct — and
+// the caller's — in scratch memory (a select between members of two structs becomes a select of their addresses: 48 bytes of
+// scratch stores per lane at the top of every workgroup, 1.1 MB per line launch in round 5's WRITE_SIZE).
+__device__ void build_window_tables(const JacParams &P, WinTab *tab, const double *Rt = nullptr, const double *pt = nullptr) {
   const int nwin = max(P.n_clones - 3, 0);
-  const int ntask = nwin * (Pt ? 3 : 2);
+  const int ntask = nwin * (Rt ? 3 : 2);
+  const double *const R_est = P.clone_R, *const R_fej = P.clone_R_fej, *const p_est = P.clone_p, *const p_fej = P.clone_p_fej;
   for (int idx = threadIdx.x; idx < ntask * 3; idx += blockDim.x) {
     const int w = idx % 3, e = idx / 3;
     const bool second = e >= 2 * nwin;
     const int s0 = second ? e - 2 * nwin : e >> 1, fej = second ? 0 : e & 1;
-    const double *Rs = second ? Pt->clone_R : (fej ? P.clone_R_fej : P.clone_R), *ps = second ? Pt->clone_p : (fej ? P.clone_p_fej : P.clone_p);
+    const double *Rs = second ? Rt : (fej ? R_fej : R_est), *ps = second ? pt : (fej ? p_fej : p_est);
     WinTab &T = tab[e];
     const M3 R0 = ldM(Rs + 9 * s0);
     const V3 p0 = ldV(ps + 3 * s0);
@@ -1951,7 +1955,7 @@ __global__ void __launch_bounds__(256) line_jacobian_nullspace_kernel(JacParams 
   } else if (wave == 1 && tri.on) {
     for (int i = lane; i < o1 - o0; i += 64) s0t_l[i] = bounding_start(Pt, tm_l[i] + Pt.cam_dt);
   }
-  build_window_tables(P, tab, tri.on ? &Pt : nullptr);  // (ends with a barrier: also orders the zero fill and the slots before what follows)
+  build_window_tables(P, tab, tri.on ? Pt.clone_R : nullptr, tri.on ? Pt.clone_p : nullptr);  // (ends with a barrier: also orders the zero fill and the slots before what follows)
   jac_stamp(2);
   if (wave == 0) {
     if (tri.on) {

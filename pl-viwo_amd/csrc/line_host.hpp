@@ -4,6 +4,7 @@
 // ximgproc::FastLineDetector).  line_api.hip builds the tracker around it; tests/host_sanitize/ compiles this
 // header alone with -fsanitize=thread / address and drives the thread protocol with recorded edge maps.
 #pragma once
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -109,8 +110,22 @@ inline std::atomic<int> &spin_budget_us() {
 // The most fitter threads the segment growth uses next to the walking thread (0 .. Fit::kThreads; 0 = the walk's own thread fits
 // afterwards).  host_extract takes one of them for a small map and both for a large one (see there).  Whole runs at workload C: 0.56 ms
 // per frame with one or two, 0.70 ms with none (without a fitter the worker finishes after the point update and the caller waits for it).
+// Default: seven (one 8-core complex holds the walking thread + seven helpers; 5, 7 and 11 measured the same there), but never more
+// than the CPUs this process may run on minus two — the caller's thread and the line worker are on the frame's critical path and a
+// polling helper that shares their CPU preempts them (a small control group, several contexts per node) — and at most
+// two when fewer than six CPUs are allowed.  INTEGRATION.md "Host threads".
+inline int default_fit_threads() {
+  int ncpu = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) ncpu = CPU_COUNT(&set);
+  if (ncpu <= 0) ncpu = (int)std::thread::hardware_concurrency();
+  int n = ncpu - 2;
+  if (ncpu < 6) n = std::min(n, 2);
+  return std::max(0, std::min(7, n));
+}
 inline std::atomic<int> &fit_threads() {
-  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min((int)Fit::kThreads, atoi(getenv("PLV_LINE_FIT_THREADS")))) : 7};
+  static std::atomic<int> v{getenv("PLV_LINE_FIT_THREADS") ? std::max(0, std::min((int)Fit::kThreads, atoi(getenv("PLV_LINE_FIT_THREADS")))) : default_fit_threads()};
   return v;
 }
 template <class Pred>
@@ -303,7 +318,9 @@ inline void fit_worker(HostStage *T, int me, int seen /* the generation current 
     {
       std::unique_lock<std::mutex> lk(F.m);
       // (a pre-wake ends the wait without a job: the thread comes round and polls again — awake when the job arrives)
-      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.prewake != seen_pw || F.quit; });
+      // (a helper beyond the configured count — the count was lowered after it was started — blocks at once: a pre-wake makes only
+      // the helpers the next job will use poll)
+      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.prewake != seen_pw || F.quit; }, me < fit_threads().load(std::memory_order_relaxed) ? -1 : 0);
       if (F.quit) return;
       if (F.gen == seen) {
         seen_pw = F.prewake;

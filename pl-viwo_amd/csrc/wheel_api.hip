@@ -267,6 +267,33 @@ __global__ void __launch_bounds__(64) wheel_kernel(WheelArgs A) {
   }
 }
 
+// Sensitivities of one constant-rate planar arc: heading `a`, turn rate `r` (the heading advances by -r dt) and forward speed `s`
+// held over dt.  d(x, y) by the heading (_a), the rate (_r) and the speed (_s); below |r| = 1e-4 the straight-line limits.  The
+// closed forms are the model's (REF: UpdaterWheel.cpp:449-461, 574-611, evaluated there twice: once per intrinsic chain and once
+// for the covariance), written here once over the two differences every one of them contains; operation order as there.
+struct ArcSens {
+  double x_a, y_a, x_r, y_r, x_s, y_s;
+};
+__device__ inline ArcSens arc_sensitivities(double a, double r, double s, double dt) {
+  ArcSens d;
+  if (fabs(r) < 0.0001) {
+    const double sa = sin(a), ca = cos(a);
+    d.x_a = s * sa * dt, d.y_a = s * ca * dt;
+    d.x_r = s * sa * dt * dt / 2, d.y_r = s * ca * dt * dt / 2;
+    d.x_s = ca * dt, d.y_s = -sa * dt;
+    return d;
+  }
+  const double a_end = a - r * dt;
+  const double dcos = cos(a_end) - cos(a), dsin = sin(a_end) - sin(a);
+  d.x_a = (s * dcos) / r;
+  d.y_a = -(s * dsin) / r;
+  d.x_r = (s * dsin) / r / r + (s * cos(a_end) * dt) / r;
+  d.y_r = (s * dcos) / r / r - (s * sin(a_end) * dt) / r;
+  d.x_s = -dsin / r;
+  d.y_s = -dcos / r;
+  return d;
+}
+
 // The 2D types (REF: preintegration_2D :502-646, preintegration_intrinsics_2D :426-470, compute_linear_system_2D :217-325):
 // scalar recursions and a 3x3 covariance, all on lane 0; the lanes then whiten one column each.
 // out: [H 3*k col-major][res 3][Cov 9][R 9 = I][meas 3 = theta x y][Hw 3*k][resw 3]
@@ -274,96 +301,71 @@ __global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
   __shared__ double Hr[3 * 24], resv[3], L[9], C2[9], meas[3];
   const int tid = threadIdx.x, k = A.k;
   if (tid == 0) {
-    double th_2D = 0, x_2D = 0, y_2D = 0;
+    double head = 0, px = 0, py = 0;   // the preintegrated planar pose: heading, position
     double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double dth_di[3] = {0, 0, 0}, dx_di[3] = {0, 0, 0}, dy_di[3] = {0, 0, 0};
+    double g_head[3] = {0, 0, 0}, g_px[3] = {0, 0, 0}, g_py[3] = {0, 0, 0};   // its gradients by (r_left, r_right, base)
     const double rl = A.st.intr[0], rr = A.st.intr[1], b = A.st.intr[2];
     for (int i = 0; i < A.n_data - 1; ++i) {
       const double dt = A.t[i + 1] - A.t[i];
       if (A.op.do_calib_int) {
-        const double w_l = A.m1[i], w_r = A.m2[i];
-        const double w = (w_r * rr - w_l * rl) / b, v = (w_r * rr + w_l * rl) / 2;
-        const double Hwx[3] = {-w_l / b, w_r / b, -(w_r * rr - w_l * rl) / (b * b)}, Hvx[3] = {w_l / 2, w_r / 2, 0};
-        double h_thw = dt;
-        double h_xth = (v * (cos(th_2D - w * dt) - cos(th_2D))) / w;
-        double h_yth = -(v * (sin(th_2D - w * dt) - sin(th_2D))) / w;
-        double h_xw = (v * (sin(th_2D - w * dt) - sin(th_2D))) / w / w + (v * cos(th_2D - w * dt) * dt) / w;
-        double h_yw = (v * (cos(th_2D - w * dt) - cos(th_2D))) / w / w - (v * sin(th_2D - w * dt) * dt) / w;
-        double h_xv = -(sin(th_2D - w * dt) - sin(th_2D)) / w;
-        double h_yv = -(cos(th_2D - w * dt) - cos(th_2D)) / w;
-        if (fabs(w) < 0.0001) {
-          h_xth = v * sin(th_2D) * dt;
-          h_yth = v * cos(th_2D) * dt;
-          h_xw = v * sin(th_2D) * dt * dt / 2;
-          h_yw = v * cos(th_2D) * dt * dt / 2;
-          h_xv = cos(th_2D) * dt;
-          h_yv = -sin(th_2D) * dt;
-        }
+        const double enc_l = A.m1[i], enc_r = A.m2[i];
+        const double rate = (enc_r * rr - enc_l * rl) / b, speed = (enc_r * rr + enc_l * rl) / 2;
+        const double rate_by[3] = {-enc_l / b, enc_r / b, -(enc_r * rr - enc_l * rl) / (b * b)}, speed_by[3] = {enc_l / 2, enc_r / 2, 0};
+        const ArcSens d = arc_sensitivities(head, rate, speed, dt);
         for (int c = 0; c < 3; ++c) {
-          dx_di[c] = ((dx_di[c] + h_xth * dth_di[c]) + h_xw * Hwx[c]) + h_xv * Hvx[c];
-          dy_di[c] = ((dy_di[c] + h_yth * dth_di[c]) + h_yw * Hwx[c]) + h_yv * Hvx[c];
+          g_px[c] = ((g_px[c] + d.x_a * g_head[c]) + d.x_r * rate_by[c]) + d.x_s * speed_by[c];
+          g_py[c] = ((g_py[c] + d.y_a * g_head[c]) + d.y_r * rate_by[c]) + d.y_s * speed_by[c];
         }
-        for (int c = 0; c < 3; ++c) dth_di[c] = dth_di[c] + h_thw * Hwx[c];
+        for (int c = 0; c < 3; ++c) g_head[c] = g_head[c] + dt * rate_by[c];
       }
-      double w1, w2, v1, v2;
+      // rate and speed at both ends of the interval, from what the type measures
+      double rate0, rate1, speed0, speed1;
       if (A.op.type == PLV_WHEEL2D_ANG) {
-        w1 = (A.m2[i] * rr - A.m1[i] * rl) / b, v1 = (A.m2[i] * rr + A.m1[i] * rl) / 2;
-        w2 = (A.m2[i + 1] * rr - A.m1[i + 1] * rl) / b, v2 = (A.m2[i + 1] * rr + A.m1[i + 1] * rl) / 2;
+        rate0 = (A.m2[i] * rr - A.m1[i] * rl) / b, speed0 = (A.m2[i] * rr + A.m1[i] * rl) / 2;
+        rate1 = (A.m2[i + 1] * rr - A.m1[i + 1] * rl) / b, speed1 = (A.m2[i + 1] * rr + A.m1[i + 1] * rl) / 2;
       } else if (A.op.type == PLV_WHEEL2D_LIN) {
-        w1 = (A.m2[i] - A.m1[i]) / b, v1 = (A.m2[i] + A.m1[i]) / 2;
-        w2 = (A.m2[i + 1] - A.m1[i + 1]) / b, v2 = (A.m2[i + 1] + A.m1[i + 1]) / 2;
+        rate0 = (A.m2[i] - A.m1[i]) / b, speed0 = (A.m2[i] + A.m1[i]) / 2;
+        rate1 = (A.m2[i + 1] - A.m1[i + 1]) / b, speed1 = (A.m2[i + 1] + A.m1[i + 1]) / 2;
       } else {
-        w1 = A.m1[i], v1 = A.m2[i], w2 = A.m1[i + 1], v2 = A.m2[i + 1];
+        rate0 = A.m1[i], speed0 = A.m2[i], rate1 = A.m1[i + 1], speed1 = A.m2[i + 1];
       }
-      const double w_alpha = (w2 - w1) / dt, v_jerk = (v2 - v1) / dt;
-      double w = w1, v = v1;
-      const double k1_th = -w * dt, k1_x = v * 1 * dt;
-      const double th2 = 0.5 * k1_th;
-      w += 0.5 * w_alpha * dt;
-      v += 0.5 * v_jerk * dt;
-      const double k2_th = -w * dt, k2_x = v * cos(th2) * dt;
-      const double th3 = 0.5 * k2_th;
-      const double k3_th = -w * dt, k3_x = v * cos(th3) * dt;
-      const double th4 = k3_th;
-      w += 0.5 * w_alpha * dt;
-      v += 0.5 * v_jerk * dt;
-      const double k4_th = -w * dt, k4_x = v * cos(th4) * dt;
-      const double th_next = th_2D + (1.0 / 6.0) * (k1_th + 2 * k2_th + 2 * k3_th + k4_th);
-      const double x_next = x_2D + (1.0 / 6.0) * (k1_x + 2 * k2_x + 2 * k3_x + k4_x);
-      double y_next;
-      if (fabs(w1) < 0.0001)
-        y_next = y_2D - v1 * sin(th_2D - w1 * dt) * dt;
+      // RK4 over the interval with rate and speed interpolated linearly; the stages' headings are relative to the interval's start
+      const double rate_slope = (rate1 - rate0) / dt, speed_slope = (speed1 - speed0) / dt;
+      double rate = rate0, speed = speed0;
+      const double s1_head = -rate * dt, s1_x = speed * 1 * dt;
+      const double mid_a = 0.5 * s1_head;
+      rate += 0.5 * rate_slope * dt;
+      speed += 0.5 * speed_slope * dt;
+      const double s2_head = -rate * dt, s2_x = speed * cos(mid_a) * dt;
+      const double mid_b = 0.5 * s2_head;
+      const double s3_head = -rate * dt, s3_x = speed * cos(mid_b) * dt;
+      const double end_c = s3_head;
+      rate += 0.5 * rate_slope * dt;
+      speed += 0.5 * speed_slope * dt;
+      const double s4_head = -rate * dt, s4_x = speed * cos(end_c) * dt;
+      const double head_next = head + (1.0 / 6.0) * (s1_head + 2 * s2_head + 2 * s3_head + s4_head);
+      const double px_next = px + (1.0 / 6.0) * (s1_x + 2 * s2_x + 2 * s3_x + s4_x);
+      double py_next;   // (the lateral coordinate takes the arc's closed form on the interval's first sample, as the reference does)
+      if (fabs(rate0) < 0.0001)
+        py_next = py - speed0 * sin(head - rate0 * dt) * dt;
       else
-        y_next = y_2D - (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1;
-      double Hwn[2], Hvn[2];
+        py_next = py - (speed0 * (cos(head - rate0 * dt) - cos(head))) / rate0;
+      // how the measurement noise enters rate and speed
+      double rate_n[2], speed_n[2];
       if (A.op.type == PLV_WHEEL2D_ANG) {
-        Hwn[0] = rl / b, Hwn[1] = -rr / b, Hvn[0] = -rl / 2, Hvn[1] = -rr / 2;
+        rate_n[0] = rl / b, rate_n[1] = -rr / b, speed_n[0] = -rl / 2, speed_n[1] = -rr / 2;
       } else if (A.op.type == PLV_WHEEL2D_LIN) {
-        Hwn[0] = 1.0 / b, Hwn[1] = -1.0 / b, Hvn[0] = -1.0 / 2, Hvn[1] = -1.0 / 2;
+        rate_n[0] = 1.0 / b, rate_n[1] = -1.0 / b, speed_n[0] = -1.0 / 2, speed_n[1] = -1.0 / 2;
       } else {
-        Hwn[0] = 1, Hwn[1] = 0, Hvn[0] = 0, Hvn[1] = 1;
+        rate_n[0] = 1, rate_n[1] = 0, speed_n[0] = 0, speed_n[1] = 1;
       }
-      double h_thw = dt;
-      double h_xth = (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1;
-      double h_yth = -(v1 * (sin(th_2D - w1 * dt) - sin(th_2D))) / w1;
-      double h_xw = (v1 * (sin(th_2D - w1 * dt) - sin(th_2D))) / w1 / w1 + (v1 * cos(th_2D - w1 * dt) * dt) / w1;
-      double h_yw = (v1 * (cos(th_2D - w1 * dt) - cos(th_2D))) / w1 / w1 - (v1 * sin(th_2D - w1 * dt) * dt) / w1;
-      double h_xv = -(sin(th_2D - w1 * dt) - sin(th_2D)) / w1;
-      double h_yv = -(cos(th_2D - w1 * dt) - cos(th_2D)) / w1;
-      if (fabs(w1) < 0.0001) {
-        h_xth = v1 * sin(th_2D) * dt;
-        h_yth = v1 * cos(th_2D) * dt;
-        h_xw = v1 * sin(th_2D) * dt * dt / 2;
-        h_yw = v1 * cos(th_2D) * dt * dt / 2;
-        h_xv = cos(th_2D) * dt;
-        h_yv = -sin(th_2D) * dt;
-      }
-      const double Ptr[9] = {1, 0, 0, h_xth, 1, 0, h_yth, 0, 1};
+      const ArcSens d = arc_sensitivities(head, rate0, speed0, dt);
+      const double Ptr[9] = {1, 0, 0, d.x_a, 1, 0, d.y_a, 0, 1};
       double Pns[6];
       for (int c = 0; c < 2; ++c) {
-        Pns[c] = h_thw * Hwn[c];
-        Pns[2 + c] = h_xw * Hwn[c] + h_xv * Hvn[c];
-        Pns[4 + c] = h_yw * Hwn[c] + h_yv * Hvn[c];
+        Pns[c] = dt * rate_n[c];
+        Pns[2 + c] = d.x_r * rate_n[c] + d.x_s * speed_n[c];
+        Pns[4 + c] = d.y_r * rate_n[c] + d.y_s * speed_n[c];
       }
       double Q0, Q1;
       if (A.op.type == PLV_WHEEL2D_ANG)
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
         }
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) C[3 * r + c] = 0.5 * (N[3 * r + c] + N[3 * c + r]);
-      th_2D = th_next, x_2D = x_next, y_2D = y_next;
+      head = head_next, px = px_next, py = py_next;
     }
     // compute_linear_system_2D
     D3 pI0 = ld3(A.st.p0), pI1 = ld3(A.st.p1);
@@ -398,9 +400,9 @@ __global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
     const D3 pOinI = mvec(mscale(-1.0, mtr(RItoO)), pIinO);
     const double theta_est = log3(mmul(mmul(mmul(RItoO, RG1), mtr(RG0)), mtr(RItoO))).z;
     const D3 d_est = mvec(mmul(RItoO, RG0), ((pI1 + mvec(mtr(RG1), pOinI)) - pI0) - mvec(mtr(RG0), pOinI));
-    resv[0] = theta_est - th_2D;
-    resv[1] = x_2D - d_est.x;
-    resv[2] = y_2D - d_est.y;
+    resv[0] = theta_est - head;
+    resv[1] = px - d_est.x;
+    resv[2] = py - d_est.y;
     for (int e = 0; e < 3 * k; ++e) Hr[e] = 0.0;
     pI0 = ld3(A.st.p0_fej), pI1 = ld3(A.st.p1_fej), RG0 = ldm(A.st.R0_fej), RG1 = ldm(A.st.R1_fej);
     const DM3 RO0toO1 = mmul(mmul(mmul(RItoO, RG1), mtr(RG0)), mtr(RItoO)), RO1toO0 = mtr(RO0toO1);
@@ -442,9 +444,9 @@ __global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
     }
     if (A.op.do_calib_int)
       for (int c = 0; c < 3; ++c) {
-        Hr[0 * k + hc + c] = -dth_di[c];
-        Hr[1 * k + hc + c] = -dx_di[c];
-        Hr[2 * k + hc + c] = -dy_di[c];
+        Hr[0 * k + hc + c] = -g_head[c];
+        Hr[1 * k + hc + c] = -g_px[c];
+        Hr[2 * k + hc + c] = -g_py[c];
       }
     for (int e = 0; e < 9; ++e) {
       C2[e] = C[e];
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(64) wheel2d_kernel(WheelArgs A) {
         L[i2 * 3 + j] = v / d;
       }
     }
-    meas[0] = th_2D, meas[1] = x_2D, meas[2] = y_2D;
+    meas[0] = head, meas[1] = px, meas[2] = py;
   }
   __syncthreads();
   double *oH = A.out, *ores = oH + 3 * k, *oC = ores + 3, *oR = oC + 9, *op = oR + 9, *oHw = op + 3, *oresw = oHw + 3 * k;

@@ -6,12 +6,22 @@
 // The image is the one the point tracker of the same context was fed last (UpdaterCamera.cpp:105-109 calls the point tracker
 // first; the reference's second equalizeHist, TrackLSD.cpp:83, reproduces the same image).  The line track store lives in the
 // library (plv_line_db_*); `export_tracks` hands it out in the layout of plv_line_tracks for code that wants LineFeature objects.
+//
+// The first constructor has TrackLSD's own signature (TrackLSD.h:85-86): the reference's call site
+//   new TrackLSD(state->cam_intrinsic_model, op->use_stereo, op->histogram, trackFEATS)
+// (UpdaterCamera.cpp:44) compiles with the class name changed; the context is the one of the camera's point tracker
+// (trackFEATS holds TrackKLT_HIP objects), which the line tracker shares as the reference's shares the point tracker's outputs
+// (TrackLSD.cpp:100-101,127-129: get_last_obs / get_last_ids).
 #pragma once
 #include <cstdlib>
+#include <map>
+#include <memory>
+#include <unordered_map>
 #include <vector>
 
 #include <Eigen/Eigen>
 
+#include "TrackKLT_HIP.h"
 #include "plviwo.h"
 #include "utils/print.h"
 #include "utils/sensor_data.h"
@@ -20,6 +30,22 @@ namespace viw {
 
 class TrackLSD_HIP {
 public:
+  // REF: TrackLSD.h:85-86 — the reference's signature
+  TrackLSD_HIP(std::unordered_map<size_t, std::shared_ptr<ov_core::CamBase>> cameras, bool stereo, ov_core::TrackBase::HistogramMethod histmethod,
+               std::map<int, std::shared_ptr<ov_core::TrackBase>> _trackFEATS)
+      : ctx(nullptr) {
+    (void)cameras, (void)histmethod;  // (intrinsics and equalisation are the point tracker's: same context, same image)
+    std::shared_ptr<ov_core::TrackKLT_HIP> klt;
+    for (auto &kv : _trackFEATS)
+      if ((klt = std::dynamic_pointer_cast<ov_core::TrackKLT_HIP>(kv.second))) break;
+    if (stereo || !klt) {
+      PRINT_ERROR(RED "[TrackLSD_HIP]: needs the monocular TrackKLT_HIP of its camera in trackFEATS\n" RESET);
+      std::exit(EXIT_FAILURE);
+    }
+    ctx = klt->context();
+    plv_line_prefetch_mode(ctx, 1);
+  }
+
   explicit TrackLSD_HIP(plv_ctx *ctx_, bool prefetch = true) : ctx(ctx_) {
     plv_line_prefetch_mode(ctx, prefetch ? 1 : 0);  // the detector's host stage runs while the device tracks the points
   }

@@ -22,9 +22,31 @@ namespace viw {
 
 class UpdaterCameraHIP {
 public:
+  // REF: UpdaterCamera.cpp:26 — the reference's signature `UpdaterCamera(shared_ptr<State> state)`: builds the camera's trackers with the
+  // reference's own constructor arguments (:41,44; TrackKLT_HIP creates and owns the plv_ctx)
+  explicit UpdaterCameraHIP(std::shared_ptr<State> state_) : state(state_), ctx(nullptr), max_obs(24) {
+    const std::shared_ptr<OptionsCamera> op = state->op->cam;
+    trackFEATS = std::make_shared<ov_core::TrackKLT_HIP>(state->cam_intrinsic_model, op->n_pts, 0, op->use_stereo, op->histogram, op->fast, op->grid_x,
+                                                         op->grid_y, op->min_px_dist);
+    trackFEATS->mirror_database(false);  // (this class reads the library's track store)
+    ctx = trackFEATS->context();
+    if (op->use_lines) trackLSDS = std::make_shared<TrackLSD_HIP>(ctx);
+  }
   UpdaterCameraHIP(std::shared_ptr<State> state_, plv_ctx *ctx_, std::shared_ptr<ov_core::TrackKLT_HIP> klt, std::shared_ptr<TrackLSD_HIP> lsd,
                    int max_obs_ = 24)
       : state(state_), ctx(ctx_), trackFEATS(klt), trackLSDS(lsd), max_obs(max_obs_) {}
+
+  // A cv::Mat header over one of the library's page-locked image blocks (plv_image_buffer, index 0..3): where the ROS callback puts
+  // its copy of the message (`cv_bridge::toCvShare(msg)->image.copyTo(up_cam->image_block(k))` instead of `.clone()`,
+  // REF: ROSSubscriber's camera callbacks) or a camera driver its frame.  frame() / feed_measurement() given such an image read it from
+  // where it lies: no host copy inside the call, the pixels cross PCIe in the frame's first kernel.  Alternate the index frame by frame.
+  cv::Mat image_block(int index) {
+    uint8_t *ptr = nullptr;
+    int stride = 0;
+    if (plv_image_buffer(ctx, index, &ptr, &stride) != PLV_OK) return cv::Mat();
+    const std::vector<int> &wh = state->op->cam->wh.at(0);
+    return cv::Mat(wh.at(1), wh.at(0), CV_8UC1, ptr, (size_t)stride);
+  }
 
   // the window as the kernels read it: clone times ascending, rotations row-major, first estimates, covariance ids
   struct View {

@@ -8,5 +8,8 @@ public:
   virtual ~CamBase();
   virtual void set_value(const Eigen::MatrixXd &calib);
   cv::Point2f undistort_cv(const cv::Point2f &uv_dist);
+  Eigen::MatrixXd get_value();                                                                         // :181
+  int w();                                                                                             // :190
+  int h();                                                                                             // :193
 };
 }  // namespace ov_core

@@ -18,6 +18,8 @@ struct MatStep {
 class Mat {
 public:
   Mat();
+  Mat(int rows, int cols, int type, void *data, size_t step = 0);   // (header over caller-owned memory)
+  void copyTo(Mat &dst) const;
   int type() const;
   bool isContinuous() const;
   bool empty() const;

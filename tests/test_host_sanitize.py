@@ -56,6 +56,28 @@ def test_line_host_stage_under_sanitizers(maps, tmp_path, san):
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
 
 
+def test_helper_threads_are_clamped_to_the_allowed_cpus(tmp_path):
+    """the default number of polling helper threads of the line detector's host stage is min(7, allowed CPUs - 2),
+    at most two below six CPUs, none below three — the caller's thread and the line worker keep a CPU each."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fit_threads_check")
+    src = os.path.join(ROOT, "tests", "host_sanitize", "fit_threads_check.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    rows = [tuple(int(x) for x in line.split()) for line in r.stdout.split("\n") if line.strip()]
+    assert rows
+    for cpus, helpers in rows:
+        want = max(0, min(7, cpus - 2))
+        if cpus < 6:
+            want = min(want, 2)
+        assert helpers == want, rows
+        assert helpers + 2 <= max(cpus, 2)
+
+
 def test_host_adapters_need_the_reference_headers():
     """pl-viwo_amd/host/*.h (the C++ adapters of INTEGRATION.md: TrackKLT_HIP : ov_core::TrackBase, ...) include the reference's own
     headers and Eigen / OpenCV; a -fsyntax-only pass needs those on the include path.  They are absent from this image, so

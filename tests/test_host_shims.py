@@ -28,6 +28,21 @@ def test_adapter_type_checks_against_the_stand_ins(header):
     assert r.returncode == 0 and not errors, "\n".join(errors[:20])
 
 
+def test_reference_call_site_compiles_with_only_the_class_names_changed():
+    """UpdaterCamera.cpp:41,44 (`new TrackKLT(cam_intrinsic_model, n_pts, 0, use_stereo, histogram, fast, grid_x, grid_y,
+    min_px_dist)`, `new TrackLSD(cam_intrinsic_model, use_stereo, histogram, trackFEATS)`) against the adapters' constructors."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(STUB, "call_sites", "updater_camera_ctor.cpp")
+    text = open(src).read()
+    assert "new TrackKLT_HIP(state->cam_intrinsic_model, op->n_pts, 0, op->use_stereo, op->histogram, op->fast, op->grid_x, op->grid_y, op->min_px_dist)" in text
+    assert "new TrackLSD_HIP(state->cam_intrinsic_model, op->use_stereo, op->histogram, trackFEATS)" in text
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I" + STUB, "-I" + os.path.join(ROOT, "include"),
+                        "-I" + HOST, src], capture_output=True, text=True)
+    errors = [l for l in r.stderr.splitlines() if "error" in l or "warning" in l]
+    assert r.returncode == 0 and not errors, "\n".join(errors[:20])
+
+
 def test_ekf_update_adapter_keeps_the_reference_contracts():
     src = open(os.path.join(HOST, "StateHelperHIP.h")).read()
     assert "if (!state->op->use_imu_res) state->build_polynomial_data(false);" in src          # StateHelper.cpp:171
