@@ -122,7 +122,7 @@ def pin_to_device(pkg, device, mode, rank_on_node=None):
         if len(cpus) < 4:
             return {"mode": "none", "why": "fewer than four allowed cores on the device's node"}
         chosen, info = cpus, {"mode": "node", "numa_node": node, "cpus": len(cpus)}
-        if mode == "ccx":
+        if mode in ("ccx", "ccx2"):
             groups = {}
             for c in cpus:
                 try:
@@ -158,7 +158,9 @@ def pin_to_device(pkg, device, mode, rank_on_node=None):
                 chosen = groups[k]
                 if len(chosen) < 10 and len(groups) > 1:   # (no SMT: the caller + worker + seven helpers need more than one complex's cores)
                     chosen = chosen + groups[k + 1 if k + 1 < len(groups) else k - 1]
-                info.update(mode="ccx", cpus=len(chosen), first_cpu=min(chosen))
+                if mode == "ccx2" and len(groups) > 1:    # (measurement aid: two adjacent L3 complexes — room for more helper threads)
+                    chosen = chosen + groups[k + 1 if k + 1 < len(groups) else k - 1]
+                info.update(mode=mode, cpus=len(chosen), first_cpu=min(chosen))
         os.sched_setaffinity(0, set(chosen))
         return info
     except OSError as e:
@@ -241,6 +243,9 @@ class Player:
         t0 = time.perf_counter()
         sm.camera_run(prep, sync=True)
         dt = time.perf_counter() - t0
+        # (the reference's TimeChecker label of this region, UpdaterCamera.cpp:79,190: recorded from the measured time, not around it)
+        sm.tc.total["[Time-Cam] feed measurement + try_update"] = sm.tc.total.get("[Time-Cam] feed measurement + try_update", 0.0) + dt
+        sm.tc.count["[Time-Cam] feed measurement + try_update"] = sm.tc.count.get("[Time-Cam] feed measurement + try_update", 0) + 1
         sm.camera_finish(prep)
         return dt
 
@@ -325,7 +330,9 @@ def cpu_baseline(wl, stream, n_frames, budget_s, thread_counts):
             "sample": f"{one['frames']} frames of the same stream through oracle/frame_oracle.cpp (feed_measurement + try_update compiled end to "
                       f"end, g++ -O3, timed inside the library with steady_clock): {one['inside_mean_ms']:.2f} ms mean / {one['inside_p50_ms']:.2f} p50 / "
                       f"{one['inside_p99_ms']:.2f} p99 per frame on 1 thread ({one['driver_call_mean_ms']:.2f} ms with the Python driver's call around "
-                      f"it); host has {os.cpu_count()} cores",
+                      f"it); host has {os.cpu_count()} cores.  Resources side by side: the HIP path = 1 GPU + its host threads (caller, line worker, "
+                      f"polling helpers: see host_threads / host_cpu_seconds_per_second at the top level) pinned to one L3 complex; this baseline = "
+                      f"{best['threads']} CPU thread(s) at its best ({best_key}), every allowed CPU available to it",
             "detail": out}
 
 
@@ -444,7 +451,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the short segments with non-default library settings (config.variants)")
     ap.add_argument("--render-workers", type=int, default=0, help="0 = min(32, cores)")
     ap.add_argument("--stream-cache", default=None, help=".npz of the rendered frames: written when missing, loaded (no rendering, no fork) when present")
-    ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,3 — the timed segment cycles through these "
+    ap.add_argument("--alternate-modes", default=None, help="measurement aid: e.g. 0,1 — the timed segment cycles through these "
                     "plv_update_compression_mode settings (0, 1) frame by frame and stderr gets the mean step time of each (drift-free A/B)")
     ap.add_argument("--alternate-spin", default=None, help="measurement aid: e.g. 300,0 — plv_line_worker_config polling budgets (us) cycled frame by frame")
     ap.add_argument("--alternate-fit", default=None, help="measurement aid: e.g. 2,0 — segment-fitter thread counts cycled frame by frame")
@@ -452,7 +459,7 @@ def main():
                     "frame in the first timed segment, mean step time of each on stderr")
     ap.add_argument("--alternate-knobs", default=None, help="measurement aid: e.g. 0,1 — plv_debug_knobs masks cycled frame by frame, "
                     "mean step time of each on stderr")
-    ap.add_argument("--pin", choices=("none", "node", "ccx"), default=os.environ.get("PLV_BENCH_PIN", "ccx"),
+    ap.add_argument("--pin", choices=("none", "node", "ccx", "ccx2"), default=os.environ.get("PLV_BENCH_PIN", "ccx"),
                     help="CPU affinity of this process and the library's threads: the cores of the GPU's NUMA node, or one L3 complex of that "
                          "node (the least busy one; with several ranks, one complex per rank)")
     ap.add_argument("--dry-run", action="store_true",
@@ -844,6 +851,17 @@ def main():
             # scalars first (whatever keeps only the scalar fields of this line still gets them); `value` is the
             # resident-image step (the contract), *_pcie_inclusive the drop-in adapter's call (host cv::Mat pointer, slot -1)
             "latency_p50_ms": pct(per, 50), "latency_p99_ms": pct(per, 99),
+            # what the step occupies on the host: CPU seconds per second of wall time over the first timed segment (the
+            # whole control group: caller, line worker, helper threads — they poll), the threads, and where they were pinned
+            "host_cpu_seconds_per_second": None if not seg.get("host_cpu") else seg["host_cpu"]["cpu_seconds_per_second"],
+            "host_threads": (2 + fit_threads) if wl["lines"] else 1,
+            "host_threads_what": (f"1 caller + 1 line worker + {fit_threads} polling helper threads of the line detector's host stage" if wl["lines"] else "1 caller"),
+            "cpu_affinity_mode": pinned.get("mode"), "cpu_affinity_cpus": pinned.get("cpus"),
+            "cpu_baseline_affinity": "every CPU the process was started with (the GPU path's pin is lifted before the CPU baseline runs)",
+            "methodology": "round 5 on: timed region = plv_camera_frame + plv_ctx_synchronize on pre-marshalled arguments (ms_per_step_python = with the Python "
+                           "driver's marshalling inside, what rounds 1-4 reported); process + library threads pinned to one L3 complex next to the GPU (--pin); "
+                           "60 untimed prologue frames; round 6: value_pcie_inclusive (any host buffer) and value_pinned_host_image (plv_image_buffer) beside the "
+                           "resident-image `value`",
             "tracked_points_per_frame": mean(per_frame["tracked"]), "lines_kept_per_frame": mean(per_frame["kept"]) if wl["lines"] else 0,
             "lines_accepted_per_frame": round(stats["lines_accepted"] / args.steps, 2), "msckf_features_per_frame": round(stats["cam_features"] / args.steps, 2),
             "ms_per_step_python": seg_py["elapsed"] / npy * 1e3,

@@ -131,22 +131,14 @@ __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P
                                                          const unsigned *__restrict__ mirror_src, unsigned *__restrict__ mirror_dst,
                                                          int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
                                                          const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
-                                                         int mirror2_words, const int *__restrict__ veto, unsigned *done_word, unsigned done_val,
+                                                         int mirror2_words, unsigned *done_word, unsigned done_val,
                                                          int *__restrict__ applied_out) {
   // done_word (pinned, optional; the launch then has ONE workgroup): behind the mirrors AND the covariance commit the workgroup stores
   // done_val there, and the host, spinning on the word, knows both the results and the covariance to be final
-  // veto (automatic compression mode): the compression met pivots it could not resolve — nothing is committed, the host redoes the
-  // update through the Householder route (plv_msckf_update_resident_wait)
-  const bool skipped = (skip && *skip == 0) || (veto && *veto != 0);  // (or: the gate accepted nothing: no correction, the covariance stays)
+  const bool skipped = skip && *skip == 0;  // (the gate accepted nothing: no correction, the covariance stays)
   // applied_out: "this update changed the state" — StateHelper::EKFUpdate reached its mean update (:156-168): read by a launch that is
   // enqueued behind the update before the host has seen its result and applies dx to its own copy of the state (the chained line launch)
   if (applied_out && blockIdx.x == 0 && threadIdx.x == 0) *applied_out = (skipped || *flag != 0) ? 0 : 1;
-  // a veto is part of the status the host (and a launch chained behind this update) reads: bit 8 = "withheld, to be run again"
-  const bool vetoed = veto && *veto != 0 && !(skip && *skip == 0);
-  if (blockIdx.x == 0) {
-    if (vetoed && threadIdx.x == 0) atomicOr(flag, 8);
-    if (vetoed) __syncthreads();
-  }
   if (blockIdx.x == 0) {
     if (skipped && dx) {
       for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.0;
@@ -211,7 +203,7 @@ static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const do
     hipLaunchKernelGGL(ekf_commit_kernel, grid, block, 0, ctx->stream, d_P, ldp, n, dC, n,
                        d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx,
                        (const unsigned *)(mirror_dst ? ctx->mirror2_src : nullptr), (unsigned *)(mirror_dst ? ctx->mirror2_dst : nullptr),
-                       (int)((ctx->mirror2_bytes + 3) / 4), ctx->commit_veto, dw, ctx->update_seq, mirror_dst ? ctx->applied_word : nullptr);
+                       (int)((ctx->mirror2_bytes + 3) / 4), dw, ctx->update_seq, mirror_dst ? ctx->applied_word : nullptr);
     ctx->update_word_used = dw != nullptr;
     if (mirror_dst && ctx->applied_word) ctx->applied_used = true;
     if (mirror_dst && ctx->mirror2_dst) ctx->mirror2_taken = true;

@@ -1284,11 +1284,11 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
   }
   ProfScope ps(ctx->prof, "lk_kernel", ctx->stream);
   CamK none{};
-  // (measurement: bit 21 of plv_debug_knobs launches the loop of rounds 2-4 instead, tools/lk_exp.py)
+  // (measurement: PLV_KNOB_LK_LEGACY_LOOP launches the loop of rounds 2-4 instead, tools/lk_exp.py)
 #define LK_LAUNCH(VV)                                                                                                                     \
   hipLaunchKernelGGL(lk_kernel<VV>, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, \
                      d_pts1, d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr)
-  if (plv::knob(1u << 21))
+  if (plv::knob(plv::PLV_KNOB_LK_LEGACY_LOOP))
     LK_LAUNCH(0);
   else
     LK_LAUNCH(1);

@@ -337,7 +337,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   plv_tracks t2 = *all;
   t2.p_FinG = t2.p_FinG_fej = p_out;  // (outputs of the triangulation: the staged copy is never read)
   FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
-  // PLV_CHAIN_EVENTS=1 (with PLV_HOST_TIMING=1): three timed events on the stream — at entry (the stream is idle: stamped at once),
+  // PLV_KNOB_CHAIN_EVENTS (with PLV_KNOB_HOST_TIMING): three timed events on the stream — at entry (the stream is idle: stamped at once),
   // behind the Jacobian launch, behind the update's last kernel — to set the device's view of the chain against the host's phases
   const bool chain_events = plv::knob(plv::PLV_KNOB_CHAIN_EVENTS) && plv::host_phases().on;
   static hipEvent_t ce[3] = {nullptr, nullptr, nullptr};
@@ -363,7 +363,7 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   // (for a line launch chained behind this update, plv_camera_try_update: the commit kernel leaves "state changed" in a device word)
   TRY(us->chain_words.reserve(64));
   us->applied_word = us->chain_words.as<int>();
-  ctx->applied_word = us->compress_mode == 2 ? nullptr : us->applied_word, ctx->applied_used = false;
+  ctx->applied_word = us->applied_word, ctx->applied_used = false;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
   us->applied_armed = rc == PLV_OK && ctx->applied_used;
   ctx->applied_word = nullptr, ctx->applied_used = false;

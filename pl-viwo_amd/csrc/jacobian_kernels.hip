@@ -12,7 +12,7 @@
 // written straight into the [Hf | Hx | res] batch layout that nullspace_kernel consumes; the batch
 // is zero-filled by a memset node in front of the launch.
 #include <hip/hip_runtime.h>
-// Phase stamps of the projected Jacobian launches (measurement aid, PLV_KERNEL_STAMPS=1: the launcher hangs a buffer on the pointer
+// Phase stamps of the projected Jacobian launches (measurement aid, PLV_KNOB_KERNEL_STAMPS: the launcher hangs a buffer on the pointer
 // and prints mean / max cycles per phase when the library unloads).  Off: one scalar load and a branch per stamp.
 namespace plv {
 #define JAC_NSTAMP 32
@@ -888,7 +888,7 @@ __device__ __forceinline__ void jacobian_rows_split(const JacParams &P, const V3
 }
 
 // jacobian_kernel + nullspace_kernel (+ triangulation in front, + the gate behind) in one launch, one workgroup of four waves per
-// batch entry.  Round 4 order of work (stamps: PLV_KERNEL_STAMPS=1):
+// batch entry.  Round 4 order of work (stamps: PLV_KNOB_KERNEL_STAMPS):
 //   1. window tables (all threads), row slots (wave 0)
 //   2. wave 0: estimate poses of the observations from the tables, then the triangulation (serial in the observations: LM);
 //      waves 1-3 meanwhile: the first-estimate interpolation + its Jacobians of every observation (position independent) into LDS,
@@ -2174,7 +2174,7 @@ __device__ void line_triangulate_one(const JacParams &P, int l, int o0, int o1, 
   ok = 1;
 }
 
-// PLV_KERNEL_STAMPS=1: per-phase cycle stamps of the projected Jacobian launches (see jac_stamp): offsets from the workgroup's start,
+// PLV_KNOB_KERNEL_STAMPS: per-phase cycle stamps of the projected Jacobian launches (see jac_stamp): offsets from the workgroup's start,
 // mean and max over the workgroups that went all the way (entries the selection took), printed when the library unloads.
 #define TRY_STAMP(x)          \
   do {                        \

@@ -190,9 +190,11 @@ void line_worker(LineTracker *T) {
       std::unique_lock<std::mutex> lk(T->jm);
       wait_polling(lk, T->jcv, [&] { return T->job_state == 1 || T->job_state == -1 || T->feed_state == 1 || T->defer_state == 1; });
       if (T->job_state == -1) return;
-      do_detect = T->job_state == 1;
-      do_feed = !do_detect && T->feed_state == 1;
-      do_deferred = !do_detect && !do_feed && T->defer_state == 1;
+      // the database hand-back first: it is short (~20 us), every entry point joins it (ltr()), and behind a detect job it would
+      // wait for that job's edge maps and its whole host stage while the caller spins
+      do_deferred = T->defer_state == 1;
+      do_detect = !do_deferred && T->job_state == 1;
+      do_feed = !do_deferred && !do_detect && T->feed_state == 1;
     }
     if (do_deferred) {  // the line update's database hand-back (plv_camera_update_lines: finish), off the caller's thread
       std::function<void()> f;
@@ -343,9 +345,9 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     b.map = (uint8_t *)(hp + bytes);
     b.half = b.map + npix;
   }
-  // the worker's host stage splits its work by the components of the edge map when the device labels them (PLV_LINE_LABELS=0: it walks
-  // the map as one sequence, as rounds 2-4 did)
-  static const bool labels_off = getenv("PLV_LINE_LABELS") && atoi(getenv("PLV_LINE_LABELS")) == 0;
+  // the worker's host stage splits its work by the components of the edge map when the device labels them (PLV_KNOB_LINE_LABELS_OFF:
+  // it walks the map as one sequence, as rounds 2-4 did)
+  const bool labels_off = plv::knob(plv::PLV_KNOB_LINE_LABELS_OFF);
   const bool with_labels = launch_only && maps_to_host && !labels_off;
   if (with_labels) {
     TRY(T->lab.reserve(npix * sizeof(int)));
@@ -1321,18 +1323,22 @@ int plv_camera_lines_submit_chained(plv_ctx *ctx, const plv_state_view *st, cons
 }
 
 int plv_camera_lines_job_pending(plv_ctx *ctx) { return ltr(ctx, false)->ujob.pending ? 1 : 0; }
-// (internal) a chained first half whose second half will not run (the point update failed): its launch is waited for and everything
-// it took out of the line database goes back
-void plv_camera_lines_job_abort(plv_ctx *ctx) {
+// (internal) a chained first half whose second half will not run (the point update failed or was run again): its launch is waited
+// for.  keep_pool = 0: everything it took out of the line database goes back (a failing exit: nothing of the frame may outlive the
+// call); keep_pool = 1: the pool stays formed for plv_camera_get_line_features / plv_camera_update_lines of the same frame, which go on
+// the unchained way (formed again it would hold the same candidates, but report the pool size after the single-view tracks were
+// dropped: plv_update_result::n_pool of such a frame was short by those — tests/test_gpu_kaist_replay.py, round 6)
+void plv_camera_lines_job_abort2(plv_ctx *ctx, int keep_pool) {
   LineTracker *T = ltr(ctx, false);
   if (!T->ujob.pending) return;
   (void)plv::stream_sync(ctx->stream);
   ctx->gate_stage.on = 0, ctx->gate_stage_taken = false;
   T->pool_prep = std::move(T->ujob.LP);
   T->pool_prep.valid = true;
-  discard_line_pool(T);
+  if (!keep_pool) discard_line_pool(T);
   T->ujob = LinesJob();
 }
+void plv_camera_lines_job_abort(plv_ctx *ctx) { plv_camera_lines_job_abort2(ctx, 0); }
 
 int plv_camera_update_lines(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, double *dx,
                             plv_update_result *res, uint64_t *line_ids, uint8_t *accepted_out, double *lines_out, int cap) {

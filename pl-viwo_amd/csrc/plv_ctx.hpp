@@ -68,7 +68,7 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 //   1  the prefetched edge kernel on its own stream behind the pyramid instead of on the ctx stream in front of the flow (measured
 //      with tools: 6-15 us per frame SLOWER, four alternating runs of 600 frames; the default stays on the ctx stream)
 //   2  the whitened update's prior factor started behind the Jacobian launch instead of before the update's upload
-//   4  the edge kernel behind flow + RANSAC (PLV_LINE_EDGES_LATE)          8  the next frame's detection on the ctx stream (PLV_AHEAD_CTX)
+//   4  the edge kernel behind flow + RANSAC (PLV_KNOB_EDGES_LATE)          8  the next frame's detection on the ctx stream (PLV_KNOB_AHEAD_CTX)
 //  16  the line pool formed after the point update (PLV_LINE_POOL_LATE)    32 / 64  point / line triangulation as its own launch
 // 128  the Jacobian launches read their inputs from the pinned staging block instead of an uploaded copy
 // 1024 the gate as chi2_t_kernel + chi2_gate_kernel behind the Jacobian launch instead of as that launch's tail (gate_core.hpp)
@@ -91,7 +91,9 @@ enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_
                   PLV_KNOB_KERNEL_STAMPS = 1u << 17,  // s_memtime stamps of the fused Jacobian launches' phases
                   PLV_KNOB_CHAIN_EVENTS = 1u << 18,   // HIP events around the chained launches (with HOST_TIMING)
                   PLV_KNOB_ALLOC_DEBUG = 1u << 19,    // every (re)allocation of a library buffer with a backtrace
-                  PLV_KNOB_HOST_FAULTS = 1u << 20 };  // HostPhase counts minor page faults instead of time
+                  PLV_KNOB_HOST_FAULTS = 1u << 20,    // HostPhase counts minor page faults instead of time
+                  PLV_KNOB_LK_LEGACY_LOOP = 1u << 21, // lk_kernel<0>: the iteration of rounds 2-4 (tools/lk_exp.py; same bits, slower)
+                  PLV_KNOB_LINE_LABELS_OFF = 1u << 22 };  // the line detector's host stage walks the edge map as one sequence (rounds 2-4) instead of by labelled components
 // The mask starts from PLV_DEBUG_KNOBS in the environment (the library's only measurement variable; plv_debug_knobs changes it at run time)
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{getenv("PLV_DEBUG_KNOBS") ? (unsigned)strtoul(getenv("PLV_DEBUG_KNOBS"), nullptr, 0) : 0u};
@@ -100,7 +102,7 @@ inline std::atomic<unsigned> &knobs() {
 inline bool knob(unsigned bit) { return (knobs().load(std::memory_order_relaxed) & bit) != 0; }
 inline bool alloc_debug() { return knob(PLV_KNOB_ALLOC_DEBUG); }
 
-// Host-side phase timing (PLV_HOST_TIMING=1): accumulated wall time per label, printed to stderr when the library unloads.
+// Host-side phase timing (PLV_KNOB_HOST_TIMING): accumulated wall time per label, printed to stderr when the library unloads.
 struct HostPhases {
   struct Rec {
     const char *label;
@@ -121,6 +123,9 @@ struct HostPhases {
       return m ? tmp[m / 2] : 0.0;
     }
   };
+  // latched when the table is first touched (the library's first call): PLV_KNOB_HOST_TIMING — and the LINE / UPDATE timing bits,
+  // latched the same way by their readers — are honoured from PLV_DEBUG_KNOBS in the environment only; setting them later through
+  // plv_debug_knobs does nothing (every scope timer would otherwise pay an atomic load per use)
   bool on = knob(PLV_KNOB_HOST_TIMING);
   std::mutex mtx;
   std::vector<Rec> recs;
@@ -151,7 +156,7 @@ inline HostPhases &host_phases() {
   static HostPhases h;
   return h;
 }
-// PLV_HOST_TIMING=1: where inside the frame an event falls (microseconds since plv_camera_frame was entered), per label
+// PLV_KNOB_HOST_TIMING: where inside the frame an event falls (microseconds since plv_camera_frame was entered), per label
 inline std::atomic<long long> &frame_t0_ns() {
   static std::atomic<long long> t{0};
   return t;
@@ -173,7 +178,7 @@ inline long thread_minor_faults() {
   getrusage(RUSAGE_THREAD, &ru);
   return ru.ru_minflt;
 }
-struct HostPhase {  // scope timer (PLV_HOST_FAULTS=1: the scope's minor page faults instead of its time)
+struct HostPhase {  // scope timer (PLV_KNOB_HOST_FAULTS: the scope's minor page faults instead of its time)
   const char *label;
   std::chrono::steady_clock::time_point t0;
   long f0 = 0;
@@ -505,7 +510,6 @@ struct plv_ctx {
   // plv_msckf_update_resident_launch): the compression and EKF kernels return at once when it is zero — an update in which the gate
   // took nothing (most line updates) costs their launches, not their pivot chains; ekf_commit_kernel then reports dx = 0.
   const int *skip_word = nullptr;
-  const int *commit_veto = nullptr;  // automatic compression mode: ekf_commit_kernel leaves the covariance alone while this word is nonzero
   // a second block the update's last kernel copies to pinned host memory next to its result block (the triangulation results of the
   // one-submission updates): set by the caller before plv_msckf_update_resident_launch, cleared (taken = true) when the chain ended in
   // the kernel that does it — else the caller enqueues a copy command as before

@@ -109,7 +109,7 @@ extern "C" int plv_feed_image_enqueue(plv_ctx *ctx, const uint8_t *img, int stri
 extern "C" int plv_line_prefetch_enabled(plv_ctx *ctx);                               // line_api.hip
 extern "C" void plv_line_edges_early(plv_ctx *ctx, const uint8_t *d_raw, int W, int H, const unsigned *d_hist);
 // the image feed with the line detector's edge kernel between its histogram and its pyramid (plv_ctx::edges_hook) when the frame's
-// lines are detected ahead of the line tracker's feed anyway; PLV_LINE_EDGES_LATE / the edge knobs keep the older orders
+// lines are detected ahead of the line tracker's feed anyway; PLV_KNOB_EDGES_LATE / the other edge knobs keep the older orders
 static int feed_with_early_edges(plv_ctx *ctx, const std::function<int()> &feed) {
   const bool early = !plv::knob(plv::PLV_KNOB_EDGES_LATE | plv::PLV_KNOB_EDGES_SIDE | plv::PLV_KNOB_EDGES_AFTER_PYRAMID) && plv_line_prefetch_enabled(ctx) != 0;
   ctx->edges_hook_fired = false;
@@ -213,7 +213,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
     plv::HostPhase ph("tracker_feed: perform_matching");
     // the line detector's pixel work (18 us) goes in FRONT of the flow: the edge maps then reach the library's line worker ~0.1 ms
     // earlier than behind flow + RANSAC, and the worker (chain walk, segment growth, assignment, matching) is the longer of the two
-    // paths that meet at the line update; PLV_LINE_EDGES_LATE=1 restores the old order
+    // paths that meet at the line update; PLV_KNOB_EDGES_LATE restores the old order
     // (plv_line_edges_fork: a measurement knob that puts the kernel on its own stream behind the pyramid instead — the flow then does
     //  not wait 18 us for it, and yet the frame is 6-15 us slower, measured alternating frame by frame)
     if (!plv::knob(plv::PLV_KNOB_EDGES_LATE) && prefetch_lines && plv_line_edges_fork(ctx) != PLV_OK) launch_prefetch();
@@ -298,6 +298,7 @@ extern "C" void plv_line_feed_pool_args(plv_ctx *ctx, const plv_state_view *st, 
 extern "C" int plv_camera_lines_submit_chained(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt, int cap);  // line_api.hip
 extern "C" int plv_camera_lines_job_pending(plv_ctx *ctx);
 extern "C" void plv_camera_lines_job_abort(plv_ctx *ctx);
+extern "C" void plv_camera_lines_job_abort2(plv_ctx *ctx, int keep_pool);
 static int poll_line_pool(void *arg) {
   plv_ctx *ctx = (plv_ctx *)arg;
   Tracker *T = trk(ctx);
@@ -1047,7 +1048,7 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   };
   // the next frame's top-up detection runs on the side stream next to the point update.  (Round 2 placed it on the ctx stream behind
   // the update when a line update follows; since the line pool is formed inside the point update's wait, the line update is submitted
-  // right after that wait and would queue behind the detection: PLV_AHEAD_CTX=1 restores that placement for measurements.)
+  // right after that wait and would queue behind the detection: PLV_KNOB_AHEAD_CTX restores that placement for measurements.)
   T->defer_db = io->opt_lines != nullptr;
   T->ahead_on_ctx_stream = io->opt_lines != nullptr && plv::knob(plv::PLV_KNOB_AHEAD_CTX);
   T->early_st = io->opt_lines ? st : nullptr;
@@ -1098,7 +1099,8 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
   if (chained && (plv_update_state(ctx)->last_route >= 5 || io->res_points->status != PLV_OK)) {
     // the point update came back rejected — and was perhaps run again on the host's verdict (update_state.hpp, RedoW): the chained
     // line launch saw the rejection and ended without touching anything (JacParams::chain_status).  The line half goes the unchained way.
-    plv_camera_lines_job_abort(ctx);
+    if (plv_update_state(ctx)->last_route >= 5) ++plv::counters().route[6];  // (plv_route_counts[6]: re-runs next to a chained line launch)
+    plv_camera_lines_job_abort2(ctx, rc == PLV_OK ? 1 : 0);  // (the frame goes on: its line pool stays formed)
     chained = false;
   }
   // REF UpdaterCamera.cpp:148-152: get_line_features runs between get_features and msckf_update — the line pool is triangulated on

@@ -116,3 +116,66 @@ def test_whitened_update_on_a_near_dependent_prior(pkg, kaist_dir, tmp_path):
     assert out["default"][0]["not_psd"] == 0 and out["default"][0]["cam_accepted"] == out["householder"][0]["cam_accepted"]
     assert sum(r == 4 for r in routes["default"]) >= len(routes["default"]) - 3, routes["default"]     # (the rest took the whitened route)
     assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 2e-3
+
+
+def test_redone_point_update_next_to_a_chained_line_launch(pkg, kaist_dir, tmp_path):
+    """ADVICE r4 (medium) / VERDICT r5 item 6.  A whitened point update that the device rejects is run again on the host's verdict from
+    the stacked rows and the column map of that update (plv_api.hip RedoW) — while the chained first half of the line update, which runs
+    inside the point update's wait, has already staged ITS batch (more rows per entry, another column map).  Until round 5 both halves
+    shared one stack and one column-map buffer: the re-run then read whatever the line half had put there (or a freed block, when the
+    larger line batch had regrown the buffer).  Here: the drive with stamps of 1.5e9 s (its first update after the initialisation is
+    rejected and redone, see the test above), lines ON, the chained line launch forced on every frame (knob 4096) — against the same
+    replay in plv_update_compression_mode(1), which never takes the whitened route and so never re-runs anything."""
+    options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
+    dst = kaist_synth.convert(kaist_dir[1], str(tmp_path / "urban_1p5e9_lines"), sd.RL, sd.RR, sd.BASE)     # (default stamps: 1.5e9 s)
+    out, routes, chained, line_rows = {}, {}, {}, {}
+    prev_knobs = pkg.debug_knobs(0)
+    try:
+        for name, mode in (("default", 0), ("householder", 1)):
+            # 4096: every frame's line launch is chained; 8192 (default mode only): every whitened update takes its factor form, which
+            # hands updates with a near-dependent prior over to the re-run — in frames whose line launch IS chained (the first update
+            # after the initialisation, the one this drive rejects by itself, has a point pool above max_msckf and is never chained)
+            pkg.debug_knobs(4096 | (8192 if mode == 0 else 0))
+            # (max_msckf 250: the first update after the initialisation pools ~190 features, and a point pool above max_msckf is not chained)
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), dst, str(tmp_path / f"traj_l_{name}.txt"), max_msckf=250))
+            op.est.cam.use_lines = True
+            seen, batches = [], []
+            init, count, count_l = system.SystemManager.__init__, system.SystemManager._count_points, system.SystemManager._count_lines
+
+            def init2(self, *a, _init=init, _mode=mode, **k):
+                _init(self, *a, **k)
+                self.ctx.update_compression_mode(_mode)
+
+            def count2(self, res, _count=count, _seen=seen, _b=batches):
+                _seen.append(self.ctx.update_compression_mode()[1])
+                _b.append(("points", int(res["n_pool"]), int(res["n_msckf"])))
+                return _count(self, res)
+
+            def count3(self, res, _count=count_l, _b=batches):
+                _b.append(("lines", int(res["n_pool"]), int(res["n_lines"])))
+                return _count(self, res)
+            system.SystemManager.__init__, system.SystemManager._count_points, system.SystemManager._count_lines = init2, count2, count3
+            c0, r0 = pkg.chain_count(), pkg.route_counts()
+            try:
+                out[name] = rp.replay(op)
+            finally:
+                system.SystemManager.__init__, system.SystemManager._count_points, system.SystemManager._count_lines = init, count, count_l
+            # (with lines on the frame's last update is the line update: the routes are counted by the library, plv_route_counts)
+            routes[name], chained[name], line_rows[name] = [a - b for a, b in zip(pkg.route_counts(), r0)], pkg.chain_count() - c0, batches
+    finally:
+        pkg.debug_knobs(prev_knobs)
+    sd_, sh = out["default"][0], out["householder"][0]
+    print("updates by route (index = last_route: 0 none, 2 Householder, 4 whitened, 5 whitened rejected and run again):", routes, " chained line launches:", chained,
+          " largest distance to the Householder route's trajectory: %.3g m" % np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max())
+    assert routes["default"][5] >= 1 and routes["householder"][5] == 0, routes     # a whitened update was rejected and run again ...
+    assert routes["default"][6] >= 1, routes                                      # ... at least once with a chained line launch staged behind it
+    assert chained["default"] >= 0.5 * sd_["line_updates"] > 0, (chained, sd_)     # ... in a replay whose line launches are chained behind the point updates
+    redo_frames = routes["default"][5]
+    print("batches of the first updates (kind, pool, taken):", line_rows["default"][:6])
+    first = next((i for i, (a, b) in enumerate(zip(line_rows["default"], line_rows["householder"])) if a != b), None)
+    if first is not None:
+        print("first differing update:", first, line_rows["default"][max(0, first - 2):first + 3], "against", line_rows["householder"][max(0, first - 2):first + 3])
+    assert sd_["not_psd"] == 0 and sd_["cam_accepted"] == sh["cam_accepted"] and sd_["cam_updates"] == sh["cam_updates"], (sd_, sh)
+    for key in ("line_pool", "lines_triangulated", "lines_accepted", "line_updates"):
+        assert sd_[key] == sh[key], (key, sd_[key], sh[key], redo_frames)
+    assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 2e-3

@@ -2,7 +2,7 @@
 """A/B of the update routes inside ONE process, alternating per iteration (run-to-run and box-to-box drift is larger than the
 difference): SURVEY 8(d)'s update sizing (F = 70 features x 15 observations, then L = 80 lines x 15) through
 plv_build_jacobians_resident + plv_msckf_update_resident, once per compression mode given on the command line.
-usage: python3 tools/ab_update.py [iterations] [modes, e.g. 0,3]"""
+usage: python3 tools/ab_update.py [iterations] [modes, e.g. 0,1]"""
 import importlib.util
 import os
 import sys
@@ -20,7 +20,7 @@ import bench_chain as bc  # noqa: E402
 import synth  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "0,3").split(",")]
+modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
 ctx = pkg.Context(pkg.default_config(752, 480))
 scene = synth.vio_scene(n_clones=15, F=bc.F_FEATS, M=bc.M_OBS, seed=3, noise_px=0.4)
 st, tr = synth.scene_views(pkg, scene)
