@@ -207,7 +207,8 @@ int plv_update_compression_mode(plv_ctx *ctx, int mode, int *last_route, int *la
 void plv_counters(unsigned long long *out8);
 /* (measurement aid) updates collected since the library was loaded, by route: index = plv_update_compression_mode's last_route
  * (0 no compression, 2 Householder, 4 whitened, 5 whitened rejected, then Householder; 1 and 3: unused since round 5); [6] counts
- * the route-5 point updates of plv_camera_try_update that had a chained line launch behind them (which is then withdrawn and redone) */
+ * the route-5 point updates of plv_camera_try_update that had a chained line launch behind them (which is then withdrawn and redone);
+ * [7] the point updates plv_camera_frame had enqueued behind the frame's flow, before its result was known, and that stood */
 void plv_route_counts(unsigned long long *out8);
 /* (test aid) Decision trace.  With it on, plv_camera_update_points (alone or inside plv_camera_try_update / plv_camera_frame) keeps, for
  * every feature of its pool, the values its verdicts were taken on; plv_last_point_decisions returns them for the last update:

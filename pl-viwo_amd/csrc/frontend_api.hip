@@ -325,6 +325,17 @@ int plv_feed_staged(plv_ctx *ctx, int slot) {
 }  // extern "C"
 namespace plv {
 int plv_front_fed_count(plv_ctx *ctx) { return (ctx && ctx->fe_state) ? fe(ctx)->fed : 0; }
+// where the flow launched last (plv_perform_matching_launch, not waited for yet) leaves its results on the device: tracked positions
+// and their normalised coordinates [n][2], the inlier mask [n] (LK status and RANSAC)
+int plv_front_match_device(plv_ctx *ctx, const float **d_p1, const float **d_n1, const uint8_t **d_mask, int *n) {
+  if (!ctx || !ctx->fe_state) return PLV_E_BADARG;
+  FrontState *s = fe(ctx);
+  if (s->pending_n < 10 || !s->pending_ran || !s->io.p) return PLV_E_BADARG;
+  const size_t nn = (size_t)s->pending_n;
+  const char *dp_ = s->io.as<char>();
+  *d_p1 = (const float *)(dp_ + nn * 8), *d_n1 = (const float *)(dp_ + nn * 24), *d_mask = (const uint8_t *)(dp_ + nn * 36), *n = s->pending_n;
+  return PLV_OK;
+}
 const uint8_t *plv_front_level0(plv_ctx *ctx, int which, int *w, int *h) {
   if (!ctx || !ctx->fe_state) return nullptr;
   FrontState *s = fe(ctx);
@@ -463,8 +474,8 @@ int plv_perform_matching_launch(plv_ctx *ctx, int n, const float *pts0, const fl
   const size_t o_p0 = 0, o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36, o_st = nn * 37,
                total = nn * 38;
   TRY(s->io.reserve(total));
-  TRY(ctx->h_pin.reserve(total));
-  char *hp = ctx->h_pin.as<char>();
+  TRY(ctx->h_pin_flow.reserve(total));
+  char *hp = ctx->h_pin_flow.as<char>();
   char *dp_ = s->io.as<char>();
   // No copy commands around the two kernels: lk_kernel reads the points and the initial guesses straight from the pinned buffer
   // (16 B per point, once) and the last kernel of the call copies the results back into it (ransac_select_kernel).
@@ -525,7 +536,7 @@ int plv_perform_matching_wait(plv_ctx *ctx, float *pts1, uint8_t *mask_out, floa
   }
   const size_t nn = (size_t)n;
   const size_t o_p1 = nn * 8, o_n0 = nn * 16, o_n1 = nn * 24, o_it = nn * 32, o_mk = nn * 36;
-  const char *hp = ctx->h_pin.as<char>();
+  const char *hp = ctx->h_pin_flow.as<char>();
   memcpy(pts1, hp + o_p1, nn * 8);
   if (n0) memcpy(n0, hp + o_n0, nn * 8);
   if (n1) memcpy(n1, hp + o_n1, nn * 8);

@@ -309,6 +309,9 @@ typedef short lk_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned __attribute__((aligned(2))) lk_u32a2;  // a 32-bit LDS read at a 16-bit boundary (gfx950 reads LDS unaligned)
 // V: 1 = the lean iteration (below; windows of up to 256 pixels), what launch_lk picks; 0 = the loop of rounds 2-4, kept for the
 // comparison (tools/lk_exp.py: same bits, 80 -> 73 us per launch at workload C).
+// (Round 6, measured and not kept: the window as a compile-time constant — every index of the level set-up a multiply-shift instead of
+// a division sequence — 73.8 us against 72.7 with the run-time window at workload C: the launch is bound by the dependent operations of
+// its slowest point's iterations, not by the set-up's instruction count; see also lk_ahead_kernel.)
 template <int V>
 __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
                                                             const float *__restrict__ pts1_init, float *__restrict__ pts1,
@@ -598,6 +601,278 @@ __global__ void __launch_bounds__(64 * LK4_WAVES) lk_kernel(PyrDesc prev, PyrDes
     }
     nextx = outx;
     nexty = outy;
+  }
+  if (tid == 0) {
+    pts1[2 * pt] = nextx;
+    pts1[2 * pt + 1] = nexty;
+    status[pt] = (uint8_t)st;
+    if (iters_out) iters_out[pt] = iters;
+  }
+  if (n0 && tid < 2) {
+    float xn, yn;
+    undistort_radtan(K.v, tid == 0 ? px0 : nextx, tid == 0 ? py0 : nexty, xn, yn);
+    float *dst = tid == 0 ? n0 : n1;
+    dst[2 * pt] = xn;
+    dst[2 * pt + 1] = yn;
+  }
+}
+
+// lk_kernel<1>'s arithmetic with another schedule of its memory traffic (round 6; windows of up to 256 pixels) —
+// AN EXPERIMENT, selected by PLV_KNOB_LK_AHEAD, measured NO FASTER (tools/lk_exp.py, workload C, 369 points: 74.8 us per launch against
+// 72.7 for lk_kernel<1>; with one iteration per level 28.7 against 27.0): a level's set-up is not waiting for memory.  The launch is as
+// long as its slowest point's chain of dependent operations — 82 iterations of ~0.56 us (wave reduction by DPP, the four partial sums
+// through LDS and a barrier, the 2 x 2 solve in float) + ~3 us per level + ~12 us of launch, dispatch and the closing undistortion.
+// The launch lasts as long as its slowest point, and that point's chain was, per pyramid level: a global read of the template tile,
+// barriers, Scharr planes and the normal matrix, then a global read of the search tile before the first iteration — two dependent
+// memory latencies (~1.5 us each) on each of five levels.  Here
+//  * the template side of EVERY level is done before the first iteration: the tiles of all levels are requested together (one
+//    latency), then Scharr planes, the lanes' template values (kept in LDS per level) and the normal matrices follow from LDS alone;
+//    the top level's search tile is requested with them;
+//  * while a level iterates, the search tile of the level below is on its way into registers (requested around twice the position
+//    the level started from) and is laid into the second tile buffer when the level ends; the level below finds it in place when
+//    its start lies inside it (the usual case: a level moves the estimate by a pixel or two) and reads its own tile as before when not.
+//    The barrier inside the iteration waits for LDS only (s_waitcnt lgkmcnt(0)): a __syncthreads() would wait for the tile as well.
+// Every value that reaches the arithmetic is the one lk_kernel<1> reads: same bits (tools/lk_exp.py, tests/test_gpu_frontend.py).
+__device__ __forceinline__ void lk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ void __launch_bounds__(64 * LK4_WAVES) lk_ahead_kernel(PyrDesc prev, PyrDesc cur, int n, const float *__restrict__ pts0,
+                                                                  const float *__restrict__ pts1_init, float *__restrict__ pts1,
+                                                                  uint8_t *__restrict__ status, int *__restrict__ iters_out, int win,
+                                                                  int max_iters, float eps, CamK K, float *__restrict__ n0,
+                                                                  float *__restrict__ n1) {
+  __shared__ uint8_t tt_all[PLV_MAX_LEVELS][LK_TT][LK_TT + 2];
+  __shared__ short tdx[LK_TT - 2][LK_TT - 2], tdy[LK_TT - 2][LK_TT - 2];
+  __shared__ int2 tpl[PLV_MAX_LEVELS][64 * LK4_WAVES];  // per level and lane: x = Iv | Ix << 16, y = Iy
+  __shared__ int partA_all[PLV_MAX_LEVELS][LK4_WAVES][3];
+  __shared__ unsigned short jtb[2][LK_JT][LK_JT];
+  __shared__ int part[2][LK4_WAVES][2];
+  const int pt = blockIdx.x;
+  if (pt >= n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int W_BITS = 14;
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const float half = (win - 1) * 0.5f;
+  const float ec = fminf(fmaxf(eps, 0.f), 10.f);
+  const double eps2 = (double)ec * (double)ec;
+  const int npx = win * win;
+  const float px0 = pts0[2 * pt], py0 = pts0[2 * pt + 1];
+  const float nx0 = pts1_init[2 * pt], ny0 = pts1_init[2 * pt + 1];
+  const int maxLevel = prev.levels - 1;
+  const bool own = tid < npx;
+  const int wy = own ? tid / win : 0, wx = own ? tid - wy * win : 0;
+  const int tt = win + 3, td = win + 1;
+  const int tile_r = tid >> 3, tile_hx = (tid & 7) * 4;  // this thread's four pixels of a 32 x 32 search tile
+  const int jpad = (LK_JT - win - 1) / 2;
+
+  // ---- every level's template tile (and the top level's search tile) in one round of global reads
+  unsigned lvl_in = 0;  // bit l: the template position of level l lies inside the image's margin (the reference's test)
+  for (int l = 0; l <= maxLevel; ++l) {
+    const float sc = 1.f / (float)(1 << l);
+    const int ipx = (int)floorf(px0 * sc - half), ipy = (int)floorf(py0 * sc - half);
+    if (!(ipx < -win || ipx >= prev.w[l] || ipy < -win || ipy >= prev.h[l])) lvl_in |= 1u << l;
+  }
+  for (int i = tid; i < (maxLevel + 1) * tt * tt; i += 64 * LK4_WAVES) {
+    const int l = i / (tt * tt), r = i - l * tt * tt;
+    if (!((lvl_in >> l) & 1u)) continue;
+    const int ty = r / tt, tx = r - ty * tt;
+    const float sc = 1.f / (float)(1 << l);
+    const int ipx = (int)floorf(px0 * sc - half), ipy = (int)floorf(py0 * sc - half);
+    const int cols = prev.w[l], rows = prev.h[l];
+    tt_all[l][ty][tx] = (prev.base + prev.off[l])[(size_t)reflect101(ipy - 1 + ty, rows) * cols + reflect101(ipx - 1 + tx, cols)];
+  }
+  int jb = 0;                     // the tile buffer the current level reads
+  bool pf_valid = false;          // a tile for the level about to start lies in jtb[jb] at (pf_x0, pf_y0)
+  int pf_x0 = 0, pf_y0 = 0;
+  {
+    const float sc = 1.f / (float)(1 << maxLevel);
+    const int jc = cur.w[maxLevel], jr = cur.h[maxLevel];
+    const int inx = (int)floorf(nx0 * sc - half), iny = (int)floorf(ny0 * sc - half);
+    if (!(inx < -win || inx >= jc || iny < -win || iny >= jr)) {
+      pf_valid = true, pf_x0 = inx - jpad, pf_y0 = iny - jpad;
+      const uint8_t *J = cur.base + cur.off[maxLevel];
+      const int Y = reflect101(pf_y0 + tile_r, jr);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) jtb[0][tile_r][tile_hx + c] = J[(size_t)Y * jc + reflect101(pf_x0 + tile_hx + c, jc)];
+    }
+  }
+  __syncthreads();
+  // ---- Scharr planes, template values and the parts of the normal matrix, level by level, from LDS
+  for (int l = maxLevel; l >= 0; --l) {
+    if (!((lvl_in >> l) & 1u)) continue;  // (uniform)
+    const float sc = 1.f / (float)(1 << l);
+    const float prevx = px0 * sc - half, prevy = py0 * sc - half;
+    const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+    const int cols = prev.w[l], rows = prev.h[l];
+    for (int i = tid; i < td * td; i += 64 * LK4_WAVES) {
+      const int y = i / td, x = i - y * td;
+      const int X = ipx + x, Y = ipy + y;
+      int dx = 0, dy = 0;
+      if (X >= 0 && Y >= 0 && X < cols && Y < rows) {  // derivative plane has a CONSTANT(0) border
+        const uint8_t *r0 = &tt_all[l][y][x], *r1 = &tt_all[l][y + 1][x], *r2 = &tt_all[l][y + 2][x];
+        const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+        const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+        dx = t0p - t0m;
+        dy = (t1m + t1p) * 3 + t1c * 10;
+      }
+      tdx[y][x] = (short)dx;
+      tdy[y][x] = (short)dy;
+    }
+    __syncthreads();
+    const float a = prevx - ipx, b = prevy - ipy;
+    const int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
+    const int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
+    const int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
+    const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    int Iv = 0, Ix = 0, Iy = 0;
+    if (own) {
+      const uint8_t(*T)[LK_TT + 2] = tt_all[l];
+      Iv = DESCALE(T[wy + 1][wx + 1] * iw00 + T[wy + 1][wx + 2] * iw01 + T[wy + 2][wx + 1] * iw10 + T[wy + 2][wx + 2] * iw11, W_BITS - 5);
+      Ix = DESCALE(tdx[wy][wx] * iw00 + tdx[wy][wx + 1] * iw01 + tdx[wy + 1][wx] * iw10 + tdx[wy + 1][wx + 1] * iw11, W_BITS);
+      Iy = DESCALE(tdy[wy][wx] * iw00 + tdy[wy][wx + 1] * iw01 + tdy[wy + 1][wx] * iw10 + tdy[wy + 1][wx + 1] * iw11, W_BITS);
+    }
+    tpl[l][tid] = make_int2((Iv & 0xffff) | (Ix << 16), Iy);  // (0 <= Iv <= 8160, |Ix|, |Iy| <= 4080)
+    const int a11 = wave_sum_i32(Ix * Ix), a12 = wave_sum_i32(Ix * Iy), a22 = wave_sum_i32(Iy * Iy);
+    if (lane == 0) partA_all[l][wave][0] = a11, partA_all[l][wave][1] = a12, partA_all[l][wave][2] = a22;
+    __syncthreads();  // (the planes are rewritten by the next level; the parts are read below)
+  }
+
+  float nextx = nx0, nexty = ny0;
+  int st = 1, iters = 0, slot = 0;
+  for (int level = maxLevel; level >= 0; --level) {
+    const float sc = 1.f / (float)(1 << level);
+    if (level == maxLevel) {
+      nextx = nx0 * sc;
+      nexty = ny0 * sc;
+    } else {
+      nextx = nextx * 2.f;
+      nexty = nexty * 2.f;
+    }
+    const bool had_pf = pf_valid;  // (a tile requested for THIS level; whatever happens to the level, it is used up)
+    const int tx0 = pf_x0, ty0 = pf_y0;
+    pf_valid = false;
+    if (!((lvl_in >> level) & 1u)) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    double sA11 = 0.0, sA12 = 0.0, sA22 = 0.0;
+#pragma unroll
+    for (int w = 0; w < LK4_WAVES; ++w) sA11 += (double)partA_all[level][w][0], sA12 += (double)partA_all[level][w][1], sA22 += (double)partA_all[level][w][2];
+    const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    D = 1.f / D;
+    const int2 tv = tpl[level][tid];
+    const int Iv = tv.x & 0xffff, Ix = tv.x >> 16, Iy = tv.y;
+    nextx -= half;
+    nexty -= half;
+    const int jc = cur.w[level], jr = cur.h[level];
+    const uint8_t *J = cur.base + cur.off[level];
+    int jx0 = 0, jy0 = 0;
+    int lo_x = -(1 << 28), lo_y = lo_x;
+    unsigned span_x = 0, span_y = 0;
+    if (had_pf) {  // the tile requested ahead of this level
+      jx0 = tx0, jy0 = ty0;
+      lo_x = max(jx0, -win), lo_y = max(jy0, -win);
+      span_x = (unsigned)(min(jx0 + LK_JT - win - 1, jc - 1) - lo_x);
+      span_y = (unsigned)(min(jy0 + LK_JT - win - 1, jr - 1) - lo_y);
+    }
+    // the search tile of the level below, around twice this level's start (registers until the level ends)
+    unsigned pfv = 0;
+    bool pf_next = false;
+    int nx0p = 0, ny0p = 0;
+    if (level > 0) {
+      const int jc1 = cur.w[level - 1], jr1 = cur.h[level - 1];
+      const int pinx = (int)floorf((nextx + half) * 2.f - half), piny = (int)floorf((nexty + half) * 2.f - half);
+      if (!(pinx < -win || pinx >= jc1 || piny < -win || piny >= jr1)) {
+        pf_next = true, nx0p = pinx - jpad, ny0p = piny - jpad;
+        const uint8_t *J1 = cur.base + cur.off[level - 1];
+        const int Y = reflect101(ny0p + tile_r, jr1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pfv |= (unsigned)J1[(size_t)Y * jc1 + reflect101(nx0p + tile_hx + c, jc1)] << (8 * c);
+      }
+    }
+    const int lane_off = wy * LK_JT + wx;
+    float pvx = __builtin_inff(), pvy = __builtin_inff(), ddx = 0.f, ddy = 0.f;
+    bool osc = false;
+    for (int j = 0; j < max_iters; ++j) {
+      const float fx = floorf(nextx), fy = floorf(nexty);
+      const int inx = (int)fx, iny = (int)fy;
+      if (((unsigned)(inx - lo_x) > span_x) | ((unsigned)(iny - lo_y) > span_y)) {
+        if (inx < -win || inx >= jc || iny < -win || iny >= jr) {
+          if (level == 0) st = 0;
+          break;
+        }
+        jx0 = inx - jpad;
+        jy0 = iny - jpad;
+        __syncthreads();
+        {
+          const int Y = reflect101(jy0 + tile_r, jr);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) jtb[jb][tile_r][tile_hx + c] = J[(size_t)Y * jc + reflect101(jx0 + tile_hx + c, jc)];
+        }
+        __syncthreads();
+        lo_x = max(jx0, -win), lo_y = max(jy0, -win);
+        span_x = (unsigned)(min(jx0 + LK_JT - win - 1, jc - 1) - lo_x);
+        span_y = (unsigned)(min(jy0 + LK_JT - win - 1, jr - 1) - lo_y);
+      }
+      ++iters;
+      const float fa = nextx - fx, fb = nexty - fy;
+      const float sa = (1.f - fa) * 16384.f, sb = 1.f - fb, la = fa * 16384.f;
+      const unsigned u00 = __float_as_uint(sa * sb + 8388608.f), u01 = __float_as_uint(la * sb + 8388608.f),
+                     u10 = __float_as_uint(sa * fb + 8388608.f);
+      const unsigned u11 = (16384u + 3u * 0x4B000000u) - u00 - u01 - u10;  // (the biases of the three cancel: the weight itself)
+      const unsigned w0 = __builtin_amdgcn_perm(u01, u00, 0x05040100), w1 = __builtin_amdgcn_perm(u11, u10, 0x05040100);
+      int pb1 = 0, pb2 = 0;
+      if (own) {
+        const unsigned short *p = &jtb[jb][0][0] + ((iny - jy0) * LK_JT + (inx - jx0) + lane_off);
+        const unsigned r0 = *(const lk_u32a2 *)p, r1 = *(const lk_u32a2 *)(p + LK_JT);
+        int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, r0), __builtin_bit_cast(lk_short2, w0), 1 << (W_BITS - 5 - 1), false);
+        v = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_short2, r1), __builtin_bit_cast(lk_short2, w1), v, false);
+        const int diff = (v >> (W_BITS - 5)) - Iv;
+        pb1 = diff * Ix;
+        pb2 = diff * Iy;
+      }
+      pb1 = wave_sum_i32_lane63(pb1);
+      pb2 = wave_sum_i32_lane63(pb2);
+      if (lane == 63) part[slot][wave][0] = pb1, part[slot][wave][1] = pb2;  // (the lane the reduction ends in: no broadcast)
+      lk_lds_barrier();
+      double sb1 = 0.0, sb2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < LK4_WAVES; ++w) sb1 += (double)part[slot][w][0], sb2 += (double)part[slot][w][1];
+      slot ^= 1;
+      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      ddx = (A12 * b2 - A22 * b1) * D;
+      ddy = (A12 * b1 - A11 * b2) * D;
+      nextx += ddx;
+      nexty += ddy;
+      if (fma((double)ddx, (double)ddx, (double)ddy * (double)ddy) <= eps2) break;
+      if (fabsf(ddx + pvx) <= 0.01f && fabsf(ddy + pvy) <= 0.01f) {
+        osc = true;
+        break;
+      }
+      pvx = ddx;
+      pvy = ddy;
+    }
+    float outx = nextx + half, outy = nexty + half;
+    if (osc) {
+      outx -= ddx * 0.5f;
+      outy -= ddy * 0.5f;
+    }
+    nextx = outx;
+    nexty = outy;
+    if (level > 0) {  // the tile requested above goes into the other buffer (every lane has left the loop at the same iteration)
+      __syncthreads();
+      if (pf_next) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) jtb[jb ^ 1][tile_r][tile_hx + c] = (unsigned short)((pfv >> (8 * c)) & 255u);
+      }
+      __syncthreads();
+      jb ^= 1;
+      pf_valid = pf_next, pf_x0 = nx0p, pf_y0 = ny0p;
+    }
   }
   if (tid == 0) {
     pts1[2 * pt] = nextx;
@@ -1290,8 +1565,11 @@ int launch_lk(plv_ctx *ctx, const PyrDesc &prev, const PyrDesc &cur, int n, cons
                      d_pts1, d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr)
   if (plv::knob(plv::PLV_KNOB_LK_LEGACY_LOOP))
     LK_LAUNCH(0);
-  else
+  else if (!plv::knob(plv::PLV_KNOB_LK_AHEAD) || win * win > 64 * LK4_WAVES)
     LK_LAUNCH(1);
+  else  // (round 6 experiment, measured no faster: see lk_ahead_kernel) templates of all levels first, search tiles requested a level ahead
+    hipLaunchKernelGGL(lk_ahead_kernel, dim3(n), dim3(64 * LK4_WAVES), 0, ctx->stream, prev, cur, n, d_pts0, pts1_init ? pts1_init : d_pts1, d_pts1,
+                       d_status, d_iters, win, max_iters, eps, K ? *K : none, K ? d_n0 : nullptr, K ? d_n1 : nullptr);
 #undef LK_LAUNCH
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;

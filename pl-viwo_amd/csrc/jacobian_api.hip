@@ -65,6 +65,14 @@ struct StageExtra {  // optional riders of the packed block (one-submission upda
   const uint8_t *flags = nullptr;
   const float *d_uvn = nullptr;
   const uint8_t *d_flags = nullptr;
+  // speculative submission (plv_points_spec): per candidate the flow index, the meta bits and the count of valid older observations
+  // (SpecSelectArgs, jacobian_kernels.hpp); out: where they, the ranges' ends the device writes and the staged arrays it patches sit
+  const int *spec_li = nullptr;
+  const uint8_t *spec_meta = nullptr, *spec_prevalid = nullptr;
+  const int *d_spec_li = nullptr;
+  const uint8_t *d_spec_meta = nullptr, *d_spec_prevalid = nullptr;
+  int *d_obs_end = nullptr;
+  float *d_obs_uv = nullptr;
 };
 int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
                  const int *col_to_state, int ld, JacParams &P, StageExtra *ex = nullptr) {
@@ -90,7 +98,9 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
                o_uv = take(8 * nobs), o_pg = take(24 * F), o_pgf = take(24 * F),
                o_rR = tr->res_R ? take(72 * nobs) : 0, o_rp = tr->res_R ? take(24 * nobs) : 0, o_cols = take(4 * (size_t)k),
                o_xuvn = ex && ex->uvn ? take(8 * nobs) : 0, o_xfl = ex && ex->flags ? take(F) : 0,
-               o_rQ = tr->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = tr->res_Q ? take(4 * (size_t)nobs) : 0;
+               o_rQ = tr->res_Q ? take(288 * (size_t)nobs) : 0, o_rc = tr->res_Q ? take(4 * (size_t)nobs) : 0,
+               o_sli = ex && ex->spec_li ? take(4 * (size_t)F) : 0, o_sme = ex && ex->spec_li ? take(F) : 0, o_spv = ex && ex->spec_li ? take(F) : 0,
+               o_send = ex && ex->spec_li ? take(4 * (size_t)F) : 0;
   const size_t total = off;
   TRY(us->h_jin.reserve(total));
   TRY(us->jin.reserve(total));
@@ -98,6 +108,12 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   memcpy(h + o_cols, col_to_state, 4 * (size_t)k);
   if (ex && ex->uvn) memcpy(h + o_xuvn, ex->uvn, 8 * nobs);
   if (ex && ex->flags) memcpy(h + o_xfl, ex->flags, F);
+  if (ex && ex->spec_li) {
+    memcpy(h + o_sli, ex->spec_li, 4 * (size_t)F);
+    memcpy(h + o_sme, ex->spec_meta, F);
+    memcpy(h + o_spv, ex->spec_prevalid, F);
+    memcpy(h + o_send, tr->obs_ptr + 1, 4 * (size_t)F);  // (overwritten by spec_select_kernel)
+  }
   memcpy(h + o_time, st->clone_time, 8 * N);
   memcpy(h + o_R, st->clone_R, 72 * N);
   memcpy(h + o_p, st->clone_p, 24 * N);
@@ -126,7 +142,7 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   }
   // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
   // few times; what a workgroup reuses it keeps in LDS)
-  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED) && !(ex && ex->spec_li);  // (the speculative batch is patched on the device)
   // (an upload by a kernel of the ctx stream instead of the copy command was measured, alternating frame by frame: no difference)
   if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
@@ -173,6 +189,11 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   if (ex) {
     ex->d_uvn = ex->uvn ? (const float *)(d + o_xuvn) : nullptr;
     ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
+    if (ex->spec_li) {
+      ex->d_spec_li = (const int *)(d + o_sli), ex->d_spec_meta = (const uint8_t *)(d + o_sme), ex->d_spec_prevalid = (const uint8_t *)(d + o_spv);
+      ex->d_obs_end = (int *)(us->jin.as<char>() + o_send), ex->d_obs_uv = (float *)(us->jin.as<char>() + o_uv);
+      P.obs_end = ex->d_obs_end;
+    }
   }
   return PLV_OK;
 }
@@ -192,6 +213,8 @@ struct FusedTri {  // triangulate on the device first and let the Jacobian launc
   const uint8_t *flags;
   int max_sel;
   size_t o_p, o_err, o_ok;  // out: where the results sit in us->tri (p [F][3], err [F], ok [F], contiguous)
+  const plv_points_spec *spec = nullptr;  // speculative submission: the candidates' membership is decided on the device (spec_select_kernel)
+  size_t o_member = 0, o_words = 0;       // out (spec): member [F] and the two words behind ok, part of the mirrored result block
 };
 int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
                     const int *col_to_state, int ld, bool project, FusedTri *ft = nullptr) {
@@ -219,14 +242,30 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     StageExtra ex;
     ex.uvn = ft->uvn;
     ex.flags = ft->flags;
+    if (ft->spec) ex.spec_li = ft->spec->li, ex.spec_meta = ft->spec->meta, ex.spec_prevalid = ft->spec->prevalid;
     TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P, &ex));
     const int nobs = tr->obs_ptr[F];
     const size_t o_pose = 0, o_valid = (size_t)nobs * 96, o_p = (o_valid + nobs + 15) & ~(size_t)15, o_err = o_p + (size_t)F * 24,
-                 o_ok = o_err + (size_t)F * 8, total = o_ok + F + 16;
+                 o_ok = o_err + (size_t)F * 8, o_member = o_ok + F, o_words = (o_member + F + 7) & ~(size_t)7, total = o_words + 16 + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
-    // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel)
-    fuse_tri = project && F <= ft->max_sel && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
+    ft->o_member = o_member, ft->o_words = o_words;
+    // one launch for triangulation + Jacobians + null space while the selection has no cap to enforce (see the kernel); a speculative
+    // batch holds more candidates than the cap, but its pool does not (spec_select_kernel empties every candidate otherwise)
+    fuse_tri = project && (F <= ft->max_sel || ft->spec) && !plv::knob(plv::PLV_KNOB_POINT_TRI_SEPARATE);
+    if (ft->spec) {
+      if (!fuse_tri || plv::knob(plv::PLV_KNOB_INPUTS_PINNED)) {
+        set_last_error("speculative point submission needs the fused triangulation launch");
+        return PLV_E_BADARG;
+      }
+      SpecSelectArgs A{};
+      A.F = F, A.n_flow = ft->spec->n_flow, A.W = ctx->cfg.width, A.H = ctx->cfg.height, A.max_sel = ft->max_sel;
+      A.obs_ptr = P.obs_ptr, A.li = ex.d_spec_li, A.meta = ex.d_spec_meta, A.prevalid = ex.d_spec_prevalid;
+      A.flow_p1 = ft->spec->d_flow_p1, A.flow_n1 = ft->spec->d_flow_n1, A.flow_mask = ft->spec->d_flow_mask;
+      A.obs_uv = ex.d_obs_uv, A.obs_uvn = const_cast<float *>(ex.d_uvn), A.obs_end = ex.d_obs_end;
+      A.sel_flags = const_cast<unsigned char *>(ex.d_flags), A.member = (unsigned char *)(d + o_member), A.words = (int *)(d + o_words);
+      TRY(launch_spec_select(ctx, A));
+    }
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
     tri_opt = ft->opt;
@@ -327,39 +366,46 @@ int plv_jacobian_columns(const plv_state_view *st, const plv_tracks *tr, int *co
 // synchronisation.  `all` carries obs_uvn; flags[f] = the host's part of the selection test.  Returns as plv_msckf_update_resident
 // (PLV_E_NOT_PSD: covariance untouched); p / ok / err (per candidate) and accepted (per candidate, 0 for unselected ones) are filled
 // in both cases.
-int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
-                            const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
-                            double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows,
-                            double *dx, void (*before_wait)(void *), void *before_wait_arg) {
-  if (!ctx || !all || !tri || !flags || !p_out || !ok_out || !err_out || !accepted || !dx || !all->obs_uvn) return PLV_E_BADARG;
+typedef plv_ctx_update_state::PointJob PointJob;
+static PointJob &point_job(plv_ctx *ctx) { return plv_update_state(ctx)->point_job; }
+static hipEvent_t g_ce[3] = {nullptr, nullptr, nullptr};
+
+int plv_points_update_submit(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri, const uint8_t *flags,
+                             int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult, double res_norm_gate,
+                             const plv_points_spec *spec) {
+  if (!ctx || !all || !tri || !flags || !all->obs_uvn) return PLV_E_BADARG;
   (void)hipSetDevice(ctx->device);
   auto *us = plv_update_state(ctx);
+  PointJob &J = point_job(ctx);
+  J = PointJob();
+  std::vector<double> p_dummy(3 * (size_t)std::max(all->n_feat, 1), 0.0);
   plv_tracks t2 = *all;
-  t2.p_FinG = t2.p_FinG_fej = p_out;  // (outputs of the triangulation: the staged copy is never read)
+  t2.p_FinG = t2.p_FinG_fej = p_dummy.data();  // (outputs of the triangulation: the staged copy is never read)
   FusedTri ft{tri, all->obs_uvn, flags, max_sel, 0, 0, 0};
+  ft.spec = spec;
   // PLV_KNOB_CHAIN_EVENTS (with PLV_KNOB_HOST_TIMING): three timed events on the stream — at entry (the stream is idle: stamped at once),
   // behind the Jacobian launch, behind the update's last kernel — to set the device's view of the chain against the host's phases
-  const bool chain_events = plv::knob(plv::PLV_KNOB_CHAIN_EVENTS) && plv::host_phases().on;
-  static hipEvent_t ce[3] = {nullptr, nullptr, nullptr};
-  const auto t_entry = std::chrono::steady_clock::now();
-  if (chain_events) {
-    for (auto &e : ce)
+  J.chain_events = plv::knob(plv::PLV_KNOB_CHAIN_EVENTS) && plv::host_phases().on;
+  J.t_entry = std::chrono::steady_clock::now();
+  if (J.chain_events) {
+    for (auto &e : g_ce)
       if (!e) (void)hipEventCreate(&e);
-    (void)hipEventRecord(ce[0], ctx->stream);
+    (void)hipEventRecord(g_ce[0], ctx->stream);
   }
   plv::HostPhase ph_a("points fused: stage + triangulate + jacobians enqueued");
   TRY(plv_update_gate_prepare(ctx, all->n_feat, 3, k, ld, sigma2, chi2_mult, res_norm_gate, 0));
   TRY(build_on_device(ctx, us, st, &t2, k, col_to_state, ld, true, &ft));
   ph_a.stop();
   plv::frame_mark("@ point Jacobian launch enqueued");
-  if (chain_events) (void)hipEventRecord(ce[1], ctx->stream);
+  if (J.chain_events) (void)hipEventRecord(g_ce[1], ctx->stream);
   us->b_single_use = true;
   const int F = all->n_feat;
-  TRY(us->h_tri.reserve((size_t)F * 33 + 16));
+  const size_t mirror_bytes = spec ? (ft.o_words + 8 - ft.o_p) : (size_t)F * 33;
+  TRY(us->h_tri.reserve(mirror_bytes + 16));
   plv::HostPhase ph_b("points fused: gate .. EKF enqueued");
   // the triangulation results reach the host with the update's result block (copied by its last kernel), or by a copy command when
   // the chain ended another way; either lands before the wait below returns
-  ctx->mirror2_src = us->tri.as<char>() + ft.o_p, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = (size_t)F * 33, ctx->mirror2_taken = false;
+  ctx->mirror2_src = us->tri.as<char>() + ft.o_p, ctx->mirror2_dst = us->h_tri.p, ctx->mirror2_bytes = mirror_bytes, ctx->mirror2_taken = false;
   // (for a line launch chained behind this update, plv_camera_try_update: the commit kernel leaves "state changed" in a device word)
   TRY(us->chain_words.reserve(64));
   us->applied_word = us->chain_words.as<int>();
@@ -371,10 +417,27 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   const bool mirrored = ctx->mirror2_taken;
   ctx->mirror2_src = nullptr, ctx->mirror2_dst = nullptr, ctx->mirror2_bytes = 0, ctx->mirror2_taken = false;
   if (!mirrored)
-    PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, (size_t)F * 33, hipMemcpyDeviceToHost, ctx->stream));
+    PLV_HIP_CHECK(plv::memcpy_async(us->h_tri.p, us->tri.as<char>() + ft.o_p, mirror_bytes, hipMemcpyDeviceToHost, ctx->stream));
   ph_b.stop();
   plv::frame_mark("@ point chain enqueued");
-  if (chain_events) (void)hipEventRecord(ce[2], ctx->stream);
+  if (J.chain_events) (void)hipEventRecord(g_ce[2], ctx->stream);
+  J.pending = true, J.mirrored = mirrored, J.rc = rc, J.F = F, J.spec = spec != nullptr;
+  J.o_p = ft.o_p, J.o_member = ft.o_member, J.o_words = ft.o_words;
+  return PLV_OK;
+}
+
+int plv_points_update_collect(plv_ctx *ctx, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows, double *dx,
+                              void (*before_wait)(void *), void *before_wait_arg, uint8_t *member, int *spec_count, int *spec_over) {
+  if (!ctx || !p_out || !ok_out || !err_out || !accepted || !dx) return PLV_E_BADARG;
+  auto *us = plv_update_state(ctx);
+  PointJob &J = point_job(ctx);
+  if (!J.pending) {
+    set_last_error("plv_points_update_collect: no point update was submitted");
+    return PLV_E_BADARG;
+  }
+  J.pending = false;
+  int rc = J.rc;
+  const int F = J.F;
   plv::HostPhase ph_c("points fused: host work inside the wait");
   if (before_wait) before_wait(before_wait_arg);  // host work of the caller that fits into the wait
   // ... and work that becomes possible DURING the wait (the line pool, once the line worker has finished the frame's feed): the
@@ -394,14 +457,14 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   plv::NsScope ns_pw(plv::counters().points_wait_ns);
   plv::HostPhase ph_d("points fused: wait");
   if (rc == PLV_OK) rc = plv_msckf_update_resident_wait(ctx, accepted, n_rows, dx);  // (ends at the update's last kernel)
-  if (rc != PLV_OK || !mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));      // (the copy command enqueued behind it)
+  if (rc != PLV_OK || !J.mirrored) PLV_HIP_CHECK(plv::stream_sync(ctx->stream));    // (the copy command enqueued behind it)
   ph_d.stop();
   plv::frame_mark("@ point update collected");
-  if (chain_events) {
-    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
-    (void)hipEventSynchronize(ce[2]);
+  if (J.chain_events) {
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - J.t_entry).count();
+    (void)hipEventSynchronize(g_ce[2]);
     float a = 0.f, b = 0.f;
-    if (hipEventElapsedTime(&a, ce[0], ce[1]) == hipSuccess && hipEventElapsedTime(&b, ce[1], ce[2]) == hipSuccess) {
+    if (hipEventElapsedTime(&a, g_ce[0], g_ce[1]) == hipSuccess && hipEventElapsedTime(&b, g_ce[1], g_ce[2]) == hipSuccess) {
       plv::host_phases().add("points fused: DEVICE entry -> Jacobian launch done", a * 1e3);
       plv::host_phases().add("points fused: DEVICE Jacobian done -> last kernel done", b * 1e3);
       plv::host_phases().add("points fused: HOST entry -> results read", host_us);
@@ -411,7 +474,25 @@ int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tr
   memcpy(p_out, h, (size_t)F * 24);
   memcpy(err_out, h + (size_t)F * 24, (size_t)F * 8);
   memcpy(ok_out, h + (size_t)F * 32, (size_t)F);
+  if (J.spec) {
+    if (member) memcpy(member, h + (J.o_member - J.o_p), (size_t)F);
+    const int *w = (const int *)(h + (J.o_words - J.o_p));
+    if (spec_count) *spec_count = w[0];
+    if (spec_over) *spec_over = w[1];
+  } else {
+    if (spec_count) *spec_count = 0;
+    if (spec_over) *spec_over = 0;
+  }
   return rc;
+}
+
+int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
+                            const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2, double chi2_mult,
+                            double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows,
+                            double *dx, void (*before_wait)(void *), void *before_wait_arg) {
+  if (!ctx || !all || !tri || !flags || !p_out || !ok_out || !err_out || !accepted || !dx || !all->obs_uvn) return PLV_E_BADARG;
+  TRY(plv_points_update_submit(ctx, st, all, tri, flags, max_sel, k, col_to_state, ld, sigma2, chi2_mult, res_norm_gate, nullptr));
+  return plv_points_update_collect(ctx, p_out, ok_out, err_out, accepted, n_rows, dx, before_wait, before_wait_arg, nullptr, nullptr, nullptr);
 }
 
 int plv_build_jacobians_resident(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *tr, int k,
@@ -592,7 +673,7 @@ int stage_line_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_vi
   }
   // measurement knob PLV_KNOB_INPUTS_PINNED: no upload — the kernels read the pinned staging block over PCIe (every byte once or a
   // few times; what a workgroup reuses it keeps in LDS)
-  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED);
+  const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED) && !(ex && ex->spec_li);  // (the speculative batch is patched on the device)
   // (an upload by a kernel of the ctx stream instead of the copy command was measured, alternating frame by frame: no difference)
   if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin_l.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = pinned_inputs ? (const char *)h : us->jin_l.as<char>();

@@ -944,7 +944,24 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
   // What the workgroup reads more than once goes to LDS in one round of loads — clone times and columns, its observations' times and
   // image points: a dependent load from memory is 500+ cycles even when it hits, and the bounding-clone search, the row pieces and
   // the triangulation's passes are chains of them.  The pointers are then redirected (same indices as before).
-  const int o0 = P.obs_ptr[f], o1 = P.obs_ptr[f + 1];
+  const int o0 = P.obs_ptr[f], o1 = P.obs_end ? P.obs_end[f] : P.obs_ptr[f + 1];
+  if (P.obs_end && tri.on && o1 - o0 < 2) {
+    // speculative submission: a candidate that is not in the frame's pool (spec_select_kernel) — an empty system, nothing triangulated
+    if (threadIdx.x == 0) {
+      tri.p_out[3 * f] = tri.p_out[3 * f + 1] = tri.p_out[3 * f + 2] = 0.0;
+      tri.ok_out[f] = 0;
+      if (tri.err_out) tri.err_out[f] = 0.0;
+      if (P.tri_dbg) P.tri_dbg[4 * f] = P.tri_dbg[4 * f + 1] = P.tri_dbg[4 * f + 2] = P.tri_dbg[4 * f + 3] = NAN;
+      P.rows[f] = 0;
+    }
+    if (f == 0 && P.cols_out)
+      for (int i = threadIdx.x; i < P.k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
+    if (gate.on) {
+      GateLds &gl0 = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
+      gate_tail(gate, gl0, nullptr, nullptr, f, jsm, 3 + P.k + 1, 3, 0, 0, P.k, P.cols_in);
+    }
+    return;
+  }
   if ((int)threadIdx.x < P.n_clones) s_ct[threadIdx.x] = P.clone_time[threadIdx.x], s_ccol[threadIdx.x] = P.clone_col[threadIdx.x];
   for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) {
     tm_l[i] = P.obs_time[o0 + i];
@@ -2349,6 +2366,60 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
                      g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
   if (jac_stamps().on) TRY_STAMP(jac_stamps().collect(ctx->stream, P.n_feat, 0));
+  return PLV_OK;
+}
+
+// (see SpecSelectArgs, jacobian_kernels.hpp) one workgroup: a pass over the candidates for membership and the pool's size, a second
+// one that writes the ranges, the flags and the survivors' new observation
+__global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
+  __shared__ int s_count;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int f = threadIdx.x; f < A.F; f += blockDim.x) {
+    const int li = A.li[f], m = A.meta[f];
+    bool survived = false;
+    if (li >= 0 && li < A.n_flow && A.flow_mask[li]) {
+      const float x = A.flow_p1[2 * li], y = A.flow_p1[2 * li + 1];
+      survived = !(x < 0 || y < 0 || (int)x >= A.W || (int)y >= A.H);  // REF TrackKLT.cpp:161-163
+    }
+    const int n_old = A.obs_ptr[f + 1] - A.obs_ptr[f] - (li >= 0 ? 1 : 0);  // (a tracked point's range ends with the slot of this frame)
+    const int n_use = n_old + ((survived && (m & 2)) ? 1 : 0);
+    const bool in_pool = ((m & 1) || !((m & 8) || survived)) && n_use >= 2;
+    mine += in_pool ? 1 : 0;
+  }
+  if (mine) atomicAdd(&s_count, mine);
+  __syncthreads();
+  const int count = s_count;
+  const bool over = count > A.max_sel;
+  if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0;
+  for (int f = threadIdx.x; f < A.F; f += blockDim.x) {
+    const int li = A.li[f], m = A.meta[f], o0 = A.obs_ptr[f], o1 = A.obs_ptr[f + 1];
+    bool survived = false;
+    float x = 0.f, y = 0.f;
+    if (li >= 0 && li < A.n_flow && A.flow_mask[li]) {
+      x = A.flow_p1[2 * li], y = A.flow_p1[2 * li + 1];
+      survived = !(x < 0 || y < 0 || (int)x >= A.W || (int)y >= A.H);
+    }
+    const int n_old = o1 - o0 - (li >= 0 ? 1 : 0);
+    const bool with_new = survived && (m & 2);
+    const int n_use = n_old + (with_new ? 1 : 0);
+    const bool in_pool = ((m & 1) || !((m & 8) || survived)) && n_use >= 2;
+    const int n_valid = (int)A.prevalid[f] + ((with_new && (m & 4)) ? 1 : 0);
+    A.member[f] = in_pool ? 1 : 0;
+    A.sel_flags[f] = (in_pool && !over && n_valid >= 2) ? 1 : 0;
+    A.obs_end[f] = (in_pool && !over) ? o0 + n_use : o0;
+    if (in_pool && with_new) {
+      const int o = o0 + n_old;
+      A.obs_uv[2 * o] = x, A.obs_uv[2 * o + 1] = y;
+      A.obs_uvn[2 * o] = A.flow_n1[2 * li], A.obs_uvn[2 * o + 1] = A.flow_n1[2 * li + 1];
+    }
+  }
+}
+int launch_spec_select(plv_ctx *ctx, const SpecSelectArgs &A) {
+  ProfScope ps(ctx->prof, "spec_select_kernel", ctx->stream);
+  hipLaunchKernelGGL(spec_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, A);
+  PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
 

@@ -65,6 +65,11 @@ struct JacParams {
   const double *anc_old;               // [candidates][3]
   const double *anc_tri_p;             // [F][3] of the point launch
   const unsigned char *anc_tri_ok;     // [F]
+  // Speculative submission (round 6, plv_camera_frame): the batch holds EVERY track the frame's flow could send into the pool and was
+  // staged before the flow's result was known; spec_select_kernel, behind the flow on the stream, decides the membership, appends the
+  // frame's own observation to the tracks that survived and leaves the end of every candidate's observation range here (obs_ptr[f] for
+  // a track that is not in the pool: an empty candidate).  null: obs_ptr[f + 1] as staged.
+  const int *obs_end;
   // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
   int use_imu_cov;
   double intr_err_mlt;
@@ -79,6 +84,33 @@ struct CpiParams {  // device pointers; State::cpis as a table sorted by time + 
   double gravity[3];
 };
 int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, double *d_R, double *d_p, unsigned char *d_ok);
+
+// The pool of CamHelper::get_features decided on the device (REF: PL-VIWO/src/update/cam/CamHelper.cpp:630-637 features_containing_older /
+// features_not_containing_newer + :740-775 remove_unusable_measurements, open_vins/ov_core/src/track/TrackKLT.cpp:158-179 the frame's
+// survivors) for a batch of candidates staged before the frame's flow had finished.  Per candidate f (device arrays unless said):
+//   li [F]        index of the track's point in the flow's batch, -1: the track was not tracked into this frame
+//   meta [F]      bit 0: the track holds an observation older than the second-oldest clone (in the pool whatever the flow says)
+//                 bit 1: the frame's own observation would be inside the window (usable), bit 2: ... and has bounding clones
+//                 bit 3: the track holds an observation newer than the previous frame already (a positive camera time offset)
+//   prevalid [F]  the track's observations before this frame that have bounding clones
+// and the flow's outputs flow_p1 / flow_n1 [n][2], flow_mask [n] (RANSAC inlier and LK status), the image size.  A track survives
+// when its point is an inlier inside the image; it is in the pool when it carries bit 0, or neither survived nor carries bit 3; a pool track of fewer
+// than two usable observations is dropped (CamHelper.cpp:766-771).  Outputs: obs_end [F], sel_flags [F] (>= 2 observations with
+// bounding clones), member [F], words [0] = pool size, [1] = 1 when the pool exceeds max_sel — then EVERY candidate is left empty (the
+// selection loop's cap, CamHelper.cpp:651-653, needs the candidates one after the other: the host runs the update the long way) —
+// and the survivors' observation of this frame written into the last slot of their range (time staged by the host).
+struct SpecSelectArgs {
+  int F, n_flow, W, H, max_sel;
+  const int *obs_ptr, *li;
+  const unsigned char *meta, *prevalid;
+  const float *flow_p1, *flow_n1;
+  const unsigned char *flow_mask;
+  float *obs_uv, *obs_uvn;
+  int *obs_end;
+  unsigned char *sel_flags, *member;
+  int *words;
+};
+int launch_spec_select(plv_ctx *ctx, const SpecSelectArgs &A);
 
 int launch_jacobians(plv_ctx *ctx, const JacParams &P);
 struct GatherArgs;

@@ -116,6 +116,7 @@ unsigned long long plv_chain_count(void) { return plv::counters().chained.load()
 void plv_route_counts(unsigned long long *out8) {
   if (!out8) return;
   for (int i = 0; i < 8; ++i) out8[i] = plv::counters().route[i].load();
+  out8[7] = plv::counters().speculated.load();  // (point updates enqueued behind the frame's flow and used as they ran)
 }
 unsigned plv_debug_knobs(long long set) {
   const unsigned prev = plv::knobs().load();
@@ -267,6 +268,7 @@ void plv_ctx_destroy(plv_ctx *ctx) {
   if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   ctx->h_pin.release();
+  ctx->h_pin_flow.release();
   ctx->h_pin_l.release();
   ctx->h_done.release();
   plv_ctx_update_state *us = nullptr;

@@ -43,6 +43,7 @@ struct Counters {
   // the line worker's side: post -> wake-up, the wait for the edge maps, chain walk + segment growth, feed post -> start, the feed
   std::atomic<unsigned long long> w_wake_ns{0}, w_maps_ns{0}, w_extract_ns{0}, w_feed_start_ns{0}, w_feed_ns{0};
   std::atomic<unsigned long long> chained{0};  // line launches enqueued behind a running point update (plv_chain_count)
+  std::atomic<unsigned long long> speculated{0};  // point updates enqueued behind the frame's flow and used (plv_route_counts[7])
   std::atomic<unsigned long long> route[8] = {};  // collected updates by plv_ctx_update_state::last_route (plv_route_counts)
 };
 inline Counters &counters() {
@@ -93,7 +94,9 @@ enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_
                   PLV_KNOB_ALLOC_DEBUG = 1u << 19,    // every (re)allocation of a library buffer with a backtrace
                   PLV_KNOB_HOST_FAULTS = 1u << 20,    // HostPhase counts minor page faults instead of time
                   PLV_KNOB_LK_LEGACY_LOOP = 1u << 21, // lk_kernel<0>: the iteration of rounds 2-4 (tools/lk_exp.py; same bits, slower)
-                  PLV_KNOB_LINE_LABELS_OFF = 1u << 22 };  // the line detector's host stage walks the edge map as one sequence (rounds 2-4) instead of by labelled components
+                  PLV_KNOB_LINE_LABELS_OFF = 1u << 22,
+                  PLV_KNOB_LK_AHEAD = 1u << 23,
+                  PLV_KNOB_NO_SPECULATION = 1u << 24 };    // plv_camera_frame submits the point update after the flow's result has reached the host (rounds 1-5), not behind the flow          // lk_ahead_kernel (round 6 experiment: all levels' templates first, search tiles a level ahead; same bits, no faster)  // the line detector's host stage walks the edge map as one sequence (rounds 2-4) instead of by labelled components
 // The mask starts from PLV_DEBUG_KNOBS in the environment (the library's only measurement variable; plv_debug_knobs changes it at run time)
 inline std::atomic<unsigned> &knobs() {
   static std::atomic<unsigned> k{getenv("PLV_DEBUG_KNOBS") ? (unsigned)strtoul(getenv("PLV_DEBUG_KNOBS"), nullptr, 0) : 0u};
@@ -481,6 +484,8 @@ struct plv_ctx {
   bool prior_pending = false;  // plv_prior_prefetch started the prior factor for the update about to be launched (k = prior_k)
   int prior_k = 0;
   plv::PinBuf h_pin;
+  plv::PinBuf h_pin_flow;  // points in / results out of the flow (plv_perform_matching_launch / _wait): a block of its own since round 6 — the point
+                           // update enqueued behind the flow (Tracker::Spec) may write ITS result block (h_pin) before the host has read the flow's
   plv::PinBuf h_pin_l;  // result block of a LINE update (fdim 6): the point update's block may still be unread when the line gate writes
   plv::PinBuf &res_pin(int fdim) { return fdim == 6 ? h_pin_l : h_pin; }
   // What a line launch chained behind the point update needs beyond its own inputs (JacParams::chain_dx ...): filled by

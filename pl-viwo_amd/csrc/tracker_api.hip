@@ -53,6 +53,23 @@ struct Tracker {
   // plv_decision_trace: the last point update's pool, feature by feature (plv_last_point_decisions)
   std::vector<uint64_t> dec_ids;
   std::vector<double> dec_vals;  // [pool][PLV_DECISION_VALUES]
+  // Speculative submission of the point update (round 6, plv_camera_frame): while the frame's flow runs on the device, every track that
+  // flow could send into the update's pool is staged and the whole update chain is enqueued behind the flow; a kernel decides the
+  // membership from the flow's result (spec_select_kernel).  plv_camera_update_points, which forms the pool on the host as before (it
+  // keeps the database), then finds its update already running.
+  const plv_state_view *spec_st = nullptr;        // set by plv_camera_frame around the feed: the update this frame will ask for
+  const plv_update_options *spec_opt = nullptr;
+  struct Spec {
+    bool active = false;                          // a speculative batch is on the stream (not collected yet)
+    double t_prev_frame = 0, state_time = 0, dt = 0, t_oldest = 0, t_oldest2 = 0;   // what the batch was staged for
+    int n_clones = 0, max_msckf = 0, max_obs = 0, k = 0, F = 0;
+    std::unordered_map<uint64_t, int> index;      // track id -> candidate
+    std::vector<uint64_t> ids;
+    std::vector<int> ptr, li, cols;
+    std::vector<uint8_t> meta, prevalid, flags;
+    std::vector<double> ot;
+    std::vector<float> ouv, ouvn;
+  } spec;
   std::mutex mtx;
 };
 
@@ -151,6 +168,127 @@ int plv_tracker_feed_downsampled(plv_ctx *ctx, double timestamp, const uint8_t *
   return tracker_feed_fed(ctx, T, timestamp, mask ? small_mask.data() : nullptr);
 }
 
+static bool has_bounding_poses(const plv_state_view &st, double t);
+extern "C++" {
+namespace plv { int plv_front_match_device(plv_ctx *ctx, const float **d_p1, const float **d_n1, const uint8_t **d_mask, int *n); }  // frontend_api.hip
+}
+// Stages every track the frame's flow could send into the point update's pool and enqueues the update behind the flow (Tracker::Spec).
+// Called with T->mtx held, between the flow's launch and the wait for it; tp[i]: the database track of flow point i (or null).
+// Anything unusual leaves spec.active false: plv_camera_update_points then submits the update itself, as it always did.
+static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, const uint64_t *flow_ids, Track *const *tp) {
+  Tracker::Spec &S = T->spec;
+  S.active = false;
+  const plv_state_view *st = T->spec_st;
+  const plv_update_options *opt = T->spec_opt;
+  if (plv::knob(plv::PLV_KNOB_NO_SPECULATION) || !st || !opt || opt->cpi || opt->max_slam > 0 || opt->n_slam > 0 || st->n_clones < 4 || opt->max_msckf < 1 ||
+      opt->max_obs < 2 || ctx->cov_n < 1 || ctx->decision_trace || n_flow < 10 || ctx->prof.on)
+    return;
+  {
+    const plv_ctx_update_state *us0 = plv_update_state(ctx);
+    if (us0->compress_mode != 0 || us0->graph_mode) return;  // (the chain must need no host decision: the whitened route)
+  }
+  plv::HostPhase ph("speculative point update: candidates staged + chain enqueued");
+  const double dt = st->cam_dt, t_oldest = st->clone_time[0], t_oldest2 = st->clone_time[1];
+  auto has_bounding = bounding_memo([st](double tq) { return has_bounding_poses(*st, tq); });
+  const double tm_new = t_now + dt;
+  const bool new_usable = !(tm_new > opt->state_time + st->dt_exp) && !(tm_new < t_oldest - st->dt_exp);
+  const bool new_bounded = new_usable && has_bounding(tm_new);
+  if (!(t_now > opt->t_prev_frame - dt)) return;  // (a surviving track counts as "seen in the newest frame": CamHelper.cpp:635, the usual case)
+  // flow index of every live track
+  std::unordered_map<const Track *, int> live;
+  live.reserve((size_t)n_flow * 2);
+  for (int i = 0; i < n_flow; ++i)
+    if (tp[i]) live.emplace(tp[i], i);
+  struct C {
+    uint64_t id;
+    const Track *tr;
+    int li, keep;
+    uint8_t meta, prevalid;
+  };
+  std::vector<C> cand;
+  cand.reserve(T->db.size());
+  for (const auto &kv : T->db) {
+    const Track &tr = kv.second;
+    bool older = false, newer_old = false;
+    int keep = 0, pv = 0;
+    for (double t : tr.t) {
+      older = older || t < t_oldest2 - dt;
+      newer_old = newer_old || t > opt->t_prev_frame - dt;
+      const double tm = t + dt;
+      if (tm > opt->state_time + st->dt_exp) return;  // (an observation newer than the window: the long way handles the hand-back)
+      if (tm < t_oldest - st->dt_exp) continue;
+      ++keep;
+      pv += has_bounding(tm) ? 1 : 0;
+    }
+    const auto lv = live.find(&tr);
+    const int li = lv == live.end() ? -1 : lv->second;
+    if (!older && newer_old) continue;  // never in the pool: in the pool = older || !(newer_old || survived)
+    if (keep + (li >= 0 && new_usable ? 1 : 0) < 2) continue;                      // cannot reach two usable observations
+    if (pv > 255) return;
+    cand.push_back(C{kv.first, &tr, li, keep,
+                     (uint8_t)((older ? 1 : 0) | (new_usable ? 2 : 0) | (new_bounded ? 4 : 0) | (newer_old ? 8 : 0)), (uint8_t)pv});
+  }
+  if (cand.empty()) return;
+  std::sort(cand.begin(), cand.end(), [](const C &a, const C &b) { return a.keep != b.keep ? a.keep > b.keep : a.id < b.id; });
+  const int F = (int)cand.size();
+  S.index.clear();
+  S.ids.resize(F), S.ptr.assign(F + 1, 0), S.li.resize(F), S.meta.resize(F), S.prevalid.resize(F), S.flags.assign(F, 0);
+  int most_valid = 0;
+  for (int f = 0; f < F; ++f) {
+    S.ptr[f + 1] = S.ptr[f] + cand[f].keep + (cand[f].li >= 0 ? 1 : 0);
+    most_valid = std::max(most_valid, (int)cand[f].prevalid + ((cand[f].li >= 0 && new_bounded) ? 1 : 0));
+  }
+  if (most_valid > opt->max_obs) return;  // (the two-step route of over-long tracks)
+  const int nobs = S.ptr[F];
+  S.ot.resize(nobs), S.ouv.resize(2 * (size_t)nobs), S.ouvn.resize(2 * (size_t)nobs);
+  for (int f = 0; f < F; ++f) {
+    const C &c = cand[f];
+    const Track &tr = *c.tr;
+    S.ids[f] = c.id, S.li[f] = c.li, S.meta[f] = c.meta, S.prevalid[f] = c.prevalid;
+    S.index.emplace(c.id, f);
+    int o = S.ptr[f];
+    for (size_t i = 0; i < tr.t.size(); ++i) {
+      if (tr.t[i] + dt < t_oldest - st->dt_exp) continue;
+      S.ot[o] = tr.t[i];
+      S.ouv[2 * o] = tr.uv[2 * i], S.ouv[2 * o + 1] = tr.uv[2 * i + 1];
+      S.ouvn[2 * o] = tr.uvn[2 * i], S.ouvn[2 * o + 1] = tr.uvn[2 * i + 1];
+      ++o;
+    }
+    if (c.li >= 0) {  // the slot of this frame's observation: the time now, the image points by the device
+      S.ot[o] = t_now;
+      S.ouv[2 * o] = S.ouv[2 * o + 1] = S.ouvn[2 * o] = S.ouvn[2 * o + 1] = 0.f;
+    }
+  }
+  std::vector<double> pf(3 * (size_t)F, 0.0);
+  plv_tracks all{};
+  all.n_feat = F;
+  all.obs_ptr = S.ptr.data();
+  all.obs_time = S.ot.data();
+  all.obs_uv = S.ouv.data();
+  all.obs_uvn = S.ouvn.data();
+  all.p_FinG = all.p_FinG_fej = pf.data();
+  S.cols.resize(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
+  int k = 0;
+  if (plv_jacobian_columns(st, &all, S.cols.data(), (int)S.cols.size(), &k) != PLV_OK || k < 1) return;
+  plv_points_spec sp{};
+  sp.n_flow = n_flow, sp.li = S.li.data(), sp.meta = S.meta.data(), sp.prevalid = S.prevalid.data();
+  int n_dev = 0;
+  if (plv::plv_front_match_device(ctx, &sp.d_flow_p1, &sp.d_flow_n1, &sp.d_flow_mask, &n_dev) != PLV_OK || n_dev != n_flow) return;
+  (void)flow_ids;
+  ctx->gate_rows_hint = 2 * most_valid;
+  if (plv_points_update_submit(ctx, st, &all, &opt->tri, S.flags.data(), opt->max_msckf, k, S.cols.data(), 2 * opt->max_obs,
+                               st->sigma_pix * st->sigma_pix, opt->chi2_mult, 3.0, &sp) != PLV_OK) {
+    // (nothing usable was enqueued: whatever the failed call left on the stream works on empty or stale candidates and commits nothing
+    //  it was not told to; the long way follows)
+    plv_update_state(ctx)->point_job.pending = false;
+    return;
+  }
+  S.active = true;
+  S.F = F, S.k = k;
+  S.t_prev_frame = opt->t_prev_frame, S.state_time = opt->state_time, S.dt = dt, S.t_oldest = t_oldest, S.t_oldest2 = t_oldest2;
+  S.n_clones = st->n_clones, S.max_msckf = opt->max_msckf, S.max_obs = opt->max_obs;
+}
+
 // the rest of TrackKLT::feed_monocular once the image is equalised and its pyramid built
 extern "C" int plv_line_edges_fork(plv_ctx *ctx);         // line_api.hip
 extern "C" void plv_line_defer_finish(plv_ctx *ctx, int on);
@@ -235,6 +373,8 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
         __builtin_prefetch(&tr.uvn.back() + 1, 1);
       }
     }
+    // the frame's point update, enqueued behind the flow before its result is known (see Tracker::Spec)
+    if (T->spec_st && T->spec_opt && !mask) spec_submit(ctx, T, timestamp, n, ids.data(), tp.data());
     plv::NsScope ns_wait(plv::counters().flow_wait_ns);
     TRY(plv_perform_matching_wait(ctx, pts_new.data(), mask_ll.data(), nullptr, n1.data(), nullptr));
   }
@@ -631,8 +771,79 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
     }
     for (size_t i = 0; i < c.tr.t.size(); ++i) give_back(c.id, c.tr.t[i], &c.tr.uv[2 * i], &c.tr.uvn[2 * i]);
   };
+  // ---- this frame's update may be on the stream already (Tracker::Spec: enqueued behind the flow by the feed, its pool decided on the
+  // device).  The pool above is the same one — formed from the database as always — and says which candidates' results to read.
+  Tracker::Spec &S = T->spec;
+  bool spec_done = false;
+  std::vector<double> s_pf, s_err;
+  std::vector<uint8_t> s_ok, s_acc;
+  int s_rows = 0, s_status = PLV_OK;
+  if (S.active) {
+    S.active = false;
+    ph_pool.stop();
+    rx_get.stop();
+    const int Fp0 = (int)pool.size();
+    const bool same = S.t_prev_frame == opt->t_prev_frame && S.state_time == opt->state_time && S.dt == dt && S.n_clones == st->n_clones &&
+                      S.t_oldest == t_oldest && S.t_oldest2 == t_oldest2 && S.max_msckf == opt->max_msckf && S.max_obs == opt->max_obs && !opt->cpi &&
+                      opt->max_slam == 0 && opt->n_slam == 0;
+    std::vector<int> cand_of(Fp0, -1);
+    bool known = true;
+    for (int f = 0; f < Fp0; ++f) {
+      const auto it = S.index.find(pool[f].id);
+      if (it == S.index.end()) known = false;
+      else cand_of[f] = it->second;
+    }
+    T->chain_index.clear();
+    T->chain_ok = same && known && Fp0 <= opt->max_msckf;  // (the selection loop cannot reach its cap: spec_select_kernel's own test)
+    if (T->chain_ok && T->early_lines)
+      for (int f = 0; f < Fp0; ++f) {
+        int v = 0;
+        for (double t : pool[f].tr.t) v += has_bounding(t + dt);
+        if (v >= 2) T->chain_index.emplace(pool[f].id, cand_of[f]);  // (the chained line launch reads the candidates' triangulation results)
+      }
+    std::vector<double> cp(3 * (size_t)S.F), ce(S.F);
+    std::vector<uint8_t> cok(S.F), cacc(S.F), cmem(S.F);
+    int count = 0, over = 0, nrows = 0;
+    int rc_s;
+    {
+      plv::RoctxRange rx_upd("[Time-Cam] MSCKF update");
+      plv::HostPhase ph_dev("update_points: device submission + wait");
+      rc_s = plv_points_update_collect(ctx, cp.data(), cok.data(), ce.data(), cacc.data(), &nrows, dx, start_detection_ahead, ctx, cmem.data(), &count, &over);
+    }
+    T->chain_ok = false;
+    auto fail = [&](const char *why) {
+      plv::set_last_error("speculative point update: %s (host pool %d, device pool %d%s)", why, Fp0, count, over ? ", over the cap" : "");
+      for (Cand &c : pool) give_back_all(c);
+      return finish(PLV_E_DEVICE);
+    };
+    if (!same) return fail("the batch was staged for another update than the one asked for");
+    if (over || Fp0 > opt->max_msckf) {
+      // the pool exceeds max_msckf: the device left every candidate empty and updated nothing; the long way below
+      if (!(over && Fp0 > opt->max_msckf && count == Fp0)) return fail("host and device disagree on the pool's size");
+      if (plv::host_phases().on) plv::host_phases().add("speculative point update: pool over the cap, run again the long way (count)", 1.0);
+    } else {
+      if (rc_s != PLV_OK && rc_s != PLV_E_NOT_PSD) {
+        for (Cand &c : pool) give_back_all(c);
+        return finish(rc_s);
+      }
+      if (!known || count != Fp0) return fail("host and device disagree on the pool");
+      for (int f = 0; f < Fp0; ++f)
+        if (!cmem[cand_of[f]]) return fail("a track of the host's pool is not in the device's");
+      s_pf.resize(3 * (size_t)Fp0), s_err.resize(Fp0), s_ok.resize(Fp0), s_acc.resize(Fp0);
+      for (int f = 0; f < Fp0; ++f) {
+        const int c = cand_of[f];
+        std::copy(cp.begin() + 3 * (size_t)c, cp.begin() + 3 * (size_t)c + 3, s_pf.begin() + 3 * (size_t)f);
+        s_err[f] = ce[c], s_ok[f] = cok[c], s_acc[f] = cacc[c];
+      }
+      s_rows = nrows;
+      s_status = rc_s == PLV_E_NOT_PSD ? rc_s : PLV_OK;
+      if (rc_s == PLV_E_NOT_PSD) std::fill(dx, dx + ctx->cov_n, 0.0);  // EKFUpdate returned false: nothing changed
+      spec_done = true;
+      ++plv::counters().speculated;
+    }
+  }
   if (pool.empty()) {
-    std::fill(dx, dx + ctx->cov_n, 0.0);
+    if (!spec_done) std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);
   }
   // ---- triangulate the whole pool in one call (the reference goes feature by feature until the cap; a
@@ -692,7 +903,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   }
   const int nobs = ptr[Fp];
   if (nobs == 0) {
-    std::fill(dx, dx + ctx->cov_n, 0.0);
+    if (!spec_done) std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);
   }
   std::vector<double> ot(nobs), pf(3 * (size_t)Fp), err(Fp);
@@ -735,7 +946,15 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   plv::HostPhase ph_dev("update_points: device submission + wait");
   std::vector<uint8_t> acc_all(Fp, 0);
   bool fused_ran = false;
-  if (fused) {
+  if (fused && spec_done) {  // the update ran behind the flow: its results, candidate by candidate
+    std::copy(s_pf.begin(), s_pf.end(), pf.begin());
+    std::copy(s_err.begin(), s_err.end(), err.begin());
+    std::copy(s_ok.begin(), s_ok.end(), ok.begin());
+    std::copy(s_acc.begin(), s_acc.end(), acc_all.begin());
+    n_rows = s_rows;
+    res->status = s_status;
+    fused_ran = true;
+  } else if (fused) {
     std::vector<uint8_t> flags(Fp);
     bool any = false;
     for (int f = 0; f < Fp; ++f) any = (flags[f] = valid_n[f] >= 2) || any;
@@ -1151,10 +1370,30 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
   if (plv::host_phases().on)
     plv::frame_t0_ns().store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
   plv::RoctxRange rx_feed("[Time-Cam] feed measurement");
+  // (round 6) with an update to follow, the feed enqueues that update behind the frame's flow (Tracker::Spec); whatever happens
+  // between here and plv_camera_update_points, a batch that was enqueued is collected before the call returns (SpecGuard)
+  Tracker *Tf = trk(ctx);
+  struct SpecGuard {
+    plv_ctx *c;
+    Tracker *T;
+    ~SpecGuard() {
+      T->spec_st = nullptr, T->spec_opt = nullptr;
+      if (!T->spec.active) return;
+      T->spec.active = false;  // (an early exit: the update ran, nobody reads it; the covariance on the device is what it left)
+      const int F = T->spec.F, n = c->cov_n;
+      std::vector<double> p(3 * (size_t)F), e(F), dx((size_t)std::max(n, 1));
+      std::vector<uint8_t> ok(F), acc(F);
+      int rows = 0;
+      (void)plv_points_update_collect(c, p.data(), ok.data(), e.data(), acc.data(), &rows, dx.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
+  } spec_guard{ctx, Tf};
+  Tf->spec.active = false;
+  if (io->update && io->update->opt_points && io->update->opt_points->max_slam == 0) Tf->spec_st = st, Tf->spec_opt = io->update->opt_points;
   if (io->slot >= 0)
     TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
   else
     TRY(plv_tracker_feed(ctx, io->timestamp, io->img, io->stride, io->mask));
+  Tf->spec_st = nullptr, Tf->spec_opt = nullptr;
   const bool lines = io->use_lines != 0;
   if (lines) {
     double vps[6];

@@ -1,5 +1,6 @@
 // update_state.hpp — per-ctx state of the update side shared by plv_api.hip and jacobian_api.hip.
 #pragma once
+#include <chrono>
 #include <vector>
 
 #include "plv_ctx.hpp"
@@ -91,13 +92,39 @@ struct plv_ctx_update_state {
   plv::DevBuf chain_words;      // home of applied_word
   int *applied_word = nullptr;  // device word ekf_commit_kernel sets to 1 when the point update changed the state (0: dx is not to be applied)
   bool applied_armed = false;   // ... and the last point launch ended in that kernel with the word as its argument
+  // a submitted point update between plv_points_update_submit and plv_points_update_collect
+  struct PointJob {
+    bool pending = false, mirrored = false, chain_events = false, spec = false;
+    int rc = 0, F = 0;
+    size_t o_p = 0, o_member = 0, o_words = 0;
+    std::chrono::steady_clock::time_point t_entry;
+  } point_job;
 };
 plv_ctx_update_state *plv_update_state(plv_ctx *ctx);
 
 extern "C" int plv_update_gate_prepare(plv_ctx *ctx, int F, int fdim, int k, int ld, double sigma2, double chi2_mult, double res_norm_gate, int probe);  // plv_api.hip
 extern "C" int plv_prior_prefetch(plv_ctx *ctx, int phase, const int *d_cols, int k, int F, int mp_max);  // plv_api.hip
 
+// Speculative submission of the point update (round 6): host arrays per candidate + where the flow leaves its results on the device
+// (SpecSelectArgs, jacobian_kernels.hpp).  The candidates' observation ranges end with a slot for the frame's own observation when
+// li >= 0 (time staged, image point and normalised point written by the device).
+struct plv_points_spec {
+  int n_flow;
+  const int *li;
+  const uint8_t *meta, *prevalid;
+  const float *d_flow_p1, *d_flow_n1;
+  const uint8_t *d_flow_mask;
+};
 // internal entry points of jacobian_api.hip used by the one-call camera updates (tracker_api.hip, line_api.hip)
+// plv_points_update_fused = plv_points_update_submit (everything enqueued: upload, [spec_select,] triangulation + Jacobians + null space +
+// gate, compression, EKFUpdate) + plv_points_update_collect (host work inside the wait, the wait, results).  With `spec` the batch is
+// the speculative one; collect then also returns the device's membership (member [F], may be null) and *spec_over (1: the pool exceeded
+// max_sel and every candidate was left empty — nothing was updated, the caller runs the update the long way).
+extern "C" int plv_points_update_submit(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
+                                        const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
+                                        double chi2_mult, double res_norm_gate, const plv_points_spec *spec);
+extern "C" int plv_points_update_collect(plv_ctx *ctx, double *p_out, uint8_t *ok_out, double *err_out, uint8_t *accepted, int *n_rows, double *dx,
+                                         void (*before_wait)(void *), void *before_wait_arg, uint8_t *member, int *spec_count, int *spec_over);
 extern "C" int plv_points_update_fused(plv_ctx *ctx, const plv_state_view *st, const plv_tracks *all, const plv_tri_options *tri,
                                        const uint8_t *flags, int max_sel, int k, const int *col_to_state, int ld, double sigma2,
                                        double chi2_mult, double res_norm_gate, double *p_out, uint8_t *ok_out, double *err_out,

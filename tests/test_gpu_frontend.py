@@ -89,6 +89,30 @@ def test_lk_bit_exact_vs_oracle(pkg, fo, seq, win):
     c.close()
 
 
+@pytest.mark.parametrize("win", [15, 9])
+def test_lk_ahead_variant_is_the_same_flow(pkg, fo, seq, win):
+    """lk_ahead_kernel (PLV_KNOB_LK_AHEAD = 1 << 23; round 6's experiment: the template side of every pyramid level before the first
+    iteration, search tiles requested a level ahead — measured no faster, kept behind the knob) returns the bits of lk_kernel<1>,
+    border / out-of-image / flat points and large initial errors (tile re-staged, requested tile missed) included."""
+    w, h, frames, warps = seq
+    c = _ctx(pkg, w, h, win_size=win)
+    c.feed_image(frames[0])
+    c.feed_image(frames[1])
+    pts0 = synth.grid_points(w, h, 250, seed=3, border=12)
+    pts0[:6] = [[2.5, 3.5], [w - 2.0, h - 3.0], [w + 30.0, 50.0], [-30.0, -30.0], [0.0, 0.0], [w - 1.0, h - 1.0]]
+    init = pts0.copy()
+    init[10:60] += np.random.default_rng(1).uniform(-25, 25, (50, 2)).astype(np.float32)
+    ref = c.lk_track(pts0, init)
+    prev = pkg.debug_knobs(1 << 23)
+    try:
+        got = c.lk_track(pts0, init)
+    finally:
+        pkg.debug_knobs(prev)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    c.close()
+
+
 @pytest.mark.parametrize("win", [15, 21])
 def test_lk_large_motion_tile_restage(pkg, fo, win):
     """Initial guesses far from the truth force the 32x32 search tile to be re-staged (a 21 x 21 window leaves it 10 pixels of slack)."""

@@ -299,25 +299,45 @@ def test_covariance_pivots_follow_the_cpu_oracle(pkg, avenue_dataset_d, tmp_path
 def test_one_call_try_update_equals_the_two_calls(pkg, street_dataset, tmp_path, monkeypatch):
     """plv_camera_try_update (point update, dx applied inside the library, line update, dx applied; the point half's database
     hand-back deferred into the line update's wait) against plv_camera_update_points / _lines with the dx applied by the driver:
-    the same filter, bit for bit."""
+    the same filter, bit for bit.  plv_camera_frame adds the feed to the call; with its point update submitted after the flow's result
+    has reached the host (rounds 1-5: knob 1 << 24) it is the same filter bit for bit as well, and with the update enqueued BEHIND the
+    flow (round 6, the default: every track the flow could send into the pool is staged, spec_select_kernel decides) the same filter to
+    rounding — the batch holds the pool's candidates in another order and over a superset of its columns — with identical counts."""
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     system = importlib.import_module("plviwo_amd.system")
-    runs = {}
+    runs, speculated = {}, {}
     # plv_camera_frame (feed + try_update in one call) / plv_camera_try_update after separate feeds / the two update calls
-    for mode, (update, frame) in (("frame", (True, True)), ("try_update", (True, False)), ("two_calls", (False, False))):
+    for mode, (update, frame, knobs) in (("frame", (True, True, 0)), ("frame_no_speculation", (True, True, 1 << 24)), ("try_update", (True, False, 0)),
+                                         ("two_calls", (False, False, 0))):
         monkeypatch.setattr(system.SystemManager, "one_call_update", update)
         monkeypatch.setattr(system.SystemManager, "one_call_frame", frame)
         op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{mode}.txt")))
         op.est.cam.use_lines = True
-        runs[mode] = rp.replay(op)
+        prev, r0 = pkg.debug_knobs(knobs), pkg.route_counts()[7]
+        try:
+            runs[mode] = rp.replay(op)
+        finally:
+            pkg.debug_knobs(prev)
+        speculated[mode] = pkg.route_counts()[7] - r0
     s0, t0, p0 = runs["two_calls"]
     assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
-    for mode in ("frame", "try_update"):
+    for mode in ("frame_no_speculation", "try_update"):
         s1, t1, p1 = runs[mode]
         for key in s0:
             if not key.startswith("time"):
                 assert s1[key] == s0[key], (mode, key, s1[key], s0[key])
         assert np.array_equal(t1, t0) and np.array_equal(p1, p0), mode
+        assert speculated[mode] == 0
+    s1, t1, p1 = runs["frame"]
+    assert speculated["frame"] >= 0.8 * s0["cam_updates"], (speculated, s0["cam_updates"])    # (the first updates pool more than max_msckf: the long way)
+    for key in s0:
+        if key.startswith("time"):
+            continue
+        if isinstance(s0[key], float):
+            assert abs(s1[key] - s0[key]) <= 1e-9 * max(1.0, abs(s0[key])), (key, s1[key], s0[key])
+        else:
+            assert s1[key] == s0[key], (key, s1[key], s0[key])
+    assert np.array_equal(t1, t0) and np.abs(p1 - p0).max() < 1e-9
 
 
 def test_gate_inside_the_jacobian_launch_equals_the_separate_launches(pkg, street_dataset, tmp_path):

@@ -2,10 +2,11 @@
 """lk_kernel on two consecutive frames of a bench workload, launch time per variant (measurement aid).
 
 Renders a few frames of the workload's drive, tracks the library's own detections through them (so that the points are tracks of a
-few frames' age, like the bench's), then times plv_lk_track of the last pair under both values of the variant knob
-(bit 21 of plv_debug_knobs: the loop of rounds 2-4 instead of the lean iteration) and checks that every variant returns the same bits.
+few frames' age, like the bench's), then times plv_lk_track of the last pair under the variant knobs (plv_debug_knobs: 0 = the default,
+lk_kernel<1>; 4 = PLV_KNOB_LK_AHEAD >> 21, lk_ahead_kernel (round 6 experiment); 1 = PLV_KNOB_LK_LEGACY_LOOP >> 21, the loop of rounds
+2-4) and checks that every variant returns the same bits.
 
-usage: python tools/lk_exp.py [workload] [variants, comma separated]"""
+usage: python tools/lk_exp.py [workload] [variants, comma separated: knob masks shifted right by 21]"""
 import os
 import sys
 
@@ -16,7 +17,7 @@ import numpy as np
 import bench
 
 wl_name = sys.argv[1] if len(sys.argv) > 1 else "C"
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0]   # 1: the loop of rounds 2-4, 0: the lean iteration (default)
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 1]   # (knob mask >> 21) 0: lk_kernel<1> (default), 4: lk_ahead_kernel, 1: the loop of rounds 2-4
 wl = bench.WORKLOADS[wl_name]
 N_FRAMES = 8
 stream = bench.build_stream(wl, N_FRAMES + 30, 8, os.environ.get("PLV_STREAM_CACHE"))      # (forks: before the GPU is touched; a profiled run loads the cache)
