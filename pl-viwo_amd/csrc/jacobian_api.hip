@@ -144,7 +144,18 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   // few times; what a workgroup reuses it keeps in LDS)
   const bool pinned_inputs = plv::knob(plv::PLV_KNOB_INPUTS_PINNED) && !(ex && ex->spec_li);  // (the speculative batch is patched on the device)
   // (an upload by a kernel of the ctx stream instead of the copy command was measured, alternating frame by frame: no difference)
-  if (!pinned_inputs) PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+  if (ex && ex->spec_li) {
+    // the speculative batch is staged while the frame's flow occupies the ctx stream: its upload goes onto a stream of its own at once
+    // (a copy command behind the flow would sit between the flow's last kernel and the update's first); the ctx stream waits for it
+    if (!us->spec_stream) {
+      PLV_HIP_CHECK(hipStreamCreateWithFlags(&us->spec_stream, hipStreamNonBlocking));
+      PLV_HIP_CHECK(hipEventCreateWithFlags(&us->spec_ev, hipEventDisableTiming));
+    }
+    PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, us->spec_stream));
+    PLV_HIP_CHECK(hipEventRecord(us->spec_ev, us->spec_stream));
+    PLV_HIP_CHECK(hipStreamWaitEvent(ctx->stream, us->spec_ev, 0));
+  } else if (!pinned_inputs)
+    PLV_HIP_CHECK(plv::memcpy_async(us->jin.p, h, total, hipMemcpyHostToDevice, ctx->stream));
   const char *d = pinned_inputs ? (const char *)h : us->jin.as<char>();
   P.n_clones = N;
   P.clone_time = (const double *)(d + o_time);
@@ -185,7 +196,9 @@ int stage_inputs(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *s
   P.cols_in = (const int *)(d + o_cols);
   P.cols_out = nullptr;
   P.in_base = d;
-  P.in_bytes = (int)total;
+  // (what every workgroup touches first thing: the whole block — or, of a speculative batch, whose block holds every candidate's
+  //  observations, the state and the ranges in front of them)
+  P.in_bytes = (ex && ex->spec_li) ? (int)o_of : (int)total;
   if (ex) {
     ex->d_uvn = ex->uvn ? (const float *)(d + o_xuvn) : nullptr;
     ex->d_flags = ex->flags ? (const uint8_t *)(d + o_xfl) : nullptr;
@@ -246,7 +259,8 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P, &ex));
     const int nobs = tr->obs_ptr[F];
     const size_t o_pose = 0, o_valid = (size_t)nobs * 96, o_p = (o_valid + nobs + 15) & ~(size_t)15, o_err = o_p + (size_t)F * 24,
-                 o_ok = o_err + (size_t)F * 8, o_member = o_ok + F, o_words = (o_member + F + 7) & ~(size_t)7, total = o_words + 16 + 16;
+                 o_ok = o_err + (size_t)F * 8, o_member = o_ok + F, o_words = (o_member + F + 7) & ~(size_t)7, o_order = o_words + 16,
+                 total = o_order + 4 * (size_t)std::max(ft->max_sel, 1) + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
     ft->o_member = o_member, ft->o_words = o_words;
@@ -264,7 +278,15 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       A.flow_p1 = ft->spec->d_flow_p1, A.flow_n1 = ft->spec->d_flow_n1, A.flow_mask = ft->spec->d_flow_mask;
       A.obs_uv = ex.d_obs_uv, A.obs_uvn = const_cast<float *>(ex.d_uvn), A.obs_end = ex.d_obs_end;
       A.sel_flags = const_cast<unsigned char *>(ex.d_flags), A.member = (unsigned char *)(d + o_member), A.words = (int *)(d + o_words);
+      if (!ctx->gate_stage.on) {
+        set_last_error("speculative point submission needs the gate inside the Jacobian launch");
+        return PLV_E_BADARG;
+      }
+      A.order = (int *)(d + o_order), A.rows_out = us->brows.as<int>();
+      A.tri_p = (double *)(d + o_p), A.tri_err = (double *)(d + o_err), A.tri_ok = (unsigned char *)(d + o_ok);
+      A.chi2 = ctx->gate_stage.chi2, A.accepted = ctx->gate_stage.accepted, A.acc_rows = ctx->gate_stage.acc_rows;
       TRY(launch_spec_select(ctx, A));
+      P.spec_order = A.order, P.spec_count = A.words + 2;
     }
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);

@@ -929,23 +929,18 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     gather_cov_block(g, blockIdx.x - F);
     return;
   }
-  const int f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double touch = 0.0;  // (one load per 128-byte line of the input block, see JacParams::in_base; never stored)
-  for (int off = threadIdx.x * 128; off < P.in_bytes; off += 256 * 128) touch += *(const volatile double *)(P.in_base + off);
-  const int ld = P.ld, k = P.k, ncol = 3 + k + 1, max_obs = tri.max_obs;
-  const FusedLds lay = fused_lds_layout(ld, ncol, 3, 2 * max(P.n_clones - 3, 0), max_obs, tri.on != 0);
-  double *X = jsm, *piv = jsm + lay.ns, *tri_smem = jsm + lay.tri, *pre = jsm + lay.pre, *cam = jsm + lay.cam;
-  WinTab *tab = reinterpret_cast<WinTab *>(jsm + lay.tab);
-  double *tm_l = jsm + lay.idx;
-  float *uv_l = reinterpret_cast<float *>(tm_l + max_obs), *uvn_l = uv_l + 2 * max_obs;
-  int *s0_l = reinterpret_cast<int *>(uvn_l + 2 * max_obs), *slot_l = s0_l + max_obs;
-  unsigned char *valid_l = reinterpret_cast<unsigned char *>(slot_l + max_obs);
-  jac_stamp(0);
-  // What the workgroup reads more than once goes to LDS in one round of loads — clone times and columns, its observations' times and
-  // image points: a dependent load from memory is 500+ cycles even when it hits, and the bounding-clone search, the row pieces and
-  // the triangulation's passes are chains of them.  The pointers are then redirected (same indices as before).
-  const int o0 = P.obs_ptr[f], o1 = P.obs_end ? P.obs_end[f] : P.obs_ptr[f + 1];
-  if (P.obs_end && tri.on && o1 - o0 < 2) {
+  int f = blockIdx.x;
+  if (P.spec_order) {  // speculative submission: one workgroup per pool entry (spec_select_kernel's list)
+    if (blockIdx.x == 0) {  // (what workgroup 0 does for the launch, whichever candidate it works on)
+      if (threadIdx.x == 0 && gate.on && gate.n_acc_next) *gate.n_acc_next = 0;
+      if (P.cols_out)
+        for (int i = threadIdx.x; i < P.k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
+    }
+    if ((int)blockIdx.x >= *P.spec_count) return;
+    f = P.spec_order[blockIdx.x];
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (P.obs_end && tri.on && P.obs_end[f] - P.obs_ptr[f] < 2) {
     // speculative submission: a candidate that is not in the frame's pool (spec_select_kernel) — an empty system, nothing triangulated
     if (threadIdx.x == 0) {
       tri.p_out[3 * f] = tri.p_out[3 * f + 1] = tri.p_out[3 * f + 2] = 0.0;
@@ -962,6 +957,21 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     }
     return;
   }
+  double touch = 0.0;  // (one load per 128-byte line of the input block, see JacParams::in_base; never stored)
+  for (int off = threadIdx.x * 128; off < P.in_bytes; off += 256 * 128) touch += *(const volatile double *)(P.in_base + off);
+  const int ld = P.ld, k = P.k, ncol = 3 + k + 1, max_obs = tri.max_obs;
+  const FusedLds lay = fused_lds_layout(ld, ncol, 3, 2 * max(P.n_clones - 3, 0), max_obs, tri.on != 0);
+  double *X = jsm, *piv = jsm + lay.ns, *tri_smem = jsm + lay.tri, *pre = jsm + lay.pre, *cam = jsm + lay.cam;
+  WinTab *tab = reinterpret_cast<WinTab *>(jsm + lay.tab);
+  double *tm_l = jsm + lay.idx;
+  float *uv_l = reinterpret_cast<float *>(tm_l + max_obs), *uvn_l = uv_l + 2 * max_obs;
+  int *s0_l = reinterpret_cast<int *>(uvn_l + 2 * max_obs), *slot_l = s0_l + max_obs;
+  unsigned char *valid_l = reinterpret_cast<unsigned char *>(slot_l + max_obs);
+  jac_stamp(0);
+  // What the workgroup reads more than once goes to LDS in one round of loads — clone times and columns, its observations' times and
+  // image points: a dependent load from memory is 500+ cycles even when it hits, and the bounding-clone search, the row pieces and
+  // the triangulation's passes are chains of them.  The pointers are then redirected (same indices as before).
+  const int o0 = P.obs_ptr[f], o1 = P.obs_end ? P.obs_end[f] : P.obs_ptr[f + 1];
   if ((int)threadIdx.x < P.n_clones) s_ct[threadIdx.x] = P.clone_time[threadIdx.x], s_ccol[threadIdx.x] = P.clone_col[threadIdx.x];
   for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) {
     tm_l[i] = P.obs_time[o0 + i];
@@ -2362,7 +2372,9 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   if (jac_stamps().on) TRY_STAMP(jac_stamps().arm(ctx->stream, P.n_feat));
-  hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(P.n_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, P.n_feat,
+  // (a speculative batch: one workgroup per pool entry, at most max_sel of them — spec_select_kernel's list — not one per candidate)
+  const int wg_feat = P.spec_order ? std::max(1, std::min(P.n_feat, P.max_sel)) : P.n_feat;
+  hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(wg_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, wg_feat,
                      g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
   if (jac_stamps().on) TRY_STAMP(jac_stamps().collect(ctx->stream, P.n_feat, 0));
@@ -2372,27 +2384,44 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
 // (see SpecSelectArgs, jacobian_kernels.hpp) one workgroup: a pass over the candidates for membership and the pool's size, a second
 // one that writes the ranges, the flags and the survivors' new observation
 __global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
-  __shared__ int s_count;
-  if (threadIdx.x == 0) s_count = 0;
+  __shared__ int s_wave[16], s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
-  int mine = 0;
-  for (int f = threadIdx.x; f < A.F; f += blockDim.x) {
-    const int li = A.li[f], m = A.meta[f];
-    bool survived = false;
-    if (li >= 0 && li < A.n_flow && A.flow_mask[li]) {
-      const float x = A.flow_p1[2 * li], y = A.flow_p1[2 * li + 1];
-      survived = !(x < 0 || y < 0 || (int)x >= A.W || (int)y >= A.H);  // REF TrackKLT.cpp:161-163
+  // pass 1: membership, and the pool's candidates listed in batch order (a prefix count over the candidates, 1024 at a time)
+  for (int f0 = 0; f0 < A.F; f0 += blockDim.x) {
+    const int f = f0 + threadIdx.x;
+    bool in_pool = false;
+    if (f < A.F) {
+      const int li = A.li[f], m = A.meta[f];
+      bool survived = false;
+      if (li >= 0 && li < A.n_flow && A.flow_mask[li]) {
+        const float x = A.flow_p1[2 * li], y = A.flow_p1[2 * li + 1];
+        survived = !(x < 0 || y < 0 || (int)x >= A.W || (int)y >= A.H);  // REF TrackKLT.cpp:161-163
+      }
+      const int n_old = A.obs_ptr[f + 1] - A.obs_ptr[f] - (li >= 0 ? 1 : 0);  // (a tracked point's range ends with the slot of this frame)
+      const int n_use = n_old + ((survived && (m & 2)) ? 1 : 0);
+      in_pool = ((m & 1) || !((m & 8) || survived)) && n_use >= 2;
     }
-    const int n_old = A.obs_ptr[f + 1] - A.obs_ptr[f] - (li >= 0 ? 1 : 0);  // (a tracked point's range ends with the slot of this frame)
-    const int n_use = n_old + ((survived && (m & 2)) ? 1 : 0);
-    const bool in_pool = ((m & 1) || !((m & 8) || survived)) && n_use >= 2;
-    mine += in_pool ? 1 : 0;
+    const unsigned long long b = __ballot(in_pool);
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    const int rank = before + __popcll(b & ((1ull << lane) - 1ull));
+    if (in_pool && rank < A.max_sel) A.order[rank] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_wave[w];
+      s_base += tot;
+    }
+    __syncthreads();
   }
-  if (mine) atomicAdd(&s_count, mine);
-  __syncthreads();
-  const int count = s_count;
+  const int count = s_base;
   const bool over = count > A.max_sel;
-  if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0;
+  if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0, A.words[2] = over ? 0 : count;
+  // pass 2: the ranges, the flags, the survivors' new observation; empty outputs for what the Jacobian launch will not work on
   for (int f = threadIdx.x; f < A.F; f += blockDim.x) {
     const int li = A.li[f], m = A.meta[f], o0 = A.obs_ptr[f], o1 = A.obs_ptr[f + 1];
     bool survived = false;
@@ -2413,6 +2442,15 @@ __global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
       const int o = o0 + n_old;
       A.obs_uv[2 * o] = x, A.obs_uv[2 * o + 1] = y;
       A.obs_uvn[2 * o] = A.flow_n1[2 * li], A.obs_uvn[2 * o + 1] = A.flow_n1[2 * li + 1];
+    }
+    if (!in_pool || over) {
+      A.rows_out[f] = 0;
+      A.tri_p[3 * f] = A.tri_p[3 * f + 1] = A.tri_p[3 * f + 2] = 0.0;
+      A.tri_err[f] = 0.0;
+      A.tri_ok[f] = 0;
+      if (A.chi2) A.chi2[f] = NAN;
+      if (A.accepted) A.accepted[f] = 0;
+      if (A.acc_rows) A.acc_rows[f] = 0;
     }
   }
 }

@@ -70,6 +70,9 @@ struct JacParams {
   // frame's own observation to the tracks that survived and leaves the end of every candidate's observation range here (obs_ptr[f] for
   // a track that is not in the pool: an empty candidate).  null: obs_ptr[f + 1] as staged.
   const int *obs_end;
+  // ... and the launch has one workgroup per POOL entry, not per candidate: workgroup b works on candidate spec_order[b] while
+  // b < *spec_count (spec_select_kernel lists the pool's candidates in batch order and leaves the others' outputs empty)
+  const int *spec_order, *spec_count;
   // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
   int use_imu_cov;
   double intr_err_mlt;
@@ -109,6 +112,12 @@ struct SpecSelectArgs {
   int *obs_end;
   unsigned char *sel_flags, *member;
   int *words;
+  // the pool's candidates in batch order [max_sel] and, for every candidate that is NOT worked on by the Jacobian launch, the outputs
+  // that launch and its gate would have left: rows, triangulation result, verdict, accepted rows
+  int *order, *rows_out;
+  double *tri_p, *tri_err, *chi2;
+  unsigned char *tri_ok, *accepted;
+  int *acc_rows;
 };
 int launch_spec_select(plv_ctx *ctx, const SpecSelectArgs &A);
 

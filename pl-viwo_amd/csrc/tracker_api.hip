@@ -14,12 +14,16 @@
 #include <sys/resource.h>
 #include "plv_ctx.hpp"
 #include "update_state.hpp"
+#include "gate_stage.hpp"
 
 namespace {
 
 struct Track {  // ov_core::Feature, one camera  (REF: open_vins/ov_core/src/feat/Feature.h:43-77)
   std::vector<double> t;
   std::vector<float> uv, uvn;  // 2 per observation
+  // (transient, Tracker::Spec) index of the track's point in the flow's batch of feed number li_seq
+  int li = -1;
+  unsigned long long li_seq = 0;
 };
 
 struct Tracker {
@@ -59,6 +63,8 @@ struct Tracker {
   // keeps the database), then finds its update already running.
   const plv_state_view *spec_st = nullptr;        // set by plv_camera_frame around the feed: the update this frame will ask for
   const plv_update_options *spec_opt = nullptr;
+  unsigned long long feed_seq = 0;                // feeds so far (Track::li_seq)
+  std::vector<double> frame_t;                    // time stamps of the last feeds, ascending (a track's observations carry these very values)
   struct Spec {
     bool active = false;                          // a speculative batch is on the stream (not collected yet)
     double t_prev_frame = 0, state_time = 0, dt = 0, t_oldest = 0, t_oldest2 = 0;   // what the batch was staged for
@@ -180,7 +186,7 @@ static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, cons
   S.active = false;
   const plv_state_view *st = T->spec_st;
   const plv_update_options *opt = T->spec_opt;
-  if (plv::knob(plv::PLV_KNOB_NO_SPECULATION) || !st || !opt || opt->cpi || opt->max_slam > 0 || opt->n_slam > 0 || st->n_clones < 4 || opt->max_msckf < 1 ||
+  if (plv::knob(plv::PLV_KNOB_NO_SPECULATION | plv::PLV_KNOB_GATE_SEPARATE | plv::PLV_KNOB_POINT_TRI_SEPARATE | plv::PLV_KNOB_INPUTS_PINNED) || !st || !opt || opt->cpi || opt->max_slam > 0 || opt->n_slam > 0 || st->n_clones < 4 || opt->max_msckf < 1 ||
       opt->max_obs < 2 || ctx->cov_n < 1 || ctx->decision_trace || n_flow < 10 || ctx->prof.on)
     return;
   {
@@ -194,11 +200,19 @@ static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, cons
   const bool new_usable = !(tm_new > opt->state_time + st->dt_exp) && !(tm_new < t_oldest - st->dt_exp);
   const bool new_bounded = new_usable && has_bounding(tm_new);
   if (!(t_now > opt->t_prev_frame - dt)) return;  // (a surviving track counts as "seen in the newest frame": CamHelper.cpp:635, the usual case)
-  // flow index of every live track
-  std::unordered_map<const Track *, int> live;
-  live.reserve((size_t)n_flow * 2);
-  for (int i = 0; i < n_flow; ++i)
-    if (tp[i]) live.emplace(tp[i], i);
+  // What the window tests say about an observation depends on its time alone, and the observations of all tracks carry the time
+  // stamps of the last few feeds: the tests are evaluated once per stamp, the tracks are then walked with integer work only.
+  const std::vector<double> &ft = T->frame_t;
+  const int nt = (int)ft.size();
+  struct TimeInfo {
+    bool older, newer_old, too_new, too_old, bounded;
+  };
+  std::vector<TimeInfo> ti(nt);
+  for (int j = 0; j < nt; ++j) {
+    const double t = ft[j], tm = t + dt;
+    ti[j] = TimeInfo{t < t_oldest2 - dt, t > opt->t_prev_frame - dt, tm > opt->state_time + st->dt_exp, tm < t_oldest - st->dt_exp, false};
+    ti[j].bounded = !ti[j].too_new && !ti[j].too_old && has_bounding_poses(*st, tm);
+  }
   struct C {
     uint64_t id;
     const Track *tr;
@@ -207,29 +221,63 @@ static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, cons
   };
   std::vector<C> cand;
   cand.reserve(T->db.size());
-  for (const auto &kv : T->db) {
-    const Track &tr = kv.second;
+  bool bail = false;
+  auto consider = [&](uint64_t id, const Track &tr, int li) {
+    const int n = (int)tr.t.size();
+    if (n == 0) return;
     bool older = false, newer_old = false;
     int keep = 0, pv = 0;
-    for (double t : tr.t) {
-      older = older || t < t_oldest2 - dt;
-      newer_old = newer_old || t > opt->t_prev_frame - dt;
-      const double tm = t + dt;
-      if (tm > opt->state_time + st->dt_exp) return;  // (an observation newer than the window: the long way handles the hand-back)
-      if (tm < t_oldest - st->dt_exp) continue;
+    int j = (int)(std::lower_bound(ft.begin(), ft.end(), tr.t[0]) - ft.begin());
+    for (int i = 0; i < n; ++i) {
+      while (j < nt && ft[j] < tr.t[i]) ++j;
+      if (j >= nt || ft[j] != tr.t[i])  // (a track handed back in pieces need not be in time order: look this one up on its own)
+        j = (int)(std::lower_bound(ft.begin(), ft.end(), tr.t[i]) - ft.begin());
+      if (j >= nt || ft[j] != tr.t[i]) {  // (an observation that is not of a recent feed — plv_db_append_measurements: the long way)
+        if (plv::host_phases().on) plv::host_phases().add("speculative point update: no - an observation time is not a recent feed's (count)", 1.0);
+        bail = true;
+        return;
+      }
+      const TimeInfo &q = ti[j];
+      older = older || q.older;
+      newer_old = newer_old || q.newer_old;
+      if (q.too_new) {  // (an observation newer than the window: the long way handles the hand-back)
+        if (plv::host_phases().on) plv::host_phases().add("speculative point update: no - an observation newer than the window (count)", 1.0);
+        bail = true;
+        return;
+      }
+      if (q.too_old) continue;
       ++keep;
-      pv += has_bounding(tm) ? 1 : 0;
+      pv += q.bounded ? 1 : 0;
     }
-    const auto lv = live.find(&tr);
-    const int li = lv == live.end() ? -1 : lv->second;
-    if (!older && newer_old) continue;  // never in the pool: in the pool = older || !(newer_old || survived)
-    if (keep + (li >= 0 && new_usable ? 1 : 0) < 2) continue;                      // cannot reach two usable observations
-    if (pv > 255) return;
-    cand.push_back(C{kv.first, &tr, li, keep,
-                     (uint8_t)((older ? 1 : 0) | (new_usable ? 2 : 0) | (new_bounded ? 4 : 0) | (newer_old ? 8 : 0)), (uint8_t)pv});
+    if (!older && newer_old) return;                                  // never in the pool: in the pool = older || !(newer_old || survived)
+    if (keep + (li >= 0 && new_usable ? 1 : 0) < 2) return;            // cannot reach two usable observations
+    if (pv > 255) {
+      bail = true;
+      return;
+    }
+    cand.push_back(C{id, &tr, li, keep, (uint8_t)((older ? 1 : 0) | (new_usable ? 2 : 0) | (new_bounded ? 4 : 0) | (newer_old ? 8 : 0)), (uint8_t)pv});
+  };
+  // the candidates in an order that does not depend on the hash map's: the tracked points in the flow's order, then the tracks of the
+  // database that were not tracked into this frame by id
+  int n_live = 0;
+  for (int i = 0; i < n_flow && !bail; ++i)
+    if (tp[i]) {
+      tp[i]->li = i, tp[i]->li_seq = T->feed_seq;
+      ++n_live;
+      consider(flow_ids[i], *tp[i], i);
+    }
+  if ((int)T->db.size() > n_live && !bail) {
+    std::vector<std::pair<uint64_t, const Track *>> rest;
+    for (const auto &kv : T->db)
+      if (kv.second.li_seq != T->feed_seq) rest.emplace_back(kv.first, &kv.second);
+    std::sort(rest.begin(), rest.end(), [](const std::pair<uint64_t, const Track *> &a, const std::pair<uint64_t, const Track *> &b) { return a.first < b.first; });
+    for (const auto &r : rest) {
+      if (bail) break;
+      consider(r.first, *r.second, -1);
+    }
   }
+  if (bail) return;
   if (cand.empty()) return;
-  std::sort(cand.begin(), cand.end(), [](const C &a, const C &b) { return a.keep != b.keep ? a.keep > b.keep : a.id < b.id; });
   const int F = (int)cand.size();
   S.index.clear();
   S.ids.resize(F), S.ptr.assign(F + 1, 0), S.li.resize(F), S.meta.resize(F), S.prevalid.resize(F), S.flags.assign(F, 0);
@@ -238,7 +286,10 @@ static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, cons
     S.ptr[f + 1] = S.ptr[f] + cand[f].keep + (cand[f].li >= 0 ? 1 : 0);
     most_valid = std::max(most_valid, (int)cand[f].prevalid + ((cand[f].li >= 0 && new_bounded) ? 1 : 0));
   }
-  if (most_valid > opt->max_obs) return;  // (the two-step route of over-long tracks)
+  if (most_valid > opt->max_obs) {  // (the two-step route of over-long tracks)
+    if (plv::host_phases().on) plv::host_phases().add("speculative point update: no - a track longer than max_obs (count)", 1.0);
+    return;
+  }
   const int nobs = S.ptr[F];
   S.ot.resize(nobs), S.ouv.resize(2 * (size_t)nobs), S.ouvn.resize(2 * (size_t)nobs);
   for (int f = 0; f < F; ++f) {
@@ -269,7 +320,22 @@ static void spec_submit(plv_ctx *ctx, Tracker *T, double t_now, int n_flow, cons
   all.p_FinG = all.p_FinG_fej = pf.data();
   S.cols.resize(ctx->cfg.max_state_dim > 0 ? ctx->cfg.max_state_dim : 1024);
   int k = 0;
-  if (plv_jacobian_columns(st, &all, S.cols.data(), (int)S.cols.size(), &k) != PLV_OK || k < 1) return;
+  {  // the column set of the candidates = that of one track observed at every feed time inside the window (+ this frame's)
+    std::vector<double> tt;
+    for (int j = 0; j < nt; ++j)
+      if (!ti[j].too_new && !ti[j].too_old) tt.push_back(ft[j]);
+    if (tt.empty() || tt.back() != t_now) tt.push_back(t_now);
+    const int one_ptr[2] = {0, (int)tt.size()};
+    std::vector<float> zuv(2 * tt.size(), 0.f);
+    const double zp[3] = {0, 0, 0};
+    plv_tracks one{};
+    one.n_feat = 1, one.obs_ptr = one_ptr, one.obs_time = tt.data(), one.obs_uv = zuv.data(), one.obs_uvn = zuv.data(), one.p_FinG = one.p_FinG_fej = zp;
+    if (plv_jacobian_columns(st, &one, S.cols.data(), (int)S.cols.size(), &k) != PLV_OK || k < 1) return;
+  }
+  if (k > GATE_KMAX || 2 * most_valid - 3 > GATE_MMAX) {  // (the gate must run inside the Jacobian launch: with it outside every candidate's block is written and walked)
+    if (plv::host_phases().on) plv::host_phases().add("speculative point update: no - the gate would not fit the Jacobian launch (count)", 1.0);
+    return;
+  }
   plv_points_spec sp{};
   sp.n_flow = n_flow, sp.li = S.li.data(), sp.meta = S.meta.data(), sp.prevalid = S.prevalid.data();
   int n_dev = 0;
@@ -296,6 +362,14 @@ extern "C" void plv_line_run_deferred(plv_ctx *ctx);
 extern "C" int plv_perform_detection_ahead(plv_ctx *ctx, const uint8_t *mask, const float *pts, const uint64_t *ids, int n_in, int on_ctx_stream);  // frontend_api.hip
 static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const uint8_t *mask) {
   const int W = ctx->cfg.width, H = ctx->cfg.height;
+  ++T->feed_seq;
+  if (T->frame_t.empty() || timestamp > T->frame_t.back()) {
+    T->frame_t.push_back(timestamp);
+    if (T->frame_t.size() > 96) T->frame_t.erase(T->frame_t.begin(), T->frame_t.begin() + 32);
+  } else if (timestamp < T->frame_t.back()) {
+    T->frame_t.clear();  // (time went backwards: a new sequence on the same context)
+    T->frame_t.push_back(timestamp);
+  }
   plv::HostPhase ph_all("tracker_feed (after the image feed)");
   // With the line prefetch on (plv_line_prefetch_mode), resize + Canny of the new image and the copies of the two maps go first on
   // the stream and the library's line worker thread walks the edge chains and grows the segments while this thread runs the point

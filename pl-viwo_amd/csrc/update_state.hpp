@@ -92,6 +92,8 @@ struct plv_ctx_update_state {
   plv::DevBuf chain_words;      // home of applied_word
   int *applied_word = nullptr;  // device word ekf_commit_kernel sets to 1 when the point update changed the state (0: dx is not to be applied)
   bool applied_armed = false;   // ... and the last point launch ended in that kernel with the word as its argument
+  hipStream_t spec_stream = nullptr;  // upload of a speculative batch (stage_inputs)
+  hipEvent_t spec_ev = nullptr;
   // a submitted point update between plv_points_update_submit and plv_points_update_collect
   struct PointJob {
     bool pending = false, mirrored = false, chain_events = false, spec = false;

@@ -344,11 +344,12 @@ def test_gate_inside_the_jacobian_launch_equals_the_separate_launches(pkg, stree
     """The chi2 gate as the tail of the projected Jacobian launches (csrc/gate_core.hpp: T = H' Ps, S, bordered Cholesky and verdict
     in the workgroup that built the rows) against chi2_t_kernel + chi2_gate_kernel behind that launch (measurement knob 1024): the same
     tile products in the same order, so the same chi2 bits, verdicts, stacks and therefore the same filter, bit for bit — and four
-    launches per frame less."""
+    launches per frame less.  (Both with the point update submitted after the flow's result, knob 1 << 24: the update enqueued behind the
+    flow needs the gate inside its launch and batches the pool in another order.)"""
     options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
     runs, launches = {}, {}
     try:
-        for name, mask in (("fused", 0), ("separate", 1024)):
+        for name, mask in (("fused", 1 << 24), ("separate", 1024 | (1 << 24))):
             pkg.debug_knobs(mask)
             op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{name}.txt")))
             op.est.cam.use_lines = True
