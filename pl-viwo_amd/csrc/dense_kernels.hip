@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(256) stack_compact_kernel(const double *__rest
     dst[(size_t)j * ldd + off + i] = A[(size_t)j * lda + (size_t)f * mp_max + i];
   }
 }
-int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd) {
-  PLV_HIP_CHECK(hipMemsetAsync(d_dst, 0, (size_t)ldd * nc * 8, ctx->stream));
+int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows) {
+  // (exact_rows: ldd is the number of accepted rows — every row of dst is written, nothing to clear)
+  if (!exact_rows) PLV_HIP_CHECK(hipMemsetAsync(d_dst, 0, (size_t)ldd * nc * 8, ctx->stream));
   ProfScope ps(ctx->prof, "stack_compact_kernel", ctx->stream);
   hipLaunchKernelGGL(stack_compact_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_dst, ldd);
   PLV_HIP_CHECK(hipGetLastError());

@@ -94,18 +94,41 @@ PLV_HD inline int fit_chain(const uint8_t *src, int w, int h, int length_thresho
     int2 ps = P[i], pe = P[i + length_threshold];
     L3 l = cr3(ps.x, ps.y, 1.0, pe.x, pe.y, 1.0);
     bool is_line = true;
-    Fit fs{0, 0, 0, 0, 0, 0};
-    fs.add(ps);
-    for (int j = 1; j < length_threshold; ++j) {
-      const int2 pt = P[i + j];
-      if (fabs(dist_pl(pt.x, pt.y, l)) > distance_threshold) {
-        is_line = false;
-        break;
+    // Is every point between the two within distance_threshold of the chord?  The reference normalises the chord (a square root and
+    // three divisions) and compares |a' x + b' y + c'| with the threshold; most starts of a chain fail this test after a few points
+    // (round 6: 27 ns per chain point, two thirds of the detector's host time).  The chord through two pixels has integer
+    // coefficients, so v = a x + b y + c is exact and |v| / sqrt(a^2 + b^2) is the distance the reference rounds: when v^2 lies
+    // clear of threshold^2 (a^2 + b^2) — by 1e-9, the reference's own rounding is below 1e-12 — the verdict is taken from the
+    // integers; a value inside that band (a tie to nine digits) is decided by the reference's arithmetic.  Same verdicts, bit for bit.
+    {
+      const double s2 = l.a * l.a + l.b * l.b, thr = (double)distance_threshold;
+      const double lim = thr * thr * s2, lim_hi = lim * (1.0 + 1e-9), lim_lo = lim * (1.0 - 1e-9);
+      L3 ln = l;
+      bool normalised = false;
+      for (int j = 1; j < length_threshold; ++j) {
+        const int2 pt = P[i + j];
+        const double v = l.a * pt.x + l.b * pt.y + l.c, v2 = v * v;
+        if (v2 < lim_lo) continue;
+        if (v2 > lim_hi) {
+          is_line = false;
+          break;
+        }
+        if (!normalised) {  // (the reference's own sequence: dist_pl normalises the chord in place at its first call)
+          const double wv = sqrt(s2);
+          ln.a /= wv, ln.b /= wv, ln.c /= wv;
+          normalised = true;
+        }
+        if (fabs(ln.a * pt.x + ln.b * pt.y + ln.c) > distance_threshold) {
+          is_line = false;
+          break;
+        }
       }
-      fs.add(pt);
     }
     if (!is_line) continue;
-    fs.add(pe);
+    // (the sums of the fit are exact integers: adding the window's points once the test has passed gives the values the reference
+    //  accumulates while it tests)
+    Fit fs{0, 0, 0, 0, 0, 0};
+    for (int j = 0; j <= length_threshold; ++j) fs.add(P[i + j]);
     l = fs.line();
     {
       float fx = (float)ps.x, fy = (float)ps.y;

@@ -769,18 +769,16 @@ static int feed_points_impl(plv_ctx *ctx, LineTracker *T, double timestamp, cons
   return PLV_OK;
 }
 
-int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vps) {
-  if (!ctx || !vps) return PLV_E_BADARG;
-  int np = 0;
-  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
+// (internal) plv_line_tracker_feed_async with the frame's tracked points handed in (pts / pids = what plv_tracker_last returns once the
+// point tracker's feed is over): the point tracker's feed posts the line feed through this the moment its point list stands, in front
+// of its own database update (plv_camera_frame, round 6: the line worker's feed is the longer path of the frame)
+int plv_line_tracker_feed_async_points(plv_ctx *ctx, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids) {
+  if (!ctx || !vps || np < 0 || (np > 0 && (!pts || !pids))) return PLV_E_BADARG;
   LineTracker *T = ltr(ctx);
   std::lock_guard<std::mutex> lk(T->mtx);
   LineTracker::FeedJob &F = T->feed;
-  F.pts.resize(2 * (size_t)std::max(np, 1));
-  F.pids.resize((size_t)std::max(np, 1));
-  TRY(plv_tracker_last(ctx, F.pts.data(), F.pids.data(), np, &np));
-  F.pts.resize(2 * (size_t)np);
-  F.pids.resize((size_t)np);
+  F.pts.assign(pts, pts + 2 * (size_t)np);
+  F.pids.assign(pids, pids + (size_t)np);
   const bool detecting = !T->walk_on_device && T->worker.joinable() && T->pending_which == PLV_PYR_CUR && T->pending_fed == plv_front_fed_count(ctx);
   if (!detecting) {  // no detection of this frame on the worker: nothing to overlap with, and the detector's HIP calls stay on this thread
     F.pool_on = false;
@@ -800,6 +798,16 @@ int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vp
   }
   T->jcv.notify_all();
   return PLV_OK;
+}
+
+int plv_line_tracker_feed_async(plv_ctx *ctx, double timestamp, const double *vps) {
+  if (!ctx || !vps) return PLV_E_BADARG;
+  int np = 0;
+  TRY(plv_tracker_last(ctx, nullptr, nullptr, 1 << 30, &np));
+  std::vector<float> pts(2 * (size_t)std::max(np, 1));
+  std::vector<uint64_t> pids((size_t)std::max(np, 1));
+  TRY(plv_tracker_last(ctx, pts.data(), pids.data(), np, &np));
+  return plv_line_tracker_feed_async_points(ctx, timestamp, vps, np, pts.data(), pids.data());
 }
 
 int plv_line_tracker_feed_wait(plv_ctx *ctx) {

@@ -945,6 +945,24 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       ctx->probe_done = true;
       return aux_join();
     }
+    // (round 6) The host holds the gate's verdicts here.  With no more accepted rows than columns the reference does not compress at
+    // all (measurement_compress_inplace returns at once when H has no more rows than columns, StateHelper.cpp:604-606) and EKFUpdate
+    // factors S = H P H^T + R of the accepted rows' size — a line update accepts one or two lines, ~20 rows, where the whitened form
+    // factors a k x k matrix (k ~ 100: 34 us of blocked Cholesky against 6) behind an information matrix it has to form first.
+    // The accepted rows are gathered into a dense block and go through EKFUpdate as they are.
+    const int *hrows = (const int *)(hpin.as<char>() + result_rows_off(n, F));
+    int m_acc = 0;
+    for (int f = 0; f < F; ++f) m_acc += std::max(hrows[f], 0);
+    if (whiten && m_acc > 0 && m_acc <= k && ekf_fast_fits(m_acc) && !plv::knob(plv::PLV_KNOB_FORCE_FACTOR_FORM)) {
+      TRY(ctx->d_stackc.reserve((size_t)m_acc * nc * 8));
+      TRY(launch_stack_compact(ctx, ctx->stack_of(fdim).as<double>(), Mtot, nc, d_acc_rows, F, mp_max, ctx->d_stackc.as<double>(), m_acc, true));
+      TRY(aux_join());  // (a prior factor started ahead of time is not used, but it reads the covariance this update rewrites)
+      const double *Hc = ctx->d_stackc.as<double>();
+      TRY(launch_ekf_fast(ctx, ctx->d_P.as<double>(), n, n, Hc, m_acc, k, m_acc, us->bcols_of(fdim).as<int>(), Hc + (size_t)k * m_acc, nullptr, d_dx, d_flag,
+                          gathers_valid, resbuf.p, hpin.p, (rb + 3) & ~(size_t)3));
+      us->last_route = 0;
+      return PLV_OK;
+    }
   }
 
   const double *dH, *dr;

@@ -63,6 +63,9 @@ struct Tracker {
   // keeps the database), then finds its update already running.
   const plv_state_view *spec_st = nullptr;        // set by plv_camera_frame around the feed: the update this frame will ask for
   const plv_update_options *spec_opt = nullptr;
+  // (plv_camera_frame) called by the feed the moment the frame's point list (pts_last / ids_last) stands, in front of the database
+  // update: posts the line tracker's feed to its worker ~20 us earlier (the line worker's path is the frame's longer one)
+  std::function<void(int, const float *, const uint64_t *)> points_ready;
   unsigned long long feed_seq = 0;                // feeds so far (Track::li_seq)
   std::vector<double> frame_t;                    // time stamps of the last feeds, ascending (a track's observations carry these very values)
   struct Spec {
@@ -456,14 +459,22 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
   // :158-173 keep in-bounds, unmasked, matched points; :176-179 database update
   std::vector<float> good;
   std::vector<uint64_t> good_ids;
+  std::vector<uint8_t> is_good((size_t)n, 0);
+  good.reserve(2 * (size_t)n), good_ids.reserve((size_t)n);
   for (int i = 0; i < n; ++i) {
     const float x = pts_new[2 * i], y = pts_new[2 * i + 1];
     if (x < 0 || y < 0 || (int)x >= W || (int)y >= H) continue;
     if (mask && mask[(size_t)(int)y * W + (int)x] > 127) continue;
     if (!mask_ll[i]) continue;
+    is_good[i] = 1;
     good.push_back(x);
     good.push_back(y);
     good_ids.push_back(ids[i]);
+  }
+  if (T->points_ready) T->points_ready((int)good_ids.size(), good.data(), good_ids.data());  // (the frame's point list stands: the line feed can start)
+  for (int i = 0; i < n; ++i) {
+    if (!is_good[i]) continue;
+    const float x = pts_new[2 * i], y = pts_new[2 * i + 1];
     Track &tr = tp[i] ? *tp[i] : T->db[ids[i]];
     if (tr.t.capacity() == 0) {  // a new track: room for a window's worth of observations (no regrowth frame after frame)
       tr.t.reserve(32);
@@ -489,6 +500,7 @@ static int tracker_feed_fed(plv_ctx *ctx, Tracker *T, double timestamp, const ui
 }
 
 extern "C" int plv_line_pool_prepare(plv_ctx *ctx, const plv_state_view *st, const plv_update_options *opt);  // line_api.hip
+extern "C" int plv_line_tracker_feed_async_points(plv_ctx *ctx, double timestamp, const double *vps, int np, const float *pts, const uint64_t *pids);
 extern "C" void plv_line_pool_discard(plv_ctx *ctx);
 extern "C" int plv_line_db_size_after_feed(plv_ctx *ctx);
 // host work placed inside the point update's wait (called without T->mtx held)
@@ -1409,9 +1421,11 @@ int plv_camera_try_update(plv_ctx *ctx, const plv_state_view *st, plv_try_update
       rc = plv_camera_update_lines(ctx, st, io->opt_lines, io->dx_lines, io->res_lines, io->line_ids, io->line_accepted, io->line_FinG,
                                    io->line_cap);
       plv_line_defer_finish(ctx, 0);
+      plv::frame_mark("@ update_lines returned");
     }
     plv_tracker_run_deferred(ctx);
     if (rc == PLV_OK) rc = apply(*io->res_lines, io->dx_lines);
+    plv::frame_mark("@ line dx applied");
   }
   if (rc != PLV_OK && io->opt_lines) {  // (every failing exit — a pool formed ahead of time or a chained launch must not outlive the call)
     if (plv_camera_lines_job_pending(ctx)) plv_camera_lines_job_abort(ctx);
@@ -1463,20 +1477,33 @@ int plv_camera_frame(plv_ctx *ctx, const plv_state_view *st, plv_camera_frame_io
   } spec_guard{ctx, Tf};
   Tf->spec.active = false;
   if (io->update && io->update->opt_points && io->update->opt_points->max_slam == 0) Tf->spec_st = st, Tf->spec_opt = io->update->opt_points;
-  if (io->slot >= 0)
-    TRY(plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask));
-  else
-    TRY(plv_tracker_feed(ctx, io->timestamp, io->img, io->stride, io->mask));
-  Tf->spec_st = nullptr, Tf->spec_opt = nullptr;
   const bool lines = io->use_lines != 0;
+  // with lines and an update to follow, the line tracker's host logic runs on the worker thread next to the point update (joined inside
+  // plv_camera_try_update) and is posted by the point tracker's feed itself, the moment the frame's point list stands
+  // (Tracker::points_ready); otherwise in place after the feed
+  bool line_feed_posted = false;
+  int line_feed_rc = PLV_OK;
+  double vps[6] = {0, 0, 0, 0, 0, 0};
+  if (lines) TRY(plv_vanishing_points(st->R_ItoC, st->intrinsics, vps));
+  if (lines && io->update && io->update->opt_lines) {
+    plv_line_feed_pool_args(ctx, st, io->update->opt_lines);  // (the worker forms the line update's pool at the end of the feed)
+    Tf->points_ready = [&](int np, const float *pts, const uint64_t *pids) {
+      line_feed_posted = true;
+      line_feed_rc = plv_line_tracker_feed_async_points(ctx, io->timestamp, vps, np, pts, pids);
+    };
+  }
+  int rc_feed;
+  if (io->slot >= 0)
+    rc_feed = plv_tracker_feed_staged(ctx, io->timestamp, io->slot, io->mask);
+  else
+    rc_feed = plv_tracker_feed(ctx, io->timestamp, io->img, io->stride, io->mask);
+  Tf->points_ready = nullptr;
+  Tf->spec_st = nullptr, Tf->spec_opt = nullptr;
+  TRY(rc_feed);
   if (lines) {
-    double vps[6];
-    TRY(plv_vanishing_points(st->R_ItoC, st->intrinsics, vps));
-    // with an update to follow, the line tracker's host logic runs on the worker thread next to the point update (joined inside
-    // plv_camera_try_update); otherwise in place
     if (io->update && io->update->opt_lines) {
-      plv_line_feed_pool_args(ctx, st, io->update->opt_lines);  // (the worker forms the line update's pool at the end of the feed)
-      TRY(plv_line_tracker_feed_async(ctx, io->timestamp, vps));
+      if (!line_feed_posted) TRY(plv_line_tracker_feed_async(ctx, io->timestamp, vps));  // (a feed that ended before its point list: first frame, nothing tracked)
+      else TRY(line_feed_rc);
     }
     else
       TRY(plv_line_tracker_feed(ctx, io->timestamp, vps));
