@@ -801,7 +801,12 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
   TRY(us->bHf.reserve_units((size_t)L, (size_t)std::max(ctx->cfg.num_features, 64), (size_t)(6 + k + 1) * ld * 8));
   TRY(us->brows.reserve((size_t)L * 4));
   TRY(us->bcols_l.reserve((size_t)k * 4));
-  if (project && ctx->cov_n > 0) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, L, ld - 6));  // (before the upload goes onto the stream)
+  // The prior factor of the whitened update, ahead of time on the side stream — not for the one-submission line update (gate probe): it
+  // accepts a line or two, fewer rows than columns, and then goes through EKFUpdate on the rows themselves (plv_api.hip, round 6); the
+  // four enqueue calls were 8-10 us of the caller's thread in front of the line launch, the factor 50 us of side-stream work per frame
+  // that nothing read.  (A probed update that does accept more rows than columns starts the factor when it knows.)
+  const bool prior_ahead = project && ctx->cov_n > 0 && !(ctx->gate_stage.on && ctx->gate_stage.probe_dst);
+  if (prior_ahead) TRY(plv_prior_prefetch(ctx, 0, nullptr, k, L, ld - 6));  // (before the upload goes onto the stream)
   JacParams P{}, Pt{};
   bool fuse_tri = false;
   double *tri_cam = nullptr, *tri_imu = nullptr, *tri_lines = nullptr;
@@ -860,7 +865,7 @@ int build_lines_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_stat
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, &Pt, tri_cam, tri_imu, tri_valid, tri_lines, tri_ok, line_max_obs));
     else
       TRY(launch_line_jacobians_projected(ctx, P, can_gather ? &g : nullptr, gblocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, line_max_obs));
-    if (can_gather)
+    if (can_gather && prior_ahead)
       TRY(plv_prior_prefetch(ctx, 1, host_copy_of(us, P.cols_in, true), k, L, ld - 6));
     us->b_projected = true;
     us->b_gather_token = can_gather ? ctx->gather_stamp : 0;

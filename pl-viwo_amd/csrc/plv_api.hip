@@ -853,13 +853,17 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   ctx->update_word_armed = !us->graph_mode && plv::knob(plv::PLV_KNOB_DONE_WORDS);
   ctx->update_word_used = false;
   us->word_seq = 0;
-  auto enqueue = [&]() -> int {
-  if (whiten && !prefetched) {
+  const bool probing = ctx->probe && !us->graph_mode;
+  auto start_prior = [&]() -> int {
     TRY(aux_join());
     TRY(prior_mark(ctx, true));  // (us->bcols is written by the Jacobian launch queued on the main stream)
     TRY(prior_start(ctx, us->bcols_of(fdim).as<int>(), k));
     aux_open = true;
-  }
+    return PLV_OK;
+  };
+  auto enqueue = [&]() -> int {
+  // (a probed update starts the factor once it knows that it takes the whitened route: few accepted rows go another way)
+  if (whiten && !prefetched && !probing) TRY(start_prior());
   if (!projected) {
     // (+ the covariance gathers the gate and the EKF step read: independent of the projection, same launch)
     TRY(launch_nullspace(ctx, F, fdim, k, ld, us->brows.as<int>(), wHf, wHx, wres, ctx->d_P.as<double>(), n, n, us->bcols_of(fdim).as<int>()));
@@ -963,6 +967,7 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       us->last_route = 0;
       return PLV_OK;
     }
+    if (whiten && !prefetched) TRY(start_prior());
   }
 
   const double *dH, *dr;
