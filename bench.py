@@ -66,7 +66,7 @@ PROLOGUE = 60      # frames before the warm-up: initialisation, the first full c
                    # their steady state (untimed set-up: with 24 the driver's 20-step run sat 10-20 % above the 200-step one)
 LEAD_IN = 2        # untimed steps at the start of every timed segment, after its garbage collection (see timed_segment)
 IMU, WHEEL, CAM = 0, 1, 2
-ROUND = "r05"
+ROUND = "r06"
 
 
 # --------------------------------------------------------------------------------------------------------------- the stream

@@ -301,6 +301,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       A.order = (int *)(d + o_order), A.rows_out = us->brows.as<int>();
       A.tri_p = (double *)(d + o_p), A.tri_err = (double *)(d + o_err), A.tri_ok = (unsigned char *)(d + o_ok);
       A.chi2 = ctx->gate_stage.chi2, A.accepted = ctx->gate_stage.accepted, A.acc_rows = ctx->gate_stage.acc_rows;
+      A.zero_word = ctx->gate_stage.n_acc_next, A.cols_out = us->bcols.as<int>(), A.cols_in = P.cols_in, A.k = k;
       TRY(launch_spec_select(ctx, A));
       P.spec_order = A.order, P.spec_count = A.words + 2;
     }

@@ -930,33 +930,13 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     return;
   }
   int f = blockIdx.x;
-  if (P.spec_order) {  // speculative submission: one workgroup per pool entry (spec_select_kernel's list)
-    if (blockIdx.x == 0) {  // (what workgroup 0 does for the launch, whichever candidate it works on)
-      if (threadIdx.x == 0 && gate.on && gate.n_acc_next) *gate.n_acc_next = 0;
-      if (P.cols_out)
-        for (int i = threadIdx.x; i < P.k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-    }
+  if (P.spec_order) {  // speculative submission: one workgroup per pool entry (spec_select_kernel's list; that kernel also does what
+                       // workgroup 0 does for a launch — the column map's copy, the other gate counter zeroed: done here, behind a
+                       // test of blockIdx.x, the same lines put the whole parameter block into scratch memory, 700 bytes per lane)
     if ((int)blockIdx.x >= *P.spec_count) return;
     f = P.spec_order[blockIdx.x];
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (P.obs_end && tri.on && P.obs_end[f] - P.obs_ptr[f] < 2) {
-    // speculative submission: a candidate that is not in the frame's pool (spec_select_kernel) — an empty system, nothing triangulated
-    if (threadIdx.x == 0) {
-      tri.p_out[3 * f] = tri.p_out[3 * f + 1] = tri.p_out[3 * f + 2] = 0.0;
-      tri.ok_out[f] = 0;
-      if (tri.err_out) tri.err_out[f] = 0.0;
-      if (P.tri_dbg) P.tri_dbg[4 * f] = P.tri_dbg[4 * f + 1] = P.tri_dbg[4 * f + 2] = P.tri_dbg[4 * f + 3] = NAN;
-      P.rows[f] = 0;
-    }
-    if (f == 0 && P.cols_out)
-      for (int i = threadIdx.x; i < P.k; i += blockDim.x) P.cols_out[i] = P.cols_in[i];
-    if (gate.on) {
-      GateLds &gl0 = *reinterpret_cast<GateLds *>(reinterpret_cast<char *>(jsm) + gate.lds_off);
-      gate_tail(gate, gl0, nullptr, nullptr, f, jsm, 3 + P.k + 1, 3, 0, 0, P.k, P.cols_in);
-    }
-    return;
-  }
   double touch = 0.0;  // (one load per 128-byte line of the input block, see JacParams::in_base; never stored)
   for (int off = threadIdx.x * 128; off < P.in_bytes; off += 256 * 128) touch += *(const volatile double *)(P.in_base + off);
   const int ld = P.ld, k = P.k, ncol = 3 + k + 1, max_obs = tri.max_obs;
@@ -2421,6 +2401,10 @@ __global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
   const int count = s_base;
   const bool over = count > A.max_sel;
   if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0, A.words[2] = over ? 0 : count;
+  // what workgroup 0 of the Jacobian launch does for the launch as a whole (that launch may not hold candidate 0 at all)
+  if (threadIdx.x == 0 && A.zero_word) *A.zero_word = 0;
+  if (A.cols_out)
+    for (int i = threadIdx.x; i < A.k; i += blockDim.x) A.cols_out[i] = A.cols_in[i];
   // pass 2: the ranges, the flags, the survivors' new observation; empty outputs for what the Jacobian launch will not work on
   for (int f = threadIdx.x; f < A.F; f += blockDim.x) {
     const int li = A.li[f], m = A.meta[f], o0 = A.obs_ptr[f], o1 = A.obs_ptr[f + 1];

@@ -118,6 +118,11 @@ struct SpecSelectArgs {
   double *tri_p, *tri_err, *chi2;
   unsigned char *tri_ok, *accepted;
   int *acc_rows;
+  // ... and what workgroup 0 of that launch does for the launch as a whole: the gate counter of the NEXT update zeroed, the column map
+  // copied to its resident home
+  int *zero_word, *cols_out;
+  const int *cols_in;
+  int k;
 };
 int launch_spec_select(plv_ctx *ctx, const SpecSelectArgs &A);
 

@@ -205,6 +205,19 @@ def summary(a, b, thr=None):
                                  at_every_20th_update=drift[::20]),
                 tie_check=None)
     out["tie_check"] = check_tie(out) if thr is not None else None
+    # the first update whose pools agree and whose verdicts do not (a run that parted on a pool goes on: what splits it NEXT is the
+    # informative event), with the deciding test of every entry the two sides judged differently and its margin on either side
+    out["first_decision_on_values"] = None
+    if thr is not None:
+        for k, (ra, rb) in enumerate(zip(a, b)):
+            if ra[0] != rb[0] or ra[3] != rb[3] or ra[6] != rb[6] or ra[0] not in ("points", "lines"):
+                continue
+            acc_a = {int(v): int(f) for v, f in zip(ra[4], ra[5])}
+            acc_b = {int(v): int(f) for v, f in zip(rb[4], rb[5])}
+            ids = sorted((set(acc_a) ^ set(acc_b)) | {i for i in set(acc_a) & set(acc_b) if acc_a[i] != acc_b[i]})
+            if ids:
+                out["first_decision_on_values"] = dict(update=k, kind=ra[0], frame=int(ra[1]), ids=ids[:8], tie=[tie_record(i, ra, rb, thr) for i in ids[:8]])
+                break
     del out["value_drift"]["all"]
     return out
 

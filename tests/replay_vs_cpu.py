@@ -73,7 +73,30 @@ def main():
         r = ctx.traj_ate(ep[ei], gt_p[gi], "posyaw")
         res[name] = dict(wall_s=round(time.time() - t0, 2), stats=stats, ate=dict(method="posyaw", n=len(ei), pos=r["pos"], ori=r["ori"]))
         runs[name] = (times, poses, dec)
+    # (round 6) The decision trace above keeps plv_camera_frame from enqueueing the point update behind the flow (the trace reads
+    # per-pool values the speculative batch does not keep): a third replay without the trace runs the library as the bench does —
+    # counts against the CPU oracle's, trajectory against both
+    traj = os.path.join(d, "out", "traj_hip_speculative.txt")
+    op = options.load_options(sd.write_config(os.path.join(d, "config"), d, traj, **cfg_kw))
+    op.est.cam.use_lines = lines
+    t0, r0 = time.time(), pkg.route_counts()
+    stats_s, times_s, poses_s = rp.replay(op)
+    rs = [x - y for x, y in zip(pkg.route_counts(), r0)]
+    et, ep = pkg.traj_load(traj)[:2]
+    gt_t, gt_p = pkg.traj_load(gt)[:2]
+    ei, gi = pkg.traj_associate(et, gt_t)
+    r = ctx.traj_ate(ep[ei], gt_p[gi], "posyaw")
+    res["hip_speculative"] = dict(wall_s=round(time.time() - t0, 2), stats=stats_s, ate=dict(method="posyaw", n=len(ei), pos=r["pos"], ori=r["ori"]),
+                                  point_updates_enqueued_behind_the_flow=rs[7], updates_by_route=rs[:6],
+                                  what="the library as bench.py runs it: no decision trace, the point update enqueued behind the frame's flow")
     (th, ph, dh), (tc, pc, dc) = runs["hip"], runs["cpu_oracle"]
+    if len(times_s) == len(tc) and np.array_equal(times_s, tc):
+        same_counts = {k: (stats_s[k], res["cpu_oracle"]["stats"][k]) for k in ("cam_features", "cam_accepted", "cam_updates", "line_pool", "lines_triangulated",
+                                                                               "lines_accepted", "line_updates", "not_psd") if k in stats_s}
+        res["hip_speculative_vs_cpu"] = dict(n=len(tc), max_pos_diff_m=float(np.abs(poses_s[:, :3] - pc[:, :3]).max()),
+                                             max_pos_diff_to_the_traced_hip_run_m=float(np.abs(poses_s[:, :3] - ph[:, :3]).max()),
+                                             counts_hip_speculative_and_cpu=same_counts,
+                                             ate_difference_m=abs(res["hip_speculative"]["ate"]["pos"]["rmse"] - res["cpu_oracle"]["ate"]["pos"]["rmse"]))
     res["decisions"] = dt.summary(dh, dc, thr=dt.thresholds(op))
     if len(th) == len(tc) and np.array_equal(th, tc):
         r = ctx.traj_ate(ph, pc, "none")
