@@ -210,6 +210,12 @@ void plv_counters(unsigned long long *out8);
  * the route-5 point updates of plv_camera_try_update that had a chained line launch behind them (which is then withdrawn and redone);
  * [7] the point updates plv_camera_frame had enqueued behind the frame's flow, before its result was known, and that stood */
 void plv_route_counts(unsigned long long *out8);
+/* (measurement aid) speculative point updates of plv_camera_frame since the library was loaded: [0] enqueued behind the frame's flow
+ * and used as they ran (= plv_route_counts[7]), [1] of those: the pool held more tracks than max_msckf but fewer than max_msckf of
+ * them passed their tests (the selection loop of CamHelper.cpp:648-699 never reaches its cap), [2] withdrawn and run again after the
+ * flow's result: max_msckf tracks or more of such a pool passed (the device committed nothing), [3] withdrawn: the pool was larger
+ * than the launch (twice max_msckf) */
+void plv_speculation_counts(unsigned long long *out4);
 /* (test aid) Decision trace.  With it on, plv_camera_update_points (alone or inside plv_camera_try_update / plv_camera_frame) keeps, for
  * every feature of its pool, the values its verdicts were taken on; plv_last_point_decisions returns them for the last update:
  * ids [n] in pool order and vals [n][PLV_DECISION_VALUES] =

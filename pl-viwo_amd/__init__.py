@@ -174,6 +174,7 @@ def load_library():
         "plv_last_point_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
         "plv_last_line_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
         "plv_route_counts": (None, [C.POINTER(C.c_ulonglong)]),
+        "plv_speculation_counts": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
@@ -716,6 +717,13 @@ def route_counts():
     """plv_route_counts (measurement aid): updates collected so far by the route they took (index = update_compression_mode()[1])"""
     out = (C.c_ulonglong * 8)()
     load_library().plv_route_counts(out)
+    return [int(v) for v in out]
+
+
+def speculation_counts():
+    """plv_speculation_counts (measurement aid): [used, used with a pool above max_msckf, withdrawn (cut by the cap), withdrawn (pool larger than the launch)]"""
+    out = (C.c_ulonglong * 4)()
+    load_library().plv_speculation_counts(out)
     return [int(v) for v in out]
 
 

@@ -132,13 +132,22 @@ __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P
                                                          int mirror_words, const int *__restrict__ skip, double *__restrict__ dx,
                                                          const unsigned *__restrict__ mirror2_src, unsigned *__restrict__ mirror2_dst,
                                                          int mirror2_words, unsigned *done_word, unsigned done_val,
-                                                         int *__restrict__ applied_out) {
+                                                         int *__restrict__ applied_out, const int *__restrict__ cap_words, int cap) {
   // done_word (pinned, optional; the launch then has ONE workgroup): behind the mirrors AND the covariance commit the workgroup stores
   // done_val there, and the host, spinning on the word, knows both the results and the covariance to be final
   const bool skipped = skip && *skip == 0;  // (the gate accepted nothing: no correction, the covariance stays)
+  // cap_words (a speculative point batch, SpecSelectArgs::words + 3): [0] the pool was larger than the selection loop's cap, [1] the
+  // candidates the Jacobian launch selected on their own verdicts.  When that count reaches the cap the loop would have stopped
+  // somewhere inside the pool (REF CamHelper.cpp:651-653) and this batch is not the reference's: status bit 16, nothing is committed,
+  // the host runs the update the long way.  (Read here, behind the kernel boundaries that complete the count.)
+  const bool capped = cap_words && cap_words[0] != 0 && cap_words[1] >= cap;
+  if (capped && blockIdx.x == 0) {
+    if (threadIdx.x == 0) atomicOr(flag, 16);
+    __syncthreads();  // (in front of the mirror of the status block below)
+  }
   // applied_out: "this update changed the state" — StateHelper::EKFUpdate reached its mean update (:156-168): read by a launch that is
   // enqueued behind the update before the host has seen its result and applies dx to its own copy of the state (the chained line launch)
-  if (applied_out && blockIdx.x == 0 && threadIdx.x == 0) *applied_out = (skipped || *flag != 0) ? 0 : 1;
+  if (applied_out && blockIdx.x == 0 && threadIdx.x == 0) *applied_out = (skipped || capped || *flag != 0) ? 0 : 1;
   if (blockIdx.x == 0) {
     if (skipped && dx) {
       for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.0;
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(1024) ekf_commit_kernel(double *__restrict__ P
   }
   if (mirror2_dst && blockIdx.x == gridDim.x - 1)  // (written by kernels launched earlier: complete)
     for (int i = threadIdx.x; i < mirror2_words; i += blockDim.x) mirror2_dst[i] = mirror2_src[i];
-  if (!(skipped || *flag != 0)) {
+  if (!(skipped || capped || *flag != 0)) {
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
       int j = idx / n, i = idx - j * n;
       if (i <= j) {
@@ -203,7 +212,8 @@ static int launch_ekf_commit(plv_ctx *ctx, double *d_P, int n, int ldp, const do
     hipLaunchKernelGGL(ekf_commit_kernel, grid, block, 0, ctx->stream, d_P, ldp, n, dC, n,
                        d_flag, (const unsigned *)mirror_src, (unsigned *)mirror_dst, (int)(mirror_bytes / 4), ctx->skip_word, d_dx,
                        (const unsigned *)(mirror_dst ? ctx->mirror2_src : nullptr), (unsigned *)(mirror_dst ? ctx->mirror2_dst : nullptr),
-                       (int)((ctx->mirror2_bytes + 3) / 4), dw, ctx->update_seq, mirror_dst ? ctx->applied_word : nullptr);
+                       (int)((ctx->mirror2_bytes + 3) / 4), dw, ctx->update_seq, mirror_dst ? ctx->applied_word : nullptr,
+                       mirror_dst ? ctx->cap_words : nullptr, ctx->cap);
     ctx->update_word_used = dw != nullptr;
     if (mirror_dst && ctx->applied_word) ctx->applied_used = true;
     if (mirror_dst && ctx->mirror2_dst) ctx->mirror2_taken = true;

@@ -243,7 +243,8 @@ struct FusedTri {  // triangulate on the device first and let the Jacobian launc
   int max_sel;
   size_t o_p, o_err, o_ok;  // out: where the results sit in us->tri (p [F][3], err [F], ok [F], contiguous)
   const plv_points_spec *spec = nullptr;  // speculative submission: the candidates' membership is decided on the device (spec_select_kernel)
-  size_t o_member = 0, o_words = 0;       // out (spec): member [F] and the two words behind ok, part of the mirrored result block
+  size_t o_member = 0, o_words = 0;       // out (spec): member [F] and the words (SpecSelectArgs) behind ok, part of the mirrored result block
+  const int *d_words = nullptr;           // out (spec): the words on the device
 };
 int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view *st, const plv_tracks *tr, int k,
                     const int *col_to_state, int ld, bool project, FusedTri *ft = nullptr) {
@@ -275,8 +276,8 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
     TRY(stage_inputs(ctx, us, st, tr, k, col_to_state, ld, P, &ex));
     const int nobs = tr->obs_ptr[F];
     const size_t o_pose = 0, o_valid = (size_t)nobs * 96, o_p = (o_valid + nobs + 15) & ~(size_t)15, o_err = o_p + (size_t)F * 24,
-                 o_ok = o_err + (size_t)F * 8, o_member = o_ok + F, o_words = (o_member + F + 7) & ~(size_t)7, o_order = o_words + 16,
-                 total = o_order + 4 * (size_t)std::max(ft->max_sel, 1) + 16;
+                 o_ok = o_err + (size_t)F * 8, o_member = o_ok + F, o_words = (o_member + F + 7) & ~(size_t)7, o_order = o_words + 32,
+                 total = o_order + 4 * (size_t)spec_grid(ft->max_sel) + 16;
     TRY(us->tri.reserve(total));
     char *d = us->tri.as<char>();
     ft->o_member = o_member, ft->o_words = o_words;
@@ -289,7 +290,7 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
         return PLV_E_BADARG;
       }
       SpecSelectArgs A{};
-      A.F = F, A.n_flow = ft->spec->n_flow, A.W = ctx->cfg.width, A.H = ctx->cfg.height, A.max_sel = ft->max_sel;
+      A.F = F, A.n_flow = ft->spec->n_flow, A.W = ctx->cfg.width, A.H = ctx->cfg.height, A.max_sel = ft->max_sel, A.grid = spec_grid(ft->max_sel);
       A.obs_ptr = P.obs_ptr, A.li = ex.d_spec_li, A.meta = ex.d_spec_meta, A.prevalid = ex.d_spec_prevalid;
       A.flow_p1 = ft->spec->d_flow_p1, A.flow_n1 = ft->spec->d_flow_n1, A.flow_mask = ft->spec->d_flow_mask;
       A.obs_uv = ex.d_obs_uv, A.obs_uvn = const_cast<float *>(ex.d_uvn), A.obs_end = ex.d_obs_end;
@@ -303,7 +304,8 @@ int build_on_device(plv_ctx *ctx, plv_ctx_update_state *us, const plv_state_view
       A.chi2 = ctx->gate_stage.chi2, A.accepted = ctx->gate_stage.accepted, A.acc_rows = ctx->gate_stage.acc_rows;
       A.zero_word = ctx->gate_stage.n_acc_next, A.cols_out = us->bcols.as<int>(), A.cols_in = P.cols_in, A.k = k;
       TRY(launch_spec_select(ctx, A));
-      P.spec_order = A.order, P.spec_count = A.words + 2;
+      P.spec_order = A.order, P.spec_count = A.words + 2, P.spec_pass = A.words + 4;
+      ft->d_words = A.words;
     }
     tri_poses = (double *)(d + o_pose), tri_valid = (unsigned char *)(d + o_valid), tri_uvn = ex.d_uvn;
     tri_p = (double *)(d + o_p), tri_ok = (unsigned char *)(d + o_ok), tri_err = (double *)(d + o_err);
@@ -440,7 +442,7 @@ int plv_points_update_submit(plv_ctx *ctx, const plv_state_view *st, const plv_t
   if (J.chain_events) (void)hipEventRecord(g_ce[1], ctx->stream);
   us->b_single_use = true;
   const int F = all->n_feat;
-  const size_t mirror_bytes = spec ? (ft.o_words + 8 - ft.o_p) : (size_t)F * 33;
+  const size_t mirror_bytes = spec ? (ft.o_words + 20 - ft.o_p) : (size_t)F * 33;
   TRY(us->h_tri.reserve(mirror_bytes + 16));
   plv::HostPhase ph_b("points fused: gate .. EKF enqueued");
   // the triangulation results reach the host with the update's result block (copied by its last kernel), or by a copy command when
@@ -450,7 +452,9 @@ int plv_points_update_submit(plv_ctx *ctx, const plv_state_view *st, const plv_t
   TRY(us->chain_words.reserve(64));
   us->applied_word = us->chain_words.as<int>();
   ctx->applied_word = us->applied_word, ctx->applied_used = false;
+  ctx->cap_words = spec ? ft.d_words + 3 : nullptr, ctx->cap = max_sel;
   int rc = plv_msckf_update_resident_launch(ctx, sigma2, chi2_mult, res_norm_gate);
+  ctx->cap_words = nullptr;
   us->applied_armed = rc == PLV_OK && ctx->applied_used;
   ctx->applied_word = nullptr, ctx->applied_used = false;
   us->pt_tri_p = (const double *)(us->tri.as<char>() + ft.o_p), us->pt_tri_ok = (const unsigned char *)(us->tri.as<char>() + ft.o_ok), us->pt_tri_F = F;
@@ -461,7 +465,7 @@ int plv_points_update_submit(plv_ctx *ctx, const plv_state_view *st, const plv_t
   ph_b.stop();
   plv::frame_mark("@ point chain enqueued");
   if (J.chain_events) (void)hipEventRecord(g_ce[2], ctx->stream);
-  J.pending = true, J.mirrored = mirrored, J.rc = rc, J.F = F, J.spec = spec != nullptr;
+  J.pending = true, J.mirrored = mirrored, J.rc = rc, J.F = F, J.spec = spec != nullptr, J.max_sel = max_sel;
   J.o_p = ft.o_p, J.o_member = ft.o_member, J.o_words = ft.o_words;
   return PLV_OK;
 }
@@ -518,7 +522,7 @@ int plv_points_update_collect(plv_ctx *ctx, double *p_out, uint8_t *ok_out, doub
     if (member) memcpy(member, h + (J.o_member - J.o_p), (size_t)F);
     const int *w = (const int *)(h + (J.o_words - J.o_p));
     if (spec_count) *spec_count = w[0];
-    if (spec_over) *spec_over = w[1];
+    if (spec_over) *spec_over = w[1] ? 1 : ((w[3] && w[4] >= J.max_sel) ? 2 : 0);  // (2: worked on, but the selection loop's cap would have cut the pool)
   } else {
     if (spec_count) *spec_count = 0;
     if (spec_over) *spec_over = 0;

@@ -1027,6 +1027,7 @@ __global__ void __launch_bounds__(256) jacobian_nullspace_kernel(JacParams P, in
     if (threadIdx.x == 0) {
       s_rows = min(2 * s_base, ld & ~1);
       P.rows[f] = 2 * s_base;
+      if (P.spec_pass) atomicAdd(P.spec_pass, 1);  // (see JacParams::spec_pass)
     }
   } else if (threadIdx.x == 0) {
     s_rows = 0;
@@ -2352,8 +2353,8 @@ int launch_jacobians_projected(plv_ctx *ctx, const JacParams &P, const GatherArg
   ctx->gate_stage_taken = gate.on != 0;
   PLV_HIP_CHECK(ensure_dyn_smem((const void *)jacobian_nullspace_kernel, (int)shm));
   if (jac_stamps().on) TRY_STAMP(jac_stamps().arm(ctx->stream, P.n_feat));
-  // (a speculative batch: one workgroup per pool entry, at most max_sel of them — spec_select_kernel's list — not one per candidate)
-  const int wg_feat = P.spec_order ? std::max(1, std::min(P.n_feat, P.max_sel)) : P.n_feat;
+  // (a speculative batch: one workgroup per pool entry, at most spec_grid(max_sel) of them — spec_select_kernel's list — not one per candidate)
+  const int wg_feat = P.spec_order ? std::max(1, std::min(P.n_feat, spec_grid(P.max_sel))) : P.n_feat;
   hipLaunchKernelGGL(jacobian_nullspace_kernel, dim3(wg_feat + (g ? gather_blocks : 0)), dim3(256), shm, ctx->stream, P, wg_feat,
                      g ? *g : none, tri, gate);
   PLV_HIP_CHECK(hipGetLastError());
@@ -2389,7 +2390,7 @@ __global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
     int before = s_base;
     for (int w = 0; w < wave; ++w) before += s_wave[w];
     const int rank = before + __popcll(b & ((1ull << lane) - 1ull));
-    if (in_pool && rank < A.max_sel) A.order[rank] = f;
+    if (in_pool && rank < A.grid) A.order[rank] = f;
     __syncthreads();
     if (threadIdx.x == 0) {
       int tot = 0;
@@ -2399,8 +2400,8 @@ __global__ void __launch_bounds__(1024) spec_select_kernel(SpecSelectArgs A) {
     __syncthreads();
   }
   const int count = s_base;
-  const bool over = count > A.max_sel;
-  if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0, A.words[2] = over ? 0 : count;
+  const bool over = count > A.grid;
+  if (threadIdx.x == 0) A.words[0] = count, A.words[1] = over ? 1 : 0, A.words[2] = over ? 0 : count, A.words[3] = (!over && count > A.max_sel) ? 1 : 0, A.words[4] = 0;
   // what workgroup 0 of the Jacobian launch does for the launch as a whole (that launch may not hold candidate 0 at all)
   if (threadIdx.x == 0 && A.zero_word) *A.zero_word = 0;
   if (A.cols_out)

@@ -73,6 +73,10 @@ struct JacParams {
   // ... and the launch has one workgroup per POOL entry, not per candidate: workgroup b works on candidate spec_order[b] while
   // b < *spec_count (spec_select_kernel lists the pool's candidates in batch order and leaves the others' outputs empty)
   const int *spec_order, *spec_count;
+  // ... and counts the candidates its workgroups selected (own verdict) in *spec_pass: a pool larger than max_sel is worked on as long
+  // as it fits the launch (SpecSelectArgs::grid); whether the selection loop's cap would have cut it is known when all of them are
+  // done — the update's commit kernel reads the count and leaves the state alone when it reached max_sel (plv_ctx::cap_words)
+  int *spec_pass;
   // use_imu_cov: CPI covariance (6 x 6 row-major) of the pose each observation was made at and the clone it hangs on
   int use_imu_cov;
   double intr_err_mlt;
@@ -99,11 +103,14 @@ int launch_cpi_poses(plv_ctx *ctx, const CpiParams &C, const double *d_tq, doubl
 // and the flow's outputs flow_p1 / flow_n1 [n][2], flow_mask [n] (RANSAC inlier and LK status), the image size.  A track survives
 // when its point is an inlier inside the image; it is in the pool when it carries bit 0, or neither survived nor carries bit 3; a pool track of fewer
 // than two usable observations is dropped (CamHelper.cpp:766-771).  Outputs: obs_end [F], sel_flags [F] (>= 2 observations with
-// bounding clones), member [F], words [0] = pool size, [1] = 1 when the pool exceeds max_sel — then EVERY candidate is left empty (the
-// selection loop's cap, CamHelper.cpp:651-653, needs the candidates one after the other: the host runs the update the long way) —
-// and the survivors' observation of this frame written into the last slot of their range (time staged by the host).
+// bounding clones), member [F], words [0] = pool size, [1] = 1 when the pool exceeds `grid` (the workgroups of the Jacobian launch) —
+// then EVERY candidate is left empty and the host runs the update the long way —, [2] = the pool entries the launch works on,
+// [3] = 1 when the pool exceeds max_sel but not grid: the selection loop's cap (CamHelper.cpp:651-653: it stops after max_sel
+// selected candidates) cuts such a pool only when max_sel of its candidates pass their own tests, which the launch counts in [4]
+// (JacParams::spec_pass) — and the survivors' observation of this frame written into the last slot of their range (time staged by
+// the host).
 struct SpecSelectArgs {
-  int F, n_flow, W, H, max_sel;
+  int F, n_flow, W, H, max_sel, grid;
   const int *obs_ptr, *li;
   const unsigned char *meta, *prevalid;
   const float *flow_p1, *flow_n1;
@@ -112,7 +119,7 @@ struct SpecSelectArgs {
   int *obs_end;
   unsigned char *sel_flags, *member;
   int *words;
-  // the pool's candidates in batch order [max_sel] and, for every candidate that is NOT worked on by the Jacobian launch, the outputs
+  // the pool's candidates in batch order [grid] and, for every candidate that is NOT worked on by the Jacobian launch, the outputs
   // that launch and its gate would have left: rows, triangulation result, verdict, accepted rows
   int *order, *rows_out;
   double *tri_p, *tri_err, *chi2;

@@ -118,6 +118,11 @@ void plv_route_counts(unsigned long long *out8) {
   for (int i = 0; i < 8; ++i) out8[i] = plv::counters().route[i].load();
   out8[7] = plv::counters().speculated.load();  // (point updates enqueued behind the frame's flow and used as they ran)
 }
+void plv_speculation_counts(unsigned long long *out4) {
+  if (!out4) return;
+  out4[0] = plv::counters().speculated.load();
+  for (int i = 0; i < 3; ++i) out4[1 + i] = plv::counters().spec_over[i].load();
+}
 unsigned plv_debug_knobs(long long set) {
   const unsigned prev = plv::knobs().load();
   if (set >= 0) plv::knobs().store((unsigned)set);
@@ -511,7 +516,7 @@ int plv_ekf_update(plv_ctx *ctx, double *P, int n, int ldp, const double *H, int
   TRY(sync(ctx));
   int flag = *(int *)(ctx->h_pin.as<char>() + (size_t)n * 8);
   if (flag != 0) {
-    set_last_error("EKFUpdate rejected: %s", (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
+    set_last_error("EKFUpdate rejected: %s", (flag & 16) ? "speculative batch over the selection cap (run again by the caller)" : (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
     return PLV_E_NOT_PSD;
   }
   memcpy(dx, ctx->h_pin.p, (size_t)n * 8);
@@ -1121,7 +1126,8 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
   const char *hb = hpin.as<char>();
   const int *hrows = (const int *)(hb + result_rows_off(n, F));
   us->last_ambiguous = 0;
-  if (us->redo_w.armed && us->last_route == 4 && *(const int *)(hb + (size_t)n * 8) != 0 && ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {
+  if (us->redo_w.armed && us->last_route == 4 && *(const int *)(hb + (size_t)n * 8) != 0 && !(*(const int *)(hb + (size_t)n * 8) & 16) &&
+      ((const int *)(hb + (size_t)n * 8))[us->acc_word_used] > 0) {  // (bit 16: not a rejection — a speculative batch the selection loop's cap would have cut, ekf_commit_kernel)
     // The whitened update came back rejected (update_state.hpp, RedoW): nothing was committed.  The stacked rows are run again the
     // reference's way — compression, then S = R P R^T + I — with the compression by Householder reflections on the rows themselves
     // (on the KAIST-layout drive with stamps of 1.5e9 s, where this happens to the first update after the initialisation, the Gram +
@@ -1166,7 +1172,7 @@ int plv_msckf_update_resident_wait(plv_ctx *ctx, uint8_t *accepted, int *n_accep
     return PLV_E_CAPACITY;
   }
   if (flag != 0) {
-    set_last_error("EKFUpdate rejected: %s", (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
+    set_last_error("EKFUpdate rejected: %s", (flag & 16) ? "speculative batch over the selection cap (run again by the caller)" : (flag & 2) ? "S not positive definite" : "negative covariance diagonal");
     return PLV_E_NOT_PSD;
   }
   memcpy(dx, hb, (size_t)n * 8);

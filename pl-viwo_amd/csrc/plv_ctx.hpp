@@ -43,6 +43,7 @@ struct Counters {
   // the line worker's side: post -> wake-up, the wait for the edge maps, chain walk + segment growth, feed post -> start, the feed
   std::atomic<unsigned long long> w_wake_ns{0}, w_maps_ns{0}, w_extract_ns{0}, w_feed_start_ns{0}, w_feed_ns{0};
   std::atomic<unsigned long long> chained{0};  // line launches enqueued behind a running point update (plv_chain_count)
+  std::atomic<unsigned long long> spec_over[3] = {};  // plv_speculation_counts [1] .. [3]
   std::atomic<unsigned long long> speculated{0};  // point updates enqueued behind the frame's flow and used (plv_route_counts[7])
   std::atomic<unsigned long long> route[8] = {};  // collected updates by plv_ctx_update_state::last_route (plv_route_counts)
 };
@@ -50,6 +51,9 @@ inline Counters &counters() {
   static Counters c;
   return c;
 }
+// workgroups of a speculative batch's Jacobian launch (pool entries it can work on): twice the selection loop's cap — at BASELINE
+// configs[2] one frame in ten pools 71 .. 100 tracks of which 40 .. 65 pass their tests (the cap, 70, is not reached)
+inline int spec_grid(int max_sel) { return 2 * (max_sel > 0 ? max_sel : 1); }
 inline hipError_t stream_sync(hipStream_t s) {
   ++counters().syncs;
   return hipStreamSynchronize(s);
@@ -502,6 +506,9 @@ struct plv_ctx {
   } chain;
   int *applied_word = nullptr;  // set by the caller of a launch that may end in ekf_commit_kernel: the kernel stores "state changed" there
   bool applied_used = false;
+  // set by the caller of a speculative point update (plv_points_update_submit) around its launch: ekf_commit_kernel's cap test
+  const int *cap_words = nullptr;
+  int cap = 0;
   // Measurement knob PLV_KNOB_DONE_WORDS — completion words in pinned memory: the last kernel of the flow (word 0) and of an update
   // (word 16) stores the call's sequence number there behind its result block (system-scope release) and the host spins on the word
   // instead of waiting on an event.  Off by default (no gain in the frame, see the knob list).

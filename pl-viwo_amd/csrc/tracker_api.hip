@@ -880,7 +880,9 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       else cand_of[f] = it->second;
     }
     T->chain_index.clear();
-    T->chain_ok = same && known && Fp0 <= opt->max_msckf;  // (the selection loop cannot reach its cap: spec_select_kernel's own test)
+    // (the device works on a pool of up to spec_grid(max_msckf) tracks; whether the selection loop's cap would have cut it is known with
+    //  the results — then the chained launch has seen the status and ended without touching anything, like behind a rejected update)
+    T->chain_ok = same && known && Fp0 <= plv::spec_grid(opt->max_msckf);
     if (T->chain_ok && T->early_lines)
       for (int f = 0; f < Fp0; ++f) {
         int v = 0;
@@ -903,10 +905,15 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       return finish(PLV_E_DEVICE);
     };
     if (!same) return fail("the batch was staged for another update than the one asked for");
-    if (over || Fp0 > opt->max_msckf) {
-      // the pool exceeds max_msckf: the device left every candidate empty and updated nothing; the long way below
-      if (!(over && Fp0 > opt->max_msckf && count == Fp0)) return fail("host and device disagree on the pool's size");
-      if (plv::host_phases().on) plv::host_phases().add("speculative point update: pool over the cap, run again the long way (count)", 1.0);
+    if (over || Fp0 > plv::spec_grid(opt->max_msckf)) {
+      // over == 1: the pool exceeds the launch — the device left every candidate empty and updated nothing; over == 2: the pool exceeds
+      // max_msckf and max_msckf of its candidates passed their tests — the selection loop would have stopped inside the pool
+      // (REF CamHelper.cpp:651-653), the device committed nothing (ekf_commit_kernel).  The long way below.
+      if (!(over && Fp0 > opt->max_msckf && count == Fp0 && (over == 1) == (Fp0 > plv::spec_grid(opt->max_msckf))))
+        return fail("host and device disagree on the pool's size");
+      if (plv::host_phases().on) plv::host_phases().add(over == 1 ? "speculative point update: pool larger than the launch, run again the long way (count)" : "speculative point update: pool cut by the selection cap, run again the long way (count)", 1.0);
+      if (plv_camera_lines_job_pending(ctx)) plv_camera_lines_job_abort2(ctx, 1);  // (a chained line launch saw the status and did nothing; its pool stays formed)
+      ++plv::counters().spec_over[over == 1 ? 2 : 1];
     } else {
       if (rc_s != PLV_OK && rc_s != PLV_E_NOT_PSD) {
         for (Cand &c : pool) give_back_all(c);
@@ -926,6 +933,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
       if (rc_s == PLV_E_NOT_PSD) std::fill(dx, dx + ctx->cov_n, 0.0);  // EKFUpdate returned false: nothing changed
       spec_done = true;
       ++plv::counters().speculated;
+      if (Fp0 > opt->max_msckf) ++plv::counters().spec_over[0];
     }
   }
   if (pool.empty()) {
@@ -1148,6 +1156,7 @@ int plv_camera_update_points(plv_ctx *ctx, const plv_state_view *st, const plv_u
   }
   res->n_msckf = (int)sel.size();
   res->n_init = (int)T->last_init.size();
+  if (plv::host_phases().on && Fp > opt->max_msckf) fprintf(stderr, "[plv over] pool %d selected %d\n", Fp, (int)sel.size());
   if (sel.empty()) {
     if (!fused_ran) std::fill(dx, dx + ctx->cov_n, 0.0);
     return finish(PLV_OK);

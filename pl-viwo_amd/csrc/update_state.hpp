@@ -97,7 +97,7 @@ struct plv_ctx_update_state {
   // a submitted point update between plv_points_update_submit and plv_points_update_collect
   struct PointJob {
     bool pending = false, mirrored = false, chain_events = false, spec = false;
-    int rc = 0, F = 0;
+    int rc = 0, F = 0, max_sel = 0;
     size_t o_p = 0, o_member = 0, o_words = 0;
     std::chrono::steady_clock::time_point t_entry;
   } point_job;

@@ -179,3 +179,57 @@ def test_redone_point_update_next_to_a_chained_line_launch(pkg, kaist_dir, tmp_p
     for key in ("line_pool", "lines_triangulated", "lines_accepted", "line_updates"):
         assert sd_[key] == sh[key], (key, sd_[key], sh[key], redo_frames)
     assert np.abs(out["default"][2][:, :3] - out["householder"][2][:, :3]).max() < 2e-3
+
+
+def test_speculative_point_update_with_pools_above_the_cap(pkg, kaist_dir, tmp_path):
+    """The point update plv_camera_frame enqueues behind the frame's flow works on its pool as long as it fits the launch (twice
+    max_msckf entries).  The reference's selection loop stops after max_msckf selected features (CamHelper.cpp:651-653): a pool above
+    max_msckf is only the reference's batch when fewer than max_msckf of its tracks pass their tests — counted by the launch, read by
+    the commit kernel, which leaves the state alone otherwise (the update is then run again the long way, and a line launch chained
+    behind it is withdrawn).  Small caps on the street drive produce all three cases; every replay has to agree with the one that
+    never speculates (knob 1 << 24): same pool and batch sizes update by update, same counts, same trajectory to rounding."""
+    options, rp, system = (importlib.import_module("plviwo_amd." + m) for m in ("options", "replay", "system"))
+    prev_knobs = pkg.debug_knobs(0)
+    seen = [0, 0, 0, 0]
+    try:
+        for cap in (18, 30):
+            out, batches = {}, {}
+            for name, knobs in (("speculative", 0), ("after_the_flow", 1 << 24)):
+                pkg.debug_knobs(knobs)
+                op = options.load_options(sd.write_config(str(tmp_path / "config"), kaist_dir[0], str(tmp_path / f"traj_{cap}_{name}.txt"), use_wheel=True, max_msckf=cap))
+                op.est.cam.use_lines = True
+                b = []
+                count, count_l = system.SystemManager._count_points, system.SystemManager._count_lines
+
+                def count2(self, res, _count=count, _b=b):
+                    _b.append(("points", int(res["n_pool"]), int(res["n_msckf"]), int(res["n_accepted"])))
+                    return _count(self, res)
+
+                def count3(self, res, _count=count_l, _b=b):
+                    _b.append(("lines", int(res["n_pool"]), int(res["n_lines"]), int(res["n_accepted"])))
+                    return _count(self, res)
+                system.SystemManager._count_points, system.SystemManager._count_lines = count2, count3
+                s0 = pkg.speculation_counts()
+                try:
+                    out[name] = rp.replay(op)
+                finally:
+                    system.SystemManager._count_points, system.SystemManager._count_lines = count, count_l
+                batches[name] = b
+                ds = [a - c for a, c in zip(pkg.speculation_counts(), s0)]
+                if knobs == 0:
+                    seen = [a + c for a, c in zip(seen, ds)]
+                    print("max_msckf", cap, "speculation counts [used, used above the cap, cut by the cap, larger than the launch]:", ds,
+                          " point updates:", out[name][0]["cam_updates"])
+                else:
+                    assert ds == [0, 0, 0, 0], ds
+            a, c = out["speculative"], out["after_the_flow"]
+            first = next((i for i, (x, y) in enumerate(zip(batches["speculative"], batches["after_the_flow"])) if x != y), None)
+            assert first is None and len(batches["speculative"]) == len(batches["after_the_flow"]), (cap, first, batches["speculative"][first], batches["after_the_flow"][first])
+            for key in ("cam_features", "cam_accepted", "cam_updates", "line_pool", "lines_triangulated", "lines_accepted", "line_updates", "not_psd"):
+                assert a[0][key] == c[0][key], (cap, key, a[0][key], c[0][key])
+            d = np.abs(a[2][:, :3] - c[2][:, :3]).max()
+            print("max_msckf", cap, "largest distance between the two trajectories: %.3g m" % d)
+            assert d < 1e-6, (cap, d)
+    finally:
+        pkg.debug_knobs(prev_knobs)
+    assert seen[0] >= 20 and seen[1] >= 1 and seen[2] >= 1 and seen[3] >= 1, seen

@@ -1,5 +1,5 @@
 set -u
-REPO=$(pwd); OUT=gpurun_out/kt5; mkdir -p $OUT; export TMPDIR=/tmp
+REPO=$(pwd); OUT=gpurun_out/kt6; mkdir -p $OUT; export TMPDIR=/tmp
 CACHE=/tmp/plv_stream_C.npz
 timeout 600 python3 bench.py --steps 30 --warmup 5 --no-cpu --no-stress --no-pcie --no-variants --stream-cache $CACHE > $OUT/b0.json 2> $OUT/b0.err
 cd /tmp
