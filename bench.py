@@ -577,6 +577,7 @@ def main():
                 pkg.line_worker_config(-1, alt_fit[f % len(alt_fit)])
             c0 = pkg.counters()
             a0 = pkg.alloc_count()
+            cls0 = (pkg.chain_count(), pkg.speculation_counts()) if trace_frames else None
             ph0 = pkg.phase_counters() if trace_frames else None
             if fw:
                 import resource
@@ -612,6 +613,9 @@ def main():
                                                           cur["lines_triangulated"] - last_stats.get("lines_triangulated", 0), cur["lines_accepted"] - last_stats.get("lines_accepted", 0),
                                                           c1["lk_iters"] - c0["lk_iters"], c1["lines_detected"] - c0["lines_detected"]) +
                                                          tuple(round((ph1t[k] - ph0[k]) * 1e-3, 1) for k in ("flow_wait", "points", "lines", "w_maps", "w_extract", "w_feed")))
+                sp1 = pkg.speculation_counts()
+                per_frame.setdefault("classes", []).append((dt * 1e3, pkg.chain_count() - cls0[0], sp1[0] - cls0[1][0], sp1[2] - cls0[1][2] + sp1[3] - cls0[1][3],
+                                                            cur["lines_accepted"] - last_stats.get("lines_accepted", 0), c1["launches"] - c0["launches"]))
                 last_stats = cur
             per_frame["tracked"].append(len(ctx.tracker_last()[1]))
             if wl["lines"]:
@@ -668,6 +672,12 @@ def main():
                 split[k.replace("[Time-Cam] ", "")] = round((v - a) / max(1, sm.tc.count[k] - c) * 1e3, 4)
         if os.environ.get("PLV_BENCH_FRAMES"):
             print("[frames] ms per step:", " ".join(f"{v:.3f}" for v in per), "| steps that (re)allocated a buffer:", grew, "| host cpu:", host_cpu, file=sys.stderr)
+            groups = {}
+            for ms_, ch_, sp_, re_, la_, ln_ in per_frame.get("classes", []):
+                groups.setdefault(("chained" if ch_ else "unchained", "speculated" if sp_ else ("withdrawn" if re_ else "after-flow"), "lines accepted" if la_ else "no line", int(ln_)), []).append(ms_)
+            for k_ in sorted(groups, key=lambda k: -len(groups[k])):
+                v_ = groups[k_]
+                print(f"[classes] {k_}: {len(v_)} frames, mean {np.mean(v_) * 1e3:.1f} us, p50 {pct(v_, 50) * 1e3:.1f}", file=sys.stderr)
             print("[frames] (ms, msckf features, line pool, lines triangulated, lines accepted, LK iterations, segments detected; us inside: flow wait, point update, line update, worker: maps wait, detection, feed) per step:", per_frame.get("trace"), file=sys.stderr)
             for row in slow:
                 print("[slow step] step %d: %.3f ms; inside its parts (ms) %s; plv_camera_frame %.3f, plv_ctx_synchronize %.3f" % row, file=sys.stderr)

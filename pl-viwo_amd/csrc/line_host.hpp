@@ -47,13 +47,27 @@ struct Fit {
   std::mutex m;
   std::condition_variable cv;
   // (atomics: written under m, read without it by a polling thread — wait_polling spins on them lock-free)
-  std::atomic<int> gen{0}, done_gen[kThreads] = {};  // a job = a new generation; thread i reports the last one it finished
-  // A labelled job (Job::hlab): its parts are claimed here by the walking thread and the helpers; a part = the components whose
-  // label it is, walked and fitted by the thread that claimed it (detect_part) into part[p]
-  bool by_parts = false;  // (guarded by m, read together with gen and job)
+  std::atomic<int> gen{0};  // a job = a new generation
+  // Round 6: the hand-over of a job takes no lock while the threads are awake.  The poster fills desc[g & 1] for the generation g it
+  // is about to post and then stores g (under m only so that a helper asleep on cv cannot miss it); a helper that sees gen change
+  // reads desc[g & 1] and checks that gen still is g — the slot is written again only for g + 2, after g + 1 has been stored, so an
+  // unchanged gen proves the copy whole (a helper the job of generation g did not count may wake that late; one it counts is
+  // waited for).  It reports in done_gen and takes m only when the poster has gone to sleep (poster_waiting).  Until round 5 every
+  // pick-up and every report locked m: eight threads at once, 6 us until the last helper had started and 8 us until the poster had
+  // seen the last report (measured on the assignment job, PLV_KNOB_LINE_TIMING).
+  struct Desc {
+    // a detection (job): by_parts = its parts are claimed by the walking thread and the helpers, a part = the components whose label
+    // it is, walked and fitted by the thread that claimed it (detect_part) into part[p]; or a generic job for the same threads
+    // (run_on_helpers): every thread it counts calls (*task)(slot), slot 1 .. nfit (0 = the poster)
+    std::atomic<const Job *> job{nullptr};
+    std::atomic<int> nfit{0};  // helper threads the job counts (thread i takes part when i < nfit): read with the rest of the slot,
+                               // so that a thread waking late for a job it was not part of cannot mix two jobs
+    std::atomic<bool> by_parts{false};
+    std::atomic<const std::function<void(int)> *> task{nullptr};
+  } desc[2];
+  alignas(64) std::atomic<int> done_gen[kThreads] = {};  // thread i reports the last generation it finished
+  alignas(64) std::atomic<int> poster_waiting{0};       // the poster blocks on cv (under m) for the reports
   std::atomic<int> prewake{0};  // bumped (under m) when a job is on its way (prewake_helpers): sleeping helpers wake and poll for it
-  // a generic job for the same threads (run_on_helpers): every thread it counts calls task(slot), slot 1 .. nfit_job (0 = the poster)
-  std::function<void(int)> task;  // (guarded by m, read together with gen)
   alignas(64) std::atomic<int> next_part{0};
   struct PartOut {
     std::vector<int> seed, seg_at, seg_n;  // per chain: raster index of its seed, first segment, segments
@@ -69,9 +83,6 @@ struct Fit {
     std::vector<FldChain> chains;
   } scratch[kThreads + 1];
   std::atomic<bool> quit{false};
-  const Job *job = nullptr;
-  int nfit_job = 0;  // fitter threads the current job uses (thread i takes part when i < nfit_job); guarded by m: a thread reads it
-                     // together with gen and job, so that one waking late for a job it was not part of cannot mix two jobs
   alignas(64) std::atomic<int> published{0};  // (own cache line: written by the walk after every chain, polled by this thread)
   alignas(64) std::atomic<bool> walk_done{false};
   alignas(64) std::atomic<int> next{0};  // next chain to fit: this thread and, once its walk is over, the walking thread claim chains here
@@ -307,54 +318,101 @@ inline void claim_parts(Fit &F, const Job &J, int slot) {
   for (int p; (p = F.next_part.fetch_add(1, std::memory_order_relaxed)) < J.parts;) detect_part(F, J, p, F.scratch[slot], slot);
 }
 
+// posts generation g = gen + 1 (the caller has filled nothing yet): fills its slot, stores g, wakes sleepers.  One poster at a time
+// (the line worker, or the caller's thread while the worker is idle: both hold the tracker's lock).
+inline int post_job(Fit &F, const Job *job, int nfit, bool by_parts, const std::function<void(int)> *task) {
+  const int g = F.gen.load(std::memory_order_relaxed) + 1;
+  Fit::Desc &D = F.desc[g & 1];
+  D.job.store(job, std::memory_order_relaxed), D.nfit.store(nfit, std::memory_order_relaxed);
+  D.by_parts.store(by_parts, std::memory_order_relaxed), D.task.store(task, std::memory_order_relaxed);
+  {
+    std::lock_guard<std::mutex> lk(F.m);
+    F.gen.store(g, std::memory_order_release);
+  }
+  F.cv.notify_all();
+  return g;
+}
+// waits until the first nfit helpers have reported generation g: polls, then blocks on cv (a report then takes m and notifies)
+inline void wait_reports(Fit &F, int nfit, int g) {
+  auto done = [&] {
+    for (int i = 0; i < nfit; ++i)
+      if (F.th[i].joinable() && F.done_gen[i].load() != g) return false;
+    return true;
+  };
+  if (done()) return;
+  const int spin_us = spin_budget_us().load(std::memory_order_relaxed);
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int i = 0; i < 8; ++i) __builtin_ia32_pause();
+      if (done()) return;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+  }
+  std::unique_lock<std::mutex> lk(F.m);
+  F.poster_waiting.store(1);
+  F.cv.wait(lk, done);
+  F.poster_waiting.store(0);
+}
+
 inline void fit_worker(HostStage *T, int me, int seen /* the generation current when the thread was made: it waits for the next */) {
   Fit &F = T->fit;
   int seen_pw = 0;
   for (;;) {
-    const Job *job;
-    int nfit;
-    bool by_parts;
-    std::function<void(int)> task;
-    {
-      std::unique_lock<std::mutex> lk(F.m);
-      // (a pre-wake ends the wait without a job: the thread comes round and polls again — awake when the job arrives)
-      // (a helper beyond the configured count — the count was lowered after it was started — blocks at once: a pre-wake makes only
-      // the helpers the next job will use poll)
-      wait_polling(lk, F.cv, [&] { return F.gen != seen || F.prewake != seen_pw || F.quit; }, me < fit_threads().load(std::memory_order_relaxed) ? -1 : 0);
-      if (F.quit) return;
-      if (F.gen == seen) {
-        seen_pw = F.prewake;
-        continue;
+    auto changed = [&] { return F.gen.load(std::memory_order_acquire) != seen || F.prewake.load(std::memory_order_acquire) != seen_pw || F.quit.load(); };
+    if (!changed()) {
+      // (a pre-wake ends the wait without a job: the thread comes round and polls again — awake when the job arrives; a helper beyond
+      // the configured count — the count was lowered after it was started — blocks at once: a pre-wake makes only the helpers the
+      // next job will use poll)
+      const int spin_us = me < fit_threads().load(std::memory_order_relaxed) ? spin_budget_us().load(std::memory_order_relaxed) : 0;
+      bool hit = false;
+      if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+          for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+          if ((hit = changed())) break;
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
       }
-      seen_pw = F.prewake;
-      seen = F.gen, job = F.job, nfit = F.nfit_job, by_parts = F.by_parts, task = F.task;
+      if (!hit) {
+        std::unique_lock<std::mutex> lk(F.m);
+        F.cv.wait(lk, changed);
+      }
     }
-    if (task || !job) {  // (a task, or a thread the task did not count waking after the poster has withdrawn it)
-      if (task && me < nfit) task(me + 1);
-      {
-        std::lock_guard<std::mutex> lk(F.m);
-        F.done_gen[me] = seen;
+    if (F.quit.load()) return;
+    seen_pw = F.prewake.load(std::memory_order_acquire);
+    const int g = F.gen.load(std::memory_order_acquire);
+    if (g == seen) continue;
+    const Fit::Desc &D = F.desc[g & 1];
+    const Job *job = D.job.load(std::memory_order_relaxed);
+    const int nfit = D.nfit.load(std::memory_order_relaxed);
+    const bool by_parts = D.by_parts.load(std::memory_order_relaxed);
+    const std::function<void(int)> *task = D.task.load(std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (F.gen.load(std::memory_order_relaxed) != g) continue;  // (posted over while this thread was reading: it was not part of g)
+    seen = g;
+    if (me >= nfit) continue;  // (a thread this job does not count takes nothing and is not waited for)
+    if (task) {
+      (*task)(me + 1);
+    } else if (job) {
+      const Job &J = *job;
+      if (by_parts) claim_parts(F, J, me + 1);
+      for (; !by_parts;) {
+        const int avail = F.published.load(std::memory_order_acquire);
+        const int c = claim_chain(F, avail);
+        if (c >= 0) {
+          fit_one(F, J, c);
+          continue;
+        }
+        if (F.walk_done.load(std::memory_order_acquire) && F.next.load(std::memory_order_relaxed) >= F.published.load(std::memory_order_acquire)) break;
+        for (int i = 0; i < 64; ++i) __builtin_ia32_pause();  // (poll every few hundred ns: the walk owns the counter's cache line meanwhile)
       }
+    }
+    F.done_gen[me].store(g);
+    if (F.poster_waiting.load()) {
+      { std::lock_guard<std::mutex> lk(F.m); }
       F.cv.notify_all();
-      continue;
     }
-    const Job &J = *job;
-    if (by_parts && me < nfit) claim_parts(F, J, me + 1);
-    for (; !by_parts && me < nfit;) {  // (a thread this job does not count takes nothing and is not waited for)
-      const int avail = F.published.load(std::memory_order_acquire);
-      const int c = claim_chain(F, avail);
-      if (c >= 0) {
-        fit_one(F, J, c);
-        continue;
-      }
-      if (F.walk_done.load(std::memory_order_acquire) && F.next.load(std::memory_order_relaxed) >= F.published.load(std::memory_order_acquire)) break;
-      for (int i = 0; i < 64; ++i) __builtin_ia32_pause();  // (poll every few hundred ns: the walk owns the counter's cache line meanwhile)
-    }
-    {
-      std::lock_guard<std::mutex> lk(F.m);
-      F.done_gen[me] = seen;
-    }
-    F.cv.notify_all();
   }
 }
 
@@ -388,16 +446,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     for (int i = 0; i < nfit; ++i)
       if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
   }
-  int gen;
-  {
-    std::lock_guard<std::mutex> lk(F.m);
-    F.job = &J;
-    F.nfit_job = nfit;
-    F.by_parts = by_parts;
-    F.task = nullptr;
-    gen = ++F.gen;
-  }
-  F.cv.notify_all();
+  const int gen = post_job(F, &J, nfit, by_parts, nullptr);
   if (by_parts) {
     claim_parts(F, J, 0);
   } else {
@@ -407,14 +456,7 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   auto T2 = std::chrono::steady_clock::now();
   if (!by_parts)
     for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
-  {
-    std::unique_lock<std::mutex> lk(F.m);
-    wait_polling(lk, F.cv, [&] {
-      for (int i = 0; i < nfit; ++i)
-        if (F.th[i].joinable() && F.done_gen[i] != gen) return false;
-      return true;
-    });
-  }
+  wait_reports(F, nfit, gen);
   J.lines.clear();
   if (by_parts) {
     // the parts' chains back in the raster order of their seeds = the detector's output order
@@ -595,41 +637,36 @@ inline void run_on_helpers(HostStage *T, int nhelpers, const std::function<void(
     for (int i = 0; i < nhelpers; ++i)
       if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
   }
-  int gen;
-  {
-    std::lock_guard<std::mutex> lk(F.m);
-    F.job = nullptr;
-    F.nfit_job = nhelpers;
-    F.by_parts = false;
-    F.task = fn;
-    gen = ++F.gen;
-  }
-  F.cv.notify_all();
+  const int gen = post_job(F, nullptr, nhelpers, false, &fn);
   fn(0);
-  std::unique_lock<std::mutex> lk(F.m);
-  wait_polling(lk, F.cv, [&] {
-    for (int i = 0; i < nhelpers; ++i)
-      if (F.th[i].joinable() && F.done_gen[i] != gen) return false;
-    return true;
-  });
-  F.task = nullptr;
+  wait_reports(F, nhelpers, gen);  // (fn lives with the caller until every thread that may call it has reported)
 }
 
 // assign_points with the lines split into contiguous ranges over the stage's threads: a line's assignment depends on nothing but the
 // line and the points, and the ranges' results are joined in line order — the same Assign as the serial call.
 inline void assign_points_parallel(HostStage *T, int nhelpers, const float *lines, int nl, const float *pts, const uint64_t *ids, int np, Assign &A,
                                    float assign_px = 5.0f) {
-  const int nt = std::max(1, std::min(nhelpers + 1, nl / 400));  // (measured at 460 lines, pinned threads: one thread 39 us, eight no faster — the hand-over costs what it saves)
+  const int nt = plv::knob(plv::PLV_KNOB_ASSIGN_ONE_THREAD) ? 1 : std::max(1, std::min(nhelpers + 1, nl / 50));
   if (nt == 1) {
     assign_points(lines, nl, pts, ids, np, A, assign_px);
     return;
   }
   std::vector<Assign> part(nt);
+  const bool timing = plv::knob(plv::PLV_KNOB_LINE_TIMING);
+  const auto ta = std::chrono::steady_clock::now();
+  float t_start[16] = {0}, t_end[16] = {0};
   run_on_helpers(T, nt - 1, [&](int slot) {
+    if (timing) t_start[slot] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ta).count();
     const int i0 = (int)((long long)nl * slot / nt), i1 = (int)((long long)nl * (slot + 1) / nt);
     assign_points(lines + 4 * (size_t)i0, i1 - i0, pts, ids, np, part[slot], assign_px);
     for (int &k : part[slot].kept) k += i0;
+    if (timing) t_end[slot] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ta).count();
   });
+  if (timing) {
+    fprintf(stderr, "assign over %d threads (start-end us):", nt);
+    for (int i = 0; i < nt; ++i) fprintf(stderr, " %.1f-%.1f", t_start[i], t_end[i]);
+    fprintf(stderr, "; all joined %.1f\n", std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - ta).count());
+  }
   A = Assign();
   for (const Assign &P : part) {
     A.kept.insert(A.kept.end(), P.kept.begin(), P.kept.end());
