@@ -267,310 +267,6 @@ int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const
   return PLV_OK;
 }
 
-// ------------------------------------------------------------------------------------------ EKFUpdate on a few accepted rows
-// A line update accepts a line or two: 10 .. 40 rows against ~100 columns.  The reference does not compress such a system
-// (measurement_compress_inplace returns at once when H has no more rows than columns, StateHelper.cpp:604-606) and EKFUpdate
-// (StateHelper.cpp:94-173) factors S = H P H^T + I of the rows' own size.  One workgroup does all of it from the gate's stack — M = H Pc,
-// S, its Cholesky factor, W = L^-1 [M | r], the negative-diagonal test, P -= W^T W, dx = W^T y — so the launch can sit on the stream
-// right behind the gate, before the host knows what the gate accepted (plv_msckf_update_resident_launch: the probe then costs no second
-// submission; until round 6 the host read the verdicts and enqueued stack_compact + ekf_ms + bchol_ekf + ekf_dc + ekf_commit: +44 us in
-// every frame that accepted a line, half the frames at BASELINE configs[2]).  Nothing to do (no accepted row), or more rows than it
-// holds (EKF_ROWS_MAX, or more rows than columns): it returns without a trace and the host, which sees the same counts, goes on as before.
-// 1/x and x^-1/2 by the hardware's estimate + two Newton steps (blocked_chol.hpp: rcp_nr / rsqrt_nr; an IEEE division is ~30 dependent
-// instructions, and the pivots of a matrix I + H P H^T are nowhere near the range where its scale / fix-up steps matter)
-__device__ __forceinline__ double rows_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-__device__ __forceinline__ double rows_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  e = fma(-x * r, r, 1.0);
-  return fma(0.5 * r, e, r);
-}
-__device__ __forceinline__ double rows_readlane(double x, int l) {
-  const long long b = __double_as_longlong(x);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// Elimination of [S | M | r] (m rows), a lane per column with the column in registers, EVERY WAVE FOR ITSELF: lanes 0 .. m - 1 of each
-// wave hold the columns of S (all waves the same ones), lanes m .. 63 the wave's share of the border columns; step j's multipliers are
-// read out of lane j (v_readlane: scalar registers, no LDS, no barrier — a barrier per step with the column published through LDS
-// measured 1700 cycles per step on 8 waves).  Leaves S = Lu D Lu^T as D (lane j of a wave keeps pivot j) and Lu^-1 [M | r] in the
-// border lanes, written back scaled by D^-1/2: W = L^-1 [M | r] of the Cholesky factor L = Lu D^1/2 (REF :135 S.llt(), :138-139).
-// MB: compile-time row bound (static register indices); rows beyond m are zeros.  Needs n1 <= (waves) x (64 - m).
-template <int MB>
-__device__ __forceinline__ void ekf_rows_eliminate(double *__restrict__ M, int n1, const double *__restrict__ S, int m1, int m, double *__restrict__ Ls,
-                                                   int *bad) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = wave * (64 - m) + lane - m;  // (border lanes)
-  const bool border = lane >= m && col < n1;
-  double v[MB];
-  if (lane < m) {
-#pragma unroll
-    for (int i = 0; i < MB; ++i) v[i] = i < m ? S[max(i, lane) * m1 + min(i, lane)] : 0.0;  // (the lower triangle is stored)
-  } else {
-#pragma unroll
-    for (int i = 0; i < MB; ++i) v[i] = (i < m && border) ? M[i * n1 + col] : 0.0;
-  }
-  bool ok = true;
-  double my_piv = 1.0;
-#pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    if (j < m && ok) {  // (uniform)
-      const double piv = rows_readlane(v[j], j);
-      ok = piv > 0.0;  // (REF: llt() on a matrix that is not positive definite — EKFUpdate's caller sees NaN; here: status bit 2, nothing written)
-      if (lane == j) my_piv = piv;
-      const double s = rows_rcp(piv) * v[j];
-#pragma unroll
-      for (int i = j + 1; i < MB; ++i) v[i] -= rows_readlane(v[i], j) * s;
-    }
-  }
-  if (!ok && threadIdx.x == 0) *bad = 2;
-  if (ok && wave == 0 && lane < m) Ls[lane] = rows_rsqrt(my_piv);  // D^-1/2
-  __syncthreads();
-  if (ok && border) {
-#pragma unroll
-    for (int q = 0; q < MB; ++q)
-      if (q < m) M[q * n1 + col] = v[q] * Ls[q];
-  }
-}
-
-#define EKF_ROWS_TILES 8  // upper 16 x 16 tiles of [dC | dx] per wave: 8 waves x 8 = 64 >= 10 * 11 / 2 (n + 1 <= 160)
-__global__ void __launch_bounds__(512) ekf_rows_kernel(double *__restrict__ P, int ldp, int n, const double *__restrict__ A, int lda, int k,
-                                                       const int *__restrict__ acc_rows, int F, int mp_max, const int *__restrict__ cols,
-                                                       double *__restrict__ dx_dev, int *__restrict__ flag_dev, double *dx_pin, int *flag_pin,
-                                                       long long *stamps) {
-#define ROWS_STAMP(i)                                                                  \
-  do {                                                                                 \
-    if (stamps && threadIdx.x == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
-  } while (0)
-  ROWS_STAMP(0);
-  // LDS: M [m][n + 1] (column n: r; becomes W | y in place), S [m][m + 1] (lower triangle), H [m][k + 1] (the accepted rows), cols (ints)
-  extern __shared__ double esm[];
-  __shared__ int s_src[EKF_ROWS_MAX], s_wave[16], s_bad, s_tab[8 * EKF_ROWS_TILES];
-  __shared__ double s_L[EKF_ROWS_MAX];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6, li = lane & 15, lq = lane >> 4;
-  const int n1 = n + 1, k1 = k + 1;
-  // What limits this kernel is how often it waits for memory (the stack and the covariance come from other workgroups' launches:
-  // ~2 us per dependent round), so what does not depend on the rows is fetched at once: the column map, and the covariance entries the
-  // commit at the very end subtracts from (upper tiles of [dC | dx], EKF_ROWS_TILES per wave) — they wait in registers.
-  const int my_col = cols[min(tid, k - 1)];
-  const int nt1 = (n1 + 15) >> 4, ntri = nt1 * (nt1 + 1) / 2;
-  if (tid < 8 * EKF_ROWS_TILES) {
-    int ta = 0, rem = min(tid, ntri - 1);
-    while (rem >= nt1 - ta) rem -= nt1 - ta, ++ta;
-    s_tab[tid] = ta * 256 + ta + rem;
-  }
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  double pv[EKF_ROWS_TILES][4];
-#pragma unroll
-  for (int u = 0; u < EKF_ROWS_TILES; ++u) {
-    const int tt = s_tab[wave + nwaves * u], ta = tt >> 8, tb = tt & 255;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pv[u][q] = P[(size_t)min(tb * 16 + li, n - 1) * ldp + min(ta * 16 + lq + 4 * q, n - 1)];
-  }
-  // the accepted rows, entry by entry in batch order (what stack_compact_kernel lists): row q of the system is row s_src[q] of the stack
-  int m = 0;
-  for (int f0 = 0; f0 < F; f0 += blockDim.x) {
-    const int f = f0 + tid;
-    const int mine = f < F ? max(acc_rows[f], 0) : 0;
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int before = m + incl - mine, total = 0;
-    for (int w = 0; w < nwaves; ++w) {
-      if (w < wave) before += s_wave[w];
-      total += s_wave[w];
-    }
-    for (int i = 0; i < mine; ++i)
-      if (before + i < EKF_ROWS_MAX) s_src[before + i] = f * mp_max + i;
-    m += total;
-    __syncthreads();
-  }
-  if (m == 0 || m > EKF_ROWS_MAX || m > k || n1 > nwaves * (64 - m)) return;  // (uniform; the last: ekf_rows_eliminate's lanes)
-  ROWS_STAMP(1);
-  if (stamps && tid == 0) stamps[15] = m;
-  const int m1 = m + 1;
-  double *M = esm, *S = esm + (size_t)EKF_ROWS_MAX * n1, *Hl = S + (size_t)EKF_ROWS_MAX * (EKF_ROWS_MAX + 1);
-  int *cols_l = reinterpret_cast<int *>(Hl + (size_t)EKF_ROWS_MAX * (EKF_ROWS_MAX_K + 1));
-  if (tid < k) cols_l[tid] = my_col;
-  __syncthreads();
-  ROWS_STAMP(2);
-  // the accepted rows go to LDS in one round (consecutive threads = consecutive rows of one column), and a wave fetches the B operands
-  // of a whole tile column of M = H P[cols, :] next to them: unconditional loads (clamped indices, the value selected afterwards) —
-  // a load behind a branch is waited for before the next one is issued
-  for (int idx = tid; idx < m * k1; idx += blockDim.x) {
-    const int kk = idx / m, i = idx - kk * m;
-    Hl[i * k1 + kk] = A[(size_t)kk * lda + s_src[i]];
-  }
-  // (P is symmetric: row cols[kk] is read along its column, consecutive j = consecutive addresses)
-  const int mt = (m + 15) >> 4, nt = (n + 15) >> 4;
-  for (int tj = wave; tj < nt; tj += nwaves) {
-    double bv[EKF_ROWS_MAX_K / 4];
-    const double *pc = P + min(tj * 16 + li, n - 1);
-#pragma unroll
-    for (int u = 0; u < EKF_ROWS_MAX_K / 4; ++u) {
-      const double x = pc[(size_t)cols_l[min(4 * u + lq, k - 1)] * ldp];
-      bv[u] = 4 * u + lq < k ? x : 0.0;
-    }
-    if (tj == wave) __syncthreads();  // (the rows are in LDS; every wave comes here exactly once, see below)
-    for (int ti = 0; ti < mt; ++ti) {
-      const double *hr = Hl + min(ti * 16 + li, m - 1) * k1;
-      d4 acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int u = 0; u < EKF_ROWS_MAX_K / 4; ++u)
-        if (4 * u < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hr[min(4 * u + lq, k - 1)], bv[u], acc, 0, 0, 0);  // (beyond k: B is zero, A any finite value)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = ti * 16 + lq + 4 * q, j = tj * 16 + li;
-        if (i < m && j < n) M[i * n1 + j] = acc[q];
-      }
-    }
-  }
-  if (wave >= nt) __syncthreads();  // (a wave without a tile column of its own meets the others here)
-  if (tid < m) M[tid * n1 + n] = Hl[tid * k1 + k];
-  __syncthreads();
-  ROWS_STAMP(3);
-  // S = (H P)[:, cols] H^T + I, lower triangle   (REF StateHelper.cpp:127-131 with R = I, UpdaterCamera.cpp:290)
-  for (int t = wave; t < mt * mt; t += nwaves) {
-    const int ti = t / mt, tl = t - ti * mt;
-    if (tl > ti) continue;
-    const double *mr = M + min(ti * 16 + li, m - 1) * n1;
-    const double *h = Hl + min(tl * 16 + li, m - 1) * k1;
-    auto fa = [&](int, int kk) { return mr[cols_l[kk]]; };
-    auto fb = [&](int kk, int) { return h[kk]; };
-    d4 acc = {0, 0, 0, 0};
-    acc = mfma_tile_f64_pipe<8>(fa, fb, k, acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = ti * 16 + lq + 4 * q, l = tl * 16 + li;
-      if (i < m && l <= i) S[i * m1 + l] = acc[q] + (i == l ? 1.0 : 0.0);
-    }
-  }
-  __syncthreads();
-  ROWS_STAMP(4);
-  // [W | y] = L^-1 [M | r]
-  if (m <= 16)
-    ekf_rows_eliminate<16>(M, n1, S, m1, m, s_L, &s_bad);
-  else if (m <= 32)
-    ekf_rows_eliminate<32>(M, n1, S, m1, m, s_L, &s_bad);
-  else
-    ekf_rows_eliminate<EKF_ROWS_MAX>(M, n1, S, m1, m, s_L, &s_bad);
-  __syncthreads();
-  ROWS_STAMP(5);
-  // [dC | dx] = W^T [W | y] in upper tiles, kept in registers until the verdict is known
-  // REF :143-152 — any P_jj - (K M^T)_jj < 0 rejects the update; :156-168 P -= K M^T, dx = K r
-  const bool factored = s_bad == 0;
-  d4 dacc[EKF_ROWS_TILES];
-#pragma unroll
-  for (int u = 0; u < EKF_ROWS_TILES; ++u) {
-    const int t = wave + nwaves * u;
-    const int tt = s_tab[t], ta = tt >> 8, tb = tt & 255;
-    const double *wa = M + min(ta * 16 + li, n), *wb = M + min(tb * 16 + li, n);
-    d4 acc = {0, 0, 0, 0};
-    if (factored && t < ntri) {  // (uniform)
-      for (int q0 = 0; q0 < m; q0 += 4) {
-        const int q = min(q0 + lq, m - 1);
-        const double a = wa[q * n1], b = wb[q * n1];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q0 + lq < m ? a : 0.0, b, acc, 0, 0, 0);
-      }
-    }
-    dacc[u] = acc;
-    if (factored && t < ntri && ta == tb) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = ta * 16 + lq + 4 * q, j = tb * 16 + li;
-        if (i == j && i < n && pv[u][q] - acc[q] < 0.0) atomicOr(&s_bad, 1);
-      }
-    }
-  }
-  __syncthreads();
-  ROWS_STAMP(6);
-  const int status = s_bad;
-#pragma unroll
-  for (int u = 0; u < EKF_ROWS_TILES; ++u) {
-    const int t = wave + nwaves * u;
-    const int tt = s_tab[t], ta = tt >> 8, tb = tt & 255;
-    if (status == 0 && t < ntri) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = ta * 16 + lq + 4 * q, j = tb * 16 + li;
-        if (i < n && j == n) dx_dev[i] = dacc[u][q], dx_pin[i] = dacc[u][q];  // (the column of y: dx)
-        if (i <= j && j < n) {
-          const double v = pv[u][q] - dacc[u][q];
-          P[(size_t)j * ldp + i] = v;
-          P[(size_t)i * ldp + j] = v;
-        }
-      }
-    }
-  }
-  if (status != 0 && tid < n) dx_dev[tid] = 0.0, dx_pin[tid] = 0.0;
-  if (tid == 0) {
-    flag_dev[0] = status;
-    flag_pin[0] = status;
-    flag_pin[3] = 1;  // "the update ran here" (cleared by the host before the launch)
-  }
-  __syncthreads();
-  ROWS_STAMP(7);
-#undef ROWS_STAMP
-}
-static size_t ekf_rows_lds(int n) {
-  return ((size_t)EKF_ROWS_MAX * (n + 1) + (size_t)EKF_ROWS_MAX * (EKF_ROWS_MAX + 1) + (size_t)EKF_ROWS_MAX * (EKF_ROWS_MAX_K + 1)) * 8 + EKF_ROWS_MAX_K * 4;
-}
-bool ekf_rows_fits(int n, int k, int F) { return F <= 1024 && k <= EKF_ROWS_MAX_K && k >= 1 && n + 1 <= 160 && EKF_ROWS_MAX + n + 1 <= 512 && ekf_rows_lds(n) <= 150 * 1024; }
-// PLV_KNOB_KERNEL_STAMPS: s_memtime stamps of ekf_rows_kernel's phases (its caller synchronises right behind the launch and collects)
-struct RowsStampHost {
-  bool on = plv::knob(plv::PLV_KNOB_KERNEL_STAMPS);
-  long long *d = nullptr;
-  double sum[8] = {}, msum = 0;
-  long n = 0;
-  ~RowsStampHost() {
-    if (!on || !n) return;
-    static const char *label[8] = {"start", "rows listed", "column map staged", "M = H Pc", "S", "eliminated", "verdict", "end"};
-    fprintf(stderr, "[plv stamps] ekf_rows_kernel: %ld launches with rows, %.1f rows on average\n", n, msum / n);
-    for (int i = 1; i < 8; ++i) fprintf(stderr, "[plv stamps]   %-20s @ %8.0f cycles\n", label[i], sum[i] / n);
-  }
-};
-static RowsStampHost &rows_stamps() {
-  static RowsStampHost h;
-  return h;
-}
-void ekf_rows_stamps_collect() {
-  RowsStampHost &R = rows_stamps();
-  if (!R.on || !R.d) return;
-  long long h[16];
-  if (hipMemcpy(h, R.d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess || !h[7]) return;
-  for (int i = 1; i < 8; ++i) R.sum[i] += (double)(h[i] - h[0]);
-  R.msum += (double)h[15];
-  ++R.n;
-}
-int launch_ekf_rows(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_stack, int lda, int k, const int *d_acc_rows, int F, int mp_max, const int *d_cols,
-                    double *d_dx, int *d_flag, double *h_dx, int *h_flag) {
-  ProfScope ps(ctx->prof, "ekf_rows_kernel", ctx->stream);
-  const size_t shm = ekf_rows_lds(n);
-  PLV_HIP_CHECK(ensure_dyn_smem((const void *)ekf_rows_kernel, (int)shm));
-  RowsStampHost &R = rows_stamps();
-  if (R.on) {
-    if (!R.d) PLV_HIP_CHECK(hipMalloc(&R.d, 16 * 8));
-    PLV_HIP_CHECK(hipMemsetAsync(R.d, 0, 16 * 8, ctx->stream));
-  }
-  hipLaunchKernelGGL(ekf_rows_kernel, dim3(1), dim3(512), shm, ctx->stream, d_P, ldp, n, d_stack, lda, k, d_acc_rows, F, mp_max, d_cols, d_dx, d_flag, h_dx, h_flag,
-                     R.on ? R.d : nullptr);
-  PLV_HIP_CHECK(hipGetLastError());
-  return PLV_OK;
-}
-
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max) {
   ProfScope ps(ctx->prof, "stack_zero_rejected_kernel", ctx->stream);
   hipLaunchKernelGGL(stack_zero_rejected_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max);

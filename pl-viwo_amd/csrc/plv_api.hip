@@ -944,31 +944,14 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
   if (probe) {
     // the gate's verdicts are in pinned memory when its launch has finished: most line updates end here (three frames in four at
     // BASELINE configs[2] accept no line), without the six launches that would find nothing to do
-    // (round 6) ... and when it accepts a line or two, EKFUpdate on those rows is already on the stream behind the gate: one workgroup
-    // that finds the accepted rows itself (ekf_rows_kernel) — no second submission after the verdicts have reached the host
-    const bool rows_kernel = whiten && a.stack_accepted_only && ekf_rows_fits(n, k, F) &&
-                             !plv::knob(plv::PLV_KNOB_FORCE_FACTOR_FORM) && !plv::knob(plv::PLV_KNOB_LINE_EKF_AFTER_PROBE);
-    int *hflag = (int *)(hpin.as<char>() + (size_t)n * 8);
-    hflag[3] = 0;
-    if (rows_kernel) TRY(aux_join());  // (a prior factor started ahead of time is not used, but it reads the covariance this kernel rewrites)
-    if (rows_kernel)
-      TRY(launch_ekf_rows(ctx, ctx->d_P.as<double>(), n, n, ctx->stack_of(fdim).as<double>(), Mtot, k, d_acc_rows, F, mp_max, us->bcols_of(fdim).as<int>(), d_dx, d_flag,
-                          hpin.as<double>(), hflag));
     if (ctx->probe_hook) ctx->probe_hook(ctx->probe_hook_arg);
     TRY(sync(ctx));
-    if (rows_kernel) ekf_rows_stamps_collect();
     const unsigned char *hacc = (const unsigned char *)(hpin.as<char>() + (size_t)n * 8 + 16);
     int any = 0;
     for (int f = 0; f < F; ++f) any |= hacc[f];
     if (!any) {
       memset(hpin.p, 0, (size_t)n * 8 + 16);  // dx = 0, status = updated-with-nothing (as the skipped chain reports it)
       ctx->probe_done = true;
-      return aux_join();
-    }
-    if (rows_kernel && hflag[3] == 1) {  // the update ran behind the gate: dx and the status word are in the result block
-      hflag[3] = 0;
-      ctx->probe_done = true;
-      us->last_route = 0;
       return aux_join();
     }
     // (round 6) The host holds the gate's verdicts here.  With no more accepted rows than columns the reference does not compress at

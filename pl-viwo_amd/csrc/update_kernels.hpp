@@ -64,13 +64,6 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
 // whitened route (dense_kernels.hip; DESIGN.md "Whitened update")
 void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
                      const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0, const int *use_m);
-// EKFUpdate of up to EKF_ROWS_MAX accepted rows straight from the gate's stack, one workgroup (dense_kernels.hip)
-#define EKF_ROWS_MAX 48
-#define EKF_ROWS_MAX_K 128  // columns (the gate inside the Jacobian launch holds as many: GATE_KMAX)
-bool ekf_rows_fits(int n, int k, int F);
-void ekf_rows_stamps_collect();  // (PLV_KNOB_KERNEL_STAMPS; call behind a synchronisation that covers the launch)
-int launch_ekf_rows(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_stack, int lda, int k, const int *d_acc_rows, int F, int mp_max, const int *d_cols,
-                    double *d_dx, int *d_flag, double *h_dx, int *h_flag);
 int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows = false);
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k);
