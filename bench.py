@@ -864,6 +864,7 @@ def main():
             # what the step occupies on the host: CPU seconds per second of wall time over the first timed segment (the
             # whole control group: caller, line worker, helper threads — they poll), the threads, and where they were pinned
             "host_cpu_seconds_per_second": None if not seg.get("host_cpu") else seg["host_cpu"]["cpu_seconds_per_second"],
+            "device_bytes_peak": pkg.memory_bytes()["device_peak"], "pinned_bytes_peak": pkg.memory_bytes()["pinned_peak"],
             "host_threads": (2 + fit_threads) if wl["lines"] else 1,
             "host_threads_what": (f"1 caller + 1 line worker + {fit_threads} polling helper threads of the line detector's host stage" if wl["lines"] else "1 caller"),
             "cpu_affinity_mode": pinned.get("mode"), "cpu_affinity_cpus": pinned.get("cpus"),

@@ -216,6 +216,15 @@ void plv_route_counts(unsigned long long *out8);
  * flow's result: max_msckf tracks or more of such a pool passed (the device committed nothing), [3] withdrawn: the pool was larger
  * than the launch (twice max_msckf) */
 void plv_speculation_counts(unsigned long long *out4);
+/* (no reference counterpart) What the library holds, all contexts of the process together: out[0] bytes of device memory, [1] bytes of
+ * pinned host memory, [2] / [3] their peaks since the library was loaded or plv_memory_policy was last called.  Buffers grow on demand
+ * and are never shrunk; a context's buffers are released by plv_ctx_destroy. */
+void plv_memory_bytes(unsigned long long *out4);
+/* How a buffer is sized when it has to grow: growth_percent of what is asked for (100 .. 1000, default 200: batch sizes wander from
+ * frame to frame and a buffer that regrows inside a frame costs that frame 0.3-0.4 ms) and never less than device_floor_kb (default
+ * 1024) / pinned_floor_kb (default 256).  -1 leaves a value as it is.  Process-wide; buffers that exist keep their size.  Resets the
+ * peaks of plv_memory_bytes.  PLV_E_BADARG for a growth below 100 or above 1000. */
+int plv_memory_policy(int growth_percent, int device_floor_kb, int pinned_floor_kb);
 /* (test aid) Decision trace.  With it on, plv_camera_update_points (alone or inside plv_camera_try_update / plv_camera_frame) keeps, for
  * every feature of its pool, the values its verdicts were taken on; plv_last_point_decisions returns them for the last update:
  * ids [n] in pool order and vals [n][PLV_DECISION_VALUES] =

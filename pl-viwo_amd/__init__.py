@@ -175,6 +175,8 @@ def load_library():
         "plv_last_line_decisions": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
         "plv_route_counts": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_speculation_counts": (None, [C.POINTER(C.c_ulonglong)]),
+        "plv_memory_bytes": (None, [C.POINTER(C.c_ulonglong)]),
+        "plv_memory_policy": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "plv_alloc_count": (C.c_ulonglong, []),
         "plv_phase_counters": (None, [C.POINTER(C.c_ulonglong)]),
         "plv_camera_update_lines": (C.c_int, [vp, C.POINTER(PlvStateView), C.POINTER(PlvUpdateOptions), dp,
@@ -725,6 +727,20 @@ def speculation_counts():
     out = (C.c_ulonglong * 4)()
     load_library().plv_speculation_counts(out)
     return [int(v) for v in out]
+
+
+def memory_bytes():
+    """plv_memory_bytes: dict(device, pinned, device_peak, pinned_peak) — bytes the library holds, all contexts of the process"""
+    out = (C.c_ulonglong * 4)()
+    load_library().plv_memory_bytes(out)
+    return dict(zip(("device", "pinned", "device_peak", "pinned_peak"), [int(v) for v in out]))
+
+
+def memory_policy(growth_percent=-1, device_floor_kb=-1, pinned_floor_kb=-1):
+    """plv_memory_policy: how generously a growing buffer is sized (process-wide); resets the peaks of memory_bytes()"""
+    rc = load_library().plv_memory_policy(growth_percent, device_floor_kb, pinned_floor_kb)
+    if rc != 0:
+        raise PlvError(rc, "plv_memory_policy")
 
 
 def device_numa_node(device=0):

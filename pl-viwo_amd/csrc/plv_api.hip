@@ -118,6 +118,21 @@ void plv_route_counts(unsigned long long *out8) {
   for (int i = 0; i < 8; ++i) out8[i] = plv::counters().route[i].load();
   out8[7] = plv::counters().speculated.load();  // (point updates enqueued behind the frame's flow and used as they ran)
 }
+void plv_memory_bytes(unsigned long long *out4) {
+  if (!out4) return;
+  plv::MemoryBook &b = plv::memory_book();
+  out4[0] = (unsigned long long)std::max(0ll, b.dev.load()), out4[1] = (unsigned long long)std::max(0ll, b.pin.load());
+  out4[2] = (unsigned long long)std::max(0ll, b.dev_peak.load()), out4[3] = (unsigned long long)std::max(0ll, b.pin_peak.load());
+}
+int plv_memory_policy(int growth_percent, int device_floor_kb, int pinned_floor_kb) {
+  plv::MemoryBook &b = plv::memory_book();
+  if ((growth_percent >= 0 && growth_percent < 100) || growth_percent > 1000) return PLV_E_BADARG;
+  if (growth_percent >= 100) b.growth_percent.store(growth_percent);
+  if (device_floor_kb >= 0) b.dev_floor_kb.store(device_floor_kb);
+  if (pinned_floor_kb >= 0) b.pin_floor_kb.store(pinned_floor_kb);
+  b.dev_peak.store(b.dev.load()), b.pin_peak.store(b.pin.load());
+  return PLV_OK;
+}
 void plv_speculation_counts(unsigned long long *out4) {
   if (!out4) return;
   out4[0] = plv::counters().speculated.load();

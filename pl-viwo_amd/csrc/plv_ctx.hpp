@@ -240,6 +240,28 @@ inline std::atomic<unsigned long long> &alloc_epoch() {  // contexts may live on
   return e;
 }
 
+// What the library holds in HBM and in pinned host memory (plv_memory_bytes), and how generously a buffer is sized when it has to
+// grow (plv_memory_policy): the defaults suit one context per GPU with 288 GB behind it, a process with many contexts or a
+// smaller device lowers them.
+struct MemoryBook {
+  std::atomic<long long> dev{0}, pin{0}, dev_peak{0}, pin_peak{0};
+  std::atomic<int> growth_percent{200}, dev_floor_kb{1024}, pin_floor_kb{256};
+  void add(std::atomic<long long> &now, std::atomic<long long> &peak, long long bytes) {
+    const long long v = now.fetch_add(bytes) + bytes;
+    long long p = peak.load();
+    while (v > p && !peak.compare_exchange_weak(p, v)) {
+    }
+  }
+  size_t sized(size_t bytes, int floor_kb) const {
+    const size_t grown = (size_t)((double)bytes * std::max(100, growth_percent.load()) / 100.0) + 256;
+    return std::max(grown, (size_t)std::max(0, floor_kb) << 10);
+  }
+};
+inline MemoryBook &memory_book() {
+  static MemoryBook b;
+  return b;
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -251,22 +273,25 @@ struct DevBuf {
       void *bt[8];
       backtrace_symbols_fd(bt, backtrace(bt, 8), 2);
     }
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    // Twice what is asked for and never less than 1 MB (the device has 288 GB): batch sizes wander from frame to frame (pool sizes,
-    // accepted rows, chain counts) and a buffer that regrows inside a frame costs that frame 0.3 - 0.4 ms (hipFree waits for the
-    // device, hipMalloc maps pages) — round 4's driver-timed run had three such frames in its twenty
-    size_t want = std::max<size_t>(2 * bytes + 256, (size_t)1 << 20);
+    release();
+    // By default twice what is asked for and never less than 1 MB (the device has 288 GB): batch sizes wander from frame to frame
+    // (pool sizes, accepted rows, chain counts) and a buffer that regrows inside a frame costs that frame 0.3 - 0.4 ms (hipFree waits
+    // for the device, hipMalloc maps pages) — round 4's driver-timed run had three such frames in its twenty.  plv_memory_policy.
+    const size_t want = memory_book().sized(bytes, memory_book().dev_floor_kb.load());
     if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
       set_last_error("hipMalloc(%zu) failed", want);
       return PLV_E_NOMEM;
     }
     cap = want;
+    memory_book().add(memory_book().dev, memory_book().dev_peak, (long long)want);
     return PLV_OK;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      memory_book().dev.fetch_sub((long long)cap);
+    }
     p = nullptr;
     cap = 0;
   }
@@ -284,19 +309,22 @@ struct PinBuf {
     if (bytes <= cap) return PLV_OK;
     ++alloc_epoch();  // kernels write into pinned blocks too (result mirrors): a captured graph holds their addresses
     if (alloc_debug()) fprintf(stderr, "[plv alloc] pinned buffer %p: %zu -> %zu bytes asked\n", (void *)this, cap, bytes);
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = std::max<size_t>(2 * bytes + 256, (size_t)1 << 18);  // (as DevBuf::reserve: generous once instead of regrowing inside a frame)
+    release();
+    const size_t want = memory_book().sized(bytes, memory_book().pin_floor_kb.load());  // (as DevBuf::reserve: generous once instead of regrowing inside a frame)
     if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
       set_last_error("hipHostMalloc(%zu) failed", want);
       return PLV_E_NOMEM;
     }
     cap = want;
+    memory_book().add(memory_book().pin, memory_book().pin_peak, (long long)want);
     return PLV_OK;
   }
   void release() {
-    if (p) (void)hipHostFree(p);
+    if (p) {
+      (void)hipHostFree(p);
+      memory_book().pin.fetch_sub((long long)cap);
+    }
     p = nullptr;
     cap = 0;
   }

@@ -50,6 +50,31 @@ def test_replay_camera_imu_wheel(pkg, dataset, tmp_path):
     assert all(len(x) == 20 for x in rows) and all(float(x[8]) > 0 and float(x[14]) > 0 for x in rows)
 
 
+def test_memory_policy_bounds_what_the_library_holds(pkg, dataset, tmp_path):
+    """every buffer of the library grows to twice what is asked for and never below 1 MB (256 KB pinned) — right for one
+    context per 288 GB device, several-fold too much for a process with many contexts.  plv_memory_policy sets growth and floors,
+    plv_memory_bytes reports what is held: the same replay under the default policy and under (growth 100 %, floors 64 KB) gives the
+    same trajectory, the tight one holds a fraction of the memory, and both stay under a bound that a regression would break."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs = {}
+    try:
+        for name, policy in (("default", (200, 1024, 256)), ("tight", (100, 64, 64))):
+            pkg.memory_policy(*policy)          # (resets the peaks)
+            held = pkg.memory_bytes()
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), dataset, str(tmp_path / f"traj_{name}.txt")))
+            stats, times, poses = rp.replay(op)
+            m = pkg.memory_bytes()
+            runs[name] = (poses, m["device_peak"] - held["device"], m["pinned_peak"] - held["pinned"])
+            print(name, "policy", policy, ": device %.1f MB, pinned %.1f MB at the peak of the replay" % (runs[name][1] / 2**20, runs[name][2] / 2**20))
+    finally:
+        pkg.memory_policy(200, 1024, 256)
+    assert np.array_equal(runs["default"][0], runs["tight"][0])
+    assert 0 < runs["tight"][1] < 0.6 * runs["default"][1] and 0 < runs["tight"][2] < 0.6 * runs["default"][2], runs
+    assert runs["default"][1] < 400 * 2**20 and runs["default"][2] < 64 * 2**20, runs      # (752 x 480, 250 points, lines on)
+    with pytest.raises(pkg.PlvError):
+        pkg.memory_policy(50, -1, -1)
+
+
 def test_replay_with_imu_residual_poses(pkg, dataset, tmp_path):
     """est.use_imu_res (the shipped configuration's choice): observation poses from the preintegrated IMU records instead of the
     polynomial through the clones.  Camera frames sit on clone times here, so both give the same filter to a few millimetres."""
