@@ -336,7 +336,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   FldParams fp{ctx->cfg.line_length_threshold, (float)ctx->cfg.line_distance_threshold, ctx->cfg.canny_th1, ctx->cfg.canny_th2};
   const size_t bytes = 16 + kChainCap * (sizeof(FldChain) + sizeof(int));
   const size_t lab_off = bytes + ((2 * npix + 63) & ~(size_t)63) + npix * sizeof(int2);  // (behind the host stage's chain points)
-  TRY(T->pin.reserve(std::max(bytes + slot_cap * sizeof(float4), lab_off + npix + 64)));
+  // (behind the labels: the parts' pixel lists, ccl_flatten_kernel)
+  const size_t nblk = (npix + 255) / 256, sorted_off = (lab_off + npix + 63) & ~(size_t)63, bins_off = sorted_off + nblk * 256;
+  const size_t pin_end = bins_off + nblk * (size_t)(plv::line_label_parts() + 1) * sizeof(unsigned short);
+  TRY(T->pin.reserve(std::max(bytes + slot_cap * sizeof(float4), pin_end + 64)));
   char *hp = T->pin.as<char>();
   // host walk without hysteresis (the shipped thresholds are equal): the edge kernel writes the two maps straight into the pinned
   // buffer the host stage reads — no device copies of them, no copy commands behind the kernel
@@ -357,6 +360,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     b.lab_cnt = T->lab_cnt.as<int>();
     b.lab_roots = T->lab_roots.as<int>();
     b.lab_out = (uint8_t *)(hp + lab_off);
+    if (!plv::knob(plv::PLV_KNOB_PART_LISTS_OFF)) {
+      b.blk_sorted = (uint8_t *)(hp + sorted_off);
+      b.blk_bins = (unsigned short *)(hp + bins_off);
+    }
   }
   hipStream_t es = ctx->stream;
   if (launch_only && maps_to_host && T->edge_fork) {
@@ -364,6 +371,9 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     es = T->edge_stream;
   }
   T->edge_fork = false;
+  // (a helper thread the last detection's host stage was closed without — cut off in the middle of a part — reads the maps and lists
+  // this launch writes: nobody is inside a job from here on.  Immediate, unless that thread has been off its CPU for a whole frame.)
+  if (!prelaunched) plv::linehost::quiesce_helpers(T->host.fit);
   if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es, early ? T->early_hist : nullptr));
   if (with_labels && !T->ccl_stream) {
     PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->ccl_stream, hipStreamNonBlocking));
@@ -414,6 +424,7 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     J.hc = (FldChain *)(hp + 16);
     J.hlab = with_labels ? b.lab_out : nullptr;
     J.parts = with_labels ? plv::line_label_parts() : 0;
+    J.hsorted = with_labels ? b.blk_sorted : nullptr, J.hbins = with_labels ? b.blk_bins : nullptr;
     if (!maps_to_host) {
       PLV_HIP_CHECK(plv::memcpy_async(hmap, T->map.p, npix, hipMemcpyDeviceToHost, ctx->stream));
       PLV_HIP_CHECK(plv::memcpy_async(hmap + npix, T->half.p, npix, hipMemcpyDeviceToHost, ctx->stream));

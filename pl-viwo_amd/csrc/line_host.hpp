@@ -33,6 +33,10 @@ struct Job {
   // the root of the pixel's 8-connected component) % parts.  With them the host stage splits the detection by components (host_extract).
   const uint8_t *hlab = nullptr;
   int parts = 0;
+  // (nullable) the parts' pixels in raster order per run of 256 pixels (ccl_flatten_kernel: blk_sorted / blk_bins; lists_from_labels
+  // forms the same on the host): a part is then staged and seeded from its own pixels (detect_part)
+  const uint8_t *hsorted = nullptr;
+  const unsigned short *hbins = nullptr;
   int2 *hpts = nullptr;
   FldChain *hc = nullptr;
   std::vector<float> lines;
@@ -62,10 +66,27 @@ struct Fit {
     std::atomic<const Job *> job{nullptr};
     std::atomic<int> nfit{0};  // helper threads the job counts (thread i takes part when i < nfit): read with the rest of the slot,
                                // so that a thread waking late for a job it was not part of cannot mix two jobs
+    std::atomic<bool> closable{false};  // the poster closes the job itself (parts, generic jobs); false: it waits for every report
     std::atomic<bool> by_parts{false};
     std::atomic<const std::function<void(int)> *> task{nullptr};
   } desc[2];
   alignas(64) std::atomic<int> done_gen[kThreads] = {};  // thread i reports the last generation it finished
+  // Round 6b: a job no longer waits for a helper that is late or has been descheduled in the middle of its share (on a host shared
+  // with other tenants one frame in ten used to wait 1-9 ms for such a thread: bench trace, w_extract).  picked_gen[i] = the last
+  // generation helper i has started on (stored before it touches anything of the job); closed_gen = every share of the jobs up to
+  // this generation is taken care of: a helper that arrives later leaves the job alone, one inside a part of it stops at its next
+  // seed / chain.  The poster does what nobody has started (generic jobs: slot_claim) or does again what somebody has started and not
+  // finished (parts: winner / part[p][1]), closes the job, and waits only for helpers that picked it up before it was closed (they
+  // are running, or they hold the task's closure).  quiesce_helpers() — nobody is inside a job — comes before the buffers a part
+  // reads or writes are reused: at the start of the next detection, not at the end of this one.
+  // (tests: helper threads go to sleep for up to this many microseconds when they pick a job up and at every part they start — the
+  // late and descheduled helpers of a busy host, on demand: tests/host_sanitize)
+  std::atomic<int> chaos_us{0};
+  std::atomic<long> second_runs{0}, second_run_wins{0};  // parts the poster ran again; of those, the ones whose second run counted
+  alignas(64) std::atomic<int> picked_gen[kThreads] = {};
+  alignas(64) std::atomic<int> closed_gen{0};
+  std::atomic<int> slot_claim[kThreads + 1] = {};  // generic job: slot s has been started (by its helper or by the poster)
+  std::atomic<int> winner[kParts] = {};            // detection by parts: -1 undecided, else whose output counts (0 the claimer's, 1 the poster's second run)
   alignas(64) std::atomic<int> poster_waiting{0};       // the poster blocks on cv (under m) for the reports
   std::atomic<int> prewake{0};  // bumped (under m) when a job is on its way (prewake_helpers): sleeping helpers wake and poll for it
   alignas(64) std::atomic<int> next_part{0};
@@ -75,10 +96,12 @@ struct Fit {
     int chains = 0;
     float us_build = 0, us_walk = 0, us_fit = 0, us_start = 0;  // (reporting: PLV_KNOB_LINE_TIMING)
     int slot = 0, pixels = 0;
-  } part[kParts];
+  } part[kParts][2];
   std::chrono::steady_clock::time_point job_t0;
   struct Scratch {  // one per thread (index 0: the walking thread)
     std::vector<uint8_t> pad;
+    int clean_w = 0, clean_h = 0;  // pad is the bordered map of a clean_w x clean_h image with no edge left in it (what a finished walk leaves)
+    std::vector<uint32_t> seeds;   // a listed part's pixels in raster order, (y << 16) | x
     std::vector<int2> pts;
     std::vector<FldChain> chains;
   } scratch[kThreads + 1];
@@ -191,74 +214,117 @@ inline void walk_chains(const uint8_t *map, int w, int h, int length_threshold, 
   walk_padded(m, w, h, length_threshold, pts, chains, chain_cap, counts, published);
 }
 // (the walk proper, on a map with a one-pixel border that is never an edge; it clears what it consumes)
-inline void walk_padded(uint8_t *m, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
-                        std::atomic<int> *published) {
+// next(x, y): the next pixel in raster order that may still be an edge (the walk tests it), false when there is none left
+// (a seed source may end the walk early — a part somebody else has finished meanwhile: the map then still holds edges)
+template <class NextSeed>
+inline void walk_core(uint8_t *m, int w, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts, std::atomic<int> *published,
+                      NextSeed next) {
   static const int dx[8] = {1, 0, -1, -1, -1, 0, 1, 1}, dy[8] = {1, 1, 1, 0, -1, -1, -1, 0};
   const int pw = w + 2;
   int off[8];
   for (int i = 0; i < 8; ++i) off[i] = dy[i] * pw + dx[i];
   int n_chain = 0, n_slot = 0, n_pts = 0;
-  for (int r = 0; r < h; ++r) {
-    const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
-    for (int c = 0; c < w; ++c) {
-      // the next seed of this row: a vectorised byte search instead of a test per pixel (90 000 pixels, 20 000 of them edges, most
-      // of those consumed by earlier chains by the time the scan reaches them)
-      const uint8_t *nx = (const uint8_t *)memchr(row + c, 2, (size_t)(w - c));
-      if (!nx) break;
-      c = (int)(nx - row);
-      const int start = n_pts;
-      int x = c, y = r;
-      size_t idx = (size_t)(r + 1) * pw + c + 1;
-      pts[n_pts++] = make_int2(x, y);
-      m[idx] = 1;
-      float direction = 0.0f;
-      for (int step = 0;; ++step) {
-        // (eight byte tests per step.  Measured against it on the bench scene's maps: the neighbourhood read as three 32-bit words
-        // and a bit mask is 1.7x SLOWER — the words overlap the byte the previous step has just cleared and wait for that store — and
-        // eight branch-free byte loads + a loop over the set bits 1.15x slower: chains are mostly straight, the branches predict, and
-        // what a step costs is the float recurrence of `direction` (multiply, add, divide: ~20 cycles), which must stay as it is.)
-        int pick = -1;
-        float best = 7.0f;
-        if (step == 0) {
-          for (int i = 0; i < 8; ++i)
-            if (m[idx + off[i]] == 2) {
-              pick = i;
-              break;
-            }
-        } else {
-          for (int i = 0; i < 8; ++i) {
-            if (m[idx + off[i]] != 2) continue;
-            const float curr = i > 4 ? (float)(i - 8) : (float)i;
-            float diff = std::fabs(curr - direction);
-            diff = diff > 4.0f ? 8.0f - diff : diff;
-            if (diff <= best) {
-              best = diff;
-              pick = i;
-            }
+  for (int x, y; next(x, y);) {
+    size_t idx = (size_t)(y + 1) * pw + x + 1;
+    if (m[idx] != 2) continue;
+    const int start = n_pts;
+    pts[n_pts++] = make_int2(x, y);
+    m[idx] = 1;
+    float direction = 0.0f;
+    for (int step = 0;; ++step) {
+      // (eight byte tests per step.  Measured against it on the bench scene's maps: the neighbourhood read as three 32-bit words
+      // and a bit mask is 1.7x SLOWER — the words overlap the byte the previous step has just cleared and wait for that store — and
+      // eight branch-free byte loads + a loop over the set bits 1.15x slower: chains are mostly straight, the branches predict, and
+      // what a step costs is the float recurrence of `direction` (multiply, add, divide: ~20 cycles), which must stay as it is.)
+      int pick = -1;
+      float best = 7.0f;
+      if (step == 0) {
+        for (int i = 0; i < 8; ++i)
+          if (m[idx + off[i]] == 2) {
+            pick = i;
+            break;
+          }
+      } else {
+        for (int i = 0; i < 8; ++i) {
+          if (m[idx + off[i]] != 2) continue;
+          const float curr = i > 4 ? (float)(i - 8) : (float)i;
+          float diff = std::fabs(curr - direction);
+          diff = diff > 4.0f ? 8.0f - diff : diff;
+          if (diff <= best) {
+            best = diff;
+            pick = i;
           }
         }
-        if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
-        const int cdir = pick > 4 ? pick - 8 : pick;
-        direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
-        x += dx[pick];
-        y += dy[pick];
-        idx += off[pick];
-        pts[n_pts++] = make_int2(x, y);
-        m[idx] = 1;
       }
-      const int len = n_pts - start;
-      if (len >= length_threshold + 1 && n_chain < chain_cap) {
-        chains[n_chain++] = FldChain{start, len, n_slot};
-        n_slot += len / length_threshold + 1;
-        if (published) published->store(n_chain, std::memory_order_release);  // chain n_chain - 1 and its points are final
-      } else {
-        n_pts = start;
-      }
+      if (pick < 0 || (step > 0 && !(best < 2.0f))) break;
+      const int cdir = pick > 4 ? pick - 8 : pick;
+      direction = step == 0 ? (float)cdir : (direction * (float)step + (float)cdir) / (float)(step + 1);
+      x += dx[pick];
+      y += dy[pick];
+      idx += off[pick];
+      pts[n_pts++] = make_int2(x, y);
+      m[idx] = 1;
+    }
+    const int len = n_pts - start;
+    if (len >= length_threshold + 1 && n_chain < chain_cap) {
+      chains[n_chain++] = FldChain{start, len, n_slot};
+      n_slot += len / length_threshold + 1;
+      if (published) published->store(n_chain, std::memory_order_release);  // chain n_chain - 1 and its points are final
+    } else {
+      n_pts = start;
     }
   }
   counts[0] = n_chain;
   counts[1] = n_slot;
   counts[2] = n_pts;
+}
+inline void walk_padded(uint8_t *m, int w, int h, int length_threshold, int2 *pts, FldChain *chains, int chain_cap, int *counts,
+                        std::atomic<int> *published) {
+  // the seeds of a whole map: a vectorised byte search per row instead of a test per pixel (90 000 pixels, 20 000 of them edges, most
+  // of those consumed by earlier chains by the time the scan reaches them)
+  const int pw = w + 2;
+  int r = 0, c = 0;
+  walk_core(m, w, length_threshold, pts, chains, chain_cap, counts, published, [&](int &x, int &y) {
+    for (; r < h; ++r, c = 0) {
+      const uint8_t *row = m + (size_t)(r + 1) * pw + 1;
+      const uint8_t *nx = c < w ? (const uint8_t *)memchr(row + c, 2, (size_t)(w - c)) : nullptr;
+      if (!nx) continue;
+      x = (int)(nx - row), y = r;
+      c = x + 1;
+      return true;
+    }
+    return false;
+  });
+}
+// the seeds of a listed part: its pixels in raster order ((y << 16) | x)
+template <class Stop>
+inline void walk_listed(uint8_t *m, int w, const uint32_t *seeds, size_t n_seeds, int length_threshold, int2 *pts, FldChain *chains, int chain_cap,
+                        int *counts, Stop stop) {
+  size_t at = 0;
+  walk_core(m, w, length_threshold, pts, chains, chain_cap, counts, nullptr, [&](int &x, int &y) {
+    if (at >= n_seeds || stop()) return false;
+    const uint32_t s = seeds[at++];
+    x = (int)(s & 0xffffu), y = (int)(s >> 16);
+    return true;
+  });
+}
+
+// What ccl_flatten_kernel leaves next to the labels, formed from the labels on the host (the sanitizer driver and the tests): per run
+// of 256 pixels the run's pixels grouped by part, raster order inside a group.
+inline void lists_from_labels(const uint8_t *lab, int n, int parts, std::vector<uint8_t> &sorted, std::vector<unsigned short> &bins) {
+  const int nblk = (n + 255) / 256;
+  sorted.assign((size_t)nblk * 256, 0);
+  bins.assign((size_t)nblk * (parts + 1), 0);
+  for (int b = 0; b < nblk; ++b) {
+    unsigned short *bn = bins.data() + (size_t)b * (parts + 1);
+    int at = 0;
+    for (int p = 0; p < parts; ++p) {
+      bn[p] = (unsigned short)at;
+      for (int o = 0; o < 256 && b * 256 + o < n; ++o)
+        if (lab[b * 256 + o] == p + 1) sorted[(size_t)b * 256 + at++] = (uint8_t)o;
+    }
+    bn[parts] = (unsigned short)at;
+  }
 }
 
 // The host stage on the maps a job points to: chains in raster order of their seeds = the detector's output order; the tail of
@@ -279,28 +345,66 @@ inline void fit_one(Fit &F, const Job &J, int c) {
 // that are edges lie in its own component, and the walk only ever reads and clears those, so the raster walk over this map yields
 // exactly the chains the raster walk over the whole map yields inside these components, in the same order; the segments of a chain
 // depend on nothing but the chain.  The caller puts the parts' chains back into the raster order of their seeds.
-inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot = 0) {
+// kind: whose run this is — 0 the thread that claimed the part, 1 the poster doing it again because that thread has not finished
+// (host_extract); g: the job's generation.  The run gives up at its next seed / chain when the part has been decided by the other run
+// or the job has been closed; the one that gets to the end first sets winner[p] and its output (part[p][kind]) counts.
+inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, int kind, int g) {
   const auto tp0 = std::chrono::steady_clock::now();
+  auto stop = [&] { return F.winner[p].load(std::memory_order_relaxed) >= 0 || F.closed_gen.load(std::memory_order_relaxed) >= g; };
   const int w = J.w, h = J.h, pw = w + 2;
-  S.pad.resize((size_t)pw * (h + 2));
+  const bool listed = J.hsorted != nullptr && J.hbins != nullptr && w < 65536 && h < 65536;
+  if (S.pad.size() != (size_t)pw * (h + 2) || (listed && (S.clean_w != w || S.clean_h != h))) {
+    S.pad.assign((size_t)pw * (h + 2), 1);
+    S.clean_w = w, S.clean_h = h;
+  }
   uint8_t *m = S.pad.data();
-  memset(m, 1, (size_t)pw);
-  memset(m + (size_t)(h + 1) * pw, 1, (size_t)pw);
-  const uint8_t want = (uint8_t)(p + 1);
-  for (int r = 0; r < h; ++r) {
-    uint8_t *row = m + (size_t)(r + 1) * pw;
-    const uint8_t *lr = J.hlab + (size_t)r * w;
-    row[0] = 1;
-    for (int x = 0; x < w; ++x) row[x + 1] = (uint8_t)(1 + (lr[x] == want));
-    row[w + 1] = 1;
+  if (listed) {
+    // The part's own pixels (a fraction of a per cent of the map) instead of a pass over the labels of the whole image per part: the
+    // thread's map holds no edge when a walk is over — every listed pixel is a seed or a chain's — so staging a part is writing its
+    // pixels, and its seeds are those pixels in the order they are listed in (raster order).
+    const int n = w * h, nblk = (n + 255) / 256, stride = J.parts + 1;
+    S.seeds.clear();
+    int row = 0, col = 0;  // of the run's first pixel (a run is 256 pixels: it ends on the same row or the next, w >= 256, or later)
+    for (int b = 0; b < nblk; ++b) {
+      const unsigned short *bn = J.hbins + (size_t)b * stride;
+      const uint8_t *so = J.hsorted + (size_t)b * 256;
+      for (int q = bn[p], q1 = std::min<int>(bn[p + 1], 256); q < q1; ++q) {
+        int x = col + so[q], y = row;
+        while (x >= w) x -= w, ++y;
+        m[(size_t)(y + 1) * pw + x + 1] = 2;
+        S.seeds.push_back((uint32_t)y << 16 | (uint32_t)x);
+      }
+      col += 256;
+      while (col >= w) col -= w, ++row;
+    }
+  } else {
+    memset(m, 1, (size_t)pw);
+    memset(m + (size_t)(h + 1) * pw, 1, (size_t)pw);
+    const uint8_t want = (uint8_t)(p + 1);
+    for (int r = 0; r < h; ++r) {
+      uint8_t *row = m + (size_t)(r + 1) * pw;
+      const uint8_t *lr = J.hlab + (size_t)r * w;
+      row[0] = 1;
+      for (int x = 0; x < w; ++x) row[x + 1] = (uint8_t)(1 + (lr[x] == want));
+      row[w + 1] = 1;
+    }
   }
   S.pts.resize((size_t)w * h);
   S.chains.resize(kChainCap);
   int counts[4] = {0, 0, 0, 0};
   const auto tp1 = std::chrono::steady_clock::now();
-  walk_padded(m, w, h, J.length_threshold, S.pts.data(), S.chains.data(), kChainCap, counts);
+  if (listed)
+    walk_listed(m, w, S.seeds.data(), S.seeds.size(), J.length_threshold, S.pts.data(), S.chains.data(), kChainCap, counts, stop);
+  else
+    walk_padded(m, w, h, J.length_threshold, S.pts.data(), S.chains.data(), kChainCap, counts);
+  S.clean_w = w, S.clean_h = h;  // (either walk has consumed every edge of the map)
+  if (stop()) {  // (a walk that was cut short may have left edges behind)
+    if (listed)
+      for (const uint32_t sd : S.seeds) m[(size_t)((sd >> 16) + 1) * pw + (sd & 0xffffu) + 1] = 1;
+    return;
+  }
   const auto tp2 = std::chrono::steady_clock::now();
-  Fit::PartOut &O = F.part[p];
+  Fit::PartOut &O = F.part[p][kind];
   O.chains = counts[0];
   O.seed.resize(counts[0]), O.seg_at.resize(counts[0]), O.seg_n.resize(counts[0]);
   O.segs.resize((size_t)counts[1] + 1);
@@ -309,13 +413,28 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot =
     O.seed[c] = S.pts[ch.start].y * w + S.pts[ch.start].x;
     O.seg_at[c] = ch.slot;
     O.seg_n[c] = fit_chain(J.hhalf, w, h, J.length_threshold, J.distance_threshold, S.pts.data() + ch.start, ch.len, O.segs.data() + ch.slot);
+    if ((c & 7) == 7 && stop()) return;
   }
   const auto tp3 = std::chrono::steady_clock::now();
   auto us = [](auto a, auto b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
   O.us_start = us(F.job_t0, tp0), O.us_build = us(tp0, tp1), O.us_walk = us(tp1, tp2), O.us_fit = us(tp2, tp3), O.slot = slot, O.pixels = counts[2];
+  int undecided = -1;
+  F.winner[p].compare_exchange_strong(undecided, kind, std::memory_order_acq_rel);
 }
-inline void claim_parts(Fit &F, const Job &J, int slot) {
-  for (int p; (p = F.next_part.fetch_add(1, std::memory_order_relaxed)) < J.parts;) detect_part(F, J, p, F.scratch[slot], slot);
+inline void chaos_nap(Fit &F, unsigned a, unsigned b) {
+  const int c = F.chaos_us.load(std::memory_order_relaxed);
+  if (c <= 0) return;
+  unsigned x = a * 2654435761u ^ (b + 0x9e3779b9u) * 40503u;
+  x ^= x >> 15, x *= 2246822519u, x ^= x >> 13;
+  if (x & 1) std::this_thread::sleep_for(std::chrono::microseconds((x >> 8) % (unsigned)c));
+}
+inline void claim_parts(Fit &F, const Job &J, int slot, int g) {
+  while (F.closed_gen.load(std::memory_order_acquire) < g) {
+    const int p = F.next_part.fetch_add(1, std::memory_order_relaxed);
+    if (p >= J.parts) break;
+    if (slot) chaos_nap(F, (unsigned)(g * 64 + p), (unsigned)slot);
+    detect_part(F, J, p, F.scratch[slot], slot, 0, g);
+  }
 }
 
 // posts generation g = gen + 1 (the caller has filled nothing yet): fills its slot, stores g, wakes sleepers.  One poster at a time
@@ -325,6 +444,7 @@ inline int post_job(Fit &F, const Job *job, int nfit, bool by_parts, const std::
   Fit::Desc &D = F.desc[g & 1];
   D.job.store(job, std::memory_order_relaxed), D.nfit.store(nfit, std::memory_order_relaxed);
   D.by_parts.store(by_parts, std::memory_order_relaxed), D.task.store(task, std::memory_order_relaxed);
+  D.closable.store(by_parts || task != nullptr, std::memory_order_relaxed);
   {
     std::lock_guard<std::mutex> lk(F.m);
     F.gen.store(g, std::memory_order_release);
@@ -332,13 +452,41 @@ inline int post_job(Fit &F, const Job *job, int nfit, bool by_parts, const std::
   F.cv.notify_all();
   return g;
 }
-// waits until the first nfit helpers have reported generation g: polls, then blocks on cv (a report then takes m and notifies)
+// polls, then blocks on cv (a report then takes m and notifies) until done() holds
+template <class Done>
+inline void wait_helpers(Fit &F, Done done);
+// waits until the first nfit helpers have reported generation g
 inline void wait_reports(Fit &F, int nfit, int g) {
-  auto done = [&] {
+  wait_helpers(F, [&] {
     for (int i = 0; i < nfit; ++i)
       if (F.th[i].joinable() && F.done_gen[i].load() != g) return false;
     return true;
-  };
+  });
+}
+// closes job g (the poster has seen to every share of it) and waits for the helpers that picked it up before that: they are inside
+// one of its shares — a part stops at its next seed / chain — or about to find nothing left.  A helper that looks at the job later
+// sees it closed and leaves it alone (either its picked_gen store comes first in the single order of these operations and is seen
+// here, or the closed_gen store does and is seen there), so what the job points to — a closure on the poster's stack — may go.
+inline void close_job(Fit &F, int nfit, int g, bool wait = true) {
+  F.closed_gen.store(g);
+  if (!wait) return;  // (a detection by parts: what its late helpers touch stays in place until quiesce_helpers)
+  wait_helpers(F, [&] {
+    for (int i = 0; i < nfit; ++i)
+      if (F.th[i].joinable() && F.picked_gen[i].load() == g && F.done_gen[i].load() != g) return false;
+    return true;
+  });
+}
+// nobody is inside a job (a helper cut off in the middle of a part of the last detection, which was closed without it, may still be):
+// before the buffers the parts read (the pinned maps and lists) or write (Fit::part, winner) are used again
+inline void quiesce_helpers(Fit &F) {
+  wait_helpers(F, [&] {
+    for (int i = 0; i < Fit::kThreads; ++i)
+      if (F.th[i].joinable() && F.picked_gen[i].load() != F.done_gen[i].load()) return false;
+    return true;
+  });
+}
+template <class Done>
+inline void wait_helpers(Fit &F, Done done) {
   if (done()) return;
   const int spin_us = spin_budget_us().load(std::memory_order_relaxed);
   if (spin_us > 0) {
@@ -386,17 +534,28 @@ inline void fit_worker(HostStage *T, int me, int seen /* the generation current 
     const Fit::Desc &D = F.desc[g & 1];
     const Job *job = D.job.load(std::memory_order_relaxed);
     const int nfit = D.nfit.load(std::memory_order_relaxed);
-    const bool by_parts = D.by_parts.load(std::memory_order_relaxed);
+    const bool by_parts = D.by_parts.load(std::memory_order_relaxed), closable = D.closable.load(std::memory_order_relaxed);
     const std::function<void(int)> *task = D.task.load(std::memory_order_relaxed);
     std::atomic_thread_fence(std::memory_order_acquire);
     if (F.gen.load(std::memory_order_relaxed) != g) continue;  // (posted over while this thread was reading: it was not part of g)
     seen = g;
     if (me >= nfit) continue;  // (a thread this job does not count takes nothing and is not waited for)
+    chaos_nap(F, (unsigned)g, (unsigned)me + 77u);
+    F.picked_gen[me].store(g);  // (before anything of the job is touched: close_job)
+    if (closable && F.closed_gen.load() >= g) {  // too late: the poster has done this thread's share
+      F.done_gen[me].store(g);
+      if (F.poster_waiting.load()) {
+        { std::lock_guard<std::mutex> lk(F.m); }
+        F.cv.notify_all();
+      }
+      continue;
+    }
     if (task) {
-      (*task)(me + 1);
+      int unclaimed = 0;
+      if (F.slot_claim[me + 1].compare_exchange_strong(unclaimed, 1)) (*task)(me + 1);
     } else if (job) {
       const Job &J = *job;
-      if (by_parts) claim_parts(F, J, me + 1);
+      if (by_parts) claim_parts(F, J, me + 1, g);
       for (; !by_parts;) {
         const int avail = F.published.load(std::memory_order_acquire);
         const int c = claim_chain(F, avail);
@@ -435,6 +594,10 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   const bool by_parts = J.hlab != nullptr && J.parts >= 1 && J.parts <= Fit::kParts;
   const int nfit = by_parts ? std::min(fit_threads().load(std::memory_order_relaxed), J.parts - 1)
                             : std::min(std::min(fit_threads().load(std::memory_order_relaxed), 2), (size_t)J.w * J.h >= 60000 ? 2 : 1);
+  if (by_parts) {
+    quiesce_helpers(F);  // (a helper cut off inside a part of the last detection: Fit::part and winner are about to be written again)
+    for (int p = 0; p < J.parts; ++p) F.winner[p].store(-1, std::memory_order_relaxed);
+  }
   F.next_part.store(0, std::memory_order_relaxed);
   F.job_t0 = T1;
   {
@@ -447,8 +610,23 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
       if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
   }
   const int gen = post_job(F, &J, nfit, by_parts, nullptr);
+  int second_runs = 0;
   if (by_parts) {
-    claim_parts(F, J, 0);
+    claim_parts(F, J, 0, gen);
+    // Every part is claimed; those still undecided are with threads that have not finished — most of the time about to, now and then
+    // descheduled for milliseconds (other tenants' work on the same cores).  This thread has nothing else to do: it runs such a part
+    // again, into the part's second output, the earliest claimed first; whichever run ends first counts and the other gives up.
+    const bool wait_all = plv::knob(plv::PLV_KNOB_WAIT_ALL_HELPERS);  // (measurement: rounds 5-6a waited for every helper's report)
+    if (wait_all) wait_reports(F, nfit, gen);
+    for (; !wait_all;) {
+      int p = 0;
+      while (p < J.parts && F.winner[p].load(std::memory_order_acquire) >= 0) ++p;
+      if (p == J.parts) break;
+      ++second_runs;
+      detect_part(F, J, p, F.scratch[0], 0, 1, gen);
+      F.second_runs.fetch_add(1, std::memory_order_relaxed);
+      if (F.winner[p].load(std::memory_order_relaxed) == 1) F.second_run_wins.fetch_add(1, std::memory_order_relaxed);
+    }
   } else {
     walk_chains(J.hmap, J.w, J.h, J.length_threshold, J.hpts, J.hc, kChainCap, hcounts, T->pad, &F.published);
     F.walk_done.store(true, std::memory_order_release);
@@ -456,12 +634,18 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   auto T2 = std::chrono::steady_clock::now();
   if (!by_parts)
     for (int c; (c = claim_chain(F, std::min(hcounts[0], kChainCap))) >= 0;) fit_one(F, J, c);  // the walk is over: share what is left
-  wait_reports(F, nfit, gen);
+  if (by_parts)
+    close_job(F, nfit, gen, false);  // (every part is decided; a helper still inside one stops at its next seed and is waited for where
+                                     // the job's buffers are used again: quiesce_helpers)
+  else
+    wait_reports(F, nfit, gen);
+  auto T2b = std::chrono::steady_clock::now();
   J.lines.clear();
   if (by_parts) {
     // the parts' chains back in the raster order of their seeds = the detector's output order
     int total = 0;
-    for (int p = 0; p < J.parts; ++p) total += F.part[p].chains;
+    const Fit::PartOut *out[Fit::kParts];
+    for (int p = 0; p < J.parts; ++p) out[p] = &F.part[p][F.winner[p].load(std::memory_order_acquire) == 1 ? 1 : 0], total += out[p]->chains;
     if (total >= kChainCap) {
       set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
       return PLV_E_CAPACITY;
@@ -469,10 +653,10 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     std::vector<std::pair<int, int>> order;  // (seed, part << 16 | chain)
     order.reserve(total);
     for (int p = 0; p < J.parts; ++p)
-      for (int c = 0; c < F.part[p].chains; ++c) order.emplace_back(F.part[p].seed[c], (p << 16) | c);
+      for (int c = 0; c < out[p]->chains; ++c) order.emplace_back(out[p]->seed[c], (p << 16) | c);
     std::sort(order.begin(), order.end());
     for (const auto &o : order) {
-      const Fit::PartOut &O = F.part[o.second >> 16];
+      const Fit::PartOut &O = *out[o.second >> 16];
       const int c = o.second & 0xffff;
       for (int q = 0; q < O.seg_n[c]; ++q) {
         const float4 &sg = O.segs[O.seg_at[c] + q];
@@ -497,6 +681,13 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
       J.lines.insert(J.lines.end(), {x1, y1, x2, y2});
     }
   }
+  if (plv::host_phases().on) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    plv::host_phases().add("detect host stage: the worker's own parts (or walk)", us(T1, T2));
+    plv::host_phases().add("detect host stage: job closed (helpers inside a part)", us(T2, T2b));
+    plv::host_phases().add("detect host stage: parts run a second time (count)", second_runs);
+    plv::host_phases().add("detect host stage: chains merged, segments out", us(T2b, std::chrono::steady_clock::now()));
+  }
   if (timing) {
     auto T3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -506,8 +697,10 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
             hcounts[2], edges);
     if (by_parts) {
       fprintf(stderr, "  parts (thread: start + build + walk + fit us, chain points):");
-      for (int p = 0; p < J.parts; ++p)
-        fprintf(stderr, " %d(t%d: %.0f + %.0f + %.0f + %.0f, %d)", p + 1, F.part[p].slot, F.part[p].us_start, F.part[p].us_build, F.part[p].us_walk, F.part[p].us_fit, F.part[p].pixels);
+      for (int p = 0; p < J.parts; ++p) {
+        const Fit::PartOut &O = F.part[p][F.winner[p].load() == 1 ? 1 : 0];
+        fprintf(stderr, " %d(t%d%s: %.0f + %.0f + %.0f + %.0f, %d)", p + 1, O.slot, F.winner[p].load() == 1 ? " second run" : "", O.us_start, O.us_build, O.us_walk, O.us_fit, O.pixels);
+      }
       fprintf(stderr, "\n");
     }
   }
@@ -619,8 +812,9 @@ inline void prewake_helpers(HostStage *T) {
   F.cv.notify_all();
 }
 
-// fn(slot) on the calling thread (slot 0) and on `nhelpers` helper threads of the stage (slots 1 .. nhelpers), all at once; returns
-// when every one of them has returned
+// fn(slot) for slot 0 .. nhelpers, each exactly once: slot 0 on the calling thread, slot s on helper thread s - 1 of the stage — or on
+// the calling thread when that helper has not started it by the time the caller gets there (a late or descheduled helper is not
+// waited for: Fit::slot_claim, close_job).  Returns when every slot has returned.
 inline void run_on_helpers(HostStage *T, int nhelpers, const std::function<void(int)> &fn) {
   Fit &F = T->fit;
   nhelpers = std::max(0, std::min(nhelpers, (int)Fit::kThreads));
@@ -637,9 +831,19 @@ inline void run_on_helpers(HostStage *T, int nhelpers, const std::function<void(
     for (int i = 0; i < nhelpers; ++i)
       if (!F.th[i].joinable()) F.th[i] = std::thread(fit_worker, T, i, gen_now);
   }
+  for (int sl = 1; sl <= nhelpers; ++sl) F.slot_claim[sl].store(0, std::memory_order_relaxed);  // (nobody is inside a generic job now: the last one was closed)
   const int gen = post_job(F, nullptr, nhelpers, false, &fn);
   fn(0);
-  wait_reports(F, nhelpers, gen);  // (fn lives with the caller until every thread that may call it has reported)
+  if (plv::knob(plv::PLV_KNOB_WAIT_ALL_HELPERS)) {
+    wait_reports(F, nhelpers, gen);
+    F.closed_gen.store(gen);
+    return;
+  }
+  for (int sl = 1; sl <= nhelpers; ++sl) {
+    int unclaimed = 0;
+    if (F.slot_claim[sl].compare_exchange_strong(unclaimed, 1)) fn(sl);
+  }
+  close_job(F, nhelpers, gen);  // (fn lives with the caller until every thread that may call it has reported)
 }
 
 // assign_points with the lines split into contiguous ranges over the stage's threads: a line's assignment depends on nothing but the

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(CN_T *CN_T) canny_kernel(const uint8_t *__rest
 #define CCL_BIG 8
 #define CCL_HASHED 16
 #define CCL_ROOT_CAP 4096
+#define CCL_PARTS (CCL_BIG + CCL_HASHED)
 __global__ void __launch_bounds__(256) ccl_boundary_kernel(int *__restrict__ L, int w, int h, int *__restrict__ n_roots) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) *n_roots = 0;
@@ -236,16 +237,50 @@ __global__ void __launch_bounds__(1024) ccl_assign_kernel(int *__restrict__ cnt,
     cnt[root] = -(rank < CCL_BIG ? 1 + rank : 1 + CCL_BIG + (int)(((unsigned)root * 2654435761u >> 8) % (unsigned)CCL_HASHED));
   }
 }
-__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, const int *__restrict__ cnt, uint8_t *__restrict__ lab_out, int min_px) {
+// Next to the part of every pixel the launch leaves, per run of 256 pixels in raster order (= one workgroup), the pixels of every part
+// in raster order: blk_sorted[256 * b + ..] = the run's pixels (as offsets 0 .. 255 inside the run) grouped by part, blk_bins[b][p] ..
+// blk_bins[b][p + 1] the group of part p + 1.  The host stage then forms a part's private map and its seeds from the part's own
+// pixels (detect_part) instead of reading the labels of the whole image for every part.  Counting sort in LDS: a pixel's place is
+// its part's start + the part's pixels in the waves before + those in the lanes before (ballots).
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(const int *__restrict__ L, int n, const int *__restrict__ cnt, uint8_t *__restrict__ lab_out, int min_px,
+                                                          uint8_t *__restrict__ blk_sorted, unsigned short *__restrict__ blk_bins) {
+  __shared__ unsigned short wcnt[4][CCL_PARTS], start[CCL_PARTS + 1];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   uint8_t v = 0;
-  const int r = L[i];
-  if (r >= 0) {
-    const int c = cnt[r];  // -(part) for a listed root; a root beyond the list keeps its positive count
-    v = (uint8_t)(c < 0 ? -c : (c < min_px ? 255 : 1 + CCL_BIG + (int)(((unsigned)r * 2654435761u >> 8) % (unsigned)CCL_HASHED)));
+  if (i < n) {
+    const int r = L[i];
+    if (r >= 0) {
+      const int c = cnt[r];  // -(part) for a listed root; a root beyond the list keeps its positive count
+      v = (uint8_t)(c < 0 ? -c : (c < min_px ? 255 : 1 + CCL_BIG + (int)(((unsigned)r * 2654435761u >> 8) % (unsigned)CCL_HASHED)));
+    }
+    lab_out[i] = v;
   }
-  lab_out[i] = v;
+  if (!blk_sorted) return;  // (uniform)
+  const int part = (v >= 1 && v <= CCL_PARTS) ? v - 1 : -1, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int before = 0;
+  for (int p = 0; p < CCL_PARTS; ++p) {
+    const unsigned long long m = __ballot(part == p);
+    if (part == p) before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave][p] = (unsigned short)__popcll(m);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int tot = lane < CCL_PARTS ? wcnt[0][lane] + wcnt[1][lane] + wcnt[2][lane] + wcnt[3][lane] : 0, inc = tot;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane < CCL_PARTS) start[lane + 1] = (unsigned short)inc;
+    if (lane == 0) start[0] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x <= CCL_PARTS) blk_bins[(size_t)blockIdx.x * (CCL_PARTS + 1) + threadIdx.x] = start[threadIdx.x];
+  if (part >= 0) {
+    int at = start[part] + before;
+    for (int w = 0; w < wave; ++w) at += wcnt[w][part];
+    blk_sorted[(size_t)blockIdx.x * 256 + at] = (uint8_t)threadIdx.x;
+  }
 }
 
 // hysteresis: promote weak pixels adjacent to an edge until nothing changes (one workgroup sweep loop)
@@ -424,12 +459,12 @@ int launch_line_labels(plv_ctx *ctx, int w, int h, FldBuffers &b, hipStream_t st
   }
   {
     ProfScope ps(ctx->prof, "ccl_flatten_kernel", st);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_out, min_px);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b.lab_work, n, b.lab_cnt, b.lab_out, min_px, b.blk_sorted, b.blk_bins);
   }
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }
-int line_label_parts() { return CCL_BIG + CCL_HASHED; }
+int line_label_parts() { return CCL_PARTS; }
 size_t line_label_roots_bytes() { return (CCL_ROOT_CAP + 4) * sizeof(int); }
 
 // stage 2 (device variant): chain walking by one wave

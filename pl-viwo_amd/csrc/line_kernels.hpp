@@ -26,6 +26,9 @@ struct FldBuffers {
   int *lab_cnt = nullptr;       // [w*h] pixels per component at its root, then -(part) there
   int *lab_roots = nullptr;     // [line_label_roots_bytes()] the roots' list and its counter
   uint8_t *lab_out = nullptr;   // [w*h] parts, host-visible (0 not an edge, else 1 .. line_label_parts())
+  // (nullable, host-visible) the parts' pixels in raster order, per run of 256 pixels: see ccl_flatten_kernel
+  uint8_t *blk_sorted = nullptr;        // [256 * ceil(w*h / 256)]
+  unsigned short *blk_bins = nullptr;   // [ceil(w*h / 256)][line_label_parts() + 1]
 };
 
 // d_hist: d_img is the RAW image and d_hist its histogram (the kernel equalises on the fly: canny_kernel); null: d_img is the equalised image

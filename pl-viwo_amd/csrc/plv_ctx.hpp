@@ -100,6 +100,8 @@ enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_
                   PLV_KNOB_LK_LEGACY_LOOP = 1u << 21, // lk_kernel<0>: the iteration of rounds 2-4 (tools/lk_exp.py; same bits, slower)
                   PLV_KNOB_LINE_LABELS_OFF = 1u << 22,
                   PLV_KNOB_LK_AHEAD = 1u << 23,
+                  PLV_KNOB_WAIT_ALL_HELPERS = 1u << 27,   // the line worker's jobs wait for every helper thread's report (rounds 5-6a) instead of doing a late helper's share themselves
+                  PLV_KNOB_PART_LISTS_OFF = 1u << 26,     // the host stage builds a part's map from the labels of the whole image (round 5) instead of the part's own pixel list
                   PLV_KNOB_ASSIGN_ONE_THREAD = 1u << 25,  // the line feed's point-line assignment on the worker alone (rounds 1-5)
                   PLV_KNOB_NO_SPECULATION = 1u << 24 };    // plv_camera_frame submits the point update after the flow's result has reached the host (rounds 1-5), not behind the flow          // lk_ahead_kernel (round 6 experiment: all levels' templates first, search tiles a level ahead; same bits, no faster)  // the line detector's host stage walks the edge map as one sequence (rounds 2-4) instead of by labelled components
 // The mask starts from PLV_DEBUG_KNOBS in the environment (the library's only measurement variable; plv_debug_knobs changes it at run time)

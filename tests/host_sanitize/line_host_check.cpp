@@ -166,12 +166,22 @@ int main(int argc, char **argv) {
       J.hmap = maps[i].data(), J.hhalf = halves[i].data(), J.hpts = pts.data(), J.hc = chains.data();
       // every other pass with the components labelled: the detection split into 16, 3 or 1 parts over the walking thread and the
       // helpers (host_extract -> detect_part) must give the same segments in the same order
-      std::vector<uint8_t> lab;
+      // (the second half of the passes with the parts' pixel lists next to the labels — what ccl_flatten_kernel leaves: a part is then
+      // staged and seeded from its own pixels on the thread's persistent map)
+      std::vector<uint8_t> lab, sorted;
+      std::vector<unsigned short> bins;
       if ((r + i) % 2 == 1) {
         J.parts = r % 3 == 0 ? plv::linehost::Fit::kParts : (r % 3 == 1 ? 3 : 1);
         lab = component_labels(maps[i].data(), w, h, J.parts);
         J.hlab = lab.data();
+        if (r >= 3) {
+          plv::linehost::lists_from_labels(lab.data(), (int)npix, J.parts, sorted, bins);
+          J.hsorted = sorted.data(), J.hbins = bins.data();
+        }
       }
+      // (the last two passes with helper threads that fall asleep at random — when they pick a job up, when they start a part: jobs
+      // are closed without them, parts run a second time, late helpers find closed jobs; same segments, same assignment)
+      stage.fit.chaos_us.store(r >= 4 ? 20000 : 0);
       if (host_extract(&stage, J, false) != 0) return 3;
       // the same detection on this thread alone: the threaded one must give the same segments in the same order
       std::vector<int2> p2(npix);
@@ -279,8 +289,11 @@ int main(int argc, char **argv) {
       total_kept += (long)A.kept.size();
       last_lines = kept_lines;
       last = A;
+      // (the job and its label lists live in this block; the library keeps its own in place until the next detection is launched and
+      // quiesces there)
+      plv::linehost::quiesce_helpers(stage.fit);
     }
-  printf("ok: %d maps x %d repeats, %ld segments, %ld kept by the assignment, %ld matched to a line of the map before\n", n, reps, total_lines, total_kept,
-         total_matched);
+  printf("ok: %d maps x %d repeats, %ld segments, %ld kept by the assignment, %ld matched to a line of the map before; %ld parts run a second time, %ld of those runs counted\n",
+         n, reps, total_lines, total_kept, total_matched, stage.fit.second_runs.load(), stage.fit.second_run_wins.load());
   return 0;
 }

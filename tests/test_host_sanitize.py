@@ -53,6 +53,10 @@ def test_line_host_stage_under_sanitizers(maps, tmp_path, san):
     import re
     m = re.search(r"(\d+) kept by the assignment, (\d+) matched", r.stdout)
     assert m and int(m.group(1)) > 100 and int(m.group(2)) > 50, r.stdout[-500:]   # (the plain checkers had something to check)
+    # helpers that fall asleep inside their share (the driver's last passes): parts were run a second time by the poster, and some of
+    # those second runs were the ones that counted — same segments either way
+    m = re.search(r"(\d+) parts run a second time, (\d+) of those runs counted", r.stdout)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r.stdout[-500:]
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
 
 

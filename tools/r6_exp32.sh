@@ -1,0 +1,5 @@
+set -u
+OUT=gpurun_out/r6_e32; mkdir -p $OUT; export TMPDIR=/tmp
+A="--no-cpu --no-stress --no-pcie --no-variants"
+PLV_DEBUG_KNOBS=16384 PLV_BENCH_STOP_AFTER_MAIN=1 timeout 600 python3 bench.py --steps 300 --warmup 10 $A > /dev/null 2> $OUT/new.err
+PLV_DEBUG_KNOBS=$((16384+67108864)) PLV_BENCH_STOP_AFTER_MAIN=1 timeout 600 python3 bench.py --steps 300 --warmup 10 $A > /dev/null 2> $OUT/old.err
