@@ -1039,8 +1039,8 @@ __device__ __forceinline__ bool collinear_last7(const double (&x)[7], const doub
   return col;
 }
 
-__device__ __forceinline__ float epi_err9(const double (&F)[9], const float *m1, const float *m2, int i) {
-  double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
+__device__ __forceinline__ float epi_err9(const double (&F)[9], float fx1, float fy1, float fx2, float fy2) {
+  double x1 = fx1, y1 = fy1, x2 = fx2, y2 = fy2;
   double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
   double s2 = 1. / (a * a + b * b);
   double d2 = x2 * a + y2 * b + c;
@@ -1050,6 +1050,9 @@ __device__ __forceinline__ float epi_err9(const double (&F)[9], const float *m1,
   double s1 = 1. / (a * a + b * b);
   double d1 = x1 * a + y1 * b + c;
   return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+__device__ __forceinline__ float epi_err9(const double (&F)[9], const float *m1, const float *m2, int i) {
+  return epi_err9(F, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
 }
 
 // Models of hypothesis h.  Returns a 3-bit validity mask; model k (root k of the cubic, in
@@ -1217,6 +1220,16 @@ __global__ void __launch_bounds__(64) ransac_hyp_kernel(const float *__restrict_
                                                         double *__restrict__ models /* [hyp][28]: 3 x 9 + valid mask, or null */) {
   __shared__ RansacLds L;
   const int h = blockIdx.x, lane = threadIdx.x;
+  // this lane's points of the inlier count (lane, lane + 64, ..): fetched before the solver starts, so that the three counts below
+  // run on registers instead of waiting for memory once per point and model (18 dependent rounds of loads at 340 points)
+  constexpr int RH_PL = 8;
+  float2 q1[RH_PL], q2[RH_PL];
+#pragma unroll
+  for (int u = 0; u < RH_PL; ++u) {
+    const int i = min(lane + 64 * u, n - 1);
+    q1[u] = reinterpret_cast<const float2 *>(m1)[i];
+    q2[u] = reinterpret_cast<const float2 *>(m2)[i];
+  }
   double F[3][9];
   const int valid = wave_models(L, m1, m2, n, seed, h, F);
   if (models && lane < 28) {  // kept for ransac_select_kernel: the winner's model is read back instead of being solved again
@@ -1230,7 +1243,10 @@ __global__ void __launch_bounds__(64) ransac_hyp_kernel(const float *__restrict_
   for (int k = 0; k < 3; ++k) {
     if (valid & (1 << k)) {
       int c = 0;
-      for (int i = lane; i < n; i += 64) c += epi_err9(F[k], m1, m2, i) <= t;
+#pragma unroll
+      for (int u = 0; u < RH_PL; ++u)
+        if (lane + 64 * u < n) c += epi_err9(F[k], q1[u].x, q1[u].y, q2[u].x, q2[u].y) <= t;
+      for (int i = lane + 64 * RH_PL; i < n; i += 64) c += epi_err9(F[k], m1, m2, i) <= t;
       c = wave_sum_i32(c);
       if (lane == 0) counts[h * 3 + slot] = c;
       ++slot;

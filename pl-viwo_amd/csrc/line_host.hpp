@@ -90,9 +90,13 @@ struct Fit {
   alignas(64) std::atomic<int> poster_waiting{0};       // the poster blocks on cv (under m) for the reports
   std::atomic<int> prewake{0};  // bumped (under m) when a job is on its way (prewake_helpers): sleeping helpers wake and poll for it
   alignas(64) std::atomic<int> next_part{0};
+  int claim_order[kParts] = {};  // the q-th claim takes part claim_order[q] (the largest parts first: host_extract)
+  std::vector<std::pair<int, int>> merged, merge_tmp;  // (seed, part << 16 | chain) of the parts taken in so far, sorted
   struct PartOut {
     std::vector<int> seed, seg_at, seg_n;  // per chain: raster index of its seed, first segment, segments
     std::vector<float4> segs;
+    std::vector<float> lines;   // the chains' segments that pass the detector's tail (x2, FilterShortLines), chain after chain
+    std::vector<int> line_at;   // [chains + 1] chain c's lines: line_at[c] .. line_at[c + 1]
     int chains = 0;
     float us_build = 0, us_walk = 0, us_fit = 0, us_start = 0;  // (reporting: PLV_KNOB_LINE_TIMING)
     int slot = 0, pixels = 0;
@@ -415,6 +419,20 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, 
     O.seg_n[c] = fit_chain(J.hhalf, w, h, J.length_threshold, J.distance_threshold, S.pts.data() + ch.start, ch.len, O.segs.data() + ch.slot);
     if ((c & 7) == 7 && stop()) return;
   }
+  // the detector's tail on the part's own thread: what host_extract copies out in the order of the seeds
+  O.lines.clear();
+  O.line_at.resize((size_t)counts[0] + 1);
+  for (int c = 0; c < counts[0] && c < kChainCap; ++c) {
+    O.line_at[c] = (int)O.lines.size() / 4;
+    for (int q = 0; q < O.seg_n[c]; ++q) {
+      const float4 &sg = O.segs[O.seg_at[c] + q];
+      const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
+      const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+      if (!(l2 > J.thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
+      O.lines.insert(O.lines.end(), {x1, y1, x2, y2});
+    }
+  }
+  O.line_at[counts[0]] = (int)O.lines.size() / 4;
   const auto tp3 = std::chrono::steady_clock::now();
   auto us = [](auto a, auto b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
   O.us_start = us(F.job_t0, tp0), O.us_build = us(tp0, tp1), O.us_walk = us(tp1, tp2), O.us_fit = us(tp2, tp3), O.slot = slot, O.pixels = counts[2];
@@ -422,7 +440,8 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, 
   F.winner[p].compare_exchange_strong(undecided, kind, std::memory_order_acq_rel);
 }
 inline void chaos_nap(Fit &F, unsigned a, unsigned b) {
-  const int c = F.chaos_us.load(std::memory_order_relaxed);
+  int c = F.chaos_us.load(std::memory_order_relaxed);
+  if (c <= 0 && plv::knob(plv::PLV_KNOB_HELPER_NAPS)) c = 200;
   if (c <= 0) return;
   unsigned x = a * 2654435761u ^ (b + 0x9e3779b9u) * 40503u;
   x ^= x >> 15, x *= 2246822519u, x ^= x >> 13;
@@ -430,8 +449,9 @@ inline void chaos_nap(Fit &F, unsigned a, unsigned b) {
 }
 inline void claim_parts(Fit &F, const Job &J, int slot, int g) {
   while (F.closed_gen.load(std::memory_order_acquire) < g) {
-    const int p = F.next_part.fetch_add(1, std::memory_order_relaxed);
-    if (p >= J.parts) break;
+    const int q = F.next_part.fetch_add(1, std::memory_order_relaxed);
+    if (q >= J.parts) break;
+    const int p = F.claim_order[q];
     if (slot) chaos_nap(F, (unsigned)(g * 64 + p), (unsigned)slot);
     detect_part(F, J, p, F.scratch[slot], slot, 0, g);
   }
@@ -597,6 +617,17 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   if (by_parts) {
     quiesce_helpers(F);  // (a helper cut off inside a part of the last detection: Fit::part and winner are about to be written again)
     for (int p = 0; p < J.parts; ++p) F.winner[p].store(-1, std::memory_order_relaxed);
+    // the order the parts are claimed in: the largest first (the threads' shares end level), sizes from the parts' pixel lists
+    int size[Fit::kParts] = {};
+    if (J.hbins) {
+      const int nblk = (J.w * J.h + 255) / 256, stride = J.parts + 1;
+      for (int b = 0; b < nblk; ++b) {
+        const unsigned short *bn = J.hbins + (size_t)b * stride;
+        for (int p = 0; p < J.parts; ++p) size[p] += bn[p + 1] - bn[p];
+      }
+    }
+    for (int p = 0; p < J.parts; ++p) F.claim_order[p] = p;
+    if (J.hbins) std::stable_sort(F.claim_order, F.claim_order + J.parts, [&](int a, int b) { return size[a] > size[b]; });
   }
   F.next_part.store(0, std::memory_order_relaxed);
   F.job_t0 = T1;
@@ -616,12 +647,38 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
     // Every part is claimed; those still undecided are with threads that have not finished — most of the time about to, now and then
     // descheduled for milliseconds (other tenants' work on the same cores).  This thread has nothing else to do: it runs such a part
     // again, into the part's second output, the earliest claimed first; whichever run ends first counts and the other gives up.
+    // Every part is claimed; those still undecided are with threads that have not finished — most of the time about to, now and then
+    // descheduled for milliseconds (other tenants' work on the same cores).  This thread takes the decided parts' chains into the
+    // order of their seeds meanwhile (a part's chains come in that order: one merge of two sorted lists per part, all but the last
+    // of them inside the wait), and when nothing is left to take in it runs an undecided part again, into the part's second output,
+    // the earliest claimed first; whichever run ends first counts and the other gives up.
     const bool wait_all = plv::knob(plv::PLV_KNOB_WAIT_ALL_HELPERS);  // (measurement: rounds 5-6a waited for every helper's report)
     if (wait_all) wait_reports(F, nfit, gen);
-    for (; !wait_all;) {
-      int p = 0;
-      while (p < J.parts && F.winner[p].load(std::memory_order_acquire) >= 0) ++p;
-      if (p == J.parts) break;
+    F.merged.clear();
+    bool taken[Fit::kParts] = {};
+    for (int left = J.parts; left > 0;) {
+      bool progress = false;
+      for (int p = 0; p < J.parts; ++p) {
+        int wn;
+        if (taken[p] || (wn = F.winner[p].load(std::memory_order_acquire)) < 0) continue;
+        const Fit::PartOut &O = F.part[p][wn];
+        F.merge_tmp.resize(F.merged.size() + (size_t)O.chains);
+        size_t a = 0, o = 0;
+        for (int c = 0; c < O.chains;) {
+          if (a < F.merged.size() && F.merged[a].first < O.seed[c])
+            F.merge_tmp[o++] = F.merged[a++];
+          else
+            F.merge_tmp[o++] = std::make_pair(O.seed[c], (p << 16) | c), ++c;
+        }
+        while (a < F.merged.size()) F.merge_tmp[o++] = F.merged[a++];
+        F.merged.swap(F.merge_tmp);
+        taken[p] = true, progress = true, --left;
+      }
+      if (progress || left == 0) continue;
+      int q = 0;
+      while (q < J.parts && F.winner[F.claim_order[q]].load(std::memory_order_acquire) >= 0) ++q;
+      if (q == J.parts) continue;
+      const int p = F.claim_order[q];
       ++second_runs;
       detect_part(F, J, p, F.scratch[0], 0, 1, gen);
       F.second_runs.fetch_add(1, std::memory_order_relaxed);
@@ -642,29 +699,18 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   auto T2b = std::chrono::steady_clock::now();
   J.lines.clear();
   if (by_parts) {
-    // the parts' chains back in the raster order of their seeds = the detector's output order
-    int total = 0;
-    const Fit::PartOut *out[Fit::kParts];
-    for (int p = 0; p < J.parts; ++p) out[p] = &F.part[p][F.winner[p].load(std::memory_order_acquire) == 1 ? 1 : 0], total += out[p]->chains;
+    // the parts' chains in the raster order of their seeds = the detector's output order
+    const int total = (int)F.merged.size();
     if (total >= kChainCap) {
       set_last_error("plv_detect_lines: more than %d edge chains", kChainCap);
       return PLV_E_CAPACITY;
     }
-    std::vector<std::pair<int, int>> order;  // (seed, part << 16 | chain)
-    order.reserve(total);
-    for (int p = 0; p < J.parts; ++p)
-      for (int c = 0; c < out[p]->chains; ++c) order.emplace_back(out[p]->seed[c], (p << 16) | c);
-    std::sort(order.begin(), order.end());
-    for (const auto &o : order) {
+    const Fit::PartOut *out[Fit::kParts];
+    for (int p = 0; p < J.parts; ++p) out[p] = &F.part[p][F.winner[p].load(std::memory_order_acquire) == 1 ? 1 : 0];
+    for (const auto &o : F.merged) {
       const Fit::PartOut &O = *out[o.second >> 16];
       const int c = o.second & 0xffff;
-      for (int q = 0; q < O.seg_n[c]; ++q) {
-        const float4 &sg = O.segs[O.seg_at[c] + q];
-        const float x1 = sg.x * 2, y1 = sg.y * 2, x2 = sg.z * 2, y2 = sg.w * 2;  // REF :218-220
-        const float l2 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
-        if (!(l2 > J.thr2)) continue;  // FilterShortLines(lines0, 40)   REF :232, :435-448
-        J.lines.insert(J.lines.end(), {x1, y1, x2, y2});
-      }
+      J.lines.insert(J.lines.end(), O.lines.begin() + 4 * (size_t)O.line_at[c], O.lines.begin() + 4 * (size_t)O.line_at[c + 1]);
     }
     hcounts[0] = total;
   } else if (hcounts[0] >= kChainCap) {

@@ -256,6 +256,18 @@ def test_component_split_detection_matches_the_oracle(pkg, lo, scene, mount):
                 ctx.line_detect_launch(0)
                 got = ctx.detect_lines(0)       # (joins the launched detection of this frame: the labelled, component-split one)
                 assert len(ref) > 100 and got.shape == ref.shape and np.array_equal(got, ref), (scene, threads, len(ref), len(got))
+        # (round 6b) helper threads that fall asleep at random, at a job's pick-up or a part's start: the worker closes jobs without
+        # them, runs their parts a second time, takes their slots of the feed's jobs — the same segments, the same kept lines
+        pkg.line_worker_config(-1, 7)
+        pkg.debug_knobs(1 << 28)
+        for rep in range(4):
+            for img in imgs:
+                ctx.feed_image(img)
+                ref = lo.detect_lines(ctx.pyramid_level(0, 0))
+                ctx.line_detect_launch(0)
+                got = ctx.detect_lines(0)
+                assert got.shape == ref.shape and np.array_equal(got, ref), (scene, "naps", rep)
     finally:
+        pkg.debug_knobs(0)
         pkg.line_worker_config(spin, fit)
         ctx.close()

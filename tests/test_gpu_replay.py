@@ -421,6 +421,32 @@ def test_chained_line_launch_equals_the_unchained(pkg, street_dataset, tmp_path)
     assert chained["unchained"] == 0 and chained["chained"] >= 0.9 * s0["line_updates"] and chained["chained"] >= 10, chained
 
 
+def test_sleeping_helper_threads_change_nothing(pkg, street_dataset, tmp_path):
+    """Round 6b: the line worker's jobs (the detection's parts, the feed's point-line assignment and matching) no longer wait for a helper
+    thread that is late or has been descheduled inside its share — the worker runs such a part a second time and takes slots nobody
+    has started.  With helpers that fall asleep at random (measurement knob 1 << 28: up to 200 us at a job's pick-up and at a part's
+    start) and with the rounds-5 protocol (1 << 27: every helper's report is waited for): the same filter, bit for bit, as the default
+    run, over a drive with lines."""
+    options, rp = importlib.import_module("plviwo_amd.options"), importlib.import_module("plviwo_amd.replay")
+    runs = {}
+    try:
+        for name, mask in (("default", 0), ("naps", 1 << 28), ("wait_all", 1 << 27)):
+            pkg.debug_knobs(mask)
+            op = options.load_options(sd.write_config(str(tmp_path / "config"), street_dataset, str(tmp_path / f"traj_{name}.txt")))
+            op.est.cam.use_lines = True
+            runs[name] = rp.replay(op)
+    finally:
+        pkg.debug_knobs(0)
+    s0, t0, p0 = runs["default"]
+    assert s0["line_updates"] >= 10 and s0["cam_updates"] >= 40
+    for name in ("naps", "wait_all"):
+        s1, t1, p1 = runs[name]
+        for key in s0:
+            if not key.startswith("time"):
+                assert s1[key] == s0[key], (name, key, s1[key], s0[key])
+        assert np.array_equal(t1, t0) and np.array_equal(p1, p0), name
+
+
 def test_prior_factor_started_late_equals_the_prefetched(pkg, street_dataset, tmp_path):
     """The whitened update's prior factor started behind the Jacobian launch (measurement knob 2, plv_debug_knobs: the
     side stream reads the column map that launch publishes, so it must be ordered behind it — ADVICE r3: it was not) against the
