@@ -322,6 +322,10 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
   }
   const int w = W / 2, h = H / 2;
   const size_t npix = (size_t)w * h;
+  // (a helper thread the last detection's host stage was closed without — cut off in the middle of a part — reads the job, the maps and
+  // the lists this call rewrites, possibly in buffers it regrows: nobody is inside a job from here on.  Immediate, unless that thread
+  // has been off its CPU for a whole frame.)
+  if (!prelaunched) plv::linehost::quiesce_helpers(T->host.fit);
   TRY(T->half.reserve(npix));
   TRY(T->map.reserve(npix));
   TRY(T->work.reserve(npix));
@@ -371,9 +375,6 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     es = T->edge_stream;
   }
   T->edge_fork = false;
-  // (a helper thread the last detection's host stage was closed without — cut off in the middle of a part — reads the maps and lists
-  // this launch writes: nobody is inside a job from here on.  Immediate, unless that thread has been off its CPU for a whole frame.)
-  if (!prelaunched) plv::linehost::quiesce_helpers(T->host.fit);
   if (!prelaunched) TRY(launch_line_edges(ctx, d_img, W, H, fp, b, es, early ? T->early_hist : nullptr));
   if (with_labels && !T->ccl_stream) {
     PLV_HIP_CHECK(hipStreamCreateWithFlags(&T->ccl_stream, hipStreamNonBlocking));

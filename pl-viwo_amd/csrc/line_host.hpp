@@ -500,8 +500,8 @@ inline void close_job(Fit &F, int nfit, int g, bool wait = true) {
 // before the buffers the parts read (the pinned maps and lists) or write (Fit::part, winner) are used again
 inline void quiesce_helpers(Fit &F) {
   wait_helpers(F, [&] {
-    for (int i = 0; i < Fit::kThreads; ++i)
-      if (F.th[i].joinable() && F.picked_gen[i].load() != F.done_gen[i].load()) return false;
+    for (int i = 0; i < Fit::kThreads; ++i)  // (the two words only: this may run on another thread than the one that starts helpers)
+      if (F.picked_gen[i].load() != F.done_gen[i].load()) return false;
     return true;
   });
 }
@@ -518,9 +518,9 @@ inline void wait_helpers(Fit &F, Done done) {
     }
   }
   std::unique_lock<std::mutex> lk(F.m);
-  F.poster_waiting.store(1);
+  F.poster_waiting.fetch_add(1);  // (a count: the worker and, in quiesce_helpers, the caller's thread may both be asleep here)
   F.cv.wait(lk, done);
-  F.poster_waiting.store(0);
+  F.poster_waiting.fetch_sub(1);
 }
 
 inline void fit_worker(HostStage *T, int me, int seen /* the generation current when the thread was made: it waits for the next */) {
