@@ -271,3 +271,40 @@ def test_component_split_detection_matches_the_oracle(pkg, lo, scene, mount):
         pkg.debug_knobs(0)
         pkg.line_worker_config(spin, fit)
         ctx.close()
+
+
+def _strips_image(w, h, seed):
+    """slanted two-tone strips and boxes over a ramp: a few hundred edge components of all sizes, long and short chains"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = 60.0 + 40.0 * xx / w + 30.0 * yy / h
+    for _ in range(40):
+        a = rng.uniform(0, np.pi)
+        c, s_ = np.cos(a), np.sin(a)
+        u = c * (xx - rng.uniform(0, w)) + s_ * (yy - rng.uniform(0, h))
+        v = -s_ * (xx - rng.uniform(0, w)) + c * (yy - rng.uniform(0, h))
+        m = (np.abs(u) < rng.uniform(3, 0.15 * w)) & (np.abs(v) < rng.uniform(10, 0.4 * w))
+        img[m] = rng.uniform(20, 235)
+    img += rng.normal(0, 1.5, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (700, 500), (1280, 720), (354, 198)])
+def test_component_split_detection_at_other_sizes(pkg, lo, w, h):
+    """The labelled, component-split detection (round 6b: parts staged and seeded from the per-part pixel lists ccl_flatten_kernel
+    leaves per run of 256 pixels) at sizes where a run of 256 pixels spans several rows of the half-resolution map (320 x 240, 354 x
+    198: fewer than 256 columns), where the last run is partial (700 x 500, 354 x 198) and at configs[3]'s size — against the oracle's
+    sequential FastLineDetector, bit for bit; with the pixel lists off (knob 1 << 26: parts from the label image) the same."""
+    ctx = pkg.Context(pkg.default_config(w, h))
+    try:
+        for seed, knobs in ((1, 0), (2, 0), (3, 1 << 26)):
+            pkg.debug_knobs(knobs)
+            img = _strips_image(w, h, seed)
+            ctx.feed_image(img)
+            ref = lo.detect_lines(ctx.pyramid_level(0, 0))
+            ctx.line_detect_launch(0)
+            got = ctx.detect_lines(0)
+            assert len(ref) > 10 and got.shape == ref.shape and np.array_equal(got, ref), (w, h, seed, knobs, len(ref), len(got))
+    finally:
+        pkg.debug_knobs(0)
+        ctx.close()
