@@ -754,7 +754,11 @@ def chain_count():
 
 
 def debug_knobs(mask=-1):
-    """plv_debug_knobs (measurement aid): sets the mask of alternative placements (csrc/plv_ctx.hpp "Measurement knobs"), returns the previous one"""
+    """plv_debug_knobs (measurement aid): sets the mask of alternative placements (csrc/plv_ctx.hpp "Measurement knobs"), returns the previous one.
+    PLV_TEST_KNOBS_OR (tests): bits that stay set whatever mask a test asks for — e.g. 1 << 28, the napping helper threads, under the
+    whole GPU suite (tools/suite_with_naps.sh)."""
+    if mask >= 0:
+        mask |= int(os.environ.get("PLV_TEST_KNOBS_OR", "0"))
     return int(load_library().plv_debug_knobs(int(mask)))
 
 

@@ -416,6 +416,9 @@ int detect(plv_ctx *ctx, LineTracker *T, int which, std::vector<float> &lines, b
     } else {
       (void)join_job(T);  // a stale job (another image / frame) must be off the buffers before they are reused
     }
+    // (... and so must a helper thread that job was closed without: it reads the job's fields, rewritten below — found by the test
+    // suite run with napping helpers, PLV_DEBUG_KNOBS = 1 << 28: a part started after the fields of a detection without labels were in)
+    plv::linehost::quiesce_helpers(T->host.fit);
     Job &J = T->job;
     J.device = ctx->device, J.w = w, J.h = h, J.length_threshold = fp.length_threshold, J.distance_threshold = fp.distance_threshold;
     J.thr2 = thr2;

@@ -355,6 +355,7 @@ inline void fit_one(Fit &F, const Job &J, int c) {
 inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, int kind, int g) {
   const auto tp0 = std::chrono::steady_clock::now();
   auto stop = [&] { return F.winner[p].load(std::memory_order_relaxed) >= 0 || F.closed_gen.load(std::memory_order_relaxed) >= g; };
+  if (stop()) return;  // (claimed just as the job was closed: nothing of the job is touched)
   const int w = J.w, h = J.h, pw = w + 2;
   const bool listed = J.hsorted != nullptr && J.hbins != nullptr && w < 65536 && h < 65536;
   if (S.pad.size() != (size_t)pw * (h + 2) || (listed && (S.clean_w != w || S.clean_h != h))) {
@@ -372,7 +373,11 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, 
     for (int b = 0; b < nblk; ++b) {
       const unsigned short *bn = J.hbins + (size_t)b * stride;
       const uint8_t *so = J.hsorted + (size_t)b * 256;
-      for (int q = bn[p], q1 = std::min<int>(bn[p + 1], 256); q < q1; ++q) {
+      // (bounds held against any content: a detection that has been superseded — plv_line_detect_launch for another image, then a
+      // detection from scratch — may still be reading these lists while the next edge launch rewrites them; its result is dropped, but
+      // a pixel outside the image would put an edge on the map's border and the walk off the map)
+      for (int q = std::min<int>(bn[p], 256), q1 = std::min<int>(bn[p + 1], 256); q < q1; ++q) {
+        if (b * 256 + (int)so[q] >= n) continue;
         int x = col + so[q], y = row;
         while (x >= w) x -= w, ++y;
         m[(size_t)(y + 1) * pw + x + 1] = 2;
@@ -614,8 +619,9 @@ inline int host_extract(HostStage *T, Job &J, bool timing) {
   const bool by_parts = J.hlab != nullptr && J.parts >= 1 && J.parts <= Fit::kParts;
   const int nfit = by_parts ? std::min(fit_threads().load(std::memory_order_relaxed), J.parts - 1)
                             : std::min(std::min(fit_threads().load(std::memory_order_relaxed), 2), (size_t)J.w * J.h >= 60000 ? 2 : 1);
+  quiesce_helpers(F);  // (a helper cut off inside a part of the last detection: Fit::part and winner are about to be written again, and
+                       // the job it reads may be another one by now)
   if (by_parts) {
-    quiesce_helpers(F);  // (a helper cut off inside a part of the last detection: Fit::part and winner are about to be written again)
     for (int p = 0; p < J.parts; ++p) F.winner[p].store(-1, std::memory_order_relaxed);
     // the order the parts are claimed in: the largest first (the threads' shares end level), sizes from the parts' pixel lists
     int size[Fit::kParts] = {};
