@@ -446,7 +446,13 @@ inline void detect_part(Fit &F, const Job &J, int p, Fit::Scratch &S, int slot, 
 }
 inline void chaos_nap(Fit &F, unsigned a, unsigned b) {
   int c = F.chaos_us.load(std::memory_order_relaxed);
-  if (c <= 0 && plv::knob(plv::PLV_KNOB_HELPER_NAPS)) c = 200;
+  if (c <= 0 && plv::knob(plv::PLV_KNOB_HELPER_NAPS)) {
+    static const int env_us = [] {
+      const char *e = getenv("PLV_HELPER_NAP_US");  // (tests: longer naps than the knob's 200 us)
+      return e ? atoi(e) : 0;
+    }();
+    c = env_us > 0 ? env_us : 200;
+  }
   if (c <= 0) return;
   unsigned x = a * 2654435761u ^ (b + 0x9e3779b9u) * 40503u;
   x ^= x >> 15, x *= 2246822519u, x ^= x >> 13;
