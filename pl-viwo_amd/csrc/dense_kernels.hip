@@ -238,9 +238,16 @@ __global__ void __launch_bounds__(256) stack_zero_rejected_kernel(double *__rest
 // acc_rows[f] rows go to rows [sum of the accepted rows before it, ...).  The Householder route then works on ~500 rows instead of
 // the stack's F x mp_max = 3000 slots, most of them empty: three levels of the tree instead of six.
 __global__ void __launch_bounds__(256) stack_compact_kernel(const double *__restrict__ A, int lda, int nc, const int *__restrict__ acc_rows, int F, int mp_max,
-                                                            double *__restrict__ dst, int ldd) {
+                                                            double *__restrict__ dst, int ldd, int *__restrict__ total_out) {
   __shared__ int s_off;
   const int f = blockIdx.x;
+  if (total_out && f == 0 && threadIdx.x < 64) {  // (for a reader on the device: the rows dst holds, launch_tsqr's m_dev)
+    int tot = 0;
+    for (int g = threadIdx.x; g < F; g += 64) tot += max(acc_rows[g], 0);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+    if (threadIdx.x == 0) *total_out = tot;
+  }
   const int rows = max(acc_rows[f], 0);
   if (rows == 0) return;
   if (threadIdx.x < 64) {
@@ -258,11 +265,12 @@ __global__ void __launch_bounds__(256) stack_compact_kernel(const double *__rest
     dst[(size_t)j * ldd + off + i] = A[(size_t)j * lda + (size_t)f * mp_max + i];
   }
 }
-int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows) {
+int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows,
+                         int *d_total_out) {
   // (exact_rows: ldd is the number of accepted rows — every row of dst is written, nothing to clear)
   if (!exact_rows) PLV_HIP_CHECK(hipMemsetAsync(d_dst, 0, (size_t)ldd * nc * 8, ctx->stream));
   ProfScope ps(ctx->prof, "stack_compact_kernel", ctx->stream);
-  hipLaunchKernelGGL(stack_compact_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_dst, ldd);
+  hipLaunchKernelGGL(stack_compact_kernel, dim3(F), dim3(256), 0, ctx->stream, d_A, lda, nc, d_acc_rows, F, mp_max, d_dst, ldd, d_total_out);
   PLV_HIP_CHECK(hipGetLastError());
   return PLV_OK;
 }

@@ -100,6 +100,7 @@ enum : unsigned { PLV_KNOB_CHAIN_ALWAYS = 4096u, PLV_KNOB_NO_CHAIN = 2048u, PLV_
                   PLV_KNOB_LK_LEGACY_LOOP = 1u << 21, // lk_kernel<0>: the iteration of rounds 2-4 (tools/lk_exp.py; same bits, slower)
                   PLV_KNOB_LINE_LABELS_OFF = 1u << 22,
                   PLV_KNOB_LK_AHEAD = 1u << 23,
+                  PLV_KNOB_TSQR_TREE = 1u << 29,          // the Householder compression as the tree of unblocked workgroup factorisations (rounds 1-6a) instead of hqr_kernel
                   PLV_KNOB_HELPER_NAPS = 1u << 28,        // tests: the line detector's helper threads fall asleep (up to 200 us) at random when they pick a job up or start a part
                   PLV_KNOB_WAIT_ALL_HELPERS = 1u << 27,   // the line worker's jobs wait for every helper thread's report (rounds 5-6a) instead of doing a late helper's share themselves
                   PLV_KNOB_PART_LISTS_OFF = 1u << 26,     // the host stage builds a part's map from the labels of the whole image (round 5) instead of the part's own pixel list

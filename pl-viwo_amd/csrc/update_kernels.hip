@@ -358,6 +358,250 @@ __global__ void __launch_bounds__(1024) qr_accum_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// K13b (round 6b): the same factor by a BLOCKED Householder QR in ONE workgroup, in place.  The tree above spends a column step (a
+// barrier or two, ~1 us) per column, per 64-row chunk and per level — 1260 steps for a 750 x 105 stack — although the stack is only
+// seven times taller than wide.  Here a column step spans all rows at once: panels of 16 columns live in the registers of the 512
+// threads (thread t holds rows d0 + t, d0 + t + 512, ..), a step's norm is one wave sum + eight partials, its dot products with the
+// panel's later columns go through LDS transposed (every thread writes its 15 partial products, 32 lanes add 512 of them per column)
+// — 105 steps in all —, and the columns behind the panel are updated with the panel's block reflector I - V T V^T on MFMA tiles
+// (W = V^T A_tile summed over the waves' row ranges, T^T W, A_tile -= V (T^T W)); V stays where the panel was (unit diagonal
+// implied), R ends in the top nc rows.  Same reflectors as the unblocked kernel (LAPACK dgeqrt's arithmetic), so the factor agrees
+// with it to rounding.  m <= 512 * RP rows.  Measured (tools/tsqr_ab.py, events around the launches, one box): 750 x 105 599 us
+// against 1400 for the tree's three launches, 300 x 105 396 against 955, 900 x 135 ~1100 against 2350, 1500 x 105 ~1100 against 1900;
+// of the 599: the 105 column steps 230 (2.2 us each: sixteen sums over 512 threads through LDS, a square root and two divisions),
+// V^T V and T 72, the eight passes over the trailing columns ~300 (every round of loads from the L2 is ~1 us for a lone workgroup).
+#define HQ_T 512
+template <int RP>
+__global__ void __launch_bounds__(HQ_T) hqr_kernel(double *__restrict__ A, int lda, int m, int nc, int sign_fix, double *__restrict__ Vg, int ldv, const int *__restrict__ m_dev,
+           double *__restrict__ Rout, int ldro, const int *__restrict__ first_m_dev, int first_m, int first_cap) {
+  // Several workgroups (a stack of more rows than one holds in registers): the rows are split evenly, workgroup b factors its share in
+  // place and leaves its R — nc rows — at rows b * nc of Rout; a second launch factors the stacked R's.  m_dev: the rows that hold
+  // anything (a stack gathered on the device), at least nc of them taken (rows of zeros change no factor).
+  // (the launch over the stacked R's: nothing to do when the first launch's rows fitted one workgroup — that one left the final R)
+  if (first_m_dev && min(max(*first_m_dev, nc), first_m) <= first_cap) return;
+  {
+    const int m_tot = m_dev ? min(max(*m_dev, nc), m) : m;
+    const int cap = HQ_T * RP, nb_act = (m_tot + cap - 1) / cap, bs = (((m_tot + nb_act - 1) / nb_act) + 15) & ~15;
+    if (sign_fix == 2) sign_fix = nb_act == 1 ? 1 : 0;  // (first of two launches: final when it is alone)
+    const int b = blockIdx.x, r_lo = b * bs, r_hi = min(m_tot, r_lo + bs);
+    if (b >= nb_act) {  // nothing for this workgroup: an R of zeros
+      for (int idx = threadIdx.x; idx < nc * nc; idx += HQ_T) Rout[(size_t)(idx / nc) * ldro + (size_t)b * nc + idx % nc] = 0.0;
+      return;
+    }
+    A += r_lo;
+    m = r_hi - r_lo;
+    Vg += (size_t)b * ldv * 16;
+  }
+  __shared__ double buf[16 * HQ_T];  // a step's partial products [column][thread]; the MFMA phases' partial tiles [wave][256]
+  __shared__ double wv[2][16], prow[2][16], tau_s[16], sg[208];  // (wv, prow: by the parity of the column step)
+  __shared__ double VtV[16][17], Tm[16][17], Wm[4][16][17], W2[4][16][17];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int np = (nc + 15) >> 4;
+  for (int p = 0; p < np; ++p) {
+    const int c0 = 16 * p, d0 = c0, bw = min(16, nc - c0), mp = m - d0;
+    double a[RP][16];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      const int row = d0 + t + HQ_T * q;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[q][c] = (row < m && c < bw) ? A[(size_t)(c0 + c) * lda + row] : 0.0;
+    }
+    // (slot 0 of the register row is always the step's pivot column: a finished column goes to memory and the others move up, so the
+    // step is ONE piece of code with fixed register indices — unrolled sixteen times it was 80 KB of instructions, more than the
+    // instruction cache holds, and a step took 3.5 us; slots beyond the panel's width hold zeros)
+    for (int j = 0; j < bw; ++j) {
+      const int d = d0 + j;
+      // one round of sums for the step: x_0 = sum over the rows below the pivot of a_j^2, x_c = the same rows' a_j a_c (c = 1 .. 15);
+      // the pivot row's own entries go through LDS as they are.  With v = a_j * scale below the pivot and 1 on it, v^T a_c is
+      // a_dc + scale * x_c: one barrier less per step than the norm first and the products with v afterwards.
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double pc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RP; ++q)
+          if (d0 + t + HQ_T * q > d) pc += a[q][0] * a[q][c];  // (rows beyond m hold zeros)
+        buf[c * HQ_T + t] = pc;
+      }
+      if (t == j) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) prow[j & 1][c] = a[0][c];
+      }
+      __syncthreads();
+      {
+        const int c = t >> 5, sgm = t & 31;
+        const double *src = buf + c * HQ_T + sgm;  // (lanes side by side: every read of the wave covers all banks once)
+        double x = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x += src[32 * u];
+        x += dpp_mov_f64<0x111>(x);
+        x += dpp_mov_f64<0x112>(x);
+        x += dpp_mov_f64<0x114>(x);
+        x += dpp_mov_f64<0x118>(x);
+        x += dpp_mov_f64<0x142>(x);  // (lane 31: rows 0 + 1 of the wave, lane 63: rows 2 + 3 — the wave's two columns)
+        if ((lane & 31) == 31) wv[j & 1][c] = x;
+      }
+      __syncthreads();
+      const double ss = wv[j & 1][0], alpha = prow[j & 1][0];
+      double tau = 0.0, scale = 0.0, beta = alpha;
+      if (ss > 0.0) {
+        beta = sqrt(alpha * alpha + ss);
+        if (alpha >= 0.0) beta = -beta;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      double v[RP];
+#pragma unroll
+      for (int q = 0; q < RP; ++q) {
+        const int row = d0 + t + HQ_T * q;
+        v[q] = row > d ? a[q][0] * scale : (row == d ? 1.0 : 0.0);
+      }
+      // the finished column to memory (R above and on the diagonal, v below), the others one slot up with the reflector applied
+#pragma unroll
+      for (int q = 0; q < RP; ++q) {
+        const int row = d0 + t + HQ_T * q;
+        if (row < m) {
+          A[(size_t)(c0 + j) * lda + row] = row > d ? v[q] : (row == d ? beta : a[q][0]);
+          Vg[(size_t)j * ldv + (row - d0)] = v[q];  // (the reflector with its unit diagonal and the zeros above it: the MFMA phases' operand)
+        }
+      }
+#pragma unroll
+      for (int c = 1; c < 16; ++c) {
+        const double tw = tau * (prow[j & 1][c] + scale * wv[j & 1][c]);
+#pragma unroll
+        for (int q = 0; q < RP; ++q) a[q][c - 1] = a[q][c] - tw * v[q];
+      }
+#pragma unroll
+      for (int q = 0; q < RP; ++q) a[q][15] = 0.0;
+      if (t == 0) tau_s[j] = tau;
+      // (two barriers a step: the next step writes buf before its first barrier, behind this step's second, which every reader of
+      //  buf has passed; prow and wv alternate by the step's parity)
+    }
+    __syncthreads();
+    if (c0 + 16 >= nc) break;  // (the last panel: nothing behind it)
+    const int ck = ((mp + 7) / 8 + 3) & ~3;  // rows of a wave's range (a multiple of the MFMA's four k)
+    const int off0 = wave * ck, rb0 = d0 + off0, rk = max(0, min(ck, m - rb0));
+    const double *vcol = Vg + (size_t)(lane & 15) * ldv;  // this lane's column of V (operand maps: lane & 15 = the tile's row / column)
+    {  // ---- VtV = V^T V, then T
+      d4 acc = {0, 0, 0, 0};
+      auto fa = [&](int, int kk) { return vcol[off0 + kk]; };
+      auto fb = [&](int kk, int) { return vcol[off0 + kk]; };
+      acc = mfma_tile_f64_pipe<8>(fa, fb, rk, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) buf[wave * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[q];
+      __syncthreads();
+      if (t < 256) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) x += buf[w * 256 + t];
+        VtV[t >> 4][t & 15] = x;
+      }
+      __syncthreads();
+      if (t < 16) {  // row t of T (upper triangular): T(0:j, j) = -tau_j T(0:j, 0:j) V(:, 0:j)^T v_j
+        for (int jj = 0; jj < 16; ++jj) {
+          double x = 0.0;
+          if (jj == t) x = jj < bw ? tau_s[jj] : 0.0;
+          if (jj > t && jj < bw) {
+            double s_ = 0.0;
+            for (int l = t; l < jj; ++l) s_ += Tm[t][l] * VtV[l][jj];
+            x = -tau_s[jj] * s_;
+          }
+          Tm[t][jj] = x;
+        }
+      }
+      __syncthreads();
+    }
+    // the columns behind the panel, four tiles (64 columns) a pass: the loads of a pass are in flight together — V once, the tiles
+    // beside it — and a pass has one set of barriers (a tile a pass took 17 us of mostly waiting at 750 rows)
+    for (int tc0 = c0 + 16; tc0 < nc; tc0 += 64) {
+      const int ng = min(4, (nc - tc0 + 15) >> 4);  // tiles of this pass
+      {  // W_g = V^T A_tile_g over the waves' row ranges
+        d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        const double *acol[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acol[g] = A + (size_t)min(tc0 + 16 * g + (lane & 15), nc - 1) * lda + rb0;  // (beyond the last column: it again, never used)
+        const int kq = lane >> 4;
+        for (int k0 = 0; k0 < rk; k0 += 16) {  // (four k-steps of four rows: 4 + 16 loads in flight)
+          double av[4], bv[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 4 * u + kq, kc = min(kk, rk - 1);
+            const double x = vcol[off0 + kc];
+            av[u] = kk < rk ? x : 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g][u] = acol[g][kc];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (g < ng)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[g][u], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) buf[(wave * 4 + g) * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[g][q];
+      }
+      __syncthreads();
+      for (int e = t; e < 1024; e += HQ_T) {  // (tile g = e >> 8, entry e & 255)
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) x += buf[(w * 4 + (e >> 8)) * 256 + (e & 255)];
+        Wm[e >> 8][(e >> 4) & 15][e & 15] = x;
+      }
+      __syncthreads();
+      for (int e = t; e < 1024; e += HQ_T) {  // W2_g = T^T W_g
+        const int g = e >> 8, i = (e >> 4) & 15, jj = e & 15;
+        double x = 0.0;
+        for (int l = 0; l <= i; ++l) x += Tm[l][i] * Wm[g][l][jj];
+        W2[g][i][jj] = x;
+      }
+      __syncthreads();
+      for (int rb = wave; rb * 16 < mp; rb += 8) {  // A_tile_g -= V W2_g, sixteen rows a time
+        const int r0 = d0 + rb * 16;
+        const int ri = min(rb * 16 + (lane & 15), mp - 1);  // (rows beyond the last: a valid row again, its results are not stored)
+        double av[4], old[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = Vg[(size_t)(4 * u + (lane >> 4)) * ldv + ri];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = min(r0 + (lane >> 4) + 4 * q, m - 1), col = min(tc0 + 16 * g + (lane & 15), nc - 1);
+            old[g][q] = A[(size_t)col * lda + row];
+          }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (g < ng) {
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], W2[g][4 * u + (lane >> 4)][lane & 15], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = r0 + (lane >> 4) + 4 * q, col = tc0 + 16 * g + (lane & 15);
+              if (row < m && col < nc) A[(size_t)col * lda + row] = old[g][q] - acc[q];
+            }
+          }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- R alone in the top nc rows: zeros below the diagonal, optionally rows with a negative diagonal negated; with several
+  // workgroups: into this workgroup's rows of Rout instead
+  __syncthreads();
+  for (int i = t; i < nc; i += HQ_T) sg[i] = (sign_fix && A[(size_t)i * lda + i] < 0.0) ? -1.0 : 1.0;
+  __syncthreads();
+  for (int idx = t; idx < nc * nc; idx += HQ_T) {
+    const int j = idx / nc, i = idx - j * nc;  // (column j, row i)
+    double *e = A + (size_t)j * lda + i;
+    const double x = i > j ? 0.0 : (sg[i] < 0.0 ? -*e : *e);
+    if (Rout)
+      Rout[(size_t)j * ldro + (size_t)blockIdx.x * nc + i] = x;
+    else
+      *e = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Dense gathers of the covariance blocks the update contracts with, so that no MFMA operand load
 // goes through a dependent index load:  Pc = P[cols, :] (k x n, row-major), Ps = P[cols, cols]
 // (k x k, row-major), inv[state] = position of that state in cols or -1.
@@ -789,7 +1033,37 @@ int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a_in, int max_mp) {
 // non-negative diagonal at d_out (ld = nc... returned in *ld_out).  d_A and d_tmp are ping-pong
 // workspaces, both overwritten.  Returns the device pointer holding the result in *result.
 int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,
-                int *ld_out) {
+                int *ld_out, const int *m_dev) {
+  // (round 6b) blocked, in place, one workgroup per 2048 rows (PLV_KNOB_TSQR_TREE: the tree of rounds 1-6a); a stack less than one
+  // and a half times as tall as wide stays with the tree: one pass of one workgroup there, 269 against 322 us at 120 x 105
+  {
+    const int cap = HQ_T * 4, nb = m <= HQ_T * 2 ? 1 : (m + cap - 1) / cap;
+    const int ldv = ((nb == 1 ? m : cap) + 63) & ~63;  // the panels' reflectors, explicit (16 columns), live in the workspace
+    const size_t v_elems = (size_t)nb * ldv * 16, r_elems = nb > 1 ? (size_t)nb * nc * nc : 0;
+    const int ldv2 = (nb * nc + 63) & ~63;
+    const size_t need = v_elems + r_elems + (nb > 1 ? (size_t)ldv2 * 16 : 0);
+    if ((2 * m >= 3 * nc || m_dev) && m >= nc && nc <= 208 && nb <= 8 && need <= tmp_elems && !plv::knob(plv::PLV_KNOB_TSQR_TREE)) {
+      ProfScope ps(ctx->prof, "hqr_kernel", ctx->stream);
+      double *Vg = d_tmp, *Rst = d_tmp + v_elems, *Vg2 = Rst + r_elems;
+      const int ldro = nb * nc;
+      if (nb == 1 && m <= HQ_T * 2)
+        hipLaunchKernelGGL(hqr_kernel<2>, dim3(1), dim3(HQ_T), 0, ctx->stream, d_A, lda, m, nc, 1, Vg, ldv, m_dev, (double *)nullptr, 0, (const int *)nullptr, 0, 0);
+      else
+        hipLaunchKernelGGL(hqr_kernel<4>, dim3(nb), dim3(HQ_T), 0, ctx->stream, d_A, lda, m, nc, nb == 1 ? 1 : 2, Vg, ldv, m_dev, nb > 1 ? Rst : (double *)nullptr,
+                           ldro, (const int *)nullptr, 0, 0);
+      if (nb > 1) {  // the stacked R's (nb * nc rows: at most 8 x 208); returns at once when the rows fitted the first launch's first workgroup
+        if (ldro <= HQ_T * 2)
+          hipLaunchKernelGGL(hqr_kernel<2>, dim3(1), dim3(HQ_T), 0, ctx->stream, Rst, ldro, ldro, nc, 1, Vg2, ldv2, (const int *)nullptr, (double *)nullptr, 0, m_dev, m, cap);
+        else
+          hipLaunchKernelGGL(hqr_kernel<4>, dim3(1), dim3(HQ_T), 0, ctx->stream, Rst, ldro, ldro, nc, 1, Vg2, ldv2, (const int *)nullptr, (double *)nullptr, 0, m_dev, m, cap);
+      }
+      PLV_HIP_CHECK(hipGetLastError());
+      *result = nb > 1 ? Rst : d_A;
+      *ld_out = nb > 1 ? ldro : lda;
+      return PLV_OK;
+    }
+    // (else the tree below: it sizes its launches on the host and takes the bound m; rows beyond *m_dev are zeros)
+  }
   size_t shm = ((size_t)nc * nc + QR_CHUNK + 8) * sizeof(double);
   if (shm > 160 * 1024 || nc * QR_PARTS > 1024) {
     set_last_error("tsqr: %d columns exceed the LDS-resident R capacity", nc);

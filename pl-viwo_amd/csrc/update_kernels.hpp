@@ -46,8 +46,10 @@ struct GatherArgs;
 int gather_args(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k, GatherArgs &g);
 int launch_gather_cov(plv_ctx *ctx, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_chi2(plv_ctx *ctx, int F, const Chi2Args &a, int max_mp);
+// m_dev (nullable, device word): the rows of d_A that hold anything — d_A is a gathered stack whose row count only the device knows
+// (launch_stack_compact's d_total_out); m is then the bound the launch is sized for, rows beyond *m_dev are not read
 int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp, size_t tmp_elems, double **result,
-                int *ld_out);
+                int *ld_out, const int *m_dev = nullptr);
 int launch_ekf(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H, int r, int k, int ldh, const int *d_cols,
                const double *d_res, const double *d_Rdiag, double *d_dx, int *d_flag, bool gathered = false);
 
@@ -64,7 +66,8 @@ int launch_ekf_fast(plv_ctx *ctx, double *d_P, int n, int ldp, const double *d_H
 // whitened route (dense_kernels.hip; DESIGN.md "Whitened update")
 void launch_whiten_b(plv_ctx *ctx, const double *Lt, int k, const double *Gs, const double *gv, double *cv, double *B, int *d_flag,
                      const double *d_P, int ldp, int n, const int *d_cols, double *Y0, double *GP, double *d0, const int *use_m);
-int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows = false);
+int launch_stack_compact(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max, double *d_dst, int ldd, bool exact_rows = false,
+                         int *d_total_out = nullptr /* device word: the rows gathered */);
 int launch_stack_zero_rejected(plv_ctx *ctx, double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);
 int launch_prior_factor(plv_ctx *ctx, hipStream_t st, const double *d_P, int n, int ldp, const int *d_cols, int k);
 int launch_gram_information(plv_ctx *ctx, const double *d_A, int lda, int nc, const int *d_acc_rows, int F, int mp_max);

@@ -99,7 +99,10 @@ def test_chi2_batch_parity(ctx, oracle):
     assert np.allclose(chi1, chi0, rtol=1e-9)
 
 
-@pytest.mark.parametrize("m,k", [(1890, 98), (300, 40), (2600, 128), (150, 98), (99, 98), (5000, 20)])
+# (round 6b: hqr_kernel — one workgroup up to 1024 / 2048 rows, several above with a second launch over their R's; the tree of
+# unblocked factorisations below 1.5 x the width.  Sizes on both sides of every switch, widths that are no multiple of 16.)
+@pytest.mark.parametrize("m,k", [(1890, 98), (300, 40), (2600, 128), (150, 98), (99, 98), (5000, 20), (2049, 104), (1025, 33), (1024, 15), (700, 191), (4100, 150),
+                                 (160, 104), (8200, 64)])
 def test_compress_parity(ctx, oracle, m, k):
     rng = np.random.default_rng(m + k)
     H = rng.normal(size=(m, k))
@@ -112,6 +115,29 @@ def test_compress_parity(ctx, oracle, m, k):
     assert np.all(np.tril(R1, -1) == 0) and np.all(np.diag(R1) >= 0)
     assert _rel(R1, R0) < 1e-9 and _rel(z1, z0) < 1e-9
     assert np.allclose(R1.T @ R1, H.T @ H, rtol=1e-10, atol=1e-9)
+
+
+def test_compress_blocked_and_tree_agree(ctx, pkg):
+    """hqr_kernel (default) and the tree of rounds 1-6a (knob 1 << 29) on a stack with dependent and empty columns: the same R^T R and the
+    same |R|, |z| where the factor is determined (the leading independent columns)."""
+    rng = np.random.default_rng(77)
+    m, k = 900, 104
+    H = rng.normal(size=(m, k))
+    H[:, 60] = H[:, 10] - 2.0 * H[:, 20]
+    H[:, 70] = 0.0
+    r = rng.normal(size=m)
+    try:
+        pkg.debug_knobs(0)
+        R1, z1 = ctx.compress(H, r)
+        pkg.debug_knobs(1 << 29)
+        R2, z2 = ctx.compress(H, r)
+    finally:
+        pkg.debug_knobs(0)
+    G = H.T @ H
+    for R in (R1, R2):
+        assert np.all(np.tril(R, -1) == 0) and np.all(np.diag(R) >= 0)
+        assert np.abs(R.T @ R - G).max() < 1e-10 * np.abs(G).max()
+    assert np.allclose(R1[:60, :60], R2[:60, :60], rtol=1e-9, atol=1e-11) and np.allclose(z1[:60], z2[:60], rtol=1e-9, atol=1e-11)
 
 
 def test_compress_fat_is_identity(ctx):
