@@ -1042,7 +1042,8 @@ int launch_tsqr(plv_ctx *ctx, double *d_A, int lda, int m, int nc, double *d_tmp
     const size_t v_elems = (size_t)nb * ldv * 16, r_elems = nb > 1 ? (size_t)nb * nc * nc : 0;
     const int ldv2 = (nb * nc + 63) & ~63;
     const size_t need = v_elems + r_elems + (nb > 1 ? (size_t)ldv2 * 16 : 0);
-    if ((2 * m >= 3 * nc || m_dev) && m >= nc && nc <= 208 && nb <= 8 && need <= tmp_elems && !plv::knob(plv::PLV_KNOB_TSQR_TREE)) {
+    const bool tree_holds = ((size_t)nc * nc + QR_CHUNK + 8) * sizeof(double) <= 160 * 1024 && nc * QR_PARTS <= 1024;  // (its R lives in LDS: ~140 columns)
+    if ((2 * m >= 3 * nc || m_dev || !tree_holds) && m >= nc && nc <= 208 && nb <= 8 && need <= tmp_elems && !(plv::knob(plv::PLV_KNOB_TSQR_TREE) && tree_holds)) {
       ProfScope ps(ctx->prof, "hqr_kernel", ctx->stream);
       double *Vg = d_tmp, *Rst = d_tmp + v_elems, *Vg2 = Rst + r_elems;
       const int ldro = nb * nc;
