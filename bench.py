@@ -475,7 +475,7 @@ def main():
     stream = None
     if not args.dry_run:
         nprof = max(10, min(40, args.steps))
-        seg2 = 0 if args.no_pcie else 2 * args.steps
+        seg2 = 0 if args.no_pcie else 3 * args.steps      # (one segment alternating resident / any host buffer / pinned block)
         nvar = 0 if args.no_variants else max(10, min(40, args.steps))
         npy = max(10, min(40, args.steps))      # (the segment timed through the Python driver: config.ms_per_step_python)
         n_gpu_frames = PROLOGUE + args.warmup + args.steps + seg2 + npy + nprof + 6 * nvar + 8 * LEAD_IN   # (three alternating variants of 2 * nvar frames)
@@ -530,7 +530,8 @@ def main():
     alt_fit = [int(m) for m in args.alternate_fit.split(",")] if args.alternate_fit else None
     alt_img = args.alternate_images.split(",") if args.alternate_images else None
 
-    def timed_segment(n_steps, hook=None, through_python=False):
+    def timed_segment(n_steps, hook=None, through_python=False, images=None):
+        ai = images or alt_img    # the image's hand-over alternating frame by frame ("resident", "host", "pinned")
         per_frame = {"kept": [], "tracked": []}
         cnt = {k: 0 for k in ("launches", "syncs", "copies", "copy_bytes", "lk_iters", "lines_detected", "frame_ns", "sync_ns", "ambiguous_frames",
                               "redone_frames", "whitened_frames")}
@@ -539,7 +540,9 @@ def main():
         gc.disable()      # (the driver is Python: its collector must not land inside a 0.6 ms step)
         # the collection above is a pause of milliseconds in which the library's threads go to sleep and the caches cool: two untimed
         # steps (more warm-up, same code path) lead back into the steady state the timed steps are meant to show
-        for _ in range(LEAD_IN):
+        for li in range(LEAD_IN):
+            if ai:
+                pl.staged, pl.pinned = ai[(li - LEAD_IN) % len(ai)] == "resident", ai[(li - LEAD_IN) % len(ai)] == "pinned"
             nf = pl.next_frame()
             if hook:
                 hook(0)
@@ -560,8 +563,8 @@ def main():
         chain0, routes0 = pkg.chain_count(), pkg.route_counts()
         last_stats = dict(sm.stats)
         for f in range(n_steps):
-            if alt_img:
-                pl.staged, pl.pinned = alt_img[f % len(alt_img)] == "resident", alt_img[f % len(alt_img)] == "pinned"
+            if ai:
+                pl.staged, pl.pinned = ai[f % len(ai)] == "resident", ai[f % len(ai)] == "pinned"
             nf = pl.next_frame()            # untimed: IMU / wheel messages, cloning, marginalisation (+ staging of the image in segment 1)
             if nf is None:
                 raise RuntimeError(f"bench: the rendered stream ended {n_steps - f} frames before a timed segment did (n_gpu_frames undersized)")
@@ -697,13 +700,19 @@ def main():
         print("[main segment] ms per step %.4f  p50 %.4f" % (seg["elapsed"] / args.steps * 1e3, float(np.median(seg["per"]))), file=sys.stderr)
         sm.close()
         sys.exit(0)
-    seg_pcie = seg_pin = None
+    seg_pcie = seg_pin = seg_res_alt = None
     if not args.no_pcie:
-        pl.staged = False
-        seg_pcie = timed_segment(args.steps)                          # (2) host images: the host copy + the PCIe transfer inside the step
-        pl.pinned = True
-        seg_pin = timed_segment(args.steps)                           # (2b) the image in the library's page-locked block: the PCIe transfer inside the step
+        # (2) host images, measured ALTERNATING with the resident hand-over over the next 3 * steps frames (frame f: resident, any host
+        # buffer, the library's pinned block, ...): consecutive segments are other frames of the drive, whose cost differs by more than
+        # the hand-over's (round 6: 20-step segments showed the pinned block 40 us SLOWER than any buffer, frame by frame it is 13 us
+        # faster) — the three means below come from interleaved frames of one segment
+        seg_alt = timed_segment(3 * args.steps, images=("resident", "host", "pinned"))
         pl.staged, pl.pinned = True, False
+
+        def third(j):
+            v = [float(x) for x in seg_alt["per"][j::3]]
+            return dict(seg_alt, per=v, elapsed=reduce_max(float(np.mean(v)) * 1e-3 * args.steps, dist))
+        seg_res_alt, seg_pcie, seg_pin = third(0), third(1), third(2)
     seg_py = timed_segment(npy, through_python=True)                  # (3) as (1), the Python driver's marshalling inside the step
     elapsed, per, per_frame, cnt, stats, split = (seg[k] for k in ("elapsed", "per", "per_frame", "cnt", "stats", "split"))
     n_state = sm.state.n
@@ -880,6 +889,7 @@ def main():
             "value_pcie_inclusive": None if seg_pcie is None else args.steps * world / seg_pcie["elapsed"],
             # the image in the library's page-locked block when the step starts (plv_image_buffer: the adapters' route): the transfer is inside
             "ms_per_step_pinned_host_image": None if seg_pin is None else seg_pin["elapsed"] / args.steps * 1e3,
+            "ms_per_step_resident_on_the_alternate_frames": None if seg_res_alt is None else seg_res_alt["elapsed"] / args.steps * 1e3,
             "value_pinned_host_image": None if seg_pin is None else args.steps * world / seg_pin["elapsed"],
             "vs_cpu_all_cores_pinned_host_image": (None if (cpu is None or seg_pin is None) else cpu["ms_per_frame_all_cores"] / (seg_pin["elapsed"] / args.steps * 1e3)),
             "vs_cpu_1_thread": vs.get("speedup_resident"), "vs_cpu_all_cores": vs.get("speedup_vs_cpu_all_cores"),
@@ -924,9 +934,12 @@ def main():
                 "host_cpu": seg.get("host_cpu"),
                 "latency_ms": {"mean": float(np.mean(per)), "p50": pct(per, 50), "p99": pct(per, 99), "max": float(np.max(per))},
                 "pcie_inclusive": None if seg_pcie is None else {
-                    "what": "second timed segment, the next frames of the stream: the image is any host buffer (plv_tracker_feed), its "
-                            f"{wl['w'] * wl['h'] // 1024} KB host copy into the library's page-locked block and the PCIe transfer inside the step; "
-                            "pinned_host_image: third segment, the image already in that block (plv_image_buffer), the transfer inside the step",
+                    "what": "second timed segment, the next 3 x steps frames of the stream, the image's hand-over ALTERNATING frame by frame: resident "
+                            "(resident_on_the_alternate_frames), any host buffer (this entry: plv_tracker_feed, its "
+                            f"{wl['w'] * wl['h'] // 1024} KB host copy into the library's page-locked block and the PCIe transfer inside the step), "
+                            "the image already in that block (pinned_host_image: plv_image_buffer, the transfer inside the step)",
+                    "resident_on_the_alternate_frames": None if seg_res_alt is None else {"ms_per_step": seg_res_alt["elapsed"] / args.steps * 1e3,
+                        "latency_ms": {"mean": float(np.mean(seg_res_alt["per"])), "p50": pct(seg_res_alt["per"], 50), "p99": pct(seg_res_alt["per"], 99)}},
                     "pinned_host_image": None if seg_pin is None else {"ms_per_step": seg_pin["elapsed"] / args.steps * 1e3,
                         "latency_ms": {"mean": float(np.mean(seg_pin["per"])), "p50": pct(seg_pin["per"], 50), "p99": pct(seg_pin["per"], 99)}},
                     "value": args.steps * world / seg_pcie["elapsed"], "ms_per_step": seg_pcie["elapsed"] / args.steps * 1e3,
