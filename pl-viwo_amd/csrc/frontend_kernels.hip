@@ -1273,7 +1273,7 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
 // processed set is a prefix and the winner is the first occurrence of the prefix maximum.
 // Then re-solves the winning hypothesis and writes mask = klt_status & inlier
 // (REF: TrackKLT.cpp:876-879).  klt may be null.  info[0] = inliers, info[1] = iterations used.
-__global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
+__global__ void __launch_bounds__(256) ransac_select_kernel(const float *__restrict__ m1, const float *__restrict__ m2, int n,
                                                            float t, double conf, int max_iters, unsigned seed,
                                                            const int *__restrict__ counts, const uint8_t *__restrict__ klt,
                                                            uint8_t *__restrict__ mask, int *__restrict__ info,
@@ -1281,11 +1281,18 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
                                                            unsigned *__restrict__ mir_dst, int mir_words, uint8_t *__restrict__ mir_mask,
                                                            unsigned *done_word, unsigned done_val) {
   __shared__ RansacLds L;
-  const int lane = threadIdx.x;
+  __shared__ double sF[9];
+  __shared__ int s_kroot;
+  // (round 6b) 256 threads when the hypotheses' models are at hand: the replay of the adaptive loop stays with wave 0, the copy for the
+  // host and the inlier mask are spread over all four waves (64 threads when the winner has to be solved again: wave_models' barriers)
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   // (perform_matching: this is the last kernel of the call; it copies what lk_kernel left for the host — positions, normalised
   // coordinates, iteration counts — and its own mask into the caller's pinned buffer, so that no copy command follows it)
   if (mir_dst)
-    for (int i = lane; i < mir_words; i += 64) mir_dst[i] = mir_src[i];
+    for (int i = tid; i < mir_words; i += nthr) mir_dst[i] = mir_src[i];
+  int kroot = -1;
+  double Fk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < 64) {
   const int total = n == 7 ? 1 : max_iters;
   int best = 0, bh = -1, bslot = 0, niters = total, used = total;
   bool stop = false;
@@ -1347,7 +1354,7 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
     }
   }
   // slot -> root index
-  int kroot = -1, seen = 0;
+  int seen = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     if (valid & (1 << k)) {
@@ -1358,18 +1365,30 @@ __global__ void __launch_bounds__(64) ransac_select_kernel(const float *__restri
     info[0] = best;
     info[1] = used;
   }
-  for (int i = lane; i < n; i += 64) {
-    uint8_t in = 0;
-    if (kroot == 0) in = epi_err9(F[0], m1, m2, i) <= t;
-    else if (kroot == 1) in = epi_err9(F[1], m1, m2, i) <= t;
-    else if (kroot == 2) in = epi_err9(F[2], m1, m2, i) <= t;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) Fk[e] = kroot == 0 ? F[0][e] : (kroot == 1 ? F[1][e] : F[2][e]);
+  if (nthr > 64 && lane == 0) {
+    s_kroot = kroot;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sF[e] = Fk[e];
+  }
+  }  // (wave 0)
+  if (nthr > 64) {
+    __syncthreads();
+    kroot = s_kroot;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Fk[e] = sF[e];
+  }
+  for (int i = tid; i < n; i += nthr) {
+    const uint8_t in = kroot >= 0 ? (epi_err9(Fk, m1, m2, i) <= t) : 0;
     const uint8_t mv = (in && (!klt || klt[i])) ? 1 : 0;
     mask[i] = mv;
     if (mir_mask) mir_mask[i] = mv;
   }
-  if (done_word) {  // everything the host reads of this call is written: say so (one wave: every lane's stores precede the fence)
+  if (done_word) {  // everything the host reads of this call is written: say so (every thread's stores precede its fence, the word the barrier)
     __threadfence_system();
-    if (lane == 0) __hip_atomic_store(done_word, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done_word, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1622,7 +1641,7 @@ int launch_ransac(plv_ctx *ctx, const float *d_m1, const float *d_m2, int n, dou
   }
   {
     ProfScope ps(ctx->prof, "ransac_select_kernel", ctx->stream);
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(d_models ? 256 : 64), 0, ctx->stream, d_m1, d_m2, n, t, conf, max_iters, seed,
                        d_counts, d_klt, d_mask, d_info, (const double *)d_models, (const unsigned *)mir_src, (unsigned *)mir_dst,
                        (int)(mir_bytes / 4), mir_mask, mir_dst ? done_word : nullptr, done_val);
     if (mirrored) *mirrored = mir_dst != nullptr;
