@@ -1010,8 +1010,8 @@ int plv_msckf_update_resident_launch(plv_ctx *ctx, double sigma2, double chi2_mu
       // (round 6b) the stack is F slots of mp_max rows, the accepted rows a fraction of them and the rest zeros: gathered first (the
       // count stays on the device: hqr_kernel reads it), 2.3 ms of six tree levels over 2100 rows became ~0.8 at workload C
       TRY(ctx->d_stackc.reserve((size_t)Mtot * nc * 8));
-      TRY(ctx->d_prior_near.reserve(64));
-      int *m_dev = ctx->d_prior_near.as<int>() + 8;  // (a spare word of the small device block)
+      TRY(ctx->d_count_words.reserve(64));
+      int *m_dev = ctx->d_count_words.as<int>();
       TRY(launch_stack_compact(ctx, ctx->stack_of(fdim).as<double>(), Mtot, nc, d_acc_rows, F, mp_max, ctx->d_stackc.as<double>(), Mtot, false, m_dev));
       TRY(launch_tsqr(ctx, ctx->d_stackc.as<double>(), Mtot, Mtot, nc, ctx->d_stack2.as<double>(), tmp_elems, &R, &ldr, m_dev));
     } else {

@@ -514,6 +514,7 @@ struct plv_ctx {
   plv::DevBuf &stack_of(int fdim) { return fdim == 6 ? d_stack_l : d_stack; }
   // whitened route: prior factor Lp^T, W0 = Lp^-1 P[cols, :], W0^T W0 (side stream), information matrix [G | g] (main stream)
   plv::DevBuf d_Lt, d_W0, d_dW, d_Gs, d_GP, d_Y0, d_C1, d_stackc;
+  plv::DevBuf d_count_words; // int: [0] the rows a device-side gather of the stack left (launch_stack_compact -> hqr_kernel, mode 1)
   plv::DevBuf d_prior_near;  // int: near-dependent pivots the last prior factor met (blocked_chol.hip, PLV_PRIOR_AMB)
   hipStream_t aux_stream = nullptr;  // work that only needs the covariance, concurrent with the Jacobians and the gate
   hipEvent_t aux_fork = nullptr, aux_join = nullptr;
